@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""bench.py -- the BASELINE.json metric: CG iterations/s (+ SpMV achieved HBM GB/s) on 3-D 7-point Poisson 256^3, fp64,
+KSPCG + PCJACOBI, MATAIJHIPX/VECHIPX kernels, on N GPUs of one node (strong scaling: the 256^3 problem is split by rows).
+
+A "step" is one CG iteration (one pass of the loop body cg.c:220-349: MatMult, 2 dots, 1 norm, 2 AXPY, 1 AYPX, PCApply).
+Inputs (CSR matrix, b = A*1, x0 = 0) are resident in HBM before the timed region.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel (CSR SpMV): algorithmic bytes per launch / mean launch duration measured with HIP events
+                  on the compute stream inside the timed region, against the 8 TB/s HBM3E peak
+  cpu_baseline -- the CPU oracle (scalar restatement of the reference path, 1 core) timed on a bounded sample of the same
+                  workload on this host (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); measured copy peak is 6290
+
+
+def assemble(ks, stencil, n, rs, re):
+    f = {7: ks.HipxAssemble_poisson7, 27: ks.HipxAssemble_bench27}[stencil]
+    nz = f(n, rs, re, None, None, None)
+    ai = np.zeros(re - rs + 1, np.int32)
+    aj = np.zeros(nz, np.int32)
+    aa = np.zeros(nz, np.float64)
+    f(n, rs, re, ai.ctypes.data_as(C.c_void_p), aj.ctypes.data_as(C.c_void_p), aa.ctypes.data_as(C.c_void_p))
+    return ai, aj, aa
+
+
+def cpu_baseline(ai, aj, aa, b, budget_s, stencil, n):
+    """Oracle CG + Jacobi on the same system, bounded to ~budget_s seconds of CPU work.  Checker code, timed as a baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    t0 = time.perf_counter()
+    orc.ksp_solve("cg", ai, aj, aa, b, pc="jacobi", rtol=1e-50, max_it=2)
+    t2 = time.perf_counter() - t0  # includes set-up + 2 iterations
+    its = int(max(3, min(60, budget_s / max(t2 / 3.0, 1e-3))))
+    t0 = time.perf_counter()
+    _, done, _, _ = orc.ksp_solve("cg", ai, aj, aa, b, pc="jacobi", rtol=1e-50, max_it=its)
+    t_its = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    orc.ksp_solve("cg", ai, aj, aa, b, pc="jacobi", rtol=1e-50, max_it=1)
+    t_one = time.perf_counter() - t0
+    per_it = (t_its - t_one) / max(done - 1, 1)
+    return {"value": 1.0 / per_it, "unit": "CG iterations/s", "cores": 1, "kind": "port",
+            "sample": "%d CG+Jacobi iterations of the oracle (scalar C restatement of cg.c/aij.c, gcc -O2) on the same %d-pt %d^3 system" % (done, stencil, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=256, help="grid points per side")
+    ap.add_argument("--stencil", type=int, default=7, choices=[7, 27])
+    ap.add_argument("--fused", type=int, default=0, help="1: fused SpMV+dot and AXPY+AXPY+PC+norm+dot kernels (same arithmetic)")
+    ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (0 auto, 1 plain loads, 2 non-temporal loads)")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+    assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch N > 1 with torch.distributed.run)"
+
+    from petsc_amd import _lib
+    from petsc_amd import dist as pdist
+    hx = _lib.init(local_rank)
+    _, ks = _lib.load()
+
+    n, N = args.n, args.n ** 3
+    ranges = pdist.split_ownership(N, world)
+    rs, re = int(ranges[rank]), int(ranges[rank + 1])
+    ai, aj, aa = assemble(ks, args.stencil, n, rs, re)
+    m = re - rs
+    if world > 1:
+        idb = (C.c_char * 128)()
+        if rank == 0:
+            _lib.chk(hx.hipxCommGetUniqueId(idb))
+        box = [bytes(idb)]
+        dist.broadcast_object_list(box, src=0)
+        _lib.chk(hx.hipxCommInit(box[0], rank, world))
+        plan = pdist.build_plan(ai, aj, aa, ranges, rank, dist=dist)
+        M, keep = pdist.create_device_mat(plan, world)
+        nnz_local = int(plan["Ai"][-1])
+    else:
+        A = _lib.mat_create_csr(m, m, ai, aj, aa)
+        M, keep = _lib.HipxMat(m=m, A=A, B=None, halo=None, lvec=None, nranks=1), [A]
+        nnz_local = int(ai[-1])
+    _lib.chk(hx.hipxMatSetSpMVVariant(M.A, args.variant))
+
+    # b = A * 1 (ex2.c:139 style), x0 = 0
+    ones = _lib.DVec(m, np.ones(m))
+    B = _lib.DVec(m)
+    X = _lib.DVec(m)
+    _lib.chk(ks.HipxMatMult(C.byref(M), ones.ptr, B.ptr))
+    pc = _lib.HipxPC()
+    ks.HipxPCSetDefaults(C.byref(pc))
+    _lib.chk(ks.HipxPCSetUp(C.byref(pc), C.byref(M)))
+    ksp = _lib.HipxKSP()
+    ks.HipxKSPSetDefaults(C.byref(ksp))
+    ksp.rtol, ksp.abstol, ksp.divtol = 1e-50, 1e-300, 1e300
+    ksp.max_it = args.warmup + args.steps + 10
+    ksp.fused = args.fused
+    _lib.chk(ks.HipxKSPCGBegin(C.byref(ksp), C.byref(M), C.byref(pc), B.ptr, X.ptr))
+    _lib.chk(ks.HipxKSPCGStep(C.byref(ksp), C.byref(M), C.byref(pc), B.ptr, X.ptr, args.warmup))
+    assert ksp.reason == 0 and ksp.its == args.warmup, (ksp.reason, ksp.its)
+
+    def sync():
+        _lib.chk(hx.hipxDeviceSynchronize())
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    _lib.chk(hx.hipxProfileSpMV(1))
+    sync()
+    t0 = time.perf_counter()
+    _lib.chk(ks.HipxKSPCGStep(C.byref(ksp), C.byref(M), C.byref(pc), B.ptr, X.ptr, args.steps))
+    sync()
+    elapsed = time.perf_counter() - t0
+    assert ksp.reason == 0 and ksp.its == args.warmup + args.steps, (ksp.reason, ksp.its)
+    cnt, tot_ms = C.c_int(), C.c_double()
+    _lib.chk(hx.hipxProfileSpMVGet(C.byref(cnt), C.byref(tot_ms)))
+    _lib.chk(hx.hipxProfileSpMV(0))
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    rnorm = float(ksp.rnorm)
+
+    # roofline of the dominant kernel (the diagonal-block / sequential SpMV launch of this rank)
+    spmv_bytes = 12 * nnz_local + 4 * (m + 1) + 16 * m  # val + col + row offsets + x + y
+    spmv_ms = tot_ms.value / max(cnt.value, 1)
+    achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+
+    out = None
+    if rank == 0:
+        value = args.steps / elapsed
+        out = {
+            "metric": "CG iterations/sec, %d-pt Poisson %d^3 fp64, KSPCG+PCJACOBI" % (args.stencil, n),
+            "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "3-D %d-pt Poisson %d^3 (N=%d rows, nnz=%d local), KSPCG + PCJACOBI, b = A*1, x0 = 0; rows split over %d rank(s)"
+                                   % (args.stencil, n, N, nnz_local, world),
+                       "global_rows": N, "parallelism": "rows%d" % world, "fused": args.fused, "spmv_variant": args.variant,
+                       "residual_norm_after": rnorm},
+            "roofline": {"bound": "hbm", "kernel": "spmv_stream_kernel (CSR MatMult)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": cnt.value, "avg_launch_ms": spmv_ms, "algorithmic_bytes": spmv_bytes,
+                         "frac_of_measured_copy_peak_6290": achieved / 6290.0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            bh = B.get()
+            out["cpu_baseline"] = cpu_baseline(ai, aj, aa, bh, args.cpu_baseline_seconds, args.stencil, n)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        _lib.chk(hx.hipxCommFinalize())
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+/*
+ * hipx.h -- C ABI of libhipx.so: the MI355X (gfx950) kernels behind PETSc's Krylov inner loop.
+ *
+ * This is the drop-in boundary.  Plain C: raw device pointers, sizes, scalars; no PETSc types, no
+ * torch types, no C++.  The PETSc-facing plugin (petsc_amd/plugin, libpetschipx.so) fills the
+ * reference's ops tables (struct _VecOps include/petsc/private/vecimpl.h:18-110, struct _MatOps
+ * include/petsc/private/matimpl.h:38-213, struct _PCOps include/petsc/private/pcimpl.h:11-31) with
+ * thin C functions that call the entry points below; INTEGRATION.md shows that binding.
+ * Each entry point cites the reference routine it replaces (paths relative to the PETSc tree).
+ *
+ * Conventions
+ *   - one process drives one GPU (hipxInit(device)); all work is enqueued on the library's compute
+ *     stream; calls that return a scalar to the host block until it is valid, all other calls may
+ *     return with work enqueued (stream order keeps them correct) -- SURVEY.md 8(b) "Threading".
+ *   - every function returns 0 (== PETSC_SUCCESS) or a nonzero code: HIPX_ERR_* below or
+ *     HIPX_ERR_HIP_BASE + hipError_t.  hipxGetErrorString() describes the last failure.
+ *   - PetscScalar = double, PetscInt = int32 (hipx_int); row offsets may be 64-bit on request.
+ *   - arithmetic is IEEE fp64 without FMA contraction: elementwise kernels and the CSR row sums
+ *     reproduce the reference's -O2 x86-64 results bit for bit; reductions use a fixed,
+ *     run-to-run deterministic order (they cannot match a BLAS bitwise, see oracle/petsc_oracle.h).
+ */
+#ifndef HIPX_H
+#define HIPX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t hipx_int;
+
+#define HIPX_SUCCESS        0
+#define HIPX_ERR_ARG        62   /* PETSC_ERR_ARG_WRONG      */
+#define HIPX_ERR_MEM        55   /* PETSC_ERR_MEM            */
+#define HIPX_ERR_SUP        56   /* PETSC_ERR_SUP            */
+#define HIPX_ERR_ORDER      58   /* PETSC_ERR_ORDER (not initialised) */
+#define HIPX_ERR_GPU        97   /* PETSC_ERR_GPU            */
+#define HIPX_ERR_ZEROPIVOT  71   /* PETSC_ERR_MAT_LU_ZRPVT   */
+#define HIPX_ERR_HIP_BASE   10000
+
+/* ---- runtime ------------------------------------------------------------------------------- */
+int         hipxInit(int device);            /* hipSetDevice + streams + reduction scratch; idempotent */
+int         hipxFinalize(void);
+int         hipxIsInitialized(void);
+const char *hipxGetErrorString(void);
+int         hipxDeviceName(char *buf, size_t len);
+void       *hipxComputeStream(void);         /* hipStream_t, for callers that enqueue their own work */
+void       *hipxCommStream(void);
+int         hipxStreamSynchronize(void);     /* compute stream */
+int         hipxDeviceSynchronize(void);
+
+int hipxMalloc(void **dptr, size_t bytes);
+int hipxFree(void *dptr);
+int hipxMallocHost(void **hptr, size_t bytes); /* pinned */
+int hipxFreeHost(void *hptr);
+int hipxMemcpyHtoD(void *dst, const void *src, size_t bytes); /* blocking, ordered after the compute stream */
+int hipxMemcpyDtoH(void *dst, const void *src, size_t bytes); /* blocking */
+int hipxMemcpyDtoD(void *dst, const void *src, size_t bytes); /* async on the compute stream */
+int hipxMemset(void *dst, int value, size_t bytes);           /* async on the compute stream */
+
+/* timing helpers on the compute stream (HIP events; used by bench.py for roofline.achieved) */
+int hipxEventCreate(void **ev);
+int hipxEventDestroy(void *ev);
+int hipxEventRecord(void *ev);
+int hipxEventElapsedMs(void *start, void *stop, float *ms); /* synchronises on stop */
+
+/* SpMV instrumentation for roofline.achieved: when enabled, every SpMV launch (hipxMatMult / MatMultDot /
+   the diagonal-block product of hipxMatMultMPI) is bracketed by HIP events on the compute stream */
+int hipxProfileSpMV(int enable);
+int hipxProfileSpMVGet(int *count, double *total_ms); /* synchronises, returns and clears the tally */
+
+/* ---- Vec BLAS-1 (device pointers; n = local length) ------------------------------------------ */
+/* replaces VecSet_Seq dvec2.c:642 */                 int hipxVecSet(double *x, hipx_int n, double alpha);
+/* replaces VecCopy_Seq bvec2.c:151 */                int hipxVecCopy(const double *x, double *y, hipx_int n);
+/* replaces VecScale_Seq bvec2.c:167 */               int hipxVecScale(double *x, hipx_int n, double alpha);
+/* replaces VecSwap_Seq bvec2.c (BLAS dswap) */       int hipxVecSwap(double *x, double *y, hipx_int n);
+/* replaces VecAXPY_Seq bvec1.c:70 */                 int hipxVecAXPY(double *y, double alpha, const double *x, hipx_int n);
+/* replaces VecAYPX_Seq dvec2.c:753 */                int hipxVecAYPX(double *y, double beta, const double *x, hipx_int n);
+/* replaces VecAXPBY_Seq bvec1.c:91 */                int hipxVecAXPBY(double *y, double alpha, double beta, const double *x, hipx_int n);
+/* replaces VecWAXPY_Seq dvec2.c:791 */               int hipxVecWAXPY(double *w, double alpha, const double *x, const double *y, hipx_int n);
+/* replaces VecAXPBYPCZ_Seq bvec1.c:120 */            int hipxVecAXPBYPCZ(double *z, double alpha, double beta, double gamma, const double *x, const double *y, hipx_int n);
+/* replaces VecPointwiseMult_Seq bvec2.c:72 */        int hipxVecPointwiseMult(double *w, const double *x, const double *y, hipx_int n);
+/* replaces VecPointwiseDivide_Seq bvec2.c:99 */      int hipxVecPointwiseDivide(double *w, const double *x, const double *y, hipx_int n);
+/* replaces VecReciprocal_Default vinv.c:1208 */      int hipxVecReciprocal(double *x, hipx_int n);
+/* replaces VecAbs (vinv.c) */                        int hipxVecAbs(double *x, hipx_int n);
+/* replaces VecShift (rvector.c) */                   int hipxVecShift(double *x, hipx_int n, double shift);
+/* PCSetUp_Jacobi zero fix-up jacobi.c:255-266 */     int hipxVecReplaceZeros(double *x, hipx_int n, double value, hipx_int *nreplaced_host);
+/* replaces VecMAXPY_Seq dvec2.c:658: y += sum_j alpha[j] x[j]; alpha on host, x = host array of nv device pointers */
+int hipxVecMAXPY(double *y, hipx_int nv, const double *alpha, const double *const *x, hipx_int n);
+/* replaces VecMAXPBY rvector.c:1394: y = beta y + sum_j alpha[j] x[j] */
+int hipxVecMAXPBY(double *y, hipx_int nv, const double *alpha, double beta, const double *const *x, hipx_int n);
+
+/* reductions: blocking, result written to *host */
+/* replaces VecDot_Seq/VecTDot_Seq bvec1.c:10-49 */   int hipxVecDot(const double *x, const double *y, hipx_int n, double *result);
+/* replaces VecMDot_Seq/VecMTDot_Seq dvec2.c:83 */    int hipxVecMDot(const double *x, hipx_int nv, const double *const *y, hipx_int n, double *results);
+/* replaces VecNorm_Seq bvec2.c:185; type: 0 NORM_1, 1 NORM_2, 2 FROBENIUS, 3 INFINITY, 4 NORM_1_AND_2 (results[2]).
+   The returned value is the LOCAL norm (NORM_2 already square-rooted) as VecNorm_Seq returns it. */
+int hipxVecNorm(const double *x, hipx_int n, int type, double *results);
+/* replaces VecDotNorm2 (rvector.c): dp = x.y, nm = y.y in one pass */
+int hipxVecDotNorm2(const double *x, const double *y, hipx_int n, double *dp, double *nm);
+/* replaces VecSum / VecMax / VecMin (dvec2.c:592-640); idx may be NULL */
+int hipxVecSum(const double *x, hipx_int n, double *result);
+int hipxVecMax(const double *x, hipx_int n, hipx_int *idx, double *result);
+int hipxVecMin(const double *x, hipx_int n, hipx_int *idx, double *result);
+
+/* split-phase reductions (enqueue now, read later): slot in [0, HIPX_MAX_RED_SLOTS) */
+#define HIPX_MAX_RED_SLOTS 64
+int hipxVecDotBegin(const double *x, const double *y, hipx_int n, int slot);
+int hipxRedEnd(int slot, int nvals, double *results); /* synchronises the compute stream, copies nvals sums */
+
+/* fused CG kernels (same arithmetic as the separate calls, fewer HBM passes) */
+/* x += a p ; r -= a w ; z = r .* d ; sums[0] = z.z ; sums[1] = z.r  (cg.c:305-309,344 with PCJACOBI) */
+int hipxCGFusedUpdate(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n, double *sums2);
+
+/* ---- Mat (CSR = Mat_SeqAIJ src/mat/impls/aij/seq/aij.h:47-78,150-168) ----------------------- */
+typedef struct hipxMat_s *hipxMat;
+
+/* Upload a host CSR matrix (m rows, n cols, 0-based, as MatAssemblyEnd_SeqAIJ leaves it; aij.c:1085).
+   i has m+1 entries, j/a have i[m].  The triggering event in the plugin is MatAssemblyEnd. */
+int hipxMatCreateCSR(hipx_int m, hipx_int n, const hipx_int *i, const hipx_int *j, const double *a, hipxMat *A);
+int hipxMatCreateCSR64(hipx_int m, hipx_int n, const int64_t *i, const hipx_int *j, const double *a, hipxMat *A);
+/* compressed-row variant (Mat_CompressedRow matimpl.h:425-430) for the MPIAIJ off-diagonal block:
+   only rows ridx[0..nrows) hold entries; ci has nrows+1 offsets. */
+int hipxMatCreateCSRCompressedRow(hipx_int m, hipx_int n, hipx_int nrows, const hipx_int *ci, const hipx_int *ridx, const hipx_int *j, const double *a, hipxMat *A);
+int hipxMatUpdateValues(hipxMat A, const double *a);          /* same nonzero pattern, new values (host) */
+int hipxMatDestroy(hipxMat *A);
+int hipxMatGetInfo(hipxMat A, hipx_int *m, hipx_int *n, int64_t *nnz, int64_t *device_bytes);
+/* replaces MatMult_SeqAIJ aij.c:1444 */              int hipxMatMult(hipxMat A, const double *x, double *y);
+/* replaces MatMultAdd_SeqAIJ aij.c:1606 (z may alias y) */ int hipxMatMultAdd(hipxMat A, const double *x, const double *y, double *z);
+/* replaces MatGetDiagonal_SeqAIJ aij.c:1347 */       int hipxMatGetDiagonal(hipxMat A, double *d);
+/* replaces MatSOR_SeqAIJ aij.c:1842 (flag = MatSORType bits petscmat.h:1664-1671); b, x device vectors */
+int hipxMatSOR(hipxMat A, const double *b, double omega, int flag, double shift, hipx_int its, hipx_int lits, double *x);
+/* tuning knobs (plugin option -mat_aijhipx_*): kernel variant 0 = auto */
+int hipxMatSetSpMVVariant(hipxMat A, int variant);
+/* y = A x and *dot = x.y fused in the SpMV epilogue (cg.c:257-258) */
+int hipxMatMultDot(hipxMat A, const double *x, double *y, double *dot);
+
+/* ---- PC ------------------------------------------------------------------------------------------ */
+/* PCSetUp_Jacobi jacobi.c:205-266 (DIAGONAL, fixdiag): d = 1/diag(A), zeros -> 1 */
+int hipxPCJacobiSetUp(hipxMat A, double *dinv);
+
+/* ---- multi-GPU: MPIAIJ ghost exchange (replaces VecScatterBegin/End vscat.c:1294,1353 on this path
+        and PetscSFBcast{Begin,End}_Basic sfbasic.c:352-390) and scalar all-reduces
+        (VecXDot_MPI_Default pvecimpl.h:105-111, VecNorm_MPI_Default pvecimpl.h:150-175) ------------- */
+#define HIPX_COMM_ID_BYTES 128
+int hipxCommGetUniqueId(void *id128);                         /* rank 0; broadcast the bytes yourself (MPI_Bcast / torch store) */
+int hipxCommInit(const void *id128, int rank, int nranks);    /* RCCL communicator on the comm stream */
+int hipxCommFinalize(void);
+int hipxCommRank(int *rank, int *nranks);
+int hipxCommAllreduceSum(double *host_vals, int n);           /* n <= 64 doubles, device-staged ncclAllReduce */
+
+typedef struct hipxHalo_s *hipxHalo;
+/* nsend/nrecv neighbours; send_idx = local indices of owned entries to pack per neighbour (concatenated,
+   offsets in send_off[nsend+1]); received values land contiguously in lvec (recv_off[nrecv+1]) exactly as
+   mmaij.c:108-117 lays lvec[k] <-> garray[k]. */
+int hipxHaloCreate(int nsend, const int *send_ranks, const hipx_int *send_off, const hipx_int *send_idx,
+                   int nrecv, const int *recv_ranks, const hipx_int *recv_off, hipxHalo *h);
+int hipxHaloDestroy(hipxHalo *h);
+int hipxHaloBegin(hipxHalo h, const double *x, double *lvec); /* pack on compute stream -> send/recv on comm stream */
+int hipxHaloEnd(hipxHalo h);                                  /* compute stream waits for the exchange */
+/* replaces MatMult_MPIAIJ mpiaij.c:1047-1061: halo begin; y = Ad x (overlapped); halo end; y += Bo lvec */
+int hipxMatMultMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *lvec, double *y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,113 @@
+/*
+ * hipx_ksp.h -- C host layer above the kernel ABI (hipx.h): the Krylov callers of the hot path,
+ * restated in C so that the path can be driven without libpetsc (bench.py, tests, torchrun ranks).
+ *
+ * It mirrors the reference's caller code, statement by statement, over device vectors:
+ *   KSPSolve_CG      src/ksp/ksp/impls/cg/cg.c:119-352
+ *   KSPSolve_GMRES   src/ksp/ksp/impls/gmres/gmres.c:88-238,298-395 + borthog2.c:35-113
+ *   KSPConvergedDefault  src/ksp/ksp/interface/iterativ.c:1490-1585
+ *   PCApply_Jacobi / PCApply_SOR / PCApply_None   jacobi.c:354, sor.c:27, pcnone
+ *   MatMult_SeqAIJ / MatMult_MPIAIJ   aij.c:1444, mpiaij.c:1047
+ *   VecDot_MPI / VecNorm_MPI reductions   pvecimpl.h:97-175 (local kernel + all-reduce)
+ * When PETSc itself is the host (libpetschipx.so plugin), none of this is used: the reference's own
+ * KSPSolve_CG/GMRES call the same kernels through the Vec/Mat ops tables.
+ */
+#ifndef HIPX_KSP_H
+#define HIPX_KSP_H
+#include "hipx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { HIPX_PC_NONE = 0, HIPX_PC_JACOBI = 1, HIPX_PC_SOR = 2 };
+enum { HIPX_KSP_NORM_NONE = 0, HIPX_KSP_NORM_PRECONDITIONED = 1, HIPX_KSP_NORM_UNPRECONDITIONED = 2, HIPX_KSP_NORM_NATURAL = 3 };
+
+/* Mat: MATSEQAIJHIPX (A only) or MATMPIAIJHIPX (diag block A, off-diag block B, halo, lvec) */
+typedef struct {
+  hipx_int m;        /* local rows */
+  hipxMat  A;        /* seq matrix or diagonal block */
+  hipxMat  B;        /* off-diagonal block (compressed rows), NULL when sequential */
+  hipxHalo halo;     /* ghost exchange plan, NULL when sequential */
+  double  *lvec;     /* device ghost values, length = ghost count */
+  int      nranks;   /* communicator size (1 = no reductions across ranks) */
+} HipxMat;
+
+typedef struct {
+  int      type;
+  double  *dinv;     /* PCJACOBI: device inverse diagonal (jacobi.c:205-266) */
+  int      sor_flag; /* MatSORType, default SOR_LOCAL_SYMMETRIC_SWEEP (sor.c:442-446) */
+  double   sor_omega, sor_shift;
+  hipx_int sor_its, sor_lits;
+} HipxPC;
+
+typedef struct {
+  /* parameters (defaults: itfunc.c KSPCreate, cg.c:696, gmres.c:906-915) */
+  int      normtype;
+  double   rtol, abstol, divtol;
+  hipx_int max_it, min_it;
+  hipx_int gmres_restart;
+  double   gmres_haptol;
+  int      gmres_cgs_refine; /* 0 never, 1 if needed, 2 always */
+  int      guess_nonzero;
+  int      fused;            /* CG only: use the fused SpMV+dot / update+PC+dots kernels (same arithmetic) */
+  /* results */
+  hipx_int its;
+  int      reason;
+  double   rnorm, rnorm0, ttol;
+  double  *history;          /* host array, hist_len entries (KSPSetResidualHistory) */
+  hipx_int hist_len, hist_n;
+  /* CG stepping state (HipxKSPCGBegin / HipxKSPCGStep) */
+  double  *R, *Z, *P;        /* device work vectors (KSPSetWorkVecs(3), cg.c:80) */
+  double   beta, betaold, dpi, a;
+  hipx_int i;
+  hipx_int work_n;
+} HipxKSP;
+
+void HipxKSPSetDefaults(HipxKSP *ksp);
+void HipxPCSetDefaults(HipxPC *pc);
+int  HipxKSPDestroyWork(HipxKSP *ksp);
+
+int HipxMatMult(HipxMat *A, const double *x, double *y);                 /* MatMult_SeqAIJ | MatMult_MPIAIJ */
+int HipxPCSetUp(HipxPC *pc, HipxMat *A);                                 /* PCSetUp_Jacobi | PCSetUp_SOR (nothing) */
+int HipxPCApply(HipxPC *pc, HipxMat *A, const double *x, double *y);     /* PCApply */
+int HipxPCDestroy(HipxPC *pc);
+int HipxVecDot(HipxMat *A, const double *x, const double *y, hipx_int n, double *r);   /* VecTDot_Seq | _MPI */
+int HipxVecNorm2(HipxMat *A, const double *x, hipx_int n, double *r);                   /* VecNorm_Seq | _MPI, NORM_2 */
+
+int HipxKSPSolve_CG(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, double *x);
+int HipxKSPSolve_GMRES(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, double *x);
+
+/* split form of KSPSolve_CG for benchmarking exactly K iterations: Begin = cg.c:134-217 (set-up, first
+   residual/preconditioned norm), Step(nsteps) = nsteps passes of the loop body cg.c:220-349 */
+int HipxKSPCGBegin(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, double *x);
+int HipxKSPCGStep(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, double *x, hipx_int nsteps);
+
+/* ---- MATMPIAIJHIPX host set-up (petsc_amd/host/hipx_mpiaij.c) ------------------------------------ */
+typedef struct {
+  hipx_int  m, nghost, nrows_c;
+  hipx_int *Ai, *Aj; /* diagonal block, local column ids */
+  double   *Aa;
+  hipx_int *Bi, *Bj; /* off-diagonal block in compressed-row form: Bi[nrows_c+1], Bj = positions in garray */
+  double   *Ba;
+  hipx_int *ridx;    /* Mat_CompressedRow.rindex (matimpl.h:425-430) */
+  hipx_int *garray;  /* sorted global ghost columns (mmaij.c:51,119) */
+} HipxMPIAIJSplit;
+/* MatSetValues_MPIAIJ diag/off-diag split (mpiaij.c:560-640) + MatSetUpMultiply_MPIAIJ (mmaij.c:8-125) */
+int      HipxMatSetUpMultiply_MPIAIJ(hipx_int m, hipx_int cstart, hipx_int cend, const hipx_int *ai, const hipx_int *aj, const double *aa, HipxMPIAIJSplit *s);
+void     HipxMPIAIJSplitFree(HipxMPIAIJSplit *s);
+hipx_int HipxMPIAIJSplitSize(void);
+/* receive side of the ghost plan: garray grouped by owning rank (contiguous because sorted) */
+int  HipxHaloRecvPlan(hipx_int nghost, const hipx_int *garray, int nranks, const hipx_int *ranges, int *nrecv, int *recv_ranks, hipx_int *recv_off);
+/* PetscSplitOwnership (src/sys/utils/psplit.c) */
+void HipxSplitOwnership(hipx_int N, int size, hipx_int *ranges);
+
+/* ---- driver assembly (petsc_amd/host/hipx_drivers.c): ex2.c:70-94, 3-D 7-point analogue, bench_kspsolve.c:115-303 */
+int64_t HipxAssemble_ex2(hipx_int m, hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, hipx_int *aj, double *aa);
+int64_t HipxAssemble_poisson7(hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, hipx_int *aj, double *aa);
+int64_t HipxAssemble_bench27(hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, hipx_int *aj, double *aa);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,98 @@
+"""ctypes bindings of the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY: import from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never from petsc_amd/."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class OrcKSP(C.Structure):
+    _fields_ = [("m", C.c_int), ("ai", C.c_void_p), ("aj", C.c_void_p), ("aa", C.c_void_p), ("nranks", C.c_int), ("ranges", C.c_void_p),
+                ("pc_type", C.c_int), ("sor_flag", C.c_int), ("sor_omega", C.c_double), ("sor_shift", C.c_double), ("sor_its", C.c_int),
+                ("sor_lits", C.c_int), ("normtype", C.c_int), ("rtol", C.c_double), ("abstol", C.c_double), ("divtol", C.c_double),
+                ("max_it", C.c_int), ("min_it", C.c_int), ("gmres_restart", C.c_int), ("gmres_haptol", C.c_double), ("gmres_cgs_refine", C.c_int),
+                ("guess_nonzero", C.c_int), ("its", C.c_int), ("reason", C.c_int), ("rnorm", C.c_double), ("history", C.c_void_p),
+                ("hist_len", C.c_int), ("hist_n", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", HERE, "-s"])
+        _lib = C.CDLL(path)
+        for f in ("orc_laplace2d_5pt", "orc_poisson3d_7pt", "orc_poisson3d_27pt"):
+            getattr(_lib, f).restype = C.c_int64
+        _lib.orc_VecDot_Seq.restype = C.c_double
+        _lib.orc_VecNorm_Seq.restype = C.c_double
+    return _lib
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def stencil(kind, n, rstart=None, rend=None, m=None):
+    """CSR (ai, aj, aa) of rows [rstart, rend) with global columns.  kind: '5pt' (m x n grid), '7pt', '27pt'."""
+    L = lib()
+    if kind == "5pt":
+        N = (m if m is not None else n) * n
+        f = lambda *a: L.orc_laplace2d_5pt(m if m is not None else n, n, *a)  # noqa: E731
+    elif kind == "7pt":
+        N = n ** 3
+        f = lambda *a: L.orc_poisson3d_7pt(n, *a)  # noqa: E731
+    elif kind == "27pt":
+        N = n ** 3
+        f = lambda *a: L.orc_poisson3d_27pt(n, *a)  # noqa: E731
+    else:
+        raise ValueError(kind)
+    rs = 0 if rstart is None else rstart
+    re = N if rend is None else rend
+    nz = f(rs, re, None, None, None)
+    ai = np.zeros(re - rs + 1, np.int32)
+    aj = np.zeros(max(nz, 1), np.int32)
+    aa = np.zeros(max(nz, 1), np.float64)
+    f(rs, re, P(ai), P(aj), P(aa))
+    return ai, aj[:nz], aa[:nz]
+
+
+def matmult(ai, aj, aa, x):
+    y = np.zeros(len(ai) - 1)
+    lib().orc_MatMult_SeqAIJ(len(ai) - 1, P(ai), P(aj), P(aa), P(x), P(y))
+    return y
+
+
+def ksp_solve(kind, ai, aj, aa, b, pc="jacobi", rtol=1e-5, max_it=10000, normtype=1, restart=30, refine=0, sor_flag=12, omega=1.0,
+              nranks=1, x0=None, abstol=1e-50, sor_its=1, sor_lits=1):
+    L = lib()
+    k = OrcKSP()
+    L.orc_KSPSetDefaults(C.byref(k))
+    m = len(ai) - 1
+    k.m = m
+    k.ai, k.aj, k.aa = ai.ctypes.data, aj.ctypes.data, aa.ctypes.data
+    k.pc_type = {"none": 0, "jacobi": 1, "sor": 2}[pc]
+    k.sor_flag = sor_flag
+    k.sor_omega = omega
+    k.sor_its, k.sor_lits = sor_its, sor_lits
+    k.rtol, k.abstol, k.max_it, k.normtype = rtol, abstol, max_it, normtype
+    k.gmres_restart, k.gmres_cgs_refine = restart, refine
+    ranges = None
+    if nranks > 1:
+        ranges = np.zeros(nranks + 1, np.int32)
+        L.orc_PetscSplitOwnership(m, nranks, P(ranges))
+        k.nranks = nranks
+        k.ranges = ranges.ctypes.data
+    hist = np.zeros(max_it + 2 + max_it // max(restart, 1) + 2)
+    k.history, k.hist_len = hist.ctypes.data, len(hist)
+    x = np.zeros(m) if x0 is None else np.array(x0, dtype=np.float64)
+    k.guess_nonzero = 0 if x0 is None else 1
+    bb = np.ascontiguousarray(b, dtype=np.float64)
+    (L.orc_KSPSolve_CG if kind == "cg" else L.orc_KSPSolve_GMRES)(C.byref(k), P(bb), P(x))
+    return x, int(k.its), int(k.reason), hist[:min(k.hist_n, len(hist))].copy()

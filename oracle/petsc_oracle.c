@@ -1,0 +1,993 @@
+/*
+ * petsc_oracle.c -- CPU restatement of the reference KSP hot path.  TEST INFRASTRUCTURE ONLY
+ * (see petsc_oracle.h).  Build: gcc -O2 -ffp-contract=off -fPIC -shared (oracle/Makefile).
+ *
+ * Each function follows the cited reference routine statement by statement where the arithmetic
+ * order matters (SpMV row sums, SOR sweeps, AYPX/WAXPY/AXPBY special cases, Givens updates).
+ */
+#include "petsc_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ============================ synthetic operators ============================================ */
+
+/* src/ksp/ksp/tutorials/ex2.c:70-94.  Ii = i*n + j, j fastest; -1 at Ii-n (i>0), Ii+n (i<m-1),
+   Ii-1 (j>0), Ii+1 (j<n-1); 4 on the diagonal.  MatAssemblyEnd_SeqAIJ keeps columns sorted, so
+   the assembled row is (Ii-n, Ii-1, Ii, Ii+1, Ii+n). */
+int64_t orc_laplace2d_5pt(OInt m, OInt n, OInt rstart, OInt rend, OInt *ai, OInt *aj, OScalar *aa)
+{
+  int64_t nz = 0;
+  for (OInt Ii = rstart; Ii < rend; Ii++) {
+    OInt i = Ii / n, j = Ii - i * n;
+    if (ai) ai[Ii - rstart] = (OInt)nz;
+#define PUT(J, V) \
+  do { \
+    if (ai) { aj[nz] = (J); aa[nz] = (V); } \
+    nz++; \
+  } while (0)
+    if (i > 0) PUT(Ii - n, -1.0);
+    if (j > 0) PUT(Ii - 1, -1.0);
+    PUT(Ii, 4.0);
+    if (j < n - 1) PUT(Ii + 1, -1.0);
+    if (i < m - 1) PUT(Ii + n, -1.0);
+  }
+  if (ai) ai[rend - rstart] = (OInt)nz;
+  return nz;
+}
+
+/* 3-D analogue of ex2: Ii = x + n*y + n*n*z; 6 on the diagonal, -1 at +-1, +-n, +-n^2. */
+int64_t orc_poisson3d_7pt(OInt n, OInt rstart, OInt rend, OInt *ai, OInt *aj, OScalar *aa)
+{
+  int64_t nz = 0;
+  const OInt n2 = n * n;
+  for (OInt Ii = rstart; Ii < rend; Ii++) {
+    OInt x = Ii % n, y = (Ii / n) % n, z = Ii / n2;
+    if (ai) ai[Ii - rstart] = (OInt)nz;
+    if (z > 0) PUT(Ii - n2, -1.0);
+    if (y > 0) PUT(Ii - n, -1.0);
+    if (x > 0) PUT(Ii - 1, -1.0);
+    PUT(Ii, 6.0);
+    if (x < n - 1) PUT(Ii + 1, -1.0);
+    if (y < n - 1) PUT(Ii + n, -1.0);
+    if (z < n - 1) PUT(Ii + n2, -1.0);
+  }
+  if (ai) ai[rend - rstart] = (OInt)nz;
+  return nz;
+}
+
+/* src/ksp/ksp/tutorials/bench_kspsolve.c:115-303 (FillCOO): h = 1/(n-1); corner -h/13, edge -3h/26,
+   face -3h/13, centre 44h/13, written exactly as the reference writes them (-1.0/13*h, ...).  The COO
+   triples are sorted by column at assembly, so the row is emitted in increasing column order
+   (dz outer, dy, dx inner). */
+int64_t orc_poisson3d_27pt(OInt n, OInt rstart, OInt rend, OInt *ai, OInt *aj, OScalar *aa)
+{
+  int64_t       nz = 0;
+  const OInt    n2 = n * n, n1 = n - 1;
+  const OScalar h     = 1.0 / (n - 1);
+  const OScalar vcorn = -1.0 / 13 * h, vedge = -3.0 / 26 * h, vface = -3.0 / 13 * h, vcent = 44.0 / 13 * h;
+  for (OInt Ii = rstart; Ii < rend; Ii++) {
+    OInt x = Ii % n, y = (Ii / n) % n, z = Ii / n2;
+    if (ai) ai[Ii - rstart] = (OInt)nz;
+    for (int dz = -1; dz <= 1; dz++) {
+      if ((dz < 0 && z == 0) || (dz > 0 && z == n1)) continue;
+      for (int dy = -1; dy <= 1; dy++) {
+        if ((dy < 0 && y == 0) || (dy > 0 && y == n1)) continue;
+        for (int dx = -1; dx <= 1; dx++) {
+          if ((dx < 0 && x == 0) || (dx > 0 && x == n1)) continue;
+          int     order = (dx != 0) + (dy != 0) + (dz != 0);
+          OScalar v     = order == 3 ? vcorn : order == 2 ? vedge : order == 1 ? vface : vcent;
+          PUT(Ii + dx + dy * n + dz * n2, v);
+        }
+      }
+    }
+  }
+  if (ai) ai[rend - rstart] = (OInt)nz;
+  return nz;
+}
+#undef PUT
+
+/* ============================ Mat_SeqAIJ ====================================================== */
+
+/* src/mat/impls/aij/seq/aij.c:1486-1494 with PetscSparseDensePlusDot (aij.h:608-614, the plain-loop
+   branch: no unroll macro, no AVX-512 at -O2 without -march): sum starts at 0 and accumulates
+   left to right, one rounded multiply and one rounded add per entry. */
+void orc_MatMult_SeqAIJ(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, const OScalar *x, OScalar *y)
+{
+  for (OInt i = 0; i < m; i++) {
+    OInt           n   = ai[i + 1] - ai[i];
+    const OInt    *idx = aj + ai[i];
+    const OScalar *v   = aa + ai[i];
+    OScalar        sum = 0.0;
+    for (OInt k = 0; k < n; k++) sum += v[k] * x[idx[k]];
+    y[i] = sum;
+  }
+}
+
+/* aij.c:1467-1481: compressed-row variant (y zeroed, only rows listed in ridx are computed). */
+void orc_MatMult_SeqAIJ_cprow(OInt m, OInt nrows, const OInt *ci, const OInt *ridx, const OInt *aj, const OScalar *aa, const OScalar *x, OScalar *y)
+{
+  memset(y, 0, (size_t)m * sizeof(OScalar));
+  for (OInt i = 0; i < nrows; i++) {
+    OInt    n   = ci[i + 1] - ci[i];
+    OScalar sum = 0.0;
+    for (OInt k = 0; k < n; k++) sum += aa[ci[i] + k] * x[aj[ci[i] + k]];
+    y[ridx[i]] = sum;
+  }
+}
+
+/* aij.c:1606-1658: z_i = y_i + sum_k a_k x_jk, the sum seeded with y_i. */
+void orc_MatMultAdd_SeqAIJ(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, const OScalar *x, const OScalar *y, OScalar *z)
+{
+  for (OInt i = 0; i < m; i++) {
+    OInt    n   = ai[i + 1] - ai[i];
+    OScalar sum = y[i];
+    for (OInt k = 0; k < n; k++) sum += aa[ai[i] + k] * x[aj[ai[i] + k]];
+    z[i] = sum;
+  }
+}
+
+/* include/petsc/private/matimpl.h:1835-1890 (MatGetDiagonalMarkers): diag[i] = index of the entry
+   with column i in row i; if missing, the reference points at the first entry beyond the diagonal and
+   reports diagDense = false.  Returns 1 when every diagonal entry is present. */
+int orc_MatGetDiagonalMarkers_SeqAIJ(OInt m, const OInt *ai, const OInt *aj, OInt *diag)
+{
+  int dense = 1;
+  for (OInt i = 0; i < m; i++) {
+    OInt k, found = 0;
+    for (k = ai[i]; k < ai[i + 1]; k++) {
+      if (aj[k] >= i) {
+        found = (aj[k] == i);
+        break;
+      }
+    }
+    diag[i] = k;
+    if (!found) dense = 0;
+  }
+  return dense;
+}
+
+/* aij.c:1347-1380: v_i = a[diag[i]] when the diagonal entry exists, else 0. */
+void orc_MatGetDiagonal_SeqAIJ(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, OScalar *v)
+{
+  for (OInt i = 0; i < m; i++) {
+    v[i] = 0.0;
+    for (OInt k = ai[i]; k < ai[i + 1]; k++) {
+      if (aj[k] == i) {
+        v[i] = aa[k];
+        break;
+      }
+    }
+  }
+}
+
+/* aij.c:1797-1840 (MatInvertDiagonalForSOR_SeqAIJ) + aij.c:1842-2007 (MatSOR_SeqAIJ).
+   PetscSparseDenseMinusDot(sum,r,xv,xi,nnz): sum -= xv[k]*r[xi[k]], left to right (aij.h:519-560).
+   Returns 0, or 1 if a zero diagonal was met (the reference flags MAT_FACTOR_NUMERIC_ZEROPIVOT). */
+int orc_MatSOR_SeqAIJ(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, const OScalar *b, OScalar omega, int flag, OScalar fshift, OInt its,
+                      OInt lits, OScalar *x)
+{
+  OInt    *diag  = (OInt *)malloc((size_t)(m + 1) * sizeof(OInt));
+  OScalar *idiag = (OScalar *)malloc((size_t)(m + 1) * sizeof(OScalar));
+  OScalar *mdiag = (OScalar *)malloc((size_t)(m + 1) * sizeof(OScalar));
+  OScalar *t     = (OScalar *)malloc((size_t)(m + 1) * sizeof(OScalar));
+  int      zeropivot = 0;
+  OInt     i, n;
+  const OInt    *idx;
+  const OScalar *v, *xb;
+  OScalar        sum, d, scale;
+
+  its = its * lits; /* aij.c:1855 */
+  orc_MatGetDiagonalMarkers_SeqAIJ(m, ai, aj, diag);
+  if (omega == 1.0 && fshift <= 0.0) { /* aij.c:1815-1827 */
+    for (i = 0; i < m; i++) {
+      mdiag[i] = aa[diag[i]];
+      if (!fabs(mdiag[i])) zeropivot = 1;
+      idiag[i] = 1.0 / aa[diag[i]];
+    }
+  } else { /* aij.c:1829-1833 */
+    for (i = 0; i < m; i++) {
+      mdiag[i] = aa[diag[i]];
+      idiag[i] = omega / (fshift + aa[diag[i]]);
+    }
+  }
+
+#define MINUSDOT(sum, r, xv, xi, nnz) \
+  do { \
+    for (OInt __k = 0; __k < (nnz); __k++) (sum) -= (xv)[__k] * (r)[(xi)[__k]]; \
+  } while (0)
+#define PLUSDOT(sum, r, xv, xi, nnz) \
+  do { \
+    for (OInt __k = 0; __k < (nnz); __k++) (sum) += (xv)[__k] * (r)[(xi)[__k]]; \
+  } while (0)
+
+  if (flag == ORC_SOR_APPLY_UPPER) { /* aij.c:1867-1884 */
+    for (i = 0; i < m; i++) {
+      d   = fshift + mdiag[i];
+      n   = ai[i + 1] - diag[i] - 1;
+      idx = aj + diag[i] + 1;
+      v   = aa + diag[i] + 1;
+      sum = b[i] * d / omega;
+      PLUSDOT(sum, b, v, idx, n);
+      x[i] = sum;
+    }
+    goto done;
+  }
+  if (flag & ORC_SOR_EISENSTAT) { /* aij.c:1887-1929 */
+    scale = (2.0 / omega) - 1.0;
+    for (i = m - 1; i >= 0; i--) {
+      n   = ai[i + 1] - diag[i] - 1;
+      idx = aj + diag[i] + 1;
+      v   = aa + diag[i] + 1;
+      sum = b[i];
+      MINUSDOT(sum, x, v, idx, n);
+      x[i] = sum * idiag[i];
+    }
+    for (i = 0; i < m; i++) t[i] = b[i] - scale * (aa[diag[i]]) * x[i];
+    for (i = 0; i < m; i++) {
+      n   = diag[i] - ai[i];
+      idx = aj + ai[i];
+      v   = aa + ai[i];
+      sum = t[i];
+      MINUSDOT(sum, t, v, idx, n);
+      t[i] = sum * idiag[i];
+      x[i] += t[i];
+    }
+    goto done;
+  }
+  if (flag & ORC_SOR_ZERO_INITIAL_GUESS) { /* aij.c:1930-1960 */
+    if (flag & ORC_SOR_FORWARD_SWEEP || flag & ORC_SOR_LOCAL_FORWARD_SWEEP) {
+      for (i = 0; i < m; i++) {
+        n   = diag[i] - ai[i];
+        idx = aj + ai[i];
+        v   = aa + ai[i];
+        sum = b[i];
+        MINUSDOT(sum, x, v, idx, n);
+        t[i] = sum;
+        x[i] = sum * idiag[i];
+      }
+      xb = t;
+    } else xb = b;
+    if (flag & ORC_SOR_BACKWARD_SWEEP || flag & ORC_SOR_LOCAL_BACKWARD_SWEEP) {
+      for (i = m - 1; i >= 0; i--) {
+        n   = ai[i + 1] - diag[i] - 1;
+        idx = aj + diag[i] + 1;
+        v   = aa + diag[i] + 1;
+        sum = xb[i];
+        MINUSDOT(sum, x, v, idx, n);
+        if (xb == b) x[i] = sum * idiag[i];
+        else x[i] = (1 - omega) * x[i] + sum * idiag[i];
+      }
+    }
+    its--;
+  }
+  while (its--) { /* aij.c:1961-2002 */
+    if (flag & ORC_SOR_FORWARD_SWEEP || flag & ORC_SOR_LOCAL_FORWARD_SWEEP) {
+      for (i = 0; i < m; i++) {
+        n   = diag[i] - ai[i];
+        idx = aj + ai[i];
+        v   = aa + ai[i];
+        sum = b[i];
+        MINUSDOT(sum, x, v, idx, n);
+        t[i] = sum;
+        n    = ai[i + 1] - diag[i] - 1;
+        idx  = aj + diag[i] + 1;
+        v    = aa + diag[i] + 1;
+        MINUSDOT(sum, x, v, idx, n);
+        x[i] = (1. - omega) * x[i] + sum * idiag[i];
+      }
+      xb = t;
+    } else xb = b;
+    if (flag & ORC_SOR_BACKWARD_SWEEP || flag & ORC_SOR_LOCAL_BACKWARD_SWEEP) {
+      for (i = m - 1; i >= 0; i--) {
+        sum = xb[i];
+        if (xb == b) {
+          n   = ai[i + 1] - ai[i];
+          idx = aj + ai[i];
+          v   = aa + ai[i];
+          MINUSDOT(sum, x, v, idx, n);
+          x[i] = (1. - omega) * x[i] + (sum + mdiag[i] * x[i]) * idiag[i];
+        } else {
+          n   = ai[i + 1] - diag[i] - 1;
+          idx = aj + diag[i] + 1;
+          v   = aa + diag[i] + 1;
+          MINUSDOT(sum, x, v, idx, n);
+          x[i] = (1. - omega) * x[i] + sum * idiag[i];
+        }
+      }
+    }
+  }
+done:
+  free(diag);
+  free(idiag);
+  free(mdiag);
+  free(t);
+  return zeropivot;
+}
+
+/* ============================ Mat_MPIAIJ set-up ================================================ */
+
+static int cmp_oint(const void *a, const void *b)
+{
+  OInt x = *(const OInt *)a, y = *(const OInt *)b;
+  return (x > y) - (x < y);
+}
+
+/* Row slab [.,.) with global columns -> diagonal block A (columns in [cstart,cend), stored local:
+   col - cstart; mpiaij.c MatSetValues_MPIAIJ:560-640) and off-diagonal block B; then mmaij.c:27-65:
+   collect the distinct global columns of B, SORT them (PetscSortInt, mmaij.c:51) into garray and
+   rewrite B's column ids to positions in garray.  Returns ec = number of ghost columns. */
+OInt orc_MatSetUpMultiply_MPIAIJ(OInt m, OInt cstart, OInt cend, const OInt *ai, const OInt *aj, const OScalar *aa, OInt *Ai, OInt *Aj, OScalar *Aa, OInt *Bi,
+                                 OInt *Bj, OScalar *Ba, OInt *garray)
+{
+  OInt na = 0, nb = 0, ec = 0;
+  for (OInt i = 0; i < m; i++) {
+    Ai[i] = na;
+    Bi[i] = nb;
+    for (OInt k = ai[i]; k < ai[i + 1]; k++) {
+      if (aj[k] >= cstart && aj[k] < cend) {
+        Aj[na] = aj[k] - cstart;
+        Aa[na] = aa[k];
+        na++;
+      } else {
+        Bj[nb] = aj[k];
+        Ba[nb] = aa[k];
+        nb++;
+      }
+    }
+  }
+  Ai[m] = na;
+  Bi[m] = nb;
+  /* distinct global columns of B, sorted */
+  if (nb) {
+    OInt *tmp = (OInt *)malloc((size_t)nb * sizeof(OInt));
+    memcpy(tmp, Bj, (size_t)nb * sizeof(OInt));
+    qsort(tmp, (size_t)nb, sizeof(OInt), cmp_oint);
+    for (OInt k = 0; k < nb; k++)
+      if (!k || tmp[k] != tmp[k - 1]) garray[ec++] = tmp[k];
+    free(tmp);
+    for (OInt k = 0; k < nb; k++) { /* gid -> lid by binary search (the reference uses a hash map) */
+      OInt lo = 0, hi = ec - 1, g = Bj[k];
+      while (lo < hi) {
+        OInt mid = (lo + hi) / 2;
+        if (garray[mid] < g) lo = mid + 1;
+        else hi = mid;
+      }
+      Bj[k] = lo;
+    }
+  }
+  return ec;
+}
+
+/* src/mat/utils/compressedrow.c MatCheckCompressedRow: list of rows with at least one entry. */
+OInt orc_MatCheckCompressedRow(OInt m, const OInt *bi, OInt *ci, OInt *ridx)
+{
+  OInt nrows = 0;
+  ci[0]      = 0;
+  for (OInt i = 0; i < m; i++) {
+    if (bi[i + 1] > bi[i]) {
+      ridx[nrows]   = i;
+      ci[nrows + 1] = bi[i + 1];
+      nrows++;
+    }
+  }
+  return nrows;
+}
+
+/* src/sys/utils/psplit.c PetscSplitOwnership: n = N/size + ((N % size) > rank). */
+void orc_PetscSplitOwnership(OInt N, int size, OInt *ranges)
+{
+  ranges[0] = 0;
+  for (int r = 0; r < size; r++) ranges[r + 1] = ranges[r] + N / size + ((N % size) > r);
+}
+
+/* ============================ Vec_Seq ========================================================== */
+
+/* bvec1.c:10-49 -> BLAS ddot (third-party; see header).  Published definition, left-to-right. */
+OScalar orc_VecDot_Seq(OInt n, const OScalar *x, const OScalar *y)
+{
+  OScalar s = 0.0;
+  for (OInt i = 0; i < n; i++) s += x[i] * y[i];
+  return s;
+}
+
+void orc_VecMDot_Seq(OInt n, const OScalar *x, OInt nv, const OScalar *const *y, OScalar *z)
+{
+  for (OInt j = 0; j < nv; j++) z[j] = orc_VecDot_Seq(n, x, y[j]);
+}
+
+/* bvec2.c:185-235.  NORM_2 = sqrt(ddot(x,x)) (:204); NORM_1 = dasum; NORM_INFINITY with NaN
+   propagation (:207-216); NORM_1_AND_2 fills z2[0], z2[1]. Returns the requested norm (z2 optional). */
+OScalar orc_VecNorm_Seq(OInt n, const OScalar *x, int type, OScalar *z2)
+{
+  OScalar z[2] = {0.0, 0.0};
+  if (n) {
+    if (type == ORC_NORM_2 || type == ORC_NORM_FROBENIUS) {
+      z[0] = sqrt(orc_VecDot_Seq(n, x, x));
+    } else if (type == ORC_NORM_INFINITY) {
+      for (OInt i = 0; i < n; i++) {
+        OScalar tmp = fabs(x[i]);
+        if ((tmp > z[0]) || (tmp != tmp)) {
+          z[0] = tmp;
+          if (tmp != tmp) break;
+        }
+      }
+    } else if (type == ORC_NORM_1 || type == ORC_NORM_1_AND_2) {
+      for (OInt i = 0; i < n; i++) z[0] += fabs(x[i]);
+      if (type == ORC_NORM_1_AND_2) z[1] = sqrt(orc_VecDot_Seq(n, x, x));
+    }
+  }
+  if (z2) {
+    z2[0] = z[0];
+    if (type == ORC_NORM_1_AND_2) z2[1] = z[1];
+  }
+  return z[0];
+}
+
+/* bvec1.c:70-89: alpha == 0 is a no-op (:75); otherwise BLAS daxpy: y_i += a*x_i. */
+void orc_VecAXPY_Seq(OInt n, OScalar *y, OScalar a, const OScalar *x)
+{
+  if (a == 0.0) return;
+  for (OInt i = 0; i < n; i++) y[i] += a * x[i];
+}
+
+/* dvec2.c:753-782 */
+void orc_VecAYPX_Seq(OInt n, OScalar *y, OScalar b, const OScalar *x)
+{
+  if (b == 0.0) memcpy(y, x, (size_t)n * sizeof(OScalar));
+  else if (b == 1.0) orc_VecAXPY_Seq(n, y, b, x);
+  else if (b == -1.0)
+    for (OInt i = 0; i < n; i++) y[i] = x[i] - y[i];
+  else
+    for (OInt i = 0; i < n; i++) y[i] = x[i] + b * y[i];
+}
+
+/* bvec1.c:91-118 */
+void orc_VecAXPBY_Seq(OInt n, OScalar *y, OScalar a, OScalar b, const OScalar *x)
+{
+  if (a == 0.0) orc_VecScale_Seq(n, y, b);
+  else if (b == 1.0) orc_VecAXPY_Seq(n, y, a, x);
+  else if (a == 1.0) orc_VecAYPX_Seq(n, y, b, x);
+  else if (b == 0.0)
+    for (OInt i = 0; i < n; i++) y[i] = a * x[i];
+  else
+    for (OInt i = 0; i < n; i++) y[i] = a * x[i] + b * y[i];
+}
+
+/* dvec2.c:791-822 */
+void orc_VecWAXPY_Seq(OInt n, OScalar *w, OScalar a, const OScalar *x, const OScalar *y)
+{
+  if (a == 1.0)
+    for (OInt i = 0; i < n; i++) w[i] = y[i] + x[i];
+  else if (a == -1.0)
+    for (OInt i = 0; i < n; i++) w[i] = y[i] - x[i];
+  else if (a == 0.0) memcpy(w, y, (size_t)n * sizeof(OScalar));
+  else
+    for (OInt i = 0; i < n; i++) w[i] = y[i] + a * x[i];
+}
+
+/* bvec1.c:120-147 */
+void orc_VecAXPBYPCZ_Seq(OInt n, OScalar *z, OScalar a, OScalar b, OScalar c, const OScalar *x, const OScalar *y)
+{
+  if (a == 1.0)
+    for (OInt i = 0; i < n; i++) z[i] = x[i] + b * y[i] + c * z[i];
+  else if (c == 1.0)
+    for (OInt i = 0; i < n; i++) z[i] = a * x[i] + b * y[i] + z[i];
+  else if (c == 0.0)
+    for (OInt i = 0; i < n; i++) z[i] = a * x[i] + b * y[i];
+  else
+    for (OInt i = 0; i < n; i++) z[i] = a * x[i] + b * y[i] + c * z[i];
+}
+
+/* dvec2.c:658-693 with the plain-loop PetscKernelAXPY{,2,3,4} (petscaxpy.h:197-235): the first nv&3
+   vectors in one pass, then groups of four: y_i += a1*p1_i + a2*p2_i + a3*p3_i + a4*p4_i. */
+void orc_VecMAXPY_Seq(OInt n, OScalar *y, OInt nv, const OScalar *alpha, const OScalar *const *x)
+{
+  OInt j_rem = nv & 0x3;
+  switch (j_rem) {
+  case 3:
+    for (OInt i = 0; i < n; i++) y[i] += alpha[0] * x[0][i] + alpha[1] * x[1][i] + alpha[2] * x[2][i];
+    break;
+  case 2:
+    for (OInt i = 0; i < n; i++) y[i] += alpha[0] * x[0][i] + alpha[1] * x[1][i];
+    break;
+  case 1:
+    for (OInt i = 0; i < n; i++) y[i] += alpha[0] * x[0][i];
+  default:
+    break;
+  }
+  for (OInt j = j_rem; j < nv; j += 4) {
+    const OScalar a0 = alpha[j], a1 = alpha[j + 1], a2 = alpha[j + 2], a3 = alpha[j + 3];
+    const OScalar *p0 = x[j], *p1 = x[j + 1], *p2 = x[j + 2], *p3 = x[j + 3];
+    for (OInt i = 0; i < n; i++) y[i] += a0 * p0[i] + a1 * p1[i] + a2 * p2[i] + a3 * p3[i];
+  }
+}
+
+/* rvector.c:1394-1440 with no ops->maxpby on VECSEQ: beta == 0 -> VecSet(y,0), else VecScale(y,beta);
+   then VecMAXPY. */
+void orc_VecMAXPBY(OInt n, OScalar *y, OInt nv, const OScalar *alpha, OScalar beta, const OScalar *const *x)
+{
+  if (beta == 0.0) memset(y, 0, (size_t)n * sizeof(OScalar));
+  else orc_VecScale_Seq(n, y, beta);
+  orc_VecMAXPY_Seq(n, y, nv, alpha, x);
+}
+
+/* bvec2.c:72-97 */
+void orc_VecPointwiseMult_Seq(OInt n, OScalar *w, const OScalar *x, const OScalar *y)
+{
+  for (OInt i = 0; i < n; i++) w[i] = x[i] * y[i];
+}
+
+/* bvec2.c:99-109 via ScalDiv (bvec2.c:99-102): y == 0 -> (x == 0 ? 1 : 0), else x / y. */
+void orc_VecPointwiseDivide_Seq(OInt n, OScalar *w, const OScalar *x, const OScalar *y)
+{
+  for (OInt i = 0; i < n; i++) w[i] = (y[i] == 0.0) ? (x[i] == 0.0 ? 1.0 : 0.0) : x[i] / y[i];
+}
+
+/* vinv.c:1208-1229 (VecReciprocal_Default via VecApplyUnary_Private): x != 0 -> 1/x, 0 stays 0. */
+void orc_VecReciprocal(OInt n, OScalar *x)
+{
+  for (OInt i = 0; i < n; i++)
+    if (x[i] != 0.0) x[i] = 1.0 / x[i];
+}
+
+/* bvec2.c:167-183: alpha == 0 -> VecSet(0); alpha == 1 -> no-op; else BLAS dscal. */
+void orc_VecScale_Seq(OInt n, OScalar *x, OScalar a)
+{
+  if (a == 0.0) memset(x, 0, (size_t)n * sizeof(OScalar));
+  else if (a != 1.0)
+    for (OInt i = 0; i < n; i++) x[i] *= a;
+}
+
+void orc_VecSet_Seq(OInt n, OScalar *x, OScalar a)
+{
+  for (OInt i = 0; i < n; i++) x[i] = a;
+}
+
+void orc_VecCopy_Seq(OInt n, const OScalar *x, OScalar *y)
+{
+  if (x != y) memcpy(y, x, (size_t)n * sizeof(OScalar));
+}
+
+/* ============================ PC =============================================================== */
+
+/* jacobi.c:205-266 (PC_JACOBI_DIAGONAL, useabs = FALSE, fixdiag = TRUE, matrix not flagged SPD):
+   diag <- MatGetDiagonal; VecReciprocal; zeros -> 1. */
+void orc_PCSetUp_Jacobi(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, OScalar *diag)
+{
+  orc_MatGetDiagonal_SeqAIJ(m, ai, aj, aa, diag);
+  orc_VecReciprocal(m, diag);
+  for (OInt i = 0; i < m; i++)
+    if (diag[i] == 0.0) diag[i] = 1.0;
+}
+
+/* ============================ KSP ============================================================== */
+
+void orc_KSPSetDefaults(OrcKSP *ksp)
+{
+  /* itfunc.c KSPCreate defaults; cg.c:696; gmres.c:906-915; sor.c:442-446 */
+  ksp->nranks           = 1;
+  ksp->ranges           = NULL;
+  ksp->pc_type          = ORC_PC_JACOBI;
+  ksp->sor_flag         = ORC_SOR_LOCAL_SYMMETRIC_SWEEP;
+  ksp->sor_omega        = 1.0;
+  ksp->sor_shift        = 0.0;
+  ksp->sor_its          = 1;
+  ksp->sor_lits         = 1;
+  ksp->normtype         = ORC_KSP_NORM_PRECONDITIONED;
+  ksp->rtol             = 1e-5;
+  ksp->abstol           = 1e-50;
+  ksp->divtol           = 1e4;
+  ksp->max_it           = 10000;
+  ksp->min_it           = 0;
+  ksp->gmres_restart    = 30;
+  ksp->gmres_haptol     = 1e-30;
+  ksp->gmres_cgs_refine = 0;
+  ksp->guess_nonzero    = 0;
+  ksp->its              = 0;
+  ksp->reason           = 0;
+  ksp->rnorm            = 0;
+  ksp->history          = NULL;
+  ksp->hist_len         = 0;
+  ksp->hist_n           = 0;
+}
+
+typedef struct {
+  OrcKSP  *ksp;
+  OScalar *jdiag;   /* PCJACOBI inverse diagonal */
+  OScalar  rnorm0, ttol;
+  /* per-rank diagonal blocks for PCSOR on a simulated MPIAIJ partition */
+  OInt    **Ai, **Aj;
+  OScalar **Aa;
+} Ctx;
+
+static void ctx_setup(Ctx *c, OrcKSP *ksp)
+{
+  static const OInt one_range[2] = {0, 0};
+  (void)one_range;
+  c->ksp   = ksp;
+  c->jdiag = NULL;
+  c->Ai = c->Aj = NULL;
+  c->Aa         = NULL;
+  if (ksp->pc_type == ORC_PC_JACOBI) {
+    c->jdiag = (OScalar *)malloc((size_t)ksp->m * sizeof(OScalar));
+    orc_PCSetUp_Jacobi(ksp->m, ksp->ai, ksp->aj, ksp->aa, c->jdiag); /* the diagonal is owned by the row's rank: same values at any nranks */
+  } else if (ksp->pc_type == ORC_PC_SOR && ksp->nranks > 1) {
+    int nr = ksp->nranks;
+    c->Ai  = (OInt **)calloc((size_t)nr, sizeof(OInt *));
+    c->Aj  = (OInt **)calloc((size_t)nr, sizeof(OInt *));
+    c->Aa  = (OScalar **)calloc((size_t)nr, sizeof(OScalar *));
+    for (int r = 0; r < nr; r++) {
+      OInt rs = ksp->ranges[r], re = ksp->ranges[r + 1], ml = re - rs;
+      OInt nz = ksp->ai[re] - ksp->ai[rs];
+      OInt *li = (OInt *)malloc((size_t)(ml + 1) * sizeof(OInt));
+      for (OInt i = 0; i <= ml; i++) li[i] = ksp->ai[rs + i] - ksp->ai[rs];
+      c->Ai[r]    = (OInt *)malloc((size_t)(ml + 1) * sizeof(OInt));
+      c->Aj[r]    = (OInt *)malloc((size_t)(nz + 1) * sizeof(OInt));
+      c->Aa[r]    = (OScalar *)malloc((size_t)(nz + 1) * sizeof(OScalar));
+      OInt    *Bi = (OInt *)malloc((size_t)(ml + 1) * sizeof(OInt));
+      OInt    *Bj = (OInt *)malloc((size_t)(nz + 1) * sizeof(OInt));
+      OScalar *Ba = (OScalar *)malloc((size_t)(nz + 1) * sizeof(OScalar));
+      OInt    *ga = (OInt *)malloc((size_t)(nz + 1) * sizeof(OInt));
+      orc_MatSetUpMultiply_MPIAIJ(ml, rs, re, li, ksp->aj + ksp->ai[rs], ksp->aa + ksp->ai[rs], c->Ai[r], c->Aj[r], c->Aa[r], Bi, Bj, Ba, ga);
+      free(li);
+      free(Bi);
+      free(Bj);
+      free(Ba);
+      free(ga);
+    }
+  }
+}
+
+static void ctx_free(Ctx *c)
+{
+  free(c->jdiag);
+  if (c->Ai) {
+    for (int r = 0; r < c->ksp->nranks; r++) {
+      free(c->Ai[r]);
+      free(c->Aj[r]);
+      free(c->Aa[r]);
+    }
+    free(c->Ai);
+    free(c->Aj);
+    free(c->Aa);
+  }
+}
+
+/* KSP_PCApply -> PCApply_Jacobi (jacobi.c:354-362) | PCApply_SOR (sor.c:27-36) -> MatSOR_SeqAIJ, or
+   MatSOR_MPIAIJ (mpiaij.c:1394-1486): with SOR_ZERO_INITIAL_GUESS and its == 1 each rank does one local
+   sweep on its diagonal block (mpiaij.c:1408-1412: `sor(A, bb, omega, flag, fshift, lits, 1, xx)`). */
+static void pc_apply(Ctx *c, const OScalar *r, OScalar *z)
+{
+  OrcKSP *ksp = c->ksp;
+  if (ksp->pc_type == ORC_PC_NONE) memcpy(z, r, (size_t)ksp->m * sizeof(OScalar)); /* pcnone: VecCopy */
+  else if (ksp->pc_type == ORC_PC_JACOBI) orc_VecPointwiseMult_Seq(ksp->m, z, r, c->jdiag);
+  else {
+    int flag = ksp->sor_flag | ORC_SOR_ZERO_INITIAL_GUESS;
+    if (ksp->nranks <= 1) orc_MatSOR_SeqAIJ(ksp->m, ksp->ai, ksp->aj, ksp->aa, r, ksp->sor_omega, flag, ksp->sor_shift, ksp->sor_its, ksp->sor_lits, z);
+    else
+      for (int rk = 0; rk < ksp->nranks; rk++) {
+        OInt rs = ksp->ranges[rk], ml = ksp->ranges[rk + 1] - rs;
+        orc_MatSOR_SeqAIJ(ml, c->Ai[rk], c->Aj[rk], c->Aa[rk], r + rs, ksp->sor_omega, flag, ksp->sor_shift, ksp->sor_lits, 1, z + rs);
+      }
+  }
+}
+
+static void log_history(OrcKSP *ksp, OScalar rnorm)
+{
+  if (ksp->history && ksp->hist_n < ksp->hist_len) ksp->history[ksp->hist_n] = rnorm;
+  ksp->hist_n++;
+}
+
+/* iterativ.c:1490-1585 KSPConvergedDefault (zero or nonzero guess with the default context:
+   initialrtol = mininitialrtol = convmaxits = FALSE). */
+static int converged_default(Ctx *c, OInt n, OScalar rnorm, const OScalar *b)
+{
+  OrcKSP *ksp = c->ksp;
+  if (ksp->normtype == ORC_KSP_NORM_NONE) return 0;
+  if (!n) {
+    if (ksp->guess_nonzero) {
+      OScalar snorm = 0.0;
+      if (ksp->normtype == ORC_KSP_NORM_UNPRECONDITIONED) snorm = orc_VecNorm_Seq(ksp->m, b, ORC_NORM_2, NULL);
+      else {
+        OScalar *z = (OScalar *)malloc((size_t)ksp->m * sizeof(OScalar));
+        pc_apply(c, b, z);
+        if (ksp->normtype == ORC_KSP_NORM_PRECONDITIONED) snorm = orc_VecNorm_Seq(ksp->m, z, ORC_NORM_2, NULL);
+        else snorm = sqrt(fabs(orc_VecDot_Seq(ksp->m, b, z)));
+        free(z);
+      }
+      if (!snorm) snorm = rnorm;
+      c->rnorm0 = snorm;
+    } else c->rnorm0 = rnorm;
+    c->ttol = fmax(ksp->rtol * c->rnorm0, ksp->abstol);
+  }
+  /* chknorm = 0 by default: `if (n <= ksp->chknorm) return` skips the test at n == 0 */
+  if (n <= 0) return 0;
+  if (isnan(rnorm) || isinf(rnorm)) return ORC_KSP_DIVERGED_NANORINF;
+  if (n < ksp->min_it) return 0;
+  if (rnorm <= c->ttol) return (rnorm < ksp->abstol) ? ORC_KSP_CONVERGED_ATOL : ORC_KSP_CONVERGED_RTOL;
+  if (rnorm >= ksp->divtol * c->rnorm0) return ORC_KSP_DIVERGED_DTOL;
+  return 0;
+}
+
+/* cg.c:119-352 (KSP_CG_SYMMETRIC, no trust region, no eigenvalue estimate).  W aliases Z (cg.c:145). */
+int orc_KSPSolve_CG(OrcKSP *ksp, const OScalar *B, OScalar *X)
+{
+  Ctx      c;
+  OInt     n = ksp->m, i;
+  OScalar  dpi = 0.0, a = 1.0, beta = 0.0, betaold = 1.0, b = 0, dpiold, dp = 0.0;
+  OScalar *R = (OScalar *)malloc((size_t)n * sizeof(OScalar));
+  OScalar *Z = (OScalar *)malloc((size_t)n * sizeof(OScalar));
+  OScalar *P = (OScalar *)malloc((size_t)n * sizeof(OScalar));
+  OScalar *W = Z;
+
+  ctx_setup(&c, ksp);
+  ksp->its    = 0;
+  ksp->reason = 0;
+  ksp->hist_n = 0;
+  if (!ksp->guess_nonzero) memset(X, 0, (size_t)n * sizeof(OScalar)); /* itfunc.c:908 VecSet(x,0) */
+  if (ksp->guess_nonzero) {
+    orc_MatMult_SeqAIJ(n, ksp->ai, ksp->aj, ksp->aa, X, R); /* cg.c:154 */
+    orc_VecAYPX_Seq(n, R, -1.0, B);                          /* cg.c:156 */
+  } else orc_VecCopy_Seq(n, B, R);                           /* cg.c:162 */
+
+  switch (ksp->normtype) { /* cg.c:168-190 */
+  case ORC_KSP_NORM_PRECONDITIONED:
+    pc_apply(&c, R, Z);
+    dp = orc_VecNorm_Seq(n, Z, ORC_NORM_2, NULL);
+    break;
+  case ORC_KSP_NORM_UNPRECONDITIONED:
+    dp = orc_VecNorm_Seq(n, R, ORC_NORM_2, NULL);
+    break;
+  case ORC_KSP_NORM_NATURAL:
+    pc_apply(&c, R, Z);
+    beta = orc_VecDot_Seq(n, Z, R);
+    dp   = sqrt(fabs(beta));
+    break;
+  default:
+    dp = 0.0;
+  }
+  if (isnan(dp) || isinf(dp)) {
+    ksp->reason = ORC_KSP_DIVERGED_NANORINF;
+    goto done;
+  }
+  log_history(ksp, dp);
+  ksp->rnorm  = dp;
+  ksp->reason = converged_default(&c, 0, dp, B); /* cg.c:205 */
+  if (ksp->reason) goto done;
+
+  if (ksp->normtype != ORC_KSP_NORM_PRECONDITIONED && ksp->normtype != ORC_KSP_NORM_NATURAL) pc_apply(&c, R, Z); /* cg.c:214 */
+  if (ksp->normtype != ORC_KSP_NORM_NATURAL) beta = orc_VecDot_Seq(n, Z, R);                                      /* cg.c:216 */
+
+  i = 0;
+  do {
+    ksp->its = i + 1;
+    if (beta == 0.0) { /* cg.c:223 */
+      ksp->reason = ORC_KSP_CONVERGED_ATOL;
+      break;
+    } else if ((i > 0) && (beta * betaold < 0.0)) { /* cg.c:228 */
+      ksp->reason = ORC_KSP_DIVERGED_INDEFINITE_PC;
+      break;
+    }
+    if (!i) {
+      orc_VecCopy_Seq(n, Z, P); /* cg.c:236 */
+      b = 0.0;
+    } else {
+      b = beta / betaold;
+      orc_VecAYPX_Seq(n, P, b, Z); /* cg.c:249 */
+    }
+    dpiold = dpi;
+    orc_MatMult_SeqAIJ(n, ksp->ai, ksp->aj, ksp->aa, P, W); /* cg.c:257 */
+    dpi     = orc_VecDot_Seq(n, P, W);                       /* cg.c:258 */
+    betaold = beta;
+    if (isnan(dpi) || isinf(dpi)) {
+      ksp->reason = ORC_KSP_DIVERGED_NANORINF;
+      break;
+    }
+    if ((dpi == 0.0) || ((i > 0) && (((dpi > 0) - (dpi < 0)) * ((dpiold > 0) - (dpiold < 0)) < 0.0))) { /* cg.c:262 */
+      ksp->reason = ORC_KSP_DIVERGED_INDEFINITE_MAT;
+      break;
+    }
+    a = beta / dpi;                    /* cg.c:288 */
+    orc_VecAXPY_Seq(n, X, a, P);       /* cg.c:305 */
+    orc_VecAXPY_Seq(n, R, -a, W);      /* cg.c:306 */
+    if (ksp->normtype == ORC_KSP_NORM_PRECONDITIONED) {
+      pc_apply(&c, R, Z);                                  /* cg.c:308 */
+      dp = orc_VecNorm_Seq(n, Z, ORC_NORM_2, NULL);        /* cg.c:309 */
+    } else if (ksp->normtype == ORC_KSP_NORM_UNPRECONDITIONED) {
+      dp = orc_VecNorm_Seq(n, R, ORC_NORM_2, NULL);
+    } else if (ksp->normtype == ORC_KSP_NORM_NATURAL) {
+      pc_apply(&c, R, Z);
+      beta = orc_VecDot_Seq(n, Z, R);
+      dp   = sqrt(fabs(beta));
+    } else dp = 0.0;
+    if (isnan(dp) || isinf(dp)) {
+      ksp->reason = ORC_KSP_DIVERGED_NANORINF;
+      break;
+    }
+    ksp->rnorm = dp;
+    log_history(ksp, dp);
+    ksp->reason = converged_default(&c, i + 1, dp, B); /* cg.c:328 */
+    if (ksp->reason) break;
+    if (ksp->normtype != ORC_KSP_NORM_PRECONDITIONED && ksp->normtype != ORC_KSP_NORM_NATURAL) pc_apply(&c, R, Z); /* cg.c:342 */
+    if (ksp->normtype != ORC_KSP_NORM_NATURAL) beta = orc_VecDot_Seq(n, Z, R);                                      /* cg.c:344 */
+    i++;
+  } while (i < ksp->max_it);
+  if (i >= ksp->max_it) ksp->reason = ORC_KSP_DIVERGED_ITS;
+done:
+  ctx_free(&c);
+  free(R);
+  free(Z);
+  free(P);
+  return ksp->reason;
+}
+
+/* gmres.c:88-238 (KSPGMRESCycle, KSPSolve_GMRES), :298-345 (BuildSoln), :349-395 (UpdateHessenberg),
+   borthog2.c:35-113 (classical Gram-Schmidt), left preconditioning (KSP_PCApplyBAorAB: w = B A v,
+   kspimpl.h), KSPInitialResidual (itres.c:35-75). */
+int orc_KSPSolve_GMRES(OrcKSP *ksp, const OScalar *B, OScalar *X)
+{
+  Ctx       c;
+  const OInt n = ksp->m, max_k = ksp->gmres_restart, N = max_k + 1;
+  OScalar **VV   = (OScalar **)malloc((size_t)(max_k + 2) * sizeof(OScalar *));
+  OScalar  *TEMP = (OScalar *)malloc((size_t)n * sizeof(OScalar));
+  OScalar  *TMOP = (OScalar *)malloc((size_t)n * sizeof(OScalar));
+  OScalar  *hh   = (OScalar *)calloc((size_t)(max_k + 2) * (max_k + 1), sizeof(OScalar));
+  OScalar  *grs  = (OScalar *)calloc((size_t)(max_k + 2), sizeof(OScalar));
+  OScalar  *cc   = (OScalar *)calloc((size_t)(max_k + 2), sizeof(OScalar));
+  OScalar  *ss   = (OScalar *)calloc((size_t)(max_k + 2), sizeof(OScalar));
+  OScalar  *nrs  = (OScalar *)calloc((size_t)(max_k + 2), sizeof(OScalar));
+  OScalar  *lhh  = (OScalar *)calloc((size_t)(max_k + 2), sizeof(OScalar));
+  OInt      itcount = 0;
+  int       guess_nonzero = ksp->guess_nonzero;
+  (void)N;
+#define HH(a, b) (hh + (b) * (max_k + 2) + (a)) /* gmresimpl.h: column-major, leading dimension max_k+2 */
+  for (OInt k = 0; k < max_k + 2; k++) VV[k] = (OScalar *)malloc((size_t)n * sizeof(OScalar));
+  ctx_setup(&c, ksp);
+  ksp->its    = 0;
+  ksp->reason = 0;
+  ksp->hist_n = 0;
+  ksp->rnorm  = -1.0;
+  if (!ksp->guess_nonzero) memset(X, 0, (size_t)n * sizeof(OScalar));
+
+  while (!ksp->reason) {
+    OScalar res, tt, hapbnd;
+    OInt    it     = 0;
+    int     hapend = 0;
+    /* KSPInitialResidual, PC_LEFT */
+    if (ksp->guess_nonzero) {
+      orc_MatMult_SeqAIJ(n, ksp->ai, ksp->aj, ksp->aa, X, TEMP);
+      orc_VecCopy_Seq(n, B, TMOP);
+      orc_VecAXPY_Seq(n, TMOP, -1.0, TEMP);
+      pc_apply(&c, TMOP, VV[0]);
+    } else {
+      orc_VecCopy_Seq(n, B, TMOP);
+      pc_apply(&c, B, VV[0]);
+    }
+    /* KSPGMRESCycle */
+    res = orc_VecNorm_Seq(n, VV[0], ORC_NORM_2, NULL); /* VecNormalize gmres.c:98 */
+    if (res != 0.0) orc_VecScale_Seq(n, VV[0], 1.0 / res);
+    if (isnan(res) || isinf(res)) {
+      ksp->reason = ORC_KSP_DIVERGED_NANORINF;
+      break;
+    }
+    grs[0]     = res;
+    ksp->rnorm = res;
+    log_history(ksp, res);
+    if (!res) {
+      ksp->reason = ORC_KSP_CONVERGED_ATOL;
+      break;
+    }
+    ksp->reason = converged_default(&c, ksp->its, res, B);
+    while (!ksp->reason && it < max_k && ksp->its < ksp->max_it) {
+      if (it) log_history(ksp, res);
+      /* KSP_PCApplyBAorAB, left: VV[it+1] = B (A VV[it]) */
+      orc_MatMult_SeqAIJ(n, ksp->ai, ksp->aj, ksp->aa, VV[it], TMOP);
+      pc_apply(&c, TMOP, VV[it + 1]);
+      /* classical Gram-Schmidt, borthog2.c */
+      {
+        OScalar *h      = HH(0, it);
+        int      refine = (ksp->gmres_cgs_refine == 2);
+        for (OInt j = 0; j <= it; j++) h[j] = 0.0;
+        orc_VecMDot_Seq(n, VV[it + 1], it + 1, (const OScalar *const *)VV, lhh);
+        for (OInt j = 0; j <= it; j++) lhh[j] = -lhh[j];
+        orc_VecMAXPY_Seq(n, VV[it + 1], it + 1, lhh, (const OScalar *const *)VV);
+        for (OInt j = 0; j <= it; j++) h[j] -= lhh[j];
+        if (ksp->gmres_cgs_refine == 1) {
+          OScalar hnrm = 0.0, wnrm;
+          for (OInt j = 0; j <= it; j++) hnrm += lhh[j] * lhh[j];
+          hnrm = sqrt(hnrm);
+          wnrm = orc_VecNorm_Seq(n, VV[it + 1], ORC_NORM_2, NULL);
+          if (wnrm < hnrm) refine = 1;
+        }
+        if (refine) {
+          orc_VecMDot_Seq(n, VV[it + 1], it + 1, (const OScalar *const *)VV, lhh);
+          for (OInt j = 0; j <= it; j++) lhh[j] = -lhh[j];
+          orc_VecMAXPY_Seq(n, VV[it + 1], it + 1, lhh, (const OScalar *const *)VV);
+          for (OInt j = 0; j <= it; j++) h[j] -= lhh[j];
+        }
+      }
+      tt = orc_VecNorm_Seq(n, VV[it + 1], ORC_NORM_2, NULL); /* VecNormalize gmres.c:143 */
+      if (tt != 0.0) orc_VecScale_Seq(n, VV[it + 1], 1.0 / tt);
+      if (isnan(tt) || isinf(tt)) {
+        ksp->reason = ORC_KSP_DIVERGED_NANORINF;
+        break;
+      }
+      *HH(it + 1, it) = tt;
+      hapbnd          = fabs(tt / grs[it]);
+      if (hapbnd > ksp->gmres_haptol) hapbnd = ksp->gmres_haptol;
+      if (tt < hapbnd) hapend = 1;
+      { /* KSPGMRESUpdateHessenberg gmres.c:349-395 */
+        OScalar *h = HH(0, it), *cp = cc, *sp = ss, t;
+        for (OInt j = 1; j <= it; j++) {
+          t  = *h;
+          *h = *cp * t + *sp * *(h + 1);
+          h++;
+          *h = *cp++ * *h - (*sp++ * t);
+        }
+        if (!hapend) {
+          t = sqrt(*h * *h + *(h + 1) * *(h + 1));
+          if (t == 0.0) {
+            ksp->reason = ORC_KSP_DIVERGED_BREAKDOWN; /* KSP_DIVERGED_NULL in the reference */
+            break;
+          }
+          *cp         = *h / t;
+          *sp         = *(h + 1) / t;
+          grs[it + 1] = -(*sp * grs[it]);
+          grs[it]     = *cp * grs[it];
+          *h          = *cp * *h + *sp * *(h + 1);
+          res         = fabs(grs[it + 1]);
+        } else res = 0.0;
+      }
+      it++;
+      ksp->its++;
+      ksp->rnorm  = res;
+      ksp->reason = converged_default(&c, ksp->its, res, B);
+      if (hapend) {
+        if (ksp->normtype == ORC_KSP_NORM_NONE) ksp->reason = ORC_KSP_CONVERGED_HAPPY_BREAKDOWN;
+        else if (!ksp->reason) {
+          ksp->reason = ORC_KSP_DIVERGED_BREAKDOWN;
+          break;
+        }
+      }
+    }
+    /* KSPGMRESBuildSoln(GRS(0), x, x, ksp, it-1) gmres.c:298-345 */
+    if (it - 1 >= 0) {
+      OInt itl = it - 1;
+      if (*HH(itl, itl) != 0.0) {
+        nrs[itl] = grs[itl] / *HH(itl, itl);
+        for (OInt ii = 1; ii <= itl; ii++) {
+          OInt    k = itl - ii;
+          OScalar t = grs[k];
+          for (OInt j = k + 1; j <= itl; j++) t = t - *HH(k, j) * nrs[j];
+          nrs[k] = t / *HH(k, k);
+        }
+        orc_VecMAXPBY(n, TEMP, itl + 1, nrs, 0.0, (const OScalar *const *)VV); /* gmres.c:337 */
+        /* KSPUnwindPreconditioner: nothing to do for left preconditioning */
+        orc_VecAXPY_Seq(n, X, 1.0, TEMP); /* gmres.c:342 */
+      } else ksp->reason = ORC_KSP_DIVERGED_BREAKDOWN;
+    }
+    if (ksp->reason == 0 && ksp->its >= ksp->max_it) ksp->reason = ORC_KSP_DIVERGED_ITS;
+    if (it && ksp->reason) log_history(ksp, res);
+    itcount += it;
+    if (itcount >= ksp->max_it) {
+      if (!ksp->reason) ksp->reason = ORC_KSP_DIVERGED_ITS;
+      break;
+    }
+    ksp->guess_nonzero = 1; /* gmres.c:233 */
+  }
+  ksp->guess_nonzero = guess_nonzero;
+#undef HH
+  ctx_free(&c);
+  for (OInt k = 0; k < max_k + 2; k++) free(VV[k]);
+  free(VV);
+  free(TEMP);
+  free(TMOP);
+  free(hh);
+  free(grs);
+  free(cc);
+  free(ss);
+  free(nrs);
+  free(lhh);
+  return ksp->reason;
+}

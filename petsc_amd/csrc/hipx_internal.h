@@ -1,0 +1,57 @@
+// hipx_internal.h -- shared state of libhipx.so (one process = one GPU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include "hipx.h"
+
+namespace hipx {
+
+constexpr int kRedBlocks     = 1024;  // fixed reduction grid -> fixed summation order (deterministic)
+constexpr int kRedThreads    = 256;
+constexpr int kMaxRedVals    = 32;    // sums produced by one reduction launch (MDot batches)
+constexpr int kEwMaxBlocks   = 4096;  // grid cap of the grid-stride elementwise kernels
+constexpr int kEwThreads     = 256;
+
+struct Runtime {
+  bool        initialized = false;
+  int         device      = -1;
+  hipStream_t compute     = nullptr;
+  hipStream_t comm        = nullptr;
+  // reduction scratch: per slot kMaxRedVals x kRedBlocks partials, a ticket counter and a pinned result line
+  double       *d_partials = nullptr;  // [HIPX_MAX_RED_SLOTS][kMaxRedVals][kRedBlocks]
+  unsigned int *d_tickets  = nullptr;  // [HIPX_MAX_RED_SLOTS]
+  double       *h_results  = nullptr;  // pinned, mapped: [HIPX_MAX_RED_SLOTS][kMaxRedVals]
+  double       *d_results  = nullptr;  // device alias of h_results
+  double       *d_scalars  = nullptr;  // staging for kernel arguments that exceed the arg buffer (MAXPY alphas, pointer tables)
+  void        **d_ptrs     = nullptr;
+  int           next_slot  = 0;
+  char          errmsg[512] = "no error";
+};
+
+Runtime &rt();
+int      fail(int code, const char *what, const char *file, int line);
+
+inline double *slot_partials(int slot) { return rt().d_partials + (size_t)slot * kMaxRedVals * kRedBlocks; }
+inline double *slot_results_dev(int slot) { return rt().d_results + (size_t)slot * kMaxRedVals; }
+inline double *slot_results_host(int slot) { return rt().h_results + (size_t)slot * kMaxRedVals; }
+
+}  // namespace hipx
+
+#define HIPX_CHECK_INIT() \
+  do { \
+    if (!hipx::rt().initialized) return hipx::fail(HIPX_ERR_ORDER, "hipxInit() has not been called", __FILE__, __LINE__); \
+  } while (0)
+
+#define HIPX_HIP(call) \
+  do { \
+    hipError_t e_ = (call); \
+    if (e_ != hipSuccess) return hipx::fail(HIPX_ERR_HIP_BASE + (int)e_, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+#define HIPX_LAUNCH_CHECK() HIPX_HIP(hipGetLastError())
+
+#define HIPX_ARG(cond, msg) \
+  do { \
+    if (!(cond)) return hipx::fail(HIPX_ERR_ARG, msg, __FILE__, __LINE__); \
+  } while (0)

@@ -1,0 +1,507 @@
+// hipx_mat.hip -- CSR (Mat_SeqAIJ) kernels for gfx950 behind include/hipx.h.
+//
+// SpMV ("row-block stream" kernel, the MatMult_SeqAIJ replacement, aij.c:1444-1502)
+//   HBM-bound: 12 B per nonzero (8 B value + 4 B column) + 4 B per row offset + x + y.
+//   * the host cuts the rows into row blocks: consecutive rows whose nonzeros fit an LDS tile of CAP
+//     products (and at most 256 rows, one row per thread in the reduce phase);
+//   * phase 1 (stream): the 256 threads of a workgroup read the block's val[] and col[] ranges as one
+//     contiguous, 32/16-byte-per-lane coalesced stream (4 nonzeros per lane per step, all loads issued
+//     before first use), gather x[col] through L1/L2 and park the rounded products in LDS;
+//   * phase 2 (row sums): thread t adds row t's products from LDS left to right, starting from 0 (or
+//     from y_t for MatMultAdd): the same association as PetscSparseDensePlusDot (aij.h:608-614), one
+//     rounded multiply + one rounded add per entry, no FMA -> y is bit-identical to MatMult_SeqAIJ;
+//   * XCD-aware block order: workgroup b runs on XCD b % 8 (observed dispatch rule, speed only); the
+//     row blocks are remapped so that each XCD walks one contiguous slab of rows, which keeps the
+//     x-window a slab touches (rows +-n^2 for the 7-point stencil) resident in that XCD's 4 MiB L2
+//     instead of being fetched by all eight;
+//   * val/col are read once -> optional non-temporal loads keep them from evicting x out of L2.
+//   Rows longer than the LDS tile take a block-wide strided path (tree sum, not left-to-right).
+#include "hipx_internal.h"
+#include "hipx_reduce.h"
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace hipx;
+
+struct hipxMat_s {
+  hipx_int  m = 0, n = 0;
+  int64_t   nnz       = 0;
+  bool      is64      = false;  // 64-bit row offsets
+  void     *d_i       = nullptr;
+  hipx_int *d_j       = nullptr;
+  double   *d_a       = nullptr;
+  int64_t  *d_diagpos = nullptr;  // position of a_ii in a[], -1 if absent
+  // row blocks
+  hipx_int *d_rb    = nullptr;
+  hipx_int  nblocks = 0;
+  // compressed rows (off-diagonal block of MPIAIJ): logical rows = nrows_c, y index = ridx[row]
+  bool      compressed = false;
+  hipx_int  nrows_c    = 0;
+  hipx_int *d_ridx     = nullptr;
+  int       variant    = 0;
+  int64_t   device_bytes = 0;
+  // SOR level schedule (built lazily)
+  bool      sor_ready = false;
+  hipx_int  nlevels = 0;
+  hipx_int *d_lev_ptr = nullptr, *d_lev_rows = nullptr;
+  std::vector<hipx_int> h_lev_ptr;
+  double   *d_idiag = nullptr, *d_t = nullptr;
+  double    sor_omega = 0, sor_shift = 0;
+  bool      diag_dense = true;
+  // fused SpMV+dot partials
+  double   *d_dotpart = nullptr;
+};
+
+namespace {
+
+// optional event bracketing of every SpMV launch (bench.py roofline.achieved)
+struct SpmvProf {
+  bool                    on = false;
+  std::vector<hipEvent_t> ev;  // pairs
+  size_t                  used = 0;
+};
+SpmvProf &prof()
+{
+  static SpmvProf p;
+  return p;
+}
+inline int prof_mark(bool start)
+{
+  SpmvProf &p = prof();
+  if (!p.on) return HIPX_SUCCESS;
+  if (start && p.used + 2 > p.ev.size()) {
+    for (int k = 0; k < 2; k++) {
+      hipEvent_t e;
+      HIPX_HIP(hipEventCreate(&e));
+      p.ev.push_back(e);
+    }
+  }
+  HIPX_HIP(hipEventRecord(p.ev[p.used++], rt().compute));
+  return HIPX_SUCCESS;
+}
+
+constexpr int SPMV_THREADS = 256;
+constexpr int SPMV_CAP     = 2048;  // products staged in LDS per row block (16 KiB)
+constexpr int SPMV_ROWS    = 256;   // rows per block (one thread each in phase 2)
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+typedef int    int4v __attribute__((ext_vector_type(4)));
+
+template <bool NT, typename T>
+__device__ __forceinline__ T stream_load(const T *p)
+{
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+
+// MODE: 0 y = A x ; 1 z = y + A x
+template <typename IT, bool NT, int MODE, bool CPROW, bool DOT>
+__global__ __launch_bounds__(SPMV_THREADS) void spmv_stream_kernel(const hipx_int *__restrict__ rb, hipx_int nblocks, hipx_int blocks_per_xcd, const IT *__restrict__ ai,
+                                                                    const hipx_int *__restrict__ aj, const double *__restrict__ aa, const double *__restrict__ x,
+                                                                    const double *yin, double *yout, const hipx_int *__restrict__ ridx, double *dotpart)
+{
+  __shared__ double prod[SPMV_CAP];
+  // XCD-aware remap: hardware block id -> (xcd, slot) -> contiguous slab per XCD
+  const hipx_int bid = (hipx_int)blockIdx.x;
+  const hipx_int b   = (bid & 7) * blocks_per_xcd + (bid >> 3);
+  double         mydot = 0.0;
+  if (b < nblocks) {
+    const hipx_int r0 = rb[b], r1 = rb[b + 1];
+    const IT       k0 = ai[r0], k1 = ai[r1];
+    const IT       ka = k0 & ~(IT)3;  // 32-byte aligned start of the val stream (arrays are padded by 4)
+    const int      t  = threadIdx.x;
+    const hipx_int row = r0 + t;
+    // this thread's row extent for phase 2: issue now, consume after the barrier
+    IT rs = 0, re = 0;
+    if (row < r1) {
+      rs = ai[row];
+      re = ai[row + 1];
+    }
+    if ((k1 - ka) <= (IT)SPMV_CAP) {
+      const IT nq = (k1 - ka + 3) >> 2;  // quads to stream (>= 1 unless every row of the block is empty)
+      if (nq > 0) {
+        const dbl2   *a2  = reinterpret_cast<const dbl2 *>(aa + ka);
+        const int4v  *j4  = reinterpret_cast<const int4v *>(aj + ka);
+        constexpr int NIT = SPMV_CAP / 4 / SPMV_THREADS;
+        dbl2          va[NIT], vb[NIT];
+        int4v         vc[NIT];
+        double        xv[NIT][4];
+        // branch-free issue: out-of-range lanes re-read the last quad (clamped), so every load of the
+        // block is in flight before the first use
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+          const IT q  = (IT)t + (IT)it * SPMV_THREADS;
+          const IT qc = q < nq ? q : nq - 1;
+          va[it]      = stream_load<NT>(a2 + 2 * qc);
+          vb[it]      = stream_load<NT>(a2 + 2 * qc + 1);
+          vc[it]      = stream_load<NT>(j4 + qc);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+          xv[it][0] = x[vc[it].x];
+          xv[it][1] = x[vc[it].y];
+          xv[it][2] = x[vc[it].z];
+          xv[it][3] = x[vc[it].w];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+          const IT q = (IT)t + (IT)it * SPMV_THREADS;
+          if (q < nq) {
+            dbl2 p0, p1;
+            p0.x = va[it].x * xv[it][0];
+            p0.y = va[it].y * xv[it][1];
+            p1.x = vb[it].x * xv[it][2];
+            p1.y = vb[it].y * xv[it][3];
+            reinterpret_cast<dbl2 *>(prod)[2 * q]     = p0;
+            reinterpret_cast<dbl2 *>(prod)[2 * q + 1] = p1;
+          }
+        }
+      }
+      __syncthreads();
+      if (row < r1) {
+        const hipx_int orow = CPROW ? ridx[row] : row;
+        double         sum  = (MODE == 1) ? yin[orow] : 0.0;
+        const double  *pr   = prod + (int)(rs - ka);
+        const int      len  = (int)(re - rs);
+        int            k    = 0;
+        for (; k + 4 <= len; k += 4) {  // four independent LDS reads, then the dependent left-to-right adds
+          const double p0 = pr[k], p1 = pr[k + 1], p2 = pr[k + 2], p3 = pr[k + 3];
+          sum += p0;
+          sum += p1;
+          sum += p2;
+          sum += p3;
+        }
+        if (k + 2 <= len) {
+          const double p0 = pr[k], p1 = pr[k + 1];
+          sum += p0;
+          sum += p1;
+          k += 2;
+        }
+        if (k < len) sum += pr[k];
+        yout[orow] = sum;
+        if (DOT) mydot = x[orow] * sum;
+      }
+    } else {
+      // long row(s): the host guarantees r1 == r0 + 1 here.  Block-wide strided products, tree sum.
+      double acc = 0.0;
+      for (IT k = k0 + t; k < k1; k += SPMV_THREADS) acc += aa[k] * x[aj[k]];
+      acc = hipx::wave_sum(acc);
+      if ((t & 63) == 0) prod[t >> 6] = acc;
+      __syncthreads();
+      if (t == 0) {
+        const hipx_int orow = CPROW ? ridx[r0] : r0;
+        double         sum  = (MODE == 1) ? yin[orow] : 0.0;
+        sum += ((prod[0] + prod[1]) + (prod[2] + prod[3]));
+        yout[orow] = sum;
+        if (DOT) mydot = x[orow] * sum;
+      }
+    }
+  }
+  if (DOT) {
+    __shared__ double sd[SPMV_THREADS / 64];
+    __syncthreads();
+    double w = hipx::wave_sum(mydot);
+    if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) dotpart[bid] = (sd[0] + sd[1]) + (sd[2] + sd[3]);
+  }
+}
+
+template <typename IT>
+__global__ void diagpos_kernel(hipx_int m, const IT *ai, const hipx_int *aj, int64_t *diagpos, unsigned int *missing)
+{
+  for (hipx_int r = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (hipx_int)gridDim.x * blockDim.x) {
+    int64_t pos = -1;
+    for (IT k = ai[r]; k < ai[r + 1]; k++) {
+      if (aj[k] == r) {
+        pos = (int64_t)k;
+        break;
+      }
+    }
+    diagpos[r] = pos;
+    if (pos < 0) atomicAdd(missing, 1u);
+  }
+}
+
+__global__ void getdiag_kernel(hipx_int m, const int64_t *diagpos, const double *aa, double *d)
+{
+  for (hipx_int r = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (hipx_int)gridDim.x * blockDim.x) {
+    int64_t p = diagpos[r];
+    d[r]      = p >= 0 ? aa[p] : 0.0;  // aij.c:1347-1380: missing diagonal -> 0
+  }
+}
+
+// PCSetUp_Jacobi (jacobi.c:205-266): d = diag; VecReciprocal (0 stays 0); zeros -> 1.  One pass.
+__global__ void jacobi_setup_kernel(hipx_int m, const int64_t *diagpos, const double *aa, double *dinv)
+{
+  for (hipx_int r = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (hipx_int)gridDim.x * blockDim.x) {
+    int64_t p = diagpos[r];
+    double  v = p >= 0 ? aa[p] : 0.0;
+    if (v != 0.0) v = 1.0 / v;
+    if (v == 0.0) v = 1.0;
+    dinv[r] = v;
+  }
+}
+
+template <typename IT>
+void build_row_blocks(hipx_int nrows, const IT *ai, std::vector<hipx_int> &rb)
+{
+  rb.clear();
+  rb.push_back(0);
+  hipx_int r = 0;
+  while (r < nrows) {
+    const IT ka = ai[r] & ~(IT)3;
+    hipx_int r1 = r;
+    while (r1 < nrows && (r1 - r) < SPMV_ROWS && (ai[r1 + 1] - ka) <= (IT)SPMV_CAP) r1++;
+    if (r1 == r) r1 = r + 1;  // one long row: block-wide path
+    rb.push_back(r1);
+    r = r1;
+  }
+}
+
+template <typename IT>
+int create_common(hipx_int m, hipx_int n, hipx_int nrows, const IT *ai, const hipx_int *ridx, const hipx_int *aj, const double *aa, bool is64, hipxMat *out)
+{
+  HIPX_ARG(m >= 0 && n >= 0 && nrows >= 0 && out, "bad sizes");
+  hipxMat A  = new hipxMat_s;
+  A->m       = m;
+  A->n       = n;
+  A->is64    = is64;
+  A->nnz     = nrows ? (int64_t)ai[nrows] : 0;
+  A->compressed = ridx != nullptr;
+  A->nrows_c = nrows;
+  const size_t pad = 8;  // the stream kernel reads whole quads: pad so a quad never leaves the allocation
+  HIPX_HIP(hipMalloc(&A->d_i, sizeof(IT) * ((size_t)nrows + 1)));
+  HIPX_HIP(hipMalloc((void **)&A->d_j, sizeof(hipx_int) * ((size_t)A->nnz + pad)));
+  HIPX_HIP(hipMalloc((void **)&A->d_a, sizeof(double) * ((size_t)A->nnz + pad)));
+  HIPX_HIP(hipMemsetAsync(A->d_j + A->nnz, 0, sizeof(hipx_int) * pad, rt().compute));
+  HIPX_HIP(hipMemsetAsync(A->d_a + A->nnz, 0, sizeof(double) * pad, rt().compute));
+  static const IT zero = 0;
+  HIPX_HIP(hipMemcpyAsync(A->d_i, nrows ? ai : &zero, sizeof(IT) * ((size_t)nrows + 1), hipMemcpyHostToDevice, rt().compute));
+  if (A->nnz) {
+    HIPX_HIP(hipMemcpyAsync(A->d_j, aj, sizeof(hipx_int) * (size_t)A->nnz, hipMemcpyHostToDevice, rt().compute));
+    HIPX_HIP(hipMemcpyAsync(A->d_a, aa, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice, rt().compute));
+  }
+  A->device_bytes = (int64_t)(sizeof(IT) * ((size_t)nrows + 1) + (sizeof(hipx_int) + sizeof(double)) * ((size_t)A->nnz + pad));
+  if (ridx) {
+    HIPX_HIP(hipMalloc((void **)&A->d_ridx, sizeof(hipx_int) * ((size_t)nrows + 1)));
+    if (nrows) HIPX_HIP(hipMemcpyAsync(A->d_ridx, ridx, sizeof(hipx_int) * (size_t)nrows, hipMemcpyHostToDevice, rt().compute));
+    A->device_bytes += (int64_t)sizeof(hipx_int) * nrows;
+  }
+  std::vector<hipx_int> rb;
+  if (nrows) build_row_blocks<IT>(nrows, ai, rb);
+  else rb.assign(1, 0);
+  A->nblocks = (hipx_int)rb.size() - 1;
+  HIPX_HIP(hipMalloc((void **)&A->d_rb, sizeof(hipx_int) * rb.size()));
+  HIPX_HIP(hipMemcpyAsync(A->d_rb, rb.data(), sizeof(hipx_int) * rb.size(), hipMemcpyHostToDevice, rt().compute));
+  A->device_bytes += (int64_t)(sizeof(hipx_int) * rb.size());
+  HIPX_HIP(hipStreamSynchronize(rt().compute));  // rb (and the caller's arrays) may go away after return
+  if (!ridx && m) {
+    HIPX_HIP(hipMalloc((void **)&A->d_diagpos, sizeof(int64_t) * (size_t)m));
+    unsigned int *cnt = rt().d_tickets + (HIPX_MAX_RED_SLOTS - 1);
+    HIPX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int), rt().compute));
+    hipx_int g = std::min<hipx_int>((m + 255) / 256, 4096);
+    diagpos_kernel<IT><<<(unsigned)g, 256, 0, rt().compute>>>(m, (const IT *)A->d_i, A->d_j, A->d_diagpos, cnt);
+    HIPX_LAUNCH_CHECK();
+    unsigned int missing = 0;
+    HIPX_HIP(hipMemcpyAsync(&missing, cnt, sizeof(unsigned int), hipMemcpyDeviceToHost, rt().compute));
+    HIPX_HIP(hipStreamSynchronize(rt().compute));
+    HIPX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int), rt().compute));
+    A->diag_dense = (missing == 0) && (m <= n);
+    A->device_bytes += (int64_t)sizeof(int64_t) * m;
+  }
+  *out = A;
+  return HIPX_SUCCESS;
+}
+
+template <typename IT, int MODE, bool DOT>
+int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
+{
+  if (A->nblocks == 0) return HIPX_SUCCESS;
+  const hipx_int per_xcd = (A->nblocks + 7) / 8;
+  const unsigned grid    = (unsigned)(per_xcd * 8);
+  const bool     nt      = (A->variant == 2);
+  hipStream_t    s       = rt().compute;
+#define HIPX_SPMV_ARGS A->d_rb, A->nblocks, per_xcd, (const IT *)A->d_i, A->d_j, A->d_a, x, yin, yout, A->d_ridx, dotpart
+  if (A->compressed) {
+    if (nt) spmv_stream_kernel<IT, true, MODE, true, DOT><<<grid, SPMV_THREADS, 0, s>>>(HIPX_SPMV_ARGS);
+    else spmv_stream_kernel<IT, false, MODE, true, DOT><<<grid, SPMV_THREADS, 0, s>>>(HIPX_SPMV_ARGS);
+  } else {
+    if (nt) spmv_stream_kernel<IT, true, MODE, false, DOT><<<grid, SPMV_THREADS, 0, s>>>(HIPX_SPMV_ARGS);
+    else spmv_stream_kernel<IT, false, MODE, false, DOT><<<grid, SPMV_THREADS, 0, s>>>(HIPX_SPMV_ARGS);
+  }
+#undef HIPX_SPMV_ARGS
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+template <int MODE, bool DOT>
+int launch_spmv(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart);
+
+template <int MODE, bool DOT>
+int launch_spmv(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
+{
+  const bool timed = (MODE == 0) && !A->compressed;  // the MatMult kernel proper
+  int        ierr;
+  if (timed && (ierr = prof_mark(true))) return ierr;
+  ierr = A->is64 ? launch_spmv_t<int64_t, MODE, DOT>(A, x, yin, yout, dotpart) : launch_spmv_t<hipx_int, MODE, DOT>(A, x, yin, yout, dotpart);
+  if (ierr) return ierr;
+  if (timed && (ierr = prof_mark(false))) return ierr;
+  return HIPX_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hipxProfileSpMV(int enable)
+{
+  HIPX_CHECK_INIT();
+  prof().on   = enable != 0;
+  prof().used = 0;
+  return HIPX_SUCCESS;
+}
+
+int hipxProfileSpMVGet(int *count, double *total_ms)
+{
+  HIPX_CHECK_INIT();
+  SpmvProf &p = prof();
+  HIPX_HIP(hipStreamSynchronize(rt().compute));
+  double tot = 0.0;
+  for (size_t k = 0; k + 1 < p.used; k += 2) {
+    float ms = 0.f;
+    HIPX_HIP(hipEventElapsedTime(&ms, p.ev[k], p.ev[k + 1]));
+    tot += ms;
+  }
+  if (count) *count = (int)(p.used / 2);
+  if (total_ms) *total_ms = tot;
+  p.used = 0;
+  return HIPX_SUCCESS;
+}
+
+int hipxMatCreateCSR(hipx_int m, hipx_int n, const hipx_int *i, const hipx_int *j, const double *a, hipxMat *A)
+{
+  HIPX_CHECK_INIT();
+  return create_common<hipx_int>(m, n, m, i, nullptr, j, a, false, A);
+}
+
+int hipxMatCreateCSR64(hipx_int m, hipx_int n, const int64_t *i, const hipx_int *j, const double *a, hipxMat *A)
+{
+  HIPX_CHECK_INIT();
+  return create_common<int64_t>(m, n, m, i, nullptr, j, a, true, A);
+}
+
+int hipxMatCreateCSRCompressedRow(hipx_int m, hipx_int n, hipx_int nrows, const hipx_int *ci, const hipx_int *ridx, const hipx_int *j, const double *a, hipxMat *A)
+{
+  HIPX_CHECK_INIT();
+  static const hipx_int dummy = 0;
+  return create_common<hipx_int>(m, n, nrows, ci, ridx ? ridx : &dummy, j, a, false, A);
+}
+
+int hipxMatUpdateValues(hipxMat A, const double *a)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A, "null matrix");
+  if (A->nnz) HIPX_HIP(hipMemcpyAsync(A->d_a, a, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice, rt().compute));
+  HIPX_HIP(hipStreamSynchronize(rt().compute));
+  A->sor_omega = 0;  // idiag must be rebuilt (aij.c:1807 idiagState)
+  return HIPX_SUCCESS;
+}
+
+int hipxMatDestroy(hipxMat *pA)
+{
+  HIPX_CHECK_INIT();
+  if (!pA || !*pA) return HIPX_SUCCESS;
+  hipxMat A = *pA;
+  HIPX_HIP(hipStreamSynchronize(rt().compute));
+  (void)hipFree(A->d_i);
+  (void)hipFree(A->d_j);
+  (void)hipFree(A->d_a);
+  (void)hipFree(A->d_diagpos);
+  (void)hipFree(A->d_rb);
+  (void)hipFree(A->d_ridx);
+  (void)hipFree(A->d_lev_ptr);
+  (void)hipFree(A->d_lev_rows);
+  (void)hipFree(A->d_idiag);
+  (void)hipFree(A->d_t);
+  (void)hipFree(A->d_dotpart);
+  delete A;
+  *pA = nullptr;
+  return HIPX_SUCCESS;
+}
+
+int hipxMatGetInfo(hipxMat A, hipx_int *m, hipx_int *n, int64_t *nnz, int64_t *device_bytes)
+{
+  HIPX_ARG(A, "null matrix");
+  if (m) *m = A->m;
+  if (n) *n = A->n;
+  if (nnz) *nnz = A->nnz;
+  if (device_bytes) *device_bytes = A->device_bytes;
+  return HIPX_SUCCESS;
+}
+
+int hipxMatSetSpMVVariant(hipxMat A, int variant)
+{
+  HIPX_ARG(A && variant >= 0 && variant <= 2, "variant must be 0 (auto), 1 (plain loads) or 2 (non-temporal loads)");
+  A->variant = variant;
+  return HIPX_SUCCESS;
+}
+
+int hipxMatMult(hipxMat A, const double *x, double *y)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A && (x || !A->n) && (y || !A->m), "null argument");
+  HIPX_ARG(x != y, "MatMult: x and y must differ (matrix.c:2706)");
+  if (A->compressed) {  // aij.c:1468: y is zeroed, only the listed rows are written
+    if (A->m) HIPX_HIP(hipMemsetAsync(y, 0, sizeof(double) * (size_t)A->m, rt().compute));
+  }
+  return launch_spmv<0, false>(A, x, nullptr, y, nullptr);
+}
+
+int hipxMatMultAdd(hipxMat A, const double *x, const double *y, double *z)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A && (x || !A->n), "null argument");
+  HIPX_ARG(x != z, "MatMultAdd: x and z must differ (matrix.c:2860)");
+  if (A->compressed && y != z && A->m) HIPX_HIP(hipMemcpyAsync(z, y, sizeof(double) * (size_t)A->m, hipMemcpyDeviceToDevice, rt().compute));  // aij.c:1629
+  return launch_spmv<1, false>(A, x, A->compressed ? z : y, z, nullptr);
+}
+
+int hipxMatMultDot(hipxMat A, const double *x, double *y, double *dot)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A && !A->compressed && A->m == A->n, "MatMultDot needs a square, uncompressed matrix");
+  *dot = 0.0;
+  if (!A->nblocks) return HIPX_SUCCESS;
+  const hipx_int npart = ((A->nblocks + 7) / 8) * 8;
+  if (!A->d_dotpart) HIPX_HIP(hipMalloc((void **)&A->d_dotpart, sizeof(double) * (size_t)npart));
+  int ierr = launch_spmv<0, true>(A, x, nullptr, y, A->d_dotpart);
+  if (ierr) return ierr;
+  return hipxVecSum(A->d_dotpart, npart, dot);
+}
+
+int hipxMatGetDiagonal(hipxMat A, double *d)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A && !A->compressed, "MatGetDiagonal: needs an uncompressed matrix");
+  if (!A->m) return HIPX_SUCCESS;
+  hipx_int g = std::min<hipx_int>((A->m + 255) / 256, 4096);
+  getdiag_kernel<<<(unsigned)g, 256, 0, rt().compute>>>(A->m, A->d_diagpos, A->d_a, d);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+int hipxPCJacobiSetUp(hipxMat A, double *dinv)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A && !A->compressed, "PCJacobiSetUp: needs an uncompressed matrix");
+  if (!A->m) return HIPX_SUCCESS;
+  hipx_int g = std::min<hipx_int>((A->m + 255) / 256, 4096);
+  jacobi_setup_kernel<<<(unsigned)g, 256, 0, rt().compute>>>(A->m, A->d_diagpos, A->d_a, dinv);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+}  // extern "C"

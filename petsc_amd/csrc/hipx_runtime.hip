@@ -1,0 +1,180 @@
+// hipx_runtime.hip -- device, streams, memory and events behind the C ABI (include/hipx.h).
+#include "hipx_internal.h"
+#include <cstring>
+
+namespace hipx {
+Runtime &rt()
+{
+  static Runtime r;
+  return r;
+}
+int fail(int code, const char *what, const char *file, int line)
+{
+  snprintf(rt().errmsg, sizeof(rt().errmsg), "hipx error %d: %s (%s:%d)", code, what, file, line);
+  return code;
+}
+}  // namespace hipx
+using namespace hipx;
+
+extern "C" {
+
+int hipxInit(int device)
+{
+  Runtime &r = rt();
+  if (r.initialized) return HIPX_SUCCESS;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) return fail(HIPX_ERR_GPU, "no HIP device visible: libhipx has no CPU fallback", __FILE__, __LINE__);
+  HIPX_ARG(device >= 0 && device < count, "device ordinal out of range");
+  HIPX_HIP(hipSetDevice(device));
+  r.device = device;
+  HIPX_HIP(hipStreamCreateWithFlags(&r.compute, hipStreamNonBlocking));
+  HIPX_HIP(hipStreamCreateWithFlags(&r.comm, hipStreamNonBlocking));
+  HIPX_HIP(hipMalloc((void **)&r.d_partials, sizeof(double) * HIPX_MAX_RED_SLOTS * kMaxRedVals * kRedBlocks));
+  HIPX_HIP(hipMalloc((void **)&r.d_tickets, sizeof(unsigned int) * HIPX_MAX_RED_SLOTS));
+  HIPX_HIP(hipMemset(r.d_tickets, 0, sizeof(unsigned int) * HIPX_MAX_RED_SLOTS));
+  HIPX_HIP(hipHostMalloc((void **)&r.h_results, sizeof(double) * HIPX_MAX_RED_SLOTS * kMaxRedVals, hipHostMallocMapped));
+  memset(r.h_results, 0, sizeof(double) * HIPX_MAX_RED_SLOTS * kMaxRedVals);
+  HIPX_HIP(hipHostGetDevicePointer((void **)&r.d_results, r.h_results, 0));
+  HIPX_HIP(hipMalloc((void **)&r.d_scalars, sizeof(double) * 4096));
+  HIPX_HIP(hipMalloc((void **)&r.d_ptrs, sizeof(void *) * 4096));
+  HIPX_HIP(hipDeviceSynchronize());
+  r.initialized = true;
+  return HIPX_SUCCESS;
+}
+
+int hipxFinalize(void)
+{
+  Runtime &r = rt();
+  if (!r.initialized) return HIPX_SUCCESS;
+  HIPX_HIP(hipDeviceSynchronize());
+  (void)hipFree(r.d_partials);
+  (void)hipFree(r.d_tickets);
+  (void)hipHostFree(r.h_results);
+  (void)hipFree(r.d_scalars);
+  (void)hipFree(r.d_ptrs);
+  (void)hipStreamDestroy(r.compute);
+  (void)hipStreamDestroy(r.comm);
+  r = Runtime();
+  return HIPX_SUCCESS;
+}
+
+int         hipxIsInitialized(void) { return rt().initialized ? 1 : 0; }
+const char *hipxGetErrorString(void) { return rt().errmsg; }
+
+int hipxDeviceName(char *buf, size_t len)
+{
+  HIPX_CHECK_INIT();
+  hipDeviceProp_t p;
+  HIPX_HIP(hipGetDeviceProperties(&p, rt().device));
+  snprintf(buf, len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+  return HIPX_SUCCESS;
+}
+
+void *hipxComputeStream(void) { return (void *)rt().compute; }
+void *hipxCommStream(void) { return (void *)rt().comm; }
+
+int hipxStreamSynchronize(void)
+{
+  HIPX_CHECK_INIT();
+  HIPX_HIP(hipStreamSynchronize(rt().compute));
+  return HIPX_SUCCESS;
+}
+int hipxDeviceSynchronize(void)
+{
+  HIPX_CHECK_INIT();
+  HIPX_HIP(hipDeviceSynchronize());
+  return HIPX_SUCCESS;
+}
+
+int hipxMalloc(void **dptr, size_t bytes)
+{
+  HIPX_CHECK_INIT();
+  *dptr = nullptr;
+  if (!bytes) return HIPX_SUCCESS;
+  hipError_t e = hipMalloc(dptr, bytes);
+  if (e == hipErrorOutOfMemory) return fail(HIPX_ERR_MEM, "hipMalloc: out of device memory", __FILE__, __LINE__);
+  HIPX_HIP(e);
+  return HIPX_SUCCESS;
+}
+int hipxFree(void *dptr)
+{
+  HIPX_CHECK_INIT();
+  if (dptr) {
+    HIPX_HIP(hipStreamSynchronize(rt().compute));
+    HIPX_HIP(hipFree(dptr));
+  }
+  return HIPX_SUCCESS;
+}
+int hipxMallocHost(void **hptr, size_t bytes)
+{
+  HIPX_CHECK_INIT();
+  HIPX_HIP(hipHostMalloc(hptr, bytes ? bytes : 8, hipHostMallocDefault));
+  return HIPX_SUCCESS;
+}
+int hipxFreeHost(void *hptr)
+{
+  HIPX_CHECK_INIT();
+  if (hptr) HIPX_HIP(hipHostFree(hptr));
+  return HIPX_SUCCESS;
+}
+int hipxMemcpyHtoD(void *dst, const void *src, size_t bytes)
+{
+  HIPX_CHECK_INIT();
+  if (!bytes) return HIPX_SUCCESS;
+  HIPX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, rt().compute));
+  HIPX_HIP(hipStreamSynchronize(rt().compute));
+  return HIPX_SUCCESS;
+}
+int hipxMemcpyDtoH(void *dst, const void *src, size_t bytes)
+{
+  HIPX_CHECK_INIT();
+  if (!bytes) return HIPX_SUCCESS;
+  HIPX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, rt().compute));
+  HIPX_HIP(hipStreamSynchronize(rt().compute));
+  return HIPX_SUCCESS;
+}
+int hipxMemcpyDtoD(void *dst, const void *src, size_t bytes)
+{
+  HIPX_CHECK_INIT();
+  if (!bytes || dst == src) return HIPX_SUCCESS;
+  HIPX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, rt().compute));
+  return HIPX_SUCCESS;
+}
+int hipxMemset(void *dst, int value, size_t bytes)
+{
+  HIPX_CHECK_INIT();
+  if (!bytes) return HIPX_SUCCESS;
+  HIPX_HIP(hipMemsetAsync(dst, value, bytes, rt().compute));
+  return HIPX_SUCCESS;
+}
+
+int hipxEventCreate(void **ev)
+{
+  HIPX_CHECK_INIT();
+  hipEvent_t e;
+  HIPX_HIP(hipEventCreate(&e));
+  *ev = (void *)e;
+  return HIPX_SUCCESS;
+}
+int hipxEventDestroy(void *ev)
+{
+  HIPX_CHECK_INIT();
+  HIPX_HIP(hipEventDestroy((hipEvent_t)ev));
+  return HIPX_SUCCESS;
+}
+int hipxEventRecord(void *ev)
+{
+  HIPX_CHECK_INIT();
+  HIPX_HIP(hipEventRecord((hipEvent_t)ev, rt().compute));
+  return HIPX_SUCCESS;
+}
+int hipxEventElapsedMs(void *start, void *stop, float *ms)
+{
+  HIPX_CHECK_INIT();
+  HIPX_HIP(hipEventSynchronize((hipEvent_t)stop));
+  HIPX_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return HIPX_SUCCESS;
+}
+
+}  // extern "C"

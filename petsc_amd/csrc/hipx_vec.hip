@@ -1,0 +1,896 @@
+// hipx_vec.hip -- Vec BLAS-1 kernels for gfx950 (wave64), behind include/hipx.h.
+//
+// Elementwise ops: HBM-bound streams.  Each thread moves 4 x 16 B per operand per launch (all loads
+// issued before the first use), blocks of 256 threads, enough blocks to cover the vector: at N = 16.7 M
+// that is 8192 workgroups, >> 256 CUs.  No FMA contraction (-ffp-contract=off): y + a*x rounds the
+// product and the sum separately, exactly like the reference's scalar loops / reference BLAS, so every
+// elementwise result is bit-identical to the CPU path (src/vec/vec/impls/seq/{bvec1,bvec2,dvec2}.c).
+//
+// Reductions: one launch, fixed grid (kRedBlocks x 256), per-thread register accumulation in a fixed
+// element order -> wave64 __shfl_down tree -> LDS across the 4 waves -> per-block partial -> the last
+// block to arrive (agent-scope release/acquire around a ticket counter) folds the partials in fixed
+// order and writes the scalar into pinned, device-mapped host memory.  The host only waits on the
+// stream: no D2H memcpy call on the dot/norm path (3 such waits per CG iteration, cg.c:258,309,344).
+#include "hipx_internal.h"
+#include "hipx_reduce.h"
+#include <cmath>
+#include <cstring>
+
+using namespace hipx;
+
+namespace {
+
+constexpr int EW_UNROLL = 4;
+
+inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---------------------------------------------------------------- elementwise, 1..3 operands
+template <class F>
+__global__ __launch_bounds__(kEwThreads) void ew1_kernel(double *y, hipx_int n, F f, bool vec)
+{
+  const hipx_int base = (hipx_int)blockIdx.x * (kEwThreads * EW_UNROLL) + threadIdx.x;
+  if (vec) {
+    const hipx_int n2 = n >> 1;
+    double2       *y2 = reinterpret_cast<double2 *>(y);
+    double2        v[EW_UNROLL];
+#pragma unroll
+    for (int k = 0; k < EW_UNROLL; k++) {
+      hipx_int p = base + k * kEwThreads;
+      if (p < n2) v[k] = y2[p];
+    }
+#pragma unroll
+    for (int k = 0; k < EW_UNROLL; k++) {
+      hipx_int p = base + k * kEwThreads;
+      if (p < n2) {
+        v[k].x = f(v[k].x);
+        v[k].y = f(v[k].y);
+        y2[p]  = v[k];
+      }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = f(y[n - 1]);
+  } else {
+    for (hipx_int i = (hipx_int)blockIdx.x * kEwThreads + threadIdx.x; i < n; i += (hipx_int)gridDim.x * kEwThreads) y[i] = f(y[i]);
+  }
+}
+
+template <class F>
+__global__ __launch_bounds__(kEwThreads) void ew2_kernel(double *y, const double *x, hipx_int n, F f, bool vec)
+{
+  const hipx_int base = (hipx_int)blockIdx.x * (kEwThreads * EW_UNROLL) + threadIdx.x;
+  if (vec) {
+    const hipx_int n2 = n >> 1;
+    double2       *y2 = reinterpret_cast<double2 *>(y);
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    double2        vy[EW_UNROLL], vx[EW_UNROLL];
+#pragma unroll
+    for (int k = 0; k < EW_UNROLL; k++) {
+      hipx_int p = base + k * kEwThreads;
+      if (p < n2) {
+        vy[k] = y2[p];
+        vx[k] = x2[p];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < EW_UNROLL; k++) {
+      hipx_int p = base + k * kEwThreads;
+      if (p < n2) {
+        vy[k].x = f(vy[k].x, vx[k].x);
+        vy[k].y = f(vy[k].y, vx[k].y);
+        y2[p]   = vy[k];
+      }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = f(y[n - 1], x[n - 1]);
+  } else {
+    for (hipx_int i = (hipx_int)blockIdx.x * kEwThreads + threadIdx.x; i < n; i += (hipx_int)gridDim.x * kEwThreads) y[i] = f(y[i], x[i]);
+  }
+}
+
+template <class F>
+__global__ __launch_bounds__(kEwThreads) void ew3_kernel(double *w, const double *x, const double *y, hipx_int n, F f, bool vec)
+{
+  const hipx_int base = (hipx_int)blockIdx.x * (kEwThreads * EW_UNROLL) + threadIdx.x;
+  if (vec) {
+    const hipx_int n2 = n >> 1;
+    double2       *w2 = reinterpret_cast<double2 *>(w);
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    const double2 *y2 = reinterpret_cast<const double2 *>(y);
+    double2        vw[EW_UNROLL], vx[EW_UNROLL], vy[EW_UNROLL];
+#pragma unroll
+    for (int k = 0; k < EW_UNROLL; k++) {
+      hipx_int p = base + k * kEwThreads;
+      if (p < n2) {
+        if (F::reads_w) vw[k] = w2[p];
+        vx[k] = x2[p];
+        vy[k] = y2[p];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < EW_UNROLL; k++) {
+      hipx_int p = base + k * kEwThreads;
+      if (p < n2) {
+        double2 o;
+        o.x   = f(vw[k].x, vx[k].x, vy[k].x);
+        o.y   = f(vw[k].y, vx[k].y, vy[k].y);
+        w2[p] = o;
+      }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) w[n - 1] = f(F::reads_w ? w[n - 1] : 0.0, x[n - 1], y[n - 1]);
+  } else {
+    for (hipx_int i = (hipx_int)blockIdx.x * kEwThreads + threadIdx.x; i < n; i += (hipx_int)gridDim.x * kEwThreads)
+      w[i] = f(F::reads_w ? w[i] : 0.0, x[i], y[i]);
+  }
+}
+
+inline unsigned ew_grid(hipx_int n, bool vec)
+{
+  if (vec) {
+    hipx_int n2 = n >> 1;
+    hipx_int g  = (n2 + kEwThreads * EW_UNROLL - 1) / (kEwThreads * EW_UNROLL);
+    return (unsigned)(g < 1 ? 1 : g);
+  }
+  hipx_int g = (n + kEwThreads - 1) / kEwThreads;
+  if (g > kEwMaxBlocks) g = kEwMaxBlocks;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+template <class F>
+int launch_ew1(double *y, hipx_int n, F f)
+{
+  if (n <= 0) return HIPX_SUCCESS;
+  bool vec = aligned16(y) && n >= 2;
+  ew1_kernel<F><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(y, n, f, vec);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+template <class F>
+int launch_ew2(double *y, const double *x, hipx_int n, F f)
+{
+  if (n <= 0) return HIPX_SUCCESS;
+  bool vec = aligned16(y) && aligned16(x) && n >= 2;
+  ew2_kernel<F><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(y, x, n, f, vec);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+template <class F>
+int launch_ew3(double *w, const double *x, const double *y, hipx_int n, F f)
+{
+  if (n <= 0) return HIPX_SUCCESS;
+  bool vec = aligned16(w) && aligned16(x) && aligned16(y) && n >= 2;
+  ew3_kernel<F><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(w, x, y, n, f, vec);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+// functors (each mirrors one reference loop; see the ABI comments in hipx.h)
+struct FSet { double a; __device__ double operator()(double) const { return a; } };
+struct FScale { double a; __device__ double operator()(double y) const { return y * a; } };
+struct FShift { double a; __device__ double operator()(double y) const { return y + a; } };
+struct FRecip { __device__ double operator()(double y) const { return y != 0.0 ? 1.0 / y : y; } };  // vinv.c:1208-1229
+struct FAbs { __device__ double operator()(double y) const { return fabs(y); } };
+struct FAxpy { double a; __device__ double operator()(double y, double x) const { return y + a * x; } };            // daxpy
+struct FAypx { double b; __device__ double operator()(double y, double x) const { return x + b * y; } };            // dvec2.c:774
+struct FXmy { __device__ double operator()(double y, double x) const { return x - y; } };                           // dvec2.c:767
+struct FAxpby { double a, b; __device__ double operator()(double y, double x) const { return a * x + b * y; } };    // bvec1.c:111
+struct FAx { double a; __device__ double operator()(double, double x) const { return a * x; } };                    // bvec1.c:108
+struct FWaxpy { static constexpr bool reads_w = false; double a; __device__ double operator()(double, double x, double y) const { return y + a * x; } };
+struct FWadd { static constexpr bool reads_w = false; __device__ double operator()(double, double x, double y) const { return y + x; } };
+struct FWsub { static constexpr bool reads_w = false; __device__ double operator()(double, double x, double y) const { return y - x; } };
+struct FPmult { static constexpr bool reads_w = false; __device__ double operator()(double, double x, double y) const { return x * y; } };
+struct FPdiv { static constexpr bool reads_w = false; __device__ double operator()(double, double x, double y) const { return y == 0.0 ? (x == 0.0 ? 1.0 : 0.0) : x / y; } };
+// bvec1.c:120-147: four association orders
+struct FAbc0 { static constexpr bool reads_w = true; double b, c; __device__ double operator()(double z, double x, double y) const { return x + b * y + c * z; } };
+struct FAbc1 { static constexpr bool reads_w = true; double a, b; __device__ double operator()(double z, double x, double y) const { return a * x + b * y + z; } };
+struct FAbc2 { static constexpr bool reads_w = false; double a, b; __device__ double operator()(double, double x, double y) const { return a * x + b * y; } };
+struct FAbc3 { static constexpr bool reads_w = true; double a, b, c; __device__ double operator()(double z, double x, double y) const { return a * x + b * y + c * z; } };
+
+// ---------------------------------------------------------------- swap
+__global__ __launch_bounds__(kEwThreads) void swap_kernel(double *x, double *y, hipx_int n)
+{
+  for (hipx_int i = (hipx_int)blockIdx.x * kEwThreads + threadIdx.x; i < n; i += (hipx_int)gridDim.x * kEwThreads) {
+    double t = x[i];
+    x[i]     = y[i];
+    y[i]     = t;
+  }
+}
+
+// ---------------------------------------------------------------- MAXPY: y (= beta y) += sum_j a_j x_j, up to 8 vectors per pass
+constexpr int MAXPY_B = 8;
+struct MaxpyArgs {
+  const double *x[MAXPY_B];
+  double        a[MAXPY_B];
+};
+// mode: 0 y += ..., 1 y = beta*y + ..., 2 y = 0 + ... (beta == 0: VecSet(y,0) then MAXPY, rvector.c:1434)
+template <int NV>
+__global__ __launch_bounds__(kEwThreads) void maxpy_kernel(double *y, MaxpyArgs args, double beta, int mode, hipx_int n, bool vec)
+{
+  const hipx_int base = (hipx_int)blockIdx.x * (kEwThreads * EW_UNROLL) + threadIdx.x;
+  if (vec) {
+    const hipx_int n2 = n >> 1;
+    double2       *y2 = reinterpret_cast<double2 *>(y);
+#pragma unroll
+    for (int k = 0; k < EW_UNROLL; k++) {
+      hipx_int p = base + k * kEwThreads;
+      if (p < n2) {
+        double2 acc = (mode == 2) ? make_double2(0.0, 0.0) : y2[p];
+        if (mode == 1) {
+          acc.x *= beta;
+          acc.y *= beta;
+        }
+        // association of dvec2.c:658-693 / petscaxpy.h:197-235: groups of (nv & 3) then fours, each group summed
+        // left to right before being added to y.
+        constexpr int REM = NV & 3;
+        if (REM) {
+          double2 g = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int j = 0; j < REM; j++) {
+            double2 xv = reinterpret_cast<const double2 *>(args.x[j])[p];
+            if (j == 0) {
+              g.x = args.a[j] * xv.x;
+              g.y = args.a[j] * xv.y;
+            } else {
+              g.x = g.x + args.a[j] * xv.x;
+              g.y = g.y + args.a[j] * xv.y;
+            }
+          }
+          acc.x += g.x;
+          acc.y += g.y;
+        }
+#pragma unroll
+        for (int j0 = REM; j0 < NV; j0 += 4) {
+          double2 g = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            double2 xv = reinterpret_cast<const double2 *>(args.x[j0 + j])[p];
+            if (j == 0) {
+              g.x = args.a[j0] * xv.x;
+              g.y = args.a[j0] * xv.y;
+            } else {
+              g.x = g.x + args.a[j0 + j] * xv.x;
+              g.y = g.y + args.a[j0 + j] * xv.y;
+            }
+          }
+          acc.x += g.x;
+          acc.y += g.y;
+        }
+        y2[p] = acc;
+      }
+    }
+  }
+  // scalar path (unaligned operands) and odd tail
+  hipx_int i0, step;
+  if (vec) {
+    if (!((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)) return;
+    i0   = n - 1;
+    step = n;
+  } else {
+    i0   = (hipx_int)blockIdx.x * kEwThreads + threadIdx.x;
+    step = (hipx_int)gridDim.x * kEwThreads;
+  }
+  for (hipx_int i = i0; i < n; i += step) {
+    double acc = (mode == 2) ? 0.0 : y[i];
+    if (mode == 1) acc *= beta;
+    constexpr int REM = NV & 3;
+    if (REM) {
+      double g = 0.0;
+#pragma unroll
+      for (int j = 0; j < REM; j++) g = (j == 0) ? args.a[j] * args.x[j][i] : g + args.a[j] * args.x[j][i];
+      acc += g;
+    }
+#pragma unroll
+    for (int j0 = REM; j0 < NV; j0 += 4) {
+      double g = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) g = (j == 0) ? args.a[j0] * args.x[j0][i] : g + args.a[j0 + j] * args.x[j0 + j][i];
+      acc += g;
+    }
+    y[i] = acc;
+  }
+}
+
+// x . y_j for j < NV (NV = 1: dot).  Each thread walks pairs p = tid, tid + T, ... in steps of 2 double2.
+template <int NV>
+struct MDotArgs {
+  const double *y[NV];
+};
+template <int NV>
+__global__ __launch_bounds__(kRedThreads) void mdot_kernel(const double *x, MDotArgs<NV> ys, hipx_int n, bool vec, double *partials, unsigned int *ticket,
+                                                            double *results)
+{
+  double acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; v++) acc[v] = 0.0;
+  const hipx_int T   = (hipx_int)gridDim.x * kRedThreads;
+  const hipx_int tid = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x;
+  if (vec) {
+    const hipx_int n2 = n >> 1;
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    for (hipx_int p = tid; p < n2; p += 2 * T) {
+      const hipx_int q  = p + T;
+      const bool     hq = q < n2;
+      double2        xa = x2[p], xb = hq ? x2[q] : make_double2(0.0, 0.0);
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        const double2 *y2 = reinterpret_cast<const double2 *>(ys.y[v]);
+        double2        ya = y2[p], yb = hq ? y2[q] : make_double2(0.0, 0.0);
+        acc[v] += xa.x * ya.x;
+        acc[v] += xa.y * ya.y;
+        acc[v] += xb.x * yb.x;
+        acc[v] += xb.y * yb.y;
+      }
+    }
+    if ((n & 1) && tid == 0) {
+#pragma unroll
+      for (int v = 0; v < NV; v++) acc[v] += x[n - 1] * ys.y[v][n - 1];
+    }
+  } else {
+    for (hipx_int i = tid; i < n; i += T) {
+#pragma unroll
+      for (int v = 0; v < NV; v++) acc[v] += x[i] * ys.y[v][i];
+    }
+  }
+  block_finish<NV, RED_SUM>(acc, partials, ticket, results);
+}
+
+// sums of |x| (NORM_1), x*x (NORM_2) in one pass: acc[0] = sum |x|, acc[1] = sum x^2
+__global__ __launch_bounds__(kRedThreads) void norm12_kernel(const double *x, hipx_int n, bool vec, double *partials, unsigned int *ticket, double *results)
+{
+  double         acc[2] = {0.0, 0.0};
+  const hipx_int T      = (hipx_int)gridDim.x * kRedThreads;
+  const hipx_int tid    = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x;
+  if (vec) {
+    const hipx_int n2 = n >> 1;
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    for (hipx_int p = tid; p < n2; p += T) {
+      double2 a = x2[p];
+      acc[0] += fabs(a.x);
+      acc[0] += fabs(a.y);
+      acc[1] += a.x * a.x;
+      acc[1] += a.y * a.y;
+    }
+    if ((n & 1) && tid == 0) {
+      acc[0] += fabs(x[n - 1]);
+      acc[1] += x[n - 1] * x[n - 1];
+    }
+  } else {
+    for (hipx_int i = tid; i < n; i += T) {
+      acc[0] += fabs(x[i]);
+      acc[1] += x[i] * x[i];
+    }
+  }
+  block_finish<2, RED_SUM>(acc, partials, ticket, results);
+}
+
+__global__ __launch_bounds__(kRedThreads) void sum_kernel(const double *x, hipx_int n, double *partials, unsigned int *ticket, double *results)
+{
+  double         acc[1] = {0.0};
+  const hipx_int T      = (hipx_int)gridDim.x * kRedThreads;
+  for (hipx_int i = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += T) acc[0] += x[i];
+  block_finish<1, RED_SUM>(acc, partials, ticket, results);
+}
+
+// NORM_INFINITY with the reference's NaN propagation (bvec2.c:207-216)
+__global__ __launch_bounds__(kRedThreads) void norminf_kernel(const double *x, hipx_int n, double *partials, unsigned int *ticket, double *results)
+{
+  double         acc[1] = {0.0};
+  const hipx_int T      = (hipx_int)gridDim.x * kRedThreads;
+  for (hipx_int i = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += T) {
+    double t = fabs(x[i]);
+    acc[0]   = (t > acc[0] || t != t) ? t : acc[0];
+  }
+  block_finish<1, RED_MAXNAN>(acc, partials, ticket, results);
+}
+
+// x.y and y.y in one pass (VecDotNorm2)
+__global__ __launch_bounds__(kRedThreads) void dotnorm2_kernel(const double *x, const double *y, hipx_int n, double *partials, unsigned int *ticket, double *results)
+{
+  double         acc[2] = {0.0, 0.0};
+  const hipx_int T      = (hipx_int)gridDim.x * kRedThreads;
+  for (hipx_int i = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += T) {
+    double a = x[i], b = y[i];
+    acc[0] += a * b;
+    acc[1] += b * b;
+  }
+  block_finish<2, RED_SUM>(acc, partials, ticket, results);
+}
+
+// fused CG update (cg.c:305-309,344 with PCJACOBI): x += a p; r -= a w; z = r*d; sums z.z, z.r
+__global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n,
+                                                                bool vec, double *partials, unsigned int *ticket, double *results)
+{
+  double         acc[2] = {0.0, 0.0};
+  const hipx_int T      = (hipx_int)gridDim.x * kRedThreads;
+  const hipx_int tid    = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x;
+  const double   ma     = -a;
+  if (vec) {
+    const hipx_int n2 = n >> 1;
+    double2       *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r), *z2 = reinterpret_cast<double2 *>(z);
+    const double2 *p2 = reinterpret_cast<const double2 *>(p), *w2 = reinterpret_cast<const double2 *>(w), *d2 = reinterpret_cast<const double2 *>(d);
+    for (hipx_int q = tid; q < n2; q += T) {
+      double2 xv = x2[q], rv = r2[q], pv = p2[q], wv = w2[q], dv = d2[q], zv;
+      xv.x  = xv.x + a * pv.x;
+      xv.y  = xv.y + a * pv.y;
+      rv.x  = rv.x + ma * wv.x;
+      rv.y  = rv.y + ma * wv.y;
+      zv.x  = rv.x * dv.x;
+      zv.y  = rv.y * dv.y;
+      x2[q] = xv;
+      r2[q] = rv;
+      z2[q] = zv;
+      acc[0] += zv.x * zv.x;
+      acc[0] += zv.y * zv.y;
+      acc[1] += zv.x * rv.x;
+      acc[1] += zv.y * rv.y;
+    }
+    if ((n & 1) && tid == 0) {
+      hipx_int i  = n - 1;
+      double   xv = x[i] + a * p[i], rv = r[i] + ma * w[i], zv = rv * d[i];
+      x[i] = xv;
+      r[i] = rv;
+      z[i] = zv;
+      acc[0] += zv * zv;
+      acc[1] += zv * rv;
+    }
+  } else {
+    for (hipx_int i = tid; i < n; i += T) {
+      double xv = x[i] + a * p[i], rv = r[i] + ma * w[i], zv = rv * d[i];
+      x[i] = xv;
+      r[i] = rv;
+      z[i] = zv;
+      acc[0] += zv * zv;
+      acc[1] += zv * rv;
+    }
+  }
+  block_finish<2, RED_SUM>(acc, partials, ticket, results);
+}
+
+// max / min with index: two small kernels (setup-time operations, not on the solver loop)
+__global__ __launch_bounds__(kRedThreads) void minmax_stage1(const double *x, hipx_int n, int want_max, double *pv, hipx_int *pi)
+{
+  __shared__ double   sv[kRedThreads];
+  __shared__ hipx_int si[kRedThreads];
+  double              best = want_max ? -HUGE_VAL : HUGE_VAL;
+  hipx_int            bi   = -1;
+  const hipx_int      T    = (hipx_int)gridDim.x * kRedThreads;
+  for (hipx_int i = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += T) {
+    double v = x[i];
+    if (bi < 0 || (want_max ? v > best : v < best)) {
+      best = v;
+      bi   = i;
+    }
+  }
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = kRedThreads / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      double   ov = sv[threadIdx.x + s];
+      hipx_int oi = si[threadIdx.x + s];
+      bool     take = oi >= 0 && (si[threadIdx.x] < 0 || (want_max ? ov > sv[threadIdx.x] : ov < sv[threadIdx.x]) || (ov == sv[threadIdx.x] && oi < si[threadIdx.x]));
+      if (take) {
+        sv[threadIdx.x] = ov;
+        si[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    pv[blockIdx.x] = sv[0];
+    pi[blockIdx.x] = si[0];
+  }
+}
+
+__global__ void replace_zeros_kernel(double *x, hipx_int n, double value, unsigned int *count)
+{
+  for (hipx_int i = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (hipx_int)gridDim.x * blockDim.x) {
+    if (x[i] == 0.0) {
+      x[i] = value;
+      atomicAdd(count, 1u);
+    }
+  }
+}
+
+inline unsigned red_grid(hipx_int n)
+{
+  // enough blocks to cover n once at 4 elements/thread, capped at kRedBlocks; a fixed function of n only
+  hipx_int g = (n + kRedThreads * 4 - 1) / (kRedThreads * 4);
+  if (g > kRedBlocks) g = kRedBlocks;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+int red_wait(int slot, int nvals, double *out)
+{
+  HIPX_HIP(hipStreamSynchronize(rt().compute));
+  const volatile double *h = slot_results_host(slot);
+  for (int v = 0; v < nvals; v++) out[v] = h[v];
+  return HIPX_SUCCESS;
+}
+
+template <int NV>
+int launch_mdot(const double *x, const double *const *y, hipx_int n, int slot)
+{
+  MDotArgs<NV> a;
+  bool         vec = aligned16(x) && n >= 2;
+  for (int v = 0; v < NV; v++) {
+    a.y[v] = y[v];
+    vec    = vec && aligned16(y[v]);
+  }
+  mdot_kernel<NV><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, a, n, vec, slot_partials(slot), rt().d_tickets + slot, slot_results_dev(slot));
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+int mdot_dispatch(const double *x, int nv, const double *const *y, hipx_int n, int slot)
+{
+  switch (nv) {
+  case 1: return launch_mdot<1>(x, y, n, slot);
+  case 2: return launch_mdot<2>(x, y, n, slot);
+  case 3: return launch_mdot<3>(x, y, n, slot);
+  case 4: return launch_mdot<4>(x, y, n, slot);
+  case 5: return launch_mdot<5>(x, y, n, slot);
+  case 6: return launch_mdot<6>(x, y, n, slot);
+  case 7: return launch_mdot<7>(x, y, n, slot);
+  case 8: return launch_mdot<8>(x, y, n, slot);
+  }
+  return fail(HIPX_ERR_ARG, "mdot batch size", __FILE__, __LINE__);
+}
+
+template <int NV>
+int launch_maxpy(double *y, const double *alpha, const double *const *x, double beta, int mode, hipx_int n)
+{
+  MaxpyArgs a;
+  bool      vec = aligned16(y) && n >= 2;
+  for (int j = 0; j < NV; j++) {
+    a.x[j] = x[j];
+    a.a[j] = alpha[j];
+    vec    = vec && aligned16(x[j]);
+  }
+  maxpy_kernel<NV><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(y, a, beta, mode, n, vec);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+int maxpy_dispatch(double *y, int nv, const double *alpha, const double *const *x, double beta, int mode, hipx_int n)
+{
+  switch (nv) {
+  case 1: return launch_maxpy<1>(y, alpha, x, beta, mode, n);
+  case 2: return launch_maxpy<2>(y, alpha, x, beta, mode, n);
+  case 3: return launch_maxpy<3>(y, alpha, x, beta, mode, n);
+  case 4: return launch_maxpy<4>(y, alpha, x, beta, mode, n);
+  case 5: return launch_maxpy<5>(y, alpha, x, beta, mode, n);
+  case 6: return launch_maxpy<6>(y, alpha, x, beta, mode, n);
+  case 7: return launch_maxpy<7>(y, alpha, x, beta, mode, n);
+  case 8: return launch_maxpy<8>(y, alpha, x, beta, mode, n);
+  }
+  return fail(HIPX_ERR_ARG, "maxpy batch size", __FILE__, __LINE__);
+}
+
+}  // namespace
+
+extern "C" {
+
+int hipxVecSet(double *x, hipx_int n, double alpha)
+{
+  HIPX_CHECK_INIT();
+  if (n <= 0) return HIPX_SUCCESS;
+  if (alpha == 0.0) {  // dvec2.c:649 PetscArrayzero
+    HIPX_HIP(hipMemsetAsync(x, 0, (size_t)n * sizeof(double), rt().compute));
+    return HIPX_SUCCESS;
+  }
+  return launch_ew1(x, n, FSet{alpha});
+}
+
+int hipxVecCopy(const double *x, double *y, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  if (n <= 0 || x == y) return HIPX_SUCCESS;
+  HIPX_HIP(hipMemcpyAsync(y, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, rt().compute));
+  return HIPX_SUCCESS;
+}
+
+int hipxVecScale(double *x, hipx_int n, double alpha)
+{
+  HIPX_CHECK_INIT();
+  if (alpha == 0.0) return hipxVecSet(x, n, 0.0);  // bvec2.c:172
+  if (alpha == 1.0) return HIPX_SUCCESS;           // bvec2.c:174
+  return launch_ew1(x, n, FScale{alpha});
+}
+
+int hipxVecShift(double *x, hipx_int n, double shift)
+{
+  HIPX_CHECK_INIT();
+  if (shift == 0.0) return HIPX_SUCCESS;
+  return launch_ew1(x, n, FShift{shift});
+}
+
+int hipxVecReciprocal(double *x, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  return launch_ew1(x, n, FRecip{});
+}
+
+int hipxVecAbs(double *x, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  return launch_ew1(x, n, FAbs{});
+}
+
+int hipxVecSwap(double *x, double *y, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  if (n <= 0 || x == y) return HIPX_SUCCESS;
+  hipx_int g = (n + kEwThreads - 1) / kEwThreads;
+  if (g > kEwMaxBlocks) g = kEwMaxBlocks;
+  swap_kernel<<<(unsigned)g, kEwThreads, 0, rt().compute>>>(x, y, n);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+int hipxVecAXPY(double *y, double alpha, const double *x, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  if (alpha == 0.0) return HIPX_SUCCESS;  // bvec1.c:75
+  return launch_ew2(y, x, n, FAxpy{alpha});
+}
+
+int hipxVecAYPX(double *y, double beta, const double *x, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  if (beta == 0.0) return hipxVecCopy(x, y, n);               // dvec2.c:756
+  if (beta == 1.0) return launch_ew2(y, x, n, FAxpy{beta});   // dvec2.c:758 -> VecAXPY_Seq(y, 1, x)
+  if (beta == -1.0) return launch_ew2(y, x, n, FXmy{});       // dvec2.c:767
+  return launch_ew2(y, x, n, FAypx{beta});                    // dvec2.c:774
+}
+
+int hipxVecAXPBY(double *y, double a, double b, const double *x, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  if (a == 0.0) return hipxVecScale(y, n, b);    // bvec1.c:94
+  if (b == 1.0) return hipxVecAXPY(y, a, x, n);  // bvec1.c:96
+  if (a == 1.0) return hipxVecAYPX(y, b, x, n);  // bvec1.c:98
+  if (b == 0.0) return launch_ew2(y, x, n, FAx{a});
+  return launch_ew2(y, x, n, FAxpby{a, b});
+}
+
+int hipxVecWAXPY(double *w, double alpha, const double *x, const double *y, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  if (alpha == 1.0) return launch_ew3(w, x, y, n, FWadd{});   // dvec2.c:805
+  if (alpha == -1.0) return launch_ew3(w, x, y, n, FWsub{});  // dvec2.c:808
+  if (alpha == 0.0) return hipxVecCopy(y, w, n);              // dvec2.c:810
+  return launch_ew3(w, x, y, n, FWaxpy{alpha});
+}
+
+int hipxVecAXPBYPCZ(double *z, double alpha, double beta, double gamma, const double *x, const double *y, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  if (alpha == 1.0) return launch_ew3(z, x, y, n, FAbc0{beta, gamma});
+  if (gamma == 1.0) return launch_ew3(z, x, y, n, FAbc1{alpha, beta});
+  if (gamma == 0.0) return launch_ew3(z, x, y, n, FAbc2{alpha, beta});
+  return launch_ew3(z, x, y, n, FAbc3{alpha, beta, gamma});
+}
+
+int hipxVecPointwiseMult(double *w, const double *x, const double *y, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  return launch_ew3(w, x, y, n, FPmult{});
+}
+
+int hipxVecPointwiseDivide(double *w, const double *x, const double *y, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  return launch_ew3(w, x, y, n, FPdiv{});
+}
+
+int hipxVecReplaceZeros(double *x, hipx_int n, double value, hipx_int *nreplaced_host)
+{
+  HIPX_CHECK_INIT();
+  unsigned int *cnt = rt().d_tickets + (HIPX_MAX_RED_SLOTS - 1);  // last slot is reserved for this counter
+  HIPX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int), rt().compute));
+  if (n > 0) {
+    hipx_int g = (n + 255) / 256;
+    if (g > kEwMaxBlocks) g = kEwMaxBlocks;
+    replace_zeros_kernel<<<(unsigned)g, 256, 0, rt().compute>>>(x, n, value, cnt);
+    HIPX_LAUNCH_CHECK();
+  }
+  unsigned int h = 0;
+  HIPX_HIP(hipMemcpyAsync(&h, cnt, sizeof(unsigned int), hipMemcpyDeviceToHost, rt().compute));
+  HIPX_HIP(hipStreamSynchronize(rt().compute));
+  HIPX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int), rt().compute));
+  if (nreplaced_host) *nreplaced_host = (hipx_int)h;
+  return HIPX_SUCCESS;
+}
+
+int hipxVecMAXPY(double *y, hipx_int nv, const double *alpha, const double *const *x, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(nv >= 0, "nv < 0");
+  if (n <= 0 || nv == 0) return HIPX_SUCCESS;
+  // the reference processes (nv & 3) vectors first, then groups of four (dvec2.c:672-690); batches here keep
+  // that grouping: first batch takes (nv & 3) + 4 (or fewer), later batches multiples of 4.
+  hipx_int done = 0, rem = nv & 3;
+  while (done < nv) {
+    hipx_int left = nv - done, take;
+    if (left <= MAXPY_B) take = left;
+    else take = (done == 0 && rem) ? rem + 4 : MAXPY_B;
+    int ierr = maxpy_dispatch(y, take, alpha + done, x + done, 0.0, 0, n);
+    if (ierr) return ierr;
+    done += take;
+  }
+  return HIPX_SUCCESS;
+}
+
+int hipxVecMAXPBY(double *y, hipx_int nv, const double *alpha, double beta, const double *const *x, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  // rvector.c:1394-1440 with no ops->maxpby: beta == 0 -> VecSet(y, 0) else VecScale(y, beta); then VecMAXPY.
+  int ierr;
+  if (beta == 0.0) ierr = hipxVecSet(y, n, 0.0);
+  else ierr = hipxVecScale(y, n, beta);
+  if (ierr) return ierr;
+  return hipxVecMAXPY(y, nv, alpha, x, n);
+}
+
+int hipxVecDotBegin(const double *x, const double *y, hipx_int n, int slot)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 1, "reduction slot out of range");
+  if (n <= 0) {
+    slot_results_host(slot)[0] = 0.0;
+    return HIPX_SUCCESS;
+  }
+  const double *ys[1] = {y};
+  return mdot_dispatch(x, 1, ys, n, slot);
+}
+
+int hipxRedEnd(int slot, int nvals, double *results)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 1 && nvals >= 0 && nvals <= kMaxRedVals, "reduction slot / count out of range");
+  return red_wait(slot, nvals, results);
+}
+
+int hipxVecDot(const double *x, const double *y, hipx_int n, double *result)
+{
+  HIPX_CHECK_INIT();
+  if (n <= 0) {
+    *result = 0.0;
+    return HIPX_SUCCESS;
+  }
+  int ierr = hipxVecDotBegin(x, y, n, 0);
+  if (ierr) return ierr;
+  return red_wait(0, 1, result);
+}
+
+int hipxVecMDot(const double *x, hipx_int nv, const double *const *y, hipx_int n, double *results)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(nv >= 0, "nv < 0");
+  if (n <= 0) {
+    for (hipx_int j = 0; j < nv; j++) results[j] = 0.0;
+    return HIPX_SUCCESS;
+  }
+  // batches of <= 8 vectors, each in its own slot so a single wait at the end suffices
+  hipx_int done = 0;
+  int      slot = 1;
+  while (done < nv) {
+    hipx_int take = nv - done > 8 ? 8 : nv - done;
+    int      ierr = mdot_dispatch(x, take, y + done, n, slot);
+    if (ierr) return ierr;
+    done += take;
+    slot++;
+  }
+  HIPX_HIP(hipStreamSynchronize(rt().compute));
+  done = 0;
+  slot = 1;
+  while (done < nv) {
+    hipx_int               take = nv - done > 8 ? 8 : nv - done;
+    const volatile double *h    = slot_results_host(slot);
+    for (hipx_int v = 0; v < take; v++) results[done + v] = h[v];
+    done += take;
+    slot++;
+  }
+  return HIPX_SUCCESS;
+}
+
+int hipxVecNorm(const double *x, hipx_int n, int type, double *results)
+{
+  HIPX_CHECK_INIT();
+  results[0] = 0.0;
+  if (type == 4) results[1] = 0.0;
+  if (n <= 0) return HIPX_SUCCESS;
+  const int slot = 0;
+  if (type == 1 || type == 2) {  // NORM_2 / FROBENIUS: sqrt(x.x), bvec2.c:204
+    const double *ys[1] = {x};
+    int           ierr  = mdot_dispatch(x, 1, ys, n, slot);
+    if (ierr) return ierr;
+    double s;
+    ierr = red_wait(slot, 1, &s);
+    if (ierr) return ierr;
+    results[0] = sqrt(s);
+  } else if (type == 0 || type == 4) {
+    norm12_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, aligned16(x) && n >= 2, slot_partials(slot), rt().d_tickets + slot, slot_results_dev(slot));
+    HIPX_LAUNCH_CHECK();
+    double s[2];
+    int    ierr = red_wait(slot, 2, s);
+    if (ierr) return ierr;
+    results[0] = s[0];
+    if (type == 4) results[1] = sqrt(s[1]);
+  } else if (type == 3) {
+    norminf_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, slot_partials(slot), rt().d_tickets + slot, slot_results_dev(slot));
+    HIPX_LAUNCH_CHECK();
+    return red_wait(slot, 1, results);
+  } else return fail(HIPX_ERR_ARG, "unknown NormType", __FILE__, __LINE__);
+  return HIPX_SUCCESS;
+}
+
+int hipxVecDotNorm2(const double *x, const double *y, hipx_int n, double *dp, double *nm)
+{
+  HIPX_CHECK_INIT();
+  *dp = *nm = 0.0;
+  if (n <= 0) return HIPX_SUCCESS;
+  dotnorm2_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, y, n, slot_partials(0), rt().d_tickets, slot_results_dev(0));
+  HIPX_LAUNCH_CHECK();
+  double s[2];
+  int    ierr = red_wait(0, 2, s);
+  if (ierr) return ierr;
+  *dp = s[0];
+  *nm = s[1];
+  return HIPX_SUCCESS;
+}
+
+int hipxVecSum(const double *x, hipx_int n, double *result)
+{
+  HIPX_CHECK_INIT();
+  *result = 0.0;
+  if (n <= 0) return HIPX_SUCCESS;
+  sum_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, slot_partials(0), rt().d_tickets, slot_results_dev(0));
+  HIPX_LAUNCH_CHECK();
+  return red_wait(0, 1, result);
+}
+
+static int minmax(const double *x, hipx_int n, int want_max, hipx_int *idx, double *result)
+{
+  HIPX_CHECK_INIT();
+  if (n <= 0) {  // dvec2.c:592-640: empty vector -> idx -1, +-PETSC_MAX_REAL-like sentinel
+    if (idx) *idx = -1;
+    *result = want_max ? -1.7976931348623157e308 : 1.7976931348623157e308;
+    return HIPX_SUCCESS;
+  }
+  const unsigned g  = red_grid(n);
+  double        *pv = slot_partials(0);
+  hipx_int      *pi = reinterpret_cast<hipx_int *>(slot_partials(1));
+  minmax_stage1<<<g, kRedThreads, 0, rt().compute>>>(x, n, want_max, pv, pi);
+  HIPX_LAUNCH_CHECK();
+  static double   hv[kRedBlocks];
+  static hipx_int hi[kRedBlocks];
+  HIPX_HIP(hipMemcpyAsync(hv, pv, g * sizeof(double), hipMemcpyDeviceToHost, rt().compute));
+  HIPX_HIP(hipMemcpyAsync(hi, pi, g * sizeof(hipx_int), hipMemcpyDeviceToHost, rt().compute));
+  HIPX_HIP(hipStreamSynchronize(rt().compute));
+  double   best = hv[0];
+  hipx_int bi   = hi[0];
+  for (unsigned b = 1; b < g; b++) {
+    if (hi[b] < 0) continue;
+    if ((want_max ? hv[b] > best : hv[b] < best) || (hv[b] == best && hi[b] < bi)) {
+      best = hv[b];
+      bi   = hi[b];
+    }
+  }
+  *result = best;
+  if (idx) *idx = bi;
+  return HIPX_SUCCESS;
+}
+int hipxVecMax(const double *x, hipx_int n, hipx_int *idx, double *result) { return minmax(x, n, 1, idx, result); }
+int hipxVecMin(const double *x, hipx_int n, hipx_int *idx, double *result) { return minmax(x, n, 0, idx, result); }
+
+int hipxCGFusedUpdate(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n, double *sums2)
+{
+  HIPX_CHECK_INIT();
+  sums2[0] = sums2[1] = 0.0;
+  if (n <= 0) return HIPX_SUCCESS;
+  bool vec = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(p) && aligned16(w) && aligned16(d) && n >= 2;
+  cg_fused_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, a, n, vec, slot_partials(0), rt().d_tickets, slot_results_dev(0));
+  HIPX_LAUNCH_CHECK();
+  return red_wait(0, 2, sums2);
+}
+
+}  // extern "C"

@@ -1,0 +1,523 @@
+/*
+ * hipx_ksp.c -- C host layer over libhipx.so: the reference's Krylov callers restated over device
+ * vectors (see include/hipx_ksp.h for the file:line map).  Plain C11, built with gcc.
+ * No CPU fallback: every numerical step is a libhipx kernel; a missing GPU fails in hipxInit().
+ */
+#include "hipx_ksp.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define CHK(call) \
+  do { \
+    int ierr_ = (call); \
+    if (ierr_) return ierr_; \
+  } while (0)
+
+/* KSPConvergedReason values (include/petscksp.h) */
+enum {
+  KSP_CONVERGED_ITERATING        = 0,
+  KSP_CONVERGED_RTOL             = 2,
+  KSP_CONVERGED_ATOL             = 3,
+  KSP_CONVERGED_HAPPY_BREAKDOWN  = 8,
+  KSP_DIVERGED_ITS               = -3,
+  KSP_DIVERGED_DTOL              = -4,
+  KSP_DIVERGED_BREAKDOWN         = -5,
+  KSP_DIVERGED_INDEFINITE_PC     = -8,
+  KSP_DIVERGED_NANORINF          = -9,
+  KSP_DIVERGED_INDEFINITE_MAT    = -10,
+  KSP_DIVERGED_PC_FAILED         = -11
+};
+
+void HipxKSPSetDefaults(HipxKSP *ksp)
+{
+  memset(ksp, 0, sizeof(*ksp));
+  ksp->normtype         = HIPX_KSP_NORM_PRECONDITIONED;
+  ksp->rtol             = 1e-5;
+  ksp->abstol           = 1e-50;
+  ksp->divtol           = 1e4;
+  ksp->max_it           = 10000;
+  ksp->gmres_restart    = 30;
+  ksp->gmres_haptol     = 1e-30;
+  ksp->gmres_cgs_refine = 0;
+}
+
+void HipxPCSetDefaults(HipxPC *pc)
+{
+  memset(pc, 0, sizeof(*pc));
+  pc->type      = HIPX_PC_JACOBI;
+  pc->sor_flag  = 12; /* SOR_LOCAL_SYMMETRIC_SWEEP */
+  pc->sor_omega = 1.0;
+  pc->sor_shift = 0.0;
+  pc->sor_its   = 1;
+  pc->sor_lits  = 1;
+}
+
+/* MatMult_SeqAIJ (aij.c:1444) | MatMult_MPIAIJ (mpiaij.c:1047-1061) */
+int HipxMatMult(HipxMat *A, const double *x, double *y)
+{
+  if (A->B) return hipxMatMultMPI(A->A, A->B, A->halo, x, A->lvec, y);
+  return hipxMatMult(A->A, x, y);
+}
+
+/* VecTDot_Seq (bvec1.c:40) | VecTDot_MPI (pvec2.c, pvecimpl.h:105-111): local dot + SUM all-reduce */
+int HipxVecDot(HipxMat *A, const double *x, const double *y, hipx_int n, double *r)
+{
+  CHK(hipxVecDot(x, y, n, r));
+  if (A->nranks > 1) CHK(hipxCommAllreduceSum(r, 1));
+  return 0;
+}
+
+/* VecNorm_Seq NORM_2 = sqrt(ddot(x,x)) (bvec2.c:204) | VecNorm_MPI_Default (pvecimpl.h:150-175):
+   local norm squared, SUM all-reduce, sqrt */
+int HipxVecNorm2(HipxMat *A, const double *x, hipx_int n, double *r)
+{
+  double s;
+  CHK(hipxVecDot(x, x, n, &s));
+  if (A->nranks > 1) {
+    /* the reference squares the already-rooted local norm (pvecimpl.h:163); sqrt(s)^2 may differ from s
+       in the last bit, keep the reference's sequence */
+    double w = sqrt(s);
+    w        = w * w;
+    CHK(hipxCommAllreduceSum(&w, 1));
+    *r = sqrt(w);
+  } else *r = sqrt(s);
+  return 0;
+}
+
+int HipxPCSetUp(HipxPC *pc, HipxMat *A)
+{
+  if (pc->type == HIPX_PC_JACOBI) {
+    if (!pc->dinv) CHK(hipxMalloc((void **)&pc->dinv, sizeof(double) * (size_t)(A->m ? A->m : 1)));
+    CHK(hipxPCJacobiSetUp(A->A, pc->dinv)); /* MatGetDiagonal_MPIAIJ = diagonal of the diag block (mpiaij.c:1158-1167) */
+  }
+  return 0;
+}
+
+int HipxPCDestroy(HipxPC *pc)
+{
+  if (pc->dinv) CHK(hipxFree(pc->dinv));
+  pc->dinv = NULL;
+  return 0;
+}
+
+/* PCApply_None (VecCopy) | PCApply_Jacobi (jacobi.c:354-362: VecPointwiseMult(y, x, diag)) |
+   PCApply_SOR (sor.c:27-36) -> MatSOR_SeqAIJ, or MatSOR_MPIAIJ (mpiaij.c:1394-1412): with zero initial guess and
+   its == 1 one local sweep on the diagonal block: sor(A, bb, omega, flag, fshift, lits, 1, xx). */
+int HipxPCApply(HipxPC *pc, HipxMat *A, const double *x, double *y)
+{
+  switch (pc->type) {
+  case HIPX_PC_NONE:
+    return hipxVecCopy(x, y, A->m);
+  case HIPX_PC_JACOBI:
+    return hipxVecPointwiseMult(y, x, pc->dinv, A->m);
+  case HIPX_PC_SOR: {
+    int flag = pc->sor_flag | 16; /* SOR_ZERO_INITIAL_GUESS */
+    if (A->B) {
+      if (pc->sor_its != 1) return HIPX_ERR_SUP; /* multi-sweep parallel SOR needs the ghost update; not on the hot path */
+      return hipxMatSOR(A->A, x, pc->sor_omega, flag, pc->sor_shift, pc->sor_lits, 1, y);
+    }
+    return hipxMatSOR(A->A, x, pc->sor_omega, flag, pc->sor_shift, pc->sor_its, pc->sor_lits, y);
+  }
+  }
+  return HIPX_ERR_ARG;
+}
+
+static void log_history(HipxKSP *ksp, double rnorm)
+{
+  if (ksp->history && ksp->hist_n < ksp->hist_len) ksp->history[ksp->hist_n] = rnorm;
+  ksp->hist_n++;
+}
+
+/* iterativ.c:1490-1585 with the default context (initialrtol = mininitialrtol = convmaxits = FALSE) */
+static int converged_default(HipxKSP *ksp, HipxMat *A, HipxPC *pc, hipx_int n, double rnorm, const double *b, int *reason)
+{
+  *reason = KSP_CONVERGED_ITERATING;
+  if (ksp->normtype == HIPX_KSP_NORM_NONE) return 0;
+  if (!n) {
+    if (ksp->guess_nonzero) {
+      double snorm = 0.0;
+      if (ksp->normtype == HIPX_KSP_NORM_UNPRECONDITIONED) CHK(HipxVecNorm2(A, b, A->m, &snorm));
+      else {
+        double *z;
+        CHK(hipxMalloc((void **)&z, sizeof(double) * (size_t)(A->m ? A->m : 1)));
+        CHK(HipxPCApply(pc, A, b, z));
+        if (ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED) CHK(HipxVecNorm2(A, z, A->m, &snorm));
+        else {
+          double d;
+          CHK(HipxVecDot(A, b, z, A->m, &d));
+          snorm = sqrt(fabs(d));
+        }
+        CHK(hipxFree(z));
+      }
+      if (!snorm) snorm = rnorm;
+      ksp->rnorm0 = snorm;
+    } else ksp->rnorm0 = rnorm;
+    ksp->ttol = fmax(ksp->rtol * ksp->rnorm0, ksp->abstol);
+  }
+  if (n <= 0) return 0; /* chknorm == 0 */
+  if (isnan(rnorm) || isinf(rnorm)) {
+    *reason = KSP_DIVERGED_NANORINF;
+    return 0;
+  }
+  if (n < ksp->min_it) return 0;
+  if (rnorm <= ksp->ttol) *reason = (rnorm < ksp->abstol) ? KSP_CONVERGED_ATOL : KSP_CONVERGED_RTOL;
+  else if (rnorm >= ksp->divtol * ksp->rnorm0) *reason = KSP_DIVERGED_DTOL;
+  return 0;
+}
+
+static int ensure_cg_work(HipxKSP *ksp, hipx_int n)
+{
+  if (ksp->R && ksp->work_n == n) return 0;
+  CHK(HipxKSPDestroyWork(ksp));
+  size_t bytes = sizeof(double) * (size_t)(n ? n : 1);
+  CHK(hipxMalloc((void **)&ksp->R, bytes));
+  CHK(hipxMalloc((void **)&ksp->Z, bytes));
+  CHK(hipxMalloc((void **)&ksp->P, bytes));
+  ksp->work_n = n;
+  return 0;
+}
+
+int HipxKSPDestroyWork(HipxKSP *ksp)
+{
+  if (ksp->R) CHK(hipxFree(ksp->R));
+  if (ksp->Z) CHK(hipxFree(ksp->Z));
+  if (ksp->P) CHK(hipxFree(ksp->P));
+  ksp->R = ksp->Z = ksp->P = NULL;
+  ksp->work_n = 0;
+  return 0;
+}
+
+/* cg.c:134-217: everything before the do-loop */
+int HipxKSPCGBegin(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double *X)
+{
+  const hipx_int n  = A->m;
+  double         dp = 0.0;
+  CHK(ensure_cg_work(ksp, n));
+  double *R = ksp->R, *Z = ksp->Z;
+  ksp->its    = 0;
+  ksp->reason = 0;
+  ksp->hist_n = 0;
+  ksp->i      = 0;
+  ksp->dpi    = 0.0;
+  ksp->a      = 1.0;
+  ksp->beta   = 0.0;
+  ksp->betaold = 1.0;
+  if (!ksp->guess_nonzero) CHK(hipxVecSet(X, n, 0.0)); /* itfunc.c:908 */
+  if (ksp->guess_nonzero) {
+    CHK(HipxMatMult(A, X, R));         /* cg.c:154 */
+    CHK(hipxVecAYPX(R, -1.0, B, n));   /* cg.c:156 */
+  } else CHK(hipxVecCopy(B, R, n));    /* cg.c:162 */
+
+  switch (ksp->normtype) { /* cg.c:168-190 */
+  case HIPX_KSP_NORM_PRECONDITIONED:
+    CHK(HipxPCApply(pc, A, R, Z));
+    CHK(HipxVecNorm2(A, Z, n, &dp));
+    break;
+  case HIPX_KSP_NORM_UNPRECONDITIONED:
+    CHK(HipxVecNorm2(A, R, n, &dp));
+    break;
+  case HIPX_KSP_NORM_NATURAL:
+    CHK(HipxPCApply(pc, A, R, Z));
+    CHK(HipxVecDot(A, Z, R, n, &ksp->beta));
+    dp = sqrt(fabs(ksp->beta));
+    break;
+  default:
+    dp = 0.0;
+  }
+  if (isnan(dp) || isinf(dp)) { /* KSPCheckNorm, kspimpl.h:571 */
+    ksp->reason = KSP_DIVERGED_NANORINF;
+    return 0;
+  }
+  log_history(ksp, dp);
+  ksp->rnorm = dp;
+  CHK(converged_default(ksp, A, pc, 0, dp, B, &ksp->reason)); /* cg.c:205 */
+  if (ksp->reason) return 0;
+  if (ksp->normtype != HIPX_KSP_NORM_PRECONDITIONED && ksp->normtype != HIPX_KSP_NORM_NATURAL) CHK(HipxPCApply(pc, A, R, Z)); /* cg.c:214 */
+  if (ksp->normtype != HIPX_KSP_NORM_NATURAL) {
+    CHK(HipxVecDot(A, Z, R, n, &ksp->beta)); /* cg.c:216 */
+    if (isnan(ksp->beta) || isinf(ksp->beta)) ksp->reason = KSP_DIVERGED_NANORINF;
+  }
+  return 0;
+}
+
+/* nsteps passes of the loop body cg.c:220-349 (stops early when ksp->reason is set) */
+int HipxKSPCGStep(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double *X, hipx_int nsteps)
+{
+  const hipx_int n = A->m;
+  double        *R = ksp->R, *Z = ksp->Z, *P = ksp->P, *W = ksp->Z; /* W aliases Z, cg.c:145 */
+  double         dp = 0.0, b, dpiold;
+  const int      fused = ksp->fused && pc->type == HIPX_PC_JACOBI && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED && !A->B && A->nranks <= 1;
+  for (hipx_int s = 0; s < nsteps && !ksp->reason && ksp->i < ksp->max_it; s++) {
+    const hipx_int i = ksp->i;
+    ksp->its = i + 1;
+    if (ksp->beta == 0.0) { /* cg.c:223 */
+      ksp->reason = KSP_CONVERGED_ATOL;
+      break;
+    } else if ((i > 0) && (ksp->beta * ksp->betaold < 0.0)) { /* cg.c:228 */
+      ksp->reason = KSP_DIVERGED_INDEFINITE_PC;
+      break;
+    }
+    if (!i) {
+      CHK(hipxVecCopy(Z, P, n)); /* cg.c:236 */
+      b = 0.0;
+    } else {
+      b = ksp->beta / ksp->betaold;
+      CHK(hipxVecAYPX(P, b, Z, n)); /* cg.c:249 */
+    }
+    dpiold = ksp->dpi;
+    if (fused) CHK(hipxMatMultDot(A->A, P, W, &ksp->dpi)); /* cg.c:257-258 in one pass */
+    else {
+      CHK(HipxMatMult(A, P, W));                 /* cg.c:257 */
+      CHK(HipxVecDot(A, P, W, n, &ksp->dpi));    /* cg.c:258 */
+    }
+    ksp->betaold = ksp->beta;
+    if (isnan(ksp->dpi) || isinf(ksp->dpi)) { /* KSPCheckDot */
+      ksp->reason = KSP_DIVERGED_NANORINF;
+      break;
+    }
+    if ((ksp->dpi == 0.0) || ((i > 0) && ((((ksp->dpi > 0) - (ksp->dpi < 0)) * ((dpiold > 0) - (dpiold < 0))) < 0.0))) { /* cg.c:262 */
+      ksp->reason = KSP_DIVERGED_INDEFINITE_MAT;
+      break;
+    }
+    ksp->a = ksp->beta / ksp->dpi; /* cg.c:288 */
+    if (fused) {
+      /* cg.c:305-309 + cg.c:344 in one pass: x += a p; r -= a w; z = r .* d; dp = ||z||; beta = z.r */
+      double sums[2];
+      CHK(hipxCGFusedUpdate(X, R, Z, P, W, pc->dinv, ksp->a, n, sums));
+      dp = sqrt(sums[0]);
+      if (isnan(dp) || isinf(dp)) {
+        ksp->reason = KSP_DIVERGED_NANORINF;
+        break;
+      }
+      ksp->rnorm = dp;
+      log_history(ksp, dp);
+      CHK(converged_default(ksp, A, pc, i + 1, dp, B, &ksp->reason));
+      if (ksp->reason) break;
+      ksp->beta = sums[1];
+      if (isnan(ksp->beta) || isinf(ksp->beta)) {
+        ksp->reason = KSP_DIVERGED_NANORINF;
+        break;
+      }
+      ksp->i++;
+      continue;
+    }
+    CHK(hipxVecAXPY(X, ksp->a, P, n));  /* cg.c:305 */
+    CHK(hipxVecAXPY(R, -ksp->a, W, n)); /* cg.c:306 */
+    if (ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED) {
+      CHK(HipxPCApply(pc, A, R, Z));     /* cg.c:308 */
+      CHK(HipxVecNorm2(A, Z, n, &dp));   /* cg.c:309 */
+    } else if (ksp->normtype == HIPX_KSP_NORM_UNPRECONDITIONED) {
+      CHK(HipxVecNorm2(A, R, n, &dp));
+    } else if (ksp->normtype == HIPX_KSP_NORM_NATURAL) {
+      CHK(HipxPCApply(pc, A, R, Z));
+      CHK(HipxVecDot(A, Z, R, n, &ksp->beta));
+      dp = sqrt(fabs(ksp->beta));
+    } else dp = 0.0;
+    if (isnan(dp) || isinf(dp)) {
+      ksp->reason = KSP_DIVERGED_NANORINF;
+      break;
+    }
+    ksp->rnorm = dp;
+    log_history(ksp, dp);
+    CHK(converged_default(ksp, A, pc, i + 1, dp, B, &ksp->reason)); /* cg.c:328 */
+    if (ksp->reason) break;
+    if (ksp->normtype != HIPX_KSP_NORM_PRECONDITIONED && ksp->normtype != HIPX_KSP_NORM_NATURAL) CHK(HipxPCApply(pc, A, R, Z)); /* cg.c:342 */
+    if (ksp->normtype != HIPX_KSP_NORM_NATURAL) {
+      CHK(HipxVecDot(A, Z, R, n, &ksp->beta)); /* cg.c:344 */
+      if (isnan(ksp->beta) || isinf(ksp->beta)) {
+        ksp->reason = KSP_DIVERGED_NANORINF;
+        break;
+      }
+    }
+    ksp->i++;
+  }
+  if (!ksp->reason && ksp->i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS; /* cg.c:350 */
+  return 0;
+}
+
+int HipxKSPSolve_CG(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, double *x)
+{
+  CHK(HipxKSPCGBegin(ksp, A, pc, b, x));
+  if (ksp->reason) return 0;
+  CHK(HipxKSPCGStep(ksp, A, pc, b, x, ksp->max_it));
+  return 0;
+}
+
+/* gmres.c:88-238 (cycle + solve), :298-345 (BuildSoln), :349-395 (UpdateHessenberg), borthog2.c:35-113,
+   left preconditioning, KSPInitialResidual itres.c:35-75.  VV(0..max_k) live in one contiguous slab
+   (cf. VecDuplicateVecs_Seq_GEMV bvec2.c:670) so MDot/MAXPY stream through consecutive memory. */
+int HipxKSPSolve_GMRES(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double *X)
+{
+  const hipx_int n = A->m, max_k = ksp->gmres_restart;
+  const size_t   ld = ((size_t)(n ? n : 1) + 1) & ~(size_t)1; /* keep every basis vector 16-byte aligned */
+  double        *slab = NULL, *TEMP, *TMOP;
+  double       **VV   = (double **)malloc(sizeof(double *) * (size_t)(max_k + 2));
+  double        *hh   = (double *)calloc((size_t)(max_k + 2) * (size_t)(max_k + 1), sizeof(double));
+  double        *grs  = (double *)calloc((size_t)(max_k + 2), sizeof(double));
+  double        *cc   = (double *)calloc((size_t)(max_k + 2), sizeof(double));
+  double        *ss   = (double *)calloc((size_t)(max_k + 2), sizeof(double));
+  double        *nrs  = (double *)calloc((size_t)(max_k + 2), sizeof(double));
+  double        *lhh  = (double *)calloc((size_t)(max_k + 2), sizeof(double));
+  hipx_int       itcount = 0;
+  const int      guess_nonzero = ksp->guess_nonzero;
+  int            ierr = 0;
+#define HH(a, b) (hh + (size_t)(b) * (size_t)(max_k + 2) + (a))
+#define GCHK(call) \
+  do { \
+    ierr = (call); \
+    if (ierr) goto cleanup; \
+  } while (0)
+  GCHK(hipxMalloc((void **)&slab, sizeof(double) * ld * (size_t)(max_k + 4)));
+  TEMP = slab;
+  TMOP = slab + ld;
+  for (hipx_int k = 0; k < max_k + 2; k++) VV[k] = slab + ld * (size_t)(k + 2);
+  ksp->its    = 0;
+  ksp->reason = 0;
+  ksp->hist_n = 0;
+  ksp->rnorm  = -1.0;
+  if (!ksp->guess_nonzero) GCHK(hipxVecSet(X, n, 0.0));
+
+  while (!ksp->reason) {
+    double   res = 0.0, tt, hapbnd;
+    hipx_int it     = 0;
+    int      hapend = 0;
+    if (ksp->guess_nonzero) { /* KSPInitialResidual, PC_LEFT */
+      GCHK(HipxMatMult(A, X, TEMP));
+      GCHK(hipxVecCopy(B, TMOP, n));
+      GCHK(hipxVecAXPY(TMOP, -1.0, TEMP, n));
+      GCHK(HipxPCApply(pc, A, TMOP, VV[0]));
+    } else {
+      GCHK(hipxVecCopy(B, TMOP, n));
+      GCHK(HipxPCApply(pc, A, B, VV[0]));
+    }
+    GCHK(HipxVecNorm2(A, VV[0], n, &res)); /* VecNormalize gmres.c:98 */
+    if (isnan(res) || isinf(res)) {
+      ksp->reason = KSP_DIVERGED_NANORINF;
+      break;
+    }
+    if (res != 0.0) GCHK(hipxVecScale(VV[0], n, 1.0 / res));
+    grs[0]     = res;
+    ksp->rnorm = res;
+    log_history(ksp, res);
+    if (!res) {
+      ksp->reason = KSP_CONVERGED_ATOL;
+      break;
+    }
+    GCHK(converged_default(ksp, A, pc, ksp->its, res, B, &ksp->reason));
+    while (!ksp->reason && it < max_k && ksp->its < ksp->max_it) {
+      if (it) log_history(ksp, res);
+      GCHK(HipxMatMult(A, VV[it], TMOP)); /* KSP_PCApplyBAorAB, left */
+      GCHK(HipxPCApply(pc, A, TMOP, VV[it + 1]));
+      { /* borthog2.c:35-113 */
+        double *h      = HH(0, it);
+        int     refine = (ksp->gmres_cgs_refine == 2);
+        for (hipx_int j = 0; j <= it; j++) h[j] = 0.0;
+        GCHK(hipxVecMDot(VV[it + 1], it + 1, (const double *const *)VV, n, lhh));
+        if (A->nranks > 1) GCHK(hipxCommAllreduceSum(lhh, it + 1));
+        for (hipx_int j = 0; j <= it; j++) {
+          if (isnan(lhh[j]) || isinf(lhh[j])) ksp->reason = KSP_DIVERGED_NANORINF;
+          lhh[j] = -lhh[j];
+        }
+        if (ksp->reason) break;
+        GCHK(hipxVecMAXPY(VV[it + 1], it + 1, lhh, (const double *const *)VV, n));
+        for (hipx_int j = 0; j <= it; j++) h[j] -= lhh[j];
+        if (ksp->gmres_cgs_refine == 1) {
+          double hnrm = 0.0, wnrm;
+          for (hipx_int j = 0; j <= it; j++) hnrm += lhh[j] * lhh[j];
+          hnrm = sqrt(hnrm);
+          GCHK(HipxVecNorm2(A, VV[it + 1], n, &wnrm));
+          if (wnrm < hnrm) refine = 1;
+        }
+        if (refine) {
+          GCHK(hipxVecMDot(VV[it + 1], it + 1, (const double *const *)VV, n, lhh));
+          if (A->nranks > 1) GCHK(hipxCommAllreduceSum(lhh, it + 1));
+          for (hipx_int j = 0; j <= it; j++) lhh[j] = -lhh[j];
+          GCHK(hipxVecMAXPY(VV[it + 1], it + 1, lhh, (const double *const *)VV, n));
+          for (hipx_int j = 0; j <= it; j++) h[j] -= lhh[j];
+        }
+      }
+      GCHK(HipxVecNorm2(A, VV[it + 1], n, &tt)); /* VecNormalize gmres.c:143 */
+      if (isnan(tt) || isinf(tt)) {
+        ksp->reason = KSP_DIVERGED_NANORINF;
+        break;
+      }
+      if (tt != 0.0) GCHK(hipxVecScale(VV[it + 1], n, 1.0 / tt));
+      *HH(it + 1, it) = tt;
+      hapbnd          = fabs(tt / grs[it]);
+      if (hapbnd > ksp->gmres_haptol) hapbnd = ksp->gmres_haptol;
+      if (tt < hapbnd) hapend = 1;
+      { /* KSPGMRESUpdateHessenberg gmres.c:349-395 */
+        double *h = HH(0, it), *cp = cc, *sp = ss, t;
+        for (hipx_int j = 1; j <= it; j++) {
+          t  = *h;
+          *h = *cp * t + *sp * *(h + 1);
+          h++;
+          *h = *cp++ * *h - (*sp++ * t);
+        }
+        if (!hapend) {
+          t = sqrt(*h * *h + *(h + 1) * *(h + 1));
+          if (t == 0.0) {
+            ksp->reason = KSP_DIVERGED_BREAKDOWN;
+            break;
+          }
+          *cp         = *h / t;
+          *sp         = *(h + 1) / t;
+          grs[it + 1] = -(*sp * grs[it]);
+          grs[it]     = *cp * grs[it];
+          *h          = *cp * *h + *sp * *(h + 1);
+          res         = fabs(grs[it + 1]);
+        } else res = 0.0;
+      }
+      it++;
+      ksp->its++;
+      ksp->rnorm = res;
+      GCHK(converged_default(ksp, A, pc, ksp->its, res, B, &ksp->reason));
+      if (hapend) {
+        if (ksp->normtype == HIPX_KSP_NORM_NONE) ksp->reason = KSP_CONVERGED_HAPPY_BREAKDOWN;
+        else if (!ksp->reason) {
+          ksp->reason = KSP_DIVERGED_BREAKDOWN;
+          break;
+        }
+      }
+    }
+    if (it - 1 >= 0) { /* KSPGMRESBuildSoln gmres.c:298-345 */
+      hipx_int itl = it - 1;
+      if (*HH(itl, itl) != 0.0) {
+        nrs[itl] = grs[itl] / *HH(itl, itl);
+        for (hipx_int ii = 1; ii <= itl; ii++) {
+          hipx_int k = itl - ii;
+          double   t = grs[k];
+          for (hipx_int j = k + 1; j <= itl; j++) t = t - *HH(k, j) * nrs[j];
+          nrs[k] = t / *HH(k, k);
+        }
+        GCHK(hipxVecMAXPBY(TEMP, itl + 1, nrs, 0.0, (const double *const *)VV, n)); /* gmres.c:337 */
+        GCHK(hipxVecAXPY(X, 1.0, TEMP, n));                                         /* gmres.c:342 */
+      } else ksp->reason = KSP_DIVERGED_BREAKDOWN;
+    }
+    if (ksp->reason == 0 && ksp->its >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS;
+    if (it && ksp->reason) log_history(ksp, res);
+    itcount += it;
+    if (itcount >= ksp->max_it) {
+      if (!ksp->reason) ksp->reason = KSP_DIVERGED_ITS;
+      break;
+    }
+    ksp->guess_nonzero = 1; /* gmres.c:233 */
+  }
+cleanup:
+  ksp->guess_nonzero = guess_nonzero;
+  if (slab) {
+    int e2 = hipxFree(slab);
+    if (!ierr) ierr = e2;
+  }
+  free(VV);
+  free(hh);
+  free(grs);
+  free(cc);
+  free(ss);
+  free(nrs);
+  free(lhh);
+#undef HH
+#undef GCHK
+  return ierr;
+}

@@ -1,0 +1,114 @@
+"""GPU parity of the whole inner loop: KSPCG / KSPGMRES + PCJACOBI / PCNONE driven through the C host layer over the
+HIP kernels, against the oracle's restatement of cg.c / gmres.c on the same inputs.
+Bar (north_star): identical iteration counts and convergence reasons; fp64 residual histories within 1e-12 relative
+(reductions are the only non-bit-exact step; long CG runs amplify their rounding, so long histories are held to 1e-9)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def solve_gpu(kind, ai, aj, aa, b, pc="jacobi", rtol=1e-5, max_it=10000, normtype=1, restart=30, refine=0, fused=0, x0=None):
+    from petsc_amd import _lib
+    hx, ks = _lib.load()
+    N = len(ai) - 1
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    M = _lib.HipxMat(m=N, A=A, B=None, halo=None, lvec=None, nranks=1)
+    p = _lib.HipxPC()
+    ks.HipxPCSetDefaults(C.byref(p))
+    p.type = {"none": 0, "jacobi": 1, "sor": 2}[pc]
+    k = _lib.HipxKSP()
+    ks.HipxKSPSetDefaults(C.byref(k))
+    k.rtol, k.max_it, k.normtype, k.gmres_restart, k.gmres_cgs_refine, k.fused = rtol, max_it, normtype, restart, refine, fused
+    hist = np.zeros(max_it + 100)
+    k.history, k.hist_len = hist.ctypes.data, len(hist)
+    B = _lib.DVec(N, b)
+    X = _lib.DVec(N, x0 if x0 is not None else np.zeros(N))
+    k.guess_nonzero = 0 if x0 is None else 1
+    _lib.chk(ks.HipxPCSetUp(C.byref(p), C.byref(M)))
+    f = ks.HipxKSPSolve_CG if kind == "cg" else ks.HipxKSPSolve_GMRES
+    _lib.chk(f(C.byref(k), C.byref(M), C.byref(p), B.ptr, X.ptr))
+    x = X.get()
+    out = (x, int(k.its), int(k.reason), hist[:k.hist_n].copy())
+    ks.HipxKSPDestroyWork(C.byref(k))
+    ks.HipxPCDestroy(C.byref(p))
+    B.free()
+    X.free()
+    _lib.mat_destroy(A)
+    return out
+
+
+def compare(g, o, tol):
+    xg, ig, rg, hg = g
+    xo, io, ro, ho = o
+    assert (ig, rg) == (io, ro)
+    assert len(hg) == len(ho)
+    rel = np.abs(hg - ho) / np.abs(ho)
+    assert rel.max() <= tol, rel.max()
+    return rel.max()
+
+
+def test_config1_ex2_100x100_cg_jacobi(hx):
+    """BASELINE config 1: ex2 -m 100 -n 100 -ksp_type cg -pc_type jacobi (reference: 160 iterations, error 5.70785e-05)."""
+    m = n = 100
+    ai, aj, aa = orc.stencil("5pt", n, m=m)
+    u = np.ones(m * n)
+    b = orc.matmult(ai, aj, aa, u)
+    rtol = 1e-2 / ((m + 1) * (n + 1))
+    g = solve_gpu("cg", ai, aj, aa, b, rtol=rtol)
+    o = orc.ksp_solve("cg", ai, aj, aa, b, rtol=rtol)
+    compare(g, o, 1e-9)
+    assert g[1] == 160 and "%g" % np.linalg.norm(g[0] - u) == "5.70785e-05"  # survey run of the reference, SURVEY.md section 6
+    rel = np.abs(g[3][:40] - o[3][:40]) / o[3][:40]
+    assert rel.max() <= 1e-12
+
+
+@pytest.mark.parametrize("kind,n", [("7pt", 20), ("27pt", 16)])
+@pytest.mark.parametrize("pc", ["jacobi", "none"])
+@pytest.mark.parametrize("normtype", [1, 2, 3])
+def test_cg_histories(hx, kind, n, pc, normtype):
+    ai, aj, aa = orc.stencil(kind, n)
+    b = orc.matmult(ai, aj, aa, np.ones(len(ai) - 1))
+    g = solve_gpu("cg", ai, aj, aa, b, pc=pc, rtol=1e-8, normtype=normtype)
+    o = orc.ksp_solve("cg", ai, aj, aa, b, pc=pc, rtol=1e-8, normtype=normtype)
+    compare(g, o, 1e-11)
+    assert np.abs(g[0] - o[0]).max() <= 1e-11
+
+
+def test_cg_fused_path_same_history(hx):
+    ai, aj, aa = orc.stencil("7pt", 24)
+    b = orc.matmult(ai, aj, aa, np.ones(len(ai) - 1))
+    g0 = solve_gpu("cg", ai, aj, aa, b, rtol=1e-8, fused=0)
+    g1 = solve_gpu("cg", ai, aj, aa, b, rtol=1e-8, fused=1)
+    o = orc.ksp_solve("cg", ai, aj, aa, b, rtol=1e-8)
+    compare(g0, o, 1e-11)
+    compare(g1, o, 1e-11)
+
+
+def test_cg_nonzero_guess_and_max_it(hx):
+    ai, aj, aa = orc.stencil("7pt", 12)
+    N = len(ai) - 1
+    b = orc.matmult(ai, aj, aa, np.ones(N))
+    x0 = np.linspace(0, 1, N)
+    g = solve_gpu("cg", ai, aj, aa, b, rtol=1e-9, x0=x0)
+    o = orc.ksp_solve("cg", ai, aj, aa, b, rtol=1e-9, x0=x0)
+    compare(g, o, 1e-11)
+    g = solve_gpu("cg", ai, aj, aa, b, rtol=1e-30, max_it=7)
+    o = orc.ksp_solve("cg", ai, aj, aa, b, rtol=1e-30, max_it=7)
+    compare(g, o, 1e-12)
+    assert g[2] == -3  # KSP_DIVERGED_ITS
+
+
+@pytest.mark.parametrize("refine", [0, 1, 2])
+@pytest.mark.parametrize("restart", [30, 5])
+def test_gmres_jacobi_histories(hx, refine, restart):
+    ai, aj, aa = orc.stencil("27pt", 12)
+    b = orc.matmult(ai, aj, aa, np.ones(len(ai) - 1))
+    g = solve_gpu("gmres", ai, aj, aa, b, rtol=1e-8, restart=restart, refine=refine)
+    o = orc.ksp_solve("gmres", ai, aj, aa, b, rtol=1e-8, restart=restart, refine=refine)
+    compare(g, o, 1e-10)
+    assert np.abs(g[0] - o[0]).max() <= 1e-10

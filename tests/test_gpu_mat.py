@@ -1,0 +1,217 @@
+"""GPU parity of the CSR kernels against the oracle's MatMult_SeqAIJ / MatMultAdd_SeqAIJ / MatGetDiagonal restatements.
+Bar: bit-exact y for every row that fits the LDS tile (left-to-right row sums, no FMA); rows longer than the tile use a
+tree sum and must agree to 1e-14 relative."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def xvec(n):
+    return 1.0 + (np.arange(n) % 17) / 17.0
+
+
+def spmv_gpu(hx, ai, aj, aa, x, ncols=None, variant=0, y0=None):
+    from petsc_amd import _lib
+    m = len(ai) - 1
+    n = ncols if ncols is not None else m
+    A = _lib.mat_create_csr(m, n, ai, aj, aa)
+    _lib.chk(hx.hipxMatSetSpMVVariant(A, variant))
+    X, Y = _lib.DVec(n, x), _lib.DVec(m)
+    if y0 is None:
+        _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    else:
+        Y0 = _lib.DVec(m, y0)
+        _lib.chk(hx.hipxMatMultAdd(A, X.ptr, Y0.ptr, Y.ptr))
+        Y0.free()
+    y = Y.get()
+    X.free()
+    Y.free()
+    _lib.mat_destroy(A)
+    return y
+
+
+@pytest.mark.parametrize("kind,n,m", [("5pt", 100, 100), ("5pt", 7, 8), ("7pt", 1, None), ("7pt", 2, None), ("7pt", 33, None), ("7pt", 64, None),
+                                       ("27pt", 3, None), ("27pt", 17, None), ("27pt", 40, None)])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_stencil_spmv_bit_exact(hx, kind, n, m, variant):
+    ai, aj, aa = orc.stencil(kind, n, m=m)
+    N = len(ai) - 1
+    x = xvec(N)
+    y = spmv_gpu(hx, ai, aj, aa, x, variant=variant)
+    assert np.array_equal(y, orc.matmult(ai, aj, aa, x))
+
+
+def random_csr(m, n, rng, maxlen, empty_frac=0.2):
+    lens = rng.integers(0, maxlen + 1, size=m)
+    lens[rng.random(m) < empty_frac] = 0
+    ai = np.zeros(m + 1, np.int32)
+    ai[1:] = np.cumsum(lens)
+    aj = np.zeros(ai[-1], np.int32)
+    for r in range(m):
+        k = lens[r]
+        if k:
+            aj[ai[r]:ai[r + 1]] = np.sort(rng.choice(n, size=min(k, n), replace=False))[:k]
+    aa = rng.standard_normal(ai[-1])
+    return ai, aj, aa
+
+
+@pytest.mark.parametrize("seed,m,n,maxlen", [(0, 1, 1, 1), (1, 17, 29, 5), (2, 1000, 777, 40), (3, 5000, 5000, 8), (4, 300, 4000, 300), (5, 257, 100, 0)])
+def test_ragged_rows_bit_exact_and_multadd(hx, seed, m, n, maxlen):
+    rng = np.random.default_rng(seed)
+    ai, aj, aa = random_csr(m, n, rng, maxlen)
+    x = rng.standard_normal(n)
+    y = spmv_gpu(hx, ai, aj, aa, x, ncols=n)
+    assert np.array_equal(y, orc.matmult(ai, aj, aa, x))
+    y0 = rng.standard_normal(m)
+    z = spmv_gpu(hx, ai, aj, aa, x, ncols=n, y0=y0)
+    zr = np.zeros(m)
+    orc.lib().orc_MatMultAdd_SeqAIJ(m, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(y0), orc.P(zr))
+    assert np.array_equal(z, zr)
+
+
+def test_long_rows_beyond_lds_tile(hx):
+    """Rows with more nonzeros than the 2048-entry LDS tile take the block-wide path (tree sum): 1e-14 relative."""
+    rng = np.random.default_rng(11)
+    m, n = 40, 20000
+    lens = np.array([3, 5000, 0, 2047, 2049, 7, 12000] + [4] * 33)
+    ai = np.zeros(m + 1, np.int32)
+    ai[1:] = np.cumsum(lens)
+    aj = np.concatenate([np.sort(rng.choice(n, size=k, replace=False)) for k in lens]).astype(np.int32)
+    aa = rng.standard_normal(ai[-1])
+    x = rng.standard_normal(n)
+    y = spmv_gpu(hx, ai, aj, aa, x, ncols=n)
+    yr = orc.matmult(ai, aj, aa, x)
+    short = lens <= 2040
+    assert np.array_equal(y[short], yr[short])
+    mag = np.array([np.abs(aa[ai[r]:ai[r + 1]] * x[aj[ai[r]:ai[r + 1]]]).sum() for r in range(m)])
+    assert np.all(np.abs(y - yr) <= 1e-14 * (mag + 1e-300))
+
+
+def test_empty_matrix_and_empty_rows(hx):
+    ai = np.zeros(1, np.int32)
+    y = spmv_gpu(hx, ai, np.zeros(0, np.int32), np.zeros(0), np.zeros(0))
+    assert y.size == 0
+    ai = np.zeros(11, np.int32)
+    y = spmv_gpu(hx, ai, np.zeros(0, np.int32), np.zeros(0), np.ones(10))
+    assert np.array_equal(y, np.zeros(10))
+
+
+def test_int64_row_offsets(hx):
+    ai, aj, aa = orc.stencil("27pt", 12)
+    x = xvec(len(ai) - 1)
+    y = spmv_gpu(hx, ai.astype(np.int64), aj, aa, x)
+    assert np.array_equal(y, orc.matmult(ai, aj, aa, x))
+
+
+def test_get_diagonal_and_jacobi_setup(hx):
+    from petsc_amd import _lib
+    rng = np.random.default_rng(5)
+    ai, aj, aa = orc.stencil("7pt", 10)
+    aa = aa.copy()
+    N = len(ai) - 1
+    # knock out one diagonal value (zero pivot) -> PCJACOBI puts 1 there (jacobi.c:255-266)
+    d0 = [k for k in range(ai[7], ai[8]) if aj[k] == 7][0]
+    aa[d0] = 0.0
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    D = _lib.DVec(N)
+    _lib.chk(hx.hipxMatGetDiagonal(A, D.ptr))
+    dref = np.zeros(N)
+    orc.lib().orc_MatGetDiagonal_SeqAIJ(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(dref))
+    assert np.array_equal(D.get(), dref)
+    _lib.chk(hx.hipxPCJacobiSetUp(A, D.ptr))
+    jref = np.zeros(N)
+    orc.lib().orc_PCSetUp_Jacobi(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(jref))
+    assert np.array_equal(D.get(), jref) and jref[7] == 1.0
+    # missing diagonal entry -> 0 (aij.c:1347-1380)
+    ai2, aj2, aa2 = random_csr(50, 50, rng, 4)
+    A2 = _lib.mat_create_csr(50, 50, ai2, aj2, aa2)
+    D2 = _lib.DVec(50)
+    _lib.chk(hx.hipxMatGetDiagonal(A2, D2.ptr))
+    d2 = np.zeros(50)
+    orc.lib().orc_MatGetDiagonal_SeqAIJ(50, orc.P(ai2), orc.P(aj2), orc.P(aa2), orc.P(d2))
+    assert np.array_equal(D2.get(), d2)
+    for v in (D, D2):
+        v.free()
+    _lib.mat_destroy(A)
+    _lib.mat_destroy(A2)
+
+
+def test_compressed_row_offdiag_block(hx):
+    """MPIAIJ off-diagonal block: compressed rows, MatMult zeroes y, MatMultAdd in place (mpiaij.c:1059)."""
+    from petsc_amd import _lib
+    n, nr = 8, 3
+    N = n ** 3
+    ranges = np.zeros(nr + 1, np.int32)
+    orc.lib().orc_PetscSplitOwnership(N, nr, orc.P(ranges))
+    rs, re = int(ranges[1]), int(ranges[2])
+    ai, aj, aa = orc.stencil("27pt", n, rs, re)
+    m, nz = re - rs, len(aj)
+    Ai, Aj, Bi, Bj, ga = (np.zeros(k, np.int32) for k in (m + 1, nz + 1, m + 1, nz + 1, nz + 1))
+    Aa, Ba = np.zeros(nz + 1), np.zeros(nz + 1)
+    ec = orc.lib().orc_MatSetUpMultiply_MPIAIJ(m, rs, re, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(Ai), orc.P(Aj), orc.P(Aa), orc.P(Bi), orc.P(Bj), orc.P(Ba), orc.P(ga))
+    ci, ridx = np.zeros(m + 1, np.int32), np.zeros(m + 1, np.int32)
+    nrc = orc.lib().orc_MatCheckCompressedRow(m, orc.P(Bi), orc.P(ci), orc.P(ridx))
+    B = _lib.mat_create_cprow(m, ec, nrc, ci[:nrc + 1], ridx[:nrc], Bj[:Bi[m]], Ba[:Bi[m]])
+    lv = xvec(ec)
+    LV, Y = _lib.DVec(ec, lv), _lib.DVec(m, np.full(m, 7.0))
+    _lib.chk(hx.hipxMatMult(B, LV.ptr, Y.ptr))
+    yr = np.zeros(m)
+    orc.lib().orc_MatMult_SeqAIJ_cprow(m, nrc, orc.P(ci), orc.P(ridx), orc.P(Bj), orc.P(Ba), orc.P(lv), orc.P(yr))
+    assert np.array_equal(Y.get(), yr)
+    y0 = np.random.default_rng(3).standard_normal(m)
+    Y.set(y0)
+    _lib.chk(hx.hipxMatMultAdd(B, LV.ptr, Y.ptr, Y.ptr))
+    zr = np.zeros(m)
+    orc.lib().orc_MatMultAdd_SeqAIJ(m, orc.P(Bi), orc.P(Bj), orc.P(Ba), orc.P(lv), orc.P(y0), orc.P(zr))
+    assert np.array_equal(Y.get(), zr)
+    LV.free()
+    Y.free()
+    _lib.mat_destroy(B)
+
+
+def test_full_size_7pt_256_properties(hx):
+    """BASELINE config 2 size (N = 16.7 M, nnz = 117 M): A*1 is known in closed form (6 - #neighbours), A is symmetric
+    (x.Ay == y.Ax to rounding), and a strided sample of rows is compared with the oracle bit for bit."""
+    from petsc_amd import _lib
+    _, ks = _lib.load()
+    n = 256
+    N = n ** 3
+    nz = ks.HipxAssemble_poisson7(n, 0, N, None, None, None)
+    assert nz == 7 * N - 6 * n * n
+    ai, aj, aa = np.zeros(N + 1, np.int32), np.zeros(nz, np.int32), np.zeros(nz)
+    ks.HipxAssemble_poisson7(n, 0, N, ai.ctypes.data_as(C.c_void_p), aj.ctypes.data_as(C.c_void_p), aa.ctypes.data_as(C.c_void_p))
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    ones = np.ones(N)
+    X, Y = _lib.DVec(N, ones), _lib.DVec(N)
+    _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    y = Y.get()
+    assert np.array_equal(y, 6.0 - (np.diff(ai) - 1))
+    x = xvec(N)
+    X.set(x)
+    _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    y = Y.get()
+    rows = np.arange(0, N, 4099)
+    for r in rows[:2000]:
+        s = 0.0
+        for k in range(ai[r], ai[r + 1]):
+            s += aa[k] * x[aj[k]]
+        assert y[r] == s
+    d1, d2 = C.c_double(), C.c_double()
+    W = _lib.DVec(N, ones)
+    _lib.chk(hx.hipxVecDot(W.ptr, Y.ptr, N, C.byref(d1)))  # 1 . (A x)
+    _lib.chk(hx.hipxMatMult(A, W.ptr, Y.ptr))
+    _lib.chk(hx.hipxVecDot(X.ptr, Y.ptr, N, C.byref(d2)))  # x . (A 1)
+    assert abs(d1.value - d2.value) <= 1e-12 * abs(d1.value)
+    dot = C.c_double()
+    _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(dot)))
+    ref = C.c_double()
+    _lib.chk(hx.hipxVecDot(X.ptr, Y.ptr, N, C.byref(ref)))
+    assert abs(dot.value - ref.value) <= 1e-13 * abs(ref.value)
+    for v in (X, Y, W):
+        v.free()
+    _lib.mat_destroy(A)
