@@ -33,26 +33,27 @@ struct hipxMat_s {
   hipx_int *d_j       = nullptr;
   double   *d_a       = nullptr;
   int64_t  *d_diagpos = nullptr;  // position of a_ii in a[], -1 if absent
-  // row blocks
-  hipx_int *d_rb    = nullptr;
-  hipx_int  nblocks = 0;
+  // row blocks, one set per kernel geometry (built lazily from the host copy of the row offsets)
+  static constexpr int kMaxCfg = 8;
+  hipx_int *d_rb[kMaxCfg]    = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipx_int  nblocks[kMaxCfg] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool      rb_ready[kMaxCfg] = {false, false, false, false, false, false, false, false};
+  std::vector<int64_t> h_i;  // host copy of the row offsets (set-up only)
+  void     *sor_state = nullptr;  // hipxSorState, owned by hipx_sor.hip
+  unsigned long long value_state = 1;
   // compressed rows (off-diagonal block of MPIAIJ): logical rows = nrows_c, y index = ridx[row]
   bool      compressed = false;
   hipx_int  nrows_c    = 0;
   hipx_int *d_ridx     = nullptr;
   int       variant    = 0;
   int64_t   device_bytes = 0;
-  // SOR level schedule (built lazily)
-  bool      sor_ready = false;
-  hipx_int  nlevels = 0;
-  hipx_int *d_lev_ptr = nullptr, *d_lev_rows = nullptr;
-  std::vector<hipx_int> h_lev_ptr;
-  double   *d_idiag = nullptr, *d_t = nullptr;
-  double    sor_omega = 0, sor_shift = 0;
   bool      diag_dense = true;
   // fused SpMV+dot partials
   double   *d_dotpart = nullptr;
 };
+
+extern "C" void hipxSorStateFree_(void *p);
+extern "C" void hipxSorInvalidate_(void *p);
 
 namespace {
 
@@ -82,9 +83,20 @@ inline int prof_mark(bool start)
   return HIPX_SUCCESS;
 }
 
-constexpr int SPMV_THREADS = 256;
-constexpr int SPMV_CAP     = 2048;  // products staged in LDS per row block (16 KiB)
-constexpr int SPMV_ROWS    = 256;   // rows per block (one thread each in phase 2)
+// kernel geometries: THREADS per workgroup, CAP = products staged in LDS per row block, RPT = rows per thread in the
+// row-sum phase (a block holds at most THREADS * RPT rows)
+struct SpmvCfg {
+  int threads, cap, rpt;
+};
+constexpr SpmvCfg kCfg[] = {
+  {256, 2048, 1},  // 0: 16 KiB LDS, 8 workgroups / CU
+  {256, 4096, 2},  // 1: 32 KiB LDS
+  {512, 4096, 1},  // 2
+  {128, 1024, 1},  // 3
+  {256, 3072, 2},  // 4: 24 KiB
+  {512, 8192, 2},  // 5: 64 KiB
+};
+constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 typedef int    int4v __attribute__((ext_vector_type(4)));
@@ -97,7 +109,7 @@ __device__ __forceinline__ T stream_load(const T *p)
 }
 
 // MODE: 0 y = A x ; 1 z = y + A x
-template <typename IT, bool NT, int MODE, bool CPROW, bool DOT>
+template <typename IT, int SPMV_THREADS, int SPMV_CAP, int RPT, bool NT, int MODE, bool CPROW, bool DOT>
 __global__ __launch_bounds__(SPMV_THREADS) void spmv_stream_kernel(const hipx_int *__restrict__ rb, hipx_int nblocks, hipx_int blocks_per_xcd, const IT *__restrict__ ai,
                                                                     const hipx_int *__restrict__ aj, const double *__restrict__ aa, const double *__restrict__ x,
                                                                     const double *yin, double *yout, const hipx_int *__restrict__ ridx, double *dotpart)
@@ -112,12 +124,16 @@ __global__ __launch_bounds__(SPMV_THREADS) void spmv_stream_kernel(const hipx_in
     const IT       k0 = ai[r0], k1 = ai[r1];
     const IT       ka = k0 & ~(IT)3;  // 32-byte aligned start of the val stream (arrays are padded by 4)
     const int      t  = threadIdx.x;
-    const hipx_int row = r0 + t;
-    // this thread's row extent for phase 2: issue now, consume after the barrier
-    IT rs = 0, re = 0;
-    if (row < r1) {
-      rs = ai[row];
-      re = ai[row + 1];
+    // this thread's row extents for phase 2 (rows r0 + t + j*THREADS): issue the loads now, consume after the barrier
+    IT rs[RPT], re[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const hipx_int row = r0 + t + j * SPMV_THREADS;
+      rs[j] = re[j] = 0;
+      if (row < r1) {
+        rs[j] = ai[row];
+        re[j] = ai[row + 1];
+      }
     }
     if ((k1 - ka) <= (IT)SPMV_CAP) {
       const IT nq = (k1 - ka + 3) >> 2;  // quads to stream (>= 1 unless every row of the block is empty)
@@ -160,28 +176,32 @@ __global__ __launch_bounds__(SPMV_THREADS) void spmv_stream_kernel(const hipx_in
         }
       }
       __syncthreads();
-      if (row < r1) {
-        const hipx_int orow = CPROW ? ridx[row] : row;
-        double         sum  = (MODE == 1) ? yin[orow] : 0.0;
-        const double  *pr   = prod + (int)(rs - ka);
-        const int      len  = (int)(re - rs);
-        int            k    = 0;
-        for (; k + 4 <= len; k += 4) {  // four independent LDS reads, then the dependent left-to-right adds
-          const double p0 = pr[k], p1 = pr[k + 1], p2 = pr[k + 2], p3 = pr[k + 3];
-          sum += p0;
-          sum += p1;
-          sum += p2;
-          sum += p3;
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        const hipx_int row = r0 + t + j * SPMV_THREADS;
+        if (row < r1) {
+          const hipx_int orow = CPROW ? ridx[row] : row;
+          double         sum  = (MODE == 1) ? yin[orow] : 0.0;
+          const double  *pr   = prod + (int)(rs[j] - ka);
+          const int      len  = (int)(re[j] - rs[j]);
+          int            k    = 0;
+          for (; k + 4 <= len; k += 4) {  // four independent LDS reads, then the dependent left-to-right adds
+            const double p0 = pr[k], p1 = pr[k + 1], p2 = pr[k + 2], p3 = pr[k + 3];
+            sum += p0;
+            sum += p1;
+            sum += p2;
+            sum += p3;
+          }
+          if (k + 2 <= len) {
+            const double p0 = pr[k], p1 = pr[k + 1];
+            sum += p0;
+            sum += p1;
+            k += 2;
+          }
+          if (k < len) sum += pr[k];
+          yout[orow] = sum;
+          if (DOT) mydot += x[orow] * sum;
         }
-        if (k + 2 <= len) {
-          const double p0 = pr[k], p1 = pr[k + 1];
-          sum += p0;
-          sum += p1;
-          k += 2;
-        }
-        if (k < len) sum += pr[k];
-        yout[orow] = sum;
-        if (DOT) mydot = x[orow] * sum;
       }
     } else {
       // long row(s): the host guarantees r1 == r0 + 1 here.  Block-wide strided products, tree sum.
@@ -193,7 +213,9 @@ __global__ __launch_bounds__(SPMV_THREADS) void spmv_stream_kernel(const hipx_in
       if (t == 0) {
         const hipx_int orow = CPROW ? ridx[r0] : r0;
         double         sum  = (MODE == 1) ? yin[orow] : 0.0;
-        sum += ((prod[0] + prod[1]) + (prod[2] + prod[3]));
+        double         tot  = prod[0];
+        for (int w = 1; w < SPMV_THREADS / 64; w++) tot += prod[w];
+        sum += tot;
         yout[orow] = sum;
         if (DOT) mydot = x[orow] * sum;
       }
@@ -205,7 +227,11 @@ __global__ __launch_bounds__(SPMV_THREADS) void spmv_stream_kernel(const hipx_in
     double w = hipx::wave_sum(mydot);
     if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = w;
     __syncthreads();
-    if (threadIdx.x == 0) dotpart[bid] = (sd[0] + sd[1]) + (sd[2] + sd[3]);
+    if (threadIdx.x == 0) {
+      double tot = sd[0];
+      for (int w = 1; w < SPMV_THREADS / 64; w++) tot += sd[w];
+      dotpart[bid] = tot;
+    }
   }
 }
 
@@ -245,16 +271,17 @@ __global__ void jacobi_setup_kernel(hipx_int m, const int64_t *diagpos, const do
   }
 }
 
-template <typename IT>
-void build_row_blocks(hipx_int nrows, const IT *ai, std::vector<hipx_int> &rb)
+void build_row_blocks(hipx_int nrows, const int64_t *ai, int cfg, std::vector<hipx_int> &rb)
 {
+  const int64_t  cap  = kCfg[cfg].cap;
+  const hipx_int rows = kCfg[cfg].threads * kCfg[cfg].rpt;
   rb.clear();
   rb.push_back(0);
   hipx_int r = 0;
   while (r < nrows) {
-    const IT ka = ai[r] & ~(IT)3;
-    hipx_int r1 = r;
-    while (r1 < nrows && (r1 - r) < SPMV_ROWS && (ai[r1 + 1] - ka) <= (IT)SPMV_CAP) r1++;
+    const int64_t ka = ai[r] & ~(int64_t)3;
+    hipx_int      r1 = r;
+    while (r1 < nrows && (r1 - r) < rows && (ai[r1 + 1] - ka) <= cap) r1++;
     if (r1 == r) r1 = r + 1;  // one long row: block-wide path
     rb.push_back(r1);
     r = r1;
@@ -290,14 +317,9 @@ int create_common(hipx_int m, hipx_int n, hipx_int nrows, const IT *ai, const hi
     if (nrows) HIPX_HIP(hipMemcpyAsync(A->d_ridx, ridx, sizeof(hipx_int) * (size_t)nrows, hipMemcpyHostToDevice, rt().compute));
     A->device_bytes += (int64_t)sizeof(hipx_int) * nrows;
   }
-  std::vector<hipx_int> rb;
-  if (nrows) build_row_blocks<IT>(nrows, ai, rb);
-  else rb.assign(1, 0);
-  A->nblocks = (hipx_int)rb.size() - 1;
-  HIPX_HIP(hipMalloc((void **)&A->d_rb, sizeof(hipx_int) * rb.size()));
-  HIPX_HIP(hipMemcpyAsync(A->d_rb, rb.data(), sizeof(hipx_int) * rb.size(), hipMemcpyHostToDevice, rt().compute));
-  A->device_bytes += (int64_t)(sizeof(hipx_int) * rb.size());
-  HIPX_HIP(hipStreamSynchronize(rt().compute));  // rb (and the caller's arrays) may go away after return
+  A->h_i.resize((size_t)nrows + 1);
+  for (hipx_int r = 0; r <= nrows; r++) A->h_i[r] = nrows ? (int64_t)ai[r] : 0;
+  HIPX_HIP(hipStreamSynchronize(rt().compute));  // the caller's arrays may go away after return
   if (!ridx && m) {
     HIPX_HIP(hipMalloc((void **)&A->d_diagpos, sizeof(int64_t) * (size_t)m));
     unsigned int *cnt = rt().d_tickets + (HIPX_MAX_RED_SLOTS - 1);
@@ -316,25 +338,79 @@ int create_common(hipx_int m, hipx_int n, hipx_int nrows, const IT *ai, const hi
   return HIPX_SUCCESS;
 }
 
+// variant -> (geometry, non-temporal loads).  0 = auto.
+inline void decode_variant(int variant, int &cfg, bool &nt)
+{
+  if (variant <= 0) variant = 1;
+  cfg = (variant - 1) >> 1;
+  nt  = ((variant - 1) & 1) != 0;
+  if (cfg >= kNumCfg) cfg = 0;
+}
+
+int ensure_row_blocks(hipxMat A, int cfg)
+{
+  if (A->rb_ready[cfg]) return HIPX_SUCCESS;
+  std::vector<hipx_int> rb;
+  const hipx_int        nrows = A->nrows_c;
+  if (nrows) build_row_blocks(nrows, A->h_i.data(), cfg, rb);
+  else rb.assign(1, 0);
+  A->nblocks[cfg] = (hipx_int)rb.size() - 1;
+  HIPX_HIP(hipMalloc((void **)&A->d_rb[cfg], sizeof(hipx_int) * rb.size()));
+  HIPX_HIP(hipMemcpyAsync(A->d_rb[cfg], rb.data(), sizeof(hipx_int) * rb.size(), hipMemcpyHostToDevice, rt().compute));
+  HIPX_HIP(hipStreamSynchronize(rt().compute));
+  A->device_bytes += (int64_t)(sizeof(hipx_int) * rb.size());
+  A->rb_ready[cfg] = true;
+  return HIPX_SUCCESS;
+}
+
+template <typename IT, int CFG, bool NT, int MODE, bool CPROW, bool DOT>
+int launch_cfg(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
+{
+  const hipx_int nb = A->nblocks[CFG];
+  if (nb == 0) return HIPX_SUCCESS;
+  const hipx_int per_xcd = (nb + 7) / 8;
+  const unsigned grid    = (unsigned)(per_xcd * 8);
+  spmv_stream_kernel<IT, kCfg[CFG].threads, kCfg[CFG].cap, kCfg[CFG].rpt, NT, MODE, CPROW, DOT>
+    <<<grid, kCfg[CFG].threads, 0, rt().compute>>>(A->d_rb[CFG], nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_a, x, yin, yout, A->d_ridx, dotpart);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+template <typename IT, int MODE, bool CPROW, bool DOT>
+int launch_spmv_c(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
+{
+  int  cfg;
+  bool nt;
+  decode_variant(A->variant, cfg, nt);
+  int ierr = ensure_row_blocks(A, cfg);
+  if (ierr) return ierr;
+#define HIPX_CASE(C) \
+  case C: \
+    return nt ? launch_cfg<IT, C, true, MODE, CPROW, DOT>(A, x, yin, yout, dotpart) : launch_cfg<IT, C, false, MODE, CPROW, DOT>(A, x, yin, yout, dotpart);
+  switch (cfg) {
+    HIPX_CASE(0)
+    HIPX_CASE(1)
+    HIPX_CASE(2)
+    HIPX_CASE(3)
+    HIPX_CASE(4)
+    HIPX_CASE(5)
+  }
+#undef HIPX_CASE
+  return fail(HIPX_ERR_ARG, "unknown SpMV geometry", __FILE__, __LINE__);
+}
+
 template <typename IT, int MODE, bool DOT>
 int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
 {
-  if (A->nblocks == 0) return HIPX_SUCCESS;
-  const hipx_int per_xcd = (A->nblocks + 7) / 8;
-  const unsigned grid    = (unsigned)(per_xcd * 8);
-  const bool     nt      = (A->variant == 2);
-  hipStream_t    s       = rt().compute;
-#define HIPX_SPMV_ARGS A->d_rb, A->nblocks, per_xcd, (const IT *)A->d_i, A->d_j, A->d_a, x, yin, yout, A->d_ridx, dotpart
-  if (A->compressed) {
-    if (nt) spmv_stream_kernel<IT, true, MODE, true, DOT><<<grid, SPMV_THREADS, 0, s>>>(HIPX_SPMV_ARGS);
-    else spmv_stream_kernel<IT, false, MODE, true, DOT><<<grid, SPMV_THREADS, 0, s>>>(HIPX_SPMV_ARGS);
-  } else {
-    if (nt) spmv_stream_kernel<IT, true, MODE, false, DOT><<<grid, SPMV_THREADS, 0, s>>>(HIPX_SPMV_ARGS);
-    else spmv_stream_kernel<IT, false, MODE, false, DOT><<<grid, SPMV_THREADS, 0, s>>>(HIPX_SPMV_ARGS);
-  }
-#undef HIPX_SPMV_ARGS
-  HIPX_LAUNCH_CHECK();
-  return HIPX_SUCCESS;
+  return A->compressed ? launch_spmv_c<IT, MODE, true, DOT>(A, x, yin, yout, dotpart) : launch_spmv_c<IT, MODE, false, DOT>(A, x, yin, yout, dotpart);
+}
+
+int dot_partials_count(hipxMat A)
+{
+  int  cfg;
+  bool nt;
+  decode_variant(A->variant, cfg, nt);
+  return (int)(((A->nblocks[cfg] + 7) / 8) * 8);
 }
 
 template <int MODE, bool DOT>
@@ -406,7 +482,8 @@ int hipxMatUpdateValues(hipxMat A, const double *a)
   HIPX_ARG(A, "null matrix");
   if (A->nnz) HIPX_HIP(hipMemcpyAsync(A->d_a, a, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice, rt().compute));
   HIPX_HIP(hipStreamSynchronize(rt().compute));
-  A->sor_omega = 0;  // idiag must be rebuilt (aij.c:1807 idiagState)
+  A->value_state++;  // SOR's level-ordered copy and inverse diagonal must be rebuilt (aij.c:1807 idiagState)
+  hipxSorInvalidate_(A->sor_state);
   return HIPX_SUCCESS;
 }
 
@@ -420,15 +497,32 @@ int hipxMatDestroy(hipxMat *pA)
   (void)hipFree(A->d_j);
   (void)hipFree(A->d_a);
   (void)hipFree(A->d_diagpos);
-  (void)hipFree(A->d_rb);
+  for (int c = 0; c < hipxMat_s::kMaxCfg; c++) (void)hipFree(A->d_rb[c]);
   (void)hipFree(A->d_ridx);
-  (void)hipFree(A->d_lev_ptr);
-  (void)hipFree(A->d_lev_rows);
-  (void)hipFree(A->d_idiag);
-  (void)hipFree(A->d_t);
   (void)hipFree(A->d_dotpart);
+  hipxSorStateFree_(A->sor_state);
   delete A;
   *pA = nullptr;
+  return HIPX_SUCCESS;
+}
+
+// internal accessor for hipx_sor.hip (not part of the public ABI)
+int hipxMatInternal_(hipxMat A, hipx_int *m, hipx_int *n, int64_t *nnz, int *is64, void **d_i, hipx_int **d_j, double **d_a, int64_t **d_diagpos, int *diag_dense,
+                     int *compressed, void ***sor_slot, unsigned long long *value_state)
+{
+  HIPX_ARG(A, "null matrix");
+  *m = A->m;
+  *n = A->n;
+  *nnz = A->nnz;
+  *is64 = A->is64;
+  *d_i = A->d_i;
+  *d_j = A->d_j;
+  *d_a = A->d_a;
+  *d_diagpos = A->d_diagpos;
+  *diag_dense = A->diag_dense;
+  *compressed = A->compressed;
+  *sor_slot = &A->sor_state;
+  *value_state = A->value_state;
   return HIPX_SUCCESS;
 }
 
@@ -444,7 +538,12 @@ int hipxMatGetInfo(hipxMat A, hipx_int *m, hipx_int *n, int64_t *nnz, int64_t *d
 
 int hipxMatSetSpMVVariant(hipxMat A, int variant)
 {
-  HIPX_ARG(A && variant >= 0 && variant <= 2, "variant must be 0 (auto), 1 (plain loads) or 2 (non-temporal loads)");
+  HIPX_ARG(A && variant >= 0 && variant <= 2 * kNumCfg, "variant: 0 auto, else 1 + 2*geometry + (1 if non-temporal loads)");
+  if (A->d_dotpart && variant != A->variant) {
+    HIPX_HIP(hipStreamSynchronize(rt().compute));
+    (void)hipFree(A->d_dotpart);
+    A->d_dotpart = nullptr;
+  }
   A->variant = variant;
   return HIPX_SUCCESS;
 }
@@ -474,8 +573,15 @@ int hipxMatMultDot(hipxMat A, const double *x, double *y, double *dot)
   HIPX_CHECK_INIT();
   HIPX_ARG(A && !A->compressed && A->m == A->n, "MatMultDot needs a square, uncompressed matrix");
   *dot = 0.0;
-  if (!A->nblocks) return HIPX_SUCCESS;
-  const hipx_int npart = ((A->nblocks + 7) / 8) * 8;
+  {
+    int  cfg;
+    bool nt;
+    decode_variant(A->variant, cfg, nt);
+    int ierr0 = ensure_row_blocks(A, cfg);
+    if (ierr0) return ierr0;
+  }
+  const hipx_int npart = dot_partials_count(A);
+  if (!npart) return HIPX_SUCCESS;
   if (!A->d_dotpart) HIPX_HIP(hipMalloc((void **)&A->d_dotpart, sizeof(double) * (size_t)npart));
   int ierr = launch_spmv<0, true>(A, x, nullptr, y, A->d_dotpart);
   if (ierr) return ierr;

