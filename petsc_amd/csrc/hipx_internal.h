@@ -7,8 +7,9 @@
 
 namespace hipx {
 
-constexpr int kRedBlocks     = 1024;  // fixed reduction grid -> fixed summation order (deterministic)
-constexpr int kRedThreads    = 256;
+constexpr int kRedBlocks     = 256;   // one workgroup per CU: fixed reduction grid -> fixed summation order, and only 256
+                                        // arrivals on the ticket counter (one contended word takes ~12 ns per atomic)
+constexpr int kRedThreads    = 1024;
 constexpr int kMaxRedVals    = 32;    // sums produced by one reduction launch (MDot batches)
 constexpr int kEwMaxBlocks   = 4096;  // grid cap of the grid-stride elementwise kernels
 constexpr int kEwThreads     = 256;
@@ -23,6 +24,9 @@ struct Runtime {
   unsigned int *d_tickets  = nullptr;  // [HIPX_MAX_RED_SLOTS]
   double       *h_results  = nullptr;  // pinned, mapped: [HIPX_MAX_RED_SLOTS][kMaxRedVals]
   double       *d_results  = nullptr;  // device alias of h_results
+  unsigned long long *h_flags = nullptr;  // pinned, mapped: completion sequence number per slot (host polls it)
+  unsigned long long *d_flags = nullptr;
+  unsigned long long  seq[HIPX_MAX_RED_SLOTS] = {0};
   double       *d_scalars  = nullptr;  // staging for kernel arguments that exceed the arg buffer (MAXPY alphas, pointer tables)
   void        **d_ptrs     = nullptr;
   int           next_slot  = 0;
@@ -35,6 +39,21 @@ int      fail(int code, const char *what, const char *file, int line);
 inline double *slot_partials(int slot) { return rt().d_partials + (size_t)slot * kMaxRedVals * kRedBlocks; }
 inline double *slot_results_dev(int slot) { return rt().d_results + (size_t)slot * kMaxRedVals; }
 inline double *slot_results_host(int slot) { return rt().h_results + (size_t)slot * kMaxRedVals; }
+
+// where a reduction launch puts its partials / results and how it signals completion
+struct RedOut {
+  double             *partials;
+  unsigned int       *ticket;
+  double             *results;
+  unsigned long long *flag;
+  unsigned long long  seq;
+};
+inline RedOut red_out(int slot)
+{
+  Runtime &r = rt();
+  return RedOut{slot_partials(slot), r.d_tickets + slot, slot_results_dev(slot), r.d_flags + slot, ++r.seq[slot]};
+}
+int red_wait(int slot, int nvals, double *out);
 
 }  // namespace hipx
 

@@ -27,8 +27,10 @@ enum { RED_SUM = 0, RED_MAXNAN = 1 };
 // __syncthreads -> one-lane agent-scope release + drained vmcnt -> relaxed ticket; consumer: agent acquire ->
 // __syncthreads -> plain loads.
 template <int NV, int OP>
-__device__ __forceinline__ void block_finish(double (&acc)[NV], double *partials, unsigned int *ticket, double *results)
+__device__ __forceinline__ void block_finish(double (&acc)[NV], RedOut out)
 {
+  double *partials = out.partials, *results = out.results;
+  unsigned int *ticket = out.ticket;
   __shared__ double   s_w[NV][kRedThreads / 64];
   __shared__ unsigned s_last;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -80,9 +82,14 @@ __device__ __forceinline__ void block_finish(double (&acc)[NV], double *partials
       if (OP == RED_SUM) r += s_w[v][w];
       else r = (s_w[v][w] > r || s_w[v][w] != s_w[v][w]) ? s_w[v][w] : r;
     }
-    results[v] = r;  // pinned host memory, visible to the host once the stream has drained
+    results[v] = r;  // pinned, fine-grained host memory
   }
-  if (threadIdx.x == 0) *ticket = 0u;  // re-arm for the next launch on this slot (stream-ordered)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *ticket = 0u;  // re-arm for the next launch on this slot (stream-ordered)
+    __threadfence_system();  // results before flag, visible to the host
+    __hip_atomic_store(out.flag, out.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 

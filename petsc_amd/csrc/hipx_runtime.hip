@@ -16,6 +16,33 @@ int fail(int code, const char *what, const char *file, int line)
 }  // namespace hipx
 using namespace hipx;
 
+// Completion of a blocking reduction: the last workgroup writes the sums into pinned host memory, fences at system
+// scope and then stores the launch's sequence number; the host spins on that word instead of paying a
+// hipStreamSynchronize round trip (3 such waits per CG iteration).  hipStreamQuery every few thousand spins surfaces
+// a faulted kernel instead of hanging.
+int hipx::red_wait(int slot, int nvals, double *out)
+{
+  Runtime                     &r    = rt();
+  volatile unsigned long long *flag = r.h_flags + slot;
+  const unsigned long long     want = r.seq[slot];
+  unsigned long                spins = 0;
+  while (*flag != want) {
+    if ((++spins & 0x3fff) == 0) {
+      hipError_t e = hipStreamQuery(r.compute);
+      if (e != hipSuccess && e != hipErrorNotReady) return fail(HIPX_ERR_HIP_BASE + (int)e, hipGetErrorString(e), __FILE__, __LINE__);
+      if (e == hipSuccess && *flag != want) {  // stream drained but the flag never came: treat as a device fault
+        HIPX_HIP(hipStreamSynchronize(r.compute));
+        if (*flag != want) return fail(HIPX_ERR_GPU, "reduction kernel finished without signalling", __FILE__, __LINE__);
+      }
+    }
+    __builtin_ia32_pause();
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  const volatile double *h = slot_results_host(slot);
+  for (int v = 0; v < nvals; v++) out[v] = h[v];
+  return HIPX_SUCCESS;
+}
+
 extern "C" {
 
 int hipxInit(int device)
@@ -36,6 +63,9 @@ int hipxInit(int device)
   HIPX_HIP(hipHostMalloc((void **)&r.h_results, sizeof(double) * HIPX_MAX_RED_SLOTS * kMaxRedVals, hipHostMallocMapped));
   memset(r.h_results, 0, sizeof(double) * HIPX_MAX_RED_SLOTS * kMaxRedVals);
   HIPX_HIP(hipHostGetDevicePointer((void **)&r.d_results, r.h_results, 0));
+  HIPX_HIP(hipHostMalloc((void **)&r.h_flags, sizeof(unsigned long long) * HIPX_MAX_RED_SLOTS, hipHostMallocMapped));
+  memset(r.h_flags, 0, sizeof(unsigned long long) * HIPX_MAX_RED_SLOTS);
+  HIPX_HIP(hipHostGetDevicePointer((void **)&r.d_flags, r.h_flags, 0));
   HIPX_HIP(hipMalloc((void **)&r.d_scalars, sizeof(double) * 4096));
   HIPX_HIP(hipMalloc((void **)&r.d_ptrs, sizeof(void *) * 4096));
   HIPX_HIP(hipDeviceSynchronize());
@@ -51,6 +81,7 @@ int hipxFinalize(void)
   (void)hipFree(r.d_partials);
   (void)hipFree(r.d_tickets);
   (void)hipHostFree(r.h_results);
+  (void)hipHostFree(r.h_flags);
   (void)hipFree(r.d_scalars);
   (void)hipFree(r.d_ptrs);
   (void)hipStreamDestroy(r.compute);

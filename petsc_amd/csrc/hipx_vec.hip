@@ -293,8 +293,7 @@ struct MDotArgs {
   const double *y[NV];
 };
 template <int NV>
-__global__ __launch_bounds__(kRedThreads) void mdot_kernel(const double *x, MDotArgs<NV> ys, hipx_int n, bool vec, double *partials, unsigned int *ticket,
-                                                            double *results)
+__global__ __launch_bounds__(kRedThreads) void mdot_kernel(const double *x, MDotArgs<NV> ys, hipx_int n, bool vec, RedOut out)
 {
   double acc[NV];
 #pragma unroll
@@ -304,18 +303,33 @@ __global__ __launch_bounds__(kRedThreads) void mdot_kernel(const double *x, MDot
   if (vec) {
     const hipx_int n2 = n >> 1;
     const double2 *x2 = reinterpret_cast<const double2 *>(x);
-    for (hipx_int p = tid; p < n2; p += 2 * T) {
-      const hipx_int q  = p + T;
-      const bool     hq = q < n2;
-      double2        xa = x2[p], xb = hq ? x2[q] : make_double2(0.0, 0.0);
+    // each workgroup owns one contiguous chunk (spreads the concurrently active lines over all HBM channels; a
+    // grid-wide stride of a power-of-two number of MiB makes every wave hit the same channels at the same time)
+    constexpr int  U     = (NV <= 2) ? 4 : 2;  // pairs in flight per thread and operand
+    const hipx_int chunk = (n2 + (hipx_int)gridDim.x - 1) / (hipx_int)gridDim.x;
+    const hipx_int c0    = (hipx_int)blockIdx.x * chunk;
+    const hipx_int c1    = (c0 + chunk < n2) ? c0 + chunk : n2;
+    for (hipx_int p = c0 + (hipx_int)threadIdx.x; p < c1; p += U * kRedThreads) {
+      double2 xa[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const hipx_int q = p + u * kRedThreads;
+        xa[u]            = (q < c1) ? x2[q] : make_double2(0.0, 0.0);
+      }
 #pragma unroll
       for (int v = 0; v < NV; v++) {
         const double2 *y2 = reinterpret_cast<const double2 *>(ys.y[v]);
-        double2        ya = y2[p], yb = hq ? y2[q] : make_double2(0.0, 0.0);
-        acc[v] += xa.x * ya.x;
-        acc[v] += xa.y * ya.y;
-        acc[v] += xb.x * yb.x;
-        acc[v] += xb.y * yb.y;
+        double2        ya[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const hipx_int q = p + u * kRedThreads;
+          ya[u]            = (q < c1) ? y2[q] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          acc[v] += xa[u].x * ya[u].x;
+          acc[v] += xa[u].y * ya[u].y;
+        }
       }
     }
     if ((n & 1) && tid == 0) {
@@ -328,11 +342,11 @@ __global__ __launch_bounds__(kRedThreads) void mdot_kernel(const double *x, MDot
       for (int v = 0; v < NV; v++) acc[v] += x[i] * ys.y[v][i];
     }
   }
-  block_finish<NV, RED_SUM>(acc, partials, ticket, results);
+  block_finish<NV, RED_SUM>(acc, out);
 }
 
 // sums of |x| (NORM_1), x*x (NORM_2) in one pass: acc[0] = sum |x|, acc[1] = sum x^2
-__global__ __launch_bounds__(kRedThreads) void norm12_kernel(const double *x, hipx_int n, bool vec, double *partials, unsigned int *ticket, double *results)
+__global__ __launch_bounds__(kRedThreads) void norm12_kernel(const double *x, hipx_int n, bool vec, RedOut out)
 {
   double         acc[2] = {0.0, 0.0};
   const hipx_int T      = (hipx_int)gridDim.x * kRedThreads;
@@ -357,19 +371,19 @@ __global__ __launch_bounds__(kRedThreads) void norm12_kernel(const double *x, hi
       acc[1] += x[i] * x[i];
     }
   }
-  block_finish<2, RED_SUM>(acc, partials, ticket, results);
+  block_finish<2, RED_SUM>(acc, out);
 }
 
-__global__ __launch_bounds__(kRedThreads) void sum_kernel(const double *x, hipx_int n, double *partials, unsigned int *ticket, double *results)
+__global__ __launch_bounds__(kRedThreads) void sum_kernel(const double *x, hipx_int n, RedOut out)
 {
   double         acc[1] = {0.0};
   const hipx_int T      = (hipx_int)gridDim.x * kRedThreads;
   for (hipx_int i = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += T) acc[0] += x[i];
-  block_finish<1, RED_SUM>(acc, partials, ticket, results);
+  block_finish<1, RED_SUM>(acc, out);
 }
 
 // NORM_INFINITY with the reference's NaN propagation (bvec2.c:207-216)
-__global__ __launch_bounds__(kRedThreads) void norminf_kernel(const double *x, hipx_int n, double *partials, unsigned int *ticket, double *results)
+__global__ __launch_bounds__(kRedThreads) void norminf_kernel(const double *x, hipx_int n, RedOut out)
 {
   double         acc[1] = {0.0};
   const hipx_int T      = (hipx_int)gridDim.x * kRedThreads;
@@ -377,11 +391,11 @@ __global__ __launch_bounds__(kRedThreads) void norminf_kernel(const double *x, h
     double t = fabs(x[i]);
     acc[0]   = (t > acc[0] || t != t) ? t : acc[0];
   }
-  block_finish<1, RED_MAXNAN>(acc, partials, ticket, results);
+  block_finish<1, RED_MAXNAN>(acc, out);
 }
 
 // x.y and y.y in one pass (VecDotNorm2)
-__global__ __launch_bounds__(kRedThreads) void dotnorm2_kernel(const double *x, const double *y, hipx_int n, double *partials, unsigned int *ticket, double *results)
+__global__ __launch_bounds__(kRedThreads) void dotnorm2_kernel(const double *x, const double *y, hipx_int n, RedOut out)
 {
   double         acc[2] = {0.0, 0.0};
   const hipx_int T      = (hipx_int)gridDim.x * kRedThreads;
@@ -390,12 +404,12 @@ __global__ __launch_bounds__(kRedThreads) void dotnorm2_kernel(const double *x, 
     acc[0] += a * b;
     acc[1] += b * b;
   }
-  block_finish<2, RED_SUM>(acc, partials, ticket, results);
+  block_finish<2, RED_SUM>(acc, out);
 }
 
 // fused CG update (cg.c:305-309,344 with PCJACOBI): x += a p; r -= a w; z = r*d; sums z.z, z.r
 __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n,
-                                                                bool vec, double *partials, unsigned int *ticket, double *results)
+                                                                bool vec, RedOut out)
 {
   double         acc[2] = {0.0, 0.0};
   const hipx_int T      = (hipx_int)gridDim.x * kRedThreads;
@@ -405,7 +419,10 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
     const hipx_int n2 = n >> 1;
     double2       *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r), *z2 = reinterpret_cast<double2 *>(z);
     const double2 *p2 = reinterpret_cast<const double2 *>(p), *w2 = reinterpret_cast<const double2 *>(w), *d2 = reinterpret_cast<const double2 *>(d);
-    for (hipx_int q = tid; q < n2; q += T) {
+    const hipx_int chunk = (n2 + (hipx_int)gridDim.x - 1) / (hipx_int)gridDim.x;
+    const hipx_int c0    = (hipx_int)blockIdx.x * chunk;
+    const hipx_int c1    = (c0 + chunk < n2) ? c0 + chunk : n2;
+    for (hipx_int q = c0 + (hipx_int)threadIdx.x; q < c1; q += kRedThreads) {
       double2 xv = x2[q], rv = r2[q], pv = p2[q], wv = w2[q], dv = d2[q], zv;
       xv.x  = xv.x + a * pv.x;
       xv.y  = xv.y + a * pv.y;
@@ -440,7 +457,7 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
       acc[1] += zv * rv;
     }
   }
-  block_finish<2, RED_SUM>(acc, partials, ticket, results);
+  block_finish<2, RED_SUM>(acc, out);
 }
 
 // max / min with index: two small kernels (setup-time operations, not on the solver loop)
@@ -491,18 +508,10 @@ __global__ void replace_zeros_kernel(double *x, hipx_int n, double value, unsign
 
 inline unsigned red_grid(hipx_int n)
 {
-  // enough blocks to cover n once at 4 elements/thread, capped at kRedBlocks; a fixed function of n only
-  hipx_int g = (n + kRedThreads * 4 - 1) / (kRedThreads * 4);
+  // enough 1024-thread workgroups to cover n at 8 elements/thread, capped at kRedBlocks (one per CU); a function of n only
+  hipx_int g = (n + kRedThreads * 8 - 1) / (kRedThreads * 8);
   if (g > kRedBlocks) g = kRedBlocks;
   return (unsigned)(g < 1 ? 1 : g);
-}
-
-int red_wait(int slot, int nvals, double *out)
-{
-  HIPX_HIP(hipStreamSynchronize(rt().compute));
-  const volatile double *h = slot_results_host(slot);
-  for (int v = 0; v < nvals; v++) out[v] = h[v];
-  return HIPX_SUCCESS;
 }
 
 template <int NV>
@@ -514,7 +523,7 @@ int launch_mdot(const double *x, const double *const *y, hipx_int n, int slot)
     a.y[v] = y[v];
     vec    = vec && aligned16(y[v]);
   }
-  mdot_kernel<NV><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, a, n, vec, slot_partials(slot), rt().d_tickets + slot, slot_results_dev(slot));
+  mdot_kernel<NV><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, a, n, vec, red_out(slot));
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -735,7 +744,9 @@ int hipxVecDotBegin(const double *x, const double *y, hipx_int n, int slot)
   HIPX_CHECK_INIT();
   HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 1, "reduction slot out of range");
   if (n <= 0) {
+    HIPX_HIP(hipStreamSynchronize(rt().compute));
     slot_results_host(slot)[0] = 0.0;
+    rt().h_flags[slot]         = ++rt().seq[slot];
     return HIPX_SUCCESS;
   }
   const double *ys[1] = {y};
@@ -779,13 +790,12 @@ int hipxVecMDot(const double *x, hipx_int nv, const double *const *y, hipx_int n
     done += take;
     slot++;
   }
-  HIPX_HIP(hipStreamSynchronize(rt().compute));
   done = 0;
   slot = 1;
   while (done < nv) {
-    hipx_int               take = nv - done > 8 ? 8 : nv - done;
-    const volatile double *h    = slot_results_host(slot);
-    for (hipx_int v = 0; v < take; v++) results[done + v] = h[v];
+    hipx_int take = nv - done > 8 ? 8 : nv - done;
+    int      ierr = red_wait(slot, take, results + done);
+    if (ierr) return ierr;
     done += take;
     slot++;
   }
@@ -808,7 +818,7 @@ int hipxVecNorm(const double *x, hipx_int n, int type, double *results)
     if (ierr) return ierr;
     results[0] = sqrt(s);
   } else if (type == 0 || type == 4) {
-    norm12_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, aligned16(x) && n >= 2, slot_partials(slot), rt().d_tickets + slot, slot_results_dev(slot));
+    norm12_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, aligned16(x) && n >= 2, red_out(slot));
     HIPX_LAUNCH_CHECK();
     double s[2];
     int    ierr = red_wait(slot, 2, s);
@@ -816,7 +826,7 @@ int hipxVecNorm(const double *x, hipx_int n, int type, double *results)
     results[0] = s[0];
     if (type == 4) results[1] = sqrt(s[1]);
   } else if (type == 3) {
-    norminf_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, slot_partials(slot), rt().d_tickets + slot, slot_results_dev(slot));
+    norminf_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, red_out(slot));
     HIPX_LAUNCH_CHECK();
     return red_wait(slot, 1, results);
   } else return fail(HIPX_ERR_ARG, "unknown NormType", __FILE__, __LINE__);
@@ -828,7 +838,7 @@ int hipxVecDotNorm2(const double *x, const double *y, hipx_int n, double *dp, do
   HIPX_CHECK_INIT();
   *dp = *nm = 0.0;
   if (n <= 0) return HIPX_SUCCESS;
-  dotnorm2_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, y, n, slot_partials(0), rt().d_tickets, slot_results_dev(0));
+  dotnorm2_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, y, n, red_out(0));
   HIPX_LAUNCH_CHECK();
   double s[2];
   int    ierr = red_wait(0, 2, s);
@@ -843,7 +853,7 @@ int hipxVecSum(const double *x, hipx_int n, double *result)
   HIPX_CHECK_INIT();
   *result = 0.0;
   if (n <= 0) return HIPX_SUCCESS;
-  sum_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, slot_partials(0), rt().d_tickets, slot_results_dev(0));
+  sum_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, red_out(0));
   HIPX_LAUNCH_CHECK();
   return red_wait(0, 1, result);
 }
@@ -888,7 +898,7 @@ int hipxCGFusedUpdate(double *x, double *r, double *z, const double *p, const do
   sums2[0] = sums2[1] = 0.0;
   if (n <= 0) return HIPX_SUCCESS;
   bool vec = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(p) && aligned16(w) && aligned16(d) && n >= 2;
-  cg_fused_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, a, n, vec, slot_partials(0), rt().d_tickets, slot_results_dev(0));
+  cg_fused_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, a, n, vec, red_out(0));
   HIPX_LAUNCH_CHECK();
   return red_wait(0, 2, sums2);
 }
