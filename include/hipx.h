@@ -42,6 +42,7 @@ typedef int32_t hipx_int;
 /* ---- runtime ------------------------------------------------------------------------------- */
 int         hipxInit(int device);            /* hipSetDevice + streams + reduction scratch; idempotent */
 int         hipxFinalize(void);
+int         hipxGetDeviceCount(int *count);  /* usable before hipxInit: one rank per GPU picks rank % count */
 int         hipxIsInitialized(void);
 const char *hipxGetErrorString(void);
 int         hipxDeviceName(char *buf, size_t len);

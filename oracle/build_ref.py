@@ -1,0 +1,142 @@
+"""oracle/build_ref.py -- compile the REFERENCE itself (PETSc, C sources where they lie under /root/reference) into
+oracle/_ref/ with plain gcc.  Test infrastructure: the result is the strongest oracle (the reference's own MatMult_SeqAIJ,
+KSPSolve_CG, ... ) and the CPU baseline ("kind": "reference"), and the host library the plugin libpetschipx.so loads into.
+
+The reference's own build system (./configure, gmakefile) is NOT run.  This script:
+  1. uses the hand-written configuration oracle/ref_conf/petscconf.h (facts about this image + our choices),
+  2. walks /root/reference/src with the reference's documented selection rule -- a directory is compiled unless its
+     `makefile` carries a `#requires<kind> 'X'` line that the configuration does not satisfy (doc/developers/buildsystem.md);
+     tests/, tutorials/, benchmarks/, ftn-* are never part of the library,
+  3. compiles every selected .c with gcc -O2 (parallel), links oracle/_ref/lib/libpetsc.so against libmkl_rt,
+  4. builds the reference's tutorial drivers ex2 and bench_kspsolve (their sources, unmodified) plus oracle/ref_driver.c.
+No reference source is copied into the repository; outputs go only to oracle/_ref/ (git-ignored, shipped by gpurun).
+"""
+import concurrent.futures as cf
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+OUT = os.path.join(HERE, "_ref")
+CONF = os.path.join(HERE, "ref_conf")
+PKGS = "sys vec mat dm ksp snes ts tao ml".split()
+SKIPDIRS = {"benchmarks", "build", "mex-scripts", "tests", "tutorials"}
+BLAS_DIR = "/opt/conda/lib"
+CFLAGS = ["-fPIC", "-O2", "-fstack-protector", "-fvisibility=hidden", "-w", "-I" + CONF, "-I" + os.path.join(REF, "include")]
+
+
+def conf_defines():
+    txt = open(os.path.join(CONF, "petscconf.h")).read()
+    return set(re.findall(r"^#define\s+(PETSC_\w+)", txt, flags=re.M))
+
+
+def dir_selected(makefile, defs):
+    """The reference's rule: conditions on separate lines are AND-ed, values on one line are OR-ed."""
+    for line in open(makefile, errors="replace"):
+        if not line.startswith("#requires"):
+            continue
+        toks = line[len("#requires"):].replace("'", "").split()
+        if not toks:
+            continue
+        key, vals = toks[0], toks[1:]
+        if key in ("package", "define", "function"):
+            ok = any(v in defs for v in vals)
+        elif key == "precision":
+            ok = "double" in vals
+        elif key == "scalar":
+            ok = "real" in vals
+        elif key == "language":
+            ok = "C" in vals or "c" in vals
+        else:
+            raise RuntimeError("unknown #requires kind in %s: %s" % (makefile, line))
+        if not ok:
+            return False
+    return True
+
+
+def select_sources():
+    defs = conf_defines()
+    srcs = []
+    for pkg in PKGS:
+        for root, dirs, files in os.walk(os.path.join(REF, "src", pkg)):
+            dirs.sort()
+            if os.path.basename(root).startswith("ftn-"):
+                dirs[:] = []
+                continue
+            dirs[:] = [d for d in dirs if d not in SKIPDIRS]
+            mk = os.path.join(root, "makefile")
+            if os.path.isfile(mk) and not dir_selected(mk, defs):
+                dirs[:] = []
+                continue
+            srcs += [os.path.join(root, f) for f in sorted(files) if f.endswith(".c")]
+    return srcs
+
+
+def _compile(job):
+    src, obj = job
+    if os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src):
+        return None
+    os.makedirs(os.path.dirname(obj), exist_ok=True)
+    r = subprocess.run(["gcc"] + CFLAGS + ["-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    return (src, r.stdout) if r.returncode else None
+
+
+def build(verbose=False, jobs=None):
+    if not os.path.isdir(os.path.join(REF, "src")):
+        raise RuntimeError("reference tree not present: oracle/_ref can only be (re)built where /root/reference exists")
+    lib = os.path.join(OUT, "lib", "libpetsc.so")
+    os.makedirs(os.path.join(OUT, "lib"), exist_ok=True)
+    os.makedirs(os.path.join(OUT, "bin"), exist_ok=True)
+    stamp = os.path.join(OUT, "conf.stamp")
+    conf_txt = "".join(open(os.path.join(CONF, f)).read() for f in sorted(os.listdir(CONF))) + " ".join(CFLAGS)
+    if os.path.exists(stamp) and open(stamp).read() != conf_txt:
+        shutil.rmtree(os.path.join(OUT, "obj"), ignore_errors=True)  # configuration changed: rebuild everything
+    srcs = select_sources()
+    pairs = [(s, os.path.join(OUT, "obj", os.path.relpath(s, REF)[:-2] + ".o")) for s in srcs]
+    jobs = jobs or max(1, (os.cpu_count() or 2))
+    failed = []
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        for res in ex.map(_compile, pairs):
+            if res:
+                failed.append(res)
+    if failed:
+        for src, out in failed[:5]:
+            sys.stderr.write("FAILED %s\n%s\n" % (src, out[-2000:]))
+        raise RuntimeError("%d reference files failed to compile" % len(failed))
+    objs = [o for _, o in pairs]
+    if not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+        rsp = os.path.join(OUT, "objs.rsp")
+        open(rsp, "w").write("\n".join(objs))
+        cmd = ["gcc", "-shared", "-fPIC", "-Wl,-soname,libpetsc.so", "-o", lib, "@" + rsp, "-L" + BLAS_DIR, "-Wl,-rpath," + BLAS_DIR, "-lmkl_rt", "-lm", "-ldl", "-lpthread"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode:
+            sys.stderr.write(r.stdout[-4000:])
+            raise RuntimeError("linking libpetsc.so failed")
+    open(stamp, "w").write(conf_txt)
+    # drivers: the reference's own tutorials (sources unmodified, compiled in place) + our thin driver
+    tut = os.path.join(REF, "src", "ksp", "ksp", "tutorials")
+    drivers = {"ex2": os.path.join(tut, "ex2.c"), "bench_kspsolve": os.path.join(tut, "bench_kspsolve.c"), "ref_driver": os.path.join(HERE, "ref_driver.c")}
+    for name, src in drivers.items():
+        exe = os.path.join(OUT, "bin", name)
+        if not os.path.exists(src):
+            continue
+        if os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(src), os.path.getmtime(lib)):
+            continue
+        cmd = ["gcc", "-O2", "-w", "-I" + CONF, "-I" + os.path.join(REF, "include"), src, "-o", exe, "-L" + os.path.join(OUT, "lib"), "-lpetsc",
+               "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + BLAS_DIR, "-L" + BLAS_DIR, "-lmkl_rt", "-lm", "-rdynamic"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode:
+            sys.stderr.write(r.stdout[-4000:])
+            raise RuntimeError("building driver %s failed" % name)
+    if verbose:
+        print("reference built: %d sources -> %s" % (len(srcs), lib))
+    return lib
+
+
+if __name__ == "__main__":
+    import time
+    t = time.time()
+    print(build(verbose=True), "%.1fs" % (time.time() - t))

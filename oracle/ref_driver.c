@@ -1,0 +1,151 @@
+/*
+ * ref_driver.c -- thin PETSc driver used as (a) the strongest oracle: the REFERENCE's own KSPSolve / MatMult on the
+ * BASELINE operators, on the CPU types (-mat_type aij -vec_type standard), (b) the end-to-end check of the drop-in:
+ * the same binary with -dll_prepend libpetschipx.so -mat_type aijhipx -vec_type hipx, (c) the CPU baseline
+ * ("kind": "reference") of bench.py.  Test infrastructure; linked against oracle/_ref/lib/libpetsc.so.
+ *
+ *   ref_driver -n 64 -stencil 7|27|5 [-m rows for 5-pt] [-matmult_its K] [-ksp_type cg -pc_type jacobi -ksp_rtol ...]
+ * Operators: 5-pt = ex2.c:70-94, 7-pt = its 3-D analogue, 27-pt = bench_kspsolve.c:115-303.
+ * b = A*1, x0 = 0.  Prints full-precision residual history (-history), iteration count, error norm, KSPSolve seconds.
+ */
+#include <petscksp.h>
+#include <petsctime.h>
+
+static PetscErrorCode Assemble(Mat A, PetscInt stencil, PetscInt m, PetscInt n, PetscInt Istart, PetscInt Iend)
+{
+  PetscInt    cols[27];
+  PetscScalar vals[27];
+
+  PetscFunctionBeginUser;
+  for (PetscInt Ii = Istart; Ii < Iend; Ii++) {
+    PetscInt nc = 0;
+    if (stencil == 5) {
+      PetscInt i = Ii / n, j = Ii - i * n;
+      if (i > 0) { cols[nc] = Ii - n; vals[nc++] = -1.0; }
+      if (j > 0) { cols[nc] = Ii - 1; vals[nc++] = -1.0; }
+      cols[nc] = Ii; vals[nc++] = 4.0;
+      if (j < n - 1) { cols[nc] = Ii + 1; vals[nc++] = -1.0; }
+      if (i < m - 1) { cols[nc] = Ii + n; vals[nc++] = -1.0; }
+    } else if (stencil == 7) {
+      PetscInt n2 = n * n, x = Ii % n, y = (Ii / n) % n, z = Ii / n2;
+      if (z > 0) { cols[nc] = Ii - n2; vals[nc++] = -1.0; }
+      if (y > 0) { cols[nc] = Ii - n; vals[nc++] = -1.0; }
+      if (x > 0) { cols[nc] = Ii - 1; vals[nc++] = -1.0; }
+      cols[nc] = Ii; vals[nc++] = 6.0;
+      if (x < n - 1) { cols[nc] = Ii + 1; vals[nc++] = -1.0; }
+      if (y < n - 1) { cols[nc] = Ii + n; vals[nc++] = -1.0; }
+      if (z < n - 1) { cols[nc] = Ii + n2; vals[nc++] = -1.0; }
+    } else {
+      PetscInt    n2 = n * n, n1 = n - 1, x = Ii % n, y = (Ii / n) % n, z = Ii / n2;
+      PetscScalar h = 1.0 / (n - 1), v[4];
+      v[0] = 44.0 / 13 * h; v[1] = -3.0 / 13 * h; v[2] = -3.0 / 26 * h; v[3] = -1.0 / 13 * h; /* bench_kspsolve.c:122-126 */
+      for (int dz = -1; dz <= 1; dz++) {
+        if ((dz < 0 && z == 0) || (dz > 0 && z == n1)) continue;
+        for (int dy = -1; dy <= 1; dy++) {
+          if ((dy < 0 && y == 0) || (dy > 0 && y == n1)) continue;
+          for (int dx = -1; dx <= 1; dx++) {
+            if ((dx < 0 && x == 0) || (dx > 0 && x == n1)) continue;
+            cols[nc] = Ii + dx + dy * n + dz * n2;
+            vals[nc++] = v[(dx != 0) + (dy != 0) + (dz != 0)];
+          }
+        }
+      }
+    }
+    PetscCall(MatSetValues(A, 1, &Ii, nc, cols, vals, INSERT_VALUES));
+  }
+  PetscCall(MatAssemblyBegin(A, MAT_FINAL_ASSEMBLY));
+  PetscCall(MatAssemblyEnd(A, MAT_FINAL_ASSEMBLY));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+int main(int argc, char **argv)
+{
+  Mat         A;
+  Vec         x, b, u;
+  KSP         ksp;
+  PetscInt    n = 16, m = 0, stencil = 7, N, Istart, Iend, its, mm_its = 0, nhist = 0;
+  PetscReal   norm, *hist = NULL;
+  PetscBool   history = PETSC_FALSE, dump_y = PETSC_FALSE;
+  PetscLogDouble t0, t1;
+  KSPConvergedReason reason;
+
+  PetscFunctionBeginUser;
+  PetscCall(PetscInitialize(&argc, &argv, NULL, NULL));
+  PetscCall(PetscOptionsGetInt(NULL, NULL, "-n", &n, NULL));
+  PetscCall(PetscOptionsGetInt(NULL, NULL, "-stencil", &stencil, NULL));
+  m = n;
+  PetscCall(PetscOptionsGetInt(NULL, NULL, "-m", &m, NULL));
+  PetscCall(PetscOptionsGetInt(NULL, NULL, "-matmult_its", &mm_its, NULL));
+  PetscCall(PetscOptionsGetBool(NULL, NULL, "-history", &history, NULL));
+  PetscCall(PetscOptionsGetBool(NULL, NULL, "-dump_y", &dump_y, NULL));
+  N = (stencil == 5) ? m * n : n * n * n;
+
+  PetscCall(MatCreate(PETSC_COMM_WORLD, &A));
+  PetscCall(MatSetSizes(A, PETSC_DECIDE, PETSC_DECIDE, N, N));
+  PetscCall(MatSetFromOptions(A));
+  PetscCall(MatSeqAIJSetPreallocation(A, stencil, NULL));
+  PetscCall(MatMPIAIJSetPreallocation(A, stencil, NULL, stencil, NULL));
+  PetscCall(MatGetOwnershipRange(A, &Istart, &Iend));
+  PetscCall(Assemble(A, stencil, m, n, Istart, Iend));
+  PetscCall(MatCreateVecs(A, &u, &b));
+  PetscCall(VecSetFromOptions(u));
+  PetscCall(VecDuplicate(u, &x));
+  PetscCall(VecDestroy(&b));
+  PetscCall(VecDuplicate(u, &b));
+  PetscCall(VecSet(u, 1.0));
+  PetscCall(MatMult(A, u, b));
+
+  if (mm_its > 0 || dump_y) { /* SpMV leg: x_i = 1 + (i mod 17)/17 */
+    PetscScalar *a;
+    Vec          y;
+    PetscCall(VecDuplicate(u, &y));
+    PetscCall(VecGetArrayWrite(x, &a));
+    for (PetscInt i = Istart; i < Iend; i++) a[i - Istart] = 1.0 + (PetscReal)(i % 17) / 17.0;
+    PetscCall(VecRestoreArrayWrite(x, &a));
+    PetscCall(MatMult(A, x, y));
+    PetscCall(VecNorm(y, NORM_2, &norm));
+    PetscCall(PetscTime(&t0));
+    for (PetscInt k = 0; k < mm_its; k++) PetscCall(MatMult(A, x, y));
+    PetscCall(VecNorm(y, NORM_INFINITY, &norm)); /* also drains any asynchronous work */
+    PetscCall(PetscTime(&t1));
+    PetscCall(VecNorm(y, NORM_2, &norm));
+    PetscCall(PetscPrintf(PETSC_COMM_WORLD, "MatMult its %" PetscInt_FMT " seconds %.6e ynorm %.17g\n", mm_its, (double)(t1 - t0), (double)norm));
+    if (dump_y) {
+      const PetscScalar *ya;
+      PetscCall(VecGetArrayRead(y, &ya));
+      for (PetscInt i = 0; i < Iend - Istart; i++) PetscCall(PetscPrintf(PETSC_COMM_SELF, "y %" PetscInt_FMT " %.17g\n", i + Istart, (double)ya[i]));
+      PetscCall(VecRestoreArrayRead(y, &ya));
+    }
+    PetscCall(VecDestroy(&y));
+  }
+
+  PetscCall(KSPCreate(PETSC_COMM_WORLD, &ksp));
+  PetscCall(KSPSetOperators(ksp, A, A));
+  PetscCall(KSPSetFromOptions(ksp));
+  if (history) {
+    PetscCall(PetscMalloc1(100000, &hist));
+    PetscCall(KSPSetResidualHistory(ksp, hist, 100000, PETSC_TRUE));
+  }
+  PetscCall(KSPSetUp(ksp));
+  PetscCall(VecSet(x, 0.0));
+  PetscCall(PetscTime(&t0));
+  PetscCall(KSPSolve(ksp, b, x));
+  PetscCall(PetscTime(&t1));
+  PetscCall(KSPGetIterationNumber(ksp, &its));
+  PetscCall(KSPGetConvergedReason(ksp, &reason));
+  if (history) {
+    PetscCall(KSPGetResidualHistory(ksp, NULL, &nhist));
+    for (PetscInt i = 0; i < nhist; i++) PetscCall(PetscPrintf(PETSC_COMM_WORLD, "hist %" PetscInt_FMT " %.17g\n", i, (double)hist[i]));
+  }
+  PetscCall(VecAXPY(x, -1.0, u));
+  PetscCall(VecNorm(x, NORM_2, &norm));
+  PetscCall(PetscPrintf(PETSC_COMM_WORLD, "iterations %" PetscInt_FMT " reason %d error %.17g KSPSolve_seconds %.6e\n", its, (int)reason, (double)norm, (double)(t1 - t0)));
+  PetscCall(PetscFree(hist));
+  PetscCall(KSPDestroy(&ksp));
+  PetscCall(VecDestroy(&u));
+  PetscCall(VecDestroy(&x));
+  PetscCall(VecDestroy(&b));
+  PetscCall(MatDestroy(&A));
+  PetscCall(PetscFinalize());
+  return 0;
+}

@@ -73,6 +73,14 @@ int hipxInit(int device)
   return HIPX_SUCCESS;
 }
 
+int hipxGetDeviceCount(int *count)
+{
+  *count = 0;
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) return fail(HIPX_ERR_GPU, "no HIP device visible: libhipx has no CPU fallback", __FILE__, __LINE__);
+  return HIPX_SUCCESS;
+}
+
 int hipxFinalize(void)
 {
   Runtime &r = rt();

@@ -1,0 +1,37 @@
+"""Builds petsc_amd/lib/libpetschipx.so: the PETSc plugin (C, gcc) against the reference's headers where they lie
+(/root/reference/include and the private impl headers under /root/reference/src) and the configuration in
+oracle/ref_conf.  Needs oracle/_ref (oracle/build_ref.py) for -lpetsc."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+LIB = os.path.join(ROOT, "petsc_amd", "lib")
+SRCS = ["vechipx.c", "mathipx.c", "matmpihipx.c", "pchipx.c", "register.c"]
+
+
+def build(verbose=False):
+    target = os.path.join(LIB, "libpetschipx.so")
+    srcs = [os.path.join(HERE, s) for s in SRCS]
+    deps = srcs + [os.path.join(HERE, "hipxplugin.h"), os.path.join(ROOT, "include", "hipx.h"), os.path.join(LIB, "libhipx.so"),
+                   os.path.join(ROOT, "oracle", "_ref", "lib", "libpetsc.so")]
+    if os.path.exists(target) and all(os.path.getmtime(d) <= os.path.getmtime(target) for d in deps):
+        return target
+    cmd = ["gcc", "-std=gnu11", "-O2", "-fPIC", "-shared", "-Wall", "-Wno-unused-parameter",
+           "-I" + os.path.join(ROOT, "oracle", "ref_conf"), "-I" + os.path.join(REF, "include"), "-I" + REF, "-I" + os.path.join(REF, "include", "petsc"),
+           "-I" + os.path.join(ROOT, "include"), "-o", target] + srcs + \
+          ["-L" + LIB, "-lhipx", "-L" + os.path.join(ROOT, "oracle", "_ref", "lib"), "-lpetsc",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/../../oracle/_ref/lib", "-Wl,-rpath,/opt/conda/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode:
+        sys.stderr.write(r.stdout[-6000:])
+        raise RuntimeError("building libpetschipx.so failed")
+    return target
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

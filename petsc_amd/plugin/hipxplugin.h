@@ -1,0 +1,66 @@
+/*
+ * hipxplugin.h -- internal header of libpetschipx.so, the PETSc-facing side of the drop-in boundary.
+ *
+ * The plugin registers VECSEQHIPX / VECMPIHIPX / VECHIPX, MATSEQAIJHIPX / MATMPIAIJHIPX / MATAIJHIPX and
+ * PCJACOBIHIPX with an UNMODIFIED libpetsc (loaded with -dll_prepend, src/sys/dll/reg.c:79) and fills the
+ * reference's ops tables with thin C functions that call the kernel ABI (include/hipx.h).
+ * It only uses symbols a default (hidden-visibility) libpetsc exports; parent-class behaviour is obtained by
+ * calling the exported parent creator and capturing its ops table (SURVEY.md Appendix B recipe).
+ */
+#pragma once
+#include <petsc/private/vecimpl.h>
+#include <petsc/private/matimpl.h>
+#include <petsc/private/pcimpl.h>
+#include <../src/vec/vec/impls/dvecimpl.h>
+#include <../src/vec/vec/impls/mpi/pvecimpl.h>
+#include <../src/mat/impls/aij/seq/aij.h>
+#include <../src/mat/impls/aij/mpi/mpiaij.h>
+#include "hipx.h"
+
+#define VECSEQHIPX    "seqhipx"
+#define VECMPIHIPX    "mpihipx"
+#define VECHIPX       "hipx"
+#define MATSEQAIJHIPX "seqaijhipx"
+#define MATMPIAIJHIPX "mpiaijhipx"
+#define MATAIJHIPX    "aijhipx"
+#define PCJACOBIHIPX  "jacobihipx"
+
+/* HIP / kernel-library failures surface as PETSC_ERR_GPU with the library's message (no silent fallback) */
+#define PetscCallHIPX(call) \
+  do { \
+    int hipx_ierr_ = (call); \
+    PetscCheck(!hipx_ierr_, PETSC_COMM_SELF, PETSC_ERR_GPU, "libhipx: %s", hipxGetErrorString()); \
+  } while (0)
+
+/* Device mirror of a vector.  It lives behind the parent's data block: v->data is re-allocated as
+   [ Vec_Seq | Vec_MPI (whichever is larger) ][ VecHIPXExt ], so the parent ops keep working on the front part. */
+typedef struct {
+  PetscScalar *d_array;      /* device copy, NULL until first needed */
+  PetscInt     d_n;          /* allocated length */
+  PetscBool    d_owned;      /* PETSC_FALSE for sub-arrays of a VecDuplicateVecs slab */
+  void        *slab_owner;   /* device slab shared by duplicatevecs siblings (freed by destroyvecs) */
+  PetscInt     magic;
+} VecHIPXExt;
+
+#define VECHIPX_MAGIC   0x48495058
+#define VECHIPX_EXT_OFF ((sizeof(Vec_MPI) > sizeof(Vec_Seq) ? sizeof(Vec_MPI) : sizeof(Vec_Seq)) + 16 - ((sizeof(Vec_MPI) > sizeof(Vec_Seq) ? sizeof(Vec_MPI) : sizeof(Vec_Seq)) % 16))
+
+static inline VecHIPXExt *VecHIPXGetExt(Vec v) { return (VecHIPXExt *)((char *)v->data + VECHIPX_EXT_OFF); }
+
+PETSC_INTERN PetscBool      VecIsHIPX(Vec v);
+PETSC_INTERN PetscErrorCode VecHIPXInitRuntime(void);
+/* device access with host/device coherence driven by v->offloadmask (include/petscdevicetypes.h:239-246) */
+PETSC_INTERN PetscErrorCode VecHIPXGetDeviceRead(Vec v, const PetscScalar **d, void **tmp);
+PETSC_INTERN PetscErrorCode VecHIPXRestoreDeviceRead(Vec v, const PetscScalar **d, void **tmp);
+PETSC_INTERN PetscErrorCode VecHIPXGetDeviceWrite(Vec v, PetscScalar **d, void **tmp);  /* contents undefined on entry */
+PETSC_INTERN PetscErrorCode VecHIPXGetDeviceReadWrite(Vec v, PetscScalar **d, void **tmp);
+PETSC_INTERN PetscErrorCode VecHIPXRestoreDeviceWrite(Vec v, PetscScalar **d, void **tmp);
+
+PETSC_INTERN PetscErrorCode VecCreate_SeqHIPX(Vec);
+PETSC_INTERN PetscErrorCode VecCreate_MPIHIPX(Vec);
+PETSC_INTERN PetscErrorCode VecCreate_HIPX(Vec);
+PETSC_INTERN PetscErrorCode MatCreate_SeqAIJHIPX(Mat);
+PETSC_INTERN PetscErrorCode MatCreate_MPIAIJHIPX(Mat);
+PETSC_INTERN PetscErrorCode PCCreate_JacobiHIPX(PC);
+PETSC_INTERN PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA); /* uploads / refreshes the device CSR */
+PETSC_INTERN PetscBool      MatIsSeqAIJHIPX(Mat A);

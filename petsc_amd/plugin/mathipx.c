@@ -1,0 +1,237 @@
+/*
+ * mathipx.c -- MATSEQAIJHIPX: a Mat_SeqAIJ (src/mat/impls/aij/seq/aij.h:47-78,150-168) whose MatMult / MatMultAdd /
+ * MatSOR / MatGetDiagonal run as HIP kernels.  Assembly, viewing, loading, MatSetValues, duplication ... stay with the
+ * parent class (MatCreate_SeqAIJ is exported, aij.h:459); the CSR arrays are uploaded once per nonzero state and the
+ * values refreshed when the object state changes (the triggering event is MatAssemblyEnd, aij.c:1085).
+ * Slots of struct _MatOps (include/petsc/private/matimpl.h:38-213) owned here: mult, multadd, sor, getdiagonal,
+ * assemblyend, duplicate, destroy (+ MatConvert_seqaij_seqaijhipx_C so -mat_type aijhipx works on an assembled matrix,
+ * matreg.c:146-150).
+ */
+#include "hipxplugin.h"
+
+typedef struct {
+  hipxMat          dA;
+  PetscObjectState nonzerostate; /* pattern the device copy was built from */
+  PetscObjectState valuestate;   /* object state of the values on the device */
+  PetscErrorCode (*parent_assemblyend)(Mat, MatAssemblyType);
+  PetscErrorCode (*parent_destroy)(Mat);
+  PetscErrorCode (*parent_duplicate)(Mat, MatDuplicateOption, Mat *);
+  PetscInt spmv_variant;
+} Mat_SeqAIJHIPX;
+
+static PetscErrorCode MatMult_SeqAIJHIPX(Mat, Vec, Vec);
+
+PetscBool MatIsSeqAIJHIPX(Mat A)
+{
+  return (PetscBool)(A && A->ops->mult == MatMult_SeqAIJHIPX);
+}
+
+/* device CSR, (re)built lazily */
+PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA)
+{
+  Mat_SeqAIJHIPX  *h = (Mat_SeqAIJHIPX *)A->spptr;
+  Mat_SeqAIJ      *a = (Mat_SeqAIJ *)A->data;
+  PetscObjectState state;
+
+  PetscFunctionBegin;
+  PetscCheck(A->assembled, PetscObjectComm((PetscObject)A), PETSC_ERR_ARG_WRONGSTATE, "Not for unassembled matrix");
+  PetscCall(PetscObjectStateGet((PetscObject)A, &state));
+  if (!h->dA || h->nonzerostate != A->nonzerostate) {
+    const PetscScalar *aa;
+    if (h->dA) PetscCallHIPX(hipxMatDestroy(&h->dA));
+    PetscCall(MatSeqAIJGetArrayRead(A, &aa));
+    PetscCallHIPX(hipxMatCreateCSR(A->rmap->n, A->cmap->n, a->i, a->j, aa, &h->dA));
+    PetscCall(MatSeqAIJRestoreArrayRead(A, &aa));
+    if (h->spmv_variant) PetscCallHIPX(hipxMatSetSpMVVariant(h->dA, (int)h->spmv_variant));
+    h->nonzerostate = A->nonzerostate;
+    h->valuestate   = state;
+  } else if (h->valuestate != state) {
+    const PetscScalar *aa;
+    PetscCall(MatSeqAIJGetArrayRead(A, &aa));
+    PetscCallHIPX(hipxMatUpdateValues(h->dA, aa));
+    PetscCall(MatSeqAIJRestoreArrayRead(A, &aa));
+    h->valuestate  = state;
+  }
+  *dA = h->dA;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* MatMult_SeqAIJ aij.c:1444-1502 */
+static PetscErrorCode MatMult_SeqAIJHIPX(Mat A, Vec xx, Vec yy)
+{
+  Mat_SeqAIJ        *a = (Mat_SeqAIJ *)A->data;
+  hipxMat            dA;
+  const PetscScalar *x;
+  PetscScalar       *y;
+  void              *tx, *ty;
+
+  PetscFunctionBegin;
+  PetscCall(MatSeqAIJHIPXGetDeviceMat(A, &dA));
+  PetscCall(VecHIPXGetDeviceRead(xx, &x, &tx));
+  PetscCall(VecHIPXGetDeviceWrite(yy, &y, &ty));
+  PetscCallHIPX(hipxMatMult(dA, x, y));
+  PetscCall(VecHIPXRestoreDeviceWrite(yy, &y, &ty));
+  PetscCall(VecHIPXRestoreDeviceRead(xx, &x, &tx));
+  PetscCall(PetscLogFlops(2.0 * a->nz - a->nonzerorowcnt)); /* aij.c:1497 */
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* MatMultAdd_SeqAIJ aij.c:1606-1658: zz = yy + A xx (zz may be yy) */
+static PetscErrorCode MatMultAdd_SeqAIJHIPX(Mat A, Vec xx, Vec yy, Vec zz)
+{
+  Mat_SeqAIJ        *a = (Mat_SeqAIJ *)A->data;
+  hipxMat            dA;
+  const PetscScalar *x, *y;
+  PetscScalar       *z;
+  void              *tx, *ty = NULL, *tz;
+
+  PetscFunctionBegin;
+  PetscCall(MatSeqAIJHIPXGetDeviceMat(A, &dA));
+  PetscCall(VecHIPXGetDeviceRead(xx, &x, &tx));
+  if (zz == yy) {
+    PetscCall(VecHIPXGetDeviceReadWrite(zz, &z, &tz));
+    y = z;
+  } else {
+    PetscCall(VecHIPXGetDeviceRead(yy, &y, &ty));
+    PetscCall(VecHIPXGetDeviceWrite(zz, &z, &tz));
+  }
+  PetscCallHIPX(hipxMatMultAdd(dA, x, y, z));
+  PetscCall(VecHIPXRestoreDeviceWrite(zz, &z, &tz));
+  if (zz != yy) PetscCall(VecHIPXRestoreDeviceRead(yy, &y, &ty));
+  PetscCall(VecHIPXRestoreDeviceRead(xx, &x, &tx));
+  PetscCall(PetscLogFlops(2.0 * a->nz)); /* aij.c:1653 */
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* MatGetDiagonal_SeqAIJ aij.c:1347-1380 */
+static PetscErrorCode MatGetDiagonal_SeqAIJHIPX(Mat A, Vec v)
+{
+  hipxMat      dA;
+  PetscScalar *d;
+  void        *t;
+
+  PetscFunctionBegin;
+  PetscCall(MatSeqAIJHIPXGetDeviceMat(A, &dA));
+  PetscCall(VecHIPXGetDeviceWrite(v, &d, &t));
+  PetscCallHIPX(hipxMatGetDiagonal(dA, d));
+  PetscCall(VecHIPXRestoreDeviceWrite(v, &d, &t));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* MatSOR_SeqAIJ aij.c:1842-2007 */
+static PetscErrorCode MatSOR_SeqAIJHIPX(Mat A, Vec bb, PetscReal omega, MatSORType flag, PetscReal fshift, PetscInt its, PetscInt lits, Vec xx)
+{
+  Mat_SeqAIJ        *a = (Mat_SeqAIJ *)A->data;
+  hipxMat            dA;
+  const PetscScalar *b;
+  PetscScalar       *x;
+  void              *tb, *tx;
+  int                ierr;
+
+  PetscFunctionBegin;
+  PetscCall(MatSeqAIJHIPXGetDeviceMat(A, &dA));
+  PetscCall(VecHIPXGetDeviceRead(bb, &b, &tb));
+  if (flag & SOR_ZERO_INITIAL_GUESS) PetscCall(VecHIPXGetDeviceWrite(xx, &x, &tx));
+  else PetscCall(VecHIPXGetDeviceReadWrite(xx, &x, &tx));
+  ierr = hipxMatSOR(dA, b, omega, (int)flag, fshift, its, lits, x);
+  if (ierr == HIPX_ERR_ZEROPIVOT) { /* aij.c:1818-1824: flag the matrix, PCApply_SOR turns it into pc->failedreason (sor.c:34) */
+    A->factorerrortype             = MAT_FACTOR_NUMERIC_ZEROPIVOT;
+    A->factorerror_zeropivot_value = 0.0;
+    ierr                           = 0;
+  }
+  PetscCheck(ierr != HIPX_ERR_SUP, PETSC_COMM_SELF, PETSC_ERR_SUP, "libhipx: %s", hipxGetErrorString());
+  PetscCheck(!ierr, PETSC_COMM_SELF, ierr == 73 ? PETSC_ERR_ARG_WRONGSTATE : PETSC_ERR_GPU, "libhipx: %s", hipxGetErrorString());
+  PetscCall(VecHIPXRestoreDeviceWrite(xx, &x, &tx));
+  PetscCall(VecHIPXRestoreDeviceRead(bb, &b, &tb));
+  PetscCall(PetscLogFlops(2.0 * a->nz * its * lits));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode MatAssemblyEnd_SeqAIJHIPX(Mat A, MatAssemblyType mode)
+{
+  Mat_SeqAIJHIPX *h = (Mat_SeqAIJHIPX *)A->spptr;
+
+  PetscFunctionBegin;
+  PetscCall((*h->parent_assemblyend)(A, mode)); /* MatAssemblyEnd_SeqAIJ aij.c:1085: compaction, nz, rmax, inode / compressed-row checks */
+  (void)mode; /* the device copy is refreshed at the next product: MatSeqAIJHIPXGetDeviceMat compares object states */
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode MatDestroy_SeqAIJHIPX(Mat A)
+{
+  Mat_SeqAIJHIPX *h = (Mat_SeqAIJHIPX *)A->spptr;
+  PetscErrorCode (*pdestroy)(Mat) = h->parent_destroy;
+
+  PetscFunctionBegin;
+  if (h->dA) PetscCallHIPX(hipxMatDestroy(&h->dA));
+  PetscCall(PetscObjectComposeFunction((PetscObject)A, "MatConvert_seqaij_seqaijhipx_C", NULL));
+  PetscCall(PetscFree(A->spptr));
+  PetscCall((*pdestroy)(A));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode MatConvert_SeqAIJ_SeqAIJHIPX(Mat, MatType, MatReuse, Mat *);
+
+static PetscErrorCode MatDuplicate_SeqAIJHIPX(Mat A, MatDuplicateOption op, Mat *B)
+{
+  Mat_SeqAIJHIPX *h = (Mat_SeqAIJHIPX *)A->spptr;
+
+  PetscFunctionBegin;
+  PetscCall((*h->parent_duplicate)(A, op, B)); /* MatDuplicate_SeqAIJ: B comes back as a plain seqaij with A's ops copied */
+  (*B)->spptr = NULL;
+  PetscCall(MatConvert_SeqAIJ_SeqAIJHIPX(*B, MATSEQAIJHIPX, MAT_INPLACE_MATRIX, B));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode MatSetFromOptions_SeqAIJHIPX(Mat A, PetscOptionItems PetscOptionsObject)
+{
+  Mat_SeqAIJHIPX *h = (Mat_SeqAIJHIPX *)A->spptr;
+
+  PetscFunctionBegin;
+  PetscOptionsHeadBegin(PetscOptionsObject, "SeqAIJHIPX options");
+  PetscCall(PetscOptionsInt("-mat_aijhipx_spmv_variant", "SpMV kernel geometry / load policy (0 = auto)", "None", h->spmv_variant, &h->spmv_variant, NULL));
+  PetscOptionsHeadEnd();
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* in-place conversion of a (possibly assembled) seqaij matrix: install our ops, keep the parent's for everything else */
+static PetscErrorCode MatConvert_SeqAIJ_SeqAIJHIPX(Mat A, MatType mtype, MatReuse reuse, Mat *newmat)
+{
+  Mat             B;
+  Mat_SeqAIJHIPX *h;
+
+  PetscFunctionBegin;
+  (void)mtype;
+  PetscCall(VecHIPXInitRuntime());
+  if (reuse == MAT_INITIAL_MATRIX) PetscCall(MatDuplicate(A, MAT_COPY_VALUES, newmat));
+  else if (reuse == MAT_REUSE_MATRIX) PetscCall(MatCopy(A, *newmat, SAME_NONZERO_PATTERN));
+  B = *newmat;
+  if (MatIsSeqAIJHIPX(B) && B->spptr) PetscFunctionReturn(PETSC_SUCCESS);
+  PetscCall(PetscNew(&h));
+  h->parent_assemblyend = B->ops->assemblyend;
+  h->parent_destroy     = B->ops->destroy;
+  h->parent_duplicate   = B->ops->duplicate;
+  B->spptr              = h;
+  B->ops->mult           = MatMult_SeqAIJHIPX;
+  B->ops->multadd        = MatMultAdd_SeqAIJHIPX;
+  B->ops->getdiagonal    = MatGetDiagonal_SeqAIJHIPX;
+  B->ops->sor            = MatSOR_SeqAIJHIPX;
+  B->ops->assemblyend    = MatAssemblyEnd_SeqAIJHIPX;
+  B->ops->destroy        = MatDestroy_SeqAIJHIPX;
+  B->ops->duplicate      = MatDuplicate_SeqAIJHIPX;
+  B->ops->setfromoptions = MatSetFromOptions_SeqAIJHIPX;
+  /* MatCreateVecs() hands out VECHIPX vectors, so KSP/PC work vectors live on the device (matrix.c:10069,10080) */
+  PetscCall(PetscFree(B->defaultvectype));
+  PetscCall(PetscStrallocpy(VECHIPX, &B->defaultvectype));
+  PetscCall(PetscObjectChangeTypeName((PetscObject)B, MATSEQAIJHIPX));
+  PetscCall(PetscObjectComposeFunction((PetscObject)B, "MatConvert_seqaij_seqaijhipx_C", MatConvert_SeqAIJ_SeqAIJHIPX));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PetscErrorCode MatCreate_SeqAIJHIPX(Mat B)
+{
+  PetscFunctionBegin;
+  PetscCall(MatCreate_SeqAIJ(B));
+  PetscCall(MatConvert_SeqAIJ_SeqAIJHIPX(B, MATSEQAIJHIPX, MAT_INPLACE_MATRIX, &B));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}

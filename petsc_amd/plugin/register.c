@@ -1,0 +1,20 @@
+/*
+ * register.c -- entry symbol of libpetschipx.so.  PetscDLLibraryOpen (src/sys/dll/dl.c:139-205) strips "lib" and ".so"
+ * from the file name and calls PetscDLLibraryRegister_<base>(); it is reached with
+ *     ./app -dll_prepend /path/libpetschipx.so -vec_type hipx -mat_type aijhipx [-pc_type jacobihipx]
+ * (src/sys/dll/reg.c:79,150) or by calling the function directly after PetscInitialize() when the library is linked.
+ */
+#include "hipxplugin.h"
+
+PETSC_EXTERN PetscErrorCode PetscDLLibraryRegister_petschipx(void)
+{
+  PetscFunctionBegin;
+  PetscCall(VecRegister(VECSEQHIPX, VecCreate_SeqHIPX));
+  PetscCall(VecRegister(VECMPIHIPX, VecCreate_MPIHIPX));
+  PetscCall(VecRegister(VECHIPX, VecCreate_HIPX));
+  PetscCall(MatRegister(MATSEQAIJHIPX, MatCreate_SeqAIJHIPX));
+  PetscCall(MatRegister(MATMPIAIJHIPX, MatCreate_MPIAIJHIPX));
+  PetscCall(MatRegisterRootName(MATAIJHIPX, MATSEQAIJHIPX, MATMPIAIJHIPX)); /* -mat_type aijhipx resolves by communicator size, matreg.c:128-138 */
+  PetscCall(PCRegister(PCJACOBIHIPX, PCCreate_JacobiHIPX));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}

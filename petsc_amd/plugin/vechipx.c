@@ -1,0 +1,807 @@
+/*
+ * vechipx.c -- VECSEQHIPX / VECMPIHIPX / VECHIPX: PETSc vectors whose Vec BLAS-1 ops run as HIP kernels (libhipx).
+ *
+ * Subclassing recipe (works against a default hidden-visibility libpetsc): the creator calls
+ * VecSetType(v, VECSEQ | VECMPI) (-> hidden VecCreate_Seq / exported VecCreate_MPI, src/vec/vec/impls/seq/bvec3.c:22,
+ * impls/mpi/pbvec.c), keeps the parent's ops table for everything host-side (view, setvalues, load, ...), and overrides
+ * the slots of struct _VecOps (include/petsc/private/vecimpl.h:18-110) that are on the Krylov path.
+ *
+ * Coherence: the host array stays where the parent put it (VECHEADER); the device mirror is allocated on first use.
+ * v->offloadmask in {CPU, GPU, BOTH} (include/petscdevicetypes.h:239-246) says where the valid copy is:
+ *   getarray      -> device-to-host if GPU is newer, then CPU      (host may write)
+ *   getarrayread  -> device-to-host if GPU is newer, then BOTH
+ *   getarraywrite -> no copy, CPU
+ *   a kernel that reads  -> host-to-device if CPU is newer, then BOTH
+ *   a kernel that writes -> GPU
+ * Reductions return with the scalar valid (blocking); every other op only enqueues work on libhipx's compute stream.
+ */
+#include "hipxplugin.h"
+
+static PetscBool hipx_runtime_up = PETSC_FALSE;
+
+PetscErrorCode VecHIPXInitRuntime(void)
+{
+  PetscInt    dev = -1;
+  PetscMPIInt rank;
+  int         ndev = 0;
+
+  PetscFunctionBegin;
+  if (hipx_runtime_up) PetscFunctionReturn(PETSC_SUCCESS);
+  PetscCall(PetscOptionsGetInt(NULL, NULL, "-hipx_device", &dev, NULL));
+  if (dev < 0) { /* one rank per GPU: local rank modulo the visible devices */
+    PetscCallMPI(MPI_Comm_rank(PETSC_COMM_WORLD, &rank));
+    PetscCallHIPX(hipxGetDeviceCount(&ndev));
+    dev = ndev > 0 ? rank % ndev : 0;
+  }
+  PetscCallHIPX(hipxInit((int)dev));
+  hipx_runtime_up = PETSC_TRUE;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* ------------------------------------------------------------------ device mirror management */
+static PetscErrorCode VecGetArray_HIPX(Vec, PetscScalar **);
+
+PetscBool VecIsHIPX(Vec v)
+{
+  return (PetscBool)(v && v->ops->getarray == VecGetArray_HIPX && VecHIPXGetExt(v)->magic == VECHIPX_MAGIC);
+}
+
+static PetscErrorCode VecHIPXAllocate(Vec v)
+{
+  VecHIPXExt *e = VecHIPXGetExt(v);
+  PetscInt    n = v->map->n;
+
+  PetscFunctionBegin;
+  if (e->d_array && e->d_n >= n) PetscFunctionReturn(PETSC_SUCCESS);
+  if (e->d_array && e->d_owned) PetscCallHIPX(hipxFree(e->d_array));
+  PetscCallHIPX(hipxMalloc((void **)&e->d_array, sizeof(PetscScalar) * (size_t)(n ? n : 1)));
+  e->d_n     = n;
+  e->d_owned = PETSC_TRUE;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecHIPXCopyToDevice(Vec v)
+{
+  VecHIPXExt *e = VecHIPXGetExt(v);
+
+  PetscFunctionBegin;
+  PetscCall(VecHIPXAllocate(v));
+  if (v->offloadmask == PETSC_OFFLOAD_CPU || v->offloadmask == PETSC_OFFLOAD_UNALLOCATED) {
+    const PetscScalar *h = *(PetscScalar **)v->data; /* VECHEADER: array is the first member */
+    if (v->map->n && h) PetscCallHIPX(hipxMemcpyHtoD(e->d_array, h, sizeof(PetscScalar) * (size_t)v->map->n));
+    v->offloadmask = PETSC_OFFLOAD_BOTH;
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecHIPXCopyToHost(Vec v)
+{
+  VecHIPXExt *e = VecHIPXGetExt(v);
+
+  PetscFunctionBegin;
+  if (v->offloadmask == PETSC_OFFLOAD_GPU) {
+    PetscScalar *h = *(PetscScalar **)v->data;
+    if (v->map->n) PetscCallHIPX(hipxMemcpyDtoH(h, e->d_array, sizeof(PetscScalar) * (size_t)v->map->n));
+    v->offloadmask = PETSC_OFFLOAD_BOTH;
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* Foreign vectors (any other VecType handed to one of our ops; PetscCheckSameTypeAndComm is compiled out in optimized
+   builds, petscimpl.h:613-639): staged through a temporary device buffer so the op still runs on the GPU. */
+typedef struct {
+  PetscScalar *d;
+  PetscScalar *h;
+  int          mode; /* 0 read, 1 write, 2 read-write */
+} HIPXTmp;
+
+static PetscErrorCode VecHIPXForeignGet(Vec v, PetscScalar **d, void **tmp, int mode)
+{
+  HIPXTmp *t;
+  size_t   bytes = sizeof(PetscScalar) * (size_t)(v->map->n ? v->map->n : 1);
+
+  PetscFunctionBegin;
+  PetscCall(PetscNew(&t));
+  t->mode = mode;
+  PetscCallHIPX(hipxMalloc((void **)&t->d, bytes));
+  if (mode == 0) PetscCall(VecGetArrayRead(v, (const PetscScalar **)&t->h));
+  else if (mode == 1) PetscCall(VecGetArrayWrite(v, &t->h));
+  else PetscCall(VecGetArray(v, &t->h));
+  if (mode != 1 && v->map->n) PetscCallHIPX(hipxMemcpyHtoD(t->d, t->h, sizeof(PetscScalar) * (size_t)v->map->n));
+  *d   = t->d;
+  *tmp = t;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecHIPXForeignRestore(Vec v, void **tmp)
+{
+  HIPXTmp *t = (HIPXTmp *)*tmp;
+
+  PetscFunctionBegin;
+  if (t->mode != 0 && v->map->n) PetscCallHIPX(hipxMemcpyDtoH(t->h, t->d, sizeof(PetscScalar) * (size_t)v->map->n));
+  if (t->mode == 0) PetscCall(VecRestoreArrayRead(v, (const PetscScalar **)&t->h));
+  else if (t->mode == 1) PetscCall(VecRestoreArrayWrite(v, &t->h));
+  else PetscCall(VecRestoreArray(v, &t->h));
+  PetscCallHIPX(hipxFree(t->d));
+  PetscCall(PetscFree(t));
+  *tmp = NULL;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PetscErrorCode VecHIPXGetDeviceRead(Vec v, const PetscScalar **d, void **tmp)
+{
+  PetscFunctionBegin;
+  *tmp = NULL;
+  if (VecIsHIPX(v)) {
+    PetscCall(VecHIPXCopyToDevice(v));
+    *d = VecHIPXGetExt(v)->d_array;
+  } else PetscCall(VecHIPXForeignGet(v, (PetscScalar **)d, tmp, 0));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PetscErrorCode VecHIPXRestoreDeviceRead(Vec v, const PetscScalar **d, void **tmp)
+{
+  PetscFunctionBegin;
+  if (*tmp) PetscCall(VecHIPXForeignRestore(v, tmp));
+  *d = NULL;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PetscErrorCode VecHIPXGetDeviceWrite(Vec v, PetscScalar **d, void **tmp)
+{
+  PetscFunctionBegin;
+  *tmp = NULL;
+  if (VecIsHIPX(v)) {
+    PetscCall(VecHIPXAllocate(v));
+    *d = VecHIPXGetExt(v)->d_array;
+  } else PetscCall(VecHIPXForeignGet(v, d, tmp, 1));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PetscErrorCode VecHIPXGetDeviceReadWrite(Vec v, PetscScalar **d, void **tmp)
+{
+  PetscFunctionBegin;
+  *tmp = NULL;
+  if (VecIsHIPX(v)) {
+    PetscCall(VecHIPXCopyToDevice(v));
+    *d = VecHIPXGetExt(v)->d_array;
+  } else PetscCall(VecHIPXForeignGet(v, d, tmp, 2));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PetscErrorCode VecHIPXRestoreDeviceWrite(Vec v, PetscScalar **d, void **tmp)
+{
+  PetscFunctionBegin;
+  if (*tmp) PetscCall(VecHIPXForeignRestore(v, tmp));
+  else v->offloadmask = PETSC_OFFLOAD_GPU;
+  *d = NULL;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* ------------------------------------------------------------------ host array access (ops->getarray & co) */
+static PetscErrorCode VecGetArray_HIPX(Vec v, PetscScalar **a)
+{
+  PetscFunctionBegin;
+  PetscCall(VecHIPXCopyToHost(v));
+  *a             = *(PetscScalar **)v->data;
+  v->offloadmask = PETSC_OFFLOAD_CPU; /* the caller may write: the device copy is stale from now on */
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecGetArrayRead_HIPX(Vec v, const PetscScalar **a)
+{
+  PetscFunctionBegin;
+  PetscCall(VecHIPXCopyToHost(v));
+  *a = *(PetscScalar **)v->data;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecGetArrayWrite_HIPX(Vec v, PetscScalar **a)
+{
+  PetscFunctionBegin;
+  *a             = *(PetscScalar **)v->data;
+  v->offloadmask = PETSC_OFFLOAD_CPU;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecRestoreArray_HIPX(Vec v, PetscScalar **a)
+{
+  (void)v;
+  (void)a;
+  return PETSC_SUCCESS;
+}
+
+static PetscErrorCode VecRestoreArrayRead_HIPX(Vec v, const PetscScalar **a)
+{
+  (void)v;
+  (void)a;
+  return PETSC_SUCCESS;
+}
+
+static PetscErrorCode (*parent_placearray)(Vec, const PetscScalar *);
+static PetscErrorCode (*parent_replacearray)(Vec, const PetscScalar *);
+static PetscErrorCode (*parent_resetarray)(Vec);
+static PetscErrorCode (*parent_destroy_seq)(Vec);
+static PetscErrorCode (*parent_destroy_mpi)(Vec);
+
+static PetscErrorCode VecPlaceArray_HIPX(Vec v, const PetscScalar *a)
+{
+  PetscFunctionBegin;
+  PetscCall(VecHIPXCopyToHost(v)); /* the original array must hold current values when it comes back (VecResetArray) */
+  PetscCall((*parent_placearray)(v, a));
+  v->offloadmask = PETSC_OFFLOAD_CPU;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecReplaceArray_HIPX(Vec v, const PetscScalar *a)
+{
+  PetscFunctionBegin;
+  PetscCall((*parent_replacearray)(v, a));
+  v->offloadmask = PETSC_OFFLOAD_CPU;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecResetArray_HIPX(Vec v)
+{
+  PetscFunctionBegin;
+  PetscCall((*parent_resetarray)(v));
+  v->offloadmask = PETSC_OFFLOAD_CPU;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* ------------------------------------------------------------------ BLAS-1, local part (shared by seq and mpi) */
+#define RD(v, p, t)  PetscCall(VecHIPXGetDeviceRead(v, &p, &t))
+#define RDX(v, p, t) PetscCall(VecHIPXRestoreDeviceRead(v, &p, &t))
+#define RW(v, p, t)  PetscCall(VecHIPXGetDeviceReadWrite(v, &p, &t))
+#define WR(v, p, t)  PetscCall(VecHIPXGetDeviceWrite(v, &p, &t))
+#define WRX(v, p, t) PetscCall(VecHIPXRestoreDeviceWrite(v, &p, &t))
+
+static PetscErrorCode VecSet_HIPX(Vec x, PetscScalar alpha) /* VecSet_Seq dvec2.c:642 */
+{
+  PetscScalar *d;
+  void        *t;
+
+  PetscFunctionBegin;
+  WR(x, d, t);
+  PetscCallHIPX(hipxVecSet(d, x->map->n, alpha));
+  WRX(x, d, t);
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecCopy_HIPX(Vec x, Vec y) /* VecCopy_Seq bvec2.c:151 */
+{
+  const PetscScalar *dx;
+  PetscScalar       *dy;
+  void              *tx, *ty;
+
+  PetscFunctionBegin;
+  if (x == y) PetscFunctionReturn(PETSC_SUCCESS);
+  RD(x, dx, tx);
+  WR(y, dy, ty);
+  PetscCallHIPX(hipxVecCopy(dx, dy, x->map->n));
+  WRX(y, dy, ty);
+  RDX(x, dx, tx);
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecScale_HIPX(Vec x, PetscScalar alpha) /* VecScale_Seq bvec2.c:167 */
+{
+  PetscScalar *d;
+  void        *t;
+
+  PetscFunctionBegin;
+  if (alpha == (PetscScalar)0.0) PetscCall(VecSet_HIPX(x, 0.0));
+  else if (alpha != (PetscScalar)1.0) {
+    RW(x, d, t);
+    PetscCallHIPX(hipxVecScale(d, x->map->n, alpha));
+    WRX(x, d, t);
+    PetscCall(PetscLogFlops(x->map->n));
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecSwap_HIPX(Vec x, Vec y)
+{
+  PetscScalar *dx, *dy;
+  void        *tx, *ty;
+
+  PetscFunctionBegin;
+  if (x == y) PetscFunctionReturn(PETSC_SUCCESS);
+  RW(x, dx, tx);
+  RW(y, dy, ty);
+  PetscCallHIPX(hipxVecSwap(dx, dy, x->map->n));
+  WRX(y, dy, ty);
+  WRX(x, dx, tx);
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecAXPY_HIPX(Vec y, PetscScalar alpha, Vec x) /* VecAXPY_Seq bvec1.c:70 */
+{
+  const PetscScalar *dx;
+  PetscScalar       *dy;
+  void              *tx, *ty;
+
+  PetscFunctionBegin;
+  if (alpha == (PetscScalar)0.0) PetscFunctionReturn(PETSC_SUCCESS); /* bvec1.c:75 */
+  RD(x, dx, tx);
+  RW(y, dy, ty);
+  PetscCallHIPX(hipxVecAXPY(dy, alpha, dx, y->map->n));
+  WRX(y, dy, ty);
+  RDX(x, dx, tx);
+  PetscCall(PetscLogFlops(2.0 * y->map->n)); /* bvec1.c:81 */
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecAYPX_HIPX(Vec y, PetscScalar beta, Vec x) /* VecAYPX_Seq dvec2.c:753 */
+{
+  const PetscScalar *dx;
+  PetscScalar       *dy;
+  void              *tx, *ty;
+
+  PetscFunctionBegin;
+  if (beta == (PetscScalar)0.0) {
+    PetscCall(VecCopy_HIPX(x, y));
+    PetscFunctionReturn(PETSC_SUCCESS);
+  }
+  RD(x, dx, tx);
+  RW(y, dy, ty);
+  PetscCallHIPX(hipxVecAYPX(dy, beta, dx, y->map->n));
+  WRX(y, dy, ty);
+  RDX(x, dx, tx);
+  PetscCall(PetscLogFlops((beta == (PetscScalar)-1.0 ? 1.0 : 2.0) * y->map->n)); /* dvec2.c:769,776 */
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecAXPBY_HIPX(Vec y, PetscScalar a, PetscScalar b, Vec x) /* VecAXPBY_Seq bvec1.c:91 */
+{
+  const PetscScalar *dx;
+  PetscScalar       *dy;
+  void              *tx, *ty;
+
+  PetscFunctionBegin;
+  if (a == (PetscScalar)0.0) {
+    PetscCall(VecScale_HIPX(y, b));
+    PetscFunctionReturn(PETSC_SUCCESS);
+  }
+  RD(x, dx, tx);
+  RW(y, dy, ty);
+  PetscCallHIPX(hipxVecAXPBY(dy, a, b, dx, y->map->n));
+  WRX(y, dy, ty);
+  RDX(x, dx, tx);
+  PetscCall(PetscLogFlops(3.0 * y->map->n));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecWAXPY_HIPX(Vec w, PetscScalar alpha, Vec x, Vec y) /* VecWAXPY_Seq dvec2.c:791 */
+{
+  const PetscScalar *dx, *dy;
+  PetscScalar       *dw;
+  void              *tx, *ty, *tw;
+
+  PetscFunctionBegin;
+  RD(x, dx, tx);
+  RD(y, dy, ty);
+  WR(w, dw, tw);
+  PetscCallHIPX(hipxVecWAXPY(dw, alpha, dx, dy, w->map->n));
+  WRX(w, dw, tw);
+  RDX(y, dy, ty);
+  RDX(x, dx, tx);
+  PetscCall(PetscLogFlops(2.0 * w->map->n));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecAXPBYPCZ_HIPX(Vec z, PetscScalar a, PetscScalar b, PetscScalar c, Vec x, Vec y) /* bvec1.c:120 */
+{
+  const PetscScalar *dx, *dy;
+  PetscScalar       *dz;
+  void              *tx, *ty, *tz;
+
+  PetscFunctionBegin;
+  RD(x, dx, tx);
+  RD(y, dy, ty);
+  RW(z, dz, tz);
+  PetscCallHIPX(hipxVecAXPBYPCZ(dz, a, b, c, dx, dy, z->map->n));
+  WRX(z, dz, tz);
+  RDX(y, dy, ty);
+  RDX(x, dx, tx);
+  PetscCall(PetscLogFlops(4.0 * z->map->n));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecPointwiseMult_HIPX(Vec w, Vec x, Vec y) /* VecPointwiseMult_Seq bvec2.c:72 (w may alias x or y) */
+{
+  const PetscScalar *dx, *dy;
+  PetscScalar       *dw;
+  void              *tx, *ty, *tw;
+
+  PetscFunctionBegin;
+  RD(x, dx, tx);
+  RD(y, dy, ty);
+  if (w == x || w == y) RW(w, dw, tw);
+  else WR(w, dw, tw);
+  PetscCallHIPX(hipxVecPointwiseMult(dw, dx, dy, w->map->n));
+  WRX(w, dw, tw);
+  RDX(y, dy, ty);
+  RDX(x, dx, tx);
+  PetscCall(PetscLogFlops(w->map->n)); /* bvec2.c:95 */
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecPointwiseDivide_HIPX(Vec w, Vec x, Vec y) /* bvec2.c:99 */
+{
+  const PetscScalar *dx, *dy;
+  PetscScalar       *dw;
+  void              *tx, *ty, *tw;
+
+  PetscFunctionBegin;
+  RD(x, dx, tx);
+  RD(y, dy, ty);
+  if (w == x || w == y) RW(w, dw, tw);
+  else WR(w, dw, tw);
+  PetscCallHIPX(hipxVecPointwiseDivide(dw, dx, dy, w->map->n));
+  WRX(w, dw, tw);
+  RDX(y, dy, ty);
+  RDX(x, dx, tx);
+  PetscCall(PetscLogFlops(w->map->n));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecReciprocal_HIPX(Vec x) /* VecReciprocal_Default vinv.c:1208 */
+{
+  PetscScalar *d;
+  void        *t;
+
+  PetscFunctionBegin;
+  RW(x, d, t);
+  PetscCallHIPX(hipxVecReciprocal(d, x->map->n));
+  WRX(x, d, t);
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecAbs_HIPX(Vec x)
+{
+  PetscScalar *d;
+  void        *t;
+
+  PetscFunctionBegin;
+  RW(x, d, t);
+  PetscCallHIPX(hipxVecAbs(d, x->map->n));
+  WRX(x, d, t);
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecShift_HIPX(Vec x, PetscScalar s)
+{
+  PetscScalar *d;
+  void        *t;
+
+  PetscFunctionBegin;
+  RW(x, d, t);
+  PetscCallHIPX(hipxVecShift(d, x->map->n, s));
+  WRX(x, d, t);
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+#define HIPX_MAXV 64
+static PetscErrorCode VecMAXPY_HIPX(Vec y, PetscInt nv, const PetscScalar *alpha, Vec *x) /* VecMAXPY_Seq dvec2.c:658 */
+{
+  PetscScalar *dy;
+  void        *ty;
+
+  PetscFunctionBegin;
+  RW(y, dy, ty);
+  for (PetscInt s = 0; s < nv; s += HIPX_MAXV) { /* batches keep the reference's (nv & 3)-then-fours grouping only for nv <= 64 */
+    const PetscScalar *dx[HIPX_MAXV];
+    void              *tx[HIPX_MAXV];
+    PetscInt           m = PetscMin(HIPX_MAXV, nv - s);
+    for (PetscInt j = 0; j < m; j++) RD(x[s + j], dx[j], tx[j]);
+    PetscCallHIPX(hipxVecMAXPY(dy, m, alpha + s, (const double *const *)dx, y->map->n));
+    for (PetscInt j = 0; j < m; j++) RDX(x[s + j], dx[j], tx[j]);
+  }
+  WRX(y, dy, ty);
+  PetscCall(PetscLogFlops(nv * 2.0 * y->map->n));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecDotLocal_HIPX(Vec x, Vec y, PetscScalar *z) /* VecDot_Seq / VecTDot_Seq bvec1.c:10-49 (real scalars: identical) */
+{
+  const PetscScalar *dx, *dy;
+  void              *tx, *ty;
+
+  PetscFunctionBegin;
+  RD(x, dx, tx);
+  RD(y, dy, ty);
+  PetscCallHIPX(hipxVecDot(dx, dy, x->map->n, z));
+  RDX(y, dy, ty);
+  RDX(x, dx, tx);
+  PetscCall(PetscLogFlops(PetscMax(2.0 * x->map->n - 1, 0.0))); /* bvec1.c:22 */
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecMDotLocal_HIPX(Vec x, PetscInt nv, const Vec y[], PetscScalar *z) /* VecMDot_Seq dvec2.c:83 */
+{
+  const PetscScalar *dx;
+  void              *tx;
+
+  PetscFunctionBegin;
+  RD(x, dx, tx);
+  for (PetscInt s = 0; s < nv; s += 32) {
+    const PetscScalar *dy[32];
+    void              *ty[32];
+    PetscInt           m = PetscMin(32, nv - s);
+    for (PetscInt j = 0; j < m; j++) RD(y[s + j], dy[j], ty[j]);
+    PetscCallHIPX(hipxVecMDot(dx, m, (const double *const *)dy, x->map->n, z + s));
+    for (PetscInt j = 0; j < m; j++) RDX(y[s + j], dy[j], ty[j]);
+  }
+  RDX(x, dx, tx);
+  PetscCall(PetscLogFlops(PetscMax(nv * (2.0 * x->map->n - 1), 0.0)));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecNormLocal_HIPX(Vec x, NormType type, PetscReal *z) /* VecNorm_Seq bvec2.c:185 */
+{
+  const PetscScalar *dx;
+  void              *tx;
+  int                t = (type == NORM_1) ? 0 : (type == NORM_2) ? 1 : (type == NORM_FROBENIUS) ? 2 : (type == NORM_INFINITY) ? 3 : 4;
+
+  PetscFunctionBegin;
+  RD(x, dx, tx);
+  PetscCallHIPX(hipxVecNorm(dx, x->map->n, t, z));
+  RDX(x, dx, tx);
+  if (type == NORM_2 || type == NORM_FROBENIUS) PetscCall(PetscLogFlops(PetscMax(2.0 * x->map->n - 1, 0.0)));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecDotNorm2Local_HIPX(Vec s, Vec t, PetscScalar *dp, PetscScalar *nm)
+{
+  const PetscScalar *ds, *dt;
+  void              *ts, *tt;
+
+  PetscFunctionBegin;
+  RD(s, ds, ts);
+  RD(t, dt, tt);
+  PetscCallHIPX(hipxVecDotNorm2(ds, dt, s->map->n, dp, nm));
+  RDX(t, dt, tt);
+  RDX(s, ds, ts);
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecSumLocal_HIPX(Vec x, PetscScalar *sum)
+{
+  const PetscScalar *dx;
+  void              *tx;
+
+  PetscFunctionBegin;
+  RD(x, dx, tx);
+  PetscCallHIPX(hipxVecSum(dx, x->map->n, sum));
+  RDX(x, dx, tx);
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecMaxLocal_HIPX(Vec x, PetscInt *idx, PetscReal *z) /* dvec2.c:592-640 */
+{
+  const PetscScalar *dx;
+  void              *tx;
+  hipx_int           i;
+
+  PetscFunctionBegin;
+  RD(x, dx, tx);
+  PetscCallHIPX(hipxVecMax(dx, x->map->n, &i, z));
+  RDX(x, dx, tx);
+  if (!x->map->n) *z = PETSC_MIN_REAL;
+  if (idx) *idx = i;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecMinLocal_HIPX(Vec x, PetscInt *idx, PetscReal *z)
+{
+  const PetscScalar *dx;
+  void              *tx;
+  hipx_int           i;
+
+  PetscFunctionBegin;
+  RD(x, dx, tx);
+  PetscCallHIPX(hipxVecMin(dx, x->map->n, &i, z));
+  RDX(x, dx, tx);
+  if (!x->map->n) *z = PETSC_MAX_REAL;
+  if (idx) *idx = i;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* ------------------------------------------------------------------ MPI wrappers (pvecimpl.h:97-175: local kernel + MPI_Allreduce) */
+static PetscErrorCode VecDot_MPIHIPX(Vec x, Vec y, PetscScalar *z)
+{
+  PetscFunctionBegin;
+  PetscCall(VecXDot_MPI_Default(x, y, z, VecDotLocal_HIPX));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+static PetscErrorCode VecMDot_MPIHIPX(Vec x, PetscInt nv, const Vec y[], PetscScalar *z)
+{
+  PetscFunctionBegin;
+  PetscCall(VecMXDot_MPI_Default(x, nv, y, z, VecMDotLocal_HIPX));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+static PetscErrorCode VecNorm_MPIHIPX(Vec x, NormType type, PetscReal *z)
+{
+  PetscFunctionBegin;
+  PetscCall(VecNorm_MPI_Default(x, type, z, VecNormLocal_HIPX));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+static PetscErrorCode VecDotNorm2_MPIHIPX(Vec s, Vec t, PetscScalar *dp, PetscScalar *nm)
+{
+  PetscFunctionBegin;
+  PetscCall(VecDotNorm2_MPI_Default(s, t, dp, nm, VecDotNorm2Local_HIPX));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+static PetscErrorCode VecSum_MPIHIPX(Vec x, PetscScalar *sum)
+{
+  PetscFunctionBegin;
+  PetscCall(VecSumLocal_HIPX(x, sum));
+  PetscCallMPI(MPIU_Allreduce(MPI_IN_PLACE, sum, 1, MPIU_SCALAR, MPIU_SUM, PetscObjectComm((PetscObject)x)));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* ------------------------------------------------------------------ life cycle */
+static PetscErrorCode VecHIPXFreeDevice(Vec v)
+{
+  VecHIPXExt *e = VecHIPXGetExt(v);
+
+  PetscFunctionBegin;
+  if (e->magic == VECHIPX_MAGIC && e->d_array && e->d_owned) PetscCallHIPX(hipxFree(e->d_array));
+  e->d_array = NULL;
+  e->magic   = 0;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecDestroy_SeqHIPX(Vec v)
+{
+  PetscFunctionBegin;
+  PetscCall(VecHIPXFreeDevice(v));
+  PetscCall((*parent_destroy_seq)(v)); /* frees the host array and v->data (bvec2.c:621) */
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecDestroy_MPIHIPX(Vec v)
+{
+  PetscFunctionBegin;
+  PetscCall(VecHIPXFreeDevice(v));
+  PetscCall((*parent_destroy_mpi)(v));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecDuplicateVecs_HIPX(Vec w, PetscInt m, Vec *V[])
+{
+  PetscFunctionBegin;
+  PetscCall(PetscMalloc1(m, V));
+  for (PetscInt i = 0; i < m; i++) PetscCall(VecDuplicate(w, &(*V)[i]));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecDestroyVecs_HIPX(PetscInt m, Vec V[])
+{
+  PetscFunctionBegin;
+  for (PetscInt i = 0; i < m; i++) PetscCall(VecDestroy(&V[i]));
+  PetscCall(PetscFree(V));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* re-allocate v->data as [parent struct | VecHIPXExt] */
+static PetscErrorCode VecHIPXExtend(Vec v, size_t parent_size)
+{
+  char       *blk;
+  VecHIPXExt *e;
+
+  PetscFunctionBegin;
+  PetscCall(PetscCalloc1(VECHIPX_EXT_OFF + sizeof(VecHIPXExt), &blk));
+  PetscCall(PetscMemcpy(blk, v->data, parent_size));
+  PetscCall(PetscFree(v->data));
+  v->data  = blk;
+  e        = VecHIPXGetExt(v);
+  e->magic = VECHIPX_MAGIC;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static void VecHIPXInstallLocalOps(Vec v)
+{
+  struct _VecOps *o = v->ops;
+  o->duplicatevecs    = VecDuplicateVecs_HIPX;
+  o->destroyvecs      = VecDestroyVecs_HIPX;
+  o->scale            = VecScale_HIPX;
+  o->copy             = VecCopy_HIPX;
+  o->set              = VecSet_HIPX;
+  o->swap             = VecSwap_HIPX;
+  o->axpy             = VecAXPY_HIPX;
+  o->axpby            = VecAXPBY_HIPX;
+  o->maxpy            = VecMAXPY_HIPX;
+  o->aypx             = VecAYPX_HIPX;
+  o->waxpy            = VecWAXPY_HIPX;
+  o->axpbypcz         = VecAXPBYPCZ_HIPX;
+  o->pointwisemult    = VecPointwiseMult_HIPX;
+  o->pointwisedivide  = VecPointwiseDivide_HIPX;
+  o->reciprocal       = VecReciprocal_HIPX;
+  o->abs              = VecAbs_HIPX;
+  o->shift            = VecShift_HIPX;
+  o->maxpby           = NULL; /* interface falls back to VecSet/VecScale + VecMAXPY (rvector.c:1434), as on VECSEQ */
+  o->getarray         = VecGetArray_HIPX;
+  o->restorearray     = VecRestoreArray_HIPX;
+  o->getarrayread     = VecGetArrayRead_HIPX;
+  o->restorearrayread = VecRestoreArrayRead_HIPX;
+  o->getarraywrite    = VecGetArrayWrite_HIPX;
+  o->restorearraywrite = VecRestoreArray_HIPX;
+  o->placearray       = VecPlaceArray_HIPX;
+  o->replacearray     = VecReplaceArray_HIPX;
+  o->resetarray       = VecResetArray_HIPX;
+  o->dot_local        = VecDotLocal_HIPX;
+  o->tdot_local       = VecDotLocal_HIPX;
+  o->mdot_local       = VecMDotLocal_HIPX;
+  o->mtdot_local      = VecMDotLocal_HIPX;
+  o->norm_local       = VecNormLocal_HIPX;
+}
+
+PetscErrorCode VecCreate_SeqHIPX(Vec v)
+{
+  PetscFunctionBegin;
+  PetscCall(VecHIPXInitRuntime());
+  PetscCall(VecSetType(v, VECSEQ)); /* allocates + zeroes the host array, seeds the norm cache (bvec3.c:22-41) */
+  if (!parent_destroy_seq) {
+    parent_destroy_seq  = v->ops->destroy;
+    parent_placearray   = v->ops->placearray;
+    parent_replacearray = v->ops->replacearray;
+    parent_resetarray   = v->ops->resetarray;
+  }
+  PetscCall(VecHIPXExtend(v, sizeof(Vec_Seq)));
+  VecHIPXInstallLocalOps(v);
+  v->ops->dot      = VecDotLocal_HIPX;
+  v->ops->tdot     = VecDotLocal_HIPX;
+  v->ops->mdot     = VecMDotLocal_HIPX;
+  v->ops->mtdot    = VecMDotLocal_HIPX;
+  v->ops->norm     = VecNormLocal_HIPX;
+  v->ops->dotnorm2 = VecDotNorm2Local_HIPX;
+  v->ops->sum      = VecSumLocal_HIPX;
+  v->ops->max      = VecMaxLocal_HIPX;
+  v->ops->min      = VecMinLocal_HIPX;
+  v->ops->destroy  = VecDestroy_SeqHIPX;
+  v->offloadmask   = PETSC_OFFLOAD_CPU;
+  PetscCall(PetscObjectChangeTypeName((PetscObject)v, VECSEQHIPX));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PetscErrorCode VecCreate_MPIHIPX(Vec v)
+{
+  PetscFunctionBegin;
+  PetscCall(VecHIPXInitRuntime());
+  PetscCall(VecSetType(v, VECMPI)); /* VecCreate_MPI is exported (pvecimpl.h:74) but the registry route needs no symbol at all */
+  if (!parent_destroy_mpi) {
+    parent_destroy_mpi = v->ops->destroy;
+    if (!parent_placearray) {
+      parent_placearray   = v->ops->placearray;
+      parent_replacearray = v->ops->replacearray;
+      parent_resetarray   = v->ops->resetarray;
+    }
+  }
+  PetscCall(VecHIPXExtend(v, sizeof(Vec_MPI)));
+  VecHIPXInstallLocalOps(v);
+  v->ops->dot      = VecDot_MPIHIPX;
+  v->ops->tdot     = VecDot_MPIHIPX;
+  v->ops->mdot     = VecMDot_MPIHIPX;
+  v->ops->mtdot    = VecMDot_MPIHIPX;
+  v->ops->norm     = VecNorm_MPIHIPX;
+  v->ops->dotnorm2 = VecDotNorm2_MPIHIPX;
+  v->ops->sum      = VecSum_MPIHIPX;
+  v->ops->destroy  = VecDestroy_MPIHIPX;
+  v->offloadmask   = PETSC_OFFLOAD_CPU;
+  PetscCall(PetscObjectChangeTypeName((PetscObject)v, VECMPIHIPX));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* root type: dispatch on communicator size like VecCreate_Standard (pbvec.c:666-675) */
+PetscErrorCode VecCreate_HIPX(Vec v)
+{
+  PetscMPIInt size;
+
+  PetscFunctionBegin;
+  PetscCallMPI(MPI_Comm_size(PetscObjectComm((PetscObject)v), &size));
+  if (size == 1) PetscCall(VecSetType(v, VECSEQHIPX));
+  else PetscCall(VecSetType(v, VECMPIHIPX));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}

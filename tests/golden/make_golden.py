@@ -44,6 +44,44 @@ def main():
             out[name]["iterations"] = int(m.group(1))
     json.dump(out, open(os.path.join(HERE, "ref_outputs.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
+    ref_runs()
+
+
+RUNS = {
+    # name: (driver args)  -- all with b = A*1, x0 = 0 (oracle/ref_driver.c)
+    "config1_ex2_100x100_cg_jacobi": "-stencil 5 -m 100 -n 100 -ksp_type cg -pc_type jacobi -ksp_rtol 9.8029604940692086e-07",
+    "p7_n20_cg_jacobi": "-stencil 7 -n 20 -ksp_type cg -pc_type jacobi -ksp_rtol 1e-8",
+    "p7_n20_cg_none_unpre": "-stencil 7 -n 20 -ksp_type cg -pc_type none -ksp_norm_type unpreconditioned -ksp_rtol 1e-8",
+    "p7_n20_cg_jacobi_natural": "-stencil 7 -n 20 -ksp_type cg -pc_type jacobi -ksp_norm_type natural -ksp_rtol 1e-8",
+    "p27_n16_cg_jacobi": "-stencil 27 -n 16 -ksp_type cg -pc_type jacobi -ksp_rtol 1e-8",
+    "p27_n12_gmres_jacobi": "-stencil 27 -n 12 -ksp_type gmres -pc_type jacobi -ksp_rtol 1e-8",
+    "p27_n12_gmres5_jacobi": "-stencil 27 -n 12 -ksp_type gmres -ksp_gmres_restart 5 -pc_type jacobi -ksp_rtol 1e-8",
+    "p7_n16_gmres_sor": "-stencil 7 -n 16 -ksp_type gmres -pc_type sor -ksp_rtol 1e-8",
+    "p27_n12_gmres_sor": "-stencil 27 -n 12 -ksp_type gmres -pc_type sor -ksp_rtol 1e-8",
+    "p7_n16_cg_ssor": "-stencil 7 -n 16 -ksp_type cg -pc_type sor -ksp_rtol 1e-8",
+    "ex2_3_gmres_ssor": "-stencil 5 -m 8 -n 7 -pc_type sor -pc_sor_symmetric -ksp_gmres_cgs_refinement_type refine_always -ksp_rtol 1.3888888888888889e-04",
+}
+SPMV = {"p7_n8": "-stencil 7 -n 8", "p27_n6": "-stencil 27 -n 6", "p5_9x7": "-stencil 5 -m 9 -n 7"}
+
+
+def ref_runs():
+    """Outputs of the reference library itself (oracle/_ref, built by oracle/build_ref.py) at full precision."""
+    import subprocess
+    exe = os.path.join(HERE, "..", "..", "oracle", "_ref", "bin", "ref_driver")
+    if not os.path.exists(exe):
+        print("oracle/_ref not built: ref_runs.json not regenerated")
+        return
+    out = {"_how": "oracle/_ref/bin/ref_driver <args> -history (reference libpetsc built by oracle/build_ref.py: gcc -O2, MPIUNI, libmkl_rt)", "ksp": {}, "spmv": {}}
+    for name, args in RUNS.items():
+        txt = subprocess.check_output([exe] + args.split() + ["-history"], text=True)
+        hist = [float(l.split()[2]) for l in txt.splitlines() if l.startswith("hist ")]
+        m = re.search(r"iterations (\d+) reason (-?\d+) error (\S+)", txt)
+        out["ksp"][name] = {"args": args, "iterations": int(m.group(1)), "reason": int(m.group(2)), "error": float(m.group(3)), "history": [repr(h) for h in hist]}
+    for name, args in SPMV.items():
+        txt = subprocess.check_output([exe] + args.split() + ["-dump_y", "-ksp_max_it", "1"], text=True)
+        out["spmv"][name] = {"args": args, "y": [l.split()[2] for l in txt.splitlines() if l.startswith("y ")]}
+    json.dump(out, open(os.path.join(HERE, "ref_runs.json"), "w"), indent=0)
+    print("ref_runs.json:", {k: v["iterations"] for k, v in out["ksp"].items()})
 
 
 if __name__ == "__main__":

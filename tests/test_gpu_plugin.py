@@ -1,0 +1,98 @@
+"""GPU: the drop-in itself.  UNMODIFIED reference executables (the reference's tutorials ex2 and bench_kspsolve and our
+thin ref_driver, all linked against the reference's libpetsc built by oracle/build_ref.py) are run with
+    -dll_prepend petsc_amd/lib/libpetschipx.so -vec_type hipx -mat_type aijhipx
+and must reproduce the reference's golden outputs and the CPU run of the same binary."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref", "bin")
+PLUGIN = os.path.join(ROOT, "petsc_amd", "lib", "libpetschipx.so")
+HIPX = ["-dll_prepend", PLUGIN, "-vec_type", "hipx", "-mat_type", "aijhipx"]
+
+
+def run(exe, args):
+    p = os.path.join(BIN, exe)
+    assert os.path.exists(p) and os.path.exists(PLUGIN), "oracle/_ref or the plugin is not built: run __graft_entry__.build() where /root/reference exists"
+    env = dict(os.environ, HIPX_NO_TORCH="1")
+    r = subprocess.run([p] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    return r.stdout
+
+
+def hist_of(txt):
+    return np.array([float(l.split()[2]) for l in txt.splitlines() if l.startswith("hist ")])
+
+
+def test_ex2_golden_suffix3_with_hipx_types():
+    """output/ex2_3.out: GMRES + symmetric SOR; -petsc_ci prints %g like the reference's test harness."""
+    args = ["-pc_type", "sor", "-pc_sor_symmetric", "-ksp_monitor", "-ksp_gmres_cgs_refinement_type", "refine_always", "-petsc_ci"]
+    out = run("ex2", args + HIPX)
+    golden = """  0 KSP Residual norm 2.98499
+  1 KSP Residual norm 1.13133
+  2 KSP Residual norm 0.575925
+  3 KSP Residual norm 0.108871
+  4 KSP Residual norm 0.0213225
+  5 KSP Residual norm 0.00325239
+  6 KSP Residual norm 0.000874208
+  7 KSP Residual norm 0.000179613
+Norm of error 0.000300302 iterations 7
+"""
+    assert out == golden
+    assert out == run("ex2", args)
+
+
+def test_ex2_config1_cg_jacobi_and_jacobihipx():
+    """BASELINE config 1: 160 iterations, Norm of error 5.70785e-05."""
+    base = ["-m", "100", "-n", "100", "-ksp_type", "cg"]
+    cpu = run("ex2", base + ["-pc_type", "jacobi"])
+    assert cpu.strip() == "Norm of error 5.70785e-05 iterations 160"
+    assert run("ex2", base + ["-pc_type", "jacobi"] + HIPX) == cpu
+    assert run("ex2", base + ["-pc_type", "jacobihipx"] + HIPX) == cpu
+
+
+def test_view_reports_hipx_types_and_kernels_ran():
+    out = run("ex2", ["-m", "20", "-n", "20", "-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_view"] + HIPX)
+    assert "type: seqaijhipx" in out
+    out = run("ex2", ["-m", "20", "-n", "20", "-ksp_type", "cg", "-pc_type", "jacobi", "-vec_view", "::ascii_info"] + HIPX)
+    assert "error" not in out.lower().replace("norm of error", "")
+
+
+@pytest.mark.parametrize("args", ["-stencil 7 -n 24 -ksp_type cg -pc_type jacobi -ksp_rtol 1e-8",
+                                  "-stencil 27 -n 16 -ksp_type cg -pc_type jacobi -ksp_rtol 1e-8",
+                                  "-stencil 27 -n 14 -ksp_type gmres -pc_type sor -ksp_rtol 1e-8",
+                                  "-stencil 7 -n 20 -ksp_type gmres -ksp_gmres_restart 7 -pc_type jacobi -ksp_rtol 1e-8",
+                                  "-stencil 7 -n 16 -ksp_type cg -pc_type sor -ksp_rtol 1e-8",
+                                  "-stencil 7 -n 16 -ksp_type bcgs -pc_type jacobi -ksp_rtol 1e-8",
+                                  "-stencil 7 -n 16 -ksp_type cg -ksp_cg_single_reduction -pc_type jacobi -ksp_rtol 1e-8"])
+def test_ref_driver_histories_cpu_vs_hipx(args):
+    a = args.split() + ["-history"]
+    cpu, gpu = run("ref_driver", a), run("ref_driver", a + HIPX)
+    hc, hg = hist_of(cpu), hist_of(gpu)
+    ic = re.search(r"iterations (\d+) reason (-?\d+) error (\S+)", cpu)
+    ig = re.search(r"iterations (\d+) reason (-?\d+) error (\S+)", gpu)
+    assert ic.group(1, 2) == ig.group(1, 2)
+    assert len(hc) == len(hg)
+    assert np.abs(hc - hg).max() <= 1e-12 * hc[0]
+    assert (np.abs(hc - hg) / hc).max() <= 1e-7
+    assert abs(float(ic.group(3)) - float(ig.group(3))) <= 1e-7 * float(ic.group(3)) + 1e-13
+
+
+def test_matmult_bit_exact_cpu_vs_hipx():
+    a = "-stencil 27 -n 10 -dump_y -ksp_max_it 1".split()
+    cpu, gpu = run("ref_driver", a), run("ref_driver", a + HIPX)
+    yc = [l for l in cpu.splitlines() if l.startswith("y ")]
+    yg = [l for l in gpu.splitlines() if l.startswith("y ")]
+    assert yc == yg and len(yc) == 1000
+
+
+def test_bench_kspsolve_matmult_and_ksp_goldens_with_aijhipx():
+    out = run("bench_kspsolve", ["-print_timing", "false", "-matmult", "-its", "10", "-n", "8", "-mat_type", "aijhipx", "-dll_prepend", PLUGIN])
+    ref = run("bench_kspsolve", ["-print_timing", "false", "-matmult", "-its", "10", "-n", "8"])
+    assert out.split() == ref.split() and "Number of nonzeros = 10648" in out

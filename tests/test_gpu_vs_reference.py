@@ -1,0 +1,36 @@
+"""GPU: the HIP path (C ABI + C host layer) against outputs of the REFERENCE ITSELF (tests/golden/ref_runs.json)."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from test_gpu_ksp import solve_gpu
+from test_gpu_mat import spmv_gpu
+from test_oracle_vs_reference import R, build, parse, solve_kwargs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", sorted(R["spmv"]))
+def test_spmv_bit_exact_vs_reference_matmult(hx, name):
+    d, _ = parse(R["spmv"][name]["args"])
+    ai, aj, aa = build(d)
+    N = len(ai) - 1
+    x = 1.0 + (np.arange(N) % 17) / 17.0
+    y = spmv_gpu(hx, ai, aj, aa, x)
+    assert np.array_equal(y, np.array([float(v) for v in R["spmv"][name]["y"]]))
+
+
+@pytest.mark.parametrize("name", sorted(R["ksp"]))
+def test_krylov_history_vs_reference(hx, name):
+    g = R["ksp"][name]
+    d, flags = parse(g["args"])
+    ai, aj, aa = build(d)
+    b = orc.matmult(ai, aj, aa, np.ones(len(ai) - 1))
+    kind, kw = solve_kwargs(d, flags)
+    x, its, reason, hist = solve_gpu(kind, ai, aj, aa, b, **kw)
+    href = np.array([float(v) for v in g["history"]])
+    assert its == g["iterations"] and reason == g["reason"]
+    assert len(hist) == len(href)
+    assert np.abs(hist - href).max() <= 1e-12 * href[0]  # north_star: residuals within 1e-12 relative (to the initial residual)
+    assert (np.abs(hist - href) / href).max() <= 1e-8
+    assert abs(np.linalg.norm(x - 1) - g["error"]) <= 1e-8 * max(g["error"], 1e-30) + 1e-13
