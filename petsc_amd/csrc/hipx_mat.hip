@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 using namespace hipx;
@@ -41,6 +42,16 @@ struct hipxMat_s {
   hipx_int *d_sched[kMaxCfg] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // launch slot -> row block (null = identity)
   int64_t   far_offset = 0;   // typical max |col - row| of a row (0 = unknown / irregular): drives the block schedule
   int       sched_mode = 0;   // 1 = band-aware schedule (cuts x re-fetch from the Infinity Cache; no time gain measured), 0 = natural order
+  // LDS x-tile variant: block-local 16-bit column ids + per-block window descriptors (built lazily on the host)
+  bool           tile_ready = false;
+  unsigned short *d_lcol    = nullptr;
+  hipx_int      *d_wdesc    = nullptr;
+  int            tile_mode  = 0;   // 1 = LDS x-tile kernel (variant 21), 2 = packed 16-bit columns + hardware gather (variant 22)
+  bool           pk_ready   = false;
+  unsigned short *d_pk      = nullptr;   // (window id << 12) | offset inside the window
+  hipx_int      *d_pkbase   = nullptr;   // PK_WMAX window starts per row block (-1 in slot 0 = block keeps 32-bit columns)
+  int64_t        pk_fallback_blocks = 0;
+  int64_t        tile_fallback_blocks = 0;
   int       probe      = 0;   // phase-attribution probe kernels (scripts/spmv_variants.py); results are NOT A x
   std::vector<int64_t> h_i;  // host copy of the row offsets (set-up only)
   void     *sor_state = nullptr;  // hipxSorState, owned by hipx_sor.hip
@@ -250,6 +261,293 @@ __global__ __launch_bounds__(SPMV_THREADS) void spmv_stream_kernel(const hipx_in
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS x-tile SpMV.  Same row blocks, same products, same left-to-right row sums as spmv_stream_kernel (bit-identical
+// y), but the block's x entries are first staged in LDS through COALESCED loads of a few contiguous windows of x, and
+// the column of every nonzero is stored as a 16-bit position inside that tile:
+//   * the 64-lane scattered 8-byte gather (10-17 % of the stream kernel's time, probe runs) becomes ds_read_b64,
+//   * the index stream shrinks from 4 to 2 bytes per nonzero.
+// Per block the host records up to TILE_WMAX windows [start, len) covering the distinct columns of the block (gaps of
+// up to TILE_GAP unused entries are absorbed into a window); blocks whose windows do not fit (irregular rows) keep
+// the global gather with their 32-bit columns -- the format degrades per block, not per matrix.
+constexpr int TILE_THREADS = 256;
+constexpr int TILE_CAP     = 2048;  // products per block (as cfg 0)
+constexpr int TILE_XCAP    = 2048;  // x entries staged per block (16 KiB)
+constexpr int TILE_WMAX    = 12;
+constexpr int TILE_GAP     = 16;
+constexpr int TILE_DW      = 2 + 3 * TILE_WMAX;  // ints per descriptor: nwin, total, then (start, len, offset) per window
+
+typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
+
+template <typename IT, int MODE, bool DOT>
+__global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const hipx_int *__restrict__ rb, hipx_int nblocks, hipx_int blocks_per_xcd, const IT *__restrict__ ai,
+                                                                  const hipx_int *__restrict__ aj, const unsigned short *__restrict__ lcol,
+                                                                  const hipx_int *__restrict__ wdesc, const double *__restrict__ aa, const double *__restrict__ x,
+                                                                  const double *yin, double *yout, double *dotpart)
+{
+  __shared__ double prod[TILE_CAP];
+  __shared__ double xt[TILE_XCAP];
+  const hipx_int bid = (hipx_int)blockIdx.x;
+  const hipx_int b   = (bid & 7) * blocks_per_xcd + (bid >> 3);
+  double         mydot = 0.0;
+  if (b < nblocks) {
+    const hipx_int r0 = rb[b], r1 = rb[b + 1];
+    const IT       k0 = ai[r0], k1 = ai[r1];
+    const IT       ka = k0 & ~(IT)3;
+    const int      t  = threadIdx.x;
+    const hipx_int row = r0 + t;
+    IT             rs = 0, re = 0;
+    if (row < r1) {
+      rs = ai[row];
+      re = ai[row + 1];
+    }
+    const hipx_int *desc = wdesc + (size_t)b * TILE_DW;
+    const int       nwin = desc[0];
+    if ((k1 - ka) <= (IT)TILE_CAP) {
+      const IT      nq  = (k1 - ka + 3) >> 2;
+      constexpr int NIT = TILE_CAP / 4 / TILE_THREADS;
+      dbl2          va[NIT], vb[NIT];
+      if (nq > 0) {
+        const dbl2 *a2 = reinterpret_cast<const dbl2 *>(aa + ka);
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {  // values first: the longest stream, in flight while the x tile is staged
+          const IT q  = (IT)t + (IT)it * TILE_THREADS;
+          const IT qc = q < nq ? q : nq - 1;
+          va[it]      = a2[2 * qc];
+          vb[it]      = a2[2 * qc + 1];
+        }
+        if (nwin >= 0) {
+          ushort4v vl[NIT];
+          const ushort4v *l4 = reinterpret_cast<const ushort4v *>(lcol + ka);
+#pragma unroll
+          for (int it = 0; it < NIT; it++) {
+            const IT q  = (IT)t + (IT)it * TILE_THREADS;
+            const IT qc = q < nq ? q : nq - 1;
+            vl[it]      = l4[qc];
+          }
+          for (int w = 0; w < nwin; w++) {  // coalesced staging of the block's x windows
+            const hipx_int s = desc[2 + 3 * w], len = desc[3 + 3 * w], off = desc[4 + 3 * w];
+            for (hipx_int i = t; i < len; i += TILE_THREADS) xt[off + i] = x[s + i];
+          }
+          __syncthreads();
+#pragma unroll
+          for (int it = 0; it < NIT; it++) {
+            const IT q = (IT)t + (IT)it * TILE_THREADS;
+            if (q < nq) {
+              dbl2 p0, p1;
+              p0.x = va[it].x * xt[vl[it].x];
+              p0.y = va[it].y * xt[vl[it].y];
+              p1.x = vb[it].x * xt[vl[it].z];
+              p1.y = vb[it].y * xt[vl[it].w];
+              reinterpret_cast<dbl2 *>(prod)[2 * q]     = p0;
+              reinterpret_cast<dbl2 *>(prod)[2 * q + 1] = p1;
+            }
+          }
+        } else {  // block whose columns do not fit the tile: global gather with the 32-bit columns
+          const int4v *j4 = reinterpret_cast<const int4v *>(aj + ka);
+#pragma unroll
+          for (int it = 0; it < NIT; it++) {
+            const IT q = (IT)t + (IT)it * TILE_THREADS;
+            if (q < nq) {
+              const int4v c = j4[q];
+              dbl2        p0, p1;
+              p0.x = va[it].x * x[c.x];
+              p0.y = va[it].y * x[c.y];
+              p1.x = vb[it].x * x[c.z];
+              p1.y = vb[it].y * x[c.w];
+              reinterpret_cast<dbl2 *>(prod)[2 * q]     = p0;
+              reinterpret_cast<dbl2 *>(prod)[2 * q + 1] = p1;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (row < r1) {
+        double        sum = (MODE == 1) ? yin[row] : 0.0;
+        const double *pr  = prod + (int)(rs - ka);
+        const int     len = (int)(re - rs);
+        int           k   = 0;
+        for (; k + 4 <= len; k += 4) {
+          const double p0 = pr[k], p1 = pr[k + 1], p2 = pr[k + 2], p3 = pr[k + 3];
+          sum += p0;
+          sum += p1;
+          sum += p2;
+          sum += p3;
+        }
+        if (k + 2 <= len) {
+          const double p0 = pr[k], p1 = pr[k + 1];
+          sum += p0;
+          sum += p1;
+          k += 2;
+        }
+        if (k < len) sum += pr[k];
+        yout[row] = sum;
+        if (DOT) mydot = x[row] * sum;
+      }
+    } else {  // one long row
+      double acc = 0.0;
+      for (IT k = k0 + t; k < k1; k += TILE_THREADS) acc += aa[k] * x[aj[k]];
+      acc = hipx::wave_sum(acc);
+      if ((t & 63) == 0) prod[t >> 6] = acc;
+      __syncthreads();
+      if (t == 0) {
+        double sum = (MODE == 1) ? yin[r0] : 0.0;
+        double tot = prod[0];
+        for (int w = 1; w < TILE_THREADS / 64; w++) tot += prod[w];
+        sum += tot;
+        yout[r0] = sum;
+        if (DOT) mydot = x[r0] * sum;
+      }
+    }
+  }
+  if (DOT) {
+    __shared__ double sd[TILE_THREADS / 64];
+    __syncthreads();
+    double w = hipx::wave_sum(mydot);
+    if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = sd[0];
+      for (int k = 1; k < TILE_THREADS / 64; k++) tot += sd[k];
+      dotpart[bid] = tot;
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Packed-column SpMV: the stream kernel with the 4-byte column replaced by a 2-byte (window id : 4, offset : 12) code.
+// Each row block records up to 16 windows of x (start columns); column = start[id] + offset.  The window starts of a
+// block live in lanes 0..15 of every wave and are fetched with a wave shuffle, so the gather still goes through the
+// hardware (L1/L2) path, with no extra barrier and no extra LDS.  Index traffic: 2 instead of 4 bytes per nonzero.
+// Blocks whose columns need more than 16 windows of 4096 keep their 32-bit columns (per-block fallback).
+constexpr int PK_WMAX = 16;
+constexpr int PK_WLEN = 4096;
+
+template <typename IT, int MODE, bool DOT>
+__global__ __launch_bounds__(256) void spmv_pk16_kernel(const hipx_int *__restrict__ rb, hipx_int nblocks, hipx_int blocks_per_xcd, const IT *__restrict__ ai,
+                                                        const hipx_int *__restrict__ aj, const unsigned short *__restrict__ pk, const hipx_int *__restrict__ pkbase,
+                                                        const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout, double *dotpart, hipx_int ncols)
+{
+  constexpr int THREADS = 256, CAP = 2048;
+  __shared__ double prod[CAP];
+  const hipx_int bid = (hipx_int)blockIdx.x;
+  const hipx_int b   = (bid & 7) * blocks_per_xcd + (bid >> 3);
+  double         mydot = 0.0;
+  if (b < nblocks) {
+    const hipx_int r0 = rb[b], r1 = rb[b + 1];
+    const IT       k0 = ai[r0], k1 = ai[r1];
+    const IT       ka = k0 & ~(IT)3;
+    const int      t  = threadIdx.x;
+    const hipx_int row = r0 + t;
+    IT             rs = 0, re = 0;
+    if (row < r1) {
+      rs = ai[row];
+      re = ai[row + 1];
+    }
+    const int base_reg = pkbase[(size_t)b * PK_WMAX + (t & (PK_WMAX - 1))];  // lanes 0..15 of each wave hold the window starts
+    const int packed   = __shfl(base_reg, 0, 64) >= 0;                          // wave-uniform: slot 0 is -1 for fallback blocks
+    if ((k1 - ka) <= (IT)CAP) {
+      const IT      nq  = (k1 - ka + 3) >> 2;
+      constexpr int NIT = CAP / 4 / THREADS;
+      if (nq > 0) {
+        const dbl2 *a2 = reinterpret_cast<const dbl2 *>(aa + ka);
+        dbl2        va[NIT], vb[NIT];
+        int         c[NIT][4];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+          const IT q  = (IT)t + (IT)it * THREADS;
+          const IT qc = q < nq ? q : nq - 1;
+          va[it]      = a2[2 * qc];
+          vb[it]      = a2[2 * qc + 1];
+          if (packed) {
+            const ushort4v v = reinterpret_cast<const ushort4v *>(pk + ka)[qc];
+            c[it][0] = __shfl(base_reg, v.x >> 12, 64) + (v.x & 0xfff);
+            c[it][1] = __shfl(base_reg, v.y >> 12, 64) + (v.y & 0xfff);
+            c[it][2] = __shfl(base_reg, v.z >> 12, 64) + (v.z & 0xfff);
+            c[it][3] = __shfl(base_reg, v.w >> 12, 64) + (v.w & 0xfff);
+            // the first / last quad of a block also carries entries of the neighbouring blocks, whose codes refer to THEIR
+            // windows: decoded against ours they may point anywhere -> clamp (their products are never summed)
+#pragma unroll
+            for (int e = 0; e < 4; e++) c[it][e] = ((unsigned)c[it][e] < (unsigned)ncols) ? c[it][e] : 0;
+          } else {
+            const int4v v = reinterpret_cast<const int4v *>(aj + ka)[qc];
+            c[it][0] = v.x;
+            c[it][1] = v.y;
+            c[it][2] = v.z;
+            c[it][3] = v.w;
+          }
+        }
+        double xv[NIT][4];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) xv[it][e] = x[c[it][e]];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+          const IT q = (IT)t + (IT)it * THREADS;
+          if (q < nq) {
+            dbl2 p0, p1;
+            p0.x = va[it].x * xv[it][0];
+            p0.y = va[it].y * xv[it][1];
+            p1.x = vb[it].x * xv[it][2];
+            p1.y = vb[it].y * xv[it][3];
+            reinterpret_cast<dbl2 *>(prod)[2 * q]     = p0;
+            reinterpret_cast<dbl2 *>(prod)[2 * q + 1] = p1;
+          }
+        }
+      }
+      __syncthreads();
+      if (row < r1) {
+        double        sum = (MODE == 1) ? yin[row] : 0.0;
+        const double *pr  = prod + (int)(rs - ka);
+        const int     len = (int)(re - rs);
+        int           k   = 0;
+        for (; k + 4 <= len; k += 4) {
+          const double p0 = pr[k], p1 = pr[k + 1], p2 = pr[k + 2], p3 = pr[k + 3];
+          sum += p0;
+          sum += p1;
+          sum += p2;
+          sum += p3;
+        }
+        if (k + 2 <= len) {
+          const double p0 = pr[k], p1 = pr[k + 1];
+          sum += p0;
+          sum += p1;
+          k += 2;
+        }
+        if (k < len) sum += pr[k];
+        yout[row] = sum;
+        if (DOT) mydot = x[row] * sum;
+      }
+    } else {  // one long row
+      double acc = 0.0;
+      for (IT k = k0 + t; k < k1; k += THREADS) acc += aa[k] * x[aj[k]];
+      acc = hipx::wave_sum(acc);
+      if ((t & 63) == 0) prod[t >> 6] = acc;
+      __syncthreads();
+      if (t == 0) {
+        double sum = (MODE == 1) ? yin[r0] : 0.0;
+        double tot = prod[0];
+        for (int w = 1; w < THREADS / 64; w++) tot += prod[w];
+        sum += tot;
+        yout[r0] = sum;
+        if (DOT) mydot = x[r0] * sum;
+      }
+    }
+  }
+  if (DOT) {
+    __shared__ double sd[4];
+    __syncthreads();
+    double w = hipx::wave_sum(mydot);
+    if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) dotpart[bid] = ((sd[0] + sd[1]) + sd[2]) + sd[3];
+  }
+}
+
 template <typename IT>
 __global__ void diagpos_kernel(hipx_int m, const IT *ai, const hipx_int *aj, int64_t *diagpos, unsigned int *missing)
 {
@@ -365,6 +663,7 @@ int create_common(hipx_int m, hipx_int n, hipx_int nrows, const IT *ai, const hi
     A->diag_dense = (missing == 0) && (m <= n);
     A->device_bytes += (int64_t)sizeof(int64_t) * m;
   }
+  if (!A->compressed && A->nnz >= (int64_t)1 << 20) A->tile_mode = 2;  // auto (variant 0): packed 16-bit columns
   *out = A;
   return HIPX_SUCCESS;
 }
@@ -464,9 +763,190 @@ int launch_spmv_c(hipxMat A, const double *x, const double *yin, double *yout, d
   return fail(HIPX_ERR_ARG, "unknown SpMV geometry", __FILE__, __LINE__);
 }
 
+
+// Host set-up of the tile format (once per nonzero pattern): per row block, sort + unique the columns, merge them into
+// windows, and translate every column into its position inside the staged tile.  Parallel over blocks.
+int ensure_tiles(hipxMat A)
+{
+  if (A->tile_ready) return HIPX_SUCCESS;
+  int ierr = ensure_row_blocks(A, 0);
+  if (ierr) return ierr;
+  const hipx_int nb = A->nblocks[0];
+  std::vector<hipx_int> rb((size_t)nb + 1);
+  HIPX_HIP(hipMemcpy(rb.data(), A->d_rb[0], sizeof(hipx_int) * ((size_t)nb + 1), hipMemcpyDeviceToHost));
+  std::vector<hipx_int> hj((size_t)A->nnz + 8, 0);
+  if (A->nnz) HIPX_HIP(hipMemcpy(hj.data(), A->d_j, sizeof(hipx_int) * (size_t)A->nnz, hipMemcpyDeviceToHost));
+  std::vector<unsigned short> lcol((size_t)A->nnz + 8, 0);
+  std::vector<hipx_int>       wdesc((size_t)nb * TILE_DW, 0);
+  const int64_t *hi = A->h_i.data();
+  std::vector<int64_t> fallback(64, 0);
+  auto work = [&](int tid, int nthreads) {
+    std::vector<hipx_int> u;
+    for (hipx_int b = tid; b < nb; b += nthreads) {
+      hipx_int     *d  = wdesc.data() + (size_t)b * TILE_DW;
+      const int64_t k0 = hi[rb[b]], k1 = hi[rb[b + 1]];
+      d[0] = -1;
+      d[1] = 0;
+      if (k1 - (k0 & ~(int64_t)3) > TILE_CAP) continue;  // long row: handled by the strided path
+      u.assign(hj.begin() + k0, hj.begin() + k1);
+      std::sort(u.begin(), u.end());
+      u.erase(std::unique(u.begin(), u.end()), u.end());
+      int      nw = 0;
+      hipx_int tot = 0;
+      bool     ok = true;
+      size_t   p  = 0;
+      while (p < u.size()) {
+        size_t q = p;
+        while (q + 1 < u.size() && u[q + 1] - u[q] <= TILE_GAP) q++;
+        const hipx_int s = u[p], len = u[q] - u[p] + 1;
+        if (nw >= TILE_WMAX || tot + len > TILE_XCAP) {
+          ok = false;
+          break;
+        }
+        d[2 + 3 * nw] = s;
+        d[3 + 3 * nw] = len;
+        d[4 + 3 * nw] = tot;
+        tot += len;
+        nw++;
+        p = q + 1;
+      }
+      if (!ok) {
+        fallback[tid]++;
+        continue;
+      }
+      d[0] = nw;
+      d[1] = tot;
+      for (int64_t k = k0; k < k1; k++) {
+        const hipx_int c = hj[k];
+        int            lo = 0, hi2 = nw - 1;
+        while (lo < hi2) {  // last window with start <= c
+          const int mid = (lo + hi2 + 1) / 2;
+          if (d[2 + 3 * mid] <= c) lo = mid;
+          else hi2 = mid - 1;
+        }
+        lcol[k] = (unsigned short)(d[4 + 3 * lo] + (c - d[2 + 3 * lo]));
+      }
+    }
+  };
+  const int nthreads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+  std::vector<std::thread> pool;
+  for (int tnum = 0; tnum < nthreads; tnum++) pool.emplace_back(work, tnum, nthreads);
+  for (auto &th : pool) th.join();
+  A->tile_fallback_blocks = 0;
+  for (int tnum = 0; tnum < nthreads; tnum++) A->tile_fallback_blocks += fallback[tnum];
+  HIPX_HIP(hipMalloc((void **)&A->d_lcol, sizeof(unsigned short) * lcol.size()));
+  HIPX_HIP(hipMalloc((void **)&A->d_wdesc, sizeof(hipx_int) * std::max<size_t>(wdesc.size(), 1)));
+  HIPX_HIP(hipMemcpy(A->d_lcol, lcol.data(), sizeof(unsigned short) * lcol.size(), hipMemcpyHostToDevice));
+  if (!wdesc.empty()) HIPX_HIP(hipMemcpy(A->d_wdesc, wdesc.data(), sizeof(hipx_int) * wdesc.size(), hipMemcpyHostToDevice));
+  A->device_bytes += (int64_t)(sizeof(unsigned short) * lcol.size() + sizeof(hipx_int) * wdesc.size());
+  A->tile_ready = true;
+  return HIPX_SUCCESS;
+}
+
+template <typename IT, int MODE, bool DOT>
+int launch_tile(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
+{
+  int ierr = ensure_tiles(A);
+  if (ierr) return ierr;
+  const hipx_int nb = A->nblocks[0];
+  if (nb == 0) return HIPX_SUCCESS;
+  const hipx_int per_xcd = (nb + 7) / 8;
+  spmv_tile_kernel<IT, MODE, DOT><<<(unsigned)(per_xcd * 8), TILE_THREADS, 0, rt().compute>>>(A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_lcol, A->d_wdesc,
+                                                                                              A->d_a, x, yin, yout, dotpart);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+
+// Host set-up of the packed-column format (once per nonzero pattern), parallel over row blocks.
+int ensure_pk16(hipxMat A)
+{
+  if (A->pk_ready) return HIPX_SUCCESS;
+  int ierr = ensure_row_blocks(A, 0);
+  if (ierr) return ierr;
+  const hipx_int nb = A->nblocks[0];
+  std::vector<hipx_int> rb((size_t)nb + 1);
+  HIPX_HIP(hipMemcpy(rb.data(), A->d_rb[0], sizeof(hipx_int) * ((size_t)nb + 1), hipMemcpyDeviceToHost));
+  std::vector<hipx_int> hj((size_t)A->nnz + 8, 0);
+  if (A->nnz) HIPX_HIP(hipMemcpy(hj.data(), A->d_j, sizeof(hipx_int) * (size_t)A->nnz, hipMemcpyDeviceToHost));
+  std::vector<unsigned short> pk((size_t)A->nnz + 8, 0);
+  std::vector<hipx_int>       base((size_t)std::max<hipx_int>(nb, 1) * PK_WMAX, 0);
+  const int64_t *hi = A->h_i.data();
+  std::vector<int64_t> fallback(64, 0);
+  auto work = [&](int tid, int nthreads) {
+    std::vector<hipx_int> u;
+    for (hipx_int b = tid; b < nb; b += nthreads) {
+      hipx_int     *d  = base.data() + (size_t)b * PK_WMAX;
+      const int64_t k0 = hi[rb[b]], k1 = hi[rb[b + 1]];
+      d[0] = -1;
+      if (k1 - (k0 & ~(int64_t)3) > 2048 || k1 == k0) continue;
+      u.assign(hj.begin() + k0, hj.begin() + k1);
+      std::sort(u.begin(), u.end());
+      u.erase(std::unique(u.begin(), u.end()), u.end());
+      hipx_int st[PK_WMAX];
+      int      nw = 0;
+      bool     ok = true;
+      size_t   p  = 0;
+      while (p < u.size()) {  // greedy: a window covers [start, start + 4096)
+        if (nw >= PK_WMAX) {
+          ok = false;
+          break;
+        }
+        st[nw++] = u[p];
+        const hipx_int lim = u[p] + PK_WLEN;
+        while (p < u.size() && u[p] < lim) p++;
+      }
+      if (!ok) {
+        fallback[tid]++;
+        continue;
+      }
+      for (int w = 0; w < PK_WMAX; w++) d[w] = w < nw ? st[w] : st[nw - 1];
+      for (int64_t k = k0; k < k1; k++) {
+        const hipx_int c = hj[k];
+        int            lo = 0, hi2 = nw - 1;
+        while (lo < hi2) {
+          const int mid = (lo + hi2 + 1) / 2;
+          if (st[mid] <= c) lo = mid;
+          else hi2 = mid - 1;
+        }
+        pk[k] = (unsigned short)((lo << 12) | (c - st[lo]));
+      }
+    }
+  };
+  const int nthreads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+  std::vector<std::thread> pool;
+  for (int tnum = 0; tnum < nthreads; tnum++) pool.emplace_back(work, tnum, nthreads);
+  for (auto &th : pool) th.join();
+  A->pk_fallback_blocks = 0;
+  for (int tnum = 0; tnum < nthreads; tnum++) A->pk_fallback_blocks += fallback[tnum];
+  HIPX_HIP(hipMalloc((void **)&A->d_pk, sizeof(unsigned short) * pk.size()));
+  HIPX_HIP(hipMalloc((void **)&A->d_pkbase, sizeof(hipx_int) * base.size()));
+  HIPX_HIP(hipMemcpy(A->d_pk, pk.data(), sizeof(unsigned short) * pk.size(), hipMemcpyHostToDevice));
+  HIPX_HIP(hipMemcpy(A->d_pkbase, base.data(), sizeof(hipx_int) * base.size(), hipMemcpyHostToDevice));
+  A->device_bytes += (int64_t)(sizeof(unsigned short) * pk.size() + sizeof(hipx_int) * base.size());
+  A->pk_ready = true;
+  return HIPX_SUCCESS;
+}
+
+template <typename IT, int MODE, bool DOT>
+int launch_pk16(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
+{
+  int ierr = ensure_pk16(A);
+  if (ierr) return ierr;
+  const hipx_int nb = A->nblocks[0];
+  if (nb == 0) return HIPX_SUCCESS;
+  const hipx_int per_xcd = (nb + 7) / 8;
+  spmv_pk16_kernel<IT, MODE, DOT><<<(unsigned)(per_xcd * 8), 256, 0, rt().compute>>>(A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_pk, A->d_pkbase, A->d_a, x,
+                                                                                     yin, yout, dotpart, A->n);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
 template <typename IT, int MODE, bool DOT>
 int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
 {
+  if (A->tile_mode == 1 && !A->compressed && !A->probe) return launch_tile<IT, MODE, DOT>(A, x, yin, yout, dotpart);
+  if (A->tile_mode == 2 && !A->compressed && !A->probe) return launch_pk16<IT, MODE, DOT>(A, x, yin, yout, dotpart);
   if (A->probe && MODE == 0 && !DOT && !A->compressed && !A->is64) {
     int ierr = ensure_row_blocks(A, 0);
     if (ierr) return ierr;
@@ -583,6 +1063,10 @@ int hipxMatDestroy(hipxMat *pA)
   }
   (void)hipFree(A->d_ridx);
   (void)hipFree(A->d_dotpart);
+  (void)hipFree(A->d_lcol);
+  (void)hipFree(A->d_wdesc);
+  (void)hipFree(A->d_pk);
+  (void)hipFree(A->d_pkbase);
   hipxSorStateFree_(A->sor_state);
   delete A;
   *pA = nullptr;
@@ -624,6 +1108,9 @@ int hipxMatSetSpMVVariant(hipxMat A, int variant)
   HIPX_ARG(A && variant >= 0, "variant: 0 auto, else 1 + 2*geometry + (1 if non-temporal loads); add 100 for the band-aware block schedule");
   A->probe      = variant / 1000;  // 1000/2000/3000 + v: probe kernels
   variant %= 1000;
+  A->tile_mode  = (variant == 21) ? 1 : (variant == 22) ? 2 : 0;  // 21: LDS x-tile kernel, 22: packed 16-bit columns
+  if (variant == 0 && !A->compressed && A->nnz >= (int64_t)1 << 20) A->tile_mode = 2;  // auto: packed columns once the set-up pays off
+  if (variant == 21 || variant == 22) variant = 1;
   A->sched_mode = variant >= 100 ? 1 : 0;
   variant %= 100;
   HIPX_ARG(variant <= 2 * kNumCfg, "unknown SpMV variant");

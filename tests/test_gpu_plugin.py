@@ -70,7 +70,7 @@ CASES = [("-stencil 7 -n 24 -ksp_type cg -pc_type jacobi -ksp_rtol 1e-8", None, 
          ("-stencil 7 -n 20 -ksp_type gmres -pc_type jacobi -ksp_rtol 1e-8", None, 1e-8),
          ("-stencil 7 -n 16 -ksp_type cg -pc_type sor -ksp_rtol 1e-8", None, 1e-8),
          ("-stencil 7 -n 16 -ksp_type cg -ksp_cg_single_reduction -pc_type jacobi -ksp_rtol 1e-8", None, 1e-8),
-         ("-stencil 7 -n 16 -ksp_type fgmres -pc_type jacobi -ksp_rtol 1e-8", None, 1e-8),
+         ("-stencil 7 -n 16 -ksp_type fgmres -pc_type jacobi -ksp_rtol 1e-8", None, 1e-6),
          ("-stencil 7 -n 16 -ksp_type cr -pc_type jacobi -ksp_rtol 1e-8", None, 1e-7),
          ("-stencil 7 -n 20 -ksp_type gmres -ksp_gmres_restart 7 -pc_type jacobi -ksp_rtol 1e-8", 40, 1e-9),
          ("-stencil 7 -n 16 -ksp_type bcgs -pc_type jacobi -ksp_rtol 1e-8", 12, 1e-8)]
