@@ -85,9 +85,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=256, help="grid points per side")
+    ap.add_argument("--grid", dest="n", type=int, default=256, help="grid points per side (not --n: torchrun would read it as an abbreviation of its own options)")
     ap.add_argument("--stencil", type=int, default=7, choices=[7, 27])
-    ap.add_argument("--fused", type=int, default=0, help="1: fused SpMV+dot and AXPY+AXPY+PC+norm+dot kernels (same arithmetic)")
+    ap.add_argument("--fused", type=int, default=1, help="1 (default): fused SpMV+dot and AXPY+AXPY+PCJACOBI+norm+dot kernels -- same arithmetic and order per element, fewer HBM passes; 0: one kernel per reference Vec/Mat call (cg.c:249-344)")
     ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (0 auto, 1 plain loads, 2 non-temporal loads)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -96,6 +96,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("HIPX_ALL_RANKS_DEVICE0") == "1":  # debugging aid on a 1-GPU box: every rank drives GPU 0
+        local_rank = 0
     import torch
     dist = None
     if world > 1:
@@ -115,7 +117,7 @@ def main():
     ai, aj, aa = assemble(ks, args.stencil, n, rs, re)
     m = re - rs
     if world > 1:
-        idb = (C.c_char * 128)()
+        idb = (C.c_char * 256)()
         if rank == 0:
             _lib.chk(hx.hipxCommGetUniqueId(idb))
         box = [bytes(idb)]

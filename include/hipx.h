@@ -144,9 +144,10 @@ int hipxPCJacobiSetUp(hipxMat A, double *dinv);
 /* ---- multi-GPU: MPIAIJ ghost exchange (replaces VecScatterBegin/End vscat.c:1294,1353 on this path
         and PetscSFBcast{Begin,End}_Basic sfbasic.c:352-390) and scalar all-reduces
         (VecXDot_MPI_Default pvecimpl.h:105-111, VecNorm_MPI_Default pvecimpl.h:150-175) ------------- */
-#define HIPX_COMM_ID_BYTES 128
-int hipxCommGetUniqueId(void *id128);                         /* rank 0; broadcast the bytes yourself (MPI_Bcast / torch store) */
-int hipxCommInit(const void *id128, int rank, int nranks);    /* RCCL communicator on the comm stream */
+#define HIPX_COMM_ID_BYTES 256 /* two ncclUniqueId: one communicator for the ghost exchange (comm stream), one for the
+                                  scalar all-reduces (compute stream), so the two never serialise against each other */
+int hipxCommGetUniqueId(void *id256);                         /* rank 0; broadcast the bytes yourself (MPI_Bcast / torch store) */
+int hipxCommInit(const void *id256, int rank, int nranks);    /* RCCL communicators */
 int hipxCommFinalize(void);
 int hipxCommRank(int *rank, int *nranks);
 int hipxCommAllreduceSum(double *host_vals, int n);           /* n <= 64 doubles, device-staged ncclAllReduce */

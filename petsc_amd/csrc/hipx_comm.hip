@@ -20,7 +20,8 @@ namespace {
 
 struct Comm {
   bool       active = false;
-  ncclComm_t comm   = nullptr;
+  ncclComm_t comm   = nullptr;  // ghost exchange, comm stream
+  ncclComm_t rcomm  = nullptr;  // scalar all-reduces, compute stream
   int        rank = 0, nranks = 1;
   double    *d_red = nullptr;  // all-reduce staging
   double    *h_red = nullptr;  // pinned
@@ -55,25 +56,27 @@ struct hipxHalo_s {
 
 extern "C" {
 
-int hipxCommGetUniqueId(void *id128)
+int hipxCommGetUniqueId(void *id256)
 {
   HIPX_CHECK_INIT();
-  static_assert(NCCL_UNIQUE_ID_BYTES == HIPX_COMM_ID_BYTES, "unique id size");
-  ncclUniqueId id;
-  HIPX_NCCL(ncclGetUniqueId(&id));
-  memcpy(id128, &id, HIPX_COMM_ID_BYTES);
+  static_assert(2 * NCCL_UNIQUE_ID_BYTES == HIPX_COMM_ID_BYTES, "unique id size");
+  ncclUniqueId id[2];
+  HIPX_NCCL(ncclGetUniqueId(&id[0]));
+  HIPX_NCCL(ncclGetUniqueId(&id[1]));
+  memcpy(id256, id, HIPX_COMM_ID_BYTES);
   return HIPX_SUCCESS;
 }
 
-int hipxCommInit(const void *id128, int rank, int nranks)
+int hipxCommInit(const void *id256, int rank, int nranks)
 {
   HIPX_CHECK_INIT();
   Comm &c = cm();
   if (c.active) return HIPX_SUCCESS;
   HIPX_ARG(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank / nranks");
-  ncclUniqueId id;
-  memcpy(&id, id128, HIPX_COMM_ID_BYTES);
-  HIPX_NCCL(ncclCommInitRank(&c.comm, nranks, id, rank));
+  ncclUniqueId id[2];
+  memcpy(id, id256, HIPX_COMM_ID_BYTES);
+  HIPX_NCCL(ncclCommInitRank(&c.comm, nranks, id[0], rank));
+  HIPX_NCCL(ncclCommInitRank(&c.rcomm, nranks, id[1], rank));
   c.rank   = rank;
   c.nranks = nranks;
   HIPX_HIP(hipMalloc((void **)&c.d_red, sizeof(double) * 64));
@@ -88,6 +91,7 @@ int hipxCommFinalize(void)
   if (!c.active) return HIPX_SUCCESS;
   HIPX_HIP(hipDeviceSynchronize());
   HIPX_NCCL(ncclCommDestroy(c.comm));
+  HIPX_NCCL(ncclCommDestroy(c.rcomm));
   (void)hipFree(c.d_red);
   (void)hipHostFree(c.h_red);
   c = Comm();
@@ -111,7 +115,7 @@ int hipxCommAllreduceSum(double *vals, int n)
   hipStream_t s = rt().compute;
   memcpy(c.h_red, vals, sizeof(double) * (size_t)n);
   HIPX_HIP(hipMemcpyAsync(c.d_red, c.h_red, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
-  HIPX_NCCL(ncclAllReduce(c.d_red, c.d_red, (size_t)n, ncclDouble, ncclSum, c.comm, s));
+  HIPX_NCCL(ncclAllReduce(c.d_red, c.d_red, (size_t)n, ncclDouble, ncclSum, c.rcomm, s));
   HIPX_HIP(hipMemcpyAsync(c.h_red, c.d_red, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
   HIPX_HIP(hipStreamSynchronize(s));
   memcpy(vals, c.h_red, sizeof(double) * (size_t)n);

@@ -13,7 +13,7 @@ timeout 600 python bench.py --steps 100 --warmup 10 > gpurun_out/bench_v1.log 2>
 timeout 300 python bench.py --steps 100 --warmup 10 --variant 2 --no-cpu-baseline > gpurun_out/bench_v2nt.log 2>&1
 timeout 300 python bench.py --steps 100 --warmup 10 --fused 1 --no-cpu-baseline > gpurun_out/bench_fused.log 2>&1
 timeout 300 python bench.py --steps 100 --warmup 10 --fused 1 --variant 2 --no-cpu-baseline > gpurun_out/bench_fused_nt.log 2>&1
-timeout 300 python bench.py --steps 30 --warmup 5 --stencil 27 --n 128 --no-cpu-baseline > gpurun_out/bench_27.log 2>&1
+timeout 300 python bench.py --steps 30 --warmup 5 --stencil 27 --grid 128 --no-cpu-baseline > gpurun_out/bench_27.log 2>&1
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof1" -o r1 -- python "$GRAFT_REPO_ROOT/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/rocprof1.log" 2>&1
 cd "$GRAFT_REPO_ROOT"
 find gpurun_out/prof1 -name "*stats*" | head; ls -la gpurun_out/prof1/* | head -20

@@ -9,7 +9,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smok
 timeout 600 python bench.py > gpurun_out/bench11.log 2>&1
 timeout 300 python bench.py --fused 1 --no-cpu-baseline > gpurun_out/bench11_fused.log 2>&1
 timeout 300 python bench.py --variant 1 --no-cpu-baseline > gpurun_out/bench11_v1.log 2>&1
-timeout 300 python bench.py --stencil 27 --n 160 --no-cpu-baseline > gpurun_out/bench11_27.log 2>&1
+timeout 300 python bench.py --stencil 27 --grid 160 --no-cpu-baseline > gpurun_out/bench11_27.log 2>&1
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof11" -o stats -- python "$R/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > "$R/gpurun_out/rocprof11.log" 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/pmc11_fetch" -o pmc -- python "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$R/gpurun_out/pmc11_fetch.log" 2>&1

@@ -16,7 +16,7 @@ def test_single_rank_comm_allreduce_and_self_halo(hx):
     from petsc_amd import _lib
     from petsc_amd import dist as pdist
     _, ks = _lib.load()
-    idb = (C.c_char * 128)()
+    idb = (C.c_char * 256)()
     _lib.chk(hx.hipxCommGetUniqueId(idb))
     _lib.chk(hx.hipxCommInit(idb, 0, 1))
     v = (C.c_double * 3)(1.5, -2.0, 7.0)
