@@ -247,17 +247,9 @@ __global__ __launch_bounds__(SPMV_THREADS) void spmv_stream_kernel(const hipx_in
       }
     }
   }
-  if (DOT) {
-    __shared__ double sd[SPMV_THREADS / 64];
-    __syncthreads();
-    double w = hipx::wave_sum(mydot);
-    if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = w;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double tot = sd[0];
-      for (int w = 1; w < SPMV_THREADS / 64; w++) tot += sd[w];
-      dotpart[bid] = tot;
-    }
+  if (DOT) {  // one partial per WAVE, no barrier: the workgroup retires as soon as its rows are written
+    const double w = hipx::wave_sum(mydot);
+    if ((threadIdx.x & 63) == 0) dotpart[(size_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6)] = w;
   }
 }
 
@@ -401,17 +393,9 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const hipx_int 
       }
     }
   }
-  if (DOT) {
-    __shared__ double sd[TILE_THREADS / 64];
-    __syncthreads();
-    double w = hipx::wave_sum(mydot);
-    if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = w;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double tot = sd[0];
-      for (int k = 1; k < TILE_THREADS / 64; k++) tot += sd[k];
-      dotpart[bid] = tot;
-    }
+  if (DOT) {  // one partial per WAVE, no barrier: the workgroup retires as soon as its rows are written
+    const double w = hipx::wave_sum(mydot);
+    if ((threadIdx.x & 63) == 0) dotpart[(size_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6)] = w;
   }
 }
 
@@ -446,6 +430,7 @@ __global__ __launch_bounds__(256) void spmv_pk16_kernel(const hipx_int *__restri
       rs = ai[row];
       re = ai[row + 1];
     }
+    const double xrow = (DOT && row < r1) ? x[row] : 0.0;  // early: see spmv_pk16r_kernel
     const int base_reg = pkbase[(size_t)b * PK_WMAX + (t & (PK_WMAX - 1))];  // lanes 0..15 of each wave hold the window starts
     const int packed   = __shfl(base_reg, 0, 64) >= 0;                          // wave-uniform: slot 0 is -1 for fallback blocks
     if ((k1 - ka) <= (IT)CAP) {
@@ -520,7 +505,7 @@ __global__ __launch_bounds__(256) void spmv_pk16_kernel(const hipx_int *__restri
         }
         if (k < len) sum += pr[k];
         yout[row] = sum;
-        if (DOT) mydot = x[row] * sum;
+        if (DOT) mydot = xrow * sum;
       }
     } else {  // one long row
       double acc = 0.0;
@@ -538,13 +523,152 @@ __global__ __launch_bounds__(256) void spmv_pk16_kernel(const hipx_int *__restri
       }
     }
   }
-  if (DOT) {
-    __shared__ double sd[4];
-    __syncthreads();
-    double w = hipx::wave_sum(mydot);
-    if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = w;
-    __syncthreads();
-    if (threadIdx.x == 0) dotpart[bid] = ((sd[0] + sd[1]) + sd[2]) + sd[3];
+  if (DOT) {  // one partial per WAVE, no barrier: the workgroup retires as soon as its rows are written
+    const double w = hipx::wave_sum(mydot);
+    if ((threadIdx.x & 63) == 0) dotpart[(size_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6)] = w;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Packed-column SpMV, row-parallel gather ("pk16r").  Phase 1 only moves the block's values and 16-bit column codes
+// into LDS (coalesced 32 B + 8 B per lane); phase 2 lets thread t walk row t left to right: value and code from LDS,
+// x through the hardware gather.  Because neighbouring lanes now hold neighbouring ROWS, the k-th gather of a wave
+// touches x[row + offset_k] for 64 consecutive rows -- 4-5 cache lines instead of the ~20 that the nonzero-major
+// order of spmv_pk16_kernel spreads one gather instruction over (7 stencil offsets interleaved across the lanes).
+// Same products, same left-to-right sums: y is bit-identical.  Blocks without a packed code keep the pk16 path.
+template <typename IT, int MODE, bool DOT>
+__global__ __launch_bounds__(256) void spmv_pk16r_kernel(const hipx_int *__restrict__ rb, hipx_int nblocks, hipx_int blocks_per_xcd, const IT *__restrict__ ai,
+                                                         const hipx_int *__restrict__ aj, const unsigned short *__restrict__ pk, const hipx_int *__restrict__ pkbase,
+                                                         const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout, double *dotpart, hipx_int ncols)
+{
+  constexpr int THREADS = 256, CAP = 2048;
+  __shared__ double         vals[CAP];
+  __shared__ unsigned short codes[CAP];
+  const hipx_int bid = (hipx_int)blockIdx.x;
+  const hipx_int b   = (bid & 7) * blocks_per_xcd + (bid >> 3);
+  double         mydot = 0.0;
+  if (b < nblocks) {
+    const hipx_int r0 = rb[b], r1 = rb[b + 1];
+    const IT       k0 = ai[r0], k1 = ai[r1];
+    const IT       ka = k0 & ~(IT)3;
+    const int      t  = threadIdx.x;
+    const hipx_int row = r0 + t;
+    IT             rs = 0, re = 0;
+    if (row < r1) {
+      rs = ai[row];
+      re = ai[row + 1];
+    }
+    // x[row] for the fused dot is fetched NOW: issued at the tail it would add one memory round trip to the life of every
+    // wave (262k waves / 8k resident = 32 generations x ~1 us = the 32 us the fused kernel used to lose)
+    const double xrow = (DOT && row < r1) ? x[row] : 0.0;
+    const int base_reg = pkbase[(size_t)b * PK_WMAX + (t & (PK_WMAX - 1))];
+    const int packed   = __shfl(base_reg, 0, 64) >= 0;
+    if ((k1 - ka) <= (IT)CAP) {
+      const IT      nq  = (k1 - ka + 3) >> 2;
+      constexpr int NIT = CAP / 4 / THREADS;
+      if (packed) {
+        if (nq > 0) {
+          const dbl2     *a2 = reinterpret_cast<const dbl2 *>(aa + ka);
+          const ushort4v *c4 = reinterpret_cast<const ushort4v *>(pk + ka);
+          dbl2            va[NIT], vb[NIT];
+          ushort4v        vc[NIT];
+#pragma unroll
+          for (int it = 0; it < NIT; it++) {
+            const IT q  = (IT)t + (IT)it * THREADS;
+            const IT qc = q < nq ? q : nq - 1;
+            va[it]      = a2[2 * qc];
+            vb[it]      = a2[2 * qc + 1];
+            vc[it]      = c4[qc];
+          }
+#pragma unroll
+          for (int it = 0; it < NIT; it++) {
+            const IT q = (IT)t + (IT)it * THREADS;
+            if (q < nq) {
+              reinterpret_cast<dbl2 *>(vals)[2 * q]     = va[it];
+              reinterpret_cast<dbl2 *>(vals)[2 * q + 1] = vb[it];
+              reinterpret_cast<ushort4v *>(codes)[q]    = vc[it];
+            }
+          }
+        }
+        __syncthreads();
+        // all 64 lanes of a wave run the shuffle loop the same number of times (wave-max row length): __shfl needs
+        // the source lanes (0..15, which hold the window starts) active
+        const int len = (row < r1) ? (int)(re - rs) : 0;
+        int       maxlen = len;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+        const int s0  = (int)(rs - ka);
+        double    sum = (MODE == 1 && row < r1) ? yin[row] : 0.0;
+        for (int k = 0; k < maxlen; k += 4) {
+          double xv[4], av[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const bool     on   = (k + e) < len;
+            const int      idx  = on ? s0 + k + e : 0;
+            const unsigned code = codes[idx];
+            const int      col  = __shfl(base_reg, code >> 12, 64) + (int)(code & 0xfff);
+            av[e]               = vals[idx];
+            xv[e]               = on ? x[col] : 0.0;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            if ((k + e) < len) sum += av[e] * xv[e];
+        }
+        if (row < r1) {
+          yout[row] = sum;
+          if (DOT) mydot = xrow * sum;
+        }
+      } else {
+        // 32-bit columns: products staged in LDS (the spmv_stream_kernel path)
+        double *prod = vals;
+        if (nq > 0) {
+          const dbl2 *a2 = reinterpret_cast<const dbl2 *>(aa + ka);
+#pragma unroll
+          for (int it = 0; it < NIT; it++) {
+            const IT q = (IT)t + (IT)it * THREADS;
+            if (q < nq) {
+              const dbl2  v0 = a2[2 * q], v1 = a2[2 * q + 1];
+              const int4v c  = reinterpret_cast<const int4v *>(aj + ka)[q];
+              dbl2        p0, p1;
+              p0.x = v0.x * x[c.x];
+              p0.y = v0.y * x[c.y];
+              p1.x = v1.x * x[c.z];
+              p1.y = v1.y * x[c.w];
+              reinterpret_cast<dbl2 *>(prod)[2 * q]     = p0;
+              reinterpret_cast<dbl2 *>(prod)[2 * q + 1] = p1;
+            }
+          }
+        }
+        __syncthreads();
+        if (row < r1) {
+          double        sum = (MODE == 1) ? yin[row] : 0.0;
+          const double *pr  = prod + (int)(rs - ka);
+          const int     len = (int)(re - rs);
+          for (int k = 0; k < len; k++) sum += pr[k];
+          yout[row] = sum;
+          if (DOT) mydot = xrow * sum;
+        }
+      }
+    } else {  // one long row
+      double acc = 0.0;
+      for (IT k = k0 + t; k < k1; k += THREADS) acc += aa[k] * x[aj[k]];
+      acc = hipx::wave_sum(acc);
+      if ((t & 63) == 0) vals[t >> 6] = acc;
+      __syncthreads();
+      if (t == 0) {
+        double sum = (MODE == 1) ? yin[r0] : 0.0;
+        double tot = vals[0];
+        for (int w = 1; w < THREADS / 64; w++) tot += vals[w];
+        sum += tot;
+        yout[r0] = sum;
+        if (DOT) mydot = x[r0] * sum;
+      }
+    }
+  }
+  if (DOT) {  // one partial per WAVE, no barrier: the workgroup retires as soon as its rows are written
+    const double w = hipx::wave_sum(mydot);
+    if ((threadIdx.x & 63) == 0) dotpart[(size_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6)] = w;
   }
 }
 
@@ -599,6 +723,16 @@ void build_row_blocks(hipx_int nrows, const int64_t *ai, int cfg, std::vector<hi
     rb.push_back(r1);
     r = r1;
   }
+}
+
+// variant 0 (auto): packed 16-bit columns once the host set-up pays off (>= 2^20 nonzeros); short rows (<= 16 entries on
+// average: every thread of a block owns a row) use the row-parallel gather, longer rows the product-staging kernel.
+// Measured on MI355X: 7-pt 256^3 0.302 (row-parallel) / 0.319 (staged) / 0.346 ms (32-bit columns); 27-pt 128^3
+// 0.155 / 0.128 / 0.139 ms.
+int auto_tile_mode(hipxMat A)
+{
+  if (A->compressed || A->nnz < ((int64_t)1 << 20) || A->nrows_c <= 0) return 0;
+  return (A->nnz <= (int64_t)16 * A->nrows_c) ? 3 : 2;
 }
 
 template <typename IT>
@@ -663,7 +797,7 @@ int create_common(hipx_int m, hipx_int n, hipx_int nrows, const IT *ai, const hi
     A->diag_dense = (missing == 0) && (m <= n);
     A->device_bytes += (int64_t)sizeof(int64_t) * m;
   }
-  if (!A->compressed && A->nnz >= (int64_t)1 << 20) A->tile_mode = 2;  // auto (variant 0): packed 16-bit columns
+  A->tile_mode = auto_tile_mode(A);  // variant 0
   *out = A;
   return HIPX_SUCCESS;
 }
@@ -936,8 +1070,12 @@ int launch_pk16(hipxMat A, const double *x, const double *yin, double *yout, dou
   const hipx_int nb = A->nblocks[0];
   if (nb == 0) return HIPX_SUCCESS;
   const hipx_int per_xcd = (nb + 7) / 8;
-  spmv_pk16_kernel<IT, MODE, DOT><<<(unsigned)(per_xcd * 8), 256, 0, rt().compute>>>(A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_pk, A->d_pkbase, A->d_a, x,
-                                                                                     yin, yout, dotpart, A->n);
+  if (A->tile_mode == 3)
+    spmv_pk16r_kernel<IT, MODE, DOT><<<(unsigned)(per_xcd * 8), 256, 0, rt().compute>>>(A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_pk, A->d_pkbase, A->d_a, x,
+                                                                                        yin, yout, dotpart, A->n);
+  else
+    spmv_pk16_kernel<IT, MODE, DOT><<<(unsigned)(per_xcd * 8), 256, 0, rt().compute>>>(A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_pk, A->d_pkbase, A->d_a, x,
+                                                                                       yin, yout, dotpart, A->n);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -946,7 +1084,7 @@ template <typename IT, int MODE, bool DOT>
 int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
 {
   if (A->tile_mode == 1 && !A->compressed && !A->probe) return launch_tile<IT, MODE, DOT>(A, x, yin, yout, dotpart);
-  if (A->tile_mode == 2 && !A->compressed && !A->probe) return launch_pk16<IT, MODE, DOT>(A, x, yin, yout, dotpart);
+  if (A->tile_mode >= 2 && !A->compressed && !A->probe) return launch_pk16<IT, MODE, DOT>(A, x, yin, yout, dotpart);
   if (A->probe && MODE == 0 && !DOT && !A->compressed && !A->is64) {
     int ierr = ensure_row_blocks(A, 0);
     if (ierr) return ierr;
@@ -970,7 +1108,8 @@ int dot_partials_count(hipxMat A)
   int  cfg;
   bool nt;
   decode_variant(A->variant, cfg, nt);
-  return (int)(((A->nblocks[cfg] + 7) / 8) * 8);
+  const int waves = (A->tile_mode ? 256 : kCfg[cfg].threads) / 64;
+  return (int)(((A->nblocks[A->tile_mode ? 0 : cfg] + 7) / 8) * 8) * waves;
 }
 
 template <int MODE, bool DOT>
@@ -1108,9 +1247,9 @@ int hipxMatSetSpMVVariant(hipxMat A, int variant)
   HIPX_ARG(A && variant >= 0, "variant: 0 auto, else 1 + 2*geometry + (1 if non-temporal loads); add 100 for the band-aware block schedule");
   A->probe      = variant / 1000;  // 1000/2000/3000 + v: probe kernels
   variant %= 1000;
-  A->tile_mode  = (variant == 21) ? 1 : (variant == 22) ? 2 : 0;  // 21: LDS x-tile kernel, 22: packed 16-bit columns
-  if (variant == 0 && !A->compressed && A->nnz >= (int64_t)1 << 20) A->tile_mode = 2;  // auto: packed columns once the set-up pays off
-  if (variant == 21 || variant == 22) variant = 1;
+  A->tile_mode  = (variant == 21) ? 1 : (variant == 22) ? 2 : (variant == 23) ? 3 : 0;  // 21: LDS x-tile, 22: packed columns, 23: packed + row-parallel gather
+  if (variant == 0) A->tile_mode = auto_tile_mode(A);
+  if (variant >= 21 && variant <= 23) variant = 1;
   A->sched_mode = variant >= 100 ? 1 : 0;
   variant %= 100;
   HIPX_ARG(variant <= 2 * kNumCfg, "unknown SpMV variant");
