@@ -151,6 +151,9 @@ int hipxCommInit(const void *id256, int rank, int nranks);    /* RCCL communicat
 int hipxCommFinalize(void);
 int hipxCommRank(int *rank, int *nranks);
 int hipxCommAllreduceSum(double *host_vals, int n);           /* n <= 64 doubles, device-staged ncclAllReduce */
+/* VecTDot_MPI / VecMDot_MPI (pvecimpl.h:97-111) in one stream-ordered chain: local dot kernel(s) -> ncclAllReduce on the
+   result words -> host notification; the host waits once, after the all-reduce.  nv <= 8.  Single rank: plain local dots. */
+int hipxVecMDotAllreduce(const double *x, hipx_int nv, const double *const *y, hipx_int n, double *results);
 
 typedef struct hipxHalo_s *hipxHalo;
 /* nsend/nrecv neighbours; send_idx = local indices of owned entries to pack per neighbour (concatenated,

@@ -11,6 +11,7 @@
 //     MatMultAdd wait for the receive (the mpiaij.c:1056-1059 shape with stream-level overlap).
 #include "hipx_internal.h"
 #include <rccl/rccl.h>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -120,6 +121,25 @@ int hipxCommAllreduceSum(double *vals, int n)
   HIPX_HIP(hipStreamSynchronize(s));
   memcpy(vals, c.h_red, sizeof(double) * (size_t)n);
   return HIPX_SUCCESS;
+}
+
+int hipxVecMDotAllreduce(const double *x, hipx_int nv, const double *const *y, hipx_int n, double *results)
+{
+  HIPX_CHECK_INIT();
+  Comm &c = cm();
+  HIPX_ARG(nv >= 1 && nv <= 8, "1 <= nv <= 8");
+  static const bool force = getenv("HIPX_FORCE_ALLREDUCE") != nullptr;  // test hook: run the chain on a 1-rank communicator too
+  if (!c.active || (c.nranks == 1 && !force)) return hipxVecMDot(x, nv, y, n, results);
+  const int slot = HIPX_MAX_RED_SLOTS - 2;  // reserved for this chain
+  if (n > 0) {
+    int ierr = launch_mdot_nosignal(x, (int)nv, y, n, slot);
+    if (ierr) return ierr;
+  } else HIPX_HIP(hipMemsetAsync(slot_results_dev(slot), 0, sizeof(double) * (size_t)nv, rt().compute));  // rank without rows
+  // the result words live in pinned, device-mapped host memory: RCCL reduces them in place
+  HIPX_NCCL(ncclAllReduce(slot_results_dev(slot), slot_results_dev(slot), (size_t)nv, ncclDouble, ncclSum, c.rcomm, rt().compute));
+  int ierr = red_signal(slot);
+  if (ierr) return ierr;
+  return red_wait(slot, (int)nv, results);
 }
 
 int hipxHaloCreate(int nsend, const int *send_ranks, const hipx_int *send_off, const hipx_int *send_idx, int nrecv, const int *recv_ranks, const hipx_int *recv_off,

@@ -46,13 +46,16 @@ struct RedOut {
   unsigned int       *ticket;
   double             *results;
   unsigned long long *flag;
-  unsigned long long  seq;
+  unsigned long long  seq;  // 0: do not signal (a later stage on the stream -- all-reduce + hipx::red_signal -- will)
 };
-inline RedOut red_out(int slot)
+inline RedOut red_out(int slot, bool signal = true)
 {
   Runtime &r = rt();
-  return RedOut{slot_partials(slot), r.d_tickets + slot, slot_results_dev(slot), r.d_flags + slot, ++r.seq[slot]};
+  return RedOut{slot_partials(slot), r.d_tickets + slot, slot_results_dev(slot), r.d_flags + slot, signal ? ++r.seq[slot] : 0ull};
 }
+// multi-GPU reductions without a host round trip between the local kernel and the all-reduce (hipx_comm.hip)
+int launch_mdot_nosignal(const double *x, int nv, const double *const *y, hipx_int n, int slot);
+int red_signal(int slot);  // enqueue: publish the slot's results to the host (sequence flag), stream-ordered
 int red_wait(int slot, int nvals, double *out);
 
 }  // namespace hipx

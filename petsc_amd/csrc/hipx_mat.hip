@@ -51,6 +51,9 @@ struct hipxMat_s {
   unsigned short *d_pk      = nullptr;   // (window id << 12) | offset inside the window
   hipx_int      *d_pkbase   = nullptr;   // PK_WMAX window starts per row block (-1 in slot 0 = block keeps 32-bit columns)
   int64_t        pk_fallback_blocks = 0;
+  bool           pk_all_packed = false;   // every row block packed and tile-sized: the persistent kernel applies
+  void          *d_pkblk = nullptr;       // PkBlk per row block
+  int            persist_wg_per_cu = 4;
   int64_t        tile_fallback_blocks = 0;
   int       probe      = 0;   // phase-attribution probe kernels (scripts/spmv_variants.py); results are NOT A x
   std::vector<int64_t> h_i;  // host copy of the row offsets (set-up only)
@@ -672,6 +675,122 @@ __global__ __launch_bounds__(256) void spmv_pk16r_kernel(const hipx_int *__restr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent, software-pipelined form of spmv_pk16r_kernel ("pk16p").  A workgroup's life in the one-shot kernels is a
+// chain of dependent round trips (block header -> value/code stream -> barrier -> x gather -> row sums -> store); with
+// 8 workgroups per CU the chip spends 32 "generations" of ~9 us on 7-pt 256^3, i.e. it is latency-paced.  Here a
+// persistent workgroup walks a contiguous run of row blocks and keeps the NEXT block's header, values and codes in
+// flight (registers) while it gathers x and sums the rows of the CURRENT block out of a double-buffered LDS tile:
+// the HBM stream never waits for the gather.  One barrier per row block.  Requires every block to be packed and to fit
+// the tile (no long rows); otherwise the launcher falls back to spmv_pk16r_kernel.  Bit-identical y.
+struct PkBlk {        // per row block, precomputed on the host
+  hipx_int r0, nrows; // first row, number of rows
+  hipx_int nq, pad;   // quads to stream (from the 32-byte aligned start)
+  int64_t  ka;        // aligned start in a[] / pk[]
+};
+
+template <typename IT, int MODE, bool DOT>
+__global__ __launch_bounds__(256) void spmv_pk16p_kernel(const PkBlk *__restrict__ blk, hipx_int nblocks, hipx_int blocks_per_xcd, hipx_int chunk, const IT *__restrict__ ai,
+                                                         const unsigned short *__restrict__ pk, const hipx_int *__restrict__ pkbase, const double *__restrict__ aa,
+                                                         const double *__restrict__ x, const double *yin, double *yout, double *dotpart)
+{
+  constexpr int THREADS = 256, CAP = 2048, NIT = CAP / 4 / THREADS;
+  __shared__ double         vals[2][CAP];
+  __shared__ unsigned short codes[2][CAP];
+  const int      t   = threadIdx.x;
+  const hipx_int bid = (hipx_int)blockIdx.x;
+  // XCD-aware: hardware block bid runs on XCD bid % 8; each XCD owns one contiguous slab of row blocks, each persistent
+  // workgroup one contiguous chunk of that slab
+  const hipx_int xcd = bid & 7, l = bid >> 3;
+  hipx_int       it  = xcd * blocks_per_xcd + l * chunk;
+  hipx_int       end = it + chunk;
+  const hipx_int slab_end = min(nblocks, (xcd + 1) * blocks_per_xcd);
+  if (end > slab_end) end = slab_end;
+  double mydot = 0.0;
+  // ---- prologue: first block's stream into registers
+  dbl2     va[NIT], vb[NIT];
+  ushort4v vc[NIT];
+  PkBlk    nb;
+  IT       nrs = 0, nre = 0;
+  int      nbase = 0;
+  double   nxrow = 0.0, nyin = 0.0;
+  auto prefetch = [&](hipx_int b) {
+    nb = blk[b];
+    const dbl2     *a2 = reinterpret_cast<const dbl2 *>(aa + nb.ka);
+    const ushort4v *c4 = reinterpret_cast<const ushort4v *>(pk + nb.ka);
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+      const hipx_int q  = t + k * THREADS;
+      const hipx_int qc = q < nb.nq ? q : (nb.nq > 0 ? nb.nq - 1 : 0);
+      va[k]             = a2[2 * qc];
+      vb[k]             = a2[2 * qc + 1];
+      vc[k]             = c4[qc];
+    }
+    nrs = nre = 0;
+    if (t < nb.nrows) {
+      nrs = ai[nb.r0 + t];
+      nre = ai[nb.r0 + t + 1];
+      if (DOT) nxrow = x[nb.r0 + t];
+      if (MODE == 1) nyin = yin[nb.r0 + t];
+    }
+    nbase = pkbase[(size_t)b * PK_WMAX + (t & (PK_WMAX - 1))];
+  };
+  if (it < end) prefetch(it);
+  int buf = 0;
+  while (it < end) {
+    // ---- current block: registers -> LDS
+    const PkBlk cb    = nb;
+    const IT    rs    = nrs, re = nre;
+    const int   base_reg = nbase;
+    const double xrow = nxrow, y0 = nyin;
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+      const hipx_int q = t + k * THREADS;
+      if (q < cb.nq) {
+        reinterpret_cast<dbl2 *>(vals[buf])[2 * q]     = va[k];
+        reinterpret_cast<dbl2 *>(vals[buf])[2 * q + 1] = vb[k];
+        reinterpret_cast<ushort4v *>(codes[buf])[q]    = vc[k];
+      }
+    }
+    __syncthreads();
+    // ---- next block's stream goes in flight now and lands while this block gathers and sums
+    if (it + 1 < end) prefetch(it + 1);
+    const bool live = t < cb.nrows;
+    const int  len  = live ? (int)(re - rs) : 0;
+    int        maxlen = len;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+    const int s0  = (int)((int64_t)rs - cb.ka);
+    double    sum = (MODE == 1) ? y0 : 0.0;
+    for (int k = 0; k < maxlen; k += 4) {
+      double xv[4], av[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const bool     on   = (k + e) < len;
+        const int      idx  = on ? s0 + k + e : 0;
+        const unsigned code = codes[buf][idx];
+        const int      col  = __shfl(base_reg, code >> 12, 64) + (int)(code & 0xfff);
+        av[e]               = vals[buf][idx];
+        xv[e]               = on ? x[col] : 0.0;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if ((k + e) < len) sum += av[e] * xv[e];
+    }
+    if (live) {
+      yout[cb.r0 + t] = sum;
+      if (DOT) mydot += xrow * sum;
+    }
+    buf ^= 1;
+    it++;
+  }
+  if (DOT) {
+    const double w = hipx::wave_sum(mydot);
+    if ((threadIdx.x & 63) == 0) dotpart[(size_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6)] = w;
+  }
+}
+
 template <typename IT>
 __global__ void diagpos_kernel(hipx_int m, const IT *ai, const hipx_int *aj, int64_t *diagpos, unsigned int *missing)
 {
@@ -1053,6 +1172,27 @@ int ensure_pk16(hipxMat A)
   for (auto &th : pool) th.join();
   A->pk_fallback_blocks = 0;
   for (int tnum = 0; tnum < nthreads; tnum++) A->pk_fallback_blocks += fallback[tnum];
+  {
+    std::vector<PkBlk> bm((size_t)std::max<hipx_int>(nb, 1));
+    bool all = true;
+    for (hipx_int b = 0; b < nb; b++) {
+      const int64_t k0 = hi[rb[b]], k1 = hi[rb[b + 1]], ka = k0 & ~(int64_t)3;
+      bm[b].r0    = rb[b];
+      bm[b].nrows = rb[b + 1] - rb[b];
+      bm[b].nq    = (hipx_int)((k1 - ka + 3) >> 2);
+      bm[b].pad   = 0;
+      bm[b].ka    = ka;
+      if (k1 - ka > 2048) all = false;                         // long row
+      if (k1 > k0 && base[(size_t)b * PK_WMAX] < 0) all = false;  // block kept its 32-bit columns
+      if (k1 == k0) {  // empty block: give it harmless window starts so the persistent kernel can treat it as packed
+        for (int w = 0; w < PK_WMAX; w++) base[(size_t)b * PK_WMAX + w] = 0;
+      }
+    }
+    A->pk_all_packed = all && A->pk_fallback_blocks == 0;
+    HIPX_HIP(hipMalloc(&A->d_pkblk, sizeof(PkBlk) * bm.size()));
+    HIPX_HIP(hipMemcpy(A->d_pkblk, bm.data(), sizeof(PkBlk) * bm.size(), hipMemcpyHostToDevice));
+    A->device_bytes += (int64_t)(sizeof(PkBlk) * bm.size());
+  }
   HIPX_HIP(hipMalloc((void **)&A->d_pk, sizeof(unsigned short) * pk.size()));
   HIPX_HIP(hipMalloc((void **)&A->d_pkbase, sizeof(hipx_int) * base.size()));
   HIPX_HIP(hipMemcpy(A->d_pk, pk.data(), sizeof(unsigned short) * pk.size(), hipMemcpyHostToDevice));
@@ -1070,7 +1210,12 @@ int launch_pk16(hipxMat A, const double *x, const double *yin, double *yout, dou
   const hipx_int nb = A->nblocks[0];
   if (nb == 0) return HIPX_SUCCESS;
   const hipx_int per_xcd = (nb + 7) / 8;
-  if (A->tile_mode == 3)
+  if (A->tile_mode == 4 && A->pk_all_packed) {
+    const hipx_int wg    = 32 * A->persist_wg_per_cu;                    // persistent workgroups per XCD
+    const hipx_int chunk = (per_xcd + wg - 1) / wg;
+    spmv_pk16p_kernel<IT, MODE, DOT><<<(unsigned)(wg * 8), 256, 0, rt().compute>>>((const PkBlk *)A->d_pkblk, nb, per_xcd, chunk, (const IT *)A->d_i, A->d_pk, A->d_pkbase,
+                                                                                  A->d_a, x, yin, yout, dotpart);
+  } else if (A->tile_mode >= 3)
     spmv_pk16r_kernel<IT, MODE, DOT><<<(unsigned)(per_xcd * 8), 256, 0, rt().compute>>>(A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_pk, A->d_pkbase, A->d_a, x,
                                                                                         yin, yout, dotpart, A->n);
   else
@@ -1109,7 +1254,8 @@ int dot_partials_count(hipxMat A)
   bool nt;
   decode_variant(A->variant, cfg, nt);
   const int waves = (A->tile_mode ? 256 : kCfg[cfg].threads) / 64;
-  return (int)(((A->nblocks[A->tile_mode ? 0 : cfg] + 7) / 8) * 8) * waves;
+  const int grid  = (int)(((A->nblocks[A->tile_mode ? 0 : cfg] + 7) / 8) * 8);
+  return std::max(grid, 8 * 32 * 8) * waves;  // also covers the persistent kernel's fixed grid (<= 8 workgroups per CU)
 }
 
 template <int MODE, bool DOT>
@@ -1206,6 +1352,7 @@ int hipxMatDestroy(hipxMat *pA)
   (void)hipFree(A->d_wdesc);
   (void)hipFree(A->d_pk);
   (void)hipFree(A->d_pkbase);
+  (void)hipFree(A->d_pkblk);
   hipxSorStateFree_(A->sor_state);
   delete A;
   *pA = nullptr;
@@ -1247,9 +1394,14 @@ int hipxMatSetSpMVVariant(hipxMat A, int variant)
   HIPX_ARG(A && variant >= 0, "variant: 0 auto, else 1 + 2*geometry + (1 if non-temporal loads); add 100 for the band-aware block schedule");
   A->probe      = variant / 1000;  // 1000/2000/3000 + v: probe kernels
   variant %= 1000;
-  A->tile_mode  = (variant == 21) ? 1 : (variant == 22) ? 2 : (variant == 23) ? 3 : 0;  // 21: LDS x-tile, 22: packed columns, 23: packed + row-parallel gather
+  A->tile_mode  = (variant == 21) ? 1 : (variant == 22) ? 2 : (variant == 23) ? 3 : (variant >= 24 && variant <= 29) ? 4 : 0;
+  // 21: LDS x-tile, 22: packed columns, 23: packed + row-parallel gather, 24..29: persistent pipelined form with 4, 1, 2, 3, 5, 6 workgroups per CU
+  if (variant >= 24 && variant <= 29) {
+    static const int wgs[6] = {4, 1, 2, 3, 5, 6};
+    A->persist_wg_per_cu   = wgs[variant - 24];
+  }
   if (variant == 0) A->tile_mode = auto_tile_mode(A);
-  if (variant >= 21 && variant <= 23) variant = 1;
+  if (variant >= 21 && variant <= 29) variant = 1;
   A->sched_mode = variant >= 100 ? 1 : 0;
   variant %= 100;
   HIPX_ARG(variant <= 2 * kNumCfg, "unknown SpMV variant");
@@ -1297,6 +1449,7 @@ int hipxMatMultDot(hipxMat A, const double *x, double *y, double *dot)
   const hipx_int npart = dot_partials_count(A);
   if (!npart) return HIPX_SUCCESS;
   if (!A->d_dotpart) HIPX_HIP(hipMalloc((void **)&A->d_dotpart, sizeof(double) * (size_t)npart));
+  HIPX_HIP(hipMemsetAsync(A->d_dotpart, 0, sizeof(double) * (size_t)npart, rt().compute));  // grids differ per kernel form: unwritten partials must be 0
   int ierr = launch_spmv<0, true>(A, x, nullptr, y, A->d_dotpart);
   if (ierr) return ierr;
   return hipxVecSum(A->d_dotpart, npart, dot);

@@ -88,7 +88,7 @@ __device__ __forceinline__ void block_finish(double (&acc)[NV], RedOut out)
   if (threadIdx.x == 0) {
     *ticket = 0u;  // re-arm for the next launch on this slot (stream-ordered)
     __threadfence_system();  // results before flag, visible to the host
-    __hip_atomic_store(out.flag, out.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (out.seq) __hip_atomic_store(out.flag, out.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

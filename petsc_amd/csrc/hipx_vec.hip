@@ -514,6 +514,8 @@ inline unsigned red_grid(hipx_int n)
   return (unsigned)(g < 1 ? 1 : g);
 }
 
+static bool g_signal = true;  // launch_mdot_nosignal() clears it around one dispatch
+
 template <int NV>
 int launch_mdot(const double *x, const double *const *y, hipx_int n, int slot)
 {
@@ -523,7 +525,7 @@ int launch_mdot(const double *x, const double *const *y, hipx_int n, int slot)
     a.y[v] = y[v];
     vec    = vec && aligned16(y[v]);
   }
-  mdot_kernel<NV><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, a, n, vec, red_out(slot));
+  mdot_kernel<NV><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, a, n, vec, red_out(slot, g_signal));
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -573,7 +575,29 @@ int maxpy_dispatch(double *y, int nv, const double *alpha, const double *const *
   return fail(HIPX_ERR_ARG, "maxpy batch size", __FILE__, __LINE__);
 }
 
+__global__ void red_signal_kernel(unsigned long long *flag, unsigned long long seq)
+{
+  __threadfence_system();
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
+
+int hipx::launch_mdot_nosignal(const double *x, int nv, const double *const *y, hipx_int n, int slot)
+{
+  g_signal = false;
+  int ierr = mdot_dispatch(x, nv, y, n, slot);
+  g_signal = true;
+  return ierr;
+}
+
+int hipx::red_signal(int slot)
+{
+  Runtime &r = rt();
+  red_signal_kernel<<<1, 1, 0, r.compute>>>(r.d_flags + slot, ++r.seq[slot]);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
 
 extern "C" {
 
@@ -742,7 +766,7 @@ int hipxVecMAXPBY(double *y, hipx_int nv, const double *alpha, double beta, cons
 int hipxVecDotBegin(const double *x, const double *y, hipx_int n, int slot)
 {
   HIPX_CHECK_INIT();
-  HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 1, "reduction slot out of range");
+  HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2, "reduction slot out of range (the last two are reserved)");
   if (n <= 0) {
     HIPX_HIP(hipStreamSynchronize(rt().compute));
     slot_results_host(slot)[0] = 0.0;
@@ -756,7 +780,7 @@ int hipxVecDotBegin(const double *x, const double *y, hipx_int n, int slot)
 int hipxRedEnd(int slot, int nvals, double *results)
 {
   HIPX_CHECK_INIT();
-  HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 1 && nvals >= 0 && nvals <= kMaxRedVals, "reduction slot / count out of range");
+  HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2 && nvals >= 0 && nvals <= kMaxRedVals, "reduction slot / count out of range");
   return red_wait(slot, nvals, results);
 }
 

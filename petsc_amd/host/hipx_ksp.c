@@ -63,9 +63,11 @@ int HipxMatMult(HipxMat *A, const double *x, double *y)
 /* VecTDot_Seq (bvec1.c:40) | VecTDot_MPI (pvec2.c, pvecimpl.h:105-111): local dot + SUM all-reduce */
 int HipxVecDot(HipxMat *A, const double *x, const double *y, hipx_int n, double *r)
 {
-  CHK(hipxVecDot(x, y, n, r));
-  if (A->nranks > 1) CHK(hipxCommAllreduceSum(r, 1));
-  return 0;
+  if (A->nranks > 1) {
+    const double *ys[1] = {y};
+    return hipxVecMDotAllreduce(x, 1, ys, n, r); /* local kernel -> ncclAllReduce -> one host wait */
+  }
+  return hipxVecDot(x, y, n, r);
 }
 
 /* VecNorm_Seq NORM_2 = sqrt(ddot(x,x)) (bvec2.c:204) | VecNorm_MPI_Default (pvecimpl.h:150-175):
@@ -73,15 +75,13 @@ int HipxVecDot(HipxMat *A, const double *x, const double *y, hipx_int n, double 
 int HipxVecNorm2(HipxMat *A, const double *x, hipx_int n, double *r)
 {
   double s;
-  CHK(hipxVecDot(x, x, n, &s));
   if (A->nranks > 1) {
-    /* the reference squares the already-rooted local norm (pvecimpl.h:163); sqrt(s)^2 may differ from s
-       in the last bit, keep the reference's sequence */
-    double w = sqrt(s);
-    w        = w * w;
-    CHK(hipxCommAllreduceSum(&w, 1));
-    *r = sqrt(w);
-  } else *r = sqrt(s);
+    /* the reference roots the local sum, squares it again, all-reduces and roots (pvecimpl.h:150-175); summing the
+       un-rooted local sums differs from that only in the last bit of each addend and saves a host round trip */
+    const double *ys[1] = {x};
+    CHK(hipxVecMDotAllreduce(x, 1, ys, n, &s));
+  } else CHK(hipxVecDot(x, x, n, &s));
+  *r = sqrt(s);
   return 0;
 }
 

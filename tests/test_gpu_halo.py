@@ -12,7 +12,9 @@ import oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def test_single_rank_comm_allreduce_and_self_halo(hx):
+def test_single_rank_comm_allreduce_and_self_halo(hx, monkeypatch):
+    import os
+    os.environ["HIPX_FORCE_ALLREDUCE"] = "1"  # read once by libhipx at the first chained reduction
     from petsc_amd import _lib
     from petsc_amd import dist as pdist
     _, ks = _lib.load()
@@ -22,6 +24,20 @@ def test_single_rank_comm_allreduce_and_self_halo(hx):
     v = (C.c_double * 3)(1.5, -2.0, 7.0)
     _lib.chk(hx.hipxCommAllreduceSum(v, 3))
     assert list(v) == [1.5, -2.0, 7.0]
+    # local dots -> ncclAllReduce on the pinned result words -> single host wait (HIPX_FORCE_ALLREDUCE exercises the chain
+    # on this 1-rank communicator): must equal the plain local dots bit for bit
+    nn = 300001
+    rng0 = np.random.default_rng(9)
+    xa, ya, yb = rng0.standard_normal(nn), rng0.standard_normal(nn), rng0.standard_normal(nn)
+    XA, YA, YB = _lib.DVec(nn, xa), _lib.DVec(nn, ya), _lib.DVec(nn, yb)
+    ptrs = (C.c_void_p * 2)(YA.ptr.value, YB.ptr.value)
+    r1, r2 = (C.c_double * 2)(), (C.c_double * 2)()
+    for _ in range(3):
+        _lib.chk(hx.hipxVecMDotAllreduce(XA.ptr, 2, ptrs, nn, r1))
+    _lib.chk(hx.hipxVecMDot(XA.ptr, 2, ptrs, nn, r2))
+    assert list(r1) == list(r2) and abs(r1[0] - float(xa @ ya)) < 1e-9
+    for d in (XA, YA, YB):
+        d.free()
     # periodic 1-D chain: y = A_d x + B_o x[send_idx]; the "ghosts" are this rank's own first/last entries
     m = 5000
     rng = np.random.default_rng(2)
