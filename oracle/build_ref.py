@@ -25,6 +25,18 @@ CONF = os.path.join(HERE, "ref_conf")
 PKGS = "sys vec mat dm ksp snes ts tao ml".split()
 SKIPDIRS = {"benchmarks", "build", "mex-scripts", "tests", "tutorials"}
 BLAS_DIR = "/opt/conda/lib"
+KATS = {  # name -> source (reference tree)
+    "vec_tut_ex1": "vec/vec/tutorials/ex1.c",   # Max/Min/Scale/Copy/AXPY/AYPX/Swap/WAXPY/PointwiseMult/Divide/MAXPY/Dot/MDot/Norm, exact text
+    "vec_ex21": "vec/vec/tests/ex21.c",         # VecMax with index, VecSetStdBasis
+    "vec_ex28": "vec/vec/tests/ex28.c",         # repeated VecDotBegin/End
+    "vec_ex31": "vec/vec/tests/ex31.c",
+    "vec_ex34": "vec/vec/tests/ex34.c",         # norm caching semantics
+    "vec_ex43": "vec/vec/tests/ex43.c",         # VecMDot/Dot/MTDot/TDot
+    "vec_ex52": "vec/vec/tests/ex52.c",
+    "vec_ex60": "vec/vec/tests/ex60.c",         # VecPlaceArray + VecReciprocal
+    "vec_ex63": "vec/vec/tests/ex63.c",         # VecExp (parent op through our array hooks)
+    "mat_ex5": "mat/tests/ex5.c",               # MatMult/MultAdd/MultTranspose (+ diagonal scale)
+}
 CFLAGS = ["-fPIC", "-O2", "-fstack-protector", "-fvisibility=hidden", "-w", "-I" + CONF, "-I" + os.path.join(REF, "include")]
 
 
@@ -119,6 +131,10 @@ def build(verbose=False, jobs=None):
     # drivers: the reference's own tutorials (sources unmodified, compiled in place) + our thin driver
     tut = os.path.join(REF, "src", "ksp", "ksp", "tutorials")
     drivers = {"ex2": os.path.join(tut, "ex2.c"), "bench_kspsolve": os.path.join(tut, "bench_kspsolve.c"), "ref_driver": os.path.join(HERE, "ref_driver.c")}
+    # the reference's own known-answer tests for this path (sources unmodified, compiled in place): they are run with
+    # -vec_type hipx / -mat_type aijhipx against the reference's golden outputs (tests/test_gpu_plugin_kats.py)
+    for name, rel in KATS.items():
+        drivers["kat_" + name] = os.path.join(REF, "src", rel)
     for name, src in drivers.items():
         exe = os.path.join(OUT, "bin", name)
         if not os.path.exists(src):

@@ -44,7 +44,35 @@ def main():
             out[name]["iterations"] = int(m.group(1))
     json.dump(out, open(os.path.join(HERE, "ref_outputs.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
+    kats()
     ref_runs()
+
+
+# The reference's own known-answer tests for this path: (executable built by oracle/build_ref.py, args, the filter of the
+# reference's TEST block restated as python, golden file).  The hipx run appends -vec_type hipx / replaces the mat type.
+KATS = [
+    ("vec_tut_ex1", "kat_vec_tut_ex1", "", "none", "vec/vec/tutorials/output/ex1_1.out"),
+    ("vec_ex43", "kat_vec_ex43", "", "none", "vec/vec/tests/output/ex43_1.out"),
+    ("vec_ex34", "kat_vec_ex34", "", "none", "vec/vec/tests/output/ex34_1.out"),
+    ("vec_ex60", "kat_vec_ex60", "", "seqname", "vec/vec/tests/output/ex60_1.out"),
+    ("vec_ex21", "kat_vec_ex21", "", "ex21", "vec/vec/tests/output/ex21_1.out"),
+    ("vec_ex28", "kat_vec_ex28", "", "none", "vec/vec/tests/output/empty.out"),
+    ("vec_ex31", "kat_vec_ex31", "", "none", "vec/vec/tests/output/empty.out"),
+    ("vec_ex52", "kat_vec_ex52", "", "none", "vec/vec/tests/output/empty.out"),
+    ("vec_ex63", "kat_vec_ex63", "", "none", "vec/vec/tests/output/empty.out"),
+    ("mat_ex5_11_A", "kat_mat_ex5", "-mat_type seqaij -rectA", "notype", "mat/tests/output/ex5_11_A.out"),
+    ("mat_ex5_11_B", "kat_mat_ex5", "-mat_type seqaij -rectB", "notype", "mat/tests/output/ex5_11_B.out"),
+    ("mat_ex5_21", "kat_mat_ex5", "-mat_type mpiaij", "notype", "mat/tests/output/ex5_21.out"),
+    ("mat_ex5_31", "kat_mat_ex5", "-mat_type mpiaij -test_diagonalscale", "notype", "mat/tests/output/ex5_31.out"),
+]
+
+
+def kats():
+    out = {}
+    for name, exe, args, filt, gold in KATS:
+        out[name] = {"exe": exe, "args": args, "filter": filt, "golden_file": "src/" + gold, "golden": open(os.path.join("/root/reference/src", gold)).read()}
+    json.dump(out, open(os.path.join(HERE, "kats.json"), "w"), indent=0)
+    print("kats.json:", sorted(out))
 
 
 RUNS = {
