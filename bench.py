@@ -188,7 +188,7 @@ def main():
         pass
     auto = "spmv_pk16r_kernel (CSR MatMult, packed 16-bit columns, row-parallel gather)" if nnz_local <= 16 * m else "spmv_pk16_kernel (CSR MatMult, packed 16-bit columns)"
     kname = {0: auto, 22: "spmv_pk16_kernel (CSR MatMult, packed 16-bit columns)", 23: "spmv_pk16r_kernel (CSR MatMult, packed 16-bit columns, row-parallel gather)",
-             21: "spmv_tile_kernel"}.get(args.variant, "spmv_stream_kernel (CSR MatMult, 32-bit columns)")
+             }.get(args.variant, "spmv_stream_kernel (CSR MatMult, 32-bit columns)")
     out = None
     if rank == 0:
         value = args.steps / elapsed

@@ -42,19 +42,12 @@ struct hipxMat_s {
   hipx_int *d_sched[kMaxCfg] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // launch slot -> row block (null = identity)
   int64_t   far_offset = 0;   // typical max |col - row| of a row (0 = unknown / irregular): drives the block schedule
   int       sched_mode = 0;   // 1 = band-aware schedule (cuts x re-fetch from the Infinity Cache; no time gain measured), 0 = natural order
-  // LDS x-tile variant: block-local 16-bit column ids + per-block window descriptors (built lazily on the host)
-  bool           tile_ready = false;
-  unsigned short *d_lcol    = nullptr;
-  hipx_int      *d_wdesc    = nullptr;
-  int            tile_mode  = 0;   // 1 = LDS x-tile kernel (variant 21), 2 = packed 16-bit columns + hardware gather (variant 22)
+  // packed-column formats (built lazily on the host, once per nonzero pattern)
+  int            tile_mode  = 0;   // 2 = packed 16-bit columns, products staged in LDS (variant 22); 3 = + row-parallel gather (variant 23)
   bool           pk_ready   = false;
   unsigned short *d_pk      = nullptr;   // (window id << 12) | offset inside the window
   hipx_int      *d_pkbase   = nullptr;   // PK_WMAX window starts per row block (-1 in slot 0 = block keeps 32-bit columns)
   int64_t        pk_fallback_blocks = 0;
-  bool           pk_all_packed = false;   // every row block packed and tile-sized: the persistent kernel applies
-  void          *d_pkblk = nullptr;       // PkBlk per row block
-  int            persist_wg_per_cu = 4;
-  int64_t        tile_fallback_blocks = 0;
   int       probe      = 0;   // phase-attribution probe kernels (scripts/spmv_variants.py); results are NOT A x
   std::vector<int64_t> h_i;  // host copy of the row offsets (set-up only)
   void     *sor_state = nullptr;  // hipxSorState, owned by hipx_sor.hip
@@ -118,6 +111,7 @@ constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 typedef int    int4v __attribute__((ext_vector_type(4)));
+typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
 
 template <bool NT, typename T>
 __device__ __forceinline__ T stream_load(const T *p)
@@ -247,152 +241,6 @@ __global__ __launch_bounds__(SPMV_THREADS) void spmv_stream_kernel(const hipx_in
         sum += tot;
         yout[orow] = sum;
         if (DOT) mydot = x[orow] * sum;
-      }
-    }
-  }
-  if (DOT) {  // one partial per WAVE, no barrier: the workgroup retires as soon as its rows are written
-    const double w = hipx::wave_sum(mydot);
-    if ((threadIdx.x & 63) == 0) dotpart[(size_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6)] = w;
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// LDS x-tile SpMV.  Same row blocks, same products, same left-to-right row sums as spmv_stream_kernel (bit-identical
-// y), but the block's x entries are first staged in LDS through COALESCED loads of a few contiguous windows of x, and
-// the column of every nonzero is stored as a 16-bit position inside that tile:
-//   * the 64-lane scattered 8-byte gather (10-17 % of the stream kernel's time, probe runs) becomes ds_read_b64,
-//   * the index stream shrinks from 4 to 2 bytes per nonzero.
-// Per block the host records up to TILE_WMAX windows [start, len) covering the distinct columns of the block (gaps of
-// up to TILE_GAP unused entries are absorbed into a window); blocks whose windows do not fit (irregular rows) keep
-// the global gather with their 32-bit columns -- the format degrades per block, not per matrix.
-constexpr int TILE_THREADS = 256;
-constexpr int TILE_CAP     = 2048;  // products per block (as cfg 0)
-constexpr int TILE_XCAP    = 2048;  // x entries staged per block (16 KiB)
-constexpr int TILE_WMAX    = 12;
-constexpr int TILE_GAP     = 16;
-constexpr int TILE_DW      = 2 + 3 * TILE_WMAX;  // ints per descriptor: nwin, total, then (start, len, offset) per window
-
-typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
-
-template <typename IT, int MODE, bool DOT>
-__global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const hipx_int *__restrict__ rb, hipx_int nblocks, hipx_int blocks_per_xcd, const IT *__restrict__ ai,
-                                                                  const hipx_int *__restrict__ aj, const unsigned short *__restrict__ lcol,
-                                                                  const hipx_int *__restrict__ wdesc, const double *__restrict__ aa, const double *__restrict__ x,
-                                                                  const double *yin, double *yout, double *dotpart)
-{
-  __shared__ double prod[TILE_CAP];
-  __shared__ double xt[TILE_XCAP];
-  const hipx_int bid = (hipx_int)blockIdx.x;
-  const hipx_int b   = (bid & 7) * blocks_per_xcd + (bid >> 3);
-  double         mydot = 0.0;
-  if (b < nblocks) {
-    const hipx_int r0 = rb[b], r1 = rb[b + 1];
-    const IT       k0 = ai[r0], k1 = ai[r1];
-    const IT       ka = k0 & ~(IT)3;
-    const int      t  = threadIdx.x;
-    const hipx_int row = r0 + t;
-    IT             rs = 0, re = 0;
-    if (row < r1) {
-      rs = ai[row];
-      re = ai[row + 1];
-    }
-    const hipx_int *desc = wdesc + (size_t)b * TILE_DW;
-    const int       nwin = desc[0];
-    if ((k1 - ka) <= (IT)TILE_CAP) {
-      const IT      nq  = (k1 - ka + 3) >> 2;
-      constexpr int NIT = TILE_CAP / 4 / TILE_THREADS;
-      dbl2          va[NIT], vb[NIT];
-      if (nq > 0) {
-        const dbl2 *a2 = reinterpret_cast<const dbl2 *>(aa + ka);
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {  // values first: the longest stream, in flight while the x tile is staged
-          const IT q  = (IT)t + (IT)it * TILE_THREADS;
-          const IT qc = q < nq ? q : nq - 1;
-          va[it]      = a2[2 * qc];
-          vb[it]      = a2[2 * qc + 1];
-        }
-        if (nwin >= 0) {
-          ushort4v vl[NIT];
-          const ushort4v *l4 = reinterpret_cast<const ushort4v *>(lcol + ka);
-#pragma unroll
-          for (int it = 0; it < NIT; it++) {
-            const IT q  = (IT)t + (IT)it * TILE_THREADS;
-            const IT qc = q < nq ? q : nq - 1;
-            vl[it]      = l4[qc];
-          }
-          for (int w = 0; w < nwin; w++) {  // coalesced staging of the block's x windows
-            const hipx_int s = desc[2 + 3 * w], len = desc[3 + 3 * w], off = desc[4 + 3 * w];
-            for (hipx_int i = t; i < len; i += TILE_THREADS) xt[off + i] = x[s + i];
-          }
-          __syncthreads();
-#pragma unroll
-          for (int it = 0; it < NIT; it++) {
-            const IT q = (IT)t + (IT)it * TILE_THREADS;
-            if (q < nq) {
-              dbl2 p0, p1;
-              p0.x = va[it].x * xt[vl[it].x];
-              p0.y = va[it].y * xt[vl[it].y];
-              p1.x = vb[it].x * xt[vl[it].z];
-              p1.y = vb[it].y * xt[vl[it].w];
-              reinterpret_cast<dbl2 *>(prod)[2 * q]     = p0;
-              reinterpret_cast<dbl2 *>(prod)[2 * q + 1] = p1;
-            }
-          }
-        } else {  // block whose columns do not fit the tile: global gather with the 32-bit columns
-          const int4v *j4 = reinterpret_cast<const int4v *>(aj + ka);
-#pragma unroll
-          for (int it = 0; it < NIT; it++) {
-            const IT q = (IT)t + (IT)it * TILE_THREADS;
-            if (q < nq) {
-              const int4v c = j4[q];
-              dbl2        p0, p1;
-              p0.x = va[it].x * x[c.x];
-              p0.y = va[it].y * x[c.y];
-              p1.x = vb[it].x * x[c.z];
-              p1.y = vb[it].y * x[c.w];
-              reinterpret_cast<dbl2 *>(prod)[2 * q]     = p0;
-              reinterpret_cast<dbl2 *>(prod)[2 * q + 1] = p1;
-            }
-          }
-        }
-      }
-      __syncthreads();
-      if (row < r1) {
-        double        sum = (MODE == 1) ? yin[row] : 0.0;
-        const double *pr  = prod + (int)(rs - ka);
-        const int     len = (int)(re - rs);
-        int           k   = 0;
-        for (; k + 4 <= len; k += 4) {
-          const double p0 = pr[k], p1 = pr[k + 1], p2 = pr[k + 2], p3 = pr[k + 3];
-          sum += p0;
-          sum += p1;
-          sum += p2;
-          sum += p3;
-        }
-        if (k + 2 <= len) {
-          const double p0 = pr[k], p1 = pr[k + 1];
-          sum += p0;
-          sum += p1;
-          k += 2;
-        }
-        if (k < len) sum += pr[k];
-        yout[row] = sum;
-        if (DOT) mydot = x[row] * sum;
-      }
-    } else {  // one long row
-      double acc = 0.0;
-      for (IT k = k0 + t; k < k1; k += TILE_THREADS) acc += aa[k] * x[aj[k]];
-      acc = hipx::wave_sum(acc);
-      if ((t & 63) == 0) prod[t >> 6] = acc;
-      __syncthreads();
-      if (t == 0) {
-        double sum = (MODE == 1) ? yin[r0] : 0.0;
-        double tot = prod[0];
-        for (int w = 1; w < TILE_THREADS / 64; w++) tot += prod[w];
-        sum += tot;
-        yout[r0] = sum;
-        if (DOT) mydot = x[r0] * sum;
       }
     }
   }
@@ -675,122 +523,6 @@ __global__ __launch_bounds__(256) void spmv_pk16r_kernel(const hipx_int *__restr
   }
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------
-// Persistent, software-pipelined form of spmv_pk16r_kernel ("pk16p").  A workgroup's life in the one-shot kernels is a
-// chain of dependent round trips (block header -> value/code stream -> barrier -> x gather -> row sums -> store); with
-// 8 workgroups per CU the chip spends 32 "generations" of ~9 us on 7-pt 256^3, i.e. it is latency-paced.  Here a
-// persistent workgroup walks a contiguous run of row blocks and keeps the NEXT block's header, values and codes in
-// flight (registers) while it gathers x and sums the rows of the CURRENT block out of a double-buffered LDS tile:
-// the HBM stream never waits for the gather.  One barrier per row block.  Requires every block to be packed and to fit
-// the tile (no long rows); otherwise the launcher falls back to spmv_pk16r_kernel.  Bit-identical y.
-struct PkBlk {        // per row block, precomputed on the host
-  hipx_int r0, nrows; // first row, number of rows
-  hipx_int nq, pad;   // quads to stream (from the 32-byte aligned start)
-  int64_t  ka;        // aligned start in a[] / pk[]
-};
-
-template <typename IT, int MODE, bool DOT>
-__global__ __launch_bounds__(256) void spmv_pk16p_kernel(const PkBlk *__restrict__ blk, hipx_int nblocks, hipx_int blocks_per_xcd, hipx_int chunk, const IT *__restrict__ ai,
-                                                         const unsigned short *__restrict__ pk, const hipx_int *__restrict__ pkbase, const double *__restrict__ aa,
-                                                         const double *__restrict__ x, const double *yin, double *yout, double *dotpart)
-{
-  constexpr int THREADS = 256, CAP = 2048, NIT = CAP / 4 / THREADS;
-  __shared__ double         vals[2][CAP];
-  __shared__ unsigned short codes[2][CAP];
-  const int      t   = threadIdx.x;
-  const hipx_int bid = (hipx_int)blockIdx.x;
-  // XCD-aware: hardware block bid runs on XCD bid % 8; each XCD owns one contiguous slab of row blocks, each persistent
-  // workgroup one contiguous chunk of that slab
-  const hipx_int xcd = bid & 7, l = bid >> 3;
-  hipx_int       it  = xcd * blocks_per_xcd + l * chunk;
-  hipx_int       end = it + chunk;
-  const hipx_int slab_end = min(nblocks, (xcd + 1) * blocks_per_xcd);
-  if (end > slab_end) end = slab_end;
-  double mydot = 0.0;
-  // ---- prologue: first block's stream into registers
-  dbl2     va[NIT], vb[NIT];
-  ushort4v vc[NIT];
-  PkBlk    nb;
-  IT       nrs = 0, nre = 0;
-  int      nbase = 0;
-  double   nxrow = 0.0, nyin = 0.0;
-  auto prefetch = [&](hipx_int b) {
-    nb = blk[b];
-    const dbl2     *a2 = reinterpret_cast<const dbl2 *>(aa + nb.ka);
-    const ushort4v *c4 = reinterpret_cast<const ushort4v *>(pk + nb.ka);
-#pragma unroll
-    for (int k = 0; k < NIT; k++) {
-      const hipx_int q  = t + k * THREADS;
-      const hipx_int qc = q < nb.nq ? q : (nb.nq > 0 ? nb.nq - 1 : 0);
-      va[k]             = a2[2 * qc];
-      vb[k]             = a2[2 * qc + 1];
-      vc[k]             = c4[qc];
-    }
-    nrs = nre = 0;
-    if (t < nb.nrows) {
-      nrs = ai[nb.r0 + t];
-      nre = ai[nb.r0 + t + 1];
-      if (DOT) nxrow = x[nb.r0 + t];
-      if (MODE == 1) nyin = yin[nb.r0 + t];
-    }
-    nbase = pkbase[(size_t)b * PK_WMAX + (t & (PK_WMAX - 1))];
-  };
-  if (it < end) prefetch(it);
-  int buf = 0;
-  while (it < end) {
-    // ---- current block: registers -> LDS
-    const PkBlk cb    = nb;
-    const IT    rs    = nrs, re = nre;
-    const int   base_reg = nbase;
-    const double xrow = nxrow, y0 = nyin;
-#pragma unroll
-    for (int k = 0; k < NIT; k++) {
-      const hipx_int q = t + k * THREADS;
-      if (q < cb.nq) {
-        reinterpret_cast<dbl2 *>(vals[buf])[2 * q]     = va[k];
-        reinterpret_cast<dbl2 *>(vals[buf])[2 * q + 1] = vb[k];
-        reinterpret_cast<ushort4v *>(codes[buf])[q]    = vc[k];
-      }
-    }
-    __syncthreads();
-    // ---- next block's stream goes in flight now and lands while this block gathers and sums
-    if (it + 1 < end) prefetch(it + 1);
-    const bool live = t < cb.nrows;
-    const int  len  = live ? (int)(re - rs) : 0;
-    int        maxlen = len;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
-    const int s0  = (int)((int64_t)rs - cb.ka);
-    double    sum = (MODE == 1) ? y0 : 0.0;
-    for (int k = 0; k < maxlen; k += 4) {
-      double xv[4], av[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const bool     on   = (k + e) < len;
-        const int      idx  = on ? s0 + k + e : 0;
-        const unsigned code = codes[buf][idx];
-        const int      col  = __shfl(base_reg, code >> 12, 64) + (int)(code & 0xfff);
-        av[e]               = vals[buf][idx];
-        xv[e]               = on ? x[col] : 0.0;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; e++)
-        if ((k + e) < len) sum += av[e] * xv[e];
-    }
-    if (live) {
-      yout[cb.r0 + t] = sum;
-      if (DOT) mydot += xrow * sum;
-    }
-    buf ^= 1;
-    it++;
-  }
-  if (DOT) {
-    const double w = hipx::wave_sum(mydot);
-    if ((threadIdx.x & 63) == 0) dotpart[(size_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6)] = w;
-  }
-}
-
 template <typename IT>
 __global__ void diagpos_kernel(hipx_int m, const IT *ai, const hipx_int *aj, int64_t *diagpos, unsigned int *missing)
 {
@@ -1017,100 +749,6 @@ int launch_spmv_c(hipxMat A, const double *x, const double *yin, double *yout, d
 }
 
 
-// Host set-up of the tile format (once per nonzero pattern): per row block, sort + unique the columns, merge them into
-// windows, and translate every column into its position inside the staged tile.  Parallel over blocks.
-int ensure_tiles(hipxMat A)
-{
-  if (A->tile_ready) return HIPX_SUCCESS;
-  int ierr = ensure_row_blocks(A, 0);
-  if (ierr) return ierr;
-  const hipx_int nb = A->nblocks[0];
-  std::vector<hipx_int> rb((size_t)nb + 1);
-  HIPX_HIP(hipMemcpy(rb.data(), A->d_rb[0], sizeof(hipx_int) * ((size_t)nb + 1), hipMemcpyDeviceToHost));
-  std::vector<hipx_int> hj((size_t)A->nnz + 8, 0);
-  if (A->nnz) HIPX_HIP(hipMemcpy(hj.data(), A->d_j, sizeof(hipx_int) * (size_t)A->nnz, hipMemcpyDeviceToHost));
-  std::vector<unsigned short> lcol((size_t)A->nnz + 8, 0);
-  std::vector<hipx_int>       wdesc((size_t)nb * TILE_DW, 0);
-  const int64_t *hi = A->h_i.data();
-  std::vector<int64_t> fallback(64, 0);
-  auto work = [&](int tid, int nthreads) {
-    std::vector<hipx_int> u;
-    for (hipx_int b = tid; b < nb; b += nthreads) {
-      hipx_int     *d  = wdesc.data() + (size_t)b * TILE_DW;
-      const int64_t k0 = hi[rb[b]], k1 = hi[rb[b + 1]];
-      d[0] = -1;
-      d[1] = 0;
-      if (k1 - (k0 & ~(int64_t)3) > TILE_CAP) continue;  // long row: handled by the strided path
-      u.assign(hj.begin() + k0, hj.begin() + k1);
-      std::sort(u.begin(), u.end());
-      u.erase(std::unique(u.begin(), u.end()), u.end());
-      int      nw = 0;
-      hipx_int tot = 0;
-      bool     ok = true;
-      size_t   p  = 0;
-      while (p < u.size()) {
-        size_t q = p;
-        while (q + 1 < u.size() && u[q + 1] - u[q] <= TILE_GAP) q++;
-        const hipx_int s = u[p], len = u[q] - u[p] + 1;
-        if (nw >= TILE_WMAX || tot + len > TILE_XCAP) {
-          ok = false;
-          break;
-        }
-        d[2 + 3 * nw] = s;
-        d[3 + 3 * nw] = len;
-        d[4 + 3 * nw] = tot;
-        tot += len;
-        nw++;
-        p = q + 1;
-      }
-      if (!ok) {
-        fallback[tid]++;
-        continue;
-      }
-      d[0] = nw;
-      d[1] = tot;
-      for (int64_t k = k0; k < k1; k++) {
-        const hipx_int c = hj[k];
-        int            lo = 0, hi2 = nw - 1;
-        while (lo < hi2) {  // last window with start <= c
-          const int mid = (lo + hi2 + 1) / 2;
-          if (d[2 + 3 * mid] <= c) lo = mid;
-          else hi2 = mid - 1;
-        }
-        lcol[k] = (unsigned short)(d[4 + 3 * lo] + (c - d[2 + 3 * lo]));
-      }
-    }
-  };
-  const int nthreads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-  std::vector<std::thread> pool;
-  for (int tnum = 0; tnum < nthreads; tnum++) pool.emplace_back(work, tnum, nthreads);
-  for (auto &th : pool) th.join();
-  A->tile_fallback_blocks = 0;
-  for (int tnum = 0; tnum < nthreads; tnum++) A->tile_fallback_blocks += fallback[tnum];
-  HIPX_HIP(hipMalloc((void **)&A->d_lcol, sizeof(unsigned short) * lcol.size()));
-  HIPX_HIP(hipMalloc((void **)&A->d_wdesc, sizeof(hipx_int) * std::max<size_t>(wdesc.size(), 1)));
-  HIPX_HIP(hipMemcpy(A->d_lcol, lcol.data(), sizeof(unsigned short) * lcol.size(), hipMemcpyHostToDevice));
-  if (!wdesc.empty()) HIPX_HIP(hipMemcpy(A->d_wdesc, wdesc.data(), sizeof(hipx_int) * wdesc.size(), hipMemcpyHostToDevice));
-  A->device_bytes += (int64_t)(sizeof(unsigned short) * lcol.size() + sizeof(hipx_int) * wdesc.size());
-  A->tile_ready = true;
-  return HIPX_SUCCESS;
-}
-
-template <typename IT, int MODE, bool DOT>
-int launch_tile(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
-{
-  int ierr = ensure_tiles(A);
-  if (ierr) return ierr;
-  const hipx_int nb = A->nblocks[0];
-  if (nb == 0) return HIPX_SUCCESS;
-  const hipx_int per_xcd = (nb + 7) / 8;
-  spmv_tile_kernel<IT, MODE, DOT><<<(unsigned)(per_xcd * 8), TILE_THREADS, 0, rt().compute>>>(A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_lcol, A->d_wdesc,
-                                                                                              A->d_a, x, yin, yout, dotpart);
-  HIPX_LAUNCH_CHECK();
-  return HIPX_SUCCESS;
-}
-
-
 // Host set-up of the packed-column format (once per nonzero pattern), parallel over row blocks.
 int ensure_pk16(hipxMat A)
 {
@@ -1172,27 +810,6 @@ int ensure_pk16(hipxMat A)
   for (auto &th : pool) th.join();
   A->pk_fallback_blocks = 0;
   for (int tnum = 0; tnum < nthreads; tnum++) A->pk_fallback_blocks += fallback[tnum];
-  {
-    std::vector<PkBlk> bm((size_t)std::max<hipx_int>(nb, 1));
-    bool all = true;
-    for (hipx_int b = 0; b < nb; b++) {
-      const int64_t k0 = hi[rb[b]], k1 = hi[rb[b + 1]], ka = k0 & ~(int64_t)3;
-      bm[b].r0    = rb[b];
-      bm[b].nrows = rb[b + 1] - rb[b];
-      bm[b].nq    = (hipx_int)((k1 - ka + 3) >> 2);
-      bm[b].pad   = 0;
-      bm[b].ka    = ka;
-      if (k1 - ka > 2048) all = false;                         // long row
-      if (k1 > k0 && base[(size_t)b * PK_WMAX] < 0) all = false;  // block kept its 32-bit columns
-      if (k1 == k0) {  // empty block: give it harmless window starts so the persistent kernel can treat it as packed
-        for (int w = 0; w < PK_WMAX; w++) base[(size_t)b * PK_WMAX + w] = 0;
-      }
-    }
-    A->pk_all_packed = all && A->pk_fallback_blocks == 0;
-    HIPX_HIP(hipMalloc(&A->d_pkblk, sizeof(PkBlk) * bm.size()));
-    HIPX_HIP(hipMemcpy(A->d_pkblk, bm.data(), sizeof(PkBlk) * bm.size(), hipMemcpyHostToDevice));
-    A->device_bytes += (int64_t)(sizeof(PkBlk) * bm.size());
-  }
   HIPX_HIP(hipMalloc((void **)&A->d_pk, sizeof(unsigned short) * pk.size()));
   HIPX_HIP(hipMalloc((void **)&A->d_pkbase, sizeof(hipx_int) * base.size()));
   HIPX_HIP(hipMemcpy(A->d_pk, pk.data(), sizeof(unsigned short) * pk.size(), hipMemcpyHostToDevice));
@@ -1210,12 +827,7 @@ int launch_pk16(hipxMat A, const double *x, const double *yin, double *yout, dou
   const hipx_int nb = A->nblocks[0];
   if (nb == 0) return HIPX_SUCCESS;
   const hipx_int per_xcd = (nb + 7) / 8;
-  if (A->tile_mode == 4 && A->pk_all_packed) {
-    const hipx_int wg    = 32 * A->persist_wg_per_cu;                    // persistent workgroups per XCD
-    const hipx_int chunk = (per_xcd + wg - 1) / wg;
-    spmv_pk16p_kernel<IT, MODE, DOT><<<(unsigned)(wg * 8), 256, 0, rt().compute>>>((const PkBlk *)A->d_pkblk, nb, per_xcd, chunk, (const IT *)A->d_i, A->d_pk, A->d_pkbase,
-                                                                                  A->d_a, x, yin, yout, dotpart);
-  } else if (A->tile_mode >= 3)
+  if (A->tile_mode >= 3)
     spmv_pk16r_kernel<IT, MODE, DOT><<<(unsigned)(per_xcd * 8), 256, 0, rt().compute>>>(A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_pk, A->d_pkbase, A->d_a, x,
                                                                                         yin, yout, dotpart, A->n);
   else
@@ -1228,7 +840,6 @@ int launch_pk16(hipxMat A, const double *x, const double *yin, double *yout, dou
 template <typename IT, int MODE, bool DOT>
 int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
 {
-  if (A->tile_mode == 1 && !A->compressed && !A->probe) return launch_tile<IT, MODE, DOT>(A, x, yin, yout, dotpart);
   if (A->tile_mode >= 2 && !A->compressed && !A->probe) return launch_pk16<IT, MODE, DOT>(A, x, yin, yout, dotpart);
   if (A->probe && MODE == 0 && !DOT && !A->compressed && !A->is64) {
     int ierr = ensure_row_blocks(A, 0);
@@ -1254,8 +865,7 @@ int dot_partials_count(hipxMat A)
   bool nt;
   decode_variant(A->variant, cfg, nt);
   const int waves = (A->tile_mode ? 256 : kCfg[cfg].threads) / 64;
-  const int grid  = (int)(((A->nblocks[A->tile_mode ? 0 : cfg] + 7) / 8) * 8);
-  return std::max(grid, 8 * 32 * 8) * waves;  // also covers the persistent kernel's fixed grid (<= 8 workgroups per CU)
+  return (int)(((A->nblocks[A->tile_mode ? 0 : cfg] + 7) / 8) * 8) * waves;
 }
 
 template <int MODE, bool DOT>
@@ -1348,11 +958,8 @@ int hipxMatDestroy(hipxMat *pA)
   }
   (void)hipFree(A->d_ridx);
   (void)hipFree(A->d_dotpart);
-  (void)hipFree(A->d_lcol);
-  (void)hipFree(A->d_wdesc);
   (void)hipFree(A->d_pk);
   (void)hipFree(A->d_pkbase);
-  (void)hipFree(A->d_pkblk);
   hipxSorStateFree_(A->sor_state);
   delete A;
   *pA = nullptr;
@@ -1394,14 +1001,8 @@ int hipxMatSetSpMVVariant(hipxMat A, int variant)
   HIPX_ARG(A && variant >= 0, "variant: 0 auto, else 1 + 2*geometry + (1 if non-temporal loads); add 100 for the band-aware block schedule");
   A->probe      = variant / 1000;  // 1000/2000/3000 + v: probe kernels
   variant %= 1000;
-  A->tile_mode  = (variant == 21) ? 1 : (variant == 22) ? 2 : (variant == 23) ? 3 : (variant >= 24 && variant <= 29) ? 4 : 0;
-  // 21: LDS x-tile, 22: packed columns, 23: packed + row-parallel gather, 24..29: persistent pipelined form with 4, 1, 2, 3, 5, 6 workgroups per CU
-  if (variant >= 24 && variant <= 29) {
-    static const int wgs[6] = {4, 1, 2, 3, 5, 6};
-    A->persist_wg_per_cu   = wgs[variant - 24];
-  }
-  if (variant == 0) A->tile_mode = auto_tile_mode(A);
-  if (variant >= 21 && variant <= 29) variant = 1;
+  A->tile_mode  = (variant == 22) ? 2 : (variant == 23) ? 3 : 0;  // 22: packed columns, 23: packed columns + row-parallel gather
+  if (variant == 22 || variant == 23) variant = 1;
   A->sched_mode = variant >= 100 ? 1 : 0;
   variant %= 100;
   HIPX_ARG(variant <= 2 * kNumCfg, "unknown SpMV variant");
