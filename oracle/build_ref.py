@@ -40,8 +40,13 @@ KATS = {  # name -> source (reference tree)
 CFLAGS = ["-fPIC", "-O2", "-fstack-protector", "-fvisibility=hidden", "-w", "-I" + CONF, "-I" + os.path.join(REF, "include")]
 
 
-def conf_defines():
-    txt = open(os.path.join(CONF, "petscconf.h")).read()
+MPI_DIR = "/opt/conda"  # MPICH 3.3.2 of the image (its mpicc wrapper points at a missing compiler: use include/lib directly)
+
+
+def conf_defines(arch):
+    """PETSC_* macros of the configuration for this arch, through the preprocessor (the header has an #if for mpich)."""
+    cmd = ["gcc", "-dM", "-E", "-I" + CONF, os.path.join(CONF, "petscconf.h")] + (["-DHIPX_REF_MPICH"] if arch == "mpich" else [])
+    txt = subprocess.check_output(cmd, text=True)
     return set(re.findall(r"^#define\s+(PETSC_\w+)", txt, flags=re.M))
 
 
@@ -69,8 +74,8 @@ def dir_selected(makefile, defs):
     return True
 
 
-def select_sources():
-    defs = conf_defines()
+def select_sources(arch="mpiuni"):
+    defs = conf_defines(arch)
     srcs = []
     for pkg in PKGS:
         for root, dirs, files in os.walk(os.path.join(REF, "src", pkg)):
@@ -88,26 +93,35 @@ def select_sources():
 
 
 def _compile(job):
-    src, obj = job
+    src, obj, flags = job
     if os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src):
         return None
     os.makedirs(os.path.dirname(obj), exist_ok=True)
-    r = subprocess.run(["gcc"] + CFLAGS + ["-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    r = subprocess.run(["gcc"] + flags + ["-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     return (src, r.stdout) if r.returncode else None
 
 
-def build(verbose=False, jobs=None):
+def arch_flags(arch):
+    """(output dir, compile flags, link flags) -- mpiuni: the reference's single-process MPI stub; mpich: the image's MPICH."""
+    if arch == "mpich":
+        return (os.path.join(OUT, "mpich"), CFLAGS + ["-DHIPX_REF_MPICH", "-I" + os.path.join(MPI_DIR, "include")],
+                ["-L" + os.path.join(MPI_DIR, "lib"), "-Wl,-rpath," + os.path.join(MPI_DIR, "lib"), "-lmpi"])
+    return OUT, CFLAGS, []
+
+
+def build(verbose=False, jobs=None, arch="mpiuni"):
     if not os.path.isdir(os.path.join(REF, "src")):
         raise RuntimeError("reference tree not present: oracle/_ref can only be (re)built where /root/reference exists")
-    lib = os.path.join(OUT, "lib", "libpetsc.so")
-    os.makedirs(os.path.join(OUT, "lib"), exist_ok=True)
-    os.makedirs(os.path.join(OUT, "bin"), exist_ok=True)
-    stamp = os.path.join(OUT, "conf.stamp")
-    conf_txt = "".join(open(os.path.join(CONF, f)).read() for f in sorted(os.listdir(CONF))) + " ".join(CFLAGS)
+    OUTA, cflags, mpilink = arch_flags(arch)
+    lib = os.path.join(OUTA, "lib", "libpetsc.so")
+    os.makedirs(os.path.join(OUTA, "lib"), exist_ok=True)
+    os.makedirs(os.path.join(OUTA, "bin"), exist_ok=True)
+    stamp = os.path.join(OUTA, "conf.stamp")
+    conf_txt = "".join(open(os.path.join(CONF, f)).read() for f in sorted(os.listdir(CONF))) + " ".join(cflags)
     if os.path.exists(stamp) and open(stamp).read() != conf_txt:
-        shutil.rmtree(os.path.join(OUT, "obj"), ignore_errors=True)  # configuration changed: rebuild everything
-    srcs = select_sources()
-    pairs = [(s, os.path.join(OUT, "obj", os.path.relpath(s, REF)[:-2] + ".o")) for s in srcs]
+        shutil.rmtree(os.path.join(OUTA, "obj"), ignore_errors=True)  # configuration changed: rebuild everything
+    srcs = select_sources(arch)
+    pairs = [(s, os.path.join(OUTA, "obj", os.path.relpath(s, REF)[:-2] + ".o"), cflags) for s in srcs]
     jobs = jobs or max(1, (os.cpu_count() or 2))
     failed = []
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
@@ -118,11 +132,11 @@ def build(verbose=False, jobs=None):
         for src, out in failed[:5]:
             sys.stderr.write("FAILED %s\n%s\n" % (src, out[-2000:]))
         raise RuntimeError("%d reference files failed to compile" % len(failed))
-    objs = [o for _, o in pairs]
+    objs = [o for _, o, _ in pairs]
     if not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
-        rsp = os.path.join(OUT, "objs.rsp")
+        rsp = os.path.join(OUTA, "objs.rsp")
         open(rsp, "w").write("\n".join(objs))
-        cmd = ["gcc", "-shared", "-fPIC", "-Wl,-soname,libpetsc.so", "-o", lib, "@" + rsp, "-L" + BLAS_DIR, "-Wl,-rpath," + BLAS_DIR, "-lmkl_rt", "-lm", "-ldl", "-lpthread"]
+        cmd = ["gcc", "-shared", "-fPIC", "-Wl,-soname,libpetsc.so", "-o", lib, "@" + rsp, "-L" + BLAS_DIR, "-Wl,-rpath," + BLAS_DIR, "-lmkl_rt", "-lm", "-ldl", "-lpthread"] + mpilink
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode:
             sys.stderr.write(r.stdout[-4000:])
@@ -136,23 +150,24 @@ def build(verbose=False, jobs=None):
     for name, rel in KATS.items():
         drivers["kat_" + name] = os.path.join(REF, "src", rel)
     for name, src in drivers.items():
-        exe = os.path.join(OUT, "bin", name)
+        exe = os.path.join(OUTA, "bin", name)
         if not os.path.exists(src):
             continue
         if os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(src), os.path.getmtime(lib)):
             continue
-        cmd = ["gcc", "-O2", "-w", "-I" + CONF, "-I" + os.path.join(REF, "include"), src, "-o", exe, "-L" + os.path.join(OUT, "lib"), "-lpetsc",
-               "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + BLAS_DIR, "-L" + BLAS_DIR, "-lmkl_rt", "-lm", "-rdynamic"]
+        cmd = ["gcc", "-O2", "-w"] + [f for f in cflags if f.startswith("-I") or f.startswith("-D")] + [src, "-o", exe, "-L" + os.path.join(OUTA, "lib"), "-lpetsc",
+               "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + BLAS_DIR, "-L" + BLAS_DIR, "-lmkl_rt", "-lm", "-rdynamic"] + mpilink
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode:
             sys.stderr.write(r.stdout[-4000:])
             raise RuntimeError("building driver %s failed" % name)
     if verbose:
-        print("reference built: %d sources -> %s" % (len(srcs), lib))
+        print("reference built (%s): %d sources -> %s" % (arch, len(srcs), lib))
     return lib
 
 
 if __name__ == "__main__":
     import time
-    t = time.time()
-    print(build(verbose=True), "%.1fs" % (time.time() - t))
+    for a in (["mpiuni", "mpich"] if "--all" in sys.argv else [sys.argv[1]] if len(sys.argv) > 1 else ["mpiuni"]):
+        t = time.time()
+        print(build(verbose=True, arch=a), "%.1fs" % (time.time() - t))

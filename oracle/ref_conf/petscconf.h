@@ -10,9 +10,14 @@
 #define INCLUDED_PETSCCONF_H
 
 /* ---- identity ---- */
-#define PETSC_ARCH "oracle-ref"
 #define PETSC_DIR "/root/reference"
-#define PETSC_LIB_DIR "/root/repo/oracle/_ref/lib"
+#if defined(HIPX_REF_MPICH) /* second build of the same sources against the image's MPICH 3.3.2 (/opt/conda), for np > 1 parity runs */
+  #define PETSC_ARCH "oracle-ref-mpich"
+  #define PETSC_LIB_DIR "/root/repo/oracle/_ref/mpich/lib"
+#else
+  #define PETSC_ARCH "oracle-ref"
+  #define PETSC_LIB_DIR "/root/repo/oracle/_ref/lib"
+#endif
 #define PETSC_LIB_NAME_SUFFIX ""
 #define PETSC_SLSUFFIX "so"
 #define PETSC_DIR_SEPARATOR '/'
@@ -27,9 +32,32 @@
 #define PETSC_USE_REAL_DOUBLE 1
 #define PETSC_CLANGUAGE_C 1
 #define PETSC_DEVICELANGUAGE_C 1
-#define PETSC_HAVE_MPIUNI 1
+#if defined(HIPX_REF_MPICH)
+  #define PETSC_HAVE_MPICH 1
+  #define PETSC_PKG_MPICH_NUMVERSION 30302300
+  #define PETSC_HAVE_MPIEXEC_ENVIRONMENTAL_VARIABLE MPIR_CVAR_CH3
+  #define PETSC_HAVE_MPIIO 1
+  #define PETSC_HAVE_MPI_COMBINER_CONTIGUOUS 1
+  #define PETSC_HAVE_MPI_COMBINER_DUP 1
+  #define PETSC_HAVE_MPI_COMBINER_NAMED 1
+  #define PETSC_HAVE_MPI_FEATURE_DYNAMIC_WINDOW 1
+  #define PETSC_HAVE_MPI_GET_ACCUMULATE 1
+  #define PETSC_HAVE_MPI_GET_LIBRARY_VERSION 1
+  #define PETSC_HAVE_MPI_INIT_THREAD 1
+  #define PETSC_HAVE_MPI_INT64_T 1
+  #define PETSC_HAVE_MPI_LONG_DOUBLE 1
+  #define PETSC_HAVE_MPI_NEIGHBORHOOD_COLLECTIVES 1
+  #define PETSC_HAVE_MPI_NONBLOCKING_COLLECTIVES 1
+  #define PETSC_HAVE_MPI_ONE_SIDED 1
+  #define PETSC_HAVE_MPI_PROCESS_SHARED_MEMORY 1
+  #define PETSC_HAVE_MPI_REDUCE_SCATTER_BLOCK 1
+  #define PETSC_HAVE_MPI_RGET 1
+  #define PETSC_HAVE_MPI_WIN_CREATE 1
+#else
+  #define PETSC_HAVE_MPIUNI 1
+  #define PETSC_HAVE_MPI_LARGE_COUNT 1
+#endif
 #define PETSC_HAVE_MPI_COUNT 1
-#define PETSC_HAVE_MPI_LARGE_COUNT 1
 #define PETSC_HAVE_MPI_REDUCE_LOCAL 1
 #define PETSC_MPIU_IS_COLORING_VALUE_TYPE MPI_UNSIGNED_SHORT
 #define PETSC_IS_COLORING_MAX USHRT_MAX

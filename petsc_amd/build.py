@@ -92,11 +92,13 @@ def build_all(force=False, verbose=False):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import build_ref  # noqa: E402
         out["ref"] = build_ref.build(verbose=verbose)
+        out["ref_mpich"] = build_ref.build(verbose=verbose, arch="mpich")  # same sources against the image's MPICH, for np > 1 parity
         plug = os.path.join(ROOT, "petsc_amd", "plugin", "build_plugin.py")
         if os.path.exists(plug):
             sys.path.insert(0, os.path.join(ROOT, "petsc_amd", "plugin"))
             import build_plugin  # noqa: E402
             out["plugin"] = build_plugin.build(verbose=verbose)
+            out["plugin_mpich"] = build_plugin.build(verbose=verbose, arch="mpich")
     return out
 
 

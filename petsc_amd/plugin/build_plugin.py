@@ -12,18 +12,24 @@ LIB = os.path.join(ROOT, "petsc_amd", "lib")
 SRCS = ["vechipx.c", "mathipx.c", "matmpihipx.c", "pchipx.c", "register.c"]
 
 
-def build(verbose=False):
-    target = os.path.join(LIB, "libpetschipx.so")
+def build(verbose=False, arch="mpiuni"):
+    """arch 'mpiuni': libpetschipx.so against oracle/_ref/lib; arch 'mpich': libpetschipx_mpich.so against oracle/_ref/mpich/lib
+    (MPI types in the ops signatures differ between the reference's MPI stub and a real MPI, hence two builds of one source)."""
+    mpich = arch == "mpich"
+    refdir = os.path.join(ROOT, "oracle", "_ref", "mpich") if mpich else os.path.join(ROOT, "oracle", "_ref")
+    target = os.path.join(LIB, "libpetschipx_mpich.so" if mpich else "libpetschipx.so")
     srcs = [os.path.join(HERE, s) for s in SRCS]
     deps = srcs + [os.path.join(HERE, "hipxplugin.h"), os.path.join(ROOT, "include", "hipx.h"), os.path.join(LIB, "libhipx.so"),
-                   os.path.join(ROOT, "oracle", "_ref", "lib", "libpetsc.so")]
+                   os.path.join(refdir, "lib", "libpetsc.so")]
     if os.path.exists(target) and all(os.path.getmtime(d) <= os.path.getmtime(target) for d in deps):
         return target
-    cmd = ["gcc", "-std=gnu11", "-O2", "-fPIC", "-shared", "-Wall", "-Wno-unused-parameter",
-           "-I" + os.path.join(ROOT, "oracle", "ref_conf"), "-I" + os.path.join(REF, "include"), "-I" + REF, "-I" + os.path.join(REF, "include", "petsc"),
+    extra = ["-DHIPX_REF_MPICH", "-DHIPX_PLUGIN_REGISTER=PetscDLLibraryRegister_petschipx_mpich", "-I/opt/conda/include"] if mpich else []
+    cmd = ["gcc", "-std=gnu11", "-O2", "-fPIC", "-shared", "-Wall", "-Wno-unused-parameter"] + extra + \
+          ["-I" + os.path.join(ROOT, "oracle", "ref_conf"), "-I" + os.path.join(REF, "include"), "-I" + REF, "-I" + os.path.join(REF, "include", "petsc"),
            "-I" + os.path.join(ROOT, "include"), "-o", target] + srcs + \
-          ["-L" + LIB, "-lhipx", "-L" + os.path.join(ROOT, "oracle", "_ref", "lib"), "-lpetsc",
-           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/../../oracle/_ref/lib", "-Wl,-rpath,/opt/conda/lib"]
+          ["-L" + LIB, "-lhipx", "-L" + os.path.join(refdir, "lib"), "-lpetsc",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + ("$ORIGIN/../../oracle/_ref/mpich/lib" if mpich else "$ORIGIN/../../oracle/_ref/lib"), "-Wl,-rpath,/opt/conda/lib"] + \
+          (["-L/opt/conda/lib", "-lmpi"] if mpich else [])
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -34,4 +40,4 @@ def build(verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(verbose=True))
+    print(build(verbose=True), build(verbose=True, arch="mpich"))

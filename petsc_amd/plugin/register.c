@@ -6,7 +6,12 @@
  */
 #include "hipxplugin.h"
 
-PETSC_EXTERN PetscErrorCode PetscDLLibraryRegister_petschipx(void)
+/* the entry symbol is derived from the file name; the MPICH flavour of the plugin is built as libpetschipx_mpich.so */
+#if !defined(HIPX_PLUGIN_REGISTER)
+  #define HIPX_PLUGIN_REGISTER PetscDLLibraryRegister_petschipx
+#endif
+
+PETSC_EXTERN PetscErrorCode HIPX_PLUGIN_REGISTER(void)
 {
   PetscFunctionBegin;
   PetscCall(VecRegister(VECSEQHIPX, VecCreate_SeqHIPX));

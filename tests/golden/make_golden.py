@@ -67,7 +67,27 @@ KATS = [
 ]
 
 
+# np > 1 variants of the same tests (TEST blocks: `nsize: N`); run with mpiexec against oracle/_ref/mpich (MPICH build of the
+# same reference sources).  ex2 suffix 2 prints through -ksp_monitor (%g in the golden, 14 digits in today's reference).
+KATS_MPI = [
+    ("vec_tut_ex1_np2", "kat_vec_tut_ex1", 2, "", "none", "vec/vec/tutorials/output/ex1_1.out"),
+    ("vec_ex21_np2", "kat_vec_ex21", 2, "", "type", "vec/vec/tests/output/ex21_2.out"),
+    ("vec_ex28_np3", "kat_vec_ex28", 3, "", "none", "vec/vec/tests/output/empty.out"),
+    ("vec_ex28_np3_async", "kat_vec_ex28", 3, "-splitreduction_async -options_left no", "none", "vec/vec/tests/output/empty.out"),
+    ("vec_ex31_np2", "kat_vec_ex31", 2, "", "none", "vec/vec/tests/output/empty.out"),
+    ("vec_ex52_np2", "kat_vec_ex52", 2, "", "none", "vec/vec/tests/output/empty.out"),
+    ("mat_ex5_23", "kat_mat_ex5", 3, "-mat_type mpiaij", "notype", "mat/tests/output/ex5_23.out"),
+    ("mat_ex5_33", "kat_mat_ex5", 3, "-mat_type mpiaij -test_diagonalscale", "notype", "mat/tests/output/ex5_33.out"),
+    ("ksp_ex2_2", "ex2", 2, "-ksp_monitor -m 5 -n 5 -ksp_gmres_cgs_refinement_type refine_always", "monitor", "ksp/ksp/tutorials/output/ex2_2.out"),
+]
+
+
 def kats():
+    out = {}
+    for name, exe, np_, args, filt, gold in KATS_MPI:
+        out[name] = {"exe": exe, "nsize": np_, "args": args, "filter": filt, "golden_file": "src/" + gold, "golden": open(os.path.join("/root/reference/src", gold)).read()}
+    json.dump(out, open(os.path.join(HERE, "kats_mpi.json"), "w"), indent=0)
+    print("kats_mpi.json:", sorted(out))
     out = {}
     for name, exe, args, filt, gold in KATS:
         out[name] = {"exe": exe, "args": args, "filter": filt, "golden_file": "src/" + gold, "golden": open(os.path.join("/root/reference/src", gold)).read()}

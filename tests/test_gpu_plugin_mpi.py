@@ -1,0 +1,92 @@
+"""GPU: the plugin's MPI types on REAL MPI ranks.  The reference (same C sources, oracle/build_ref.py arch "mpich") is run under
+mpiexec with -vec_type hipx / -mat_type (mpi)aijhipx on 2-3 ranks that share the box's one GPU, and held to
+  * the reference's own np > 1 golden outputs (tests/golden/kats_mpi.json: ex1 np 2 exact text, ex21_2, ex28 np 3 with and
+    without -splitreduction_async, ex31/ex52 np 2, mat ex5_23 / ex5_33 np 3, ksp ex2_2 np 2), and
+  * the CPU MPI run of the same executable on the same ranks, launched here beside it (bit-exact y = A x through
+    MatMult_MPIAIJ with hipx diagonal/off-diagonal blocks; residual histories to 1e-12 * ||r0||).
+This exercises VecMPIHIPX reductions (device partial + MPI_Allreduce), VecDotBegin/End split reductions, ghost scatter into a
+hipx lvec and the A_d x + B x_ghost composition -- the pieces that were covered by construction only with one rank."""
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref", "mpich", "bin")
+PLUGIN = os.path.join(ROOT, "petsc_amd", "lib", "libpetschipx_mpich.so")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+K = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kats_mpi.json")))
+ENV = dict(os.environ, HIPX_NO_TORCH="1")
+
+
+def mpirun(np_, exe, args, hipx, timeout=150):
+    assert os.path.exists(os.path.join(BIN, exe)) and os.path.exists(PLUGIN), "oracle/_ref/mpich or the MPICH plugin is not built"
+    cmd = [MPIEXEC, "-n", str(np_), os.path.join(BIN, exe)] + args
+    if hipx:
+        cmd += ["-dll_prepend", PLUGIN, "-vec_type", "hipx"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout, env=ENV)
+    assert r.returncode == 0, "%s\n%s" % (" ".join(cmd), r.stdout[-3000:])
+    return r.stdout
+
+
+def apply_filter(kind, text):
+    lines = text.splitlines()
+    if kind == "notype":  # filter: grep -v type, no diff_args -j: white space is not significant
+        lines = [" ".join(ln.split()) for ln in lines if "type" not in ln]
+    elif kind == "type":
+        lines = [ln for ln in lines if "type" not in ln]
+    elif kind == "monitor":  # the golden was written with %g; today's monitor prints 14 digits: reformat the numbers
+        out = []
+        for ln in lines:
+            m = re.match(r"(\s*\d+ KSP Residual norm )(\S+)\s*$", ln)
+            out.append(m.group(1) + "%g" % float(m.group(2)) if m else ln)
+        lines = out
+    return "\n".join(lines).strip()
+
+
+@pytest.mark.parametrize("name", sorted(K))
+def test_reference_np_kat_with_hipx_types(name):
+    k = K[name]
+    args = k["args"].replace("-mat_type mpiaij", "-mat_type mpiaijhipx").split()
+    if k["exe"] == "ex2":
+        args += ["-mat_type", "aijhipx"]
+    got = apply_filter(k["filter"], mpirun(k["nsize"], k["exe"], args, True))
+    want = apply_filter(k["filter"], k["golden"])
+    assert got == want, "np-%d KAT %s differs from %s:\n--- got\n%s\n--- want\n%s" % (k["nsize"], name, k["golden_file"], got[:1500], want[:1500])
+
+
+def parse_driver(txt):
+    hist = [float(l.split()[2]) for l in txt.splitlines() if l.startswith("hist ")]
+    y = sorted((int(l.split()[1]), l.split()[2]) for l in txt.splitlines() if l.startswith("y "))  # ranks print in any order
+    m = re.search(r"iterations (\d+) reason (-?\d+) error (\S+)", txt)
+    return hist, y, (int(m.group(1)), int(m.group(2)), float(m.group(3))) if m else None
+
+
+@pytest.mark.parametrize("np_,args", [(2, "-stencil 7 -n 8"), (3, "-stencil 27 -n 6"), (3, "-stencil 5 -m 9 -n 7")])
+def test_matmult_mpiaijhipx_bit_exact_vs_cpu_mpi(np_, args):
+    a = args.split() + ["-dump_y", "-ksp_max_it", "1"]
+    _, y_cpu, _ = parse_driver(mpirun(np_, "ref_driver", a, False))
+    _, y_gpu, _ = parse_driver(mpirun(np_, "ref_driver", a + ["-mat_type", "aijhipx"], True))
+    assert len(y_cpu) > 0 and y_gpu == y_cpu  # printed with %.17g: string equality is bit equality
+
+
+@pytest.mark.parametrize("np_,args,tol", [
+    (2, "-stencil 7 -n 20 -ksp_type cg -pc_type jacobi -ksp_rtol 1e-8", 1e-12),
+    (3, "-stencil 27 -n 16 -ksp_type cg -pc_type jacobi -ksp_rtol 1e-8", 1e-12),
+    (2, "-stencil 27 -n 12 -ksp_type gmres -pc_type jacobi -ksp_rtol 1e-8", 1e-10),
+    (3, "-stencil 7 -n 16 -ksp_type cg -pc_type jacobi -ksp_norm_type natural -ksp_rtol 1e-8", 1e-12),
+])
+def test_ksp_history_np_vs_cpu_mpi(np_, args, tol):
+    a = args.split() + ["-history"]
+    h_cpu, _, t_cpu = parse_driver(mpirun(np_, "ref_driver", a, False))
+    h_gpu, _, t_gpu = parse_driver(mpirun(np_, "ref_driver", a + ["-mat_type", "aijhipx"], True))
+    assert t_gpu[0] == t_cpu[0] and t_gpu[1] == t_cpu[1]
+    assert len(h_gpu) == len(h_cpu)
+    r0 = h_cpu[0]
+    for g, c in zip(h_gpu, h_cpu):
+        assert abs(g - c) <= tol * r0 + 1e-9 * abs(c)
+    assert abs(t_gpu[2] - t_cpu[2]) <= 1e-10 * max(1.0, abs(t_cpu[2])) + 1e-6 * abs(t_cpu[2])
