@@ -87,6 +87,16 @@ int main(int argc, char **argv)
   PetscCall(MatMPIAIJSetPreallocation(A, stencil, NULL, stencil, NULL));
   PetscCall(MatGetOwnershipRange(A, &Istart, &Iend));
   PetscCall(Assemble(A, stencil, m, n, Istart, Iend));
+  {
+    PetscBool dup = PETSC_FALSE; /* -dup_mat: run everything on MatDuplicate(A) (exercises the duplicate op of Mat subclasses) */
+    PetscCall(PetscOptionsGetBool(NULL, NULL, "-dup_mat", &dup, NULL));
+    if (dup) {
+      Mat C;
+      PetscCall(MatDuplicate(A, MAT_COPY_VALUES, &C));
+      PetscCall(MatDestroy(&A));
+      A = C;
+    }
+  }
   PetscCall(MatCreateVecs(A, &u, &b));
   PetscCall(VecSetFromOptions(u));
   PetscCall(VecDuplicate(u, &x));

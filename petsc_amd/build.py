@@ -64,7 +64,9 @@ def build_hipx(force=False, verbose=False):
     target = os.path.join(LIB, "libhipx.so")
     if force or _newer(target, objs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs +
-             ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
+             # nodelete: a host that dlclose()s its plugins at finalize (PetscFinalize does) must not unmap code objects the
+             # HIP runtime still has registered; the library stays resident until process exit, as under ctypes
+             ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-z,nodelete"])
     return target
 
 

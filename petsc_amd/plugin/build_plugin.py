@@ -28,7 +28,7 @@ def build(verbose=False, arch="mpiuni"):
           ["-I" + os.path.join(ROOT, "oracle", "ref_conf"), "-I" + os.path.join(REF, "include"), "-I" + REF, "-I" + os.path.join(REF, "include", "petsc"),
            "-I" + os.path.join(ROOT, "include"), "-o", target] + srcs + \
           ["-L" + LIB, "-lhipx", "-L" + os.path.join(refdir, "lib"), "-lpetsc",
-           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + ("$ORIGIN/../../oracle/_ref/mpich/lib" if mpich else "$ORIGIN/../../oracle/_ref/lib"), "-Wl,-rpath,/opt/conda/lib"] + \
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + ("$ORIGIN/../../oracle/_ref/mpich/lib" if mpich else "$ORIGIN/../../oracle/_ref/lib"), "-Wl,-rpath,/opt/conda/lib", "-Wl,-z,nodelete"] + \
           (["-L/opt/conda/lib", "-lmpi"] if mpich else [])
     if verbose:
         print(" ".join(cmd))

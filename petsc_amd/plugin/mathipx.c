@@ -177,9 +177,11 @@ static PetscErrorCode MatDuplicate_SeqAIJHIPX(Mat A, MatDuplicateOption op, Mat 
   Mat_SeqAIJHIPX *h = (Mat_SeqAIJHIPX *)A->spptr;
 
   PetscFunctionBegin;
-  PetscCall((*h->parent_duplicate)(A, op, B)); /* MatDuplicate_SeqAIJ: B comes back as a plain seqaij with A's ops copied */
-  (*B)->spptr = NULL;
-  PetscCall(MatConvert_SeqAIJ_SeqAIJHIPX(*B, MATSEQAIJHIPX, MAT_INPLACE_MATRIX, B));
+  /* MatDuplicate_SeqAIJ (aij.c:4929-4938) creates B with MatSetType(B, A's type name), i.e. through MatCreate_SeqAIJHIPX:
+     B is already complete, its device CSR is uploaded lazily at the first product */
+  PetscCall((*h->parent_duplicate)(A, op, B));
+  if (!(MatIsSeqAIJHIPX(*B) && (*B)->spptr)) PetscCall(MatConvert_SeqAIJ_SeqAIJHIPX(*B, MATSEQAIJHIPX, MAT_INPLACE_MATRIX, B));
+  ((Mat_SeqAIJHIPX *)(*B)->spptr)->spmv_variant = h->spmv_variant;
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 

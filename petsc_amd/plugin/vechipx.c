@@ -633,11 +633,21 @@ static PetscErrorCode VecDotNorm2_MPIHIPX(Vec s, Vec t, PetscScalar *dp, PetscSc
   PetscCall(VecDotNorm2_MPI_Default(s, t, dp, nm, VecDotNorm2Local_HIPX));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
-static PetscErrorCode VecSum_MPIHIPX(Vec x, PetscScalar *sum)
+/* ops->sum is the LOCAL sum for every type: VecSum() itself reduces over the communicator (vinv.c:1548-1558) */
+static PetscErrorCode VecMax_MPIHIPX(Vec x, PetscInt *idx, PetscReal *z) /* pvec2.c:56-63 with the device local op */
 {
+  const MPI_Op ops[] = {MPIU_MAXLOC, MPIU_MAX};
+
   PetscFunctionBegin;
-  PetscCall(VecSumLocal_HIPX(x, sum));
-  PetscCallMPI(MPIU_Allreduce(MPI_IN_PLACE, sum, 1, MPIU_SCALAR, MPIU_SUM, PetscObjectComm((PetscObject)x)));
+  PetscCall(VecMinMax_MPI_Default(x, idx, z, VecMaxLocal_HIPX, ops));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+static PetscErrorCode VecMin_MPIHIPX(Vec x, PetscInt *idx, PetscReal *z) /* pvec2.c:65-72 */
+{
+  const MPI_Op ops[] = {MPIU_MINLOC, MPIU_MIN};
+
+  PetscFunctionBegin;
+  PetscCall(VecMinMax_MPI_Default(x, idx, z, VecMinLocal_HIPX, ops));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -666,6 +676,29 @@ static PetscErrorCode VecDestroy_MPIHIPX(Vec v)
   PetscFunctionBegin;
   PetscCall(VecHIPXFreeDevice(v));
   PetscCall((*parent_destroy_mpi)(v));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* VecDuplicate_MPI (pbvec.c:23-66) builds the duplicate with VecCreate_MPI_Private and copies win's ops table over it, which
+   would leave our ops on a plain Vec_MPI block without the VecHIPXExt tail.  Like the reference's device subclasses
+   (VecDuplicate_MPICUPM), duplicate through our own creator instead; the layout object is shared, as the parent does. */
+static PetscErrorCode VecDuplicate_MPIHIPX(Vec win, Vec *V)
+{
+  Vec v;
+
+  PetscFunctionBegin;
+  PetscCheck(!((Vec_MPI *)win->data)->localrep, PetscObjectComm((PetscObject)win), PETSC_ERR_SUP, "ghosted vectors are not supported by VECMPIHIPX");
+  PetscCall(VecCreate(PetscObjectComm((PetscObject)win), &v));
+  PetscCall(PetscLayoutReference(win->map, &v->map));
+  PetscCall(VecSetType(v, VECMPIHIPX));
+  v->ops[0]             = win->ops[0];
+  v->stash.donotstash   = win->stash.donotstash;
+  v->stash.ignorenegidx = win->stash.ignorenegidx;
+  v->stash.bs           = win->stash.bs;
+  v->bstash.bs          = win->bstash.bs;
+  PetscCall(PetscObjectListDuplicate(((PetscObject)win)->olist, &((PetscObject)v)->olist));
+  PetscCall(PetscFunctionListDuplicate(((PetscObject)win)->qlist, &((PetscObject)v)->qlist));
+  *V = v;
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -787,8 +820,11 @@ PetscErrorCode VecCreate_MPIHIPX(Vec v)
   v->ops->mtdot    = VecMDot_MPIHIPX;
   v->ops->norm     = VecNorm_MPIHIPX;
   v->ops->dotnorm2 = VecDotNorm2_MPIHIPX;
-  v->ops->sum      = VecSum_MPIHIPX;
+  v->ops->sum      = VecSumLocal_HIPX;
+  v->ops->max      = VecMax_MPIHIPX;
+  v->ops->min      = VecMin_MPIHIPX;
   v->ops->destroy  = VecDestroy_MPIHIPX;
+  v->ops->duplicate = VecDuplicate_MPIHIPX;
   v->offloadmask   = PETSC_OFFLOAD_CPU;
   PetscCall(PetscObjectChangeTypeName((PetscObject)v, VECMPIHIPX));
   PetscFunctionReturn(PETSC_SUCCESS);

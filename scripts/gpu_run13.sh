@@ -1,9 +1,11 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT" || exit 1
-export TMPDIR=/tmp
-mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_halo.py tests/test_gpu_plugin.py -m gpu -q --timeout 600 -p no:cacheprovider > gpurun_out/pytest13.log 2>&1
-echo "pytest exit $?" >> gpurun_out/pytest13.log
-timeout 900 python scripts/gmres_sor_timing.py 128 27 > gpurun_out/gmres_sor_27_128.log 2>&1
-timeout 900 python scripts/gmres_sor_timing.py 192 7 > gpurun_out/gmres_sor_7_192.log 2>&1
-tail -3 gpurun_out/pytest13.log; grep -v amdgpu gpurun_out/gmres_sor_27_128.log gpurun_out/gmres_sor_7_192.log
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp HIPX_NO_TORCH=1
+B=oracle/_ref/mpich/bin; P=petsc_amd/lib/libpetschipx_mpich.so; M=/opt/conda/bin/mpiexec
+A="-m 5 -n 5 -ksp_gmres_cgs_refinement_type refine_always"
+{
+echo "== np2 vec only gdb"; timeout 100 $M -n 2 /opt/rocm/bin/rocgdb -batch -ex run -ex bt --args $B/ex2 $A -dll_prepend $P -vec_type hipx 2>&1 | grep -v "New Thread\|Thread.*exited\|libthread_db" | head -150
+echo "== np1 vec only"; timeout 60 $M -n 1 $B/ex2 $A -dll_prepend $P -vec_type hipx 2>&1 | tail -3
+echo "== np2 ex31"; timeout 60 $M -n 2 $B/kat_vec_ex31 -dll_prepend $P -vec_type hipx 2>&1 | tail -3
+for i in 1 2 3; do echo "== np2 full gdb $i"; timeout 100 $M -n 2 /opt/rocm/bin/rocgdb -batch -ex run -ex bt --args $B/ex2 $A -dll_prepend $P -vec_type hipx -mat_type aijhipx 2>&1 | grep -v "New Thread\|Thread.*exited\|libthread_db" | tail -40; done
+} > gpurun_out/mpi_dbg.log 2>&1
+tail -250 gpurun_out/mpi_dbg.log

@@ -69,6 +69,8 @@ CASES = [("-stencil 7 -n 24 -ksp_type cg -pc_type jacobi -ksp_rtol 1e-8", None, 
          ("-stencil 27 -n 14 -ksp_type gmres -pc_type sor -ksp_rtol 1e-8", None, 1e-8),
          ("-stencil 7 -n 20 -ksp_type gmres -pc_type jacobi -ksp_rtol 1e-8", None, 1e-8),
          ("-stencil 7 -n 16 -ksp_type cg -pc_type sor -ksp_rtol 1e-8", None, 1e-8),
+         ("-stencil 7 -n 16 -ksp_type cg -pc_type sor -ksp_rtol 1e-8 -dup_mat", None, 1e-8),  # operator = MatDuplicate(A)
+         ("-stencil 7 -n 16 -ksp_type cg -pc_type bjacobi -sub_pc_type sor -ksp_rtol 1e-8", None, 1e-8),  # local-vector views
          ("-stencil 7 -n 16 -ksp_type cg -ksp_cg_single_reduction -pc_type jacobi -ksp_rtol 1e-8", None, 1e-8),
          ("-stencil 7 -n 16 -ksp_type fgmres -pc_type jacobi -ksp_rtol 1e-8", None, 1e-6),
          ("-stencil 7 -n 16 -ksp_type cr -pc_type jacobi -ksp_rtol 1e-8", None, 1e-7),

@@ -66,12 +66,19 @@ def parse_driver(txt):
     return hist, y, (int(m.group(1)), int(m.group(2)), float(m.group(3))) if m else None
 
 
-@pytest.mark.parametrize("np_,args", [(2, "-stencil 7 -n 8"), (3, "-stencil 27 -n 6"), (3, "-stencil 5 -m 9 -n 7")])
+@pytest.mark.parametrize("np_,args", [(2, "-stencil 7 -n 8"), (3, "-stencil 27 -n 6"), (3, "-stencil 5 -m 9 -n 7"), (2, "-stencil 27 -n 6 -dup_mat")])
 def test_matmult_mpiaijhipx_bit_exact_vs_cpu_mpi(np_, args):
     a = args.split() + ["-dump_y", "-ksp_max_it", "1"]
     _, y_cpu, _ = parse_driver(mpirun(np_, "ref_driver", a, False))
     _, y_gpu, _ = parse_driver(mpirun(np_, "ref_driver", a + ["-mat_type", "aijhipx"], True))
     assert len(y_cpu) > 0 and y_gpu == y_cpu  # printed with %.17g: string equality is bit equality
+
+
+def test_hipx_vectors_with_host_mpiaij_and_default_pc():
+    """-vec_type hipx only: CPU MPIAIJ matrix, block Jacobi/ILU(0) default PC -- duplicates of MPI hipx vectors, local-vector
+    views into them (PCApply_BJacobi_Singleblock), clean exit (heap-checked by glibc)."""
+    args = "-m 5 -n 5 -ksp_monitor -ksp_gmres_cgs_refinement_type refine_always".split()
+    assert mpirun(2, "ex2", args, True) == mpirun(2, "ex2", args, False)
 
 
 @pytest.mark.parametrize("np_,args,tol", [
