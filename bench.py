@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--grid", dest="n", type=int, default=256, help="grid points per side (not --n: torchrun would read it as an abbreviation of its own options)")
     ap.add_argument("--stencil", type=int, default=7, choices=[7, 27])
     ap.add_argument("--fused", type=int, default=1, help="1 (default): fused SpMV+dot and AXPY+AXPY+PCJACOBI+norm+dot kernels -- same arithmetic and order per element, fewer HBM passes; 0: one kernel per reference Vec/Mat call (cg.c:249-344)")
-    ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (0 auto, 1 plain loads, 2 non-temporal loads)")
+    ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (include/hipx.h hipxMatSetSpMVVariant): 0 auto, 1 32-bit-column stream kernel, 22/23 packed 16-bit columns, 24/25 packed columns + 8-bit value dictionary")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -176,19 +176,19 @@ def main():
     spmv_ms = tot_ms.value / max(cnt.value, 1)
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
 
+    kbuf = C.create_string_buffer(256)
+    _lib.chk(hx.hipxMatGetSpMVKernel(M.A, kbuf, 256))
+    kname = kbuf.value.decode()
     # HBM traffic of the SpMV launch cannot be counted from inside this process; it comes from the committed rocprofv3
-    # PMC passes of this same command (profiles/README.md), when they match the kernel variant and workload
+    # PMC passes of this same command (profiles/README.md, scripts/pmc_summary.py), matched on kernel and workload
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "spmv_traffic.json")))
-        key = "%dpt_%d_v%d_g%d" % (args.stencil, n, args.variant, world)
+        key = "%dpt_%d_%s_g%d" % (args.stencil, n, kname.split(" ")[0], world)
         if key in tj:
             traffic = tj[key]["traffic_bytes"]
     except Exception:
         pass
-    auto = "spmv_pk16r_kernel (CSR MatMult, packed 16-bit columns, row-parallel gather)" if nnz_local <= 16 * m else "spmv_pk16_kernel (CSR MatMult, packed 16-bit columns)"
-    kname = {0: auto, 22: "spmv_pk16_kernel (CSR MatMult, packed 16-bit columns)", 23: "spmv_pk16r_kernel (CSR MatMult, packed 16-bit columns, row-parallel gather)",
-             }.get(args.variant, "spmv_stream_kernel (CSR MatMult, 32-bit columns)")
     out = None
     if rank == 0:
         value = args.steps / elapsed
@@ -203,7 +203,9 @@ def main():
                        "residual_norm_after": rnorm},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": cnt.value, "avg_launch_ms": spmv_ms, "algorithmic_bytes": spmv_bytes,
-                         "frac_of_measured_copy_peak_6290": achieved / 6290.0},
+                         "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+                         "note": "achieved = CSR algorithmic bytes (12 nnz + 4 (N+1) + 16 N, SURVEY 8(d)) / launch time; the packed kernels move fewer bytes "
+                                 "than that (16-bit column codes; 8-bit value codes when a[] has <= 256 distinct values), see traffic"},
         }
         if world == 1 and not args.no_cpu_baseline:
             ref = cpu_baseline_reference(args.stencil, n, 24 if n >= 200 else 100)

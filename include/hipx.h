@@ -132,8 +132,14 @@ int hipxMatGetInfo(hipxMat A, hipx_int *m, hipx_int *n, int64_t *nnz, int64_t *d
 /* replaces MatGetDiagonal_SeqAIJ aij.c:1347 */       int hipxMatGetDiagonal(hipxMat A, double *d);
 /* replaces MatSOR_SeqAIJ aij.c:1842 (flag = MatSORType bits petscmat.h:1664-1671); b, x device vectors */
 int hipxMatSOR(hipxMat A, const double *b, double omega, int flag, double shift, hipx_int its, hipx_int lits, double *x);
-/* tuning knobs (plugin option -mat_aijhipx_*): kernel variant 0 = auto */
+/* tuning knobs (plugin option -mat_aijhipx_spmv_variant): kernel variant.  0 = auto (>= 2^20 nonzeros: packed 16-bit
+   column codes, row-parallel gather for short rows, and an 8-bit value dictionary when a[] holds <= 256 distinct bit
+   patterns); 1..12 = 32-bit-column stream kernel geometries; 22 / 23 = packed columns (staged / row-parallel);
+   24 / 25 = 22 / 23 plus the value dictionary (falls back to 22 / 23 when the dictionary does not fit).
+   Every variant produces the bit-identical y (same products, same left-to-right row sums as aij.c:1486-1494). */
 int hipxMatSetSpMVVariant(hipxMat A, int variant);
+/* name of the kernel the next hipxMatMult will launch (builds the packed formats if they are pending) */
+int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len);
 /* y = A x and *dot = x.y fused in the SpMV epilogue (cg.c:257-258) */
 int hipxMatMultDot(hipxMat A, const double *x, double *y, double *dot);
 

@@ -19,6 +19,9 @@
 #include "hipx_internal.h"
 #include "hipx_reduce.h"
 #include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -48,6 +51,14 @@ struct hipxMat_s {
   unsigned short *d_pk      = nullptr;   // (window id << 12) | offset inside the window
   hipx_int      *d_pkbase   = nullptr;   // PK_WMAX window starts per row block (-1 in slot 0 = block keeps 32-bit columns)
   int64_t        pk_fallback_blocks = 0;
+  // value dictionary (<= 256 distinct bit patterns in a[]): 1-byte code per nonzero, rebuilt when the values change
+  bool           auto_sel = true;     // variant 0: the library picks the kernel form
+  int            vd_mode  = 0;        // 1 = use the dictionary kernels when the dictionary exists
+  bool           vd_ready = false;    // dictionary attempted for the current values
+  bool           vd_ok    = false;    // ... and it fits
+  int            vd_count = 0;
+  unsigned char *d_vc     = nullptr;
+  double        *d_vdict  = nullptr;  // 256 entries
   int       probe      = 0;   // phase-attribution probe kernels (scripts/spmv_variants.py); results are NOT A x
   std::vector<int64_t> h_i;  // host copy of the row offsets (set-up only)
   void     *sor_state = nullptr;  // hipxSorState, owned by hipx_sor.hip
@@ -112,6 +123,7 @@ constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 typedef int    int4v __attribute__((ext_vector_type(4)));
 typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
+typedef unsigned char  uchar4v __attribute__((ext_vector_type(4)));
 
 template <bool NT, typename T>
 __device__ __forceinline__ T stream_load(const T *p)
@@ -260,10 +272,13 @@ __global__ __launch_bounds__(SPMV_THREADS) void spmv_stream_kernel(const hipx_in
 constexpr int PK_WMAX = 16;
 constexpr int PK_WLEN = 4096;
 
-template <typename IT, int MODE, bool DOT>
+// VD = true: values come from the <= 256-entry dictionary of exact bit patterns through a 1-byte code (see spmv_pk16r_kernel);
+// the dictionary is read through L1 (2 KiB, always resident), so no extra barrier is needed before the products.
+template <typename IT, int MODE, bool DOT, bool VD>
 __global__ __launch_bounds__(256) void spmv_pk16_kernel(const hipx_int *__restrict__ rb, hipx_int nblocks, hipx_int blocks_per_xcd, const IT *__restrict__ ai,
                                                         const hipx_int *__restrict__ aj, const unsigned short *__restrict__ pk, const hipx_int *__restrict__ pkbase,
-                                                        const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout, double *dotpart, hipx_int ncols)
+                                                        const double *__restrict__ aa, const unsigned char *__restrict__ vc, const double *__restrict__ vdict,
+                                                        const double *__restrict__ x, const double *yin, double *yout, double *dotpart, hipx_int ncols)
 {
   constexpr int THREADS = 256, CAP = 2048;
   __shared__ double prod[CAP];
@@ -295,8 +310,16 @@ __global__ __launch_bounds__(256) void spmv_pk16_kernel(const hipx_int *__restri
         for (int it = 0; it < NIT; it++) {
           const IT q  = (IT)t + (IT)it * THREADS;
           const IT qc = q < nq ? q : nq - 1;
-          va[it]      = a2[2 * qc];
-          vb[it]      = a2[2 * qc + 1];
+          if (VD && packed) {
+            const uchar4v u = reinterpret_cast<const uchar4v *>(vc + ka)[qc];
+            va[it].x = vdict[u.x];
+            va[it].y = vdict[u.y];
+            vb[it].x = vdict[u.z];
+            vb[it].y = vdict[u.w];
+          } else {
+            va[it] = a2[2 * qc];
+            vb[it] = a2[2 * qc + 1];
+          }
           if (packed) {
             const ushort4v v = reinterpret_cast<const ushort4v *>(pk + ka)[qc];
             c[it][0] = __shfl(base_reg, v.x >> 12, 64) + (v.x & 0xfff);
@@ -388,14 +411,21 @@ __global__ __launch_bounds__(256) void spmv_pk16_kernel(const hipx_int *__restri
 // touches x[row + offset_k] for 64 consecutive rows -- 4-5 cache lines instead of the ~20 that the nonzero-major
 // order of spmv_pk16_kernel spreads one gather instruction over (7 stencil offsets interleaved across the lanes).
 // Same products, same left-to-right sums: y is bit-identical.  Blocks without a packed code keep the pk16 path.
-template <typename IT, int MODE, bool DOT>
+//
+// VD = true ("pk16rv"): the matrix has at most 256 distinct values (constant-coefficient stencils have 2-4): the 8-byte
+// value stream is replaced by a 1-byte code into a dictionary of the exact bit patterns (hipxMat_s::d_vdict), held in LDS.
+// Matrix traffic per nonzero: 2 + 1 instead of 2 + 8 bytes.  The products use the same doubles in the same order: y is
+// bit-identical to the plain kernels.  Blocks that keep 32-bit columns, and long rows, still read a[] itself.
+template <typename IT, int MODE, bool DOT, bool VD, int W, int DBG = 0>
 __global__ __launch_bounds__(256) void spmv_pk16r_kernel(const hipx_int *__restrict__ rb, hipx_int nblocks, hipx_int blocks_per_xcd, const IT *__restrict__ ai,
                                                          const hipx_int *__restrict__ aj, const unsigned short *__restrict__ pk, const hipx_int *__restrict__ pkbase,
-                                                         const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout, double *dotpart, hipx_int ncols)
+                                                         const double *__restrict__ aa, const unsigned char *__restrict__ vc, const double *__restrict__ vdict,
+                                                         const double *__restrict__ x, const double *yin, double *yout, double *dotpart, hipx_int ncols)
 {
   constexpr int THREADS = 256, CAP = 2048;
-  __shared__ double         vals[CAP];
-  __shared__ unsigned short codes[CAP];
+  // VD: vals[0..255] = dictionary, the value codes live behind it (bytes); else vals[] = the block's values
+  __shared__ double         vals[VD ? (256 + (CAP + 16) / 8) : CAP];
+  __shared__ unsigned short codes[CAP + 16];
   const hipx_int bid = (hipx_int)blockIdx.x;
   const hipx_int b   = (bid & 7) * blocks_per_xcd + (bid >> 3);
   double         mydot = 0.0;
@@ -419,18 +449,39 @@ __global__ __launch_bounds__(256) void spmv_pk16r_kernel(const hipx_int *__restr
       const IT      nq  = (k1 - ka + 3) >> 2;
       constexpr int NIT = CAP / 4 / THREADS;
       if (packed) {
-        if (nq > 0) {
+        unsigned char *vcl = reinterpret_cast<unsigned char *>(vals + 256);  // VD only
+        int            sh  = 0;                                              // LDS index of entry ka
+        if constexpr (VD) {
+          // 8 nonzeros per lane: one 16-byte load of column codes, one 8-byte load of value codes
+          const IT ka8 = k0 & ~(IT)7;
+          const IT nq8 = (k1 - ka8 + 7) >> 3;
+          sh           = (int)(ka - ka8);
+          vals[t]      = vdict[t];
+          for (IT q = t; q < nq8; q += THREADS) {
+            int4v              c8;
+            unsigned long long v8;
+            if constexpr (DBG == 3) {  // probe: no phase-1 matrix loads
+              c8 = int4v{0, 0, 0, 0};
+              v8 = 0;
+            } else {
+              c8 = reinterpret_cast<const int4v *>(pk + ka8)[q];
+              v8 = reinterpret_cast<const unsigned long long *>(vc + ka8)[q];
+            }
+            reinterpret_cast<int4v *>(codes)[q]            = c8;
+            reinterpret_cast<unsigned long long *>(vcl)[q] = v8;
+          }
+        } else if (nq > 0) {
           const dbl2     *a2 = reinterpret_cast<const dbl2 *>(aa + ka);
           const ushort4v *c4 = reinterpret_cast<const ushort4v *>(pk + ka);
           dbl2            va[NIT], vb[NIT];
-          ushort4v        vc[NIT];
+          ushort4v        vq[NIT];
 #pragma unroll
           for (int it = 0; it < NIT; it++) {
             const IT q  = (IT)t + (IT)it * THREADS;
             const IT qc = q < nq ? q : nq - 1;
             va[it]      = a2[2 * qc];
             vb[it]      = a2[2 * qc + 1];
-            vc[it]      = c4[qc];
+            vq[it]      = c4[qc];
           }
 #pragma unroll
           for (int it = 0; it < NIT; it++) {
@@ -438,7 +489,7 @@ __global__ __launch_bounds__(256) void spmv_pk16r_kernel(const hipx_int *__restr
             if (q < nq) {
               reinterpret_cast<dbl2 *>(vals)[2 * q]     = va[it];
               reinterpret_cast<dbl2 *>(vals)[2 * q + 1] = vb[it];
-              reinterpret_cast<ushort4v *>(codes)[q]    = vc[it];
+              reinterpret_cast<ushort4v *>(codes)[q]    = vq[it];
             }
           }
         }
@@ -449,24 +500,35 @@ __global__ __launch_bounds__(256) void spmv_pk16r_kernel(const hipx_int *__restr
         int       maxlen = len;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
-        const int s0  = (int)(rs - ka);
+        const int s0  = (int)(rs - ka) + sh;
         double    sum = (MODE == 1 && row < r1) ? yin[row] : 0.0;
-        for (int k = 0; k < maxlen; k += 4) {
-          double xv[4], av[4];
+        // W gathers in flight per lane before the first one is consumed (the sum itself stays strictly left to right)
+        for (int k = 0; k < (DBG == 2 ? 0 : maxlen); k += W) {
+          double xv[W], av[W];
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
+          for (int e = 0; e < W; e++) {
             const bool     on   = (k + e) < len;
-            const int      idx  = on ? s0 + k + e : 0;
+            const int      idx  = on ? s0 + k + e : sh;
             const unsigned code = codes[idx];
             const int      col  = __shfl(base_reg, code >> 12, 64) + (int)(code & 0xfff);
-            av[e]               = vals[idx];
-            xv[e]               = on ? x[col] : 0.0;
+            if constexpr (VD) av[e] = vals[vcl[idx]];
+            else av[e] = vals[idx];
+            if constexpr (DBG == 1) xv[e] = (double)col;  // probe: no x gather
+            else xv[e] = on ? x[col] : 0.0;
           }
 #pragma unroll
-          for (int e = 0; e < 4; e++)
+          for (int e = 0; e < W; e++)
             if ((k + e) < len) sum += av[e] * xv[e];
         }
         if (row < r1) {
+          yout[row] = sum;
+          if (DOT) mydot = xrow * sum;
+        }
+      } else if constexpr (VD) {
+        // block kept its 32-bit columns (rare: scattered columns AND few distinct values): plain row walk, no LDS staging
+        if (row < r1) {
+          double sum = (MODE == 1) ? yin[row] : 0.0;
+          for (IT k = rs; k < re; k++) sum += aa[k] * x[aj[k]];
           yout[row] = sum;
           if (DOT) mydot = xrow * sum;
         }
@@ -586,6 +648,128 @@ int auto_tile_mode(hipxMat A)
   return (A->nnz <= (int64_t)16 * A->nrows_c) ? 3 : 2;
 }
 
+// Value dictionary: succeeds when a[] holds at most 256 distinct bit patterns (compared as 64-bit integers, so -0.0, NaN
+// payloads etc. stay exact).  Host set-up, parallel; a 64 Ki-entry prefix is examined first so that general matrices
+// (all values distinct) cost one small copy.
+struct VdTable {
+  static constexpr int kSlots = 1024;
+  uint64_t key[kSlots];
+  int      code[kSlots];
+  int      count = 0;
+  VdTable() { std::fill(code, code + kSlots, -1); }
+  static inline unsigned slot_of(uint64_t k) { return (unsigned)((k * 0x9E3779B97F4A7C15ull) >> 54); }
+  inline int find(uint64_t k) const
+  {
+    unsigned s = slot_of(k);
+    while (code[s] >= 0) {
+      if (key[s] == k) return code[s];
+      s = (s + 1) & (kSlots - 1);
+    }
+    return -1;
+  }
+  inline bool insert(uint64_t k)  // false = dictionary full
+  {
+    unsigned s = slot_of(k);
+    while (code[s] >= 0) {
+      if (key[s] == k) return true;
+      s = (s + 1) & (kSlots - 1);
+    }
+    if (count >= 256) return false;
+    key[s]  = k;
+    code[s] = count++;
+    return true;
+  }
+};
+
+int ensure_vdict(hipxMat A)
+{
+  if (A->vd_ready) return HIPX_SUCCESS;
+  A->vd_ready = true;
+  A->vd_ok    = false;
+  const size_t nnz = (size_t)A->nnz;
+  if (!nnz) return HIPX_SUCCESS;
+  HIPX_HIP(hipStreamSynchronize(rt().compute));
+  {
+    const size_t          np = std::min<size_t>(nnz, 65536);
+    std::vector<uint64_t> pre(np);
+    HIPX_HIP(hipMemcpy(pre.data(), A->d_a, sizeof(uint64_t) * np, hipMemcpyDeviceToHost));
+    VdTable t;
+    for (size_t k = 0; k < np; k++)
+      if (!t.insert(pre[k])) return HIPX_SUCCESS;
+  }
+  std::vector<uint64_t> ha(nnz);
+  HIPX_HIP(hipMemcpy(ha.data(), A->d_a, sizeof(uint64_t) * nnz, hipMemcpyDeviceToHost));
+  const int            nthreads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+  std::vector<VdTable> local((size_t)nthreads);
+  std::atomic<bool>    overflow(false);
+  auto chunk = [&](int tid, size_t &lo, size_t &hi) {
+    lo = nnz * (size_t)tid / (size_t)nthreads;
+    hi = nnz * (size_t)(tid + 1) / (size_t)nthreads;
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int tid = 0; tid < nthreads; tid++)
+      pool.emplace_back([&, tid]() {
+        size_t lo, hi;
+        chunk(tid, lo, hi);
+        VdTable &t    = local[(size_t)tid];
+        uint64_t last = ~ha[lo < nnz ? lo : 0];
+        for (size_t k = lo; k < hi; k++) {
+          const uint64_t v = ha[k];
+          if (v == last) continue;
+          last = v;
+          if (!t.insert(v)) {
+            overflow.store(true);
+            return;
+          }
+          if ((k & 0xfffff) == 0 && overflow.load()) return;
+        }
+      });
+    for (auto &th : pool) th.join();
+  }
+  if (overflow.load()) return HIPX_SUCCESS;
+  std::vector<uint64_t> dict;
+  for (const VdTable &t : local)
+    for (int sl = 0; sl < VdTable::kSlots; sl++)
+      if (t.code[sl] >= 0) dict.push_back(t.key[sl]);
+  std::sort(dict.begin(), dict.end());
+  dict.erase(std::unique(dict.begin(), dict.end()), dict.end());
+  if (dict.size() > 256) return HIPX_SUCCESS;
+  VdTable global;
+  for (uint64_t v : dict) global.insert(v);  // code = rank in the sorted dictionary (deterministic)
+  std::vector<unsigned char> hc(nnz + 16, 0);
+  {
+    std::vector<std::thread> pool;
+    for (int tid = 0; tid < nthreads; tid++)
+      pool.emplace_back([&, tid]() {
+        size_t lo, hi;
+        chunk(tid, lo, hi);
+        uint64_t last = 0;
+        int      lc   = -1;
+        for (size_t k = lo; k < hi; k++) {
+          const uint64_t v = ha[k];
+          if (lc < 0 || v != last) {
+            last = v;
+            lc   = global.find(v);
+          }
+          hc[k] = (unsigned char)lc;
+        }
+      });
+    for (auto &th : pool) th.join();
+  }
+  dict.resize(256, 0);
+  if (!A->d_vc) {
+    HIPX_HIP(hipMalloc((void **)&A->d_vc, hc.size()));
+    HIPX_HIP(hipMalloc((void **)&A->d_vdict, sizeof(uint64_t) * 256));
+    A->device_bytes += (int64_t)(hc.size() + sizeof(uint64_t) * 256);
+  }
+  HIPX_HIP(hipMemcpy(A->d_vc, hc.data(), hc.size(), hipMemcpyHostToDevice));
+  HIPX_HIP(hipMemcpy(A->d_vdict, dict.data(), sizeof(uint64_t) * 256, hipMemcpyHostToDevice));
+  A->vd_count = (int)global.count;
+  A->vd_ok    = true;
+  return HIPX_SUCCESS;
+}
+
 template <typename IT>
 int create_common(hipx_int m, hipx_int n, hipx_int nrows, const IT *ai, const hipx_int *ridx, const hipx_int *aj, const double *aa, bool is64, hipxMat *out)
 {
@@ -649,6 +833,7 @@ int create_common(hipx_int m, hipx_int n, hipx_int nrows, const IT *ai, const hi
     A->device_bytes += (int64_t)sizeof(int64_t) * m;
   }
   A->tile_mode = auto_tile_mode(A);  // variant 0
+  A->vd_mode   = A->tile_mode ? 1 : 0;
   *out = A;
   return HIPX_SUCCESS;
 }
@@ -827,12 +1012,27 @@ int launch_pk16(hipxMat A, const double *x, const double *yin, double *yout, dou
   const hipx_int nb = A->nblocks[0];
   if (nb == 0) return HIPX_SUCCESS;
   const hipx_int per_xcd = (nb + 7) / 8;
-  if (A->tile_mode >= 3)
-    spmv_pk16r_kernel<IT, MODE, DOT><<<(unsigned)(per_xcd * 8), 256, 0, rt().compute>>>(A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_pk, A->d_pkbase, A->d_a, x,
-                                                                                        yin, yout, dotpart, A->n);
-  else
-    spmv_pk16_kernel<IT, MODE, DOT><<<(unsigned)(per_xcd * 8), 256, 0, rt().compute>>>(A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_pk, A->d_pkbase, A->d_a, x,
-                                                                                       yin, yout, dotpart, A->n);
+  bool           vd      = false;
+  if (A->vd_mode) {
+    if ((ierr = ensure_vdict(A))) return ierr;
+    vd = A->vd_ok;
+  }
+  const unsigned grid = (unsigned)(per_xcd * 8);
+#define HIPX_PK_ARGS A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_pk, A->d_pkbase, A->d_a, A->d_vc, A->d_vdict, x, yin, yout, dotpart, A->n
+  static const int vd_batch = getenv("HIPX_PKR_BATCH") ? atoi(getenv("HIPX_PKR_BATCH")) : 8;  // tuning hook
+  if (A->tile_mode >= 3 || (vd && A->auto_sel)) {  // with the dictionary the row-parallel form wins for long rows too (27-pt: 0.193 vs 0.219 ms)
+    if (vd && vd_batch == 4) spmv_pk16r_kernel<IT, MODE, DOT, true, 4><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
+    else if (vd && vd_batch == 16) spmv_pk16r_kernel<IT, MODE, DOT, true, 16><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
+    else if (vd && A->probe == 1 && MODE == 0 && !DOT) spmv_pk16r_kernel<IT, 0, false, true, 8, 1><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
+    else if (vd && A->probe == 2 && MODE == 0 && !DOT) spmv_pk16r_kernel<IT, 0, false, true, 8, 2><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
+    else if (vd && A->probe == 3 && MODE == 0 && !DOT) spmv_pk16r_kernel<IT, 0, false, true, 8, 3><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
+    else if (vd) spmv_pk16r_kernel<IT, MODE, DOT, true, 8><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
+    else spmv_pk16r_kernel<IT, MODE, DOT, false, 4><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
+  } else {
+    if (vd) spmv_pk16_kernel<IT, MODE, DOT, true><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
+    else spmv_pk16_kernel<IT, MODE, DOT, false><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
+  }
+#undef HIPX_PK_ARGS
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -840,7 +1040,7 @@ int launch_pk16(hipxMat A, const double *x, const double *yin, double *yout, dou
 template <typename IT, int MODE, bool DOT>
 int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
 {
-  if (A->tile_mode >= 2 && !A->compressed && !A->probe) return launch_pk16<IT, MODE, DOT>(A, x, yin, yout, dotpart);
+  if (A->tile_mode >= 2 && !A->compressed && (!A->probe || A->vd_mode)) return launch_pk16<IT, MODE, DOT>(A, x, yin, yout, dotpart);
   if (A->probe && MODE == 0 && !DOT && !A->compressed && !A->is64) {
     int ierr = ensure_row_blocks(A, 0);
     if (ierr) return ierr;
@@ -937,6 +1137,7 @@ int hipxMatUpdateValues(hipxMat A, const double *a)
   HIPX_ARG(A, "null matrix");
   if (A->nnz) HIPX_HIP(hipMemcpyAsync(A->d_a, a, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice, rt().compute));
   HIPX_HIP(hipStreamSynchronize(rt().compute));
+  A->vd_ready = false;  // the value dictionary is rebuilt at the next product
   A->value_state++;  // SOR's level-ordered copy and inverse diagonal must be rebuilt (aij.c:1807 idiagState)
   hipxSorInvalidate_(A->sor_state);
   return HIPX_SUCCESS;
@@ -960,6 +1161,8 @@ int hipxMatDestroy(hipxMat *pA)
   (void)hipFree(A->d_dotpart);
   (void)hipFree(A->d_pk);
   (void)hipFree(A->d_pkbase);
+  (void)hipFree(A->d_vc);
+  (void)hipFree(A->d_vdict);
   hipxSorStateFree_(A->sor_state);
   delete A;
   *pA = nullptr;
@@ -1001,8 +1204,15 @@ int hipxMatSetSpMVVariant(hipxMat A, int variant)
   HIPX_ARG(A && variant >= 0, "variant: 0 auto, else 1 + 2*geometry + (1 if non-temporal loads); add 100 for the band-aware block schedule");
   A->probe      = variant / 1000;  // 1000/2000/3000 + v: probe kernels
   variant %= 1000;
-  A->tile_mode  = (variant == 22) ? 2 : (variant == 23) ? 3 : 0;  // 22: packed columns, 23: packed columns + row-parallel gather
-  if (variant == 22 || variant == 23) variant = 1;
+  // 22: packed columns, 23: packed columns + row-parallel gather, 24 / 25: the same two with the value dictionary
+  A->tile_mode = (variant == 22 || variant == 24) ? 2 : (variant == 23 || variant == 25) ? 3 : 0;
+  A->vd_mode   = (variant == 24 || variant == 25) ? 1 : 0;
+  A->auto_sel = (variant == 0);
+  if (variant == 0) {
+    A->tile_mode = auto_tile_mode(A);
+    A->vd_mode   = A->tile_mode ? 1 : 0;
+  }
+  if (variant >= 22 && variant <= 25) variant = 1;
   A->sched_mode = variant >= 100 ? 1 : 0;
   variant %= 100;
   HIPX_ARG(variant <= 2 * kNumCfg, "unknown SpMV variant");
@@ -1012,6 +1222,26 @@ int hipxMatSetSpMVVariant(hipxMat A, int variant)
     A->d_dotpart = nullptr;
   }
   A->variant = variant;
+  return HIPX_SUCCESS;
+}
+
+int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A && buf && len > 0, "null argument");
+  const char *name = "spmv_stream_kernel (CSR MatMult, 32-bit columns)";
+  if (A->tile_mode >= 2 && !A->compressed && !A->probe) {
+    int ierr = ensure_pk16(A);
+    if (ierr) return ierr;
+    bool vd = false;
+    if (A->vd_mode) {
+      if ((ierr = ensure_vdict(A))) return ierr;
+      vd = A->vd_ok;
+    }
+    if (A->tile_mode >= 3 || (vd && A->auto_sel)) name = vd ? "spmv_pk16r_kernel<VD> (CSR MatMult, packed 16-bit columns, row-parallel gather, 8-bit value dictionary)" : "spmv_pk16r_kernel (CSR MatMult, packed 16-bit columns, row-parallel gather)";
+    else name = vd ? "spmv_pk16_kernel<VD> (CSR MatMult, packed 16-bit columns, 8-bit value dictionary)" : "spmv_pk16_kernel (CSR MatMult, packed 16-bit columns)";
+  }
+  snprintf(buf, len, "%s", name);
   return HIPX_SUCCESS;
 }
 

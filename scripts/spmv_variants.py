@@ -22,7 +22,7 @@ X = _lib.DVec(N, 1.0 + (np.arange(N) % 17) / 17.0)
 Y = _lib.DVec(N)
 bytes_ = 12 * len(aj) + 4 * (N + 1) + 16 * N
 ref = None
-for v in [1, 22, 23, 1001, 3001, 101]:
+for v in ([int(a) for a in sys.argv[3].split(',')] if len(sys.argv) > 3 else [1, 22, 23, 24, 25, 0]):
     _lib.chk(hx.hipxMatSetSpMVVariant(A, v))
     for _ in range(5):
         _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
@@ -36,6 +36,9 @@ for v in [1, 22, 23, 1001, 3001, 101]:
     if ref is None:
         ref = y
     t = ms.value / cnt.value
+    kn = C.create_string_buffer(256)
+    _lib.chk(hx.hipxMatGetSpMVKernel(A, kn, 256))
+    print(kn.value.decode().split(" ")[0], end="  ")
     print("variant %2d  cfg %d probe %d : %.4f ms  %.1f GB/s  (%.1f%% of 8 TB/s)  identical=%s" % (v, ((v % 100) - 1) // 2, v // 1000, t, bytes_ / t / 1e6, bytes_ / t / 1e6 / 80, np.array_equal(y, ref)))
 
 # read-stream ceiling on this box: dot of two 1 GiB vectors (pure coalesced reads), AXPY (2 reads + 1 write)

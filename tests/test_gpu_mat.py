@@ -37,7 +37,7 @@ def spmv_gpu(hx, ai, aj, aa, x, ncols=None, variant=0, y0=None):
 
 @pytest.mark.parametrize("kind,n,m", [("5pt", 100, 100), ("5pt", 7, 8), ("7pt", 1, None), ("7pt", 2, None), ("7pt", 33, None), ("7pt", 64, None),
                                        ("27pt", 3, None), ("27pt", 17, None), ("27pt", 40, None)])
-@pytest.mark.parametrize("variant", [1, 2, 3, 22, 23, 101])
+@pytest.mark.parametrize("variant", [1, 2, 3, 22, 23, 24, 25, 101])
 def test_stencil_spmv_bit_exact(hx, kind, n, m, variant):
     ai, aj, aa = orc.stencil(kind, n, m=m)
     N = len(ai) - 1
@@ -61,7 +61,7 @@ def random_csr(m, n, rng, maxlen, empty_frac=0.2):
 
 
 @pytest.mark.parametrize("seed,m,n,maxlen", [(0, 1, 1, 1), (1, 17, 29, 5), (2, 1000, 777, 40), (3, 5000, 5000, 8), (4, 300, 4000, 300), (5, 257, 100, 0)])
-@pytest.mark.parametrize("variant", [1, 22, 23])
+@pytest.mark.parametrize("variant", [1, 22, 23, 24, 25])
 def test_ragged_rows_bit_exact_and_multadd(hx, seed, m, n, maxlen, variant):
     rng = np.random.default_rng(seed)
     ai, aj, aa = random_csr(m, n, rng, maxlen)
@@ -73,6 +73,70 @@ def test_ragged_rows_bit_exact_and_multadd(hx, seed, m, n, maxlen, variant):
     zr = np.zeros(m)
     orc.lib().orc_MatMultAdd_SeqAIJ(m, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(y0), orc.P(zr))
     assert np.array_equal(z, zr)
+
+
+def kernel_name(hx, A):
+    buf = C.create_string_buffer(256)
+    from petsc_amd import _lib
+    _lib.chk(hx.hipxMatGetSpMVKernel(A, buf, 256))
+    return buf.value.decode()
+
+
+@pytest.mark.parametrize("seed,m,n,maxlen", [(1, 17, 29, 5), (2, 1000, 777, 40), (3, 5000, 5000, 8), (4, 300, 4000, 300), (6, 1500, 200000, 12)])
+@pytest.mark.parametrize("variant", [24, 25])
+def test_value_dictionary_ragged_rows_bit_exact(hx, seed, m, n, maxlen, variant):
+    """Few distinct values (incl. -0.0, a denormal, +-inf-free extremes) on irregular rows: the 8-bit value-code kernels must
+    reproduce MatMult_SeqAIJ bit for bit, also after hipxMatUpdateValues (dictionary rebuilt) and when the new values no
+    longer fit a dictionary (falls back to the 8-byte value stream)."""
+    from petsc_amd import _lib
+    rng = np.random.default_rng(seed)
+    ai, aj, _ = random_csr(m, n, rng, maxlen)
+    pool = np.array([-1.0, 6.0, -0.0, 0.0, 4.9e-324, 1.0e150, -3.0 / 13.0, 44.0 / 13.0, 1e-17])
+    aa = pool[rng.integers(0, len(pool), size=ai[-1])]
+    x = rng.standard_normal(n)
+    A = _lib.mat_create_csr(m, n, ai, aj, aa)
+    _lib.chk(hx.hipxMatSetSpMVVariant(A, variant))
+    X, Y = _lib.DVec(n, x), _lib.DVec(m)
+    if ai[-1]:
+        assert "<VD>" in kernel_name(hx, A)
+    _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    yr = orc.matmult(ai, aj, aa, x)
+    assert np.array_equal(Y.get(), yr) and np.array_equal(np.signbit(Y.get()), np.signbit(yr))
+    aa2 = (pool * 0.5)[rng.integers(0, len(pool), size=ai[-1])]       # other dictionary
+    _lib.chk(hx.hipxMatUpdateValues(A, orc.P(aa2)))
+    _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    assert np.array_equal(Y.get(), orc.matmult(ai, aj, aa2, x))
+    aa3 = rng.standard_normal(ai[-1])                                 # all distinct: no dictionary
+    _lib.chk(hx.hipxMatUpdateValues(A, orc.P(aa3)))
+    if ai[-1] > 300:
+        assert "<VD>" not in kernel_name(hx, A)
+    _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    assert np.array_equal(Y.get(), orc.matmult(ai, aj, aa3, x))
+    X.free()
+    Y.free()
+    _lib.mat_destroy(A)
+
+
+def test_auto_variant_selects_packed_kernels(hx):
+    """variant 0 on >= 2^20 nonzeros: short rows -> row-parallel packed kernel, long rows -> staged packed kernel; constant
+    coefficient stencils get the value dictionary, matrices with distinct values do not.  (Guards the default path.)"""
+    from petsc_amd import _lib
+    rng = np.random.default_rng(3)
+    for kind, n, want in [("7pt", 56, "spmv_pk16r_kernel<VD>"), ("27pt", 36, "spmv_pk16r_kernel<VD>")]:
+        ai, aj, aa = orc.stencil(kind, n)
+        N = len(ai) - 1
+        x = xvec(N)
+        for vals, w in [(aa, want), (aa * (1.0 + 1e-3 * rng.standard_normal(aa.size)), "spmv_pk16r_kernel" if kind == "7pt" else "spmv_pk16_kernel")]:
+            A = _lib.mat_create_csr(N, N, ai, aj, vals)
+            assert kernel_name(hx, A).startswith(w + " "), kernel_name(hx, A)
+            _lib.chk(hx.hipxMatSetSpMVVariant(A, 0))  # explicit "auto" must not change the selection
+            assert kernel_name(hx, A).startswith(w + " ")
+            X, Y = _lib.DVec(N, x), _lib.DVec(N)
+            _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+            assert np.array_equal(Y.get(), orc.matmult(ai, aj, vals, x))
+            X.free()
+            Y.free()
+            _lib.mat_destroy(A)
 
 
 def test_long_rows_beyond_lds_tile(hx):
@@ -88,6 +152,10 @@ def test_long_rows_beyond_lds_tile(hx):
     y = spmv_gpu(hx, ai, aj, aa, x, ncols=n)
     assert np.array_equal(spmv_gpu(hx, ai, aj, aa, x, ncols=n, variant=22), y)
     assert np.array_equal(spmv_gpu(hx, ai, aj, aa, x, ncols=n, variant=23), y)
+    aq = np.round(aa)  # few distinct values: dictionary kernels, long rows still take the block-wide path
+    yq = spmv_gpu(hx, ai, aj, aq, x, ncols=n, variant=1)
+    assert np.array_equal(spmv_gpu(hx, ai, aj, aq, x, ncols=n, variant=24), yq)
+    assert np.array_equal(spmv_gpu(hx, ai, aj, aq, x, ncols=n, variant=25), yq)
     yr = orc.matmult(ai, aj, aa, x)
     short = lens <= 2040
     assert np.array_equal(y[short], yr[short])
