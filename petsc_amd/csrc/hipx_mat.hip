@@ -48,6 +48,8 @@ struct hipxMat_s {
   // packed-column formats (built lazily on the host, once per nonzero pattern)
   int            tile_mode  = 0;   // 2 = packed 16-bit columns, products staged in LDS (variant 22); 3 = + row-parallel gather (variant 23)
   bool           pk_ready   = false;
+  int            pk_cfg     = 0;         // row-block geometry (kCfg index) the packed format was built on
+  void          *d_pkdesc   = nullptr;   // PkDesc per row block: (r0, r1, k0, k1) in one load
   unsigned short *d_pk      = nullptr;   // (window id << 12) | offset inside the window
   hipx_int      *d_pkbase   = nullptr;   // PK_WMAX window starts per row block (-1 in slot 0 = block keeps 32-bit columns)
   int64_t        pk_fallback_blocks = 0;
@@ -117,6 +119,7 @@ constexpr SpmvCfg kCfg[] = {
   {128, 1024, 1},  // 3
   {256, 3072, 2},  // 4: 24 KiB
   {512, 8192, 2},  // 5: 64 KiB
+  {256, 8192, 4},  // 6: row blocks of the value-dictionary kernel with 4 rows per thread (3 B of LDS per nonzero there)
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(SPMV_THREADS) void spmv_stream_kernel(const hipx_in
 constexpr int PK_WMAX = 16;
 constexpr int PK_WLEN = 4096;
 
-// VD = true: values come from the <= 256-entry dictionary of exact bit patterns through a 1-byte code (see spmv_pk16r_kernel);
+// VD = true: values come from the <= 256-entry dictionary of exact bit patterns through a 1-byte code (see spmv_vd_kernel);
 // the dictionary is read through L1 (2 KiB, always resident), so no extra barrier is needed before the products.
 template <typename IT, int MODE, bool DOT, bool VD>
 __global__ __launch_bounds__(256) void spmv_pk16_kernel(const hipx_int *__restrict__ rb, hipx_int nblocks, hipx_int blocks_per_xcd, const IT *__restrict__ ai,
@@ -411,21 +414,14 @@ __global__ __launch_bounds__(256) void spmv_pk16_kernel(const hipx_int *__restri
 // touches x[row + offset_k] for 64 consecutive rows -- 4-5 cache lines instead of the ~20 that the nonzero-major
 // order of spmv_pk16_kernel spreads one gather instruction over (7 stencil offsets interleaved across the lanes).
 // Same products, same left-to-right sums: y is bit-identical.  Blocks without a packed code keep the pk16 path.
-//
-// VD = true ("pk16rv"): the matrix has at most 256 distinct values (constant-coefficient stencils have 2-4): the 8-byte
-// value stream is replaced by a 1-byte code into a dictionary of the exact bit patterns (hipxMat_s::d_vdict), held in LDS.
-// Matrix traffic per nonzero: 2 + 1 instead of 2 + 8 bytes.  The products use the same doubles in the same order: y is
-// bit-identical to the plain kernels.  Blocks that keep 32-bit columns, and long rows, still read a[] itself.
-template <typename IT, int MODE, bool DOT, bool VD, int W, int DBG = 0>
+template <typename IT, int MODE, bool DOT>
 __global__ __launch_bounds__(256) void spmv_pk16r_kernel(const hipx_int *__restrict__ rb, hipx_int nblocks, hipx_int blocks_per_xcd, const IT *__restrict__ ai,
                                                          const hipx_int *__restrict__ aj, const unsigned short *__restrict__ pk, const hipx_int *__restrict__ pkbase,
-                                                         const double *__restrict__ aa, const unsigned char *__restrict__ vc, const double *__restrict__ vdict,
-                                                         const double *__restrict__ x, const double *yin, double *yout, double *dotpart, hipx_int ncols)
+                                                         const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout, double *dotpart, hipx_int ncols)
 {
   constexpr int THREADS = 256, CAP = 2048;
-  // VD: vals[0..255] = dictionary, the value codes live behind it (bytes); else vals[] = the block's values
-  __shared__ double         vals[VD ? (256 + (CAP + 16) / 8) : CAP];
-  __shared__ unsigned short codes[CAP + 16];
+  __shared__ double         vals[CAP];
+  __shared__ unsigned short codes[CAP];
   const hipx_int bid = (hipx_int)blockIdx.x;
   const hipx_int b   = (bid & 7) * blocks_per_xcd + (bid >> 3);
   double         mydot = 0.0;
@@ -449,28 +445,7 @@ __global__ __launch_bounds__(256) void spmv_pk16r_kernel(const hipx_int *__restr
       const IT      nq  = (k1 - ka + 3) >> 2;
       constexpr int NIT = CAP / 4 / THREADS;
       if (packed) {
-        unsigned char *vcl = reinterpret_cast<unsigned char *>(vals + 256);  // VD only
-        int            sh  = 0;                                              // LDS index of entry ka
-        if constexpr (VD) {
-          // 8 nonzeros per lane: one 16-byte load of column codes, one 8-byte load of value codes
-          const IT ka8 = k0 & ~(IT)7;
-          const IT nq8 = (k1 - ka8 + 7) >> 3;
-          sh           = (int)(ka - ka8);
-          vals[t]      = vdict[t];
-          for (IT q = t; q < nq8; q += THREADS) {
-            int4v              c8;
-            unsigned long long v8;
-            if constexpr (DBG == 3) {  // probe: no phase-1 matrix loads
-              c8 = int4v{0, 0, 0, 0};
-              v8 = 0;
-            } else {
-              c8 = reinterpret_cast<const int4v *>(pk + ka8)[q];
-              v8 = reinterpret_cast<const unsigned long long *>(vc + ka8)[q];
-            }
-            reinterpret_cast<int4v *>(codes)[q]            = c8;
-            reinterpret_cast<unsigned long long *>(vcl)[q] = v8;
-          }
-        } else if (nq > 0) {
+        if (nq > 0) {
           const dbl2     *a2 = reinterpret_cast<const dbl2 *>(aa + ka);
           const ushort4v *c4 = reinterpret_cast<const ushort4v *>(pk + ka);
           dbl2            va[NIT], vb[NIT];
@@ -500,35 +475,24 @@ __global__ __launch_bounds__(256) void spmv_pk16r_kernel(const hipx_int *__restr
         int       maxlen = len;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
-        const int s0  = (int)(rs - ka) + sh;
+        const int s0  = (int)(rs - ka);
         double    sum = (MODE == 1 && row < r1) ? yin[row] : 0.0;
-        // W gathers in flight per lane before the first one is consumed (the sum itself stays strictly left to right)
-        for (int k = 0; k < (DBG == 2 ? 0 : maxlen); k += W) {
-          double xv[W], av[W];
+        for (int k = 0; k < maxlen; k += 4) {
+          double xv[4], av[4];
 #pragma unroll
-          for (int e = 0; e < W; e++) {
+          for (int e = 0; e < 4; e++) {
             const bool     on   = (k + e) < len;
-            const int      idx  = on ? s0 + k + e : sh;
+            const int      idx  = on ? s0 + k + e : 0;
             const unsigned code = codes[idx];
             const int      col  = __shfl(base_reg, code >> 12, 64) + (int)(code & 0xfff);
-            if constexpr (VD) av[e] = vals[vcl[idx]];
-            else av[e] = vals[idx];
-            if constexpr (DBG == 1) xv[e] = (double)col;  // probe: no x gather
-            else xv[e] = on ? x[col] : 0.0;
+            av[e]               = vals[idx];
+            xv[e]               = on ? x[col] : 0.0;
           }
 #pragma unroll
-          for (int e = 0; e < W; e++)
+          for (int e = 0; e < 4; e++)
             if ((k + e) < len) sum += av[e] * xv[e];
         }
         if (row < r1) {
-          yout[row] = sum;
-          if (DOT) mydot = xrow * sum;
-        }
-      } else if constexpr (VD) {
-        // block kept its 32-bit columns (rare: scattered columns AND few distinct values): plain row walk, no LDS staging
-        if (row < r1) {
-          double sum = (MODE == 1) ? yin[row] : 0.0;
-          for (IT k = rs; k < re; k++) sum += aa[k] * x[aj[k]];
           yout[row] = sum;
           if (DOT) mydot = xrow * sum;
         }
@@ -580,6 +544,150 @@ __global__ __launch_bounds__(256) void spmv_pk16r_kernel(const hipx_int *__restr
     }
   }
   if (DOT) {  // one partial per WAVE, no barrier: the workgroup retires as soon as its rows are written
+    const double w = hipx::wave_sum(mydot);
+    if ((threadIdx.x & 63) == 0) dotpart[(size_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6)] = w;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Value-dictionary SpMV with RPT rows per thread ("vd").  With 3 bytes of matrix per nonzero the kernel is no longer bound
+// by HBM but by the length of each wave's dependent chain (block bounds -> row offsets / codes -> barrier -> gathers), so:
+//  * the block bounds (r0, r1, k0, k1) come from one 24-byte descriptor instead of rb[] followed by ai[rb[]];
+//  * a thread owns RPT rows (row blocks of 256*RPT rows, 2048*RPT nonzeros), whose gathers are issued together: the fixed
+//    latencies are paid once per RPT rows.
+// Products and left-to-right row sums are those of MatMult_SeqAIJ (aij.c:1486-1494): y is bit-identical.
+struct PkDesc {
+  hipx_int  r0, r1;
+  long long k0, k1;
+};
+
+template <typename IT, int MODE, bool DOT, int RPT, int W, int DBG = 0>
+__global__ __launch_bounds__(256) void spmv_vd_kernel(const PkDesc *__restrict__ desc, hipx_int nblocks, hipx_int blocks_per_xcd, const IT *__restrict__ ai, const hipx_int *__restrict__ aj,
+                                                      const unsigned short *__restrict__ pk, const hipx_int *__restrict__ pkbase, const double *__restrict__ aa,
+                                                      const unsigned char *__restrict__ vc, const double *__restrict__ vdict, const double *__restrict__ x, const double *yin, double *yout,
+                                                      double *dotpart, hipx_int ncols)
+{
+  constexpr int THREADS = 256, CAP = 2048 * RPT;
+  __shared__ double         dict[256];
+  __shared__ unsigned short codes[CAP + 16];
+  __shared__ unsigned char  vcl[CAP + 16];
+  const hipx_int bid = (hipx_int)blockIdx.x;
+  const hipx_int b   = (bid & 7) * blocks_per_xcd + (bid >> 3);
+  double         mydot = 0.0;
+  if (b < nblocks) {
+    const PkDesc   d  = desc[b];
+    const hipx_int r0 = d.r0, r1 = d.r1;
+    const IT       k0 = (IT)d.k0, k1 = (IT)d.k1;
+    const IT       ka = k0 & ~(IT)3;
+    const int      t  = threadIdx.x;
+    IT             rs[RPT], re[RPT];
+    double         xrow[RPT];
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) {
+      const hipx_int row = r0 + t + rr * THREADS;
+      rs[rr] = re[rr] = 0;
+      xrow[rr]        = 0.0;
+      if (row < r1) {
+        rs[rr] = ai[row];
+        re[rr] = ai[row + 1];
+        if (DOT) xrow[rr] = x[row];
+      }
+    }
+    const int base_reg = pkbase[(size_t)b * PK_WMAX + (t & (PK_WMAX - 1))];
+    const int packed   = __shfl(base_reg, 0, 64) >= 0;
+    if ((k1 - ka) <= (IT)CAP) {
+      if (packed) {
+        const IT  ka8 = k0 & ~(IT)7;
+        const IT  nq8 = (k1 - ka8 + 7) >> 3;
+        dict[t]       = vdict[t];
+        for (IT q = t; q < nq8; q += THREADS) {
+          int4v              c8;
+          unsigned long long v8;
+          if constexpr (DBG == 3) {
+            c8 = int4v{0, 0, 0, 0};
+            v8 = 0;
+          } else {
+            c8 = reinterpret_cast<const int4v *>(pk + ka8)[q];
+            v8 = reinterpret_cast<const unsigned long long *>(vc + ka8)[q];
+          }
+          reinterpret_cast<int4v *>(codes)[q]            = c8;
+          reinterpret_cast<unsigned long long *>(vcl)[q] = v8;
+        }
+        __syncthreads();
+        int    len[RPT], s0[RPT], maxlen = 0;
+        double sum[RPT];
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) {
+          const hipx_int row = r0 + t + rr * THREADS;
+          len[rr] = (row < r1) ? (int)(re[rr] - rs[rr]) : 0;
+          s0[rr]  = (int)(rs[rr] - ka8);
+          sum[rr] = (MODE == 1 && row < r1) ? yin[row] : 0.0;
+          maxlen  = max(maxlen, len[rr]);
+        }
+        // every lane of a wave runs the same trip count: __shfl needs lanes 0..15 (the window starts) active
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+        if (DBG == 2) maxlen = 0;
+        for (int k = 0; k < maxlen; k += W) {
+          double xv[RPT][W], av[RPT][W];
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++) {
+#pragma unroll
+            for (int e = 0; e < W; e++) {
+              const bool     on   = (k + e) < len[rr];
+              const int      idx  = on ? s0[rr] + k + e : 0;
+              const unsigned code = codes[idx];
+              const int      col  = __shfl(base_reg, code >> 12, 64) + (int)(code & 0xfff);
+              av[rr][e]           = dict[vcl[idx]];
+              if constexpr (DBG == 1) xv[rr][e] = (double)col;
+              else xv[rr][e] = on ? x[col] : 0.0;
+            }
+          }
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++) {
+#pragma unroll
+            for (int e = 0; e < W; e++)
+              if ((k + e) < len[rr]) sum[rr] += av[rr][e] * xv[rr][e];
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) {
+          const hipx_int row = r0 + t + rr * THREADS;
+          if (row < r1) {
+            yout[row] = sum[rr];
+            if (DOT) mydot += xrow[rr] * sum[rr];
+          }
+        }
+      } else {
+        // block kept its 32-bit columns (scattered columns AND few distinct values: rare): plain row walk
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) {
+          const hipx_int row = r0 + t + rr * THREADS;
+          if (row < r1) {
+            double sum = (MODE == 1) ? yin[row] : 0.0;
+            for (IT k = rs[rr]; k < re[rr]; k++) sum += aa[k] * x[aj[k]];
+            yout[row] = sum;
+            if (DOT) mydot += xrow[rr] * sum;
+          }
+        }
+      }
+    } else {  // one long row
+      double acc = 0.0;
+      for (IT k = k0 + t; k < k1; k += THREADS) acc += aa[k] * x[aj[k]];
+      acc = hipx::wave_sum(acc);
+      if ((t & 63) == 0) dict[t >> 6] = acc;
+      __syncthreads();
+      if (t == 0) {
+        double sum = (MODE == 1) ? yin[r0] : 0.0;
+        double tot = dict[0];
+        for (int w = 1; w < THREADS / 64; w++) tot += dict[w];
+        sum += tot;
+        yout[r0] = sum;
+        if (DOT) mydot = x[r0] * sum;
+      }
+    }
+  }
+  if (DOT) {
     const double w = hipx::wave_sum(mydot);
     if ((threadIdx.x & 63) == 0) dotpart[(size_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6)] = w;
   }
@@ -935,14 +1043,25 @@ int launch_spmv_c(hipxMat A, const double *x, const double *yin, double *yout, d
 
 
 // Host set-up of the packed-column format (once per nonzero pattern), parallel over row blocks.
-int ensure_pk16(hipxMat A)
+int ensure_pk16(hipxMat A, int cfg = 0)
 {
-  if (A->pk_ready) return HIPX_SUCCESS;
-  int ierr = ensure_row_blocks(A, 0);
+  if (A->pk_ready && A->pk_cfg == cfg) return HIPX_SUCCESS;
+  int ierr = ensure_row_blocks(A, cfg);
   if (ierr) return ierr;
-  const hipx_int nb = A->nblocks[0];
+  if (A->pk_ready) {  // built on another block geometry (the value dictionary appeared / went away): rebuild
+    HIPX_HIP(hipStreamSynchronize(rt().compute));
+    (void)hipFree(A->d_pk);
+    (void)hipFree(A->d_pkbase);
+    (void)hipFree(A->d_pkdesc);
+    A->d_pk = nullptr;
+    A->d_pkbase = nullptr;
+    A->d_pkdesc = nullptr;
+    A->pk_ready = false;
+  }
+  const int64_t  pkcap = kCfg[cfg].cap;
+  const hipx_int nb = A->nblocks[cfg];
   std::vector<hipx_int> rb((size_t)nb + 1);
-  HIPX_HIP(hipMemcpy(rb.data(), A->d_rb[0], sizeof(hipx_int) * ((size_t)nb + 1), hipMemcpyDeviceToHost));
+  HIPX_HIP(hipMemcpy(rb.data(), A->d_rb[cfg], sizeof(hipx_int) * ((size_t)nb + 1), hipMemcpyDeviceToHost));
   std::vector<hipx_int> hj((size_t)A->nnz + 8, 0);
   if (A->nnz) HIPX_HIP(hipMemcpy(hj.data(), A->d_j, sizeof(hipx_int) * (size_t)A->nnz, hipMemcpyDeviceToHost));
   std::vector<unsigned short> pk((size_t)A->nnz + 8, 0);
@@ -955,7 +1074,7 @@ int ensure_pk16(hipxMat A)
       hipx_int     *d  = base.data() + (size_t)b * PK_WMAX;
       const int64_t k0 = hi[rb[b]], k1 = hi[rb[b + 1]];
       d[0] = -1;
-      if (k1 - (k0 & ~(int64_t)3) > 2048 || k1 == k0) continue;
+      if (k1 - (k0 & ~(int64_t)3) > pkcap || k1 == k0) continue;
       u.assign(hj.begin() + k0, hj.begin() + k1);
       std::sort(u.begin(), u.end());
       u.erase(std::unique(u.begin(), u.end()), u.end());
@@ -999,40 +1118,69 @@ int ensure_pk16(hipxMat A)
   HIPX_HIP(hipMalloc((void **)&A->d_pkbase, sizeof(hipx_int) * base.size()));
   HIPX_HIP(hipMemcpy(A->d_pk, pk.data(), sizeof(unsigned short) * pk.size(), hipMemcpyHostToDevice));
   HIPX_HIP(hipMemcpy(A->d_pkbase, base.data(), sizeof(hipx_int) * base.size(), hipMemcpyHostToDevice));
-  A->device_bytes += (int64_t)(sizeof(unsigned short) * pk.size() + sizeof(hipx_int) * base.size());
+  std::vector<PkDesc> desc((size_t)std::max<hipx_int>(nb, 1));
+  for (hipx_int b = 0; b < nb; b++) desc[(size_t)b] = PkDesc{rb[b], rb[b + 1], (long long)hi[rb[b]], (long long)hi[rb[b + 1]]};
+  HIPX_HIP(hipMalloc(&A->d_pkdesc, sizeof(PkDesc) * desc.size()));
+  HIPX_HIP(hipMemcpy(A->d_pkdesc, desc.data(), sizeof(PkDesc) * desc.size(), hipMemcpyHostToDevice));
+  A->device_bytes += (int64_t)(sizeof(unsigned short) * pk.size() + sizeof(hipx_int) * base.size() + sizeof(PkDesc) * desc.size());
+  A->pk_cfg   = cfg;
   A->pk_ready = true;
   return HIPX_SUCCESS;
+}
+
+// which packed form the next launch takes: vd (dictionary kernel), rowpar (row-parallel gather), rpt (rows per thread of
+// spmv_vd_kernel, 0 = other kernels), cfg (row-block geometry the packed format is built on)
+int select_pk(hipxMat A, bool &vd, bool &rowpar, int &rpt, int &cfg)
+{
+  // tuning hook: rows per thread of the dictionary kernel.  Measured on MI355X (7-pt 256^3 / 27-pt 160^3, ms):
+  // 1 row: 0.188 / 0.191, 2 rows: 0.167 / 0.176 (default), 4 rows: 0.172 / 0.204
+  static const int vd_rpt = getenv("HIPX_VD_RPT") ? atoi(getenv("HIPX_VD_RPT")) : 2;
+  vd = false;
+  if (A->vd_mode) {
+    int ierr = ensure_vdict(A);
+    if (ierr) return ierr;
+    vd = A->vd_ok;
+  }
+  rowpar = A->tile_mode >= 3 || (vd && A->auto_sel);  // with the dictionary the row-parallel form wins for long rows too
+  rpt    = (vd && rowpar) ? ((vd_rpt == 1 || vd_rpt == 4) ? vd_rpt : 2) : 0;
+  cfg    = rpt == 2 ? 1 : rpt == 4 ? 6 : 0;
+  return ensure_pk16(A, cfg);
 }
 
 template <typename IT, int MODE, bool DOT>
 int launch_pk16(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
 {
-  int ierr = ensure_pk16(A);
+  bool vd, rowpar;
+  int  rpt, cfg;
+  int  ierr = select_pk(A, vd, rowpar, rpt, cfg);
   if (ierr) return ierr;
-  const hipx_int nb = A->nblocks[0];
+  const hipx_int nb = A->nblocks[cfg];
   if (nb == 0) return HIPX_SUCCESS;
   const hipx_int per_xcd = (nb + 7) / 8;
-  bool           vd      = false;
-  if (A->vd_mode) {
-    if ((ierr = ensure_vdict(A))) return ierr;
-    vd = A->vd_ok;
-  }
   const unsigned grid = (unsigned)(per_xcd * 8);
-#define HIPX_PK_ARGS A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_pk, A->d_pkbase, A->d_a, A->d_vc, A->d_vdict, x, yin, yout, dotpart, A->n
-  static const int vd_batch = getenv("HIPX_PKR_BATCH") ? atoi(getenv("HIPX_PKR_BATCH")) : 8;  // tuning hook
-  if (A->tile_mode >= 3 || (vd && A->auto_sel)) {  // with the dictionary the row-parallel form wins for long rows too (27-pt: 0.193 vs 0.219 ms)
-    if (vd && vd_batch == 4) spmv_pk16r_kernel<IT, MODE, DOT, true, 4><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
-    else if (vd && vd_batch == 16) spmv_pk16r_kernel<IT, MODE, DOT, true, 16><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
-    else if (vd && A->probe == 1 && MODE == 0 && !DOT) spmv_pk16r_kernel<IT, 0, false, true, 8, 1><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
-    else if (vd && A->probe == 2 && MODE == 0 && !DOT) spmv_pk16r_kernel<IT, 0, false, true, 8, 2><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
-    else if (vd && A->probe == 3 && MODE == 0 && !DOT) spmv_pk16r_kernel<IT, 0, false, true, 8, 3><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
-    else if (vd) spmv_pk16r_kernel<IT, MODE, DOT, true, 8><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
-    else spmv_pk16r_kernel<IT, MODE, DOT, false, 4><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
+#define HIPX_PK_ARGS A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_pk, A->d_pkbase, A->d_a
+#define HIPX_VD_LAUNCH(R, WW, D) \
+  spmv_vd_kernel<IT, MODE, DOT, R, WW, D><<<grid, 256, 0, rt().compute>>>((const PkDesc *)A->d_pkdesc, nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_pk, A->d_pkbase, A->d_a, A->d_vc, \
+                                                                            A->d_vdict, x, yin, yout, dotpart, A->n)
+  if (rpt > 0) {
+    const int probe = (MODE == 0 && !DOT) ? A->probe : 0;
+    if (probe) {
+      if constexpr (MODE == 0 && !DOT) {
+        if (probe == 1) HIPX_VD_LAUNCH(2, 4, 1);
+        else if (probe == 2) HIPX_VD_LAUNCH(2, 4, 2);
+        else HIPX_VD_LAUNCH(2, 4, 3);
+      }
+    } else if (rpt == 1) HIPX_VD_LAUNCH(1, 8, 0);
+    else if (rpt == 4) HIPX_VD_LAUNCH(4, 2, 0);
+    else HIPX_VD_LAUNCH(2, 4, 0);
+  } else if (rowpar) {
+    spmv_pk16r_kernel<IT, MODE, DOT><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS, x, yin, yout, dotpart, A->n);
   } else {
-    if (vd) spmv_pk16_kernel<IT, MODE, DOT, true><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
-    else spmv_pk16_kernel<IT, MODE, DOT, false><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS);
+    if (vd) spmv_pk16_kernel<IT, MODE, DOT, true><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS, A->d_vc, A->d_vdict, x, yin, yout, dotpart, A->n);
+    else spmv_pk16_kernel<IT, MODE, DOT, false><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS, A->d_vc, A->d_vdict, x, yin, yout, dotpart, A->n);
   }
 #undef HIPX_PK_ARGS
+#undef HIPX_VD_LAUNCH
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -1161,6 +1309,7 @@ int hipxMatDestroy(hipxMat *pA)
   (void)hipFree(A->d_dotpart);
   (void)hipFree(A->d_pk);
   (void)hipFree(A->d_pkbase);
+  (void)hipFree(A->d_pkdesc);
   (void)hipFree(A->d_vc);
   (void)hipFree(A->d_vdict);
   hipxSorStateFree_(A->sor_state);
@@ -1231,14 +1380,12 @@ int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
   HIPX_ARG(A && buf && len > 0, "null argument");
   const char *name = "spmv_stream_kernel (CSR MatMult, 32-bit columns)";
   if (A->tile_mode >= 2 && !A->compressed && !A->probe) {
-    int ierr = ensure_pk16(A);
+    bool vd, rowpar;
+    int  rpt, cfg;
+    int  ierr = select_pk(A, vd, rowpar, rpt, cfg);
     if (ierr) return ierr;
-    bool vd = false;
-    if (A->vd_mode) {
-      if ((ierr = ensure_vdict(A))) return ierr;
-      vd = A->vd_ok;
-    }
-    if (A->tile_mode >= 3 || (vd && A->auto_sel)) name = vd ? "spmv_pk16r_kernel<VD> (CSR MatMult, packed 16-bit columns, row-parallel gather, 8-bit value dictionary)" : "spmv_pk16r_kernel (CSR MatMult, packed 16-bit columns, row-parallel gather)";
+    if (rpt > 0) name = "spmv_vd_kernel (CSR MatMult, packed 16-bit columns, 8-bit value dictionary, row-parallel gather)";
+    else if (rowpar) name = "spmv_pk16r_kernel (CSR MatMult, packed 16-bit columns, row-parallel gather)";
     else name = vd ? "spmv_pk16_kernel<VD> (CSR MatMult, packed 16-bit columns, 8-bit value dictionary)" : "spmv_pk16_kernel (CSR MatMult, packed 16-bit columns)";
   }
   snprintf(buf, len, "%s", name);

@@ -98,7 +98,7 @@ def test_value_dictionary_ragged_rows_bit_exact(hx, seed, m, n, maxlen, variant)
     _lib.chk(hx.hipxMatSetSpMVVariant(A, variant))
     X, Y = _lib.DVec(n, x), _lib.DVec(m)
     if ai[-1]:
-        assert "<VD>" in kernel_name(hx, A)
+        assert "value dictionary" in kernel_name(hx, A)
     _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
     yr = orc.matmult(ai, aj, aa, x)
     assert np.array_equal(Y.get(), yr) and np.array_equal(np.signbit(Y.get()), np.signbit(yr))
@@ -109,7 +109,7 @@ def test_value_dictionary_ragged_rows_bit_exact(hx, seed, m, n, maxlen, variant)
     aa3 = rng.standard_normal(ai[-1])                                 # all distinct: no dictionary
     _lib.chk(hx.hipxMatUpdateValues(A, orc.P(aa3)))
     if ai[-1] > 300:
-        assert "<VD>" not in kernel_name(hx, A)
+        assert "value dictionary" not in kernel_name(hx, A)
     _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
     assert np.array_equal(Y.get(), orc.matmult(ai, aj, aa3, x))
     X.free()
@@ -122,7 +122,7 @@ def test_auto_variant_selects_packed_kernels(hx):
     coefficient stencils get the value dictionary, matrices with distinct values do not.  (Guards the default path.)"""
     from petsc_amd import _lib
     rng = np.random.default_rng(3)
-    for kind, n, want in [("7pt", 56, "spmv_pk16r_kernel<VD>"), ("27pt", 36, "spmv_pk16r_kernel<VD>")]:
+    for kind, n, want in [("7pt", 56, "spmv_vd_kernel"), ("27pt", 36, "spmv_vd_kernel")]:
         ai, aj, aa = orc.stencil(kind, n)
         N = len(ai) - 1
         x = xvec(N)
@@ -152,10 +152,13 @@ def test_long_rows_beyond_lds_tile(hx):
     y = spmv_gpu(hx, ai, aj, aa, x, ncols=n)
     assert np.array_equal(spmv_gpu(hx, ai, aj, aa, x, ncols=n, variant=22), y)
     assert np.array_equal(spmv_gpu(hx, ai, aj, aa, x, ncols=n, variant=23), y)
-    aq = np.round(aa)  # few distinct values: dictionary kernels, long rows still take the block-wide path
-    yq = spmv_gpu(hx, ai, aj, aq, x, ncols=n, variant=1)
-    assert np.array_equal(spmv_gpu(hx, ai, aj, aq, x, ncols=n, variant=24), yq)
-    assert np.array_equal(spmv_gpu(hx, ai, aj, aq, x, ncols=n, variant=25), yq)
+    aq = np.round(aa)  # few distinct values: dictionary kernels; rows beyond THEIR tile (2048 / 4096 / 8192) take the block-wide path
+    yqr = orc.matmult(ai, aj, aq, x)
+    magq = np.array([np.abs(aq[ai[r]:ai[r + 1]] * x[aj[ai[r]:ai[r + 1]]]).sum() for r in range(m)])
+    for v in (24, 25):
+        yq = spmv_gpu(hx, ai, aj, aq, x, ncols=n, variant=v)
+        assert np.array_equal(yq[lens <= 2040], yqr[lens <= 2040])
+        assert np.all(np.abs(yq - yqr) <= 1e-14 * (magq + 1e-300))
     yr = orc.matmult(ai, aj, aa, x)
     short = lens <= 2040
     assert np.array_equal(y[short], yr[short])
