@@ -555,6 +555,8 @@ __global__ __launch_bounds__(256) void spmv_pk16r_kernel(const hipx_int *__restr
 //  * the block bounds (r0, r1, k0, k1) come from one 24-byte descriptor instead of rb[] followed by ai[rb[]];
 //  * a thread owns RPT rows (row blocks of 256*RPT rows, 2048*RPT nonzeros), whose gathers are issued together: the fixed
 //    latencies are paid once per RPT rows.
+//  * phase 1 merges the 16-bit column code and the 8-bit value code of a nonzero into one 32-bit LDS word, so phase 2 issues
+//    one bank-conflict-free LDS read per nonzero (a row's words are consecutive; rows of odd length spread over all banks).
 // Products and left-to-right row sums are those of MatMult_SeqAIJ (aij.c:1486-1494): y is bit-identical.
 struct PkDesc {
   hipx_int  r0, r1;
@@ -568,9 +570,8 @@ __global__ __launch_bounds__(256) void spmv_vd_kernel(const PkDesc *__restrict__
                                                       double *dotpart, hipx_int ncols)
 {
   constexpr int THREADS = 256, CAP = 2048 * RPT;
-  __shared__ double         dict[256];
-  __shared__ unsigned short codes[CAP + 16];
-  __shared__ unsigned char  vcl[CAP + 16];
+  __shared__ double   dict[256];
+  __shared__ unsigned words[CAP + 16];  // (value code << 16) | column code: one conflict-free 32-bit LDS read per nonzero in phase 2
   const hipx_int bid = (hipx_int)blockIdx.x;
   const hipx_int b   = (bid & 7) * blocks_per_xcd + (bid >> 3);
   double         mydot = 0.0;
@@ -610,8 +611,18 @@ __global__ __launch_bounds__(256) void spmv_vd_kernel(const PkDesc *__restrict__
             c8 = reinterpret_cast<const int4v *>(pk + ka8)[q];
             v8 = reinterpret_cast<const unsigned long long *>(vc + ka8)[q];
           }
-          reinterpret_cast<int4v *>(codes)[q]            = c8;
-          reinterpret_cast<unsigned long long *>(vcl)[q] = v8;
+          int4v w0, w1;  // 8 nonzeros: column codes c8 = 8 x u16, value codes v8 = 8 x u8
+          const unsigned vlo = (unsigned)v8, vhi = (unsigned)(v8 >> 32);
+          w0.x = (int)(((unsigned)c8.x & 0xffffu) | ((vlo & 0xffu) << 16));
+          w0.y = (int)(((unsigned)c8.x >> 16) | ((vlo & 0xff00u) << 8));
+          w0.z = (int)(((unsigned)c8.y & 0xffffu) | (vlo & 0xff0000u));
+          w0.w = (int)(((unsigned)c8.y >> 16) | ((vlo >> 24) << 16));
+          w1.x = (int)(((unsigned)c8.z & 0xffffu) | ((vhi & 0xffu) << 16));
+          w1.y = (int)(((unsigned)c8.z >> 16) | ((vhi & 0xff00u) << 8));
+          w1.z = (int)(((unsigned)c8.w & 0xffffu) | (vhi & 0xff0000u));
+          w1.w = (int)(((unsigned)c8.w >> 16) | ((vhi >> 24) << 16));
+          reinterpret_cast<int4v *>(words)[2 * q]     = w0;
+          reinterpret_cast<int4v *>(words)[2 * q + 1] = w1;
         }
         __syncthreads();
         int    len[RPT], s0[RPT], maxlen = 0;
@@ -636,9 +647,9 @@ __global__ __launch_bounds__(256) void spmv_vd_kernel(const PkDesc *__restrict__
             for (int e = 0; e < W; e++) {
               const bool     on   = (k + e) < len[rr];
               const int      idx  = on ? s0[rr] + k + e : 0;
-              const unsigned code = codes[idx];
-              const int      col  = __shfl(base_reg, code >> 12, 64) + (int)(code & 0xfff);
-              av[rr][e]           = dict[vcl[idx]];
+              const unsigned word = words[idx];
+              const int      col  = __shfl(base_reg, (word >> 12) & 15, 64) + (int)(word & 0xfff);
+              av[rr][e]           = dict[word >> 16];
               if constexpr (DBG == 1) xv[rr][e] = (double)col;
               else xv[rr][e] = on ? x[col] : 0.0;
             }

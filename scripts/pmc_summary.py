@@ -1,0 +1,39 @@
+"""Summarise rocprofv3 PMC passes of bench.py into profiles/spmv_traffic.json (what bench.py reports as roofline.traffic).
+  python scripts/pmc_summary.py <fetch_dir> <write_dir> <key> [--kernel spmv_vd_kernel]
+<fetch_dir>/<write_dir> hold pmc_counter_collection.csv of `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs
+(separate passes, --kernel-trace only).  Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md:
+FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE counts 64 B per 128 B request on gfx950 for wide streams (calibrated on
+our AXPY: 2 x 134 MB read -> FETCH_SIZE = half), so read bytes = 2 x FETCH_SIZE x 1024."""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def per_launch(path, counter, kernel):
+    vals = {}
+    for row in csv.DictReader(open(os.path.join(path, "pmc_counter_collection.csv"))):
+        if row["Counter_Name"] == counter and kernel in row["Kernel_Name"]:
+            vals.setdefault(row["Dispatch_Id"], 0.0)
+            vals[row["Dispatch_Id"]] += float(row["Counter_Value"])
+    v = list(vals.values())
+    return (sum(v) / len(v), len(v)) if v else (None, 0)
+
+
+def main():
+    fetch_dir, write_dir, key = sys.argv[1:4]
+    kernel = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else "spmv_"
+    f, nf = per_launch(fetch_dir, "FETCH_SIZE", kernel)
+    w, nw = per_launch(write_dir, "WRITE_SIZE", kernel)
+    p = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+    tj = json.load(open(p)) if os.path.exists(p) else {}
+    tj[key] = {"kernel": kernel, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "launches_sampled": min(nf, nw),
+               "traffic_bytes": int(2 * f * 1024 + w * 1024)}
+    json.dump(tj, open(p, "w"), indent=1)
+    print(key, tj[key])
+
+
+if __name__ == "__main__":
+    main()
