@@ -113,6 +113,9 @@ int hipxRedEnd(int slot, int nvals, double *results); /* synchronises the comput
 /* fused CG kernels (same arithmetic as the separate calls, fewer HBM passes) */
 /* x += a p ; r -= a w ; z = r .* d ; sums[0] = z.z ; sums[1] = z.r  (cg.c:305-309,344 with PCJACOBI) */
 int hipxCGFusedUpdate(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n, double *sums2);
+/* x == NULL in hipxCGFusedUpdate: the x update is deferred; it is then done by
+   p = z + b p ; x += a p_old  (cg.c:249 of the next iteration + cg.c:305 of this one: p is read once) */
+int hipxCGAypxAxpy(double *p, double b, const double *z, double *x, double a, hipx_int n);
 
 /* ---- Mat (CSR = Mat_SeqAIJ src/mat/impls/aij/seq/aij.h:47-78,150-168) ----------------------- */
 typedef struct hipxMat_s *hipxMat;
@@ -160,6 +163,9 @@ int hipxCommAllreduceSum(double *host_vals, int n);           /* n <= 64 doubles
 /* VecTDot_MPI / VecMDot_MPI (pvecimpl.h:97-111) in one stream-ordered chain: local dot kernel(s) -> ncclAllReduce on the
    result words -> host notification; the host waits once, after the all-reduce.  nv <= 8.  Single rank: plain local dots. */
 int hipxVecMDotAllreduce(const double *x, hipx_int nv, const double *const *y, hipx_int n, double *results);
+/* hipxCGFusedUpdate with the two sums all-reduced over the communicator in the same chain (VecNorm_MPI + VecTDot_MPI of
+   cg.c:309,344 in one 16-byte all-reduce) */
+int hipxCGFusedUpdateAllreduce(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n, double *sums2);
 
 typedef struct hipxHalo_s *hipxHalo;
 /* nsend/nrecv neighbours; send_idx = local indices of owned entries to pack per neighbour (concatenated,

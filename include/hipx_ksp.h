@@ -62,6 +62,8 @@ typedef struct {
   double   beta, betaold, dpi, a;
   hipx_int i;
   hipx_int work_n;
+  int      x_pending;        /* fused CG: x += a_pending * P of the last iteration not applied yet (merged into the next AYPX pass) */
+  double   a_pending;
 } HipxKSP;
 
 void HipxKSPSetDefaults(HipxKSP *ksp);

@@ -132,14 +132,30 @@ int hipxVecMDotAllreduce(const double *x, hipx_int nv, const double *const *y, h
   if (!c.active || (c.nranks == 1 && !force)) return hipxVecMDot(x, nv, y, n, results);
   const int slot = HIPX_MAX_RED_SLOTS - 2;  // reserved for this chain
   if (n > 0) {
-    int ierr = launch_mdot_nosignal(x, (int)nv, y, n, slot);
+    int ierr = launch_mdot_nosignal(x, (int)nv, y, n, slot, c.d_red);
     if (ierr) return ierr;
-  } else HIPX_HIP(hipMemsetAsync(slot_results_dev(slot), 0, sizeof(double) * (size_t)nv, rt().compute));  // rank without rows
-  // the result words live in pinned, device-mapped host memory: RCCL reduces them in place
-  HIPX_NCCL(ncclAllReduce(slot_results_dev(slot), slot_results_dev(slot), (size_t)nv, ncclDouble, ncclSum, c.rcomm, rt().compute));
-  int ierr = red_signal(slot);
+  } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * (size_t)nv, rt().compute));  // rank without rows
+  HIPX_NCCL(ncclAllReduce(c.d_red, c.d_red, (size_t)nv, ncclDouble, ncclSum, c.rcomm, rt().compute));
+  int ierr = red_signal(slot, c.d_red, (int)nv);
   if (ierr) return ierr;
   return red_wait(slot, (int)nv, results);
+}
+
+int hipxCGFusedUpdateAllreduce(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n, double *sums2)
+{
+  HIPX_CHECK_INIT();
+  Comm &c = cm();
+  static const bool force = getenv("HIPX_FORCE_ALLREDUCE") != nullptr;
+  if (!c.active || (c.nranks == 1 && !force)) return hipxCGFusedUpdate(x, r, z, p, w, d, a, n, sums2);
+  const int slot = HIPX_MAX_RED_SLOTS - 2;
+  if (n > 0) {
+    int ierr = launch_cg_fused_nosignal(x, r, z, p, w, d, a, n, slot, c.d_red);
+    if (ierr) return ierr;
+  } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * 2, rt().compute));
+  HIPX_NCCL(ncclAllReduce(c.d_red, c.d_red, 2, ncclDouble, ncclSum, c.rcomm, rt().compute));
+  int ierr = red_signal(slot, c.d_red, 2);
+  if (ierr) return ierr;
+  return red_wait(slot, 2, sums2);
 }
 
 int hipxHaloCreate(int nsend, const int *send_ranks, const hipx_int *send_off, const hipx_int *send_idx, int nrecv, const int *recv_ranks, const hipx_int *recv_off,

@@ -54,8 +54,11 @@ inline RedOut red_out(int slot, bool signal = true)
   return RedOut{slot_partials(slot), r.d_tickets + slot, slot_results_dev(slot), r.d_flags + slot, signal ? ++r.seq[slot] : 0ull};
 }
 // multi-GPU reductions without a host round trip between the local kernel and the all-reduce (hipx_comm.hip)
-int launch_mdot_nosignal(const double *x, int nv, const double *const *y, hipx_int n, int slot);
-int red_signal(int slot);  // enqueue: publish the slot's results to the host (sequence flag), stream-ordered
+// The local kernel leaves its sums in device memory (dev_results), RCCL reduces them there, and red_signal() copies the
+// reduced words into the slot's host-mapped result area before raising the sequence flag.
+int launch_mdot_nosignal(const double *x, int nv, const double *const *y, hipx_int n, int slot, double *dev_results);
+int launch_cg_fused_nosignal(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n, int slot, double *dev_results);
+int red_signal(int slot, const double *dev_results, int nvals);  // enqueue: publish to the host (values, then sequence flag), stream-ordered
 int red_wait(int slot, int nvals, double *out);
 
 }  // namespace hipx

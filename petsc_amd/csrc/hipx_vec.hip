@@ -183,6 +183,51 @@ struct FAbc1 { static constexpr bool reads_w = true; double a, b; __device__ dou
 struct FAbc2 { static constexpr bool reads_w = false; double a, b; __device__ double operator()(double, double x, double y) const { return a * x + b * y; } };
 struct FAbc3 { static constexpr bool reads_w = true; double a, b, c; __device__ double operator()(double z, double x, double y) const { return a * x + b * y + c * z; } };
 
+// CG: p = z + b p (cg.c:249, general-beta loop dvec2.c:774) and the x += a p_old (cg.c:305) left over from the previous
+// iteration in one pass: p is read once.  Same arithmetic per element as the two separate kernels.
+__global__ __launch_bounds__(kEwThreads) void cg_aypx_axpy_kernel(double *p, double *x, const double *z, double b, double a, hipx_int n, bool vec)
+{
+  const hipx_int base = (hipx_int)blockIdx.x * (kEwThreads * EW_UNROLL) + threadIdx.x;
+  if (vec) {
+    const hipx_int n2 = n >> 1;
+    double2       *p2 = reinterpret_cast<double2 *>(p), *x2 = reinterpret_cast<double2 *>(x);
+    const double2 *z2 = reinterpret_cast<const double2 *>(z);
+    double2        vp[EW_UNROLL], vx[EW_UNROLL], vz[EW_UNROLL];
+#pragma unroll
+    for (int k = 0; k < EW_UNROLL; k++) {
+      hipx_int q = base + k * kEwThreads;
+      if (q < n2) {
+        vp[k] = p2[q];
+        vx[k] = x2[q];
+        vz[k] = z2[q];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < EW_UNROLL; k++) {
+      hipx_int q = base + k * kEwThreads;
+      if (q < n2) {
+        vx[k].x = vx[k].x + a * vp[k].x;
+        vx[k].y = vx[k].y + a * vp[k].y;
+        vp[k].x = vz[k].x + b * vp[k].x;
+        vp[k].y = vz[k].y + b * vp[k].y;
+        x2[q]   = vx[k];
+        p2[q]   = vp[k];
+      }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+      const double po = p[n - 1];
+      x[n - 1]        = x[n - 1] + a * po;
+      p[n - 1]        = z[n - 1] + b * po;
+    }
+  } else {
+    for (hipx_int i = (hipx_int)blockIdx.x * kEwThreads + threadIdx.x; i < n; i += (hipx_int)gridDim.x * kEwThreads) {
+      const double po = p[i];
+      x[i]            = x[i] + a * po;
+      p[i]            = z[i] + b * po;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- swap
 __global__ __launch_bounds__(kEwThreads) void swap_kernel(double *x, double *y, hipx_int n)
 {
@@ -408,6 +453,8 @@ __global__ __launch_bounds__(kRedThreads) void dotnorm2_kernel(const double *x, 
 }
 
 // fused CG update (cg.c:305-309,344 with PCJACOBI): x += a p; r -= a w; z = r*d; sums z.z, z.r
+// UPX = false: the x update is left to cg_aypx_axpy_kernel of the next iteration (p is then read once per iteration)
+template <bool UPX>
 __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n,
                                                                 bool vec, RedOut out)
 {
@@ -422,26 +469,43 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
     const hipx_int chunk = (n2 + (hipx_int)gridDim.x - 1) / (hipx_int)gridDim.x;
     const hipx_int c0    = (hipx_int)blockIdx.x * chunk;
     const hipx_int c1    = (c0 + chunk < n2) ? c0 + chunk : n2;
-    for (hipx_int q = c0 + (hipx_int)threadIdx.x; q < c1; q += kRedThreads) {
-      double2 xv = x2[q], rv = r2[q], pv = p2[q], wv = w2[q], dv = d2[q], zv;
-      xv.x  = xv.x + a * pv.x;
-      xv.y  = xv.y + a * pv.y;
+    auto step = [&](hipx_int q, double2 xv, double2 rv, const double2 pv, const double2 wv, const double2 dv) {
+      double2 zv;
+      if (UPX) {
+        xv.x  = xv.x + a * pv.x;
+        xv.y  = xv.y + a * pv.y;
+        x2[q] = xv;
+      }
       rv.x  = rv.x + ma * wv.x;
       rv.y  = rv.y + ma * wv.y;
       zv.x  = rv.x * dv.x;
       zv.y  = rv.y * dv.y;
-      x2[q] = xv;
       r2[q] = rv;
       z2[q] = zv;
       acc[0] += zv.x * zv.x;
       acc[0] += zv.y * zv.y;
       acc[1] += zv.x * rv.x;
       acc[1] += zv.y * rv.y;
+    };
+    // two elements per stream in flight per thread (10 x 16-byte loads issued before the first use); the per-thread
+    // accumulation order is unchanged (q, then q + kRedThreads)
+    hipx_int q = c0 + (hipx_int)threadIdx.x;
+    for (; q + kRedThreads < c1; q += 2 * kRedThreads) {
+      const hipx_int q1 = q + kRedThreads;
+      const double2  z0 = {0.0, 0.0};
+      const double2  xa = UPX ? x2[q] : z0, ra = r2[q], pa = UPX ? p2[q] : z0, wa = w2[q], da = d2[q];
+      const double2  xb = UPX ? x2[q1] : z0, rb = r2[q1], pb = UPX ? p2[q1] : z0, wb = w2[q1], db = d2[q1];
+      step(q, xa, ra, pa, wa, da);
+      step(q1, xb, rb, pb, wb, db);
+    }
+    if (q < c1) {
+      const double2 z0 = {0.0, 0.0};
+      step(q, UPX ? x2[q] : z0, r2[q], UPX ? p2[q] : z0, w2[q], d2[q]);
     }
     if ((n & 1) && tid == 0) {
       hipx_int i  = n - 1;
-      double   xv = x[i] + a * p[i], rv = r[i] + ma * w[i], zv = rv * d[i];
-      x[i] = xv;
+      double   rv = r[i] + ma * w[i], zv = rv * d[i];
+      if (UPX) x[i] = x[i] + a * p[i];
       r[i] = rv;
       z[i] = zv;
       acc[0] += zv * zv;
@@ -449,8 +513,8 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
     }
   } else {
     for (hipx_int i = tid; i < n; i += T) {
-      double xv = x[i] + a * p[i], rv = r[i] + ma * w[i], zv = rv * d[i];
-      x[i] = xv;
+      double rv = r[i] + ma * w[i], zv = rv * d[i];
+      if (UPX) x[i] = x[i] + a * p[i];
       r[i] = rv;
       z[i] = zv;
       acc[0] += zv * zv;
@@ -514,7 +578,14 @@ inline unsigned red_grid(hipx_int n)
   return (unsigned)(g < 1 ? 1 : g);
 }
 
-static bool g_signal = true;  // launch_mdot_nosignal() clears it around one dispatch
+static bool    g_signal  = true;     // launch_*_nosignal() clear it around one dispatch ...
+static double *g_results = nullptr;  // ... and redirect the kernel's result words to device memory
+static inline RedOut red_out_g(int slot)
+{
+  RedOut o = red_out(slot, g_signal);
+  if (g_results) o.results = g_results;
+  return o;
+}
 
 template <int NV>
 int launch_mdot(const double *x, const double *const *y, hipx_int n, int slot)
@@ -525,7 +596,7 @@ int launch_mdot(const double *x, const double *const *y, hipx_int n, int slot)
     a.y[v] = y[v];
     vec    = vec && aligned16(y[v]);
   }
-  mdot_kernel<NV><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, a, n, vec, red_out(slot, g_signal));
+  mdot_kernel<NV><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, a, n, vec, red_out_g(slot));
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -575,28 +646,50 @@ int maxpy_dispatch(double *y, int nv, const double *alpha, const double *const *
   return fail(HIPX_ERR_ARG, "maxpy batch size", __FILE__, __LINE__);
 }
 
-__global__ void red_signal_kernel(unsigned long long *flag, unsigned long long seq)
+__global__ void red_signal_kernel(unsigned long long *flag, unsigned long long seq, double *results, const double *src, int nvals)
 {
+  for (int v = 0; v < nvals; v++) results[v] = src[v];
   __threadfence_system();
   __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace
 
-int hipx::launch_mdot_nosignal(const double *x, int nv, const double *const *y, hipx_int n, int slot)
+int hipx::launch_mdot_nosignal(const double *x, int nv, const double *const *y, hipx_int n, int slot, double *dev_results)
 {
-  g_signal = false;
-  int ierr = mdot_dispatch(x, nv, y, n, slot);
-  g_signal = true;
+  g_signal  = false;
+  g_results = dev_results;
+  int ierr  = mdot_dispatch(x, nv, y, n, slot);
+  g_signal  = true;
+  g_results = nullptr;
   return ierr;
 }
 
-int hipx::red_signal(int slot)
+int hipx::red_signal(int slot, const double *dev_results, int nvals)
 {
   Runtime &r = rt();
-  red_signal_kernel<<<1, 1, 0, r.compute>>>(r.d_flags + slot, ++r.seq[slot]);
+  red_signal_kernel<<<1, 1, 0, r.compute>>>(r.d_flags + slot, ++r.seq[slot], slot_results_dev(slot), dev_results, nvals);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
+}
+
+static int launch_cg_fused(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n, int slot)
+{
+  bool vec = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(p) && aligned16(w) && aligned16(d) && n >= 2;
+  if (x) cg_fused_kernel<true><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, a, n, vec, red_out_g(slot));
+  else cg_fused_kernel<false><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, a, n, vec, red_out_g(slot));
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+int hipx::launch_cg_fused_nosignal(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n, int slot, double *dev_results)
+{
+  g_signal  = false;
+  g_results = dev_results;
+  int ierr  = launch_cg_fused(x, r, z, p, w, d, a, n, slot);
+  g_signal  = true;
+  g_results = nullptr;
+  return ierr;
 }
 
 extern "C" {
@@ -921,10 +1014,24 @@ int hipxCGFusedUpdate(double *x, double *r, double *z, const double *p, const do
   HIPX_CHECK_INIT();
   sums2[0] = sums2[1] = 0.0;
   if (n <= 0) return HIPX_SUCCESS;
-  bool vec = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(p) && aligned16(w) && aligned16(d) && n >= 2;
-  cg_fused_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, a, n, vec, red_out(0));
-  HIPX_LAUNCH_CHECK();
+  int ierr = launch_cg_fused(x, r, z, p, w, d, a, n, 0);
+  if (ierr) return ierr;
   return red_wait(0, 2, sums2);
+}
+
+int hipxCGAypxAxpy(double *p, double b, const double *z, double *x, double a, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  if (n <= 0) return HIPX_SUCCESS;
+  if (b == 0.0 || b == 1.0 || b == -1.0 || a == 0.0) {  // the reference's special-cased loops: keep them literally
+    int ierr = hipxVecAXPY(x, a, p, n);
+    if (ierr) return ierr;
+    return hipxVecAYPX(p, b, z, n);
+  }
+  bool vec = aligned16(p) && aligned16(x) && aligned16(z) && n >= 2;
+  cg_aypx_axpy_kernel<<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, z, b, a, n, vec);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
 }
 
 }  // extern "C"

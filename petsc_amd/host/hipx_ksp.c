@@ -203,6 +203,8 @@ int HipxKSPCGBegin(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double
   ksp->a      = 1.0;
   ksp->beta   = 0.0;
   ksp->betaold = 1.0;
+  ksp->x_pending = 0;
+  ksp->a_pending = 0.0;
   if (!ksp->guess_nonzero) CHK(hipxVecSet(X, n, 0.0)); /* itfunc.c:908 */
   if (ksp->guess_nonzero) {
     CHK(HipxMatMult(A, X, R));         /* cg.c:154 */
@@ -247,7 +249,10 @@ int HipxKSPCGStep(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double 
   const hipx_int n = A->m;
   double        *R = ksp->R, *Z = ksp->Z, *P = ksp->P, *W = ksp->Z; /* W aliases Z, cg.c:145 */
   double         dp = 0.0, b, dpiold;
-  const int      fused = ksp->fused && pc->type == HIPX_PC_JACOBI && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED && !A->B && A->nranks <= 1;
+  /* fused update kernel (AXPY, AXPY, PCJACOBI, norm, dot): any rank count, its two sums all-reduced together;
+     SpMV + dot fusion: only without an off-diagonal block (the dot needs the complete w) */
+  const int      fused_upd = ksp->fused && pc->type == HIPX_PC_JACOBI && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED;
+  const int      fused     = fused_upd && !A->B && A->nranks <= 1;
   for (hipx_int s = 0; s < nsteps && !ksp->reason && ksp->i < ksp->max_it; s++) {
     const hipx_int i = ksp->i;
     ksp->its = i + 1;
@@ -263,7 +268,10 @@ int HipxKSPCGStep(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double 
       b = 0.0;
     } else {
       b = ksp->beta / ksp->betaold;
-      CHK(hipxVecAYPX(P, b, Z, n)); /* cg.c:249 */
+      if (ksp->x_pending) { /* cg.c:249 and the deferred cg.c:305 of the previous iteration in one pass over P */
+        CHK(hipxCGAypxAxpy(P, b, Z, X, ksp->a_pending, n));
+        ksp->x_pending = 0;
+      } else CHK(hipxVecAYPX(P, b, Z, n)); /* cg.c:249 */
     }
     dpiold = ksp->dpi;
     if (fused) CHK(hipxMatMultDot(A->A, P, W, &ksp->dpi)); /* cg.c:257-258 in one pass */
@@ -281,10 +289,14 @@ int HipxKSPCGStep(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double 
       break;
     }
     ksp->a = ksp->beta / ksp->dpi; /* cg.c:288 */
-    if (fused) {
-      /* cg.c:305-309 + cg.c:344 in one pass: x += a p; r -= a w; z = r .* d; dp = ||z||; beta = z.r */
+    if (fused_upd) {
+      /* cg.c:306-309 + cg.c:344 in one pass: r -= a w; z = r .* d; dp = ||z||; beta = z.r.  x += a p (cg.c:305) is deferred
+         to the AYPX pass of the next iteration (or to the flush below): same operands, same arithmetic, p read once */
       double sums[2];
-      CHK(hipxCGFusedUpdate(X, R, Z, P, W, pc->dinv, ksp->a, n, sums));
+      if (A->nranks > 1) CHK(hipxCGFusedUpdateAllreduce(NULL, R, Z, P, W, pc->dinv, ksp->a, n, sums));
+      else CHK(hipxCGFusedUpdate(NULL, R, Z, P, W, pc->dinv, ksp->a, n, sums));
+      ksp->x_pending = 1;
+      ksp->a_pending = ksp->a;
       dp = sqrt(sums[0]);
       if (isnan(dp) || isinf(dp)) {
         ksp->reason = KSP_DIVERGED_NANORINF;
@@ -331,6 +343,10 @@ int HipxKSPCGStep(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double 
       }
     }
     ksp->i++;
+  }
+  if (ksp->x_pending) { /* X is complete whenever this function returns */
+    CHK(hipxVecAXPY(X, ksp->a_pending, P, n));
+    ksp->x_pending = 0;
   }
   if (!ksp->reason && ksp->i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS; /* cg.c:350 */
   return 0;

@@ -75,6 +75,44 @@ def test_single_rank_comm_allreduce_and_self_halo(hx, monkeypatch):
     M = _lib.HipxMat(m=m, A=A, B=B, halo=halo, lvec=LV.ptr, nranks=1)
     _lib.chk(ks.HipxMatMult(C.byref(M), X.ptr, Y.ptr))
     assert np.array_equal(Y.get(), z)
+    # CG on the multi-rank code path (nranks = 2 in the descriptor: every dot/norm goes through the kernel -> ncclAllReduce ->
+    # host-flag chain on this 1-rank communicator, MatMult through the halo): the fused update kernel with its 16-byte
+    # all-reduce must reproduce the one-kernel-per-call path
+    M2 = _lib.HipxMat(m=m, A=A, B=B, halo=halo, lvec=LV.ptr, nranks=2)
+    bvec = orc.matmult(ai, aj, aa, np.ones(m))
+    BV = _lib.DVec(m, bvec)
+    pcj = _lib.HipxPC()
+    ks.HipxPCSetDefaults(C.byref(pcj))
+    _lib.chk(ks.HipxPCSetUp(C.byref(pcj), C.byref(M2)))
+    sols = []
+    for fused in (0, 1):
+        k = _lib.HipxKSP()
+        ks.HipxKSPSetDefaults(C.byref(k))
+        k.rtol, k.max_it, k.fused = 1e-30, 8, fused
+        hist = np.zeros(64)
+        k.history, k.hist_len = hist.ctypes.data, 64
+        XS = _lib.DVec(m, np.zeros(m))
+        _lib.chk(ks.HipxKSPSolve_CG(C.byref(k), C.byref(M2), C.byref(pcj), BV.ptr, XS.ptr))
+        sols.append((XS.get(), int(k.its), int(k.reason), hist[:k.hist_n].copy()))
+        ks.HipxKSPDestroyWork(C.byref(k))
+        XS.free()
+    assert sols[0][1:3] == sols[1][1:3] == (8, -3)
+    assert np.abs(sols[0][3] - sols[1][3]).max() <= 1e-12 * sols[0][3][0]
+    assert np.abs(sols[0][0] - sols[1][0]).max() <= 1e-12 * np.abs(sols[0][0]).max()
+    # the chained fused update alone: identical to the local kernel bit for bit on one rank
+    rr = rng.standard_normal((6, m))
+    def fused_update(fn):
+        vs = [_lib.DVec(m, rr[i]) for i in range(6)]
+        out = (C.c_double * 2)()
+        _lib.chk(fn(vs[0].ptr, vs[1].ptr, vs[2].ptr, vs[3].ptr, vs[4].ptr, vs[5].ptr, 0.37, m, out))
+        res = (vs[0].get(), vs[1].get(), vs[2].get(), list(out))
+        for v in vs:
+            v.free()
+        return res
+    ua, ub = fused_update(hx.hipxCGFusedUpdate), fused_update(hx.hipxCGFusedUpdateAllreduce)
+    assert all(np.array_equal(p, q) for p, q in zip(ua[:3], ub[:3])) and ua[3] == ub[3]
+    ks.HipxPCDestroy(C.byref(pcj))
+    BV.free()
     _lib.chk(hx.hipxHaloDestroy(C.byref(halo)))
     for d in (X, Y, LV):
         d.free()

@@ -94,6 +94,53 @@ def test_cg_fused_path_same_history(hx):
     compare(g1, o, 1e-11)
 
 
+def test_cg_fused_stepping_deferred_x_update(hx):
+    """Fused CG defers x += a p into the next iteration's AYPX pass.  Whatever the chunking of HipxKSPCGStep calls (each
+    return flushes the pending update), x must be bit-identical to the single-call run, and equal to the unfused solver's x
+    within the rounding of the reductions; convergence inside a chunk and max_it stops included."""
+    from petsc_amd import _lib
+    _, ks = _lib.load()
+    ai, aj, aa = orc.stencil("7pt", 20)
+    N = len(ai) - 1
+    b = orc.matmult(ai, aj, aa, np.ones(N))
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    M = _lib.HipxMat(m=N, A=A, B=None, halo=None, lvec=None, nranks=1)
+    p = _lib.HipxPC()
+    ks.HipxPCSetDefaults(C.byref(p))
+    _lib.chk(ks.HipxPCSetUp(C.byref(p), C.byref(M)))
+    B = _lib.DVec(N, b)
+
+    def run(chunks, fused, rtol=1e-9, max_it=10000):
+        k = _lib.HipxKSP()
+        ks.HipxKSPSetDefaults(C.byref(k))
+        k.rtol, k.max_it, k.fused = rtol, max_it, fused
+        X = _lib.DVec(N, np.zeros(N))
+        _lib.chk(ks.HipxKSPCGBegin(C.byref(k), C.byref(M), C.byref(p), B.ptr, X.ptr))
+        xs = []
+        for c in chunks:
+            _lib.chk(ks.HipxKSPCGStep(C.byref(k), C.byref(M), C.byref(p), B.ptr, X.ptr, c))
+            xs.append(X.get())
+        out = (xs, int(k.its), int(k.reason))
+        ks.HipxKSPDestroyWork(C.byref(k))
+        X.free()
+        return out
+
+    one = run([10000], 1)
+    assert one[2] == 2 and one[1] > 20
+    parts = run([1, 2, 1, 7, 10000], 1)
+    assert parts[1:] == one[1:] and np.array_equal(parts[0][-1], one[0][-1])
+    unf = run([1, 2, 1, 7, 10000], 0)
+    assert unf[1:] == one[1:]
+    for xa, xb in zip(parts[0], unf[0]):  # also after 1, 3, 4, 11 iterations: x is complete at every return
+        assert np.abs(xa - xb).max() <= 1e-12 * np.abs(xb).max()
+    lim = run([10000], 1, rtol=1e-30, max_it=9)
+    liu = run([10000], 0, rtol=1e-30, max_it=9)
+    assert lim[2] == -3 and lim[1:] == liu[1:] and np.abs(lim[0][-1] - liu[0][-1]).max() <= 1e-12 * np.abs(liu[0][-1]).max()
+    ks.HipxPCDestroy(C.byref(p))
+    B.free()
+    _lib.mat_destroy(A)
+
+
 def test_cg_nonzero_guess_and_max_it(hx):
     ai, aj, aa = orc.stencil("7pt", 12)
     N = len(ai) - 1
