@@ -20,11 +20,11 @@
 #include "hipx_reduce.h"
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <thread>
 #include <vector>
 
 using namespace hipx;
@@ -704,6 +704,162 @@ __global__ __launch_bounds__(256) void spmv_vd_kernel(const PkDesc *__restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Set-up of the packed formats ON THE DEVICE (once per nonzero pattern / value state; ~1 ms at 117 M nonzeros, where the
+// first host-side version needed 1.4 GB of D2H copies and 0.5 s of host work).
+//
+// pk_build_kernel: one workgroup per row block.  Windows are aligned to 4096 columns (window key = col >> 12): the block's
+// distinct keys are collected in a 64-slot LDS set (atomicCAS), sorted by one thread, and every column is rewritten as
+// (rank of its key : 4 | col & 4095 : 12).  More than 16 keys -> the block keeps its 32-bit columns (base[] = -1).
+__global__ __launch_bounds__(256) void pk_build_kernel(const PkDesc *__restrict__ desc, hipx_int nblocks, long long cap, const hipx_int *__restrict__ aj, unsigned short *__restrict__ pk,
+                                                       hipx_int *__restrict__ pkbase, unsigned int *fallback)
+{
+  __shared__ int keys[64];
+  __shared__ int sorted[PK_WMAX];
+  __shared__ int nkeys, bad;
+  const hipx_int b = (hipx_int)blockIdx.x;
+  if (b >= nblocks) return;
+  const PkDesc    d    = desc[b];
+  const long long k0   = d.k0, k1 = d.k1;
+  hipx_int       *base = pkbase + (size_t)b * PK_WMAX;
+  const int       t    = threadIdx.x;
+  if (k1 - (k0 & ~3LL) > cap || k1 == k0) {  // one long row (block-wide path) or an empty block
+    if (t < PK_WMAX) base[t] = -1;
+    return;
+  }
+  if (t < 64) keys[t] = -1;
+  if (t == 0) {
+    nkeys = 0;
+    bad   = 0;
+  }
+  __syncthreads();
+  for (long long k = k0 + t; k < k1; k += 256) {
+    const int key = aj[k] >> 12;
+    unsigned  s   = ((unsigned)key * 0x9E3779B1u) >> 26;
+    for (int probe = 0; probe < 64; probe++) {
+      const int old = atomicCAS(&keys[s], -1, key);
+      if (old == -1) {
+        if (atomicAdd(&nkeys, 1) >= PK_WMAX) bad = 1;
+        break;
+      }
+      if (old == key) break;
+      s = (s + 1) & 63;
+    }
+    if (bad) break;
+  }
+  __syncthreads();
+  if (bad || nkeys > PK_WMAX) {
+    if (t < PK_WMAX) base[t] = -1;
+    if (t == 0) atomicAdd(fallback, 1u);
+    return;
+  }
+  if (t == 0) {
+    int n = 0;
+    for (int s = 0; s < 64; s++)
+      if (keys[s] != -1) {
+        int key = keys[s], i = n++;
+        while (i > 0 && sorted[i - 1] > key) {
+          sorted[i] = sorted[i - 1];
+          i--;
+        }
+        sorted[i] = key;
+      }
+    for (int w = n; w < PK_WMAX; w++) sorted[w] = sorted[n - 1];
+  }
+  __syncthreads();
+  if (t < PK_WMAX) base[t] = sorted[t] << 12;
+  for (long long k = k0 + t; k < k1; k += 256) {
+    const int c = aj[k], key = c >> 12;
+    int       w = 0;
+#pragma unroll
+    for (int i = PK_WMAX - 1; i >= 0; i--)
+      if (sorted[i] == key) w = i;  // first match (the padding repeats the last key)
+    pk[k] = (unsigned short)((w << 12) | (c & (PK_WLEN - 1)));
+  }
+}
+
+// Value dictionary, pass 1: every workgroup collects the distinct bit patterns of its contiguous chunk of a[] in a 512-slot
+// LDS set (64-bit atomicCAS) and appends them (<= 256) to a global list; the host merges the lists (a few thousand
+// entries), sorts, and assigns the codes.  More than 256 distinct patterns anywhere -> overflow flag, everybody stops.
+constexpr unsigned long long VD_EMPTY = 0x7FF8DEADBEEF0001ull;  // a NaN payload no assembled matrix holds; if one does: no dictionary
+__device__ __forceinline__ unsigned vd_hash(unsigned long long k, int bits) { return (unsigned)((k * 0x9E3779B97F4A7C15ull) >> (64 - bits)); }
+
+__global__ __launch_bounds__(256) void vd_collect_kernel(const unsigned long long *__restrict__ a, long long nnz, unsigned long long *__restrict__ list, unsigned int *counters,
+                                                         unsigned int list_cap)
+{
+  __shared__ unsigned long long tab[512];
+  __shared__ unsigned int       cnt, pos, basei, ovf;
+  const int t = threadIdx.x;
+  tab[t]       = VD_EMPTY;
+  tab[t + 256] = VD_EMPTY;
+  if (t == 0) cnt = pos = basei = ovf = 0;
+  __syncthreads();
+  const long long chunk = (nnz + gridDim.x - 1) / gridDim.x;
+  const long long c0 = (long long)blockIdx.x * chunk, c1 = (c0 + chunk < nnz) ? c0 + chunk : nnz;
+  unsigned long long last = VD_EMPTY;
+  for (long long k = c0 + t; k < c1; k += 256) {
+    if (((k - c0) & 0xffff) < 256 && __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;  // someone overflowed
+    const unsigned long long v = a[k];
+    if (v == last) continue;
+    last = v;
+    if (v == VD_EMPTY) {
+      ovf = 1;
+      break;
+    }
+    unsigned s = vd_hash(v, 9);
+    for (;;) {
+      const unsigned long long old = atomicCAS(&tab[s], VD_EMPTY, v);
+      if (old == VD_EMPTY) {
+        if (atomicAdd(&cnt, 1u) >= 256u) ovf = 1;
+        break;
+      }
+      if (old == v) break;
+      s = (s + 1) & 511;
+    }
+    if (ovf) break;
+  }
+  __syncthreads();
+  if (ovf) {
+    if (t == 0) atomicExch(&counters[1], 1u);
+    return;
+  }
+  if (t == 0) basei = atomicAdd(&counters[0], cnt);
+  __syncthreads();
+  for (int s = t; s < 512; s += 256)
+    if (tab[s] != VD_EMPTY) {
+      const unsigned r = basei + atomicAdd(&pos, 1u);
+      if (r < list_cap) list[r] = tab[s];
+    }
+}
+
+// pass 2: a[k] -> 1-byte code through the (host-built) 1024-slot table, 8 nonzeros per thread and store
+__global__ __launch_bounds__(256) void vd_encode_kernel(const unsigned long long *__restrict__ a, long long nnz, const unsigned long long *__restrict__ gkeys, const short *__restrict__ gcodes,
+                                                        unsigned char *__restrict__ vc)
+{
+  __shared__ unsigned long long keys[1024];
+  __shared__ short              codes[1024];
+  for (int s = threadIdx.x; s < 1024; s += 256) {
+    keys[s]  = gkeys[s];
+    codes[s] = gcodes[s];
+  }
+  __syncthreads();
+  const long long nq = (nnz + 7) >> 3;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long long)gridDim.x * 256) {
+    unsigned long long out = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const long long k = q * 8 + e;
+      if (k < nnz) {
+        const unsigned long long v = a[k];
+        unsigned                 s = vd_hash(v, 10);
+        while (codes[s] >= 0 && keys[s] != v) s = (s + 1) & 1023;
+        out |= (unsigned long long)(unsigned char)codes[s] << (8 * e);
+      }
+    }
+    reinterpret_cast<unsigned long long *>(vc)[q] = out;
+  }
+}
+
 template <typename IT>
 __global__ void diagpos_kernel(hipx_int m, const IT *ai, const hipx_int *aj, int64_t *diagpos, unsigned int *missing)
 {
@@ -768,8 +924,8 @@ int auto_tile_mode(hipxMat A)
 }
 
 // Value dictionary: succeeds when a[] holds at most 256 distinct bit patterns (compared as 64-bit integers, so -0.0, NaN
-// payloads etc. stay exact).  Host set-up, parallel; a 64 Ki-entry prefix is examined first so that general matrices
-// (all values distinct) cost one small copy.
+// payloads etc. stay exact).  VdTable: the host side of the code table (prefix check, code assignment); the passes over
+// a[] run on the device (vd_collect_kernel / vd_encode_kernel).
 struct VdTable {
   static constexpr int kSlots = 1024;
   uint64_t key[kSlots];
@@ -799,95 +955,6 @@ struct VdTable {
     return true;
   }
 };
-
-int ensure_vdict(hipxMat A)
-{
-  if (A->vd_ready) return HIPX_SUCCESS;
-  A->vd_ready = true;
-  A->vd_ok    = false;
-  const size_t nnz = (size_t)A->nnz;
-  if (!nnz) return HIPX_SUCCESS;
-  HIPX_HIP(hipStreamSynchronize(rt().compute));
-  {
-    const size_t          np = std::min<size_t>(nnz, 65536);
-    std::vector<uint64_t> pre(np);
-    HIPX_HIP(hipMemcpy(pre.data(), A->d_a, sizeof(uint64_t) * np, hipMemcpyDeviceToHost));
-    VdTable t;
-    for (size_t k = 0; k < np; k++)
-      if (!t.insert(pre[k])) return HIPX_SUCCESS;
-  }
-  std::vector<uint64_t> ha(nnz);
-  HIPX_HIP(hipMemcpy(ha.data(), A->d_a, sizeof(uint64_t) * nnz, hipMemcpyDeviceToHost));
-  const int            nthreads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-  std::vector<VdTable> local((size_t)nthreads);
-  std::atomic<bool>    overflow(false);
-  auto chunk = [&](int tid, size_t &lo, size_t &hi) {
-    lo = nnz * (size_t)tid / (size_t)nthreads;
-    hi = nnz * (size_t)(tid + 1) / (size_t)nthreads;
-  };
-  {
-    std::vector<std::thread> pool;
-    for (int tid = 0; tid < nthreads; tid++)
-      pool.emplace_back([&, tid]() {
-        size_t lo, hi;
-        chunk(tid, lo, hi);
-        VdTable &t    = local[(size_t)tid];
-        uint64_t last = ~ha[lo < nnz ? lo : 0];
-        for (size_t k = lo; k < hi; k++) {
-          const uint64_t v = ha[k];
-          if (v == last) continue;
-          last = v;
-          if (!t.insert(v)) {
-            overflow.store(true);
-            return;
-          }
-          if ((k & 0xfffff) == 0 && overflow.load()) return;
-        }
-      });
-    for (auto &th : pool) th.join();
-  }
-  if (overflow.load()) return HIPX_SUCCESS;
-  std::vector<uint64_t> dict;
-  for (const VdTable &t : local)
-    for (int sl = 0; sl < VdTable::kSlots; sl++)
-      if (t.code[sl] >= 0) dict.push_back(t.key[sl]);
-  std::sort(dict.begin(), dict.end());
-  dict.erase(std::unique(dict.begin(), dict.end()), dict.end());
-  if (dict.size() > 256) return HIPX_SUCCESS;
-  VdTable global;
-  for (uint64_t v : dict) global.insert(v);  // code = rank in the sorted dictionary (deterministic)
-  std::vector<unsigned char> hc(nnz + 16, 0);
-  {
-    std::vector<std::thread> pool;
-    for (int tid = 0; tid < nthreads; tid++)
-      pool.emplace_back([&, tid]() {
-        size_t lo, hi;
-        chunk(tid, lo, hi);
-        uint64_t last = 0;
-        int      lc   = -1;
-        for (size_t k = lo; k < hi; k++) {
-          const uint64_t v = ha[k];
-          if (lc < 0 || v != last) {
-            last = v;
-            lc   = global.find(v);
-          }
-          hc[k] = (unsigned char)lc;
-        }
-      });
-    for (auto &th : pool) th.join();
-  }
-  dict.resize(256, 0);
-  if (!A->d_vc) {
-    HIPX_HIP(hipMalloc((void **)&A->d_vc, hc.size()));
-    HIPX_HIP(hipMalloc((void **)&A->d_vdict, sizeof(uint64_t) * 256));
-    A->device_bytes += (int64_t)(hc.size() + sizeof(uint64_t) * 256);
-  }
-  HIPX_HIP(hipMemcpy(A->d_vc, hc.data(), hc.size(), hipMemcpyHostToDevice));
-  HIPX_HIP(hipMemcpy(A->d_vdict, dict.data(), sizeof(uint64_t) * 256, hipMemcpyHostToDevice));
-  A->vd_count = (int)global.count;
-  A->vd_ok    = true;
-  return HIPX_SUCCESS;
-}
 
 template <typename IT>
 int create_common(hipx_int m, hipx_int n, hipx_int nrows, const IT *ai, const hipx_int *ridx, const hipx_int *aj, const double *aa, bool is64, hipxMat *out)
@@ -1053,14 +1120,98 @@ int launch_spmv_c(hipxMat A, const double *x, const double *yin, double *yout, d
 }
 
 
-// Host set-up of the packed-column format (once per nonzero pattern), parallel over row blocks.
+struct SetupTimer {  // HIPX_SETUP_TIMING=1: wall time of the packed-format set-up steps on stderr
+  const char *what;
+  std::chrono::steady_clock::time_point t0;
+  static bool on() { static const bool v = getenv("HIPX_SETUP_TIMING") != nullptr; return v; }
+  explicit SetupTimer(const char *w) : what(w), t0(std::chrono::steady_clock::now()) {}
+  ~SetupTimer()
+  {
+    if (!on()) return;
+    (void)hipStreamSynchronize(rt().compute);
+    fprintf(stderr, "[hipx set-up] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
+
+int ensure_vdict(hipxMat A)
+{
+  if (A->vd_ready) return HIPX_SUCCESS;
+  SetupTimer tm("value dictionary (device)");
+  A->vd_ready = true;
+  A->vd_ok    = false;
+  const size_t nnz = (size_t)A->nnz;
+  if (!nnz) return HIPX_SUCCESS;
+  hipStream_t st = rt().compute;
+  {  // cheap reject for general matrices: 64 Ki-entry prefix on the host
+    const size_t          np = std::min<size_t>(nnz, 65536);
+    std::vector<uint64_t> pre(np);
+    HIPX_HIP(hipMemcpyAsync(pre.data(), A->d_a, sizeof(uint64_t) * np, hipMemcpyDeviceToHost, st));
+    HIPX_HIP(hipStreamSynchronize(st));
+    VdTable t;
+    for (size_t k = 0; k < np; k++)
+      if (!t.insert(pre[k])) return HIPX_SUCCESS;
+  }
+  const unsigned      grid = 2048, cap = grid * 256;
+  unsigned long long *d_list = nullptr;
+  unsigned int       *d_cnt  = nullptr;
+  HIPX_HIP(hipMalloc((void **)&d_list, sizeof(unsigned long long) * cap));
+  HIPX_HIP(hipMalloc((void **)&d_cnt, sizeof(unsigned int) * 2));
+  HIPX_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * 2, st));
+  vd_collect_kernel<<<grid, 256, 0, st>>>((const unsigned long long *)A->d_a, (long long)nnz, d_list, d_cnt, cap);
+  unsigned int hc[2] = {0, 0};
+  HIPX_HIP(hipMemcpyAsync(hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
+  HIPX_HIP(hipStreamSynchronize(st));
+  std::vector<uint64_t> dict;
+  if (!hc[1] && hc[0] <= cap) {
+    dict.resize(hc[0]);
+    if (hc[0]) HIPX_HIP(hipMemcpy(dict.data(), d_list, sizeof(uint64_t) * hc[0], hipMemcpyDeviceToHost));
+    std::sort(dict.begin(), dict.end());
+    dict.erase(std::unique(dict.begin(), dict.end()), dict.end());
+  }
+  (void)hipFree(d_list);
+  (void)hipFree(d_cnt);
+  if (hc[1] || hc[0] > cap || dict.empty() || dict.size() > 256) return HIPX_SUCCESS;
+  VdTable global;
+  for (uint64_t v : dict) global.insert(v);  // code = rank in the sorted dictionary (deterministic)
+  std::vector<short> codes(VdTable::kSlots);
+  for (int sl = 0; sl < VdTable::kSlots; sl++) codes[(size_t)sl] = (short)global.code[sl];
+  const size_t vcbytes = ((nnz + 7) / 8) * 8 + 16;
+  if (!A->d_vc) {
+    HIPX_HIP(hipMalloc((void **)&A->d_vc, vcbytes));
+    HIPX_HIP(hipMalloc((void **)&A->d_vdict, sizeof(uint64_t) * 256));
+    A->device_bytes += (int64_t)(vcbytes + sizeof(uint64_t) * 256);
+  }
+  unsigned long long *d_keys  = nullptr;
+  short              *d_codes = nullptr;
+  HIPX_HIP(hipMalloc((void **)&d_keys, sizeof(uint64_t) * VdTable::kSlots));
+  HIPX_HIP(hipMalloc((void **)&d_codes, sizeof(short) * VdTable::kSlots));
+  HIPX_HIP(hipMemcpyAsync(d_keys, global.key, sizeof(uint64_t) * VdTable::kSlots, hipMemcpyHostToDevice, st));
+  HIPX_HIP(hipMemcpyAsync(d_codes, codes.data(), sizeof(short) * VdTable::kSlots, hipMemcpyHostToDevice, st));
+  HIPX_HIP(hipMemsetAsync(A->d_vc, 0, vcbytes, st));
+  vd_encode_kernel<<<4096, 256, 0, st>>>((const unsigned long long *)A->d_a, (long long)nnz, d_keys, d_codes, A->d_vc);
+  dict.resize(256, 0);
+  HIPX_HIP(hipMemcpyAsync(A->d_vdict, dict.data(), sizeof(uint64_t) * 256, hipMemcpyHostToDevice, st));
+  HIPX_HIP(hipStreamSynchronize(st));
+  HIPX_LAUNCH_CHECK();
+  (void)hipFree(d_keys);
+  (void)hipFree(d_codes);
+  A->vd_count = (int)global.count;
+  A->vd_ok    = true;
+  return HIPX_SUCCESS;
+}
+
 int ensure_pk16(hipxMat A, int cfg = 0)
 {
   if (A->pk_ready && A->pk_cfg == cfg) return HIPX_SUCCESS;
-  int ierr = ensure_row_blocks(A, cfg);
-  if (ierr) return ierr;
+  int ierr;
+  {
+    SetupTimer tm("row blocks (host)");
+    if ((ierr = ensure_row_blocks(A, cfg))) return ierr;
+  }
+  SetupTimer tm("packed columns (device)");
+  hipStream_t st = rt().compute;
   if (A->pk_ready) {  // built on another block geometry (the value dictionary appeared / went away): rebuild
-    HIPX_HIP(hipStreamSynchronize(rt().compute));
+    HIPX_HIP(hipStreamSynchronize(st));
     (void)hipFree(A->d_pk);
     (void)hipFree(A->d_pkbase);
     (void)hipFree(A->d_pkdesc);
@@ -1069,71 +1220,29 @@ int ensure_pk16(hipxMat A, int cfg = 0)
     A->d_pkdesc = nullptr;
     A->pk_ready = false;
   }
-  const int64_t  pkcap = kCfg[cfg].cap;
   const hipx_int nb = A->nblocks[cfg];
   std::vector<hipx_int> rb((size_t)nb + 1);
   HIPX_HIP(hipMemcpy(rb.data(), A->d_rb[cfg], sizeof(hipx_int) * ((size_t)nb + 1), hipMemcpyDeviceToHost));
-  std::vector<hipx_int> hj((size_t)A->nnz + 8, 0);
-  if (A->nnz) HIPX_HIP(hipMemcpy(hj.data(), A->d_j, sizeof(hipx_int) * (size_t)A->nnz, hipMemcpyDeviceToHost));
-  std::vector<unsigned short> pk((size_t)A->nnz + 8, 0);
-  std::vector<hipx_int>       base((size_t)std::max<hipx_int>(nb, 1) * PK_WMAX, 0);
-  const int64_t *hi = A->h_i.data();
-  std::vector<int64_t> fallback(64, 0);
-  auto work = [&](int tid, int nthreads) {
-    std::vector<hipx_int> u;
-    for (hipx_int b = tid; b < nb; b += nthreads) {
-      hipx_int     *d  = base.data() + (size_t)b * PK_WMAX;
-      const int64_t k0 = hi[rb[b]], k1 = hi[rb[b + 1]];
-      d[0] = -1;
-      if (k1 - (k0 & ~(int64_t)3) > pkcap || k1 == k0) continue;
-      u.assign(hj.begin() + k0, hj.begin() + k1);
-      std::sort(u.begin(), u.end());
-      u.erase(std::unique(u.begin(), u.end()), u.end());
-      hipx_int st[PK_WMAX];
-      int      nw = 0;
-      bool     ok = true;
-      size_t   p  = 0;
-      while (p < u.size()) {  // greedy: a window covers [start, start + 4096)
-        if (nw >= PK_WMAX) {
-          ok = false;
-          break;
-        }
-        st[nw++] = u[p];
-        const hipx_int lim = u[p] + PK_WLEN;
-        while (p < u.size() && u[p] < lim) p++;
-      }
-      if (!ok) {
-        fallback[tid]++;
-        continue;
-      }
-      for (int w = 0; w < PK_WMAX; w++) d[w] = w < nw ? st[w] : st[nw - 1];
-      for (int64_t k = k0; k < k1; k++) {
-        const hipx_int c = hj[k];
-        int            lo = 0, hi2 = nw - 1;
-        while (lo < hi2) {
-          const int mid = (lo + hi2 + 1) / 2;
-          if (st[mid] <= c) lo = mid;
-          else hi2 = mid - 1;
-        }
-        pk[k] = (unsigned short)((lo << 12) | (c - st[lo]));
-      }
-    }
-  };
-  const int nthreads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-  std::vector<std::thread> pool;
-  for (int tnum = 0; tnum < nthreads; tnum++) pool.emplace_back(work, tnum, nthreads);
-  for (auto &th : pool) th.join();
-  A->pk_fallback_blocks = 0;
-  for (int tnum = 0; tnum < nthreads; tnum++) A->pk_fallback_blocks += fallback[tnum];
-  HIPX_HIP(hipMalloc((void **)&A->d_pk, sizeof(unsigned short) * pk.size()));
-  HIPX_HIP(hipMalloc((void **)&A->d_pkbase, sizeof(hipx_int) * base.size()));
-  HIPX_HIP(hipMemcpy(A->d_pk, pk.data(), sizeof(unsigned short) * pk.size(), hipMemcpyHostToDevice));
-  HIPX_HIP(hipMemcpy(A->d_pkbase, base.data(), sizeof(hipx_int) * base.size(), hipMemcpyHostToDevice));
+  const int64_t      *hi = A->h_i.data();
   std::vector<PkDesc> desc((size_t)std::max<hipx_int>(nb, 1));
   for (hipx_int b = 0; b < nb; b++) desc[(size_t)b] = PkDesc{rb[b], rb[b + 1], (long long)hi[rb[b]], (long long)hi[rb[b + 1]]};
+  const size_t npk = (size_t)A->nnz + 16, nbase = (size_t)std::max<hipx_int>(nb, 1) * PK_WMAX;
   HIPX_HIP(hipMalloc(&A->d_pkdesc, sizeof(PkDesc) * desc.size()));
-  HIPX_HIP(hipMemcpy(A->d_pkdesc, desc.data(), sizeof(PkDesc) * desc.size(), hipMemcpyHostToDevice));
-  A->device_bytes += (int64_t)(sizeof(unsigned short) * pk.size() + sizeof(hipx_int) * base.size() + sizeof(PkDesc) * desc.size());
+  HIPX_HIP(hipMalloc((void **)&A->d_pk, sizeof(unsigned short) * npk));
+  HIPX_HIP(hipMalloc((void **)&A->d_pkbase, sizeof(hipx_int) * nbase));
+  HIPX_HIP(hipMemcpyAsync(A->d_pkdesc, desc.data(), sizeof(PkDesc) * desc.size(), hipMemcpyHostToDevice, st));
+  HIPX_HIP(hipMemsetAsync(A->d_pk, 0, sizeof(unsigned short) * npk, st));
+  HIPX_HIP(hipMemsetAsync(A->d_pkbase, 0xff, sizeof(hipx_int) * nbase, st));
+  unsigned int *cnt = rt().d_tickets + (HIPX_MAX_RED_SLOTS - 1);  // scratch word, zero between uses
+  HIPX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
+  if (nb) pk_build_kernel<<<(unsigned)nb, 256, 0, st>>>((const PkDesc *)A->d_pkdesc, nb, (long long)kCfg[cfg].cap, A->d_j, A->d_pk, A->d_pkbase, cnt);
+  unsigned int fb = 0;
+  HIPX_HIP(hipMemcpyAsync(&fb, cnt, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+  HIPX_HIP(hipStreamSynchronize(st));  // desc[] (host) is read by the copy above
+  HIPX_LAUNCH_CHECK();
+  HIPX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
+  A->pk_fallback_blocks = fb;
+  A->device_bytes += (int64_t)(sizeof(unsigned short) * npk + sizeof(hipx_int) * nbase + sizeof(PkDesc) * desc.size());
   A->pk_cfg   = cfg;
   A->pk_ready = true;
   return HIPX_SUCCESS;
