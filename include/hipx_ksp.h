@@ -64,11 +64,14 @@ typedef struct {
   hipx_int work_n;
   int      x_pending;        /* fused CG: x += a_pending * P of the last iteration not applied yet (merged into the next AYPX pass) */
   double   a_pending;
+  int      defer_flush;      /* 1: HipxKSPCGStep may return with the x update pending; the caller ends with HipxKSPCGFlush */
+  int      external_test;    /* 1: the caller runs its own convergence test after every step (the PETSc plugin: ksp->converged) */
 } HipxKSP;
 
 void HipxKSPSetDefaults(HipxKSP *ksp);
 void HipxPCSetDefaults(HipxPC *pc);
 int  HipxKSPDestroyWork(HipxKSP *ksp);
+int  HipxKSPCGFlush(HipxKSP *ksp, HipxMat *A, double *x); /* applies a pending x += a p (defer_flush callers) */
 
 int HipxMatMult(HipxMat *A, const double *x, double *y);                 /* MatMult_SeqAIJ | MatMult_MPIAIJ */
 int HipxPCSetUp(HipxPC *pc, HipxMat *A);                                 /* PCSetUp_Jacobi | PCSetUp_SOR (nothing) */

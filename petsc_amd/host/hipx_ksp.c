@@ -133,7 +133,7 @@ static void log_history(HipxKSP *ksp, double rnorm)
 static int converged_default(HipxKSP *ksp, HipxMat *A, HipxPC *pc, hipx_int n, double rnorm, const double *b, int *reason)
 {
   *reason = KSP_CONVERGED_ITERATING;
-  if (ksp->normtype == HIPX_KSP_NORM_NONE) return 0;
+  if (ksp->normtype == HIPX_KSP_NORM_NONE || ksp->external_test) return 0;
   if (!n) {
     if (ksp->guess_nonzero) {
       double snorm = 0.0;
@@ -344,11 +344,17 @@ int HipxKSPCGStep(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double 
     }
     ksp->i++;
   }
-  if (ksp->x_pending) { /* X is complete whenever this function returns */
-    CHK(hipxVecAXPY(X, ksp->a_pending, P, n));
+  if (!ksp->defer_flush) CHK(HipxKSPCGFlush(ksp, A, X)); /* X is complete whenever this function returns */
+  if (!ksp->reason && ksp->i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS; /* cg.c:350 */
+  return 0;
+}
+
+int HipxKSPCGFlush(HipxKSP *ksp, HipxMat *A, double *X)
+{
+  if (ksp->x_pending) {
+    CHK(hipxVecAXPY(X, ksp->a_pending, ksp->P, A->m)); /* cg.c:305 of the last iteration */
     ksp->x_pending = 0;
   }
-  if (!ksp->reason && ksp->i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS; /* cg.c:350 */
   return 0;
 }
 

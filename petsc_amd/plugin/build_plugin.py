@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 LIB = os.path.join(ROOT, "petsc_amd", "lib")
-SRCS = ["vechipx.c", "mathipx.c", "matmpihipx.c", "pchipx.c", "register.c"]
+SRCS = ["vechipx.c", "mathipx.c", "matmpihipx.c", "pchipx.c", "ksphipx.c", "register.c"]
 
 
 def build(verbose=False, arch="mpiuni"):
@@ -19,7 +19,7 @@ def build(verbose=False, arch="mpiuni"):
     refdir = os.path.join(ROOT, "oracle", "_ref", "mpich") if mpich else os.path.join(ROOT, "oracle", "_ref")
     target = os.path.join(LIB, "libpetschipx_mpich.so" if mpich else "libpetschipx.so")
     srcs = [os.path.join(HERE, s) for s in SRCS]
-    deps = srcs + [os.path.join(HERE, "hipxplugin.h"), os.path.join(ROOT, "include", "hipx.h"), os.path.join(LIB, "libhipx.so"),
+    deps = srcs + [os.path.join(HERE, "hipxplugin.h"), os.path.join(ROOT, "include", "hipx.h"), os.path.join(ROOT, "include", "hipx_ksp.h"), os.path.join(LIB, "libhipx.so"), os.path.join(LIB, "libhipxksp.so"),
                    os.path.join(refdir, "lib", "libpetsc.so")]
     if os.path.exists(target) and all(os.path.getmtime(d) <= os.path.getmtime(target) for d in deps):
         return target
@@ -27,7 +27,7 @@ def build(verbose=False, arch="mpiuni"):
     cmd = ["gcc", "-std=gnu11", "-O2", "-fPIC", "-shared", "-Wall", "-Wno-unused-parameter"] + extra + \
           ["-I" + os.path.join(ROOT, "oracle", "ref_conf"), "-I" + os.path.join(REF, "include"), "-I" + REF, "-I" + os.path.join(REF, "include", "petsc"),
            "-I" + os.path.join(ROOT, "include"), "-o", target] + srcs + \
-          ["-L" + LIB, "-lhipx", "-L" + os.path.join(refdir, "lib"), "-lpetsc",
+          ["-L" + LIB, "-lhipxksp", "-lhipx", "-L" + os.path.join(refdir, "lib"), "-lpetsc",
            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + ("$ORIGIN/../../oracle/_ref/mpich/lib" if mpich else "$ORIGIN/../../oracle/_ref/lib"), "-Wl,-rpath,/opt/conda/lib", "-Wl,-z,nodelete"] + \
           (["-L/opt/conda/lib", "-lmpi"] if mpich else [])
     if verbose:

@@ -11,6 +11,7 @@
 #include <petsc/private/vecimpl.h>
 #include <petsc/private/matimpl.h>
 #include <petsc/private/pcimpl.h>
+#include <petsc/private/kspimpl.h>
 #include <../src/vec/vec/impls/dvecimpl.h>
 #include <../src/vec/vec/impls/mpi/pvecimpl.h>
 #include <../src/mat/impls/aij/seq/aij.h>
@@ -62,5 +63,6 @@ PETSC_INTERN PetscErrorCode VecCreate_HIPX(Vec);
 PETSC_INTERN PetscErrorCode MatCreate_SeqAIJHIPX(Mat);
 PETSC_INTERN PetscErrorCode MatCreate_MPIAIJHIPX(Mat);
 PETSC_INTERN PetscErrorCode PCCreate_JacobiHIPX(PC);
+PETSC_INTERN PetscErrorCode KSPCreate_CGHIPX(KSP); /* "cghipx": KSPCG with the fused device kernels on the hot-path configuration */
 PETSC_INTERN PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA); /* uploads / refreshes the device CSR */
 PETSC_INTERN PetscBool      MatIsSeqAIJHIPX(Mat A);

@@ -1,0 +1,121 @@
+/*
+ * ksphipx.c -- KSPCGHIPX ("cghipx"): KSPCG whose solve runs the fused device kernels of libhipx when the configuration is
+ * the hot path's (sequential MATSEQAIJHIPX operator, default PCJACOBI, left preconditioning, preconditioned norm, no
+ * eigenvalue estimates / trust radius / single-reduction variant), and the reference's own KSPSolve_CG otherwise.
+ *
+ * Subclass recipe as for the Mat types: KSPCreate_CG (PETSC_EXTERN, cg.c:686) builds the object, we keep its solve op as the
+ * fall-back and install ours.  The fused solve is the C host layer's stepping CG (include/hipx_ksp.h: the statement-by-
+ * statement mirror of cg.c:119-352), one iteration per call, with PETSc's OWN residual history, monitors and convergence
+ * test invoked between iterations exactly where KSPSolve_CG invokes them (cg.c:196-205, 326-328) -- so -ksp_monitor,
+ * -ksp_converged_reason, KSPSetConvergenceTest keep working.  Per iteration: SpMV+dot, fused update (r, z, two sums),
+ * AYPX+deferred AXPY = 3 kernels + 1 partial fold instead of 8 launches and 3 blocking reductions.
+ */
+#include "hipxplugin.h"
+#include <petsc/private/kspimpl.h>
+#include <../src/ksp/ksp/impls/cg/cgimpl.h>
+#include "hipx_ksp.h"
+
+#define KSPCGHIPX "cghipx"
+
+static PetscErrorCode (*parent_solve_cg)(KSP) = NULL;
+
+static PetscBool KSPCGHIPXApplicable(KSP ksp, Mat *Aout)
+{
+  KSP_CG       *cg = (KSP_CG *)ksp->data;
+  Mat           Amat, Pmat;
+  PetscBool     isjac = PETSC_FALSE, useabs = PETSC_FALSE, fixdiag = PETSC_TRUE;
+  PCJacobiType  jt;
+  PetscMPIInt   size;
+
+  if (ksp->calc_sings || cg->singlereduction || cg->radius != 0.0 || cg->type != KSP_CG_SYMMETRIC || cg->obj_min != 0.0) return PETSC_FALSE;
+  if (ksp->pc_side != PC_LEFT || ksp->normtype != KSP_NORM_PRECONDITIONED || ksp->transpose_solve) return PETSC_FALSE;
+  if (ksp->dscale) return PETSC_FALSE;
+  if (MPI_Comm_size(PetscObjectComm((PetscObject)ksp), &size) || size != 1) return PETSC_FALSE;
+  if (PCGetOperators(ksp->pc, &Amat, &Pmat) || Amat != Pmat || !MatIsSeqAIJHIPX(Amat) || Amat->rmap->n != Amat->cmap->n) return PETSC_FALSE;
+  if (PetscObjectTypeCompare((PetscObject)ksp->pc, PCJACOBI, &isjac) || !isjac) return PETSC_FALSE;
+  if (PCJacobiGetType(ksp->pc, &jt) || jt != PC_JACOBI_DIAGONAL) return PETSC_FALSE;
+  if (PCJacobiGetUseAbs(ksp->pc, &useabs) || useabs) return PETSC_FALSE;
+  if (PCJacobiGetFixDiagonal(ksp->pc, &fixdiag) || !fixdiag) return PETSC_FALSE;
+  if (!VecIsHIPX(ksp->vec_rhs) || !VecIsHIPX(ksp->vec_sol)) return PETSC_FALSE;
+  {
+    MatNullSpace nsp = NULL;
+    if (MatGetNullSpace(Amat, &nsp) || nsp) return PETSC_FALSE; /* KSPSolve removes it through the PC; keep that on the reference path */
+  }
+  *Aout = Amat;
+  return PETSC_TRUE;
+}
+
+static PetscErrorCode KSPSolve_CGHIPX(KSP ksp)
+{
+  Mat                Amat = NULL;
+  hipxMat            dA;
+  HipxMat            M;
+  HipxPC             hpc;
+  HipxKSP            k;
+  const PetscScalar *db;
+  PetscScalar       *dx;
+  void              *tb, *tx;
+  PetscInt           n;
+
+  PetscFunctionBegin;
+  if (!KSPCGHIPXApplicable(ksp, &Amat)) {
+    PetscCall(PetscInfo(ksp, "KSPCGHIPX: configuration outside the fused path, running the reference KSPSolve_CG\n"));
+    PetscCall((*parent_solve_cg)(ksp));
+    PetscFunctionReturn(PETSC_SUCCESS);
+  }
+  n = Amat->rmap->n;
+  PetscCall(MatSeqAIJHIPXGetDeviceMat(Amat, &dA));
+  M.m = (hipx_int)n; M.A = dA; M.B = NULL; M.halo = NULL; M.lvec = NULL; M.nranks = 1;
+  HipxPCSetDefaults(&hpc);
+  hpc.type = HIPX_PC_JACOBI;
+  PetscCallHIPX(HipxPCSetUp(&hpc, &M)); /* 1/diag, 0 -> 1: jacobi.c:205-266 on the device */
+  HipxKSPSetDefaults(&k);
+  k.normtype      = HIPX_KSP_NORM_PRECONDITIONED;
+  k.max_it        = (hipx_int)ksp->max_it;
+  k.guess_nonzero = ksp->guess_zero ? 0 : 1;
+  k.fused         = 1;
+  k.external_test = 1;                                  /* PETSc's (*ksp->converged) decides */
+  k.defer_flush   = ksp->numbermonitors ? 0 : 1;        /* monitors may look at the solution: keep x complete for them */
+  PetscCall(VecHIPXGetDeviceRead(ksp->vec_rhs, &db, &tb));
+  PetscCall(VecHIPXGetDeviceReadWrite(ksp->vec_sol, &dx, &tx));
+
+  ksp->its = 0;
+  PetscCallHIPX(HipxKSPCGBegin(&k, &M, &hpc, db, dx)); /* cg.c:134-217 */
+  if (k.reason) ksp->reason = (KSPConvergedReason)k.reason; /* KSPCheckNorm: NaN/Inf */
+  else {
+    ksp->rnorm = k.rnorm;
+    PetscCall(KSPLogResidualHistory(ksp, k.rnorm));
+    PetscCall(KSPMonitor(ksp, 0, k.rnorm));
+    PetscCall((*ksp->converged)(ksp, 0, k.rnorm, &ksp->reason, ksp->cnvP)); /* cg.c:205 */
+  }
+  while (!ksp->reason) {
+    const hipx_int ibefore = k.i;
+    PetscCallHIPX(HipxKSPCGStep(&k, &M, &hpc, db, dx, 1)); /* one pass of cg.c:220-349 */
+    ksp->its = (PetscInt)k.its;
+    if (k.i > ibefore) { /* the pass completed: history, monitors and the convergence test as in cg.c:326-328 */
+      ksp->rnorm = k.rnorm;
+      PetscCall(KSPLogResidualHistory(ksp, k.rnorm));
+      PetscCall(KSPMonitor(ksp, (PetscInt)k.i, k.rnorm));
+      PetscCall((*ksp->converged)(ksp, (PetscInt)k.i, k.rnorm, &ksp->reason, ksp->cnvP));
+    }
+    /* breakdown / NaN inside the pass (cg.c:223-232,262-268, KSPCheckDot/KSPCheckNorm) or max_it reached (cg.c:350) */
+    if (!ksp->reason && k.reason) ksp->reason = (KSPConvergedReason)k.reason;
+  }
+  PetscCallHIPX(HipxKSPCGFlush(&k, &M, dx));
+  PetscCallHIPX(HipxKSPDestroyWork(&k));
+  PetscCallHIPX(HipxPCDestroy(&hpc));
+  PetscCall(VecHIPXRestoreDeviceWrite(ksp->vec_sol, &dx, &tx));
+  PetscCall(VecHIPXRestoreDeviceRead(ksp->vec_rhs, &db, &tb));
+  PetscCall(PetscObjectStateIncrease((PetscObject)ksp->vec_sol));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PetscErrorCode KSPCreate_CGHIPX(KSP ksp)
+{
+  PetscFunctionBegin;
+  PetscCall(VecHIPXInitRuntime());
+  PetscCall(KSPCreate_CG(ksp)); /* PETSC_EXTERN, cg.c:686 */
+  if (!parent_solve_cg) parent_solve_cg = ksp->ops->solve;
+  ksp->ops->solve = KSPSolve_CGHIPX;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}

@@ -21,5 +21,6 @@ PETSC_EXTERN PetscErrorCode HIPX_PLUGIN_REGISTER(void)
   PetscCall(MatRegister(MATMPIAIJHIPX, MatCreate_MPIAIJHIPX));
   PetscCall(MatRegisterRootName(MATAIJHIPX, MATSEQAIJHIPX, MATMPIAIJHIPX)); /* -mat_type aijhipx resolves by communicator size, matreg.c:128-138 */
   PetscCall(PCRegister(PCJACOBIHIPX, PCCreate_JacobiHIPX));
+  PetscCall(KSPRegister("cghipx", KSPCreate_CGHIPX));
   PetscFunctionReturn(PETSC_SUCCESS);
 }

@@ -110,3 +110,31 @@ def test_bench_kspsolve_matmult_and_ksp_goldens_with_aijhipx():
     out = run("bench_kspsolve", ["-print_timing", "false", "-matmult", "-its", "10", "-n", "8", "-mat_type", "aijhipx", "-dll_prepend", PLUGIN])
     ref = run("bench_kspsolve", ["-print_timing", "false", "-matmult", "-its", "10", "-n", "8"])
     assert out.split() == ref.split() and "Number of nonzeros = 10648" in out
+
+
+def test_ksp_cghipx_fused_solve_inside_petsc():
+    """-ksp_type cghipx: KSPCG subclass whose solve runs the fused device kernels (C host layer) under PETSc's own monitors,
+    history and convergence test.  Must agree with the reference's KSPSolve_CG on the CPU and on the hipx types."""
+    base = ["-m", "100", "-n", "100", "-pc_type", "jacobi"]
+    cpu = run("ex2", base + ["-ksp_type", "cg"])
+    assert cpu.strip() == "Norm of error 5.70785e-05 iterations 160"          # BASELINE config 1
+    assert run("ex2", base + ["-ksp_type", "cghipx"] + HIPX) == cpu
+    # monitors / converged reason come from PETSc itself, every iteration
+    mon_cpu = run("ex2", base + ["-ksp_type", "cg", "-ksp_monitor", "-ksp_converged_reason"])
+    mon_gpu = run("ex2", base + ["-ksp_type", "cghipx", "-ksp_monitor", "-ksp_converged_reason"] + HIPX)
+    rc = [float(m) for m in re.findall(r"KSP Residual norm (\S+)", mon_cpu)]
+    rg = [float(m) for m in re.findall(r"KSP Residual norm (\S+)", mon_gpu)]
+    assert len(rc) == len(rg) == 161 and np.abs(np.array(rc) - np.array(rg)).max() <= 1e-12 * rc[0]
+    assert "CONVERGED_RTOL iterations 160" in mon_gpu and "CONVERGED_RTOL iterations 160" in mon_cpu
+    # full-precision histories through ref_driver (3-D 7-pt and 27-pt), max_it stop, non-default configuration falls back
+    for args in ("-stencil 7 -n 24 -pc_type jacobi -ksp_rtol 1e-8", "-stencil 27 -n 16 -pc_type jacobi -ksp_rtol 1e-8",
+                 "-stencil 7 -n 16 -pc_type jacobi -ksp_rtol 1e-30 -ksp_max_it 9", "-stencil 7 -n 16 -pc_type sor -ksp_rtol 1e-8",
+                 "-stencil 7 -n 16 -pc_type jacobi -ksp_norm_type unpreconditioned -ksp_rtol 1e-8"):
+        a = args.split() + ["-history"]
+        c, g = run("ref_driver", a + ["-ksp_type", "cg"]), run("ref_driver", a + ["-ksp_type", "cghipx"] + HIPX)
+        hc, hg = hist_of(c), hist_of(g)
+        ic = re.search(r"iterations (\d+) reason (-?\d+) error (\S+)", c)
+        ig = re.search(r"iterations (\d+) reason (-?\d+) error (\S+)", g)
+        assert ic.group(1, 2) == ig.group(1, 2), (args, ic.groups(), ig.groups())
+        assert len(hc) == len(hg) and np.abs(hc - hg).max() <= 1e-12 * hc[0], args
+        assert abs(float(ic.group(3)) - float(ig.group(3))) <= 1e-5 * float(ic.group(3)) + 1e-13
