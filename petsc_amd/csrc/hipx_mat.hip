@@ -566,8 +566,8 @@ struct PkDesc {
 template <typename IT, int MODE, bool DOT, int RPT, int W, int DBG = 0>
 __global__ __launch_bounds__(256) void spmv_vd_kernel(const PkDesc *__restrict__ desc, hipx_int nblocks, hipx_int blocks_per_xcd, const IT *__restrict__ ai, const hipx_int *__restrict__ aj,
                                                       const unsigned short *__restrict__ pk, const hipx_int *__restrict__ pkbase, const double *__restrict__ aa,
-                                                      const unsigned char *__restrict__ vc, const double *__restrict__ vdict, const double *__restrict__ x, const double *yin, double *yout,
-                                                      double *dotpart, hipx_int ncols)
+                                                      const unsigned char *__restrict__ vc, const double *__restrict__ vdict, int ndict, const double *__restrict__ x, const double *yin,
+                                                      double *yout, double *dotpart, hipx_int ncols)
 {
   constexpr int THREADS = 256, CAP = 2048 * RPT;
   __shared__ double   dict[256];
@@ -581,26 +581,30 @@ __global__ __launch_bounds__(256) void spmv_vd_kernel(const PkDesc *__restrict__
     const IT       k0 = (IT)d.k0, k1 = (IT)d.k1;
     const IT       ka = k0 & ~(IT)3;
     const int      t  = threadIdx.x;
+    // The gather address unit is the busiest block of this kernel (profiles/r01c_spmv_counters.json), so the bookkeeping
+    // loads are kept to the lanes that need them: one row offset per lane (the end offset comes from the next lane),
+    // window starts on lanes 0..15 of each wave, the dictionary on its first ndict lanes.
     IT             rs[RPT], re[RPT];
     double         xrow[RPT];
 #pragma unroll
     for (int rr = 0; rr < RPT; rr++) {
       const hipx_int row = r0 + t + rr * THREADS;
-      rs[rr] = re[rr] = 0;
-      xrow[rr]        = 0.0;
-      if (row < r1) {
-        rs[rr] = ai[row];
-        re[rr] = ai[row + 1];
-        if (DOT) xrow[rr] = x[row];
-      }
+      const IT       me  = (row <= r1) ? ai[row] : (IT)0;           // ai[r1] exists: r1 <= number of rows
+      IT             nx;                                            // = ai[row + 1] for lanes 0..62
+      if constexpr (sizeof(IT) == 4) nx = (IT)__shfl_down((int)me, 1, 64);
+      else nx = (IT)__shfl_down((long long)me, 1, 64);
+      if ((t & 63) == 63) nx = (row < r1) ? ai[row + 1] : (IT)0;
+      rs[rr]   = (row < r1) ? me : (IT)0;
+      re[rr]   = (row < r1) ? nx : (IT)0;
+      xrow[rr] = (DOT && row < r1) ? x[row] : 0.0;
     }
-    const int base_reg = pkbase[(size_t)b * PK_WMAX + (t & (PK_WMAX - 1))];
+    const int base_reg = ((t & 63) < PK_WMAX) ? pkbase[(size_t)b * PK_WMAX + (t & (PK_WMAX - 1))] : 0;
     const int packed   = __shfl(base_reg, 0, 64) >= 0;
     if ((k1 - ka) <= (IT)CAP) {
       if (packed) {
         const IT  ka8 = k0 & ~(IT)7;
         const IT  nq8 = (k1 - ka8 + 7) >> 3;
-        dict[t]       = vdict[t];
+        if (t < ndict) dict[t] = vdict[t];
         for (IT q = t; q < nq8; q += THREADS) {
           int4v              c8;
           unsigned long long v8;
@@ -1281,7 +1285,7 @@ int launch_pk16(hipxMat A, const double *x, const double *yin, double *yout, dou
 #define HIPX_PK_ARGS A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_pk, A->d_pkbase, A->d_a
 #define HIPX_VD_LAUNCH(R, WW, D) \
   spmv_vd_kernel<IT, MODE, DOT, R, WW, D><<<grid, 256, 0, rt().compute>>>((const PkDesc *)A->d_pkdesc, nb, per_xcd, (const IT *)A->d_i, A->d_j, A->d_pk, A->d_pkbase, A->d_a, A->d_vc, \
-                                                                            A->d_vdict, x, yin, yout, dotpart, A->n)
+                                                                            A->d_vdict, A->vd_count, x, yin, yout, dotpart, A->n)
   if (rpt > 0) {
     const int probe = (MODE == 0 && !DOT) ? A->probe : 0;
     if (probe) {
