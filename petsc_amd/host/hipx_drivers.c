@@ -59,7 +59,30 @@ int64_t HipxAssemble_poisson7(hipx_int n, hipx_int rstart, hipx_int rend, hipx_i
   return nz;
 }
 
+/* 27-point stencil, both row-offset widths (ai32 or ai64 non-NULL; both NULL = count only): 512^3 has 3.6e9 nonzeros */
+static int64_t assemble_bench27(hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, int64_t *ai64, hipx_int *aj, double *aa);
+
 int64_t HipxAssemble_bench27(hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, hipx_int *aj, double *aa)
+{
+  return assemble_bench27(n, rstart, rend, ai, NULL, aj, aa);
+}
+
+int64_t HipxAssemble_bench27_64(hipx_int n, hipx_int rstart, hipx_int rend, int64_t *ai, hipx_int *aj, double *aa)
+{
+  return assemble_bench27(n, rstart, rend, NULL, ai, aj, aa);
+}
+
+#undef EMIT
+#define EMIT(J, V) \
+  do { \
+    if (aj) { \
+      aj[nz] = (hipx_int)(J); \
+      aa[nz] = (V); \
+    } \
+    nz++; \
+  } while (0)
+
+static int64_t assemble_bench27(hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, int64_t *ai64, hipx_int *aj, double *aa)
 {
   int64_t        nz = 0;
   const hipx_int n2 = n * n, n1 = n - 1;
@@ -69,6 +92,7 @@ int64_t HipxAssemble_bench27(hipx_int n, hipx_int rstart, hipx_int rend, hipx_in
   hipx_int       x = rstart % n, y = (rstart / n) % n, z = rstart / n2;
   for (hipx_int Ii = rstart; Ii < rend; Ii++) {
     if (ai) ai[Ii - rstart] = (hipx_int)nz;
+    if (ai64) ai64[Ii - rstart] = nz;
     for (int dz = -1; dz <= 1; dz++) {
       if ((dz < 0 && z == 0) || (dz > 0 && z == n1)) continue;
       for (int dy = -1; dy <= 1; dy++) {
@@ -88,5 +112,6 @@ int64_t HipxAssemble_bench27(hipx_int n, hipx_int rstart, hipx_int rend, hipx_in
     }
   }
   if (ai) ai[rend - rstart] = (hipx_int)nz;
+  if (ai64) ai64[rend - rstart] = nz;
   return nz;
 }

@@ -1,0 +1,23 @@
+"""GPU, BASELINE full sizes through size-independent properties.  Config 3's matrix (27-pt Poisson 512^3: 134,217,728 rows,
+3,609,741,304 nonzeros -> 64-bit row offsets, 46.5 GB of CSR) on one GPU: sampled rows of y = A x bit-identical to the
+left-to-right row sums recomputed on the host, CG + PCJACOBI steps run (scripts/config3_single_gpu.py).  Needs ~51 GB of
+host memory; skipped on smaller hosts."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config3_matrix_int64_offsets_on_one_gpu():
+    avail_gb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1e6
+    if avail_gb < 120:
+        pytest.skip("needs ~51 GB of free host memory (have %.0f GB)" % avail_gb)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "config3_single_gpu.py"), "512"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    out = r.stdout
+    assert r.returncode == 0, out[-3000:]
+    assert "nnz=3609741304" in out and "sampled rows bit-identical: 8999 of 8999" in out, out[-2000:]
+    assert "value dictionary" in out and "reason 0" in out
