@@ -32,7 +32,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 def assemble(ks, stencil, n, rs, re):
     f = {7: ks.HipxAssemble_poisson7, 27: ks.HipxAssemble_bench27}[stencil]
     nz = f(n, rs, re, None, None, None)
-    ai = np.zeros(re - rs + 1, np.int32)
+    wide = nz >= 2 ** 31 - 8  # 64-bit row offsets (27-pt 512^3 / 7-pt 1024^3 on one rank)
+    if wide:
+        f = {7: ks.HipxAssemble_poisson7_64, 27: ks.HipxAssemble_bench27_64}[stencil]
+    ai = np.zeros(re - rs + 1, np.int64 if wide else np.int32)
     aj = np.zeros(nz, np.int32)
     aa = np.zeros(nz, np.float64)
     f(n, rs, re, ai.ctypes.data_as(C.c_void_p), aj.ctypes.data_as(C.c_void_p), aa.ctypes.data_as(C.c_void_p))
@@ -172,7 +175,7 @@ def main():
     rnorm = float(ksp.rnorm)
 
     # roofline of the dominant kernel (the diagonal-block / sequential SpMV launch of this rank)
-    spmv_bytes = 12 * nnz_local + 4 * (m + 1) + 16 * m  # val + col + row offsets + x + y
+    spmv_bytes = 12 * nnz_local + (8 if ai.dtype == np.int64 else 4) * (m + 1) + 16 * m  # val + col + row offsets + x + y
     spmv_ms = tot_ms.value / max(cnt.value, 1)
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
 
@@ -208,7 +211,8 @@ def main():
                                  "than that (16-bit column codes; 8-bit value codes when a[] has <= 256 distinct values), see traffic"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            ref = cpu_baseline_reference(args.stencil, n, 24 if n >= 200 else 100)
+            ref = cpu_baseline_reference(args.stencil, n, 24 if n >= 200 else 100) if N <= 2 ** 25 else {
+                "value": None, "unit": "CG iterations/s", "cores": 1, "kind": "reference", "sample": "not timed: the bounded-sample rule (10-30 s of CPU work) cannot hold at this size"}
             if ref is None:
                 bh = B.get()
                 ref = cpu_baseline(ai, aj, aa, bh, args.cpu_baseline_seconds, args.stencil, n)

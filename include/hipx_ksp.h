@@ -110,6 +110,7 @@ void HipxSplitOwnership(hipx_int N, int size, hipx_int *ranges);
 /* ---- driver assembly (petsc_amd/host/hipx_drivers.c): ex2.c:70-94, 3-D 7-point analogue, bench_kspsolve.c:115-303 */
 int64_t HipxAssemble_ex2(hipx_int m, hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, hipx_int *aj, double *aa);
 int64_t HipxAssemble_poisson7(hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, hipx_int *aj, double *aa);
+int64_t HipxAssemble_poisson7_64(hipx_int n, hipx_int rstart, hipx_int rend, int64_t *ai, hipx_int *aj, double *aa);
 int64_t HipxAssemble_bench27(hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, hipx_int *aj, double *aa);
 int64_t HipxAssemble_bench27_64(hipx_int n, hipx_int rstart, hipx_int rend, int64_t *ai, hipx_int *aj, double *aa); /* 64-bit row offsets (512^3: 3.6e9 nonzeros) */
 

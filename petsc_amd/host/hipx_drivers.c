@@ -33,13 +33,36 @@ int64_t HipxAssemble_ex2(hipx_int m, hipx_int n, hipx_int rstart, hipx_int rend,
   return nz;
 }
 
+static int64_t assemble_poisson7(hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, int64_t *ai64, hipx_int *aj, double *aa);
+
 int64_t HipxAssemble_poisson7(hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, hipx_int *aj, double *aa)
+{
+  return assemble_poisson7(n, rstart, rend, ai, NULL, aj, aa);
+}
+
+int64_t HipxAssemble_poisson7_64(hipx_int n, hipx_int rstart, hipx_int rend, int64_t *ai, hipx_int *aj, double *aa)
+{
+  return assemble_poisson7(n, rstart, rend, NULL, ai, aj, aa);
+}
+
+#undef EMIT
+#define EMIT(J, V) \
+  do { \
+    if (aj) { \
+      aj[nz] = (hipx_int)(J); \
+      aa[nz] = (V); \
+    } \
+    nz++; \
+  } while (0)
+
+static int64_t assemble_poisson7(hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, int64_t *ai64, hipx_int *aj, double *aa)
 {
   int64_t        nz = 0;
   const hipx_int n2 = n * n;
   hipx_int       x = rstart % n, y = (rstart / n) % n, z = rstart / n2;
   for (hipx_int Ii = rstart; Ii < rend; Ii++) {
     if (ai) ai[Ii - rstart] = (hipx_int)nz;
+    if (ai64) ai64[Ii - rstart] = nz;
     if (z > 0) EMIT(Ii - n2, -1.0);
     if (y > 0) EMIT(Ii - n, -1.0);
     if (x > 0) EMIT(Ii - 1, -1.0);
@@ -56,6 +79,7 @@ int64_t HipxAssemble_poisson7(hipx_int n, hipx_int rstart, hipx_int rend, hipx_i
     }
   }
   if (ai) ai[rend - rstart] = (hipx_int)nz;
+  if (ai64) ai64[rend - rstart] = nz;
   return nz;
 }
 
