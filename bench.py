@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--grid", dest="n", type=int, default=256, help="grid points per side (not --n: torchrun would read it as an abbreviation of its own options)")
     ap.add_argument("--stencil", type=int, default=7, choices=[7, 27])
     ap.add_argument("--fused", type=int, default=1, help="1 (default): fused SpMV+dot and AXPY+AXPY+PCJACOBI+norm+dot kernels -- same arithmetic and order per element, fewer HBM passes; 0: one kernel per reference Vec/Mat call (cg.c:249-344)")
+    ap.add_argument("--pipeline", type=int, default=1, help="1 (default): launch-ahead fused CG (iteration i+1 enqueued before the host has seen iteration i's sums; device-resident scalars); 0: host waits between kernels")
     ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (include/hipx.h hipxMatSetSpMVVariant): 0 auto, 1 32-bit-column stream kernel, 22/23 packed 16-bit columns, 24/25 packed columns + 8-bit value dictionary")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -148,6 +149,7 @@ def main():
     ksp.rtol, ksp.abstol, ksp.divtol = 1e-50, 1e-300, 1e300
     ksp.max_it = args.warmup + args.steps + 10
     ksp.fused = args.fused
+    ksp.pipeline = args.pipeline
     _lib.chk(ks.HipxKSPCGBegin(C.byref(ksp), C.byref(M), C.byref(pc), B.ptr, X.ptr))
     _lib.chk(ks.HipxKSPCGStep(C.byref(ksp), C.byref(M), C.byref(pc), B.ptr, X.ptr, args.warmup))
     assert ksp.reason == 0 and ksp.its == args.warmup, (ksp.reason, ksp.its)
@@ -202,7 +204,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "3-D %d-pt Poisson %d^3 (N=%d rows, nnz=%d local), KSPCG + PCJACOBI, b = A*1, x0 = 0; rows split over %d rank(s)"
                                    % (args.stencil, n, N, nnz_local, world),
-                       "global_rows": N, "parallelism": "rows%d" % world, "fused": args.fused, "spmv_variant": args.variant,
+                       "global_rows": N, "parallelism": "rows%d" % world, "fused": args.fused, "pipeline": args.pipeline, "spmv_variant": args.variant,
                        "residual_norm_after": rnorm},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": cnt.value, "avg_launch_ms": spmv_ms, "algorithmic_bytes": spmv_bytes,

@@ -116,6 +116,13 @@ int hipxCGFusedUpdate(double *x, double *r, double *z, const double *p, const do
 /* x == NULL in hipxCGFusedUpdate: the x update is deferred; it is then done by
    p = z + b p ; x += a p_old  (cg.c:249 of the next iteration + cg.c:305 of this one: p is read once) */
 int hipxCGAypxAxpy(double *p, double b, const double *z, double *x, double a, hipx_int n);
+/* Launch-ahead forms: the scalars are read from device memory (results of kernels queued earlier on the compute stream), so
+   the next iteration can be enqueued before the host has seen them.  b = *dev_beta_new / *dev_beta_old (cg.c:248),
+   a = *dev_beta / *dev_dpi (cg.c:288): the same IEEE quotients the host forms.  hipxRedEnd(slot, ...) collects the sums;
+   dev_dot / dev_sums2 receive device copies of them. */
+int hipxCGAypxAxpyDev(double *p, const double *z, double *x, const double *dev_beta_new, const double *dev_beta_old, const double *dev_dpi, hipx_int n);
+int hipxCGFusedUpdateBegin(double *x, double *r, double *z, const double *p, const double *w, const double *d, const double *dev_beta, const double *dev_dpi, hipx_int n, int slot,
+                           double *dev_sums2);
 
 /* ---- Mat (CSR = Mat_SeqAIJ src/mat/impls/aij/seq/aij.h:47-78,150-168) ----------------------- */
 typedef struct hipxMat_s *hipxMat;
@@ -145,6 +152,7 @@ int hipxMatSetSpMVVariant(hipxMat A, int variant);
 int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len);
 /* y = A x and *dot = x.y fused in the SpMV epilogue (cg.c:257-258) */
 int hipxMatMultDot(hipxMat A, const double *x, double *y, double *dot);
+int hipxMatMultDotBegin(hipxMat A, const double *x, double *y, int slot, double *dev_dot); /* enqueue only; hipxRedEnd(slot, 1, &dot) waits */
 
 /* ---- PC ------------------------------------------------------------------------------------------ */
 /* PCSetUp_Jacobi jacobi.c:205-266 (DIAGONAL, fixdiag): d = 1/diag(A), zeros -> 1 */

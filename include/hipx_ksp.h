@@ -66,6 +66,8 @@ typedef struct {
   double   a_pending;
   int      defer_flush;      /* 1: HipxKSPCGStep may return with the x update pending; the caller ends with HipxKSPCGFlush */
   int      external_test;    /* 1: the caller runs its own convergence test after every step (the PETSc plugin: ksp->converged) */
+  int      pipeline;         /* fused CG on one rank: enqueue iteration i+1 before the host has seen the sums of iteration i (default 1) */
+  double  *dscal;            /* device scalars of the launch-ahead path: [0] p.w, [2+2q] z.z, [3+2q] z.r of the iterations of parity q */
 } HipxKSP;
 
 void HipxKSPSetDefaults(HipxKSP *ksp);

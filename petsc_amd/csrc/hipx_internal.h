@@ -47,12 +47,14 @@ struct RedOut {
   double             *results;
   unsigned long long *flag;
   unsigned long long  seq;  // 0: do not signal (a later stage on the stream -- all-reduce + hipx::red_signal -- will)
+  double             *dres; // optional device-memory copy of the results, for kernels queued behind this one (launch-ahead CG)
 };
-inline RedOut red_out(int slot, bool signal = true)
+inline RedOut red_out(int slot, bool signal = true, double *dres = nullptr)
 {
   Runtime &r = rt();
-  return RedOut{slot_partials(slot), r.d_tickets + slot, slot_results_dev(slot), r.d_flags + slot, signal ? ++r.seq[slot] : 0ull};
+  return RedOut{slot_partials(slot), r.d_tickets + slot, slot_results_dev(slot), r.d_flags + slot, signal ? ++r.seq[slot] : 0ull, dres};
 }
+int launch_sum(const double *x, hipx_int n, int slot, double *dres);  // fold of per-wave partials: results -> host slot (+ device copy)
 // multi-GPU reductions without a host round trip between the local kernel and the all-reduce (hipx_comm.hip)
 // The local kernel leaves its sums in device memory (dev_results), RCCL reduces them there, and red_signal() copies the
 // reduced words into the slot's host-mapped result area before raising the sequence flag.

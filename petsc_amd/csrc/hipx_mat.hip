@@ -74,6 +74,7 @@ struct hipxMat_s {
   bool      diag_dense = true;
   // fused SpMV+dot partials
   double   *d_dotpart = nullptr;
+  hipx_int  dotpart_cap = 0;
 };
 
 extern "C" void hipxSorStateFree_(void *p);
@@ -1331,13 +1332,26 @@ int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, d
   return A->compressed ? launch_spmv_c<IT, MODE, true, DOT>(A, x, yin, yout, dotpart) : launch_spmv_c<IT, MODE, false, DOT>(A, x, yin, yout, dotpart);
 }
 
-int dot_partials_count(hipxMat A)
+// number of per-wave dot partials the next fused launch writes (every one of them is written by every launch of that
+// kernel form, so the fold reads exactly these and no clearing pass is needed)
+int dot_partials_count(hipxMat A, hipx_int *npart)
 {
-  int  cfg;
-  bool nt;
-  decode_variant(A->variant, cfg, nt);
-  const int waves = (A->tile_mode ? 256 : kCfg[cfg].threads) / 64;
-  return (int)(((A->nblocks[A->tile_mode ? 0 : cfg] + 7) / 8) * 8) * waves;
+  int cfg, waves;
+  if (A->tile_mode >= 2 && !A->compressed && (!A->probe || A->vd_mode)) {
+    bool vd, rowpar;
+    int  rpt;
+    int  ierr = select_pk(A, vd, rowpar, rpt, cfg);
+    if (ierr) return ierr;
+    waves = 4;
+  } else {
+    bool nt;
+    decode_variant(A->variant, cfg, nt);
+    int ierr = ensure_row_blocks(A, cfg);
+    if (ierr) return ierr;
+    waves = kCfg[cfg].threads / 64;
+  }
+  *npart = (hipx_int)(((A->nblocks[cfg] + 7) / 8) * 8) * waves;
+  return HIPX_SUCCESS;
 }
 
 template <int MODE, bool DOT>
@@ -1492,7 +1506,8 @@ int hipxMatSetSpMVVariant(hipxMat A, int variant)
   if (A->d_dotpart && variant != A->variant) {
     HIPX_HIP(hipStreamSynchronize(rt().compute));
     (void)hipFree(A->d_dotpart);
-    A->d_dotpart = nullptr;
+    A->d_dotpart   = nullptr;
+    A->dotpart_cap = 0;
   }
   A->variant = variant;
   return HIPX_SUCCESS;
@@ -1536,25 +1551,43 @@ int hipxMatMultAdd(hipxMat A, const double *x, const double *y, double *z)
   return launch_spmv<1, false>(A, x, A->compressed ? z : y, z, nullptr);
 }
 
+static int matmultdot_launch(hipxMat A, const double *x, double *y, hipx_int *npart_out)
+{
+  hipx_int npart = 0;
+  int      ierr0 = dot_partials_count(A, &npart);
+  if (ierr0) return ierr0;
+  *npart_out = npart;
+  if (!npart) return HIPX_SUCCESS;
+  if (npart > A->dotpart_cap) {
+    HIPX_HIP(hipStreamSynchronize(rt().compute));
+    (void)hipFree(A->d_dotpart);
+    HIPX_HIP(hipMalloc((void **)&A->d_dotpart, sizeof(double) * (size_t)npart));
+    A->dotpart_cap = npart;
+  }
+  *npart_out = npart;
+  return launch_spmv<0, true>(A, x, nullptr, y, A->d_dotpart);
+}
+
 int hipxMatMultDot(hipxMat A, const double *x, double *y, double *dot)
 {
   HIPX_CHECK_INIT();
   HIPX_ARG(A && !A->compressed && A->m == A->n, "MatMultDot needs a square, uncompressed matrix");
   *dot = 0.0;
-  {
-    int  cfg;
-    bool nt;
-    decode_variant(A->variant, cfg, nt);
-    int ierr0 = ensure_row_blocks(A, cfg);
-    if (ierr0) return ierr0;
-  }
-  const hipx_int npart = dot_partials_count(A);
-  if (!npart) return HIPX_SUCCESS;
-  if (!A->d_dotpart) HIPX_HIP(hipMalloc((void **)&A->d_dotpart, sizeof(double) * (size_t)npart));
-  HIPX_HIP(hipMemsetAsync(A->d_dotpart, 0, sizeof(double) * (size_t)npart, rt().compute));  // grids differ per kernel form: unwritten partials must be 0
-  int ierr = launch_spmv<0, true>(A, x, nullptr, y, A->d_dotpart);
-  if (ierr) return ierr;
+  hipx_int npart = 0;
+  int      ierr  = matmultdot_launch(A, x, y, &npart);
+  if (ierr || !npart) return ierr;
   return hipxVecSum(A->d_dotpart, npart, dot);
+}
+
+int hipxMatMultDotBegin(hipxMat A, const double *x, double *y, int slot, double *dev_dot)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A && !A->compressed && A->m == A->n && A->m > 0, "MatMultDotBegin needs a square, non-empty, uncompressed matrix");
+  HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2, "reduction slot out of range");
+  hipx_int npart = 0;
+  int      ierr  = matmultdot_launch(A, x, y, &npart);
+  if (ierr) return ierr;
+  return launch_sum(A->d_dotpart, npart, slot, dev_dot);
 }
 
 int hipxMatGetDiagonal(hipxMat A, double *d)

@@ -83,6 +83,7 @@ __device__ __forceinline__ void block_finish(double (&acc)[NV], RedOut out)
       else r = (s_w[v][w] > r || s_w[v][w] != s_w[v][w]) ? s_w[v][w] : r;
     }
     results[v] = r;  // pinned, fine-grained host memory
+    if (out.dres) out.dres[v] = r;
   }
   __syncthreads();
   if (threadIdx.x == 0) {

@@ -185,8 +185,13 @@ struct FAbc3 { static constexpr bool reads_w = true; double a, b, c; __device__ 
 
 // CG: p = z + b p (cg.c:249, general-beta loop dvec2.c:774) and the x += a p_old (cg.c:305) left over from the previous
 // iteration in one pass: p is read once.  Same arithmetic per element as the two separate kernels.
-__global__ __launch_bounds__(kEwThreads) void cg_aypx_axpy_kernel(double *p, double *x, const double *z, double b, double a, hipx_int n, bool vec)
+template <bool DEVS>
+__global__ __launch_bounds__(kEwThreads) void cg_aypx_axpy_kernel(double *p, double *x, const double *z, double b_arg, double a_arg, const double *dev_beta_new,
+                                                                   const double *dev_beta_old, const double *dev_dpi, hipx_int n, bool vec)
 {
+  // DEVS: b = beta_new / beta_old (cg.c:248) and a = beta_old / dpi (cg.c:288) from device-resident results
+  const double b = DEVS ? (*dev_beta_new / *dev_beta_old) : b_arg;
+  const double a = DEVS ? (*dev_beta_old / *dev_dpi) : a_arg;
   const hipx_int base = (hipx_int)blockIdx.x * (kEwThreads * EW_UNROLL) + threadIdx.x;
   if (vec) {
     const hipx_int n2 = n >> 1;
@@ -454,10 +459,13 @@ __global__ __launch_bounds__(kRedThreads) void dotnorm2_kernel(const double *x, 
 
 // fused CG update (cg.c:305-309,344 with PCJACOBI): x += a p; r -= a w; z = r*d; sums z.z, z.r
 // UPX = false: the x update is left to cg_aypx_axpy_kernel of the next iteration (p is then read once per iteration)
-template <bool UPX>
-__global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n,
-                                                                bool vec, RedOut out)
+// DEVS = true: a = *dev_beta / *dev_dpi is formed on the device from the results of kernels queued before this one (the host
+// forms the same IEEE quotient for its own bookkeeping), so the launch does not have to wait for the host to see them.
+template <bool UPX, bool DEVS>
+__global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a_arg,
+                                                                const double *dev_beta, const double *dev_dpi, hipx_int n, bool vec, RedOut out)
 {
+  const double a = DEVS ? (*dev_beta / *dev_dpi) : a_arg;
   double         acc[2] = {0.0, 0.0};
   const hipx_int T      = (hipx_int)gridDim.x * kRedThreads;
   const hipx_int tid    = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x;
@@ -676,8 +684,15 @@ int hipx::red_signal(int slot, const double *dev_results, int nvals)
 static int launch_cg_fused(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n, int slot)
 {
   bool vec = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(p) && aligned16(w) && aligned16(d) && n >= 2;
-  if (x) cg_fused_kernel<true><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, a, n, vec, red_out_g(slot));
-  else cg_fused_kernel<false><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, a, n, vec, red_out_g(slot));
+  if (x) cg_fused_kernel<true, false><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, a, nullptr, nullptr, n, vec, red_out_g(slot));
+  else cg_fused_kernel<false, false><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, a, nullptr, nullptr, n, vec, red_out_g(slot));
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+int hipx::launch_sum(const double *x, hipx_int n, int slot, double *dres)
+{
+  sum_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, red_out(slot, true, dres));
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -1029,7 +1044,29 @@ int hipxCGAypxAxpy(double *p, double b, const double *z, double *x, double a, hi
     return hipxVecAYPX(p, b, z, n);
   }
   bool vec = aligned16(p) && aligned16(x) && aligned16(z) && n >= 2;
-  cg_aypx_axpy_kernel<<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, z, b, a, n, vec);
+  cg_aypx_axpy_kernel<false><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, z, b, a, nullptr, nullptr, nullptr, n, vec);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+int hipxCGAypxAxpyDev(double *p, const double *z, double *x, const double *dev_beta_new, const double *dev_beta_old, const double *dev_dpi, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  if (n <= 0) return HIPX_SUCCESS;
+  bool vec = aligned16(p) && aligned16(x) && aligned16(z) && n >= 2;
+  cg_aypx_axpy_kernel<true><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, z, 0.0, 0.0, dev_beta_new, dev_beta_old, dev_dpi, n, vec);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+int hipxCGFusedUpdateBegin(double *x, double *r, double *z, const double *p, const double *w, const double *d, const double *dev_beta, const double *dev_dpi, hipx_int n, int slot,
+                           double *dev_sums2)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2 && n > 0 && dev_beta && dev_dpi, "bad slot / empty vector / null scalars");
+  bool vec = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(p) && aligned16(w) && aligned16(d) && n >= 2;
+  if (x) cg_fused_kernel<true, true><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, red_out(slot, true, dev_sums2));
+  else cg_fused_kernel<false, true><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, red_out(slot, true, dev_sums2));
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }

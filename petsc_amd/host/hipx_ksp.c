@@ -37,6 +37,7 @@ void HipxKSPSetDefaults(HipxKSP *ksp)
   ksp->abstol           = 1e-50;
   ksp->divtol           = 1e4;
   ksp->max_it           = 10000;
+  ksp->pipeline         = 1;
   ksp->gmres_restart    = 30;
   ksp->gmres_haptol     = 1e-30;
   ksp->gmres_cgs_refine = 0;
@@ -174,6 +175,7 @@ static int ensure_cg_work(HipxKSP *ksp, hipx_int n)
   CHK(hipxMalloc((void **)&ksp->R, bytes));
   CHK(hipxMalloc((void **)&ksp->Z, bytes));
   CHK(hipxMalloc((void **)&ksp->P, bytes));
+  CHK(hipxMalloc((void **)&ksp->dscal, sizeof(double) * 8));
   ksp->work_n = n;
   return 0;
 }
@@ -183,6 +185,8 @@ int HipxKSPDestroyWork(HipxKSP *ksp)
   if (ksp->R) CHK(hipxFree(ksp->R));
   if (ksp->Z) CHK(hipxFree(ksp->Z));
   if (ksp->P) CHK(hipxFree(ksp->P));
+  if (ksp->dscal) CHK(hipxFree(ksp->dscal));
+  ksp->dscal = NULL;
   ksp->R = ksp->Z = ksp->P = NULL;
   ksp->work_n = 0;
   return 0;
@@ -243,6 +247,95 @@ int HipxKSPCGBegin(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double
   return 0;
 }
 
+/* Launch-ahead form of the fused loop (one rank, PCJACOBI, preconditioned norm).  Per iteration i the device runs
+     A(i): p = z + b p ; x += a_{i-1} p_{i-1}        (cg.c:249 + deferred cg.c:305)
+     B(i): w = A p ; p.w                             (cg.c:257-258)
+     C(i): r -= a w ; z = r .* d ; z.z ; z.r         (cg.c:306-309,344)
+   with b and a formed ON THE DEVICE from the sums of the kernels queued before (same IEEE quotients as the host's).  The host
+   enqueues C(i) right behind B(i), waits for p.w only to run the reference's breakdown checks (cg.c:262-268), then enqueues
+   A(i+1), B(i+1), C(i+1) while C(i) is still running, and only then waits for the sums of C(i) to log the norm and test
+   convergence (cg.c:326-328).  What has been enqueued ahead when the loop stops is harmless: A(i+1) applies exactly the x
+   update of iteration i that was due anyway, B and C only touch work vectors (x is never written by C).  The arithmetic and
+   its order are those of the plain loop: histories and x are bit-identical to pipeline = 0. */
+static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double *X, hipx_int nsteps)
+{
+  const hipx_int n = A->m;
+  double        *R = ksp->R, *Z = ksp->Z, *P = ksp->P, *W = ksp->Z;
+  double        *ds = ksp->dscal;
+  int            ahead = 0; /* A(i), B(i), C(i) of the current iteration already enqueued */
+  enum { SLOT_DOT = 1, SLOT_SUMS = 2 };
+  for (hipx_int s = 0; s < nsteps && !ksp->reason && ksp->i < ksp->max_it; s++) {
+    const hipx_int i  = ksp->i;
+    const int      q  = (int)(i & 1);
+    double        *dbeta_i = ds + 3 + 2 * (1 - q); /* z.r of iteration i-1 */
+    double         sums[2], dp, dpiold;
+    ksp->its = i + 1;
+    if (ksp->beta == 0.0) { /* cg.c:223 */
+      ksp->reason = KSP_CONVERGED_ATOL;
+      break;
+    } else if ((i > 0) && (ksp->beta * ksp->betaold < 0.0)) { /* cg.c:228 */
+      ksp->reason = KSP_DIVERGED_INDEFINITE_PC;
+      break;
+    }
+    if (!ahead) {
+      CHK(hipxMemcpyHtoD(dbeta_i, &ksp->beta, sizeof(double)));
+      if (!i) CHK(hipxVecCopy(Z, P, n)); /* cg.c:236 */
+      else {
+        const double b = ksp->beta / ksp->betaold;
+        if (ksp->x_pending) {
+          CHK(hipxCGAypxAxpy(P, b, Z, X, ksp->a_pending, n));
+          ksp->x_pending = 0;
+        } else CHK(hipxVecAYPX(P, b, Z, n)); /* cg.c:249 */
+      }
+      CHK(hipxMatMultDotBegin(A->A, P, W, SLOT_DOT, ds));
+      CHK(hipxCGFusedUpdateBegin(NULL, R, Z, P, W, pc->dinv, dbeta_i, ds, n, SLOT_SUMS + q, ds + 2 + 2 * q));
+    }
+    ahead  = 0;
+    dpiold = ksp->dpi;
+    CHK(hipxRedEnd(SLOT_DOT, 1, &ksp->dpi));
+    ksp->betaold = ksp->beta;
+    if (isnan(ksp->dpi) || isinf(ksp->dpi)) { /* KSPCheckDot */
+      ksp->reason = KSP_DIVERGED_NANORINF;
+      break;
+    }
+    if ((ksp->dpi == 0.0) || ((i > 0) && ((((ksp->dpi > 0) - (ksp->dpi < 0)) * ((dpiold > 0) - (dpiold < 0))) < 0.0))) { /* cg.c:262 */
+      ksp->reason = KSP_DIVERGED_INDEFINITE_MAT;
+      break;
+    }
+    ksp->a         = ksp->beta / ksp->dpi; /* cg.c:288 */
+    ksp->x_pending = 1;                    /* C(i) leaves x += a p to A(i+1) or to the flush */
+    ksp->a_pending = ksp->a;
+    if (s + 1 < nsteps && i + 1 < ksp->max_it) { /* enqueue iteration i+1 while C(i) runs */
+      double *dbeta_n = ds + 3 + 2 * q; /* z.r of iteration i, written by C(i) */
+      CHK(hipxCGAypxAxpyDev(P, Z, X, dbeta_n, dbeta_i, ds, n));
+      CHK(hipxMatMultDotBegin(A->A, P, W, SLOT_DOT, ds));
+      CHK(hipxCGFusedUpdateBegin(NULL, R, Z, P, W, pc->dinv, dbeta_n, ds, n, SLOT_SUMS + (1 - q), ds + 2 + 2 * (1 - q)));
+      ahead          = 1;
+      ksp->x_pending = 0; /* A(i+1) applies it */
+    }
+    CHK(hipxRedEnd(SLOT_SUMS + q, 2, sums));
+    dp = sqrt(sums[0]);
+    if (isnan(dp) || isinf(dp)) {
+      ksp->reason = KSP_DIVERGED_NANORINF;
+      break;
+    }
+    ksp->rnorm = dp;
+    log_history(ksp, dp);
+    CHK(converged_default(ksp, A, pc, i + 1, dp, B, &ksp->reason));
+    if (ksp->reason) break;
+    ksp->beta = sums[1];
+    if (isnan(ksp->beta) || isinf(ksp->beta)) {
+      ksp->reason = KSP_DIVERGED_NANORINF;
+      break;
+    }
+    ksp->i++;
+  }
+  if (ahead) CHK(hipxStreamSynchronize()); /* stopped with iteration i+1 in flight: x is complete once A(i+1) has run */
+  if (!ksp->defer_flush) CHK(HipxKSPCGFlush(ksp, A, X));
+  if (!ksp->reason && ksp->i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS; /* cg.c:350 */
+  return 0;
+}
+
 /* nsteps passes of the loop body cg.c:220-349 (stops early when ksp->reason is set) */
 int HipxKSPCGStep(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double *X, hipx_int nsteps)
 {
@@ -253,6 +346,7 @@ int HipxKSPCGStep(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double 
      SpMV + dot fusion: only without an off-diagonal block (the dot needs the complete w) */
   const int      fused_upd = ksp->fused && pc->type == HIPX_PC_JACOBI && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED;
   const int      fused     = fused_upd && !A->B && A->nranks <= 1;
+  if (fused && ksp->pipeline && n > 0) return cg_step_pipelined(ksp, A, pc, B, X, nsteps);
   for (hipx_int s = 0; s < nsteps && !ksp->reason && ksp->i < ksp->max_it; s++) {
     const hipx_int i = ksp->i;
     ksp->its = i + 1;

@@ -110,17 +110,19 @@ def test_cg_fused_stepping_deferred_x_update(hx):
     _lib.chk(ks.HipxPCSetUp(C.byref(p), C.byref(M)))
     B = _lib.DVec(N, b)
 
-    def run(chunks, fused, rtol=1e-9, max_it=10000):
+    def run(chunks, fused, rtol=1e-9, max_it=10000, pipeline=1):
         k = _lib.HipxKSP()
         ks.HipxKSPSetDefaults(C.byref(k))
-        k.rtol, k.max_it, k.fused = rtol, max_it, fused
+        k.rtol, k.max_it, k.fused, k.pipeline = rtol, max_it, fused, pipeline
+        hist = np.zeros(4096)
+        k.history, k.hist_len = hist.ctypes.data, len(hist)
         X = _lib.DVec(N, np.zeros(N))
         _lib.chk(ks.HipxKSPCGBegin(C.byref(k), C.byref(M), C.byref(p), B.ptr, X.ptr))
         xs = []
         for c in chunks:
             _lib.chk(ks.HipxKSPCGStep(C.byref(k), C.byref(M), C.byref(p), B.ptr, X.ptr, c))
             xs.append(X.get())
-        out = (xs, int(k.its), int(k.reason))
+        out = (xs, int(k.its), int(k.reason), hist[:k.hist_n].copy())
         ks.HipxKSPDestroyWork(C.byref(k))
         X.free()
         return out
@@ -128,14 +130,19 @@ def test_cg_fused_stepping_deferred_x_update(hx):
     one = run([10000], 1)
     assert one[2] == 2 and one[1] > 20
     parts = run([1, 2, 1, 7, 10000], 1)
-    assert parts[1:] == one[1:] and np.array_equal(parts[0][-1], one[0][-1])
+    assert parts[1:3] == one[1:3] and np.array_equal(parts[0][-1], one[0][-1]) and np.array_equal(parts[3], one[3])
+    # launch-ahead (iteration i+1 enqueued before the host has seen the sums of iteration i) vs the plain fused loop:
+    # same kernels' arithmetic, scalars formed on the device -> bit-identical history and x, also when the solve converges
+    # with an iteration in flight
+    plain = run([10000], 1, pipeline=0)
+    assert plain[1:3] == one[1:3] and np.array_equal(plain[3], one[3]) and np.array_equal(plain[0][-1], one[0][-1])
     unf = run([1, 2, 1, 7, 10000], 0)
-    assert unf[1:] == one[1:]
+    assert unf[1:3] == one[1:3]
     for xa, xb in zip(parts[0], unf[0]):  # also after 1, 3, 4, 11 iterations: x is complete at every return
         assert np.abs(xa - xb).max() <= 1e-12 * np.abs(xb).max()
     lim = run([10000], 1, rtol=1e-30, max_it=9)
     liu = run([10000], 0, rtol=1e-30, max_it=9)
-    assert lim[2] == -3 and lim[1:] == liu[1:] and np.abs(lim[0][-1] - liu[0][-1]).max() <= 1e-12 * np.abs(liu[0][-1]).max()
+    assert lim[2] == -3 and lim[1:3] == liu[1:3] and np.abs(lim[0][-1] - liu[0][-1]).max() <= 1e-12 * np.abs(liu[0][-1]).max()
     ks.HipxPCDestroy(C.byref(p))
     B.free()
     _lib.mat_destroy(A)
