@@ -70,6 +70,8 @@ typedef struct {
   double  *dscal;            /* device scalars of the launch-ahead path: [0] p.w, [2+2q] z.z, [3+2q] z.r of the iterations of parity q */
 } HipxKSP;
 
+/* sizeof of the three descriptor structs, so that a foreign-language mirror (petsc_amd/_lib.py) can verify its layout */
+int  HipxStructSizes(int *mat, int *pc, int *ksp);
 void HipxKSPSetDefaults(HipxKSP *ksp);
 void HipxPCSetDefaults(HipxPC *pc);
 int  HipxKSPDestroyWork(HipxKSP *ksp);

@@ -116,6 +116,11 @@ def load():
     d = declared_functions()
     _bind(hx, d["hipx"])
     _bind(ks, d["ksp"])
+    sm, sp, sk = C.c_int(), C.c_int(), C.c_int()
+    ks.HipxStructSizes(C.byref(sm), C.byref(sp), C.byref(sk))
+    got = (C.sizeof(HipxMat), C.sizeof(HipxPC), C.sizeof(HipxKSP))
+    if got != (sm.value, sp.value, sk.value):
+        raise HipxError("ctypes mirrors of HipxMat/HipxPC/HipxKSP are out of date: %s vs C %s (include/hipx_ksp.h)" % (got, (sm.value, sp.value, sk.value)))
     _libs["hipx"], _libs["ksp"] = hx, ks
     return hx, ks
 

@@ -29,6 +29,14 @@ enum {
   KSP_DIVERGED_PC_FAILED         = -11
 };
 
+int HipxStructSizes(int *mat, int *pc, int *ksp)
+{
+  *mat = (int)sizeof(HipxMat);
+  *pc  = (int)sizeof(HipxPC);
+  *ksp = (int)sizeof(HipxKSP);
+  return 0;
+}
+
 void HipxKSPSetDefaults(HipxKSP *ksp)
 {
   memset(ksp, 0, sizeof(*ksp));
