@@ -121,8 +121,8 @@ int hipxCGAypxAxpy(double *p, double b, const double *z, double *x, double a, hi
    a = *dev_beta / *dev_dpi (cg.c:288): the same IEEE quotients the host forms.  hipxRedEnd(slot, ...) collects the sums;
    dev_dot / dev_sums2 receive device copies of them. */
 int hipxCGAypxAxpyDev(double *p, const double *z, double *x, const double *dev_beta_new, const double *dev_beta_old, const double *dev_dpi, hipx_int n);
-int hipxCGFusedUpdateBegin(double *x, double *r, double *z, const double *p, const double *w, const double *d, const double *dev_beta, const double *dev_dpi, hipx_int n, int slot,
-                           double *dev_sums2);
+int hipxCGFusedUpdateBegin(double *x, double *r, double *z, const double *p, const double *w, const double *d, double dconst, const double *dev_beta, const double *dev_dpi,
+                           hipx_int n, int slot, double *dev_sums2); /* d == NULL: z = r * dconst (constant Jacobi diagonal), one vector pass less */
 
 /* ---- Mat (CSR = Mat_SeqAIJ src/mat/impls/aij/seq/aij.h:47-78,150-168) ----------------------- */
 typedef struct hipxMat_s *hipxMat;

@@ -39,6 +39,8 @@ typedef struct {
   int      sor_flag; /* MatSORType, default SOR_LOCAL_SYMMETRIC_SWEEP (sor.c:442-446) */
   double   sor_omega, sor_shift;
   hipx_int sor_its, sor_lits;
+  int      dconst_valid; /* PCJACOBI: every entry of dinv is the same double (constant-coefficient operator) ... */
+  double   dconst;       /* ... namely this one: the fused update multiplies by it instead of streaming dinv */
 } HipxPC;
 
 typedef struct {

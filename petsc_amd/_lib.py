@@ -22,7 +22,7 @@ class HipxMat(C.Structure):
 
 class HipxPC(C.Structure):
     _fields_ = [("type", C.c_int), ("dinv", C.c_void_p), ("sor_flag", C.c_int), ("sor_omega", C.c_double), ("sor_shift", C.c_double),
-                ("sor_its", C.c_int32), ("sor_lits", C.c_int32)]
+                ("sor_its", C.c_int32), ("sor_lits", C.c_int32), ("dconst_valid", C.c_int), ("dconst", C.c_double)]
 
 
 class HipxKSP(C.Structure):

@@ -461,9 +461,11 @@ __global__ __launch_bounds__(kRedThreads) void dotnorm2_kernel(const double *x, 
 // UPX = false: the x update is left to cg_aypx_axpy_kernel of the next iteration (p is then read once per iteration)
 // DEVS = true: a = *dev_beta / *dev_dpi is formed on the device from the results of kernels queued before this one (the host
 // forms the same IEEE quotient for its own bookkeeping), so the launch does not have to wait for the host to see them.
-template <bool UPX, bool DEVS>
+// CONSTD = true: the Jacobi diagonal is one constant (constant-coefficient operators): z = r * dconst without reading d[] --
+// the same product, one vector pass less.
+template <bool UPX, bool DEVS, bool CONSTD = false>
 __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a_arg,
-                                                                const double *dev_beta, const double *dev_dpi, hipx_int n, bool vec, RedOut out)
+                                                                const double *dev_beta, const double *dev_dpi, hipx_int n, bool vec, RedOut out, double dconst = 0.0)
 {
   const double a = DEVS ? (*dev_beta / *dev_dpi) : a_arg;
   double         acc[2] = {0.0, 0.0};
@@ -501,18 +503,19 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
     for (; q + kRedThreads < c1; q += 2 * kRedThreads) {
       const hipx_int q1 = q + kRedThreads;
       const double2  z0 = {0.0, 0.0};
-      const double2  xa = UPX ? x2[q] : z0, ra = r2[q], pa = UPX ? p2[q] : z0, wa = w2[q], da = d2[q];
-      const double2  xb = UPX ? x2[q1] : z0, rb = r2[q1], pb = UPX ? p2[q1] : z0, wb = w2[q1], db = d2[q1];
+      const double2  dc = {dconst, dconst};
+      const double2  xa = UPX ? x2[q] : z0, ra = r2[q], pa = UPX ? p2[q] : z0, wa = w2[q], da = CONSTD ? dc : d2[q];
+      const double2  xb = UPX ? x2[q1] : z0, rb = r2[q1], pb = UPX ? p2[q1] : z0, wb = w2[q1], db = CONSTD ? dc : d2[q1];
       step(q, xa, ra, pa, wa, da);
       step(q1, xb, rb, pb, wb, db);
     }
     if (q < c1) {
-      const double2 z0 = {0.0, 0.0};
-      step(q, UPX ? x2[q] : z0, r2[q], UPX ? p2[q] : z0, w2[q], d2[q]);
+      const double2 z0 = {0.0, 0.0}, dc = {dconst, dconst};
+      step(q, UPX ? x2[q] : z0, r2[q], UPX ? p2[q] : z0, w2[q], CONSTD ? dc : d2[q]);
     }
     if ((n & 1) && tid == 0) {
       hipx_int i  = n - 1;
-      double   rv = r[i] + ma * w[i], zv = rv * d[i];
+      double   rv = r[i] + ma * w[i], zv = rv * (CONSTD ? dconst : d[i]);
       if (UPX) x[i] = x[i] + a * p[i];
       r[i] = rv;
       z[i] = zv;
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
     }
   } else {
     for (hipx_int i = tid; i < n; i += T) {
-      double rv = r[i] + ma * w[i], zv = rv * d[i];
+      double rv = r[i] + ma * w[i], zv = rv * (CONSTD ? dconst : d[i]);
       if (UPX) x[i] = x[i] + a * p[i];
       r[i] = rv;
       z[i] = zv;
@@ -1059,14 +1062,22 @@ int hipxCGAypxAxpyDev(double *p, const double *z, double *x, const double *dev_b
   return HIPX_SUCCESS;
 }
 
-int hipxCGFusedUpdateBegin(double *x, double *r, double *z, const double *p, const double *w, const double *d, const double *dev_beta, const double *dev_dpi, hipx_int n, int slot,
-                           double *dev_sums2)
+int hipxCGFusedUpdateBegin(double *x, double *r, double *z, const double *p, const double *w, const double *d, double dconst, const double *dev_beta, const double *dev_dpi,
+                           hipx_int n, int slot, double *dev_sums2)
 {
   HIPX_CHECK_INIT();
   HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2 && n > 0 && dev_beta && dev_dpi, "bad slot / empty vector / null scalars");
   bool vec = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(p) && aligned16(w) && aligned16(d) && n >= 2;
-  if (x) cg_fused_kernel<true, true><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, red_out(slot, true, dev_sums2));
-  else cg_fused_kernel<false, true><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, red_out(slot, true, dev_sums2));
+  const unsigned g = red_grid(n);
+  RedOut         o = red_out(slot, true, dev_sums2);
+  hipStream_t    st = rt().compute;
+  if (d) {
+    if (x) cg_fused_kernel<true, true, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o);
+    else cg_fused_kernel<false, true, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o);
+  } else {  // d == NULL: constant Jacobi diagonal
+    if (x) cg_fused_kernel<true, true, true><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o, dconst);
+    else cg_fused_kernel<false, true, true><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o, dconst);
+  }
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }

@@ -99,6 +99,17 @@ int HipxPCSetUp(HipxPC *pc, HipxMat *A)
   if (pc->type == HIPX_PC_JACOBI) {
     if (!pc->dinv) CHK(hipxMalloc((void **)&pc->dinv, sizeof(double) * (size_t)(A->m ? A->m : 1)));
     CHK(hipxPCJacobiSetUp(A->A, pc->dinv)); /* MatGetDiagonal_MPIAIJ = diagonal of the diag block (mpiaij.c:1158-1167) */
+    pc->dconst_valid = 0;
+    if (A->m > 0) { /* constant-coefficient operators: min == max (same bits, not NaN) -> the fused update skips the dinv stream */
+      double   lo, hi;
+      hipx_int ilo, ihi;
+      CHK(hipxVecMin(pc->dinv, A->m, &ilo, &lo));
+      CHK(hipxVecMax(pc->dinv, A->m, &ihi, &hi));
+      if (lo == hi && memcmp(&lo, &hi, sizeof(double)) == 0) {
+        pc->dconst_valid = 1;
+        pc->dconst       = lo;
+      }
+    }
   }
   return 0;
 }
@@ -271,6 +282,7 @@ static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double 
   double        *R = ksp->R, *Z = ksp->Z, *P = ksp->P, *W = ksp->Z;
   double        *ds = ksp->dscal;
   int            ahead = 0; /* A(i), B(i), C(i) of the current iteration already enqueued */
+  const int      dcon  = pc->dconst_valid && !getenv("HIPX_NO_DCONST"); /* constant Jacobi diagonal: multiply by the scalar */
   enum { SLOT_DOT = 1, SLOT_SUMS = 2 };
   for (hipx_int s = 0; s < nsteps && !ksp->reason && ksp->i < ksp->max_it; s++) {
     const hipx_int i  = ksp->i;
@@ -296,7 +308,7 @@ static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double 
         } else CHK(hipxVecAYPX(P, b, Z, n)); /* cg.c:249 */
       }
       CHK(hipxMatMultDotBegin(A->A, P, W, SLOT_DOT, ds));
-      CHK(hipxCGFusedUpdateBegin(NULL, R, Z, P, W, pc->dinv, dbeta_i, ds, n, SLOT_SUMS + q, ds + 2 + 2 * q));
+      CHK(hipxCGFusedUpdateBegin(NULL, R, Z, P, W, dcon ? NULL : pc->dinv, pc->dconst, dbeta_i, ds, n, SLOT_SUMS + q, ds + 2 + 2 * q));
     }
     ahead  = 0;
     dpiold = ksp->dpi;
@@ -317,7 +329,7 @@ static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double 
       double *dbeta_n = ds + 3 + 2 * q; /* z.r of iteration i, written by C(i) */
       CHK(hipxCGAypxAxpyDev(P, Z, X, dbeta_n, dbeta_i, ds, n));
       CHK(hipxMatMultDotBegin(A->A, P, W, SLOT_DOT, ds));
-      CHK(hipxCGFusedUpdateBegin(NULL, R, Z, P, W, pc->dinv, dbeta_n, ds, n, SLOT_SUMS + (1 - q), ds + 2 + 2 * (1 - q)));
+      CHK(hipxCGFusedUpdateBegin(NULL, R, Z, P, W, dcon ? NULL : pc->dinv, pc->dconst, dbeta_n, ds, n, SLOT_SUMS + (1 - q), ds + 2 + 2 * (1 - q)));
       ahead          = 1;
       ksp->x_pending = 0; /* A(i+1) applies it */
     }

@@ -148,6 +148,27 @@ def test_cg_fused_stepping_deferred_x_update(hx):
     _lib.mat_destroy(A)
 
 
+def test_cg_pipelined_variable_and_constant_diagonal(hx):
+    """The launch-ahead loop multiplies by the Jacobi scalar when the inverse diagonal is one constant (the Poisson stencils)
+    and streams dinv otherwise: both must follow the oracle, and the scalar form must equal the streamed form bit for bit."""
+    import os
+    ai, aj, aa = orc.stencil("7pt", 18)
+    N = len(ai) - 1
+    sc = 1.0 + 0.1 * (np.arange(N) % 7)                       # S A S: SPD, non-constant diagonal
+    aav = aa * sc[np.repeat(np.arange(N), np.diff(ai))] * sc[aj]
+    for vals in (aa, aav):
+        b = orc.matmult(ai, aj, vals, np.ones(N))
+        o = orc.ksp_solve("cg", ai, aj, vals, b, rtol=1e-9)
+        g1 = solve_gpu("cg", ai, aj, vals, b, rtol=1e-9, fused=1)
+        compare(g1, o, 1e-10)
+        os.environ["HIPX_NO_DCONST"] = "1"
+        try:
+            g2 = solve_gpu("cg", ai, aj, vals, b, rtol=1e-9, fused=1)
+        finally:
+            del os.environ["HIPX_NO_DCONST"]
+        assert g1[1:3] == g2[1:3] and np.array_equal(g1[3], g2[3]) and np.array_equal(g1[0], g2[0])
+
+
 def test_cg_nonzero_guess_and_max_it(hx):
     ai, aj, aa = orc.stencil("7pt", 12)
     N = len(ai) - 1
