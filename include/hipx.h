@@ -120,9 +120,13 @@ int hipxCGAypxAxpy(double *p, double b, const double *z, double *x, double a, hi
    the next iteration can be enqueued before the host has seen them.  b = *dev_beta_new / *dev_beta_old (cg.c:248),
    a = *dev_beta / *dev_dpi (cg.c:288): the same IEEE quotients the host forms.  hipxRedEnd(slot, ...) collects the sums;
    dev_dot / dev_sums2 receive device copies of them. */
-int hipxCGAypxAxpyDev(double *p, const double *z, double *x, const double *dev_beta_new, const double *dev_beta_old, const double *dev_dpi, hipx_int n);
+int hipxCGAypxAxpyDev(double *p, const double *z, const double *r, double dconst, double *x, const double *dev_beta_new, const double *dev_beta_old, const double *dev_dpi,
+                      hipx_int n); /* z == NULL: z is re-formed as r * dconst (constant Jacobi diagonal, z never stored) */
+/* host-scalar form of the same: p = r * dconst + b p ; x += a p_old (x == NULL: no x update) */
+int hipxCGAypxAxpyR(double *p, double b, const double *r, double dconst, double *x, double a, hipx_int n);
 int hipxCGFusedUpdateBegin(double *x, double *r, double *z, const double *p, const double *w, const double *d, double dconst, const double *dev_beta, const double *dev_dpi,
-                           hipx_int n, int slot, double *dev_sums2); /* d == NULL: z = r * dconst (constant Jacobi diagonal), one vector pass less */
+                           hipx_int n, int slot, double *dev_sums2); /* d == NULL: z = r * dconst (constant Jacobi diagonal), one vector pass less;
+                                                                      then z == NULL as well: z is not stored (hipxCGAypxAxpyDev/R re-form it) */
 
 /* ---- Mat (CSR = Mat_SeqAIJ src/mat/impls/aij/seq/aij.h:47-78,150-168) ----------------------- */
 typedef struct hipxMat_s *hipxMat;

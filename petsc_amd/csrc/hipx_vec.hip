@@ -185,8 +185,10 @@ struct FAbc3 { static constexpr bool reads_w = true; double a, b, c; __device__ 
 
 // CG: p = z + b p (cg.c:249, general-beta loop dvec2.c:774) and the x += a p_old (cg.c:305) left over from the previous
 // iteration in one pass: p is read once.  Same arithmetic per element as the two separate kernels.
-template <bool DEVS>
-__global__ __launch_bounds__(kEwThreads) void cg_aypx_axpy_kernel(double *p, double *x, const double *z, double b_arg, double a_arg, const double *dev_beta_new,
+// ZR = true: z is not stored anywhere; it is re-formed as r * dconst (constant Jacobi diagonal: the product cg_fused_kernel
+// would have written), so the iteration has no z stream at all.  UPX = false: no pending x update (first pass after a flush).
+template <bool DEVS, bool ZR, bool UPX>
+__global__ __launch_bounds__(kEwThreads) void cg_aypx_axpy_kernel(double *p, double *x, const double *z, double dconst, double b_arg, double a_arg, const double *dev_beta_new,
                                                                    const double *dev_beta_old, const double *dev_dpi, hipx_int n, bool vec)
 {
   // DEVS: b = beta_new / beta_old (cg.c:248) and a = beta_old / dpi (cg.c:288) from device-resident results
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(kEwThreads) void cg_aypx_axpy_kernel(double *p, dou
       hipx_int q = base + k * kEwThreads;
       if (q < n2) {
         vp[k] = p2[q];
-        vx[k] = x2[q];
+        if (UPX) vx[k] = x2[q];
         vz[k] = z2[q];
       }
     }
@@ -211,24 +213,30 @@ __global__ __launch_bounds__(kEwThreads) void cg_aypx_axpy_kernel(double *p, dou
     for (int k = 0; k < EW_UNROLL; k++) {
       hipx_int q = base + k * kEwThreads;
       if (q < n2) {
-        vx[k].x = vx[k].x + a * vp[k].x;
-        vx[k].y = vx[k].y + a * vp[k].y;
+        if (ZR) {
+          vz[k].x = vz[k].x * dconst;
+          vz[k].y = vz[k].y * dconst;
+        }
+        if (UPX) {
+          vx[k].x = vx[k].x + a * vp[k].x;
+          vx[k].y = vx[k].y + a * vp[k].y;
+          x2[q]   = vx[k];
+        }
         vp[k].x = vz[k].x + b * vp[k].x;
         vp[k].y = vz[k].y + b * vp[k].y;
-        x2[q]   = vx[k];
         p2[q]   = vp[k];
       }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-      const double po = p[n - 1];
-      x[n - 1]        = x[n - 1] + a * po;
-      p[n - 1]        = z[n - 1] + b * po;
+      const double po = p[n - 1], zv = ZR ? z[n - 1] * dconst : z[n - 1];
+      if (UPX) x[n - 1] = x[n - 1] + a * po;
+      p[n - 1] = zv + b * po;
     }
   } else {
     for (hipx_int i = (hipx_int)blockIdx.x * kEwThreads + threadIdx.x; i < n; i += (hipx_int)gridDim.x * kEwThreads) {
-      const double po = p[i];
-      x[i]            = x[i] + a * po;
-      p[i]            = z[i] + b * po;
+      const double po = p[i], zv = ZR ? z[i] * dconst : z[i];
+      if (UPX) x[i] = x[i] + a * po;
+      p[i] = zv + b * po;
     }
   }
 }
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
       zv.x  = rv.x * dv.x;
       zv.y  = rv.y * dv.y;
       r2[q] = rv;
-      z2[q] = zv;
+      if (!CONSTD || z) z2[q] = zv;  // constant diagonal + z == NULL: z is never stored (cg_aypx_axpy_kernel<.., ZR> re-forms it)
       acc[0] += zv.x * zv.x;
       acc[0] += zv.y * zv.y;
       acc[1] += zv.x * rv.x;
@@ -518,7 +526,7 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
       double   rv = r[i] + ma * w[i], zv = rv * (CONSTD ? dconst : d[i]);
       if (UPX) x[i] = x[i] + a * p[i];
       r[i] = rv;
-      z[i] = zv;
+      if (!CONSTD || z) z[i] = zv;
       acc[0] += zv * zv;
       acc[1] += zv * rv;
     }
@@ -527,7 +535,7 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
       double rv = r[i] + ma * w[i], zv = rv * (CONSTD ? dconst : d[i]);
       if (UPX) x[i] = x[i] + a * p[i];
       r[i] = rv;
-      z[i] = zv;
+      if (!CONSTD || z) z[i] = zv;
       acc[0] += zv * zv;
       acc[1] += zv * rv;
     }
@@ -1047,17 +1055,31 @@ int hipxCGAypxAxpy(double *p, double b, const double *z, double *x, double a, hi
     return hipxVecAYPX(p, b, z, n);
   }
   bool vec = aligned16(p) && aligned16(x) && aligned16(z) && n >= 2;
-  cg_aypx_axpy_kernel<false><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, z, b, a, nullptr, nullptr, nullptr, n, vec);
+  cg_aypx_axpy_kernel<false, false, true><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, z, 0.0, b, a, nullptr, nullptr, nullptr, n, vec);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
 
-int hipxCGAypxAxpyDev(double *p, const double *z, double *x, const double *dev_beta_new, const double *dev_beta_old, const double *dev_dpi, hipx_int n)
+int hipxCGAypxAxpyR(double *p, double b, const double *r, double dconst, double *x, double a, hipx_int n)
 {
   HIPX_CHECK_INIT();
   if (n <= 0) return HIPX_SUCCESS;
-  bool vec = aligned16(p) && aligned16(x) && aligned16(z) && n >= 2;
-  cg_aypx_axpy_kernel<true><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, z, 0.0, 0.0, dev_beta_new, dev_beta_old, dev_dpi, n, vec);
+  bool vec = aligned16(p) && aligned16(x) && aligned16(r) && n >= 2;
+  if (x) cg_aypx_axpy_kernel<false, true, true><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, r, dconst, b, a, nullptr, nullptr, nullptr, n, vec);
+  else cg_aypx_axpy_kernel<false, true, false><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, r, dconst, b, a, nullptr, nullptr, nullptr, n, vec);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+int hipxCGAypxAxpyDev(double *p, const double *z, const double *r, double dconst, double *x, const double *dev_beta_new, const double *dev_beta_old, const double *dev_dpi, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  if (n <= 0) return HIPX_SUCCESS;
+  HIPX_ARG((z || r) && x && dev_beta_new && dev_beta_old && dev_dpi, "null argument");
+  const double *src = z ? z : r;
+  bool          vec = aligned16(p) && aligned16(x) && aligned16(src) && n >= 2;
+  if (z) cg_aypx_axpy_kernel<true, false, true><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, src, 0.0, 0.0, 0.0, dev_beta_new, dev_beta_old, dev_dpi, n, vec);
+  else cg_aypx_axpy_kernel<true, true, true><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, src, dconst, 0.0, 0.0, dev_beta_new, dev_beta_old, dev_dpi, n, vec);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -1067,6 +1089,7 @@ int hipxCGFusedUpdateBegin(double *x, double *r, double *z, const double *p, con
 {
   HIPX_CHECK_INIT();
   HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2 && n > 0 && dev_beta && dev_dpi, "bad slot / empty vector / null scalars");
+  HIPX_ARG(z || !d, "z may only be omitted with a constant diagonal (d == NULL)");
   bool vec = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(p) && aligned16(w) && aligned16(d) && n >= 2;
   const unsigned g = red_grid(n);
   RedOut         o = red_out(slot, true, dev_sums2);

@@ -302,13 +302,16 @@ static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double 
       if (!i) CHK(hipxVecCopy(Z, P, n)); /* cg.c:236 */
       else {
         const double b = ksp->beta / ksp->betaold;
-        if (ksp->x_pending) {
+        if (dcon) { /* z = r * dconst is not stored in this mode */
+          CHK(hipxCGAypxAxpyR(P, b, R, pc->dconst, ksp->x_pending ? X : NULL, ksp->a_pending, n));
+          ksp->x_pending = 0;
+        } else if (ksp->x_pending) {
           CHK(hipxCGAypxAxpy(P, b, Z, X, ksp->a_pending, n));
           ksp->x_pending = 0;
         } else CHK(hipxVecAYPX(P, b, Z, n)); /* cg.c:249 */
       }
       CHK(hipxMatMultDotBegin(A->A, P, W, SLOT_DOT, ds));
-      CHK(hipxCGFusedUpdateBegin(NULL, R, Z, P, W, dcon ? NULL : pc->dinv, pc->dconst, dbeta_i, ds, n, SLOT_SUMS + q, ds + 2 + 2 * q));
+      CHK(hipxCGFusedUpdateBegin(NULL, R, dcon ? NULL : Z, P, W, dcon ? NULL : pc->dinv, pc->dconst, dbeta_i, ds, n, SLOT_SUMS + q, ds + 2 + 2 * q));
     }
     ahead  = 0;
     dpiold = ksp->dpi;
@@ -327,9 +330,9 @@ static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double 
     ksp->a_pending = ksp->a;
     if (s + 1 < nsteps && i + 1 < ksp->max_it) { /* enqueue iteration i+1 while C(i) runs */
       double *dbeta_n = ds + 3 + 2 * q; /* z.r of iteration i, written by C(i) */
-      CHK(hipxCGAypxAxpyDev(P, Z, X, dbeta_n, dbeta_i, ds, n));
+      CHK(hipxCGAypxAxpyDev(P, dcon ? NULL : Z, R, pc->dconst, X, dbeta_n, dbeta_i, ds, n));
       CHK(hipxMatMultDotBegin(A->A, P, W, SLOT_DOT, ds));
-      CHK(hipxCGFusedUpdateBegin(NULL, R, Z, P, W, dcon ? NULL : pc->dinv, pc->dconst, dbeta_n, ds, n, SLOT_SUMS + (1 - q), ds + 2 + 2 * (1 - q)));
+      CHK(hipxCGFusedUpdateBegin(NULL, R, dcon ? NULL : Z, P, W, dcon ? NULL : pc->dinv, pc->dconst, dbeta_n, ds, n, SLOT_SUMS + (1 - q), ds + 2 + 2 * (1 - q)));
       ahead          = 1;
       ksp->x_pending = 0; /* A(i+1) applies it */
     }
