@@ -1,5 +1,5 @@
 """CPU: the bench.py contract (the driver parses ONE JSON line).  Checks the committed line of the last GPU run
-(profiles/r01e_bench_default.json, produced by `python bench.py` on an MI355X) and the command-line defaults."""
+(profiles/r01f_bench_default.json, produced by `python bench.py` on an MI355X) and the command-line defaults."""
 import glob
 import json
 import os
