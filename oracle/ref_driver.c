@@ -10,6 +10,38 @@
  */
 #include <petscksp.h>
 #include <petsctime.h>
+#include <../src/mat/impls/aij/mpi/mpiaij.h> /* -dump_split: the reference's own Mat_MPIAIJ pieces (garray, A, B) */
+
+/* -dump_split: what MatAssemblyEnd_MPIAIJ / MatSetUpMultiply_MPIAIJ (mmaij.c:8-125) left on every rank, rank by rank:
+     split <rank> <rstart> <rend> <nghost>
+     garray <rank> <k> <global column>
+     ad <rank> <local row> <local column> <value>          diagonal block
+     bo <rank> <local row> <ghost index> <value>           off-diagonal block, columns compacted to garray order */
+static PetscErrorCode DumpSplit(Mat A)
+{
+  PetscBool   ismpi;
+  PetscMPIInt rank;
+  PetscInt    rs, re;
+
+  PetscFunctionBeginUser;
+  PetscCall(PetscObjectBaseTypeCompare((PetscObject)A, MATMPIAIJ, &ismpi));
+  PetscCheck(ismpi, PETSC_COMM_WORLD, PETSC_ERR_SUP, "-dump_split needs an MPIAIJ matrix (np > 1)");
+  PetscCallMPI(MPI_Comm_rank(PETSC_COMM_WORLD, &rank));
+  PetscCall(MatGetOwnershipRange(A, &rs, &re));
+  {
+    Mat_MPIAIJ *a  = (Mat_MPIAIJ *)A->data;
+    Mat_SeqAIJ *ad = (Mat_SeqAIJ *)a->A->data, *bo = (Mat_SeqAIJ *)a->B->data;
+    PetscInt    ng = a->B->cmap->n;
+    PetscCall(PetscSynchronizedPrintf(PETSC_COMM_WORLD, "split %d %" PetscInt_FMT " %" PetscInt_FMT " %" PetscInt_FMT "\n", (int)rank, rs, re, ng));
+    for (PetscInt k = 0; k < ng; k++) PetscCall(PetscSynchronizedPrintf(PETSC_COMM_WORLD, "garray %d %" PetscInt_FMT " %" PetscInt_FMT "\n", (int)rank, k, a->garray[k]));
+    for (PetscInt r = 0; r < re - rs; r++) {
+      for (PetscInt k = ad->i[r]; k < ad->i[r + 1]; k++) PetscCall(PetscSynchronizedPrintf(PETSC_COMM_WORLD, "ad %d %" PetscInt_FMT " %" PetscInt_FMT " %.17g\n", (int)rank, r, ad->j[k], (double)ad->a[k]));
+      for (PetscInt k = bo->i[r]; k < bo->i[r + 1]; k++) PetscCall(PetscSynchronizedPrintf(PETSC_COMM_WORLD, "bo %d %" PetscInt_FMT " %" PetscInt_FMT " %.17g\n", (int)rank, r, bo->j[k], (double)bo->a[k]));
+    }
+    PetscCall(PetscSynchronizedFlush(PETSC_COMM_WORLD, PETSC_STDOUT));
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
 
 static PetscErrorCode Assemble(Mat A, PetscInt stencil, PetscInt m, PetscInt n, PetscInt Istart, PetscInt Iend)
 {
@@ -87,6 +119,16 @@ int main(int argc, char **argv)
   PetscCall(MatMPIAIJSetPreallocation(A, stencil, NULL, stencil, NULL));
   PetscCall(MatGetOwnershipRange(A, &Istart, &Iend));
   PetscCall(Assemble(A, stencil, m, n, Istart, Iend));
+  {
+    PetscBool dump_split = PETSC_FALSE;
+    PetscCall(PetscOptionsGetBool(NULL, NULL, "-dump_split", &dump_split, NULL));
+    if (dump_split) {
+      PetscCall(DumpSplit(A));
+      PetscCall(MatDestroy(&A));
+      PetscCall(PetscFinalize());
+      return 0;
+    }
+  }
   {
     PetscBool dup = PETSC_FALSE; /* -dup_mat: run everything on MatDuplicate(A) (exercises the duplicate op of Mat subclasses) */
     PetscCall(PetscOptionsGetBool(NULL, NULL, "-dup_mat", &dup, NULL));

@@ -1,0 +1,60 @@
+"""CPU: the product's MPIAIJ split (petsc_amd/host/hipx_mpiaij.c: ownership ranges, diagonal / off-diagonal blocks, garray,
+ghost-compacted columns -- the integer work SURVEY.md 8 demands bit-exact) against THE REFERENCE ITSELF under real MPI:
+`mpiexec -n P oracle/_ref/mpich/bin/ref_driver -dump_split` prints what MatAssemblyEnd_MPIAIJ + MatSetUpMultiply_MPIAIJ
+(mpiaij.c:769-846, mmaij.c:8-125) left on every rank.  Needs the MPICH build of the reference (oracle/build_ref.py mpich)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_host import host_stencil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "mpich", "bin", "ref_driver")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+@pytest.mark.parametrize("kind,n,m,nranks", [("7pt", 5, None, 2), ("7pt", 6, None, 3), ("27pt", 5, None, 3), ("27pt", 6, None, 4), ("5pt", 7, 9, 3)])
+def test_split_equals_reference_under_mpi(built, kind, n, m, nranks):
+    if not (os.path.exists(EXE) and os.path.exists(MPIEXEC)):
+        pytest.skip("MPICH build of the reference not present")
+    from petsc_amd import _lib
+    from petsc_amd import dist as pdist
+    _, ks = _lib.load()
+    args = ["-stencil", kind[:-2], "-n", str(n)] + (["-m", str(m)] if m else [])
+    r = subprocess.run([MPIEXEC, "-n", str(nranks), EXE] + args + ["-dump_split"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120,
+                       env=dict(os.environ, HIPX_NO_TORCH="1"))
+    assert r.returncode == 0, r.stdout[-2000:]
+    ref = {k: {"garray": {}, "ad": [], "bo": []} for k in range(nranks)}
+    for ln in r.stdout.splitlines():
+        t = ln.split()
+        if t[0] == "split":
+            ref[int(t[1])].update(rs=int(t[2]), re=int(t[3]), ng=int(t[4]))
+        elif t[0] == "garray":
+            ref[int(t[1])]["garray"][int(t[2])] = int(t[3])
+        elif t[0] in ("ad", "bo"):
+            ref[int(t[1])][t[0]].append((int(t[2]), int(t[3]), float(t[4])))
+    N = (m or n) * n if kind == "5pt" else n ** 3
+    ranges = pdist.split_ownership(N, nranks)
+    for rank in range(nranks):
+        q = ref[rank]
+        assert (int(ranges[rank]), int(ranges[rank + 1])) == (q["rs"], q["re"])            # PetscSplitOwnership
+        ai, aj, aa = host_stencil(ks, kind, n, q["rs"], q["re"], m)
+        p = pdist.build_plan(ai, aj, aa, ranges, rank, dist=None) if nranks == 1 else _plan_local(pdist, ai, aj, aa, ranges, rank)
+        assert p["nghost"] == q["ng"]
+        assert [q["garray"][k] for k in range(q["ng"])] == list(p["garray"])                 # mmaij.c:27-65: sorted unique ghost columns
+        mine_ad = [(row, int(p["Aj"][k]), float(p["Aa"][k])) for row in range(p["m"]) for k in range(p["Ai"][row], p["Ai"][row + 1])]
+        assert mine_ad == q["ad"]                                                            # diagonal block, local columns
+        mine_bo = [(int(p["ridx"][c]), int(p["Bj"][k]), float(p["Ba"][k])) for c in range(p["nrows_c"]) for k in range(p["Bi"][c], p["Bi"][c + 1])]
+        assert mine_bo == q["bo"]                                                            # off-diagonal block, columns in garray order
+
+
+def _plan_local(pdist, ai, aj, aa, ranges, rank):
+    """build_plan without the request exchange (only the local split is compared here)."""
+    class _NoDist:
+        @staticmethod
+        def all_gather_object(out, obj, group=None):
+            for k in range(len(out)):
+                out[k] = [None] * len(out)
+    return pdist.build_plan(ai, aj, aa, ranges, rank, dist=_NoDist)
