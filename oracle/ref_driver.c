@@ -10,7 +10,8 @@
  */
 #include <petscksp.h>
 #include <petsctime.h>
-#include <../src/mat/impls/aij/mpi/mpiaij.h> /* -dump_split: the reference's own Mat_MPIAIJ pieces (garray, A, B) */
+#include <../src/mat/impls/aij/mpi/mpiaij.h> /* -dump_split: the reference's own Mat_MPIAIJ pieces (garray, A, B, Mvctx) */
+#include <petscsf.h>
 
 /* -dump_split: what MatAssemblyEnd_MPIAIJ / MatSetUpMultiply_MPIAIJ (mmaij.c:8-125) left on every rank, rank by rank:
      split <rank> <rstart> <rend> <nghost>
@@ -37,6 +38,22 @@ static PetscErrorCode DumpSplit(Mat A)
     for (PetscInt r = 0; r < re - rs; r++) {
       for (PetscInt k = ad->i[r]; k < ad->i[r + 1]; k++) PetscCall(PetscSynchronizedPrintf(PETSC_COMM_WORLD, "ad %d %" PetscInt_FMT " %" PetscInt_FMT " %.17g\n", (int)rank, r, ad->j[k], (double)ad->a[k]));
       for (PetscInt k = bo->i[r]; k < bo->i[r + 1]; k++) PetscCall(PetscSynchronizedPrintf(PETSC_COMM_WORLD, "bo %d %" PetscInt_FMT " %" PetscInt_FMT " %.17g\n", (int)rank, r, bo->j[k], (double)bo->a[k]));
+    }
+    { /* the ghost exchange the reference set up (a->Mvctx is a PetscSF: roots = owned entries of x, leaves = lvec):
+           recv <rank> <from> <leaf = index into lvec> <root = local index on the owner>
+           send <rank> <to> <position in the message> <local index of the owned entry> */
+      PetscMPIInt        nr, ni;
+      const PetscMPIInt *ranks, *iranks;
+      const PetscInt    *roff, *rmine, *rremote, *ioff, *iroot;
+      PetscCall(PetscSFSetUp(a->Mvctx));
+      PetscCall(PetscSFGetRootRanks(a->Mvctx, &nr, &ranks, &roff, &rmine, &rremote));
+      PetscCall(PetscSFGetLeafRanks(a->Mvctx, &ni, &iranks, &ioff, &iroot));
+      for (PetscMPIInt k = 0; k < nr; k++)
+        for (PetscInt j = roff[k]; j < roff[k + 1]; j++)
+          PetscCall(PetscSynchronizedPrintf(PETSC_COMM_WORLD, "recv %d %d %" PetscInt_FMT " %" PetscInt_FMT "\n", (int)rank, (int)ranks[k], rmine ? rmine[j] : j, rremote[j]));
+      for (PetscMPIInt k = 0; k < ni; k++)
+        for (PetscInt j = ioff[k]; j < ioff[k + 1]; j++)
+          PetscCall(PetscSynchronizedPrintf(PETSC_COMM_WORLD, "send %d %d %" PetscInt_FMT " %" PetscInt_FMT "\n", (int)rank, (int)iranks[k], j - ioff[k], iroot[j]));
     }
     PetscCall(PetscSynchronizedFlush(PETSC_COMM_WORLD, PETSC_STDOUT));
   }

@@ -26,7 +26,7 @@ def test_split_equals_reference_under_mpi(built, kind, n, m, nranks):
     r = subprocess.run([MPIEXEC, "-n", str(nranks), EXE] + args + ["-dump_split"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120,
                        env=dict(os.environ, HIPX_NO_TORCH="1"))
     assert r.returncode == 0, r.stdout[-2000:]
-    ref = {k: {"garray": {}, "ad": [], "bo": []} for k in range(nranks)}
+    ref = {k: {"garray": {}, "ad": [], "bo": [], "recv": [], "send": []} for k in range(nranks)}
     for ln in r.stdout.splitlines():
         t = ln.split()
         if t[0] == "split":
@@ -35,8 +35,34 @@ def test_split_equals_reference_under_mpi(built, kind, n, m, nranks):
             ref[int(t[1])]["garray"][int(t[2])] = int(t[3])
         elif t[0] in ("ad", "bo"):
             ref[int(t[1])][t[0]].append((int(t[2]), int(t[3]), float(t[4])))
+        elif t[0] in ("recv", "send"):
+            ref[int(t[1])][t[0]].append((int(t[2]), int(t[3]), int(t[4])))
     N = (m or n) * n if kind == "5pt" else n ** 3
     ranges = pdist.split_ownership(N, nranks)
+    # ghost exchange: the request lists every rank would send at set-up (what torch.distributed carries in bench.py)
+    slabs = [host_stencil(ks, kind, n, int(ranges[r]), int(ranges[r + 1]), m) for r in range(nranks)]
+    first = [_plan_local(pdist, *slabs[r], ranges, r) for r in range(nranks)]
+    requests = []
+    for r in range(nranks):
+        req = [None] * nranks
+        for k, owner in enumerate(first[r]["recv_ranks"]):
+            req[int(owner)] = first[r]["garray"][first[r]["recv_off"][k]:first[r]["recv_off"][k + 1]].copy()
+        requests.append(req)
+
+    class _Gathered:
+        @staticmethod
+        def all_gather_object(out, obj, group=None):
+            for k in range(len(out)):
+                out[k] = requests[k]
+
+    for rank in range(nranks):
+        q, pl = ref[rank], pdist.build_plan(*slabs[rank], ranges, rank, dist=_Gathered)
+        # receive side: lvec[leaf] <- entry `root` of rank `from` (PetscSFGetRootRanks); ours: garray grouped by owner
+        mine_recv = [(int(o), int(k), int(pl["garray"][k]) - int(ranges[int(o)])) for j, o in enumerate(pl["recv_ranks"]) for k in range(pl["recv_off"][j], pl["recv_off"][j + 1])]
+        assert sorted(mine_recv) == sorted(q["recv"])
+        # send side: message to rank `to`, position by position (PetscSFGetLeafRanks irootloc) = our pack list
+        mine_send = [(int(t_), int(k - pl["send_off"][j]), int(pl["send_idx"][k])) for j, t_ in enumerate(pl["send_ranks"]) for k in range(pl["send_off"][j], pl["send_off"][j + 1])]
+        assert sorted(mine_send) == sorted(q["send"])
     for rank in range(nranks):
         q = ref[rank]
         assert (int(ranges[rank]), int(ranges[rank + 1])) == (q["rs"], q["re"])            # PetscSplitOwnership
