@@ -8,6 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
+import oracle as orc
 from test_host import host_stencil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -74,6 +75,17 @@ def test_split_equals_reference_under_mpi(built, kind, n, m, nranks):
         assert mine_ad == q["ad"]                                                            # diagonal block, local columns
         mine_bo = [(int(p["ridx"][c]), int(p["Bj"][k]), float(p["Ba"][k])) for c in range(p["nrows_c"]) for k in range(p["Bi"][c], p["Bi"][c + 1])]
         assert mine_bo == q["bo"]                                                            # off-diagonal block, columns in garray order
+        # the ORACLE's restatement of the same routine is pinned to the reference here as well
+        mloc, nz = q["re"] - q["rs"], len(aj)
+        Ai, Aj, Bi, Bj, ga = (np.zeros(k, np.int32) for k in (mloc + 1, nz + 1, mloc + 1, nz + 1, nz + 1))
+        Aa, Ba = np.zeros(nz + 1), np.zeros(nz + 1)
+        ng = orc.lib().orc_MatSetUpMultiply_MPIAIJ(mloc, q["rs"], q["re"], orc.P(ai), orc.P(aj), orc.P(aa), orc.P(Ai), orc.P(Aj), orc.P(Aa), orc.P(Bi), orc.P(Bj), orc.P(Ba), orc.P(ga))
+        assert ng == q["ng"] and list(ga[:ng]) == [q["garray"][k] for k in range(ng)]
+        assert [(r_, int(Aj[k]), float(Aa[k])) for r_ in range(mloc) for k in range(Ai[r_], Ai[r_ + 1])] == q["ad"]
+        assert [(r_, int(Bj[k]), float(Ba[k])) for r_ in range(mloc) for k in range(Bi[r_], Bi[r_ + 1])] == q["bo"]
+    oranges = np.zeros(nranks + 1, np.int32)
+    orc.lib().orc_PetscSplitOwnership(N, nranks, orc.P(oranges))
+    assert [int(v) for v in oranges] == [ref[k]["rs"] for k in range(nranks)] + [N]
 
 
 def _plan_local(pdist, ai, aj, aa, ranges, rank):
