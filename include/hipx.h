@@ -149,7 +149,9 @@ int hipxMatSOR(hipxMat A, const double *b, double omega, int flag, double shift,
 /* tuning knobs (plugin option -mat_aijhipx_spmv_variant): kernel variant.  0 = auto (>= 2^20 nonzeros: packed 16-bit
    column codes, row-parallel gather for short rows, and an 8-bit value dictionary when a[] holds <= 256 distinct bit
    patterns); 1..12 = 32-bit-column stream kernel geometries; 22 / 23 = packed columns (staged / row-parallel);
-   24 / 25 = 22 / 23 plus the value dictionary (falls back to 22 / 23 when the dictionary does not fit).
+   24 / 25 = 22 / 23 plus the value dictionary (falls back to 22 / 23 when the dictionary does not fit);
+   26 = row templates: a matrix whose rows are <= 256 distinct (column - row, value) sequences (stencil operators in natural
+   ordering) is stored as one template id per row (falls back to 25).  Auto picks 26 when the dictionary exists.
    Every variant produces the bit-identical y (same products, same left-to-right row sums as aij.c:1486-1494). */
 int hipxMatSetSpMVVariant(hipxMat A, int variant);
 /* name of the kernel the next hipxMatMult will launch (builds the packed formats if they are pending) */

@@ -61,6 +61,19 @@ struct hipxMat_s {
   int            vd_count = 0;
   unsigned char *d_vc     = nullptr;
   double        *d_vdict  = nullptr;  // 256 entries
+  // row templates (stencil-structured matrices): every row is one of <= 256 (offset, value) sequences; the matrix then is
+  // ONE byte per row.  Built lazily on the device, verified entry by entry (hash collisions cannot slip through).
+  int            tmpl_mode  = 0;      // 1 = use the template kernel when the templates exist
+  bool           tmpl_ready = false;  // attempted for the current pattern + values
+  bool           tmpl_ok    = false;
+  int            ntmpl = 0, tmpl_nent = 0;
+  unsigned char *d_tid    = nullptr;  // template id per row
+  int           *d_tstart = nullptr;  // ntmpl + 1 offsets into toff / tval
+  int           *d_toff   = nullptr;  // column - row
+  double        *d_tval   = nullptr;
+  std::vector<int>     h_tstart, h_toff, h_tdiag;  // host copies (SOR set-up reads them); h_tdiag = index of the diagonal entry or -1
+  std::vector<int64_t> h_tcount;                   // rows per template
+  std::vector<double>  h_tval;
   int       probe      = 0;   // phase-attribution probe kernels (scripts/spmv_variants.py); results are NOT A x
   std::vector<int64_t> h_i;  // host copy of the row offsets (set-up only)
   void     *sor_state = nullptr;  // hipxSorState, owned by hipx_sor.hip
@@ -865,6 +878,171 @@ __global__ __launch_bounds__(256) void vd_encode_kernel(const unsigned long long
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row templates.  A stencil matrix in natural ordering repeats a handful of rows: the sequence of (column - row, value)
+// pairs of a row is one of 27 "templates" for the 7- and 27-point operators (interior + boundary combinations).  When a
+// matrix has <= 256 distinct templates (<= TMPL_MAX_ENT entries in total) it is stored as ONE BYTE PER ROW plus the
+// template table; MatMult then moves x, y and 1 B/row instead of 12 B per nonzero.  The products and the left-to-right
+// row sums are those of MatMult_SeqAIJ (aij.c:1486-1494) on the same doubles: y is bit-identical.
+// Set-up on the device: 64-bit hash per row -> distinct hashes (vd_collect_kernel) -> ids + representative rows ->
+// tmpl_verify_kernel compares EVERY row with its template entry by entry (a hash collision disables the format, it can
+// never produce a wrong matrix).
+constexpr int TMPL_MAX     = 256;
+constexpr int TMPL_MAX_ENT = 3072;
+
+__device__ __forceinline__ unsigned long long tm_mix(unsigned long long h, unsigned long long v)
+{
+  h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+  h *= 0xff51afd7ed558ccdULL;
+  h ^= h >> 32;
+  return h;
+}
+
+template <typename IT>
+__global__ __launch_bounds__(256) void tmpl_hash_kernel(hipx_int m, const IT *__restrict__ ai, const hipx_int *__restrict__ aj, const unsigned long long *__restrict__ aa,
+                                                        unsigned long long *__restrict__ hash)
+{
+  for (hipx_int r = (hipx_int)blockIdx.x * 256 + threadIdx.x; r < m; r += (hipx_int)gridDim.x * 256) {
+    const IT           s = ai[r], e = ai[r + 1];
+    unsigned long long h = tm_mix(0x243F6A8885A308D3ull, (unsigned long long)(e - s));
+    for (IT k = s; k < e; k++) {
+      h = tm_mix(h, (unsigned long long)(unsigned)(aj[k] - r));
+      h = tm_mix(h, aa[k]);
+    }
+    if (h == VD_EMPTY) h ^= 1;
+    hash[r] = h;
+  }
+}
+
+// hash -> template id through the host-built open-addressing table; first row and row count of every template
+__global__ __launch_bounds__(256) void tmpl_assign_kernel(hipx_int m, const unsigned long long *__restrict__ hash, const unsigned long long *__restrict__ gkeys,
+                                                          const short *__restrict__ gcodes, unsigned char *__restrict__ tid, int *rep, unsigned long long *count)
+{
+  __shared__ unsigned long long keys[1024];
+  __shared__ short              codes[1024];
+  __shared__ unsigned int       hist[TMPL_MAX];
+  __shared__ int                first[TMPL_MAX];
+  for (int s = threadIdx.x; s < 1024; s += 256) {
+    keys[s]  = gkeys[s];
+    codes[s] = gcodes[s];
+  }
+  hist[threadIdx.x]  = 0;
+  first[threadIdx.x] = 0x7fffffff;
+  __syncthreads();
+  for (hipx_int r = (hipx_int)blockIdx.x * 256 + threadIdx.x; r < m; r += (hipx_int)gridDim.x * 256) {
+    const unsigned long long v = hash[r];
+    unsigned                 s = vd_hash(v, 10);
+    while (codes[s] >= 0 && keys[s] != v) s = (s + 1) & 1023;
+    const int id = codes[s] >= 0 ? codes[s] : 0;
+    tid[r]       = (unsigned char)id;
+    atomicAdd(&hist[id], 1u);
+    atomicMin(&first[id], (int)r);
+  }
+  __syncthreads();
+  if (hist[threadIdx.x]) {
+    atomicAdd(&count[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+    atomicMin(&rep[threadIdx.x], first[threadIdx.x]);
+  }
+}
+
+template <typename IT>
+__global__ __launch_bounds__(256) void tmpl_verify_kernel(hipx_int m, hipx_int ncols, const IT *__restrict__ ai, const hipx_int *__restrict__ aj, const unsigned long long *__restrict__ aa,
+                                                          const unsigned char *__restrict__ tid, const int *__restrict__ tstart, const int *__restrict__ toff,
+                                                          const unsigned long long *__restrict__ tval, unsigned int *bad)
+{
+  for (hipx_int r = (hipx_int)blockIdx.x * 256 + threadIdx.x; r < m; r += (hipx_int)gridDim.x * 256) {
+    const IT  s = ai[r], e = ai[r + 1];
+    const int t = tid[r], ts = tstart[t], te = tstart[t + 1];
+    bool      ok = (long long)(e - s) == (long long)(te - ts);
+    if (ok)
+      for (int k = 0; k < te - ts; k++) {
+        const long long c = (long long)r + toff[ts + k];
+        ok = ok && (aj[s + k] - r) == toff[ts + k] && aa[s + k] == tval[ts + k] && c >= 0 && c < ncols;
+      }
+    if (!ok) atomicAdd(bad, 1u);
+  }
+}
+
+// Template SpMV.  Persistent workgroups (the template table is loaded into LDS once per workgroup), each XCD walks one
+// contiguous slab of row chunks and the workgroups of an XCD take neighbouring chunks, so the x planes a chunk touches
+// (rows +-n, +-n^2) are shared through that XCD's L2.  Thread t of a chunk owns rows base + t + rr*256: the k-th gather of
+// a wave reads x[row + off_k] for 64 consecutive rows = one 512-byte contiguous run when the lanes share a template
+// (interior), and the LDS reads of the template entries broadcast.
+template <int MODE, bool DOT, int RPT, int W>
+__global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const int *__restrict__ tstart,
+                                                        const int *__restrict__ toff, const double *__restrict__ tval, int ntmpl, int nent, const double *__restrict__ x,
+                                                        const double *yin, double *yout, double *dotpart)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s_val   = reinterpret_cast<double *>(smem);                      // nent (padded to even)
+  int    *s_off   = reinterpret_cast<int *>(smem + 8 * (size_t)((nent + 1) & ~1));
+  int    *s_start = s_off + ((nent + 3) & ~3);                             // ntmpl + 1
+  const int t = threadIdx.x;
+  for (int k = t; k < nent; k += 256) {
+    s_val[k] = tval[k];
+    s_off[k] = toff[k];
+  }
+  for (int k = t; k <= ntmpl; k += 256) s_start[k] = tstart[k];
+  __syncthreads();
+  const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, slot = bid >> 3, bpx = (hipx_int)gridDim.x >> 3;
+  const hipx_int c0 = xcd * chunks_per_xcd, c1 = (c0 + chunks_per_xcd < nchunks) ? c0 + chunks_per_xcd : nchunks;
+  double         mydot = 0.0;
+  for (hipx_int c = c0 + slot; c < c1; c += bpx) {
+    const hipx_int base = c * (256 * RPT);
+    int            s0[RPT], len[RPT], maxlen = 0;
+    double         sum[RPT], xrow[RPT];
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) {
+      const hipx_int row = base + t + rr * 256;
+      s0[rr] = 0;
+      len[rr] = 0;
+      sum[rr] = 0.0;
+      xrow[rr] = 0.0;
+      if (row < m) {
+        const int id = tid[row];
+        s0[rr]  = s_start[id];
+        len[rr] = s_start[id + 1] - s0[rr];
+        if (MODE == 1) sum[rr] = yin[row];
+        if (DOT) xrow[rr] = x[row];
+      }
+      maxlen = max(maxlen, len[rr]);
+    }
+    for (int k = 0; k < maxlen; k += W) {
+      double xv[RPT][W], av[RPT][W];
+#pragma unroll
+      for (int rr = 0; rr < RPT; rr++) {
+        const hipx_int row = base + t + rr * 256;
+#pragma unroll
+        for (int e = 0; e < W; e++) {
+          const bool on  = (k + e) < len[rr];
+          const int  idx = on ? s0[rr] + k + e : 0;
+          av[rr][e]      = s_val[idx];
+          xv[rr][e]      = on ? x[row + s_off[idx]] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < RPT; rr++) {
+#pragma unroll
+        for (int e = 0; e < W; e++)
+          if ((k + e) < len[rr]) sum[rr] += av[rr][e] * xv[rr][e];
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) {
+      const hipx_int row = base + t + rr * 256;
+      if (row < m) {
+        yout[row] = sum[rr];
+        if (DOT) mydot += xrow[rr] * sum[rr];
+      }
+    }
+  }
+  if (DOT) {
+    const double w = hipx::wave_sum(mydot);
+    if ((threadIdx.x & 63) == 0) dotpart[(size_t)bid * 4 + (threadIdx.x >> 6)] = w;
+  }
+}
+
 template <typename IT>
 __global__ void diagpos_kernel(hipx_int m, const IT *ai, const hipx_int *aj, int64_t *diagpos, unsigned int *missing)
 {
@@ -1025,6 +1203,7 @@ int create_common(hipx_int m, hipx_int n, hipx_int nrows, const IT *ai, const hi
   }
   A->tile_mode = auto_tile_mode(A);  // variant 0
   A->vd_mode   = A->tile_mode ? 1 : 0;
+  A->tmpl_mode = A->tile_mode ? 1 : 0;
   *out = A;
   return HIPX_SUCCESS;
 }
@@ -1253,6 +1432,172 @@ int ensure_pk16(hipxMat A, int cfg = 0)
   return HIPX_SUCCESS;
 }
 
+
+// Row templates (see spmv_tmpl_kernel): attempted once per pattern + value state.
+void free_templates(hipxMat A)
+{
+  (void)hipFree(A->d_tid);
+  (void)hipFree(A->d_tstart);
+  (void)hipFree(A->d_toff);
+  (void)hipFree(A->d_tval);
+  A->d_tid = nullptr;
+  A->d_tstart = nullptr;
+  A->d_toff = nullptr;
+  A->d_tval = nullptr;
+  A->tmpl_ok = false;
+  A->ntmpl = A->tmpl_nent = 0;
+}
+
+template <typename IT>
+int build_templates(hipxMat A)
+{
+  SetupTimer tm("row templates (device)");
+  hipStream_t    st = rt().compute;
+  const hipx_int m  = A->nrows_c;
+  unsigned long long *d_hash = nullptr, *d_list = nullptr, *d_keys = nullptr, *d_count = nullptr;
+  unsigned int       *d_cnt = nullptr;
+  short              *d_codes = nullptr;
+  int                *d_rep = nullptr;
+  struct Guard {
+    void **p[7];
+    ~Guard()
+    {
+      for (auto q : p)
+        if (q && *q) (void)hipFree(*q);
+    }
+  } guard{{(void **)&d_hash, (void **)&d_list, (void **)&d_keys, (void **)&d_count, (void **)&d_cnt, (void **)&d_codes, (void **)&d_rep}};
+  const unsigned grid = 2048, cap = grid * 256;
+  HIPX_HIP(hipMalloc((void **)&d_hash, sizeof(unsigned long long) * (size_t)m));
+  HIPX_HIP(hipMalloc((void **)&d_list, sizeof(unsigned long long) * cap));
+  HIPX_HIP(hipMalloc((void **)&d_cnt, sizeof(unsigned int) * 2));
+  HIPX_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * 2, st));
+  const unsigned g = (unsigned)std::min<hipx_int>((m + 255) / 256, 8192);
+  tmpl_hash_kernel<IT><<<g, 256, 0, st>>>(m, (const IT *)A->d_i, A->d_j, (const unsigned long long *)A->d_a, d_hash);
+  vd_collect_kernel<<<grid, 256, 0, st>>>(d_hash, (long long)m, d_list, d_cnt, cap);
+  unsigned int hc[2] = {0, 0};
+  HIPX_HIP(hipMemcpyAsync(hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
+  HIPX_HIP(hipStreamSynchronize(st));
+  HIPX_LAUNCH_CHECK();
+  if (hc[1] || hc[0] > cap || !hc[0]) return HIPX_SUCCESS;  // more than 256 distinct rows somewhere: no templates
+  std::vector<uint64_t> keys(hc[0]);
+  HIPX_HIP(hipMemcpy(keys.data(), d_list, sizeof(uint64_t) * hc[0], hipMemcpyDeviceToHost));
+  std::sort(keys.begin(), keys.end());
+  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  if (keys.size() > (size_t)TMPL_MAX) return HIPX_SUCCESS;
+  const int nt = (int)keys.size();
+  VdTable   table;
+  for (uint64_t v : keys) table.insert(v);
+  std::vector<short> codes(VdTable::kSlots);
+  for (int sl = 0; sl < VdTable::kSlots; sl++) codes[(size_t)sl] = (short)table.code[sl];
+  std::vector<int> rep(TMPL_MAX, 0x7fffffff);
+  HIPX_HIP(hipMalloc((void **)&d_keys, sizeof(uint64_t) * VdTable::kSlots));
+  HIPX_HIP(hipMalloc((void **)&d_codes, sizeof(short) * VdTable::kSlots));
+  HIPX_HIP(hipMalloc((void **)&d_rep, sizeof(int) * TMPL_MAX));
+  HIPX_HIP(hipMalloc((void **)&d_count, sizeof(unsigned long long) * TMPL_MAX));
+  HIPX_HIP(hipMalloc((void **)&A->d_tid, (size_t)m + 64));
+  HIPX_HIP(hipMemcpyAsync(d_keys, table.key, sizeof(uint64_t) * VdTable::kSlots, hipMemcpyHostToDevice, st));
+  HIPX_HIP(hipMemcpyAsync(d_codes, codes.data(), sizeof(short) * VdTable::kSlots, hipMemcpyHostToDevice, st));
+  HIPX_HIP(hipMemcpyAsync(d_rep, rep.data(), sizeof(int) * TMPL_MAX, hipMemcpyHostToDevice, st));
+  HIPX_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long) * TMPL_MAX, st));
+  HIPX_HIP(hipMemsetAsync(A->d_tid, 0, (size_t)m + 64, st));
+  tmpl_assign_kernel<<<std::min<unsigned>(g, 2048u), 256, 0, st>>>(m, d_hash, d_keys, d_codes, A->d_tid, d_rep, d_count);
+  std::vector<unsigned long long> count(TMPL_MAX);
+  HIPX_HIP(hipMemcpyAsync(rep.data(), d_rep, sizeof(int) * TMPL_MAX, hipMemcpyDeviceToHost, st));
+  HIPX_HIP(hipMemcpyAsync(count.data(), d_count, sizeof(unsigned long long) * TMPL_MAX, hipMemcpyDeviceToHost, st));
+  HIPX_HIP(hipStreamSynchronize(st));
+  HIPX_LAUNCH_CHECK();
+  // representative rows -> template table (host copies of those few rows)
+  const int64_t *hi = A->h_i.data();
+  A->h_tstart.assign((size_t)nt + 1, 0);
+  A->h_tcount.assign((size_t)nt, 0);
+  for (int t = 0; t < nt; t++) {
+    if (rep[t] < 0 || rep[t] >= m) return HIPX_SUCCESS;
+    A->h_tstart[t + 1] = A->h_tstart[t] + (int)(hi[rep[t] + 1] - hi[rep[t]]);
+    A->h_tcount[t]     = (int64_t)count[t];
+    if (A->h_tstart[t + 1] > TMPL_MAX_ENT) return HIPX_SUCCESS;
+  }
+  const int nent = A->h_tstart[nt];
+  A->h_toff.assign((size_t)std::max(nent, 1), 0);
+  A->h_tval.assign((size_t)std::max(nent, 1), 0.0);
+  A->h_tdiag.assign((size_t)nt, -1);
+  std::vector<hipx_int> cols;
+  for (int t = 0; t < nt; t++) {
+    const int len = A->h_tstart[t + 1] - A->h_tstart[t];
+    if (!len) continue;
+    cols.resize((size_t)len);
+    HIPX_HIP(hipMemcpy(cols.data(), A->d_j + hi[rep[t]], sizeof(hipx_int) * (size_t)len, hipMemcpyDeviceToHost));
+    HIPX_HIP(hipMemcpy(A->h_tval.data() + A->h_tstart[t], A->d_a + hi[rep[t]], sizeof(double) * (size_t)len, hipMemcpyDeviceToHost));
+    for (int k = 0; k < len; k++) {
+      A->h_toff[(size_t)A->h_tstart[t] + k] = (int)(cols[(size_t)k] - rep[t]);
+      if (cols[(size_t)k] == rep[t] && A->h_tdiag[t] < 0) A->h_tdiag[t] = k;
+    }
+  }
+  HIPX_HIP(hipMalloc((void **)&A->d_tstart, sizeof(int) * ((size_t)nt + 1)));
+  HIPX_HIP(hipMalloc((void **)&A->d_toff, sizeof(int) * A->h_toff.size()));
+  HIPX_HIP(hipMalloc((void **)&A->d_tval, sizeof(double) * A->h_tval.size()));
+  HIPX_HIP(hipMemcpyAsync(A->d_tstart, A->h_tstart.data(), sizeof(int) * ((size_t)nt + 1), hipMemcpyHostToDevice, st));
+  HIPX_HIP(hipMemcpyAsync(A->d_toff, A->h_toff.data(), sizeof(int) * A->h_toff.size(), hipMemcpyHostToDevice, st));
+  HIPX_HIP(hipMemcpyAsync(A->d_tval, A->h_tval.data(), sizeof(double) * A->h_tval.size(), hipMemcpyHostToDevice, st));
+  HIPX_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * 2, st));
+  tmpl_verify_kernel<IT><<<g, 256, 0, st>>>(m, A->n, (const IT *)A->d_i, A->d_j, (const unsigned long long *)A->d_a, A->d_tid, A->d_tstart, A->d_toff,
+                                             (const unsigned long long *)A->d_tval, d_cnt);
+  HIPX_HIP(hipMemcpyAsync(hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
+  HIPX_HIP(hipStreamSynchronize(st));
+  HIPX_LAUNCH_CHECK();
+  if (hc[0]) return HIPX_SUCCESS;  // a hash collision (or a column outside the matrix): keep the general formats
+  A->ntmpl     = nt;
+  A->tmpl_nent = nent;
+  A->tmpl_ok   = true;
+  A->device_bytes += (int64_t)m + 64 + (int64_t)(sizeof(int) * ((size_t)nt + 1) + 12 * A->h_toff.size());
+  return HIPX_SUCCESS;
+}
+
+int ensure_templates(hipxMat A)
+{
+  if (A->tmpl_ready) return HIPX_SUCCESS;
+  A->tmpl_ready = true;
+  free_templates(A);
+  if (A->compressed || A->nrows_c <= 0 || A->nnz <= 0) return HIPX_SUCCESS;
+  int ierr = A->is64 ? build_templates<int64_t>(A) : build_templates<hipx_int>(A);
+  if (ierr || !A->tmpl_ok) free_templates(A);
+  return ierr;
+}
+
+template <int MODE, bool DOT>
+int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart, hipx_int *npart)
+{
+  constexpr int  RPT = 2, W = 4;
+  const hipx_int m = A->nrows_c, nchunks = (m + 256 * RPT - 1) / (256 * RPT);
+  hipx_int       grid = std::min<hipx_int>(2048, ((nchunks + 7) / 8) * 8);
+  if (grid < 8) grid = 8;
+  if (npart) {
+    *npart = grid * 4;
+    return HIPX_SUCCESS;
+  }
+  const hipx_int cpx  = (nchunks + 7) / 8;
+  const size_t   smem = 8 * (size_t)((A->tmpl_nent + 1) & ~1) + 4 * (size_t)((A->tmpl_nent + 3) & ~3) + 4 * ((size_t)A->ntmpl + 1) + 16;
+  spmv_tmpl_kernel<MODE, DOT, RPT, W><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout,
+                                                                                      dotpart);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+// does the next product run the template kernel?  (builds the templates if they are pending)
+int use_templates(hipxMat A, bool &use)
+{
+  use = false;
+  static const bool off = getenv("HIPX_NO_TMPL") != nullptr;
+  if (!A->tmpl_mode || A->compressed || A->probe || (off && A->auto_sel)) return HIPX_SUCCESS;
+  int ierr;
+  if (A->auto_sel) {  // auto: only matrices whose values already fit the 256-entry dictionary are worth the hashing passes
+    if ((ierr = ensure_vdict(A))) return ierr;
+    if (!A->vd_ok) return HIPX_SUCCESS;
+  }
+  if ((ierr = ensure_templates(A))) return ierr;
+  use = A->tmpl_ok;
+  return HIPX_SUCCESS;
+}
+
 // which packed form the next launch takes: vd (dictionary kernel), rowpar (row-parallel gather), rpt (rows per thread of
 // spmv_vd_kernel, 0 = other kernels), cfg (row-block geometry the packed format is built on)
 int select_pk(hipxMat A, bool &vd, bool &rowpar, int &rpt, int &cfg)
@@ -1313,6 +1658,12 @@ int launch_pk16(hipxMat A, const double *x, const double *yin, double *yout, dou
 template <typename IT, int MODE, bool DOT>
 int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
 {
+  {
+    bool tm = false;
+    int  ierr = use_templates(A, tm);
+    if (ierr) return ierr;
+    if (tm) return launch_tmpl<MODE, DOT>(A, x, yin, yout, dotpart, nullptr);
+  }
   if (A->tile_mode >= 2 && !A->compressed && (!A->probe || A->vd_mode)) return launch_pk16<IT, MODE, DOT>(A, x, yin, yout, dotpart);
   if (A->probe && MODE == 0 && !DOT && !A->compressed && !A->is64) {
     int ierr = ensure_row_blocks(A, 0);
@@ -1337,6 +1688,12 @@ int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, d
 int dot_partials_count(hipxMat A, hipx_int *npart)
 {
   int cfg, waves;
+  {
+    bool tm = false;
+    int  ierr = use_templates(A, tm);
+    if (ierr) return ierr;
+    if (tm) return launch_tmpl<0, true>(A, nullptr, nullptr, nullptr, nullptr, npart);
+  }
   if (A->tile_mode >= 2 && !A->compressed && (!A->probe || A->vd_mode)) {
     bool vd, rowpar;
     int  rpt;
@@ -1424,6 +1781,7 @@ int hipxMatUpdateValues(hipxMat A, const double *a)
   if (A->nnz) HIPX_HIP(hipMemcpyAsync(A->d_a, a, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice, rt().compute));
   HIPX_HIP(hipStreamSynchronize(rt().compute));
   A->vd_ready = false;  // the value dictionary is rebuilt at the next product
+  A->tmpl_ready = false;  // ... and so are the row templates
   A->value_state++;  // SOR's level-ordered copy and inverse diagonal must be rebuilt (aij.c:1807 idiagState)
   hipxSorInvalidate_(A->sor_state);
   return HIPX_SUCCESS;
@@ -1450,6 +1808,7 @@ int hipxMatDestroy(hipxMat *pA)
   (void)hipFree(A->d_pkdesc);
   (void)hipFree(A->d_vc);
   (void)hipFree(A->d_vdict);
+  free_templates(A);
   hipxSorStateFree_(A->sor_state);
   delete A;
   *pA = nullptr;
@@ -1476,6 +1835,30 @@ int hipxMatInternal_(hipxMat A, hipx_int *m, hipx_int *n, int64_t *nnz, int *is6
   return HIPX_SUCCESS;
 }
 
+// internal accessor for hipx_sor.hip: the row templates (host tables + device ids), built on demand; *ok = 0 when the matrix
+// has none
+int hipxMatTemplates_(hipxMat A, int *ok, int *ntmpl, const int **tstart, const int **toff, const double **tval, const int **tdiag, const int64_t **tcount,
+                      const unsigned char **d_tid)
+{
+  HIPX_ARG(A, "null matrix");
+  *ok = 0;
+  if (A->compressed || A->nrows_c <= 0) return HIPX_SUCCESS;
+  int ierr;
+  if ((ierr = ensure_vdict(A))) return ierr;
+  if (!A->vd_ok) return HIPX_SUCCESS;
+  if ((ierr = ensure_templates(A))) return ierr;
+  if (!A->tmpl_ok) return HIPX_SUCCESS;
+  *ok     = 1;
+  *ntmpl  = A->ntmpl;
+  *tstart = A->h_tstart.data();
+  *toff   = A->h_toff.data();
+  *tval   = A->h_tval.data();
+  *tdiag  = A->h_tdiag.data();
+  *tcount = A->h_tcount.data();
+  *d_tid  = A->d_tid;
+  return HIPX_SUCCESS;
+}
+
 int hipxMatGetInfo(hipxMat A, hipx_int *m, hipx_int *n, int64_t *nnz, int64_t *device_bytes)
 {
   HIPX_ARG(A, "null matrix");
@@ -1492,14 +1875,17 @@ int hipxMatSetSpMVVariant(hipxMat A, int variant)
   A->probe      = variant / 1000;  // 1000/2000/3000 + v: probe kernels
   variant %= 1000;
   // 22: packed columns, 23: packed columns + row-parallel gather, 24 / 25: the same two with the value dictionary
-  A->tile_mode = (variant == 22 || variant == 24) ? 2 : (variant == 23 || variant == 25) ? 3 : 0;
-  A->vd_mode   = (variant == 24 || variant == 25) ? 1 : 0;
+  // 26: row templates (falls back to 25 when the matrix has more than 256 distinct rows)
+  A->tile_mode = (variant == 22 || variant == 24) ? 2 : (variant == 23 || variant == 25 || variant == 26) ? 3 : 0;
+  A->vd_mode   = (variant == 24 || variant == 25 || variant == 26) ? 1 : 0;
+  A->tmpl_mode = (variant == 26) ? 1 : 0;
   A->auto_sel = (variant == 0);
   if (variant == 0) {
     A->tile_mode = auto_tile_mode(A);
     A->vd_mode   = A->tile_mode ? 1 : 0;
+    A->tmpl_mode = A->tile_mode ? 1 : 0;
   }
-  if (variant >= 22 && variant <= 25) variant = 1;
+  if (variant >= 22 && variant <= 26) variant = 1;
   A->sched_mode = variant >= 100 ? 1 : 0;
   variant %= 100;
   HIPX_ARG(variant <= 2 * kNumCfg, "unknown SpMV variant");
@@ -1518,7 +1904,13 @@ int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
   HIPX_CHECK_INIT();
   HIPX_ARG(A && buf && len > 0, "null argument");
   const char *name = "spmv_stream_kernel (CSR MatMult, 32-bit columns)";
-  if (A->tile_mode >= 2 && !A->compressed && !A->probe) {
+  bool        tm   = false;
+  {
+    int ierr = use_templates(A, tm);
+    if (ierr) return ierr;
+  }
+  if (tm) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row)";
+  else if (A->tile_mode >= 2 && !A->compressed && !A->probe) {
     bool vd, rowpar;
     int  rpt, cfg;
     int  ierr = select_pk(A, vd, rowpar, rpt, cfg);

@@ -37,7 +37,7 @@ def spmv_gpu(hx, ai, aj, aa, x, ncols=None, variant=0, y0=None):
 
 @pytest.mark.parametrize("kind,n,m", [("5pt", 100, 100), ("5pt", 7, 8), ("7pt", 1, None), ("7pt", 2, None), ("7pt", 33, None), ("7pt", 64, None),
                                        ("27pt", 3, None), ("27pt", 17, None), ("27pt", 40, None)])
-@pytest.mark.parametrize("variant", [1, 2, 3, 22, 23, 24, 25, 101])
+@pytest.mark.parametrize("variant", [1, 2, 3, 22, 23, 24, 25, 26, 101])
 def test_stencil_spmv_bit_exact(hx, kind, n, m, variant):
     ai, aj, aa = orc.stencil(kind, n, m=m)
     N = len(ai) - 1
@@ -61,7 +61,7 @@ def random_csr(m, n, rng, maxlen, empty_frac=0.2):
 
 
 @pytest.mark.parametrize("seed,m,n,maxlen", [(0, 1, 1, 1), (1, 17, 29, 5), (2, 1000, 777, 40), (3, 5000, 5000, 8), (4, 300, 4000, 300), (5, 257, 100, 0), (7, 2000, 9000, 160)])
-@pytest.mark.parametrize("variant", [1, 22, 23, 24, 25])
+@pytest.mark.parametrize("variant", [1, 22, 23, 24, 25, 26])
 def test_ragged_rows_bit_exact_and_multadd(hx, seed, m, n, maxlen, variant):
     rng = np.random.default_rng(seed)
     ai, aj, aa = random_csr(m, n, rng, maxlen)
@@ -119,10 +119,10 @@ def test_value_dictionary_ragged_rows_bit_exact(hx, seed, m, n, maxlen, variant)
 
 def test_auto_variant_selects_packed_kernels(hx):
     """variant 0 on >= 2^20 nonzeros: short rows -> row-parallel packed kernel, long rows -> staged packed kernel; constant
-    coefficient stencils get the value dictionary, matrices with distinct values do not.  (Guards the default path.)"""
+    coefficient stencils get the row templates (1 byte per row), matrices with distinct values do not.  (Guards the default path.)"""
     from petsc_amd import _lib
     rng = np.random.default_rng(3)
-    for kind, n, want in [("7pt", 56, "spmv_vd_kernel"), ("27pt", 36, "spmv_vd_kernel")]:
+    for kind, n, want in [("7pt", 56, "spmv_tmpl_kernel"), ("27pt", 36, "spmv_tmpl_kernel")]:
         ai, aj, aa = orc.stencil(kind, n)
         N = len(ai) - 1
         x = xvec(N)
@@ -137,6 +137,47 @@ def test_auto_variant_selects_packed_kernels(hx):
             X.free()
             Y.free()
             _lib.mat_destroy(A)
+
+
+@pytest.mark.parametrize("kind,n,m", [("5pt", 31, 17), ("7pt", 21, None), ("27pt", 14, None)])
+def test_row_templates_kernel_selected_and_bit_exact(hx, kind, n, m):
+    """Variant 26: stencil matrices are stored as one template id per row.  Same doubles, same left-to-right row sums ->
+    bit-identical MatMult / MatMultAdd / fused dot; new values (hipxMatUpdateValues) rebuild the templates; values that
+    make every row distinct fall back to the general packed kernels; 64-bit row offsets take the same path."""
+    from petsc_amd import _lib
+    rng = np.random.default_rng(5)
+    ai, aj, aa = orc.stencil(kind, n, m=m)
+    N = len(ai) - 1
+    x = rng.standard_normal(N)
+    for wide in (False, True):
+        A = _lib.mat_create_csr(N, N, ai.astype(np.int64) if wide else ai, aj, aa)
+        _lib.chk(hx.hipxMatSetSpMVVariant(A, 26))
+        assert kernel_name(hx, A).startswith("spmv_tmpl_kernel "), kernel_name(hx, A)
+        X, Y, Y0 = _lib.DVec(N, x), _lib.DVec(N), _lib.DVec(N, x[::-1].copy())
+        _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+        yr = orc.matmult(ai, aj, aa, x)
+        assert np.array_equal(Y.get(), yr)
+        _lib.chk(hx.hipxMatMultAdd(A, X.ptr, Y0.ptr, Y.ptr))
+        zr = np.zeros(N)
+        orc.lib().orc_MatMultAdd_SeqAIJ(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(x[::-1].copy()), orc.P(zr))
+        assert np.array_equal(Y.get(), zr)
+        dot = C.c_double()
+        _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(dot)))
+        assert np.array_equal(Y.get(), yr) and abs(dot.value - float(x @ yr)) <= 1e-12 * np.abs(x * yr).sum()
+        aa2 = aa * 0.75                                                   # other values, same templates' shape
+        _lib.chk(hx.hipxMatUpdateValues(A, orc.P(aa2)))
+        assert kernel_name(hx, A).startswith("spmv_tmpl_kernel ")
+        _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+        assert np.array_equal(Y.get(), orc.matmult(ai, aj, aa2, x))
+        if N > 300:
+            aa3 = aa * (1.0 + 1e-3 * rng.standard_normal(aa.size))       # every row distinct: no templates
+            _lib.chk(hx.hipxMatUpdateValues(A, orc.P(aa3)))
+            assert not kernel_name(hx, A).startswith("spmv_tmpl_kernel ")
+            _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+            assert np.array_equal(Y.get(), orc.matmult(ai, aj, aa3, x))
+        for v in (X, Y, Y0):
+            v.free()
+        _lib.mat_destroy(A)
 
 
 def test_long_rows_beyond_lds_tile(hx):
@@ -279,6 +320,14 @@ def test_full_size_7pt_256_properties(hx):
         for k in range(ai[r], ai[r + 1]):
             s += aa[k] * x[aj[k]]
         assert y[r] == s
+    assert kernel_name(hx, A).startswith("spmv_tmpl_kernel ")
+    for variant in (25, 23, 1):  # every kernel form gives the same 16.7 M doubles, bit for bit
+        _lib.chk(hx.hipxMatSetSpMVVariant(A, variant))
+        Yv = _lib.DVec(N)
+        _lib.chk(hx.hipxMatMult(A, X.ptr, Yv.ptr))
+        assert np.array_equal(Yv.get(), y), variant
+        Yv.free()
+    _lib.chk(hx.hipxMatSetSpMVVariant(A, 0))
     d1, d2 = C.c_double(), C.c_double()
     W = _lib.DVec(N, ones)
     _lib.chk(hx.hipxVecDot(W.ptr, Y.ptr, N, C.byref(d1)))  # 1 . (A x)
