@@ -2,23 +2,39 @@
 """bench.py -- the BASELINE.json metric: CG iterations/s (+ SpMV achieved HBM GB/s) on 3-D 7-point Poisson 256^3, fp64,
 KSPCG + PCJACOBI, MATAIJHIPX/VECHIPX kernels, on N GPUs of one node (strong scaling: the 256^3 problem is split by rows).
 
-A "step" is one CG iteration (one pass of the loop body cg.c:220-349: MatMult, 2 dots, 1 norm, 2 AXPY, 1 AYPX, PCApply).
-Inputs (CSR matrix, b = A*1, x0 = 0) are resident in HBM before the timed region.
+A "step" is one Krylov iteration (CG: one pass of the loop body cg.c:220-349 -- MatMult, 2 dots, 1 norm, 2 AXPY, 1 AYPX,
+PCApply; GMRES: one pass of gmres.c:123-166).  Inputs (CSR matrix, b = A*1, x0 = 0) are resident in HBM before the timed
+region.  No per-launch events are recorded inside the timed region; kernel durations come from a second pass of the same K steps.
 
-  python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus 1 --steps 200 --warmup 20                                  # BASELINE config 2 (default)
+  python bench.py --ksp gmres --pc sor --stencil 27 --grid 256                       # config 3's solver on one GPU
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  ... --gpus 8 --stencil 27 --grid 512 --ksp gmres --pc sor                          # config 3
+  ... --gpus 8 --grid 1024 --scaling weak --pc none                                  # config 5: 1024 x 1024 x 128 rows per GPU
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (CSR SpMV): algorithmic bytes per launch / mean launch duration measured with HIP events
-                  on the compute stream inside the timed region, against the 8 TB/s HBM3E peak
-  cpu_baseline -- the CPU oracle (scalar restatement of the reference path, 1 core) timed on a bounded sample of the same
-                  workload on this host (rank 0, N = 1 only)
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  parity_gate      -- BASELINE.md 3.5: the first 24 iterations of THIS configuration on the GPU against the reference's own
+                      KSPSolve on the host (oracle/_ref), entry by entry; `value` is null when the gate fails
+  roofline         -- dominant kernel (the CSR SpMV the solver launches): HIP-event launch time; `frac` = HBM bytes the kernel
+                      really moves (rocprofv3 PMC passes run from inside this script, see `traffic_source`) / time / 8 TB/s;
+                      `effective_gbps` = algorithmic CSR bytes / time
+  roofline_general -- the same for the general-valued CSR kernel (packed 16-bit columns, no value dictionary / row templates:
+                      what a matrix with arbitrary values gets), timed in this run
+  plugin           -- the drop-in itself: the reference's executable + libpetschipx.so (KSPSolve_CG over the hipx types, and
+                      -ksp_type cghipx), its/s of KSPSolve
+  cpu_baseline     -- the reference's own KSPSolve (oracle/_ref) on this host: P = physical cores (mpiexec) and 1 core
 """
 import argparse
 import ctypes as C
+import csv
+import glob
 import json
 import os
+import re
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,60 +43,274 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); measured copy peak is 6290
+GATE_ITS = 24
+GATE_TOL = 1e-12       # north_star: residual history within 1e-12 relative, per entry
 
 
-def assemble(ks, stencil, n, rs, re):
-    f = {7: ks.HipxAssemble_poisson7, 27: ks.HipxAssemble_bench27}[stencil]
-    nz = f(n, rs, re, None, None, None)
-    wide = nz >= 2 ** 31 - 8  # 64-bit row offsets (27-pt 512^3 / 7-pt 1024^3 on one rank)
-    if wide:
-        f = {7: ks.HipxAssemble_poisson7_64, 27: ks.HipxAssemble_bench27_64}[stencil]
+def assemble(ks, stencil, dims, rs, re):
+    nx, ny, nz = dims
+    cube = nx == ny == nz
+    if stencil == 7:
+        def f(ai, ai64, aj, aa):
+            return ks.HipxAssemble_poisson7_box(nx, ny, nz, rs, re, ai, ai64, aj, aa)
+    else:
+        assert cube, "the 27-point operator of bench_kspsolve.c is defined on a cube"
+
+        def f(ai, ai64, aj, aa):
+            if ai64 is not None:
+                return ks.HipxAssemble_bench27_64(nx, rs, re, ai64, aj, aa)
+            return ks.HipxAssemble_bench27(nx, rs, re, ai, aj, aa)
+    nnz = f(None, None, None, None)
+    wide = nnz >= 2 ** 31 - 8  # 64-bit row offsets (27-pt 512^3 / 7-pt 1024^3 on one rank)
     ai = np.zeros(re - rs + 1, np.int64 if wide else np.int32)
-    aj = np.zeros(nz, np.int32)
-    aa = np.zeros(nz, np.float64)
-    f(n, rs, re, ai.ctypes.data_as(C.c_void_p), aj.ctypes.data_as(C.c_void_p), aa.ctypes.data_as(C.c_void_p))
+    aj = np.zeros(nnz, np.int32)
+    aa = np.zeros(nnz, np.float64)
+    p = ai.ctypes.data_as(C.c_void_p)
+    f(None if wide else p, p if wide else None, aj.ctypes.data_as(C.c_void_p), aa.ctypes.data_as(C.c_void_p))
     return ai, aj, aa
 
 
-def cpu_baseline_reference(stencil, n, its):
-    """The REFERENCE itself (oracle/_ref: libpetsc compiled from /root/reference by oracle/build_ref.py) on the host:
-    its own MatSetValues assembly, KSPSolve_CG, MatMult_SeqAIJ, PCJACOBI, MKL BLAS-1 -- one rank (MPIUNI), one thread."""
-    import re
-    import subprocess
-    exe = os.path.join(ROOT, "oracle", "_ref", "bin", "ref_driver")
+def physical_cores():
+    """Physical cores this process may use: distinct (package, core) pairs among the CPUs of its affinity mask."""
+    allowed = os.sched_getaffinity(0)
+    cores = set()
+    for c in allowed:
+        try:
+            pkg = open("/sys/devices/system/cpu/cpu%d/topology/physical_package_id" % c).read().strip()
+            core = open("/sys/devices/system/cpu/cpu%d/topology/core_id" % c).read().strip()
+            cores.add((pkg, core))
+        except OSError:
+            cores.add(("?", str(c)))
+    return max(1, len(cores))
+
+
+def ref_driver(np_, args, plugin=False, timeout=900):
+    """The REFERENCE itself (oracle/_ref: libpetsc compiled from /root/reference by oracle/build_ref.py): its own MatSetValues
+    assembly, KSPSolve, MatMult_SeqAIJ / _MPIAIJ, PCJACOBI / PCSOR, MKL BLAS-1 (one thread per rank)."""
+    mp = np_ > 1
+    exe = os.path.join(ROOT, "oracle", "_ref", "mpich" if mp else "", "bin", "ref_driver")
     if not os.path.exists(exe):
         return None
-    env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
-    cmd = [exe, "-stencil", str(stencil), "-n", str(n), "-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_rtol", "1e-50", "-ksp_max_it", str(its),
-           "-mat_type", "aij", "-vec_type", "standard"]
+    cmd = (["/opt/conda/bin/mpiexec", "-n", str(np_)] if mp else []) + [exe] + args
+    if plugin:
+        so = os.path.join(ROOT, "petsc_amd", "lib", "libpetschipx_mpich.so" if mp else "libpetschipx.so")
+        if not os.path.exists(so):
+            return None
+        cmd += ["-dll_prepend", so, "-vec_type", "hipx", "-mat_type", "aijhipx"]
+    else:
+        cmd += ["-mat_type", "aij", "-vec_type", "standard"]
+    env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1", HIPX_NO_TORCH="1")
     try:
-        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600).stdout
-        m = re.search(r"iterations (\d+) reason (-?\d+) error \S+ KSPSolve_seconds (\S+)", out)
-        done, secs = int(m.group(1)), float(m.group(3))
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=timeout).stdout
+        m = re.search(r"iterations (\d+) reason (-?\d+) error (\S+) KSPSolve_seconds (\S+)", out)
+        hist = [float(l.split()[2]) for l in out.splitlines() if l.startswith("hist ")]
+        return {"its": int(m.group(1)), "reason": int(m.group(2)), "error": float(m.group(3)), "seconds": float(m.group(4)), "history": hist}
     except Exception:
         return None
-    return {"value": done / secs, "unit": "CG iterations/s", "cores": 1, "kind": "reference",
-            "sample": "%d iterations of the reference's own KSPSolve (KSPCG + PCJACOBI, MATSEQAIJ, VECSEQ, MKL BLAS single-threaded, gcc -O2; oracle/_ref) "
-                      "on the same %d-pt %d^3 system; KSPSolve wall %.3f s, assembly excluded" % (done, stencil, n, secs)}
 
 
-def cpu_baseline(ai, aj, aa, b, budget_s, stencil, n):
-    """Oracle CG + Jacobi on the same system, bounded to ~budget_s seconds of CPU work.  Checker code, timed as a baseline."""
+def solver_args(args, its):
+    a = ["-stencil", str(args.stencil), "-n", str(args.n), "-ksp_type", args.ksp, "-pc_type", args.pc, "-ksp_rtol", "1e-50", "-ksp_max_it", str(its)]
+    if args.ksp == "cg":
+        a += ["-ksp_norm_type", "preconditioned"]
+    return a
+
+
+def oracle_port_baseline(ai, aj, aa, b, budget_s, stencil, n):
+    """Fallback when oracle/_ref is not on the box: the oracle's scalar C restatement.  Checker code, timed as a baseline."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     t0 = time.perf_counter()
     orc.ksp_solve("cg", ai, aj, aa, b, pc="jacobi", rtol=1e-50, max_it=2)
-    t2 = time.perf_counter() - t0  # includes set-up + 2 iterations
+    t2 = time.perf_counter() - t0
     its = int(max(3, min(60, budget_s / max(t2 / 3.0, 1e-3))))
     t0 = time.perf_counter()
-    _, done, _, _ = orc.ksp_solve("cg", ai, aj, aa, b, pc="jacobi", rtol=1e-50, max_it=its)
+    _, done, _, hist = orc.ksp_solve("cg", ai, aj, aa, b, pc="jacobi", rtol=1e-50, max_it=its)
     t_its = time.perf_counter() - t0
     t0 = time.perf_counter()
     orc.ksp_solve("cg", ai, aj, aa, b, pc="jacobi", rtol=1e-50, max_it=1)
     t_one = time.perf_counter() - t0
     per_it = (t_its - t_one) / max(done - 1, 1)
-    return {"value": 1.0 / per_it, "unit": "CG iterations/s", "cores": 1, "kind": "port",
-            "sample": "%d CG+Jacobi iterations of the oracle (scalar C restatement of cg.c/aij.c, gcc -O2) on the same %d-pt %d^3 system" % (done, stencil, n)}
+    return {"value": 1.0 / per_it, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": "%d CG+Jacobi iterations of the oracle (scalar C restatement of cg.c/aij.c, gcc -O2) on the same %d-pt %d^3 system" % (done, stencil, n)}, hist
+
+
+class Problem:
+    """One rank's share of the system on the device + the solver objects of the C host layer."""
+
+    def __init__(self, args, rank, world, dist):
+        from petsc_amd import _lib
+        from petsc_amd import dist as pdist
+        self.lib, self.args, self.world = _lib, args, world
+        self.hx, self.ks = _lib.load()
+        n = args.n
+        self.dims = (n, n, n) if args.scaling == "strong" else (n, n, (n // 8) * world)  # weak: config 5 = n x n x n/8 rows per GPU
+        self.N = self.dims[0] * self.dims[1] * self.dims[2]
+        ranges = pdist.split_ownership(self.N, world)
+        rs, re = int(ranges[rank]), int(ranges[rank + 1])
+        self.ai, self.aj, self.aa = assemble(self.ks, args.stencil, self.dims, rs, re)
+        self.m = re - rs
+        if world > 1:
+            plan = pdist.build_plan(self.ai, self.aj, self.aa, ranges, rank, dist=dist)
+            self.M, self.keep = pdist.create_device_mat(plan, world)
+            self.nnz_local = int(plan["Ai"][-1])
+        else:
+            A = _lib.mat_create_csr(self.m, self.m, self.ai, self.aj, self.aa)
+            self.M, self.keep = _lib.HipxMat(m=self.m, A=A, B=None, halo=None, lvec=None, nranks=1), [A]
+            self.nnz_local = int(self.ai[-1])
+        self.ones = _lib.DVec(self.m, np.ones(self.m))
+        self.B = _lib.DVec(self.m)
+        self.X = _lib.DVec(self.m)
+        _lib.chk(self.ks.HipxMatMult(C.byref(self.M), self.ones.ptr, self.B.ptr))  # b = A * 1 (ex2.c:139 style)
+        self.pc = None
+        self.ksp = None
+
+    def setup(self, variant, no_dconst=False):
+        lib, ks, args = self.lib, self.ks, self.args
+        lib.chk(self.hx.hipxMatSetSpMVVariant(self.M.A, variant))
+        if no_dconst:
+            os.environ["HIPX_NO_DCONST"] = "1"
+        else:
+            os.environ.pop("HIPX_NO_DCONST", None)
+        if self.pc is not None:
+            ks.HipxKSPDestroyWork(C.byref(self.ksp))
+            ks.HipxPCDestroy(C.byref(self.pc))
+        self.pc = lib.HipxPC()
+        ks.HipxPCSetDefaults(C.byref(self.pc))
+        self.pc.type = {"none": 0, "jacobi": 1, "sor": 2}[args.pc]
+        lib.chk(ks.HipxPCSetUp(C.byref(self.pc), C.byref(self.M)))
+        self.ksp = lib.HipxKSP()
+        ks.HipxKSPSetDefaults(C.byref(self.ksp))
+        self.ksp.rtol, self.ksp.abstol, self.ksp.divtol = 1e-50, 1e-300, 1e300
+        self.ksp.fused, self.ksp.pipeline = args.fused, args.pipeline
+        kbuf = C.create_string_buffer(256)
+        lib.chk(self.hx.hipxMatGetSpMVKernel(self.M.A, kbuf, 256))
+        return kbuf.value.decode()
+
+    def solve(self, its, history=False):
+        """A fresh solve of exactly `its` iterations from x0 = 0 (rtol = 1e-50: never converges earlier)."""
+        lib, ks = self.lib, self.ks
+        self.ksp.max_it = its
+        hist = np.zeros(its + 8)
+        if history:
+            self.ksp.history, self.ksp.hist_len = hist.ctypes.data, len(hist)
+        else:
+            self.ksp.history, self.ksp.hist_len = None, 0
+        lib.chk(self.hx.hipxVecSet(self.X.ptr, self.m, 0.0))
+        f = ks.HipxKSPSolve_CG if self.args.ksp == "cg" else ks.HipxKSPSolve_GMRES
+        lib.chk(f(C.byref(self.ksp), C.byref(self.M), C.byref(self.pc), self.B.ptr, self.X.ptr))
+        assert self.ksp.its == its and self.ksp.reason == -3, (self.ksp.its, self.ksp.reason)
+        return hist[:self.ksp.hist_n].copy()
+
+    def begin(self, total_its):
+        self.ksp.max_it = total_its
+        self.ksp.history, self.ksp.hist_len = None, 0
+        self.lib.chk(self.hx.hipxVecSet(self.X.ptr, self.m, 0.0))
+        self.lib.chk(self.ks.HipxKSPCGBegin(C.byref(self.ksp), C.byref(self.M), C.byref(self.pc), self.B.ptr, self.X.ptr))
+
+    def step(self, k):
+        self.lib.chk(self.ks.HipxKSPCGStep(C.byref(self.ksp), C.byref(self.M), C.byref(self.pc), self.B.ptr, self.X.ptr, k))
+        assert self.ksp.reason == 0, self.ksp.reason
+
+    def spmv_bytes(self):
+        return 12 * self.nnz_local + (8 if self.ai.dtype == np.int64 else 4) * (self.m + 1) + 16 * self.m  # SURVEY 8(d)
+
+
+def timed_steps(P, args, sync, dist, torch):
+    """W untimed + K timed iterations (max over ranks), then the same K again with HIP events around every SpMV launch."""
+    hx, lib = P.hx, P.lib
+    if args.ksp == "cg":
+        P.begin(args.warmup + 2 * args.steps + 10)
+        P.step(args.warmup)
+        sync()
+        t0 = time.perf_counter()
+        P.step(args.steps)
+        sync()
+        elapsed = time.perf_counter() - t0
+        lib.chk(hx.hipxProfileSpMV(1))
+        P.step(args.steps)
+        sync()
+    else:  # GMRES: a solve of exactly K iterations from x0 = 0 (restarts, solution update and work-vector set-up included)
+        P.solve(max(args.warmup, 1))
+        sync()
+        t0 = time.perf_counter()
+        P.solve(args.steps)
+        sync()
+        elapsed = time.perf_counter() - t0
+        lib.chk(hx.hipxProfileSpMV(1))
+        P.solve(args.steps)
+        sync()
+    cnt, tot_ms = C.c_int(), C.c_double()
+    lib.chk(hx.hipxProfileSpMVGet(C.byref(cnt), C.byref(tot_ms)))
+    lib.chk(hx.hipxProfileSpMV(0))
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    return elapsed, tot_ms.value / max(cnt.value, 1), cnt.value, float(P.ksp.rnorm)
+
+
+def pmc_traffic(args, variant, kernel_prefix):
+    """HBM bytes per launch of the SpMV kernel: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate passes, only
+    --kernel-trace beside them) over `bench.py --spmv-only`, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section)
+    prescribes for gfx950: read bytes = 2 x FETCH_SIZE KiB x 1024; write bytes = WRITE_SIZE KiB x 1024.  The same passes also
+    measure an AXPY of known size as a calibration of that correction."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="hipx_pmc_")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--spmv-only", "6", "--grid", str(args.n), "--stencil", str(args.stencil), "--variant", str(variant)]
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240, cwd=tmp, env=dict(os.environ, TMPDIR=tmp))
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            per = {}
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != ctr:
+                    continue
+                key = "spmv" if kernel_prefix in row["Kernel_Name"] else "copy" if "ew2_kernel" in row["Kernel_Name"] else None
+                if key:
+                    per.setdefault(key, {}).setdefault(row["Dispatch_Id"], 0.0)
+                    per[key][row["Dispatch_Id"]] += float(row["Counter_Value"])
+            for key, v in per.items():
+                out[(key, ctr)] = sum(v.values()) / len(v)
+                out[(key, "n")] = len(v)
+        if ("spmv", "FETCH_SIZE") not in out or ("spmv", "WRITE_SIZE") not in out:
+            return None
+        res = {"bytes": int(2 * out[("spmv", "FETCH_SIZE")] * 1024 + out[("spmv", "WRITE_SIZE")] * 1024),
+               "FETCH_SIZE_KiB": out[("spmv", "FETCH_SIZE")], "WRITE_SIZE_KiB": out[("spmv", "WRITE_SIZE")], "launches_sampled": out[("spmv", "n")]}
+        if ("copy", "FETCH_SIZE") in out:
+            nbytes = 8 * args.n ** 3
+            res["calibration"] = {"kernel": "hipxVecAXPY on %d doubles (reads %d B, writes %d B)" % (args.n ** 3, 2 * nbytes, nbytes),
+                                  "read_bytes_over_FETCH_SIZE": 2 * nbytes / (out[("copy", "FETCH_SIZE")] * 1024),
+                                  "write_bytes_over_WRITE_SIZE": nbytes / (out[("copy", "WRITE_SIZE")] * 1024) if out.get(("copy", "WRITE_SIZE")) else None}
+        return res
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def spmv_only(args):
+    """Internal mode for the PMC passes: set up the matrix, launch the SpMV kernel (and an AXPY of known size) a few times."""
+    from petsc_amd import _lib
+    hx = _lib.init(0)
+    _, ks = _lib.load()
+    n = args.n
+    N = n ** 3
+    ai, aj, aa = assemble(ks, args.stencil, (n, n, n), 0, N)
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    _lib.chk(hx.hipxMatSetSpMVVariant(A, args.variant))
+    X, Y = _lib.DVec(N, 1.0 + (np.arange(N) % 17) / 17.0), _lib.DVec(N)
+    for _ in range(args.spmv_only):
+        _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+        _lib.chk(hx.hipxVecAXPY(Y.ptr, 0.5, X.ptr, N))  # calibration of the FETCH_SIZE / WRITE_SIZE correction: 2 N doubles read, N written
+    _lib.chk(hx.hipxDeviceSynchronize())
 
 
 def main():
@@ -90,12 +320,24 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--grid", dest="n", type=int, default=256, help="grid points per side (not --n: torchrun would read it as an abbreviation of its own options)")
     ap.add_argument("--stencil", type=int, default=7, choices=[7, 27])
+    ap.add_argument("--ksp", default="cg", choices=["cg", "gmres"])
+    ap.add_argument("--pc", default="jacobi", choices=["jacobi", "sor", "none"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="weak: every GPU owns grid x grid x grid/8 rows (config 5: --grid 1024)")
     ap.add_argument("--fused", type=int, default=1, help="1 (default): fused SpMV+dot and AXPY+AXPY+PCJACOBI+norm+dot kernels -- same arithmetic and order per element, fewer HBM passes; 0: one kernel per reference Vec/Mat call (cg.c:249-344)")
     ap.add_argument("--pipeline", type=int, default=1, help="1 (default): launch-ahead fused CG (iteration i+1 enqueued before the host has seen iteration i's sums; device-resident scalars); 0: host waits between kernels")
-    ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (include/hipx.h hipxMatSetSpMVVariant): 0 auto, 1 32-bit-column stream kernel, 22/23 packed 16-bit columns, 24/25 packed columns + 8-bit value dictionary")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (include/hipx.h hipxMatSetSpMVVariant): 0 auto, 1 32-bit-column stream kernel, 22/23 packed 16-bit columns, 24/25 + 8-bit value dictionary, 26 row templates")
+    ap.add_argument("--general-variant", type=int, default=23, help="kernel of the roofline_general leg (what a matrix with arbitrary values gets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic then comes from profiles/spmv_traffic.json)")
+    ap.add_argument("--no-plugin", action="store_true")
+    ap.add_argument("--no-general", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="the timed legs only: no plugin / PMC / CPU-baseline / general-kernel legs")
+    ap.add_argument("--spmv-only", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.spmv_only:
+        return spmv_only(args)
+    if args.quick:
+        args.no_cpu_baseline = args.no_traffic = args.no_plugin = args.no_general = True
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,15 +353,7 @@ def main():
     assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch N > 1 with torch.distributed.run)"
 
     from petsc_amd import _lib
-    from petsc_amd import dist as pdist
     hx = _lib.init(local_rank)
-    _, ks = _lib.load()
-
-    n, N = args.n, args.n ** 3
-    ranges = pdist.split_ownership(N, world)
-    rs, re = int(ranges[rank]), int(ranges[rank + 1])
-    ai, aj, aa = assemble(ks, args.stencil, n, rs, re)
-    m = re - rs
     if world > 1:
         idb = (C.c_char * 256)()
         if rank == 0:
@@ -127,32 +361,8 @@ def main():
         box = [bytes(idb)]
         dist.broadcast_object_list(box, src=0)
         _lib.chk(hx.hipxCommInit(box[0], rank, world))
-        plan = pdist.build_plan(ai, aj, aa, ranges, rank, dist=dist)
-        M, keep = pdist.create_device_mat(plan, world)
-        nnz_local = int(plan["Ai"][-1])
-    else:
-        A = _lib.mat_create_csr(m, m, ai, aj, aa)
-        M, keep = _lib.HipxMat(m=m, A=A, B=None, halo=None, lvec=None, nranks=1), [A]
-        nnz_local = int(ai[-1])
-    _lib.chk(hx.hipxMatSetSpMVVariant(M.A, args.variant))
-
-    # b = A * 1 (ex2.c:139 style), x0 = 0
-    ones = _lib.DVec(m, np.ones(m))
-    B = _lib.DVec(m)
-    X = _lib.DVec(m)
-    _lib.chk(ks.HipxMatMult(C.byref(M), ones.ptr, B.ptr))
-    pc = _lib.HipxPC()
-    ks.HipxPCSetDefaults(C.byref(pc))
-    _lib.chk(ks.HipxPCSetUp(C.byref(pc), C.byref(M)))
-    ksp = _lib.HipxKSP()
-    ks.HipxKSPSetDefaults(C.byref(ksp))
-    ksp.rtol, ksp.abstol, ksp.divtol = 1e-50, 1e-300, 1e300
-    ksp.max_it = args.warmup + args.steps + 10
-    ksp.fused = args.fused
-    ksp.pipeline = args.pipeline
-    _lib.chk(ks.HipxKSPCGBegin(C.byref(ksp), C.byref(M), C.byref(pc), B.ptr, X.ptr))
-    _lib.chk(ks.HipxKSPCGStep(C.byref(ksp), C.byref(M), C.byref(pc), B.ptr, X.ptr, args.warmup))
-    assert ksp.reason == 0 and ksp.its == args.warmup, (ksp.reason, ksp.its)
+    P = Problem(args, rank, world, dist)
+    n, N = args.n, P.N
 
     def sync():
         _lib.chk(hx.hipxDeviceSynchronize())
@@ -160,65 +370,112 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    _lib.chk(hx.hipxProfileSpMV(1))
-    sync()
-    t0 = time.perf_counter()
-    _lib.chk(ks.HipxKSPCGStep(C.byref(ksp), C.byref(M), C.byref(pc), B.ptr, X.ptr, args.steps))
-    sync()
-    elapsed = time.perf_counter() - t0
-    assert ksp.reason == 0 and ksp.its == args.warmup + args.steps, (ksp.reason, ksp.its)
-    cnt, tot_ms = C.c_int(), C.c_double()
-    _lib.chk(hx.hipxProfileSpMVGet(C.byref(cnt), C.byref(tot_ms)))
-    _lib.chk(hx.hipxProfileSpMV(0))
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-    rnorm = float(ksp.rnorm)
+    kname = P.setup(args.variant)
+    # ---- parity gate: this configuration's first iterations against the reference's own KSPSolve
+    gate = {"iterations": GATE_ITS, "tolerance": GATE_TOL, "max_rel_diff": None, "pass": None, "reference": None}
+    ref1 = None
+    cube = args.scaling == "strong"
+    if world == 1 and cube and not args.no_cpu_baseline and N <= 2 ** 25:
+        ref1 = ref_driver(1, solver_args(args, GATE_ITS) + ["-history"])
+    if world == 1 and ref1 is not None and len(ref1["history"]) > 0:
+        hist = P.solve(GATE_ITS, history=True)
+        href = np.array(ref1["history"])
+        if len(hist) == len(href):
+            rel = float((np.abs(hist - href) / np.abs(href)).max())
+            gate.update({"max_rel_diff": rel, "pass": bool(rel <= GATE_TOL), "reference": "oracle/_ref ref_driver (the reference's KSPSolve, MATSEQAIJ/VECSEQ), %d history entries" % len(href)})
+        else:
+            gate.update({"pass": False, "reference": "history lengths differ: %d vs %d" % (len(hist), len(href))})
+    elif world == 1:
+        gate["reference"] = "not run: oracle/_ref not on this box, or --no-cpu-baseline / size"
 
-    # roofline of the dominant kernel (the diagonal-block / sequential SpMV launch of this rank)
-    spmv_bytes = 12 * nnz_local + (8 if ai.dtype == np.int64 else 4) * (m + 1) + 16 * m  # val + col + row offsets + x + y
-    spmv_ms = tot_ms.value / max(cnt.value, 1)
-    achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+    # ---- the timed legs
+    elapsed, spmv_ms, launches, rnorm = timed_steps(P, args, sync, dist, torch)
+    spmv_bytes = P.spmv_bytes()
+    general = None
+    if world == 1 and not args.no_general and args.ksp == "cg":
+        gname = P.setup(args.general_variant, no_dconst=True)
+        g_elapsed, g_ms, g_launches, _ = timed_steps(P, args, sync, dist, torch)
+        general = {"bound": "hbm", "kernel": gname, "avg_launch_ms": g_ms, "launches": g_launches, "algorithmic_bytes": spmv_bytes,
+                   "achieved": spmv_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "iterations_per_s": args.steps / g_elapsed,
+                   "note": "same solver with --variant %d and the constant-Jacobi-diagonal shortcut off: the kernels a matrix with arbitrary values gets" % args.general_variant}
+        general["frac"] = general["achieved"] / HBM_PEAK_GBS
+        P.setup(args.variant)
 
-    kbuf = C.create_string_buffer(256)
-    _lib.chk(hx.hipxMatGetSpMVKernel(M.A, kbuf, 256))
-    kname = kbuf.value.decode()
-    # HBM traffic of the SpMV launch cannot be counted from inside this process; it comes from the committed rocprofv3
-    # PMC passes of this same command (profiles/README.md, scripts/pmc_summary.py), matched on kernel and workload
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "spmv_traffic.json")))
-        key = "%dpt_%d_%s_g%d" % (args.stencil, n, kname.split(" ")[0], world)
-        if key in tj:
-            traffic = tj[key]["traffic_bytes"]
-    except Exception:
-        pass
     out = None
     if rank == 0:
-        value = args.steps / elapsed
+        achieved_alg = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+        traffic, source = None, None
+        if world == 1 and cube and not args.no_traffic:
+            t = pmc_traffic(args, args.variant, kname.split(" ")[0])
+            if t:
+                traffic, source = t, "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes launched by this run (bench.py --spmv-only), gfx950 correction read = 2 x FETCH_SIZE"
+            if general is not None:
+                tg = pmc_traffic(args, args.general_variant, general["kernel"].split(" ")[0])
+                if tg:
+                    general["traffic"] = tg["bytes"]
+                    general["traffic_detail"] = tg
+                    general["frac_counter_bytes"] = tg["bytes"] / (general["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if traffic is None:
+            try:  # committed PMC passes of the same kernel and workload (profiles/README.md)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "spmv_traffic.json")))
+                key = "%dpt_%d_%s_g%d" % (args.stencil, n, kname.split(" ")[0], world)
+                if key in tj:
+                    traffic, source = {"bytes": tj[key]["traffic_bytes"]}, "profiles/spmv_traffic.json (committed rocprofv3 PMC passes of this kernel on this workload; not measured in this run)"
+            except Exception:
+                pass
+        tbytes = traffic["bytes"] if traffic else None
+        achieved = (tbytes / (spmv_ms * 1e-3) / 1e9) if (tbytes and spmv_ms > 0) else achieved_alg
+        gate_ok = gate["pass"] is not False
+        value = args.steps / elapsed if gate_ok else None
+        pcname = {"jacobi": "PCJACOBI", "sor": "PCSOR", "none": "PCNONE"}[args.pc]
         out = {
-            "metric": "CG iterations/sec, %d-pt Poisson %d^3 fp64, KSPCG+PCJACOBI" % (args.stencil, n),
+            "metric": "%s iterations/sec, %d-pt Poisson %s fp64, KSP%s+%s" % (args.ksp.upper(), args.stencil, "%d^3" % n if cube else "%dx%dx%d" % P.dims, args.ksp.upper(), pcname),
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "3-D %d-pt Poisson %d^3 (N=%d rows, nnz=%d local), KSPCG + PCJACOBI, b = A*1, x0 = 0; rows split over %d rank(s)"
-                                   % (args.stencil, n, N, nnz_local, world),
+            "config": {"workload": "3-D %d-pt Poisson %dx%dx%d (N=%d rows, nnz=%d local), KSP%s + %s, b = A*1, x0 = 0; rows split over %d rank(s)"
+                                   % (args.stencil, P.dims[0], P.dims[1], P.dims[2], N, P.nnz_local, args.ksp.upper(), pcname, world),
                        "global_rows": N, "parallelism": "rows%d" % world, "fused": args.fused, "pipeline": args.pipeline, "spmv_variant": args.variant,
                        "residual_norm_after": rnorm},
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": cnt.value, "avg_launch_ms": spmv_ms, "algorithmic_bytes": spmv_bytes,
-                         "frac_of_measured_copy_peak_6290": achieved / 6290.0,
-                         "note": "achieved = CSR algorithmic bytes (12 nnz + 4 (N+1) + 16 N, SURVEY 8(d)) / launch time; the packed kernels move fewer bytes "
-                                 "than that (16-bit column codes; 8-bit value codes when a[] has <= 256 distinct values), see traffic"},
+            "parity_gate": gate,
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "basis": "HBM bytes moved (PMC counters) / launch time" if tbytes else "algorithmic CSR bytes / launch time (no counter bytes available)",
+                         "traffic": tbytes, "traffic_source": source, "traffic_detail": traffic,
+                         "launches": launches, "avg_launch_ms": spmv_ms, "algorithmic_bytes": spmv_bytes, "effective_gbps": achieved_alg,
+                         "effective_frac_of_peak": achieved_alg / HBM_PEAK_GBS, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+                         "note": "effective_gbps = CSR algorithmic bytes (12 nnz + 4 (N+1) + 16 N, SURVEY 8(d)) / launch time: the compressed formats (row templates, "
+                                 "value dictionary, 16-bit columns) move fewer bytes than that, so it can exceed the HBM peak; frac is on the bytes really moved"},
+            "roofline_general": general,
         }
+        if world == 1 and not args.no_plugin and cube and args.ksp == "cg" and args.pc == "jacobi" and N <= 2 ** 25:
+            plug = {}
+            for label, ksp in (("reference KSPSolve_CG over hipx types", "cg"), ("-ksp_type cghipx (fused kernels under PETSc's monitors / convergence test)", "cghipx")):
+                a = [x if x != "cg" else ksp for x in solver_args(args, 400)]
+                r = ref_driver(1, a, plugin=True)
+                plug[ksp] = {"what": label, "iterations_per_s": (r["its"] / r["seconds"]) if r else None, "iterations": r["its"] if r else None,
+                             "KSPSolve_seconds": r["seconds"] if r else None}
+            out["plugin"] = plug
+        else:
+            out["plugin"] = None
         if world == 1 and not args.no_cpu_baseline:
-            ref = cpu_baseline_reference(args.stencil, n, 24 if n >= 200 else 100) if N <= 2 ** 25 else {
-                "value": None, "unit": "CG iterations/s", "cores": 1, "kind": "reference", "sample": "not timed: the bounded-sample rule (10-30 s of CPU work) cannot hold at this size"}
-            if ref is None:
-                bh = B.get()
-                ref = cpu_baseline(ai, aj, aa, bh, args.cpu_baseline_seconds, args.stencil, n)
-            out["cpu_baseline"] = ref
+            cores = physical_cores()
+            base = None
+            if cube and N <= 2 ** 25:
+                its_p = 100 if n >= 200 else 300
+                rp = ref_driver(cores, solver_args(args, its_p)) if cores > 1 else None
+                r1 = ref1 if ref1 is not None else ref_driver(1, solver_args(args, GATE_ITS))
+                if rp is not None or r1 is not None:
+                    best = rp if rp is not None else r1
+                    base = {"value": best["its"] / best["seconds"], "unit": "iterations/s", "cores": cores if rp is not None else 1, "kind": "reference",
+                            "value_1core": (r1["its"] / r1["seconds"]) if r1 else None,
+                            "sample": "the reference's own KSPSolve (KSP%s + %s, MAT(MPI)AIJ, VEC(MPI), MKL BLAS one thread per rank, gcc -O2; oracle/_ref) on the same %d-pt %d^3 system: "
+                                      "%s iterations on %d MPI ranks = physical cores of this host (KSPSolve wall %s s), %s iterations on 1 core (%s s); assembly excluded"
+                                      % (args.ksp.upper(), pcname, args.stencil, n, rp["its"] if rp else "-", cores, "%.3f" % rp["seconds"] if rp else "-",
+                                         r1["its"] if r1 else "-", "%.3f" % r1["seconds"] if r1 else "-")}
+            if base is None and cube and args.ksp == "cg" and args.pc == "jacobi" and N <= 2 ** 25:
+                base, _ = oracle_port_baseline(P.ai, P.aj, P.aa, P.B.get(), 20.0, args.stencil, n)
+            out["cpu_baseline"] = base
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -146,6 +146,10 @@ int hipxMatGetInfo(hipxMat A, hipx_int *m, hipx_int *n, int64_t *nnz, int64_t *d
 /* replaces MatGetDiagonal_SeqAIJ aij.c:1347 */       int hipxMatGetDiagonal(hipxMat A, double *d);
 /* replaces MatSOR_SeqAIJ aij.c:1842 (flag = MatSORType bits petscmat.h:1664-1671); b, x device vectors */
 int hipxMatSOR(hipxMat A, const double *b, double omega, int flag, double shift, hipx_int its, hipx_int lits, double *x);
+/* which schedule the last hipxMatSOR call used: 2 = strands (stencil matrices with row templates: one lane per grid line, a wave
+   = 64 lines, neighbours through LDS), 1 = level-ordered dependency-driven sweep, 0 = one launch per level; -1 = none yet.
+   HIPX_SOR_MODE=strand|dep|levels forces one (all are bit-identical to aij.c:1930-2002). */
+int hipxMatGetSORMode(hipxMat A, int *mode);
 /* tuning knobs (plugin option -mat_aijhipx_spmv_variant): kernel variant.  0 = auto (>= 2^20 nonzeros: packed 16-bit
    column codes, row-parallel gather for short rows, and an 8-bit value dictionary when a[] holds <= 256 distinct bit
    patterns); 1..12 = 32-bit-column stream kernel geometries; 22 / 23 = packed columns (staged / row-parallel);

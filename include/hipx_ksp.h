@@ -117,6 +117,8 @@ void HipxSplitOwnership(hipx_int N, int size, hipx_int *ranges);
 int64_t HipxAssemble_ex2(hipx_int m, hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, hipx_int *aj, double *aa);
 int64_t HipxAssemble_poisson7(hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, hipx_int *aj, double *aa);
 int64_t HipxAssemble_poisson7_64(hipx_int n, hipx_int rstart, hipx_int rend, int64_t *ai, hipx_int *aj, double *aa);
+/* nx x ny x nz box (x fastest); exactly one of ai (32-bit offsets) / ai64 may be non-NULL, both NULL = count only */
+int64_t HipxAssemble_poisson7_box(hipx_int nx, hipx_int ny, hipx_int nz, hipx_int rstart, hipx_int rend, hipx_int *ai, int64_t *ai64, hipx_int *aj, double *aa);
 int64_t HipxAssemble_bench27(hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, hipx_int *aj, double *aa);
 int64_t HipxAssemble_bench27_64(hipx_int n, hipx_int rstart, hipx_int rend, int64_t *ai, hipx_int *aj, double *aa); /* 64-bit row offsets (512^3: 3.6e9 nonzeros) */
 

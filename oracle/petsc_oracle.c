@@ -927,8 +927,11 @@ int orc_KSPSolve_GMRES(OrcKSP *ksp, const OScalar *B, OScalar *X)
         }
         if (!hapend) {
           t = sqrt(*h * *h + *(h + 1) * *(h + 1));
-          if (t == 0.0) {
-            ksp->reason = ORC_KSP_DIVERGED_BREAKDOWN; /* KSP_DIVERGED_NULL in the reference */
+          if (t == 0.0) { /* gmres.c:374-378 sets KSP_DIVERGED_NULL and returns; gmres.c:158-161 then counts the iteration and breaks */
+            ksp->reason = ORC_KSP_DIVERGED_NULL;
+            it++;
+            ksp->its++;
+            ksp->rnorm = res;
             break;
           }
           *cp         = *h / t;

@@ -55,6 +55,7 @@ enum {
   ORC_KSP_CONVERGED_ATOL           = 3,
   ORC_KSP_CONVERGED_ITS            = 4,
   ORC_KSP_CONVERGED_HAPPY_BREAKDOWN = 8,
+  ORC_KSP_DIVERGED_NULL            = -2,
   ORC_KSP_DIVERGED_ITS             = -3,
   ORC_KSP_DIVERGED_DTOL            = -4,
   ORC_KSP_DIVERGED_BREAKDOWN       = -5,

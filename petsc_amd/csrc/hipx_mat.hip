@@ -1770,7 +1770,8 @@ int hipxMatCreateCSR64(hipx_int m, hipx_int n, const int64_t *i, const hipx_int 
 int hipxMatCreateCSRCompressedRow(hipx_int m, hipx_int n, hipx_int nrows, const hipx_int *ci, const hipx_int *ridx, const hipx_int *j, const double *a, hipxMat *A)
 {
   HIPX_CHECK_INIT();
-  static const hipx_int dummy = 0;
+  HIPX_ARG(ridx || nrows == 0, "compressed-row matrix needs the row index list (Mat_CompressedRow.rindex)");
+  static const hipx_int dummy = 0;  // nrows == 0: marks the matrix as compressed, never dereferenced
   return create_common<hipx_int>(m, n, nrows, ci, ridx ? ridx : &dummy, j, a, false, A);
 }
 

@@ -46,6 +46,10 @@ struct hipxSorState {
   double    omega = 0.0, shift = 0.0;
   bool      idiag_valid = false, values_valid = false;
   unsigned int zero_pivots = 0;
+  void     *strand = nullptr;   // StrandState: strand-scheduled sweeps for template (stencil) matrices
+  bool      strand_tried = false;
+  int       last_mode = -1;
+  unsigned long long strand_vstate = 0;  // value state of the matrix the strand tables were built from
 };
 
 extern "C" {
@@ -165,19 +169,23 @@ __global__ void sor_apply_upper_kernel(hipx_int m, const hipx_int *perm, const i
 // for belongs to a workgroup that has already started (and workgroups are never pre-empted).  Spins are bounded:
 // a lane that gives up raises the error word instead of hanging the device.
 constexpr unsigned long long SOR_SENTINEL = 0x7FF4DEADBEEF0001ULL;
-constexpr int                SOR_SPIN_MAX = 1 << 20;  // ~0.5 s of polling per lane before the launch is declared stuck
+constexpr long long          SOR_SPIN_TICKS = 400000000LL;  // 4 s of the 100 MHz wall clock (wall_clock64) before a launch is declared stuck:
+                                                             // elapsed time, not poll counts, so GPU sharing / pre-emption cannot trip it
 
 __device__ __forceinline__ double sor_poll(const double *p, unsigned int *err)
 {
   const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
   unsigned long long        v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int                       spins = 0;
+  long long                 t0 = 0;
   while (v == SOR_SENTINEL) {
     __builtin_amdgcn_s_sleep(8);
     v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ++spins;
     if ((spins & 0xff) == 0) {  // global abort: once any lane has given up, nobody waits any more (bounds the whole launch)
-      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || spins > SOR_SPIN_MAX) {
+      const long long now = (long long)wall_clock64();
+      if (!t0) t0 = now;
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || now - t0 > SOR_SPIN_TICKS) {
         __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -318,6 +326,638 @@ int run_levels(hipxSorState *S, bool forward, const double *b, double *x, double
   return HIPX_SUCCESS;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Strand-scheduled sweeps for stencil-structured matrices (row templates, hipx_mat.hip).
+//
+// The level schedule above pays one cross-CU memory hop (2.5-6 us) per dependency level: 1785 levels on a 27-point
+// 512x512x64 slab = 24 ms per symmetric sweep.  Here the critical chain stays inside a wave:
+//   * a STRAND is a run of L consecutive rows (an x-line of the grid; L is read off the interior template).  Inside a strand
+//     every row depends on its predecessor, so a strand is sequential by nature: ONE LANE walks it front to back.
+//   * a PANEL is 64 consecutive strands = one wave.  Lane l trails lane l-1 by the two rows the stencil demands, so a wave is
+//     a skewed wavefront that advances every lane by one row per iteration; the values a lane needs from its neighbours'
+//     strands go through a tagged LDS window ({value, position} slots: a slot is valid for exactly one row), never through
+//     memory.
+//   * strands of OTHER panels ("far": the plane below, the line next to the panel) are staged into the same window by a
+//     LOADER wave of the workgroup, which polls the NEW vector (sentinel = not published yet, as above) a few rows ahead of
+//     its consumers; it also streams the per-row operands (b or t, old x, template id) into an LDS ring.  The COMPUTE wave
+//     therefore never waits for a global load: its iteration is LDS reads, a handful of fp64 operations and two stores.
+//   * panels are taken in ticket order = natural order, so every value a panel can wait for belongs to a panel that is
+//     already running (no deadlock, any grid size); waits are bounded by wall-clock time and end in an error code.
+// The matrix itself is not read at all: rows come from the template table in LDS (1 byte per row from HBM).
+// Arithmetic per row is MatSOR_SeqAIJ's (aij.c:1930-2002): same operands, same left-to-right order, no FMA -> bit-identical.
+// SIMT model used to design and check the schedule: scripts/sor_strand_model.py.
+constexpr int ST_WP   = 16;  // window positions per LDS row
+constexpr int ST_RQ   = 16;  // per-row operand ring (positions per lane)
+constexpr int ST_SB   = 8;   // positions per staging batch
+constexpr int ST_LA   = 10;  // staging look-ahead beyond the leading consumer
+constexpr int ST_NB   = 3;   // bands of strands a panel may touch
+constexpr int ST_MAXW = 4;   // strands per band
+constexpr int ST_CH   = 4;   // dependency entries per chunk in the compute wave
+
+struct StBand {
+  int dsmin, width, rowbase, pad;
+};
+struct StParams {
+  hipx_int m, L, nstr, npanels;
+  int      nbands, nrows, ntmpl, ndep, nold, maxchunks;
+  StBand   band[ST_NB];
+  int      off_win, off_rowq, off_prog, off_ctl, off_tinfo, off_tdiag, off_dep, off_old, lds_bytes;
+};
+struct __attribute__((aligned(16))) StEntry {  // dep: pk = (window row offset << 16) | (dp & 0xffff), lo = logical row offset; old: pk = ACTUAL column - row
+  int    pk, lo;
+  double val;
+};
+struct __attribute__((aligned(16))) StTinfo {
+  int dstart, dcnt, ostart, ocnt;
+};
+struct __attribute__((aligned(16))) StDiag {
+  double idiag, mdiag;
+};
+struct __attribute__((aligned(16))) StSlot {  // one window slot: valid for the row at position `tag` only
+  double v;
+  int    tag, pad;
+};
+struct __attribute__((aligned(16))) StRow {  // per-row operands staged by the loader
+  double a, b;
+  int    tid, tag, pad0, pad1;
+};
+typedef int st_int4 __attribute__((ext_vector_type(4)));
+// LDS is addressed through explicit address-space-3 pointers: generic pointers made the compiler emit FLAT accesses, which
+// count on vmcnt as well -- the compute wave must never wait on the memory counters.  `volatile` 16-byte vector accesses
+// compile to single ds_read_b128 / ds_write_b128 (checked in the ISA): a slot is read and written whole.
+typedef __attribute__((address_space(3))) char    st_lds_char;
+typedef __attribute__((address_space(3))) int     st_lds_int;
+typedef __attribute__((address_space(3))) st_int4 st_lds_int4;
+
+__device__ __forceinline__ st_int4 st_ld4v(st_lds_char *base, int byteoff) { return *reinterpret_cast<volatile st_lds_int4 *>(base + byteoff); }
+__device__ __forceinline__ st_int4 st_ld4(st_lds_char *base, int byteoff) { return *reinterpret_cast<st_lds_int4 *>(base + byteoff); }
+__device__ __forceinline__ void    st_st4v(st_lds_char *base, int byteoff, st_int4 v) { *reinterpret_cast<volatile st_lds_int4 *>(base + byteoff) = v; }
+__device__ __forceinline__ double  st_dbl(int lo, int hi) { return __longlong_as_double(((long long)(unsigned)hi << 32) | (unsigned)lo); }
+__device__ __forceinline__ st_int4 st_pack_slot(double v, int tag)
+{
+  const long long b = __double_as_longlong(v);
+  st_int4         r;
+  r.x = (int)(unsigned)b;
+  r.y = (int)(unsigned)((unsigned long long)b >> 32);
+  r.z = tag;
+  r.w = 0;
+  return r;
+}
+
+template <bool FWD>
+__device__ __forceinline__ hipx_int st_actual(long long q, hipx_int m)
+{
+  return FWD ? (hipx_int)q : (hipx_int)((long long)m - 1 - q);
+}
+
+__device__ __forceinline__ int st_strand_len(long long S, const StParams &P)
+{
+  if (S < 0 || S >= P.nstr) return 0;
+  const long long rem = (long long)P.m - S * P.L;
+  return (int)(rem < P.L ? rem : P.L);
+}
+
+// KIND as in sor_level_kernel: 0 fwd zero guess, 1 bwd with t, 2 bwd zero guess, 3 fwd general, 4 bwd whole row
+template <int KIND, bool ALIGNED>
+__global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const unsigned char *__restrict__ tid, const StTinfo *__restrict__ g_tinfo, const StDiag *__restrict__ g_tdiag,
+                                                         const StEntry *__restrict__ g_dep, const StEntry *__restrict__ g_old, const double *asrc, double *t, const double *xold,
+                                                         double *xnew, double omega, unsigned int *ctl)
+{
+  constexpr bool FWD     = (KIND == 0 || KIND == 3);
+  constexpr bool NEEDOLD = (KIND == 1 || KIND == 3 || KIND == 4);  // the row's own old value
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  st_lds_char          *lds    = (st_lds_char *)smem;
+  volatile st_lds_int  *s_prog = (volatile st_lds_int *)(lds + P.off_prog);
+  volatile st_lds_int  *s_ctl  = (volatile st_lds_int *)(lds + P.off_ctl);
+  unsigned int *err  = ctl + 1;
+  const int     lane = threadIdx.x & 63;
+  const bool    loader = threadIdx.x >= 64;
+  const hipx_int m = P.m, L = P.L;
+  // template tables -> LDS (16-byte records)
+  for (int i = threadIdx.x; i < P.ntmpl; i += 128) {
+    st_st4v(lds, P.off_tinfo + 16 * i, reinterpret_cast<const st_int4 *>(g_tinfo)[i]);
+    st_st4v(lds, P.off_tdiag + 16 * i, reinterpret_cast<const st_int4 *>(g_tdiag)[i]);
+  }
+  for (int i = threadIdx.x; i < P.ndep; i += 128) st_st4v(lds, P.off_dep + 16 * i, reinterpret_cast<const st_int4 *>(g_dep)[i]);
+  for (int i = threadIdx.x; i < P.nold; i += 128) st_st4v(lds, P.off_old + 16 * i, reinterpret_cast<const st_int4 *>(g_old)[i]);
+  for (;;) {
+    __syncthreads();  // both waves are done with the previous panel (and the tables are in place)
+    if (threadIdx.x == 0) s_ctl[0] = (int)atomicAdd(&ctl[0], 1u);
+    {
+      const st_int4 empty = {0, 0, -1, 0};
+      for (int i = threadIdx.x; i < P.nrows * ST_WP; i += 128) st_st4v(lds, P.off_win + 16 * i, empty);
+      const st_int4 empty_row = {0, -1, 0, 0};  // second half of a StRow: {tid, tag, -, -}
+      for (int i = threadIdx.x; i < 64 * ST_RQ; i += 128) st_st4v(lds, P.off_rowq + 32 * i + 16, empty_row);
+    }
+    if (threadIdx.x < 64) s_prog[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_ctl[1] = 0;
+    __syncthreads();
+    const unsigned panel = (unsigned)s_ctl[0];
+    if (panel >= (unsigned)P.npanels) return;
+    const long long S0  = (long long)panel * 64;
+    const long long S   = S0 + lane;
+    const int       len = st_strand_len(S, P);
+    if (!loader) {
+      // ------------------------------------------------------------------ compute wave
+      int       p = 0, k = 0;
+      bool      have = false;
+      double    sum = 0.0, rb = 0.0;
+      st_int4   ti = {0, 0, 0, 0};  // {dstart, dcnt, ostart, ocnt}
+      double    idiag = 0.0, mdiag = 0.0;
+      long long t0 = 0;
+      for (unsigned it = 1;; it++) {
+        const bool active = p < len;
+        if (!__any(active)) break;
+        if (active) {
+          const long long q = S * L + p;
+          const hipx_int  r = st_actual<FWD>(q, m);
+          if (!have) {
+            const int     ro = P.off_rowq + 32 * (lane * ST_RQ + (p & (ST_RQ - 1)));
+            const st_int4 w1 = st_ld4v(lds, ro + 16);  // tag first: operands are written before the tag
+            const st_int4 w0 = st_ld4v(lds, ro);
+            if (w1.y == p) {
+              rb   = st_dbl(w0.z, w0.w);
+              ti   = st_ld4(lds, P.off_tinfo + 16 * w1.x);
+              const st_int4 dg = st_ld4(lds, P.off_tdiag + 16 * w1.x);
+              idiag = st_dbl(dg.x, dg.y);
+              mdiag = st_dbl(dg.z, dg.w);
+              have = true;
+              k    = 0;
+              sum  = st_dbl(w0.x, w0.y);
+              if (KIND == 4) {  // aij.c:1984-1990: the lower part and the diagonal use OLD values, in row order, first
+                for (int e = 0; e < ti.w; e++) {
+                  const st_int4 oe = st_ld4(lds, P.off_old + 16 * (ti.z + e));
+                  sum -= st_dbl(oe.z, oe.w) * xold[(long long)r + oe.x];
+                }
+              }
+            }
+          }
+          if (have) {
+            bool ok = true;
+            for (int c = 0; c < P.maxchunks; c++) {
+              if (ok && k < ti.y) {
+                const int n = (ti.y - k) < ST_CH ? (ti.y - k) : ST_CH;
+                st_int4   e[ST_CH], sl[ST_CH];
+                int       pos[ST_CH];
+                double    val[ST_CH];
+#pragma unroll
+                for (int j = 0; j < ST_CH; j++) e[j] = st_ld4(lds, P.off_dep + 16 * (ti.x + k + (j < n ? j : n - 1)));
+#pragma unroll
+                for (int j = 0; j < ST_CH; j++) {
+                  pos[j] = p + (int)(short)(e[j].x & 0xffff);
+                  sl[j]  = st_ld4v(lds, P.off_win + 16 * ((lane + (e[j].x >> 16)) * ST_WP + (pos[j] & (ST_WP - 1))));
+                }
+#pragma unroll
+                for (int j = 0; j < ST_CH; j++) {
+                  val[j] = st_dbl(sl[j].x, sl[j].y);
+                  if (j < n && sl[j].z != pos[j]) {
+                    if (sl[j].z > pos[j]) {  // the slot has moved on (this lane fell far behind its producer): read the value itself
+                      const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(xnew + st_actual<FWD>(q + e[j].y, m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                      if (v == SOR_SENTINEL) ok = false;
+                      else val[j] = __longlong_as_double((long long)v);
+                    } else ok = false;  // not produced yet
+                  }
+                }
+                if (ok) {
+#pragma unroll
+                  for (int j = 0; j < ST_CH; j++)
+                    if (j < n) sum -= st_dbl(e[j].z, e[j].w) * val[j];
+                  k += n;
+                }
+              }
+            }
+            if (ok && k >= ti.y) {
+              double out;
+              if (KIND == 0) {
+                t[r] = sum;
+                out  = sum * idiag;
+              } else if (KIND == 1) {
+                out = (1 - omega) * rb + sum * idiag;
+              } else if (KIND == 2) {
+                out = sum * idiag;
+              } else if (KIND == 3) {
+                t[r] = sum;
+                for (int e2 = 0; e2 < ti.w; e2++) {  // upper part: old values (aij.c:1973-1976)
+                  const st_int4 oe = st_ld4(lds, P.off_old + 16 * (ti.z + e2));
+                  sum -= st_dbl(oe.z, oe.w) * xold[(long long)r + oe.x];
+                }
+                out = (1. - omega) * rb + sum * idiag;
+              } else {
+                out = (1. - omega) * rb + (sum + mdiag * rb) * idiag;
+              }
+              const st_int4 pub = st_pack_slot(out, p);
+#pragma unroll
+              for (int b = 0; b < ST_NB; b++) {
+                if (b < P.nbands) {
+                  const int u = lane - P.band[b].dsmin;
+                  if (u >= 0 && u < 64 + P.band[b].width - 1) st_st4v(lds, P.off_win + 16 * ((P.band[b].rowbase + u) * ST_WP + (p & (ST_WP - 1))), pub);
+                }
+              }
+              sor_publish(xnew + r, out);
+              p++;
+              have = false;
+            }
+          }
+        }
+        s_prog[lane] = p;
+        if ((it & 0x3ff) == 0) {  // bounded wait: elapsed wall-clock time, and a global abort word so one stuck panel ends the launch
+          const long long now = (long long)wall_clock64();
+          if (!t0) t0 = now;
+          if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || now - t0 > SOR_SPIN_TICKS) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      if (lane == 0) s_ctl[1] = 1;
+    } else {
+      // ------------------------------------------------------------------ loader wave
+      int rqf = 0;  // next position of the own strand whose operands are to be staged
+      int sf[2 * ST_NB];
+#pragma unroll
+      for (int d = 0; d < 2 * ST_NB; d++) sf[d] = 0;
+      for (;;) {
+        if (s_ctl[1]) break;
+        bool      issued = false;
+        const int myp    = s_prog[lane];
+        // (a) operands of the own strand: positions [rqf, rqf + ST_SB) while they fit the ring
+        int           nrow = 0;
+        double        va[ST_SB], vb[ST_SB];
+        unsigned char vt[ST_SB];
+        unsigned long long tb = 0;  // ALIGNED: the 8 template ids as loaded; unpacked when they land (no wait before the far loads are issued)
+        if (rqf < len && rqf + ST_SB <= myp + ST_RQ) nrow = (len - rqf) < ST_SB ? (len - rqf) : ST_SB;
+        if (nrow > 0) {
+          issued = true;
+          const long long q0 = S * L + rqf;
+          if (ALIGNED) {  // L, m multiples of 8 and 16-byte aligned vectors: the 8 rows are one aligned 64-byte run
+            typedef double dbl2 __attribute__((ext_vector_type(2)));
+            const hipx_int r0 = FWD ? (hipx_int)q0 : (hipx_int)((long long)m - 8 - q0);  // lowest actual row of the run
+            const dbl2    *pa = reinterpret_cast<const dbl2 *>(asrc + r0);
+            const dbl2    *pb = reinterpret_cast<const dbl2 *>(xold + (NEEDOLD ? r0 : 0));
+            tb = *reinterpret_cast<const unsigned long long *>(tid + r0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const dbl2 a2 = pa[j];
+              dbl2       b2 = {0.0, 0.0};
+              if (NEEDOLD) b2 = pb[j];
+              const int j0 = FWD ? 2 * j : 7 - 2 * j, j1 = FWD ? 2 * j + 1 : 6 - 2 * j;
+              va[j0] = a2.x;
+              va[j1] = a2.y;
+              vb[j0] = b2.x;
+              vb[j1] = b2.y;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < ST_SB; j++) {
+              const hipx_int r = st_actual<FWD>(q0 + (j < nrow ? j : nrow - 1), m);
+              va[j]            = asrc[r];
+              vb[j]            = NEEDOLD ? xold[r] : 0.0;
+              vt[j]            = tid[r];
+            }
+          }
+        }
+        // (b) far strands: every duty = one window row of another panel's strand, staged ahead of its consumers
+        unsigned long long fv[2 * ST_NB][ST_SB];
+        int                fn[2 * ST_NB], frow[2 * ST_NB];
+#pragma unroll
+        for (int d = 0; d < 2 * ST_NB; d++) {
+          fn[d]   = 0;
+          frow[d] = 0;
+          const int b = d >> 1, which = d & 1;
+          if (b < P.nbands) {
+            const int       w = P.band[b].width, u = lane + 64 * which;
+            const long long strand = S0 + u + P.band[b].dsmin;
+            const bool      valid  = u < 64 + w - 1 && (strand < S0 || strand > S0 + 63) && strand >= 0 && strand < P.nstr;
+            if (valid) {
+              int lead = -1000000;  // most advanced consumer of this row that is still running
+              for (int c = u - (w - 1); c <= u; c++) {
+                if (c >= 0 && c < 64) {
+                  const int pc = s_prog[c];
+                  if (pc < st_strand_len(S0 + c, P) && pc > lead) lead = pc;
+                }
+              }
+              const int slen = st_strand_len(strand, P);
+              int       tgt  = lead + ST_LA + 1;
+              if (tgt > slen) tgt = slen;
+              int n = tgt - sf[d];
+              if (n > ST_SB) n = ST_SB;
+              if (n > 0) {
+                issued  = true;
+                fn[d]   = n;
+                frow[d] = P.band[b].rowbase + u;
+                const long long q0 = strand * L + sf[d];
+#pragma unroll
+                for (int j = 0; j < ST_SB; j++)
+                  fv[d][j] = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(xnew + st_actual<FWD>(q0 + (j < n ? j : n - 1), m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
+          }
+        }
+        // everything is in flight; now land it in LDS
+        if (nrow > 0) {
+          if (ALIGNED) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) vt[FWD ? j : 7 - j] = (unsigned char)(tb >> (8 * j));
+          }
+#pragma unroll
+          for (int j = 0; j < ST_SB; j++) {
+            if (j < nrow) {
+              const int       ro = P.off_rowq + 32 * (lane * ST_RQ + ((rqf + j) & (ST_RQ - 1)));
+              const long long ba = __double_as_longlong(va[j]), bb = __double_as_longlong(vb[j]);
+              st_int4         w0, w1;
+              w0.x = (int)(unsigned)ba;
+              w0.y = (int)(unsigned)((unsigned long long)ba >> 32);
+              w0.z = (int)(unsigned)bb;
+              w0.w = (int)(unsigned)((unsigned long long)bb >> 32);
+              w1.x = (int)vt[j];
+              w1.y = rqf + j;
+              w1.z = 0;
+              w1.w = 0;
+              st_st4v(lds, ro, w0);  // operands first, tag last: the compute wave tests the tag (LDS executes a wave's accesses in order)
+              st_st4v(lds, ro + 16, w1);
+            }
+          }
+          rqf += nrow;
+        }
+#pragma unroll
+        for (int d = 0; d < 2 * ST_NB; d++) {
+          if (fn[d] > 0) {
+            int  cnt = 0;
+            bool acc = true;
+#pragma unroll
+            for (int j = 0; j < ST_SB; j++) {
+              if (j < fn[d] && acc && fv[d][j] != SOR_SENTINEL) {
+                st_st4v(lds, P.off_win + 16 * (frow[d] * ST_WP + ((sf[d] + j) & (ST_WP - 1))), st_pack_slot(__longlong_as_double((long long)fv[d][j]), sf[d] + j));
+                cnt++;
+              } else acc = false;
+            }
+            sf[d] += cnt;
+          }
+        }
+        if (!__any(issued)) __builtin_amdgcn_s_sleep(4);
+      }
+    }
+  }
+}
+
+__global__ void st_verify_kernel(const StParams P, int forward, const unsigned char *__restrict__ tid, const StTinfo *__restrict__ tinfo, const StEntry *__restrict__ dep, unsigned int *bad)
+{
+  for (hipx_int r = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; r < P.m; r += (hipx_int)gridDim.x * blockDim.x) {
+    const long long q = forward ? (long long)r : (long long)P.m - 1 - r;
+    const long long S = q / P.L, p = q - S * P.L;
+    const StTinfo   ti = tinfo[tid[r]];
+    bool            ok = true;
+    for (int k = 0; k < ti.dcnt; k++) {
+      const StEntry   e  = dep[ti.dstart + k];
+      const int       dp = (int)(short)(e.pk & 0xffff);
+      const long long qs = q + e.lo;  // logical source row: must sit in strand S + ds at position p + dp
+      const long long ds = (e.lo - dp) / P.L;
+      ok = ok && qs >= 0 && qs < P.m && qs / P.L == S + ds && qs - (S + ds) * P.L == p + dp && (e.lo - dp) % P.L == 0;
+    }
+    if (!ok) atomicAdd(bad, 1u);
+  }
+}
+
+struct StrandDir {
+  bool      ok = false;
+  StParams  P;
+  StTinfo  *d_tinfo = nullptr;
+  StDiag   *d_tdiag = nullptr;
+  StEntry  *d_dep = nullptr, *d_old = nullptr;
+  std::vector<StDiag> h_tdiag;
+};
+struct StrandState {
+  bool                 ok = false;
+  const unsigned char *d_tid = nullptr;
+  int                  ntmpl = 0;
+  std::vector<double>  diagval;  // diagonal value of every template
+  StrandDir            dir[2];   // [0] forward (dependencies = lower part), [1] backward
+  unsigned int        *d_ctl = nullptr;
+  unsigned long long   value_state = 0;
+  double               omega = 0.0, shift = 0.0;
+  bool                 diag_uploaded = false;
+};
+
+void strand_free(StrandState *T)
+{
+  if (!T) return;
+  for (auto &D : T->dir) {
+    (void)hipFree(D.d_tinfo);
+    (void)hipFree(D.d_tdiag);
+    (void)hipFree(D.d_dep);
+    (void)hipFree(D.d_old);
+  }
+  (void)hipFree(T->d_ctl);
+  delete T;
+}
+
+// strand length: the centre of the cluster of offsets closest above {-1, 0, +1} in the most common template (n for an
+// n x n x nz grid in natural ordering)
+hipx_int strand_length(const int *toff, int len)
+{
+  std::vector<int> offs(toff, toff + len);
+  std::sort(offs.begin(), offs.end());
+  hipx_int best = 0;
+  for (size_t i = 0; i < offs.size();) {
+    size_t j = i;
+    while (j + 1 < offs.size() && offs[j + 1] == offs[j] + 1) j++;
+    const long long c = ((long long)offs[i] + offs[j]) / 2;
+    if (c > 1 && (!best || c < best)) best = (hipx_int)c;
+    i = j + 1;
+  }
+  return best;
+}
+
+int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const int *toff, const double *tval, const int *tdiag, const int64_t *tcount, const unsigned char *d_tid)
+{
+  T->ok    = false;
+  T->d_tid = d_tid;
+  T->ntmpl = ntmpl;
+  int best = 0;
+  for (int t = 1; t < ntmpl; t++)
+    if (tcount[t] > tcount[best]) best = t;
+  const hipx_int L = strand_length(toff + tstart[best], tstart[best + 1] - tstart[best]);
+  if (L < 4 || L > m) return HIPX_SUCCESS;
+  T->diagval.assign((size_t)ntmpl, 0.0);
+  for (int t = 0; t < ntmpl; t++) {
+    if (tdiag[t] < 0) return HIPX_SUCCESS;
+    T->diagval[(size_t)t] = tval[tstart[t] + tdiag[t]];
+  }
+  hipStream_t st = rt().compute;
+  HIPX_HIP(hipMalloc((void **)&T->d_ctl, sizeof(unsigned int) * 4));
+  HIPX_HIP(hipMemsetAsync(T->d_ctl, 0, sizeof(unsigned int) * 4, st));
+  for (int dirn = 0; dirn < 2; dirn++) {
+    StrandDir &D   = T->dir[dirn];
+    const bool fwd = dirn == 0;
+    // logical strand deltas of the dependency side
+    std::vector<int> dsall = {0};
+    bool             fits  = true;
+    auto decomp = [&](int lo, int &ds, int &dp) {
+      ds = (int)std::floor((double)lo / (double)L + 0.5);
+      dp = lo - ds * (int)L;
+    };
+    for (int t = 0; t < ntmpl && fits; t++)
+      for (int k = tstart[t]; k < tstart[t + 1]; k++) {
+        const int off = toff[k];
+        if (fwd ? off < 0 : off > 0) {
+          int ds, dp;
+          decomp(fwd ? off : -off, ds, dp);
+          if (dp < -3 || dp > 3) fits = false;
+          dsall.push_back(ds);
+        }
+      }
+    if (!fits) continue;
+    std::sort(dsall.begin(), dsall.end());
+    dsall.erase(std::unique(dsall.begin(), dsall.end()), dsall.end());
+    StParams &P = D.P;
+    memset(&P, 0, sizeof(P));
+    P.m = m;
+    P.L = L;
+    P.nstr    = (hipx_int)(((long long)m + L - 1) / L);
+    P.npanels = (P.nstr + 63) / 64;
+    P.ntmpl   = ntmpl;
+    int nb = 0;
+    for (size_t i = 0; i < dsall.size() && fits;) {
+      size_t j = i;
+      while (j + 1 < dsall.size() && dsall[j + 1] == dsall[j] + 1) j++;
+      if (nb >= ST_NB || (int)(j - i + 1) > ST_MAXW) fits = false;
+      else {
+        P.band[nb].dsmin   = dsall[i];
+        P.band[nb].width   = (int)(j - i + 1);
+        P.band[nb].rowbase = P.nrows;
+        P.nrows += 64 + P.band[nb].width - 1;
+        nb++;
+      }
+      i = j + 1;
+    }
+    if (!fits) continue;
+    P.nbands = nb;
+    auto band_of = [&](int ds) {
+      for (int b = 0; b < nb; b++)
+        if (ds >= P.band[b].dsmin && ds < P.band[b].dsmin + P.band[b].width) return b;
+      return -1;
+    };
+    std::vector<StTinfo> tinfo((size_t)ntmpl);
+    std::vector<StEntry> dep, old;
+    int                  maxdep = 0;
+    for (int t = 0; t < ntmpl; t++) {
+      StTinfo &ti = tinfo[(size_t)t];
+      ti.dstart   = (int)dep.size();
+      ti.ostart   = (int)old.size();
+      for (int k = tstart[t]; k < tstart[t + 1]; k++) {
+        const int off = toff[k];
+        if (fwd ? off < 0 : off > 0) {
+          int ds, dp;
+          decomp(fwd ? off : -off, ds, dp);
+          const int b = band_of(ds);
+          StEntry   e;
+          e.pk  = ((P.band[b].rowbase + ds - P.band[b].dsmin) << 16) | (dp & 0xffff);
+          e.lo  = fwd ? off : -off;
+          e.val = tval[k];
+          dep.push_back(e);
+        } else if (fwd ? off > 0 : off <= 0) {  // forward: upper part (KIND 3); backward: lower part then the diagonal (KIND 4)
+          StEntry e;
+          e.pk  = off;
+          e.lo  = 0;
+          e.val = tval[k];
+          old.push_back(e);
+        }
+      }
+      ti.dcnt = (int)dep.size() - ti.dstart;
+      ti.ocnt = (int)old.size() - ti.ostart;
+      maxdep  = std::max(maxdep, ti.dcnt);
+    }
+    P.ndep      = (int)dep.size();
+    P.nold      = (int)old.size();
+    P.maxchunks = (maxdep + ST_CH - 1) / ST_CH;
+    int o = 0;
+    P.off_win   = o; o += P.nrows * ST_WP * (int)sizeof(StSlot);
+    P.off_rowq  = o; o += 64 * ST_RQ * (int)sizeof(StRow);
+    P.off_tinfo = o; o += ntmpl * (int)sizeof(StTinfo);
+    P.off_tdiag = o; o += ntmpl * (int)sizeof(StDiag);
+    P.off_dep   = o; o += std::max(P.ndep, 1) * (int)sizeof(StEntry);
+    P.off_old   = o; o += std::max(P.nold, 1) * (int)sizeof(StEntry);
+    P.off_prog  = o; o += 64 * 4;
+    P.off_ctl   = o; o += 16;
+    P.lds_bytes = o;
+    if (P.lds_bytes > 78 * 1024) continue;  // two workgroups per CU must fit the 160 KiB
+    if (dep.empty()) dep.push_back(StEntry{0, 0, 0.0});
+    if (old.empty()) old.push_back(StEntry{0, 0, 0.0});
+    HIPX_HIP(hipMalloc((void **)&D.d_tinfo, sizeof(StTinfo) * (size_t)ntmpl));
+    HIPX_HIP(hipMalloc((void **)&D.d_tdiag, sizeof(StDiag) * (size_t)ntmpl));
+    HIPX_HIP(hipMalloc((void **)&D.d_dep, sizeof(StEntry) * dep.size()));
+    HIPX_HIP(hipMalloc((void **)&D.d_old, sizeof(StEntry) * old.size()));
+    HIPX_HIP(hipMemcpyAsync(D.d_tinfo, tinfo.data(), sizeof(StTinfo) * (size_t)ntmpl, hipMemcpyHostToDevice, st));
+    HIPX_HIP(hipMemcpyAsync(D.d_dep, dep.data(), sizeof(StEntry) * dep.size(), hipMemcpyHostToDevice, st));
+    HIPX_HIP(hipMemcpyAsync(D.d_old, old.data(), sizeof(StEntry) * old.size(), hipMemcpyHostToDevice, st));
+    // every row's dependency entries must decompose into (strand delta, position delta) as the tables say
+    HIPX_HIP(hipMemsetAsync(T->d_ctl + 2, 0, sizeof(unsigned int), st));
+    st_verify_kernel<<<(unsigned)std::min<hipx_int>((m + 255) / 256, 4096), 256, 0, st>>>(P, fwd ? 1 : 0, d_tid, D.d_tinfo, D.d_dep, T->d_ctl + 2);
+    unsigned int bad = 0;
+    HIPX_HIP(hipMemcpyAsync(&bad, T->d_ctl + 2, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    HIPX_HIP(hipStreamSynchronize(st));  // also: tinfo / dep / old (host vectors) are consumed
+    HIPX_LAUNCH_CHECK();
+    D.ok = bad == 0;
+  }
+  T->ok = T->dir[0].ok && T->dir[1].ok;
+  return HIPX_SUCCESS;
+}
+
+// inverse diagonals per template: the same IEEE operations as invert_diag_kernel on the same doubles
+int strand_set_diag(StrandState *T, double omega, double shift)
+{
+  if (T->diag_uploaded && T->omega == omega && T->shift == shift) return HIPX_SUCCESS;
+  const bool plain = (omega == 1.0 && shift <= 0.0);
+  for (auto &D : T->dir) {
+    D.h_tdiag.resize((size_t)T->ntmpl);
+    for (int t = 0; t < T->ntmpl; t++) {
+      const double d = T->diagval[(size_t)t];
+      D.h_tdiag[(size_t)t].mdiag = d;
+      D.h_tdiag[(size_t)t].idiag = plain ? 1.0 / d : omega / (shift + d);
+    }
+    HIPX_HIP(hipMemcpy(D.d_tdiag, D.h_tdiag.data(), sizeof(StDiag) * (size_t)T->ntmpl, hipMemcpyHostToDevice));
+  }
+  T->omega = omega;
+  T->shift = shift;
+  T->diag_uploaded = true;
+  return HIPX_SUCCESS;
+}
+
+template <int KIND>
+int run_strand(StrandState *T, const double *asrc, double *t, const double *xold, double *xnew, double omega)
+{
+  constexpr bool FWD = (KIND == 0 || KIND == 3);
+  StrandDir     &D   = T->dir[FWD ? 0 : 1];
+  const StParams P   = D.P;
+  hipStream_t    st  = rt().compute;
+  const hipx_int g   = std::min<hipx_int>((P.m + 255) / 256, 4096);
+  sor_fill_kernel<<<(unsigned)g, 256, 0, st>>>(xnew, P.m);
+  HIPX_HIP(hipMemsetAsync(T->d_ctl, 0, sizeof(unsigned int), st));  // ticket; the error word is sticky until read
+  static int per_cu = 0;
+  if (!per_cu) {
+    const char *e = getenv("HIPX_SOR_WG_PER_CU");
+    per_cu        = e ? atoi(e) : 2;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 2) per_cu = 2;
+  }
+  unsigned grid = (unsigned)std::min<long long>((long long)P.npanels, 256LL * per_cu);
+  const bool aligned = (P.L % 8 == 0) && (P.m % 8 == 0) && ((reinterpret_cast<uintptr_t>(asrc) | reinterpret_cast<uintptr_t>(xold)) % 16 == 0);
+  static bool attr_set[5][2] = {{false}};
+  auto launch = [&](auto kern, int ai) -> int {
+    if (!attr_set[KIND][ai]) {
+      HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      attr_set[KIND][ai] = true;
+    }
+    kern<<<grid, 128, (size_t)P.lds_bytes, st>>>(P, T->d_tid, D.d_tinfo, D.d_tdiag, D.d_dep, D.d_old, asrc, t, xold, xnew, omega, T->d_ctl);
+    return HIPX_SUCCESS;
+  };
+  int ierr = aligned ? launch(sor_strand_kernel<KIND, true>, 1) : launch(sor_strand_kernel<KIND, false>, 0);
+  if (ierr) return ierr;
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
 int build_schedule(hipxSorState *S, hipx_int m, int64_t nnz, int is64, const void *d_i, const hipx_int *d_j)
 {
   // host copy of the pattern (set-up only; the sweeps never touch the host)
@@ -360,7 +1000,6 @@ int build_schedule(hipxSorState *S, hipx_int m, int64_t nnz, int is64, const voi
   HIPX_HIP(hipMalloc((void **)&S->d_pa, sizeof(double) * (size_t)(nnz ? nnz : 1)));
   HIPX_HIP(hipMalloc((void **)&S->d_idiag, sizeof(double) * (size_t)m));
   HIPX_HIP(hipMalloc((void **)&S->d_mdiag, sizeof(double) * (size_t)m));
-  HIPX_HIP(hipMalloc((void **)&S->d_t, sizeof(double) * (size_t)m));
   HIPX_HIP(hipMemcpy(S->d_perm, perm.data(), sizeof(hipx_int) * (size_t)m, hipMemcpyHostToDevice));
   HIPX_HIP(hipMemcpy(S->d_pi, pi.data(), sizeof(int64_t) * ((size_t)m + 1), hipMemcpyHostToDevice));
   {  // wave-aligned slot map: every level starts on a multiple of 64 slots
@@ -373,9 +1012,6 @@ int build_schedule(hipxSorState *S, hipx_int m, int64_t nnz, int is64, const voi
     S->nslots = (hipx_int)slot.size();
     HIPX_HIP(hipMalloc((void **)&S->d_slot, sizeof(hipx_int) * std::max<size_t>(slot.size(), 1)));
     if (!slot.empty()) HIPX_HIP(hipMemcpy(S->d_slot, slot.data(), sizeof(hipx_int) * slot.size(), hipMemcpyHostToDevice));
-    HIPX_HIP(hipMalloc((void **)&S->d_w1, sizeof(double) * (size_t)m));
-    HIPX_HIP(hipMalloc((void **)&S->d_ctl, sizeof(unsigned int) * 2));
-    HIPX_HIP(hipMemset(S->d_ctl, 0, sizeof(unsigned int) * 2));
   }
   S->m     = m;
   S->is64  = is64 != 0;
@@ -408,8 +1044,43 @@ extern "C" void hipxSorStateFree_(void *p)
   (void)hipFree(S->d_sks);
   (void)hipFree(S->d_w1);
   (void)hipFree(S->d_ctl);
+  strand_free((StrandState *)S->strand);
   delete S;
 }
+
+extern "C" {
+int hipxMatTemplates_(hipxMat A, int *ok, int *ntmpl, const int **tstart, const int **toff, const double **tval, const int **tdiag, const int64_t **tcount,
+                      const unsigned char **d_tid);
+}
+
+// schedule the last hipxMatSOR call used: 0 one launch per level, 1 level-ordered dependency-driven, 2 strands; -1 = none yet
+extern "C" int hipxMatGetSORMode(hipxMat A, int *mode)
+{
+  HIPX_ARG(A && mode, "null argument");
+  hipx_int           m, n;
+  int64_t            nnz;
+  int                is64, diag_dense, compressed;
+  void              *d_i;
+  hipx_int          *d_j;
+  double            *d_a;
+  int64_t           *d_diagpos;
+  void             **slot;
+  unsigned long long vstate;
+  int ierr = hipxMatInternal_(A, &m, &n, &nnz, &is64, &d_i, &d_j, &d_a, &d_diagpos, &diag_dense, &compressed, &slot, &vstate);
+  if (ierr) return ierr;
+  *mode = *slot ? ((hipxSorState *)*slot)->last_mode : -1;
+  return HIPX_SUCCESS;
+}
+
+namespace {
+// one sweep in the active mode (2 = strands, 1 = level-ordered dependency-driven)
+template <int KIND>
+int run_sweep(hipxSorState *S, const double *b, const double *xold, double *xnew, double omega)
+{
+  if (S->mode == 2) return run_strand<KIND>((StrandState *)S->strand, KIND == 1 ? S->d_t : b, S->d_t, xold, xnew, omega);
+  return run_dep<KIND>(S, b, xold, xnew, omega);
+}
+}  // namespace
 
 extern "C" int hipxMatSOR(hipxMat A, const double *b, double omega, int flag, double shift, hipx_int its, hipx_int lits, double *x)
 {
@@ -438,41 +1109,97 @@ extern "C" int hipxMatSOR(hipxMat A, const double *b, double omega, int flag, do
     *slot = S;
   }
   hipStream_t st = rt().compute;
-  if (!S->ready) {
-    HIPX_HIP(hipStreamSynchronize(st));
-    if ((ierr = build_schedule(S, m, nnz, is64, d_i, d_j))) return ierr;
+  // mode: HIPX_SOR_MODE = strand | dep | levels; default: strands when the matrix has row templates, else the level-ordered
+  // dependency-driven sweep (one launch per level when padding every level to a wave would blow up the slot map)
+  int want = -1;
+  {
+    const char *e = getenv("HIPX_SOR_MODE");
+    if (e && !strcmp(e, "levels")) want = 0;
+    else if (e && !strcmp(e, "dep")) want = 1;
+    else if (e && !strcmp(e, "strand")) want = 2;
   }
-  static unsigned long long last_state_dummy = 0;
-  (void)last_state_dummy;
+  if (S->strand_vstate != vstate) {  // new values: the templates (which carry the values) are rebuilt
+    if (S->strand) {
+      HIPX_HIP(hipStreamSynchronize(st));
+      strand_free((StrandState *)S->strand);
+      S->strand = nullptr;
+    }
+    S->strand_tried  = false;
+    S->strand_vstate = vstate;
+  }
+  if ((want == -1 || want == 2) && flag != 64 && !S->strand_tried) {
+    S->strand_tried = true;
+    int                  tok = 0, ntmpl = 0;
+    const int           *tstart, *toff, *tdiag;
+    const double        *tval;
+    const int64_t       *tcount;
+    const unsigned char *d_tid;
+    if ((ierr = hipxMatTemplates_(A, &tok, &ntmpl, &tstart, &toff, &tval, &tdiag, &tcount, &d_tid))) return ierr;
+    if (tok) {
+      StrandState *T = new StrandState;
+      S->strand      = T;
+      if ((ierr = strand_build(T, m, ntmpl, tstart, toff, tval, tdiag, tcount, d_tid))) return ierr;
+      if (!T->ok) {
+        strand_free(T);
+        S->strand = nullptr;
+      }
+    }
+  }
+  const bool use_strand = S->strand && (want == -1 || want == 2) && flag != 64;
+  if (want == 2 && !use_strand && flag != 64) return fail(HIPX_ERR_SUP, "HIPX_SOR_MODE=strand: the matrix has no row templates / strand structure", __FILE__, __LINE__);
+  if (!S->d_t) {  // work vectors shared by every mode
+      HIPX_HIP(hipMalloc((void **)&S->d_w1, sizeof(double) * (size_t)m));
+    HIPX_HIP(hipMalloc((void **)&S->d_ctl, sizeof(unsigned int) * 2));
+    HIPX_HIP(hipMemsetAsync(S->d_ctl, 0, sizeof(unsigned int) * 2, st));
+    S->m = m;
+  }
   const hipx_int g = std::min<hipx_int>((m + 255) / 256, 4096);
-  if (!S->values_valid) {
-    permute_rows_kernel<<<(unsigned)g, 256, 0, st>>>(m, S->d_perm, S->d_pi, d_i, is64, d_j, d_a, d_diagpos, S->d_pj, S->d_pa, S->d_pd);
-    HIPX_LAUNCH_CHECK();
-    S->values_valid = true;
-    S->idiag_valid  = false;
-    if (!S->d_smeta) {
-      HIPX_HIP(hipMalloc((void **)&S->d_smeta, sizeof(int4) * (size_t)std::max<hipx_int>(S->nslots, 1)));
-      HIPX_HIP(hipMalloc((void **)&S->d_sks, sizeof(int64_t) * (size_t)std::max<hipx_int>(S->nslots, 1)));
+  if (use_strand) {
+    StrandState *T = (StrandState *)S->strand;
+    const bool plain = (omega == 1.0 && shift <= 0.0);
+    if (plain && shift == 0.0)
+      for (double d : T->diagval)
+        if (d == 0.0) return fail(HIPX_ERR_ZEROPIVOT, "Zero diagonal on a row (aij.c:1820)", __FILE__, __LINE__);
+    if ((ierr = strand_set_diag(T, omega, shift))) return ierr;
+    S->mode = 2;
+  } else {
+    if (!S->ready) {
+      HIPX_HIP(hipStreamSynchronize(st));
+      if ((ierr = build_schedule(S, m, nnz, is64, d_i, d_j))) return ierr;
     }
-    if (S->nslots) {
-      slot_meta_kernel<<<(unsigned)std::min<hipx_int>((S->nslots + 255) / 256, 4096), 256, 0, st>>>(S->nslots, S->d_slot, S->d_perm, S->d_pi, S->d_pd, S->d_smeta, S->d_sks);
+    if (!S->values_valid) {
+      permute_rows_kernel<<<(unsigned)g, 256, 0, st>>>(m, S->d_perm, S->d_pi, d_i, is64, d_j, d_a, d_diagpos, S->d_pj, S->d_pa, S->d_pd);
       HIPX_LAUNCH_CHECK();
+      S->values_valid = true;
+      S->idiag_valid  = false;
+      if (!S->d_smeta) {
+        HIPX_HIP(hipMalloc((void **)&S->d_smeta, sizeof(int4) * (size_t)std::max<hipx_int>(S->nslots, 1)));
+        HIPX_HIP(hipMalloc((void **)&S->d_sks, sizeof(int64_t) * (size_t)std::max<hipx_int>(S->nslots, 1)));
+      }
+      if (S->nslots) {
+        slot_meta_kernel<<<(unsigned)std::min<hipx_int>((S->nslots + 255) / 256, 4096), 256, 0, st>>>(S->nslots, S->d_slot, S->d_perm, S->d_pi, S->d_pd, S->d_smeta, S->d_sks);
+        HIPX_LAUNCH_CHECK();
+      }
     }
+    if (!S->idiag_valid || S->omega != omega || S->shift != shift) {  // aij.c:1807
+      unsigned int *cnt = rt().d_tickets + (HIPX_MAX_RED_SLOTS - 1);
+      HIPX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
+      const int plain = (omega == 1.0 && shift <= 0.0);
+      invert_diag_kernel<<<(unsigned)g, 256, 0, st>>>(m, d_diagpos, d_a, omega, shift, plain, S->d_idiag, S->d_mdiag, cnt);
+      HIPX_LAUNCH_CHECK();
+      HIPX_HIP(hipMemcpyAsync(&S->zero_pivots, cnt, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+      HIPX_HIP(hipStreamSynchronize(st));
+      HIPX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
+      S->omega       = omega;
+      S->shift       = shift;
+      S->idiag_valid = true;
+      if (S->zero_pivots && plain && shift == 0.0) return fail(HIPX_ERR_ZEROPIVOT, "Zero diagonal on a row (aij.c:1820)", __FILE__, __LINE__);
+    }
+    // a level-per-wave slot map pads every level to 64 slots: with long dependency chains (nlevels ~ m: banded / 1-D
+    // orderings) that is 64 slots per row -- run one launch per level there instead
+    S->mode = (want == 0 || (int64_t)S->nslots > 4 * (int64_t)m + 65536) ? 0 : 1;
   }
-  if (!S->idiag_valid || S->omega != omega || S->shift != shift) {  // aij.c:1807
-    unsigned int *cnt = rt().d_tickets + (HIPX_MAX_RED_SLOTS - 1);
-    HIPX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
-    const int plain = (omega == 1.0 && shift <= 0.0);
-    invert_diag_kernel<<<(unsigned)g, 256, 0, st>>>(m, d_diagpos, d_a, omega, shift, plain, S->d_idiag, S->d_mdiag, cnt);
-    HIPX_LAUNCH_CHECK();
-    HIPX_HIP(hipMemcpyAsync(&S->zero_pivots, cnt, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-    HIPX_HIP(hipStreamSynchronize(st));
-    HIPX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
-    S->omega       = omega;
-    S->shift       = shift;
-    S->idiag_valid = true;
-    if (S->zero_pivots && plain && shift == 0.0) return fail(HIPX_ERR_ZEROPIVOT, "Zero diagonal on a row (aij.c:1820)", __FILE__, __LINE__);
-  }
+  S->last_mode = S->mode;
   its = its * lits;  // aij.c:1855
   if (flag == 64) {  // SOR_APPLY_UPPER
     sor_apply_upper_kernel<<<(unsigned)g, 256, 0, st>>>(m, S->d_perm, S->d_pi, S->d_pd, S->d_pj, S->d_pa, S->d_mdiag, b, x, omega, shift);
@@ -480,43 +1207,40 @@ extern "C" int hipxMatSOR(hipxMat A, const double *b, double omega, int flag, do
     return HIPX_SUCCESS;
   }
   const bool fwd = (flag & 1) || (flag & 4), bwd = (flag & 2) || (flag & 8);
-  {
-    const char *e = getenv("HIPX_SOR_MODE");  // "levels": one launch per level (debugging / comparison)
-    S->mode = (e && !strcmp(e, "levels")) ? 0 : 1;
-  }
-  if (S->mode == 1) {
+  if (S->mode >= 1) {
     // dependency-driven sweeps: each sweep reads OLD, writes NEW (sentinel-filled); the result ends in the user's x
     const size_t bytes = sizeof(double) * (size_t)m;
     double      *W     = S->d_w1;
     if (flag & 16) {  // SOR_ZERO_INITIAL_GUESS, aij.c:1930-1960
       if (fwd && bwd) {
-        if ((ierr = run_dep<0>(S, b, nullptr, W, omega))) return ierr;
-        if ((ierr = run_dep<1>(S, b, W, x, omega))) return ierr;
+        if ((ierr = run_sweep<0>(S, b, nullptr, W, omega))) return ierr;
+        if ((ierr = run_sweep<1>(S, b, W, x, omega))) return ierr;
       } else if (fwd) {
-        if ((ierr = run_dep<0>(S, b, nullptr, x, omega))) return ierr;
+        if ((ierr = run_sweep<0>(S, b, nullptr, x, omega))) return ierr;
       } else if (bwd) {
-        if ((ierr = run_dep<2>(S, b, nullptr, x, omega))) return ierr;
+        if ((ierr = run_sweep<2>(S, b, nullptr, x, omega))) return ierr;
       }
       its--;
     }
     while (its--) {  // aij.c:1961-2002
       if (fwd && bwd) {
-        if ((ierr = run_dep<3>(S, b, x, W, omega))) return ierr;
-        if ((ierr = run_dep<1>(S, b, W, x, omega))) return ierr;
+        if ((ierr = run_sweep<3>(S, b, x, W, omega))) return ierr;
+        if ((ierr = run_sweep<1>(S, b, W, x, omega))) return ierr;
       } else if (fwd) {
-        if ((ierr = run_dep<3>(S, b, x, W, omega))) return ierr;
+        if ((ierr = run_sweep<3>(S, b, x, W, omega))) return ierr;
         HIPX_HIP(hipMemcpyAsync(x, W, bytes, hipMemcpyDeviceToDevice, st));
       } else if (bwd) {
-        if ((ierr = run_dep<4>(S, b, x, W, omega))) return ierr;
+        if ((ierr = run_sweep<4>(S, b, x, W, omega))) return ierr;
         HIPX_HIP(hipMemcpyAsync(x, W, bytes, hipMemcpyDeviceToDevice, st));
       }
     }
-    unsigned int herr = 0;
-    HIPX_HIP(hipMemcpyAsync(&herr, S->d_ctl + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    unsigned int *ctl  = S->mode == 2 ? ((StrandState *)S->strand)->d_ctl : S->d_ctl;
+    unsigned int  herr = 0;
+    HIPX_HIP(hipMemcpyAsync(&herr, ctl + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
     HIPX_HIP(hipStreamSynchronize(st));
     if (herr) {
-      HIPX_HIP(hipMemsetAsync(S->d_ctl, 0, 2 * sizeof(unsigned int), st));
-      return fail(HIPX_ERR_GPU, "MatSOR: a dependency was never published (spin limit reached)", __FILE__, __LINE__);
+      HIPX_HIP(hipMemsetAsync(ctl, 0, 2 * sizeof(unsigned int), st));
+      return fail(HIPX_ERR_GPU, "MatSOR: a dependency was never published (wait limit reached)", __FILE__, __LINE__);
     }
     return HIPX_SUCCESS;
   }

@@ -33,16 +33,16 @@ int64_t HipxAssemble_ex2(hipx_int m, hipx_int n, hipx_int rstart, hipx_int rend,
   return nz;
 }
 
-static int64_t assemble_poisson7(hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, int64_t *ai64, hipx_int *aj, double *aa);
+static int64_t assemble_poisson7(hipx_int nx, hipx_int ny, hipx_int nz, hipx_int rstart, hipx_int rend, hipx_int *ai, int64_t *ai64, hipx_int *aj, double *aa);
 
 int64_t HipxAssemble_poisson7(hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, hipx_int *aj, double *aa)
 {
-  return assemble_poisson7(n, rstart, rend, ai, NULL, aj, aa);
+  return assemble_poisson7(n, n, n, rstart, rend, ai, NULL, aj, aa);
 }
 
 int64_t HipxAssemble_poisson7_64(hipx_int n, hipx_int rstart, hipx_int rend, int64_t *ai, hipx_int *aj, double *aa)
 {
-  return assemble_poisson7(n, rstart, rend, NULL, ai, aj, aa);
+  return assemble_poisson7(n, n, n, rstart, rend, NULL, ai, aj, aa);
 }
 
 #undef EMIT
@@ -55,11 +55,18 @@ int64_t HipxAssemble_poisson7_64(hipx_int n, hipx_int rstart, hipx_int rend, int
     nz++; \
   } while (0)
 
-static int64_t assemble_poisson7(hipx_int n, hipx_int rstart, hipx_int rend, hipx_int *ai, int64_t *ai64, hipx_int *aj, double *aa)
+/* nx x ny x nz box, x fastest (the cube of SURVEY 8(d) is nx = ny = nz; config 5's weak scaling stacks z-slabs: nz grows with the
+   rank count) */
+int64_t HipxAssemble_poisson7_box(hipx_int nx, hipx_int ny, hipx_int nz, hipx_int rstart, hipx_int rend, hipx_int *ai, int64_t *ai64, hipx_int *aj, double *aa)
+{
+  return assemble_poisson7(nx, ny, nz, rstart, rend, ai, ai64, aj, aa);
+}
+
+static int64_t assemble_poisson7(hipx_int n, hipx_int ny, hipx_int nzz, hipx_int rstart, hipx_int rend, hipx_int *ai, int64_t *ai64, hipx_int *aj, double *aa)
 {
   int64_t        nz = 0;
-  const hipx_int n2 = n * n;
-  hipx_int       x = rstart % n, y = (rstart / n) % n, z = rstart / n2;
+  const hipx_int n2 = n * ny;
+  hipx_int       x = rstart % n, y = (rstart / n) % ny, z = rstart / n2;
   for (hipx_int Ii = rstart; Ii < rend; Ii++) {
     if (ai) ai[Ii - rstart] = (hipx_int)nz;
     if (ai64) ai64[Ii - rstart] = nz;
@@ -68,11 +75,11 @@ static int64_t assemble_poisson7(hipx_int n, hipx_int rstart, hipx_int rend, hip
     if (x > 0) EMIT(Ii - 1, -1.0);
     EMIT(Ii, 6.0);
     if (x < n - 1) EMIT(Ii + 1, -1.0);
-    if (y < n - 1) EMIT(Ii + n, -1.0);
-    if (z < n - 1) EMIT(Ii + n2, -1.0);
+    if (y < ny - 1) EMIT(Ii + n, -1.0);
+    if (z < nzz - 1) EMIT(Ii + n2, -1.0);
     if (++x == n) {
       x = 0;
-      if (++y == n) {
+      if (++y == ny) {
         y = 0;
         z++;
       }

@@ -22,6 +22,7 @@ enum {
   KSP_CONVERGED_HAPPY_BREAKDOWN  = 8,
   KSP_DIVERGED_ITS               = -3,
   KSP_DIVERGED_DTOL              = -4,
+  KSP_DIVERGED_NULL              = -2,
   KSP_DIVERGED_BREAKDOWN         = -5,
   KSP_DIVERGED_INDEFINITE_PC     = -8,
   KSP_DIVERGED_NANORINF          = -9,
@@ -486,6 +487,17 @@ int HipxKSPSolve_CG(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, doubl
 /* gmres.c:88-238 (cycle + solve), :298-345 (BuildSoln), :349-395 (UpdateHessenberg), borthog2.c:35-113,
    left preconditioning, KSPInitialResidual itres.c:35-75.  VV(0..max_k) live in one contiguous slab
    (cf. VecDuplicateVecs_Seq_GEMV bvec2.c:670) so MDot/MAXPY stream through consecutive memory. */
+/* VecMDot_MPI (pvecimpl.h:97-111): one all-reduce of nv sums; the device-staged reduction takes 64 doubles at a time, so
+   restarts of any length work (the reference has no limit on gmres_restart) */
+static int allreduce_chunked(double *vals, hipx_int n)
+{
+  for (hipx_int k = 0; k < n; k += 64) {
+    int ierr = hipxCommAllreduceSum(vals + k, (int)((n - k) < 64 ? (n - k) : 64));
+    if (ierr) return ierr;
+  }
+  return 0;
+}
+
 int HipxKSPSolve_GMRES(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double *X)
 {
   const hipx_int n = A->m, max_k = ksp->gmres_restart;
@@ -553,7 +565,7 @@ int HipxKSPSolve_GMRES(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, do
         int     refine = (ksp->gmres_cgs_refine == 2);
         for (hipx_int j = 0; j <= it; j++) h[j] = 0.0;
         GCHK(hipxVecMDot(VV[it + 1], it + 1, (const double *const *)VV, n, lhh));
-        if (A->nranks > 1) GCHK(hipxCommAllreduceSum(lhh, it + 1));
+        if (A->nranks > 1) GCHK(allreduce_chunked(lhh, it + 1));
         for (hipx_int j = 0; j <= it; j++) {
           if (isnan(lhh[j]) || isinf(lhh[j])) ksp->reason = KSP_DIVERGED_NANORINF;
           lhh[j] = -lhh[j];
@@ -570,7 +582,7 @@ int HipxKSPSolve_GMRES(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, do
         }
         if (refine) {
           GCHK(hipxVecMDot(VV[it + 1], it + 1, (const double *const *)VV, n, lhh));
-          if (A->nranks > 1) GCHK(hipxCommAllreduceSum(lhh, it + 1));
+          if (A->nranks > 1) GCHK(allreduce_chunked(lhh, it + 1));
           for (hipx_int j = 0; j <= it; j++) lhh[j] = -lhh[j];
           GCHK(hipxVecMAXPY(VV[it + 1], it + 1, lhh, (const double *const *)VV, n));
           for (hipx_int j = 0; j <= it; j++) h[j] -= lhh[j];
@@ -596,8 +608,11 @@ int HipxKSPSolve_GMRES(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, do
         }
         if (!hapend) {
           t = sqrt(*h * *h + *(h + 1) * *(h + 1));
-          if (t == 0.0) {
-            ksp->reason = KSP_DIVERGED_BREAKDOWN;
+          if (t == 0.0) { /* gmres.c:374-378: the reason is set, the cycle still counts this iteration (it++, its++) before it leaves */
+            ksp->reason = KSP_DIVERGED_NULL;
+            it++;
+            ksp->its++;
+            ksp->rnorm = res;
             break;
           }
           *cp         = *h / t;

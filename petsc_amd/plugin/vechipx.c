@@ -244,6 +244,10 @@ static PetscErrorCode VecReplaceArray_HIPX(Vec v, const PetscScalar *a)
 static PetscErrorCode VecResetArray_HIPX(Vec v)
 {
   PetscFunctionBegin;
+  /* results computed on the device while the caller's array was placed must reach that array before it is handed back
+     (Place / work on the GPU / Reset: PCApply_BJacobi_Multiblock bjacobi.c:886-895; the reference's device vectors do the
+     same, veccupmimpl.h:804-807) */
+  PetscCall(VecHIPXCopyToHost(v));
   PetscCall((*parent_resetarray)(v));
   v->offloadmask = PETSC_OFFLOAD_CPU;
   PetscFunctionReturn(PETSC_SUCCESS);

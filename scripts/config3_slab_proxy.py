@@ -24,7 +24,7 @@ N = n ** 3
 ranges = pdist.split_ownership(N, nranks)
 rs, re = int(ranges[rank]), int(ranges[rank + 1])
 t0 = time.perf_counter()
-ai, aj, aa = bench.assemble(ks, 27, n, rs, re)
+ai, aj, aa = bench.assemble(ks, 27, (n, n, n), rs, re)
 plan = pdist.build_plan(ai, aj, aa, ranges, rank, dist=None) if nranks == 1 else None
 if plan is None:  # build_plan needs the exchange only for the send lists; the split itself is local
     import types
@@ -56,7 +56,13 @@ def timed(name, fn, reps, byts):
 nza, nzb = int(plan["Ai"][-1]), int(plan["Bi"][-1]) if plan["nrows_c"] else 0
 timed("diag SpMV (MatMult A)", lambda: hx.hipxMatMult(A, X.ptr, Y.ptr), 20, 12 * nza + 4 * (m + 1) + 16 * m)
 timed("offdiag MatMultAdd (B)", lambda: hx.hipxMatMultAdd(B, LV.ptr, Y.ptr, Y.ptr), 20, 12 * nzb + 24 * plan["nrows_c"])
-timed("SOR local symmetric sweep", lambda: hx.hipxMatSOR(A, X.ptr, 1.0, 12 | 16, 0.0, 1, 1, Y.ptr), 3, 2 * 12 * nza + 40 * m)
+ysor = {}
+for mode in ("strand", "dep"):
+    os.environ["HIPX_SOR_MODE"] = mode
+    timed("SOR local symmetric sweep [%s]" % mode, lambda: hx.hipxMatSOR(A, X.ptr, 1.0, 12 | 16, 0.0, 1, 1, Y.ptr), 5 if mode == "strand" else 2, 2 * 12 * nza + 40 * m)
+    ysor[mode] = Y.get()
+del os.environ["HIPX_SOR_MODE"]
+print("SOR strand == dep bit for bit:", np.array_equal(ysor["strand"], ysor["dep"]))
 vs = [_lib.DVec(m, np.full(m, 1.0 / (k + 1))) for k in range(30)]
 ptrs = (C.c_void_p * 30)(*[v.ptr.value for v in vs])
 res = (C.c_double * 30)()

@@ -16,40 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from petsc_amd import _lib  # noqa: E402
 
-n = 80                      # nodes per side: 512,000 nodes x 3 dof = 1,536,000 rows (Flan_1565: 1,564,794)
-nn = n ** 3
-N = 3 * nn
-rng = np.random.default_rng(1565)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from surrogates import flan_surrogate  # noqa: E402
+
 t0 = time.time()
-# node numbering: lexicographic, then shuffled inside windows of 512 consecutive ids (a mesh generator's numbering is local
-# but not a perfect grid order)
-perm = np.arange(nn, dtype=np.int64).reshape(-1, 512)
-perm = np.take_along_axis(perm, np.argsort(rng.random(perm.shape), axis=1), axis=1).reshape(-1)
-gx, gy, gz = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
-gx, gy, gz = gx.ravel(), gy.ravel(), gz.ravel()
-u_all = gx + n * gy + n * n * gz
-rows_l, cols_l = [], []
-for dz in (-1, 0, 1):
-    for dy in (-1, 0, 1):
-        for dx in (-1, 0, 1):
-            ok = (gx + dx >= 0) & (gx + dx < n) & (gy + dy >= 0) & (gy + dy < n) & (gz + dz >= 0) & (gz + dz < n)
-            u = perm[u_all[ok]]
-            v = perm[u_all[ok] + dx + n * dy + n * n * dz]
-            for a in range(3):
-                for b in range(3):
-                    rows_l.append(3 * u + a)
-                    cols_l.append(3 * v + b)
-rows = np.concatenate(rows_l)
-cols = np.concatenate(cols_l)
-del rows_l, cols_l
-order = np.argsort(rows * N + cols, kind="stable")
-rows, cols = rows[order], cols[order].astype(np.int32)
-del order
-lens = np.bincount(rows, minlength=N)
-ai = np.zeros(N + 1, np.int32)
-ai[1:] = np.cumsum(lens)
-nnz = int(ai[-1])
-aa = rng.standard_normal(nnz)  # all distinct: no value dictionary
+rng = np.random.default_rng(7)
+ai, cols, aa = flan_surrogate()
+N, nnz = len(ai) - 1, int(ai[-1])
+lens = np.diff(ai)
 print("surrogate: N=%d nnz=%d (%.1f per row, max %d) built in %.1f s" % (N, nnz, nnz / N, lens.max(), time.time() - t0), flush=True)
 hx = _lib.init(0)
 _, ks = _lib.load()

@@ -16,7 +16,7 @@ st = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 hx = _lib.init(0)
 _, ks = _lib.load()
 N = n ** 3
-ai, aj, aa = bench.assemble(ks, st, n, 0, N)
+ai, aj, aa = bench.assemble(ks, st, (n, n, n), 0, N)
 A = _lib.mat_create_csr(N, N, ai, aj, aa)
 X = _lib.DVec(N, 1.0 + (np.arange(N) % 17) / 17.0)
 Y = _lib.DVec(N)

@@ -1,0 +1,40 @@
+"""Synthetic stand-ins for inputs the container does not hold (test + benchmark infrastructure)."""
+import numpy as np
+
+
+def flan_surrogate(n=80, seed=1565):
+    """Surrogate for BASELINE config 4 (SuiteSparse Janna/Flan_1565: 1,564,794 rows, ~117 M nonzeros, ~75 per row, irregular;
+    not in the container and no network -- SURVEY.md 8(d) asks for a documented substitute).  A hexahedral elasticity mesh like
+    Flan_1565's: n^3 nodes x 3 degrees of freedom (n = 80: 1,536,000 rows), every node coupled to its 27 neighbours by a dense
+    3x3 block (up to 81 entries per row, ~79 on average, 121 M nonzeros), node numbering shuffled inside windows of 512, ALL
+    values distinct (standard normal), so neither a value dictionary nor row templates apply.  Returns CSR (ai, aj, aa)."""
+    nn = n ** 3
+    N = 3 * nn
+    rng = np.random.default_rng(seed)
+    perm = np.arange(nn, dtype=np.int64).reshape(-1, 512)
+    perm = np.take_along_axis(perm, np.argsort(rng.random(perm.shape), axis=1), axis=1).reshape(-1)
+    gx, gy, gz = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    gx, gy, gz = gx.ravel(), gy.ravel(), gz.ravel()
+    u_all = gx + n * gy + n * n * gz
+    rows_l, cols_l = [], []
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                ok = (gx + dx >= 0) & (gx + dx < n) & (gy + dy >= 0) & (gy + dy < n) & (gz + dz >= 0) & (gz + dz < n)
+                u = perm[u_all[ok]]
+                v = perm[u_all[ok] + dx + n * dy + n * n * dz]
+                for a in range(3):
+                    for b in range(3):
+                        rows_l.append(3 * u + a)
+                        cols_l.append(3 * v + b)
+    rows = np.concatenate(rows_l)
+    cols = np.concatenate(cols_l)
+    del rows_l, cols_l
+    order = np.argsort(rows * N + cols, kind="stable")
+    rows, cols = rows[order], cols[order].astype(np.int32)
+    del order
+    lens = np.bincount(rows, minlength=N)
+    ai = np.zeros(N + 1, np.int32)
+    ai[1:] = np.cumsum(lens)
+    aa = rng.standard_normal(int(ai[-1]))
+    return ai, cols, aa

@@ -22,7 +22,14 @@ def test_committed_bench_line_has_every_contract_field():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    if "effective_gbps" in r:  # round 2 on: achieved / frac are on the HBM bytes the kernel really moves, the algorithmic figure is effective_gbps
+        assert abs(r["effective_gbps"] - r["algorithmic_bytes"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["effective_gbps"]
+        if r["traffic"]:
+            assert abs(r["achieved"] - r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"] and r["frac"] < 1.0
+            assert r["traffic_source"]
+        assert d["value"] is None or d["parity_gate"]["pass"] is not False
+    else:
+        assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert r["algorithmic_bytes"] == 12 * 117047296 + 4 * (16777216 + 1) + 16 * 16777216
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
@@ -33,5 +40,5 @@ def test_committed_bench_line_has_every_contract_field():
 def test_bench_cli_defaults():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120,
                          env=dict(os.environ, HIPX_NO_TORCH="1")).stdout
-    for flag in ("--gpus", "--steps", "--warmup", "--grid", "--stencil", "--fused", "--pipeline", "--variant"):
+    for flag in ("--gpus", "--steps", "--warmup", "--grid", "--stencil", "--fused", "--pipeline", "--variant", "--ksp", "--pc", "--scaling"):
         assert flag in out, flag

@@ -3,6 +3,7 @@ HIP kernels, against the oracle's restatement of cg.c / gmres.c on the same inpu
 Bar (north_star): identical iteration counts and convergence reasons; fp64 residual histories within 1e-12 relative
 (reductions are the only non-bit-exact step; long CG runs amplify their rounding, so long histories are held to 1e-9)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -43,16 +44,32 @@ def solve_gpu(kind, ai, aj, aa, b, pc="jacobi", rtol=1e-5, max_it=10000, normtyp
     return out
 
 
-def compare(g, o, tol):
-    """Same iteration count and reason; every history entry within 1e-12 of the oracle's RELATIVE TO THE INITIAL RESIDUAL
-    (the north_star criterion: the only non-bit-exact steps are the dot/norm reductions), and within `tol` pointwise
-    (rounding of the reductions is amplified along a long Krylov recurrence, so late entries are held to `tol`)."""
+# Tolerances, all PER ENTRY and RELATIVE TO THAT ENTRY (north_star: 1e-12).  The kernels are bit-identical to the reference
+# except for the dot/norm reductions (a BLAS there, a fixed tree here); each reduction differs by O(eps) and the Krylov
+# recurrence carries that perturbation forward.
+TOL_STRICT = 1e-12   # histories whose residual has not yet dropped far below ||r0||: holds entry by entry
+# A solve run to rtol = 1e-8 .. 1e-9 ends with residuals 1e-8 .. 1e-9 of ||r0||: an O(eps ||r0||) perturbation of the
+# recurrence (1e-16 .. 1e-15 relative to r0, what TOL_STRICT measures on the early entries) is 1e-7 .. 1e-6 of those late
+# entries at worst; measured margins are recorded in gpurun_out/parity_measured.json and quoted in profiles/README.md.
+TOL_CONVERGED = 1e-9
+TOL_GMRES = 1e-8
+
+
+def compare(g, o, tol, name=None):
+    """Same iteration count and reason; every history entry within `tol` of the oracle's, relative to that entry; the leading
+    entries (residual still within 1e-3 of the initial one) within TOL_STRICT."""
+    import inspect
+    from parity_log import record
     xg, ig, rg, hg = g
     xo, io, ro, ho = o
     assert (ig, rg) == (io, ro)
     assert len(hg) == len(ho)
-    assert np.abs(hg - ho).max() <= 1e-12 * abs(ho[0]), np.abs(hg - ho).max() / abs(ho[0])
     rel = np.abs(hg - ho) / np.abs(ho)
+    head = np.abs(ho) >= 1e-3 * abs(ho[0])
+    name = name or inspect.stack()[1].function + "/" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0]
+    record(name, rel.max(), tol)
+    record(name + " [head]", rel[head].max(), TOL_STRICT)
+    assert rel[head].max() <= TOL_STRICT, (rel[head].max(), int(rel[head].argmax()))
     assert rel.max() <= tol, rel.max()
     return rel.max()
 
@@ -177,12 +194,12 @@ def test_cg_fused_odd_sizes(hx, kind, n, m):
     assert N % 2 == 1
     b = orc.matmult(ai, aj, aa, np.ones(N))
     o = orc.ksp_solve("cg", ai, aj, aa, b, rtol=1e-9)
-    compare(solve_gpu("cg", ai, aj, aa, b, rtol=1e-9, fused=1), o, float("inf"))
-    compare(solve_gpu("cg", ai, aj, aa, b, rtol=1e-9, fused=0), o, float("inf"))
+    compare(solve_gpu("cg", ai, aj, aa, b, rtol=1e-9, fused=1), o, TOL_CONVERGED)
+    compare(solve_gpu("cg", ai, aj, aa, b, rtol=1e-9, fused=0), o, TOL_CONVERGED)
     sc = 1.0 + 0.1 * (np.arange(N) % 5)  # non-constant diagonal: streamed dinv
     aav = aa * sc[np.repeat(np.arange(N), np.diff(ai))] * sc[aj]
     bv = orc.matmult(ai, aj, aav, np.ones(N))
-    compare(solve_gpu("cg", ai, aj, aav, bv, rtol=1e-9, fused=1), orc.ksp_solve("cg", ai, aj, aav, bv, rtol=1e-9), float("inf"))
+    compare(solve_gpu("cg", ai, aj, aav, bv, rtol=1e-9, fused=1), orc.ksp_solve("cg", ai, aj, aav, bv, rtol=1e-9), TOL_CONVERGED)
 
 
 def test_cg_nonzero_guess_and_max_it(hx):

@@ -1,6 +1,8 @@
-"""GPU parity of MatSOR (level-scheduled sweeps) against the oracle's MatSOR_SeqAIJ restatement (aij.c:1842-2007):
-bit-exact x for every sweep type the reference implements on this path, and GMRES/CG + PCSOR histories."""
+"""GPU parity of MatSOR against the oracle's MatSOR_SeqAIJ restatement (aij.c:1842-2007): bit-exact x for every sweep type
+the reference implements on this path, in every schedule libhipx has (strands for stencil matrices, the level-ordered
+dependency-driven sweep, one launch per level), up to BASELINE sizes (>= 1 M rows), and GMRES/CG + PCSOR histories."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -14,12 +16,39 @@ pytestmark = pytest.mark.gpu
 FWD, BWD, SYM, LFWD, LBWD, LSYM, ZERO, UPPER = 1, 2, 3, 4, 8, 12, 16, 64
 
 
-def sor_gpu(hx, ai, aj, aa, b, omega, flag, shift, its, lits, x0):
+MODES = {"levels": 0, "dep": 1, "strand": 2}
+
+
+class sor_mode:
+    """HIPX_SOR_MODE for the calls inside the block (read by hipxMatSOR at every call); None = the library's own choice."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = os.environ.pop("HIPX_SOR_MODE", None)
+        if self.mode:
+            os.environ["HIPX_SOR_MODE"] = self.mode
+
+    def __exit__(self, *a):
+        os.environ.pop("HIPX_SOR_MODE", None)
+        if self.old is not None:
+            os.environ["HIPX_SOR_MODE"] = self.old
+
+
+def sor_gpu(hx, ai, aj, aa, b, omega, flag, shift, its, lits, x0, mode=None, want_mode=None):
     from petsc_amd import _lib
     N = len(ai) - 1
     A = _lib.mat_create_csr(N, N, ai, aj, aa)
     B, X = _lib.DVec(N, b), _lib.DVec(N, x0)
-    _lib.chk(hx.hipxMatSOR(A, B.ptr, omega, flag, shift, its, lits, X.ptr))
+    with sor_mode(mode):
+        _lib.chk(hx.hipxMatSOR(A, B.ptr, omega, flag, shift, its, lits, X.ptr))
+    used = C.c_int(-2)
+    _lib.chk(hx.hipxMatGetSORMode(A, C.byref(used)))
+    if mode and flag != UPPER:
+        assert used.value == MODES[mode], (used.value, mode)
+    if want_mode is not None and flag != UPPER:
+        assert used.value == MODES[want_mode], (used.value, want_mode)
     x = X.get()
     B.free()
     X.free()
@@ -33,18 +62,127 @@ def sor_cpu(ai, aj, aa, b, omega, flag, shift, its, lits, x0):
     return x
 
 
-@pytest.mark.parametrize("kind,n,m", [("5pt", 9, 7), ("7pt", 12, None), ("27pt", 9, None)])
+@pytest.mark.parametrize("kind,n,m", [("5pt", 9, 7), ("7pt", 12, None), ("27pt", 9, None), ("7pt", 16, None), ("27pt", 24, None), ("5pt", 64, 40)])
 @pytest.mark.parametrize("flag", [SYM | ZERO, LSYM | ZERO, FWD | ZERO, BWD | ZERO, SYM, FWD, BWD, UPPER])
 @pytest.mark.parametrize("omega,shift,its,lits", [(1.0, 0.0, 1, 1), (1.3, 0.0, 2, 1), (0.8, 0.25, 1, 3)])
-def test_sor_sweeps_bit_exact(hx, kind, n, m, flag, omega, shift, its, lits):
+@pytest.mark.parametrize("mode", ["strand", "dep", "levels"])
+def test_sor_sweeps_bit_exact(hx, kind, n, m, flag, omega, shift, its, lits, mode):
+    """Every sweep kind of aij.c:1930-2002 in every schedule; grids with L % 8 == 0 (16, 24, 64: the loader's aligned 64-byte
+    runs) and without (9, 12), strands shorter than a panel and several panels per plane."""
+    if mode != "strand" and (n >= 24 or (flag, omega) != (SYM | ZERO, 1.0)) and n > 12:
+        pytest.skip("the level-ordered schedules are covered on the small grids")
     ai, aj, aa = orc.stencil(kind, n, m=m)
     N = len(ai) - 1
     rng = np.random.default_rng(7)
     b = rng.standard_normal(N)
     x0 = rng.standard_normal(N)
-    g = sor_gpu(hx, ai, aj, aa, b, omega, flag, shift, its, lits, x0)
+    g = sor_gpu(hx, ai, aj, aa, b, omega, flag, shift, its, lits, x0, mode=mode)
     o = sor_cpu(ai, aj, aa, b, omega, flag, shift, its, lits, x0)
     assert np.array_equal(g, o), np.abs(g - o).max()
+
+
+def assemble_c(stencil, n):
+    from petsc_amd import _lib
+    _, ks = _lib.load()
+    f = {7: ks.HipxAssemble_poisson7, 27: ks.HipxAssemble_bench27}[stencil]
+    N = n ** 3
+    nz = f(n, 0, N, None, None, None)
+    ai, aj, aa = np.zeros(N + 1, np.int32), np.zeros(nz, np.int32), np.zeros(nz)
+    f(n, 0, N, ai.ctypes.data_as(C.c_void_p), aj.ctypes.data_as(C.c_void_p), aa.ctypes.data_as(C.c_void_p))
+    return ai, aj, aa
+
+
+@pytest.mark.parametrize("stencil,n", [(7, 128), (27, 96), (27, 128), (7, 200)])
+@pytest.mark.parametrize("mode", ["strand", "dep"])
+def test_sor_bit_exact_at_scale(hx, stencil, n, mode):
+    """>= 1 M rows (7-pt 128^3 = 2.1 M, 27-pt 96^3 = 0.88 M, 27-pt 128^3: the size class where the first dependency-driven
+    sweep gave up during round 1; 7-pt 200^3 = 8 M rows = several rounds of panels per CU): PCSOR's default symmetric sweep and
+    a general 2-iteration sweep, bit-identical to the sequential CPU sweep, in both dependency-driven schedules."""
+    if mode == "dep" and n > 128:
+        pytest.skip("level-ordered schedule: covered at 128^3")
+    ai, aj, aa = assemble_c(stencil, n)
+    N = len(ai) - 1
+    rng = np.random.default_rng(11)
+    b = rng.standard_normal(N)
+    x0 = rng.standard_normal(N)
+    for flag, omega, its in [(LSYM | ZERO, 1.0, 1), (SYM, 1.2, 2)]:
+        g = sor_gpu(hx, ai, aj, aa, b, omega, flag, 0.0, its, 1, x0, mode=mode)
+        o = sor_cpu(ai, aj, aa, b, omega, flag, 0.0, its, 1, x0)
+        assert np.array_equal(g, o), (flag, np.abs(g - o).max())
+
+
+def test_sor_config3_rank_slab_bit_exact(hx):
+    """BASELINE config 3's per-rank operator: the diagonal block of rank 3 of 8 of the 27-pt 512^3 matrix (512 x 512 x 64 =
+    16.8 M rows, 447 M nonzeros, split as MatSetUpMultiply_MPIAIJ does) -- PCSOR's local symmetric sweep, bit-identical to the
+    sequential CPU sweep.  This is the sweep GMRES(30)+PCSOR runs on every rank (mpiaij.c:1408-1412)."""
+    import sys
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from petsc_amd import _lib
+    from petsc_amd import dist as pdist
+    _, ks = _lib.load()
+    n, nranks, rank = 512, 8, 3
+    ranges = pdist.split_ownership(n ** 3, nranks)
+    rs, re = int(ranges[rank]), int(ranges[rank + 1])
+    ai, aj, aa = bench.assemble(ks, 27, (n, n, n), rs, re)
+    fake = types.SimpleNamespace(all_gather_object=lambda out, obj, group=None: out.__setitem__(slice(None), [obj] * len(out)))
+    plan = pdist.build_plan(ai, aj, aa, ranges, rank, dist=fake)
+    del ai, aj, aa
+    Ai, Aj, Aa = plan["Ai"], plan["Aj"], plan["Aa"]
+    m = plan["m"]
+    assert m == 512 * 512 * 64
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(m)
+    g = sor_gpu(hx, Ai, Aj, Aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, np.zeros(m), want_mode="strand")
+    o = sor_cpu(Ai, Aj, Aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, np.zeros(m))
+    assert np.array_equal(g, o), np.abs(g - o).max()
+
+
+def test_sor_default_schedule_selection(hx):
+    """The library's own choice: strands for stencil matrices, the level-ordered sweep for matrices without row templates
+    (variable coefficients), and after hipxMatUpdateValues the choice follows the new values."""
+    from petsc_amd import _lib
+    ai, aj, aa = orc.stencil("7pt", 20)
+    N = len(ai) - 1
+    rng = np.random.default_rng(2)
+    b, x0 = rng.standard_normal(N), rng.standard_normal(N)
+    g = sor_gpu(hx, ai, aj, aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0, want_mode="strand")
+    assert np.array_equal(g, sor_cpu(ai, aj, aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0))
+    aav = aa * (1.0 + 0.01 * rng.standard_normal(aa.size))
+    g = sor_gpu(hx, ai, aj, aav, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0, want_mode="dep")
+    assert np.array_equal(g, sor_cpu(ai, aj, aav, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0))
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    B, X = _lib.DVec(N, b), _lib.DVec(N, x0)
+    used = C.c_int()
+    for vals, want in [(aa, 2), (aav, 1), (aa * 2.0, 2)]:
+        _lib.chk(hx.hipxMatUpdateValues(A, orc.P(np.ascontiguousarray(vals))))
+        _lib.chk(hx.hipxMatSOR(A, B.ptr, 1.0, LSYM | ZERO, 0.0, 1, 1, X.ptr))
+        _lib.chk(hx.hipxMatGetSORMode(A, C.byref(used)))
+        assert used.value == want
+        assert np.array_equal(X.get(), sor_cpu(ai, aj, np.ascontiguousarray(vals), b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0))
+    B.free()
+    X.free()
+    _lib.mat_destroy(A)
+
+
+def test_sor_long_dependency_chain_uses_level_launches(hx):
+    """Tridiagonal matrix: one row per level.  Padding every level to a wave would need 64 slots per row; the library runs one
+    launch per level there (and still matches the CPU sweep bit for bit)."""
+    m = 3000
+    ai = np.zeros(m + 1, np.int32)
+    cols, vals = [], []
+    rng = np.random.default_rng(4)
+    for r in range(m):
+        for c in (r - 1, r, r + 1):
+            if 0 <= c < m:
+                cols.append(c)
+                vals.append(4.0 + rng.random() if c == r else -1.0 - rng.random())
+        ai[r + 1] = len(cols)
+    aj, aa = np.array(cols, np.int32), np.array(vals)
+    b, x0 = rng.standard_normal(m), rng.standard_normal(m)
+    g = sor_gpu(hx, ai, aj, aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0, want_mode="levels")
+    assert np.array_equal(g, sor_cpu(ai, aj, aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0))
 
 
 def test_sor_structurally_unsymmetric_matrix(hx):
