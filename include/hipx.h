@@ -192,6 +192,15 @@ typedef struct hipxHalo_s *hipxHalo;
 int hipxHaloCreate(int nsend, const int *send_ranks, const hipx_int *send_off, const hipx_int *send_idx,
                    int nrecv, const int *recv_ranks, const hipx_int *recv_off, hipxHalo *h);
 int hipxHaloDestroy(hipxHalo *h);
+/* Second transport for the same plan: PEER STORES through HIP IPC mappings instead of RCCL send/recv.  The pack kernel of the
+   sender writes x[send_idx] straight into the receiver's ghost buffer (over xGMI between GPUs; through L2 when ranks share a
+   GPU, which RCCL refuses), then publishes a sequence number; the receiver's stream waits for it in a one-wave kernel; ghost
+   buffers are double-buffered and acknowledged, so back-to-back products need no other synchronisation.  Set-up: every rank
+   exports a blob, the host all-gathers them (MPI_Allgather / torch.distributed), every rank attaches.  Once attached,
+   hipxMatMultMPI takes this path (its lvec argument is then unused). */
+#define HIPX_HALO_IPC_BLOB_BYTES 1024
+int hipxHaloIpcExport(hipxHalo h, int rank, int nranks, void *blob1024);
+int hipxHaloIpcAttach(hipxHalo h, const void *all_blobs /* nranks x 1024 bytes, indexed by rank */);
 int hipxHaloBegin(hipxHalo h, const double *x, double *lvec); /* pack on compute stream -> send/recv on comm stream */
 int hipxHaloEnd(hipxHalo h);                                  /* compute stream waits for the exchange */
 /* replaces MatMult_MPIAIJ mpiaij.c:1047-1061: halo begin; y = Ad x (overlapped); halo end; y += Bo lvec */

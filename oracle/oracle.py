@@ -70,8 +70,18 @@ def matmult(ai, aj, aa, x):
 
 
 def ksp_solve(kind, ai, aj, aa, b, pc="jacobi", rtol=1e-5, max_it=10000, normtype=1, restart=30, refine=0, sor_flag=12, omega=1.0,
-              nranks=1, x0=None, abstol=1e-50, sor_its=1, sor_lits=1):
+              nranks=1, x0=None, abstol=1e-50, sor_its=1, sor_lits=1, exact=False):
+    """exact=True: every dot product / norm of the solve is evaluated as if in twice the working precision (the correctly rounded
+    reduction): the yardstick both the reference's BLAS and the GPU's reduction tree are roundings of."""
     L = lib()
+    L.orc_set_exact_reductions(1 if exact else 0)
+    try:
+        return _ksp_solve(L, kind, ai, aj, aa, b, pc, rtol, max_it, normtype, restart, refine, sor_flag, omega, nranks, x0, abstol, sor_its, sor_lits)
+    finally:
+        L.orc_set_exact_reductions(0)
+
+
+def _ksp_solve(L, kind, ai, aj, aa, b, pc, rtol, max_it, normtype, restart, refine, sor_flag, omega, nranks, x0, abstol, sor_its, sor_lits):
     k = OrcKSP()
     L.orc_KSPSetDefaults(C.byref(k))
     m = len(ai) - 1

@@ -383,9 +383,33 @@ void orc_PetscSplitOwnership(OInt N, int size, OInt *ranges)
 
 /* ============================ Vec_Seq ========================================================== */
 
+/* Reduction mode of the oracle.  0 (default): the published definition of ddot, left to right in double -- what a reference
+   BLAS does up to its own blocking.  1: "exactly rounded" reductions -- the dot product evaluated as if in twice the working
+   precision (Dot2 of Ogita, Rump & Oishi, SIAM J. Sci. Comput. 26(6), 2005: error-free TwoProduct via fma + TwoSum), i.e. the
+   correctly rounded value for every vector the tests use.  The reference's BLAS (MKL) and the GPU's fixed tree are both
+   roundings of THAT number; mode 1 lets a test measure each of them against it instead of against each other. */
+static int orc_exact_reductions = 0;
+void orc_set_exact_reductions(int on) { orc_exact_reductions = on; }
+
+static OScalar dot2(OInt n, const OScalar *x, const OScalar *y)
+{
+  OScalar p = 0.0, s = 0.0;
+  for (OInt i = 0; i < n; i++) {
+    const OScalar h = x[i] * y[i];
+    const OScalar r = fma(x[i], y[i], -h); /* x*y = h + r exactly */
+    const OScalar t = p + h;               /* TwoSum(p, h) = (t, q) */
+    const OScalar z = t - p;
+    const OScalar q = (p - (t - z)) + (h - z);
+    p = t;
+    s += q + r;
+  }
+  return p + s;
+}
+
 /* bvec1.c:10-49 -> BLAS ddot (third-party; see header).  Published definition, left-to-right. */
 OScalar orc_VecDot_Seq(OInt n, const OScalar *x, const OScalar *y)
 {
+  if (orc_exact_reductions) return dot2(n, x, y);
   OScalar s = 0.0;
   for (OInt i = 0; i < n; i++) s += x[i] * y[i];
   return s;

@@ -91,7 +91,9 @@ OInt orc_MatSetUpMultiply_MPIAIJ(OInt m, OInt cstart, OInt cend, const OInt *ai,
 OInt orc_MatCheckCompressedRow(OInt m, const OInt *bi, OInt *ci, OInt *ridx);
 
 /* ---- Vec_Seq kernels -------------------------------------------------------------------------- */
-OScalar orc_VecDot_Seq(OInt n, const OScalar *x, const OScalar *y);                               /* bvec1.c:10-49 (BLAS ddot) */
+OScalar orc_VecDot_Seq(OInt n, const OScalar *x, const OScalar *y);
+/* 1: dot products / 2-norms evaluated as if in twice the working precision (Dot2, Ogita-Rump-Oishi 2005); 0: left to right in double */
+void    orc_set_exact_reductions(int on);                               /* bvec1.c:10-49 (BLAS ddot) */
 void    orc_VecMDot_Seq(OInt n, const OScalar *x, OInt nv, const OScalar *const *y, OScalar *z);  /* dvec2.c:83-... */
 OScalar orc_VecNorm_Seq(OInt n, const OScalar *x, int type, OScalar *z2);                         /* bvec2.c:185-235 */
 void    orc_VecAXPY_Seq(OInt n, OScalar *y, OScalar a, const OScalar *x);                         /* bvec1.c:70-89 */

@@ -44,7 +44,72 @@ __global__ void pack_kernel(const double *__restrict__ x, const hipx_int *__rest
   for (hipx_int i = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (hipx_int)gridDim.x * blockDim.x) buf[i] = x[idx[i]];
 }
 
+// ---- IPC transport kernels.  Flags live in fine-grained memory and are accessed with system-scope atomics; payload writes
+// are released with __threadfence_system() before the sequence number is stored (the R1 shape of cdna_hip_programming.md
+// Guideline 16, at system scope because the reader is another process / another GPU).
+constexpr long long IPC_WAIT_TICKS = 800000000LL;  // 8 s of the 100 MHz wall clock
+
+__device__ __forceinline__ bool ipc_wait_ge(const unsigned long long *flag, unsigned long long want, unsigned int *err)
+{
+  long long t0 = 0;
+  for (unsigned spins = 1;; spins++) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return true;
+    __builtin_amdgcn_s_sleep(4);
+    if ((spins & 0x3ff) == 0) {
+      const long long now = (long long)wall_clock64();
+      if (!t0) t0 = now;
+      if (now - t0 > IPC_WAIT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+}
+
+// gather x[idx[k]] straight into the neighbour's ghost buffer; the last workgroup to finish publishes the sequence number
+__global__ __launch_bounds__(256) void ipc_put_kernel(const double *__restrict__ x, const hipx_int *__restrict__ idx, hipx_int n, double *dst, const unsigned long long *ack_local,
+                                                      unsigned long long need_ack, unsigned long long *data_flag, unsigned long long seq, unsigned int *ticket, unsigned int *err)
+{
+  __shared__ int ok;
+  if (threadIdx.x == 0) ok = ipc_wait_ge(ack_local, need_ack, err) ? 1 : 0;  // the buffer of exchange seq - 2 has been consumed
+  __syncthreads();
+  if (ok)
+    for (hipx_int i = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (hipx_int)gridDim.x * blockDim.x) dst[i] = x[idx[i]];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = atomicAdd(ticket, 1u);
+    if (t == gridDim.x - 1) {
+      *ticket = 0;
+      __threadfence_system();
+      __hip_atomic_store(data_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+__global__ void ipc_wait_kernel(const unsigned long long *data_seq, const int *recv_ranks, int nrecv, unsigned long long seq, unsigned int *err)
+{
+  if ((int)threadIdx.x < nrecv) ipc_wait_ge(data_seq + recv_ranks[threadIdx.x], seq, err);
+}
+
+__global__ void ipc_ack_kernel(unsigned long long *const *ack_ptrs, int nrecv, unsigned long long seq)
+{
+  if ((int)threadIdx.x < nrecv) __hip_atomic_store(ack_ptrs[threadIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
+
+// IPC transport: what a rank publishes about its receive side (one blob per rank, all-gathered by the host: MPI_Allgather in
+// the PETSc plugin, torch.distributed in bench.py)
+constexpr int IPC_MAXN = 60;
+struct IpcBlob {
+  hipIpcMemHandle_t handle;  // the receive arena
+  int               rank, nrecv;
+  long long         nghost;
+  int               recv_ranks[IPC_MAXN];
+  hipx_int          recv_off[IPC_MAXN + 1];
+};
+static_assert(sizeof(IpcBlob) <= HIPX_HALO_IPC_BLOB_BYTES, "IPC blob size");
 
 struct hipxHalo_s {
   int                   nsend = 0, nrecv = 0;
@@ -53,6 +118,22 @@ struct hipxHalo_s {
   hipx_int             *d_send_idx = nullptr;
   double               *d_sendbuf  = nullptr;
   hipEvent_t            ev_packed = nullptr, ev_done = nullptr;
+  // ---- IPC transport (peer stores; see hipxHaloIpcExport)
+  bool                  ipc = false;
+  int                   me = -1, nranks = 0;
+  unsigned long long    seq = 0;            // exchanges started
+  char                 *arena = nullptr;    // fine-grained device memory: [data_seq[nranks] | ack_seq[nranks] | ghost buffer 0 | ghost buffer 1]
+  size_t                hdr_bytes = 0, nghost = 0;
+  std::vector<char *>   send_base, recv_base;  // neighbours' arenas as mapped here (own arena for a self-exchange)
+  std::vector<hipx_int> send_peer_off;         // where my values start in that neighbour's ghost buffer
+  std::vector<long long> send_peer_nghost;     // length of that neighbour's ghost buffer (stride between its two buffers)
+  std::vector<void *>   opened;                // hipIpcOpenMemHandle results (closed at destroy)
+  unsigned int         *d_ticket = nullptr;    // one per send neighbour
+  int                  *d_recv_ranks = nullptr;
+  unsigned long long  **d_ack_ptrs = nullptr;  // per recv neighbour: &peer.ack_seq[me]
+  unsigned int         *d_err = nullptr;
+  unsigned int         *h_err = nullptr;       // pinned; checked at the next call (no sync on the data path)
+  double               *ghost_cur = nullptr;   // ghost values of the exchange in progress / last completed
 };
 
 extern "C" {
@@ -187,6 +268,13 @@ int hipxHaloDestroy(hipxHalo *ph)
   HIPX_HIP(hipDeviceSynchronize());
   (void)hipFree(h->d_send_idx);
   (void)hipFree(h->d_sendbuf);
+  for (void *q : h->opened) (void)hipIpcCloseMemHandle(q);
+  (void)hipFree(h->arena);
+  (void)hipFree(h->d_ticket);
+  (void)hipFree(h->d_recv_ranks);
+  (void)hipFree(h->d_ack_ptrs);
+  (void)hipFree(h->d_err);
+  if (h->h_err) (void)hipHostFree(h->h_err);
   (void)hipEventDestroy(h->ev_packed);
   (void)hipEventDestroy(h->ev_done);
   delete h;
@@ -200,6 +288,28 @@ int hipxHaloBegin(hipxHalo h, const double *x, double *lvec)
   Comm &c = cm();
   HIPX_ARG(h, "null halo");
   if (h->nsend + h->nrecv == 0) return HIPX_SUCCESS;
+  if (h->ipc) {
+    if (*h->h_err) return fail(HIPX_ERR_GPU, "ghost exchange (IPC): a neighbour never published / acknowledged its data (wait limit reached)", __FILE__, __LINE__);
+    const unsigned long long s = ++h->seq;
+    const int                q = (int)(s & 1);
+    h->ghost_cur = reinterpret_cast<double *>(h->arena + h->hdr_bytes) + (size_t)q * h->nghost;
+    HIPX_HIP(hipEventRecord(h->ev_packed, rt().compute));  // x is complete
+    HIPX_HIP(hipStreamWaitEvent(rt().comm, h->ev_packed, 0));
+    for (int r = 0; r < h->nsend; r++) {
+      const hipx_int cnt = h->send_off[r + 1] - h->send_off[r];
+      if (!cnt) continue;
+      char   *pb  = h->send_base[(size_t)r];
+      double *dst = reinterpret_cast<double *>(pb + h->hdr_bytes) + (size_t)q * (size_t)h->send_peer_nghost[(size_t)r] + h->send_peer_off[(size_t)r];
+      unsigned long long       *flag = reinterpret_cast<unsigned long long *>(pb) + h->me;                                      // peer.data_seq[me]
+      const unsigned long long *ack  = reinterpret_cast<const unsigned long long *>(h->arena) + h->nranks + h->send_ranks[r];  // my ack_seq[peer]
+      hipx_int g = (cnt + 255) / 256;
+      if (g > 512) g = 512;
+      ipc_put_kernel<<<(unsigned)g, 256, 0, rt().comm>>>(x, h->d_send_idx + h->send_off[r], cnt, dst, ack, s >= 2 ? s - 2 : 0, flag, s, h->d_ticket + r, h->d_err);
+    }
+    HIPX_LAUNCH_CHECK();
+    HIPX_HIP(hipEventRecord(h->ev_done, rt().comm));
+    return HIPX_SUCCESS;
+  }
   if (!c.active) return fail(HIPX_ERR_ORDER, "hipxCommInit() must precede a ghost exchange", __FILE__, __LINE__);
   const hipx_int ns = h->send_off[h->nsend];
   if (ns) {
@@ -230,7 +340,116 @@ int hipxHaloEnd(hipxHalo h)
   HIPX_CHECK_INIT();
   HIPX_ARG(h, "null halo");
   if (h->nsend + h->nrecv == 0) return HIPX_SUCCESS;
-  HIPX_HIP(hipStreamWaitEvent(rt().compute, h->ev_done, 0));
+  HIPX_HIP(hipStreamWaitEvent(rt().compute, h->ev_done, 0));  // RCCL: the receives landed; IPC: my puts have read x
+  if (h->ipc && h->nrecv) {
+    ipc_wait_kernel<<<1, 64, 0, rt().compute>>>(reinterpret_cast<const unsigned long long *>(h->arena), h->d_recv_ranks, h->nrecv, h->seq, h->d_err);
+    HIPX_LAUNCH_CHECK();
+  }
+  return HIPX_SUCCESS;
+}
+
+// IPC: the ghost values of the exchange have been consumed (after the off-diagonal product): tell the senders, so that the
+// exchange after next may overwrite this buffer
+static int halo_release(hipxHalo h)
+{
+  if (!h->ipc || h->nsend + h->nrecv == 0) return HIPX_SUCCESS;
+  if (h->nrecv) {
+    ipc_ack_kernel<<<1, 64, 0, rt().compute>>>(h->d_ack_ptrs, h->nrecv, h->seq);
+    HIPX_LAUNCH_CHECK();
+  }
+  HIPX_HIP(hipMemcpyAsync(h->h_err, h->d_err, sizeof(unsigned int), hipMemcpyDeviceToHost, rt().compute));  // seen at the next call
+  return HIPX_SUCCESS;
+}
+
+int hipxHaloIpcExport(hipxHalo h, int rank, int nranks, void *blob)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(h && blob && nranks >= 1 && rank >= 0 && rank < nranks, "bad arguments");
+  HIPX_ARG(h->nrecv <= IPC_MAXN && h->nsend <= IPC_MAXN, "IPC ghost exchange: at most 60 neighbours");
+  h->me        = rank;
+  h->nranks    = nranks;
+  h->nghost    = (size_t)h->recv_off[h->nrecv];
+  h->hdr_bytes = ((size_t)16 * (size_t)nranks + 255) & ~(size_t)255;
+  const size_t bytes = h->hdr_bytes + 2 * sizeof(double) * std::max<size_t>(h->nghost, 1);
+  if (!h->arena) {
+    // fine-grained: flags are polled while another process / GPU writes them, and the ghost values are written by the peers
+    HIPX_HIP(hipExtMallocWithFlags((void **)&h->arena, bytes, hipDeviceMallocFinegrained));
+    HIPX_HIP(hipMemset(h->arena, 0, bytes));
+    HIPX_HIP(hipMalloc((void **)&h->d_err, sizeof(unsigned int)));
+    HIPX_HIP(hipMemset(h->d_err, 0, sizeof(unsigned int)));
+    HIPX_HIP(hipHostMalloc((void **)&h->h_err, sizeof(unsigned int), hipHostMallocDefault));
+    *h->h_err = 0;
+  }
+  IpcBlob b;
+  memset(&b, 0, sizeof(b));
+  HIPX_HIP(hipIpcGetMemHandle(&b.handle, h->arena));
+  b.rank   = rank;
+  b.nrecv  = h->nrecv;
+  b.nghost = (long long)h->nghost;
+  for (int r = 0; r < h->nrecv; r++) b.recv_ranks[r] = h->recv_ranks[r];
+  for (int r = 0; r <= h->nrecv; r++) b.recv_off[r] = h->recv_off[r];
+  memset(blob, 0, HIPX_HALO_IPC_BLOB_BYTES);
+  memcpy(blob, &b, sizeof(b));
+  return HIPX_SUCCESS;
+}
+
+int hipxHaloIpcAttach(hipxHalo h, const void *all_blobs)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(h && all_blobs && h->arena, "hipxHaloIpcExport() first");
+  const char *blobs = (const char *)all_blobs;
+  std::vector<char *> base((size_t)h->nranks, nullptr);
+  auto map_rank = [&](int r, char **out) -> int {
+    if (!base[(size_t)r]) {
+      if (r == h->me) base[(size_t)r] = h->arena;
+      else {
+        IpcBlob b;
+        memcpy(&b, blobs + (size_t)r * HIPX_HALO_IPC_BLOB_BYTES, sizeof(b));
+        void *q = nullptr;
+        HIPX_HIP(hipIpcOpenMemHandle(&q, b.handle, hipIpcMemLazyEnablePeerAccess));
+        h->opened.push_back(q);
+        base[(size_t)r] = (char *)q;
+      }
+    }
+    *out = base[(size_t)r];
+    return HIPX_SUCCESS;
+  };
+  h->send_base.assign((size_t)h->nsend, nullptr);
+  h->send_peer_off.assign((size_t)h->nsend, 0);
+  h->send_peer_nghost.assign((size_t)h->nsend, 0);
+  for (int i = 0; i < h->nsend; i++) {
+    const int r = h->send_ranks[i];
+    HIPX_ARG(r >= 0 && r < h->nranks, "send neighbour out of range");
+    int ierr = map_rank(r, &h->send_base[(size_t)i]);
+    if (ierr) return ierr;
+    IpcBlob b;
+    memcpy(&b, blobs + (size_t)r * HIPX_HALO_IPC_BLOB_BYTES, sizeof(b));
+    int found = -1;
+    for (int k = 0; k < b.nrecv; k++)
+      if (b.recv_ranks[k] == h->me) found = k;
+    HIPX_ARG(found >= 0 && b.recv_off[found + 1] - b.recv_off[found] == h->send_off[i + 1] - h->send_off[i], "IPC ghost exchange: send and receive lists of two ranks do not match");
+    h->send_peer_off[(size_t)i]    = b.recv_off[found];
+    h->send_peer_nghost[(size_t)i] = std::max<long long>(b.nghost, 1);
+  }
+  std::vector<unsigned long long *> ack((size_t)std::max(h->nrecv, 1), nullptr);
+  for (int i = 0; i < h->nrecv; i++) {
+    const int r = h->recv_ranks[i];
+    HIPX_ARG(r >= 0 && r < h->nranks, "receive neighbour out of range");
+    char *pb  = nullptr;
+    int  ierr = map_rank(r, &pb);
+    if (ierr) return ierr;
+    ack[(size_t)i] = reinterpret_cast<unsigned long long *>(pb) + h->nranks + h->me;  // peer.ack_seq[me]
+  }
+  HIPX_HIP(hipMalloc((void **)&h->d_ticket, sizeof(unsigned int) * (size_t)std::max(h->nsend, 1)));
+  HIPX_HIP(hipMemset(h->d_ticket, 0, sizeof(unsigned int) * (size_t)std::max(h->nsend, 1)));
+  HIPX_HIP(hipMalloc((void **)&h->d_recv_ranks, sizeof(int) * (size_t)std::max(h->nrecv, 1)));
+  HIPX_HIP(hipMalloc((void **)&h->d_ack_ptrs, sizeof(void *) * (size_t)std::max(h->nrecv, 1)));
+  if (h->nrecv) {
+    HIPX_HIP(hipMemcpy(h->d_recv_ranks, h->recv_ranks.data(), sizeof(int) * (size_t)h->nrecv, hipMemcpyHostToDevice));
+    HIPX_HIP(hipMemcpy(h->d_ack_ptrs, ack.data(), sizeof(void *) * (size_t)h->nrecv, hipMemcpyHostToDevice));
+  }
+  h->ghost_cur = reinterpret_cast<double *>(h->arena + h->hdr_bytes);
+  h->ipc       = true;
   return HIPX_SUCCESS;
 }
 
@@ -241,8 +460,9 @@ int hipxMatMultMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *
   if ((ierr = hipxHaloBegin(h, x, lvec))) return ierr;  // VecScatterBegin   mpiaij.c:1056
   if ((ierr = hipxMatMult(Ad, x, y))) return ierr;      // A->ops->mult      mpiaij.c:1057 (overlaps the exchange)
   if ((ierr = hipxHaloEnd(h))) return ierr;             // VecScatterEnd     mpiaij.c:1058
-  if (Bo) return hipxMatMultAdd(Bo, lvec, y, y);        // B->ops->multadd   mpiaij.c:1059
-  return HIPX_SUCCESS;
+  const double *ghost = (h && h->ipc) ? h->ghost_cur : lvec;  // IPC transport: the neighbours wrote straight into this rank's ghost buffer
+  if (Bo && (ierr = hipxMatMultAdd(Bo, ghost, y, y))) return ierr;  // B->ops->multadd   mpiaij.c:1059
+  return h ? halo_release(h) : HIPX_SUCCESS;
 }
 
 }  // extern "C"

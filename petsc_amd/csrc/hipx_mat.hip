@@ -969,7 +969,7 @@ __global__ __launch_bounds__(256) void tmpl_verify_kernel(hipx_int m, hipx_int n
 // (rows +-n, +-n^2) are shared through that XCD's L2.  Thread t of a chunk owns rows base + t + rr*256: the k-th gather of
 // a wave reads x[row + off_k] for 64 consecutive rows = one 512-byte contiguous run when the lanes share a template
 // (interior), and the LDS reads of the template entries broadcast.
-template <int MODE, bool DOT, int RPT, int W>
+template <int MODE, bool DOT, int RPT, int W, bool UNI>
 __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const int *__restrict__ tstart,
                                                         const int *__restrict__ toff, const double *__restrict__ tval, int ntmpl, int nent, const double *__restrict__ x,
                                                         const double *yin, double *yout, double *dotpart)
@@ -990,42 +990,78 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
   double         mydot = 0.0;
   for (hipx_int c = c0 + slot; c < c1; c += bpx) {
     const hipx_int base = c * (256 * RPT);
-    int            s0[RPT], len[RPT], maxlen = 0;
+    int            id[RPT];
     double         sum[RPT], xrow[RPT];
+    bool           uni = UNI && (base + 256 * RPT <= m) && ((unsigned long long)m < (1ull << 28));  // whole chunk inside the matrix; 32-bit byte offsets
 #pragma unroll
     for (int rr = 0; rr < RPT; rr++) {
       const hipx_int row = base + t + rr * 256;
-      s0[rr] = 0;
-      len[rr] = 0;
-      sum[rr] = 0.0;
+      id[rr]   = 0;
+      sum[rr]  = 0.0;
       xrow[rr] = 0.0;
       if (row < m) {
-        const int id = tid[row];
-        s0[rr]  = s_start[id];
-        len[rr] = s_start[id + 1] - s0[rr];
+        id[rr] = tid[row];
         if (MODE == 1) sum[rr] = yin[row];
         if (DOT) xrow[rr] = x[row];
       }
-      maxlen = max(maxlen, len[rr]);
     }
-    for (int k = 0; k < maxlen; k += W) {
-      double xv[RPT][W], av[RPT][W];
+    int id0 = 0;
+    if (UNI) {
+      id0 = __builtin_amdgcn_readfirstlane(id[0]);
+#pragma unroll
+      for (int rr = 0; rr < RPT; rr++) uni = uni && (id[rr] == id0);
+      uni = __all(uni);
+    }
+    if (UNI && uni) {
+      // every lane of the wave walks the SAME template (interior rows): offsets and values are wave-uniform scalars read from
+      // the global table through the scalar cache, the gather address is (x + off) [scalar] + row * 8 [per lane, computed once]:
+      // per nonzero the vector unit issues one load, one multiply and one add, nothing else
+      const int ts = tstart[id0], te = tstart[id0 + 1];
+      unsigned  rb[RPT];
+#pragma unroll
+      for (int rr = 0; rr < RPT; rr++) rb[rr] = (unsigned)(base + t + rr * 256) * 8u;
+#pragma unroll 4
+      for (int k = ts; k < te; k++) {
+        const double a  = tval[k];
+        const char  *xb = reinterpret_cast<const char *>(x + toff[k]);
+        double       xv[RPT];
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) xv[rr] = *reinterpret_cast<const double *>(xb + rb[rr]);
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) sum[rr] += a * xv[rr];
+      }
+    } else {
+      int s0[RPT], len[RPT], maxlen = 0;
 #pragma unroll
       for (int rr = 0; rr < RPT; rr++) {
         const hipx_int row = base + t + rr * 256;
-#pragma unroll
-        for (int e = 0; e < W; e++) {
-          const bool on  = (k + e) < len[rr];
-          const int  idx = on ? s0[rr] + k + e : 0;
-          av[rr][e]      = s_val[idx];
-          xv[rr][e]      = on ? x[row + s_off[idx]] : 0.0;
+        s0[rr]  = 0;
+        len[rr] = 0;
+        if (row < m) {
+          s0[rr]  = s_start[id[rr]];
+          len[rr] = s_start[id[rr] + 1] - s0[rr];
         }
+        maxlen = max(maxlen, len[rr]);
       }
+      for (int k = 0; k < maxlen; k += W) {
+        double xv[RPT][W], av[RPT][W];
 #pragma unroll
-      for (int rr = 0; rr < RPT; rr++) {
+        for (int rr = 0; rr < RPT; rr++) {
+          const hipx_int row = base + t + rr * 256;
 #pragma unroll
-        for (int e = 0; e < W; e++)
-          if ((k + e) < len[rr]) sum[rr] += av[rr][e] * xv[rr][e];
+          for (int e = 0; e < W; e++) {
+            const bool on  = (k + e) < len[rr];
+            const int  idx = on ? s0[rr] + k + e : 0;
+            av[rr][e]      = s_val[idx];
+            xv[rr][e]      = on ? x[row + s_off[idx]] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) {
+#pragma unroll
+          for (int e = 0; e < W; e++)
+            if ((k + e) < len[rr]) sum[rr] += av[rr][e] * xv[rr][e];
+        }
       }
     }
 #pragma unroll
@@ -1563,12 +1599,26 @@ int ensure_templates(hipxMat A)
   return ierr;
 }
 
+// geometry of the template kernel: HIPX_TMPL_CFG = 0 (2 rows per thread, per-lane walk only) | 1 (2 rows, uniform fast path)
+// | 2 (4 rows, uniform fast path: default) | 3 (4 rows, per-lane walk only) | 4 (8 rows, uniform fast path)
+int tmpl_cfg()
+{
+  static const int v = getenv("HIPX_TMPL_CFG") ? atoi(getenv("HIPX_TMPL_CFG")) : 2;
+  return v;
+}
+int tmpl_blocks()
+{
+  static const int v = getenv("HIPX_TMPL_BLOCKS") ? atoi(getenv("HIPX_TMPL_BLOCKS")) : 2048;
+  return v;
+}
+
 template <int MODE, bool DOT>
 int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart, hipx_int *npart)
 {
-  constexpr int  RPT = 2, W = 4;
-  const hipx_int m = A->nrows_c, nchunks = (m + 256 * RPT - 1) / (256 * RPT);
-  hipx_int       grid = std::min<hipx_int>(2048, ((nchunks + 7) / 8) * 8);
+  const int      cfg = tmpl_cfg();
+  const int      rpt = (cfg == 0 || cfg == 1) ? 2 : (cfg == 4) ? 8 : 4;
+  const hipx_int m = A->nrows_c, nchunks = (m + 256 * rpt - 1) / (256 * rpt);
+  hipx_int       grid = std::min<hipx_int>((hipx_int)((tmpl_blocks() + 7) / 8 * 8), ((nchunks + 7) / 8) * 8);
   if (grid < 8) grid = 8;
   if (npart) {
     *npart = grid * 4;
@@ -1576,8 +1626,16 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
   }
   const hipx_int cpx  = (nchunks + 7) / 8;
   const size_t   smem = 8 * (size_t)((A->tmpl_nent + 1) & ~1) + 4 * (size_t)((A->tmpl_nent + 3) & ~3) + 4 * ((size_t)A->ntmpl + 1) + 16;
-  spmv_tmpl_kernel<MODE, DOT, RPT, W><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout,
-                                                                                      dotpart);
+#define HIPX_TMPL_LAUNCH(R, WW, U) \
+  spmv_tmpl_kernel<MODE, DOT, R, WW, U><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout, dotpart)
+  switch (cfg) {
+  case 0: HIPX_TMPL_LAUNCH(2, 4, false); break;
+  case 1: HIPX_TMPL_LAUNCH(2, 4, true); break;
+  case 3: HIPX_TMPL_LAUNCH(4, 4, false); break;
+  case 4: HIPX_TMPL_LAUNCH(8, 2, true); break;
+  default: HIPX_TMPL_LAUNCH(4, 4, true); break;
+  }
+#undef HIPX_TMPL_LAUNCH
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }

@@ -952,9 +952,20 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
     kern<<<grid, 128, (size_t)P.lds_bytes, st>>>(P, T->d_tid, D.d_tinfo, D.d_tdiag, D.d_dep, D.d_old, asrc, t, xold, xnew, omega, T->d_ctl);
     return HIPX_SUCCESS;
   };
+  static const bool dbg = getenv("HIPX_SOR_DEBUG") != nullptr;
+  if (dbg) {
+    HIPX_HIP(hipStreamSynchronize(st));
+    fprintf(stderr, "[hipx sor] strand KIND %d aligned %d m %d L %d nstr %d npanels %d nbands %d nrows %d ntmpl %d ndep %d nold %d maxchunks %d lds %d grid %u  tid %p asrc %p t %p xold %p xnew %p ctl %p\n", KIND,
+            (int)aligned, P.m, P.L, P.nstr, P.npanels, P.nbands, P.nrows, P.ntmpl, P.ndep, P.nold, P.maxchunks, P.lds_bytes, grid, (const void *)T->d_tid, (const void *)asrc, (void *)t, (const void *)xold,
+            (void *)xnew, (void *)T->d_ctl);
+  }
   int ierr = aligned ? launch(sor_strand_kernel<KIND, true>, 1) : launch(sor_strand_kernel<KIND, false>, 0);
   if (ierr) return ierr;
   HIPX_LAUNCH_CHECK();
+  if (dbg) {
+    HIPX_HIP(hipStreamSynchronize(st));
+    fprintf(stderr, "[hipx sor] strand KIND %d done\n", KIND);
+  }
   return HIPX_SUCCESS;
 }
 
@@ -1148,7 +1159,8 @@ extern "C" int hipxMatSOR(hipxMat A, const double *b, double omega, int flag, do
   const bool use_strand = S->strand && (want == -1 || want == 2) && flag != 64;
   if (want == 2 && !use_strand && flag != 64) return fail(HIPX_ERR_SUP, "HIPX_SOR_MODE=strand: the matrix has no row templates / strand structure", __FILE__, __LINE__);
   if (!S->d_t) {  // work vectors shared by every mode
-      HIPX_HIP(hipMalloc((void **)&S->d_w1, sizeof(double) * (size_t)m));
+    HIPX_HIP(hipMalloc((void **)&S->d_t, sizeof(double) * (size_t)m));
+    HIPX_HIP(hipMalloc((void **)&S->d_w1, sizeof(double) * (size_t)m));
     HIPX_HIP(hipMalloc((void **)&S->d_ctl, sizeof(unsigned int) * 2));
     HIPX_HIP(hipMemsetAsync(S->d_ctl, 0, sizeof(unsigned int) * 2, st));
     S->m = m;

@@ -44,15 +44,24 @@ def solve_gpu(kind, ai, aj, aa, b, pc="jacobi", rtol=1e-5, max_it=10000, normtyp
     return out
 
 
-# Tolerances, all PER ENTRY and RELATIVE TO THAT ENTRY (north_star: 1e-12).  The kernels are bit-identical to the reference
-# except for the dot/norm reductions (a BLAS there, a fixed tree here); each reduction differs by O(eps) and the Krylov
-# recurrence carries that perturbation forward.
-TOL_STRICT = 1e-12   # histories whose residual has not yet dropped far below ||r0||: holds entry by entry
-# A solve run to rtol = 1e-8 .. 1e-9 ends with residuals 1e-8 .. 1e-9 of ||r0||: an O(eps ||r0||) perturbation of the
-# recurrence (1e-16 .. 1e-15 relative to r0, what TOL_STRICT measures on the early entries) is 1e-7 .. 1e-6 of those late
-# entries at worst; measured margins are recorded in gpurun_out/parity_measured.json and quoted in profiles/README.md.
+# Tolerances, all PER ENTRY and RELATIVE TO THAT ENTRY (north_star: 1e-12).
+# Every kernel is bit-identical to the reference except the dot/norm reductions: the reference calls a BLAS (MKL: blocked SIMD
+# partial sums), the oracle's default is the textbook left-to-right sum, the GPU uses a fixed tree.  All three are roundings
+# of the same exact sum and differ from it by up to n * eps (n = 1.7e7 at 256^3: the reference's own history is 1e-11 away from
+# the exactly-rounded one after 24 iterations, measured in test_gpu_scale_parity.py).  The yardstick is therefore the oracle
+# with EXACTLY ROUNDED reductions (oracle exact=True: Dot2, twice the working precision): the GPU history must be within 1e-12
+# of it, which by the triangle inequality puts it at least as close to the reference as the reference is to the exact history.
+TOL_STRICT = 1e-12
+# Solves run to rtol 1e-8 .. 1e-9: the last entries are 1e-8 .. 1e-9 of ||r0||, so an O(eps) perturbation of the recurrence
+# (what TOL_STRICT bounds on the leading entries) is a 1e9-fold larger fraction of them.  Measured margins:
+# gpurun_out/parity_measured.json, quoted in profiles/README.md.
 TOL_CONVERGED = 1e-9
 TOL_GMRES = 1e-8
+
+
+def exact_solve(*a, **kw):
+    """The oracle's solve with exactly rounded reductions (see above)."""
+    return orc.ksp_solve(*a, exact=True, **kw)
 
 
 def compare(g, o, tol, name=None):
@@ -82,7 +91,7 @@ def test_config1_ex2_100x100_cg_jacobi(hx):
     b = orc.matmult(ai, aj, aa, u)
     rtol = 1e-2 / ((m + 1) * (n + 1))
     g = solve_gpu("cg", ai, aj, aa, b, rtol=rtol)
-    o = orc.ksp_solve("cg", ai, aj, aa, b, rtol=rtol)
+    o = exact_solve("cg", ai, aj, aa, b, rtol=rtol)
     compare(g, o, 1e-9)
     assert g[1] == 160 and "%g" % np.linalg.norm(g[0] - u) == "5.70785e-05"  # survey run of the reference, SURVEY.md section 6
     rel = np.abs(g[3][:40] - o[3][:40]) / o[3][:40]
@@ -96,7 +105,7 @@ def test_cg_histories(hx, kind, n, pc, normtype):
     ai, aj, aa = orc.stencil(kind, n)
     b = orc.matmult(ai, aj, aa, np.ones(len(ai) - 1))
     g = solve_gpu("cg", ai, aj, aa, b, pc=pc, rtol=1e-8, normtype=normtype)
-    o = orc.ksp_solve("cg", ai, aj, aa, b, pc=pc, rtol=1e-8, normtype=normtype)
+    o = exact_solve("cg", ai, aj, aa, b, pc=pc, rtol=1e-8, normtype=normtype)
     compare(g, o, 1e-11)
     assert np.abs(g[0] - o[0]).max() <= 1e-11
 
@@ -106,7 +115,7 @@ def test_cg_fused_path_same_history(hx):
     b = orc.matmult(ai, aj, aa, np.ones(len(ai) - 1))
     g0 = solve_gpu("cg", ai, aj, aa, b, rtol=1e-8, fused=0)
     g1 = solve_gpu("cg", ai, aj, aa, b, rtol=1e-8, fused=1)
-    o = orc.ksp_solve("cg", ai, aj, aa, b, rtol=1e-8)
+    o = exact_solve("cg", ai, aj, aa, b, rtol=1e-8)
     compare(g0, o, 1e-11)
     compare(g1, o, 1e-11)
 
@@ -175,7 +184,7 @@ def test_cg_pipelined_variable_and_constant_diagonal(hx):
     aav = aa * sc[np.repeat(np.arange(N), np.diff(ai))] * sc[aj]
     for vals in (aa, aav):
         b = orc.matmult(ai, aj, vals, np.ones(N))
-        o = orc.ksp_solve("cg", ai, aj, vals, b, rtol=1e-9)
+        o = exact_solve("cg", ai, aj, vals, b, rtol=1e-9)
         g1 = solve_gpu("cg", ai, aj, vals, b, rtol=1e-9, fused=1)
         compare(g1, o, 1e-10)
         os.environ["HIPX_NO_DCONST"] = "1"
@@ -193,13 +202,13 @@ def test_cg_fused_odd_sizes(hx, kind, n, m):
     N = len(ai) - 1
     assert N % 2 == 1
     b = orc.matmult(ai, aj, aa, np.ones(N))
-    o = orc.ksp_solve("cg", ai, aj, aa, b, rtol=1e-9)
+    o = exact_solve("cg", ai, aj, aa, b, rtol=1e-9)
     compare(solve_gpu("cg", ai, aj, aa, b, rtol=1e-9, fused=1), o, TOL_CONVERGED)
     compare(solve_gpu("cg", ai, aj, aa, b, rtol=1e-9, fused=0), o, TOL_CONVERGED)
     sc = 1.0 + 0.1 * (np.arange(N) % 5)  # non-constant diagonal: streamed dinv
     aav = aa * sc[np.repeat(np.arange(N), np.diff(ai))] * sc[aj]
     bv = orc.matmult(ai, aj, aav, np.ones(N))
-    compare(solve_gpu("cg", ai, aj, aav, bv, rtol=1e-9, fused=1), orc.ksp_solve("cg", ai, aj, aav, bv, rtol=1e-9), TOL_CONVERGED)
+    compare(solve_gpu("cg", ai, aj, aav, bv, rtol=1e-9, fused=1), exact_solve("cg", ai, aj, aav, bv, rtol=1e-9), TOL_CONVERGED)
 
 
 def test_cg_nonzero_guess_and_max_it(hx):
@@ -208,10 +217,10 @@ def test_cg_nonzero_guess_and_max_it(hx):
     b = orc.matmult(ai, aj, aa, np.ones(N))
     x0 = np.linspace(0, 1, N)
     g = solve_gpu("cg", ai, aj, aa, b, rtol=1e-9, x0=x0)
-    o = orc.ksp_solve("cg", ai, aj, aa, b, rtol=1e-9, x0=x0)
+    o = exact_solve("cg", ai, aj, aa, b, rtol=1e-9, x0=x0)
     compare(g, o, 1e-11)
     g = solve_gpu("cg", ai, aj, aa, b, rtol=1e-30, max_it=7)
-    o = orc.ksp_solve("cg", ai, aj, aa, b, rtol=1e-30, max_it=7)
+    o = exact_solve("cg", ai, aj, aa, b, rtol=1e-30, max_it=7)
     compare(g, o, 1e-12)
     assert g[2] == -3  # KSP_DIVERGED_ITS
 
@@ -222,6 +231,6 @@ def test_gmres_jacobi_histories(hx, refine, restart):
     ai, aj, aa = orc.stencil("27pt", 12)
     b = orc.matmult(ai, aj, aa, np.ones(len(ai) - 1))
     g = solve_gpu("gmres", ai, aj, aa, b, rtol=1e-8, restart=restart, refine=refine)
-    o = orc.ksp_solve("gmres", ai, aj, aa, b, rtol=1e-8, restart=restart, refine=refine)
+    o = exact_solve("gmres", ai, aj, aa, b, rtol=1e-8, restart=restart, refine=refine)
     compare(g, o, 1e-8)
     assert np.abs(g[0] - o[0]).max() <= 1e-10
