@@ -205,6 +205,10 @@ int hipxHaloBegin(hipxHalo h, const double *x, double *lvec); /* pack on compute
 int hipxHaloEnd(hipxHalo h);                                  /* compute stream waits for the exchange */
 /* replaces MatMult_MPIAIJ mpiaij.c:1047-1061: halo begin; y = Ad x (overlapped); halo end; y += Bo lvec */
 int hipxMatMultMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *lvec, double *y);
+/* replaces MatMultAdd_MPIAIJ mpiaij.c:1072-1083: halo begin; z = y + Ad x (overlapped); halo end; z += Bo lvec */
+int hipxMatMultAddMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *lvec, const double *y, double *z);
+/* which transport the next exchange of this plan takes: 1 = IPC peer stores, 2 = RCCL send/recv, 0 = none set up */
+int hipxHaloTransport(hipxHalo h, int *transport);
 
 #ifdef __cplusplus
 }

@@ -465,4 +465,23 @@ int hipxMatMultMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *
   return h ? halo_release(h) : HIPX_SUCCESS;
 }
 
+int hipxMatMultAddMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *lvec, const double *y, double *z)
+{
+  HIPX_CHECK_INIT();
+  int ierr;
+  if ((ierr = hipxHaloBegin(h, x, lvec))) return ierr;   // VecScatterBegin        mpiaij.c:1078
+  if ((ierr = hipxMatMultAdd(Ad, x, y, z))) return ierr; // A->ops->multadd        mpiaij.c:1079
+  if ((ierr = hipxHaloEnd(h))) return ierr;              // VecScatterEnd          mpiaij.c:1080
+  const double *ghost = (h && h->ipc) ? h->ghost_cur : lvec;
+  if (Bo && (ierr = hipxMatMultAdd(Bo, ghost, z, z))) return ierr;  // B->ops->multadd   mpiaij.c:1081
+  return h ? halo_release(h) : HIPX_SUCCESS;
+}
+
+int hipxHaloTransport(hipxHalo h, int *transport)
+{
+  HIPX_ARG(h && transport, "null argument");
+  *transport = h->ipc ? 1 : (cm().active ? 2 : 0);
+  return HIPX_SUCCESS;
+}
+
 }  // extern "C"

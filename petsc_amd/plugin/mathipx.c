@@ -40,7 +40,12 @@ PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA)
     const PetscScalar *aa;
     if (h->dA) PetscCallHIPX(hipxMatDestroy(&h->dA));
     PetscCall(MatSeqAIJGetArrayRead(A, &aa));
-    PetscCallHIPX(hipxMatCreateCSR(A->rmap->n, A->cmap->n, a->i, a->j, aa, &h->dA));
+    if (a->compressedrow.use && a->compressedrow.nrows < A->rmap->n && A->rmap->n != A->cmap->n) { /* rectangular: never asked for a diagonal / SOR */
+      /* Mat_CompressedRow (matimpl.h:425-430; MatAssemblyEnd_SeqAIJ checks it, aij.c:1138): the off-diagonal block of an MPIAIJ
+         matrix has entries in a few rows only -- MatMult_SeqAIJ / MatMultAdd_SeqAIJ then walk the listed rows (aij.c:1463-1478,
+         1624-1641), and so does the device kernel (y is not streamed for the empty rows) */
+      PetscCallHIPX(hipxMatCreateCSRCompressedRow(A->rmap->n, A->cmap->n, a->compressedrow.nrows, a->compressedrow.i, a->compressedrow.rindex, a->j, aa, &h->dA));
+    } else PetscCallHIPX(hipxMatCreateCSR(A->rmap->n, A->cmap->n, a->i, a->j, aa, &h->dA));
     PetscCall(MatSeqAIJRestoreArrayRead(A, &aa));
     if (h->spmv_variant) PetscCallHIPX(hipxMatSetSpMVVariant(h->dA, (int)h->spmv_variant));
     h->nonzerostate = A->nonzerostate;

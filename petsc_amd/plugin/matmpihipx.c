@@ -7,16 +7,201 @@
  * garray, the compacted B and Mvctx; we convert the pieces right after it (pattern of the reference's device
  * subclasses: mpiaijhipsparse.hip.cxx:154-157, mpiaijcupm.hpp:430-438).
  *
- * Ghost exchange in this build: the stock VecScatter (PetscSF over MPI, host buffers; a host-only libpetsc treats every
- * pointer as host memory, sfpack.c:706-721).  The RCCL/xGMI exchange of libhipx (hipxHalo*, hipxMatMultMPI) is driven by
- * the C host layer (include/hipx_ksp.h) and by bench.py; wiring it under Mvctx is listed as next step in DESIGN.md.
+ * MatMult / MatMultAdd run the ghost exchange ON THE DEVICE (libhipx hipxMatMultMPI: RCCL send/recv over xGMI, or peer stores
+ * through HIP IPC mappings) with the plan the reference built in a->Mvctx; the stock VecScatter on host buffers (a host-only
+ * libpetsc treats every pointer as host memory, sfpack.c:706-721) remains as the fall-back and for every other user of Mvctx.
  */
 #include "hipxplugin.h"
+#include <petscsf.h>
 
+/* Ghost exchange of MatMult / MatMultAdd: the reference's own plan (a->Mvctx, a PetscSF built by MatSetUpMultiply_MPIAIJ,
+   mmaij.c:108-125: roots = owned entries of x, leaves = lvec) is read back with PetscSFGetRootRanks / PetscSFGetLeafRanks and
+   handed to libhipx, which runs it on the device:
+     transport "rccl": ncclSend / ncclRecv over xGMI on the comm stream (one rank per GPU),
+     transport "ipc" : peer stores through HIP IPC mappings (also when several ranks share a GPU, which RCCL refuses),
+     transport "host": the stock VecScatter on host buffers (PetscSF over MPI) -- the parent's MatMult_MPIAIJ, kept as fall-back.
+   -mat_mpiaijhipx_halo <auto|rccl|ipc|host> (or HIPX_HALO); auto = rccl when every rank drives its own device, else ipc. */
 typedef struct {
   PetscErrorCode (*parent_assemblyend)(Mat, MatAssemblyType);
   PetscErrorCode (*parent_destroy)(Mat);
+  PetscErrorCode (*parent_mult)(Mat, Vec, Vec);
+  PetscErrorCode (*parent_multadd)(Mat, Vec, Vec, Vec);
+  hipxHalo         halo;
+  PetscInt         transport; /* 0 host, 1 ipc, 2 rccl */
+  PetscObjectState nzstate;   /* nonzero state the plan was built from */
 } Mat_MPIAIJHIPX;
+
+static PetscBool hipx_rccl_up = PETSC_FALSE;
+
+static PetscErrorCode MatMPIAIJHIPXBuildHalo(Mat A)
+{
+  Mat_MPIAIJHIPX    *h = (Mat_MPIAIJHIPX *)A->spptr;
+  Mat_MPIAIJ        *a = (Mat_MPIAIJ *)A->data;
+  MPI_Comm           comm = PetscObjectComm((PetscObject)A);
+  PetscMPIInt        rank, size, nr, ni;
+  const PetscMPIInt *ranks, *iranks;
+  const PetscInt    *roff, *rmine, *rremote, *ioff, *iroot;
+  char               want[16] = "auto";
+  const char        *env      = getenv("HIPX_HALO");
+  PetscBool          contiguous = PETSC_TRUE, allok;
+  PetscInt           transport;
+
+  PetscFunctionBegin;
+  if (h->halo) PetscCallHIPX(hipxHaloDestroy(&h->halo));
+  h->transport = 0;
+  h->nzstate   = A->nonzerostate;
+  PetscCallMPI(MPI_Comm_rank(comm, &rank));
+  PetscCallMPI(MPI_Comm_size(comm, &size));
+  if (env) PetscCall(PetscStrncpy(want, env, sizeof(want)));
+  PetscCall(PetscOptionsGetString(((PetscObject)A)->options, ((PetscObject)A)->prefix, "-mat_mpiaijhipx_halo", want, sizeof(want), NULL));
+  if (size == 1 || !a->Mvctx || !strcmp(want, "host")) PetscFunctionReturn(PETSC_SUCCESS);
+  { /* the device exchange is bootstrapped over PETSC_COMM_WORLD ranks (one RCCL communicator per process) */
+    int cmp;
+    PetscCallMPI(MPI_Comm_compare(comm, PETSC_COMM_WORLD, &cmp));
+    if (cmp != MPI_IDENT && cmp != MPI_CONGRUENT) PetscFunctionReturn(PETSC_SUCCESS);
+  }
+  PetscCall(PetscSFSetUp(a->Mvctx));
+  PetscCall(PetscSFGetRootRanks(a->Mvctx, &nr, &ranks, &roff, &rmine, &rremote));
+  PetscCall(PetscSFGetLeafRanks(a->Mvctx, &ni, &iranks, &ioff, &iroot));
+  /* lvec[k] <-> garray[k] (mmaij.c:108-117) and garray is sorted, so the leaves a rank sends are one contiguous run of lvec */
+  for (PetscMPIInt k = 0; k < nr && contiguous; k++)
+    for (PetscInt j = roff[k]; j < roff[k + 1]; j++)
+      if (rmine && rmine[j] != j) {
+        contiguous = PETSC_FALSE;
+        break;
+      }
+  PetscCallMPI(MPIU_Allreduce(&contiguous, &allok, 1, MPIU_BOOL, MPI_LAND, comm));
+  if (!allok) PetscFunctionReturn(PETSC_SUCCESS);
+  if (!strcmp(want, "rccl")) transport = 2;
+  else if (!strcmp(want, "ipc")) transport = 1;
+  else { /* auto: RCCL needs one device per rank */
+    int          dev = 0, ndev = 1, *all;
+    char         host[MPI_MAX_PROCESSOR_NAME];
+    int          hl = 0;
+    unsigned int key = 5381;
+    PetscBool    shared = PETSC_FALSE;
+    PetscCallHIPX(hipxGetDeviceCount(&ndev));
+    dev = ndev > 0 ? rank % ndev : 0; /* VecHIPXInitRuntime's choice (or -hipx_device: then every rank drives that one device) */
+    {
+      PetscInt d = -1;
+      PetscCall(PetscOptionsGetInt(NULL, NULL, "-hipx_device", &d, NULL));
+      if (d >= 0) dev = (int)d;
+    }
+    PetscCallMPI(MPI_Get_processor_name(host, &hl));
+    for (int c = 0; c < hl; c++) key = key * 33u + (unsigned char)host[c];
+    PetscCall(PetscMalloc1(2 * (size_t)size, &all));
+    {
+      int mine[2] = {(int)(key & 0x7fffffff), dev};
+      PetscCallMPI(MPI_Allgather(mine, 2, MPI_INT, all, 2, MPI_INT, comm));
+    }
+    for (int p = 0; p < size && !shared; p++)
+      for (int q = p + 1; q < size; q++)
+        if (all[2 * p] == all[2 * q] && all[2 * p + 1] == all[2 * q + 1]) {
+          shared = PETSC_TRUE;
+          break;
+        }
+    PetscCall(PetscFree(all));
+    transport = shared ? 1 : 2;
+  }
+  {
+    int      *sr, *rr;
+    hipx_int *so, *si, *ro;
+    PetscCall(PetscMalloc5(ni + 1, &sr, ni + 2, &so, ioff[ni] + 1, &si, nr + 1, &rr, nr + 2, &ro));
+    for (PetscMPIInt k = 0; k < ni; k++) sr[k] = (int)iranks[k];
+    for (PetscMPIInt k = 0; k <= ni; k++) so[k] = (hipx_int)ioff[k];
+    for (PetscInt j = 0; j < ioff[ni]; j++) si[j] = (hipx_int)iroot[j];
+    for (PetscMPIInt k = 0; k < nr; k++) rr[k] = (int)ranks[k];
+    for (PetscMPIInt k = 0; k <= nr; k++) ro[k] = (hipx_int)roff[k];
+    PetscCallHIPX(hipxHaloCreate((int)ni, sr, so, si, (int)nr, rr, ro, &h->halo));
+    PetscCall(PetscFree5(sr, so, si, rr, ro));
+  }
+  if (transport == 2) {
+    if (!hipx_rccl_up) { /* ncclUniqueId of rank 0 travels over MPI */
+      char id[HIPX_COMM_ID_BYTES];
+      if (!rank) PetscCallHIPX(hipxCommGetUniqueId(id));
+      PetscCallMPI(MPI_Bcast(id, HIPX_COMM_ID_BYTES, MPI_BYTE, 0, comm));
+      PetscCallHIPX(hipxCommInit(id, (int)rank, (int)size));
+      hipx_rccl_up = PETSC_TRUE;
+    }
+  } else {
+    char *mine, *all;
+    PetscCall(PetscMalloc2(HIPX_HALO_IPC_BLOB_BYTES, &mine, (size_t)HIPX_HALO_IPC_BLOB_BYTES * size, &all));
+    PetscCallHIPX(hipxHaloIpcExport(h->halo, (int)rank, (int)size, mine));
+    PetscCallMPI(MPI_Allgather(mine, HIPX_HALO_IPC_BLOB_BYTES, MPI_BYTE, all, HIPX_HALO_IPC_BLOB_BYTES, MPI_BYTE, comm));
+    PetscCallHIPX(hipxHaloIpcAttach(h->halo, all));
+    PetscCall(PetscFree2(mine, all));
+  }
+  h->transport = transport;
+  PetscCall(PetscInfo(A, "MATMPIAIJHIPX ghost exchange on the device: transport %s, %d send / %d receive neighbours\n", transport == 2 ? "rccl" : "ipc", (int)ni, (int)nr));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* MatMult_MPIAIJ mpiaij.c:1047-1061 / MatMultAdd_MPIAIJ mpiaij.c:1072-1083 with the exchange on the device: pack + send on the
+   comm stream while the diagonal block multiplies on the compute stream, then the off-diagonal block accumulates */
+static PetscErrorCode MatMultAdd_MPIAIJHIPX_Private(Mat A, Vec xx, Vec yy, Vec zz)
+{
+  Mat_MPIAIJHIPX    *h = (Mat_MPIAIJHIPX *)A->spptr;
+  Mat_MPIAIJ        *a = (Mat_MPIAIJ *)A->data;
+  hipxMat            dA, dB;
+  const PetscScalar *x, *y = NULL;
+  PetscScalar       *z, *lv;
+  void              *tx, *ty = NULL, *tz, *tl;
+
+  PetscFunctionBegin;
+  PetscCall(MatSeqAIJHIPXGetDeviceMat(a->A, &dA));
+  PetscCall(MatSeqAIJHIPXGetDeviceMat(a->B, &dB));
+  PetscCall(VecHIPXGetDeviceRead(xx, &x, &tx));
+  PetscCall(VecHIPXGetDeviceWrite(a->lvec, &lv, &tl));
+  if (!yy) {
+    PetscCall(VecHIPXGetDeviceWrite(zz, &z, &tz));
+    PetscCallHIPX(hipxMatMultMPI(dA, dB, h->halo, x, lv, z));
+  } else {
+    if (zz == yy) {
+      PetscCall(VecHIPXGetDeviceReadWrite(zz, &z, &tz));
+      y = z;
+    } else {
+      PetscCall(VecHIPXGetDeviceRead(yy, &y, &ty));
+      PetscCall(VecHIPXGetDeviceWrite(zz, &z, &tz));
+    }
+    PetscCallHIPX(hipxMatMultAddMPI(dA, dB, h->halo, x, lv, y, z));
+    if (zz != yy) PetscCall(VecHIPXRestoreDeviceRead(yy, &y, &ty));
+  }
+  PetscCall(VecHIPXRestoreDeviceWrite(zz, &z, &tz));
+  PetscCall(VecHIPXRestoreDeviceWrite(a->lvec, &lv, &tl));
+  PetscCall(VecHIPXRestoreDeviceRead(xx, &x, &tx));
+  {
+    Mat_SeqAIJ *sa = (Mat_SeqAIJ *)a->A->data, *sb = (Mat_SeqAIJ *)a->B->data;
+    PetscCall(PetscLogFlops(yy ? 2.0 * sa->nz + 2.0 * sb->nz : 2.0 * sa->nz - sa->nonzerorowcnt + 2.0 * sb->nz)); /* aij.c:1497,1653 */
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscBool MatMPIAIJHIPXDevicePath(Mat A, Vec xx, Vec zz)
+{
+  Mat_MPIAIJHIPX *h = (Mat_MPIAIJHIPX *)A->spptr;
+  Mat_MPIAIJ     *a = (Mat_MPIAIJ *)A->data;
+  return (PetscBool)(h->transport && h->halo && h->nzstate == A->nonzerostate && a->A && a->B && MatIsSeqAIJHIPX(a->A) && MatIsSeqAIJHIPX(a->B) && a->lvec && VecIsHIPX(a->lvec) && VecIsHIPX(xx) && VecIsHIPX(zz));
+}
+
+static PetscErrorCode MatMult_MPIAIJHIPX(Mat A, Vec xx, Vec yy)
+{
+  Mat_MPIAIJHIPX *h = (Mat_MPIAIJHIPX *)A->spptr;
+
+  PetscFunctionBegin;
+  if (MatMPIAIJHIPXDevicePath(A, xx, yy)) PetscCall(MatMultAdd_MPIAIJHIPX_Private(A, xx, NULL, yy));
+  else PetscCall((*h->parent_mult)(A, xx, yy));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode MatMultAdd_MPIAIJHIPX(Mat A, Vec xx, Vec yy, Vec zz)
+{
+  Mat_MPIAIJHIPX *h = (Mat_MPIAIJHIPX *)A->spptr;
+
+  PetscFunctionBegin;
+  if (MatMPIAIJHIPXDevicePath(A, xx, zz) && VecIsHIPX(yy)) PetscCall(MatMultAdd_MPIAIJHIPX_Private(A, xx, yy, zz));
+  else PetscCall((*h->parent_multadd)(A, xx, yy, zz));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
 
 static PetscErrorCode MatAssemblyEnd_MPIAIJHIPX(Mat A, MatAssemblyType mode)
 {
@@ -35,6 +220,7 @@ static PetscErrorCode MatAssemblyEnd_MPIAIJHIPX(Mat A, MatAssemblyType mode)
       PetscCall(VecDestroy(&a->lvec));
       a->lvec = lv;
     }
+    if (!h->halo || h->nzstate != A->nonzerostate) PetscCall(MatMPIAIJHIPXBuildHalo(A)); /* collective: every rank assembles */
   }
   PetscFunctionReturn(PETSC_SUCCESS);
 }
@@ -45,6 +231,7 @@ static PetscErrorCode MatDestroy_MPIAIJHIPX(Mat A)
   PetscErrorCode (*pdestroy)(Mat) = h->parent_destroy;
 
   PetscFunctionBegin;
+  if (h->halo) PetscCallHIPX(hipxHaloDestroy(&h->halo));
   PetscCall(PetscFree(A->spptr));
   PetscCall((*pdestroy)(A));
   PetscFunctionReturn(PETSC_SUCCESS);
@@ -60,9 +247,13 @@ PetscErrorCode MatCreate_MPIAIJHIPX(Mat B)
   PetscCall(PetscNew(&h));
   h->parent_assemblyend = B->ops->assemblyend;
   h->parent_destroy     = B->ops->destroy;
+  h->parent_mult        = B->ops->mult;
+  h->parent_multadd     = B->ops->multadd;
   B->spptr              = h;
   B->ops->assemblyend   = MatAssemblyEnd_MPIAIJHIPX;
   B->ops->destroy       = MatDestroy_MPIAIJHIPX;
+  B->ops->mult          = MatMult_MPIAIJHIPX;
+  B->ops->multadd       = MatMultAdd_MPIAIJHIPX;
   PetscCall(PetscFree(B->defaultvectype));
   PetscCall(PetscStrallocpy(VECHIPX, &B->defaultvectype));
   PetscCall(PetscObjectChangeTypeName((PetscObject)B, MATMPIAIJHIPX));

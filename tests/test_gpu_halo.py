@@ -119,3 +119,67 @@ def test_single_rank_comm_allreduce_and_self_halo(hx, monkeypatch):
     _lib.mat_destroy(A)
     _lib.mat_destroy(B)
     _lib.chk(hx.hipxCommFinalize())
+
+
+def test_ipc_transport_self_exchange_back_to_back(hx):
+    """The IPC transport (peer stores + sequence flags + acknowledged double buffers) on one process exchanging with itself:
+    MatMult_MPIAIJ's composition bit-identical to the oracle, 40 products back to back with x changing every time (any lost
+    acknowledgement or stale buffer shows up as a wrong y), and MatMultAdd_MPIAIJ."""
+    from petsc_amd import _lib
+    m = 6000
+    rng = np.random.default_rng(12)
+    ai, aj, aa = orc.stencil("5pt", 60, m=100)
+    ng = 192
+    send_idx = np.sort(rng.choice(m, size=ng, replace=False)).astype(np.int32)
+    rows = np.arange(3, m, 5, dtype=np.int32)
+    ci = np.arange(0, 3 * len(rows) + 1, 3, dtype=np.int32)
+    bj = np.sort(rng.integers(0, ng, size=(len(rows), 3)), axis=1).astype(np.int32).ravel()
+    ba = rng.standard_normal(len(bj))
+    A = _lib.mat_create_csr(m, m, ai, aj, aa)
+    B = _lib.mat_create_cprow(m, ng, len(rows), ci, rows, bj, ba)
+    halo = C.c_void_p()
+    sr = np.zeros(1, np.int32)
+    so = np.array([0, ng], np.int32)
+    _lib.chk(hx.hipxHaloCreate(1, sr.ctypes.data_as(C.c_void_p), so.ctypes.data_as(C.c_void_p), send_idx.ctypes.data_as(C.c_void_p), 1, sr.ctypes.data_as(C.c_void_p),
+                               so.ctypes.data_as(C.c_void_p), C.byref(halo)))
+    blob = (C.c_char * 1024)()
+    _lib.chk(hx.hipxHaloIpcExport(halo, 0, 1, blob))
+    _lib.chk(hx.hipxHaloIpcAttach(halo, blob))
+    tr = C.c_int()
+    _lib.chk(hx.hipxHaloTransport(halo, C.byref(tr)))
+    assert tr.value == 1
+    bi_full = np.zeros(m + 1, np.int32)
+    cnt = np.zeros(m, np.int32)
+    cnt[rows] = 3
+    bi_full[1:] = np.cumsum(cnt)
+
+    def expect(x, y0=None):
+        yd = orc.matmult(ai, aj, aa, x)
+        if y0 is not None:
+            yd2 = np.zeros(m)
+            orc.lib().orc_MatMultAdd_SeqAIJ(m, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(y0), orc.P(yd2))
+            yd = yd2
+        z = np.zeros(m)
+        lv = np.ascontiguousarray(x[send_idx])
+        orc.lib().orc_MatMultAdd_SeqAIJ(m, orc.P(bi_full), orc.P(bj), orc.P(ba), orc.P(lv), orc.P(yd), orc.P(z))
+        return z
+
+    xs = [rng.standard_normal(m) for _ in range(40)]
+    Xs = [_lib.DVec(m, x) for x in xs]
+    Ys = [_lib.DVec(m) for _ in xs]
+    LV = _lib.DVec(ng)
+    for X, Y in zip(Xs, Ys):  # enqueued back to back: no host synchronisation between the products
+        _lib.chk(hx.hipxMatMultMPI(A, B, halo, X.ptr, LV.ptr, Y.ptr))
+    for x, Y in zip(xs, Ys):
+        assert np.array_equal(Y.get(), expect(x))
+    y0 = rng.standard_normal(m)
+    Y0, Z = _lib.DVec(m, y0), _lib.DVec(m)
+    _lib.chk(hx.hipxMatMultAddMPI(A, B, halo, Xs[3].ptr, LV.ptr, Y0.ptr, Z.ptr))
+    assert np.array_equal(Z.get(), expect(xs[3], y0))
+    _lib.chk(hx.hipxMatMultAddMPI(A, B, halo, Xs[5].ptr, LV.ptr, Y0.ptr, Y0.ptr))  # in place
+    assert np.array_equal(Y0.get(), expect(xs[5], y0))
+    _lib.chk(hx.hipxHaloDestroy(C.byref(halo)))
+    for d in Xs + Ys + [LV, Y0, Z]:
+        d.free()
+    _lib.mat_destroy(A)
+    _lib.mat_destroy(B)

@@ -23,12 +23,12 @@ K = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kats_mpi.j
 ENV = dict(os.environ, HIPX_NO_TORCH="1")
 
 
-def mpirun(np_, exe, args, hipx, timeout=150):
+def mpirun(np_, exe, args, hipx, timeout=150, env=None):
     assert os.path.exists(os.path.join(BIN, exe)) and os.path.exists(PLUGIN), "oracle/_ref/mpich or the MPICH plugin is not built"
     cmd = [MPIEXEC, "-n", str(np_), os.path.join(BIN, exe)] + args
     if hipx:
         cmd += ["-dll_prepend", PLUGIN, "-vec_type", "hipx"]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout, env=ENV)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout, env=dict(ENV, **(env or {})))
     assert r.returncode == 0, "%s\n%s" % (" ".join(cmd), r.stdout[-3000:])
     return r.stdout
 
@@ -97,3 +97,21 @@ def test_ksp_history_np_vs_cpu_mpi(np_, args, tol):
     for g, c in zip(h_gpu, h_cpu):
         assert abs(g - c) <= tol * r0 + 1e-9 * abs(c)
     assert abs(t_gpu[2] - t_cpu[2]) <= 1e-10 * max(1.0, abs(t_cpu[2])) + 1e-6 * abs(t_cpu[2])
+
+
+@pytest.mark.parametrize("halo", ["ipc", "host"])
+def test_mpiaijhipx_ghost_exchange_transports(halo):
+    """MatMult_MPIAIJ over hipx blocks with the ghost exchange ON THE DEVICE (ranks share this box's GPU, so the transport is
+    the IPC one: peer stores, no host staging) and through the stock host VecScatter: both bit-identical to the CPU MPI run;
+    -info names the transport; a 60-iteration CG solve (60 back-to-back exchanges + reductions) follows the CPU history."""
+    a = "-stencil 27 -n 10 -dump_y -ksp_max_it 1".split()
+    _, y_cpu, _ = parse_driver(mpirun(3, "ref_driver", a, False))
+    out = mpirun(3, "ref_driver", a + ["-mat_type", "aijhipx", "-info", ":mat"], True, env={"HIPX_HALO": halo})
+    _, y_gpu, _ = parse_driver(out)
+    assert len(y_cpu) > 0 and y_gpu == y_cpu
+    assert ("transport ipc" in out) == (halo == "ipc"), out[-1500:]
+    a = "-stencil 7 -n 24 -ksp_type cg -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 60 -history".split()
+    h_cpu, _, t_cpu = parse_driver(mpirun(2, "ref_driver", a, False))
+    h_gpu, _, t_gpu = parse_driver(mpirun(2, "ref_driver", a + ["-mat_type", "aijhipx"], True, env={"HIPX_HALO": halo}))
+    assert t_gpu[:2] == t_cpu[:2] and len(h_gpu) == len(h_cpu) == 61
+    assert max(abs(g - c) / c for g, c in zip(h_gpu, h_cpu)) <= 1e-11
