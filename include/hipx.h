@@ -139,6 +139,15 @@ int hipxMatCreateCSR64(hipx_int m, hipx_int n, const int64_t *i, const hipx_int 
    only rows ridx[0..nrows) hold entries; ci has nrows+1 offsets. */
 int hipxMatCreateCSRCompressedRow(hipx_int m, hipx_int n, hipx_int nrows, const hipx_int *ci, const hipx_int *ridx, const hipx_int *j, const double *a, hipxMat *A);
 int hipxMatUpdateValues(hipxMat A, const double *a);          /* same nonzero pattern, new values (host) */
+int hipxMatGetValues(hipxMat A, double *a_host);              /* the value array back to the host (CSR order) */
+/* COO assembly on the device.  replaces MatSetValuesCOO_SeqAIJ aij.c:4710-4733; jmap (nz + 1) / perm (ntot) are the maps
+   MatSetPreallocationCOO_SeqAIJ leaves in MatCOOStruct_SeqAIJ (aij.c:4524-4707, aij.h:170-176): entry k of the CSR value array
+   is the sum of v[perm[jmap[k] .. jmap[k+1])], added left to right.  hipxMatCreateCSR* accept a == NULL (pattern only). */
+typedef struct hipxCOO_s *hipxCOO;
+int hipxCOOCreate(int64_t nz, const int64_t *jmap, int64_t ntot, const int64_t *perm, hipxCOO *coo);
+int hipxCOODestroy(hipxCOO *coo);
+int hipxMatSetValuesCOO(hipxMat A, hipxCOO coo, const double *v, int64_t n, int v_on_device, int insert);
+int hipxPointerIsDevice(const void *p, int *is_device);
 int hipxMatDestroy(hipxMat *A);
 int hipxMatGetInfo(hipxMat A, hipx_int *m, hipx_int *n, int64_t *nnz, int64_t *device_bytes);
 /* replaces MatMult_SeqAIJ aij.c:1444 */              int hipxMatMult(hipxMat A, const double *x, double *y);

@@ -36,6 +36,7 @@ KATS = {  # name -> source (reference tree)
     "vec_ex60": "vec/vec/tests/ex60.c",         # VecPlaceArray + VecReciprocal
     "vec_ex63": "vec/vec/tests/ex63.c",         # VecExp (parent op through our array hooks)
     "mat_ex5": "mat/tests/ex5.c",               # MatMult/MultAdd/MultTranspose (+ diagonal scale)
+    "mat_ex123": "mat/tests/ex123.c",           # MatSetPreallocationCOO / MatSetValuesCOO (repeated and negative indices, ADD/INSERT)
 }
 CFLAGS = ["-fPIC", "-O2", "-fstack-protector", "-fvisibility=hidden", "-w", "-I" + CONF, "-I" + os.path.join(REF, "include")]
 

@@ -56,7 +56,7 @@ def parse_header(path):
 
     def ctype(t):
         t = t.strip()
-        if "*" in t or t in ("hipxMat", "hipxHalo"):
+        if "*" in t or t in ("hipxMat", "hipxHalo", "hipxCOO"):
             return C.c_char_p if t.replace(" ", "") == "constchar*" else C.c_void_p
         base = t.replace("const", "").strip()
         return {"int": C.c_int, "hipx_int": C.c_int32, "double": C.c_double, "float": C.c_float, "size_t": C.c_size_t,

@@ -1196,7 +1196,8 @@ int create_common(hipx_int m, hipx_int n, hipx_int nrows, const IT *ai, const hi
   HIPX_HIP(hipMemcpyAsync(A->d_i, nrows ? ai : &zero, sizeof(IT) * ((size_t)nrows + 1), hipMemcpyHostToDevice, rt().compute));
   if (A->nnz) {
     HIPX_HIP(hipMemcpyAsync(A->d_j, aj, sizeof(hipx_int) * (size_t)A->nnz, hipMemcpyHostToDevice, rt().compute));
-    HIPX_HIP(hipMemcpyAsync(A->d_a, aa, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice, rt().compute));
+    if (aa) HIPX_HIP(hipMemcpyAsync(A->d_a, aa, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice, rt().compute));
+    else HIPX_HIP(hipMemsetAsync(A->d_a, 0, sizeof(double) * (size_t)A->nnz, rt().compute));  // pattern only (values follow from hipxMatSetValuesCOO)
   }
   A->device_bytes = (int64_t)(sizeof(IT) * ((size_t)nrows + 1) + (sizeof(hipx_int) + sizeof(double)) * ((size_t)A->nnz + pad));
   if (ridx) {
@@ -2060,6 +2061,113 @@ int hipxPCJacobiSetUp(hipxMat A, double *dinv)
   hipx_int g = std::min<hipx_int>((A->m + 255) / 256, 4096);
   jacobi_setup_kernel<<<(unsigned)g, 256, 0, rt().compute>>>(A->m, A->d_diagpos, A->d_a, dinv);
   HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// COO assembly on the device (MatSetValuesCOO_SeqAIJ, aij.c:4710-4733).  The integer part -- sorting the (i, j) pairs, merging
+// repeats: jmap / perm of MatSetPreallocationCOO_SeqAIJ (aij.c:4524-4707) -- is the reference's own host routine, run once per
+// pattern; its two maps live on the device afterwards and every MatSetValuesCOO is one kernel:
+//   a[k] = (INSERT ? 0 : a[k]) + sum_{q = jmap[k]}^{jmap[k+1]-1} v[perm[q]]      (left to right: the host loop's order)
+struct hipxCOO_s {
+  int64_t  nz = 0, ntot = 0;
+  int64_t *d_jmap = nullptr, *d_perm = nullptr;
+  double  *d_v = nullptr;  // staging for host-resident value arrays
+  int64_t  v_cap = 0;
+};
+
+namespace {
+__global__ __launch_bounds__(256) void coo_setvalues_kernel(int64_t nz, const int64_t *__restrict__ jmap, const int64_t *__restrict__ perm, const double *__restrict__ v, int insert,
+                                                            double *__restrict__ a)
+{
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nz; k += (int64_t)gridDim.x * 256) {
+    double sum = 0.0;
+    for (int64_t q = jmap[k]; q < jmap[k + 1]; q++) sum += v[perm[q]];
+    a[k] = (insert ? 0.0 : a[k]) + sum;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int hipxCOOCreate(int64_t nz, const int64_t *jmap, int64_t ntot, const int64_t *perm, hipxCOO *out)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(nz >= 0 && ntot >= 0 && out && (jmap || !nz) && (perm || !ntot), "bad COO maps");
+  hipxCOO c = new hipxCOO_s;
+  c->nz     = nz;
+  c->ntot   = ntot;
+  HIPX_HIP(hipMalloc((void **)&c->d_jmap, sizeof(int64_t) * ((size_t)nz + 1)));
+  HIPX_HIP(hipMalloc((void **)&c->d_perm, sizeof(int64_t) * (size_t)std::max<int64_t>(ntot, 1)));
+  static const int64_t zero = 0;
+  HIPX_HIP(hipMemcpy(c->d_jmap, nz ? jmap : &zero, sizeof(int64_t) * ((size_t)nz + 1), hipMemcpyHostToDevice));
+  if (ntot) HIPX_HIP(hipMemcpy(c->d_perm, perm, sizeof(int64_t) * (size_t)ntot, hipMemcpyHostToDevice));
+  *out = c;
+  return HIPX_SUCCESS;
+}
+
+int hipxCOODestroy(hipxCOO *pc)
+{
+  if (!pc || !*pc) return HIPX_SUCCESS;
+  hipxCOO c = *pc;
+  HIPX_HIP(hipStreamSynchronize(rt().compute));
+  (void)hipFree(c->d_jmap);
+  (void)hipFree(c->d_perm);
+  (void)hipFree(c->d_v);
+  delete c;
+  *pc = nullptr;
+  return HIPX_SUCCESS;
+}
+
+int hipxMatSetValuesCOO(hipxMat A, hipxCOO c, const double *v, int64_t n, int v_on_device, int insert)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A && c && (v || !n) && n >= 0, "null argument");
+  HIPX_ARG(c->nz == A->nnz, "the COO maps were built for another nonzero pattern");
+  hipStream_t   st = rt().compute;
+  const double *dv = v;
+  if (!v_on_device && n) {
+    if (n > c->v_cap) {
+      HIPX_HIP(hipStreamSynchronize(st));
+      (void)hipFree(c->d_v);
+      HIPX_HIP(hipMalloc((void **)&c->d_v, sizeof(double) * (size_t)n));
+      c->v_cap = n;
+    }
+    HIPX_HIP(hipMemcpyAsync(c->d_v, v, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+    dv = c->d_v;
+  }
+  if (c->nz) {
+    const unsigned g = (unsigned)std::min<int64_t>((c->nz + 255) / 256, 16384);
+    coo_setvalues_kernel<<<g, 256, 0, st>>>(c->nz, c->d_jmap, c->d_perm, dv, insert, A->d_a);
+    HIPX_LAUNCH_CHECK();
+  }
+  if (!v_on_device) HIPX_HIP(hipStreamSynchronize(st));  // the caller's host array may change after return
+  A->vd_ready   = false;
+  A->tmpl_ready = false;
+  A->value_state++;
+  hipxSorInvalidate_(A->sor_state);
+  return HIPX_SUCCESS;
+}
+
+int hipxMatGetValues(hipxMat A, double *a_host)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A && (a_host || !A->nnz), "null argument");
+  if (A->nnz) HIPX_HIP(hipMemcpyAsync(a_host, A->d_a, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToHost, rt().compute));
+  HIPX_HIP(hipStreamSynchronize(rt().compute));
+  return HIPX_SUCCESS;
+}
+
+int hipxPointerIsDevice(const void *p, int *is_device)
+{
+  HIPX_ARG(is_device, "null argument");
+  *is_device = 0;
+  if (!p) return HIPX_SUCCESS;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) == hipSuccess) *is_device = (at.type == hipMemoryTypeDevice) ? 1 : 0;
+  else (void)hipGetLastError();  // unregistered host memory: not an error
   return HIPX_SUCCESS;
 }
 

@@ -422,7 +422,7 @@ __device__ __forceinline__ int st_strand_len(long long S, const StParams &P)
 template <int KIND, bool ALIGNED>
 __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const unsigned char *__restrict__ tid, const StTinfo *__restrict__ g_tinfo, const StDiag *__restrict__ g_tdiag,
                                                          const StEntry *__restrict__ g_dep, const StEntry *__restrict__ g_old, const double *asrc, double *t, const double *xold,
-                                                         double *xnew, double omega, unsigned int *ctl)
+                                                         double *xnew, double omega, unsigned int *ctl, unsigned long long *stats)
 {
   constexpr bool FWD     = (KIND == 0 || KIND == 3);
   constexpr bool NEEDOLD = (KIND == 1 || KIND == 3 || KIND == 4);  // the row's own old value
@@ -463,12 +463,15 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
       int       p = 0, k = 0;
       bool      have = false;
       double    sum = 0.0, rb = 0.0;
+      unsigned  st_iters = 0, st_rowwait = 0, st_depwait = 0, st_fallback = 0;  // HIPX_SOR_DEBUG statistics (stats != nullptr)
+      const long long st_t0 = stats ? (long long)wall_clock64() : 0;
       st_int4   ti = {0, 0, 0, 0};  // {dstart, dcnt, ostart, ocnt}
       double    idiag = 0.0, mdiag = 0.0;
       long long t0 = 0;
       for (unsigned it = 1;; it++) {
         const bool active = p < len;
         if (!__any(active)) break;
+        st_iters++;
         if (active) {
           const long long q = S * L + p;
           const hipx_int  r = st_actual<FWD>(q, m);
@@ -476,6 +479,7 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
             const int     ro = P.off_rowq + 32 * (lane * ST_RQ + (p & (ST_RQ - 1)));
             const st_int4 w1 = st_ld4v(lds, ro + 16);  // tag first: operands are written before the tag
             const st_int4 w0 = st_ld4v(lds, ro);
+            if (w1.y != p) st_rowwait++;
             if (w1.y == p) {
               rb   = st_dbl(w0.z, w0.w);
               ti   = st_ld4(lds, P.off_tinfo + 16 * w1.x);
@@ -514,6 +518,7 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
                   if (j < n && sl[j].z != pos[j]) {
                     if (sl[j].z > pos[j]) {  // the slot has moved on (this lane fell far behind its producer): read the value itself
                       const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(xnew + st_actual<FWD>(q + e[j].y, m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                      st_fallback++;
                       if (v == SOR_SENTINEL) ok = false;
                       else val[j] = __longlong_as_double((long long)v);
                     } else ok = false;  // not produced yet
@@ -527,6 +532,7 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
                 }
               }
             }
+            if (!ok) st_depwait++;
             if (ok && k >= ti.y) {
               double out;
               if (KIND == 0) {
@@ -571,9 +577,21 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
         }
       }
       if (lane == 0) s_ctl[1] = 1;
+      if (stats) {
+        atomicAdd(&stats[1], (unsigned long long)st_rowwait);
+        atomicAdd(&stats[2], (unsigned long long)st_depwait);
+        atomicAdd(&stats[5], (unsigned long long)st_fallback);
+        atomicAdd(&stats[7], (unsigned long long)len);
+        if (lane == 0) {
+          atomicAdd(&stats[0], (unsigned long long)st_iters);
+          atomicAdd(&stats[6], (unsigned long long)((long long)wall_clock64() - st_t0));
+          atomicAdd(&stats[8], 1ull);
+        }
+      }
     } else {
       // ------------------------------------------------------------------ loader wave
       int rqf = 0;  // next position of the own strand whose operands are to be staged
+      unsigned st_pass = 0, st_idle = 0;
       int sf[2 * ST_NB];
 #pragma unroll
       for (int d = 0; d < 2 * ST_NB; d++) sf[d] = 0;
@@ -695,7 +713,15 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
             sf[d] += cnt;
           }
         }
-        if (!__any(issued)) __builtin_amdgcn_s_sleep(4);
+        st_pass++;
+        if (!__any(issued)) {
+          st_idle++;
+          __builtin_amdgcn_s_sleep(4);
+        }
+      }
+      if (stats && lane == 0) {
+        atomicAdd(&stats[3], (unsigned long long)st_pass);
+        atomicAdd(&stats[4], (unsigned long long)st_idle);
       }
     }
   }
@@ -734,6 +760,7 @@ struct StrandState {
   std::vector<double>  diagval;  // diagonal value of every template
   StrandDir            dir[2];   // [0] forward (dependencies = lower part), [1] backward
   unsigned int        *d_ctl = nullptr;
+  unsigned long long  *d_stats = nullptr;
   unsigned long long   value_state = 0;
   double               omega = 0.0, shift = 0.0;
   bool                 diag_uploaded = false;
@@ -749,6 +776,7 @@ void strand_free(StrandState *T)
     (void)hipFree(D.d_old);
   }
   (void)hipFree(T->d_ctl);
+  (void)hipFree(T->d_stats);
   delete T;
 }
 
@@ -943,17 +971,19 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
   }
   unsigned grid = (unsigned)std::min<long long>((long long)P.npanels, 256LL * per_cu);
   const bool aligned = (P.L % 8 == 0) && (P.m % 8 == 0) && ((reinterpret_cast<uintptr_t>(asrc) | reinterpret_cast<uintptr_t>(xold)) % 16 == 0);
+  static const bool dbg = getenv("HIPX_SOR_DEBUG") != nullptr;
   static bool attr_set[5][2] = {{false}};
   auto launch = [&](auto kern, int ai) -> int {
     if (!attr_set[KIND][ai]) {
       HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       attr_set[KIND][ai] = true;
     }
-    kern<<<grid, 128, (size_t)P.lds_bytes, st>>>(P, T->d_tid, D.d_tinfo, D.d_tdiag, D.d_dep, D.d_old, asrc, t, xold, xnew, omega, T->d_ctl);
+    kern<<<grid, 128, (size_t)P.lds_bytes, st>>>(P, T->d_tid, D.d_tinfo, D.d_tdiag, D.d_dep, D.d_old, asrc, t, xold, xnew, omega, T->d_ctl, dbg ? T->d_stats : nullptr);
     return HIPX_SUCCESS;
   };
-  static const bool dbg = getenv("HIPX_SOR_DEBUG") != nullptr;
   if (dbg) {
+    if (!T->d_stats) HIPX_HIP(hipMalloc((void **)&T->d_stats, sizeof(unsigned long long) * 16));
+    HIPX_HIP(hipMemsetAsync(T->d_stats, 0, sizeof(unsigned long long) * 16, st));
     HIPX_HIP(hipStreamSynchronize(st));
     fprintf(stderr, "[hipx sor] strand KIND %d aligned %d m %d L %d nstr %d npanels %d nbands %d nrows %d ntmpl %d ndep %d nold %d maxchunks %d lds %d grid %u  tid %p asrc %p t %p xold %p xnew %p ctl %p\n", KIND,
             (int)aligned, P.m, P.L, P.nstr, P.npanels, P.nbands, P.nrows, P.ntmpl, P.ndep, P.nold, P.maxchunks, P.lds_bytes, grid, (const void *)T->d_tid, (const void *)asrc, (void *)t, (const void *)xold,
@@ -964,7 +994,12 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
   HIPX_LAUNCH_CHECK();
   if (dbg) {
     HIPX_HIP(hipStreamSynchronize(st));
-    fprintf(stderr, "[hipx sor] strand KIND %d done\n", KIND);
+    unsigned long long hs[16];
+    HIPX_HIP(hipMemcpy(hs, T->d_stats, sizeof(hs), hipMemcpyDeviceToHost));
+    const double np = (double)std::max<unsigned long long>(hs[8], 1);
+    fprintf(stderr, "[hipx sor] strand KIND %d done: panels %llu, compute iterations/panel %.0f, wall/panel %.1f us (%.3f us/iteration), rows %llu, lane-iterations waiting: operands %llu deps %llu, "
+                    "fallback loads %llu, loader passes/panel %.0f (idle %.0f)\n",
+            KIND, hs[8], hs[0] / np, hs[6] / np / 100.0, hs[0] ? hs[6] / 100.0 / (double)hs[0] : 0.0, hs[7], hs[1], hs[2], hs[5], hs[3] / np, hs[4] / np);
   }
   return HIPX_SUCCESS;
 }

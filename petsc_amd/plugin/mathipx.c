@@ -16,7 +16,10 @@ typedef struct {
   PetscErrorCode (*parent_assemblyend)(Mat, MatAssemblyType);
   PetscErrorCode (*parent_destroy)(Mat);
   PetscErrorCode (*parent_duplicate)(Mat, MatDuplicateOption, Mat *);
-  PetscInt spmv_variant;
+  PetscErrorCode (*parent_prealloc_coo)(Mat, PetscCount, PetscInt[], PetscInt[]);
+  PetscInt  spmv_variant;
+  hipxCOO   coo;       /* device copies of the reference's COO maps (MatCOOStruct_SeqAIJ jmap / perm) */
+  PetscBool dev_newer; /* the device value array is ahead of the host copy a->a (MatSetValuesCOO ran on the device) */
 } Mat_SeqAIJHIPX;
 
 static PetscErrorCode MatMult_SeqAIJHIPX(Mat, Vec, Vec);
@@ -36,6 +39,11 @@ PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA)
   PetscFunctionBegin;
   PetscCheck(A->assembled, PetscObjectComm((PetscObject)A), PETSC_ERR_ARG_WRONGSTATE, "Not for unassembled matrix");
   PetscCall(PetscObjectStateGet((PetscObject)A, &state));
+  if (h->dev_newer && h->dA && h->nonzerostate == A->nonzerostate) { /* values were assembled on the device: nothing to upload */
+    h->valuestate = state;
+    *dA           = h->dA;
+    PetscFunctionReturn(PETSC_SUCCESS);
+  }
   if (!h->dA || h->nonzerostate != A->nonzerostate) {
     const PetscScalar *aa;
     if (h->dA) PetscCallHIPX(hipxMatDestroy(&h->dA));
@@ -152,6 +160,94 @@ static PetscErrorCode MatSOR_SeqAIJHIPX(Mat A, Vec bb, PetscReal omega, MatSORTy
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+
+/* ---- COO assembly on the device.  MatSetPreallocationCOO_SeqAIJ (aij.c:4524-4707) stays the reference's host
+   routine -- integer work, once per pattern; its jmap / perm maps are mirrored on the device and MatSetValuesCOO_SeqAIJ
+   (aij.c:4710-4733) becomes one kernel (same left-to-right sums -> bit-identical values).  The host copy a->a is refreshed
+   lazily: the value-array accessors of Mat_SeqAIJOps copy it back when a host routine asks for it. */
+static PetscErrorCode MatSeqAIJHIPXSyncValuesToHost(Mat A)
+{
+  Mat_SeqAIJHIPX *h = (Mat_SeqAIJHIPX *)A->spptr;
+  Mat_SeqAIJ     *a = (Mat_SeqAIJ *)A->data;
+
+  PetscFunctionBegin;
+  if (h->dev_newer && h->dA) {
+    PetscCallHIPX(hipxMatGetValues(h->dA, a->a));
+    h->dev_newer = PETSC_FALSE; /* both copies equal; a later host write bumps the object state and is uploaded as before */
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode MatSeqAIJGetArray_SeqAIJHIPX(Mat A, PetscScalar *array[])
+{
+  PetscFunctionBegin;
+  PetscCall(MatSeqAIJHIPXSyncValuesToHost(A));
+  *array = ((Mat_SeqAIJ *)A->data)->a;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode MatSeqAIJGetArrayRead_SeqAIJHIPX(Mat A, const PetscScalar *array[])
+{
+  PetscFunctionBegin;
+  PetscCall(MatSeqAIJHIPXSyncValuesToHost(A));
+  *array = ((Mat_SeqAIJ *)A->data)->a;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode MatSeqAIJGetArrayWrite_SeqAIJHIPX(Mat A, PetscScalar *array[])
+{
+  PetscFunctionBegin;
+  ((Mat_SeqAIJHIPX *)A->spptr)->dev_newer = PETSC_FALSE; /* the host overwrites every value: the restore bumps the object state -> uploaded at the next product */
+  *array = ((Mat_SeqAIJ *)A->data)->a;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode MatSetPreallocationCOO_SeqAIJHIPX(Mat A, PetscCount n, PetscInt coo_i[], PetscInt coo_j[])
+{
+  Mat_SeqAIJHIPX      *h = (Mat_SeqAIJHIPX *)A->spptr;
+  PetscContainer       container;
+  MatCOOStruct_SeqAIJ *coo;
+
+  PetscFunctionBegin;
+  PetscCheck(h->parent_prealloc_coo, PETSC_COMM_SELF, PETSC_ERR_PLIB, "MATSEQAIJ did not provide MatSetPreallocationCOO");
+  if (h->coo) PetscCallHIPX(hipxCOODestroy(&h->coo));
+  if (h->dA) PetscCallHIPX(hipxMatDestroy(&h->dA)); /* new pattern */
+  h->dev_newer = PETSC_FALSE;
+  PetscCall((*h->parent_prealloc_coo)(A, n, coo_i, coo_j));
+  PetscCall(PetscObjectQuery((PetscObject)A, "__PETSc_MatCOOStruct_Host", (PetscObject *)&container));
+  PetscCheck(container, PETSC_COMM_SELF, PETSC_ERR_PLIB, "Not found MatCOOStruct on this matrix");
+  PetscCall(PetscContainerGetPointer(container, &coo));
+  PetscCallHIPX(hipxCOOCreate((int64_t)coo->nz, (const int64_t *)coo->jmap, (int64_t)coo->Atot, (const int64_t *)coo->perm, &h->coo));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode MatSetValuesCOO_SeqAIJHIPX(Mat A, const PetscScalar v[], InsertMode imode)
+{
+  Mat_SeqAIJHIPX      *h = (Mat_SeqAIJHIPX *)A->spptr;
+  Mat_SeqAIJ          *a = (Mat_SeqAIJ *)A->data;
+  PetscContainer       container;
+  MatCOOStruct_SeqAIJ *coo;
+  int                  ondev = 0;
+
+  PetscFunctionBegin;
+  PetscCheck(h->coo, PETSC_COMM_SELF, PETSC_ERR_ORDER, "MatSetPreallocationCOO() has not been called");
+  PetscCall(PetscObjectQuery((PetscObject)A, "__PETSc_MatCOOStruct_Host", (PetscObject *)&container));
+  PetscCall(PetscContainerGetPointer(container, &coo));
+  if (!h->dA || h->nonzerostate != A->nonzerostate) { /* device CSR of the preallocated pattern; values start at zero (aij.c:4693) */
+    if (h->dA) PetscCallHIPX(hipxMatDestroy(&h->dA));
+    if (imode == ADD_VALUES) PetscCallHIPX(hipxMatCreateCSR(A->rmap->n, A->cmap->n, a->i, a->j, a->a, &h->dA));
+    else PetscCallHIPX(hipxMatCreateCSR(A->rmap->n, A->cmap->n, a->i, a->j, NULL, &h->dA));
+    if (h->spmv_variant) PetscCallHIPX(hipxMatSetSpMVVariant(h->dA, (int)h->spmv_variant));
+    h->nonzerostate = A->nonzerostate;
+  } else if (!h->dev_newer && imode == ADD_VALUES) { /* the host copy is the current one: bring it over before adding to it */
+    PetscCallHIPX(hipxMatUpdateValues(h->dA, a->a));
+  }
+  PetscCallHIPX(hipxPointerIsDevice(v, &ondev));
+  PetscCallHIPX(hipxMatSetValuesCOO(h->dA, h->coo, v, (int64_t)coo->n, ondev, imode == INSERT_VALUES ? 1 : 0));
+  h->dev_newer = PETSC_TRUE;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 static PetscErrorCode MatAssemblyEnd_SeqAIJHIPX(Mat A, MatAssemblyType mode)
 {
   Mat_SeqAIJHIPX *h = (Mat_SeqAIJHIPX *)A->spptr;
@@ -169,6 +265,7 @@ static PetscErrorCode MatDestroy_SeqAIJHIPX(Mat A)
 
   PetscFunctionBegin;
   if (h->dA) PetscCallHIPX(hipxMatDestroy(&h->dA));
+  if (h->coo) PetscCallHIPX(hipxCOODestroy(&h->coo));
   PetscCall(PetscObjectComposeFunction((PetscObject)A, "MatConvert_seqaij_seqaijhipx_C", NULL));
   PetscCall(PetscFree(A->spptr));
   PetscCall((*pdestroy)(A));
@@ -227,6 +324,15 @@ static PetscErrorCode MatConvert_SeqAIJ_SeqAIJHIPX(Mat A, MatType mtype, MatReus
   B->ops->destroy        = MatDestroy_SeqAIJHIPX;
   B->ops->duplicate      = MatDuplicate_SeqAIJHIPX;
   B->ops->setfromoptions = MatSetFromOptions_SeqAIJHIPX;
+  PetscCall(PetscObjectQueryFunction((PetscObject)B, "MatSetPreallocationCOO_C", &h->parent_prealloc_coo));
+  PetscCall(PetscObjectComposeFunction((PetscObject)B, "MatSetPreallocationCOO_C", MatSetPreallocationCOO_SeqAIJHIPX));
+  PetscCall(PetscObjectComposeFunction((PetscObject)B, "MatSetValuesCOO_C", MatSetValuesCOO_SeqAIJHIPX));
+  { /* host routines that read or write the value array go through these (aij.c:4294-4400) */
+    Mat_SeqAIJ *sa = (Mat_SeqAIJ *)B->data;
+    sa->ops->getarray      = MatSeqAIJGetArray_SeqAIJHIPX;
+    sa->ops->getarrayread  = MatSeqAIJGetArrayRead_SeqAIJHIPX;
+    sa->ops->getarraywrite = MatSeqAIJGetArrayWrite_SeqAIJHIPX;
+  }
   /* MatCreateVecs() hands out VECHIPX vectors, so KSP/PC work vectors live on the device (matrix.c:10069,10080) */
   PetscCall(PetscFree(B->defaultvectype));
   PetscCall(PetscStrallocpy(VECHIPX, &B->defaultvectype));

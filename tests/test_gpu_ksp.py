@@ -186,7 +186,7 @@ def test_cg_pipelined_variable_and_constant_diagonal(hx):
         b = orc.matmult(ai, aj, vals, np.ones(N))
         o = exact_solve("cg", ai, aj, vals, b, rtol=1e-9)
         g1 = solve_gpu("cg", ai, aj, vals, b, rtol=1e-9, fused=1)
-        compare(g1, o, 1e-10)
+        compare(g1, o, TOL_CONVERGED)
         os.environ["HIPX_NO_DCONST"] = "1"
         try:
             g2 = solve_gpu("cg", ai, aj, vals, b, rtol=1e-9, fused=1)
