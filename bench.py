@@ -84,14 +84,14 @@ def physical_cores():
     return max(1, len(cores))
 
 
-def ref_driver(np_, args, plugin=False, timeout=900):
+def ref_driver(np_, args, plugin=False, timeout=900, bind=False):
     """The REFERENCE itself (oracle/_ref: libpetsc compiled from /root/reference by oracle/build_ref.py): its own MatSetValues
     assembly, KSPSolve, MatMult_SeqAIJ / _MPIAIJ, PCJACOBI / PCSOR, MKL BLAS-1 (one thread per rank)."""
     mp = np_ > 1
     exe = os.path.join(ROOT, "oracle", "_ref", "mpich" if mp else "", "bin", "ref_driver")
     if not os.path.exists(exe):
         return None
-    cmd = (["/opt/conda/bin/mpiexec", "-n", str(np_)] if mp else []) + [exe] + args
+    cmd = (["/opt/conda/bin/mpiexec"] + (["-bind-to", "core"] if bind else []) + ["-n", str(np_)] if mp else []) + [exe] + args
     if plugin:
         so = os.path.join(ROOT, "petsc_amd", "lib", "libpetschipx_mpich.so" if mp else "libpetschipx.so")
         if not os.path.exists(so):
@@ -475,16 +475,25 @@ def main():
             cores = physical_cores()
             base = None
             if cube and N <= 2 ** 25:
-                its_p = 100 if n >= 200 else 300
-                rp = ref_driver(cores, solver_args(args, its_p)) if cores > 1 else None
+                # the box's host cores: P = physical cores, and P/2, P/4 beside it (a memory-bound solve does not always peak at
+                # P = cores; an over-subscribed or quota-limited container shows up here too); the best rate is the baseline
+                its_p = 40 if n >= 200 else 200
+                tried, rp = [], None
+                for p_ in [c for c in dict.fromkeys([cores, cores // 2, cores // 4]) if c > 1]:
+                    r = ref_driver(p_, solver_args(args, its_p), bind=True) or ref_driver(p_, solver_args(args, its_p))
+                    if r is not None:
+                        r["ranks"] = p_
+                        tried.append({"ranks": p_, "iterations_per_s": r["its"] / r["seconds"]})
+                        if rp is None or r["its"] / r["seconds"] > rp["its"] / rp["seconds"]:
+                            rp = r
                 r1 = ref1 if ref1 is not None else ref_driver(1, solver_args(args, GATE_ITS))
                 if rp is not None or r1 is not None:
                     best = rp if rp is not None else r1
-                    base = {"value": best["its"] / best["seconds"], "unit": "iterations/s", "cores": cores if rp is not None else 1, "kind": "reference",
-                            "value_1core": (r1["its"] / r1["seconds"]) if r1 else None,
+                    base = {"value": best["its"] / best["seconds"], "unit": "iterations/s", "cores": rp["ranks"] if rp is not None else 1, "kind": "reference",
+                            "physical_cores": cores, "ranks_tried": tried, "value_1core": (r1["its"] / r1["seconds"]) if r1 else None,
                             "sample": "the reference's own KSPSolve (KSP%s + %s, MAT(MPI)AIJ, VEC(MPI), MKL BLAS one thread per rank, gcc -O2; oracle/_ref) on the same %d-pt %d^3 system: "
-                                      "%s iterations on %d MPI ranks = physical cores of this host (KSPSolve wall %s s), %s iterations on 1 core (%s s); assembly excluded"
-                                      % (args.ksp.upper(), pcname, args.stencil, n, rp["its"] if rp else "-", cores, "%.3f" % rp["seconds"] if rp else "-",
+                                      "%s iterations on %d MPI ranks, the best of the rank counts tried on this host's %d physical cores (KSPSolve wall %s s), %s iterations on 1 core (%s s); assembly excluded"
+                                      % (args.ksp.upper(), pcname, args.stencil, n, rp["its"] if rp else "-", rp["ranks"] if rp else 0, cores, "%.3f" % rp["seconds"] if rp else "-",
                                          r1["its"] if r1 else "-", "%.3f" % r1["seconds"] if r1 else "-")}
             if base is None and cube and args.ksp == "cg" and args.pc == "jacobi" and N <= 2 ** 25:
                 base, _ = oracle_port_baseline(P.ai, P.aj, P.aa, P.B.get(), 20.0, args.stencil, n)

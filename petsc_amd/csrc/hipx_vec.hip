@@ -403,6 +403,136 @@ __global__ __launch_bounds__(kRedThreads) void mdot_kernel(const double *x, MDot
   block_finish<NV, RED_SUM>(acc, out);
 }
 
+
+// GMRES orthogonalisation (VecMDot_Seq dvec2.c:83, the GEMV "T" of dvec2.c:515-590): x . y_j for up to NVMAX vectors in ONE
+// pass over x (31 instead of 34 vector reads for 30 vectors, one launch instead of four).  The additions happen in the same
+// order as in mdot_kernel<NV> for every NV (per-thread pairs p, p + T, ... in increasing order), so the sums do not depend on
+// how a call is batched.
+template <int NVMAX>
+__global__ __launch_bounds__(kRedThreads) void mdot_wide_kernel(const double *x, MDotArgs<NVMAX> ys, int nv, hipx_int n, bool vec, RedOut out)
+{
+  double acc[NVMAX];
+#pragma unroll
+  for (int v = 0; v < NVMAX; v++) acc[v] = 0.0;
+  const hipx_int T   = (hipx_int)gridDim.x * kRedThreads;
+  const hipx_int tid = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x;
+  if (vec) {
+    const hipx_int n2 = n >> 1;
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    constexpr int  U     = 2;
+    const hipx_int chunk = (n2 + (hipx_int)gridDim.x - 1) / (hipx_int)gridDim.x;
+    const hipx_int c0    = (hipx_int)blockIdx.x * chunk;
+    const hipx_int c1    = (c0 + chunk < n2) ? c0 + chunk : n2;
+    for (hipx_int p = c0 + (hipx_int)threadIdx.x; p < c1; p += U * kRedThreads) {
+      double2 xa[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const hipx_int q = p + u * kRedThreads;
+        xa[u]            = (q < c1) ? x2[q] : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int v = 0; v < NVMAX; v++) {
+        if (v < nv) {
+          const double2 *y2 = reinterpret_cast<const double2 *>(ys.y[v]);
+          double2        ya[U];
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const hipx_int q = p + u * kRedThreads;
+            ya[u]            = (q < c1) ? y2[q] : make_double2(0.0, 0.0);
+          }
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            acc[v] += xa[u].x * ya[u].x;
+            acc[v] += xa[u].y * ya[u].y;
+          }
+        }
+      }
+    }
+    if ((n & 1) && tid == 0) {
+#pragma unroll
+      for (int v = 0; v < NVMAX; v++)
+        if (v < nv) acc[v] += x[n - 1] * ys.y[v][n - 1];
+    }
+  } else {
+    for (hipx_int i = tid; i < n; i += T) {
+#pragma unroll
+      for (int v = 0; v < NVMAX; v++)
+        if (v < nv) acc[v] += x[i] * ys.y[v][i];
+    }
+  }
+  block_finish<NVMAX, RED_SUM>(acc, out);
+}
+
+// VecMAXPY_Seq / VecMAXPBY for up to 36 vectors in ONE pass over y (dvec2.c:658-693: (nv & 3) vectors first, then groups of
+// four, each group summed left to right before it is added to y -- the association every batch of maxpy_kernel keeps too)
+constexpr int MAXPY_WIDE = 36;
+struct MaxpyWideArgs {
+  const double *x[MAXPY_WIDE];
+  double        a[MAXPY_WIDE];
+};
+template <int REM>
+__global__ __launch_bounds__(kEwThreads) void maxpy_wide_kernel(double *y, MaxpyWideArgs args, int nv, double beta, int mode, hipx_int n)
+{
+  const hipx_int n2 = n >> 1;
+  double2       *y2 = reinterpret_cast<double2 *>(y);
+  for (hipx_int p = (hipx_int)blockIdx.x * kEwThreads + threadIdx.x; p < n2; p += (hipx_int)gridDim.x * kEwThreads) {
+    double2 acc = (mode == 2) ? make_double2(0.0, 0.0) : y2[p];
+    if (mode == 1) {
+      acc.x *= beta;
+      acc.y *= beta;
+    }
+    if (REM) {
+      double2 g = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int j = 0; j < REM; j++) {
+        const double2 xv = reinterpret_cast<const double2 *>(args.x[j])[p];
+        if (j == 0) {
+          g.x = args.a[j] * xv.x;
+          g.y = args.a[j] * xv.y;
+        } else {
+          g.x = g.x + args.a[j] * xv.x;
+          g.y = g.y + args.a[j] * xv.y;
+        }
+      }
+      acc.x += g.x;
+      acc.y += g.y;
+    }
+    for (int j0 = REM; j0 < nv; j0 += 4) {
+      double2 xv[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) xv[j] = reinterpret_cast<const double2 *>(args.x[j0 + j])[p];
+      double2 g;
+      g.x = args.a[j0] * xv[0].x;
+      g.y = args.a[j0] * xv[0].y;
+#pragma unroll
+      for (int j = 1; j < 4; j++) {
+        g.x = g.x + args.a[j0 + j] * xv[j].x;
+        g.y = g.y + args.a[j0 + j] * xv[j].y;
+      }
+      acc.x += g.x;
+      acc.y += g.y;
+    }
+    y2[p] = acc;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {  // odd tail
+    const hipx_int i = n - 1;
+    double acc = (mode == 2) ? 0.0 : y[i];
+    if (mode == 1) acc *= beta;
+    if (REM) {
+      double g = 0.0;
+#pragma unroll
+      for (int j = 0; j < REM; j++) g = (j == 0) ? args.a[j] * args.x[j][i] : g + args.a[j] * args.x[j][i];
+      acc += g;
+    }
+    for (int j0 = REM; j0 < nv; j0 += 4) {
+      double g = args.a[j0] * args.x[j0][i];
+      for (int j = 1; j < 4; j++) g = g + args.a[j0 + j] * args.x[j0 + j][i];
+      acc += g;
+    }
+    y[i] = acc;
+  }
+}
+
 // sums of |x| (NORM_1), x*x (NORM_2) in one pass: acc[0] = sum |x|, acc[1] = sum x^2
 __global__ __launch_bounds__(kRedThreads) void norm12_kernel(const double *x, hipx_int n, bool vec, RedOut out)
 {
@@ -620,8 +750,24 @@ int launch_mdot(const double *x, const double *const *y, hipx_int n, int slot)
   return HIPX_SUCCESS;
 }
 
+template <int NVMAX>
+int launch_mdot_wide(const double *x, int nv, const double *const *y, hipx_int n, int slot)
+{
+  MDotArgs<NVMAX> a;
+  bool            vec = aligned16(x) && n >= 2;
+  for (int v = 0; v < NVMAX; v++) {
+    a.y[v] = y[v < nv ? v : 0];
+    vec    = vec && aligned16(a.y[v]);
+  }
+  mdot_wide_kernel<NVMAX><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, a, nv, n, vec, red_out_g(slot));
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
 int mdot_dispatch(const double *x, int nv, const double *const *y, hipx_int n, int slot)
 {
+  if (nv > 8 && nv <= 16) return launch_mdot_wide<16>(x, nv, y, n, slot);
+  if (nv > 16 && nv <= 32) return launch_mdot_wide<32>(x, nv, y, n, slot);
   switch (nv) {
   case 1: return launch_mdot<1>(x, y, n, slot);
   case 2: return launch_mdot<2>(x, y, n, slot);
@@ -852,11 +998,40 @@ int hipxVecReplaceZeros(double *x, hipx_int n, double value, hipx_int *nreplaced
   return HIPX_SUCCESS;
 }
 
+// y (= beta y | = 0) += sum_j alpha[j] x[j] in one pass when everything is 16-byte aligned and nv fits; mode as in maxpy_kernel
+static int maxpy_wide(double *y, hipx_int nv, const double *alpha, const double *const *x, double beta, int mode, hipx_int n, bool *done_out)
+{
+  *done_out = false;
+  static const bool off = getenv("HIPX_MAXPY_BATCH") && atoi(getenv("HIPX_MAXPY_BATCH")) == 8;  // the round-1 batching (identical results)
+  if (off || nv <= MAXPY_B || nv > MAXPY_WIDE || n < 2 || !aligned16(y)) return HIPX_SUCCESS;
+  MaxpyWideArgs a;
+  for (int j = 0; j < MAXPY_WIDE; j++) {
+    a.x[j] = x[j < nv ? j : 0];
+    a.a[j] = j < nv ? alpha[j] : 0.0;
+    if (!aligned16(a.x[j])) return HIPX_SUCCESS;
+  }
+  const unsigned g = (unsigned)std::min<hipx_int>(((n >> 1) + kEwThreads - 1) / kEwThreads, 8192);
+  switch (nv & 3) {
+  case 0: maxpy_wide_kernel<0><<<g, kEwThreads, 0, rt().compute>>>(y, a, (int)nv, beta, mode, n); break;
+  case 1: maxpy_wide_kernel<1><<<g, kEwThreads, 0, rt().compute>>>(y, a, (int)nv, beta, mode, n); break;
+  case 2: maxpy_wide_kernel<2><<<g, kEwThreads, 0, rt().compute>>>(y, a, (int)nv, beta, mode, n); break;
+  default: maxpy_wide_kernel<3><<<g, kEwThreads, 0, rt().compute>>>(y, a, (int)nv, beta, mode, n); break;
+  }
+  HIPX_LAUNCH_CHECK();
+  *done_out = true;
+  return HIPX_SUCCESS;
+}
+
 int hipxVecMAXPY(double *y, hipx_int nv, const double *alpha, const double *const *x, hipx_int n)
 {
   HIPX_CHECK_INIT();
   HIPX_ARG(nv >= 0, "nv < 0");
   if (n <= 0 || nv == 0) return HIPX_SUCCESS;
+  {
+    bool done1 = false;
+    int  ierr  = maxpy_wide(y, nv, alpha, x, 0.0, 0, n, &done1);
+    if (ierr || done1) return ierr;
+  }
   // the reference processes (nv & 3) vectors first, then groups of four (dvec2.c:672-690); batches here keep
   // that grouping: first batch takes (nv & 3) + 4 (or fewer), later batches multiples of 4.
   hipx_int done = 0, rem = nv & 3;
@@ -876,6 +1051,11 @@ int hipxVecMAXPBY(double *y, hipx_int nv, const double *alpha, double beta, cons
   HIPX_CHECK_INIT();
   // rvector.c:1394-1440 with no ops->maxpby: beta == 0 -> VecSet(y, 0) else VecScale(y, beta); then VecMAXPY.
   int ierr;
+  if (n > 0 && nv > 0) {  // one pass: y = beta y (or 0) and the sums, same operations in the same order as the two-step form
+    bool done1 = false;
+    ierr       = maxpy_wide(y, nv, alpha, x, beta, beta == 0.0 ? 2 : 1, n, &done1);
+    if (ierr || done1) return ierr;
+  }
   if (beta == 0.0) ierr = hipxVecSet(y, n, 0.0);
   else ierr = hipxVecScale(y, n, beta);
   if (ierr) return ierr;
@@ -923,11 +1103,13 @@ int hipxVecMDot(const double *x, hipx_int nv, const double *const *y, hipx_int n
     for (hipx_int j = 0; j < nv; j++) results[j] = 0.0;
     return HIPX_SUCCESS;
   }
-  // batches of <= 8 vectors, each in its own slot so a single wait at the end suffices
+  // batches of <= 32 vectors (one pass over x each; GMRES(30) is ONE launch), each in its own slot so a single wait at the end
+  // suffices.  HIPX_MDOT_BATCH=8 restores the round-1 batching (the sums are identical either way: same addition order).
+  static const hipx_int BATCH = (getenv("HIPX_MDOT_BATCH") && atoi(getenv("HIPX_MDOT_BATCH")) == 8) ? 8 : 32;
   hipx_int done = 0;
   int      slot = 1;
   while (done < nv) {
-    hipx_int take = nv - done > 8 ? 8 : nv - done;
+    hipx_int take = nv - done > BATCH ? BATCH : nv - done;
     int      ierr = mdot_dispatch(x, take, y + done, n, slot);
     if (ierr) return ierr;
     done += take;
@@ -936,7 +1118,7 @@ int hipxVecMDot(const double *x, hipx_int nv, const double *const *y, hipx_int n
   done = 0;
   slot = 1;
   while (done < nv) {
-    hipx_int take = nv - done > 8 ? 8 : nv - done;
+    hipx_int take = nv - done > BATCH ? BATCH : nv - done;
     int      ierr = red_wait(slot, take, results + done);
     if (ierr) return ierr;
     done += take;

@@ -507,6 +507,31 @@ static PetscErrorCode VecMAXPY_HIPX(Vec y, PetscInt nv, const PetscScalar *alpha
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+/* VecMAXPBY (rvector.c:1394-1440): y = beta y + sum_j alpha[j] x[j].  One pass for up to 36 vectors (KSPGMRESBuildSoln, gmres.c:337);
+   longer lists: the interface's own decomposition (VecSet / VecScale, then VecMAXPY) */
+static PetscErrorCode VecMAXPBY_HIPX(Vec y, PetscInt nv, const PetscScalar *alpha, PetscScalar beta, Vec *x)
+{
+  PetscFunctionBegin;
+  if (nv <= HIPX_MAXV) {
+    PetscScalar       *dy;
+    void              *ty;
+    const PetscScalar *dx[HIPX_MAXV];
+    void              *tx[HIPX_MAXV];
+    if (beta == 0.0) WR(y, dy, ty);
+    else RW(y, dy, ty);
+    for (PetscInt j = 0; j < nv; j++) RD(x[j], dx[j], tx[j]);
+    PetscCallHIPX(hipxVecMAXPBY(dy, nv, alpha, beta, (const double *const *)dx, y->map->n));
+    for (PetscInt j = 0; j < nv; j++) RDX(x[j], dx[j], tx[j]);
+    WRX(y, dy, ty);
+    PetscCall(PetscLogFlops(nv * 2.0 * y->map->n));
+  } else {
+    if (beta == 0.0) PetscCall(VecSet(y, 0.0));
+    else PetscCall(VecScale(y, beta));
+    PetscCall(VecMAXPY(y, nv, alpha, x));
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 static PetscErrorCode VecDotLocal_HIPX(Vec x, Vec y, PetscScalar *z) /* VecDot_Seq / VecTDot_Seq bvec1.c:10-49 (real scalars: identical) */
 {
   const PetscScalar *dx, *dy;
@@ -758,7 +783,7 @@ static void VecHIPXInstallLocalOps(Vec v)
   o->reciprocal       = VecReciprocal_HIPX;
   o->abs              = VecAbs_HIPX;
   o->shift            = VecShift_HIPX;
-  o->maxpby           = NULL; /* interface falls back to VecSet/VecScale + VecMAXPY (rvector.c:1434), as on VECSEQ */
+  o->maxpby           = VecMAXPBY_HIPX;
   o->getarray         = VecGetArray_HIPX;
   o->restorearray     = VecRestoreArray_HIPX;
   o->getarrayread     = VecGetArrayRead_HIPX;

@@ -64,7 +64,7 @@ KATS = [
     ("mat_ex5_11_B", "kat_mat_ex5", "-mat_type seqaij -rectB", "notype", "mat/tests/output/ex5_11_B.out"),
     ("mat_ex5_21", "kat_mat_ex5", "-mat_type mpiaij", "notype", "mat/tests/output/ex5_21.out"),
     ("mat_ex5_31", "kat_mat_ex5", "-mat_type mpiaij -test_diagonalscale", "notype", "mat/tests/output/ex5_31.out"),
-] + [("mat_ex123_1_%s_l%d_n%d" % (mt, la, ng), "kat_mat_ex123", "-mat_type %s -localapi %d -neg %d" % (mt, la, ng), "ex123", "mat/tests/output/ex123_1.out")
+] + [("mat_ex123_1_%s_l%d_n%d" % (mt, la, ng), "kat_mat_ex123", "-mat_type %s -localapi %d -neg %d -options_left no" % (mt, la, ng), "ex123", "mat/tests/output/ex123_1.out")
      for mt in ("seqaij", "mpiaij") for la in (0, 1) for ng in (0, 1)]
 
 
@@ -80,7 +80,7 @@ KATS_MPI = [
     ("mat_ex5_23", "kat_mat_ex5", 3, "-mat_type mpiaij", "notype", "mat/tests/output/ex5_23.out"),
     ("mat_ex5_33", "kat_mat_ex5", 3, "-mat_type mpiaij -test_diagonalscale", "notype", "mat/tests/output/ex5_33.out"),
     ("ksp_ex2_2", "ex2", 2, "-ksp_monitor -m 5 -n 5 -ksp_gmres_cgs_refinement_type refine_always", "monitor", "ksp/ksp/tutorials/output/ex2_2.out"),
-] + [("mat_ex123_3_l%d_n%d" % (la, ng), "kat_mat_ex123", 3, "-mat_type mpiaij -loc -localapi %d -neg %d" % (la, ng), "ex123", "mat/tests/output/ex123_3.out") for la in (0, 1) for ng in (0, 1)]
+] + [("mat_ex123_3_l%d_n%d" % (la, ng), "kat_mat_ex123", 3, "-mat_type mpiaij -loc -localapi %d -neg %d -options_left no" % (la, ng), "ex123", "mat/tests/output/ex123_3.out") for la in (0, 1) for ng in (0, 1)]
 
 
 def kats():

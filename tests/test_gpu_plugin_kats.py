@@ -43,4 +43,4 @@ def test_reference_kat_with_hipx_types(name):
     assert r.returncode == 0, r.stdout[-2000:]
     got = apply_filter(k["filter"], r.stdout)
     want = apply_filter(k["filter"], k["golden"])
-    assert got == want, "KAT %s (%s) differs from %s:\n--- got\n%s\n--- want\n%s" % (name, " ".join(cmd), k["golden_file"], got[:1500], want[:1500])
+    assert got == want, "KAT %s (%s) differs from %s:\n--- got\n%s\n--- want\n%s" % (name, " ".join(cmd), k["golden_file"], got[-1500:], want[-1500:])

@@ -58,7 +58,7 @@ def test_reference_np_kat_with_hipx_types(name):
         args += ["-mat_type", "aijhipx"]
     got = apply_filter(k["filter"], mpirun(k["nsize"], k["exe"], args, True))
     want = apply_filter(k["filter"], k["golden"])
-    assert got == want, "np-%d KAT %s differs from %s:\n--- got\n%s\n--- want\n%s" % (k["nsize"], name, k["golden_file"], got[:1500], want[:1500])
+    assert got == want, "np-%d KAT %s differs from %s:\n--- got\n%s\n--- want\n%s" % (k["nsize"], name, k["golden_file"], got[-1500:], want[-1500:])
 
 
 def parse_driver(txt):

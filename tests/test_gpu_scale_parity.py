@@ -36,7 +36,9 @@ MPIEXEC = "/opt/conda/bin/mpiexec"
 TOL_HISTORY = 1e-12
 # np > 1 and sequential GMRES+SOR runs are compared CPU-vs-GPU of the same executable (no exact yardstick under MPI): both sides
 # carry their own reduction rounding (MPI_Allreduce of per-rank BLAS partials vs per-rank trees); measured margins are recorded.
-TOL_GMRES_SOR = 1e-11   # GMRES(30)+PCSOR, 60-90 iterations with restarts: GPU vs the exactly rounded yardstick (measured margins are recorded)
+TOL_GMRES_SOR = 1e-9    # GMRES(30)+PCSOR, 60-90 iterations with two restarts: GPU vs the exactly rounded yardstick.  Measured: np=1 5.9e-10
+                        # (the CPU run of the same executable is 5.8e-8 from the yardstick there: the last entries before convergence are
+                        # that sensitive to reduction rounding), np=2 4.9e-11, np=3 3.6e-11, np=4 2.2e-11 (CPU runs: 8e-11 .. 1.5e-10)
 TOL_PIPELINED = 1e-6    # pipelined / single-reduction CG against the CPU run of the same executable (see the test)
 
 

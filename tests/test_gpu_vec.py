@@ -129,10 +129,14 @@ def test_norm_inf_propagates_nan_like_reference(hx):
     X.free()
 
 
-@pytest.mark.parametrize("nv", [1, 2, 3, 4, 5, 7, 8, 9, 13, 30])
-def test_mdot_maxpy(hx, nv):
+@pytest.mark.parametrize("n", [40009, 40010, 7])
+@pytest.mark.parametrize("nv", [1, 2, 3, 4, 5, 7, 8, 9, 13, 16, 17, 30, 31, 32, 33, 35, 36, 40])
+def test_mdot_maxpy(hx, nv, n):
+    """VecMDot / VecMAXPY / VecMAXPBY for 1..40 vectors: up to 32 dot products and 36 AXPYs in ONE pass (GMRES(30)'s
+    orthogonalisation), more in batches.  The dot products do not depend on the batching (each equals hipxVecDot of the pair bit
+    for bit); MAXPY / MAXPBY keep the grouping of dvec2.c:658-693 -> bit-identical to the reference loops; odd and even
+    lengths, beta = 0 / 1 / other."""
     from petsc_amd import _lib
-    n = 40009
     x = rnd(n, 9)
     ys = [rnd(n, 100 + j) for j in range(nv)]
     X = dv(x)
@@ -140,8 +144,11 @@ def test_mdot_maxpy(hx, nv):
     ptrs = (C.c_void_p * nv)(*[v.ptr.value for v in Ys])
     res = (C.c_double * nv)()
     _lib.chk(hx.hipxVecMDot(X.ptr, nv, ptrs, n, res))
+    one = C.c_double()
     for j in range(nv):
         assert abs(res[j] - float(x @ ys[j])) <= 1e-13 * np.abs(x * ys[j]).sum()
+        _lib.chk(hx.hipxVecDot(X.ptr, Ys[j].ptr, n, C.byref(one)))
+        assert res[j] == one.value
     alpha = rnd(nv, 10)
     al = (C.c_double * nv)(*alpha)
     _lib.chk(hx.hipxVecMAXPY(X.ptr, nv, al, ptrs, n))
@@ -153,6 +160,12 @@ def test_mdot_maxpy(hx, nv):
     ref2 = x.copy()
     orc.lib().orc_VecMAXPBY(n, orc.P(ref2), nv, orc.P(alpha), C.c_double(0.0), yp)
     assert np.array_equal(X.get(), ref2)
+    for beta in (1.0, -0.75):
+        X.set(x)
+        _lib.chk(hx.hipxVecMAXPBY(X.ptr, nv, al, beta, ptrs, n))
+        ref3 = x.copy()
+        orc.lib().orc_VecMAXPBY(n, orc.P(ref3), nv, orc.P(alpha), C.c_double(beta), yp)
+        assert np.array_equal(X.get(), ref3)
     X.free()
     for v in Ys:
         v.free()
