@@ -71,6 +71,9 @@ struct hipxMat_s {
   int           *d_tstart = nullptr;  // ntmpl + 1 offsets into toff / tval
   int           *d_toff   = nullptr;  // column - row
   double        *d_tval   = nullptr;
+  unsigned long long *d_tq = nullptr;   // chunk queue of the template kernel: one ticket counter per XCD (64 bytes apart), never reset
+  unsigned long long  tq_launches = 0;  // launches so far on this geometry (the kernel subtracts launches * tickets-per-launch)
+  int                 tq_geom = -1;     // geometry (grid, rows per chunk) the counters have been used with
   std::vector<int>     h_tstart, h_toff, h_tdiag;  // host copies (SOR set-up reads them); h_tdiag = index of the diagonal entry or -1
   std::vector<int64_t> h_tcount;                   // rows per template
   std::vector<double>  h_tval;
@@ -972,9 +975,10 @@ __global__ __launch_bounds__(256) void tmpl_verify_kernel(hipx_int m, hipx_int n
 template <int MODE, bool DOT, int RPT, int W, bool UNI>
 __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const int *__restrict__ tstart,
                                                         const int *__restrict__ toff, const double *__restrict__ tval, int ntmpl, int nent, const double *__restrict__ x,
-                                                        const double *yin, double *yout, double *dotpart)
+                                                        const double *yin, double *yout, double *dotpart, unsigned long long *tq, unsigned long long launch)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ long long s_tk;
   double *s_val   = reinterpret_cast<double *>(smem);                      // nent (padded to even)
   int    *s_off   = reinterpret_cast<int *>(smem + 8 * (size_t)((nent + 1) & ~1));
   int    *s_start = s_off + ((nent + 3) & ~3);                             // ntmpl + 1
@@ -985,10 +989,24 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
   }
   for (int k = t; k <= ntmpl; k += 256) s_start[k] = tstart[k];
   __syncthreads();
-  const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, slot = bid >> 3, bpx = (hipx_int)gridDim.x >> 3;
+  const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, bpx = (hipx_int)gridDim.x >> 3;
   const hipx_int c0 = xcd * chunks_per_xcd, c1 = (c0 + chunks_per_xcd < nchunks) ? c0 + chunks_per_xcd : nchunks;
   double         mydot = 0.0;
-  for (hipx_int c = c0 + slot; c < c1; c += bpx) {
+  // Chunk queue: the workgroups of an XCD (hardware block b runs on XCD b % 8: observed rule, used for locality only) pull the
+  // chunks of that XCD's slab IN ORDER from one ticket counter, so at any moment they work on a window of consecutive chunks:
+  // the planes of x a window touches (rows +-n, +-n^2) stay in that XCD's 4 MiB L2 and x is fetched from HBM about once
+  // (a static chunk -> workgroup map lets the workgroups drift apart: measured 2.6x).  Every workgroup takes exactly one ticket
+  // beyond the end, so a launch consumes (chunks + workgroups) tickets per XCD and the counters never need a reset.
+  const long long     nloc = (long long)(c1 > c0 ? c1 - c0 : 0);
+  unsigned long long *ctr  = tq + (size_t)xcd * 8;
+  const long long     tbase = (long long)(launch * (unsigned long long)(nloc + bpx));
+  if (t == 0) s_tk = (long long)atomicAdd(ctr, 1ull) - tbase;
+  __syncthreads();
+  long long tk = s_tk;
+  while (tk < nloc) {
+    long long nxt = 0;
+    if (t == 0) nxt = (long long)atomicAdd(ctr, 1ull) - tbase;  // the next ticket travels while this chunk is processed
+    const hipx_int c    = c0 + (hipx_int)tk;
     const hipx_int base = c * (256 * RPT);
     int            id[RPT];
     double         sum[RPT], xrow[RPT];
@@ -1072,6 +1090,10 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
         if (DOT) mydot += xrow[rr] * sum[rr];
       }
     }
+    __syncthreads();  // everybody has read the current ticket
+    if (t == 0) s_tk = nxt;
+    __syncthreads();
+    tk = s_tk;
   }
   if (DOT) {
     const double w = hipx::wave_sum(mydot);
@@ -1477,6 +1499,10 @@ void free_templates(hipxMat A)
   (void)hipFree(A->d_tstart);
   (void)hipFree(A->d_toff);
   (void)hipFree(A->d_tval);
+  (void)hipFree(A->d_tq);
+  A->d_tq = nullptr;
+  A->tq_launches = 0;
+  A->tq_geom = -1;
   A->d_tid = nullptr;
   A->d_tstart = nullptr;
   A->d_toff = nullptr;
@@ -1600,11 +1626,12 @@ int ensure_templates(hipxMat A)
   return ierr;
 }
 
-// geometry of the template kernel: HIPX_TMPL_CFG = 0 (2 rows per thread, per-lane walk only) | 1 (2 rows, uniform fast path)
-// | 2 (4 rows, uniform fast path: default) | 3 (4 rows, per-lane walk only) | 4 (8 rows, uniform fast path)
+// geometry of the template kernel: HIPX_TMPL_CFG = 0 (2 rows per thread, per-lane walk only) | 1 (2 rows, uniform fast path:
+// default -- the smaller chunk keeps the x window of an XCD inside its L2) | 2 (4 rows, uniform fast path) | 3 (4 rows, per-lane
+// walk only) | 4 (8 rows, uniform fast path)
 int tmpl_cfg()
 {
-  static const int v = getenv("HIPX_TMPL_CFG") ? atoi(getenv("HIPX_TMPL_CFG")) : 2;
+  static const int v = getenv("HIPX_TMPL_CFG") ? atoi(getenv("HIPX_TMPL_CFG")) : 1;
   return v;
 }
 int tmpl_blocks()
@@ -1627,8 +1654,17 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
   }
   const hipx_int cpx  = (nchunks + 7) / 8;
   const size_t   smem = 8 * (size_t)((A->tmpl_nent + 1) & ~1) + 4 * (size_t)((A->tmpl_nent + 3) & ~3) + 4 * ((size_t)A->ntmpl + 1) + 16;
+  const int      geom = (int)grid * 16 + rpt;
+  if (!A->d_tq || A->tq_geom != geom) {  // ticket counters of the chunk queue (zeroed once per geometry)
+    if (!A->d_tq) HIPX_HIP(hipMalloc((void **)&A->d_tq, 8 * 64));
+    HIPX_HIP(hipMemsetAsync(A->d_tq, 0, 8 * 64, rt().compute));
+    A->tq_launches = 0;
+    A->tq_geom     = geom;
+  }
+  const unsigned long long launch = A->tq_launches++;
 #define HIPX_TMPL_LAUNCH(R, WW, U) \
-  spmv_tmpl_kernel<MODE, DOT, R, WW, U><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout, dotpart)
+  spmv_tmpl_kernel<MODE, DOT, R, WW, U><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout, dotpart, \
+                                                                                      A->d_tq, launch)
   switch (cfg) {
   case 0: HIPX_TMPL_LAUNCH(2, 4, false); break;
   case 1: HIPX_TMPL_LAUNCH(2, 4, true); break;

@@ -353,7 +353,7 @@ constexpr int ST_SB   = 8;   // positions per staging batch
 constexpr int ST_LA   = 10;  // staging look-ahead beyond the leading consumer
 constexpr int ST_NB   = 3;   // bands of strands a panel may touch
 constexpr int ST_MAXW = 4;   // strands per band
-constexpr int ST_CH   = 4;   // dependency entries per chunk in the compute wave
+constexpr int ST_ME   = 16;  // dependency entries of a row the compute wave keeps in registers (27-point: 13)
 
 struct StBand {
   int dsmin, width, rowbase, pad;
@@ -460,80 +460,88 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
     const int       len = st_strand_len(S, P);
     if (!loader) {
       // ------------------------------------------------------------------ compute wave
-      int       p = 0, k = 0;
+      // One row per lane per iteration at best.  A row's operands and its template's dependency entries are fetched ONCE
+      // into registers (at the end of the iteration that finished the previous row, so the LDS round trips overlap the loop
+      // overhead); an iteration then is: read the <= ST_ME window slots (issued back to back), compare their tags, and, when
+      // every value is there, the left-to-right subtraction chain, the scale by 1/d and the publish.
+      int       p = 0, dcnt = 0, ostart = 0, ocnt = 0;
       bool      have = false;
-      double    sum = 0.0, rb = 0.0;
+      double    s0 = 0.0, rb = 0.0, idiag = 0.0, mdiag = 0.0;
+      st_int4   e[ST_ME];
+#pragma unroll
+      for (int j = 0; j < ST_ME; j++) e[j] = st_int4{0, 0, 0, 0};
       unsigned  st_iters = 0, st_rowwait = 0, st_depwait = 0, st_fallback = 0;  // HIPX_SOR_DEBUG statistics (stats != nullptr)
       const long long st_t0 = stats ? (long long)wall_clock64() : 0;
-      st_int4   ti = {0, 0, 0, 0};  // {dstart, dcnt, ostart, ocnt}
-      double    idiag = 0.0, mdiag = 0.0;
       long long t0 = 0;
+      auto fetch_row = [&]() {  // operands + template of the row at position p, if the loader has staged them
+        const int     ro = P.off_rowq + 32 * (lane * ST_RQ + (p & (ST_RQ - 1)));
+        const st_int4 w1 = st_ld4v(lds, ro + 16);  // tag first: operands are written before the tag
+        const st_int4 w0 = st_ld4v(lds, ro);
+        if (w1.y != p) {
+          st_rowwait++;
+          return;
+        }
+        const st_int4 ti = st_ld4(lds, P.off_tinfo + 16 * w1.x);
+        const st_int4 dg = st_ld4(lds, P.off_tdiag + 16 * w1.x);
+        dcnt   = ti.y;
+        ostart = ti.z;
+        ocnt   = ti.w;
+#pragma unroll
+        for (int j = 0; j < ST_ME; j++)
+          if (j < dcnt) e[j] = st_ld4(lds, P.off_dep + 16 * (ti.x + j));
+        rb    = st_dbl(w0.z, w0.w);
+        idiag = st_dbl(dg.x, dg.y);
+        mdiag = st_dbl(dg.z, dg.w);
+        s0    = st_dbl(w0.x, w0.y);
+        have  = true;
+        if (KIND == 4) {  // aij.c:1984-1990: the lower part and the diagonal use OLD values, in row order, first
+          const hipx_int r = st_actual<FWD>(S * L + p, m);
+          for (int q2 = 0; q2 < ocnt; q2++) {
+            const st_int4 oe = st_ld4(lds, P.off_old + 16 * (ostart + q2));
+            s0 -= st_dbl(oe.z, oe.w) * xold[(long long)r + oe.x];
+          }
+        }
+      };
       for (unsigned it = 1;; it++) {
         const bool active = p < len;
         if (!__any(active)) break;
         st_iters++;
         if (active) {
-          const long long q = S * L + p;
-          const hipx_int  r = st_actual<FWD>(q, m);
-          if (!have) {
-            const int     ro = P.off_rowq + 32 * (lane * ST_RQ + (p & (ST_RQ - 1)));
-            const st_int4 w1 = st_ld4v(lds, ro + 16);  // tag first: operands are written before the tag
-            const st_int4 w0 = st_ld4v(lds, ro);
-            if (w1.y != p) st_rowwait++;
-            if (w1.y == p) {
-              rb   = st_dbl(w0.z, w0.w);
-              ti   = st_ld4(lds, P.off_tinfo + 16 * w1.x);
-              const st_int4 dg = st_ld4(lds, P.off_tdiag + 16 * w1.x);
-              idiag = st_dbl(dg.x, dg.y);
-              mdiag = st_dbl(dg.z, dg.w);
-              have = true;
-              k    = 0;
-              sum  = st_dbl(w0.x, w0.y);
-              if (KIND == 4) {  // aij.c:1984-1990: the lower part and the diagonal use OLD values, in row order, first
-                for (int e = 0; e < ti.w; e++) {
-                  const st_int4 oe = st_ld4(lds, P.off_old + 16 * (ti.z + e));
-                  sum -= st_dbl(oe.z, oe.w) * xold[(long long)r + oe.x];
-                }
+          if (!have) fetch_row();
+          if (have) {
+            const long long q = S * L + p;
+            const hipx_int  r = st_actual<FWD>(q, m);
+            bool            ok = true;
+            double          val[ST_ME];
+            st_int4         sl[ST_ME];
+#pragma unroll
+            for (int j = 0; j < ST_ME; j++) {
+              if (j < dcnt) {
+                const int pos = p + (int)(short)(e[j].x & 0xffff);
+                sl[j]         = st_ld4v(lds, P.off_win + 16 * ((lane + (e[j].x >> 16)) * ST_WP + (pos & (ST_WP - 1))));
               }
             }
-          }
-          if (have) {
-            bool ok = true;
-            for (int c = 0; c < P.maxchunks; c++) {
-              if (ok && k < ti.y) {
-                const int n = (ti.y - k) < ST_CH ? (ti.y - k) : ST_CH;
-                st_int4   e[ST_CH], sl[ST_CH];
-                int       pos[ST_CH];
-                double    val[ST_CH];
 #pragma unroll
-                for (int j = 0; j < ST_CH; j++) e[j] = st_ld4(lds, P.off_dep + 16 * (ti.x + k + (j < n ? j : n - 1)));
-#pragma unroll
-                for (int j = 0; j < ST_CH; j++) {
-                  pos[j] = p + (int)(short)(e[j].x & 0xffff);
-                  sl[j]  = st_ld4v(lds, P.off_win + 16 * ((lane + (e[j].x >> 16)) * ST_WP + (pos[j] & (ST_WP - 1))));
-                }
-#pragma unroll
-                for (int j = 0; j < ST_CH; j++) {
-                  val[j] = st_dbl(sl[j].x, sl[j].y);
-                  if (j < n && sl[j].z != pos[j]) {
-                    if (sl[j].z > pos[j]) {  // the slot has moved on (this lane fell far behind its producer): read the value itself
-                      const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(xnew + st_actual<FWD>(q + e[j].y, m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                      st_fallback++;
-                      if (v == SOR_SENTINEL) ok = false;
-                      else val[j] = __longlong_as_double((long long)v);
-                    } else ok = false;  // not produced yet
-                  }
-                }
-                if (ok) {
-#pragma unroll
-                  for (int j = 0; j < ST_CH; j++)
-                    if (j < n) sum -= st_dbl(e[j].z, e[j].w) * val[j];
-                  k += n;
+            for (int j = 0; j < ST_ME; j++) {
+              if (j < dcnt) {
+                const int pos = p + (int)(short)(e[j].x & 0xffff);
+                val[j]        = st_dbl(sl[j].x, sl[j].y);
+                if (sl[j].z != pos) {
+                  if (sl[j].z > pos) {  // the slot has moved on (this lane fell far behind its producer): read the value itself
+                    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(xnew + st_actual<FWD>(q + e[j].y, m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    st_fallback++;
+                    if (v == SOR_SENTINEL) ok = false;
+                    else val[j] = __longlong_as_double((long long)v);
+                  } else ok = false;  // not produced yet
                 }
               }
             }
             if (!ok) st_depwait++;
-            if (ok && k >= ti.y) {
+            if (ok) {
+              double sum = s0;
+#pragma unroll
+              for (int j = 0; j < ST_ME; j++)
+                if (j < dcnt) sum -= st_dbl(e[j].z, e[j].w) * val[j];
               double out;
               if (KIND == 0) {
                 t[r] = sum;
@@ -544,8 +552,8 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
                 out = sum * idiag;
               } else if (KIND == 3) {
                 t[r] = sum;
-                for (int e2 = 0; e2 < ti.w; e2++) {  // upper part: old values (aij.c:1973-1976)
-                  const st_int4 oe = st_ld4(lds, P.off_old + 16 * (ti.z + e2));
+                for (int e2 = 0; e2 < ocnt; e2++) {  // upper part: old values (aij.c:1973-1976)
+                  const st_int4 oe = st_ld4(lds, P.off_old + 16 * (ostart + e2));
                   sum -= st_dbl(oe.z, oe.w) * xold[(long long)r + oe.x];
                 }
                 out = (1. - omega) * rb + sum * idiag;
@@ -563,6 +571,7 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
               sor_publish(xnew + r, out);
               p++;
               have = false;
+              if (p < len) fetch_row();  // the next row's operands: ready when the next iteration starts
             }
           }
         }
@@ -898,7 +907,8 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
     }
     P.ndep      = (int)dep.size();
     P.nold      = (int)old.size();
-    P.maxchunks = (maxdep + ST_CH - 1) / ST_CH;
+    P.maxchunks = maxdep;
+    if (maxdep > ST_ME) continue;  // rows with more dependency entries than the compute wave caches: level-ordered schedule
     int o = 0;
     P.off_win   = o; o += P.nrows * ST_WP * (int)sizeof(StSlot);
     P.off_rowq  = o; o += 64 * ST_RQ * (int)sizeof(StRow);
