@@ -40,7 +40,8 @@ struct hipxSorState {
   int4     *d_smeta = nullptr;  // per slot {original row | -1, diagonal offset, row length, 0}: one load instead of slot -> perm -> pi/pd
   int64_t  *d_sks = nullptr;    // per slot start of the row in pj/pa
   bool      smeta_valid = false;
-  double   *d_w1 = nullptr;
+  double   *d_w1 = nullptr, *d_w2 = nullptr;
+  bool      mdiag_valid = false;  // d_mdiag holds the diagonal of the current values (Eisenstat in strand mode)
   unsigned int *d_ctl = nullptr;  // [0] block ticket, [1] error flag
   int       mode = 1;           // 1 = dependency-driven single launch per sweep, 0 = one launch per level
   double    omega = 0.0, shift = 0.0;
@@ -141,6 +142,12 @@ __global__ __launch_bounds__(SOR_THREADS) void sor_level_kernel(hipx_int p0, hip
     for (int64_t k = s; k < e; k++) sum -= pa[k] * x[pj[k]];
     x[i] = (1. - omega) * x[i] + (sum + mdiag[i] * x[i]) * idiag[i];
   }
+}
+
+// SOR_EISENSTAT, middle step (aij.c:1909-1911): t = b - scale * a_ii * x, evaluated as (scale * a_ii) * x like the host loop
+__global__ void sor_eisenstat_mid_kernel(hipx_int m, const double *__restrict__ mdiag, const double *__restrict__ b, const double *__restrict__ x, double scale, double *__restrict__ t)
+{
+  for (hipx_int i = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (hipx_int)gridDim.x * blockDim.x) t[i] = b[i] - scale * mdiag[i] * x[i];
 }
 
 // SOR_APPLY_UPPER (aij.c:1867-1884): x_i = b_i * (shift + d_i) / omega + sum_{j>i} a_ij b_j  -- no dependencies
@@ -1054,8 +1061,6 @@ int build_schedule(hipxSorState *S, hipx_int m, int64_t nnz, int is64, const voi
   HIPX_HIP(hipMalloc((void **)&S->d_pd, sizeof(hipx_int) * (size_t)m));
   HIPX_HIP(hipMalloc((void **)&S->d_pj, sizeof(hipx_int) * (size_t)(nnz ? nnz : 1)));
   HIPX_HIP(hipMalloc((void **)&S->d_pa, sizeof(double) * (size_t)(nnz ? nnz : 1)));
-  HIPX_HIP(hipMalloc((void **)&S->d_idiag, sizeof(double) * (size_t)m));
-  HIPX_HIP(hipMalloc((void **)&S->d_mdiag, sizeof(double) * (size_t)m));
   HIPX_HIP(hipMemcpy(S->d_perm, perm.data(), sizeof(hipx_int) * (size_t)m, hipMemcpyHostToDevice));
   HIPX_HIP(hipMemcpy(S->d_pi, pi.data(), sizeof(int64_t) * ((size_t)m + 1), hipMemcpyHostToDevice));
   {  // wave-aligned slot map: every level starts on a multiple of 64 slots
@@ -1080,7 +1085,7 @@ int build_schedule(hipxSorState *S, hipx_int m, int64_t nnz, int is64, const voi
 extern "C" void hipxSorInvalidate_(void *p)
 {
   hipxSorState *S = (hipxSorState *)p;
-  if (S) S->values_valid = S->idiag_valid = false;
+  if (S) S->values_valid = S->idiag_valid = S->mdiag_valid = false;
 }
 
 extern "C" void hipxSorStateFree_(void *p)
@@ -1099,6 +1104,7 @@ extern "C" void hipxSorStateFree_(void *p)
   (void)hipFree(S->d_smeta);
   (void)hipFree(S->d_sks);
   (void)hipFree(S->d_w1);
+  (void)hipFree(S->d_w2);
   (void)hipFree(S->d_ctl);
   strand_free((StrandState *)S->strand);
   delete S;
@@ -1156,8 +1162,7 @@ extern "C" int hipxMatSOR(hipxMat A, const double *b, double omega, int flag, do
   if (ierr) return ierr;
   HIPX_ARG(!compressed && m == n, "MatSOR needs a square, uncompressed matrix");
   if (!diag_dense) return fail(73 /* PETSC_ERR_ARG_WRONGSTATE */, "Matrix must have all diagonal locations to invert them (aij.c:1809)", __FILE__, __LINE__);
-  if (flag & 128) return fail(HIPX_ERR_SUP, "SOR_APPLY_LOWER is not implemented (aij.c:1886)", __FILE__, __LINE__);
-  if (flag & 32) return fail(HIPX_ERR_SUP, "SOR_EISENSTAT is not provided by MATSEQAIJHIPX", __FILE__, __LINE__);
+  if (flag & 128) return fail(HIPX_ERR_SUP, "SOR_APPLY_LOWER is not implemented (aij.c:1886: the reference raises the same error)", __FILE__, __LINE__);
   if (!m) return HIPX_SUCCESS;
   hipxSorState *S = (hipxSorState *)*slot;
   if (!S) {
@@ -1206,6 +1211,8 @@ extern "C" int hipxMatSOR(hipxMat A, const double *b, double omega, int flag, do
   if (!S->d_t) {  // work vectors shared by every mode
     HIPX_HIP(hipMalloc((void **)&S->d_t, sizeof(double) * (size_t)m));
     HIPX_HIP(hipMalloc((void **)&S->d_w1, sizeof(double) * (size_t)m));
+    HIPX_HIP(hipMalloc((void **)&S->d_idiag, sizeof(double) * (size_t)m));
+    HIPX_HIP(hipMalloc((void **)&S->d_mdiag, sizeof(double) * (size_t)m));
     HIPX_HIP(hipMalloc((void **)&S->d_ctl, sizeof(unsigned int) * 2));
     HIPX_HIP(hipMemsetAsync(S->d_ctl, 0, sizeof(unsigned int) * 2, st));
     S->m = m;
@@ -1261,6 +1268,41 @@ extern "C" int hipxMatSOR(hipxMat A, const double *b, double omega, int flag, do
   if (flag == 64) {  // SOR_APPLY_UPPER
     sor_apply_upper_kernel<<<(unsigned)g, 256, 0, st>>>(m, S->d_perm, S->d_pi, S->d_pd, S->d_pj, S->d_pa, S->d_mdiag, b, x, omega, shift);
     HIPX_LAUNCH_CHECK();
+    return HIPX_SUCCESS;
+  }
+  if (flag & 32) {
+    // SOR_EISENSTAT (aij.c:1887-1929): x = (E + U)^-1 b  [a backward zero-guess sweep];  t = b - (2/omega - 1) D x;
+    // t = (E + L)^-1 t  [a forward zero-guess sweep with t as right-hand side];  x = x + t
+    if (!S->d_w2) HIPX_HIP(hipMalloc((void **)&S->d_w2, sizeof(double) * (size_t)m));
+    if (S->mode == 2 && !S->mdiag_valid) {  // the diagonal itself (strand mode keeps 1/d per template only)
+      unsigned int *cnt = rt().d_tickets + (HIPX_MAX_RED_SLOTS - 1);
+      invert_diag_kernel<<<(unsigned)g, 256, 0, st>>>(m, d_diagpos, d_a, omega, shift, 0, S->d_idiag, S->d_mdiag, cnt);
+      HIPX_LAUNCH_CHECK();
+      S->mdiag_valid = true;
+      S->idiag_valid = false;
+    }
+    const double scale = (2.0 / omega) - 1.0;
+    if (S->mode >= 1) {
+      if ((ierr = run_sweep<2>(S, b, nullptr, x, omega))) return ierr;
+      sor_eisenstat_mid_kernel<<<(unsigned)g, 256, 0, st>>>(m, S->d_mdiag, b, x, scale, S->d_w1);
+      HIPX_LAUNCH_CHECK();
+      if ((ierr = run_sweep<0>(S, S->d_w1, nullptr, S->d_w2, omega))) return ierr;  // (writes the unscaled sums to d_t: unused here)
+      if ((ierr = hipxVecAXPY(x, 1.0, S->d_w2, m))) return ierr;
+      unsigned int *ctl  = S->mode == 2 ? ((StrandState *)S->strand)->d_ctl : S->d_ctl;
+      unsigned int  herr = 0;
+      HIPX_HIP(hipMemcpyAsync(&herr, ctl + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+      HIPX_HIP(hipStreamSynchronize(st));
+      if (herr) {
+        HIPX_HIP(hipMemsetAsync(ctl, 0, 2 * sizeof(unsigned int), st));
+        return fail(HIPX_ERR_GPU, "MatSOR: a dependency was never published (wait limit reached)", __FILE__, __LINE__);
+      }
+    } else {
+      if ((ierr = run_levels<2>(S, false, b, x, omega))) return ierr;
+      sor_eisenstat_mid_kernel<<<(unsigned)g, 256, 0, st>>>(m, S->d_mdiag, b, x, scale, S->d_w1);
+      HIPX_LAUNCH_CHECK();
+      if ((ierr = run_levels<0>(S, true, S->d_w1, S->d_w2, omega))) return ierr;
+      if ((ierr = hipxVecAXPY(x, 1.0, S->d_w2, m))) return ierr;
+    }
     return HIPX_SUCCESS;
   }
   const bool fwd = (flag & 1) || (flag & 4), bwd = (flag & 2) || (flag & 8);

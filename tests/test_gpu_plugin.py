@@ -138,3 +138,15 @@ def test_ksp_cghipx_fused_solve_inside_petsc():
         assert ic.group(1, 2) == ig.group(1, 2), (args, ic.groups(), ig.groups())
         assert len(hc) == len(hg) and np.abs(hc - hg).max() <= 1e-12 * hc[0], args
         assert abs(float(ic.group(3)) - float(ig.group(3))) <= 1e-5 * float(ic.group(3)) + 1e-13
+
+
+def test_pc_eisenstat_on_hipx_types():
+    """PCEISENSTAT (src/ksp/pc/impls/eisens/eisen.c) drives MatSOR with SOR_EISENSTAT and SOR_APPLY_UPPER: the CG history of the
+    reference over the hipx types follows its CPU run."""
+    a = "-stencil 7 -n 20 -ksp_type cg -pc_type eisenstat -ksp_rtol 1e-8 -history".split()
+    c, g = run("ref_driver", a), run("ref_driver", a + HIPX)
+    hc, hg = hist_of(c), hist_of(g)
+    ic = re.search(r"iterations (\d+) reason (-?\d+) error (\S+)", c)
+    ig = re.search(r"iterations (\d+) reason (-?\d+) error (\S+)", g)
+    assert ic.group(1, 2) == ig.group(1, 2) and len(hc) == len(hg) > 5
+    assert (np.abs(hc - hg) / hc).max() <= 1e-9

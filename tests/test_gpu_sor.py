@@ -13,7 +13,7 @@ from test_gpu_mat import random_csr
 
 pytestmark = pytest.mark.gpu
 
-FWD, BWD, SYM, LFWD, LBWD, LSYM, ZERO, UPPER = 1, 2, 3, 4, 8, 12, 16, 64
+FWD, BWD, SYM, LFWD, LBWD, LSYM, ZERO, EISENSTAT, UPPER = 1, 2, 3, 4, 8, 12, 16, 32, 64
 
 
 MODES = {"levels": 0, "dep": 1, "strand": 2}
@@ -136,6 +136,21 @@ def test_sor_config3_rank_slab_bit_exact(hx):
     b = rng.standard_normal(m)
     g = sor_gpu(hx, Ai, Aj, Aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, np.zeros(m), want_mode="strand")
     o = sor_cpu(Ai, Aj, Aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, np.zeros(m))
+    assert np.array_equal(g, o), np.abs(g - o).max()
+
+
+@pytest.mark.parametrize("kind,n,m", [("5pt", 9, 7), ("7pt", 12, None), ("27pt", 16, None), ("27pt", 9, None)])
+@pytest.mark.parametrize("omega,shift", [(1.0, 0.0), (1.4, 0.0), (0.7, 0.3)])
+@pytest.mark.parametrize("mode", ["strand", "dep", "levels"])
+def test_sor_eisenstat_bit_exact(hx, kind, n, m, omega, shift, mode):
+    """SOR_EISENSTAT (aij.c:1887-1929, what PCEISENSTAT applies): (L + E)^-1 A (U + E)^-1 b by Eisenstat's trick = a backward
+    sweep, a diagonal update and a forward sweep; bit-identical to the reference loops in every schedule."""
+    ai, aj, aa = orc.stencil(kind, n, m=m)
+    N = len(ai) - 1
+    rng = np.random.default_rng(21)
+    b, x0 = rng.standard_normal(N), rng.standard_normal(N)
+    g = sor_gpu(hx, ai, aj, aa, b, omega, EISENSTAT, shift, 1, 1, x0, mode=mode)
+    o = sor_cpu(ai, aj, aa, b, omega, EISENSTAT, shift, 1, 1, x0)
     assert np.array_equal(g, o), np.abs(g - o).max()
 
 
