@@ -152,7 +152,7 @@ class Problem:
         self.m = re - rs
         if world > 1:
             plan = pdist.build_plan(self.ai, self.aj, self.aa, ranges, rank, dist=dist)
-            self.M, self.keep = pdist.create_device_mat(plan, world)
+            self.M, self.keep = pdist.create_device_mat(plan, world, rank=rank, dist=dist, transport=args.transport)
             self.nnz_local = int(plan["Ai"][-1])
         else:
             A = _lib.mat_create_csr(self.m, self.m, self.ai, self.aj, self.aa)
@@ -322,6 +322,8 @@ def main():
     ap.add_argument("--stencil", type=int, default=7, choices=[7, 27])
     ap.add_argument("--ksp", default="cg", choices=["cg", "gmres"])
     ap.add_argument("--pc", default="jacobi", choices=["jacobi", "sor", "none"])
+    ap.add_argument("--transport", default=os.environ.get("HIPX_TRANSPORT", "rccl"), choices=["rccl", "ipc"],
+                    help="multi-GPU data path: RCCL send/recv + all-reduce over xGMI (default), or IPC peer stores (also when ranks share a GPU)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="weak: every GPU owns grid x grid x grid/8 rows (config 5: --grid 1024)")
     ap.add_argument("--fused", type=int, default=1, help="1 (default): fused SpMV+dot and AXPY+AXPY+PCJACOBI+norm+dot kernels -- same arithmetic and order per element, fewer HBM passes; 0: one kernel per reference Vec/Mat call (cg.c:249-344)")
     ap.add_argument("--pipeline", type=int, default=1, help="1 (default): launch-ahead fused CG (iteration i+1 enqueued before the host has seen iteration i's sums; device-resident scalars); 0: host waits between kernels")
@@ -349,18 +351,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        # gloo carries the set-up exchanges and the timing barrier; the data path (ghost values, dot/norm sums) is libhipx's own
+        dist.init_process_group(backend="gloo" if os.environ.get("HIPX_ALL_RANKS_DEVICE0") == "1" else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
     assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch N > 1 with torch.distributed.run)"
 
     from petsc_amd import _lib
     hx = _lib.init(local_rank)
     if world > 1:
-        idb = (C.c_char * 256)()
-        if rank == 0:
-            _lib.chk(hx.hipxCommGetUniqueId(idb))
-        box = [bytes(idb)]
-        dist.broadcast_object_list(box, src=0)
-        _lib.chk(hx.hipxCommInit(box[0], rank, world))
+        from petsc_amd import dist as pdist
+        pdist.comm_init(rank, world, dist, args.transport)
     P = Problem(args, rank, world, dist)
     n, N = args.n, P.N
 
@@ -449,7 +448,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "3-D %d-pt Poisson %dx%dx%d (N=%d rows, nnz=%d local), KSP%s + %s, b = A*1, x0 = 0; rows split over %d rank(s)"
                                    % (args.stencil, P.dims[0], P.dims[1], P.dims[2], N, P.nnz_local, args.ksp.upper(), pcname, world),
-                       "global_rows": N, "parallelism": "rows%d" % world, "fused": args.fused, "pipeline": args.pipeline, "spmv_variant": args.variant,
+                       "global_rows": N, "parallelism": "rows%d" % world, "transport": args.transport if world > 1 else None, "fused": args.fused, "pipeline": args.pipeline, "spmv_variant": args.variant,
                        "residual_norm_after": rnorm},
             "parity_gate": gate,
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

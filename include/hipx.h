@@ -185,6 +185,11 @@ int hipxPCJacobiSetUp(hipxMat A, double *dinv);
 int hipxCommGetUniqueId(void *id256);                         /* rank 0; broadcast the bytes yourself (MPI_Bcast / torch store) */
 int hipxCommInit(const void *id256, int rank, int nranks);    /* RCCL communicators */
 int hipxCommFinalize(void);
+/* RCCL-free alternative for the scalar all-reduces: IPC-mapped arenas, peer stores + sequence flags, contributions added in rank
+   order (the same bits on every rank).  Also works when ranks share a GPU.  Export on every rank, all-gather the 64-byte handles
+   (MPI / torch.distributed), attach.  Pair it with hipxHaloIpcExport/Attach for the ghost exchange. */
+int hipxCommIpcExport(int rank, int nranks, void *handle64);
+int hipxCommIpcAttach(const void *all_handles /* nranks x 64 bytes, by rank */);
 int hipxCommRank(int *rank, int *nranks);
 int hipxCommAllreduceSum(double *host_vals, int n);           /* n <= 64 doubles, device-staged ncclAllReduce */
 /* VecTDot_MPI / VecMDot_MPI (pvecimpl.h:97-111) in one stream-ordered chain: local dot kernel(s) -> ncclAllReduce on the

@@ -26,6 +26,17 @@ struct Comm {
   int        rank = 0, nranks = 1;
   double    *d_red = nullptr;  // all-reduce staging
   double    *h_red = nullptr;  // pinned
+  // IPC transport of the scalar all-reduces (hipxCommIpcExport / Attach): every rank stores its partial sums into every peer's
+  // arena and publishes a sequence number; each rank then adds the nranks contributions in rank order (bitwise the same sum on
+  // every rank).  Double-buffered by sequence parity: a rank can be at most one reduction ahead of a peer that still reads.
+  bool                ipc = false;
+  char               *arena = nullptr;         // fine-grained: [flags[nranks] | in[nranks][2][64]]
+  size_t              hdr = 0;
+  std::vector<char *> peer;                    // arenas of all ranks as mapped here
+  char              **d_peer = nullptr;
+  std::vector<void *> opened;
+  unsigned long long  seq = 0;
+  unsigned int       *d_err = nullptr;
 };
 Comm &cm()
 {
@@ -97,6 +108,35 @@ __global__ void ipc_ack_kernel(unsigned long long *const *ack_ptrs, int nrecv, u
   if ((int)threadIdx.x < nrecv) __hip_atomic_store(ack_ptrs[threadIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+
+__global__ __launch_bounds__(64) void ipc_allreduce_kernel(double *vals, int n, int me, int nranks, char *const *peer, size_t hdr, unsigned long long seq, unsigned int *err)
+{
+  const int t = threadIdx.x, q = (int)(seq & 1);
+  if (t < n) {
+    const double v = vals[t];
+    for (int p = 0; p < nranks; p++) {
+      double *in = reinterpret_cast<double *>(peer[p] + hdr) + ((size_t)me * 2 + q) * 64;
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(in + t), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (t < nranks) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(peer[t]) + me, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    ipc_wait_ge(reinterpret_cast<const unsigned long long *>(peer[me]) + t, seq, err);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (t < n) {
+    double sum = 0.0;
+    for (int p = 0; p < nranks; p++) {
+      const double *in = reinterpret_cast<const double *>(peer[me] + hdr) + ((size_t)p * 2 + q) * 64;
+      sum += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(in + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    }
+    vals[t] = sum;
+  }
+}
+
 }  // namespace
 
 // IPC transport: what a rank publishes about its receive side (one blob per rank, all-gathered by the host: MPI_Allgather in
@@ -136,6 +176,71 @@ struct hipxHalo_s {
   double               *ghost_cur = nullptr;   // ghost values of the exchange in progress / last completed
 };
 
+
+// in-place sum of n <= 64 doubles in device memory over all ranks, enqueued on the compute stream
+static int allreduce_dev(double *d_vals, int n)
+{
+  Comm &c = cm();
+  if (c.ipc) {
+    ipc_allreduce_kernel<<<1, 64, 0, rt().compute>>>(d_vals, n, c.rank, c.nranks, c.d_peer, c.hdr, ++c.seq, c.d_err);
+    HIPX_LAUNCH_CHECK();
+    return HIPX_SUCCESS;
+  }
+  HIPX_NCCL(ncclAllReduce(d_vals, d_vals, (size_t)n, ncclDouble, ncclSum, c.rcomm, rt().compute));
+  return HIPX_SUCCESS;
+}
+
+extern "C" {
+
+int hipxCommIpcExport(int rank, int nranks, void *handle64)
+{
+  HIPX_CHECK_INIT();
+  Comm &c = cm();
+  HIPX_ARG(!c.active && nranks >= 1 && nranks <= 64 && rank >= 0 && rank < nranks && handle64, "bad arguments (at most 64 ranks)");
+  c.rank   = rank;
+  c.nranks = nranks;
+  c.hdr    = ((size_t)8 * nranks + 255) & ~(size_t)255;
+  const size_t bytes = c.hdr + sizeof(double) * 64 * 2 * (size_t)nranks;
+  HIPX_HIP(hipExtMallocWithFlags((void **)&c.arena, bytes, hipDeviceMallocFinegrained));
+  HIPX_HIP(hipMemset(c.arena, 0, bytes));
+  hipIpcMemHandle_t h;
+  HIPX_HIP(hipIpcGetMemHandle(&h, c.arena));
+  static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle size");
+  memset(handle64, 0, 64);
+  memcpy(handle64, &h, sizeof(h));
+  return HIPX_SUCCESS;
+}
+
+int hipxCommIpcAttach(const void *all_handles)
+{
+  HIPX_CHECK_INIT();
+  Comm &c = cm();
+  HIPX_ARG(c.arena && all_handles && !c.active, "hipxCommIpcExport() first");
+  c.peer.assign((size_t)c.nranks, nullptr);
+  for (int r = 0; r < c.nranks; r++) {
+    if (r == c.rank) c.peer[(size_t)r] = c.arena;
+    else {
+      hipIpcMemHandle_t h;
+      memcpy(&h, (const char *)all_handles + 64 * (size_t)r, sizeof(h));
+      void *q = nullptr;
+      HIPX_HIP(hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess));
+      c.opened.push_back(q);
+      c.peer[(size_t)r] = (char *)q;
+    }
+  }
+  HIPX_HIP(hipMalloc((void **)&c.d_peer, sizeof(char *) * (size_t)c.nranks));
+  HIPX_HIP(hipMemcpy(c.d_peer, c.peer.data(), sizeof(char *) * (size_t)c.nranks, hipMemcpyHostToDevice));
+  HIPX_HIP(hipMalloc((void **)&c.d_err, sizeof(unsigned int)));
+  HIPX_HIP(hipMemset(c.d_err, 0, sizeof(unsigned int)));
+  HIPX_HIP(hipMalloc((void **)&c.d_red, sizeof(double) * 64));
+  HIPX_HIP(hipHostMalloc((void **)&c.h_red, sizeof(double) * 64, hipHostMallocDefault));
+  c.ipc    = true;
+  c.active = true;
+  return HIPX_SUCCESS;
+}
+
+}  // extern "C"
+
 extern "C" {
 
 int hipxCommGetUniqueId(void *id256)
@@ -172,8 +277,15 @@ int hipxCommFinalize(void)
   Comm &c = cm();
   if (!c.active) return HIPX_SUCCESS;
   HIPX_HIP(hipDeviceSynchronize());
-  HIPX_NCCL(ncclCommDestroy(c.comm));
-  HIPX_NCCL(ncclCommDestroy(c.rcomm));
+  if (c.ipc) {
+    for (void *q : c.opened) (void)hipIpcCloseMemHandle(q);
+    (void)hipFree(c.arena);
+    (void)hipFree(c.d_peer);
+    (void)hipFree(c.d_err);
+  } else {
+    HIPX_NCCL(ncclCommDestroy(c.comm));
+    HIPX_NCCL(ncclCommDestroy(c.rcomm));
+  }
   (void)hipFree(c.d_red);
   (void)hipHostFree(c.h_red);
   c = Comm();
@@ -197,7 +309,10 @@ int hipxCommAllreduceSum(double *vals, int n)
   hipStream_t s = rt().compute;
   memcpy(c.h_red, vals, sizeof(double) * (size_t)n);
   HIPX_HIP(hipMemcpyAsync(c.d_red, c.h_red, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
-  HIPX_NCCL(ncclAllReduce(c.d_red, c.d_red, (size_t)n, ncclDouble, ncclSum, c.rcomm, s));
+  {
+    int ierr = allreduce_dev(c.d_red, n);
+    if (ierr) return ierr;
+  }
   HIPX_HIP(hipMemcpyAsync(c.h_red, c.d_red, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
   HIPX_HIP(hipStreamSynchronize(s));
   memcpy(vals, c.h_red, sizeof(double) * (size_t)n);
@@ -216,7 +331,10 @@ int hipxVecMDotAllreduce(const double *x, hipx_int nv, const double *const *y, h
     int ierr = launch_mdot_nosignal(x, (int)nv, y, n, slot, c.d_red);
     if (ierr) return ierr;
   } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * (size_t)nv, rt().compute));  // rank without rows
-  HIPX_NCCL(ncclAllReduce(c.d_red, c.d_red, (size_t)nv, ncclDouble, ncclSum, c.rcomm, rt().compute));
+  {
+    int ierr = allreduce_dev(c.d_red, (int)nv);
+    if (ierr) return ierr;
+  }
   int ierr = red_signal(slot, c.d_red, (int)nv);
   if (ierr) return ierr;
   return red_wait(slot, (int)nv, results);
@@ -233,7 +351,10 @@ int hipxCGFusedUpdateAllreduce(double *x, double *r, double *z, const double *p,
     int ierr = launch_cg_fused_nosignal(x, r, z, p, w, d, a, n, slot, c.d_red);
     if (ierr) return ierr;
   } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * 2, rt().compute));
-  HIPX_NCCL(ncclAllReduce(c.d_red, c.d_red, 2, ncclDouble, ncclSum, c.rcomm, rt().compute));
+  {
+    int ierr = allreduce_dev(c.d_red, 2);
+    if (ierr) return ierr;
+  }
   int ierr = red_signal(slot, c.d_red, 2);
   if (ierr) return ierr;
   return red_wait(slot, 2, sums2);
@@ -310,7 +431,7 @@ int hipxHaloBegin(hipxHalo h, const double *x, double *lvec)
     HIPX_HIP(hipEventRecord(h->ev_done, rt().comm));
     return HIPX_SUCCESS;
   }
-  if (!c.active) return fail(HIPX_ERR_ORDER, "hipxCommInit() must precede a ghost exchange", __FILE__, __LINE__);
+  if (!c.active || c.ipc) return fail(HIPX_ERR_ORDER, "hipxCommInit() (RCCL) or hipxHaloIpcAttach() must precede a ghost exchange", __FILE__, __LINE__);
   const hipx_int ns = h->send_off[h->nsend];
   if (ns) {
     hipx_int g = (ns + 255) / 256;
@@ -480,7 +601,7 @@ int hipxMatMultAddMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, doubl
 int hipxHaloTransport(hipxHalo h, int *transport)
 {
   HIPX_ARG(h && transport, "null argument");
-  *transport = h->ipc ? 1 : (cm().active ? 2 : 0);
+  *transport = h->ipc ? 1 : ((cm().active && !cm().ipc) ? 2 : 0);
   return HIPX_SUCCESS;
 }
 

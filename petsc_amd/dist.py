@@ -84,7 +84,26 @@ def build_plan(ai, aj, aa, ranges, rank, dist=None, group=None):
     return out
 
 
-def create_device_mat(plan, nranks):
+def comm_init(rank, nranks, dist, transport="rccl"):
+    """Scalar all-reduce + ghost-exchange transport of libhipx for torchrun ranks: "rccl" (ncclUniqueId of rank 0 broadcast
+    through torch.distributed) or "ipc" (IPC-mapped arenas, peer stores: also when the ranks share one GPU)."""
+    hx, _ = _lib.load()
+    if transport == "ipc":
+        h = (C.c_char * 64)()
+        _lib.chk(hx.hipxCommIpcExport(rank, nranks, h))
+        allh = [None] * nranks
+        dist.all_gather_object(allh, bytes(h))
+        _lib.chk(hx.hipxCommIpcAttach(b"".join(allh)))
+    else:
+        idb = (C.c_char * 256)()
+        if rank == 0:
+            _lib.chk(hx.hipxCommGetUniqueId(idb))
+        box = [bytes(idb)]
+        dist.broadcast_object_list(box, src=0)
+        _lib.chk(hx.hipxCommInit(box[0], rank, nranks))
+
+
+def create_device_mat(plan, nranks, rank=0, dist=None, transport="rccl"):
     """Uploads the blocks and creates the halo object: returns (HipxMat struct, keepalive list)."""
     hx, _ = _lib.load()
     m, ng = plan["m"], plan["nghost"]
@@ -98,6 +117,12 @@ def create_device_mat(plan, nranks):
         _lib.chk(hx.hipxHaloCreate(len(p["send_ranks"]), p["send_ranks"].ctypes.data_as(C.c_void_p), p["send_off"].ctypes.data_as(C.c_void_p),
                                    p["send_idx"].ctypes.data_as(C.c_void_p), len(p["recv_ranks"]), p["recv_ranks"].ctypes.data_as(C.c_void_p),
                                    p["recv_off"].ctypes.data_as(C.c_void_p), C.byref(halo)))
+        if transport == "ipc":
+            blob = (C.c_char * 1024)()
+            _lib.chk(hx.hipxHaloIpcExport(halo, rank, nranks, blob))
+            allb = [None] * nranks
+            dist.all_gather_object(allb, bytes(blob))
+            _lib.chk(hx.hipxHaloIpcAttach(halo, b"".join(allb)))
         lvec = _lib.DVec(max(ng, 1))
         M.B, M.halo, M.lvec = B, halo, lvec.ptr
         keep += [B, halo, lvec]
