@@ -8,13 +8,28 @@ import oracle as orc
 from petsc_amd import dist as pdist
 
 rank, world = int(sys.argv[1]), int(sys.argv[2])
+kind = sys.argv[3] if len(sys.argv) > 3 else "27pt"
+n = int(sys.argv[4]) if len(sys.argv) > 4 else 7
 dist.init_process_group("gloo", rank=rank, world_size=world)
-n = 7
 N = n ** 3
 ranges = pdist.split_ownership(N, world)
 rs, re = int(ranges[rank]), int(ranges[rank + 1])
-ai, aj, aa = orc.stencil("27pt", n, rs, re)
+ai, aj, aa = orc.stencil(kind, n, rs, re)
 plan = pdist.build_plan(ai, aj, aa, ranges, rank, dist=dist)
+# send / receive symmetry over all ranks: what rank a sends to b is exactly (ids and order) what b expects from a
+allp = [None] * world
+dist.all_gather_object(allp, {"rs": rs, "send_ranks": plan["send_ranks"], "send_off": plan["send_off"], "send_idx": plan["send_idx"],
+                              "recv_ranks": plan["recv_ranks"], "recv_off": plan["recv_off"], "garray": plan["garray"]})
+for a in range(world):
+    pa = allp[a]
+    for k, b in enumerate(pa["send_ranks"]):
+        pb = allp[int(b)]
+        kk = list(pb["recv_ranks"]).index(a)  # b must list a as a source
+        sent_global = pa["rs"] + pa["send_idx"][pa["send_off"][k]:pa["send_off"][k + 1]]
+        assert np.array_equal(sent_global, pb["garray"][pb["recv_off"][kk]:pb["recv_off"][kk + 1]]), (a, int(b))
+    for kk, a2 in enumerate(pa["recv_ranks"]):
+        assert a in list(allp[int(a2)]["send_ranks"]), (a, int(a2))
+    assert len(set(map(int, pa["recv_ranks"]))) == len(pa["recv_ranks"]) and a not in pa["recv_ranks"] and a not in pa["send_ranks"]
 # global x known everywhere; emulate the exchange: every rank packs what it was asked for, all ranks gather the packs
 xg = 1.0 + (np.arange(N) % 17) / 17.0
 xl = xg[rs:re]

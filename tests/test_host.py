@@ -81,13 +81,16 @@ def test_mpiaij_split_garray_bit_exact_vs_oracle(built, nranks):
         ks.HipxMPIAIJSplitFree(C.byref(s))
 
 
-def test_two_rank_gloo_plan_exchange_and_simulated_matmult(built, tmp_path):
-    """world_size 2 on CPU (gloo): each rank builds its slab, split and receive plan in C, exchanges the send lists
-    exactly as bench.py does for N > 1, and checks y = A_d x_local + B_o x_ghost against the oracle's global product
-    (the arithmetic here is the oracle's: this covers the plan, not the kernels)."""
+@pytest.mark.parametrize("world,kind,n,port", [(2, "27pt", 7, 29631), (4, "7pt", 9, 29641), (4, "27pt", 6, 29651), (8, "27pt", 9, 29661), (8, "7pt", 5, 29671), (3, "27pt", 4, 29681)])
+def test_gloo_plan_exchange_and_simulated_matmult(built, tmp_path, world, kind, n, port):
+    """world_size 2-8 on CPU (gloo): each rank builds its slab, split and receive plan in C, exchanges the send lists
+    exactly as bench.py does for N > 1, and checks (a) send / receive symmetry over ALL ranks (ids and order), (b) the ghost
+    values land as lvec[k] <-> garray[k], (c) y = A_d x_local + B_o x_ghost against the oracle's global product.  Uneven splits
+    (9^3 rows over 4 or 8 ranks, 64 rows over 3), slabs thinner than a plane (8 ranks on 5^3: a rank talks to more than two
+    neighbours), 7- and 27-point stencils.  (The arithmetic here is the oracle's: this covers the plan, not the kernels.)"""
     script = os.path.join(ROOT, "tests", "_gloo_plan_worker.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "oracle"))
-    procs = [subprocess.Popen([sys.executable, script, str(r), "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "oracle"))
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), kind, str(n)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
