@@ -995,17 +995,29 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
   // Chunk queue: the workgroups of an XCD (hardware block b runs on XCD b % 8: observed rule, used for locality only) pull the
   // chunks of that XCD's slab IN ORDER from one ticket counter, so at any moment they work on a window of consecutive chunks:
   // the planes of x a window touches (rows +-n, +-n^2) stay in that XCD's 4 MiB L2 and x is fetched from HBM about once
-  // (a static chunk -> workgroup map lets the workgroups drift apart: measured 2.6x).  Every workgroup takes exactly one ticket
-  // beyond the end, so a launch consumes (chunks + workgroups) tickets per XCD and the counters never need a reset.
+  // (a static chunk -> workgroup map lets the workgroups drift apart: measured 2.6x).  The counters never need a reset: a launch
+  // consumes a known number of tickets per XCD (see tbase).
   const long long     nloc = (long long)(c1 > c0 ? c1 - c0 : 0);
   unsigned long long *ctr  = tq + (size_t)xcd * 8;
-  const long long     tbase = (long long)(launch * (unsigned long long)(nloc + bpx));
-  if (t == 0) s_tk = (long long)atomicAdd(ctr, 1ull) - tbase;
+  // two tickets are always in flight per workgroup (the current chunk and the next one, whose template ids are prefetched while
+  // the current chunk computes): every workgroup takes exactly two tickets beyond the end of its XCD's slab
+  const long long     tbase = (long long)(launch * (unsigned long long)(nloc + 2 * bpx));
+  __shared__ long long s_tk2[2];
+  if (t == 0) {
+    s_tk2[0] = (long long)atomicAdd(ctr, 1ull) - tbase;
+    s_tk2[1] = (long long)atomicAdd(ctr, 1ull) - tbase;
+  }
   __syncthreads();
-  long long tk = s_tk;
+  long long tk = s_tk2[0], tk1 = s_tk2[1];
+  int       idn[RPT];  // template ids of the NEXT chunk (one dependent memory round trip less per chunk)
+#pragma unroll
+  for (int rr = 0; rr < RPT; rr++) {
+    const long long row = (tk < nloc) ? ((long long)(c0 + tk) * (256 * RPT) + t + rr * 256) : (long long)m;
+    idn[rr]             = (row < m) ? tid[row] : 0;
+  }
   while (tk < nloc) {
     long long nxt = 0;
-    if (t == 0) nxt = (long long)atomicAdd(ctr, 1ull) - tbase;  // the next ticket travels while this chunk is processed
+    if (t == 0) nxt = (long long)atomicAdd(ctr, 1ull) - tbase;  // the ticket after next travels while this chunk is processed
     const hipx_int c    = c0 + (hipx_int)tk;
     const hipx_int base = c * (256 * RPT);
     int            id[RPT];
@@ -1014,14 +1026,18 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
 #pragma unroll
     for (int rr = 0; rr < RPT; rr++) {
       const hipx_int row = base + t + rr * 256;
-      id[rr]   = 0;
+      id[rr]   = idn[rr];
       sum[rr]  = 0.0;
       xrow[rr] = 0.0;
       if (row < m) {
-        id[rr] = tid[row];
         if (MODE == 1) sum[rr] = yin[row];
         if (DOT) xrow[rr] = x[row];
       }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) {  // issue the next chunk's id loads now; they are consumed at the top of the next pass
+      const long long row = (tk1 < nloc) ? ((long long)(c0 + tk1) * (256 * RPT) + t + rr * 256) : (long long)m;
+      idn[rr]             = (row < m) ? tid[row] : 0;
     }
     int id0 = 0;
     if (UNI) {
@@ -1090,10 +1106,11 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
         if (DOT) mydot += xrow[rr] * sum[rr];
       }
     }
-    __syncthreads();  // everybody has read the current ticket
+    __syncthreads();  // everybody has read the tickets
     if (t == 0) s_tk = nxt;
     __syncthreads();
-    tk = s_tk;
+    tk  = tk1;
+    tk1 = s_tk;
   }
   if (DOT) {
     const double w = hipx::wave_sum(mydot);

@@ -397,7 +397,10 @@ typedef __attribute__((address_space(3))) char    st_lds_char;
 typedef __attribute__((address_space(3))) int     st_lds_int;
 typedef __attribute__((address_space(3))) st_int4 st_lds_int4;
 
-__device__ __forceinline__ st_int4 st_ld4v(st_lds_char *base, int byteoff) { return *reinterpret_cast<volatile st_lds_int4 *>(base + byteoff); }
+// reads of slots another wave writes: plain 16-byte loads (one ds_read_b128 each, free to issue back to back) -- the compute
+// loop declares memory clobbered once per iteration (asm volatile "" ::: "memory"), so nothing read in an earlier iteration is
+// reused; `volatile` loads would be kept in strict order with a wait between them
+__device__ __forceinline__ st_int4 st_ld4v(st_lds_char *base, int byteoff) { return *reinterpret_cast<st_lds_int4 *>(base + byteoff); }
 __device__ __forceinline__ st_int4 st_ld4(st_lds_char *base, int byteoff) { return *reinterpret_cast<st_lds_int4 *>(base + byteoff); }
 __device__ __forceinline__ void    st_st4v(st_lds_char *base, int byteoff, st_int4 v) { *reinterpret_cast<volatile st_lds_int4 *>(base + byteoff) = v; }
 __device__ __forceinline__ double  st_dbl(int lo, int hi) { return __longlong_as_double(((long long)(unsigned)hi << 32) | (unsigned)lo); }
@@ -410,6 +413,43 @@ __device__ __forceinline__ st_int4 st_pack_slot(double v, int tag)
   r.z = tag;
   r.w = 0;
   return r;
+}
+
+// ---- hand-issued memory operations of the compute wave.  hipcc keeps one in-order counter per memory class and is
+// conservative at control-flow joins: a rarely taken global load (or a register it re-uses while a read is in flight) puts
+// `s_waitcnt vmcnt(..)` / `lgkmcnt(0)` into the common path, and vmcnt also counts the wave's own stores -- i.e. HBM latency in
+// a loop that must run at LDS speed.  The loads below are therefore issued from inline asm with their wait INSIDE the
+// statement (cdna_hip_programming.md 5.7: the compiler does not count memory operations inside an asm statement, so every one
+// of them is complete when the statement ends).
+// 16 window / table reads as ONE burst: 16 x ds_read_b128 back to back, one s_waitcnt lgkmcnt(0).
+__device__ __forceinline__ void st_lds_burst16(st_int4 (&o)[16], const unsigned (&a)[16])
+{
+  asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+               "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7])
+               : "memory");
+  // the second half ties the first eight results (read-write operands): nothing may use them before this statement's wait
+  asm volatile("ds_read_b128 %8, %16\n\tds_read_b128 %9, %17\n\tds_read_b128 %10, %18\n\tds_read_b128 %11, %19\n\t"
+               "ds_read_b128 %12, %20\n\tds_read_b128 %13, %21\n\tds_read_b128 %14, %22\n\tds_read_b128 %15, %23\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]), "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]),
+                 "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])
+               : "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15])
+               : "memory");
+}
+// agent-scope 8-byte load, complete on return (rare paths only: it drains this wave's stores as well)
+__device__ __forceinline__ unsigned long long st_gload64_wait(const void *p)
+{
+  unsigned long long v;
+  asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ unsigned st_gload32_wait(const void *p)
+{
+  unsigned v;
+  asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
 }
 
 template <bool FWD>
@@ -435,6 +475,7 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
   constexpr bool NEEDOLD = (KIND == 1 || KIND == 3 || KIND == 4);  // the row's own old value
   extern __shared__ __attribute__((aligned(16))) char smem[];
   st_lds_char          *lds    = (st_lds_char *)smem;
+  const unsigned        lds_base = (unsigned)(size_t)lds;  // byte address of the dynamic LDS region (for the hand-issued reads)
   volatile st_lds_int  *s_prog = (volatile st_lds_int *)(lds + P.off_prog);
   volatile st_lds_int  *s_ctl  = (volatile st_lds_int *)(lds + P.off_ctl);
   unsigned int *err  = ctl + 1;
@@ -493,9 +534,13 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
         dcnt   = ti.y;
         ostart = ti.z;
         ocnt   = ti.w;
+        {  // all ST_ME entries in one burst; entries past the row's count repeat its last one (never used)
+          const int last = dcnt > 0 ? dcnt - 1 : 0;
+          unsigned  ea[ST_ME];
 #pragma unroll
-        for (int j = 0; j < ST_ME; j++)
-          if (j < dcnt) e[j] = st_ld4(lds, P.off_dep + 16 * (ti.x + j));
+          for (int j = 0; j < ST_ME; j++) ea[j] = lds_base + (unsigned)(P.off_dep + 16 * (ti.x + (j < dcnt ? j : last)));
+          st_lds_burst16(e, ea);
+        }
         rb    = st_dbl(w0.z, w0.w);
         idiag = st_dbl(dg.x, dg.y);
         mdiag = st_dbl(dg.z, dg.w);
@@ -513,33 +558,40 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
         const bool active = p < len;
         if (!__any(active)) break;
         st_iters++;
+        asm volatile("" ::: "memory");  // other waves have written LDS since the last iteration: re-read, do not reuse
         if (active) {
           if (!have) fetch_row();
           if (have) {
             const long long q = S * L + p;
             const hipx_int  r = st_actual<FWD>(q, m);
-            bool            ok = true;
             double          val[ST_ME];
             st_int4         sl[ST_ME];
+            int             pos[ST_ME];
+            // all window slots of the row in one burst (slots past the row's count re-read its last one)
+            unsigned sa[ST_ME];
 #pragma unroll
             for (int j = 0; j < ST_ME; j++) {
-              if (j < dcnt) {
-                const int pos = p + (int)(short)(e[j].x & 0xffff);
-                sl[j]         = st_ld4v(lds, P.off_win + 16 * ((lane + (e[j].x >> 16)) * ST_WP + (pos & (ST_WP - 1))));
-              }
+              pos[j] = p + (int)(short)(e[j].x & 0xffff);
+              sa[j]  = lds_base + (unsigned)(P.off_win + 16 * ((lane + (e[j].x >> 16)) * ST_WP + (pos[j] & (ST_WP - 1))));
             }
+            st_lds_burst16(sl, sa);
+            unsigned notyet = 0, moved = 0;
 #pragma unroll
             for (int j = 0; j < ST_ME; j++) {
-              if (j < dcnt) {
-                const int pos = p + (int)(short)(e[j].x & 0xffff);
-                val[j]        = st_dbl(sl[j].x, sl[j].y);
-                if (sl[j].z != pos) {
-                  if (sl[j].z > pos) {  // the slot has moved on (this lane fell far behind its producer): read the value itself
-                    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(xnew + st_actual<FWD>(q + e[j].y, m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    st_fallback++;
-                    if (v == SOR_SENTINEL) ok = false;
-                    else val[j] = __longlong_as_double((long long)v);
-                  } else ok = false;  // not produced yet
+              val[j]            = st_dbl(sl[j].x, sl[j].y);
+              const unsigned in = (j < dcnt) ? 1u : 0u;
+              notyet |= in & (sl[j].z < pos[j] ? 1u : 0u);
+              moved |= (in & (sl[j].z > pos[j] ? 1u : 0u)) << j;
+            }
+            bool ok = notyet == 0;
+            if (ok && moved) {  // rare: a slot has moved on (this lane fell far behind its producer): read the value itself
+#pragma unroll
+              for (int j = 0; j < ST_ME; j++) {
+                if ((moved >> j) & 1u) {
+                  const unsigned long long v = st_gload64_wait(xnew + st_actual<FWD>(q + e[j].y, m));
+                  st_fallback++;
+                  if (v == SOR_SENTINEL) ok = false;
+                  else val[j] = __longlong_as_double((long long)v);
                 }
               }
             }
@@ -547,8 +599,10 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
             if (ok) {
               double sum = s0;
 #pragma unroll
-              for (int j = 0; j < ST_ME; j++)
-                if (j < dcnt) sum -= st_dbl(e[j].z, e[j].w) * val[j];
+              for (int j = 0; j < ST_ME; j++) {  // left to right (PetscSparseDenseMinusDot); entries past the count leave the sum untouched
+                const double nx = sum - st_dbl(e[j].z, e[j].w) * val[j];
+                sum             = (j < dcnt) ? nx : sum;
+              }
               double out;
               if (KIND == 0) {
                 t[r] = sum;
@@ -578,6 +632,7 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
               sor_publish(xnew + r, out);
               p++;
               have = false;
+              asm volatile("" ::: "memory");
               if (p < len) fetch_row();  // the next row's operands: ready when the next iteration starts
             }
           }
@@ -586,7 +641,8 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
         if ((it & 0x3ff) == 0) {  // bounded wait: elapsed wall-clock time, and a global abort word so one stuck panel ends the launch
           const long long now = (long long)wall_clock64();
           if (!t0) t0 = now;
-          if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || now - t0 > SOR_SPIN_TICKS) {
+          const unsigned abort_word = st_gload32_wait(err);
+          if (abort_word || now - t0 > SOR_SPIN_TICKS) {
             __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
           }
@@ -740,6 +796,10 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
         atomicAdd(&stats[4], (unsigned long long)st_idle);
       }
     }
+    // Both roles share this function: without this, loads the LOADER branch may leave pending at the back edge of the panel loop
+    // count as pending in the COMPUTE branch too (the compiler merges the two paths), which plants vmcnt waits -- i.e. waits for
+    // the compute wave's own stores -- in front of every register those loads use.  Drain everything here, explicitly.
+    __builtin_amdgcn_s_waitcnt(0);
   }
 }
 
