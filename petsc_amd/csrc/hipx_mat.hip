@@ -1099,12 +1099,18 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
       }
     }
 #pragma unroll
+    double cdot = 0.0;
     for (int rr = 0; rr < RPT; rr++) {
       const hipx_int row = base + t + rr * 256;
       if (row < m) {
         yout[row] = sum[rr];
-        if (DOT) mydot += xrow[rr] * sum[rr];
+        if (DOT) cdot += xrow[rr] * sum[rr];
       }
+    }
+    if (DOT) {  // one partial per wave and CHUNK (not per workgroup: which workgroup gets which chunk changes from run to run,
+                // the fused dot must not): the fold reads them in chunk order
+      const double w = hipx::wave_sum(cdot);
+      if ((threadIdx.x & 63) == 0) dotpart[(size_t)c * 4 + (threadIdx.x >> 6)] = w;
     }
     __syncthreads();  // everybody has read the tickets
     if (t == 0) s_tk = nxt;
@@ -1112,10 +1118,7 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
     tk  = tk1;
     tk1 = s_tk;
   }
-  if (DOT) {
-    const double w = hipx::wave_sum(mydot);
-    if ((threadIdx.x & 63) == 0) dotpart[(size_t)bid * 4 + (threadIdx.x >> 6)] = w;
-  }
+  (void)mydot;
 }
 
 template <typename IT>
@@ -1666,7 +1669,7 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
   hipx_int       grid = std::min<hipx_int>((hipx_int)((tmpl_blocks() + 7) / 8 * 8), ((nchunks + 7) / 8) * 8);
   if (grid < 8) grid = 8;
   if (npart) {
-    *npart = grid * 4;
+    *npart = nchunks * 4;  // one dot partial per wave and chunk
     return HIPX_SUCCESS;
   }
   const hipx_int cpx  = (nchunks + 7) / 8;
