@@ -1098,8 +1098,8 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
         }
       }
     }
-#pragma unroll
     double cdot = 0.0;
+#pragma unroll
     for (int rr = 0; rr < RPT; rr++) {
       const hipx_int row = base + t + rr * 256;
       if (row < m) {
