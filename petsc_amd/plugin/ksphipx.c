@@ -1,6 +1,6 @@
 /*
  * ksphipx.c -- KSPCGHIPX ("cghipx"): KSPCG whose solve runs the fused device kernels of libhipx when the configuration is
- * the hot path's (sequential MATSEQAIJHIPX operator, default PCJACOBI, left preconditioning, preconditioned norm, no
+ * the hot path's (MATSEQAIJHIPX operator, or MATMPIAIJHIPX with the device ghost exchange; default PCJACOBI, left preconditioning, preconditioned norm, no
  * eigenvalue estimates / trust radius / single-reduction variant), and the reference's own KSPSolve_CG otherwise.
  *
  * Subclass recipe as for the Mat types: KSPCreate_CG (PETSC_EXTERN, cg.c:686) builds the object, we keep its solve op as the
@@ -30,8 +30,18 @@ static PetscBool KSPCGHIPXApplicable(KSP ksp, Mat *Aout)
   if (ksp->calc_sings || cg->singlereduction || cg->radius != 0.0 || cg->type != KSP_CG_SYMMETRIC || cg->obj_min != 0.0) return PETSC_FALSE;
   if (ksp->pc_side != PC_LEFT || ksp->normtype != KSP_NORM_PRECONDITIONED || ksp->transpose_solve) return PETSC_FALSE;
   if (ksp->dscale) return PETSC_FALSE;
-  if (MPI_Comm_size(PetscObjectComm((PetscObject)ksp), &size) || size != 1) return PETSC_FALSE;
-  if (PCGetOperators(ksp->pc, &Amat, &Pmat) || Amat != Pmat || !MatIsSeqAIJHIPX(Amat) || Amat->rmap->n != Amat->cmap->n) return PETSC_FALSE;
+  if (MPI_Comm_size(PetscObjectComm((PetscObject)ksp), &size)) return PETSC_FALSE;
+  if (PCGetOperators(ksp->pc, &Amat, &Pmat) || Amat != Pmat || Amat->rmap->n != Amat->cmap->n) return PETSC_FALSE;
+  if (size == 1) {
+    if (!MatIsSeqAIJHIPX(Amat)) return PETSC_FALSE;
+  } else { /* MATMPIAIJHIPX with its ghost exchange and the scalar all-reduces on the device (RCCL or IPC transport) */
+    PetscBool ismpi = PETSC_FALSE;
+    hipxMat   dA, dB;
+    hipxHalo  halo = NULL;
+    Vec       lvec;
+    if (PetscObjectTypeCompare((PetscObject)Amat, MATMPIAIJHIPX, &ismpi) || !ismpi) return PETSC_FALSE;
+    if (MatMPIAIJHIPXGetDevice(Amat, &dA, &dB, &halo, &lvec) || !halo) return PETSC_FALSE;
+  }
   if (PetscObjectTypeCompare((PetscObject)ksp->pc, PCJACOBI, &isjac) || !isjac) return PETSC_FALSE;
   if (PCJacobiGetType(ksp->pc, &jt) || jt != PC_JACOBI_DIAGONAL) return PETSC_FALSE;
   if (PCJacobiGetUseAbs(ksp->pc, &useabs) || useabs) return PETSC_FALSE;
@@ -54,8 +64,11 @@ static PetscErrorCode KSPSolve_CGHIPX(KSP ksp)
   HipxKSP            k;
   const PetscScalar *db;
   PetscScalar       *dx;
-  void              *tb, *tx;
+  void              *tb, *tx, *tlv = NULL;
   PetscInt           n;
+  PetscMPIInt        size;
+  Vec                lvecv = NULL;
+  PetscScalar       *dlv   = NULL;
 
   PetscFunctionBegin;
   if (!KSPCGHIPXApplicable(ksp, &Amat)) {
@@ -64,8 +77,17 @@ static PetscErrorCode KSPSolve_CGHIPX(KSP ksp)
     PetscFunctionReturn(PETSC_SUCCESS);
   }
   n = Amat->rmap->n;
-  PetscCall(MatSeqAIJHIPXGetDeviceMat(Amat, &dA));
-  M.m = (hipx_int)n; M.A = dA; M.B = NULL; M.halo = NULL; M.lvec = NULL; M.nranks = 1;
+  PetscCallMPI(MPI_Comm_size(PetscObjectComm((PetscObject)ksp), &size));
+  if (size == 1) {
+    PetscCall(MatSeqAIJHIPXGetDeviceMat(Amat, &dA));
+    M.m = (hipx_int)n; M.A = dA; M.B = NULL; M.halo = NULL; M.lvec = NULL; M.nranks = 1;
+  } else {
+    hipxMat  dB;
+    hipxHalo halo;
+    PetscCall(MatMPIAIJHIPXGetDevice(Amat, &dA, &dB, &halo, &lvecv));
+    PetscCall(VecHIPXGetDeviceWrite(lvecv, &dlv, &tlv));
+    M.m = (hipx_int)n; M.A = dA; M.B = dB; M.halo = halo; M.lvec = dlv; M.nranks = (int)size;
+  }
   HipxPCSetDefaults(&hpc);
   hpc.type = HIPX_PC_JACOBI;
   PetscCallHIPX(HipxPCSetUp(&hpc, &M)); /* 1/diag, 0 -> 1: jacobi.c:205-266 on the device */
@@ -104,6 +126,7 @@ static PetscErrorCode KSPSolve_CGHIPX(KSP ksp)
   PetscCallHIPX(HipxKSPCGFlush(&k, &M, dx));
   PetscCallHIPX(HipxKSPDestroyWork(&k));
   PetscCallHIPX(HipxPCDestroy(&hpc));
+  if (lvecv) PetscCall(VecHIPXRestoreDeviceWrite(lvecv, &dlv, &tlv));
   PetscCall(VecHIPXRestoreDeviceWrite(ksp->vec_sol, &dx, &tx));
   PetscCall(VecHIPXRestoreDeviceRead(ksp->vec_rhs, &db, &tb));
   PetscCall(PetscObjectStateIncrease((PetscObject)ksp->vec_sol));

@@ -31,7 +31,7 @@ typedef struct {
   PetscObjectState nzstate;   /* nonzero state the plan was built from */
 } Mat_MPIAIJHIPX;
 
-static PetscBool hipx_rccl_up = PETSC_FALSE;
+static PetscBool hipx_rccl_up = PETSC_FALSE, hipx_ipc_comm_up = PETSC_FALSE;
 
 static PetscErrorCode MatMPIAIJHIPXBuildHalo(Mat A)
 {
@@ -130,6 +130,15 @@ static PetscErrorCode MatMPIAIJHIPXBuildHalo(Mat A)
     PetscCallMPI(MPI_Allgather(mine, HIPX_HALO_IPC_BLOB_BYTES, MPI_BYTE, all, HIPX_HALO_IPC_BLOB_BYTES, MPI_BYTE, comm));
     PetscCallHIPX(hipxHaloIpcAttach(h->halo, all));
     PetscCall(PetscFree2(mine, all));
+    if (!hipx_rccl_up && !hipx_ipc_comm_up) { /* scalar all-reduces of the fused solver (cghipx) through the same IPC machinery */
+      char hmine[64], *hall;
+      PetscCall(PetscMalloc1((size_t)64 * size, &hall));
+      PetscCallHIPX(hipxCommIpcExport((int)rank, (int)size, hmine));
+      PetscCallMPI(MPI_Allgather(hmine, 64, MPI_BYTE, hall, 64, MPI_BYTE, comm));
+      PetscCallHIPX(hipxCommIpcAttach(hall));
+      PetscCall(PetscFree(hall));
+      hipx_ipc_comm_up = PETSC_TRUE;
+    }
   }
   h->transport = transport;
   PetscCall(PetscInfo(A, "MATMPIAIJHIPX ghost exchange on the device: transport %s, %d send / %d receive neighbours\n", transport == 2 ? "rccl" : "ipc", (int)ni, (int)nr));
@@ -176,11 +185,31 @@ static PetscErrorCode MatMultAdd_MPIAIJHIPX_Private(Mat A, Vec xx, Vec yy, Vec z
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+static PetscErrorCode MatMult_MPIAIJHIPX(Mat, Vec, Vec);
+
 static PetscBool MatMPIAIJHIPXDevicePath(Mat A, Vec xx, Vec zz)
 {
   Mat_MPIAIJHIPX *h = (Mat_MPIAIJHIPX *)A->spptr;
   Mat_MPIAIJ     *a = (Mat_MPIAIJ *)A->data;
   return (PetscBool)(h->transport && h->halo && h->nzstate == A->nonzerostate && a->A && a->B && MatIsSeqAIJHIPX(a->A) && MatIsSeqAIJHIPX(a->B) && a->lvec && VecIsHIPX(a->lvec) && VecIsHIPX(xx) && VecIsHIPX(zz));
+}
+
+/* for KSPCGHIPX: the device pieces of an assembled MATMPIAIJHIPX whose ghost exchange runs on the device (NULL halo otherwise) */
+PetscErrorCode MatMPIAIJHIPXGetDevice(Mat A, hipxMat *dA, hipxMat *dB, hipxHalo *halo, Vec *lvec)
+{
+  Mat_MPIAIJHIPX *h = (Mat_MPIAIJHIPX *)A->spptr;
+  Mat_MPIAIJ     *a = (Mat_MPIAIJ *)A->data;
+
+  PetscFunctionBegin;
+  *halo = NULL;
+  if (A->ops->mult == MatMult_MPIAIJHIPX && h->transport && h->halo && h->nzstate == A->nonzerostate && a->A && a->B && MatIsSeqAIJHIPX(a->A) && MatIsSeqAIJHIPX(a->B) && a->lvec && VecIsHIPX(a->lvec) &&
+      (hipx_rccl_up || hipx_ipc_comm_up)) {
+    PetscCall(MatSeqAIJHIPXGetDeviceMat(a->A, dA));
+    PetscCall(MatSeqAIJHIPXGetDeviceMat(a->B, dB));
+    *halo = h->halo;
+    *lvec = a->lvec;
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
 }
 
 static PetscErrorCode MatMult_MPIAIJHIPX(Mat A, Vec xx, Vec yy)

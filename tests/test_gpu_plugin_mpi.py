@@ -118,3 +118,17 @@ def test_mpiaijhipx_ghost_exchange_transports(halo):
     h_gpu, _, t_gpu = parse_driver(mpirun(2, "ref_driver", a + ["-mat_type", "aijhipx"], True, env={"HIPX_HALO": halo}))
     assert t_gpu[:2] == t_cpu[:2] and len(h_gpu) == len(h_cpu) == 61
     assert max(abs(g - c) / c for g, c in zip(h_gpu, h_cpu)) <= 1e-11
+
+
+@pytest.mark.parametrize("np_,args", [(2, "-stencil 7 -n 24 -pc_type jacobi -ksp_rtol 1e-8"), (3, "-stencil 27 -n 16 -pc_type jacobi -ksp_rtol 1e-8"), (2, "-stencil 7 -n 16 -pc_type jacobi -ksp_rtol 1e-30 -ksp_max_it 9")])
+def test_cghipx_on_mpiaijhipx_fused_solve(np_, args):
+    """-ksp_type cghipx on an MPI operator: the fused device CG (SpMV with the device ghost exchange, fused update with its two
+    sums all-reduced on the device) under PETSc's monitors / convergence test, against the CPU MPI run of KSPCG."""
+    a = args.split() + ["-history"]
+    h_cpu, _, t_cpu = parse_driver(mpirun(np_, "ref_driver", a + ["-ksp_type", "cg"], False))
+    out = mpirun(np_, "ref_driver", a + ["-ksp_type", "cghipx", "-mat_type", "aijhipx", "-info", ":ksp"], True)
+    h_gpu, _, t_gpu = parse_driver(out)
+    assert "running the reference KSPSolve_CG" not in out  # the fused path was taken
+    assert t_gpu[:2] == t_cpu[:2] and len(h_gpu) == len(h_cpu)
+    assert max(abs(g - c) / c for g, c in zip(h_gpu, h_cpu)) <= 1e-9
+    assert abs(t_gpu[2] - t_cpu[2]) <= 1e-6 * abs(t_cpu[2]) + 1e-12
