@@ -360,7 +360,9 @@ constexpr int ST_SB   = 8;   // positions per staging batch
 constexpr int ST_LA   = 10;  // staging look-ahead beyond the leading consumer
 constexpr int ST_NB   = 3;   // bands of strands a panel may touch
 constexpr int ST_MAXW = 4;   // strands per band
-constexpr int ST_ME   = 16;  // dependency entries of a row the compute wave keeps in registers (27-point: 13)
+constexpr int ST_ME   = 16;  // most dependency entries a row may have on this schedule (27-point: 13)
+constexpr int ST_NULLPK  = 0x7fff7fff;  // pk of a padding entry
+constexpr int ST_NULLTAG = 0x7ffffff0;  // tag of the null slot (no row position reaches it)
 
 struct StBand {
   int dsmin, width, rowbase, pad;
@@ -369,7 +371,7 @@ struct StParams {
   hipx_int m, L, nstr, npanels;
   int      nbands, nrows, ntmpl, ndep, nold, maxchunks;
   StBand   band[ST_NB];
-  int      off_win, off_rowq, off_prog, off_ctl, off_tinfo, off_tdiag, off_dep, off_old, lds_bytes;
+  int      off_win, off_rowq, off_prog, off_ctl, off_tinfo, off_tdiag, off_dep, off_old, off_null, me, lds_bytes;
 };
 struct __attribute__((aligned(16))) StEntry {  // dep: pk = (window row offset << 16) | (dp & 0xffff), lo = logical row offset; old: pk = ACTUAL column - row
   int    pk, lo;
@@ -438,6 +440,19 @@ __device__ __forceinline__ void st_lds_burst16(st_int4 (&o)[16], const unsigned 
                : "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15])
                : "memory");
 }
+__device__ __forceinline__ void st_lds_burst4(st_int4 (&o)[4], const unsigned (&a)[4])
+{
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
+               : "memory");
+}
+template <int ME>
+__device__ __forceinline__ void st_lds_burst(st_int4 (&o)[ME], const unsigned (&a)[ME])
+{
+  if constexpr (ME == 4) st_lds_burst4(o, a);
+  else st_lds_burst16(o, a);
+}
 // agent-scope 8-byte load, complete on return (rare paths only: it drains this wave's stores as well)
 __device__ __forceinline__ unsigned long long st_gload64_wait(const void *p)
 {
@@ -466,7 +481,9 @@ __device__ __forceinline__ int st_strand_len(long long S, const StParams &P)
 }
 
 // KIND as in sor_level_kernel: 0 fwd zero guess, 1 bwd with t, 2 bwd zero guess, 3 fwd general, 4 bwd whole row
-template <int KIND, bool ALIGNED>
+// ME: dependency entries per row the compute wave handles (the templates' lists are padded to ME with null entries: coefficient 0,
+// pointing at a slot that always reads {0.0, ST_NULLTAG}); 4 for the 5-/7-point operators, 16 for the 27-point one
+template <int KIND, bool ALIGNED, int ME>
 __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const unsigned char *__restrict__ tid, const StTinfo *__restrict__ g_tinfo, const StDiag *__restrict__ g_tdiag,
                                                          const StEntry *__restrict__ g_dep, const StEntry *__restrict__ g_old, const double *asrc, double *t, const double *xold,
                                                          double *xnew, double omega, unsigned int *ctl, unsigned long long *stats)
@@ -499,7 +516,10 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
       for (int i = threadIdx.x; i < 64 * ST_RQ; i += 128) st_st4v(lds, P.off_rowq + 32 * i + 16, empty_row);
     }
     if (threadIdx.x < 64) s_prog[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_ctl[1] = 0;
+    if (threadIdx.x == 0) {
+      s_ctl[1] = 0;
+      st_st4v(lds, P.off_null, st_int4{0, 0, ST_NULLTAG, 0});  // the null slot: value +0.0
+    }
     __syncthreads();
     const unsigned panel = (unsigned)s_ctl[0];
     if (panel >= (unsigned)P.npanels) return;
@@ -508,16 +528,26 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
     const int       len = st_strand_len(S, P);
     if (!loader) {
       // ------------------------------------------------------------------ compute wave
-      // One row per lane per iteration at best.  A row's operands and its template's dependency entries are fetched ONCE
-      // into registers (at the end of the iteration that finished the previous row, so the LDS round trips overlap the loop
-      // overhead); an iteration then is: read the <= ST_ME window slots (issued back to back), compare their tags, and, when
-      // every value is there, the left-to-right subtraction chain, the scale by 1/d and the publish.
-      int       p = 0, dcnt = 0, ostart = 0, ocnt = 0;
+      // One row per lane per iteration at best; with ONE wave per SIMD the loop runs at the latency of its own instruction
+      // stream, so everything that depends only on the row is done once, when the row is fetched (at the end of the iteration
+      // that finished its predecessor): the ME slot addresses, the tags to expect and the coefficients sit in registers.  An
+      // iteration is then: ONE burst of ME window reads, ME tag compares, and -- when every value is there -- the left-to-right
+      // subtraction chain, the scale by 1/d, the publish.  Padding entries have coefficient 0 and read the null slot (value 0):
+      // they subtract +0.0, which leaves every sum bit-identical, so the chain needs no predication.
+      int       p = 0, ostart = 0, ocnt = 0;
       bool      have = false;
       double    s0 = 0.0, rb = 0.0, idiag = 0.0, mdiag = 0.0;
-      st_int4   e[ST_ME];
+      unsigned  sa[ME];   // LDS byte address of the slot of entry j
+      int       pos[ME];  // the tag it must carry
+      int       elo[ME];  // logical row offset (rare path: the value itself from memory)
+      double    cf[ME];   // coefficient
 #pragma unroll
-      for (int j = 0; j < ST_ME; j++) e[j] = st_int4{0, 0, 0, 0};
+      for (int j = 0; j < ME; j++) {
+        sa[j]  = lds_base + (unsigned)P.off_null;
+        pos[j] = ST_NULLTAG;
+        elo[j] = 0;
+        cf[j]  = 0.0;
+      }
       unsigned  st_iters = 0, st_rowwait = 0, st_depwait = 0, st_fallback = 0;  // HIPX_SOR_DEBUG statistics (stats != nullptr)
       const long long st_t0 = stats ? (long long)wall_clock64() : 0;
       long long t0 = 0;
@@ -531,15 +561,21 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
         }
         const st_int4 ti = st_ld4(lds, P.off_tinfo + 16 * w1.x);
         const st_int4 dg = st_ld4(lds, P.off_tdiag + 16 * w1.x);
-        dcnt   = ti.y;
         ostart = ti.z;
         ocnt   = ti.w;
-        {  // all ST_ME entries in one burst; entries past the row's count repeat its last one (never used)
-          const int last = dcnt > 0 ? dcnt - 1 : 0;
-          unsigned  ea[ST_ME];
+        st_int4  e[ME];
+        unsigned ea[ME];
 #pragma unroll
-          for (int j = 0; j < ST_ME; j++) ea[j] = lds_base + (unsigned)(P.off_dep + 16 * (ti.x + (j < dcnt ? j : last)));
-          st_lds_burst16(e, ea);
+        for (int j = 0; j < ME; j++) ea[j] = lds_base + (unsigned)(P.off_dep + 16 * (ti.x + j));
+        st_lds_burst<ME>(e, ea);
+#pragma unroll
+        for (int j = 0; j < ME; j++) {
+          const bool null = e[j].x == ST_NULLPK;
+          const int  ps   = p + (int)(short)(e[j].x & 0xffff);
+          pos[j] = null ? ST_NULLTAG : ps;
+          sa[j]  = lds_base + (unsigned)(null ? P.off_null : P.off_win + 16 * ((lane + (e[j].x >> 16)) * ST_WP + (ps & (ST_WP - 1))));
+          elo[j] = e[j].y;
+          cf[j]  = st_dbl(e[j].z, e[j].w);
         }
         rb    = st_dbl(w0.z, w0.w);
         idiag = st_dbl(dg.x, dg.y);
@@ -564,31 +600,21 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
           if (have) {
             const long long q = S * L + p;
             const hipx_int  r = st_actual<FWD>(q, m);
-            double          val[ST_ME];
-            st_int4         sl[ST_ME];
-            int             pos[ST_ME];
-            // all window slots of the row in one burst (slots past the row's count re-read its last one)
-            unsigned sa[ST_ME];
+            st_int4         sl[ME];
+            st_lds_burst<ME>(sl, sa);
+            bool neq = false;
 #pragma unroll
-            for (int j = 0; j < ST_ME; j++) {
-              pos[j] = p + (int)(short)(e[j].x & 0xffff);
-              sa[j]  = lds_base + (unsigned)(P.off_win + 16 * ((lane + (e[j].x >> 16)) * ST_WP + (pos[j] & (ST_WP - 1))));
-            }
-            st_lds_burst16(sl, sa);
-            unsigned notyet = 0, moved = 0;
+            for (int j = 0; j < ME; j++) neq = neq || (sl[j].z != pos[j]);
+            bool   ok = true;
+            double val[ME];
 #pragma unroll
-            for (int j = 0; j < ST_ME; j++) {
-              val[j]            = st_dbl(sl[j].x, sl[j].y);
-              const unsigned in = (j < dcnt) ? 1u : 0u;
-              notyet |= in & (sl[j].z < pos[j] ? 1u : 0u);
-              moved |= (in & (sl[j].z > pos[j] ? 1u : 0u)) << j;
-            }
-            bool ok = notyet == 0;
-            if (ok && moved) {  // rare: a slot has moved on (this lane fell far behind its producer): read the value itself
+            for (int j = 0; j < ME; j++) val[j] = st_dbl(sl[j].x, sl[j].y);
+            if (neq) {  // not produced yet (tag behind), or the slot has moved on (tag ahead: this lane fell far behind its producer)
 #pragma unroll
-              for (int j = 0; j < ST_ME; j++) {
-                if ((moved >> j) & 1u) {
-                  const unsigned long long v = st_gload64_wait(xnew + st_actual<FWD>(q + e[j].y, m));
+              for (int j = 0; j < ME; j++) {
+                if (sl[j].z < pos[j]) ok = false;
+                else if (sl[j].z > pos[j]) {
+                  const unsigned long long v = st_gload64_wait(xnew + st_actual<FWD>(q + elo[j], m));
                   st_fallback++;
                   if (v == SOR_SENTINEL) ok = false;
                   else val[j] = __longlong_as_double((long long)v);
@@ -599,10 +625,7 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
             if (ok) {
               double sum = s0;
 #pragma unroll
-              for (int j = 0; j < ST_ME; j++) {  // left to right (PetscSparseDenseMinusDot); entries past the count leave the sum untouched
-                const double nx = sum - st_dbl(e[j].z, e[j].w) * val[j];
-                sum             = (j < dcnt) ? nx : sum;
-              }
+              for (int j = 0; j < ME; j++) sum -= cf[j] * val[j];  // left to right (PetscSparseDenseMinusDot); null entries subtract +0.0
               double out;
               if (KIND == 0) {
                 t[r] = sum;
@@ -945,10 +968,18 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
     std::vector<StTinfo> tinfo((size_t)ntmpl);
     std::vector<StEntry> dep, old;
     int                  maxdep = 0;
+    for (int t = 0; t < ntmpl; t++) {  // first pass: the longest dependency list decides the kernel's entry count ME
+      int c = 0;
+      for (int k = tstart[t]; k < tstart[t + 1]; k++) c += (fwd ? toff[k] < 0 : toff[k] > 0) ? 1 : 0;
+      maxdep = std::max(maxdep, c);
+    }
+    if (maxdep > ST_ME) continue;  // rows with more dependency entries than the compute wave handles: level-ordered schedule
+    const int ME = maxdep <= 4 ? 4 : ST_ME;
     for (int t = 0; t < ntmpl; t++) {
       StTinfo &ti = tinfo[(size_t)t];
       ti.dstart   = (int)dep.size();
       ti.ostart   = (int)old.size();
+      int ndep_t  = 0;
       for (int k = tstart[t]; k < tstart[t + 1]; k++) {
         const int off = toff[k];
         if (fwd ? off < 0 : off > 0) {
@@ -960,6 +991,7 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
           e.lo  = fwd ? off : -off;
           e.val = tval[k];
           dep.push_back(e);
+          ndep_t++;
         } else if (fwd ? off > 0 : off <= 0) {  // forward: upper part (KIND 3); backward: lower part then the diagonal (KIND 4)
           StEntry e;
           e.pk  = off;
@@ -968,14 +1000,14 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
           old.push_back(e);
         }
       }
-      ti.dcnt = (int)dep.size() - ti.dstart;
+      ti.dcnt = ndep_t;
+      for (int k = ndep_t; k < ME; k++) dep.push_back(StEntry{ST_NULLPK, 0, 0.0});  // padding: coefficient 0, reads the null slot
       ti.ocnt = (int)old.size() - ti.ostart;
-      maxdep  = std::max(maxdep, ti.dcnt);
     }
     P.ndep      = (int)dep.size();
     P.nold      = (int)old.size();
     P.maxchunks = maxdep;
-    if (maxdep > ST_ME) continue;  // rows with more dependency entries than the compute wave caches: level-ordered schedule
+    P.me        = ME;
     int o = 0;
     P.off_win   = o; o += P.nrows * ST_WP * (int)sizeof(StSlot);
     P.off_rowq  = o; o += 64 * ST_RQ * (int)sizeof(StRow);
@@ -985,6 +1017,7 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
     P.off_old   = o; o += std::max(P.nold, 1) * (int)sizeof(StEntry);
     P.off_prog  = o; o += 64 * 4;
     P.off_ctl   = o; o += 16;
+    P.off_null  = o; o += 16;
     P.lds_bytes = o;
     if (P.lds_bytes > 78 * 1024) continue;  // two workgroups per CU must fit the 160 KiB
     if (dep.empty()) dep.push_back(StEntry{0, 0, 0.0});
@@ -1049,7 +1082,7 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
   unsigned grid = (unsigned)std::min<long long>((long long)P.npanels, 256LL * per_cu);
   const bool aligned = (P.L % 8 == 0) && (P.m % 8 == 0) && ((reinterpret_cast<uintptr_t>(asrc) | reinterpret_cast<uintptr_t>(xold)) % 16 == 0);
   static const bool dbg = getenv("HIPX_SOR_DEBUG") != nullptr;
-  static bool attr_set[5][2] = {{false}};
+  static bool attr_set[5][4] = {{false}};
   auto launch = [&](auto kern, int ai) -> int {
     if (!attr_set[KIND][ai]) {
       HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
@@ -1066,7 +1099,9 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
             (int)aligned, P.m, P.L, P.nstr, P.npanels, P.nbands, P.nrows, P.ntmpl, P.ndep, P.nold, P.maxchunks, P.lds_bytes, grid, (const void *)T->d_tid, (const void *)asrc, (void *)t, (const void *)xold,
             (void *)xnew, (void *)T->d_ctl);
   }
-  int ierr = aligned ? launch(sor_strand_kernel<KIND, true>, 1) : launch(sor_strand_kernel<KIND, false>, 0);
+  int ierr;
+  if (P.me == 4) ierr = aligned ? launch(sor_strand_kernel<KIND, true, 4>, 1) : launch(sor_strand_kernel<KIND, false, 4>, 0);
+  else ierr = aligned ? launch(sor_strand_kernel<KIND, true, ST_ME>, 3) : launch(sor_strand_kernel<KIND, false, ST_ME>, 2);
   if (ierr) return ierr;
   HIPX_LAUNCH_CHECK();
   if (dbg) {
