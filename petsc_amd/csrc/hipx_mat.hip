@@ -66,7 +66,7 @@ struct hipxMat_s {
   int            tmpl_mode  = 0;      // 1 = use the template kernel when the templates exist
   bool           tmpl_ready = false;  // attempted for the current pattern + values
   bool           tmpl_ok    = false;
-  int            ntmpl = 0, tmpl_nent = 0;
+  int            ntmpl = 0, tmpl_nent = 0, tmpl_maxlen = 0;
   unsigned char *d_tid    = nullptr;  // template id per row
   int           *d_tstart = nullptr;  // ntmpl + 1 offsets into toff / tval
   int           *d_toff   = nullptr;  // column - row
@@ -74,6 +74,7 @@ struct hipxMat_s {
   unsigned long long *d_tq = nullptr;   // chunk queue of the template kernel: one ticket counter per XCD (64 bytes apart), never reset
   unsigned long long  tq_launches = 0;  // launches so far on this geometry (the kernel subtracts launches * tickets-per-launch)
   int                 tq_geom = -1;     // geometry (grid, rows per chunk) the counters have been used with
+  long long           tmpl_maxoff = -1; // farthest forward offset of the most common template (-1: not computed yet)
   std::vector<int>     h_tstart, h_toff, h_tdiag;  // host copies (SOR set-up reads them); h_tdiag = index of the diagonal entry or -1
   std::vector<int64_t> h_tcount;                   // rows per template
   std::vector<double>  h_tval;
@@ -975,7 +976,7 @@ __global__ __launch_bounds__(256) void tmpl_verify_kernel(hipx_int m, hipx_int n
 template <int MODE, bool DOT, int RPT, int W, bool UNI>
 __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const int *__restrict__ tstart,
                                                         const int *__restrict__ toff, const double *__restrict__ tval, int ntmpl, int nent, const double *__restrict__ x,
-                                                        const double *yin, double *yout, double *dotpart, unsigned long long *tq, unsigned long long launch)
+                                                        const double *yin, double *yout, double *dotpart, unsigned long long *tq, unsigned long long launch, long long pf_off)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ long long s_tk;
@@ -1009,6 +1010,14 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
   }
   __syncthreads();
   long long tk = s_tk2[0], tk1 = s_tk2[1];
+  // First-touch prefetch.  Of the gathers of a row only ONE stream misses the L2: the farthest forward offset (+n^2 for a 3-D
+  // stencil: the plane nobody has touched yet); everything else was fetched one or two planes ago.  With ~1/7 of the loads
+  // going to HBM the chip holds too few bytes in flight (measured 2-3 TB/s).  So the first 16*RPT lanes of a workgroup touch
+  // that stream for the chunk one round (= workgroups per XCD) ahead of the one they just finished: one load instruction per
+  // workgroup and chunk, the same lines the gathers fetch later, only earlier.  The value is consumed at the END of the next
+  // pass (memory operations retire in order: by then every younger load has been waited for anyway).
+  double    pf = 0.0;
+  unsigned  sink = 0;
   int       idn[RPT];  // template ids of the NEXT chunk (one dependent memory round trip less per chunk)
 #pragma unroll
   for (int rr = 0; rr < RPT; rr++) {
@@ -1112,6 +1121,11 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
       const double w = hipx::wave_sum(cdot);
       if ((threadIdx.x & 63) == 0) dotpart[(size_t)c * 4 + (threadIdx.x >> 6)] = w;
     }
+    sink += (__double_as_longlong(pf) == 0x7ff8123456789abcLL) ? 1u : 0u;  // consume the previous pass's prefetch (no wait: see above)
+    if (pf_off && t < 16 * RPT) {
+      const long long prow = (long long)base + pf_off + (long long)t * 16;  // pf_off = farthest forward offset + the look-ahead distance
+      if (prow < (long long)m) pf = x[prow];
+    }
     __syncthreads();  // everybody has read the tickets
     if (t == 0) s_tk = nxt;
     __syncthreads();
@@ -1119,6 +1133,7 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
     tk1 = s_tk;
   }
   (void)mydot;
+  if (sink == 0xffffffffu) yout[0] = pf;  // never true: keeps the prefetch loads alive
 }
 
 template <typename IT>
@@ -1523,6 +1538,7 @@ void free_templates(hipxMat A)
   A->d_tq = nullptr;
   A->tq_launches = 0;
   A->tq_geom = -1;
+  A->tmpl_maxoff = -1;
   A->d_tid = nullptr;
   A->d_tstart = nullptr;
   A->d_toff = nullptr;
@@ -1631,6 +1647,8 @@ int build_templates(hipxMat A)
   A->ntmpl     = nt;
   A->tmpl_nent = nent;
   A->tmpl_ok   = true;
+  A->tmpl_maxlen = 0;
+  for (int tt = 0; tt < nt; tt++) A->tmpl_maxlen = std::max(A->tmpl_maxlen, A->h_tstart[(size_t)tt + 1] - A->h_tstart[(size_t)tt]);
   A->device_bytes += (int64_t)m + 64 + (int64_t)(sizeof(int) * ((size_t)nt + 1) + 12 * A->h_toff.size());
   return HIPX_SUCCESS;
 }
@@ -1647,8 +1665,9 @@ int ensure_templates(hipxMat A)
 }
 
 // geometry of the template kernel: HIPX_TMPL_CFG = 0 (2 rows per thread, per-lane walk only) | 1 (2 rows, uniform fast path:
-// default -- the smaller chunk keeps the x window of an XCD inside its L2) | 2 (4 rows, uniform fast path) | 3 (4 rows, per-lane
-// walk only) | 4 (8 rows, uniform fast path)
+// default -- the smaller chunk keeps the x window of an XCD inside its L2) | 2 (4 rows, uniform fast path).  Tried and dropped
+// (measured on MI355X, 7-pt 256^3 inside CG): the template cached in scalar registers with all gathers of a chunk issued as one
+// group -- 116 VGPRs, 4 waves per SIMD: 0.163 ms against 0.146 ms; the kernel wants occupancy, not fewer round trips.
 int tmpl_cfg()
 {
   static const int v = getenv("HIPX_TMPL_CFG") ? atoi(getenv("HIPX_TMPL_CFG")) : 1;
@@ -1664,7 +1683,7 @@ template <int MODE, bool DOT>
 int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart, hipx_int *npart)
 {
   const int      cfg = tmpl_cfg();
-  const int      rpt = (cfg == 0 || cfg == 1) ? 2 : (cfg == 4) ? 8 : 4;
+  const int      rpt = (cfg == 2) ? 4 : 2;
   const hipx_int m = A->nrows_c, nchunks = (m + 256 * rpt - 1) / (256 * rpt);
   hipx_int       grid = std::min<hipx_int>((hipx_int)((tmpl_blocks() + 7) / 8 * 8), ((nchunks + 7) / 8) * 8);
   if (grid < 8) grid = 8;
@@ -1682,15 +1701,30 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
     A->tq_geom     = geom;
   }
   const unsigned long long launch = A->tq_launches++;
+  // first-touch prefetch offset: the largest forward offset of the most common template, when it lies beyond a chunk (else off)
+  long long pf_off = 0;
+  {
+    static const bool off = getenv("HIPX_TMPL_NOPF") != nullptr;
+    if (A->tmpl_maxoff < 0) {
+      int best = 0;
+      for (int tt = 1; tt < A->ntmpl; tt++)
+        if (A->h_tcount[(size_t)tt] > A->h_tcount[(size_t)best]) best = tt;
+      A->tmpl_maxoff = 0;
+      for (int k = A->h_tstart[(size_t)best]; k < A->h_tstart[(size_t)best + 1]; k++) A->tmpl_maxoff = std::max<long long>(A->tmpl_maxoff, A->h_toff[(size_t)k]);
+    }
+    pf_off = A->tmpl_maxoff;
+    static const char *ds = getenv("HIPX_TMPL_PFDIST");  // look-ahead in chunks; default: one round of the XCD's workgroups
+    const long long    dist = ds ? atoll(ds) : (long long)(grid >> 3);
+    if (off || pf_off < 4 * 256 * rpt) pf_off = 0;
+    else pf_off += dist * 256 * rpt;
+  }
 #define HIPX_TMPL_LAUNCH(R, WW, U) \
   spmv_tmpl_kernel<MODE, DOT, R, WW, U><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout, dotpart, \
-                                                                                      A->d_tq, launch)
+                                                                                      A->d_tq, launch, pf_off)
   switch (cfg) {
   case 0: HIPX_TMPL_LAUNCH(2, 4, false); break;
-  case 1: HIPX_TMPL_LAUNCH(2, 4, true); break;
-  case 3: HIPX_TMPL_LAUNCH(4, 4, false); break;
-  case 4: HIPX_TMPL_LAUNCH(8, 2, true); break;
-  default: HIPX_TMPL_LAUNCH(4, 4, true); break;
+  case 2: HIPX_TMPL_LAUNCH(4, 4, true); break;
+  default: HIPX_TMPL_LAUNCH(2, 4, true); break;
   }
 #undef HIPX_TMPL_LAUNCH
   HIPX_LAUNCH_CHECK();

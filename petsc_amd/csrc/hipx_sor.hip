@@ -550,6 +550,7 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
       }
       unsigned  st_iters = 0, st_rowwait = 0, st_depwait = 0, st_fallback = 0;  // HIPX_SOR_DEBUG statistics (stats != nullptr)
       const long long st_t0 = stats ? (long long)wall_clock64() : 0;
+      if (stats && lane == 0) stats[16 + 4 * (size_t)panel] = (unsigned long long)st_t0;
       long long t0 = 0;
       auto fetch_row = [&]() {  // operands + template of the row at position p, if the loader has staged them
         const int     ro = P.off_rowq + 32 * (lane * ST_RQ + (p & (ST_RQ - 1)));
@@ -653,6 +654,7 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
                 }
               }
               sor_publish(xnew + r, out);
+              if (stats && p == 0 && (lane == 0 || lane == 63)) stats[16 + 4 * (size_t)panel + (lane ? 2 : 1)] = (unsigned long long)wall_clock64();
               p++;
               have = false;
               asm volatile("" ::: "memory");
@@ -681,6 +683,7 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
           atomicAdd(&stats[0], (unsigned long long)st_iters);
           atomicAdd(&stats[6], (unsigned long long)((long long)wall_clock64() - st_t0));
           atomicAdd(&stats[8], 1ull);
+          stats[16 + 4 * (size_t)panel + 3] = (unsigned long long)wall_clock64();
         }
       }
     } else {
@@ -860,6 +863,7 @@ struct StrandState {
   StrandDir            dir[2];   // [0] forward (dependencies = lower part), [1] backward
   unsigned int        *d_ctl = nullptr;
   unsigned long long  *d_stats = nullptr;
+  long long            stats_panels = 0;
   unsigned long long   value_state = 0;
   double               omega = 0.0, shift = 0.0;
   bool                 diag_uploaded = false;
@@ -1092,8 +1096,15 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
     return HIPX_SUCCESS;
   };
   if (dbg) {
-    if (!T->d_stats) HIPX_HIP(hipMalloc((void **)&T->d_stats, sizeof(unsigned long long) * 16));
-    HIPX_HIP(hipMemsetAsync(T->d_stats, 0, sizeof(unsigned long long) * 16, st));
+    if (T->d_stats && T->stats_panels < P.npanels) {
+      (void)hipFree(T->d_stats);
+      T->d_stats = nullptr;
+    }
+    if (!T->d_stats) {
+      HIPX_HIP(hipMalloc((void **)&T->d_stats, sizeof(unsigned long long) * (16 + 4 * (size_t)P.npanels)));
+      T->stats_panels = P.npanels;
+    }
+    HIPX_HIP(hipMemsetAsync(T->d_stats, 0, sizeof(unsigned long long) * (16 + 4 * (size_t)P.npanels), st));
     HIPX_HIP(hipStreamSynchronize(st));
     fprintf(stderr, "[hipx sor] strand KIND %d aligned %d m %d L %d nstr %d npanels %d nbands %d nrows %d ntmpl %d ndep %d nold %d maxchunks %d lds %d grid %u  tid %p asrc %p t %p xold %p xnew %p ctl %p\n", KIND,
             (int)aligned, P.m, P.L, P.nstr, P.npanels, P.nbands, P.nrows, P.ntmpl, P.ndep, P.nold, P.maxchunks, P.lds_bytes, grid, (const void *)T->d_tid, (const void *)asrc, (void *)t, (const void *)xold,
@@ -1112,6 +1123,19 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
     fprintf(stderr, "[hipx sor] strand KIND %d done: panels %llu, compute iterations/panel %.0f, wall/panel %.1f us (%.3f us/iteration), rows %llu, lane-iterations waiting: operands %llu deps %llu, "
                     "fallback loads %llu, loader passes/panel %.0f (idle %.0f)\n",
             KIND, hs[8], hs[0] / np, hs[6] / np / 100.0, hs[0] ? hs[6] / 100.0 / (double)hs[0] : 0.0, hs[7], hs[1], hs[2], hs[5], hs[3] / np, hs[4] / np);
+    if (const char *dump = getenv("HIPX_SOR_DEBUG_DUMP")) {  // per panel: start, first row of lane 0, first row of lane 63, end (wall-clock ticks, 10 ns)
+      std::vector<unsigned long long> pt(4 * (size_t)P.npanels);
+      HIPX_HIP(hipMemcpy(pt.data(), T->d_stats + 16, sizeof(unsigned long long) * pt.size(), hipMemcpyDeviceToHost));
+      char name[512];
+      snprintf(name, sizeof(name), "%s_kind%d.txt", dump, KIND);
+      if (FILE *f = fopen(name, "w")) {
+        unsigned long long base = ~0ull;
+        for (size_t i = 0; i < (size_t)P.npanels; i++) base = std::min(base, pt[4 * i]);
+        for (size_t i = 0; i < (size_t)P.npanels; i++)
+          fprintf(f, "%zu %.2f %.2f %.2f %.2f\n", i, (pt[4 * i] - base) / 100.0, (pt[4 * i + 1] - base) / 100.0, (pt[4 * i + 2] - base) / 100.0, (pt[4 * i + 3] - base) / 100.0);
+        fclose(f);
+      }
+    }
   }
   return HIPX_SUCCESS;
 }
