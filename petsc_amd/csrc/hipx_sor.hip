@@ -356,6 +356,14 @@ int run_levels(hipxSorState *S, bool forward, const double *b, double *x, double
 // SIMT model used to design and check the schedule: scripts/sor_strand_model.py.
 constexpr int ST_WP   = 16;  // window positions per LDS row
 constexpr int ST_RQ   = 16;  // per-row operand ring (positions per lane)
+// LDS bank swizzle.  Lane s of the compute wave reads slot (p_s & 15) of window row (s + const): with the slots of a row in
+// natural order the 64 addresses of one ds_read_b128 fall into the same four banks when the lanes are at the same position
+// (64-way conflict: ~512 clocks per read, 13 reads per iteration) and into 16 bank groups when they are one position apart.
+// The LDS pipe is shared by the two panels of a CU, so a neighbour SPINNING on such reads starved the panel that had work
+// (measured: 613 clocks per burst; panels in "slow mode" at 3 us per row next to fast ones at 1.4).  Position q of window row
+// w lives in slot (q + 7 w) & 15 instead: lanes k positions apart are then (7 - k) slots apart -- conflict-free for k = 0, 2, 4,
+// 6, two-way for k = 1, 5, four-way for k = 3 (lanes in flow are 2 apart, blocked ones 1).  Same rotation for the operand ring.
+constexpr int ST_ROT = 7;
 constexpr int ST_SB   = 8;   // positions per staging batch
 constexpr int ST_LA   = 10;  // staging look-ahead beyond the leading consumer
 constexpr int ST_NB   = 3;   // bands of strands a panel may touch
@@ -372,6 +380,11 @@ struct StParams {
   int      nbands, nrows, ntmpl, ndep, nold, maxchunks;
   StBand   band[ST_NB];
   int      off_win, off_rowq, off_prog, off_ctl, off_tinfo, off_tdiag, off_dep, off_old, off_null, me, lds_bytes;
+  int      trace_it0;    // ... first iteration of the per-iteration log of lane trace_lane
+  int      trace_rows;   // ... per-row stamps on (they cost one scattered store per row)
+  int      trace_lane;   // ... and the loader lane whose passes are logged
+  int      poll_sys;     // experiment (HIPX_SOR_POLL=sys): far polls at system scope
+  int      trace_panel;  // HIPX_SOR_DEBUG + HIPX_SOR_TRACE_PANEL: the panel whose rows / loader passes are time-stamped (-1: none)
 };
 struct __attribute__((aligned(16))) StEntry {  // dep: pk = (window row offset << 16) | (dp & 0xffff), lo = logical row offset; old: pk = ACTUAL column - row
   int    pk, lo;
@@ -452,6 +465,39 @@ __device__ __forceinline__ void st_lds_burst(st_int4 (&o)[ME], const unsigned (&
 {
   if constexpr (ME == 4) st_lds_burst4(o, a);
   else st_lds_burst16(o, a);
+}
+// The per-iteration burst of the compute wave: the ME window slots of the current row AND the two halves of an operand-ring
+// record (32 bytes at `ra`) in one go, one wait.  The record's SECOND half (template id, tag) is read BEFORE the first one
+// (operands): the loader writes operands first and the tag last, and LDS executes a wave's accesses in order, so a tag that
+// reads as valid guarantees the operands read after it are the ones it belongs to.
+__device__ __forceinline__ void st_lds_burst_row16(st_int4 (&o)[16], st_int4 &w0, st_int4 &w1, const unsigned (&a)[16], unsigned ra)
+{
+  asm volatile("ds_read_b128 %0, %9\n\tds_read_b128 %1, %10\n\tds_read_b128 %2, %11\n\tds_read_b128 %3, %12\n\t"
+               "ds_read_b128 %4, %13\n\tds_read_b128 %5, %14\n\tds_read_b128 %6, %15\n\tds_read_b128 %7, %16\n\tds_read_b128 %8, %17 offset:16"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(w1)
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(ra)
+               : "memory");
+  asm volatile("ds_read_b128 %9, %18\n\tds_read_b128 %10, %19\n\tds_read_b128 %11, %20\n\tds_read_b128 %12, %21\n\t"
+               "ds_read_b128 %13, %22\n\tds_read_b128 %14, %23\n\tds_read_b128 %15, %24\n\tds_read_b128 %16, %25\n\tds_read_b128 %17, %26\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]), "+v"(w1), "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]),
+                 "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15]), "=&v"(w0)
+               : "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]), "v"(ra)
+               : "memory");
+}
+__device__ __forceinline__ void st_lds_burst_row4(st_int4 (&o)[4], st_int4 &w0, st_int4 &w1, const unsigned (&a)[4], unsigned ra)
+{
+  asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %9\n\tds_read_b128 %5, %10 offset:16\n\t"
+               "ds_read_b128 %4, %10\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(w0), "=&v"(w1)
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(ra)
+               : "memory");
+}
+template <int ME>
+__device__ __forceinline__ void st_lds_burst_row(st_int4 (&o)[ME], st_int4 &w0, st_int4 &w1, const unsigned (&a)[ME], unsigned ra)
+{
+  if constexpr (ME == 4) st_lds_burst_row4(o, w0, w1, a, ra);
+  else st_lds_burst_row16(o, w0, w1, a, ra);
 }
 // agent-scope 8-byte load, complete on return (rare paths only: it drains this wave's stores as well)
 __device__ __forceinline__ unsigned long long st_gload64_wait(const void *p)
@@ -534,34 +580,49 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
       // iteration is then: ONE burst of ME window reads, ME tag compares, and -- when every value is there -- the left-to-right
       // subtraction chain, the scale by 1/d, the publish.  Padding entries have coefficient 0 and read the null slot (value 0):
       // they subtract +0.0, which leaves every sum bit-identical, so the chain needs no predication.
-      int       p = 0, ostart = 0, ocnt = 0;
+      int       p = 0, ostart = 0, ocnt = 0, dstart = 0, cur_tid = -1, setp = 0;  // setp: the position pos[] / sa[] are set for
       bool      have = false;
       double    s0 = 0.0, rb = 0.0, idiag = 0.0, mdiag = 0.0;
-      unsigned  sa[ME];   // LDS byte address of the slot of entry j
-      int       pos[ME];  // the tag it must carry
-      int       elo[ME];  // logical row offset (rare path: the value itself from memory)
-      double    cf[ME];   // coefficient
+      unsigned  sa[ME];    // LDS byte address of the slot of entry j for the row at position p
+      unsigned  wrow[ME];  // ... of slot 0 of its window row (the null slot for a padding entry)
+      int       msk[ME];   // ST_WP - 1, or 0 for a padding entry (its address does not move)
+      int       apos[ME];  // the tag the slot must carry: position + rotation of the window row (the slot is apos & 15)
+      double    cf[ME];    // coefficient
 #pragma unroll
       for (int j = 0; j < ME; j++) {
-        sa[j]  = lds_base + (unsigned)P.off_null;
-        pos[j] = ST_NULLTAG;
-        elo[j] = 0;
-        cf[j]  = 0.0;
+        sa[j] = wrow[j] = lds_base + (unsigned)P.off_null;
+        msk[j]  = 0;
+        apos[j] = ST_NULLTAG;
+        cf[j]   = 0.0;
+      }
+      const unsigned rq_base = lds_base + (unsigned)(P.off_rowq + 32 * ST_RQ * lane);
+      const int      rq_rot  = ST_ROT * lane;
+      unsigned       pubrow[ST_NB];  // this lane's own window row in band b (byte address of slot 0), ~0u: the band has none for it
+      int            pubrot[ST_NB];  // ... and its slot rotation
+#pragma unroll
+      for (int b = 0; b < ST_NB; b++) {
+        pubrow[b] = ~0u;
+        pubrot[b] = 0;
+        if (b < P.nbands) {
+          const int u = lane - P.band[b].dsmin;
+          if (u >= 0 && u < 64 + P.band[b].width - 1) {
+            pubrow[b] = lds_base + (unsigned)(P.off_win + 16 * ST_WP * (P.band[b].rowbase + u));
+            pubrot[b] = ST_ROT * (P.band[b].rowbase + u);
+          }
+        }
       }
       unsigned  st_iters = 0, st_rowwait = 0, st_depwait = 0, st_fallback = 0;  // HIPX_SOR_DEBUG statistics (stats != nullptr)
+      unsigned  st_nfast = 0, st_nslow = 0, st_nsetup = 0;                     // iterations in which ANY lane took the path
+      long long st_cburst = 0, st_cfast = 0;                                   // shader clocks spent in the burst / in the fast finish
       const long long st_t0 = stats ? (long long)wall_clock64() : 0;
+      const long long st_c0 = stats ? (long long)clock64() : 0;
       if (stats && lane == 0) stats[16 + 4 * (size_t)panel] = (unsigned long long)st_t0;
       long long t0 = 0;
-      auto fetch_row = [&]() {  // operands + template of the row at position p, if the loader has staged them
-        const int     ro = P.off_rowq + 32 * (lane * ST_RQ + (p & (ST_RQ - 1)));
-        const st_int4 w1 = st_ld4v(lds, ro + 16);  // tag first: operands are written before the tag
-        const st_int4 w0 = st_ld4v(lds, ro);
-        if (w1.y != p) {
-          st_rowwait++;
-          return;
-        }
-        const st_int4 ti = st_ld4(lds, P.off_tinfo + 16 * w1.x);
-        const st_int4 dg = st_ld4(lds, P.off_tdiag + 16 * w1.x);
+      // the template of the row at position p has changed (first row, boundary rows): entry table -> registers
+      auto load_template = [&](int tnew) __attribute__((always_inline)) {
+        const st_int4 ti = st_ld4(lds, P.off_tinfo + 16 * tnew);
+        const st_int4 dg = st_ld4(lds, P.off_tdiag + 16 * tnew);
+        dstart = ti.x;
         ostart = ti.z;
         ocnt   = ti.w;
         st_int4  e[ME];
@@ -572,17 +633,33 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
 #pragma unroll
         for (int j = 0; j < ME; j++) {
           const bool null = e[j].x == ST_NULLPK;
-          const int  ps   = p + (int)(short)(e[j].x & 0xffff);
-          pos[j] = null ? ST_NULLTAG : ps;
-          sa[j]  = lds_base + (unsigned)(null ? P.off_null : P.off_win + 16 * ((lane + (e[j].x >> 16)) * ST_WP + (ps & (ST_WP - 1))));
-          elo[j] = e[j].y;
-          cf[j]  = st_dbl(e[j].z, e[j].w);
+          const int wr = lane + (e[j].x >> 16);  // window row
+          wrow[j] = lds_base + (unsigned)(null ? P.off_null : P.off_win + 16 * ST_WP * wr);
+          msk[j]  = null ? 0 : ST_WP - 1;
+          apos[j] = null ? ST_NULLTAG : p + (int)(short)(e[j].x & 0xffff) + ST_ROT * wr;
+          sa[j]   = wrow[j] + (unsigned)((apos[j] & msk[j]) << 4);
+          cf[j]   = st_dbl(e[j].z, e[j].w);
         }
-        rb    = st_dbl(w0.z, w0.w);
-        idiag = st_dbl(dg.x, dg.y);
-        mdiag = st_dbl(dg.z, dg.w);
-        s0    = st_dbl(w0.x, w0.y);
-        have  = true;
+        idiag   = st_dbl(dg.x, dg.y);
+        mdiag   = st_dbl(dg.z, dg.w);
+        cur_tid = tnew;
+        setp    = p;
+      };
+      // operands of the row at position p have arrived (w0 = {a, old value}, w1 = {template id, tag})
+      auto start_row = [&](const st_int4 &w0, const st_int4 &w1) __attribute__((always_inline)) {
+        s0 = st_dbl(w0.x, w0.y);
+        rb = st_dbl(w0.z, w0.w);
+        if (w1.x != cur_tid) load_template(w1.x);
+        else if (setp != p) {  // same template, the next position (p = setp + 1): every tag and slot moves on by one
+          const int step = p - setp;
+#pragma unroll
+          for (int j = 0; j < ME; j++) {
+            apos[j] += (msk[j] & 1) * step;  // (a padding entry stays where it is)
+            sa[j] = wrow[j] + (unsigned)((apos[j] & msk[j]) << 4);
+          }
+          setp = p;
+        }
+        have = true;
         if (KIND == 4) {  // aij.c:1984-1990: the lower part and the diagonal use OLD values, in row order, first
           const hipx_int r = st_actual<FWD>(S * L + p, m);
           for (int q2 = 0; q2 < ocnt; q2++) {
@@ -591,39 +668,52 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
           }
         }
       };
+      // Two panels share a CU and their compute waves may share a SIMD: a wave that spins on values that are not there yet takes
+      // issue cycles from one that has work (measured: panels next to a spinning neighbour ran at 2.9 us per row instead of 1.4).
+      // So the wave runs at raised priority and, after an iteration in which none of its lanes finished a row, sleeps briefly.
+      __builtin_amdgcn_s_setprio(3);
+      int idle = 0;
       for (unsigned it = 1;; it++) {
         const bool active = p < len;
         if (!__any(active)) break;
         st_iters++;
+        const int  p_before    = p;
+        const bool have_before = have;
+        int        dbg_diff = 0x7ffffff, dbg_rtag = -2, dbg_mask = 0;
+        const bool dbg_on = stats && P.trace_panel == (int)panel && lane == P.trace_lane;
+        long long  dbg_c0 = dbg_on ? (long long)clock64() : 0, dbg_c1 = 0, dbg_c2 = 0, dbg_c3 = 0;
         asm volatile("" ::: "memory");  // other waves have written LDS since the last iteration: re-read, do not reuse
         if (active) {
-          if (!have) fetch_row();
-          if (have) {
+          // ONE burst per iteration: the ME slots of the current row and the operand record of the NEXT row (of the current one
+          // while it is still missing); one wait
+          st_int4        sl[ME], w0, w1;
+          const int      qr = have ? p + 1 : p;
+          const unsigned ra = rq_base + (unsigned)(32 * ((qr + rq_rot) & (ST_RQ - 1)));
+          const long long c_b0 = stats ? (long long)clock64() : 0;
+          st_lds_burst_row<ME>(sl, w0, w1, sa, ra);
+          dbg_rtag = w1.y;
+          if (__any(!have)) dbg_mask |= 1 << 29;
+          if (stats) st_cburst += (long long)clock64() - c_b0;
+          if (stats && __any(!have)) st_nsetup++;
+          if (!have) {
+            if (w1.y == p) start_row(w0, w1);  // (the slots read above belonged to no row: compute in the next iteration)
+            else st_rowwait++;
+          } else {
             const long long q = S * L + p;
             const hipx_int  r = st_actual<FWD>(q, m);
-            st_int4         sl[ME];
-            st_lds_burst<ME>(sl, sa);
-            bool neq = false;
+            int             diff = 0;  // OR of (tag - expected): 0 = all there; negative = at least one not produced yet (wait, nothing
+                                       // else to find out); positive = a slot has moved on (rare: the value comes from memory)
 #pragma unroll
-            for (int j = 0; j < ME; j++) neq = neq || (sl[j].z != pos[j]);
-            bool   ok = true;
-            double val[ME];
+            for (int j = 0; j < ME; j++) diff |= sl[j].z - apos[j];
+            if (dbg_on) dbg_c1 = (long long)clock64();  // (moves the burst/compare boundary to here: burst + whatever the !have lanes did + the tag compare)
+            if (__any(diff > 0)) dbg_mask |= 1 << 30;
+            if (stats && P.trace_panel == (int)panel && lane == P.trace_lane) {
+              dbg_diff = diff;
 #pragma unroll
-            for (int j = 0; j < ME; j++) val[j] = st_dbl(sl[j].x, sl[j].y);
-            if (neq) {  // not produced yet (tag behind), or the slot has moved on (tag ahead: this lane fell far behind its producer)
-#pragma unroll
-              for (int j = 0; j < ME; j++) {
-                if (sl[j].z < pos[j]) ok = false;
-                else if (sl[j].z > pos[j]) {
-                  const unsigned long long v = st_gload64_wait(xnew + st_actual<FWD>(q + elo[j], m));
-                  st_fallback++;
-                  if (v == SOR_SENTINEL) ok = false;
-                  else val[j] = __longlong_as_double((long long)v);
-                }
-              }
+              for (int j = 0; j < ME; j++) dbg_mask |= (sl[j].z < apos[j] ? 1 : 0) << j;
             }
-            if (!ok) st_depwait++;
-            if (ok) {
+            // the row's values are all there: subtraction chain, scale, publish, move on to the next row
+            auto finish = [&](const double (&val)[ME]) __attribute__((always_inline)) {
               double sum = s0;
 #pragma unroll
               for (int j = 0; j < ME; j++) sum -= cf[j] * val[j];  // left to right (PetscSparseDenseMinusDot); null entries subtract +0.0
@@ -645,24 +735,82 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
               } else {
                 out = (1. - omega) * rb + (sum + mdiag * rb) * idiag;
               }
-              const st_int4 pub = st_pack_slot(out, p);
 #pragma unroll
-              for (int b = 0; b < ST_NB; b++) {
-                if (b < P.nbands) {
-                  const int u = lane - P.band[b].dsmin;
-                  if (u >= 0 && u < 64 + P.band[b].width - 1) st_st4v(lds, P.off_win + 16 * ((P.band[b].rowbase + u) * ST_WP + (p & (ST_WP - 1))), pub);
-                }
-              }
+              for (int b = 0; b < ST_NB; b++)
+                if (pubrow[b] != ~0u)  // the tag is the position plus the row's rotation; so is the slot
+                  *reinterpret_cast<volatile st_lds_int4 *>((st_lds_char *)(size_t)(pubrow[b] + (unsigned)(((p + pubrot[b]) & (ST_WP - 1)) << 4))) = st_pack_slot(out, p + pubrot[b]);
               sor_publish(xnew + r, out);
               if (stats && p == 0 && (lane == 0 || lane == 63)) stats[16 + 4 * (size_t)panel + (lane ? 2 : 1)] = (unsigned long long)wall_clock64();
+              if (stats && P.trace_panel == (int)panel && P.trace_rows)  // HIPX_SOR_TRACE_PANEL: completion time of every row of this panel
+                stats[16 + 4 * (size_t)P.npanels + (size_t)lane * (size_t)L + (size_t)p] = (unsigned long long)wall_clock64();
               p++;
               have = false;
               asm volatile("" ::: "memory");
-              if (p < len) fetch_row();  // the next row's operands: ready when the next iteration starts
+              if (p < len && w1.y == p) start_row(w0, w1);  // the next row's operands came with this iteration's burst
+            };
+            if (stats && __any(diff == 0)) st_nfast++;
+            if (stats && __any(diff > 0)) st_nslow++;
+            if (!diff) {  // the common case: straight from the registers the burst filled
+              double val[ME];
+#pragma unroll
+              for (int j = 0; j < ME; j++) val[j] = st_dbl(sl[j].x, sl[j].y);
+              const long long c_f0 = stats ? (long long)clock64() : 0;
+              if (dbg_on) dbg_c2 = c_f0;
+              finish(val);
+              if (stats) st_cfast += (long long)clock64() - c_f0;
+              if (dbg_on) dbg_c3 = (long long)clock64();
+            } else if (diff < 0) {
+              st_depwait++;
+              if (stats && P.trace_panel == (int)panel && P.trace_rows) {  // which entry is late?  (first one in arithmetic order), all lanes together + lane 0 alone
+                int jf = 0, jtag = 0, jexp = 0;  // (selects, not indexed reads: a register array indexed at run time goes to scratch)
+#pragma unroll
+                for (int j = ME - 1; j >= 0; j--)
+                  if (sl[j].z < apos[j]) {
+                    jf   = j;
+                    jtag = sl[j].z;
+                    jexp = apos[j];
+                  }
+                unsigned long long *h = stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)L + 2 * 4096 * 8;
+                atomicAdd(&h[jf], 1ull);
+                if (lane == 0) atomicAdd(&h[16 + jf], 1ull);
+                if (lane == 32) atomicAdd(&h[32 + jf], 1ull);
+              }
+            } else {  // no tag behind, at least one ahead: the slot has moved on (this lane fell far behind its producer)
+              bool   ok = true;
+              double val[ME];
+#pragma unroll
+              for (int j = 0; j < ME; j++) {
+                val[j] = st_dbl(sl[j].x, sl[j].y);
+                if (sl[j].z < apos[j]) ok = false;
+                else if (sl[j].z > apos[j]) {
+                  const int                elo = st_ld4(lds, P.off_dep + 16 * (dstart + j)).y;  // logical row offset of the entry
+                  const unsigned long long v   = st_gload64_wait(xnew + st_actual<FWD>(q + elo, m));
+                  st_fallback++;
+                  if (v == SOR_SENTINEL) ok = false;
+                  else val[j] = __longlong_as_double((long long)v);
+                }
+              }
+              if (ok) finish(val);
+              else st_depwait++;
             }
           }
         }
         s_prog[lane] = p;
+        if (stats && P.trace_panel == (int)panel && lane == P.trace_lane && (int)it >= P.trace_it0 && (int)it < P.trace_it0 + 4096) {  // iteration log of one lane
+          unsigned long long *ev = stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)L + 4096 * 8 + (size_t)((int)it - P.trace_it0) * 8;
+          ev[0] = (unsigned long long)wall_clock64();
+          ev[1] = (unsigned long long)it;
+          ev[2] = (unsigned long long)p_before;
+          ev[3] = (unsigned long long)p;
+          ev[4] = (unsigned long long)((have_before ? 1 : 0) | (have ? 2 : 0));
+          ev[5] = (unsigned long long)(unsigned)dbg_diff | ((unsigned long long)(unsigned)(dbg_c1 - dbg_c0) << 32);       // burst
+          ev[6] = (unsigned long long)(unsigned)(dbg_c2 - dbg_c1) | ((unsigned long long)(unsigned)(dbg_c3 - dbg_c2) << 32);  // compare | finish
+          ev[7] = (unsigned long long)(unsigned)dbg_mask | ((unsigned long long)(unsigned)((long long)clock64() - dbg_c0) << 32);  // whole iteration so far
+        }
+        if (!__any(p != p_before || have != have_before)) {
+          idle = idle < 4 ? idle + 1 : 4;
+          if (idle >= 2) __builtin_amdgcn_s_sleep(2);   // ~128 clocks; the loader pass that can change anything takes thousands
+        } else idle = 0;
         if ((it & 0x3ff) == 0) {  // bounded wait: elapsed wall-clock time, and a global abort word so one stuck panel ends the launch
           const long long now = (long long)wall_clock64();
           if (!t0) t0 = now;
@@ -673,14 +821,25 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
           }
         }
       }
+      __builtin_amdgcn_s_setprio(0);
       if (lane == 0) s_ctl[1] = 1;
       if (stats) {
+        for (int o = 32; o > 0; o >>= 1) {  // the finish-path clocks of the lane that finished most often
+          const long long other = __shfl_xor(st_cfast, o);
+          st_cfast = other > st_cfast ? other : st_cfast;
+        }
         atomicAdd(&stats[1], (unsigned long long)st_rowwait);
         atomicAdd(&stats[2], (unsigned long long)st_depwait);
         atomicAdd(&stats[5], (unsigned long long)st_fallback);
         atomicAdd(&stats[7], (unsigned long long)len);
         if (lane == 0) {
           atomicAdd(&stats[0], (unsigned long long)st_iters);
+          atomicAdd(&stats[9], (unsigned long long)st_nfast);
+          atomicAdd(&stats[10], (unsigned long long)st_nslow);
+          atomicAdd(&stats[11], (unsigned long long)st_nsetup);
+          atomicAdd(&stats[12], (unsigned long long)st_cburst);
+          atomicAdd(&stats[13], (unsigned long long)st_cfast);
+          atomicAdd(&stats[14], (unsigned long long)((long long)clock64() - st_c0));
           atomicAdd(&stats[6], (unsigned long long)((long long)wall_clock64() - st_t0));
           atomicAdd(&stats[8], 1ull);
           stats[16 + 4 * (size_t)panel + 3] = (unsigned long long)wall_clock64();
@@ -746,15 +905,24 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
             const long long strand = S0 + u + P.band[b].dsmin;
             const bool      valid  = u < 64 + w - 1 && (strand < S0 || strand > S0 + 63) && strand >= 0 && strand < P.nstr;
             if (valid) {
-              int lead = -1000000;  // most advanced consumer of this row that is still running
+              int lead = -1000000, trail = 1000000;  // most / least advanced consumer of this row that is still running
               for (int c = u - (w - 1); c <= u; c++) {
                 if (c >= 0 && c < 64) {
                   const int pc = s_prog[c];
-                  if (pc < st_strand_len(S0 + c, P) && pc > lead) lead = pc;
+                  if (pc < st_strand_len(S0 + c, P)) {
+                    if (pc > lead) lead = pc;
+                    if (pc < trail) trail = pc;
+                  }
                 }
               }
               const int slen = st_strand_len(strand, P);
               int       tgt  = lead + ST_LA + 1;
+              // ... but never over a slot the slowest consumer still needs: position q goes where q - 16 was, and a consumer at
+              // `trail` reads positions >= trail - 1.  (Without this bound a panel whose producers are far ahead always stages to
+              // the limit, the third consumer of a row -- four positions behind the first -- finds its slot gone, takes the
+              // memory path, which drains the wave's stores (~2 us), falls further behind ...: measured, a whole plane at 3 us
+              // per row instead of 1.3, and every later plane behind it.)
+              if (tgt > trail + ST_WP - 2) tgt = trail + ST_WP - 2;
               if (tgt > slen) tgt = slen;
               int n = tgt - sf[d];
               if (n > ST_SB) n = ST_SB;
@@ -765,7 +933,10 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
                 const long long q0 = strand * L + sf[d];
 #pragma unroll
                 for (int j = 0; j < ST_SB; j++)
-                  fv[d][j] = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(xnew + st_actual<FWD>(q0 + (j < n ? j : n - 1), m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                {
+                  const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xnew + st_actual<FWD>(q0 + (j < n ? j : n - 1), m));
+                  fv[d][j] = P.poll_sys ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
               }
             }
           }
@@ -779,7 +950,7 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
 #pragma unroll
           for (int j = 0; j < ST_SB; j++) {
             if (j < nrow) {
-              const int       ro = P.off_rowq + 32 * (lane * ST_RQ + ((rqf + j) & (ST_RQ - 1)));
+              const int       ro = P.off_rowq + 32 * (lane * ST_RQ + ((rqf + j + ST_ROT * lane) & (ST_RQ - 1)));
               const long long ba = __double_as_longlong(va[j]), bb = __double_as_longlong(vb[j]);
               st_int4         w0, w1;
               w0.x = (int)(unsigned)ba;
@@ -804,12 +975,22 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
 #pragma unroll
             for (int j = 0; j < ST_SB; j++) {
               if (j < fn[d] && acc && fv[d][j] != SOR_SENTINEL) {
-                st_st4v(lds, P.off_win + 16 * (frow[d] * ST_WP + ((sf[d] + j) & (ST_WP - 1))), st_pack_slot(__longlong_as_double((long long)fv[d][j]), sf[d] + j));
+                st_st4v(lds, P.off_win + 16 * (frow[d] * ST_WP + ((sf[d] + j + ST_ROT * frow[d]) & (ST_WP - 1))), st_pack_slot(__longlong_as_double((long long)fv[d][j]), sf[d] + j + ST_ROT * frow[d]));
                 cnt++;
               } else acc = false;
             }
             sf[d] += cnt;
           }
+        }
+        if (stats && P.trace_panel == (int)panel && st_pass < 4096 && lane == P.trace_lane) {  // trace: the loader's view
+          unsigned long long *tr = stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)L + (size_t)st_pass * 8;
+          tr[0] = (unsigned long long)wall_clock64();
+          tr[1] = (unsigned long long)myp;
+          tr[2] = (unsigned long long)rqf;
+#pragma unroll
+          for (int d = 0; d < 3; d++) tr[3 + d] = (unsigned long long)sf[d];
+          tr[6] = (unsigned long long)(fn[0] | (fn[1] << 8) | (fn[2] << 16));  // rows asked for in this pass
+          tr[7] = (unsigned long long)(nrow | (s_prog[0] << 8) | ((unsigned long long)s_prog[1] << 24) | ((unsigned long long)s_prog[2] << 40));
         }
         st_pass++;
         if (!__any(issued)) {
@@ -1071,7 +1252,15 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
 {
   constexpr bool FWD = (KIND == 0 || KIND == 3);
   StrandDir     &D   = T->dir[FWD ? 0 : 1];
-  const StParams P   = D.P;
+  StParams       P   = D.P;
+  P.trace_panel      = -1;
+  P.trace_lane       = 32;
+  P.trace_it0        = getenv("HIPX_SOR_TRACE_IT0") ? atoi(getenv("HIPX_SOR_TRACE_IT0")) : 600;
+  P.trace_rows       = getenv("HIPX_SOR_TRACE_ROWS") ? atoi(getenv("HIPX_SOR_TRACE_ROWS")) : 1;
+  {
+    static const bool ps = getenv("HIPX_SOR_POLL") && !strcmp(getenv("HIPX_SOR_POLL"), "sys");
+    P.poll_sys = ps ? 1 : 0;
+  }
   hipStream_t    st  = rt().compute;
   const hipx_int g   = std::min<hipx_int>((P.m + 255) / 256, 4096);
   sor_fill_kernel<<<(unsigned)g, 256, 0, st>>>(xnew, P.m);
@@ -1096,15 +1285,18 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
     return HIPX_SUCCESS;
   };
   if (dbg) {
-    if (T->d_stats && T->stats_panels < P.npanels) {
+    const long long stats_words = 16 + 4 * (long long)P.npanels + 64 * (long long)P.L + 2 * 4096 * 8 + 64;
+    if (T->d_stats && T->stats_panels < stats_words) {
       (void)hipFree(T->d_stats);
       T->d_stats = nullptr;
     }
     if (!T->d_stats) {
-      HIPX_HIP(hipMalloc((void **)&T->d_stats, sizeof(unsigned long long) * (16 + 4 * (size_t)P.npanels)));
-      T->stats_panels = P.npanels;
+      HIPX_HIP(hipMalloc((void **)&T->d_stats, sizeof(unsigned long long) * (size_t)stats_words));
+      T->stats_panels = stats_words;
     }
-    HIPX_HIP(hipMemsetAsync(T->d_stats, 0, sizeof(unsigned long long) * (16 + 4 * (size_t)P.npanels), st));
+    HIPX_HIP(hipMemsetAsync(T->d_stats, 0, sizeof(unsigned long long) * (size_t)stats_words, st));
+    if (const char *tp = getenv("HIPX_SOR_TRACE_PANEL")) P.trace_panel = atoi(tp);
+    P.trace_lane = getenv("HIPX_SOR_TRACE_LANE") ? atoi(getenv("HIPX_SOR_TRACE_LANE")) : 32;
     HIPX_HIP(hipStreamSynchronize(st));
     fprintf(stderr, "[hipx sor] strand KIND %d aligned %d m %d L %d nstr %d npanels %d nbands %d nrows %d ntmpl %d ndep %d nold %d maxchunks %d lds %d grid %u  tid %p asrc %p t %p xold %p xnew %p ctl %p\n", KIND,
             (int)aligned, P.m, P.L, P.nstr, P.npanels, P.nbands, P.nrows, P.ntmpl, P.ndep, P.nold, P.maxchunks, P.lds_bytes, grid, (const void *)T->d_tid, (const void *)asrc, (void *)t, (const void *)xold,
@@ -1123,6 +1315,9 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
     fprintf(stderr, "[hipx sor] strand KIND %d done: panels %llu, compute iterations/panel %.0f, wall/panel %.1f us (%.3f us/iteration), rows %llu, lane-iterations waiting: operands %llu deps %llu, "
                     "fallback loads %llu, loader passes/panel %.0f (idle %.0f)\n",
             KIND, hs[8], hs[0] / np, hs[6] / np / 100.0, hs[0] ? hs[6] / 100.0 / (double)hs[0] : 0.0, hs[7], hs[1], hs[2], hs[5], hs[3] / np, hs[4] / np);
+    fprintf(stderr, "[hipx sor]   per panel (lane 0's view): iterations with a finishing lane %.0f, with a fallback lane %.0f, with a lane setting up %.0f; shader clocks: total %.0f (%.0f per "
+                    "iteration), in the burst %.0f (%.0f per iteration), in the finish path %.0f (%.0f per finishing iteration)\n",
+            hs[9] / np, hs[10] / np, hs[11] / np, hs[14] / np, hs[0] ? (double)hs[14] / hs[0] : 0.0, hs[12] / np, hs[0] ? (double)hs[12] / hs[0] : 0.0, hs[13] / np, hs[9] ? (double)hs[13] / hs[9] : 0.0);
     if (const char *dump = getenv("HIPX_SOR_DEBUG_DUMP")) {  // per panel: start, first row of lane 0, first row of lane 63, end (wall-clock ticks, 10 ns)
       std::vector<unsigned long long> pt(4 * (size_t)P.npanels);
       HIPX_HIP(hipMemcpy(pt.data(), T->d_stats + 16, sizeof(unsigned long long) * pt.size(), hipMemcpyDeviceToHost));
@@ -1134,6 +1329,17 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
         for (size_t i = 0; i < (size_t)P.npanels; i++)
           fprintf(f, "%zu %.2f %.2f %.2f %.2f\n", i, (pt[4 * i] - base) / 100.0, (pt[4 * i + 1] - base) / 100.0, (pt[4 * i + 2] - base) / 100.0, (pt[4 * i + 3] - base) / 100.0);
         fclose(f);
+      }
+      if (getenv("HIPX_SOR_TRACE_PANEL")) {
+        std::vector<unsigned long long> tr(64 * (size_t)P.L + 2 * 4096 * 8 + 64);
+        HIPX_HIP(hipMemcpy(tr.data(), T->d_stats + 16 + 4 * (size_t)P.npanels, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost));
+        snprintf(name, sizeof(name), "%s_trace%d.bin", dump, KIND);
+        if (FILE *f = fopen(name, "wb")) {
+          const long long hdr[4] = {(long long)P.L, 64, 4096, 8};
+          fwrite(hdr, sizeof(hdr), 1, f);
+          fwrite(tr.data(), sizeof(unsigned long long), tr.size(), f);
+          fclose(f);
+        }
       }
     }
   }

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Round 2, GPU call K: SOR compute wave with incremental row advance (one LDS burst per iteration).
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out"; mkdir -p "$O"
+echo "== sor tests"; timeout 900 python -m pytest tests/test_gpu_sor.py -x -q --timeout=300 -p no:cacheprovider > "$O/r2k_sor.log" 2>&1; tail -4 "$O/r2k_sor.log" | cut -c1-300
+echo "== slab proxy"; timeout 600 python scripts/config3_slab_proxy.py 2>&1 | grep -v amdgpu.ids | tee "$O/r2k_slab.log" | grep SOR
+HIPX_SOR_DEBUG=1 HIPX_SOR_DEBUG_DUMP="$O/r2k_sorpanels" timeout 300 python scripts/config3_slab_proxy.py 2>&1 | grep "hipx sor\]   per panel\|hipx sor\] strand KIND . done" | head -4 | cut -c1-600 | tee "$O/r2k_sorstats.log"
+echo "== 7pt 256 sor"; HIPX_SOR_DEBUG=1 timeout 300 python bench.py --ksp gmres --pc sor --stencil 7 --grid 256 --steps 30 --warmup 3 --quick 2>&1 | grep "strand KIND . done\|^{" | tail -3 | cut -c1-400 | tee "$O/r2k_sor7.log"
