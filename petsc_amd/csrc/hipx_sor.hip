@@ -369,6 +369,9 @@ constexpr int ST_LA   = 10;  // staging look-ahead beyond the leading consumer
 constexpr int ST_NB   = 3;   // bands of strands a panel may touch
 constexpr int ST_MAXW = 4;   // strands per band
 constexpr int ST_ME   = 16;  // most dependency entries a row may have on this schedule (27-point: 13)
+constexpr int ST_MF   = 12;  // split kernel: entries of the F wave (the first ones of the list) ...
+constexpr int ST_MC   = 4;   // ... and of the C wave (the last ones)
+constexpr int ST_CQ   = 4;   // depth of the F -> C hand-over ring (16-byte records)
 constexpr int ST_NULLPK  = 0x7fff7fff;  // pk of a padding entry
 constexpr int ST_NULLTAG = 0x7ffffff0;  // tag of the null slot (no row position reaches it)
 
@@ -380,6 +383,7 @@ struct StParams {
   int      nbands, nrows, ntmpl, ndep, nold, maxchunks;
   StBand   band[ST_NB];
   int      off_win, off_rowq, off_prog, off_ctl, off_tinfo, off_tdiag, off_dep, off_old, off_null, me, lds_bytes;
+  int      split, off_cq, off_progF, off_depF, off_depC;  // split kernel (ME 16): hand-over ring F -> C, F's progress, the two entry tables
   int      trace_it0;    // ... first iteration of the per-iteration log of lane trace_lane
   int      trace_rows;   // ... per-row stamps on (they cost one scattered store per row)
   int      trace_lane;   // ... and the loader lane whose passes are logged
@@ -460,22 +464,35 @@ __device__ __forceinline__ void st_lds_burst4(st_int4 (&o)[4], const unsigned (&
                : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
                : "memory");
 }
+__device__ __forceinline__ void st_lds_burst12(st_int4 (&o)[12], const unsigned (&a)[12])
+{
+  asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %9\n\tds_read_b128 %4, %10\n\tds_read_b128 %5, %11"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5])
+               : "memory");
+  asm volatile("ds_read_b128 %6, %12\n\tds_read_b128 %7, %13\n\tds_read_b128 %8, %14\n\tds_read_b128 %9, %15\n\tds_read_b128 %10, %16\n\tds_read_b128 %11, %17\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11])
+               : "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11])
+               : "memory");
+}
 template <int ME>
 __device__ __forceinline__ void st_lds_burst(st_int4 (&o)[ME], const unsigned (&a)[ME])
 {
   if constexpr (ME == 4) st_lds_burst4(o, a);
+  else if constexpr (ME == 12) st_lds_burst12(o, a);
   else st_lds_burst16(o, a);
 }
 // The per-iteration burst of the compute wave: the ME window slots of the current row AND the two halves of an operand-ring
 // record (32 bytes at `ra`) in one go, one wait.  The record's SECOND half (template id, tag) is read BEFORE the first one
 // (operands): the loader writes operands first and the tag last, and LDS executes a wave's accesses in order, so a tag that
 // reads as valid guarantees the operands read after it are the ones it belongs to.
-__device__ __forceinline__ void st_lds_burst_row16(st_int4 (&o)[16], st_int4 &w0, st_int4 &w1, const unsigned (&a)[16], unsigned ra)
+__device__ __forceinline__ void st_lds_burst_row16(st_int4 (&o)[16], st_int4 &w0, st_int4 &w1, const unsigned (&a)[16], unsigned ra, unsigned rt)
 {
   asm volatile("ds_read_b128 %0, %9\n\tds_read_b128 %1, %10\n\tds_read_b128 %2, %11\n\tds_read_b128 %3, %12\n\t"
-               "ds_read_b128 %4, %13\n\tds_read_b128 %5, %14\n\tds_read_b128 %6, %15\n\tds_read_b128 %7, %16\n\tds_read_b128 %8, %17 offset:16"
+               "ds_read_b128 %4, %13\n\tds_read_b128 %5, %14\n\tds_read_b128 %6, %15\n\tds_read_b128 %7, %16\n\tds_read_b128 %8, %17"
                : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(w1)
-               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(ra)
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(rt)
                : "memory");
   asm volatile("ds_read_b128 %9, %18\n\tds_read_b128 %10, %19\n\tds_read_b128 %11, %20\n\tds_read_b128 %12, %21\n\t"
                "ds_read_b128 %13, %22\n\tds_read_b128 %14, %23\n\tds_read_b128 %15, %24\n\tds_read_b128 %16, %25\n\tds_read_b128 %17, %26\n\t"
@@ -485,19 +502,35 @@ __device__ __forceinline__ void st_lds_burst_row16(st_int4 (&o)[16], st_int4 &w0
                : "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]), "v"(ra)
                : "memory");
 }
-__device__ __forceinline__ void st_lds_burst_row4(st_int4 (&o)[4], st_int4 &w0, st_int4 &w1, const unsigned (&a)[4], unsigned ra)
+__device__ __forceinline__ void st_lds_burst_row4(st_int4 (&o)[4], st_int4 &w0, st_int4 &w1, const unsigned (&a)[4], unsigned ra, unsigned rt)
 {
-  asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %9\n\tds_read_b128 %5, %10 offset:16\n\t"
+  asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %9\n\tds_read_b128 %5, %11\n\t"
                "ds_read_b128 %4, %10\n\ts_waitcnt lgkmcnt(0)"
                : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(w0), "=&v"(w1)
-               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(ra)
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(ra), "v"(rt)
+               : "memory");
+}
+__device__ __forceinline__ void st_lds_burst_row12(st_int4 (&o)[12], st_int4 &w0, st_int4 &w1, const unsigned (&a)[12], unsigned ra, unsigned rt)
+{
+  asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %8\n\tds_read_b128 %2, %9\n\tds_read_b128 %3, %10\n\tds_read_b128 %4, %11\n\tds_read_b128 %5, %12\n\t"
+               "ds_read_b128 %6, %13"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(w1)
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(rt)
+               : "memory");
+  asm volatile("ds_read_b128 %7, %14\n\tds_read_b128 %8, %15\n\tds_read_b128 %9, %16\n\tds_read_b128 %10, %17\n\tds_read_b128 %11, %18\n\tds_read_b128 %12, %19\n\t"
+               "ds_read_b128 %13, %20\n\ts_waitcnt lgkmcnt(0)"
+               : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(w1), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]),
+                 "=&v"(w0)
+               : "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(ra)
                : "memory");
 }
 template <int ME>
-__device__ __forceinline__ void st_lds_burst_row(st_int4 (&o)[ME], st_int4 &w0, st_int4 &w1, const unsigned (&a)[ME], unsigned ra)
+__device__ __forceinline__ void st_lds_burst_row(st_int4 (&o)[ME], st_int4 &w0, st_int4 &w1, const unsigned (&a)[ME], unsigned ra, unsigned rt)
 {
-  if constexpr (ME == 4) st_lds_burst_row4(o, w0, w1, a, ra);
-  else st_lds_burst_row16(o, w0, w1, a, ra);
+  // w1 <- 16 bytes at rt (the half that carries the tag: read FIRST), w0 <- 16 bytes at ra
+  if constexpr (ME == 4) st_lds_burst_row4(o, w0, w1, a, ra, rt);
+  else if constexpr (ME == 12) st_lds_burst_row12(o, w0, w1, a, ra, rt);
+  else st_lds_burst_row16(o, w0, w1, a, ra, rt);
 }
 // agent-scope 8-byte load, complete on return (rare paths only: it drains this wave's stores as well)
 __device__ __forceinline__ unsigned long long st_gload64_wait(const void *p)
@@ -526,42 +559,585 @@ __device__ __forceinline__ int st_strand_len(long long S, const StParams &P)
   return (int)(rem < P.L ? rem : P.L);
 }
 
-// KIND as in sor_level_kernel: 0 fwd zero guess, 1 bwd with t, 2 bwd zero guess, 3 fwd general, 4 bwd whole row
-// ME: dependency entries per row the compute wave handles (the templates' lists are padded to ME with null entries: coefficient 0,
-// pointing at a slot that always reads {0.0, ST_NULLTAG}); 4 for the 5-/7-point operators, 16 for the 27-point one
-template <int KIND, bool ALIGNED, int ME>
-__global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const unsigned char *__restrict__ tid, const StTinfo *__restrict__ g_tinfo, const StDiag *__restrict__ g_tdiag,
-                                                         const StEntry *__restrict__ g_dep, const StEntry *__restrict__ g_old, const double *asrc, double *t, const double *xold,
-                                                         double *xnew, double omega, unsigned int *ctl, unsigned long long *stats)
+// One compute role of a panel.  ROLE 0: the whole row (two-wave kernel: ME = 4 or 16 entries).  SPLIT kernel (27-point class, ME 16):
+// ROLE 1 = the F wave: the first 12 entries of the row's list -- the far ones, staged by the loader long before they are needed --
+// subtracted from the operand; the partial sum goes to the C wave through a two-deep LDS ring.  ROLE 2 = the C wave: the last
+// (at most) 4 entries -- the previous line of the same plane and the row's own predecessor: the ones the NEXT lane is waiting
+// for -- then the scale, the publish, the stores.  The lane-to-lane critical path of a line is then ~1/3 of the instructions.
+// The left-to-right order of the subtractions is unchanged (F's end is C's start), so the sums are bit-identical.
+template <int KIND, int ME, int ROLE>
+__device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *lds, const unsigned lds_base, volatile st_lds_int *s_prog_own, volatile st_lds_int *s_prog_c,
+                                                volatile st_lds_int *s_ctl, unsigned int *err, const int lane, const unsigned panel, const long long S, const int len, double *t,
+                                                const double *xold, double *xnew, const double omega, unsigned long long *stats, const int par,
+                                                unsigned long long *fst = nullptr)
+{
+  constexpr bool FWD = (KIND == 0 || KIND == 3);
+  const hipx_int m = P.m, L = P.L;
+  const int      stride = ROLE == 1 ? 2 : 1;  // the two F waves take the even and the odd rows of every strand (row sums do not depend on each other)
+  int       p = ROLE == 1 ? par : 0, ostart = 0, ocnt = 0, dtab = 0, cur_tid = -1, setp = 0;  // setp: the position apos[] / sa[] are set for; dtab: byte offset of the template's entry list
+  bool      have = false;
+  double    s0 = 0.0, rb = 0.0, idiag = 0.0, mdiag = 0.0;
+  unsigned  sa[ME];    // LDS byte address of the slot of entry j for the row at position p
+  unsigned  wrow[ME];  // ... of slot 0 of its window row (the null slot for a padding entry)
+  int       msk[ME];   // ST_WP - 1, or 0 for a padding entry (its address does not move)
+  int       apos[ME];  // the tag the slot must carry: position + rotation of the window row (the slot is apos & 15)
+  double    cf[ME];    // coefficient
+#pragma unroll
+  for (int j = 0; j < ME; j++) {
+    sa[j] = wrow[j] = lds_base + (unsigned)P.off_null;
+    msk[j]  = 0;
+    apos[j] = ST_NULLTAG;
+    cf[j]   = 0.0;
+  }
+  // the per-row record {operand a | partial sum, old value}{template id, tag}: from the loader's operand ring, or (ROLE 2) from the
+  // two-deep hand-over ring the F wave fills
+  const unsigned rec_base = lds_base + (unsigned)(P.off_rowq + 32 * ST_RQ * lane);
+  const unsigned cq_base  = lds_base + (unsigned)(P.off_cq + 16 * ST_CQ * lane);  // SPLIT: {partial sum, template id, tag}, ST_CQ deep
+  const int      rq_rot   = ST_ROT * lane;
+  unsigned       pubrow[ST_NB];  // this lane's own window row in band b (byte address of slot 0), ~0u: the band has none for it
+  int            pubrot[ST_NB];  // ... and its slot rotation
+#pragma unroll
+  for (int b = 0; b < ST_NB; b++) {
+    pubrow[b] = ~0u;
+    pubrot[b] = 0;
+    if (b < P.nbands) {
+      const int u = lane - P.band[b].dsmin;
+      if (u >= 0 && u < 64 + P.band[b].width - 1) {
+        pubrow[b] = lds_base + (unsigned)(P.off_win + 16 * ST_WP * (P.band[b].rowbase + u));
+        pubrot[b] = ST_ROT * (P.band[b].rowbase + u);
+      }
+    }
+  }
+  unsigned  st_iters = 0, st_rowwait = 0, st_depwait = 0, st_fallback = 0;  // HIPX_SOR_DEBUG statistics (stats != nullptr)
+  unsigned  f_far = 0, f_full = 0, f_fire = 0, f_row = 0;
+  unsigned  st_nfast = 0, st_nslow = 0, st_nsetup = 0;                     // iterations in which ANY lane took the path
+  long long st_cburst = 0, st_cfast = 0;                                   // shader clocks spent in the burst / in the fast finish
+  const long long st_t0 = stats ? (long long)wall_clock64() : 0;
+  const long long st_c0 = stats ? (long long)clock64() : 0;
+  if (stats && lane == 0) stats[16 + 4 * (size_t)panel] = (unsigned long long)st_t0;
+  long long t0 = 0;
+  // the template of the row at position p has changed (first row, boundary rows): entry table -> registers
+  auto load_template = [&](int tnew) __attribute__((always_inline)) {
+    st_int4 ti = {0, 0, 0, 0}, dg = {0, 0, 0, 0};
+    if (ROLE != 1) {
+      ti = st_ld4(lds, P.off_tinfo + 16 * tnew);
+      dg = st_ld4(lds, P.off_tdiag + 16 * tnew);
+    }
+    dtab   = ROLE == 0 ? P.off_dep + 16 * ti.x : (ROLE == 1 ? P.off_depF : P.off_depC) + 16 * ME * tnew;
+    ostart = ti.z;
+    ocnt   = ti.w;
+    st_int4  e[ME];
+    unsigned ea[ME];
+#pragma unroll
+    for (int j = 0; j < ME; j++) ea[j] = lds_base + (unsigned)(dtab + 16 * j);
+    st_lds_burst<ME>(e, ea);
+#pragma unroll
+    for (int j = 0; j < ME; j++) {
+      const bool null = e[j].x == ST_NULLPK;
+      const int wr = lane + (e[j].x >> 16);  // window row
+      wrow[j] = lds_base + (unsigned)(null ? P.off_null : P.off_win + 16 * ST_WP * wr);
+      msk[j]  = null ? 0 : ST_WP - 1;
+      apos[j] = null ? ST_NULLTAG : p + (int)(short)(e[j].x & 0xffff) + ST_ROT * wr;
+      sa[j]   = wrow[j] + (unsigned)((apos[j] & msk[j]) << 4);
+      cf[j]   = st_dbl(e[j].z, e[j].w);
+    }
+    idiag   = st_dbl(dg.x, dg.y);
+    mdiag   = st_dbl(dg.z, dg.w);
+    cur_tid = tnew;
+    setp    = p;
+  };
+  // operands of the row at position p have arrived (w0 = {a, old value}, w1 = {template id, tag})
+  auto start_row = [&](const st_int4 &w0, const st_int4 &w1) __attribute__((always_inline)) {
+    s0 = st_dbl(w0.x, w0.y);
+    rb = st_dbl(w0.z, w0.w);
+    if (w1.x != cur_tid) load_template(w1.x);
+    else if (setp != p) {  // same template, the next position (p = setp + 1): every tag and slot moves on by one
+      const int step = p - setp;
+#pragma unroll
+      for (int j = 0; j < ME; j++) {
+        apos[j] += (msk[j] & 1) * step;  // (a padding entry stays where it is)
+        sa[j] = wrow[j] + (unsigned)((apos[j] & msk[j]) << 4);
+      }
+      setp = p;
+    }
+    have = true;
+    if (KIND == 4) {  // aij.c:1984-1990: the lower part and the diagonal use OLD values, in row order, first
+      const hipx_int r = st_actual<FWD>(S * L + p, m);
+      for (int q2 = 0; q2 < ocnt; q2++) {
+        const st_int4 oe = st_ld4(lds, P.off_old + 16 * (ostart + q2));
+        s0 -= st_dbl(oe.z, oe.w) * xold[(long long)r + oe.x];
+      }
+    }
+  };
+  // Two panels share a CU and their compute waves may share a SIMD: a wave that spins on values that are not there yet takes
+  // issue cycles from one that has work (measured: panels next to a spinning neighbour ran at 2.9 us per row instead of 1.4).
+  // So the wave runs at raised priority and, after an iteration in which none of its lanes finished a row, sleeps briefly.
+  __builtin_amdgcn_s_setprio(3);
+  int idle = 0;
+  for (unsigned it = 1;; it++) {
+    const bool active = p < len;
+    if (!__any(active)) break;
+    st_iters++;
+    const int  p_before    = p;
+    const bool have_before = have;
+    int        dbg_diff = 0x7ffffff, dbg_rtag = -2, dbg_mask = 0;
+    const bool dbg_on = stats && P.trace_panel == (int)panel && lane == P.trace_lane;
+    long long  dbg_c0 = dbg_on ? (long long)clock64() : 0, dbg_c1 = 0, dbg_c2 = 0, dbg_c3 = 0;
+    asm volatile("" ::: "memory");  // other waves have written LDS since the last iteration: re-read, do not reuse
+    if (active) {
+      // ONE burst per iteration: the ME slots of the current row and the operand record of the NEXT row (of the current one
+      // while it is still missing); one wait
+      st_int4        sl[ME], w0, w1;
+      const int      qr = have ? p + stride : p;
+      const unsigned ra = rec_base + (unsigned)(32 * ((qr + rq_rot) & (ST_RQ - 1)));
+      const unsigned rt = ROLE == 2 ? cq_base + (unsigned)(16 * (qr & (ST_CQ - 1))) : ra + 16;
+      const long long c_b0 = stats ? (long long)clock64() : 0;
+      st_lds_burst_row<ME>(sl, w0, w1, sa, ra, rt);
+      if (ROLE == 2) {  // w1 is F's record {sum, id, tag}, w0 the loader's {a, old value} of the same row (valid while C has not passed it:
+                        // the loader recycles ring slots by C's progress): bring both into the usual shape
+        w0.x = w1.x;
+        w0.y = w1.y;
+        w1.x = w1.z;
+        w1.y = w1.w;
+      }
+      dbg_rtag = w1.y;
+      if (__any(!have)) dbg_mask |= 1 << 29;
+      if (stats) st_cburst += (long long)clock64() - c_b0;
+      if (stats && __any(!have)) st_nsetup++;
+      if (!have) {
+        if (w1.y == p) start_row(w0, w1);  // (the slots read above belonged to no row: compute in the next iteration)
+        else {
+          st_rowwait++;
+          if (ROLE == 1 && fst && lane == 32) f_row++;
+        }
+      } else {
+        const long long q = S * L + p;
+        const hipx_int  r = st_actual<FWD>(q, m);
+        int             diff = 0;  // OR of (tag - expected): 0 = all there; negative = at least one not produced yet (wait, nothing
+                                   // else to find out); positive = a slot has moved on (rare: the value comes from memory)
+#pragma unroll
+        for (int j = 0; j < ME; j++) diff |= sl[j].z - apos[j];
+        if (ROLE == 1 && fst && lane == 32) {  // F-wave statistics (HIPX_SOR_DEBUG): lane 32's view
+          if (diff < 0) f_far++;
+          else if (p - (int)s_prog_c[lane] > ST_CQ - 1) f_full++;
+          else if (diff == 0) f_fire++;
+        }
+        if (ROLE == 1 && p - (int)s_prog_c[lane] > ST_CQ - 1) diff |= (int)0x80000000;  // the hand-over slot still holds row p - ST_CQ: wait for C
+        if (dbg_on) dbg_c1 = (long long)clock64();  // (moves the burst/compare boundary to here: burst + whatever the !have lanes did + the tag compare)
+        if (__any(diff > 0)) dbg_mask |= 1 << 30;
+        if (stats && P.trace_panel == (int)panel && lane == P.trace_lane) {
+          dbg_diff = diff;
+#pragma unroll
+          for (int j = 0; j < ME; j++) dbg_mask |= (sl[j].z < apos[j] ? 1 : 0) << j;
+        }
+        // the row's values are all there: subtraction chain, scale, publish, move on to the next row
+        auto finish = [&](const double (&val)[ME]) __attribute__((always_inline)) {
+          double sum = s0;
+#pragma unroll
+          for (int j = 0; j < ME; j++) sum -= cf[j] * val[j];  // left to right (PetscSparseDenseMinusDot); null entries subtract +0.0
+          if (ROLE == 1) {  // hand the partial sum and the template id to the C wave
+            const long long bs = __double_as_longlong(sum);
+            *reinterpret_cast<volatile st_lds_int4 *>((st_lds_char *)(size_t)(cq_base + (unsigned)(16 * (p & (ST_CQ - 1))))) =
+              st_int4{(int)(unsigned)bs, (int)(unsigned)((unsigned long long)bs >> 32), cur_tid, p};  // one 16-byte store: sum and tag arrive together
+            p += stride;
+            have = false;
+            asm volatile("" ::: "memory");
+            if (p < len && w1.y == p) start_row(w0, w1);
+            return;
+          }
+          double out;
+          if (KIND == 0) {
+            t[r] = sum;
+            out  = sum * idiag;
+          } else if (KIND == 1) {
+            out = (1 - omega) * rb + sum * idiag;
+          } else if (KIND == 2) {
+            out = sum * idiag;
+          } else if (KIND == 3) {
+            t[r] = sum;
+            for (int e2 = 0; e2 < ocnt; e2++) {  // upper part: old values (aij.c:1973-1976)
+              const st_int4 oe = st_ld4(lds, P.off_old + 16 * (ostart + e2));
+              sum -= st_dbl(oe.z, oe.w) * xold[(long long)r + oe.x];
+            }
+            out = (1. - omega) * rb + sum * idiag;
+          } else {
+            out = (1. - omega) * rb + (sum + mdiag * rb) * idiag;
+          }
+#pragma unroll
+          for (int b = 0; b < ST_NB; b++)
+            if (pubrow[b] != ~0u)  // the tag is the position plus the row's rotation; so is the slot
+              *reinterpret_cast<volatile st_lds_int4 *>((st_lds_char *)(size_t)(pubrow[b] + (unsigned)(((p + pubrot[b]) & (ST_WP - 1)) << 4))) = st_pack_slot(out, p + pubrot[b]);
+          sor_publish(xnew + r, out);
+          if (stats && p == 0 && (lane == 0 || lane == 63)) stats[16 + 4 * (size_t)panel + (lane ? 2 : 1)] = (unsigned long long)wall_clock64();
+          if (stats && P.trace_panel == (int)panel && P.trace_rows)  // HIPX_SOR_TRACE_PANEL: completion time of every row of this panel
+            stats[16 + 4 * (size_t)P.npanels + (size_t)lane * (size_t)L + (size_t)p] = (unsigned long long)wall_clock64();
+          p++;
+          have = false;
+          asm volatile("" ::: "memory");
+          if (p < len && w1.y == p) start_row(w0, w1);  // the next row's operands came with this iteration's burst
+        };
+        if (stats && __any(diff == 0)) st_nfast++;
+        if (stats && __any(diff > 0)) st_nslow++;
+        if (!diff) {  // the common case: straight from the registers the burst filled
+          double val[ME];
+#pragma unroll
+          for (int j = 0; j < ME; j++) val[j] = st_dbl(sl[j].x, sl[j].y);
+          const long long c_f0 = stats ? (long long)clock64() : 0;
+          if (dbg_on) dbg_c2 = c_f0;
+          finish(val);
+          if (stats) st_cfast += (long long)clock64() - c_f0;
+          if (dbg_on) dbg_c3 = (long long)clock64();
+        } else if (diff < 0) {
+          st_depwait++;
+          if (stats && P.trace_panel == (int)panel && P.trace_rows) {  // which entry is late?  (first one in arithmetic order), all lanes together + lane 0 alone
+            int jf = 0, jtag = 0, jexp = 0;  // (selects, not indexed reads: a register array indexed at run time goes to scratch)
+#pragma unroll
+            for (int j = ME - 1; j >= 0; j--)
+              if (sl[j].z < apos[j]) {
+                jf   = j;
+                jtag = sl[j].z;
+                jexp = apos[j];
+              }
+            unsigned long long *h = stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)L + 2 * 4096 * 8;
+            atomicAdd(&h[jf], 1ull);
+            if (lane == 0) atomicAdd(&h[16 + jf], 1ull);
+            if (lane == 32) atomicAdd(&h[32 + jf], 1ull);
+          }
+        } else {  // no tag behind, at least one ahead: the slot has moved on (this lane fell far behind its producer)
+          bool   ok = true;
+          double val[ME];
+#pragma unroll
+          for (int j = 0; j < ME; j++) {
+            val[j] = st_dbl(sl[j].x, sl[j].y);
+            if (sl[j].z < apos[j]) ok = false;
+            else if (sl[j].z > apos[j]) {
+              const int                elo = st_ld4(lds, dtab + 16 * j).y;  // logical row offset of the entry
+              const unsigned long long v   = st_gload64_wait(xnew + st_actual<FWD>(q + elo, m));
+              st_fallback++;
+              if (v == SOR_SENTINEL) ok = false;
+              else val[j] = __longlong_as_double((long long)v);
+            }
+          }
+          if (ok) finish(val);
+          else st_depwait++;
+        }
+      }
+    }
+    s_prog_own[lane] = p;
+    if (ROLE == 1 && s_ctl[1]) break;  // C has given up (bounded wait)
+    if (stats && P.trace_panel == (int)panel && lane == P.trace_lane && (int)it >= P.trace_it0 && (int)it < P.trace_it0 + 4096) {  // iteration log of one lane
+      unsigned long long *ev = stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)L + 4096 * 8 + (size_t)((int)it - P.trace_it0) * 8;
+      ev[0] = (unsigned long long)wall_clock64();
+      ev[1] = (unsigned long long)it;
+      ev[2] = (unsigned long long)p_before;
+      ev[3] = (unsigned long long)p;
+      ev[4] = (unsigned long long)((have_before ? 1 : 0) | (have ? 2 : 0));
+      ev[5] = (unsigned long long)(unsigned)dbg_diff | ((unsigned long long)(unsigned)(dbg_c1 - dbg_c0) << 32);       // burst
+      ev[6] = (unsigned long long)(unsigned)(dbg_c2 - dbg_c1) | ((unsigned long long)(unsigned)(dbg_c3 - dbg_c2) << 32);  // compare | finish
+      ev[7] = (unsigned long long)(unsigned)dbg_mask | ((unsigned long long)(unsigned)((long long)clock64() - dbg_c0) << 32);  // whole iteration so far
+    }
+    if (!__any(p != p_before || have != have_before)) {
+      idle = idle < 4 ? idle + 1 : 4;
+      if (idle >= 2) __builtin_amdgcn_s_sleep(2);   // ~128 clocks; the loader pass that can change anything takes thousands
+    } else idle = 0;
+    if (ROLE != 1 && (it & 0x3ff) == 0) {  // bounded wait: elapsed wall-clock time, and a global abort word so one stuck panel ends the launch
+      const long long now = (long long)wall_clock64();
+      if (!t0) t0 = now;
+      const unsigned abort_word = st_gload32_wait(err);
+      if (abort_word || now - t0 > SOR_SPIN_TICKS) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __builtin_amdgcn_s_setprio(0);
+  if (ROLE == 1) {
+    if (fst && lane == 32) {
+      atomicAdd(&fst[0], (unsigned long long)st_iters);
+      atomicAdd(&fst[1], (unsigned long long)f_row);
+      atomicAdd(&fst[2], (unsigned long long)f_far);
+      atomicAdd(&fst[3], (unsigned long long)f_full);
+      atomicAdd(&fst[4], (unsigned long long)f_fire);
+    }
+    return;
+  }
+  if (lane == 0) s_ctl[1] = 1;
+  if (stats) {
+    for (int o = 32; o > 0; o >>= 1) {  // the finish-path clocks of the lane that finished most often
+      const long long other = __shfl_xor(st_cfast, o);
+      st_cfast = other > st_cfast ? other : st_cfast;
+    }
+    atomicAdd(&stats[1], (unsigned long long)st_rowwait);
+    atomicAdd(&stats[2], (unsigned long long)st_depwait);
+    atomicAdd(&stats[5], (unsigned long long)st_fallback);
+    atomicAdd(&stats[7], (unsigned long long)len);
+    if (lane == 0) {
+      atomicAdd(&stats[0], (unsigned long long)st_iters);
+      atomicAdd(&stats[9], (unsigned long long)st_nfast);
+      atomicAdd(&stats[10], (unsigned long long)st_nslow);
+      atomicAdd(&stats[11], (unsigned long long)st_nsetup);
+      atomicAdd(&stats[12], (unsigned long long)st_cburst);
+      atomicAdd(&stats[13], (unsigned long long)st_cfast);
+      atomicAdd(&stats[14], (unsigned long long)((long long)clock64() - st_c0));
+      atomicAdd(&stats[6], (unsigned long long)((long long)wall_clock64() - st_t0));
+      atomicAdd(&stats[8], 1ull);
+      stats[16 + 4 * (size_t)panel + 3] = (unsigned long long)wall_clock64();
+    }
+  }
+}
+
+// The loader wave of a panel: operands of the own strands into the operand ring, far strands into the window.
+template <int KIND, bool ALIGNED, bool SPLIT>
+__device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *lds, volatile st_lds_int *s_lead, volatile st_lds_int *s_trail, volatile st_lds_int *s_ctl, const int lane,
+                                               const unsigned panel, const long long S0, const long long S, const int len, const unsigned char *__restrict__ tid, const double *asrc,
+                                               const double *xold, const double *xnew, unsigned long long *stats)
 {
   constexpr bool FWD     = (KIND == 0 || KIND == 3);
   constexpr bool NEEDOLD = (KIND == 1 || KIND == 3 || KIND == 4);  // the row's own old value
+  const hipx_int m = P.m, L = P.L;
+  int rqf = 0;  // next position of the own strand whose operands are to be staged
+  unsigned st_pass = 0, st_idle = 0;
+  int sf[2 * ST_NB];
+#pragma unroll
+  for (int d = 0; d < 2 * ST_NB; d++) sf[d] = 0;
+  // which far duties does this lane have at all (fixed for the panel)?  The second half (d >= ST_NB) is empty for most patterns:
+  // its loads, registers and LDS writes are skipped as a whole
+  bool dvalid[2 * ST_NB];
+  bool any_hi = false;
+#pragma unroll
+  for (int d = 0; d < 2 * ST_NB; d++) {
+    const int b = d >> 1, which = d & 1;
+    dvalid[d]   = false;
+    if (b < P.nbands) {
+      const int       w = P.band[b].width, u = lane + 64 * which;
+      const long long strand = S0 + u + P.band[b].dsmin;
+      dvalid[d] = u < 64 + w - 1 && (strand < S0 || strand > S0 + 63) && strand >= 0 && strand < P.nstr;
+    }
+    if (d >= ST_NB && dvalid[d]) any_hi = true;
+  }
+  const bool wave_hi = __any(any_hi);
+  for (;;) {
+    if (s_ctl[1]) break;
+    bool      issued = false;
+    // SPLIT: s_lead = the two F waves' progress arrays (even rows, odd rows): every row below the smaller one has been consumed
+    const int myp    = SPLIT ? min((int)s_lead[lane], (int)s_lead[64 + lane]) : (int)s_lead[lane];
+    // (a) operands of the own strand: up to ST_SB positions from rqf on, in groups of 4, as far as the ring has room.  (Whole
+    // groups of 8 only -- the first version -- capped the strand at 8 rows per two passes: ~0.9 us per row.)
+    int           nrow = 0;
+    double        va[ST_SB], vb[ST_SB];
+    unsigned char vt[ST_SB];
+    unsigned      tb[2] = {0, 0};  // ALIGNED: the template ids of each group of 4 as loaded; unpacked when they land
+    const int ring_tail = SPLIT ? (int)s_trail[lane] : myp;  // SPLIT: the C wave still reads the row's old value from the ring
+    if (rqf < len) {
+      int room = (ring_tail + ST_RQ - rqf) & ~3;
+      if (room > ST_SB) room = ST_SB;
+      nrow = (len - rqf) < room ? (len - rqf) : room;
+    }
+    if (nrow > 0) {
+      issued = true;
+      const long long q0 = S * L + rqf;
+      if (ALIGNED) {  // L, m multiples of 8 and 16-byte aligned vectors: every group of 4 rows is one aligned 32-byte run
+        typedef double dbl2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+          if (4 * g < nrow) {
+            const long long qg = q0 + 4 * g;
+            const hipx_int  rg = FWD ? (hipx_int)qg : (hipx_int)((long long)m - 4 - qg);  // lowest actual row of the group
+            const dbl2     *pa = reinterpret_cast<const dbl2 *>(asrc + rg);
+            const dbl2     *pb = reinterpret_cast<const dbl2 *>(xold + (NEEDOLD ? rg : 0));
+            tb[g]              = *reinterpret_cast<const unsigned *>(tid + rg);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const dbl2 a2 = pa[h];
+              dbl2       b2 = {0.0, 0.0};
+              if (NEEDOLD) b2 = pb[h];
+              const int j0 = 4 * g + (FWD ? 2 * h : 3 - 2 * h), j1 = 4 * g + (FWD ? 2 * h + 1 : 2 - 2 * h);
+              va[j0] = a2.x;
+              va[j1] = a2.y;
+              vb[j0] = b2.x;
+              vb[j1] = b2.y;
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < ST_SB; j++) {
+          const hipx_int r = st_actual<FWD>(q0 + (j < nrow ? j : nrow - 1), m);
+          va[j]            = asrc[r];
+          vb[j]            = NEEDOLD ? xold[r] : 0.0;
+          vt[j]            = tid[r];
+        }
+      }
+    }
+    // (b) far strands: every duty = one window row of another panel's strand, staged ahead of its consumers.  Two rounds of
+    // ST_NB duties (the second one is usually empty), so that only ST_NB * ST_SB values are in registers at a time.
+    int fn[2 * ST_NB];
+#pragma unroll
+    for (int d = 0; d < 2 * ST_NB; d++) fn[d] = 0;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      if (half == 1 && !wave_hi) break;
+      unsigned long long fv[ST_NB][ST_SB];
+      int                frow[ST_NB];
+#pragma unroll
+      for (int i = 0; i < ST_NB; i++) {
+        const int d = half * ST_NB + i;
+        frow[i]     = 0;
+        if (dvalid[d]) {
+          const int       b = d >> 1, which = d & 1;
+          const int       w = P.band[b].width, u = lane + 64 * which;
+          const long long strand = S0 + u + P.band[b].dsmin;
+          int lead = -1000000, trail = 1000000;  // most / least advanced consumer of this row that is still running
+          for (int c = u - (w - 1); c <= u; c++) {
+            if (c >= 0 && c < 64) {
+              const int pl = SPLIT ? max((int)s_lead[c], (int)s_lead[64 + c]) : (int)s_lead[c], pt = s_trail[c];  // (SPLIT: the F waves lead, the C wave trails)
+              if (pt < st_strand_len(S0 + c, P)) {
+                if (pl > lead) lead = pl;
+                if (pt < trail) trail = pt;
+              }
+            }
+          }
+          const int slen = st_strand_len(strand, P);
+          int       tgt  = lead + ST_LA + 1;
+          // ... but never over a slot the slowest consumer still needs: position q goes where q - 16 was, and a consumer at
+          // `trail` reads positions >= trail - 1.  (Without this bound a panel whose producers are far ahead always stages to
+          // the limit, the third consumer of a row -- four positions behind the first -- finds its slot gone, takes the
+          // memory path, which drains the wave's stores (~2 us), falls further behind ...: measured, a whole plane at 3 us
+          // per row instead of 1.3, and every later plane behind it.)
+          if (tgt > trail + ST_WP - 2) tgt = trail + ST_WP - 2;
+          if (tgt > slen) tgt = slen;
+          int n = tgt - sf[d];
+          if (n > ST_SB) n = ST_SB;
+          if (n > 0) {
+            issued  = true;
+            fn[d]   = n;
+            frow[i] = P.band[b].rowbase + u;
+            const long long q0 = strand * L + sf[d];
+#pragma unroll
+            for (int j = 0; j < ST_SB; j++) {
+              const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xnew + st_actual<FWD>(q0 + (j < n ? j : n - 1), m));
+              fv[i][j] = P.poll_sys ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
+      }
+      // everything of this round is in flight; now land it in LDS (first round: the operands too)
+      if (half == 0 && nrow > 0) {
+        if (ALIGNED) {
+#pragma unroll
+          for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) vt[4 * g + (FWD ? k : 3 - k)] = (unsigned char)(tb[g] >> (8 * k));
+        }
+#pragma unroll
+        for (int j = 0; j < ST_SB; j++) {
+          if (j < nrow) {
+            const int       ro = P.off_rowq + 32 * (lane * ST_RQ + ((rqf + j + ST_ROT * lane) & (ST_RQ - 1)));
+            const long long ba = __double_as_longlong(va[j]), bb = __double_as_longlong(vb[j]);
+            st_int4         w0, w1;
+            w0.x = (int)(unsigned)ba;
+            w0.y = (int)(unsigned)((unsigned long long)ba >> 32);
+            w0.z = (int)(unsigned)bb;
+            w0.w = (int)(unsigned)((unsigned long long)bb >> 32);
+            w1.x = (int)vt[j];
+            w1.y = rqf + j;
+            w1.z = 0;
+            w1.w = 0;
+            st_st4v(lds, ro, w0);  // operands first, tag last: the compute wave tests the tag (LDS executes a wave's accesses in order)
+            st_st4v(lds, ro + 16, w1);
+          }
+        }
+        rqf += nrow;
+      }
+#pragma unroll
+      for (int i = 0; i < ST_NB; i++) {
+        const int d = half * ST_NB + i;
+        if (fn[d] > 0) {
+          int  cnt = 0;
+          bool acc = true;
+#pragma unroll
+          for (int j = 0; j < ST_SB; j++) {
+            if (j < fn[d] && acc && fv[i][j] != SOR_SENTINEL) {
+              st_st4v(lds, P.off_win + 16 * (frow[i] * ST_WP + ((sf[d] + j + ST_ROT * frow[i]) & (ST_WP - 1))), st_pack_slot(__longlong_as_double((long long)fv[i][j]), sf[d] + j + ST_ROT * frow[i]));
+              cnt++;
+            } else acc = false;
+          }
+          sf[d] += cnt;
+        }
+      }
+    }
+    if (stats && P.trace_panel == (int)panel && st_pass < 4096 && lane == P.trace_lane) {  // trace: the loader's view
+      unsigned long long *tr = stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)L + (size_t)st_pass * 8;
+      tr[0] = (unsigned long long)wall_clock64();
+      tr[1] = (unsigned long long)myp;
+      tr[2] = (unsigned long long)rqf;
+#pragma unroll
+      for (int d = 0; d < 3; d++) tr[3 + d] = (unsigned long long)sf[d];
+      tr[6] = (unsigned long long)(fn[0] | (fn[1] << 8) | (fn[2] << 16));  // rows asked for in this pass
+      tr[7] = (unsigned long long)(nrow | (s_trail[0] << 8) | ((unsigned long long)s_trail[1] << 24) | ((unsigned long long)s_trail[2] << 40));
+    }
+    st_pass++;
+    if (!__any(issued)) {
+      st_idle++;
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  if (stats && lane == 0) {
+    atomicAdd(&stats[3], (unsigned long long)st_pass);
+    atomicAdd(&stats[4], (unsigned long long)st_idle);
+  }
+}
+
+// KIND as in sor_level_kernel: 0 fwd zero guess, 1 bwd with t, 2 bwd zero guess, 3 fwd general, 4 bwd whole row
+// ME: dependency entries per row (the templates' lists are padded to ME with null entries: coefficient 0, pointing at a slot that
+// always reads {0.0, ST_NULLTAG}); 4 for the 5-/7-point operators, 16 for the 27-point one.  SPLIT (ME 16 only): three waves
+// per panel -- C, F, loader (see st_compute_role) -- instead of compute + loader.
+template <int KIND, bool ALIGNED, int ME, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 256 : 128, SPLIT ? 2 : 1) void sor_strand_kernel(const StParams P, const unsigned char *__restrict__ tid, const StTinfo *__restrict__ g_tinfo,
+                                                                       const StDiag *__restrict__ g_tdiag, const StEntry *__restrict__ g_dep, const StEntry *__restrict__ g_old,
+                                                                       const StEntry *__restrict__ g_depF, const StEntry *__restrict__ g_depC, const double *asrc, double *t,
+                                                                       const double *xold, double *xnew, double omega, unsigned int *ctl, unsigned long long *stats)
+{
+  constexpr int NT = SPLIT ? 256 : 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   st_lds_char          *lds    = (st_lds_char *)smem;
   const unsigned        lds_base = (unsigned)(size_t)lds;  // byte address of the dynamic LDS region (for the hand-issued reads)
-  volatile st_lds_int  *s_prog = (volatile st_lds_int *)(lds + P.off_prog);
-  volatile st_lds_int  *s_ctl  = (volatile st_lds_int *)(lds + P.off_ctl);
+  volatile st_lds_int  *s_prog  = (volatile st_lds_int *)(lds + P.off_prog);   // progress of the compute (C) wave's lanes
+  volatile st_lds_int  *s_progF = (volatile st_lds_int *)(lds + P.off_progF);  // SPLIT: progress of the two F waves' lanes (64 + 64)
+  volatile st_lds_int  *s_ctl   = (volatile st_lds_int *)(lds + P.off_ctl);
   unsigned int *err  = ctl + 1;
   const int     lane = threadIdx.x & 63;
-  const bool    loader = threadIdx.x >= 64;
-  const hipx_int m = P.m, L = P.L;
+  const int     wave = threadIdx.x >> 6;
   // template tables -> LDS (16-byte records)
-  for (int i = threadIdx.x; i < P.ntmpl; i += 128) {
+  for (int i = threadIdx.x; i < P.ntmpl; i += NT) {
     st_st4v(lds, P.off_tinfo + 16 * i, reinterpret_cast<const st_int4 *>(g_tinfo)[i]);
     st_st4v(lds, P.off_tdiag + 16 * i, reinterpret_cast<const st_int4 *>(g_tdiag)[i]);
   }
-  for (int i = threadIdx.x; i < P.ndep; i += 128) st_st4v(lds, P.off_dep + 16 * i, reinterpret_cast<const st_int4 *>(g_dep)[i]);
-  for (int i = threadIdx.x; i < P.nold; i += 128) st_st4v(lds, P.off_old + 16 * i, reinterpret_cast<const st_int4 *>(g_old)[i]);
+  if (SPLIT) {
+    for (int i = threadIdx.x; i < P.ntmpl * ST_MF; i += NT) st_st4v(lds, P.off_depF + 16 * i, reinterpret_cast<const st_int4 *>(g_depF)[i]);
+    for (int i = threadIdx.x; i < P.ntmpl * ST_MC; i += NT) st_st4v(lds, P.off_depC + 16 * i, reinterpret_cast<const st_int4 *>(g_depC)[i]);
+  } else {
+    for (int i = threadIdx.x; i < P.ndep; i += NT) st_st4v(lds, P.off_dep + 16 * i, reinterpret_cast<const st_int4 *>(g_dep)[i]);
+  }
+  for (int i = threadIdx.x; i < P.nold; i += NT) st_st4v(lds, P.off_old + 16 * i, reinterpret_cast<const st_int4 *>(g_old)[i]);
   for (;;) {
-    __syncthreads();  // both waves are done with the previous panel (and the tables are in place)
+    __syncthreads();  // all waves are done with the previous panel (and the tables are in place)
     if (threadIdx.x == 0) s_ctl[0] = (int)atomicAdd(&ctl[0], 1u);
     {
       const st_int4 empty = {0, 0, -1, 0};
-      for (int i = threadIdx.x; i < P.nrows * ST_WP; i += 128) st_st4v(lds, P.off_win + 16 * i, empty);
+      for (int i = threadIdx.x; i < P.nrows * ST_WP; i += NT) st_st4v(lds, P.off_win + 16 * i, empty);
       const st_int4 empty_row = {0, -1, 0, 0};  // second half of a StRow: {tid, tag, -, -}
-      for (int i = threadIdx.x; i < 64 * ST_RQ; i += 128) st_st4v(lds, P.off_rowq + 32 * i + 16, empty_row);
+      for (int i = threadIdx.x; i < 64 * ST_RQ; i += NT) st_st4v(lds, P.off_rowq + 32 * i + 16, empty_row);
+      if (SPLIT)
+        for (int i = threadIdx.x; i < 64 * ST_CQ; i += NT) st_st4v(lds, P.off_cq + 16 * i, st_int4{0, 0, 0, -1});
     }
-    if (threadIdx.x < 64) s_prog[threadIdx.x] = 0;
+    if (threadIdx.x < 64) {
+      s_prog[threadIdx.x] = 0;
+      if (SPLIT) {
+        s_progF[threadIdx.x]      = 0;
+        s_progF[64 + threadIdx.x] = 1;
+      }
+    }
     if (threadIdx.x == 0) {
       s_ctl[1] = 0;
       st_st4v(lds, P.off_null, st_int4{0, 0, ST_NULLTAG, 0});  // the null slot: value +0.0
@@ -572,443 +1148,23 @@ __global__ __launch_bounds__(128) void sor_strand_kernel(const StParams P, const
     const long long S0  = (long long)panel * 64;
     const long long S   = S0 + lane;
     const int       len = st_strand_len(S, P);
-    if (!loader) {
-      // ------------------------------------------------------------------ compute wave
-      // One row per lane per iteration at best; with ONE wave per SIMD the loop runs at the latency of its own instruction
-      // stream, so everything that depends only on the row is done once, when the row is fetched (at the end of the iteration
-      // that finished its predecessor): the ME slot addresses, the tags to expect and the coefficients sit in registers.  An
-      // iteration is then: ONE burst of ME window reads, ME tag compares, and -- when every value is there -- the left-to-right
-      // subtraction chain, the scale by 1/d, the publish.  Padding entries have coefficient 0 and read the null slot (value 0):
-      // they subtract +0.0, which leaves every sum bit-identical, so the chain needs no predication.
-      int       p = 0, ostart = 0, ocnt = 0, dstart = 0, cur_tid = -1, setp = 0;  // setp: the position pos[] / sa[] are set for
-      bool      have = false;
-      double    s0 = 0.0, rb = 0.0, idiag = 0.0, mdiag = 0.0;
-      unsigned  sa[ME];    // LDS byte address of the slot of entry j for the row at position p
-      unsigned  wrow[ME];  // ... of slot 0 of its window row (the null slot for a padding entry)
-      int       msk[ME];   // ST_WP - 1, or 0 for a padding entry (its address does not move)
-      int       apos[ME];  // the tag the slot must carry: position + rotation of the window row (the slot is apos & 15)
-      double    cf[ME];    // coefficient
-#pragma unroll
-      for (int j = 0; j < ME; j++) {
-        sa[j] = wrow[j] = lds_base + (unsigned)P.off_null;
-        msk[j]  = 0;
-        apos[j] = ST_NULLTAG;
-        cf[j]   = 0.0;
-      }
-      const unsigned rq_base = lds_base + (unsigned)(P.off_rowq + 32 * ST_RQ * lane);
-      const int      rq_rot  = ST_ROT * lane;
-      unsigned       pubrow[ST_NB];  // this lane's own window row in band b (byte address of slot 0), ~0u: the band has none for it
-      int            pubrot[ST_NB];  // ... and its slot rotation
-#pragma unroll
-      for (int b = 0; b < ST_NB; b++) {
-        pubrow[b] = ~0u;
-        pubrot[b] = 0;
-        if (b < P.nbands) {
-          const int u = lane - P.band[b].dsmin;
-          if (u >= 0 && u < 64 + P.band[b].width - 1) {
-            pubrow[b] = lds_base + (unsigned)(P.off_win + 16 * ST_WP * (P.band[b].rowbase + u));
-            pubrot[b] = ST_ROT * (P.band[b].rowbase + u);
-          }
-        }
-      }
-      unsigned  st_iters = 0, st_rowwait = 0, st_depwait = 0, st_fallback = 0;  // HIPX_SOR_DEBUG statistics (stats != nullptr)
-      unsigned  st_nfast = 0, st_nslow = 0, st_nsetup = 0;                     // iterations in which ANY lane took the path
-      long long st_cburst = 0, st_cfast = 0;                                   // shader clocks spent in the burst / in the fast finish
-      const long long st_t0 = stats ? (long long)wall_clock64() : 0;
-      const long long st_c0 = stats ? (long long)clock64() : 0;
-      if (stats && lane == 0) stats[16 + 4 * (size_t)panel] = (unsigned long long)st_t0;
-      long long t0 = 0;
-      // the template of the row at position p has changed (first row, boundary rows): entry table -> registers
-      auto load_template = [&](int tnew) __attribute__((always_inline)) {
-        const st_int4 ti = st_ld4(lds, P.off_tinfo + 16 * tnew);
-        const st_int4 dg = st_ld4(lds, P.off_tdiag + 16 * tnew);
-        dstart = ti.x;
-        ostart = ti.z;
-        ocnt   = ti.w;
-        st_int4  e[ME];
-        unsigned ea[ME];
-#pragma unroll
-        for (int j = 0; j < ME; j++) ea[j] = lds_base + (unsigned)(P.off_dep + 16 * (ti.x + j));
-        st_lds_burst<ME>(e, ea);
-#pragma unroll
-        for (int j = 0; j < ME; j++) {
-          const bool null = e[j].x == ST_NULLPK;
-          const int wr = lane + (e[j].x >> 16);  // window row
-          wrow[j] = lds_base + (unsigned)(null ? P.off_null : P.off_win + 16 * ST_WP * wr);
-          msk[j]  = null ? 0 : ST_WP - 1;
-          apos[j] = null ? ST_NULLTAG : p + (int)(short)(e[j].x & 0xffff) + ST_ROT * wr;
-          sa[j]   = wrow[j] + (unsigned)((apos[j] & msk[j]) << 4);
-          cf[j]   = st_dbl(e[j].z, e[j].w);
-        }
-        idiag   = st_dbl(dg.x, dg.y);
-        mdiag   = st_dbl(dg.z, dg.w);
-        cur_tid = tnew;
-        setp    = p;
-      };
-      // operands of the row at position p have arrived (w0 = {a, old value}, w1 = {template id, tag})
-      auto start_row = [&](const st_int4 &w0, const st_int4 &w1) __attribute__((always_inline)) {
-        s0 = st_dbl(w0.x, w0.y);
-        rb = st_dbl(w0.z, w0.w);
-        if (w1.x != cur_tid) load_template(w1.x);
-        else if (setp != p) {  // same template, the next position (p = setp + 1): every tag and slot moves on by one
-          const int step = p - setp;
-#pragma unroll
-          for (int j = 0; j < ME; j++) {
-            apos[j] += (msk[j] & 1) * step;  // (a padding entry stays where it is)
-            sa[j] = wrow[j] + (unsigned)((apos[j] & msk[j]) << 4);
-          }
-          setp = p;
-        }
-        have = true;
-        if (KIND == 4) {  // aij.c:1984-1990: the lower part and the diagonal use OLD values, in row order, first
-          const hipx_int r = st_actual<FWD>(S * L + p, m);
-          for (int q2 = 0; q2 < ocnt; q2++) {
-            const st_int4 oe = st_ld4(lds, P.off_old + 16 * (ostart + q2));
-            s0 -= st_dbl(oe.z, oe.w) * xold[(long long)r + oe.x];
-          }
-        }
-      };
-      // Two panels share a CU and their compute waves may share a SIMD: a wave that spins on values that are not there yet takes
-      // issue cycles from one that has work (measured: panels next to a spinning neighbour ran at 2.9 us per row instead of 1.4).
-      // So the wave runs at raised priority and, after an iteration in which none of its lanes finished a row, sleeps briefly.
-      __builtin_amdgcn_s_setprio(3);
-      int idle = 0;
-      for (unsigned it = 1;; it++) {
-        const bool active = p < len;
-        if (!__any(active)) break;
-        st_iters++;
-        const int  p_before    = p;
-        const bool have_before = have;
-        int        dbg_diff = 0x7ffffff, dbg_rtag = -2, dbg_mask = 0;
-        const bool dbg_on = stats && P.trace_panel == (int)panel && lane == P.trace_lane;
-        long long  dbg_c0 = dbg_on ? (long long)clock64() : 0, dbg_c1 = 0, dbg_c2 = 0, dbg_c3 = 0;
-        asm volatile("" ::: "memory");  // other waves have written LDS since the last iteration: re-read, do not reuse
-        if (active) {
-          // ONE burst per iteration: the ME slots of the current row and the operand record of the NEXT row (of the current one
-          // while it is still missing); one wait
-          st_int4        sl[ME], w0, w1;
-          const int      qr = have ? p + 1 : p;
-          const unsigned ra = rq_base + (unsigned)(32 * ((qr + rq_rot) & (ST_RQ - 1)));
-          const long long c_b0 = stats ? (long long)clock64() : 0;
-          st_lds_burst_row<ME>(sl, w0, w1, sa, ra);
-          dbg_rtag = w1.y;
-          if (__any(!have)) dbg_mask |= 1 << 29;
-          if (stats) st_cburst += (long long)clock64() - c_b0;
-          if (stats && __any(!have)) st_nsetup++;
-          if (!have) {
-            if (w1.y == p) start_row(w0, w1);  // (the slots read above belonged to no row: compute in the next iteration)
-            else st_rowwait++;
-          } else {
-            const long long q = S * L + p;
-            const hipx_int  r = st_actual<FWD>(q, m);
-            int             diff = 0;  // OR of (tag - expected): 0 = all there; negative = at least one not produced yet (wait, nothing
-                                       // else to find out); positive = a slot has moved on (rare: the value comes from memory)
-#pragma unroll
-            for (int j = 0; j < ME; j++) diff |= sl[j].z - apos[j];
-            if (dbg_on) dbg_c1 = (long long)clock64();  // (moves the burst/compare boundary to here: burst + whatever the !have lanes did + the tag compare)
-            if (__any(diff > 0)) dbg_mask |= 1 << 30;
-            if (stats && P.trace_panel == (int)panel && lane == P.trace_lane) {
-              dbg_diff = diff;
-#pragma unroll
-              for (int j = 0; j < ME; j++) dbg_mask |= (sl[j].z < apos[j] ? 1 : 0) << j;
-            }
-            // the row's values are all there: subtraction chain, scale, publish, move on to the next row
-            auto finish = [&](const double (&val)[ME]) __attribute__((always_inline)) {
-              double sum = s0;
-#pragma unroll
-              for (int j = 0; j < ME; j++) sum -= cf[j] * val[j];  // left to right (PetscSparseDenseMinusDot); null entries subtract +0.0
-              double out;
-              if (KIND == 0) {
-                t[r] = sum;
-                out  = sum * idiag;
-              } else if (KIND == 1) {
-                out = (1 - omega) * rb + sum * idiag;
-              } else if (KIND == 2) {
-                out = sum * idiag;
-              } else if (KIND == 3) {
-                t[r] = sum;
-                for (int e2 = 0; e2 < ocnt; e2++) {  // upper part: old values (aij.c:1973-1976)
-                  const st_int4 oe = st_ld4(lds, P.off_old + 16 * (ostart + e2));
-                  sum -= st_dbl(oe.z, oe.w) * xold[(long long)r + oe.x];
-                }
-                out = (1. - omega) * rb + sum * idiag;
-              } else {
-                out = (1. - omega) * rb + (sum + mdiag * rb) * idiag;
-              }
-#pragma unroll
-              for (int b = 0; b < ST_NB; b++)
-                if (pubrow[b] != ~0u)  // the tag is the position plus the row's rotation; so is the slot
-                  *reinterpret_cast<volatile st_lds_int4 *>((st_lds_char *)(size_t)(pubrow[b] + (unsigned)(((p + pubrot[b]) & (ST_WP - 1)) << 4))) = st_pack_slot(out, p + pubrot[b]);
-              sor_publish(xnew + r, out);
-              if (stats && p == 0 && (lane == 0 || lane == 63)) stats[16 + 4 * (size_t)panel + (lane ? 2 : 1)] = (unsigned long long)wall_clock64();
-              if (stats && P.trace_panel == (int)panel && P.trace_rows)  // HIPX_SOR_TRACE_PANEL: completion time of every row of this panel
-                stats[16 + 4 * (size_t)P.npanels + (size_t)lane * (size_t)L + (size_t)p] = (unsigned long long)wall_clock64();
-              p++;
-              have = false;
-              asm volatile("" ::: "memory");
-              if (p < len && w1.y == p) start_row(w0, w1);  // the next row's operands came with this iteration's burst
-            };
-            if (stats && __any(diff == 0)) st_nfast++;
-            if (stats && __any(diff > 0)) st_nslow++;
-            if (!diff) {  // the common case: straight from the registers the burst filled
-              double val[ME];
-#pragma unroll
-              for (int j = 0; j < ME; j++) val[j] = st_dbl(sl[j].x, sl[j].y);
-              const long long c_f0 = stats ? (long long)clock64() : 0;
-              if (dbg_on) dbg_c2 = c_f0;
-              finish(val);
-              if (stats) st_cfast += (long long)clock64() - c_f0;
-              if (dbg_on) dbg_c3 = (long long)clock64();
-            } else if (diff < 0) {
-              st_depwait++;
-              if (stats && P.trace_panel == (int)panel && P.trace_rows) {  // which entry is late?  (first one in arithmetic order), all lanes together + lane 0 alone
-                int jf = 0, jtag = 0, jexp = 0;  // (selects, not indexed reads: a register array indexed at run time goes to scratch)
-#pragma unroll
-                for (int j = ME - 1; j >= 0; j--)
-                  if (sl[j].z < apos[j]) {
-                    jf   = j;
-                    jtag = sl[j].z;
-                    jexp = apos[j];
-                  }
-                unsigned long long *h = stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)L + 2 * 4096 * 8;
-                atomicAdd(&h[jf], 1ull);
-                if (lane == 0) atomicAdd(&h[16 + jf], 1ull);
-                if (lane == 32) atomicAdd(&h[32 + jf], 1ull);
-              }
-            } else {  // no tag behind, at least one ahead: the slot has moved on (this lane fell far behind its producer)
-              bool   ok = true;
-              double val[ME];
-#pragma unroll
-              for (int j = 0; j < ME; j++) {
-                val[j] = st_dbl(sl[j].x, sl[j].y);
-                if (sl[j].z < apos[j]) ok = false;
-                else if (sl[j].z > apos[j]) {
-                  const int                elo = st_ld4(lds, P.off_dep + 16 * (dstart + j)).y;  // logical row offset of the entry
-                  const unsigned long long v   = st_gload64_wait(xnew + st_actual<FWD>(q + elo, m));
-                  st_fallback++;
-                  if (v == SOR_SENTINEL) ok = false;
-                  else val[j] = __longlong_as_double((long long)v);
-                }
-              }
-              if (ok) finish(val);
-              else st_depwait++;
-            }
-          }
-        }
-        s_prog[lane] = p;
-        if (stats && P.trace_panel == (int)panel && lane == P.trace_lane && (int)it >= P.trace_it0 && (int)it < P.trace_it0 + 4096) {  // iteration log of one lane
-          unsigned long long *ev = stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)L + 4096 * 8 + (size_t)((int)it - P.trace_it0) * 8;
-          ev[0] = (unsigned long long)wall_clock64();
-          ev[1] = (unsigned long long)it;
-          ev[2] = (unsigned long long)p_before;
-          ev[3] = (unsigned long long)p;
-          ev[4] = (unsigned long long)((have_before ? 1 : 0) | (have ? 2 : 0));
-          ev[5] = (unsigned long long)(unsigned)dbg_diff | ((unsigned long long)(unsigned)(dbg_c1 - dbg_c0) << 32);       // burst
-          ev[6] = (unsigned long long)(unsigned)(dbg_c2 - dbg_c1) | ((unsigned long long)(unsigned)(dbg_c3 - dbg_c2) << 32);  // compare | finish
-          ev[7] = (unsigned long long)(unsigned)dbg_mask | ((unsigned long long)(unsigned)((long long)clock64() - dbg_c0) << 32);  // whole iteration so far
-        }
-        if (!__any(p != p_before || have != have_before)) {
-          idle = idle < 4 ? idle + 1 : 4;
-          if (idle >= 2) __builtin_amdgcn_s_sleep(2);   // ~128 clocks; the loader pass that can change anything takes thousands
-        } else idle = 0;
-        if ((it & 0x3ff) == 0) {  // bounded wait: elapsed wall-clock time, and a global abort word so one stuck panel ends the launch
-          const long long now = (long long)wall_clock64();
-          if (!t0) t0 = now;
-          const unsigned abort_word = st_gload32_wait(err);
-          if (abort_word || now - t0 > SOR_SPIN_TICKS) {
-            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-      if (lane == 0) s_ctl[1] = 1;
-      if (stats) {
-        for (int o = 32; o > 0; o >>= 1) {  // the finish-path clocks of the lane that finished most often
-          const long long other = __shfl_xor(st_cfast, o);
-          st_cfast = other > st_cfast ? other : st_cfast;
-        }
-        atomicAdd(&stats[1], (unsigned long long)st_rowwait);
-        atomicAdd(&stats[2], (unsigned long long)st_depwait);
-        atomicAdd(&stats[5], (unsigned long long)st_fallback);
-        atomicAdd(&stats[7], (unsigned long long)len);
-        if (lane == 0) {
-          atomicAdd(&stats[0], (unsigned long long)st_iters);
-          atomicAdd(&stats[9], (unsigned long long)st_nfast);
-          atomicAdd(&stats[10], (unsigned long long)st_nslow);
-          atomicAdd(&stats[11], (unsigned long long)st_nsetup);
-          atomicAdd(&stats[12], (unsigned long long)st_cburst);
-          atomicAdd(&stats[13], (unsigned long long)st_cfast);
-          atomicAdd(&stats[14], (unsigned long long)((long long)clock64() - st_c0));
-          atomicAdd(&stats[6], (unsigned long long)((long long)wall_clock64() - st_t0));
-          atomicAdd(&stats[8], 1ull);
-          stats[16 + 4 * (size_t)panel + 3] = (unsigned long long)wall_clock64();
-        }
-      }
+    if (SPLIT) {
+      if (wave == 0) st_compute_role<KIND, ST_MC, 2>(P, lds, lds_base, s_prog, s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, stats, 0);
+      else if (wave <= 2)
+        st_compute_role<KIND, ST_MF, 1>(P, lds, lds_base, s_progF + 64 * (wave - 1), s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, nullptr, wave - 1,
+                                        stats ? stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)P.L + 2 * 4096 * 8 + 48 + 8 * (wave - 1) : nullptr);
+      else st_loader_role<KIND, ALIGNED, true>(P, lds, s_progF, s_prog, s_ctl, lane, panel, S0, S, len, tid, asrc, xold, xnew, stats);
     } else {
-      // ------------------------------------------------------------------ loader wave
-      int rqf = 0;  // next position of the own strand whose operands are to be staged
-      unsigned st_pass = 0, st_idle = 0;
-      int sf[2 * ST_NB];
-#pragma unroll
-      for (int d = 0; d < 2 * ST_NB; d++) sf[d] = 0;
-      for (;;) {
-        if (s_ctl[1]) break;
-        bool      issued = false;
-        const int myp    = s_prog[lane];
-        // (a) operands of the own strand: positions [rqf, rqf + ST_SB) while they fit the ring
-        int           nrow = 0;
-        double        va[ST_SB], vb[ST_SB];
-        unsigned char vt[ST_SB];
-        unsigned long long tb = 0;  // ALIGNED: the 8 template ids as loaded; unpacked when they land (no wait before the far loads are issued)
-        if (rqf < len && rqf + ST_SB <= myp + ST_RQ) nrow = (len - rqf) < ST_SB ? (len - rqf) : ST_SB;
-        if (nrow > 0) {
-          issued = true;
-          const long long q0 = S * L + rqf;
-          if (ALIGNED) {  // L, m multiples of 8 and 16-byte aligned vectors: the 8 rows are one aligned 64-byte run
-            typedef double dbl2 __attribute__((ext_vector_type(2)));
-            const hipx_int r0 = FWD ? (hipx_int)q0 : (hipx_int)((long long)m - 8 - q0);  // lowest actual row of the run
-            const dbl2    *pa = reinterpret_cast<const dbl2 *>(asrc + r0);
-            const dbl2    *pb = reinterpret_cast<const dbl2 *>(xold + (NEEDOLD ? r0 : 0));
-            tb = *reinterpret_cast<const unsigned long long *>(tid + r0);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              const dbl2 a2 = pa[j];
-              dbl2       b2 = {0.0, 0.0};
-              if (NEEDOLD) b2 = pb[j];
-              const int j0 = FWD ? 2 * j : 7 - 2 * j, j1 = FWD ? 2 * j + 1 : 6 - 2 * j;
-              va[j0] = a2.x;
-              va[j1] = a2.y;
-              vb[j0] = b2.x;
-              vb[j1] = b2.y;
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < ST_SB; j++) {
-              const hipx_int r = st_actual<FWD>(q0 + (j < nrow ? j : nrow - 1), m);
-              va[j]            = asrc[r];
-              vb[j]            = NEEDOLD ? xold[r] : 0.0;
-              vt[j]            = tid[r];
-            }
-          }
-        }
-        // (b) far strands: every duty = one window row of another panel's strand, staged ahead of its consumers
-        unsigned long long fv[2 * ST_NB][ST_SB];
-        int                fn[2 * ST_NB], frow[2 * ST_NB];
-#pragma unroll
-        for (int d = 0; d < 2 * ST_NB; d++) {
-          fn[d]   = 0;
-          frow[d] = 0;
-          const int b = d >> 1, which = d & 1;
-          if (b < P.nbands) {
-            const int       w = P.band[b].width, u = lane + 64 * which;
-            const long long strand = S0 + u + P.band[b].dsmin;
-            const bool      valid  = u < 64 + w - 1 && (strand < S0 || strand > S0 + 63) && strand >= 0 && strand < P.nstr;
-            if (valid) {
-              int lead = -1000000, trail = 1000000;  // most / least advanced consumer of this row that is still running
-              for (int c = u - (w - 1); c <= u; c++) {
-                if (c >= 0 && c < 64) {
-                  const int pc = s_prog[c];
-                  if (pc < st_strand_len(S0 + c, P)) {
-                    if (pc > lead) lead = pc;
-                    if (pc < trail) trail = pc;
-                  }
-                }
-              }
-              const int slen = st_strand_len(strand, P);
-              int       tgt  = lead + ST_LA + 1;
-              // ... but never over a slot the slowest consumer still needs: position q goes where q - 16 was, and a consumer at
-              // `trail` reads positions >= trail - 1.  (Without this bound a panel whose producers are far ahead always stages to
-              // the limit, the third consumer of a row -- four positions behind the first -- finds its slot gone, takes the
-              // memory path, which drains the wave's stores (~2 us), falls further behind ...: measured, a whole plane at 3 us
-              // per row instead of 1.3, and every later plane behind it.)
-              if (tgt > trail + ST_WP - 2) tgt = trail + ST_WP - 2;
-              if (tgt > slen) tgt = slen;
-              int n = tgt - sf[d];
-              if (n > ST_SB) n = ST_SB;
-              if (n > 0) {
-                issued  = true;
-                fn[d]   = n;
-                frow[d] = P.band[b].rowbase + u;
-                const long long q0 = strand * L + sf[d];
-#pragma unroll
-                for (int j = 0; j < ST_SB; j++)
-                {
-                  const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xnew + st_actual<FWD>(q0 + (j < n ? j : n - 1), m));
-                  fv[d][j] = P.poll_sys ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-              }
-            }
-          }
-        }
-        // everything is in flight; now land it in LDS
-        if (nrow > 0) {
-          if (ALIGNED) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) vt[FWD ? j : 7 - j] = (unsigned char)(tb >> (8 * j));
-          }
-#pragma unroll
-          for (int j = 0; j < ST_SB; j++) {
-            if (j < nrow) {
-              const int       ro = P.off_rowq + 32 * (lane * ST_RQ + ((rqf + j + ST_ROT * lane) & (ST_RQ - 1)));
-              const long long ba = __double_as_longlong(va[j]), bb = __double_as_longlong(vb[j]);
-              st_int4         w0, w1;
-              w0.x = (int)(unsigned)ba;
-              w0.y = (int)(unsigned)((unsigned long long)ba >> 32);
-              w0.z = (int)(unsigned)bb;
-              w0.w = (int)(unsigned)((unsigned long long)bb >> 32);
-              w1.x = (int)vt[j];
-              w1.y = rqf + j;
-              w1.z = 0;
-              w1.w = 0;
-              st_st4v(lds, ro, w0);  // operands first, tag last: the compute wave tests the tag (LDS executes a wave's accesses in order)
-              st_st4v(lds, ro + 16, w1);
-            }
-          }
-          rqf += nrow;
-        }
-#pragma unroll
-        for (int d = 0; d < 2 * ST_NB; d++) {
-          if (fn[d] > 0) {
-            int  cnt = 0;
-            bool acc = true;
-#pragma unroll
-            for (int j = 0; j < ST_SB; j++) {
-              if (j < fn[d] && acc && fv[d][j] != SOR_SENTINEL) {
-                st_st4v(lds, P.off_win + 16 * (frow[d] * ST_WP + ((sf[d] + j + ST_ROT * frow[d]) & (ST_WP - 1))), st_pack_slot(__longlong_as_double((long long)fv[d][j]), sf[d] + j + ST_ROT * frow[d]));
-                cnt++;
-              } else acc = false;
-            }
-            sf[d] += cnt;
-          }
-        }
-        if (stats && P.trace_panel == (int)panel && st_pass < 4096 && lane == P.trace_lane) {  // trace: the loader's view
-          unsigned long long *tr = stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)L + (size_t)st_pass * 8;
-          tr[0] = (unsigned long long)wall_clock64();
-          tr[1] = (unsigned long long)myp;
-          tr[2] = (unsigned long long)rqf;
-#pragma unroll
-          for (int d = 0; d < 3; d++) tr[3 + d] = (unsigned long long)sf[d];
-          tr[6] = (unsigned long long)(fn[0] | (fn[1] << 8) | (fn[2] << 16));  // rows asked for in this pass
-          tr[7] = (unsigned long long)(nrow | (s_prog[0] << 8) | ((unsigned long long)s_prog[1] << 24) | ((unsigned long long)s_prog[2] << 40));
-        }
-        st_pass++;
-        if (!__any(issued)) {
-          st_idle++;
-          __builtin_amdgcn_s_sleep(4);
-        }
-      }
-      if (stats && lane == 0) {
-        atomicAdd(&stats[3], (unsigned long long)st_pass);
-        atomicAdd(&stats[4], (unsigned long long)st_idle);
-      }
+      if (wave == 0) st_compute_role<KIND, ME, 0>(P, lds, lds_base, s_prog, s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, stats, 0);
+      else st_loader_role<KIND, ALIGNED, false>(P, lds, s_prog, s_prog, s_ctl, lane, panel, S0, S, len, tid, asrc, xold, xnew, stats);
     }
-    // Both roles share this function: without this, loads the LOADER branch may leave pending at the back edge of the panel loop
-    // count as pending in the COMPUTE branch too (the compiler merges the two paths), which plants vmcnt waits -- i.e. waits for
+    // All roles share this function: without this, loads the LOADER branch may leave pending at the back edge of the panel loop
+    // count as pending in the COMPUTE branches too (the compiler merges the paths), which plants vmcnt waits -- i.e. waits for
     // the compute wave's own stores -- in front of every register those loads use.  Drain everything here, explicitly.
     __builtin_amdgcn_s_waitcnt(0);
   }
 }
+
 
 __global__ void st_verify_kernel(const StParams P, int forward, const unsigned char *__restrict__ tid, const StTinfo *__restrict__ tinfo, const StEntry *__restrict__ dep, unsigned int *bad)
 {
@@ -1030,10 +1186,10 @@ __global__ void st_verify_kernel(const StParams P, int forward, const unsigned c
 
 struct StrandDir {
   bool      ok = false;
-  StParams  P;
+  StParams  P, Ps;  // Ps: the layout of the split kernel (P.split)
   StTinfo  *d_tinfo = nullptr;
   StDiag   *d_tdiag = nullptr;
-  StEntry  *d_dep = nullptr, *d_old = nullptr;
+  StEntry  *d_dep = nullptr, *d_old = nullptr, *d_depF = nullptr, *d_depC = nullptr;
   std::vector<StDiag> h_tdiag;
 };
 struct StrandState {
@@ -1057,6 +1213,8 @@ void strand_free(StrandState *T)
     (void)hipFree(D.d_tinfo);
     (void)hipFree(D.d_tdiag);
     (void)hipFree(D.d_dep);
+    (void)hipFree(D.d_depF);
+    (void)hipFree(D.d_depC);
     (void)hipFree(D.d_old);
   }
   (void)hipFree(T->d_ctl);
@@ -1193,6 +1351,18 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
     P.nold      = (int)old.size();
     P.maxchunks = maxdep;
     P.me        = ME;
+    // split kernel (ME 16): the list of a template cut into its first (up to) 12 and last (up to) 4 entries, fixed strides
+    static const bool split_on = !(getenv("HIPX_SOR_SPLIT") && atoi(getenv("HIPX_SOR_SPLIT")) == 0);
+    std::vector<StEntry> depF, depC;
+    P.split = (ME == ST_ME && split_on) ? 1 : 0;
+    if (P.split) {
+      for (int t = 0; t < ntmpl; t++) {
+        const StTinfo &ti = tinfo[(size_t)t];
+        const int      nC = std::min(ti.dcnt, ST_MC), nF = ti.dcnt - nC;
+        for (int k = 0; k < ST_MF; k++) depF.push_back(k < nF ? dep[(size_t)ti.dstart + k] : StEntry{ST_NULLPK, 0, 0.0});
+        for (int k = 0; k < ST_MC; k++) depC.push_back(k < nC ? dep[(size_t)ti.dstart + nF + k] : StEntry{ST_NULLPK, 0, 0.0});
+      }
+    }
     int o = 0;
     P.off_win   = o; o += P.nrows * ST_WP * (int)sizeof(StSlot);
     P.off_rowq  = o; o += 64 * ST_RQ * (int)sizeof(StRow);
@@ -1203,8 +1373,25 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
     P.off_prog  = o; o += 64 * 4;
     P.off_ctl   = o; o += 16;
     P.off_null  = o; o += 16;
+    P.off_cq = P.off_progF = P.off_depF = P.off_depC = 0;
     P.lds_bytes = o;
     if (P.lds_bytes > 78 * 1024) continue;  // two workgroups per CU must fit the 160 KiB
+    D.Ps = P;
+    if (P.split) {  // the split kernel's own layout: its two tables instead of the whole-row one, no old-value lists (kinds 0-2 only)
+      StParams &Q = D.Ps;
+      o           = P.off_dep;
+      Q.off_depF  = o; o += ntmpl * ST_MF * (int)sizeof(StEntry);
+      Q.off_depC  = o; o += ntmpl * ST_MC * (int)sizeof(StEntry);
+      Q.off_old   = o;
+      Q.nold      = 0;
+      Q.off_prog  = o; o += 64 * 4;
+      Q.off_progF = o; o += 2 * 64 * 4;
+      Q.off_ctl   = o; o += 16;
+      Q.off_null  = o; o += 16;
+      Q.off_cq    = o; o += 64 * ST_CQ * 16;
+      Q.lds_bytes = o;
+      if (Q.lds_bytes > 78 * 1024) P.split = Q.split = 0;
+    }
     if (dep.empty()) dep.push_back(StEntry{0, 0, 0.0});
     if (old.empty()) old.push_back(StEntry{0, 0, 0.0});
     HIPX_HIP(hipMalloc((void **)&D.d_tinfo, sizeof(StTinfo) * (size_t)ntmpl));
@@ -1214,6 +1401,12 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
     HIPX_HIP(hipMemcpyAsync(D.d_tinfo, tinfo.data(), sizeof(StTinfo) * (size_t)ntmpl, hipMemcpyHostToDevice, st));
     HIPX_HIP(hipMemcpyAsync(D.d_dep, dep.data(), sizeof(StEntry) * dep.size(), hipMemcpyHostToDevice, st));
     HIPX_HIP(hipMemcpyAsync(D.d_old, old.data(), sizeof(StEntry) * old.size(), hipMemcpyHostToDevice, st));
+    if (P.split) {
+      HIPX_HIP(hipMalloc((void **)&D.d_depF, sizeof(StEntry) * depF.size()));
+      HIPX_HIP(hipMalloc((void **)&D.d_depC, sizeof(StEntry) * depC.size()));
+      HIPX_HIP(hipMemcpyAsync(D.d_depF, depF.data(), sizeof(StEntry) * depF.size(), hipMemcpyHostToDevice, st));
+      HIPX_HIP(hipMemcpyAsync(D.d_depC, depC.data(), sizeof(StEntry) * depC.size(), hipMemcpyHostToDevice, st));
+    }
     // every row's dependency entries must decompose into (strand delta, position delta) as the tables say
     HIPX_HIP(hipMemsetAsync(T->d_ctl + 2, 0, sizeof(unsigned int), st));
     st_verify_kernel<<<(unsigned)std::min<hipx_int>((m + 255) / 256, 4096), 256, 0, st>>>(P, fwd ? 1 : 0, d_tid, D.d_tinfo, D.d_dep, T->d_ctl + 2);
@@ -1275,13 +1468,27 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
   unsigned grid = (unsigned)std::min<long long>((long long)P.npanels, 256LL * per_cu);
   const bool aligned = (P.L % 8 == 0) && (P.m % 8 == 0) && ((reinterpret_cast<uintptr_t>(asrc) | reinterpret_cast<uintptr_t>(xold)) % 16 == 0);
   static const bool dbg = getenv("HIPX_SOR_DEBUG") != nullptr;
-  static bool attr_set[5][4] = {{false}};
+  static bool attr_set[5][6] = {{false}};
+  // The split kernel pays when the far entries come FIRST in the row's list (forward sweeps: lower planes, then the previous line,
+  // then the row's predecessor): the F waves run ahead with them.  In a backward sweep the list starts with the near entries, the
+  // far subtractions depend on them, and nothing can run ahead (measured on the config-3 slab: forward 2.1 us per line and 0.94 us
+  // per row against 3.25 / 1.4 with two waves; backward 2x SLOWER than with two waves).  HIPX_SOR_SPLIT = 0 off | 1 forward
+  // zero-guess sweep only (default) | 2 every sweep of kinds 0-2.
+  static const int split_mode = getenv("HIPX_SOR_SPLIT") ? atoi(getenv("HIPX_SOR_SPLIT")) : 1;
+  const bool     split    = P.split && (split_mode >= 2 ? KIND <= 2 : (split_mode == 1 && KIND == 0));
+  const unsigned nthreads = (P.me != 4 && split) ? 256 : 128;
+  if (split) {
+    const int tp = P.trace_panel, tl = P.trace_lane, ti = P.trace_it0, tr = P.trace_rows, ps = P.poll_sys;
+    P = D.Ps;
+    P.trace_panel = tp; P.trace_lane = tl; P.trace_it0 = ti; P.trace_rows = tr; P.poll_sys = ps;
+  }
   auto launch = [&](auto kern, int ai) -> int {
     if (!attr_set[KIND][ai]) {
       HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       attr_set[KIND][ai] = true;
     }
-    kern<<<grid, 128, (size_t)P.lds_bytes, st>>>(P, T->d_tid, D.d_tinfo, D.d_tdiag, D.d_dep, D.d_old, asrc, t, xold, xnew, omega, T->d_ctl, dbg ? T->d_stats : nullptr);
+    kern<<<grid, nthreads, (size_t)P.lds_bytes, st>>>(P, T->d_tid, D.d_tinfo, D.d_tdiag, D.d_dep, D.d_old, D.d_depF, D.d_depC, asrc, t, xold, xnew, omega, T->d_ctl,
+                                                       dbg ? T->d_stats : nullptr);
     return HIPX_SUCCESS;
   };
   if (dbg) {
@@ -1303,8 +1510,11 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
             (void *)xnew, (void *)T->d_ctl);
   }
   int ierr;
-  if (P.me == 4) ierr = aligned ? launch(sor_strand_kernel<KIND, true, 4>, 1) : launch(sor_strand_kernel<KIND, false, 4>, 0);
-  else ierr = aligned ? launch(sor_strand_kernel<KIND, true, ST_ME>, 3) : launch(sor_strand_kernel<KIND, false, ST_ME>, 2);
+  if (P.me == 4) ierr = aligned ? launch(sor_strand_kernel<KIND, true, 4, false>, 1) : launch(sor_strand_kernel<KIND, false, 4, false>, 0);
+  else if (split) {
+    if constexpr (KIND <= 2) ierr = aligned ? launch(sor_strand_kernel<KIND, true, ST_ME, true>, 5) : launch(sor_strand_kernel<KIND, false, ST_ME, true>, 4);
+    else ierr = HIPX_ERR_SUP;
+  } else ierr = aligned ? launch(sor_strand_kernel<KIND, true, ST_ME, false>, 3) : launch(sor_strand_kernel<KIND, false, ST_ME, false>, 2);
   if (ierr) return ierr;
   HIPX_LAUNCH_CHECK();
   if (dbg) {
@@ -1318,6 +1528,13 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
     fprintf(stderr, "[hipx sor]   per panel (lane 0's view): iterations with a finishing lane %.0f, with a fallback lane %.0f, with a lane setting up %.0f; shader clocks: total %.0f (%.0f per "
                     "iteration), in the burst %.0f (%.0f per iteration), in the finish path %.0f (%.0f per finishing iteration)\n",
             hs[9] / np, hs[10] / np, hs[11] / np, hs[14] / np, hs[0] ? (double)hs[14] / hs[0] : 0.0, hs[12] / np, hs[0] ? (double)hs[12] / hs[0] : 0.0, hs[13] / np, hs[9] ? (double)hs[13] / hs[9] : 0.0);
+    if (split) {
+      unsigned long long fs[16];
+      HIPX_HIP(hipMemcpy(fs, T->d_stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)P.L + 2 * 4096 * 8 + 48, sizeof(fs), hipMemcpyDeviceToHost));
+      for (int w = 0; w < 2; w++)
+        fprintf(stderr, "[hipx sor]   F wave %d, lane 32, per panel: iterations %.0f, waiting for operands %.0f, for far values %.0f, for room in the hand-over ring %.0f, rows done %.0f\n", w,
+                fs[8 * w] / np, fs[8 * w + 1] / np, fs[8 * w + 2] / np, fs[8 * w + 3] / np, fs[8 * w + 4] / np);
+    }
     if (const char *dump = getenv("HIPX_SOR_DEBUG_DUMP")) {  // per panel: start, first row of lane 0, first row of lane 63, end (wall-clock ticks, 10 ns)
       std::vector<unsigned long long> pt(4 * (size_t)P.npanels);
       HIPX_HIP(hipMemcpy(pt.data(), T->d_stats + 16, sizeof(unsigned long long) * pt.size(), hipMemcpyDeviceToHost));
