@@ -1667,7 +1667,8 @@ int ensure_templates(hipxMat A)
 // geometry of the template kernel: HIPX_TMPL_CFG = 0 (2 rows per thread, per-lane walk only) | 1 (2 rows, uniform fast path:
 // default -- the smaller chunk keeps the x window of an XCD inside its L2) | 2 (4 rows, uniform fast path).  Tried and dropped
 // (measured on MI355X, 7-pt 256^3 inside CG): the template cached in scalar registers with all gathers of a chunk issued as one
-// group -- 116 VGPRs, 4 waves per SIMD: 0.163 ms against 0.146 ms; the kernel wants occupancy, not fewer round trips.
+// group -- 116 VGPRs, 4 waves per SIMD: 0.163 ms against 0.146 ms; the kernel wants occupancy, not fewer round trips.  Also tried:
+// adjacent row pairs per thread with one 16-byte gather per entry (half the memory instructions): 0.169 ms against 0.144 ms.
 int tmpl_cfg()
 {
   static const int v = getenv("HIPX_TMPL_CFG") ? atoi(getenv("HIPX_TMPL_CFG")) : 1;

@@ -1,14 +1,18 @@
 #!/bin/bash
-# rocprofv3 evidence for profiles/: kernel stats of the default bench, then FETCH_SIZE / WRITE_SIZE passes (separate runs,
+# rocprofv3 evidence for profiles/: kernel stats of the default bench (timed legs only: the plugin / PMC / CPU-baseline legs start
+# their own processes), kernel stats + FETCH_SIZE / WRITE_SIZE of the SOR sweeps on the config-3 slab (separate passes,
 # --kernel-trace only).  Usage: bash scripts/gpu_profile.sh <tag>   (outputs under gpurun_out/<tag>_*)
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 R="$GRAFT_REPO_ROOT"; T=${1:-prof}
 mkdir -p gpurun_out
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/${T}_stats" -o stats -- python "$R/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > "$R/gpurun_out/${T}_stats.log" 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/${T}_fetch" -o pmc -- python "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$R/gpurun_out/${T}_fetch.log" 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/${T}_write" -o pmc -- python "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$R/gpurun_out/${T}_write.log" 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/${T}_stats" -o stats -- python "$R/bench.py" --no-traffic --no-plugin --no-cpu-baseline > "$R/gpurun_out/${T}_stats.log" 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/${T}_sor_stats" -o stats -- python "$R/scripts/config3_slab_proxy.py" > "$R/gpurun_out/${T}_sor_stats.log" 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/${T}_sor_fetch" -o pmc -- python "$R/scripts/config3_slab_proxy.py" > "$R/gpurun_out/${T}_sor_fetch.log" 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/${T}_sor_write" -o pmc -- python "$R/scripts/config3_slab_proxy.py" > "$R/gpurun_out/${T}_sor_write.log" 2>&1
 cd "$R"
-rm -f gpurun_out/${T}_*/stats_kernel_trace.csv gpurun_out/${T}_*/pmc_kernel_trace.csv   # large, not needed
-head -8 gpurun_out/${T}_stats/stats_kernel_stats.csv | cut -c1-200
+python scripts/pmc_summary.py --sor "gpurun_out/${T}_sor_fetch" "gpurun_out/${T}_sor_write" > "gpurun_out/${T}_sor_traffic.json" 2> "gpurun_out/${T}_sor_traffic.err"
+find gpurun_out/${T}_stats gpurun_out/${T}_sor_stats gpurun_out/${T}_sor_fetch gpurun_out/${T}_sor_write -name "*kernel_trace.csv" -delete 2>/dev/null  # large, not needed
+for d in stats sor_stats; do f=$(find gpurun_out/${T}_$d -name "*kernel_stats.csv" | head -1); echo "== $f"; head -8 "$f" | cut -c1-200; done
+cat "gpurun_out/${T}_sor_traffic.json" | cut -c1-600

@@ -22,7 +22,48 @@ def per_launch(path, counter, kernel):
     return (sum(v) / len(v), len(v)) if v else (None, 0)
 
 
+def sor_main(fetch_dir, write_dir):
+    """--sor: bytes per launch of the strand SOR kernels (forward = KIND 0, backward = KIND 1 instantiations) and of the AXPY that
+    calibrates the FETCH_SIZE unit in the same pass."""
+    def find(d):
+        for root, _, files in os.walk(d):
+            for fn in files:
+                if fn.endswith("counter_collection.csv"):
+                    return os.path.join(root, fn)
+        raise SystemExit("no counter_collection.csv under " + d)
+    out = {}
+    for counter, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
+        acc = {}
+        for row in csv.DictReader(open(find(d))):
+            if row["Counter_Name"] != counter:
+                continue
+            kn = row["Kernel_Name"]
+            if "sor_strand_kernel<0" in kn or "sor_strand_kernelILi0" in kn:
+                key = "sor_strand_kernel forward (KIND 0)"
+            elif "sor_strand_kernel<1" in kn or "sor_strand_kernelILi1" in kn:
+                key = "sor_strand_kernel backward (KIND 1)"
+            elif "sor_dep_kernel" in kn:
+                key = "sor_dep_kernel"
+            elif "sor_fill_kernel" in kn:
+                key = "sor_fill_kernel"
+            else:
+                continue
+            acc.setdefault(key, {}).setdefault(row["Dispatch_Id"], 0.0)
+            acc[key][row["Dispatch_Id"]] += float(row["Counter_Value"])
+        for key, v in acc.items():
+            vals = list(v.values())
+            out.setdefault(key, {})[counter + "_KiB_per_launch"] = sum(vals) / len(vals)
+            out[key]["launches_sampled"] = len(vals)
+    for key, v in out.items():
+        f, w = v.get("FETCH_SIZE_KiB_per_launch"), v.get("WRITE_SIZE_KiB_per_launch")
+        if f is not None and w is not None:
+            v["traffic_bytes_per_launch"] = int(2 * f * 1024 + w * 1024)  # same correction as for the SpMV (see the header)
+    print(json.dumps(out, indent=1))
+
+
 def main():
+    if sys.argv[1] == "--sor":
+        return sor_main(sys.argv[2], sys.argv[3])
     fetch_dir, write_dir, key = sys.argv[1:4]
     kernel = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else "spmv_"
     f, nf = per_launch(fetch_dir, "FETCH_SIZE", kernel)
