@@ -71,6 +71,9 @@ CASES = [("-stencil 7 -n 24 -ksp_type cg -pc_type jacobi -ksp_rtol 1e-8", None, 
          ("-stencil 7 -n 16 -ksp_type cg -pc_type sor -ksp_rtol 1e-8", None, 1e-8),
          ("-stencil 7 -n 16 -ksp_type cg -pc_type sor -ksp_rtol 1e-8 -dup_mat", None, 1e-8),  # operator = MatDuplicate(A)
          ("-stencil 7 -n 16 -ksp_type cg -pc_type bjacobi -sub_pc_type sor -ksp_rtol 1e-8", None, 1e-8),  # local-vector views
+         # PCApply_BJacobi_Multiblock (bjacobi.c:886-895): VecPlaceArray on hipx work vectors, sub-solve on the device, VecResetArray
+         ("-stencil 7 -n 16 -ksp_type cg -pc_type bjacobi -pc_bjacobi_local_blocks 2 -sub_pc_type sor -ksp_rtol 1e-8", None, 1e-8),
+         ("-stencil 7 -n 16 -ksp_type gmres -pc_type bjacobi -pc_bjacobi_local_blocks 3 -sub_pc_type jacobi -ksp_rtol 1e-8", None, 1e-8),
          ("-stencil 7 -n 16 -ksp_type cg -ksp_cg_single_reduction -pc_type jacobi -ksp_rtol 1e-8", None, 1e-8),
          ("-stencil 7 -n 16 -ksp_type fgmres -pc_type jacobi -ksp_rtol 1e-8", None, 1e-6),
          ("-stencil 7 -n 16 -ksp_type cr -pc_type jacobi -ksp_rtol 1e-8", None, 1e-7),
