@@ -140,6 +140,12 @@ int hipxMatCreateCSR64(hipx_int m, hipx_int n, const int64_t *i, const hipx_int 
 int hipxMatCreateCSRCompressedRow(hipx_int m, hipx_int n, hipx_int nrows, const hipx_int *ci, const hipx_int *ridx, const hipx_int *j, const double *a, hipxMat *A);
 int hipxMatUpdateValues(hipxMat A, const double *a);          /* same nonzero pattern, new values (host) */
 int hipxMatGetValues(hipxMat A, double *a_host);              /* the value array back to the host (CSR order) */
+/* Value-only updates on the device copy (no host round trip).  Same arithmetic as the reference:
+   MatScale_SeqAIJ aij.c:2604-2617 (a *= alpha), MatZeroEntries_SeqAIJ, MatDiagonalScale_SeqAIJ aij.c:2333-2371
+   ((a * l_i) * r_j: left pass first; l, r device pointers of length m / n, either may be NULL). */
+int hipxMatScale(hipxMat A, double alpha);
+int hipxMatZeroEntries(hipxMat A);
+int hipxMatDiagonalScale(hipxMat A, const double *l, const double *r);
 /* COO assembly on the device.  replaces MatSetValuesCOO_SeqAIJ aij.c:4710-4733; jmap (nz + 1) / perm (ntot) are the maps
    MatSetPreallocationCOO_SeqAIJ leaves in MatCOOStruct_SeqAIJ (aij.c:4524-4707, aij.h:170-176): entry k of the CSR value array
    is the sum of v[perm[jmap[k] .. jmap[k+1])], added left to right.  hipxMatCreateCSR* accept a == NULL (pattern only). */

@@ -156,6 +156,34 @@ int main(int argc, char **argv)
       A = C;
     }
   }
+  {
+    PetscBool matops = PETSC_FALSE; /* -mat_ops: A <- D_l (1.25 A) D_r with non-constant diagonal scalings, then one entry set from the host
+                                       (MatScale, MatDiagonalScale, MatSetValues + assembly in a row: value-only ops of Mat subclasses) */
+    PetscCall(PetscOptionsGetBool(NULL, NULL, "-mat_ops", &matops, NULL));
+    if (matops) {
+      Vec          l, r;
+      PetscScalar *la, *ra;
+      PetscInt     rs, re;
+      PetscCall(MatCreateVecs(A, &r, &l));
+      PetscCall(VecGetOwnershipRange(l, &rs, &re));
+      PetscCall(VecGetArrayWrite(l, &la));
+      PetscCall(VecGetArrayWrite(r, &ra));
+      for (PetscInt i = rs; i < re; i++) {
+        la[i - rs] = 1.0 + (PetscReal)(i % 7) / 7.0;
+        ra[i - rs] = 1.0 + (PetscReal)(i % 5) / 5.0;
+      }
+      PetscCall(VecRestoreArrayWrite(l, &la));
+      PetscCall(VecRestoreArrayWrite(r, &ra));
+      PetscCall(MatScale(A, 1.25));
+      PetscCall(MatDiagonalScale(A, l, r));
+      PetscCall(MatSetValue(A, rs, rs, 7.5, ADD_VALUES)); /* host-side update right after the device-side ones */
+      PetscCall(MatAssemblyBegin(A, MAT_FINAL_ASSEMBLY));
+      PetscCall(MatAssemblyEnd(A, MAT_FINAL_ASSEMBLY));
+      PetscCall(MatDiagonalScale(A, r, NULL));
+      PetscCall(VecDestroy(&l));
+      PetscCall(VecDestroy(&r));
+    }
+  }
   PetscCall(MatCreateVecs(A, &u, &b));
   PetscCall(VecSetFromOptions(u));
   PetscCall(VecDuplicate(u, &x));

@@ -1878,6 +1878,34 @@ int launch_spmv(hipxMat A, const double *x, const double *yin, double *yout, dou
 
 }  // namespace
 
+// ---- value-only operations on the device copy (MatScale / MatZeroEntries / MatDiagonalScale without a host round trip)
+namespace {
+template <typename IT>
+__global__ void mat_rowscale_kernel(hipx_int nrows, const IT *__restrict__ ai, const hipx_int *__restrict__ ridx, const double *__restrict__ l, double *a)
+{
+  for (hipx_int r = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (hipx_int)gridDim.x * blockDim.x) {
+    const double x = l[ridx ? ridx[r] : r];  // aij.c:2350-2354: (*v++) *= l[i]
+    for (IT k = ai[r]; k < ai[r + 1]; k++) a[k] *= x;
+  }
+}
+__global__ void mat_colscale_kernel(int64_t nnz, const hipx_int *__restrict__ aj, const double *__restrict__ rvec, double *a)
+{
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) a[k] *= rvec[aj[k]];  // aij.c:2365
+}
+__global__ void mat_scale_kernel(int64_t nnz, double alpha, double *a)
+{
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) a[k] *= alpha;  // dscal (aij.c:2613)
+}
+void values_changed(hipxMat A)
+{
+  A->vd_ready   = false;
+  A->tmpl_ready = false;
+  A->value_state++;
+  hipxSorInvalidate_(A->sor_state);
+}
+}  // namespace
+
+
 extern "C" {
 
 int hipxProfileSpMV(int enable)
@@ -1935,6 +1963,47 @@ int hipxMatUpdateValues(hipxMat A, const double *a)
   A->tmpl_ready = false;  // ... and so are the row templates
   A->value_state++;  // SOR's level-ordered copy and inverse diagonal must be rebuilt (aij.c:1807 idiagState)
   hipxSorInvalidate_(A->sor_state);
+  return HIPX_SUCCESS;
+}
+
+int hipxMatScale(hipxMat A, double alpha)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A, "null matrix");
+  if (A->nnz) {
+    const unsigned g = (unsigned)std::min<int64_t>((A->nnz + 255) / 256, 8192);
+    mat_scale_kernel<<<g, 256, 0, rt().compute>>>(A->nnz, alpha, A->d_a);
+    HIPX_LAUNCH_CHECK();
+  }
+  values_changed(A);
+  return HIPX_SUCCESS;
+}
+
+int hipxMatZeroEntries(hipxMat A)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A, "null matrix");
+  if (A->nnz) HIPX_HIP(hipMemsetAsync(A->d_a, 0, sizeof(double) * (size_t)A->nnz, rt().compute));
+  values_changed(A);
+  return HIPX_SUCCESS;
+}
+
+int hipxMatDiagonalScale(hipxMat A, const double *l, const double *r)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A, "null matrix");
+  if (A->nnz && l) {  // left first, then right: (a * l_i) * r_j, the reference's two passes (aij.c:2343-2369)
+    const unsigned g = (unsigned)std::min<hipx_int>((A->nrows_c + 255) / 256, 8192);
+    if (A->is64) mat_rowscale_kernel<int64_t><<<g ? g : 1, 256, 0, rt().compute>>>(A->nrows_c, (const int64_t *)A->d_i, A->compressed ? A->d_ridx : nullptr, l, A->d_a);
+    else mat_rowscale_kernel<hipx_int><<<g ? g : 1, 256, 0, rt().compute>>>(A->nrows_c, (const hipx_int *)A->d_i, A->compressed ? A->d_ridx : nullptr, l, A->d_a);
+    HIPX_LAUNCH_CHECK();
+  }
+  if (A->nnz && r) {
+    const unsigned g = (unsigned)std::min<int64_t>((A->nnz + 255) / 256, 8192);
+    mat_colscale_kernel<<<g, 256, 0, rt().compute>>>(A->nnz, A->d_j, r, A->d_a);
+    HIPX_LAUNCH_CHECK();
+  }
+  values_changed(A);
   return HIPX_SUCCESS;
 }
 

@@ -20,6 +20,7 @@ typedef struct {
   PetscInt  spmv_variant;
   hipxCOO   coo;       /* device copies of the reference's COO maps (MatCOOStruct_SeqAIJ jmap / perm) */
   PetscBool dev_newer; /* the device value array is ahead of the host copy a->a (MatSetValuesCOO ran on the device) */
+  PetscObjectState synced_state; /* object state at which host and device values are known to be equal (device-side MatScale ...) */
 } Mat_SeqAIJHIPX;
 
 static PetscErrorCode MatMult_SeqAIJHIPX(Mat, Vec, Vec);
@@ -58,6 +59,8 @@ PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA)
     if (h->spmv_variant) PetscCallHIPX(hipxMatSetSpMVVariant(h->dA, (int)h->spmv_variant));
     h->nonzerostate = A->nonzerostate;
     h->valuestate   = state;
+  } else if (h->valuestate != state && h->synced_state == state) {
+    h->valuestate = state; /* the values changed ON the device and were copied back: nothing to upload */
   } else if (h->valuestate != state) {
     const PetscScalar *aa;
     PetscCall(MatSeqAIJGetArrayRead(A, &aa));
@@ -248,6 +251,72 @@ static PetscErrorCode MatSetValuesCOO_SeqAIJHIPX(Mat A, const PetscScalar v[], I
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+/* Value-only operations on the device copy: the kernel does the arithmetic, the host array a->a is then refreshed
+   by ONE device-to-host copy -- no host pass over the values and no re-upload.  (Leaving the host copy stale, as after
+   MatSetValuesCOO with device values, would be unsafe here: MatSetValues_SeqAIJ, MatGetRow_SeqAIJ, MatDuplicateNoCreate_SeqAIJ ...
+   read a->a directly, and a CPU build of libpetsc has none of the offload-mask checks the reference's own device types rely
+   on.)  The interface functions (MatScale / MatDiagonalScale, matrix.c) bump the object state once after the op: synced_state
+   records that state so that MatSeqAIJHIPXGetDeviceMat does not upload identical values again.  MatZeroEntries stays the
+   parent's (it is the prelude of a host-side MatSetValues assembly). */
+static PetscErrorCode MatSeqAIJHIPXDeviceValuesChanged(Mat A)
+{
+  Mat_SeqAIJHIPX  *h = (Mat_SeqAIJHIPX *)A->spptr;
+  Mat_SeqAIJ      *a = (Mat_SeqAIJ *)A->data;
+  PetscObjectState state;
+
+  PetscFunctionBegin;
+  PetscCallHIPX(hipxMatGetValues(h->dA, a->a));
+  h->dev_newer = PETSC_FALSE;
+  PetscCall(PetscObjectStateGet((PetscObject)A, &state));
+  h->synced_state = state + 1; /* what the object state will be when the interface function returns */
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode MatScale_SeqAIJHIPX(Mat A, PetscScalar alpha) /* MatScale_SeqAIJ aij.c:2604-2617 */
+{
+  Mat_SeqAIJHIPX *h = (Mat_SeqAIJHIPX *)A->spptr;
+  Mat_SeqAIJ     *a = (Mat_SeqAIJ *)A->data;
+  hipxMat         dA;
+
+  PetscFunctionBegin;
+  PetscCall(MatSeqAIJHIPXGetDeviceMat(A, &dA));
+  PetscCallHIPX(hipxMatScale(dA, alpha));
+  PetscCall(MatSeqAIJHIPXDeviceValuesChanged(A));
+  (void)h;
+  PetscCall(PetscLogFlops(a->nz));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode MatDiagonalScale_SeqAIJHIPX(Mat A, Vec ll, Vec rr) /* MatDiagonalScale_SeqAIJ aij.c:2333-2371 */
+{
+  Mat_SeqAIJHIPX    *h = (Mat_SeqAIJHIPX *)A->spptr;
+  Mat_SeqAIJ        *a = (Mat_SeqAIJ *)A->data;
+  hipxMat            dA;
+  const PetscScalar *l = NULL, *r = NULL;
+  void              *tl = NULL, *tr = NULL;
+  PetscInt           m, n;
+
+  PetscFunctionBegin;
+  if (ll) {
+    PetscCall(VecGetLocalSize(ll, &m));
+    PetscCheck(m == A->rmap->n, PETSC_COMM_SELF, PETSC_ERR_ARG_SIZ, "Left scaling vector wrong length");
+  }
+  if (rr) {
+    PetscCall(VecGetLocalSize(rr, &n));
+    PetscCheck(n == A->cmap->n, PETSC_COMM_SELF, PETSC_ERR_ARG_SIZ, "Right scaling vector wrong length");
+  }
+  PetscCall(MatSeqAIJHIPXGetDeviceMat(A, &dA));
+  if (ll) PetscCall(VecHIPXGetDeviceRead(ll, &l, &tl));
+  if (rr) PetscCall(VecHIPXGetDeviceRead(rr, &r, &tr));
+  PetscCallHIPX(hipxMatDiagonalScale(dA, l, r));
+  if (rr) PetscCall(VecHIPXRestoreDeviceRead(rr, &r, &tr));
+  if (ll) PetscCall(VecHIPXRestoreDeviceRead(ll, &l, &tl));
+  PetscCall(MatSeqAIJHIPXDeviceValuesChanged(A));
+  (void)h;
+  PetscCall(PetscLogFlops((ll ? a->nz : 0) + (rr ? a->nz : 0)));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 static PetscErrorCode MatAssemblyEnd_SeqAIJHIPX(Mat A, MatAssemblyType mode)
 {
   Mat_SeqAIJHIPX *h = (Mat_SeqAIJHIPX *)A->spptr;
@@ -324,6 +393,8 @@ static PetscErrorCode MatConvert_SeqAIJ_SeqAIJHIPX(Mat A, MatType mtype, MatReus
   B->ops->destroy        = MatDestroy_SeqAIJHIPX;
   B->ops->duplicate      = MatDuplicate_SeqAIJHIPX;
   B->ops->setfromoptions = MatSetFromOptions_SeqAIJHIPX;
+  B->ops->scale          = MatScale_SeqAIJHIPX;
+  B->ops->diagonalscale  = MatDiagonalScale_SeqAIJHIPX;
   PetscCall(PetscObjectQueryFunction((PetscObject)B, "MatSetPreallocationCOO_C", &h->parent_prealloc_coo));
   PetscCall(PetscObjectComposeFunction((PetscObject)B, "MatSetPreallocationCOO_C", MatSetPreallocationCOO_SeqAIJHIPX));
   PetscCall(PetscObjectComposeFunction((PetscObject)B, "MatSetValuesCOO_C", MatSetValuesCOO_SeqAIJHIPX));

@@ -114,6 +114,19 @@ def test_matmult_bit_exact_cpu_vs_hipx():
     assert yc == yg and len(yc) == 1000
 
 
+def test_matscale_diagonalscale_on_device_then_host_update_bit_exact():
+    """MatScale / MatDiagonalScale run on the device copy (hipxMatScale, hipxMatDiagonalScale: (a l_i) r_j like
+    aij.c:2333-2371), a host-side MatSetValue + assembly and another MatDiagonalScale follow: the product is bit-identical to the
+    CPU types', and so is the solve's history."""
+    a = "-stencil 27 -n 10 -mat_ops -dump_y -ksp_type gmres -pc_type jacobi -ksp_rtol 1e-8 -history".split()
+    cpu, gpu = run("ref_driver", a), run("ref_driver", a + HIPX)
+    yc = [l for l in cpu.splitlines() if l.startswith("y ")]
+    yg = [l for l in gpu.splitlines() if l.startswith("y ")]
+    assert yc == yg and len(yc) == 1000
+    hc, hg = hist_of(cpu), hist_of(gpu)
+    assert len(hc) == len(hg) and np.abs(hc - hg).max() <= 1e-12 * hc[0]
+
+
 def test_bench_kspsolve_matmult_and_ksp_goldens_with_aijhipx():
     out = run("bench_kspsolve", ["-print_timing", "false", "-matmult", "-its", "10", "-n", "8", "-mat_type", "aijhipx", "-dll_prepend", PLUGIN])
     ref = run("bench_kspsolve", ["-print_timing", "false", "-matmult", "-its", "10", "-n", "8"])

@@ -69,7 +69,8 @@ def parse_driver(txt):
     return hist, y, (int(m.group(1)), int(m.group(2)), float(m.group(3))) if m else None
 
 
-@pytest.mark.parametrize("np_,args", [(2, "-stencil 7 -n 8"), (3, "-stencil 27 -n 6"), (3, "-stencil 5 -m 9 -n 7"), (2, "-stencil 27 -n 6 -dup_mat")])
+@pytest.mark.parametrize("np_,args", [(2, "-stencil 7 -n 8"), (3, "-stencil 27 -n 6"), (3, "-stencil 5 -m 9 -n 7"), (2, "-stencil 27 -n 6 -dup_mat"),
+                                      (2, "-stencil 27 -n 6 -mat_ops"), (3, "-stencil 7 -n 8 -mat_ops")])  # MatScale / MatDiagonalScale on the device blocks
 def test_matmult_mpiaijhipx_bit_exact_vs_cpu_mpi(np_, args):
     a = args.split() + ["-dump_y", "-ksp_max_it", "1"]
     _, y_cpu, _ = parse_driver(mpirun(np_, "ref_driver", a, False))
