@@ -889,7 +889,8 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
 // The loader wave of a panel: operands of the own strands into the operand ring, far strands into the window.
 template <int KIND, bool ALIGNED, bool SPLIT>
 __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *lds, volatile st_lds_int *s_lead, volatile st_lds_int *s_trail, volatile st_lds_int *s_ctl, const int lane,
-                                               const unsigned panel, const long long S0, const long long S, const int len, const unsigned char *__restrict__ tid, const double *asrc,
+                                               const unsigned panel, const long long S0, const int cnt, const long long S, const int len, const unsigned char *__restrict__ tid,
+                                               const double *asrc,
                                                const double *xold, const double *xnew, unsigned long long *stats)
 {
   constexpr bool FWD     = (KIND == 0 || KIND == 3);
@@ -911,7 +912,7 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
     if (b < P.nbands) {
       const int       w = P.band[b].width, u = lane + 64 * which;
       const long long strand = S0 + u + P.band[b].dsmin;
-      dvalid[d] = u < 64 + w - 1 && (strand < S0 || strand > S0 + 63) && strand >= 0 && strand < P.nstr;
+      dvalid[d] = u < 64 + w - 1 && (strand < S0 || strand >= S0 + cnt) && strand >= 0 && strand < P.nstr;
     }
     if (d >= ST_NB && dvalid[d]) any_hi = true;
   }
@@ -989,7 +990,7 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
           const long long strand = S0 + u + P.band[b].dsmin;
           int lead = -1000000, trail = 1000000;  // most / least advanced consumer of this row that is still running
           for (int c = u - (w - 1); c <= u; c++) {
-            if (c >= 0 && c < 64) {
+            if (c >= 0 && c < cnt) {
               const int pl = SPLIT ? max((int)s_lead[c], (int)s_lead[64 + c]) : (int)s_lead[c], pt = s_trail[c];  // (SPLIT: the F waves lead, the C wave trails)
               if (pt < st_strand_len(S0 + c, P)) {
                 if (pl > lead) lead = pl;
@@ -1095,7 +1096,8 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
 template <int KIND, bool ALIGNED, int ME, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 256 : 128, SPLIT ? 2 : 1) void sor_strand_kernel(const StParams P, const unsigned char *__restrict__ tid, const StTinfo *__restrict__ g_tinfo,
                                                                        const StDiag *__restrict__ g_tdiag, const StEntry *__restrict__ g_dep, const StEntry *__restrict__ g_old,
-                                                                       const StEntry *__restrict__ g_depF, const StEntry *__restrict__ g_depC, const double *asrc, double *t,
+                                                                       const StEntry *__restrict__ g_depF, const StEntry *__restrict__ g_depC, const int *__restrict__ pstart,
+                                                                       const double *asrc, double *t,
                                                                        const double *xold, double *xnew, double omega, unsigned int *ctl, unsigned long long *stats)
 {
   constexpr int NT = SPLIT ? 256 : 128;
@@ -1145,18 +1147,21 @@ __global__ __launch_bounds__(SPLIT ? 256 : 128, SPLIT ? 2 : 1) void sor_strand_k
     __syncthreads();
     const unsigned panel = (unsigned)s_ctl[0];
     if (panel >= (unsigned)P.npanels) return;
-    const long long S0  = (long long)panel * 64;
+    // a panel is a run of <= 64 consecutive strands (pstart: built by the host, see strand_build: runs are cut so that a
+    // panel's far strands end where a producer panel ends)
+    const long long S0  = pstart[panel];
+    const int       cnt = pstart[panel + 1] - pstart[panel];
     const long long S   = S0 + lane;
-    const int       len = st_strand_len(S, P);
+    const int       len = lane < cnt ? st_strand_len(S, P) : 0;
     if (SPLIT) {
       if (wave == 0) st_compute_role<KIND, ST_MC, 2>(P, lds, lds_base, s_prog, s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, stats, 0);
       else if (wave <= 2)
         st_compute_role<KIND, ST_MF, 1>(P, lds, lds_base, s_progF + 64 * (wave - 1), s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, nullptr, wave - 1,
                                         stats ? stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)P.L + 2 * 4096 * 8 + 48 + 8 * (wave - 1) : nullptr);
-      else st_loader_role<KIND, ALIGNED, true>(P, lds, s_progF, s_prog, s_ctl, lane, panel, S0, S, len, tid, asrc, xold, xnew, stats);
+      else st_loader_role<KIND, ALIGNED, true>(P, lds, s_progF, s_prog, s_ctl, lane, panel, S0, cnt, S, len, tid, asrc, xold, xnew, stats);
     } else {
       if (wave == 0) st_compute_role<KIND, ME, 0>(P, lds, lds_base, s_prog, s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, stats, 0);
-      else st_loader_role<KIND, ALIGNED, false>(P, lds, s_prog, s_prog, s_ctl, lane, panel, S0, S, len, tid, asrc, xold, xnew, stats);
+      else st_loader_role<KIND, ALIGNED, false>(P, lds, s_prog, s_prog, s_ctl, lane, panel, S0, cnt, S, len, tid, asrc, xold, xnew, stats);
     }
     // All roles share this function: without this, loads the LOADER branch may leave pending at the back edge of the panel loop
     // count as pending in the COMPUTE branches too (the compiler merges the paths), which plants vmcnt waits -- i.e. waits for
@@ -1190,6 +1195,8 @@ struct StrandDir {
   StTinfo  *d_tinfo = nullptr;
   StDiag   *d_tdiag = nullptr;
   StEntry  *d_dep = nullptr, *d_old = nullptr, *d_depF = nullptr, *d_depC = nullptr;
+  int      *d_pstart = nullptr;  // first strand of every panel (npanels + 1)
+  std::vector<int>    h_pstart;
   std::vector<StDiag> h_tdiag;
 };
 struct StrandState {
@@ -1215,6 +1222,7 @@ void strand_free(StrandState *T)
     (void)hipFree(D.d_dep);
     (void)hipFree(D.d_depF);
     (void)hipFree(D.d_depC);
+    (void)hipFree(D.d_pstart);
     (void)hipFree(D.d_old);
   }
   (void)hipFree(T->d_ctl);
@@ -1303,6 +1311,39 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
     }
     if (!fits) continue;
     P.nbands = nb;
+    // Panel boundaries.  With 64 strands per panel and ny a multiple of 64 the boundaries of every plane line up, and the last
+    // lane of panel (z, b) needs line 64 (b + 1) of plane z - 1 = the FIRST lane of panel (z - 1, b + 1), which itself waits for
+    // the last lane of (z - 1, b): two loader hand-offs per plane (measured 12.4 us per plane hop = 2 rows + 2 x 4.9 us).  So the
+    // boundaries of plane z are shifted by z (mod 64) lines: its panels end where panels of plane z - 1 end, seen through the
+    // largest delta of the farthest band, and a plane hop costs ONE hand-off.  Planes stay separate panels (the first line of a
+    // plane does not depend on the last line of the plane below it; a panel straddling the two would chain them: tried, 25x
+    // slower).  Any partition into runs of <= 64 consecutive strands is valid (dependencies only point to lower strands), so this
+    // is a scheduling choice only (HIPX_SOR_STAGGER=0: off).
+    {
+      static const bool stagger_on = !(getenv("HIPX_SOR_STAGGER") && atoi(getenv("HIPX_SOR_STAGGER")) == 0);
+      long long np = 0, sh = 0;  // strands per plane, boundary shift per plane
+      if (nb >= 2 && P.band[0].width >= 2 && (P.band[0].width & 1)) {
+        np = -((long long)P.band[0].dsmin + (P.band[0].width - 1) / 2);      // centre delta of the farthest band: one plane down
+        sh = np + ((long long)P.band[0].dsmin + P.band[0].width - 1);         // np - |largest delta| (1 for the 27-point stencil)
+        if (!stagger_on || np < 128 || sh <= 0 || sh >= 64) np = sh = 0;
+      }
+      D.h_pstart.clear();
+      if (!np) {
+        for (long long s0 = 0; s0 < P.nstr; s0 += 64) D.h_pstart.push_back((int)s0);
+      } else {
+        for (long long z = 0; z * np < P.nstr; z++) {
+          const long long base = z * np, end = std::min<long long>(P.nstr, base + np), off = (z * sh) % 64;
+          long long       s0 = base, c = off ? 64 - off : 64;
+          while (s0 < end) {
+            D.h_pstart.push_back((int)s0);
+            s0 += std::min<long long>(c, end - s0);
+            c = 64;
+          }
+        }
+      }
+      D.h_pstart.push_back((int)P.nstr);
+      P.npanels = (hipx_int)D.h_pstart.size() - 1;
+    }
     auto band_of = [&](int ds) {
       for (int b = 0; b < nb; b++)
         if (ds >= P.band[b].dsmin && ds < P.band[b].dsmin + P.band[b].width) return b;
@@ -1401,6 +1442,8 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
     HIPX_HIP(hipMemcpyAsync(D.d_tinfo, tinfo.data(), sizeof(StTinfo) * (size_t)ntmpl, hipMemcpyHostToDevice, st));
     HIPX_HIP(hipMemcpyAsync(D.d_dep, dep.data(), sizeof(StEntry) * dep.size(), hipMemcpyHostToDevice, st));
     HIPX_HIP(hipMemcpyAsync(D.d_old, old.data(), sizeof(StEntry) * old.size(), hipMemcpyHostToDevice, st));
+    HIPX_HIP(hipMalloc((void **)&D.d_pstart, sizeof(int) * D.h_pstart.size()));
+    HIPX_HIP(hipMemcpyAsync(D.d_pstart, D.h_pstart.data(), sizeof(int) * D.h_pstart.size(), hipMemcpyHostToDevice, st));
     if (P.split) {
       HIPX_HIP(hipMalloc((void **)&D.d_depF, sizeof(StEntry) * depF.size()));
       HIPX_HIP(hipMalloc((void **)&D.d_depC, sizeof(StEntry) * depC.size()));
@@ -1487,7 +1530,7 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
       HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       attr_set[KIND][ai] = true;
     }
-    kern<<<grid, nthreads, (size_t)P.lds_bytes, st>>>(P, T->d_tid, D.d_tinfo, D.d_tdiag, D.d_dep, D.d_old, D.d_depF, D.d_depC, asrc, t, xold, xnew, omega, T->d_ctl,
+    kern<<<grid, nthreads, (size_t)P.lds_bytes, st>>>(P, T->d_tid, D.d_tinfo, D.d_tdiag, D.d_dep, D.d_old, D.d_depF, D.d_depC, D.d_pstart, asrc, t, xold, xnew, omega, T->d_ctl,
                                                        dbg ? T->d_stats : nullptr);
     return HIPX_SUCCESS;
   };
