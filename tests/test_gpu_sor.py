@@ -267,3 +267,18 @@ def test_gmres_sor_and_cg_ssor_histories(hx, kind, n):
     g = solve_gpu("cg", ai, aj, aa, b, pc="sor", rtol=1e-8)
     o = exact_solve("cg", ai, aj, aa, b, pc="sor", rtol=1e-8)
     compare(g, o, 1e-8)
+
+
+@pytest.mark.parametrize("env", [{}, {"HIPX_SOR_SPLIT": "0"}, {"HIPX_SOR_SPLIT": "2"}, {"HIPX_SOR_STAGGER": "0"}, {"HIPX_SOR_SPLIT": "2", "HIPX_SOR_WG_PER_CU": "1"}],
+                         ids=["default", "nosplit", "split-all", "nostagger", "split-all-1wg"])
+def test_strand_kernel_variants_bit_exact(env):
+    """The strand kernels' variants (two-wave / split C-F-F-loader kernel for forward only or for every kind, staggered panel
+    boundaries on / off, one or two workgroups per CU) all give the reference's bits: tests/_sor_variant_worker.py, one process per
+    variant (the switches are read once per process)."""
+    import subprocess
+    import sys
+    e = dict(os.environ, **env)
+    e["PYTHONPATH"] = os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__))), e.get("PYTHONPATH", "")])
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_sor_variant_worker.py")], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "SOR_VARIANT_OK" in r.stdout, r.stdout[-2000:]
