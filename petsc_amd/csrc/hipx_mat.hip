@@ -1668,7 +1668,9 @@ int ensure_templates(hipxMat A)
 // default -- the smaller chunk keeps the x window of an XCD inside its L2) | 2 (4 rows, uniform fast path).  Tried and dropped
 // (measured on MI355X, 7-pt 256^3 inside CG): the template cached in scalar registers with all gathers of a chunk issued as one
 // group -- 116 VGPRs, 4 waves per SIMD: 0.163 ms against 0.146 ms; the kernel wants occupancy, not fewer round trips.  Also tried:
-// adjacent row pairs per thread with one 16-byte gather per entry (half the memory instructions): 0.169 ms against 0.144 ms.
+// adjacent row pairs per thread with one 16-byte gather per entry (half the memory instructions): 0.169 ms against 0.144 ms; the x
+// ranges a chunk touches copied into an LDS tile with 16-byte coalesced loads and the row sums formed from LDS (one global round
+// trip per chunk, 40 VGPRs, 16 KiB of LDS per workgroup): 0.163 ms against 0.146 ms (0.137 against 0.114 stand-alone).
 int tmpl_cfg()
 {
   static const int v = getenv("HIPX_TMPL_CFG") ? atoi(getenv("HIPX_TMPL_CFG")) : 1;
