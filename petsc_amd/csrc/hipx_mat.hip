@@ -1670,7 +1670,8 @@ int ensure_templates(hipxMat A)
 // group -- 116 VGPRs, 4 waves per SIMD: 0.163 ms against 0.146 ms; the kernel wants occupancy, not fewer round trips.  Also tried:
 // adjacent row pairs per thread with one 16-byte gather per entry (half the memory instructions): 0.169 ms against 0.144 ms; the x
 // ranges a chunk touches copied into an LDS tile with 16-byte coalesced loads and the row sums formed from LDS (one global round
-// trip per chunk, 40 VGPRs, 16 KiB of LDS per workgroup): 0.163 ms against 0.146 ms (0.137 against 0.114 stand-alone).
+// trip per chunk, 40 VGPRs, 16 KiB of LDS per workgroup): 0.163 ms against 0.146 ms (0.137 against 0.114 stand-alone); one chunk per
+// workgroup without the ticket queue (XCD-aware static map, 32768 one-shot workgroups): 0.157 ms against 0.146 ms.
 int tmpl_cfg()
 {
   static const int v = getenv("HIPX_TMPL_CFG") ? atoi(getenv("HIPX_TMPL_CFG")) : 1;
