@@ -1728,7 +1728,7 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
   switch (cfg) {
   case 0: HIPX_TMPL_LAUNCH(2, 4, false); break;
   case 2: HIPX_TMPL_LAUNCH(4, 4, true); break;
-  default: HIPX_TMPL_LAUNCH(2, 4, true); break;
+  default: HIPX_TMPL_LAUNCH(2, 2, true); break;
   }
 #undef HIPX_TMPL_LAUNCH
   HIPX_LAUNCH_CHECK();
