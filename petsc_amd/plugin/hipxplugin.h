@@ -66,4 +66,5 @@ PETSC_INTERN PetscErrorCode PCCreate_JacobiHIPX(PC);
 PETSC_INTERN PetscErrorCode KSPCreate_CGHIPX(KSP); /* "cghipx": KSPCG with the fused device kernels on the hot-path configuration */
 PETSC_INTERN PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA); /* uploads / refreshes the device CSR */
 PETSC_INTERN PetscBool      MatIsSeqAIJHIPX(Mat A);
+PETSC_INTERN PetscErrorCode MatSeqAIJHIPXSetValuesCOO_Private(Mat A, hipxCOO coo, const PetscScalar v[], PetscCount n, InsertMode imode);
 PETSC_INTERN PetscErrorCode MatMPIAIJHIPXGetDevice(Mat A, hipxMat *dA, hipxMat *dB, hipxHalo *halo, Vec *lvec); /* halo == NULL: no device exchange */

@@ -224,18 +224,15 @@ static PetscErrorCode MatSetPreallocationCOO_SeqAIJHIPX(Mat A, PetscCount n, Pet
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
-static PetscErrorCode MatSetValuesCOO_SeqAIJHIPX(Mat A, const PetscScalar v[], InsertMode imode)
+/* values v[] (host or device pointer, n entries) through device-resident COO maps into the device CSR of A; also used by
+   MATMPIAIJHIPX for its two blocks (MatSetValuesCOO_MPIAIJ's local part, mpiaij.c:6803-6813) */
+PetscErrorCode MatSeqAIJHIPXSetValuesCOO_Private(Mat A, hipxCOO coo, const PetscScalar v[], PetscCount n, InsertMode imode)
 {
-  Mat_SeqAIJHIPX      *h = (Mat_SeqAIJHIPX *)A->spptr;
-  Mat_SeqAIJ          *a = (Mat_SeqAIJ *)A->data;
-  PetscContainer       container;
-  MatCOOStruct_SeqAIJ *coo;
-  int                  ondev = 0;
+  Mat_SeqAIJHIPX *h = (Mat_SeqAIJHIPX *)A->spptr;
+  Mat_SeqAIJ     *a = (Mat_SeqAIJ *)A->data;
+  int             ondev = 0;
 
   PetscFunctionBegin;
-  PetscCheck(h->coo, PETSC_COMM_SELF, PETSC_ERR_ORDER, "MatSetPreallocationCOO() has not been called");
-  PetscCall(PetscObjectQuery((PetscObject)A, "__PETSc_MatCOOStruct_Host", (PetscObject *)&container));
-  PetscCall(PetscContainerGetPointer(container, &coo));
   if (!h->dA || h->nonzerostate != A->nonzerostate) { /* device CSR of the preallocated pattern; values start at zero (aij.c:4693) */
     if (h->dA) PetscCallHIPX(hipxMatDestroy(&h->dA));
     if (imode == ADD_VALUES) PetscCallHIPX(hipxMatCreateCSR(A->rmap->n, A->cmap->n, a->i, a->j, a->a, &h->dA));
@@ -246,8 +243,23 @@ static PetscErrorCode MatSetValuesCOO_SeqAIJHIPX(Mat A, const PetscScalar v[], I
     PetscCallHIPX(hipxMatUpdateValues(h->dA, a->a));
   }
   PetscCallHIPX(hipxPointerIsDevice(v, &ondev));
-  PetscCallHIPX(hipxMatSetValuesCOO(h->dA, h->coo, v, (int64_t)coo->n, ondev, imode == INSERT_VALUES ? 1 : 0));
+  PetscCallHIPX(hipxMatSetValuesCOO(h->dA, coo, v, (int64_t)n, ondev, imode == INSERT_VALUES ? 1 : 0));
   h->dev_newer = PETSC_TRUE;
+  PetscCall(PetscObjectStateIncrease((PetscObject)A)); /* like MatSeqAIJRestoreArray: cached diagonals / norms of the block are stale */
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode MatSetValuesCOO_SeqAIJHIPX(Mat A, const PetscScalar v[], InsertMode imode)
+{
+  Mat_SeqAIJHIPX      *h = (Mat_SeqAIJHIPX *)A->spptr;
+  PetscContainer       container;
+  MatCOOStruct_SeqAIJ *coo;
+
+  PetscFunctionBegin;
+  PetscCheck(h->coo, PETSC_COMM_SELF, PETSC_ERR_ORDER, "MatSetPreallocationCOO() has not been called");
+  PetscCall(PetscObjectQuery((PetscObject)A, "__PETSc_MatCOOStruct_Host", (PetscObject *)&container));
+  PetscCall(PetscContainerGetPointer(container, &coo));
+  PetscCall(MatSeqAIJHIPXSetValuesCOO_Private(A, h->coo, v, coo->n, imode));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 

@@ -26,6 +26,10 @@ typedef struct {
   PetscErrorCode (*parent_destroy)(Mat);
   PetscErrorCode (*parent_mult)(Mat, Vec, Vec);
   PetscErrorCode (*parent_multadd)(Mat, Vec, Vec, Vec);
+  PetscErrorCode (*parent_prealloc_coo)(Mat, PetscCount, PetscInt[], PetscInt[]);
+  PetscErrorCode (*parent_setvalues_coo)(Mat, const PetscScalar[], InsertMode);
+  hipxCOO          cooA, cooB; /* device copies of Ajmap1/Aperm1 and Bjmap1/Bperm1 (MatCOOStruct_MPIAIJ, mpiaij.h:62-89) */
+  PetscBool        coo_local;  /* no rank sends or receives COO entries: MatSetValuesCOO runs on the device */
   hipxHalo         halo;
   PetscInt         transport; /* 0 host, 1 ipc, 2 rccl */
   PetscObjectState nzstate;   /* nonzero state the plan was built from */
@@ -254,6 +258,57 @@ static PetscErrorCode MatAssemblyEnd_MPIAIJHIPX(Mat A, MatAssemblyType mode)
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+/* COO assembly.  The parent builds the pattern, the blocks (already seqaijhipx: it converts them to the root type,
+   mpiaij.c:6725-6726) and the maps; when no entry has to travel between ranks -- every rank sets its own rows, as
+   bench_kspsolve.c:301-302 does -- MatSetValuesCOO is two applications of the device kernel, one per block, and the values never
+   touch the host.  Otherwise the parent's host path (PetscSFReduce of the remote entries) runs as before. */
+static PetscErrorCode MatSetPreallocationCOO_MPIAIJHIPX(Mat A, PetscCount n, PetscInt coo_i[], PetscInt coo_j[])
+{
+  Mat_MPIAIJHIPX      *h = (Mat_MPIAIJHIPX *)A->spptr;
+  Mat_MPIAIJ          *a;
+  PetscContainer       container;
+  MatCOOStruct_MPIAIJ *coo;
+  PetscMPIInt          mine, all;
+
+  PetscFunctionBegin;
+  if (h->cooA) PetscCallHIPX(hipxCOODestroy(&h->cooA));
+  if (h->cooB) PetscCallHIPX(hipxCOODestroy(&h->cooB));
+  h->coo_local = PETSC_FALSE;
+  PetscCall((*h->parent_prealloc_coo)(A, n, coo_i, coo_j));
+  a = (Mat_MPIAIJ *)A->data;
+  PetscCall(PetscObjectQuery((PetscObject)A, "__PETSc_MatCOOStruct_Host", (PetscObject *)&container));
+  PetscCall(PetscContainerGetPointer(container, &coo));
+  mine = (coo->sendlen == 0 && coo->recvlen == 0 && coo->Annz2 == 0 && coo->Bnnz2 == 0 && MatIsSeqAIJHIPX(a->A) && MatIsSeqAIJHIPX(a->B)) ? 1 : 0;
+  PetscCallMPI(MPIU_Allreduce(&mine, &all, 1, MPI_INT, MPI_MIN, PetscObjectComm((PetscObject)A)));
+  if (all) {
+    PetscCallHIPX(hipxCOOCreate((int64_t)coo->Annz, (const int64_t *)coo->Ajmap1, (int64_t)coo->Atot1, (const int64_t *)coo->Aperm1, &h->cooA));
+    PetscCallHIPX(hipxCOOCreate((int64_t)coo->Bnnz, (const int64_t *)coo->Bjmap1, (int64_t)coo->Btot1, (const int64_t *)coo->Bperm1, &h->cooB));
+    h->coo_local = PETSC_TRUE;
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode MatSetValuesCOO_MPIAIJHIPX(Mat A, const PetscScalar v[], InsertMode imode)
+{
+  Mat_MPIAIJHIPX      *h = (Mat_MPIAIJHIPX *)A->spptr;
+  Mat_MPIAIJ          *a = (Mat_MPIAIJ *)A->data;
+  PetscContainer       container;
+  MatCOOStruct_MPIAIJ *coo;
+
+  PetscFunctionBegin;
+  if (!h->coo_local) {
+    PetscCall((*h->parent_setvalues_coo)(A, v, imode));
+    PetscFunctionReturn(PETSC_SUCCESS);
+  }
+  PetscCall(PetscObjectQuery((PetscObject)A, "__PETSc_MatCOOStruct_Host", (PetscObject *)&container));
+  PetscCheck(container, PetscObjectComm((PetscObject)A), PETSC_ERR_PLIB, "Not found MatCOOStruct on this matrix");
+  PetscCall(PetscContainerGetPointer(container, &coo));
+  if (getenv("HIPX_TRACE_COO")) fprintf(stderr, "[petschipx] MatSetValuesCOO_MPIAIJHIPX: device path, %lld + %lld nonzeros\n", (long long)coo->Annz, (long long)coo->Bnnz);
+  PetscCall(MatSeqAIJHIPXSetValuesCOO_Private(a->A, h->cooA, v, coo->n, imode)); /* mpiaij.c:6804-6808 */
+  PetscCall(MatSeqAIJHIPXSetValuesCOO_Private(a->B, h->cooB, v, coo->n, imode)); /* mpiaij.c:6809-6813 */
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 static PetscErrorCode MatDestroy_MPIAIJHIPX(Mat A)
 {
   Mat_MPIAIJHIPX *h = (Mat_MPIAIJHIPX *)A->spptr;
@@ -261,6 +316,10 @@ static PetscErrorCode MatDestroy_MPIAIJHIPX(Mat A)
 
   PetscFunctionBegin;
   if (h->halo) PetscCallHIPX(hipxHaloDestroy(&h->halo));
+  if (h->cooA) PetscCallHIPX(hipxCOODestroy(&h->cooA));
+  if (h->cooB) PetscCallHIPX(hipxCOODestroy(&h->cooB));
+  PetscCall(PetscObjectComposeFunction((PetscObject)A, "MatSetPreallocationCOO_C", NULL));
+  PetscCall(PetscObjectComposeFunction((PetscObject)A, "MatSetValuesCOO_C", NULL));
   PetscCall(PetscFree(A->spptr));
   PetscCall((*pdestroy)(A));
   PetscFunctionReturn(PETSC_SUCCESS);
@@ -283,6 +342,10 @@ PetscErrorCode MatCreate_MPIAIJHIPX(Mat B)
   B->ops->destroy       = MatDestroy_MPIAIJHIPX;
   B->ops->mult          = MatMult_MPIAIJHIPX;
   B->ops->multadd       = MatMultAdd_MPIAIJHIPX;
+  PetscCall(PetscObjectQueryFunction((PetscObject)B, "MatSetPreallocationCOO_C", &h->parent_prealloc_coo));
+  PetscCall(PetscObjectQueryFunction((PetscObject)B, "MatSetValuesCOO_C", &h->parent_setvalues_coo));
+  PetscCall(PetscObjectComposeFunction((PetscObject)B, "MatSetPreallocationCOO_C", MatSetPreallocationCOO_MPIAIJHIPX));
+  PetscCall(PetscObjectComposeFunction((PetscObject)B, "MatSetValuesCOO_C", MatSetValuesCOO_MPIAIJHIPX));
   PetscCall(PetscFree(B->defaultvectype));
   PetscCall(PetscStrallocpy(VECHIPX, &B->defaultvectype));
   PetscCall(PetscObjectChangeTypeName((PetscObject)B, MATMPIAIJHIPX));

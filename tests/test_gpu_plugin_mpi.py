@@ -78,6 +78,19 @@ def test_matmult_mpiaijhipx_bit_exact_vs_cpu_mpi(np_, args):
     assert len(y_cpu) > 0 and y_gpu == y_cpu  # printed with %.17g: string equality is bit equality
 
 
+@pytest.mark.parametrize("np_", [2, 3])
+def test_bench_kspsolve_coo_assembly_on_device_np(np_):
+    """bench_kspsolve.c:301-302 assembles with MatSetPreallocationCOO / MatSetValuesCOO, every rank its own rows: with
+    MATMPIAIJHIPX the values go through the device COO kernel of both blocks (MatSetValuesCOO_MPIAIJHIPX, no entry travels
+    between ranks); the -matmult leg and the KSP leg print what the CPU types print."""
+    mm = ["-print_timing", "false", "-matmult", "-its", "10", "-n", "8"]
+    assert mpirun(np_, "bench_kspsolve", mm + ["-mat_type", "aijhipx", "-options_left", "no"], True).split() == mpirun(np_, "bench_kspsolve", mm, False).split()
+    traced = mpirun(np_, "bench_kspsolve", mm + ["-mat_type", "aijhipx", "-options_left", "no"], True, env={"HIPX_TRACE_COO": "1"})
+    assert traced.count("MatSetValuesCOO_MPIAIJHIPX: device path") == np_  # every rank took the device path
+    ks = ["-print_timing", "false", "-n", "8", "-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_rtol", "1e-8"]
+    assert mpirun(np_, "bench_kspsolve", ks + ["-mat_type", "aijhipx", "-options_left", "no"], True).split() == mpirun(np_, "bench_kspsolve", ks, False).split()
+
+
 def test_hipx_vectors_with_host_mpiaij_and_default_pc():
     """-vec_type hipx only: CPU MPIAIJ matrix, block Jacobi/ILU(0) default PC -- duplicates of MPI hipx vectors, local-vector
     views into them (PCApply_BJacobi_Singleblock), clean exit (heap-checked by glibc)."""
