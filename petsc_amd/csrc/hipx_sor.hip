@@ -477,11 +477,31 @@ __device__ __forceinline__ void st_lds_burst12(st_int4 (&o)[12], const unsigned 
                : "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11])
                : "memory");
 }
+__device__ __forceinline__ void st_lds_burst13(st_int4 (&o)[13], const unsigned (&a)[13])
+{
+  asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %8\n\tds_read_b128 %2, %9\n\tds_read_b128 %3, %10\n\tds_read_b128 %4, %11\n\tds_read_b128 %5, %12\n\tds_read_b128 %6, %13"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6])
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6])
+               : "memory");
+  asm volatile("ds_read_b128 %7, %13\n\tds_read_b128 %8, %14\n\tds_read_b128 %9, %15\n\tds_read_b128 %10, %16\n\tds_read_b128 %11, %17\n\tds_read_b128 %12, %18\n\ts_waitcnt lgkmcnt(0)"
+               : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12])
+               : "v"(a[7]), "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12])
+               : "memory");
+}
+__device__ __forceinline__ void st_lds_burst9(st_int4 (&o)[9], const unsigned (&a)[9])
+{
+  asm volatile("ds_read_b128 %0, %9\n\tds_read_b128 %1, %10\n\tds_read_b128 %2, %11\n\tds_read_b128 %3, %12\n\tds_read_b128 %4, %13\n\tds_read_b128 %5, %14\n\tds_read_b128 %6, %15\n\tds_read_b128 %7, %16\n\tds_read_b128 %8, %17\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8])
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8])
+               : "memory");
+}
 template <int ME>
 __device__ __forceinline__ void st_lds_burst(st_int4 (&o)[ME], const unsigned (&a)[ME])
 {
   if constexpr (ME == 4) st_lds_burst4(o, a);
+  else if constexpr (ME == 9) st_lds_burst9(o, a);
   else if constexpr (ME == 12) st_lds_burst12(o, a);
+  else if constexpr (ME == 13) st_lds_burst13(o, a);
   else st_lds_burst16(o, a);
 }
 // The per-iteration burst of the compute wave: the ME window slots of the current row AND the two halves of an operand-ring
@@ -525,12 +545,37 @@ __device__ __forceinline__ void st_lds_burst_row12(st_int4 (&o)[12], st_int4 &w0
                : "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(ra)
                : "memory");
 }
+__device__ __forceinline__ void st_lds_burst_row13(st_int4 (&o)[13], st_int4 &w0, st_int4 &w1, const unsigned (&a)[13], unsigned ra, unsigned rt)
+{
+  asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\tds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(w1)
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(rt)
+               : "memory");
+  asm volatile("ds_read_b128 %8, %15\n\tds_read_b128 %9, %16\n\tds_read_b128 %10, %17\n\tds_read_b128 %11, %18\n\tds_read_b128 %12, %19\n\tds_read_b128 %13, %20\n\tds_read_b128 %14, %21\n\ts_waitcnt lgkmcnt(0)"
+               : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(w1), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]),
+                 "=&v"(w0)
+               : "v"(a[7]), "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(ra)
+               : "memory");
+}
+__device__ __forceinline__ void st_lds_burst_row9(st_int4 (&o)[9], st_int4 &w0, st_int4 &w1, const unsigned (&a)[9], unsigned ra, unsigned rt)
+{
+  asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %9\n\tds_read_b128 %4, %10\n\tds_read_b128 %5, %11"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(w1)
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(rt)
+               : "memory");
+  asm volatile("ds_read_b128 %6, %11\n\tds_read_b128 %7, %12\n\tds_read_b128 %8, %13\n\tds_read_b128 %9, %14\n\tds_read_b128 %10, %15\n\ts_waitcnt lgkmcnt(0)"
+               : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(w1), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(w0)
+               : "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(ra)
+               : "memory");
+}
 template <int ME>
 __device__ __forceinline__ void st_lds_burst_row(st_int4 (&o)[ME], st_int4 &w0, st_int4 &w1, const unsigned (&a)[ME], unsigned ra, unsigned rt)
 {
   // w1 <- 16 bytes at rt (the half that carries the tag: read FIRST), w0 <- 16 bytes at ra
   if constexpr (ME == 4) st_lds_burst_row4(o, w0, w1, a, ra, rt);
+  else if constexpr (ME == 9) st_lds_burst_row9(o, w0, w1, a, ra, rt);
   else if constexpr (ME == 12) st_lds_burst_row12(o, w0, w1, a, ra, rt);
+  else if constexpr (ME == 13) st_lds_burst_row13(o, w0, w1, a, ra, rt);
   else st_lds_burst_row16(o, w0, w1, a, ra, rt);
 }
 // agent-scope 8-byte load, complete on return (rare paths only: it drains this wave's stores as well)
@@ -1125,7 +1170,7 @@ __global__ __launch_bounds__(SPLIT ? 256 : 128, SPLIT ? 2 : 1) void sor_strand_k
     st_st4v(lds, P.off_tdiag + 16 * i, reinterpret_cast<const st_int4 *>(g_tdiag)[i]);
   }
   if (SPLIT) {
-    for (int i = threadIdx.x; i < P.ntmpl * ST_MF; i += NT) st_st4v(lds, P.off_depF + 16 * i, reinterpret_cast<const st_int4 *>(g_depF)[i]);
+    for (int i = threadIdx.x; i < P.ntmpl * (ME - ST_MC); i += NT) st_st4v(lds, P.off_depF + 16 * i, reinterpret_cast<const st_int4 *>(g_depF)[i]);
     for (int i = threadIdx.x; i < P.ntmpl * ST_MC; i += NT) st_st4v(lds, P.off_depC + 16 * i, reinterpret_cast<const st_int4 *>(g_depC)[i]);
   } else {
     for (int i = threadIdx.x; i < P.ndep; i += NT) st_st4v(lds, P.off_dep + 16 * i, reinterpret_cast<const st_int4 *>(g_dep)[i]);
@@ -1165,7 +1210,7 @@ __global__ __launch_bounds__(SPLIT ? 256 : 128, SPLIT ? 2 : 1) void sor_strand_k
     if (SPLIT) {
       if (wave == 0) st_compute_role<KIND, ST_MC, 2>(P, lds, lds_base, s_prog, s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, stats, 0);
       else if (wave <= 2)
-        st_compute_role<KIND, ST_MF, 1>(P, lds, lds_base, s_progF + 64 * (wave - 1), s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, nullptr, wave - 1,
+        st_compute_role<KIND, (SPLIT ? ME - ST_MC : ME), 1>(P, lds, lds_base, s_progF + 64 * (wave - 1), s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, nullptr, wave - 1,
                                         stats ? stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)P.L + 2 * 4096 * 8 + 48 + 8 * (wave - 1) : nullptr);
       else st_loader_role<KIND, ALIGNED, true>(P, lds, s_progF, s_prog, s_ctl, lane, panel, S0, cnt, S, len, tid, asrc, xold, xnew, stats);
     } else {
@@ -1367,7 +1412,7 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
       maxdep = std::max(maxdep, c);
     }
     if (maxdep > ST_ME) continue;  // rows with more dependency entries than the compute wave handles: level-ordered schedule
-    const int ME = maxdep <= 4 ? 4 : ST_ME;
+    const int ME = maxdep <= 4 ? 4 : (maxdep <= 13 ? 13 : ST_ME);  // 13: the 27-point class (3 fewer padding entries per row and iteration)
     for (int t = 0; t < ntmpl; t++) {
       StTinfo &ti = tinfo[(size_t)t];
       ti.dstart   = (int)dep.size();
@@ -1404,12 +1449,12 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
     // split kernel (ME 16): the list of a template cut into its first (up to) 12 and last (up to) 4 entries, fixed strides
     static const bool split_on = !(getenv("HIPX_SOR_SPLIT") && atoi(getenv("HIPX_SOR_SPLIT")) == 0);
     std::vector<StEntry> depF, depC;
-    P.split = (ME == ST_ME && split_on) ? 1 : 0;
+    P.split = (ME >= 13 && split_on) ? 1 : 0;
     if (P.split) {
       for (int t = 0; t < ntmpl; t++) {
         const StTinfo &ti = tinfo[(size_t)t];
         const int      nC = std::min(ti.dcnt, ST_MC), nF = ti.dcnt - nC;
-        for (int k = 0; k < ST_MF; k++) depF.push_back(k < nF ? dep[(size_t)ti.dstart + k] : StEntry{ST_NULLPK, 0, 0.0});
+        for (int k = 0; k < ME - ST_MC; k++) depF.push_back(k < nF ? dep[(size_t)ti.dstart + k] : StEntry{ST_NULLPK, 0, 0.0});
         for (int k = 0; k < ST_MC; k++) depC.push_back(k < nC ? dep[(size_t)ti.dstart + nF + k] : StEntry{ST_NULLPK, 0, 0.0});
       }
     }
@@ -1430,7 +1475,7 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
     if (P.split) {  // the split kernel's own layout: its two tables instead of the whole-row one, no old-value lists (kinds 0-2 only)
       StParams &Q = D.Ps;
       o           = P.off_dep;
-      Q.off_depF  = o; o += ntmpl * ST_MF * (int)sizeof(StEntry);
+      Q.off_depF  = o; o += ntmpl * (ME - ST_MC) * (int)sizeof(StEntry);
       Q.off_depC  = o; o += ntmpl * ST_MC * (int)sizeof(StEntry);
       Q.off_old   = o;
       Q.nold      = 0;
@@ -1523,7 +1568,7 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
   unsigned grid = (unsigned)std::min<long long>((long long)P.npanels, 256LL * per_cu);
   const bool aligned = (P.L % 8 == 0) && (P.m % 8 == 0) && ((reinterpret_cast<uintptr_t>(asrc) | reinterpret_cast<uintptr_t>(xold)) % 16 == 0);
   static const bool dbg = getenv("HIPX_SOR_DEBUG") != nullptr;
-  static bool attr_set[5][6] = {{false}};
+  static bool attr_set[5][10] = {{false}};
   // The split kernel pays when the far entries come FIRST in the row's list (forward sweeps: lower planes, then the previous line,
   // then the row's predecessor): the F waves run ahead with them.  In a backward sweep the list starts with the near entries, the
   // far subtractions depend on them, and nothing can run ahead (measured on the config-3 slab: forward 2.1 us per line and 0.94 us
@@ -1567,9 +1612,12 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
   int ierr;
   if (P.me == 4) ierr = aligned ? launch(sor_strand_kernel<KIND, true, 4, false>, 1) : launch(sor_strand_kernel<KIND, false, 4, false>, 0);
   else if (split) {
-    if constexpr (KIND <= 2) ierr = aligned ? launch(sor_strand_kernel<KIND, true, ST_ME, true>, 5) : launch(sor_strand_kernel<KIND, false, ST_ME, true>, 4);
-    else ierr = HIPX_ERR_SUP;
-  } else ierr = aligned ? launch(sor_strand_kernel<KIND, true, ST_ME, false>, 3) : launch(sor_strand_kernel<KIND, false, ST_ME, false>, 2);
+    if constexpr (KIND <= 2) {
+      if (P.me == 13) ierr = aligned ? launch(sor_strand_kernel<KIND, true, 13, true>, 9) : launch(sor_strand_kernel<KIND, false, 13, true>, 8);
+      else ierr = aligned ? launch(sor_strand_kernel<KIND, true, ST_ME, true>, 5) : launch(sor_strand_kernel<KIND, false, ST_ME, true>, 4);
+    } else ierr = HIPX_ERR_SUP;
+  } else if (P.me == 13) ierr = aligned ? launch(sor_strand_kernel<KIND, true, 13, false>, 7) : launch(sor_strand_kernel<KIND, false, 13, false>, 6);
+  else ierr = aligned ? launch(sor_strand_kernel<KIND, true, ST_ME, false>, 3) : launch(sor_strand_kernel<KIND, false, ST_ME, false>, 2);
   if (ierr) return ierr;
   HIPX_LAUNCH_CHECK();
   if (dbg) {
