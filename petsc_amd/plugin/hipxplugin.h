@@ -39,7 +39,6 @@ typedef struct {
   PetscScalar *d_array;      /* device copy, NULL until first needed */
   PetscInt     d_n;          /* allocated length */
   PetscBool    d_owned;      /* PETSC_FALSE for sub-arrays of a VecDuplicateVecs slab */
-  void        *slab_owner;   /* device slab shared by duplicatevecs siblings (freed by destroyvecs) */
   PetscInt     magic;
 } VecHIPXExt;
 
