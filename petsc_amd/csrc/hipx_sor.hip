@@ -1147,14 +1147,17 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
 // ME: dependency entries per row (the templates' lists are padded to ME with null entries: coefficient 0, pointing at a slot that
 // always reads {0.0, ST_NULLTAG}); 4 for the 5-/7-point operators, 16 for the 27-point one.  SPLIT (ME 16 only): three waves
 // per panel -- C, F, loader (see st_compute_role) -- instead of compute + loader.
-template <int KIND, bool ALIGNED, int ME, bool SPLIT>
+// DBG: the HIPX_SOR_DEBUG instrumentation is compiled into its own instantiation (the production kernel carries none of the
+// ~12 `if (stats)` tests per iteration)
+template <int KIND, bool ALIGNED, int ME, bool SPLIT, bool DBG>
 __global__ __launch_bounds__(SPLIT ? 256 : 128, SPLIT ? 2 : 1) void sor_strand_kernel(const StParams P, const unsigned char *__restrict__ tid, const StTinfo *__restrict__ g_tinfo,
                                                                        const StDiag *__restrict__ g_tdiag, const StEntry *__restrict__ g_dep, const StEntry *__restrict__ g_old,
                                                                        const StEntry *__restrict__ g_depF, const StEntry *__restrict__ g_depC, const int *__restrict__ pstart,
                                                                        const double *asrc, double *t,
-                                                                       const double *xold, double *xnew, double omega, unsigned int *ctl, unsigned long long *stats)
+                                                                       const double *xold, double *xnew, double omega, unsigned int *ctl, unsigned long long *stats_arg)
 {
   constexpr int NT = SPLIT ? 256 : 128;
+  unsigned long long *const stats = DBG ? stats_arg : nullptr;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   st_lds_char          *lds    = (st_lds_char *)smem;
   const unsigned        lds_base = (unsigned)(size_t)lds;  // byte address of the dynamic LDS region (for the hand-issued reads)
@@ -1568,7 +1571,7 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
   unsigned grid = (unsigned)std::min<long long>((long long)P.npanels, 256LL * per_cu);
   const bool aligned = (P.L % 8 == 0) && (P.m % 8 == 0) && ((reinterpret_cast<uintptr_t>(asrc) | reinterpret_cast<uintptr_t>(xold)) % 16 == 0);
   static const bool dbg = getenv("HIPX_SOR_DEBUG") != nullptr;
-  static bool attr_set[5][10] = {{false}};
+  static bool attr_set[5][20] = {{false}};
   // The split kernel pays when the far entries come FIRST in the row's list (forward sweeps: lower planes, then the previous line,
   // then the row's predecessor): the F waves run ahead with them.  In a backward sweep the list starts with the near entries, the
   // far subtractions depend on them, and nothing can run ahead (measured on the config-3 slab: forward 2.1 us per line and 0.94 us
@@ -1610,14 +1613,16 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
             (void *)xnew, (void *)T->d_ctl);
   }
   int ierr;
-  if (P.me == 4) ierr = aligned ? launch(sor_strand_kernel<KIND, true, 4, false>, 1) : launch(sor_strand_kernel<KIND, false, 4, false>, 0);
+#define HIPX_ST_LAUNCH(AL, MEV, SP, IDX) (dbg ? launch(sor_strand_kernel<KIND, AL, MEV, SP, true>, 2 * (IDX) + 1) : launch(sor_strand_kernel<KIND, AL, MEV, SP, false>, 2 * (IDX)))
+  if (P.me == 4) ierr = aligned ? HIPX_ST_LAUNCH(true, 4, false, 1) : HIPX_ST_LAUNCH(false, 4, false, 0);
   else if (split) {
     if constexpr (KIND <= 2) {
-      if (P.me == 13) ierr = aligned ? launch(sor_strand_kernel<KIND, true, 13, true>, 9) : launch(sor_strand_kernel<KIND, false, 13, true>, 8);
-      else ierr = aligned ? launch(sor_strand_kernel<KIND, true, ST_ME, true>, 5) : launch(sor_strand_kernel<KIND, false, ST_ME, true>, 4);
+      if (P.me == 13) ierr = aligned ? HIPX_ST_LAUNCH(true, 13, true, 9) : HIPX_ST_LAUNCH(false, 13, true, 8);
+      else ierr = aligned ? HIPX_ST_LAUNCH(true, ST_ME, true, 5) : HIPX_ST_LAUNCH(false, ST_ME, true, 4);
     } else ierr = HIPX_ERR_SUP;
-  } else if (P.me == 13) ierr = aligned ? launch(sor_strand_kernel<KIND, true, 13, false>, 7) : launch(sor_strand_kernel<KIND, false, 13, false>, 6);
-  else ierr = aligned ? launch(sor_strand_kernel<KIND, true, ST_ME, false>, 3) : launch(sor_strand_kernel<KIND, false, ST_ME, false>, 2);
+  } else if (P.me == 13) ierr = aligned ? HIPX_ST_LAUNCH(true, 13, false, 7) : HIPX_ST_LAUNCH(false, 13, false, 6);
+  else ierr = aligned ? HIPX_ST_LAUNCH(true, ST_ME, false, 3) : HIPX_ST_LAUNCH(false, ST_ME, false, 2);
+#undef HIPX_ST_LAUNCH
   if (ierr) return ierr;
   HIPX_LAUNCH_CHECK();
   if (dbg) {
