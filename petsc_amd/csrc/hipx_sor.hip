@@ -654,6 +654,9 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
       }
     }
   }
+  bool pubany[ST_NB];  // wave-uniform: does any lane publish into band b at all?  (the far bands of a stencil: no -- skip the block)
+#pragma unroll
+  for (int b = 0; b < ST_NB; b++) pubany[b] = __any(pubrow[b] != ~0u);
   unsigned  st_iters = 0, st_rowwait = 0, st_depwait = 0, st_fallback = 0;  // HIPX_SOR_DEBUG statistics (stats != nullptr)
   unsigned  f_far = 0, f_full = 0, f_fire = 0, f_row = 0;
   unsigned  st_nfast = 0, st_nslow = 0, st_nsetup = 0;                     // iterations in which ANY lane took the path
@@ -811,7 +814,7 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
           }
 #pragma unroll
           for (int b = 0; b < ST_NB; b++)
-            if (pubrow[b] != ~0u)  // the tag is the position plus the row's rotation; so is the slot
+            if (pubany[b] && pubrow[b] != ~0u)  // the tag is the position plus the row's rotation; so is the slot
               *reinterpret_cast<volatile st_lds_int4 *>((st_lds_char *)(size_t)(pubrow[b] + (unsigned)(((p + pubrot[b]) & (ST_WP - 1)) << 4))) = st_pack_slot(out, p + pubrot[b]);
           sor_publish(xnew + r, out);
           if (stats && p == 0 && (lane == 0 || lane == 63)) stats[16 + 4 * (size_t)panel + (lane ? 2 : 1)] = (unsigned long long)wall_clock64();
