@@ -625,13 +625,13 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
   double    s0 = 0.0, rb = 0.0, idiag = 0.0, mdiag = 0.0;
   unsigned  sa[ME];    // LDS byte address of the slot of entry j for the row at position p
   unsigned  wrow[ME];  // ... of slot 0 of its window row (the null slot for a padding entry)
-  int       msk[ME];   // ST_WP - 1, or 0 for a padding entry (its address does not move)
+  int       inc[ME];   // what the tag moves by per row of this wave: 1 (2 for an F wave), or 0 for a padding entry (ST_NULLTAG & 15 == 0: its slot is the null slot itself)
   int       apos[ME];  // the tag the slot must carry: position + rotation of the window row (the slot is apos & 15)
   double    cf[ME];    // coefficient
 #pragma unroll
   for (int j = 0; j < ME; j++) {
     sa[j] = wrow[j] = lds_base + (unsigned)P.off_null;
-    msk[j]  = 0;
+    inc[j]  = 0;
     apos[j] = ST_NULLTAG;
     cf[j]   = 0.0;
   }
@@ -685,9 +685,9 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
       const bool null = e[j].x == ST_NULLPK;
       const int wr = lane + (e[j].x >> 16);  // window row
       wrow[j] = lds_base + (unsigned)(null ? P.off_null : P.off_win + 16 * ST_WP * wr);
-      msk[j]  = null ? 0 : ST_WP - 1;
+      inc[j]  = null ? 0 : stride;
       apos[j] = null ? ST_NULLTAG : p + (int)(short)(e[j].x & 0xffff) + ST_ROT * wr;
-      sa[j]   = wrow[j] + (unsigned)((apos[j] & msk[j]) << 4);
+      sa[j]   = wrow[j] + (unsigned)((apos[j] & (ST_WP - 1)) << 4);
       cf[j]   = st_dbl(e[j].z, e[j].w);
     }
     idiag   = st_dbl(dg.x, dg.y);
@@ -700,12 +700,11 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
     s0 = st_dbl(w0.x, w0.y);
     rb = st_dbl(w0.z, w0.w);
     if (w1.x != cur_tid) load_template(w1.x);
-    else if (setp != p) {  // same template, the next position (p = setp + 1): every tag and slot moves on by one
-      const int step = p - setp;
+    else if (setp != p) {  // same template, the wave's next row of this strand (p = setp + stride): every tag and slot moves on
 #pragma unroll
       for (int j = 0; j < ME; j++) {
-        apos[j] += (msk[j] & 1) * step;  // (a padding entry stays where it is)
-        sa[j] = wrow[j] + (unsigned)((apos[j] & msk[j]) << 4);
+        apos[j] += inc[j];  // (a padding entry stays where it is)
+        sa[j] = wrow[j] + (unsigned)((apos[j] & (ST_WP - 1)) << 4);
       }
       setp = p;
     }
