@@ -389,6 +389,8 @@ struct StParams {
   int      trace_lane;   // ... and the loader lane whose passes are logged
   int      poll_adapt;   // ask for (last pass's rows + 2) rows per far strand instead of always 8 (default: the ME 4 kernels; HIPX_SOR_ADAPT=0|1)
   int      poll_sys;     // experiment (HIPX_SOR_POLL=sys): far polls at system scope
+  int      lock, off_lock, lock_wrow;  // lockstep C wave (st_lock_c): on; its per-template table {c0,c1}{c2,c3}{mask}; window row of the strand before the panel's first
+  unsigned rolemap;      // split kernel: role (0 C, 1 F even, 2 F odd, 3 loader) of the wave on SIMD s of the CU's first / second resident workgroup: nibble s / 4 + s; 0: by wave index
   int      trace_panel;  // HIPX_SOR_DEBUG + HIPX_SOR_TRACE_PANEL: the panel whose rows / loader passes are time-stamped (-1: none)
 };
 struct __attribute__((aligned(16))) StEntry {  // dep: pk = (window row offset << 16) | (dp & 0xffff), lo = logical row offset; old: pk = ACTUAL column - row
@@ -934,6 +936,123 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
   }
 }
 
+// lane i <- lane i-1 (lane 0 keeps `first`): one DPP wavefront shift per 32-bit half, no LDS
+__device__ __forceinline__ double st_from_prev_lane(double first, double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(first), __double2loint(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(first), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// The C wave of the split kernel in LOCKSTEP (forward zero-guess sweep).  For the box stencils the near part of a row's list is
+// a subset of {previous line: x-1, x, x+1; own line: x-1}, in that order: lane i needs rows p-1, p, p+1 of lane i-1 and its own
+// row p-1.  So the wave runs with a fixed skew of two rows per lane -- in iteration k lane i is at row k - 2 i -- every lane keeps
+// its last three results in registers, and the neighbour's three arrive with a DPP shift: no window slots, no tags, no publish
+// into LDS for the near entries, nothing lane-divergent in the iteration.  What still comes through LDS: the partial sum of the
+// far entries from the F waves (tagged hand-over ring, as before) and, for lane 0 only, the line before the panel's first one
+// (another panel's: staged into the window by the loader, tagged).  If any lane's inputs are missing the whole wave retries --
+// in the free-running form a late lane stalls every lane after it anyway.  The arithmetic is the same left-to-right chain
+// (absent entries subtract +0.0 * +0.0 like the padding entries of the other kernels): bit-identical.
+// Eligibility is decided by the host (strand_build): every template's list = far entries (strands of other panels: delta
+// <= -64), then near entries from the canonical four in canonical order.
+template <bool PAIR>
+__device__ __forceinline__ void st_lock_c(const StParams &P, const unsigned lds_base, volatile st_lds_int *s_prog, volatile st_lds_int *s_ctl, unsigned int *err, const int lane,
+                                          const long long S, const int len, double *t, double *xnew)
+{
+  const unsigned cq_base = lds_base + (unsigned)(P.off_cq + 16 * ST_CQ * lane);
+  const unsigned null_a  = lds_base + (unsigned)P.off_null;
+  const unsigned up_row  = lds_base + (unsigned)(P.off_win + 16 * ST_WP * P.lock_wrow);
+  const int      up_rot  = ST_ROT * P.lock_wrow;
+  const unsigned lock_b  = lds_base + (unsigned)P.off_lock;
+  const unsigned diag_b  = lds_base + (unsigned)P.off_tdiag;
+  const long long r0     = S * (long long)P.L;
+  int       p = -2 * lane, cur_tid = -1, mask = 0, idle = 0;
+  double    c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0, idiag = 0.0, H1 = 0.0, H2 = 0.0, H3 = 0.0, psum = 0.0;
+  long long t0 = 0;
+  __builtin_amdgcn_s_setprio(3);
+  for (unsigned it = 1;; it++) {
+    if (!__any(p < len)) break;
+    const bool active = p >= 0 && p < len;
+    asm volatile("" ::: "memory");  // other waves have written LDS since the last iteration
+    // one burst: the F waves' record of row p {sum, template id, tag}; lane 0: positions p-1, p, p+1 of the line before the panel
+    const int e0 = p - 1 + up_rot;  // the tag position p-1 carries in that window row (slot = tag & 15)
+    unsigned  a[4];
+    st_int4   o[4];
+    a[0] = cq_base + (unsigned)(16 * (p & (ST_CQ - 1)));
+    a[1] = lane == 0 ? up_row + (unsigned)((e0 & (ST_WP - 1)) << 4) : null_a;
+    a[2] = lane == 0 ? up_row + (unsigned)(((e0 + 1) & (ST_WP - 1)) << 4) : null_a;
+    a[3] = lane == 0 ? up_row + (unsigned)(((e0 + 2) & (ST_WP - 1)) << 4) : null_a;
+    st_lds_burst4(o, a);
+    bool ok = !active || o[0].w == p;
+    if (active && o[0].w == p && o[0].z != cur_tid) {  // the row's template differs from the last row's (strand ends): coefficients -> registers
+      unsigned b[4];
+      st_int4  q[4];
+      b[0] = lock_b + (unsigned)(48 * o[0].z);
+      b[1] = b[0] + 16;
+      b[2] = b[0] + 32;
+      b[3] = diag_b + (unsigned)(16 * o[0].z);
+      st_lds_burst4(q, b);
+      c0      = st_dbl(q[0].x, q[0].y);
+      c1      = st_dbl(q[0].z, q[0].w);
+      c2      = st_dbl(q[1].x, q[1].y);
+      c3      = st_dbl(q[1].z, q[1].w);
+      mask    = q[2].x;
+      idiag   = st_dbl(q[3].x, q[3].y);
+      cur_tid = o[0].z;
+    }
+    if (lane == 0 && active && ok) {  // the entries of the line before: there only if the loader has staged them
+      if (((mask & 1) && o[1].z != e0) || ((mask & 2) && o[2].z != e0 + 1) || ((mask & 4) && o[3].z != e0 + 2)) ok = false;
+    }
+    if ((it & 0x3ff) == 0) {  // bounded wait: elapsed wall-clock time, and the global abort word
+      const long long now = (long long)wall_clock64();
+      if (!t0) t0 = now;
+      const unsigned abort_word = st_gload32_wait(err);
+      if (abort_word || now - t0 > SOR_SPIN_TICKS) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    if (__any(!ok)) {  // a record or a staged value is not there yet: the whole wave tries again
+      idle = idle < 4 ? idle + 1 : 4;
+      if (idle >= 2) __builtin_amdgcn_s_sleep(1);
+      continue;
+    }
+    idle = 0;
+    const double u1 = st_from_prev_lane(st_dbl(o[3].x, o[3].y), H1);  // previous line, position p+1 (lane i-1 is at row p+2: its last result)
+    const double u2 = st_from_prev_lane(st_dbl(o[2].x, o[2].y), H2);  // ... position p
+    const double u3 = st_from_prev_lane(st_dbl(o[1].x, o[1].y), H3);  // ... position p-1
+    double       sum = st_dbl(o[0].x, o[0].y);
+    sum -= c0 * ((mask & 1) ? u3 : 0.0);
+    sum -= c1 * ((mask & 2) ? u2 : 0.0);
+    sum -= c2 * ((mask & 4) ? u1 : 0.0);
+    sum -= c3 * ((mask & 8) ? H1 : 0.0);
+    const double out = sum * idiag;
+    if (PAIR) {
+      // rows leave in pairs (even row, next one): one 16-byte store each for t and x instead of two 8-byte ones -- every lane's store is
+      // its own cache line, and the CU's address pipeline is what the sweep waits for.  The skew is even, so "p is odd" is the same
+      // in every lane; strands have even lengths here (L, m multiples of 8): both rows of a pair are active or neither is.
+      if ((p & 1) && active) {
+        const long long bs0 = __double_as_longlong(psum), bs1 = __double_as_longlong(sum), bo0 = __double_as_longlong(H1), bo1 = __double_as_longlong(out);
+        const st_int4   vs = {(int)(unsigned)bs0, (int)(unsigned)((unsigned long long)bs0 >> 32), (int)(unsigned)bs1, (int)(unsigned)((unsigned long long)bs1 >> 32)};
+        const st_int4   vo = {(int)(unsigned)bo0, (int)(unsigned)((unsigned long long)bo0 >> 32), (int)(unsigned)bo1, (int)(unsigned)((unsigned long long)bo1 >> 32)};
+        *reinterpret_cast<st_int4 *>(t + (r0 + p - 1)) = vs;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(xnew + (r0 + p - 1)), "v"(vo) : "memory");  // each 8-byte half is its own ready flag
+      }
+      psum = sum;
+    } else if (active) {
+      t[r0 + p] = sum;
+      sor_publish(xnew + (r0 + p), out);
+    }
+    H3 = H2;
+    H2 = H1;
+    H1 = active ? out : 0.0;
+    p++;
+    s_prog[lane] = p > 0 ? p : 0;
+  }
+  __builtin_amdgcn_s_setprio(0);
+  if (lane == 0) s_ctl[1] = 1;
+}
+
 // The loader wave of a panel: operands of the own strands into the operand ring, far strands into the window.
 template <int KIND, bool ALIGNED, bool SPLIT>
 __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *lds, volatile st_lds_int *s_lead, volatile st_lds_int *s_trail, volatile st_lds_int *s_ctl, const int lane,
@@ -1032,11 +1151,15 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
     for (int half = 0; half < 2; half++) {
       if (half == 1 && !wave_hi) break;
       unsigned long long fv[ST_NB][ST_SB];
-      int                frow[ST_NB];
+      st_int4            fq[ST_NB][ST_SB / 2];  // poll16: the same rows as loaded, two per register quad
+      int                frow[ST_NB], fodd[ST_NB];
 #pragma unroll
       for (int i = 0; i < ST_NB; i++) {
         const int d = half * ST_NB + i;
         frow[i]     = 0;
+        fodd[i]     = 0;
+#pragma unroll
+        for (int g = 0; g < ST_SB / 2; g++) fq[i][g] = st_int4{0, 0, 0, 0};
         if (dvalid[d]) {
           const int       b = d >> 1, which = d & 1;
           const int       w = P.band[b].width, u = lane + 64 * which;
@@ -1067,12 +1190,31 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
             fn[d]   = n;
             frow[i] = P.band[b].rowbase + u;
             const long long q0 = strand * L + sf[d];
+            if (ALIGNED) {
+              // two rows per request: the pair (even position, next one) is one aligned 16-byte run (L and m are multiples of 8).  The
+              // loaders' polls are most of what the CU's address pipeline sees -- every lane of every request is its own cache line --
+              // and that pipeline, shared with the compute wave's stores, is what the sweep waits for.
+              const int       odd = sf[d] & 1;  // an odd start: the pair's first half was accepted by an earlier pass, asked for again, skipped below
+              const long long qa  = q0 - odd;
+              fodd[i] = odd;
 #pragma unroll
-            for (int j = 0; j < ST_SB; j++) {
-              if (j < n) {  // (wave-divergent count: lanes that ask for fewer rows skip the loads)
-                const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xnew + st_actual<FWD>(q0 + j, m));
-                fv[i][j] = P.poll_sys ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              } else fv[i][j] = SOR_SENTINEL;
+              for (int g = 0; g < ST_SB / 2; g++) {
+                if (2 * g < n + odd) {
+                  const double *src = FWD ? xnew + (qa + 2 * g) : xnew + ((long long)m - 2 - qa - 2 * g);
+                  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(fq[i][g]) : "v"(src) : "memory");
+                } else {
+                  fq[i][g].x = fq[i][g].z = (int)(unsigned)SOR_SENTINEL;
+                  fq[i][g].y = fq[i][g].w = (int)(unsigned)(SOR_SENTINEL >> 32);
+                }
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < ST_SB; j++) {
+                if (j < n) {  // (wave-divergent count: lanes that ask for fewer rows skip the loads)
+                  const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xnew + st_actual<FWD>(q0 + j, m));
+                  fv[i][j] = P.poll_sys ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else fv[i][j] = SOR_SENTINEL;
+              }
             }
           }
         }
@@ -1105,18 +1247,39 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
         }
         rqf += nrow;
       }
+      if (ALIGNED) {
+        // the hand-issued loads are not counted by the compiler: one explicit wait, tied to every register they fill
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(fq[0][0]), "+v"(fq[0][1]), "+v"(fq[0][2]), "+v"(fq[0][3]), "+v"(fq[1][0]), "+v"(fq[1][1]), "+v"(fq[1][2]), "+v"(fq[1][3]), "+v"(fq[2][0]),
+                       "+v"(fq[2][1]), "+v"(fq[2][2]), "+v"(fq[2][3])
+                     :
+                     : "memory");
+        static_assert(ST_NB == 3 && ST_SB == 8, "the wait above names the registers");
+      }
+      auto fval = [&](int i, int j) __attribute__((always_inline)) -> unsigned long long {  // row j of duty i as loaded (static indices only)
+        if (ALIGNED) {  // backward: the pair's halves are in descending logical order
+          const st_int4 &q      = fq[i][j >> 1];
+          const bool     second = FWD ? (j & 1) != 0 : (j & 1) == 0;
+          return second ? (((unsigned long long)(unsigned)q.w << 32) | (unsigned)q.z) : (((unsigned long long)(unsigned)q.y << 32) | (unsigned)q.x);
+        }
+        return fv[i][j];
+      };
 #pragma unroll
       for (int i = 0; i < ST_NB; i++) {
         const int d = half * ST_NB + i;
         if (fn[d] > 0) {
-          int  cnt = 0;
-          bool acc = true;
+          int       cnt = 0;
+          bool      acc = true;
+          const int a0  = sf[d] - fodd[i];  // position of fv[i][0] (poll16: the even position at or below sf[d])
 #pragma unroll
           for (int j = 0; j < ST_SB; j++) {
-            if (j < fn[d] && acc && fv[i][j] != SOR_SENTINEL) {
-              st_st4v(lds, P.off_win + 16 * (frow[i] * ST_WP + ((sf[d] + j + ST_ROT * frow[i]) & (ST_WP - 1))), st_pack_slot(__longlong_as_double((long long)fv[i][j]), sf[d] + j + ST_ROT * frow[i]));
-              cnt++;
-            } else acc = false;
+            if (j >= fodd[i]) {
+              const unsigned long long v = fval(i, j);
+              if (j < fn[d] + fodd[i] && acc && v != SOR_SENTINEL) {
+                st_st4v(lds, P.off_win + 16 * (frow[i] * ST_WP + ((a0 + j + ST_ROT * frow[i]) & (ST_WP - 1))), st_pack_slot(__longlong_as_double((long long)v), a0 + j + ST_ROT * frow[i]));
+                cnt++;
+              } else acc = false;
+            }
           }
           sf[d] += cnt;
           if (P.poll_adapt) want[d] = cnt + 2 < ST_SB ? cnt + 2 : ST_SB;
@@ -1168,7 +1331,6 @@ __global__ __launch_bounds__(SPLIT ? 256 : 128, SPLIT ? 2 : 1) void sor_strand_k
   volatile st_lds_int  *s_ctl   = (volatile st_lds_int *)(lds + P.off_ctl);
   unsigned int *err  = ctl + 1;
   const int     lane = threadIdx.x & 63;
-  const int     wave = threadIdx.x >> 6;
   // template tables -> LDS (16-byte records)
   for (int i = threadIdx.x; i < P.ntmpl; i += NT) {
     st_st4v(lds, P.off_tinfo + 16 * i, reinterpret_cast<const st_int4 *>(g_tinfo)[i]);
@@ -1177,10 +1339,28 @@ __global__ __launch_bounds__(SPLIT ? 256 : 128, SPLIT ? 2 : 1) void sor_strand_k
   if (SPLIT) {
     for (int i = threadIdx.x; i < P.ntmpl * (ME - ST_MC); i += NT) st_st4v(lds, P.off_depF + 16 * i, reinterpret_cast<const st_int4 *>(g_depF)[i]);
     for (int i = threadIdx.x; i < P.ntmpl * ST_MC; i += NT) st_st4v(lds, P.off_depC + 16 * i, reinterpret_cast<const st_int4 *>(g_depC)[i]);
+    if (KIND == 0 && P.lock)  // the lockstep C wave's table: three records per template, stored behind the C entries
+      for (int i = threadIdx.x; i < 3 * P.ntmpl; i += NT) st_st4v(lds, P.off_lock + 16 * i, reinterpret_cast<const st_int4 *>(g_depC)[P.ntmpl * ST_MC + i]);
   } else {
     for (int i = threadIdx.x; i < P.ndep; i += NT) st_st4v(lds, P.off_dep + 16 * i, reinterpret_cast<const st_int4 *>(g_dep)[i]);
   }
   for (int i = threadIdx.x; i < P.nold; i += NT) st_st4v(lds, P.off_old + 16 * i, reinterpret_cast<const st_int4 *>(g_old)[i]);
+  // Roles by SIMD, not by wave index.  The four waves of a workgroup land on the CU's four SIMDs in the same order for both
+  // resident workgroups, so with roles by wave index the two C waves -- the critical path of both panels -- share one SIMD's
+  // issue slots while the SIMD with the two loaders idles.  The first workgroup to arrive on a CU (a counter per CU in ctl[4...])
+  // keeps the natural order, the second one takes the rotated one.
+  int wave = threadIdx.x >> 6;
+  if (SPLIT && P.rolemap) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID: SIMD_ID 5:4, CU_ID 11:8, SH_ID 12, SE_ID 15:13
+    if (lane == 0) s_ctl[4 + wave] = (int)((hw >> 4) & 3);
+    if (threadIdx.x == 0) {
+      const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15;  // HW_REG_XCC_ID
+      s_ctl[2] = (int)(atomicAdd(&ctl[4 + ((xcc << 8) | ((hw >> 8) & 0xff))], 1u) & 1u);
+    }
+    __syncthreads();
+    const int sm = (1 << s_ctl[4]) | (1 << s_ctl[5]) | (1 << s_ctl[6]) | (1 << s_ctl[7]);
+    if (sm == 15) wave = __builtin_amdgcn_readfirstlane((int)((P.rolemap >> (4 * (4 * s_ctl[2] + s_ctl[4 + wave]))) & 3u));  // (one wave per SIMD; otherwise keep the wave index)
+  }
   for (;;) {
     __syncthreads();  // all waves are done with the previous panel (and the tables are in place)
     if (threadIdx.x == 0) s_ctl[0] = (int)atomicAdd(&ctl[0], 1u);
@@ -1213,8 +1393,10 @@ __global__ __launch_bounds__(SPLIT ? 256 : 128, SPLIT ? 2 : 1) void sor_strand_k
     const long long S   = S0 + lane;
     const int       len = lane < cnt ? st_strand_len(S, P) : 0;
     if (SPLIT) {
-      if (wave == 0) st_compute_role<KIND, ST_MC, 2>(P, lds, lds_base, s_prog, s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, stats, 0);
-      else if (wave <= 2)
+      if (wave == 0) {
+        if (KIND == 0 && P.lock) st_lock_c<ALIGNED>(P, lds_base, s_prog, s_ctl, err, lane, S, len, t, xnew);
+        else st_compute_role<KIND, ST_MC, 2>(P, lds, lds_base, s_prog, s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, stats, 0);
+      } else if (wave <= 2)
         st_compute_role<KIND, (SPLIT ? ME - ST_MC : ME), 1>(P, lds, lds_base, s_progF + 64 * (wave - 1), s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, nullptr, wave - 1,
                                         stats ? stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)P.L + 2 * 4096 * 8 + 48 + 8 * (wave - 1) : nullptr);
       else st_loader_role<KIND, ALIGNED, true>(P, lds, s_progF, s_prog, s_ctl, lane, panel, S0, cnt, S, len, tid, asrc, xold, xnew, stats);
@@ -1322,8 +1504,8 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
     T->diagval[(size_t)t] = tval[tstart[t] + tdiag[t]];
   }
   hipStream_t st = rt().compute;
-  HIPX_HIP(hipMalloc((void **)&T->d_ctl, sizeof(unsigned int) * 4));
-  HIPX_HIP(hipMemsetAsync(T->d_ctl, 0, sizeof(unsigned int) * 4, st));
+  HIPX_HIP(hipMalloc((void **)&T->d_ctl, sizeof(unsigned int) * (4 + 4096)));  // [0] ticket, [1] error, [2] verify, [4...] arrivals per CU (role parity)
+  HIPX_HIP(hipMemsetAsync(T->d_ctl, 0, sizeof(unsigned int) * (4 + 4096), st));
   for (int dirn = 0; dirn < 2; dirn++) {
     StrandDir &D   = T->dir[dirn];
     const bool fwd = dirn == 0;
@@ -1455,10 +1637,47 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
     static const bool split_on = !(getenv("HIPX_SOR_SPLIT") && atoi(getenv("HIPX_SOR_SPLIT")) == 0);
     std::vector<StEntry> depF, depC;
     P.split = (ME >= 13 && split_on) ? 1 : 0;
+    // lockstep C wave (st_lock_c; forward sweep): every list must be far entries (strands of other panels: delta <= -64) followed
+    // by near entries out of {(-1,-1), (-1,0), (-1,+1), (0,-1)} in this order.  HIPX_SOR_LOCKSTEP=0|1.
+    static const bool lock_on = !(getenv("HIPX_SOR_LOCKSTEP") && atoi(getenv("HIPX_SOR_LOCKSTEP")) == 0);
+    bool              lock = P.split && fwd && lock_on && L >= 4;
+    std::vector<int>  nfar((size_t)ntmpl, 0);
+    std::vector<StEntry> lockrec;  // per template: {c0, c1} {c2, c3} {mask}
+    for (int t = 0; t < ntmpl && lock; t++) {
+      const StTinfo &ti = tinfo[(size_t)t];
+      double         c[4] = {0.0, 0.0, 0.0, 0.0};
+      int            msk = 0, last = -1;
+      for (int k = 0; k < ti.dcnt; k++) {
+        const StEntry &e = dep[(size_t)ti.dstart + k];
+        int            ds, dp;
+        decomp(e.lo, ds, dp);
+        if (ds <= -64) {
+          if (last >= 0) lock = false;  // a far entry behind a near one: the F waves' part is not a prefix
+          nfar[(size_t)t]++;
+        } else {
+          const int ci = (ds == -1 && dp >= -1 && dp <= 1) ? dp + 1 : ((ds == 0 && dp == -1) ? 3 : -1);
+          if (ci < 0 || ci <= last) lock = false;
+          else {
+            last  = ci;
+            c[ci] = e.val;
+            msk |= 1 << ci;
+          }
+        }
+      }
+      if (nfar[(size_t)t] > ME - ST_MC) lock = false;
+      StEntry r0, r1, r2;
+      memcpy(&r0, &c[0], 16);
+      memcpy(&r1, &c[2], 16);
+      r2 = StEntry{msk, 0, 0.0};
+      lockrec.push_back(r0);
+      lockrec.push_back(r1);
+      lockrec.push_back(r2);
+    }
+    if (getenv("HIPX_SOR_TRACE")) fprintf(stderr, "[hipx sor] strand %s: ME %d split %d lockstep %d\n", fwd ? "forward" : "backward", ME, P.split, lock ? 1 : 0);
     if (P.split) {
       for (int t = 0; t < ntmpl; t++) {
         const StTinfo &ti = tinfo[(size_t)t];
-        const int      nC = std::min(ti.dcnt, ST_MC), nF = ti.dcnt - nC;
+        const int      nF = lock ? nfar[(size_t)t] : ti.dcnt - std::min(ti.dcnt, ST_MC), nC = ti.dcnt - nF;
         for (int k = 0; k < ME - ST_MC; k++) depF.push_back(k < nF ? dep[(size_t)ti.dstart + k] : StEntry{ST_NULLPK, 0, 0.0});
         for (int k = 0; k < ST_MC; k++) depC.push_back(k < nC ? dep[(size_t)ti.dstart + nF + k] : StEntry{ST_NULLPK, 0, 0.0});
       }
@@ -1471,7 +1690,7 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
     P.off_dep   = o; o += std::max(P.ndep, 1) * (int)sizeof(StEntry);
     P.off_old   = o; o += std::max(P.nold, 1) * (int)sizeof(StEntry);
     P.off_prog  = o; o += 64 * 4;
-    P.off_ctl   = o; o += 16;
+    P.off_ctl   = o; o += 32;
     P.off_null  = o; o += 16;
     P.off_cq = P.off_progF = P.off_depF = P.off_depC = 0;
     P.lds_bytes = o;
@@ -1486,9 +1705,16 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
       Q.nold      = 0;
       Q.off_prog  = o; o += 64 * 4;
       Q.off_progF = o; o += 2 * 64 * 4;
-      Q.off_ctl   = o; o += 16;
+      Q.off_ctl   = o; o += 32;
       Q.off_null  = o; o += 16;
       Q.off_cq    = o; o += 64 * ST_CQ * 16;
+      if (lock) {
+        Q.lock     = 1;
+        Q.off_lock = o; o += 48 * ntmpl;
+        for (int b = 0; b < nb; b++)
+          if (P.band[b].dsmin <= -1 && -1 < P.band[b].dsmin + P.band[b].width) Q.lock_wrow = P.band[b].rowbase + (-1 - P.band[b].dsmin);  // window row of (lane 0, strand delta -1)
+        depC.insert(depC.end(), lockrec.begin(), lockrec.end());
+      }
       Q.lds_bytes = o;
       if (Q.lds_bytes > 78 * 1024) P.split = Q.split = 0;
     }
@@ -1571,7 +1797,8 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
     if (per_cu > 2) per_cu = 2;
   }
   unsigned grid = (unsigned)std::min<long long>((long long)P.npanels, 256LL * per_cu);
-  const bool aligned = (P.L % 8 == 0) && (P.m % 8 == 0) && ((reinterpret_cast<uintptr_t>(asrc) | reinterpret_cast<uintptr_t>(xold)) % 16 == 0);
+  static const bool want_aligned = !(getenv("HIPX_SOR_ALIGNED") && atoi(getenv("HIPX_SOR_ALIGNED")) == 0);  // 0: the kernels for any L / alignment (8-byte polls, scalar operand loads)
+  const bool aligned = want_aligned && (P.L % 8 == 0) && (P.m % 8 == 0) && ((reinterpret_cast<uintptr_t>(asrc) | reinterpret_cast<uintptr_t>(xold) | reinterpret_cast<uintptr_t>(xnew) | reinterpret_cast<uintptr_t>(t)) % 16 == 0);  // (a null t / xold counts as aligned)
   static const bool dbg = getenv("HIPX_SOR_DEBUG") != nullptr;
   static bool attr_set[5][20] = {{false}};
   // The split kernel pays when the far entries come FIRST in the row's list (forward sweeps: lower planes, then the previous line,
@@ -1586,6 +1813,11 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
     const int tp = P.trace_panel, tl = P.trace_lane, ti = P.trace_it0, tr = P.trace_rows, ps = P.poll_sys, pad = P.poll_adapt;
     P = D.Ps;
     P.trace_panel = tp; P.trace_lane = tl; P.trace_it0 = ti; P.trace_rows = tr; P.poll_sys = ps; P.poll_adapt = pad;
+    // roles by SIMD: C on SIMD 0, the F waves on 1 and 2, the loader on 3, in BOTH resident workgroups (measured on the slab: 5.33 ms
+    // against 5.49 by wave index -- which the hardware already rotates between the two workgroups -- and 5.41 for the two mappings
+    // that keep the C waves on different SIMDs).  HIPX_SOR_ROLEMAP=<hex nibbles, SIMD 0 first / second workgroup in the high half> | 0
+    static const unsigned rolemap = getenv("HIPX_SOR_ROLEMAP") ? (unsigned)strtoul(getenv("HIPX_SOR_ROLEMAP"), nullptr, 16) : 0x32103210u;
+    P.rolemap = rolemap;
   }
   auto launch = [&](auto kern, int ai) -> int {
     if (!attr_set[KIND][ai]) {

@@ -16,8 +16,44 @@ import oracle as orc  # noqa: E402
 from petsc_amd import _lib  # noqa: E402
 import test_gpu_sor as T  # noqa: E402
 
+
+
+def box27(nx, ny, nz):
+    """27-point operator on an nx x ny x nz box (x fastest), diagonal 26 + small row-dependent term, off-diagonals -1 .. -1.3
+    by direction: CSR with sorted columns."""
+    rows, cols, vals = [], [], []
+    idx = np.arange(nx * ny * nz)
+    x, y, z = idx % nx, (idx // nx) % ny, idx // (nx * ny)
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                ok = (x + dx >= 0) & (x + dx < nx) & (y + dy >= 0) & (y + dy < ny) & (z + dz >= 0) & (z + dz < nz)
+                rows.append(idx[ok])
+                cols.append((idx + dx + nx * dy + nx * ny * dz)[ok])
+                vals.append(np.full(ok.sum(), 26.5 if (dx, dy, dz) == (0, 0, 0) else -1.0 - 0.1 * abs(dx) - 0.05 * abs(dy) - 0.15 * abs(dz)))
+    r, c, v = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    o = np.lexsort((c, r))
+    r, c, v = r[o], c[o], v[o]
+    ai = np.zeros(nx * ny * nz + 1, np.int32)
+    np.add.at(ai, r + 1, 1)
+    return np.cumsum(ai).astype(np.int32), c.astype(np.int32), v.astype(np.float64)
+
+
 hx = _lib.init(0)
 bad = 0
+# boxes whose planes are not whole panels (80 and 200 lines: panels straddle planes / staggered boundaries with ragged ends), strands of 16
+# and 24 rows: the lockstep C wave (HIPX_SOR_LOCKSTEP=1) is eligible here (far strands are >= 64 lines away); 3 and 5 planes
+for (nx, ny, nz) in ((16, 80, 3), (24, 200, 5), (8, 65, 2)):
+    ai, aj, aa = box27(nx, ny, nz)
+    N = len(ai) - 1
+    rng = np.random.default_rng(5)
+    b, x0 = rng.standard_normal(N), rng.standard_normal(N)
+    for omega, flag, its in ((1.0, T.FWD | T.ZERO, 1), (1.3, T.SYM | T.ZERO, 2), (1.3, T.SYM, 1)):
+        g = T.sor_gpu(hx, ai, aj, aa, b, omega, flag, 0.0, its, 1, x0, mode="strand")
+        o = T.sor_cpu(ai, aj, aa, b, omega, flag, 0.0, its, 1, x0)
+        if not np.array_equal(g, o):
+            bad += 1
+            print("MISMATCH box %dx%dx%d omega %.1f flag %d its %d: max diff %.3e, first at %d" % (nx, ny, nz, omega, flag, its, np.abs(g - o).max(), int(np.flatnonzero(g != o)[0])))
 for n in (24, 128):  # 24^3: one panel per plane, no stagger; 128^3: two panels per plane, 128 planes, staggered boundaries
     ai, aj, aa = orc.stencil("27pt", n)
     N = len(ai) - 1

@@ -269,8 +269,9 @@ def test_gmres_sor_and_cg_ssor_histories(hx, kind, n):
     compare(g, o, 1e-8)
 
 
-@pytest.mark.parametrize("env", [{}, {"HIPX_SOR_SPLIT": "0"}, {"HIPX_SOR_SPLIT": "2"}, {"HIPX_SOR_STAGGER": "0"}, {"HIPX_SOR_SPLIT": "2", "HIPX_SOR_WG_PER_CU": "1"}],
-                         ids=["default", "nosplit", "split-all", "nostagger", "split-all-1wg"])
+@pytest.mark.parametrize("env", [{}, {"HIPX_SOR_SPLIT": "0"}, {"HIPX_SOR_SPLIT": "2"}, {"HIPX_SOR_STAGGER": "0"}, {"HIPX_SOR_SPLIT": "2", "HIPX_SOR_WG_PER_CU": "1"},
+                                 {"HIPX_SOR_LOCKSTEP": "1"}, {"HIPX_SOR_LOCKSTEP": "1", "HIPX_SOR_STAGGER": "0"}, {"HIPX_SOR_LOCKSTEP": "0", "HIPX_SOR_ROLEMAP": "0"}],
+                         ids=["default", "nosplit", "split-all", "nostagger", "split-all-1wg", "lockstep", "lockstep-nostagger", "free-running-roles-by-wave"])
 def test_strand_kernel_variants_bit_exact(env):
     """The strand kernels' variants (two-wave / split C-F-F-loader kernel for forward only or for every kind, staggered panel
     boundaries on / off, one or two workgroups per CU) all give the reference's bits: tests/_sor_variant_worker.py, one process per
