@@ -613,7 +613,7 @@ __device__ __forceinline__ int st_strand_len(long long S, const StParams &P)
 // (at most) 4 entries -- the previous line of the same plane and the row's own predecessor: the ones the NEXT lane is waiting
 // for -- then the scale, the publish, the stores.  The lane-to-lane critical path of a line is then ~1/3 of the instructions.
 // The left-to-right order of the subtractions is unchanged (F's end is C's start), so the sums are bit-identical.
-template <int KIND, int ME, int ROLE>
+template <int KIND, int ME, int ROLE, bool PAIR = false>
 __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *lds, const unsigned lds_base, volatile st_lds_int *s_prog_own, volatile st_lds_int *s_prog_c,
                                                 volatile st_lds_int *s_ctl, unsigned int *err, const int lane, const unsigned panel, const long long S, const int len, double *t,
                                                 const double *xold, double *xnew, const double omega, unsigned long long *stats, const int par,
@@ -625,6 +625,7 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
   int       p = ROLE == 1 ? par : 0, ostart = 0, ocnt = 0, dtab = 0, cur_tid = -1, setp = 0;  // setp: the position apos[] / sa[] are set for; dtab: byte offset of the template's entry list
   bool      have = false;
   double    s0 = 0.0, rb = 0.0, idiag = 0.0, mdiag = 0.0;
+  double    hold_out = 0.0, hold_sum = 0.0;  // PAIR: the even row of a pair, stored together with the odd one
   unsigned  sa[ME];    // LDS byte address of the slot of entry j for the row at position p
   unsigned  wrow[ME];  // ... of slot 0 of its window row (the null slot for a padding entry)
   int       inc[ME];   // what the tag moves by per row of this wave: 1 (2 for an F wave), or 0 for a padding entry (ST_NULLTAG & 15 == 0: its slot is the null slot itself)
@@ -795,16 +796,17 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
             if (p < len && w1.y == p) start_row(w0, w1);
             return;
           }
-          double out;
+          double       out;
+          const double tsum = sum;  // what goes to t (kinds 0 and 3)
           if (KIND == 0) {
-            t[r] = sum;
-            out  = sum * idiag;
+            if (!PAIR) t[r] = sum;
+            out = sum * idiag;
           } else if (KIND == 1) {
             out = (1 - omega) * rb + sum * idiag;
           } else if (KIND == 2) {
             out = sum * idiag;
           } else if (KIND == 3) {
-            t[r] = sum;
+            if (!PAIR) t[r] = sum;
             for (int e2 = 0; e2 < ocnt; e2++) {  // upper part: old values (aij.c:1973-1976)
               const st_int4 oe = st_ld4(lds, P.off_old + 16 * (ostart + e2));
               sum -= st_dbl(oe.z, oe.w) * xold[(long long)r + oe.x];
@@ -817,7 +819,27 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
           for (int b = 0; b < ST_NB; b++)
             if (pubany[b] && pubrow[b] != ~0u)  // the tag is the position plus the row's rotation; so is the slot
               *reinterpret_cast<volatile st_lds_int4 *>((st_lds_char *)(size_t)(pubrow[b] + (unsigned)(((p + pubrot[b]) & (ST_WP - 1)) << 4))) = st_pack_slot(out, p + pubrot[b]);
-          sor_publish(xnew + r, out);
+          if (PAIR) {
+            // rows go to memory in pairs (even position, next one): one 16-byte store instead of two 8-byte ones.  A store whose lanes
+            // all hit different cache lines costs the CU's request path ~190 ns (scripts/diag/ta_probe.hip) whatever its width, and
+            // that path -- shared with the loaders' polls -- is what the sweep waits for.  L and m are multiples of 8 here: strands
+            // have even lengths and a pair is 16-byte aligned (backward sweeps: the pair's rows are in descending memory order).
+            if (p & 1) {
+              const double    lo_v = FWD ? hold_out : out, hi_v = FWD ? out : hold_out;
+              const long long b0 = __double_as_longlong(lo_v), b1 = __double_as_longlong(hi_v);
+              const st_int4   vo = {(int)(unsigned)b0, (int)(unsigned)((unsigned long long)b0 >> 32), (int)(unsigned)b1, (int)(unsigned)((unsigned long long)b1 >> 32)};
+              double         *dst = xnew + (FWD ? r - 1 : r);
+              asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(vo) : "memory");  // each 8-byte half is its own ready flag
+              if (KIND == 0 || KIND == 3) {
+                const long long c0 = __double_as_longlong(hold_sum), c1 = __double_as_longlong(tsum);
+                const st_int4   vs = {(int)(unsigned)c0, (int)(unsigned)((unsigned long long)c0 >> 32), (int)(unsigned)c1, (int)(unsigned)((unsigned long long)c1 >> 32)};
+                asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(t + (r - 1)), "v"(vs) : "memory");
+              }
+            } else {
+              hold_out = out;
+              hold_sum = tsum;
+            }
+          } else sor_publish(xnew + r, out);
           if (stats && p == 0 && (lane == 0 || lane == 63)) stats[16 + 4 * (size_t)panel + (lane ? 2 : 1)] = (unsigned long long)wall_clock64();
           if (stats && P.trace_panel == (int)panel && P.trace_rows)  // HIPX_SOR_TRACE_PANEL: completion time of every row of this panel
             stats[16 + 4 * (size_t)P.npanels + (size_t)lane * (size_t)L + (size_t)p] = (unsigned long long)wall_clock64();
@@ -957,8 +979,10 @@ __device__ __forceinline__ double st_from_prev_lane(double first, double v)
 // <= -64), then near entries from the canonical four in canonical order.
 template <bool PAIR>
 __device__ __forceinline__ void st_lock_c(const StParams &P, const unsigned lds_base, volatile st_lds_int *s_prog, volatile st_lds_int *s_ctl, unsigned int *err, const int lane,
-                                          const long long S, const int len, double *t, double *xnew)
+                                          const long long S, const int len, double *t, double *xnew, unsigned long long *stats, const unsigned panel)
 {
+  unsigned st_iters = 0, st_stall = 0;  // HIPX_SOR_DEBUG (stats != nullptr: the DBG instantiation only)
+  if (stats && lane == 0) stats[16 + 4 * (size_t)panel] = (unsigned long long)wall_clock64();
   const unsigned cq_base = lds_base + (unsigned)(P.off_cq + 16 * ST_CQ * lane);
   const unsigned null_a  = lds_base + (unsigned)P.off_null;
   const unsigned up_row  = lds_base + (unsigned)(P.off_win + 16 * ST_WP * P.lock_wrow);
@@ -1012,7 +1036,9 @@ __device__ __forceinline__ void st_lock_c(const StParams &P, const unsigned lds_
         break;
       }
     }
+    st_iters++;
     if (__any(!ok)) {  // a record or a staged value is not there yet: the whole wave tries again
+      st_stall++;
       idle = idle < 4 ? idle + 1 : 4;
       if (idle >= 2) __builtin_amdgcn_s_sleep(1);
       continue;
@@ -1027,6 +1053,7 @@ __device__ __forceinline__ void st_lock_c(const StParams &P, const unsigned lds_
     sum -= c2 * ((mask & 4) ? u1 : 0.0);
     sum -= c3 * ((mask & 8) ? H1 : 0.0);
     const double out = sum * idiag;
+    if (stats && p == 0 && active && (lane == 0 || lane == 63)) stats[16 + 4 * (size_t)panel + (lane ? 2 : 1)] = (unsigned long long)wall_clock64();
     if (PAIR) {
       // rows leave in pairs (even row, next one): one 16-byte store each for t and x instead of two 8-byte ones -- every lane's store is
       // its own cache line, and the CU's address pipeline is what the sweep waits for.  The skew is even, so "p is odd" is the same
@@ -1036,7 +1063,9 @@ __device__ __forceinline__ void st_lock_c(const StParams &P, const unsigned lds_
         const st_int4   vs = {(int)(unsigned)bs0, (int)(unsigned)((unsigned long long)bs0 >> 32), (int)(unsigned)bs1, (int)(unsigned)((unsigned long long)bs1 >> 32)};
         const st_int4   vo = {(int)(unsigned)bo0, (int)(unsigned)((unsigned long long)bo0 >> 32), (int)(unsigned)bo1, (int)(unsigned)((unsigned long long)bo1 >> 32)};
         *reinterpret_cast<st_int4 *>(t + (r0 + p - 1)) = vs;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(xnew + (r0 + p - 1)), "v"(vo) : "memory");  // each 8-byte half is its own ready flag
+        // (s_nop: a store of more than 8 bytes must not be followed at once by a write to its data registers, and the compiler's hazard
+        // recognizer does not look into asm statements)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(xnew + (r0 + p - 1)), "v"(vo) : "memory");  // each 8-byte half is its own ready flag
       }
       psum = sum;
     } else if (active) {
@@ -1051,6 +1080,14 @@ __device__ __forceinline__ void st_lock_c(const StParams &P, const unsigned lds_
   }
   __builtin_amdgcn_s_setprio(0);
   if (lane == 0) s_ctl[1] = 1;
+  if (stats && lane == 0) {
+    stats[16 + 4 * (size_t)panel + 3] = (unsigned long long)wall_clock64();
+    atomicAdd(&stats[0], (unsigned long long)st_iters);
+    atomicAdd(&stats[2], (unsigned long long)st_stall * 64ull);  // (reported as lane-iterations waiting for dependencies)
+    atomicAdd(&stats[8], 1ull);
+    atomicAdd(&stats[6], stats[16 + 4 * (size_t)panel + 3] - stats[16 + 4 * (size_t)panel]);
+  }
+  if (stats) atomicAdd(&stats[7], (unsigned long long)len);
 }
 
 // The loader wave of a panel: operands of the own strands into the operand ring, far strands into the window.
@@ -1394,14 +1431,14 @@ __global__ __launch_bounds__(SPLIT ? 256 : 128, SPLIT ? 2 : 1) void sor_strand_k
     const int       len = lane < cnt ? st_strand_len(S, P) : 0;
     if (SPLIT) {
       if (wave == 0) {
-        if (KIND == 0 && P.lock) st_lock_c<ALIGNED>(P, lds_base, s_prog, s_ctl, err, lane, S, len, t, xnew);
-        else st_compute_role<KIND, ST_MC, 2>(P, lds, lds_base, s_prog, s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, stats, 0);
+        if (KIND == 0 && P.lock) st_lock_c<ALIGNED>(P, lds_base, s_prog, s_ctl, err, lane, S, len, t, xnew, stats, panel);
+        else st_compute_role<KIND, ST_MC, 2, ALIGNED>(P, lds, lds_base, s_prog, s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, stats, 0);
       } else if (wave <= 2)
         st_compute_role<KIND, (SPLIT ? ME - ST_MC : ME), 1>(P, lds, lds_base, s_progF + 64 * (wave - 1), s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, nullptr, wave - 1,
                                         stats ? stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)P.L + 2 * 4096 * 8 + 48 + 8 * (wave - 1) : nullptr);
       else st_loader_role<KIND, ALIGNED, true>(P, lds, s_progF, s_prog, s_ctl, lane, panel, S0, cnt, S, len, tid, asrc, xold, xnew, stats);
     } else {
-      if (wave == 0) st_compute_role<KIND, ME, 0>(P, lds, lds_base, s_prog, s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, stats, 0);
+      if (wave == 0) st_compute_role<KIND, ME, 0, ALIGNED>(P, lds, lds_base, s_prog, s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, stats, 0);
       else st_loader_role<KIND, ALIGNED, false>(P, lds, s_prog, s_prog, s_ctl, lane, panel, S0, cnt, S, len, tid, asrc, xold, xnew, stats);
     }
     // All roles share this function: without this, loads the LOADER branch may leave pending at the back edge of the panel loop
