@@ -369,8 +369,7 @@ constexpr int ST_LA   = 10;  // staging look-ahead beyond the leading consumer
 constexpr int ST_NB   = 3;   // bands of strands a panel may touch
 constexpr int ST_MAXW = 4;   // strands per band
 constexpr int ST_ME   = 16;  // most dependency entries a row may have on this schedule (27-point: 13)
-constexpr int ST_MF   = 12;  // split kernel: entries of the F wave (the first ones of the list) ...
-constexpr int ST_MC   = 4;   // ... and of the C wave (the last ones)
+constexpr int ST_MC   = 4;   // split kernel: entries of the C wave (the last ones of the list; the F waves take the first ME - ST_MC)
 constexpr int ST_CQ   = 4;   // depth of the F -> C hand-over ring (16-byte records)
 constexpr int ST_NULLPK  = 0x7fff7fff;  // pk of a padding entry
 constexpr int ST_NULLTAG = 0x7ffffff0;  // tag of the null slot (no row position reaches it)
@@ -422,7 +421,6 @@ typedef __attribute__((address_space(3))) st_int4 st_lds_int4;
 // reads of slots another wave writes: plain 16-byte loads (one ds_read_b128 each, free to issue back to back) -- the compute
 // loop declares memory clobbered once per iteration (asm volatile "" ::: "memory"), so nothing read in an earlier iteration is
 // reused; `volatile` loads would be kept in strict order with a wait between them
-__device__ __forceinline__ st_int4 st_ld4v(st_lds_char *base, int byteoff) { return *reinterpret_cast<st_lds_int4 *>(base + byteoff); }
 __device__ __forceinline__ st_int4 st_ld4(st_lds_char *base, int byteoff) { return *reinterpret_cast<st_lds_int4 *>(base + byteoff); }
 __device__ __forceinline__ void    st_st4v(st_lds_char *base, int byteoff, st_int4 v) { *reinterpret_cast<volatile st_lds_int4 *>(base + byteoff) = v; }
 __device__ __forceinline__ double  st_dbl(int lo, int hi) { return __longlong_as_double(((long long)(unsigned)hi << 32) | (unsigned)lo); }
@@ -607,9 +605,10 @@ __device__ __forceinline__ int st_strand_len(long long S, const StParams &P)
   return (int)(rem < P.L ? rem : P.L);
 }
 
-// One compute role of a panel.  ROLE 0: the whole row (two-wave kernel: ME = 4 or 16 entries).  SPLIT kernel (27-point class, ME 16):
-// ROLE 1 = the F wave: the first 12 entries of the row's list -- the far ones, staged by the loader long before they are needed --
-// subtracted from the operand; the partial sum goes to the C wave through a two-deep LDS ring.  ROLE 2 = the C wave: the last
+// One compute role of a panel.  ROLE 0: the whole row (two-wave kernel: ME = 4, 13 or 16 entries).  SPLIT kernel (27-point class, ME 13 / 16):
+// ROLE 1 = an F wave: the first ME - 4 entries of the row's list -- the far ones, staged by the loader long before they are needed --
+// subtracted from the operand; the partial sum goes to the C wave through an ST_CQ-deep LDS ring.  ROLE 2 = the free-running C wave
+// (st_lock_c is the lockstep one, used whenever the matrix allows it): the last
 // (at most) 4 entries -- the previous line of the same plane and the row's own predecessor: the ones the NEXT lane is waiting
 // for -- then the scale, the publish, the stores.  The lane-to-lane critical path of a line is then ~1/3 of the instructions.
 // The left-to-right order of the subtractions is unchanged (F's end is C's start), so the sums are bit-identical.
@@ -625,7 +624,7 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
   int       p = ROLE == 1 ? par : 0, ostart = 0, ocnt = 0, dtab = 0, cur_tid = -1, setp = 0;  // setp: the position apos[] / sa[] are set for; dtab: byte offset of the template's entry list
   bool      have = false;
   double    s0 = 0.0, rb = 0.0, idiag = 0.0, mdiag = 0.0;
-  double    hold_out = 0.0, hold_sum = 0.0;  // PAIR: the even row of a pair, stored together with the odd one
+  double    hold_out = 0.0, hold_sum = 0.0;  // PAIR (kernels for aligned strands): the even row of a pair, stored together with the odd one
   unsigned  sa[ME];    // LDS byte address of the slot of entry j for the row at position p
   unsigned  wrow[ME];  // ... of slot 0 of its window row (the null slot for a padding entry)
   int       inc[ME];   // what the tag moves by per row of this wave: 1 (2 for an F wave), or 0 for a padding entry (ST_NULLTAG & 15 == 0: its slot is the null slot itself)
@@ -731,7 +730,7 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
     st_iters++;
     const int  p_before    = p;
     const bool have_before = have;
-    int        dbg_diff = 0x7ffffff, dbg_rtag = -2, dbg_mask = 0;
+    int        dbg_diff = 0x7ffffff, dbg_mask = 0;
     const bool dbg_on = stats && P.trace_panel == (int)panel && lane == P.trace_lane;
     long long  dbg_c0 = dbg_on ? (long long)clock64() : 0, dbg_c1 = 0, dbg_c2 = 0, dbg_c3 = 0;
     asm volatile("" ::: "memory");  // other waves have written LDS since the last iteration: re-read, do not reuse
@@ -751,7 +750,6 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
         w1.x = w1.z;
         w1.y = w1.w;
       }
-      dbg_rtag = w1.y;
       if (__any(!have)) dbg_mask |= 1 << 29;
       if (stats) st_cburst += (long long)clock64() - c_b0;
       if (stats && __any(!have)) st_nsetup++;
@@ -862,14 +860,10 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
         } else if (diff < 0) {
           st_depwait++;
           if (stats && P.trace_panel == (int)panel && P.trace_rows) {  // which entry is late?  (first one in arithmetic order), all lanes together + lane 0 alone
-            int jf = 0, jtag = 0, jexp = 0;  // (selects, not indexed reads: a register array indexed at run time goes to scratch)
+            int jf = 0;  // (selects, not indexed reads: a register array indexed at run time goes to scratch)
 #pragma unroll
             for (int j = ME - 1; j >= 0; j--)
-              if (sl[j].z < apos[j]) {
-                jf   = j;
-                jtag = sl[j].z;
-                jexp = apos[j];
-              }
+              if (sl[j].z < apos[j]) jf = j;
             unsigned long long *h = stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)L + 2 * 4096 * 8;
             atomicAdd(&h[jf], 1ull);
             if (lane == 0) atomicAdd(&h[16 + jf], 1ull);
@@ -1148,6 +1142,12 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
       const long long q0 = S * L + rqf;
       if (ALIGNED) {  // L, m multiples of 8 and 16-byte aligned vectors: every group of 4 rows is one aligned 32-byte run
         typedef double dbl2 __attribute__((ext_vector_type(2)));
+        if (nrow > 4) {  // both groups: their eight template ids are eight consecutive bytes (4-byte aligned): one request instead of two
+          typedef unsigned uint2a __attribute__((ext_vector_type(2), aligned(4)));
+          const uint2a t8 = *reinterpret_cast<const uint2a *>(tid + (FWD ? (long long)q0 : (long long)m - 8 - q0));
+          tb[FWD ? 0 : 1] = t8.x;
+          tb[FWD ? 1 : 0] = t8.y;
+        }
 #pragma unroll
         for (int g = 0; g < 2; g++) {
           if (4 * g < nrow) {
@@ -1155,7 +1155,7 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
             const hipx_int  rg = FWD ? (hipx_int)qg : (hipx_int)((long long)m - 4 - qg);  // lowest actual row of the group
             const dbl2     *pa = reinterpret_cast<const dbl2 *>(asrc + rg);
             const dbl2     *pb = reinterpret_cast<const dbl2 *>(xold + (NEEDOLD ? rg : 0));
-            tb[g]              = *reinterpret_cast<const unsigned *>(tid + rg);
+            if (nrow <= 4) tb[g] = *reinterpret_cast<const unsigned *>(tid + rg);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
               const dbl2 a2 = pa[h];
