@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
       xrow[rr] = 0.0;
       if (row < m) {
         if (MODE == 1) sum[rr] = yin[row];
-        if (DOT) xrow[rr] = x[row];
+        if (DOT && !UNI) xrow[rr] = x[row];
       }
     }
 #pragma unroll
@@ -1063,17 +1063,35 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
       unsigned  rb[RPT];
 #pragma unroll
       for (int rr = 0; rr < RPT; rr++) rb[rr] = (unsigned)(base + t + rr * 256) * 8u;
+      bool got = false;  // fused dot: x[row] is the diagonal entry's gather (offset 0) -- one request per row block less than loading it again
 #pragma unroll 4
       for (int k = ts; k < te; k++) {
         const double a  = tval[k];
-        const char  *xb = reinterpret_cast<const char *>(x + toff[k]);
+        const int    o  = toff[k];
+        const char  *xb = reinterpret_cast<const char *>(x + o);
         double       xv[RPT];
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) xv[rr] = *reinterpret_cast<const double *>(xb + rb[rr]);
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) sum[rr] += a * xv[rr];
+        if (DOT && o == 0) {  // (wave-uniform: the template's offsets are scalars)
+          got = true;
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++) xrow[rr] = xv[rr];
+        }
+      }
+      if (DOT && !got) {
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) xrow[rr] = x[base + t + rr * 256];
       }
     } else {
+      if (DOT && UNI) {
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) {
+          const hipx_int row = base + t + rr * 256;
+          if (row < m) xrow[rr] = x[row];
+        }
+      }
       int s0[RPT], len[RPT], maxlen = 0;
 #pragma unroll
       for (int rr = 0; rr < RPT; rr++) {
