@@ -87,8 +87,21 @@ def build_oracle(force=False):
     return os.path.join(ROOT, "oracle", "liboracle.so")
 
 
+def build_diag(force=False):
+    """scripts/diag/*.hip: stand-alone hardware probes (request-path cost, wave placement, DPP wave shift) that
+    scripts/gpu_final.sh runs on the GPU box; built in-tree like the libraries (git-ignored, shipped by gpurun)."""
+    d = os.path.join(ROOT, "scripts", "diag")
+    out = []
+    for src in sorted(f for f in os.listdir(d) if f.endswith(".hip")) if os.path.isdir(d) else []:
+        s, t = os.path.join(d, src), os.path.join(d, src[:-4])
+        if force or _newer(t, [s]):
+            _run([HIPCC, "--offload-arch=gfx950", "-O2", "-w", "-o", t, s])
+        out.append(t)
+    return out
+
+
 def build_all(force=False, verbose=False):
-    out = {"hipx": build_hipx(force, verbose), "host": build_host(force), "oracle": build_oracle(force)}
+    out = {"hipx": build_hipx(force, verbose), "host": build_host(force), "oracle": build_oracle(force), "diag": build_diag(force)}
     ref = os.path.join(ROOT, "oracle", "build_ref.py")
     if os.path.exists(ref) and os.path.isdir("/root/reference/src"):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
