@@ -42,3 +42,17 @@ def test_no_gpu_means_loud_failure_not_fallback(built):
     assert hx.hipxVecDot(x.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), 4, C.byref(r)) == 58  # PETSC_ERR_ORDER: not initialised
     with pytest.raises(_lib.HipxError):
         _lib.init(0)
+
+
+def test_hardware_probes_are_built_with_the_libraries(built):
+    """scripts/diag/*.hip (request-path cost, wave placement: what profiles/r02_request_path_probe.txt and
+    r02_wave_placement.txt come from) are compiled for gfx950 by build(), next to their sources."""
+    import glob
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    srcs = glob.glob(os.path.join(root, "scripts", "diag", "*.hip"))
+    assert len(srcs) >= 2
+    for s in srcs:
+        exe = s[:-4]
+        assert os.path.exists(exe) and os.access(exe, os.X_OK), exe
+        assert b"gfx950" in open(exe, "rb").read()  # the embedded code object's target
