@@ -10,6 +10,8 @@
 //   mode 8: 16-byte sc1 loads, the four quarters of a lane's own line in four consecutive requests (a far poll of 8 rows)
 //   mode 9: 16-byte sc1 stores, 4 adjacent lanes share one 64-byte line (a line-granular flush)
 //   mode 10: 16-byte plain stores, every lane its own line (the t store)
+//   mode 11 / 12: 16-byte sc1 / plain stores, the four quarters of a lane's own line in four consecutive requests (a line of 8 rows
+//           kept in registers and stored at once)
 // Two 64-lane workgroups per CU (512 workgroups), each issues REPS x 8 requests; lines are re-used across repetitions (L2 hits):
 // the rate is the request path's, not HBM's.  Build: hipcc --offload-arch=gfx950 -O2 -o ta_probe ta_probe.hip  (petsc_amd/build.py)
 #include <hip/hip_runtime.h>
@@ -29,7 +31,7 @@ __global__ void probe(char *base, int reps, int *sink)
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       // modes 7 / 8: requests k = 0..3 and 4..7 walk the four quarters of one line each; the others take a new line per request
-      const size_t step = (MODE == 7 || MODE == 8) ? (size_t)((k & 3) * 16 + (k >> 2) * 64 + (r & 7) * 128) : (size_t)(k * 64 + (r & 7) * 512);
+      const size_t step = (MODE == 7 || MODE == 8 || MODE == 11 || MODE == 12) ? (size_t)((k & 3) * 16 + (k >> 2) * 64 + (r & 7) * 128) : (size_t)(k * 64 + (r & 7) * 512);
       const char  *p    = w + off + step;
       if (MODE == 0) {
         int2v t;
@@ -43,7 +45,7 @@ __global__ void probe(char *base, int reps, int *sink)
         int2v t = {r, k};
         asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
         v[k] = int4v{0, 0, 0, 0};
-      } else if (MODE == 10) {
+      } else if (MODE == 10 || MODE == 12) {
         int4v t = {r, k, r, k};
         asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
         v[k] = int4v{0, 0, 0, 0};
@@ -96,5 +98,7 @@ int main()
   run<8>(d, sink, "16 B sc1 loads, a line per lane, 4 quarters of the line in a row");
   run<9>(d, sink, "16 B sc1 stores, 4 lanes per 64 B line");
   run<10>(d, sink, "16 B plain stores, a line per lane");
+  run<11>(d, sink, "16 B sc1 stores, a line per lane, 4 quarters of the line in a row");
+  run<12>(d, sink, "16 B plain stores, a line per lane, 4 quarters of the line in a row");
   return 0;
 }
