@@ -624,6 +624,7 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
   int       p = ROLE == 1 ? par : 0, ostart = 0, ocnt = 0, dtab = 0, cur_tid = -1, setp = 0;  // setp: the position apos[] / sa[] are set for; dtab: byte offset of the template's entry list
   bool      have = false;
   double    s0 = 0.0, rb = 0.0, idiag = 0.0, mdiag = 0.0;
+  st_int4   tq0 = {0, 0, 0, 0}, tq1 = {0, 0, 0, 0}, tq2 = {0, 0, 0, 0};  // PAIR, kinds 0 / 3: the three pairs of t before the current one
   double    hold_out = 0.0, hold_sum = 0.0;  // PAIR (kernels for aligned strands): the even row of a pair, stored together with the odd one
   unsigned  sa[ME];    // LDS byte address of the slot of entry j for the row at position p
   unsigned  wrow[ME];  // ... of slot 0 of its window row (the null slot for a padding entry)
@@ -828,10 +829,19 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
               const st_int4   vo = {(int)(unsigned)b0, (int)(unsigned)((unsigned long long)b0 >> 32), (int)(unsigned)b1, (int)(unsigned)((unsigned long long)b1 >> 32)};
               double         *dst = xnew + (FWD ? r - 1 : r);
               asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(vo) : "memory");  // each 8-byte half is its own ready flag
-              if (KIND == 0 || KIND == 3) {
+              if (KIND == 0 || KIND == 3) {  // t: a line of 8 rows at a time, four consecutive plain stores (see st_lock_c)
                 const long long c0 = __double_as_longlong(hold_sum), c1 = __double_as_longlong(tsum);
                 const st_int4   vs = {(int)(unsigned)c0, (int)(unsigned)((unsigned long long)c0 >> 32), (int)(unsigned)c1, (int)(unsigned)((unsigned long long)c1 >> 32)};
-                asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(t + (r - 1)), "v"(vs) : "memory");
+                if ((p & 7) == 7) {
+                  st_int4 *tp = reinterpret_cast<st_int4 *>(t + (r - 7));
+                  tp[0] = tq0;
+                  tp[1] = tq1;
+                  tp[2] = tq2;
+                  tp[3] = vs;
+                }
+                tq0 = tq1;
+                tq1 = tq2;
+                tq2 = vs;
               }
             } else {
               hold_out = out;
@@ -986,6 +996,7 @@ __device__ __forceinline__ void st_lock_c(const StParams &P, const unsigned lds_
   const long long r0     = S * (long long)P.L;
   int       p = -2 * lane, cur_tid = -1, mask = 0, idle = 0;
   double    c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0, idiag = 0.0, H1 = 0.0, H2 = 0.0, H3 = 0.0, psum = 0.0;
+  st_int4   tq0 = {0, 0, 0, 0}, tq1 = {0, 0, 0, 0}, tq2 = {0, 0, 0, 0};  // the three pairs of t before the current one (one line = four pairs)
   long long t0 = 0;
   __builtin_amdgcn_s_setprio(3);
   for (unsigned it = 1;; it++) {
@@ -1056,7 +1067,19 @@ __device__ __forceinline__ void st_lock_c(const StParams &P, const unsigned lds_
         const long long bs0 = __double_as_longlong(psum), bs1 = __double_as_longlong(sum), bo0 = __double_as_longlong(H1), bo1 = __double_as_longlong(out);
         const st_int4   vs = {(int)(unsigned)bs0, (int)(unsigned)((unsigned long long)bs0 >> 32), (int)(unsigned)bs1, (int)(unsigned)((unsigned long long)bs1 >> 32)};
         const st_int4   vo = {(int)(unsigned)bo0, (int)(unsigned)((unsigned long long)bo0 >> 32), (int)(unsigned)bo1, (int)(unsigned)((unsigned long long)bo1 >> 32)};
-        *reinterpret_cast<st_int4 *>(t + (r0 + p - 1)) = vs;
+        if ((p & 7) == 7) {
+          // t: nobody waits for it, so a whole line of 8 rows (this pair and the three before it, kept in registers) goes out as four
+          // consecutive plain stores, which the cache combines: 68 instead of 180 ns of the CU's request path each
+          // (profiles/r02_request_path_probe.txt, modes 10 / 12).  Strand lengths are multiples of 8 here.
+          st_int4 *tp = reinterpret_cast<st_int4 *>(t + (r0 + p - 7));
+          tp[0] = tq0;
+          tp[1] = tq1;
+          tp[2] = tq2;
+          tp[3] = vs;
+        }
+        tq0 = tq1;
+        tq1 = tq2;
+        tq2 = vs;
         // (s_nop: a store of more than 8 bytes must not be followed at once by a write to its data registers, and the compiler's hazard
         // recognizer does not look into asm statements)
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(xnew + (r0 + p - 1)), "v"(vo) : "memory");  // each 8-byte half is its own ready flag
