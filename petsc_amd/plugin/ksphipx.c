@@ -133,6 +133,8 @@ static PetscErrorCode KSPSolve_CGHIPX(KSP ksp)
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+PETSC_EXTERN PetscErrorCode KSPCreate_CG(KSP); /* cg.c:686: exported by libpetsc, declared in no header */
+
 PetscErrorCode KSPCreate_CGHIPX(KSP ksp)
 {
   PetscFunctionBegin;
