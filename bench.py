@@ -6,23 +6,28 @@ A "step" is one Krylov iteration (CG: one pass of the loop body cg.c:220-349 -- 
 PCApply; GMRES: one pass of gmres.c:123-166).  Inputs (CSR matrix, b = A*1, x0 = 0) are resident in HBM before the timed
 region.  No per-launch events are recorded inside the timed region; kernel durations come from a second pass of the same K steps.
 
-  python bench.py --gpus 1 --steps 200 --warmup 20                                  # BASELINE config 2 (default)
-  python bench.py --ksp gmres --pc sor --stencil 27 --grid 256                       # config 3's solver on one GPU
+  python bench.py                                   # BASELINE config 2 on one GPU + the other single-GPU configurations
+  python bench.py --gpus 8                          # self-launches 8 ranks (torch.distributed.run), one GPU per rank
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
-  ... --gpus 8 --stencil 27 --grid 512 --ksp gmres --pc sor                          # config 3
-  ... --gpus 8 --grid 1024 --scaling weak --pc none                                  # config 5: 1024 x 1024 x 128 rows per GPU
+  python bench.py --ksp gmres --pc sor --stencil 27 --grid 256 --quick               # config 3's solver alone
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
-  parity_gate      -- BASELINE.md 3.5: the first 24 iterations of THIS configuration on the GPU against the reference's own
-                      KSPSolve on the host (oracle/_ref), entry by entry; `value` is null when the gate fails
+  parity_gate      -- N = 1: the first 24 iterations of THIS configuration against the REFERENCE's own KSPSolve run beside it
+                      with exact (twice-working-precision) BLAS reductions (oracle/_ref + oracle/libexactblas.so), entry by
+                      entry, 1e-12 relative; N > 1: against the committed history of that same yardstick
+                      (tests/golden/exact_histories.json).  `value` is null when the gate fails; "ungated": true when it
+                      could not run.
   roofline         -- dominant kernel (the CSR SpMV the solver launches): HIP-event launch time; `frac` = HBM bytes the kernel
-                      really moves (rocprofv3 PMC passes run from inside this script, see `traffic_source`) / time / 8 TB/s;
-                      `effective_gbps` = algorithmic CSR bytes / time
-  roofline_general -- the same for the general-valued CSR kernel (packed 16-bit columns, no value dictionary / row templates:
-                      what a matrix with arbitrary values gets), timed in this run
-  plugin           -- the drop-in itself: the reference's executable + libpetschipx.so (KSPSolve_CG over the hipx types, and
-                      -ksp_type cghipx), its/s of KSPSolve
-  cpu_baseline     -- the reference's own KSPSolve (oracle/_ref) on this host: P = physical cores (mpiexec) and 1 core
+                      really moves (rocprofv3 PMC passes run from inside this script) / time / 8 TB/s; `effective_gbps` =
+                      algorithmic CSR bytes / time
+  roofline_general -- the same for the general-valued CSR kernel (what a matrix with arbitrary values gets), timed in this run
+  plugin           -- the drop-in itself: the reference's executable + libpetschipx.so, its/s of KSPSolve
+  cpu_baseline     -- the reference's own KSPSolve (oracle/_ref) on this host: best of P, P/2, P/4 MPI ranks, and 1 core
+  other_configs    -- N = 1: BASELINE configs 3 / 4 / 5 on one GPU (GMRES(30)+PCSOR 27-pt 256^3 with `roofline_sor`; the Flan_1565
+                      surrogate's SpMV with `roofline_longrow`; config 5's per-GPU share 1024 x 1024 x 128), each with its
+                      own cpu_baseline;  N > 1: the north_star scaling legs (27-pt 512^3 CG+Jacobi strong, config 5 weak,
+                      config 3) with per-rank SpMV / ghost-exchange / all-reduce times
+  multi_gpu        -- N > 1: transports probed and timed (RCCL send/recv + all-reduce, IPC peer stores), devices per rank
 """
 import argparse
 import ctypes as C
@@ -32,6 +37,7 @@ import json
 import os
 import re
 import shutil
+import socket
 import subprocess
 import sys
 import tempfile
@@ -45,6 +51,41 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); measured copy peak is 6290
 GATE_ITS = 24
 GATE_TOL = 1e-12       # north_star: residual history within 1e-12 relative, per entry
+GMRES_SOR_TOL = 1e-9   # GMRES(30)+SOR: 30-vector Gram-Schmidt amplifies reduction rounding (tests/test_gpu_scale_parity.py)
+SHIM = os.path.join(ROOT, "oracle", "libexactblas.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden", "exact_histories.json")
+
+
+# ------------------------------------------------------------------------------------------------------------ configurations
+class Cfg:
+    """One benchmark configuration: operator, solver, how it is split."""
+
+    def __init__(self, stencil, dims, ksp, pc, scaling="strong", label=None, golden=None):
+        self.stencil, self.dims, self.ksp, self.pc, self.scaling, self.label, self.golden = stencil, tuple(dims), ksp, pc, scaling, label, golden
+        self.N = dims[0] * dims[1] * dims[2]
+        self.cube = dims[0] == dims[1] == dims[2]
+
+    def shape(self):
+        return "%d^3" % self.dims[0] if self.cube else "%dx%dx%d" % self.dims
+
+    def pcname(self):
+        return {"jacobi": "PCJACOBI", "sor": "PCSOR", "none": "PCNONE"}[self.pc]
+
+    def metric(self):
+        return "%s iterations/sec, %d-pt Poisson %s fp64, KSP%s+%s" % (self.ksp.upper(), self.stencil, self.shape(), self.ksp.upper(), self.pcname())
+
+    def golden_key(self):
+        if self.golden:
+            return self.golden
+        return "%s_%s_%dpt_%s" % (self.ksp, self.pc, self.stencil, str(self.dims[0]) if self.cube else "%dx%dx%d" % self.dims)
+
+    def driver_args(self, its):
+        a = ["-stencil", str(self.stencil), "-n", str(self.dims[0]), "-ksp_type", self.ksp, "-pc_type", self.pc, "-ksp_rtol", "1e-50", "-ksp_max_it", str(its)]
+        if not self.cube:
+            a += ["-ny", str(self.dims[1]), "-nz", str(self.dims[2])]
+        if self.ksp == "cg":
+            a += ["-ksp_norm_type", "preconditioned"]
+        return a
 
 
 def assemble(ks, stencil, dims, rs, re):
@@ -84,9 +125,10 @@ def physical_cores():
     return max(1, len(cores))
 
 
-def ref_driver(np_, args, plugin=False, timeout=900, bind=False):
+def ref_driver(np_, args, plugin=False, timeout=900, bind=False, exact=False):
     """The REFERENCE itself (oracle/_ref: libpetsc compiled from /root/reference by oracle/build_ref.py): its own MatSetValues
-    assembly, KSPSolve, MatMult_SeqAIJ / _MPIAIJ, PCJACOBI / PCSOR, MKL BLAS-1 (one thread per rank)."""
+    assembly, KSPSolve, MatMult_SeqAIJ / _MPIAIJ, PCJACOBI / PCSOR, MKL BLAS-1 (one thread per rank).  exact=True: the same
+    executable with oracle/libexactblas.so LD_PRELOADed (twice-working-precision ddot / dgemv: the parity yardstick)."""
     mp = np_ > 1
     exe = os.path.join(ROOT, "oracle", "_ref", "mpich" if mp else "", "bin", "ref_driver")
     if not os.path.exists(exe):
@@ -100,6 +142,10 @@ def ref_driver(np_, args, plugin=False, timeout=900, bind=False):
     else:
         cmd += ["-mat_type", "aij", "-vec_type", "standard"]
     env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1", HIPX_NO_TORCH="1")
+    if exact:
+        if not os.path.exists(SHIM) or plugin:
+            return None
+        env["LD_PRELOAD"] = SHIM
     try:
         out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=timeout).stdout
         m = re.search(r"iterations (\d+) reason (-?\d+) error (\S+) KSPSolve_seconds (\S+)", out)
@@ -109,11 +155,12 @@ def ref_driver(np_, args, plugin=False, timeout=900, bind=False):
         return None
 
 
-def solver_args(args, its):
-    a = ["-stencil", str(args.stencil), "-n", str(args.n), "-ksp_type", args.ksp, "-pc_type", args.pc, "-ksp_rtol", "1e-50", "-ksp_max_it", str(its)]
-    if args.ksp == "cg":
-        a += ["-ksp_norm_type", "preconditioned"]
-    return a
+def golden_history(key):
+    try:
+        e = json.load(open(GOLDEN))[key]
+        return np.array([float.fromhex(v) for v in e["history_hex"]]), e["source"]
+    except Exception:
+        return None, None
 
 
 def oracle_port_baseline(ai, aj, aa, b, budget_s, stencil, n):
@@ -135,38 +182,48 @@ def oracle_port_baseline(ai, aj, aa, b, budget_s, stencil, n):
             "sample": "%d CG+Jacobi iterations of the oracle (scalar C restatement of cg.c/aij.c, gcc -O2) on the same %d-pt %d^3 system" % (done, stencil, n)}, hist
 
 
+# ------------------------------------------------------------------------------------------------------------------ one problem
 class Problem:
     """One rank's share of the system on the device + the solver objects of the C host layer."""
 
-    def __init__(self, args, rank, world, dist):
+    def __init__(self, cfg, rank, world, dist, transport="rccl", fused=1, pipeline=1, keep_host=False):
         from petsc_amd import _lib
         from petsc_amd import dist as pdist
-        self.lib, self.args, self.world = _lib, args, world
+        self.lib, self.cfg, self.world, self.fused, self.pipeline = _lib, cfg, world, fused, pipeline
         self.hx, self.ks = _lib.load()
-        n = args.n
-        self.dims = (n, n, n) if args.scaling == "strong" else (n, n, (n // 8) * world)  # weak: config 5 = n x n x n/8 rows per GPU
-        self.N = self.dims[0] * self.dims[1] * self.dims[2]
+        self.dims, self.N = cfg.dims, cfg.N
         ranges = pdist.split_ownership(self.N, world)
         rs, re = int(ranges[rank]), int(ranges[rank + 1])
-        self.ai, self.aj, self.aa = assemble(self.ks, args.stencil, self.dims, rs, re)
+        ai, aj, aa = assemble(self.ks, cfg.stencil, self.dims, rs, re)
         self.m = re - rs
+        self.wide = ai.dtype == np.int64
+        self.halo = self.lvec = self.Bm = None
         if world > 1:
-            plan = pdist.build_plan(self.ai, self.aj, self.aa, ranges, rank, dist=dist)
-            self.M, self.keep = pdist.create_device_mat(plan, world, rank=rank, dist=dist, transport=args.transport)
+            plan = pdist.build_plan(ai, aj, aa, ranges, rank, dist=dist)
+            self.M, keep = pdist.create_device_mat(plan, world, rank=rank, dist=dist, transport=transport)
+            self.Am = keep[0]
+            if len(keep) > 1:
+                self.Bm, self.halo, self.lvec = keep[1], keep[2], keep[3]
             self.nnz_local = int(plan["Ai"][-1])
+            self.nghost = int(plan["nghost"])
+            del plan
         else:
-            A = _lib.mat_create_csr(self.m, self.m, self.ai, self.aj, self.aa)
-            self.M, self.keep = _lib.HipxMat(m=self.m, A=A, B=None, halo=None, lvec=None, nranks=1), [A]
-            self.nnz_local = int(self.ai[-1])
+            self.Am = _lib.mat_create_csr(self.m, self.m, ai, aj, aa)
+            self.M = _lib.HipxMat(m=self.m, A=self.Am, B=None, halo=None, lvec=None, nranks=1)
+            self.nnz_local = int(ai[-1])
+            self.nghost = 0
+        self.host_csr = (ai, aj, aa) if keep_host else None
+        del ai, aj, aa
         self.ones = _lib.DVec(self.m, np.ones(self.m))
         self.B = _lib.DVec(self.m)
         self.X = _lib.DVec(self.m)
         _lib.chk(self.ks.HipxMatMult(C.byref(self.M), self.ones.ptr, self.B.ptr))  # b = A * 1 (ex2.c:139 style)
+        self.ones.free()
         self.pc = None
         self.ksp = None
 
-    def setup(self, variant, no_dconst=False):
-        lib, ks, args = self.lib, self.ks, self.args
+    def setup(self, variant=0, no_dconst=False):
+        lib, ks = self.lib, self.ks
         lib.chk(self.hx.hipxMatSetSpMVVariant(self.M.A, variant))
         if no_dconst:
             os.environ["HIPX_NO_DCONST"] = "1"
@@ -177,12 +234,12 @@ class Problem:
             ks.HipxPCDestroy(C.byref(self.pc))
         self.pc = lib.HipxPC()
         ks.HipxPCSetDefaults(C.byref(self.pc))
-        self.pc.type = {"none": 0, "jacobi": 1, "sor": 2}[args.pc]
+        self.pc.type = {"none": 0, "jacobi": 1, "sor": 2}[self.cfg.pc]
         lib.chk(ks.HipxPCSetUp(C.byref(self.pc), C.byref(self.M)))
         self.ksp = lib.HipxKSP()
         ks.HipxKSPSetDefaults(C.byref(self.ksp))
         self.ksp.rtol, self.ksp.abstol, self.ksp.divtol = 1e-50, 1e-300, 1e300
-        self.ksp.fused, self.ksp.pipeline = args.fused, args.pipeline
+        self.ksp.fused, self.ksp.pipeline = self.fused, self.pipeline
         kbuf = C.create_string_buffer(256)
         lib.chk(self.hx.hipxMatGetSpMVKernel(self.M.A, kbuf, 256))
         return kbuf.value.decode()
@@ -191,16 +248,16 @@ class Problem:
         """A fresh solve of exactly `its` iterations from x0 = 0 (rtol = 1e-50: never converges earlier)."""
         lib, ks = self.lib, self.ks
         self.ksp.max_it = its
-        hist = np.zeros(its + 8)
+        hist = np.zeros(its + 8 + its // 30)
         if history:
             self.ksp.history, self.ksp.hist_len = hist.ctypes.data, len(hist)
         else:
             self.ksp.history, self.ksp.hist_len = None, 0
         lib.chk(self.hx.hipxVecSet(self.X.ptr, self.m, 0.0))
-        f = ks.HipxKSPSolve_CG if self.args.ksp == "cg" else ks.HipxKSPSolve_GMRES
+        f = ks.HipxKSPSolve_CG if self.cfg.ksp == "cg" else ks.HipxKSPSolve_GMRES
         lib.chk(f(C.byref(self.ksp), C.byref(self.M), C.byref(self.pc), self.B.ptr, self.X.ptr))
         assert self.ksp.its == its and self.ksp.reason == -3, (self.ksp.its, self.ksp.reason)
-        return hist[:self.ksp.hist_n].copy()
+        return hist[:min(self.ksp.hist_n, len(hist))].copy()
 
     def begin(self, total_its):
         self.ksp.max_it = total_its
@@ -213,48 +270,81 @@ class Problem:
         assert self.ksp.reason == 0, self.ksp.reason
 
     def spmv_bytes(self):
-        return 12 * self.nnz_local + (8 if self.ai.dtype == np.int64 else 4) * (self.m + 1) + 16 * self.m
+        return 12 * self.nnz_local + (8 if self.wide else 4) * (self.m + 1) + 16 * self.m
+
+    def destroy(self):
+        lib, ks, hx = self.lib, self.ks, self.hx
+        lib.chk(hx.hipxDeviceSynchronize())
+        if self.pc is not None:
+            ks.HipxKSPDestroyWork(C.byref(self.ksp))
+            ks.HipxPCDestroy(C.byref(self.pc))
+            self.pc = self.ksp = None
+        for v in (self.B, self.X, self.lvec):
+            if v is not None:
+                v.free()
+        if self.halo is not None:
+            lib.chk(hx.hipxHaloDestroy(C.byref(self.halo)))
+        for m_ in (self.Am, self.Bm):
+            if m_ is not None:
+                lib.mat_destroy(m_)
+        self.Am = self.Bm = self.halo = self.lvec = self.B = self.X = None
+        self.host_csr = None
 
 
-def timed_steps(P, args, sync, dist, torch):
-    """W untimed + K timed iterations (max over ranks), then the same K again with HIP events around every SpMV launch."""
+SECTIONS = {"halo_ms": 0, "allreduce_ms": 1, "offdiag_ms": 2, "sor_ms": 3}  # HIPX_PROF_* of include/hipx.h
+
+
+def timed_steps(P, steps, warmup, sync, dist, torch):
+    """W untimed + K timed iterations (max over ranks), then the same K again with HIP events around every SpMV launch (and, on
+    this second pass only, around the ghost exchange, the all-reduces, the off-diagonal product and MatSOR)."""
     hx, lib = P.hx, P.lib
-    if args.ksp == "cg":
-        P.begin(args.warmup + 2 * args.steps + 10)
-        P.step(args.warmup)
+    if P.cfg.ksp == "cg":
+        P.begin(warmup + 2 * steps + 10)
+        P.step(warmup)
         sync()
         t0 = time.perf_counter()
-        P.step(args.steps)
+        P.step(steps)
         sync()
         elapsed = time.perf_counter() - t0
         lib.chk(hx.hipxProfileSpMV(1))
-        P.step(args.steps)
+        lib.chk(hx.hipxProfileSections(1))
+        P.step(steps)
         sync()
     else:  # GMRES: a solve of exactly K iterations from x0 = 0 (restarts, solution update and work-vector set-up included)
-        P.solve(max(args.warmup, 1))
+        P.solve(max(warmup, 1))
         sync()
         t0 = time.perf_counter()
-        P.solve(args.steps)
+        P.solve(steps)
         sync()
         elapsed = time.perf_counter() - t0
         lib.chk(hx.hipxProfileSpMV(1))
-        P.solve(args.steps)
+        lib.chk(hx.hipxProfileSections(1))
+        P.solve(steps)
         sync()
     cnt, tot_ms = C.c_int(), C.c_double()
     lib.chk(hx.hipxProfileSpMVGet(C.byref(cnt), C.byref(tot_ms)))
     lib.chk(hx.hipxProfileSpMV(0))
+    sec = {}
+    for name, sid in SECTIONS.items():
+        c2, t2 = C.c_int(), C.c_double()
+        lib.chk(hx.hipxProfileSectionGet(sid, C.byref(c2), C.byref(t2)))
+        if c2.value:
+            sec[name] = t2.value / c2.value
+            sec[name.replace("_ms", "_calls")] = c2.value
+    lib.chk(hx.hipxProfileSections(0))
+    local = elapsed
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-    return elapsed, tot_ms.value / max(cnt.value, 1), cnt.value, float(P.ksp.rnorm)
+    return {"elapsed": elapsed, "elapsed_local": local, "spmv_ms": tot_ms.value / max(cnt.value, 1), "launches": cnt.value, "rnorm": float(P.ksp.rnorm), "sections": sec}
 
 
-def pmc_traffic(args, variant, kernel_prefix):
-    """HBM bytes per launch of the SpMV kernel: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate passes, only
-    --kernel-trace beside them) over `bench.py --spmv-only`, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section)
-    prescribes for gfx950: read bytes = 2 x FETCH_SIZE KiB x 1024; write bytes = WRITE_SIZE KiB x 1024.  The same passes also
-    measure an AXPY of known size as a calibration of that correction."""
+def pmc_traffic(extra_args, kernel_prefix, calib_bytes=None):
+    """HBM bytes per launch of one kernel: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate passes, only
+    --kernel-trace beside them) over an internal mode of this script, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM
+    section) prescribes for gfx950: read bytes = 2 x FETCH_SIZE KiB x 1024; write bytes = WRITE_SIZE KiB x 1024.  The same passes
+    also measure an AXPY of known size as a calibration of that correction."""
     exe = shutil.which("rocprofv3")
     if not exe:
         return None
@@ -263,9 +353,8 @@ def pmc_traffic(args, variant, kernel_prefix):
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr)
-            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--spmv-only", "6", "--grid", str(args.n), "--stencil", str(args.stencil), "--variant", str(variant)]
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240, cwd=tmp, env=dict(os.environ, TMPDIR=tmp))
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__)] + extra_args
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=400, cwd=tmp, env=dict(os.environ, TMPDIR=tmp))
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None
@@ -273,22 +362,32 @@ def pmc_traffic(args, variant, kernel_prefix):
             for row in csv.DictReader(open(files[0])):
                 if row["Counter_Name"] != ctr:
                     continue
-                key = "spmv" if kernel_prefix in row["Kernel_Name"] else "copy" if "ew2_kernel" in row["Kernel_Name"] else None
+                kn = row["Kernel_Name"]
+                key = None
+                for pref in (kernel_prefix if isinstance(kernel_prefix, (list, tuple)) else [kernel_prefix]):
+                    if pref in kn:
+                        key = pref
+                if key is None and "ew2_kernel" in kn:
+                    key = "copy"
                 if key:
                     per.setdefault(key, {}).setdefault(row["Dispatch_Id"], 0.0)
                     per[key][row["Dispatch_Id"]] += float(row["Counter_Value"])
             for key, v in per.items():
                 out[(key, ctr)] = sum(v.values()) / len(v)
                 out[(key, "n")] = len(v)
-        if ("spmv", "FETCH_SIZE") not in out or ("spmv", "WRITE_SIZE") not in out:
+        res = {}
+        for pref in (kernel_prefix if isinstance(kernel_prefix, (list, tuple)) else [kernel_prefix]):
+            if (pref, "FETCH_SIZE") in out and (pref, "WRITE_SIZE") in out:
+                res[pref] = {"bytes": int(2 * out[(pref, "FETCH_SIZE")] * 1024 + out[(pref, "WRITE_SIZE")] * 1024),
+                             "FETCH_SIZE_KiB": out[(pref, "FETCH_SIZE")], "WRITE_SIZE_KiB": out[(pref, "WRITE_SIZE")], "launches_sampled": out[(pref, "n")]}
+        if not res:
             return None
-        res = {"bytes": int(2 * out[("spmv", "FETCH_SIZE")] * 1024 + out[("spmv", "WRITE_SIZE")] * 1024),
-               "FETCH_SIZE_KiB": out[("spmv", "FETCH_SIZE")], "WRITE_SIZE_KiB": out[("spmv", "WRITE_SIZE")], "launches_sampled": out[("spmv", "n")]}
-        if ("copy", "FETCH_SIZE") in out:
-            nbytes = 8 * args.n ** 3
-            res["calibration"] = {"kernel": "hipxVecAXPY on %d doubles (reads %d B, writes %d B)" % (args.n ** 3, 2 * nbytes, nbytes),
-                                  "read_bytes_over_FETCH_SIZE": 2 * nbytes / (out[("copy", "FETCH_SIZE")] * 1024),
-                                  "write_bytes_over_WRITE_SIZE": nbytes / (out[("copy", "WRITE_SIZE")] * 1024) if out.get(("copy", "WRITE_SIZE")) else None}
+        if ("copy", "FETCH_SIZE") in out and calib_bytes:
+            cal = {"kernel": "hipxVecAXPY on %d doubles (reads %d B, writes %d B)" % (calib_bytes // 8, 2 * calib_bytes, calib_bytes),
+                   "read_bytes_over_FETCH_SIZE": 2 * calib_bytes / (out[("copy", "FETCH_SIZE")] * 1024),
+                   "write_bytes_over_WRITE_SIZE": calib_bytes / (out[("copy", "WRITE_SIZE")] * 1024) if out.get(("copy", "WRITE_SIZE")) else None}
+            for v in res.values():
+                v["calibration"] = cal
         return res
     except Exception:
         return None
@@ -313,6 +412,170 @@ def spmv_only(args):
     _lib.chk(hx.hipxDeviceSynchronize())
 
 
+def sor_only(args):
+    """Internal mode for the PMC passes of the PCSOR kernels: a few symmetric zero-guess sweeps (PCApply_SOR) on the operator."""
+    from petsc_amd import _lib
+    hx = _lib.init(0)
+    _, ks = _lib.load()
+    n = args.n
+    N = n ** 3
+    ai, aj, aa = assemble(ks, args.stencil, (n, n, n), 0, N)
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    B, X = _lib.DVec(N, 1.0 + (np.arange(N) % 17) / 17.0), _lib.DVec(N)
+    for _ in range(args.sor_only):
+        _lib.chk(hx.hipxMatSOR(A, B.ptr, 1.0, 12 | 16, 0.0, 1, 1, X.ptr))
+        _lib.chk(hx.hipxVecAXPY(X.ptr, 0.5, B.ptr, N))
+    _lib.chk(hx.hipxDeviceSynchronize())
+
+
+# ------------------------------------------------------------------------------------------------------------ multi-GPU helpers
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-run this command as N ranks under torch.distributed.run (the driver's own
+    recipe), one rank per GPU.  On a box with fewer GPUs than ranks the ranks share devices (IPC transport; the line says so)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["HIPX_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+def probe_transport(t, rank, world, dev, dist, timeout=90.0):
+    """Every rank runs petsc_amd/commprobe.py in a child process (bring-up + all-reduce + ring ghost exchange with known answers);
+    usable only if every rank's child exits 0 in time.  Returns (ok, note)."""
+    box = [None]
+    if rank == 0:
+        box[0] = tempfile.mkdtemp(prefix="hipx_probe_%s_" % t)
+    dist.broadcast_object_list(box, src=0)
+    d = box[0]
+    env = dict(os.environ, HIPX_NO_TORCH="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "petsc_amd.commprobe", "--transport", t, "--rank", str(rank), "--world", str(world), "--device", str(dev), "--dir", d, "--timeout", str(timeout * 0.6)]
+    ok, note = False, ""
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout, cwd=ROOT, env=env)
+        ok = r.returncode == 0
+        note = (r.stdout.strip().splitlines() or [""])[-1][-300:]
+    except subprocess.TimeoutExpired:
+        note = "probe timed out after %.0f s (hang inside the transport)" % timeout
+    except Exception as e:  # noqa: BLE001
+        note = "probe could not run: %s" % e
+    notes = [None] * world
+    dist.all_gather_object(notes, (ok, note))
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(d, ignore_errors=True)
+    allok = all(o for o, _ in notes)
+    return allok, [n for _, n in notes]
+
+
+def parity_vs_golden(P, its, tol):
+    """History of a fresh `its`-iteration solve against the committed exact-reduction history of the same configuration."""
+    key = P.cfg.golden_key()
+    if P.cfg.ksp == "gmres":
+        key += "_np%d" % P.world
+    href, source = golden_history(key)
+    if href is None:
+        return {"pass": None, "ungated": True, "reference": "no committed history for %s (tests/golden/exact_histories.json)" % key}
+    its = min(its, len(href) - 1)
+    hist = P.solve(its, history=True)
+    k = min(len(hist), its + 1)
+    rel = float((np.abs(hist[:k] - href[:k]) / np.abs(href[:k])).max())
+    return {"pass": bool(rel <= tol and k == its + 1), "max_rel_diff": rel, "tolerance": tol, "iterations": its, "entries": k,
+            "reference": "tests/golden/exact_histories.json[%s] (%s: the reference's arithmetic with exact BLAS reductions)" % (key, source)}
+
+
+def run_leg(cfg, rank, world, dist, torch, transport, steps, warmup, sync, variant=0, parity_its=GATE_ITS, fused=1, pipeline=1):
+    """One configuration on the current communicator: timed steps + section times per rank + parity vs the committed yardstick."""
+    t0 = time.perf_counter()
+    P = Problem(cfg, rank, world, dist, transport=transport, fused=fused, pipeline=pipeline)
+    kname = P.setup(variant)
+    t_setup = time.perf_counter() - t0
+    tol = GATE_TOL if cfg.ksp == "cg" else GMRES_SOR_TOL
+    par = parity_vs_golden(P, parity_its, tol)
+    r = timed_steps(P, steps, warmup, sync, dist, torch)
+    mine = {"rank": rank, "rows": P.m, "nnz": P.nnz_local, "ghosts": P.nghost, "spmv_ms": r["spmv_ms"], "elapsed_s": r["elapsed_local"]}
+    mine.update(r["sections"])
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    mode = C.c_int(-1)
+    if cfg.pc == "sor":
+        P.lib.chk(P.hx.hipxMatGetSORMode(P.M.A, C.byref(mode)))
+    out = {"metric": cfg.metric(), "iterations_per_s": steps / r["elapsed"], "ms_per_step": 1e3 * r["elapsed"] / steps, "steps": steps, "warmup": warmup,
+           "scaling": cfg.scaling, "global_rows": cfg.N, "spmv_kernel": kname, "parity": par, "residual_norm_after": r["rnorm"],
+           "setup_seconds": t_setup, "per_rank": per_rank}
+    if cfg.pc == "sor":
+        out["sor_schedule"] = {2: "strand", 1: "dependency-driven", 0: "levels"}.get(mode.value, str(mode.value))
+    nnz_l, m_l, wide = P.nnz_local, P.m, P.wide
+    out["spmv_algorithmic_bytes_rank0"] = P.spmv_bytes()
+    P.destroy()
+    return out, (nnz_l, m_l, wide)
+
+
+# ----------------------------------------------------------------------------------------------------------- single-GPU extra legs
+def cpu_baseline_for(cfg, ranks, its, what):
+    r = ref_driver(ranks, cfg.driver_args(its), bind=True, timeout=1200) or ref_driver(ranks, cfg.driver_args(its), timeout=1200)
+    if r is None:
+        return None
+    return {"value": r["its"] / r["seconds"], "unit": "iterations/s", "cores": ranks, "kind": "reference",
+            "sample": "the reference's own KSPSolve (%s, MAT(MPI)AIJ, MKL one thread per rank; oracle/_ref) on the same system: %d iterations on %d MPI ranks, KSPSolve wall %.3f s; assembly excluded"
+                      % (what, r["its"], ranks, r["seconds"])}
+
+
+def leg_surrogate_spmv(hx, lib):
+    """BASELINE config 4's stand-in (SuiteSparse Flan_1565 is not in the image; tests/surrogates.py documents the substitute): the
+    SpMV of a 1.5 M-row, 121 M-nonzero, all-values-distinct FEM-like matrix with the kernel auto picks, sampled rows checked."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from surrogates import flan_surrogate
+    t0 = time.perf_counter()
+    ai, aj, aa = flan_surrogate()
+    N, nnz = len(ai) - 1, int(ai[-1])
+    A = lib.mat_create_csr(N, N, ai, aj, aa)
+    xh = 1.0 + (np.arange(N) % 17) / 17.0
+    X, Y = lib.DVec(N, xh), lib.DVec(N)
+    kbuf = C.create_string_buffer(256)
+    lib.chk(hx.hipxMatGetSpMVKernel(A, kbuf, 256))
+    for _ in range(5):
+        lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    lib.chk(hx.hipxProfileSpMV(1))
+    for _ in range(50):
+        lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    cnt, tot = C.c_int(), C.c_double()
+    lib.chk(hx.hipxProfileSpMVGet(C.byref(cnt), C.byref(tot)))
+    lib.chk(hx.hipxProfileSpMV(0))
+    y = Y.get()
+    rows = np.random.default_rng(4).integers(0, N, 1500)
+    bad = 0
+    for r in rows:  # MatMult_SeqAIJ aij.c:1486-1494: left-to-right sum of rounded products, starting from 0
+        s = 0.0
+        for k in range(ai[r], ai[r + 1]):
+            s += aa[k] * xh[aj[k]]
+        bad += int(s != y[r])
+    ms = tot.value / max(cnt.value, 1)
+    byts = 12 * nnz + 4 * (N + 1) + 16 * N
+    out = {"what": "config 4 surrogate (Flan_1565-like: %d rows, %d nonzeros, %.1f per row, all values distinct)" % (N, nnz, nnz / N), "kernel": kbuf.value.decode(),
+           "roofline_longrow": {"bound": "hbm", "avg_launch_ms": ms, "launches": cnt.value, "algorithmic_bytes": byts, "achieved": byts / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
+           "sampled_rows_bit_identical": bool(bad == 0), "sampled_rows": len(rows), "build_seconds": time.perf_counter() - t0}
+    for v in (X, Y):
+        v.free()
+    lib.mat_destroy(A)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -322,46 +585,53 @@ def main():
     ap.add_argument("--stencil", type=int, default=7, choices=[7, 27])
     ap.add_argument("--ksp", default="cg", choices=["cg", "gmres"])
     ap.add_argument("--pc", default="jacobi", choices=["jacobi", "sor", "none"])
-    ap.add_argument("--transport", default=os.environ.get("HIPX_TRANSPORT", "rccl"), choices=["rccl", "ipc"],
-                    help="multi-GPU data path: RCCL send/recv + all-reduce over xGMI (default), or IPC peer stores (also when ranks share a GPU)")
+    ap.add_argument("--transport", default=os.environ.get("HIPX_TRANSPORT", "auto"), choices=["auto", "rccl", "ipc"],
+                    help="multi-GPU data path: RCCL send/recv + all-reduce over xGMI, or IPC peer stores (also when ranks share a GPU); auto: probe both, time both, report the faster as `value`")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="weak: every GPU owns grid x grid x grid/8 rows (config 5: --grid 1024)")
     ap.add_argument("--fused", type=int, default=1, help="1 (default): fused SpMV+dot and AXPY+AXPY+PCJACOBI+norm+dot kernels -- same arithmetic and order per element, fewer HBM passes; 0: one kernel per reference Vec/Mat call (cg.c:249-344)")
     ap.add_argument("--pipeline", type=int, default=1, help="1 (default): launch-ahead fused CG (iteration i+1 enqueued before the host has seen iteration i's sums; device-resident scalars); 0: host waits between kernels")
-    ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (include/hipx.h hipxMatSetSpMVVariant): 0 auto, 1 32-bit-column stream kernel, 22/23 packed 16-bit columns, 24/25 + 8-bit value dictionary, 26 row templates")
+    ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (include/hipx.h hipxMatSetSpMVVariant): 0 auto")
     ap.add_argument("--general-variant", type=int, default=23, help="kernel of the roofline_general leg (what a matrix with arbitrary values gets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic then comes from profiles/spmv_traffic.json)")
     ap.add_argument("--no-plugin", action="store_true")
     ap.add_argument("--no-general", action="store_true")
-    ap.add_argument("--quick", action="store_true", help="the timed legs only: no plugin / PMC / CPU-baseline / general-kernel legs")
+    ap.add_argument("--no-other", action="store_true", help="skip the other_configs legs (configs 3/4/5 on one GPU; the scaling legs on N GPUs)")
+    ap.add_argument("--quick", action="store_true", help="the timed legs only: no plugin / PMC / CPU-baseline / general-kernel / other-config legs")
     ap.add_argument("--spmv-only", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--sor-only", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.spmv_only:
         return spmv_only(args)
+    if args.sor_only:
+        return sor_only(args)
     if args.quick:
-        args.no_cpu_baseline = args.no_traffic = args.no_plugin = args.no_general = True
+        args.no_cpu_baseline = args.no_traffic = args.no_plugin = args.no_general = args.no_other = True
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("HIPX_ALL_RANKS_DEVICE0") == "1":  # debugging aid on a 1-GPU box: every rank drives GPU 0
-        local_rank = 0
     import torch
+    ndev = torch.cuda.device_count()
+    share_all = os.environ.get("HIPX_ALL_RANKS_DEVICE0") == "1"
+    dev = 0 if share_all else (local_rank % max(ndev, 1))
+    shared = share_all or world > max(ndev, 1)  # fewer GPUs than ranks: ranks share devices, RCCL refuses that ("Duplicate GPU")
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        # gloo carries the set-up exchanges and the timing barrier; the data path (ghost values, dot/norm sums) is libhipx's own
-        dist.init_process_group(backend="gloo" if os.environ.get("HIPX_ALL_RANKS_DEVICE0") == "1" else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
-    assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch N > 1 with torch.distributed.run)"
+        # gloo carries the set-up exchanges and the timing barrier only; the data path (ghost values, dot/norm sums) is libhipx's own
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
 
     from petsc_amd import _lib
-    hx = _lib.init(local_rank)
-    if world > 1:
-        from petsc_amd import dist as pdist
-        pdist.comm_init(rank, world, dist, args.transport)
-    P = Problem(args, rank, world, dist)
-    n, N = args.n, P.N
+    hx = _lib.init(dev)
+    _, ks = _lib.load()
+    n = args.n
+    dims = (n, n, n) if args.scaling == "strong" else (n, n, (n // 8) * world)  # weak: config 5 = n x n x n/8 rows per GPU
+    head = Cfg(args.stencil, dims, args.ksp, args.pc, args.scaling)
+    N = head.N
 
     def sync():
         _lib.chk(hx.hipxDeviceSynchronize())
@@ -369,142 +639,282 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    if world > 1:
+        return main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync)
+
+    # =========================================================================================================== one GPU
+    P = Problem(head, 0, 1, None, fused=args.fused, pipeline=args.pipeline, keep_host=True)
     kname = P.setup(args.variant)
-    # ---- parity gate: this configuration's first iterations against the reference's own KSPSolve
+    # ---- parity gate: this configuration's first iterations against the reference's own KSPSolve run
+    # beside it with exact BLAS reductions (the reference minus its BLAS's rounding noise)
     gate = {"iterations": GATE_ITS, "tolerance": GATE_TOL, "max_rel_diff": None, "pass": None, "reference": None,
-            "criterion": "every entry of the GPU residual history within 1e-12 (relative) of the history with EXACTLY ROUNDED reductions (the oracle's KSPSolve restatement "
-                         "with Dot2 dot products): the reference's BLAS and the GPU's reduction tree are two roundings of that history, so this bounds the GPU's distance to "
-                         "the reference by the reference's own distance to it (also reported) + 1e-12"}
-    ref1 = None
-    cube = args.scaling == "strong"
-    if world == 1 and cube and not args.no_cpu_baseline and N <= 2 ** 25:
-        ref1 = ref_driver(1, solver_args(args, GATE_ITS) + ["-history"])
-    if world == 1 and cube and not args.no_cpu_baseline and N <= 2 ** 25:
+            "criterion": "every entry of the GPU residual history within 1e-12 (relative) of the REFERENCE's own KSPSolve (oracle/_ref: its cg.c / gmres.c, MatMult_SeqAIJ, Vec loops) run on this host "
+                         "with oracle/libexactblas.so preloaded: ddot / dgemv in twice the working precision (Dot2), i.e. the reference without its BLAS's summation-order noise; the restated oracle's "
+                         "exact mode and the committed golden history are bit-identical to that run (tests/test_oracle_exact.py) and are reported beside it"}
+    ref1 = refx = None
+    gate_on = not args.no_cpu_baseline and N <= 2 ** 25
+    if gate_on:
         hist = P.solve(GATE_ITS, history=True)
-        hexact = None
-        try:  # checker leg: the oracle (CPU restatement of cg.c / gmres.c) with exactly rounded reductions on the same system
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import oracle as orc
-            hexact = orc.ksp_solve(args.ksp, P.ai, P.aj, P.aa, P.B.get(), pc=args.pc, rtol=1e-50, max_it=GATE_ITS, exact=True)[3]
-        except Exception as e:  # noqa: BLE001
-            gate["reference"] = "oracle not available: %s" % e
-        if hexact is not None and len(hexact) == len(hist):
-            rel = float((np.abs(hist - hexact) / np.abs(hexact)).max())
-            gate.update({"max_rel_diff": rel, "pass": bool(rel <= GATE_TOL), "reference": "oracle (exactly rounded reductions), %d history entries" % len(hexact)})
+        ref1 = ref_driver(1, head.driver_args(GATE_ITS) + ["-history"])
+        refx = ref_driver(1, head.driver_args(GATE_ITS) + ["-history"], exact=True)
+        tol = GATE_TOL if head.ksp == "cg" else GMRES_SOR_TOL
+        gate["tolerance"] = tol
+        hgold, gsrc = golden_history(head.golden_key() + ("_np1" if head.ksp == "gmres" else ""))
+        hyard, what = None, None
+        if refx is not None and len(refx["history"]) == len(hist):
+            hyard, what = np.array(refx["history"]), "the REFERENCE's KSPSolve with exact BLAS reductions, run on this host (%d history entries)" % len(hist)
+        elif hgold is not None and len(hgold) >= len(hist):
+            hyard, what = hgold[:len(hist)], "tests/golden/exact_histories.json (%s; oracle/_ref not on this box)" % gsrc
+        else:
+            try:  # last resort: the restated oracle's exact mode
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle as orc
+                ai, aj, aa = P.host_csr
+                hyard = orc.ksp_solve(head.ksp, ai, aj, aa, P.B.get(), pc=head.pc, rtol=1e-50, max_it=GATE_ITS, exact=True)[3]
+                what = "oracle restatement, exact mode (oracle/_ref and the golden file are not available)"
+            except Exception as e:  # noqa: BLE001
+                gate["reference"] = "no yardstick available: %s" % e
+        if hyard is not None and len(hyard) == len(hist):
+            rel = float((np.abs(hist - hyard) / np.abs(hyard)).max())
+            gate.update({"max_rel_diff": rel, "pass": bool(rel <= tol), "reference": what})
+            if hgold is not None and len(hgold) >= len(hist):
+                gate["yardstick_vs_committed_golden_max_abs_diff"] = float(np.abs(hyard - hgold[:len(hist)]).max())
             if ref1 is not None and len(ref1["history"]) == len(hist):
                 href = np.array(ref1["history"])
-                gate["gpu_vs_reference_max_rel_diff"] = float((np.abs(hist - href) / np.abs(href)).max())
-                gate["reference_vs_exact_max_rel_diff"] = float((np.abs(href - hexact) / np.abs(hexact)).max())
-        elif hexact is not None:
-            gate.update({"pass": False, "reference": "history lengths differ: %d vs %d" % (len(hist), len(hexact))})
-    elif world == 1:
-        gate["reference"] = "not run: --no-cpu-baseline / size / box shape"
+                gate["gpu_vs_reference_mkl_max_rel_diff"] = float((np.abs(hist - href) / np.abs(href)).max())
+                gate["reference_mkl_vs_reference_exact_max_rel_diff"] = float((np.abs(href - hyard) / np.abs(hyard)).max())
+        elif hyard is not None:
+            gate.update({"pass": False, "reference": "history lengths differ: %d vs %d" % (len(hist), len(hyard))})
+    else:
+        gate["reference"] = "not run: --no-cpu-baseline / --quick / size"
+    P.host_csr = None
 
     # ---- the timed legs
-    elapsed, spmv_ms, launches, rnorm = timed_steps(P, args, sync, dist, torch)
+    r = timed_steps(P, args.steps, args.warmup, sync, None, torch)
+    elapsed, spmv_ms, launches, rnorm = r["elapsed"], r["spmv_ms"], r["launches"], r["rnorm"]
     spmv_bytes = P.spmv_bytes()
     general = None
-    if world == 1 and not args.no_general and args.ksp == "cg":
+    if not args.no_general and head.ksp == "cg":
         gname = P.setup(args.general_variant, no_dconst=True)
-        g_elapsed, g_ms, g_launches, _ = timed_steps(P, args, sync, dist, torch)
-        general = {"bound": "hbm", "kernel": gname, "avg_launch_ms": g_ms, "launches": g_launches, "algorithmic_bytes": spmv_bytes,
-                   "achieved": spmv_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "iterations_per_s": args.steps / g_elapsed,
+        g = timed_steps(P, args.steps, args.warmup, sync, None, torch)
+        general = {"bound": "hbm", "kernel": gname, "avg_launch_ms": g["spmv_ms"], "launches": g["launches"], "algorithmic_bytes": spmv_bytes,
+                   "achieved": spmv_bytes / (g["spmv_ms"] * 1e-3) / 1e9 if g["spmv_ms"] > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "iterations_per_s": args.steps / g["elapsed"],
                    "note": "same solver with --variant %d and the constant-Jacobi-diagonal shortcut off: the kernels a matrix with arbitrary values gets" % args.general_variant}
         general["frac"] = general["achieved"] / HBM_PEAK_GBS
         P.setup(args.variant)
+    nnz_local = P.nnz_local
+    P.destroy()
 
+    achieved_alg = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+    traffic, source = None, None
+    if head.cube and not args.no_traffic:
+        base = ["--grid", str(n), "--stencil", str(args.stencil), "--spmv-only", "6"]
+        k0 = kname.split(" ")[0]
+        t = pmc_traffic(base + ["--variant", str(args.variant)], k0, 8 * N)
+        if t and k0 in t:
+            traffic, source = t[k0], "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes launched by this run (bench.py --spmv-only), gfx950 correction read = 2 x FETCH_SIZE"
+        if general is not None:
+            kg = general["kernel"].split(" ")[0]
+            tg = pmc_traffic(base + ["--variant", str(args.general_variant)], kg, 8 * N)
+            if tg and kg in tg:
+                general["traffic"] = tg[kg]["bytes"]
+                general["traffic_detail"] = tg[kg]
+                general["frac_counter_bytes"] = tg[kg]["bytes"] / (general["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if traffic is None:
+        try:  # committed PMC passes of the same kernel and workload (profiles/README.md)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "spmv_traffic.json")))
+            key = "%dpt_%d_%s_g%d" % (args.stencil, n, kname.split(" ")[0], 1)
+            if key in tj:
+                traffic, source = {"bytes": tj[key]["traffic_bytes"]}, "profiles/spmv_traffic.json (committed rocprofv3 PMC passes of this kernel on this workload; not measured in this run)"
+        except Exception:
+            pass
+    tbytes = traffic["bytes"] if traffic else None
+    achieved = (tbytes / (spmv_ms * 1e-3) / 1e9) if (tbytes and spmv_ms > 0) else achieved_alg
+    value = args.steps / elapsed if gate["pass"] is not False else None
+    out = {
+        "metric": head.metric(), "value": value, "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "3-D %d-pt Poisson %dx%dx%d (N=%d rows, nnz=%d local), KSP%s + %s, b = A*1, x0 = 0; rows split over 1 rank(s)"
+                               % (args.stencil, dims[0], dims[1], dims[2], N, nnz_local, args.ksp.upper(), head.pcname()),
+                   "global_rows": N, "parallelism": "rows1", "transport": None, "fused": args.fused, "pipeline": args.pipeline, "spmv_variant": args.variant,
+                   "residual_norm_after": rnorm},
+        "ungated": gate["pass"] is None,
+        "parity_gate": gate,
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "basis": "HBM bytes moved (PMC counters) / launch time" if tbytes else "algorithmic CSR bytes / launch time (no counter bytes available)",
+                     "traffic": tbytes, "traffic_source": source, "traffic_detail": traffic,
+                     "launches": launches, "avg_launch_ms": spmv_ms, "algorithmic_bytes": spmv_bytes, "effective_gbps": achieved_alg,
+                     "effective_frac_of_peak": achieved_alg / HBM_PEAK_GBS, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+                     "note": "effective_gbps = CSR algorithmic bytes (12 nnz + 4 (N+1) + 16 N, SURVEY 8(d)) / launch time: the compressed formats (row templates, "
+                             "value dictionary, 16-bit columns) move fewer bytes than that, so it can exceed the HBM peak; frac is on the bytes really moved"},
+        "roofline_general": general,
+    }
+    if not args.no_plugin and head.cube and args.ksp == "cg" and args.pc == "jacobi" and N <= 2 ** 25:
+        plug = {}
+        for label, ksp in (("reference KSPSolve_CG over hipx types", "cg"), ("-ksp_type cghipx (fused kernels under PETSc's monitors / convergence test)", "cghipx")):
+            a = [x if x != "cg" else ksp for x in head.driver_args(400)]
+            rr = ref_driver(1, a, plugin=True)
+            plug[ksp] = {"what": label, "iterations_per_s": (rr["its"] / rr["seconds"]) if rr else None, "iterations": rr["its"] if rr else None,
+                         "KSPSolve_seconds": rr["seconds"] if rr else None}
+        out["plugin"] = plug
+    else:
+        out["plugin"] = None
+    best_ranks = None
+    if not args.no_cpu_baseline:
+        cores = physical_cores()
+        base = None
+        if N <= 2 ** 25:
+            # the box's host cores: P = physical cores, and P/2, P/4 beside it (a memory-bound solve does not always peak at
+            # P = cores; an over-subscribed or quota-limited container shows up here too); the best rate is the baseline
+            its_p = 40 if n >= 200 else 200
+            tried, rp = [], None
+            for p_ in [c for c in dict.fromkeys([cores, cores // 2, cores // 4]) if c > 1]:
+                rr = ref_driver(p_, head.driver_args(its_p), bind=True) or ref_driver(p_, head.driver_args(its_p))
+                if rr is not None:
+                    rr["ranks"] = p_
+                    tried.append({"ranks": p_, "iterations_per_s": rr["its"] / rr["seconds"]})
+                    if rp is None or rr["its"] / rr["seconds"] > rp["its"] / rp["seconds"]:
+                        rp = rr
+            r1 = ref1 if ref1 is not None else ref_driver(1, head.driver_args(GATE_ITS))
+            if rp is not None or r1 is not None:
+                best = rp if rp is not None else r1
+                best_ranks = rp["ranks"] if rp is not None else None
+                base = {"value": best["its"] / best["seconds"], "unit": "iterations/s", "cores": rp["ranks"] if rp is not None else 1, "kind": "reference",
+                        "physical_cores": cores, "ranks_tried": tried, "value_1core": (r1["its"] / r1["seconds"]) if r1 else None,
+                        "sample": "the reference's own KSPSolve (KSP%s + %s, MAT(MPI)AIJ, VEC(MPI), MKL BLAS one thread per rank, gcc -O2; oracle/_ref) on the same %d-pt %s system: "
+                                  "%s iterations on %d MPI ranks, the best of the rank counts tried on this host's %d physical cores (KSPSolve wall %s s), %s iterations on 1 core (%s s); assembly excluded"
+                                  % (args.ksp.upper(), head.pcname(), args.stencil, head.shape(), rp["its"] if rp else "-", rp["ranks"] if rp else 0, cores, "%.3f" % rp["seconds"] if rp else "-",
+                                     r1["its"] if r1 else "-", "%.3f" % r1["seconds"] if r1 else "-")}
+        if base is None and head.cube and args.ksp == "cg" and args.pc == "jacobi" and N <= 2 ** 25:
+            ai, aj, aa = assemble(ks, args.stencil, dims, 0, N)
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle as orc
+            base, _ = oracle_port_baseline(ai, aj, aa, orc.matmult(ai, aj, aa, np.ones(N)), 20.0, args.stencil, n)
+            del ai, aj, aa
+        out["cpu_baseline"] = base
+    else:
+        out["cpu_baseline"] = None
+
+    # ---- BASELINE configs 3 / 4 / 5 on this GPU (driver-timed: VERDICT r2 item 5)
+    if not args.no_other:
+        other = {}
+        legs = [("config3_solver_gmres30_sor_27pt_256", Cfg(27, (256, 256, 256), "gmres", "sor", golden="gmres_sor_27pt_256"), 60, 5, 35, 10),
+                ("config5_share_cg_none_7pt_1024x1024x128", Cfg(7, (1024, 1024, 128), "cg", "none", scaling="weak"), 50, 5, 12, 10),
+                # the 1-GPU point of north_star's >= 6x target (27-pt 512^3: 3.6e9 nonzeros, 64-bit row offsets, 46 GB of CSR in HBM)
+                ("cg_jacobi_27pt_512_strong", Cfg(27, (512, 512, 512), "cg", "jacobi"), 30, 3, 16, 0)]
+        for name, cfg, st, wu, pits, cpu_its in legs:
+            try:
+                res, (nnz_l, m_l, _) = run_leg(cfg, 0, 1, None, torch, None, st, wu, sync, parity_its=pits)
+                pr = res.pop("per_rank")[0]
+                res["spmv_ms"] = pr["spmv_ms"]
+                if cfg.pc == "sor" and "sor_ms" in pr:
+                    ssor = 2 * 12 * nnz_l + 40 * m_l  # two passes over a, j + 5 vector passes
+                    res["roofline_sor"] = {"bound": "hbm", "kernel": "sor_strand_kernel forward + backward (one PCApply_SOR = symmetric sweep)", "avg_call_ms": pr["sor_ms"], "calls": pr.get("sor_calls"),
+                                           "algorithmic_bytes": ssor, "effective_gbps": ssor / (pr["sor_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+                    if not args.no_traffic:
+                        t = pmc_traffic(["--grid", "256", "--stencil", "27", "--sor-only", "4"], ["sor_strand_kernel<0", "sor_strand_kernel<1"], 8 * cfg.N)
+                        if t and len(t) == 2:
+                            tb = sum(v["bytes"] for v in t.values())
+                            res["roofline_sor"].update({"traffic": tb, "traffic_detail": t, "achieved": tb / (pr["sor_ms"] * 1e-3) / 1e9, "frac": tb / (pr["sor_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                        "traffic_source": "rocprofv3 --pmc passes launched by this run (bench.py --sor-only): forward + backward strand kernels"})
+                if not args.no_cpu_baseline and best_ranks and cpu_its:
+                    res["cpu_baseline"] = cpu_baseline_for(cfg, best_ranks, cpu_its, "KSP%s + %s" % (cfg.ksp.upper(), cfg.pcname()))
+                other[name] = res
+            except Exception as e:  # noqa: BLE001
+                other[name] = {"error": str(e)[:400]}
+        try:
+            other["config4_surrogate_spmv"] = leg_surrogate_spmv(hx, _lib)
+        except Exception as e:  # noqa: BLE001
+            other["config4_surrogate_spmv"] = {"error": str(e)[:400]}
+        out["other_configs"] = other
+    print(json.dumps(out))
+    sys.stdout.flush()
+
+
+def main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync):
+    """N > 1 ranks: probe the transports out of process, time the headline configuration on each usable one (RCCL first: the
+    north_star's transport; IPC peer stores as the alternative / fallback), report the faster as `value`, then run the scaling
+    legs on it.  Every leg checks its first iterations against the committed exact-reduction history of the same system."""
+    from petsc_amd import _lib
+    from petsc_amd import dist as pdist
+    uid = C.c_ulonglong()
+    _lib.chk(hx.hipxDeviceUID(C.byref(uid)))
+    devs = [None] * world
+    dist.all_gather_object(devs, {"rank": rank, "device": dev, "device_uid": "%016x" % uid.value})
+    distinct = len({d["device_uid"] for d in devs})
+    shared = shared or distinct < world
+    want = [args.transport] if args.transport != "auto" else (["ipc"] if shared else ["rccl", "ipc"])
+    multi = {"ranks": world, "distinct_devices": distinct, "devices": devs, "transports": {}, "launcher": "self (bench.py -> torch.distributed.run)" if os.environ.get("HIPX_SELF_LAUNCHED") else "external (torch.distributed.run)"}
+    if shared:
+        multi["note"] = "ranks share GPUs on this box (%d device(s) for %d ranks): RCCL refuses that, the IPC transport runs; this is a functional run, not a scaling measurement" % (distinct, world)
+    legs, best = {}, None
+    for t in want:
+        ok, notes = probe_transport(t, rank, world, dev, dist)
+        multi["transports"][t] = {"probe_ok": ok, "probe": notes[:2] + (["..."] if world > 2 else [])}
+        if not ok:
+            continue
+        try:
+            pdist.comm_init(rank, world, dist, t)
+            res, _ = run_leg(head, rank, world, dist, torch, t, args.steps, args.warmup, sync, variant=args.variant, fused=args.fused, pipeline=args.pipeline)
+            nr = C.c_int()
+            _lib.chk(hx.hipxCommRank(None, C.byref(nr)))
+            res["comm_nranks"] = nr.value
+            legs[t] = res
+            multi["transports"][t].update({"iterations_per_s": res["iterations_per_s"], "parity": res["parity"], "comm_nranks": nr.value})
+            _lib.chk(hx.hipxCommFinalize())
+            if res["parity"]["pass"] is not False and (best is None or res["iterations_per_s"] > legs[best]["iterations_per_s"]):
+                best = t
+        except Exception as e:  # noqa: BLE001  (a rank-local failure here cannot be recovered collectively: report and stop)
+            multi["transports"][t]["error"] = str(e)[:300]
+            raise
     out = None
     if rank == 0:
-        achieved_alg = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
-        traffic, source = None, None
-        if world == 1 and cube and not args.no_traffic:
-            t = pmc_traffic(args, args.variant, kname.split(" ")[0])
-            if t:
-                traffic, source = t, "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes launched by this run (bench.py --spmv-only), gfx950 correction read = 2 x FETCH_SIZE"
-            if general is not None:
-                tg = pmc_traffic(args, args.general_variant, general["kernel"].split(" ")[0])
-                if tg:
-                    general["traffic"] = tg["bytes"]
-                    general["traffic_detail"] = tg
-                    general["frac_counter_bytes"] = tg["bytes"] / (general["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-        if traffic is None:
-            try:  # committed PMC passes of the same kernel and workload (profiles/README.md)
-                tj = json.load(open(os.path.join(ROOT, "profiles", "spmv_traffic.json")))
-                key = "%dpt_%d_%s_g%d" % (args.stencil, n, kname.split(" ")[0], world)
-                if key in tj:
-                    traffic, source = {"bytes": tj[key]["traffic_bytes"]}, "profiles/spmv_traffic.json (committed rocprofv3 PMC passes of this kernel on this workload; not measured in this run)"
-            except Exception:
-                pass
-        tbytes = traffic["bytes"] if traffic else None
-        achieved = (tbytes / (spmv_ms * 1e-3) / 1e9) if (tbytes and spmv_ms > 0) else achieved_alg
-        gate_ok = gate["pass"] is not False
-        value = args.steps / elapsed if gate_ok else None
-        pcname = {"jacobi": "PCJACOBI", "sor": "PCSOR", "none": "PCNONE"}[args.pc]
-        out = {
-            "metric": "%s iterations/sec, %d-pt Poisson %s fp64, KSP%s+%s" % (args.ksp.upper(), args.stencil, "%d^3" % n if cube else "%dx%dx%d" % P.dims, args.ksp.upper(), pcname),
-            "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "3-D %d-pt Poisson %dx%dx%d (N=%d rows, nnz=%d local), KSP%s + %s, b = A*1, x0 = 0; rows split over %d rank(s)"
-                                   % (args.stencil, P.dims[0], P.dims[1], P.dims[2], N, P.nnz_local, args.ksp.upper(), pcname, world),
-                       "global_rows": N, "parallelism": "rows%d" % world, "transport": args.transport if world > 1 else None, "fused": args.fused, "pipeline": args.pipeline, "spmv_variant": args.variant,
-                       "residual_norm_after": rnorm},
-            "parity_gate": gate,
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "basis": "HBM bytes moved (PMC counters) / launch time" if tbytes else "algorithmic CSR bytes / launch time (no counter bytes available)",
-                         "traffic": tbytes, "traffic_source": source, "traffic_detail": traffic,
-                         "launches": launches, "avg_launch_ms": spmv_ms, "algorithmic_bytes": spmv_bytes, "effective_gbps": achieved_alg,
-                         "effective_frac_of_peak": achieved_alg / HBM_PEAK_GBS, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
-                         "note": "effective_gbps = CSR algorithmic bytes (12 nnz + 4 (N+1) + 16 N, SURVEY 8(d)) / launch time: the compressed formats (row templates, "
-                                 "value dictionary, 16-bit columns) move fewer bytes than that, so it can exceed the HBM peak; frac is on the bytes really moved"},
-            "roofline_general": general,
-        }
-        if world == 1 and not args.no_plugin and cube and args.ksp == "cg" and args.pc == "jacobi" and N <= 2 ** 25:
-            plug = {}
-            for label, ksp in (("reference KSPSolve_CG over hipx types", "cg"), ("-ksp_type cghipx (fused kernels under PETSc's monitors / convergence test)", "cghipx")):
-                a = [x if x != "cg" else ksp for x in solver_args(args, 400)]
-                r = ref_driver(1, a, plugin=True)
-                plug[ksp] = {"what": label, "iterations_per_s": (r["its"] / r["seconds"]) if r else None, "iterations": r["its"] if r else None,
-                             "KSPSolve_seconds": r["seconds"] if r else None}
-            out["plugin"] = plug
+        pcname = head.pcname()
+        if best is None:
+            out = {"metric": head.metric(), "value": None, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                   "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": head.metric()}, "multi_gpu": multi,
+                   "error": "no transport came up on every rank (or parity failed on all)"}
         else:
-            out["plugin"] = None
-        if world == 1 and not args.no_cpu_baseline:
-            cores = physical_cores()
-            base = None
-            if cube and N <= 2 ** 25:
-                # the box's host cores: P = physical cores, and P/2, P/4 beside it (a memory-bound solve does not always peak at
-                # P = cores; an over-subscribed or quota-limited container shows up here too); the best rate is the baseline
-                its_p = 40 if n >= 200 else 200
-                tried, rp = [], None
-                for p_ in [c for c in dict.fromkeys([cores, cores // 2, cores // 4]) if c > 1]:
-                    r = ref_driver(p_, solver_args(args, its_p), bind=True) or ref_driver(p_, solver_args(args, its_p))
-                    if r is not None:
-                        r["ranks"] = p_
-                        tried.append({"ranks": p_, "iterations_per_s": r["its"] / r["seconds"]})
-                        if rp is None or r["its"] / r["seconds"] > rp["its"] / rp["seconds"]:
-                            rp = r
-                r1 = ref1 if ref1 is not None else ref_driver(1, solver_args(args, GATE_ITS))
-                if rp is not None or r1 is not None:
-                    best = rp if rp is not None else r1
-                    base = {"value": best["its"] / best["seconds"], "unit": "iterations/s", "cores": rp["ranks"] if rp is not None else 1, "kind": "reference",
-                            "physical_cores": cores, "ranks_tried": tried, "value_1core": (r1["its"] / r1["seconds"]) if r1 else None,
-                            "sample": "the reference's own KSPSolve (KSP%s + %s, MAT(MPI)AIJ, VEC(MPI), MKL BLAS one thread per rank, gcc -O2; oracle/_ref) on the same %d-pt %d^3 system: "
-                                      "%s iterations on %d MPI ranks, the best of the rank counts tried on this host's %d physical cores (KSPSolve wall %s s), %s iterations on 1 core (%s s); assembly excluded"
-                                      % (args.ksp.upper(), pcname, args.stencil, n, rp["its"] if rp else "-", rp["ranks"] if rp else 0, cores, "%.3f" % rp["seconds"] if rp else "-",
-                                         r1["its"] if r1 else "-", "%.3f" % r1["seconds"] if r1 else "-")}
-            if base is None and cube and args.ksp == "cg" and args.pc == "jacobi" and N <= 2 ** 25:
-                base, _ = oracle_port_baseline(P.ai, P.aj, P.aa, P.B.get(), 20.0, args.stencil, n)
-            out["cpu_baseline"] = base
-        else:
-            out["cpu_baseline"] = None
+            res = legs[best]
+            out = {"metric": head.metric(), "value": res["iterations_per_s"] if res["parity"]["pass"] is not False else None, "unit": "iterations/s", "n_gpus": world,
+                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+                   "dtype": "f64", "data": "synthetic",
+                   "config": {"workload": "3-D %d-pt Poisson %dx%dx%d (N=%d rows), KSP%s + %s, b = A*1, x0 = 0; rows split over %d rank(s)"
+                                          % (head.stencil, head.dims[0], head.dims[1], head.dims[2], head.N, head.ksp.upper(), pcname, world),
+                              "global_rows": head.N, "parallelism": "rows%d" % world, "transport": best, "fused": args.fused, "pipeline": args.pipeline, "spmv_variant": args.variant,
+                              "residual_norm_after": res["residual_norm_after"]},
+                   "ungated": res["parity"]["pass"] is None, "parity_gate": res["parity"],
+                   "roofline": {"bound": "hbm", "kernel": res["spmv_kernel"], "avg_launch_ms": res["per_rank"][0]["spmv_ms"], "algorithmic_bytes": res["spmv_algorithmic_bytes_rank0"],
+                                "achieved": res["spmv_algorithmic_bytes_rank0"] / (res["per_rank"][0]["spmv_ms"] * 1e-3) / 1e9 if res["per_rank"][0]["spmv_ms"] > 0 else None,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                                "note": "rank 0's diagonal-block SpMV on the algorithmic CSR bytes of its slab (the N = 1 line carries the counter-based figure)"},
+                   "per_rank": res["per_rank"], "cpu_baseline": None, "multi_gpu": multi}
+            if out["roofline"]["achieved"]:
+                out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
+    # ---- the north_star scaling legs on the faster transport
+    if best is not None and not args.no_other:
+        pdist.comm_init(rank, world, dist, best)
+        other = {}
+        scaling_legs = [("cg_jacobi_27pt_512_strong", Cfg(27, (512, 512, 512), "cg", "jacobi", "strong"), 60, 5, 16),
+                        ("config5_cg_none_7pt_1024x1024x%d_weak" % (128 * world), Cfg(7, (1024, 1024, 128 * world), "cg", "none", "weak"), 60, 5, 12),
+                        ("config3_solver_gmres30_sor_27pt_256_parity", Cfg(27, (256, 256, 256), "gmres", "sor", "strong", golden="gmres_sor_27pt_256"), 60, 5, 35),
+                        ("config3_gmres30_sor_27pt_512_strong", Cfg(27, (512, 512, 512), "gmres", "sor", "strong", golden="gmres_sor_27pt_512"), 60, 5, 0)]
+        for name, cfg, st, wu, pits in scaling_legs:
+            try:
+                res, _ = run_leg(cfg, rank, world, dist, torch, best, st, wu, sync, parity_its=pits)
+                other[name] = res
+            except Exception as e:  # noqa: BLE001
+                other[name] = {"error": str(e)[:400]}
+        if out is not None:
+            out["other_configs"] = other
+        _lib.chk(hx.hipxCommFinalize())
+    if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
-    if dist is not None:
-        dist.barrier()
-        _lib.chk(hx.hipxCommFinalize())
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -46,6 +46,7 @@ int         hipxGetDeviceCount(int *count);  /* usable before hipxInit: one rank
 int         hipxIsInitialized(void);
 const char *hipxGetErrorString(void);
 int         hipxDeviceName(char *buf, size_t len);
+int         hipxDeviceUID(unsigned long long *uid); /* hash of the current device's PCI bus id: equal across processes iff they drive the same GPU */
 void       *hipxComputeStream(void);         /* hipStream_t, for callers that enqueue their own work */
 void       *hipxCommStream(void);
 int         hipxStreamSynchronize(void);     /* compute stream */
@@ -70,6 +71,15 @@ int hipxEventElapsedMs(void *start, void *stop, float *ms); /* synchronises on s
    the diagonal-block product of hipxMatMultMPI) is bracketed by HIP events on the compute stream */
 int hipxProfileSpMV(int enable);
 int hipxProfileSpMVGet(int *count, double *total_ms); /* synchronises, returns and clears the tally */
+
+/* the same for the other sections of the path (per-rank diagnosis of a multi-GPU run): events on the stream the section runs on */
+#define HIPX_PROF_HALO      0 /* ghost exchange on the comm stream: pack/put + send/recv (hipxHaloBegin) */
+#define HIPX_PROF_ALLREDUCE 1 /* scalar all-reduce on the compute stream (RCCL or IPC) */
+#define HIPX_PROF_OFFDIAG   2 /* off-diagonal-block MatMultAdd incl. the wait for the ghost values (hipxMatMultMPI) */
+#define HIPX_PROF_SOR       3 /* hipxMatSOR: one call = all its sweeps */
+#define HIPX_PROF_NSECTIONS 4
+int hipxProfileSections(int enable);
+int hipxProfileSectionGet(int id, int *count, double *total_ms); /* synchronises the device, returns and clears the tally */
 
 /* ---- Vec BLAS-1 (device pointers; n = local length) ------------------------------------------ */
 /* replaces VecSet_Seq dvec2.c:642 */                 int hipxVecSet(double *x, hipx_int n, double alpha);
@@ -223,6 +233,12 @@ int hipxHaloIpcExport(hipxHalo h, int rank, int nranks, void *blob1024);
 int hipxHaloIpcAttach(hipxHalo h, const void *all_blobs /* nranks x 1024 bytes, indexed by rank */);
 int hipxHaloBegin(hipxHalo h, const double *x, double *lvec); /* pack on compute stream -> send/recv on comm stream */
 int hipxHaloEnd(hipxHalo h);                                  /* compute stream waits for the exchange */
+/* Callers of the Begin/End pair (instead of hipxMatMultMPI): where the ghost values of the exchange just ended are -- lvec
+   itself with RCCL, the exchange's IPC ghost buffer with peer stores (lvec is then not written) -- and, once every kernel that
+   reads them has been enqueued on the compute stream, hipxHaloRelease: with IPC it acknowledges the buffer to the senders
+   (the exchange after next may overwrite it); a no-op with RCCL.  Every Begin/End needs its Release. */
+int hipxHaloGhost(hipxHalo h, const double *lvec, const double **ghost);
+int hipxHaloRelease(hipxHalo h);
 /* replaces MatMult_MPIAIJ mpiaij.c:1047-1061: halo begin; y = Ad x (overlapped); halo end; y += Bo lvec */
 int hipxMatMultMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *lvec, double *y);
 /* replaces MatMultAdd_MPIAIJ mpiaij.c:1072-1083: halo begin; z = y + Ad x (overlapped); halo end; z += Bo lvec */

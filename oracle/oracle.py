@@ -28,7 +28,7 @@ def lib():
         if not os.path.exists(path):
             subprocess.check_call(["make", "-C", HERE, "-s"])
         _lib = C.CDLL(path)
-        for f in ("orc_laplace2d_5pt", "orc_poisson3d_7pt", "orc_poisson3d_27pt"):
+        for f in ("orc_laplace2d_5pt", "orc_poisson3d_7pt", "orc_poisson3d_27pt", "orc_poisson3d_7pt_box"):
             getattr(_lib, f).restype = C.c_int64
         _lib.orc_VecDot_Seq.restype = C.c_double
         _lib.orc_VecNorm_Seq.restype = C.c_double
@@ -51,6 +51,10 @@ def stencil(kind, n, rstart=None, rend=None, m=None):
     elif kind == "27pt":
         N = n ** 3
         f = lambda *a: L.orc_poisson3d_27pt(n, *a)  # noqa: E731
+    elif kind == "7pt_box":  # n = (nx, ny, nz)
+        nx, ny, nz_ = n
+        N = nx * ny * nz_
+        f = lambda *a: L.orc_poisson3d_7pt_box(nx, ny, nz_, *a)  # noqa: E731
     else:
         raise ValueError(kind)
     rs = 0 if rstart is None else rstart

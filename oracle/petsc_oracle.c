@@ -56,6 +56,26 @@ int64_t orc_poisson3d_7pt(OInt n, OInt rstart, OInt rend, OInt *ai, OInt *aj, OS
   return nz;
 }
 
+/* the same operator on an nx x ny x nz box (x fastest): BASELINE config 5's per-GPU share is 1024 x 1024 x 128 */
+int64_t orc_poisson3d_7pt_box(OInt nx, OInt ny, OInt nzz, OInt rstart, OInt rend, OInt *ai, OInt *aj, OScalar *aa)
+{
+  int64_t    nz = 0;
+  const OInt n2 = nx * ny;
+  for (OInt Ii = rstart; Ii < rend; Ii++) {
+    OInt x = Ii % nx, y = (Ii / nx) % ny, z = Ii / n2;
+    if (ai) ai[Ii - rstart] = (OInt)nz;
+    if (z > 0) PUT(Ii - n2, -1.0);
+    if (y > 0) PUT(Ii - nx, -1.0);
+    if (x > 0) PUT(Ii - 1, -1.0);
+    PUT(Ii, 6.0);
+    if (x < nx - 1) PUT(Ii + 1, -1.0);
+    if (y < ny - 1) PUT(Ii + nx, -1.0);
+    if (z < nzz - 1) PUT(Ii + n2, -1.0);
+  }
+  if (ai) ai[rend - rstart] = (OInt)nz;
+  return nz;
+}
+
 /* src/ksp/ksp/tutorials/bench_kspsolve.c:115-303 (FillCOO): h = 1/(n-1); corner -h/13, edge -3h/26,
    face -3h/13, centre 44h/13, written exactly as the reference writes them (-1.0/13*h, ...).  The COO
    triples are sorted by column at assembly, so the row is emitted in increasing column order

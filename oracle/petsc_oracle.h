@@ -70,6 +70,7 @@ enum { ORC_PC_NONE = 0, ORC_PC_JACOBI = 1, ORC_PC_SOR = 2 };
 /* rows [rstart,rend) of the operator; pass ai==NULL to only count: returns nnz of the slab.    */
 int64_t orc_laplace2d_5pt(OInt m, OInt n, OInt rstart, OInt rend, OInt *ai, OInt *aj, OScalar *aa);   /* ex2.c:70-94 */
 int64_t orc_poisson3d_7pt(OInt n, OInt rstart, OInt rend, OInt *ai, OInt *aj, OScalar *aa);           /* 3-D analogue, SURVEY 8(d) */
+int64_t orc_poisson3d_7pt_box(OInt nx, OInt ny, OInt nz, OInt rstart, OInt rend, OInt *ai, OInt *aj, OScalar *aa); /* nx x ny x nz box */
 int64_t orc_poisson3d_27pt(OInt n, OInt rstart, OInt rend, OInt *ai, OInt *aj, OScalar *aa);          /* bench_kspsolve.c:115-303 */
 
 /* ---- Mat_SeqAIJ kernels ---------------------------------------------------------------------- */

@@ -60,6 +60,8 @@ static PetscErrorCode DumpSplit(Mat A)
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+static PetscInt box_ny = 0, box_nz = 0; /* -ny / -nz: 7-point operator on an n x ny x nz box (BASELINE config 5's per-GPU share: 1024 x 1024 x 128) */
+
 static PetscErrorCode Assemble(Mat A, PetscInt stencil, PetscInt m, PetscInt n, PetscInt Istart, PetscInt Iend)
 {
   PetscInt    cols[27];
@@ -76,14 +78,15 @@ static PetscErrorCode Assemble(Mat A, PetscInt stencil, PetscInt m, PetscInt n, 
       if (j < n - 1) { cols[nc] = Ii + 1; vals[nc++] = -1.0; }
       if (i < m - 1) { cols[nc] = Ii + n; vals[nc++] = -1.0; }
     } else if (stencil == 7) {
-      PetscInt n2 = n * n, x = Ii % n, y = (Ii / n) % n, z = Ii / n2;
+      PetscInt ny = box_ny ? box_ny : n, nz = box_nz ? box_nz : n;
+      PetscInt n2 = n * ny, x = Ii % n, y = (Ii / n) % ny, z = Ii / n2;
       if (z > 0) { cols[nc] = Ii - n2; vals[nc++] = -1.0; }
       if (y > 0) { cols[nc] = Ii - n; vals[nc++] = -1.0; }
       if (x > 0) { cols[nc] = Ii - 1; vals[nc++] = -1.0; }
       cols[nc] = Ii; vals[nc++] = 6.0;
       if (x < n - 1) { cols[nc] = Ii + 1; vals[nc++] = -1.0; }
-      if (y < n - 1) { cols[nc] = Ii + n; vals[nc++] = -1.0; }
-      if (z < n - 1) { cols[nc] = Ii + n2; vals[nc++] = -1.0; }
+      if (y < ny - 1) { cols[nc] = Ii + n; vals[nc++] = -1.0; }
+      if (z < nz - 1) { cols[nc] = Ii + n2; vals[nc++] = -1.0; }
     } else {
       PetscInt    n2 = n * n, n1 = n - 1, x = Ii % n, y = (Ii / n) % n, z = Ii / n2;
       PetscScalar h = 1.0 / (n - 1), v[4];
@@ -127,7 +130,10 @@ int main(int argc, char **argv)
   PetscCall(PetscOptionsGetInt(NULL, NULL, "-matmult_its", &mm_its, NULL));
   PetscCall(PetscOptionsGetBool(NULL, NULL, "-history", &history, NULL));
   PetscCall(PetscOptionsGetBool(NULL, NULL, "-dump_y", &dump_y, NULL));
-  N = (stencil == 5) ? m * n : n * n * n;
+  PetscCall(PetscOptionsGetInt(NULL, NULL, "-ny", &box_ny, NULL));
+  PetscCall(PetscOptionsGetInt(NULL, NULL, "-nz", &box_nz, NULL));
+  PetscCheck((!box_ny && !box_nz) || stencil == 7, PETSC_COMM_WORLD, PETSC_ERR_SUP, "-ny / -nz: 7-point operator only");
+  N = (stencil == 5) ? m * n : (stencil == 7 ? n * (box_ny ? box_ny : n) * (box_nz ? box_nz : n) : n * n * n);
 
   PetscCall(MatCreate(PETSC_COMM_WORLD, &A));
   PetscCall(MatSetSizes(A, PETSC_DECIDE, PETSC_DECIDE, N, N));
@@ -180,6 +186,23 @@ int main(int argc, char **argv)
       PetscCall(MatAssemblyBegin(A, MAT_FINAL_ASSEMBLY));
       PetscCall(MatAssemblyEnd(A, MAT_FINAL_ASSEMBLY));
       PetscCall(MatDiagonalScale(A, r, NULL));
+      { /* -mat_ops_block_edit: right after a device-side value op that the MPI type forwards to its blocks WITHOUT an object-state
+           increase (MatDiagonalScale_MPIAIJ mpiaij.c:1985-1993), edit one value of the diagonal block in place on the host
+           (MatSeqAIJGetArray / RestoreArray: exactly one state increase): a subclass that predicts states uploads nothing here */
+        PetscBool edit = PETSC_FALSE;
+        PetscCall(PetscOptionsGetBool(NULL, NULL, "-mat_ops_block_edit", &edit, NULL));
+        if (edit) {
+          Mat          Ad = A;
+          PetscScalar *arr;
+          PetscMPIInt  sz;
+          PetscCallMPI(MPI_Comm_size(PETSC_COMM_WORLD, &sz));
+          if (sz > 1) PetscCall(MatMPIAIJGetSeqAIJ(A, &Ad, NULL, NULL));
+          PetscCall(MatSeqAIJGetArray(Ad, &arr));
+          arr[0] *= 1.5;
+          arr[3] += 0.125;
+          PetscCall(MatSeqAIJRestoreArray(Ad, &arr));
+        }
+      }
       PetscCall(VecDestroy(&l));
       PetscCall(VecDestroy(&r));
     }

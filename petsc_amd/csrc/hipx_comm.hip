@@ -36,7 +36,8 @@ struct Comm {
   char              **d_peer = nullptr;
   std::vector<void *> opened;
   unsigned long long  seq = 0;
-  unsigned int       *d_err = nullptr;
+  unsigned int       *d_err = nullptr;  // device alias of h_err
+  unsigned int       *h_err = nullptr;  // pinned, host-mapped: a wait that gave up (read by the host after every reduction it waits for)
 };
 Comm &cm()
 {
@@ -58,9 +59,21 @@ __global__ void pack_kernel(const double *__restrict__ x, const hipx_int *__rest
 // ---- IPC transport kernels.  Flags live in fine-grained memory and are accessed with system-scope atomics; payload writes
 // are released with __threadfence_system() before the sequence number is stored (the R1 shape of cdna_hip_programming.md
 // Guideline 16, at system scope because the reader is another process / another GPU).
-constexpr long long IPC_WAIT_TICKS = 800000000LL;  // 8 s of the 100 MHz wall clock
+// How long a rank waits for a peer before it gives up (ticks of the 100 MHz wall clock).  MPI semantics allow arbitrary skew
+// between collective calls (first-call format builds, rank-0 I/O, a debugger), so the default is generous: 300 s;
+// HIPX_IPC_WAIT_SECONDS changes it (0 = wait for ever).  The error word lives in pinned host-mapped memory: the host reads
+// it after every reduction / exchange it waits for and turns a timeout into HIPX_ERR_GPU instead of returning stale sums.
+static long long ipc_wait_ticks()
+{
+  static const long long t = [] {
+    const char *e = getenv("HIPX_IPC_WAIT_SECONDS");
+    const double s = e ? atof(e) : 300.0;
+    return s <= 0.0 ? (long long)0x7fffffffffffffffLL : (long long)(s * 1e8);
+  }();
+  return t;
+}
 
-__device__ __forceinline__ bool ipc_wait_ge(const unsigned long long *flag, unsigned long long want, unsigned int *err)
+__device__ __forceinline__ bool ipc_wait_ge(const unsigned long long *flag, unsigned long long want, unsigned int *err, long long IPC_WAIT_TICKS)
 {
   long long t0 = 0;
   for (unsigned spins = 1;; spins++) {
@@ -69,8 +82,8 @@ __device__ __forceinline__ bool ipc_wait_ge(const unsigned long long *flag, unsi
     if ((spins & 0x3ff) == 0) {
       const long long now = (long long)wall_clock64();
       if (!t0) t0 = now;
-      if (now - t0 > IPC_WAIT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (now - t0 > IPC_WAIT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return false;
       }
     }
@@ -79,10 +92,10 @@ __device__ __forceinline__ bool ipc_wait_ge(const unsigned long long *flag, unsi
 
 // gather x[idx[k]] straight into the neighbour's ghost buffer; the last workgroup to finish publishes the sequence number
 __global__ __launch_bounds__(256) void ipc_put_kernel(const double *__restrict__ x, const hipx_int *__restrict__ idx, hipx_int n, double *dst, const unsigned long long *ack_local,
-                                                      unsigned long long need_ack, unsigned long long *data_flag, unsigned long long seq, unsigned int *ticket, unsigned int *err)
+                                                      unsigned long long need_ack, unsigned long long *data_flag, unsigned long long seq, unsigned int *ticket, unsigned int *err, long long limit)
 {
   __shared__ int ok;
-  if (threadIdx.x == 0) ok = ipc_wait_ge(ack_local, need_ack, err) ? 1 : 0;  // the buffer of exchange seq - 2 has been consumed
+  if (threadIdx.x == 0) ok = ipc_wait_ge(ack_local, need_ack, err, limit) ? 1 : 0;  // the buffer of exchange seq - 2 has been consumed
   __syncthreads();
   if (ok)
     for (hipx_int i = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (hipx_int)gridDim.x * blockDim.x) dst[i] = x[idx[i]];
@@ -98,9 +111,9 @@ __global__ __launch_bounds__(256) void ipc_put_kernel(const double *__restrict__
   }
 }
 
-__global__ void ipc_wait_kernel(const unsigned long long *data_seq, const int *recv_ranks, int nrecv, unsigned long long seq, unsigned int *err)
+__global__ void ipc_wait_kernel(const unsigned long long *data_seq, const int *recv_ranks, int nrecv, unsigned long long seq, unsigned int *err, long long limit)
 {
-  if ((int)threadIdx.x < nrecv) ipc_wait_ge(data_seq + recv_ranks[threadIdx.x], seq, err);
+  if ((int)threadIdx.x < nrecv) ipc_wait_ge(data_seq + recv_ranks[threadIdx.x], seq, err, limit);
 }
 
 __global__ void ipc_ack_kernel(unsigned long long *const *ack_ptrs, int nrecv, unsigned long long seq)
@@ -109,7 +122,7 @@ __global__ void ipc_ack_kernel(unsigned long long *const *ack_ptrs, int nrecv, u
 }
 
 
-__global__ __launch_bounds__(64) void ipc_allreduce_kernel(double *vals, int n, int me, int nranks, char *const *peer, size_t hdr, unsigned long long seq, unsigned int *err)
+__global__ __launch_bounds__(64) void ipc_allreduce_kernel(double *vals, int n, int me, int nranks, char *const *peer, size_t hdr, unsigned long long seq, unsigned int *err, long long limit)
 {
   const int t = threadIdx.x, q = (int)(seq & 1);
   if (t < n) {
@@ -123,7 +136,7 @@ __global__ __launch_bounds__(64) void ipc_allreduce_kernel(double *vals, int n, 
   __syncthreads();
   if (t < nranks) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(peer[t]) + me, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    ipc_wait_ge(reinterpret_cast<const unsigned long long *>(peer[me]) + t, seq, err);
+    ipc_wait_ge(reinterpret_cast<const unsigned long long *>(peer[me]) + t, seq, err, limit);
   }
   __threadfence_system();
   __syncthreads();
@@ -181,12 +194,21 @@ struct hipxHalo_s {
 static int allreduce_dev(double *d_vals, int n)
 {
   Comm &c = cm();
+  int   ierr;
+  if ((ierr = prof_section(HIPX_PROF_ALLREDUCE, true, rt().compute))) return ierr;
   if (c.ipc) {
-    ipc_allreduce_kernel<<<1, 64, 0, rt().compute>>>(d_vals, n, c.rank, c.nranks, c.d_peer, c.hdr, ++c.seq, c.d_err);
+    ipc_allreduce_kernel<<<1, 64, 0, rt().compute>>>(d_vals, n, c.rank, c.nranks, c.d_peer, c.hdr, ++c.seq, c.d_err, ipc_wait_ticks());
     HIPX_LAUNCH_CHECK();
-    return HIPX_SUCCESS;
-  }
-  HIPX_NCCL(ncclAllReduce(d_vals, d_vals, (size_t)n, ncclDouble, ncclSum, c.rcomm, rt().compute));
+  } else HIPX_NCCL(ncclAllReduce(d_vals, d_vals, (size_t)n, ncclDouble, ncclSum, c.rcomm, rt().compute));
+  return prof_section(HIPX_PROF_ALLREDUCE, false, rt().compute);
+}
+
+// the IPC all-reduce kernel gave up on a peer (wait limit): the sums it produced are not sums -- fail loudly
+static int comm_err_check()
+{
+  Comm &c = cm();
+  if (c.ipc && c.h_err && *reinterpret_cast<volatile unsigned int *>(c.h_err))
+    return fail(HIPX_ERR_GPU, "all-reduce (IPC): a peer rank did not contribute within the wait limit (HIPX_IPC_WAIT_SECONDS); the result is invalid", __FILE__, __LINE__);
   return HIPX_SUCCESS;
 }
 
@@ -230,8 +252,9 @@ int hipxCommIpcAttach(const void *all_handles)
   }
   HIPX_HIP(hipMalloc((void **)&c.d_peer, sizeof(char *) * (size_t)c.nranks));
   HIPX_HIP(hipMemcpy(c.d_peer, c.peer.data(), sizeof(char *) * (size_t)c.nranks, hipMemcpyHostToDevice));
-  HIPX_HIP(hipMalloc((void **)&c.d_err, sizeof(unsigned int)));
-  HIPX_HIP(hipMemset(c.d_err, 0, sizeof(unsigned int)));
+  HIPX_HIP(hipHostMalloc((void **)&c.h_err, sizeof(unsigned int), hipHostMallocMapped));
+  *c.h_err = 0;
+  HIPX_HIP(hipHostGetDevicePointer((void **)&c.d_err, c.h_err, 0));
   HIPX_HIP(hipMalloc((void **)&c.d_red, sizeof(double) * 64));
   HIPX_HIP(hipHostMalloc((void **)&c.h_red, sizeof(double) * 64, hipHostMallocDefault));
   c.ipc    = true;
@@ -281,7 +304,7 @@ int hipxCommFinalize(void)
     for (void *q : c.opened) (void)hipIpcCloseMemHandle(q);
     (void)hipFree(c.arena);
     (void)hipFree(c.d_peer);
-    (void)hipFree(c.d_err);
+    if (c.h_err) (void)hipHostFree(c.h_err);
   } else {
     HIPX_NCCL(ncclCommDestroy(c.comm));
     HIPX_NCCL(ncclCommDestroy(c.rcomm));
@@ -316,7 +339,7 @@ int hipxCommAllreduceSum(double *vals, int n)
   HIPX_HIP(hipMemcpyAsync(c.h_red, c.d_red, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
   HIPX_HIP(hipStreamSynchronize(s));
   memcpy(vals, c.h_red, sizeof(double) * (size_t)n);
-  return HIPX_SUCCESS;
+  return comm_err_check();
 }
 
 int hipxVecMDotAllreduce(const double *x, hipx_int nv, const double *const *y, hipx_int n, double *results)
@@ -337,7 +360,8 @@ int hipxVecMDotAllreduce(const double *x, hipx_int nv, const double *const *y, h
   }
   int ierr = red_signal(slot, c.d_red, (int)nv);
   if (ierr) return ierr;
-  return red_wait(slot, (int)nv, results);
+  if ((ierr = red_wait(slot, (int)nv, results))) return ierr;
+  return comm_err_check();
 }
 
 int hipxCGFusedUpdateAllreduce(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n, double *sums2)
@@ -357,7 +381,8 @@ int hipxCGFusedUpdateAllreduce(double *x, double *r, double *z, const double *p,
   }
   int ierr = red_signal(slot, c.d_red, 2);
   if (ierr) return ierr;
-  return red_wait(slot, 2, sums2);
+  if ((ierr = red_wait(slot, 2, sums2))) return ierr;
+  return comm_err_check();
 }
 
 int hipxHaloCreate(int nsend, const int *send_ranks, const hipx_int *send_off, const hipx_int *send_idx, int nrecv, const int *recv_ranks, const hipx_int *recv_off,
@@ -416,6 +441,10 @@ int hipxHaloBegin(hipxHalo h, const double *x, double *lvec)
     h->ghost_cur = reinterpret_cast<double *>(h->arena + h->hdr_bytes) + (size_t)q * h->nghost;
     HIPX_HIP(hipEventRecord(h->ev_packed, rt().compute));  // x is complete
     HIPX_HIP(hipStreamWaitEvent(rt().comm, h->ev_packed, 0));
+    {
+      int ierr = prof_section(HIPX_PROF_HALO, true, rt().comm);
+      if (ierr) return ierr;
+    }
     for (int r = 0; r < h->nsend; r++) {
       const hipx_int cnt = h->send_off[r + 1] - h->send_off[r];
       if (!cnt) continue;
@@ -425,9 +454,13 @@ int hipxHaloBegin(hipxHalo h, const double *x, double *lvec)
       const unsigned long long *ack  = reinterpret_cast<const unsigned long long *>(h->arena) + h->nranks + h->send_ranks[r];  // my ack_seq[peer]
       hipx_int g = (cnt + 255) / 256;
       if (g > 512) g = 512;
-      ipc_put_kernel<<<(unsigned)g, 256, 0, rt().comm>>>(x, h->d_send_idx + h->send_off[r], cnt, dst, ack, s >= 2 ? s - 2 : 0, flag, s, h->d_ticket + r, h->d_err);
+      ipc_put_kernel<<<(unsigned)g, 256, 0, rt().comm>>>(x, h->d_send_idx + h->send_off[r], cnt, dst, ack, s >= 2 ? s - 2 : 0, flag, s, h->d_ticket + r, h->d_err, ipc_wait_ticks());
     }
     HIPX_LAUNCH_CHECK();
+    {
+      int ierr = prof_section(HIPX_PROF_HALO, false, rt().comm);
+      if (ierr) return ierr;
+    }
     HIPX_HIP(hipEventRecord(h->ev_done, rt().comm));
     return HIPX_SUCCESS;
   }
@@ -442,6 +475,10 @@ int hipxHaloBegin(hipxHalo h, const double *x, double *lvec)
   // the comm stream may start once the pack kernel (and whatever produced x) has finished
   HIPX_HIP(hipEventRecord(h->ev_packed, rt().compute));
   HIPX_HIP(hipStreamWaitEvent(rt().comm, h->ev_packed, 0));
+  {
+    int ierr = prof_section(HIPX_PROF_HALO, true, rt().comm);
+    if (ierr) return ierr;
+  }
   HIPX_NCCL(ncclGroupStart());
   for (int r = 0; r < h->nrecv; r++) {
     const hipx_int cnt = h->recv_off[r + 1] - h->recv_off[r];
@@ -452,6 +489,10 @@ int hipxHaloBegin(hipxHalo h, const double *x, double *lvec)
     if (cnt) HIPX_NCCL(ncclSend(h->d_sendbuf + h->send_off[r], (size_t)cnt, ncclDouble, h->send_ranks[r], c.comm, rt().comm));
   }
   HIPX_NCCL(ncclGroupEnd());
+  {
+    int ierr = prof_section(HIPX_PROF_HALO, false, rt().comm);
+    if (ierr) return ierr;
+  }
   HIPX_HIP(hipEventRecord(h->ev_done, rt().comm));
   return HIPX_SUCCESS;
 }
@@ -463,7 +504,7 @@ int hipxHaloEnd(hipxHalo h)
   if (h->nsend + h->nrecv == 0) return HIPX_SUCCESS;
   HIPX_HIP(hipStreamWaitEvent(rt().compute, h->ev_done, 0));  // RCCL: the receives landed; IPC: my puts have read x
   if (h->ipc && h->nrecv) {
-    ipc_wait_kernel<<<1, 64, 0, rt().compute>>>(reinterpret_cast<const unsigned long long *>(h->arena), h->d_recv_ranks, h->nrecv, h->seq, h->d_err);
+    ipc_wait_kernel<<<1, 64, 0, rt().compute>>>(reinterpret_cast<const unsigned long long *>(h->arena), h->d_recv_ranks, h->nrecv, h->seq, h->d_err, ipc_wait_ticks());
     HIPX_LAUNCH_CHECK();
   }
   return HIPX_SUCCESS;
@@ -580,9 +621,11 @@ int hipxMatMultMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *
   int ierr;
   if ((ierr = hipxHaloBegin(h, x, lvec))) return ierr;  // VecScatterBegin   mpiaij.c:1056
   if ((ierr = hipxMatMult(Ad, x, y))) return ierr;      // A->ops->mult      mpiaij.c:1057 (overlaps the exchange)
+  if ((ierr = prof_section(HIPX_PROF_OFFDIAG, true, rt().compute))) return ierr;
   if ((ierr = hipxHaloEnd(h))) return ierr;             // VecScatterEnd     mpiaij.c:1058
   const double *ghost = (h && h->ipc) ? h->ghost_cur : lvec;  // IPC transport: the neighbours wrote straight into this rank's ghost buffer
   if (Bo && (ierr = hipxMatMultAdd(Bo, ghost, y, y))) return ierr;  // B->ops->multadd   mpiaij.c:1059
+  if ((ierr = prof_section(HIPX_PROF_OFFDIAG, false, rt().compute))) return ierr;
   return h ? halo_release(h) : HIPX_SUCCESS;
 }
 
@@ -596,6 +639,20 @@ int hipxMatMultAddMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, doubl
   const double *ghost = (h && h->ipc) ? h->ghost_cur : lvec;
   if (Bo && (ierr = hipxMatMultAdd(Bo, ghost, z, z))) return ierr;  // B->ops->multadd   mpiaij.c:1081
   return h ? halo_release(h) : HIPX_SUCCESS;
+}
+
+int hipxHaloGhost(hipxHalo h, const double *lvec, const double **ghost)
+{
+  HIPX_ARG(h && ghost, "null argument");
+  *ghost = h->ipc ? h->ghost_cur : lvec;
+  return HIPX_SUCCESS;
+}
+
+int hipxHaloRelease(hipxHalo h)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(h, "null halo");
+  return halo_release(h);
 }
 
 int hipxHaloTransport(hipxHalo h, int *transport)

@@ -63,6 +63,10 @@ int launch_cg_fused_nosignal(double *x, double *r, double *z, const double *p, c
 int red_signal(int slot, const double *dev_results, int nvals);  // enqueue: publish to the host (values, then sequence flag), stream-ordered
 int red_wait(int slot, int nvals, double *out);
 
+// optional HIP-event bracketing of named sections of the hot path (bench.py: per-rank diagnosis of a scaling curve).
+// Sections: see HIPX_PROF_* in hipx.h.  Off by default; when on, every bracket costs two hipEventRecord calls.
+int prof_section(int id, bool start, hipStream_t s);
+
 }  // namespace hipx
 
 #define HIPX_CHECK_INIT() \

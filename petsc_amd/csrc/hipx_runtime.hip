@@ -1,6 +1,7 @@
 // hipx_runtime.hip -- device, streams, memory and events behind the C ABI (include/hipx.h).
 #include "hipx_internal.h"
 #include <cstring>
+#include <vector>
 
 namespace hipx {
 Runtime &rt()
@@ -43,7 +44,64 @@ int hipx::red_wait(int slot, int nvals, double *out)
   return HIPX_SUCCESS;
 }
 
+namespace {
+struct SectionProf {
+  bool                    on = false;
+  std::vector<hipEvent_t> ev[HIPX_PROF_NSECTIONS];  // pairs
+  size_t                  used[HIPX_PROF_NSECTIONS] = {0};
+};
+SectionProf &sprof()
+{
+  static SectionProf p;
+  return p;
+}
+}  // namespace
+
+int hipx::prof_section(int id, bool start, hipStream_t s)
+{
+  SectionProf &p = sprof();
+  if (!p.on || id < 0 || id >= HIPX_PROF_NSECTIONS) return HIPX_SUCCESS;
+  if (start && p.used[id] + 2 > p.ev[id].size()) {
+    if (p.ev[id].size() >= 200000) return HIPX_SUCCESS;  // bounded: the tally stops growing, the run goes on
+    for (int k = 0; k < 2; k++) {
+      hipEvent_t e;
+      HIPX_HIP(hipEventCreate(&e));
+      p.ev[id].push_back(e);
+    }
+  }
+  if (!start && (p.used[id] & 1) == 0) return HIPX_SUCCESS;  // a stop without its start (tally was full)
+  HIPX_HIP(hipEventRecord(p.ev[id][p.used[id]++], s));
+  return HIPX_SUCCESS;
+}
+
 extern "C" {
+
+int hipxProfileSections(int enable)
+{
+  HIPX_CHECK_INIT();
+  SectionProf &p = sprof();
+  p.on = enable != 0;
+  for (int k = 0; k < HIPX_PROF_NSECTIONS; k++) p.used[k] = 0;
+  return HIPX_SUCCESS;
+}
+
+int hipxProfileSectionGet(int id, int *count, double *total_ms)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(id >= 0 && id < HIPX_PROF_NSECTIONS, "unknown profile section");
+  SectionProf &p = sprof();
+  HIPX_HIP(hipDeviceSynchronize());
+  double tot = 0.0;
+  for (size_t k = 0; k + 1 < p.used[id]; k += 2) {
+    float ms = 0.f;
+    HIPX_HIP(hipEventElapsedTime(&ms, p.ev[id][k], p.ev[id][k + 1]));
+    tot += ms;
+  }
+  if (count) *count = (int)(p.used[id] / 2);
+  if (total_ms) *total_ms = tot;
+  p.used[id] = 0;
+  return HIPX_SUCCESS;
+}
 
 int hipxInit(int device)
 {
@@ -56,7 +114,12 @@ int hipxInit(int device)
   HIPX_HIP(hipSetDevice(device));
   r.device = device;
   HIPX_HIP(hipStreamCreateWithFlags(&r.compute, hipStreamNonBlocking));
-  HIPX_HIP(hipStreamCreateWithFlags(&r.comm, hipStreamNonBlocking));
+  {  // the exchange kernels are tiny and latency-critical: highest priority, so that they are dispatched ahead of the
+     // (possibly persistent) SpMV workgroups of the compute stream they overlap with
+    int lo = 0, hi = 0;
+    HIPX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPX_HIP(hipStreamCreateWithPriority(&r.comm, hipStreamNonBlocking, hi));
+  }
   HIPX_HIP(hipMalloc((void **)&r.d_partials, sizeof(double) * HIPX_MAX_RED_SLOTS * kMaxRedVals * kRedBlocks));
   HIPX_HIP(hipMalloc((void **)&r.d_tickets, sizeof(unsigned int) * HIPX_MAX_RED_SLOTS));
   HIPX_HIP(hipMemset(r.d_tickets, 0, sizeof(unsigned int) * HIPX_MAX_RED_SLOTS));
@@ -107,6 +170,17 @@ int hipxDeviceName(char *buf, size_t len)
   hipDeviceProp_t p;
   HIPX_HIP(hipGetDeviceProperties(&p, rt().device));
   snprintf(buf, len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+  return HIPX_SUCCESS;
+}
+
+int hipxDeviceUID(unsigned long long *uid)
+{
+  HIPX_CHECK_INIT();
+  char bus[64] = {0};
+  HIPX_HIP(hipDeviceGetPCIBusId(bus, (int)sizeof(bus), rt().device));
+  unsigned long long h = 1469598103934665603ULL;  // FNV-1a of "domain:bus:device.function": the same GPU gives the same id in every process,
+  for (const char *c = bus; *c; c++) h = (h ^ (unsigned char)*c) * 1099511628211ULL;  // whatever HIP_VISIBLE_DEVICES renumbering the launcher applied
+  *uid = h;
   return HIPX_SUCCESS;
 }
 

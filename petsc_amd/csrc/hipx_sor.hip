@@ -2088,7 +2088,18 @@ int run_sweep(hipxSorState *S, const double *b, const double *xold, double *xnew
 }
 }  // namespace
 
+static int mat_sor_impl(hipxMat A, const double *b, double omega, int flag, double shift, hipx_int its, hipx_int lits, double *x);
+
 extern "C" int hipxMatSOR(hipxMat A, const double *b, double omega, int flag, double shift, hipx_int its, hipx_int lits, double *x)
+{
+  HIPX_CHECK_INIT();
+  int ierr = prof_section(HIPX_PROF_SOR, true, rt().compute);  // bench.py: HIP events around the whole call (all its sweeps)
+  if (ierr) return ierr;
+  if ((ierr = mat_sor_impl(A, b, omega, flag, shift, its, lits, x))) return ierr;
+  return prof_section(HIPX_PROF_SOR, false, rt().compute);
+}
+
+static int mat_sor_impl(hipxMat A, const double *b, double omega, int flag, double shift, hipx_int its, hipx_int lits, double *x)
 {
   HIPX_CHECK_INIT();
   HIPX_ARG(A && b && x, "null argument");

@@ -20,7 +20,6 @@ typedef struct {
   PetscInt  spmv_variant;
   hipxCOO   coo;       /* device copies of the reference's COO maps (MatCOOStruct_SeqAIJ jmap / perm) */
   PetscBool dev_newer; /* the device value array is ahead of the host copy a->a (MatSetValuesCOO ran on the device) */
-  PetscObjectState synced_state; /* object state at which host and device values are known to be equal (device-side MatScale ...) */
 } Mat_SeqAIJHIPX;
 
 static PetscErrorCode MatMult_SeqAIJHIPX(Mat, Vec, Vec);
@@ -59,8 +58,6 @@ PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA)
     if (h->spmv_variant) PetscCallHIPX(hipxMatSetSpMVVariant(h->dA, (int)h->spmv_variant));
     h->nonzerostate = A->nonzerostate;
     h->valuestate   = state;
-  } else if (h->valuestate != state && h->synced_state == state) {
-    h->valuestate = state; /* the values changed ON the device and were copied back: nothing to upload */
   } else if (h->valuestate != state) {
     const PetscScalar *aa;
     PetscCall(MatSeqAIJGetArrayRead(A, &aa));
@@ -267,8 +264,7 @@ static PetscErrorCode MatSetValuesCOO_SeqAIJHIPX(Mat A, const PetscScalar v[], I
    by ONE device-to-host copy -- no host pass over the values and no re-upload.  (Leaving the host copy stale, as after
    MatSetValuesCOO with device values, would be unsafe here: MatSetValues_SeqAIJ, MatGetRow_SeqAIJ, MatDuplicateNoCreate_SeqAIJ ...
    read a->a directly, and a CPU build of libpetsc has none of the offload-mask checks the reference's own device types rely
-   on.)  The interface functions (MatScale / MatDiagonalScale, matrix.c) bump the object state once after the op: synced_state
-   records that state so that MatSeqAIJHIPXGetDeviceMat does not upload identical values again.  MatZeroEntries stays the
+   on.)  MatZeroEntries stays the
    parent's (it is the prelude of a host-side MatSetValues assembly). */
 static PetscErrorCode MatSeqAIJHIPXDeviceValuesChanged(Mat A)
 {
@@ -279,8 +275,13 @@ static PetscErrorCode MatSeqAIJHIPXDeviceValuesChanged(Mat A)
   PetscFunctionBegin;
   PetscCallHIPX(hipxMatGetValues(h->dA, a->a));
   h->dev_newer = PETSC_FALSE;
+  /* Host and device hold the same values NOW: give that moment its own object state and record it.  No guess about what the
+     caller does next: MatScale()/MatDiagonalScale() bump the state once more after the op (one redundant upload at the next
+     product), MatDiagonalScale_MPIAIJ (mpiaij.c:1985-1993) calls the blocks' ops directly and does not -- and any later host
+     edit (MatSeqAIJRestoreArray, MatSetValues + assembly ...) moves the state past the recorded one, so it is always uploaded. */
+  PetscCall(PetscObjectStateIncrease((PetscObject)A));
   PetscCall(PetscObjectStateGet((PetscObject)A, &state));
-  h->synced_state = state + 1; /* what the object state will be when the interface function returns */
+  h->valuestate = state;
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 

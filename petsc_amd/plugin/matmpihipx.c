@@ -78,25 +78,20 @@ static PetscErrorCode MatMPIAIJHIPXBuildHalo(Mat A)
   if (!allok) PetscFunctionReturn(PETSC_SUCCESS);
   if (!strcmp(want, "rccl")) transport = 2;
   else if (!strcmp(want, "ipc")) transport = 1;
-  else { /* auto: RCCL needs one device per rank */
-    int          dev = 0, ndev = 1, *all;
-    char         host[MPI_MAX_PROCESSOR_NAME];
-    int          hl = 0;
-    unsigned int key = 5381;
-    PetscBool    shared = PETSC_FALSE;
-    PetscCallHIPX(hipxGetDeviceCount(&ndev));
-    dev = ndev > 0 ? rank % ndev : 0; /* VecHIPXInitRuntime's choice (or -hipx_device: then every rank drives that one device) */
-    {
-      PetscInt d = -1;
-      PetscCall(PetscOptionsGetInt(NULL, NULL, "-hipx_device", &d, NULL));
-      if (d >= 0) dev = (int)d;
-    }
+  else { /* auto: RCCL needs one device per rank.  Compare the real identity of the device each rank drives (PCI bus id) within
+            a host: ordinals say nothing when the launcher binds one GPU per rank through HIP/ROCR_VISIBLE_DEVICES */
+    unsigned long long uid = 0, *all;
+    char               host[MPI_MAX_PROCESSOR_NAME];
+    int                hl = 0;
+    unsigned long long key = 5381;
+    PetscBool          shared = PETSC_FALSE;
+    PetscCallHIPX(hipxDeviceUID(&uid));
     PetscCallMPI(MPI_Get_processor_name(host, &hl));
     for (int c = 0; c < hl; c++) key = key * 33u + (unsigned char)host[c];
     PetscCall(PetscMalloc1(2 * (size_t)size, &all));
     {
-      int mine[2] = {(int)(key & 0x7fffffff), dev};
-      PetscCallMPI(MPI_Allgather(mine, 2, MPI_INT, all, 2, MPI_INT, comm));
+      unsigned long long mine[2] = {key, uid};
+      PetscCallMPI(MPI_Allgather(mine, 2, MPI_UNSIGNED_LONG_LONG, all, 2, MPI_UNSIGNED_LONG_LONG, comm));
     }
     for (int p = 0; p < size && !shared; p++)
       for (int q = p + 1; q < size; q++)
@@ -105,6 +100,7 @@ static PetscErrorCode MatMPIAIJHIPXBuildHalo(Mat A)
           break;
         }
     PetscCall(PetscFree(all));
+    if (!shared && hipx_ipc_comm_up) shared = PETSC_TRUE; /* an IPC communicator is already up in this process: stay on it (hipxCommInit would refuse) */
     transport = shared ? 1 : 2;
   }
   {
@@ -119,30 +115,57 @@ static PetscErrorCode MatMPIAIJHIPXBuildHalo(Mat A)
     PetscCallHIPX(hipxHaloCreate((int)ni, sr, so, si, (int)nr, rr, ro, &h->halo));
     PetscCall(PetscFree5(sr, so, si, rr, ro));
   }
-  if (transport == 2) {
-    if (!hipx_rccl_up) { /* ncclUniqueId of rank 0 travels over MPI */
-      char id[HIPX_COMM_ID_BYTES];
-      if (!rank) PetscCallHIPX(hipxCommGetUniqueId(id));
-      PetscCallMPI(MPI_Bcast(id, HIPX_COMM_ID_BYTES, MPI_BYTE, 0, comm));
-      PetscCallHIPX(hipxCommInit(id, (int)rank, (int)size));
-      hipx_rccl_up = PETSC_TRUE;
+  /* Bring the transport up; a failure on ANY rank (RCCL bootstrap, hipIpcOpenMemHandle to a GPU this process cannot map, ...)
+     makes every rank fall back together: RCCL -> IPC peer stores -> the stock host PetscSF scatter (transport 0). */
+  for (;;) {
+    int ierr = 0, anyerr = 0;
+    if (transport == 2) {
+      if (!hipx_rccl_up) { /* ncclUniqueId of rank 0 travels over MPI */
+        char id[HIPX_COMM_ID_BYTES];
+        memset(id, 0, sizeof(id));
+        if (!rank) ierr = hipxCommGetUniqueId(id);
+        PetscCallMPI(MPI_Bcast(id, HIPX_COMM_ID_BYTES, MPI_BYTE, 0, comm));
+        if (!ierr && !hipx_ipc_comm_up) ierr = hipxCommInit(id, (int)rank, (int)size);
+        else if (hipx_ipc_comm_up) ierr = HIPX_ERR_ORDER;
+      }
+    } else {
+      char *mine, *all;
+      PetscCall(PetscMalloc2(HIPX_HALO_IPC_BLOB_BYTES, &mine, (size_t)HIPX_HALO_IPC_BLOB_BYTES * size, &all));
+      memset(mine, 0, HIPX_HALO_IPC_BLOB_BYTES);
+      ierr = hipxHaloIpcExport(h->halo, (int)rank, (int)size, mine);
+      PetscCallMPI(MPI_Allgather(mine, HIPX_HALO_IPC_BLOB_BYTES, MPI_BYTE, all, HIPX_HALO_IPC_BLOB_BYTES, MPI_BYTE, comm));
+      PetscCallMPI(MPI_Allreduce(&ierr, &anyerr, 1, MPI_INT, MPI_MAX, comm));
+      if (!anyerr) ierr = hipxHaloIpcAttach(h->halo, all);
+      PetscCall(PetscFree2(mine, all));
+      PetscCallMPI(MPI_Allreduce(&ierr, &anyerr, 1, MPI_INT, MPI_MAX, comm));
+      if (!anyerr && !hipx_rccl_up && !hipx_ipc_comm_up) { /* scalar all-reduces of the fused solver (cghipx) through the same IPC machinery */
+        char hmine[64], *hall;
+        PetscCall(PetscMalloc1((size_t)64 * size, &hall));
+        memset(hmine, 0, sizeof(hmine));
+        ierr = hipxCommIpcExport((int)rank, (int)size, hmine);
+        PetscCallMPI(MPI_Allgather(hmine, 64, MPI_BYTE, hall, 64, MPI_BYTE, comm));
+        PetscCallMPI(MPI_Allreduce(&ierr, &anyerr, 1, MPI_INT, MPI_MAX, comm));
+        if (!anyerr) ierr = hipxCommIpcAttach(hall);
+        PetscCall(PetscFree(hall));
+        PetscCallMPI(MPI_Allreduce(&ierr, &anyerr, 1, MPI_INT, MPI_MAX, comm));
+        if (!anyerr) hipx_ipc_comm_up = PETSC_TRUE;
+        else anyerr = 0; /* the ghost exchange itself is up; only cghipx's device all-reduce is not (it then reduces through MPI) */
+        ierr = 0;
+      }
     }
-  } else {
-    char *mine, *all;
-    PetscCall(PetscMalloc2(HIPX_HALO_IPC_BLOB_BYTES, &mine, (size_t)HIPX_HALO_IPC_BLOB_BYTES * size, &all));
-    PetscCallHIPX(hipxHaloIpcExport(h->halo, (int)rank, (int)size, mine));
-    PetscCallMPI(MPI_Allgather(mine, HIPX_HALO_IPC_BLOB_BYTES, MPI_BYTE, all, HIPX_HALO_IPC_BLOB_BYTES, MPI_BYTE, comm));
-    PetscCallHIPX(hipxHaloIpcAttach(h->halo, all));
-    PetscCall(PetscFree2(mine, all));
-    if (!hipx_rccl_up && !hipx_ipc_comm_up) { /* scalar all-reduces of the fused solver (cghipx) through the same IPC machinery */
-      char hmine[64], *hall;
-      PetscCall(PetscMalloc1((size_t)64 * size, &hall));
-      PetscCallHIPX(hipxCommIpcExport((int)rank, (int)size, hmine));
-      PetscCallMPI(MPI_Allgather(hmine, 64, MPI_BYTE, hall, 64, MPI_BYTE, comm));
-      PetscCallHIPX(hipxCommIpcAttach(hall));
-      PetscCall(PetscFree(hall));
-      hipx_ipc_comm_up = PETSC_TRUE;
+    PetscCallMPI(MPI_Allreduce(&ierr, &anyerr, 1, MPI_INT, MPI_MAX, comm));
+    if (!anyerr) {
+      if (transport == 2) hipx_rccl_up = PETSC_TRUE;
+      break;
     }
+    PetscCall(PetscInfo(A, "MATMPIAIJHIPX: transport %s could not be brought up on every rank (code %d: %s)\n", transport == 2 ? "rccl" : "ipc", anyerr, ierr ? hipxGetErrorString() : "another rank failed"));
+    if (transport == 2 && !strcmp(want, "auto")) {
+      transport = 1;
+      continue;
+    }
+    PetscCallHIPX(hipxHaloDestroy(&h->halo)); /* back to the reference's own host scatter */
+    h->transport = 0;
+    PetscFunctionReturn(PETSC_SUCCESS);
   }
   h->transport = transport;
   PetscCall(PetscInfo(A, "MATMPIAIJHIPX ghost exchange on the device: transport %s, %d send / %d receive neighbours\n", transport == 2 ? "rccl" : "ipc", (int)ni, (int)nr));

@@ -1,0 +1,64 @@
+"""GPU: bench.py's multi-rank path as the driver will run it -- `python bench.py --gpus N` WITHOUT a launcher (self-launch) and
+under torch.distributed.run -- on this one-GPU box: the ranks share the device, so the transport is the IPC one (peer stores);
+the out-of-process transport probe, the slab split, the device ghost exchange, the all-reduces and the parity gate against the
+committed exact-reduction history all run with 2 (and 3) real ranks.  VERDICT r2 item 1."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def clean_env():
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HIPX_ALL_RANKS_DEVICE0"):
+        env.pop(k, None)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return env
+
+
+def last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert lines, out[-3000:]
+    return json.loads(lines[-1])
+
+
+def test_self_launch_two_ranks_headline_shape_with_parity():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "64", "--steps", "10", "--warmup", "3", "--quick"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=clean_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["unit"] == "iterations/s" and d["scaling"] == "strong"
+    mg = d["multi_gpu"]
+    assert mg["ranks"] == 2 and mg["launcher"].startswith("self")
+    assert mg["distinct_devices"] == 1 and "ipc" in mg["transports"] and "rccl" not in mg["transports"]  # one GPU here: shared, IPC only
+    assert mg["transports"]["ipc"]["probe_ok"] is True and mg["transports"]["ipc"]["comm_nranks"] == 2
+    assert d["config"]["transport"] == "ipc" and d["config"]["parallelism"] == "rows2"
+    g = d["parity_gate"]  # vs tests/golden/exact_histories.json[cg_jacobi_7pt_64]: the reference with exact BLAS reductions
+    assert g["pass"] is True and g["max_rel_diff"] <= 1e-12 and d["ungated"] is False
+    assert len(d["per_rank"]) == 2 and all(p["rows"] == 64 ** 3 // 2 for p in d["per_rank"])
+    assert all(p["halo_ms"] >= 0 and p["allreduce_ms"] > 0 and p["spmv_ms"] > 0 for p in d["per_rank"])
+
+
+def test_torchrun_three_ranks_weak_box():
+    """The driver's own recipe (python -m torch.distributed.run ... bench.py --gpus N), 3 ranks, weak mode: 64 x 64 x 8 rows per
+    rank -- uneven nothing, but a different box per rank count; --pc none; history vs nothing committed -> ungated but finite."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", "29631",
+           os.path.join(ROOT, "bench.py"), "--gpus", "3", "--grid", "64", "--scaling", "weak", "--pc", "none", "--steps", "8", "--warmup", "2", "--quick"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=clean_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 3 and d["scaling"] == "weak" and d["config"]["global_rows"] == 64 * 64 * 24
+    assert d["multi_gpu"]["launcher"].startswith("external") and d["ungated"] is True and d["value"] > 0
+
+
+def test_self_launch_two_ranks_weak_with_golden():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "64", "--scaling", "weak", "--pc", "none", "--steps", "8", "--warmup", "2", "--quick"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=clean_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["parity_gate"]["pass"] is True and d["parity_gate"]["max_rel_diff"] <= 1e-12  # cg_none_7pt_64x64x16

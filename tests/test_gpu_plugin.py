@@ -127,6 +127,16 @@ def test_matscale_diagonalscale_on_device_then_host_update_bit_exact():
     assert len(hc) == len(hg) and np.abs(hc - hg).max() <= 1e-12 * hc[0]
 
 
+def test_device_value_op_then_in_place_host_edit_is_uploaded():
+    """After a device-side MatDiagonalScale the host edits a value in place (MatSeqAIJGetArray / RestoreArray): the next product
+    must see it (the device copy is re-uploaded, never trusted on a predicted object state)."""
+    a = "-stencil 7 -n 9 -mat_ops -mat_ops_block_edit -dump_y -ksp_max_it 1".split()
+    cpu, gpu = run("ref_driver", a), run("ref_driver", a + HIPX)
+    yc = [l for l in cpu.splitlines() if l.startswith("y ")]
+    yg = [l for l in gpu.splitlines() if l.startswith("y ")]
+    assert yc == yg and len(yc) == 729
+
+
 def test_bench_kspsolve_matmult_and_ksp_goldens_with_aijhipx():
     out = run("bench_kspsolve", ["-print_timing", "false", "-matmult", "-its", "10", "-n", "8", "-mat_type", "aijhipx", "-dll_prepend", PLUGIN])
     ref = run("bench_kspsolve", ["-print_timing", "false", "-matmult", "-its", "10", "-n", "8"])

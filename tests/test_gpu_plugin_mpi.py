@@ -70,7 +70,10 @@ def parse_driver(txt):
 
 
 @pytest.mark.parametrize("np_,args", [(2, "-stencil 7 -n 8"), (3, "-stencil 27 -n 6"), (3, "-stencil 5 -m 9 -n 7"), (2, "-stencil 27 -n 6 -dup_mat"),
-                                      (2, "-stencil 27 -n 6 -mat_ops"), (3, "-stencil 7 -n 8 -mat_ops")])  # MatScale / MatDiagonalScale on the device blocks
+                                      (2, "-stencil 27 -n 6 -mat_ops"), (3, "-stencil 7 -n 8 -mat_ops"),  # MatScale / MatDiagonalScale on the device blocks
+                                      # ... followed by an in-place host edit of the diagonal block (one state increase right after
+                                      # MatDiagonalScale_MPIAIJ's un-counted block ops: ADVICE r2, mathipx.c state bookkeeping)
+                                      (2, "-stencil 27 -n 6 -mat_ops -mat_ops_block_edit"), (3, "-stencil 7 -n 8 -mat_ops -mat_ops_block_edit")])
 def test_matmult_mpiaijhipx_bit_exact_vs_cpu_mpi(np_, args):
     a = args.split() + ["-dump_y", "-ksp_max_it", "1"]
     _, y_cpu, _ = parse_driver(mpirun(np_, "ref_driver", a, False))

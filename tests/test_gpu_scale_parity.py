@@ -42,7 +42,13 @@ TOL_GMRES_SOR = 1e-9    # GMRES(30)+PCSOR, 60-90 iterations with two restarts: G
 TOL_PIPELINED = 1e-6    # pipelined / single-reduction CG against the CPU run of the same executable (see the test)
 
 
-def launch(np_, args, hipx):
+SHIM = os.path.join(ROOT, "oracle", "libexactblas.so")
+
+
+def launch(np_, args, hipx, exact=False):
+    """exact=True (CPU types only): the reference's own executable with oracle/libexactblas.so LD_PRELOADed -- its KSPSolve, its
+    MatMult_SeqAIJ, its Vec loops, the BLAS reductions (ddot / dgemv) evaluated in twice the working precision (oracle/exactblas.c;
+    pinned on the CPU by tests/test_oracle_exact.py).  That run IS the yardstick: the reference without its BLAS's rounding noise."""
     mp = np_ > 1
     exe = os.path.join(REF, "mpich" if mp else "", "bin", "ref_driver")
     plugin = os.path.join(ROOT, "petsc_amd", "lib", "libpetschipx_mpich.so" if mp else "libpetschipx.so")
@@ -51,6 +57,9 @@ def launch(np_, args, hipx):
     if hipx:
         cmd += ["-dll_prepend", plugin, "-vec_type", "hipx", "-mat_type", "aijhipx"]
     env = dict(os.environ, HIPX_NO_TORCH="1", MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
+    if exact:
+        assert not hipx and os.path.exists(SHIM), "oracle/libexactblas.so is not built"
+        env["LD_PRELOAD"] = SHIM
     return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
 
 
@@ -110,6 +119,7 @@ def test_config2_cg_jacobi_256_history_vs_reference(hx):
     n, its = 256, 50
     args = ["-stencil", "7", "-n", str(n), "-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_rtol", "1e-50", "-ksp_max_it", str(its), "-history"]
     p_ref = launch(1, args, False)  # the reference on the host cores, while the GPU legs run
+    p_refx = launch(1, args, False, exact=True)  # the reference with exact BLAS reductions: THE yardstick
     p_cg = launch(1, args, True)
     host = {}
     for name, fused, pipe in [("host layer, one kernel per call", 0, 0), ("host layer, fused kernels", 1, 0), ("host layer, fused + launch-ahead", 1, 1)]:
@@ -127,13 +137,17 @@ def test_config2_cg_jacobi_256_history_vs_reference(hx):
     del ai, aj, aa
     cgx = collect(p_cgx)
     ref = collect(p_ref)
+    refx = collect(p_refx)
     assert ref[1] == its and ref[2] == -3  # KSP_DIVERGED_ITS after exactly 50 iterations
-    d_ref = check_history("256^3 CG+Jacobi: the REFERENCE (MKL reductions) vs exactly rounded reductions", ref, exact, tol=1e-8)
+    # the restated oracle's exact mode and the reference's own KSPSolve_CG with exact BLAS reductions: the same history, bit for bit
+    assert refx[1:3] == exact[1:3] and np.array_equal(refx[0], exact[0]), np.abs(refx[0] - exact[0]).max()
+    record("256^3 CG+Jacobi: restated oracle (exact mode) vs the REFERENCE with exact BLAS reductions", float(np.abs(refx[0] - exact[0]).max()), 0.0)
+    d_ref = check_history("256^3 CG+Jacobi: the REFERENCE (MKL reductions) vs the REFERENCE with exact BLAS reductions", ref, refx, tol=1e-8)
     for name, got in host.items():
-        check_history("256^3 CG+Jacobi: %s vs exactly rounded reductions" % name, got, exact)
+        check_history("256^3 CG+Jacobi: %s vs the REFERENCE with exact BLAS reductions" % name, got, refx)
         assert abs(got[3] - ref[3]) <= 1e-9 * ref[3]
-    check_history("256^3 CG+Jacobi: plugin, reference KSPSolve_CG over hipx types vs exactly rounded reductions", cg, exact)
-    check_history("256^3 CG+Jacobi: plugin, -ksp_type cghipx vs exactly rounded reductions", cgx, exact)
+    check_history("256^3 CG+Jacobi: plugin, reference KSPSolve_CG over hipx types vs the REFERENCE with exact BLAS reductions", cg, refx)
+    check_history("256^3 CG+Jacobi: plugin, -ksp_type cghipx vs the REFERENCE with exact BLAS reductions", cgx, refx)
     # and directly against the reference: within the reference's own distance to the exact history (+ the tolerance)
     for name, got in list(host.items()) + [("plugin cg", cg), ("plugin cghipx", cgx)]:
         check_history("256^3 CG+Jacobi: %s vs the REFERENCE" % name, got, ref, tol=d_ref + TOL_HISTORY)
@@ -152,6 +166,7 @@ def test_config3_solver_gmres30_sor_27pt_64_vs_reference(np_):
     n = 64
     args = ["-stencil", "27", "-n", str(n), "-ksp_type", "gmres", "-pc_type", "sor", "-ksp_rtol", "1e-8", "-history"]
     p_ref = launch(np_, args, False)
+    p_refx = launch(np_, args, False, exact=True)
     p_gpu = launch(np_, args, True)
     ai, aj, aa = orc.stencil("27pt", n)
     b = orc.matmult(ai, aj, aa, np.ones(n ** 3))
@@ -159,7 +174,12 @@ def test_config3_solver_gmres30_sor_27pt_64_vs_reference(np_):
     exact = (he, ie, re_)
     got = collect(p_gpu)
     ref = collect(p_ref)
+    refx = collect(p_refx)
     assert ref[2] > 0 and ref[1] > 10
+    # the two yardsticks (restated oracle, exact mode / the reference's own KSPSolve_GMRES with exact BLAS reductions) against each
+    # other, and the GPU against the reference-made one
+    check_history("27-pt 64^3 GMRES(30)+PCSOR np=%d: restated oracle (exact mode) vs the REFERENCE with exact BLAS reductions" % np_, exact, refx, tol=TOL_GMRES_SOR)
+    check_history("27-pt 64^3 GMRES(30)+PCSOR np=%d: plugin vs the REFERENCE with exact BLAS reductions" % np_, got, refx, tol=TOL_GMRES_SOR)
     d_ref = check_history("27-pt 64^3 GMRES(30)+PCSOR np=%d: CPU run (MKL / MPI_Allreduce reductions) vs exactly rounded reductions" % np_, ref, exact, tol=1e-6)
     check_history("27-pt 64^3 GMRES(30)+PCSOR np=%d: plugin vs exactly rounded reductions" % np_, got, exact, tol=TOL_GMRES_SOR)
     check_history("27-pt 64^3 GMRES(30)+PCSOR np=%d: plugin vs CPU run" % np_, got, ref, tol=d_ref + TOL_GMRES_SOR)
