@@ -102,6 +102,11 @@ int hipxVecMAXPY(double *y, hipx_int nv, const double *alpha, const double *cons
 /* replaces VecMAXPBY rvector.c:1394: y = beta y + sum_j alpha[j] x[j] */
 int hipxVecMAXPBY(double *y, hipx_int nv, const double *alpha, double beta, const double *const *x, hipx_int n);
 
+/* indexed gather / scatter on the compute stream: dst[didx ? didx[k] : k] (= | +=) src[sidx ? sidx[k] : k], k < n; the index lists
+   are DEVICE arrays.  mode 0 insert, 1 add (didx must then hold no duplicates).  Replaces the Pack / UnpackAndInsert / UnpackAndAdd
+   loops of PetscSF (src/vec/is/sf/impls/basic/sfpack.c:706-790) for unit = one scalar. */
+int hipxVecScatterIndexed(const double *src, const hipx_int *sidx, double *dst, const hipx_int *didx, hipx_int n, int mode);
+
 /* reductions: blocking, result written to *host */
 /* replaces VecDot_Seq/VecTDot_Seq bvec1.c:10-49 */   int hipxVecDot(const double *x, const double *y, hipx_int n, double *result);
 /* replaces VecMDot_Seq/VecMTDot_Seq dvec2.c:83 */    int hipxVecMDot(const double *x, hipx_int nv, const double *const *y, hipx_int n, double *results);

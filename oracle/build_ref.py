@@ -37,6 +37,9 @@ KATS = {  # name -> source (reference tree)
     "vec_ex63": "vec/vec/tests/ex63.c",         # VecExp (parent op through our array hooks)
     "mat_ex5": "mat/tests/ex5.c",               # MatMult/MultAdd/MultTranspose (+ diagonal scale)
     "mat_ex123": "mat/tests/ex123.c",           # MatSetPreallocationCOO / MatSetValuesCOO (repeated and negative indices, ADD/INSERT)
+    "sf_ex1": "vec/is/sf/tests/ex1.c",          # PetscSF Bcast / Reduce / FetchAndOp / Gather / Scatter / Compose ... (-sf_type hipx: SURVEY 8(f3))
+    "sf_ex2": "vec/is/sf/tests/ex2.c",          # VecScatter from a device vector into a host-resident one (the reference's own hip test)
+    "sf_ex4": "vec/is/sf/tests/ex4.c",          # PetscSFCompose
 }
 CFLAGS = ["-fPIC", "-O2", "-fstack-protector", "-fvisibility=hidden", "-w", "-I" + CONF, "-I" + os.path.join(REF, "include")]
 

@@ -110,6 +110,114 @@ static PetscErrorCode Assemble(Mat A, PetscInt stencil, PetscInt m, PetscInt n, 
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+/* -scatter_test: general VecScatters between two parallel vectors of the type -vec_type selects -- self edges and remote edges,
+   non-contiguous and out-of-order leaves, several leaves per root -- in every mode the Krylov path's callers use: forward INSERT,
+   forward ADD, reverse ADD (several leaves summed into one root: the MatMultTranspose shape), reverse INSERT on a one-to-one plan.
+   Prints every entry with 17 digits, rank by rank: the CPU types and the hipx types (+ -sf_type hipx) must print the same text. */
+static PetscErrorCode ScatterTest(PetscInt nloc)
+{
+  Vec          x, y;
+  IS           ix, iy;
+  VecScatter   sc, one;
+  PetscMPIInt  rank, size;
+  PetscInt     N, rs, re, *from, *to, ne;
+  PetscScalar *a;
+
+  PetscFunctionBeginUser;
+  PetscCallMPI(MPI_Comm_rank(PETSC_COMM_WORLD, &rank));
+  PetscCallMPI(MPI_Comm_size(PETSC_COMM_WORLD, &size));
+  PetscCall(VecCreate(PETSC_COMM_WORLD, &x));
+  PetscCall(VecSetSizes(x, nloc + rank, PETSC_DECIDE)); /* uneven ownership */
+  PetscCall(VecSetFromOptions(x));
+  PetscCall(VecGetSize(x, &N));
+  PetscCall(VecGetOwnershipRange(x, &rs, &re));
+  PetscCall(VecCreate(PETSC_COMM_WORLD, &y));
+  PetscCall(VecSetSizes(y, 2 * (re - rs) + 3, PETSC_DECIDE));
+  PetscCall(VecSetFromOptions(y));
+  /* every rank lists 2 (re - rs) edges: entry g of x goes to y positions 2 (g') and 2 (g') + 1 of a PERMUTED owner: from = a stride-7
+     walk over all of x (lands on every rank incl. myself), to = my own y range backwards with a hole pattern */
+  ne = 2 * (re - rs);
+  PetscCall(PetscMalloc2(ne, &from, ne, &to));
+  {
+    PetscInt ys, ye;
+    PetscCall(VecGetOwnershipRange(y, &ys, &ye));
+    for (PetscInt k = 0; k < ne; k++) {
+      from[k] = (7 * (rs + k / 2) + 3 * (k % 2) * (rank + 1)) % N; /* roots: some referenced twice, from every rank */
+      to[k]   = ye - 1 - k - (k >= ne / 2 ? 3 : 0);                /* leaves: my y range backwards, a hole of 3 in the middle */
+    }
+  }
+  PetscCall(ISCreateGeneral(PETSC_COMM_WORLD, ne, from, PETSC_COPY_VALUES, &ix));
+  PetscCall(ISCreateGeneral(PETSC_COMM_WORLD, ne, to, PETSC_COPY_VALUES, &iy));
+  PetscCall(VecScatterCreate(x, ix, y, iy, &sc));
+  PetscCall(ISDestroy(&ix));
+  PetscCall(ISDestroy(&iy));
+  /* a one-to-one plan for the INSERT reverse leg: y position (global) p <- x entry (p * 5) mod N restricted to distinct roots */
+  {
+    PetscInt cnt = 0;
+    for (PetscInt g = rs; g < re; g++) {
+      from[cnt] = (g + N / 2 + 1) % N; /* a rotation of x: one-to-one, mostly remote */
+      to[cnt]   = 2 * g;               /* into the even positions of y (global) */
+      cnt++;
+    }
+    {
+      PetscInt M;
+      PetscCall(VecGetSize(y, &M));
+      for (PetscInt k = 0; k < cnt; k++) to[k] = to[k] % M;
+    }
+    PetscCall(ISCreateGeneral(PETSC_COMM_WORLD, cnt, from, PETSC_COPY_VALUES, &ix));
+    PetscCall(ISCreateGeneral(PETSC_COMM_WORLD, cnt, to, PETSC_COPY_VALUES, &iy));
+    PetscCall(VecScatterCreate(x, ix, y, iy, &one));
+    PetscCall(ISDestroy(&ix));
+    PetscCall(ISDestroy(&iy));
+  }
+  PetscCall(PetscFree2(from, to));
+  PetscCall(VecGetArrayWrite(x, &a));
+  for (PetscInt g = rs; g < re; g++) a[g - rs] = 1.0 + (PetscReal)(g % 17) / 17.0 + 1e-3 * g;
+  PetscCall(VecRestoreArrayWrite(x, &a));
+  PetscCall(VecSet(y, -1.0));
+  PetscCall(VecScale(x, 1.0)); /* touch x through a Vec op: with device vector types the current copy now lives on the device */
+#define DUMP(tag, v) \
+  do { \
+    const PetscScalar *va; \
+    PetscInt           vs, ve; \
+    PetscCall(VecGetOwnershipRange(v, &vs, &ve)); \
+    PetscCall(VecGetArrayRead(v, &va)); \
+    for (PetscInt i = vs; i < ve; i++) PetscCall(PetscSynchronizedPrintf(PETSC_COMM_WORLD, "%s %" PetscInt_FMT " %.17g\n", tag, i, (double)va[i - vs])); \
+    PetscCall(PetscSynchronizedFlush(PETSC_COMM_WORLD, PETSC_STDOUT)); \
+    PetscCall(VecRestoreArrayRead(v, &va)); \
+  } while (0)
+  PetscCall(VecScatterBegin(sc, x, y, INSERT_VALUES, SCATTER_FORWARD));
+  PetscCall(VecScatterEnd(sc, x, y, INSERT_VALUES, SCATTER_FORWARD));
+  DUMP("fwd_insert", y);
+  PetscCall(VecScale(y, 0.5));
+  PetscCall(VecScatterBegin(sc, x, y, ADD_VALUES, SCATTER_FORWARD));
+  PetscCall(VecScatterEnd(sc, x, y, ADD_VALUES, SCATTER_FORWARD));
+  DUMP("fwd_add", y);
+  PetscCall(VecScale(y, 1.25));
+  PetscCall(VecScatterBegin(sc, y, x, ADD_VALUES, SCATTER_REVERSE));
+  PetscCall(VecScatterEnd(sc, y, x, ADD_VALUES, SCATTER_REVERSE));
+  DUMP("rev_add", x);
+  PetscCall(VecScale(x, 0.75));
+  PetscCall(VecScatterBegin(one, x, y, INSERT_VALUES, SCATTER_FORWARD));
+  PetscCall(VecScatterEnd(one, x, y, INSERT_VALUES, SCATTER_FORWARD));
+  DUMP("one_fwd", y);
+  PetscCall(VecScale(y, 3.0));
+  PetscCall(VecScatterBegin(one, y, x, INSERT_VALUES, SCATTER_REVERSE));
+  PetscCall(VecScatterEnd(one, y, x, INSERT_VALUES, SCATTER_REVERSE));
+  DUMP("one_rev", x);
+  {
+    PetscSFType t;
+    PetscCall(PetscSFGetType(sc, &t));
+    PetscCall(PetscPrintf(PETSC_COMM_WORLD, "scatter type %s\n", t));
+  }
+#undef DUMP
+  PetscCall(VecScatterDestroy(&sc));
+  PetscCall(VecScatterDestroy(&one));
+  PetscCall(VecDestroy(&x));
+  PetscCall(VecDestroy(&y));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 int main(int argc, char **argv)
 {
   Mat         A;
@@ -123,6 +231,15 @@ int main(int argc, char **argv)
 
   PetscFunctionBeginUser;
   PetscCall(PetscInitialize(&argc, &argv, NULL, NULL));
+  {
+    PetscInt stest = 0;
+    PetscCall(PetscOptionsGetInt(NULL, NULL, "-scatter_test", &stest, NULL));
+    if (stest > 0) {
+      PetscCall(ScatterTest(stest));
+      PetscCall(PetscFinalize());
+      return 0;
+    }
+  }
   PetscCall(PetscOptionsGetInt(NULL, NULL, "-n", &n, NULL));
   PetscCall(PetscOptionsGetInt(NULL, NULL, "-stencil", &stencil, NULL));
   m = n;

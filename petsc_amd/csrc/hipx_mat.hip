@@ -973,7 +973,10 @@ __global__ __launch_bounds__(256) void tmpl_verify_kernel(hipx_int m, hipx_int n
 // (rows +-n, +-n^2) are shared through that XCD's L2.  Thread t of a chunk owns rows base + t + rr*256: the k-th gather of
 // a wave reads x[row + off_k] for 64 consecutive rows = one 512-byte contiguous run when the lanes share a template
 // (interior), and the LDS reads of the template entries broadcast.
-template <int MODE, bool DOT, int RPT, int W, bool UNI>
+// PROBE != 0: developer timing probes (HIPX_TMPL_PROBE, WRONG RESULTS by construction; scripts/spmv_variants.py): 1 = y is not stored;
+// 2 = every gather of a row reads x[row + k] (k = entry index: the row's own cache lines -- no far lines at all); 3 = far offsets
+// folded into +-4096 doubles of the row (same number of distinct lines per gather, all of them recently touched: no far-plane HBM stream)
+template <int MODE, bool DOT, int RPT, int W, bool UNI, int PROBE = 0>
 __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const int *__restrict__ tstart,
                                                         const int *__restrict__ toff, const double *__restrict__ tval, int ntmpl, int nent, const double *__restrict__ x,
                                                         const double *yin, double *yout, double *dotpart, unsigned long long *tq, unsigned long long launch, long long pf_off)
@@ -1067,7 +1070,9 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
 #pragma unroll 4
       for (int k = ts; k < te; k++) {
         const double a  = tval[k];
-        const int    o  = toff[k];
+        int          o  = toff[k];
+        if (PROBE == 2) o = k - ts;
+        if (PROBE == 3) o = (o > 4096 || o < -4096) ? (o % 4096) : o;
         const char  *xb = reinterpret_cast<const char *>(x + o);
         double       xv[RPT];
 #pragma unroll
@@ -1130,10 +1135,11 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
     for (int rr = 0; rr < RPT; rr++) {
       const hipx_int row = base + t + rr * 256;
       if (row < m) {
-        yout[row] = sum[rr];
-        if (DOT) cdot += xrow[rr] * sum[rr];
+        if (PROBE != 1) yout[row] = sum[rr];
+        if (DOT || PROBE == 1) cdot += xrow[rr] * sum[rr];
       }
     }
+    if (PROBE == 1 && !DOT && cdot == 1.2345e300) yout[0] = cdot;  // keeps the sums alive
     if (DOT) {  // one partial per wave and CHUNK (not per workgroup: which workgroup gets which chunk changes from run to run,
                 // the fused dot must not): the fold reads them in chunk order
       const double w = hipx::wave_sum(cdot);
@@ -1746,7 +1752,19 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
   switch (cfg) {
   case 0: HIPX_TMPL_LAUNCH(2, 4, false); break;
   case 2: HIPX_TMPL_LAUNCH(4, 4, true); break;
-  default: HIPX_TMPL_LAUNCH(2, 2, true); break;
+  default: {
+    static const int probe = getenv("HIPX_TMPL_PROBE") ? atoi(getenv("HIPX_TMPL_PROBE")) : 0;
+    if (probe >= 1 && probe <= 3) {
+#define HIPX_TMPL_LAUNCH_P(PR) \
+  spmv_tmpl_kernel<MODE, DOT, 2, 2, true, PR><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout, \
+                                                                                           dotpart, A->d_tq, launch, pf_off)
+      if (probe == 1) HIPX_TMPL_LAUNCH_P(1);
+      else if (probe == 2) HIPX_TMPL_LAUNCH_P(2);
+      else HIPX_TMPL_LAUNCH_P(3);
+#undef HIPX_TMPL_LAUNCH_P
+    } else HIPX_TMPL_LAUNCH(2, 2, true);
+    break;
+  }
   }
 #undef HIPX_TMPL_LAUNCH
   HIPX_LAUNCH_CHECK();

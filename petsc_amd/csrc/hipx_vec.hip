@@ -1288,3 +1288,32 @@ int hipxCGFusedUpdateBegin(double *x, double *r, double *z, const double *p, con
 }
 
 }  // extern "C"
+
+// ---- indexed gather / scatter (PetscSF pack / unpack on the device: sfpack.c Pack / UnpackAndInsert / UnpackAndAdd for unit = one
+// scalar).  dst[didx ? didx[k] : k] (= | +=) src[sidx ? sidx[k] : k].  mode 1 (add) requires didx without duplicates inside one
+// call (the caller checks at set-up): then the result does not depend on the thread schedule -- bit-identical to the sequential loop.
+namespace {
+__global__ __launch_bounds__(256) void scatter_indexed_kernel(const double *__restrict__ src, const hipx_int *__restrict__ sidx, double *dst, const hipx_int *__restrict__ didx, hipx_int n,
+                                                              int mode)
+{
+  for (hipx_int k = (hipx_int)blockIdx.x * 256 + threadIdx.x; k < n; k += (hipx_int)gridDim.x * 256) {
+    const double   v = src[sidx ? sidx[k] : k];
+    const hipx_int d = didx ? didx[k] : k;
+    if (mode == 0) dst[d] = v;
+    else dst[d] = dst[d] + v;
+  }
+}
+}  // namespace
+
+extern "C" int hipxVecScatterIndexed(const double *src, const hipx_int *sidx, double *dst, const hipx_int *didx, hipx_int n, int mode)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(n >= 0 && (mode == 0 || mode == 1), "bad arguments");
+  if (!n) return HIPX_SUCCESS;
+  HIPX_ARG(src && dst, "null vector");
+  hipx_int g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  scatter_indexed_kernel<<<(unsigned)g, 256, 0, rt().compute>>>(src, sidx, dst, didx, n, mode);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}

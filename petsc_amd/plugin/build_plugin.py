@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 LIB = os.path.join(ROOT, "petsc_amd", "lib")
-SRCS = ["vechipx.c", "mathipx.c", "matmpihipx.c", "pchipx.c", "ksphipx.c", "register.c"]
+SRCS = ["vechipx.c", "mathipx.c", "matmpihipx.c", "commhipx.c", "sfhipx.c", "pchipx.c", "ksphipx.c", "register.c"]
 
 
 def build(verbose=False, arch="mpiuni"):

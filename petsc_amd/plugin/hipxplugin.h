@@ -67,3 +67,10 @@ PETSC_INTERN PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA); /* up
 PETSC_INTERN PetscBool      MatIsSeqAIJHIPX(Mat A);
 PETSC_INTERN PetscErrorCode MatSeqAIJHIPXSetValuesCOO_Private(Mat A, hipxCOO coo, const PetscScalar v[], PetscCount n, InsertMode imode);
 PETSC_INTERN PetscErrorCode MatMPIAIJHIPXGetDevice(Mat A, hipxMat *dA, hipxMat *dB, hipxHalo *halo, Vec *lvec); /* halo == NULL: no device exchange */
+/* commhipx.c: transport bring-up of a ghost-exchange plan (collective; RCCL -> IPC -> none) */
+PETSC_INTERN PetscErrorCode HipxHaloBringUp(MPI_Comm comm, PetscObject obj, hipxHalo *halo, const char *want, PetscInt *transport);
+PETSC_INTERN PetscBool      HipxCommIsUp(void);
+/* sfhipx.c: PetscSF type "hipx" */
+#define PETSCSFHIPX "hipx"
+PETSC_INTERN PetscErrorCode PetscSFCreate_HIPX(PetscSF);
+PETSC_INTERN PetscBool      hipx_vec_memtype_ops; /* -vec_hipx_memtype: VecGetArray*AndMemType hand out device pointers (every PetscSF that sees these vectors must be of type hipx) */

@@ -20,7 +20,9 @@
      transport "rccl": ncclSend / ncclRecv over xGMI on the comm stream (one rank per GPU),
      transport "ipc" : peer stores through HIP IPC mappings (also when several ranks share a GPU, which RCCL refuses),
      transport "host": the stock VecScatter on host buffers (PetscSF over MPI) -- the parent's MatMult_MPIAIJ, kept as fall-back.
-   -mat_mpiaijhipx_halo <auto|rccl|ipc|host> (or HIPX_HALO); auto = rccl when every rank drives its own device, else ipc. */
+     "sf"            : Mvctx is re-typed to the PetscSF type hipx (sfhipx.c) and MatMult calls PetscSFBcastWithMemTypeBegin / End on
+                       device pointers: the same transports behind the reference's own scatter interface.
+   -mat_mpiaijhipx_halo <auto|rccl|ipc|host|sf> (or HIPX_HALO); auto = rccl when every rank drives its own device, else ipc. */
 typedef struct {
   PetscErrorCode (*parent_assemblyend)(Mat, MatAssemblyType);
   PetscErrorCode (*parent_destroy)(Mat);
@@ -35,7 +37,6 @@ typedef struct {
   PetscObjectState nzstate;   /* nonzero state the plan was built from */
 } Mat_MPIAIJHIPX;
 
-static PetscBool hipx_rccl_up = PETSC_FALSE, hipx_ipc_comm_up = PETSC_FALSE;
 
 static PetscErrorCode MatMPIAIJHIPXBuildHalo(Mat A)
 {
@@ -59,6 +60,14 @@ static PetscErrorCode MatMPIAIJHIPXBuildHalo(Mat A)
   if (env) PetscCall(PetscStrncpy(want, env, sizeof(want)));
   PetscCall(PetscOptionsGetString(((PetscObject)A)->options, ((PetscObject)A)->prefix, "-mat_mpiaijhipx_halo", want, sizeof(want), NULL));
   if (size == 1 || !a->Mvctx || !strcmp(want, "host")) PetscFunctionReturn(PETSC_SUCCESS);
+  if (!strcmp(want, "sf")) { /* the exchange through the PetscSF interface: Mvctx becomes a PetscSF of type hipx (sfhipx.c), MatMult hands it
+                                device pointers (PetscSFBcastWithMemTypeBegin / End around the diagonal-block product, mpiaij.c:1056-1059) */
+    PetscCall(PetscSFSetType(a->Mvctx, PETSCSFHIPX));
+    PetscCall(PetscSFSetUp(a->Mvctx));
+    h->transport = 3;
+    PetscCall(PetscInfo(A, "MATMPIAIJHIPX ghost exchange through PetscSF type hipx\n"));
+    PetscFunctionReturn(PETSC_SUCCESS);
+  }
   { /* the device exchange is bootstrapped over PETSC_COMM_WORLD ranks (one RCCL communicator per process) */
     int cmp;
     PetscCallMPI(MPI_Comm_compare(comm, PETSC_COMM_WORLD, &cmp));
@@ -76,33 +85,6 @@ static PetscErrorCode MatMPIAIJHIPXBuildHalo(Mat A)
       }
   PetscCallMPI(MPIU_Allreduce(&contiguous, &allok, 1, MPIU_BOOL, MPI_LAND, comm));
   if (!allok) PetscFunctionReturn(PETSC_SUCCESS);
-  if (!strcmp(want, "rccl")) transport = 2;
-  else if (!strcmp(want, "ipc")) transport = 1;
-  else { /* auto: RCCL needs one device per rank.  Compare the real identity of the device each rank drives (PCI bus id) within
-            a host: ordinals say nothing when the launcher binds one GPU per rank through HIP/ROCR_VISIBLE_DEVICES */
-    unsigned long long uid = 0, *all;
-    char               host[MPI_MAX_PROCESSOR_NAME];
-    int                hl = 0;
-    unsigned long long key = 5381;
-    PetscBool          shared = PETSC_FALSE;
-    PetscCallHIPX(hipxDeviceUID(&uid));
-    PetscCallMPI(MPI_Get_processor_name(host, &hl));
-    for (int c = 0; c < hl; c++) key = key * 33u + (unsigned char)host[c];
-    PetscCall(PetscMalloc1(2 * (size_t)size, &all));
-    {
-      unsigned long long mine[2] = {key, uid};
-      PetscCallMPI(MPI_Allgather(mine, 2, MPI_UNSIGNED_LONG_LONG, all, 2, MPI_UNSIGNED_LONG_LONG, comm));
-    }
-    for (int p = 0; p < size && !shared; p++)
-      for (int q = p + 1; q < size; q++)
-        if (all[2 * p] == all[2 * q] && all[2 * p + 1] == all[2 * q + 1]) {
-          shared = PETSC_TRUE;
-          break;
-        }
-    PetscCall(PetscFree(all));
-    if (!shared && hipx_ipc_comm_up) shared = PETSC_TRUE; /* an IPC communicator is already up in this process: stay on it (hipxCommInit would refuse) */
-    transport = shared ? 1 : 2;
-  }
   {
     int      *sr, *rr;
     hipx_int *so, *si, *ro;
@@ -115,58 +97,8 @@ static PetscErrorCode MatMPIAIJHIPXBuildHalo(Mat A)
     PetscCallHIPX(hipxHaloCreate((int)ni, sr, so, si, (int)nr, rr, ro, &h->halo));
     PetscCall(PetscFree5(sr, so, si, rr, ro));
   }
-  /* Bring the transport up; a failure on ANY rank (RCCL bootstrap, hipIpcOpenMemHandle to a GPU this process cannot map, ...)
-     makes every rank fall back together: RCCL -> IPC peer stores -> the stock host PetscSF scatter (transport 0). */
-  for (;;) {
-    int ierr = 0, anyerr = 0;
-    if (transport == 2) {
-      if (!hipx_rccl_up) { /* ncclUniqueId of rank 0 travels over MPI */
-        char id[HIPX_COMM_ID_BYTES];
-        memset(id, 0, sizeof(id));
-        if (!rank) ierr = hipxCommGetUniqueId(id);
-        PetscCallMPI(MPI_Bcast(id, HIPX_COMM_ID_BYTES, MPI_BYTE, 0, comm));
-        if (!ierr && !hipx_ipc_comm_up) ierr = hipxCommInit(id, (int)rank, (int)size);
-        else if (hipx_ipc_comm_up) ierr = HIPX_ERR_ORDER;
-      }
-    } else {
-      char *mine, *all;
-      PetscCall(PetscMalloc2(HIPX_HALO_IPC_BLOB_BYTES, &mine, (size_t)HIPX_HALO_IPC_BLOB_BYTES * size, &all));
-      memset(mine, 0, HIPX_HALO_IPC_BLOB_BYTES);
-      ierr = hipxHaloIpcExport(h->halo, (int)rank, (int)size, mine);
-      PetscCallMPI(MPI_Allgather(mine, HIPX_HALO_IPC_BLOB_BYTES, MPI_BYTE, all, HIPX_HALO_IPC_BLOB_BYTES, MPI_BYTE, comm));
-      PetscCallMPI(MPI_Allreduce(&ierr, &anyerr, 1, MPI_INT, MPI_MAX, comm));
-      if (!anyerr) ierr = hipxHaloIpcAttach(h->halo, all);
-      PetscCall(PetscFree2(mine, all));
-      PetscCallMPI(MPI_Allreduce(&ierr, &anyerr, 1, MPI_INT, MPI_MAX, comm));
-      if (!anyerr && !hipx_rccl_up && !hipx_ipc_comm_up) { /* scalar all-reduces of the fused solver (cghipx) through the same IPC machinery */
-        char hmine[64], *hall;
-        PetscCall(PetscMalloc1((size_t)64 * size, &hall));
-        memset(hmine, 0, sizeof(hmine));
-        ierr = hipxCommIpcExport((int)rank, (int)size, hmine);
-        PetscCallMPI(MPI_Allgather(hmine, 64, MPI_BYTE, hall, 64, MPI_BYTE, comm));
-        PetscCallMPI(MPI_Allreduce(&ierr, &anyerr, 1, MPI_INT, MPI_MAX, comm));
-        if (!anyerr) ierr = hipxCommIpcAttach(hall);
-        PetscCall(PetscFree(hall));
-        PetscCallMPI(MPI_Allreduce(&ierr, &anyerr, 1, MPI_INT, MPI_MAX, comm));
-        if (!anyerr) hipx_ipc_comm_up = PETSC_TRUE;
-        else anyerr = 0; /* the ghost exchange itself is up; only cghipx's device all-reduce is not (it then reduces through MPI) */
-        ierr = 0;
-      }
-    }
-    PetscCallMPI(MPI_Allreduce(&ierr, &anyerr, 1, MPI_INT, MPI_MAX, comm));
-    if (!anyerr) {
-      if (transport == 2) hipx_rccl_up = PETSC_TRUE;
-      break;
-    }
-    PetscCall(PetscInfo(A, "MATMPIAIJHIPX: transport %s could not be brought up on every rank (code %d: %s)\n", transport == 2 ? "rccl" : "ipc", anyerr, ierr ? hipxGetErrorString() : "another rank failed"));
-    if (transport == 2 && !strcmp(want, "auto")) {
-      transport = 1;
-      continue;
-    }
-    PetscCallHIPX(hipxHaloDestroy(&h->halo)); /* back to the reference's own host scatter */
-    h->transport = 0;
-    PetscFunctionReturn(PETSC_SUCCESS);
-  }
+  PetscCall(HipxHaloBringUp(comm, (PetscObject)A, &h->halo, want, &transport));
+  if (!transport) PetscFunctionReturn(PETSC_SUCCESS); /* back to the reference's own host scatter */
   h->transport = transport;
   PetscCall(PetscInfo(A, "MATMPIAIJHIPX ghost exchange on the device: transport %s, %d send / %d receive neighbours\n", transport == 2 ? "rccl" : "ipc", (int)ni, (int)nr));
   PetscFunctionReturn(PETSC_SUCCESS);
@@ -188,7 +120,23 @@ static PetscErrorCode MatMultAdd_MPIAIJHIPX_Private(Mat A, Vec xx, Vec yy, Vec z
   PetscCall(MatSeqAIJHIPXGetDeviceMat(a->B, &dB));
   PetscCall(VecHIPXGetDeviceRead(xx, &x, &tx));
   PetscCall(VecHIPXGetDeviceWrite(a->lvec, &lv, &tl));
-  if (!yy) {
+  if (h->transport == 3) { /* mpiaij.c:1056-1059 / 1078-1081 with the scatter = PetscSF hipx on device buffers */
+    PetscCall(PetscSFBcastWithMemTypeBegin(a->Mvctx, MPIU_SCALAR, PETSC_MEMTYPE_HIP, x, PETSC_MEMTYPE_HIP, lv, MPI_REPLACE));
+    if (!yy) {
+      PetscCall(VecHIPXGetDeviceWrite(zz, &z, &tz));
+      PetscCallHIPX(hipxMatMult(dA, x, z));
+    } else if (zz == yy) {
+      PetscCall(VecHIPXGetDeviceReadWrite(zz, &z, &tz));
+      PetscCallHIPX(hipxMatMultAdd(dA, x, z, z));
+    } else {
+      PetscCall(VecHIPXGetDeviceRead(yy, &y, &ty));
+      PetscCall(VecHIPXGetDeviceWrite(zz, &z, &tz));
+      PetscCallHIPX(hipxMatMultAdd(dA, x, y, z));
+      PetscCall(VecHIPXRestoreDeviceRead(yy, &y, &ty));
+    }
+    PetscCall(PetscSFBcastEnd(a->Mvctx, MPIU_SCALAR, x, lv, MPI_REPLACE));
+    PetscCallHIPX(hipxMatMultAdd(dB, lv, z, z));
+  } else if (!yy) {
     PetscCall(VecHIPXGetDeviceWrite(zz, &z, &tz));
     PetscCallHIPX(hipxMatMultMPI(dA, dB, h->halo, x, lv, z));
   } else {
@@ -218,7 +166,7 @@ static PetscBool MatMPIAIJHIPXDevicePath(Mat A, Vec xx, Vec zz)
 {
   Mat_MPIAIJHIPX *h = (Mat_MPIAIJHIPX *)A->spptr;
   Mat_MPIAIJ     *a = (Mat_MPIAIJ *)A->data;
-  return (PetscBool)(h->transport && h->halo && h->nzstate == A->nonzerostate && a->A && a->B && MatIsSeqAIJHIPX(a->A) && MatIsSeqAIJHIPX(a->B) && a->lvec && VecIsHIPX(a->lvec) && VecIsHIPX(xx) && VecIsHIPX(zz));
+  return (PetscBool)(h->transport && (h->halo || h->transport == 3) && h->nzstate == A->nonzerostate && a->A && a->B && MatIsSeqAIJHIPX(a->A) && MatIsSeqAIJHIPX(a->B) && a->lvec && VecIsHIPX(a->lvec) && VecIsHIPX(xx) && VecIsHIPX(zz));
 }
 
 /* for KSPCGHIPX: the device pieces of an assembled MATMPIAIJHIPX whose ghost exchange runs on the device (NULL halo otherwise) */
@@ -230,7 +178,7 @@ PetscErrorCode MatMPIAIJHIPXGetDevice(Mat A, hipxMat *dA, hipxMat *dB, hipxHalo 
   PetscFunctionBegin;
   *halo = NULL;
   if (A->ops->mult == MatMult_MPIAIJHIPX && h->transport && h->halo && h->nzstate == A->nonzerostate && a->A && a->B && MatIsSeqAIJHIPX(a->A) && MatIsSeqAIJHIPX(a->B) && a->lvec && VecIsHIPX(a->lvec) &&
-      (hipx_rccl_up || hipx_ipc_comm_up)) {
+      HipxCommIsUp()) {
     PetscCall(MatSeqAIJHIPXGetDeviceMat(a->A, dA));
     PetscCall(MatSeqAIJHIPXGetDeviceMat(a->B, dB));
     *halo = h->halo;

@@ -5,6 +5,7 @@
  * (src/sys/dll/reg.c:79,150) or by calling the function directly after PetscInitialize() when the library is linked.
  */
 #include "hipxplugin.h"
+#include <petscsf.h>
 
 /* the entry symbol is derived from the file name; the MPICH flavour of the plugin is built as libpetschipx_mpich.so */
 #if !defined(HIPX_PLUGIN_REGISTER)
@@ -22,5 +23,7 @@ PETSC_EXTERN PetscErrorCode HIPX_PLUGIN_REGISTER(void)
   PetscCall(MatRegisterRootName(MATAIJHIPX, MATSEQAIJHIPX, MATMPIAIJHIPX)); /* -mat_type aijhipx resolves by communicator size, matreg.c:128-138 */
   PetscCall(PCRegister(PCJACOBIHIPX, PCCreate_JacobiHIPX));
   PetscCall(KSPRegister("cghipx", KSPCreate_CGHIPX));
+  PetscCall(PetscSFInitializePackage()); /* registers "basic", whose creator the hipx type builds on */
+  PetscCall(PetscSFRegister(PETSCSFHIPX, PetscSFCreate_HIPX));
   PetscFunctionReturn(PETSC_SUCCESS);
 }

@@ -34,6 +34,7 @@ PetscErrorCode VecHIPXInitRuntime(void)
     dev = ndev > 0 ? rank % ndev : 0;
   }
   PetscCallHIPX(hipxInit((int)dev));
+  PetscCall(PetscOptionsGetBool(NULL, NULL, "-vec_hipx_memtype", &hipx_vec_memtype_ops, NULL));
   hipx_runtime_up = PETSC_TRUE;
   PetscFunctionReturn(PETSC_SUCCESS);
 }
@@ -215,6 +216,62 @@ static PetscErrorCode VecRestoreArrayRead_HIPX(Vec v, const PetscScalar **a)
 {
   (void)v;
   (void)a;
+  return PETSC_SUCCESS;
+}
+
+/* VecGetArray*AndMemType (rvector.c:2290-2560): the device mirror with PETSC_MEMTYPE_HIP.  Installed only with -vec_hipx_memtype:
+   a host-only libpetsc gives device pointers to whatever PetscSF the caller uses (vscat.c:41-60), and only the PetscSF type "hipx"
+   (sfhipx.c) knows what to do with them -- run with -sf_type hipx. */
+PetscBool hipx_vec_memtype_ops = PETSC_FALSE;
+
+static PetscErrorCode VecGetArrayAndMemType_HIPX(Vec v, PetscScalar **a, PetscMemType *m)
+{
+  PetscFunctionBegin;
+  PetscCall(VecHIPXCopyToDevice(v));
+  *a             = VecHIPXGetExt(v)->d_array;
+  v->offloadmask = PETSC_OFFLOAD_GPU; /* the caller may write on the device */
+  if (m) *m = PETSC_MEMTYPE_HIP;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecGetArrayReadAndMemType_HIPX(Vec v, const PetscScalar **a, PetscMemType *m)
+{
+  PetscFunctionBegin;
+  PetscCall(VecHIPXCopyToDevice(v));
+  *a = VecHIPXGetExt(v)->d_array;
+  if (m) *m = PETSC_MEMTYPE_HIP;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecGetArrayWriteAndMemType_HIPX(Vec v, PetscScalar **a, PetscMemType *m)
+{
+  PetscFunctionBegin;
+  PetscCall(VecHIPXAllocate(v));
+  *a             = VecHIPXGetExt(v)->d_array;
+  v->offloadmask = PETSC_OFFLOAD_GPU;
+  if (m) *m = PETSC_MEMTYPE_HIP;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode VecRestoreArrayAndMemType_HIPX(Vec v, PetscScalar **a)
+{
+  (void)v;
+  (void)a;
+  return PETSC_SUCCESS;
+}
+
+static PetscErrorCode VecRestoreArrayReadAndMemType_HIPX(Vec v, const PetscScalar **a)
+{
+  (void)v;
+  (void)a;
+  return PETSC_SUCCESS;
+}
+
+static PetscErrorCode VecRestoreArrayWriteAndMemType_HIPX(Vec v, PetscScalar **a, PetscMemType *m)
+{
+  (void)v;
+  (void)a;
+  (void)m;
   return PETSC_SUCCESS;
 }
 
@@ -798,6 +855,14 @@ static void VecHIPXInstallLocalOps(Vec v)
   o->mdot_local       = VecMDotLocal_HIPX;
   o->mtdot_local      = VecMDotLocal_HIPX;
   o->norm_local       = VecNormLocal_HIPX;
+  if (hipx_vec_memtype_ops) {
+    o->getarrayandmemtype          = VecGetArrayAndMemType_HIPX;
+    o->restorearrayandmemtype      = VecRestoreArrayAndMemType_HIPX;
+    o->getarrayreadandmemtype      = VecGetArrayReadAndMemType_HIPX;
+    o->restorearrayreadandmemtype  = VecRestoreArrayReadAndMemType_HIPX;
+    o->getarraywriteandmemtype     = VecGetArrayWriteAndMemType_HIPX;
+    o->restorearraywriteandmemtype = VecRestoreArrayWriteAndMemType_HIPX;
+  }
 }
 
 PetscErrorCode VecCreate_SeqHIPX(Vec v)
