@@ -198,6 +198,10 @@ int hipxMatMultDotBegin(hipxMat A, const double *x, double *y, int slot, double 
 /* PCSetUp_Jacobi jacobi.c:205-266 (DIAGONAL, fixdiag): d = 1/diag(A), zeros -> 1 */
 int hipxPCJacobiSetUp(hipxMat A, double *dinv);
 
+/* replaces PCApply_PBJacobi / PCApplyTranspose_PBJacobi pbjacobi.c:4-124,126-241: y_i = D_i^{-1} x_i, diag = mbs inverted bs x bs blocks,
+   column-major (what MatInvertBlockDiagonal leaves), all device pointers */
+int hipxPCPBJacobiApply(const double *diag, hipx_int bs, hipx_int mbs, const double *x, double *y, int transpose);
+
 /* ---- multi-GPU: MPIAIJ ghost exchange (replaces VecScatterBegin/End vscat.c:1294,1353 on this path
         and PetscSFBcast{Begin,End}_Basic sfbasic.c:352-390) and scalar all-reduces
         (VecXDot_MPI_Default pvecimpl.h:105-111, VecNorm_MPI_Default pvecimpl.h:150-175) ------------- */

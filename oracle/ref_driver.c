@@ -255,6 +255,11 @@ int main(int argc, char **argv)
   PetscCall(MatCreate(PETSC_COMM_WORLD, &A));
   PetscCall(MatSetSizes(A, PETSC_DECIDE, PETSC_DECIDE, N, N));
   PetscCall(MatSetFromOptions(A));
+  {
+    PetscInt bs = 1; /* -mat_block_size b: the operator declared with point blocks of b rows (PCPBJACOBI inverts the b x b diagonal blocks) */
+    PetscCall(PetscOptionsGetInt(NULL, NULL, "-mat_block_size", &bs, NULL));
+    if (bs > 1) PetscCall(MatSetBlockSize(A, bs));
+  }
   PetscCall(MatSeqAIJSetPreallocation(A, stencil, NULL));
   PetscCall(MatMPIAIJSetPreallocation(A, stencil, NULL, stencil, NULL));
   PetscCall(MatGetOwnershipRange(A, &Istart, &Iend));
@@ -359,6 +364,27 @@ int main(int argc, char **argv)
   PetscCall(KSPCreate(PETSC_COMM_WORLD, &ksp));
   PetscCall(KSPSetOperators(ksp, A, A));
   PetscCall(KSPSetFromOptions(ksp));
+  {
+    PetscBool dump_pc = PETSC_FALSE; /* -dump_pc: z = PCApply(b) and z' = PCApplyTranspose(b), every entry with 17 digits */
+    PetscCall(PetscOptionsGetBool(NULL, NULL, "-dump_pc", &dump_pc, NULL));
+    if (dump_pc) {
+      PC                 pc;
+      Vec                z;
+      const PetscScalar *za;
+      PetscCall(KSPSetUp(ksp));
+      PetscCall(KSPGetPC(ksp, &pc));
+      PetscCall(VecDuplicate(b, &z));
+      for (int tr = 0; tr < 2; tr++) {
+        if (tr) PetscCall(PCApplyTranspose(pc, b, z));
+        else PetscCall(PCApply(pc, b, z));
+        PetscCall(VecGetArrayRead(z, &za));
+        for (PetscInt i = 0; i < Iend - Istart; i++) PetscCall(PetscSynchronizedPrintf(PETSC_COMM_WORLD, "%s %" PetscInt_FMT " %.17g\n", tr ? "zt" : "z", i + Istart, (double)za[i]));
+        PetscCall(PetscSynchronizedFlush(PETSC_COMM_WORLD, PETSC_STDOUT));
+        PetscCall(VecRestoreArrayRead(z, &za));
+      }
+      PetscCall(VecDestroy(&z));
+    }
+  }
   if (history) {
     PetscCall(PetscMalloc1(100000, &hist));
     PetscCall(KSPSetResidualHistory(ksp, hist, 100000, PETSC_TRUE));

@@ -81,6 +81,8 @@ struct hipxMat_s {
   int       probe      = 0;   // phase-attribution probe kernels (scripts/spmv_variants.py); results are NOT A x
   std::vector<int64_t> h_i;  // host copy of the row offsets (set-up only)
   void     *sor_state = nullptr;  // hipxSorState, owned by hipx_sor.hip
+  void     *sell_state = nullptr; // SellState, owned by hipx_sell.hip (variant 28: sliced-ELLPACK copy)
+  int       sell_mode  = 0;
   unsigned long long value_state = 1;
   // compressed rows (off-diagonal block of MPIAIJ): logical rows = nrows_c, y index = ridx[row]
   bool      compressed = false;
@@ -95,6 +97,12 @@ struct hipxMat_s {
 };
 
 extern "C" void hipxSorStateFree_(void *p);
+extern "C" void     hipxSellFree_(void *p);
+extern "C" void     hipxSellValuesChanged_(void *p);
+extern "C" void     hipxSellInvalidate_(void *p);
+extern "C" int      hipxSellEnsure_(hipxMat A, void **slot, int *ok, int *packed, double *pad_ratio, int64_t *bytes);
+extern "C" hipx_int hipxSellDotPartials_(void *p);
+extern "C" int      hipxSellLaunch_(void *p, int mode, int dot, const double *x, const double *yin, double *yout, double *dotpart);
 extern "C" void hipxSorInvalidate_(void *p);
 
 namespace {
@@ -975,7 +983,9 @@ __global__ __launch_bounds__(256) void tmpl_verify_kernel(hipx_int m, hipx_int n
 // (interior), and the LDS reads of the template entries broadcast.
 // PROBE != 0: developer timing probes (HIPX_TMPL_PROBE, WRONG RESULTS by construction; scripts/spmv_variants.py): 1 = y is not stored;
 // 2 = every gather of a row reads x[row + k] (k = entry index: the row's own cache lines -- no far lines at all); 3 = far offsets
-// folded into +-4096 doubles of the row (same number of distinct lines per gather, all of them recently touched: no far-plane HBM stream)
+// folded into +-4096 doubles of the row (same number of distinct lines per gather, all of them recently touched: no far-plane HBM stream);
+// 4 = correct results, but the chunks are assigned statically (round robin over the XCD's workgroups): no ticket atomics, no barriers;
+// 5 = 4 without the first-touch prefetch; 6 = 5 without the template-id loads (id 0 everywhere: wrong rows at the boundaries)
 template <int MODE, bool DOT, int RPT, int W, bool UNI, int PROBE = 0>
 __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const int *__restrict__ tstart,
                                                         const int *__restrict__ toff, const double *__restrict__ tval, int ntmpl, int nent, const double *__restrict__ x,
@@ -1007,12 +1017,15 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
   // the current chunk computes): every workgroup takes exactly two tickets beyond the end of its XCD's slab
   const long long     tbase = (long long)(launch * (unsigned long long)(nloc + 2 * bpx));
   __shared__ long long s_tk2[2];
-  if (t == 0) {
-    s_tk2[0] = (long long)atomicAdd(ctr, 1ull) - tbase;
-    s_tk2[1] = (long long)atomicAdd(ctr, 1ull) - tbase;
+  constexpr bool STATICQ = PROBE >= 4;
+  if (!STATICQ) {
+    if (t == 0) {
+      s_tk2[0] = (long long)atomicAdd(ctr, 1ull) - tbase;
+      s_tk2[1] = (long long)atomicAdd(ctr, 1ull) - tbase;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  long long tk = s_tk2[0], tk1 = s_tk2[1];
+  long long tk = STATICQ ? (long long)(bid >> 3) : s_tk2[0], tk1 = STATICQ ? (long long)(bid >> 3) + bpx : s_tk2[1];
   // First-touch prefetch.  Of the gathers of a row only ONE stream misses the L2: the farthest forward offset (+n^2 for a 3-D
   // stencil: the plane nobody has touched yet); everything else was fetched one or two planes ago.  With ~1/7 of the loads
   // going to HBM the chip holds too few bytes in flight (measured 2-3 TB/s).  So the first 16*RPT lanes of a workgroup touch
@@ -1025,11 +1038,11 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
 #pragma unroll
   for (int rr = 0; rr < RPT; rr++) {
     const long long row = (tk < nloc) ? ((long long)(c0 + tk) * (256 * RPT) + t + rr * 256) : (long long)m;
-    idn[rr]             = (row < m) ? tid[row] : 0;
+    idn[rr]             = (row < m && PROBE != 6) ? tid[row] : 0;
   }
   while (tk < nloc) {
     long long nxt = 0;
-    if (t == 0) nxt = (long long)atomicAdd(ctr, 1ull) - tbase;  // the ticket after next travels while this chunk is processed
+    if (!STATICQ && t == 0) nxt = (long long)atomicAdd(ctr, 1ull) - tbase;  // the ticket after next travels while this chunk is processed
     const hipx_int c    = c0 + (hipx_int)tk;
     const hipx_int base = c * (256 * RPT);
     int            id[RPT];
@@ -1049,7 +1062,7 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
 #pragma unroll
     for (int rr = 0; rr < RPT; rr++) {  // issue the next chunk's id loads now; they are consumed at the top of the next pass
       const long long row = (tk1 < nloc) ? ((long long)(c0 + tk1) * (256 * RPT) + t + rr * 256) : (long long)m;
-      idn[rr]             = (row < m) ? tid[row] : 0;
+      idn[rr]             = (row < m && PROBE != 6) ? tid[row] : 0;
     }
     int id0 = 0;
     if (UNI) {
@@ -1146,15 +1159,20 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
       if ((threadIdx.x & 63) == 0) dotpart[(size_t)c * 4 + (threadIdx.x >> 6)] = w;
     }
     sink += (__double_as_longlong(pf) == 0x7ff8123456789abcLL) ? 1u : 0u;  // consume the previous pass's prefetch (no wait: see above)
-    if (pf_off && t < 16 * RPT) {
+    if (PROBE < 5 && pf_off && t < 16 * RPT) {
       const long long prow = (long long)base + pf_off + (long long)t * 16;  // pf_off = farthest forward offset + the look-ahead distance
       if (prow < (long long)m) pf = x[prow];
     }
-    __syncthreads();  // everybody has read the tickets
-    if (t == 0) s_tk = nxt;
-    __syncthreads();
-    tk  = tk1;
-    tk1 = s_tk;
+    if (STATICQ) {
+      tk  = tk1;
+      tk1 = tk1 + bpx;
+    } else {
+      __syncthreads();  // everybody has read the tickets
+      if (t == 0) s_tk = nxt;
+      __syncthreads();
+      tk  = tk1;
+      tk1 = s_tk;
+    }
   }
   (void)mydot;
   if (sink == 0xffffffffu) yout[0] = pf;  // never true: keeps the prefetch loads alive
@@ -1754,13 +1772,16 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
   case 2: HIPX_TMPL_LAUNCH(4, 4, true); break;
   default: {
     static const int probe = getenv("HIPX_TMPL_PROBE") ? atoi(getenv("HIPX_TMPL_PROBE")) : 0;
-    if (probe >= 1 && probe <= 3) {
+    if (probe >= 1 && probe <= 6) {
 #define HIPX_TMPL_LAUNCH_P(PR) \
   spmv_tmpl_kernel<MODE, DOT, 2, 2, true, PR><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout, \
                                                                                            dotpart, A->d_tq, launch, pf_off)
       if (probe == 1) HIPX_TMPL_LAUNCH_P(1);
       else if (probe == 2) HIPX_TMPL_LAUNCH_P(2);
-      else HIPX_TMPL_LAUNCH_P(3);
+      else if (probe == 3) HIPX_TMPL_LAUNCH_P(3);
+      else if (probe == 4) HIPX_TMPL_LAUNCH_P(4);
+      else if (probe == 5) HIPX_TMPL_LAUNCH_P(5);
+      else HIPX_TMPL_LAUNCH_P(6);
 #undef HIPX_TMPL_LAUNCH_P
     } else HIPX_TMPL_LAUNCH(2, 2, true);
     break;
@@ -1844,9 +1865,29 @@ int launch_pk16(hipxMat A, const double *x, const double *yin, double *yout, dou
   return HIPX_SUCCESS;
 }
 
+// variant 28: the SELL-64 copy (hipx_sell.hip) when it applies; *use = false -> the CSR kernels
+int use_sell(hipxMat A, bool &use)
+{
+  use = false;
+  if (!A->sell_mode || A->compressed || A->probe) return HIPX_SUCCESS;
+  int     ok = 0, packed = 0;
+  double  pad = 0.0;
+  int64_t bytes = 0;
+  int     ierr = hipxSellEnsure_(A, &A->sell_state, &ok, &packed, &pad, &bytes);
+  if (ierr) return ierr;
+  use = ok != 0;
+  return HIPX_SUCCESS;
+}
+
 template <typename IT, int MODE, bool DOT>
 int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
 {
+  {
+    bool sl = false;
+    int  ierr = use_sell(A, sl);
+    if (ierr) return ierr;
+    if (sl) return hipxSellLaunch_(A->sell_state, MODE, DOT ? 1 : 0, x, yin, yout, dotpart);
+  }
   {
     bool tm = false;
     int  ierr = use_templates(A, tm);
@@ -1877,6 +1918,15 @@ int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, d
 int dot_partials_count(hipxMat A, hipx_int *npart)
 {
   int cfg, waves;
+  {
+    bool sl = false;
+    int  ierr = use_sell(A, sl);
+    if (ierr) return ierr;
+    if (sl) {
+      *npart = hipxSellDotPartials_(A->sell_state);
+      return HIPX_SUCCESS;
+    }
+  }
   {
     bool tm = false;
     int  ierr = use_templates(A, tm);
@@ -1941,6 +1991,7 @@ void values_changed(hipxMat A)
   A->tmpl_ready = false;
   A->value_state++;
   hipxSorInvalidate_(A->sor_state);
+  hipxSellValuesChanged_(A->sell_state);
 }
 }  // namespace
 
@@ -2002,6 +2053,7 @@ int hipxMatUpdateValues(hipxMat A, const double *a)
   A->tmpl_ready = false;  // ... and so are the row templates
   A->value_state++;  // SOR's level-ordered copy and inverse diagonal must be rebuilt (aij.c:1807 idiagState)
   hipxSorInvalidate_(A->sor_state);
+  hipxSellValuesChanged_(A->sell_state);
   return HIPX_SUCCESS;
 }
 
@@ -2069,6 +2121,7 @@ int hipxMatDestroy(hipxMat *pA)
   (void)hipFree(A->d_vdict);
   free_templates(A);
   hipxSorStateFree_(A->sor_state);
+  hipxSellFree_(A->sell_state);
   delete A;
   *pA = nullptr;
   return HIPX_SUCCESS;
@@ -2138,6 +2191,11 @@ int hipxMatSetSpMVVariant(hipxMat A, int variant)
   A->tile_mode = (variant == 22 || variant == 24) ? 2 : (variant == 23 || variant == 25 || variant == 26) ? 3 : 0;
   A->vd_mode   = (variant == 24 || variant == 25 || variant == 26) ? 1 : 0;
   A->tmpl_mode = (variant == 26) ? 1 : 0;
+  A->sell_mode = (variant == 28) ? 1 : 0;  // 28: SELL-64 copy (hipx_sell.hip); falls back to 23 when the format does not apply
+  if (variant == 28) {
+    A->tile_mode = 3;
+    variant      = 23;
+  }
   A->auto_sel = (variant == 0);
   if (variant == 0) {
     A->tile_mode = auto_tile_mode(A);
@@ -2168,7 +2226,13 @@ int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
     int ierr = use_templates(A, tm);
     if (ierr) return ierr;
   }
-  if (tm) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row)";
+  bool sl = false;
+  {
+    int ierr = use_sell(A, sl);
+    if (ierr) return ierr;
+  }
+  if (sl) name = "spmv_sell_kernel (MatMult on the SELL-64 copy: one lane per row, 16-bit window-coded columns)";
+  else if (tm) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row)";
   else if (A->tile_mode >= 2 && !A->compressed && !A->probe) {
     bool vd, rowpar;
     int  rpt, cfg;
@@ -2347,6 +2411,7 @@ int hipxMatSetValuesCOO(hipxMat A, hipxCOO c, const double *v, int64_t n, int v_
   A->tmpl_ready = false;
   A->value_state++;
   hipxSorInvalidate_(A->sor_state);
+  hipxSellValuesChanged_(A->sell_state);
   return HIPX_SUCCESS;
 }
 

@@ -62,6 +62,7 @@ PETSC_INTERN PetscErrorCode VecCreate_HIPX(Vec);
 PETSC_INTERN PetscErrorCode MatCreate_SeqAIJHIPX(Mat);
 PETSC_INTERN PetscErrorCode MatCreate_MPIAIJHIPX(Mat);
 PETSC_INTERN PetscErrorCode PCCreate_JacobiHIPX(PC);
+PETSC_INTERN PetscErrorCode PCCreate_PBJacobiHIPX(PC); /* "pbjacobihipx": PCPBJACOBI with the apply on the device */
 PETSC_INTERN PetscErrorCode KSPCreate_CGHIPX(KSP); /* "cghipx": KSPCG with the fused device kernels on the hot-path configuration */
 PETSC_INTERN PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA); /* uploads / refreshes the device CSR */
 PETSC_INTERN PetscBool      MatIsSeqAIJHIPX(Mat A);

@@ -22,6 +22,7 @@ PETSC_EXTERN PetscErrorCode HIPX_PLUGIN_REGISTER(void)
   PetscCall(MatRegister(MATMPIAIJHIPX, MatCreate_MPIAIJHIPX));
   PetscCall(MatRegisterRootName(MATAIJHIPX, MATSEQAIJHIPX, MATMPIAIJHIPX)); /* -mat_type aijhipx resolves by communicator size, matreg.c:128-138 */
   PetscCall(PCRegister(PCJACOBIHIPX, PCCreate_JacobiHIPX));
+  PetscCall(PCRegister("pbjacobihipx", PCCreate_PBJacobiHIPX));
   PetscCall(KSPRegister("cghipx", KSPCreate_CGHIPX));
   PetscCall(PetscSFInitializePackage()); /* registers "basic", whose creator the hipx type builds on */
   PetscCall(PetscSFRegister(PETSCSFHIPX, PetscSFCreate_HIPX));

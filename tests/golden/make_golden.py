@@ -67,8 +67,8 @@ KATS = [
     # the reference's PetscSF tests with the PetscSF type hipx (sfhipx.c).  ex1 / ex4: host buffers -> the parent's path
     # under the new type; ex2 is the reference's own device test (a VecScatter out of a device vector): -vec_hipx_memtype hands the
     # SF the device mirror, the type hipx runs it on the device
-    ("sf_ex1_basic_1", "kat_sf_ex1", "-user_sf_type hipx -sf_type hipx", "notype", "vec/is/sf/tests/output/ex1_basic_1.out"),
-    ("sf_ex4_1", "kat_sf_ex4", "-sf_type hipx", "notype", "vec/is/sf/tests/output/ex4_1.out"),
+    ("sf_ex1_basic_1", "kat_sf_ex1", "-user_sf_type hipx -sf_type hipx -options_left no", "notype", "vec/is/sf/tests/output/ex1_basic_1.out"),
+    ("sf_ex4_1", "kat_sf_ex4", "-sf_type hipx -options_left no", "notype", "vec/is/sf/tests/output/ex4_1.out"),
     ("sf_ex2_device", "kat_sf_ex2", "-vec_hipx_memtype -sf_type hipx", "none", "vec/is/sf/tests/output/ex2_1.out"),
 ] + [("mat_ex123_1_%s_l%d_n%d" % (mt, la, ng), "kat_mat_ex123", "-mat_type %s -localapi %d -neg %d -options_left no" % (mt, la, ng), "ex123", "mat/tests/output/ex123_1.out")
      for mt in ("seqaij", "mpiaij") for la in (0, 1) for ng in (0, 1)]
@@ -86,8 +86,8 @@ KATS_MPI = [
     ("mat_ex5_23", "kat_mat_ex5", 3, "-mat_type mpiaij", "notype", "mat/tests/output/ex5_23.out"),
     ("mat_ex5_33", "kat_mat_ex5", 3, "-mat_type mpiaij -test_diagonalscale", "notype", "mat/tests/output/ex5_33.out"),
     ("ksp_ex2_2", "ex2", 2, "-ksp_monitor -m 5 -n 5 -ksp_gmres_cgs_refinement_type refine_always", "monitor", "ksp/ksp/tutorials/output/ex2_2.out"),
-    ("sf_ex1_basic_2", "kat_sf_ex1", 2, "-user_sf_type hipx -sf_type hipx", "type", "vec/is/sf/tests/output/ex1_basic_2.out"),
-    ("sf_ex1_basic_3", "kat_sf_ex1", 3, "-user_sf_type hipx -sf_type hipx", "type", "vec/is/sf/tests/output/ex1_basic_3.out"),
+    ("sf_ex1_basic_2", "kat_sf_ex1", 2, "-user_sf_type hipx -sf_type hipx -options_left no", "type", "vec/is/sf/tests/output/ex1_basic_2.out"),
+    ("sf_ex1_basic_3", "kat_sf_ex1", 3, "-user_sf_type hipx -sf_type hipx -options_left no", "type", "vec/is/sf/tests/output/ex1_basic_3.out"),
 ] + [("mat_ex123_3_l%d_n%d" % (la, ng), "kat_mat_ex123", 3, "-mat_type mpiaij -loc -localapi %d -neg %d -options_left no" % (la, ng), "ex123", "mat/tests/output/ex123_3.out") for la in (0, 1) for ng in (0, 1)]
 
 

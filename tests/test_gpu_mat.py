@@ -37,7 +37,7 @@ def spmv_gpu(hx, ai, aj, aa, x, ncols=None, variant=0, y0=None):
 
 @pytest.mark.parametrize("kind,n,m", [("5pt", 100, 100), ("5pt", 7, 8), ("7pt", 1, None), ("7pt", 2, None), ("7pt", 33, None), ("7pt", 64, None),
                                        ("27pt", 3, None), ("27pt", 17, None), ("27pt", 40, None)])
-@pytest.mark.parametrize("variant", [1, 2, 3, 22, 23, 24, 25, 26, 101])
+@pytest.mark.parametrize("variant", [1, 2, 3, 22, 23, 24, 25, 26, 28, 101])
 def test_stencil_spmv_bit_exact(hx, kind, n, m, variant):
     ai, aj, aa = orc.stencil(kind, n, m=m)
     N = len(ai) - 1
@@ -61,7 +61,7 @@ def random_csr(m, n, rng, maxlen, empty_frac=0.2):
 
 
 @pytest.mark.parametrize("seed,m,n,maxlen", [(0, 1, 1, 1), (1, 17, 29, 5), (2, 1000, 777, 40), (3, 5000, 5000, 8), (4, 300, 4000, 300), (5, 257, 100, 0), (7, 2000, 9000, 160)])
-@pytest.mark.parametrize("variant", [1, 22, 23, 24, 25, 26])
+@pytest.mark.parametrize("variant", [1, 22, 23, 24, 25, 26, 28])
 def test_ragged_rows_bit_exact_and_multadd(hx, seed, m, n, maxlen, variant):
     rng = np.random.default_rng(seed)
     ai, aj, aa = random_csr(m, n, rng, maxlen)
@@ -342,3 +342,80 @@ def test_full_size_7pt_256_properties(hx):
     for v in (X, Y, W):
         v.free()
     _lib.mat_destroy(A)
+
+
+def test_sell_copy_selection_padding_limit_fused_dot_and_value_update(hx):
+    """variant 28 (hipx_sell.hip): the SELL-64 copy is used when its padding stays below the limit, with 16-bit
+    window-coded columns when every slice fits 16 windows of 4096 columns (else 32-bit columns); very ragged matrices keep the CSR
+    kernels; the fused x . (A x) and hipxMatUpdateValues go through the copy; -0.0 row sums keep their sign (padding is never
+    multiplied)."""
+    from petsc_amd import _lib
+    rng = np.random.default_rng(11)
+    # (1) FEM-like long rows, all values distinct: packed SELL
+    n, per = 6000, 60
+    ai = np.arange(0, (n + 1) * per, per, dtype=np.int32)
+    aj = np.sort((np.arange(n)[:, None] + rng.integers(-400, 400, size=(n, per))) % n, axis=1).astype(np.int32)
+    for r in range(n):  # distinct columns per row
+        while len(np.unique(aj[r])) < per:
+            aj[r] = np.sort(np.unique(np.concatenate([aj[r], rng.integers(0, n, per)]))[:per])
+    aj = aj.ravel()
+    aa = rng.standard_normal(ai[-1])
+    x = rng.standard_normal(n)
+    A = _lib.mat_create_csr(n, n, ai, aj, aa)
+    _lib.chk(hx.hipxMatSetSpMVVariant(A, 28))
+    assert kernel_name(hx, A).startswith("spmv_sell_kernel "), kernel_name(hx, A)
+    X, Y = _lib.DVec(n, x), _lib.DVec(n)
+    _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    yr = orc.matmult(ai, aj, aa, x)
+    assert np.array_equal(Y.get(), yr)
+    d = C.c_double()
+    _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(d)))  # fused dot: one partial per slice, folded in slice order
+    assert np.array_equal(Y.get(), yr) and abs(d.value - float(x @ yr)) <= 1e-12 * abs(float(np.abs(x) @ np.abs(yr)))
+    d2 = C.c_double()
+    _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(d2)))
+    assert d2.value == d.value  # deterministic
+    aa2 = rng.standard_normal(ai[-1])
+    _lib.chk(hx.hipxMatUpdateValues(A, orc.P(aa2)))
+    _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    assert np.array_equal(Y.get(), orc.matmult(ai, aj, aa2, x))
+    _lib.mat_destroy(A)
+    # (2) columns spread over the whole matrix: more than 16 windows per slice -> 32-bit columns, same bits
+    n2 = 300000
+    ai2, aj2, aa2 = random_csr(2000, n2, rng, 30, empty_frac=0.0)
+    ai2[1:] = np.cumsum(np.full(2000, 30))  # random_csr may have produced shorter rows: rebuild exactly 30 per row
+    aj2 = np.sort(rng.integers(0, n2, size=(2000, 30)), axis=1).astype(np.int32).ravel()
+    aa2 = rng.standard_normal(2000 * 30)
+    x2 = rng.standard_normal(n2)
+    A2 = _lib.mat_create_csr(2000, n2, ai2, aj2, aa2)
+    _lib.chk(hx.hipxMatSetSpMVVariant(A2, 28))
+    assert kernel_name(hx, A2).startswith("spmv_sell_kernel ")
+    X2, Y2 = _lib.DVec(n2, x2), _lib.DVec(2000)
+    _lib.chk(hx.hipxMatMult(A2, X2.ptr, Y2.ptr))
+    assert np.array_equal(Y2.get(), orc.matmult(ai2, aj2, aa2, x2))
+    _lib.mat_destroy(A2)
+    # (3) one long row among empty ones: padding far above the limit -> the CSR kernel stays
+    ai3 = np.zeros(513, np.int32)
+    ai3[7:] = 200
+    aj3 = np.arange(200, dtype=np.int32)
+    aa3 = rng.standard_normal(200)
+    A3 = _lib.mat_create_csr(512, 512, ai3, aj3, aa3)
+    _lib.chk(hx.hipxMatSetSpMVVariant(A3, 28))
+    assert not kernel_name(hx, A3).startswith("spmv_sell_kernel")
+    X3, Y3 = _lib.DVec(512, x[:512]), _lib.DVec(512)
+    _lib.chk(hx.hipxMatMult(A3, X3.ptr, Y3.ptr))
+    assert np.array_equal(Y3.get(), orc.matmult(ai3, aj3, aa3, x[:512]))
+    _lib.mat_destroy(A3)
+    # (4) signed zeros: a row of -0.0 products sums to -0.0 (no +0.0 padding term may enter the sum)
+    ai4 = np.array([0, 2, 3] + [3 + 5 * k for k in range(1, 63)], np.int32)
+    aj4 = np.concatenate([[0, 1], [2], np.tile(np.arange(5), 62)]).astype(np.int32)
+    aa4 = np.concatenate([[-0.0, -0.0], [1.0], rng.standard_normal(5 * 62)])
+    x4 = np.abs(rng.standard_normal(64)) + 1.0
+    A4 = _lib.mat_create_csr(64, 64, ai4, aj4, aa4)
+    _lib.chk(hx.hipxMatSetSpMVVariant(A4, 28))
+    X4, Y4 = _lib.DVec(64, x4), _lib.DVec(64)
+    _lib.chk(hx.hipxMatMult(A4, X4.ptr, Y4.ptr))
+    y4, y4r = Y4.get(), orc.matmult(ai4, aj4, aa4, x4)
+    assert np.array_equal(y4, y4r) and np.array_equal(np.signbit(y4), np.signbit(y4r))
+    _lib.mat_destroy(A4)
+    for v in (X, Y, X2, Y2, X3, Y3, X4, Y4):
+        v.free()

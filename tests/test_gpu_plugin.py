@@ -181,3 +181,19 @@ def test_pc_eisenstat_on_hipx_types():
     ig = re.search(r"iterations (\d+) reason (-?\d+) error (\S+)", g)
     assert ic.group(1, 2) == ig.group(1, 2) and len(hc) == len(hg) > 5
     assert (np.abs(hc - hg) / hc).max() <= 1e-9
+
+
+@pytest.mark.parametrize("bs,n", [(2, 8), (3, 9), (4, 8), (8, 8)])
+def test_pbjacobi_apply_on_device_bit_exact(bs, n):
+    """-pc_type pbjacobihipx = PCPBJACOBI (host set-up: MatInvertBlockDiagonal) with PCApply / PCApplyTranspose as one
+    device kernel (pbjacobi.c:4-124,126-241: column-major inverted blocks, products added left to right): z = PCApply(b) and
+    z' = PCApplyTranspose(b) bit-identical to the CPU types' PCPBJACOBI, and the preconditioned solve follows it."""
+    a = ("-stencil 27 -n %d -mat_block_size %d -dump_pc -ksp_type gmres -ksp_rtol 1e-8 -history" % (n, bs)).split()
+    cpu = run("ref_driver", a + ["-pc_type", "pbjacobi"])
+    gpu = run("ref_driver", a + HIPX + ["-pc_type", "pbjacobihipx"])
+    for tag in ("z ", "zt "):
+        zc = [l for l in cpu.splitlines() if l.startswith(tag)]
+        zg = [l for l in gpu.splitlines() if l.startswith(tag)]
+        assert zc == zg and len(zc) == n ** 3
+    hc, hg = hist_of(cpu), hist_of(gpu)
+    assert len(hc) == len(hg) > 3 and np.abs(hc - hg).max() <= 1e-10 * hc[0]

@@ -215,7 +215,7 @@ def test_config4_surrogate_full_vector_bit_exact(hx):
     A = _lib.mat_create_csr(N, N, ai, aj, aa)
     X, Y = _lib.DVec(N, x), _lib.DVec(N)
     kn = C.create_string_buffer(256)
-    for variant in (0, 22, 23, 1):
+    for variant in (0, 22, 23, 28, 1):
         _lib.chk(hx.hipxMatSetSpMVVariant(A, variant))
         _lib.chk(hx.hipxMatGetSpMVKernel(A, kn, 256))
         assert b"dictionary" not in kn.value and b"tmpl" not in kn.value
