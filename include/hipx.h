@@ -160,6 +160,9 @@ int hipxMatGetValues(hipxMat A, double *a_host);              /* the value array
    ((a * l_i) * r_j: left pass first; l, r device pointers of length m / n, either may be NULL). */
 int hipxMatScale(hipxMat A, double alpha);
 int hipxMatZeroEntries(hipxMat A);
+/* replaces MatAXPY_SeqAIJ with SAME_NONZERO_PATTERN aij.c:2926-2945: Y.a += alpha X.a on the device copies (daxpy over the value
+   arrays: product and sum rounded separately).  The caller guarantees identical patterns (sizes and nonzero counts are checked). */
+int hipxMatAXPY(hipxMat Y, double alpha, hipxMat X);
 int hipxMatDiagonalScale(hipxMat A, const double *l, const double *r);
 /* COO assembly on the device.  replaces MatSetValuesCOO_SeqAIJ aij.c:4710-4733; jmap (nz + 1) / perm (ntot) are the maps
    MatSetPreallocationCOO_SeqAIJ leaves in MatCOOStruct_SeqAIJ (aij.c:4524-4707, aij.h:170-176): entry k of the CSR value array

@@ -329,6 +329,26 @@ int main(int argc, char **argv)
       PetscCall(VecDestroy(&r));
     }
   }
+  {
+    PetscBool axpy = PETSC_FALSE; /* -mat_axpy: A <- A + 0.37 C with C = a non-uniformly scaled copy of A (same nonzero pattern): MatAXPY_SeqAIJ aij.c:2926 */
+    PetscCall(PetscOptionsGetBool(NULL, NULL, "-mat_axpy", &axpy, NULL));
+    if (axpy) {
+      Mat          C;
+      Vec          l;
+      PetscScalar *la;
+      PetscInt     rs, re;
+      PetscCall(MatDuplicate(A, MAT_COPY_VALUES, &C));
+      PetscCall(MatCreateVecs(C, NULL, &l));
+      PetscCall(VecGetOwnershipRange(l, &rs, &re));
+      PetscCall(VecGetArrayWrite(l, &la));
+      for (PetscInt i = rs; i < re; i++) la[i - rs] = 0.3 + (PetscReal)(i % 11) / 7.0;
+      PetscCall(VecRestoreArrayWrite(l, &la));
+      PetscCall(MatDiagonalScale(C, l, NULL));
+      PetscCall(MatAXPY(A, 0.37, C, SAME_NONZERO_PATTERN));
+      PetscCall(VecDestroy(&l));
+      PetscCall(MatDestroy(&C));
+    }
+  }
   PetscCall(MatCreateVecs(A, &u, &b));
   PetscCall(VecSetFromOptions(u));
   PetscCall(VecDuplicate(u, &x));

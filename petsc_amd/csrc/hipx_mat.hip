@@ -1981,6 +1981,10 @@ __global__ void mat_colscale_kernel(int64_t nnz, const hipx_int *__restrict__ aj
 {
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) a[k] *= rvec[aj[k]];  // aij.c:2365
 }
+__global__ void mat_axpy_kernel(int64_t nnz, double alpha, const double *__restrict__ x, double *y)
+{
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) y[k] = y[k] + alpha * x[k];  // daxpy on the value arrays (aij.c:2940)
+}
 __global__ void mat_scale_kernel(int64_t nnz, double alpha, double *a)
 {
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) a[k] *= alpha;  // dscal (aij.c:2613)
@@ -2067,6 +2071,20 @@ int hipxMatScale(hipxMat A, double alpha)
     HIPX_LAUNCH_CHECK();
   }
   values_changed(A);
+  return HIPX_SUCCESS;
+}
+
+int hipxMatAXPY(hipxMat Y, double alpha, hipxMat X)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(Y && X, "null matrix");
+  HIPX_ARG(Y->m == X->m && Y->n == X->n && Y->nnz == X->nnz && Y->compressed == X->compressed, "MatAXPY (SAME_NONZERO_PATTERN): the two matrices must share one nonzero pattern");
+  if (Y->nnz && alpha != 0.0) {
+    const unsigned g = (unsigned)std::min<int64_t>((Y->nnz + 255) / 256, 8192);
+    mat_axpy_kernel<<<g, 256, 0, rt().compute>>>(Y->nnz, alpha, X->d_a, Y->d_a);
+    HIPX_LAUNCH_CHECK();
+  }
+  values_changed(Y);
   return HIPX_SUCCESS;
 }
 

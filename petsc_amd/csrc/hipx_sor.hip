@@ -388,7 +388,6 @@ struct StParams {
   int      trace_lane;   // ... and the loader lane whose passes are logged
   int      poll_adapt;   // ask for (last pass's rows + 2) rows per far strand instead of always 8 (default: the ME 4 kernels; HIPX_SOR_ADAPT=0|1)
   int      poll_sys;     // experiment (HIPX_SOR_POLL=sys): far polls at system scope
-  int      tflush, off_tbuf, off_tfl;   // lockstep kernel: t collected in LDS (16 rows per lane) and written out as whole lines by the loader; lines flushed per lane
   int      lock, off_lock, lock_wrow;  // lockstep C wave (st_lock_c): on; its per-template table {c0,c1}{c2,c3}{mask}; window row of the strand before the panel's first
   unsigned rolemap;      // split kernel: role (0 C, 1 F even, 2 F odd, 3 loader) of the wave on SIMD s of the CU's first / second resident workgroup: nibble s / 4 + s; 0: by wave index
   int      trace_panel;  // HIPX_SOR_DEBUG + HIPX_SOR_TRACE_PANEL: the panel whose rows / loader passes are time-stamped (-1: none)
@@ -464,14 +463,6 @@ __device__ __forceinline__ void st_lds_burst4(st_int4 (&o)[4], const unsigned (&
   asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
                : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
                : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
-               : "memory");
-}
-// ... and one 4-byte word with them (the lockstep C wave: how far the loader has written its t ring out)
-__device__ __forceinline__ void st_lds_burst4w(st_int4 (&o)[4], int &w, const unsigned (&a)[4], unsigned wa)
-{
-  asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %7\n\tds_read_b128 %3, %8\n\tds_read_b32 %4, %9\n\ts_waitcnt lgkmcnt(0)"
-               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(w)
-               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(wa)
                : "memory");
 }
 __device__ __forceinline__ void st_lds_burst12(st_int4 (&o)[12], const unsigned (&a)[12])
@@ -629,9 +620,8 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
 {
   constexpr bool FWD = (KIND == 0 || KIND == 3);
   const hipx_int m = P.m, L = P.L;
-  constexpr bool FW     = (ROLE == 1 || ROLE == 3);  // an F wave: ROLE 1 hands over the partial sum, ROLE 3 (backward lockstep kernel) the products
-  const int      stride = FW ? 2 : 1;  // the two F waves take the even and the odd rows of every strand (row sums do not depend on each other)
-  int       p = FW ? par : 0, ostart = 0, ocnt = 0, dtab = 0, cur_tid = -1, setp = 0;  // setp: the position apos[] / sa[] are set for; dtab: byte offset of the template's entry list
+  const int      stride = ROLE == 1 ? 2 : 1;  // the two F waves take the even and the odd rows of every strand (row sums do not depend on each other)
+  int       p = ROLE == 1 ? par : 0, ostart = 0, ocnt = 0, dtab = 0, cur_tid = -1, setp = 0;  // setp: the position apos[] / sa[] are set for; dtab: byte offset of the template's entry list
   bool      have = false;
   double    s0 = 0.0, rb = 0.0, idiag = 0.0, mdiag = 0.0;
   st_int4   tq0 = {0, 0, 0, 0}, tq1 = {0, 0, 0, 0}, tq2 = {0, 0, 0, 0};  // PAIR, kinds 0 / 3: the three pairs of t before the current one
@@ -681,11 +671,11 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
   // the template of the row at position p has changed (first row, boundary rows): entry table -> registers
   auto load_template = [&](int tnew) __attribute__((always_inline)) {
     st_int4 ti = {0, 0, 0, 0}, dg = {0, 0, 0, 0};
-    if (!FW) {
+    if (ROLE != 1) {
       ti = st_ld4(lds, P.off_tinfo + 16 * tnew);
       dg = st_ld4(lds, P.off_tdiag + 16 * tnew);
     }
-    dtab   = ROLE == 0 ? P.off_dep + 16 * ti.x : (FW ? P.off_depF : P.off_depC) + 16 * ME * tnew;
+    dtab   = ROLE == 0 ? P.off_dep + 16 * ti.x : (ROLE == 1 ? P.off_depF : P.off_depC) + 16 * ME * tnew;
     ostart = ti.z;
     ocnt   = ti.w;
     st_int4  e[ME];
@@ -768,7 +758,7 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
         if (w1.y == p) start_row(w0, w1);  // (the slots read above belonged to no row: compute in the next iteration)
         else {
           st_rowwait++;
-          if (FW && fst && lane == 32) f_row++;
+          if (ROLE == 1 && fst && lane == 32) f_row++;
         }
       } else {
         const long long q = S * L + p;
@@ -777,12 +767,12 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
                                    // else to find out); positive = a slot has moved on (rare: the value comes from memory)
 #pragma unroll
         for (int j = 0; j < ME; j++) diff |= sl[j].z - apos[j];
-        if (FW && fst && lane == 32) {  // F-wave statistics (HIPX_SOR_DEBUG): lane 32's view
+        if (ROLE == 1 && fst && lane == 32) {  // F-wave statistics (HIPX_SOR_DEBUG): lane 32's view
           if (diff < 0) f_far++;
           else if (p - (int)s_prog_c[lane] > ST_CQ - 1) f_full++;
           else if (diff == 0) f_fire++;
         }
-        if (FW && p - (int)s_prog_c[lane] > ST_CQ - 1) diff |= (int)0x80000000;  // the hand-over slot still holds row p - ST_CQ: wait for C
+        if (ROLE == 1 && p - (int)s_prog_c[lane] > ST_CQ - 1) diff |= (int)0x80000000;  // the hand-over slot still holds row p - ST_CQ: wait for C
         if (dbg_on) dbg_c1 = (long long)clock64();  // (moves the burst/compare boundary to here: burst + whatever the !have lanes did + the tag compare)
         if (__any(diff > 0)) dbg_mask |= 1 << 30;
         if (stats && P.trace_panel == (int)panel && lane == P.trace_lane) {
@@ -792,27 +782,6 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
         }
         // the row's values are all there: subtraction chain, scale, publish, move on to the next row
         auto finish = [&](const double (&val)[ME]) __attribute__((always_inline)) {
-          if (ROLE == 3) {
-            // Backward lockstep kernel: the far entries come LAST in the row's list, so what the C wave needs from here are their
-            // rounded PRODUCTS (it subtracts them one by one, in order, after the near entries): nine doubles + template id + tag in
-            // five 16-byte records; the one with the tag is written last (LDS executes a wave's accesses in order).
-            static_assert(ROLE != 3 || ME == 9, "five hand-over records hold nine products");
-            const unsigned qb = lds_base + (unsigned)(P.off_cq + 80 * ST_CQ * lane + 80 * (p & (ST_CQ - 1)));
-            long long      pb[ME];
-#pragma unroll
-            for (int j = 0; j < ME; j++) pb[j] = __double_as_longlong(cf[j] * val[j]);
-#pragma unroll
-            for (int k = 0; k < ME / 2; k++)
-              *reinterpret_cast<volatile st_lds_int4 *>((st_lds_char *)(size_t)(qb + 16u * k)) =
-                st_int4{(int)(unsigned)pb[2 * k], (int)(unsigned)((unsigned long long)pb[2 * k] >> 32), (int)(unsigned)pb[2 * k + 1], (int)(unsigned)((unsigned long long)pb[2 * k + 1] >> 32)};
-            *reinterpret_cast<volatile st_lds_int4 *>((st_lds_char *)(size_t)(qb + 16u * (ME / 2))) =
-              st_int4{(int)(unsigned)pb[ME - 1], (int)(unsigned)((unsigned long long)pb[ME - 1] >> 32), cur_tid, p};
-            p += stride;
-            have = false;
-            asm volatile("" ::: "memory");
-            if (p < len && w1.y == p) start_row(w0, w1);
-            return;
-          }
           double sum = s0;
 #pragma unroll
           for (int j = 0; j < ME; j++) sum -= cf[j] * val[j];  // left to right (PetscSparseDenseMinusDot); null entries subtract +0.0
@@ -931,7 +900,7 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
       }
     }
     s_prog_own[lane] = p;
-    if (FW && s_ctl[1]) break;  // C has given up (bounded wait)
+    if (ROLE == 1 && s_ctl[1]) break;  // C has given up (bounded wait)
     if (stats && P.trace_panel == (int)panel && lane == P.trace_lane && (int)it >= P.trace_it0 && (int)it < P.trace_it0 + 4096) {  // iteration log of one lane
       unsigned long long *ev = stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)L + 4096 * 8 + (size_t)((int)it - P.trace_it0) * 8;
       ev[0] = (unsigned long long)wall_clock64();
@@ -947,7 +916,7 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
       idle = idle < 4 ? idle + 1 : 4;
       if (idle >= 2) __builtin_amdgcn_s_sleep(2);   // ~128 clocks; the loader pass that can change anything takes thousands
     } else idle = 0;
-    if (!FW && (it & 0x3ff) == 0) {  // bounded wait: elapsed wall-clock time, and a global abort word so one stuck panel ends the launch
+    if (ROLE != 1 && (it & 0x3ff) == 0) {  // bounded wait: elapsed wall-clock time, and a global abort word so one stuck panel ends the launch
       const long long now = (long long)wall_clock64();
       if (!t0) t0 = now;
       const unsigned abort_word = st_gload32_wait(err);
@@ -958,7 +927,7 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
     }
   }
   __builtin_amdgcn_s_setprio(0);
-  if (FW) {
+  if (ROLE == 1) {
     if (fst && lane == 32) {
       atomicAdd(&fst[0], (unsigned long long)st_iters);
       atomicAdd(&fst[1], (unsigned long long)f_row);
@@ -1025,8 +994,6 @@ __device__ __forceinline__ void st_lock_c(const StParams &P, const unsigned lds_
   const unsigned lock_b  = lds_base + (unsigned)P.off_lock;
   const unsigned diag_b  = lds_base + (unsigned)P.off_tdiag;
   const long long r0     = S * (long long)P.L;
-  const unsigned tbuf_b  = lds_base + (unsigned)(P.off_tbuf + 8 * lane);  // t ring: row p of this lane at + 512 (p & 15)
-  const unsigned tfl_a   = lds_base + (unsigned)(P.tflush ? P.off_tfl + 4 * lane : P.off_null);
   int       p = -2 * lane, cur_tid = -1, mask = 0, idle = 0;
   double    c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0, idiag = 0.0, H1 = 0.0, H2 = 0.0, H3 = 0.0, psum = 0.0;
   st_int4   tq0 = {0, 0, 0, 0}, tq1 = {0, 0, 0, 0}, tq2 = {0, 0, 0, 0};  // the three pairs of t before the current one (one line = four pairs)
@@ -1044,10 +1011,8 @@ __device__ __forceinline__ void st_lock_c(const StParams &P, const unsigned lds_
     a[1] = lane == 0 ? up_row + (unsigned)((e0 & (ST_WP - 1)) << 4) : null_a;
     a[2] = lane == 0 ? up_row + (unsigned)(((e0 + 1) & (ST_WP - 1)) << 4) : null_a;
     a[3] = lane == 0 ? up_row + (unsigned)(((e0 + 2) & (ST_WP - 1)) << 4) : null_a;
-    int tflv = 0;
-    st_lds_burst4w(o, tflv, a, tfl_a);
+    st_lds_burst4(o, a);
     bool ok = !active || o[0].w == p;
-    if (P.tflush && active && p - 8 * tflv >= 16) ok = false;  // the t ring still holds row p - 16: the loader has not written that line out yet
     if (active && o[0].w == p && o[0].z != cur_tid) {  // the row's template differs from the last row's (strand ends): coefficients -> registers
       unsigned b[4];
       st_int4  q[4];
@@ -1094,10 +1059,6 @@ __device__ __forceinline__ void st_lock_c(const StParams &P, const unsigned lds_
     sum -= c3 * ((mask & 8) ? H1 : 0.0);
     const double out = sum * idiag;
     if (stats && p == 0 && active && (lane == 0 || lane == 63)) stats[16 + 4 * (size_t)panel + (lane ? 2 : 1)] = (unsigned long long)wall_clock64();
-    if (PAIR && P.tflush && active) {  // t goes to the LDS ring (the loader writes whole lines); x leaves in pairs as below
-      const long long tb = __double_as_longlong(sum);
-      asm volatile("ds_write_b64 %0, %1" ::"v"(tbuf_b + (unsigned)(512 * (p & 15))), "v"(tb) : "memory");
-    }
     if (PAIR) {
       // rows leave in pairs (even row, next one): one 16-byte store each for t and x instead of two 8-byte ones -- every lane's store is
       // its own cache line, and the CU's address pipeline is what the sweep waits for.  The skew is even, so "p is odd" is the same
@@ -1106,7 +1067,7 @@ __device__ __forceinline__ void st_lock_c(const StParams &P, const unsigned lds_
         const long long bs0 = __double_as_longlong(psum), bs1 = __double_as_longlong(sum), bo0 = __double_as_longlong(H1), bo1 = __double_as_longlong(out);
         const st_int4   vs = {(int)(unsigned)bs0, (int)(unsigned)((unsigned long long)bs0 >> 32), (int)(unsigned)bs1, (int)(unsigned)((unsigned long long)bs1 >> 32)};
         const st_int4   vo = {(int)(unsigned)bo0, (int)(unsigned)((unsigned long long)bo0 >> 32), (int)(unsigned)bo1, (int)(unsigned)((unsigned long long)bo1 >> 32)};
-        if (!P.tflush && (p & 7) == 7) {
+        if ((p & 7) == 7) {
           // t: nobody waits for it, so a whole line of 8 rows (this pair and the three before it, kept in registers) goes out as four
           // consecutive plain stores, which the cache combines: 68 instead of 180 ns of the CU's request path each
           // (profiles/r02_request_path_probe.txt, modes 10 / 12).  Strand lengths are multiples of 8 here.
@@ -1146,138 +1107,12 @@ __device__ __forceinline__ void st_lock_c(const StParams &P, const unsigned lds_
   if (stats) atomicAdd(&stats[7], (unsigned long long)len);
 }
 
-// The lockstep C wave of a BACKWARD sweep (kinds 1 and 2).  Everything is in the sweep's logical order (row q = m - 1 - r, strands
-// of L logical rows): the previous logical strand is lane i - 1 as in the forward case.  A backward row's list starts with the
-// near entries -- own line x-1 [(0,-1)], then the previous line x+1, x, x-1 [(-1,+1), (-1,0), (-1,-1)] -- and ends with the far ones,
-// so the F waves (ROLE 3) hand over the far entries' rounded products and this wave subtracts them, in order, after the near ones:
-// the same chain of roundings as MatSOR_SeqAIJ's PetscSparseDenseMinusDot.  Skew, register history, DPP shift, the line before the
-// panel from the window (lane 0): as in st_lock_c.
-template <int KIND, bool PAIR>
-__device__ __forceinline__ void st_lock_cb(const StParams &P, const unsigned lds_base, volatile st_lds_int *s_prog, volatile st_lds_int *s_ctl, unsigned int *err, const int lane,
-                                           const long long S, const int len, double *xnew, const double omega, unsigned long long *stats, const unsigned panel)
-{
-  static_assert(KIND == 1 || KIND == 2, "backward kinds with a dependency list only");
-  constexpr int NP = 9;  // products per row (ROLE 3 of st_compute_role)
-  unsigned st_iters = 0, st_stall = 0;
-  if (stats && lane == 0) stats[16 + 4 * (size_t)panel] = (unsigned long long)wall_clock64();
-  const unsigned  cq_base  = lds_base + (unsigned)(P.off_cq + 80 * ST_CQ * lane);
-  const unsigned  rec_base = lds_base + (unsigned)(P.off_rowq + 32 * ST_RQ * lane);
-  const int       rq_rot   = ST_ROT * lane;
-  const unsigned  null_a   = lds_base + (unsigned)P.off_null;
-  const unsigned  up_row   = lds_base + (unsigned)(P.off_win + 16 * ST_WP * P.lock_wrow);
-  const int       up_rot   = ST_ROT * P.lock_wrow;
-  const unsigned  lock_b   = lds_base + (unsigned)P.off_lock;
-  const unsigned  diag_b   = lds_base + (unsigned)P.off_tdiag;
-  const long long q0       = S * (long long)P.L;
-  int       p = -2 * lane, cur_tid = -1, mask = 0, idle = 0;
-  double    c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0, idiag = 0.0, H1 = 0.0, H2 = 0.0, H3 = 0.0;
-  long long t0 = 0;
-  __builtin_amdgcn_s_setprio(3);
-  for (unsigned it = 1;; it++) {
-    if (!__any(p < len)) break;
-    const bool active = p >= 0 && p < len;
-    asm volatile("" ::: "memory");
-    // one burst: the five records of the F waves for row p (products 0..8, template id, tag), the loader's operand record of row p
-    // {t (or b), old x} (still there: the loader recycles ring slots by THIS wave's progress), lane 0: positions p-1, p, p+1 of the
-    // line before the panel
-    const int e0 = p - 1 + up_rot;
-    unsigned  a[9];
-    st_int4   o[9];
-#pragma unroll
-    for (int k = 0; k < 5; k++) a[k] = cq_base + (unsigned)(80 * (p & (ST_CQ - 1)) + 16 * k);
-    a[5] = rec_base + (unsigned)(32 * ((p + rq_rot) & (ST_RQ - 1)));
-    a[6] = lane == 0 ? up_row + (unsigned)((e0 & (ST_WP - 1)) << 4) : null_a;
-    a[7] = lane == 0 ? up_row + (unsigned)(((e0 + 1) & (ST_WP - 1)) << 4) : null_a;
-    a[8] = lane == 0 ? up_row + (unsigned)(((e0 + 2) & (ST_WP - 1)) << 4) : null_a;
-    st_lds_burst9(o, a);
-    const int rtid = o[4].z, rtag = o[4].w;
-    bool      ok   = !active || rtag == p;
-    if (active && rtag == p && rtid != cur_tid) {
-      unsigned b[4];
-      st_int4  q[4];
-      b[0] = lock_b + (unsigned)(48 * rtid);
-      b[1] = b[0] + 16;
-      b[2] = b[0] + 32;
-      b[3] = diag_b + (unsigned)(16 * rtid);
-      st_lds_burst4(q, b);
-      c0      = st_dbl(q[0].x, q[0].y);  // (0,-1): own line
-      c1      = st_dbl(q[0].z, q[0].w);  // (-1,+1)
-      c2      = st_dbl(q[1].x, q[1].y);  // (-1, 0)
-      c3      = st_dbl(q[1].z, q[1].w);  // (-1,-1)
-      mask    = q[2].x;
-      idiag   = st_dbl(q[3].x, q[3].y);
-      cur_tid = rtid;
-    }
-    if (lane == 0 && active && ok) {
-      if (((mask & 8) && o[6].z != e0) || ((mask & 4) && o[7].z != e0 + 1) || ((mask & 2) && o[8].z != e0 + 2)) ok = false;
-    }
-    if ((it & 0x3ff) == 0) {
-      const long long now = (long long)wall_clock64();
-      if (!t0) t0 = now;
-      const unsigned abort_word = st_gload32_wait(err);
-      if (abort_word || now - t0 > SOR_SPIN_TICKS) {
-        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-    st_iters++;
-    if (__any(!ok)) {
-      st_stall++;
-      idle = idle < 4 ? idle + 1 : 4;
-      if (idle >= 2) __builtin_amdgcn_s_sleep(1);
-      continue;
-    }
-    idle = 0;
-    const double u1 = st_from_prev_lane(st_dbl(o[8].x, o[8].y), H1);  // previous line, position p+1
-    const double u2 = st_from_prev_lane(st_dbl(o[7].x, o[7].y), H2);  // ... p
-    const double u3 = st_from_prev_lane(st_dbl(o[6].x, o[6].y), H3);  // ... p-1
-    double       sum = st_dbl(o[5].x, o[5].y);                        // t[r] (kind 1) / b[r] (kind 2)
-    const double rb  = st_dbl(o[5].z, o[5].w);                        // old x[r]
-    sum -= c0 * ((mask & 1) ? H1 : 0.0);
-    sum -= c1 * ((mask & 2) ? u1 : 0.0);
-    sum -= c2 * ((mask & 4) ? u2 : 0.0);
-    sum -= c3 * ((mask & 8) ? u3 : 0.0);
-#pragma unroll
-    for (int k = 0; k < NP / 2; k++) {  // the far entries' products, in list order (absent ones are +0.0)
-      sum -= st_dbl(o[k].x, o[k].y);
-      sum -= st_dbl(o[k].z, o[k].w);
-    }
-    sum -= st_dbl(o[4].x, o[4].y);
-    const double    out = KIND == 1 ? (1 - omega) * rb + sum * idiag : sum * idiag;
-    const long long q   = q0 + p;
-    const hipx_int  r   = st_actual<false>(q, P.m);
-    if (stats && p == 0 && active && (lane == 0 || lane == 63)) stats[16 + 4 * (size_t)panel + (lane ? 2 : 1)] = (unsigned long long)wall_clock64();
-    if (PAIR) {
-      if ((p & 1) && active) {  // logical rows p-1, p = actual rows r+1, r: one 16-byte publish at r
-        const long long b0 = __double_as_longlong(out), b1 = __double_as_longlong(H1);
-        const st_int4   vo = {(int)(unsigned)b0, (int)(unsigned)((unsigned long long)b0 >> 32), (int)(unsigned)b1, (int)(unsigned)((unsigned long long)b1 >> 32)};
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(xnew + r), "v"(vo) : "memory");
-      }
-    } else if (active) sor_publish(xnew + r, out);
-    H3 = H2;
-    H2 = H1;
-    H1 = active ? out : 0.0;
-    p++;
-    s_prog[lane] = p > 0 ? p : 0;
-  }
-  __builtin_amdgcn_s_setprio(0);
-  if (lane == 0) s_ctl[1] = 1;
-  if (stats && lane == 0) {
-    stats[16 + 4 * (size_t)panel + 3] = (unsigned long long)wall_clock64();
-    atomicAdd(&stats[0], (unsigned long long)st_iters);
-    atomicAdd(&stats[2], (unsigned long long)st_stall * 64ull);
-    atomicAdd(&stats[8], 1ull);
-    atomicAdd(&stats[6], stats[16 + 4 * (size_t)panel + 3] - stats[16 + 4 * (size_t)panel]);
-  }
-  if (stats) atomicAdd(&stats[7], (unsigned long long)len);
-}
-
 // The loader wave of a panel: operands of the own strands into the operand ring, far strands into the window.
 template <int KIND, bool ALIGNED, bool SPLIT>
 __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *lds, volatile st_lds_int *s_lead, volatile st_lds_int *s_trail, volatile st_lds_int *s_ctl, const int lane,
                                                const unsigned panel, const long long S0, const int cnt, const long long S, const int len, const unsigned char *__restrict__ tid,
                                                const double *asrc,
-                                               const double *xold, const double *xnew, unsigned long long *stats, double *tout = nullptr)
+                                               const double *xold, const double *xnew, unsigned long long *stats)
 {
   constexpr bool FWD     = (KIND == 0 || KIND == 3);
   constexpr bool NEEDOLD = (KIND == 1 || KIND == 3 || KIND == 4);  // the row's own old value
@@ -1308,40 +1143,8 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
     if (d >= ST_NB && dvalid[d]) any_hi = true;
   }
   const bool wave_hi = __any(any_hi);
-  // t through LDS (lockstep forward kernel, P.tflush): lane 4 s + q writes quarter q of the finished 8-row lines of strands
-  // 16 j + s, j = 0..3 -- four lanes per 64-byte line: 17 ns of the CU's request path per wave-wide store instead of 185 ns
-  int        tfl[4] = {0, 0, 0, 0};  // lines of strand 16 j + (lane >> 2) written out so far
-  const int  lastlen_t = st_strand_len((long long)P.nstr - 1, P);                 // every strand has L rows except the matrix's last one
-  const int  last_u_t  = (int)min((long long)P.nstr - 1 - S0, 100000LL);          // ... its index relative to the panel's first strand
-  const bool tflush = SPLIT && ALIGNED && KIND == 0 && P.tflush && tout != nullptr;
-  auto flush_t = [&]() __attribute__((always_inline)) {
-    volatile st_lds_int *s_tfl = (volatile st_lds_int *)(lds + P.off_tfl);
-    bool                 more  = false;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int s = 16 * j + (lane >> 2), q = lane & 3;
-      if (s < cnt) {
-        const int prog = s_trail[s];  // rows of that strand the C wave has finished (their t is in the ring)
-        if (8 * (tfl[j] + 1) <= prog) {
-          const int       row0 = 8 * tfl[j] + 2 * q;
-          const long long lo   = *reinterpret_cast<volatile __attribute__((address_space(3))) long long *>(lds + P.off_tbuf + 512 * (row0 & 15) + 8 * s);
-          const long long hi   = *reinterpret_cast<volatile __attribute__((address_space(3))) long long *>(lds + P.off_tbuf + 512 * ((row0 + 1) & 15) + 8 * s);
-          const st_int4   v    = {(int)(unsigned)lo, (int)(unsigned)((unsigned long long)lo >> 32), (int)(unsigned)hi, (int)(unsigned)((unsigned long long)hi >> 32)};
-          *reinterpret_cast<st_int4 *>(tout + ((S0 + s) * (long long)L + row0)) = v;
-          tfl[j]++;
-          if (q == 0) s_tfl[s] = tfl[j];  // (after the reads, in program order: the C wave may overwrite the line's slots now)
-        }
-        if (8 * tfl[j] < (s == last_u_t ? lastlen_t : (int)L)) more = true;
-      }
-    }
-    return more;
-  };
   for (;;) {
     if (s_ctl[1]) break;
-    if (tflush) {  // up to two lines per strand and pass (the C wave finishes a line in about one pass)
-      (void)flush_t();
-      (void)flush_t();
-    }
     bool      issued = false;
     // SPLIT: s_lead = the two F waves' progress arrays (even rows, odd rows): every row below the smaller one has been consumed
     const int myp    = SPLIT ? min((int)s_lead[lane], (int)s_lead[64 + lane]) : (int)s_lead[lane];
@@ -1559,10 +1362,6 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
       __builtin_amdgcn_s_sleep(4);
     }
   }
-  if (tflush) {  // the C wave is done: write out what is left of the ring (bounded: nothing moves if the launch was aborted)
-    for (int rep = 0; rep < (int)(L / 8) + 2; rep++)
-      if (!__any(flush_t())) break;
-  }
   if (stats && lane == 0) {
     atomicAdd(&stats[3], (unsigned long long)st_pass);
     atomicAdd(&stats[4], (unsigned long long)st_idle);
@@ -1600,7 +1399,7 @@ __global__ __launch_bounds__(SPLIT ? 256 : 128, SPLIT ? 2 : 1) void sor_strand_k
   if (SPLIT) {
     for (int i = threadIdx.x; i < P.ntmpl * (ME - ST_MC); i += NT) st_st4v(lds, P.off_depF + 16 * i, reinterpret_cast<const st_int4 *>(g_depF)[i]);
     for (int i = threadIdx.x; i < P.ntmpl * ST_MC; i += NT) st_st4v(lds, P.off_depC + 16 * i, reinterpret_cast<const st_int4 *>(g_depC)[i]);
-    if (P.lock)  // the lockstep C wave's table: three records per template, stored behind the C entries
+    if (KIND == 0 && P.lock)  // the lockstep C wave's table: three records per template, stored behind the C entries
       for (int i = threadIdx.x; i < 3 * P.ntmpl; i += NT) st_st4v(lds, P.off_lock + 16 * i, reinterpret_cast<const st_int4 *>(g_depC)[P.ntmpl * ST_MC + i]);
   } else {
     for (int i = threadIdx.x; i < P.ndep; i += NT) st_st4v(lds, P.off_dep + 16 * i, reinterpret_cast<const st_int4 *>(g_dep)[i]);
@@ -1630,12 +1429,11 @@ __global__ __launch_bounds__(SPLIT ? 256 : 128, SPLIT ? 2 : 1) void sor_strand_k
       for (int i = threadIdx.x; i < P.nrows * ST_WP; i += NT) st_st4v(lds, P.off_win + 16 * i, empty);
       const st_int4 empty_row = {0, -1, 0, 0};  // second half of a StRow: {tid, tag, -, -}
       for (int i = threadIdx.x; i < 64 * ST_RQ; i += NT) st_st4v(lds, P.off_rowq + 32 * i + 16, empty_row);
-      if (SPLIT)  // (backward lockstep kernel: five records per row, the tag in the last one; -1 everywhere does no harm)
-        for (int i = threadIdx.x; i < 64 * ST_CQ * ((KIND != 0 && P.lock) ? 5 : 1); i += NT) st_st4v(lds, P.off_cq + 16 * i, st_int4{0, 0, 0, -1});
+      if (SPLIT)
+        for (int i = threadIdx.x; i < 64 * ST_CQ; i += NT) st_st4v(lds, P.off_cq + 16 * i, st_int4{0, 0, 0, -1});
     }
     if (threadIdx.x < 64) {
       s_prog[threadIdx.x] = 0;
-      if (SPLIT && P.tflush) ((volatile st_lds_int *)(lds + P.off_tfl))[threadIdx.x] = 0;
       if (SPLIT) {
         s_progF[threadIdx.x]      = 0;
         s_progF[64 + threadIdx.x] = 1;
@@ -1655,20 +1453,13 @@ __global__ __launch_bounds__(SPLIT ? 256 : 128, SPLIT ? 2 : 1) void sor_strand_k
     const long long S   = S0 + lane;
     const int       len = lane < cnt ? st_strand_len(S, P) : 0;
     if (SPLIT) {
-      constexpr bool BWDLOCK = (KIND == 1 || KIND == 2) && ME == 13;  // the backward lockstep roles exist for the 13-entry class
       if (wave == 0) {
         if (KIND == 0 && P.lock) st_lock_c<ALIGNED>(P, lds_base, s_prog, s_ctl, err, lane, S, len, t, xnew, stats, panel);
-        else if (BWDLOCK && P.lock) {
-          if constexpr (BWDLOCK) st_lock_cb<KIND, ALIGNED>(P, lds_base, s_prog, s_ctl, err, lane, S, len, xnew, omega, stats, panel);
-        } else st_compute_role<KIND, ST_MC, 2, ALIGNED>(P, lds, lds_base, s_prog, s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, stats, 0);
-      } else if (wave <= 2) {
-        unsigned long long *fstat = stats ? stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)P.L + 2 * 4096 * 8 + 48 + 8 * (wave - 1) : nullptr;
-        if (BWDLOCK && P.lock) {
-          if constexpr (BWDLOCK) st_compute_role<KIND, 9, 3>(P, lds, lds_base, s_progF + 64 * (wave - 1), s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, nullptr, wave - 1, fstat);
-        } else
-          st_compute_role<KIND, (SPLIT ? ME - ST_MC : ME), 1>(P, lds, lds_base, s_progF + 64 * (wave - 1), s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, nullptr, wave - 1, fstat);
-      }
-      else st_loader_role<KIND, ALIGNED, true>(P, lds, s_progF, s_prog, s_ctl, lane, panel, S0, cnt, S, len, tid, asrc, xold, xnew, stats, t);
+        else st_compute_role<KIND, ST_MC, 2, ALIGNED>(P, lds, lds_base, s_prog, s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, stats, 0);
+      } else if (wave <= 2)
+        st_compute_role<KIND, (SPLIT ? ME - ST_MC : ME), 1>(P, lds, lds_base, s_progF + 64 * (wave - 1), s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, nullptr, wave - 1,
+                                        stats ? stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)P.L + 2 * 4096 * 8 + 48 + 8 * (wave - 1) : nullptr);
+      else st_loader_role<KIND, ALIGNED, true>(P, lds, s_progF, s_prog, s_ctl, lane, panel, S0, cnt, S, len, tid, asrc, xold, xnew, stats);
     } else {
       if (wave == 0) st_compute_role<KIND, ME, 0, ALIGNED>(P, lds, lds_base, s_prog, s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, stats, 0);
       else st_loader_role<KIND, ALIGNED, false>(P, lds, s_prog, s_prog, s_ctl, lane, panel, S0, cnt, S, len, tid, asrc, xold, xnew, stats);
@@ -1942,50 +1733,10 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
       lockrec.push_back(r1);
       lockrec.push_back(r2);
     }
-    // backward lockstep kernel (st_lock_cb + the F waves handing over products; HIPX_SOR_LOCKSTEP_BWD=1, work in progress): every list
-    // must be near entries out of {(0,-1), (-1,+1), (-1,0), (-1,-1)} in this order followed by at most nine far entries
-    static const bool lockb_on = getenv("HIPX_SOR_LOCKSTEP_BWD") && atoi(getenv("HIPX_SOR_LOCKSTEP_BWD")) != 0;
-    bool              lockb = P.split && !fwd && lockb_on && L >= 4 && ME == 13;
-    std::vector<int>  nnear((size_t)ntmpl, 0);
-    for (int t = 0; t < ntmpl && lockb; t++) {
-      const StTinfo &ti = tinfo[(size_t)t];
-      double         c[4] = {0.0, 0.0, 0.0, 0.0};
-      int            msk = 0, last = -1, nf = 0;
-      for (int k = 0; k < ti.dcnt; k++) {
-        const StEntry &e = dep[(size_t)ti.dstart + k];
-        int            ds, dp;
-        decomp(e.lo, ds, dp);
-        if (ds <= -64) nf++;
-        else {
-          const int ci = (ds == 0 && dp == -1) ? 0 : ((ds == -1 && dp >= -1 && dp <= 1) ? 2 - dp : -1);  // (-1,+1) -> 1, (-1,0) -> 2, (-1,-1) -> 3
-          if (nf > 0 || ci < 0 || ci <= last) lockb = false;  // a near entry behind a far one, or out of the canonical order
-          else {
-            last  = ci;
-            c[ci] = e.val;
-            msk |= 1 << ci;
-            nnear[(size_t)t]++;
-          }
-        }
-      }
-      if (nf > 9) lockb = false;
-      StEntry r0, r1, r2;
-      memcpy(&r0, &c[0], 16);
-      memcpy(&r1, &c[2], 16);
-      r2 = StEntry{msk, 0, 0.0};
-      lockrec.push_back(r0);
-      lockrec.push_back(r1);
-      lockrec.push_back(r2);
-    }
-    if (getenv("HIPX_SOR_TRACE")) fprintf(stderr, "[hipx sor] strand %s: ME %d split %d lockstep %d\n", fwd ? "forward" : "backward", ME, P.split, (lock || lockb) ? 1 : 0);
+    if (getenv("HIPX_SOR_TRACE")) fprintf(stderr, "[hipx sor] strand %s: ME %d split %d lockstep %d\n", fwd ? "forward" : "backward", ME, P.split, lock ? 1 : 0);
     if (P.split) {
       for (int t = 0; t < ntmpl; t++) {
         const StTinfo &ti = tinfo[(size_t)t];
-        if (lockb) {  // F waves: the far entries (the END of the list), nine per template; no C entries (st_lock_cb has its own table)
-          const int nn = nnear[(size_t)t], nF = ti.dcnt - nn;
-          for (int k = 0; k < ME - ST_MC; k++) depF.push_back(k < nF ? dep[(size_t)ti.dstart + nn + k] : StEntry{ST_NULLPK, 0, 0.0});
-          for (int k = 0; k < ST_MC; k++) depC.push_back(StEntry{ST_NULLPK, 0, 0.0});
-          continue;
-        }
         const int      nF = lock ? nfar[(size_t)t] : ti.dcnt - std::min(ti.dcnt, ST_MC), nC = ti.dcnt - nF;
         for (int k = 0; k < ME - ST_MC; k++) depF.push_back(k < nF ? dep[(size_t)ti.dstart + k] : StEntry{ST_NULLPK, 0, 0.0});
         for (int k = 0; k < ST_MC; k++) depC.push_back(k < nC ? dep[(size_t)ti.dstart + nF + k] : StEntry{ST_NULLPK, 0, 0.0});
@@ -2023,59 +1774,6 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
         for (int b = 0; b < nb; b++)
           if (P.band[b].dsmin <= -1 && -1 < P.band[b].dsmin + P.band[b].width) Q.lock_wrow = P.band[b].rowbase + (-1 - P.band[b].dsmin);  // window row of (lane 0, strand delta -1)
         depC.insert(depC.end(), lockrec.begin(), lockrec.end());
-        // t through LDS (HIPX_SOR_TFLUSH=1): in lockstep nobody touches the window rows of the panel's own strands (the near band
-        // is the last one: it contains delta 0), so the band keeps ONE row -- the line before the panel -- and the 16 KiB pay for a
-        // 16-row ring of t per lane, which the loader writes out as whole 64-byte lines, four lanes per line.
-        static const bool tflush_on = getenv("HIPX_SOR_TFLUSH") && atoi(getenv("HIPX_SOR_TFLUSH")) != 0;
-        if (tflush_on && L % 8 == 0 && m % 8 == 0 && P.band[nb - 1].dsmin + P.band[nb - 1].width == 1) {
-          const int o_old = o;
-          Q.nrows     = P.band[nb - 1].rowbase + 1;
-          o           = 0;
-          Q.off_win   = o; o += Q.nrows * ST_WP * (int)sizeof(StSlot);
-          Q.off_rowq  = o; o += 64 * ST_RQ * (int)sizeof(StRow);
-          Q.off_tinfo = o; o += ntmpl * (int)sizeof(StTinfo);
-          Q.off_tdiag = o; o += ntmpl * (int)sizeof(StDiag);
-          Q.off_depF  = o; o += ntmpl * (ME - ST_MC) * (int)sizeof(StEntry);
-          Q.off_depC  = o; o += ntmpl * ST_MC * (int)sizeof(StEntry);
-          Q.off_old   = o;
-          Q.off_prog  = o; o += 64 * 4;
-          Q.off_progF = o; o += 2 * 64 * 4;
-          Q.off_ctl   = o; o += 32;
-          Q.off_null  = o; o += 16;
-          Q.off_cq    = o; o += 64 * ST_CQ * 16;
-          Q.off_lock  = o; o += 48 * ntmpl;
-          Q.off_tbuf  = o; o += 16 * 64 * 8;
-          Q.off_tfl   = o; o += 64 * 4;
-          Q.tflush    = 1;
-          (void)o_old;
-        }
-      }
-      if (lockb) {
-        // the backward lockstep kernel's layout: the near band keeps ONE window row (the line before the panel; the band is the last
-        // one, it contains delta 0), the hand-over ring holds five records per row
-        Q.lock      = 1;
-        Q.nrows     = P.band[nb - 1].rowbase + 1;
-        for (int b = 0; b < nb; b++)
-          if (P.band[b].dsmin <= -1 && -1 < P.band[b].dsmin + P.band[b].width) Q.lock_wrow = P.band[b].rowbase + (-1 - P.band[b].dsmin);
-        o           = 0;
-        Q.off_win   = o; o += Q.nrows * ST_WP * (int)sizeof(StSlot);
-        Q.off_rowq  = o; o += 64 * ST_RQ * (int)sizeof(StRow);
-        Q.off_tinfo = o; o += ntmpl * (int)sizeof(StTinfo);
-        Q.off_tdiag = o; o += ntmpl * (int)sizeof(StDiag);
-        Q.off_depF  = o; o += ntmpl * (ME - ST_MC) * (int)sizeof(StEntry);
-        Q.off_depC  = o; o += ntmpl * ST_MC * (int)sizeof(StEntry);
-        Q.off_old   = o;
-        Q.off_prog  = o; o += 64 * 4;
-        Q.off_progF = o; o += 2 * 64 * 4;
-        Q.off_ctl   = o; o += 32;
-        Q.off_null  = o; o += 16;
-        Q.off_cq    = o; o += 64 * ST_CQ * 80;
-        Q.off_lock  = o; o += 48 * ntmpl;
-        depC.insert(depC.end(), lockrec.begin(), lockrec.end());
-        if (P.band[nb - 1].dsmin + P.band[nb - 1].width != 1 || o > 78 * 1024) {  // (cannot happen for the box stencils; keep the generic split layout then)
-          fprintf(stderr, "[hipx sor] backward lockstep layout does not fit: %d bytes\n", o);
-          return HIPX_ERR_SUP;
-        }
       }
       Q.lds_bytes = o;
       if (Q.lds_bytes > 78 * 1024) P.split = Q.split = 0;
@@ -2161,7 +1859,6 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
   unsigned grid = (unsigned)std::min<long long>((long long)P.npanels, 256LL * per_cu);
   static const bool want_aligned = !(getenv("HIPX_SOR_ALIGNED") && atoi(getenv("HIPX_SOR_ALIGNED")) == 0);  // 0: the kernels for any L / alignment (8-byte polls, scalar operand loads)
   const bool aligned = want_aligned && (P.L % 8 == 0) && (P.m % 8 == 0) && ((reinterpret_cast<uintptr_t>(asrc) | reinterpret_cast<uintptr_t>(xold) | reinterpret_cast<uintptr_t>(xnew) | reinterpret_cast<uintptr_t>(t)) % 16 == 0);  // (a null t / xold counts as aligned)
-  if (!aligned) P.tflush = 0;  // (the LDS layout stays; t is stored directly)
   static const bool dbg = getenv("HIPX_SOR_DEBUG") != nullptr;
   static bool attr_set[5][20] = {{false}};
   // The split kernel pays when the far entries come FIRST in the row's list (forward sweeps: lower planes, then the previous line,
@@ -2170,7 +1867,7 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
   // per row against 3.25 / 1.4 with two waves; backward 2x SLOWER than with two waves).  HIPX_SOR_SPLIT = 0 off | 1 forward
   // zero-guess sweep only (default) | 2 every sweep of kinds 0-2.
   static const int split_mode = getenv("HIPX_SOR_SPLIT") ? atoi(getenv("HIPX_SOR_SPLIT")) : 1;
-  const bool     split    = P.split && ((split_mode >= 2 ? KIND <= 2 : (split_mode == 1 && KIND == 0)) || (KIND >= 1 && KIND <= 2 && D.Ps.lock));
+  const bool     split    = P.split && (split_mode >= 2 ? KIND <= 2 : (split_mode == 1 && KIND == 0));
   const unsigned nthreads = (P.me != 4 && split) ? 256 : 128;
   if (split) {
     const int tp = P.trace_panel, tl = P.trace_lane, ti = P.trace_it0, tr = P.trace_rows, ps = P.poll_sys, pad = P.poll_adapt;

@@ -300,6 +300,28 @@ static PetscErrorCode MatScale_SeqAIJHIPX(Mat A, PetscScalar alpha) /* MatScale_
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+static PetscErrorCode (*parent_axpy_seq)(Mat, PetscScalar, Mat, MatStructure);
+
+/* MatAXPY_SeqAIJ aij.c:2926-2989: SAME_NONZERO_PATTERN is a daxpy over the value arrays -- on the device copies when both matrices
+   are of this type; every other structure flag (SUBSET / DIFFERENT / UNKNOWN: pattern work) stays with the parent */
+static PetscErrorCode MatAXPY_SeqAIJHIPX(Mat Y, PetscScalar a, Mat X, MatStructure str)
+{
+  Mat_SeqAIJ *x = (Mat_SeqAIJ *)X->data, *y = (Mat_SeqAIJ *)Y->data;
+  hipxMat     dX, dY;
+
+  PetscFunctionBegin;
+  if (str != SAME_NONZERO_PATTERN || !MatIsSeqAIJHIPX(X) || !MatIsSeqAIJHIPX(Y) || x->nz != y->nz || X == Y) {
+    PetscCall((*parent_axpy_seq)(Y, a, X, str));
+    PetscFunctionReturn(PETSC_SUCCESS);
+  }
+  PetscCall(MatSeqAIJHIPXGetDeviceMat(X, &dX));
+  PetscCall(MatSeqAIJHIPXGetDeviceMat(Y, &dY));
+  PetscCallHIPX(hipxMatAXPY(dY, a, dX));
+  PetscCall(MatSeqAIJHIPXDeviceValuesChanged(Y));
+  PetscCall(PetscLogFlops(2.0 * y->nz));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 static PetscErrorCode MatDiagonalScale_SeqAIJHIPX(Mat A, Vec ll, Vec rr) /* MatDiagonalScale_SeqAIJ aij.c:2333-2371 */
 {
   Mat_SeqAIJHIPX    *h = (Mat_SeqAIJHIPX *)A->spptr;
@@ -406,6 +428,8 @@ static PetscErrorCode MatConvert_SeqAIJ_SeqAIJHIPX(Mat A, MatType mtype, MatReus
   B->ops->destroy        = MatDestroy_SeqAIJHIPX;
   B->ops->duplicate      = MatDuplicate_SeqAIJHIPX;
   B->ops->setfromoptions = MatSetFromOptions_SeqAIJHIPX;
+  if (!parent_axpy_seq) parent_axpy_seq = B->ops->axpy;
+  B->ops->axpy           = MatAXPY_SeqAIJHIPX;
   B->ops->scale          = MatScale_SeqAIJHIPX;
   B->ops->diagonalscale  = MatDiagonalScale_SeqAIJHIPX;
   PetscCall(PetscObjectQueryFunction((PetscObject)B, "MatSetPreallocationCOO_C", &h->parent_prealloc_coo));

@@ -17,10 +17,12 @@ PLUGIN = os.path.join(ROOT, "petsc_amd", "lib", "libpetschipx.so")
 HIPX = ["-dll_prepend", PLUGIN, "-vec_type", "hipx", "-mat_type", "aijhipx"]
 
 
-def run(exe, args):
+def run(exe, args, exact_blas=False):
     p = os.path.join(BIN, exe)
     assert os.path.exists(p) and os.path.exists(PLUGIN), "oracle/_ref or the plugin is not built: run __graft_entry__.build() where /root/reference exists"
     env = dict(os.environ, HIPX_NO_TORCH="1")
+    if exact_blas:  # the CPU run with the published (unfused) daxpy and twice-working-precision reductions: oracle/exactblas.c
+        env["LD_PRELOAD"] = os.path.join(ROOT, "oracle", "libexactblas.so")
     r = subprocess.run([p] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
     return r.stdout
@@ -197,3 +199,15 @@ def test_pbjacobi_apply_on_device_bit_exact(bs, n):
         assert zc == zg and len(zc) == n ** 3
     hc, hg = hist_of(cpu), hist_of(gpu)
     assert len(hc) == len(hg) > 3 and np.abs(hc - hg).max() <= 1e-10 * hc[0]
+
+
+def test_mataxpy_same_pattern_on_device_bit_exact():
+    """MatAXPY(Y, a, X, SAME_NONZERO_PATTERN) = a daxpy over the value arrays (aij.c:2926-2945) runs on the device
+    copies (hipxMatAXPY).  An optimised host BLAS fuses the multiply-add; the published daxpy (and every plain-C loop of the
+    reference) rounds twice -- the CPU side therefore runs with oracle/libexactblas.so, which pins that definition: the product
+    y = (A + 0.37 D A) x is then bit-identical."""
+    a = "-stencil 27 -n 9 -mat_axpy -dump_y -ksp_max_it 1".split()
+    cpu, gpu = run("ref_driver", a, exact_blas=True), run("ref_driver", a + HIPX)
+    yc = [l for l in cpu.splitlines() if l.startswith("y ")]
+    yg = [l for l in gpu.splitlines() if l.startswith("y ")]
+    assert yc == yg and len(yc) == 729
