@@ -255,6 +255,13 @@ int hipxHaloRelease(hipxHalo h);
 int hipxMatMultMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *lvec, double *y);
 /* replaces MatMultAdd_MPIAIJ mpiaij.c:1072-1083: halo begin; z = y + Ad x (overlapped); halo end; z += Bo lvec */
 int hipxMatMultAddMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *lvec, const double *y, double *z);
+/* Launch-ahead CG on several ranks (round 3): the reductions complete on the stream -- local kernel -> all-reduce -> publish to the host
+   slot (hipxRedEnd collects it) AND to device memory -- so the next iteration's kernels (hipxCGAypxAxpyDev, ...Begin forms, which read
+   their scalars from device memory) can be queued before the host has seen the sums.  hipxMatMultMPIDotBegin = MatMult_MPIAIJ +
+   VecTDot_MPI (cg.c:257-258); hipxCGFusedUpdateBeginAllreduce = hipxCGFusedUpdateBegin + the 16-byte all-reduce of its two sums. */
+int hipxMatMultMPIDotBegin(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *lvec, double *y, hipx_int n, int slot, double *dev_dot);
+int hipxCGFusedUpdateBeginAllreduce(double *x, double *r, double *z, const double *p, const double *w, const double *d, double dconst, const double *dev_beta, const double *dev_dpi,
+                                    hipx_int n, int slot, double *dev_sums2);
 /* which transport the next exchange of this plan takes: 1 = IPC peer stores, 2 = RCCL send/recv, 0 = none set up */
 int hipxHaloTransport(hipxHalo h, int *transport);
 

@@ -385,6 +385,39 @@ int hipxCGFusedUpdateAllreduce(double *x, double *r, double *z, const double *p,
   return comm_err_check();
 }
 
+// ---- launch-ahead CG on several ranks: the reductions complete ON THE STREAM (local kernel -> all-reduce -> publish to the host
+// slot and to device memory), so the kernels of the next iteration, which read their scalars from device memory, can be queued
+// before the host has seen anything.  Same arithmetic as hipxVecMDotAllreduce / hipxCGFusedUpdateAllreduce.
+int hipxMatMultMPIDotBegin(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *lvec, double *y, hipx_int n, int slot, double *dev_dot)
+{
+  HIPX_CHECK_INIT();
+  Comm &c = cm();
+  HIPX_ARG(c.active && slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2 && dev_dot, "communicator not initialised / bad slot");
+  int ierr = hipxMatMultMPI(Ad, Bo, h, x, lvec, y);  // mpiaij.c:1047-1061
+  if (ierr) return ierr;
+  const double *ys[1] = {y};
+  if (n > 0) {
+    if ((ierr = launch_mdot_nosignal(x, 1, ys, n, slot, c.d_red))) return ierr;  // cg.c:258 VecXDot(P, W), local part
+  } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double), rt().compute));
+  if ((ierr = allreduce_dev(c.d_red, 1))) return ierr;
+  return red_signal(slot, c.d_red, 1, dev_dot);
+}
+
+int hipxCGFusedUpdateBeginAllreduce(double *x, double *r, double *z, const double *p, const double *w, const double *d, double dconst, const double *dev_beta, const double *dev_dpi,
+                                    hipx_int n, int slot, double *dev_sums2)
+{
+  HIPX_CHECK_INIT();
+  Comm &c = cm();
+  HIPX_ARG(c.active && slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2 && dev_beta && dev_dpi && dev_sums2, "communicator not initialised / bad slot / null scalars");
+  HIPX_ARG(z || !d, "z may only be omitted with a constant diagonal (d == NULL)");
+  int ierr;
+  if (n > 0) {
+    if ((ierr = launch_cg_fused_dev_nosignal(x, r, z, p, w, d, dconst, dev_beta, dev_dpi, n, slot, c.d_red))) return ierr;
+  } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * 2, rt().compute));
+  if ((ierr = allreduce_dev(c.d_red, 2))) return ierr;
+  return red_signal(slot, c.d_red, 2, dev_sums2);
+}
+
 int hipxHaloCreate(int nsend, const int *send_ranks, const hipx_int *send_off, const hipx_int *send_idx, int nrecv, const int *recv_ranks, const hipx_int *recv_off,
                    hipxHalo *out)
 {

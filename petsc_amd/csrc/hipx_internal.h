@@ -60,7 +60,9 @@ int launch_sum(const double *x, hipx_int n, int slot, double *dres);  // fold of
 // reduced words into the slot's host-mapped result area before raising the sequence flag.
 int launch_mdot_nosignal(const double *x, int nv, const double *const *y, hipx_int n, int slot, double *dev_results);
 int launch_cg_fused_nosignal(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n, int slot, double *dev_results);
-int red_signal(int slot, const double *dev_results, int nvals);  // enqueue: publish to the host (values, then sequence flag), stream-ordered
+int launch_cg_fused_dev_nosignal(double *x, double *r, double *z, const double *p, const double *w, const double *d, double dconst, const double *dev_beta, const double *dev_dpi, hipx_int n,
+                                 int slot, double *dev_results);
+int red_signal(int slot, const double *dev_results, int nvals, double *dres = nullptr);  // enqueue: publish to the host (values, then sequence flag) and optionally to device memory, stream-ordered
 int red_wait(int slot, int nvals, double *out);
 
 // optional HIP-event bracketing of named sections of the hot path (bench.py: per-rank diagnosis of a scaling curve).

@@ -986,7 +986,10 @@ __global__ __launch_bounds__(256) void tmpl_verify_kernel(hipx_int m, hipx_int n
 // folded into +-4096 doubles of the row (same number of distinct lines per gather, all of them recently touched: no far-plane HBM stream);
 // 4 = correct results, but the chunks are assigned statically (round robin over the XCD's workgroups): no ticket atomics, no barriers;
 // 5 = 4 without the first-touch prefetch; 6 = 5 without the template-id loads (id 0 everywhere: wrong rows at the boundaries)
-template <int MODE, bool DOT, int RPT, int W, bool UNI, int PROBE = 0>
+// SHORT: no template has more than 8 entries (5-/7-point operators): the wave-uniform fast path keeps the current template's offsets
+// and values in (scalar) registers across chunks -- consecutive interior chunks share one template, so the two dependent scalar
+// round trips (table start, then entries) in front of every chunk's gathers disappear.
+template <int MODE, bool DOT, int RPT, int W, bool UNI, int PROBE = 0, bool SHORT = false>
 __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const int *__restrict__ tstart,
                                                         const int *__restrict__ toff, const double *__restrict__ tval, int ntmpl, int nent, const double *__restrict__ x,
                                                         const double *yin, double *yout, double *dotpart, unsigned long long *tq, unsigned long long launch, long long pf_off)
@@ -1035,6 +1038,8 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
   double    pf = 0.0;
   unsigned  sink = 0;
   int       idn[RPT];  // template ids of the NEXT chunk (one dependent memory round trip less per chunk)
+  int       cid = -1, ccnt = 0, co[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // SHORT: the cached template (wave-uniform values)
+  double    ca[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int rr = 0; rr < RPT; rr++) {
     const long long row = (tk < nloc) ? ((long long)(c0 + tk) * (256 * RPT) + t + rr * 256) : (long long)m;
@@ -1071,7 +1076,51 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
       for (int rr = 0; rr < RPT; rr++) uni = uni && (id[rr] == id0);
       uni = __all(uni);
     }
-    if (UNI && uni) {
+    if (UNI && SHORT && uni) {
+      if (id0 != cid) {  // (wave-uniform branch) a new template: 8 entries in one batch of scalar loads; the tables carry 8 entries of slack
+        const int ts = tstart[id0];
+        ccnt         = tstart[id0 + 1] - ts;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          co[k] = toff[ts + k];
+          ca[k] = tval[ts + k];
+        }
+        cid = id0;
+      }
+      unsigned rb[RPT];
+#pragma unroll
+      for (int rr = 0; rr < RPT; rr++) rb[rr] = (unsigned)(base + t + rr * 256) * 8u;
+      bool got = false;
+#pragma unroll
+      for (int g = 0; g < 8; g += 4) {
+        if (g < ccnt) {  // (wave-uniform) four entries per group: 4 x RPT gathers in flight; entries past the template's end gather
+                         // x[row] (offset 0 in the padded table: a line the row reads anyway) and are never multiplied
+          double xv[4][RPT];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const char *xb = reinterpret_cast<const char *>(x + ((g + e < ccnt) ? co[g + e] : 0));
+#pragma unroll
+            for (int rr = 0; rr < RPT; rr++) xv[e][rr] = *reinterpret_cast<const double *>(xb + rb[rr]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            if (g + e < ccnt) {
+#pragma unroll
+              for (int rr = 0; rr < RPT; rr++) sum[rr] += ca[g + e] * xv[e][rr];
+              if (DOT && co[g + e] == 0) {
+                got = true;
+#pragma unroll
+                for (int rr = 0; rr < RPT; rr++) xrow[rr] = xv[e][rr];
+              }
+            }
+          }
+        }
+      }
+      if (DOT && !got) {
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) xrow[rr] = x[base + t + rr * 256];
+      }
+    } else if (UNI && uni) {
       // every lane of the wave walks the SAME template (interior rows): offsets and values are wave-uniform scalars read from
       // the global table through the scalar cache, the gather address is (x + off) [scalar] + row * 8 [per lane, computed once]:
       // per nonzero the vector unit issues one load, one multiply and one add, nothing else
@@ -1674,8 +1723,10 @@ int build_templates(hipxMat A)
     }
   }
   HIPX_HIP(hipMalloc((void **)&A->d_tstart, sizeof(int) * ((size_t)nt + 1)));
-  HIPX_HIP(hipMalloc((void **)&A->d_toff, sizeof(int) * A->h_toff.size()));
-  HIPX_HIP(hipMalloc((void **)&A->d_tval, sizeof(double) * A->h_tval.size()));
+  HIPX_HIP(hipMalloc((void **)&A->d_toff, sizeof(int) * (A->h_toff.size() + 8)));  // + 8: the SHORT fast path loads 8 entries per template unconditionally
+  HIPX_HIP(hipMalloc((void **)&A->d_tval, sizeof(double) * (A->h_tval.size() + 8)));
+  HIPX_HIP(hipMemsetAsync(A->d_toff, 0, sizeof(int) * (A->h_toff.size() + 8), st));
+  HIPX_HIP(hipMemsetAsync(A->d_tval, 0, sizeof(double) * (A->h_tval.size() + 8), st));
   HIPX_HIP(hipMemcpyAsync(A->d_tstart, A->h_tstart.data(), sizeof(int) * ((size_t)nt + 1), hipMemcpyHostToDevice, st));
   HIPX_HIP(hipMemcpyAsync(A->d_toff, A->h_toff.data(), sizeof(int) * A->h_toff.size(), hipMemcpyHostToDevice, st));
   HIPX_HIP(hipMemcpyAsync(A->d_tval, A->h_tval.data(), sizeof(double) * A->h_tval.size(), hipMemcpyHostToDevice, st));
@@ -1783,7 +1834,13 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
       else if (probe == 5) HIPX_TMPL_LAUNCH_P(5);
       else HIPX_TMPL_LAUNCH_P(6);
 #undef HIPX_TMPL_LAUNCH_P
-    } else HIPX_TMPL_LAUNCH(2, 2, true);
+    } else {
+      static const bool noshort = getenv("HIPX_TMPL_NOSHORT") != nullptr;
+      if (A->tmpl_maxlen <= 8 && !noshort)
+        spmv_tmpl_kernel<MODE, DOT, 2, 2, true, 0, true><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout,
+                                                                                                  dotpart, A->d_tq, launch, pf_off);
+      else HIPX_TMPL_LAUNCH(2, 2, true);
+    }
     break;
   }
   }

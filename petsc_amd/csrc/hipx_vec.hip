@@ -811,9 +811,12 @@ int maxpy_dispatch(double *y, int nv, const double *alpha, const double *const *
   return fail(HIPX_ERR_ARG, "maxpy batch size", __FILE__, __LINE__);
 }
 
-__global__ void red_signal_kernel(unsigned long long *flag, unsigned long long seq, double *results, const double *src, int nvals)
+__global__ void red_signal_kernel(unsigned long long *flag, unsigned long long seq, double *results, const double *src, int nvals, double *dres)
 {
-  for (int v = 0; v < nvals; v++) results[v] = src[v];
+  for (int v = 0; v < nvals; v++) {
+    results[v] = src[v];
+    if (dres) dres[v] = src[v];  // device copy for the kernels queued behind (launch-ahead CG on several ranks)
+  }
   __threadfence_system();
   __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -830,10 +833,10 @@ int hipx::launch_mdot_nosignal(const double *x, int nv, const double *const *y, 
   return ierr;
 }
 
-int hipx::red_signal(int slot, const double *dev_results, int nvals)
+int hipx::red_signal(int slot, const double *dev_results, int nvals, double *dres)
 {
   Runtime &r = rt();
-  red_signal_kernel<<<1, 1, 0, r.compute>>>(r.d_flags + slot, ++r.seq[slot], slot_results_dev(slot), dev_results, nvals);
+  red_signal_kernel<<<1, 1, 0, r.compute>>>(r.d_flags + slot, ++r.seq[slot], slot_results_dev(slot), dev_results, nvals, dres);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -843,6 +846,27 @@ static int launch_cg_fused(double *x, double *r, double *z, const double *p, con
   bool vec = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(p) && aligned16(w) && aligned16(d) && n >= 2;
   if (x) cg_fused_kernel<true, false><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, a, nullptr, nullptr, n, vec, red_out_g(slot));
   else cg_fused_kernel<false, false><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, a, nullptr, nullptr, n, vec, red_out_g(slot));
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+// the launch-ahead update kernel (scalars read from device memory) with its two sums left in device memory, no host signal:
+// an all-reduce follows on the stream (hipx_comm.hip)
+int hipx::launch_cg_fused_dev_nosignal(double *x, double *r, double *z, const double *p, const double *w, const double *d, double dconst, const double *dev_beta, const double *dev_dpi,
+                                       hipx_int n, int slot, double *dev_results)
+{
+  bool vec = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(p) && aligned16(w) && aligned16(d) && n >= 2;
+  const unsigned g = red_grid(n);
+  RedOut         o = red_out(slot, false, nullptr);
+  o.results        = dev_results;
+  hipStream_t st   = rt().compute;
+  if (d) {
+    if (x) cg_fused_kernel<true, true, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o);
+    else cg_fused_kernel<false, true, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o);
+  } else {
+    if (x) cg_fused_kernel<true, true, true><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o, dconst);
+    else cg_fused_kernel<false, true, true><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o, dconst);
+  }
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }

@@ -277,6 +277,19 @@ int HipxKSPCGBegin(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double
    convergence (cg.c:326-328).  What has been enqueued ahead when the loop stops is harmless: A(i+1) applies exactly the x
    update of iteration i that was due anyway, B and C only touch work vectors (x is never written by C).  The arithmetic and
    its order are those of the plain loop: histories and x are bit-identical to pipeline = 0. */
+/* B(i) and C(i) of the launch-ahead loop on one rank or on several (then with the all-reduce on the stream, hipx_comm.hip) */
+static int mm_dot_begin(HipxMat *A, const double *p, double *w, int slot, double *dev_dot)
+{
+  if (A->nranks > 1) return hipxMatMultMPIDotBegin(A->A, A->B, A->halo, p, A->lvec, w, A->m, slot, dev_dot);
+  return hipxMatMultDotBegin(A->A, p, w, slot, dev_dot);
+}
+static int fused_update_begin(HipxMat *A, double *r, double *z, const double *p, const double *w, const double *d, double dconst, const double *dev_beta, const double *dev_dpi, hipx_int n, int slot,
+                              double *dev_sums2)
+{
+  if (A->nranks > 1) return hipxCGFusedUpdateBeginAllreduce(NULL, r, z, p, w, d, dconst, dev_beta, dev_dpi, n, slot, dev_sums2);
+  return hipxCGFusedUpdateBegin(NULL, r, z, p, w, d, dconst, dev_beta, dev_dpi, n, slot, dev_sums2);
+}
+
 static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double *X, hipx_int nsteps)
 {
   const hipx_int n = A->m;
@@ -311,8 +324,8 @@ static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double 
           ksp->x_pending = 0;
         } else CHK(hipxVecAYPX(P, b, Z, n)); /* cg.c:249 */
       }
-      CHK(hipxMatMultDotBegin(A->A, P, W, SLOT_DOT, ds));
-      CHK(hipxCGFusedUpdateBegin(NULL, R, dcon ? NULL : Z, P, W, dcon ? NULL : pc->dinv, pc->dconst, dbeta_i, ds, n, SLOT_SUMS + q, ds + 2 + 2 * q));
+      CHK(mm_dot_begin(A, P, W, SLOT_DOT, ds));
+      CHK(fused_update_begin(A, R, dcon ? NULL : Z, P, W, dcon ? NULL : pc->dinv, pc->dconst, dbeta_i, ds, n, SLOT_SUMS + q, ds + 2 + 2 * q));
     }
     ahead  = 0;
     dpiold = ksp->dpi;
@@ -332,8 +345,8 @@ static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double 
     if (s + 1 < nsteps && i + 1 < ksp->max_it) { /* enqueue iteration i+1 while C(i) runs */
       double *dbeta_n = ds + 3 + 2 * q; /* z.r of iteration i, written by C(i) */
       CHK(hipxCGAypxAxpyDev(P, dcon ? NULL : Z, R, pc->dconst, X, dbeta_n, dbeta_i, ds, n));
-      CHK(hipxMatMultDotBegin(A->A, P, W, SLOT_DOT, ds));
-      CHK(hipxCGFusedUpdateBegin(NULL, R, dcon ? NULL : Z, P, W, dcon ? NULL : pc->dinv, pc->dconst, dbeta_n, ds, n, SLOT_SUMS + (1 - q), ds + 2 + 2 * (1 - q)));
+      CHK(mm_dot_begin(A, P, W, SLOT_DOT, ds));
+      CHK(fused_update_begin(A, R, dcon ? NULL : Z, P, W, dcon ? NULL : pc->dinv, pc->dconst, dbeta_n, ds, n, SLOT_SUMS + (1 - q), ds + 2 + 2 * (1 - q)));
       ahead          = 1;
       ksp->x_pending = 0; /* A(i+1) applies it */
     }
@@ -370,7 +383,9 @@ int HipxKSPCGStep(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double 
      SpMV + dot fusion: only without an off-diagonal block (the dot needs the complete w) */
   const int      fused_upd = ksp->fused && pc->type == HIPX_PC_JACOBI && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED;
   const int      fused     = fused_upd && !A->B && A->nranks <= 1;
-  if (fused && ksp->pipeline && n > 0) return cg_step_pipelined(ksp, A, pc, B, X, nsteps);
+  /* launch-ahead form: one rank (SpMV + dot fused), or several ranks with a device ghost exchange (round 3: the all-reduces complete
+     on the stream, see mm_dot_begin / fused_update_begin); ksp->pipeline == 2 keeps several ranks on the host-synchronised loop */
+  if (ksp->pipeline && n > 0 && (fused || (fused_upd && A->nranks > 1 && A->B && A->halo && ksp->pipeline != 2))) return cg_step_pipelined(ksp, A, pc, B, X, nsteps);
   for (hipx_int s = 0; s < nsteps && !ksp->reason && ksp->i < ksp->max_it; s++) {
     const hipx_int i = ksp->i;
     ksp->its = i + 1;

@@ -33,7 +33,8 @@ typedef struct {
   hipxCOO          cooA, cooB; /* device copies of Ajmap1/Aperm1 and Bjmap1/Bperm1 (MatCOOStruct_MPIAIJ, mpiaij.h:62-89) */
   PetscBool        coo_local;  /* no rank sends or receives COO entries: MatSetValuesCOO runs on the device */
   hipxHalo         halo;
-  PetscInt         transport; /* 0 host, 1 ipc, 2 rccl */
+  PetscSF          sf;        /* transport 3: a PetscSF of type hipx with Mvctx's graph */
+  PetscInt         transport; /* 0 host, 1 ipc, 2 rccl, 3 PetscSF type hipx */
   PetscObjectState nzstate;   /* nonzero state the plan was built from */
 } Mat_MPIAIJHIPX;
 
@@ -53,6 +54,7 @@ static PetscErrorCode MatMPIAIJHIPXBuildHalo(Mat A)
 
   PetscFunctionBegin;
   if (h->halo) PetscCallHIPX(hipxHaloDestroy(&h->halo));
+  PetscCall(PetscSFDestroy(&h->sf));
   h->transport = 0;
   h->nzstate   = A->nonzerostate;
   PetscCallMPI(MPI_Comm_rank(comm, &rank));
@@ -62,8 +64,10 @@ static PetscErrorCode MatMPIAIJHIPXBuildHalo(Mat A)
   if (size == 1 || !a->Mvctx || !strcmp(want, "host")) PetscFunctionReturn(PETSC_SUCCESS);
   if (!strcmp(want, "sf")) { /* the exchange through the PetscSF interface: Mvctx becomes a PetscSF of type hipx (sfhipx.c), MatMult hands it
                                 device pointers (PetscSFBcastWithMemTypeBegin / End around the diagonal-block product, mpiaij.c:1056-1059) */
-    PetscCall(PetscSFSetType(a->Mvctx, PETSCSFHIPX));
-    PetscCall(PetscSFSetUp(a->Mvctx));
+    PetscCall(PetscSFDestroy(&h->sf));
+    PetscCall(PetscSFDuplicate(a->Mvctx, PETSCSF_DUPLICATE_GRAPH, &h->sf)); /* the same star forest (roots = owned x, leaves = lvec), not set up yet ... */
+    PetscCall(PetscSFSetType(h->sf, PETSCSFHIPX));                           /* ... so its type can still be chosen (Mvctx itself stays the host fall-back) */
+    PetscCall(PetscSFSetUp(h->sf));
     h->transport = 3;
     PetscCall(PetscInfo(A, "MATMPIAIJHIPX ghost exchange through PetscSF type hipx\n"));
     PetscFunctionReturn(PETSC_SUCCESS);
@@ -121,7 +125,7 @@ static PetscErrorCode MatMultAdd_MPIAIJHIPX_Private(Mat A, Vec xx, Vec yy, Vec z
   PetscCall(VecHIPXGetDeviceRead(xx, &x, &tx));
   PetscCall(VecHIPXGetDeviceWrite(a->lvec, &lv, &tl));
   if (h->transport == 3) { /* mpiaij.c:1056-1059 / 1078-1081 with the scatter = PetscSF hipx on device buffers */
-    PetscCall(PetscSFBcastWithMemTypeBegin(a->Mvctx, MPIU_SCALAR, PETSC_MEMTYPE_HIP, x, PETSC_MEMTYPE_HIP, lv, MPI_REPLACE));
+    PetscCall(PetscSFBcastWithMemTypeBegin(h->sf, MPIU_SCALAR, PETSC_MEMTYPE_HIP, x, PETSC_MEMTYPE_HIP, lv, MPI_REPLACE));
     if (!yy) {
       PetscCall(VecHIPXGetDeviceWrite(zz, &z, &tz));
       PetscCallHIPX(hipxMatMult(dA, x, z));
@@ -134,7 +138,7 @@ static PetscErrorCode MatMultAdd_MPIAIJHIPX_Private(Mat A, Vec xx, Vec yy, Vec z
       PetscCallHIPX(hipxMatMultAdd(dA, x, y, z));
       PetscCall(VecHIPXRestoreDeviceRead(yy, &y, &ty));
     }
-    PetscCall(PetscSFBcastEnd(a->Mvctx, MPIU_SCALAR, x, lv, MPI_REPLACE));
+    PetscCall(PetscSFBcastEnd(h->sf, MPIU_SCALAR, x, lv, MPI_REPLACE));
     PetscCallHIPX(hipxMatMultAdd(dB, lv, z, z));
   } else if (!yy) {
     PetscCall(VecHIPXGetDeviceWrite(zz, &z, &tz));
@@ -287,6 +291,7 @@ static PetscErrorCode MatDestroy_MPIAIJHIPX(Mat A)
 
   PetscFunctionBegin;
   if (h->halo) PetscCallHIPX(hipxHaloDestroy(&h->halo));
+  PetscCall(PetscSFDestroy(&h->sf));
   if (h->cooA) PetscCallHIPX(hipxCOODestroy(&h->cooA));
   if (h->cooB) PetscCallHIPX(hipxCOODestroy(&h->cooB));
   PetscCall(PetscObjectComposeFunction((PetscObject)A, "MatSetPreallocationCOO_C", NULL));

@@ -62,3 +62,19 @@ def test_self_launch_two_ranks_weak_with_golden():
     assert r.returncode == 0, r.stdout[-3000:]
     d = last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["parity_gate"]["pass"] is True and d["parity_gate"]["max_rel_diff"] <= 1e-12  # cg_none_7pt_64x64x16
+
+
+def test_launch_ahead_cg_on_two_ranks_equals_host_synchronised_loop():
+    """Round 3: the fused CG runs launch-ahead on several ranks too (the all-reduces complete on the stream and feed device-resident
+    scalars: hipxMatMultMPIDotBegin, hipxCGFusedUpdateBeginAllreduce).  Same arithmetic as the host-synchronised loop
+    (--pipeline 2): identical residual after the timed steps, identical distance to the committed exact-reduction history."""
+    out = {}
+    for pipe in ("1", "2"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "64", "--steps", "25", "--warmup", "4", "--quick", "--pipeline", pipe],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=clean_env(), cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-3000:]
+        out[pipe] = last_json(r.stdout)
+    a, b = out["1"], out["2"]
+    assert a["parity_gate"]["pass"] is True and b["parity_gate"]["pass"] is True
+    assert a["config"]["residual_norm_after"] == b["config"]["residual_norm_after"]
+    assert a["parity_gate"]["max_rel_diff"] == b["parity_gate"]["max_rel_diff"]
