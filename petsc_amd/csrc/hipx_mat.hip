@@ -81,6 +81,11 @@ struct hipxMat_s {
   int       probe      = 0;   // phase-attribution probe kernels (scripts/spmv_variants.py); results are NOT A x
   std::vector<int64_t> h_i;  // host copy of the row offsets (set-up only)
   void     *sor_state = nullptr;  // hipxSorState, owned by hipx_sor.hip
+  // pattern templates (variant 29): the rows' (column - row) lists only -- <= 256 distinct ones; the values stay in a[] and are streamed
+  bool           ptm_ready = false, ptm_ok = false, ptm_build = false;  // ptm_build: build_templates() is running in pattern-only mode
+  int            ptm_mode = 0, ptm_ntmpl = 0, ptm_nent = 0, ptm_maxlen = 0;
+  unsigned char *d_ptid    = nullptr;
+  int           *d_ptstart = nullptr, *d_ptoff = nullptr;
   void     *sell_state = nullptr; // SellState, owned by hipx_sell.hip (variant 28: sliced-ELLPACK copy)
   int       sell_mode  = 0;
   unsigned long long value_state = 1;
@@ -734,6 +739,89 @@ __global__ __launch_bounds__(256) void spmv_vd_kernel(const PkDesc *__restrict__
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pattern-template SpMV ("tp", variant 29): spmv_pk16r_kernel without column codes.  The column of a row's k-th entry is
+// row + toff[tstart[id] + k] with id = ptid[row] (one byte per row, <= 256 distinct (column - row) lists: stencil PATTERNS with any
+// values); the values are streamed from a[] exactly as in the CSR kernels.  Matrix bytes per launch: 8 nnz + (1 + 4) N against
+// 12 nnz + 4 N of CSR and 10 nnz + 4 N of the packed-column kernels.  Phase 1 copies the row block's values to LDS (coalesced),
+// phase 2 lets thread t walk row t left to right (value from LDS, offset from the table -- neighbouring lanes share the pattern,
+// so the table read is one cache line per wave --, x through the gather: x[row + offset] of 64 consecutive rows = 4-5 lines).
+// Same products, same order: y is bit-identical.
+template <typename IT, int MODE, bool DOT>
+__global__ __launch_bounds__(256) void spmv_tp_kernel(const hipx_int *__restrict__ rb, hipx_int nblocks, hipx_int blocks_per_xcd, const IT *__restrict__ ai, const unsigned char *__restrict__ ptid,
+                                                      const int *__restrict__ tstart, const int *__restrict__ toff, const double *__restrict__ aa, const double *__restrict__ x, const double *yin,
+                                                      double *yout, double *dotpart)
+{
+  constexpr int THREADS = 256, CAP = 2048;
+  __shared__ double vals[CAP];
+  const hipx_int bid = (hipx_int)blockIdx.x;
+  const hipx_int b   = (bid & 7) * blocks_per_xcd + (bid >> 3);
+  double         mydot = 0.0;
+  if (b < nblocks) {
+    const hipx_int r0 = rb[b], r1 = rb[b + 1];
+    const IT       k0 = ai[r0], k1 = ai[r1];
+    const IT       ka = k0 & ~(IT)3;
+    const int      t  = threadIdx.x;
+    const hipx_int row = r0 + t;
+    IT             rs = 0, re = 0;
+    int            ts = 0;
+    if (row < r1) {
+      rs = ai[row];
+      re = ai[row + 1];
+      ts = tstart[ptid[row]];
+    }
+    const double xrow = (DOT && row < r1) ? x[row] : 0.0;
+    const IT     nq  = (k1 - ka + 3) >> 2;  // (row blocks hold <= CAP entries: patterns longer than 1024 entries never get here)
+    constexpr int NIT = CAP / 4 / THREADS;
+    if (nq > 0) {
+      const dbl2 *a2 = reinterpret_cast<const dbl2 *>(aa + ka);
+      dbl2        va[NIT], vb[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const IT q  = (IT)t + (IT)it * THREADS;
+        const IT qc = q < nq ? q : nq - 1;
+        va[it]      = a2[2 * qc];
+        vb[it]      = a2[2 * qc + 1];
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const IT q = (IT)t + (IT)it * THREADS;
+        if (q < nq) {
+          reinterpret_cast<dbl2 *>(vals)[2 * q]     = va[it];
+          reinterpret_cast<dbl2 *>(vals)[2 * q + 1] = vb[it];
+        }
+      }
+    }
+    __syncthreads();
+    if (row < r1) {
+      const int  len = (int)(re - rs);
+      const int  s0  = (int)(rs - ka);
+      const int *to  = toff + ts;
+      double     sum = (MODE == 1) ? yin[row] : 0.0;
+      for (int k = 0; k < len; k += 4) {
+        double xv[4], av[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const bool on = (k + e) < len;
+          const int  kk = on ? k + e : 0;
+          av[e]         = vals[s0 + kk];
+          xv[e]         = x[(long long)row + to[kk]];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if ((k + e) < len) sum += av[e] * xv[e];
+      }
+      yout[row] = sum;
+      if (DOT) mydot = xrow * sum;
+    }
+  }
+  if (DOT) {
+    const double w = hipx::wave_sum(mydot);
+    if ((threadIdx.x & 63) == 0) dotpart[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = w;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Set-up of the packed formats ON THE DEVICE (once per nonzero pattern / value state; ~1 ms at 117 M nonzeros, where the
 // first host-side version needed 1.4 GB of D2H copies and 0.5 s of host work).
@@ -913,14 +1001,14 @@ __device__ __forceinline__ unsigned long long tm_mix(unsigned long long h, unsig
 
 template <typename IT>
 __global__ __launch_bounds__(256) void tmpl_hash_kernel(hipx_int m, const IT *__restrict__ ai, const hipx_int *__restrict__ aj, const unsigned long long *__restrict__ aa,
-                                                        unsigned long long *__restrict__ hash)
+                                                        unsigned long long *__restrict__ hash, int with_values)
 {
   for (hipx_int r = (hipx_int)blockIdx.x * 256 + threadIdx.x; r < m; r += (hipx_int)gridDim.x * 256) {
     const IT           s = ai[r], e = ai[r + 1];
     unsigned long long h = tm_mix(0x243F6A8885A308D3ull, (unsigned long long)(e - s));
     for (IT k = s; k < e; k++) {
       h = tm_mix(h, (unsigned long long)(unsigned)(aj[k] - r));
-      h = tm_mix(h, aa[k]);
+      if (with_values) h = tm_mix(h, aa[k]);
     }
     if (h == VD_EMPTY) h ^= 1;
     hash[r] = h;
@@ -961,7 +1049,7 @@ __global__ __launch_bounds__(256) void tmpl_assign_kernel(hipx_int m, const unsi
 template <typename IT>
 __global__ __launch_bounds__(256) void tmpl_verify_kernel(hipx_int m, hipx_int ncols, const IT *__restrict__ ai, const hipx_int *__restrict__ aj, const unsigned long long *__restrict__ aa,
                                                           const unsigned char *__restrict__ tid, const int *__restrict__ tstart, const int *__restrict__ toff,
-                                                          const unsigned long long *__restrict__ tval, unsigned int *bad)
+                                                          const unsigned long long *__restrict__ tval, unsigned int *bad, int with_values)
 {
   for (hipx_int r = (hipx_int)blockIdx.x * 256 + threadIdx.x; r < m; r += (hipx_int)gridDim.x * 256) {
     const IT  s = ai[r], e = ai[r + 1];
@@ -970,7 +1058,7 @@ __global__ __launch_bounds__(256) void tmpl_verify_kernel(hipx_int m, hipx_int n
     if (ok)
       for (int k = 0; k < te - ts; k++) {
         const long long c = (long long)r + toff[ts + k];
-        ok = ok && (aj[s + k] - r) == toff[ts + k] && aa[s + k] == tval[ts + k] && c >= 0 && c < ncols;
+        ok = ok && (aj[s + k] - r) == toff[ts + k] && (!with_values || aa[s + k] == tval[ts + k]) && c >= 0 && c < ncols;
       }
     if (!ok) atomicAdd(bad, 1u);
   }
@@ -986,10 +1074,7 @@ __global__ __launch_bounds__(256) void tmpl_verify_kernel(hipx_int m, hipx_int n
 // folded into +-4096 doubles of the row (same number of distinct lines per gather, all of them recently touched: no far-plane HBM stream);
 // 4 = correct results, but the chunks are assigned statically (round robin over the XCD's workgroups): no ticket atomics, no barriers;
 // 5 = 4 without the first-touch prefetch; 6 = 5 without the template-id loads (id 0 everywhere: wrong rows at the boundaries)
-// SHORT: no template has more than 8 entries (5-/7-point operators): the wave-uniform fast path keeps the current template's offsets
-// and values in (scalar) registers across chunks -- consecutive interior chunks share one template, so the two dependent scalar
-// round trips (table start, then entries) in front of every chunk's gathers disappear.
-template <int MODE, bool DOT, int RPT, int W, bool UNI, int PROBE = 0, bool SHORT = false>
+template <int MODE, bool DOT, int RPT, int W, bool UNI, int PROBE = 0>
 __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const int *__restrict__ tstart,
                                                         const int *__restrict__ toff, const double *__restrict__ tval, int ntmpl, int nent, const double *__restrict__ x,
                                                         const double *yin, double *yout, double *dotpart, unsigned long long *tq, unsigned long long launch, long long pf_off)
@@ -1038,8 +1123,6 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
   double    pf = 0.0;
   unsigned  sink = 0;
   int       idn[RPT];  // template ids of the NEXT chunk (one dependent memory round trip less per chunk)
-  int       cid = -1, ccnt = 0, co[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // SHORT: the cached template (wave-uniform values)
-  double    ca[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int rr = 0; rr < RPT; rr++) {
     const long long row = (tk < nloc) ? ((long long)(c0 + tk) * (256 * RPT) + t + rr * 256) : (long long)m;
@@ -1076,51 +1159,7 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
       for (int rr = 0; rr < RPT; rr++) uni = uni && (id[rr] == id0);
       uni = __all(uni);
     }
-    if (UNI && SHORT && uni) {
-      if (id0 != cid) {  // (wave-uniform branch) a new template: 8 entries in one batch of scalar loads; the tables carry 8 entries of slack
-        const int ts = tstart[id0];
-        ccnt         = tstart[id0 + 1] - ts;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          co[k] = toff[ts + k];
-          ca[k] = tval[ts + k];
-        }
-        cid = id0;
-      }
-      unsigned rb[RPT];
-#pragma unroll
-      for (int rr = 0; rr < RPT; rr++) rb[rr] = (unsigned)(base + t + rr * 256) * 8u;
-      bool got = false;
-#pragma unroll
-      for (int g = 0; g < 8; g += 4) {
-        if (g < ccnt) {  // (wave-uniform) four entries per group: 4 x RPT gathers in flight; entries past the template's end gather
-                         // x[row] (offset 0 in the padded table: a line the row reads anyway) and are never multiplied
-          double xv[4][RPT];
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const char *xb = reinterpret_cast<const char *>(x + ((g + e < ccnt) ? co[g + e] : 0));
-#pragma unroll
-            for (int rr = 0; rr < RPT; rr++) xv[e][rr] = *reinterpret_cast<const double *>(xb + rb[rr]);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            if (g + e < ccnt) {
-#pragma unroll
-              for (int rr = 0; rr < RPT; rr++) sum[rr] += ca[g + e] * xv[e][rr];
-              if (DOT && co[g + e] == 0) {
-                got = true;
-#pragma unroll
-                for (int rr = 0; rr < RPT; rr++) xrow[rr] = xv[e][rr];
-              }
-            }
-          }
-        }
-      }
-      if (DOT && !got) {
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++) xrow[rr] = x[base + t + rr * 256];
-      }
-    } else if (UNI && uni) {
+    if (UNI && uni) {
       // every lane of the wave walks the SAME template (interior rows): offsets and values are wave-uniform scalars read from
       // the global table through the scalar cache, the gather address is (x + off) [scalar] + row * 8 [per lane, computed once]:
       // per nonzero the vector unit issues one load, one multiply and one add, nothing else
@@ -1224,6 +1263,226 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
     }
   }
   (void)mydot;
+  if (sink == 0xffffffffu) yout[0] = pf;  // never true: keeps the prefetch loads alive
+}
+
+
+// Template SpMV, second form (round 3).  Same storage and arithmetic as spmv_tmpl_kernel; what changes is how a workgroup gets its
+// chunks and WHEN a wave issues its long-latency requests.  Vector memory operations of a wave return in order, so a wait for this
+// chunk's gathers (L2 hits: the x planes were touched a round ago) also waits for everything issued BEFORE them -- in the first form the
+// ticket atomic (whose result the compiler's atomic optimiser wants at once), the template ids of the next chunk (a stream nobody has
+// touched: an HBM round trip) and the first-touch prefetch; and each __syncthreads() drains the wave's loads (s_waitcnt vmcnt(0) in
+// front of s_barrier).  Probes on the MI355X (7-pt 256^3, profiles/r03_tmpl_probes.txt): dropping the y stores, turning every gather
+// into a same-line access or folding the far offsets changes nothing (0.116-0.120 ms against 0.120): a chunk costs ~7 us of WAITING.
+// Here:
+//   * static round-robin chunks (workgroup j of an XCD takes chunks j, j + W, j + 2W ... of the XCD's slab: no ticket, no barrier, no
+//     LDS hand-over) with a drift throttle instead of the queue: every finished chunk bumps a per-XCD counter (an atomic WITHOUT
+//     return), and a workgroup that is more than LAG rounds ahead of the counter polls it -- the planes of x the resident workgroups
+//     touch stay inside the XCD's L2 as with the queue (a plain static map lets them drift: 2.6x the traffic);
+//   * the template ids are loaded DEPTH chunks ahead and, like the first-touch prefetch (now for the workgroup's own next chunk) and
+//     the throttle's poll, issued right BEHIND the chunk's last gather group: the gathers' wait leaves them in flight and they have
+//     whole chunks of time to land.
+//   * PFW (a fifth wave per workgroup, HIPX_TMPL_PFW=1): whatever a compute wave loads late still costs it an HBM round trip at the top of
+//     the next chunk (the compiler drains the wave's counter where it cannot count across the loop edge).  The prefetch wave touches,
+//     two rounds ahead of the workgroup's compute waves (progress word in LDS), the template-id lines and the farthest forward x lines of
+//     the chunks to come and waits for them itself: the compute waves then only ever see L2 hits.
+template <int MODE, bool DOT, int W, bool UNI, bool PFW>
+__global__ __launch_bounds__(PFW ? 320 : 256) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmv_tmpl2_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const int *__restrict__ tstart,
+                                                         const int *__restrict__ toff, const double *__restrict__ tval, int ntmpl, int nent, const double *__restrict__ x,
+                                                         const double *yin, double *yout, double *dotpart, unsigned long long *tq, unsigned long long launch, long long pf_far, int lag)
+{
+  constexpr int RPT = 2, DEPTH = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s_val   = reinterpret_cast<double *>(smem);
+  int    *s_off   = reinterpret_cast<int *>(smem + 8 * (size_t)((nent + 1) & ~1));
+  int    *s_start = s_off + ((nent + 3) & ~3);
+  const int t = threadIdx.x;
+  __shared__ int s_round;
+  if (t < 256) {
+    for (int k = t; k < nent; k += 256) {
+      s_val[k] = tval[k];
+      s_off[k] = toff[k];
+    }
+    for (int k = t; k <= ntmpl; k += 256) s_start[k] = tstart[k];
+  }
+  if (t == 0) s_round = 0;
+  __syncthreads();
+  const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, bpx = (hipx_int)gridDim.x >> 3, j = bid >> 3;
+  const hipx_int c0 = xcd * chunks_per_xcd, c1 = (c0 + chunks_per_xcd < nchunks) ? c0 + chunks_per_xcd : nchunks;
+  const long long     nloc = (long long)(c1 > c0 ? c1 - c0 : 0);
+  unsigned int  *done  = reinterpret_cast<unsigned int *>(tq + (size_t)xcd * 8);  // chunks finished in this XCD's slab, all launches (mod 2^32)
+  const unsigned dbase = (unsigned)(launch * (unsigned long long)nloc);           // ... of which the earlier launches account for this many
+  auto chunk_row = [&](long long q, int rr) -> long long { return (q < nloc) ? ((long long)(c0 + q) * (256 * RPT) + t + rr * 256) : (long long)m; };
+  if (PFW && t >= 256) {  // the prefetch wave
+    const int lane = t - 256;
+    constexpr int AHEAD = 2;
+    unsigned  acc = 0;
+    long long r = 0;
+    for (long long q = j; q < nloc; q += bpx, r++) {
+      for (int spin = 0; spin < 100000 && r > (long long)__hip_atomic_load(&s_round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + AHEAD; spin++) __builtin_amdgcn_s_sleep(1);
+      const long long base = (long long)(c0 + q) * (256 * RPT);
+      if (lane < 4) {  // the chunk's 512 template ids: four 128-byte lines
+        const long long r0 = base + (long long)lane * 128;
+        if (r0 < m) acc += tid[r0];
+      } else if (lane < 4 + 16 * RPT && pf_far) {  // the farthest forward x lines of the chunk: 512 doubles = 32 lines
+        const long long prow = base + pf_far + (long long)(lane - 4) * 16;
+        if (prow < (long long)m) acc += (unsigned)__double_as_longlong(x[prow]);
+      }
+    }
+    if (acc == 0x9e3779b9u && nloc < 0) yout[0] = 0.0;  // never true: keeps the loads alive
+    return;
+  }
+  int idq[DEPTH + 1][RPT];  // template ids of the chunks q, q + bpx, ... (q + DEPTH bpx is loaded while q is processed)
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) {
+      const long long r_ = chunk_row((long long)j + (long long)d * bpx, rr);
+      idq[d][rr]         = (r_ < m) ? tid[r_] : 0;
+    }
+  double             pf = 0.0;
+  unsigned           sink = 0;
+  unsigned           seen = dbase;  // the counter as this wave last saw it
+  long long          round = 0;
+  for (long long q = j; q < nloc; q += bpx, round++) {
+    if (lag > 0 && round > lag) {  // drift throttle (a locality heuristic, never needed for correctness: bounded spinning)
+      const unsigned need = dbase + (unsigned)(round - lag) * (unsigned)bpx;
+      for (int spin = 0; (int)(seen - need) < 0 && spin < 2000; spin++) {
+        __builtin_amdgcn_s_sleep(2);
+        seen = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    const hipx_int c    = c0 + (hipx_int)q;
+    const hipx_int base = c * (256 * RPT);
+    double         sum[RPT], xrow[RPT];
+    bool           uni = UNI && (base + 256 * RPT <= m) && ((unsigned long long)m < (1ull << 28));
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) {
+      const hipx_int row = base + t + rr * 256;
+      sum[rr]  = 0.0;
+      xrow[rr] = 0.0;
+      if (row < m && MODE == 1) sum[rr] = yin[row];
+    }
+    // the requests nothing in THIS chunk waits for
+    auto issue_ahead = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rr = 0; rr < RPT; rr++) {
+        const long long r2 = chunk_row(q + (long long)DEPTH * bpx, rr);
+        idq[DEPTH][rr]     = (r2 < m) ? tid[r2] : 0;
+      }
+      if (!PFW && pf_far && t < 16 * RPT) {  // first touch of the farthest forward x lines of this workgroup's NEXT chunk
+        const long long prow = (long long)base + (long long)bpx * (256 * RPT) + pf_far + (long long)t * 16;
+        if (prow < (long long)m) pf = x[prow];
+      }
+      if (lag > 0) seen = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (one address per wave: one request)
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    int id0 = 0;
+    if (UNI) {
+      id0 = __builtin_amdgcn_readfirstlane(idq[0][0]);
+#pragma unroll
+      for (int rr = 0; rr < RPT; rr++) uni = uni && (idq[0][rr] == id0);
+      uni = __all(uni);
+    }
+    if (UNI && uni) {
+      const int ts = tstart[id0], te = tstart[id0 + 1];
+      unsigned  rb[RPT];
+#pragma unroll
+      for (int rr = 0; rr < RPT; rr++) rb[rr] = (unsigned)(base + t + rr * 256) * 8u;
+      bool got = false;
+      for (int k = ts; k < te; k += 4) {  // groups of four entries (the tables carry 4 entries of slack: offset 0, never multiplied)
+        double a[4], xv[4][RPT];
+        int    o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          a[e] = tval[k + e];
+          o[e] = toff[k + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const char *xb = reinterpret_cast<const char *>(x + ((k + e < te) ? o[e] : 0));
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++) xv[e][rr] = *reinterpret_cast<const double *>(xb + rb[rr]);
+        }
+        if (k + 4 >= te) issue_ahead();  // behind the LAST group's gathers
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          if (k + e < te) {
+#pragma unroll
+            for (int rr = 0; rr < RPT; rr++) sum[rr] += a[e] * xv[e][rr];
+            if (DOT && o[e] == 0) {
+              got = true;
+#pragma unroll
+              for (int rr = 0; rr < RPT; rr++) xrow[rr] = xv[e][rr];
+            }
+          }
+        }
+      }
+      if (te <= ts) issue_ahead();
+      if (DOT && !got) {
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) xrow[rr] = x[base + t + rr * 256];
+      }
+    } else {
+      int s0[RPT], len[RPT], maxlen = 0;
+#pragma unroll
+      for (int rr = 0; rr < RPT; rr++) {
+        const hipx_int row = base + t + rr * 256;
+        s0[rr]  = 0;
+        len[rr] = 0;
+        if (row < m) {
+          s0[rr]  = s_start[idq[0][rr]];
+          len[rr] = s_start[idq[0][rr] + 1] - s0[rr];
+          if (DOT) xrow[rr] = x[row];
+        }
+        maxlen = max(maxlen, len[rr]);
+      }
+      for (int k = 0; k < maxlen; k += W) {
+        double xv[RPT][W], av[RPT][W];
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) {
+          const hipx_int row = base + t + rr * 256;
+#pragma unroll
+          for (int e = 0; e < W; e++) {
+            const bool on  = (k + e) < len[rr];
+            const int  idx = on ? s0[rr] + k + e : 0;
+            av[rr][e]      = s_val[idx];
+            xv[rr][e]      = on ? x[row + s_off[idx]] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) {
+#pragma unroll
+          for (int e = 0; e < W; e++)
+            if ((k + e) < len[rr]) sum[rr] += av[rr][e] * xv[rr][e];
+        }
+      }
+      issue_ahead();
+    }
+    double cdot = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) {
+      const hipx_int row = base + t + rr * 256;
+      if (row < m) {
+        yout[row] = sum[rr];
+        if (DOT) cdot += xrow[rr] * sum[rr];
+      }
+    }
+    if (DOT) {
+      const double w = hipx::wave_sum(cdot);
+      if ((threadIdx.x & 63) == 0) dotpart[(size_t)c * 4 + (threadIdx.x >> 6)] = w;
+    }
+    if (t == 0) {
+      __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // result unused: an atomic without return
+      if (PFW) __hip_atomic_store(&s_round, (int)round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+      for (int rr = 0; rr < RPT; rr++) idq[d][rr] = idq[d + 1][rr];
+    sink += (__double_as_longlong(pf) == 0x7ff8123456789abcLL) ? 1u : 0u;
+  }
   if (sink == 0xffffffffu) yout[0] = pf;  // never true: keeps the prefetch loads alive
 }
 
@@ -1662,7 +1921,7 @@ int build_templates(hipxMat A)
   HIPX_HIP(hipMalloc((void **)&d_cnt, sizeof(unsigned int) * 2));
   HIPX_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * 2, st));
   const unsigned g = (unsigned)std::min<hipx_int>((m + 255) / 256, 8192);
-  tmpl_hash_kernel<IT><<<g, 256, 0, st>>>(m, (const IT *)A->d_i, A->d_j, (const unsigned long long *)A->d_a, d_hash);
+  tmpl_hash_kernel<IT><<<g, 256, 0, st>>>(m, (const IT *)A->d_i, A->d_j, (const unsigned long long *)A->d_a, d_hash, A->ptm_build ? 0 : 1);
   vd_collect_kernel<<<grid, 256, 0, st>>>(d_hash, (long long)m, d_list, d_cnt, cap);
   unsigned int hc[2] = {0, 0};
   HIPX_HIP(hipMemcpyAsync(hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
@@ -1723,7 +1982,7 @@ int build_templates(hipxMat A)
     }
   }
   HIPX_HIP(hipMalloc((void **)&A->d_tstart, sizeof(int) * ((size_t)nt + 1)));
-  HIPX_HIP(hipMalloc((void **)&A->d_toff, sizeof(int) * (A->h_toff.size() + 8)));  // + 8: the SHORT fast path loads 8 entries per template unconditionally
+  HIPX_HIP(hipMalloc((void **)&A->d_toff, sizeof(int) * (A->h_toff.size() + 8)));
   HIPX_HIP(hipMalloc((void **)&A->d_tval, sizeof(double) * (A->h_tval.size() + 8)));
   HIPX_HIP(hipMemsetAsync(A->d_toff, 0, sizeof(int) * (A->h_toff.size() + 8), st));
   HIPX_HIP(hipMemsetAsync(A->d_tval, 0, sizeof(double) * (A->h_tval.size() + 8), st));
@@ -1732,7 +1991,7 @@ int build_templates(hipxMat A)
   HIPX_HIP(hipMemcpyAsync(A->d_tval, A->h_tval.data(), sizeof(double) * A->h_tval.size(), hipMemcpyHostToDevice, st));
   HIPX_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * 2, st));
   tmpl_verify_kernel<IT><<<g, 256, 0, st>>>(m, A->n, (const IT *)A->d_i, A->d_j, (const unsigned long long *)A->d_a, A->d_tid, A->d_tstart, A->d_toff,
-                                             (const unsigned long long *)A->d_tval, d_cnt);
+                                             (const unsigned long long *)A->d_tval, d_cnt, A->ptm_build ? 0 : 1);
   HIPX_HIP(hipMemcpyAsync(hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
   HIPX_HIP(hipStreamSynchronize(st));
   HIPX_LAUNCH_CHECK();
@@ -1754,6 +2013,79 @@ int ensure_templates(hipxMat A)
   if (A->compressed || A->nrows_c <= 0 || A->nnz <= 0) return HIPX_SUCCESS;
   int ierr = A->is64 ? build_templates<int64_t>(A) : build_templates<hipx_int>(A);
   if (ierr || !A->tmpl_ok) free_templates(A);
+  return ierr;
+}
+
+
+// Pattern templates (variant 29): the same device passes as the row templates with the values left out of the hash and of the
+// verification, so a matrix with ARBITRARY values on a stencil pattern qualifies (variable-coefficient operators).  build_templates()
+// writes into the row-template fields: they are stashed, the build runs in pattern-only mode, its result moves to the ptm fields.
+void free_pattern_templates(hipxMat A)
+{
+  (void)hipFree(A->d_ptid);
+  (void)hipFree(A->d_ptstart);
+  (void)hipFree(A->d_ptoff);
+  A->d_ptid    = nullptr;
+  A->d_ptstart = nullptr;
+  A->d_ptoff   = nullptr;
+  A->ptm_ok    = false;
+  A->ptm_ntmpl = A->ptm_nent = A->ptm_maxlen = 0;
+}
+
+int ensure_pattern_templates(hipxMat A)
+{
+  if (A->ptm_ready) return HIPX_SUCCESS;
+  A->ptm_ready = true;
+  free_pattern_templates(A);
+  if (A->compressed || A->nrows_c <= 0 || A->nnz <= 0) return HIPX_SUCCESS;
+  // stash the row templates
+  unsigned char *s_tid = A->d_tid;
+  int           *s_tstart = A->d_tstart, *s_toff = A->d_toff;
+  double        *s_tval = A->d_tval;
+  const bool     s_ok = A->tmpl_ok;
+  const int      s_nt = A->ntmpl, s_ne = A->tmpl_nent, s_ml = A->tmpl_maxlen;
+  std::vector<int>     h1 = std::move(A->h_tstart), h2 = std::move(A->h_toff), h3 = std::move(A->h_tdiag);
+  std::vector<int64_t> h4 = std::move(A->h_tcount);
+  std::vector<double>  h5 = std::move(A->h_tval);
+  A->d_tid = nullptr;
+  A->d_tstart = A->d_toff = nullptr;
+  A->d_tval = nullptr;
+  A->tmpl_ok = false;
+  A->ntmpl = A->tmpl_nent = A->tmpl_maxlen = 0;
+  A->ptm_build = true;
+  const int64_t bytes0 = A->device_bytes;
+  int ierr = A->is64 ? build_templates<int64_t>(A) : build_templates<hipx_int>(A);
+  A->ptm_build = false;
+  if (!ierr && A->tmpl_ok && A->tmpl_maxlen <= 1024) {
+    A->d_ptid     = A->d_tid;
+    A->d_ptstart  = A->d_tstart;
+    A->d_ptoff    = A->d_toff;
+    A->ptm_ok     = true;
+    A->ptm_ntmpl  = A->ntmpl;
+    A->ptm_nent   = A->tmpl_nent;
+    A->ptm_maxlen = A->tmpl_maxlen;
+    (void)hipFree(A->d_tval);
+  } else {
+    (void)hipFree(A->d_tid);
+    (void)hipFree(A->d_tstart);
+    (void)hipFree(A->d_toff);
+    (void)hipFree(A->d_tval);
+    A->device_bytes = bytes0;
+  }
+  // restore the row templates
+  A->d_tid = s_tid;
+  A->d_tstart = s_tstart;
+  A->d_toff = s_toff;
+  A->d_tval = s_tval;
+  A->tmpl_ok = s_ok;
+  A->ntmpl = s_nt;
+  A->tmpl_nent = s_ne;
+  A->tmpl_maxlen = s_ml;
+  A->h_tstart = std::move(h1);
+  A->h_toff = std::move(h2);
+  A->h_tdiag = std::move(h3);
+  A->h_tcount = std::move(h4);
+  A->h_tval = std::move(h5);
   return ierr;
 }
 
@@ -1790,7 +2122,9 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
   }
   const hipx_int cpx  = (nchunks + 7) / 8;
   const size_t   smem = 8 * (size_t)((A->tmpl_nent + 1) & ~1) + 4 * (size_t)((A->tmpl_nent + 3) & ~3) + 4 * ((size_t)A->ntmpl + 1) + 16;
-  const int      geom = (int)grid * 16 + rpt;
+  static const int v2 = getenv("HIPX_TMPL_V2") ? atoi(getenv("HIPX_TMPL_V2")) : 1;  // 1 (default): spmv_tmpl2_kernel; 0: the first form
+  const bool     use_v2 = v2 && cfg == 1 && !(getenv("HIPX_TMPL_PROBE") && atoi(getenv("HIPX_TMPL_PROBE")));
+  const int      geom = (int)grid * 16 + rpt + (use_v2 ? (1 << 28) : 0);  // (the two forms take a different number of tickets per launch)
   if (!A->d_tq || A->tq_geom != geom) {  // ticket counters of the chunk queue (zeroed once per geometry)
     if (!A->d_tq) HIPX_HIP(hipMalloc((void **)&A->d_tq, 8 * 64));
     HIPX_HIP(hipMemsetAsync(A->d_tq, 0, 8 * 64, rt().compute));
@@ -1818,6 +2152,20 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
 #define HIPX_TMPL_LAUNCH(R, WW, U) \
   spmv_tmpl_kernel<MODE, DOT, R, WW, U><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout, dotpart, \
                                                                                       A->d_tq, launch, pf_off)
+  if (use_v2) {
+    static const int lag = getenv("HIPX_TMPL_LAG") ? atoi(getenv("HIPX_TMPL_LAG")) : 1;  // rounds a workgroup may run ahead of its XCD (0: no throttle)
+    const long long  far = (A->tmpl_maxoff >= 4 * 256 * rpt && !getenv("HIPX_TMPL_NOPF")) ? A->tmpl_maxoff : 0;
+    static const int pfw = getenv("HIPX_TMPL_PFW") ? atoi(getenv("HIPX_TMPL_PFW")) : 0;
+    if (pfw) {  // five waves per workgroup: six workgroups fit a CU (30 waves)
+      const unsigned g5 = (unsigned)std::min<hipx_int>(grid, (hipx_int)(getenv("HIPX_TMPL_BLOCKS") ? tmpl_blocks() : 1536));
+      spmv_tmpl2_kernel<MODE, DOT, 2, true, true><<<g5, 320, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout, dotpart, A->d_tq, launch,
+                                                                                far, lag);
+    } else
+      spmv_tmpl2_kernel<MODE, DOT, 2, true, false><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout, dotpart,
+                                                                                              A->d_tq, launch, far, lag);
+    HIPX_LAUNCH_CHECK();
+    return HIPX_SUCCESS;
+  }
   switch (cfg) {
   case 0: HIPX_TMPL_LAUNCH(2, 4, false); break;
   case 2: HIPX_TMPL_LAUNCH(4, 4, true); break;
@@ -1834,13 +2182,7 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
       else if (probe == 5) HIPX_TMPL_LAUNCH_P(5);
       else HIPX_TMPL_LAUNCH_P(6);
 #undef HIPX_TMPL_LAUNCH_P
-    } else {
-      static const bool noshort = getenv("HIPX_TMPL_NOSHORT") != nullptr;
-      if (A->tmpl_maxlen <= 8 && !noshort)
-        spmv_tmpl_kernel<MODE, DOT, 2, 2, true, 0, true><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout,
-                                                                                                  dotpart, A->d_tq, launch, pf_off);
-      else HIPX_TMPL_LAUNCH(2, 2, true);
-    }
+    } else HIPX_TMPL_LAUNCH(2, 2, true);
     break;
   }
   }
@@ -1922,6 +2264,31 @@ int launch_pk16(hipxMat A, const double *x, const double *yin, double *yout, dou
   return HIPX_SUCCESS;
 }
 
+// variant 29: pattern templates + streamed values (spmv_tp_kernel) when the matrix has <= 256 row patterns
+int use_pattern_templates(hipxMat A, bool &use)
+{
+  use = false;
+  if (!A->ptm_mode || A->compressed || A->probe) return HIPX_SUCCESS;
+  int ierr = ensure_pattern_templates(A);
+  if (ierr) return ierr;
+  if (!A->ptm_ok) return HIPX_SUCCESS;
+  if ((ierr = ensure_row_blocks(A, 0))) return ierr;
+  use = true;
+  return HIPX_SUCCESS;
+}
+
+template <typename IT, int MODE, bool DOT>
+int launch_tp(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
+{
+  const hipx_int nb = A->nblocks[0];
+  if (nb == 0) return HIPX_SUCCESS;
+  const hipx_int per_xcd = (nb + 7) / 8;
+  const unsigned grid = (unsigned)(per_xcd * 8);
+  spmv_tp_kernel<IT, MODE, DOT><<<grid, 256, 0, rt().compute>>>(A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_ptid, A->d_ptstart, A->d_ptoff, A->d_a, x, yin, yout, dotpart);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
 // variant 28: the SELL-64 copy (hipx_sell.hip) when it applies; *use = false -> the CSR kernels
 int use_sell(hipxMat A, bool &use)
 {
@@ -1944,6 +2311,12 @@ int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, d
     int  ierr = use_sell(A, sl);
     if (ierr) return ierr;
     if (sl) return hipxSellLaunch_(A->sell_state, MODE, DOT ? 1 : 0, x, yin, yout, dotpart);
+  }
+  {
+    bool tp = false;
+    int  ierr = use_pattern_templates(A, tp);
+    if (ierr) return ierr;
+    if (tp) return launch_tp<IT, MODE, DOT>(A, x, yin, yout, dotpart);
   }
   {
     bool tm = false;
@@ -1981,6 +2354,12 @@ int dot_partials_count(hipxMat A, hipx_int *npart)
     if (ierr) return ierr;
     if (sl) {
       *npart = hipxSellDotPartials_(A->sell_state);
+      return HIPX_SUCCESS;
+    }
+    bool tp = false;
+    if ((ierr = use_pattern_templates(A, tp))) return ierr;
+    if (tp) {
+      *npart = (hipx_int)(((A->nblocks[0] + 7) / 8) * 8) * 4;
       return HIPX_SUCCESS;
     }
   }
@@ -2195,6 +2574,7 @@ int hipxMatDestroy(hipxMat *pA)
   (void)hipFree(A->d_vc);
   (void)hipFree(A->d_vdict);
   free_templates(A);
+  free_pattern_templates(A);
   hipxSorStateFree_(A->sor_state);
   hipxSellFree_(A->sell_state);
   delete A;
@@ -2267,7 +2647,8 @@ int hipxMatSetSpMVVariant(hipxMat A, int variant)
   A->vd_mode   = (variant == 24 || variant == 25 || variant == 26) ? 1 : 0;
   A->tmpl_mode = (variant == 26) ? 1 : 0;
   A->sell_mode = (variant == 28) ? 1 : 0;  // 28: SELL-64 copy (hipx_sell.hip); falls back to 23 when the format does not apply
-  if (variant == 28) {
+  A->ptm_mode = (variant == 29) ? 1 : 0;   // 29: pattern templates + streamed values (spmv_tp_kernel); falls back to 23
+  if (variant == 28 || variant == 29) {
     A->tile_mode = 3;
     variant      = 23;
   }
@@ -2306,7 +2687,13 @@ int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
     int ierr = use_sell(A, sl);
     if (ierr) return ierr;
   }
+  bool tp = false;
+  if (!sl) {
+    int ierr = use_pattern_templates(A, tp);
+    if (ierr) return ierr;
+  }
   if (sl) name = "spmv_sell_kernel (MatMult on the SELL-64 copy: one lane per row, 16-bit window-coded columns)";
+  else if (tp) name = "spmv_tp_kernel (CSR MatMult, pattern templates: 1-byte pattern id per row, values streamed from a[])";
   else if (tm) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row)";
   else if (A->tile_mode >= 2 && !A->compressed && !A->probe) {
     bool vd, rowpar;

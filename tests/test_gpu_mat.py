@@ -37,7 +37,7 @@ def spmv_gpu(hx, ai, aj, aa, x, ncols=None, variant=0, y0=None):
 
 @pytest.mark.parametrize("kind,n,m", [("5pt", 100, 100), ("5pt", 7, 8), ("7pt", 1, None), ("7pt", 2, None), ("7pt", 33, None), ("7pt", 64, None),
                                        ("27pt", 3, None), ("27pt", 17, None), ("27pt", 40, None)])
-@pytest.mark.parametrize("variant", [1, 2, 3, 22, 23, 24, 25, 26, 28, 101])
+@pytest.mark.parametrize("variant", [1, 2, 3, 22, 23, 24, 25, 26, 28, 29, 101])
 def test_stencil_spmv_bit_exact(hx, kind, n, m, variant):
     ai, aj, aa = orc.stencil(kind, n, m=m)
     N = len(ai) - 1
@@ -61,7 +61,7 @@ def random_csr(m, n, rng, maxlen, empty_frac=0.2):
 
 
 @pytest.mark.parametrize("seed,m,n,maxlen", [(0, 1, 1, 1), (1, 17, 29, 5), (2, 1000, 777, 40), (3, 5000, 5000, 8), (4, 300, 4000, 300), (5, 257, 100, 0), (7, 2000, 9000, 160)])
-@pytest.mark.parametrize("variant", [1, 22, 23, 24, 25, 26, 28])
+@pytest.mark.parametrize("variant", [1, 22, 23, 24, 25, 26, 28, 29])
 def test_ragged_rows_bit_exact_and_multadd(hx, seed, m, n, maxlen, variant):
     rng = np.random.default_rng(seed)
     ai, aj, aa = random_csr(m, n, rng, maxlen)
@@ -419,3 +419,48 @@ def test_sell_copy_selection_padding_limit_fused_dot_and_value_update(hx):
     _lib.mat_destroy(A4)
     for v in (X, Y, X2, Y2, X3, Y3, X4, Y4):
         v.free()
+
+
+@pytest.mark.parametrize("kind,n", [("7pt", 40), ("27pt", 24), ("5pt", 90)])
+def test_pattern_templates_with_arbitrary_values(hx, kind, n):
+    """variant 29: a variable-coefficient operator -- the stencil PATTERN with all-distinct values -- gets the
+    pattern-template kernel (1-byte pattern id per row, values streamed): bit-identical y, MatMultAdd, the fused dot, and a value
+    update on the same pattern; a matrix with more than 256 row patterns keeps the packed CSR kernel."""
+    from petsc_amd import _lib
+    rng = np.random.default_rng(5)
+    ai, aj, aa = orc.stencil(kind, n)
+    N = len(ai) - 1
+    aa = aa * (1.0 + 0.3 * rng.standard_normal(aa.size))  # all distinct: no value dictionary, no (offset, value) templates
+    x = rng.standard_normal(N)
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    _lib.chk(hx.hipxMatSetSpMVVariant(A, 29))
+    assert kernel_name(hx, A).startswith("spmv_tp_kernel "), kernel_name(hx, A)
+    X, Y, Y0 = _lib.DVec(N, x), _lib.DVec(N), _lib.DVec(N, x[::-1].copy())
+    _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    yr = orc.matmult(ai, aj, aa, x)
+    assert np.array_equal(Y.get(), yr)
+    _lib.chk(hx.hipxMatMultAdd(A, X.ptr, Y0.ptr, Y.ptr))
+    zr = np.zeros(N)
+    orc.lib().orc_MatMultAdd_SeqAIJ(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(x[::-1].copy()), orc.P(zr))
+    assert np.array_equal(Y.get(), zr)
+    d = C.c_double()
+    _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(d)))
+    assert np.array_equal(Y.get(), yr) and abs(d.value - float(x @ yr)) <= 1e-12 * float(np.abs(x) @ np.abs(yr))
+    aa2 = aa * (1.0 + 0.1 * rng.standard_normal(aa.size))
+    _lib.chk(hx.hipxMatUpdateValues(A, orc.P(aa2)))
+    assert kernel_name(hx, A).startswith("spmv_tp_kernel ")
+    _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    assert np.array_equal(Y.get(), orc.matmult(ai, aj, aa2, x))
+    for v in (X, Y, Y0):
+        v.free()
+    _lib.mat_destroy(A)
+    ai3, aj3, aa3 = random_csr(3000, 3000, rng, 12)
+    A3 = _lib.mat_create_csr(3000, 3000, ai3, aj3, aa3)
+    _lib.chk(hx.hipxMatSetSpMVVariant(A3, 29))
+    assert not kernel_name(hx, A3).startswith("spmv_tp_kernel")
+    X3, Y3 = _lib.DVec(3000, x[:3000] if N >= 3000 else rng.standard_normal(3000)), _lib.DVec(3000)
+    _lib.chk(hx.hipxMatMult(A3, X3.ptr, Y3.ptr))
+    assert np.array_equal(Y3.get(), orc.matmult(ai3, aj3, aa3, X3.get()))
+    X3.free()
+    Y3.free()
+    _lib.mat_destroy(A3)
