@@ -591,7 +591,8 @@ def main():
     ap.add_argument("--fused", type=int, default=1, help="1 (default): fused SpMV+dot and AXPY+AXPY+PCJACOBI+norm+dot kernels -- same arithmetic and order per element, fewer HBM passes; 0: one kernel per reference Vec/Mat call (cg.c:249-344)")
     ap.add_argument("--pipeline", type=int, default=1, help="1 (default): launch-ahead fused CG (iteration i+1 enqueued before the host has seen iteration i's sums; device-resident scalars); 0: host waits between kernels")
     ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (include/hipx.h hipxMatSetSpMVVariant): 0 auto")
-    ap.add_argument("--general-variant", type=int, default=23, help="kernel of the roofline_general leg (what a matrix with arbitrary values gets)")
+    ap.add_argument("--general-variant", type=int, default=29, help="kernel of the roofline_general leg: what a matrix with arbitrary values on this pattern gets (29: pattern templates + streamed values, "
+                    "the auto choice for short rows on <= 256 row patterns; 23: packed 16-bit columns, what an unstructured matrix gets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic then comes from profiles/spmv_traffic.json)")
     ap.add_argument("--no-plugin", action="store_true")
@@ -700,7 +701,8 @@ def main():
         general = {"bound": "hbm", "kernel": gname, "avg_launch_ms": g["spmv_ms"], "launches": g["launches"], "algorithmic_bytes": spmv_bytes,
                    "achieved": spmv_bytes / (g["spmv_ms"] * 1e-3) / 1e9 if g["spmv_ms"] > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "iterations_per_s": args.steps / g["elapsed"],
-                   "note": "same solver with --variant %d and the constant-Jacobi-diagonal shortcut off: the kernels a matrix with arbitrary values gets" % args.general_variant}
+                   "note": "same solver with --variant %d and the constant-Jacobi-diagonal shortcut off: the kernels a matrix with arbitrary VALUES on this pattern gets (29 = pattern templates, values "
+                           "streamed: the auto choice for such a matrix; an unstructured matrix gets 23, packed 16-bit columns)" % args.general_variant}
         general["frac"] = general["achieved"] / HBM_PEAK_GBS
         P.setup(args.variant)
     nnz_local = P.nnz_local

@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(256) void tmpl_verify_kernel(hipx_int m, hipx_int n
 // 2 = every gather of a row reads x[row + k] (k = entry index: the row's own cache lines -- no far lines at all); 3 = far offsets
 // folded into +-4096 doubles of the row (same number of distinct lines per gather, all of them recently touched: no far-plane HBM stream);
 // 4 = correct results, but the chunks are assigned statically (round robin over the XCD's workgroups): no ticket atomics, no barriers;
-// 5 = 4 without the first-touch prefetch; 6 = 5 without the template-id loads (id 0 everywhere: wrong rows at the boundaries)
+// 5 = 4 without the first-touch prefetch
 template <int MODE, bool DOT, int RPT, int W, bool UNI, int PROBE = 0>
 __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const int *__restrict__ tstart,
                                                         const int *__restrict__ toff, const double *__restrict__ tval, int ntmpl, int nent, const double *__restrict__ x,
@@ -1126,7 +1126,7 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
 #pragma unroll
   for (int rr = 0; rr < RPT; rr++) {
     const long long row = (tk < nloc) ? ((long long)(c0 + tk) * (256 * RPT) + t + rr * 256) : (long long)m;
-    idn[rr]             = (row < m && PROBE != 6) ? tid[row] : 0;
+    idn[rr]             = (row < m) ? tid[row] : 0;
   }
   while (tk < nloc) {
     long long nxt = 0;
@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
 #pragma unroll
     for (int rr = 0; rr < RPT; rr++) {  // issue the next chunk's id loads now; they are consumed at the top of the next pass
       const long long row = (tk1 < nloc) ? ((long long)(c0 + tk1) * (256 * RPT) + t + rr * 256) : (long long)m;
-      idn[rr]             = (row < m && PROBE != 6) ? tid[row] : 0;
+      idn[rr]             = (row < m) ? tid[row] : 0;
     }
     int id0 = 0;
     if (UNI) {
@@ -1266,225 +1266,6 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
   if (sink == 0xffffffffu) yout[0] = pf;  // never true: keeps the prefetch loads alive
 }
 
-
-// Template SpMV, second form (round 3).  Same storage and arithmetic as spmv_tmpl_kernel; what changes is how a workgroup gets its
-// chunks and WHEN a wave issues its long-latency requests.  Vector memory operations of a wave return in order, so a wait for this
-// chunk's gathers (L2 hits: the x planes were touched a round ago) also waits for everything issued BEFORE them -- in the first form the
-// ticket atomic (whose result the compiler's atomic optimiser wants at once), the template ids of the next chunk (a stream nobody has
-// touched: an HBM round trip) and the first-touch prefetch; and each __syncthreads() drains the wave's loads (s_waitcnt vmcnt(0) in
-// front of s_barrier).  Probes on the MI355X (7-pt 256^3, profiles/r03_tmpl_probes.txt): dropping the y stores, turning every gather
-// into a same-line access or folding the far offsets changes nothing (0.116-0.120 ms against 0.120): a chunk costs ~7 us of WAITING.
-// Here:
-//   * static round-robin chunks (workgroup j of an XCD takes chunks j, j + W, j + 2W ... of the XCD's slab: no ticket, no barrier, no
-//     LDS hand-over) with a drift throttle instead of the queue: every finished chunk bumps a per-XCD counter (an atomic WITHOUT
-//     return), and a workgroup that is more than LAG rounds ahead of the counter polls it -- the planes of x the resident workgroups
-//     touch stay inside the XCD's L2 as with the queue (a plain static map lets them drift: 2.6x the traffic);
-//   * the template ids are loaded DEPTH chunks ahead and, like the first-touch prefetch (now for the workgroup's own next chunk) and
-//     the throttle's poll, issued right BEHIND the chunk's last gather group: the gathers' wait leaves them in flight and they have
-//     whole chunks of time to land.
-//   * PFW (a fifth wave per workgroup, HIPX_TMPL_PFW=1): whatever a compute wave loads late still costs it an HBM round trip at the top of
-//     the next chunk (the compiler drains the wave's counter where it cannot count across the loop edge).  The prefetch wave touches,
-//     two rounds ahead of the workgroup's compute waves (progress word in LDS), the template-id lines and the farthest forward x lines of
-//     the chunks to come and waits for them itself: the compute waves then only ever see L2 hits.
-template <int MODE, bool DOT, int W, bool UNI, bool PFW>
-__global__ __launch_bounds__(PFW ? 320 : 256) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmv_tmpl2_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const int *__restrict__ tstart,
-                                                         const int *__restrict__ toff, const double *__restrict__ tval, int ntmpl, int nent, const double *__restrict__ x,
-                                                         const double *yin, double *yout, double *dotpart, unsigned long long *tq, unsigned long long launch, long long pf_far, int lag)
-{
-  constexpr int RPT = 2, DEPTH = 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *s_val   = reinterpret_cast<double *>(smem);
-  int    *s_off   = reinterpret_cast<int *>(smem + 8 * (size_t)((nent + 1) & ~1));
-  int    *s_start = s_off + ((nent + 3) & ~3);
-  const int t = threadIdx.x;
-  __shared__ int s_round;
-  if (t < 256) {
-    for (int k = t; k < nent; k += 256) {
-      s_val[k] = tval[k];
-      s_off[k] = toff[k];
-    }
-    for (int k = t; k <= ntmpl; k += 256) s_start[k] = tstart[k];
-  }
-  if (t == 0) s_round = 0;
-  __syncthreads();
-  const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, bpx = (hipx_int)gridDim.x >> 3, j = bid >> 3;
-  const hipx_int c0 = xcd * chunks_per_xcd, c1 = (c0 + chunks_per_xcd < nchunks) ? c0 + chunks_per_xcd : nchunks;
-  const long long     nloc = (long long)(c1 > c0 ? c1 - c0 : 0);
-  unsigned int  *done  = reinterpret_cast<unsigned int *>(tq + (size_t)xcd * 8);  // chunks finished in this XCD's slab, all launches (mod 2^32)
-  const unsigned dbase = (unsigned)(launch * (unsigned long long)nloc);           // ... of which the earlier launches account for this many
-  auto chunk_row = [&](long long q, int rr) -> long long { return (q < nloc) ? ((long long)(c0 + q) * (256 * RPT) + t + rr * 256) : (long long)m; };
-  if (PFW && t >= 256) {  // the prefetch wave
-    const int lane = t - 256;
-    constexpr int AHEAD = 2;
-    unsigned  acc = 0;
-    long long r = 0;
-    for (long long q = j; q < nloc; q += bpx, r++) {
-      for (int spin = 0; spin < 100000 && r > (long long)__hip_atomic_load(&s_round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + AHEAD; spin++) __builtin_amdgcn_s_sleep(1);
-      const long long base = (long long)(c0 + q) * (256 * RPT);
-      if (lane < 4) {  // the chunk's 512 template ids: four 128-byte lines
-        const long long r0 = base + (long long)lane * 128;
-        if (r0 < m) acc += tid[r0];
-      } else if (lane < 4 + 16 * RPT && pf_far) {  // the farthest forward x lines of the chunk: 512 doubles = 32 lines
-        const long long prow = base + pf_far + (long long)(lane - 4) * 16;
-        if (prow < (long long)m) acc += (unsigned)__double_as_longlong(x[prow]);
-      }
-    }
-    if (acc == 0x9e3779b9u && nloc < 0) yout[0] = 0.0;  // never true: keeps the loads alive
-    return;
-  }
-  int idq[DEPTH + 1][RPT];  // template ids of the chunks q, q + bpx, ... (q + DEPTH bpx is loaded while q is processed)
-#pragma unroll
-  for (int d = 0; d < DEPTH; d++)
-#pragma unroll
-    for (int rr = 0; rr < RPT; rr++) {
-      const long long r_ = chunk_row((long long)j + (long long)d * bpx, rr);
-      idq[d][rr]         = (r_ < m) ? tid[r_] : 0;
-    }
-  double             pf = 0.0;
-  unsigned           sink = 0;
-  unsigned           seen = dbase;  // the counter as this wave last saw it
-  long long          round = 0;
-  for (long long q = j; q < nloc; q += bpx, round++) {
-    if (lag > 0 && round > lag) {  // drift throttle (a locality heuristic, never needed for correctness: bounded spinning)
-      const unsigned need = dbase + (unsigned)(round - lag) * (unsigned)bpx;
-      for (int spin = 0; (int)(seen - need) < 0 && spin < 2000; spin++) {
-        __builtin_amdgcn_s_sleep(2);
-        seen = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    const hipx_int c    = c0 + (hipx_int)q;
-    const hipx_int base = c * (256 * RPT);
-    double         sum[RPT], xrow[RPT];
-    bool           uni = UNI && (base + 256 * RPT <= m) && ((unsigned long long)m < (1ull << 28));
-#pragma unroll
-    for (int rr = 0; rr < RPT; rr++) {
-      const hipx_int row = base + t + rr * 256;
-      sum[rr]  = 0.0;
-      xrow[rr] = 0.0;
-      if (row < m && MODE == 1) sum[rr] = yin[row];
-    }
-    // the requests nothing in THIS chunk waits for
-    auto issue_ahead = [&]() {
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int rr = 0; rr < RPT; rr++) {
-        const long long r2 = chunk_row(q + (long long)DEPTH * bpx, rr);
-        idq[DEPTH][rr]     = (r2 < m) ? tid[r2] : 0;
-      }
-      if (!PFW && pf_far && t < 16 * RPT) {  // first touch of the farthest forward x lines of this workgroup's NEXT chunk
-        const long long prow = (long long)base + (long long)bpx * (256 * RPT) + pf_far + (long long)t * 16;
-        if (prow < (long long)m) pf = x[prow];
-      }
-      if (lag > 0) seen = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (one address per wave: one request)
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    int id0 = 0;
-    if (UNI) {
-      id0 = __builtin_amdgcn_readfirstlane(idq[0][0]);
-#pragma unroll
-      for (int rr = 0; rr < RPT; rr++) uni = uni && (idq[0][rr] == id0);
-      uni = __all(uni);
-    }
-    if (UNI && uni) {
-      const int ts = tstart[id0], te = tstart[id0 + 1];
-      unsigned  rb[RPT];
-#pragma unroll
-      for (int rr = 0; rr < RPT; rr++) rb[rr] = (unsigned)(base + t + rr * 256) * 8u;
-      bool got = false;
-      for (int k = ts; k < te; k += 4) {  // groups of four entries (the tables carry 4 entries of slack: offset 0, never multiplied)
-        double a[4], xv[4][RPT];
-        int    o[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          a[e] = tval[k + e];
-          o[e] = toff[k + e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const char *xb = reinterpret_cast<const char *>(x + ((k + e < te) ? o[e] : 0));
-#pragma unroll
-          for (int rr = 0; rr < RPT; rr++) xv[e][rr] = *reinterpret_cast<const double *>(xb + rb[rr]);
-        }
-        if (k + 4 >= te) issue_ahead();  // behind the LAST group's gathers
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          if (k + e < te) {
-#pragma unroll
-            for (int rr = 0; rr < RPT; rr++) sum[rr] += a[e] * xv[e][rr];
-            if (DOT && o[e] == 0) {
-              got = true;
-#pragma unroll
-              for (int rr = 0; rr < RPT; rr++) xrow[rr] = xv[e][rr];
-            }
-          }
-        }
-      }
-      if (te <= ts) issue_ahead();
-      if (DOT && !got) {
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++) xrow[rr] = x[base + t + rr * 256];
-      }
-    } else {
-      int s0[RPT], len[RPT], maxlen = 0;
-#pragma unroll
-      for (int rr = 0; rr < RPT; rr++) {
-        const hipx_int row = base + t + rr * 256;
-        s0[rr]  = 0;
-        len[rr] = 0;
-        if (row < m) {
-          s0[rr]  = s_start[idq[0][rr]];
-          len[rr] = s_start[idq[0][rr] + 1] - s0[rr];
-          if (DOT) xrow[rr] = x[row];
-        }
-        maxlen = max(maxlen, len[rr]);
-      }
-      for (int k = 0; k < maxlen; k += W) {
-        double xv[RPT][W], av[RPT][W];
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++) {
-          const hipx_int row = base + t + rr * 256;
-#pragma unroll
-          for (int e = 0; e < W; e++) {
-            const bool on  = (k + e) < len[rr];
-            const int  idx = on ? s0[rr] + k + e : 0;
-            av[rr][e]      = s_val[idx];
-            xv[rr][e]      = on ? x[row + s_off[idx]] : 0.0;
-          }
-        }
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++) {
-#pragma unroll
-          for (int e = 0; e < W; e++)
-            if ((k + e) < len[rr]) sum[rr] += av[rr][e] * xv[rr][e];
-        }
-      }
-      issue_ahead();
-    }
-    double cdot = 0.0;
-#pragma unroll
-    for (int rr = 0; rr < RPT; rr++) {
-      const hipx_int row = base + t + rr * 256;
-      if (row < m) {
-        yout[row] = sum[rr];
-        if (DOT) cdot += xrow[rr] * sum[rr];
-      }
-    }
-    if (DOT) {
-      const double w = hipx::wave_sum(cdot);
-      if ((threadIdx.x & 63) == 0) dotpart[(size_t)c * 4 + (threadIdx.x >> 6)] = w;
-    }
-    if (t == 0) {
-      __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // result unused: an atomic without return
-      if (PFW) __hip_atomic_store(&s_round, (int)round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-#pragma unroll
-    for (int d = 0; d < DEPTH; d++)
-#pragma unroll
-      for (int rr = 0; rr < RPT; rr++) idq[d][rr] = idq[d + 1][rr];
-    sink += (__double_as_longlong(pf) == 0x7ff8123456789abcLL) ? 1u : 0u;
-  }
-  if (sink == 0xffffffffu) yout[0] = pf;  // never true: keeps the prefetch loads alive
-}
 
 template <typename IT>
 __global__ void diagpos_kernel(hipx_int m, const IT *ai, const hipx_int *aj, int64_t *diagpos, unsigned int *missing)
@@ -1648,6 +1429,8 @@ int create_common(hipx_int m, hipx_int n, hipx_int nrows, const IT *ai, const hi
   A->tile_mode = auto_tile_mode(A);  // variant 0
   A->vd_mode   = A->tile_mode ? 1 : 0;
   A->tmpl_mode = A->tile_mode ? 1 : 0;
+  A->ptm_mode  = A->tile_mode ? 1 : 0;
+  A->sell_mode = A->tile_mode ? 2 : 0;
   *out = A;
   return HIPX_SUCCESS;
 }
@@ -2097,6 +1880,12 @@ int ensure_pattern_templates(hipxMat A)
 // ranges a chunk touches copied into an LDS tile with 16-byte coalesced loads and the row sums formed from LDS (one global round
 // trip per chunk, 40 VGPRs, 16 KiB of LDS per workgroup): 0.163 ms against 0.146 ms (0.137 against 0.114 stand-alone); one chunk per
 // workgroup without the ticket queue (XCD-aware static map, 32768 one-shot workgroups): 0.157 ms against 0.146 ms.
+// Round 3 (profiles/r03_tmpl_probes.txt, 7-pt 256^3 stand-alone 0.119-0.121 ms): timing probes (HIPX_TMPL_PROBE) show that neither the
+// y stores (0.116), nor the gathers' far lines (every gather folded onto the row's own lines: 0.118; far offsets folded into +-4096:
+// 0.120) carry the time; static round-robin chunks without tickets and barriers: 0.102 stand-alone but 0.158 inside CG (the workgroups
+// drift, x is re-fetched); the same with a progress throttle (done counter polled per chunk): 1.2 ms (the throttle's bounded spins
+// expire: not every workgroup is co-resident); a fifth wave per workgroup that first-touches ids and far x lines two rounds ahead:
+// 0.144 (a quarter of the compute waves gone, nothing gained); the current template kept in scalar registers across chunks: +-0.
 int tmpl_cfg()
 {
   static const int v = getenv("HIPX_TMPL_CFG") ? atoi(getenv("HIPX_TMPL_CFG")) : 1;
@@ -2122,9 +1911,7 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
   }
   const hipx_int cpx  = (nchunks + 7) / 8;
   const size_t   smem = 8 * (size_t)((A->tmpl_nent + 1) & ~1) + 4 * (size_t)((A->tmpl_nent + 3) & ~3) + 4 * ((size_t)A->ntmpl + 1) + 16;
-  static const int v2 = getenv("HIPX_TMPL_V2") ? atoi(getenv("HIPX_TMPL_V2")) : 1;  // 1 (default): spmv_tmpl2_kernel; 0: the first form
-  const bool     use_v2 = v2 && cfg == 1 && !(getenv("HIPX_TMPL_PROBE") && atoi(getenv("HIPX_TMPL_PROBE")));
-  const int      geom = (int)grid * 16 + rpt + (use_v2 ? (1 << 28) : 0);  // (the two forms take a different number of tickets per launch)
+  const int      geom = (int)grid * 16 + rpt;
   if (!A->d_tq || A->tq_geom != geom) {  // ticket counters of the chunk queue (zeroed once per geometry)
     if (!A->d_tq) HIPX_HIP(hipMalloc((void **)&A->d_tq, 8 * 64));
     HIPX_HIP(hipMemsetAsync(A->d_tq, 0, 8 * 64, rt().compute));
@@ -2152,26 +1939,12 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
 #define HIPX_TMPL_LAUNCH(R, WW, U) \
   spmv_tmpl_kernel<MODE, DOT, R, WW, U><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout, dotpart, \
                                                                                       A->d_tq, launch, pf_off)
-  if (use_v2) {
-    static const int lag = getenv("HIPX_TMPL_LAG") ? atoi(getenv("HIPX_TMPL_LAG")) : 1;  // rounds a workgroup may run ahead of its XCD (0: no throttle)
-    const long long  far = (A->tmpl_maxoff >= 4 * 256 * rpt && !getenv("HIPX_TMPL_NOPF")) ? A->tmpl_maxoff : 0;
-    static const int pfw = getenv("HIPX_TMPL_PFW") ? atoi(getenv("HIPX_TMPL_PFW")) : 0;
-    if (pfw) {  // five waves per workgroup: six workgroups fit a CU (30 waves)
-      const unsigned g5 = (unsigned)std::min<hipx_int>(grid, (hipx_int)(getenv("HIPX_TMPL_BLOCKS") ? tmpl_blocks() : 1536));
-      spmv_tmpl2_kernel<MODE, DOT, 2, true, true><<<g5, 320, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout, dotpart, A->d_tq, launch,
-                                                                                far, lag);
-    } else
-      spmv_tmpl2_kernel<MODE, DOT, 2, true, false><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout, dotpart,
-                                                                                              A->d_tq, launch, far, lag);
-    HIPX_LAUNCH_CHECK();
-    return HIPX_SUCCESS;
-  }
   switch (cfg) {
   case 0: HIPX_TMPL_LAUNCH(2, 4, false); break;
   case 2: HIPX_TMPL_LAUNCH(4, 4, true); break;
   default: {
     static const int probe = getenv("HIPX_TMPL_PROBE") ? atoi(getenv("HIPX_TMPL_PROBE")) : 0;
-    if (probe >= 1 && probe <= 6) {
+    if (probe >= 1 && probe <= 5) {
 #define HIPX_TMPL_LAUNCH_P(PR) \
   spmv_tmpl_kernel<MODE, DOT, 2, 2, true, PR><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout, \
                                                                                            dotpart, A->d_tq, launch, pf_off)
@@ -2179,8 +1952,7 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
       else if (probe == 2) HIPX_TMPL_LAUNCH_P(2);
       else if (probe == 3) HIPX_TMPL_LAUNCH_P(3);
       else if (probe == 4) HIPX_TMPL_LAUNCH_P(4);
-      else if (probe == 5) HIPX_TMPL_LAUNCH_P(5);
-      else HIPX_TMPL_LAUNCH_P(6);
+      else HIPX_TMPL_LAUNCH_P(5);
 #undef HIPX_TMPL_LAUNCH_P
     } else HIPX_TMPL_LAUNCH(2, 2, true);
     break;
@@ -2269,8 +2041,14 @@ int use_pattern_templates(hipxMat A, bool &use)
 {
   use = false;
   if (!A->ptm_mode || A->compressed || A->probe) return HIPX_SUCCESS;
-  int ierr = ensure_pattern_templates(A);
-  if (ierr) return ierr;
+  int ierr;
+  if (A->auto_sel) {  // auto: short rows only (long rows stream better through the staged kernel), and only when the values do not fit the
+                      // 8-bit dictionary (3 bytes per nonzero beat 8)
+    if (A->nnz < (1 << 20) || A->nnz > 16 * (int64_t)A->nrows_c) return HIPX_SUCCESS;
+    if ((ierr = ensure_vdict(A))) return ierr;
+    if (A->vd_ok) return HIPX_SUCCESS;
+  }
+  if ((ierr = ensure_pattern_templates(A))) return ierr;
   if (!A->ptm_ok) return HIPX_SUCCESS;
   if ((ierr = ensure_row_blocks(A, 0))) return ierr;
   use = true;
@@ -2290,10 +2068,17 @@ int launch_tp(hipxMat A, const double *x, const double *yin, double *yout, doubl
 }
 
 // variant 28: the SELL-64 copy (hipx_sell.hip) when it applies; *use = false -> the CSR kernels
-int use_sell(hipxMat A, bool &use)
+int use_sell(hipxMat A, bool &use, bool auto_stage = false)
 {
   use = false;
   if (!A->sell_mode || A->compressed || A->probe) return HIPX_SUCCESS;
+  if ((A->sell_mode == 2) != auto_stage) return HIPX_SUCCESS;  // explicit (variant 28): ahead of everything; auto: behind the template forms
+  if (auto_stage) {  // auto: long rows with arbitrary values (FEM): measured 4-8 % ahead of the staged packed kernel, a tie on 27-point rows
+    if (A->nnz < (1 << 20) || A->nnz <= 32 * (int64_t)A->nrows_c) return HIPX_SUCCESS;
+    int ierr = ensure_vdict(A);
+    if (ierr) return ierr;
+    if (A->vd_ok) return HIPX_SUCCESS;
+  }
   int     ok = 0, packed = 0;
   double  pad = 0.0;
   int64_t bytes = 0;
@@ -2313,16 +2098,22 @@ int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, d
     if (sl) return hipxSellLaunch_(A->sell_state, MODE, DOT ? 1 : 0, x, yin, yout, dotpart);
   }
   {
+    bool tm = false;
+    int  ierr = use_templates(A, tm);
+    if (ierr) return ierr;
+    if (tm) return launch_tmpl<MODE, DOT>(A, x, yin, yout, dotpart, nullptr);
+  }
+  {
     bool tp = false;
     int  ierr = use_pattern_templates(A, tp);
     if (ierr) return ierr;
     if (tp) return launch_tp<IT, MODE, DOT>(A, x, yin, yout, dotpart);
   }
   {
-    bool tm = false;
-    int  ierr = use_templates(A, tm);
+    bool sl = false;
+    int  ierr = use_sell(A, sl, true);
     if (ierr) return ierr;
-    if (tm) return launch_tmpl<MODE, DOT>(A, x, yin, yout, dotpart, nullptr);
+    if (sl) return hipxSellLaunch_(A->sell_state, MODE, DOT ? 1 : 0, x, yin, yout, dotpart);
   }
   if (A->tile_mode >= 2 && !A->compressed && (!A->probe || A->vd_mode)) return launch_pk16<IT, MODE, DOT>(A, x, yin, yout, dotpart);
   if (A->probe && MODE == 0 && !DOT && !A->compressed && !A->is64) {
@@ -2356,18 +2147,24 @@ int dot_partials_count(hipxMat A, hipx_int *npart)
       *npart = hipxSellDotPartials_(A->sell_state);
       return HIPX_SUCCESS;
     }
-    bool tp = false;
-    if ((ierr = use_pattern_templates(A, tp))) return ierr;
-    if (tp) {
-      *npart = (hipx_int)(((A->nblocks[0] + 7) / 8) * 8) * 4;
-      return HIPX_SUCCESS;
-    }
   }
   {
     bool tm = false;
     int  ierr = use_templates(A, tm);
     if (ierr) return ierr;
     if (tm) return launch_tmpl<0, true>(A, nullptr, nullptr, nullptr, nullptr, npart);
+    bool tp = false;
+    if ((ierr = use_pattern_templates(A, tp))) return ierr;
+    if (tp) {
+      *npart = (hipx_int)(((A->nblocks[0] + 7) / 8) * 8) * 4;
+      return HIPX_SUCCESS;
+    }
+    bool sa = false;
+    if ((ierr = use_sell(A, sa, true))) return ierr;
+    if (sa) {
+      *npart = hipxSellDotPartials_(A->sell_state);
+      return HIPX_SUCCESS;
+    }
   }
   if (A->tile_mode >= 2 && !A->compressed && (!A->probe || A->vd_mode)) {
     bool vd, rowpar;
@@ -2657,6 +2454,8 @@ int hipxMatSetSpMVVariant(hipxMat A, int variant)
     A->tile_mode = auto_tile_mode(A);
     A->vd_mode   = A->tile_mode ? 1 : 0;
     A->tmpl_mode = A->tile_mode ? 1 : 0;
+    A->ptm_mode  = A->tile_mode ? 1 : 0;  // (used when neither the row templates nor the value dictionary apply: arbitrary values on a stencil pattern)
+    A->sell_mode = A->tile_mode ? 2 : 0;  // (auto stage: long rows with arbitrary values)
   }
   if (variant >= 22 && variant <= 26) variant = 1;
   A->sched_mode = variant >= 100 ? 1 : 0;
@@ -2688,13 +2487,18 @@ int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
     if (ierr) return ierr;
   }
   bool tp = false;
-  if (!sl) {
+  if (!sl && !tm) {
     int ierr = use_pattern_templates(A, tp);
     if (ierr) return ierr;
   }
+  if (!sl && !tm && !tp) {
+    int ierr = use_sell(A, sl, true);
+    if (ierr) return ierr;
+  }
   if (sl) name = "spmv_sell_kernel (MatMult on the SELL-64 copy: one lane per row, 16-bit window-coded columns)";
-  else if (tp) name = "spmv_tp_kernel (CSR MatMult, pattern templates: 1-byte pattern id per row, values streamed from a[])";
   else if (tm) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row)";
+  else if (tp) name = "spmv_tp_kernel (CSR MatMult, pattern templates: 1-byte pattern id per row, values streamed from a[])";
+  else if (false) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row)";
   else if (A->tile_mode >= 2 && !A->compressed && !A->probe) {
     bool vd, rowpar;
     int  rpt, cfg;

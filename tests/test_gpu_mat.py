@@ -118,7 +118,8 @@ def test_value_dictionary_ragged_rows_bit_exact(hx, seed, m, n, maxlen, variant)
 
 
 def test_auto_variant_selects_packed_kernels(hx):
-    """variant 0 on >= 2^20 nonzeros: short rows -> row-parallel packed kernel, long rows -> staged packed kernel; constant
+    """variant 0 on >= 2^20 nonzeros: short rows on <= 256 row patterns -> pattern templates (values streamed), other short rows ->
+    row-parallel packed kernel, long rows -> staged packed kernel; constant
     coefficient stencils get the row templates (1 byte per row), matrices with distinct values do not.  (Guards the default path.)"""
     from petsc_amd import _lib
     rng = np.random.default_rng(3)
@@ -126,7 +127,7 @@ def test_auto_variant_selects_packed_kernels(hx):
         ai, aj, aa = orc.stencil(kind, n)
         N = len(ai) - 1
         x = xvec(N)
-        for vals, w in [(aa, want), (aa * (1.0 + 1e-3 * rng.standard_normal(aa.size)), "spmv_pk16r_kernel" if kind == "7pt" else "spmv_pk16_kernel")]:
+        for vals, w in [(aa, want), (aa * (1.0 + 1e-3 * rng.standard_normal(aa.size)), "spmv_tp_kernel" if kind == "7pt" else "spmv_pk16_kernel")]:  # round 3: short rows on a stencil pattern with arbitrary values -> pattern templates
             A = _lib.mat_create_csr(N, N, ai, aj, vals)
             assert kernel_name(hx, A).startswith(w + " "), kernel_name(hx, A)
             _lib.chk(hx.hipxMatSetSpMVVariant(A, 0))  # explicit "auto" must not change the selection
