@@ -755,7 +755,10 @@ def main():
     }
     if not args.no_plugin and head.cube and args.ksp == "cg" and args.pc == "jacobi" and N <= 2 ** 25:
         plug = {}
-        for label, ksp in (("reference KSPSolve_CG over hipx types", "cg"), ("-ksp_type cghipx (fused kernels under PETSc's monitors / convergence test)", "cghipx")):
+        for label, ksp in (("reference KSPSolve_CG over hipx types", "cg"), ("-ksp_type cghipx (fused kernels under PETSc's monitors / convergence test)", "cghipx"),
+                           # the reference's reduction-fused / pipelined callers, unmodified, over the hipx types (their VecDotBegin/End
+                           # split reductions end in one blocking device reduction per VecDotEnd group)
+                           ("reference KSPSolve_PIPECG over hipx types (pipecg.c)", "pipecg"), ("reference KSPSolve_GROPPCG over hipx types (groppcg.c)", "groppcg")):
             a = [x if x != "cg" else ksp for x in head.driver_args(400)]
             rr = ref_driver(1, a, plugin=True)
             plug[ksp] = {"what": label, "iterations_per_s": (rr["its"] / rr["seconds"]) if rr else None, "iterations": rr["its"] if rr else None,

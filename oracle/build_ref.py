@@ -49,7 +49,7 @@ MPI_DIR = "/opt/conda"  # MPICH 3.3.2 of the image (its mpicc wrapper points at 
 
 def conf_defines(arch):
     """PETSC_* macros of the configuration for this arch, through the preprocessor (the header has an #if for mpich)."""
-    cmd = ["gcc", "-dM", "-E", "-I" + CONF, os.path.join(CONF, "petscconf.h")] + (["-DHIPX_REF_MPICH"] if arch == "mpich" else [])
+    cmd = ["gcc", "-dM", "-E", "-I" + CONF, os.path.join(CONF, "petscconf.h")] + (["-DHIPX_REF_MPICH"] if arch == "mpich" else []) + (["-DHIPX_REF_INT64"] if arch == "int64" else [])
     txt = subprocess.check_output(cmd, text=True)
     return set(re.findall(r"^#define\s+(PETSC_\w+)", txt, flags=re.M))
 
@@ -110,6 +110,8 @@ def arch_flags(arch):
     if arch == "mpich":
         return (os.path.join(OUT, "mpich"), CFLAGS + ["-DHIPX_REF_MPICH", "-I" + os.path.join(MPI_DIR, "include")],
                 ["-L" + os.path.join(MPI_DIR, "lib"), "-Wl,-rpath," + os.path.join(MPI_DIR, "lib"), "-lmpi"])
+    if arch == "int64":  # MPIUNI with 64-bit PetscInt (--with-64-bit-indices): systems beyond 2^31 nonzeros through the drop-in (27-pt 512^3)
+        return os.path.join(OUT, "int64"), CFLAGS + ["-DHIPX_REF_INT64"], []
     return OUT, CFLAGS, []
 
 

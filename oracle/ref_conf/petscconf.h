@@ -71,6 +71,9 @@
 #define PETSC_USE_VISIBILITY_C 1
 #define PETSC_USE_VISIBILITY_CXX 1
 #define PETSC_USE_CTABLE 1
+#if defined(HIPX_REF_INT64) /* third build of the same sources: 64-bit PetscInt (configure --with-64-bit-indices) */
+#define PETSC_USE_64BIT_INDICES 1
+#endif
 #define PETSC_USE_LOG 1
 #define PETSC_USE_INFO 1
 #define PETSC_USE_ISATTY 1

@@ -108,12 +108,14 @@ def build_all(force=False, verbose=False):
         import build_ref  # noqa: E402
         out["ref"] = build_ref.build(verbose=verbose)
         out["ref_mpich"] = build_ref.build(verbose=verbose, arch="mpich")  # same sources against the image's MPICH, for np > 1 parity
+        out["ref_int64"] = build_ref.build(verbose=verbose, arch="int64")  # same sources with 64-bit PetscInt (systems beyond 2^31 nonzeros through the drop-in)
         plug = os.path.join(ROOT, "petsc_amd", "plugin", "build_plugin.py")
         if os.path.exists(plug):
             sys.path.insert(0, os.path.join(ROOT, "petsc_amd", "plugin"))
             import build_plugin  # noqa: E402
             out["plugin"] = build_plugin.build(verbose=verbose)
             out["plugin_mpich"] = build_plugin.build(verbose=verbose, arch="mpich")
+            out["plugin_int64"] = build_plugin.build(verbose=verbose, arch="int64")
     return out
 
 

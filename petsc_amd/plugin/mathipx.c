@@ -29,6 +29,39 @@ PetscBool MatIsSeqAIJHIPX(Mat A)
   return (PetscBool)(A && A->ops->mult == MatMult_SeqAIJHIPX);
 }
 
+/* The CSR arrays of Mat_SeqAIJ -> libhipx.  hipx_int is 32-bit; with a 64-bit-PetscInt libpetsc (--with-64-bit-indices: systems beyond
+   2^31 nonzeros, e.g. the 27-pt 512^3 operator on ONE GPU) the row offsets go through as they are (hipxMatCreateCSR64), the column
+   indices -- which address a vector of < 2^31 local entries -- are narrowed into a temporary. */
+static PetscErrorCode MatSeqAIJHIPXCreateDevice(Mat A, const PetscScalar *aa, PetscBool use_cprow, hipxMat *dA)
+{
+  Mat_SeqAIJ *a = (Mat_SeqAIJ *)A->data;
+
+  PetscFunctionBegin;
+#if defined(PETSC_USE_64BIT_INDICES)
+  {
+    hipx_int *j32;
+    PetscCheck(A->rmap->n < PETSC_INT32_MAX && A->cmap->n < PETSC_INT32_MAX, PETSC_COMM_SELF, PETSC_ERR_SUP, "MATSEQAIJHIPX: local sizes must stay below 2^31 (only the nonzero count may exceed it)");
+    PetscCall(PetscMalloc1((size_t)a->nz + 1, &j32));
+    for (PetscInt k = 0; k < a->nz; k++) j32[k] = (hipx_int)a->j[k];
+    if (use_cprow) {
+      hipx_int *ci, *ri, nr = (hipx_int)a->compressedrow.nrows;
+      PetscCheck(a->nz < PETSC_INT32_MAX, PETSC_COMM_SELF, PETSC_ERR_SUP, "compressed-row block beyond 2^31 nonzeros");
+      PetscCall(PetscMalloc2((size_t)nr + 1, &ci, (size_t)nr + 1, &ri));
+      for (hipx_int k = 0; k <= nr; k++) ci[k] = (hipx_int)a->compressedrow.i[k];
+      for (hipx_int k = 0; k < nr; k++) ri[k] = (hipx_int)a->compressedrow.rindex[k];
+      PetscCallHIPX(hipxMatCreateCSRCompressedRow((hipx_int)A->rmap->n, (hipx_int)A->cmap->n, nr, ci, ri, j32, aa, dA));
+      PetscCall(PetscFree2(ci, ri));
+    } else PetscCallHIPX(hipxMatCreateCSR64((hipx_int)A->rmap->n, (hipx_int)A->cmap->n, (const int64_t *)a->i, j32, aa, dA));
+    PetscCall(PetscFree(j32));
+  }
+#else
+  if (use_cprow) PetscCallHIPX(hipxMatCreateCSRCompressedRow(A->rmap->n, A->cmap->n, a->compressedrow.nrows, a->compressedrow.i, a->compressedrow.rindex, a->j, aa, dA));
+  else PetscCallHIPX(hipxMatCreateCSR(A->rmap->n, A->cmap->n, a->i, a->j, aa, dA));
+#endif
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+
 /* device CSR, (re)built lazily */
 PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA)
 {
@@ -52,8 +85,8 @@ PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA)
       /* Mat_CompressedRow (matimpl.h:425-430; MatAssemblyEnd_SeqAIJ checks it, aij.c:1138): the off-diagonal block of an MPIAIJ
          matrix has entries in a few rows only -- MatMult_SeqAIJ / MatMultAdd_SeqAIJ then walk the listed rows (aij.c:1463-1478,
          1624-1641), and so does the device kernel (y is not streamed for the empty rows) */
-      PetscCallHIPX(hipxMatCreateCSRCompressedRow(A->rmap->n, A->cmap->n, a->compressedrow.nrows, a->compressedrow.i, a->compressedrow.rindex, a->j, aa, &h->dA));
-    } else PetscCallHIPX(hipxMatCreateCSR(A->rmap->n, A->cmap->n, a->i, a->j, aa, &h->dA));
+      PetscCall(MatSeqAIJHIPXCreateDevice(A, aa, PETSC_TRUE, &h->dA));
+    } else PetscCall(MatSeqAIJHIPXCreateDevice(A, aa, PETSC_FALSE, &h->dA));
     PetscCall(MatSeqAIJRestoreArrayRead(A, &aa));
     if (h->spmv_variant) PetscCallHIPX(hipxMatSetSpMVVariant(h->dA, (int)h->spmv_variant));
     h->nonzerostate = A->nonzerostate;
@@ -232,8 +265,8 @@ PetscErrorCode MatSeqAIJHIPXSetValuesCOO_Private(Mat A, hipxCOO coo, const Petsc
   PetscFunctionBegin;
   if (!h->dA || h->nonzerostate != A->nonzerostate) { /* device CSR of the preallocated pattern; values start at zero (aij.c:4693) */
     if (h->dA) PetscCallHIPX(hipxMatDestroy(&h->dA));
-    if (imode == ADD_VALUES) PetscCallHIPX(hipxMatCreateCSR(A->rmap->n, A->cmap->n, a->i, a->j, a->a, &h->dA));
-    else PetscCallHIPX(hipxMatCreateCSR(A->rmap->n, A->cmap->n, a->i, a->j, NULL, &h->dA));
+    if (imode == ADD_VALUES) PetscCall(MatSeqAIJHIPXCreateDevice(A, a->a, PETSC_FALSE, &h->dA));
+    else PetscCall(MatSeqAIJHIPXCreateDevice(A, NULL, PETSC_FALSE, &h->dA));
     if (h->spmv_variant) PetscCallHIPX(hipxMatSetSpMVVariant(h->dA, (int)h->spmv_variant));
     h->nonzerostate = A->nonzerostate;
   } else if (!h->dev_newer && imode == ADD_VALUES) { /* the host copy is the current one: bring it over before adding to it */

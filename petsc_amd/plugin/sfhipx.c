@@ -448,10 +448,10 @@ static PetscErrorCode PetscSFDestroy_HIPX(PetscSF sf)
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
-static PetscErrorCode SFHIPXExtDestroy(void **p)
+static PetscErrorCode SFHIPXExtDestroy(PetscCtxRt ctx)
 {
   PetscFunctionBegin;
-  PetscCall(PetscFree(*p));
+  PetscCall(PetscFree(*(void **)ctx));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
