@@ -86,6 +86,8 @@ struct hipxMat_s {
   int            ptm_mode = 0, ptm_ntmpl = 0, ptm_nent = 0, ptm_maxlen = 0;
   unsigned char *d_ptid    = nullptr;
   int           *d_ptstart = nullptr, *d_ptoff = nullptr;
+  std::vector<int>     h_ptstart, h_ptoff, h_ptdiag;  // host copies (SOR set-up for variable-coefficient stencils reads them)
+  std::vector<int64_t> h_ptcount;
   void     *sell_state = nullptr; // SellState, owned by hipx_sell.hip (variant 28: sliced-ELLPACK copy)
   int       sell_mode  = 0;
   unsigned long long value_state = 1;
@@ -1847,6 +1849,10 @@ int ensure_pattern_templates(hipxMat A)
     A->ptm_ntmpl  = A->ntmpl;
     A->ptm_nent   = A->tmpl_nent;
     A->ptm_maxlen = A->tmpl_maxlen;
+    A->h_ptstart  = std::move(A->h_tstart);
+    A->h_ptoff    = std::move(A->h_toff);
+    A->h_ptdiag   = std::move(A->h_tdiag);
+    A->h_ptcount  = std::move(A->h_tcount);
     (void)hipFree(A->d_tval);
   } else {
     (void)hipFree(A->d_tid);
@@ -2420,6 +2426,29 @@ int hipxMatTemplates_(hipxMat A, int *ok, int *ntmpl, const int **tstart, const 
   *tdiag  = A->h_tdiag.data();
   *tcount = A->h_tcount.data();
   *d_tid  = A->d_tid;
+  return HIPX_SUCCESS;
+}
+
+// internal accessor for hipx_sor.hip: the PATTERN templates (the rows' (column - row) lists without the values: matrices with
+// arbitrary values on a stencil pattern), built on demand; host tables + the device copies the coefficient-stream kernel reads
+int hipxMatPatternTemplates_(hipxMat A, int *ok, int *ntmpl, const int **tstart, const int **toff, const int **tdiag, const int64_t **tcount, const unsigned char **d_tid,
+                             const int **d_tstart, const int **d_toff)
+{
+  HIPX_ARG(A, "null matrix");
+  *ok = 0;
+  if (A->compressed || A->nrows_c <= 0) return HIPX_SUCCESS;
+  int ierr;
+  if ((ierr = ensure_pattern_templates(A))) return ierr;
+  if (!A->ptm_ok || A->h_ptstart.empty()) return HIPX_SUCCESS;
+  *ok       = 1;
+  *ntmpl    = A->ptm_ntmpl;
+  *tstart   = A->h_ptstart.data();
+  *toff     = A->h_ptoff.data();
+  *tdiag    = A->h_ptdiag.data();
+  *tcount   = A->h_ptcount.data();
+  *d_tid    = A->d_ptid;
+  *d_tstart = A->d_ptstart;
+  *d_toff   = A->d_ptoff;
   return HIPX_SUCCESS;
 }
 

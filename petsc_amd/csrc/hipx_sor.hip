@@ -49,6 +49,7 @@ struct hipxSorState {
   unsigned int zero_pivots = 0;
   void     *strand = nullptr;   // StrandState: strand-scheduled sweeps for template (stencil) matrices
   bool      strand_tried = false;
+  const int *var_tstart = nullptr, *var_toff = nullptr;  // device tables of the pattern templates (owned by the matrix)
   int       last_mode = -1;
   unsigned long long strand_vstate = 0;  // value state of the matrix the strand tables were built from
 };
@@ -391,6 +392,10 @@ struct StParams {
   int      lock, off_lock, lock_wrow;  // lockstep C wave (st_lock_c): on; its per-template table {c0,c1}{c2,c3}{mask}; window row of the strand before the panel's first
   unsigned rolemap;      // split kernel: role (0 C, 1 F even, 2 F odd, 3 loader) of the wave on SIMD s of the CU's first / second resident workgroup: nibble s / 4 + s; 0: by wave index
   int      trace_panel;  // HIPX_SOR_DEBUG + HIPX_SOR_TRACE_PANEL: the panel whose rows / loader passes are time-stamped (-1: none)
+  // variable-coefficient kernels (pattern templates: the tables hold the STRUCTURE of every row only; the coefficients and the
+  // inverse diagonal of every row come from a per-direction stream the loader stages into an LDS ring)
+  int      var, cw, rq, off_cring, wgcu;  // on; doubles per coefficient record (ME coefficients, 1 / d, padding to even); ring depth
+                                          // (operand AND coefficient ring); LDS offset of the coefficient ring; workgroups per CU that fit
 };
 struct __attribute__((aligned(16))) StEntry {  // dep: pk = (window row offset << 16) | (dp & 0xffff), lo = logical row offset; old: pk = ACTUAL column - row
   int    pk, lo;
@@ -612,14 +617,18 @@ __device__ __forceinline__ int st_strand_len(long long S, const StParams &P)
 // (at most) 4 entries -- the previous line of the same plane and the row's own predecessor: the ones the NEXT lane is waiting
 // for -- then the scale, the publish, the stores.  The lane-to-lane critical path of a line is then ~1/3 of the instructions.
 // The left-to-right order of the subtractions is unchanged (F's end is C's start), so the sums are bit-identical.
-template <int KIND, int ME, int ROLE, bool PAIR = false>
+// CWT > 0 (ROLE 0 only): the variable-coefficient form -- the row's coefficients and 1 / d are read from the coefficient ring
+// (CWT doubles per record, staged by the loader next to the operand record) when the row starts, instead of from the template.
+template <int KIND, int ME, int ROLE, bool PAIR = false, int CWT = 0>
 __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *lds, const unsigned lds_base, volatile st_lds_int *s_prog_own, volatile st_lds_int *s_prog_c,
                                                 volatile st_lds_int *s_ctl, unsigned int *err, const int lane, const unsigned panel, const long long S, const int len, double *t,
                                                 const double *xold, double *xnew, const double omega, unsigned long long *stats, const int par,
                                                 unsigned long long *fst = nullptr)
 {
   constexpr bool FWD = (KIND == 0 || KIND == 3);
+  static_assert(CWT == 0 || (ROLE == 0 && KIND <= 2 && CWT >= ME + 1 && CWT % 2 == 0), "variable coefficients: whole-row compute wave, sweeps without old-value lists");
   const hipx_int m = P.m, L = P.L;
+  const int      RQ = CWT ? P.rq : ST_RQ;  // depth of the operand ring (a power of two)
   const int      stride = ROLE == 1 ? 2 : 1;  // the two F waves take the even and the odd rows of every strand (row sums do not depend on each other)
   int       p = ROLE == 1 ? par : 0, ostart = 0, ocnt = 0, dtab = 0, cur_tid = -1, setp = 0;  // setp: the position apos[] / sa[] are set for; dtab: byte offset of the template's entry list
   bool      have = false;
@@ -640,7 +649,8 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
   }
   // the per-row record {operand a | partial sum, old value}{template id, tag}: from the loader's operand ring, or (ROLE 2) from the
   // two-deep hand-over ring the F wave fills
-  const unsigned rec_base = lds_base + (unsigned)(P.off_rowq + 32 * ST_RQ * lane);
+  const unsigned rec_base = lds_base + (unsigned)(P.off_rowq + 32 * RQ * lane);
+  const int      crec_off = CWT ? P.off_cring + 8 * CWT * RQ * lane : 0;  // this lane's coefficient records (byte offset in the LDS region)
   const unsigned cq_base  = lds_base + (unsigned)(P.off_cq + 16 * ST_CQ * lane);  // SPLIT: {partial sum, template id, tag}, ST_CQ deep
   const int      rq_rot   = ST_ROT * lane;
   unsigned       pubrow[ST_NB];  // this lane's own window row in band b (byte address of slot 0), ~0u: the band has none for it
@@ -711,6 +721,17 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
       }
       setp = p;
     }
+    if constexpr (CWT > 0) {
+      // the record was written before the operand record's tag (the loader's LDS writes execute in order) and its slot is not
+      // reused before this lane's progress passes p: valid now.  Padding entries carry 0.0, like the templates' null entries.
+      st_int4   cr[CWT / 2];
+      const int cb = crec_off + 8 * CWT * ((p + rq_rot) & (RQ - 1));
+#pragma unroll
+      for (int h = 0; h < CWT / 2; h++) cr[h] = st_ld4(lds, cb + 16 * h);
+#pragma unroll
+      for (int j = 0; j < ME; j++) cf[j] = (j & 1) ? st_dbl(cr[j >> 1].z, cr[j >> 1].w) : st_dbl(cr[j >> 1].x, cr[j >> 1].y);
+      idiag = (ME & 1) ? st_dbl(cr[ME >> 1].z, cr[ME >> 1].w) : st_dbl(cr[ME >> 1].x, cr[ME >> 1].y);
+    }
     have = true;
     if (KIND == 4) {  // aij.c:1984-1990: the lower part and the diagonal use OLD values, in row order, first
       const hipx_int r = st_actual<FWD>(S * L + p, m);
@@ -740,7 +761,7 @@ __device__ __forceinline__ void st_compute_role(const StParams &P, st_lds_char *
       // while it is still missing); one wait
       st_int4        sl[ME], w0, w1;
       const int      qr = have ? p + stride : p;
-      const unsigned ra = rec_base + (unsigned)(32 * ((qr + rq_rot) & (ST_RQ - 1)));
+      const unsigned ra = rec_base + (unsigned)(32 * ((qr + rq_rot) & (RQ - 1)));
       const unsigned rt = ROLE == 2 ? cq_base + (unsigned)(16 * (qr & (ST_CQ - 1))) : ra + 16;
       const long long c_b0 = stats ? (long long)clock64() : 0;
       st_lds_burst_row<ME>(sl, w0, w1, sa, ra, rt);
@@ -1108,15 +1129,20 @@ __device__ __forceinline__ void st_lock_c(const StParams &P, const unsigned lds_
 }
 
 // The loader wave of a panel: operands of the own strands into the operand ring, far strands into the window.
-template <int KIND, bool ALIGNED, bool SPLIT>
+// CWT > 0: variable coefficients -- the loader also stages every row's coefficient record (CWT doubles from the stream cs, which is
+// indexed by LOGICAL position: ascending addresses in both sweep directions) into the coefficient ring, before the operand record's tag.
+template <int KIND, bool ALIGNED, bool SPLIT, int CWT = 0>
 __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *lds, volatile st_lds_int *s_lead, volatile st_lds_int *s_trail, volatile st_lds_int *s_ctl, const int lane,
                                                const unsigned panel, const long long S0, const int cnt, const long long S, const int len, const unsigned char *__restrict__ tid,
                                                const double *asrc,
-                                               const double *xold, const double *xnew, unsigned long long *stats)
+                                               const double *xold, const double *xnew, unsigned long long *stats, const double *__restrict__ cs = nullptr)
 {
   constexpr bool FWD     = (KIND == 0 || KIND == 3);
   constexpr bool NEEDOLD = (KIND == 1 || KIND == 3 || KIND == 4);  // the row's own old value
+  constexpr int  VSB     = CWT == 0 ? ST_SB : (CWT <= 6 ? 8 : 4);  // rows staged per pass (the coefficient records of a pass sit in registers: VSB * CWT doubles)
+  typedef double st_dbl2 __attribute__((ext_vector_type(2)));
   const hipx_int m = P.m, L = P.L;
+  const int      RQ = CWT ? P.rq : ST_RQ;
   int rqf = 0;  // next position of the own strand whose operands are to be staged
   unsigned st_pass = 0, st_idle = 0;
   int sf[2 * ST_NB];
@@ -1156,8 +1182,8 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
     unsigned      tb[2] = {0, 0};  // ALIGNED: the template ids of each group of 4 as loaded; unpacked when they land
     const int ring_tail = SPLIT ? (int)s_trail[lane] : myp;  // SPLIT: the C wave still reads the row's old value from the ring
     if (rqf < len) {
-      int room = (ring_tail + ST_RQ - rqf) & ~3;
-      if (room > ST_SB) room = ST_SB;
+      int room = (ring_tail + RQ - rqf) & ~3;
+      if (room > VSB) room = VSB;
       nrow = (len - rqf) < room ? (len - rqf) : room;
     }
     if (nrow > 0) {
@@ -1200,6 +1226,18 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
           vb[j]            = NEEDOLD ? xold[r] : 0.0;
           vt[j]            = tid[r];
         }
+      }
+    }
+    st_dbl2 cv[CWT ? VSB : 1][CWT ? CWT / 2 : 1];
+    if constexpr (CWT > 0) {
+      if (nrow > 0) {
+        const st_dbl2 *src = reinterpret_cast<const st_dbl2 *>(cs + (S * L + rqf) * CWT);  // (hipMalloc'ed, CWT even: 16-byte aligned)
+#pragma unroll
+        for (int j = 0; j < VSB; j++)
+          if (j < nrow) {
+#pragma unroll
+            for (int h = 0; h < CWT / 2; h++) cv[j][h] = src[j * (CWT / 2) + h];
+          }
       }
     }
     // (b) far strands: every duty = one window row of another panel's strand, staged ahead of its consumers.  Two rounds of
@@ -1290,7 +1328,17 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
 #pragma unroll
         for (int j = 0; j < ST_SB; j++) {
           if (j < nrow) {
-            const int       ro = P.off_rowq + 32 * (lane * ST_RQ + ((rqf + j + ST_ROT * lane) & (ST_RQ - 1)));
+            const int       ro = P.off_rowq + 32 * (lane * RQ + ((rqf + j + ST_ROT * lane) & (RQ - 1)));
+            if constexpr (CWT > 0) {
+              if (j < VSB) {
+                const int co = P.off_cring + 8 * CWT * (lane * RQ + ((rqf + j + ST_ROT * lane) & (RQ - 1)));
+#pragma unroll
+                for (int h = 0; h < CWT / 2; h++) {
+                  const long long c0 = __double_as_longlong(cv[j < VSB ? j : 0][h].x), c1 = __double_as_longlong(cv[j < VSB ? j : 0][h].y);
+                  st_st4v(lds, co + 16 * h, st_int4{(int)(unsigned)c0, (int)(unsigned)((unsigned long long)c0 >> 32), (int)(unsigned)c1, (int)(unsigned)((unsigned long long)c1 >> 32)});
+                }
+              }
+            }
             const long long ba = __double_as_longlong(va[j]), bb = __double_as_longlong(vb[j]);
             st_int4         w0, w1;
             w0.x = (int)(unsigned)ba;
@@ -1374,13 +1422,17 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
 // per panel -- C, F, loader (see st_compute_role) -- instead of compute + loader.
 // DBG: the HIPX_SOR_DEBUG instrumentation is compiled into its own instantiation (the production kernel carries none of the
 // ~12 `if (stats)` tests per iteration)
-template <int KIND, bool ALIGNED, int ME, bool SPLIT, bool DBG>
+// CWT > 0: variable coefficients (pattern templates + the coefficient stream cs; two-wave kernel, kinds 0-2).
+template <int KIND, bool ALIGNED, int ME, bool SPLIT, bool DBG, int CWT = 0>
 __global__ __launch_bounds__(SPLIT ? 256 : 128, SPLIT ? 2 : 1) void sor_strand_kernel(const StParams P, const unsigned char *__restrict__ tid, const StTinfo *__restrict__ g_tinfo,
                                                                        const StDiag *__restrict__ g_tdiag, const StEntry *__restrict__ g_dep, const StEntry *__restrict__ g_old,
                                                                        const StEntry *__restrict__ g_depF, const StEntry *__restrict__ g_depC, const int *__restrict__ pstart,
                                                                        const double *asrc, double *t,
-                                                                       const double *xold, double *xnew, double omega, unsigned int *ctl, unsigned long long *stats_arg)
+                                                                       const double *xold, double *xnew, double omega, unsigned int *ctl, unsigned long long *stats_arg,
+                                                                       const double *__restrict__ cs)
 {
+  static_assert(CWT == 0 || !SPLIT, "variable coefficients: two-wave kernel only");
+  const int RQ = CWT ? P.rq : ST_RQ;
   constexpr int NT = SPLIT ? 256 : 128;
   unsigned long long *const stats = DBG ? stats_arg : nullptr;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1428,7 +1480,7 @@ __global__ __launch_bounds__(SPLIT ? 256 : 128, SPLIT ? 2 : 1) void sor_strand_k
       const st_int4 empty = {0, 0, -1, 0};
       for (int i = threadIdx.x; i < P.nrows * ST_WP; i += NT) st_st4v(lds, P.off_win + 16 * i, empty);
       const st_int4 empty_row = {0, -1, 0, 0};  // second half of a StRow: {tid, tag, -, -}
-      for (int i = threadIdx.x; i < 64 * ST_RQ; i += NT) st_st4v(lds, P.off_rowq + 32 * i + 16, empty_row);
+      for (int i = threadIdx.x; i < 64 * RQ; i += NT) st_st4v(lds, P.off_rowq + 32 * i + 16, empty_row);
       if (SPLIT)
         for (int i = threadIdx.x; i < 64 * ST_CQ; i += NT) st_st4v(lds, P.off_cq + 16 * i, st_int4{0, 0, 0, -1});
     }
@@ -1461,8 +1513,8 @@ __global__ __launch_bounds__(SPLIT ? 256 : 128, SPLIT ? 2 : 1) void sor_strand_k
                                         stats ? stats + 16 + 4 * (size_t)P.npanels + 64 * (size_t)P.L + 2 * 4096 * 8 + 48 + 8 * (wave - 1) : nullptr);
       else st_loader_role<KIND, ALIGNED, true>(P, lds, s_progF, s_prog, s_ctl, lane, panel, S0, cnt, S, len, tid, asrc, xold, xnew, stats);
     } else {
-      if (wave == 0) st_compute_role<KIND, ME, 0, ALIGNED>(P, lds, lds_base, s_prog, s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, stats, 0);
-      else st_loader_role<KIND, ALIGNED, false>(P, lds, s_prog, s_prog, s_ctl, lane, panel, S0, cnt, S, len, tid, asrc, xold, xnew, stats);
+      if (wave == 0) st_compute_role<KIND, ME, 0, ALIGNED, CWT>(P, lds, lds_base, s_prog, s_prog, s_ctl, err, lane, panel, S, len, t, xold, xnew, omega, stats, 0);
+      else st_loader_role<KIND, ALIGNED, false, CWT>(P, lds, s_prog, s_prog, s_ctl, lane, panel, S0, cnt, S, len, tid, asrc, xold, xnew, stats, cs);
     }
     // All roles share this function: without this, loads the LOADER branch may leave pending at the back edge of the panel loop
     // count as pending in the COMPUTE branches too (the compiler merges the paths), which plants vmcnt waits -- i.e. waits for
@@ -1490,8 +1542,36 @@ __global__ void st_verify_kernel(const StParams P, int forward, const unsigned c
   }
 }
 
+// Variable coefficients: one record of cw doubles per LOGICAL position q (row q forward, row m - 1 - q backward): the row's
+// dependency-side coefficients in CSR order (= the order of the pattern template's entry list, padded with 0.0 to me), then the
+// inverse diagonal with the same IEEE operations as invert_diag_kernel (aij.c:1807-1830), then 0.0 up to cw.
+template <typename IT>
+__global__ void st_cstream_kernel(hipx_int m, int forward, int me, int cw, const IT *__restrict__ ai, const double *__restrict__ aa, const int64_t *__restrict__ diagpos,
+                                  const unsigned char *__restrict__ tid, const int *__restrict__ tstart, const int *__restrict__ toff, double omega, double shift, int plain,
+                                  double *__restrict__ cs, unsigned int *zero_count)
+{
+  for (hipx_int q = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; q < m; q += (hipx_int)gridDim.x * blockDim.x) {
+    const hipx_int r  = forward ? q : m - 1 - q;
+    const int      t  = tid[r];
+    const int64_t  k0 = (int64_t)ai[r];
+    const int      e0 = tstart[t], e1 = tstart[t + 1];
+    double        *out = cs + (size_t)q * (size_t)cw;
+    int            j = 0;
+    for (int e = e0; e < e1; e++) {
+      const int off = toff[e];
+      if ((forward ? off < 0 : off > 0) && j < me) out[j++] = aa[k0 + (e - e0)];
+    }
+    for (; j < me; j++) out[j] = 0.0;
+    const double d = aa[diagpos[r]];
+    if (d == 0.0 && plain && shift == 0.0) atomicAdd(zero_count, 1u);
+    out[me] = plain ? 1.0 / d : omega / (shift + d);
+    for (j = me + 1; j < cw; j++) out[j] = 0.0;
+  }
+}
+
 struct StrandDir {
   bool      ok = false;
+  double   *d_cs = nullptr;  // variable coefficients: the coefficient stream of this direction (m * P.cw doubles)
   StParams  P, Ps;  // Ps: the layout of the split kernel (P.split)
   StTinfo  *d_tinfo = nullptr;
   StDiag   *d_tdiag = nullptr;
@@ -1512,6 +1592,9 @@ struct StrandState {
   unsigned long long   value_state = 0;
   double               omega = 0.0, shift = 0.0;
   bool                 diag_uploaded = false;
+  bool                 var = false;       // built from PATTERN templates: coefficients per row from the streams (kinds 0-2 only)
+  bool                 cs_valid = false;  // ... which hold the current values, omega and shift
+  unsigned int         zero_pivots = 0;
 };
 
 void strand_free(StrandState *T)
@@ -1525,6 +1608,7 @@ void strand_free(StrandState *T)
     (void)hipFree(D.d_depC);
     (void)hipFree(D.d_pstart);
     (void)hipFree(D.d_old);
+    (void)hipFree(D.d_cs);
   }
   (void)hipFree(T->d_ctl);
   (void)hipFree(T->d_stats);
@@ -1548,9 +1632,12 @@ hipx_int strand_length(const int *toff, int len)
   return best;
 }
 
-int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const int *toff, const double *tval, const int *tdiag, const int64_t *tcount, const unsigned char *d_tid)
+// var: the tables come from PATTERN templates (tval == nullptr): structure only, no split / lockstep kernels, no old-value lists
+int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const int *toff, const double *tval, const int *tdiag, const int64_t *tcount, const unsigned char *d_tid,
+                 bool var = false)
 {
   T->ok    = false;
+  T->var   = var;
   T->d_tid = d_tid;
   T->ntmpl = ntmpl;
   int best = 0;
@@ -1561,7 +1648,7 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
   T->diagval.assign((size_t)ntmpl, 0.0);
   for (int t = 0; t < ntmpl; t++) {
     if (tdiag[t] < 0) return HIPX_SUCCESS;
-    T->diagval[(size_t)t] = tval[tstart[t] + tdiag[t]];
+    T->diagval[(size_t)t] = var ? 1.0 : tval[tstart[t] + tdiag[t]];
   }
   hipStream_t st = rt().compute;
   HIPX_HIP(hipMalloc((void **)&T->d_ctl, sizeof(unsigned int) * (4 + 4096)));  // [0] ticket, [1] error, [2] verify, [4...] arrivals per CU (role parity)
@@ -1658,7 +1745,7 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
       for (int k = tstart[t]; k < tstart[t + 1]; k++) c += (fwd ? toff[k] < 0 : toff[k] > 0) ? 1 : 0;
       maxdep = std::max(maxdep, c);
     }
-    if (maxdep > ST_ME) continue;  // rows with more dependency entries than the compute wave handles: level-ordered schedule
+    if (maxdep > (var ? 13 : ST_ME)) continue;  // rows with more dependency entries than the compute wave handles: level-ordered schedule
     const int ME = maxdep <= 4 ? 4 : (maxdep <= 13 ? 13 : ST_ME);  // 13: the 27-point class (3 fewer padding entries per row and iteration)
     for (int t = 0; t < ntmpl; t++) {
       StTinfo &ti = tinfo[(size_t)t];
@@ -1674,10 +1761,10 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
           StEntry   e;
           e.pk  = ((P.band[b].rowbase + ds - P.band[b].dsmin) << 16) | (dp & 0xffff);
           e.lo  = fwd ? off : -off;
-          e.val = tval[k];
+          e.val = var ? 0.0 : tval[k];
           dep.push_back(e);
           ndep_t++;
-        } else if (fwd ? off > 0 : off <= 0) {  // forward: upper part (KIND 3); backward: lower part then the diagonal (KIND 4)
+        } else if (!var && (fwd ? off > 0 : off <= 0)) {  // forward: upper part (KIND 3); backward: lower part then the diagonal (KIND 4)
           StEntry e;
           e.pk  = off;
           e.lo  = 0;
@@ -1696,7 +1783,7 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
     // split kernel (ME 16): the list of a template cut into its first (up to) 12 and last (up to) 4 entries, fixed strides
     static const bool split_on = !(getenv("HIPX_SOR_SPLIT") && atoi(getenv("HIPX_SOR_SPLIT")) == 0);
     std::vector<StEntry> depF, depC;
-    P.split = (ME >= 13 && split_on) ? 1 : 0;
+    P.split = (ME >= 13 && split_on && !var) ? 1 : 0;
     // lockstep C wave (st_lock_c; forward sweep): every list must be far entries (strands of other panels: delta <= -64) followed
     // by near entries out of {(-1,-1), (-1,0), (-1,+1), (0,-1)} in this order.  HIPX_SOR_LOCKSTEP=0|1.
     static const bool lock_on = !(getenv("HIPX_SOR_LOCKSTEP") && atoi(getenv("HIPX_SOR_LOCKSTEP")) == 0);
@@ -1742,9 +1829,19 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
         for (int k = 0; k < ST_MC; k++) depC.push_back(k < nC ? dep[(size_t)ti.dstart + nF + k] : StEntry{ST_NULLPK, 0, 0.0});
       }
     }
+    if (var) {
+      // ring depth: 8 rows ahead fit two workgroups per CU for the 5-/7-point class (48-byte records); the 27-point class (112-byte
+      // records) needs 57 KiB for that depth -> one workgroup per CU, or depth 4 with two (HIPX_SOR_VAR_RING=4|8|16)
+      static const int ring_env = getenv("HIPX_SOR_VAR_RING") ? atoi(getenv("HIPX_SOR_VAR_RING")) : 0;
+      P.var = 1;
+      P.cw  = (ME + 2) & ~1;  // ME coefficients + 1 / d, padded to whole 16-byte words: 6 (ME 4), 14 (ME 13)
+      P.rq  = (ring_env == 4 || ring_env == 8 || ring_env == 16) ? ring_env : 8;
+    }
+    const int RQ = var ? P.rq : ST_RQ;
     int o = 0;
     P.off_win   = o; o += P.nrows * ST_WP * (int)sizeof(StSlot);
-    P.off_rowq  = o; o += 64 * ST_RQ * (int)sizeof(StRow);
+    P.off_rowq  = o; o += 64 * RQ * (int)sizeof(StRow);
+    if (var) { P.off_cring = o; o += 64 * RQ * P.cw * 8; }
     P.off_tinfo = o; o += ntmpl * (int)sizeof(StTinfo);
     P.off_tdiag = o; o += ntmpl * (int)sizeof(StDiag);
     P.off_dep   = o; o += std::max(P.ndep, 1) * (int)sizeof(StEntry);
@@ -1754,7 +1851,8 @@ int strand_build(StrandState *T, hipx_int m, int ntmpl, const int *tstart, const
     P.off_null  = o; o += 16;
     P.off_cq = P.off_progF = P.off_depF = P.off_depC = 0;
     P.lds_bytes = o;
-    if (P.lds_bytes > 78 * 1024) continue;  // two workgroups per CU must fit the 160 KiB
+    P.wgcu      = P.lds_bytes > 78 * 1024 ? 1 : 2;
+    if (P.lds_bytes > (var ? 156 : 78) * 1024) continue;  // two workgroups per CU must fit the 160 KiB (variable coefficients: one may do)
     D.Ps = P;
     if (P.split) {  // the split kernel's own layout: its two tables instead of the whole-row one, no old-value lists (kinds 0-2 only)
       StParams &Q = D.Ps;
@@ -1828,6 +1926,33 @@ int strand_set_diag(StrandState *T, double omega, double shift)
   return HIPX_SUCCESS;
 }
 
+// variable coefficients: (re)build the two coefficient streams from the matrix's current values, omega and shift
+int strand_set_cs(StrandState *T, hipx_int m, int is64, const void *d_i, const double *d_a, const int64_t *d_diagpos, const int *d_tstart, const int *d_toff, double omega, double shift)
+{
+  if (T->cs_valid && T->omega == omega && T->shift == shift) return HIPX_SUCCESS;
+  hipStream_t   st    = rt().compute;
+  const int     plain = (omega == 1.0 && shift <= 0.0) ? 1 : 0;
+  unsigned int *cnt   = T->d_ctl + 3;
+  HIPX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
+  const unsigned g = (unsigned)std::min<hipx_int>((m + 255) / 256, 8192);
+  for (int dirn = 0; dirn < 2; dirn++) {
+    StrandDir &D = T->dir[dirn];
+    if (!D.d_cs) HIPX_HIP(hipMalloc((void **)&D.d_cs, sizeof(double) * (size_t)m * (size_t)D.P.cw));
+    if (is64)
+      st_cstream_kernel<int64_t><<<g, 256, 0, st>>>(m, dirn == 0 ? 1 : 0, D.P.me, D.P.cw, (const int64_t *)d_i, d_a, d_diagpos, T->d_tid, d_tstart, d_toff, omega, shift, plain, D.d_cs, cnt);
+    else
+      st_cstream_kernel<hipx_int><<<g, 256, 0, st>>>(m, dirn == 0 ? 1 : 0, D.P.me, D.P.cw, (const hipx_int *)d_i, d_a, d_diagpos, T->d_tid, d_tstart, d_toff, omega, shift, plain, D.d_cs, cnt);
+    HIPX_LAUNCH_CHECK();
+  }
+  HIPX_HIP(hipMemcpyAsync(&T->zero_pivots, cnt, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+  HIPX_HIP(hipStreamSynchronize(st));
+  T->zero_pivots /= 2;  // (both directions count the same rows)
+  T->omega    = omega;
+  T->shift    = shift;
+  T->cs_valid = true;
+  return HIPX_SUCCESS;
+}
+
 template <int KIND>
 int run_strand(StrandState *T, const double *asrc, double *t, const double *xold, double *xnew, double omega)
 {
@@ -1856,11 +1981,11 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 2) per_cu = 2;
   }
-  unsigned grid = (unsigned)std::min<long long>((long long)P.npanels, 256LL * per_cu);
+  unsigned grid = (unsigned)std::min<long long>((long long)P.npanels, 256LL * std::min(per_cu, P.wgcu ? P.wgcu : 2));
   static const bool want_aligned = !(getenv("HIPX_SOR_ALIGNED") && atoi(getenv("HIPX_SOR_ALIGNED")) == 0);  // 0: the kernels for any L / alignment (8-byte polls, scalar operand loads)
   const bool aligned = want_aligned && (P.L % 8 == 0) && (P.m % 8 == 0) && ((reinterpret_cast<uintptr_t>(asrc) | reinterpret_cast<uintptr_t>(xold) | reinterpret_cast<uintptr_t>(xnew) | reinterpret_cast<uintptr_t>(t)) % 16 == 0);  // (a null t / xold counts as aligned)
   static const bool dbg = getenv("HIPX_SOR_DEBUG") != nullptr;
-  static bool attr_set[5][20] = {{false}};
+  static bool attr_set[5][24] = {{false}};
   // The split kernel pays when the far entries come FIRST in the row's list (forward sweeps: lower planes, then the previous line,
   // then the row's predecessor): the F waves run ahead with them.  In a backward sweep the list starts with the near entries, the
   // far subtractions depend on them, and nothing can run ahead (measured on the config-3 slab: forward 2.1 us per line and 0.94 us
@@ -1881,11 +2006,11 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
   }
   auto launch = [&](auto kern, int ai) -> int {
     if (!attr_set[KIND][ai]) {
-      HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (P.var ? 158 : 80) * 1024));
       attr_set[KIND][ai] = true;
     }
     kern<<<grid, nthreads, (size_t)P.lds_bytes, st>>>(P, T->d_tid, D.d_tinfo, D.d_tdiag, D.d_dep, D.d_old, D.d_depF, D.d_depC, D.d_pstart, asrc, t, xold, xnew, omega, T->d_ctl,
-                                                       dbg ? T->d_stats : nullptr);
+                                                       (dbg && !P.var) ? T->d_stats : nullptr, D.d_cs);
     return HIPX_SUCCESS;
   };
   if (dbg) {
@@ -1908,7 +2033,13 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
   }
   int ierr;
 #define HIPX_ST_LAUNCH(AL, MEV, SP, IDX) (dbg ? launch(sor_strand_kernel<KIND, AL, MEV, SP, true>, 2 * (IDX) + 1) : launch(sor_strand_kernel<KIND, AL, MEV, SP, false>, 2 * (IDX)))
-  if (P.me == 4) ierr = aligned ? HIPX_ST_LAUNCH(true, 4, false, 1) : HIPX_ST_LAUNCH(false, 4, false, 0);
+  if (P.var) {  // variable coefficients: two-wave kernels of kinds 0-2, entry counts 4 and 13 (the production instantiation only)
+    if constexpr (KIND <= 2) {
+      if (P.me == 4) ierr = aligned ? launch(sor_strand_kernel<KIND, true, 4, false, false, 6>, 20) : launch(sor_strand_kernel<KIND, false, 4, false, false, 6>, 21);
+      else if (P.me == 13) ierr = aligned ? launch(sor_strand_kernel<KIND, true, 13, false, false, 14>, 22) : launch(sor_strand_kernel<KIND, false, 13, false, false, 14>, 23);
+      else ierr = HIPX_ERR_SUP;
+    } else ierr = HIPX_ERR_SUP;
+  } else if (P.me == 4) ierr = aligned ? HIPX_ST_LAUNCH(true, 4, false, 1) : HIPX_ST_LAUNCH(false, 4, false, 0);
   else if (split) {
     if constexpr (KIND <= 2) {
       if (P.me == 13) ierr = aligned ? HIPX_ST_LAUNCH(true, 13, true, 9) : HIPX_ST_LAUNCH(false, 13, true, 8);
@@ -2057,6 +2188,8 @@ extern "C" void hipxSorStateFree_(void *p)
 extern "C" {
 int hipxMatTemplates_(hipxMat A, int *ok, int *ntmpl, const int **tstart, const int **toff, const double **tval, const int **tdiag, const int64_t **tcount,
                       const unsigned char **d_tid);
+int hipxMatPatternTemplates_(hipxMat A, int *ok, int *ntmpl, const int **tstart, const int **toff, const int **tdiag, const int64_t **tcount, const unsigned char **d_tid,
+                             const int **d_tstart, const int **d_toff);
 }
 
 // schedule the last hipxMatSOR call used: 0 one launch per level, 1 level-ordered dependency-driven, 2 strands; -1 = none yet
@@ -2160,8 +2293,31 @@ static int mat_sor_impl(hipxMat A, const double *b, double omega, int flag, doub
         S->strand = nullptr;
       }
     }
+    // arbitrary values on a stencil pattern (variable-coefficient operators): the same schedule from the PATTERN templates, the
+    // coefficients streamed per row (HIPX_SOR_VAR=0: off)
+    static const bool var_on = !(getenv("HIPX_SOR_VAR") && atoi(getenv("HIPX_SOR_VAR")) == 0);
+    if (!S->strand && var_on) {
+      const int *d_pts = nullptr, *d_pto = nullptr;
+      tok = 0;
+      if ((ierr = hipxMatPatternTemplates_(A, &tok, &ntmpl, &tstart, &toff, &tdiag, &tcount, &d_tid, &d_pts, &d_pto))) return ierr;
+      if (tok) {
+        StrandState *T = new StrandState;
+        S->strand      = T;
+        if ((ierr = strand_build(T, m, ntmpl, tstart, toff, nullptr, tdiag, tcount, d_tid, true))) return ierr;
+        if (!T->ok) {
+          strand_free(T);
+          S->strand = nullptr;
+        } else {
+          S->var_tstart = d_pts;
+          S->var_toff   = d_pto;
+        }
+      }
+    }
   }
-  const bool use_strand = S->strand && (want == -1 || want == 2) && flag != 64;
+  // the variable-coefficient kernels cover the sweeps without old-value lists (kinds 0-2): zero initial guess with one iteration
+  // (what PCSOR applies by default) and Eisenstat; anything else on such a matrix takes the level-ordered schedule
+  const bool var_fits   = !S->strand || !((StrandState *)S->strand)->var || (flag & 32) || ((flag & 16) && (int64_t)its * (int64_t)lits == 1);
+  const bool use_strand = S->strand && var_fits && (want == -1 || want == 2) && flag != 64;
   if (want == 2 && !use_strand && flag != 64) return fail(HIPX_ERR_SUP, "HIPX_SOR_MODE=strand: the matrix has no row templates / strand structure", __FILE__, __LINE__);
   if (!S->d_t) {  // work vectors shared by every mode
     HIPX_HIP(hipMalloc((void **)&S->d_t, sizeof(double) * (size_t)m));
@@ -2176,10 +2332,15 @@ static int mat_sor_impl(hipxMat A, const double *b, double omega, int flag, doub
   if (use_strand) {
     StrandState *T = (StrandState *)S->strand;
     const bool plain = (omega == 1.0 && shift <= 0.0);
-    if (plain && shift == 0.0)
-      for (double d : T->diagval)
-        if (d == 0.0) return fail(HIPX_ERR_ZEROPIVOT, "Zero diagonal on a row (aij.c:1820)", __FILE__, __LINE__);
-    if ((ierr = strand_set_diag(T, omega, shift))) return ierr;
+    if (T->var) {
+      if ((ierr = strand_set_cs(T, m, is64, d_i, d_a, d_diagpos, S->var_tstart, S->var_toff, omega, shift))) return ierr;
+      if (T->zero_pivots && plain && shift == 0.0) return fail(HIPX_ERR_ZEROPIVOT, "Zero diagonal on a row (aij.c:1820)", __FILE__, __LINE__);
+    } else {
+      if (plain && shift == 0.0)
+        for (double d : T->diagval)
+          if (d == 0.0) return fail(HIPX_ERR_ZEROPIVOT, "Zero diagonal on a row (aij.c:1820)", __FILE__, __LINE__);
+      if ((ierr = strand_set_diag(T, omega, shift))) return ierr;
+    }
     S->mode = 2;
   } else {
     if (!S->ready) {

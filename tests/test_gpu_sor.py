@@ -154,9 +154,59 @@ def test_sor_eisenstat_bit_exact(hx, kind, n, m, omega, shift, mode):
     assert np.array_equal(g, o), np.abs(g - o).max()
 
 
+def perturbed(aa, seed=7):
+    """arbitrary values on the same pattern: every entry its own value, the diagonal kept dominant"""
+    rng = np.random.default_rng(seed)
+    return np.ascontiguousarray(aa * (1.0 + 0.3 * rng.random(aa.size)))
+
+
+@pytest.mark.parametrize("kind,n,m", [("5pt", 9, 7), ("7pt", 12, None), ("27pt", 9, None), ("7pt", 16, None), ("27pt", 24, None), ("5pt", 64, 40), ("27pt", 16, None)])
+@pytest.mark.parametrize("flag", [SYM | ZERO, LSYM | ZERO, FWD | ZERO, BWD | ZERO, EISENSTAT])
+@pytest.mark.parametrize("omega,shift", [(1.0, 0.0), (1.3, 0.0), (0.8, 0.25)])
+def test_sor_variable_coefficients_strand_bit_exact(hx, kind, n, m, flag, omega, shift):
+    """Arbitrary values on a stencil pattern (no row templates: every row has its own coefficients): the strand schedule from the
+    PATTERN templates with the coefficients streamed per row -- bit-identical to MatSOR_SeqAIJ for the sweeps PCSOR applies by
+    default (zero initial guess, one iteration: aij.c:1930-1960) and for Eisenstat (aij.c:1887-1929)."""
+    ai, aj, aa = orc.stencil(kind, n, m=m)
+    aa = perturbed(aa)
+    N = len(ai) - 1
+    rng = np.random.default_rng(N + flag)
+    b, x0 = rng.standard_normal(N), rng.standard_normal(N)
+    g = sor_gpu(hx, ai, aj, aa, b, omega, flag, shift, 1, 1, x0, want_mode="strand")
+    o = sor_cpu(ai, aj, aa, b, omega, flag, shift, 1, 1, x0)
+    assert np.array_equal(g, o), np.abs(g - o).max()
+
+
+@pytest.mark.parametrize("stencil,n", [(7, 128), (27, 96), (27, 128), (7, 100)])
+def test_sor_variable_coefficients_at_scale(hx, stencil, n):
+    """>= 1 M rows with arbitrary values (7-pt 100^3: strands of a length that is not a multiple of 8 -> the kernels for any
+    alignment), the default symmetric sweep; then new VALUES through hipxMatUpdateValues: the coefficient streams follow."""
+    from petsc_amd import _lib
+    ai, aj, aa = assemble_c(stencil, n)
+    aa = perturbed(aa)
+    N = len(ai) - 1
+    rng = np.random.default_rng(13)
+    b = rng.standard_normal(N)
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    B, X = _lib.DVec(N, b), _lib.DVec(N)
+    used = C.c_int()
+    for vals in (aa, perturbed(aa, 9)):
+        _lib.chk(hx.hipxMatUpdateValues(A, orc.P(vals)))
+        _lib.chk(hx.hipxMatSOR(A, B.ptr, 1.0, LSYM | ZERO, 0.0, 1, 1, X.ptr))
+        _lib.chk(hx.hipxMatGetSORMode(A, C.byref(used)))
+        assert used.value == MODES["strand"]
+        o = sor_cpu(ai, aj, vals, b, 1.0, LSYM | ZERO, 0.0, 1, 1, np.zeros(N))
+        g = X.get()
+        assert np.array_equal(g, o), np.abs(g - o).max()
+    B.free()
+    X.free()
+    _lib.mat_destroy(A)
+
+
 def test_sor_default_schedule_selection(hx):
-    """The library's own choice: strands for stencil matrices, the level-ordered sweep for matrices without row templates
-    (variable coefficients), and after hipxMatUpdateValues the choice follows the new values."""
+    """The library's own choice: strands for stencil matrices -- from the row templates, or from the pattern templates with
+    streamed coefficients when the values are arbitrary (then only for the sweeps without old-value lists; the level-ordered
+    sweep otherwise) -- and after hipxMatUpdateValues the choice follows the new values."""
     from petsc_amd import _lib
     ai, aj, aa = orc.stencil("7pt", 20)
     N = len(ai) - 1
@@ -165,12 +215,14 @@ def test_sor_default_schedule_selection(hx):
     g = sor_gpu(hx, ai, aj, aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0, want_mode="strand")
     assert np.array_equal(g, sor_cpu(ai, aj, aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0))
     aav = aa * (1.0 + 0.01 * rng.standard_normal(aa.size))
-    g = sor_gpu(hx, ai, aj, aav, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0, want_mode="dep")
+    g = sor_gpu(hx, ai, aj, aav, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0, want_mode="strand")  # (variable coefficients: streamed per row)
     assert np.array_equal(g, sor_cpu(ai, aj, aav, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0))
+    g = sor_gpu(hx, ai, aj, aav, b, 1.2, SYM, 0.0, 2, 1, x0, want_mode="dep")  # (sweeps with old-value lists: level-ordered there)
+    assert np.array_equal(g, sor_cpu(ai, aj, aav, b, 1.2, SYM, 0.0, 2, 1, x0))
     A = _lib.mat_create_csr(N, N, ai, aj, aa)
     B, X = _lib.DVec(N, b), _lib.DVec(N, x0)
     used = C.c_int()
-    for vals, want in [(aa, 2), (aav, 1), (aa * 2.0, 2)]:
+    for vals, want in [(aa, 2), (aav, 2), (aa * 2.0, 2)]:
         _lib.chk(hx.hipxMatUpdateValues(A, orc.P(np.ascontiguousarray(vals))))
         _lib.chk(hx.hipxMatSOR(A, B.ptr, 1.0, LSYM | ZERO, 0.0, 1, 1, X.ptr))
         _lib.chk(hx.hipxMatGetSORMode(A, C.byref(used)))
