@@ -575,6 +575,49 @@ def leg_surrogate_spmv(hx, lib):
     return out
 
 
+def leg_sor_arbitrary_values(hx, lib, ks, n=256):
+    """PCSOR's default application (one symmetric zero-guess sweep) on config 3's operator with ARBITRARY values on its pattern (every
+    nonzero its own value -- variable-coefficient operators: no row templates): the strand schedule with streamed coefficients, checked
+    bit for bit against the level-ordered dependency-driven sweep of the same library (itself held to MatSOR_SeqAIJ by tests/test_gpu_sor.py)."""
+    N = n ** 3
+    ai, aj, aa = assemble(ks, 27, (n, n, n), 0, N)
+    aa *= 1.0 + 0.3 * np.random.default_rng(1).random(aa.size)
+    A = lib.mat_create_csr(N, N, ai, aj, aa)
+    nnz = int(ai[-1])
+    del ai, aj, aa
+    B, X = lib.DVec(N, 1.0 + (np.arange(N) % 17) / 17.0), lib.DVec(N)
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    lib.chk(hx.hipxEventCreate(C.byref(e0)))
+    lib.chk(hx.hipxEventCreate(C.byref(e1)))
+    res, xs = {}, {}
+    old = os.environ.pop("HIPX_SOR_MODE", None)
+    try:
+        for mode, reps in (("strand", 5), ("dep", 2)):
+            os.environ["HIPX_SOR_MODE"] = mode
+            for _ in range(2):
+                lib.chk(hx.hipxMatSOR(A, B.ptr, 1.0, 12 | 16, 0.0, 1, 1, X.ptr))
+            lib.chk(hx.hipxEventRecord(e0))
+            for _ in range(reps):
+                lib.chk(hx.hipxMatSOR(A, B.ptr, 1.0, 12 | 16, 0.0, 1, 1, X.ptr))
+            lib.chk(hx.hipxEventRecord(e1))
+            ms = C.c_float()
+            lib.chk(hx.hipxEventElapsedMs(e0, e1, C.byref(ms)))
+            res[mode] = ms.value / reps
+            xs[mode] = X.get()
+    finally:
+        os.environ.pop("HIPX_SOR_MODE", None)
+        if old is not None:
+            os.environ["HIPX_SOR_MODE"] = old
+    ssor = 2 * 12 * nnz + 40 * N
+    out = {"what": "27-pt %d^3 pattern, every nonzero its own value: one PCApply_SOR (symmetric zero-guess sweep)" % n,
+           "strand_streamed_coefficients_ms": res["strand"], "level_ordered_ms": res["dep"], "bit_identical_to_level_ordered": bool(np.array_equal(xs["strand"], xs["dep"])),
+           "algorithmic_bytes": ssor, "effective_gbps": ssor / (res["strand"] * 1e-3) / 1e9}
+    B.free()
+    X.free()
+    lib.mat_destroy(A)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -833,6 +876,10 @@ def main():
             other["config4_surrogate_spmv"] = leg_surrogate_spmv(hx, _lib)
         except Exception as e:  # noqa: BLE001
             other["config4_surrogate_spmv"] = {"error": str(e)[:400]}
+        try:
+            other["config3_sor_arbitrary_values_27pt_256"] = leg_sor_arbitrary_values(hx, _lib, ks)
+        except Exception as e:  # noqa: BLE001
+            other["config3_sor_arbitrary_values_27pt_256"] = {"error": str(e)[:400]}
         out["other_configs"] = other
     print(json.dumps(out))
     sys.stdout.flush()

@@ -171,6 +171,11 @@ typedef struct hipxCOO_s *hipxCOO;
 int hipxCOOCreate(int64_t nz, const int64_t *jmap, int64_t ntot, const int64_t *perm, hipxCOO *coo);
 int hipxCOODestroy(hipxCOO *coo);
 int hipxMatSetValuesCOO(hipxMat A, hipxCOO coo, const double *v, int64_t n, int v_on_device, int insert);
+/* the remote part of MatSetValuesCOO_MPIAIJ mpiaij.c:6817-6822 (entries other ranks sent): maps with a target index per entry
+   (Aimap2 / Ajmap2 / Aperm2 of MatCOOStruct_MPIAIJ, mpiaij.h:80-81); a[imap[k]] += v[perm[jmap[k] .. jmap[k+1])], one addition
+   after the other onto the matrix value, as the reference's loop does.  v is the DEVICE receive buffer. */
+int hipxCOOCreateIndexed(int64_t nz, const int64_t *imap, const int64_t *jmap, int64_t ntot, const int64_t *perm, hipxCOO *coo);
+int hipxMatAddValuesCOOIndexed(hipxMat A, hipxCOO coo, const double *v_dev);
 int hipxPointerIsDevice(const void *p, int *is_device);
 int hipxMatDestroy(hipxMat *A);
 int hipxMatGetInfo(hipxMat A, hipx_int *m, hipx_int *n, int64_t *nnz, int64_t *device_bytes);

@@ -62,6 +62,46 @@ static PetscErrorCode DumpSplit(Mat A)
 
 static PetscInt box_ny = 0, box_nz = 0; /* -ny / -nz: 7-point operator on an n x ny x nz box (BASELINE config 5's per-GPU share: 1024 x 1024 x 128) */
 
+/* row Ii of the operator: columns (ascending) and values; returns the count */
+static PetscInt StencilRow(PetscInt stencil, PetscInt m, PetscInt n, PetscInt Ii, PetscInt cols[27], PetscScalar vals[27])
+{
+  PetscInt nc = 0;
+  if (stencil == 5) {
+    PetscInt i = Ii / n, j = Ii - i * n;
+    if (i > 0) { cols[nc] = Ii - n; vals[nc++] = -1.0; }
+    if (j > 0) { cols[nc] = Ii - 1; vals[nc++] = -1.0; }
+    cols[nc] = Ii; vals[nc++] = 4.0;
+    if (j < n - 1) { cols[nc] = Ii + 1; vals[nc++] = -1.0; }
+    if (i < m - 1) { cols[nc] = Ii + n; vals[nc++] = -1.0; }
+  } else if (stencil == 7) {
+    PetscInt ny = box_ny ? box_ny : n, nz = box_nz ? box_nz : n;
+    PetscInt n2 = n * ny, x = Ii % n, y = (Ii / n) % ny, z = Ii / n2;
+    if (z > 0) { cols[nc] = Ii - n2; vals[nc++] = -1.0; }
+    if (y > 0) { cols[nc] = Ii - n; vals[nc++] = -1.0; }
+    if (x > 0) { cols[nc] = Ii - 1; vals[nc++] = -1.0; }
+    cols[nc] = Ii; vals[nc++] = 6.0;
+    if (x < n - 1) { cols[nc] = Ii + 1; vals[nc++] = -1.0; }
+    if (y < ny - 1) { cols[nc] = Ii + n; vals[nc++] = -1.0; }
+    if (z < nz - 1) { cols[nc] = Ii + n2; vals[nc++] = -1.0; }
+  } else {
+    PetscInt    n2 = n * n, n1 = n - 1, x = Ii % n, y = (Ii / n) % n, z = Ii / n2;
+    PetscScalar h = 1.0 / (n - 1), v[4];
+    v[0] = 44.0 / 13 * h; v[1] = -3.0 / 13 * h; v[2] = -3.0 / 26 * h; v[3] = -1.0 / 13 * h; /* bench_kspsolve.c:122-126 */
+    for (int dz = -1; dz <= 1; dz++) {
+      if ((dz < 0 && z == 0) || (dz > 0 && z == n1)) continue;
+      for (int dy = -1; dy <= 1; dy++) {
+        if ((dy < 0 && y == 0) || (dy > 0 && y == n1)) continue;
+        for (int dx = -1; dx <= 1; dx++) {
+          if ((dx < 0 && x == 0) || (dx > 0 && x == n1)) continue;
+          cols[nc] = Ii + dx + dy * n + dz * n2;
+          vals[nc++] = v[(dx != 0) + (dy != 0) + (dz != 0)];
+        }
+      }
+    }
+  }
+  return nc;
+}
+
 static PetscErrorCode Assemble(Mat A, PetscInt stencil, PetscInt m, PetscInt n, PetscInt Istart, PetscInt Iend)
 {
   PetscInt    cols[27];
@@ -69,44 +109,73 @@ static PetscErrorCode Assemble(Mat A, PetscInt stencil, PetscInt m, PetscInt n, 
 
   PetscFunctionBeginUser;
   for (PetscInt Ii = Istart; Ii < Iend; Ii++) {
-    PetscInt nc = 0;
-    if (stencil == 5) {
-      PetscInt i = Ii / n, j = Ii - i * n;
-      if (i > 0) { cols[nc] = Ii - n; vals[nc++] = -1.0; }
-      if (j > 0) { cols[nc] = Ii - 1; vals[nc++] = -1.0; }
-      cols[nc] = Ii; vals[nc++] = 4.0;
-      if (j < n - 1) { cols[nc] = Ii + 1; vals[nc++] = -1.0; }
-      if (i < m - 1) { cols[nc] = Ii + n; vals[nc++] = -1.0; }
-    } else if (stencil == 7) {
-      PetscInt ny = box_ny ? box_ny : n, nz = box_nz ? box_nz : n;
-      PetscInt n2 = n * ny, x = Ii % n, y = (Ii / n) % ny, z = Ii / n2;
-      if (z > 0) { cols[nc] = Ii - n2; vals[nc++] = -1.0; }
-      if (y > 0) { cols[nc] = Ii - n; vals[nc++] = -1.0; }
-      if (x > 0) { cols[nc] = Ii - 1; vals[nc++] = -1.0; }
-      cols[nc] = Ii; vals[nc++] = 6.0;
-      if (x < n - 1) { cols[nc] = Ii + 1; vals[nc++] = -1.0; }
-      if (y < ny - 1) { cols[nc] = Ii + n; vals[nc++] = -1.0; }
-      if (z < nz - 1) { cols[nc] = Ii + n2; vals[nc++] = -1.0; }
-    } else {
-      PetscInt    n2 = n * n, n1 = n - 1, x = Ii % n, y = (Ii / n) % n, z = Ii / n2;
-      PetscScalar h = 1.0 / (n - 1), v[4];
-      v[0] = 44.0 / 13 * h; v[1] = -3.0 / 13 * h; v[2] = -3.0 / 26 * h; v[3] = -1.0 / 13 * h; /* bench_kspsolve.c:122-126 */
-      for (int dz = -1; dz <= 1; dz++) {
-        if ((dz < 0 && z == 0) || (dz > 0 && z == n1)) continue;
-        for (int dy = -1; dy <= 1; dy++) {
-          if ((dy < 0 && y == 0) || (dy > 0 && y == n1)) continue;
-          for (int dx = -1; dx <= 1; dx++) {
-            if ((dx < 0 && x == 0) || (dx > 0 && x == n1)) continue;
-            cols[nc] = Ii + dx + dy * n + dz * n2;
-            vals[nc++] = v[(dx != 0) + (dy != 0) + (dz != 0)];
-          }
-        }
-      }
-    }
+    PetscInt nc = StencilRow(stencil, m, n, Ii, cols, vals);
     PetscCall(MatSetValues(A, 1, &Ii, nc, cols, vals, INSERT_VALUES));
   }
   PetscCall(MatAssemblyBegin(A, MAT_FINAL_ASSEMBLY));
   PetscCall(MatAssemblyEnd(A, MAT_FINAL_ASSEMBLY));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* -coo_assemble 1|2: the same operator through MatSetPreallocationCOO / MatSetValuesCOO (bench_kspsolve.c:301-302's route).
+   1: every rank sets its own rows.  2: entries TRAVEL between ranks (MatSetValuesCOO_MPIAIJ's pack / PetscSFReduce / remote add,
+   mpiaij.c:6798-6822): the first rows of every rank get half of each value from their owner and half from the rank before it (exact
+   halves: the assembled matrix equals the MatSetValues one bit for bit, whatever the order of the two additions).  The values are set twice (ones first, then the operator: INSERT_VALUES must overwrite).
+   -coo_device_values: the value array is handed over as the pointer VecGetArrayReadAndMemType gives for a -vec_type vector (device
+   memory for the hipx type with -vec_hipx_memtype). */
+static PetscErrorCode AssembleCOO(Mat A, PetscInt mode, PetscInt stencil, PetscInt m, PetscInt n, PetscInt Istart, PetscInt Iend)
+{
+  PetscMPIInt        rank, size;
+  const PetscInt    *ranges;
+  PetscInt           cols[27], share, nb, nbs = 0, nbe = 0, *ci, *cj;
+  PetscScalar        vals[27], *cv, *ones;
+  PetscCount         cnt = 0, k = 0;
+  PetscBool          devvals = PETSC_FALSE;
+  Vec                vv = NULL;
+  const PetscScalar *vptr;
+
+  PetscFunctionBeginUser;
+  PetscCallMPI(MPI_Comm_rank(PETSC_COMM_WORLD, &rank));
+  PetscCallMPI(MPI_Comm_size(PETSC_COMM_WORLD, &size));
+  PetscCall(PetscOptionsGetBool(NULL, NULL, "-coo_device_values", &devvals, NULL));
+  PetscCall(MatGetOwnershipRanges(A, &ranges));
+  share = (mode == 2 && size > 1) ? 7 : 0; /* rows per rank that get a part of their values from the rank before */
+  if (share) {
+    nb  = (rank + 1) % size;
+    nbs = ranges[nb];
+    nbe = PetscMin(ranges[nb] + share, ranges[nb + 1]);
+  }
+  for (PetscInt Ii = Istart; Ii < Iend; Ii++) cnt += StencilRow(stencil, m, n, Ii, cols, vals);
+  for (PetscInt Ii = nbs; Ii < nbe; Ii++) cnt += StencilRow(stencil, m, n, Ii, cols, vals);
+  PetscCall(PetscMalloc4(cnt, &ci, cnt, &cj, cnt, &cv, cnt, &ones));
+  for (PetscInt Ii = nbs; Ii < nbe; Ii++) { /* the travelling entries first: they are not in row order on the sender */
+    PetscInt nc = StencilRow(stencil, m, n, Ii, cols, vals);
+    for (PetscInt c = 0; c < nc; c++, k++) { ci[k] = Ii; cj[k] = cols[c]; cv[k] = 0.5 * vals[c]; }
+  }
+  for (PetscInt Ii = Istart; Ii < Iend; Ii++) {
+    PetscInt    nc = StencilRow(stencil, m, n, Ii, cols, vals);
+    PetscScalar w  = (share && Ii < Istart + share) ? 0.5 : 1.0;
+    for (PetscInt c = 0; c < nc; c++, k++) { ci[k] = Ii; cj[k] = cols[c]; cv[k] = w * vals[c]; }
+  }
+  for (PetscCount q = 0; q < cnt; q++) ones[q] = 1.0;
+  PetscCall(MatSetPreallocationCOO(A, cnt, ci, cj));
+  PetscCall(MatSetValuesCOO(A, ones, INSERT_VALUES));
+  if (devvals) {
+    PetscMemType mt;
+    PetscScalar *w;
+    PetscCall(VecCreate(PETSC_COMM_SELF, &vv));
+    PetscCall(VecSetSizes(vv, (PetscInt)cnt, (PetscInt)cnt));
+    PetscCall(VecSetFromOptions(vv));
+    PetscCall(VecGetArrayWrite(vv, &w));
+    PetscCall(PetscArraycpy(w, cv, cnt));
+    PetscCall(VecRestoreArrayWrite(vv, &w));
+    PetscCall(VecGetArrayReadAndMemType(vv, &vptr, &mt));
+    PetscCall(PetscPrintf(PETSC_COMM_WORLD, "coo values memtype %d\n", (int)mt));
+    PetscCall(MatSetValuesCOO(A, vptr, INSERT_VALUES));
+    PetscCall(VecRestoreArrayReadAndMemType(vv, &vptr));
+    PetscCall(VecDestroy(&vv));
+  } else PetscCall(MatSetValuesCOO(A, cv, INSERT_VALUES));
+  PetscCall(PetscFree4(ci, cj, cv, ones));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -263,7 +332,15 @@ int main(int argc, char **argv)
   PetscCall(MatSeqAIJSetPreallocation(A, stencil, NULL));
   PetscCall(MatMPIAIJSetPreallocation(A, stencil, NULL, stencil, NULL));
   PetscCall(MatGetOwnershipRange(A, &Istart, &Iend));
-  PetscCall(Assemble(A, stencil, m, n, Istart, Iend));
+  {
+    PetscInt coo = 0;
+    PetscCall(PetscOptionsGetInt(NULL, NULL, "-coo_assemble", &coo, NULL));
+    if (coo) {
+      PetscCall(MatSetUp(A));
+      PetscCall(MatGetOwnershipRange(A, &Istart, &Iend));
+      PetscCall(AssembleCOO(A, coo, stencil, m, n, Istart, Iend));
+    } else PetscCall(Assemble(A, stencil, m, n, Istart, Iend));
+  }
   {
     PetscBool dump_split = PETSC_FALSE;
     PetscCall(PetscOptionsGetBool(NULL, NULL, "-dump_split", &dump_split, NULL));

@@ -2632,6 +2632,7 @@ int hipxPCJacobiSetUp(hipxMat A, double *dinv)
 struct hipxCOO_s {
   int64_t  nz = 0, ntot = 0;
   int64_t *d_jmap = nullptr, *d_perm = nullptr;
+  int64_t *d_imap = nullptr;  // indexed form (hipxCOOCreateIndexed): entry k of the maps belongs to a[imap[k]]
   double  *d_v = nullptr;  // staging for host-resident value arrays
   int64_t  v_cap = 0;
 };
@@ -2646,9 +2647,49 @@ __global__ __launch_bounds__(256) void coo_setvalues_kernel(int64_t nz, const in
     a[k] = (insert ? 0.0 : a[k]) + sum;
   }
 }
+// remote part of MatSetValuesCOO_MPIAIJ (mpiaij.c:6817-6822): a[imap[k]] += v[perm[q]] one by one, left to right, ON TOP of the value the
+// local part left there (no partial sum: the reference adds every received entry to the matrix value itself)
+__global__ __launch_bounds__(256) void coo_addindexed_kernel(int64_t nz, const int64_t *__restrict__ imap, const int64_t *__restrict__ jmap, const int64_t *__restrict__ perm,
+                                                             const double *__restrict__ v, double *__restrict__ a)
+{
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nz; k += (int64_t)gridDim.x * 256) {
+    const int64_t dst = imap[k];
+    double        s   = a[dst];
+    for (int64_t q = jmap[k]; q < jmap[k + 1]; q++) s += v[perm[q]];
+    a[dst] = s;
+  }
+}
 }  // namespace
 
 extern "C" {
+
+int hipxCOOCreateIndexed(int64_t nz, const int64_t *imap, const int64_t *jmap, int64_t ntot, const int64_t *perm, hipxCOO *out)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(nz >= 0 && (imap || !nz), "bad COO maps");
+  int ierr = hipxCOOCreate(nz, jmap, ntot, perm, out);
+  if (ierr) return ierr;
+  HIPX_HIP(hipMalloc((void **)&(*out)->d_imap, sizeof(int64_t) * (size_t)std::max<int64_t>(nz, 1)));
+  if (nz) HIPX_HIP(hipMemcpy((*out)->d_imap, imap, sizeof(int64_t) * (size_t)nz, hipMemcpyHostToDevice));
+  return HIPX_SUCCESS;
+}
+
+int hipxMatAddValuesCOOIndexed(hipxMat A, hipxCOO c, const double *v_dev)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A && c && c->d_imap && (v_dev || !c->ntot), "null argument / not an indexed COO map");
+  if (c->nz) {
+    const unsigned g = (unsigned)std::min<int64_t>((c->nz + 255) / 256, 16384);
+    coo_addindexed_kernel<<<g, 256, 0, rt().compute>>>(c->nz, c->d_imap, c->d_jmap, c->d_perm, v_dev, A->d_a);
+    HIPX_LAUNCH_CHECK();
+  }
+  A->vd_ready   = false;
+  A->tmpl_ready = false;
+  A->value_state++;
+  hipxSorInvalidate_(A->sor_state);
+  hipxSellValuesChanged_(A->sell_state);
+  return HIPX_SUCCESS;
+}
 
 int hipxCOOCreate(int64_t nz, const int64_t *jmap, int64_t ntot, const int64_t *perm, hipxCOO *out)
 {
@@ -2673,6 +2714,7 @@ int hipxCOODestroy(hipxCOO *pc)
   HIPX_HIP(hipStreamSynchronize(rt().compute));
   (void)hipFree(c->d_jmap);
   (void)hipFree(c->d_perm);
+  (void)hipFree(c->d_imap);
   (void)hipFree(c->d_v);
   delete c;
   *pc = nullptr;

@@ -67,6 +67,7 @@ PETSC_INTERN PetscErrorCode KSPCreate_CGHIPX(KSP); /* "cghipx": KSPCG with the f
 PETSC_INTERN PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA); /* uploads / refreshes the device CSR */
 PETSC_INTERN PetscBool      MatIsSeqAIJHIPX(Mat A);
 PETSC_INTERN PetscErrorCode MatSeqAIJHIPXSetValuesCOO_Private(Mat A, hipxCOO coo, const PetscScalar v[], PetscCount n, InsertMode imode);
+PetscErrorCode MatSeqAIJHIPXAddValuesCOOIndexed_Private(Mat, hipxCOO, const PetscScalar *);
 PETSC_INTERN PetscErrorCode MatMPIAIJHIPXGetDevice(Mat A, hipxMat *dA, hipxMat *dB, hipxHalo *halo, Vec *lvec); /* halo == NULL: no device exchange */
 /* commhipx.c: transport bring-up of a ghost-exchange plan (collective; RCCL -> IPC -> none) */
 PETSC_INTERN PetscErrorCode HipxHaloBringUp(MPI_Comm comm, PetscObject obj, hipxHalo *halo, const char *want, PetscInt *transport);

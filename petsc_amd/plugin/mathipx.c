@@ -279,6 +279,18 @@ PetscErrorCode MatSeqAIJHIPXSetValuesCOO_Private(Mat A, hipxCOO coo, const Petsc
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+/* the remote part of MatSetValuesCOO_MPIAIJ for one block (mpiaij.c:6817-6822): received entries (DEVICE buffer) added onto the
+   device values the local part just wrote */
+PetscErrorCode MatSeqAIJHIPXAddValuesCOOIndexed_Private(Mat A, hipxCOO coo2, const PetscScalar *d_recv)
+{
+  Mat_SeqAIJHIPX *h = (Mat_SeqAIJHIPX *)A->spptr;
+
+  PetscFunctionBegin;
+  PetscCheck(h->dA && h->dev_newer, PETSC_COMM_SELF, PETSC_ERR_ORDER, "the local part of MatSetValuesCOO has not run on the device");
+  PetscCallHIPX(hipxMatAddValuesCOOIndexed(h->dA, coo2, d_recv));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 static PetscErrorCode MatSetValuesCOO_SeqAIJHIPX(Mat A, const PetscScalar v[], InsertMode imode)
 {
   Mat_SeqAIJHIPX      *h = (Mat_SeqAIJHIPX *)A->spptr;

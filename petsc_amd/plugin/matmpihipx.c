@@ -31,7 +31,14 @@ typedef struct {
   PetscErrorCode (*parent_prealloc_coo)(Mat, PetscCount, PetscInt[], PetscInt[]);
   PetscErrorCode (*parent_setvalues_coo)(Mat, const PetscScalar[], InsertMode);
   hipxCOO          cooA, cooB; /* device copies of Ajmap1/Aperm1 and Bjmap1/Bperm1 (MatCOOStruct_MPIAIJ, mpiaij.h:62-89) */
-  PetscBool        coo_local;  /* no rank sends or receives COO entries: MatSetValuesCOO runs on the device */
+  PetscBool        coo_local;  /* MatSetValuesCOO runs on the device (both blocks are seqaijhipx on every rank) */
+  /* entries that travel between ranks (mpiaij.c:6798-6822): packed, exchanged and added on the device */
+  PetscBool        coo_travel;
+  hipxCOO          cooA2, cooB2;    /* Aimap2/Ajmap2/Aperm2, Bimap2/Bjmap2/Bperm2 */
+  PetscSF          coosf;           /* coo->sf's graph with the PetscSF type hipx: PetscSFReduce on device buffers */
+  hipx_int        *d_cperm;         /* Cperm1 on the device */
+  PetscScalar     *d_send, *d_recv; /* coo->sendlen / coo->recvlen scalars */
+  PetscScalar     *d_v;             /* staging for a host-resident value array (coo->n scalars) */
   hipxHalo         halo;
   PetscSF          sf;        /* transport 3: a PetscSF of type hipx with Mvctx's graph */
   PetscInt         transport; /* 0 host, 1 ipc, 2 rccl, 3 PetscSF type hipx */
@@ -237,28 +244,62 @@ static PetscErrorCode MatAssemblyEnd_MPIAIJHIPX(Mat A, MatAssemblyType mode)
    mpiaij.c:6725-6726) and the maps; when no entry has to travel between ranks -- every rank sets its own rows, as
    bench_kspsolve.c:301-302 does -- MatSetValuesCOO is two applications of the device kernel, one per block, and the values never
    touch the host.  Otherwise the parent's host path (PetscSFReduce of the remote entries) runs as before. */
+static PetscErrorCode MatMPIAIJHIPXResetCOO(Mat_MPIAIJHIPX *h)
+{
+  PetscFunctionBegin;
+  if (h->cooA) PetscCallHIPX(hipxCOODestroy(&h->cooA));
+  if (h->cooB) PetscCallHIPX(hipxCOODestroy(&h->cooB));
+  if (h->cooA2) PetscCallHIPX(hipxCOODestroy(&h->cooA2));
+  if (h->cooB2) PetscCallHIPX(hipxCOODestroy(&h->cooB2));
+  PetscCall(PetscSFDestroy(&h->coosf));
+  if (h->d_cperm) PetscCallHIPX(hipxFree(h->d_cperm));
+  if (h->d_send) PetscCallHIPX(hipxFree(h->d_send));
+  if (h->d_recv) PetscCallHIPX(hipxFree(h->d_recv));
+  if (h->d_v) PetscCallHIPX(hipxFree(h->d_v));
+  h->d_cperm = NULL;
+  h->d_send = h->d_recv = h->d_v = NULL;
+  h->coo_local = h->coo_travel = PETSC_FALSE;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 static PetscErrorCode MatSetPreallocationCOO_MPIAIJHIPX(Mat A, PetscCount n, PetscInt coo_i[], PetscInt coo_j[])
 {
   Mat_MPIAIJHIPX      *h = (Mat_MPIAIJHIPX *)A->spptr;
   Mat_MPIAIJ          *a;
   PetscContainer       container;
   MatCOOStruct_MPIAIJ *coo;
-  PetscMPIInt          mine, all;
+  PetscMPIInt          mine[2], all[2];
 
   PetscFunctionBegin;
-  if (h->cooA) PetscCallHIPX(hipxCOODestroy(&h->cooA));
-  if (h->cooB) PetscCallHIPX(hipxCOODestroy(&h->cooB));
-  h->coo_local = PETSC_FALSE;
+  PetscCall(MatMPIAIJHIPXResetCOO(h));
   PetscCall((*h->parent_prealloc_coo)(A, n, coo_i, coo_j));
   a = (Mat_MPIAIJ *)A->data;
   PetscCall(PetscObjectQuery((PetscObject)A, "__PETSc_MatCOOStruct_Host", (PetscObject *)&container));
   PetscCall(PetscContainerGetPointer(container, &coo));
-  mine = (coo->sendlen == 0 && coo->recvlen == 0 && coo->Annz2 == 0 && coo->Bnnz2 == 0 && MatIsSeqAIJHIPX(a->A) && MatIsSeqAIJHIPX(a->B)) ? 1 : 0;
-  PetscCallMPI(MPIU_Allreduce(&mine, &all, 1, MPI_INT, MPI_MIN, PetscObjectComm((PetscObject)A)));
-  if (all) {
+  /* [0]: this rank can run the device path (MIN over ranks); [1]: some entry travels between ranks (MAX over ranks, sent negated) */
+  mine[0] = (MatIsSeqAIJHIPX(a->A) && MatIsSeqAIJHIPX(a->B) && coo->n < (PetscCount)PETSC_INT32_MAX && !getenv("HIPX_COO_HOST")) ? 1 : 0;
+  mine[1] = (coo->sendlen == 0 && coo->recvlen == 0 && coo->Annz2 == 0 && coo->Bnnz2 == 0) ? 1 : 0;
+  PetscCallMPI(MPIU_Allreduce(mine, all, 2, MPI_INT, MPI_MIN, PetscObjectComm((PetscObject)A)));
+  if (all[0]) {
     PetscCallHIPX(hipxCOOCreate((int64_t)coo->Annz, (const int64_t *)coo->Ajmap1, (int64_t)coo->Atot1, (const int64_t *)coo->Aperm1, &h->cooA));
     PetscCallHIPX(hipxCOOCreate((int64_t)coo->Bnnz, (const int64_t *)coo->Bjmap1, (int64_t)coo->Btot1, (const int64_t *)coo->Bperm1, &h->cooB));
     h->coo_local = PETSC_TRUE;
+    if (!all[1]) { /* entries travel: the remote maps, the device buffers and coo->sf's graph in a PetscSF of type hipx (sfhipx.c) */
+      hipx_int *cp;
+      PetscCallHIPX(hipxCOOCreateIndexed((int64_t)coo->Annz2, (const int64_t *)coo->Aimap2, (const int64_t *)coo->Ajmap2, (int64_t)coo->Atot2, (const int64_t *)coo->Aperm2, &h->cooA2));
+      PetscCallHIPX(hipxCOOCreateIndexed((int64_t)coo->Bnnz2, (const int64_t *)coo->Bimap2, (const int64_t *)coo->Bjmap2, (int64_t)coo->Btot2, (const int64_t *)coo->Bperm2, &h->cooB2));
+      PetscCall(PetscMalloc1(coo->sendlen + 1, &cp));
+      for (PetscInt i = 0; i < coo->sendlen; i++) cp[i] = (hipx_int)coo->Cperm1[i];
+      PetscCallHIPX(hipxMalloc((void **)&h->d_cperm, sizeof(hipx_int) * (size_t)(coo->sendlen + 1)));
+      PetscCallHIPX(hipxMemcpyHtoD(h->d_cperm, cp, sizeof(hipx_int) * (size_t)coo->sendlen));
+      PetscCall(PetscFree(cp));
+      PetscCallHIPX(hipxMalloc((void **)&h->d_send, sizeof(PetscScalar) * (size_t)(coo->sendlen + 1)));
+      PetscCallHIPX(hipxMalloc((void **)&h->d_recv, sizeof(PetscScalar) * (size_t)(coo->recvlen + 1)));
+      PetscCall(PetscSFDuplicate(coo->sf, PETSCSF_DUPLICATE_GRAPH, &h->coosf)); /* (re-typing a set-up SF in place is not supported: sf.c) */
+      PetscCall(PetscSFSetType(h->coosf, PETSCSFHIPX));
+      PetscCall(PetscSFSetUp(h->coosf));
+      h->coo_travel = PETSC_TRUE;
+    }
   }
   PetscFunctionReturn(PETSC_SUCCESS);
 }
@@ -269,6 +310,7 @@ static PetscErrorCode MatSetValuesCOO_MPIAIJHIPX(Mat A, const PetscScalar v[], I
   Mat_MPIAIJ          *a = (Mat_MPIAIJ *)A->data;
   PetscContainer       container;
   MatCOOStruct_MPIAIJ *coo;
+  const PetscScalar   *dv = v;
 
   PetscFunctionBegin;
   if (!h->coo_local) {
@@ -278,9 +320,27 @@ static PetscErrorCode MatSetValuesCOO_MPIAIJHIPX(Mat A, const PetscScalar v[], I
   PetscCall(PetscObjectQuery((PetscObject)A, "__PETSc_MatCOOStruct_Host", (PetscObject *)&container));
   PetscCheck(container, PetscObjectComm((PetscObject)A), PETSC_ERR_PLIB, "Not found MatCOOStruct on this matrix");
   PetscCall(PetscContainerGetPointer(container, &coo));
-  if (getenv("HIPX_TRACE_COO")) fprintf(stderr, "[petschipx] MatSetValuesCOO_MPIAIJHIPX: device path, %lld + %lld nonzeros\n", (long long)coo->Annz, (long long)coo->Bnnz);
-  PetscCall(MatSeqAIJHIPXSetValuesCOO_Private(a->A, h->cooA, v, coo->n, imode)); /* mpiaij.c:6804-6808 */
-  PetscCall(MatSeqAIJHIPXSetValuesCOO_Private(a->B, h->cooB, v, coo->n, imode)); /* mpiaij.c:6809-6813 */
+  if (getenv("HIPX_TRACE_COO"))
+    fprintf(stderr, "[petschipx] MatSetValuesCOO_MPIAIJHIPX: device path, %lld + %lld nonzeros%s\n", (long long)coo->Annz, (long long)coo->Bnnz, h->coo_travel ? ", entries travel between ranks" : "");
+  if (h->coo_travel) {
+    int ondev = 0;
+    PetscCallHIPX(hipxPointerIsDevice(v, &ondev));
+    if (!ondev && coo->n) { /* one upload serves the pack and both blocks */
+      if (!h->d_v) PetscCallHIPX(hipxMalloc((void **)&h->d_v, sizeof(PetscScalar) * (size_t)coo->n));
+      PetscCallHIPX(hipxMemcpyHtoD(h->d_v, v, sizeof(PetscScalar) * (size_t)coo->n));
+      dv = h->d_v;
+    }
+    /* mpiaij.c:6798-6801: pack the entries other ranks own, start sending them to their owners */
+    if (coo->sendlen) PetscCallHIPX(hipxVecScatterIndexed(dv, h->d_cperm, h->d_send, NULL, (hipx_int)coo->sendlen, 0));
+    PetscCall(PetscSFReduceWithMemTypeBegin(h->coosf, MPIU_SCALAR, PETSC_MEMTYPE_HIP, h->d_send, PETSC_MEMTYPE_HIP, h->d_recv, MPI_REPLACE));
+  }
+  PetscCall(MatSeqAIJHIPXSetValuesCOO_Private(a->A, h->cooA, dv, coo->n, imode)); /* mpiaij.c:6804-6808 */
+  PetscCall(MatSeqAIJHIPXSetValuesCOO_Private(a->B, h->cooB, dv, coo->n, imode)); /* mpiaij.c:6809-6813 */
+  if (h->coo_travel) {
+    PetscCall(PetscSFReduceEnd(h->coosf, MPIU_SCALAR, h->d_send, h->d_recv, MPI_REPLACE)); /* mpiaij.c:6814 */
+    PetscCall(MatSeqAIJHIPXAddValuesCOOIndexed_Private(a->A, h->cooA2, h->d_recv));        /* mpiaij.c:6817-6819 */
+    PetscCall(MatSeqAIJHIPXAddValuesCOOIndexed_Private(a->B, h->cooB2, h->d_recv));        /* mpiaij.c:6820-6822 */
+  }
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -292,8 +352,7 @@ static PetscErrorCode MatDestroy_MPIAIJHIPX(Mat A)
   PetscFunctionBegin;
   if (h->halo) PetscCallHIPX(hipxHaloDestroy(&h->halo));
   PetscCall(PetscSFDestroy(&h->sf));
-  if (h->cooA) PetscCallHIPX(hipxCOODestroy(&h->cooA));
-  if (h->cooB) PetscCallHIPX(hipxCOODestroy(&h->cooB));
+  PetscCall(MatMPIAIJHIPXResetCOO(h));
   PetscCall(PetscObjectComposeFunction((PetscObject)A, "MatSetPreallocationCOO_C", NULL));
   PetscCall(PetscObjectComposeFunction((PetscObject)A, "MatSetValuesCOO_C", NULL));
   PetscCall(PetscFree(A->spptr));

@@ -88,7 +88,9 @@ KATS_MPI = [
     ("ksp_ex2_2", "ex2", 2, "-ksp_monitor -m 5 -n 5 -ksp_gmres_cgs_refinement_type refine_always", "monitor", "ksp/ksp/tutorials/output/ex2_2.out"),
     ("sf_ex1_basic_2", "kat_sf_ex1", 2, "-user_sf_type hipx -sf_type hipx -options_left no", "type", "vec/is/sf/tests/output/ex1_basic_2.out"),
     ("sf_ex1_basic_3", "kat_sf_ex1", 3, "-user_sf_type hipx -sf_type hipx -options_left no", "type", "vec/is/sf/tests/output/ex1_basic_3.out"),
-] + [("mat_ex123_3_l%d_n%d" % (la, ng), "kat_mat_ex123", 3, "-mat_type mpiaij -loc -localapi %d -neg %d -options_left no" % (la, ng), "ex123", "mat/tests/output/ex123_3.out") for la in (0, 1) for ng in (0, 1)]
+] + [("mat_ex123_3_l%d_n%d" % (la, ng), "kat_mat_ex123", 3, "-mat_type mpiaij -loc -localapi %d -neg %d -options_left no" % (la, ng), "ex123", "mat/tests/output/ex123_3.out") for la in (0, 1) for ng in (0, 1)
+] + [  # rectangular local blocks, every entry in the off-diagonal block (suite 4, nsize 4)
+    ("mat_ex123_4_l%d_n%d" % (la, ng), "kat_mat_ex123", 4, "-mat_type mpiaij -loc -locdiag 0 -localapi %d -neg %d -options_left no" % (la, ng), "ex123", "mat/tests/output/ex123_4.out") for la in (0, 1) for ng in (0, 1)]
 
 
 def kats():

@@ -94,6 +94,28 @@ def test_bench_kspsolve_coo_assembly_on_device_np(np_):
     assert mpirun(np_, "bench_kspsolve", ks + ["-mat_type", "aijhipx", "-options_left", "no"], True).split() == mpirun(np_, "bench_kspsolve", ks, False).split()
 
 
+@pytest.mark.parametrize("np_,args", [(2, "-stencil 27 -n 6"), (3, "-stencil 7 -n 8"), (3, "-stencil 27 -n 6 -coo_device_values -vec_hipx_memtype"),
+                                      (2, "-stencil 5 -m 9 -n 7 -coo_device_values -vec_hipx_memtype")])
+def test_coo_entries_travelling_between_ranks_on_the_device(np_, args):
+    """MatSetValuesCOO_MPIAIJ's remote part (mpiaij.c:6798-6822): `ref_driver -coo_assemble 2` has every rank set half of each value of
+    the first rows of the NEXT rank (the owner sets the other half).  With MATMPIAIJHIPX the entries are packed on the device
+    (hipxVecScatterIndexed), sent through a PetscSF of type hipx (device PetscSFReduce, MPI_REPLACE) and added to both blocks by
+    the indexed COO kernel -- with host values and with a device-resident value array.  The assembled operator must equal the
+    MatSetValues one bit for bit: y = A x and a CG history are compared with the CPU run of the standard assembly."""
+    tail = ["-dump_y", "-history", "-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_max_it", "8"]
+    base = [x for x in args.split() if x not in ("-coo_device_values", "-vec_hipx_memtype")] + tail
+    h_cpu, y_cpu, _ = parse_driver(mpirun(np_, "ref_driver", base, False))
+    h_coo_cpu, y_coo_cpu, _ = parse_driver(mpirun(np_, "ref_driver", base + ["-coo_assemble", "2"], False))
+    assert y_coo_cpu == y_cpu and h_coo_cpu == h_cpu  # the driver's travelling assembly reproduces the operator on the CPU types
+    out = mpirun(np_, "ref_driver", args.split() + tail + ["-coo_assemble", "2", "-mat_type", "aijhipx", "-options_left", "no"], True, env={"HIPX_TRACE_COO": "1"})
+    h_gpu, y_gpu, _ = parse_driver(out)
+    assert out.count("entries travel between ranks") == 2 * np_, out[-2000:]  # both MatSetValuesCOO calls of every rank took the device path
+    if "-coo_device_values" in args:
+        assert "coo values memtype 3" in out  # PETSC_MEMTYPE_HIP: the value array was device memory
+    assert len(y_cpu) > 0 and y_gpu == y_cpu
+    assert len(h_gpu) == len(h_cpu) and max(abs(a - b) for a, b in zip(h_gpu, h_cpu)) <= 1e-12 * h_cpu[0]
+
+
 def test_hipx_vectors_with_host_mpiaij_and_default_pc():
     """-vec_type hipx only: CPU MPIAIJ matrix, block Jacobi/ILU(0) default PC -- duplicates of MPI hipx vectors, local-vector
     views into them (PCApply_BJacobi_Singleblock), clean exit (heap-checked by glibc)."""
