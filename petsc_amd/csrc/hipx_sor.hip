@@ -1140,6 +1140,9 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
   constexpr bool FWD     = (KIND == 0 || KIND == 3);
   constexpr bool NEEDOLD = (KIND == 1 || KIND == 3 || KIND == 4);  // the row's own old value
   constexpr int  VSB     = CWT == 0 ? ST_SB : (CWT <= 6 ? 8 : 4);  // rows staged per pass (the coefficient records of a pass sit in registers: VSB * CWT doubles)
+  // the 27-point class with streamed coefficients: its ring is short (LDS), so rows are staged one by one as slots come free (not in
+  // whole groups of 4, which lets the ring run empty before it is refilled) and the operands take the per-row loads of the unaligned form
+  constexpr bool FINE    = CWT > 6;
   typedef double st_dbl2 __attribute__((ext_vector_type(2)));
   const hipx_int m = P.m, L = P.L;
   const int      RQ = CWT ? P.rq : ST_RQ;
@@ -1182,14 +1185,14 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
     unsigned      tb[2] = {0, 0};  // ALIGNED: the template ids of each group of 4 as loaded; unpacked when they land
     const int ring_tail = SPLIT ? (int)s_trail[lane] : myp;  // SPLIT: the C wave still reads the row's old value from the ring
     if (rqf < len) {
-      int room = (ring_tail + RQ - rqf) & ~3;
+      int room = FINE ? (ring_tail + RQ - rqf) : ((ring_tail + RQ - rqf) & ~3);
       if (room > VSB) room = VSB;
       nrow = (len - rqf) < room ? (len - rqf) : room;
     }
     if (nrow > 0) {
       issued = true;
       const long long q0 = S * L + rqf;
-      if (ALIGNED) {  // L, m multiples of 8 and 16-byte aligned vectors: every group of 4 rows is one aligned 32-byte run
+      if (ALIGNED && !FINE) {  // L, m multiples of 8 and 16-byte aligned vectors: every group of 4 rows is one aligned 32-byte run
         typedef double dbl2 __attribute__((ext_vector_type(2)));
         if (nrow > 4) {  // both groups: their eight template ids are eight consecutive bytes (4-byte aligned): one request instead of two
           typedef unsigned uint2a __attribute__((ext_vector_type(2), aligned(4)));
@@ -1221,6 +1224,7 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
       } else {
 #pragma unroll
         for (int j = 0; j < ST_SB; j++) {
+          if (FINE && j >= nrow) continue;  // (row-granular staging: no padding loads)
           const hipx_int r = st_actual<FWD>(q0 + (j < nrow ? j : nrow - 1), m);
           va[j]            = asrc[r];
           vb[j]            = NEEDOLD ? xold[r] : 0.0;
@@ -1319,7 +1323,7 @@ __device__ __forceinline__ void st_loader_role(const StParams &P, st_lds_char *l
       }
       // everything of this round is in flight; now land it in LDS (first round: the operands too)
       if (half == 0 && nrow > 0) {
-        if (ALIGNED) {
+        if (ALIGNED && !FINE) {
 #pragma unroll
           for (int g = 0; g < 2; g++)
 #pragma unroll
