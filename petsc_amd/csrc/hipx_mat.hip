@@ -69,6 +69,10 @@ struct hipxMat_s {
   int            ntmpl = 0, tmpl_nent = 0, tmpl_maxlen = 0;
   unsigned char *d_tid    = nullptr;  // template id per row
   int           *d_tstart = nullptr;  // ntmpl + 1 offsets into toff / tval
+  // sub-template form: every template is the most common one (tmpl_base) with some entries left out (boundary rows of a stencil:
+  // same offsets, same values, fewer neighbours) -> bit k of d_tmask[t] says whether entry k of the base template is in template t
+  unsigned int  *d_tmask  = nullptr;
+  int            tmpl_base = -1;
   int           *d_toff   = nullptr;  // column - row
   double        *d_tval   = nullptr;
   unsigned long long *d_tq = nullptr;   // chunk queue of the template kernel: one ticket counter per XCD (64 bytes apart), never reset
@@ -1079,19 +1083,23 @@ __global__ __launch_bounds__(256) void tmpl_verify_kernel(hipx_int m, hipx_int n
 template <int MODE, bool DOT, int RPT, int W, bool UNI, int PROBE = 0>
 __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const int *__restrict__ tstart,
                                                         const int *__restrict__ toff, const double *__restrict__ tval, int ntmpl, int nent, const double *__restrict__ x,
-                                                        const double *yin, double *yout, double *dotpart, unsigned long long *tq, unsigned long long launch, long long pf_off)
+                                                        const double *yin, double *yout, double *dotpart, unsigned long long *tq, unsigned long long launch, long long pf_off,
+                                                        const unsigned int *__restrict__ tmask, int tsub)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ long long s_tk;
   double *s_val   = reinterpret_cast<double *>(smem);                      // nent (padded to even)
   int    *s_off   = reinterpret_cast<int *>(smem + 8 * (size_t)((nent + 1) & ~1));
   int    *s_start = s_off + ((nent + 3) & ~3);                             // ntmpl + 1
+  unsigned int *s_mask = reinterpret_cast<unsigned int *>(s_start + ntmpl + 1);  // ntmpl (sub-template form)
   const int t = threadIdx.x;
   for (int k = t; k < nent; k += 256) {
     s_val[k] = tval[k];
     s_off[k] = toff[k];
   }
   for (int k = t; k <= ntmpl; k += 256) s_start[k] = tstart[k];
+  if (tsub >= 0)
+    for (int k = t; k < ntmpl; k += 256) s_mask[k] = tmask[k];
   __syncthreads();
   const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, bpx = (hipx_int)gridDim.x >> 3;
   const hipx_int c0 = xcd * chunks_per_xcd, c1 = (c0 + chunks_per_xcd < nchunks) ? c0 + chunks_per_xcd : nchunks;
@@ -1138,6 +1146,7 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
     int            id[RPT];
     double         sum[RPT], xrow[RPT];
     bool           uni = UNI && (base + 256 * RPT <= m) && ((unsigned long long)m < (1ull << 28));  // whole chunk inside the matrix; 32-bit byte offsets
+    const bool     whole = uni;
 #pragma unroll
     for (int rr = 0; rr < RPT; rr++) {
       const hipx_int row = base + t + rr * 256;
@@ -1191,6 +1200,37 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
       if (DOT && !got) {
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) xrow[rr] = x[base + t + rr * 256];
+      }
+    } else if (UNI && PROBE == 0 && whole && tsub >= 0) {
+      // Sub-template walk.  The lanes of this wave do not share a template (a line's first / last row, ...), but every template is
+      // the base template with entries left out: all lanes walk the BASE template's entries -- scalar offsets and values, one
+      // gather address computation per row as above -- and a lane takes part in entry k only if bit k of its template's mask is
+      // set (exec-masked load, multiply, add: same operands, same order as the lane's own list).  Without this the wave -- and,
+      // through the chunk barrier, its whole workgroup -- fell to the per-lane walk below (LDS look-ups per entry, ~4x the
+      // instructions): half of the waves of a 256-wide grid line contain such a row.
+      const int ts = tstart[tsub], te = tstart[tsub + 1];
+      unsigned  rb[RPT], mk[RPT];
+#pragma unroll
+      for (int rr = 0; rr < RPT; rr++) {
+        rb[rr] = (unsigned)(base + t + rr * 256) * 8u;
+        mk[rr] = s_mask[id[rr]];
+      }
+#pragma unroll 4
+      for (int k = ts; k < te; k++) {
+        const double   a   = tval[k];
+        const int      o   = toff[k];
+        const unsigned bit = 1u << (k - ts);
+        const char    *xb  = reinterpret_cast<const char *>(x + o);
+        double         xv[RPT];
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) xv[rr] = (mk[rr] & bit) ? *reinterpret_cast<const double *>(xb + rb[rr]) : 0.0;
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++)
+          if (mk[rr] & bit) sum[rr] += a * xv[rr];
+        if (DOT && o == 0) {  // (every template holds the diagonal: checked when the masks were built)
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++) xrow[rr] = xv[rr];
+        }
       }
     } else {
       if (DOT && UNI) {
@@ -1670,6 +1710,9 @@ void free_templates(hipxMat A)
   (void)hipFree(A->d_toff);
   (void)hipFree(A->d_tval);
   (void)hipFree(A->d_tq);
+  (void)hipFree(A->d_tmask);
+  A->d_tmask   = nullptr;
+  A->tmpl_base = -1;
   A->d_tq = nullptr;
   A->tq_launches = 0;
   A->tq_geom = -1;
@@ -1787,6 +1830,33 @@ int build_templates(hipxMat A)
   A->tmpl_maxlen = 0;
   for (int tt = 0; tt < nt; tt++) A->tmpl_maxlen = std::max(A->tmpl_maxlen, A->h_tstart[(size_t)tt + 1] - A->h_tstart[(size_t)tt]);
   A->device_bytes += (int64_t)m + 64 + (int64_t)(sizeof(int) * ((size_t)nt + 1) + 12 * A->h_toff.size());
+  if (!A->ptm_build) {  // sub-template form (see d_tmask): is every template an ordered subsequence of the most common one, diagonal included?
+    int best = 0;
+    for (int tt = 1; tt < nt; tt++)
+      if (A->h_tcount[(size_t)tt] > A->h_tcount[(size_t)best]) best = tt;
+    const int b0 = A->h_tstart[(size_t)best], len0 = A->h_tstart[(size_t)best + 1] - b0;
+    bool      sub = len0 >= 1 && len0 <= 32;
+    std::vector<unsigned int> mask((size_t)nt, 0u);
+    for (int tt = 0; tt < nt && sub; tt++) {
+      int  j = 0;
+      bool diag = false;
+      for (int k = A->h_tstart[(size_t)tt]; k < A->h_tstart[(size_t)tt + 1] && sub; k++) {
+        while (j < len0 && !(A->h_toff[(size_t)b0 + j] == A->h_toff[(size_t)k] && !memcmp(&A->h_tval[(size_t)b0 + j], &A->h_tval[(size_t)k], sizeof(double)))) j++;
+        if (j >= len0) sub = false;
+        else {
+          mask[(size_t)tt] |= 1u << j;
+          diag = diag || A->h_toff[(size_t)k] == 0;
+          j++;
+        }
+      }
+      if (!diag) sub = false;
+    }
+    if (sub) {
+      HIPX_HIP(hipMalloc((void **)&A->d_tmask, sizeof(unsigned int) * (size_t)nt));
+      HIPX_HIP(hipMemcpy(A->d_tmask, mask.data(), sizeof(unsigned int) * (size_t)nt, hipMemcpyHostToDevice));
+      A->tmpl_base = best;
+    }
+  }
   return HIPX_SUCCESS;
 }
 
@@ -1916,7 +1986,9 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
     return HIPX_SUCCESS;
   }
   const hipx_int cpx  = (nchunks + 7) / 8;
-  const size_t   smem = 8 * (size_t)((A->tmpl_nent + 1) & ~1) + 4 * (size_t)((A->tmpl_nent + 3) & ~3) + 4 * ((size_t)A->ntmpl + 1) + 16;
+  const size_t   smem = 8 * (size_t)((A->tmpl_nent + 1) & ~1) + 4 * (size_t)((A->tmpl_nent + 3) & ~3) + 4 * ((size_t)A->ntmpl + 1) + 4 * (size_t)A->ntmpl + 16;
+  static const bool nosub = getenv("HIPX_TMPL_NOSUB") != nullptr;
+  const int      tbase = (A->d_tmask && !nosub) ? A->tmpl_base : -1;
   const int      geom = (int)grid * 16 + rpt;
   if (!A->d_tq || A->tq_geom != geom) {  // ticket counters of the chunk queue (zeroed once per geometry)
     if (!A->d_tq) HIPX_HIP(hipMalloc((void **)&A->d_tq, 8 * 64));
@@ -1944,7 +2016,7 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
   }
 #define HIPX_TMPL_LAUNCH(R, WW, U) \
   spmv_tmpl_kernel<MODE, DOT, R, WW, U><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout, dotpart, \
-                                                                                      A->d_tq, launch, pf_off)
+                                                                                      A->d_tq, launch, pf_off, A->d_tmask, tbase)
   switch (cfg) {
   case 0: HIPX_TMPL_LAUNCH(2, 4, false); break;
   case 2: HIPX_TMPL_LAUNCH(4, 4, true); break;
@@ -1953,7 +2025,7 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
     if (probe >= 1 && probe <= 5) {
 #define HIPX_TMPL_LAUNCH_P(PR) \
   spmv_tmpl_kernel<MODE, DOT, 2, 2, true, PR><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout, \
-                                                                                           dotpart, A->d_tq, launch, pf_off)
+                                                                                           dotpart, A->d_tq, launch, pf_off, A->d_tmask, tbase)
       if (probe == 1) HIPX_TMPL_LAUNCH_P(1);
       else if (probe == 2) HIPX_TMPL_LAUNCH_P(2);
       else if (probe == 3) HIPX_TMPL_LAUNCH_P(3);
@@ -2525,6 +2597,7 @@ int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
     if (ierr) return ierr;
   }
   if (sl) name = "spmv_sell_kernel (MatMult on the SELL-64 copy: one lane per row, 16-bit window-coded columns)";
+  else if (tm && A->d_tmask && !getenv("HIPX_TMPL_NOSUB")) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row; every template a subset of the interior one: uniform masked walk)";
   else if (tm) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row)";
   else if (tp) name = "spmv_tp_kernel (CSR MatMult, pattern templates: 1-byte pattern id per row, values streamed from a[])";
   else if (false) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row)";
