@@ -321,6 +321,22 @@ int main(int argc, char **argv)
   PetscCheck((!box_ny && !box_nz) || stencil == 7, PETSC_COMM_WORLD, PETSC_ERR_SUP, "-ny / -nz: 7-point operator only");
   N = (stencil == 5) ? m * n : (stencil == 7 ? n * (box_ny ? box_ny : n) * (box_nz ? box_nz : n) : n * n * n);
 
+  {
+    char      file[PETSC_MAX_PATH_LEN];
+    PetscBool fromfile = PETSC_FALSE; /* -f <PETSc binary Mat>: the operator comes from a file (MatLoad: BASELINE config 4's route for a SuiteSparse matrix) */
+    PetscCall(PetscOptionsGetString(NULL, NULL, "-f", file, sizeof(file), &fromfile));
+    if (fromfile) {
+      PetscViewer viewer;
+      PetscCall(PetscViewerBinaryOpen(PETSC_COMM_WORLD, file, FILE_MODE_READ, &viewer));
+      PetscCall(MatCreate(PETSC_COMM_WORLD, &A));
+      PetscCall(MatSetFromOptions(A));
+      PetscCall(MatLoad(A, viewer));
+      PetscCall(PetscViewerDestroy(&viewer));
+      PetscCall(MatGetSize(A, &N, NULL));
+      PetscCall(MatGetOwnershipRange(A, &Istart, &Iend));
+      goto assembled;
+    }
+  }
   PetscCall(MatCreate(PETSC_COMM_WORLD, &A));
   PetscCall(MatSetSizes(A, PETSC_DECIDE, PETSC_DECIDE, N, N));
   PetscCall(MatSetFromOptions(A));
@@ -341,6 +357,7 @@ int main(int argc, char **argv)
       PetscCall(AssembleCOO(A, coo, stencil, m, n, Istart, Iend));
     } else PetscCall(Assemble(A, stencil, m, n, Istart, Iend));
   }
+assembled:
   {
     PetscBool dump_split = PETSC_FALSE;
     PetscCall(PetscOptionsGetBool(NULL, NULL, "-dump_split", &dump_split, NULL));

@@ -1170,7 +1170,50 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
       for (int rr = 0; rr < RPT; rr++) uni = uni && (id[rr] == id0);
       uni = __all(uni);
     }
-    if (UNI && uni) {
+    if (UNI && PROBE == 0 && whole && tsub >= 0) {
+      // Sub-template walk (every template is the base template with entries left out: boundary rows of a stencil).  ALL lanes of ALL
+      // waves walk the BASE template's entries -- offsets and values are wave-uniform scalars -- and a lane takes part in entry k
+      // only if bit k of its template's mask is set (exec-masked load, multiply, add: same operands, same order as the lane's own
+      // list, so y is bit-identical).  Entries go in batches of 8: the batch's 16 scalar loads are issued together (ONE wait on the
+      // scalar cache), then its 8 x RPT gathers (ONE memory round trip), then the arithmetic.  Before this form a wave holding a
+      // line's first / last row fell to the per-lane walk below (LDS look-ups per entry) and, through the chunk barrier, held its
+      // workgroup back; and the uniform walk waited for the scalar cache once per entry and for memory once per 4 entries.
+      const int ts = tstart[tsub], te = tstart[tsub + 1];
+      unsigned  rb[RPT], mk[RPT];
+#pragma unroll
+      for (int rr = 0; rr < RPT; rr++) {
+        rb[rr] = (unsigned)(base + t + rr * 256) * 8u;
+        mk[rr] = s_mask[id[rr]];
+      }
+      for (int k0 = ts; k0 < te; k0 += 8) {
+        int    oo[8];
+        double av[8], xv[8][RPT];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int k = (k0 + e < te) ? k0 + e : te - 1;
+          oo[e] = toff[k];
+          av[e] = tval[k];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const unsigned bit = (k0 + e < te) ? (1u << (k0 + e - ts)) : 0u;
+          const char    *xb  = reinterpret_cast<const char *>(x + oo[e]);
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++) xv[e][rr] = (mk[rr] & bit) ? *reinterpret_cast<const double *>(xb + rb[rr]) : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const unsigned bit = (k0 + e < te) ? (1u << (k0 + e - ts)) : 0u;
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++)
+            if (mk[rr] & bit) sum[rr] += av[e] * xv[e][rr];
+          if (DOT && bit && oo[e] == 0) {  // (every template holds the diagonal: checked when the masks were built)
+#pragma unroll
+            for (int rr = 0; rr < RPT; rr++) xrow[rr] = xv[e][rr];
+          }
+        }
+      }
+    } else if (UNI && uni) {
       // every lane of the wave walks the SAME template (interior rows): offsets and values are wave-uniform scalars read from
       // the global table through the scalar cache, the gather address is (x + off) [scalar] + row * 8 [per lane, computed once]:
       // per nonzero the vector unit issues one load, one multiply and one add, nothing else
@@ -1200,37 +1243,6 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
       if (DOT && !got) {
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) xrow[rr] = x[base + t + rr * 256];
-      }
-    } else if (UNI && PROBE == 0 && whole && tsub >= 0) {
-      // Sub-template walk.  The lanes of this wave do not share a template (a line's first / last row, ...), but every template is
-      // the base template with entries left out: all lanes walk the BASE template's entries -- scalar offsets and values, one
-      // gather address computation per row as above -- and a lane takes part in entry k only if bit k of its template's mask is
-      // set (exec-masked load, multiply, add: same operands, same order as the lane's own list).  Without this the wave -- and,
-      // through the chunk barrier, its whole workgroup -- fell to the per-lane walk below (LDS look-ups per entry, ~4x the
-      // instructions): half of the waves of a 256-wide grid line contain such a row.
-      const int ts = tstart[tsub], te = tstart[tsub + 1];
-      unsigned  rb[RPT], mk[RPT];
-#pragma unroll
-      for (int rr = 0; rr < RPT; rr++) {
-        rb[rr] = (unsigned)(base + t + rr * 256) * 8u;
-        mk[rr] = s_mask[id[rr]];
-      }
-#pragma unroll 4
-      for (int k = ts; k < te; k++) {
-        const double   a   = tval[k];
-        const int      o   = toff[k];
-        const unsigned bit = 1u << (k - ts);
-        const char    *xb  = reinterpret_cast<const char *>(x + o);
-        double         xv[RPT];
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++) xv[rr] = (mk[rr] & bit) ? *reinterpret_cast<const double *>(xb + rb[rr]) : 0.0;
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++)
-          if (mk[rr] & bit) sum[rr] += a * xv[rr];
-        if (DOT && o == 0) {  // (every template holds the diagonal: checked when the masks were built)
-#pragma unroll
-          for (int rr = 0; rr < RPT; rr++) xrow[rr] = xv[rr];
-        }
       }
     } else {
       if (DOT && UNI) {

@@ -38,3 +38,26 @@ def flan_surrogate(n=80, seed=1565):
     ai[1:] = np.cumsum(lens)
     aa = rng.standard_normal(int(ai[-1]))
     return ai, cols, aa
+
+
+def flan_surrogate_spd(n=80, seed=1565):
+    """The same pattern as flan_surrogate() with SYMMETRIC POSITIVE DEFINITE values, for BASELINE config 4's solver (KSPCG +
+    PCJACOBI; Flan_1565 is SPD): a_ij = a_ji = -(0.05 + u(i, j)) with u a hash of the unordered pair in [0, 1) (all off-diagonal
+    values distinct up to hash collisions: no dictionary, no templates), a_ii = 1 + sum_j |a_ij| + u(i, i) (strictly diagonally
+    dominant, distinct diagonals: the constant-diagonal Jacobi shortcut does not apply).  Returns CSR (ai, aj, aa)."""
+    ai, aj, _ = flan_surrogate(n, seed)
+    N = len(ai) - 1
+    rows = np.repeat(np.arange(N, dtype=np.int64), np.diff(ai))
+    cols = aj.astype(np.int64)
+    lo, hi = np.minimum(rows, cols), np.maximum(rows, cols)
+    key = (lo * N + hi).astype(np.uint64)
+    h = key * np.uint64(0x9E3779B97F4A7C15)
+    h ^= h >> np.uint64(29)
+    h *= np.uint64(0xBF58476D1CE4E5B9)
+    u = (h >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    aa = -(0.05 + u)
+    diag = rows == cols
+    off_abs = np.where(diag, 0.0, -aa)
+    rowsum = np.bincount(rows, weights=off_abs, minlength=N)
+    aa[diag] = 1.0 + rowsum[rows[diag]] + u[diag]
+    return ai, aj, aa
