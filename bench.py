@@ -88,6 +88,38 @@ class Cfg:
         return a
 
 
+class MatrixCfg(Cfg):
+    """A given matrix (BASELINE config 4: SuiteSparse Flan_1565 from a file, or its documented stand-in) solved with KSPCG + PCJACOBI on one GPU.
+    `load()` returns CSR (ai, aj, aa); `binfile` (a PETSc binary Mat file of the same matrix, written on demand) is what the REFERENCE
+    reads with MatLoad (`ref_driver -f`) for the parity yardstick and the CPU baseline."""
+
+    def __init__(self, name, load, ksp="cg", pc="jacobi"):
+        self.name, self._load, self.ksp, self.pc, self.scaling, self.label, self.golden = name, load, ksp, pc, "strong", None, None
+        self.stencil, self.dims, self.N, self.cube = 0, (0, 0, 0), 0, False
+        self.binfile = None
+
+    def load(self):
+        ai, aj, aa = self._load()
+        self.N = len(ai) - 1
+        self.dims = (self.N, 1, 1)
+        return ai, aj, aa
+
+    def shape(self):
+        return self.name
+
+    def metric(self):
+        return "%s iterations/sec, %s fp64, KSP%s+%s" % (self.ksp.upper(), self.name, self.ksp.upper(), self.pcname())
+
+    def golden_key(self):
+        return "none:" + self.name
+
+    def driver_args(self, its):
+        a = ["-f", self.binfile, "-ksp_type", self.ksp, "-pc_type", self.pc, "-ksp_rtol", "1e-50", "-ksp_max_it", str(its)]
+        if self.ksp == "cg":
+            a += ["-ksp_norm_type", "preconditioned"]
+        return a
+
+
 def assemble(ks, stencil, dims, rs, re):
     nx, ny, nz = dims
     cube = nx == ny == nz
@@ -192,9 +224,15 @@ class Problem:
         self.lib, self.cfg, self.world, self.fused, self.pipeline = _lib, cfg, world, fused, pipeline
         self.hx, self.ks = _lib.load()
         self.dims, self.N = cfg.dims, cfg.N
-        ranges = pdist.split_ownership(self.N, world)
-        rs, re = int(ranges[rank]), int(ranges[rank + 1])
-        ai, aj, aa = assemble(self.ks, cfg.stencil, self.dims, rs, re)
+        if isinstance(cfg, MatrixCfg):
+            assert world == 1, "a matrix from a file runs on one GPU here"
+            ai, aj, aa = cfg.load()
+            self.dims, self.N = cfg.dims, cfg.N
+            ranges, rs, re = None, 0, cfg.N
+        else:
+            ranges = pdist.split_ownership(self.N, world)
+            rs, re = int(ranges[rank]), int(ranges[rank + 1])
+            ai, aj, aa = assemble(self.ks, cfg.stencil, self.dims, rs, re)
         self.m = re - rs
         self.wide = ai.dtype == np.int64
         self.halo = self.lvec = self.Bm = None
@@ -618,6 +656,65 @@ def leg_sor_arbitrary_values(hx, lib, ks, n=256):
     return out
 
 
+def leg_matrix_solver(cfg, steps, warmup, sync, torch, best_ranks=None, parity_its=10, cpu_its=10, tmpdir=None):
+    """BASELINE config 4's solver leg: KSPCG + PCJACOBI on a given matrix (a file, or the SPD Flan-like stand-in) on one GPU --
+    iterations/s, the SpMV kernel auto picks with its roofline on the CSR bytes, the first iterations against the REFERENCE's own
+    MatLoad + KSPSolve with exact BLAS reductions (`ref_driver -f`, oracle/libexactblas.so preloaded), and that reference timed on the
+    host cores."""
+    from petsc_amd import matio
+    t0 = time.perf_counter()
+    P = Problem(cfg, 0, 1, None, keep_host=True)
+    kname = P.setup(0)
+    t_setup = time.perf_counter() - t0
+    par = {"pass": None, "reference": "oracle/_ref not on this box"}
+    own_tmp = None
+    exe = os.path.join(ROOT, "oracle", "_ref", "bin", "ref_driver")
+    if os.path.exists(exe) and parity_its:
+        if cfg.binfile is None:
+            own_tmp = tmpdir or tempfile.mkdtemp(prefix="hipx_mat_")
+            cfg.binfile = os.path.join(own_tmp, "matrix.bin")
+            matio.write_petsc_binary(cfg.binfile, *P.host_csr)
+        hist = P.solve(parity_its, history=True)
+        refx = ref_driver(1, cfg.driver_args(parity_its) + ["-history"], exact=True, timeout=1800)
+        if refx is not None and len(refx["history"]) == len(hist):
+            href = np.array(refx["history"])
+            rel = float((np.abs(hist - href) / np.abs(href)).max())
+            par = {"pass": bool(rel <= GATE_TOL), "max_rel_diff": rel, "tolerance": GATE_TOL, "iterations": parity_its, "entries": len(hist),
+                   "reference": "the REFERENCE's MatLoad + KSPSolve on the same file with exact BLAS reductions (ref_driver -f, oracle/libexactblas.so)"}
+        else:
+            par = {"pass": None, "reference": "the reference run on the file did not return a history"}
+    P.host_csr = None
+    r = timed_steps(P, steps, warmup, sync, None, torch)
+    byts = P.spmv_bytes()
+    out = {"metric": cfg.metric(), "iterations_per_s": steps / r["elapsed"], "ms_per_step": 1e3 * r["elapsed"] / steps, "steps": steps, "warmup": warmup,
+           "rows": P.m, "nnz": P.nnz_local, "spmv_kernel": kname, "parity": par, "residual_norm_after": r["rnorm"], "setup_seconds": t_setup,
+           "roofline_spmv": {"bound": "hbm", "avg_launch_ms": r["spmv_ms"], "launches": r["launches"], "algorithmic_bytes": byts,
+                             "achieved": byts / (r["spmv_ms"] * 1e-3) / 1e9 if r["spmv_ms"] > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": byts / (r["spmv_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if r["spmv_ms"] > 0 else 0.0, "traffic": None}}
+    P.destroy()
+    if best_ranks and cpu_its and cfg.binfile:
+        out["cpu_baseline"] = cpu_baseline_for(cfg, best_ranks, cpu_its, "KSPCG + PCJACOBI, MatLoad of the same file")
+    if own_tmp and not tmpdir:
+        shutil.rmtree(own_tmp, ignore_errors=True)
+        cfg.binfile = None
+    return out
+
+
+def config4_cfg(path=None):
+    """config 4's matrix: the file if one is given (--matrix-file / HIPX_FLAN_FILE: MatrixMarket or PETSc binary), else the SPD stand-in."""
+    from petsc_amd import matio
+    path = path or os.environ.get("HIPX_FLAN_FILE")
+    if path:
+        cfg = MatrixCfg("matrix file %s" % os.path.basename(path), lambda: matio.read_matrix(path))
+        with open(path, "rb") as f:
+            if not f.read(14).startswith(b"%%MatrixMarket") and not path.endswith(".gz"):
+                cfg.binfile = path  # already a PETSc binary file: the reference reads it as it is
+        return cfg
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from surrogates import flan_surrogate_spd
+    return MatrixCfg("Flan_1565 stand-in (hexahedral elasticity pattern, 1536000 rows, 121 M nonzeros, SPD, distinct values; tests/surrogates.py)", flan_surrogate_spd)
+
+
 # ---------------------------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -640,6 +737,8 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic then comes from profiles/spmv_traffic.json)")
     ap.add_argument("--no-plugin", action="store_true")
     ap.add_argument("--no-general", action="store_true")
+    ap.add_argument("--matrix-file", default=None, help="N = 1: solve this matrix (MatrixMarket coordinate file, optionally .gz, or PETSc binary Mat) with KSPCG + PCJACOBI "
+                                                        "instead of a Poisson operator: BASELINE config 4 with the real SuiteSparse file")
     ap.add_argument("--no-other", action="store_true", help="skip the other_configs legs (configs 3/4/5 on one GPU; the scaling legs on N GPUs)")
     ap.add_argument("--quick", action="store_true", help="the timed legs only: no plugin / PMC / CPU-baseline / general-kernel / other-config legs")
     ap.add_argument("--spmv-only", type=int, default=0, help=argparse.SUPPRESS)
@@ -687,6 +786,18 @@ def main():
         return main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync)
 
     # =========================================================================================================== one GPU
+    if args.matrix_file:  # BASELINE config 4 with a supplied file: the whole line is that solve
+        cfg4 = config4_cfg(args.matrix_file)
+        ranks4 = None if args.no_cpu_baseline else max(2, physical_cores() // 4)
+        r4 = leg_matrix_solver(cfg4, args.steps, args.warmup, sync, torch, best_ranks=ranks4)
+        rf = dict(r4["roofline_spmv"], kernel=r4["spmv_kernel"], basis="algorithmic CSR bytes / launch time (no counter pass on a file matrix)")
+        print(json.dumps({"metric": cfg4.metric(), "value": r4["iterations_per_s"] if r4["parity"].get("pass") is not False else None, "unit": "iterations/s", "n_gpus": 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": r4["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                          "dtype": "f64", "data": "file: %s" % args.matrix_file,
+                          "config": {"workload": "%s (N=%d rows, nnz=%d), KSPCG + PCJACOBI, b = A*1, x0 = 0" % (cfg4.name, r4["rows"], r4["nnz"]), "global_rows": r4["rows"], "parallelism": "rows1"},
+                          "ungated": r4["parity"].get("pass") is None, "parity_gate": r4["parity"], "roofline": rf, "cpu_baseline": r4.get("cpu_baseline")}))
+        sys.stdout.flush()
+        return
     P = Problem(head, 0, 1, None, fused=args.fused, pipeline=args.pipeline, keep_host=True)
     kname = P.setup(args.variant)
     # ---- parity gate: this configuration's first iterations against the reference's own KSPSolve run
@@ -876,6 +987,10 @@ def main():
             other["config4_surrogate_spmv"] = leg_surrogate_spmv(hx, _lib)
         except Exception as e:  # noqa: BLE001
             other["config4_surrogate_spmv"] = {"error": str(e)[:400]}
+        try:
+            other["config4_solver_cg_jacobi"] = leg_matrix_solver(config4_cfg(), 100, 10, sync, torch, best_ranks=None if args.no_cpu_baseline else best_ranks)
+        except Exception as e:  # noqa: BLE001
+            other["config4_solver_cg_jacobi"] = {"error": str(e)[:400]}
         try:
             other["config3_sor_arbitrary_values_27pt_256"] = leg_sor_arbitrary_values(hx, _lib, ks)
         except Exception as e:  # noqa: BLE001

@@ -29,6 +29,18 @@
 
 using namespace hipx;
 
+// Pair form of the template SpMV (spmv_pair_kernel): the base template's entries grouped by the EVEN column offsets e_j whose
+// 16-byte pairs (x[r + e], x[r + e + 1], r = the thread's even row) are loaded; slot 1 of a pair is the entry at offset e itself, slot
+// 0 the entry at e - 1 (row r takes the previous lane's second element, row r + 1 the pair's first), slot 2 the entry at e + 1 (row r
+// takes the second element, row r + 1 the next lane's first).  kb = the entry's index in the base template (its bit in the row
+// masks) or -1; pairs ascend in e, so slots 0, 1, 2 of pair 0, 1, ... is the entries' own (ascending-column) order.
+struct hipxPairPlan {
+  int    npairs, jdiag;
+  int    e[16];
+  int    kb[16][3];
+  double a[16][3];
+};
+
 struct hipxMat_s {
   hipx_int  m = 0, n = 0;
   int64_t   nnz       = 0;
@@ -73,6 +85,8 @@ struct hipxMat_s {
   // same offsets, same values, fewer neighbours) -> bit k of d_tmask[t] says whether entry k of the base template is in template t
   unsigned int  *d_tmask  = nullptr;
   int            tmpl_base = -1;
+  bool           pair_ok = false;  // ... and the base template fits the pair form (<= 16 even-offset pairs)
+  hipxPairPlan   pair_plan;
   int           *d_toff   = nullptr;  // column - row
   double        *d_tval   = nullptr;
   unsigned long long *d_tq = nullptr;   // chunk queue of the template kernel: one ticket counter per XCD (64 bytes apart), never reset
@@ -1321,6 +1335,167 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
 }
 
 
+// lane i <- lane i - 1 (lane 0 gets `first`): DPP wavefront shift, no LDS
+__device__ __forceinline__ double pair_prev_lane(double first, double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(first), __double2loint(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(first), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// lane i <- lane i + 1 (lane 63 gets `last`): through the LDS crossbar (ds_bpermute: no memory access, no bank conflicts)
+__device__ __forceinline__ double pair_next_lane(double last, double v, int lane)
+{
+  const int src = ((lane + 1) & 63) << 2;
+  const int lo  = __builtin_amdgcn_ds_bpermute(src, __double2loint(v));
+  const int hi  = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
+  return lane == 63 ? last : __hiloint2double(hi, lo);
+}
+
+// Template SpMV, pair form (the sub-template form's matrices: every row = the base template with entries left out).  What bounded
+// spmv_tmpl_kernel on these matrices was not HBM but the CU's address pipeline: a wave-wide 8-byte gather occupies it for ~16 cycles
+// whatever its width (SQ / TA counters: profiles/r03_tmpl_sq_counters.txt), and a row costs one gather per nonzero.  Here a thread
+// owns the two CONSECUTIVE rows r, r + 1 (r even) and loads x in aligned 16-byte pairs (x[r + e], x[r + e + 1]) for the EVEN offsets e
+// only; the entries at e - 1 and e + 1 take their operands from the neighbouring lanes' pairs (one DPP shift / one ds_bpermute; the
+// wave's first / last lane from a scalar load of the element just outside the wave's 128-element run).  7-point: 5 pair loads per
+// 128 rows instead of 14 gathers; 27-point: 9 instead of 54.  y leaves as one 16-byte store, the two template ids arrive as one
+// 2-byte load.  Arithmetic per row: the row's own entries in ascending column order, product and sum rounded separately -- the
+// bits of MatMult_SeqAIJ (aij.c:1486-1494).  Whole chunks of 512 rows only (the rest: spmv_tmpl_tail_kernel); chunk queue, XCD
+// slabs and first-touch prefetch as in spmv_tmpl_kernel.
+template <int MODE, bool DOT, int NP>
+__global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask,
+                                                        int ntmpl, const hipxPairPlan plan, const double *__restrict__ x, const double *yin, double *yout, double *dotpart,
+                                                        unsigned long long *tq, unsigned long long launch, long long pf_off)
+{
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  __shared__ unsigned int s_mask[256];
+  __shared__ long long    s_tk;
+  __shared__ long long    s_tk2[2];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  for (int k = t; k < ntmpl; k += 256) s_mask[k] = tmask[k];
+  const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, bpx = (hipx_int)gridDim.x >> 3;
+  const hipx_int c0 = xcd * chunks_per_xcd, c1 = (c0 + chunks_per_xcd < nchunks) ? c0 + chunks_per_xcd : nchunks;
+  const long long     nloc  = (long long)(c1 > c0 ? c1 - c0 : 0);
+  unsigned long long *ctr   = tq + (size_t)xcd * 8;
+  const long long     tbase = (long long)(launch * (unsigned long long)(nloc + 2 * bpx));
+  if (t == 0) {
+    s_tk2[0] = (long long)atomicAdd(ctr, 1ull) - tbase;
+    s_tk2[1] = (long long)atomicAdd(ctr, 1ull) - tbase;
+  }
+  __syncthreads();
+  long long tk = s_tk2[0], tk1 = s_tk2[1];
+  double    pf = 0.0;
+  unsigned  sink = 0;
+  const unsigned short *tid2 = reinterpret_cast<const unsigned short *>(tid);  // rows r, r + 1: one 2-byte load (r even)
+  unsigned idn = (tk < nloc) ? (unsigned)tid2[((long long)(c0 + tk) * 512 + 2 * t) >> 1] : 0u;
+  while (tk < nloc) {
+    long long nxt = 0;
+    if (t == 0) nxt = (long long)atomicAdd(ctr, 1ull) - tbase;  // the ticket after next travels while this chunk is processed
+    const hipx_int  c    = c0 + (hipx_int)tk;
+    const long long base = (long long)c * 512;
+    const long long r    = base + 2 * t;           // this thread's even row
+    const long long W    = base + 128 * wv;         // first row of this wave's run
+    const unsigned  id2  = idn;
+    idn = (tk1 < nloc) ? (unsigned)tid2[((long long)(c0 + tk1) * 512 + 2 * t) >> 1] : 0u;  // next chunk's ids: consumed at the top of the next pass
+    // (1) every pair of the chunk in flight at once (zero outside the vector: such a pair is used by no row that exists)
+    dbl2 P[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+      P[j] = dbl2{0.0, 0.0};
+      if (j < plan.npairs) {
+        const long long q = r + plan.e[j];
+        if (q >= 0 && q + 1 < (long long)m) P[j] = *reinterpret_cast<const dbl2 *>(x + q);
+      }
+    }
+    // (2) the elements just outside the wave's run, for the entries at e - 1 (first lane) and e + 1 (last lane): wave-uniform
+    // addresses -> scalar loads, off the vector memory path
+    double eL[NP], eR[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+      eL[j] = eR[j] = 0.0;
+      if (j < plan.npairs) {
+        const long long ql = W - 1 + plan.e[j], qr = W + 128 + plan.e[j];
+        if (plan.kb[j][0] >= 0 && ql >= 0 && ql < (long long)m) eL[j] = x[ql];
+        if (plan.kb[j][2] >= 0 && qr >= 0 && qr < (long long)m) eR[j] = x[qr];
+      }
+    }
+    dbl2 s2 = dbl2{0.0, 0.0};
+    if (MODE == 1) s2 = *reinterpret_cast<const dbl2 *>(yin + r);
+    double         sum0 = s2.x, sum1 = s2.y, xr0 = 0.0, xr1 = 0.0;
+    const unsigned mk0 = s_mask[id2 & 0xffu], mk1 = s_mask[id2 >> 8];
+    // (3) the walk: pairs in ascending offset, slots 0, 1, 2 = the base template's entries in their own order
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+      if (j < plan.npairs) {
+        if (plan.kb[j][0] >= 0) {  // entry at e - 1: row r <- x[r + e - 1] = the previous lane's second element, row r + 1 <- x[r + e]
+          const double   A = pair_prev_lane(eL[j], P[j].y), B = P[j].x;
+          const unsigned bit = 1u << plan.kb[j][0];
+          const double   a = plan.a[j][0];
+          if (mk0 & bit) sum0 += a * A;
+          if (mk1 & bit) sum1 += a * B;
+        }
+        if (plan.kb[j][1] >= 0) {  // entry at e
+          const unsigned bit = 1u << plan.kb[j][1];
+          const double   a = plan.a[j][1];
+          if (mk0 & bit) sum0 += a * P[j].x;
+          if (mk1 & bit) sum1 += a * P[j].y;
+        }
+        if (plan.kb[j][2] >= 0) {  // entry at e + 1: row r <- x[r + e + 1], row r + 1 <- x[r + e + 2] = the next lane's first element
+          const double   A = P[j].y, B = pair_next_lane(eR[j], P[j].x, lane);
+          const unsigned bit = 1u << plan.kb[j][2];
+          const double   a = plan.a[j][2];
+          if (mk0 & bit) sum0 += a * A;
+          if (mk1 & bit) sum1 += a * B;
+        }
+        if (DOT && j == plan.jdiag) {
+          xr0 = P[j].x;
+          xr1 = P[j].y;
+        }
+      }
+    }
+    *reinterpret_cast<dbl2 *>(yout + r) = dbl2{sum0, sum1};
+    if (DOT) {  // one partial per wave and CHUNK, folded in chunk order by the caller (as spmv_tmpl_kernel)
+      const double w = hipx::wave_sum(xr0 * sum0 + xr1 * sum1);
+      if (lane == 0) dotpart[(size_t)c * 4 + wv] = w;
+    }
+    sink += (__double_as_longlong(pf) == 0x7ff8123456789abcLL) ? 1u : 0u;  // consume the previous pass's prefetch
+    if (pf_off && t < 32) {
+      const long long prow = base + pf_off + (long long)t * 16;
+      if (prow < (long long)m) pf = x[prow];
+    }
+    __syncthreads();  // everybody has read the tickets
+    if (t == 0) s_tk = nxt;
+    __syncthreads();
+    tk  = tk1;
+    tk1 = s_tk;
+  }
+  if (sink == 0xffffffffu) yout[0] = pf;  // never true: keeps the prefetch loads alive
+}
+
+// rows [row0, m) of a template matrix, one row per thread and pass (the partial last chunk of spmv_pair_kernel): the row's own
+// template from the global tables; dot partials in the layout of the chunked kernels (4 per chunk of 512 rows: rows t, t + 256)
+template <int MODE, bool DOT>
+__global__ __launch_bounds__(256) void spmv_tmpl_tail_kernel(hipx_int m, hipx_int row0, hipx_int chunk, const unsigned char *__restrict__ tid, const int *__restrict__ tstart,
+                                                             const int *__restrict__ toff, const double *__restrict__ tval, const double *__restrict__ x, const double *yin, double *yout,
+                                                             double *dotpart)
+{
+  double cdot = 0.0;
+  for (int rr = 0; rr < 2; rr++) {
+    const long long row = (long long)row0 + threadIdx.x + rr * 256;
+    if (row < (long long)m) {
+      const int id = tid[row];
+      double    sum = (MODE == 1) ? yin[row] : 0.0;
+      for (int k = tstart[id]; k < tstart[id + 1]; k++) sum += tval[k] * x[row + toff[k]];
+      yout[row] = sum;
+      if (DOT) cdot += x[row] * sum;
+    }
+  }
+  if (DOT) {
+    const double w = hipx::wave_sum(cdot);
+    if ((threadIdx.x & 63) == 0) dotpart[(size_t)chunk * 4 + (threadIdx.x >> 6)] = w;
+  }
+}
+
 template <typename IT>
 __global__ void diagpos_kernel(hipx_int m, const IT *ai, const hipx_int *aj, int64_t *diagpos, unsigned int *missing)
 {
@@ -1725,6 +1900,7 @@ void free_templates(hipxMat A)
   (void)hipFree(A->d_tmask);
   A->d_tmask   = nullptr;
   A->tmpl_base = -1;
+  A->pair_ok   = false;
   A->d_tq = nullptr;
   A->tq_launches = 0;
   A->tq_geom = -1;
@@ -1867,6 +2043,48 @@ int build_templates(hipxMat A)
       HIPX_HIP(hipMalloc((void **)&A->d_tmask, sizeof(unsigned int) * (size_t)nt));
       HIPX_HIP(hipMemcpy(A->d_tmask, mask.data(), sizeof(unsigned int) * (size_t)nt, hipMemcpyHostToDevice));
       A->tmpl_base = best;
+      // pair plan (hipxPairPlan): even offsets -> pairs; an odd offset o hangs on pair(o + 1) as slot 0 if that pair exists, else on
+      // pair(o - 1) as slot 2 (created if need be)
+      hipxPairPlan &pp = A->pair_plan;
+      memset(&pp, 0, sizeof(pp));
+      std::vector<int> ev;
+      for (int k = 0; k < len0; k++) {
+        const int o = A->h_toff[(size_t)b0 + k];
+        if ((o & 1) == 0) ev.push_back(o);
+      }
+      for (int k = 0; k < len0; k++) {
+        const int o = A->h_toff[(size_t)b0 + k];
+        if ((o & 1) && std::find(ev.begin(), ev.end(), o + 1) == ev.end() && std::find(ev.begin(), ev.end(), o - 1) == ev.end()) ev.push_back(o - 1);
+      }
+      std::sort(ev.begin(), ev.end());
+      bool pok = ev.size() <= 16 && !ev.empty();
+      if (pok) {
+        pp.npairs = (int)ev.size();
+        pp.jdiag  = -1;
+        for (int j = 0; j < 16; j++) pp.kb[j][0] = pp.kb[j][1] = pp.kb[j][2] = -1;
+        for (int j = 0; j < pp.npairs; j++) {
+          pp.e[j] = ev[(size_t)j];
+          if (ev[(size_t)j] == 0) pp.jdiag = j;
+        }
+        int lastj = -1, lasts = -1;
+        for (int k = 0; k < len0 && pok; k++) {
+          const int    o = A->h_toff[(size_t)b0 + k];
+          int          j = -1, sl = -1;
+          const auto   at = [&](int off) { const auto it = std::find(ev.begin(), ev.end(), off); return it == ev.end() ? -1 : (int)(it - ev.begin()); };
+          if ((o & 1) == 0) { j = at(o); sl = 1; }
+          else if (at(o + 1) >= 0) { j = at(o + 1); sl = 0; }
+          else { j = at(o - 1); sl = 2; }
+          if (j < 0 || pp.kb[j][sl] >= 0 || j < lastj || (j == lastj && sl <= lasts)) pok = false;  // (order of the walk must be the entries' order)
+          else {
+            pp.kb[j][sl] = k;
+            pp.a[j][sl]  = A->h_tval[(size_t)b0 + k];
+            lastj = j;
+            lasts = sl;
+          }
+        }
+        if (pp.jdiag < 0 || pp.kb[pp.jdiag][1] < 0) pok = false;
+      }
+      A->pair_ok = pok;
     }
   }
   return HIPX_SUCCESS;
@@ -1990,18 +2208,25 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
 {
   const int      cfg = tmpl_cfg();
   const int      rpt = (cfg == 2) ? 4 : 2;
-  const hipx_int m = A->nrows_c, nchunks = (m + 256 * rpt - 1) / (256 * rpt);
-  hipx_int       grid = std::min<hipx_int>((hipx_int)((tmpl_blocks() + 7) / 8 * 8), ((nchunks + 7) / 8) * 8);
-  if (grid < 8) grid = 8;
+  const hipx_int m = A->nrows_c;
+  hipx_int       nchunks = (m + 256 * rpt - 1) / (256 * rpt);
   if (npart) {
     *npart = nchunks * 4;  // one dot partial per wave and chunk
     return HIPX_SUCCESS;
   }
-  const hipx_int cpx  = (nchunks + 7) / 8;
-  const size_t   smem = 8 * (size_t)((A->tmpl_nent + 1) & ~1) + 4 * (size_t)((A->tmpl_nent + 3) & ~3) + 4 * ((size_t)A->ntmpl + 1) + 4 * (size_t)A->ntmpl + 16;
   static const bool nosub = getenv("HIPX_TMPL_NOSUB") != nullptr;
   const int      tbase = (A->d_tmask && !nosub) ? A->tmpl_base : -1;
-  const int      geom = (int)grid * 16 + rpt;
+  // pair form (spmv_pair_kernel): sub-template matrices, 16-byte aligned vectors, the default geometry; it takes the whole chunks
+  static const bool nopair = getenv("HIPX_TMPL_NOPAIR") != nullptr;
+  static const int  probe0 = getenv("HIPX_TMPL_PROBE") ? atoi(getenv("HIPX_TMPL_PROBE")) : 0;
+  const bool     vec_aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(yout) | (MODE == 1 ? reinterpret_cast<uintptr_t>(yin) : (uintptr_t)0)) & 15) == 0;
+  const bool     use_pair = A->pair_ok && tbase >= 0 && !nopair && !probe0 && cfg == 1 && vec_aligned && m >= 512 && A->ntmpl <= 256;
+  if (use_pair) nchunks = m / 512;
+  hipx_int       grid = std::min<hipx_int>((hipx_int)((tmpl_blocks() + 7) / 8 * 8), ((nchunks + 7) / 8) * 8);
+  if (grid < 8) grid = 8;
+  const hipx_int cpx  = (nchunks + 7) / 8;
+  const size_t   smem = 8 * (size_t)((A->tmpl_nent + 1) & ~1) + 4 * (size_t)((A->tmpl_nent + 3) & ~3) + 4 * ((size_t)A->ntmpl + 1) + 4 * (size_t)A->ntmpl + 16;
+  const int      geom = (int)grid * 16 + (use_pair ? 9 : rpt);
   if (!A->d_tq || A->tq_geom != geom) {  // ticket counters of the chunk queue (zeroed once per geometry)
     if (!A->d_tq) HIPX_HIP(hipMalloc((void **)&A->d_tq, 8 * 64));
     HIPX_HIP(hipMemsetAsync(A->d_tq, 0, 8 * 64, rt().compute));
@@ -2025,6 +2250,16 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
     const long long    dist = ds ? atoll(ds) : (long long)(grid >> 3);
     if (off || pf_off < 4 * 256 * rpt) pf_off = 0;
     else pf_off += dist * 256 * rpt;
+  }
+  if (use_pair) {
+    if (A->pair_plan.npairs <= 8) spmv_pair_kernel<MODE, DOT, 8><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off);
+    else spmv_pair_kernel<MODE, DOT, 16><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off);
+    HIPX_LAUNCH_CHECK();
+    if (nchunks * 512 < m) {
+      spmv_tmpl_tail_kernel<MODE, DOT><<<1, 256, 0, rt().compute>>>(m, nchunks * 512, nchunks, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, x, yin, yout, dotpart);
+      HIPX_LAUNCH_CHECK();
+    }
+    return HIPX_SUCCESS;
   }
 #define HIPX_TMPL_LAUNCH(R, WW, U) \
   spmv_tmpl_kernel<MODE, DOT, R, WW, U><<<(unsigned)grid, 256, smem, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, A->ntmpl, A->tmpl_nent, x, yin, yout, dotpart, \
@@ -2609,6 +2844,8 @@ int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
     if (ierr) return ierr;
   }
   if (sl) name = "spmv_sell_kernel (MatMult on the SELL-64 copy: one lane per row, 16-bit window-coded columns)";
+  else if (tm && A->pair_ok && A->d_tmask && !getenv("HIPX_TMPL_NOSUB") && !getenv("HIPX_TMPL_NOPAIR") && !getenv("HIPX_TMPL_PROBE") && tmpl_cfg() == 1 && A->nrows_c >= 512)
+    name = "spmv_pair_kernel (CSR MatMult, row templates: 1 byte per row; two consecutive rows per thread, 16-byte loads of x at the even offsets, +-1 entries from the neighbouring lanes)";
   else if (tm && A->d_tmask && !getenv("HIPX_TMPL_NOSUB")) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row; every template a subset of the interior one: uniform masked walk)";
   else if (tm) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row)";
   else if (tp) name = "spmv_tp_kernel (CSR MatMult, pattern templates: 1-byte pattern id per row, values streamed from a[])";

@@ -211,3 +211,26 @@ def test_mataxpy_same_pattern_on_device_bit_exact():
     yc = [l for l in cpu.splitlines() if l.startswith("y ")]
     yg = [l for l in gpu.splitlines() if l.startswith("y ")]
     assert yc == yg and len(yc) == 729
+
+
+def test_matload_of_a_file_into_the_hipx_types(tmp_path):
+    """BASELINE config 4's route (a SuiteSparse file -> MatLoad -> KSPCG + PCJACOBI): `ref_driver -f <PETSc binary>` with
+    -mat_type aijhipx -vec_type hipx against the CPU types -- a matrix with arbitrary distinct values (no templates, no dictionary):
+    y = A x bit-identical, the history within 1e-12 of the CPU run made with exact BLAS reductions."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from petsc_amd import matio
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from surrogates import flan_surrogate_spd
+    ai, aj, aa = flan_surrogate_spd(16)
+    f = str(tmp_path / "spd.bin")
+    matio.write_petsc_binary(f, ai, aj, aa)
+    a = ["-f", f, "-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_rtol", "1e-50", "-ksp_max_it", "12", "-ksp_norm_type", "preconditioned", "-history", "-dump_y"]
+    cpu = run("ref_driver", a, exact_blas=True)
+    gpu = run("ref_driver", a + HIPX)
+    y_cpu = [l.split()[2] for l in cpu.splitlines() if l.startswith("y ")]
+    y_gpu = [l.split()[2] for l in gpu.splitlines() if l.startswith("y ")]
+    assert len(y_cpu) == len(ai) - 1 and y_gpu == y_cpu
+    hc, hg = hist_of(cpu), hist_of(gpu)
+    assert len(hc) == 13 and len(hg) == 13
+    assert max(abs(g - c) / abs(c) for g, c in zip(hg, hc)) <= 1e-12

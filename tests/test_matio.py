@@ -72,7 +72,8 @@ def test_reference_matload_reads_what_we_write(tmp_path):
     low = aj <= rows
     mtx = tmp_path / "p7.mtx"
     with open(str(mtx), "w") as f:
-        f.write("%%MatrixMarket matrix coordinate real symmetric\n%d %d %d\n" % (len(ai) - 1, len(ai) - 1, int(low.sum())))
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n")
+        f.write("%d %d %d\n" % (len(ai) - 1, len(ai) - 1, int(low.sum())))
         for r, c, v in zip(rows[low], aj[low], aa[low]):
             f.write("%d %d %.17g\n" % (r + 1, c + 1, v))
     bi, bj, ba = matio.read_matrix(str(mtx))
