@@ -1364,7 +1364,7 @@ __device__ __forceinline__ double pair_next_lane(double last, double v, int lane
 template <int MODE, bool DOT, int NP>
 __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask,
                                                         int ntmpl, const hipxPairPlan plan, const double *__restrict__ x, const double *yin, double *yout, double *dotpart,
-                                                        unsigned long long *tq, unsigned long long launch, long long pf_off)
+                                                        unsigned long long *tq, unsigned long long launch, long long pf_off, int nq)
 {
   typedef double dbl2 __attribute__((ext_vector_type(2)));
   __shared__ unsigned int s_mask[256];
@@ -1375,9 +1375,15 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
   for (int k = t; k < ntmpl; k += 256) s_mask[k] = tmask[k];
   const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, bpx = (hipx_int)gridDim.x >> 3;
   const hipx_int c0 = xcd * chunks_per_xcd, c1 = (c0 + chunks_per_xcd < nchunks) ? c0 + chunks_per_xcd : nchunks;
-  const long long     nloc  = (long long)(c1 > c0 ? c1 - c0 : 0);
-  unsigned long long *ctr   = tq + (size_t)xcd * 8;
-  const long long     tbase = (long long)(launch * (unsigned long long)(nloc + 2 * bpx));
+  const long long     nall  = (long long)(c1 > c0 ? c1 - c0 : 0);
+  // nq ticket counters per XCD (a returning atomic on ONE address is served every ~30 ns: with 256 workgroups per XCD taking a ticket
+  // per chunk that alone is the kernel's time): workgroup w of the XCD draws from counter w % nq, whose tickets k stand for the chunks
+  // k * nq + w % nq of the slab -- each sub-queue walks the slab in order, and the sub-queues stay abreast of each other because
+  // their workgroups are statistically identical
+  const int           q     = (int)((bid >> 3) % nq);
+  const long long     nloc  = (nall - q + nq - 1) / nq;  // chunks of this sub-queue
+  unsigned long long *ctr   = tq + 64 + ((size_t)xcd * 8 + (size_t)q) * 16;
+  const long long     tbase = (long long)(launch * (unsigned long long)(nloc + 2 * (bpx / nq)));
   if (t == 0) {
     s_tk2[0] = (long long)atomicAdd(ctr, 1ull) - tbase;
     s_tk2[1] = (long long)atomicAdd(ctr, 1ull) - tbase;
@@ -1387,24 +1393,25 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
   double    pf = 0.0;
   unsigned  sink = 0;
   const unsigned short *tid2 = reinterpret_cast<const unsigned short *>(tid);  // rows r, r + 1: one 2-byte load (r even)
-  unsigned idn = (tk < nloc) ? (unsigned)tid2[((long long)(c0 + tk) * 512 + 2 * t) >> 1] : 0u;
+  unsigned idn = (tk < nloc) ? (unsigned)tid2[((long long)(c0 + tk * nq + q) * 512 + 2 * t) >> 1] : 0u;
   while (tk < nloc) {
     long long nxt = 0;
     if (t == 0) nxt = (long long)atomicAdd(ctr, 1ull) - tbase;  // the ticket after next travels while this chunk is processed
-    const hipx_int  c    = c0 + (hipx_int)tk;
+    const hipx_int  c    = c0 + (hipx_int)(tk * nq + q);
     const long long base = (long long)c * 512;
     const long long r    = base + 2 * t;           // this thread's even row
     const long long W    = base + 128 * wv;         // first row of this wave's run
     const unsigned  id2  = idn;
-    idn = (tk1 < nloc) ? (unsigned)tid2[((long long)(c0 + tk1) * 512 + 2 * t) >> 1] : 0u;  // next chunk's ids: consumed at the top of the next pass
+    idn = (tk1 < nloc) ? (unsigned)tid2[((long long)(c0 + tk1 * nq + q) * 512 + 2 * t) >> 1] : 0u;  // next chunk's ids: consumed at the top of the next pass
     // (1) every pair of the chunk in flight at once (zero outside the vector: such a pair is used by no row that exists)
     dbl2 P[NP];
 #pragma unroll
     for (int j = 0; j < NP; j++) {
       P[j] = dbl2{0.0, 0.0};
       if (j < plan.npairs) {
-        const long long q = r + plan.e[j];
-        if (q >= 0 && q + 1 < (long long)m) P[j] = *reinterpret_cast<const dbl2 *>(x + q);
+        const long long qp = r + plan.e[j];
+        if (qp >= 0 && qp + 1 < (long long)m) P[j] = *reinterpret_cast<const dbl2 *>(x + qp);
+        else if (qp >= 0 && qp < (long long)m) P[j].x = x[qp];  // (an odd row count: the vector's last element is the first half of a pair)
       }
     }
     // (2) the elements just outside the wave's run, for the entries at e - 1 (first lane) and e + 1 (last lane): wave-uniform
@@ -2228,8 +2235,8 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
   const size_t   smem = 8 * (size_t)((A->tmpl_nent + 1) & ~1) + 4 * (size_t)((A->tmpl_nent + 3) & ~3) + 4 * ((size_t)A->ntmpl + 1) + 4 * (size_t)A->ntmpl + 16;
   const int      geom = (int)grid * 16 + (use_pair ? 9 : rpt);
   if (!A->d_tq || A->tq_geom != geom) {  // ticket counters of the chunk queue (zeroed once per geometry)
-    if (!A->d_tq) HIPX_HIP(hipMalloc((void **)&A->d_tq, 8 * 64));
-    HIPX_HIP(hipMemsetAsync(A->d_tq, 0, 8 * 64, rt().compute));
+    if (!A->d_tq) HIPX_HIP(hipMalloc((void **)&A->d_tq, 8192 + 64));  // [0, 512): one counter per XCD (spmv_tmpl_kernel); [512, 8704): 8 x 8 counters, 128 bytes apart (spmv_pair_kernel)
+    HIPX_HIP(hipMemsetAsync(A->d_tq, 0, 8192 + 64, rt().compute));
     A->tq_launches = 0;
     A->tq_geom     = geom;
   }
@@ -2252,8 +2259,11 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
     else pf_off += dist * 256 * rpt;
   }
   if (use_pair) {
-    if (A->pair_plan.npairs <= 8) spmv_pair_kernel<MODE, DOT, 8><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off);
-    else spmv_pair_kernel<MODE, DOT, 16><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off);
+    static const int nq_env = getenv("HIPX_TMPL_NQ") ? atoi(getenv("HIPX_TMPL_NQ")) : 4;
+    int nq = (nq_env == 1 || nq_env == 2 || nq_env == 4 || nq_env == 8) ? nq_env : 4;
+    while (nq > 1 && (((grid >> 3) % nq) != 0 || cpx < 4 * nq)) nq >>= 1;  // every sub-queue needs the same number of workgroups (and a few chunks)
+    if (A->pair_plan.npairs <= 8) spmv_pair_kernel<MODE, DOT, 8><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, nq);
+    else spmv_pair_kernel<MODE, DOT, 16><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, nq);
     HIPX_LAUNCH_CHECK();
     if (nchunks * 512 < m) {
       spmv_tmpl_tail_kernel<MODE, DOT><<<1, 256, 0, rt().compute>>>(m, nchunks * 512, nchunks, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, x, yin, yout, dotpart);

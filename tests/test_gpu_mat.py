@@ -117,21 +117,28 @@ def test_value_dictionary_ragged_rows_bit_exact(hx, seed, m, n, maxlen, variant)
     _lib.mat_destroy(A)
 
 
+TEMPLATE_KERNELS = ("spmv_tmpl_kernel", "spmv_pair_kernel")  # row templates: the general walk, or the pair form (every row a subset of the interior row)
+
+
+def is_template_kernel(name):
+    return name.startswith(tuple(k + " " for k in TEMPLATE_KERNELS))
+
+
 def test_auto_variant_selects_packed_kernels(hx):
     """variant 0 on >= 2^20 nonzeros: short rows on <= 256 row patterns -> pattern templates (values streamed), other short rows ->
     row-parallel packed kernel, long rows -> staged packed kernel; constant
     coefficient stencils get the row templates (1 byte per row), matrices with distinct values do not.  (Guards the default path.)"""
     from petsc_amd import _lib
     rng = np.random.default_rng(3)
-    for kind, n, want in [("7pt", 56, "spmv_tmpl_kernel"), ("27pt", 36, "spmv_tmpl_kernel")]:
+    for kind, n, want in [("7pt", 56, TEMPLATE_KERNELS), ("27pt", 36, TEMPLATE_KERNELS)]:
         ai, aj, aa = orc.stencil(kind, n)
         N = len(ai) - 1
         x = xvec(N)
         for vals, w in [(aa, want), (aa * (1.0 + 1e-3 * rng.standard_normal(aa.size)), "spmv_tp_kernel" if kind == "7pt" else "spmv_pk16_kernel")]:  # round 3: short rows on a stencil pattern with arbitrary values -> pattern templates
             A = _lib.mat_create_csr(N, N, ai, aj, vals)
-            assert kernel_name(hx, A).startswith(w + " "), kernel_name(hx, A)
+            assert kernel_name(hx, A).startswith(tuple(k + " " for k in ((w,) if isinstance(w, str) else w))), kernel_name(hx, A)
             _lib.chk(hx.hipxMatSetSpMVVariant(A, 0))  # explicit "auto" must not change the selection
-            assert kernel_name(hx, A).startswith(w + " ")
+            assert kernel_name(hx, A).startswith(tuple(k + " " for k in ((w,) if isinstance(w, str) else w)))
             X, Y = _lib.DVec(N, x), _lib.DVec(N)
             _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
             assert np.array_equal(Y.get(), orc.matmult(ai, aj, vals, x))
@@ -153,7 +160,7 @@ def test_row_templates_kernel_selected_and_bit_exact(hx, kind, n, m):
     for wide in (False, True):
         A = _lib.mat_create_csr(N, N, ai.astype(np.int64) if wide else ai, aj, aa)
         _lib.chk(hx.hipxMatSetSpMVVariant(A, 26))
-        assert kernel_name(hx, A).startswith("spmv_tmpl_kernel "), kernel_name(hx, A)
+        assert is_template_kernel(kernel_name(hx, A)), kernel_name(hx, A)
         X, Y, Y0 = _lib.DVec(N, x), _lib.DVec(N), _lib.DVec(N, x[::-1].copy())
         _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
         yr = orc.matmult(ai, aj, aa, x)
@@ -167,13 +174,13 @@ def test_row_templates_kernel_selected_and_bit_exact(hx, kind, n, m):
         assert np.array_equal(Y.get(), yr) and abs(dot.value - float(x @ yr)) <= 1e-12 * np.abs(x * yr).sum()
         aa2 = aa * 0.75                                                   # other values, same templates' shape
         _lib.chk(hx.hipxMatUpdateValues(A, orc.P(aa2)))
-        assert kernel_name(hx, A).startswith("spmv_tmpl_kernel ")
+        assert is_template_kernel(kernel_name(hx, A))
         _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
         assert np.array_equal(Y.get(), orc.matmult(ai, aj, aa2, x))
         if N > 300:
             aa3 = aa * (1.0 + 1e-3 * rng.standard_normal(aa.size))       # every row distinct: no templates
             _lib.chk(hx.hipxMatUpdateValues(A, orc.P(aa3)))
-            assert not kernel_name(hx, A).startswith("spmv_tmpl_kernel ")
+            assert not is_template_kernel(kernel_name(hx, A))
             _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
             assert np.array_equal(Y.get(), orc.matmult(ai, aj, aa3, x))
         for v in (X, Y, Y0):
@@ -321,7 +328,7 @@ def test_full_size_7pt_256_properties(hx):
         for k in range(ai[r], ai[r + 1]):
             s += aa[k] * x[aj[k]]
         assert y[r] == s
-    assert kernel_name(hx, A).startswith("spmv_tmpl_kernel ")
+    assert is_template_kernel(kernel_name(hx, A))
     for variant in (25, 23, 1):  # every kernel form gives the same 16.7 M doubles, bit for bit
         _lib.chk(hx.hipxMatSetSpMVVariant(A, variant))
         Yv = _lib.DVec(N)
@@ -465,3 +472,53 @@ def test_pattern_templates_with_arbitrary_values(hx, kind, n):
     X3.free()
     Y3.free()
     _lib.mat_destroy(A3)
+
+
+@pytest.mark.parametrize("kind,n,m", [("7pt", 16, None), ("7pt", 21, None), ("27pt", 14, None), ("27pt", 15, None), ("5pt", 64, 40), ("5pt", 33, 31), ("7pt", 40, None)])
+def test_pair_form_of_the_template_kernel_bit_exact(hx, kind, n, m):
+    """spmv_pair_kernel: stencil matrices whose rows are all subsets of the interior row -- two consecutive rows per thread, aligned
+    16-byte loads of x at the even offsets, the +-1 entries from the neighbouring lanes.  Grids with even and odd line lengths (odd:
+    the pairs straddle lines and the plane offsets are odd), row counts that are not multiples of the 512-row chunk (tail kernel),
+    MatMult / MatMultAdd / fused dot, and vectors that are NOT 16-byte aligned (the general template kernel takes over): y
+    bit-identical to MatMult_SeqAIJ every time.  A row-scaled copy (templates, but not subsets of one base row) keeps the general kernel."""
+    from petsc_amd import _lib
+    rng = np.random.default_rng(17)
+    ai, aj, aa = orc.stencil(kind, n, m=m)
+    N = len(ai) - 1
+    x = rng.standard_normal(N)
+    y0 = rng.standard_normal(N)
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    _lib.chk(hx.hipxMatSetSpMVVariant(A, 26))  # row templates whatever the size (auto keeps small matrices on the plain kernels)
+    name = kernel_name(hx, A)
+    assert name.startswith("spmv_pair_kernel " if N >= 512 else "spmv_tmpl_kernel "), name
+    yr = orc.matmult(ai, aj, aa, x)
+    zr = np.zeros(N)
+    orc.lib().orc_MatMultAdd_SeqAIJ(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(y0), orc.P(zr))
+    X, Y, Y0 = _lib.DVec(N + 2, np.concatenate([x, [0.0, 0.0]])), _lib.DVec(N + 2), _lib.DVec(N + 2, np.concatenate([y0, [0.0, 0.0]]))
+    for _ in range(3):  # (the chunk queue's ticket counters run on from launch to launch)
+        _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+        assert np.array_equal(Y.get()[:N], yr)
+    _lib.chk(hx.hipxMatMultAdd(A, X.ptr, Y0.ptr, Y.ptr))
+    assert np.array_equal(Y.get()[:N], zr)
+    dot = C.c_double()
+    _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(dot)))
+    assert np.array_equal(Y.get()[:N], yr) and abs(dot.value - float(x @ yr)) <= 1e-12 * np.abs(x * yr).sum()
+    # vectors shifted by one double: not 16-byte aligned -> the general template kernel, same bits; then aligned again
+    Xs, Ys = _lib.DVec(N + 2, np.concatenate([[0.0], x, [0.0]])), _lib.DVec(N + 2)
+    _lib.chk(hx.hipxMatMult(A, Xs.offset(1), Ys.offset(1)))
+    assert np.array_equal(Ys.get()[1:N + 1], yr)
+    _lib.chk(hx.hipxMatMultDot(A, Xs.offset(1), Ys.offset(1), C.byref(dot)))
+    assert np.array_equal(Ys.get()[1:N + 1], yr) and abs(dot.value - float(x @ yr)) <= 1e-12 * np.abs(x * yr).sum()
+    _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    assert np.array_equal(Y.get()[:N], yr)
+    _lib.mat_destroy(A)
+    # rows scaled by one of three factors: still <= 256 row templates, but no common base row
+    scale = np.repeat(np.array([1.0, 0.5, 2.0])[np.arange(N) % 3], np.diff(ai))
+    A = _lib.mat_create_csr(N, N, ai, aj, aa * scale)
+    _lib.chk(hx.hipxMatSetSpMVVariant(A, 26))
+    assert kernel_name(hx, A).startswith("spmv_tmpl_kernel "), kernel_name(hx, A)
+    _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    assert np.array_equal(Y.get()[:N], orc.matmult(ai, aj, aa * scale, x))
+    _lib.mat_destroy(A)
+    for v in (X, Y, Y0, Xs, Ys):
+        v.free()
