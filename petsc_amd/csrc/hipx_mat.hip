@@ -1368,11 +1368,13 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
 {
   typedef double dbl2 __attribute__((ext_vector_type(2)));
   __shared__ unsigned int s_mask[256];
+  __shared__ double       s_a[48];  // the plan's coefficients (read at use: 96 SGPRs less to keep alive)
   __shared__ long long    s_tk;
   __shared__ long long    s_tk2[2];
   const int t = threadIdx.x, lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   for (int k = t; k < ntmpl; k += 256) s_mask[k] = tmask[k];
+  if (t < 48) s_a[t] = plan.a[t / 3][t % 3];
   const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, bpx = (hipx_int)gridDim.x >> 3;
   const hipx_int c0 = xcd * chunks_per_xcd, c1 = (c0 + chunks_per_xcd < nchunks) ? c0 + chunks_per_xcd : nchunks;
   const long long     nall  = (long long)(c1 > c0 ? c1 - c0 : 0);
@@ -1414,16 +1416,16 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
         else if (qp >= 0 && qp < (long long)m) P[j].x = x[qp];  // (an odd row count: the vector's last element is the first half of a pair)
       }
     }
-    // (2) the elements just outside the wave's run, for the entries at e - 1 (first lane) and e + 1 (last lane): wave-uniform
-    // addresses -> scalar loads, off the vector memory path
-    double eL[NP], eR[NP];
+    // (2) the elements just outside the wave's run, for the entries at e - 1 (the wave's first lane needs x[W - 1 + e]) and e + 1 (its
+    // last lane needs x[W + 128 + e]): one load per pair with two active lanes
+    double edge[NP];
 #pragma unroll
     for (int j = 0; j < NP; j++) {
-      eL[j] = eR[j] = 0.0;
-      if (j < plan.npairs) {
-        const long long ql = W - 1 + plan.e[j], qr = W + 128 + plan.e[j];
-        if (plan.kb[j][0] >= 0 && ql >= 0 && ql < (long long)m) eL[j] = x[ql];
-        if (plan.kb[j][2] >= 0 && qr >= 0 && qr < (long long)m) eR[j] = x[qr];
+      edge[j] = 0.0;
+      if (j < plan.npairs && (plan.kb[j][0] >= 0 || plan.kb[j][2] >= 0)) {
+        const long long qe = (lane == 0) ? W - 1 + plan.e[j] : W + 128 + plan.e[j];
+        const bool      on = (lane == 0) ? plan.kb[j][0] >= 0 : (lane == 63 && plan.kb[j][2] >= 0);
+        if (on && qe >= 0 && qe < (long long)m) edge[j] = x[qe];
       }
     }
     dbl2 s2 = dbl2{0.0, 0.0};
@@ -1435,22 +1437,22 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
     for (int j = 0; j < NP; j++) {
       if (j < plan.npairs) {
         if (plan.kb[j][0] >= 0) {  // entry at e - 1: row r <- x[r + e - 1] = the previous lane's second element, row r + 1 <- x[r + e]
-          const double   A = pair_prev_lane(eL[j], P[j].y), B = P[j].x;
+          const double   A = pair_prev_lane(edge[j], P[j].y), B = P[j].x;
           const unsigned bit = 1u << plan.kb[j][0];
-          const double   a = plan.a[j][0];
+          const double   a = s_a[3 * j + 0];
           if (mk0 & bit) sum0 += a * A;
           if (mk1 & bit) sum1 += a * B;
         }
         if (plan.kb[j][1] >= 0) {  // entry at e
           const unsigned bit = 1u << plan.kb[j][1];
-          const double   a = plan.a[j][1];
+          const double   a = s_a[3 * j + 1];
           if (mk0 & bit) sum0 += a * P[j].x;
           if (mk1 & bit) sum1 += a * P[j].y;
         }
         if (plan.kb[j][2] >= 0) {  // entry at e + 1: row r <- x[r + e + 1], row r + 1 <- x[r + e + 2] = the next lane's first element
-          const double   A = P[j].y, B = pair_next_lane(eR[j], P[j].x, lane);
+          const double   A = P[j].y, B = pair_next_lane(edge[j], P[j].x, lane);
           const unsigned bit = 1u << plan.kb[j][2];
-          const double   a = plan.a[j][2];
+          const double   a = s_a[3 * j + 2];
           if (mk0 & bit) sum0 += a * A;
           if (mk1 & bit) sum1 += a * B;
         }
@@ -1477,6 +1479,99 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
     tk1 = s_tk;
   }
   if (sink == 0xffffffffu) yout[0] = pf;  // never true: keeps the prefetch loads alive
+}
+
+// The same chunk body, NOT persistent: one workgroup per chunk of 512 rows, block b works on chunk (b % 8) * chunks_per_xcd + b / 8 (the
+// hardware places block b on XCD b % 8 and starts blocks in index order: each XCD still walks its slab front to back, so the planes of
+// x a window of chunks touches stay in that XCD's L2).  No ticket atomics, no barriers after the mask table, no prefetch loads: in
+// the persistent kernel every one of those sat in the SAME in-order vmcnt queue as the chunk's gathers -- a wave waiting for its
+// (L2-resident) pairs also waited for the HBM misses of the prefetch and of the next chunk's template ids, and for the returning
+// ticket atomic: one loaded-HBM latency per chunk and workgroup, serialised, which is what the 0.14 ms were made of (SQ_WAIT_ANY
+// 82 %, profiles/r03_tmpl_sq_counters.txt).  Here a workgroup issues everything it needs at once and leaves; the CU's other
+// resident workgroups (6-7) cover its one miss latency.
+template <int MODE, bool DOT, int NP>
+__global__ __launch_bounds__(256) void spmv_pair_np_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask,
+                                                           int ntmpl, const hipxPairPlan plan, const double *__restrict__ x, const double *yin, double *yout, double *dotpart)
+{
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  __shared__ unsigned int s_mask[256];
+  __shared__ double       s_a[48];  // the plan's coefficients (read at use: 96 SGPRs less to keep alive)
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+  const hipx_int c = xcd * chunks_per_xcd + slot;
+  if (slot >= chunks_per_xcd || c >= nchunks) return;
+  const long long base = (long long)c * 512;
+  const long long r    = base + 2 * t;           // this thread's even row
+  const long long W    = base + 128 * wv;         // first row of this wave's run
+  const unsigned  id2  = reinterpret_cast<const unsigned short *>(tid)[r >> 1];  // rows r, r + 1: one 2-byte load
+  for (int k = t; k < ntmpl; k += 256) s_mask[k] = tmask[k];
+  if (t < 48) s_a[t] = plan.a[t / 3][t % 3];
+  {
+    // (1) every pair of the chunk in flight at once (zero outside the vector: such a pair is used by no row that exists)
+    dbl2 P[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+      P[j] = dbl2{0.0, 0.0};
+      if (j < plan.npairs) {
+        const long long qp = r + plan.e[j];
+        if (qp >= 0 && qp + 1 < (long long)m) P[j] = *reinterpret_cast<const dbl2 *>(x + qp);
+        else if (qp >= 0 && qp < (long long)m) P[j].x = x[qp];  // (an odd row count: the vector's last element is the first half of a pair)
+      }
+    }
+    // (2) the elements just outside the wave's run, for the entries at e - 1 (the wave's first lane needs x[W - 1 + e]) and e + 1 (its
+    // last lane needs x[W + 128 + e]): one load per pair with two active lanes
+    double edge[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+      edge[j] = 0.0;
+      if (j < plan.npairs && (plan.kb[j][0] >= 0 || plan.kb[j][2] >= 0)) {
+        const long long qe = (lane == 0) ? W - 1 + plan.e[j] : W + 128 + plan.e[j];
+        const bool      on = (lane == 0) ? plan.kb[j][0] >= 0 : (lane == 63 && plan.kb[j][2] >= 0);
+        if (on && qe >= 0 && qe < (long long)m) edge[j] = x[qe];
+      }
+    }
+    dbl2 s2 = dbl2{0.0, 0.0};
+    if (MODE == 1) s2 = *reinterpret_cast<const dbl2 *>(yin + r);
+    double         sum0 = s2.x, sum1 = s2.y, xr0 = 0.0, xr1 = 0.0;
+    __syncthreads();  // the mask table is in place (the loads above are in flight meanwhile)
+    const unsigned mk0 = s_mask[id2 & 0xffu], mk1 = s_mask[id2 >> 8];
+    // (3) the walk: pairs in ascending offset, slots 0, 1, 2 = the base template's entries in their own order
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+      if (j < plan.npairs) {
+        if (plan.kb[j][0] >= 0) {  // entry at e - 1: row r <- x[r + e - 1] = the previous lane's second element, row r + 1 <- x[r + e]
+          const double   A = pair_prev_lane(edge[j], P[j].y), B = P[j].x;
+          const unsigned bit = 1u << plan.kb[j][0];
+          const double   a = s_a[3 * j + 0];
+          if (mk0 & bit) sum0 += a * A;
+          if (mk1 & bit) sum1 += a * B;
+        }
+        if (plan.kb[j][1] >= 0) {  // entry at e
+          const unsigned bit = 1u << plan.kb[j][1];
+          const double   a = s_a[3 * j + 1];
+          if (mk0 & bit) sum0 += a * P[j].x;
+          if (mk1 & bit) sum1 += a * P[j].y;
+        }
+        if (plan.kb[j][2] >= 0) {  // entry at e + 1: row r <- x[r + e + 1], row r + 1 <- x[r + e + 2] = the next lane's first element
+          const double   A = P[j].y, B = pair_next_lane(edge[j], P[j].x, lane);
+          const unsigned bit = 1u << plan.kb[j][2];
+          const double   a = s_a[3 * j + 2];
+          if (mk0 & bit) sum0 += a * A;
+          if (mk1 & bit) sum1 += a * B;
+        }
+        if (DOT && j == plan.jdiag) {
+          xr0 = P[j].x;
+          xr1 = P[j].y;
+        }
+      }
+    }
+    *reinterpret_cast<dbl2 *>(yout + r) = dbl2{sum0, sum1};
+    if (DOT) {  // one partial per wave and CHUNK, folded in chunk order by the caller (as spmv_tmpl_kernel)
+      const double w = hipx::wave_sum(xr0 * sum0 + xr1 * sum1);
+      if (lane == 0) dotpart[(size_t)c * 4 + wv] = w;
+    }
+  }
 }
 
 // rows [row0, m) of a template matrix, one row per thread and pass (the partial last chunk of spmv_pair_kernel): the row's own
@@ -2262,6 +2357,12 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
     static const int nq_env = getenv("HIPX_TMPL_NQ") ? atoi(getenv("HIPX_TMPL_NQ")) : 4;
     int nq = (nq_env == 1 || nq_env == 2 || nq_env == 4 || nq_env == 8) ? nq_env : 4;
     while (nq > 1 && (((grid >> 3) % nq) != 0 || cpx < 4 * nq)) nq >>= 1;  // every sub-queue needs the same number of workgroups (and a few chunks)
+    static const bool persist = getenv("HIPX_TMPL_PERSIST") != nullptr;
+    if (!persist) {
+      const unsigned g = (unsigned)(8 * cpx);
+      if (A->pair_plan.npairs <= 8) spmv_pair_np_kernel<MODE, DOT, 8><<<g, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart);
+      else spmv_pair_np_kernel<MODE, DOT, 16><<<g, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart);
+    } else
     if (A->pair_plan.npairs <= 8) spmv_pair_kernel<MODE, DOT, 8><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, nq);
     else spmv_pair_kernel<MODE, DOT, 16><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, nq);
     HIPX_LAUNCH_CHECK();
