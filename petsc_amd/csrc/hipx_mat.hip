@@ -1362,19 +1362,21 @@ __device__ __forceinline__ double pair_next_lane(double last, double v, int lane
 // bits of MatMult_SeqAIJ (aij.c:1486-1494).  Whole chunks of 512 rows only (the rest: spmv_tmpl_tail_kernel); chunk queue, XCD
 // slabs and first-touch prefetch as in spmv_tmpl_kernel.
 template <int MODE, bool DOT, int NP>
-__global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask,
+__global__ __launch_bounds__(320) void spmv_pair_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask,
                                                         int ntmpl, const hipxPairPlan plan, const double *__restrict__ x, const double *yin, double *yout, double *dotpart,
-                                                        unsigned long long *tq, unsigned long long launch, long long pf_off, int nq)
+                                                        unsigned long long *tq, unsigned long long launch, long long pf_off, int nq, long long pf_rows)
 {
   typedef double dbl2 __attribute__((ext_vector_type(2)));
   __shared__ unsigned int s_mask[256];
-  __shared__ double       s_a[48];  // the plan's coefficients (read at use: 96 SGPRs less to keep alive)
   __shared__ long long    s_tk;
   __shared__ long long    s_tk2[2];
   const int t = threadIdx.x, lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  // wave 4 (threads 256-319) is the PREFETCH wave: it touches the lines the chunk one round ahead will need from HBM (the far plane of x,
+  // the template ids) and does nothing else -- so that no load of a compute wave misses the L2: vmcnt retires in order, and a miss
+  // issued by a compute wave (the old first-touch prefetch, the next chunk's ids) held up every later wait of that wave
+  const bool pfw = wv == 4;
   for (int k = t; k < ntmpl; k += 256) s_mask[k] = tmask[k];
-  if (t < 48) s_a[t] = plan.a[t / 3][t % 3];
   const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, bpx = (hipx_int)gridDim.x >> 3;
   const hipx_int c0 = xcd * chunks_per_xcd, c1 = (c0 + chunks_per_xcd < nchunks) ? c0 + chunks_per_xcd : nchunks;
   const long long     nall  = (long long)(c1 > c0 ? c1 - c0 : 0);
@@ -1395,7 +1397,7 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
   double    pf = 0.0;
   unsigned  sink = 0;
   const unsigned short *tid2 = reinterpret_cast<const unsigned short *>(tid);  // rows r, r + 1: one 2-byte load (r even)
-  unsigned idn = (tk < nloc) ? (unsigned)tid2[((long long)(c0 + tk * nq + q) * 512 + 2 * t) >> 1] : 0u;
+  unsigned idn = (tk < nloc && !pfw) ? (unsigned)tid2[((long long)(c0 + tk * nq + q) * 512 + 2 * t) >> 1] : 0u;
   while (tk < nloc) {
     long long nxt = 0;
     if (t == 0) nxt = (long long)atomicAdd(ctr, 1ull) - tbase;  // the ticket after next travels while this chunk is processed
@@ -1403,74 +1405,80 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
     const long long base = (long long)c * 512;
     const long long r    = base + 2 * t;           // this thread's even row
     const long long W    = base + 128 * wv;         // first row of this wave's run
+    if (!pfw) {
     const unsigned  id2  = idn;
-    idn = (tk1 < nloc) ? (unsigned)tid2[((long long)(c0 + tk1 * nq + q) * 512 + 2 * t) >> 1] : 0u;  // next chunk's ids: consumed at the top of the next pass
-    // (1) every pair of the chunk in flight at once (zero outside the vector: such a pair is used by no row that exists)
-    dbl2 P[NP];
+      idn = (tk1 < nloc) ? (unsigned)tid2[((long long)(c0 + tk1 * nq + q) * 512 + 2 * t) >> 1] : 0u;  // next chunk's ids: consumed at the top of the next pass
+      // (1) every pair of the chunk in flight at once (zero outside the vector: such a pair is used by no row that exists)
+      dbl2 P[NP];
 #pragma unroll
-    for (int j = 0; j < NP; j++) {
-      P[j] = dbl2{0.0, 0.0};
-      if (j < plan.npairs) {
-        const long long qp = r + plan.e[j];
-        if (qp >= 0 && qp + 1 < (long long)m) P[j] = *reinterpret_cast<const dbl2 *>(x + qp);
-        else if (qp >= 0 && qp < (long long)m) P[j].x = x[qp];  // (an odd row count: the vector's last element is the first half of a pair)
-      }
-    }
-    // (2) the elements just outside the wave's run, for the entries at e - 1 (the wave's first lane needs x[W - 1 + e]) and e + 1 (its
-    // last lane needs x[W + 128 + e]): one load per pair with two active lanes
-    double edge[NP];
-#pragma unroll
-    for (int j = 0; j < NP; j++) {
-      edge[j] = 0.0;
-      if (j < plan.npairs && (plan.kb[j][0] >= 0 || plan.kb[j][2] >= 0)) {
-        const long long qe = (lane == 0) ? W - 1 + plan.e[j] : W + 128 + plan.e[j];
-        const bool      on = (lane == 0) ? plan.kb[j][0] >= 0 : (lane == 63 && plan.kb[j][2] >= 0);
-        if (on && qe >= 0 && qe < (long long)m) edge[j] = x[qe];
-      }
-    }
-    dbl2 s2 = dbl2{0.0, 0.0};
-    if (MODE == 1) s2 = *reinterpret_cast<const dbl2 *>(yin + r);
-    double         sum0 = s2.x, sum1 = s2.y, xr0 = 0.0, xr1 = 0.0;
-    const unsigned mk0 = s_mask[id2 & 0xffu], mk1 = s_mask[id2 >> 8];
-    // (3) the walk: pairs in ascending offset, slots 0, 1, 2 = the base template's entries in their own order
-#pragma unroll
-    for (int j = 0; j < NP; j++) {
-      if (j < plan.npairs) {
-        if (plan.kb[j][0] >= 0) {  // entry at e - 1: row r <- x[r + e - 1] = the previous lane's second element, row r + 1 <- x[r + e]
-          const double   A = pair_prev_lane(edge[j], P[j].y), B = P[j].x;
-          const unsigned bit = 1u << plan.kb[j][0];
-          const double   a = s_a[3 * j + 0];
-          if (mk0 & bit) sum0 += a * A;
-          if (mk1 & bit) sum1 += a * B;
-        }
-        if (plan.kb[j][1] >= 0) {  // entry at e
-          const unsigned bit = 1u << plan.kb[j][1];
-          const double   a = s_a[3 * j + 1];
-          if (mk0 & bit) sum0 += a * P[j].x;
-          if (mk1 & bit) sum1 += a * P[j].y;
-        }
-        if (plan.kb[j][2] >= 0) {  // entry at e + 1: row r <- x[r + e + 1], row r + 1 <- x[r + e + 2] = the next lane's first element
-          const double   A = P[j].y, B = pair_next_lane(edge[j], P[j].x, lane);
-          const unsigned bit = 1u << plan.kb[j][2];
-          const double   a = s_a[3 * j + 2];
-          if (mk0 & bit) sum0 += a * A;
-          if (mk1 & bit) sum1 += a * B;
-        }
-        if (DOT && j == plan.jdiag) {
-          xr0 = P[j].x;
-          xr1 = P[j].y;
+      for (int j = 0; j < NP; j++) {
+        P[j] = dbl2{0.0, 0.0};
+        if (j < plan.npairs) {
+          const long long qp = r + plan.e[j];
+          if (qp >= 0 && qp + 1 < (long long)m) P[j] = *reinterpret_cast<const dbl2 *>(x + qp);
+          else if (qp >= 0 && qp < (long long)m) P[j].x = x[qp];  // (an odd row count: the vector's last element is the first half of a pair)
         }
       }
-    }
-    *reinterpret_cast<dbl2 *>(yout + r) = dbl2{sum0, sum1};
-    if (DOT) {  // one partial per wave and CHUNK, folded in chunk order by the caller (as spmv_tmpl_kernel)
-      const double w = hipx::wave_sum(xr0 * sum0 + xr1 * sum1);
-      if (lane == 0) dotpart[(size_t)c * 4 + wv] = w;
-    }
-    sink += (__double_as_longlong(pf) == 0x7ff8123456789abcLL) ? 1u : 0u;  // consume the previous pass's prefetch
-    if (pf_off && t < 32) {
-      const long long prow = base + pf_off + (long long)t * 16;
-      if (prow < (long long)m) pf = x[prow];
+      // (2) the elements just outside the wave's run, for the entries at e - 1 (first lane) and e + 1 (last lane): wave-uniform
+      // addresses -> scalar loads, off the vector memory path
+      double eL[NP], eR[NP];
+#pragma unroll
+      for (int j = 0; j < NP; j++) {
+        eL[j] = eR[j] = 0.0;
+        if (j < plan.npairs) {
+          const long long ql = W - 1 + plan.e[j], qr = W + 128 + plan.e[j];
+          if (plan.kb[j][0] >= 0 && ql >= 0 && ql < (long long)m) eL[j] = x[ql];
+          if (plan.kb[j][2] >= 0 && qr >= 0 && qr < (long long)m) eR[j] = x[qr];
+        }
+      }
+      dbl2 s2 = dbl2{0.0, 0.0};
+      if (MODE == 1) s2 = *reinterpret_cast<const dbl2 *>(yin + r);
+      double         sum0 = s2.x, sum1 = s2.y, xr0 = 0.0, xr1 = 0.0;
+      const unsigned mk0 = s_mask[id2 & 0xffu], mk1 = s_mask[id2 >> 8];
+      // (3) the walk: pairs in ascending offset, slots 0, 1, 2 = the base template's entries in their own order
+#pragma unroll
+      for (int j = 0; j < NP; j++) {
+        if (j < plan.npairs) {
+          if (plan.kb[j][0] >= 0) {  // entry at e - 1: row r <- x[r + e - 1] = the previous lane's second element, row r + 1 <- x[r + e]
+            const double   A = pair_prev_lane(eL[j], P[j].y), B = P[j].x;
+            const unsigned bit = 1u << plan.kb[j][0];
+            const double   a = plan.a[j][0];
+            if (mk0 & bit) sum0 += a * A;
+            if (mk1 & bit) sum1 += a * B;
+          }
+          if (plan.kb[j][1] >= 0) {  // entry at e
+            const unsigned bit = 1u << plan.kb[j][1];
+            const double   a = plan.a[j][1];
+            if (mk0 & bit) sum0 += a * P[j].x;
+            if (mk1 & bit) sum1 += a * P[j].y;
+          }
+          if (plan.kb[j][2] >= 0) {  // entry at e + 1: row r <- x[r + e + 1], row r + 1 <- x[r + e + 2] = the next lane's first element
+            const double   A = P[j].y, B = pair_next_lane(eR[j], P[j].x, lane);
+            const unsigned bit = 1u << plan.kb[j][2];
+            const double   a = plan.a[j][2];
+            if (mk0 & bit) sum0 += a * A;
+            if (mk1 & bit) sum1 += a * B;
+          }
+          if (DOT && j == plan.jdiag) {
+            xr0 = P[j].x;
+            xr1 = P[j].y;
+          }
+        }
+      }
+      *reinterpret_cast<dbl2 *>(yout + r) = dbl2{sum0, sum1};
+      if (DOT) {  // one partial per wave and CHUNK, folded in chunk order by the caller (as spmv_tmpl_kernel)
+        const double w = hipx::wave_sum(xr0 * sum0 + xr1 * sum1);
+        if (lane == 0) dotpart[(size_t)c * 4 + wv] = w;
+      }
+    } else {
+      sink += (__double_as_longlong(pf) == 0x7ff8123456789abcLL) ? 1u : 0u;  // (the previous pass's lines have arrived: one pass of slack)
+      if (pf_off) {
+        const int       pl = t - 256;
+        const long long prow = base + pf_off + (long long)pl * 16;          // 32 lines of the far plane of x, one round of workgroups ahead
+        const long long trow = base + pf_rows + (long long)(pl - 32) * 128;  // 4 lines of template ids, one round ahead
+        if (pl < 32 && prow < (long long)m) pf = x[prow];
+        else if (pl >= 32 && pl < 36 && trow < (long long)m) pf = (double)tid[trow];
+      }
     }
     __syncthreads();  // everybody has read the tickets
     if (t == 0) s_tk = nxt;
@@ -1495,7 +1503,6 @@ __global__ __launch_bounds__(256) void spmv_pair_np_kernel(hipx_int m, hipx_int 
 {
   typedef double dbl2 __attribute__((ext_vector_type(2)));
   __shared__ unsigned int s_mask[256];
-  __shared__ double       s_a[48];  // the plan's coefficients (read at use: 96 SGPRs less to keep alive)
   const int t = threadIdx.x, lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, slot = bid >> 3;
@@ -1506,7 +1513,6 @@ __global__ __launch_bounds__(256) void spmv_pair_np_kernel(hipx_int m, hipx_int 
   const long long W    = base + 128 * wv;         // first row of this wave's run
   const unsigned  id2  = reinterpret_cast<const unsigned short *>(tid)[r >> 1];  // rows r, r + 1: one 2-byte load
   for (int k = t; k < ntmpl; k += 256) s_mask[k] = tmask[k];
-  if (t < 48) s_a[t] = plan.a[t / 3][t % 3];
   {
     // (1) every pair of the chunk in flight at once (zero outside the vector: such a pair is used by no row that exists)
     dbl2 P[NP];
@@ -1519,16 +1525,16 @@ __global__ __launch_bounds__(256) void spmv_pair_np_kernel(hipx_int m, hipx_int 
         else if (qp >= 0 && qp < (long long)m) P[j].x = x[qp];  // (an odd row count: the vector's last element is the first half of a pair)
       }
     }
-    // (2) the elements just outside the wave's run, for the entries at e - 1 (the wave's first lane needs x[W - 1 + e]) and e + 1 (its
-    // last lane needs x[W + 128 + e]): one load per pair with two active lanes
-    double edge[NP];
+    // (2) the elements just outside the wave's run, for the entries at e - 1 (first lane) and e + 1 (last lane): wave-uniform
+    // addresses -> scalar loads, off the vector memory path
+    double eL[NP], eR[NP];
 #pragma unroll
     for (int j = 0; j < NP; j++) {
-      edge[j] = 0.0;
-      if (j < plan.npairs && (plan.kb[j][0] >= 0 || plan.kb[j][2] >= 0)) {
-        const long long qe = (lane == 0) ? W - 1 + plan.e[j] : W + 128 + plan.e[j];
-        const bool      on = (lane == 0) ? plan.kb[j][0] >= 0 : (lane == 63 && plan.kb[j][2] >= 0);
-        if (on && qe >= 0 && qe < (long long)m) edge[j] = x[qe];
+      eL[j] = eR[j] = 0.0;
+      if (j < plan.npairs) {
+        const long long ql = W - 1 + plan.e[j], qr = W + 128 + plan.e[j];
+        if (plan.kb[j][0] >= 0 && ql >= 0 && ql < (long long)m) eL[j] = x[ql];
+        if (plan.kb[j][2] >= 0 && qr >= 0 && qr < (long long)m) eR[j] = x[qr];
       }
     }
     dbl2 s2 = dbl2{0.0, 0.0};
@@ -1541,22 +1547,22 @@ __global__ __launch_bounds__(256) void spmv_pair_np_kernel(hipx_int m, hipx_int 
     for (int j = 0; j < NP; j++) {
       if (j < plan.npairs) {
         if (plan.kb[j][0] >= 0) {  // entry at e - 1: row r <- x[r + e - 1] = the previous lane's second element, row r + 1 <- x[r + e]
-          const double   A = pair_prev_lane(edge[j], P[j].y), B = P[j].x;
+          const double   A = pair_prev_lane(eL[j], P[j].y), B = P[j].x;
           const unsigned bit = 1u << plan.kb[j][0];
-          const double   a = s_a[3 * j + 0];
+          const double   a = plan.a[j][0];
           if (mk0 & bit) sum0 += a * A;
           if (mk1 & bit) sum1 += a * B;
         }
         if (plan.kb[j][1] >= 0) {  // entry at e
           const unsigned bit = 1u << plan.kb[j][1];
-          const double   a = s_a[3 * j + 1];
+          const double   a = plan.a[j][1];
           if (mk0 & bit) sum0 += a * P[j].x;
           if (mk1 & bit) sum1 += a * P[j].y;
         }
         if (plan.kb[j][2] >= 0) {  // entry at e + 1: row r <- x[r + e + 1], row r + 1 <- x[r + e + 2] = the next lane's first element
-          const double   A = P[j].y, B = pair_next_lane(edge[j], P[j].x, lane);
+          const double   A = P[j].y, B = pair_next_lane(eR[j], P[j].x, lane);
           const unsigned bit = 1u << plan.kb[j][2];
-          const double   a = s_a[3 * j + 2];
+          const double   a = plan.a[j][2];
           if (mk0 & bit) sum0 += a * A;
           if (mk1 & bit) sum1 += a * B;
         }
@@ -2363,8 +2369,8 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
       if (A->pair_plan.npairs <= 8) spmv_pair_np_kernel<MODE, DOT, 8><<<g, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart);
       else spmv_pair_np_kernel<MODE, DOT, 16><<<g, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart);
     } else
-    if (A->pair_plan.npairs <= 8) spmv_pair_kernel<MODE, DOT, 8><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, nq);
-    else spmv_pair_kernel<MODE, DOT, 16><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, nq);
+    if (A->pair_plan.npairs <= 8) spmv_pair_kernel<MODE, DOT, 8><<<(unsigned)grid, 320, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, nq, pf_off ? pf_off - A->tmpl_maxoff : 0);
+    else spmv_pair_kernel<MODE, DOT, 16><<<(unsigned)grid, 320, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, nq, pf_off ? pf_off - A->tmpl_maxoff : 0);
     HIPX_LAUNCH_CHECK();
     if (nchunks * 512 < m) {
       spmv_tmpl_tail_kernel<MODE, DOT><<<1, 256, 0, rt().compute>>>(m, nchunks * 512, nchunks, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, x, yin, yout, dotpart);
