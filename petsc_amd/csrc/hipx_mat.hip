@@ -1184,50 +1184,7 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
       for (int rr = 0; rr < RPT; rr++) uni = uni && (id[rr] == id0);
       uni = __all(uni);
     }
-    if (UNI && PROBE == 0 && whole && tsub >= 0) {
-      // Sub-template walk (every template is the base template with entries left out: boundary rows of a stencil).  ALL lanes of ALL
-      // waves walk the BASE template's entries -- offsets and values are wave-uniform scalars -- and a lane takes part in entry k
-      // only if bit k of its template's mask is set (exec-masked load, multiply, add: same operands, same order as the lane's own
-      // list, so y is bit-identical).  Entries go in batches of 8: the batch's 16 scalar loads are issued together (ONE wait on the
-      // scalar cache), then its 8 x RPT gathers (ONE memory round trip), then the arithmetic.  Before this form a wave holding a
-      // line's first / last row fell to the per-lane walk below (LDS look-ups per entry) and, through the chunk barrier, held its
-      // workgroup back; and the uniform walk waited for the scalar cache once per entry and for memory once per 4 entries.
-      const int ts = tstart[tsub], te = tstart[tsub + 1];
-      unsigned  rb[RPT], mk[RPT];
-#pragma unroll
-      for (int rr = 0; rr < RPT; rr++) {
-        rb[rr] = (unsigned)(base + t + rr * 256) * 8u;
-        mk[rr] = s_mask[id[rr]];
-      }
-      for (int k0 = ts; k0 < te; k0 += 8) {
-        int    oo[8];
-        double av[8], xv[8][RPT];
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          const int k = (k0 + e < te) ? k0 + e : te - 1;
-          oo[e] = toff[k];
-          av[e] = tval[k];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          const unsigned bit = (k0 + e < te) ? (1u << (k0 + e - ts)) : 0u;
-          const char    *xb  = reinterpret_cast<const char *>(x + oo[e]);
-#pragma unroll
-          for (int rr = 0; rr < RPT; rr++) xv[e][rr] = (mk[rr] & bit) ? *reinterpret_cast<const double *>(xb + rb[rr]) : 0.0;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          const unsigned bit = (k0 + e < te) ? (1u << (k0 + e - ts)) : 0u;
-#pragma unroll
-          for (int rr = 0; rr < RPT; rr++)
-            if (mk[rr] & bit) sum[rr] += av[e] * xv[e][rr];
-          if (DOT && bit && oo[e] == 0) {  // (every template holds the diagonal: checked when the masks were built)
-#pragma unroll
-            for (int rr = 0; rr < RPT; rr++) xrow[rr] = xv[e][rr];
-          }
-        }
-      }
-    } else if (UNI && uni) {
+    if (UNI && uni) {
       // every lane of the wave walks the SAME template (interior rows): offsets and values are wave-uniform scalars read from
       // the global table through the scalar cache, the gather address is (x + off) [scalar] + row * 8 [per lane, computed once]:
       // per nonzero the vector unit issues one load, one multiply and one add, nothing else
@@ -1257,6 +1214,37 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
       if (DOT && !got) {
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) xrow[rr] = x[base + t + rr * 256];
+      }
+    } else if (UNI && PROBE == 0 && whole && tsub >= 0) {
+      // Sub-template walk.  The lanes of this wave do not share a template (a line's first / last row, ...), but every template is
+      // the base template with entries left out: all lanes walk the BASE template's entries -- scalar offsets and values, one
+      // gather address computation per row as above -- and a lane takes part in entry k only if bit k of its template's mask is
+      // set (exec-masked load, multiply, add: same operands, same order as the lane's own list).  Without this the wave -- and,
+      // through the chunk barrier, its whole workgroup -- fell to the per-lane walk below (LDS look-ups per entry, ~4x the
+      // instructions): half of the waves of a 256-wide grid line contain such a row.
+      const int ts = tstart[tsub], te = tstart[tsub + 1];
+      unsigned  rb[RPT], mk[RPT];
+#pragma unroll
+      for (int rr = 0; rr < RPT; rr++) {
+        rb[rr] = (unsigned)(base + t + rr * 256) * 8u;
+        mk[rr] = s_mask[id[rr]];
+      }
+#pragma unroll 4
+      for (int k = ts; k < te; k++) {
+        const double   a   = tval[k];
+        const int      o   = toff[k];
+        const unsigned bit = 1u << (k - ts);
+        const char    *xb  = reinterpret_cast<const char *>(x + o);
+        double         xv[RPT];
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) xv[rr] = (mk[rr] & bit) ? *reinterpret_cast<const double *>(xb + rb[rr]) : 0.0;
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++)
+          if (mk[rr] & bit) sum[rr] += a * xv[rr];
+        if (DOT && o == 0) {  // (every template holds the diagonal: checked when the masks were built)
+#pragma unroll
+          for (int rr = 0; rr < RPT; rr++) xrow[rr] = xv[rr];
+        }
       }
     } else {
       if (DOT && UNI) {
@@ -1334,7 +1322,6 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
   if (sink == 0xffffffffu) yout[0] = pf;  // never true: keeps the prefetch loads alive
 }
 
-
 // lane i <- lane i - 1 (lane 0 gets `first`): DPP wavefront shift, no LDS
 __device__ __forceinline__ double pair_prev_lane(double first, double v)
 {
@@ -1351,20 +1338,21 @@ __device__ __forceinline__ double pair_next_lane(double last, double v, int lane
   return lane == 63 ? last : __hiloint2double(hi, lo);
 }
 
-// Template SpMV, pair form (the sub-template form's matrices: every row = the base template with entries left out).  What bounded
-// spmv_tmpl_kernel on these matrices was not HBM but the CU's address pipeline: a wave-wide 8-byte gather occupies it for ~16 cycles
-// whatever its width (SQ / TA counters: profiles/r03_tmpl_sq_counters.txt), and a row costs one gather per nonzero.  Here a thread
-// owns the two CONSECUTIVE rows r, r + 1 (r even) and loads x in aligned 16-byte pairs (x[r + e], x[r + e + 1]) for the EVEN offsets e
-// only; the entries at e - 1 and e + 1 take their operands from the neighbouring lanes' pairs (one DPP shift / one ds_bpermute; the
-// wave's first / last lane from a scalar load of the element just outside the wave's 128-element run).  7-point: 5 pair loads per
-// 128 rows instead of 14 gathers; 27-point: 9 instead of 54.  y leaves as one 16-byte store, the two template ids arrive as one
-// 2-byte load.  Arithmetic per row: the row's own entries in ascending column order, product and sum rounded separately -- the
-// bits of MatMult_SeqAIJ (aij.c:1486-1494).  Whole chunks of 512 rows only (the rest: spmv_tmpl_tail_kernel); chunk queue, XCD
-// slabs and first-touch prefetch as in spmv_tmpl_kernel.
+// Template SpMV, pair form (the sub-template form's matrices: every row = the base template with entries left out; base templates with
+// <= 8 even-offset pairs: the 5-/7-point class).  A thread owns the two CONSECUTIVE rows r, r + 1 (r even) and loads x in aligned
+// 16-byte pairs (x[r + e], x[r + e + 1]) for the EVEN offsets e only; the entries at e - 1 and e + 1 take their operands from the
+// neighbouring lanes' pairs (one DPP shift / one ds_bpermute; the wave's first / last lane from a scalar load of the element just
+// outside the wave's 128-element run).  7-point: 5 pair loads per 128 rows instead of 14 gathers; y leaves as one 16-byte store, the
+// two template ids arrive as one 2-byte load.  Arithmetic per row: the row's own entries in ascending column order, product and sum
+// rounded separately -- the bits of MatMult_SeqAIJ (aij.c:1486-1494).  Whole chunks of 512 rows only (the rest:
+// spmv_tmpl_tail_kernel); chunk queue, XCD slabs and first-touch prefetch as in spmv_tmpl_kernel.  Measured (7-pt 256^3, same-box
+// A/B against spmv_tmpl_kernel with the sub-template walk): -11 %, 0 %, -15 % on three boxes (DESIGN 3.1 lists what else was tried on
+// this kernel in round 3 and did not move it: the 27-point class with 16 pairs (register pressure: slower), several ticket counters per
+// XCD, a non-persistent one-chunk-per-workgroup launch, a fifth wave that does the prefetching).
 template <int MODE, bool DOT, int NP>
-__global__ __launch_bounds__(320) void spmv_pair_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask,
+__global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask,
                                                         int ntmpl, const hipxPairPlan plan, const double *__restrict__ x, const double *yin, double *yout, double *dotpart,
-                                                        unsigned long long *tq, unsigned long long launch, long long pf_off, int nq, long long pf_rows)
+                                                        unsigned long long *tq, unsigned long long launch, long long pf_off)
 {
   typedef double dbl2 __attribute__((ext_vector_type(2)));
   __shared__ unsigned int s_mask[256];
@@ -1372,22 +1360,12 @@ __global__ __launch_bounds__(320) void spmv_pair_kernel(hipx_int m, hipx_int nch
   __shared__ long long    s_tk2[2];
   const int t = threadIdx.x, lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  // wave 4 (threads 256-319) is the PREFETCH wave: it touches the lines the chunk one round ahead will need from HBM (the far plane of x,
-  // the template ids) and does nothing else -- so that no load of a compute wave misses the L2: vmcnt retires in order, and a miss
-  // issued by a compute wave (the old first-touch prefetch, the next chunk's ids) held up every later wait of that wave
-  const bool pfw = wv == 4;
   for (int k = t; k < ntmpl; k += 256) s_mask[k] = tmask[k];
   const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, bpx = (hipx_int)gridDim.x >> 3;
   const hipx_int c0 = xcd * chunks_per_xcd, c1 = (c0 + chunks_per_xcd < nchunks) ? c0 + chunks_per_xcd : nchunks;
-  const long long     nall  = (long long)(c1 > c0 ? c1 - c0 : 0);
-  // nq ticket counters per XCD (a returning atomic on ONE address is served every ~30 ns: with 256 workgroups per XCD taking a ticket
-  // per chunk that alone is the kernel's time): workgroup w of the XCD draws from counter w % nq, whose tickets k stand for the chunks
-  // k * nq + w % nq of the slab -- each sub-queue walks the slab in order, and the sub-queues stay abreast of each other because
-  // their workgroups are statistically identical
-  const int           q     = (int)((bid >> 3) % nq);
-  const long long     nloc  = (nall - q + nq - 1) / nq;  // chunks of this sub-queue
-  unsigned long long *ctr   = tq + 64 + ((size_t)xcd * 8 + (size_t)q) * 16;
-  const long long     tbase = (long long)(launch * (unsigned long long)(nloc + 2 * (bpx / nq)));
+  const long long     nloc  = (long long)(c1 > c0 ? c1 - c0 : 0);
+  unsigned long long *ctr   = tq + (size_t)xcd * 8;
+  const long long     tbase = (long long)(launch * (unsigned long long)(nloc + 2 * bpx));
   if (t == 0) {
     s_tk2[0] = (long long)atomicAdd(ctr, 1ull) - tbase;
     s_tk2[1] = (long long)atomicAdd(ctr, 1ull) - tbase;
@@ -1397,123 +1375,16 @@ __global__ __launch_bounds__(320) void spmv_pair_kernel(hipx_int m, hipx_int nch
   double    pf = 0.0;
   unsigned  sink = 0;
   const unsigned short *tid2 = reinterpret_cast<const unsigned short *>(tid);  // rows r, r + 1: one 2-byte load (r even)
-  unsigned idn = (tk < nloc && !pfw) ? (unsigned)tid2[((long long)(c0 + tk * nq + q) * 512 + 2 * t) >> 1] : 0u;
+  unsigned idn = (tk < nloc) ? (unsigned)tid2[((long long)(c0 + tk) * 512 + 2 * t) >> 1] : 0u;
   while (tk < nloc) {
     long long nxt = 0;
     if (t == 0) nxt = (long long)atomicAdd(ctr, 1ull) - tbase;  // the ticket after next travels while this chunk is processed
-    const hipx_int  c    = c0 + (hipx_int)(tk * nq + q);
+    const hipx_int  c    = c0 + (hipx_int)tk;
     const long long base = (long long)c * 512;
     const long long r    = base + 2 * t;           // this thread's even row
     const long long W    = base + 128 * wv;         // first row of this wave's run
-    if (!pfw) {
     const unsigned  id2  = idn;
-      idn = (tk1 < nloc) ? (unsigned)tid2[((long long)(c0 + tk1 * nq + q) * 512 + 2 * t) >> 1] : 0u;  // next chunk's ids: consumed at the top of the next pass
-      // (1) every pair of the chunk in flight at once (zero outside the vector: such a pair is used by no row that exists)
-      dbl2 P[NP];
-#pragma unroll
-      for (int j = 0; j < NP; j++) {
-        P[j] = dbl2{0.0, 0.0};
-        if (j < plan.npairs) {
-          const long long qp = r + plan.e[j];
-          if (qp >= 0 && qp + 1 < (long long)m) P[j] = *reinterpret_cast<const dbl2 *>(x + qp);
-          else if (qp >= 0 && qp < (long long)m) P[j].x = x[qp];  // (an odd row count: the vector's last element is the first half of a pair)
-        }
-      }
-      // (2) the elements just outside the wave's run, for the entries at e - 1 (first lane) and e + 1 (last lane): wave-uniform
-      // addresses -> scalar loads, off the vector memory path
-      double eL[NP], eR[NP];
-#pragma unroll
-      for (int j = 0; j < NP; j++) {
-        eL[j] = eR[j] = 0.0;
-        if (j < plan.npairs) {
-          const long long ql = W - 1 + plan.e[j], qr = W + 128 + plan.e[j];
-          if (plan.kb[j][0] >= 0 && ql >= 0 && ql < (long long)m) eL[j] = x[ql];
-          if (plan.kb[j][2] >= 0 && qr >= 0 && qr < (long long)m) eR[j] = x[qr];
-        }
-      }
-      dbl2 s2 = dbl2{0.0, 0.0};
-      if (MODE == 1) s2 = *reinterpret_cast<const dbl2 *>(yin + r);
-      double         sum0 = s2.x, sum1 = s2.y, xr0 = 0.0, xr1 = 0.0;
-      const unsigned mk0 = s_mask[id2 & 0xffu], mk1 = s_mask[id2 >> 8];
-      // (3) the walk: pairs in ascending offset, slots 0, 1, 2 = the base template's entries in their own order
-#pragma unroll
-      for (int j = 0; j < NP; j++) {
-        if (j < plan.npairs) {
-          if (plan.kb[j][0] >= 0) {  // entry at e - 1: row r <- x[r + e - 1] = the previous lane's second element, row r + 1 <- x[r + e]
-            const double   A = pair_prev_lane(eL[j], P[j].y), B = P[j].x;
-            const unsigned bit = 1u << plan.kb[j][0];
-            const double   a = plan.a[j][0];
-            if (mk0 & bit) sum0 += a * A;
-            if (mk1 & bit) sum1 += a * B;
-          }
-          if (plan.kb[j][1] >= 0) {  // entry at e
-            const unsigned bit = 1u << plan.kb[j][1];
-            const double   a = plan.a[j][1];
-            if (mk0 & bit) sum0 += a * P[j].x;
-            if (mk1 & bit) sum1 += a * P[j].y;
-          }
-          if (plan.kb[j][2] >= 0) {  // entry at e + 1: row r <- x[r + e + 1], row r + 1 <- x[r + e + 2] = the next lane's first element
-            const double   A = P[j].y, B = pair_next_lane(eR[j], P[j].x, lane);
-            const unsigned bit = 1u << plan.kb[j][2];
-            const double   a = plan.a[j][2];
-            if (mk0 & bit) sum0 += a * A;
-            if (mk1 & bit) sum1 += a * B;
-          }
-          if (DOT && j == plan.jdiag) {
-            xr0 = P[j].x;
-            xr1 = P[j].y;
-          }
-        }
-      }
-      *reinterpret_cast<dbl2 *>(yout + r) = dbl2{sum0, sum1};
-      if (DOT) {  // one partial per wave and CHUNK, folded in chunk order by the caller (as spmv_tmpl_kernel)
-        const double w = hipx::wave_sum(xr0 * sum0 + xr1 * sum1);
-        if (lane == 0) dotpart[(size_t)c * 4 + wv] = w;
-      }
-    } else {
-      sink += (__double_as_longlong(pf) == 0x7ff8123456789abcLL) ? 1u : 0u;  // (the previous pass's lines have arrived: one pass of slack)
-      if (pf_off) {
-        const int       pl = t - 256;
-        const long long prow = base + pf_off + (long long)pl * 16;          // 32 lines of the far plane of x, one round of workgroups ahead
-        const long long trow = base + pf_rows + (long long)(pl - 32) * 128;  // 4 lines of template ids, one round ahead
-        if (pl < 32 && prow < (long long)m) pf = x[prow];
-        else if (pl >= 32 && pl < 36 && trow < (long long)m) pf = (double)tid[trow];
-      }
-    }
-    __syncthreads();  // everybody has read the tickets
-    if (t == 0) s_tk = nxt;
-    __syncthreads();
-    tk  = tk1;
-    tk1 = s_tk;
-  }
-  if (sink == 0xffffffffu) yout[0] = pf;  // never true: keeps the prefetch loads alive
-}
-
-// The same chunk body, NOT persistent: one workgroup per chunk of 512 rows, block b works on chunk (b % 8) * chunks_per_xcd + b / 8 (the
-// hardware places block b on XCD b % 8 and starts blocks in index order: each XCD still walks its slab front to back, so the planes of
-// x a window of chunks touches stay in that XCD's L2).  No ticket atomics, no barriers after the mask table, no prefetch loads: in
-// the persistent kernel every one of those sat in the SAME in-order vmcnt queue as the chunk's gathers -- a wave waiting for its
-// (L2-resident) pairs also waited for the HBM misses of the prefetch and of the next chunk's template ids, and for the returning
-// ticket atomic: one loaded-HBM latency per chunk and workgroup, serialised, which is what the 0.14 ms were made of (SQ_WAIT_ANY
-// 82 %, profiles/r03_tmpl_sq_counters.txt).  Here a workgroup issues everything it needs at once and leaves; the CU's other
-// resident workgroups (6-7) cover its one miss latency.
-template <int MODE, bool DOT, int NP>
-__global__ __launch_bounds__(256) void spmv_pair_np_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask,
-                                                           int ntmpl, const hipxPairPlan plan, const double *__restrict__ x, const double *yin, double *yout, double *dotpart)
-{
-  typedef double dbl2 __attribute__((ext_vector_type(2)));
-  __shared__ unsigned int s_mask[256];
-  const int t = threadIdx.x, lane = t & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, slot = bid >> 3;
-  const hipx_int c = xcd * chunks_per_xcd + slot;
-  if (slot >= chunks_per_xcd || c >= nchunks) return;
-  const long long base = (long long)c * 512;
-  const long long r    = base + 2 * t;           // this thread's even row
-  const long long W    = base + 128 * wv;         // first row of this wave's run
-  const unsigned  id2  = reinterpret_cast<const unsigned short *>(tid)[r >> 1];  // rows r, r + 1: one 2-byte load
-  for (int k = t; k < ntmpl; k += 256) s_mask[k] = tmask[k];
-  {
+    idn = (tk1 < nloc) ? (unsigned)tid2[((long long)(c0 + tk1) * 512 + 2 * t) >> 1] : 0u;  // next chunk's ids: consumed at the top of the next pass
     // (1) every pair of the chunk in flight at once (zero outside the vector: such a pair is used by no row that exists)
     dbl2 P[NP];
 #pragma unroll
@@ -1540,7 +1411,6 @@ __global__ __launch_bounds__(256) void spmv_pair_np_kernel(hipx_int m, hipx_int 
     dbl2 s2 = dbl2{0.0, 0.0};
     if (MODE == 1) s2 = *reinterpret_cast<const dbl2 *>(yin + r);
     double         sum0 = s2.x, sum1 = s2.y, xr0 = 0.0, xr1 = 0.0;
-    __syncthreads();  // the mask table is in place (the loads above are in flight meanwhile)
     const unsigned mk0 = s_mask[id2 & 0xffu], mk1 = s_mask[id2 >> 8];
     // (3) the walk: pairs in ascending offset, slots 0, 1, 2 = the base template's entries in their own order
 #pragma unroll
@@ -1577,7 +1447,18 @@ __global__ __launch_bounds__(256) void spmv_pair_np_kernel(hipx_int m, hipx_int 
       const double w = hipx::wave_sum(xr0 * sum0 + xr1 * sum1);
       if (lane == 0) dotpart[(size_t)c * 4 + wv] = w;
     }
+    sink += (__double_as_longlong(pf) == 0x7ff8123456789abcLL) ? 1u : 0u;  // consume the previous pass's prefetch
+    if (pf_off && t < 32) {
+      const long long prow = base + pf_off + (long long)t * 16;
+      if (prow < (long long)m) pf = x[prow];
+    }
+    __syncthreads();  // everybody has read the tickets
+    if (t == 0) s_tk = nxt;
+    __syncthreads();
+    tk  = tk1;
+    tk1 = s_tk;
   }
+  if (sink == 0xffffffffu) yout[0] = pf;  // never true: keeps the prefetch loads alive
 }
 
 // rows [row0, m) of a template matrix, one row per thread and pass (the partial last chunk of spmv_pair_kernel): the row's own
@@ -2328,7 +2209,7 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
   static const bool nopair = getenv("HIPX_TMPL_NOPAIR") != nullptr;
   static const int  probe0 = getenv("HIPX_TMPL_PROBE") ? atoi(getenv("HIPX_TMPL_PROBE")) : 0;
   const bool     vec_aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(yout) | (MODE == 1 ? reinterpret_cast<uintptr_t>(yin) : (uintptr_t)0)) & 15) == 0;
-  const bool     use_pair = A->pair_ok && tbase >= 0 && !nopair && !probe0 && cfg == 1 && vec_aligned && m >= 512 && A->ntmpl <= 256;
+  const bool     use_pair = A->pair_ok && A->pair_plan.npairs <= 8 && tbase >= 0 && !nopair && !probe0 && cfg == 1 && vec_aligned && m >= 512 && A->ntmpl <= 256;
   if (use_pair) nchunks = m / 512;
   hipx_int       grid = std::min<hipx_int>((hipx_int)((tmpl_blocks() + 7) / 8 * 8), ((nchunks + 7) / 8) * 8);
   if (grid < 8) grid = 8;
@@ -2336,8 +2217,8 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
   const size_t   smem = 8 * (size_t)((A->tmpl_nent + 1) & ~1) + 4 * (size_t)((A->tmpl_nent + 3) & ~3) + 4 * ((size_t)A->ntmpl + 1) + 4 * (size_t)A->ntmpl + 16;
   const int      geom = (int)grid * 16 + (use_pair ? 9 : rpt);
   if (!A->d_tq || A->tq_geom != geom) {  // ticket counters of the chunk queue (zeroed once per geometry)
-    if (!A->d_tq) HIPX_HIP(hipMalloc((void **)&A->d_tq, 8192 + 64));  // [0, 512): one counter per XCD (spmv_tmpl_kernel); [512, 8704): 8 x 8 counters, 128 bytes apart (spmv_pair_kernel)
-    HIPX_HIP(hipMemsetAsync(A->d_tq, 0, 8192 + 64, rt().compute));
+    if (!A->d_tq) HIPX_HIP(hipMalloc((void **)&A->d_tq, 8 * 64));
+    HIPX_HIP(hipMemsetAsync(A->d_tq, 0, 8 * 64, rt().compute));
     A->tq_launches = 0;
     A->tq_geom     = geom;
   }
@@ -2360,17 +2241,7 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
     else pf_off += dist * 256 * rpt;
   }
   if (use_pair) {
-    static const int nq_env = getenv("HIPX_TMPL_NQ") ? atoi(getenv("HIPX_TMPL_NQ")) : 4;
-    int nq = (nq_env == 1 || nq_env == 2 || nq_env == 4 || nq_env == 8) ? nq_env : 4;
-    while (nq > 1 && (((grid >> 3) % nq) != 0 || cpx < 4 * nq)) nq >>= 1;  // every sub-queue needs the same number of workgroups (and a few chunks)
-    static const bool persist = getenv("HIPX_TMPL_PERSIST") != nullptr;
-    if (!persist) {
-      const unsigned g = (unsigned)(8 * cpx);
-      if (A->pair_plan.npairs <= 8) spmv_pair_np_kernel<MODE, DOT, 8><<<g, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart);
-      else spmv_pair_np_kernel<MODE, DOT, 16><<<g, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart);
-    } else
-    if (A->pair_plan.npairs <= 8) spmv_pair_kernel<MODE, DOT, 8><<<(unsigned)grid, 320, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, nq, pf_off ? pf_off - A->tmpl_maxoff : 0);
-    else spmv_pair_kernel<MODE, DOT, 16><<<(unsigned)grid, 320, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, nq, pf_off ? pf_off - A->tmpl_maxoff : 0);
+    spmv_pair_kernel<MODE, DOT, 8><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off);
     HIPX_LAUNCH_CHECK();
     if (nchunks * 512 < m) {
       spmv_tmpl_tail_kernel<MODE, DOT><<<1, 256, 0, rt().compute>>>(m, nchunks * 512, nchunks, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, x, yin, yout, dotpart);
@@ -2961,7 +2832,7 @@ int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
     if (ierr) return ierr;
   }
   if (sl) name = "spmv_sell_kernel (MatMult on the SELL-64 copy: one lane per row, 16-bit window-coded columns)";
-  else if (tm && A->pair_ok && A->d_tmask && !getenv("HIPX_TMPL_NOSUB") && !getenv("HIPX_TMPL_NOPAIR") && !getenv("HIPX_TMPL_PROBE") && tmpl_cfg() == 1 && A->nrows_c >= 512)
+  else if (tm && A->pair_ok && A->pair_plan.npairs <= 8 && A->d_tmask && !getenv("HIPX_TMPL_NOSUB") && !getenv("HIPX_TMPL_NOPAIR") && !getenv("HIPX_TMPL_PROBE") && tmpl_cfg() == 1 && A->nrows_c >= 512)
     name = "spmv_pair_kernel (CSR MatMult, row templates: 1 byte per row; two consecutive rows per thread, 16-byte loads of x at the even offsets, +-1 entries from the neighbouring lanes)";
   else if (tm && A->d_tmask && !getenv("HIPX_TMPL_NOSUB")) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row; every template a subset of the interior one: uniform masked walk)";
   else if (tm) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row)";

@@ -490,7 +490,7 @@ def test_pair_form_of_the_template_kernel_bit_exact(hx, kind, n, m):
     A = _lib.mat_create_csr(N, N, ai, aj, aa)
     _lib.chk(hx.hipxMatSetSpMVVariant(A, 26))  # row templates whatever the size (auto keeps small matrices on the plain kernels)
     name = kernel_name(hx, A)
-    assert name.startswith("spmv_pair_kernel " if N >= 512 else "spmv_tmpl_kernel "), name
+    assert name.startswith("spmv_pair_kernel " if (N >= 512 and kind != "27pt") else "spmv_tmpl_kernel "), name  # (pair form: base templates with <= 8 even-offset pairs)
     yr = orc.matmult(ai, aj, aa, x)
     zr = np.zeros(N)
     orc.lib().orc_MatMultAdd_SeqAIJ(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(y0), orc.P(zr))
