@@ -917,6 +917,15 @@ def main():
             rr = ref_driver(1, a, plugin=True)
             plug[ksp] = {"what": label, "iterations_per_s": (rr["its"] / rr["seconds"]) if rr else None, "iterations": rr["its"] if rr else None,
                          "KSPSolve_seconds": rr["seconds"] if rr else None}
+        # Chebyshev as a smoother (first kind, no norms, bounds given: 7-pt Poisson + Jacobi has its spectrum in (0, 2)): the
+        # reference's KSPSolve_Chebyshev over the hipx types (4 kernels per iteration) and -ksp_type chebyshevhipx (SpMV + one fused kernel)
+        for label, ksp in (("reference KSPSolve_Chebyshev over hipx types (smoother configuration: -ksp_norm_type none)", "chebyshev"),
+                           ("-ksp_type chebyshevhipx (SpMV + one fused kernel per iteration, bit-identical solution)", "chebyshevhipx")):
+            a = ["-stencil", str(head.stencil), "-n", str(head.dims[0]), "-ksp_type", ksp, "-pc_type", "jacobi", "-ksp_norm_type", "none", "-ksp_max_it", "400",
+                 "-ksp_chebyshev_eigenvalues", "0.1,2.0"]
+            rr = ref_driver(1, a, plugin=True)
+            plug[ksp] = {"what": label, "iterations_per_s": (rr["its"] / rr["seconds"]) if rr else None, "iterations": rr["its"] if rr else None,
+                         "KSPSolve_seconds": rr["seconds"] if rr else None, "error_norm": rr["error"] if rr else None}
         out["plugin"] = plug
     else:
         out["plugin"] = None

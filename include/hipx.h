@@ -102,6 +102,11 @@ int hipxVecMAXPY(double *y, hipx_int nv, const double *alpha, const double *cons
 /* replaces VecMAXPBY rvector.c:1394: y = beta y + sum_j alpha[j] x[j] */
 int hipxVecMAXPBY(double *y, hipx_int nv, const double *alpha, double beta, const double *const *x, hipx_int n);
 
+/* the vector work of one Chebyshev iteration (KSPSolve_Chebyshev_FirstKind cheby.c:475-511 with PCJACOBI or PCNONE, no norm) in one pass:
+   r = b - Ap (VecAYPX, -1), z = r * dinv (PCApply_Jacobi; dinv == NULL: z = r), pnext = alpha pprev + beta pcur + gamma z (VecAXPBYPCZ_Seq
+   bvec1.c:120-147, same association orders); r_out != NULL also stores r.  Element by element the operations of the three reference loops. */
+int hipxVecChebyshevStep(double *pnext, double alpha, double beta, double gamma, const double *pprev, const double *pcur, const double *dinv, const double *b, const double *Ap, double *r_out,
+                         hipx_int n);
 /* indexed gather / scatter on the compute stream: dst[didx ? didx[k] : k] (= | +=) src[sidx ? sidx[k] : k], k < n; the index lists
    are DEVICE arrays.  mode 0 insert, 1 add (didx must then hold no duplicates).  Replaces the Pack / UnpackAndInsert / UnpackAndAdd
    loops of PetscSF (src/vec/is/sf/impls/basic/sfpack.c:706-790) for unit = one scalar. */

@@ -88,6 +88,9 @@ int HipxVecNorm2(HipxMat *A, const double *x, hipx_int n, double *r);           
 
 int HipxKSPSolve_CG(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, double *x);
 int HipxKSPSolve_GMRES(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, double *x);
+/* replaces KSPSolve_Chebyshev_FirstKind cheby.c:389-555 with given eigenvalue bounds (cheby.c:40-62); ksp->normtype NONE + PCJACOBI / PCNONE
+   + ksp->fused: SpMV + one fused elementwise kernel per iteration, no reductions */
+int HipxKSPSolve_Chebyshev(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, double *x, double emin, double emax);
 
 /* split form of KSPSolve_CG for benchmarking exactly K iterations: Begin = cg.c:134-217 (set-up, first
    residual/preconditioned norm), Step(nsteps) = nsteps passes of the loop body cg.c:220-349 */

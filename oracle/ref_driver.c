@@ -514,6 +514,16 @@ assembled:
     PetscCall(KSPGetResidualHistory(ksp, NULL, &nhist));
     for (PetscInt i = 0; i < nhist; i++) PetscCall(PetscPrintf(PETSC_COMM_WORLD, "hist %" PetscInt_FMT " %.17g\n", i, (double)hist[i]));
   }
+  {
+    PetscBool dump_x = PETSC_FALSE; /* -dump_x: the solution, every entry with 17 digits (solvers without reductions must reproduce it bit for bit) */
+    PetscCall(PetscOptionsGetBool(NULL, NULL, "-dump_x", &dump_x, NULL));
+    if (dump_x) {
+      const PetscScalar *xa;
+      PetscCall(VecGetArrayRead(x, &xa));
+      for (PetscInt i = 0; i < Iend - Istart; i++) PetscCall(PetscPrintf(PETSC_COMM_SELF, "x %" PetscInt_FMT " %.17g\n", i + Istart, (double)xa[i]));
+      PetscCall(VecRestoreArrayRead(x, &xa));
+    }
+  }
   PetscCall(VecAXPY(x, -1.0, u));
   PetscCall(VecNorm(x, NORM_2, &norm));
   PetscCall(PetscPrintf(PETSC_COMM_WORLD, "iterations %" PetscInt_FMT " reason %d error %.17g KSPSolve_seconds %.6e\n", its, (int)reason, (double)norm, (double)(t1 - t0)));

@@ -888,6 +888,32 @@ int hipx::launch_cg_fused_nosignal(double *x, double *r, double *z, const double
   return ierr;
 }
 
+// One Chebyshev iteration's vector work in one pass (cheby.c:475-511 with PCJACOBI / PCNONE and no norm requested):
+//   r = b - A p_k            VecAYPX(r, -1, b), dvec2.c:767           (Ap = A p_k comes from the SpMV before)
+//   z = r * dinv  |  z = r   PCApply_Jacobi = VecPointwiseMult, jacobi.c:301  |  PCNONE
+//   p_next = alpha p_prev + beta p_k + gamma z   VecAXPBYPCZ_Seq, bvec1.c:120-147: its four association orders (BR)
+// Every element sees the same operations in the same order as the three reference loops: p_next is bit-identical; 5 vector reads
+// and 1 write instead of 7 and 3, one launch instead of three.
+namespace {
+template <int BR, bool JAC, bool ROUT>
+__global__ __launch_bounds__(256) void cheby_step_kernel(double *__restrict__ pn, double a, double b, double c, const double *__restrict__ pp, const double *__restrict__ pc,
+                                                         const double *__restrict__ dinv, const double *__restrict__ rhs, const double *__restrict__ Ap, double *__restrict__ rout, hipx_int n)
+{
+  for (hipx_int i = (hipx_int)blockIdx.x * 256 + threadIdx.x; i < n; i += (hipx_int)gridDim.x * 256) {
+    const double r = rhs[i] - Ap[i];
+    const double z = JAC ? r * dinv[i] : r;
+    const double x = pp[i], y = pc[i];
+    double       o;
+    if (BR == 0) o = x + b * y + c * z;
+    else if (BR == 1) o = a * x + b * y + z;
+    else if (BR == 2) o = a * x + b * y;
+    else o = a * x + b * y + c * z;
+    pn[i] = o;
+    if (ROUT) rout[i] = r;
+  }
+}
+}  // namespace
+
 extern "C" {
 
 int hipxVecSet(double *x, hipx_int n, double alpha)
@@ -989,6 +1015,33 @@ int hipxVecAXPBYPCZ(double *z, double alpha, double beta, double gamma, const do
   if (gamma == 1.0) return launch_ew3(z, x, y, n, FAbc1{alpha, beta});
   if (gamma == 0.0) return launch_ew3(z, x, y, n, FAbc2{alpha, beta});
   return launch_ew3(z, x, y, n, FAbc3{alpha, beta, gamma});
+}
+
+int hipxVecChebyshevStep(double *pnext, double alpha, double beta, double gamma, const double *pprev, const double *pcur, const double *dinv, const double *b, const double *Ap, double *r_out,
+                         hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(n >= 0 && (n == 0 || (pnext && pprev && pcur && b && Ap)), "null argument");
+  if (n <= 0) return HIPX_SUCCESS;
+  const int      br = (alpha == 1.0) ? 0 : ((gamma == 1.0) ? 1 : ((gamma == 0.0) ? 2 : 3));
+  const unsigned g  = (unsigned)std::min<hipx_int>((n + 255) / 256, 16384);
+  hipStream_t    st = rt().compute;
+#define HIPX_CHEB(BRV) \
+  do { \
+    if (dinv && r_out) cheby_step_kernel<BRV, true, true><<<g, 256, 0, st>>>(pnext, alpha, beta, gamma, pprev, pcur, dinv, b, Ap, r_out, n); \
+    else if (dinv) cheby_step_kernel<BRV, true, false><<<g, 256, 0, st>>>(pnext, alpha, beta, gamma, pprev, pcur, dinv, b, Ap, r_out, n); \
+    else if (r_out) cheby_step_kernel<BRV, false, true><<<g, 256, 0, st>>>(pnext, alpha, beta, gamma, pprev, pcur, dinv, b, Ap, r_out, n); \
+    else cheby_step_kernel<BRV, false, false><<<g, 256, 0, st>>>(pnext, alpha, beta, gamma, pprev, pcur, dinv, b, Ap, r_out, n); \
+  } while (0)
+  switch (br) {
+  case 0: HIPX_CHEB(0); break;
+  case 1: HIPX_CHEB(1); break;
+  case 2: HIPX_CHEB(2); break;
+  default: HIPX_CHEB(3); break;
+  }
+#undef HIPX_CHEB
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
 }
 
 int hipxVecPointwiseMult(double *w, const double *x, const double *y, hipx_int n)

@@ -499,6 +499,127 @@ int HipxKSPSolve_CG(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, doubl
   return 0;
 }
 
+/* KSPSolve_Chebyshev_FirstKind (cheby.c:389-555), statement by statement, with the eigenvalue bounds given (-ksp_chebyshev_eigenvalues /
+   KSPChebyshevSetEigenvalues: cheby.c:40-62 returns them as they are).  With no norm requested (the smoother configuration:
+   KSP_NORM_NONE) and PCJACOBI or PCNONE an iteration is the SpMV plus ONE elementwise kernel (hipxVecChebyshevStep: residual, PC
+   application and the three-term update in one pass, bit-identical to the three reference loops); otherwise the reference's own
+   sequence of MatMult / VecAYPX / PCApply / VecNorm / VecAXPBYPCZ.  No reduction anywhere on the fused path: the solution is
+   bit-identical to the CPU run on any number of ranks. */
+enum { KSP_CONVERGED_ITS = 4 };
+int HipxKSPSolve_Chebyshev(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double *X, double emin, double emax)
+{
+  const hipx_int n = A->m;
+  double        *p[3], *r = NULL, rnorm = 0.0;
+  int            km1 = 0, k = 1, kp1 = 2, ierr = 0;
+  const size_t   bytes = sizeof(double) * (size_t)(n ? n : 1);
+  const int      fast = (ksp->normtype == HIPX_KSP_NORM_NONE) && (pc->type == HIPX_PC_NONE || pc->type == HIPX_PC_JACOBI) && ksp->fused;
+#define CCHK(call) \
+  do { \
+    ierr = (call); \
+    if (ierr) goto cleanup; \
+  } while (0)
+  p[0] = X;
+  p[1] = p[2] = NULL;
+  CCHK(hipxMalloc((void **)&p[1], bytes));
+  CCHK(hipxMalloc((void **)&p[2], bytes));
+  CCHK(hipxMalloc((void **)&r, bytes));
+  ksp->its    = 0;
+  ksp->reason = 0;
+  ksp->hist_n = 0;
+  {
+    const double scale = 2.0 / (emax + emin), alpha = 1.0 - scale * emin, Gamma = 1.0, mu = 1.0 / alpha, omegaprod = 2.0 / alpha; /* cheby.c:420-426 */
+    double       c[3], omega;
+    hipx_int     i;
+    c[km1] = 1.0;
+    c[k]   = mu;
+    if (ksp->guess_nonzero) { /* cheby.c:431-436 */
+      CCHK(HipxMatMult(A, X, r));
+      CCHK(hipxVecAYPX(r, -1.0, B, n));
+    } else {
+      CCHK(hipxVecSet(X, n, 0.0)); /* KSPSolve zeroes the solution for a zero initial guess (itfunc.c) */
+      CCHK(hipxVecCopy(B, r, n));
+    }
+    if (ksp->normtype) { /* cheby.c:439-459 */
+      if (ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED) {
+        CCHK(HipxPCApply(pc, A, r, p[k]));
+        CCHK(HipxVecNorm2(A, p[k], n, &rnorm));
+      } else CCHK(HipxVecNorm2(A, r, n, &rnorm));
+      ksp->rnorm = rnorm;
+      log_history(ksp, rnorm);
+      CCHK(converged_default(ksp, A, pc, 0, rnorm, B, &ksp->reason));
+    } else ksp->reason = KSP_CONVERGED_ITERATING;
+    if (ksp->reason || ksp->max_it == 0) {
+      if (ksp->max_it == 0) ksp->reason = KSP_DIVERGED_ITS;
+      goto cleanup;
+    }
+    if (ksp->normtype != HIPX_KSP_NORM_PRECONDITIONED) CCHK(HipxPCApply(pc, A, r, p[k])); /* cheby.c:464 */
+    CCHK(hipxVecAYPX(p[k], scale, p[km1], n));                                             /* p[k] = scale B^{-1} r + p[km1] */
+    ksp->its = 1;
+    for (i = 1; i < ksp->max_it; i++) { /* cheby.c:470-517 */
+      int ktmp;
+      ksp->its++;
+      CCHK(HipxMatMult(A, p[k], r));
+      if (fast) {
+        c[kp1] = 2.0 * mu * c[k] - c[km1];
+        omega  = omegaprod * c[k] / c[kp1];
+        CCHK(hipxVecChebyshevStep(p[kp1], 1.0 - omega, omega, omega * Gamma * scale, p[km1], p[k], pc->type == HIPX_PC_JACOBI ? pc->dinv : NULL, B, r, NULL, n));
+      } else {
+        CCHK(hipxVecAYPX(r, -1.0, B, n));
+        if (ksp->normtype) {
+          if (ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED) {
+            CCHK(HipxPCApply(pc, A, r, p[kp1]));
+            CCHK(HipxVecNorm2(A, p[kp1], n, &rnorm));
+          } else CCHK(HipxVecNorm2(A, r, n, &rnorm));
+          if (isnan(rnorm) || isinf(rnorm)) { /* KSPCheckNorm */
+            ksp->reason = KSP_DIVERGED_NANORINF;
+            break;
+          }
+          ksp->rnorm = rnorm;
+          log_history(ksp, rnorm);
+          CCHK(converged_default(ksp, A, pc, i, rnorm, B, &ksp->reason));
+          if (ksp->reason) break;
+          if (ksp->normtype != HIPX_KSP_NORM_PRECONDITIONED) CCHK(HipxPCApply(pc, A, r, p[kp1]));
+        } else CCHK(HipxPCApply(pc, A, r, p[kp1]));
+        c[kp1] = 2.0 * mu * c[k] - c[km1];
+        omega  = omegaprod * c[k] / c[kp1];
+        CCHK(hipxVecAXPBYPCZ(p[kp1], 1.0 - omega, omega, omega * Gamma * scale, p[km1], p[k], n));
+      }
+      ktmp = km1;
+      km1  = k;
+      k    = kp1;
+      kp1  = ktmp;
+    }
+    if (!ksp->reason) { /* cheby.c:518-548 */
+      if (ksp->normtype) {
+        CCHK(HipxMatMult(A, p[k], r));
+        CCHK(hipxVecAYPX(r, -1.0, B, n));
+        if (ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED) {
+          CCHK(HipxPCApply(pc, A, r, p[kp1]));
+          CCHK(HipxVecNorm2(A, p[kp1], n, &rnorm));
+        } else CCHK(HipxVecNorm2(A, r, n, &rnorm));
+        if (isnan(rnorm) || isinf(rnorm)) ksp->reason = KSP_DIVERGED_NANORINF;
+        else {
+          ksp->rnorm = rnorm;
+          log_history(ksp, rnorm);
+        }
+      }
+      if (!ksp->reason && ksp->its >= ksp->max_it) {
+        if (ksp->normtype != HIPX_KSP_NORM_NONE) {
+          CCHK(converged_default(ksp, A, pc, i, rnorm, B, &ksp->reason));
+          if (!ksp->reason) ksp->reason = KSP_DIVERGED_ITS;
+        } else ksp->reason = KSP_CONVERGED_ITS;
+      }
+    }
+    if (k) CCHK(hipxVecCopy(p[k], X, n)); /* cheby.c:551-552: the solution ends in the user's vector */
+  }
+cleanup:
+  if (p[1]) (void)hipxFree(p[1]);
+  if (p[2]) (void)hipxFree(p[2]);
+  if (r) (void)hipxFree(r);
+#undef CCHK
+  return ierr;
+}
+
 /* gmres.c:88-238 (cycle + solve), :298-345 (BuildSoln), :349-395 (UpdateHessenberg), borthog2.c:35-113,
    left preconditioning, KSPInitialResidual itres.c:35-75.  VV(0..max_k) live in one contiguous slab
    (cf. VecDuplicateVecs_Seq_GEMV bvec2.c:670) so MDot/MAXPY stream through consecutive memory. */

@@ -64,6 +64,7 @@ PETSC_INTERN PetscErrorCode MatCreate_MPIAIJHIPX(Mat);
 PETSC_INTERN PetscErrorCode PCCreate_JacobiHIPX(PC);
 PETSC_INTERN PetscErrorCode PCCreate_PBJacobiHIPX(PC); /* "pbjacobihipx": PCPBJACOBI with the apply on the device */
 PETSC_INTERN PetscErrorCode KSPCreate_CGHIPX(KSP); /* "cghipx": KSPCG with the fused device kernels on the hot-path configuration */
+PETSC_INTERN PetscErrorCode KSPCreate_ChebyshevHIPX(KSP); /* "chebyshevhipx": KSPCHEBYSHEV, first kind without norms on one fused kernel per iteration */
 PETSC_INTERN PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA); /* uploads / refreshes the device CSR */
 PETSC_INTERN PetscBool      MatIsSeqAIJHIPX(Mat A);
 PETSC_INTERN PetscErrorCode MatSeqAIJHIPXSetValuesCOO_Private(Mat A, hipxCOO coo, const PetscScalar v[], PetscCount n, InsertMode imode);

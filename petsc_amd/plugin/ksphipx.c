@@ -133,6 +133,118 @@ static PetscErrorCode KSPSolve_CGHIPX(KSP ksp)
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+/* ---- KSPCHEBYSHEVHIPX ("chebyshevhipx"): KSPCHEBYSHEV whose first-kind solve with no norm requested (the smoother configuration) runs
+   one SpMV + one fused elementwise kernel per iteration (HipxKSPSolve_Chebyshev: residual, Jacobi application and the three-term
+   update of cheby.c:475-511 in one pass, no reductions): bit-identical solution.  Eigenvalue estimation (the kspest machinery of
+   KSPSetUp_Chebyshev), the fourth-kind polynomials, norms / monitors and every other configuration stay the parent's. */
+#include <../src/ksp/ksp/impls/cheby/chebyshevimpl.h>
+
+static PetscErrorCode (*parent_setup_cheby)(KSP) = NULL; /* KSPSetUp_Chebyshev: it (re)installs the solve op of the polynomial kind at every set-up */
+
+static PetscBool KSPChebyshevHIPXApplicable(KSP ksp, Mat *Aout, PetscBool *jac, PetscReal *emin, PetscReal *emax)
+{
+  KSP_Chebyshev *cheb = (KSP_Chebyshev *)ksp->data;
+  Mat            Amat, Pmat;
+  PetscBool      isjac = PETSC_FALSE, isnone = PETSC_FALSE, useabs = PETSC_FALSE, fixdiag = PETSC_TRUE;
+  PCJacobiType   jt;
+  PetscMPIInt    size;
+
+  if (cheb->chebykind != KSP_CHEBYSHEV_FIRST || ksp->normtype != KSP_NORM_NONE || ksp->numbermonitors || ksp->transpose_solve || ksp->dscale) return PETSC_FALSE;
+  if (MPI_Comm_size(PetscObjectComm((PetscObject)ksp), &size) || size != 1) return PETSC_FALSE;
+  if (PCGetOperators(ksp->pc, &Amat, &Pmat) || Amat != Pmat || Amat->rmap->n != Amat->cmap->n || !MatIsSeqAIJHIPX(Amat)) return PETSC_FALSE;
+  if (PetscObjectTypeCompare((PetscObject)ksp->pc, PCJACOBI, &isjac) || PetscObjectTypeCompare((PetscObject)ksp->pc, PCNONE, &isnone) || (!isjac && !isnone)) return PETSC_FALSE;
+  if (isjac) {
+    if (PCJacobiGetType(ksp->pc, &jt) || jt != PC_JACOBI_DIAGONAL) return PETSC_FALSE;
+    if (PCJacobiGetUseAbs(ksp->pc, &useabs) || useabs) return PETSC_FALSE;
+    if (PCJacobiGetFixDiagonal(ksp->pc, &fixdiag) || !fixdiag) return PETSC_FALSE;
+  }
+  if (!VecIsHIPX(ksp->vec_rhs) || !VecIsHIPX(ksp->vec_sol)) return PETSC_FALSE;
+  {
+    MatNullSpace nsp = NULL;
+    if (MatGetNullSpace(Amat, &nsp) || nsp) return PETSC_FALSE;
+  }
+  /* the bounds exactly as KSPChebyshevGetEigenvalues_Chebyshev (cheby.c:40-62) returns them */
+  *emax = *emin = 0;
+  if (cheb->emax != 0.) *emax = cheb->emax;
+  else if (cheb->emax_computed != 0.) *emax = cheb->tform[2] * cheb->emin_computed + cheb->tform[3] * cheb->emax_computed;
+  else if (cheb->emax_provided != 0.) *emax = cheb->tform[2] * cheb->emin_provided + cheb->tform[3] * cheb->emax_provided;
+  if (cheb->emin != 0.) *emin = cheb->emin;
+  else if (cheb->emin_computed != 0.) *emin = cheb->tform[0] * cheb->emin_computed + cheb->tform[1] * cheb->emax_computed;
+  else if (cheb->emin_provided != 0.) *emin = cheb->tform[0] * cheb->emin_provided + cheb->tform[1] * cheb->emax_provided;
+  if (*emax == 0. || *emax + *emin == 0.) return PETSC_FALSE;
+  *Aout = Amat;
+  *jac  = isjac;
+  return PETSC_TRUE;
+}
+
+static PetscErrorCode KSPSolve_ChebyshevHIPX(KSP ksp)
+{
+  Mat                Amat = NULL;
+  PetscBool          jac  = PETSC_FALSE;
+  PetscReal          emin = 0, emax = 0;
+  hipxMat            dA;
+  HipxMat            M;
+  HipxPC             hpc;
+  HipxKSP            k;
+  const PetscScalar *db;
+  PetscScalar       *dx;
+  void              *tb, *tx;
+
+  PetscFunctionBegin;
+  if (!KSPChebyshevHIPXApplicable(ksp, &Amat, &jac, &emin, &emax)) {
+    PetscErrorCode (*psolve)(KSP) = NULL;
+    PetscCall(PetscInfo(ksp, "KSPCHEBYSHEVHIPX: configuration outside the fused path, running the reference KSPSolve_Chebyshev\n"));
+    PetscCall(PetscObjectQueryFunction((PetscObject)ksp, "KSPChebyshevHIPXParentSolve_C", &psolve));
+    PetscCheck(psolve, PetscObjectComm((PetscObject)ksp), PETSC_ERR_ORDER, "KSPSetUp() has not run");
+    PetscCall((*psolve)(ksp));
+    PetscFunctionReturn(PETSC_SUCCESS);
+  }
+  PetscCall(MatSeqAIJHIPXGetDeviceMat(Amat, &dA));
+  M.m = (hipx_int)Amat->rmap->n; M.A = dA; M.B = NULL; M.halo = NULL; M.lvec = NULL; M.nranks = 1;
+  HipxPCSetDefaults(&hpc);
+  hpc.type = jac ? HIPX_PC_JACOBI : HIPX_PC_NONE;
+  PetscCallHIPX(HipxPCSetUp(&hpc, &M));
+  HipxKSPSetDefaults(&k);
+  k.normtype      = HIPX_KSP_NORM_NONE;
+  k.max_it        = (hipx_int)ksp->max_it;
+  k.guess_nonzero = ksp->guess_zero ? 0 : 1;
+  k.fused         = 1;
+  PetscCall(VecHIPXGetDeviceRead(ksp->vec_rhs, &db, &tb));
+  PetscCall(VecHIPXGetDeviceReadWrite(ksp->vec_sol, &dx, &tx));
+  PetscCallHIPX(HipxKSPSolve_Chebyshev(&k, &M, &hpc, db, dx, (double)emin, (double)emax));
+  ksp->its    = (PetscInt)k.its;
+  ksp->reason = (KSPConvergedReason)k.reason;
+  PetscCallHIPX(HipxPCDestroy(&hpc));
+  PetscCall(VecHIPXRestoreDeviceWrite(ksp->vec_sol, &dx, &tx));
+  PetscCall(VecHIPXRestoreDeviceRead(ksp->vec_rhs, &db, &tb));
+  PetscCall(PetscObjectStateIncrease((PetscObject)ksp->vec_sol));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* the parent's set-up picks the solve routine of the polynomial kind (cheby.c:757-766): keep that one as the fall-back of THIS object, put ours in front */
+static PetscErrorCode KSPSetUp_ChebyshevHIPX(KSP ksp)
+{
+  PetscFunctionBegin;
+  PetscCall((*parent_setup_cheby)(ksp));
+  if (ksp->ops->solve != KSPSolve_ChebyshevHIPX) {
+    PetscCall(PetscObjectComposeFunction((PetscObject)ksp, "KSPChebyshevHIPXParentSolve_C", ksp->ops->solve));
+    ksp->ops->solve = KSPSolve_ChebyshevHIPX;
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PETSC_EXTERN PetscErrorCode KSPCreate_Chebyshev(KSP); /* cheby.c:908: exported by libpetsc */
+
+PetscErrorCode KSPCreate_ChebyshevHIPX(KSP ksp)
+{
+  PetscFunctionBegin;
+  PetscCall(VecHIPXInitRuntime());
+  PetscCall(KSPCreate_Chebyshev(ksp));
+  if (!parent_setup_cheby) parent_setup_cheby = ksp->ops->setup;
+  ksp->ops->setup = KSPSetUp_ChebyshevHIPX;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 PETSC_EXTERN PetscErrorCode KSPCreate_CG(KSP); /* cg.c:686: exported by libpetsc, declared in no header */
 
 PetscErrorCode KSPCreate_CGHIPX(KSP ksp)

@@ -226,11 +226,41 @@ def test_matload_of_a_file_into_the_hipx_types(tmp_path):
     f = str(tmp_path / "spd.bin")
     matio.write_petsc_binary(f, ai, aj, aa)
     a = ["-f", f, "-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_rtol", "1e-50", "-ksp_max_it", "12", "-ksp_norm_type", "preconditioned", "-history", "-dump_y"]
-    cpu = run("ref_driver", a, exact_blas=True)
+    # The reference takes its INODE MatMult on this matrix (3 x 3 blocks: consecutive rows share their column pattern; inode.c sums a row
+    # two columns at a time: sum += a0 x0 + a1 x1), which rounds differently from MatMult_SeqAIJ's one-by-one sum that libhipx reproduces:
+    # bit-identical y against -mat_no_inode, a few ulps (and histories within 1e-12) against the default.
+    cpu = run("ref_driver", a + ["-mat_no_inode"], exact_blas=True)
+    cpu_inode = run("ref_driver", a, exact_blas=True)
     gpu = run("ref_driver", a + HIPX)
-    y_cpu = [l.split()[2] for l in cpu.splitlines() if l.startswith("y ")]
-    y_gpu = [l.split()[2] for l in gpu.splitlines() if l.startswith("y ")]
+    ys = lambda t: [l.split()[2] for l in t.splitlines() if l.startswith("y ")]  # noqa: E731
+    y_cpu, y_in, y_gpu = ys(cpu), ys(cpu_inode), ys(gpu)
     assert len(y_cpu) == len(ai) - 1 and y_gpu == y_cpu
-    hc, hg = hist_of(cpu), hist_of(gpu)
-    assert len(hc) == 13 and len(hg) == 13
-    assert max(abs(g - c) / abs(c) for g, c in zip(hg, hc)) <= 1e-12
+    yi, yg = np.array([float(v) for v in y_in]), np.array([float(v) for v in y_gpu])
+    assert np.abs(yi - yg).max() <= 1e-14 * np.abs(yi).max()
+    for ref in (cpu, cpu_inode):
+        hc, hg = hist_of(ref), hist_of(gpu)
+        assert len(hc) == 13 and len(hg) == 13
+        assert max(abs(g - c) / abs(c) for g, c in zip(hg, hc)) <= 1e-12
+
+
+@pytest.mark.parametrize("args", ["-stencil 7 -n 12 -pc_type jacobi -ksp_max_it 8", "-stencil 27 -n 10 -pc_type jacobi -ksp_max_it 5", "-stencil 5 -m 31 -n 17 -pc_type none -ksp_max_it 12",
+                                  "-stencil 7 -n 12 -pc_type jacobi -ksp_max_it 1", "-stencil 7 -n 12 -pc_type jacobi -ksp_max_it 7 -ksp_initial_guess_nonzero"])
+def test_ksp_chebyshevhipx_fused_smoother_bit_identical(args):
+    """KSPCHEBYSHEV as a smoother (first kind, -ksp_norm_type none, given eigenvalue bounds): `-ksp_type chebyshevhipx` runs every iteration
+    as the SpMV plus ONE fused kernel (residual + PCJACOBI / PCNONE + three-term update of cheby.c:475-511) -- no reductions anywhere, so
+    the solution is bit-identical to the reference's KSPSolve_Chebyshev on the CPU types, entry by entry; the reference's own chebyshev
+    over the hipx types gives the same bits through four kernels per iteration.  With a norm requested the type falls back to the parent."""
+    a = args.split() + ["-ksp_chebyshev_eigenvalues", "0.15,1.95", "-ksp_norm_type", "none", "-dump_x"]
+    xs = lambda t: [l.split()[2] for l in t.splitlines() if l.startswith("x ")]  # noqa: E731
+    cpu = run("ref_driver", a + ["-ksp_type", "chebyshev"])
+    gpu_ref = run("ref_driver", a + ["-ksp_type", "chebyshev"] + HIPX)
+    gpu = run("ref_driver", a + ["-ksp_type", "chebyshevhipx", "-info"] + HIPX)
+    assert len(xs(cpu)) > 100 and xs(gpu_ref) == xs(cpu) and xs(gpu) == xs(cpu)
+    assert "outside the fused path" not in gpu
+    assert re.search(r"iterations (\d+) reason (-?\d+)", gpu).groups() == re.search(r"iterations (\d+) reason (-?\d+)", cpu).groups()
+    # a norm type: the parent's solve (monitors, history) over the hipx types
+    b = [x for x in a if x not in ("-ksp_norm_type", "none")] + ["-ksp_norm_type", "preconditioned", "-history"]
+    cpu_n, gpu_n = run("ref_driver", b + ["-ksp_type", "chebyshev"]), run("ref_driver", b + ["-ksp_type", "chebyshevhipx", "-info"] + HIPX)
+    assert "outside the fused path" in gpu_n
+    hc, hg = hist_of(cpu_n), hist_of(gpu_n)
+    assert len(hc) == len(hg) and len(hc) > 1 and (np.abs(hc - hg) / hc).max() <= 1e-12
