@@ -1349,10 +1349,10 @@ __device__ __forceinline__ double pair_next_lane(double last, double v, int lane
 // A/B against spmv_tmpl_kernel with the sub-template walk): -11 %, 0 %, -15 % on three boxes (DESIGN 3.1 lists what else was tried on
 // this kernel in round 3 and did not move it: the 27-point class with 16 pairs (register pressure: slower), several ticket counters per
 // XCD, a non-persistent one-chunk-per-workgroup launch, a fifth wave that does the prefetching).
-template <int MODE, bool DOT, int NP>
+template <int MODE, bool DOT, int NP, bool TRACE = false>
 __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask,
                                                         int ntmpl, const hipxPairPlan plan, const double *__restrict__ x, const double *yin, double *yout, double *dotpart,
-                                                        unsigned long long *tq, unsigned long long launch, long long pf_off)
+                                                        unsigned long long *tq, unsigned long long launch, long long pf_off, unsigned long long *trace = nullptr)
 {
   typedef double dbl2 __attribute__((ext_vector_type(2)));
   __shared__ unsigned int s_mask[256];
@@ -1376,7 +1376,10 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
   unsigned  sink = 0;
   const unsigned short *tid2 = reinterpret_cast<const unsigned short *>(tid);  // rows r, r + 1: one 2-byte load (r even)
   unsigned idn = (tk < nloc) ? (unsigned)tid2[((long long)(c0 + tk) * 512 + 2 * t) >> 1] : 0u;
+  unsigned ntr = 0;  // TRACE (HIPX_TMPL_TRACE: developer timing of one workgroup's passes; 100 MHz wall clock)
   while (tk < nloc) {
+    unsigned long long ts[6];
+    if (TRACE) ts[0] = wall_clock64();
     long long nxt = 0;
     if (t == 0) nxt = (long long)atomicAdd(ctr, 1ull) - tbase;  // the ticket after next travels while this chunk is processed
     const hipx_int  c    = c0 + (hipx_int)tk;
@@ -1408,6 +1411,7 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
         if (plan.kb[j][2] >= 0 && qr >= 0 && qr < (long long)m) eR[j] = x[qr];
       }
     }
+    if (TRACE) ts[1] = wall_clock64();  // everything issued
     dbl2 s2 = dbl2{0.0, 0.0};
     if (MODE == 1) s2 = *reinterpret_cast<const dbl2 *>(yin + r);
     double         sum0 = s2.x, sum1 = s2.y, xr0 = 0.0, xr1 = 0.0;
@@ -1442,6 +1446,10 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
         }
       }
     }
+    if (TRACE) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      ts[2] = wall_clock64() + (__double_as_longlong(sum0 + sum1) == 0x7ff8123456789abcLL ? 1 : 0);  // the sums exist: every load has returned
+    }
     *reinterpret_cast<dbl2 *>(yout + r) = dbl2{sum0, sum1};
     if (DOT) {  // one partial per wave and CHUNK, folded in chunk order by the caller (as spmv_tmpl_kernel)
       const double w = hipx::wave_sum(xr0 * sum0 + xr1 * sum1);
@@ -1452,9 +1460,20 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
       const long long prow = base + pf_off + (long long)t * 16;
       if (prow < (long long)m) pf = x[prow];
     }
+    if (TRACE) ts[3] = wall_clock64();  // store, dot partial and prefetch issued
     __syncthreads();  // everybody has read the tickets
+    if (TRACE) ts[4] = wall_clock64();
     if (t == 0) s_tk = nxt;
     __syncthreads();
+    if (TRACE) {
+      ts[5] = wall_clock64();
+      if (trace && (bid == 8 || bid == 1032) && t == 0 && ntr < 64) {
+        unsigned long long *o = trace + ((bid == 8 ? 0 : 64) + ntr) * 8;
+        for (int q = 0; q < 6; q++) o[q] = ts[q];
+        o[6] = (unsigned long long)c;
+        ntr++;
+      }
+    }
     tk  = tk1;
     tk1 = s_tk;
   }
@@ -2241,6 +2260,27 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
     else pf_off += dist * 256 * rpt;
   }
   if (use_pair) {
+    static const bool tracing = getenv("HIPX_TMPL_TRACE") != nullptr;
+    if (tracing) {  // developer timing: passes of workgroups 8 and 1032 (start, issued, loads back, stored, barrier 1, barrier 2; 10 ns ticks) on stderr
+      static unsigned long long *d_tr = nullptr;
+      if (!d_tr) HIPX_HIP(hipMalloc((void **)&d_tr, 128 * 8 * sizeof(unsigned long long)));
+      HIPX_HIP(hipMemsetAsync(d_tr, 0, 128 * 8 * sizeof(unsigned long long), rt().compute));
+      spmv_pair_kernel<MODE, DOT, 8, true><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, d_tr);
+      HIPX_LAUNCH_CHECK();
+      static int dumps = 0;
+      if (dumps < 2 && launch >= 5) {
+        unsigned long long h[128 * 8];
+        HIPX_HIP(hipStreamSynchronize(rt().compute));
+        HIPX_HIP(hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost));
+        for (int w = 0; w < 2; w++)
+          for (int e = 0; e < 64 && h[(w * 64 + e) * 8]; e++) {
+            const unsigned long long *o = h + (w * 64 + e) * 8;
+            fprintf(stderr, "[hipx tmpl trace] wg %d pass %2d chunk %6llu start %8.2f us | issue %5.2f loads %5.2f store %5.2f barrier1 %5.2f barrier2 %5.2f | pass %5.2f us\n", w ? 1032 : 8, e, o[6],
+                    (o[0] - h[0]) / 100.0, (o[1] - o[0]) / 100.0, (o[2] - o[1]) / 100.0, (o[3] - o[2]) / 100.0, (o[4] - o[3]) / 100.0, (o[5] - o[4]) / 100.0, (o[5] - o[0]) / 100.0);
+          }
+        dumps++;
+      }
+    } else
     spmv_pair_kernel<MODE, DOT, 8><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off);
     HIPX_LAUNCH_CHECK();
     if (nchunks * 512 < m) {
