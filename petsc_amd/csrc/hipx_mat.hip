@@ -36,6 +36,7 @@ using namespace hipx;
 // masks) or -1; pairs ascend in e, so slots 0, 1, 2 of pair 0, 1, ... is the entries' own (ascending-column) order.
 struct hipxPairPlan {
   int    npairs, jdiag;
+  int    jodd, eodd;  // the ONE pair that has entries at e - 1 / e + 1 (-1: none) and its offset: the pair kernel loads one edge pair per wave
   int    e[16];
   int    kb[16][3];
   double a[16][3];
@@ -1399,17 +1400,15 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
         else if (qp >= 0 && qp < (long long)m) P[j].x = x[qp];  // (an odd row count: the vector's last element is the first half of a pair)
       }
     }
-    // (2) the elements just outside the wave's run, for the entries at e - 1 (first lane) and e + 1 (last lane): wave-uniform
-    // addresses -> scalar loads, off the vector memory path
-    double eL[NP], eR[NP];
-#pragma unroll
-    for (int j = 0; j < NP; j++) {
-      eL[j] = eR[j] = 0.0;
-      if (j < plan.npairs) {
-        const long long ql = W - 1 + plan.e[j], qr = W + 128 + plan.e[j];
-        if (plan.kb[j][0] >= 0 && ql >= 0 && ql < (long long)m) eL[j] = x[ql];
-        if (plan.kb[j][2] >= 0 && qr >= 0 && qr < (long long)m) eR[j] = x[qr];
-      }
+    // (2) the elements just outside the wave's run, for the entries at e - 1 (the first lane needs x[W - 1 + e]) and e + 1 (the last lane
+    // needs x[W + 128 + e]) of the one pair that has such entries.  Wave-uniform addresses, which the compiler would fetch through the
+    // SCALAR cache -- where data that is new in every pass always misses, and a miss cost 1.5-5 us under this kernel's load
+    // (HIPX_TMPL_TRACE: the longest phase of a pass).  So: ONE vector load, lane 0 on the left element, lane 1 on the right one; read
+    // back with v_readlane after the pairs have arrived.
+    double edge = 0.0;
+    if (plan.jodd >= 0) {
+      const long long qe = W - 1 + plan.eodd + (long long)lane * 129;  // lane 0: W - 1 + e, lane 1: W + 128 + e
+      if (lane < 2 && qe >= 0 && qe < (long long)m) edge = x[qe];
     }
     if (TRACE) ts[1] = wall_clock64();  // everything issued
     dbl2 s2 = dbl2{0.0, 0.0};
@@ -1421,7 +1420,7 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
     for (int j = 0; j < NP; j++) {
       if (j < plan.npairs) {
         if (plan.kb[j][0] >= 0) {  // entry at e - 1: row r <- x[r + e - 1] = the previous lane's second element, row r + 1 <- x[r + e]
-          const double   A = pair_prev_lane(eL[j], P[j].y), B = P[j].x;
+          const double   A = pair_prev_lane(__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(edge), 0), __builtin_amdgcn_readlane(__double2loint(edge), 0)), P[j].y), B = P[j].x;
           const unsigned bit = 1u << plan.kb[j][0];
           const double   a = plan.a[j][0];
           if (mk0 & bit) sum0 += a * A;
@@ -1434,7 +1433,7 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
           if (mk1 & bit) sum1 += a * P[j].y;
         }
         if (plan.kb[j][2] >= 0) {  // entry at e + 1: row r <- x[r + e + 1], row r + 1 <- x[r + e + 2] = the next lane's first element
-          const double   A = P[j].y, B = pair_next_lane(eR[j], P[j].x, lane);
+          const double   A = P[j].y, B = pair_next_lane(__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(edge), 1), __builtin_amdgcn_readlane(__double2loint(edge), 1)), P[j].x, lane);
           const unsigned bit = 1u << plan.kb[j][2];
           const double   a = plan.a[j][2];
           if (mk0 & bit) sum0 += a * A;
@@ -2091,6 +2090,14 @@ int build_templates(hipxMat A)
           }
         }
         if (pp.jdiag < 0 || pp.kb[pp.jdiag][1] < 0) pok = false;
+        pp.jodd = -1;
+        pp.eodd = 0;
+        for (int j = 0; j < pp.npairs && pok; j++)
+          if (pp.kb[j][0] >= 0 || pp.kb[j][2] >= 0) {
+            if (pp.jodd >= 0) pok = false;  // (several pairs with odd neighbours -- odd line lengths, the 27-point class: the general template kernel)
+            pp.jodd = j;
+            pp.eodd = pp.e[j];
+          }
       }
       A->pair_ok = pok;
     }
