@@ -1085,6 +1085,22 @@ __global__ __launch_bounds__(256) void tmpl_verify_kernel(hipx_int m, hipx_int n
   }
 }
 
+// The chunk queue's ticket, drawn WITHOUT an immediate wait.  Written as atomicAdd() the draw compiles to the returning atomic followed at
+// once by s_waitcnt vmcnt(0) (the value is wanted in a scalar register): the drawing wave stood still for the L2 round trip of a
+// contended atomic -- 1.6-2.3 us -- at the START of every pass, before it issued its loads, and the other three waves met it at the
+// pass's barrier (HIPX_TMPL_TRACE: that was the longest phase of a pass after the scalar-cache misses were gone).  Here the atomic is
+// issued by hand and its result is collected at the END of the pass (ticket_collect), a whole pass of work later.
+__device__ __forceinline__ void ticket_draw(unsigned long long *ctr, unsigned long long &raw)
+{
+  const unsigned long long one = 1ull;
+  asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0" : "=&v"(raw) : "v"(ctr), "v"(one) : "memory");
+}
+__device__ __forceinline__ long long ticket_collect(unsigned long long &raw)
+{
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw) : : "memory");
+  return (long long)raw;
+}
+
 // Template SpMV.  Persistent workgroups (the template table is loaded into LDS once per workgroup), each XCD walks one
 // contiguous slab of row chunks and the workgroups of an XCD take neighbouring chunks, so the x planes a chunk touches
 // (rows +-n, +-n^2) are shared through that XCD's L2.  Thread t of a chunk owns rows base + t + rr*256: the k-th gather of
@@ -1154,8 +1170,8 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
     idn[rr]             = (row < m) ? tid[row] : 0;
   }
   while (tk < nloc) {
-    long long nxt = 0;
-    if (!STATICQ && t == 0) nxt = (long long)atomicAdd(ctr, 1ull) - tbase;  // the ticket after next travels while this chunk is processed
+    unsigned long long nxt_raw = 0;
+    if (!STATICQ && t == 0) ticket_draw(ctr, nxt_raw);  // the ticket after next travels while this chunk is processed (collected at the end of the pass)
     const hipx_int c    = c0 + (hipx_int)tk;
     const hipx_int base = c * (256 * RPT);
     int            id[RPT];
@@ -1313,7 +1329,7 @@ __global__ __launch_bounds__(256) void spmv_tmpl_kernel(hipx_int m, hipx_int nch
       tk1 = tk1 + bpx;
     } else {
       __syncthreads();  // everybody has read the tickets
-      if (t == 0) s_tk = nxt;
+      if (t == 0) s_tk = ticket_collect(nxt_raw) - tbase;
       __syncthreads();
       tk  = tk1;
       tk1 = s_tk;
@@ -1353,7 +1369,7 @@ __device__ __forceinline__ double pair_next_lane(double last, double v, int lane
 template <int MODE, bool DOT, int NP, bool TRACE = false>
 __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask,
                                                         int ntmpl, const hipxPairPlan plan, const double *__restrict__ x, const double *yin, double *yout, double *dotpart,
-                                                        unsigned long long *tq, unsigned long long launch, long long pf_off, unsigned long long *trace = nullptr)
+                                                        unsigned long long *tq, unsigned long long launch, long long pf_off, int tg, unsigned long long *trace = nullptr)
 {
   typedef double dbl2 __attribute__((ext_vector_type(2)));
   __shared__ unsigned int s_mask[256];
@@ -1364,7 +1380,11 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
   for (int k = t; k < ntmpl; k += 256) s_mask[k] = tmask[k];
   const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, bpx = (hipx_int)gridDim.x >> 3;
   const hipx_int c0 = xcd * chunks_per_xcd, c1 = (c0 + chunks_per_xcd < nchunks) ? c0 + chunks_per_xcd : nchunks;
-  const long long     nloc  = (long long)(c1 > c0 ? c1 - c0 : 0);
+  const long long     nall  = (long long)(c1 > c0 ? c1 - c0 : 0);
+  // one ticket = tg consecutive chunks: the returning atomic on the XCD's counter takes 1.6-2.3 us under this kernel's load, and because a
+  // wave's memory operations retire in order it holds up whatever that wave loads next -- drawn once per tg passes it is amortised,
+  // and the workgroup's waves only meet at a barrier when the ticket changes (between the chunks of a ticket they run free)
+  const long long     nloc  = (nall + tg - 1) / tg;  // tickets of this XCD's slab
   unsigned long long *ctr   = tq + (size_t)xcd * 8;
   const long long     tbase = (long long)(launch * (unsigned long long)(nloc + 2 * bpx));
   if (t == 0) {
@@ -1376,19 +1396,25 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
   double    pf = 0.0;
   unsigned  sink = 0;
   const unsigned short *tid2 = reinterpret_cast<const unsigned short *>(tid);  // rows r, r + 1: one 2-byte load (r even)
-  unsigned idn = (tk < nloc) ? (unsigned)tid2[((long long)(c0 + tk) * 512 + 2 * t) >> 1] : 0u;
+  unsigned idn = (tk < nloc) ? (unsigned)tid2[((long long)(c0 + tk * tg) * 512 + 2 * t) >> 1] : 0u;
+  int                sub = 0;      // chunk of the current ticket
+  unsigned long long nxt_raw = 0;  // (thread 0) the ticket after next, in flight
   unsigned ntr = 0;  // TRACE (HIPX_TMPL_TRACE: developer timing of one workgroup's passes; 100 MHz wall clock)
   while (tk < nloc) {
     unsigned long long ts[6];
     if (TRACE) ts[0] = wall_clock64();
-    long long nxt = 0;
-    if (t == 0) nxt = (long long)atomicAdd(ctr, 1ull) - tbase;  // the ticket after next travels while this chunk is processed
-    const hipx_int  c    = c0 + (hipx_int)tk;
+    if (t == 0 && sub == 0) ticket_draw(ctr, nxt_raw);  // the ticket after next travels while this ticket's chunks are processed
+    const long long ci   = tk * tg + sub;  // (< nall: the loop's last statement sees to it)
+    const hipx_int  c    = c0 + (hipx_int)ci;
     const long long base = (long long)c * 512;
     const long long r    = base + 2 * t;           // this thread's even row
     const long long W    = base + 128 * wv;         // first row of this wave's run
     const unsigned  id2  = idn;
-    idn = (tk1 < nloc) ? (unsigned)tid2[((long long)(c0 + tk1) * 512 + 2 * t) >> 1] : 0u;  // next chunk's ids: consumed at the top of the next pass
+    {  // the next chunk's ids (this ticket's next chunk, else the first chunk of the next ticket): consumed at the top of the next pass
+      const bool      same = sub + 1 < tg && ci + 1 < nall;
+      const long long cn   = same ? ci + 1 : tk1 * tg;
+      idn = (same || tk1 < nloc) ? (unsigned)tid2[((long long)(c0 + cn) * 512 + 2 * t) >> 1] : 0u;
+    }
     // (1) every pair of the chunk in flight at once (zero outside the vector: such a pair is used by no row that exists)
     dbl2 P[NP];
 #pragma unroll
@@ -1460,11 +1486,16 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
       if (prow < (long long)m) pf = x[prow];
     }
     if (TRACE) ts[3] = wall_clock64();  // store, dot partial and prefetch issued
-    __syncthreads();  // everybody has read the tickets
-    if (TRACE) ts[4] = wall_clock64();
-    if (t == 0) s_tk = nxt;
-    __syncthreads();
+    sub++;
+    const bool advance = sub == tg || ci + 1 >= nall;  // (wave-uniform, workgroup-uniform)
+    if (advance) {
+      __syncthreads();  // everybody has read the tickets
+      if (TRACE) ts[4] = wall_clock64();
+      if (t == 0) s_tk = ticket_collect(nxt_raw) - tbase;
+      __syncthreads();
+    }
     if (TRACE) {
+      if (!advance) ts[4] = wall_clock64();
       ts[5] = wall_clock64();
       if (trace && (bid == 8 || bid == 1032) && t == 0 && ntr < 64) {
         unsigned long long *o = trace + ((bid == 8 ? 0 : 64) + ntr) * 8;
@@ -1473,8 +1504,11 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
         ntr++;
       }
     }
-    tk  = tk1;
-    tk1 = s_tk;
+    if (advance) {
+      tk  = tk1;
+      tk1 = s_tk;
+      sub = 0;
+    }
   }
   if (sink == 0xffffffffu) yout[0] = pf;  // never true: keeps the prefetch loads alive
 }
@@ -2267,12 +2301,14 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
     else pf_off += dist * 256 * rpt;
   }
   if (use_pair) {
+    static const int tg_env = getenv("HIPX_TMPL_TG") ? atoi(getenv("HIPX_TMPL_TG")) : 2;
+    const int        tg = (tg_env == 1 || tg_env == 2 || tg_env == 4 || tg_env == 8) ? tg_env : 2;  // chunks per ticket
     static const bool tracing = getenv("HIPX_TMPL_TRACE") != nullptr;
     if (tracing) {  // developer timing: passes of workgroups 8 and 1032 (start, issued, loads back, stored, barrier 1, barrier 2; 10 ns ticks) on stderr
       static unsigned long long *d_tr = nullptr;
       if (!d_tr) HIPX_HIP(hipMalloc((void **)&d_tr, 128 * 8 * sizeof(unsigned long long)));
       HIPX_HIP(hipMemsetAsync(d_tr, 0, 128 * 8 * sizeof(unsigned long long), rt().compute));
-      spmv_pair_kernel<MODE, DOT, 8, true><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, d_tr);
+      spmv_pair_kernel<MODE, DOT, 8, true><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, tg, d_tr);
       HIPX_LAUNCH_CHECK();
       static int dumps = 0;
       if (dumps < 2 && launch >= 5) {
@@ -2288,7 +2324,7 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
         dumps++;
       }
     } else
-    spmv_pair_kernel<MODE, DOT, 8><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off);
+    spmv_pair_kernel<MODE, DOT, 8><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, tg);
     HIPX_LAUNCH_CHECK();
     if (nchunks * 512 < m) {
       spmv_tmpl_tail_kernel<MODE, DOT><<<1, 256, 0, rt().compute>>>(m, nchunks * 512, nchunks, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, x, yin, yout, dotpart);
