@@ -36,7 +36,7 @@ using namespace hipx;
 // masks) or -1; pairs ascend in e, so slots 0, 1, 2 of pair 0, 1, ... is the entries' own (ascending-column) order.
 struct hipxPairPlan {
   int    npairs, jdiag;
-  int    jodd, eodd;  // the ONE pair that has entries at e - 1 / e + 1 (-1: none) and its offset: the pair kernel loads one edge pair per wave
+  int    jodd, eodd;  // jodd >= 0: some pair has entries at e - 1 / e + 1 (the kernel then loads the waves' edge elements); eodd: unused
   int    e[16];
   int    kb[16][3];
   double a[16][3];
@@ -1373,11 +1373,16 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
 {
   typedef double dbl2 __attribute__((ext_vector_type(2)));
   __shared__ unsigned int s_mask[256];
+  __shared__ int          s_pe[16], s_ph[16];  // per pair: its offset e; bit 0 / 1: it has an entry at e - 1 / e + 1 (the edge load's per-lane table)
   __shared__ long long    s_tk;
   __shared__ long long    s_tk2[2];
   const int t = threadIdx.x, lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   for (int k = t; k < ntmpl; k += 256) s_mask[k] = tmask[k];
+  if (t < 16) {
+    s_pe[t] = plan.e[t];
+    s_ph[t] = (t < plan.npairs) ? ((plan.kb[t][0] >= 0 ? 1 : 0) | (plan.kb[t][2] >= 0 ? 2 : 0)) : 0;
+  }
   const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, bpx = (hipx_int)gridDim.x >> 3;
   const hipx_int c0 = xcd * chunks_per_xcd, c1 = (c0 + chunks_per_xcd < nchunks) ? c0 + chunks_per_xcd : nchunks;
   const long long     nall  = (long long)(c1 > c0 ? c1 - c0 : 0);
@@ -1427,14 +1432,15 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
       }
     }
     // (2) the elements just outside the wave's run, for the entries at e - 1 (the first lane needs x[W - 1 + e]) and e + 1 (the last lane
-    // needs x[W + 128 + e]) of the one pair that has such entries.  Wave-uniform addresses, which the compiler would fetch through the
-    // SCALAR cache -- where data that is new in every pass always misses, and a miss cost 1.5-5 us under this kernel's load
-    // (HIPX_TMPL_TRACE: the longest phase of a pass).  So: ONE vector load, lane 0 on the left element, lane 1 on the right one; read
-    // back with v_readlane after the pairs have arrived.
+    // needs x[W + 128 + e]).  Wave-uniform addresses, which the compiler would fetch through the SCALAR cache -- where data that is new in
+    // every pass always misses, and a miss cost 1.5-5 us under this kernel's load (HIPX_TMPL_TRACE: the longest phase of a pass, and what
+    // made some workgroups three times slower than others).  So: ONE vector load for all pairs, lane 2 j on pair j's left element, lane
+    // 2 j + 1 on its right one (offsets per lane from a small LDS table); read back with v_readlane after the pairs have arrived.
     double edge = 0.0;
-    if (plan.jodd >= 0) {
-      const long long qe = W - 1 + plan.eodd + (long long)lane * 129;  // lane 0: W - 1 + e, lane 1: W + 128 + e
-      if (lane < 2 && qe >= 0 && qe < (long long)m) edge = x[qe];
+    if (plan.jodd >= 0 && lane < 2 * plan.npairs) {
+      const int       pj = lane >> 1, right = lane & 1;
+      const long long qe = W + s_pe[pj] + (right ? 128 : -1);
+      if (((s_ph[pj] >> right) & 1) && qe >= 0 && qe < (long long)m) edge = x[qe];
     }
     if (TRACE) ts[1] = wall_clock64();  // everything issued
     dbl2 s2 = dbl2{0.0, 0.0};
@@ -1446,7 +1452,7 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
     for (int j = 0; j < NP; j++) {
       if (j < plan.npairs) {
         if (plan.kb[j][0] >= 0) {  // entry at e - 1: row r <- x[r + e - 1] = the previous lane's second element, row r + 1 <- x[r + e]
-          const double   A = pair_prev_lane(__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(edge), 0), __builtin_amdgcn_readlane(__double2loint(edge), 0)), P[j].y), B = P[j].x;
+          const double   A = pair_prev_lane(__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(edge), 2 * j), __builtin_amdgcn_readlane(__double2loint(edge), 2 * j)), P[j].y), B = P[j].x;
           const unsigned bit = 1u << plan.kb[j][0];
           const double   a = plan.a[j][0];
           if (mk0 & bit) sum0 += a * A;
@@ -1459,7 +1465,7 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
           if (mk1 & bit) sum1 += a * P[j].y;
         }
         if (plan.kb[j][2] >= 0) {  // entry at e + 1: row r <- x[r + e + 1], row r + 1 <- x[r + e + 2] = the next lane's first element
-          const double   A = P[j].y, B = pair_next_lane(__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(edge), 1), __builtin_amdgcn_readlane(__double2loint(edge), 1)), P[j].x, lane);
+          const double   A = P[j].y, B = pair_next_lane(__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(edge), 2 * j + 1), __builtin_amdgcn_readlane(__double2loint(edge), 2 * j + 1)), P[j].x, lane);
           const unsigned bit = 1u << plan.kb[j][2];
           const double   a = plan.a[j][2];
           if (mk0 & bit) sum0 += a * A;
@@ -2128,7 +2134,6 @@ int build_templates(hipxMat A)
         pp.eodd = 0;
         for (int j = 0; j < pp.npairs && pok; j++)
           if (pp.kb[j][0] >= 0 || pp.kb[j][2] >= 0) {
-            if (pp.jodd >= 0) pok = false;  // (several pairs with odd neighbours -- odd line lengths, the 27-point class: the general template kernel)
             pp.jodd = j;
             pp.eodd = pp.e[j];
           }
@@ -2267,9 +2272,10 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
   const int      tbase = (A->d_tmask && !nosub) ? A->tmpl_base : -1;
   // pair form (spmv_pair_kernel): sub-template matrices, 16-byte aligned vectors, the default geometry; it takes the whole chunks
   static const bool nopair = getenv("HIPX_TMPL_NOPAIR") != nullptr;
+  static const int  pair_maxp = getenv("HIPX_TMPL_PAIRMAX") ? atoi(getenv("HIPX_TMPL_PAIRMAX")) : 16;  // most pairs a base template may have for the pair form
   static const int  probe0 = getenv("HIPX_TMPL_PROBE") ? atoi(getenv("HIPX_TMPL_PROBE")) : 0;
   const bool     vec_aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(yout) | (MODE == 1 ? reinterpret_cast<uintptr_t>(yin) : (uintptr_t)0)) & 15) == 0;
-  const bool     use_pair = A->pair_ok && A->pair_plan.npairs <= 8 && tbase >= 0 && !nopair && !probe0 && cfg == 1 && vec_aligned && m >= 512 && A->ntmpl <= 256;
+  const bool     use_pair = A->pair_ok && A->pair_plan.npairs <= pair_maxp && tbase >= 0 && !nopair && !probe0 && cfg == 1 && vec_aligned && m >= 512 && A->ntmpl <= 256;
   if (use_pair) nchunks = m / 512;
   hipx_int       grid = std::min<hipx_int>((hipx_int)((tmpl_blocks() + 7) / 8 * 8), ((nchunks + 7) / 8) * 8);
   if (grid < 8) grid = 8;
@@ -2324,7 +2330,12 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
         dumps++;
       }
     } else
-    spmv_pair_kernel<MODE, DOT, 8><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, tg);
+    if (A->pair_plan.npairs <= 8)
+      spmv_pair_kernel<MODE, DOT, 8><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, tg);
+    else if (A->pair_plan.npairs <= 12)
+      spmv_pair_kernel<MODE, DOT, 12><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, tg);
+    else
+      spmv_pair_kernel<MODE, DOT, 16><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, tg);
     HIPX_LAUNCH_CHECK();
     if (nchunks * 512 < m) {
       spmv_tmpl_tail_kernel<MODE, DOT><<<1, 256, 0, rt().compute>>>(m, nchunks * 512, nchunks, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, x, yin, yout, dotpart);
@@ -2915,7 +2926,7 @@ int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
     if (ierr) return ierr;
   }
   if (sl) name = "spmv_sell_kernel (MatMult on the SELL-64 copy: one lane per row, 16-bit window-coded columns)";
-  else if (tm && A->pair_ok && A->pair_plan.npairs <= 8 && A->d_tmask && !getenv("HIPX_TMPL_NOSUB") && !getenv("HIPX_TMPL_NOPAIR") && !getenv("HIPX_TMPL_PROBE") && tmpl_cfg() == 1 && A->nrows_c >= 512)
+  else if (tm && A->pair_ok && A->pair_plan.npairs <= (getenv("HIPX_TMPL_PAIRMAX") ? atoi(getenv("HIPX_TMPL_PAIRMAX")) : 16) && A->d_tmask && !getenv("HIPX_TMPL_NOSUB") && !getenv("HIPX_TMPL_NOPAIR") && !getenv("HIPX_TMPL_PROBE") && tmpl_cfg() == 1 && A->nrows_c >= 512)
     name = "spmv_pair_kernel (CSR MatMult, row templates: 1 byte per row; two consecutive rows per thread, 16-byte loads of x at the even offsets, +-1 entries from the neighbouring lanes)";
   else if (tm && A->d_tmask && !getenv("HIPX_TMPL_NOSUB")) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row; every template a subset of the interior one: uniform masked walk)";
   else if (tm) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row)";

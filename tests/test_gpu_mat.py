@@ -490,8 +490,10 @@ def test_pair_form_of_the_template_kernel_bit_exact(hx, kind, n, m):
     A = _lib.mat_create_csr(N, N, ai, aj, aa)
     _lib.chk(hx.hipxMatSetSpMVVariant(A, 26))  # row templates whatever the size (auto keeps small matrices on the plain kernels)
     name = kernel_name(hx, A)
-    # pair form: base templates with <= 8 even-offset pairs of which at most one has entries at e +- 1 (5-/7-point operators on even line lengths)
-    assert name.startswith("spmv_pair_kernel " if (N >= 512 and kind != "27pt" and n % 2 == 0) else "spmv_tmpl_kernel "), name
+    if N >= 512 and n % 2 == 0:
+        assert name.startswith("spmv_pair_kernel "), name  # (even line lengths: 5 / 5 / 9 pairs for the 5- / 7- / 27-point operators)
+    else:
+        assert is_template_kernel(name), name             # (odd line lengths: more pairs; beyond 16 the general template kernel)
     yr = orc.matmult(ai, aj, aa, x)
     zr = np.zeros(N)
     orc.lib().orc_MatMultAdd_SeqAIJ(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(y0), orc.P(zr))
