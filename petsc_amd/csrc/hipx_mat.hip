@@ -2307,8 +2307,10 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
     else pf_off += dist * 256 * rpt;
   }
   if (use_pair) {
-    static const int tg_env = getenv("HIPX_TMPL_TG") ? atoi(getenv("HIPX_TMPL_TG")) : 2;
-    const int        tg = (tg_env == 1 || tg_env == 2 || tg_env == 4 || tg_env == 8) ? tg_env : 2;  // chunks per ticket
+    // chunks per ticket (HIPX_TMPL_TG = 1 | 2 | 4 | 8): measured 7-pt 256^3 0.1212 / 0.1241 / 0.1320 ms for 1 / 2 / 4, 7-pt 512^3 0.864 / 0.790 / 0.797:
+    // one chunk per ticket while the slabs are short, two on large matrices
+    static const int tg_env = getenv("HIPX_TMPL_TG") ? atoi(getenv("HIPX_TMPL_TG")) : 0;
+    const int        tg = (tg_env == 1 || tg_env == 2 || tg_env == 4 || tg_env == 8) ? tg_env : (nchunks > 49152 ? 2 : 1);
     static const bool tracing = getenv("HIPX_TMPL_TRACE") != nullptr;
     if (tracing) {  // developer timing: passes of workgroups 8 and 1032 (start, issued, loads back, stored, barrier 1, barrier 2; 10 ns ticks) on stderr
       static unsigned long long *d_tr = nullptr;
