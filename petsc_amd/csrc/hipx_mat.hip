@@ -1405,6 +1405,7 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
   int                sub = 0;      // chunk of the current ticket
   unsigned long long nxt_raw = 0;  // (thread 0) the ticket after next, in flight
   unsigned ntr = 0;  // TRACE (HIPX_TMPL_TRACE: developer timing of one workgroup's passes; 100 MHz wall clock)
+  unsigned long long npass = 0, t_first = TRACE ? wall_clock64() : 0;
   while (tk < nloc) {
     unsigned long long ts[6];
     if (TRACE) ts[0] = wall_clock64();
@@ -1492,6 +1493,7 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
       if (prow < (long long)m) pf = x[prow];
     }
     if (TRACE) ts[3] = wall_clock64();  // store, dot partial and prefetch issued
+    npass++;
     sub++;
     const bool advance = sub == tg || ci + 1 >= nall;  // (wave-uniform, workgroup-uniform)
     if (advance) {
@@ -1515,6 +1517,12 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
       tk1 = s_tk;
       sub = 0;
     }
+  }
+  if (TRACE && trace && t == 0) {  // per workgroup: passes done, first and last stamp
+    unsigned long long *o = trace + 128 * 8 + (size_t)bid * 4;
+    o[0] = npass;
+    o[1] = t_first;
+    o[2] = wall_clock64();
   }
   if (sink == 0xffffffffu) yout[0] = pf;  // never true: keeps the prefetch loads alive
 }
@@ -2314,8 +2322,9 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
     static const bool tracing = getenv("HIPX_TMPL_TRACE") != nullptr;
     if (tracing) {  // developer timing: passes of workgroups 8 and 1032 (start, issued, loads back, stored, barrier 1, barrier 2; 10 ns ticks) on stderr
       static unsigned long long *d_tr = nullptr;
-      if (!d_tr) HIPX_HIP(hipMalloc((void **)&d_tr, 128 * 8 * sizeof(unsigned long long)));
-      HIPX_HIP(hipMemsetAsync(d_tr, 0, 128 * 8 * sizeof(unsigned long long), rt().compute));
+      const size_t trw = 128 * 8 + 4 * 4096;
+      if (!d_tr) HIPX_HIP(hipMalloc((void **)&d_tr, trw * sizeof(unsigned long long)));
+      HIPX_HIP(hipMemsetAsync(d_tr, 0, trw * sizeof(unsigned long long), rt().compute));
       spmv_pair_kernel<MODE, DOT, 8, true><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, tg, d_tr);
       HIPX_LAUNCH_CHECK();
       static int dumps = 0;
@@ -2329,6 +2338,28 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
             fprintf(stderr, "[hipx tmpl trace] wg %d pass %2d chunk %6llu start %8.2f us | issue %5.2f loads %5.2f store %5.2f barrier1 %5.2f barrier2 %5.2f | pass %5.2f us\n", w ? 1032 : 8, e, o[6],
                     (o[0] - h[0]) / 100.0, (o[1] - o[0]) / 100.0, (o[2] - o[1]) / 100.0, (o[3] - o[2]) / 100.0, (o[4] - o[3]) / 100.0, (o[5] - o[4]) / 100.0, (o[5] - o[0]) / 100.0);
           }
+        {  // passes per workgroup and the span it was alive: by XCD, and the spread
+          std::vector<unsigned long long> w(4 * 4096);
+          HIPX_HIP(hipMemcpy(w.data(), d_tr + 128 * 8, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+          unsigned long long t0 = ~0ull;
+          for (hipx_int b = 0; b < grid && b < 4096; b++)
+            if (w[4 * b + 1]) t0 = std::min(t0, w[4 * b + 1]);
+          for (int xc = 0; xc < 8; xc++) {
+            unsigned long long np = 0, mn = ~0ull, mx = 0, late = 0, nw = 0;
+            for (hipx_int b = xc; b < grid && b < 4096; b += 8) {
+              np += w[4 * b];
+              if (w[4 * b]) {
+                mn = std::min(mn, w[4 * b]);
+                mx = std::max(mx, w[4 * b]);
+                nw++;
+              }
+              if (w[4 * b + 1] - t0 > 1000) late++;  // started more than 10 us after the first workgroup
+            }
+            fprintf(stderr, "[hipx tmpl trace] XCD %d: %llu passes by %llu workgroups (min %llu, max %llu per workgroup), %llu workgroups started > 10 us late\n", xc, np, nw, mn, mx, late);
+          }
+          for (hipx_int b = 0; b < 64 && b < grid; b++)
+            fprintf(stderr, "[hipx tmpl trace] wg %4d: %3llu passes, start %7.2f us, end %7.2f us\n", (int)(b * 8), w[4 * (b * 8)], (w[4 * (b * 8) + 1] - t0) / 100.0, (w[4 * (b * 8) + 2] - t0) / 100.0);
+        }
         dumps++;
       }
     } else
