@@ -1533,98 +1533,6 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
   if (sink == 0xffffffffu) yout[0] = pf;  // never true: keeps the prefetch loads alive
 }
 
-// The pair form with a CONTROL wave.  A wave's vector-memory operations retire in order, so anything slow a compute wave issues -- the
-// first touch of the far plane of x (an HBM miss), the next chunk's template ids (another), the returning ticket atomic -- holds up the
-// wait for its L2-resident pairs; with those in the compute waves a pass took ~3 us = one loaded HBM round trip, whatever else was
-// done (per-workgroup pass counts: HIPX_TMPL_TRACE).  Here the workgroup has a fifth wave that does nothing but (a) touch, one
-// round of workgroups ahead, the lines the compute waves will need from HBM -- 32 lines of x's far plane and 4 lines of ids per
-// chunk -- with loads whose results nobody reads (asm, no wait), and (b) draw the tickets: the atomic for the ticket after next is
-// issued at the start of a ticket and collected at its end with vmcnt(tg), which leaves this ticket's tg prefetch loads in flight.
-// The compute waves issue only loads that hit the L2; the five waves meet at two barriers per ticket (tg chunks).
-template <int MODE, bool DOT, int NP>
-__global__ __launch_bounds__(320) void spmv_pair5_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask,
-                                                         int ntmpl, const hipxPairPlan plan, const double *__restrict__ x, const double *yin, double *yout, double *dotpart,
-                                                         unsigned long long *tq, unsigned long long launch, long long pf_off, long long pf_rows, int tg)
-{
-  __shared__ unsigned int s_mask[256];
-  __shared__ int          s_pe[16], s_ph[16];
-  __shared__ long long    s_tk;
-  __shared__ long long    s_tk2[2];
-  const int  t = threadIdx.x, lane = t & 63;
-  const int  wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const bool ctl = wv == 4;
-  for (int k = t; k < ntmpl; k += 320) s_mask[k] = tmask[k];
-  if (t < 16) {
-    s_pe[t] = plan.e[t];
-    s_ph[t] = (t < plan.npairs) ? ((plan.kb[t][0] >= 0 ? 1 : 0) | (plan.kb[t][2] >= 0 ? 2 : 0)) : 0;
-  }
-  const hipx_int bid = (hipx_int)blockIdx.x, xcd = bid & 7, bpx = (hipx_int)gridDim.x >> 3;
-  const hipx_int c0 = xcd * chunks_per_xcd, c1 = (c0 + chunks_per_xcd < nchunks) ? c0 + chunks_per_xcd : nchunks;
-  const long long     nall  = (long long)(c1 > c0 ? c1 - c0 : 0);
-  const long long     nloc  = (nall + tg - 1) / tg;  // tickets of this XCD's slab (tg consecutive chunks each)
-  unsigned long long *ctr   = tq + (size_t)xcd * 8;
-  const long long     tbase = (long long)(launch * (unsigned long long)(nloc + 2 * bpx));
-  if (t == 256) {
-    s_tk2[0] = (long long)atomicAdd(ctr, 1ull) - tbase;
-    s_tk2[1] = (long long)atomicAdd(ctr, 1ull) - tbase;
-  }
-  __syncthreads();
-  long long tk = s_tk2[0], tk1 = s_tk2[1];
-  const unsigned short *tid2 = reinterpret_cast<const unsigned short *>(tid);  // rows r, r + 1: one 2-byte load (r even)
-  unsigned           idn = (tk < nloc && !ctl) ? (unsigned)tid2[((long long)(c0 + tk * tg) * 512 + 2 * t) >> 1] : 0u;
-  unsigned long long nxt_raw = 0;  // (thread 256) the ticket after next, in flight
-  unsigned           touch = 0;    // (control wave) destination of the prefetch loads: never read, kept live so that its register is never reused
-  int                nissued = 0;  // (control wave) prefetch loads issued after the ticket atomic of the current ticket
-  while (tk < nloc) {
-    if (ctl) {
-      if (t == 256) ticket_draw(ctr, nxt_raw);
-      nissued = 0;
-      if (pf_off) {
-        for (int sub = 0; sub < tg; sub++) {
-          const long long ci = tk * tg + sub;
-          if (ci >= nall) break;
-          const long long base = (long long)(c0 + ci) * 512;
-          const long long prow = base + pf_off + (long long)lane * 16;            // lanes 0-31: the far plane of x, one round of workgroups ahead
-          const long long trow = base + pf_rows + (long long)(lane - 32) * 128;   // lanes 32-35: the template ids of the same chunk
-          const char     *addr = (lane < 32) ? reinterpret_cast<const char *>(x + prow) : reinterpret_cast<const char *>(tid + trow);
-          const bool      on   = (lane < 32) ? prow < (long long)m : (lane < 36 && trow < (long long)m);
-          if (on) asm volatile("global_load_dword %0, %1, off" : "+v"(touch) : "v"(addr) : "memory");
-          nissued += __any(on) ? 1 : 0;  // (the load instruction exists for the wave iff some lane wants it)
-        }
-      }
-    } else {
-      for (int sub = 0; sub < tg; sub++) {
-        const long long ci = tk * tg + sub;
-        if (ci >= nall) break;
-        const unsigned id2 = idn;
-        {  // the next chunk's ids (this ticket's next chunk, else the first chunk of the next ticket): consumed at the top of the next pass
-          const bool      same = sub + 1 < tg && ci + 1 < nall;
-          const long long cn   = same ? ci + 1 : tk1 * tg;
-          idn = (same || tk1 < nloc) ? (unsigned)tid2[((long long)(c0 + cn) * 512 + 2 * t) >> 1] : 0u;
-        }
-        pair_chunk<MODE, DOT, NP>(m, plan, x, yin, yout, dotpart, s_mask, s_pe, s_ph, c0 + (hipx_int)ci, t, lane, wv, id2);
-      }
-    }
-    __syncthreads();  // everybody has read the tickets
-    if (t == 256) {
-      // the atomic is older than the nissued prefetch loads of this ticket: leave exactly those in flight
-      if (nissued == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(nxt_raw) : : "memory");
-      else if (nissued == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(nxt_raw) : : "memory");
-      else if (nissued == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(nxt_raw) : : "memory");
-      else if (nissued == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(nxt_raw) : : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt_raw) : : "memory");
-      s_tk = (long long)nxt_raw - tbase;
-    }
-    __syncthreads();
-    tk  = tk1;
-    tk1 = s_tk;
-  }
-  if (ctl) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch) : : "memory");
-    if (touch == 0x9e3779b9u && nloc < 0) yout[0] = 0.0;  // never true: keeps the register alive to the end
-  }
-}
-
 // rows [row0, m) of a template matrix, one row per thread and pass (the partial last chunk of spmv_pair_kernel): the row's own
 // template from the global tables; dot partials in the layout of the chunked kernels (4 per chunk of 512 rows: rows t, t + 256)
 template <int MODE, bool DOT>
@@ -2417,18 +2325,6 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
     // one chunk per ticket while the slabs are short, two on large matrices
     static const int tg_env = getenv("HIPX_TMPL_TG") ? atoi(getenv("HIPX_TMPL_TG")) : 0;
     const int        tg = (tg_env == 1 || tg_env == 2 || tg_env == 4 || tg_env == 8) ? tg_env : (nchunks > 49152 ? 2 : 1);
-    static const int ctl_env = getenv("HIPX_TMPL_CTRL") ? atoi(getenv("HIPX_TMPL_CTRL")) : 1;
-    if (ctl_env && !getenv("HIPX_TMPL_TRACE")) {  // control-wave form (HIPX_TMPL_CTRL=0: the four-wave kernel)
-      static const int tg5_env = getenv("HIPX_TMPL_TG") ? atoi(getenv("HIPX_TMPL_TG")) : 0;
-      const int        tg5 = (tg5_env == 1 || tg5_env == 2 || tg5_env == 4) ? tg5_env : 2;
-      const long long  pfr = pf_off ? pf_off - A->tmpl_maxoff : 0;
-      if (A->pair_plan.npairs <= 8)
-        spmv_pair5_kernel<MODE, DOT, 8><<<(unsigned)grid, 320, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, pfr, tg5);
-      else if (A->pair_plan.npairs <= 12)
-        spmv_pair5_kernel<MODE, DOT, 12><<<(unsigned)grid, 320, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, pfr, tg5);
-      else
-        spmv_pair5_kernel<MODE, DOT, 16><<<(unsigned)grid, 320, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, pfr, tg5);
-    } else {
     static const bool tracing = getenv("HIPX_TMPL_TRACE") != nullptr;
     if (tracing) {  // developer timing: passes of workgroups 8 and 1032 (start, issued, loads back, stored, barrier 1, barrier 2; 10 ns ticks) on stderr
       static unsigned long long *d_tr = nullptr;
@@ -2479,7 +2375,6 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
       spmv_pair_kernel<MODE, DOT, 12><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, tg);
     else
       spmv_pair_kernel<MODE, DOT, 16><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, tg);
-    }
     HIPX_LAUNCH_CHECK();
     if (nchunks * 512 < m) {
       spmv_tmpl_tail_kernel<MODE, DOT><<<1, 256, 0, rt().compute>>>(m, nchunks * 512, nchunks, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, x, yin, yout, dotpart);
