@@ -2,9 +2,7 @@
 // reference keeps in src/mat/impls/sell/seq/sell.c (MatMult_SeqSELL sell.c:319-460: slices of rows stored column-major so that
 // consecutive lanes read consecutive memory).  Here a slice is 64 rows = one wavefront, lane l owns row 64 s + l:
 //
-//   values   val[soff[s] + (k / 2) * 128 + l * 2 + k % 2]     k-th entry of the lane's row: entries 2 j, 2 j + 1 side by side (16 B per lane: one
-//            1-KiB run per wave and pair; slice widths are even) -- one 16-byte load per two entries: the CU's address pipeline is
-//            occupied per wave-wide request, whatever its width (8 B per lane: 0.288 ms on the config-4 stand-in, 16 B: see DESIGN 3.1)
+//   values   val[soff[s] + k * 64 + l]                       k-th entry of the lane's row (8 B per lane: one 512-B run per wave and k)
 //   columns  col16[coff[s] + (k / 4) * 256 + l * 4 + k % 4]  16-bit code (window id : 4 | offset : 12), 4 entries per 8-byte load;
 //            base[s * 16 + id] = first column of window id (<= 16 windows of 4096 columns per slice); matrices with a slice
 //            that needs more windows keep 32-bit columns col32[soff[s] + k * 64 + l]
@@ -141,7 +139,7 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(hipx_int m, hipx_int nsl
   for (int k = 0; k < w; k++) {
     const bool     on = k < len;
     const hipx_int c  = on ? aj[k0 + k] : (len ? aj[k0 + len - 1] : 0);  // padding: a column the row touches anyway (never multiplied)
-    val[so + (int64_t)(k >> 1) * (2 * SELL_C) + lane * 2 + (k & 1)] = on ? aa[k0 + k] : 0.0;
+    val[so + (int64_t)k * SELL_C + lane] = on ? aa[k0 + k] : 0.0;
     if (pack) {
       const int key = c >> 12;
       int       id  = 0;
@@ -172,7 +170,7 @@ __global__ __launch_bounds__(256) void sell_values_kernel(hipx_int m, hipx_int n
   }
   const int64_t so = soff[s];
   const int     w  = (int)((soff[s + 1] - so) >> 6);
-  for (int k = 0; k < w; k++) val[so + (int64_t)(k >> 1) * (2 * SELL_C) + lane * 2 + (k & 1)] = k < len ? aa[k0 + k] : 0.0;
+  for (int k = 0; k < w; k++) val[so + (int64_t)k * SELL_C + lane] = k < len ? aa[k0 + k] : 0.0;
 }
 
 // MODE 0: y = A x; MODE 1: z = y + A x (the sum starts from y_i, aij.c:1648).  DOT: one partial of x . y per slice (fixed order).
@@ -192,7 +190,7 @@ __global__ __launch_bounds__(256) void spmv_sell_kernel(hipx_int m, hipx_int nsl
   const int      len = row < m ? (int)lens[row] : 0;
   const int64_t  so = soff[s];
   const int      w  = (int)((soff[s + 1] - so) >> 6);
-  const double  *vp = val + so + lane * 2;
+  const double  *vp = val + so + lane;
   double         sum = (MODE == 1 && row < m) ? yin[row] : 0.0;
   int            mybase = 0;
   const unsigned short *cp = nullptr;
@@ -205,11 +203,7 @@ __global__ __launch_bounds__(256) void spmv_sell_kernel(hipx_int m, hipx_int nsl
     double a[U];
     int    c[U];
 #pragma unroll
-    for (int e = 0; e < U; e += 2) {  // (the arrays carry U * 64 slots of slack: no bounds test on the stream)
-      const double2 v2 = *reinterpret_cast<const double2 *>(vp + (int64_t)((k + e) >> 1) * (2 * SELL_C));
-      a[e]     = v2.x;
-      a[e + 1] = v2.y;
-    }
+    for (int e = 0; e < U; e++) a[e] = vp[(int64_t)(k + e) * SELL_C];  // (the arrays carry U * 64 slots of slack: no bounds test on the stream)
     if (PACK) {
 #pragma unroll
       for (int e = 0; e < U; e += 4) {
@@ -316,7 +310,6 @@ int hipxSellEnsure_(hipxMat A, void **slot, int *ok, int *packed, double *pad_ra
     (void)hipFree(d_w);
     std::vector<int64_t> soff((size_t)S->nslices + 1, 0), coff((size_t)S->nslices + 1, 0);
     for (hipx_int s = 0; s < S->nslices; s++) {
-      w[(size_t)s]        = (w[(size_t)s] + 1) & ~1;  // even widths: values are stored and loaded in pairs
       soff[(size_t)s + 1] = soff[(size_t)s] + (int64_t)w[(size_t)s] * SELL_C;
       coff[(size_t)s + 1] = coff[(size_t)s] + (int64_t)((w[(size_t)s] + 3) & ~3) * SELL_C;
     }
