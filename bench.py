@@ -1042,9 +1042,14 @@ def main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync):
             _lib.chk(hx.hipxCommFinalize())
             if res["parity"]["pass"] is not False and (best is None or res["iterations_per_s"] > legs[best]["iterations_per_s"]):
                 best = t
-        except Exception as e:  # noqa: BLE001  (a rank-local failure here cannot be recovered collectively: report and stop)
+        except Exception as e:  # noqa: BLE001  (a rank-local failure here cannot be recovered collectively: say what happened on stdout -- one line, the
+            # contract's shape, value null -- and end the job: the launcher tears the other ranks down instead of leaving them in a collective)
             multi["transports"][t]["error"] = str(e)[:300]
-            raise
+            print(json.dumps({"metric": head.metric(), "value": None, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                              "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": head.metric()},
+                              "multi_gpu": multi, "error": "rank %d failed on transport %s: %s" % (rank, t, str(e)[:300])}))
+            sys.stdout.flush()
+            os._exit(3)
     out = None
     if rank == 0:
         pcname = head.pcname()
