@@ -1,9 +1,13 @@
 #!/bin/bash
-# template SpMV (pair form) against the number of persistent workgroups (HIPX_TMPL_BLOCKS): latency-bound (time ~ 1 / workgroups) or throughput-bound (flat)?
+# cg_fused_kernel with four elements per stream in flight: tests + per-kernel averages of the headline CG loop (rocprofv3 stats)
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-for b in 512 768 1024 1280 1536 2048; do
-  HIPX_TMPL_BLOCKS=$b timeout 600 python bench.py --quick --stencil 7 --grid 256 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('blocks $b: spmv %.4f ms  %.1f it/s' % (d['roofline']['avg_launch_ms'], d['value']))"
-done
+mkdir -p gpurun_out
+SECONDS=0
+timeout 900 python -m pytest tests/test_gpu_ksp.py tests/test_gpu_vec.py -m gpu -q --timeout 600 -p no:cacheprovider > gpurun_out/r03z_pytest.log 2>&1
+echo "pytest exit $? after ${SECONDS}s: $(tail -1 gpurun_out/r03z_pytest.log)"
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r03z_stats" -o stats -- python "$GRAFT_REPO_ROOT/bench.py" --no-traffic --no-plugin --no-cpu-baseline --no-other --no-general > "$GRAFT_REPO_ROOT/gpurun_out/r03z_stats.log" 2>&1)
+find gpurun_out/r03z_stats -name "*kernel_trace.csv" -delete
+f=$(find gpurun_out/r03z_stats -name "*kernel_stats.csv" | head -1); head -6 "$f" | cut -c1-60,200-330
+tail -1 gpurun_out/r03z_stats.log | cut -c1-200
+echo "total ${SECONDS}s"
