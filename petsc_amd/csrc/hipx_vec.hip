@@ -638,21 +638,6 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
     // two elements per stream in flight per thread (10 x 16-byte loads issued before the first use); the per-thread
     // accumulation order is unchanged (q, then q + kRedThreads)
     hipx_int q = c0 + (hipx_int)threadIdx.x;
-    // four elements per stream in flight per thread where the chunk allows (the chip wants ~40 KiB in flight per CU at its streaming rate; two
-    // per stream = 64 KiB per 1024-thread workgroup was marginal: 5.2 TB/s against the elementwise kernels' 6.8), same accumulation order
-    for (; q + 3 * kRedThreads < c1; q += 4 * kRedThreads) {
-      const hipx_int q1 = q + kRedThreads, q2 = q + 2 * kRedThreads, q3 = q + 3 * kRedThreads;
-      const double2  z0 = {0.0, 0.0};
-      const double2  dc = {dconst, dconst};
-      const double2  xa = UPX ? x2[q] : z0, ra = r2[q], pa = UPX ? p2[q] : z0, wa = w2[q], da = CONSTD ? dc : d2[q];
-      const double2  xb = UPX ? x2[q1] : z0, rb = r2[q1], pb = UPX ? p2[q1] : z0, wb = w2[q1], db = CONSTD ? dc : d2[q1];
-      const double2  xc = UPX ? x2[q2] : z0, rc = r2[q2], pc = UPX ? p2[q2] : z0, wc = w2[q2], dcc = CONSTD ? dc : d2[q2];
-      const double2  xd = UPX ? x2[q3] : z0, rd = r2[q3], pd = UPX ? p2[q3] : z0, wd = w2[q3], dd = CONSTD ? dc : d2[q3];
-      step(q, xa, ra, pa, wa, da);
-      step(q1, xb, rb, pb, wb, db);
-      step(q2, xc, rc, pc, wc, dcc);
-      step(q3, xd, rd, pd, wd, dd);
-    }
     for (; q + kRedThreads < c1; q += 2 * kRedThreads) {
       const hipx_int q1 = q + kRedThreads;
       const double2  z0 = {0.0, 0.0};
