@@ -168,6 +168,10 @@ int hipxMatZeroEntries(hipxMat A);
 /* replaces MatAXPY_SeqAIJ with SAME_NONZERO_PATTERN aij.c:2926-2945: Y.a += alpha X.a on the device copies (daxpy over the value
    arrays: product and sum rounded separately).  The caller guarantees identical patterns (sizes and nonzero counts are checked). */
 int hipxMatAXPY(hipxMat Y, double alpha, hipxMat X);
+/* one iteration of KSPSolve_Chebyshev_FirstKind cheby.c:475-511 (PCJACOBI: dinv, PCNONE: dinv == NULL; no norm): pnext = alpha pprev + beta pcur +
+   gamma (dinv .* (b - A pcur)), the SpMV and hipxVecChebyshevStep in ONE kernel when the matrix takes the pair form of the template kernel
+   (else the two kernels, the step in place); bit-identical to MatMult + VecAYPX + VecPointwiseMult + VecAXPBYPCZ */
+int hipxMatMultChebyshev(hipxMat A, const double *pcur, double *pnext, double alpha, double beta, double gamma, const double *pprev, const double *dinv, const double *b);
 int hipxMatDiagonalScale(hipxMat A, const double *l, const double *r);
 /* COO assembly on the device.  replaces MatSetValuesCOO_SeqAIJ aij.c:4710-4733; jmap (nz + 1) / perm (ntot) are the maps
    MatSetPreallocationCOO_SeqAIJ leaves in MatCOOStruct_SeqAIJ (aij.c:4524-4707, aij.h:170-176): entry k of the CSR value array

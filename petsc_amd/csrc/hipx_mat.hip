@@ -42,6 +42,15 @@ struct hipxPairPlan {
   double a[16][3];
 };
 
+// Chebyshev epilogue of the pair-form SpMV (hipxMatMultChebyshev): instead of y = A x the kernel stores
+//   pnext = alpha pprev + beta x + gamma (dinv .* (b - A x))      (x = the current iterate: the diagonal pair of the walk)
+// element by element the operations of hipxVecChebyshevStep (cheby.c:475-511).  br: VecAXPBYPCZ_Seq's association order (bvec1.c:120-147).
+struct hipxPairEpi {
+  const double *b, *dinv, *pprev;
+  double        alpha, beta, gamma;
+  int           br;
+};
+
 struct hipxMat_s {
   hipx_int  m = 0, n = 0;
   int64_t   nnz       = 0;
@@ -1368,14 +1377,21 @@ __device__ __forceinline__ double pair_next_lane(double last, double v, int lane
 // XCD, a non-persistent one-chunk-per-workgroup launch, a fifth wave that does the prefetching).
 // One chunk of 512 rows (rows c * 512 ... + 511) in the pair form: thread t owns rows r = c * 512 + 2 t and r + 1; id2 = the two rows'
 // template ids.  Shared by the two persistent kernels below.
-template <int MODE, bool DOT, int NP>
+template <int MODE, bool DOT, int NP, int EPI = 0>
 __device__ __forceinline__ void pair_chunk(const hipx_int m, const hipxPairPlan &plan, const double *__restrict__ x, const double *yin, double *yout, double *dotpart,
-                                           const unsigned int *s_mask, const int *s_pe, const int *s_ph, const hipx_int c, const int t, const int lane, const int wv, const unsigned id2)
+                                           const unsigned int *s_mask, const int *s_pe, const int *s_ph, const hipx_int c, const int t, const int lane, const int wv, const unsigned id2,
+                                           const hipxPairEpi &epi = hipxPairEpi{})
 {
   typedef double dbl2 __attribute__((ext_vector_type(2)));
   const long long base = (long long)c * 512;
   const long long r    = base + 2 * t;     // this thread's even row
   const long long W    = base + 128 * wv;   // first row of this wave's run
+  dbl2            eb = dbl2{0.0, 0.0}, ep = dbl2{0.0, 0.0}, ed = dbl2{1.0, 1.0};
+  if (EPI == 1) {  // the epilogue's own streams, issued with the pairs
+    eb = *reinterpret_cast<const dbl2 *>(epi.b + r);
+    ep = *reinterpret_cast<const dbl2 *>(epi.pprev + r);
+    if (epi.dinv) ed = *reinterpret_cast<const dbl2 *>(epi.dinv + r);
+  }
   // (1) every pair of the chunk in flight at once (zero outside the vector: such a pair is used by no row that exists)
   dbl2 P[NP];
 #pragma unroll
@@ -1426,10 +1442,28 @@ __device__ __forceinline__ void pair_chunk(const hipx_int m, const hipxPairPlan 
         if (mk0 & bit) sum0 += a * A;
         if (mk1 & bit) sum1 += a * B;
       }
-      if (DOT && j == plan.jdiag) {
+      if ((DOT || EPI) && j == plan.jdiag) {
         xr0 = P[j].x;
         xr1 = P[j].y;
       }
+    }
+  }
+  if (EPI == 1) {
+    const double r0 = eb.x - sum0, r1 = eb.y - sum1;
+    const double z0 = epi.dinv ? r0 * ed.x : r0, z1 = epi.dinv ? r1 * ed.y : r1;
+    const double a = epi.alpha, b = epi.beta, g = epi.gamma;
+    if (epi.br == 0) {
+      sum0 = ep.x + b * xr0 + g * z0;
+      sum1 = ep.y + b * xr1 + g * z1;
+    } else if (epi.br == 1) {
+      sum0 = a * ep.x + b * xr0 + z0;
+      sum1 = a * ep.y + b * xr1 + z1;
+    } else if (epi.br == 2) {
+      sum0 = a * ep.x + b * xr0;
+      sum1 = a * ep.y + b * xr1;
+    } else {
+      sum0 = a * ep.x + b * xr0 + g * z0;
+      sum1 = a * ep.y + b * xr1 + g * z1;
     }
   }
   *reinterpret_cast<dbl2 *>(yout + r) = dbl2{sum0, sum1};
@@ -1439,10 +1473,10 @@ __device__ __forceinline__ void pair_chunk(const hipx_int m, const hipxPairPlan 
   }
 }
 
-template <int MODE, bool DOT, int NP, bool TRACE = false>
+template <int MODE, bool DOT, int NP, bool TRACE = false, int EPI = 0>
 __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nchunks, hipx_int chunks_per_xcd, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask,
                                                         int ntmpl, const hipxPairPlan plan, const double *__restrict__ x, const double *yin, double *yout, double *dotpart,
-                                                        unsigned long long *tq, unsigned long long launch, long long pf_off, int tg, unsigned long long *trace = nullptr)
+                                                        unsigned long long *tq, unsigned long long launch, long long pf_off, int tg, unsigned long long *trace = nullptr, const hipxPairEpi epi = hipxPairEpi{})
 {
   __shared__ unsigned int s_mask[256];
   __shared__ int          s_pe[16], s_ph[16];  // per pair: its offset e; bit 0 / 1: it has an entry at e - 1 / e + 1 (the edge load's per-lane table)
@@ -1491,7 +1525,7 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
       const long long cn   = same ? ci + 1 : tk1 * tg;
       idn = (same || tk1 < nloc) ? (unsigned)tid2[((long long)(c0 + cn) * 512 + 2 * t) >> 1] : 0u;
     }
-    pair_chunk<MODE, DOT, NP>(m, plan, x, yin, yout, dotpart, s_mask, s_pe, s_ph, c, t, lane, wv, id2);
+    pair_chunk<MODE, DOT, NP, EPI>(m, plan, x, yin, yout, dotpart, s_mask, s_pe, s_ph, c, t, lane, wv, id2, epi);
     if (TRACE) ts[1] = ts[2] = wall_clock64();
     sink += (__double_as_longlong(pf) == 0x7ff8123456789abcLL) ? 1u : 0u;  // consume the previous pass's prefetch
     if (pf_off && t < 32) {
@@ -1535,10 +1569,10 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
 
 // rows [row0, m) of a template matrix, one row per thread and pass (the partial last chunk of spmv_pair_kernel): the row's own
 // template from the global tables; dot partials in the layout of the chunked kernels (4 per chunk of 512 rows: rows t, t + 256)
-template <int MODE, bool DOT>
+template <int MODE, bool DOT, int EPI = 0>
 __global__ __launch_bounds__(256) void spmv_tmpl_tail_kernel(hipx_int m, hipx_int row0, hipx_int chunk, const unsigned char *__restrict__ tid, const int *__restrict__ tstart,
                                                              const int *__restrict__ toff, const double *__restrict__ tval, const double *__restrict__ x, const double *yin, double *yout,
-                                                             double *dotpart)
+                                                             double *dotpart, const hipxPairEpi epi = hipxPairEpi{})
 {
   double cdot = 0.0;
   for (int rr = 0; rr < 2; rr++) {
@@ -1547,6 +1581,13 @@ __global__ __launch_bounds__(256) void spmv_tmpl_tail_kernel(hipx_int m, hipx_in
       const int id = tid[row];
       double    sum = (MODE == 1) ? yin[row] : 0.0;
       for (int k = tstart[id]; k < tstart[id + 1]; k++) sum += tval[k] * x[row + toff[k]];
+      if (EPI == 1) {
+        const double r0 = epi.b[row] - sum, z0 = epi.dinv ? r0 * epi.dinv[row] : r0, xp = epi.pprev[row], xc = x[row];
+        if (epi.br == 0) sum = xp + epi.beta * xc + epi.gamma * z0;
+        else if (epi.br == 1) sum = epi.alpha * xp + epi.beta * xc + z0;
+        else if (epi.br == 2) sum = epi.alpha * xp + epi.beta * xc;
+        else sum = epi.alpha * xp + epi.beta * xc + epi.gamma * z0;
+      }
       yout[row] = sum;
       if (DOT) cdot += x[row] * sum;
     }
@@ -2271,6 +2312,10 @@ int tmpl_blocks()
   return v;
 }
 
+// hipxMatMultChebyshev: the epilogue the next pair-form launch (MODE 0, no dot) applies; g_epi_done tells the caller it did
+static hipxPairEpi g_epi;
+static bool        g_epi_on = false, g_epi_done = false;
+
 template <int MODE, bool DOT>
 int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart, hipx_int *npart)
 {
@@ -2288,7 +2333,8 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
   static const bool nopair = getenv("HIPX_TMPL_NOPAIR") != nullptr;
   static const int  pair_maxp = getenv("HIPX_TMPL_PAIRMAX") ? atoi(getenv("HIPX_TMPL_PAIRMAX")) : 16;  // most pairs a base template may have for the pair form
   static const int  probe0 = getenv("HIPX_TMPL_PROBE") ? atoi(getenv("HIPX_TMPL_PROBE")) : 0;
-  const bool     vec_aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(yout) | (MODE == 1 ? reinterpret_cast<uintptr_t>(yin) : (uintptr_t)0)) & 15) == 0;
+  const bool     vec_aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(yout) | (MODE == 1 ? reinterpret_cast<uintptr_t>(yin) : (uintptr_t)0) |
+                                 ((MODE == 0 && !DOT && g_epi_on) ? (reinterpret_cast<uintptr_t>(g_epi.b) | reinterpret_cast<uintptr_t>(g_epi.pprev) | reinterpret_cast<uintptr_t>(g_epi.dinv)) : (uintptr_t)0)) & 15) == 0;
   const bool     use_pair = A->pair_ok && A->pair_plan.npairs <= pair_maxp && tbase >= 0 && !nopair && !probe0 && cfg == 1 && vec_aligned && m >= 512 && A->ntmpl <= 256;
   if (use_pair) nchunks = m / 512;
   hipx_int       grid = std::min<hipx_int>((hipx_int)((tmpl_blocks() + 7) / 8 * 8), ((nchunks + 7) / 8) * 8);
@@ -2325,6 +2371,23 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
     // one chunk per ticket while the slabs are short, two on large matrices
     static const int tg_env = getenv("HIPX_TMPL_TG") ? atoi(getenv("HIPX_TMPL_TG")) : 0;
     const int        tg = (tg_env == 1 || tg_env == 2 || tg_env == 4 || tg_env == 8) ? tg_env : (nchunks > 49152 ? 2 : 1);
+    if (MODE == 0 && !DOT && g_epi_on) {  // SpMV + Chebyshev step in one kernel
+      if constexpr (MODE == 0 && !DOT) {
+        if (A->pair_plan.npairs <= 8)
+          spmv_pair_kernel<0, false, 8, false, 1><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, tg, nullptr, g_epi);
+        else if (A->pair_plan.npairs <= 12)
+          spmv_pair_kernel<0, false, 12, false, 1><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, tg, nullptr, g_epi);
+        else
+          spmv_pair_kernel<0, false, 16, false, 1><<<(unsigned)grid, 256, 0, rt().compute>>>(m, nchunks, cpx, A->d_tid, A->d_tmask, A->ntmpl, A->pair_plan, x, yin, yout, dotpart, A->d_tq, launch, pf_off, tg, nullptr, g_epi);
+        HIPX_LAUNCH_CHECK();
+        if (nchunks * 512 < m) {
+          spmv_tmpl_tail_kernel<0, false, 1><<<1, 256, 0, rt().compute>>>(m, nchunks * 512, nchunks, A->d_tid, A->d_tstart, A->d_toff, A->d_tval, x, yin, yout, dotpart, g_epi);
+          HIPX_LAUNCH_CHECK();
+        }
+        g_epi_done = true;
+        return HIPX_SUCCESS;
+      }
+    }
     static const bool tracing = getenv("HIPX_TMPL_TRACE") != nullptr;
     if (tracing) {  // developer timing: passes of workgroups 8 and 1032 (start, issued, loads back, stored, barrier 1, barrier 2; 10 ns ticks) on stderr
       static unsigned long long *d_tr = nullptr;
@@ -2982,6 +3045,25 @@ int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
   }
   snprintf(buf, len, "%s", name);
   return HIPX_SUCCESS;
+}
+
+// replaces one iteration of KSPSolve_Chebyshev_FirstKind (cheby.c:475-511 with PCJACOBI / PCNONE, no norm): pnext = alpha pprev + beta pcur +
+// gamma (dinv .* (b - A pcur)) -- ONE kernel when the matrix takes the pair form (the Chebyshev step as the SpMV's epilogue: the current
+// iterate is the walk's diagonal pair, so the kernel adds three streams to the SpMV's and stores pnext instead of A pcur), else the
+// SpMV followed by hipxVecChebyshevStep in place.  Element by element the operations of the reference's loops: bit-identical.
+int hipxMatMultChebyshev(hipxMat A, const double *pcur, double *pnext, double alpha, double beta, double gamma, const double *pprev, const double *dinv, const double *b)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A && !A->compressed && A->m == A->n && (A->m == 0 || (pcur && pnext && pprev && b)), "null argument / not a square uncompressed matrix");
+  HIPX_ARG(pcur != pnext && pprev != pnext, "the three iterates must be different vectors");
+  if (!A->m) return HIPX_SUCCESS;
+  g_epi      = hipxPairEpi{b, dinv, pprev, alpha, beta, gamma, (alpha == 1.0) ? 0 : ((gamma == 1.0) ? 1 : ((gamma == 0.0) ? 2 : 3))};
+  g_epi_on   = true;
+  g_epi_done = false;
+  int ierr   = launch_spmv<0, false>(A, pcur, nullptr, pnext, nullptr);
+  g_epi_on   = false;
+  if (!ierr && !g_epi_done) ierr = hipxVecChebyshevStep(pnext, alpha, beta, gamma, pprev, pcur, dinv, b, pnext, nullptr, A->m);  // (A pcur sits in pnext: in place)
+  return ierr;
 }
 
 int hipxMatMult(hipxMat A, const double *x, double *y)

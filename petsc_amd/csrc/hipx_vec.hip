@@ -896,8 +896,8 @@ int hipx::launch_cg_fused_nosignal(double *x, double *r, double *z, const double
 // and 1 write instead of 7 and 3, one launch instead of three.
 namespace {
 template <int BR, bool JAC, bool ROUT>
-__global__ __launch_bounds__(256) void cheby_step_kernel(double *__restrict__ pn, double a, double b, double c, const double *__restrict__ pp, const double *__restrict__ pc,
-                                                         const double *__restrict__ dinv, const double *__restrict__ rhs, const double *__restrict__ Ap, double *__restrict__ rout, hipx_int n)
+__global__ __launch_bounds__(256) void cheby_step_kernel(double *pn, double a, double b, double c, const double *__restrict__ pp, const double *__restrict__ pc,
+                                                         const double *__restrict__ dinv, const double *__restrict__ rhs, const double *Ap, double *__restrict__ rout, hipx_int n)  // (Ap may be pn: in place)
 {
   for (hipx_int i = (hipx_int)blockIdx.x * 256 + threadIdx.x; i < n; i += (hipx_int)gridDim.x * 256) {
     const double r = rhs[i] - Ap[i];

@@ -558,12 +558,17 @@ int HipxKSPSolve_Chebyshev(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B
     for (i = 1; i < ksp->max_it; i++) { /* cheby.c:470-517 */
       int ktmp;
       ksp->its++;
-      CCHK(HipxMatMult(A, p[k], r));
-      if (fast) {
+      if (fast && A->nranks == 1) { /* one kernel: the step as the SpMV's epilogue (hipxMatMultChebyshev) */
+        c[kp1] = 2.0 * mu * c[k] - c[km1];
+        omega  = omegaprod * c[k] / c[kp1];
+        CCHK(hipxMatMultChebyshev(A->A, p[k], p[kp1], 1.0 - omega, omega, omega * Gamma * scale, p[km1], pc->type == HIPX_PC_JACOBI ? pc->dinv : NULL, B));
+      } else if (fast) {
+        CCHK(HipxMatMult(A, p[k], r));
         c[kp1] = 2.0 * mu * c[k] - c[km1];
         omega  = omegaprod * c[k] / c[kp1];
         CCHK(hipxVecChebyshevStep(p[kp1], 1.0 - omega, omega, omega * Gamma * scale, p[km1], p[k], pc->type == HIPX_PC_JACOBI ? pc->dinv : NULL, B, r, NULL, n));
       } else {
+        CCHK(HipxMatMult(A, p[k], r));
         CCHK(hipxVecAYPX(r, -1.0, B, n));
         if (ksp->normtype) {
           if (ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED) {
