@@ -525,3 +525,33 @@ def test_pair_form_of_the_template_kernel_bit_exact(hx, kind, n, m):
     _lib.mat_destroy(A)
     for v in (X, Y, Y0, Xs, Ys):
         v.free()
+
+
+@pytest.mark.parametrize("kind,n", [("7pt", 33), ("7pt", 24), ("27pt", 16), ("27pt", 13)])
+def test_pair_form_chebyshev_epilogue(hx, kind, n):
+    """hipxMatMultChebyshev (SpMV + the Chebyshev recurrence in one kernel) against hipxMatMult + hipxVecChebyshevStep: bit for bit (same
+    operations in the same order per element; the row sums are those of hipxMatMult); the four association orders of VecAXPBYPCZ_Seq,
+    PCJACOBI and PCNONE, odd and even vector lengths."""
+    from petsc_amd import _lib
+    rng = np.random.default_rng(11)
+    ai, aj, aa = orc.stencil(kind, n)
+    N = len(ai) - 1
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    if not kernel_name(hx, A).startswith("spmv_pair_kernel "):
+        _lib.mat_destroy(A)
+        pytest.skip("matrix does not take the pair form: " + kernel_name(hx, A))
+    null = C.c_void_p()
+    bvec, dinv, pk, po = rng.standard_normal(N), 1.0 / (1.0 + rng.random(N)), rng.standard_normal(N), rng.standard_normal(N)
+    Bv, D, PK, PP, PNx, R, Y = _lib.DVec(N, bvec), _lib.DVec(N, dinv), _lib.DVec(N, pk), _lib.DVec(N, po), _lib.DVec(N), _lib.DVec(N), _lib.DVec(N)
+    for al, be, ga in [(1.0, 0.0, 0.7), (0.8, 1.7, 1.0), (0.8, 1.7, 0.0), (0.9, 1.3, 0.6)]:
+        for use_d in (1, 0):
+            dp = D.ptr if use_d else null
+            _lib.chk(hx.hipxMatMultChebyshev(A, PK.ptr, PNx.ptr, C.c_double(al), C.c_double(be), C.c_double(ga), PP.ptr, dp, Bv.ptr))
+            got_p = PNx.get()
+            _lib.chk(hx.hipxMatMult(A, PK.ptr, Y.ptr))
+            _lib.chk(hx.hipxVecChebyshevStep(PNx.ptr, C.c_double(al), C.c_double(be), C.c_double(ga), PP.ptr, PK.ptr, dp, Bv.ptr, Y.ptr, R.ptr, N))
+            assert np.array_equal(got_p, PNx.get())
+            assert np.array_equal(R.get(), bvec - orc.matmult(ai, aj, aa, pk))
+    for v in (Bv, D, PK, PP, PNx, R, Y):
+        v.free()
+    _lib.mat_destroy(A)
