@@ -527,19 +527,19 @@ def test_pair_form_of_the_template_kernel_bit_exact(hx, kind, n, m):
         v.free()
 
 
-@pytest.mark.parametrize("kind,n", [("7pt", 33), ("7pt", 24), ("27pt", 16), ("27pt", 13)])
-def test_pair_form_chebyshev_epilogue(hx, kind, n):
+@pytest.mark.parametrize("kind,n,m", [("7pt", 24, None), ("7pt", 18, 11), ("27pt", 16, None), ("5pt", 50, None), ("7pt", 15, None)])
+def test_pair_form_chebyshev_epilogue(hx, kind, n, m):
     """hipxMatMultChebyshev (SpMV + the Chebyshev recurrence in one kernel) against hipxMatMult + hipxVecChebyshevStep: bit for bit (same
     operations in the same order per element; the row sums are those of hipxMatMult); the four association orders of VecAXPBYPCZ_Seq,
-    PCJACOBI and PCNONE, odd and even vector lengths."""
+    PCJACOBI and PCNONE; row counts that are not multiples of the 512-row chunk (tail kernel); a grid with odd lines (two kernels)."""
     from petsc_amd import _lib
     rng = np.random.default_rng(11)
-    ai, aj, aa = orc.stencil(kind, n)
+    ai, aj, aa = orc.stencil(kind, n, m=m)
     N = len(ai) - 1
     A = _lib.mat_create_csr(N, N, ai, aj, aa)
-    if not kernel_name(hx, A).startswith("spmv_pair_kernel "):
-        _lib.mat_destroy(A)
-        pytest.skip("matrix does not take the pair form: " + kernel_name(hx, A))
+    _lib.chk(hx.hipxMatSetSpMVVariant(A, 26))
+    name = kernel_name(hx, A)
+    assert is_template_kernel(name) and (n % 2 or name.startswith("spmv_pair_kernel ")), name  # (odd lines: pair form with more pairs, or two kernels)
     null = C.c_void_p()
     bvec, dinv, pk, po = rng.standard_normal(N), 1.0 / (1.0 + rng.random(N)), rng.standard_normal(N), rng.standard_normal(N)
     Bv, D, PK, PP, PNx, R, Y = _lib.DVec(N, bvec), _lib.DVec(N, dinv), _lib.DVec(N, pk), _lib.DVec(N, po), _lib.DVec(N), _lib.DVec(N), _lib.DVec(N)
