@@ -203,6 +203,8 @@ int hipxMatGetSORMode(hipxMat A, int *mode);
    24 / 25 = 22 / 23 plus the value dictionary (falls back to 22 / 23 when the dictionary does not fit);
    26 = row templates: a matrix whose rows are <= 256 distinct (column - row, value) sequences (stencil operators in natural
    ordering) is stored as one template id per row (falls back to 25).  Auto picks 26 when the dictionary exists.
+   30 = 26 with the march form of the template kernel (three planes of x resident in LDS) whenever the base template has that shape,
+   however few workgroups that gives (auto and 26 take it from 192 workgroups on).
    Every variant produces the bit-identical y (same products, same left-to-right row sums as aij.c:1486-1494). */
 int hipxMatSetSpMVVariant(hipxMat A, int variant);
 /* name of the kernel the next hipxMatMult will launch (builds the packed formats if they are pending) */

@@ -34,6 +34,17 @@ using namespace hipx;
 // 0 the entry at e - 1 (row r takes the previous lane's second element, row r + 1 the pair's first), slot 2 the entry at e + 1 (row r
 // takes the second element, row r + 1 the next lane's first).  kb = the entry's index in the base template (its bit in the row
 // masks) or -1; pairs ascend in e, so slots 0, 1, 2 of pair 0, 1, ... is the entries' own (ascending-column) order.
+// March form of the template SpMV (spmv_march_kernel): the base template's offsets o_k = a_k S + b_k with a_k in {-1, 0, +1} (the 'plane' below,
+// the row's own plane, the plane above: S = the stride between them, e.g. n^2 for an n^3 grid in natural ordering) and |b_k| <= H.  A workgroup
+// owns the rows i0 ... i0 + L - 1 of every plane of its segment and marches through the planes keeping three of them (with H halo elements
+// either side) in LDS: every element of x is fetched ONCE per workgroup (plus halo) instead of once per entry.
+struct hipxMarchPlan {
+  int      ne, nlo, nmid;  // base template: entries [0, nlo) on the plane below, [nlo, nlo + nmid) on the own plane, the rest above (ascending columns)
+  int      S, H, L;        // plane stride (even), halo (even), rows per plane and workgroup
+  unsigned full;           // mask of all ne entries
+  int      b[32];
+  double   a[32];
+};
 struct hipxPairPlan {
   int    npairs, jdiag;
   int    jodd, eodd;  // jodd >= 0: some pair has entries at e - 1 / e + 1 (the kernel then loads the waves' edge elements); eodd: unused
@@ -97,6 +108,10 @@ struct hipxMat_s {
   int            tmpl_base = -1;
   bool           pair_ok = false;  // ... and the base template fits the pair form (<= 16 even-offset pairs)
   hipxPairPlan   pair_plan;
+  bool           march_ok = false;  // ... and its offsets split into three 'planes' S rows apart (march form, spmv_march_kernel)
+  hipxMarchPlan  march_plan;
+  bool           march_force = false;  // hipxMatSetSpMVVariant(30)
+  hipx_int       dot_npart_used = 0;  // dot partials the last fused template launch wrote when it was not the count dot_partials_count() gave (march form)
   int           *d_toff   = nullptr;  // column - row
   double        *d_tval   = nullptr;
   unsigned long long *d_tq = nullptr;   // chunk queue of the template kernel: one ticket counter per XCD (64 bytes apart), never reset
@@ -1567,6 +1582,228 @@ __global__ __launch_bounds__(256) void spmv_pair_kernel(hipx_int m, hipx_int nch
   if (sink == 0xffffffffu) yout[0] = pf;  // never true: keeps the prefetch loads alive
 }
 
+// Template SpMV, march form (hipxMarchPlan; sub-template matrices whose base template spans three planes S rows apart: the 3-D stencils in natural
+// ordering, S = n^2; 2-D ones with S = n).  The pair form fetches a row's operands entry by entry: 5 pair loads per two rows of the 7-point
+// operator, every one an L2 hit but every one a trip through the CU's L1-L2 request path -- 48 bytes per row against the 17 the format moves
+// from HBM -- and that path is what bounds it (round 3: every latency measure left it where it was, doubling the operand loads doubled its time).
+// Here a workgroup owns rows i0 ... i0 + L - 1 of EVERY plane of its segment and marches through the planes with three of them resident in
+// LDS (L + 2 H elements each: H = the largest in-plane offset): per plane step it loads the next plane's L + 2 H elements ONCE (16-byte
+// loads, a whole step ahead of their use, through registers), and every entry's operand is an LDS read.  (L + 2 H) / L * 8 + 8 + 1 bytes per
+// row through the L2 = 19-20.  Static work split (tiles x segments of planes, all resident at once: no tickets); segments start with two extra
+// plane loads.  Arithmetic per row: the base template's entries in ascending column order, entries a row does not have skipped (template
+// mask), product and sum rounded separately -- the bits of MatMult_SeqAIJ (aij.c:1486-1494).  The dot partial is per workgroup and wave
+// (static split: deterministic).
+// NEMAX: the entries the loops are unrolled for; EXACT: the base template has exactly NEMAX entries (5 / 7 / 9 / 27: no test per entry -- with one,
+// every entry is its own basic block and waits for its own LDS reads)
+template <int MODE, bool DOT, int NEMAX, bool EXACT = false, bool TRACE = false>
+__global__ __launch_bounds__(256, 2) void spmv_march_kernel(hipx_int m, const hipxMarchPlan plan, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask, int ntmpl,
+                                                         const double *__restrict__ x, const double *yin, double *yout, double *dotpart, int tiles, int nseg, int pps, int nplanes, int xcdmap,
+                                                         unsigned long long *trace = nullptr)
+{
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *sb = reinterpret_cast<double *>(smem);  // three plane buffers of W doubles
+  __shared__ unsigned int s_mask[256];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int S = plan.S, H = plan.H, L = plan.L, W = L + 2 * H, W2 = W >> 1;
+  for (int k = t; k < ntmpl; k += 256) s_mask[k] = tmask[k];
+  const int units = tiles * nseg;
+  int       u = (int)blockIdx.x;
+  if (xcdmap) u = ((int)blockIdx.x & 7) * (units >> 3) + ((int)blockIdx.x >> 3);  // an XCD's workgroups: neighbouring tiles (they share halos through its L2)
+  const int tj = u % tiles, seg = u / tiles;
+  const int i0 = tj * L, Lw = (S - i0 < L) ? S - i0 : L;
+  const int k0 = seg * pps, k1 = (k0 + pps < nplanes) ? k0 + pps : nplanes;
+  double    acc = 0.0;
+  // the base template's values and in-plane offsets in VECTOR registers (every lane the same value): as scalars they do not fit (27 entries =
+  // 81 SGPRs), the compiler re-fetches them with scalar loads, and a scalar load's wait (lgkmcnt(0): SMEM returns out of order) also
+  // drains every LDS read in flight -- the entry loop below then runs one LDS latency per entry.  This kernel has registers to spare
+  // (LDS limits it to two workgroups per CU).
+  double av[NEMAX];
+  int    bv2[(NEMAX + 1) / 2];  // two 16-bit offsets per register (|b| <= H <= 1040)
+#pragma unroll
+  for (int e = 0; e < NEMAX; e++) {
+    int lo = 0, hi = 0;
+    if (EXACT || e < plan.ne) {
+      lo = __double2loint(plan.a[e]);
+      hi = __double2hiint(plan.a[e]);
+    }
+    int vlo, vhi;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vlo) : "s"(lo));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vhi) : "s"(hi));
+    av[e] = __hiloint2double(vhi, vlo);
+  }
+#pragma unroll
+  for (int e = 0; e < NEMAX; e += 2) {
+    const int b0 = (EXACT || e < plan.ne) ? plan.b[e] : 0, b1 = (e + 1 < NEMAX && (EXACT || e + 1 < plan.ne)) ? plan.b[e + 1 < 32 ? e + 1 : 31] : 0;
+    const int pk = (b0 & 0xffff) | (b1 << 16);
+    int       vb;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vb) : "s"(pk));
+    bv2[e >> 1] = vb;
+  }
+  // Every memory instruction of the plane loop is issued UNCONDITIONALLY (clamped addresses, the value selected afterwards) and in a fixed
+  // order per step -- y of the plane before, the next plane's template ids, then the plane loads: a wave's memory operations retire in
+  // order, so a wait for one load is a wait for everything issued before it, and the compiler can only count what is certain to have
+  // been issued after it.  With this order the wait on plane k + 1 (issued two steps before) leaves the loads of plane k + 2 in flight.
+  constexpr int NLD = 7;  // 16-byte loads per thread and plane: W <= 3584
+  constexpr int NQ  = 8;  // rows per thread and plane step (L <= 2048)
+  dbl2          R0[NLD], R1[NLD];             // planes in flight: two steps ahead of their use
+  unsigned char id0[NQ], id1[NQ];             // template ids of this thread's rows, one step ahead
+  const auto load_plane = [&](int p, dbl2 (&R)[NLD]) {
+    const long long g0 = (long long)p * S + i0 - H;  // even: S, L, H are (m too: the launcher sees to it)
+#pragma unroll
+    for (int q = 0; q < NLD; q++) {
+      const int       idx = q * 256 + t;
+      const long long g   = g0 + 2 * (long long)(idx < W2 ? idx : W2 - 1);
+      const bool      in  = g >= 0 && g < (long long)m;
+      const dbl2      v   = *reinterpret_cast<const dbl2 *>(x + (in ? g : 0));
+      R[q].x = in ? v.x : 0.0;
+      R[q].y = in ? v.y : 0.0;
+    }
+  };
+  const auto store_plane = [&](int slot, const dbl2 (&R)[NLD]) {
+    dbl2 *d = reinterpret_cast<dbl2 *>(sb + (size_t)slot * W);
+#pragma unroll
+    for (int q = 0; q < NLD; q++) {
+      const int idx = q * 256 + t;
+      if (idx < W2) d[idx] = R[q];
+    }
+  };
+  // thread t's row of group q (rows q * 256 ... + 255 of the tile): rotated by 32 + 64 (q / 2).  The rows that lack entries come in adjacent
+  // pairs (last point of a grid line, first point of the next); unrotated they would sit in the same one or two waves for every group (256-
+  // point lines: lanes 0 and 255, waves 0 and 3 in all eight groups), and a wave with such a row takes the select path below, twice the
+  // instructions -- the whole workgroup then runs at that wave's pace.  Rotated, each wave meets them in one pair of groups out of four.
+  int pq[NQ / 2];
+#pragma unroll
+  for (int j = 0; j < NQ / 2; j++) pq[j] = (t + 32 + 64 * j) & 255;
+  const auto load_ids = [&](int p, unsigned char (&ids)[NQ]) {
+    const long long rb = (long long)p * S + i0;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int i = q * 256 + pq[q >> 1];
+      ids[q] = tid[(i < Lw && rb + i < (long long)m) ? rb + i : 0];
+    }
+  };
+  double    sprev[NQ];
+  unsigned  mprev[NQ];
+  long long rbprev = 0;
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    sprev[q] = 0.0;
+    mprev[q] = 0u;
+  }
+  int s_lo = 0, s_mid = 1, s_hi = 2;
+  load_ids(k0, id0);
+  load_plane(k0 - 1, R0);
+  load_plane(k0, R1);
+  store_plane(s_lo, R0);
+  store_plane(s_mid, R1);
+  load_plane(k0 + 1, R0);
+  load_plane(k0 + 2, R1);
+  __syncthreads();
+  // one plane step: RA holds plane k + 1 (loaded two steps ago), idc the ids of plane k; plane k + 3 goes into RA, the ids of plane k + 1 into idn
+  const auto step = [&](int k, dbl2 (&RA)[NLD], const unsigned char (&idc)[NQ], unsigned char (&idn)[NQ]) {
+    unsigned long long ts[6];
+    if (TRACE) ts[0] = wall_clock64();
+    store_plane(s_hi, RA);
+    if (TRACE) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ts[1] = wall_clock64();
+    }
+    __syncthreads();
+    if (TRACE) ts[2] = wall_clock64();
+    if (k > k0) {  // y of the plane before: the stores have this whole step to complete
+#pragma unroll
+      for (int q = 0; q < NQ; q++)
+        if (mprev[q]) yout[rbprev + q * 256 + pq[q >> 1]] = sprev[q];
+    }
+    load_ids(k + 1, idn);
+    load_plane(k + 3, RA);
+    if (TRACE) ts[3] = wall_clock64();
+    const long long rowbase = (long long)k * S + i0;
+    const double   *plo = sb + (size_t)s_lo * W + H, *pmid = sb + (size_t)s_mid * W + H, *phi = sb + (size_t)s_hi * W + H;
+    double          sum[NQ];
+    unsigned        mk[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int       i = q * 256 + pq[q >> 1];
+      const long long row = rowbase + i;
+      const bool      valid = i < Lw && row < (long long)m;
+      mk[q]  = valid ? s_mask[idc[q]] : 0u;
+      sum[q] = (MODE == 1 && valid) ? yin[row] : 0.0;
+    }
+    // two groups (128 rows of this wave) at a time, entry by entry: 2 independent sums, every LDS read issued unconditionally.  All 128 rows
+    // interior rows: product and sum per entry.  Otherwise the select form: a row that lacks the entry keeps its sum (the product is formed
+    // and dropped -- the bits of skipping it); the asm statement pins the read outside any branch (left alone the compiler turns the select
+    // back into a branch around read + multiply + add per row and entry: one LDS latency each, measured 3.8 us per step for 7 entries).
+#pragma unroll
+    for (int j = 0; j < NQ / 2; j++) {
+      if (2 * j * 256 < L) {  // (L = 1024: the buffers end after four groups)
+        const int  q0 = 2 * j, q1 = 2 * j + 1;
+        const bool uni = __builtin_amdgcn_ballot_w64(((mk[q0] ^ plan.full) | (mk[q1] ^ plan.full)) != 0u) == 0ull;
+        if (uni) {
+#pragma unroll
+          for (int e = 0; e < NEMAX; e++) {
+            if (EXACT || e < plan.ne) {
+              const double *pb = ((e < plan.nlo) ? plo : ((e < plan.nlo + plan.nmid) ? pmid : phi)) + ((e & 1) ? (bv2[e >> 1] >> 16) : ((bv2[e >> 1] << 16) >> 16)) + pq[j];
+              const double  a  = av[e];
+              sum[q0] += a * pb[q0 * 256];
+              sum[q1] += a * pb[q1 * 256];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < NEMAX; e++) {
+            if (EXACT || e < plan.ne) {
+              const double *pb = ((e < plan.nlo) ? plo : ((e < plan.nlo + plan.nmid) ? pmid : phi)) + ((e & 1) ? (bv2[e >> 1] >> 16) : ((bv2[e >> 1] << 16) >> 16)) + pq[j];
+              const double  a  = av[e];
+              double        x0 = pb[q0 * 256], x1 = pb[q1 * 256];
+              asm volatile("" : "+v"(x0), "+v"(x1));
+              const double t0 = sum[q0] + a * x0, t1 = sum[q1] + a * x1;
+              sum[q0] = ((mk[q0] >> e) & 1u) ? t0 : sum[q0];
+              sum[q1] = ((mk[q1] >> e) & 1u) ? t1 : sum[q1];
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      if (DOT && mk[q]) acc += pmid[q * 256 + pq[q >> 1]] * sum[q];  // (every existing row has its diagonal entry: mk != 0)
+      sprev[q] = sum[q];
+      mprev[q] = mk[q];
+    }
+    rbprev = rowbase;
+    if (TRACE) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ts[4] = wall_clock64();
+    }
+    __syncthreads();
+    if (TRACE) {
+      ts[5] = wall_clock64();
+      if (trace && t == 0 && (blockIdx.x == 8 || blockIdx.x == 301) && k - k0 < 40) {
+        unsigned long long *o = trace + ((blockIdx.x == 8 ? 0 : 40) + (k - k0)) * 8;
+        for (int q = 0; q < 6; q++) o[q] = ts[q];
+        o[6] = (unsigned long long)k;
+      }
+    }
+    const int o = s_lo;
+    s_lo  = s_mid;
+    s_mid = s_hi;
+    s_hi  = o;
+  };
+  for (int k = k0; k < k1; k += 2) {
+    step(k, R0, id0, id1);
+    if (k + 1 < k1) step(k + 1, R1, id1, id0);
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; q++)
+    if (mprev[q]) yout[rbprev + q * 256 + pq[q >> 1]] = sprev[q];
+  if (DOT) {
+    const double w = hipx::wave_sum(acc);
+    if (lane == 0) dotpart[(size_t)blockIdx.x * 4 + wv] = w;
+  }
+}
+
 // rows [row0, m) of a template matrix, one row per thread and pass (the partial last chunk of spmv_pair_kernel): the row's own
 // template from the global tables; dot partials in the layout of the chunked kernels (4 per chunk of 512 rows: rows t, t + 256)
 template <int MODE, bool DOT, int EPI = 0>
@@ -2003,6 +2240,7 @@ void free_templates(hipxMat A)
   A->d_tmask   = nullptr;
   A->tmpl_base = -1;
   A->pair_ok   = false;
+  A->march_ok  = false;
   A->d_tq = nullptr;
   A->tq_launches = 0;
   A->tq_geom = -1;
@@ -2194,6 +2432,49 @@ int build_templates(hipxMat A)
           }
       }
       A->pair_ok = pok;
+      // march plan (hipxMarchPlan): split the ascending offsets at the largest gap on either side of the diagonal
+      {
+        hipxMarchPlan &mp = A->march_plan;
+        memset(&mp, 0, sizeof(mp));
+        A->march_ok = false;
+        int kd = -1;
+        for (int k = 0; k < len0; k++)
+          if (A->h_toff[(size_t)b0 + k] == 0) kd = k;
+        int cutlo = -1, cuthi = -1;  // entries [0, cutlo] below, [cuthi, len0) above
+        long long glo = 0, ghi = 0;
+        for (int k = 0; k + 1 <= kd; k++) {
+          const long long g = (long long)A->h_toff[(size_t)b0 + k + 1] - A->h_toff[(size_t)b0 + k];
+          if (g > glo) { glo = g; cutlo = k; }
+        }
+        for (int k = kd; k + 1 < len0; k++) {
+          const long long g = (long long)A->h_toff[(size_t)b0 + k + 1] - A->h_toff[(size_t)b0 + k];
+          if (g > ghi) { ghi = g; cuthi = k + 1; }
+        }
+        if (kd >= 0 && cutlo >= 0 && cuthi >= 0 && len0 <= 32) {
+          const long long lo0 = A->h_toff[(size_t)b0], lo1 = A->h_toff[(size_t)b0 + cutlo], hi0 = A->h_toff[(size_t)b0 + cuthi], hi1 = A->h_toff[(size_t)b0 + len0 - 1];
+          const long long S = (hi0 + hi1) / 2;
+          long long       H = 0;
+          bool            ok = (hi0 + hi1) % 2 == 0 && lo0 + lo1 == -(hi0 + hi1) && S % 2 == 0 && S >= 1024;
+          for (int k = 0; k < len0 && ok; k++) {
+            const long long o = A->h_toff[(size_t)b0 + k], a = k <= cutlo ? -1 : (k >= cuthi ? 1 : 0), b = o - a * S;
+            H       = std::max(H, b < 0 ? -b : b);
+            mp.b[k] = (int)b;
+            mp.a[k] = A->h_tval[(size_t)b0 + k];
+          }
+          H = (H + 1) & ~1ll;
+          if (ok && 2 * H < S && H <= 1040) {
+            mp.ne    = len0;
+            mp.nlo   = cutlo + 1;
+            mp.nmid  = cuthi - cutlo - 1;
+            mp.S     = (int)S;
+            mp.H     = (int)H;
+            mp.L     = (S / 2048 >= 16) ? 2048 : 1024;
+            if (getenv("HIPX_TMPL_MARCH_L")) mp.L = atoi(getenv("HIPX_TMPL_MARCH_L")) == 1024 ? 1024 : 2048;  // (developer switch)
+            mp.full  = len0 == 32 ? 0xffffffffu : ((1u << len0) - 1u);
+            A->march_ok = true;
+          }
+        }
+      }
     }
   }
   return HIPX_SUCCESS;
@@ -2336,6 +2617,76 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
   const bool     vec_aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(yout) | (MODE == 1 ? reinterpret_cast<uintptr_t>(yin) : (uintptr_t)0) |
                                  ((MODE == 0 && !DOT && g_epi_on) ? (reinterpret_cast<uintptr_t>(g_epi.b) | reinterpret_cast<uintptr_t>(g_epi.pprev) | reinterpret_cast<uintptr_t>(g_epi.dinv)) : (uintptr_t)0)) & 15) == 0;
   const bool     use_pair = A->pair_ok && A->pair_plan.npairs <= pair_maxp && tbase >= 0 && !nopair && !probe0 && cfg == 1 && vec_aligned && m >= 512 && A->ntmpl <= 256;
+  if (DOT) A->dot_npart_used = 0;
+  // march form (spmv_march_kernel): three-plane base templates, 16-byte aligned x, enough tiles x segments to fill the chip
+  {
+    static const bool nomarch = getenv("HIPX_TMPL_NOMARCH") != nullptr;
+    static const int  units_env = getenv("HIPX_TMPL_MARCH_UNITS") ? atoi(getenv("HIPX_TMPL_MARCH_UNITS")) : 512;  // target number of workgroups (2 per CU resident)
+    const hipxMarchPlan &mp = A->march_plan;
+    if (A->march_ok && tbase >= 0 && !nomarch && !probe0 && cfg == 1 && !g_epi_on && A->ntmpl <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && m % 2 == 0) {
+      const int tiles   = (mp.S + mp.L - 1) / mp.L;
+      const int nplanes = (int)((m + mp.S - 1) / mp.S);
+      int       nseg    = std::max(1, std::min(nplanes / 4, (units_env + tiles / 2) / tiles));
+      const int pps     = (nplanes + nseg - 1) / nseg;
+      nseg              = (nplanes + pps - 1) / pps;
+      const int units   = tiles * nseg;
+      if ((units >= 192 || A->march_force) && (hipx_int)units <= nchunks && mp.ne <= 32) {
+        const size_t lds = 3 * (size_t)(mp.L + 2 * mp.H) * sizeof(double);
+        const int    xm  = (units % 8 == 0) ? 1 : 0;
+        if (DOT) A->dot_npart_used = (hipx_int)units * 4;
+#define HIPX_MARCH_LAUNCH(NE, EX)                                                                                                                                                      \
+  do {                                                                                                                                                                             \
+    static bool attr = false;                                                                                                                                                      \
+    if (!attr) {                                                                                                                                                                   \
+      HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_march_kernel<MODE, DOT, NE, EX>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                 \
+      attr = true;                                                                                                                                                                 \
+    }                                                                                                                                                                              \
+    spmv_march_kernel<MODE, DOT, NE, EX><<<(unsigned)units, 256, lds, rt().compute>>>(m, mp, A->d_tid, A->d_tmask, A->ntmpl, x, yin, yout, dotpart, tiles, nseg, pps, nplanes, xm); \
+  } while (0)
+        static const bool mtrace = getenv("HIPX_TMPL_TRACE") != nullptr;
+        if (mtrace && MODE == 0 && DOT) {  // developer timing: the steps of workgroups 8 and 301 (10 ns ticks) on stderr, twice
+          if constexpr (MODE == 0 && DOT) {
+            static unsigned long long *d_tr = nullptr;
+            static int                 nl = 0, dumps = 0;
+            if (!d_tr) HIPX_HIP(hipMalloc((void **)&d_tr, 80 * 8 * sizeof(unsigned long long)));
+            HIPX_HIP(hipMemsetAsync(d_tr, 0, 80 * 8 * sizeof(unsigned long long), rt().compute));
+            static bool attr2 = false;
+            if (!attr2) {
+              HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_march_kernel<0, true, 7, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+              HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_march_kernel<0, true, 27, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+              attr2 = true;
+            }
+            if (mp.ne != 7 && mp.ne != 27) return fail(HIPX_ERR_ARG, "HIPX_TMPL_TRACE: the march-form trace is built for 7 and 27 entries", __FILE__, __LINE__);
+            if (mp.ne == 7) spmv_march_kernel<0, true, 7, true, true><<<(unsigned)units, 256, lds, rt().compute>>>(m, mp, A->d_tid, A->d_tmask, A->ntmpl, x, yin, yout, dotpart, tiles, nseg, pps, nplanes, xm, d_tr);
+            else spmv_march_kernel<0, true, 27, true, true><<<(unsigned)units, 256, lds, rt().compute>>>(m, mp, A->d_tid, A->d_tmask, A->ntmpl, x, yin, yout, dotpart, tiles, nseg, pps, nplanes, xm, d_tr);
+            HIPX_LAUNCH_CHECK();
+            if (++nl >= 6 && dumps < 2) {
+              unsigned long long h[80 * 8];
+              HIPX_HIP(hipStreamSynchronize(rt().compute));
+              HIPX_HIP(hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost));
+              for (int w = 0; w < 2; w++)
+                for (int e = 0; e < 40 && h[(w * 40 + e) * 8]; e++) {
+                  const unsigned long long *o = h + (w * 40 + e) * 8;
+                  fprintf(stderr, "[hipx march trace] wg %3d plane %4llu start %8.2f us | wait+lds-store %5.2f barrier1 %5.2f issue %5.2f compute %5.2f barrier2 %5.2f | step %5.2f us\n", w ? 301 : 8, o[6],
+                          (o[0] - h[0]) / 100.0, (o[1] - o[0]) / 100.0, (o[2] - o[1]) / 100.0, (o[3] - o[2]) / 100.0, (o[4] - o[3]) / 100.0, (o[5] - o[4]) / 100.0, (o[5] - o[0]) / 100.0);
+                }
+              dumps++;
+            }
+            return HIPX_SUCCESS;
+          }
+        }
+        if (mp.ne == 7) HIPX_MARCH_LAUNCH(7, true);
+        else if (mp.ne == 27) HIPX_MARCH_LAUNCH(27, true);
+        else if (mp.ne == 5) HIPX_MARCH_LAUNCH(5, true);
+        else if (mp.ne == 9) HIPX_MARCH_LAUNCH(9, true);
+        else if (mp.ne <= 8) HIPX_MARCH_LAUNCH(8, false);
+        else HIPX_MARCH_LAUNCH(32, false);
+#undef HIPX_MARCH_LAUNCH
+        HIPX_LAUNCH_CHECK();
+        return HIPX_SUCCESS;
+      }
+    }
+  }
   if (use_pair) nchunks = m / 512;
   hipx_int       grid = std::min<hipx_int>((hipx_int)((tmpl_blocks() + 7) / 8 * 8), ((nchunks + 7) / 8) * 8);
   if (grid < 8) grid = 8;
@@ -2972,6 +3323,9 @@ int hipxMatSetSpMVVariant(hipxMat A, int variant)
   variant %= 1000;
   // 22: packed columns, 23: packed columns + row-parallel gather, 24 / 25: the same two with the value dictionary
   // 26: row templates (falls back to 25 when the matrix has more than 256 distinct rows)
+  // 30: 26 with the march form of the template kernel whenever the base template has its three-plane shape (auto and 26 want >= 192 workgroups)
+  A->march_force = (variant == 30);
+  if (variant == 30) variant = 26;
   A->tile_mode = (variant == 22 || variant == 24) ? 2 : (variant == 23 || variant == 25 || variant == 26) ? 3 : 0;
   A->vd_mode   = (variant == 24 || variant == 25 || variant == 26) ? 1 : 0;
   A->tmpl_mode = (variant == 26) ? 1 : 0;
@@ -3003,6 +3357,20 @@ int hipxMatSetSpMVVariant(hipxMat A, int variant)
   return HIPX_SUCCESS;
 }
 
+// (what launch_tmpl decides for 16-byte aligned vectors)
+static bool march_applies(hipxMat A)
+{
+  if (!A->march_ok || A->tmpl_base < 0 || !A->d_tmask || A->nrows_c % 2 || getenv("HIPX_TMPL_NOMARCH") || getenv("HIPX_TMPL_NOSUB") || getenv("HIPX_TMPL_PROBE") || tmpl_cfg() != 1 || A->ntmpl > 256) return false;
+  const hipxMarchPlan &mp = A->march_plan;
+  const hipx_int       m = A->nrows_c;
+  const int            target = getenv("HIPX_TMPL_MARCH_UNITS") ? atoi(getenv("HIPX_TMPL_MARCH_UNITS")) : 512;
+  const int            tiles = (mp.S + mp.L - 1) / mp.L, nplanes = (int)((m + mp.S - 1) / mp.S);
+  int                  nseg = std::max(1, std::min(nplanes / 4, (target + tiles / 2) / tiles));
+  const int            pps = (nplanes + nseg - 1) / nseg;
+  nseg                     = (nplanes + pps - 1) / pps;
+  return (tiles * nseg >= 192 || A->march_force) && (hipx_int)(tiles * nseg) <= (m + 511) / 512;
+}
+
 int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
 {
   HIPX_CHECK_INIT();
@@ -3028,6 +3396,8 @@ int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
     if (ierr) return ierr;
   }
   if (sl) name = "spmv_sell_kernel (MatMult on the SELL-64 copy: one lane per row, 16-bit window-coded columns)";
+  else if (tm && march_applies(A))
+    name = "spmv_march_kernel (CSR MatMult, row templates: 1 byte per row; three planes of x resident in LDS, every operand an LDS read)";
   else if (tm && A->pair_ok && A->pair_plan.npairs <= (getenv("HIPX_TMPL_PAIRMAX") ? atoi(getenv("HIPX_TMPL_PAIRMAX")) : 16) && A->d_tmask && !getenv("HIPX_TMPL_NOSUB") && !getenv("HIPX_TMPL_NOPAIR") && !getenv("HIPX_TMPL_PROBE") && tmpl_cfg() == 1 && A->nrows_c >= 512)
     name = "spmv_pair_kernel (CSR MatMult, row templates: 1 byte per row; two consecutive rows per thread, 16-byte loads of x at the even offsets, +-1 entries from the neighbouring lanes)";
   else if (tm && A->d_tmask && !getenv("HIPX_TMPL_NOSUB")) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row; every template a subset of the interior one: uniform masked walk)";
@@ -3099,8 +3469,10 @@ static int matmultdot_launch(hipxMat A, const double *x, double *y, hipx_int *np
     HIPX_HIP(hipMalloc((void **)&A->d_dotpart, sizeof(double) * (size_t)npart));
     A->dotpart_cap = npart;
   }
-  *npart_out = npart;
-  return launch_spmv<0, true>(A, x, nullptr, y, A->d_dotpart);
+  A->dot_npart_used = 0;
+  int ierr = launch_spmv<0, true>(A, x, nullptr, y, A->d_dotpart);
+  *npart_out = A->dot_npart_used ? A->dot_npart_used : npart;  // (the march form of the template kernel writes one partial per workgroup and wave)
+  return ierr;
 }
 
 int hipxMatMultDot(hipxMat A, const double *x, double *y, double *dot)

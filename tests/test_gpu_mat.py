@@ -117,7 +117,7 @@ def test_value_dictionary_ragged_rows_bit_exact(hx, seed, m, n, maxlen, variant)
     _lib.mat_destroy(A)
 
 
-TEMPLATE_KERNELS = ("spmv_tmpl_kernel", "spmv_pair_kernel")  # row templates: the general walk, or the pair form (every row a subset of the interior row)
+TEMPLATE_KERNELS = ("spmv_tmpl_kernel", "spmv_pair_kernel", "spmv_march_kernel")  # row templates: the general walk, the pair form (every row a subset of the interior row), the march form (three-plane base rows)
 
 
 def is_template_kernel(name):
@@ -553,5 +553,64 @@ def test_pair_form_chebyshev_epilogue(hx, kind, n, m):
             assert np.array_equal(got_p, PNx.get())
             assert np.array_equal(R.get(), bvec - orc.matmult(ai, aj, aa, pk))
     for v in (Bv, D, PK, PP, PNx, R, Y):
+        v.free()
+    _lib.mat_destroy(A)
+
+
+def _leading_block(ai, aj, aa, M):
+    """Leading principal M x M block of a CSR matrix (rows near the cut lose their entries beyond it)."""
+    import scipy.sparse as sp
+    N = len(ai) - 1
+    B = sp.csr_matrix((aa, aj, ai), shape=(N, N))[:M, :M].tocsr()
+    B.sort_indices()
+    return B.indptr.astype(ai.dtype), B.indices.astype(aj.dtype), B.data.copy()
+
+
+@pytest.mark.parametrize("kind,n,m,cut", [("7pt", 32, None, 0), ("7pt", 40, None, 0), ("7pt_box", (34, 34, 9), None, 0), ("27pt", 34, None, 0), ("27pt", 36, None, 0), ("5pt", 1024, 40, 0),
+                                          ("5pt", 1500, 24, 0), ("7pt", 40, None, 1600 * 17 + 334), ("27pt", 34, None, 1156 * 9 + 2), ("7pt", 40, None, 1600 * 17 + 333)])
+def test_march_form_of_the_template_kernel_bit_exact(hx, kind, n, m, cut):
+    """spmv_march_kernel (variant 30: whenever the base template has the three-plane shape): planes of 1024 ... 2.25 M rows, one and several tiles
+    per plane (the last one partial), 7 / 27 / 5 entries, a row count that is not a multiple of the plane (leading block of a stencil
+    matrix), MatMult / MatMultAdd / fused dot, then vectors that are not 16-byte aligned (another template kernel takes over) -- y
+    bit-identical to MatMult_SeqAIJ every time, and the same bits as the pair form's."""
+    from petsc_amd import _lib
+    rng = np.random.default_rng(23)
+    ai, aj, aa = orc.stencil(kind, n, m=m)
+    if cut:
+        ai, aj, aa = _leading_block(ai, aj, aa, cut)
+    N = len(ai) - 1
+    x, y0 = rng.standard_normal(N), rng.standard_normal(N)
+    yr = orc.matmult(ai, aj, aa, x)
+    zr = np.zeros(N)
+    orc.lib().orc_MatMultAdd_SeqAIJ(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(y0), orc.P(zr))
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    _lib.chk(hx.hipxMatSetSpMVVariant(A, 30))
+    name = kernel_name(hx, A)
+    assert is_template_kernel(name) and name.startswith("spmv_march_kernel ") == (N % 2 == 0), name  # (an odd row count keeps the other template kernels)
+    X, Y, Y0 = _lib.DVec(N + 2, np.concatenate([x, [0.0, 0.0]])), _lib.DVec(N + 2), _lib.DVec(N + 2, np.concatenate([y0, [0.0, 0.0]]))
+    for _ in range(2):
+        Y.set(np.full(N + 2, np.nan))
+        _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+        assert np.array_equal(Y.get()[:N], yr)
+    _lib.chk(hx.hipxMatMultAdd(A, X.ptr, Y0.ptr, Y.ptr))
+    assert np.array_equal(Y.get()[:N], zr)
+    dot, dot2 = C.c_double(), C.c_double()
+    Y.set(np.full(N + 2, np.nan))
+    _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(dot)))
+    assert np.array_equal(Y.get()[:N], yr) and abs(dot.value - float(x @ yr)) <= 1e-12 * np.abs(x * yr).sum()
+    _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(dot2)))
+    assert dot2.value == dot.value  # deterministic (static split)
+    Xs, Ys = _lib.DVec(N + 2, np.concatenate([[0.0], x, [0.0]])), _lib.DVec(N + 2)   # x not 16-byte aligned: not the march form
+    _lib.chk(hx.hipxMatMult(A, Xs.offset(1), Ys.offset(1)))
+    assert np.array_equal(Ys.get()[1:N + 1], yr)
+    _lib.chk(hx.hipxMatMultDot(A, Xs.offset(1), Ys.offset(1), C.byref(dot2)))
+    assert np.array_equal(Ys.get()[1:N + 1], yr) and abs(dot2.value - dot.value) <= 1e-12 * np.abs(x * yr).sum()
+    _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(dot2)))
+    assert dot2.value == dot.value
+    _lib.chk(hx.hipxMatSetSpMVVariant(A, 26))  # the pair form (these sizes give too few workgroups for the march form): same bits
+    assert not kernel_name(hx, A).startswith("spmv_march_kernel ")
+    _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    assert np.array_equal(Y.get()[:N], yr)
+    for v in (X, Y, Y0, Xs, Ys):
         v.free()
     _lib.mat_destroy(A)
