@@ -1740,27 +1740,47 @@ __global__ __launch_bounds__(256, 2) void spmv_march_kernel(hipx_int m, const hi
       if (2 * j * 256 < L) {  // (L = 1024: the buffers end after four groups)
         const int  q0 = 2 * j, q1 = 2 * j + 1;
         const bool uni = __builtin_amdgcn_ballot_w64(((mk[q0] ^ plan.full) | (mk[q1] ^ plan.full)) != 0u) == 0ull;
-        if (uni) {
+        // entries in batches of EC: the batch's 2 EC LDS reads are issued together (the asm statements pin them there: left alone the compiler
+        // reuses one address and one destination register for every read, i.e. one LDS latency per entry), then the sums.  EC = 8, or 4 for
+        // the long templates (their 27 values and offsets already fill the register file: 8 spilled to scratch and cost more than it gained)
+        constexpr int EC = (NEMAX > 8) ? 4 : 8;
 #pragma unroll
-          for (int e = 0; e < NEMAX; e++) {
-            if (EXACT || e < plan.ne) {
+        for (int c0 = 0; c0 < NEMAX; c0 += EC) {
+          double xa[EC], xb[EC];
+#pragma unroll
+          for (int w = 0; w < EC; w++) {
+            const int e = c0 + w;
+            xa[w] = xb[w] = 0.0;
+            if (e < NEMAX && (EXACT || e < plan.ne)) {
               const double *pb = ((e < plan.nlo) ? plo : ((e < plan.nlo + plan.nmid) ? pmid : phi)) + ((e & 1) ? (bv2[e >> 1] >> 16) : ((bv2[e >> 1] << 16) >> 16)) + pq[j];
-              const double  a  = av[e];
-              sum[q0] += a * pb[q0 * 256];
-              sum[q1] += a * pb[q1 * 256];
+              xa[w] = pb[q0 * 256];
+              xb[w] = pb[q1 * 256];
             }
           }
-        } else {
+          if constexpr (EC == 8) {
+            asm volatile("" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xa[4]), "+v"(xa[5]), "+v"(xa[6]), "+v"(xa[7]) : : "memory");
+            asm volatile("" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3]), "+v"(xb[4]), "+v"(xb[5]), "+v"(xb[6]), "+v"(xb[7]));
+          } else {
+            asm volatile("" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3]) : : "memory");
+          }
+          if (uni) {
 #pragma unroll
-          for (int e = 0; e < NEMAX; e++) {
-            if (EXACT || e < plan.ne) {
-              const double *pb = ((e < plan.nlo) ? plo : ((e < plan.nlo + plan.nmid) ? pmid : phi)) + ((e & 1) ? (bv2[e >> 1] >> 16) : ((bv2[e >> 1] << 16) >> 16)) + pq[j];
-              const double  a  = av[e];
-              double        x0 = pb[q0 * 256], x1 = pb[q1 * 256];
-              asm volatile("" : "+v"(x0), "+v"(x1));
-              const double t0 = sum[q0] + a * x0, t1 = sum[q1] + a * x1;
-              sum[q0] = ((mk[q0] >> e) & 1u) ? t0 : sum[q0];
-              sum[q1] = ((mk[q1] >> e) & 1u) ? t1 : sum[q1];
+            for (int w = 0; w < EC; w++) {
+              const int e = c0 + w;
+              if (e < NEMAX && (EXACT || e < plan.ne)) {
+                sum[q0] += av[e] * xa[w];
+                sum[q1] += av[e] * xb[w];
+              }
+            }
+          } else {
+#pragma unroll
+            for (int w = 0; w < EC; w++) {
+              const int e = c0 + w;
+              if (e < NEMAX && (EXACT || e < plan.ne)) {
+                const double t0 = sum[q0] + av[e] * xa[w], t1 = sum[q1] + av[e] * xb[w];
+                sum[q0] = ((mk[q0] >> e) & 1u) ? t0 : sum[q0];
+                sum[q1] = ((mk[q1] >> e) & 1u) ? t1 : sum[q1];
+              }
             }
           }
         }
@@ -2462,14 +2482,15 @@ int build_templates(hipxMat A)
             mp.a[k] = A->h_tval[(size_t)b0 + k];
           }
           H = (H + 1) & ~1ll;
-          if (ok && 2 * H < S && H <= 1040) {
+          const int Lsel = (getenv("HIPX_TMPL_MARCH_L") ? atoi(getenv("HIPX_TMPL_MARCH_L")) == 1024 : S / 2048 < 16) ? 1024 : 2048;  // (HIPX_TMPL_MARCH_L: developer switch)
+          // three plane buffers of L + 2 H doubles, two workgroups per CU: <= 80 KiB (7-pt / 27-pt up to 680-point lines; longer lines keep the pair form)
+          if (ok && 2 * H < S && 3 * (size_t)(Lsel + 2 * H) * sizeof(double) <= 80 * 1024) {
             mp.ne    = len0;
             mp.nlo   = cutlo + 1;
             mp.nmid  = cuthi - cutlo - 1;
             mp.S     = (int)S;
             mp.H     = (int)H;
-            mp.L     = (S / 2048 >= 16) ? 2048 : 1024;
-            if (getenv("HIPX_TMPL_MARCH_L")) mp.L = atoi(getenv("HIPX_TMPL_MARCH_L")) == 1024 ? 1024 : 2048;  // (developer switch)
+            mp.L     = Lsel;
             mp.full  = len0 == 32 ? 0xffffffffu : ((1u << len0) - 1u);
             A->march_ok = true;
           }
