@@ -2451,7 +2451,7 @@ int build_templates(hipxMat A)
             pp.eodd = pp.e[j];
           }
       }
-      A->pair_ok = pok;
+      A->pair_ok = pok && A->m == A->n;  // (both forms bound their loads of x by the ROW count)
       // march plan (hipxMarchPlan): split the ascending offsets at the largest gap on either side of the diagonal
       {
         hipxMarchPlan &mp = A->march_plan;
@@ -2470,7 +2470,7 @@ int build_templates(hipxMat A)
           const long long g = (long long)A->h_toff[(size_t)b0 + k + 1] - A->h_toff[(size_t)b0 + k];
           if (g > ghi) { ghi = g; cuthi = k + 1; }
         }
-        if (kd >= 0 && cutlo >= 0 && cuthi >= 0 && len0 <= 32) {
+        if (kd >= 0 && cutlo >= 0 && cuthi >= 0 && len0 <= 32 && A->m == A->n) {
           const long long lo0 = A->h_toff[(size_t)b0], lo1 = A->h_toff[(size_t)b0 + cutlo], hi0 = A->h_toff[(size_t)b0 + cuthi], hi1 = A->h_toff[(size_t)b0 + len0 - 1];
           const long long S = (hi0 + hi1) / 2;
           long long       H = 0;

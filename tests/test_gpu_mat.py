@@ -614,3 +614,28 @@ def test_march_form_of_the_template_kernel_bit_exact(hx, kind, n, m, cut):
     for v in (X, Y, Y0, Xs, Ys):
         v.free()
     _lib.mat_destroy(A)
+
+
+@pytest.mark.parametrize("kind,n,rows", [("7pt", 40, 1600 * 20), ("27pt", 34, 1156 * 20)])
+def test_rectangular_template_matrix_keeps_the_general_template_kernel(hx, kind, n, rows):
+    """The first `rows` rows of a stencil matrix with ALL its columns (rows x n^3: what a row slab looks like before it is split into blocks):
+    row templates apply, but the pair and march forms bound their loads of x by the row count -- they are for square matrices only.  The
+    general template kernel takes it; y bit-identical to MatMult_SeqAIJ (the last rows reach columns beyond `rows`)."""
+    from petsc_amd import _lib
+    rng = np.random.default_rng(29)
+    ai, aj, aa = orc.stencil(kind, n, rstart=0, rend=rows)
+    N = n ** 3
+    assert aj.max() >= rows
+    x = rng.standard_normal(N)
+    yr = np.zeros(rows)
+    orc.lib().orc_MatMult_SeqAIJ(rows, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(yr))
+    A = _lib.mat_create_csr(rows, N, ai, aj, aa)
+    for variant in (26, 30):
+        _lib.chk(hx.hipxMatSetSpMVVariant(A, variant))
+        assert kernel_name(hx, A).startswith("spmv_tmpl_kernel "), kernel_name(hx, A)
+        X, Y = _lib.DVec(N, x), _lib.DVec(rows)
+        _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+        assert np.array_equal(Y.get(), yr)
+        X.free()
+        Y.free()
+    _lib.mat_destroy(A)
