@@ -12,8 +12,9 @@ P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
 P2="SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS"
 P3="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_INSTS_SENDMSG"
 P4="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"
+P5="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS"  # (a pass of its own: if a name is unknown only this pass fails)
 i=0
-for P in "$P1" "$P2" "$P3" "$P4"; do
+for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   i=$((i + 1))
   (cd /tmp && timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d "$R/gpurun_out/${T}_sq$i" -o pmc -- python "$R/bench.py" --spmv-only 6 --variant $V > "$R/gpurun_out/${T}_sq$i.log" 2>&1)
   echo "pass $i exit $?"
@@ -22,7 +23,7 @@ python - "$T" <<'PY'
 import csv, glob, sys, collections
 T = sys.argv[1]
 tab = collections.defaultdict(lambda: collections.defaultdict(list))
-for i in (1, 2, 3, 4):
+for i in (1, 2, 3, 4, 5):
     for f in glob.glob("gpurun_out/%s_sq%d/**/*counter_collection.csv" % (T, i), recursive=True):
         per = collections.defaultdict(float)
         for row in csv.DictReader(open(f)):
