@@ -114,6 +114,7 @@ struct hipxMat_s {
   hipx_int       dot_npart_used = 0;  // dot partials the last fused template launch wrote when it was not the count dot_partials_count() gave (march form)
   int           *d_toff   = nullptr;  // column - row
   double        *d_tval   = nullptr;
+  double             *d_march_dump = nullptr;  // march form, long templates: where the dot partials go when no dot was asked for
   unsigned long long *d_tq = nullptr;   // chunk queue of the template kernel: one ticket counter per XCD (64 bytes apart), never reset
   unsigned long long  tq_launches = 0;  // launches so far on this geometry (the kernel subtracts launches * tickets-per-launch)
   int                 tq_geom = -1;     // geometry (grid, rows per chunk) the counters have been used with
@@ -2256,6 +2257,8 @@ void free_templates(hipxMat A)
   (void)hipFree(A->d_toff);
   (void)hipFree(A->d_tval);
   (void)hipFree(A->d_tq);
+  (void)hipFree(A->d_march_dump);
+  A->d_march_dump = nullptr;
   (void)hipFree(A->d_tmask);
   A->d_tmask   = nullptr;
   A->tmpl_base = -1;
@@ -2655,14 +2658,18 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
         const size_t lds = 3 * (size_t)(mp.L + 2 * mp.H) * sizeof(double);
         const int    xm  = (units % 8 == 0) ? 1 : 0;
         if (DOT) A->dot_npart_used = (hipx_int)units * 4;
+        // the long templates run the kernel WITH the dot also when nobody wants it (the partials go to a dump): without it the compiler schedules the
+        // 27-entry loop into 80 registers of scratch per lane (312 bytes; with the dot: none)
+        if (!DOT && mp.ne > 9 && !A->d_march_dump) HIPX_HIP(hipMalloc((void **)&A->d_march_dump, sizeof(double) * 4 * 8192));
+        if (!DOT && mp.ne > 9 && units > 8192) return fail(HIPX_ERR_ARG, "march form: more than 8192 workgroups", __FILE__, __LINE__);
 #define HIPX_MARCH_LAUNCH(NE, EX)                                                                                                                                                      \
   do {                                                                                                                                                                             \
     static bool attr = false;                                                                                                                                                      \
     if (!attr) {                                                                                                                                                                   \
-      HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_march_kernel<MODE, DOT, NE, EX>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                 \
+      HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_march_kernel<MODE, (DOT || (NE > 9)), NE, EX>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));   \
       attr = true;                                                                                                                                                                 \
     }                                                                                                                                                                              \
-    spmv_march_kernel<MODE, DOT, NE, EX><<<(unsigned)units, 256, lds, rt().compute>>>(m, mp, A->d_tid, A->d_tmask, A->ntmpl, x, yin, yout, dotpart, tiles, nseg, pps, nplanes, xm); \
+    spmv_march_kernel<MODE, (DOT || (NE > 9)), NE, EX><<<(unsigned)units, 256, lds, rt().compute>>>(m, mp, A->d_tid, A->d_tmask, A->ntmpl, x, yin, yout, DOT ? dotpart : A->d_march_dump, tiles, nseg, pps, nplanes, xm); \
   } while (0)
         static const bool mtrace = getenv("HIPX_TMPL_TRACE") != nullptr;
         if (mtrace && MODE == 0 && DOT) {  // developer timing: the steps of workgroups 8 and 301 (10 ns ticks) on stderr, twice
