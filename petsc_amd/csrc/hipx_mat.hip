@@ -2650,7 +2650,7 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
     if (A->march_ok && tbase >= 0 && !nomarch && !probe0 && cfg == 1 && !g_epi_on && A->ntmpl <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && m % 2 == 0) {
       const int tiles   = (mp.S + mp.L - 1) / mp.L;
       const int nplanes = (int)((m + mp.S - 1) / mp.S);
-      int       nseg    = std::max(1, std::min(nplanes / 4, (units_env + tiles / 2) / tiles));
+      int       nseg    = std::max(1, std::min(nplanes / 8, (units_env + tiles / 2) / tiles));  // >= 8 planes per segment: its two extra plane loads stay <= 25 %
       const int pps     = (nplanes + nseg - 1) / nseg;
       nseg              = (nplanes + pps - 1) / pps;
       const int units   = tiles * nseg;
@@ -3393,7 +3393,7 @@ static bool march_applies(hipxMat A)
   const hipx_int       m = A->nrows_c;
   const int            target = getenv("HIPX_TMPL_MARCH_UNITS") ? atoi(getenv("HIPX_TMPL_MARCH_UNITS")) : 512;
   const int            tiles = (mp.S + mp.L - 1) / mp.L, nplanes = (int)((m + mp.S - 1) / mp.S);
-  int                  nseg = std::max(1, std::min(nplanes / 4, (target + tiles / 2) / tiles));
+  int                  nseg = std::max(1, std::min(nplanes / 8, (target + tiles / 2) / tiles));
   const int            pps = (nplanes + nseg - 1) / nseg;
   nseg                     = (nplanes + pps - 1) / pps;
   return (tiles * nseg >= 192 || A->march_force) && (hipx_int)(tiles * nseg) <= (m + 511) / 512;
