@@ -125,6 +125,21 @@ int hipxVecSum(const double *x, hipx_int n, double *result);
 int hipxVecMax(const double *x, hipx_int n, hipx_int *idx, double *result);
 int hipxVecMin(const double *x, hipx_int n, hipx_int *idx, double *result);
 
+/* Reduction mode of every sum-reduction of this library (Dot/TDot/MDot/Norm 1,2/DotNorm2/Sum, the sums of the fused CG kernels, and
+   the all-reduces of the multi-rank forms):
+     HIPX_RED_FAST (default)  plain fp64 partial sums in a fixed order: deterministic, ~1e-15 relative from the exact value;
+     HIPX_RED_EXACT           compensated sums (Dot2 / Sum2, Ogita-Rump-Oishi): every sum is carried as an unevaluated (hi, lo) pair
+                              through the thread loop, the wave and workgroup folds, the fold of the workgroups' partials and the
+                              fold over the ranks, and rounded ONCE: the result is the correctly rounded dot product (as if computed
+                              in twice the working precision) whatever the grid shape and the rank count -- the value the reference
+                              computes when its BLAS ddot/dnrm2/dasum/dgemv (bvec1.c:27, bvec2.c:202-223, dvec2.c:557) are exactly
+                              rounded (oracle/exactblas.c).  Costs no extra HBM traffic; SpMV + dot fusions fall back to SpMV, then dot.
+   The environment variable HIPX_REDUCTIONS=exact|fast sets the initial mode at hipxInit. */
+#define HIPX_RED_FAST  0
+#define HIPX_RED_EXACT 1
+int hipxSetReductionMode(int mode);
+int hipxGetReductionMode(int *mode);
+
 /* split-phase reductions (enqueue now, read later): slot in [0, HIPX_MAX_RED_SLOTS) */
 #define HIPX_MAX_RED_SLOTS 64
 int hipxVecDotBegin(const double *x, const double *y, hipx_int n, int slot);
@@ -236,6 +251,10 @@ int hipxCommIpcExport(int rank, int nranks, void *handle64);
 int hipxCommIpcAttach(const void *all_handles /* nranks x 64 bytes, by rank */);
 int hipxCommRank(int *rank, int *nranks);
 int hipxCommAllreduceSum(double *host_vals, int n);           /* n <= 64 doubles, device-staged ncclAllReduce */
+/* HIPX_ERR_GPU if an all-reduce of the IPC transport gave up on a peer (wait limit) since the communicator came up: the sums it
+   produced are not sums.  The host-synchronised forms check this themselves; callers that collect stream-ordered reductions with
+   hipxRedEnd (the launch-ahead CG on several ranks) call it after each one. */
+int hipxCommCheckError(void);
 /* VecTDot_MPI / VecMDot_MPI (pvecimpl.h:97-111) in one stream-ordered chain: local dot kernel(s) -> ncclAllReduce on the
    result words -> host notification; the host waits once, after the all-reduce.  nv <= 8.  Single rank: plain local dots. */
 int hipxVecMDotAllreduce(const double *x, hipx_int nv, const double *const *y, hipx_int n, double *results);

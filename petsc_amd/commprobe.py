@@ -61,6 +61,26 @@ def probe(transport, rank, world, device, d, timeout):
         want = np.array([world * (world + 1) / 2.0 + k * world, 0.25 * world * (world + 1)])
         if not np.array_equal(v, want):
             raise RuntimeError("all-reduce returned %s, expected %s" % (v, want))
+    # compensated reductions over the ranks (hipxSetReductionMode(exact): every rank's (hi, lo) pair folded in rank order, rounded once):
+    # a cancelling dot product cut into one slab per rank must come out as the correctly rounded value of the WHOLE sum on every rank
+    from fractions import Fraction
+    L = 1024
+    rng = np.random.default_rng(20260926)
+    half = world * L // 2
+    a, b = rng.standard_normal(half) * 10.0 ** rng.integers(-6, 6, half), rng.standard_normal(half)
+    perm = rng.permutation(2 * half)
+    gx, gy = np.concatenate([a, a])[perm], np.concatenate([b, -b * (1.0 + 1e-10 * rng.standard_normal(half))])[perm]
+    want = float(sum(Fraction(float(u)) * Fraction(float(v)) for u, v in zip(gx, gy)))
+    _lib.chk(hx.hipxSetReductionMode(1))
+    X, Y = _lib.DVec(L, gx[rank * L:(rank + 1) * L]), _lib.DVec(L, gy[rank * L:(rank + 1) * L])
+    ptrs, res = (C.c_void_p * 1)(Y.ptr.value), (C.c_double * 1)()
+    for k in range(3):
+        _lib.chk(hx.hipxVecMDotAllreduce(X.ptr, 1, ptrs, L, res))
+        if res[0] != want:
+            raise RuntimeError("compensated all-reduce returned %r, the correctly rounded sum is %r" % (res[0], want))
+    _lib.chk(hx.hipxSetReductionMode(0))
+    X.free()
+    Y.free()
     # ring ghost exchange: rank r sends x[0:n] to r+1 and receives from r-1 (a slab partition's neighbour pattern)
     n = 4096
     right, left = (rank + 1) % world, (rank - 1) % world

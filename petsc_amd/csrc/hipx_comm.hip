@@ -10,6 +10,7 @@
 //   * the diagonal-block SpMV runs on the compute stream meanwhile; an event makes the off-diagonal
 //     MatMultAdd wait for the receive (the mpiaij.c:1056-1059 shape with stream-level overlap).
 #include "hipx_internal.h"
+#include "hipx_reduce.h"
 #include <rccl/rccl.h>
 #include <cstdlib>
 #include <cstring>
@@ -25,6 +26,7 @@ struct Comm {
   ncclComm_t rcomm  = nullptr;  // scalar all-reduces, compute stream
   int        rank = 0, nranks = 1;
   double    *d_red = nullptr;  // all-reduce staging
+  double    *d_gather = nullptr;  // compensated mode over RCCL: the ranks' (hi, lo) pairs, all-gathered, folded in rank order
   double    *h_red = nullptr;  // pinned
   // IPC transport of the scalar all-reduces (hipxCommIpcExport / Attach): every rank stores its partial sums into every peer's
   // arena and publishes a sequence number; each rank then adds the nranks contributions in rank order (bitwise the same sum on
@@ -122,9 +124,13 @@ __global__ void ipc_ack_kernel(unsigned long long *const *ack_ptrs, int nrecv, u
 }
 
 
-__global__ __launch_bounds__(64) void ipc_allreduce_kernel(double *vals, int n, int me, int nranks, char *const *peer, size_t hdr, unsigned long long seq, unsigned int *err, long long limit)
+// pairs = 1 (compensated mode): vals holds n unrounded (hi, lo) pairs -- 2n words travel -- and every rank folds the nranks pairs of
+// each sum in rank order with TwoSum, rounding hi + lo once: the same bits on every rank and for every way of cutting the rows.
+__global__ __launch_bounds__(64) void ipc_allreduce_kernel(double *vals, int nsums, int pairs, int me, int nranks, char *const *peer, size_t hdr, unsigned long long seq, unsigned int *err,
+                                                           long long limit)
 {
   const int t = threadIdx.x, q = (int)(seq & 1);
+  const int n = pairs ? 2 * nsums : nsums;
   if (t < n) {
     const double v = vals[t];
     for (int p = 0; p < nranks; p++) {
@@ -140,7 +146,21 @@ __global__ __launch_bounds__(64) void ipc_allreduce_kernel(double *vals, int n, 
   }
   __threadfence_system();
   __syncthreads();
-  if (t < n) {
+  if (pairs) {
+    double res = 0.0;
+    if (t < nsums) {
+      Acc<true> acc;
+      for (int p = 0; p < nranks; p++) {
+        const double *in = reinterpret_cast<const double *>(peer[me] + hdr) + ((size_t)p * 2 + q) * 64;
+        const double  hi = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(in + 2 * t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        const double  lo = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(in + 2 * t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        acc.merge(hi, lo);
+      }
+      res = acc.s + acc.c;
+    }
+    __syncthreads();  // every pair of vals[] has been read (by the stores above) before the sums overwrite the front of it
+    if (t < nsums) vals[t] = res;
+  } else if (t < n) {
     double sum = 0.0;
     for (int p = 0; p < nranks; p++) {
       const double *in = reinterpret_cast<const double *>(peer[me] + hdr) + ((size_t)p * 2 + q) * 64;
@@ -190,18 +210,36 @@ struct hipxHalo_s {
 };
 
 
-// in-place sum of n <= 64 doubles in device memory over all ranks, enqueued on the compute stream
-static int allreduce_dev(double *d_vals, int n)
+// the ranks' (hi, lo) pairs of nsums sums (gathered rank by rank) -> the nsums correctly rounded totals, in rank order
+__global__ __launch_bounds__(64) void dd_fold_ranks_kernel(const double *gathered, int nsums, int nranks, double *vals)
+{
+  const int t = threadIdx.x;
+  if (t >= nsums) return;
+  Acc<true> acc;
+  for (int p = 0; p < nranks; p++) acc.merge(gathered[(size_t)p * 2 * nsums + 2 * t], gathered[(size_t)p * 2 * nsums + 2 * t + 1]);
+  vals[t] = acc.s + acc.c;
+}
+
+// in-place sum of n doubles in device memory over all ranks, enqueued on the compute stream.  Plain mode: n <= 64 sums.  Compensated
+// mode (pairs): d_vals holds n <= 32 unrounded (hi, lo) pairs on entry (what the local kernels leave when RedOut::pairs is set) and the
+// n rounded totals on exit; the pairs of all ranks are folded in rank order (IPC: inside the kernel; RCCL: all-gather + a fold kernel).
+static int allreduce_dev(double *d_vals, int n, bool pairs = false)
 {
   Comm &c = cm();
   int   ierr;
   if ((ierr = prof_section(HIPX_PROF_ALLREDUCE, true, rt().compute))) return ierr;
   if (c.ipc) {
-    ipc_allreduce_kernel<<<1, 64, 0, rt().compute>>>(d_vals, n, c.rank, c.nranks, c.d_peer, c.hdr, ++c.seq, c.d_err, ipc_wait_ticks());
+    ipc_allreduce_kernel<<<1, 64, 0, rt().compute>>>(d_vals, n, pairs ? 1 : 0, c.rank, c.nranks, c.d_peer, c.hdr, ++c.seq, c.d_err, ipc_wait_ticks());
+    HIPX_LAUNCH_CHECK();
+  } else if (pairs) {
+    HIPX_NCCL(ncclAllGather(d_vals, c.d_gather, (size_t)(2 * n), ncclDouble, c.rcomm, rt().compute));
+    dd_fold_ranks_kernel<<<1, 64, 0, rt().compute>>>(c.d_gather, n, c.nranks, d_vals);
     HIPX_LAUNCH_CHECK();
   } else HIPX_NCCL(ncclAllReduce(d_vals, d_vals, (size_t)n, ncclDouble, ncclSum, c.rcomm, rt().compute));
   return prof_section(HIPX_PROF_ALLREDUCE, false, rt().compute);
 }
+// what the local kernels of the all-reduce chains leave in c.d_red: sums, or (compensated mode) unrounded pairs
+static inline bool red_pairs() { return rt().red_exact != 0; }
 
 // the IPC all-reduce kernel gave up on a peer (wait limit): the sums it produced are not sums -- fail loudly
 static int comm_err_check()
@@ -290,6 +328,7 @@ int hipxCommInit(const void *id256, int rank, int nranks)
   c.rank   = rank;
   c.nranks = nranks;
   HIPX_HIP(hipMalloc((void **)&c.d_red, sizeof(double) * 64));
+  HIPX_HIP(hipMalloc((void **)&c.d_gather, sizeof(double) * 64 * (size_t)nranks));
   HIPX_HIP(hipHostMalloc((void **)&c.h_red, sizeof(double) * 64, hipHostMallocDefault));
   c.active = true;
   return HIPX_SUCCESS;
@@ -310,6 +349,7 @@ int hipxCommFinalize(void)
     HIPX_NCCL(ncclCommDestroy(c.rcomm));
   }
   (void)hipFree(c.d_red);
+  (void)hipFree(c.d_gather);
   (void)hipHostFree(c.h_red);
   c = Comm();
   return HIPX_SUCCESS;
@@ -322,6 +362,8 @@ int hipxCommRank(int *rank, int *nranks)
   if (nranks) *nranks = c.active ? c.nranks : 1;
   return HIPX_SUCCESS;
 }
+
+int hipxCommCheckError(void) { return comm_err_check(); }
 
 int hipxCommAllreduceSum(double *vals, int n)
 {
@@ -353,9 +395,9 @@ int hipxVecMDotAllreduce(const double *x, hipx_int nv, const double *const *y, h
   if (n > 0) {
     int ierr = launch_mdot_nosignal(x, (int)nv, y, n, slot, c.d_red);
     if (ierr) return ierr;
-  } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * (size_t)nv, rt().compute));  // rank without rows
+  } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * 2 * (size_t)nv, rt().compute));  // rank without rows (sums or pairs)
   {
-    int ierr = allreduce_dev(c.d_red, (int)nv);
+    int ierr = allreduce_dev(c.d_red, (int)nv, red_pairs());
     if (ierr) return ierr;
   }
   int ierr = red_signal(slot, c.d_red, (int)nv);
@@ -374,9 +416,9 @@ int hipxCGFusedUpdateAllreduce(double *x, double *r, double *z, const double *p,
   if (n > 0) {
     int ierr = launch_cg_fused_nosignal(x, r, z, p, w, d, a, n, slot, c.d_red);
     if (ierr) return ierr;
-  } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * 2, rt().compute));
+  } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * 4, rt().compute));
   {
-    int ierr = allreduce_dev(c.d_red, 2);
+    int ierr = allreduce_dev(c.d_red, 2, red_pairs());
     if (ierr) return ierr;
   }
   int ierr = red_signal(slot, c.d_red, 2);
@@ -398,8 +440,8 @@ int hipxMatMultMPIDotBegin(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, 
   const double *ys[1] = {y};
   if (n > 0) {
     if ((ierr = launch_mdot_nosignal(x, 1, ys, n, slot, c.d_red))) return ierr;  // cg.c:258 VecXDot(P, W), local part
-  } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double), rt().compute));
-  if ((ierr = allreduce_dev(c.d_red, 1))) return ierr;
+  } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * 2, rt().compute));
+  if ((ierr = allreduce_dev(c.d_red, 1, red_pairs()))) return ierr;
   return red_signal(slot, c.d_red, 1, dev_dot);
 }
 
@@ -413,8 +455,8 @@ int hipxCGFusedUpdateBeginAllreduce(double *x, double *r, double *z, const doubl
   int ierr;
   if (n > 0) {
     if ((ierr = launch_cg_fused_dev_nosignal(x, r, z, p, w, d, dconst, dev_beta, dev_dpi, n, slot, c.d_red))) return ierr;
-  } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * 2, rt().compute));
-  if ((ierr = allreduce_dev(c.d_red, 2))) return ierr;
+  } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * 4, rt().compute));
+  if ((ierr = allreduce_dev(c.d_red, 2, red_pairs()))) return ierr;
   return red_signal(slot, c.d_red, 2, dev_sums2);
 }
 

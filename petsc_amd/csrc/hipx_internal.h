@@ -30,6 +30,7 @@ struct Runtime {
   double       *d_scalars  = nullptr;  // staging for kernel arguments that exceed the arg buffer (MAXPY alphas, pointer tables)
   void        **d_ptrs     = nullptr;
   int           next_slot  = 0;
+  int           red_exact  = 0;        // hipxSetReductionMode: 1 = compensated (Dot2 / Sum2) sums in every reduction kernel
   char          errmsg[512] = "no error";
 };
 
@@ -48,12 +49,15 @@ struct RedOut {
   unsigned long long *flag;
   unsigned long long  seq;  // 0: do not signal (a later stage on the stream -- all-reduce + hipx::red_signal -- will)
   double             *dres; // optional device-memory copy of the results, for kernels queued behind this one (launch-ahead CG)
+  int                 pairs; // compensated kernels only: leave every sum as an unrounded (hi, lo) pair in results[2v], results[2v+1]
+                             // (a fold over the ranks follows on the stream, hipx_comm.hip); 0: results[v] = hi + lo
 };
 inline RedOut red_out(int slot, bool signal = true, double *dres = nullptr)
 {
   Runtime &r = rt();
-  return RedOut{slot_partials(slot), r.d_tickets + slot, slot_results_dev(slot), r.d_flags + slot, signal ? ++r.seq[slot] : 0ull, dres};
+  return RedOut{slot_partials(slot), r.d_tickets + slot, slot_results_dev(slot), r.d_flags + slot, signal ? ++r.seq[slot] : 0ull, dres, 0};
 }
+int launch_dot(const double *x, const double *y, hipx_int n, int slot, double *dres);  // x.y -> host slot (+ device copy), enqueue only
 int launch_sum(const double *x, hipx_int n, int slot, double *dres);  // fold of per-wave partials: results -> host slot (+ device copy)
 // multi-GPU reductions without a host round trip between the local kernel and the all-reduce (hipx_comm.hip)
 // The local kernel leaves its sums in device memory (dev_results), RCCL reduces them there, and red_signal() copies the

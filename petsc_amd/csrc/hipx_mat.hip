@@ -3508,6 +3508,10 @@ int hipxMatMultDot(hipxMat A, const double *x, double *y, double *dot)
   HIPX_CHECK_INIT();
   HIPX_ARG(A && !A->compressed && A->m == A->n, "MatMultDot needs a square, uncompressed matrix");
   *dot = 0.0;
+  if (rt().red_exact) {  // compensated mode: the product, then Dot2 over the complete vectors (the epilogue's per-wave partials are plain sums)
+    int ierr = hipxMatMult(A, x, y);
+    return ierr ? ierr : hipxVecDot(x, y, A->m, dot);
+  }
   hipx_int npart = 0;
   int      ierr  = matmultdot_launch(A, x, y, &npart);
   if (ierr || !npart) return ierr;
@@ -3519,6 +3523,10 @@ int hipxMatMultDotBegin(hipxMat A, const double *x, double *y, int slot, double 
   HIPX_CHECK_INIT();
   HIPX_ARG(A && !A->compressed && A->m == A->n && A->m > 0, "MatMultDotBegin needs a square, non-empty, uncompressed matrix");
   HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2, "reduction slot out of range");
+  if (rt().red_exact) {
+    int ierr = hipxMatMult(A, x, y);
+    return ierr ? ierr : launch_dot(x, y, A->m, slot, dev_dot);
+  }
   hipx_int npart = 0;
   int      ierr  = matmultdot_launch(A, x, y, &npart);
   if (ierr) return ierr;

@@ -1,6 +1,7 @@
 // hipx_runtime.hip -- device, streams, memory and events behind the C ABI (include/hipx.h).
 #include "hipx_internal.h"
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 
 namespace hipx {
@@ -132,7 +133,25 @@ int hipxInit(int device)
   HIPX_HIP(hipMalloc((void **)&r.d_scalars, sizeof(double) * 4096));
   HIPX_HIP(hipMalloc((void **)&r.d_ptrs, sizeof(void *) * 4096));
   HIPX_HIP(hipDeviceSynchronize());
+  {
+    const char *e = getenv("HIPX_REDUCTIONS");
+    r.red_exact   = (e && (!strcmp(e, "exact") || !strcmp(e, "1"))) ? 1 : 0;
+  }
   r.initialized = true;
+  return HIPX_SUCCESS;
+}
+
+int hipxSetReductionMode(int mode)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(mode == HIPX_RED_FAST || mode == HIPX_RED_EXACT, "unknown reduction mode");
+  HIPX_HIP(hipStreamSynchronize(rt().compute));  // nothing queued may see the switch half-way (pairs vs sums in the all-reduce chain)
+  rt().red_exact = mode;
+  return HIPX_SUCCESS;
+}
+int hipxGetReductionMode(int *mode)
+{
+  *mode = rt().red_exact;
   return HIPX_SUCCESS;
 }
 

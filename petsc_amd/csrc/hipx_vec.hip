@@ -350,12 +350,10 @@ template <int NV>
 struct MDotArgs {
   const double *y[NV];
 };
-template <int NV>
+template <int NV, bool COMP>
 __global__ __launch_bounds__(kRedThreads) void mdot_kernel(const double *x, MDotArgs<NV> ys, hipx_int n, bool vec, RedOut out)
 {
-  double acc[NV];
-#pragma unroll
-  for (int v = 0; v < NV; v++) acc[v] = 0.0;
+  Acc<COMP> acc[NV];
   const hipx_int T   = (hipx_int)gridDim.x * kRedThreads;
   const hipx_int tid = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x;
   if (vec) {
@@ -385,22 +383,22 @@ __global__ __launch_bounds__(kRedThreads) void mdot_kernel(const double *x, MDot
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-          acc[v] += xa[u].x * ya[u].x;
-          acc[v] += xa[u].y * ya[u].y;
+          acc[v].prod(xa[u].x, ya[u].x);
+          acc[v].prod(xa[u].y, ya[u].y);
         }
       }
     }
     if ((n & 1) && tid == 0) {
 #pragma unroll
-      for (int v = 0; v < NV; v++) acc[v] += x[n - 1] * ys.y[v][n - 1];
+      for (int v = 0; v < NV; v++) acc[v].prod(x[n - 1], ys.y[v][n - 1]);
     }
   } else {
     for (hipx_int i = tid; i < n; i += T) {
 #pragma unroll
-      for (int v = 0; v < NV; v++) acc[v] += x[i] * ys.y[v][i];
+      for (int v = 0; v < NV; v++) acc[v].prod(x[i], ys.y[v][i]);
     }
   }
-  block_finish<NV, RED_SUM>(acc, out);
+  finish_sums<NV, COMP>(acc, out);
 }
 
 
@@ -408,12 +406,10 @@ __global__ __launch_bounds__(kRedThreads) void mdot_kernel(const double *x, MDot
 // pass over x (31 instead of 34 vector reads for 30 vectors, one launch instead of four).  The additions happen in the same
 // order as in mdot_kernel<NV> for every NV (per-thread pairs p, p + T, ... in increasing order), so the sums do not depend on
 // how a call is batched.
-template <int NVMAX>
+template <int NVMAX, bool COMP>
 __global__ __launch_bounds__(kRedThreads) void mdot_wide_kernel(const double *x, MDotArgs<NVMAX> ys, int nv, hipx_int n, bool vec, RedOut out)
 {
-  double acc[NVMAX];
-#pragma unroll
-  for (int v = 0; v < NVMAX; v++) acc[v] = 0.0;
+  Acc<COMP> acc[NVMAX];
   const hipx_int T   = (hipx_int)gridDim.x * kRedThreads;
   const hipx_int tid = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x;
   if (vec) {
@@ -442,8 +438,8 @@ __global__ __launch_bounds__(kRedThreads) void mdot_wide_kernel(const double *x,
           }
 #pragma unroll
           for (int u = 0; u < U; u++) {
-            acc[v] += xa[u].x * ya[u].x;
-            acc[v] += xa[u].y * ya[u].y;
+            acc[v].prod(xa[u].x, ya[u].x);
+            acc[v].prod(xa[u].y, ya[u].y);
           }
         }
       }
@@ -451,16 +447,16 @@ __global__ __launch_bounds__(kRedThreads) void mdot_wide_kernel(const double *x,
     if ((n & 1) && tid == 0) {
 #pragma unroll
       for (int v = 0; v < NVMAX; v++)
-        if (v < nv) acc[v] += x[n - 1] * ys.y[v][n - 1];
+        if (v < nv) acc[v].prod(x[n - 1], ys.y[v][n - 1]);
     }
   } else {
     for (hipx_int i = tid; i < n; i += T) {
 #pragma unroll
       for (int v = 0; v < NVMAX; v++)
-        if (v < nv) acc[v] += x[i] * ys.y[v][i];
+        if (v < nv) acc[v].prod(x[i], ys.y[v][i]);
     }
   }
-  block_finish<NVMAX, RED_SUM>(acc, out);
+  finish_sums<NVMAX, COMP>(acc, out);
 }
 
 // VecMAXPY_Seq / VecMAXPBY for up to 36 vectors in ONE pass over y (dvec2.c:658-693: (nv & 3) vectors first, then groups of
@@ -534,9 +530,10 @@ __global__ __launch_bounds__(kEwThreads) void maxpy_wide_kernel(double *y, Maxpy
 }
 
 // sums of |x| (NORM_1), x*x (NORM_2) in one pass: acc[0] = sum |x|, acc[1] = sum x^2
+template <bool COMP>
 __global__ __launch_bounds__(kRedThreads) void norm12_kernel(const double *x, hipx_int n, bool vec, RedOut out)
 {
-  double         acc[2] = {0.0, 0.0};
+  Acc<COMP>      acc[2];
   const hipx_int T      = (hipx_int)gridDim.x * kRedThreads;
   const hipx_int tid    = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x;
   if (vec) {
@@ -544,30 +541,31 @@ __global__ __launch_bounds__(kRedThreads) void norm12_kernel(const double *x, hi
     const double2 *x2 = reinterpret_cast<const double2 *>(x);
     for (hipx_int p = tid; p < n2; p += T) {
       double2 a = x2[p];
-      acc[0] += fabs(a.x);
-      acc[0] += fabs(a.y);
-      acc[1] += a.x * a.x;
-      acc[1] += a.y * a.y;
+      acc[0].add(fabs(a.x));
+      acc[0].add(fabs(a.y));
+      acc[1].prod(a.x, a.x);
+      acc[1].prod(a.y, a.y);
     }
     if ((n & 1) && tid == 0) {
-      acc[0] += fabs(x[n - 1]);
-      acc[1] += x[n - 1] * x[n - 1];
+      acc[0].add(fabs(x[n - 1]));
+      acc[1].prod(x[n - 1], x[n - 1]);
     }
   } else {
     for (hipx_int i = tid; i < n; i += T) {
-      acc[0] += fabs(x[i]);
-      acc[1] += x[i] * x[i];
+      acc[0].add(fabs(x[i]));
+      acc[1].prod(x[i], x[i]);
     }
   }
-  block_finish<2, RED_SUM>(acc, out);
+  finish_sums<2, COMP>(acc, out);
 }
 
+template <bool COMP>
 __global__ __launch_bounds__(kRedThreads) void sum_kernel(const double *x, hipx_int n, RedOut out)
 {
-  double         acc[1] = {0.0};
+  Acc<COMP>      acc[1];
   const hipx_int T      = (hipx_int)gridDim.x * kRedThreads;
-  for (hipx_int i = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += T) acc[0] += x[i];
-  block_finish<1, RED_SUM>(acc, out);
+  for (hipx_int i = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += T) acc[0].add(x[i]);
+  finish_sums<1, COMP>(acc, out);
 }
 
 // NORM_INFINITY with the reference's NaN propagation (bvec2.c:207-216)
@@ -583,16 +581,17 @@ __global__ __launch_bounds__(kRedThreads) void norminf_kernel(const double *x, h
 }
 
 // x.y and y.y in one pass (VecDotNorm2)
+template <bool COMP>
 __global__ __launch_bounds__(kRedThreads) void dotnorm2_kernel(const double *x, const double *y, hipx_int n, RedOut out)
 {
-  double         acc[2] = {0.0, 0.0};
+  Acc<COMP>      acc[2];
   const hipx_int T      = (hipx_int)gridDim.x * kRedThreads;
   for (hipx_int i = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += T) {
     double a = x[i], b = y[i];
-    acc[0] += a * b;
-    acc[1] += b * b;
+    acc[0].prod(a, b);
+    acc[1].prod(b, b);
   }
-  block_finish<2, RED_SUM>(acc, out);
+  finish_sums<2, COMP>(acc, out);
 }
 
 // fused CG update (cg.c:305-309,344 with PCJACOBI): x += a p; r -= a w; z = r*d; sums z.z, z.r
@@ -601,12 +600,12 @@ __global__ __launch_bounds__(kRedThreads) void dotnorm2_kernel(const double *x, 
 // forms the same IEEE quotient for its own bookkeeping), so the launch does not have to wait for the host to see them.
 // CONSTD = true: the Jacobi diagonal is one constant (constant-coefficient operators): z = r * dconst without reading d[] --
 // the same product, one vector pass less.
-template <bool UPX, bool DEVS, bool CONSTD = false>
+template <bool UPX, bool DEVS, bool CONSTD = false, bool COMP = false>
 __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a_arg,
                                                                 const double *dev_beta, const double *dev_dpi, hipx_int n, bool vec, RedOut out, double dconst = 0.0)
 {
   const double a = DEVS ? (*dev_beta / *dev_dpi) : a_arg;
-  double         acc[2] = {0.0, 0.0};
+  Acc<COMP>      acc[2];
   const hipx_int T      = (hipx_int)gridDim.x * kRedThreads;
   const hipx_int tid    = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x;
   const double   ma     = -a;
@@ -630,10 +629,10 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
       zv.y  = rv.y * dv.y;
       r2[q] = rv;
       if (!CONSTD || z) z2[q] = zv;  // constant diagonal + z == NULL: z is never stored (cg_aypx_axpy_kernel<.., ZR> re-forms it)
-      acc[0] += zv.x * zv.x;
-      acc[0] += zv.y * zv.y;
-      acc[1] += zv.x * rv.x;
-      acc[1] += zv.y * rv.y;
+      acc[0].prod(zv.x, zv.x);
+      acc[0].prod(zv.y, zv.y);
+      acc[1].prod(zv.x, rv.x);
+      acc[1].prod(zv.y, rv.y);
     };
     // two elements per stream in flight per thread (10 x 16-byte loads issued before the first use); the per-thread
     // accumulation order is unchanged (q, then q + kRedThreads)
@@ -657,8 +656,8 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
       if (UPX) x[i] = x[i] + a * p[i];
       r[i] = rv;
       if (!CONSTD || z) z[i] = zv;
-      acc[0] += zv * zv;
-      acc[1] += zv * rv;
+      acc[0].prod(zv, zv);
+      acc[1].prod(zv, rv);
     }
   } else {
     for (hipx_int i = tid; i < n; i += T) {
@@ -666,11 +665,11 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
       if (UPX) x[i] = x[i] + a * p[i];
       r[i] = rv;
       if (!CONSTD || z) z[i] = zv;
-      acc[0] += zv * zv;
-      acc[1] += zv * rv;
+      acc[0].prod(zv, zv);
+      acc[1].prod(zv, rv);
     }
   }
-  block_finish<2, RED_SUM>(acc, out);
+  finish_sums<2, COMP>(acc, out);
 }
 
 // max / min with index: two small kernels (setup-time operations, not on the solver loop)
@@ -729,11 +728,29 @@ inline unsigned red_grid(hipx_int n)
 
 static bool    g_signal  = true;     // launch_*_nosignal() clear it around one dispatch ...
 static double *g_results = nullptr;  // ... and redirect the kernel's result words to device memory
+static double *g_dres    = nullptr;  // launch_dot(): device copy of the result beside the host slot
 static inline RedOut red_out_g(int slot)
 {
-  RedOut o = red_out(slot, g_signal);
-  if (g_results) o.results = g_results;
+  RedOut o = red_out(slot, g_signal, g_dres);
+  if (g_results) {
+    o.results = g_results;
+    o.pairs   = rt().red_exact;  // compensated mode: the fold over the ranks that follows takes unrounded (hi, lo) pairs
+  }
   return o;
+}
+
+// every launch of the fused CG update kernel: x update or not, plain or compensated sums
+template <bool DEVS, bool CONSTD>
+static inline void cg_fused_go(unsigned g, hipStream_t st, double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, const double *dev_beta,
+                               const double *dev_dpi, hipx_int n, bool vec, RedOut o, double dconst)
+{
+  if (rt().red_exact) {
+    if (x) cg_fused_kernel<true, DEVS, CONSTD, true><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, a, dev_beta, dev_dpi, n, vec, o, dconst);
+    else cg_fused_kernel<false, DEVS, CONSTD, true><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, a, dev_beta, dev_dpi, n, vec, o, dconst);
+  } else {
+    if (x) cg_fused_kernel<true, DEVS, CONSTD, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, a, dev_beta, dev_dpi, n, vec, o, dconst);
+    else cg_fused_kernel<false, DEVS, CONSTD, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, a, dev_beta, dev_dpi, n, vec, o, dconst);
+  }
 }
 
 template <int NV>
@@ -745,7 +762,8 @@ int launch_mdot(const double *x, const double *const *y, hipx_int n, int slot)
     a.y[v] = y[v];
     vec    = vec && aligned16(y[v]);
   }
-  mdot_kernel<NV><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, a, n, vec, red_out_g(slot));
+  if (rt().red_exact) mdot_kernel<NV, true><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, a, n, vec, red_out_g(slot));
+  else mdot_kernel<NV, false><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, a, n, vec, red_out_g(slot));
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -759,7 +777,14 @@ int launch_mdot_wide(const double *x, int nv, const double *const *y, hipx_int n
     a.y[v] = y[v < nv ? v : 0];
     vec    = vec && aligned16(a.y[v]);
   }
-  mdot_wide_kernel<NVMAX><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, a, nv, n, vec, red_out_g(slot));
+  if constexpr (2 * NVMAX <= kMaxRedVals) {  // compensated sums take two partial rows each: batches of <= 16 (hipxVecMDot splits)
+    if (rt().red_exact) {
+      mdot_wide_kernel<NVMAX, true><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, a, nv, n, vec, red_out_g(slot));
+      HIPX_LAUNCH_CHECK();
+      return HIPX_SUCCESS;
+    }
+  } else if (rt().red_exact) return fail(HIPX_ERR_ARG, "compensated mdot: at most 16 vectors per launch", __FILE__, __LINE__);
+  mdot_wide_kernel<NVMAX, false><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, a, nv, n, vec, red_out_g(slot));
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -844,8 +869,7 @@ int hipx::red_signal(int slot, const double *dev_results, int nvals, double *dre
 static int launch_cg_fused(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n, int slot)
 {
   bool vec = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(p) && aligned16(w) && aligned16(d) && n >= 2;
-  if (x) cg_fused_kernel<true, false><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, a, nullptr, nullptr, n, vec, red_out_g(slot));
-  else cg_fused_kernel<false, false><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, r, z, p, w, d, a, nullptr, nullptr, n, vec, red_out_g(slot));
+  cg_fused_go<false, false>(red_grid(n), rt().compute, x, r, z, p, w, d, a, nullptr, nullptr, n, vec, red_out_g(slot), 0.0);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -859,21 +883,27 @@ int hipx::launch_cg_fused_dev_nosignal(double *x, double *r, double *z, const do
   const unsigned g = red_grid(n);
   RedOut         o = red_out(slot, false, nullptr);
   o.results        = dev_results;
+  o.pairs          = rt().red_exact;  // (the all-reduce that follows folds the ranks' pairs)
   hipStream_t st   = rt().compute;
-  if (d) {
-    if (x) cg_fused_kernel<true, true, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o);
-    else cg_fused_kernel<false, true, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o);
-  } else {
-    if (x) cg_fused_kernel<true, true, true><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o, dconst);
-    else cg_fused_kernel<false, true, true><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o, dconst);
-  }
+  if (d) cg_fused_go<true, false>(g, st, x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o, 0.0);
+  else cg_fused_go<true, true>(g, st, x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o, dconst);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
 
+int hipx::launch_dot(const double *x, const double *y, hipx_int n, int slot, double *dres)
+{
+  const double *ys[1] = {y};
+  g_dres              = dres;
+  int ierr            = mdot_dispatch(x, 1, ys, n, slot);
+  g_dres              = nullptr;
+  return ierr;
+}
+
 int hipx::launch_sum(const double *x, hipx_int n, int slot, double *dres)
 {
-  sum_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, red_out(slot, true, dres));
+  if (rt().red_exact) sum_kernel<true><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, red_out(slot, true, dres));
+  else sum_kernel<false><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, red_out(slot, true, dres));
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -1182,7 +1212,8 @@ int hipxVecMDot(const double *x, hipx_int nv, const double *const *y, hipx_int n
   }
   // batches of <= 32 vectors (one pass over x each; GMRES(30) is ONE launch), each in its own slot so a single wait at the end
   // suffices.  HIPX_MDOT_BATCH=8 restores the round-1 batching (the sums are identical either way: same addition order).
-  static const hipx_int BATCH = (getenv("HIPX_MDOT_BATCH") && atoi(getenv("HIPX_MDOT_BATCH")) == 8) ? 8 : 32;
+  static const hipx_int BATCH0 = (getenv("HIPX_MDOT_BATCH") && atoi(getenv("HIPX_MDOT_BATCH")) == 8) ? 8 : 32;
+  const hipx_int        BATCH  = (rt().red_exact && BATCH0 > 16) ? 16 : BATCH0;  // compensated sums: two partial rows each
   hipx_int done = 0;
   int      slot = 1;
   while (done < nv) {
@@ -1220,7 +1251,8 @@ int hipxVecNorm(const double *x, hipx_int n, int type, double *results)
     if (ierr) return ierr;
     results[0] = sqrt(s);
   } else if (type == 0 || type == 4) {
-    norm12_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, aligned16(x) && n >= 2, red_out(slot));
+    if (rt().red_exact) norm12_kernel<true><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, aligned16(x) && n >= 2, red_out(slot));
+    else norm12_kernel<false><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, aligned16(x) && n >= 2, red_out(slot));
     HIPX_LAUNCH_CHECK();
     double s[2];
     int    ierr = red_wait(slot, 2, s);
@@ -1240,7 +1272,8 @@ int hipxVecDotNorm2(const double *x, const double *y, hipx_int n, double *dp, do
   HIPX_CHECK_INIT();
   *dp = *nm = 0.0;
   if (n <= 0) return HIPX_SUCCESS;
-  dotnorm2_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, y, n, red_out(0));
+  if (rt().red_exact) dotnorm2_kernel<true><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, y, n, red_out(0));
+  else dotnorm2_kernel<false><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, y, n, red_out(0));
   HIPX_LAUNCH_CHECK();
   double s[2];
   int    ierr = red_wait(0, 2, s);
@@ -1255,7 +1288,8 @@ int hipxVecSum(const double *x, hipx_int n, double *result)
   HIPX_CHECK_INIT();
   *result = 0.0;
   if (n <= 0) return HIPX_SUCCESS;
-  sum_kernel<<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, red_out(0));
+  if (rt().red_exact) sum_kernel<true><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, red_out(0));
+  else sum_kernel<false><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, red_out(0));
   HIPX_LAUNCH_CHECK();
   return red_wait(0, 1, result);
 }
@@ -1353,13 +1387,8 @@ int hipxCGFusedUpdateBegin(double *x, double *r, double *z, const double *p, con
   const unsigned g = red_grid(n);
   RedOut         o = red_out(slot, true, dev_sums2);
   hipStream_t    st = rt().compute;
-  if (d) {
-    if (x) cg_fused_kernel<true, true, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o);
-    else cg_fused_kernel<false, true, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o);
-  } else {  // d == NULL: constant Jacobi diagonal
-    if (x) cg_fused_kernel<true, true, true><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o, dconst);
-    else cg_fused_kernel<false, true, true><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o, dconst);
-  }
+  if (d) cg_fused_go<true, false>(g, st, x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o, 0.0);
+  else cg_fused_go<true, true>(g, st, x, r, z, p, w, d, 0.0, dev_beta, dev_dpi, n, vec, o, dconst);  // d == NULL: constant Jacobi diagonal
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }

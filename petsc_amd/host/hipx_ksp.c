@@ -97,6 +97,10 @@ int HipxVecNorm2(HipxMat *A, const double *x, hipx_int n, double *r)
 
 int HipxPCSetUp(HipxPC *pc, HipxMat *A)
 {
+  if (pc->type == HIPX_PC_NONE) { /* PCApply_None = VecCopy (none.c:6): z = r, i.e. the constant "diagonal" 1.0 of the fused kernels (r * 1.0 == r, every bit) */
+    pc->dconst_valid = 1;
+    pc->dconst       = 1.0;
+  }
   if (pc->type == HIPX_PC_JACOBI) {
     if (!pc->dinv) CHK(hipxMalloc((void **)&pc->dinv, sizeof(double) * (size_t)(A->m ? A->m : 1)));
     CHK(hipxPCJacobiSetUp(A->A, pc->dinv)); /* MatGetDiagonal_MPIAIJ = diagonal of the diag block (mpiaij.c:1158-1167) */
@@ -296,7 +300,7 @@ static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double 
   double        *R = ksp->R, *Z = ksp->Z, *P = ksp->P, *W = ksp->Z;
   double        *ds = ksp->dscal;
   int            ahead = 0; /* A(i), B(i), C(i) of the current iteration already enqueued */
-  const int      dcon  = pc->dconst_valid && !getenv("HIPX_NO_DCONST"); /* constant Jacobi diagonal: multiply by the scalar */
+  const int      dcon  = pc->dconst_valid && (pc->type == HIPX_PC_NONE || !getenv("HIPX_NO_DCONST")); /* constant Jacobi diagonal (or PCNONE: 1.0): multiply by the scalar */
   enum { SLOT_DOT = 1, SLOT_SUMS = 2 };
   for (hipx_int s = 0; s < nsteps && !ksp->reason && ksp->i < ksp->max_it; s++) {
     const hipx_int i  = ksp->i;
@@ -330,6 +334,7 @@ static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double 
     ahead  = 0;
     dpiold = ksp->dpi;
     CHK(hipxRedEnd(SLOT_DOT, 1, &ksp->dpi));
+    if (A->nranks > 1) CHK(hipxCommCheckError()); /* an all-reduce that gave up on a peer did not produce sums */
     ksp->betaold = ksp->beta;
     if (isnan(ksp->dpi) || isinf(ksp->dpi)) { /* KSPCheckDot */
       ksp->reason = KSP_DIVERGED_NANORINF;
@@ -351,6 +356,7 @@ static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double 
       ksp->x_pending = 0; /* A(i+1) applies it */
     }
     CHK(hipxRedEnd(SLOT_SUMS + q, 2, sums));
+    if (A->nranks > 1) CHK(hipxCommCheckError());
     dp = sqrt(sums[0]);
     if (isnan(dp) || isinf(dp)) {
       ksp->reason = KSP_DIVERGED_NANORINF;
@@ -381,11 +387,12 @@ int HipxKSPCGStep(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double 
   double         dp = 0.0, b, dpiold;
   /* fused update kernel (AXPY, AXPY, PCJACOBI, norm, dot): any rank count, its two sums all-reduced together;
      SpMV + dot fusion: only without an off-diagonal block (the dot needs the complete w) */
-  const int      fused_upd = ksp->fused && pc->type == HIPX_PC_JACOBI && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED;
+  const int      fused_any = ksp->fused && (pc->type == HIPX_PC_JACOBI || (pc->type == HIPX_PC_NONE && pc->dconst_valid)) && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED;
+  const int      fused_upd = fused_any && pc->type == HIPX_PC_JACOBI; /* the host-synchronised loop below streams dinv; PCNONE (round 4) takes the launch-ahead loop, whose kernels multiply by a scalar */
   const int      fused     = fused_upd && !A->B && A->nranks <= 1;
   /* launch-ahead form: one rank (SpMV + dot fused), or several ranks with a device ghost exchange (round 3: the all-reduces complete
      on the stream, see mm_dot_begin / fused_update_begin); ksp->pipeline == 2 keeps several ranks on the host-synchronised loop */
-  if (ksp->pipeline && n > 0 && (fused || (fused_upd && A->nranks > 1 && A->B && A->halo && ksp->pipeline != 2))) return cg_step_pipelined(ksp, A, pc, B, X, nsteps);
+  if (ksp->pipeline && n > 0 && fused_any && ((!A->B && A->nranks <= 1) || (A->nranks > 1 && A->B && A->halo && ksp->pipeline != 2))) return cg_step_pipelined(ksp, A, pc, B, X, nsteps);
   for (hipx_int s = 0; s < nsteps && !ksp->reason && ksp->i < ksp->max_it; s++) {
     const hipx_int i = ksp->i;
     ksp->its = i + 1;
@@ -615,7 +622,8 @@ int HipxKSPSolve_Chebyshev(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B
         } else ksp->reason = KSP_CONVERGED_ITS;
       }
     }
-    if (k) CCHK(hipxVecCopy(p[k], X, n)); /* cheby.c:551-552: the solution ends in the user's vector */
+    /* cheby.c:551-552: the solution ends in the user's vector -- but KSPCheckNorm (cheby.c:491) RETURNS on a NaN/Inf norm: vec_sol keeps what it held */
+    if (k && ksp->reason != KSP_DIVERGED_NANORINF) CCHK(hipxVecCopy(p[k], X, n));
   }
 cleanup:
   if (p[1]) (void)hipxFree(p[1]);

@@ -54,10 +54,13 @@ PetscErrorCode HipxHaloBringUp(MPI_Comm comm, PetscObject obj, hipxHalo *halo, c
       if (!hipx_rccl_up) { /* ncclUniqueId of rank 0 travels over MPI */
         char id[HIPX_COMM_ID_BYTES];
         memset(id, 0, sizeof(id));
-        if (!rank) ierr = hipxCommGetUniqueId(id);
+        int  iderr = 0; /* rank 0's hipxCommGetUniqueId result travels with the id: if it failed, NO rank may enter ncclCommInitRank (the others would wait for rank 0 for ever) */
+        if (!rank) iderr = hipxCommGetUniqueId(id);
         PetscCallMPI(MPI_Bcast(id, HIPX_COMM_ID_BYTES, MPI_BYTE, 0, comm));
-        if (!ierr && !hipx_ipc_comm_up) ierr = hipxCommInit(id, (int)rank, (int)size);
+        PetscCallMPI(MPI_Bcast(&iderr, 1, MPI_INT, 0, comm));
+        if (iderr) ierr = iderr;
         else if (hipx_ipc_comm_up) ierr = HIPX_ERR_ORDER;
+        else ierr = hipxCommInit(id, (int)rank, (int)size);
       }
     } else {
       char *mine, *all;

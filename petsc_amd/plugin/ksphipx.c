@@ -23,7 +23,7 @@ static PetscBool KSPCGHIPXApplicable(KSP ksp, Mat *Aout)
 {
   KSP_CG       *cg = (KSP_CG *)ksp->data;
   Mat           Amat, Pmat;
-  PetscBool     isjac = PETSC_FALSE, useabs = PETSC_FALSE, fixdiag = PETSC_TRUE;
+  PetscBool     isjac = PETSC_FALSE, isnone = PETSC_FALSE, useabs = PETSC_FALSE, fixdiag = PETSC_TRUE;
   PCJacobiType  jt;
   PetscMPIInt   size;
 
@@ -42,10 +42,14 @@ static PetscBool KSPCGHIPXApplicable(KSP ksp, Mat *Aout)
     if (PetscObjectTypeCompare((PetscObject)Amat, MATMPIAIJHIPX, &ismpi) || !ismpi) return PETSC_FALSE;
     if (MatMPIAIJHIPXGetDevice(Amat, &dA, &dB, &halo, &lvec) || !halo) return PETSC_FALSE;
   }
-  if (PetscObjectTypeCompare((PetscObject)ksp->pc, PCJACOBI, &isjac) || !isjac) return PETSC_FALSE;
-  if (PCJacobiGetType(ksp->pc, &jt) || jt != PC_JACOBI_DIAGONAL) return PETSC_FALSE;
-  if (PCJacobiGetUseAbs(ksp->pc, &useabs) || useabs) return PETSC_FALSE;
-  if (PCJacobiGetFixDiagonal(ksp->pc, &fixdiag) || !fixdiag) return PETSC_FALSE;
+  if (PetscObjectTypeCompare((PetscObject)ksp->pc, PCJACOBI, &isjac)) return PETSC_FALSE;
+  if (PetscObjectTypeCompare((PetscObject)ksp->pc, PCNONE, &isnone)) return PETSC_FALSE; /* PCApply_None = VecCopy (none.c:6): the fused kernels with the constant 1.0 */
+  if (!isjac && !isnone) return PETSC_FALSE;
+  if (isjac) {
+    if (PCJacobiGetType(ksp->pc, &jt) || jt != PC_JACOBI_DIAGONAL) return PETSC_FALSE;
+    if (PCJacobiGetUseAbs(ksp->pc, &useabs) || useabs) return PETSC_FALSE;
+    if (PCJacobiGetFixDiagonal(ksp->pc, &fixdiag) || !fixdiag) return PETSC_FALSE;
+  }
   if (!VecIsHIPX(ksp->vec_rhs) || !VecIsHIPX(ksp->vec_sol)) return PETSC_FALSE;
   {
     MatNullSpace nsp = NULL;
@@ -89,7 +93,11 @@ static PetscErrorCode KSPSolve_CGHIPX(KSP ksp)
     M.m = (hipx_int)n; M.A = dA; M.B = dB; M.halo = halo; M.lvec = dlv; M.nranks = (int)size;
   }
   HipxPCSetDefaults(&hpc);
-  hpc.type = HIPX_PC_JACOBI;
+  {
+    PetscBool isnone = PETSC_FALSE;
+    PetscCall(PetscObjectTypeCompare((PetscObject)ksp->pc, PCNONE, &isnone));
+    hpc.type = isnone ? HIPX_PC_NONE : HIPX_PC_JACOBI;
+  }
   PetscCallHIPX(HipxPCSetUp(&hpc, &M)); /* 1/diag, 0 -> 1: jacobi.c:205-266 on the device */
   HipxKSPSetDefaults(&k);
   k.normtype      = HIPX_KSP_NORM_PRECONDITIONED;

@@ -40,6 +40,9 @@ typedef struct {
   hipx_int *d_rleaf, *d_rroot;
   PetscBool rleaf_contig, rroot_seq_ok, rleaf_seq_ok; /* seq_ok: no duplicate inside one rank's message */
   PetscBool rleaf_dups, rroot_dups;                   /* duplicates across the whole remote list */
+  /* the device-or-staged choice of a collective must be the SAME on every rank (a rank on the parent's Isend/Irecv path cannot meet
+     neighbours inside hipxHaloBegin): the duplicate conditions above are rank-local, these are their logical ORs over the communicator */
+  PetscBool g_bcast_sum_host, g_reduce_sum_host, g_reduce_replace_host;
   PetscInt  rleaf_start;
   PetscInt  nin, nout;      /* remote incoming / outgoing ranks */
   PetscInt *inoff, *outoff; /* message offsets (host) */
@@ -184,7 +187,18 @@ static PetscErrorCode SFHIPXBuildPlan(PetscSF sf, SF_HIPX *h)
   }
   if (h->nrleaf) PetscCallHIPX(hipxMalloc((void **)&h->d_recv_leaf, sizeof(double) * (size_t)h->nrleaf));
   if (h->nrroot) PetscCallHIPX(hipxMalloc((void **)&h->d_recv_root, sizeof(double) * (size_t)h->nrroot));
-  PetscCallMPI(MPI_Allreduce(&ok, &allok, 1, MPI_INT, MPI_MIN, comm));
+  {
+    int loc[4], glob[4];
+    loc[0] = ok ? 0 : 1;
+    loc[1] = (h->lleaf_dups || (h->rleaf_dups && !h->rleaf_seq_ok)) ? 1 : 0; /* Bcast with a sum: a leaf summed into twice inside one message */
+    loc[2] = (h->lroot_dups || (h->rroot_dups && !h->rroot_seq_ok)) ? 1 : 0; /* Reduce with a sum: a root summed into twice inside one message */
+    loc[3] = (h->lroot_dups || h->rroot_dups) ? 1 : 0;                       /* Reduce with REPLACE: the LAST leaf must win */
+    PetscCallMPI(MPI_Allreduce(loc, glob, 4, MPI_INT, MPI_MAX, comm));
+    allok                    = !glob[0];
+    h->g_bcast_sum_host      = glob[1] ? PETSC_TRUE : PETSC_FALSE;
+    h->g_reduce_sum_host     = glob[2] ? PETSC_TRUE : PETSC_FALSE;
+    h->g_reduce_replace_host = glob[3] ? PETSC_TRUE : PETSC_FALSE;
+  }
   if (!allok) PetscFunctionReturn(PETSC_SUCCESS);
   if (size > 1) {
     int      *sr, *rr;
@@ -283,7 +297,7 @@ static PetscErrorCode PetscSFBcastBegin_HIPX(PetscSF sf, MPI_Datatype unit, Pets
   h->op  = op;
   h->src = rootdata;
   h->dst = leafdata;
-  if (dev && op != MPI_REPLACE && (h->lleaf_dups || (h->rleaf_dups && !h->rleaf_seq_ok))) dev = PETSC_FALSE; /* summing into a leaf twice inside one message: keep the sequential host loop */
+  if (dev && op != MPI_REPLACE && h->g_bcast_sum_host) dev = PETSC_FALSE; /* some rank sums into a leaf twice inside one message: every rank keeps the sequential host loop */
   if (dev) {
     const double *root = (const double *)rootdata;
     double       *leaf = (double *)leafdata;
@@ -363,7 +377,7 @@ static PetscErrorCode PetscSFReduceBegin_HIPX(PetscSF sf, MPI_Datatype unit, Pet
   h->dst = rootdata;
   /* several leaves of one message (or several self leaves) on the same root: with MPIU_SUM the parallel kernel would race, with
      MPI_REPLACE the LAST one must win (sequential semantics): both stay on the host loop */
-  if (dev && (h->lroot_dups || (h->rroot_dups && (!h->rroot_seq_ok || op == MPI_REPLACE)))) dev = PETSC_FALSE;
+  if (dev && (op == MPI_REPLACE ? h->g_reduce_replace_host : h->g_reduce_sum_host)) dev = PETSC_FALSE; /* decided collectively (SFHIPXBuildPlan) */
   if (dev) {
     const double *leaf = (const double *)leafdata;
     double       *root = (double *)rootdata;

@@ -35,6 +35,19 @@ PetscErrorCode VecHIPXInitRuntime(void)
   }
   PetscCallHIPX(hipxInit((int)dev));
   PetscCall(PetscOptionsGetBool(NULL, NULL, "-vec_hipx_memtype", &hipx_vec_memtype_ops, NULL));
+  { /* -hipx_reductions exact|fast: compensated (Dot2) sums in every reduction kernel -- the values the reference's VecDot / VecNorm /
+       VecMDot return when its BLAS is exactly rounded (bvec1.c:27, bvec2.c:202-223, dvec2.c:557); default: HIPX_REDUCTIONS or fast */
+    char      mode[16] = "";
+    PetscBool set      = PETSC_FALSE;
+    PetscCall(PetscOptionsGetString(NULL, NULL, "-hipx_reductions", mode, sizeof(mode), &set));
+    if (set) {
+      PetscBool ex = PETSC_FALSE, fa = PETSC_FALSE;
+      PetscCall(PetscStrcmp(mode, "exact", &ex));
+      PetscCall(PetscStrcmp(mode, "fast", &fa));
+      PetscCheck(ex || fa, PETSC_COMM_SELF, PETSC_ERR_ARG_WRONG, "-hipx_reductions must be exact or fast, not %s", mode);
+      PetscCallHIPX(hipxSetReductionMode(ex ? HIPX_RED_EXACT : HIPX_RED_FAST));
+    }
+  }
   hipx_runtime_up = PETSC_TRUE;
   PetscFunctionReturn(PETSC_SUCCESS);
 }

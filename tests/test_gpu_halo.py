@@ -36,6 +36,21 @@ def test_single_rank_comm_allreduce_and_self_halo(hx, monkeypatch):
         _lib.chk(hx.hipxVecMDotAllreduce(XA.ptr, 2, ptrs, nn, r1))
     _lib.chk(hx.hipxVecMDot(XA.ptr, 2, ptrs, nn, r2))
     assert list(r1) == list(r2) and abs(r1[0] - float(xa @ ya)) < 1e-9
+    # exact reduction mode: the local kernel leaves (hi, lo) pairs, the ranks' pairs are all-gathered and folded (ncclAllGather + fold
+    # kernel on this 1-rank communicator): the correctly rounded dot products, equal to the plain exact-mode MDot
+    _lib.chk(hx.hipxSetReductionMode(1))
+    try:
+        _lib.chk(hx.hipxVecMDotAllreduce(XA.ptr, 2, ptrs, nn, r1))
+        _lib.chk(hx.hipxVecMDot(XA.ptr, 2, ptrs, nn, r2))
+    finally:
+        _lib.chk(hx.hipxSetReductionMode(0))
+    import os
+    shim = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "libexactblas.so"))
+    shim.exactblas_dot2.restype = C.c_double
+    shim.exactblas_dot2.argtypes = [C.c_long, C.c_void_p, C.c_void_p]
+    assert list(r1) == list(r2)
+    assert r1[0] == shim.exactblas_dot2(nn, xa.ctypes.data_as(C.c_void_p), ya.ctypes.data_as(C.c_void_p))
+    assert r1[1] == shim.exactblas_dot2(nn, xa.ctypes.data_as(C.c_void_p), yb.ctypes.data_as(C.c_void_p))
     for d in (XA, YA, YB):
         d.free()
     # periodic 1-D chain: y = A_d x + B_o x[send_idx]; the "ghosts" are this rank's own first/last entries

@@ -56,9 +56,11 @@ def launch(np_, args, hipx, exact=False):
     cmd = ([MPIEXEC, "-n", str(np_)] if mp else []) + [exe] + args
     if hipx:
         cmd += ["-dll_prepend", plugin, "-vec_type", "hipx", "-mat_type", "aijhipx"]
+        if exact:  # the device reductions in compensated (Dot2) form: what the shim makes of the reference's BLAS
+            cmd += ["-hipx_reductions", "exact"]
     env = dict(os.environ, HIPX_NO_TORCH="1", MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
-    if exact:
-        assert not hipx and os.path.exists(SHIM), "oracle/libexactblas.so is not built"
+    if exact and not hipx:
+        assert os.path.exists(SHIM), "oracle/libexactblas.so is not built"
         env["LD_PRELOAD"] = SHIM
     return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
 
@@ -184,6 +186,57 @@ def test_config3_solver_gmres30_sor_27pt_64_vs_reference(np_):
     check_history("27-pt 64^3 GMRES(30)+PCSOR np=%d: plugin vs exactly rounded reductions" % np_, got, exact, tol=TOL_GMRES_SOR)
     check_history("27-pt 64^3 GMRES(30)+PCSOR np=%d: plugin vs CPU run" % np_, got, ref, tol=d_ref + TOL_GMRES_SOR)
     assert abs(got[3] - ref[3]) <= 1e-7 * ref[3] + 1e-13
+
+
+def test_config2_exact_mode_history_equals_the_reference_with_exact_blas_bit_for_bit(hx):
+    """with the device reductions in compensated form (-hipx_reductions exact / hipxSetReductionMode) the 256^3
+    CG+Jacobi history of every GPU path -- the reference's KSPSolve_CG over the hipx types, -ksp_type cghipx, the host layer's
+    three forms -- EQUALS the reference's own run with exact BLAS reductions (oracle/libexactblas.so), entry by entry, bit for bit:
+    every other kernel of the iteration was bit-exact already."""
+    from petsc_amd import _lib
+    _, ks = _lib.load()
+    n, its = 256, 50
+    args = ["-stencil", "7", "-n", str(n), "-ksp_type", "cg", "-pc_type", "jacobi", "-ksp_rtol", "1e-50", "-ksp_max_it", str(its), "-history"]
+    p_refx = launch(1, args, False, exact=True)
+    cg = collect(launch(1, args, True, exact=True))
+    cgx = collect(launch(1, [a if a != "cg" else "cghipx" for a in args], True, exact=True))
+    host = {}
+    _lib.chk(hx.hipxSetReductionMode(1))
+    try:
+        for name, fused, pipe in [("host layer, one kernel per call", 0, 0), ("host layer, fused kernels", 1, 0), ("host layer, fused + launch-ahead", 1, 1)]:
+            host[name] = host_cg(hx, ks, n, its, fused, pipe)
+    finally:
+        _lib.chk(hx.hipxSetReductionMode(0))
+    refx = collect(p_refx)
+    for name, got in list(host.items()) + [("plugin, reference KSPSolve_CG over hipx types", cg), ("plugin, -ksp_type cghipx", cgx)]:
+        check_history("256^3 CG+Jacobi EXACT mode: %s vs the REFERENCE with exact BLAS reductions" % name, got, refx, tol=0.0)
+        assert np.array_equal(got[0], refx[0])
+    assert cg[3] == refx[3]  # the error norm the driver prints: the same solution
+
+
+@pytest.mark.parametrize("np_", [1, 2, 3, 4])
+def test_config3_solver_gmres30_sor_exact_mode_within_1e12(np_):
+    """KSPGMRES(30)+PCSOR 27-pt 64^3 to convergence, sequential and on 2-4 MPI ranks: plugin with -hipx_reductions exact against the
+    reference's own run with exact BLAS reductions at north_star's 1e-12 (fast mode: TOL_GMRES_SOR above -- the tail before
+    convergence amplifies reduction rounding; with that rounding gone the rest of the path is bit-exact)."""
+    n = 64
+    args = ["-stencil", "27", "-n", str(n), "-ksp_type", "gmres", "-pc_type", "sor", "-ksp_rtol", "1e-8", "-history"]
+    p_refx = launch(np_, args, False, exact=True)
+    got = collect(launch(np_, args, True, exact=True))
+    refx = collect(p_refx)
+    check_history("27-pt 64^3 GMRES(30)+PCSOR np=%d EXACT mode: plugin vs the REFERENCE with exact BLAS reductions" % np_, got, refx, tol=TOL_HISTORY)
+
+
+@pytest.mark.parametrize("np_", [1, 2])
+def test_pipelined_and_single_reduction_cg_exact_mode_within_1e12(np_):
+    """KSPPIPECG / KSPGROPPCG / -ksp_cg_single_reduction / CG+SOR over the hipx types with -hipx_reductions exact against the
+    reference's own run of the same solver with exact BLAS reductions: 1e-12 per entry to convergence (rtol 1e-8)."""
+    for ksp in (["-ksp_type", "pipecg"], ["-ksp_type", "groppcg"], ["-ksp_type", "cg", "-ksp_cg_single_reduction"], ["-ksp_type", "cg", "-pc_type", "sor"]):
+        args = ["-stencil", "7", "-n", "32", "-pc_type", "jacobi", "-ksp_rtol", "1e-8", "-history"] + ksp
+        p_refx = launch(np_, args, False, exact=True)
+        got = collect(launch(np_, args, True, exact=True))
+        refx = collect(p_refx)
+        check_history("7-pt 32^3 %s np=%d EXACT mode: plugin vs the REFERENCE with exact BLAS reductions" % (" ".join(ksp), np_), got, refx, tol=TOL_HISTORY)
 
 
 @pytest.mark.parametrize("np_", [1, 2])
