@@ -600,7 +600,7 @@ __global__ __launch_bounds__(kRedThreads) void dotnorm2_kernel(const double *x, 
 // forms the same IEEE quotient for its own bookkeeping), so the launch does not have to wait for the host to see them.
 // CONSTD = true: the Jacobi diagonal is one constant (constant-coefficient operators): z = r * dconst without reading d[] --
 // the same product, one vector pass less.
-template <bool UPX, bool DEVS, bool CONSTD = false, bool COMP = false>
+template <bool UPX, bool DEVS, bool CONSTD = false, bool COMP = false, bool WIDE = true>
 __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a_arg,
                                                                 const double *dev_beta, const double *dev_dpi, hipx_int n, bool vec, RedOut out, double dconst = 0.0)
 {
@@ -634,22 +634,29 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
       acc[1].prod(zv.x, rv.x);
       acc[1].prod(zv.y, rv.y);
     };
-    // two elements per stream in flight per thread (10 x 16-byte loads issued before the first use); the per-thread
-    // accumulation order is unchanged (q, then q + kRedThreads)
+    // U elements per stream in flight per thread (all loads of a round issued before the first use): 4 when only r and w are streamed
+    // (no x update, constant diagonal: the launch-ahead CG's configuration -- 8 x 16-byte loads per thread, 128 KiB in flight per CU;
+    // with 2 the kernel ran at 0.58 of the HBM peak where the five-stream AYPX kernel beside it reaches 0.75), 2 otherwise (register
+    // budget of the 1024-thread workgroup).  The per-thread accumulation order is unchanged: q, q + kRedThreads, ...
+    constexpr int  U  = (!UPX && CONSTD && WIDE) ? 4 : 2;  // (WIDE = false: the round-3 loop, kept behind HIPX_CG_FUSED_U2 for same-box A/B timing)
+    const double2  z0 = {0.0, 0.0};
+    const double2  dc = {dconst, dconst};
     hipx_int q = c0 + (hipx_int)threadIdx.x;
-    for (; q + kRedThreads < c1; q += 2 * kRedThreads) {
-      const hipx_int q1 = q + kRedThreads;
-      const double2  z0 = {0.0, 0.0};
-      const double2  dc = {dconst, dconst};
-      const double2  xa = UPX ? x2[q] : z0, ra = r2[q], pa = UPX ? p2[q] : z0, wa = w2[q], da = CONSTD ? dc : d2[q];
-      const double2  xb = UPX ? x2[q1] : z0, rb = r2[q1], pb = UPX ? p2[q1] : z0, wb = w2[q1], db = CONSTD ? dc : d2[q1];
-      step(q, xa, ra, pa, wa, da);
-      step(q1, xb, rb, pb, wb, db);
+    for (; q + (U - 1) * (hipx_int)kRedThreads < c1; q += U * kRedThreads) {
+      double2 xa[U], ra[U], pa[U], wa[U], da[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const hipx_int qu = q + u * (hipx_int)kRedThreads;
+        xa[u] = UPX ? x2[qu] : z0;
+        ra[u] = r2[qu];
+        pa[u] = UPX ? p2[qu] : z0;
+        wa[u] = w2[qu];
+        da[u] = CONSTD ? dc : d2[qu];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) step(q + u * (hipx_int)kRedThreads, xa[u], ra[u], pa[u], wa[u], da[u]);
     }
-    if (q < c1) {
-      const double2 z0 = {0.0, 0.0}, dc = {dconst, dconst};
-      step(q, UPX ? x2[q] : z0, r2[q], UPX ? p2[q] : z0, w2[q], CONSTD ? dc : d2[q]);
-    }
+    for (; q < c1; q += kRedThreads) step(q, UPX ? x2[q] : z0, r2[q], UPX ? p2[q] : z0, w2[q], CONSTD ? dc : d2[q]);
     if ((n & 1) && tid == 0) {
       hipx_int i  = n - 1;
       double   rv = r[i] + ma * w[i], zv = rv * (CONSTD ? dconst : d[i]);
@@ -744,11 +751,13 @@ template <bool DEVS, bool CONSTD>
 static inline void cg_fused_go(unsigned g, hipStream_t st, double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, const double *dev_beta,
                                const double *dev_dpi, hipx_int n, bool vec, RedOut o, double dconst)
 {
+  static const bool u2 = getenv("HIPX_CG_FUSED_U2") != nullptr;
   if (rt().red_exact) {
     if (x) cg_fused_kernel<true, DEVS, CONSTD, true><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, a, dev_beta, dev_dpi, n, vec, o, dconst);
     else cg_fused_kernel<false, DEVS, CONSTD, true><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, a, dev_beta, dev_dpi, n, vec, o, dconst);
   } else {
     if (x) cg_fused_kernel<true, DEVS, CONSTD, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, a, dev_beta, dev_dpi, n, vec, o, dconst);
+    else if (u2) cg_fused_kernel<false, DEVS, CONSTD, false, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, a, dev_beta, dev_dpi, n, vec, o, dconst);
     else cg_fused_kernel<false, DEVS, CONSTD, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, a, dev_beta, dev_dpi, n, vec, o, dconst);
   }
 }

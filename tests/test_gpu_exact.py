@@ -42,13 +42,16 @@ def dot2(L, x, y):
 
 
 def cancelling(n, seed):
-    """x.y cancels to ~1e-10 of sum |x_i y_i|, magnitudes spread over 12 decades: a plain fp64 tree is wrong in the 6th digit."""
+    """x.y cancels: sum |x_i y_i| / |x.y| ~ 1e6 sqrt(n) for the sizes that are also checked against exact rational arithmetic (a plain fp64
+    tree is wrong from the 8th digit on), ~1e2 sqrt(n) beyond (Dot2's own error n eps^2 cond must stay far below one ulp for two
+    differently associated Dot2 evaluations to round to the same double); magnitudes spread over 6 decades."""
     rng = np.random.default_rng(seed)
     h = n // 2
-    a = rng.standard_normal(h) * 10.0 ** rng.integers(-6, 6, h)
+    pert = 1e-6 if n <= 5000 else 1e-2
+    a = rng.standard_normal(h) * 10.0 ** rng.integers(-3, 3, h)
     b = rng.standard_normal(h)
     x = np.concatenate([a, a, rng.standard_normal(n - 2 * h)])
-    y = np.concatenate([b, -b * (1.0 + 1e-10 * rng.standard_normal(h)), 1e-3 * rng.standard_normal(n - 2 * h)])
+    y = np.concatenate([b, -b * (1.0 + pert * rng.standard_normal(h)), 1e-3 * rng.standard_normal(n - 2 * h)])
     p = rng.permutation(n)
     return x[p], y[p]
 
