@@ -7,8 +7,9 @@
 
 namespace hipx {
 
-constexpr int kRedBlocks     = 256;   // one workgroup per CU: fixed reduction grid -> fixed summation order, and only 256
-                                        // arrivals on the ticket counter (one contended word takes ~12 ns per atomic)
+constexpr int kRedBlocks     = 512;   // most workgroups a reduction launches (the stride of its partials).  The grid is a function of n
+                                        // only (red_grid(): one 1024-thread workgroup per CU by default, HIPX_RED_BLOCKS = 512: two) -> fixed
+                                        // summation order, and few arrivals on the ticket counter (one contended word takes ~12 ns per atomic)
 constexpr int kRedThreads    = 1024;
 constexpr int kMaxRedVals    = 32;    // sums produced by one reduction launch (MDot batches)
 constexpr int kEwMaxBlocks   = 4096;  // grid cap of the grid-stride elementwise kernels

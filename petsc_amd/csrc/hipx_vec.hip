@@ -728,8 +728,13 @@ __global__ void replace_zeros_kernel(double *x, hipx_int n, double value, unsign
 inline unsigned red_grid(hipx_int n)
 {
   // enough 1024-thread workgroups to cover n at 8 elements/thread, capped at kRedBlocks (one per CU); a function of n only
+  static const hipx_int cap = [] {
+    const char *e = getenv("HIPX_RED_BLOCKS");
+    const int   v = e ? atoi(e) : 256;
+    return (hipx_int)((v >= 1 && v <= kRedBlocks) ? v : 256);
+  }();
   hipx_int g = (n + kRedThreads * 8 - 1) / (kRedThreads * 8);
-  if (g > kRedBlocks) g = kRedBlocks;
+  if (g > cap) g = cap;
   return (unsigned)(g < 1 ? 1 : g);
 }
 
