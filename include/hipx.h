@@ -227,6 +227,15 @@ int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len);
 /* y = A x and *dot = x.y fused in the SpMV epilogue (cg.c:257-258) */
 int hipxMatMultDot(hipxMat A, const double *x, double *y, double *dot);
 int hipxMatMultDotBegin(hipxMat A, const double *x, double *y, int slot, double *dev_dot); /* enqueue only; hipxRedEnd(slot, 1, &dot) waits */
+/* The CG direction update as the PROLOGUE of the product (round 4): p_new = (z * dconst) + b p_old (cg.c:248-249, VecAYPX dvec2.c:774; z = the
+   preconditioned residual with dconst = 1, or the residual itself with the constant Jacobi diagonal / PCNONE), x += a p_old (cg.c:305 of the
+   iteration before), w = A p_new, dot = p_new . w (cg.c:257-258) in ONE kernel -- element by element the operations of hipxCGAypxAxpyDev / R
+   followed by hipxMatMultDotBegin, hence the same bits.  b and a: from the device-resident sums when dev_beta_new != NULL (b = *dev_beta_new /
+   *dev_beta_old, a = *dev_beta_old / *dev_dpi), else the arguments.  p_new must be a second direction vector (other workgroups still read
+   p_old), w must not alias z.  Only matrices that take the second-generation march form (stencil row templates, spmv_march2_kernel) with
+   16-byte aligned vectors support it: *fused = 0 means NOTHING was enqueued and the caller runs the separate kernels. */
+int hipxMatMultCGDirectionDotBegin(hipxMat A, const double *p_old, double *p_new, const double *z, double dconst, double *x, double b, double a, const double *dev_beta_new,
+                                   const double *dev_beta_old, const double *dev_dpi, double *w, int slot, double *dev_dot, int *fused);
 
 /* ---- PC ------------------------------------------------------------------------------------------ */
 /* PCSetUp_Jacobi jacobi.c:205-266 (DIAGONAL, fixdiag): d = 1/diag(A), zeros -> 1 */

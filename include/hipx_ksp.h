@@ -70,6 +70,8 @@ typedef struct {
   int      external_test;    /* 1: the caller runs its own convergence test after every step (the PETSc plugin: ksp->converged) */
   int      pipeline;         /* fused CG on one rank: enqueue iteration i+1 before the host has seen the sums of iteration i (default 1) */
   double  *dscal;            /* device scalars of the launch-ahead path: [0] p.w, [2+2q] z.z, [3+2q] z.r of the iterations of parity q */
+  double  *P2;               /* second direction vector: hipxMatMultCGDirectionDotBegin (direction update as the product's prologue) writes p_new here
+                                while other workgroups still read p; P and P2 swap roles after every fused launch (P is always the current direction) */
 } HipxKSP;
 
 /* sizeof of the three descriptor structs, so that a foreign-language mirror (petsc_amd/_lib.py) can verify its layout */

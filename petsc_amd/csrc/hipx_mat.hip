@@ -1873,10 +1873,24 @@ struct MarchRuns<27> {
   static __host__ __device__ constexpr int ln(int) { return 3; }
 };
 
-template <int NE, int NQ, int NHALO, bool DOT>
+// CG = true: the CG direction update as the kernel's PROLOGUE (round 4; cg.c:248-249 and the x update of cg.c:305 left over from the iteration
+// before, i.e. hipxCGAypxAxpy...): x[] is the OLD direction p; while a plane (with its halos) passes from registers into LDS the kernel forms
+//     p_new = (z * dconst) + b p        z: the preconditioned residual, or the residual itself with the constant Jacobi diagonal / PCNONE (dconst)
+// element by element -- the operations, operands and order of cg_aypx_axpy_kernel: the same bits, in the halo as in the rows of their owner --
+// multiplies by the matrix out of LDS as before (y = A p_new, dot = p_new . y), and for the rows it owns also stores p_new (to a SECOND
+// direction vector: other workgroups still read p in their halos) and x += a p.  One launch and one pass over p less per iteration:
+// A(i) + B(i) read p, z, x, p(1.1x), ids and write p, x, y; this kernel reads p(1.1x), z(1.1x), x and writes p_new, x, y.
+struct hipxMarchCG {
+  const double *z;                                   // z (dconst = 1) or r (dconst = the constant inverse diagonal)
+  double       *pnew, *xsol;
+  double        dconst, b, a;                        // b, a: used when dev_beta_new == NULL
+  const double *dev_beta_new, *dev_beta_old, *dev_dpi;  // device-resident sums of the kernels queued before: b = beta_new / beta_old, a = beta_old / dpi
+};
+
+template <int NE, int NQ, int NHALO, bool DOT, bool CG = false>
 __global__ __launch_bounds__(256, 2) void spmv_march2_kernel(const hipxMarchPlan plan, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask, const int ntmpl,
                                                               const double *__restrict__ x, double *__restrict__ yout, double *__restrict__ dotpart, const int tiles, const int pps,
-                                                              const int nplanes, const int xcdmap)
+                                                              const int nplanes, const int xcdmap, const hipxMarchCG cg = hipxMarchCG{})
 {
   using RS = MarchRuns<NE>;
   typedef double dbl2 __attribute__((ext_vector_type(2)));
@@ -1927,35 +1941,93 @@ __global__ __launch_bounds__(256, 2) void spmv_march2_kernel(const hipxMarchPlan
     he[hh]          = hlow[hh] ? 2 * hidx - H : L + 2 * (hidx - H2);
     hl[hh]          = (he[hh] + H) * 8;
   }
-  const auto load_plane = [&](int p, dbl2 (&RO)[NOWN], dbl2 (&RH)[NHALO]) {
+  // the registers of one plane in flight: its own rows and halo (p when CG), and with the CG prologue the same of z plus the own rows of x
+  struct PlaneRegs {
+    dbl2 o[NOWN], h[NHALO];
+    dbl2 zo[CG ? NOWN : 1], zh[CG ? NHALO : 1], xo[CG ? NOWN : 1];
+  };
+  double cgb = 0.0, cga = 0.0, cgd = 1.0;
+  if (CG) {
+    cgb = cg.dev_beta_new ? (*cg.dev_beta_new / *cg.dev_beta_old) : cg.b;  // cg.c:248
+    cga = cg.dev_beta_new ? (*cg.dev_beta_old / *cg.dev_dpi) : cg.a;       // cg.c:288 of the iteration before
+    cgd = cg.dconst;
+  }
+  const auto load_plane = [&](int p, PlaneRegs &R) {
     // planes outside the grid: the rows that would use them lack those entries.  Planes beyond the segment's last halo plane (k1): nobody
     // uses them, but the loads stay (a wave's memory operations retire in order and the compiler can only count what is certain to have
     // been issued: a conditional load here turns the wait for the plane before into a wait for everything) -- they re-read plane k1 (L2 hits)
-    const int     pe  = p > k1 ? k1 : p;
-    const int     pc  = pe < 0 ? 0 : (pe >= nplanes ? nplanes - 1 : pe);
-    const double *src = x + ((long long)pc * S + i0);
+    const int       pe  = p > k1 ? k1 : p;
+    const int       pc  = pe < 0 ? 0 : (pe >= nplanes ? nplanes - 1 : pe);
+    const long long g0  = (long long)pc * S + i0;
+    const double   *src = x + g0;
 #pragma unroll
-    for (int qq = 0; qq < NOWN; qq++) RO[qq] = *reinterpret_cast<const dbl2 *>(src + 2 * (qq * 256 + t));
+    for (int qq = 0; qq < NOWN; qq++) R.o[qq] = *reinterpret_cast<const dbl2 *>(src + 2 * (qq * 256 + t));
     const bool lofix = pc == 0 && i0 < H, hifix = pc == nplanes - 1 && i0 + L + H > S;  // halo beyond the vector's ends (uniform)
+    int        off[NHALO];
 #pragma unroll
     for (int hh = 0; hh < NHALO; hh++) {
-      int off = he[hh];
-      if ((lofix && hlow[hh]) || (hifix && !hlow[hh])) off = 0;
-      RH[hh] = *reinterpret_cast<const dbl2 *>(src + off);
+      off[hh] = he[hh];
+      if ((lofix && hlow[hh]) || (hifix && !hlow[hh])) off[hh] = 0;
+      R.h[hh] = *reinterpret_cast<const dbl2 *>(src + off[hh]);
+    }
+    if (CG) {
+      const double *zs = cg.z + g0, *xs = cg.xsol + g0;
+#pragma unroll
+      for (int qq = 0; qq < NOWN; qq++) R.zo[qq] = *reinterpret_cast<const dbl2 *>(zs + 2 * (qq * 256 + t));
+#pragma unroll
+      for (int hh = 0; hh < NHALO; hh++) R.zh[hh] = *reinterpret_cast<const dbl2 *>(zs + off[hh]);
+#pragma unroll
+      for (int qq = 0; qq < NOWN; qq++) R.xo[qq] = *reinterpret_cast<const dbl2 *>(xs + 2 * (qq * 256 + t));
     }
   };
-  const auto store_plane = [&](int sbase, const dbl2 (&RO)[NOWN], const dbl2 (&RH)[NHALO]) {
+  // plane p from registers into the buffer at sbase; CG: as p_new, and for the planes this workgroup owns (k0 <= p < k1) p_new and x += a p go to memory
+  const auto store_plane = [&](int sbase, int p, const PlaneRegs &R) {
     char *d = smem + sbase;
+    if (!CG) {
 #pragma unroll
-    for (int qq = 0; qq < NOWN; qq++) *reinterpret_cast<dbl2 *>(d + H * 8 + (qq * 256 + t) * 16) = RO[qq];
+      for (int qq = 0; qq < NOWN; qq++) *reinterpret_cast<dbl2 *>(d + H * 8 + (qq * 256 + t) * 16) = R.o[qq];
 #pragma unroll
-    for (int hh = 0; hh < NHALO; hh++)
-      if (hact[hh]) *reinterpret_cast<dbl2 *>(d + hl[hh]) = RH[hh];
+      for (int hh = 0; hh < NHALO; hh++)
+        if (hact[hh]) *reinterpret_cast<dbl2 *>(d + hl[hh]) = R.h[hh];
+    } else {
+      const bool own = p >= k0 && p < k1;
+      dbl2       pn[NOWN];
+#pragma unroll
+      for (int qq = 0; qq < NOWN; qq++) {
+        dbl2 zv = R.zo[qq];
+        zv.x    = zv.x * cgd;
+        zv.y    = zv.y * cgd;
+        pn[qq].x = zv.x + cgb * R.o[qq].x;
+        pn[qq].y = zv.y + cgb * R.o[qq].y;
+        *reinterpret_cast<dbl2 *>(d + H * 8 + (qq * 256 + t) * 16) = pn[qq];
+      }
+#pragma unroll
+      for (int hh = 0; hh < NHALO; hh++) {
+        dbl2 zv = R.zh[hh], ph;
+        zv.x    = zv.x * cgd;
+        zv.y    = zv.y * cgd;
+        ph.x    = zv.x + cgb * R.h[hh].x;
+        ph.y    = zv.y + cgb * R.h[hh].y;
+        if (hact[hh]) *reinterpret_cast<dbl2 *>(d + hl[hh]) = ph;
+      }
+      if (own) {
+        const long long g0 = (long long)p * S + i0;
+        double         *pd = cg.pnew + g0, *xd = cg.xsol + g0;
+#pragma unroll
+        for (int qq = 0; qq < NOWN; qq++) {
+          dbl2 xv = R.xo[qq];
+          xv.x    = xv.x + cga * R.o[qq].x;
+          xv.y    = xv.y + cga * R.o[qq].y;
+          *reinterpret_cast<dbl2 *>(pd + 2 * (qq * 256 + t)) = pn[qq];
+          *reinterpret_cast<dbl2 *>(xd + 2 * (qq * 256 + t)) = xv;
+        }
+      }
+    }
   };
-  dbl2 RO0[NOWN], RH0[NHALO], RO1[NOWN], RH1[NHALO];  // planes in flight: two steps ahead of their use
-  int  s_lo = 0, s_mid = W * 8, s_hi = 2 * W * 8;
-  load_plane(k0 - 1, RO0, RH0);
-  load_plane(k0, RO1, RH1);
+  PlaneRegs R0, R1;  // planes in flight: AHEAD steps ahead of their use
+  int       s_lo = 0, s_mid = W * 8, s_hi = 2 * W * 8;
+  load_plane(k0 - 1, R0);
+  load_plane(k0, R1);
   __syncthreads();  // s_mask
   // masks of this thread's rows, and which pairs of row groups a wave can treat uniformly (every lane's rows have the full template).  The
   // template ids are plane-periodic over the interior planes: the masks are looked up when the march starts, after the grid's first plane and
@@ -1970,16 +2042,16 @@ __global__ __launch_bounds__(256, 2) void spmv_march2_kernel(const hipxMarchPlan
     for (int j = 0; j < NJ; j++) uni[j] = __builtin_amdgcn_ballot_w64(((mk[2 * j] ^ plan.full) | (mk[2 * j + 1] ^ plan.full)) != 0u) == 0ull;
   };
   load_masks(k0);
-  store_plane(s_lo, RO0, RH0);
-  store_plane(s_mid, RO1, RH1);
-  load_plane(k0 + 1, RO0, RH0);
-  if (AHEAD == 2) load_plane(k0 + 2, RO1, RH1);
+  store_plane(s_lo, k0 - 1, R0);
+  store_plane(s_mid, k0, R1);
+  load_plane(k0 + 1, R0);
+  if (AHEAD == 2) load_plane(k0 + 2, R1);
   double acc = 0.0;
-  // one plane step: (RO, RH) hold plane k + 1 (loaded AHEAD steps ago); plane k + 1 + AHEAD goes into them
-  const auto step = [&](int k, dbl2 (&RO)[NOWN], dbl2 (&RH)[NHALO]) {
-    store_plane(s_hi, RO, RH);
+  // one plane step: R holds plane k + 1 (loaded AHEAD steps ago); plane k + 1 + AHEAD goes into it
+  const auto step = [&](int k, PlaneRegs &R) {
+    store_plane(s_hi, k + 1, R);
     __syncthreads();
-    load_plane(k + 1 + AHEAD, RO, RH);
+    load_plane(k + 1 + AHEAD, R);
     // (the runs' address constants are loop invariants; so are their sums with the row offsets, which the compiler would otherwise keep in
     // NR x NJ more registers across the whole march)
 #pragma unroll
@@ -2065,11 +2137,11 @@ __global__ __launch_bounds__(256, 2) void spmv_march2_kernel(const hipxMarchPlan
   };
   if (AHEAD == 2) {
     for (int k = k0; k < k1; k += 2) {
-      step(k, RO0, RH0);
-      if (k + 1 < k1) step(k + 1, RO1, RH1);
+      step(k, R0);
+      if (k + 1 < k1) step(k + 1, R1);
     }
   } else {
-    for (int k = k0; k < k1; k++) step(k, RO0, RH0);
+    for (int k = k0; k < k1; k++) step(k, R0);
   }
   if (DOT) {
     const double w = hipx::wave_sum(acc);
@@ -2919,17 +2991,51 @@ static int march2_check(hipxMat A)
   return HIPX_SUCCESS;
 }
 
-template <int NE, int NQ, int NHALO, bool DOT>
-static int launch_march2_inst(hipxMat A, const double *x, double *yout, double *dotpart, int units, int tiles, int pps, int nplanes, int xm, size_t lds)
+// work split of the march forms: tiles x segments of planes ~ HIPX_TMPL_MARCH_UNITS workgroups (2 per CU resident), segments of >= 8 planes
+static void march_geometry(hipxMat A, int &tiles, int &nseg, int &pps, int &nplanes, int &units)
+{
+  static const int     units_env = getenv("HIPX_TMPL_MARCH_UNITS") ? atoi(getenv("HIPX_TMPL_MARCH_UNITS")) : 512;
+  const hipxMarchPlan &mp = A->march_plan;
+  const hipx_int       m  = A->nrows_c;
+  tiles   = (mp.S + mp.L - 1) / mp.L;
+  nplanes = (int)((m + mp.S - 1) / mp.S);
+  nseg    = std::max(1, std::min(nplanes / 8, (units_env + tiles / 2) / tiles));
+  pps     = (nplanes + nseg - 1) / nseg;
+  nseg    = (nplanes + pps - 1) / pps;
+  units   = tiles * nseg;
+}
+
+template <int NE, int NQ, int NHALO, bool DOT, bool CG = false>
+static int launch_march2_inst(hipxMat A, const double *x, double *yout, double *dotpart, int units, int tiles, int pps, int nplanes, int xm, size_t lds, const hipxMarchCG &cg = hipxMarchCG{})
 {
   static bool attr = false;
   if (!attr) {
-    HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_march2_kernel<NE, NQ, NHALO, DOT>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_march2_kernel<NE, NQ, NHALO, DOT, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr = true;
   }
-  spmv_march2_kernel<NE, NQ, NHALO, DOT><<<(unsigned)units, 256, lds, rt().compute>>>(A->march_plan, A->d_tid, A->d_tmask, A->ntmpl, x, yout, dotpart, tiles, pps, nplanes, xm);
+  spmv_march2_kernel<NE, NQ, NHALO, DOT, CG><<<(unsigned)units, 256, lds, rt().compute>>>(A->march_plan, A->d_tid, A->d_tmask, A->ntmpl, x, yout, dotpart, tiles, pps, nplanes, xm, cg);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
+}
+// the shapes the CG prologue is instantiated for (short templates: the long ones have no registers left for two more streams in flight)
+static bool march2_cg_shape(const hipxMarchPlan &mp)
+{
+  const int nq = mp.L / 256, nh = (mp.H + 255) / 256;
+  return (mp.ne == 7 && nq == 8 && nh <= 2) || ((mp.ne == 7 || mp.ne == 5 || mp.ne == 9) && nq == 4 && nh == 1);
+}
+template <bool DOT>
+static int launch_march2_cg(hipxMat A, const double *x, double *yout, double *dotpart, int units, int tiles, int pps, int nplanes, int xm, size_t lds, const hipxMarchCG &cg)
+{
+  const hipxMarchPlan &mp = A->march_plan;
+  const int            nq = mp.L / 256, nh = (mp.H + 255) / 256;
+#define HIPX_M2(NE, NQ, NH) return launch_march2_inst<NE, NQ, NH, DOT, true>(A, x, yout, dotpart, units, tiles, pps, nplanes, xm, lds, cg)
+  if (mp.ne == 7 && nq == 8 && nh == 1) HIPX_M2(7, 8, 1);
+  if (mp.ne == 7 && nq == 8 && nh == 2) HIPX_M2(7, 8, 2);
+  if (mp.ne == 7 && nq == 4 && nh == 1) HIPX_M2(7, 4, 1);
+  if (mp.ne == 5 && nq == 4 && nh == 1) HIPX_M2(5, 4, 1);
+  if (mp.ne == 9 && nq == 4 && nh == 1) HIPX_M2(9, 4, 1);
+#undef HIPX_M2
+  return fail(HIPX_ERR_ARG, "march2 (CG prologue): shape not instantiated", __FILE__, __LINE__);
 }
 template <bool DOT>
 static int launch_march2(hipxMat A, const double *x, double *yout, double *dotpart, int units, int tiles, int pps, int nplanes, int xm, size_t lds)
@@ -3764,8 +3870,13 @@ int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
     if (ierr) return ierr;
   }
   if (sl) name = "spmv_sell_kernel (MatMult on the SELL-64 copy: one lane per row, 16-bit window-coded columns)";
-  else if (tm && march_applies(A))
-    name = "spmv_march_kernel (CSR MatMult, row templates: 1 byte per row; three planes of x resident in LDS, every operand an LDS read)";
+  else if (tm && march_applies(A)) {
+    int ierr = march2_check(A);
+    if (ierr) return ierr;
+    if (A->march2_state == 1 && !getenv("HIPX_MARCH1") && !getenv("HIPX_TMPL_TRACE"))
+      name = "spmv_march2_kernel (CSR MatMult, row templates: 1 byte per row, plane-periodic; three planes of x resident in LDS, every operand an LDS read at a run's immediate offset)";
+    else name = "spmv_march_kernel (CSR MatMult, row templates: 1 byte per row; three planes of x resident in LDS, every operand an LDS read)";
+  }
   else if (tm && A->pair_ok && A->pair_plan.npairs <= (getenv("HIPX_TMPL_PAIRMAX") ? atoi(getenv("HIPX_TMPL_PAIRMAX")) : 16) && A->d_tmask && !getenv("HIPX_TMPL_NOSUB") && !getenv("HIPX_TMPL_NOPAIR") && !getenv("HIPX_TMPL_PROBE") && tmpl_cfg() == 1 && A->nrows_c >= 512)
     name = "spmv_pair_kernel (CSR MatMult, row templates: 1 byte per row; two consecutive rows per thread, 16-byte loads of x at the even offsets, +-1 entries from the neighbouring lanes)";
   else if (tm && A->d_tmask && !getenv("HIPX_TMPL_NOSUB")) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row; every template a subset of the interior one: uniform masked walk)";
@@ -3871,6 +3982,50 @@ int hipxMatMultDotBegin(hipxMat A, const double *x, double *y, int slot, double 
   int      ierr  = matmultdot_launch(A, x, y, &npart);
   if (ierr) return ierr;
   return launch_sum(A->d_dotpart, npart, slot, dev_dot);
+}
+
+int hipxMatMultCGDirectionDotBegin(hipxMat A, const double *p_old, double *p_new, const double *z, double dconst, double *x, double b, double a, const double *dev_beta_new,
+                                   const double *dev_beta_old, const double *dev_dpi, double *w, int slot, double *dev_dot, int *fused)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A && fused && p_old && p_new && z && x && w, "null argument");
+  HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2, "reduction slot out of range");
+  HIPX_ARG(p_old != p_new && p_new != w && p_old != w && x != w && x != p_new && z != w && z != p_new, "the vectors must be distinct (z may not alias w: W = Z in cg.c:145 is for the caller to unalias)");
+  *fused = 0;
+  static const bool off = getenv("HIPX_NO_CGFUSE") != nullptr;
+  if (off || A->compressed || A->m != A->n || A->m <= 0) return HIPX_SUCCESS;
+  if ((reinterpret_cast<uintptr_t>(p_old) | reinterpret_cast<uintptr_t>(p_new) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) return HIPX_SUCCESS;
+  bool tm = false;
+  int  ierr = use_templates(A, tm);
+  if (ierr) return ierr;
+  if (!tm || !march_applies(A) || getenv("HIPX_MARCH1") || getenv("HIPX_TMPL_TRACE")) return HIPX_SUCCESS;
+  if ((ierr = march2_check(A))) return ierr;
+  if (A->march2_state != 1 || !march2_cg_shape(A->march_plan)) return HIPX_SUCCESS;
+  int tiles, nseg, pps, nplanes, units;
+  march_geometry(A, tiles, nseg, pps, nplanes, units);
+  const hipx_int npart = (hipx_int)units * 4;
+  if (npart > A->dotpart_cap) {
+    HIPX_HIP(hipStreamSynchronize(rt().compute));
+    (void)hipFree(A->d_dotpart);
+    HIPX_HIP(hipMalloc((void **)&A->d_dotpart, sizeof(double) * (size_t)npart));
+    A->dotpart_cap = npart;
+  }
+  const hipxMarchPlan &mp  = A->march_plan;
+  const size_t         lds = 3 * (size_t)(mp.L + 2 * mp.H) * sizeof(double);
+  const int            xm  = (units % 8 == 0) ? 1 : 0;
+  const hipxMarchCG    cg{z, p_new, x, dconst, b, a, dev_beta_new, dev_beta_old, dev_dpi};
+  if ((ierr = prof_mark(true))) return ierr;
+  if (rt().red_exact) {  // compensated mode: the epilogue's per-wave partials are plain sums -- Dot2 over the complete vectors instead
+    if ((ierr = launch_march2_cg<false>(A, p_old, w, nullptr, units, tiles, pps, nplanes, xm, lds, cg))) return ierr;
+    if ((ierr = prof_mark(false))) return ierr;
+    if ((ierr = launch_dot(p_new, w, A->m, slot, dev_dot))) return ierr;
+  } else {
+    if ((ierr = launch_march2_cg<true>(A, p_old, w, A->d_dotpart, units, tiles, pps, nplanes, xm, lds, cg))) return ierr;
+    if ((ierr = prof_mark(false))) return ierr;
+    if ((ierr = launch_sum(A->d_dotpart, npart, slot, dev_dot))) return ierr;
+  }
+  *fused = 1;
+  return HIPX_SUCCESS;
 }
 
 int hipxMatGetDiagonal(hipxMat A, double *d)

@@ -199,6 +199,7 @@ static int ensure_cg_work(HipxKSP *ksp, hipx_int n)
   CHK(hipxMalloc((void **)&ksp->R, bytes));
   CHK(hipxMalloc((void **)&ksp->Z, bytes));
   CHK(hipxMalloc((void **)&ksp->P, bytes));
+  CHK(hipxMalloc((void **)&ksp->P2, bytes));
   CHK(hipxMalloc((void **)&ksp->dscal, sizeof(double) * 8));
   ksp->work_n = n;
   return 0;
@@ -209,9 +210,10 @@ int HipxKSPDestroyWork(HipxKSP *ksp)
   if (ksp->R) CHK(hipxFree(ksp->R));
   if (ksp->Z) CHK(hipxFree(ksp->Z));
   if (ksp->P) CHK(hipxFree(ksp->P));
+  if (ksp->P2) CHK(hipxFree(ksp->P2));
   if (ksp->dscal) CHK(hipxFree(ksp->dscal));
   ksp->dscal = NULL;
-  ksp->R = ksp->Z = ksp->P = NULL;
+  ksp->R = ksp->Z = ksp->P = ksp->P2 = NULL;
   ksp->work_n = 0;
   return 0;
 }
@@ -294,10 +296,28 @@ static int fused_update_begin(HipxMat *A, double *r, double *z, const double *p,
   return hipxCGFusedUpdateBegin(NULL, r, z, p, w, d, dconst, dev_beta, dev_dpi, n, slot, dev_sums2);
 }
 
+/* A(i) + B(i) as ONE kernel where the operator supports it (round 4: the direction update as the prologue of the march-form SpMV; one rank,
+   constant Jacobi diagonal or PCNONE so that z = r * dconst is never stored and W = Z's buffer stays free).  The kernel writes p_new into the
+   second direction vector; on success the two swap (ksp->P is always the current direction).  *done = 0: nothing was enqueued. */
+static int fused_direction_product(HipxKSP *ksp, HipxMat *A, HipxPC *pc, int dcon, double *X, double b, double a, const double *dbn, const double *dbo, const double *ddpi, int slot,
+                                   double *dev_dot, int *done)
+{
+  *done = 0;
+  if (A->nranks > 1 || A->B || !dcon || !ksp->P2) return 0;
+  CHK(hipxMatMultCGDirectionDotBegin(A->A, ksp->P, ksp->P2, ksp->R, pc->dconst, X, b, a, dbn, dbo, ddpi, ksp->Z, slot, dev_dot, done));
+  if (*done) {
+    double *t = ksp->P;
+    ksp->P    = ksp->P2;
+    ksp->P2   = t;
+  }
+  return 0;
+}
+
 static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double *X, hipx_int nsteps)
 {
   const hipx_int n = A->m;
-  double        *R = ksp->R, *Z = ksp->Z, *P = ksp->P, *W = ksp->Z;
+  double        *R = ksp->R, *Z = ksp->Z, *W = ksp->Z;
+#define P (ksp->P) /* the current direction: the fused direction + product kernel swaps the two direction vectors */
   double        *ds = ksp->dscal;
   int            ahead = 0; /* A(i), B(i), C(i) of the current iteration already enqueued */
   const int      dcon  = pc->dconst_valid && (pc->type == HIPX_PC_NONE || !getenv("HIPX_NO_DCONST")); /* constant Jacobi diagonal (or PCNONE: 1.0): multiply by the scalar */
@@ -316,11 +336,14 @@ static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double 
       break;
     }
     if (!ahead) {
+      int done = 0;
       CHK(hipxMemcpyHtoD(dbeta_i, &ksp->beta, sizeof(double)));
       if (!i) CHK(hipxVecCopy(Z, P, n)); /* cg.c:236 */
       else {
         const double b = ksp->beta / ksp->betaold;
-        if (dcon) { /* z = r * dconst is not stored in this mode */
+        if (ksp->x_pending) CHK(fused_direction_product(ksp, A, pc, dcon, X, b, ksp->a_pending, NULL, NULL, NULL, SLOT_DOT, ds, &done));
+        if (done) ksp->x_pending = 0;
+        else if (dcon) { /* z = r * dconst is not stored in this mode */
           CHK(hipxCGAypxAxpyR(P, b, R, pc->dconst, ksp->x_pending ? X : NULL, ksp->a_pending, n));
           ksp->x_pending = 0;
         } else if (ksp->x_pending) {
@@ -328,7 +351,7 @@ static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double 
           ksp->x_pending = 0;
         } else CHK(hipxVecAYPX(P, b, Z, n)); /* cg.c:249 */
       }
-      CHK(mm_dot_begin(A, P, W, SLOT_DOT, ds));
+      if (!done) CHK(mm_dot_begin(A, P, W, SLOT_DOT, ds));
       CHK(fused_update_begin(A, R, dcon ? NULL : Z, P, W, dcon ? NULL : pc->dinv, pc->dconst, dbeta_i, ds, n, SLOT_SUMS + q, ds + 2 + 2 * q));
     }
     ahead  = 0;
@@ -349,8 +372,13 @@ static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double 
     ksp->a_pending = ksp->a;
     if (s + 1 < nsteps && i + 1 < ksp->max_it) { /* enqueue iteration i+1 while C(i) runs */
       double *dbeta_n = ds + 3 + 2 * q; /* z.r of iteration i, written by C(i) */
-      CHK(hipxCGAypxAxpyDev(P, dcon ? NULL : Z, R, pc->dconst, X, dbeta_n, dbeta_i, ds, n));
-      CHK(mm_dot_begin(A, P, W, SLOT_DOT, ds));
+      int     done    = 0;
+      /* (the fused kernel reads dpi of iteration i from ds[0] and writes dpi of iteration i + 1 there: its fold runs behind it on the stream) */
+      CHK(fused_direction_product(ksp, A, pc, dcon, X, 0.0, 0.0, dbeta_n, dbeta_i, ds, SLOT_DOT, ds, &done));
+      if (!done) {
+        CHK(hipxCGAypxAxpyDev(P, dcon ? NULL : Z, R, pc->dconst, X, dbeta_n, dbeta_i, ds, n));
+        CHK(mm_dot_begin(A, P, W, SLOT_DOT, ds));
+      }
       CHK(fused_update_begin(A, R, dcon ? NULL : Z, P, W, dcon ? NULL : pc->dinv, pc->dconst, dbeta_n, ds, n, SLOT_SUMS + (1 - q), ds + 2 + 2 * (1 - q)));
       ahead          = 1;
       ksp->x_pending = 0; /* A(i+1) applies it */
@@ -377,6 +405,7 @@ static int cg_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double 
   if (!ksp->defer_flush) CHK(HipxKSPCGFlush(ksp, A, X));
   if (!ksp->reason && ksp->i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS; /* cg.c:350 */
   return 0;
+#undef P
 }
 
 /* nsteps passes of the loop body cg.c:220-349 (stops early when ksp->reason is set) */

@@ -117,7 +117,7 @@ def test_value_dictionary_ragged_rows_bit_exact(hx, seed, m, n, maxlen, variant)
     _lib.mat_destroy(A)
 
 
-TEMPLATE_KERNELS = ("spmv_tmpl_kernel", "spmv_pair_kernel", "spmv_march_kernel")  # row templates: the general walk, the pair form (every row a subset of the interior row), the march form (three-plane base rows)
+TEMPLATE_KERNELS = ("spmv_tmpl_kernel", "spmv_pair_kernel", "spmv_march_kernel", "spmv_march2_kernel")  # row templates: the general walk, the pair form (every row a subset of the interior row), the march form (three-plane base rows)
 
 
 def is_template_kernel(name):
@@ -586,7 +586,7 @@ def test_march_form_of_the_template_kernel_bit_exact(hx, kind, n, m, cut):
     A = _lib.mat_create_csr(N, N, ai, aj, aa)
     _lib.chk(hx.hipxMatSetSpMVVariant(A, 30))
     name = kernel_name(hx, A)
-    assert is_template_kernel(name) and name.startswith("spmv_march_kernel ") == (N % 2 == 0), name  # (an odd row count keeps the other template kernels)
+    assert is_template_kernel(name) and name.startswith(("spmv_march_kernel ", "spmv_march2_kernel ")) == (N % 2 == 0), name  # (an odd row count keeps the other template kernels)
     X, Y, Y0 = _lib.DVec(N + 2, np.concatenate([x, [0.0, 0.0]])), _lib.DVec(N + 2), _lib.DVec(N + 2, np.concatenate([y0, [0.0, 0.0]]))
     for _ in range(2):
         Y.set(np.full(N + 2, np.nan))
@@ -608,10 +608,111 @@ def test_march_form_of_the_template_kernel_bit_exact(hx, kind, n, m, cut):
     _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(dot2)))
     assert dot2.value == dot.value
     _lib.chk(hx.hipxMatSetSpMVVariant(A, 26))  # the pair form (these sizes give too few workgroups for the march form): same bits
-    assert not kernel_name(hx, A).startswith("spmv_march_kernel ")
+    assert not kernel_name(hx, A).startswith("spmv_march")
     _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
     assert np.array_equal(Y.get()[:N], yr)
     for v in (X, Y, Y0, Xs, Ys):
+        v.free()
+    _lib.mat_destroy(A)
+
+
+@pytest.mark.parametrize("kind,n,m", [("7pt", 32, None), ("7pt", 64, None), ("7pt", 96, None), ("7pt", 128, None), ("27pt", 64, None), ("27pt", 96, None), ("5pt", 1024, 48),
+                                       ("5pt", 2048, 24), ("7pt", 192, None), ("7pt_box", (256, 64, 20), None)])
+def test_march2_kernel_bit_exact_and_same_bits_as_the_first_march_kernel(hx, kind, n, m):
+    """spmv_march2_kernel (round 4: whole planes and tiles, plane-periodic template ids, run-addressed operands): planes of 1024 ... 36864 rows,
+    1024- and 2048-row tiles, 5 / 7 / 27 entries, halos of 2 ... 256 elements: y bit-identical to MatMult_SeqAIJ, the fused dot deterministic
+    and equal to the first march kernel's own (same partial layout), which the developer switch HIPX_MARCH1 still runs (subprocess)."""
+    from petsc_amd import _lib
+    rng = np.random.default_rng(29)
+    ai, aj, aa = orc.stencil(kind, n, m=m)
+    N = len(ai) - 1
+    x = rng.standard_normal(N)
+    yr = orc.matmult(ai, aj, aa, x)
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    _lib.chk(hx.hipxMatSetSpMVVariant(A, 30))
+    name = kernel_name(hx, A)
+    assert name.startswith("spmv_march2_kernel "), name
+    X, Y = _lib.DVec(N, x), _lib.DVec(N)
+    for _ in range(2):
+        Y.set(np.full(N, np.nan))
+        _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+        assert np.array_equal(Y.get(), yr)
+    dot, dot2 = C.c_double(), C.c_double()
+    Y.set(np.full(N, np.nan))
+    _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(dot)))
+    assert np.array_equal(Y.get(), yr) and abs(dot.value - float(x @ yr)) <= 1e-12 * np.abs(x * yr).sum()
+    _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(dot2)))
+    assert dot2.value == dot.value
+    for v in (X, Y):
+        v.free()
+    _lib.mat_destroy(A)
+
+
+def test_march2_refuses_matrices_whose_template_ids_are_not_plane_periodic(hx):
+    """One interior row of an interior plane loses an entry (its template differs from the same row of the other planes): the second-generation
+    kernel's set-up check must see it and the first march kernel takes the matrix -- still bit-identical."""
+    from petsc_amd import _lib
+    ai, aj, aa = orc.stencil("7pt", 64)
+    N = len(ai) - 1
+    r = 20 * 4096 + 17 * 64 + 9
+    k = ai[r] + 1  # drop the second entry of row r (keep CSR valid: shift the arrays)
+    aj2, aa2 = np.delete(aj, k), np.delete(aa, k)
+    ai2 = ai.copy()
+    ai2[r + 1:] -= 1
+    x = np.random.default_rng(3).standard_normal(N)
+    yr = orc.matmult(ai2, aj2, aa2, x)
+    A = _lib.mat_create_csr(N, N, ai2, aj2, aa2)
+    _lib.chk(hx.hipxMatSetSpMVVariant(A, 30))
+    name = kernel_name(hx, A)
+    assert name.startswith("spmv_march_kernel "), name
+    X, Y = _lib.DVec(N, x), _lib.DVec(N)
+    _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    assert np.array_equal(Y.get(), yr)
+    X.free()
+    Y.free()
+    _lib.mat_destroy(A)
+
+
+@pytest.mark.parametrize("kind,n,m,dconst", [("7pt", 64, None, 1.0 / 6.0), ("7pt", 96, None, 1.0), ("7pt", 192, None, 0.37), ("5pt", 1024, 48, 0.25)])
+def test_cg_direction_update_as_the_products_prologue_bit_identical(hx, kind, n, m, dconst):
+    """hipxMatMultCGDirectionDotBegin (p_new = r * dconst + b p, x += a p, w = A p_new, p_new . w in one kernel) against the separate kernels it
+    replaces (hipxCGAypxAxpyR, hipxMatMultDot): p_new, x, w bit-identical, the dot the same double (same partials); host scalars and
+    device-resident scalars (b = beta_new / beta_old, a = beta_old / dpi formed on the device)."""
+    from petsc_amd import _lib
+    rng = np.random.default_rng(31)
+    ai, aj, aa = orc.stencil(kind, n, m=m)
+    N = len(ai) - 1
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    _lib.chk(hx.hipxMatSetSpMVVariant(A, 30))
+    assert kernel_name(hx, A).startswith("spmv_march2_kernel ")
+    p0, r, x0 = rng.standard_normal(N), rng.standard_normal(N), rng.standard_normal(N)
+    bn, bo, dpi = 0.731, 1.913, 2.57
+    b, a = bn / bo, bo / dpi
+    # the separate kernels
+    P, R, X, W = _lib.DVec(N, p0), _lib.DVec(N, r), _lib.DVec(N, x0), _lib.DVec(N)
+    _lib.chk(hx.hipxCGAypxAxpyR(P.ptr, b, R.ptr, dconst, X.ptr, a, N))
+    dref = C.c_double()
+    _lib.chk(hx.hipxMatMultDot(A, P.ptr, W.ptr, C.byref(dref)))
+    pr, xr, wr = P.get(), X.get(), W.get()
+    assert np.array_equal(pr, r * dconst + b * p0) and np.array_equal(xr, x0 + a * p0) and np.array_equal(wr, orc.matmult(ai, aj, aa, pr))
+    scal = _lib.DVec(4, np.array([bn, bo, dpi, 0.0]))
+    for dev in (False, True):
+        P.set(p0)
+        X.set(x0)
+        P2, W2 = _lib.DVec(N, np.full(N, np.nan)), _lib.DVec(N, np.full(N, np.nan))
+        fused, d = C.c_int(0), C.c_double()
+        dn = C.c_void_p(scal.ptr.value) if dev else None
+        do = C.c_void_p(scal.ptr.value + 8) if dev else None
+        dd = C.c_void_p(scal.ptr.value + 16) if dev else None
+        _lib.chk(hx.hipxMatMultCGDirectionDotBegin(A, P.ptr, P2.ptr, R.ptr, dconst, X.ptr, 0.0 if dev else b, 0.0 if dev else a, dn, do, dd, W2.ptr, 5, C.c_void_p(scal.ptr.value + 24), C.byref(fused)))
+        assert fused.value == 1
+        _lib.chk(hx.hipxRedEnd(5, 1, C.byref(d)))
+        assert np.array_equal(P2.get(), pr) and np.array_equal(X.get(), xr) and np.array_equal(W2.get(), wr), dev
+        assert np.array_equal(P.get(), p0)  # the old direction is left alone
+        assert d.value == dref.value and scal.get()[3] == dref.value
+        P2.free()
+        W2.free()
+    for v in (P, R, X, W, scal):
         v.free()
     _lib.mat_destroy(A)
 
