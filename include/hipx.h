@@ -77,7 +77,10 @@ int hipxProfileSpMVGet(int *count, double *total_ms); /* synchronises, returns a
 #define HIPX_PROF_ALLREDUCE 1 /* scalar all-reduce on the compute stream (RCCL or IPC) */
 #define HIPX_PROF_OFFDIAG   2 /* off-diagonal-block MatMultAdd incl. the wait for the ghost values (hipxMatMultMPI) */
 #define HIPX_PROF_SOR       3 /* hipxMatSOR: one call = all its sweeps */
-#define HIPX_PROF_NSECTIONS 4
+#define HIPX_PROF_CG_UPDATE 4 /* the fused CG update kernel (hipxCGFusedUpdate*: r -= a w, z, two sums) */
+#define HIPX_PROF_CG_DIR    5 /* the CG direction kernel (hipxCGAypxAxpy*: p = z + b p, x += a p) when it is not the product's prologue */
+#define HIPX_PROF_FOLD      6 /* fold of the SpMV epilogue's dot partials (hipxMatMultDot*, hipxMatMultCGDirectionDotBegin) */
+#define HIPX_PROF_NSECTIONS 7
 int hipxProfileSections(int enable);
 int hipxProfileSectionGet(int id, int *count, double *total_ms); /* synchronises the device, returns and clears the tally */
 

@@ -2108,6 +2108,7 @@ __global__ __launch_bounds__(256, 2) void spmv_march2_kernel(const hipxMarchPlan
                 if (UNI) {
                   sum0 += p0;
                   sum1 += p1;
+                  asm volatile("" : "+v"(sum0), "+v"(sum1));  // keep the two rows' dependent add chains interleaved (the scheduler strings each row's seven adds together)
                 } else {
                   const double t0 = sum0 + p0, t1 = sum1 + p1;
                   sum0 = ((mk[q0] >> e) & 1u) ? t0 : sum0;

@@ -602,7 +602,7 @@ __global__ __launch_bounds__(kRedThreads) void dotnorm2_kernel(const double *x, 
 // the same product, one vector pass less.
 template <bool UPX, bool DEVS, bool CONSTD = false, bool COMP = false, bool WIDE = true>
 __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a_arg,
-                                                                const double *dev_beta, const double *dev_dpi, hipx_int n, bool vec, RedOut out, double dconst = 0.0)
+                                                                const double *dev_beta, const double *dev_dpi, hipx_int n, bool vec, RedOut out, double dconst = 0.0, int sweep = 0)
 {
   const double a = DEVS ? (*dev_beta / *dev_dpi) : a_arg;
   Acc<COMP>      acc[2];
@@ -641,6 +641,23 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
     constexpr int  U  = (!UPX && CONSTD && WIDE) ? 4 : 2;  // (WIDE = false: the round-3 loop, kept behind HIPX_CG_FUSED_U2 for same-box A/B timing)
     const double2  z0 = {0.0, 0.0};
     const double2  dc = {dconst, dconst};
+    if (sweep) {  // all workgroups walk the vector together, round by round: workgroup b takes elements [(it G + b) U T, ... + U T) in round it
+      const hipx_int G = (hipx_int)gridDim.x, span = (hipx_int)U * kRedThreads;
+      for (hipx_int base = (hipx_int)blockIdx.x * span; base < n2; base += G * span) {
+        double2 ra[U], wa[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const hipx_int qu = base + u * (hipx_int)kRedThreads + threadIdx.x;
+          ra[u] = qu < n2 ? r2[qu] : z0;
+          wa[u] = qu < n2 ? w2[qu] : z0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const hipx_int qu = base + u * (hipx_int)kRedThreads + threadIdx.x;
+          if (qu < n2) step(qu, UPX ? x2[qu] : z0, ra[u], UPX ? p2[qu] : z0, wa[u], CONSTD ? dc : d2[qu]);
+        }
+      }
+    } else {
     hipx_int q = c0 + (hipx_int)threadIdx.x;
     for (; q + (U - 1) * (hipx_int)kRedThreads < c1; q += U * kRedThreads) {
       double2 xa[U], ra[U], pa[U], wa[U], da[U];
@@ -657,6 +674,7 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
       for (int u = 0; u < U; u++) step(q + u * (hipx_int)kRedThreads, xa[u], ra[u], pa[u], wa[u], da[u]);
     }
     for (; q < c1; q += kRedThreads) step(q, UPX ? x2[q] : z0, r2[q], UPX ? p2[q] : z0, w2[q], CONSTD ? dc : d2[q]);
+    }
     if ((n & 1) && tid == 0) {
       hipx_int i  = n - 1;
       double   rv = r[i] + ma * w[i], zv = rv * (CONSTD ? dconst : d[i]);
@@ -753,18 +771,26 @@ static inline RedOut red_out_g(int slot)
 
 // every launch of the fused CG update kernel: x update or not, plain or compensated sums
 template <bool DEVS, bool CONSTD>
-static inline void cg_fused_go(unsigned g, hipStream_t st, double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, const double *dev_beta,
+static inline void cg_fused_go(unsigned g_in, hipStream_t st, double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, const double *dev_beta,
                                const double *dev_dpi, hipx_int n, bool vec, RedOut o, double dconst)
 {
+  unsigned          g  = g_in;
+  (void)prof_section(HIPX_PROF_CG_UPDATE, true, st);
   static const bool u2 = getenv("HIPX_CG_FUSED_U2") != nullptr;
+  // the launch-ahead configuration (no x update, constant diagonal) walks the vector with all workgroups together, round by round (measured
+  // stand-alone on 256^3: 66.4 us = 6.06 TB/s against 72-74 us = 5.5 TB/s for one contiguous chunk per workgroup); HIPX_CG_FUSED_CHUNK keeps the chunks
+  static const int  sweep = getenv("HIPX_CG_FUSED_CHUNK") ? 0 : 1;
+  static const int  gover = getenv("HIPX_CG_FUSED_BLOCKS") ? atoi(getenv("HIPX_CG_FUSED_BLOCKS")) : 0;  // developer switches (timing experiments)
+  if (gover >= 1 && gover <= kRedBlocks) g = (unsigned)gover;
   if (rt().red_exact) {
     if (x) cg_fused_kernel<true, DEVS, CONSTD, true><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, a, dev_beta, dev_dpi, n, vec, o, dconst);
     else cg_fused_kernel<false, DEVS, CONSTD, true><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, a, dev_beta, dev_dpi, n, vec, o, dconst);
   } else {
     if (x) cg_fused_kernel<true, DEVS, CONSTD, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, a, dev_beta, dev_dpi, n, vec, o, dconst);
     else if (u2) cg_fused_kernel<false, DEVS, CONSTD, false, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, a, dev_beta, dev_dpi, n, vec, o, dconst);
-    else cg_fused_kernel<false, DEVS, CONSTD, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, a, dev_beta, dev_dpi, n, vec, o, dconst);
+    else cg_fused_kernel<false, DEVS, CONSTD, false><<<g, kRedThreads, 0, st>>>(x, r, z, p, w, d, a, dev_beta, dev_dpi, n, vec, o, dconst, sweep);
   }
+  (void)prof_section(HIPX_PROF_CG_UPDATE, false, st);
 }
 
 template <int NV>
@@ -916,8 +942,10 @@ int hipx::launch_dot(const double *x, const double *y, hipx_int n, int slot, dou
 
 int hipx::launch_sum(const double *x, hipx_int n, int slot, double *dres)
 {
+  (void)prof_section(HIPX_PROF_FOLD, true, rt().compute);
   if (rt().red_exact) sum_kernel<true><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, red_out(slot, true, dres));
   else sum_kernel<false><<<red_grid(n), kRedThreads, 0, rt().compute>>>(x, n, red_out(slot, true, dres));
+  (void)prof_section(HIPX_PROF_FOLD, false, rt().compute);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -1362,7 +1390,9 @@ int hipxCGAypxAxpy(double *p, double b, const double *z, double *x, double a, hi
     return hipxVecAYPX(p, b, z, n);
   }
   bool vec = aligned16(p) && aligned16(x) && aligned16(z) && n >= 2;
+  (void)prof_section(HIPX_PROF_CG_DIR, true, rt().compute);
   cg_aypx_axpy_kernel<false, false, true><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, z, 0.0, b, a, nullptr, nullptr, nullptr, n, vec);
+  (void)prof_section(HIPX_PROF_CG_DIR, false, rt().compute);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -1372,8 +1402,10 @@ int hipxCGAypxAxpyR(double *p, double b, const double *r, double dconst, double 
   HIPX_CHECK_INIT();
   if (n <= 0) return HIPX_SUCCESS;
   bool vec = aligned16(p) && aligned16(x) && aligned16(r) && n >= 2;
+  (void)prof_section(HIPX_PROF_CG_DIR, true, rt().compute);
   if (x) cg_aypx_axpy_kernel<false, true, true><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, r, dconst, b, a, nullptr, nullptr, nullptr, n, vec);
   else cg_aypx_axpy_kernel<false, true, false><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, r, dconst, b, a, nullptr, nullptr, nullptr, n, vec);
+  (void)prof_section(HIPX_PROF_CG_DIR, false, rt().compute);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -1385,8 +1417,10 @@ int hipxCGAypxAxpyDev(double *p, const double *z, const double *r, double dconst
   HIPX_ARG((z || r) && x && dev_beta_new && dev_beta_old && dev_dpi, "null argument");
   const double *src = z ? z : r;
   bool          vec = aligned16(p) && aligned16(x) && aligned16(src) && n >= 2;
+  (void)prof_section(HIPX_PROF_CG_DIR, true, rt().compute);
   if (z) cg_aypx_axpy_kernel<true, false, true><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, src, 0.0, 0.0, 0.0, dev_beta_new, dev_beta_old, dev_dpi, n, vec);
   else cg_aypx_axpy_kernel<true, true, true><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, src, dconst, 0.0, 0.0, dev_beta_new, dev_beta_old, dev_dpi, n, vec);
+  (void)prof_section(HIPX_PROF_CG_DIR, false, rt().compute);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }

@@ -212,6 +212,9 @@ int HipxKSPDestroyWork(HipxKSP *ksp)
   if (ksp->P) CHK(hipxFree(ksp->P));
   if (ksp->P2) CHK(hipxFree(ksp->P2));
   if (ksp->dscal) CHK(hipxFree(ksp->dscal));
+  if (ksp->gslab) CHK(hipxFree(ksp->gslab));
+  ksp->gslab     = NULL;
+  ksp->gslab_len = 0.0;
   ksp->dscal = NULL;
   ksp->R = ksp->Z = ksp->P = ksp->P2 = NULL;
   ksp->work_n = 0;
@@ -697,7 +700,16 @@ int HipxKSPSolve_GMRES(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, do
     ierr = (call); \
     if (ierr) goto cleanup; \
   } while (0)
-  GCHK(hipxMalloc((void **)&slab, sizeof(double) * ld * (size_t)(max_k + 4)));
+  /* the work vectors live as long as the KSP (KSPSetUp_GMRES, gmres.c:35-86: allocated once, reused by every KSPSolve): a 4.6 GB hipMalloc +
+     hipFree pair per solve of the 27-pt 256^3 system cost up to 0.3 s inside the timed region of a bench leg that ran late in the process */
+  if (!ksp->gslab || ksp->gslab_len < (double)ld * (double)(max_k + 4)) {
+    if (ksp->gslab) GCHK(hipxFree(ksp->gslab));
+    ksp->gslab     = NULL;
+    ksp->gslab_len = 0.0;
+    GCHK(hipxMalloc((void **)&ksp->gslab, sizeof(double) * ld * (size_t)(max_k + 4)));
+    ksp->gslab_len = (double)ld * (double)(max_k + 4);
+  }
+  slab = ksp->gslab;
   TEMP = slab;
   TMOP = slab + ld;
   for (hipx_int k = 0; k < max_k + 2; k++) VV[k] = slab + ld * (size_t)(k + 2);
@@ -838,10 +850,6 @@ int HipxKSPSolve_GMRES(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, do
   }
 cleanup:
   ksp->guess_nonzero = guess_nonzero;
-  if (slab) {
-    int e2 = hipxFree(slab);
-    if (!ierr) ierr = e2;
-  }
   free(VV);
   free(hh);
   free(grs);

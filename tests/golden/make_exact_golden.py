@@ -74,6 +74,11 @@ def jobs():
     for g in (1, 2, 4, 8):
         J["gmres_sor_27pt_256_np%d" % g] = (lambda g=g: gmres_sor(256, g, 35))
         J["gmres_sor_27pt_128_np%d" % g] = (lambda g=g: gmres_sor(128, g, 35))
+    # round 4: the one-rank histories of config 3's solver come from the REFERENCE itself (its KSPSolve_GMRES, MatSOR_SeqAIJ, VecMDot_Seq_GEMV) with
+    # exact BLAS reductions, not from the restated oracle (the two agree to ~1e-13: tests/test_oracle_exact.py)
+    for n in (256, 128):
+        J["gmres_sor_27pt_%d_np1" % n] = (lambda n=n: entry(ref_shim(27, n, "gmres", "sor", 35), "reference+shim",
+                                                            "config 3's solver: 27-pt %d^3, KSPGMRES(30) + PCSOR, one rank; 35 iterations" % n))
     return J
 
 
