@@ -224,6 +224,8 @@ class Problem:
         self.lib, self.cfg, self.world, self.fused, self.pipeline = _lib, cfg, world, fused, pipeline
         self.hx, self.ks = _lib.load()
         self.dims, self.N = cfg.dims, cfg.N
+        self.setup_times = {}  # where set-up time goes: host assembly / upload (+ MPI split) / device format build (first product)
+        t_a = time.perf_counter()
         if isinstance(cfg, MatrixCfg):
             assert world == 1, "a matrix from a file runs on one GPU here"
             ai, aj, aa = cfg.load()
@@ -236,6 +238,8 @@ class Problem:
         self.m = re - rs
         self.wide = ai.dtype == np.int64
         self.halo = self.lvec = self.Bm = None
+        self.setup_times["host_assembly_s"] = time.perf_counter() - t_a
+        t_a = time.perf_counter()
         if world > 1:
             plan = pdist.build_plan(ai, aj, aa, ranges, rank, dist=dist)
             self.M, keep = pdist.create_device_mat(plan, world, rank=rank, dist=dist, transport=transport)
@@ -252,10 +256,15 @@ class Problem:
             self.nghost = 0
         self.host_csr = (ai, aj, aa) if keep_host else None
         del ai, aj, aa
+        _lib.chk(self.hx.hipxDeviceSynchronize())
+        self.setup_times["upload_s"] = time.perf_counter() - t_a
+        t_a = time.perf_counter()
         self.ones = _lib.DVec(self.m, np.ones(self.m))
         self.B = _lib.DVec(self.m)
         self.X = _lib.DVec(self.m)
-        _lib.chk(self.ks.HipxMatMult(C.byref(self.M), self.ones.ptr, self.B.ptr))  # b = A * 1 (ex2.c:139 style)
+        _lib.chk(self.ks.HipxMatMult(C.byref(self.M), self.ones.ptr, self.B.ptr))  # b = A * 1 (ex2.c:139 style): the first product builds the device formats
+        _lib.chk(self.hx.hipxDeviceSynchronize())
+        self.setup_times["device_format_build_and_first_product_s"] = time.perf_counter() - t_a
         self.ones.free()
         self.pc = None
         self.ksp = None
@@ -278,6 +287,7 @@ class Problem:
         ks.HipxKSPSetDefaults(C.byref(self.ksp))
         self.ksp.rtol, self.ksp.abstol, self.ksp.divtol = 1e-50, 1e-300, 1e300
         self.ksp.fused, self.ksp.pipeline = self.fused, self.pipeline
+        self.ksp.single_reduction = 1 if self.pipeline == 3 else 0  # --pipeline 3: KSPSolve_CG_SingleReduction (cg.c:364-534), one reduction stage per iteration
         kbuf = C.create_string_buffer(256)
         lib.chk(self.hx.hipxMatGetSpMVKernel(self.M.A, kbuf, 256))
         return kbuf.value.decode()
@@ -575,17 +585,22 @@ def parity_vs_golden(P, its, tol):
     its = min(its, len(href) - 1)
     lib, hx = P.lib, P.hx
 
+    orig = C.c_int(0)
+    lib.chk(hx.hipxGetReductionMode(C.byref(orig)))  # (HIPX_REDUCTIONS=exact runs the whole line in exact mode: put it back afterwards)
+
     def dist(mode):
         lib.chk(hx.hipxSetReductionMode(mode))
         try:
             hist = P.solve(its, history=True)
         finally:
-            lib.chk(hx.hipxSetReductionMode(0))
+            lib.chk(hx.hipxSetReductionMode(orig.value))
         k = min(len(hist), its + 1)
         return float((np.abs(hist[:k] - href[:k]) / np.abs(href[:k])).max()), k
     rel_fast, k = dist(0)
     rel_exact, k2 = dist(1)
     gated = "exact" if P.cfg.ksp == "gmres" else "fast"
+    if getattr(P, "pipeline", 1) == 3:  # single-reduction CG: another recurrence for w = A p -- its history leaves the standard form's by rounding, a little more every iteration;
+        tol = max(tol, 1e-9)            # bit parity with the REFERENCE's own single-reduction run is what tests/test_gpu_scale_parity.py holds it to
     rel = rel_exact if gated == "exact" else rel_fast
     out = {"pass": bool(rel <= tol and k == its + 1 and k2 == its + 1), "max_rel_diff": rel, "tolerance": tol, "gated_reduction_mode": gated, "iterations": its, "entries": k,
            "max_rel_diff_fast_reductions": rel_fast, "max_rel_diff_exact_reductions": rel_exact,
@@ -615,7 +630,7 @@ def run_leg(cfg, rank, world, dist, torch, transport, steps, warmup, sync, varia
         P.lib.chk(P.hx.hipxMatGetSORMode(P.M.A, C.byref(mode)))
     out = {"metric": cfg.metric(), "iterations_per_s": steps / r["elapsed"], "ms_per_step": 1e3 * r["elapsed"] / steps, "steps": steps, "warmup": warmup,
            "scaling": cfg.scaling, "global_rows": cfg.N, "spmv_kernel": kname, "parity": par, "residual_norm_after": r["rnorm"],
-           "setup_seconds": t_setup, "per_rank": per_rank}
+           "setup_seconds": t_setup, "setup_split": dict(P.setup_times), "per_rank": per_rank}
     if cfg.pc == "sor":
         out["sor_schedule"] = {2: "strand", 1: "dependency-driven", 0: "levels"}.get(mode.value, str(mode.value))
     nnz_l, m_l, wide = P.nnz_local, P.m, P.wide
@@ -749,7 +764,7 @@ def leg_matrix_solver(cfg, steps, warmup, sync, torch, best_ranks=None, parity_i
     r = timed_steps(P, steps, warmup, sync, None, torch)
     byts = P.spmv_bytes()
     out = {"metric": cfg.metric(), "iterations_per_s": steps / r["elapsed"], "ms_per_step": 1e3 * r["elapsed"] / steps, "steps": steps, "warmup": warmup,
-           "rows": P.m, "nnz": P.nnz_local, "spmv_kernel": kname, "parity": par, "residual_norm_after": r["rnorm"], "setup_seconds": t_setup,
+           "rows": P.m, "nnz": P.nnz_local, "spmv_kernel": kname, "parity": par, "residual_norm_after": r["rnorm"], "setup_seconds": t_setup, "setup_split": dict(P.setup_times),
            "roofline_spmv": {"bound": "hbm", "avg_launch_ms": r["spmv_ms"], "launches": r["launches"], "algorithmic_bytes": byts,
                              "achieved": byts / (r["spmv_ms"] * 1e-3) / 1e9 if r["spmv_ms"] > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": byts / (r["spmv_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if r["spmv_ms"] > 0 else 0.0, "traffic": None}}
@@ -791,7 +806,8 @@ def main():
                     help="multi-GPU data path: RCCL send/recv + all-reduce over xGMI, or IPC peer stores (also when ranks share a GPU); auto: probe both, time both, report the faster as `value`")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="weak: every GPU owns grid x grid x grid/8 rows (config 5: --grid 1024)")
     ap.add_argument("--fused", type=int, default=1, help="1 (default): fused SpMV+dot and AXPY+AXPY+PCJACOBI+norm+dot kernels -- same arithmetic and order per element, fewer HBM passes; 0: one kernel per reference Vec/Mat call (cg.c:249-344)")
-    ap.add_argument("--pipeline", type=int, default=1, help="1 (default): launch-ahead fused CG (iteration i+1 enqueued before the host has seen iteration i's sums; device-resident scalars); 0: host waits between kernels")
+    ap.add_argument("--pipeline", type=int, default=1, help="1 (default): launch-ahead fused CG (iteration i+1 enqueued before the host has seen iteration i's sums; device-resident scalars); 0: host waits between kernels; "
+                    "2: several ranks on the host-synchronised loop; 3: single-reduction CG (cg.c:364-534: ONE reduction stage -- a 24-byte all-reduce -- per iteration instead of two)")
     ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (include/hipx.h hipxMatSetSpMVVariant): 0 auto")
     ap.add_argument("--general-variant", type=int, default=29, help="kernel of the roofline_general leg: what a matrix with arbitrary values on this pattern gets (29: pattern templates + streamed values, "
                     "the auto choice for short rows on <= 256 row patterns; 23: packed 16-bit columns, what an unstructured matrix gets)")

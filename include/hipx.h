@@ -230,6 +230,11 @@ int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len);
 /* y = A x and *dot = x.y fused in the SpMV epilogue (cg.c:257-258) */
 int hipxMatMultDot(hipxMat A, const double *x, double *y, double *dot);
 int hipxMatMultDotBegin(hipxMat A, const double *x, double *y, int slot, double *dev_dot); /* enqueue only; hipxRedEnd(slot, 1, &dot) waits */
+/* Single-reduction CG (KSPSolve_CG_SingleReduction cg.c:364-534): the vector updates between two reductions in one pass -- p = z + b p (cg.c:470),
+   w = s + b w (cg.c:477), x += a p (cg.c:490), r -= a w (cg.c:491), z = r .* d (PCApply_Jacobi; d == NULL: z = r, PCNONE) -- element by element the
+   five reference loops, hence the same bits.  The caller then forms s = A z and the three sums z.z, z.s, z.r in ONE reduction (hipxVecMDot /
+   hipxVecMDotAllreduce with y = {z, s, r}). */
+int hipxCGSingleReductionUpdate(double *p, double *w, double *x, double *r, double *z, const double *s, const double *d, double b, double a, hipx_int n);
 /* The CG direction update as the PROLOGUE of the product (round 4): p_new = (z * dconst) + b p_old (cg.c:248-249, VecAYPX dvec2.c:774; z = the
    preconditioned residual with dconst = 1, or the residual itself with the constant Jacobi diagonal / PCNONE), x += a p_old (cg.c:305 of the
    iteration before), w = A p_new, dot = p_new . w (cg.c:257-258) in ONE kernel -- element by element the operations of hipxCGAypxAxpyDev / R

@@ -70,6 +70,9 @@ typedef struct {
   int      external_test;    /* 1: the caller runs its own convergence test after every step (the PETSc plugin: ksp->converged) */
   int      pipeline;         /* fused CG on one rank: enqueue iteration i+1 before the host has seen the sums of iteration i (default 1) */
   double  *dscal;            /* device scalars of the launch-ahead path: [0] p.w, [2+2q] z.z, [3+2q] z.r of the iterations of parity q */
+  int      single_reduction; /* CG: KSPCGUseSingleReduction (cg.c:364-534): one reduction stage per iteration (three sums in one all-reduce), two more work vectors */
+  double  *S, *W;            /* its work vectors S = A z and W (= A p by recurrence) */
+  double   delta;            /* z . A z */
   double  *gslab;            /* GMRES: VEC_VV(0..restart+1) + VEC_TEMP + VEC_TEMP_MATOP in one slab, kept across solves as KSPSetUp_GMRES keeps its work vectors */
   double   gslab_len;        /* its length in doubles (a double: the slab of a 512^3 problem exceeds 2^31 elements) */
   double  *P2;               /* second direction vector: hipxMatMultCGDirectionDotBegin (direction update as the product's prologue) writes p_new here

@@ -468,9 +468,29 @@ assembled:
     PetscCall(PetscPrintf(PETSC_COMM_WORLD, "MatMult its %" PetscInt_FMT " seconds %.6e ynorm %.17g\n", mm_its, (double)(t1 - t0), (double)norm));
     if (dump_y) {
       const PetscScalar *ya;
+      PetscBool          dump_yt = PETSC_FALSE; /* -dump_yt: also yt = A^T x (MatMultTranspose) and yta = y + A^T x (MatMultTransposeAdd), every entry */
       PetscCall(VecGetArrayRead(y, &ya));
       for (PetscInt i = 0; i < Iend - Istart; i++) PetscCall(PetscPrintf(PETSC_COMM_SELF, "y %" PetscInt_FMT " %.17g\n", i + Istart, (double)ya[i]));
       PetscCall(VecRestoreArrayRead(y, &ya));
+      PetscCall(PetscOptionsGetBool(NULL, NULL, "-dump_yt", &dump_yt, NULL));
+      if (dump_yt) {
+        Vec yt, yta;
+        PetscCall(VecDuplicate(u, &yt));
+        PetscCall(VecDuplicate(u, &yta));
+        PetscCall(MatMultTranspose(A, x, yt));
+        PetscCall(MatMultTransposeAdd(A, x, y, yta));
+        PetscCall(VecGetArrayRead(yt, &ya));
+        for (PetscInt i = 0; i < Iend - Istart; i++) PetscCall(PetscPrintf(PETSC_COMM_SELF, "yt %" PetscInt_FMT " %.17g\n", i + Istart, (double)ya[i]));
+        PetscCall(VecRestoreArrayRead(yt, &ya));
+        PetscCall(VecGetArrayRead(yta, &ya));
+        for (PetscInt i = 0; i < Iend - Istart; i++) PetscCall(PetscPrintf(PETSC_COMM_SELF, "yta %" PetscInt_FMT " %.17g\n", i + Istart, (double)ya[i]));
+        PetscCall(VecRestoreArrayRead(yta, &ya));
+        PetscCall(MatMultTransposeAdd(A, x, yt, yt)); /* in place: yt <- yt + A^T x */
+        PetscCall(VecNorm(yt, NORM_2, &norm));
+        PetscCall(PetscPrintf(PETSC_COMM_WORLD, "MatMultTransposeAdd in place: norm %.17g\n", (double)norm));
+        PetscCall(VecDestroy(&yt));
+        PetscCall(VecDestroy(&yta));
+      }
     }
     PetscCall(VecDestroy(&y));
   }

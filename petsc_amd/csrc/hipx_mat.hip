@@ -112,6 +112,7 @@ struct hipxMat_s {
   bool           march_ok = false;  // ... and its offsets split into three 'planes' S rows apart (march form, spmv_march_kernel)
   hipxMarchPlan  march_plan;
   bool           march_force = false;  // hipxMatSetSpMVVariant(30)
+  int            march_nt = 256;       // 512: the plan needs the 512-thread form of spmv_march2_kernel (4096-row tiles, halos beyond the 80 KiB of the two-workgroup forms: lines of up to 1024 points)
   int            march2_state = 0;     // spmv_march2_kernel's extra conditions (whole planes and tiles, plane-periodic template ids, run structure): 0 not checked yet, 1 hold, -1 do not
   hipx_int       dot_npart_used = 0;  // dot partials the last fused template launch wrote when it was not the count dot_partials_count() gave (march form)
   int           *d_toff   = nullptr;  // column - row
@@ -1887,8 +1888,10 @@ struct hipxMarchCG {
   const double *dev_beta_new, *dev_beta_old, *dev_dpi;  // device-resident sums of the kernels queued before: b = beta_new / beta_old, a = beta_old / dpi
 };
 
-template <int NE, int NQ, int NHALO, bool DOT, bool CG = false>
-__global__ __launch_bounds__(256, 2) void spmv_march2_kernel(const hipxMarchPlan plan, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask, const int ntmpl,
+// NT = 512 (round 4, lines of up to 1024 points -- BASELINE config 5's 1024 x 1024 planes): eight waves share three plane buffers of 4096 + 2 H
+// doubles (144 KiB: one workgroup per CU, the same two waves per SIMD); thread t works in the half t / 256 of the tile.
+template <int NE, int NQ, int NHALO, bool DOT, bool CG = false, int NT = 256>
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void spmv_march2_kernel(const hipxMarchPlan plan, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask, const int ntmpl,
                                                               const double *__restrict__ x, double *__restrict__ yout, double *__restrict__ dotpart, const int tiles, const int pps,
                                                               const int nplanes, const int xcdmap, const hipxMarchCG cg = hipxMarchCG{})
 {
@@ -1896,13 +1899,13 @@ __global__ __launch_bounds__(256, 2) void spmv_march2_kernel(const hipxMarchPlan
   typedef double dbl2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ unsigned int s_mask[256];
-  constexpr int L = NQ * 256, NOWN = NQ / 2, NJ = NQ / 2, DIAG = NE / 2;
+  constexpr int L = NQ * NT, NOWN = NQ / 2, NJ = NQ / 2, DIAG = NE / 2;
   constexpr int RB = (NE > 9) ? 3 : RS::NR;  // runs per operand batch (27 entries: 9 entries x 2 rows at a time, 36 registers)
   constexpr int AHEAD = (NE > 9) ? 1 : 2;    // planes in flight in registers: two steps ahead of their use, or one for the long templates (their
                                              // 27 values fill the register file, and a step is four times as long: one is ahead enough)
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int S = plan.S, H = plan.H, W = L + 2 * H, H2 = H >> 1;
-  for (int k = t; k < ntmpl; k += 256) s_mask[k] = tmask[k];
+  for (int k = t; k < ntmpl; k += NT) s_mask[k] = tmask[k];
   const int units = (int)gridDim.x;
   int       u     = (int)blockIdx.x;
   if (xcdmap) u = ((int)blockIdx.x & 7) * (units >> 3) + ((int)blockIdx.x >> 3);  // an XCD's workgroups: neighbouring tiles (they share halos through its L2)
@@ -1921,7 +1924,7 @@ __global__ __launch_bounds__(256, 2) void spmv_march2_kernel(const hipxMarchPlan
   }
   int rjb[NJ];  // byte offset of this thread's row inside a group of 256 rows, per pair of groups (rotated: see spmv_march_kernel)
 #pragma unroll
-  for (int j = 0; j < NJ; j++) rjb[j] = ((t + 32 + 64 * j) & 255) * 8;
+  for (int j = 0; j < NJ; j++) rjb[j] = ((((t & 255) + 32 + 64 * j) & 255) + (t >> 8) * NQ * 256) * 8;  // (+ the thread's half of the tile: NQ groups of 256 rows)
   int cv[RS::NR];  // (H + b) * 8 of each run's first entry
 #pragma unroll
   for (int r = 0; r < RS::NR; r++) {
@@ -1934,7 +1937,7 @@ __global__ __launch_bounds__(256, 2) void spmv_march2_kernel(const hipxMarchPlan
   bool hact[NHALO], hlow[NHALO];
 #pragma unroll
   for (int hh = 0; hh < NHALO; hh++) {
-    const int hidx0 = hh * 256 + t;
+    const int hidx0 = hh * NT + t;
     hact[hh]        = hidx0 < H;
     const int hidx  = hact[hh] ? hidx0 : H - 1;
     hlow[hh]        = hidx < H2;
@@ -1961,7 +1964,7 @@ __global__ __launch_bounds__(256, 2) void spmv_march2_kernel(const hipxMarchPlan
     const long long g0  = (long long)pc * S + i0;
     const double   *src = x + g0;
 #pragma unroll
-    for (int qq = 0; qq < NOWN; qq++) R.o[qq] = *reinterpret_cast<const dbl2 *>(src + 2 * (qq * 256 + t));
+    for (int qq = 0; qq < NOWN; qq++) R.o[qq] = *reinterpret_cast<const dbl2 *>(src + 2 * (qq * NT + t));
     const bool lofix = pc == 0 && i0 < H, hifix = pc == nplanes - 1 && i0 + L + H > S;  // halo beyond the vector's ends (uniform)
     int        off[NHALO];
 #pragma unroll
@@ -1973,11 +1976,11 @@ __global__ __launch_bounds__(256, 2) void spmv_march2_kernel(const hipxMarchPlan
     if (CG) {
       const double *zs = cg.z + g0, *xs = cg.xsol + g0;
 #pragma unroll
-      for (int qq = 0; qq < NOWN; qq++) R.zo[qq] = *reinterpret_cast<const dbl2 *>(zs + 2 * (qq * 256 + t));
+      for (int qq = 0; qq < NOWN; qq++) R.zo[qq] = *reinterpret_cast<const dbl2 *>(zs + 2 * (qq * NT + t));
 #pragma unroll
       for (int hh = 0; hh < NHALO; hh++) R.zh[hh] = *reinterpret_cast<const dbl2 *>(zs + off[hh]);
 #pragma unroll
-      for (int qq = 0; qq < NOWN; qq++) R.xo[qq] = *reinterpret_cast<const dbl2 *>(xs + 2 * (qq * 256 + t));
+      for (int qq = 0; qq < NOWN; qq++) R.xo[qq] = *reinterpret_cast<const dbl2 *>(xs + 2 * (qq * NT + t));
     }
   };
   // plane p from registers into the buffer at sbase; CG: as p_new, and for the planes this workgroup owns (k0 <= p < k1) p_new and x += a p go to memory
@@ -1985,7 +1988,7 @@ __global__ __launch_bounds__(256, 2) void spmv_march2_kernel(const hipxMarchPlan
     char *d = smem + sbase;
     if (!CG) {
 #pragma unroll
-      for (int qq = 0; qq < NOWN; qq++) *reinterpret_cast<dbl2 *>(d + H * 8 + (qq * 256 + t) * 16) = R.o[qq];
+      for (int qq = 0; qq < NOWN; qq++) *reinterpret_cast<dbl2 *>(d + H * 8 + (qq * NT + t) * 16) = R.o[qq];
 #pragma unroll
       for (int hh = 0; hh < NHALO; hh++)
         if (hact[hh]) *reinterpret_cast<dbl2 *>(d + hl[hh]) = R.h[hh];
@@ -1999,7 +2002,7 @@ __global__ __launch_bounds__(256, 2) void spmv_march2_kernel(const hipxMarchPlan
         zv.y    = zv.y * cgd;
         pn[qq].x = zv.x + cgb * R.o[qq].x;
         pn[qq].y = zv.y + cgb * R.o[qq].y;
-        *reinterpret_cast<dbl2 *>(d + H * 8 + (qq * 256 + t) * 16) = pn[qq];
+        *reinterpret_cast<dbl2 *>(d + H * 8 + (qq * NT + t) * 16) = pn[qq];
       }
 #pragma unroll
       for (int hh = 0; hh < NHALO; hh++) {
@@ -2018,8 +2021,8 @@ __global__ __launch_bounds__(256, 2) void spmv_march2_kernel(const hipxMarchPlan
           dbl2 xv = R.xo[qq];
           xv.x    = xv.x + cga * R.o[qq].x;
           xv.y    = xv.y + cga * R.o[qq].y;
-          *reinterpret_cast<dbl2 *>(pd + 2 * (qq * 256 + t)) = pn[qq];
-          *reinterpret_cast<dbl2 *>(xd + 2 * (qq * 256 + t)) = xv;
+          *reinterpret_cast<dbl2 *>(pd + 2 * (qq * NT + t)) = pn[qq];
+          *reinterpret_cast<dbl2 *>(xd + 2 * (qq * NT + t)) = xv;
         }
       }
     }
@@ -2146,7 +2149,7 @@ __global__ __launch_bounds__(256, 2) void spmv_march2_kernel(const hipxMarchPlan
   }
   if (DOT) {
     const double w = hipx::wave_sum(acc);
-    if (lane == 0) dotpart[(size_t)blockIdx.x * 4 + wv] = w;
+    if (lane == 0) dotpart[(size_t)blockIdx.x * (NT / 64) + wv] = w;
   }
 }
 
@@ -2598,6 +2601,7 @@ void free_templates(hipxMat A)
   A->tmpl_base = -1;
   A->pair_ok   = false;
   A->march_ok  = false;
+  A->march_nt  = 256;
   A->march2_state = 0;
   A->d_tq = nullptr;
   A->tq_launches = 0;
@@ -2822,15 +2826,18 @@ int build_templates(hipxMat A)
           H = (H + 1) & ~1ll;
           const int Lsel = (getenv("HIPX_TMPL_MARCH_L") ? atoi(getenv("HIPX_TMPL_MARCH_L")) == 1024 : S / 2048 < 16) ? 1024 : 2048;  // (HIPX_TMPL_MARCH_L: developer switch)
           // three plane buffers of L + 2 H doubles, two workgroups per CU: <= 80 KiB (7-pt / 27-pt up to 680-point lines; longer lines keep the pair form)
-          if (ok && 2 * H < S && 3 * (size_t)(Lsel + 2 * H) * sizeof(double) <= 80 * 1024) {
+          bool big = false;  // halos beyond the two-workgroup budget: one 512-thread workgroup per CU over 4096-row tiles (spmv_march2_kernel<..., 512> only)
+          if (ok && 2 * H < S && 3 * (size_t)(Lsel + 2 * H) * sizeof(double) > 80 * 1024 && H <= 1024 && S % 4096 == 0 && 3 * (size_t)(4096 + 2 * H) * sizeof(double) <= 150 * 1024) big = true;
+          if (ok && 2 * H < S && (big || 3 * (size_t)(Lsel + 2 * H) * sizeof(double) <= 80 * 1024)) {
             mp.ne    = len0;
             mp.nlo   = cutlo + 1;
             mp.nmid  = cuthi - cutlo - 1;
             mp.S     = (int)S;
             mp.H     = (int)H;
-            mp.L     = Lsel;
+            mp.L     = big ? 4096 : Lsel;
             mp.full  = len0 == 32 ? 0xffffffffu : ((1u << len0) - 1u);
             A->march_ok = true;
+            A->march_nt = big ? 512 : 256;
           }
         }
       }
@@ -2970,13 +2977,13 @@ static int march2_check(hipxMat A)
   const hipxMarchPlan &mp = A->march_plan;
   const hipx_int       m  = A->nrows_c;
   if (!A->march_ok || !A->d_tid || !A->d_tmask || A->ntmpl > 256 || A->compressed || m != A->m) return HIPX_SUCCESS;
-  if (m % mp.S || mp.S % mp.L || (mp.L != 2048 && mp.L != 1024) || (mp.H & 1) || mp.H < 2 || mp.H > 768 || mp.H > mp.L) return HIPX_SUCCESS;
+  if (m % mp.S || mp.S % mp.L || (mp.L != 2048 && mp.L != 1024 && !(mp.L == 4096 && A->march_nt == 512)) || (mp.H & 1) || mp.H < 2 || mp.H > (A->march_nt == 512 ? 1024 : 768) || mp.H > mp.L) return HIPX_SUCCESS;
   const int nplanes = (int)(m / mp.S);
   if (nplanes < 3) return HIPX_SUCCESS;
   const bool runs = mp.ne == 7 ? march2_runs_ok<7>(mp) : (mp.ne == 27 ? march2_runs_ok<27>(mp) : (mp.ne == 5 ? march2_runs_ok<5>(mp) : (mp.ne == 9 ? march2_runs_ok<9>(mp) : false)));
   if (!runs) return HIPX_SUCCESS;
-  const int nq = mp.L / 256, nh = (mp.H + 255) / 256;  // the instantiated shapes (launch_march2)
-  const bool shape = (mp.ne == 7 && nq == 8 && nh <= 2) || (mp.ne == 27 && nq == 8 && (nh == 2 || nh == 3)) || (nq == 4 && nh == 1);
+  const int nq = mp.L / A->march_nt, nh = (mp.H + A->march_nt - 1) / A->march_nt;  // the instantiated shapes (launch_march2)
+  const bool shape = A->march_nt == 512 ? (mp.ne == 7 && nq == 8 && nh <= 2) : ((mp.ne == 7 && nq == 8 && nh <= 2) || (mp.ne == 27 && nq == 8 && (nh == 2 || nh == 3)) || (nq == 4 && nh == 1));
   if (!shape) return HIPX_SUCCESS;
   unsigned int *d_flag = nullptr, h_flag = 0;
   HIPX_HIP(hipMalloc((void **)&d_flag, sizeof(unsigned int)));
@@ -2995,7 +3002,8 @@ static int march2_check(hipxMat A)
 // work split of the march forms: tiles x segments of planes ~ HIPX_TMPL_MARCH_UNITS workgroups (2 per CU resident), segments of >= 8 planes
 static void march_geometry(hipxMat A, int &tiles, int &nseg, int &pps, int &nplanes, int &units)
 {
-  static const int     units_env = getenv("HIPX_TMPL_MARCH_UNITS") ? atoi(getenv("HIPX_TMPL_MARCH_UNITS")) : 512;
+  static const int     units_env0 = getenv("HIPX_TMPL_MARCH_UNITS") ? atoi(getenv("HIPX_TMPL_MARCH_UNITS")) : 0;
+  const int            units_env = units_env0 ? units_env0 : (A->march_nt == 512 ? 256 : 512);  // (one 512-thread workgroup per CU)
   const hipxMarchPlan &mp = A->march_plan;
   const hipx_int       m  = A->nrows_c;
   tiles   = (mp.S + mp.L - 1) / mp.L;
@@ -3006,29 +3014,36 @@ static void march_geometry(hipxMat A, int &tiles, int &nseg, int &pps, int &npla
   units   = tiles * nseg;
 }
 
-template <int NE, int NQ, int NHALO, bool DOT, bool CG = false>
+template <int NE, int NQ, int NHALO, bool DOT, bool CG = false, int NT = 256>
 static int launch_march2_inst(hipxMat A, const double *x, double *yout, double *dotpart, int units, int tiles, int pps, int nplanes, int xm, size_t lds, const hipxMarchCG &cg = hipxMarchCG{})
 {
   static bool attr = false;
   if (!attr) {
-    HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_march2_kernel<NE, NQ, NHALO, DOT, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_march2_kernel<NE, NQ, NHALO, DOT, CG, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, NT == 512 ? 152 * 1024 : 96 * 1024));
     attr = true;
   }
-  spmv_march2_kernel<NE, NQ, NHALO, DOT, CG><<<(unsigned)units, 256, lds, rt().compute>>>(A->march_plan, A->d_tid, A->d_tmask, A->ntmpl, x, yout, dotpart, tiles, pps, nplanes, xm, cg);
+  spmv_march2_kernel<NE, NQ, NHALO, DOT, CG, NT><<<(unsigned)units, NT, lds, rt().compute>>>(A->march_plan, A->d_tid, A->d_tmask, A->ntmpl, x, yout, dotpart, tiles, pps, nplanes, xm, cg);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
 // the shapes the CG prologue is instantiated for (short templates: the long ones have no registers left for two more streams in flight)
-static bool march2_cg_shape(const hipxMarchPlan &mp)
+static bool march2_cg_shape(hipxMat A)
 {
-  const int nq = mp.L / 256, nh = (mp.H + 255) / 256;
+  const hipxMarchPlan &mp = A->march_plan;
+  const int            nq = mp.L / A->march_nt, nh = (mp.H + A->march_nt - 1) / A->march_nt;
+  if (A->march_nt == 512) return mp.ne == 7 && nq == 8 && nh <= 2;
   return (mp.ne == 7 && nq == 8 && nh <= 2) || ((mp.ne == 7 || mp.ne == 5 || mp.ne == 9) && nq == 4 && nh == 1);
 }
 template <bool DOT>
 static int launch_march2_cg(hipxMat A, const double *x, double *yout, double *dotpart, int units, int tiles, int pps, int nplanes, int xm, size_t lds, const hipxMarchCG &cg)
 {
   const hipxMarchPlan &mp = A->march_plan;
-  const int            nq = mp.L / 256, nh = (mp.H + 255) / 256;
+  const int            nq = mp.L / A->march_nt, nh = (mp.H + A->march_nt - 1) / A->march_nt;
+  if (A->march_nt == 512) {
+    if (mp.ne == 7 && nq == 8 && nh == 1) return launch_march2_inst<7, 8, 1, DOT, true, 512>(A, x, yout, dotpart, units, tiles, pps, nplanes, xm, lds, cg);
+    if (mp.ne == 7 && nq == 8 && nh == 2) return launch_march2_inst<7, 8, 2, DOT, true, 512>(A, x, yout, dotpart, units, tiles, pps, nplanes, xm, lds, cg);
+    return fail(HIPX_ERR_ARG, "march2 (CG prologue, 512 threads): shape not instantiated", __FILE__, __LINE__);
+  }
 #define HIPX_M2(NE, NQ, NH) return launch_march2_inst<NE, NQ, NH, DOT, true>(A, x, yout, dotpart, units, tiles, pps, nplanes, xm, lds, cg)
   if (mp.ne == 7 && nq == 8 && nh == 1) HIPX_M2(7, 8, 1);
   if (mp.ne == 7 && nq == 8 && nh == 2) HIPX_M2(7, 8, 2);
@@ -3042,7 +3057,12 @@ template <bool DOT>
 static int launch_march2(hipxMat A, const double *x, double *yout, double *dotpart, int units, int tiles, int pps, int nplanes, int xm, size_t lds)
 {
   const hipxMarchPlan &mp = A->march_plan;
-  const int            nq = mp.L / 256, nh = (mp.H + 255) / 256;
+  const int            nq = mp.L / A->march_nt, nh = (mp.H + A->march_nt - 1) / A->march_nt;
+  if (A->march_nt == 512) {
+    if (mp.ne == 7 && nq == 8 && nh == 1) return launch_march2_inst<7, 8, 1, DOT, false, 512>(A, x, yout, dotpart, units, tiles, pps, nplanes, xm, lds);
+    if (mp.ne == 7 && nq == 8 && nh == 2) return launch_march2_inst<7, 8, 2, DOT, false, 512>(A, x, yout, dotpart, units, tiles, pps, nplanes, xm, lds);
+    return fail(HIPX_ERR_ARG, "march2 (512 threads): shape not instantiated", __FILE__, __LINE__);
+  }
 #define HIPX_M2(NE, NQ, NH) return launch_march2_inst<NE, NQ, NH, DOT>(A, x, yout, dotpart, units, tiles, pps, nplanes, xm, lds)
   if (mp.ne == 7 && nq == 8 && nh == 1) HIPX_M2(7, 8, 1);
   if (mp.ne == 7 && nq == 8 && nh == 2) HIPX_M2(7, 8, 2);
@@ -3084,19 +3104,23 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
   // march form (spmv_march_kernel): three-plane base templates, 16-byte aligned x, enough tiles x segments to fill the chip
   {
     static const bool nomarch = getenv("HIPX_TMPL_NOMARCH") != nullptr;
-    static const int  units_env = getenv("HIPX_TMPL_MARCH_UNITS") ? atoi(getenv("HIPX_TMPL_MARCH_UNITS")) : 512;  // target number of workgroups (2 per CU resident)
     const hipxMarchPlan &mp = A->march_plan;
-    if (A->march_ok && tbase >= 0 && !nomarch && !probe0 && cfg == 1 && !g_epi_on && A->ntmpl <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && m % 2 == 0) {
-      const int tiles   = (mp.S + mp.L - 1) / mp.L;
-      const int nplanes = (int)((m + mp.S - 1) / mp.S);
-      int       nseg    = std::max(1, std::min(nplanes / 8, (units_env + tiles / 2) / tiles));  // >= 8 planes per segment: its two extra plane loads stay <= 25 %
-      const int pps     = (nplanes + nseg - 1) / nseg;
-      nseg              = (nplanes + pps - 1) / pps;
-      const int units   = tiles * nseg;
+    bool                 big_ok = true;  // plans that only the 512-thread form of spmv_march2_kernel can run (long lines): MatMult of a matrix that passed its checks
+    if (A->march_ok && A->march_nt == 512) {
+      big_ok = false;
+      if (MODE == 0 && !getenv("HIPX_MARCH1") && !getenv("HIPX_TMPL_TRACE")) {
+        int ierr2 = march2_check(A);
+        if (ierr2) return ierr2;
+        big_ok = A->march2_state == 1 && (reinterpret_cast<uintptr_t>(yout) & 7) == 0;
+      }
+    }
+    if (A->march_ok && big_ok && tbase >= 0 && !nomarch && !probe0 && cfg == 1 && !g_epi_on && A->ntmpl <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && m % 2 == 0) {
+      int tiles, nseg, pps, nplanes, units;  // tiles x segments of >= 8 planes (a segment's two extra plane loads stay <= 25 %)
+      march_geometry(A, tiles, nseg, pps, nplanes, units);
       if ((units >= 192 || A->march_force) && (hipx_int)units <= nchunks && mp.ne <= 32) {
         const size_t lds = 3 * (size_t)(mp.L + 2 * mp.H) * sizeof(double);
         const int    xm  = (units % 8 == 0) ? 1 : 0;
-        if (DOT) A->dot_npart_used = (hipx_int)units * 4;
+        if (DOT) A->dot_npart_used = (hipx_int)units * (A->march_nt / 64);
         // the long templates run the kernel WITH the dot also when nobody wants it (the partials go to a dump): without it the compiler schedules the
         // 27-entry loop into 80 registers of scratch per lane (312 bytes; with the dot: none)
         if (!DOT && mp.ne > 9 && !A->d_march_dump) HIPX_HIP(hipMalloc((void **)&A->d_march_dump, sizeof(double) * 4 * 8192));
@@ -3836,14 +3860,13 @@ int hipxMatSetSpMVVariant(hipxMat A, int variant)
 static bool march_applies(hipxMat A)
 {
   if (!A->march_ok || A->tmpl_base < 0 || !A->d_tmask || A->nrows_c % 2 || getenv("HIPX_TMPL_NOMARCH") || getenv("HIPX_TMPL_NOSUB") || getenv("HIPX_TMPL_PROBE") || tmpl_cfg() != 1 || A->ntmpl > 256) return false;
-  const hipxMarchPlan &mp = A->march_plan;
-  const hipx_int       m = A->nrows_c;
-  const int            target = getenv("HIPX_TMPL_MARCH_UNITS") ? atoi(getenv("HIPX_TMPL_MARCH_UNITS")) : 512;
-  const int            tiles = (mp.S + mp.L - 1) / mp.L, nplanes = (int)((m + mp.S - 1) / mp.S);
-  int                  nseg = std::max(1, std::min(nplanes / 8, (target + tiles / 2) / tiles));
-  const int            pps = (nplanes + nseg - 1) / nseg;
-  nseg                     = (nplanes + pps - 1) / pps;
-  return (tiles * nseg >= 192 || A->march_force) && (hipx_int)(tiles * nseg) <= (m + 511) / 512;
+  const hipx_int m = A->nrows_c;
+  if (A->march_nt == 512) {  // long lines: the 512-thread form of spmv_march2_kernel or nothing
+    if (getenv("HIPX_MARCH1") || getenv("HIPX_TMPL_TRACE") || march2_check(A) || A->march2_state != 1) return false;
+  }
+  int tiles, nseg, pps, nplanes, units;
+  march_geometry(A, tiles, nseg, pps, nplanes, units);
+  return (units >= 192 || A->march_force) && (hipx_int)units <= (m + 511) / 512;
 }
 
 int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
@@ -4001,10 +4024,10 @@ int hipxMatMultCGDirectionDotBegin(hipxMat A, const double *p_old, double *p_new
   if (ierr) return ierr;
   if (!tm || !march_applies(A) || getenv("HIPX_MARCH1") || getenv("HIPX_TMPL_TRACE")) return HIPX_SUCCESS;
   if ((ierr = march2_check(A))) return ierr;
-  if (A->march2_state != 1 || !march2_cg_shape(A->march_plan)) return HIPX_SUCCESS;
+  if (A->march2_state != 1 || !march2_cg_shape(A)) return HIPX_SUCCESS;
   int tiles, nseg, pps, nplanes, units;
   march_geometry(A, tiles, nseg, pps, nplanes, units);
-  const hipx_int npart = (hipx_int)units * 4;
+  const hipx_int npart = (hipx_int)units * (A->march_nt / 64);
   if (npart > A->dotpart_cap) {
     HIPX_HIP(hipStreamSynchronize(rt().compute));
     (void)hipFree(A->d_dotpart);

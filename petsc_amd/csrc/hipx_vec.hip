@@ -241,6 +241,25 @@ __global__ __launch_bounds__(kEwThreads) void cg_aypx_axpy_kernel(double *p, dou
   }
 }
 
+// Single-reduction CG (KSPSolve_CG_SingleReduction, cg.c:364-534): the five vector updates between two reductions in ONE pass:
+//   p = z + b p (cg.c:470, VecAYPX)   w = s + b w (cg.c:477: w = A p by recurrence)   x += a p (cg.c:490)   r -= a w (cg.c:491)   z = r .* d (PCApply_Jacobi,
+//   cg.c:493) | z = r (PCNONE: d == NULL)
+// element by element the operations of the five reference loops in their order (z's old value feeds p before the new one is stored).
+__global__ __launch_bounds__(kEwThreads) void cg_sr_update_kernel(double *p, double *w, double *x, double *r, double *z, const double *s, const double *d, double b, double a, hipx_int n)
+{
+  const double ma = -a;
+  for (hipx_int i = (hipx_int)blockIdx.x * kEwThreads + threadIdx.x; i < n; i += (hipx_int)gridDim.x * kEwThreads) {
+    const double pn = z[i] + b * p[i];
+    const double wn = s[i] + b * w[i];
+    p[i] = pn;
+    w[i] = wn;
+    x[i] = x[i] + a * pn;
+    const double rn = r[i] + ma * wn;
+    r[i] = rn;
+    z[i] = d ? rn * d[i] : rn;
+  }
+}
+
 // ---------------------------------------------------------------- swap
 __global__ __launch_bounds__(kEwThreads) void swap_kernel(double *x, double *y, hipx_int n)
 {
@@ -1421,6 +1440,18 @@ int hipxCGAypxAxpyDev(double *p, const double *z, const double *r, double dconst
   if (z) cg_aypx_axpy_kernel<true, false, true><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, src, 0.0, 0.0, 0.0, dev_beta_new, dev_beta_old, dev_dpi, n, vec);
   else cg_aypx_axpy_kernel<true, true, true><<<ew_grid(n, vec), kEwThreads, 0, rt().compute>>>(p, x, src, dconst, 0.0, 0.0, dev_beta_new, dev_beta_old, dev_dpi, n, vec);
   (void)prof_section(HIPX_PROF_CG_DIR, false, rt().compute);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+int hipxCGSingleReductionUpdate(double *p, double *w, double *x, double *r, double *z, const double *s, const double *d, double b, double a, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  if (n <= 0) return HIPX_SUCCESS;
+  HIPX_ARG(p && w && x && r && z && s, "null argument");
+  hipx_int g = (n + kEwThreads * 2 - 1) / (kEwThreads * 2);
+  if (g > 8192) g = 8192;
+  cg_sr_update_kernel<<<(unsigned)(g < 1 ? 1 : g), kEwThreads, 0, rt().compute>>>(p, w, x, r, z, s, d, b, a, n);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }

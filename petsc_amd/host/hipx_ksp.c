@@ -212,12 +212,128 @@ int HipxKSPDestroyWork(HipxKSP *ksp)
   if (ksp->P) CHK(hipxFree(ksp->P));
   if (ksp->P2) CHK(hipxFree(ksp->P2));
   if (ksp->dscal) CHK(hipxFree(ksp->dscal));
+  if (ksp->S) CHK(hipxFree(ksp->S));
+  if (ksp->W) CHK(hipxFree(ksp->W));
+  ksp->S = ksp->W = NULL;
   if (ksp->gslab) CHK(hipxFree(ksp->gslab));
   ksp->gslab     = NULL;
   ksp->gslab_len = 0.0;
   ksp->dscal = NULL;
   ksp->R = ksp->Z = ksp->P = ksp->P2 = NULL;
   ksp->work_n = 0;
+  return 0;
+}
+
+/* ---- KSPSolve_CG_SingleReduction (cg.c:364-534, KSPCGUseSingleReduction): w = A p by recurrence from s = A z, so that the iteration's sums --
+   ||z||^2, delta = z . s, beta = z . r -- form ONE reduction stage (here: one 3-value reduction kernel, on several ranks one 24-byte all-reduce)
+   instead of the two of the standard form.  Preconditioned norm; with PCJACOBI / PCNONE and ksp->fused the five vector updates of an
+   iteration are one kernel (hipxCGSingleReductionUpdate).  Statement by statement the reference's loop: its residual history bit for bit
+   when the reductions are exact (hipxSetReductionMode). */
+static int sr_sums(HipxMat *A, const double *z, const double *s, const double *r, hipx_int n, double *sums3)
+{
+  const double *ys[3] = {z, s, r};
+  if (A->nranks > 1) return hipxVecMDotAllreduce(z, 3, ys, n, sums3);
+  return hipxVecMDot(z, 3, ys, n, sums3);
+}
+
+static int cg_sr_begin(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double *X)
+{
+  const hipx_int n = A->m;
+  double        *R = ksp->R, *Z = ksp->Z, sums[3], dp;
+  if (ksp->normtype != HIPX_KSP_NORM_PRECONDITIONED) return HIPX_ERR_SUP; /* the other norm types keep the standard loop */
+  if (!ksp->S) {
+    const size_t bytes = sizeof(double) * (size_t)(n ? n : 1);
+    CHK(hipxMalloc((void **)&ksp->S, bytes));
+    CHK(hipxMalloc((void **)&ksp->W, bytes));
+  }
+  if (!ksp->guess_nonzero) CHK(hipxVecSet(X, n, 0.0));
+  if (ksp->guess_nonzero) {
+    CHK(HipxMatMult(A, X, R));       /* cg.c:397 */
+    CHK(hipxVecAYPX(R, -1.0, B, n)); /* cg.c:398 */
+  } else CHK(hipxVecCopy(B, R, n));  /* cg.c:400 */
+  CHK(HipxPCApply(pc, A, R, Z));      /* cg.c:405 */
+  CHK(HipxMatMult(A, Z, ksp->S));     /* cg.c:439 (moved before the norm: one reduction for the three sums; the values are the same) */
+  CHK(sr_sums(A, Z, ksp->S, R, n, sums));
+  dp = sqrt(sums[0]);                 /* cg.c:406 */
+  if (isnan(dp) || isinf(dp)) {
+    ksp->reason = KSP_DIVERGED_NANORINF;
+    return 0;
+  }
+  log_history(ksp, dp);
+  ksp->rnorm = dp;
+  CHK(converged_default(ksp, A, pc, 0, dp, B, &ksp->reason)); /* cg.c:434 */
+  if (ksp->reason) return 0;
+  ksp->delta = sums[1]; /* cg.c:440 */
+  ksp->beta  = sums[2]; /* cg.c:441 */
+  if (isnan(ksp->beta) || isinf(ksp->beta)) ksp->reason = KSP_DIVERGED_NANORINF;
+  return 0;
+}
+
+static int cg_sr_step(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double *X, hipx_int nsteps)
+{
+  const hipx_int n = A->m;
+  double        *R = ksp->R, *Z = ksp->Z, *P = ksp->P, *S = ksp->S, *W = ksp->W;
+  const int      onekernel = ksp->fused && (pc->type == HIPX_PC_JACOBI || pc->type == HIPX_PC_NONE);
+  for (hipx_int st = 0; st < nsteps && !ksp->reason && ksp->i < ksp->max_it; st++) {
+    const hipx_int i = ksp->i;
+    double         b = 0.0, dpiold, sums[3], dp;
+    ksp->its = i + 1;
+    if (ksp->beta == 0.0) { /* cg.c:448 */
+      ksp->reason = KSP_CONVERGED_ATOL;
+      break;
+    } else if ((i > 0) && (ksp->beta * ksp->betaold < 0.0)) { /* cg.c:453 */
+      ksp->reason = KSP_DIVERGED_INDEFINITE_PC;
+      break;
+    }
+    dpiold = ksp->dpi;
+    if (!i) {
+      CHK(hipxVecCopy(Z, P, n));            /* cg.c:461 */
+      CHK(HipxMatMult(A, P, W));            /* cg.c:474 */
+      CHK(HipxVecDot(A, P, W, n, &ksp->dpi)); /* cg.c:475 */
+    } else {
+      b        = ksp->beta / ksp->betaold;  /* cg.c:464 */
+      ksp->dpi = ksp->delta - ksp->beta * ksp->beta * dpiold / (ksp->betaold * ksp->betaold); /* cg.c:478 */
+    }
+    ksp->betaold = ksp->beta;
+    if (isnan(ksp->beta) || isinf(ksp->beta)) { /* KSPCheckDot cg.c:481 */
+      ksp->reason = KSP_DIVERGED_NANORINF;
+      break;
+    }
+    if ((ksp->dpi == 0.0) || ((i > 0) && (ksp->dpi * dpiold <= 0.0))) { /* cg.c:483 */
+      ksp->reason = KSP_DIVERGED_INDEFINITE_MAT;
+      break;
+    }
+    ksp->a = ksp->beta / ksp->dpi; /* cg.c:488 */
+    if (i && onekernel) CHK(hipxCGSingleReductionUpdate(P, W, X, R, Z, S, pc->type == HIPX_PC_JACOBI ? pc->dinv : NULL, b, ksp->a, n));
+    else {
+      if (i) {
+        CHK(hipxVecAYPX(P, b, Z, n)); /* cg.c:470 */
+        CHK(hipxVecAYPX(W, b, S, n)); /* cg.c:477 */
+      }
+      CHK(hipxVecAXPY(X, ksp->a, P, n));  /* cg.c:490 */
+      CHK(hipxVecAXPY(R, -ksp->a, W, n)); /* cg.c:491 */
+      CHK(HipxPCApply(pc, A, R, Z));      /* cg.c:493 */
+    }
+    CHK(HipxMatMult(A, Z, S));              /* cg.c:494 */
+    CHK(sr_sums(A, Z, S, R, n, sums));      /* cg.c:495 + 523: VecNorm(Z) and VecMDot(Z, {S, R}) as one reduction */
+    dp = sqrt(sums[0]);
+    if (isnan(dp) || isinf(dp)) {
+      ksp->reason = KSP_DIVERGED_NANORINF;
+      break;
+    }
+    ksp->rnorm = dp;
+    log_history(ksp, dp);
+    CHK(converged_default(ksp, A, pc, i + 1, dp, B, &ksp->reason)); /* cg.c:514 */
+    if (ksp->reason) break;
+    ksp->delta = sums[1];
+    ksp->beta  = sums[2];
+    if (isnan(ksp->beta) || isinf(ksp->beta)) { /* cg.c:526 */
+      ksp->reason = KSP_DIVERGED_NANORINF;
+      break;
+    }
+    ksp->i++;
+  }
+  if (!ksp->reason && ksp->i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS; /* cg.c:532 */
   return 0;
 }
 
@@ -238,6 +354,7 @@ int HipxKSPCGBegin(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double
   ksp->betaold = 1.0;
   ksp->x_pending = 0;
   ksp->a_pending = 0.0;
+  if (ksp->single_reduction && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED) return cg_sr_begin(ksp, A, pc, B, X);
   if (!ksp->guess_nonzero) CHK(hipxVecSet(X, n, 0.0)); /* itfunc.c:908 */
   if (ksp->guess_nonzero) {
     CHK(HipxMatMult(A, X, R));         /* cg.c:154 */
@@ -419,6 +536,7 @@ int HipxKSPCGStep(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double 
   double         dp = 0.0, b, dpiold;
   /* fused update kernel (AXPY, AXPY, PCJACOBI, norm, dot): any rank count, its two sums all-reduced together;
      SpMV + dot fusion: only without an off-diagonal block (the dot needs the complete w) */
+  if (ksp->single_reduction && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED) return cg_sr_step(ksp, A, pc, B, X, nsteps);
   const int      fused_any = ksp->fused && (pc->type == HIPX_PC_JACOBI || (pc->type == HIPX_PC_NONE && pc->dconst_valid)) && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED;
   const int      fused_upd = fused_any && pc->type == HIPX_PC_JACOBI; /* the host-synchronised loop below streams dinv; PCNONE (round 4) takes the launch-ahead loop, whose kernels multiply by a scalar */
   const int      fused     = fused_upd && !A->B && A->nranks <= 1;

@@ -27,7 +27,7 @@ static PetscBool KSPCGHIPXApplicable(KSP ksp, Mat *Aout)
   PCJacobiType  jt;
   PetscMPIInt   size;
 
-  if (ksp->calc_sings || cg->singlereduction || cg->radius != 0.0 || cg->type != KSP_CG_SYMMETRIC || cg->obj_min != 0.0) return PETSC_FALSE;
+  if (ksp->calc_sings || cg->radius != 0.0 || cg->type != KSP_CG_SYMMETRIC || cg->obj_min != 0.0) return PETSC_FALSE; /* (-ksp_cg_single_reduction: round 4, HipxKSP.single_reduction) */
   if (ksp->pc_side != PC_LEFT || ksp->normtype != KSP_NORM_PRECONDITIONED || ksp->transpose_solve) return PETSC_FALSE;
   if (ksp->dscale) return PETSC_FALSE;
   if (MPI_Comm_size(PetscObjectComm((PetscObject)ksp), &size)) return PETSC_FALSE;
@@ -104,6 +104,7 @@ static PetscErrorCode KSPSolve_CGHIPX(KSP ksp)
   k.max_it        = (hipx_int)ksp->max_it;
   k.guess_nonzero = ksp->guess_zero ? 0 : 1;
   k.fused         = 1;
+  k.single_reduction = ((KSP_CG *)ksp->data)->singlereduction ? 1 : 0; /* KSPSolve_CG_SingleReduction (cg.c:364-534): one reduction stage per iteration */
   k.external_test = 1;                                  /* PETSc's (*ksp->converged) decides */
   k.defer_flush   = ksp->numbermonitors ? 0 : 1;        /* monitors may look at the solution: keep x complete for them */
   PetscCall(VecHIPXGetDeviceRead(ksp->vec_rhs, &db, &tb));

@@ -13,6 +13,8 @@ typedef struct {
   hipxMat          dA;
   PetscObjectState nonzerostate; /* pattern the device copy was built from */
   PetscObjectState valuestate;   /* object state of the values on the device */
+  hipxMat          dAt;          /* the transposed matrix as its own device CSR (MatMultTranspose / MatMultTransposeAdd), built at the first use */
+  PetscObjectState t_nonzerostate, t_valuestate;
   PetscErrorCode (*parent_assemblyend)(Mat, MatAssemblyType);
   PetscErrorCode (*parent_destroy)(Mat);
   PetscErrorCode (*parent_duplicate)(Mat, MatDuplicateOption, Mat *);
@@ -146,6 +148,103 @@ static PetscErrorCode MatMultAdd_SeqAIJHIPX(Mat A, Vec xx, Vec yy, Vec zz)
   if (zz != yy) PetscCall(VecHIPXRestoreDeviceRead(yy, &y, &ty));
   PetscCall(VecHIPXRestoreDeviceRead(xx, &x, &tx));
   PetscCall(PetscLogFlops(2.0 * a->nz)); /* aij.c:1653 */
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* ---- MatMultTranspose / MatMultTransposeAdd on the device (aij.c:1383-1440).  The reference walks the ROWS of A and adds alpha v[j] into
+   y[idx[j]]: column c of A receives its contributions in ascending row order, each a separately rounded product added to the running
+   value (which starts at 0 for MatMultTranspose, at zz_c for MatMultTransposeAdd).  That is exactly the left-to-right row sum of the
+   TRANSPOSED matrix in CSR form with its rows' entries in ascending column (= original row) order -- so the transpose is built once per
+   matrix state (a counting pass over the host CSR, as cheap as the upload) and the products are hipxMatMult / hipxMatMultAdd on it:
+   the same bits as the CPU loop, any of libhipx's kernel forms. */
+static PetscErrorCode MatSeqAIJHIPXGetDeviceTranspose(Mat A, hipxMat *dAt)
+{
+  Mat_SeqAIJHIPX  *h = (Mat_SeqAIJHIPX *)A->spptr;
+  Mat_SeqAIJ      *a = (Mat_SeqAIJ *)A->data;
+  PetscObjectState state;
+
+  PetscFunctionBegin;
+  PetscCheck(A->assembled, PetscObjectComm((PetscObject)A), PETSC_ERR_ARG_WRONGSTATE, "Not for unassembled matrix");
+  PetscCall(PetscObjectStateGet((PetscObject)A, &state));
+  if (!h->dAt || h->t_nonzerostate != A->nonzerostate || h->t_valuestate != state) {
+    const PetscInt     m = A->rmap->n, n = A->cmap->n, nz = a->nz, *ai = a->i, *aj = a->j;
+    const PetscScalar *aa;
+    PetscInt          *ti, *cur;
+    hipx_int          *tj;
+    PetscScalar       *ta;
+    PetscCheck(m < PETSC_INT32_MAX && n < PETSC_INT32_MAX, PETSC_COMM_SELF, PETSC_ERR_SUP, "MATSEQAIJHIPX: local sizes must stay below 2^31");
+    if (h->dAt) PetscCallHIPX(hipxMatDestroy(&h->dAt));
+    PetscCall(MatSeqAIJGetArrayRead(A, &aa)); /* (brings the host copy up to date if the values were last assembled on the device) */
+    PetscCall(PetscCalloc1((size_t)n + 1, &ti));
+    PetscCall(PetscMalloc3((size_t)n + 1, &cur, (size_t)nz + 1, &tj, (size_t)nz + 1, &ta));
+    for (PetscInt k = 0; k < nz; k++) ti[aj[k] + 1]++;
+    for (PetscInt c = 0; c < n; c++) ti[c + 1] += ti[c];
+    for (PetscInt c = 0; c < n; c++) cur[c] = ti[c];
+    for (PetscInt i = 0; i < m; i++)
+      for (PetscInt k = ai[i]; k < ai[i + 1]; k++) {
+        const PetscInt pos = cur[aj[k]]++;
+        tj[pos]            = (hipx_int)i;
+        ta[pos]            = aa[k];
+      }
+#if defined(PETSC_USE_64BIT_INDICES)
+    PetscCallHIPX(hipxMatCreateCSR64((hipx_int)n, (hipx_int)m, (const int64_t *)ti, tj, ta, &h->dAt));
+#else
+    PetscCallHIPX(hipxMatCreateCSR((hipx_int)n, (hipx_int)m, ti, tj, ta, &h->dAt));
+#endif
+    PetscCall(MatSeqAIJRestoreArrayRead(A, &aa));
+    PetscCall(PetscFree3(cur, tj, ta));
+    PetscCall(PetscFree(ti));
+    h->t_nonzerostate = A->nonzerostate;
+    h->t_valuestate   = state;
+  }
+  *dAt = h->dAt;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* MatMultTranspose_SeqAIJ aij.c:1434-1440 */
+static PetscErrorCode MatMultTranspose_SeqAIJHIPX(Mat A, Vec xx, Vec yy)
+{
+  Mat_SeqAIJ        *a = (Mat_SeqAIJ *)A->data;
+  hipxMat            dAt;
+  const PetscScalar *x;
+  PetscScalar       *y;
+  void              *tx, *ty;
+
+  PetscFunctionBegin;
+  PetscCall(MatSeqAIJHIPXGetDeviceTranspose(A, &dAt));
+  PetscCall(VecHIPXGetDeviceRead(xx, &x, &tx));
+  PetscCall(VecHIPXGetDeviceWrite(yy, &y, &ty));
+  PetscCallHIPX(hipxMatMult(dAt, x, y));
+  PetscCall(VecHIPXRestoreDeviceWrite(yy, &y, &ty));
+  PetscCall(VecHIPXRestoreDeviceRead(xx, &x, &tx));
+  PetscCall(PetscLogFlops(2.0 * a->nz)); /* aij.c:1425 */
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* MatMultTransposeAdd_SeqAIJ aij.c:1383-1432: yy = zz + A^T xx (yy may be zz) */
+static PetscErrorCode MatMultTransposeAdd_SeqAIJHIPX(Mat A, Vec xx, Vec zz, Vec yy)
+{
+  Mat_SeqAIJ        *a = (Mat_SeqAIJ *)A->data;
+  hipxMat            dAt;
+  const PetscScalar *x, *z;
+  PetscScalar       *y;
+  void              *tx, *tz = NULL, *ty;
+
+  PetscFunctionBegin;
+  PetscCall(MatSeqAIJHIPXGetDeviceTranspose(A, &dAt));
+  PetscCall(VecHIPXGetDeviceRead(xx, &x, &tx));
+  if (zz == yy) {
+    PetscCall(VecHIPXGetDeviceReadWrite(yy, &y, &ty));
+    z = y;
+  } else {
+    PetscCall(VecHIPXGetDeviceRead(zz, &z, &tz));
+    PetscCall(VecHIPXGetDeviceWrite(yy, &y, &ty));
+  }
+  PetscCallHIPX(hipxMatMultAdd(dAt, x, z, y));
+  PetscCall(VecHIPXRestoreDeviceWrite(yy, &y, &ty));
+  if (zz != yy) PetscCall(VecHIPXRestoreDeviceRead(zz, &z, &tz));
+  PetscCall(VecHIPXRestoreDeviceRead(xx, &x, &tx));
+  PetscCall(PetscLogFlops(2.0 * a->nz));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -414,6 +513,7 @@ static PetscErrorCode MatDestroy_SeqAIJHIPX(Mat A)
 
   PetscFunctionBegin;
   if (h->dA) PetscCallHIPX(hipxMatDestroy(&h->dA));
+  if (h->dAt) PetscCallHIPX(hipxMatDestroy(&h->dAt));
   if (h->coo) PetscCallHIPX(hipxCOODestroy(&h->coo));
   PetscCall(PetscObjectComposeFunction((PetscObject)A, "MatConvert_seqaij_seqaijhipx_C", NULL));
   PetscCall(PetscFree(A->spptr));
@@ -467,6 +567,8 @@ static PetscErrorCode MatConvert_SeqAIJ_SeqAIJHIPX(Mat A, MatType mtype, MatReus
   B->spptr              = h;
   B->ops->mult           = MatMult_SeqAIJHIPX;
   B->ops->multadd        = MatMultAdd_SeqAIJHIPX;
+  B->ops->multtranspose    = MatMultTranspose_SeqAIJHIPX;
+  B->ops->multtransposeadd = MatMultTransposeAdd_SeqAIJHIPX;
   B->ops->getdiagonal    = MatGetDiagonal_SeqAIJHIPX;
   B->ops->sor            = MatSOR_SeqAIJHIPX;
   B->ops->assemblyend    = MatAssemblyEnd_SeqAIJHIPX;

@@ -617,7 +617,9 @@ def test_march_form_of_the_template_kernel_bit_exact(hx, kind, n, m, cut):
 
 
 @pytest.mark.parametrize("kind,n,m", [("7pt", 32, None), ("7pt", 64, None), ("7pt", 96, None), ("7pt", 128, None), ("27pt", 64, None), ("27pt", 96, None), ("5pt", 1024, 48),
-                                       ("5pt", 2048, 24), ("7pt", 192, None), ("7pt_box", (256, 64, 20), None)])
+                                       ("5pt", 2048, 24), ("7pt", 192, None), ("7pt_box", (256, 64, 20), None),
+                                       # lines of 768 and 1024 points (BASELINE config 5's planes): the 512-thread form, 4096-row tiles, one workgroup per CU
+                                       ("7pt_box", (1024, 1024, 6), None), ("7pt_box", (768, 768, 4), None)])
 def test_march2_kernel_bit_exact_and_same_bits_as_the_first_march_kernel(hx, kind, n, m):
     """spmv_march2_kernel (round 4: whole planes and tiles, plane-periodic template ids, run-addressed operands): planes of 1024 ... 36864 rows,
     1024- and 2048-row tiles, 5 / 7 / 27 entries, halos of 2 ... 256 elements: y bit-identical to MatMult_SeqAIJ, the fused dot deterministic
@@ -673,7 +675,7 @@ def test_march2_refuses_matrices_whose_template_ids_are_not_plane_periodic(hx):
     _lib.mat_destroy(A)
 
 
-@pytest.mark.parametrize("kind,n,m,dconst", [("7pt", 64, None, 1.0 / 6.0), ("7pt", 96, None, 1.0), ("7pt", 192, None, 0.37), ("5pt", 1024, 48, 0.25)])
+@pytest.mark.parametrize("kind,n,m,dconst", [("7pt", 64, None, 1.0 / 6.0), ("7pt", 96, None, 1.0), ("7pt", 192, None, 0.37), ("5pt", 1024, 48, 0.25), ("7pt_box", (1024, 1024, 5), None, 1.0)])
 def test_cg_direction_update_as_the_products_prologue_bit_identical(hx, kind, n, m, dconst):
     """hipxMatMultCGDirectionDotBegin (p_new = r * dconst + b p, x += a p, w = A p_new, p_new . w in one kernel) against the separate kernels it
     replaces (hipxCGAypxAxpyR, hipxMatMultDot): p_new, x, w bit-identical, the dot the same double (same partials); host scalars and

@@ -116,6 +116,22 @@ def test_matmult_bit_exact_cpu_vs_hipx():
     assert yc == yg and len(yc) == 1000
 
 
+@pytest.mark.parametrize("args", ["-stencil 27 -n 10 -mat_ops", "-stencil 7 -n 12 -mat_ops", "-stencil 5 -m 30 -n 17 -mat_ops", "-stencil 27 -n 10"])
+def test_matmulttranspose_on_the_device_bit_exact(args):
+    """MatMultTranspose_SeqAIJ / MatMultTransposeAdd_SeqAIJ (aij.c:1383-1440) through MATSEQAIJHIPX (round 4): the transposed matrix as its own
+    device CSR -- column c's contributions in ascending row order, the reference's order -- so A^T x, y + A^T x (separate and in place) carry the
+    CPU loop's bits, also for the non-symmetric D_l A D_r."""
+    a = args.split() + ["-dump_y", "-dump_yt", "-ksp_max_it", "1"]
+    cpu, gpu = run("ref_driver", a), run("ref_driver", a + HIPX)
+    for tag in ("yt ", "yta "):
+        c = [l for l in cpu.splitlines() if l.startswith(tag)]
+        g = [l for l in gpu.splitlines() if l.startswith(tag)]
+        assert len(c) > 0 and c == g, tag
+    nc = [float(l.split()[-1]) for l in cpu.splitlines() if l.startswith("MatMultTransposeAdd in place")]
+    ng = [float(l.split()[-1]) for l in gpu.splitlines() if l.startswith("MatMultTransposeAdd in place")]
+    assert len(nc) == 1 and abs(nc[0] - ng[0]) <= 1e-14 * nc[0]  # (a norm: the reduction's rounding, not the product's)
+
+
 def test_matscale_diagonalscale_on_device_then_host_update_bit_exact():
     """MatScale / MatDiagonalScale run on the device copy (hipxMatScale, hipxMatDiagonalScale: (a l_i) r_j like
     aij.c:2333-2371), a host-side MatSetValue + assembly and another MatDiagonalScale follow: the product is bit-identical to the

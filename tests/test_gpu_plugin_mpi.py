@@ -81,6 +81,22 @@ def test_matmult_mpiaijhipx_bit_exact_vs_cpu_mpi(np_, args):
     assert len(y_cpu) > 0 and y_gpu == y_cpu  # printed with %.17g: string equality is bit equality
 
 
+@pytest.mark.parametrize("np_,args", [(2, "-stencil 27 -n 6 -mat_ops"), (3, "-stencil 7 -n 8 -mat_ops"), (3, "-stencil 5 -m 9 -n 7 -mat_ops")])
+def test_matmulttranspose_mpiaijhipx_bit_exact_vs_cpu_mpi(np_, args):
+    """MatMultTranspose / MatMultTransposeAdd_MPIAIJ (mpiaij.c) over hipx blocks (round 4: the blocks' transposes are device CSR matrices of their
+    own, MatMultTranspose_SeqAIJHIPX) on a NON-symmetric operator (D_l A D_r): y^T = A^T x and y + A^T x equal to the CPU MPI run's, digit for digit."""
+    a = args.split() + ["-dump_y", "-dump_yt", "-ksp_max_it", "1"]
+    cpu = mpirun(np_, "ref_driver", a, False)
+    gpu = mpirun(np_, "ref_driver", a + ["-mat_type", "aijhipx"], True)
+    for tag in ("yt ", "yta "):
+        c = sorted(l for l in cpu.splitlines() if l.startswith(tag))
+        g = sorted(l for l in gpu.splitlines() if l.startswith(tag))
+        assert len(c) > 0 and c == g, tag
+    nc = [float(l.split()[-1]) for l in cpu.splitlines() if l.startswith("MatMultTransposeAdd in place")]
+    ng = [float(l.split()[-1]) for l in gpu.splitlines() if l.startswith("MatMultTransposeAdd in place")]
+    assert len(nc) == 1 and abs(nc[0] - ng[0]) <= 1e-14 * nc[0]  # (a norm: the reduction's rounding, not the product's)
+
+
 @pytest.mark.parametrize("np_", [2, 3])
 def test_bench_kspsolve_coo_assembly_on_device_np(np_):
     """bench_kspsolve.c:301-302 assembles with MatSetPreallocationCOO / MatSetValuesCOO, every rank its own rows: with
