@@ -485,7 +485,8 @@ def suite_mode(args):
     _, ks = _lib.load()
     name = args.suite
     if name == "cg":
-        cfg = Cfg(args.stencil, (args.n, args.n, args.n), "cg", args.pc)
+        cdims = tuple(int(v) for v in args.suite_dims.split("x")) if args.suite_dims else (args.n, args.n, args.n)
+        cfg = Cfg(args.stencil, cdims, "cg", args.pc)
         P = Problem(cfg, 0, 1, None, fused=1, pipeline=1)
         P.setup(args.variant, no_dconst=bool(args.suite_no_dconst))
         P.begin(40)
@@ -1068,7 +1069,7 @@ def main():
             pmc["sor27"] = (pmc_suite(["--suite", "sor", "--grid", "256", "--stencil", "27"], "27pt_256_sor"), src % "sor (27-pt 256^3)")
             pmc["sor27var"] = (pmc_suite(["--suite", "sor", "--grid", "256", "--stencil", "27", "--suite-perturb", "1"], "27pt_256_sor_arbitrary_values"), src % "sor --suite-perturb 1")
             pmc["sell"] = (pmc_suite(["--suite", "sell"], "config4_standin_spmv"), src % "sell")
-            pmc["box"] = (pmc_suite(["--suite", "box", "--stencil", "7", "--suite-dims", "1024x1024x32", "--suite-variants", "0"], "config5_lines_spmv"), src % "box (1024 x 1024 x 32)")
+            pmc["box"] = (pmc_suite(["--suite", "cg", "--stencil", "7", "--pc", "none", "--suite-dims", "1024x1024x32"], "config5_lines_cg"), src % "cg --suite-dims 1024x1024x32 --pc none")
 
     import threading
     th = None
@@ -1168,7 +1169,12 @@ def main():
         c5 = other.get("config5_share_cg_none_7pt_1024x1024x128", {})
         if "roofline_spmv" in c5:
             put_traffic(c5["roofline_spmv"], pmc.get("box"), [c5["roofline_spmv"]["kernel"].split(" ")[0]], c5["roofline_spmv"]["avg_launch_ms"], scale=128.0 / 32.0,
-                        note="counter pass on 1024 x 1024 x 32 (the same lines and kernel, a quarter of the planes), bytes scaled by 4")
+                        note="counter pass on the same solver on 1024 x 1024 x 32 (the same lines and kernels, a quarter of the planes), bytes scaled by 4; the product kernel carries the CG direction update as its prologue")
+            if pmc.get("box") and pmc["box"][0] and "cg_update_ms" in c5:
+                _, vu = pick_kernel(pmc["box"][0], "cg_fused_kernel")
+                if vu:
+                    c5["roofline_cg_update"] = {"bound": "hbm", "kernel": "cg_fused_kernel", "avg_launch_ms": c5["cg_update_ms"], "traffic": int(vu["bytes"] * 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac_counter_bytes": vu["bytes"] * 4 / (c5["cg_update_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         c27 = other.get("cg_jacobi_27pt_512_strong", {})
         if "roofline_spmv" in c27:
             put_traffic(c27["roofline_spmv"], pmc.get("spmv27"), [c27["roofline_spmv"]["kernel"].split(" ")[0]], c27["roofline_spmv"]["avg_launch_ms"], scale=8.0,

@@ -1891,7 +1891,7 @@ struct hipxMarchCG {
 // NT = 512 (round 4, lines of up to 1024 points -- BASELINE config 5's 1024 x 1024 planes): eight waves share three plane buffers of 4096 + 2 H
 // doubles (144 KiB: one workgroup per CU, the same two waves per SIMD); thread t works in the half t / 256 of the tile.
 template <int NE, int NQ, int NHALO, bool DOT, bool CG = false, int NT = 256>
-__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void spmv_march2_kernel(const hipxMarchPlan plan, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask, const int ntmpl,
+__global__ __launch_bounds__(NT, (NT == 256 || NQ <= 4) ? 2 : 1) void spmv_march2_kernel(const hipxMarchPlan plan, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask, const int ntmpl,
                                                               const double *__restrict__ x, double *__restrict__ yout, double *__restrict__ dotpart, const int tiles, const int pps,
                                                               const int nplanes, const int xcdmap, const hipxMarchCG cg = hipxMarchCG{})
 {
@@ -1908,7 +1908,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void spmv_march2_kernel(cons
   for (int k = t; k < ntmpl; k += NT) s_mask[k] = tmask[k];
   const int units = (int)gridDim.x;
   int       u     = (int)blockIdx.x;
-  if (xcdmap) u = ((int)blockIdx.x & 7) * (units >> 3) + ((int)blockIdx.x >> 3);  // an XCD's workgroups: neighbouring tiles (they share halos through its L2)
+  if (xcdmap & 1) u = ((int)blockIdx.x & 7) * (units >> 3) + ((int)blockIdx.x >> 3);  // an XCD's workgroups: neighbouring tiles (they share halos through its L2)
   const int tj = u % tiles, seg = u / tiles;
   const int i0 = tj * L;
   const int k0 = seg * pps, k1 = (k0 + pps < nplanes) ? k0 + pps : nplanes;
@@ -1980,7 +1980,13 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void spmv_march2_kernel(cons
 #pragma unroll
       for (int hh = 0; hh < NHALO; hh++) R.zh[hh] = *reinterpret_cast<const dbl2 *>(zs + off[hh]);
 #pragma unroll
-      for (int qq = 0; qq < NOWN; qq++) R.xo[qq] = *reinterpret_cast<const dbl2 *>(xs + 2 * (qq * NT + t));
+      for (int qq = 0; qq < NOWN; qq++) {
+        if (xcdmap & 4) {  // developer variant: x is read once and overwritten -- non-temporal
+          const double *q = xs + 2 * (qq * NT + t);
+          R.xo[qq].x      = __builtin_nontemporal_load(q);
+          R.xo[qq].y      = __builtin_nontemporal_load(q + 1);
+        } else R.xo[qq] = *reinterpret_cast<const dbl2 *>(xs + 2 * (qq * NT + t));
+      }
     }
   };
   // plane p from registers into the buffer at sbase; CG: as p_new, and for the planes this workgroup owns (k0 <= p < k1) p_new and x += a p go to memory
@@ -2021,8 +2027,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void spmv_march2_kernel(cons
           dbl2 xv = R.xo[qq];
           xv.x    = xv.x + cga * R.o[qq].x;
           xv.y    = xv.y + cga * R.o[qq].y;
+          if (xcdmap & 8) {  // developer variant: non-temporal stores of x (nobody reads it before the next iteration's own rows)
+            __builtin_nontemporal_store(xv.x, xd + 2 * (qq * NT + t));
+            __builtin_nontemporal_store(xv.y, xd + 2 * (qq * NT + t) + 1);
+          } else *reinterpret_cast<dbl2 *>(xd + 2 * (qq * NT + t)) = xv;
           *reinterpret_cast<dbl2 *>(pd + 2 * (qq * NT + t)) = pn[qq];
-          *reinterpret_cast<dbl2 *>(xd + 2 * (qq * NT + t)) = xv;
         }
       }
     }
@@ -2121,8 +2130,13 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void spmv_march2_kernel(cons
           }
         }
       }
-      yb[q0 * 256 + (rjb[j] >> 3)] = sum0;
-      yb[q1 * 256 + (rjb[j] >> 3)] = sum1;
+      if (xcdmap & 2) {  // developer variant (HIPX_MARCH_NT_STORE): non-temporal stores of y
+        __builtin_nontemporal_store(sum0, &yb[q0 * 256 + (rjb[j] >> 3)]);
+        __builtin_nontemporal_store(sum1, &yb[q1 * 256 + (rjb[j] >> 3)]);
+      } else {
+        yb[q0 * 256 + (rjb[j] >> 3)] = sum0;
+        yb[q1 * 256 + (rjb[j] >> 3)] = sum1;
+      }
       if (DOT) {  // (every row has its diagonal entry: checked with the masks)
         acc += xd0 * sum0;
         acc += xd1 * sum1;
@@ -2838,6 +2852,7 @@ int build_templates(hipxMat A)
             mp.full  = len0 == 32 ? 0xffffffffu : ((1u << len0) - 1u);
             A->march_ok = true;
             A->march_nt = big ? 512 : 256;
+            if (!big && mp.L == 2048 && getenv("HIPX_MARCH_NT512")) A->march_nt = 512;  // developer switch: 2048-row tiles by 512 threads (4 rows each), two workgroups per CU = 4 waves per SIMD
           }
         }
       }
@@ -2983,7 +2998,7 @@ static int march2_check(hipxMat A)
   const bool runs = mp.ne == 7 ? march2_runs_ok<7>(mp) : (mp.ne == 27 ? march2_runs_ok<27>(mp) : (mp.ne == 5 ? march2_runs_ok<5>(mp) : (mp.ne == 9 ? march2_runs_ok<9>(mp) : false)));
   if (!runs) return HIPX_SUCCESS;
   const int nq = mp.L / A->march_nt, nh = (mp.H + A->march_nt - 1) / A->march_nt;  // the instantiated shapes (launch_march2)
-  const bool shape = A->march_nt == 512 ? (mp.ne == 7 && nq == 8 && nh <= 2) : ((mp.ne == 7 && nq == 8 && nh <= 2) || (mp.ne == 27 && nq == 8 && (nh == 2 || nh == 3)) || (nq == 4 && nh == 1));
+  const bool shape = A->march_nt == 512 ? (mp.ne == 7 && ((nq == 8 && nh <= 2) || (nq == 4 && nh == 1))) : ((mp.ne == 7 && nq == 8 && nh <= 2) || (mp.ne == 27 && nq == 8 && (nh == 2 || nh == 3)) || (nq == 4 && nh == 1));
   if (!shape) return HIPX_SUCCESS;
   unsigned int *d_flag = nullptr, h_flag = 0;
   HIPX_HIP(hipMalloc((void **)&d_flag, sizeof(unsigned int)));
@@ -3003,7 +3018,7 @@ static int march2_check(hipxMat A)
 static void march_geometry(hipxMat A, int &tiles, int &nseg, int &pps, int &nplanes, int &units)
 {
   static const int     units_env0 = getenv("HIPX_TMPL_MARCH_UNITS") ? atoi(getenv("HIPX_TMPL_MARCH_UNITS")) : 0;
-  const int            units_env = units_env0 ? units_env0 : (A->march_nt == 512 ? 256 : 512);  // (one 512-thread workgroup per CU)
+  const int            units_env = units_env0 ? units_env0 : ((A->march_nt == 512 && A->march_plan.L == 4096) ? 256 : 512);  // (long lines: one 512-thread workgroup per CU)
   const hipxMarchPlan &mp = A->march_plan;
   const hipx_int       m  = A->nrows_c;
   tiles   = (mp.S + mp.L - 1) / mp.L;
@@ -3022,7 +3037,7 @@ static int launch_march2_inst(hipxMat A, const double *x, double *yout, double *
     HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_march2_kernel<NE, NQ, NHALO, DOT, CG, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, NT == 512 ? 152 * 1024 : 96 * 1024));
     attr = true;
   }
-  spmv_march2_kernel<NE, NQ, NHALO, DOT, CG, NT><<<(unsigned)units, NT, lds, rt().compute>>>(A->march_plan, A->d_tid, A->d_tmask, A->ntmpl, x, yout, dotpart, tiles, pps, nplanes, xm, cg);
+  spmv_march2_kernel<NE, NQ, NHALO, DOT, CG, NT><<<(unsigned)units, NT, lds, rt().compute>>>(A->march_plan, A->d_tid, A->d_tmask, A->ntmpl, x, yout, dotpart, tiles, pps, nplanes, xm | (getenv("HIPX_MARCH_NT_STORE") ? 2 : 0) | (getenv("HIPX_MARCH_NT_X") ? 4 * atoi(getenv("HIPX_MARCH_NT_X")) : 0), cg);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -3031,7 +3046,7 @@ static bool march2_cg_shape(hipxMat A)
 {
   const hipxMarchPlan &mp = A->march_plan;
   const int            nq = mp.L / A->march_nt, nh = (mp.H + A->march_nt - 1) / A->march_nt;
-  if (A->march_nt == 512) return mp.ne == 7 && nq == 8 && nh <= 2;
+  if (A->march_nt == 512) return mp.ne == 7 && ((nq == 8 && nh <= 2) || (nq == 4 && nh == 1));
   return (mp.ne == 7 && nq == 8 && nh <= 2) || ((mp.ne == 7 || mp.ne == 5 || mp.ne == 9) && nq == 4 && nh == 1);
 }
 template <bool DOT>
@@ -3042,6 +3057,7 @@ static int launch_march2_cg(hipxMat A, const double *x, double *yout, double *do
   if (A->march_nt == 512) {
     if (mp.ne == 7 && nq == 8 && nh == 1) return launch_march2_inst<7, 8, 1, DOT, true, 512>(A, x, yout, dotpart, units, tiles, pps, nplanes, xm, lds, cg);
     if (mp.ne == 7 && nq == 8 && nh == 2) return launch_march2_inst<7, 8, 2, DOT, true, 512>(A, x, yout, dotpart, units, tiles, pps, nplanes, xm, lds, cg);
+    if (mp.ne == 7 && nq == 4 && nh == 1) return launch_march2_inst<7, 4, 1, DOT, true, 512>(A, x, yout, dotpart, units, tiles, pps, nplanes, xm, lds, cg);
     return fail(HIPX_ERR_ARG, "march2 (CG prologue, 512 threads): shape not instantiated", __FILE__, __LINE__);
   }
 #define HIPX_M2(NE, NQ, NH) return launch_march2_inst<NE, NQ, NH, DOT, true>(A, x, yout, dotpart, units, tiles, pps, nplanes, xm, lds, cg)
@@ -3061,6 +3077,7 @@ static int launch_march2(hipxMat A, const double *x, double *yout, double *dotpa
   if (A->march_nt == 512) {
     if (mp.ne == 7 && nq == 8 && nh == 1) return launch_march2_inst<7, 8, 1, DOT, false, 512>(A, x, yout, dotpart, units, tiles, pps, nplanes, xm, lds);
     if (mp.ne == 7 && nq == 8 && nh == 2) return launch_march2_inst<7, 8, 2, DOT, false, 512>(A, x, yout, dotpart, units, tiles, pps, nplanes, xm, lds);
+    if (mp.ne == 7 && nq == 4 && nh == 1) return launch_march2_inst<7, 4, 1, DOT, false, 512>(A, x, yout, dotpart, units, tiles, pps, nplanes, xm, lds);
     return fail(HIPX_ERR_ARG, "march2 (512 threads): shape not instantiated", __FILE__, __LINE__);
   }
 #define HIPX_M2(NE, NQ, NH) return launch_march2_inst<NE, NQ, NH, DOT>(A, x, yout, dotpart, units, tiles, pps, nplanes, xm, lds)

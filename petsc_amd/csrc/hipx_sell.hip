@@ -7,6 +7,9 @@
 //            base[s * 16 + id] = first column of window id (<= 16 windows of 4096 columns per slice); matrices with a slice
 //            that needs more windows keep 32-bit columns col32[soff[s] + k * 64 + l]
 //   len[row] entries of the row (a slice is as wide as its longest row; the padding is never multiplied)
+//   Triple-run coding (round 4, "TRI": matrices whose EVERY row consists of runs of three consecutive columns -- the rows of a FEM matrix
+//   with three unknowns per node, dense 3 x 3 blocks: MatMult_SeqBAIJ_3's operands, baij2.c:334): ONE 16-bit code per run of three entries
+//   (the run's first column; the other two are + 1, + 2): 8 + 2/3 bytes per nonzero instead of 10 -- col16[coff[s] + (k / 12) * 256 + l * 4 + (k / 3) % 4].
 //
 // Why it exists next to the CSR kernels (hipx_mat.hip): those walk a row with ONE thread after staging it through LDS; with ~80
 // entries per row (FEM matrices: Flan_1565) only 25 of a workgroup's 256 threads work in that phase (0.59 of the HBM peak, DESIGN
@@ -33,7 +36,7 @@ constexpr int SELL_WLEN = 4096; // columns per window
 constexpr int64_t kSlack = 16 * 64;  // slots past the last slice the unrolled stream may read (never used)
 
 struct SellState {
-  bool               built = false, ok = false, packed = false;
+  bool               built = false, ok = false, packed = false, tri = false;
   unsigned long long vstate = 0;
   hipx_int           m = 0, n = 0, nslices = 0;
   int64_t            total = 0, ctotal = 0;  // value slots / code slots
@@ -75,8 +78,20 @@ __global__ __launch_bounds__(256) void sell_width_kernel(hipx_int m, const IT *_
   if ((threadIdx.x & 63) == 0 && (hipx_int)blockIdx.x * 256 + (threadIdx.x & ~63) < m) width[s] = w;
 }
 
-// one wave per slice: window keys of the slice (LDS set), then the lane copies its row into the slice
+// does every row consist of runs of three consecutive columns?  (flag <- 1 otherwise)
 template <typename IT>
+__global__ __launch_bounds__(256) void sell_tri_check_kernel(hipx_int m, const IT *__restrict__ ai, const hipx_int *__restrict__ aj, unsigned int *flag)
+{
+  const hipx_int row = (hipx_int)blockIdx.x * 256 + threadIdx.x;
+  if (row >= m) return;
+  const IT k0 = ai[row], k1 = ai[row + 1];
+  bool     bad = ((long long)(k1 - k0) % 3) != 0;
+  for (IT k = k0; k + 2 < k1 && !bad; k += 3) bad = aj[k + 1] != aj[k] + 1 || aj[k + 2] != aj[k] + 2;
+  if (bad) atomicOr(flag, 1u);
+}
+
+// one wave per slice: window keys of the slice (LDS set), then the lane copies its row into the slice.  TRI: one code per run of three entries.
+template <typename IT, bool TRI = false>
 __global__ __launch_bounds__(256) void sell_fill_kernel(hipx_int m, hipx_int nslices, const IT *__restrict__ ai, const hipx_int *__restrict__ aj, const double *__restrict__ aa,
                                                         const int64_t *__restrict__ soff, const int64_t *__restrict__ coff, unsigned short *__restrict__ lenout, double *__restrict__ val,
                                                         unsigned short *__restrict__ col16, hipx_int *__restrict__ base, hipx_int *__restrict__ col32, unsigned int *unpackable)
@@ -146,11 +161,22 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(hipx_int m, hipx_int nsl
 #pragma unroll
       for (int i = SELL_WMAX - 1; i >= 0; i--)
         if (sorted[wave][i] == key) id = i;
-      col16[co + (int64_t)(k >> 2) * 256 + lane * 4 + (k & 3)] = (unsigned short)((id << 12) | (c & (SELL_WLEN - 1)));
+      if (!TRI) col16[co + (int64_t)(k >> 2) * 256 + lane * 4 + (k & 3)] = (unsigned short)((id << 12) | (c & (SELL_WLEN - 1)));
+      else if (k % 3 == 0) {  // the run's first column (padding runs repeat the row's last run start: never multiplied)
+        const int      t  = k / 3;
+        const hipx_int c0 = on ? c : (len ? aj[k0 + len - 3] : 0);
+        int            i0 = 0;
+#pragma unroll
+        for (int i = SELL_WMAX - 1; i >= 0; i--)
+          if (sorted[wave][i] == (c0 >> 12)) i0 = i;
+        col16[co + (int64_t)(t >> 2) * 256 + lane * 4 + (t & 3)] = (unsigned short)((i0 << 12) | (c0 & (SELL_WLEN - 1)));
+      }
     } else if (col32) col32[so + (int64_t)k * SELL_C + lane] = c;
   }
-  if (pack)
-    for (int k = w; k < ((w + 3) & ~3); k++) col16[co + (int64_t)(k >> 2) * 256 + lane * 4 + (k & 3)] = 0;
+  if (pack) {
+    const int nc = TRI ? w / 3 : w;
+    for (int k = nc; k < ((nc + 3) & ~3); k++) col16[co + (int64_t)(k >> 2) * 256 + lane * 4 + (k & 3)] = 0;
+  }
 }
 
 // values only (same pattern, new numbers)
@@ -175,7 +201,7 @@ __global__ __launch_bounds__(256) void sell_values_kernel(hipx_int m, hipx_int n
 
 // MODE 0: y = A x; MODE 1: z = y + A x (the sum starts from y_i, aij.c:1648).  DOT: one partial of x . y per slice (fixed order).
 // U entries per pass: U value loads + U / 4 code loads in flight, then U gathers in flight.
-template <int MODE, bool DOT, bool PACK, int U>
+template <int MODE, bool DOT, bool PACK, int U, bool TRI = false>
 __global__ __launch_bounds__(256) void spmv_sell_kernel(hipx_int m, hipx_int nslices, hipx_int slices_per_xcd, const int64_t *__restrict__ soff, const int64_t *__restrict__ coff,
                                                         const unsigned short *__restrict__ lens, const double *__restrict__ val, const unsigned short *__restrict__ col16,
                                                         const hipx_int *__restrict__ base, const hipx_int *__restrict__ col32, const double *__restrict__ x, const double *yin, double *yout,
@@ -204,13 +230,27 @@ __global__ __launch_bounds__(256) void spmv_sell_kernel(hipx_int m, hipx_int nsl
     int    c[U];
 #pragma unroll
     for (int e = 0; e < U; e++) a[e] = vp[(int64_t)(k + e) * SELL_C];  // (the arrays carry U * 64 slots of slack: no bounds test on the stream)
-    if (PACK) {
+    if (PACK && TRI) {  // U = 12: four runs of three entries per 8-byte code load
+      static_assert(!TRI || U == 12, "triple-run coding walks 12 entries per pass");
+      const uint2    cw = *reinterpret_cast<const uint2 *>(cp + (int64_t)(k / 12) * 256);
+      const unsigned cc[4] = {cw.x & 0xffffu, cw.x >> 16, cw.y & 0xffffu, cw.y >> 16};
+#pragma unroll
+      for (int f = 0; f < 4; f++) {
+        const int c0 = __shfl(mybase, (int)(cc[f] >> 12), SELL_WMAX) + (int)(cc[f] & (SELL_WLEN - 1));
+        if (3 * f + 2 < U) {
+          c[3 * f]     = c0;
+          c[3 * f + 1] = c0 + 1;
+          c[3 * f + 2] = c0 + 2;
+        }
+      }
+    } else if (PACK) {
 #pragma unroll
       for (int e = 0; e < U; e += 4) {
         const uint2 cw = *reinterpret_cast<const uint2 *>(cp + (int64_t)((k + e) >> 2) * 256);
         const unsigned cc[4] = {cw.x & 0xffffu, cw.x >> 16, cw.y & 0xffffu, cw.y >> 16};
 #pragma unroll
-        for (int f = 0; f < 4; f++) c[e + f] = __shfl(mybase, (int)(cc[f] >> 12), SELL_WMAX) + (int)(cc[f] & (SELL_WLEN - 1));
+        for (int f = 0; f < 4; f++)
+          if (e + f < U) c[e + f] = __shfl(mybase, (int)(cc[f] >> 12), SELL_WMAX) + (int)(cc[f] & (SELL_WLEN - 1));
       }
     } else {
 #pragma unroll
@@ -308,10 +348,25 @@ int hipxSellEnsure_(hipxMat A, void **slot, int *ok, int *packed, double *pad_ra
     HIPX_HIP(hipStreamSynchronize(st));
     HIPX_LAUNCH_CHECK();
     (void)hipFree(d_w);
+    // triple-run coding: every row a sequence of runs of three consecutive columns (3 unknowns per node, dense 3 x 3 blocks)?
+    static const bool notri = getenv("HIPX_SELL_NOTRI") != nullptr;
+    S->tri = false;
+    if (!notri && !cnt[0] && nnz % 3 == 0) {
+      HIPX_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * 2, st));
+      if (is64) sell_tri_check_kernel<int64_t><<<g, 256, 0, st>>>(m, (const int64_t *)d_i, d_j, d_cnt);
+      else sell_tri_check_kernel<hipx_int><<<g, 256, 0, st>>>(m, (const hipx_int *)d_i, d_j, d_cnt);
+      unsigned int bad = 1;
+      HIPX_HIP(hipMemcpyAsync(&bad, d_cnt, sizeof(bad), hipMemcpyDeviceToHost, st));
+      HIPX_HIP(hipStreamSynchronize(st));
+      HIPX_LAUNCH_CHECK();
+      S->tri = bad == 0;
+      HIPX_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * 2, st));
+    }
     std::vector<int64_t> soff((size_t)S->nslices + 1, 0), coff((size_t)S->nslices + 1, 0);
     for (hipx_int s = 0; s < S->nslices; s++) {
+      const int ncodes = S->tri ? w[(size_t)s] / 3 : w[(size_t)s];
       soff[(size_t)s + 1] = soff[(size_t)s] + (int64_t)w[(size_t)s] * SELL_C;
-      coff[(size_t)s + 1] = coff[(size_t)s] + (int64_t)((w[(size_t)s] + 3) & ~3) * SELL_C;
+      coff[(size_t)s + 1] = coff[(size_t)s] + (int64_t)((ncodes + 3) & ~3) * SELL_C;
     }
     S->total     = soff[(size_t)S->nslices];
     S->ctotal    = coff[(size_t)S->nslices];
@@ -331,12 +386,16 @@ int hipxSellEnsure_(hipxMat A, void **slot, int *ok, int *packed, double *pad_ra
     HIPX_HIP(hipMemcpyAsync(S->d_soff, soff.data(), sizeof(int64_t) * soff.size(), hipMemcpyHostToDevice, st));
     HIPX_HIP(hipMemcpyAsync(S->d_coff, coff.data(), sizeof(int64_t) * coff.size(), hipMemcpyHostToDevice, st));
     const unsigned gs = (unsigned)((S->nslices + 3) / 4);
-    if (is64) sell_fill_kernel<int64_t><<<gs, 256, 0, st>>>(m, S->nslices, (const int64_t *)d_i, d_j, d_a, S->d_soff, S->d_coff, S->d_len, S->d_val, S->d_col16, S->d_base, nullptr, d_cnt + 1);
+    if (S->tri) {
+      if (is64) sell_fill_kernel<int64_t, true><<<gs, 256, 0, st>>>(m, S->nslices, (const int64_t *)d_i, d_j, d_a, S->d_soff, S->d_coff, S->d_len, S->d_val, S->d_col16, S->d_base, nullptr, d_cnt + 1);
+      else sell_fill_kernel<hipx_int, true><<<gs, 256, 0, st>>>(m, S->nslices, (const hipx_int *)d_i, d_j, d_a, S->d_soff, S->d_coff, S->d_len, S->d_val, S->d_col16, S->d_base, nullptr, d_cnt + 1);
+    } else if (is64) sell_fill_kernel<int64_t><<<gs, 256, 0, st>>>(m, S->nslices, (const int64_t *)d_i, d_j, d_a, S->d_soff, S->d_coff, S->d_len, S->d_val, S->d_col16, S->d_base, nullptr, d_cnt + 1);
     else sell_fill_kernel<hipx_int><<<gs, 256, 0, st>>>(m, S->nslices, (const hipx_int *)d_i, d_j, d_a, S->d_soff, S->d_coff, S->d_len, S->d_val, S->d_col16, S->d_base, nullptr, d_cnt + 1);
     HIPX_HIP(hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
     HIPX_HIP(hipStreamSynchronize(st));  // soff / coff (host vectors) are read by the copies above
     HIPX_LAUNCH_CHECK();
     S->packed = cnt[1] == 0;
+    if (!S->packed) S->tri = false;
     if (!S->packed) {  // some slice spans more than 16 column windows: 32-bit columns for the whole matrix
       (void)hipFree(S->d_col16);
       (void)hipFree(S->d_base);
@@ -370,6 +429,17 @@ int hipxSellLaunch_(void *p, int mode, int dot, const double *x, const double *y
   const hipx_int spx  = (((S->nslices + 7) / 8) + 3) / 4 * 4;  // slices per XCD, whole workgroups
   const unsigned grid = (unsigned)((spx / 4) * 8);
   static const int u = getenv("HIPX_SELL_U") ? atoi(getenv("HIPX_SELL_U")) : 8;
+  if (S->tri && S->packed) {  // one code per run of three entries, 12 entries per pass
+#define HIPX_SELL_TRI(MODE, DOT) \
+  spmv_sell_kernel<MODE, DOT, true, 12, true><<<grid, 256, 0, rt().compute>>>(S->m, S->nslices, spx, S->d_soff, S->d_coff, S->d_len, S->d_val, S->d_col16, S->d_base, S->d_col32, x, yin, yout, dotpart)
+    if (mode == 0 && !dot) HIPX_SELL_TRI(0, false);
+    else if (mode == 0) HIPX_SELL_TRI(0, true);
+    else if (!dot) HIPX_SELL_TRI(1, false);
+    else HIPX_SELL_TRI(1, true);
+#undef HIPX_SELL_TRI
+    HIPX_LAUNCH_CHECK();
+    return HIPX_SUCCESS;
+  }
 #define HIPX_SELL_GO(MODE, DOT, PACK, UU) \
   spmv_sell_kernel<MODE, DOT, PACK, UU><<<grid, 256, 0, rt().compute>>>(S->m, S->nslices, spx, S->d_soff, S->d_coff, S->d_len, S->d_val, S->d_col16, S->d_base, S->d_col32, x, yin, yout, dotpart)
 #define HIPX_SELL_U(MODE, DOT, PACK) \

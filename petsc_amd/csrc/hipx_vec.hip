@@ -667,8 +667,18 @@ __global__ __launch_bounds__(kRedThreads) void cg_fused_kernel(double *x, double
 #pragma unroll
         for (int u = 0; u < U; u++) {
           const hipx_int qu = base + u * (hipx_int)kRedThreads + threadIdx.x;
-          ra[u] = qu < n2 ? r2[qu] : z0;
-          wa[u] = qu < n2 ? w2[qu] : z0;
+          const hipx_int qc = qu < n2 ? qu : 0;
+          if (sweep >= 2) {  // developer variants: non-temporal loads of w (2) / of w and r (3)
+            const double wx = __builtin_nontemporal_load(&w[2 * qc]), wy = __builtin_nontemporal_load(&w[2 * qc + 1]);
+            wa[u] = {wx, wy};
+            if (sweep >= 3) {
+              const double rx = __builtin_nontemporal_load(&r[2 * qc]), ry = __builtin_nontemporal_load(&r[2 * qc + 1]);
+              ra[u] = {rx, ry};
+            } else ra[u] = r2[qc];
+          } else {
+            ra[u] = r2[qc];
+            wa[u] = w2[qc];
+          }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -798,7 +808,9 @@ static inline void cg_fused_go(unsigned g_in, hipStream_t st, double *x, double 
   static const bool u2 = getenv("HIPX_CG_FUSED_U2") != nullptr;
   // the launch-ahead configuration (no x update, constant diagonal) walks the vector with all workgroups together, round by round (measured
   // stand-alone on 256^3: 66.4 us = 6.06 TB/s against 72-74 us = 5.5 TB/s for one contiguous chunk per workgroup); HIPX_CG_FUSED_CHUNK keeps the chunks
-  static const int  sweep = getenv("HIPX_CG_FUSED_CHUNK") ? 0 : 1;
+  // (2: w -- written by the product kernel just before, read here once -- is loaded non-temporally: 88 -> 75 us inside the CG loop on 256^3, +5 % iterations/s;
+  //  HIPX_CG_FUSED_NT = 1 | 2 | 3 selects plain loads / w / w and r)
+  static const int  sweep = getenv("HIPX_CG_FUSED_CHUNK") ? 0 : (getenv("HIPX_CG_FUSED_NT") ? atoi(getenv("HIPX_CG_FUSED_NT")) : 2);
   static const int  gover = getenv("HIPX_CG_FUSED_BLOCKS") ? atoi(getenv("HIPX_CG_FUSED_BLOCKS")) : 0;  // developer switches (timing experiments)
   if (gover >= 1 && gover <= kRedBlocks) g = (unsigned)gover;
   if (rt().red_exact) {

@@ -352,6 +352,65 @@ def test_full_size_7pt_256_properties(hx):
     _lib.mat_destroy(A)
 
 
+@pytest.mark.parametrize("nb,ragged", [(2000, False), (4099, True), (12000, True)])
+def test_sell_triple_run_column_codes_for_three_unknowns_per_node(hx, nb, ragged):
+    """SELL-64 with ONE column code per run of three consecutive columns (round 4: FEM matrices with three unknowns per node -- dense 3 x 3 blocks,
+    MatMult_SeqBAIJ_3's operands): block rows of 14 or 20 ... 26 blocks (ragged: slices are padded with whole runs), all values distinct; y, y + A x and
+    the fused dot bit-identical to the CSR loop; the same matrix with one row's run broken (a column shifted by one block) keeps the plain codes --
+    same bits."""
+    from petsc_amd import _lib
+    rng = np.random.default_rng(41 + nb)
+    nblk = rng.integers(20, 27, nb) if ragged else np.full(nb, 14)  # (mildly ragged: the SELL copy is only kept below 25 % padding)
+    rows_i, cols, = [], []
+    ai = [0]
+    aj = []
+    for b in range(nb):
+        nbrs = np.unique(np.clip(b + rng.integers(-300, 300, nblk[b] * 2), 0, nb - 1))[:nblk[b]]
+        cc = (3 * nbrs[:, None] + np.arange(3)[None, :]).ravel()
+        for r in range(3):
+            aj.append(cc)
+            ai.append(ai[-1] + len(cc))
+    ai = np.array(ai, np.int32)
+    aj = np.concatenate(aj).astype(np.int32)
+    N = 3 * nb
+    aa = rng.standard_normal(len(aj))
+    x, y0 = rng.standard_normal(N), rng.standard_normal(N)
+    yr = orc.matmult(ai, aj, aa, x)
+    zr = np.zeros(N)
+    orc.lib().orc_MatMultAdd_SeqAIJ(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(y0), orc.P(zr))
+    X, Y, Y0 = _lib.DVec(N, x), _lib.DVec(N), _lib.DVec(N, y0)
+    for broken in (False, True):
+        aj2 = aj.copy()
+        if broken:  # row 7: its first run no longer consecutive (the columns stay sorted and distinct)
+            k0 = ai[7]
+            if aj2[k0] >= 3:
+                aj2[k0] -= 3
+            else:
+                continue
+            yr2 = orc.matmult(ai, aj2, aa, x)
+        else:
+            yr2 = yr
+        A = _lib.mat_create_csr(N, N, ai, aj2, aa)
+        _lib.chk(hx.hipxMatSetSpMVVariant(A, 28))
+        assert kernel_name(hx, A).startswith("spmv_sell_kernel "), kernel_name(hx, A)
+        Y.set(np.full(N, np.nan))
+        _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+        assert np.array_equal(Y.get(), yr2), broken
+        if not broken:
+            _lib.chk(hx.hipxMatMultAdd(A, X.ptr, Y0.ptr, Y.ptr))
+            assert np.array_equal(Y.get(), zr)
+            d = C.c_double()
+            _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(d)))
+            assert np.array_equal(Y.get(), yr) and abs(d.value - float(x @ yr)) <= 1e-12 * abs(float(np.abs(x) @ np.abs(yr)))
+            aa2 = rng.standard_normal(len(aj))
+            _lib.chk(hx.hipxMatUpdateValues(A, orc.P(aa2)))
+            _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+            assert np.array_equal(Y.get(), orc.matmult(ai, aj, aa2, x))
+        _lib.mat_destroy(A)
+    for v in (X, Y, Y0):
+        v.free()
+
+
 def test_sell_copy_selection_padding_limit_fused_dot_and_value_update(hx):
     """variant 28 (hipx_sell.hip): the SELL-64 copy is used when its padding stays below the limit, with 16-bit
     window-coded columns when every slice fits 16 windows of 4096 columns (else 32-bit columns); very ragged matrices keep the CSR
