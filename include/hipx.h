@@ -273,7 +273,7 @@ int hipxCommAllreduceSum(double *host_vals, int n);           /* n <= 64 doubles
    hipxRedEnd (the launch-ahead CG on several ranks) call it after each one. */
 int hipxCommCheckError(void);
 /* VecTDot_MPI / VecMDot_MPI (pvecimpl.h:97-111) in one stream-ordered chain: local dot kernel(s) -> ncclAllReduce on the
-   result words -> host notification; the host waits once, after the all-reduce.  nv <= 8.  Single rank: plain local dots. */
+   result words -> host notification; the host waits once, after the all-reduce.  nv <= 16.  Single rank: plain local dots. */
 int hipxVecMDotAllreduce(const double *x, hipx_int nv, const double *const *y, hipx_int n, double *results);
 /* hipxCGFusedUpdate with the two sums all-reduced over the communicator in the same chain (VecNorm_MPI + VecTDot_MPI of
    cg.c:309,344 in one 16-byte all-reduce) */

@@ -388,7 +388,7 @@ int hipxVecMDotAllreduce(const double *x, hipx_int nv, const double *const *y, h
 {
   HIPX_CHECK_INIT();
   Comm &c = cm();
-  HIPX_ARG(nv >= 1 && nv <= 8, "1 <= nv <= 8");
+  HIPX_ARG(nv >= 1 && nv <= 16, "1 <= nv <= 16");  // (16 sums = 32 pair words in exact mode: the staging line and the IPC slots hold 64)
   static const bool force = getenv("HIPX_FORCE_ALLREDUCE") != nullptr;  // test hook: run the chain on a 1-rank communicator too
   if (!c.active || (c.nranks == 1 && !force)) return hipxVecMDot(x, nv, y, n, results);
   const int slot = HIPX_MAX_RED_SLOTS - 2;  // reserved for this chain

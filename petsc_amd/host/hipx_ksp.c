@@ -786,14 +786,14 @@ cleanup:
 /* gmres.c:88-238 (cycle + solve), :298-345 (BuildSoln), :349-395 (UpdateHessenberg), borthog2.c:35-113,
    left preconditioning, KSPInitialResidual itres.c:35-75.  VV(0..max_k) live in one contiguous slab
    (cf. VecDuplicateVecs_Seq_GEMV bvec2.c:670) so MDot/MAXPY stream through consecutive memory. */
-/* VecMDot_MPI (pvecimpl.h:97-111): one all-reduce of nv sums; the device-staged reduction takes 64 doubles at a time, so
-   restarts of any length work (the reference has no limit on gmres_restart) */
-static int allreduce_chunked(double *vals, hipx_int n)
+/* VecMDot_MPI (pvecimpl.h:97-111): all-reduces of <= 16 sums, so restarts of any length work (the reference has no limit on gmres_restart) */
+/* VecMDot on one rank or several.  Several: 16 vectors per chain (local kernel -> all-reduce on the stream -> one host wait) -- in the exact reduction
+   mode the ranks' sums travel as unrounded (hi, lo) pairs and are rounded once after the fold over ranks (round 4), so the orthogonalisation
+   coefficients are the correctly rounded global dot products whatever the cut into ranks */
+static int mdot_ranks(HipxMat *A, const double *x, hipx_int nv, const double *const *y, hipx_int n, double *out)
 {
-  for (hipx_int k = 0; k < n; k += 64) {
-    int ierr = hipxCommAllreduceSum(vals + k, (int)((n - k) < 64 ? (n - k) : 64));
-    if (ierr) return ierr;
-  }
+  if (A->nranks <= 1) return hipxVecMDot(x, nv, y, n, out);
+  for (hipx_int k = 0; k < nv; k += 16) CHK(hipxVecMDotAllreduce(x, (nv - k) < 16 ? (nv - k) : 16, y + k, n, out + k));
   return 0;
 }
 
@@ -872,8 +872,7 @@ int HipxKSPSolve_GMRES(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, do
         double *h      = HH(0, it);
         int     refine = (ksp->gmres_cgs_refine == 2);
         for (hipx_int j = 0; j <= it; j++) h[j] = 0.0;
-        GCHK(hipxVecMDot(VV[it + 1], it + 1, (const double *const *)VV, n, lhh));
-        if (A->nranks > 1) GCHK(allreduce_chunked(lhh, it + 1));
+        GCHK(mdot_ranks(A, VV[it + 1], it + 1, (const double *const *)VV, n, lhh));
         for (hipx_int j = 0; j <= it; j++) {
           if (isnan(lhh[j]) || isinf(lhh[j])) ksp->reason = KSP_DIVERGED_NANORINF;
           lhh[j] = -lhh[j];
@@ -889,8 +888,7 @@ int HipxKSPSolve_GMRES(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, do
           if (wnrm < hnrm) refine = 1;
         }
         if (refine) {
-          GCHK(hipxVecMDot(VV[it + 1], it + 1, (const double *const *)VV, n, lhh));
-          if (A->nranks > 1) GCHK(allreduce_chunked(lhh, it + 1));
+          GCHK(mdot_ranks(A, VV[it + 1], it + 1, (const double *const *)VV, n, lhh));
           for (hipx_int j = 0; j <= it; j++) lhh[j] = -lhh[j];
           GCHK(hipxVecMAXPY(VV[it + 1], it + 1, lhh, (const double *const *)VV, n));
           for (hipx_int j = 0; j <= it; j++) h[j] -= lhh[j];

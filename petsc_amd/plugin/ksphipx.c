@@ -11,6 +11,7 @@
  * AYPX+deferred AXPY = 3 kernels + 1 partial fold instead of 8 launches and 3 blocking reductions.
  */
 #include "hipxplugin.h"
+#include <stdlib.h>
 #include <petsc/private/kspimpl.h>
 #include <../src/ksp/ksp/impls/cg/cgimpl.h>
 #include "hipx_ksp.h"
@@ -111,6 +112,40 @@ static PetscErrorCode KSPSolve_CGHIPX(KSP ksp)
   PetscCall(VecHIPXGetDeviceReadWrite(ksp->vec_sol, &dx, &tx));
 
   ksp->its = 0;
+  /* Round 4: when nothing outside wants to look between iterations -- no monitors, the default convergence test with its default context
+     (KSPConvergedDefault, iterativ.c:1490-1585: mirrored statement by statement in the host layer), no lag / check-norm settings -- the host layer runs
+     the whole loop itself: launch-ahead (iteration i + 1 enqueued before the host has seen iteration i's sums) and the direction update as the product's
+     prologue, the forms `bench.py` times.  The residual history, its, rnorm, reason, rnorm0 and ttol are handed to the KSP afterwards exactly as the
+     stepwise loop below leaves them.  Anything else (-ksp_monitor, KSPSetConvergenceTest, ...) takes the stepwise loop. */
+  {
+    PetscBool selfdriven = PETSC_FALSE;
+    if (!ksp->numbermonitors && ksp->converged == KSPConvergedDefault && ksp->cnvP && !ksp->chknorm && !ksp->lagnorm && !getenv("HIPX_CGHIPX_STEPWISE")) {
+      KSPConvergedDefaultCtx *cctx = (KSPConvergedDefaultCtx *)ksp->cnvP;
+      if (!cctx->initialrtol && !cctx->mininitialrtol && !cctx->convmaxits) selfdriven = PETSC_TRUE;
+    }
+    if (selfdriven) {
+      double  *hist = NULL;
+      hipx_int hl   = (hipx_int)((ksp->max_it < 1000000 ? ksp->max_it : 1000000) + 2);
+      PetscCall(PetscMalloc1((size_t)hl, &hist));
+      k.external_test = 0;
+      k.defer_flush   = 0;
+      k.rtol          = ksp->rtol;
+      k.abstol        = ksp->abstol;
+      k.divtol        = ksp->divtol;
+      k.min_it        = (hipx_int)ksp->min_it;
+      k.history       = hist;
+      k.hist_len      = hl;
+      PetscCallHIPX(HipxKSPSolve_CG(&k, &M, &hpc, db, dx));
+      for (hipx_int e = 0; e < k.hist_n && e < hl; e++) PetscCall(KSPLogResidualHistory(ksp, hist[e]));
+      PetscCall(PetscFree(hist));
+      ksp->its    = (PetscInt)k.its;
+      ksp->rnorm  = k.rnorm;
+      ksp->rnorm0 = k.rnorm0;
+      ksp->ttol   = k.ttol;
+      ksp->reason = (KSPConvergedReason)k.reason;
+      goto done;
+    }
+  }
   PetscCallHIPX(HipxKSPCGBegin(&k, &M, &hpc, db, dx)); /* cg.c:134-217 */
   if (k.reason) ksp->reason = (KSPConvergedReason)k.reason; /* KSPCheckNorm: NaN/Inf */
   else {
@@ -133,6 +168,7 @@ static PetscErrorCode KSPSolve_CGHIPX(KSP ksp)
     if (!ksp->reason && k.reason) ksp->reason = (KSPConvergedReason)k.reason;
   }
   PetscCallHIPX(HipxKSPCGFlush(&k, &M, dx));
+done:
   PetscCallHIPX(HipxKSPDestroyWork(&k));
   PetscCallHIPX(HipxPCDestroy(&hpc));
   if (lvecv) PetscCall(VecHIPXRestoreDeviceWrite(lvecv, &dlv, &tlv));

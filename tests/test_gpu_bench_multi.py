@@ -85,3 +85,16 @@ def test_launch_ahead_cg_on_two_ranks_equals_host_synchronised_loop():
     assert a["parity_gate"]["max_rel_diff_exact_reductions"] == b["parity_gate"]["max_rel_diff_exact_reductions"]
     c = out["exact", "3"]  # another recurrence: close to, not equal to, the standard form
     assert abs(c["config"]["residual_norm_after"] - b["config"]["residual_norm_after"]) <= 1e-9 * b["config"]["residual_norm_after"]
+
+
+def test_gmres_sor_on_two_and_four_ranks_follows_the_exact_yardstick_at_1e12():
+    """Config 3's solver on 2 and 4 ranks sharing the GPU (IPC transport): in the exact reduction mode -- the ranks' sums folded as unrounded
+    pairs, GMRES's MDot included (round 4) -- the first 35 residual norms sit within 1e-12 of the committed exact-reduction history of the same
+    per-rank local sweeps (tests/golden/exact_histories.json gmres_sor_27pt_128_np{2,4}); bench.py gates GMRES legs in that mode."""
+    for n in (2, 4):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--ksp", "gmres", "--pc", "sor", "--stencil", "27", "--grid", "128", "--steps", "40", "--warmup", "3", "--quick"],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=clean_env(), cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-3000:]
+        d = last_json(r.stdout)
+        g = d["parity_gate"]
+        assert d["n_gpus"] == n and g["pass"] is True and g["gated_reduction_mode"] == "exact" and g["max_rel_diff"] <= 1e-12, g
