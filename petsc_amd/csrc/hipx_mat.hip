@@ -3047,6 +3047,10 @@ static bool march2_cg_shape(hipxMat A)
   const hipxMarchPlan &mp = A->march_plan;
   const int            nq = mp.L / A->march_nt, nh = (mp.H + A->march_nt - 1) / A->march_nt;
   if (A->march_nt == 512) return mp.ne == 7 && ((nq == 8 && nh <= 2) || (nq == 4 && nh == 1));
+  // the 27-entry kernels too (242-252 registers, no spills): their product is VALU-bound, so the prologue's streams ride along for free --
+  // 27-pt 512^3 CG+Jacobi 450 -> 556 it/s, 27-pt 256^3 3.55-3.62k -> 4.27k (same box; HIPX_MARCH_NOCG27 keeps the direction kernel)
+  static const bool nocg27 = getenv("HIPX_MARCH_NOCG27") != nullptr;
+  if (!nocg27 && mp.ne == 27 && nq == 8 && (nh == 2 || nh == 3)) return true;
   return (mp.ne == 7 && nq == 8 && nh <= 2) || ((mp.ne == 7 || mp.ne == 5 || mp.ne == 9) && nq == 4 && nh == 1);
 }
 template <bool DOT>
@@ -3066,6 +3070,8 @@ static int launch_march2_cg(hipxMat A, const double *x, double *yout, double *do
   if (mp.ne == 7 && nq == 4 && nh == 1) HIPX_M2(7, 4, 1);
   if (mp.ne == 5 && nq == 4 && nh == 1) HIPX_M2(5, 4, 1);
   if (mp.ne == 9 && nq == 4 && nh == 1) HIPX_M2(9, 4, 1);
+  if (mp.ne == 27 && nq == 8 && nh == 2) HIPX_M2(27, 8, 2);
+  if (mp.ne == 27 && nq == 8 && nh == 3) HIPX_M2(27, 8, 3);
 #undef HIPX_M2
   return fail(HIPX_ERR_ARG, "march2 (CG prologue): shape not instantiated", __FILE__, __LINE__);
 }

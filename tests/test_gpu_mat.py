@@ -734,7 +734,8 @@ def test_march2_refuses_matrices_whose_template_ids_are_not_plane_periodic(hx):
     _lib.mat_destroy(A)
 
 
-@pytest.mark.parametrize("kind,n,m,dconst", [("7pt", 64, None, 1.0 / 6.0), ("7pt", 96, None, 1.0), ("7pt", 192, None, 0.37), ("5pt", 1024, 48, 0.25), ("7pt_box", (1024, 1024, 5), None, 1.0)])
+@pytest.mark.parametrize("kind,n,m,dconst", [("7pt", 64, None, 1.0 / 6.0), ("7pt", 96, None, 1.0), ("7pt", 192, None, 0.37), ("5pt", 1024, 48, 0.25), ("7pt_box", (1024, 1024, 5), None, 1.0),
+                                             ("27pt", 256, None, 1.0 / 26.0)])  # (the 27-entry kernels carry the prologue from 256-point lines on)
 def test_cg_direction_update_as_the_products_prologue_bit_identical(hx, kind, n, m, dconst):
     """hipxMatMultCGDirectionDotBegin (p_new = r * dconst + b p, x += a p, w = A p_new, p_new . w in one kernel) against the separate kernels it
     replaces (hipxCGAypxAxpyR, hipxMatMultDot): p_new, x, w bit-identical, the dot the same double (same partials); host scalars and
