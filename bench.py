@@ -769,9 +769,18 @@ def leg_matrix_solver(cfg, steps, warmup, sync, torch, best_ranks=None, parity_i
            "roofline_spmv": {"bound": "hbm", "avg_launch_ms": r["spmv_ms"], "launches": r["launches"], "algorithmic_bytes": byts,
                              "achieved": byts / (r["spmv_ms"] * 1e-3) / 1e9 if r["spmv_ms"] > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": byts / (r["spmv_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if r["spmv_ms"] > 0 else 0.0, "traffic": None}}
+    if cfg.pc == "sor":  # PCSOR on a matrix without row templates: the dependency-driven (level-ordered) schedule, hipx_sor.hip
+        mode = C.c_int(-1)
+        P.lib.chk(P.hx.hipxMatGetSORMode(P.M.A, C.byref(mode)))
+        out["sor_schedule"] = {2: "strand", 1: "dependency-driven", 0: "levels"}.get(mode.value, str(mode.value))
+        if "sor_ms" in r["sections"]:
+            ssor = 2 * 12 * P.nnz_local + 40 * P.m  # two passes over a, j + 5 vector passes
+            out["roofline_sor"] = {"bound": "hbm", "kernel": "one PCApply_SOR = symmetric sweep (%s schedule)" % out["sor_schedule"], "avg_call_ms": r["sections"]["sor_ms"],
+                                   "calls": r["sections"].get("sor_calls"), "algorithmic_bytes": ssor, "effective_gbps": ssor / (r["sections"]["sor_ms"] * 1e-3) / 1e9,
+                                   "frac": ssor / (r["sections"]["sor_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
     P.destroy()
     if best_ranks and cpu_its and cfg.binfile:
-        out["cpu_baseline"] = cpu_baseline_for(cfg, best_ranks, cpu_its, "KSPCG + PCJACOBI, MatLoad of the same file")
+        out["cpu_baseline"] = cpu_baseline_for(cfg, best_ranks, cpu_its, "KSPCG + %s, MatLoad of the same file" % cfg.pcname())
     if own_tmp and not tmpdir:
         shutil.rmtree(own_tmp, ignore_errors=True)
         cfg.binfile = None
@@ -1047,6 +1056,15 @@ def main():
             other["config4_solver_cg_jacobi"] = leg_matrix_solver(cfg4, 100, 10, sync, torch, best_ranks=None, tmpdir=tmp4)
         except Exception as e:  # noqa: BLE001
             other["config4_solver_cg_jacobi"] = {"error": str(e)[:400]}
+        cfg4s = None
+        try:  # the same matrix with PCSOR (the reference's default symmetric sweep): what an UNSTRUCTURED matrix gets from hipx_sor.hip
+            cfg4s = config4_cfg()
+            cfg4s.pc = "sor"
+            if cfg4 is not None and cfg4.binfile:
+                cfg4s.binfile = cfg4.binfile
+            other["config4_solver_cg_sor"] = leg_matrix_solver(cfg4s, 30, 3, sync, torch, best_ranks=None, parity_its=5, tmpdir=tmp4)
+        except Exception as e:  # noqa: BLE001
+            other["config4_solver_cg_sor"] = {"error": str(e)[:400]}
         try:
             other["config3_sor_arbitrary_values_27pt_256"] = leg_sor_arbitrary_values(hx, _lib, ks)
         except Exception as e:  # noqa: BLE001
@@ -1116,6 +1134,8 @@ def main():
                     other[name]["cpu_baseline"] = cpu_baseline_for(cfg, best_ranks, cpu_its, "KSP%s + %s" % (cfg.ksp.upper(), cfg.pcname()))
             if not args.no_other and cfg4 is not None and cfg4.binfile and "error" not in other.get("config4_solver_cg_jacobi", {"error": 1}):
                 other["config4_solver_cg_jacobi"]["cpu_baseline"] = cpu_baseline_for(cfg4, best_ranks, 10, "KSPCG + PCJACOBI, MatLoad of the same file")
+            if not args.no_other and cfg4s is not None and cfg4s.binfile and "error" not in other.get("config4_solver_cg_sor", {"error": 1}):
+                other["config4_solver_cg_sor"]["cpu_baseline"] = cpu_baseline_for(cfg4s, best_ranks, 5, "KSPCG + PCSOR, MatLoad of the same file")
     else:
         out["cpu_baseline"] = None
     if not args.no_other:

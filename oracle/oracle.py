@@ -15,7 +15,7 @@ class OrcKSP(C.Structure):
                 ("sor_lits", C.c_int), ("normtype", C.c_int), ("rtol", C.c_double), ("abstol", C.c_double), ("divtol", C.c_double),
                 ("max_it", C.c_int), ("min_it", C.c_int), ("gmres_restart", C.c_int), ("gmres_haptol", C.c_double), ("gmres_cgs_refine", C.c_int),
                 ("guess_nonzero", C.c_int), ("its", C.c_int), ("reason", C.c_int), ("rnorm", C.c_double), ("history", C.c_void_p),
-                ("hist_len", C.c_int), ("hist_n", C.c_int)]
+                ("hist_len", C.c_int), ("hist_n", C.c_int), ("no_inode", C.c_int)]
 
 
 _lib = None

@@ -325,6 +325,279 @@ done:
   return zeropivot;
 }
 
+/* ============================ inodes (Mat_SeqAIJ with identical consecutive rows) ============== */
+
+/* MatSeqAIJCheckInode (inode.c:3920-3985): consecutive rows with the same column list form a node of at most `limit` rows
+   (-mat_inode_limit, default 5).  ns[0..node_count] receives the row offsets of the nodes (size_csr).  Returns node_count, or 0
+   when the reference does NOT use the inode routines: no rows, or more than 0.8 m nodes (inode.c:3962). */
+OInt orc_MatSeqAIJCheckInode(OInt m, const OInt *ai, const OInt *aj, OInt limit, OInt *ns)
+{
+  OInt i = 0, node_count = 0;
+  ns[0] = 0;
+  while (i < m) {
+    const OInt  nzx = ai[i + 1] - ai[i];
+    const OInt *idx = aj + ai[i];
+    OInt        j, blk = 1;
+    for (j = i + 1; j < m && blk < limit; ++j, ++blk) {
+      if (ai[j + 1] - ai[j] != nzx) break;
+      if (nzx && memcmp(idx, aj + ai[j], (size_t)nzx * sizeof(OInt))) break;
+    }
+    ns[node_count + 1] = ns[node_count] + blk;
+    node_count++;
+    i = j;
+  }
+  if (!m || (double)node_count > .8 * (double)m) return 0;
+  return node_count;
+}
+
+/* PetscKernel_A_gets_inverse_A_2 ... _5 (src/mat/impls/baij/seq/dgefa2.c:14, dgefa3.c:14, dgefa4.c, dgefa5.c:14): LINPACK dgefa
+   (LU with partial pivoting, the first largest entry of the column wins) followed by dgedi (inverse(U), then inverse(U) * inverse(L)
+   and the column interchanges), column-major, in place; every update is `y += t * x` with product and sum rounded separately.  Written
+   once for any n <= 5 (shift = 0: what MatInvertDiagonalForSOR_SeqAIJ_Inode passes, inode.c:2425).  Returns 1 on a zero pivot (the
+   reference flags MAT_FACTOR_NUMERIC_ZEROPIVOT and goes on). */
+int orc_inode_invert_block(OScalar *a, int n)
+{
+  int     ipvt[5], zero = 0;
+  OScalar work[5];
+#define A_(i, j) a[(i) + (j) * n]
+  if (n == 1) { /* inode.c:2457-2467 */
+    if (fabs(a[0]) < 100. * 2.220446049250313e-16) zero = 1;
+    a[0] = 1.0 / a[0];
+    return zero;
+  }
+  for (int k = 0; k < n - 1; k++) {
+    int     l   = k;
+    OScalar max = fabs(A_(k, k));
+    for (int i = k + 1; i < n; i++)
+      if (fabs(A_(i, k)) > max) {
+        max = fabs(A_(i, k));
+        l   = i;
+      }
+    ipvt[k] = l;
+    if (A_(l, k) == 0.0) zero = 1;
+    if (l != k) {
+      const OScalar t = A_(l, k);
+      A_(l, k)        = A_(k, k);
+      A_(k, k)        = t;
+    }
+    {
+      const OScalar t = -1. / A_(k, k);
+      for (int i = k + 1; i < n; i++) A_(i, k) *= t;
+    }
+    for (int j = k + 1; j < n; j++) {
+      const OScalar t = A_(l, j);
+      if (l != k) {
+        A_(l, j) = A_(k, j);
+        A_(k, j) = t;
+      }
+      for (int i = k + 1; i < n; i++) A_(i, j) += t * A_(i, k);
+    }
+  }
+  ipvt[n - 1] = n - 1;
+  if (A_(n - 1, n - 1) == 0.0) zero = 1;
+  for (int k = 0; k < n; k++) { /* inverse(U) */
+    A_(k, k) = 1.0 / A_(k, k);
+    {
+      const OScalar t = -A_(k, k);
+      for (int i = 0; i < k; i++) A_(i, k) *= t;
+    }
+    for (int j = k + 1; j < n; j++) {
+      const OScalar t = A_(k, j);
+      A_(k, j)        = 0.0;
+      for (int i = 0; i <= k; i++) A_(i, j) += t * A_(i, k);
+    }
+  }
+  for (int k = n - 2; k >= 0; k--) { /* inverse(U) * inverse(L) */
+    for (int i = k + 1; i < n; i++) {
+      work[i]  = A_(i, k);
+      A_(i, k) = 0.0;
+    }
+    for (int j = k + 1; j < n; j++) {
+      const OScalar t = work[j];
+      for (int i = 0; i < n; i++) A_(i, k) += t * A_(i, j);
+    }
+    if (ipvt[k] != k)
+      for (int i = 0; i < n; i++) {
+        const OScalar t  = A_(i, k);
+        A_(i, k)         = A_(i, ipvt[k]);
+        A_(i, ipvt[k])   = t;
+      }
+  }
+#undef A_
+  return zero;
+}
+
+/* the sums of one node over a segment of its rows' entries (inode.c:2539-2552 and every loop like it): the entries are taken in PAIRS,
+   `sum_r -= v_r[k] * x[idx[k]] + v_r[k+1] * x[idx[k+1]]` (two products, their sum, one subtraction), a last odd entry on its own */
+static void inode_minus(int ns, const OScalar *const *v, OInt off, const OInt *idx, OInt sz, const OScalar *src, OScalar *sum)
+{
+  OInt n;
+  for (n = 0; n < sz - 1; n += 2) {
+    const OScalar t0 = src[idx[n]], t1 = src[idx[n + 1]];
+    for (int r = 0; r < ns; r++) sum[r] -= v[r][off + n] * t0 + v[r][off + n + 1] * t1;
+  }
+  if (n == sz - 1) {
+    const OScalar t0 = src[idx[n]];
+    for (int r = 0; r < ns; r++) sum[r] -= v[r][off + n] * t0;
+  }
+}
+
+/* out_r = sum_c s_c * ibd[c * ns + r], c ascending, left to right (inode.c:2612-2614 forward, 2798-2800 backward: the same
+   expression written from the last row up) */
+static void inode_apply(int ns, const OScalar *ibd, const OScalar *s, OScalar *out)
+{
+  for (int r = 0; r < ns; r++) {
+    OScalar acc = s[0] * ibd[r];
+    for (int c = 1; c < ns; c++) acc = acc + s[c] * ibd[c * ns + r];
+    out[r] = acc;
+  }
+}
+
+/* MatInvertDiagonalForSOR_SeqAIJ_Inode (inode.c:2420-2492) + MatSOR_SeqAIJ_Inode (inode.c:2494-3810), what MatSOR_SeqAIJ runs
+   when the matrix has inodes and omega == 1, fshift == 0 (aij.c:1852): block Gauss-Seidel with the nodes' diagonal blocks.  `lits`
+   is not used (the inode routine never multiplies its by lits).  Returns 0, 1 on a zero pivot, 2 for what the reference's routine
+   does not do (omega != 1, fshift != 0: aij.c:1852 sends those to the point routine -- call orc_MatSOR_SeqAIJ; SOR_APPLY_UPPER). */
+int orc_MatSOR_SeqAIJ_Inode(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, OInt node_count, const OInt *ns, const OScalar *b, OScalar omega,
+                            int flag, OScalar fshift, OInt its, OInt lits, OScalar *x)
+{
+  (void)lits;
+  if (omega != 1.0 || fshift != 0.0 || (flag & ORC_SOR_APPLY_UPPER) || (flag & ORC_SOR_APPLY_LOWER)) return 2;
+  OInt    *diag = (OInt *)malloc((size_t)(m + 1) * sizeof(OInt));
+  OScalar *t    = (OScalar *)malloc((size_t)(m + 1) * sizeof(OScalar));
+  size_t   cnt  = 0;
+  int      zero = 0;
+  for (OInt i = 0; i < node_count; i++) cnt += (size_t)(ns[i + 1] - ns[i]) * (size_t)(ns[i + 1] - ns[i]);
+  OScalar *ibdiag = (OScalar *)malloc((cnt + 1) * sizeof(OScalar)), *bdiag = (OScalar *)malloc((cnt + 1) * sizeof(OScalar));
+  size_t  *boff   = (size_t *)malloc((size_t)(node_count + 1) * sizeof(size_t));
+  orc_MatGetDiagonalMarkers_SeqAIJ(m, ai, aj, diag);
+  cnt = 0;
+  for (OInt i = 0; i < node_count; i++) { /* inode.c:2449-2489 */
+    const OInt row = ns[i], sz = ns[i + 1] - ns[i];
+    boff[i] = cnt;
+    for (OInt j = 0; j < sz; j++)
+      for (OInt k = 0; k < sz; k++) bdiag[cnt + (size_t)(k * sz + j)] = aa[diag[row + j] - j + k];
+    memcpy(ibdiag + cnt, bdiag + cnt, (size_t)(sz * sz) * sizeof(OScalar));
+    zero |= orc_inode_invert_block(ibdiag + cnt, (int)sz);
+    cnt += (size_t)(sz * sz);
+  }
+  const int fwd = (flag & ORC_SOR_FORWARD_SWEEP) || (flag & ORC_SOR_LOCAL_FORWARD_SWEEP);
+  const int bwd = (flag & ORC_SOR_BACKWARD_SWEEP) || (flag & ORC_SOR_LOCAL_BACKWARD_SWEEP);
+  const OScalar *v[5], *xb;
+  OScalar        sum[5], out[5];
+#define NODE(i) \
+  const OInt row = ns[i]; \
+  const int  sz  = (int)(ns[(i) + 1] - ns[i]); \
+  const OInt szl = diag[row] - ai[row], len = ai[row + 1] - ai[row], szu = len - szl - sz; \
+  const OInt *idx = aj + ai[row]; \
+  for (int r = 0; r < sz; r++) v[r] = aa + ai[row + r]; \
+  (void)szl; (void)szu; (void)idx
+  if (flag & ORC_SOR_ZERO_INITIAL_GUESS) {
+    if (fwd) { /* inode.c:2527-2712 */
+      for (OInt i = 0; i < node_count; i++) {
+        NODE(i);
+        for (int r = 0; r < sz; r++) sum[r] = b[row + r];
+        inode_minus(sz, v, 0, idx, szl, x, sum);
+        for (int r = 0; r < sz; r++) t[row + r] = sum[r];
+        inode_apply(sz, ibdiag + boff[i], sum, out);
+        for (int r = 0; r < sz; r++) x[row + r] = out[r];
+      }
+      xb = t;
+    } else xb = b;
+    if (bwd) { /* inode.c:2714-2888 */
+      for (OInt i = node_count - 1; i >= 0; i--) {
+        NODE(i);
+        for (int r = 0; r < sz; r++) sum[r] = xb[row + r];
+        inode_minus(sz, v, szl + sz, idx + szl + sz, szu, x, sum);
+        inode_apply(sz, ibdiag + boff[i], sum, out);
+        for (int r = 0; r < sz; r++) x[row + r] = out[r];
+      }
+    }
+    its--;
+  }
+  while (its-- > 0) { /* inode.c:2891-3374 */
+    if (fwd) {
+      for (OInt i = 0; i < node_count; i++) {
+        NODE(i);
+        for (int r = 0; r < sz; r++) sum[r] = b[row + r];
+        inode_minus(sz, v, 0, idx, szl, x, sum);
+        for (int r = 0; r < sz; r++) t[row + r] = sum[r];
+        inode_minus(sz, v, szl + sz, idx + szl + sz, szu, x, sum);
+        inode_apply(sz, ibdiag + boff[i], sum, out);
+        for (int r = 0; r < sz; r++) x[row + r] = out[r];
+      }
+      xb = t;
+    } else xb = b;
+    if (bwd) {
+      for (OInt i = node_count - 1; i >= 0; i--) {
+        NODE(i);
+        for (int r = 0; r < sz; r++) sum[r] = xb[row + r];
+        if (xb == b) { /* the whole rows, the diagonal block with them: x += D^-1 (b - A x) (inode.c:3219-3237, 3311-3339) */
+          inode_minus(sz, v, 0, idx, len, x, sum);
+          inode_apply(sz, ibdiag + boff[i], sum, out);
+          for (int r = 0; r < sz; r++) x[row + r] += out[r];
+        } else {
+          inode_minus(sz, v, szl + sz, idx + szl + sz, szu, x, sum);
+          inode_apply(sz, ibdiag + boff[i], sum, out);
+          for (int r = 0; r < sz; r++) x[row + r] = out[r];
+        }
+      }
+    }
+  }
+  if (flag & ORC_SOR_EISENSTAT) { /* inode.c:3375-3806 */
+    for (OInt i = node_count - 1; i >= 0; i--) { /* x = (U + D)^-1 b */
+      NODE(i);
+      for (int r = 0; r < sz; r++) sum[r] = b[row + r];
+      inode_minus(sz, v, szl + sz, idx + szl + sz, szu, x, sum);
+      inode_apply(sz, ibdiag + boff[i], sum, out);
+      for (int r = 0; r < sz; r++) x[row + r] = out[r];
+    }
+    for (OInt i = 0; i < node_count; i++) { /* t = b - D x (inode.c:3559-3628) */
+      const OInt row = ns[i];
+      const int  sz  = (int)(ns[i + 1] - ns[i]);
+      if (sz == 1) t[row] = b[row] - bdiag[boff[i]] * x[row];
+      else {
+        inode_apply(sz, bdiag + boff[i], x + row, out);
+        for (int r = 0; r < sz; r++) t[row + r] = b[row + r] - out[r];
+      }
+    }
+    for (OInt i = 0; i < node_count; i++) { /* t = (L + D)^-1 t, x += t (inode.c:3634-3804) */
+      NODE(i);
+      for (int r = 0; r < sz; r++) sum[r] = t[row + r];
+      inode_minus(sz, v, 0, idx, szl, t, sum);
+      inode_apply(sz, ibdiag + boff[i], sum, out);
+      for (int r = 0; r < sz; r++) {
+        t[row + r] = out[r];
+        x[row + r] += out[r];
+      }
+    }
+  }
+#undef NODE
+  free(diag);
+  free(t);
+  free(ibdiag);
+  free(bdiag);
+  free(boff);
+  return zero;
+}
+
+/* MatSOR on a MATSEQAIJ matrix as the reference dispatches it (aij.c:1852): the inode routine when the matrix has inodes (checked
+   at assembly with the default limit 5; `no_inode` = -mat_no_inode) and omega == 1, fshift == 0; the point routine otherwise */
+int orc_MatSOR_SeqAIJ_dispatch(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, const OScalar *b, OScalar omega, int flag, OScalar fshift, OInt its,
+                               OInt lits, OScalar *x, int no_inode)
+{
+  if (!no_inode && omega == 1.0 && fshift == 0.0 && m > 0) {
+    OInt *ns = (OInt *)malloc((size_t)(m + 1) * sizeof(OInt));
+    OInt  nc = orc_MatSeqAIJCheckInode(m, ai, aj, 5, ns);
+    if (nc) {
+      int r = orc_MatSOR_SeqAIJ_Inode(m, ai, aj, aa, nc, ns, b, omega, flag, fshift, its, lits, x);
+      free(ns);
+      return r;
+    }
+    free(ns);
+  }
+  return orc_MatSOR_SeqAIJ(m, ai, aj, aa, b, omega, flag, fshift, its, lits, x);
+}
+
 /* ============================ Mat_MPIAIJ set-up ================================================ */
 
 static int cmp_oint(const void *a, const void *b)
@@ -634,6 +907,7 @@ void orc_KSPSetDefaults(OrcKSP *ksp)
   ksp->history          = NULL;
   ksp->hist_len         = 0;
   ksp->hist_n           = 0;
+  ksp->no_inode         = 0;
 }
 
 typedef struct {
@@ -708,11 +982,11 @@ static void pc_apply(Ctx *c, const OScalar *r, OScalar *z)
   else if (ksp->pc_type == ORC_PC_JACOBI) orc_VecPointwiseMult_Seq(ksp->m, z, r, c->jdiag);
   else {
     int flag = ksp->sor_flag | ORC_SOR_ZERO_INITIAL_GUESS;
-    if (ksp->nranks <= 1) orc_MatSOR_SeqAIJ(ksp->m, ksp->ai, ksp->aj, ksp->aa, r, ksp->sor_omega, flag, ksp->sor_shift, ksp->sor_its, ksp->sor_lits, z);
+    if (ksp->nranks <= 1) orc_MatSOR_SeqAIJ_dispatch(ksp->m, ksp->ai, ksp->aj, ksp->aa, r, ksp->sor_omega, flag, ksp->sor_shift, ksp->sor_its, ksp->sor_lits, z, ksp->no_inode);
     else
       for (int rk = 0; rk < ksp->nranks; rk++) {
         OInt rs = ksp->ranges[rk], ml = ksp->ranges[rk + 1] - rs;
-        orc_MatSOR_SeqAIJ(ml, c->Ai[rk], c->Aj[rk], c->Aa[rk], r + rs, ksp->sor_omega, flag, ksp->sor_shift, ksp->sor_lits, 1, z + rs);
+        orc_MatSOR_SeqAIJ_dispatch(ml, c->Ai[rk], c->Aj[rk], c->Aa[rk], r + rs, ksp->sor_omega, flag, ksp->sor_shift, ksp->sor_lits, 1, z + rs, ksp->no_inode);
       }
   }
 }

@@ -81,6 +81,13 @@ int  orc_MatGetDiagonalMarkers_SeqAIJ(OInt m, const OInt *ai, const OInt *aj, OI
 void orc_MatGetDiagonal_SeqAIJ(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, OScalar *v);                                  /* aij.c:1347-1380 */
 int  orc_MatSOR_SeqAIJ(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, const OScalar *b, OScalar omega, int flag, OScalar fshift,
                        OInt its, OInt lits, OScalar *x);                                                                                /* aij.c:1797-2007 */
+/* inodes: what MATSEQAIJ does with runs of rows that share their column list (blocked FEM matrices) */
+OInt orc_MatSeqAIJCheckInode(OInt m, const OInt *ai, const OInt *aj, OInt limit, OInt *ns);                                             /* inode.c:3920-3985 */
+int  orc_inode_invert_block(OScalar *a, int n);                                                                                         /* dgefa2.c:14 ... dgefa5.c:14 */
+int  orc_MatSOR_SeqAIJ_Inode(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, OInt node_count, const OInt *ns, const OScalar *b, OScalar omega,
+                             int flag, OScalar fshift, OInt its, OInt lits, OScalar *x);                                                /* inode.c:2420-3810 */
+int  orc_MatSOR_SeqAIJ_dispatch(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, const OScalar *b, OScalar omega, int flag, OScalar fshift, OInt its,
+                                OInt lits, OScalar *x, int no_inode);                                                                   /* aij.c:1852 */
 
 /* ---- Mat_MPIAIJ set-up (integer work: must be bit-exact) ------------------------------------- */
 /* Split rows [rstart,rend) (global columns) into diagonal block A (local cols) and off-diagonal
@@ -140,6 +147,7 @@ typedef struct {
   OScalar  rnorm;
   OScalar *history; /* caller array of length hist_len, receives rnorm per KSPLogResidualHistory */
   OInt     hist_len, hist_n;
+  int      no_inode; /* 1 = -mat_no_inode: PCSOR takes the point routine on every matrix (default 0: aij.c:1852) */
 } OrcKSP;
 
 void orc_KSPSetDefaults(OrcKSP *ksp);

@@ -495,6 +495,31 @@ assembled:
     PetscCall(VecDestroy(&y));
   }
 
+  { /* -dump_sor <MatSORType bits>: x = MatSOR(A, b, omega, flag, 0, its, lits) on this operator, every entry with 17 digits -- the relaxation
+       routine itself (MatSOR_SeqAIJ or, for a matrix with inodes, MatSOR_SeqAIJ_Inode; aij.c:1852), with -sor_its / -sor_lits /
+       -sor_omega; without SOR_ZERO_INITIAL_GUESS (16) the sweep starts from x0_i = 0.5 + (i mod 7) / 7 */
+    PetscInt  sflag = -1, sits = 1, slits = 1;
+    PetscReal somega = 1.0;
+    PetscCall(PetscOptionsGetInt(NULL, NULL, "-dump_sor", &sflag, NULL));
+    if (sflag >= 0) {
+      Vec                sx;
+      PetscScalar       *xa;
+      const PetscScalar *ca;
+      PetscCall(PetscOptionsGetInt(NULL, NULL, "-sor_its", &sits, NULL));
+      PetscCall(PetscOptionsGetInt(NULL, NULL, "-sor_lits", &slits, NULL));
+      PetscCall(PetscOptionsGetReal(NULL, NULL, "-sor_omega", &somega, NULL));
+      PetscCall(VecDuplicate(b, &sx));
+      PetscCall(VecGetArrayWrite(sx, &xa));
+      for (PetscInt i = Istart; i < Iend; i++) xa[i - Istart] = 0.5 + (PetscReal)(i % 7) / 7.0;
+      PetscCall(VecRestoreArrayWrite(sx, &xa));
+      PetscCall(MatSOR(A, b, somega, (MatSORType)sflag, 0.0, sits, slits, sx));
+      PetscCall(VecGetArrayRead(sx, &ca));
+      for (PetscInt i = 0; i < Iend - Istart; i++) PetscCall(PetscSynchronizedPrintf(PETSC_COMM_WORLD, "sor %" PetscInt_FMT " %.17g\n", i + Istart, (double)ca[i]));
+      PetscCall(PetscSynchronizedFlush(PETSC_COMM_WORLD, PETSC_STDOUT));
+      PetscCall(VecRestoreArrayRead(sx, &ca));
+      PetscCall(VecDestroy(&sx));
+    }
+  }
   PetscCall(KSPCreate(PETSC_COMM_WORLD, &ksp));
   PetscCall(KSPSetOperators(ksp, A, A));
   PetscCall(KSPSetFromOptions(ksp));

@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIBDIR = os.path.join(HERE, "lib")
+LIBDIR = os.environ.get("HIPX_LIBDIR") or os.path.join(HERE, "lib")  # HIPX_LIBDIR: a developer's A/B build of both libraries in another directory
 
 c_int_p = C.POINTER(C.c_int)
 c_dbl_p = C.POINTER(C.c_double)

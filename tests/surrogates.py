@@ -61,3 +61,37 @@ def flan_surrogate_spd(n=80, seed=1565):
     rowsum = np.bincount(rows, weights=off_abs, minlength=N)
     aa[diag] = 1.0 + rowsum[rows[diag]] + u[diag]
     return ai, aj, aa
+
+
+def inode_matrix(nnodes=60, seed=7, sizes=(1, 2, 3, 4, 5), degree=4, pivot_blocks=True):
+    """A matrix with INODES (runs of consecutive rows sharing one column list, what MatSeqAIJCheckInode finds: inode.c:3920): `nnodes`
+    mesh nodes of 1-5 unknowns each (sizes drawn from `sizes`; one run of 7 identical rows exercises the limit of 5), every node
+    coupled to itself and to ~`degree` others by dense blocks, all values distinct.  Diagonal blocks are well conditioned; with
+    pivot_blocks some of them have their largest entries OFF the diagonal, so the block inverses interchange rows (dgefa3.c:31-46).
+    Returns CSR (ai, aj, aa) with sorted columns."""
+    rng = np.random.default_rng(seed)
+    sz = rng.choice(np.array(sizes), size=nnodes)
+    if nnodes > 8:
+        sz[3] = 7  # 7 identical rows: nodes of 5 + 2
+    start = np.concatenate([[0], np.cumsum(sz)])
+    N = int(start[-1])
+    nbr = [set([u]) for u in range(nnodes)]
+    for u in range(nnodes):
+        for v in rng.choice(nnodes, size=min(degree, nnodes), replace=False):
+            nbr[u].add(int(v))
+            nbr[int(v)].add(u)
+    ai, aj, aa = [0], [], []
+    for u in range(nnodes):
+        cols = np.concatenate([np.arange(start[v], start[v + 1]) for v in sorted(nbr[u])])
+        for r in range(int(sz[u])):
+            row = int(start[u]) + r
+            vals = rng.standard_normal(len(cols)) * 0.3
+            d = np.searchsorted(cols, row)
+            vals[d] = 4.0 + rng.random() + np.abs(vals).sum()
+            if pivot_blocks and sz[u] > 1 and u % 3 == 1:  # the largest entry of this row of the diagonal block is NOT the diagonal one
+                o = np.searchsorted(cols, int(start[u]) + (r + 1) % int(sz[u]))
+                vals[o] = 2.5 * vals[d] * (1 if r % 2 else -1)
+            aj.append(cols)
+            aa.append(np.round(vals * 1024.0) / 1024.0)  # multiples of 2^-10: A * 1 is exact in ANY summation order (the reference forms
+            ai.append(ai[-1] + len(cols))                # b = A * 1 with MatMult_SeqAIJ_Inode, whose order is not MatMult_SeqAIJ's)
+    return np.array(ai, np.int32), np.concatenate(aj).astype(np.int32), np.concatenate(aa)
