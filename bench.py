@@ -633,7 +633,7 @@ def run_leg(cfg, rank, world, dist, torch, transport, steps, warmup, sync, varia
            "scaling": cfg.scaling, "global_rows": cfg.N, "spmv_kernel": kname, "parity": par, "residual_norm_after": r["rnorm"],
            "setup_seconds": t_setup, "setup_split": dict(P.setup_times), "per_rank": per_rank}
     if cfg.pc == "sor":
-        out["sor_schedule"] = {2: "strand", 1: "dependency-driven", 0: "levels"}.get(mode.value, str(mode.value))
+        out["sor_schedule"] = {3: "inode (node-level dependency-driven)", 2: "strand", 1: "dependency-driven", 0: "levels"}.get(mode.value, str(mode.value))
     nnz_l, m_l, wide = P.nnz_local, P.m, P.wide
     out["spmv_algorithmic_bytes_rank0"] = P.spmv_bytes()
     P.destroy()
@@ -772,7 +772,7 @@ def leg_matrix_solver(cfg, steps, warmup, sync, torch, best_ranks=None, parity_i
     if cfg.pc == "sor":  # PCSOR on a matrix without row templates: the dependency-driven (level-ordered) schedule, hipx_sor.hip
         mode = C.c_int(-1)
         P.lib.chk(P.hx.hipxMatGetSORMode(P.M.A, C.byref(mode)))
-        out["sor_schedule"] = {2: "strand", 1: "dependency-driven", 0: "levels"}.get(mode.value, str(mode.value))
+        out["sor_schedule"] = {3: "inode (node-level dependency-driven)", 2: "strand", 1: "dependency-driven", 0: "levels"}.get(mode.value, str(mode.value))
         if "sor_ms" in r["sections"]:
             ssor = 2 * 12 * P.nnz_local + 40 * P.m  # two passes over a, j + 5 vector passes
             out["roofline_sor"] = {"bound": "hbm", "kernel": "one PCApply_SOR = symmetric sweep (%s schedule)" % out["sor_schedule"], "avg_call_ms": r["sections"]["sor_ms"],

@@ -212,9 +212,21 @@ int hipxMatGetInfo(hipxMat A, hipx_int *m, hipx_int *n, int64_t *nnz, int64_t *d
 /* replaces MatSOR_SeqAIJ aij.c:1842 (flag = MatSORType bits petscmat.h:1664-1671); b, x device vectors */
 int hipxMatSOR(hipxMat A, const double *b, double omega, int flag, double shift, hipx_int its, hipx_int lits, double *x);
 /* which schedule the last hipxMatSOR call used: 2 = strands (stencil matrices with row templates: one lane per grid line, a wave
-   = 64 lines, neighbours through LDS), 1 = level-ordered dependency-driven sweep, 0 = one launch per level; -1 = none yet.
-   HIPX_SOR_MODE=strand|dep|levels forces one (all are bit-identical to aij.c:1930-2002). */
+   = 64 lines, neighbours through LDS), 1 = level-ordered dependency-driven sweep, 0 = one launch per level, 3 = the node-level sweep of
+   a matrix with inodes (below); -1 = none yet.  HIPX_SOR_MODE=strand|dep|levels forces one (all are bit-identical to aij.c:1930-2002). */
 int hipxMatGetSORMode(hipxMat A, int *mode);
+/* INODES (Mat_SeqAIJ_Inode, aij.h:98-132).  A MATSEQAIJ matrix whose consecutive rows share one column list (blocked FEM operators:
+   several unknowns per mesh node) is relaxed NODE by node by the reference: MatSOR_SeqAIJ hands such a matrix to MatSOR_SeqAIJ_Inode
+   when omega == 1 and fshift == 0 (aij.c:1852; inode.c:2494-3810) -- block Gauss-Seidel with the inverses of the nodes' dense diagonal
+   blocks (LINPACK dgefa/dgedi, dgefa2.c ... dgefa5.c), the rows' terms subtracted in pairs -- a DIFFERENT preconditioner from the point
+   sweep, so hipxMatSOR does the same (mode 3 of hipxMatGetSORMode: node-level dependency-driven sweep, bit-identical to inode.c).  By
+   default the nodes are found at the first hipxMatSOR call exactly as MatSeqAIJCheckInode finds them at assembly (inode.c:3920-3985: runs
+   of at most 5 identical rows; not used when they number more than 0.8 m, i.e. never on scalar stencils).  hipxMatSetInodes overrides that:
+   node_count > 0 with the node_count + 1 row offsets of the nodes (Mat_SeqAIJ_Inode::size_csr, a HOST array: what the PETSc plugin
+   passes from the matrix it wraps), or node_count == 0 for "no inodes" (-mat_no_inode).  hipxMatGetInodes reports the count in use
+   (0: none, -1: not determined yet). */
+int hipxMatSetInodes(hipxMat A, hipx_int node_count, const hipx_int *size_csr);
+int hipxMatGetInodes(hipxMat A, hipx_int *node_count);
 /* tuning knobs (plugin option -mat_aijhipx_spmv_variant): kernel variant.  0 = auto (>= 2^20 nonzeros: packed 16-bit
    column codes, row-parallel gather for short rows, and an 8-bit value dictionary when a[] holds <= 256 distinct bit
    patterns); 1..12 = 32-bit-column stream kernel geometries; 22 / 23 = packed columns (staged / row-parallel);

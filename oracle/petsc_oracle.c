@@ -327,6 +327,23 @@ done:
 
 /* ============================ inodes (Mat_SeqAIJ with identical consecutive rows) ============== */
 
+/* MatMult_SeqAIJ_Inode (inode.c:356-560), what MatMult_SeqAIJ runs when the matrix has inodes (aij.c:1459): every row's terms are
+   added in PAIRS, sum += a[k] x[j_k] + a[k+1] x[j_k+1], a last odd term alone -- the rows of a node side by side, which does not
+   change any row's arithmetic: written row by row here.  Rounding-level differences from MatMult_SeqAIJ's left-to-right sums. */
+void orc_MatMult_SeqAIJ_Inode(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, const OScalar *x, OScalar *y)
+{
+  for (OInt i = 0; i < m; i++) {
+    const OInt     sz  = ai[i + 1] - ai[i];
+    const OInt    *idx = aj + ai[i];
+    const OScalar *v   = aa + ai[i];
+    OScalar        sum = 0.;
+    OInt           n;
+    for (n = 0; n < sz - 1; n += 2) sum += v[n] * x[idx[n]] + v[n + 1] * x[idx[n + 1]];
+    if (n == sz - 1) sum += v[n] * x[idx[n]];
+    y[i] = sum;
+  }
+}
+
 /* MatSeqAIJCheckInode (inode.c:3920-3985): consecutive rows with the same column list form a node of at most `limit` rows
    (-mat_inode_limit, default 5).  ns[0..node_count] receives the row offsets of the nodes (size_csr).  Returns node_count, or 0
    when the reference does NOT use the inode routines: no rows, or more than 0.8 m nodes (inode.c:3962). */
@@ -917,7 +934,15 @@ typedef struct {
   /* per-rank diagonal blocks for PCSOR on a simulated MPIAIJ partition */
   OInt    **Ai, **Aj;
   OScalar **Aa;
+  int       inode_mult; /* the operator has inodes (one rank): MatMult is MatMult_SeqAIJ_Inode (aij.c:1459) */
 } Ctx;
+
+static void ksp_mult(const Ctx *c, const OScalar *x, OScalar *y)
+{
+  const OrcKSP *ksp = c->ksp;
+  if (c->inode_mult) orc_MatMult_SeqAIJ_Inode(ksp->m, ksp->ai, ksp->aj, ksp->aa, x, y);
+  else orc_MatMult_SeqAIJ(ksp->m, ksp->ai, ksp->aj, ksp->aa, x, y);
+}
 
 static void ctx_setup(Ctx *c, OrcKSP *ksp)
 {
@@ -927,6 +952,12 @@ static void ctx_setup(Ctx *c, OrcKSP *ksp)
   c->jdiag = NULL;
   c->Ai = c->Aj = NULL;
   c->Aa         = NULL;
+  c->inode_mult = 0;
+  if (!ksp->no_inode && ksp->nranks <= 1 && ksp->m > 0) {
+    OInt *ns      = (OInt *)malloc((size_t)(ksp->m + 1) * sizeof(OInt));
+    c->inode_mult = orc_MatSeqAIJCheckInode(ksp->m, ksp->ai, ksp->aj, 5, ns) > 0;
+    free(ns);
+  }
   if (ksp->pc_type == ORC_PC_JACOBI) {
     c->jdiag = (OScalar *)malloc((size_t)ksp->m * sizeof(OScalar));
     orc_PCSetUp_Jacobi(ksp->m, ksp->ai, ksp->aj, ksp->aa, c->jdiag); /* the diagonal is owned by the row's rank: same values at any nranks */
@@ -1045,7 +1076,7 @@ int orc_KSPSolve_CG(OrcKSP *ksp, const OScalar *B, OScalar *X)
   ksp->hist_n = 0;
   if (!ksp->guess_nonzero) memset(X, 0, (size_t)n * sizeof(OScalar)); /* itfunc.c:908 VecSet(x,0) */
   if (ksp->guess_nonzero) {
-    orc_MatMult_SeqAIJ(n, ksp->ai, ksp->aj, ksp->aa, X, R); /* cg.c:154 */
+    ksp_mult(&c, X, R); /* cg.c:154 */
     orc_VecAYPX_Seq(n, R, -1.0, B);                          /* cg.c:156 */
   } else orc_VecCopy_Seq(n, B, R);                           /* cg.c:162 */
 
@@ -1095,7 +1126,7 @@ int orc_KSPSolve_CG(OrcKSP *ksp, const OScalar *B, OScalar *X)
       orc_VecAYPX_Seq(n, P, b, Z); /* cg.c:249 */
     }
     dpiold = dpi;
-    orc_MatMult_SeqAIJ(n, ksp->ai, ksp->aj, ksp->aa, P, W); /* cg.c:257 */
+    ksp_mult(&c, P, W); /* cg.c:257 */
     dpi     = orc_VecDot_Seq(n, P, W);                       /* cg.c:258 */
     betaold = beta;
     if (isnan(dpi) || isinf(dpi)) {
@@ -1174,7 +1205,7 @@ int orc_KSPSolve_GMRES(OrcKSP *ksp, const OScalar *B, OScalar *X)
     int     hapend = 0;
     /* KSPInitialResidual, PC_LEFT */
     if (ksp->guess_nonzero) {
-      orc_MatMult_SeqAIJ(n, ksp->ai, ksp->aj, ksp->aa, X, TEMP);
+      ksp_mult(&c, X, TEMP);
       orc_VecCopy_Seq(n, B, TMOP);
       orc_VecAXPY_Seq(n, TMOP, -1.0, TEMP);
       pc_apply(&c, TMOP, VV[0]);
@@ -1200,7 +1231,7 @@ int orc_KSPSolve_GMRES(OrcKSP *ksp, const OScalar *B, OScalar *X)
     while (!ksp->reason && it < max_k && ksp->its < ksp->max_it) {
       if (it) log_history(ksp, res);
       /* KSP_PCApplyBAorAB, left: VV[it+1] = B (A VV[it]) */
-      orc_MatMult_SeqAIJ(n, ksp->ai, ksp->aj, ksp->aa, VV[it], TMOP);
+      ksp_mult(&c, VV[it], TMOP);
       pc_apply(&c, TMOP, VV[it + 1]);
       /* classical Gram-Schmidt, borthog2.c */
       {

@@ -82,6 +82,7 @@ void orc_MatGetDiagonal_SeqAIJ(OInt m, const OInt *ai, const OInt *aj, const OSc
 int  orc_MatSOR_SeqAIJ(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, const OScalar *b, OScalar omega, int flag, OScalar fshift,
                        OInt its, OInt lits, OScalar *x);                                                                                /* aij.c:1797-2007 */
 /* inodes: what MATSEQAIJ does with runs of rows that share their column list (blocked FEM matrices) */
+void orc_MatMult_SeqAIJ_Inode(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, const OScalar *x, OScalar *y);                 /* inode.c:356-560 */
 OInt orc_MatSeqAIJCheckInode(OInt m, const OInt *ai, const OInt *aj, OInt limit, OInt *ns);                                             /* inode.c:3920-3985 */
 int  orc_inode_invert_block(OScalar *a, int n);                                                                                         /* dgefa2.c:14 ... dgefa5.c:14 */
 int  orc_MatSOR_SeqAIJ_Inode(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, OInt node_count, const OInt *ns, const OScalar *b, OScalar omega,

@@ -128,6 +128,8 @@ struct hipxMat_s {
   int       probe      = 0;   // phase-attribution probe kernels (scripts/spmv_variants.py); results are NOT A x
   std::vector<int64_t> h_i;  // host copy of the row offsets (set-up only)
   void     *sor_state = nullptr;  // hipxSorState, owned by hipx_sor.hip
+  int                   inode_state = -1;  // -1: not determined (hipx_sor.hip looks at the first hipxMatSOR call), 0: none, 1: inode_sizes holds the nodes
+  std::vector<hipx_int> inode_sizes;       // node_count + 1 row offsets (Mat_SeqAIJ_Inode::size_csr)
   // pattern templates (variant 29): the rows' (column - row) lists only -- <= 256 distinct ones; the values stay in a[] and are streamed
   bool           ptm_ready = false, ptm_ok = false, ptm_build = false;  // ptm_build: build_templates() is running in pattern-only mode
   int            ptm_mode = 0, ptm_ntmpl = 0, ptm_nent = 0, ptm_maxlen = 0;
@@ -3800,6 +3802,49 @@ int hipxMatInternal_(hipxMat A, hipx_int *m, hipx_int *n, int64_t *nnz, int *is6
   *compressed = A->compressed;
   *sor_slot = &A->sor_state;
   *value_state = A->value_state;
+  return HIPX_SUCCESS;
+}
+
+// inodes (include/hipx.h).  The set-up lives with the relaxation (hipx_sor.hip); the matrix only remembers the partition
+int hipxMatSetInodes(hipxMat A, hipx_int node_count, const hipx_int *size_csr)
+{
+  HIPX_ARG(A, "null matrix");
+  HIPX_ARG(node_count >= 0 && (node_count == 0 || size_csr), "node_count > 0 needs the row offsets of the nodes");
+  if (node_count > 0) {
+    HIPX_ARG(size_csr[0] == 0 && size_csr[node_count] == A->m, "the nodes must cover rows 0 ... m - 1");
+    for (hipx_int i = 0; i < node_count; i++) HIPX_ARG(size_csr[i + 1] > size_csr[i] && size_csr[i + 1] - size_csr[i] <= 5, "a node has 1 to 5 rows (inode.c:2484)");
+    A->inode_sizes.assign(size_csr, size_csr + node_count + 1);
+    A->inode_state = 1;
+  } else {
+    A->inode_sizes.clear();
+    A->inode_state = 0;
+  }
+  hipxSorStateFree_(A->sor_state);  // schedules are per partition
+  A->sor_state = nullptr;
+  return HIPX_SUCCESS;
+}
+
+int hipxMatGetInodes(hipxMat A, hipx_int *node_count)
+{
+  HIPX_ARG(A && node_count, "null argument");
+  *node_count = A->inode_state < 0 ? -1 : (A->inode_state ? (hipx_int)A->inode_sizes.size() - 1 : 0);
+  return HIPX_SUCCESS;
+}
+
+// internal, hipx_sor.hip: the partition (state as in the struct; sizes = node_count + 1 host offsets) / the result of its own look
+int hipxMatInodes_(hipxMat A, int *state, hipx_int *node_count, const hipx_int **sizes)
+{
+  *state      = A->inode_state;
+  *node_count = A->inode_state == 1 ? (hipx_int)A->inode_sizes.size() - 1 : 0;
+  *sizes      = A->inode_state == 1 ? A->inode_sizes.data() : nullptr;
+  return HIPX_SUCCESS;
+}
+int hipxMatInodesFound_(hipxMat A, hipx_int node_count, const hipx_int *sizes)
+{
+  if (node_count > 0) {
+    A->inode_sizes.assign(sizes, sizes + node_count + 1);
+    A->inode_state = 1;
+  } else A->inode_state = 0;
   return HIPX_SUCCESS;
 }
 

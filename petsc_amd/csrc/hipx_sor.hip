@@ -52,12 +52,15 @@ struct hipxSorState {
   const int *var_tstart = nullptr, *var_toff = nullptr;  // device tables of the pattern templates (owned by the matrix)
   int       last_mode = -1;
   unsigned long long strand_vstate = 0;  // value state of the matrix the strand tables were built from
+  void     *inode = nullptr;    // InodeState: node-level sweeps of a matrix with inodes (MatSOR_SeqAIJ_Inode)
 };
 
 extern "C" {
 // accessors implemented in hipx_mat.hip
 int   hipxMatInternal_(hipxMat A, hipx_int *m, hipx_int *n, int64_t *nnz, int *is64, void **d_i, hipx_int **d_j, double **d_a, int64_t **d_diagpos, int *diag_dense,
                        int *compressed, void ***sor_slot, unsigned long long *value_state);
+int   hipxMatInodes_(hipxMat A, int *state, hipx_int *node_count, const hipx_int **sizes);
+int   hipxMatInodesFound_(hipxMat A, hipx_int node_count, const hipx_int *sizes);
 }
 
 namespace {
@@ -2100,6 +2103,447 @@ int run_strand(StrandState *T, const double *asrc, double *t, const double *xold
   return HIPX_SUCCESS;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Matrices with INODES: MatSOR_SeqAIJ_Inode (inode.c:2494-3810), which MatSOR_SeqAIJ runs instead of its own loops when the matrix
+// has inodes and omega == 1, fshift == 0 (aij.c:1852).  A node = up to 5 consecutive rows with ONE column list (the unknowns of a
+// mesh node); the sweep is block Gauss-Seidel over the nodes:
+//     s_r = rhs_r - sum over the node's off-block entries, taken in PAIRS: s_r -= (a_r[k] x[j_k] + a_r[k+1] x[j_k+1])   (inode.c:2589-2608)
+//     x_r = sum_c s_c * D^-1[r, c]   (c ascending; D = the node's dense diagonal block, inverted once per set of values by LINPACK's
+//           dgefa + dgedi: dgefa3.c:14 and its siblings for 2, 4, 5 rows)                                                (inode.c:2612-2614)
+// -- not the arithmetic of the point sweep, so these matrices get their own schedule: the level-ordered dependency-driven sweep of
+// above on the NODE graph (one lane per node, a wave = 64 nodes of one level, values polled out of the sentinel-filled new vector).
+// The node-level copy of the matrix: the shared column list once per node, the values entry-major ([entry][row of the node], padded to
+// the largest node of the matrix): a lane streams its node's entries with unit stride.
+struct InodeState {
+  bool      ready = false, values_valid = false;
+  hipx_int  nnodes = 0, nslots = 0, nlevels = 0;
+  int       nsm = 2;              // rows of the largest node
+  int4     *d_nmeta = nullptr;    // per node (level order): {first row, rows, entries before the diagonal block, entries per row}
+  int64_t  *d_nks = nullptr;      // per node: start of its entries in d_nj / d_nv
+  int4     *d_smeta = nullptr;    // per slot: the node's meta (first row = -1: padding)
+  int64_t  *d_sks = nullptr;
+  hipx_int *d_sp = nullptr;       // per slot: node index (level order)
+  hipx_int *d_nj = nullptr;
+  double   *d_nv = nullptr;
+  double   *d_ibd = nullptr, *d_bd = nullptr;  // per node nsm * nsm: inverse / copy of the diagonal block, column-major with the NODE's size as stride
+  unsigned int zero_pivots = 0;
+  int64_t   nentries = 0;
+};
+
+void inode_free(InodeState *T)
+{
+  if (!T) return;
+  (void)hipFree(T->d_nmeta);
+  (void)hipFree(T->d_nks);
+  (void)hipFree(T->d_smeta);
+  (void)hipFree(T->d_sks);
+  (void)hipFree(T->d_sp);
+  (void)hipFree(T->d_nj);
+  (void)hipFree(T->d_nv);
+  (void)hipFree(T->d_ibd);
+  (void)hipFree(T->d_bd);
+  delete T;
+}
+
+// MatSeqAIJCheckInode's comparison (inode.c:3948-3953), row against the row before it: same[i] = 1 when row i + 1 has the column list of row i
+__global__ void inode_same_kernel(hipx_int m, const void *ai_, int is64, const hipx_int *__restrict__ aj, unsigned char *__restrict__ same)
+{
+  for (hipx_int i = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < m; i += (hipx_int)gridDim.x * blockDim.x) {
+    const int64_t s0 = is64 ? ((const int64_t *)ai_)[i] : (int64_t)((const hipx_int *)ai_)[i];
+    const int64_t s1 = is64 ? ((const int64_t *)ai_)[i + 1] : (int64_t)((const hipx_int *)ai_)[i + 1];
+    const int64_t s2 = is64 ? ((const int64_t *)ai_)[i + 2] : (int64_t)((const hipx_int *)ai_)[i + 2];
+    unsigned char eq = (s1 - s0) == (s2 - s1);
+    for (int64_t k = 0; eq && k < s1 - s0; k++) eq = aj[s0 + k] == aj[s1 + k];
+    same[i] = eq;
+  }
+}
+
+// the nodes of the matrix as the reference finds them at assembly (inode.c:3940-3965; limit 5 = the default of -mat_inode_limit):
+// sizes <- node_count + 1 row offsets; returns node_count, 0 when the reference would not use the inode routines
+int inode_find(hipx_int m, int is64, const void *d_i, const hipx_int *d_j, std::vector<hipx_int> &sizes, hipx_int *node_count)
+{
+  *node_count = 0;
+  sizes.clear();
+  if (m < 2) return HIPX_SUCCESS;
+  hipStream_t    st = rt().compute;
+  unsigned char *d_same;
+  HIPX_HIP(hipMalloc((void **)&d_same, (size_t)m));
+  inode_same_kernel<<<(unsigned)std::min<hipx_int>((m + 255) / 256, 8192), 256, 0, st>>>(m, d_i, is64, d_j, d_same);
+  HIPX_LAUNCH_CHECK();
+  std::vector<unsigned char> same((size_t)m, 0);
+  HIPX_HIP(hipMemcpyAsync(same.data(), d_same, (size_t)m - 1, hipMemcpyDeviceToHost, st));
+  HIPX_HIP(hipStreamSynchronize(st));
+  HIPX_HIP(hipFree(d_same));
+  constexpr hipx_int limit = 5;
+  sizes.push_back(0);
+  hipx_int i = 0, nc = 0;
+  while (i < m) {
+    hipx_int j = i + 1, blk = 1;
+    for (; j < m && blk < limit; ++j, ++blk)
+      if (!same[(size_t)j - 1]) break;
+    sizes.push_back(sizes.back() + blk);
+    nc++;
+    i = j;
+  }
+  if ((double)nc > .8 * (double)m) {  // inode.c:3962
+    sizes.clear();
+    nc = 0;
+  }
+  *node_count = nc;
+  return HIPX_SUCCESS;
+}
+
+// node levels of the symmetrised node graph (as build_schedule does for rows), wave-aligned slots, the per-node tables
+int inode_build(InodeState *T, hipx_int m, int64_t nnz, int is64, const void *d_i, const hipx_int *d_j, const int64_t *d_diagpos, hipx_int nnodes, const hipx_int *sizes)
+{
+  std::vector<int64_t>  hi((size_t)m + 1), hd((size_t)m);
+  std::vector<hipx_int> hj((size_t)nnz);
+  if (is64) HIPX_HIP(hipMemcpy(hi.data(), d_i, sizeof(int64_t) * ((size_t)m + 1), hipMemcpyDeviceToHost));
+  else {
+    std::vector<hipx_int> tmp((size_t)m + 1);
+    HIPX_HIP(hipMemcpy(tmp.data(), d_i, sizeof(hipx_int) * ((size_t)m + 1), hipMemcpyDeviceToHost));
+    for (hipx_int r = 0; r <= m; r++) hi[r] = tmp[r];
+  }
+  if (nnz) HIPX_HIP(hipMemcpy(hj.data(), d_j, sizeof(hipx_int) * (size_t)nnz, hipMemcpyDeviceToHost));
+  HIPX_HIP(hipMemcpy(hd.data(), d_diagpos, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost));
+  std::vector<hipx_int> r2n((size_t)m);
+  int nsm = 1;
+  for (hipx_int u = 0; u < nnodes; u++) {
+    for (hipx_int r = sizes[u]; r < sizes[u + 1]; r++) r2n[r] = u;
+    nsm = std::max(nsm, (int)(sizes[u + 1] - sizes[u]));
+  }
+  // what the reference's loops assume of a node (inode.c:2529-2531, 2719-2721): every row has the node's column list (given: that is how
+  // the nodes were found, or what the caller vouches for) and the node's own columns sit together in it, starting at the first row's diagonal
+  for (hipx_int u = 0; u < nnodes; u++) {
+    const hipx_int r0 = sizes[u], ns = sizes[u + 1] - sizes[u];
+    const int64_t  len = hi[r0 + 1] - hi[r0], szl = hd[r0] - hi[r0];
+    bool           ok  = hd[r0] >= 0 && szl + ns <= len;
+    for (hipx_int r = 0; ok && r < ns; r++) ok = (hi[r0 + r + 1] - hi[r0 + r] == len) && hj[hi[r0] + szl + r] == r0 + r;
+    if (!ok) return fail(73 /* PETSC_ERR_ARG_WRONGSTATE */, "inodes: a node's rows must share one column list that holds the node's own columns (the diagonal block)", __FILE__, __LINE__);
+  }
+  std::vector<hipx_int> lev((size_t)nnodes, 0);
+  hipx_int              nlev = 0;
+  for (hipx_int u = 0; u < nnodes; u++) {
+    hipx_int      l  = lev[u];
+    const int64_t k0 = hi[sizes[u]], k1 = hi[sizes[u] + 1];
+    for (int64_t k = k0; k < k1; k++) {
+      const hipx_int j = hj[k];
+      if (j >= 0 && j < m && r2n[j] < u) l = std::max(l, lev[r2n[j]] + 1);
+    }
+    lev[u] = l;
+    for (int64_t k = k0; k < k1; k++) {
+      const hipx_int j = hj[k];
+      if (j >= 0 && j < m && r2n[j] > u) lev[r2n[j]] = std::max(lev[r2n[j]], l + 1);
+    }
+    nlev = std::max(nlev, l + 1);
+  }
+  std::vector<hipx_int> lp((size_t)nlev + 1, 0);
+  for (hipx_int u = 0; u < nnodes; u++) lp[lev[u] + 1]++;
+  for (hipx_int l = 0; l < nlev; l++) lp[l + 1] += lp[l];
+  std::vector<hipx_int> perm((size_t)nnodes), fill(lp.begin(), lp.end() - 1);
+  for (hipx_int u = 0; u < nnodes; u++) perm[fill[lev[u]]++] = u;
+  std::vector<int4>    nmeta((size_t)nnodes);
+  std::vector<int64_t> nks((size_t)nnodes + 1, 0);
+  for (hipx_int p = 0; p < nnodes; p++) {
+    const hipx_int u = perm[p], r0 = sizes[u];
+    nmeta[p]   = make_int4(r0, sizes[u + 1] - r0, (int)(hd[r0] - hi[r0]), (int)(hi[r0 + 1] - hi[r0]));
+    nks[p + 1] = nks[p] + (hi[r0 + 1] - hi[r0]);
+  }
+  std::vector<int4>     smeta;
+  std::vector<int64_t>  sks;
+  std::vector<hipx_int> sp;
+  for (hipx_int l = 0; l < nlev; l++) {
+    for (hipx_int p = lp[l]; p < lp[l + 1]; p++) {
+      smeta.push_back(nmeta[p]);
+      sks.push_back(nks[p]);
+      sp.push_back(p);
+    }
+    while (smeta.size() % 64) {
+      smeta.push_back(make_int4(-1, 0, 0, 0));
+      sks.push_back(0);
+      sp.push_back(0);
+    }
+  }
+  T->nnodes   = nnodes;
+  T->nlevels  = nlev;
+  T->nslots   = (hipx_int)smeta.size();
+  T->nsm      = std::max(nsm, 2);
+  T->nentries = nks[nnodes];
+  const size_t ne = (size_t)std::max<int64_t>(T->nentries, 1);
+  HIPX_HIP(hipMalloc((void **)&T->d_nmeta, sizeof(int4) * (size_t)nnodes));
+  HIPX_HIP(hipMalloc((void **)&T->d_nks, sizeof(int64_t) * ((size_t)nnodes + 1)));
+  HIPX_HIP(hipMalloc((void **)&T->d_smeta, sizeof(int4) * smeta.size()));
+  HIPX_HIP(hipMalloc((void **)&T->d_sks, sizeof(int64_t) * sks.size()));
+  HIPX_HIP(hipMalloc((void **)&T->d_sp, sizeof(hipx_int) * sp.size()));
+  HIPX_HIP(hipMalloc((void **)&T->d_nj, sizeof(hipx_int) * ne));
+  HIPX_HIP(hipMalloc((void **)&T->d_nv, sizeof(double) * ne * (size_t)T->nsm));
+  HIPX_HIP(hipMalloc((void **)&T->d_ibd, sizeof(double) * (size_t)nnodes * (size_t)(T->nsm * T->nsm)));
+  HIPX_HIP(hipMalloc((void **)&T->d_bd, sizeof(double) * (size_t)nnodes * (size_t)(T->nsm * T->nsm)));
+  HIPX_HIP(hipMemcpy(T->d_nmeta, nmeta.data(), sizeof(int4) * (size_t)nnodes, hipMemcpyHostToDevice));
+  HIPX_HIP(hipMemcpy(T->d_nks, nks.data(), sizeof(int64_t) * ((size_t)nnodes + 1), hipMemcpyHostToDevice));
+  HIPX_HIP(hipMemcpy(T->d_smeta, smeta.data(), sizeof(int4) * smeta.size(), hipMemcpyHostToDevice));
+  HIPX_HIP(hipMemcpy(T->d_sks, sks.data(), sizeof(int64_t) * sks.size(), hipMemcpyHostToDevice));
+  HIPX_HIP(hipMemcpy(T->d_sp, sp.data(), sizeof(hipx_int) * sp.size(), hipMemcpyHostToDevice));
+  T->ready = true;
+  return HIPX_SUCCESS;
+}
+
+// the node-level copy of the values (+ the shared column lists) and the diagonal blocks with their inverses: once per set of values
+__global__ void inode_pack_kernel(hipx_int nnodes, int nsm, const int4 *__restrict__ nmeta, const int64_t *__restrict__ nks, const void *ai_, int is64, const hipx_int *__restrict__ aj,
+                                  const double *__restrict__ aa, hipx_int *__restrict__ nj, double *__restrict__ nv)
+{
+  // one wave per node: lanes walk the entries
+  const int      lane = threadIdx.x & 63;
+  const hipx_int w0 = (hipx_int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nw = (hipx_int)((gridDim.x * blockDim.x) >> 6);
+  for (hipx_int p = w0; p < nnodes; p += nw) {
+    const int4    mt = nmeta[p];
+    const int64_t ks = nks[p];
+    for (int r = 0; r < nsm; r++) {
+      const int64_t s = (r < mt.y) ? (is64 ? ((const int64_t *)ai_)[mt.x + r] : (int64_t)((const hipx_int *)ai_)[mt.x + r]) : 0;
+      for (int k = lane; k < mt.w; k += 64) {
+        nv[(ks + k) * nsm + r] = (r < mt.y) ? aa[s + k] : 0.0;
+        if (r == 0) nj[ks + k] = aj[s + k];
+      }
+    }
+  }
+}
+
+// MatInvertDiagonalForSOR_SeqAIJ_Inode (inode.c:2449-2489): the node's block, column-major (element (j, k) = a[diag[row + j] - j + k]), and
+// its inverse by PetscKernel_A_gets_inverse_A_<n> (dgefa2.c:14, dgefa3.c:14, dgefa4.c, dgefa5.c:14 with shift = 0): LINPACK dgefa -- the
+// first largest entry of the column is the pivot, multipliers -1 / pivot, column updates y += t x -- then dgedi: inverse(U) column by
+// column, inverse(U) inverse(L) from the last column back, the interchanges undone on the columns.  One thread per node.
+__global__ void inode_invert_kernel(hipx_int nnodes, int nsm, const int4 *__restrict__ nmeta, const int64_t *__restrict__ diagpos, const double *__restrict__ aa,
+                                    double *__restrict__ ibd, double *__restrict__ bd, unsigned int *zero_pivots)
+{
+  for (hipx_int p = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; p < nnodes; p += (hipx_int)gridDim.x * blockDim.x) {
+    const int4 mt = nmeta[p];
+    const int  n  = mt.y;
+    double     a[25], work[5];
+    int        ipvt[5];
+    bool       zero = false;
+    for (int j = 0; j < n; j++)
+      for (int k = 0; k < n; k++) a[k * n + j] = aa[diagpos[mt.x + j] - j + k];
+    double *bo = bd + (size_t)p * (size_t)(nsm * nsm), *io = ibd + (size_t)p * (size_t)(nsm * nsm);
+    for (int e = 0; e < n * n; e++) bo[e] = a[e];
+#define A_(i, j) a[(i) + (j) * n]
+    if (n == 1) {
+      if (fabs(a[0]) < 100. * 2.220446049250313e-16) zero = true;  // inode.c:2459
+      a[0] = 1.0 / a[0];
+    } else {
+      for (int k = 0; k < n - 1; k++) {
+        int    l   = k;
+        double max = fabs(A_(k, k));
+        for (int i = k + 1; i < n; i++)
+          if (fabs(A_(i, k)) > max) {
+            max = fabs(A_(i, k));
+            l   = i;
+          }
+        ipvt[k] = l;
+        if (A_(l, k) == 0.0) zero = true;
+        if (l != k) {
+          const double t = A_(l, k);
+          A_(l, k)       = A_(k, k);
+          A_(k, k)       = t;
+        }
+        const double tm = -1. / A_(k, k);
+        for (int i = k + 1; i < n; i++) A_(i, k) *= tm;
+        for (int j = k + 1; j < n; j++) {
+          const double t = A_(l, j);
+          if (l != k) {
+            A_(l, j) = A_(k, j);
+            A_(k, j) = t;
+          }
+          for (int i = k + 1; i < n; i++) A_(i, j) += t * A_(i, k);
+        }
+      }
+      ipvt[n - 1] = n - 1;
+      if (A_(n - 1, n - 1) == 0.0) zero = true;
+      for (int k = 0; k < n; k++) {
+        A_(k, k)        = 1.0 / A_(k, k);
+        const double tk = -A_(k, k);
+        for (int i = 0; i < k; i++) A_(i, k) *= tk;
+        for (int j = k + 1; j < n; j++) {
+          const double t = A_(k, j);
+          A_(k, j)       = 0.0;
+          for (int i = 0; i <= k; i++) A_(i, j) += t * A_(i, k);
+        }
+      }
+      for (int k = n - 2; k >= 0; k--) {
+        for (int i = k + 1; i < n; i++) {
+          work[i]  = A_(i, k);
+          A_(i, k) = 0.0;
+        }
+        for (int j = k + 1; j < n; j++) {
+          const double t = work[j];
+          for (int i = 0; i < n; i++) A_(i, k) += t * A_(i, j);
+        }
+        if (ipvt[k] != k)
+          for (int i = 0; i < n; i++) {
+            const double t = A_(i, k);
+            A_(i, k)       = A_(i, ipvt[k]);
+            A_(i, ipvt[k]) = t;
+          }
+      }
+    }
+#undef A_
+    for (int e = 0; e < n * n; e++) io[e] = a[e];
+    if (zero) atomicAdd(zero_pivots, 1u);
+  }
+}
+
+// the entries [k0, k1) of a node, in pairs from k0 (inode.c:2589-2608): sum_r -= v_r[k] x[j_k] + v_r[k+1] x[j_k+1]; a last odd entry alone.
+// SRC 0: every operand is a NEW value (polled out of xnew), 1: every operand an old one (xold), 2: columns >= thr new, the others old
+template <int NSM, int SRC>
+__device__ __forceinline__ void inode_minus(double (&sum)[NSM], int64_t k0, int64_t k1, hipx_int thr, const hipx_int *__restrict__ nj, const double *__restrict__ nv, const double *xold,
+                                            const double *xnew, unsigned int *err)
+{
+  constexpr int CH = (NSM <= 3) ? 8 : 4;  // entries whose column / value loads are in flight before the first poll (even: pairs never straddle chunks)
+  for (int64_t k = k0; k < k1; k += CH) {
+    hipx_int  j[CH];
+    double    a[CH][NSM], v[CH];
+    const int nk = (int)((k1 - k) < CH ? (k1 - k) : CH);
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      const int64_t kk = (c < nk) ? k + c : k;
+      j[c]             = nj[kk];
+#pragma unroll
+      for (int r = 0; r < NSM; r++) a[c][r] = nv[kk * NSM + r];
+    }
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      const bool dep = SRC == 0 || (SRC == 2 && j[c] >= thr);
+      if (dep) v[c] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(xnew + j[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      else v[c] = xold[j[c]];
+    }
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      const bool dep = SRC == 0 || (SRC == 2 && j[c] >= thr);
+      if (c < nk && dep && (unsigned long long)__double_as_longlong(v[c]) == SOR_SENTINEL) v[c] = sor_poll(xnew + j[c], err);
+    }
+#pragma unroll
+    for (int c = 0; c < CH; c += 2) {
+      if (c + 1 < nk) {
+#pragma unroll
+        for (int r = 0; r < NSM; r++) sum[r] -= a[c][r] * v[c] + a[c + 1][r] * v[c + 1];
+      } else if (c < nk) {
+#pragma unroll
+        for (int r = 0; r < NSM; r++) sum[r] -= a[c][r] * v[c];
+      }
+    }
+  }
+}
+
+// KIND 0: zero-guess forward   (inode.c:2527-2712)  s = b - L x_new;  t = s;  x = D^-1 s
+// KIND 1: backward after a forward sweep, rhs = t   (inode.c:2714-2888, 3238-3253)  x = D^-1 (t - U x_new)
+// KIND 2: backward, zero guess, rhs = b             (the same loops with xb = b; Eisenstat's first step inode.c:3379-3553)
+// KIND 3: forward, general     (inode.c:2892-3207)  s = b - L x_new;  t = s;  x = D^-1 (s - U x_old)
+// KIND 4: backward alone, general (inode.c:3219-3237, 3311-3339): the WHOLE rows, block included, in one run of pairs:  x = x_old + D^-1 (b - A x)
+// KIND 5: Eisenstat's last step (inode.c:3634-3804): forward on t:  t_new = D^-1 (t - L t_new);  x += t_new
+template <int KIND, int NSM>
+__global__ __launch_bounds__(SOR_THREADS) void sor_inode_kernel(hipx_int nslots, const int4 *__restrict__ smeta, const int64_t *__restrict__ sks, const hipx_int *__restrict__ sp,
+                                                                 const hipx_int *__restrict__ nj, const double *__restrict__ nv, const double *__restrict__ ibd, const double *rhs, double *t,
+                                                                 const double *xold, double *xnew, double *xacc, unsigned int *ctl)
+{
+  constexpr bool FWD = (KIND == 0 || KIND == 3 || KIND == 5);
+  unsigned int  *err = ctl + 1;
+  const int      lane = threadIdx.x & 63;
+  const hipx_int ngroups = nslots >> 6;
+  for (;;) {
+    unsigned int v = 0;
+    if (lane == 0) v = atomicAdd(&ctl[0], 1u);
+    v = __shfl(v, 0, 64);
+    if ((hipx_int)v >= ngroups) return;
+    const hipx_int g  = (hipx_int)v * 64 + lane;
+    const hipx_int s  = FWD ? g : nslots - 1 - g;
+    const int4     mt = smeta[s];  // {first row, rows, entries before the block, entries per row}; first row < 0: padding
+    if (mt.x >= 0) {
+      const int64_t  ks = sks[s];
+      const hipx_int r0 = mt.x;
+      const int      ns = mt.y;
+      const double  *D  = ibd + (size_t)sp[s] * (size_t)(NSM * NSM);
+      double         sum[NSM], out[NSM];
+#pragma unroll
+      for (int r = 0; r < NSM; r++) sum[r] = (r < ns) ? rhs[r0 + r] : 0.0;
+      if (KIND == 0 || KIND == 3 || KIND == 5) {
+        inode_minus<NSM, 0>(sum, ks, ks + mt.z, 0, nj, nv, xold, xnew, err);
+        if (KIND != 5) {
+#pragma unroll
+          for (int r = 0; r < NSM; r++)
+            if (r < ns) t[r0 + r] = sum[r];
+        }
+        if (KIND == 3) inode_minus<NSM, 1>(sum, ks + mt.z + ns, ks + mt.w, 0, nj, nv, xold, xnew, err);
+      } else if (KIND == 1 || KIND == 2) {
+        inode_minus<NSM, 0>(sum, ks + mt.z + ns, ks + mt.w, 0, nj, nv, xold, xnew, err);
+      } else {
+        inode_minus<NSM, 2>(sum, ks, ks + mt.w, r0 + ns, nj, nv, xold, xnew, err);
+      }
+      // x_r = sum_c s_c D^-1[r, c], c ascending (inode.c:2612-2614; the backward loops write the same expression from the last row up)
+#pragma unroll
+      for (int r = 0; r < NSM; r++) {
+        double acc = sum[0] * D[r < ns ? r : 0];
+#pragma unroll
+        for (int c = 1; c < NSM; c++)
+          if (c < ns) acc = acc + sum[c] * D[(r < ns) ? c * ns + r : 0];
+        out[r] = acc;
+      }
+#pragma unroll
+      for (int r = 0; r < NSM; r++)
+        if (r < ns) {
+          if (KIND == 4) out[r] = xold[r0 + r] + out[r];
+          sor_publish(xnew + r0 + r, out[r]);
+          if (KIND == 5) xacc[r0 + r] += out[r];
+        }
+    }
+  }
+}
+
+// Eisenstat's middle step on the nodes (inode.c:3559-3628): t = b - D x, the block product summed over the node's columns in ascending order
+__global__ void inode_eisenstat_mid_kernel(hipx_int nnodes, int nsm, const int4 *__restrict__ nmeta, const double *__restrict__ bd, const double *__restrict__ b, const double *__restrict__ x,
+                                           double *__restrict__ t)
+{
+  for (hipx_int p = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; p < nnodes; p += (hipx_int)gridDim.x * blockDim.x) {
+    const int4    mt = nmeta[p];
+    const int     ns = mt.y;
+    const double *D  = bd + (size_t)p * (size_t)(nsm * nsm);
+    for (int r = 0; r < ns; r++) {
+      double acc = (ns == 1) ? D[0] * x[mt.x] : x[mt.x] * D[r];
+      for (int c = 1; c < ns; c++) acc = acc + x[mt.x + c] * D[c * ns + r];
+      t[mt.x + r] = b[mt.x + r] - acc;
+    }
+  }
+}
+
+template <int KIND>
+int run_inode(hipxSorState *S, const double *rhs, const double *xold, double *xnew, double *xacc)
+{
+  InodeState    *T  = (InodeState *)S->inode;
+  hipStream_t    st = rt().compute;
+  const hipx_int g  = std::min<hipx_int>((S->m + 255) / 256, 4096);
+  sor_fill_kernel<<<(unsigned)g, 256, 0, st>>>(xnew, S->m);
+  HIPX_HIP(hipMemsetAsync(S->d_ctl, 0, sizeof(unsigned int), st));
+  static int waves_per_cu = 0;
+  if (!waves_per_cu) {
+    const char *e = getenv("HIPX_SOR_INODE_WAVES_PER_CU");
+    waves_per_cu  = e ? atoi(e) : 2;
+    if (waves_per_cu < 1) waves_per_cu = 1;
+    if (waves_per_cu > 32) waves_per_cu = 32;
+  }
+  unsigned       grid = (unsigned)(256 * waves_per_cu * 64 / SOR_THREADS);
+  const unsigned need = (unsigned)((T->nslots + SOR_THREADS - 1) / SOR_THREADS);
+  if (grid > need) grid = need ? need : 1;
+#define HIPX_INODE_LAUNCH(NSM) \
+  sor_inode_kernel<KIND, NSM><<<grid, SOR_THREADS, 0, st>>>(T->nslots, T->d_smeta, T->d_sks, T->d_sp, T->d_nj, T->d_nv, T->d_ibd, rhs, S->d_t, xold, xnew, xacc, S->d_ctl)
+  switch (T->nsm) {
+  case 2: HIPX_INODE_LAUNCH(2); break;
+  case 3: HIPX_INODE_LAUNCH(3); break;
+  case 4: HIPX_INODE_LAUNCH(4); break;
+  default: HIPX_INODE_LAUNCH(5); break;
+  }
+#undef HIPX_INODE_LAUNCH
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
 int build_schedule(hipxSorState *S, hipx_int m, int64_t nnz, int is64, const void *d_i, const hipx_int *d_j)
 {
   // host copy of the pattern (set-up only; the sweeps never touch the host)
@@ -2165,6 +2609,7 @@ extern "C" void hipxSorInvalidate_(void *p)
 {
   hipxSorState *S = (hipxSorState *)p;
   if (S) S->values_valid = S->idiag_valid = S->mdiag_valid = false;
+  if (S && S->inode) ((InodeState *)S->inode)->values_valid = false;
 }
 
 extern "C" void hipxSorStateFree_(void *p)
@@ -2186,6 +2631,7 @@ extern "C" void hipxSorStateFree_(void *p)
   (void)hipFree(S->d_w2);
   (void)hipFree(S->d_ctl);
   strand_free((StrandState *)S->strand);
+  inode_free((InodeState *)S->inode);
   delete S;
 }
 
@@ -2271,6 +2717,20 @@ static int mat_sor_impl(hipxMat A, const double *b, double omega, int flag, doub
     else if (e && !strcmp(e, "dep")) want = 1;
     else if (e && !strcmp(e, "strand")) want = 2;
   }
+  // a matrix with inodes, relaxed with omega == 1 and no shift: MatSOR_SeqAIJ_Inode (aij.c:1852) -- the node-level sweeps
+  bool use_inode = false;
+  if (omega == 1.0 && shift == 0.0 && !getenv("HIPX_MAT_NO_INODE")) {
+    int             istate;
+    hipx_int        nnodes;
+    const hipx_int *isz;
+    if ((ierr = hipxMatInodes_(A, &istate, &nnodes, &isz))) return ierr;
+    if (istate < 0) {  // not told: look, as MatAssemblyEnd_SeqAIJ does (inode.c:3920)
+      std::vector<hipx_int> sizes;
+      if ((ierr = inode_find(m, is64, d_i, d_j, sizes, &nnodes))) return ierr;
+      if ((ierr = hipxMatInodesFound_(A, nnodes, sizes.data()))) return ierr;
+    }
+    use_inode = nnodes > 0;
+  }
   if (S->strand_vstate != vstate) {  // new values: the templates (which carry the values) are rebuilt
     if (S->strand) {
       HIPX_HIP(hipStreamSynchronize(st));
@@ -2280,7 +2740,7 @@ static int mat_sor_impl(hipxMat A, const double *b, double omega, int flag, doub
     S->strand_tried  = false;
     S->strand_vstate = vstate;
   }
-  if ((want == -1 || want == 2) && flag != 64 && !S->strand_tried) {
+  if ((want == -1 || want == 2) && flag != 64 && !S->strand_tried && !use_inode) {
     S->strand_tried = true;
     int                  tok = 0, ntmpl = 0;
     const int           *tstart, *toff, *tdiag;
@@ -2321,7 +2781,7 @@ static int mat_sor_impl(hipxMat A, const double *b, double omega, int flag, doub
   // the variable-coefficient kernels cover the sweeps without old-value lists (kinds 0-2): zero initial guess with one iteration
   // (what PCSOR applies by default) and Eisenstat; anything else on such a matrix takes the level-ordered schedule
   const bool var_fits   = !S->strand || !((StrandState *)S->strand)->var || (flag & 32) || ((flag & 16) && (int64_t)its * (int64_t)lits == 1);
-  const bool use_strand = S->strand && var_fits && (want == -1 || want == 2) && flag != 64;
+  const bool use_strand = S->strand && var_fits && (want == -1 || want == 2) && flag != 64 && !use_inode;
   if (want == 2 && !use_strand && flag != 64) return fail(HIPX_ERR_SUP, "HIPX_SOR_MODE=strand: the matrix has no row templates / strand structure", __FILE__, __LINE__);
   if (!S->d_t) {  // work vectors shared by every mode
     HIPX_HIP(hipMalloc((void **)&S->d_t, sizeof(double) * (size_t)m));
@@ -2333,6 +2793,77 @@ static int mat_sor_impl(hipxMat A, const double *b, double omega, int flag, doub
     S->m = m;
   }
   const hipx_int g = std::min<hipx_int>((m + 255) / 256, 4096);
+  if (use_inode) {
+    if (flag & (64 | 128)) return fail(HIPX_ERR_SUP, "SOR_APPLY_UPPER / SOR_APPLY_LOWER on a matrix with inodes: MatSOR_SeqAIJ_Inode has no such branch (inode.c:2494); use -mat_no_inode", __FILE__, __LINE__);
+    InodeState *T = (InodeState *)S->inode;
+    if (!T) {
+      int             istate;
+      hipx_int        nnodes;
+      const hipx_int *isz;
+      if ((ierr = hipxMatInodes_(A, &istate, &nnodes, &isz))) return ierr;
+      T        = new InodeState;
+      S->inode = T;
+      HIPX_HIP(hipStreamSynchronize(st));
+      if ((ierr = inode_build(T, m, nnz, is64, d_i, d_j, d_diagpos, nnodes, isz))) return ierr;
+    }
+    if (!T->ready) return fail(73, "inodes: the node schedule could not be built for this matrix", __FILE__, __LINE__);
+    if (!T->values_valid) {
+      unsigned int *cnt = rt().d_tickets + (HIPX_MAX_RED_SLOTS - 1);
+      HIPX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
+      inode_pack_kernel<<<(unsigned)std::min<hipx_int>((T->nnodes + 3) / 4, 8192), 256, 0, st>>>(T->nnodes, T->nsm, T->d_nmeta, T->d_nks, d_i, is64, d_j, d_a, T->d_nj, T->d_nv);
+      HIPX_LAUNCH_CHECK();
+      inode_invert_kernel<<<(unsigned)std::min<hipx_int>((T->nnodes + 255) / 256, 4096), 256, 0, st>>>(T->nnodes, T->nsm, T->d_nmeta, d_diagpos, d_a, T->d_ibd, T->d_bd, cnt);
+      HIPX_LAUNCH_CHECK();
+      HIPX_HIP(hipMemcpyAsync(&T->zero_pivots, cnt, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+      HIPX_HIP(hipStreamSynchronize(st));
+      HIPX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
+      T->values_valid = true;
+    }
+    S->mode = S->last_mode = 3;
+    double *W = S->d_w1;
+    const size_t bytes = sizeof(double) * (size_t)m;
+    // (`lits` is not used: MatSOR_SeqAIJ_Inode never multiplies its by it)
+    if (flag & 32) {  // SOR_EISENSTAT (inode.c:3375-3806): x = (U + D)^-1 b;  t = b - D x;  t = (L + D)^-1 t;  x += t
+      if (!S->d_w2) HIPX_HIP(hipMalloc((void **)&S->d_w2, sizeof(double) * (size_t)m));
+      if ((ierr = run_inode<2>(S, b, nullptr, x, nullptr))) return ierr;
+      inode_eisenstat_mid_kernel<<<(unsigned)std::min<hipx_int>((T->nnodes + 255) / 256, 4096), 256, 0, st>>>(T->nnodes, T->nsm, T->d_nmeta, T->d_bd, b, x, W);
+      HIPX_LAUNCH_CHECK();
+      if ((ierr = run_inode<5>(S, W, nullptr, S->d_w2, x))) return ierr;
+    } else {
+      const bool fwd = (flag & 1) || (flag & 4), bwd = (flag & 2) || (flag & 8);
+      if (flag & 16) {  // SOR_ZERO_INITIAL_GUESS (inode.c:2526-2890)
+        if (fwd && bwd) {
+          if ((ierr = run_inode<0>(S, b, nullptr, W, nullptr))) return ierr;
+          if ((ierr = run_inode<1>(S, S->d_t, W, x, nullptr))) return ierr;
+        } else if (fwd) {
+          if ((ierr = run_inode<0>(S, b, nullptr, x, nullptr))) return ierr;
+        } else if (bwd) {
+          if ((ierr = run_inode<2>(S, b, nullptr, x, nullptr))) return ierr;
+        }
+        its--;
+      }
+      while (its-- > 0) {  // inode.c:2891-3374
+        if (fwd && bwd) {
+          if ((ierr = run_inode<3>(S, b, x, W, nullptr))) return ierr;
+          if ((ierr = run_inode<1>(S, S->d_t, W, x, nullptr))) return ierr;
+        } else if (fwd) {
+          if ((ierr = run_inode<3>(S, b, x, W, nullptr))) return ierr;
+          HIPX_HIP(hipMemcpyAsync(x, W, bytes, hipMemcpyDeviceToDevice, st));
+        } else if (bwd) {
+          if ((ierr = run_inode<4>(S, b, x, W, nullptr))) return ierr;
+          HIPX_HIP(hipMemcpyAsync(x, W, bytes, hipMemcpyDeviceToDevice, st));
+        }
+      }
+    }
+    unsigned int herr = 0;
+    HIPX_HIP(hipMemcpyAsync(&herr, S->d_ctl + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    HIPX_HIP(hipStreamSynchronize(st));
+    if (herr) {
+      HIPX_HIP(hipMemsetAsync(S->d_ctl, 0, 2 * sizeof(unsigned int), st));
+      return fail(HIPX_ERR_GPU, "MatSOR: a dependency was never published (wait limit reached)", __FILE__, __LINE__);
+    }
+    return HIPX_SUCCESS;
+  }
   if (use_strand) {
     StrandState *T = (StrandState *)S->strand;
     const bool plain = (omega == 1.0 && shift <= 0.0);

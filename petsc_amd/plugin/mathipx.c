@@ -91,6 +91,15 @@ PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA)
     } else PetscCall(MatSeqAIJHIPXCreateDevice(A, aa, PETSC_FALSE, &h->dA));
     PetscCall(MatSeqAIJRestoreArrayRead(A, &aa));
     if (h->spmv_variant) PetscCallHIPX(hipxMatSetSpMVVariant(h->dA, (int)h->spmv_variant));
+    /* the inodes MatAssemblyEnd_SeqAIJ found (MatSeqAIJCheckInode inode.c:3920, under -mat_no_inode / -mat_inode_limit): MatSOR_SeqAIJ
+       relaxes such a matrix node by node (aij.c:1852 -> MatSOR_SeqAIJ_Inode), and so does hipxMatSOR when it is told the partition */
+    if (a->inode.use && a->inode.checked && a->inode.node_count > 0 && a->inode.size_csr && A->rmap->n == A->cmap->n) {
+      hipx_int *ns;
+      PetscCall(PetscMalloc1((size_t)a->inode.node_count + 1, &ns));
+      for (PetscInt k = 0; k <= a->inode.node_count; k++) ns[k] = (hipx_int)a->inode.size_csr[k];
+      PetscCallHIPX(hipxMatSetInodes(h->dA, (hipx_int)a->inode.node_count, ns));
+      PetscCall(PetscFree(ns));
+    } else PetscCallHIPX(hipxMatSetInodes(h->dA, 0, NULL));
     h->nonzerostate = A->nonzerostate;
     h->valuestate   = state;
   } else if (h->valuestate != state) {

@@ -63,7 +63,7 @@ def flan_surrogate_spd(n=80, seed=1565):
     return ai, aj, aa
 
 
-def inode_matrix(nnodes=60, seed=7, sizes=(1, 2, 3, 4, 5), degree=4, pivot_blocks=True):
+def inode_matrix(nnodes=60, seed=7, sizes=(1, 2, 3, 4, 5), degree=4, pivot_blocks=True, long_run=True):
     """A matrix with INODES (runs of consecutive rows sharing one column list, what MatSeqAIJCheckInode finds: inode.c:3920): `nnodes`
     mesh nodes of 1-5 unknowns each (sizes drawn from `sizes`; one run of 7 identical rows exercises the limit of 5), every node
     coupled to itself and to ~`degree` others by dense blocks, all values distinct.  Diagonal blocks are well conditioned; with
@@ -71,7 +71,7 @@ def inode_matrix(nnodes=60, seed=7, sizes=(1, 2, 3, 4, 5), degree=4, pivot_block
     Returns CSR (ai, aj, aa) with sorted columns."""
     rng = np.random.default_rng(seed)
     sz = rng.choice(np.array(sizes), size=nnodes)
-    if nnodes > 8:
+    if nnodes > 8 and long_run:
         sz[3] = 7  # 7 identical rows: nodes of 5 + 2
     start = np.concatenate([[0], np.cumsum(sz)])
     N = int(start[-1])

@@ -259,6 +259,34 @@ def test_matload_of_a_file_into_the_hipx_types(tmp_path):
         assert max(abs(g - c) / abs(c) for g, c in zip(hg, hc)) <= 1e-12
 
 
+def test_matsor_on_a_matrix_with_inodes_is_the_reference_s_node_sweep(tmp_path):
+    """A MATSEQAIJ matrix with inodes is relaxed node by node (aij.c:1852 -> MatSOR_SeqAIJ_Inode, inode.c:2494): MatSOR of the aijhipx type
+    must print what the CPU type prints -- every sweep kind, with the partition PETSc found at assembly handed to libhipx
+    (hipxMatSetInodes), under -mat_no_inode (point sweeps on both sides) and for omega != 1 (the reference falls back to the point
+    routine) -- and KSPCG + PCSOR on the 3-unknowns-per-node stand-in must follow the CPU history."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from petsc_amd import matio
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from surrogates import flan_surrogate_spd, inode_matrix
+    ai, aj, aa = inode_matrix(nnodes=150, seed=33)
+    f = str(tmp_path / "inode.bin")
+    matio.write_petsc_binary(f, ai, aj, aa)
+    sor = lambda t: [l.split()[2] for l in t.splitlines() if l.startswith("sor ")]  # noqa: E731
+    for extra in (["-dump_sor", "28"], ["-dump_sor", "3"], ["-dump_sor", "17", "-sor_its", "2"], ["-dump_sor", "2", "-sor_its", "2"], ["-dump_sor", "32"],
+                  ["-dump_sor", "28", "-mat_no_inode"], ["-dump_sor", "28", "-sor_omega", "1.3"], ["-dump_sor", "28", "-mat_inode_limit", "2"]):
+        a = ["-f", f, "-ksp_max_it", "1"] + extra
+        cpu, gpu = sor(run("ref_driver", a)), sor(run("ref_driver", a + HIPX))
+        assert len(cpu) == len(ai) - 1 and cpu == gpu, extra
+    ai, aj, aa = flan_surrogate_spd(8)
+    f = str(tmp_path / "flan8.bin")
+    matio.write_petsc_binary(f, ai, aj, aa)
+    a = ["-f", f, "-ksp_type", "cg", "-pc_type", "sor", "-ksp_rtol", "1e-50", "-ksp_max_it", "12", "-ksp_norm_type", "preconditioned", "-history"]
+    hc, hg = hist_of(run("ref_driver", a, exact_blas=True)), hist_of(run("ref_driver", a + HIPX + ["-hipx_reductions", "exact"]))
+    assert len(hc) == 13 and len(hg) == 13
+    assert max(abs(g - c) / abs(c) for g, c in zip(hg, hc)) <= 1e-12
+
+
 @pytest.mark.parametrize("args", ["-stencil 7 -n 12 -pc_type jacobi -ksp_max_it 8", "-stencil 27 -n 10 -pc_type jacobi -ksp_max_it 5", "-stencil 5 -m 31 -n 17 -pc_type none -ksp_max_it 12",
                                   "-stencil 7 -n 12 -pc_type jacobi -ksp_max_it 1", "-stencil 7 -n 12 -pc_type jacobi -ksp_max_it 7 -ksp_initial_guess_nonzero"])
 def test_ksp_chebyshevhipx_fused_smoother_bit_identical(args):

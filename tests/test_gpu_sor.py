@@ -58,7 +58,8 @@ def sor_gpu(hx, ai, aj, aa, b, omega, flag, shift, its, lits, x0, mode=None, wan
 
 def sor_cpu(ai, aj, aa, b, omega, flag, shift, its, lits, x0):
     x = np.array(x0, dtype=np.float64)
-    orc.lib().orc_MatSOR_SeqAIJ(len(ai) - 1, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(b), C.c_double(omega), flag, C.c_double(shift), its, lits, orc.P(x))
+    # (as the reference dispatches it, aij.c:1852: the point routine for every matrix of this file -- none has inodes; tests/test_gpu_inode.py)
+    orc.lib().orc_MatSOR_SeqAIJ_dispatch(len(ai) - 1, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(b), C.c_double(omega), flag, C.c_double(shift), its, lits, orc.P(x), 0)
     return x
 
 
