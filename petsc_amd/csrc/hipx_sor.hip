@@ -2126,6 +2126,11 @@ struct InodeState {
   hipx_int *d_nj = nullptr;
   double   *d_nv = nullptr;
   double   *d_ibd = nullptr, *d_bd = nullptr;  // per node nsm * nsm: inverse / copy of the diagonal block, column-major with the NODE's size as stride
+  // the same slot tables with every level padded to 4 nodes: the cooperative kernel (16 lanes per node, 4 nodes per wave)
+  hipx_int  nslots4 = 0;
+  int4     *d_smeta4 = nullptr;
+  int64_t  *d_sks4 = nullptr;
+  hipx_int *d_sp4 = nullptr;
   unsigned int zero_pivots = 0;
   int64_t   nentries = 0;
 };
@@ -2142,6 +2147,9 @@ void inode_free(InodeState *T)
   (void)hipFree(T->d_nv);
   (void)hipFree(T->d_ibd);
   (void)hipFree(T->d_bd);
+  (void)hipFree(T->d_smeta4);
+  (void)hipFree(T->d_sks4);
+  (void)hipFree(T->d_sp4);
   delete T;
 }
 
@@ -2249,21 +2257,25 @@ int inode_build(InodeState *T, hipx_int m, int64_t nnz, int is64, const void *d_
     nmeta[p]   = make_int4(r0, sizes[u + 1] - r0, (int)(hd[r0] - hi[r0]), (int)(hi[r0 + 1] - hi[r0]));
     nks[p + 1] = nks[p] + (hi[r0 + 1] - hi[r0]);
   }
-  std::vector<int4>     smeta;
-  std::vector<int64_t>  sks;
-  std::vector<hipx_int> sp;
-  for (hipx_int l = 0; l < nlev; l++) {
-    for (hipx_int p = lp[l]; p < lp[l + 1]; p++) {
-      smeta.push_back(nmeta[p]);
-      sks.push_back(nks[p]);
-      sp.push_back(p);
+  std::vector<int4>     smeta, smeta4;
+  std::vector<int64_t>  sks, sks4;
+  std::vector<hipx_int> sp, sp4;
+  const auto slots = [&](size_t pad, std::vector<int4> &sm, std::vector<int64_t> &sk, std::vector<hipx_int> &spp) {
+    for (hipx_int l = 0; l < nlev; l++) {
+      for (hipx_int p = lp[l]; p < lp[l + 1]; p++) {
+        sm.push_back(nmeta[p]);
+        sk.push_back(nks[p]);
+        spp.push_back(p);
+      }
+      while (sm.size() % pad) {
+        sm.push_back(make_int4(-1, 0, 0, 0));
+        sk.push_back(0);
+        spp.push_back(0);
+      }
     }
-    while (smeta.size() % 64) {
-      smeta.push_back(make_int4(-1, 0, 0, 0));
-      sks.push_back(0);
-      sp.push_back(0);
-    }
-  }
+  };
+  slots(64, smeta, sks, sp);
+  slots(4, smeta4, sks4, sp4);
   T->nnodes   = nnodes;
   T->nlevels  = nlev;
   T->nslots   = (hipx_int)smeta.size();
@@ -2284,6 +2296,13 @@ int inode_build(InodeState *T, hipx_int m, int64_t nnz, int is64, const void *d_
   HIPX_HIP(hipMemcpy(T->d_smeta, smeta.data(), sizeof(int4) * smeta.size(), hipMemcpyHostToDevice));
   HIPX_HIP(hipMemcpy(T->d_sks, sks.data(), sizeof(int64_t) * sks.size(), hipMemcpyHostToDevice));
   HIPX_HIP(hipMemcpy(T->d_sp, sp.data(), sizeof(hipx_int) * sp.size(), hipMemcpyHostToDevice));
+  T->nslots4 = (hipx_int)smeta4.size();
+  HIPX_HIP(hipMalloc((void **)&T->d_smeta4, sizeof(int4) * std::max<size_t>(smeta4.size(), 1)));
+  HIPX_HIP(hipMalloc((void **)&T->d_sks4, sizeof(int64_t) * std::max<size_t>(sks4.size(), 1)));
+  HIPX_HIP(hipMalloc((void **)&T->d_sp4, sizeof(hipx_int) * std::max<size_t>(sp4.size(), 1)));
+  HIPX_HIP(hipMemcpy(T->d_smeta4, smeta4.data(), sizeof(int4) * smeta4.size(), hipMemcpyHostToDevice));
+  HIPX_HIP(hipMemcpy(T->d_sks4, sks4.data(), sizeof(int64_t) * sks4.size(), hipMemcpyHostToDevice));
+  HIPX_HIP(hipMemcpy(T->d_sp4, sp4.data(), sizeof(hipx_int) * sp4.size(), hipMemcpyHostToDevice));
   T->ready = true;
   return HIPX_SUCCESS;
 }
@@ -2497,6 +2516,135 @@ __global__ __launch_bounds__(SOR_THREADS) void sor_inode_kernel(hipx_int nslots,
   }
 }
 
+// The cooperative form (default): 16 lanes per node, 4 nodes per wave.  With one lane per node a lane walks its ~40 entries in chunks and
+// every chunk's loads wait behind the polls of the chunk before: ~13 us per dependency level on the elasticity stand-in (1344 levels).
+// Here the PAIRS of a segment are dealt round-robin to the node's 16 lanes -- all column, value and operand loads of (up to) 64 entries in
+// flight at once, coalesced -- each lane forms its pairs' terms q = a[k] x[j_k] + a[k+1] x[j_k+1] for the node's rows and parks them in
+// LDS; then every lane of the group runs the SAME sequential chain sum_r -= q_r over the pairs in their order (LDS broadcasts), so the
+// rounding is the reference's; lane r < (rows of the node) then owns row r: block row times the sums, publish.  Waves take tickets in
+// level order; with 8 waves per SIMD-slot-free CU the loads of ~20 levels ahead are already waiting in their polls.
+constexpr int INO_G = 16, INO_R = 2, INO_CHP = INO_G * INO_R;  // lanes per node, pairs per lane and chunk, pairs per chunk
+
+template <int NSM, int SRC>
+__device__ __forceinline__ void inode_coop_minus(double (&sum)[NSM], double (*Q)[NSM], const int l, int64_t k0, int64_t k1, hipx_int thr, const hipx_int *__restrict__ nj,
+                                                 const double *__restrict__ nv, const double *xold, const double *xnew, unsigned int *err)
+{
+  for (int64_t kc = k0; kc < k1; kc += 2 * INO_CHP) {
+    const int cnt = (int)((k1 - kc) < 2 * INO_CHP ? (k1 - kc) : 2 * INO_CHP);  // entries of this chunk
+    const int np  = (cnt + 1) >> 1;
+    hipx_int  j0[INO_R], j1[INO_R];
+    double    a0[INO_R][NSM], a1[INO_R][NSM], x0[INO_R], x1[INO_R];
+    bool      v0[INO_R], v1[INO_R];
+#pragma unroll
+    for (int rr = 0; rr < INO_R; rr++) {
+      const int q = l + rr * INO_G;
+      v0[rr]      = 2 * q < cnt;
+      v1[rr]      = 2 * q + 1 < cnt;
+      const int64_t e0 = v0[rr] ? kc + 2 * q : k0, e1 = v1[rr] ? kc + 2 * q + 1 : e0;
+      j0[rr] = nj[e0];
+      j1[rr] = nj[e1];
+#pragma unroll
+      for (int r = 0; r < NSM; r++) {
+        a0[rr][r] = nv[e0 * NSM + r];
+        a1[rr][r] = nv[e1 * NSM + r];
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < INO_R; rr++) {
+      const bool d0 = SRC == 0 || (SRC == 2 && j0[rr] >= thr), d1 = SRC == 0 || (SRC == 2 && j1[rr] >= thr);
+      if (d0) x0[rr] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(xnew + j0[rr]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      else x0[rr] = xold[j0[rr]];
+      if (d1) x1[rr] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(xnew + j1[rr]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      else x1[rr] = xold[j1[rr]];
+    }
+#pragma unroll
+    for (int rr = 0; rr < INO_R; rr++) {
+      const bool d0 = SRC == 0 || (SRC == 2 && j0[rr] >= thr), d1 = SRC == 0 || (SRC == 2 && j1[rr] >= thr);
+      if (v0[rr] && d0 && (unsigned long long)__double_as_longlong(x0[rr]) == SOR_SENTINEL) x0[rr] = sor_poll(xnew + j0[rr], err);
+      if (v1[rr] && d1 && (unsigned long long)__double_as_longlong(x1[rr]) == SOR_SENTINEL) x1[rr] = sor_poll(xnew + j1[rr], err);
+    }
+#pragma unroll
+    for (int rr = 0; rr < INO_R; rr++) {
+      const int q = l + rr * INO_G;
+      if (v0[rr]) {
+#pragma unroll
+        for (int r = 0; r < NSM; r++) {
+          const double p0 = a0[rr][r] * x0[rr];
+          Q[q][r]         = v1[rr] ? p0 + a1[rr][r] * x1[rr] : p0;  // the last odd entry of a segment stands alone (inode.c:2603-2608)
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int q = 0; q < np; q++) {
+#pragma unroll
+      for (int r = 0; r < NSM; r++) sum[r] -= Q[q][r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+template <int KIND, int NSM>
+__global__ __launch_bounds__(SOR_THREADS) void sor_inode_coop_kernel(hipx_int nslots, const int4 *__restrict__ smeta, const int64_t *__restrict__ sks, const hipx_int *__restrict__ sp,
+                                                                      const hipx_int *__restrict__ nj, const double *__restrict__ nv, const double *__restrict__ ibd, const double *rhs,
+                                                                      double *t, const double *xold, double *xnew, double *xacc, unsigned int *ctl)
+{
+  constexpr bool FWD = (KIND == 0 || KIND == 3 || KIND == 5);
+  __shared__ double s_q[SOR_THREADS / 64][64 / INO_G][INO_CHP][NSM];
+  unsigned int  *err = ctl + 1;
+  const int      lane = threadIdx.x & 63, wv = threadIdx.x >> 6, grp = lane / INO_G, l = lane % INO_G;
+  double(*Q)[NSM]     = s_q[wv][grp];
+  const hipx_int ngroups = nslots / (64 / INO_G);
+  for (;;) {
+    unsigned int v = 0;
+    if (lane == 0) v = atomicAdd(&ctl[0], 1u);
+    v = __shfl(v, 0, 64);
+    if ((hipx_int)v >= ngroups) return;
+    const hipx_int g  = (hipx_int)v * (64 / INO_G) + grp;
+    const hipx_int s  = FWD ? g : nslots - 1 - g;
+    const int4     mt = smeta[s];
+    if (mt.x >= 0) {
+      const int64_t  ks = sks[s];
+      const hipx_int r0 = mt.x;
+      const int      ns = mt.y;
+      const double  *D  = ibd + (size_t)sp[s] * (size_t)(NSM * NSM);
+      double         sum[NSM];
+#pragma unroll
+      for (int r = 0; r < NSM; r++) sum[r] = (r < ns) ? rhs[r0 + r] : 0.0;
+      double dcol[NSM];  // row l of the block inverse: D^-1[l, c] = D[c * ns + l]
+#pragma unroll
+      for (int c = 0; c < NSM; c++) dcol[c] = (l < ns && c < ns) ? D[c * ns + l] : 0.0;
+      const double xo = (KIND == 4 && l < ns) ? xold[r0 + l] : 0.0;
+      if (KIND == 0 || KIND == 3 || KIND == 5) {
+        inode_coop_minus<NSM, 0>(sum, Q, l, ks, ks + mt.z, 0, nj, nv, xold, xnew, err);
+        if (KIND != 5 && l < ns) {
+          double sl = sum[0];
+#pragma unroll
+          for (int c = 1; c < NSM; c++) sl = (l == c) ? sum[c] : sl;
+          t[r0 + l] = sl;
+        }
+        if (KIND == 3) inode_coop_minus<NSM, 1>(sum, Q, l, ks + mt.z + ns, ks + mt.w, 0, nj, nv, xold, xnew, err);
+      } else if (KIND == 1 || KIND == 2) {
+        inode_coop_minus<NSM, 0>(sum, Q, l, ks + mt.z + ns, ks + mt.w, 0, nj, nv, xold, xnew, err);
+      } else {
+        inode_coop_minus<NSM, 2>(sum, Q, l, ks, ks + mt.w, r0 + ns, nj, nv, xold, xnew, err);
+      }
+      if (l < ns) {
+        double acc = sum[0] * dcol[0];
+#pragma unroll
+        for (int c = 1; c < NSM; c++)
+          if (c < ns) acc = acc + sum[c] * dcol[c];
+        if (KIND == 4) acc = xo + acc;
+        sor_publish(xnew + r0 + l, acc);
+        if (KIND == 5) xacc[r0 + l] += acc;
+      }
+    }
+  }
+}
+
 // Eisenstat's middle step on the nodes (inode.c:3559-3628): t = b - D x, the block product summed over the node's columns in ascending order
 __global__ void inode_eisenstat_mid_kernel(hipx_int nnodes, int nsm, const int4 *__restrict__ nmeta, const double *__restrict__ bd, const double *__restrict__ b, const double *__restrict__ x,
                                            double *__restrict__ t)
@@ -2531,6 +2679,32 @@ int run_inode(hipxSorState *S, const double *rhs, const double *xold, double *xn
   unsigned       grid = (unsigned)(256 * waves_per_cu * 64 / SOR_THREADS);
   const unsigned need = (unsigned)((T->nslots + SOR_THREADS - 1) / SOR_THREADS);
   if (grid > need) grid = need ? need : 1;
+  int coop = 1, coop_blocks = 256;  // workgroups of 4 waves; measured on the elasticity stand-in (symmetric sweep): 256 (one per CU) 7.2 ms, 512: 8.1, 1024: 13.4,
+                                    // 2048: 18.8 -- pollers crowd out the publishers
+  {
+    const char *e = getenv("HIPX_SOR_INODE_COOP");  // 0: one lane per node (the first form of this schedule: 34.8 ms)
+    if (e) coop = atoi(e);
+    e = getenv("HIPX_SOR_INODE_COOP_BLOCKS");
+    if (e) coop_blocks = atoi(e);
+    if (coop_blocks < 1) coop_blocks = 1;
+    if (coop_blocks > 4096) coop_blocks = 4096;
+  }
+  if (coop) {
+    unsigned       cgrid = (unsigned)coop_blocks;
+    const unsigned cneed = (unsigned)((T->nslots4 / (64 / INO_G) * 64 + SOR_THREADS - 1) / SOR_THREADS);
+    if (cgrid > cneed) cgrid = cneed ? cneed : 1;
+#define HIPX_INODE_COOP(NSM) \
+  sor_inode_coop_kernel<KIND, NSM><<<cgrid, SOR_THREADS, 0, st>>>(T->nslots4, T->d_smeta4, T->d_sks4, T->d_sp4, T->d_nj, T->d_nv, T->d_ibd, rhs, S->d_t, xold, xnew, xacc, S->d_ctl)
+    switch (T->nsm) {
+    case 2: HIPX_INODE_COOP(2); break;
+    case 3: HIPX_INODE_COOP(3); break;
+    case 4: HIPX_INODE_COOP(4); break;
+    default: HIPX_INODE_COOP(5); break;
+    }
+#undef HIPX_INODE_COOP
+    HIPX_LAUNCH_CHECK();
+    return HIPX_SUCCESS;
+  }
 #define HIPX_INODE_LAUNCH(NSM) \
   sor_inode_kernel<KIND, NSM><<<grid, SOR_THREADS, 0, st>>>(T->nslots, T->d_smeta, T->d_sks, T->d_sp, T->d_nj, T->d_nv, T->d_ibd, rhs, S->d_t, xold, xnew, xacc, S->d_ctl)
   switch (T->nsm) {
