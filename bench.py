@@ -674,9 +674,12 @@ def leg_surrogate_spmv(hx, lib):
     y = Y.get()
     rows = np.random.default_rng(4).integers(0, N, 1500)
     bad = 0
-    for r in rows:  # MatMult_SeqAIJ aij.c:1486-1494: left-to-right sum of rounded products, starting from 0
-        s = 0.0
-        for k in range(ai[r], ai[r + 1]):
+    for r in rows:  # three unknowns per node = a matrix with inodes: MatMult_SeqAIJ_Inode's row sums (inode.c:398-411: the terms in pairs, a last odd one alone)
+        s, k, e = 0.0, int(ai[r]), int(ai[r + 1])
+        while k + 1 < e:
+            s += aa[k] * xh[aj[k]] + aa[k + 1] * xh[aj[k + 1]]
+            k += 2
+        if k < e:
             s += aa[k] * xh[aj[k]]
         bad += int(s != y[r])
     ms = tot.value / max(cnt.value, 1)

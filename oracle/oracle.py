@@ -67,10 +67,21 @@ def stencil(kind, n, rstart=None, rend=None, m=None):
     return ai, aj[:nz], aa[:nz]
 
 
-def matmult(ai, aj, aa, x):
-    y = np.zeros(len(ai) - 1)
-    lib().orc_MatMult_SeqAIJ(len(ai) - 1, P(ai), P(aj), P(aa), P(x), P(y))
-    return y
+def matmult(ai, aj, aa, x, no_inode=False):
+    """MatMult as the reference's MATSEQAIJ dispatches it (aij.c:1459): see matmult_ref (the same function; scalar stencils have no inodes)."""
+    return matmult_ref(ai, aj, aa, x, no_inode=no_inode)
+
+
+def matmult_ref(ai, aj, aa, x, yadd=None, no_inode=False):
+    """y = A x (or yadd + A x) as the reference's MATSEQAIJ dispatches it (aij.c:1459, 1617): MatMult_SeqAIJ_Inode's pairwise row sums when
+    the matrix has inodes (runs of rows with one column list, inode.c:3920; never on a scalar stencil), MatMult_SeqAIJ's left-to-right
+    sums otherwise or with no_inode (-mat_no_inode)."""
+    m = len(ai) - 1
+    z = np.zeros(m)
+    xx = np.ascontiguousarray(x, dtype=np.float64)
+    yy = None if yadd is None else np.ascontiguousarray(yadd, dtype=np.float64)
+    lib().orc_MatMult_SeqAIJ_dispatch(m, P(ai), P(aj), P(aa), P(xx), None if yy is None else P(yy), P(z), 1 if no_inode else 0)
+    return z
 
 
 def ksp_solve(kind, ai, aj, aa, b, pc="jacobi", rtol=1e-5, max_it=10000, normtype=1, restart=30, refine=0, sor_flag=12, omega=1.0,

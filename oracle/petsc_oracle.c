@@ -344,6 +344,21 @@ void orc_MatMult_SeqAIJ_Inode(OInt m, const OInt *ai, const OInt *aj, const OSca
   }
 }
 
+/* MatMultAdd_SeqAIJ_Inode (inode.c:563-760): z = y + A x with the same pairing, every row's sum starting from y_i */
+void orc_MatMultAdd_SeqAIJ_Inode(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, const OScalar *x, const OScalar *y, OScalar *z)
+{
+  for (OInt i = 0; i < m; i++) {
+    const OInt     sz  = ai[i + 1] - ai[i];
+    const OInt    *idx = aj + ai[i];
+    const OScalar *v   = aa + ai[i];
+    OScalar        sum = y[i];
+    OInt           n;
+    for (n = 0; n < sz - 1; n += 2) sum += v[n] * x[idx[n]] + v[n + 1] * x[idx[n + 1]];
+    if (n == sz - 1) sum += v[n] * x[idx[n]];
+    z[i] = sum;
+  }
+}
+
 /* MatSeqAIJCheckInode (inode.c:3920-3985): consecutive rows with the same column list form a node of at most `limit` rows
    (-mat_inode_limit, default 5).  ns[0..node_count] receives the row offsets of the nodes (size_csr).  Returns node_count, or 0
    when the reference does NOT use the inode routines: no rows, or more than 0.8 m nodes (inode.c:3962). */
@@ -595,6 +610,25 @@ int orc_MatSOR_SeqAIJ_Inode(OInt m, const OInt *ai, const OInt *aj, const OScala
   free(bdiag);
   free(boff);
   return zero;
+}
+
+/* MatMult / MatMultAdd on a MATSEQAIJ matrix as the reference dispatches them (aij.c:1459, 1617): the inode routines when the matrix
+   has inodes (default limit 5; no_inode = -mat_no_inode).  y == NULL: MatMult. */
+void orc_MatMult_SeqAIJ_dispatch(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, const OScalar *x, const OScalar *y, OScalar *z, int no_inode)
+{
+  int inode = 0;
+  if (!no_inode && m > 0) {
+    OInt *ns = (OInt *)malloc((size_t)(m + 1) * sizeof(OInt));
+    inode    = orc_MatSeqAIJCheckInode(m, ai, aj, 5, ns) > 0;
+    free(ns);
+  }
+  if (inode) {
+    if (y) orc_MatMultAdd_SeqAIJ_Inode(m, ai, aj, aa, x, y, z);
+    else orc_MatMult_SeqAIJ_Inode(m, ai, aj, aa, x, z);
+  } else {
+    if (y) orc_MatMultAdd_SeqAIJ(m, ai, aj, aa, x, y, z);
+    else orc_MatMult_SeqAIJ(m, ai, aj, aa, x, z);
+  }
 }
 
 /* MatSOR on a MATSEQAIJ matrix as the reference dispatches it (aij.c:1852): the inode routine when the matrix has inodes (checked

@@ -83,6 +83,8 @@ int  orc_MatSOR_SeqAIJ(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa
                        OInt its, OInt lits, OScalar *x);                                                                                /* aij.c:1797-2007 */
 /* inodes: what MATSEQAIJ does with runs of rows that share their column list (blocked FEM matrices) */
 void orc_MatMult_SeqAIJ_Inode(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, const OScalar *x, OScalar *y);                 /* inode.c:356-560 */
+void orc_MatMultAdd_SeqAIJ_Inode(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, const OScalar *x, const OScalar *y, OScalar *z); /* inode.c:563-760 */
+void orc_MatMult_SeqAIJ_dispatch(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, const OScalar *x, const OScalar *y, OScalar *z, int no_inode); /* aij.c:1459, 1617 */
 OInt orc_MatSeqAIJCheckInode(OInt m, const OInt *ai, const OInt *aj, OInt limit, OInt *ns);                                             /* inode.c:3920-3985 */
 int  orc_inode_invert_block(OScalar *a, int n);                                                                                         /* dgefa2.c:14 ... dgefa5.c:14 */
 int  orc_MatSOR_SeqAIJ_Inode(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, OInt node_count, const OInt *ns, const OScalar *b, OScalar omega,

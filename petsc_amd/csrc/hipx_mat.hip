@@ -158,7 +158,8 @@ extern "C" void     hipxSellValuesChanged_(void *p);
 extern "C" void     hipxSellInvalidate_(void *p);
 extern "C" int      hipxSellEnsure_(hipxMat A, void **slot, int *ok, int *packed, double *pad_ratio, int64_t *bytes);
 extern "C" hipx_int hipxSellDotPartials_(void *p);
-extern "C" int      hipxSellLaunch_(void *p, int mode, int dot, const double *x, const double *yin, double *yout, double *dotpart);
+extern "C" int      hipxSellLaunch_(void *p, int mode, int dot, const double *x, const double *yin, double *yout, double *dotpart, int pair);
+extern "C" int      hipxMatEnsureInodes_(hipxMat A);  // hipx_sor.hip: looks for inodes if nobody has said (MatSeqAIJCheckInode)
 extern "C" void hipxSorInvalidate_(void *p);
 
 namespace {
@@ -3494,14 +3495,71 @@ int use_sell(hipxMat A, bool &use, bool auto_stage = false)
   return HIPX_SUCCESS;
 }
 
+// A matrix with inodes: the reference multiplies it with MatMult_SeqAIJ_Inode / MatMultAdd_SeqAIJ_Inode (aij.c:1459, 1617; inode.c:356-760),
+// whose row sums take the terms in pairs -- rounding-level differences from MatMult_SeqAIJ's left-to-right sums, so these matrices keep
+// to the two kernel forms that know that order: the SELL-64 copy (what long FEM rows get anyway) or, where it does not apply, a plain
+// row-per-lane CSR kernel.  The kernel variants of hipxMatSetSpMVVariant are forms of the LEFT-TO-RIGHT sum: they apply once the matrix
+// is declared free of inodes (hipxMatSetInodes(A, 0, NULL) = -mat_no_inode).
+int use_inode_pair(hipxMat A, bool &use, bool &sell)
+{
+  use = sell = false;
+  if (A->compressed || A->probe) return HIPX_SUCCESS;
+  if (getenv("HIPX_MAT_NO_INODE")) return HIPX_SUCCESS;  // developer switch, read per call (tests flip it): every matrix as under -mat_no_inode
+  int ierr;
+  if (A->inode_state < 0 && (ierr = hipxMatEnsureInodes_(A))) return ierr;
+  if (A->inode_state != 1) return HIPX_SUCCESS;
+  use = true;
+  {
+    int     ok = 0, packed = 0;
+    double  pad = 0.0;
+    int64_t bytes = 0;
+    if ((ierr = hipxSellEnsure_(A, &A->sell_state, &ok, &packed, &pad, &bytes))) return ierr;
+    sell = ok != 0;
+  }
+  return HIPX_SUCCESS;
+}
+
+template <typename IT, int MODE, bool DOT>
+__global__ __launch_bounds__(256) void spmv_inode_kernel(hipx_int m, const IT *__restrict__ ai, const hipx_int *__restrict__ aj, const double *__restrict__ aa, const double *__restrict__ x,
+                                                        const double *yin, double *yout, double *dotpart)
+{
+  const hipx_int row = (hipx_int)blockIdx.x * 256 + threadIdx.x;
+  double         sum = 0.0, p = 0.0;
+  if (row < m) {
+    const int64_t s = (int64_t)ai[row], e = (int64_t)ai[row + 1];
+    if (MODE == 1) sum = yin[row];
+    int64_t k = s;
+    for (; k + 1 < e; k += 2) sum += aa[k] * x[aj[k]] + aa[k + 1] * x[aj[k + 1]];
+    if (k < e) sum += aa[k] * x[aj[k]];
+    yout[row] = sum;
+    if (DOT) p = x[row] * sum;
+  }
+  if (DOT) {
+    const double t = hipx::wave_sum(p);
+    if ((threadIdx.x & 63) == 0) dotpart[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = t;
+  }
+}
+
 template <typename IT, int MODE, bool DOT>
 int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
 {
   {
+    bool ip = false, ips = false;
+    int  ierr = use_inode_pair(A, ip, ips);
+    if (ierr) return ierr;
+    if (ip && ips) return hipxSellLaunch_(A->sell_state, MODE, DOT ? 1 : 0, x, yin, yout, dotpart, 1);
+    if (ip) {
+      if (!A->m) return HIPX_SUCCESS;
+      spmv_inode_kernel<IT, MODE, DOT><<<(unsigned)((A->m + 255) / 256), 256, 0, rt().compute>>>(A->m, (const IT *)A->d_i, A->d_j, A->d_a, x, yin, yout, dotpart);
+      HIPX_LAUNCH_CHECK();
+      return HIPX_SUCCESS;
+    }
+  }
+  {
     bool sl = false;
     int  ierr = use_sell(A, sl);
     if (ierr) return ierr;
-    if (sl) return hipxSellLaunch_(A->sell_state, MODE, DOT ? 1 : 0, x, yin, yout, dotpart);
+    if (sl) return hipxSellLaunch_(A->sell_state, MODE, DOT ? 1 : 0, x, yin, yout, dotpart, 0);
   }
   {
     bool tm = false;
@@ -3519,7 +3577,7 @@ int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, d
     bool sl = false;
     int  ierr = use_sell(A, sl, true);
     if (ierr) return ierr;
-    if (sl) return hipxSellLaunch_(A->sell_state, MODE, DOT ? 1 : 0, x, yin, yout, dotpart);
+    if (sl) return hipxSellLaunch_(A->sell_state, MODE, DOT ? 1 : 0, x, yin, yout, dotpart, 0);
   }
   if (A->tile_mode >= 2 && !A->compressed && (!A->probe || A->vd_mode)) return launch_pk16<IT, MODE, DOT>(A, x, yin, yout, dotpart);
   if (A->probe && MODE == 0 && !DOT && !A->compressed && !A->is64) {
@@ -3545,6 +3603,15 @@ int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, d
 int dot_partials_count(hipxMat A, hipx_int *npart)
 {
   int cfg, waves;
+  {
+    bool ip = false, ips = false;
+    int  ierr = use_inode_pair(A, ip, ips);
+    if (ierr) return ierr;
+    if (ip) {
+      *npart = ips ? hipxSellDotPartials_(A->sell_state) : (hipx_int)((A->m + 255) / 256) * 4;
+      return HIPX_SUCCESS;
+    }
+  }
   {
     bool sl = false;
     int  ierr = use_sell(A, sl);
@@ -3964,6 +4031,16 @@ int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
   HIPX_CHECK_INIT();
   HIPX_ARG(A && buf && len > 0, "null argument");
   const char *name = "spmv_stream_kernel (CSR MatMult, 32-bit columns)";
+  {
+    bool ip = false, ips = false;
+    int  ierr = use_inode_pair(A, ip, ips);
+    if (ierr) return ierr;
+    if (ip) {
+      snprintf(buf, len, "%s", ips ? "spmv_sell_kernel (MatMult on the SELL-64 copy: one lane per row, 16-bit window-coded columns; matrix with inodes: pairwise row sums of MatMult_SeqAIJ_Inode)"
+                                   : "spmv_inode_kernel (CSR MatMult, one lane per row; matrix with inodes: pairwise row sums of MatMult_SeqAIJ_Inode)");
+      return HIPX_SUCCESS;
+    }
+  }
   bool        tm   = false;
   {
     int ierr = use_templates(A, tm);

@@ -201,7 +201,9 @@ __global__ __launch_bounds__(256) void sell_values_kernel(hipx_int m, hipx_int n
 
 // MODE 0: y = A x; MODE 1: z = y + A x (the sum starts from y_i, aij.c:1648).  DOT: one partial of x . y per slice (fixed order).
 // U entries per pass: U value loads + U / 4 code loads in flight, then U gathers in flight.
-template <int MODE, bool DOT, bool PACK, int U, bool TRI = false>
+// PAIR: the row sums of MatMult_SeqAIJ_Inode / MatMultAdd_SeqAIJ_Inode (inode.c:356-560, 563-760), which the reference runs on a matrix with
+// inodes (aij.c:1459, 1617): the terms enter in pairs, sum += a[k] x[j_k] + a[k+1] x[j_k+1], a last odd term alone.
+template <int MODE, bool DOT, bool PACK, int U, bool TRI = false, bool PAIR = false>
 __global__ __launch_bounds__(256) void spmv_sell_kernel(hipx_int m, hipx_int nslices, hipx_int slices_per_xcd, const int64_t *__restrict__ soff, const int64_t *__restrict__ coff,
                                                         const unsigned short *__restrict__ lens, const double *__restrict__ val, const unsigned short *__restrict__ col16,
                                                         const hipx_int *__restrict__ base, const hipx_int *__restrict__ col32, const double *__restrict__ x, const double *yin, double *yout,
@@ -259,9 +261,18 @@ __global__ __launch_bounds__(256) void spmv_sell_kernel(hipx_int m, hipx_int nsl
     double xv[U];
 #pragma unroll
     for (int e = 0; e < U; e++) xv[e] = (k + e < len) ? x[c[e]] : 0.0;
+    if (PAIR) {
+      static_assert(U % 2 == 0, "pairs never straddle passes");
 #pragma unroll
-    for (int e = 0; e < U; e++)
-      if (k + e < len) sum += a[e] * xv[e];  // product rounded, then the sum: left to right in the row's CSR order
+      for (int e = 0; e < U; e += 2) {
+        if (k + e + 1 < len) sum += a[e] * xv[e] + a[e + 1] * xv[e + 1];
+        else if (k + e < len) sum += a[e] * xv[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < U; e++)
+        if (k + e < len) sum += a[e] * xv[e];  // product rounded, then the sum: left to right in the row's CSR order
+    }
   }
   if (row < m) yout[row] = sum;
   if (DOT) {
@@ -422,13 +433,31 @@ int hipxSellEnsure_(hipxMat A, void **slot, int *ok, int *packed, double *pad_ra
 
 hipx_int hipxSellDotPartials_(void *p) { return p ? ((SellState *)p)->nslices : 0; }
 
-int hipxSellLaunch_(void *p, int mode, int dot, const double *x, const double *yin, double *yout, double *dotpart)
+int hipxSellLaunch_(void *p, int mode, int dot, const double *x, const double *yin, double *yout, double *dotpart, int pair)
 {
   SellState *S = (SellState *)p;
   if (!S || !S->ok) return fail(HIPX_ERR_ORDER, "SELL copy not built", __FILE__, __LINE__);
   const hipx_int spx  = (((S->nslices + 7) / 8) + 3) / 4 * 4;  // slices per XCD, whole workgroups
   const unsigned grid = (unsigned)((spx / 4) * 8);
   static const int u = getenv("HIPX_SELL_U") ? atoi(getenv("HIPX_SELL_U")) : 8;
+  if (pair) {  // a matrix with inodes: the pairwise row sums of MatMult_SeqAIJ_Inode
+#define HIPX_SELL_PAIR(MODE, DOT) \
+  do { \
+    if (S->tri && S->packed) \
+      spmv_sell_kernel<MODE, DOT, true, 12, true, true><<<grid, 256, 0, rt().compute>>>(S->m, S->nslices, spx, S->d_soff, S->d_coff, S->d_len, S->d_val, S->d_col16, S->d_base, S->d_col32, x, yin, yout, dotpart); \
+    else if (S->packed) \
+      spmv_sell_kernel<MODE, DOT, true, 8, false, true><<<grid, 256, 0, rt().compute>>>(S->m, S->nslices, spx, S->d_soff, S->d_coff, S->d_len, S->d_val, S->d_col16, S->d_base, S->d_col32, x, yin, yout, dotpart); \
+    else \
+      spmv_sell_kernel<MODE, DOT, false, 8, false, true><<<grid, 256, 0, rt().compute>>>(S->m, S->nslices, spx, S->d_soff, S->d_coff, S->d_len, S->d_val, S->d_col16, S->d_base, S->d_col32, x, yin, yout, dotpart); \
+  } while (0)
+    if (mode == 0 && !dot) HIPX_SELL_PAIR(0, false);
+    else if (mode == 0) HIPX_SELL_PAIR(0, true);
+    else if (!dot) HIPX_SELL_PAIR(1, false);
+    else HIPX_SELL_PAIR(1, true);
+#undef HIPX_SELL_PAIR
+    HIPX_LAUNCH_CHECK();
+    return HIPX_SUCCESS;
+  }
   if (S->tri && S->packed) {  // one code per run of three entries, 12 entries per pass
 #define HIPX_SELL_TRI(MODE, DOT) \
   spmv_sell_kernel<MODE, DOT, true, 12, true><<<grid, 256, 0, rt().compute>>>(S->m, S->nslices, spx, S->d_soff, S->d_coff, S->d_len, S->d_val, S->d_col16, S->d_base, S->d_col32, x, yin, yout, dotpart)

@@ -2816,6 +2816,29 @@ int hipxMatPatternTemplates_(hipxMat A, int *ok, int *ntmpl, const int **tstart,
                              const int **d_tstart, const int **d_toff);
 }
 
+// the inode partition of a matrix nobody has described yet: looked for as MatAssemblyEnd_SeqAIJ does (hipx_mat.hip asks before its first product)
+extern "C" int hipxMatEnsureInodes_(hipxMat A)
+{
+  hipx_int           m, n;
+  int64_t            nnz;
+  int                is64, diag_dense, compressed, istate;
+  void              *d_i;
+  hipx_int          *d_j, nnodes;
+  const hipx_int    *isz;
+  double            *d_a;
+  int64_t           *d_diagpos;
+  void             **slot;
+  unsigned long long vstate;
+  int ierr = hipxMatInternal_(A, &m, &n, &nnz, &is64, &d_i, &d_j, &d_a, &d_diagpos, &diag_dense, &compressed, &slot, &vstate);
+  if (ierr) return ierr;
+  if ((ierr = hipxMatInodes_(A, &istate, &nnodes, &isz))) return ierr;
+  if (istate >= 0) return HIPX_SUCCESS;
+  std::vector<hipx_int> sizes;
+  nnodes = 0;
+  if (!compressed && (ierr = inode_find(m, is64, d_i, d_j, sizes, &nnodes))) return ierr;
+  return hipxMatInodesFound_(A, nnodes, sizes.data());
+}
+
 // schedule the last hipxMatSOR call used: 0 one launch per level, 1 level-ordered dependency-driven, 2 strands; -1 = none yet
 extern "C" int hipxMatGetSORMode(hipxMat A, int *mode)
 {
@@ -2899,9 +2922,8 @@ static int mat_sor_impl(hipxMat A, const double *b, double omega, int flag, doub
     const hipx_int *isz;
     if ((ierr = hipxMatInodes_(A, &istate, &nnodes, &isz))) return ierr;
     if (istate < 0) {  // not told: look, as MatAssemblyEnd_SeqAIJ does (inode.c:3920)
-      std::vector<hipx_int> sizes;
-      if ((ierr = inode_find(m, is64, d_i, d_j, sizes, &nnodes))) return ierr;
-      if ((ierr = hipxMatInodesFound_(A, nnodes, sizes.data()))) return ierr;
+      if ((ierr = hipxMatEnsureInodes_(A))) return ierr;
+      if ((ierr = hipxMatInodes_(A, &istate, &nnodes, &isz))) return ierr;
     }
     use_inode = nnodes > 0;
   }

@@ -200,6 +200,7 @@ static PetscErrorCode MatSeqAIJHIPXGetDeviceTranspose(Mat A, hipxMat *dAt)
 #else
     PetscCallHIPX(hipxMatCreateCSR((hipx_int)n, (hipx_int)m, ti, tj, ta, &h->dAt));
 #endif
+    PetscCallHIPX(hipxMatSetInodes(h->dAt, 0, NULL)); /* the products with it are MatMultTranspose_SeqAIJ's left-to-right sums: never the inode order */
     PetscCall(MatSeqAIJRestoreArrayRead(A, &aa));
     PetscCall(PetscFree3(cur, tj, ta));
     PetscCall(PetscFree(ti));

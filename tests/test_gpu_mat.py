@@ -71,7 +71,7 @@ def test_ragged_rows_bit_exact_and_multadd(hx, seed, m, n, maxlen, variant):
     y0 = rng.standard_normal(m)
     z = spmv_gpu(hx, ai, aj, aa, x, ncols=n, y0=y0, variant=variant)
     zr = np.zeros(m)
-    orc.lib().orc_MatMultAdd_SeqAIJ(m, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(y0), orc.P(zr))
+    orc.lib().orc_MatMult_SeqAIJ_dispatch(m, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(y0), orc.P(zr), 0)
     assert np.array_equal(z, zr)
 
 
@@ -167,7 +167,7 @@ def test_row_templates_kernel_selected_and_bit_exact(hx, kind, n, m):
         assert np.array_equal(Y.get(), yr)
         _lib.chk(hx.hipxMatMultAdd(A, X.ptr, Y0.ptr, Y.ptr))
         zr = np.zeros(N)
-        orc.lib().orc_MatMultAdd_SeqAIJ(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(x[::-1].copy()), orc.P(zr))
+        orc.lib().orc_MatMult_SeqAIJ_dispatch(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(x[::-1].copy()), orc.P(zr), 0)
         assert np.array_equal(Y.get(), zr)
         dot = C.c_double()
         _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(dot)))
@@ -377,7 +377,7 @@ def test_sell_triple_run_column_codes_for_three_unknowns_per_node(hx, nb, ragged
     x, y0 = rng.standard_normal(N), rng.standard_normal(N)
     yr = orc.matmult(ai, aj, aa, x)
     zr = np.zeros(N)
-    orc.lib().orc_MatMultAdd_SeqAIJ(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(y0), orc.P(zr))
+    orc.lib().orc_MatMult_SeqAIJ_dispatch(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(y0), orc.P(zr), 0)
     X, Y, Y0 = _lib.DVec(N, x), _lib.DVec(N), _lib.DVec(N, y0)
     for broken in (False, True):
         aj2 = aj.copy()
@@ -508,7 +508,7 @@ def test_pattern_templates_with_arbitrary_values(hx, kind, n):
     assert np.array_equal(Y.get(), yr)
     _lib.chk(hx.hipxMatMultAdd(A, X.ptr, Y0.ptr, Y.ptr))
     zr = np.zeros(N)
-    orc.lib().orc_MatMultAdd_SeqAIJ(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(x[::-1].copy()), orc.P(zr))
+    orc.lib().orc_MatMult_SeqAIJ_dispatch(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(x[::-1].copy()), orc.P(zr), 0)
     assert np.array_equal(Y.get(), zr)
     d = C.c_double()
     _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(d)))
@@ -555,7 +555,7 @@ def test_pair_form_of_the_template_kernel_bit_exact(hx, kind, n, m):
         assert is_template_kernel(name), name             # (odd line lengths: more pairs; beyond 16 the general template kernel)
     yr = orc.matmult(ai, aj, aa, x)
     zr = np.zeros(N)
-    orc.lib().orc_MatMultAdd_SeqAIJ(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(y0), orc.P(zr))
+    orc.lib().orc_MatMult_SeqAIJ_dispatch(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(y0), orc.P(zr), 0)
     X, Y, Y0 = _lib.DVec(N + 2, np.concatenate([x, [0.0, 0.0]])), _lib.DVec(N + 2), _lib.DVec(N + 2, np.concatenate([y0, [0.0, 0.0]]))
     for _ in range(3):  # (the chunk queue's ticket counters run on from launch to launch)
         _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
@@ -641,7 +641,7 @@ def test_march_form_of_the_template_kernel_bit_exact(hx, kind, n, m, cut):
     x, y0 = rng.standard_normal(N), rng.standard_normal(N)
     yr = orc.matmult(ai, aj, aa, x)
     zr = np.zeros(N)
-    orc.lib().orc_MatMultAdd_SeqAIJ(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(y0), orc.P(zr))
+    orc.lib().orc_MatMult_SeqAIJ_dispatch(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(x), orc.P(y0), orc.P(zr), 0)
     A = _lib.mat_create_csr(N, N, ai, aj, aa)
     _lib.chk(hx.hipxMatSetSpMVVariant(A, 30))
     name = kernel_name(hx, A)

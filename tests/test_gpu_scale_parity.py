@@ -323,10 +323,18 @@ def test_config4_surrogate_full_vector_bit_exact(hx):
     N = len(ai) - 1
     assert N == 1536000 and ai[-1] > 120e6
     x = 1.0 + (np.arange(N) % 17) / 17.0
-    yr = orc.matmult(ai, aj, aa, x)
     A = _lib.mat_create_csr(N, N, ai, aj, aa)
     X, Y = _lib.DVec(N, x), _lib.DVec(N)
     kn = C.create_string_buffer(256)
+    # as it comes: three unknowns per node = a matrix with inodes -- the reference multiplies it with MatMult_SeqAIJ_Inode (pairwise row sums)
+    _lib.chk(hx.hipxMatGetSpMVKernel(A, kn, 256))
+    assert b"inodes" in kn.value, kn.value
+    _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+    assert np.array_equal(Y.get(), orc.matmult(ai, aj, aa, x))
+    # declared free of inodes (-mat_no_inode): MatMult_SeqAIJ's left-to-right sums in every kernel form
+    _lib.chk(hx.hipxMatSetInodes(A, 0, None))
+    yr = orc.matmult(ai, aj, aa, x, no_inode=True)
+    assert not np.array_equal(yr, Y.get())  # (the two orders do round differently on this matrix)
     for variant in (0, 22, 23, 28, 1):
         _lib.chk(hx.hipxMatSetSpMVVariant(A, variant))
         _lib.chk(hx.hipxMatGetSpMVKernel(A, kn, 256))
