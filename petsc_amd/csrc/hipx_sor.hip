@@ -40,6 +40,10 @@ struct hipxSorState {
   int4     *d_smeta = nullptr;  // per slot {original row | -1, diagonal offset, row length, 0}: one load instead of slot -> perm -> pi/pd
   int64_t  *d_sks = nullptr;    // per slot start of the row in pj/pa
   bool      smeta_valid = false;
+  hipx_int  nslots4 = 0;        // the same with every level padded to 4 rows: the cooperative kernel (16 lanes per row, 4 rows per wave)
+  hipx_int *d_slot4 = nullptr;
+  int4     *d_smeta4 = nullptr;
+  int64_t  *d_sks4 = nullptr;
   double   *d_w1 = nullptr, *d_w2 = nullptr;
   bool      mdiag_valid = false;  // d_mdiag holds the diagonal of the current values (Eisenstat in strand mode)
   unsigned int *d_ctl = nullptr;  // [0] block ticket, [1] error flag
@@ -299,6 +303,103 @@ __global__ __launch_bounds__(SOR_THREADS) void sor_dep_kernel(hipx_int nslots, c
   }
 }
 
+// The cooperative form of the dependency-driven sweep (round 4, default): 16 lanes per row, 4 rows per wave.  One lane per row walks its
+// entries in chunks, each chunk's loads behind the polls of the chunk before (6.8 us per dependency level on the 27-point operator);
+// here a row's entries are dealt to its 16 lanes -- every column, value and operand load of up to 32 entries in flight at once -- each
+// lane parks its products a_k x_{j_k} in LDS, and every lane of the group then runs the row's subtraction chain over them in CSR order
+// (LDS broadcasts): the bits of PetscSparseDenseMinusDot.  Lane 0 of the group scales and publishes.  (The same shape as the inode sweep
+// further down, sor_inode_coop_kernel, where it was measured first: 34.8 -> 7.2 ms.)
+constexpr int DEP_G = 16, DEP_R = 2, DEP_CH = DEP_G * DEP_R;  // lanes per row, entries per lane and chunk, entries per chunk
+
+// entries [k0, k1): operand of column j is the NEW value (polled) when DEPLOW ? j < i : j > i, else the old one -- as sor_minusdot
+template <bool DEPLOW>
+__device__ __forceinline__ double dep_coop_minus(double sum, double *Q, const int l, hipx_int i, int64_t k0, int64_t k1, const hipx_int *__restrict__ pj, const double *__restrict__ pa,
+                                                 const double *xold, const double *xnew, unsigned int *err)
+{
+  for (int64_t kc = k0; kc < k1; kc += DEP_CH) {
+    const int cnt = (int)((k1 - kc) < DEP_CH ? (k1 - kc) : DEP_CH);
+    hipx_int  j[DEP_R];
+    double    a[DEP_R], v[DEP_R];
+    bool      ok[DEP_R], dep[DEP_R];
+#pragma unroll
+    for (int rr = 0; rr < DEP_R; rr++) {
+      const int q      = l + rr * DEP_G;
+      ok[rr]           = q < cnt;
+      const int64_t kk = ok[rr] ? kc + q : k0;
+      j[rr]            = pj[kk];
+      a[rr]            = pa[kk];
+    }
+#pragma unroll
+    for (int rr = 0; rr < DEP_R; rr++) {
+      dep[rr] = DEPLOW ? (j[rr] < i) : (j[rr] > i);
+      if (dep[rr]) v[rr] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(xnew + j[rr]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      else v[rr] = xold[j[rr]];
+    }
+#pragma unroll
+    for (int rr = 0; rr < DEP_R; rr++)
+      if (ok[rr] && dep[rr] && (unsigned long long)__double_as_longlong(v[rr]) == SOR_SENTINEL) v[rr] = sor_poll(xnew + j[rr], err);
+#pragma unroll
+    for (int rr = 0; rr < DEP_R; rr++)
+      if (ok[rr]) Q[l + rr * DEP_G] = a[rr] * v[rr];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int q = 0; q < cnt; q++) sum -= Q[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  return sum;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(SOR_THREADS) void sor_dep_coop_kernel(hipx_int nslots, const int4 *__restrict__ smeta, const int64_t *__restrict__ sks, const hipx_int *__restrict__ pj,
+                                                                    const double *__restrict__ pa, const double *__restrict__ idiag, const double *__restrict__ mdiag, const double *b, double *t,
+                                                                    const double *xold, double *xnew, double omega, unsigned int *ctl)
+{
+  constexpr bool FWD = (KIND == 0 || KIND == 3);
+  __shared__ double s_q[SOR_THREADS / 64][64 / DEP_G][DEP_CH];
+  unsigned int  *err = ctl + 1;
+  const int      lane = threadIdx.x & 63, wv = threadIdx.x >> 6, grp = lane / DEP_G, l = lane % DEP_G;
+  double        *Q = s_q[wv][grp];
+  const hipx_int ngroups = nslots / (64 / DEP_G);
+  for (;;) {
+    unsigned int v = 0;
+    if (lane == 0) v = atomicAdd(&ctl[0], 1u);
+    v = __shfl(v, 0, 64);
+    if ((hipx_int)v >= ngroups) return;
+    const hipx_int g  = (hipx_int)v * (64 / DEP_G) + grp;
+    const hipx_int s  = FWD ? g : nslots - 1 - g;
+    const int4     mt = smeta[s];  // {row, offset of the diagonal, row length, -}; row < 0: padding
+    if (mt.x >= 0) {
+      const int64_t  ks = sks[s];
+      const hipx_int i  = mt.x;
+      const int64_t  kd = ks + mt.y, ke = ks + mt.z;
+      double         sum, out;
+      if (KIND == 0) {
+        sum = dep_coop_minus<true>(b[i], Q, l, i, ks, kd, pj, pa, xold, xnew, err);
+        if (l == 0) t[i] = sum;
+        out = sum * idiag[i];
+      } else if (KIND == 3) {
+        sum = dep_coop_minus<true>(b[i], Q, l, i, ks, kd, pj, pa, xold, xnew, err);
+        if (l == 0) t[i] = sum;
+        sum = dep_coop_minus<true>(sum, Q, l, i, kd + 1, ke, pj, pa, xold, xnew, err);
+        out = (1. - omega) * xold[i] + sum * idiag[i];
+      } else if (KIND == 1) {
+        sum = dep_coop_minus<false>(t[i], Q, l, i, kd + 1, ke, pj, pa, xold, xnew, err);
+        out = (1 - omega) * xold[i] + sum * idiag[i];
+      } else if (KIND == 2) {
+        sum = dep_coop_minus<false>(b[i], Q, l, i, kd + 1, ke, pj, pa, xold, xnew, err);
+        out = sum * idiag[i];
+      } else {
+        sum = dep_coop_minus<false>(b[i], Q, l, i, ks, ke, pj, pa, xold, xnew, err);
+        out = (1. - omega) * xold[i] + (sum + mdiag[i] * xold[i]) * idiag[i];
+      }
+      if (l == 0) sor_publish(xnew + i, out);
+    }
+  }
+}
+
 template <int KIND>
 int run_dep(hipxSorState *S, const double *b, const double *xold, double *xnew, double omega)
 {
@@ -312,6 +413,27 @@ int run_dep(hipxSorState *S, const double *b, const double *xold, double *xnew, 
     waves_per_cu  = e ? atoi(e) : 2;  // measured: fewer pollers = faster hops (2 beat 1, 4, 8 on 7-pt 192^3 and 27-pt 128^3)
     if (waves_per_cu < 1) waves_per_cu = 1;
     if (waves_per_cu > 32) waves_per_cu = 32;
+  }
+  // which form: the cooperative one shortens the hop from level to level (2.7 us against 6.8 - 13) but carries 4 rows per wave where the
+  // lane-per-row form carries 64 -- it wins where the levels are NARROW (unstructured orderings: the elasticity stand-in as a point
+  // matrix, ~380 rows per level: 85.6 -> 32.0 ms per symmetric sweep) and loses where they are wide (27-point 256^3 in natural
+  // ordering, 9362 rows per level: 24.3 -> 96.8 ms): decided by the average level width
+  int coop = (S->nlevels > 0 && (int64_t)S->m / S->nlevels <= 2048) ? 1 : 0, coop_blocks = 256;  // (one workgroup per CU: more pollers crowd out the publishers, see run_inode)
+  {
+    const char *e = getenv("HIPX_SOR_DEP_COOP");  // 0: one lane per row (rounds 1-3), 1: cooperative, whatever the level widths
+    if (e) coop = atoi(e);
+    e = getenv("HIPX_SOR_DEP_COOP_BLOCKS");
+    if (e) coop_blocks = atoi(e);
+    if (coop_blocks < 1) coop_blocks = 1;
+    if (coop_blocks > 4096) coop_blocks = 4096;
+  }
+  if (coop && S->d_smeta4) {
+    unsigned       cgrid = (unsigned)coop_blocks;
+    const unsigned cneed = (unsigned)((S->nslots4 / (64 / DEP_G) * 64 + SOR_THREADS - 1) / SOR_THREADS);
+    if (cgrid > cneed) cgrid = cneed ? cneed : 1;
+    sor_dep_coop_kernel<KIND><<<cgrid, SOR_THREADS, 0, st>>>(S->nslots4, S->d_smeta4, S->d_sks4, S->d_pj, S->d_pa, S->d_idiag, S->d_mdiag, b, S->d_t, xold, xnew, omega, S->d_ctl);
+    HIPX_LAUNCH_CHECK();
+    return HIPX_SUCCESS;
   }
   unsigned grid = (unsigned)(256 * waves_per_cu * 64 / SOR_THREADS);
   const unsigned need = (unsigned)((S->nslots + SOR_THREADS - 1) / SOR_THREADS);
@@ -2679,8 +2801,9 @@ int run_inode(hipxSorState *S, const double *rhs, const double *xold, double *xn
   unsigned       grid = (unsigned)(256 * waves_per_cu * 64 / SOR_THREADS);
   const unsigned need = (unsigned)((T->nslots + SOR_THREADS - 1) / SOR_THREADS);
   if (grid > need) grid = need ? need : 1;
-  int coop = 1, coop_blocks = 256;  // workgroups of 4 waves; measured on the elasticity stand-in (symmetric sweep): 256 (one per CU) 7.2 ms, 512: 8.1, 1024: 13.4,
-                                    // 2048: 18.8 -- pollers crowd out the publishers
+  // workgroups of 4 waves; measured on the elasticity stand-in (symmetric sweep): 256 (one per CU) 7.2 ms, 512: 8.1, 1024: 13.4, 2048: 18.8 --
+  // pollers crowd out the publishers.  Wide levels (> 2048 nodes on average) keep the lane-per-node form: see run_dep
+  int coop = (T->nlevels > 0 && (int64_t)T->nnodes / T->nlevels <= 2048) ? 1 : 0, coop_blocks = 256;
   {
     const char *e = getenv("HIPX_SOR_INODE_COOP");  // 0: one lane per node (the first form of this schedule: 34.8 ms)
     if (e) coop = atoi(e);
@@ -2770,6 +2893,14 @@ int build_schedule(hipxSorState *S, hipx_int m, int64_t nnz, int is64, const voi
     S->nslots = (hipx_int)slot.size();
     HIPX_HIP(hipMalloc((void **)&S->d_slot, sizeof(hipx_int) * std::max<size_t>(slot.size(), 1)));
     if (!slot.empty()) HIPX_HIP(hipMemcpy(S->d_slot, slot.data(), sizeof(hipx_int) * slot.size(), hipMemcpyHostToDevice));
+    slot.clear();  // ... and on a multiple of 4 for the cooperative kernel
+    for (hipx_int l = 0; l < nlev; l++) {
+      for (hipx_int p = S->lev_ptr[l]; p < S->lev_ptr[l + 1]; p++) slot.push_back(p);
+      while (slot.size() % 4) slot.push_back(-1);
+    }
+    S->nslots4 = (hipx_int)slot.size();
+    HIPX_HIP(hipMalloc((void **)&S->d_slot4, sizeof(hipx_int) * std::max<size_t>(slot.size(), 1)));
+    if (!slot.empty()) HIPX_HIP(hipMemcpy(S->d_slot4, slot.data(), sizeof(hipx_int) * slot.size(), hipMemcpyHostToDevice));
   }
   S->m     = m;
   S->is64  = is64 != 0;
@@ -2801,6 +2932,9 @@ extern "C" void hipxSorStateFree_(void *p)
   (void)hipFree(S->d_slot);
   (void)hipFree(S->d_smeta);
   (void)hipFree(S->d_sks);
+  (void)hipFree(S->d_slot4);
+  (void)hipFree(S->d_smeta4);
+  (void)hipFree(S->d_sks4);
   (void)hipFree(S->d_w1);
   (void)hipFree(S->d_w2);
   (void)hipFree(S->d_ctl);
@@ -3089,6 +3223,14 @@ static int mat_sor_impl(hipxMat A, const double *b, double omega, int flag, doub
       }
       if (S->nslots) {
         slot_meta_kernel<<<(unsigned)std::min<hipx_int>((S->nslots + 255) / 256, 4096), 256, 0, st>>>(S->nslots, S->d_slot, S->d_perm, S->d_pi, S->d_pd, S->d_smeta, S->d_sks);
+        HIPX_LAUNCH_CHECK();
+      }
+      if (!S->d_smeta4) {
+        HIPX_HIP(hipMalloc((void **)&S->d_smeta4, sizeof(int4) * (size_t)std::max<hipx_int>(S->nslots4, 1)));
+        HIPX_HIP(hipMalloc((void **)&S->d_sks4, sizeof(int64_t) * (size_t)std::max<hipx_int>(S->nslots4, 1)));
+      }
+      if (S->nslots4) {
+        slot_meta_kernel<<<(unsigned)std::min<hipx_int>((S->nslots4 + 255) / 256, 4096), 256, 0, st>>>(S->nslots4, S->d_slot4, S->d_perm, S->d_pi, S->d_pd, S->d_smeta4, S->d_sks4);
         HIPX_LAUNCH_CHECK();
       }
     }
