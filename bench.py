@@ -499,6 +499,11 @@ def suite_mode(args):
         from surrogates import flan_surrogate
         ai, aj, aa = flan_surrogate()
         N = len(ai) - 1
+    elif name == "sorflan":  # PCSOR's application on config 4's stand-in (a matrix with inodes: the node-level sweep)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from surrogates import flan_surrogate_spd
+        ai, aj, aa = flan_surrogate_spd()
+        N = len(ai) - 1
     else:
         dims = tuple(int(v) for v in args.suite_dims.split("x")) if args.suite_dims else (args.n, args.n, args.n)
         N = dims[0] * dims[1] * dims[2]
@@ -508,7 +513,7 @@ def suite_mode(args):
     A = _lib.mat_create_csr(N, N, ai, aj, aa)
     del ai, aj, aa
     X, Y = _lib.DVec(N, 1.0 + (np.arange(N) % 17) / 17.0), _lib.DVec(N)
-    if name == "sor":
+    if name in ("sor", "sorflan"):
         for _ in range(3):
             _lib.chk(hx.hipxMatSOR(A, X.ptr, 1.0, 12 | 16, 0.0, 1, 1, Y.ptr))
     else:
@@ -878,15 +883,16 @@ def main():
         return main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync)
 
     # =========================================================================================================== one GPU
-    if args.matrix_file:  # BASELINE config 4 with a supplied file: the whole line is that solve
-        cfg4 = config4_cfg(args.matrix_file)
+    if args.matrix_file:  # BASELINE config 4 with a supplied file (or `--matrix-file standin`: the documented stand-in): the whole line is that solve
+        cfg4 = config4_cfg(None if args.matrix_file == "standin" else args.matrix_file)
+        cfg4.pc = args.pc
         ranks4 = None if args.no_cpu_baseline else max(2, physical_cores() // 4)
-        r4 = leg_matrix_solver(cfg4, args.steps, args.warmup, sync, torch, best_ranks=ranks4)
+        r4 = leg_matrix_solver(cfg4, args.steps, args.warmup, sync, torch, best_ranks=ranks4, parity_its=0 if args.no_cpu_baseline else 10)
         rf = dict(r4["roofline_spmv"], kernel=r4["spmv_kernel"], basis="algorithmic CSR bytes / launch time (no counter pass on a file matrix)")
         print(json.dumps({"metric": cfg4.metric(), "value": r4["iterations_per_s"] if r4["parity"].get("pass") is not False else None, "unit": "iterations/s", "n_gpus": 1,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": r4["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                           "dtype": "f64", "data": "file: %s" % args.matrix_file,
-                          "config": {"workload": "%s (N=%d rows, nnz=%d), KSPCG + PCJACOBI, b = A*1, x0 = 0" % (cfg4.name, r4["rows"], r4["nnz"]), "global_rows": r4["rows"], "parallelism": "rows1"},
+                          "config": {"workload": "%s (N=%d rows, nnz=%d), KSPCG + %s, b = A*1, x0 = 0" % (cfg4.name, r4["rows"], r4["nnz"], cfg4.pcname()), "global_rows": r4["rows"], "parallelism": "rows1"},
                           "ungated": r4["parity"].get("pass") is None, "parity_gate": r4["parity"], "roofline": rf, "cpu_baseline": r4.get("cpu_baseline")}))
         sys.stdout.flush()
         return
@@ -1090,6 +1096,7 @@ def main():
             pmc["sor27"] = (pmc_suite(["--suite", "sor", "--grid", "256", "--stencil", "27"], "27pt_256_sor"), src % "sor (27-pt 256^3)")
             pmc["sor27var"] = (pmc_suite(["--suite", "sor", "--grid", "256", "--stencil", "27", "--suite-perturb", "1"], "27pt_256_sor_arbitrary_values"), src % "sor --suite-perturb 1")
             pmc["sell"] = (pmc_suite(["--suite", "sell"], "config4_standin_spmv"), src % "sell")
+            pmc["sorflan"] = (pmc_suite(["--suite", "sorflan"], "config4_standin_sor"), src % "sorflan")
             pmc["box"] = (pmc_suite(["--suite", "cg", "--stencil", "7", "--pc", "none", "--suite-dims", "1024x1024x32"], "config5_lines_cg"), src % "cg --suite-dims 1024x1024x32 --pc none")
 
     import threading
@@ -1209,7 +1216,13 @@ def main():
             if put_traffic(line, pmc.get("sor27var"), ["sor_strand_kernel<0", "sor_strand_kernel<1"], line["avg_call_ms"]):
                 line["achieved"], line["frac"] = line["achieved_on_counter_bytes"], line["frac_counter_bytes"]
             sv["roofline_sor"] = line
-        for nm in ("config4_surrogate_spmv", "config4_solver_cg_jacobi"):
+        c4s = other.get("config4_solver_cg_sor", {})
+        if "roofline_sor" in c4s:
+            kin = "sor_inode_coop_kernel" if pmc.get("sorflan") and pmc["sorflan"][0] and pick_kernel(pmc["sorflan"][0], "sor_inode_coop_kernel<0")[1] else "sor_inode_kernel"
+            if put_traffic(c4s["roofline_sor"], pmc.get("sorflan"), [kin + "<0", kin + "<1"], c4s["roofline_sor"]["avg_call_ms"],
+                           note="forward (kind 0) + backward (kind 1) launch of the node-level sweep; the sweep is bound by the dependency levels of the node graph (one hop of ~2.7 us per level, 1344 levels on this stand-in), not by bytes"):
+                c4s["roofline_sor"]["achieved"], c4s["roofline_sor"]["frac"] = c4s["roofline_sor"]["achieved_on_counter_bytes"], c4s["roofline_sor"]["frac_counter_bytes"]
+        for nm in ("config4_surrogate_spmv", "config4_solver_cg_jacobi", "config4_solver_cg_sor"):
             c4 = other.get(nm, {})
             line = c4.get("roofline_longrow") or c4.get("roofline_spmv")
             if line:

@@ -29,6 +29,27 @@ stats headline --no-traffic --no-plugin --no-cpu-baseline --no-other --no-genera
 stats 27pt_512 --quick --stencil 27 --grid 512 --steps 30 --warmup 3
 stats config5_share --quick --grid 1024 --scaling weak --pc none --steps 50 --warmup 5
 stats gmres_sor_27pt_256 --quick --ksp gmres --pc sor --stencil 27 --grid 256 --steps 60 --warmup 5
+stats config4_standin_cg_sor --matrix-file standin --pc sor --steps 30 --warmup 3 --no-cpu-baseline
 python scripts/cg_kernels_timing.py > $O/vector_kernels_standalone.txt 2>/dev/null
+# 2 and 4 ranks on this one GPU (IPC transport; RCCL refuses shared devices): a functional run whose per-rank halo / all-reduce section times are
+# lower bounds for the real thing (no xGMI hop, but four processes time-slicing one device)
+for np_ in 2 4; do for pl in 1 3; do
+  HIPX_ALL_RANKS_DEVICE0=1 timeout 600 python bench.py --gpus $np_ --grid 128 --quick --transport ipc --pipeline $pl --steps 200 --warmup 20 2>/dev/null | tail -1 > $O/multirank_one_gpu_np${np_}_pipeline${pl}.json
+done; done
+python - <<PY
+import json, glob, os
+out = {}
+for f in sorted(glob.glob("$O/multirank_one_gpu_np*_pipeline*.json")):
+    try:
+        d = json.loads(open(f).read())
+    except Exception as e:
+        out[os.path.basename(f)] = {"error": str(e)}
+        continue
+    pr = (d.get("multi_gpu") or {}).get("per_rank") or d.get("per_rank") or []
+    out[os.path.basename(f)[:-5]] = {"iterations_per_s": d.get("value"), "ms_per_step": d.get("ms_per_step"), "parity": (d.get("parity_gate") or {}).get("max_rel_diff"),
+                                     "per_rank": [{k: r.get(k) for k in ("rank", "rows", "ghosts", "spmv_ms", "halo_ms", "allreduce_ms", "offdiag_ms", "cg_update_ms")} for r in pr]}
+json.dump(out, open("$O/multirank_one_gpu.json", "w"), indent=1)
+print(json.dumps(out)[:600])
+PY
 head -5 $O/headline_kernel_stats.csv | cut -c1-150
 echo "total ${SECONDS}s"

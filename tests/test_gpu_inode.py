@@ -216,3 +216,19 @@ def test_matmult_of_a_matrix_with_inodes_sums_in_pairs(hx, which):
     for v in (X, Y, Y0):
         v.free()
     _lib.mat_destroy(A)
+
+
+@pytest.mark.parametrize("coop", ["0", "1"])
+def test_both_forms_of_the_node_sweep(hx, coop):
+    """HIPX_SOR_INODE_COOP: 1 = 16 lanes per node (what narrow levels get), 0 = one lane per node (wide levels): the same bits."""
+    ai, aj, aa = inode_matrix(nnodes=700, seed=8)
+    N = len(ai) - 1
+    rng = np.random.default_rng(6)
+    b, x0 = rng.standard_normal(N), rng.standard_normal(N)
+    os.environ["HIPX_SOR_INODE_COOP"] = coop
+    try:
+        for flag, its in ((ZERO | 12, 1), (3, 2), (2, 2), (EISENSTAT, 1)):
+            g, mode, nc = sor_gpu(hx, ai, aj, aa, b, flag, its, 1, x0)
+            assert mode == 3 and np.array_equal(g, sor_cpu(ai, aj, aa, b, flag, its, 1, x0)), (flag, its)
+    finally:
+        os.environ.pop("HIPX_SOR_INODE_COOP", None)

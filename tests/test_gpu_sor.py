@@ -336,3 +336,30 @@ def test_strand_kernel_variants_bit_exact(env):
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_sor_variant_worker.py")], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=600)
     assert r.returncode == 0 and "SOR_VARIANT_OK" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("coop", ["0", "1"])
+@pytest.mark.parametrize("flag,omega,its", [(SYM | ZERO, 1.0, 1), (SYM, 1.3, 2), (BWD, 0.9, 2), (FWD | ZERO, 1.0, 2), (EISENSTAT, 1.0, 1)])
+def test_both_forms_of_the_dependency_driven_sweep(hx, coop, flag, omega, its):
+    """HIPX_SOR_DEP_COOP: 1 = sor_dep_coop_kernel (16 lanes per row: narrow levels), 0 = sor_dep_kernel (one lane per row: wide levels) --
+    the library picks by the average level width; both are MatSOR_SeqAIJ bit for bit (an unstructured matrix and a stencil)."""
+    rng = np.random.default_rng(23)
+    for ai, aj, aa in (sor_ready(*random_csr(3000, 3000, rng, 40, empty_frac=0.0), rng), orc.stencil("27pt", 11)):
+        N = len(ai) - 1
+        b, x0 = rng.standard_normal(N), rng.standard_normal(N)
+        os.environ["HIPX_SOR_DEP_COOP"] = coop
+        try:
+            g = sor_gpu(hx, ai, aj, aa, b, omega, flag, 0.0, its, 1, x0, mode="dep")
+        finally:
+            os.environ.pop("HIPX_SOR_DEP_COOP", None)
+        assert np.array_equal(g, sor_cpu(ai, aj, aa, b, omega, flag, 0.0, its, 1, x0))
+
+
+def sor_ready(ai, aj, aa, rng):
+    """random_csr with a nonzero diagonal entry in every row (MatSOR needs one: aij.c:1809)."""
+    m = len(ai) - 1
+    rows = np.repeat(np.arange(m), np.diff(ai))
+    import scipy.sparse as sp
+    A = sp.csr_matrix((aa, aj, ai), shape=(m, m)) + sp.diags(4.0 + rng.random(m))
+    A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
