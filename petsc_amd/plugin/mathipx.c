@@ -22,7 +22,31 @@ typedef struct {
   PetscInt  spmv_variant;
   hipxCOO   coo;       /* device copies of the reference's COO maps (MatCOOStruct_SeqAIJ jmap / perm) */
   PetscBool dev_newer; /* the device value array is ahead of the host copy a->a (MatSetValuesCOO ran on the device) */
+  PetscInt  inode_sig; /* the inode partition libhipx was told: node_count, 0 = none, -1 = nothing yet (compressed-row copies: never) */
 } Mat_SeqAIJHIPX;
+
+/* The inodes of the host matrix -> libhipx (MatSeqAIJCheckInode inode.c:3920 found them at assembly, under -mat_no_inode / -mat_inode_limit;
+   MatAssemblyEnd_MPIAIJ switches them off on the off-diagonal block, mpiaij.c:824 -- AFTER a COO preallocation has already assembled that
+   block once: the state is looked at again before every use).  The reference multiplies a matrix with inodes with MatMult_SeqAIJ_Inode and
+   relaxes it node by node (aij.c:1459, 1852), and so does libhipx once it is told the partition.  Told in EVERY case: left alone, libhipx looks
+   for inodes itself -- and would find some among the empty rows of an off-diagonal block. */
+static PetscErrorCode MatSeqAIJHIPXSyncInodes(Mat A, hipxMat dA, PetscInt *sig_io)
+{
+  Mat_SeqAIJ *a   = (Mat_SeqAIJ *)A->data;
+  PetscInt    sig = (a->inode.use && a->inode.checked && a->inode.node_count > 0 && a->inode.size_csr) ? a->inode.node_count : 0;
+
+  PetscFunctionBegin;
+  if (*sig_io == sig) PetscFunctionReturn(PETSC_SUCCESS);
+  if (sig) {
+    hipx_int *ns;
+    PetscCall(PetscMalloc1((size_t)sig + 1, &ns));
+    for (PetscInt k = 0; k <= sig; k++) ns[k] = (hipx_int)a->inode.size_csr[k];
+    PetscCallHIPX(hipxMatSetInodes(dA, (hipx_int)sig, ns));
+    PetscCall(PetscFree(ns));
+  } else PetscCallHIPX(hipxMatSetInodes(dA, 0, NULL));
+  *sig_io = sig;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
 
 static PetscErrorCode MatMult_SeqAIJHIPX(Mat, Vec, Vec);
 
@@ -76,7 +100,8 @@ PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA)
   PetscCall(PetscObjectStateGet((PetscObject)A, &state));
   if (h->dev_newer && h->dA && h->nonzerostate == A->nonzerostate) { /* values were assembled on the device: nothing to upload */
     h->valuestate = state;
-    *dA           = h->dA;
+    if (h->inode_sig != -2) PetscCall(MatSeqAIJHIPXSyncInodes(A, h->dA, &h->inode_sig));
+    *dA = h->dA;
     PetscFunctionReturn(PETSC_SUCCESS);
   }
   if (!h->dA || h->nonzerostate != A->nonzerostate) {
@@ -88,18 +113,13 @@ PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA)
          matrix has entries in a few rows only -- MatMult_SeqAIJ / MatMultAdd_SeqAIJ then walk the listed rows (aij.c:1463-1478,
          1624-1641), and so does the device kernel (y is not streamed for the empty rows) */
       PetscCall(MatSeqAIJHIPXCreateDevice(A, aa, PETSC_TRUE, &h->dA));
-    } else PetscCall(MatSeqAIJHIPXCreateDevice(A, aa, PETSC_FALSE, &h->dA));
+      h->inode_sig = -2; /* compressed-row copy: libhipx never looks for inodes there */
+    } else {
+      PetscCall(MatSeqAIJHIPXCreateDevice(A, aa, PETSC_FALSE, &h->dA));
+      h->inode_sig = -1;
+    }
     PetscCall(MatSeqAIJRestoreArrayRead(A, &aa));
     if (h->spmv_variant) PetscCallHIPX(hipxMatSetSpMVVariant(h->dA, (int)h->spmv_variant));
-    /* the inodes MatAssemblyEnd_SeqAIJ found (MatSeqAIJCheckInode inode.c:3920, under -mat_no_inode / -mat_inode_limit): MatSOR_SeqAIJ
-       relaxes such a matrix node by node (aij.c:1852 -> MatSOR_SeqAIJ_Inode), and so does hipxMatSOR when it is told the partition */
-    if (a->inode.use && a->inode.checked && a->inode.node_count > 0 && a->inode.size_csr && A->rmap->n == A->cmap->n) {
-      hipx_int *ns;
-      PetscCall(PetscMalloc1((size_t)a->inode.node_count + 1, &ns));
-      for (PetscInt k = 0; k <= a->inode.node_count; k++) ns[k] = (hipx_int)a->inode.size_csr[k];
-      PetscCallHIPX(hipxMatSetInodes(h->dA, (hipx_int)a->inode.node_count, ns));
-      PetscCall(PetscFree(ns));
-    } else PetscCallHIPX(hipxMatSetInodes(h->dA, 0, NULL));
     h->nonzerostate = A->nonzerostate;
     h->valuestate   = state;
   } else if (h->valuestate != state) {
@@ -109,6 +129,7 @@ PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA)
     PetscCall(MatSeqAIJRestoreArrayRead(A, &aa));
     h->valuestate  = state;
   }
+  if (h->inode_sig != -2) PetscCall(MatSeqAIJHIPXSyncInodes(A, h->dA, &h->inode_sig));
   *dA = h->dA;
   PetscFunctionReturn(PETSC_SUCCESS);
 }
@@ -376,6 +397,8 @@ PetscErrorCode MatSeqAIJHIPXSetValuesCOO_Private(Mat A, hipxCOO coo, const Petsc
     if (h->dA) PetscCallHIPX(hipxMatDestroy(&h->dA));
     if (imode == ADD_VALUES) PetscCall(MatSeqAIJHIPXCreateDevice(A, a->a, PETSC_FALSE, &h->dA));
     else PetscCall(MatSeqAIJHIPXCreateDevice(A, NULL, PETSC_FALSE, &h->dA));
+    h->inode_sig = -1;
+    PetscCall(MatSeqAIJHIPXSyncInodes(A, h->dA, &h->inode_sig));
     if (h->spmv_variant) PetscCallHIPX(hipxMatSetSpMVVariant(h->dA, (int)h->spmv_variant));
     h->nonzerostate = A->nonzerostate;
   } else if (!h->dev_newer && imode == ADD_VALUES) { /* the host copy is the current one: bring it over before adding to it */
