@@ -209,6 +209,32 @@ __device__ __forceinline__ double sor_poll(const double *p, unsigned int *err)
   return __longlong_as_double((long long)v);
 }
 
+// the cooperative kernels' poll: the same loop with the back-off between two looks selectable (psleep: 0 none, 1, 2, 4, else 8 units of 64 clocks)
+__device__ __forceinline__ double sor_poll_sel(const double *p, unsigned int *err, const int psleep)
+{
+  const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+  unsigned long long        v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int                       spins = 0;
+  long long                 t0 = 0;
+  while (v == SOR_SENTINEL) {
+    if (psleep == 1) __builtin_amdgcn_s_sleep(1);
+    else if (psleep == 2) __builtin_amdgcn_s_sleep(2);
+    else if (psleep == 4) __builtin_amdgcn_s_sleep(4);
+    else if (psleep != 0) __builtin_amdgcn_s_sleep(8);
+    v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ++spins;
+    if ((spins & 0xff) == 0) {
+      const long long now = (long long)wall_clock64();
+      if (!t0) t0 = now;
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || now - t0 > SOR_SPIN_TICKS) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  return __longlong_as_double((long long)v);
+}
+
 __device__ __forceinline__ void sor_publish(double *p, double v)
 {
   __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2349,6 +2375,7 @@ int inode_build(InodeState *T, hipx_int m, int64_t nnz, int is64, const void *d_
     const int64_t  len = hi[r0 + 1] - hi[r0], szl = hd[r0] - hi[r0];
     bool           ok  = hd[r0] >= 0 && szl + ns <= len;
     for (hipx_int r = 0; ok && r < ns; r++) ok = (hi[r0 + r + 1] - hi[r0 + r] == len) && hj[hi[r0] + szl + r] == r0 + r;
+    for (hipx_int r = 1; ok && r < ns; r++) ok = len == 0 || memcmp(&hj[hi[r0]], &hj[hi[r0 + r]], (size_t)len * sizeof(hipx_int)) == 0;  // (a caller's partition is not taken on trust)
     if (!ok) return fail(73 /* PETSC_ERR_ARG_WRONGSTATE */, "inodes: a node's rows must share one column list that holds the node's own columns (the diagonal block)", __FILE__, __LINE__);
   }
   std::vector<hipx_int> lev((size_t)nnodes, 0);
@@ -2649,7 +2676,7 @@ constexpr int INO_G = 16, INO_R = 2, INO_CHP = INO_G * INO_R;  // lanes per node
 
 template <int NSM, int SRC>
 __device__ __forceinline__ void inode_coop_minus(double (&sum)[NSM], double (*Q)[NSM], const int l, int64_t k0, int64_t k1, hipx_int thr, const hipx_int *__restrict__ nj,
-                                                 const double *__restrict__ nv, const double *xold, const double *xnew, unsigned int *err)
+                                                 const double *__restrict__ nv, const double *xold, const double *xnew, unsigned int *err, const int psleep)
 {
   for (int64_t kc = k0; kc < k1; kc += 2 * INO_CHP) {
     const int cnt = (int)((k1 - kc) < 2 * INO_CHP ? (k1 - kc) : 2 * INO_CHP);  // entries of this chunk
@@ -2682,8 +2709,8 @@ __device__ __forceinline__ void inode_coop_minus(double (&sum)[NSM], double (*Q)
 #pragma unroll
     for (int rr = 0; rr < INO_R; rr++) {
       const bool d0 = SRC == 0 || (SRC == 2 && j0[rr] >= thr), d1 = SRC == 0 || (SRC == 2 && j1[rr] >= thr);
-      if (v0[rr] && d0 && (unsigned long long)__double_as_longlong(x0[rr]) == SOR_SENTINEL) x0[rr] = sor_poll(xnew + j0[rr], err);
-      if (v1[rr] && d1 && (unsigned long long)__double_as_longlong(x1[rr]) == SOR_SENTINEL) x1[rr] = sor_poll(xnew + j1[rr], err);
+      if (v0[rr] && d0 && (unsigned long long)__double_as_longlong(x0[rr]) == SOR_SENTINEL) x0[rr] = sor_poll_sel(xnew + j0[rr], err, psleep);
+      if (v1[rr] && d1 && (unsigned long long)__double_as_longlong(x1[rr]) == SOR_SENTINEL) x1[rr] = sor_poll_sel(xnew + j1[rr], err, psleep);
     }
 #pragma unroll
     for (int rr = 0; rr < INO_R; rr++) {
@@ -2712,7 +2739,7 @@ __device__ __forceinline__ void inode_coop_minus(double (&sum)[NSM], double (*Q)
 template <int KIND, int NSM>
 __global__ __launch_bounds__(SOR_THREADS) void sor_inode_coop_kernel(hipx_int nslots, const int4 *__restrict__ smeta, const int64_t *__restrict__ sks, const hipx_int *__restrict__ sp,
                                                                       const hipx_int *__restrict__ nj, const double *__restrict__ nv, const double *__restrict__ ibd, const double *rhs,
-                                                                      double *t, const double *xold, double *xnew, double *xacc, unsigned int *ctl)
+                                                                      double *t, const double *xold, double *xnew, double *xacc, unsigned int *ctl, const int psleep)
 {
   constexpr bool FWD = (KIND == 0 || KIND == 3 || KIND == 5);
   __shared__ double s_q[SOR_THREADS / 64][64 / INO_G][INO_CHP][NSM];
@@ -2741,18 +2768,18 @@ __global__ __launch_bounds__(SOR_THREADS) void sor_inode_coop_kernel(hipx_int ns
       for (int c = 0; c < NSM; c++) dcol[c] = (l < ns && c < ns) ? D[c * ns + l] : 0.0;
       const double xo = (KIND == 4 && l < ns) ? xold[r0 + l] : 0.0;
       if (KIND == 0 || KIND == 3 || KIND == 5) {
-        inode_coop_minus<NSM, 0>(sum, Q, l, ks, ks + mt.z, 0, nj, nv, xold, xnew, err);
+        inode_coop_minus<NSM, 0>(sum, Q, l, ks, ks + mt.z, 0, nj, nv, xold, xnew, err, psleep);
         if (KIND != 5 && l < ns) {
           double sl = sum[0];
 #pragma unroll
           for (int c = 1; c < NSM; c++) sl = (l == c) ? sum[c] : sl;
           t[r0 + l] = sl;
         }
-        if (KIND == 3) inode_coop_minus<NSM, 1>(sum, Q, l, ks + mt.z + ns, ks + mt.w, 0, nj, nv, xold, xnew, err);
+        if (KIND == 3) inode_coop_minus<NSM, 1>(sum, Q, l, ks + mt.z + ns, ks + mt.w, 0, nj, nv, xold, xnew, err, psleep);
       } else if (KIND == 1 || KIND == 2) {
-        inode_coop_minus<NSM, 0>(sum, Q, l, ks + mt.z + ns, ks + mt.w, 0, nj, nv, xold, xnew, err);
+        inode_coop_minus<NSM, 0>(sum, Q, l, ks + mt.z + ns, ks + mt.w, 0, nj, nv, xold, xnew, err, psleep);
       } else {
-        inode_coop_minus<NSM, 2>(sum, Q, l, ks, ks + mt.w, r0 + ns, nj, nv, xold, xnew, err);
+        inode_coop_minus<NSM, 2>(sum, Q, l, ks, ks + mt.w, r0 + ns, nj, nv, xold, xnew, err, psleep);
       }
       if (l < ns) {
         double acc = sum[0] * dcol[0];
@@ -2813,11 +2840,12 @@ int run_inode(hipxSorState *S, const double *rhs, const double *xold, double *xn
     if (coop_blocks > 4096) coop_blocks = 4096;
   }
   if (coop) {
+    const int      psleep = getenv("HIPX_SOR_COOP_SLEEP") ? atoi(getenv("HIPX_SOR_COOP_SLEEP")) : 1;  // back-off between two looks of a poll: s_sleep 8 / 4 / 2 / 1 / none = 7.23 / 7.13 / 7.08 / 7.06 / 7.06 ms
     unsigned       cgrid = (unsigned)coop_blocks;
     const unsigned cneed = (unsigned)((T->nslots4 / (64 / INO_G) * 64 + SOR_THREADS - 1) / SOR_THREADS);
     if (cgrid > cneed) cgrid = cneed ? cneed : 1;
 #define HIPX_INODE_COOP(NSM) \
-  sor_inode_coop_kernel<KIND, NSM><<<cgrid, SOR_THREADS, 0, st>>>(T->nslots4, T->d_smeta4, T->d_sks4, T->d_sp4, T->d_nj, T->d_nv, T->d_ibd, rhs, S->d_t, xold, xnew, xacc, S->d_ctl)
+  sor_inode_coop_kernel<KIND, NSM><<<cgrid, SOR_THREADS, 0, st>>>(T->nslots4, T->d_smeta4, T->d_sks4, T->d_sp4, T->d_nj, T->d_nv, T->d_ibd, rhs, S->d_t, xold, xnew, xacc, S->d_ctl, psleep)
     switch (T->nsm) {
     case 2: HIPX_INODE_COOP(2); break;
     case 3: HIPX_INODE_COOP(3); break;

@@ -232,3 +232,21 @@ def test_both_forms_of_the_node_sweep(hx, coop):
             assert mode == 3 and np.array_equal(g, sor_cpu(ai, aj, aa, b, flag, its, 1, x0)), (flag, its)
     finally:
         os.environ.pop("HIPX_SOR_INODE_COOP", None)
+
+
+def test_a_wrong_partition_is_refused(hx):
+    """hipxMatSetInodes with rows that do NOT share a column list: the relaxation refuses it (error 73, as PETSC_ERR_ARG_WRONGSTATE) instead of reading past rows."""
+    from petsc_amd import _lib
+    ai, aj, aa = orc.stencil("7pt", 6)
+    N = len(ai) - 1
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    ns = np.arange(0, N + 1, 2, dtype=np.int32)  # pairs of stencil rows: different columns
+    _lib.chk(hx.hipxMatSetInodes(A, len(ns) - 1, ns.ctypes.data_as(C.c_void_p)))
+    B, X = _lib.DVec(N, np.ones(N)), _lib.DVec(N)
+    rc = hx.hipxMatSOR(A, B.ptr, 1.0, ZERO | 12, 0.0, 1, 1, X.ptr)
+    assert rc == 73, rc
+    _lib.chk(hx.hipxMatSetInodes(A, 0, None))
+    _lib.chk(hx.hipxMatSOR(A, B.ptr, 1.0, ZERO | 12, 0.0, 1, 1, X.ptr))
+    B.free()
+    X.free()
+    _lib.mat_destroy(A)
