@@ -40,6 +40,7 @@ KATS = {  # name -> source (reference tree)
     "sf_ex1": "vec/is/sf/tests/ex1.c",          # PetscSF Bcast / Reduce / FetchAndOp / Gather / Scatter / Compose ... (-sf_type hipx: SURVEY 8(f3))
     "sf_ex2": "vec/is/sf/tests/ex2.c",          # VecScatter from a device vector into a host-resident one (the reference's own hip test)
     "sf_ex4": "vec/is/sf/tests/ex4.c",          # PetscSFCompose
+    "pc_ex3": "ksp/pc/tests/ex3.c",             # GMRES + symmetric PCSOR on a tridiagonal MATSEQAIJ (the reference's MatSOR test), monitor golden
 }
 CFLAGS = ["-fPIC", "-O2", "-fstack-protector", "-fvisibility=hidden", "-w", "-I" + CONF, "-I" + os.path.join(REF, "include")]
 

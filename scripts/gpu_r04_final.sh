@@ -19,6 +19,7 @@ S0=$SECONDS
 HIPX_BENCH_KEEP_PROFILES=$O/pmc timeout 1500 python bench.py > $O/bench_default.json 2>$O/bench_default.err
 echo "default bench: rc $? $((SECONDS - S0)) s" | tee -a $O/bench_default.err
 tail -1 $O/bench_default.json | cut -c1-260
+if [ -n "$HIPX_FINAL_LITE" ]; then echo "lite run: suite + smoke + default bench only; total ${SECONDS}s"; exit 0; fi
 stats() { # name, bench args...
   local name=$1; shift
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o s -- python $GRAFT_REPO_ROOT/bench.py "$@" > $O/prof_$name.json 2>/dev/null)

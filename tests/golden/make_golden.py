@@ -70,6 +70,9 @@ KATS = [
     ("sf_ex1_basic_1", "kat_sf_ex1", "-user_sf_type hipx -sf_type hipx -options_left no", "notype", "vec/is/sf/tests/output/ex1_basic_1.out"),
     ("sf_ex4_1", "kat_sf_ex4", "-sf_type hipx -options_left no", "notype", "vec/is/sf/tests/output/ex4_1.out"),
     ("sf_ex2_device", "kat_sf_ex2", "-vec_hipx_memtype -sf_type hipx", "none", "vec/is/sf/tests/output/ex2_1.out"),
+    # src/ksp/pc/tests/ex3.c, suffix sor_aij ("SOR / Richardson-SOR"): GMRES + symmetric PCSOR on the 1-D Laplacian; the vectors
+    # are VecCreateSeq's (host): MatMult / MatSOR of the hipx matrix stage them.  The golden was written with %g
+    ("pc_ex3_sor_aij", "kat_pc_ex3", "-ksp_type gmres -ksp_monitor -pc_type sor -pc_sor_symmetric -mat_type seqaij -options_left no", "monitor", "ksp/pc/tests/output/ex3_1.out"),
 ] + [("mat_ex123_1_%s_l%d_n%d" % (mt, la, ng), "kat_mat_ex123", "-mat_type %s -localapi %d -neg %d -options_left no" % (mt, la, ng), "ex123", "mat/tests/output/ex123_1.out")
      for mt in ("seqaij", "mpiaij") for la in (0, 1) for ng in (0, 1)]
 
