@@ -252,7 +252,7 @@ template <bool DEPLOW>
 __device__ __forceinline__ double sor_minusdot(double sum, hipx_int i, int64_t k0, int64_t k1, const hipx_int *__restrict__ pj, const double *__restrict__ pa,
                                                const double *xold, const double *xnew, unsigned int *err)
 {
-  constexpr int CH = 8;  // entries whose column/value loads are all in flight before the first poll
+  constexpr int CH = 16;  // entries whose column/value loads are all in flight before the first poll (16: the 13 - 14 dependency entries of a 27-point row in ONE chunk -- with 8 the second chunk's loads waited behind the first chunk's polls)
   for (int64_t k = k0; k < k1; k += CH) {
     hipx_int j[CH];
     double   a[CH], v[CH];

@@ -346,6 +346,34 @@ def test_config4_surrogate_full_vector_bit_exact(hx):
     _lib.mat_destroy(A)
 
 
+def test_config4_pcsor_at_full_size_bit_exact(hx):
+    """PCSOR's application on the config-4 stand-in at its full size (1,536,000 rows, 121 M nonzeros, 512,000 nodes of three rows, 1344 dependency
+    levels): the node-level sweep of a matrix with inodes against the oracle's MatSOR_SeqAIJ_Inode restatement (pinned bit for bit against the
+    reference's own MatSOR, tests/golden/inode_sor.json): the zero-guess symmetric sweep PCSOR applies, and two general iterations, every entry."""
+    sys.path.insert(0, os.path.dirname(__file__))
+    from petsc_amd import _lib
+    from surrogates import flan_surrogate_spd
+    ai, aj, aa = flan_surrogate_spd()
+    N = len(ai) - 1
+    rng = np.random.default_rng(12)
+    b, x0 = rng.standard_normal(N), rng.standard_normal(N)
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    B, X = _lib.DVec(N, b), _lib.DVec(N)
+    for flag, its in ((16 | 12, 1), (3, 2)):
+        X.set(x0)
+        _lib.chk(hx.hipxMatSOR(A, B.ptr, 1.0, flag, 0.0, its, 1, X.ptr))
+        mode, nc = C.c_int(-2), C.c_int32(-5)
+        _lib.chk(hx.hipxMatGetSORMode(A, C.byref(mode)))
+        _lib.chk(hx.hipxMatGetInodes(A, C.byref(nc)))
+        assert mode.value == 3 and nc.value == N // 3
+        xo = x0.copy()
+        assert orc.lib().orc_MatSOR_SeqAIJ_dispatch(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(b), C.c_double(1.0), flag, C.c_double(0.0), its, 1, orc.P(xo), 0) == 0
+        assert np.array_equal(X.get(), xo), (flag, its)
+    B.free()
+    X.free()
+    _lib.mat_destroy(A)
+
+
 @pytest.mark.parametrize("stencil,dims,pc,key_its", [(7, (512, 512, 512), "jacobi", 24), (7, (1024, 1024, 128), "none", 12), (27, (160, 160, 160), "jacobi", 40)])
 def test_large_configurations_follow_the_committed_exact_histories(hx, stencil, dims, pc, key_its):
     """VERDICT r2 item 2(c, d): 7-pt 512^3 (134 M rows), config 5's per-GPU box 1024 x 1024 x 128 (134 M rows, PCNONE) and 27-pt
