@@ -67,3 +67,43 @@ def test_krylov_history_vs_reference(name):
     assert np.abs(hist - href).max() <= 1e-12 * href[0]
     assert (np.abs(hist - href) / href).max() <= 1e-8
     assert abs(np.linalg.norm(x - 1) - g["error"]) <= 1e-9 * max(g["error"], 1e-30) + 1e-13
+
+
+# ---- matrices with inodes, LIVE against the reference (where oracle/_ref is built: this container and the GPU box; the committed vectors
+# of tests/golden/inode_sor.json cover every other place, tests/test_oracle.py)
+REF_EXE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "bin", "ref_driver")
+
+
+def _ref_lines(args, tag):
+    import subprocess
+    r = subprocess.run([REF_EXE] + args + ["-mat_type", "aij", "-vec_type", "standard"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300,
+                       env=dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-2000:]
+    return np.array([float(ln.split()[2]) for ln in r.stdout.splitlines() if ln.startswith(tag)])
+
+
+@pytest.mark.parametrize("seed,nnodes,sizes", [(101, 90, (1, 2, 3, 4, 5)), (102, 150, (3,)), (103, 120, (2, 5)), (104, 80, (4, 1))])
+def test_inode_restatements_against_the_live_reference(tmp_path, seed, nnodes, sizes):
+    """Other matrices than the golden one (node-size mixes, seeds): MatMult (inode.c:356), MatMultAdd-free y = A x, and MatSOR in five sweep
+    configurations -- the reference's executable run here, the oracle's dispatching restatements held to it bit for bit."""
+    if not os.path.exists(REF_EXE):
+        pytest.skip("oracle/_ref is not built here")
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from petsc_amd import matio
+    from surrogates import inode_matrix
+    ai, aj, aa = inode_matrix(nnodes=nnodes, seed=seed, sizes=sizes, long_run=len(sizes) > 2)
+    aa = aa * (1.0 + 1e-3 * np.random.default_rng(seed).standard_normal(len(aa)))  # no longer multiples of 2^-10: the summation orders show
+    N = len(ai) - 1
+    f = str(tmp_path / "m.bin")
+    matio.write_petsc_binary(f, ai, aj, aa)
+    x = 1.0 + (np.arange(N) % 17) / 17.0
+    y = _ref_lines(["-f", f, "-dump_y", "-ksp_max_it", "1"], "y ")
+    assert np.array_equal(y, orc.matmult_ref(ai, aj, aa, x)) and not np.array_equal(y, orc.matmult_ref(ai, aj, aa, x, no_inode=True))
+    b = orc.matmult_ref(ai, aj, aa, np.ones(N))  # ref_driver's b = MatMult(A, 1): the inode product
+    for flag, its in ((16 | 12, 1), (3, 2), (2, 2), (16 | 1, 2), (32, 1)):
+        xr = _ref_lines(["-f", f, "-dump_sor", str(flag), "-sor_its", str(its), "-ksp_max_it", "1"], "sor ")
+        xo = 0.5 + (np.arange(N) % 7) / 7.0
+        assert orc.lib().orc_MatSOR_SeqAIJ_dispatch(N, orc.P(ai), orc.P(aj), orc.P(aa), orc.P(b), C.c_double(1.0), flag, C.c_double(0.0), its, 1, orc.P(xo), 0) == 0
+        assert len(xr) == N and np.array_equal(xr, xo), (flag, its, np.abs(xr - xo).max())
