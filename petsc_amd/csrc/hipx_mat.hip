@@ -4186,9 +4186,11 @@ int hipxMatMultCGDirectionDotBegin(hipxMat A, const double *p_old, double *p_new
   static const bool off = getenv("HIPX_NO_CGFUSE") != nullptr;
   if (off || A->compressed || A->m != A->n || A->m <= 0) return HIPX_SUCCESS;
   if ((reinterpret_cast<uintptr_t>(p_old) | reinterpret_cast<uintptr_t>(p_new) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) return HIPX_SUCCESS;
-  bool tm = false;
-  int  ierr = use_templates(A, tm);
+  bool tm = false, ip = false, ips = false;
+  int  ierr = use_inode_pair(A, ip, ips);  // a matrix with inodes is multiplied in MatMult_SeqAIJ_Inode's order: never by the template kernels
   if (ierr) return ierr;
+  if (ip) return HIPX_SUCCESS;
+  if ((ierr = use_templates(A, tm))) return ierr;
   if (!tm || !march_applies(A) || getenv("HIPX_MARCH1") || getenv("HIPX_TMPL_TRACE")) return HIPX_SUCCESS;
   if ((ierr = march2_check(A))) return ierr;
   if (A->march2_state != 1 || !march2_cg_shape(A)) return HIPX_SUCCESS;
