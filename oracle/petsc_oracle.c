@@ -968,7 +968,10 @@ typedef struct {
   /* per-rank diagonal blocks for PCSOR on a simulated MPIAIJ partition */
   OInt    **Ai, **Aj;
   OScalar **Aa;
-  int       inode_mult; /* the operator has inodes (one rank): MatMult is MatMult_SeqAIJ_Inode (aij.c:1459) */
+  int       inode_mult; /* the operator has inodes (one rank): MatMult is MatMult_SeqAIJ_Inode (aij.c:1459).  On a simulated row partition
+                           (nranks > 1) the products are NOT restated per block (diagonal block with its own inodes, then the off-diagonal
+                           block without: mpiaij.c:824) -- blocked matrices on several ranks are checked against the live MPI reference
+                           instead (tests/test_gpu_plugin_mpi.py); the relaxation is dispatched per block either way (pc_apply) */
 } Ctx;
 
 static void ksp_mult(const Ctx *c, const OScalar *x, OScalar *y)
