@@ -2279,10 +2279,6 @@ struct InodeState {
   int4     *d_smeta4 = nullptr;
   int64_t  *d_sks4 = nullptr;
   hipx_int *d_sp4 = nullptr;
-  // the per-node tables in NATURAL node order (the run kernel: a workgroup owns 256 consecutive nodes)
-  int4     *d_umeta = nullptr;
-  int64_t  *d_uks = nullptr;
-  hipx_int *d_up = nullptr;
   unsigned int zero_pivots = 0;
   int64_t   nentries = 0;
 };
@@ -2302,9 +2298,6 @@ void inode_free(InodeState *T)
   (void)hipFree(T->d_smeta4);
   (void)hipFree(T->d_sks4);
   (void)hipFree(T->d_sp4);
-  (void)hipFree(T->d_umeta);
-  (void)hipFree(T->d_uks);
-  (void)hipFree(T->d_up);
   delete T;
 }
 
@@ -2459,22 +2452,6 @@ int inode_build(InodeState *T, hipx_int m, int64_t nnz, int is64, const void *d_
   HIPX_HIP(hipMemcpy(T->d_smeta4, smeta4.data(), sizeof(int4) * smeta4.size(), hipMemcpyHostToDevice));
   HIPX_HIP(hipMemcpy(T->d_sks4, sks4.data(), sizeof(int64_t) * sks4.size(), hipMemcpyHostToDevice));
   HIPX_HIP(hipMemcpy(T->d_sp4, sp4.data(), sizeof(hipx_int) * sp4.size(), hipMemcpyHostToDevice));
-  {  // natural node order
-    std::vector<int4>     um((size_t)nnodes);
-    std::vector<int64_t>  uk((size_t)nnodes);
-    std::vector<hipx_int> upv((size_t)nnodes);
-    for (hipx_int p = 0; p < nnodes; p++) {
-      um[perm[p]]  = nmeta[p];
-      uk[perm[p]]  = nks[p];
-      upv[perm[p]] = p;
-    }
-    HIPX_HIP(hipMalloc((void **)&T->d_umeta, sizeof(int4) * (size_t)nnodes));
-    HIPX_HIP(hipMalloc((void **)&T->d_uks, sizeof(int64_t) * (size_t)nnodes));
-    HIPX_HIP(hipMalloc((void **)&T->d_up, sizeof(hipx_int) * (size_t)nnodes));
-    HIPX_HIP(hipMemcpy(T->d_umeta, um.data(), sizeof(int4) * (size_t)nnodes, hipMemcpyHostToDevice));
-    HIPX_HIP(hipMemcpy(T->d_uks, uk.data(), sizeof(int64_t) * (size_t)nnodes, hipMemcpyHostToDevice));
-    HIPX_HIP(hipMemcpy(T->d_up, upv.data(), sizeof(hipx_int) * (size_t)nnodes, hipMemcpyHostToDevice));
-  }
   T->ready = true;
   return HIPX_SUCCESS;
 }
@@ -2817,160 +2794,6 @@ __global__ __launch_bounds__(SOR_THREADS) void sor_inode_coop_kernel(hipx_int ns
   }
 }
 
-// The RUN form (experimental, HIPX_SOR_INODE_RUN=1; round 4's last experiment): the cooperative form pays one memory hop (~2.6 us: publish -> visible to
-// another XCD -> poll) per dependency level whoever the producer is.  On a mesh numbering most of a node's latest predecessors are NEAR it in the
-// numbering (config-4 stand-in: 81 % of the critical path's edges stay inside a run of 256 consecutive nodes), so here a workgroup of 16 waves owns a RUN
-// of 256 consecutive nodes (natural order, runs taken in ticket order): wave w works through nodes u0 + w, u0 + w + 16, ... one node at a time with its 64
-// lanes (one pair of entries per lane and pass, the terms through LDS, the reference's chain); a NEW operand that belongs to the run is polled out of
-// the run's LDS window (~0.1 us), every other one out of the new vector in memory as before; results go to both.  Waves are independent instruction
-// streams, so a wave spinning on a node of its own workgroup does not hold that node's wave up (the reason the lanes of ONE wave may not wait for each
-// other).  Progress: wave w's nodes are taken in dependency direction, every node waits only for lower (forward) / higher (backward) nodes -- of this
-// run (another wave's earlier or current node, by induction never blocked) or of an earlier ticket.
-constexpr int RUN_NODES = 256, RUN_WAVES = 16, RUN_THREADS = RUN_WAVES * 64;
-typedef volatile __attribute__((address_space(3))) unsigned long long run_lds_u64;
-typedef __attribute__((address_space(3))) unsigned long long         run_lds_u64_nv;
-
-__device__ __forceinline__ double run_poll_lds(run_lds_u64 *w, unsigned int *err)
-{
-  unsigned long long v = *w;
-  int                spins = 0;
-  long long          t0 = 0;
-  while (v == SOR_SENTINEL) {
-    __builtin_amdgcn_s_sleep(2);  // (up to 15 waves of the workgroup poll this LDS while a 16th runs its chain out of it)
-    v = *w;
-    ++spins;
-    if ((spins & 0x3ff) == 0) {
-      const long long now = (long long)wall_clock64();
-      if (!t0) t0 = now;
-      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || now - t0 > SOR_SPIN_TICKS) {
-        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-  }
-  return __longlong_as_double((long long)v);
-}
-
-// entries [k0, k1) of the wave's node, one pair per lane and pass (128 entries per pass); SRC as in inode_minus; NEW operands of rows [row_lo, row_hi)
-// come from the run's LDS window
-template <int NSM, int SRC>
-__device__ __forceinline__ void inode_run_minus(double (&sum)[NSM], double (*Q)[NSM], const int lane, int64_t k0, int64_t k1, hipx_int thr, const hipx_int *__restrict__ nj,
-                                                const double *__restrict__ nv, const double *xold, const double *xnew, run_lds_u64 *win, hipx_int row_lo, hipx_int row_hi, unsigned int *err)
-{
-  for (int64_t kc = k0; kc < k1; kc += 128) {
-    const int  cnt = (int)((k1 - kc) < 128 ? (k1 - kc) : 128);
-    const int  np  = (cnt + 1) >> 1;
-    const bool v0 = 2 * lane < cnt, v1 = 2 * lane + 1 < cnt;
-    const int64_t e0 = v0 ? kc + 2 * lane : k0, e1 = v1 ? kc + 2 * lane + 1 : e0;
-    const hipx_int j0 = nj[e0], j1 = nj[e1];
-    double         a0[NSM], a1[NSM];
-#pragma unroll
-    for (int r = 0; r < NSM; r++) {
-      a0[r] = nv[e0 * NSM + r];
-      a1[r] = nv[e1 * NSM + r];
-    }
-    const bool d0 = SRC == 0 || (SRC == 2 && j0 >= thr), d1 = SRC == 0 || (SRC == 2 && j1 >= thr);
-    const bool l0 = d0 && j0 >= row_lo && j0 < row_hi, l1 = d1 && j1 >= row_lo && j1 < row_hi;
-    double     x0 = 0.0, x1 = 0.0;
-    // first look at the memory operands (loads overlap), then the waits
-    if (d0 && !l0) x0 = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(xnew + j0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    else if (!d0) x0 = xold[j0];
-    if (d1 && !l1) x1 = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(xnew + j1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    else if (!d1) x1 = xold[j1];
-    if (v0 && d0 && !l0 && (unsigned long long)__double_as_longlong(x0) == SOR_SENTINEL) x0 = sor_poll_sel(xnew + j0, err, 1);
-    if (v1 && d1 && !l1 && (unsigned long long)__double_as_longlong(x1) == SOR_SENTINEL) x1 = sor_poll_sel(xnew + j1, err, 1);
-    if (v0 && l0) x0 = run_poll_lds(win + (j0 - row_lo), err);
-    if (v1 && l1) x1 = run_poll_lds(win + (j1 - row_lo), err);
-    if (v0) {
-#pragma unroll
-      for (int r = 0; r < NSM; r++) {
-        const double p0 = a0[r] * x0;
-        Q[lane][r]      = v1 ? p0 + a1[r] * x1 : p0;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int q = 0; q < np; q++) {
-#pragma unroll
-      for (int r = 0; r < NSM; r++) sum[r] -= Q[q][r];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-}
-
-template <int KIND, int NSM>
-__global__ __launch_bounds__(RUN_THREADS) void sor_inode_run_kernel(hipx_int nnodes, const int4 *__restrict__ umeta, const int64_t *__restrict__ uks, const hipx_int *__restrict__ up,
-                                                                     const hipx_int *__restrict__ nj, const double *__restrict__ nv, const double *__restrict__ ibd, const double *rhs,
-                                                                     double *t, const double *xold, double *xnew, double *xacc, unsigned int *ctl)
-{
-  constexpr bool FWD = (KIND == 0 || KIND == 3 || KIND == 5);
-  __shared__ unsigned long long s_win[RUN_NODES * NSM];  // the run's rows of the NEW vector (bit patterns; sentinel = not there yet)
-  __shared__ double             s_q[RUN_WAVES][64][NSM];
-  __shared__ unsigned int       s_ticket;
-  unsigned int  *err = ctl + 1;
-  const int      lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  double(*Q)[NSM]     = s_q[wv];
-  run_lds_u64 *win    = (run_lds_u64 *)(run_lds_u64_nv *)s_win;
-  const hipx_int nruns = (nnodes + RUN_NODES - 1) / RUN_NODES;
-  for (;;) {
-    if (threadIdx.x == 0) s_ticket = atomicAdd(&ctl[0], 1u);
-    __syncthreads();
-    const unsigned int tk = s_ticket;
-    if ((hipx_int)tk >= nruns) return;
-    const hipx_int run = FWD ? (hipx_int)tk : nruns - 1 - (hipx_int)tk;
-    const hipx_int u0 = run * RUN_NODES, u1 = (u0 + RUN_NODES < nnodes) ? u0 + RUN_NODES : nnodes;
-    const hipx_int row_lo = umeta[u0].x;
-    const int4     mlast  = umeta[u1 - 1];
-    const hipx_int row_hi = mlast.x + mlast.y;
-    for (int i = threadIdx.x; i < row_hi - row_lo; i += RUN_THREADS) win[i] = SOR_SENTINEL;
-    __syncthreads();
-    for (int k = 0; k < RUN_NODES / RUN_WAVES; k++) {
-      const hipx_int u = FWD ? u0 + wv + k * RUN_WAVES : u1 - 1 - wv - k * RUN_WAVES;
-      if (u < u0 || u >= u1) break;  // (wave-uniform)
-      const int4     mt = umeta[u];
-      const int64_t  ks = uks[u];
-      const hipx_int r0 = mt.x;
-      const int      ns = mt.y, l = lane;
-      const double  *D  = ibd + (size_t)up[u] * (size_t)(NSM * NSM);
-      double         sum[NSM];
-#pragma unroll
-      for (int r = 0; r < NSM; r++) sum[r] = (r < ns) ? rhs[r0 + r] : 0.0;
-      double dcol[NSM];
-#pragma unroll
-      for (int c = 0; c < NSM; c++) dcol[c] = (l < ns && c < ns) ? D[c * ns + l] : 0.0;
-      const double xo = (KIND == 4 && l < ns) ? xold[r0 + l] : 0.0;
-      if (KIND == 0 || KIND == 3 || KIND == 5) {
-        inode_run_minus<NSM, 0>(sum, Q, lane, ks, ks + mt.z, 0, nj, nv, xold, xnew, win, row_lo, row_hi, err);
-        if (KIND != 5 && l < ns) {
-          double sl = sum[0];
-#pragma unroll
-          for (int c = 1; c < NSM; c++) sl = (l == c) ? sum[c] : sl;
-          t[r0 + l] = sl;
-        }
-        if (KIND == 3) inode_run_minus<NSM, 1>(sum, Q, lane, ks + mt.z + ns, ks + mt.w, 0, nj, nv, xold, xnew, win, row_lo, row_hi, err);
-      } else if (KIND == 1 || KIND == 2) {
-        inode_run_minus<NSM, 0>(sum, Q, lane, ks + mt.z + ns, ks + mt.w, 0, nj, nv, xold, xnew, win, row_lo, row_hi, err);
-      } else {
-        inode_run_minus<NSM, 2>(sum, Q, lane, ks, ks + mt.w, r0 + ns, nj, nv, xold, xnew, win, row_lo, row_hi, err);
-      }
-      if (l < ns) {
-        double acc = sum[0] * dcol[0];
-#pragma unroll
-        for (int c = 1; c < NSM; c++)
-          if (c < ns) acc = acc + sum[c] * dcol[c];
-        if (KIND == 4) acc = xo + acc;
-        win[r0 + l - row_lo] = (unsigned long long)__double_as_longlong(acc);
-        sor_publish(xnew + r0 + l, acc);
-        if (KIND == 5) xacc[r0 + l] += acc;
-      }
-    }
-    __syncthreads();  // the window and the ticket word are reused by the next run
-  }
-}
-
 // Eisenstat's middle step on the nodes (inode.c:3559-3628): t = b - D x, the block product summed over the node's columns in ascending order
 __global__ void inode_eisenstat_mid_kernel(hipx_int nnodes, int nsm, const int4 *__restrict__ nmeta, const double *__restrict__ bd, const double *__restrict__ b, const double *__restrict__ x,
                                            double *__restrict__ t)
@@ -3015,23 +2838,6 @@ int run_inode(hipxSorState *S, const double *rhs, const double *xold, double *xn
     if (e) coop_blocks = atoi(e);
     if (coop_blocks < 1) coop_blocks = 1;
     if (coop_blocks > 4096) coop_blocks = 4096;
-  }
-  if (getenv("HIPX_SOR_INODE_RUN") && atoi(getenv("HIPX_SOR_INODE_RUN")) && T->d_umeta) {  // experimental: see sor_inode_run_kernel
-    unsigned rgrid = getenv("HIPX_SOR_INODE_RUN_BLOCKS") ? (unsigned)atoi(getenv("HIPX_SOR_INODE_RUN_BLOCKS")) : 256u;
-    const unsigned rneed = (unsigned)((T->nnodes + RUN_NODES - 1) / RUN_NODES);
-    if (rgrid > rneed) rgrid = rneed ? rneed : 1;
-    if (rgrid < 1) rgrid = 1;
-#define HIPX_INODE_RUN(NSM) \
-  sor_inode_run_kernel<KIND, NSM><<<rgrid, RUN_THREADS, 0, st>>>(T->nnodes, T->d_umeta, T->d_uks, T->d_up, T->d_nj, T->d_nv, T->d_ibd, rhs, S->d_t, xold, xnew, xacc, S->d_ctl)
-    switch (T->nsm) {
-    case 2: HIPX_INODE_RUN(2); break;
-    case 3: HIPX_INODE_RUN(3); break;
-    case 4: HIPX_INODE_RUN(4); break;
-    default: HIPX_INODE_RUN(5); break;
-    }
-#undef HIPX_INODE_RUN
-    HIPX_LAUNCH_CHECK();
-    return HIPX_SUCCESS;
   }
   if (coop) {
     const int      psleep = getenv("HIPX_SOR_COOP_SLEEP") ? atoi(getenv("HIPX_SOR_COOP_SLEEP")) : 1;  // back-off between two looks of a poll: s_sleep 8 / 4 / 2 / 1 / none = 7.23 / 7.13 / 7.08 / 7.06 / 7.06 ms
