@@ -97,9 +97,13 @@ class MatrixCfg(Cfg):
         self.name, self._load, self.ksp, self.pc, self.scaling, self.label, self.golden = name, load, ksp, pc, "strong", None, None
         self.stencil, self.dims, self.N, self.cube = 0, (0, 0, 0), 0, False
         self.binfile = None
+        self.golden_name = None  # key stem in tests/golden/exact_histories.json ("<ksp>_<pc>_<golden_name>") when the matrix is a deterministic stand-in
+        self._cache = None       # the host CSR, shared by the legs of one bench run
 
     def load(self):
-        ai, aj, aa = self._load()
+        if self._cache is None:
+            self._cache = self._load()
+        ai, aj, aa = self._cache
         self.N = len(ai) - 1
         self.dims = (self.N, 1, 1)
         return ai, aj, aa
@@ -742,24 +746,32 @@ def leg_sor_arbitrary_values(hx, lib, ks, n=256):
     return out
 
 
-def leg_matrix_solver(cfg, steps, warmup, sync, torch, best_ranks=None, parity_its=10, cpu_its=10, tmpdir=None):
-    """BASELINE config 4's solver leg: KSPCG + PCJACOBI on a given matrix (a file, or the SPD Flan-like stand-in) on one GPU --
-    iterations/s, the SpMV kernel auto picks with its roofline on the CSR bytes, the first iterations against the REFERENCE's own
-    MatLoad + KSPSolve with exact BLAS reductions (`ref_driver -f`, oracle/libexactblas.so preloaded), and that reference timed on the
-    host cores."""
+def leg_matrix_solver(cfg, steps, warmup, sync, torch, best_ranks=None, parity_its=10, cpu_its=10, tmpdir=None, allow_ref_run=True):
+    """BASELINE config 4's solver leg: KSPCG + PCJACOBI / PCSOR on a given matrix (a file, or the SPD Flan-like stand-in) on one GPU --
+    iterations/s, the SpMV kernel auto picks with its roofline on the CSR bytes, and the first iterations against the REFERENCE's own
+    MatLoad + KSPSolve with exact BLAS reductions (`ref_driver -f`, oracle/libexactblas.so preloaded): the committed history of that run
+    (tests/golden/exact_histories.json, written by tests/golden/make_exact_golden.py from the same deterministic stand-in) when there is
+    one, else -- `allow_ref_run` -- the run itself beside this one (the matrix is written as a PETSc binary file first: tens of seconds)."""
     from petsc_amd import matio
     t0 = time.perf_counter()
     P = Problem(cfg, 0, 1, None, keep_host=True)
     kname = P.setup(0)
     t_setup = time.perf_counter() - t0
-    par = {"pass": None, "reference": "oracle/_ref not on this box"}
+    par = {"pass": None, "reference": "no committed history and no reference run (budget, or oracle/_ref not on this box)"}
     own_tmp = None
     exe = os.path.join(ROOT, "oracle", "_ref", "bin", "ref_driver")
-    if os.path.exists(exe) and parity_its:
-        if cfg.binfile is None:
-            own_tmp = tmpdir or tempfile.mkdtemp(prefix="hipx_mat_")
-            cfg.binfile = os.path.join(own_tmp, "matrix.bin")
-            matio.write_petsc_binary(cfg.binfile, *P.host_csr)
+    hgold, gsrc = (golden_history("%s_%s_%s" % (cfg.ksp, cfg.pc, cfg.golden_name)) if cfg.golden_name else (None, None))
+    if parity_its and hgold is not None and len(hgold) > parity_its:
+        hist = P.solve(parity_its, history=True)
+        href = hgold[:len(hist)]
+        rel = float((np.abs(hist - href) / np.abs(href)).max())
+        par = {"pass": bool(rel <= GATE_TOL), "max_rel_diff": rel, "tolerance": GATE_TOL, "iterations": parity_its, "entries": len(hist),
+               "reference": "tests/golden/exact_histories.json[%s_%s_%s] (%s: the REFERENCE's MatLoad + KSPSolve on the same matrix with exact BLAS reductions)" % (cfg.ksp, cfg.pc, cfg.golden_name, gsrc)}
+    if os.path.exists(exe) and allow_ref_run and cfg.binfile is None:
+        own_tmp = tmpdir or tempfile.mkdtemp(prefix="hipx_mat_")
+        cfg.binfile = os.path.join(own_tmp, "matrix.bin")
+        matio.write_petsc_binary(cfg.binfile, *P.host_csr)
+    if os.path.exists(exe) and parity_its and par["pass"] is None and cfg.binfile:
         hist = P.solve(parity_its, history=True)
         refx = ref_driver(1, cfg.driver_args(parity_its) + ["-history"], exact=True, timeout=1800)
         if refx is not None and len(refx["history"]) == len(hist):
@@ -774,7 +786,8 @@ def leg_matrix_solver(cfg, steps, warmup, sync, torch, best_ranks=None, parity_i
     byts = P.spmv_bytes()
     out = {"metric": cfg.metric(), "iterations_per_s": steps / r["elapsed"], "ms_per_step": 1e3 * r["elapsed"] / steps, "steps": steps, "warmup": warmup,
            "rows": P.m, "nnz": P.nnz_local, "spmv_kernel": kname, "parity": par, "residual_norm_after": r["rnorm"], "setup_seconds": t_setup, "setup_split": dict(P.setup_times),
-           "roofline_spmv": {"bound": "hbm", "avg_launch_ms": r["spmv_ms"], "launches": r["launches"], "algorithmic_bytes": byts,
+           "spmv_ms": r["spmv_ms"],
+           "roofline_spmv": {"bound": "hbm", "kernel": kname, "avg_launch_ms": r["spmv_ms"], "launches": r["launches"], "algorithmic_bytes": byts,
                              "achieved": byts / (r["spmv_ms"] * 1e-3) / 1e9 if r["spmv_ms"] > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": byts / (r["spmv_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if r["spmv_ms"] > 0 else 0.0, "traffic": None}}
     if cfg.pc == "sor":  # PCSOR on a matrix without row templates: the dependency-driven (level-ordered) schedule, hipx_sor.hip
@@ -807,7 +820,171 @@ def config4_cfg(path=None):
         return cfg
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from surrogates import flan_surrogate_spd
-    return MatrixCfg("Flan_1565 stand-in (hexahedral elasticity pattern, 1536000 rows, 121 M nonzeros, SPD, distinct values; tests/surrogates.py)", flan_surrogate_spd)
+    cfg = MatrixCfg("Flan_1565 stand-in (hexahedral elasticity pattern, 1536000 rows, 121 M nonzeros, SPD, distinct values; tests/surrogates.py)", flan_surrogate_spd)
+    cfg.golden_name = "flan_standin"
+    return cfg
+
+
+
+# --------------------------------------------------------------------------------------------------- the contract line (compact)
+LINE_LIMIT = 4000  # bytes: the driver keeps a few KB of stdout; round 4's 25 KB line could not be parsed
+
+
+def _num(v, digits=6):
+    """Numbers of the contract line: 6 significant digits are plenty there (bench_detail.json keeps everything)."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    try:
+        return float("%.*g" % (digits, float(v)))
+    except (TypeError, ValueError):
+        return v
+
+
+def _short(s, n):
+    s = "" if s is None else str(s)
+    return s if len(s) <= n else s[:n - 1] + "~"
+
+
+def _kshort(name):
+    """'spmv_march2_kernel (CSR MatMult, row templates: ...) + the CG ...' -> 'spmv_march2_kernel+cgdir'"""
+    if not name:
+        return name
+    base = str(name).split(" ")[0]
+    return base + ("+cgdir" if "prologue" in str(name) else "")
+
+
+def _leg_frac(leg):
+    """the dominant kernel's roofline fraction of an other_configs leg: SOR when the leg has one (it dominates), else the product"""
+    for key in ("roofline_sor", "roofline_longrow", "roofline_spmv", "roofline_cg_update"):
+        r = leg.get(key)
+        if isinstance(r, dict):
+            f = r.get("frac", r.get("frac_counter_bytes"))
+            if f is not None:
+                return key.replace("roofline_", ""), f
+            if r.get("frac_algorithmic_bytes") is not None:
+                return key.replace("roofline_", "") + " (algorithmic bytes)", r["frac_algorithmic_bytes"]
+    return None, None
+
+
+def compact_line(out):
+    """The ONE line the driver parses: the contract's fields, `parity_gate`, `roofline`, `cpu_baseline` and one number set per leg --
+    everything else (notes, per-kernel counter detail, per-rank tables, samples) is in bench_detail.json, written beside it."""
+    c = {}
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        c[k] = _num(out.get(k), 9)
+    cfg = out.get("config") or {}
+    c["config"] = {k: (_short(v, 170) if isinstance(v, str) else (v if k == "residual_norm_after" else _num(v))) for k, v in cfg.items()
+                   if k in ("workload", "global_rows", "parallelism", "transport", "fused", "pipeline", "reduction_mode", "residual_norm_after")}
+    if "error" in out:
+        c["error"] = _short(out["error"], 300)
+    c["ungated"] = out.get("ungated")
+    g = out.get("parity_gate") or {}
+    c["parity_gate"] = {k: _num(g.get(k)) for k in ("pass", "max_rel_diff", "tolerance", "iterations", "gated_reduction_mode") if k in g}
+    r = out.get("roofline")
+    if r:
+        rr = {"bound": r.get("bound"), "kernel": _kshort(r.get("kernel"))}
+        for k in ("achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_launch_ms", "effective_gbps", "iteration_frac", "dominant_by_time"):
+            if k in r:
+                rr[k] = _num(r[k])
+        if r.get("by_kernel"):  # [name, us per launch, launches per iteration, HBM bytes per launch, frac]
+            rr["by_kernel"] = [[_short(k.get("kernel") or k.get("match"), 60), _num(k.get("avg_launch_us"), 4), _num(k.get("launches_per_iteration"), 3), k.get("traffic"), _num(k.get("frac"), 4)]
+                               for k in r["by_kernel"] if k.get("launches_per_iteration", 0) >= 0.5]
+        for key in ("general", "unstructured"):
+            if isinstance(r.get(key), dict):
+                e = r[key]
+                rr[key] = {"kernel": _kshort(e.get("kernel")), "frac": _num(e.get("frac"), 4), "frac_counter_bytes": _num(e.get("frac_counter_bytes"), 4),
+                           "avg_launch_ms": _num(e.get("avg_launch_ms"), 4), "it_s": _num(e.get("iterations_per_s"), 5)}
+        c["roofline"] = rr
+    b = out.get("cpu_baseline")
+    if b:
+        c["cpu_baseline"] = {"value": _num(b.get("value")), "unit": b.get("unit"), "cores": b.get("cores"), "kind": b.get("kind"), "sample": _short(b.get("sample"), 200)}
+        if b.get("value_1core") is not None:
+            c["cpu_baseline"]["value_1core"] = _num(b["value_1core"])
+    else:
+        c["cpu_baseline"] = None
+    if out.get("plugin"):
+        c["plugin_it_s"] = {k: _num(v.get("iterations_per_s"), 5) for k, v in out["plugin"].items() if isinstance(v, dict)}
+    oc = out.get("other_configs")
+    if oc:
+        legs = {}
+        for name, leg in oc.items():
+            if not isinstance(leg, dict):
+                continue
+            if "error" in leg or "skipped" in leg:
+                legs[name] = {"error": _short(leg["error"], 80)} if "error" in leg else {"skipped": _short(leg["skipped"], 40)}
+                continue
+            e = {}
+            if leg.get("iterations_per_s") is not None:
+                e["it_s"] = _num(leg["iterations_per_s"], 5)
+            par = leg.get("parity")
+            if isinstance(par, dict):
+                e["parity"] = par.get("pass")
+                if par.get("max_rel_diff") is not None:
+                    e["rel"] = _num(par["max_rel_diff"], 3)
+            elif "sampled_rows_bit_identical" in leg:
+                e["parity"] = leg["sampled_rows_bit_identical"]
+            elif "bit_identical_to_level_ordered" in leg:
+                e["parity"] = leg["bit_identical_to_level_ordered"]
+            which, f = _leg_frac(leg)
+            if f is not None:
+                e["frac"], e["of"] = _num(f, 4), which
+            for k in ("spmv_ms", "strand_streamed_coefficients_ms"):
+                if leg.get(k) is not None:
+                    e["spmv_ms" if k == "spmv_ms" else "sor_ms"] = _num(leg[k], 4)
+            if isinstance(leg.get("roofline_sor"), dict) and leg["roofline_sor"].get("avg_call_ms") is not None:
+                e["sor_ms"] = _num(leg["roofline_sor"]["avg_call_ms"], 4)
+            if isinstance(leg.get("cpu_baseline"), dict):
+                e["cpu_it_s"] = _num(leg["cpu_baseline"].get("value"), 4)
+            legs[name] = e
+        c["other_configs"] = legs
+    mg = out.get("multi_gpu")
+    if mg:
+        c["multi_gpu"] = {"ranks": mg.get("ranks"), "distinct_devices": mg.get("distinct_devices"), "launcher": _short(mg.get("launcher"), 50),
+                          "transports": {t: {k: (_num(v.get(k), 5) if k != "parity" else (v.get(k) or {}).get("pass")) for k in ("probe_ok", "iterations_per_s", "parity", "comm_nranks") if k in v}
+                                         for t, v in (mg.get("transports") or {}).items()}}
+        if mg.get("note"):
+            c["multi_gpu"]["note"] = _short(mg["note"], 120)
+    pr = out.get("per_rank")
+    if pr:  # per rank: [rows, ghosts, product ms, ghost-exchange ms, all-reduce ms]
+        c["per_rank"] = [[p_.get("rows"), p_.get("ghosts"), _num(p_.get("spmv_ms"), 4), _num(p_.get("halo_ms"), 4), _num(p_.get("allreduce_ms"), 4)] for p_ in pr[:8]]
+    for k in ("wall_s", "budget_s", "detail"):
+        if k in out:
+            c[k] = _num(out[k], 4)
+    # never longer than the driver can read: drop the optional groups, least important first
+    def fits():
+        return len(json.dumps(c)) <= LINE_LIMIT
+    for victim in ("per_rank", "plugin_it_s", "multi_gpu"):
+        if fits():
+            break
+        c.pop(victim, None)
+    if not fits() and "other_configs" in c:  # one number per leg ...
+        c["other_configs"] = {k: (v.get("it_s", v.get("frac")) if isinstance(v, dict) else v) for k, v in c["other_configs"].items()}
+        while not fits() and c["other_configs"]:  # ... and, if a run has more legs than the line can name, the first ones only (all of them are in bench_detail.json)
+            c["other_configs"].popitem()
+            c["other_configs_truncated"] = True
+    if not fits() and "roofline" in c:
+        c["roofline"].pop("by_kernel", None)
+    return c
+
+
+def emit(out, t_start=None):
+    """Write everything to bench_detail.json (repo root, and gpurun_out/ when that exists) and print the compact contract line LAST."""
+    if t_start is not None:
+        out["wall_s"] = time.time() - t_start
+    out["detail"] = "bench_detail.json"
+    text = json.dumps(out)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(text + "\n")
+        except OSError:
+            pass
+    line = json.dumps(compact_line(out))
+    sys.stdout.flush()
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+    return line
 
 
 # ---------------------------------------------------------------------------------------------------------------------------- main
@@ -837,6 +1014,10 @@ def main():
                                                         "instead of a Poisson operator: BASELINE config 4 with the real SuiteSparse file")
     ap.add_argument("--no-other", action="store_true", help="skip the other_configs legs (configs 3/4/5 on one GPU; the scaling legs on N GPUs)")
     ap.add_argument("--quick", action="store_true", help="the timed legs only: no plugin / PMC / CPU-baseline / general-kernel / other-config legs")
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("HIPX_BENCH_BUDGET_S", "140")),
+                    help="wall-clock budget of the whole run (default 140 s): the headline (parity gate, timed steps, counter pass, CPU baseline) always runs; the optional legs (plugin rows, "
+                         "other_configs, their counter passes and CPU baselines) run in order of importance while their estimated cost still fits, the rest are reported as skipped")
+    ap.add_argument("--full", action="store_true", help="no budget: every leg, every counter pass, every CPU-baseline rank count (several minutes)")
     ap.add_argument("--suite", default=None, help=argparse.SUPPRESS)  # internal workloads of the counter passes (suite_mode)
     ap.add_argument("--suite-variants", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--suite-dims", default=None, help=argparse.SUPPRESS)
@@ -845,6 +1026,23 @@ def main():
     args = ap.parse_args()
     if args.suite:
         return suite_mode(args)
+    t_start = time.time()
+    deadline = float("inf") if (args.full or args.budget_s <= 0) else t_start + args.budget_s
+    timeline = []
+
+    def room(est):
+        """does a leg of estimated cost `est` seconds still fit the budget?"""
+        return time.time() + est <= deadline
+
+    class phase:  # with phase("name"): ...  -> timeline entry
+        def __init__(self, name):
+            self.name = name
+
+        def __enter__(self):
+            self.t = time.time()
+
+        def __exit__(self, *a):
+            timeline.append([self.name, round(time.time() - self.t, 2)])
     if args.quick:
         args.no_cpu_baseline = args.no_traffic = args.no_plugin = args.no_general = args.no_other = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -880,7 +1078,7 @@ def main():
             dist.barrier()
 
     if world > 1:
-        return main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync)
+        return main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync, t_start)
 
     # =========================================================================================================== one GPU
     if args.matrix_file:  # BASELINE config 4 with a supplied file (or `--matrix-file standin`: the documented stand-in): the whole line is that solve
@@ -889,12 +1087,11 @@ def main():
         ranks4 = None if args.no_cpu_baseline else max(2, physical_cores() // 4)
         r4 = leg_matrix_solver(cfg4, args.steps, args.warmup, sync, torch, best_ranks=ranks4, parity_its=0 if args.no_cpu_baseline else 10)
         rf = dict(r4["roofline_spmv"], kernel=r4["spmv_kernel"], basis="algorithmic CSR bytes / launch time (no counter pass on a file matrix)")
-        print(json.dumps({"metric": cfg4.metric(), "value": r4["iterations_per_s"] if r4["parity"].get("pass") is not False else None, "unit": "iterations/s", "n_gpus": 1,
+        emit({"metric": cfg4.metric(), "value": r4["iterations_per_s"] if r4["parity"].get("pass") is not False else None, "unit": "iterations/s", "n_gpus": 1,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": r4["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                           "dtype": "f64", "data": "file: %s" % args.matrix_file,
                           "config": {"workload": "%s (N=%d rows, nnz=%d), KSPCG + %s, b = A*1, x0 = 0" % (cfg4.name, r4["rows"], r4["nnz"], cfg4.pcname()), "global_rows": r4["rows"], "parallelism": "rows1"},
-                          "ungated": r4["parity"].get("pass") is None, "parity_gate": r4["parity"], "roofline": rf, "cpu_baseline": r4.get("cpu_baseline")}))
-        sys.stdout.flush()
+                          "ungated": r4["parity"].get("pass") is None, "parity_gate": r4["parity"], "roofline": rf, "cpu_baseline": r4.get("cpu_baseline")}, t_start)
         return
     P = Problem(head, 0, 1, None, fused=args.fused, pipeline=args.pipeline, keep_host=True)
     kname = P.setup(args.variant)
@@ -1005,40 +1202,59 @@ def main():
     dom = max(by_kernel, key=lambda k: k["avg_launch_us"] * k["launches_per_iteration"])
     rf["dominant_by_time"] = dom["match"]
 
-    # ---- the drop-in itself (reference executable + plugin): GPU legs, before the counter passes
+    # ---- the drop-in itself (reference executable + plugin): GPU legs, before the counter passes.  Each row is one run of the reference's
+    # executable (its own MatSetValues assembly on the host + the solve): ~10 s apiece, so the default budget takes the two rows north_star
+    # is about and leaves the rest to --full
     if not args.no_plugin and head.cube and args.ksp == "cg" and args.pc == "jacobi" and N <= 2 ** 25:
         plug = {}
-        for label, ksp in (("reference KSPSolve_CG over hipx types", "cg"), ("-ksp_type cghipx (fused kernels under PETSc's monitors / convergence test)", "cghipx"),
-                           # the reference's reduction-fused / pipelined callers, unmodified, over the hipx types (their VecDotBegin/End
-                           # split reductions end in one blocking device reduction per VecDotEnd group)
-                           ("reference KSPSolve_PIPECG over hipx types (pipecg.c)", "pipecg"), ("reference KSPSolve_GROPPCG over hipx types (groppcg.c)", "groppcg")):
-            a = [x if x != "cg" else ksp for x in head.driver_args(400)]
-            rr = ref_driver(1, a, plugin=True)
-            plug[ksp] = {"what": label, "iterations_per_s": (rr["its"] / rr["seconds"]) if rr else None, "iterations": rr["its"] if rr else None,
-                         "KSPSolve_seconds": rr["seconds"] if rr else None}
-        # Chebyshev as a smoother (first kind, no norms, bounds given: 7-pt Poisson + Jacobi has its spectrum in (0, 2)): the
-        # reference's KSPSolve_Chebyshev over the hipx types (4 kernels per iteration) and -ksp_type chebyshevhipx (SpMV + one fused kernel)
-        for label, ksp in (("reference KSPSolve_Chebyshev over hipx types (smoother configuration: -ksp_norm_type none)", "chebyshev"),
-                           ("-ksp_type chebyshevhipx (SpMV + one fused kernel per iteration, bit-identical solution)", "chebyshevhipx")):
-            a = ["-stencil", str(head.stencil), "-n", str(head.dims[0]), "-ksp_type", ksp, "-pc_type", "jacobi", "-ksp_norm_type", "none", "-ksp_max_it", "400",
-                 "-ksp_chebyshev_eigenvalues", "0.1,2.0"]
-            rr = ref_driver(1, a, plugin=True)
-            plug[ksp] = {"what": label, "iterations_per_s": (rr["its"] / rr["seconds"]) if rr else None, "iterations": rr["its"] if rr else None,
-                         "KSPSolve_seconds": rr["seconds"] if rr else None, "error_norm": rr["error"] if rr else None}
+        rows = [("reference KSPSolve_CG over hipx types", "cg", 1), ("-ksp_type cghipx (fused kernels under PETSc's monitors / convergence test)", "cghipx", 1),
+                # the reference's reduction-fused / pipelined callers, unmodified, over the hipx types
+                ("reference KSPSolve_PIPECG over hipx types (pipecg.c)", "pipecg", 0), ("reference KSPSolve_GROPPCG over hipx types (groppcg.c)", "groppcg", 0)]
+        with phase("plugin rows"):
+            for label, ksp, always in rows:
+                if not (always and room(60)) and not (args.full or room(95)):
+                    plug[ksp] = {"what": label, "skipped": "budget"}
+                    continue
+                a = [x if x != "cg" else ksp for x in head.driver_args(400)]
+                rr = ref_driver(1, a, plugin=True)
+                plug[ksp] = {"what": label, "iterations_per_s": (rr["its"] / rr["seconds"]) if rr else None, "iterations": rr["its"] if rr else None,
+                             "KSPSolve_seconds": rr["seconds"] if rr else None}
+            # Chebyshev as a smoother (first kind, no norms, bounds given: 7-pt Poisson + Jacobi has its spectrum in (0, 2)): the
+            # reference's KSPSolve_Chebyshev over the hipx types (4 kernels per iteration) and -ksp_type chebyshevhipx (SpMV + one fused kernel)
+            for label, ksp in (("reference KSPSolve_Chebyshev over hipx types (smoother configuration: -ksp_norm_type none)", "chebyshev"),
+                               ("-ksp_type chebyshevhipx (SpMV + one fused kernel per iteration, bit-identical solution)", "chebyshevhipx")):
+                if not args.full:
+                    plug[ksp] = {"what": label, "skipped": "budget (--full runs it)"}
+                    continue
+                a = ["-stencil", str(head.stencil), "-n", str(head.dims[0]), "-ksp_type", ksp, "-pc_type", "jacobi", "-ksp_norm_type", "none", "-ksp_max_it", "400",
+                     "-ksp_chebyshev_eigenvalues", "0.1,2.0"]
+                rr = ref_driver(1, a, plugin=True)
+                plug[ksp] = {"what": label, "iterations_per_s": (rr["its"] / rr["seconds"]) if rr else None, "iterations": rr["its"] if rr else None,
+                             "KSPSolve_seconds": rr["seconds"] if rr else None, "error_norm": rr["error"] if rr else None}
         out["plugin"] = plug
     else:
         out["plugin"] = None
 
-    # ---- BASELINE configs 3 / 4 / 5 on this GPU: the timed part (their counter passes and CPU baselines follow below)
+    # ---- BASELINE configs 3 / 4 / 5 on this GPU: the timed part (their counter passes and CPU baselines follow below), most important first;
+    # a leg runs when its estimated cost (seconds, measured on the round-4/5 boxes) still fits the budget with `reserve` left for the headline's
+    # own counter pass + CPU baseline
     other, leg_cfgs = {}, {}
+    reserve = 32.0
+    cfg4 = cfg4s = None
+    tmp4 = None
     if not args.no_other:
-        legs = [("config3_solver_gmres30_sor_27pt_256", Cfg(27, (256, 256, 256), "gmres", "sor", golden="gmres_sor_27pt_256"), 60, 5, 35, 10),
-                ("config5_share_cg_none_7pt_1024x1024x128", Cfg(7, (1024, 1024, 128), "cg", "none", scaling="weak"), 50, 5, 12, 10),
+        tmp4 = tempfile.mkdtemp(prefix="hipx_mat_")
+        legs = [("config3_solver_gmres30_sor_27pt_256", Cfg(27, (256, 256, 256), "gmres", "sor", golden="gmres_sor_27pt_256"), 60, 5, 35, 10, 8),
+                ("config5_share_cg_none_7pt_1024x1024x128", Cfg(7, (1024, 1024, 128), "cg", "none", scaling="weak"), 50, 5, 12, 10, 9),
                 # the 1-GPU point of north_star's >= 6x target (27-pt 512^3: 3.6e9 nonzeros, 64-bit row offsets, 46 GB of CSR in HBM)
-                ("cg_jacobi_27pt_512_strong", Cfg(27, (512, 512, 512), "cg", "jacobi"), 30, 3, 16, 0)]
-        for name, cfg, st, wu, pits, cpu_its in legs:
+                ("cg_jacobi_27pt_512_strong", Cfg(27, (512, 512, 512), "cg", "jacobi"), 30, 3, 16, 0, 24)]
+        for name, cfg, st, wu, pits, cpu_its, est in legs:
+            if not room(est + reserve):
+                other[name] = {"skipped": "budget"}
+                continue
             try:
-                res, (nnz_l, m_l, wide_l) = run_leg(cfg, 0, 1, None, torch, None, st, wu, sync, parity_its=pits)
+                with phase(name):
+                    res, (nnz_l, m_l, wide_l) = run_leg(cfg, 0, 1, None, torch, None, st, wu, sync, parity_its=pits)
                 pr = res.pop("per_rank")[0]
                 res["spmv_ms"] = pr["spmv_ms"]
                 byts = 12 * nnz_l + (8 if wide_l else 4) * (m_l + 1) + 16 * m_l
@@ -1050,54 +1266,80 @@ def main():
                 if cfg.pc == "sor" and "sor_ms" in pr:
                     ssor = 2 * 12 * nnz_l + 40 * m_l  # two passes over a, j + 5 vector passes
                     res["roofline_sor"] = {"bound": "hbm", "kernel": "sor_strand_kernel forward + backward (one PCApply_SOR = symmetric sweep)", "avg_call_ms": pr["sor_ms"], "calls": pr.get("sor_calls"),
-                                           "algorithmic_bytes": ssor, "effective_gbps": ssor / (pr["sor_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+                                           "algorithmic_bytes": ssor, "effective_gbps": ssor / (pr["sor_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                                           "frac_algorithmic_bytes": ssor / (pr["sor_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                 other[name] = res
                 leg_cfgs[name] = (cfg, cpu_its, m_l)
             except Exception as e:  # noqa: BLE001
                 other[name] = {"error": str(e)[:400]}
-        try:
-            other["config4_surrogate_spmv"] = leg_surrogate_spmv(hx, _lib)
-        except Exception as e:  # noqa: BLE001
-            other["config4_surrogate_spmv"] = {"error": str(e)[:400]}
-        cfg4, tmp4 = None, tempfile.mkdtemp(prefix="hipx_mat_")
-        try:
-            cfg4 = config4_cfg()
-            other["config4_solver_cg_jacobi"] = leg_matrix_solver(cfg4, 100, 10, sync, torch, best_ranks=None, tmpdir=tmp4)
-        except Exception as e:  # noqa: BLE001
-            other["config4_solver_cg_jacobi"] = {"error": str(e)[:400]}
-        cfg4s = None
-        try:  # the same matrix with PCSOR (the reference's default symmetric sweep): what an UNSTRUCTURED matrix gets from hipx_sor.hip
-            cfg4s = config4_cfg()
-            cfg4s.pc = "sor"
-            if cfg4 is not None and cfg4.binfile:
-                cfg4s.binfile = cfg4.binfile
-            other["config4_solver_cg_sor"] = leg_matrix_solver(cfg4s, 30, 3, sync, torch, best_ranks=None, parity_its=5, tmpdir=tmp4)
-        except Exception as e:  # noqa: BLE001
-            other["config4_solver_cg_sor"] = {"error": str(e)[:400]}
-        try:
-            other["config3_sor_arbitrary_values_27pt_256"] = leg_sor_arbitrary_values(hx, _lib, ks)
-        except Exception as e:  # noqa: BLE001
-            other["config3_sor_arbitrary_values_27pt_256"] = {"error": str(e)[:400]}
+        # config 4 (the stand-in, or HIPX_FLAN_FILE): the matrix is generated once and shared by its legs; parity against the committed
+        # history of the REFERENCE's MatLoad + KSPSolve + exact BLAS on the same (deterministic) matrix when there is one, else that run itself
+        for name, pc, st, wu, pits, est in (("config4_solver_cg_jacobi", "jacobi", 100, 10, 10, 22), ("config4_solver_cg_sor", "sor", 30, 3, 5, 24)):
+            if not room(est + reserve):
+                other[name] = {"skipped": "budget"}
+                continue
+            try:
+                with phase(name):
+                    c4 = config4_cfg()
+                    c4.pc = pc
+                    if cfg4 is not None:
+                        c4._cache, c4.binfile = cfg4._cache, cfg4.binfile
+                    other[name] = leg_matrix_solver(c4, st, wu, sync, torch, best_ranks=None, parity_its=pits, tmpdir=tmp4, allow_ref_run=args.full or room(60 + reserve))
+                    if pc == "jacobi":
+                        cfg4 = c4
+                    else:
+                        cfg4s = c4
+            except Exception as e:  # noqa: BLE001
+                other[name] = {"error": str(e)[:400]}
+        for name, est, fn in (("config3_sor_arbitrary_values_27pt_256", 12, lambda: leg_sor_arbitrary_values(hx, _lib, ks)),
+                              ("config4_surrogate_spmv", 20, lambda: leg_surrogate_spmv(hx, _lib))):
+            if not room(est + reserve):
+                other[name] = {"skipped": "budget"}
+                continue
+            try:
+                with phase(name):
+                    other[name] = fn()
+            except Exception as e:  # noqa: BLE001
+                other[name] = {"error": str(e)[:400]}
+        for c4 in (cfg4, cfg4s):
+            if c4 is not None:
+                c4._cache = None
         out["other_configs"] = other
     _lib.chk(hx.hipxDeviceSynchronize())
 
     # ---- counter passes (GPU, rocprofv3 child processes: the device must be theirs alone) in a thread, the CPU baselines (host cores only) beside them
     pmc = {}
+    ran = lambda nm: nm in other and "error" not in other[nm] and "skipped" not in other[nm]  # noqa: E731
 
     def counter_passes():
         src = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes launched by this run (bench.py --suite %s), gfx950 correction read = 2 x FETCH_SIZE"
+        todo = []
         if head.cube:
-            pmc["cg"] = (pmc_suite(["--suite", "cg", "--grid", str(n), "--stencil", str(args.stencil), "--pc", args.pc, "--variant", str(args.variant)], "headline_cg"), src % "cg")
-            if extra_lines:
-                pmc["spmv"] = (pmc_suite(["--suite", "spmv", "--grid", str(n), "--stencil", str(args.stencil), "--suite-variants", ",".join(str(e["variant"]) for e in extra_lines.values())],
-                                         "headline_general"), src % "spmv")
+            todo.append(("cg", ["--suite", "cg", "--grid", str(n), "--stencil", str(args.stencil), "--pc", args.pc, "--variant", str(args.variant)], "headline_cg", src % "cg", 0))
         if not args.no_other:
-            pmc["spmv27"] = (pmc_suite(["--suite", "spmv", "--grid", "256", "--stencil", "27", "--suite-variants", "0"], "27pt_256_spmv"), src % "spmv (27-pt 256^3)")
-            pmc["sor27"] = (pmc_suite(["--suite", "sor", "--grid", "256", "--stencil", "27"], "27pt_256_sor"), src % "sor (27-pt 256^3)")
-            pmc["sor27var"] = (pmc_suite(["--suite", "sor", "--grid", "256", "--stencil", "27", "--suite-perturb", "1"], "27pt_256_sor_arbitrary_values"), src % "sor --suite-perturb 1")
-            pmc["sell"] = (pmc_suite(["--suite", "sell"], "config4_standin_spmv"), src % "sell")
-            pmc["sorflan"] = (pmc_suite(["--suite", "sorflan"], "config4_standin_sor"), src % "sorflan")
-            pmc["box"] = (pmc_suite(["--suite", "cg", "--stencil", "7", "--pc", "none", "--suite-dims", "1024x1024x32"], "config5_lines_cg"), src % "cg --suite-dims 1024x1024x32 --pc none")
+            if ran("config3_solver_gmres30_sor_27pt_256"):
+                todo.append(("sor27", ["--suite", "sor", "--grid", "256", "--stencil", "27"], "27pt_256_sor", src % "sor (27-pt 256^3)", 14))
+        if head.cube and extra_lines:
+            todo.append(("spmv", ["--suite", "spmv", "--grid", str(n), "--stencil", str(args.stencil), "--suite-variants", ",".join(str(e["variant"]) for e in extra_lines.values())],
+                         "headline_general", src % "spmv", 14))
+        if not args.no_other:
+            if ran("config3_solver_gmres30_sor_27pt_256") or ran("cg_jacobi_27pt_512_strong"):
+                todo.append(("spmv27", ["--suite", "spmv", "--grid", "256", "--stencil", "27", "--suite-variants", "0"], "27pt_256_spmv", src % "spmv (27-pt 256^3)", 14))
+            if ran("config5_share_cg_none_7pt_1024x1024x128"):
+                todo.append(("box", ["--suite", "cg", "--stencil", "7", "--pc", "none", "--suite-dims", "1024x1024x128"], "config5_share_cg", src % "cg --suite-dims 1024x1024x128 --pc none", 22))
+            if ran("config3_sor_arbitrary_values_27pt_256"):
+                todo.append(("sor27var", ["--suite", "sor", "--grid", "256", "--stencil", "27", "--suite-perturb", "1"], "27pt_256_sor_arbitrary_values", src % "sor --suite-perturb 1", 20))
+            if ran("config4_surrogate_spmv") or ran("config4_solver_cg_jacobi"):
+                todo.append(("sell", ["--suite", "sell"], "config4_standin_spmv", src % "sell", 40))
+            if ran("config4_solver_cg_sor"):
+                todo.append(("sorflan", ["--suite", "sorflan"], "config4_standin_sor", src % "sorflan", 45))
+        for key, sargs, tag, source, est in todo:
+            if est and not room(est):
+                pmc[key] = (None, "counter pass skipped: budget")
+                continue
+            t_ = time.time()
+            pmc[key] = (pmc_suite(sargs, tag), source)
+            timeline.append(["pmc " + key, round(time.time() - t_, 2)])
 
     import threading
     th = None
@@ -1109,12 +1351,14 @@ def main():
     if not args.no_cpu_baseline:
         cores = physical_cores()
         base = None
+        t_cpu = time.time()
         if N <= 2 ** 25:
-            # the box's host cores: P = physical cores, and P/2, P/4 beside it (a memory-bound solve does not always peak at
-            # P = cores; an over-subscribed or quota-limited container shows up here too); the best rate is the baseline
+            # the box's host cores.  A memory-bound solve peaks well below P = cores ranks (round 4's boxes, 128 cores: 32 ranks 28.5 it/s, 64 ranks
+            # 16.7, 128 ranks 19.0): the default run takes P/4 ranks only; --full tries P, P/2, P/4 and reports the best
             its_p = 40 if n >= 200 else 200
             tried, rp = [], None
-            for p_ in [c for c in dict.fromkeys([cores, cores // 2, cores // 4]) if c > 1]:
+            counts = [cores, cores // 2, cores // 4] if args.full else [max(2, cores // 4)]
+            for p_ in [c for c in dict.fromkeys(counts) if c > 1]:
                 rr = ref_driver(p_, head.driver_args(its_p), bind=True) or ref_driver(p_, head.driver_args(its_p))
                 if rr is not None:
                     rr["ranks"] = p_
@@ -1127,10 +1371,10 @@ def main():
                 best_ranks = rp["ranks"] if rp is not None else None
                 base = {"value": best["its"] / best["seconds"], "unit": "iterations/s", "cores": rp["ranks"] if rp is not None else 1, "kind": "reference",
                         "physical_cores": cores, "ranks_tried": tried, "value_1core": (r1["its"] / r1["seconds"]) if r1 else None,
-                        "sample": "the reference's own KSPSolve (KSP%s + %s, MAT(MPI)AIJ, VEC(MPI), MKL BLAS one thread per rank, gcc -O2; oracle/_ref) on the same %d-pt %s system: "
-                                  "%s iterations on %d MPI ranks, the best of the rank counts tried on this host's %d physical cores (KSPSolve wall %s s), %s iterations on 1 core (%s s); assembly excluded"
+                        "sample": "reference KSPSolve (KSP%s+%s, MPIAIJ, MKL 1 thread/rank, gcc -O2; oracle/_ref) on the same %d-pt %s system: %s its on %d MPI ranks of %d physical cores "
+                                  "(KSPSolve wall %s s; rank counts tried: %s), %s its on 1 core (%s s); assembly excluded"
                                   % (args.ksp.upper(), head.pcname(), args.stencil, head.shape(), rp["its"] if rp else "-", rp["ranks"] if rp else 0, cores, "%.3f" % rp["seconds"] if rp else "-",
-                                     r1["its"] if r1 else "-", "%.3f" % r1["seconds"] if r1 else "-")}
+                                     ",".join(str(t_["ranks"]) for t_ in tried), r1["its"] if r1 else "-", "%.3f" % r1["seconds"] if r1 else "-")}
         if base is None and head.cube and args.ksp == "cg" and args.pc == "jacobi" and N <= 2 ** 25:
             ai, aj, aa = assemble(ks, args.stencil, dims, 0, N)
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -1138,17 +1382,24 @@ def main():
             base, _ = oracle_port_baseline(ai, aj, aa, orc.matmult(ai, aj, aa, np.ones(N)), 20.0, args.stencil, n)
             del ai, aj, aa
         out["cpu_baseline"] = base
+        timeline.append(["cpu baseline (headline)", round(time.time() - t_cpu, 2)])
         if best_ranks:
             for name, (cfg, cpu_its, _) in leg_cfgs.items():
-                if cpu_its and name in other and "error" not in other[name]:
+                if cpu_its and ran(name):
+                    if not room(12):
+                        other[name]["cpu_baseline"] = {"skipped": "budget"}
+                        continue
+                    t_ = time.time()
                     other[name]["cpu_baseline"] = cpu_baseline_for(cfg, best_ranks, cpu_its, "KSP%s + %s" % (cfg.ksp.upper(), cfg.pcname()))
-            if not args.no_other and cfg4 is not None and cfg4.binfile and "error" not in other.get("config4_solver_cg_jacobi", {"error": 1}):
-                other["config4_solver_cg_jacobi"]["cpu_baseline"] = cpu_baseline_for(cfg4, best_ranks, 10, "KSPCG + PCJACOBI, MatLoad of the same file")
-            if not args.no_other and cfg4s is not None and cfg4s.binfile and "error" not in other.get("config4_solver_cg_sor", {"error": 1}):
-                other["config4_solver_cg_sor"]["cpu_baseline"] = cpu_baseline_for(cfg4s, best_ranks, 5, "KSPCG + PCSOR, MatLoad of the same file")
+                    timeline.append(["cpu baseline " + name, round(time.time() - t_, 2)])
+            for name, c4, its4 in (("config4_solver_cg_jacobi", cfg4, 10), ("config4_solver_cg_sor", cfg4s, 5)):
+                if not args.no_other and c4 is not None and c4.binfile and ran(name) and room(40):
+                    t_ = time.time()
+                    other[name]["cpu_baseline"] = cpu_baseline_for(c4, best_ranks, its4, "KSPCG + %s, MatLoad of the same file" % c4.pcname())
+                    timeline.append(["cpu baseline " + name, round(time.time() - t_, 2)])
     else:
         out["cpu_baseline"] = None
-    if not args.no_other:
+    if tmp4:
         shutil.rmtree(tmp4, ignore_errors=True)
     if th is not None:
         th.join()
@@ -1159,7 +1410,7 @@ def main():
         res, source = res_src if res_src else (None, None)
         found = [pick_kernel(res, nd) for nd in needles]
         if not res or any(v is None for _, v in found):
-            line["traffic_source"] = "counter pass did not complete on this box"
+            line["traffic_source"] = source if (not res and source) else "counter pass did not complete on this box"
             return False
         tb = int(sum(v["bytes"] for _, v in found) * scale)
         line.update({"traffic": tb, "traffic_detail": {k: v for k, v in found}, "traffic_source": source + (" -- " + note if note else "")})
@@ -1198,13 +1449,13 @@ def main():
             put_traffic(c3["roofline_spmv"], pmc.get("spmv27"), [c3["roofline_spmv"]["kernel"].split(" ")[0]], c3["roofline_spmv"]["avg_launch_ms"])
         c5 = other.get("config5_share_cg_none_7pt_1024x1024x128", {})
         if "roofline_spmv" in c5:
-            put_traffic(c5["roofline_spmv"], pmc.get("box"), [c5["roofline_spmv"]["kernel"].split(" ")[0]], c5["roofline_spmv"]["avg_launch_ms"], scale=128.0 / 32.0,
-                        note="counter pass on the same solver on 1024 x 1024 x 32 (the same lines and kernels, a quarter of the planes), bytes scaled by 4; the product kernel carries the CG direction update as its prologue")
+            put_traffic(c5["roofline_spmv"], pmc.get("box"), [c5["roofline_spmv"]["kernel"].split(" ")[0]], c5["roofline_spmv"]["avg_launch_ms"],
+                        note="counter pass on the same solver at the same size (1024 x 1024 x 128); the product kernel carries the CG direction update as its prologue")
             if pmc.get("box") and pmc["box"][0] and "cg_update_ms" in c5:
                 _, vu = pick_kernel(pmc["box"][0], "cg_fused_kernel")
                 if vu:
-                    c5["roofline_cg_update"] = {"bound": "hbm", "kernel": "cg_fused_kernel", "avg_launch_ms": c5["cg_update_ms"], "traffic": int(vu["bytes"] * 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                "frac_counter_bytes": vu["bytes"] * 4 / (c5["cg_update_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                    c5["roofline_cg_update"] = {"bound": "hbm", "kernel": "cg_fused_kernel", "avg_launch_ms": c5["cg_update_ms"], "traffic": int(vu["bytes"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac_counter_bytes": vu["bytes"] / (c5["cg_update_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         c27 = other.get("cg_jacobi_27pt_512_strong", {})
         if "roofline_spmv" in c27:
             put_traffic(c27["roofline_spmv"], pmc.get("spmv27"), [c27["roofline_spmv"]["kernel"].split(" ")[0]], c27["roofline_spmv"]["avg_launch_ms"], scale=8.0,
@@ -1229,11 +1480,12 @@ def main():
                 kk = (c4.get("kernel") or c4.get("spmv_kernel") or "").split(" ")[0]
                 put_traffic(line, pmc.get("sell"), [kk or "spmv_sell_kernel"], line["avg_launch_ms"],
                             note=None if nm == "config4_surrogate_spmv" else "counter pass on the stand-in with the same pattern (other values)")
-    print(json.dumps(out))
-    sys.stdout.flush()
+    out["budget_s"] = None if deadline == float("inf") else args.budget_s
+    out["timeline"] = timeline
+    emit(out, t_start)
 
 
-def main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync):
+def main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync, t_start=None):
     """N > 1 ranks: probe the transports out of process, time the headline configuration on each usable one (RCCL first: the
     north_star's transport; IPC peer stores as the alternative / fallback), report the faster as `value`, then run the scaling
     legs on it.  Every leg checks its first iterations against the committed exact-reduction history of the same system."""
@@ -1269,9 +1521,9 @@ def main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync):
         except Exception as e:  # noqa: BLE001  (a rank-local failure here cannot be recovered collectively: say what happened on stdout -- one line, the
             # contract's shape, value null -- and end the job: the launcher tears the other ranks down instead of leaving them in a collective)
             multi["transports"][t]["error"] = str(e)[:300]
-            print(json.dumps({"metric": head.metric(), "value": None, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
-                              "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": head.metric()},
-                              "multi_gpu": multi, "error": "rank %d failed on transport %s: %s" % (rank, t, str(e)[:300])}))
+            print(json.dumps(compact_line({"metric": head.metric(), "value": None, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                                           "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": head.metric()},
+                                           "multi_gpu": multi, "error": "rank %d failed on transport %s: %s" % (rank, t, str(e)[:300])})))
             sys.stdout.flush()
             os._exit(3)
     out = None
@@ -1298,26 +1550,35 @@ def main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync):
                    "per_rank": res["per_rank"], "cpu_baseline": None, "multi_gpu": multi}
             if out["roofline"]["achieved"]:
                 out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
-    # ---- the north_star scaling legs on the faster transport
+    # ---- the north_star scaling legs on the faster transport, most important first; rank 0 decides (and tells the others) whether a leg's
+    # estimated cost still fits the budget -- a leg is collective, every rank must take the same decision
     if best is not None and not args.no_other:
         pdist.comm_init(rank, world, dist, best)
         other = {}
-        scaling_legs = [("cg_jacobi_27pt_512_strong", Cfg(27, (512, 512, 512), "cg", "jacobi", "strong"), 60, 5, 16),
-                        ("config5_cg_none_7pt_1024x1024x%d_weak" % (128 * world), Cfg(7, (1024, 1024, 128 * world), "cg", "none", "weak"), 60, 5, 12),
-                        ("config3_solver_gmres30_sor_27pt_256_parity", Cfg(27, (256, 256, 256), "gmres", "sor", "strong", golden="gmres_sor_27pt_256"), 60, 5, 35),
-                        ("config3_gmres30_sor_27pt_512_strong", Cfg(27, (512, 512, 512), "gmres", "sor", "strong", golden="gmres_sor_27pt_512"), 60, 5, 0)]
-        for name, cfg, st, wu, pits in scaling_legs:
+        deadline = float("inf") if (args.full or args.budget_s <= 0 or t_start is None) else t_start + args.budget_s
+        scaling_legs = [("cg_jacobi_27pt_512_strong", Cfg(27, (512, 512, 512), "cg", "jacobi", "strong"), 60, 5, 16, 20 + 60 // world),
+                        ("config3_gmres30_sor_27pt_512_strong", Cfg(27, (512, 512, 512), "gmres", "sor", "strong", golden="gmres_sor_27pt_512"), 60, 5, 16, 25 + 60 // world),
+                        ("config5_cg_none_7pt_1024x1024x%d_weak" % (128 * world), Cfg(7, (1024, 1024, 128 * world), "cg", "none", "weak"), 60, 5, 12, 16),
+                        ("config3_solver_gmres30_sor_27pt_256_parity", Cfg(27, (256, 256, 256), "gmres", "sor", "strong", golden="gmres_sor_27pt_256"), 60, 5, 35, 12)]
+        for name, cfg, st, wu, pits, est in scaling_legs:
+            go = [time.time() + est <= deadline]
+            dist.broadcast_object_list(go, src=0)
+            if not go[0]:
+                other[name] = {"skipped": "budget"}
+                continue
             try:
+                t_ = time.time()
                 res, _ = run_leg(cfg, rank, world, dist, torch, best, st, wu, sync, parity_its=pits)
+                res["leg_seconds"] = time.time() - t_
                 other[name] = res
             except Exception as e:  # noqa: BLE001
                 other[name] = {"error": str(e)[:400]}
         if out is not None:
             out["other_configs"] = other
+            out["budget_s"] = None if deadline == float("inf") else args.budget_s
         _lib.chk(hx.hipxCommFinalize())
     if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit(out, t_start)
     dist.barrier()
     dist.destroy_process_group()
 

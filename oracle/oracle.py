@@ -15,7 +15,8 @@ class OrcKSP(C.Structure):
                 ("sor_lits", C.c_int), ("normtype", C.c_int), ("rtol", C.c_double), ("abstol", C.c_double), ("divtol", C.c_double),
                 ("max_it", C.c_int), ("min_it", C.c_int), ("gmres_restart", C.c_int), ("gmres_haptol", C.c_double), ("gmres_cgs_refine", C.c_int),
                 ("guess_nonzero", C.c_int), ("its", C.c_int), ("reason", C.c_int), ("rnorm", C.c_double), ("history", C.c_void_p),
-                ("hist_len", C.c_int), ("hist_n", C.c_int), ("no_inode", C.c_int)]
+                ("hist_len", C.c_int), ("hist_n", C.c_int), ("no_inode", C.c_int),
+                ("mult_cb", C.c_void_p), ("pc_cb", C.c_void_p), ("user", C.c_void_p)]  # round 5: streamed operators (oracle/stream_gmres.py)
 
 
 _lib = None
@@ -82,6 +83,16 @@ def matmult_ref(ai, aj, aa, x, yadd=None, no_inode=False):
     yy = None if yadd is None else np.ascontiguousarray(yadd, dtype=np.float64)
     lib().orc_MatMult_SeqAIJ_dispatch(m, P(ai), P(aj), P(aa), P(xx), None if yy is None else P(yy), P(z), 1 if no_inode else 0)
     return z
+
+
+def matmult_mpi(ai, aj, aa, x, nranks):
+    """y = A x as MatMult_MPIAIJ forms it on `nranks` ranks (mpiaij.c:1047-1061): per rank the diagonal block's row sum, then the off-diagonal
+    block's terms added one by one (differs from the one-rank row sum by rounding when the values are not exactly summable)."""
+    m = len(ai) - 1
+    y = np.zeros(m)
+    xx = np.ascontiguousarray(x, dtype=np.float64)
+    lib().orc_MatMult_MPIAIJ(m, P(ai), P(aj), P(aa), int(nranks), P(xx), P(y))
+    return y
 
 
 def ksp_solve(kind, ai, aj, aa, b, pc="jacobi", rtol=1e-5, max_it=10000, normtype=1, restart=30, refine=0, sor_flag=12, omega=1.0,

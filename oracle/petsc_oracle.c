@@ -959,38 +959,64 @@ void orc_KSPSetDefaults(OrcKSP *ksp)
   ksp->hist_len         = 0;
   ksp->hist_n           = 0;
   ksp->no_inode         = 0;
+  ksp->mult_cb          = NULL;
+  ksp->pc_cb            = NULL;
+  ksp->user             = NULL;
 }
 
 typedef struct {
   OrcKSP  *ksp;
   OScalar *jdiag;   /* PCJACOBI inverse diagonal */
   OScalar  rnorm0, ttol;
-  /* per-rank diagonal blocks for PCSOR on a simulated MPIAIJ partition */
-  OInt    **Ai, **Aj;
-  OScalar **Aa;
-  int       inode_mult; /* the operator has inodes (one rank): MatMult is MatMult_SeqAIJ_Inode (aij.c:1459).  On a simulated row partition
-                           (nranks > 1) the products are NOT restated per block (diagonal block with its own inodes, then the off-diagonal
-                           block without: mpiaij.c:824) -- blocked matrices on several ranks are checked against the live MPI reference
-                           instead (tests/test_gpu_plugin_mpi.py); the relaxation is dispatched per block either way (pc_apply) */
+  /* per-rank blocks of a simulated MPIAIJ partition (nranks > 1): diagonal block A (local columns), off-diagonal block B (columns compacted
+     through garray), as MatSetUpMultiply_MPIAIJ leaves them (mmaij.c:27-65) */
+  OInt    **Ai, **Aj, **Bi, **Bj, **ga;
+  OScalar **Aa, **Ba;
+  OInt     *ng;
+  int       inode_mult; /* the operator has inodes (one rank): MatMult is MatMult_SeqAIJ_Inode (aij.c:1459).  On a simulated row partition of a
+                           BLOCKED matrix the per-block inode dispatch (diagonal block with its own inodes, off-diagonal block without: mpiaij.c:824)
+                           is not restated -- blocked matrices on several ranks are checked against the live MPI reference instead
+                           (tests/test_gpu_plugin_mpi.py); the relaxation is dispatched per block either way (pc_apply) */
 } Ctx;
 
+/* MatMult.  One rank: MatMult_SeqAIJ (or its inode form).  nranks > 1 (round 5: restated faithfully; until then the whole sorted row was summed
+   left to right, which differs from the reference by rounding): MatMult_MPIAIJ mpiaij.c:1047-1061 -- every rank multiplies its DIAGONAL block
+   with its own part of x (MatMult_SeqAIJ), then ADDS the off-diagonal block's terms one by one onto that sum (MatMultAdd_SeqAIJ aij.c:1606-1658
+   with lvec[k] = x[garray[k]], mmaij.c:108-117). */
 static void ksp_mult(const Ctx *c, const OScalar *x, OScalar *y)
 {
   const OrcKSP *ksp = c->ksp;
+  if (ksp->mult_cb) {
+    ksp->mult_cb(ksp->user, x, y);
+    return;
+  }
+  if (ksp->nranks > 1 && c->Ai) {
+    for (int r = 0; r < ksp->nranks; r++) {
+      OInt rs = ksp->ranges[r], ml = ksp->ranges[r + 1] - rs;
+      orc_MatMult_SeqAIJ(ml, c->Ai[r], c->Aj[r], c->Aa[r], x + rs, y + rs);
+      if (c->ng[r] > 0) {
+        OScalar *lvec = (OScalar *)malloc((size_t)c->ng[r] * sizeof(OScalar));
+        for (OInt k = 0; k < c->ng[r]; k++) lvec[k] = x[c->ga[r][k]];
+        orc_MatMultAdd_SeqAIJ(ml, c->Bi[r], c->Bj[r], c->Ba[r], lvec, y + rs, y + rs);
+        free(lvec);
+      }
+    }
+    return;
+  }
   if (c->inode_mult) orc_MatMult_SeqAIJ_Inode(ksp->m, ksp->ai, ksp->aj, ksp->aa, x, y);
   else orc_MatMult_SeqAIJ(ksp->m, ksp->ai, ksp->aj, ksp->aa, x, y);
 }
 
 static void ctx_setup(Ctx *c, OrcKSP *ksp)
 {
-  static const OInt one_range[2] = {0, 0};
-  (void)one_range;
   c->ksp   = ksp;
   c->jdiag = NULL;
-  c->Ai = c->Aj = NULL;
-  c->Aa         = NULL;
+  c->Ai = c->Aj = c->Bi = c->Bj = c->ga = NULL;
+  c->Aa = c->Ba = NULL;
+  c->ng         = NULL;
   c->inode_mult = 0;
-  if (!ksp->no_inode && ksp->nranks <= 1 && ksp->m > 0) {
+  if (ksp->mult_cb && ksp->pc_cb) return; /* streamed operator: nothing to set up here */
+  if (!ksp->no_inode && ksp->nranks <= 1 && ksp->m > 0 && !ksp->mult_cb) {
     OInt *ns      = (OInt *)malloc((size_t)(ksp->m + 1) * sizeof(OInt));
     c->inode_mult = orc_MatSeqAIJCheckInode(ksp->m, ksp->ai, ksp->aj, 5, ns) > 0;
     free(ns);
@@ -998,29 +1024,32 @@ static void ctx_setup(Ctx *c, OrcKSP *ksp)
   if (ksp->pc_type == ORC_PC_JACOBI) {
     c->jdiag = (OScalar *)malloc((size_t)ksp->m * sizeof(OScalar));
     orc_PCSetUp_Jacobi(ksp->m, ksp->ai, ksp->aj, ksp->aa, c->jdiag); /* the diagonal is owned by the row's rank: same values at any nranks */
-  } else if (ksp->pc_type == ORC_PC_SOR && ksp->nranks > 1) {
+  }
+  if (ksp->nranks > 1 && !ksp->mult_cb) {
     int nr = ksp->nranks;
     c->Ai  = (OInt **)calloc((size_t)nr, sizeof(OInt *));
     c->Aj  = (OInt **)calloc((size_t)nr, sizeof(OInt *));
+    c->Bi  = (OInt **)calloc((size_t)nr, sizeof(OInt *));
+    c->Bj  = (OInt **)calloc((size_t)nr, sizeof(OInt *));
+    c->ga  = (OInt **)calloc((size_t)nr, sizeof(OInt *));
     c->Aa  = (OScalar **)calloc((size_t)nr, sizeof(OScalar *));
+    c->Ba  = (OScalar **)calloc((size_t)nr, sizeof(OScalar *));
+    c->ng  = (OInt *)calloc((size_t)nr, sizeof(OInt));
     for (int r = 0; r < nr; r++) {
       OInt rs = ksp->ranges[r], re = ksp->ranges[r + 1], ml = re - rs;
-      OInt nz = ksp->ai[re] - ksp->ai[rs];
+      OInt nz = ksp->ai[re] - ksp->ai[rs], nb = 0;
       OInt *li = (OInt *)malloc((size_t)(ml + 1) * sizeof(OInt));
       for (OInt i = 0; i <= ml; i++) li[i] = ksp->ai[rs + i] - ksp->ai[rs];
-      c->Ai[r]    = (OInt *)malloc((size_t)(ml + 1) * sizeof(OInt));
-      c->Aj[r]    = (OInt *)malloc((size_t)(nz + 1) * sizeof(OInt));
-      c->Aa[r]    = (OScalar *)malloc((size_t)(nz + 1) * sizeof(OScalar));
-      OInt    *Bi = (OInt *)malloc((size_t)(ml + 1) * sizeof(OInt));
-      OInt    *Bj = (OInt *)malloc((size_t)(nz + 1) * sizeof(OInt));
-      OScalar *Ba = (OScalar *)malloc((size_t)(nz + 1) * sizeof(OScalar));
-      OInt    *ga = (OInt *)malloc((size_t)(nz + 1) * sizeof(OInt));
-      orc_MatSetUpMultiply_MPIAIJ(ml, rs, re, li, ksp->aj + ksp->ai[rs], ksp->aa + ksp->ai[rs], c->Ai[r], c->Aj[r], c->Aa[r], Bi, Bj, Ba, ga);
+      for (OInt k = ksp->ai[rs]; k < ksp->ai[re]; k++) nb += (ksp->aj[k] < rs || ksp->aj[k] >= re);
+      c->Ai[r] = (OInt *)malloc((size_t)(ml + 1) * sizeof(OInt));
+      c->Aj[r] = (OInt *)malloc((size_t)(nz - nb + 1) * sizeof(OInt));
+      c->Aa[r] = (OScalar *)malloc((size_t)(nz - nb + 1) * sizeof(OScalar));
+      c->Bi[r] = (OInt *)malloc((size_t)(ml + 1) * sizeof(OInt));
+      c->Bj[r] = (OInt *)malloc((size_t)(nb + 1) * sizeof(OInt));
+      c->Ba[r] = (OScalar *)malloc((size_t)(nb + 1) * sizeof(OScalar));
+      c->ga[r] = (OInt *)malloc((size_t)(nb + 1) * sizeof(OInt));
+      c->ng[r] = orc_MatSetUpMultiply_MPIAIJ(ml, rs, re, li, ksp->aj + ksp->ai[rs], ksp->aa + ksp->ai[rs], c->Ai[r], c->Aj[r], c->Aa[r], c->Bi[r], c->Bj[r], c->Ba[r], c->ga[r]);
       free(li);
-      free(Bi);
-      free(Bj);
-      free(Ba);
-      free(ga);
     }
   }
 }
@@ -1033,11 +1062,42 @@ static void ctx_free(Ctx *c)
       free(c->Ai[r]);
       free(c->Aj[r]);
       free(c->Aa[r]);
+      free(c->Bi[r]);
+      free(c->Bj[r]);
+      free(c->Ba[r]);
+      free(c->ga[r]);
     }
     free(c->Ai);
     free(c->Aj);
     free(c->Aa);
+    free(c->Bi);
+    free(c->Bj);
+    free(c->Ba);
+    free(c->ga);
+    free(c->ng);
   }
+}
+
+/* y = A x on a simulated partition over `nranks` ranks (MatMult_MPIAIJ, see ksp_mult): what the reference's drivers form b = A * 1 with under mpiexec. */
+void orc_MatMult_MPIAIJ(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, int nranks, const OScalar *x, OScalar *y)
+{
+  OrcKSP k;
+  Ctx    c;
+  OInt  *ranges = (OInt *)malloc((size_t)(nranks + 1) * sizeof(OInt));
+  orc_KSPSetDefaults(&k);
+  orc_PetscSplitOwnership(m, nranks, ranges);
+  k.m       = m;
+  k.ai      = ai;
+  k.aj      = aj;
+  k.aa      = aa;
+  k.nranks  = nranks;
+  k.ranges  = ranges;
+  k.pc_type = ORC_PC_NONE;
+  k.no_inode = 1;
+  ctx_setup(&c, &k);
+  ksp_mult(&c, x, y);
+  ctx_free(&c);
+  free(ranges);
 }
 
 /* KSP_PCApply -> PCApply_Jacobi (jacobi.c:354-362) | PCApply_SOR (sor.c:27-36) -> MatSOR_SeqAIJ, or
@@ -1046,6 +1106,10 @@ static void ctx_free(Ctx *c)
 static void pc_apply(Ctx *c, const OScalar *r, OScalar *z)
 {
   OrcKSP *ksp = c->ksp;
+  if (ksp->pc_cb) {
+    ksp->pc_cb(ksp->user, r, z);
+    return;
+  }
   if (ksp->pc_type == ORC_PC_NONE) memcpy(z, r, (size_t)ksp->m * sizeof(OScalar)); /* pcnone: VecCopy */
   else if (ksp->pc_type == ORC_PC_JACOBI) orc_VecPointwiseMult_Seq(ksp->m, z, r, c->jdiag);
   else {

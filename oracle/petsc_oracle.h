@@ -151,11 +151,18 @@ typedef struct {
   OScalar *history; /* caller array of length hist_len, receives rnorm per KSPLogResidualHistory */
   OInt     hist_len, hist_n;
   int      no_inode; /* 1 = -mat_no_inode: PCSOR takes the point routine on every matrix (default 0: aij.c:1852) */
+  /* round 5: operators too large to hold as one CSR (27-pt 512^3: 3.6e9 nonzeros).  When mult_cb is set, y = A x is the caller's routine
+     (oracle/stream_gmres.py: row slabs assembled on the fly and multiplied with orc_MatMult_SeqAIJ) and ai/aj/aa may be NULL; when pc_cb is set
+     it is KSP_PCApply (there: one orc_MatSOR_SeqAIJ sweep per rank on its diagonal block, mpiaij.c:1408-1412).  The Krylov loops are unchanged. */
+  void (*mult_cb)(void *user, const OScalar *x, OScalar *y);
+  void (*pc_cb)(void *user, const OScalar *r, OScalar *z);
+  void *user;
 } OrcKSP;
 
 void orc_KSPSetDefaults(OrcKSP *ksp);
 int  orc_KSPSolve_CG(OrcKSP *ksp, const OScalar *b, OScalar *x);    /* cg.c:119-352 */
 int  orc_KSPSolve_GMRES(OrcKSP *ksp, const OScalar *b, OScalar *x); /* gmres.c:88-238,298-420; borthog2.c:35-113 */
+void orc_MatMult_MPIAIJ(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, int nranks, const OScalar *x, OScalar *y); /* mpiaij.c:1047-1061 on a simulated row partition */
 
 /* PetscSplitOwnership (src/sys/utils/psplit.c): n_local = N/size + ((N % size) > rank) */
 void orc_PetscSplitOwnership(OInt N, int size, OInt *ranges);

@@ -61,7 +61,26 @@ def sor_main(fetch_dir, write_dir):
     print(json.dumps(out, indent=1))
 
 
+def table_main(path):
+    """--table <counter_collection.csv>: mean per launch of every counter of every kernel of one rocprofv3 --pmc pass (what scripts/gpu_run.sh
+    prints for its `pmc:` steps)."""
+    acc, names = {}, set()
+    for row in csv.DictReader(open(path)):
+        kn = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        kn = kn.split("(")[0][:90]
+        acc.setdefault(kn, {}).setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
+        acc[kn][row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+        names.add(row["Counter_Name"])
+    names = sorted(names)
+    print("%-92s %6s " % ("kernel", "n") + " ".join("%18s" % c[:18] for c in names))
+    for kn in sorted(acc):
+        n = max(len(v) for v in acc[kn].values())
+        print("%-92s %6d " % (kn, n) + " ".join("%18.1f" % (sum(acc[kn][c].values()) / len(acc[kn][c])) if c in acc[kn] else "%18s" % "-" for c in names))
+
+
 def main():
+    if sys.argv[1] == "--table":
+        return table_main(sys.argv[2])
     if sys.argv[1] == "--sor":
         return sor_main(sys.argv[2], sys.argv[3])
     fetch_dir, write_dir, key = sys.argv[1:4]

@@ -68,9 +68,10 @@ def jobs():
 
     def gmres_sor(n, nranks, its):
         ai, aj, aa = orc.stencil("27pt", n)
-        b = orc.matmult(ai, aj, aa, np.ones(n ** 3))
+        b = orc.matmult_mpi(ai, aj, aa, np.ones(n ** 3), nranks)  # b = A * 1 as the drivers form it under mpiexec: MatMult_MPIAIJ (round 5; the products of the solve likewise)
         h = orc.ksp_solve("gmres", ai, aj, aa, b, pc="sor", rtol=1e-50, max_it=its, nranks=nranks, exact=True)[3]
-        return entry(h, "oracle-exact", "config 3's solver: 27-pt %d^3, KSPGMRES(30) + PCSOR (local symmetric sweep per rank, %d rank(s): mpiaij.c:1408-1412); %d iterations" % (n, nranks, its))
+        return entry(h, "oracle-exact", "config 3's solver: 27-pt %d^3, KSPGMRES(30) + PCSOR (local symmetric sweep per rank, %d rank(s): mpiaij.c:1408-1412; products as "
+                                        "MatMult_MPIAIJ forms them: diagonal block, then the off-diagonal terms added, mpiaij.c:1056-1059); %d iterations" % (n, nranks, its))
     for g in (1, 2, 4, 8):
         J["gmres_sor_27pt_256_np%d" % g] = (lambda g=g: gmres_sor(256, g, 35))
         J["gmres_sor_27pt_128_np%d" % g] = (lambda g=g: gmres_sor(128, g, 35))
@@ -79,6 +80,42 @@ def jobs():
     for n in (256, 128):
         J["gmres_sor_27pt_%d_np1" % n] = (lambda n=n: entry(ref_shim(27, n, "gmres", "sor", 35), "reference+shim",
                                                             "config 3's solver: 27-pt %d^3, KSPGMRES(30) + PCSOR, one rank; 35 iterations" % n))
+
+    # round 5: BASELINE config 4's stand-in (tests/surrogates.py flan_surrogate_spd: deterministic) under the REFERENCE's MatLoad + KSPSolve with exact
+    # BLAS reductions -- what bench.py's config-4 legs used to run beside themselves (a 1.5 GB file written and read back: tens of seconds per run)
+    def flan(pc, its):
+        import tempfile
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        sys.path.insert(0, ROOT)
+        from surrogates import flan_surrogate_spd
+        from petsc_amd import matio
+        d = tempfile.mkdtemp(prefix="hipx_flan_")
+        f = os.path.join(d, "matrix.bin")
+        try:
+            matio.write_petsc_binary(f, *flan_surrogate_spd())
+            env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1", LD_PRELOAD=SHIM)
+            a = [REF, "-f", f, "-ksp_type", "cg", "-pc_type", pc, "-ksp_rtol", "1e-50", "-ksp_max_it", str(its), "-ksp_norm_type", "preconditioned", "-history", "-mat_type", "aij", "-vec_type", "standard"]
+            out = subprocess.run(a, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=7200).stdout
+            h = np.array([float(l.split()[2]) for l in out.splitlines() if l.startswith("hist ")])
+            assert len(h) == its + 1, out[-2000:]
+        finally:
+            import shutil
+            shutil.rmtree(d, ignore_errors=True)
+        return entry(h, "reference+shim", "BASELINE config 4's stand-in (tests/surrogates.py flan_surrogate_spd(): 1,536,000 rows, 121 M nonzeros, 3 unknowns per node = a matrix with inodes), "
+                                          "the reference's MatLoad + KSPCG + PC%s (MatMult_SeqAIJ_Inode%s); %d iterations" % (pc.upper(), " / MatSOR_SeqAIJ_Inode" if pc == "sor" else "", its))
+    J["cg_jacobi_flan_standin"] = lambda: flan("jacobi", 20)
+    J["cg_sor_flan_standin"] = lambda: flan("sor", 10)
+
+    # round 5: BASELINE config 3 at its real shape -- 27-pt 512^3 over 8 (4, 2) ranks: 3.6e9 nonzeros, streamed (oracle/stream_gmres.py: the C oracle's
+    # GMRES loop with exact reductions over per-rank products and local sweeps assembled on the fly)
+    def gmres_sor_stream(n, nranks, its):
+        import stream_gmres
+        op = stream_gmres.StreamPartitionedOperator("27pt", n, nranks, sub_rows=1 << 20, log=lambda *a: print("   ", *a, flush=True))
+        h = stream_gmres.gmres_sor_exact(op, its, log=lambda *a: print("   ", *a, flush=True))
+        return entry(h, "stream", "BASELINE config 3: 27-pt %d^3 (%.2e rows), KSPGMRES(30) + PCSOR on %d ranks (local symmetric sweep per rank, MatMult_MPIAIJ products); %d iterations"
+                     % (n, float(n) ** 3, nranks, its))
+    for g in (8, 4, 2):
+        J["gmres_sor_27pt_512_np%d" % g] = (lambda g=g: gmres_sor_stream(512, g, 35 if g == 8 else 16))
     return J
 
 

@@ -22,9 +22,18 @@ def clean_env():
 
 
 def last_json(out):
-    lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert lines, out[-3000:]
-    return json.loads(lines[-1])
+    """The contract line is the LAST stdout line and compact (< 4 KB: what the driver parses); the full result of the same run is in
+    bench_detail.json beside bench.py.  Returns the full result after checking that the line is its summary."""
+    lines = out.splitlines()
+    assert lines and lines[-1].startswith("{"), out[-3000:]
+    assert len(lines[-1]) < 4096, len(lines[-1])
+    c = json.loads(out[-8000:].splitlines()[-1])
+    d = json.load(open(os.path.join(ROOT, c["detail"])))
+    for k in ("metric", "n_gpus", "steps", "warmup", "unit", "scaling"):
+        assert c[k] == d[k], k
+    assert (c["value"] is None and d["value"] is None) or abs(c["value"] - d["value"]) <= 1e-6 * abs(d["value"])
+    assert c["parity_gate"].get("pass") == d["parity_gate"].get("pass")
+    return d
 
 
 def test_self_launch_two_ranks_headline_shape_with_parity():

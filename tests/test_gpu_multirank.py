@@ -24,7 +24,8 @@ def run_bench(nranks, extra, port):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1", "--master-port", str(port)] + base
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    line = r.stdout.splitlines()[-1]  # the compact contract line, last on stdout
+    assert len(line) < 4096
     return json.loads(line)
 
 
