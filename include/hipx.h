@@ -147,6 +147,12 @@ int hipxGetReductionMode(int *mode);
 #define HIPX_MAX_RED_SLOTS 64
 int hipxVecDotBegin(const double *x, const double *y, hipx_int n, int slot);
 int hipxRedEnd(int slot, int nvals, double *results); /* synchronises the compute stream, copies nvals sums */
+/* round 5.  w = x .* y (VecPointwiseMult_Seq bvec2.c:72-97; w may NOT alias x or y here) and, in the same pass, the sums w.w and w.x of the vector
+   just written: what KSPSolve_CG asks for right after PCApply_Jacobi = VecPointwiseMult(z, r, diag) (jacobi.c:354-362) -- VecNorm(Z) cg.c:309 and
+   VecXDot(Z, R) cg.c:344.  Enqueue only; hipxRedEnd(slot, 2, s) returns s[0] = w.w, s[1] = w.x.  The plugin's vector type keeps the two sums keyed on
+   the vectors and answers those calls from them (plugin/vechipx.c, "reduction cache"): in the exact reduction mode the values are the ones hipxVecNorm /
+   hipxVecDot return, bit for bit; in the fast mode they differ by the association of the partial sums (rounding). */
+int hipxVecPointwiseMultDotsBegin(double *w, const double *x, const double *y, hipx_int n, int slot);
 
 /* fused CG kernels (same arithmetic as the separate calls, fewer HBM passes) */
 /* x += a p ; r -= a w ; z = r .* d ; sums[0] = z.z ; sums[1] = z.r  (cg.c:305-309,344 with PCJACOBI) */
@@ -220,8 +226,16 @@ int hipxMatGetSORMode(hipxMat A, int *mode);
    when omega == 1 and fshift == 0 (aij.c:1852; inode.c:2494-3810) -- block Gauss-Seidel with the inverses of the nodes' dense diagonal
    blocks (LINPACK dgefa/dgedi, dgefa2.c ... dgefa5.c), the rows' terms subtracted in pairs -- a DIFFERENT preconditioner from the point
    sweep, so hipxMatSOR does the same (mode 3 of hipxMatGetSORMode: node-level dependency-driven sweep, bit-identical to inode.c).  By
-   default the nodes are found at the first hipxMatSOR call exactly as MatSeqAIJCheckInode finds them at assembly (inode.c:3920-3985: runs
-   of at most 5 identical rows; not used when they number more than 0.8 m, i.e. never on scalar stencils).  hipxMatSetInodes overrides that:
+   default the nodes are found at the FIRST PRODUCT OR SWEEP of a SQUARE, uncompressed matrix nobody has described (hipxMatMult / MultAdd /
+   MultDot* / hipxMatSOR: a row-compare pass on the device, an m-byte copy to the host, one stream synchronisation, once per matrix) exactly
+   as MatSeqAIJCheckInode finds them at assembly (inode.c:3920-3985: runs of at most 5 identical rows; not used when they number more than
+   0.8 m, i.e. never on scalar stencils) -- and from then on hipxMatMult / MultAdd take MatMult_SeqAIJ_Inode's PAIRWISE row sums (inode.c:356-760),
+   as the reference does on such a matrix.  Rectangular matrices are never searched (round 5): the reference switches inodes OFF on the
+   off-diagonal block of an MPIAIJ matrix (mpiaij.c:824), and an off-diagonal block handed over as plain CSR is rectangular in all but
+   degenerate splits; a caller whose off-diagonal block happens to be square says so with hipxMatSetInodes(B, 0, NULL).
+   A node whose diagonal block is singular makes hipxMatSOR return HIPX_ERR_ZEROPIVOT (x untouched), like a zero diagonal on the point path.
+   SOR_APPLY_UPPER / SOR_APPLY_LOWER on a matrix with inodes return HIPX_ERR_SUP (MatSOR_SeqAIJ_Inode has no such branch; declare the matrix
+   free of inodes to get the point routine's).  hipxMatSetInodes overrides the search:
    node_count > 0 with the node_count + 1 row offsets of the nodes (Mat_SeqAIJ_Inode::size_csr, a HOST array: what the PETSc plugin
    passes from the matrix it wraps), or node_count == 0 for "no inodes" (-mat_no_inode).  hipxMatGetInodes reports the count in use
    (0: none, -1: not determined yet). */

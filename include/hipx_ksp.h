@@ -73,7 +73,9 @@ typedef struct {
   int      single_reduction; /* CG: KSPCGUseSingleReduction (cg.c:364-534): one reduction stage per iteration (three sums in one all-reduce), two more work vectors */
   double  *S, *W;            /* its work vectors S = A z and W (= A p by recurrence) */
   double   delta;            /* z . A z */
-  double  *gslab;            /* GMRES: VEC_VV(0..restart+1) + VEC_TEMP + VEC_TEMP_MATOP in one slab, kept across solves as KSPSetUp_GMRES keeps its work vectors */
+  double  *gslab;            /* GMRES: VEC_VV(0..restart+1) + VEC_TEMP + VEC_TEMP_MATOP in one slab, kept across solves as KSPSetUp_GMRES keeps its work vectors.
+                                OWNERSHIP: the slab (several GB at BASELINE sizes) belongs to this HipxKSP from the first HipxKSPSolve_GMRES until
+                                HipxKSPDestroyWork(ksp) -- a caller that drops the struct after a solve without that call leaks it */
   double   gslab_len;        /* its length in doubles (a double: the slab of a 512^3 problem exceeds 2^31 elements) */
   double  *P2;               /* second direction vector: hipxMatMultCGDirectionDotBegin (direction update as the product's prologue) writes p_new here
                                 while other workgroups still read p; P and P2 swap roles after every fused launch (P is always the current direction) */

@@ -2988,6 +2988,32 @@ int ensure_pattern_templates(hipxMat A)
 // drift, x is re-fetched); the same with a progress throttle (done counter polled per chunk): 1.2 ms (the throttle's bounded spins
 // expire: not every workgroup is co-resident); a fifth wave per workgroup that first-touches ids and far x lines two rounds ahead:
 // 0.144 (a quarter of the compute waves gone, nothing gained); the current template kept in scalar registers across chunks: +-0.
+// Developer switches of the template / march kernels, read ONCE per process (the fused CG path looked eight of them up per iteration --
+// each getenv scans environ, microseconds of host time per launch, and is not safe against a concurrent setenv).  Tests that want another setting
+// start another process.  Only HIPX_MAT_NO_INODE is still read per call (tests flip it inside one process; one lookup per product).
+struct DevSwitches {
+  bool nomarch, nosub, nopair, march1, trace, nt_store;
+  int  probe, march_units, nt_x, pairmax;
+};
+static const DevSwitches &dev_sw()
+{
+  static const DevSwitches v = [] {
+    DevSwitches d;
+    d.nomarch     = getenv("HIPX_TMPL_NOMARCH") != nullptr;
+    d.nosub       = getenv("HIPX_TMPL_NOSUB") != nullptr;
+    d.nopair      = getenv("HIPX_TMPL_NOPAIR") != nullptr;
+    d.march1      = getenv("HIPX_MARCH1") != nullptr;
+    d.trace       = getenv("HIPX_TMPL_TRACE") != nullptr;
+    d.nt_store    = getenv("HIPX_MARCH_NT_STORE") != nullptr;
+    d.probe       = getenv("HIPX_TMPL_PROBE") ? atoi(getenv("HIPX_TMPL_PROBE")) : 0;
+    d.march_units = getenv("HIPX_TMPL_MARCH_UNITS") ? atoi(getenv("HIPX_TMPL_MARCH_UNITS")) : 0;
+    d.nt_x        = getenv("HIPX_MARCH_NT_X") ? atoi(getenv("HIPX_MARCH_NT_X")) : 0;
+    d.pairmax     = getenv("HIPX_TMPL_PAIRMAX") ? atoi(getenv("HIPX_TMPL_PAIRMAX")) : 16;
+    return d;
+  }();
+  return v;
+}
+
 int tmpl_cfg()
 {
   static const int v = getenv("HIPX_TMPL_CFG") ? atoi(getenv("HIPX_TMPL_CFG")) : 1;
@@ -3062,7 +3088,7 @@ static int launch_march2_inst(hipxMat A, const double *x, double *yout, double *
     HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_march2_kernel<NE, NQ, NHALO, DOT, CG, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, NT == 512 ? 152 * 1024 : 96 * 1024));
     attr = true;
   }
-  spmv_march2_kernel<NE, NQ, NHALO, DOT, CG, NT><<<(unsigned)units, NT, lds, rt().compute>>>(A->march_plan, A->d_tid, A->d_tmask, A->ntmpl, x, yout, dotpart, tiles, pps, nplanes, xm | (getenv("HIPX_MARCH_NT_STORE") ? 2 : 0) | (getenv("HIPX_MARCH_NT_X") ? 4 * atoi(getenv("HIPX_MARCH_NT_X")) : 0), cg);
+  spmv_march2_kernel<NE, NQ, NHALO, DOT, CG, NT><<<(unsigned)units, NT, lds, rt().compute>>>(A->march_plan, A->d_tid, A->d_tmask, A->ntmpl, x, yout, dotpart, tiles, pps, nplanes, xm | (dev_sw().nt_store ? 2 : 0) | (4 * dev_sw().nt_x), cg);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -3156,7 +3182,7 @@ int launch_tmpl(hipxMat A, const double *x, const double *yin, double *yout, dou
     bool                 big_ok = true;  // plans that only the 512-thread form of spmv_march2_kernel can run (long lines): MatMult of a matrix that passed its checks
     if (A->march_ok && A->march_nt == 512) {
       big_ok = false;
-      if (MODE == 0 && !getenv("HIPX_MARCH1") && !getenv("HIPX_TMPL_TRACE")) {
+      if (MODE == 0 && !dev_sw().march1 && !dev_sw().trace) {
         int ierr2 = march2_check(A);
         if (ierr2) return ierr2;
         big_ok = A->march2_state == 1 && (reinterpret_cast<uintptr_t>(yout) & 7) == 0;
@@ -4016,10 +4042,10 @@ int hipxMatSetSpMVVariant(hipxMat A, int variant)
 // (what launch_tmpl decides for 16-byte aligned vectors)
 static bool march_applies(hipxMat A)
 {
-  if (!A->march_ok || A->tmpl_base < 0 || !A->d_tmask || A->nrows_c % 2 || getenv("HIPX_TMPL_NOMARCH") || getenv("HIPX_TMPL_NOSUB") || getenv("HIPX_TMPL_PROBE") || tmpl_cfg() != 1 || A->ntmpl > 256) return false;
+  if (!A->march_ok || A->tmpl_base < 0 || !A->d_tmask || A->nrows_c % 2 || dev_sw().nomarch || dev_sw().nosub || dev_sw().probe || tmpl_cfg() != 1 || A->ntmpl > 256) return false;
   const hipx_int m = A->nrows_c;
   if (A->march_nt == 512) {  // long lines: the 512-thread form of spmv_march2_kernel or nothing
-    if (getenv("HIPX_MARCH1") || getenv("HIPX_TMPL_TRACE") || march2_check(A) || A->march2_state != 1) return false;
+    if (dev_sw().march1 || dev_sw().trace || march2_check(A) || A->march2_state != 1) return false;
   }
   int tiles, nseg, pps, nplanes, units;
   march_geometry(A, tiles, nseg, pps, nplanes, units);
@@ -4064,13 +4090,13 @@ int hipxMatGetSpMVKernel(hipxMat A, char *buf, size_t len)
   else if (tm && march_applies(A)) {
     int ierr = march2_check(A);
     if (ierr) return ierr;
-    if (A->march2_state == 1 && !getenv("HIPX_MARCH1") && !getenv("HIPX_TMPL_TRACE"))
+    if (A->march2_state == 1 && !dev_sw().march1 && !dev_sw().trace)
       name = "spmv_march2_kernel (CSR MatMult, row templates: 1 byte per row, plane-periodic; three planes of x resident in LDS, every operand an LDS read at a run's immediate offset)";
     else name = "spmv_march_kernel (CSR MatMult, row templates: 1 byte per row; three planes of x resident in LDS, every operand an LDS read)";
   }
-  else if (tm && A->pair_ok && A->pair_plan.npairs <= (getenv("HIPX_TMPL_PAIRMAX") ? atoi(getenv("HIPX_TMPL_PAIRMAX")) : 16) && A->d_tmask && !getenv("HIPX_TMPL_NOSUB") && !getenv("HIPX_TMPL_NOPAIR") && !getenv("HIPX_TMPL_PROBE") && tmpl_cfg() == 1 && A->nrows_c >= 512)
+  else if (tm && A->pair_ok && A->pair_plan.npairs <= dev_sw().pairmax && A->d_tmask && !dev_sw().nosub && !dev_sw().nopair && !dev_sw().probe && tmpl_cfg() == 1 && A->nrows_c >= 512)
     name = "spmv_pair_kernel (CSR MatMult, row templates: 1 byte per row; two consecutive rows per thread, 16-byte loads of x at the even offsets, +-1 entries from the neighbouring lanes)";
-  else if (tm && A->d_tmask && !getenv("HIPX_TMPL_NOSUB")) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row; every template a subset of the interior one: uniform masked walk)";
+  else if (tm && A->d_tmask && !dev_sw().nosub) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row; every template a subset of the interior one: uniform masked walk)";
   else if (tm) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row)";
   else if (tp) name = "spmv_tp_kernel (CSR MatMult, pattern templates: 1-byte pattern id per row, values streamed from a[])";
   else if (false) name = "spmv_tmpl_kernel (CSR MatMult, row templates: 1 byte per row)";
@@ -4191,7 +4217,7 @@ int hipxMatMultCGDirectionDotBegin(hipxMat A, const double *p_old, double *p_new
   if (ierr) return ierr;
   if (ip) return HIPX_SUCCESS;
   if ((ierr = use_templates(A, tm))) return ierr;
-  if (!tm || !march_applies(A) || getenv("HIPX_MARCH1") || getenv("HIPX_TMPL_TRACE")) return HIPX_SUCCESS;
+  if (!tm || !march_applies(A) || dev_sw().march1 || dev_sw().trace) return HIPX_SUCCESS;
   if ((ierr = march2_check(A))) return ierr;
   if (A->march2_state != 1 || !march2_cg_shape(A)) return HIPX_SUCCESS;
   int tiles, nseg, pps, nplanes, units;

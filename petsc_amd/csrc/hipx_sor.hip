@@ -2997,7 +2997,8 @@ extern "C" int hipxMatEnsureInodes_(hipxMat A)
   if (istate >= 0) return HIPX_SUCCESS;
   std::vector<hipx_int> sizes;
   nnodes = 0;
-  if (!compressed && (ierr = inode_find(m, is64, d_i, d_j, sizes, &nnodes))) return ierr;
+  // square matrices only: an off-diagonal block (rectangular in all but degenerate splits) has inodes switched off in the reference (mpiaij.c:824)
+  if (!compressed && m == n && (ierr = inode_find(m, is64, d_i, d_j, sizes, &nnodes))) return ierr;
   return hipxMatInodesFound_(A, nnodes, sizes.data());
 }
 
@@ -3175,6 +3176,10 @@ static int mat_sor_impl(hipxMat A, const double *b, double omega, int flag, doub
       HIPX_HIP(hipMemcpyAsync(&T->zero_pivots, cnt, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
       HIPX_HIP(hipStreamSynchronize(st));
       HIPX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
+      // a singular diagonal block: the reference's block inverses (PetscKernel_A_gets_inverse_A_2..5, inode.c:2460-2490) report a zero pivot --
+      // MAT_FACTOR_NUMERIC_ZEROPIVOT, or an error when erroriffailure is set.  Same code as the point sweep's zero diagonal: the caller decides
+      // (plugin/mathipx.c sets A->factorerrortype / honours A->erroriffailure); x is not touched
+      if (T->zero_pivots) return fail(HIPX_ERR_ZEROPIVOT, "Zero pivot in the diagonal block of a node (inode.c:2460-2490)", __FILE__, __LINE__);
       T->values_valid = true;
     }
     S->mode = S->last_mode = 3;

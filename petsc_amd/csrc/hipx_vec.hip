@@ -613,6 +613,61 @@ __global__ __launch_bounds__(kRedThreads) void dotnorm2_kernel(const double *x, 
   finish_sums<2, COMP>(acc, out);
 }
 
+// w = x .* y (VecPointwiseMult_Seq bvec2.c:72-97: one product per element) with the sums w.w and w.x of the vector just written, in the same pass.
+// What KSPSolve_CG asks for right after PCApply_Jacobi (= VecPointwiseMult(z, r, diag), jacobi.c:354-362): VecNorm(Z) (cg.c:309) and
+// VecXDot(Z, R) (cg.c:344) -- the drop-in's vector type keeps the two sums keyed on the vectors (plugin/vechipx.c: reduction cache) and
+// answers those calls without another pass over z and r.  Each workgroup owns one contiguous chunk (as mdot_kernel).
+template <bool COMP>
+__global__ __launch_bounds__(kRedThreads) void pwmult_dots_kernel(double *w, const double *x, const double *y, hipx_int n, bool vec, RedOut out)
+{
+  Acc<COMP> acc[2];
+  if (vec) {
+    const hipx_int n2 = n >> 1;
+    const double2 *x2 = reinterpret_cast<const double2 *>(x), *y2 = reinterpret_cast<const double2 *>(y);
+    double2       *w2 = reinterpret_cast<double2 *>(w);
+    constexpr int  U     = 2;
+    const hipx_int chunk = (n2 + (hipx_int)gridDim.x - 1) / (hipx_int)gridDim.x;
+    const hipx_int c0    = (hipx_int)blockIdx.x * chunk;
+    const hipx_int c1    = (c0 + chunk < n2) ? c0 + chunk : n2;
+    for (hipx_int p = c0 + (hipx_int)threadIdx.x; p < c1; p += U * kRedThreads) {
+      double2 xa[U], ya[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const hipx_int q = p + u * kRedThreads;
+        xa[u]            = (q < c1) ? x2[q] : make_double2(0.0, 0.0);
+        ya[u]            = (q < c1) ? y2[q] : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const hipx_int q = p + u * kRedThreads;
+        double2        wa;
+        wa.x = xa[u].x * ya[u].x;
+        wa.y = xa[u].y * ya[u].y;
+        if (q < c1) w2[q] = wa;
+        acc[0].prod(wa.x, wa.x);
+        acc[0].prod(wa.y, wa.y);
+        acc[1].prod(wa.x, xa[u].x);
+        acc[1].prod(wa.y, xa[u].y);
+      }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+      const double wv = x[n - 1] * y[n - 1];
+      w[n - 1]        = wv;
+      acc[0].prod(wv, wv);
+      acc[1].prod(wv, x[n - 1]);
+    }
+  } else {
+    const hipx_int T = (hipx_int)gridDim.x * kRedThreads;
+    for (hipx_int i = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += T) {
+      const double xv = x[i], wv = xv * y[i];
+      w[i] = wv;
+      acc[0].prod(wv, wv);
+      acc[1].prod(wv, xv);
+    }
+  }
+  finish_sums<2, COMP>(acc, out);
+}
+
 // fused CG update (cg.c:305-309,344 with PCJACOBI): x += a p; r -= a w; z = r*d; sums z.z, z.r
 // UPX = false: the x update is left to cg_aypx_axpy_kernel of the next iteration (p is then read once per iteration)
 // DEVS = true: a = *dev_beta / *dev_dpi is formed on the device from the results of kernels queued before this one (the host
@@ -1151,6 +1206,24 @@ int hipxVecPointwiseMult(double *w, const double *x, const double *y, hipx_int n
 {
   HIPX_CHECK_INIT();
   return launch_ew3(w, x, y, n, FPmult{});
+}
+
+int hipxVecPointwiseMultDotsBegin(double *w, const double *x, const double *y, hipx_int n, int slot)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2, "reduction slot out of range (the last two are reserved)");
+  HIPX_ARG(w != x && w != y, "PointwiseMultDots: w must not alias an operand (the sums are those of the NEW w with the OLD x)");
+  if (n <= 0) {
+    HIPX_HIP(hipStreamSynchronize(rt().compute));
+    slot_results_host(slot)[0] = slot_results_host(slot)[1] = 0.0;
+    rt().h_flags[slot]                                     = ++rt().seq[slot];
+    return HIPX_SUCCESS;
+  }
+  const bool vec = aligned16(w) && aligned16(x) && aligned16(y) && n >= 2;
+  if (rt().red_exact) pwmult_dots_kernel<true><<<red_grid(n), kRedThreads, 0, rt().compute>>>(w, x, y, n, vec, red_out(slot));
+  else pwmult_dots_kernel<false><<<red_grid(n), kRedThreads, 0, rt().compute>>>(w, x, y, n, vec, red_out(slot));
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
 }
 
 int hipxVecPointwiseDivide(double *w, const double *x, const double *y, hipx_int n)

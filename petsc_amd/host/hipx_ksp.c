@@ -354,7 +354,9 @@ int HipxKSPCGBegin(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double
   ksp->betaold = 1.0;
   ksp->x_pending = 0;
   ksp->a_pending = 0.0;
-  if (ksp->single_reduction && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED) return cg_sr_begin(ksp, A, pc, B, X);
+  if (ksp->single_reduction && ksp->normtype != HIPX_KSP_NORM_PRECONDITIONED) return HIPX_ERR_SUP; /* the single-reduction loop is built for the preconditioned norm only:
+                                                                                                       refuse, do not run the standard loop under that name */
+  if (ksp->single_reduction) return cg_sr_begin(ksp, A, pc, B, X);
   if (!ksp->guess_nonzero) CHK(hipxVecSet(X, n, 0.0)); /* itfunc.c:908 */
   if (ksp->guess_nonzero) {
     CHK(HipxMatMult(A, X, R));         /* cg.c:154 */

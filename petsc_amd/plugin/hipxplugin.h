@@ -56,6 +56,19 @@ PETSC_INTERN PetscErrorCode VecHIPXGetDeviceWrite(Vec v, PetscScalar **d, void *
 PETSC_INTERN PetscErrorCode VecHIPXGetDeviceReadWrite(Vec v, PetscScalar **d, void **tmp);
 PETSC_INTERN PetscErrorCode VecHIPXRestoreDeviceWrite(Vec v, PetscScalar **d, void **tmp);
 
+/* Reduction cache (vechipx.c).  A kernel that WRITES a vector can form, in the same pass, the sums the Krylov method asks for next
+   (MatMult: x . y of cg.c:258; VecPointwiseMult = PCApply_Jacobi: z . z and z . r of cg.c:309,344).  The sums are kept keyed on the two vectors'
+   object ids; VecDot / VecTDot / VecNorm(NORM_2) on exactly those vectors return them without another pass -- as the interface layer's own norm
+   cache does (rvector.c:211,232).  An entry dies the moment either vector is handed out for writing (every write access to a hipx vector goes
+   through the accessors of vechipx.c), so a hit is always the value the separate kernel would have computed on the same data: bit for bit in the
+   exact reduction mode, to rounding (another association of the partial sums) in the fast mode.  -hipx_reduction_cache 0 turns it off. */
+#define HIPX_RC_MATMULT 0 /* entry 0: a = x, b = y of y = A x; v[0] = x . y                  */
+#define HIPX_RC_PWMULT  1 /* entry 1: a = w, b = x of w = x .* y; v[0] = w . w, v[1] = w . x */
+PETSC_INTERN PetscBool      VecHIPXRedCacheWanted(int kind);
+PETSC_INTERN int            VecHIPXRedCacheSlot(int kind);
+PETSC_INTERN PetscErrorCode VecHIPXRedCachePut(int kind, Vec a, Vec b);
+PETSC_INTERN void           VecHIPXRedCacheInvalidate(Vec v);
+
 PETSC_INTERN PetscErrorCode VecCreate_SeqHIPX(Vec);
 PETSC_INTERN PetscErrorCode VecCreate_MPIHIPX(Vec);
 PETSC_INTERN PetscErrorCode VecCreate_HIPX(Vec);

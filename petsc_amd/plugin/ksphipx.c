@@ -74,6 +74,8 @@ static PetscErrorCode KSPSolve_CGHIPX(KSP ksp)
   PetscMPIInt        size;
   Vec                lvecv = NULL;
   PetscScalar       *dlv   = NULL;
+  int                herr  = 0;
+  char               herrmsg[512] = "";
 
   PetscFunctionBegin;
   if (!KSPCGHIPXApplicable(ksp, &Amat)) {
@@ -135,14 +137,23 @@ static PetscErrorCode KSPSolve_CGHIPX(KSP ksp)
       k.min_it        = (hipx_int)ksp->min_it;
       k.history       = hist;
       k.hist_len      = hl;
-      PetscCallHIPX(HipxKSPSolve_CG(&k, &M, &hpc, db, dx));
-      for (hipx_int e = 0; e < k.hist_n && e < hl; e++) PetscCall(KSPLogResidualHistory(ksp, hist[e]));
+      herr = HipxKSPSolve_CG(&k, &M, &hpc, db, dx); /* (an error leaves through `done`: the history is freed, the device handles go back) */
+      if (!herr) {
+        for (hipx_int e = 0; e < k.hist_n && e < hl; e++) PetscCall(KSPLogResidualHistory(ksp, hist[e]));
+        ksp->its    = (PetscInt)k.its;
+        ksp->rnorm  = k.rnorm;
+        ksp->rnorm0 = k.rnorm0;
+        ksp->ttol   = k.ttol;
+        ksp->reason = (KSPConvergedReason)k.reason;
+        if (ksp->reason == KSP_DIVERGED_NANORINF) { /* the host layer's mirror of KSPConvergedDefault knows no PC: a NaN / Inf norm after a failed
+                                                       preconditioner set-up is KSP_DIVERGED_PC_FAILED (iterativ.c:1548-1559) */
+          PCFailedReason pcreason;
+          PetscCall(PCReduceFailedReason(ksp->pc));
+          PetscCall(PCGetFailedReason(ksp->pc, &pcreason));
+          if (pcreason) ksp->reason = KSP_DIVERGED_PC_FAILED;
+        }
+      }
       PetscCall(PetscFree(hist));
-      ksp->its    = (PetscInt)k.its;
-      ksp->rnorm  = k.rnorm;
-      ksp->rnorm0 = k.rnorm0;
-      ksp->ttol   = k.ttol;
-      ksp->reason = (KSPConvergedReason)k.reason;
       goto done;
     }
   }
@@ -169,12 +180,15 @@ static PetscErrorCode KSPSolve_CGHIPX(KSP ksp)
   }
   PetscCallHIPX(HipxKSPCGFlush(&k, &M, dx));
 done:
-  PetscCallHIPX(HipxKSPDestroyWork(&k));
-  PetscCallHIPX(HipxPCDestroy(&hpc));
+  if (herr) PetscCall(PetscStrncpy(herrmsg, hipxGetErrorString(), sizeof(herrmsg))); /* (the clean-up calls below may overwrite the library's message) */
+  (void)HipxKSPDestroyWork(&k);
+  (void)HipxPCDestroy(&hpc);
   if (lvecv) PetscCall(VecHIPXRestoreDeviceWrite(lvecv, &dlv, &tlv));
   PetscCall(VecHIPXRestoreDeviceWrite(ksp->vec_sol, &dx, &tx));
   PetscCall(VecHIPXRestoreDeviceRead(ksp->vec_rhs, &db, &tb));
   PetscCall(PetscObjectStateIncrease((PetscObject)ksp->vec_sol));
+  PetscCheck(herr != HIPX_ERR_SUP, PetscObjectComm((PetscObject)ksp), PETSC_ERR_SUP, "libhipx: %s", herrmsg);
+  PetscCheck(!herr, PetscObjectComm((PetscObject)ksp), PETSC_ERR_GPU, "libhipx: %s", herrmsg);
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 

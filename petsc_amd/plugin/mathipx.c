@@ -147,7 +147,17 @@ static PetscErrorCode MatMult_SeqAIJHIPX(Mat A, Vec xx, Vec yy)
   PetscCall(MatSeqAIJHIPXGetDeviceMat(A, &dA));
   PetscCall(VecHIPXGetDeviceRead(xx, &x, &tx));
   PetscCall(VecHIPXGetDeviceWrite(yy, &y, &ty));
-  PetscCallHIPX(hipxMatMult(dA, x, y));
+  {
+    int mode = HIPX_RED_FAST;
+    /* KSPSolve_CG asks for p . (A p) right after this product (cg.c:257-258): the product's kernels can leave that sum behind (per-wave partials in
+       their epilogue) -- the reduction cache of the vector type hands it to the VecTDot that follows.  Not in the exact reduction mode (there the sum
+       is a Dot2 pass over the complete vectors either way), not for compressed-row or rectangular blocks */
+    PetscCallHIPX(hipxGetReductionMode(&mode));
+    if (mode == HIPX_RED_FAST && !tx && !ty && xx != yy && A->rmap->n == A->cmap->n && A->rmap->n > 0 && !a->compressedrow.use && VecHIPXRedCacheWanted(HIPX_RC_MATMULT)) {
+      PetscCallHIPX(hipxMatMultDotBegin(dA, x, y, VecHIPXRedCacheSlot(HIPX_RC_MATMULT), NULL));
+      PetscCall(VecHIPXRedCachePut(HIPX_RC_MATMULT, xx, yy));
+    } else PetscCallHIPX(hipxMatMult(dA, x, y));
+  }
   PetscCall(VecHIPXRestoreDeviceWrite(yy, &y, &ty));
   PetscCall(VecHIPXRestoreDeviceRead(xx, &x, &tx));
   PetscCall(PetscLogFlops(2.0 * a->nz - a->nonzerorowcnt)); /* aij.c:1497 */
@@ -310,7 +320,9 @@ static PetscErrorCode MatSOR_SeqAIJHIPX(Mat A, Vec bb, PetscReal omega, MatSORTy
   if (flag & SOR_ZERO_INITIAL_GUESS) PetscCall(VecHIPXGetDeviceWrite(xx, &x, &tx));
   else PetscCall(VecHIPXGetDeviceReadWrite(xx, &x, &tx));
   ierr = hipxMatSOR(dA, b, omega, (int)flag, fshift, its, lits, x);
-  if (ierr == HIPX_ERR_ZEROPIVOT) { /* aij.c:1818-1824: flag the matrix, PCApply_SOR turns it into pc->failedreason (sor.c:34) */
+  if (ierr == HIPX_ERR_ZEROPIVOT) { /* aij.c:1818-1824 (point rows), inode.c:2460-2490 (diagonal blocks of nodes): an error when erroriffailure is set,
+                                       else flag the matrix -- PCApply_SOR turns it into pc->failedreason (sor.c:34) */
+    PetscCheck(!A->erroriffailure, PETSC_COMM_SELF, PETSC_ERR_MAT_LU_ZRPVT, "libhipx: %s", hipxGetErrorString());
     A->factorerrortype             = MAT_FACTOR_NUMERIC_ZEROPIVOT;
     A->factorerror_zeropivot_value = 0.0;
     ierr                           = 0;

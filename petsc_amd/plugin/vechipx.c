@@ -18,6 +18,7 @@
 #include "hipxplugin.h"
 
 static PetscBool hipx_runtime_up = PETSC_FALSE;
+static PetscBool hipx_rc_on      = PETSC_TRUE; /* -hipx_reduction_cache (hipxplugin.h) */
 
 PetscErrorCode VecHIPXInitRuntime(void)
 {
@@ -35,6 +36,7 @@ PetscErrorCode VecHIPXInitRuntime(void)
   }
   PetscCallHIPX(hipxInit((int)dev));
   PetscCall(PetscOptionsGetBool(NULL, NULL, "-vec_hipx_memtype", &hipx_vec_memtype_ops, NULL));
+  PetscCall(PetscOptionsGetBool(NULL, NULL, "-hipx_reduction_cache", &hipx_rc_on, NULL));
   { /* -hipx_reductions exact|fast: compensated (Dot2) sums in every reduction kernel -- the values the reference's VecDot / VecNorm /
        VecMDot return when its BLAS is exactly rounded (bvec1.c:27, bvec2.c:202-223, dvec2.c:557); default: HIPX_REDUCTIONS or fast */
     char      mode[16] = "";
@@ -49,6 +51,74 @@ PetscErrorCode VecHIPXInitRuntime(void)
     }
   }
   hipx_runtime_up = PETSC_TRUE;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* ------------------------------------------------------------------ reduction cache (hipxplugin.h) */
+typedef struct {
+  PetscObjectId a, b;    /* the two vectors of the entry */
+  PetscBool     live;    /* both vectors untouched since the producing kernel was enqueued */
+  PetscBool     fetched; /* v[] holds the sums (the reduction slot has been waited for) */
+  PetscBool     used;    /* somebody asked for it: the producer keeps fusing */
+  double        v[2];
+} HipxRedCacheEntry;
+static HipxRedCacheEntry hipx_rc[2];
+static PetscInt          hipx_rc_miss[2] = {0, 0}, hipx_rc_calls[2] = {0, 0};
+static const int         hipx_rc_slot[2] = {60, 61}; /* libhipx reduction slots of the two producers (the host layer uses 1-3, blocking reductions 0) */
+
+int VecHIPXRedCacheSlot(int kind) { return hipx_rc_slot[kind]; }
+
+/* Fuse the sums into the next producer of this kind?  Yes while they get used; after two unused entries in a row (GMRES never asks for x . A x) the
+   producer runs its plain kernel again and tries once more every 64 calls. */
+PetscBool VecHIPXRedCacheWanted(int kind)
+{
+  if (!hipx_rc_on) return PETSC_FALSE;
+  hipx_rc_calls[kind]++;
+  if (hipx_rc_miss[kind] < 2) return PETSC_TRUE;
+  if (hipx_rc_calls[kind] % 64 == 0) {
+    hipx_rc_miss[kind] = 1;
+    return PETSC_TRUE;
+  }
+  return PETSC_FALSE;
+}
+
+PetscErrorCode VecHIPXRedCachePut(int kind, Vec a, Vec b)
+{
+  HipxRedCacheEntry *e = &hipx_rc[kind];
+
+  PetscFunctionBegin;
+  if (e->a && !e->used) hipx_rc_miss[kind]++;
+  else hipx_rc_miss[kind] = 0;
+  e->a       = ((PetscObject)a)->id;
+  e->b       = ((PetscObject)b)->id;
+  e->live    = PETSC_TRUE;
+  e->fetched = PETSC_FALSE;
+  e->used    = PETSC_FALSE;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+void VecHIPXRedCacheInvalidate(Vec v)
+{
+  const PetscObjectId id = ((PetscObject)v)->id;
+  for (int k = 0; k < 2; k++)
+    if (hipx_rc[k].live && (hipx_rc[k].a == id || hipx_rc[k].b == id)) hipx_rc[k].live = PETSC_FALSE;
+}
+
+/* the sums of a live entry on (a, b) in either order, or NULL */
+static PetscErrorCode VecHIPXRedCacheGet(int kind, Vec a, Vec b, PetscBool ordered, const double **v)
+{
+  HipxRedCacheEntry  *e  = &hipx_rc[kind];
+  const PetscObjectId ia = ((PetscObject)a)->id, ib = ((PetscObject)b)->id;
+
+  PetscFunctionBegin;
+  *v = NULL;
+  if (!e->live || !((e->a == ia && e->b == ib) || (!ordered && e->a == ib && e->b == ia))) PetscFunctionReturn(PETSC_SUCCESS);
+  if (!e->fetched) {
+    PetscCallHIPX(hipxRedEnd(hipx_rc_slot[kind], kind == HIPX_RC_PWMULT ? 2 : 1, e->v));
+    e->fetched = PETSC_TRUE;
+  }
+  e->used = PETSC_TRUE;
+  *v      = e->v;
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -165,6 +235,7 @@ PetscErrorCode VecHIPXGetDeviceWrite(Vec v, PetscScalar **d, void **tmp)
 {
   PetscFunctionBegin;
   *tmp = NULL;
+  VecHIPXRedCacheInvalidate(v);
   if (VecIsHIPX(v)) {
     PetscCall(VecHIPXAllocate(v));
     *d = VecHIPXGetExt(v)->d_array;
@@ -176,6 +247,7 @@ PetscErrorCode VecHIPXGetDeviceReadWrite(Vec v, PetscScalar **d, void **tmp)
 {
   PetscFunctionBegin;
   *tmp = NULL;
+  VecHIPXRedCacheInvalidate(v);
   if (VecIsHIPX(v)) {
     PetscCall(VecHIPXCopyToDevice(v));
     *d = VecHIPXGetExt(v)->d_array;
@@ -196,6 +268,7 @@ PetscErrorCode VecHIPXRestoreDeviceWrite(Vec v, PetscScalar **d, void **tmp)
 static PetscErrorCode VecGetArray_HIPX(Vec v, PetscScalar **a)
 {
   PetscFunctionBegin;
+  VecHIPXRedCacheInvalidate(v);
   PetscCall(VecHIPXCopyToHost(v));
   *a             = *(PetscScalar **)v->data;
   v->offloadmask = PETSC_OFFLOAD_CPU; /* the caller may write: the device copy is stale from now on */
@@ -213,6 +286,7 @@ static PetscErrorCode VecGetArrayRead_HIPX(Vec v, const PetscScalar **a)
 static PetscErrorCode VecGetArrayWrite_HIPX(Vec v, PetscScalar **a)
 {
   PetscFunctionBegin;
+  VecHIPXRedCacheInvalidate(v);
   *a             = *(PetscScalar **)v->data;
   v->offloadmask = PETSC_OFFLOAD_CPU;
   PetscFunctionReturn(PETSC_SUCCESS);
@@ -240,6 +314,7 @@ PetscBool hipx_vec_memtype_ops = PETSC_FALSE;
 static PetscErrorCode VecGetArrayAndMemType_HIPX(Vec v, PetscScalar **a, PetscMemType *m)
 {
   PetscFunctionBegin;
+  VecHIPXRedCacheInvalidate(v);
   PetscCall(VecHIPXCopyToDevice(v));
   *a             = VecHIPXGetExt(v)->d_array;
   v->offloadmask = PETSC_OFFLOAD_GPU; /* the caller may write on the device */
@@ -259,6 +334,7 @@ static PetscErrorCode VecGetArrayReadAndMemType_HIPX(Vec v, const PetscScalar **
 static PetscErrorCode VecGetArrayWriteAndMemType_HIPX(Vec v, PetscScalar **a, PetscMemType *m)
 {
   PetscFunctionBegin;
+  VecHIPXRedCacheInvalidate(v);
   PetscCall(VecHIPXAllocate(v));
   *a             = VecHIPXGetExt(v)->d_array;
   v->offloadmask = PETSC_OFFLOAD_GPU;
@@ -297,6 +373,7 @@ static PetscErrorCode (*parent_destroy_mpi)(Vec);
 static PetscErrorCode VecPlaceArray_HIPX(Vec v, const PetscScalar *a)
 {
   PetscFunctionBegin;
+  VecHIPXRedCacheInvalidate(v);
   PetscCall(VecHIPXCopyToHost(v)); /* the original array must hold current values when it comes back (VecResetArray) */
   PetscCall((*parent_placearray)(v, a));
   v->offloadmask = PETSC_OFFLOAD_CPU;
@@ -306,6 +383,7 @@ static PetscErrorCode VecPlaceArray_HIPX(Vec v, const PetscScalar *a)
 static PetscErrorCode VecReplaceArray_HIPX(Vec v, const PetscScalar *a)
 {
   PetscFunctionBegin;
+  VecHIPXRedCacheInvalidate(v);
   PetscCall((*parent_replacearray)(v, a));
   v->offloadmask = PETSC_OFFLOAD_CPU;
   PetscFunctionReturn(PETSC_SUCCESS);
@@ -314,6 +392,7 @@ static PetscErrorCode VecReplaceArray_HIPX(Vec v, const PetscScalar *a)
 static PetscErrorCode VecResetArray_HIPX(Vec v)
 {
   PetscFunctionBegin;
+  VecHIPXRedCacheInvalidate(v);
   /* results computed on the device while the caller's array was placed must reach that array before it is handed back
      (Place / work on the GPU / Reset: PCApply_BJacobi_Multiblock bjacobi.c:886-895; the reference's device vectors do the
      same, veccupmimpl.h:804-807) */
@@ -493,7 +572,11 @@ static PetscErrorCode VecPointwiseMult_HIPX(Vec w, Vec x, Vec y) /* VecPointwise
   RD(y, dy, ty);
   if (w == x || w == y) RW(w, dw, tw);
   else WR(w, dw, tw);
-  PetscCallHIPX(hipxVecPointwiseMult(dw, dx, dy, w->map->n));
+  if (w != x && w != y && !tx && !ty && !tw && dw != dx && dw != dy && w->map->n > 0 && VecHIPXRedCacheWanted(HIPX_RC_PWMULT)) {
+    /* PCApply_Jacobi inside a Krylov loop: the sums w . w and w . x ride along (hipxplugin.h: reduction cache) */
+    PetscCallHIPX(hipxVecPointwiseMultDotsBegin(dw, dx, dy, w->map->n, VecHIPXRedCacheSlot(HIPX_RC_PWMULT)));
+    PetscCall(VecHIPXRedCachePut(HIPX_RC_PWMULT, w, x));
+  } else PetscCallHIPX(hipxVecPointwiseMult(dw, dx, dy, w->map->n));
   WRX(w, dw, tw);
   RDX(y, dy, ty);
   RDX(x, dx, tx);
@@ -608,6 +691,19 @@ static PetscErrorCode VecDotLocal_HIPX(Vec x, Vec y, PetscScalar *z) /* VecDot_S
   void              *tx, *ty;
 
   PetscFunctionBegin;
+  if (x != y) { /* a sum the kernel that wrote one of the two vectors left behind? (reduction cache, hipxplugin.h) */
+    const double *c;
+    PetscCall(VecHIPXRedCacheGet(HIPX_RC_MATMULT, x, y, PETSC_FALSE, &c));
+    if (c) *z = c[0];
+    else {
+      PetscCall(VecHIPXRedCacheGet(HIPX_RC_PWMULT, x, y, PETSC_FALSE, &c));
+      if (c) *z = c[1];
+    }
+    if (c) {
+      PetscCall(PetscLogFlops(PetscMax(2.0 * x->map->n - 1, 0.0)));
+      PetscFunctionReturn(PETSC_SUCCESS);
+    }
+  }
   RD(x, dx, tx);
   RD(y, dy, ty);
   PetscCallHIPX(hipxVecDot(dx, dy, x->map->n, z));
@@ -644,6 +740,17 @@ static PetscErrorCode VecNormLocal_HIPX(Vec x, NormType type, PetscReal *z) /* V
   int                t = (type == NORM_1) ? 0 : (type == NORM_2) ? 1 : (type == NORM_FROBENIUS) ? 2 : (type == NORM_INFINITY) ? 3 : 4;
 
   PetscFunctionBegin;
+  if ((type == NORM_2 || type == NORM_FROBENIUS) && hipx_rc[HIPX_RC_PWMULT].live && hipx_rc[HIPX_RC_PWMULT].a == ((PetscObject)x)->id) {
+    HipxRedCacheEntry *e = &hipx_rc[HIPX_RC_PWMULT]; /* x was written by the fused VecPointwiseMult: sqrt(x . x), bvec2.c:204 */
+    if (!e->fetched) {
+      PetscCallHIPX(hipxRedEnd(hipx_rc_slot[HIPX_RC_PWMULT], 2, e->v));
+      e->fetched = PETSC_TRUE;
+    }
+    e->used = PETSC_TRUE;
+    *z      = PetscSqrtReal(e->v[0]);
+    PetscCall(PetscLogFlops(PetscMax(2.0 * x->map->n - 1, 0.0)));
+    PetscFunctionReturn(PETSC_SUCCESS);
+  }
   RD(x, dx, tx);
   PetscCallHIPX(hipxVecNorm(dx, x->map->n, t, z));
   RDX(x, dx, tx);
@@ -756,6 +863,7 @@ static PetscErrorCode VecHIPXFreeDevice(Vec v)
   VecHIPXExt *e = VecHIPXGetExt(v);
 
   PetscFunctionBegin;
+  VecHIPXRedCacheInvalidate(v);
   if (e->magic == VECHIPX_MAGIC && e->d_array && e->d_owned) PetscCallHIPX(hipxFree(e->d_array));
   e->d_array = NULL;
   e->magic   = 0;

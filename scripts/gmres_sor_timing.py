@@ -49,3 +49,5 @@ for pcname, pct in (("sor", 2), ("jacobi", 1)):
     _lib.chk(hx.hipxDeviceSynchronize())
     dt = time.perf_counter() - t0
     print("GMRES(30)+%s: %d iterations in %.3f s = %.1f it/s (rnorm %.3e)" % (pcname, ksp.its, dt, ksp.its / dt, ksp.rnorm))
+    _lib.chk(ks.HipxKSPDestroyWork(C.byref(ksp)))  # the GMRES slab belongs to the HipxKSP until this call (include/hipx_ksp.h)
+    _lib.chk(ks.HipxPCDestroy(C.byref(pc)))

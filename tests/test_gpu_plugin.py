@@ -310,3 +310,34 @@ def test_ksp_chebyshevhipx_fused_smoother_bit_identical(args):
     assert "outside the fused path" in gpu_n
     hc, hg = hist_of(cpu_n), hist_of(gpu_n)
     assert len(hc) == len(hg) and len(hc) > 1 and (np.abs(hc - hg) / hc).max() <= 1e-12
+
+
+@pytest.mark.parametrize("args", ["-stencil 7 -n 48 -ksp_type cg -pc_type jacobi -ksp_norm_type preconditioned -ksp_rtol 1e-50 -ksp_max_it 60",
+                                  "-stencil 27 -n 24 -ksp_type cg -pc_type jacobihipx -ksp_norm_type natural -ksp_rtol 1e-50 -ksp_max_it 40",
+                                  "-stencil 7 -n 32 -ksp_type cg -pc_type jacobi -ksp_norm_type unpreconditioned -ksp_rtol 1e-50 -ksp_max_it 40",
+                                  "-stencil 7 -n 24 -ksp_type cg -ksp_cg_single_reduction -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 40",
+                                  "-stencil 7 -n 24 -ksp_type gmres -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 45",
+                                  "-stencil 7 -n 24 -ksp_type bcgs -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 12"])
+def test_reduction_cache_returns_what_the_separate_kernels_return(args):
+    """Round 5: the reference's UNMODIFIED Krylov loops over the hipx types get p . A p from the product's epilogue and z . z,
+    z . r from the kernel that applies PCJACOBI (VecPointwiseMult), keyed on the vectors (plugin/vechipx.c: reduction cache) -- three vector passes
+    and three launches fewer per CG iteration.  A cached sum must be the sum the separate kernel returns on the same data: with EXACT reductions
+    the histories with and without the cache are the same doubles; with the default reductions they differ by the association of the partial sums."""
+    a = args.split() + ["-history"]
+    on = hist_of(run("ref_driver", a + HIPX + ["-hipx_reductions", "exact"]))
+    off = hist_of(run("ref_driver", a + HIPX + ["-hipx_reductions", "exact", "-hipx_reduction_cache", "0"]))
+    assert len(on) == len(off) > 10 and np.array_equal(on, off), np.abs(on - off).max()
+    on_f = hist_of(run("ref_driver", a + HIPX))
+    off_f = hist_of(run("ref_driver", a + HIPX + ["-hipx_reduction_cache", "0"]))
+    assert len(on_f) == len(off_f) == len(on)
+    tol = 1e-12 if "bcgs" not in args and "gmres" not in args else 1e-9
+    assert (np.abs(on_f - off_f) / off_f).max() <= tol
+    assert (np.abs(on_f - on) / on).max() <= (1e-11 if tol == 1e-12 else 1e-8)
+
+
+def test_reduction_cache_entries_die_with_the_first_write():
+    """The reference's own Vec tests with the cache on (it is on by default in every other test of this file too): ex1 of the tutorials prints
+    norms and dots taken right after VecPointwiseMult / VecScale / VecAXPY on the same vectors -- a stale entry would show up in its exact-text golden."""
+    on = run("kat_vec_tut_ex1", HIPX[:4])
+    off = run("kat_vec_tut_ex1", HIPX[:4] + ["-hipx_reduction_cache", "0"])
+    assert on == off and "error" not in on.lower().replace("norm of error", "")
