@@ -1017,6 +1017,7 @@ def main():
     ap.add_argument("--budget-s", type=float, default=float(os.environ.get("HIPX_BENCH_BUDGET_S", "140")),
                     help="wall-clock budget of the whole run (default 140 s): the headline (parity gate, timed steps, counter pass, CPU baseline) always runs; the optional legs (plugin rows, "
                          "other_configs, their counter passes and CPU baselines) run in order of importance while their estimated cost still fits, the rest are reported as skipped")
+    ap.add_argument("--parity-its", type=int, default=GATE_ITS, help="N > 1: entries of the committed exact-reduction history the headline leg is gated on (default 24; 35 covers a GMRES(30) restart)")
     ap.add_argument("--full", action="store_true", help="no budget: every leg, every counter pass, every CPU-baseline rank count (several minutes)")
     ap.add_argument("--suite", default=None, help=argparse.SUPPRESS)  # internal workloads of the counter passes (suite_mode)
     ap.add_argument("--suite-variants", default=None, help=argparse.SUPPRESS)
@@ -1509,7 +1510,7 @@ def main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync, t_st
             continue
         try:
             pdist.comm_init(rank, world, dist, t)
-            res, _ = run_leg(head, rank, world, dist, torch, t, args.steps, args.warmup, sync, variant=args.variant, fused=args.fused, pipeline=args.pipeline)
+            res, _ = run_leg(head, rank, world, dist, torch, t, args.steps, args.warmup, sync, variant=args.variant, parity_its=args.parity_its, fused=args.fused, pipeline=args.pipeline)
             nr = C.c_int()
             _lib.chk(hx.hipxCommRank(None, C.byref(nr)))
             res["comm_nranks"] = nr.value

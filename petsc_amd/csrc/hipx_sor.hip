@@ -57,7 +57,15 @@ struct hipxSorState {
   int       last_mode = -1;
   unsigned long long strand_vstate = 0;  // value state of the matrix the strand tables were built from
   void     *inode = nullptr;    // InodeState: node-level sweeps of a matrix with inodes (MatSOR_SeqAIJ_Inode)
+  void     *box = nullptr;      // hipx_sorbox.hip: plane-march schedule of constant-coefficient box stencils (zero-guess sweeps)
+  bool      box_tried = false;
 };
+
+// hipx_sorbox.hip
+extern "C" int  hipxSorBoxBuild_(long long m, int ntmpl, const int *tstart, const int *toff, const double *tval, const int *tdiag, const int64_t *tcount, const unsigned char *d_tid, void **out);
+extern "C" int  hipxSorBoxRun_(void *box, int kind, const double *rhs, double *tout, double *xout, double omega, double shift, int xfull);
+extern "C" int  hipxSorBoxError_(void *box, unsigned int *err);
+extern "C" void hipxSorBoxFree_(void *box);
 
 extern "C" {
 // accessors implemented in hipx_mat.hip
@@ -2968,6 +2976,7 @@ extern "C" void hipxSorStateFree_(void *p)
   (void)hipFree(S->d_ctl);
   strand_free((StrandState *)S->strand);
   inode_free((InodeState *)S->inode);
+  hipxSorBoxFree_(S->box);
   delete S;
 }
 
@@ -3076,6 +3085,7 @@ static int mat_sor_impl(hipxMat A, const double *b, double omega, int flag, doub
     if (e && !strcmp(e, "levels")) want = 0;
     else if (e && !strcmp(e, "dep")) want = 1;
     else if (e && !strcmp(e, "strand")) want = 2;
+    else if (e && !strcmp(e, "box")) want = 4;
   }
   // a matrix with inodes, relaxed with omega == 1 and no shift: MatSOR_SeqAIJ_Inode (aij.c:1852) -- the node-level sweeps
   bool use_inode = false;
@@ -3096,8 +3106,75 @@ static int mat_sor_impl(hipxMat A, const double *b, double omega, int flag, doub
       strand_free((StrandState *)S->strand);
       S->strand = nullptr;
     }
+    if (S->box) {
+      HIPX_HIP(hipStreamSynchronize(st));
+      hipxSorBoxFree_(S->box);
+      S->box = nullptr;
+    }
+    S->box_tried     = false;
     S->strand_tried  = false;
     S->strand_vstate = vstate;
+  }
+  // Plane march (hipx_sorbox.hip, round 5): PCSOR's default application -- a zero-guess forward / backward / symmetric sweep, one iteration -- on a
+  // constant-coefficient box stencil in natural ordering.  HIPX_SOR_MODE=box forces it (error when it does not apply), HIPX_SOR_BOX=0 turns it off
+  {
+    static const bool box_off = !(getenv("HIPX_SOR_BOX") && atoi(getenv("HIPX_SOR_BOX")) != 0);  // (opt-in until it is validated on the MI355X: HIPX_SOR_BOX=1)
+    const bool box_sweep = (flag & 16) && !(flag & 32) && flag != 64 && (int64_t)its * (int64_t)lits == 1 && ((flag & 1) || (flag & 2) || (flag & 4) || (flag & 8));
+    const bool aligned   = !((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(x)) & 15);
+    if ((want == 4 || (want == -1 && !box_off)) && box_sweep && aligned && !use_inode) {
+      if (!S->box_tried) {
+        S->box_tried = true;
+        int                  tok = 0, ntmpl = 0;
+        const int           *tstart, *toff, *tdiag;
+        const double        *tval;
+        const int64_t       *tcount;
+        const unsigned char *d_tid;
+        if ((ierr = hipxMatTemplates_(A, &tok, &ntmpl, &tstart, &toff, &tval, &tdiag, &tcount, &d_tid))) return ierr;
+        if (tok && (ierr = hipxSorBoxBuild_((long long)m, ntmpl, tstart, toff, tval, tdiag, tcount, d_tid, &S->box))) return ierr;
+      }
+      if (S->box) {
+        const bool plain = (omega == 1.0 && shift <= 0.0);
+        double     dgv   = 0.0;
+        {
+          int                  tok = 0, ntmpl = 0;
+          const int           *tstart, *toff, *tdiag;
+          const double        *tval;
+          const int64_t       *tcount;
+          const unsigned char *d_tid;
+          if ((ierr = hipxMatTemplates_(A, &tok, &ntmpl, &tstart, &toff, &tval, &tdiag, &tcount, &d_tid))) return ierr;
+          dgv = tok ? tval[tstart[0] + tdiag[0]] : 1.0;  // (one diagonal value on these matrices: hipxSorBoxBuild_ checked)
+        }
+        if (plain && shift == 0.0 && dgv == 0.0) return fail(HIPX_ERR_ZEROPIVOT, "Zero diagonal on a row (aij.c:1820)", __FILE__, __LINE__);
+        if (!S->d_t) {
+          HIPX_HIP(hipMalloc((void **)&S->d_t, sizeof(double) * (size_t)m));
+          HIPX_HIP(hipMalloc((void **)&S->d_w1, sizeof(double) * (size_t)m));
+          HIPX_HIP(hipMalloc((void **)&S->d_idiag, sizeof(double) * (size_t)m));
+          HIPX_HIP(hipMalloc((void **)&S->d_mdiag, sizeof(double) * (size_t)m));
+          HIPX_HIP(hipMalloc((void **)&S->d_ctl, sizeof(unsigned int) * 2));
+          HIPX_HIP(hipMemsetAsync(S->d_ctl, 0, sizeof(unsigned int) * 2, st));
+          S->m = m;
+        }
+        const hipx_int gf  = std::min<hipx_int>((m + 255) / 256, 4096);
+        const bool     fwd = (flag & 1) || (flag & 4), bwd = (flag & 2) || (flag & 8);
+        if (fwd && bwd) {  // the forward result itself is not needed: the backward sweep re-forms x = t idiag from t (aij.c:1955)
+          sor_fill_kernel<<<(unsigned)gf, 256, 0, st>>>(S->d_w1, m);
+          sor_fill_kernel<<<(unsigned)gf, 256, 0, st>>>(x, m);
+          HIPX_LAUNCH_CHECK();
+          if ((ierr = hipxSorBoxRun_(S->box, 0, b, S->d_t, S->d_w1, omega, shift, 0))) return ierr;
+          if ((ierr = hipxSorBoxRun_(S->box, 1, S->d_t, nullptr, x, omega, shift, 1))) return ierr;
+        } else {
+          sor_fill_kernel<<<(unsigned)gf, 256, 0, st>>>(x, m);
+          HIPX_LAUNCH_CHECK();
+          if ((ierr = hipxSorBoxRun_(S->box, fwd ? 0 : 2, b, S->d_t, x, omega, shift, 1))) return ierr;
+        }
+        S->mode = S->last_mode = 4;
+        unsigned int herr = 0;
+        if ((ierr = hipxSorBoxError_(S->box, &herr))) return ierr;
+        if (herr) return fail(HIPX_ERR_GPU, "MatSOR (plane march): a dependency was never published (wait limit reached)", __FILE__, __LINE__);
+        return HIPX_SUCCESS;
+      }
+    }
+    if (want == 4) return fail(HIPX_ERR_SUP, "HIPX_SOR_MODE=box: not a zero-guess sweep of a constant-coefficient box stencil in natural ordering (or unaligned vectors)", __FILE__, __LINE__);
   }
   if ((want == -1 || want == 2) && flag != 64 && !S->strand_tried && !use_inode) {
     S->strand_tried = true;

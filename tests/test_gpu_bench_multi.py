@@ -107,3 +107,48 @@ def test_gmres_sor_on_two_and_four_ranks_follows_the_exact_yardstick_at_1e12():
         d = last_json(r.stdout)
         g = d["parity_gate"]
         assert d["n_gpus"] == n and g["pass"] is True and g["gated_reduction_mode"] == "exact" and g["max_rel_diff"] <= 1e-12, g
+
+
+def _mem_available_gb():
+    for ln in open("/proc/meminfo"):
+        if ln.startswith("MemAvailable:"):
+            return int(ln.split()[1]) / 1048576.0
+    return 0.0
+
+
+def test_config3_at_its_real_shape_eight_ranks_on_this_gpu():
+    """BASELINE config 3 itself -- 27-pt 512^3, KSPGMRES(30) + PCSOR over EIGHT ranks (16.8 M-row slabs of 451 M nonzeros each: 8 x 5.8 GB of CSR fit this
+    one MI355X) -- run functionally: the 8-rank split, garray / ghost lists of 2 x 512^2 values per interior rank, MatMult_MPIAIJ's order (diagonal block, then the
+    ghost terms added), per-rank local symmetric sweeps, GMRES's 30-vector orthogonalisation with the ranks' sums folded as unrounded pairs.  The yardstick
+    (tests/golden/exact_histories.json[gmres_sor_27pt_512_np8], round 5) is the C oracle's GMRES loop with exact reductions over products and local sweeps
+    streamed slab by slab (oracle/stream_gmres.py: 3.6e9 nonzeros do not fit the build container as one matrix); 35 iterations = one restart.  VERDICT r4 item 2.
+    The ranks time-slice one device over the IPC transport: a functional run, not a scaling measurement."""
+    if _mem_available_gb() < 170:
+        pytest.skip("the 8 ranks assemble 8 x 5.4 GB slabs (and split them) on the host: needs ~170 GB of RAM, this box has %.0f GB available" % _mem_available_gb())
+    env = dict(clean_env(), HIPX_ALL_RANKS_DEVICE0="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--ksp", "gmres", "--pc", "sor", "--stencil", "27", "--grid", "512", "--steps", "35", "--warmup", "2",
+                        "--quick", "--transport", "ipc", "--parity-its", "35"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:]
+    d = last_json(r.stdout)
+    g = d["parity_gate"]
+    assert d["n_gpus"] == 8 and d["config"]["global_rows"] == 512 ** 3 and d["config"]["transport"] == "ipc"
+    assert g["pass"] is True and g["gated_reduction_mode"] == "exact" and g["iterations"] == 35 and g["entries"] == 36 and g["max_rel_diff"] <= 1e-12, g
+    assert g["max_rel_diff_fast_reductions"] <= 1e-8
+    assert len(d["per_rank"]) == 8 and all(p["rows"] == 512 ** 3 // 8 for p in d["per_rank"])
+    assert [p["ghosts"] for p in d["per_rank"]] == [512 * 512] + [2 * 512 * 512] * 6 + [512 * 512]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump({"what": "config 3 at its real shape: 8 ranks time-slicing ONE MI355X (IPC transport)", "parity_gate": g, "iterations_per_s": d["value"], "ms_per_step": d["ms_per_step"],
+               "per_rank": d["per_rank"]}, open(os.path.join(ROOT, "gpurun_out", "config3_real_shape_np8_one_gpu.json"), "w"), indent=1)
+
+
+def test_headline_256_on_eight_ranks_on_this_gpu():
+    """The headline system (7-pt 256^3, KSPCG + PCJACOBI) on eight ranks sharing this GPU: the 8-rank plan at BASELINE shape against the committed history of
+    the reference + exact BLAS (cg_jacobi_7pt_256), in the default reduction mode at 1e-12."""
+    env = dict(clean_env(), HIPX_ALL_RANKS_DEVICE0="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "60", "--warmup", "5", "--quick", "--transport", "ipc", "--parity-its", "50"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:]
+    d = last_json(r.stdout)
+    g = d["parity_gate"]
+    assert d["n_gpus"] == 8 and g["pass"] is True and g["iterations"] == 50 and g["max_rel_diff"] <= 1e-12, g
+    assert [p["ghosts"] for p in d["per_rank"]] == [256 * 256] + [2 * 256 * 256] * 6 + [256 * 256]
