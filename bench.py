@@ -642,7 +642,7 @@ def run_leg(cfg, rank, world, dist, torch, transport, steps, warmup, sync, varia
            "scaling": cfg.scaling, "global_rows": cfg.N, "spmv_kernel": kname, "parity": par, "residual_norm_after": r["rnorm"],
            "setup_seconds": t_setup, "setup_split": dict(P.setup_times), "per_rank": per_rank}
     if cfg.pc == "sor":
-        out["sor_schedule"] = {3: "inode (node-level dependency-driven)", 2: "strand", 1: "dependency-driven", 0: "levels"}.get(mode.value, str(mode.value))
+        out["sor_schedule"] = {4: "plane march", 3: "inode (node-level dependency-driven)", 2: "strand", 1: "dependency-driven", 0: "levels"}.get(mode.value, str(mode.value))
     nnz_l, m_l, wide = P.nnz_local, P.m, P.wide
     out["spmv_algorithmic_bytes_rank0"] = P.spmv_bytes()
     P.destroy()
@@ -793,7 +793,7 @@ def leg_matrix_solver(cfg, steps, warmup, sync, torch, best_ranks=None, parity_i
     if cfg.pc == "sor":  # PCSOR on a matrix without row templates: the dependency-driven (level-ordered) schedule, hipx_sor.hip
         mode = C.c_int(-1)
         P.lib.chk(P.hx.hipxMatGetSORMode(P.M.A, C.byref(mode)))
-        out["sor_schedule"] = {3: "inode (node-level dependency-driven)", 2: "strand", 1: "dependency-driven", 0: "levels"}.get(mode.value, str(mode.value))
+        out["sor_schedule"] = {4: "plane march", 3: "inode (node-level dependency-driven)", 2: "strand", 1: "dependency-driven", 0: "levels"}.get(mode.value, str(mode.value))
         if "sor_ms" in r["sections"]:
             ssor = 2 * 12 * P.nnz_local + 40 * P.m  # two passes over a, j + 5 vector passes
             out["roofline_sor"] = {"bound": "hbm", "kernel": "one PCApply_SOR = symmetric sweep (%s schedule)" % out["sor_schedule"], "avg_call_ms": r["sections"]["sor_ms"],
@@ -1266,7 +1266,8 @@ def main():
                         res[k2] = pr[k2]
                 if cfg.pc == "sor" and "sor_ms" in pr:
                     ssor = 2 * 12 * nnz_l + 40 * m_l  # two passes over a, j + 5 vector passes
-                    res["roofline_sor"] = {"bound": "hbm", "kernel": "sor_strand_kernel forward + backward (one PCApply_SOR = symmetric sweep)", "avg_call_ms": pr["sor_ms"], "calls": pr.get("sor_calls"),
+                    res["roofline_sor"] = {"bound": "hbm", "kernel": "%s forward + backward (one PCApply_SOR = symmetric sweep)" % ("sor_box_kernel" if res.get("sor_schedule") == "plane march" else "sor_strand_kernel"),
+                                           "avg_call_ms": pr["sor_ms"], "calls": pr.get("sor_calls"),
                                            "algorithmic_bytes": ssor, "effective_gbps": ssor / (pr["sor_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                                            "frac_algorithmic_bytes": ssor / (pr["sor_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                 other[name] = res
@@ -1444,7 +1445,8 @@ def main():
     if not args.no_other:
         c3 = other.get("config3_solver_gmres30_sor_27pt_256", {})
         if "roofline_sor" in c3:
-            if put_traffic(c3["roofline_sor"], pmc.get("sor27"), ["sor_strand_kernel<0", "sor_strand_kernel<1"], c3["roofline_sor"]["avg_call_ms"]):
+            needles = ["sor_box_kernel<false", "sor_box_kernel<true"] if c3.get("sor_schedule") == "plane march" else ["sor_strand_kernel<0", "sor_strand_kernel<1"]
+            if put_traffic(c3["roofline_sor"], pmc.get("sor27"), needles, c3["roofline_sor"]["avg_call_ms"]):
                 c3["roofline_sor"]["achieved"], c3["roofline_sor"]["frac"] = c3["roofline_sor"]["achieved_on_counter_bytes"], c3["roofline_sor"]["frac_counter_bytes"]
         if "roofline_spmv" in c3:
             put_traffic(c3["roofline_spmv"], pmc.get("spmv27"), [c3["roofline_spmv"]["kernel"].split(" ")[0]], c3["roofline_spmv"]["avg_launch_ms"])

@@ -217,9 +217,13 @@ int hipxMatGetInfo(hipxMat A, hipx_int *m, hipx_int *n, int64_t *nnz, int64_t *d
 /* replaces MatGetDiagonal_SeqAIJ aij.c:1347 */       int hipxMatGetDiagonal(hipxMat A, double *d);
 /* replaces MatSOR_SeqAIJ aij.c:1842 (flag = MatSORType bits petscmat.h:1664-1671); b, x device vectors */
 int hipxMatSOR(hipxMat A, const double *b, double omega, int flag, double shift, hipx_int its, hipx_int lits, double *x);
-/* which schedule the last hipxMatSOR call used: 2 = strands (stencil matrices with row templates: one lane per grid line, a wave
-   = 64 lines, neighbours through LDS), 1 = level-ordered dependency-driven sweep, 0 = one launch per level, 3 = the node-level sweep of
-   a matrix with inodes (below); -1 = none yet.  HIPX_SOR_MODE=strand|dep|levels forces one (all are bit-identical to aij.c:1930-2002). */
+/* which schedule the last hipxMatSOR call used: 4 = plane march (round 5: zero-guess forward / backward / symmetric sweeps -- PCSOR's default
+   application -- of constant-coefficient box stencils in natural ordering, 7-point ... 27-point: a workgroup owns four consecutive planes of a
+   block of 64 grid lines, one line per lane, every operand of the recurrence in LDS or registers; csrc/hipx_sorbox.hip), 2 = strands (stencil
+   matrices with row templates: one lane per grid line, a wave = 64 lines, neighbours through LDS windows, operands through memory), 1 =
+   level-ordered dependency-driven sweep, 0 = one launch per level, 3 = the node-level sweep of a matrix with inodes (below); -1 = none yet.
+   HIPX_SOR_MODE=box|strand|dep|levels forces one, HIPX_SOR_BOX=0 keeps the plane march out of the default choice (all are bit-identical to
+   aij.c:1930-2002). */
 int hipxMatGetSORMode(hipxMat A, int *mode);
 /* INODES (Mat_SeqAIJ_Inode, aij.h:98-132).  A MATSEQAIJ matrix whose consecutive rows share one column list (blocked FEM operators:
    several unknowns per mesh node) is relaxed NODE by node by the reference: MatSOR_SeqAIJ hands such a matrix to MatSOR_SeqAIJ_Inode

@@ -3118,7 +3118,7 @@ static int mat_sor_impl(hipxMat A, const double *b, double omega, int flag, doub
   // Plane march (hipx_sorbox.hip, round 5): PCSOR's default application -- a zero-guess forward / backward / symmetric sweep, one iteration -- on a
   // constant-coefficient box stencil in natural ordering.  HIPX_SOR_MODE=box forces it (error when it does not apply), HIPX_SOR_BOX=0 turns it off
   {
-    static const bool box_off = !(getenv("HIPX_SOR_BOX") && atoi(getenv("HIPX_SOR_BOX")) != 0);  // (opt-in until it is validated on the MI355X: HIPX_SOR_BOX=1)
+    static const bool box_off = getenv("HIPX_SOR_BOX") && atoi(getenv("HIPX_SOR_BOX")) == 0;
     const bool box_sweep = (flag & 16) && !(flag & 32) && flag != 64 && (int64_t)its * (int64_t)lits == 1 && ((flag & 1) || (flag & 2) || (flag & 4) || (flag & 8));
     const bool aligned   = !((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(x)) & 15);
     if ((want == 4 || (want == -1 && !box_off)) && box_sweep && aligned && !use_inode) {

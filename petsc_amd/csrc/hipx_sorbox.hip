@@ -35,15 +35,16 @@ namespace {
 
 constexpr int BX_P = 4, BX_G = 8;                             // planes per workgroup, rows per staging group
 constexpr int BX_RX = 16, BX_RB = 32, BX_RS = 32, BX_RW = 32;  // ring rows: own x lines / rhs / south plane / west lines
-constexpr int BX_THREADS = 2 * BX_P * 64;                      // P compute waves + P helper waves
+constexpr int BX_THREADS = 4 * BX_P * 64;                      // P compute waves + 2 P stagers (even / odd groups) + P flushers
 // LDS layout (doubles)
 constexpr int BX_OX = 0;                                        // X [P][64][RX + 1]
 constexpr int BX_OS = BX_OX + BX_P * 64 * (BX_RX + 1);          // S [66][RS + 1]
 constexpr int BX_OW = BX_OS + 66 * (BX_RS + 1);                 // W [P][2][RW]
 constexpr int BX_OB = BX_OW + BX_P * 2 * BX_RW;                 // B [P][64][RB + 1]
 constexpr int BX_OT = BX_OB + BX_P * 64 * (BX_RB + 1);          // TR[P][64][RX + 1]   (forward sweeps only)
-constexpr int BX_OC = BX_OT + BX_P * 64 * (BX_RX + 1);          // counters (ints): cprog[P + 1], hprog[P], flush[P], abort
-constexpr int BX_LDS_BYTES = BX_OC * 8 + 64;
+constexpr int BX_OC = BX_OT + BX_P * 64 * (BX_RX + 1);          // counters (ints): (P + 2) records of 4, abort, ticket
+constexpr int BX_LDS_BYTES = BX_OC * 8 + 4 * (8 * BX_P + 4);
+static_assert(BX_RW == BX_RS, "the stager writes both halo rings with one row mask");
 constexpr unsigned long long BX_SENTINEL = 0x7FF4DEADBEEF0001ULL;  // = SOR_SENTINEL of hipx_sor.hip (sor_fill_kernel fills x with it)
 constexpr long long          BX_SPIN_TICKS = 400000000LL;           // 4 s of the 100 MHz wall clock
 
@@ -56,22 +57,34 @@ struct BoxParams {
   double       *xout, *tout;
   const int2   *order;          // (J, c) of ticket n
   unsigned int *ctl;            // [0] ticket, [1] error
+  int          dbg;             // HIPX_SORBOX_DEBUG (timing probes, WRONG RESULTS): 1 = no staging / flushing (the compute waves alone), 2 = also no waiting for the lower plane
+  unsigned long long *stats;    // HIPX_SORBOX_STATS: spin counts of the compute waves by unmet condition [4], stager ring waits [1], stager halo polls [1], steps [1]
 };
 
 typedef __attribute__((address_space(3))) double bx_lds_double;
 typedef __attribute__((address_space(3))) int    bx_lds_int;
 typedef double bx_double2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ int bx_cnt_load(bx_lds_int *p) { return __hip_atomic_load((int *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// (readfirstlane: a counter is the same for every lane -- as a VGPR value the compiler takes every branch on it for divergent and wraps the waits in
+// exec-mask bookkeeping: measured ~680 clocks per readiness check that never had to wait)
+__device__ __forceinline__ int bx_cnt_load(bx_lds_int *p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load((int *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 __device__ __forceinline__ void bx_cnt_store(bx_lds_int *p, int v) { __hip_atomic_store((int *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// Ordering between the waves of ONE workgroup goes through LDS only: a wave's LDS operations complete in order, so "ring writes before the counter"
+// is s_waitcnt lgkmcnt(0) and "counter before ring reads" is program order (the counter's value has been waited for when it is compared).  The
+// __builtin_amdgcn_fence forms also wait for vmcnt(0) -- the stager would sit out the full latency of the loads it has just issued for the NEXT
+// groups at every publish (measured: 424 ns per step in a workgroup without any dependency, the memory latency of one group divided by eight).
+__device__ __forceinline__ void bx_lds_release() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void bx_lds_acquire() { asm volatile("" ::: "memory"); }
+
 // wait until *p >= want (uniform over the wave); false when the launch was aborted
+template <int SLEEP = 4>
 __device__ __forceinline__ bool bx_wait_ge(bx_lds_int *p, int want, bx_lds_int *abortw, unsigned int *gerr)
 {
   int       spins = 0;
   long long t0    = 0;
   while (bx_cnt_load(p) < want) {
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(SLEEP);  // (the helpers' waits: groups of eight steps, nothing is lost by looking every ~256 clocks)
     if (bx_cnt_load(abortw)) return false;
     if ((++spins & 0x3ff) == 0) {
       const long long now = (long long)wall_clock64();
@@ -119,27 +132,35 @@ __device__ __forceinline__ void bx_store2_sc1(double *p, bx_double2 v)
 // EM: bit e set = the interior row has the dependency-side entry at canonical position e.  KIND as in hipx_sor.hip: 0 forward zero-guess
 // (t = sum, x = sum idiag), 1 backward after forward (x = (1 - w) (t idiag) + sum idiag: aij.c:1955 with the forward result x = t idiag
 // re-formed from t), 2 backward zero-guess alone.
+// Waves of a workgroup: w = 0..P-1 compute (plane k0 + w), P..2P-1 stagers (right-hand side + west lines + south plane into the LDS rings),
+// 2P..3P-1 flushers (results out of the rings to memory).  Counters (LDS, one 16-byte record per plane: {steps relaxed, steps staged, steps
+// flushed}) are the only synchronisation inside the workgroup; between workgroups a row of x in memory is its own ready flag.
 template <bool REV, int EM, int KIND>
 __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams Q)
 {
   extern __shared__ double bx_smem[];
   bx_lds_double *L   = (bx_lds_double *)bx_smem;
+  // Counters, one 16-byte record per READER so that a wave fetches everything it waits for with one LDS access:
+  //   C[w] (compute wave w)        = {steps relaxed by plane w - 1, steps staged for plane w, steps relaxed by plane w + 1, steps flushed of plane w}
+  //   H[w] (stagers / flusher of w) = {steps relaxed by plane w, steps relaxed by plane w + 1, steps staged for plane w, -}
+  // A writer stores its counter into every record that holds it (one ds_write_b32, one lane per copy).  Planes that do not exist read "far ahead".
   bx_lds_int    *cnt = (bx_lds_int *)(L + BX_OC);
-  bx_lds_int    *cprog = cnt, *hprog = cnt + (BX_P + 1), *flushp = cnt + (2 * BX_P + 1), *abortw = cnt + (3 * BX_P + 1), *tick = cnt + (3 * BX_P + 2);
+  bx_lds_int    *dummy = cnt + 8 * BX_P, *abortw = dummy + 1, *tick = dummy + 2;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  auto Crec = [&](int w_) -> bx_lds_int * { return cnt + 8 * w_; };
+  auto Hrec = [&](int w_) -> bx_lds_int * { return cnt + 8 * w_ + 4; };
   if (threadIdx.x == 0) {
-    for (int q = 0; q < BX_P; q++) {
-      bx_cnt_store(cprog + q, 0);
-      bx_cnt_store(hprog + q, 0);
-      bx_cnt_store(flushp + q, 0);
-    }
-    bx_cnt_store(cprog + BX_P, 0x3fffffff);  // "the wave above the last one": never holds anybody back
+    for (int q = 0; q < 8 * BX_P; q++) bx_cnt_store(cnt + q, 0);
+    bx_cnt_store(Crec(0) + 0, 0x3fffffff);
+    bx_cnt_store(Crec(BX_P - 1) + 2, 0x3fffffff);
+    bx_cnt_store(Hrec(BX_P - 1) + 1, 0x3fffffff);
     bx_cnt_store(abortw, 0);
     bx_cnt_store(tick, (int)atomicAdd(Q.ctl, 1u));  // workgroups take their (block, chunk) in ticket order: every dependency has an earlier ticket
   }
   __syncthreads();
   const int2 jc = Q.order[bx_cnt_load(tick)];
   const int  J = jc.x, c = jc.y, k0 = BX_P * c;
+  if (Q.stats && threadIdx.x == 0) Q.stats[8 + 2 * (c * Q.nb + J)] = wall_clock64();
   const int  nx = Q.nx, ny = Q.ny, nz = Q.nz, T = Q.T;
   const double z0 = Q.z0;
   unsigned int *gerr = Q.ctl + 1;
@@ -149,12 +170,13 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     const int  w = wave, s = lane, k = k0 + w;
     const int  j = 64 * J - k + s;
     const bool valid = j >= 0 && j < ny && k < nz;
-    double Lr[3][2], Mr[2], xp = z0;  // lower plane lines j-1, j, j+1 at rows i-1, i; previous line at rows i-1, i; own x(i-1)
+    const int  i0 = -2 - 2 * s - 4 * w;  // row of this lane in step t: t + i0
+    double Lr[3][2], Mr[2], xcur = z0;   // lower plane lines j-1, j, j+1 at rows i-1, i; previous line at rows i-1, i; this lane's latest result
 #pragma unroll
     for (int l = 0; l < 3; l++) Lr[l][0] = Lr[l][1] = z0;
     Mr[0] = Mr[1] = z0;
-    // ring bases of this lane's four neighbour lines (element offsets; the row slot is added per step)
-    int nb_base[4], nb_mask[4];
+    // ring bases of the three lower-plane lines and (lane 0) of the west line that stands in for lane -1 (element offsets)
+    int nb_base[3], nb_mask[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
       const int q = s + d;  // line index in the lower plane's slot
@@ -169,185 +191,207 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
         nb_mask[d] = BX_RX - 1;
       }
     }
-    if (s == 0) {
-      nb_base[3] = BX_OW + (w * 2 + 1) * BX_RW;
-      nb_mask[3] = BX_RW - 1;
-    } else {
-      nb_base[3] = BX_OX + (w * 64 + (s - 1)) * (BX_RX + 1);
-      nb_mask[3] = BX_RX - 1;
-    }
+    const int wo = BX_OW + (w * 2 + 1) * BX_RW;
     const int xo = BX_OX + (w * 64 + s) * (BX_RX + 1), bo = BX_OB + (w * 64 + s) * (BX_RB + 1), to = BX_OT + (w * 64 + s) * (BX_RX + 1);
-    bool alive = true;
-    for (int t = 0; t < T && alive; t++) {
-      if (w > 0) alive = alive && bx_wait_ge(cprog + (w - 1), t - 2 < T ? t - 2 : T, abortw, gerr);  // the lower plane's row i + 1 of line j + 1: relaxed in wave w - 1's step t - 3
-      alive = alive && bx_wait_ge(hprog + w, t + 1, abortw, gerr);                                    // this step's right-hand side and west / south rows are staged
-      alive = alive && bx_wait_ge(cprog + (w + 1), t - 8, abortw, gerr);                              // x ring: plane k + 1 reads a row up to 7 steps after it was written
-      alive = alive && bx_wait_ge(flushp + w, t - BX_RX + 1, abortw, gerr);                           // the rows this step overwrites have left for memory
-      if (!alive) break;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      const int i = t - 2 - 2 * s - 4 * w;
-      if (i >= -1 && i < nx) {
-        double N[4];
-        const bool inr = i + 1 < nx;
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-          const double v = L[nb_base[d] + ((i + 1) & nb_mask[d])];
-          N[d]           = inr ? v : z0;
+    bx_lds_int *crec = Crec(w);
+    // where this wave's "steps relaxed" goes: C[w + 1].x, C[w - 1].z, H[w].x, H[w - 1].y -- lanes 0-3 store one copy each
+    bx_lds_int *pub = dummy;
+    if (lane == 0 && w + 1 < BX_P) pub = Crec(w + 1) + 0;
+    if (lane == 1 && w > 0) pub = Crec(w - 1) + 2;
+    if (lane == 2) pub = Hrec(w) + 0;
+    if (lane == 3 && w > 0) pub = Hrec(w - 1) + 1;
+    // what step t needs, checked before its operands are requested:
+    //   lower plane: its row i + 1 of line j + 1 was relaxed in wave w - 1's step t - 3            -> relaxed(w - 1) >= t - 2
+    //   right-hand side / west / south rows of the step are staged                                  -> staged(w)      >= t + 1
+    //   x ring (16 rows): plane k + 1 reads a row up to 7 steps after it was written                -> relaxed(w + 1) >= t - 8
+    //   x / t rings: the rows this step overwrites have left for memory                             -> flushed(w)     >= t - 15
+    int c_low = 0, c_stg = 0, c_up = 0, c_fl = 0;  // the record as last looked at (uniform)
+    int r_low = 0, r_stg = 0, r_up = 0, r_fl = 0;  // ... as last requested (in flight until taken)
+    auto look_issue = [&]() {  // four reads of one record; no wait here
+      r_low = __hip_atomic_load((int *)(crec + 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      r_stg = __hip_atomic_load((int *)(crec + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      r_up  = __hip_atomic_load((int *)(crec + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      r_fl  = __hip_atomic_load((int *)(crec + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto look_take = [&]() {  // uniform values (readfirstlane: a VGPR condition would make every wait a divergent loop)
+      c_low = __builtin_amdgcn_readfirstlane(r_low), c_stg = __builtin_amdgcn_readfirstlane(r_stg), c_up = __builtin_amdgcn_readfirstlane(r_up), c_fl = __builtin_amdgcn_readfirstlane(r_fl);
+    };
+    const int staged_all = Q.ngroups * BX_G;
+    auto ready = [&](int t) -> bool {
+      if (Q.dbg == 2) return true;
+      const bool core = (c_low >= (t - 2 < T ? t - 2 : T)) & (c_up >= t - 8);
+      if (Q.dbg == 1) return core;
+      return core & (c_stg >= (t + 1 < staged_all ? t + 1 : staged_all)) & (c_fl >= t - (BX_RX - 1));
+    };
+    unsigned sp_low = 0, sp_stg = 0, sp_up = 0, sp_fl = 0;  // spins by the first unmet condition (HIPX_SORBOX_STATS)
+    auto wait_ready = [&](int t) -> bool {  // (the record has just been looked at)
+      int       spins = 0;
+      long long t0    = 0;
+      while (!ready(t)) {
+        if (Q.stats) {
+          if (c_low < (t - 2 < T ? t - 2 : T)) sp_low++;
+          else if (c_stg < (t + 1 < staged_all ? t + 1 : staged_all)) sp_stg++;
+          else if (c_up < t - 8) sp_up++;
+          else sp_fl++;
         }
-        if (i >= 0) {
-          const double rhs = L[bo + (i & (BX_RB - 1))];
-          double       sum = rhs;
-          auto val = [&](int e) -> double {
-            if (e < 9) {
-              const int l = e / 3, cc = e % 3;
-              return cc < 2 ? Lr[l][cc] : N[l];
-            }
-            if (e < 12) return (e - 9) < 2 ? Mr[e - 9] : N[3];
-            return xp;
-          };
-#pragma unroll
-          for (int q = 0; q < 13; q++) {
-            const int e = REV ? 12 - q : q;
-            if ((EM >> e) & 1) sum = sum - Q.coef[e] * val(e);
+        if (bx_cnt_load(abortw)) return false;
+        if ((++spins & 0x3ff) == 0) {
+          const long long now = (long long)wall_clock64();
+          if (!t0) t0 = now;
+          if (__hip_atomic_load(gerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || now - t0 > BX_SPIN_TICKS) {
+            __hip_atomic_store(gerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bx_cnt_store(abortw, 1);
+            return false;
           }
-          double xv;
-          if (KIND == 1) xv = Q.omw * (rhs * Q.idiag) + sum * Q.idiag;
-          else xv = sum * Q.idiag;
-          if (!valid) xv = z0;  // a lane without a line publishes the zero element for its neighbours
-          L[xo + (i & (BX_RX - 1))] = xv;
-          if (KIND == 0) L[to + (i & (BX_RX - 1))] = sum;
-          xp = xv;
         }
-#pragma unroll
-        for (int l = 0; l < 3; l++) {
-          Lr[l][0] = Lr[l][1];
-          Lr[l][1] = N[l];
-        }
-        Mr[0] = Mr[1];
-        Mr[1] = N[3];
+        look_issue();
+        look_take();
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) bx_cnt_store(cprog + w, t + 1);
+      return true;
+    };
+    // One step, as a software pipeline two steps deep -- no LDS latency is left on a step's path:
+    //   top      the record is requested (it decides, at the bottom, whether step t + 2 may be prepared)
+    //   middle   row i is relaxed out of registers: its operands were requested TWO steps ago; the results go to the rings and the step is
+    //            published with NO wait in between -- a wave's LDS operations are executed in order, whoever sees the counter sees the rows
+    //   bottom   the record is looked at; the operands of step t + 2 are requested
+    struct Ops {
+      double n0, n1, n2, rhs, west;  // rows i + 1 of the lower plane's three lines, the right-hand side of row i, the west line's row i + 1
+    };
+    auto request = [&](int t) -> Ops {
+      const int i = t + i0;
+      Ops       o;
+      o.n0   = L[nb_base[0] + ((i + 1) & nb_mask[0])];
+      o.n1   = L[nb_base[1] + ((i + 1) & nb_mask[1])];
+      o.n2   = L[nb_base[2] + ((i + 1) & nb_mask[2])];
+      o.rhs  = L[bo + (i & (BX_RB - 1))];
+      o.west = L[wo + ((i + 1) & (BX_RW - 1))];
+      return o;
+    };
+    Ops P1, P2;  // operands of steps t + 1 and t + 2 (in flight)
+    look_issue();
+    look_take();
+    bool alive = wait_ready(T > 1 ? 1 : 0);
+    if (alive) {
+      bx_lds_acquire();
+      P1 = request(0);
+      P2 = T > 1 ? request(1) : P1;
+    }
+    unsigned long long tsec[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;  // HIPX_SORBOX_STATS: shader clocks by section of the step
+    const bool         timing  = Q.stats != nullptr;
+#define BX_TICK(k) \
+  if (timing) { \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    tsec[k] += now_ - tprev; \
+    tprev = now_; \
+  }
+    if (timing) tprev = __builtin_readcyclecounter();
+    for (int t = 0; t < T && alive; t++) {
+      const int i = t + i0;
+      const Ops O = P1;  // this step's operands
+      P1          = P2;
+      BX_TICK(0)
+      if (t + 2 < T) look_issue();
+      BX_TICK(1)
+      // the previous line's row i + 1: lane s - 1 relaxed it in the step before (wavefront shift); lane 0 takes the west line's
+      const double xsrc = xcur;
+      const int    nlo = __builtin_amdgcn_update_dpp(__double2loint(O.west), __double2loint(xsrc), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+      const int    nhi = __builtin_amdgcn_update_dpp(__double2hiint(O.west), __double2hiint(xsrc), 0x138, 0xf, 0xf, false);
+      const bool   inr = i + 1 >= 0 && i + 1 < nx;
+      double       N[4];
+      N[0] = inr ? O.n0 : z0;
+      N[1] = inr ? O.n1 : z0;
+      N[2] = inr ? O.n2 : z0;
+      N[3] = inr ? __hiloint2double(nhi, nlo) : z0;
+      double xnew = z0;
+      if (i >= 0 && i < nx) {
+        const double rhs = O.rhs;
+        double       sum = rhs;
+        auto val = [&](int e) -> double {
+          if (e < 9) {
+            const int l = e / 3, cc = e % 3;
+            return cc < 2 ? Lr[l][cc] : N[l];
+          }
+          if (e < 12) return (e - 9) < 2 ? Mr[e - 9] : N[3];
+          return xcur;
+        };
+#pragma unroll
+        for (int q = 0; q < 13; q++) {
+          const int e = REV ? 12 - q : q;
+          if ((EM >> e) & 1) sum = sum - Q.coef[e] * val(e);
+        }
+        double xv;
+        if (KIND == 1) xv = Q.omw * (rhs * Q.idiag) + sum * Q.idiag;
+        else xv = sum * Q.idiag;
+        if (!valid) xv = z0;  // a lane without a line publishes the zero element for its neighbours
+        L[xo + (i & (BX_RX - 1))] = xv;
+        if (KIND == 0) L[to + (i & (BX_RX - 1))] = sum;
+        xnew = xv;
+      }
+      xcur = xnew;  // (z0 outside the line: what the next lane must see for a row beyond the end)
+#pragma unroll
+      for (int l = 0; l < 3; l++) {
+        Lr[l][0] = Lr[l][1];
+        Lr[l][1] = N[l];
+      }
+      Mr[0] = Mr[1];
+      Mr[1] = N[3];
+      asm volatile("" ::: "memory");  // (ring writes, then the counter: program order = LDS order)
+      if (lane < 4) bx_cnt_store(pub, t + 1);
+      BX_TICK(2)
+      if (t + 2 < T) {
+        look_take();
+        if (!ready(t + 2)) {
+          alive = wait_ready(t + 2);
+          if (!alive) break;
+        }
+        bx_lds_acquire();
+        BX_TICK(3)
+        P2 = request(t + 2);
+      }
+      BX_TICK(4)
+    }
+    if (timing && lane == 0 && J == 0 && c == 0 && w == 1)
+      for (int q = 0; q < 5; q++) Q.stats[8 + 2 * Q.nb * Q.nch + q] = tsec[q];
+    if (Q.stats && lane == 0) {
+      if (w == BX_P - 1) Q.stats[8 + 2 * (c * Q.nb + J) + 1] = wall_clock64();
+      atomicAdd(Q.stats + 0, (unsigned long long)sp_low);
+      atomicAdd(Q.stats + 1, (unsigned long long)sp_stg);
+      atomicAdd(Q.stats + 2, (unsigned long long)sp_up);
+      atomicAdd(Q.stats + 3, (unsigned long long)sp_fl);
+      atomicAdd(Q.stats + 6, (unsigned long long)T);
     }
     return;
   }
 
-  // -------------------------------------------------------------------------------------------------- helper wave of plane k0 + w
-  const int  w = wave - BX_P, k = k0 + w;
+  const int  role = wave / BX_P - 1;  // 0, 1 stagers (groups of this parity), 2 flusher
+  if (Q.dbg) return;
+  const int  w = wave % BX_P, k = k0 + w;
   const bool plane_ok = k < nz;
   const long long nxl = nx, nyl = ny;
   auto phys = [&](int r, int jj, int kk) -> long long {  // element index of logical row (r, jj, kk); pairs (r, r + 1), r even, are 16-byte aligned
     const long long lr = (long long)r + nxl * ((long long)jj + nyl * (long long)kk);
     return REV ? Q.m - 2 - lr : lr;  // REV: the pair (r, r + 1) lies at m - 2 - lr, halves swapped
   };
-  int  g = 0, fg = 0;  // next group to stage / to flush
-  bool alive = true;
-  // right-hand side: the loads of group g + 1 are in flight while group g's halo rows are polled and results are flushed
-  bx_double2 pre[4];
-  auto rhs_issue = [&](int gg) {
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-      const int  s = 16 * p + (lane >> 2), qd = lane & 3, jj = 64 * J - k + s;
-      const int  r = BX_G * gg - 2 - 2 * s - 4 * w + 2 * qd;
-      const bool ok = plane_ok && r >= 0 && r < nx && jj >= 0 && jj < ny;
-      pre[p]        = *reinterpret_cast<const bx_double2 *>(ok ? Q.rhs + phys(r, jj, k) : Q.rhs);  // (a lane without a row reads element 0: never stored)
-    }
-  };
-  auto rhs_store = [&](int gg) {
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-      const int s = 16 * p + (lane >> 2), qd = lane & 3, jj = 64 * J - k + s;
-      const int r = BX_G * gg - 2 - 2 * s - 4 * w + 2 * qd;
-      if (plane_ok && r >= 0 && r < nx && jj >= 0 && jj < ny) {
-        const int bo = BX_OB + (w * 64 + s) * (BX_RB + 1);
-        L[bo + (r & (BX_RB - 1))]       = REV ? pre[p].y : pre[p].x;
-        L[bo + ((r + 1) & (BX_RB - 1))] = REV ? pre[p].x : pre[p].y;
-      }
-    }
-  };
-  if (Q.ngroups > 0) rhs_issue(0);
-  while (alive && (g < Q.ngroups || fg * BX_G < T)) {
-    bool did = false;
-    // ---- stage group g: everything the compute wave reads in steps [8 g, 8 g + 8)
-    if (g < Q.ngroups && bx_cnt_load(cprog + w) >= BX_G * g - (BX_RB - BX_G) && bx_cnt_load(cprog + w) >= BX_G * g - (BX_RW - 16) && bx_cnt_load(cprog + (w + 1)) >= BX_G * g - (BX_RW - 16)) {
-      did = true;
-      // (a) right-hand side rows [8 g - 2 - 2 s - 4 w, + 8) of the 64 lines: four lanes per line, a pair of rows each
-      rhs_store(g);
-      if (g + 1 < Q.ngroups) rhs_issue(g + 1);
-      // (b) the two west lines of plane k (lines 64 J - k - 2, - 1: block J - 1's last lanes), rows [8 g - 4 w, + 8): task 0 of lanes 0-7;
-      // (c) helper 0: the south plane k0 - 1 (66 lines: the chunk below and, there, block J - 1's last lanes), line index q rows
-      //     [8 g - 2 max(q - 2, 0), + 8): tasks 1-5.  All loads of a group are issued together (16 bytes, agent scope), one wait; a half that still
-      //     holds the sentinel is polled on its own afterwards
-      constexpr int NT = 6;
-      bx_double2    hv[NT];
-      const double *hp[NT];
-      bool          hin[NT], hmem[NT];  // the task exists for this lane / its rows come from memory (else: the zero element)
-      int           hoff[NT], hmask[NT], hr[NT];
-#pragma unroll
-      for (int tk = 0; tk < NT; tk++) {
-        int q, qd, jj, kk, r;
-        if (tk == 0) {
-          q = lane >> 2, qd = lane & 3, jj = 64 * J - k - 2 + q, kk = k;
-          r         = BX_G * g - 4 * w + 2 * qd;
-          hin[tk]   = lane < 8 && r >= 0 && r < nx;
-          hmem[tk]  = hin[tk] && plane_ok && jj >= 0 && jj < ny;
-          hoff[tk]  = BX_OW + (w * 2 + (q & 1)) * BX_RW;
-          hmask[tk] = BX_RW - 1;
-        } else {
-          const int task = lane + 64 * (tk - 1);
-          q = task >> 2, qd = task & 3, jj = 64 * J - (k0 - 1) + q - 2, kk = k0 - 1;
-          r         = BX_G * g - 2 * (q > 2 ? q - 2 : 0) + 2 * qd;
-          hin[tk]   = w == 0 && task < 66 * 4 && r >= 0 && r < nx;
-          hmem[tk]  = hin[tk] && k0 > 0 && jj >= 0 && jj < ny;
-          hoff[tk]  = BX_OS + (q < 66 ? q : 0) * (BX_RS + 1);
-          hmask[tk] = BX_RS - 1;
-        }
-        hr[tk] = r;
-        hp[tk] = hmem[tk] ? Q.xout + phys(r, jj, kk) : Q.xout;
-      }
-      if (w == 0) {
-#pragma unroll
-        for (int tk = 0; tk < NT; tk++) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(hv[tk]) : "v"(hp[tk]) : "memory");
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]), "+v"(hv[4]), "+v"(hv[5])::"memory");
-      } else {
-        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(hv[0]) : "v"(hp[0]) : "memory");
-      }
-#pragma unroll
-      for (int tk = 0; tk < NT; tk++) {
-        if (tk > 0 && w != 0) break;
-        if (hin[tk]) {
-          bx_double2 v = hv[tk];
-          if (hmem[tk]) {
-            if ((unsigned long long)__double_as_longlong(v.x) == BX_SENTINEL || (unsigned long long)__double_as_longlong(v.y) == BX_SENTINEL) v = bx_poll2(hp[tk], abortw, gerr);
-            if (REV) {
-              const double tmp = v.x;
-              v.x              = v.y;
-              v.y              = tmp;
-            }
-          } else v.x = v.y = z0;
-          L[hoff[tk] + (hr[tk] & hmask[tk])]       = v.x;
-          L[hoff[tk] + ((hr[tk] + 1) & hmask[tk])] = v.y;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      g++;
-      if (lane == 0) bx_cnt_store(hprog + w, BX_G * g);
-    }
-    // ---- flush group fg: the results of steps [8 fg, 8 fg + 8) leave for memory
-    if (fg * BX_G < T) {
+  bx_lds_int *hrec = Hrec(w);  // {relaxed(w), relaxed(w + 1), staged(w)}
+
+  if (role == 2) {
+    // ---------------------------------------------------------------------------------------------------- flusher of plane k0 + w
+    for (int fg = 0; fg * BX_G < T; fg++) {
       const int need = (fg + 1) * BX_G < T ? (fg + 1) * BX_G : T;
-      if (bx_cnt_load(cprog + w) >= need) {
-        did = true;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (plane_ok) {
+      if (!bx_wait_ge(hrec, need, abortw, gerr)) return;
+      bx_lds_acquire();
+      if (plane_ok) {
 #pragma unroll
-          for (int p = 0; p < 4; p++) {
-            const int s = 16 * p + (lane >> 2), qd = lane & 3, jj = 64 * J - k + s;
-            const int r = BX_G * fg - 2 - 2 * s - 4 * w + 2 * qd;
-            if (r >= 0 && r < nx && jj >= 0 && jj < ny) {
-              const int       xo = BX_OX + (w * 64 + s) * (BX_RX + 1);
-              const long long e  = phys(r, jj, k);
-              bx_double2      v;
+        for (int p = 0; p < 4; p++) {
+          const int s = 16 * p + (lane >> 2), qd = lane & 3, jj = 64 * J - k + s;
+          const int r = BX_G * fg - 2 - 2 * s - 4 * w + 2 * qd;
+          if (r >= 0 && r < nx && jj >= 0 && jj < ny) {
+            const int       xo = BX_OX + (w * 64 + s) * (BX_RX + 1);
+            const long long e  = phys(r, jj, k);
+            // forward sweep inside a symmetric application: only the lines other workgroups read go to memory (the last two lanes, the
+            // chunk's top plane); the result of the application is the backward sweep's
+            if (Q.xfull || s >= 62 || w == BX_P - 1) {
+              bx_double2 v;
               v.x = L[xo + (r & (BX_RX - 1))];
               v.y = L[xo + ((r + 1) & (BX_RX - 1))];
               if (REV) {
@@ -355,28 +399,132 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
                 v.x              = v.y;
                 v.y              = tmp;
               }
-              // forward sweep inside a symmetric application: only the lines other workgroups read go to memory (the last two lanes, the
-              // chunk's top plane); the result of the application is the backward sweep's
-              if (Q.xfull || s >= 62 || w == BX_P - 1) bx_store2_sc1(Q.xout + e, v);
-              if (KIND == 0) {
-                const int  to = BX_OT + (w * 64 + s) * (BX_RX + 1);
-                bx_double2 tv;
-                tv.x = L[to + (r & (BX_RX - 1))];
-                tv.y = L[to + ((r + 1) & (BX_RX - 1))];
-                *reinterpret_cast<bx_double2 *>(Q.tout + e) = tv;  // (forward: never REV)
-              }
+              bx_store2_sc1(Q.xout + e, v);
+            }
+            if (KIND == 0) {
+              const int  to = BX_OT + (w * 64 + s) * (BX_RX + 1);
+              bx_double2 tv;
+              tv.x = L[to + (r & (BX_RX - 1))];
+              tv.y = L[to + ((r + 1) & (BX_RX - 1))];
+              *reinterpret_cast<bx_double2 *>(Q.tout + e) = tv;  // (forward: never REV)
             }
           }
         }
-        fg++;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) bx_cnt_store(flushp + w, fg * BX_G < T ? fg * BX_G : T);
+      }
+      bx_lds_release();  // (the ring reads are done; the stores may still be on their way)
+      if (lane == 0) bx_cnt_store(Crec(w) + 3, need);
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------------------------------- stager of plane k0 + w
+  // Everything of group g + 1 -- right-hand side (a), west lines (b), south plane (c, stager 0) -- is requested from memory while group g is
+  // being consumed: 16-byte loads, four lanes per 64-byte line segment, the halo loads at agent scope (a row of x another workgroup has not
+  // written yet reads as the sentinel and is polled on its own when its turn comes).
+  // A plane has TWO stagers, one for the even and one for the odd groups: a stager's loads for its next group (two groups on) are requested right
+  // after it has published the current one and are the only ones it has in flight when it needs them -- about sixteen steps later.  (One stager with
+  // two groups in flight waits, at every group, for the loads it has JUST issued -- the compiler's vmcnt(0) -- and the whole workgroup settles at
+  // memory latency / 8 per step: measured 400-424 ns per step in workgroups without any outside dependency.)
+  constexpr int NT = 6;  // halo tasks per lane: 0 = west lines (lanes 0-7), 1-5 = south plane (stager 0)
+  bx_double2    pre[1][4], hv[1][NT];
+  // what halo task tk of group g is for this lane (recomputed where needed: only the loaded values live across the two groups in flight)
+  auto halo_desc = [&](int g, const int tk, bool &in, bool &mem, int &off, int &r, const double *&ptr) {
+    int q, qd, jj, kk;
+    if (tk == 0) {  // (b) the two west lines of plane k (lines 64 J - k - 2, - 1: block J - 1's last lanes), rows [8 g - 4 w, + 8): lanes 0-7
+      q = lane >> 2, qd = lane & 3, jj = 64 * J - k - 2 + q, kk = k;
+      r   = BX_G * g - 4 * w + 2 * qd;
+      in  = lane < 8 && r >= 0 && r < nx;
+      mem = in && plane_ok && jj >= 0 && jj < ny;
+      off = BX_OW + (w * 2 + (q & 1)) * BX_RW + (r & (BX_RW - 1));
+    } else {  // (c) stager 0: the south plane k0 - 1 (66 lines: the chunk below and, there, block J - 1's last lanes), line index q rows [8 g - 2 max(q - 2, 0), + 8)
+      const int task = lane + 64 * (tk - 1);
+      q = task >> 2, qd = task & 3, jj = 64 * J - (k0 - 1) + q - 2, kk = k0 - 1;
+      r   = BX_G * g - 2 * (q > 2 ? q - 2 : 0) + 2 * qd;
+      in  = w == 0 && task < 66 * 4 && r >= 0 && r < nx;
+      mem = in && k0 > 0 && jj >= 0 && jj < ny;
+      off = BX_OS + (q < 66 ? q : 0) * (BX_RS + 1) + (r & (BX_RS - 1));
+    }
+    ptr = mem ? Q.xout + phys(r, jj, kk) : Q.xout;
+  };
+  auto issue = [&](int g, const int sl) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {  // (a) rows [8 g - 2 - 2 s - 4 w, + 8) of the 64 lines
+      const int  s = 16 * p + (lane >> 2), qd = lane & 3, jj = 64 * J - k + s;
+      const int  r = BX_G * g - 2 - 2 * s - 4 * w + 2 * qd;
+      const bool ok = plane_ok && r >= 0 && r < nx && jj >= 0 && jj < ny;
+      pre[sl][p]    = *reinterpret_cast<const bx_double2 *>(ok ? Q.rhs + phys(r, jj, k) : Q.rhs);  // (a lane without a row reads element 0: never stored)
+    }
+    // agent-scope (sc1) loads the compiler can see: the values are waited for where they are used, two groups later
+    auto ld = [&](const double *q) -> bx_double2 {
+      const unsigned long long *u = reinterpret_cast<const unsigned long long *>(q);
+      bx_double2                v;
+      v.x = __longlong_as_double((long long)__hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      v.y = __longlong_as_double((long long)__hip_atomic_load(u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      return v;
+    };
+#pragma unroll
+    for (int tk = 0; tk < NT; tk++) {
+      if (tk > 0 && w != 0) break;
+      bool          in, mem;
+      int           off, r;
+      const double *ptr;
+      halo_desc(g, tk, in, mem, off, r, ptr);
+      hv[sl][tk] = ld(ptr);
+    }
+  };
+  unsigned npoll = 0, nring = 0;
+  auto stage = [&](int g, const int sl) -> bool {
+    if (Q.stats && (bx_cnt_load(hrec) < BX_G * g - (BX_RW - 16) || bx_cnt_load(hrec + 1) < BX_G * g - (BX_RW - 16))) nring++;
+    // ring space: rhs ring (32 rows) -> the wave is past step 8 g - 24; west / south rings (32 rows, read up to 13 steps after staging) -> waves w and w + 1 past 8 g - 16
+    if (!bx_wait_ge(hrec, BX_G * g - (BX_RW - 16), abortw, gerr) || !bx_wait_ge(hrec + 1, BX_G * g - (BX_RW - 16), abortw, gerr)) return false;
+    bx_lds_acquire();
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int s = 16 * p + (lane >> 2), qd = lane & 3, jj = 64 * J - k + s;
+      const int r = BX_G * g - 2 - 2 * s - 4 * w + 2 * qd;
+      if (plane_ok && r >= 0 && r < nx && jj >= 0 && jj < ny) {
+        const int bo = BX_OB + (w * 64 + s) * (BX_RB + 1);
+        L[bo + (r & (BX_RB - 1))]       = REV ? pre[sl][p].y : pre[sl][p].x;
+        L[bo + ((r + 1) & (BX_RB - 1))] = REV ? pre[sl][p].x : pre[sl][p].y;
       }
     }
-    if (!did) {
-      __builtin_amdgcn_s_sleep(2);
-      if (bx_cnt_load(abortw)) alive = false;
+#pragma unroll
+    for (int tk = 0; tk < NT; tk++) {
+      if (tk > 0 && w != 0) break;
+      bool          in, mem;
+      int           off, r;
+      const double *ptr;
+      halo_desc(g, tk, in, mem, off, r, ptr);
+      if (in) {
+        bx_double2 v = hv[sl][tk];
+        if (mem) {
+          if ((unsigned long long)__double_as_longlong(v.x) == BX_SENTINEL || (unsigned long long)__double_as_longlong(v.y) == BX_SENTINEL) {
+            npoll++;
+            v = bx_poll2(ptr, abortw, gerr);
+          }
+          if (REV) {
+            const double tmp = v.x;
+            v.x              = v.y;
+            v.y              = tmp;
+          }
+        } else v.x = v.y = z0;
+        L[off] = v.x;
+        L[off - (r & (BX_RW - 1)) + ((r + 1) & (BX_RW - 1))] = v.y;  // (RW == RS: the same row mask for both rings)
+      }
     }
+    bx_lds_release();
+    if (!bx_wait_ge(hrec + 2, BX_G * g, abortw, gerr)) return false;  // (groups are published in order: the other stager's group g - 1 first)
+    if (lane < 2) bx_cnt_store(lane == 0 ? Crec(w) + 1 : hrec + 2, BX_G * (g + 1));
+    return true;
+  };
+  if (role < Q.ngroups) issue(role, 0);
+  for (int g = role; g < Q.ngroups; g += 2) {
+    if (!stage(g, 0)) return;
+    if (g + 2 < Q.ngroups) issue(g + 2, 0);
+  }
+  if (Q.stats) {
+    atomicAdd(Q.stats + 4, (unsigned long long)(lane == 0 ? nring : 0));
+    atomicAdd(Q.stats + 5, (unsigned long long)npoll);
   }
 }
 
@@ -403,6 +551,7 @@ struct hipxSorBox_s {
   double        coefF[13], coefB[13], diag = 0.0, z0 = 0.0;
   int2         *d_order = nullptr;
   unsigned int *d_ctl = nullptr;
+  unsigned long long *d_stats = nullptr;
 };
 typedef hipxSorBox_s *hipxSorBox;
 
@@ -412,6 +561,7 @@ extern "C" void hipxSorBoxFree_(void *p)
   if (!B) return;
   (void)hipFree(B->d_order);
   (void)hipFree(B->d_ctl);
+  (void)hipFree(B->d_stats);
   delete B;
 }
 
@@ -564,12 +714,50 @@ extern "C" int hipxSorBoxRun_(void *p, int kind, const double *rhs, double *tout
   Q.z0    = B->z0;
   Q.omw   = 1.0 - omega;
   Q.rhs = rhs, Q.xout = xout, Q.tout = tout, Q.order = B->d_order, Q.ctl = B->d_ctl;
+  static const bool want_stats = getenv("HIPX_SORBOX_STATS") != nullptr;  // developer switch: where the waves wait
+  static const int  dbg        = getenv("HIPX_SORBOX_DEBUG") ? atoi(getenv("HIPX_SORBOX_DEBUG")) : 0;
+  Q.dbg = dbg;
+  Q.stats = nullptr;
+  if (want_stats) {
+    const size_t nst = 16 + 2 * (size_t)B->nb * B->nch;
+    if (!B->d_stats) HIPX_HIP(hipMalloc((void **)&B->d_stats, nst * sizeof(unsigned long long)));
+    HIPX_HIP(hipMemsetAsync(B->d_stats, 0, nst * sizeof(unsigned long long), rt().compute));
+    Q.stats = B->d_stats;
+  }
   memcpy(Q.coef, kind == 0 ? B->coefF : B->coefB, sizeof(Q.coef));
   HIPX_HIP(hipMemsetAsync(B->d_ctl, 0, sizeof(unsigned int), rt().compute));  // the ticket; the error word is sticky until read
   const bool box27 = B->em == 0x1FFF;
-  if (kind == 0) return box27 ? box_launch<false, 0x1FFF, 0>(B, Q) : box_launch<false, 0x1410, 0>(B, Q);
-  if (kind == 1) return box27 ? box_launch<true, 0x1FFF, 1>(B, Q) : box_launch<true, 0x1410, 1>(B, Q);
-  return box27 ? box_launch<true, 0x1FFF, 2>(B, Q) : box_launch<true, 0x1410, 2>(B, Q);
+  int        ierr;
+  if (kind == 0) ierr = box27 ? box_launch<false, 0x1FFF, 0>(B, Q) : box_launch<false, 0x1410, 0>(B, Q);
+  else if (kind == 1) ierr = box27 ? box_launch<true, 0x1FFF, 1>(B, Q) : box_launch<true, 0x1410, 1>(B, Q);
+  else ierr = box27 ? box_launch<true, 0x1FFF, 2>(B, Q) : box_launch<true, 0x1410, 2>(B, Q);
+  if (!ierr && want_stats) {
+    const size_t                    nst = 16 + 2 * (size_t)B->nb * B->nch;
+    std::vector<unsigned long long> hvv(nst);
+    unsigned long long             *h = hvv.data();
+    HIPX_HIP(hipMemcpyAsync(h, B->d_stats, nst * sizeof(unsigned long long), hipMemcpyDeviceToHost, rt().compute));
+    HIPX_HIP(hipStreamSynchronize(rt().compute));
+    {
+      const unsigned long long *ts = h + 8 + 2 * (size_t)B->nb * B->nch;
+      fprintf(stderr, "[sorbox sections, shader clocks per step, workgroup (0,0) wave 1] top wait + publish %.0f, copies %.0f, readiness %.0f, requests %.0f, arithmetic + ring writes %.0f\n", (double)ts[0] / B->T,
+              (double)ts[1] / B->T, (double)ts[2] / B->T, (double)ts[3] / B->T, (double)ts[4] / B->T);
+    }
+    {  // time stamps (100 MHz): when workgroup (J, c) started and when its top plane finished, relative to the first start
+      unsigned long long t0 = ~0ull;
+      for (size_t q = 0; q < (size_t)B->nb * B->nch; q++)
+        if (h[8 + 2 * q] && h[8 + 2 * q] < t0) t0 = h[8 + 2 * q];
+      auto us = [&](int J, int c, int e) { return (double)(long long)(h[8 + 2 * ((size_t)c * B->nb + J) + e] - t0) * 0.01; };
+      const int cl = B->nch - 1, Jl = B->nb - 1, cm = B->nch / 2;
+      fprintf(stderr, "[sorbox stamps us] (J,c): start..end  (0,0) %.1f..%.1f  (0,1) %.1f..%.1f  (0,2) %.1f..%.1f  (1,0) %.1f..%.1f  (2,0) %.1f..%.1f  (1,1) %.1f..%.1f  (0,%d) %.1f..%.1f  (%d,%d) %.1f..%.1f  (%d,%d) %.1f..%.1f\n",
+              us(0, 0, 0), us(0, 0, 1), us(0, cl > 0 ? 1 : 0, 0), us(0, cl > 0 ? 1 : 0, 1), us(0, cl > 1 ? 2 : 0, 0), us(0, cl > 1 ? 2 : 0, 1), us(Jl > 0 ? 1 : 0, 0, 0), us(Jl > 0 ? 1 : 0, 0, 1),
+              us(Jl > 1 ? 2 : 0, 0, 0), us(Jl > 1 ? 2 : 0, 0, 1), us(Jl > 0 ? 1 : 0, cl > 0 ? 1 : 0, 0), us(Jl > 0 ? 1 : 0, cl > 0 ? 1 : 0, 1), cm, us(0, cm, 0), us(0, cm, 1), Jl, 0, us(Jl, 0, 0), us(Jl, 0, 1), Jl, cl,
+              us(Jl, cl, 0), us(Jl, cl, 1));
+    }
+    const double nw = (double)B->nb * B->nch * BX_P;
+    fprintf(stderr, "[sorbox kind %d %dx%dx%d] per compute wave: steps %.0f, spins waiting for lower plane %.1f, stager %.1f, upper plane %.1f, flusher %.1f; per stager: ring waits %.1f, halo polls %.1f\n", kind,
+            B->nx, B->ny, B->nz, (double)h[6] / nw, (double)h[0] / nw, (double)h[1] / nw, (double)h[2] / nw, (double)h[3] / nw, (double)h[4] / nw, (double)h[5] / nw);
+  }
+  return ierr;
 }
 
 extern "C" int hipxSorBoxError_(void *p, unsigned int *err)

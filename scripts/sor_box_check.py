@@ -71,8 +71,29 @@ def where(d, nx, ny, nz):
     return "%d rows differ; first (i, j, k) = %s; planes %s..%s, lines %s..%s, i %s..%s" % (len(bad), list(zip(i[:4], j[:4], k[:4])), k.min(), k.max(), j.min(), j.max(), i.min(), i.max())
 
 
+if "stats" in sys.argv:  # HIPX_SORBOX_STATS=1 python scripts/sor_box_check.py stats: one application on 27-pt 256^3 and on config 3's slab, wait statistics on stderr
+    import bench
+    for dims, planes in (((256, 256, 256), None), ((512, 512, 512), 64)):
+        n = dims[0]
+        N = n * n * (planes or n)
+        ai, aj, aa = bench.assemble(ks, 27, dims, 0, N)
+        if planes:
+            keep = aj < N
+            rows = np.repeat(np.arange(N, dtype=np.int64), np.diff(ai))[keep]
+            aj, aa = aj[keep], aa[keep]
+            ai = np.zeros(N + 1, np.int32)
+            ai[1:] = np.cumsum(np.bincount(rows, minlength=N))
+        A = _lib.mat_create_csr(N, N, ai, aj, aa)
+        b = 1.0 + (np.arange(N) % 17) / 17.0
+        sor(A, N, b, LSYM | ZERO, 1.0, 0.0, "box")
+        sor(A, N, b, LSYM | ZERO, 1.0, 0.0, "box")
+        _lib.mat_destroy(A)
+    sys.exit(0)
+
 nfail = 0
 small = [(8, 70, 6, True), (8, 70, 6, False), (16, 66, 9, False), (6, 130, 3, True), (12, 12, 12, True), (10, 5, 70, True), (4, 64, 4, True), (32, 40, 5, True), (64, 64, 64, True), (64, 64, 64, False)]
+if "timeonly" in sys.argv:
+    small = []
 for nx, ny, nz, full in small:
     ai, aj, aa = box_csr(nx, ny, nz, full)
     N = nx * ny * nz
@@ -126,7 +147,7 @@ for name, st, dims, planes in big:
     del ai, aj, aa
     b = 1.0 + (np.arange(N) % 17) / 17.0
     res = {}
-    for mode in ("box", "strand", "dep"):
+    for mode in (("box",) if "timeonly" in sys.argv else ("box", "strand", "dep")):
         if mode == "dep" and N > 40e6:
             continue
         try:

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 FWD, BWD, SYM, LFWD, LBWD, LSYM, ZERO, EISENSTAT, UPPER = 1, 2, 3, 4, 8, 12, 16, 32, 64
 
 
-MODES = {"levels": 0, "dep": 1, "strand": 2}
+MODES = {"levels": 0, "dep": 1, "strand": 2, "box": 4}
 
 
 class sor_mode:
@@ -135,8 +135,10 @@ def test_sor_config3_rank_slab_bit_exact(hx):
     assert m == 512 * 512 * 64
     rng = np.random.default_rng(3)
     b = rng.standard_normal(m)
-    g = sor_gpu(hx, Ai, Aj, Aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, np.zeros(m), want_mode="strand")
+    g = sor_gpu(hx, Ai, Aj, Aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, np.zeros(m), want_mode="box")  # (round 5: the library's choice on this operator is the plane march)
     o = sor_cpu(Ai, Aj, Aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, np.zeros(m))
+    assert np.array_equal(g, o), np.abs(g - o).max()
+    g = sor_gpu(hx, Ai, Aj, Aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, np.zeros(m), mode="strand")
     assert np.array_equal(g, o), np.abs(g - o).max()
 
 
@@ -205,7 +207,8 @@ def test_sor_variable_coefficients_at_scale(hx, stencil, n):
 
 
 def test_sor_default_schedule_selection(hx):
-    """The library's own choice: strands for stencil matrices -- from the row templates, or from the pattern templates with
+    """The library's own choice: the plane march for the zero-guess sweeps of constant-coefficient boxes (round 5), strands for the other sweeps
+    of stencil matrices -- from the row templates, or from the pattern templates with
     streamed coefficients when the values are arbitrary (then only for the sweeps without old-value lists; the level-ordered
     sweep otherwise) -- and after hipxMatUpdateValues the choice follows the new values."""
     from petsc_amd import _lib
@@ -213,8 +216,10 @@ def test_sor_default_schedule_selection(hx):
     N = len(ai) - 1
     rng = np.random.default_rng(2)
     b, x0 = rng.standard_normal(N), rng.standard_normal(N)
-    g = sor_gpu(hx, ai, aj, aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0, want_mode="strand")
+    g = sor_gpu(hx, ai, aj, aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0, want_mode="box")  # (constant coefficients, zero-guess sweep: the plane march)
     assert np.array_equal(g, sor_cpu(ai, aj, aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0))
+    g = sor_gpu(hx, ai, aj, aa, b, 1.2, SYM, 0.0, 2, 1, x0, want_mode="strand")  # (sweeps with old values: the strands)
+    assert np.array_equal(g, sor_cpu(ai, aj, aa, b, 1.2, SYM, 0.0, 2, 1, x0))
     aav = aa * (1.0 + 0.01 * rng.standard_normal(aa.size))
     g = sor_gpu(hx, ai, aj, aav, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0, want_mode="strand")  # (variable coefficients: streamed per row)
     assert np.array_equal(g, sor_cpu(ai, aj, aav, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0))
@@ -223,7 +228,7 @@ def test_sor_default_schedule_selection(hx):
     A = _lib.mat_create_csr(N, N, ai, aj, aa)
     B, X = _lib.DVec(N, b), _lib.DVec(N, x0)
     used = C.c_int()
-    for vals, want in [(aa, 2), (aav, 2), (aa * 2.0, 2)]:
+    for vals, want in [(aa, 4), (aav, 2), (aa * 2.0, 4)]:
         _lib.chk(hx.hipxMatUpdateValues(A, orc.P(np.ascontiguousarray(vals))))
         _lib.chk(hx.hipxMatSOR(A, B.ptr, 1.0, LSYM | ZERO, 0.0, 1, 1, X.ptr))
         _lib.chk(hx.hipxMatGetSORMode(A, C.byref(used)))
@@ -363,3 +368,88 @@ def sor_ready(ai, aj, aa, rng):
     A = sp.csr_matrix((aa, aj, ai), shape=(m, m)) + sp.diags(4.0 + rng.random(m))
     A.sort_indices()
     return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+
+
+def box_csr(nx, ny, nz, full27, seed=3):
+    """constant-coefficient box stencil in natural ordering, nx x ny x nz (x fastest): 27-point (one value per position of the 3 x 3 x 3 cube, all
+    couplings negative) or the 7-point star"""
+    rng = np.random.default_rng(seed)
+    N = nx * ny * nz
+    I, Jg, K = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    i, j, k = I.ravel(order="F"), Jg.ravel(order="F"), K.ravel(order="F")
+    rows, cols, vals = [], [], []
+    for dk in (-1, 0, 1):
+        for dj in (-1, 0, 1):
+            for di in (-1, 0, 1):
+                nd = abs(di) + abs(dj) + abs(dk)
+                if not full27 and nd > 1:
+                    continue
+                ok = (i + di >= 0) & (i + di < nx) & (j + dj >= 0) & (j + dj < ny) & (k + dk >= 0) & (k + dk < nz)
+                r = (i + nx * (j + ny * k))[ok]
+                rows.append(r)
+                cols.append(r + di + nx * dj + nx * ny * dk)
+                vals.append(np.full(len(r), 7.5 + rng.random() if nd == 0 else -(0.125 + 0.5 * rng.random())))
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    o = np.lexsort((cols, rows))
+    ai = np.zeros(N + 1, np.int32)
+    ai[1:] = np.cumsum(np.bincount(rows, minlength=N))
+    return ai, cols[o].astype(np.int32), vals[o]
+
+
+@pytest.mark.parametrize("nx,ny,nz,full27", [(8, 70, 6, True), (8, 70, 6, False), (16, 66, 9, False), (6, 130, 3, True), (12, 12, 12, True), (10, 5, 70, True), (4, 64, 4, True),
+                                             (32, 40, 5, True), (64, 64, 64, True), (64, 64, 64, False), (130, 9, 11, True)])
+@pytest.mark.parametrize("flag,omega,shift", [(LSYM | ZERO, 1.0, 0.0), (SYM | ZERO, 1.0, 0.0), (FWD | ZERO, 1.0, 0.0), (BWD | ZERO, 1.0, 0.0), (LSYM | ZERO, 1.3, 0.25), (LFWD | ZERO, 0.8, 0.0),
+                                              (LBWD | ZERO, 1.3, 0.0)])
+def test_plane_march_bit_exact(hx, nx, ny, nz, full27, flag, omega, shift):
+    """Round 5: the plane-march schedule (csrc/hipx_sorbox.hip) -- zero-guess forward / backward / symmetric sweeps of constant-coefficient box
+    stencils: blocks that cross the grid's edges (the skewed block boundaries leave lanes without a line), grids of one block and of several, chunks
+    of planes that do not fill a workgroup, lines shorter than a staging group, omega / shift -- bit-identical to MatSOR_SeqAIJ (aij.c:1930-1958)."""
+    ai, aj, aa = box_csr(nx, ny, nz, full27)
+    N = nx * ny * nz
+    b = np.random.default_rng(5).standard_normal(N)
+    g = sor_gpu(hx, ai, aj, aa, b, omega, flag, shift, 1, 1, np.zeros(N), mode="box")
+    o = sor_cpu(ai, aj, aa, b, omega, flag, shift, 1, 1, np.zeros(N))
+    assert np.array_equal(g, o), np.abs(g - o).max()
+
+
+def test_plane_march_declines_what_it_does_not_cover(hx):
+    """Couplings of both signs, a second diagonal value, an odd line length, arbitrary values, nonzero-guess sweeps: the plane march says no and the
+    strands / levels run (still bit-identical)."""
+    ai, aj, aa = box_csr(12, 10, 9, True)
+    N = 12 * 10 * 9
+    rng = np.random.default_rng(8)
+    b, x0 = rng.standard_normal(N), rng.standard_normal(N)
+    rows = np.repeat(np.arange(N), np.diff(ai))
+    mixed = aa.copy()
+    mixed[(aj == rows + 1) | (aj == rows - 1)] *= -1.0  # the x-couplings positive, the others negative
+    twodiag = aa.copy()
+    twodiag[(aj == rows) & (rows % 12 == 0)] += 1.0     # another diagonal value on the rows of one face
+    for vals in (mixed, twodiag):
+        g = sor_gpu(hx, ai, aj, vals, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0, want_mode="strand")
+        assert np.array_equal(g, sor_cpu(ai, aj, vals, b, 1.0, LSYM | ZERO, 0.0, 1, 1, x0))
+    ai2, aj2, aa2 = box_csr(11, 10, 9, True)  # odd line length
+    N2 = 11 * 10 * 9
+    b2 = rng.standard_normal(N2)
+    g = sor_gpu(hx, ai2, aj2, aa2, b2, 1.0, LSYM | ZERO, 0.0, 1, 1, np.zeros(N2), want_mode="strand")
+    assert np.array_equal(g, sor_cpu(ai2, aj2, aa2, b2, 1.0, LSYM | ZERO, 0.0, 1, 1, np.zeros(N2)))
+    g = sor_gpu(hx, ai, aj, aa, b, 1.0, LSYM, 0.0, 2, 1, x0, want_mode="strand")  # nonzero guess, two iterations
+    assert np.array_equal(g, sor_cpu(ai, aj, aa, b, 1.0, LSYM, 0.0, 2, 1, x0))
+    with pytest.raises(Exception):
+        sor_gpu(hx, ai, aj, aa, b, 1.0, LSYM, 0.0, 2, 1, x0, mode="box")
+
+
+@pytest.mark.parametrize("stencil,dims", [(27, (128, 128, 128)), (7, (128, 128, 128)), (7, (512, 256, 96)), (27, (256, 256, 256))])
+def test_plane_march_at_scale_equals_the_level_ordered_sweep(hx, stencil, dims):
+    """2 M - 16.8 M rows (several rounds of workgroups per CU, 64 chunks of planes): the plane march against the level-ordered sweep of the same
+    library (itself held to the CPU loop by test_sor_bit_exact_at_scale), PCSOR's default application."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from petsc_amd import _lib
+    _, ks = _lib.load()
+    N = dims[0] * dims[1] * dims[2]
+    ai, aj, aa = bench.assemble(ks, stencil, dims, 0, N)
+    b = 1.0 + (np.arange(N) % 17) / 17.0
+    g = sor_gpu(hx, ai, aj, aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, np.zeros(N), mode="box")
+    o = sor_gpu(hx, ai, aj, aa, b, 1.0, LSYM | ZERO, 0.0, 1, 1, np.zeros(N), mode="dep")
+    assert np.array_equal(g, o), np.abs(g - o).max()
