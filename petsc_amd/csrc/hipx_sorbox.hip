@@ -43,7 +43,7 @@ constexpr int BX_OW = BX_OS + 66 * (BX_RS + 1);                 // W [P][2][RW]
 constexpr int BX_OB = BX_OW + BX_P * 2 * BX_RW;                 // B [P][64][RB + 1]
 constexpr int BX_OT = BX_OB + BX_P * 64 * (BX_RB + 1);          // TR[P][64][RX + 1]   (forward sweeps only)
 constexpr int BX_OC = BX_OT + BX_P * 64 * (BX_RX + 1);          // counters (ints): (P + 2) records of 4, abort, ticket
-constexpr int BX_LDS_BYTES = BX_OC * 8 + 4 * (8 * BX_P + 4);
+constexpr int BX_LDS_BYTES = BX_OC * 8 + 2 * (8 * BX_P + 8) + 16;
 static_assert(BX_RW == BX_RS, "the stager writes both halo rings with one row mask");
 constexpr unsigned long long BX_SENTINEL = 0x7FF4DEADBEEF0001ULL;  // = SOR_SENTINEL of hipx_sor.hip (sor_fill_kernel fills x with it)
 constexpr long long          BX_SPIN_TICKS = 400000000LL;           // 4 s of the 100 MHz wall clock
@@ -132,28 +132,68 @@ __device__ __forceinline__ void bx_store2_sc1(double *p, bx_double2 v)
 // EM: bit e set = the interior row has the dependency-side entry at canonical position e.  KIND as in hipx_sor.hip: 0 forward zero-guess
 // (t = sum, x = sum idiag), 1 backward after forward (x = (1 - w) (t idiag) + sum idiag: aij.c:1955 with the forward result x = t idiag
 // re-formed from t), 2 backward zero-guess alone.
-// Waves of a workgroup: w = 0..P-1 compute (plane k0 + w), P..2P-1 stagers (right-hand side + west lines + south plane into the LDS rings),
-// 2P..3P-1 flushers (results out of the rings to memory).  Counters (LDS, one 16-byte record per plane: {steps relaxed, steps staged, steps
-// flushed}) are the only synchronisation inside the workgroup; between workgroups a row of x in memory is its own ready flag.
+// Waves of a workgroup: w = 0..P-1 compute (plane k0 + w), then two stagers per plane (even / odd groups: right-hand side + west lines + south
+// plane into the LDS rings), then one flusher per plane (results out of the rings to memory).  Counters in LDS are the only synchronisation
+// inside the workgroup; between workgroups a row of x in memory is its own ready flag.
+//
+// What a step costs is INSTRUCTIONS: a lone wave issues one instruction every 4-5 clocks whatever its kind, and the dependent arithmetic of a
+// 27-point row (13 products and differences + the scaling) is 88 clocks by itself (scripts/diag/lat_probe.hip).  The first versions of this loop
+// took ~240 instructions per step (register rotations as moves, four counter reads, selects for the rows beyond a line's ends, exec-mask
+// bookkeeping around a divergent branch): 520 ns per step free-running.  Hence:
+//   * the loop is unrolled by four: the three-row windows of the four neighbour lines are circular over FOUR registers (two more rows are in
+//     flight: operands are requested two steps ahead), the slot of a row is (step & 3) -- no moves;
+//   * a line has a row nx holding the zero element (written by its lane one step after its last row, staged for the west / south lines) and the
+//     rings start out filled with the zero element: rows -1 and nx need no select;
+//   * every lane does the arithmetic of every step; only the ring writes are predicated;
+//   * a wave's four counters are 16-bit fields of ONE 8-byte record: one LDS read per step, requested before the arithmetic, looked at after it.
+typedef __attribute__((address_space(3))) unsigned short     bx_lds_u16;
+typedef __attribute__((address_space(3))) unsigned long long bx_lds_u64;
+__device__ __forceinline__ void bx_put16(bx_lds_u16 *p, int v) { __hip_atomic_store((unsigned short *)p, (unsigned short)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int  bx_get16(bx_lds_u16 *p) { return __builtin_amdgcn_readfirstlane((int)__hip_atomic_load((unsigned short *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+// wait until the 16-bit counter *p >= want (uniform over the wave); false when the launch was aborted.  Helper waves: groups of eight steps,
+// nothing is lost by looking every ~256 clocks
+__device__ __forceinline__ bool bx_wait16(bx_lds_u16 *p, int want, bx_lds_int *abortw, unsigned int *gerr)
+{
+  int       spins = 0;
+  long long t0    = 0;
+  while (bx_get16(p) < want) {
+    __builtin_amdgcn_s_sleep(4);
+    if (bx_cnt_load(abortw)) return false;
+    if ((++spins & 0x3ff) == 0) {
+      const long long now = (long long)wall_clock64();
+      if (!t0) t0 = now;
+      if (__hip_atomic_load(gerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || now - t0 > BX_SPIN_TICKS) {
+        __hip_atomic_store(gerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bx_cnt_store(abortw, 1);
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
 template <bool REV, int EM, int KIND>
 __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams Q)
 {
   extern __shared__ double bx_smem[];
-  bx_lds_double *L   = (bx_lds_double *)bx_smem;
-  // Counters, one 16-byte record per READER so that a wave fetches everything it waits for with one LDS access:
-  //   C[w] (compute wave w)        = {steps relaxed by plane w - 1, steps staged for plane w, steps relaxed by plane w + 1, steps flushed of plane w}
-  //   H[w] (stagers / flusher of w) = {steps relaxed by plane w, steps relaxed by plane w + 1, steps staged for plane w, -}
-  // A writer stores its counter into every record that holds it (one ds_write_b32, one lane per copy).  Planes that do not exist read "far ahead".
-  bx_lds_int    *cnt = (bx_lds_int *)(L + BX_OC);
-  bx_lds_int    *dummy = cnt + 8 * BX_P, *abortw = dummy + 1, *tick = dummy + 2;
+  bx_lds_double *L = (bx_lds_double *)bx_smem;
+  // Counters: 16-bit "steps done", one 8-byte record per READER so that a wave fetches everything it waits for with one LDS access:
+  //   C[w] (compute wave w)         = {relaxed by plane w - 1, staged for plane w, relaxed by plane w + 1, flushed of plane w}
+  //   H[w] (stagers / flusher of w) = {relaxed by plane w, relaxed by plane w + 1, staged for plane w, -}
+  // A writer stores its counter into every record that holds it (one ds_write_b16, one lane per copy).  Planes that do not exist read 0xffff.
+  bx_lds_u16 *c16 = (bx_lds_u16 *)(L + BX_OC);
+  bx_lds_int *abortw = (bx_lds_int *)(c16 + 8 * BX_P + 8), *tick = abortw + 1;
+  bx_lds_u16 *dummy = c16 + 8 * BX_P;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  auto Crec = [&](int w_) -> bx_lds_int * { return cnt + 8 * w_; };
-  auto Hrec = [&](int w_) -> bx_lds_int * { return cnt + 8 * w_ + 4; };
+  auto Crec = [&](int w_) -> bx_lds_u16 * { return c16 + 8 * w_; };
+  auto Hrec = [&](int w_) -> bx_lds_u16 * { return c16 + 8 * w_ + 4; };
+  const double z0 = Q.z0;
+  for (int q = threadIdx.x; q < BX_OB; q += BX_THREADS) L[q] = z0;  // the x, south and west rings start out as the zero element (rows -1 of every line)
   if (threadIdx.x == 0) {
-    for (int q = 0; q < 8 * BX_P; q++) bx_cnt_store(cnt + q, 0);
-    bx_cnt_store(Crec(0) + 0, 0x3fffffff);
-    bx_cnt_store(Crec(BX_P - 1) + 2, 0x3fffffff);
-    bx_cnt_store(Hrec(BX_P - 1) + 1, 0x3fffffff);
+    for (int q = 0; q < 8 * BX_P + 8; q++) bx_put16(c16 + q, 0);
+    bx_put16(Crec(0) + 0, 0xffff);
+    bx_put16(Crec(BX_P - 1) + 2, 0xffff);
+    bx_put16(Hrec(BX_P - 1) + 1, 0xffff);
     bx_cnt_store(abortw, 0);
     bx_cnt_store(tick, (int)atomicAdd(Q.ctl, 1u));  // workgroups take their (block, chunk) in ticket order: every dependency has an earlier ticket
   }
@@ -161,8 +201,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
   const int2 jc = Q.order[bx_cnt_load(tick)];
   const int  J = jc.x, c = jc.y, k0 = BX_P * c;
   if (Q.stats && threadIdx.x == 0) Q.stats[8 + 2 * (c * Q.nb + J)] = wall_clock64();
-  const int  nx = Q.nx, ny = Q.ny, nz = Q.nz, T = Q.T;
-  const double z0 = Q.z0;
+  const int  nx = Q.nx, ny = Q.ny, nz = Q.nz, T = Q.T;  // T: a multiple of four
   unsigned int *gerr = Q.ctl + 1;
 
   if (wave < BX_P) {
@@ -170,12 +209,8 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     const int  w = wave, s = lane, k = k0 + w;
     const int  j = 64 * J - k + s;
     const bool valid = j >= 0 && j < ny && k < nz;
-    const int  i0 = -2 - 2 * s - 4 * w;  // row of this lane in step t: t + i0
-    double Lr[3][2], Mr[2], xcur = z0;   // lower plane lines j-1, j, j+1 at rows i-1, i; previous line at rows i-1, i; this lane's latest result
-#pragma unroll
-    for (int l = 0; l < 3; l++) Lr[l][0] = Lr[l][1] = z0;
-    Mr[0] = Mr[1] = z0;
-    // ring bases of the three lower-plane lines and (lane 0) of the west line that stands in for lane -1 (element offsets)
+    const int  i0 = -2 - 2 * s - 4 * w;  // row of this lane in step t: t + i0 (-1: its neighbours' rows 0 arrive; nx: it publishes the line's zero element)
+    // byte offsets of the rings this lane reads (the row slot is added per step) and writes
     int nb_base[3], nb_mask[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
@@ -193,9 +228,9 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     }
     const int wo = BX_OW + (w * 2 + 1) * BX_RW;
     const int xo = BX_OX + (w * 64 + s) * (BX_RX + 1), bo = BX_OB + (w * 64 + s) * (BX_RB + 1), to = BX_OT + (w * 64 + s) * (BX_RX + 1);
-    bx_lds_int *crec = Crec(w);
-    // where this wave's "steps relaxed" goes: C[w + 1].x, C[w - 1].z, H[w].x, H[w - 1].y -- lanes 0-3 store one copy each
-    bx_lds_int *pub = dummy;
+    bx_lds_u64 *crec = (bx_lds_u64 *)Crec(w);
+    // where this wave's "steps relaxed" goes: C[w + 1][0], C[w - 1][2], H[w][0], H[w - 1][1] -- lanes 0-3 store one copy each
+    bx_lds_u16 *pub = dummy + (lane & 7);
     if (lane == 0 && w + 1 < BX_P) pub = Crec(w + 1) + 0;
     if (lane == 1 && w > 0) pub = Crec(w - 1) + 2;
     if (lane == 2) pub = Hrec(w) + 0;
@@ -205,16 +240,12 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     //   right-hand side / west / south rows of the step are staged                                  -> staged(w)      >= t + 1
     //   x ring (16 rows): plane k + 1 reads a row up to 7 steps after it was written                -> relaxed(w + 1) >= t - 8
     //   x / t rings: the rows this step overwrites have left for memory                             -> flushed(w)     >= t - 15
-    int c_low = 0, c_stg = 0, c_up = 0, c_fl = 0;  // the record as last looked at (uniform)
-    int r_low = 0, r_stg = 0, r_up = 0, r_fl = 0;  // ... as last requested (in flight until taken)
-    auto look_issue = [&]() {  // four reads of one record; no wait here
-      r_low = __hip_atomic_load((int *)(crec + 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      r_stg = __hip_atomic_load((int *)(crec + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      r_up  = __hip_atomic_load((int *)(crec + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      r_fl  = __hip_atomic_load((int *)(crec + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto look_take = [&]() {  // uniform values (readfirstlane: a VGPR condition would make every wait a divergent loop)
-      c_low = __builtin_amdgcn_readfirstlane(r_low), c_stg = __builtin_amdgcn_readfirstlane(r_stg), c_up = __builtin_amdgcn_readfirstlane(r_up), c_fl = __builtin_amdgcn_readfirstlane(r_fl);
+    unsigned long long raw = 0;
+    int                c_low = 0, c_stg = 0, c_up = 0, c_fl = 0;
+    auto look_issue = [&]() { raw = __hip_atomic_load((unsigned long long *)crec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto look_take = [&]() {
+      const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)raw), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(raw >> 32));
+      c_low = (int)(lo & 0xffffu), c_stg = (int)(lo >> 16), c_up = (int)(hi & 0xffffu), c_fl = (int)(hi >> 16);
     };
     const int staged_all = Q.ngroups * BX_G;
     auto ready = [&](int t) -> bool {
@@ -249,109 +280,84 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
       }
       return true;
     };
-    // One step, as a software pipeline two steps deep -- no LDS latency is left on a step's path:
-    //   top      the record is requested (it decides, at the bottom, whether step t + 2 may be prepared)
-    //   middle   row i is relaxed out of registers: its operands were requested TWO steps ago; the results go to the rings and the step is
-    //            published with NO wait in between -- a wave's LDS operations are executed in order, whoever sees the counter sees the rows
-    //   bottom   the record is looked at; the operands of step t + 2 are requested
-    struct Ops {
-      double n0, n1, n2, rhs, west;  // rows i + 1 of the lower plane's three lines, the right-hand side of row i, the west line's row i + 1
-    };
-    auto request = [&](int t) -> Ops {
-      const int i = t + i0;
-      Ops       o;
-      o.n0   = L[nb_base[0] + ((i + 1) & nb_mask[0])];
-      o.n1   = L[nb_base[1] + ((i + 1) & nb_mask[1])];
-      o.n2   = L[nb_base[2] + ((i + 1) & nb_mask[2])];
-      o.rhs  = L[bo + (i & (BX_RB - 1))];
-      o.west = L[wo + ((i + 1) & (BX_RW - 1))];
-      return o;
-    };
-    Ops P1, P2;  // operands of steps t + 1 and t + 2 (in flight)
+    // registers of the recurrence: Wn[line][slot], line 0-2 = the lower plane's lines j - 1, j, j + 1, line 3 = the previous line of this plane;
+    // in step t slot (t - 1) & 3 holds row i - 1, t & 3 row i, (t + 1) & 3 row i + 1 and (t + 2) & 3 the row arriving for step t + 1
+    double Wn[4][4], Rr[2], Ww[2], xcur = z0;
+#pragma unroll
+    for (int l = 0; l < 4; l++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) Wn[l][q] = z0;
+    Rr[0] = Rr[1] = Ww[0] = Ww[1] = z0;
+    bool alive = true;
+    // the operands of step u: rows i + 1 of the lower plane's lines into window slot (u + 1) & 3, the right-hand side of row i and the west line's
+    // row i + 1 into slot u & 1
+#define BX_REQUEST(U, S4, S2) \
+  { \
+    const int r1_ = (U) + i0 + 1; \
+    Wn[0][S4] = L[nb_base[0] + (r1_ & nb_mask[0])]; \
+    Wn[1][S4] = L[nb_base[1] + (r1_ & nb_mask[1])]; \
+    Wn[2][S4] = L[nb_base[2] + (r1_ & nb_mask[2])]; \
+    Rr[S2]    = L[bo + ((r1_ - 1) & (BX_RB - 1))]; \
+    Ww[S2]    = L[wo + (r1_ & (BX_RW - 1))]; \
+  }
+    // one step (PH = t & 3): the record is requested; row i is relaxed out of registers; the results go to the rings and the step is published with
+    // NO wait in between (a wave's LDS operations are executed in order: whoever sees the counter sees the rows); the record decides whether step
+    // t + 2 may be prepared; its operands are requested
+#define BX_STEP(PH) \
+  { \
+    const int t_ = t + (PH), i = t_ + i0; \
+    constexpr int M1 = ((PH) + 3) & 3, C0 = (PH), P1 = ((PH) + 1) & 3, S2 = (PH) & 1; \
+    if (t_ + 2 < T) look_issue(); \
+    { /* the previous line's row i + 1: lane s - 1 relaxed it in the step before (wavefront shift); lane 0 takes the west line's */ \
+      const int nlo = __builtin_amdgcn_update_dpp(__double2loint(Ww[S2]), __double2loint(xcur), 0x138 /* wave_shr:1 */, 0xf, 0xf, false); \
+      const int nhi = __builtin_amdgcn_update_dpp(__double2hiint(Ww[S2]), __double2hiint(xcur), 0x138, 0xf, 0xf, false); \
+      Wn[3][P1]     = __hiloint2double(nhi, nlo); \
+    } \
+    const double rhs = Rr[S2]; \
+    double       sum = rhs; \
+    _Pragma("unroll") for (int q = 0; q < 13; q++) \
+    { \
+      const int e = REV ? 12 - q : q; \
+      if ((EM >> e) & 1) { \
+        const int    l_ = e < 12 ? e / 3 : 0, cc = e % 3; \
+        const double v_ = e == 12 ? xcur : (cc == 0 ? Wn[l_][M1] : (cc == 1 ? Wn[l_][C0] : Wn[l_][P1])); \
+        sum             = sum - Q.coef[e] * v_; \
+      } \
+    } \
+    double xv; \
+    if (KIND == 1) xv = Q.omw * (rhs * Q.idiag) + sum * Q.idiag; \
+    else xv = sum * Q.idiag; \
+    xcur = (valid && (unsigned)i < (unsigned)nx) ? xv : z0; /* beyond the line, and a lane without a line: the zero element */ \
+    if ((unsigned)i <= (unsigned)nx) L[xo + (i & (BX_RX - 1))] = xcur; \
+    if (KIND == 0 && (unsigned)i < (unsigned)nx) L[to + (i & (BX_RX - 1))] = sum; \
+    asm volatile("" ::: "memory"); /* ring writes, then the counter: program order = LDS order */ \
+    if (lane < 4) bx_put16(pub, t_ + 1); \
+    if (t_ + 2 < T) { \
+      look_take(); \
+      if (!ready(t_ + 2)) { \
+        alive = wait_ready(t_ + 2); \
+        if (!alive) break; \
+      } \
+      bx_lds_acquire(); \
+      BX_REQUEST(t_ + 2, M1, S2) \
+    } \
+  }
     look_issue();
     look_take();
-    bool alive = wait_ready(T > 1 ? 1 : 0);
+    alive = wait_ready(1);
     if (alive) {
       bx_lds_acquire();
-      P1 = request(0);
-      P2 = T > 1 ? request(1) : P1;
+      BX_REQUEST(0, 1, 0)
+      BX_REQUEST(1, 2, 1)
     }
-    unsigned long long tsec[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;  // HIPX_SORBOX_STATS: shader clocks by section of the step
-    const bool         timing  = Q.stats != nullptr;
-#define BX_TICK(k) \
-  if (timing) { \
-    const unsigned long long now_ = __builtin_readcyclecounter(); \
-    tsec[k] += now_ - tprev; \
-    tprev = now_; \
-  }
-    if (timing) tprev = __builtin_readcyclecounter();
-    for (int t = 0; t < T && alive; t++) {
-      const int i = t + i0;
-      const Ops O = P1;  // this step's operands
-      P1          = P2;
-      BX_TICK(0)
-      if (t + 2 < T) look_issue();
-      BX_TICK(1)
-      // the previous line's row i + 1: lane s - 1 relaxed it in the step before (wavefront shift); lane 0 takes the west line's
-      const double xsrc = xcur;
-      const int    nlo = __builtin_amdgcn_update_dpp(__double2loint(O.west), __double2loint(xsrc), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-      const int    nhi = __builtin_amdgcn_update_dpp(__double2hiint(O.west), __double2hiint(xsrc), 0x138, 0xf, 0xf, false);
-      const bool   inr = i + 1 >= 0 && i + 1 < nx;
-      double       N[4];
-      N[0] = inr ? O.n0 : z0;
-      N[1] = inr ? O.n1 : z0;
-      N[2] = inr ? O.n2 : z0;
-      N[3] = inr ? __hiloint2double(nhi, nlo) : z0;
-      double xnew = z0;
-      if (i >= 0 && i < nx) {
-        const double rhs = O.rhs;
-        double       sum = rhs;
-        auto val = [&](int e) -> double {
-          if (e < 9) {
-            const int l = e / 3, cc = e % 3;
-            return cc < 2 ? Lr[l][cc] : N[l];
-          }
-          if (e < 12) return (e - 9) < 2 ? Mr[e - 9] : N[3];
-          return xcur;
-        };
-#pragma unroll
-        for (int q = 0; q < 13; q++) {
-          const int e = REV ? 12 - q : q;
-          if ((EM >> e) & 1) sum = sum - Q.coef[e] * val(e);
-        }
-        double xv;
-        if (KIND == 1) xv = Q.omw * (rhs * Q.idiag) + sum * Q.idiag;
-        else xv = sum * Q.idiag;
-        if (!valid) xv = z0;  // a lane without a line publishes the zero element for its neighbours
-        L[xo + (i & (BX_RX - 1))] = xv;
-        if (KIND == 0) L[to + (i & (BX_RX - 1))] = sum;
-        xnew = xv;
-      }
-      xcur = xnew;  // (z0 outside the line: what the next lane must see for a row beyond the end)
-#pragma unroll
-      for (int l = 0; l < 3; l++) {
-        Lr[l][0] = Lr[l][1];
-        Lr[l][1] = N[l];
-      }
-      Mr[0] = Mr[1];
-      Mr[1] = N[3];
-      asm volatile("" ::: "memory");  // (ring writes, then the counter: program order = LDS order)
-      if (lane < 4) bx_cnt_store(pub, t + 1);
-      BX_TICK(2)
-      if (t + 2 < T) {
-        look_take();
-        if (!ready(t + 2)) {
-          alive = wait_ready(t + 2);
-          if (!alive) break;
-        }
-        bx_lds_acquire();
-        BX_TICK(3)
-        P2 = request(t + 2);
-      }
-      BX_TICK(4)
+    for (int t = 0; t < T && alive; t += 4) {
+      BX_STEP(0)
+      BX_STEP(1)
+      BX_STEP(2)
+      BX_STEP(3)
     }
-    if (timing && lane == 0 && J == 0 && c == 0 && w == 1)
-      for (int q = 0; q < 5; q++) Q.stats[8 + 2 * Q.nb * Q.nch + q] = tsec[q];
+#undef BX_STEP
+#undef BX_REQUEST
     if (Q.stats && lane == 0) {
       if (w == BX_P - 1) Q.stats[8 + 2 * (c * Q.nb + J) + 1] = wall_clock64();
       atomicAdd(Q.stats + 0, (unsigned long long)sp_low);
@@ -372,13 +378,13 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     const long long lr = (long long)r + nxl * ((long long)jj + nyl * (long long)kk);
     return REV ? Q.m - 2 - lr : lr;  // REV: the pair (r, r + 1) lies at m - 2 - lr, halves swapped
   };
-  bx_lds_int *hrec = Hrec(w);  // {relaxed(w), relaxed(w + 1), staged(w)}
+  bx_lds_u16 *hrec = Hrec(w);  // {relaxed(w), relaxed(w + 1), staged(w)}
 
   if (role == 2) {
     // ---------------------------------------------------------------------------------------------------- flusher of plane k0 + w
     for (int fg = 0; fg * BX_G < T; fg++) {
       const int need = (fg + 1) * BX_G < T ? (fg + 1) * BX_G : T;
-      if (!bx_wait_ge(hrec, need, abortw, gerr)) return;
+      if (!bx_wait16(hrec, need, abortw, gerr)) return;
       bx_lds_acquire();
       if (plane_ok) {
 #pragma unroll
@@ -412,47 +418,47 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
         }
       }
       bx_lds_release();  // (the ring reads are done; the stores may still be on their way)
-      if (lane == 0) bx_cnt_store(Crec(w) + 3, need);
+      if (lane == 0) bx_put16(Crec(w) + 3, need);
     }
     return;
   }
 
   // ---------------------------------------------------------------------------------------------------------- stager of plane k0 + w
-  // Everything of group g + 1 -- right-hand side (a), west lines (b), south plane (c, stager 0) -- is requested from memory while group g is
-  // being consumed: 16-byte loads, four lanes per 64-byte line segment, the halo loads at agent scope (a row of x another workgroup has not
-  // written yet reads as the sentinel and is polled on its own when its turn comes).
+  // Everything of a group -- right-hand side (a), west lines (b), south plane (c, stagers 0) -- is requested from memory two groups before it is
+  // staged: 16-byte loads, four lanes per 64-byte line segment, the halo loads at agent scope (a row of x another workgroup has not written yet
+  // reads as the sentinel and is polled on its own when its turn comes).
   // A plane has TWO stagers, one for the even and one for the odd groups: a stager's loads for its next group (two groups on) are requested right
   // after it has published the current one and are the only ones it has in flight when it needs them -- about sixteen steps later.  (One stager with
   // two groups in flight waits, at every group, for the loads it has JUST issued -- the compiler's vmcnt(0) -- and the whole workgroup settles at
-  // memory latency / 8 per step: measured 400-424 ns per step in workgroups without any outside dependency.)
-  constexpr int NT = 6;  // halo tasks per lane: 0 = west lines (lanes 0-7), 1-5 = south plane (stager 0)
-  bx_double2    pre[1][4], hv[1][NT];
-  // what halo task tk of group g is for this lane (recomputed where needed: only the loaded values live across the two groups in flight)
+  // memory latency / 8 per step.)
+  constexpr int NT = 6;  // halo tasks per lane: 0 = west lines (lanes 0-7), 1-5 = south plane (stagers 0)
+  bx_double2    pre[4], hv[NT];
+  // what halo task tk of group g is for this lane (recomputed where needed: only the loaded values live across the groups in flight)
   auto halo_desc = [&](int g, const int tk, bool &in, bool &mem, int &off, int &r, const double *&ptr) {
     int q, qd, jj, kk;
     if (tk == 0) {  // (b) the two west lines of plane k (lines 64 J - k - 2, - 1: block J - 1's last lanes), rows [8 g - 4 w, + 8): lanes 0-7
       q = lane >> 2, qd = lane & 3, jj = 64 * J - k - 2 + q, kk = k;
       r   = BX_G * g - 4 * w + 2 * qd;
-      in  = lane < 8 && r >= 0 && r < nx;
-      mem = in && plane_ok && jj >= 0 && jj < ny;
+      in  = lane < 8 && r >= 0 && r <= nx;  // (row nx: the line's zero element)
+      mem = in && r < nx && plane_ok && jj >= 0 && jj < ny;
       off = BX_OW + (w * 2 + (q & 1)) * BX_RW + (r & (BX_RW - 1));
-    } else {  // (c) stager 0: the south plane k0 - 1 (66 lines: the chunk below and, there, block J - 1's last lanes), line index q rows [8 g - 2 max(q - 2, 0), + 8)
+    } else {  // (c) stagers 0: the south plane k0 - 1 (66 lines: the chunk below and, there, block J - 1's last lanes), line index q rows [8 g - 2 max(q - 2, 0), + 8)
       const int task = lane + 64 * (tk - 1);
       q = task >> 2, qd = task & 3, jj = 64 * J - (k0 - 1) + q - 2, kk = k0 - 1;
       r   = BX_G * g - 2 * (q > 2 ? q - 2 : 0) + 2 * qd;
-      in  = w == 0 && task < 66 * 4 && r >= 0 && r < nx;
-      mem = in && k0 > 0 && jj >= 0 && jj < ny;
+      in  = w == 0 && task < 66 * 4 && r >= 0 && r <= nx;
+      mem = in && r < nx && k0 > 0 && jj >= 0 && jj < ny;
       off = BX_OS + (q < 66 ? q : 0) * (BX_RS + 1) + (r & (BX_RS - 1));
     }
     ptr = mem ? Q.xout + phys(r, jj, kk) : Q.xout;
   };
-  auto issue = [&](int g, const int sl) {
+  auto issue = [&](int g) {
 #pragma unroll
     for (int p = 0; p < 4; p++) {  // (a) rows [8 g - 2 - 2 s - 4 w, + 8) of the 64 lines
       const int  s = 16 * p + (lane >> 2), qd = lane & 3, jj = 64 * J - k + s;
       const int  r = BX_G * g - 2 - 2 * s - 4 * w + 2 * qd;
       const bool ok = plane_ok && r >= 0 && r < nx && jj >= 0 && jj < ny;
-      pre[sl][p]    = *reinterpret_cast<const bx_double2 *>(ok ? Q.rhs + phys(r, jj, k) : Q.rhs);  // (a lane without a row reads element 0: never stored)
+      pre[p]        = *reinterpret_cast<const bx_double2 *>(ok ? Q.rhs + phys(r, jj, k) : Q.rhs);  // (a lane without a row reads element 0: never stored)
     }
     // agent-scope (sc1) loads the compiler can see: the values are waited for where they are used, two groups later
     auto ld = [&](const double *q) -> bx_double2 {
@@ -469,14 +475,14 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
       int           off, r;
       const double *ptr;
       halo_desc(g, tk, in, mem, off, r, ptr);
-      hv[sl][tk] = ld(ptr);
+      hv[tk] = ld(ptr);
     }
   };
   unsigned npoll = 0, nring = 0;
-  auto stage = [&](int g, const int sl) -> bool {
-    if (Q.stats && (bx_cnt_load(hrec) < BX_G * g - (BX_RW - 16) || bx_cnt_load(hrec + 1) < BX_G * g - (BX_RW - 16))) nring++;
+  auto stage = [&](int g) -> bool {
+    if (Q.stats && (bx_get16(hrec) < BX_G * g - (BX_RW - 16) || bx_get16(hrec + 1) < BX_G * g - (BX_RW - 16))) nring++;
     // ring space: rhs ring (32 rows) -> the wave is past step 8 g - 24; west / south rings (32 rows, read up to 13 steps after staging) -> waves w and w + 1 past 8 g - 16
-    if (!bx_wait_ge(hrec, BX_G * g - (BX_RW - 16), abortw, gerr) || !bx_wait_ge(hrec + 1, BX_G * g - (BX_RW - 16), abortw, gerr)) return false;
+    if (!bx_wait16(hrec, BX_G * g - (BX_RW - 16), abortw, gerr) || !bx_wait16(hrec + 1, BX_G * g - (BX_RW - 16), abortw, gerr)) return false;
     bx_lds_acquire();
 #pragma unroll
     for (int p = 0; p < 4; p++) {
@@ -484,8 +490,8 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
       const int r = BX_G * g - 2 - 2 * s - 4 * w + 2 * qd;
       if (plane_ok && r >= 0 && r < nx && jj >= 0 && jj < ny) {
         const int bo = BX_OB + (w * 64 + s) * (BX_RB + 1);
-        L[bo + (r & (BX_RB - 1))]       = REV ? pre[sl][p].y : pre[sl][p].x;
-        L[bo + ((r + 1) & (BX_RB - 1))] = REV ? pre[sl][p].x : pre[sl][p].y;
+        L[bo + (r & (BX_RB - 1))]       = REV ? pre[p].y : pre[p].x;
+        L[bo + ((r + 1) & (BX_RB - 1))] = REV ? pre[p].x : pre[p].y;
       }
     }
 #pragma unroll
@@ -496,7 +502,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
       const double *ptr;
       halo_desc(g, tk, in, mem, off, r, ptr);
       if (in) {
-        bx_double2 v = hv[sl][tk];
+        bx_double2 v = hv[tk];
         if (mem) {
           if ((unsigned long long)__double_as_longlong(v.x) == BX_SENTINEL || (unsigned long long)__double_as_longlong(v.y) == BX_SENTINEL) {
             npoll++;
@@ -513,14 +519,14 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
       }
     }
     bx_lds_release();
-    if (!bx_wait_ge(hrec + 2, BX_G * g, abortw, gerr)) return false;  // (groups are published in order: the other stager's group g - 1 first)
-    if (lane < 2) bx_cnt_store(lane == 0 ? Crec(w) + 1 : hrec + 2, BX_G * (g + 1));
+    if (!bx_wait16(hrec + 2, BX_G * g, abortw, gerr)) return false;  // (groups are published in order: the other stager's group g - 1 first)
+    if (lane < 2) bx_put16(lane == 0 ? Crec(w) + 1 : hrec + 2, BX_G * (g + 1));
     return true;
   };
-  if (role < Q.ngroups) issue(role, 0);
+  if (role < Q.ngroups) issue(role);
   for (int g = role; g < Q.ngroups; g += 2) {
-    if (!stage(g, 0)) return;
-    if (g + 2 < Q.ngroups) issue(g + 2, 0);
+    if (!stage(g)) return;
+    if (g + 2 < Q.ngroups) issue(g + 2);
   }
   if (Q.stats) {
     atomicAdd(Q.stats + 4, (unsigned long long)(lane == 0 ? nring : 0));
@@ -592,7 +598,7 @@ extern "C" int hipxSorBoxBuild_(long long m, int ntmpl, const int *tstart, const
   else if (centres.size() == 2) S = centres[1];
   else if (centres.size() == 4) S = centres[2];
   else return HIPX_SUCCESS;
-  if (Lx < 4 || (Lx & 1) || S % Lx || m % S || S / Lx < 3) return HIPX_SUCCESS;
+  if (Lx < 4 || Lx > 60000 || (Lx & 1) || S % Lx || m % S || S / Lx < 3) return HIPX_SUCCESS;  // (16-bit step counters: lines of up to 60000 rows)
   const int nx = (int)Lx, ny = (int)(S / Lx), nz = (int)(m / S);
   auto pos_of = [&](long long off, int &p) -> bool {
     const long long dk = (long long)std::floor((double)off / (double)S + 0.5), rem = off - dk * S;
@@ -666,7 +672,7 @@ extern "C" int hipxSorBoxBuild_(long long m, int ntmpl, const int *tstart, const
   }
   B->nb      = (ny + nz - 2) / 64 + 1;
   B->nch     = (nz + BX_P - 1) / BX_P;
-  B->T       = nx + 2 + 2 * 63 + 4 * (BX_P - 1);
+  B->T       = (nx + 3 + 2 * 63 + 4 * (BX_P - 1) + 3) & ~3;  // rows -2 .. nx of the last lane of the last wave, rounded up to the unrolled loop's four
   B->ngroups = (B->T + BX_G - 1) / BX_G;
   // ticket order: by estimated start (a chunk hop ~ 4 P steps + a hand-off, a block hop ~ 128 steps + a hand-off); every dependency of (J, c)
   // -- (J - 1, c), (J - 1, c - 1), (J, c - 1) -- starts earlier
@@ -737,11 +743,6 @@ extern "C" int hipxSorBoxRun_(void *p, int kind, const double *rhs, double *tout
     unsigned long long             *h = hvv.data();
     HIPX_HIP(hipMemcpyAsync(h, B->d_stats, nst * sizeof(unsigned long long), hipMemcpyDeviceToHost, rt().compute));
     HIPX_HIP(hipStreamSynchronize(rt().compute));
-    {
-      const unsigned long long *ts = h + 8 + 2 * (size_t)B->nb * B->nch;
-      fprintf(stderr, "[sorbox sections, shader clocks per step, workgroup (0,0) wave 1] top wait + publish %.0f, copies %.0f, readiness %.0f, requests %.0f, arithmetic + ring writes %.0f\n", (double)ts[0] / B->T,
-              (double)ts[1] / B->T, (double)ts[2] / B->T, (double)ts[3] / B->T, (double)ts[4] / B->T);
-    }
     {  // time stamps (100 MHz): when workgroup (J, c) started and when its top plane finished, relative to the first start
       unsigned long long t0 = ~0ull;
       for (size_t q = 0; q < (size_t)B->nb * B->nch; q++)
