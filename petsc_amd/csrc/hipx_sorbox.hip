@@ -179,7 +179,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
   bx_lds_double *L = (bx_lds_double *)bx_smem;
   // Counters: 16-bit "steps done", one 8-byte record per READER so that a wave fetches everything it waits for with one LDS access:
   //   C[w] (compute wave w)         = {relaxed by plane w - 1, staged for plane w, relaxed by plane w + 1, flushed of plane w}
-  //   H[w] (stagers / flusher of w) = {relaxed by plane w, relaxed by plane w + 1, staged for plane w, -}
+  //   H[w] (stagers / flusher of w) = {relaxed by plane w, relaxed by plane w + 1, staged for plane w, plane w's share of the south plane staged}
   // A writer stores its counter into every record that holds it (one ds_write_b16, one lane per copy).  Planes that do not exist read 0xffff.
   bx_lds_u16 *c16 = (bx_lds_u16 *)(L + BX_OC);
   bx_lds_int *abortw = (bx_lds_int *)(c16 + 8 * BX_P + 8), *tick = abortw + 1;
@@ -431,7 +431,9 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
   // after it has published the current one and are the only ones it has in flight when it needs them -- about sixteen steps later.  (One stager with
   // two groups in flight waits, at every group, for the loads it has JUST issued -- the compiler's vmcnt(0) -- and the whole workgroup settles at
   // memory latency / 8 per step.)
-  constexpr int NT = 6;  // halo tasks per lane: 0 = west lines (lanes 0-7), 1-5 = south plane (stagers 0)
+  // The south plane's 66 x 4 pairs are shared by the stagers of ALL planes (task 1: pair 64 w + lane; task 2, plane 0 only: the last eight): three tasks
+  // per lane at most -- a stager polls its pending tasks one after the other, a memory round trip each, and that time is on every hop between chunks
+  constexpr int NT = 3;  // halo tasks per lane: 0 = west lines of the own plane (lanes 0-7), 1, 2 = south plane
   bx_double2    pre[4], hv[NT];
   // what halo task tk of group g is for this lane (recomputed where needed: only the loaded values live across the groups in flight)
   auto halo_desc = [&](int g, const int tk, bool &in, bool &mem, int &off, int &r, const double *&ptr) {
@@ -442,11 +444,11 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
       in  = lane < 8 && r >= 0 && r <= nx;  // (row nx: the line's zero element)
       mem = in && r < nx && plane_ok && jj >= 0 && jj < ny;
       off = BX_OW + (w * 2 + (q & 1)) * BX_RW + (r & (BX_RW - 1));
-    } else {  // (c) stagers 0: the south plane k0 - 1 (66 lines: the chunk below and, there, block J - 1's last lanes), line index q rows [8 g - 2 max(q - 2, 0), + 8)
-      const int task = lane + 64 * (tk - 1);
+    } else {  // (c) the south plane k0 - 1 (66 lines: the chunk below and, there, block J - 1's last lanes), line index q rows [8 g - 2 max(q - 2, 0), + 8)
+      const int task = tk == 1 ? 64 * w + lane : 64 * BX_P + lane;
       q = task >> 2, qd = task & 3, jj = 64 * J - (k0 - 1) + q - 2, kk = k0 - 1;
       r   = BX_G * g - 2 * (q > 2 ? q - 2 : 0) + 2 * qd;
-      in  = w == 0 && task < 66 * 4 && r >= 0 && r <= nx;
+      in  = (tk == 1 || (w == 0 && lane < 66 * 4 - 64 * BX_P)) && task < 66 * 4 && r >= 0 && r <= nx;
       mem = in && r < nx && k0 > 0 && jj >= 0 && jj < ny;
       off = BX_OS + (q < 66 ? q : 0) * (BX_RS + 1) + (r & (BX_RS - 1));
     }
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     };
 #pragma unroll
     for (int tk = 0; tk < NT; tk++) {
-      if (tk > 0 && w != 0) break;
+      if (tk == 2 && w != 0) break;
       bool          in, mem;
       int           off, r;
       const double *ptr;
@@ -483,6 +485,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     if (Q.stats && (bx_get16(hrec) < BX_G * g - (BX_RW - 16) || bx_get16(hrec + 1) < BX_G * g - (BX_RW - 16))) nring++;
     // ring space: rhs ring (32 rows) -> the wave is past step 8 g - 24; west / south rings (32 rows, read up to 13 steps after staging) -> waves w and w + 1 past 8 g - 16
     if (!bx_wait16(hrec, BX_G * g - (BX_RW - 16), abortw, gerr) || !bx_wait16(hrec + 1, BX_G * g - (BX_RW - 16), abortw, gerr)) return false;
+    if (w > 0 && !bx_wait16(Hrec(0), BX_G * g - (BX_RS - 16), abortw, gerr)) return false;  // (its share of the south ring: read by wave 0)
     bx_lds_acquire();
 #pragma unroll
     for (int p = 0; p < 4; p++) {
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     }
 #pragma unroll
     for (int tk = 0; tk < NT; tk++) {
-      if (tk > 0 && w != 0) break;
+      if (tk == 2 && w != 0) break;
       bool          in, mem;
       int           off, r;
       const double *ptr;
@@ -520,7 +523,12 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     }
     bx_lds_release();
     if (!bx_wait16(hrec + 2, BX_G * g, abortw, gerr)) return false;  // (groups are published in order: the other stager's group g - 1 first)
-    if (lane < 2) bx_put16(lane == 0 ? Crec(w) + 1 : hrec + 2, BX_G * (g + 1));
+    if (w == 0) {  // plane 0's rows are complete when the other planes' stagers have staged their shares of the south plane
+#pragma unroll
+      for (int o = 1; o < BX_P; o++)
+        if (!bx_wait16(Hrec(o) + 3, BX_G * (g + 1), abortw, gerr)) return false;
+      if (lane < 2) bx_put16(lane == 0 ? Crec(w) + 1 : hrec + 2, BX_G * (g + 1));
+    } else if (lane < 3) bx_put16(lane == 0 ? Crec(w) + 1 : (lane == 1 ? hrec + 2 : hrec + 3), BX_G * (g + 1));
     return true;
   };
   if (role < Q.ngroups) issue(role);

@@ -167,3 +167,37 @@ def test_committed_exact_goldens_are_reproducible_at_their_smallest_size():
     h = orc.ksp_solve("cg", ai, aj, aa, b, pc="jacobi", rtol=1e-50, max_it=len(e["history"]) - 1, exact=True)[3]
     assert np.array_equal(h, np.array([float.fromhex(v) for v in e["history_hex"]]))
     assert np.array_equal(h, np.array(e["history"]))
+
+
+@pytest.mark.parametrize("n,nranks", [(24, 3), (32, 8), (40, 5)])
+def test_streamed_gmres_sor_equals_the_stored_matrix_oracle(n, nranks):
+    """oracle/stream_gmres.py (round 5: the yardstick of BASELINE config 3 at its real shape, 27-pt 512^3 on 8 ranks, 3.6e9 nonzeros never held as one
+    matrix): the C oracle's GMRES loop over per-rank products (MatMult_MPIAIJ's order: diagonal block, then the off-diagonal terms added) and per-rank
+    local sweeps assembled slab by slab -- bit-identical, over a restart, to the same loop on the stored matrix (orc.ksp_solve with nranks), whose
+    products take the same order since this round (orc.matmult_mpi)."""
+    import stream_gmres as sg
+    ai, aj, aa = orc.stencil("27pt", n)
+    op = sg.StreamPartitionedOperator("27pt", n, nranks, sub_rows=7000)
+    b = np.empty(n ** 3)
+    op.mult(np.ones(n ** 3), b)
+    assert np.array_equal(b, orc.matmult_mpi(ai, aj, aa, np.ones(n ** 3), nranks))
+    h0 = orc.ksp_solve("gmres", ai, aj, aa, b, pc="sor", rtol=1e-50, max_it=35, nranks=nranks, exact=True)[3]
+    h1 = sg.gmres_sor_exact(op, 35)
+    assert len(h0) == len(h1) == 36 and np.array_equal(h0, h1)
+    x = np.random.default_rng(n).standard_normal(n ** 3)
+    y = np.empty(n ** 3)
+    assert np.array_equal(op.mult(x, y), orc.matmult_mpi(ai, aj, aa, x, nranks))
+
+
+def test_committed_np_goldens_are_the_oracles_with_the_partitioned_product():
+    """tests/golden/exact_histories.json gmres_sor_27pt_128_np{2,4,8} (regenerated in round 5): the oracle's exact mode with b = A * 1 and every product
+    formed as MatMult_MPIAIJ forms them; the 512^3 entries come from the streamed form of the same loop."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "exact_histories.json")))
+    ai, aj, aa = orc.stencil("27pt", 128)
+    b = orc.matmult_mpi(ai, aj, aa, np.ones(128 ** 3), 8)
+    h = orc.ksp_solve("gmres", ai, aj, aa, b, pc="sor", rtol=1e-50, max_it=12, nranks=8, exact=True)[3]
+    want = [float.fromhex(v) for v in g["gmres_sor_27pt_128_np8"]["history_hex"]][:len(h)]
+    assert list(h) == want
+    for k in ("gmres_sor_27pt_512_np8", "gmres_sor_27pt_512_np4"):
+        assert g[k]["source"] == "stream" and len(g[k]["history_hex"]) >= 17
