@@ -236,7 +236,7 @@ int hipxMatGetSORMode(hipxMat A, int *mode);
    0.8 m, i.e. never on scalar stencils) -- and from then on hipxMatMult / MultAdd take MatMult_SeqAIJ_Inode's PAIRWISE row sums (inode.c:356-760),
    as the reference does on such a matrix.  Rectangular matrices are never searched (round 5): the reference switches inodes OFF on the
    off-diagonal block of an MPIAIJ matrix (mpiaij.c:824), and an off-diagonal block handed over as plain CSR is rectangular in all but
-   degenerate splits; a caller whose off-diagonal block happens to be square says so with hipxMatSetInodes(B, 0, NULL) (INTEGRATION.md 14).
+   degenerate splits; a caller whose off-diagonal block happens to be square says so with hipxMatSetInodes(B, 0, NULL) (INTEGRATION.md section 14).
    A node whose diagonal block is singular makes hipxMatSOR return HIPX_ERR_ZEROPIVOT (x untouched), like a zero diagonal on the point path.
    SOR_APPLY_UPPER / SOR_APPLY_LOWER on a matrix with inodes return HIPX_ERR_SUP (MatSOR_SeqAIJ_Inode has no such branch; declare the matrix
    free of inodes to get the point routine's).  hipxMatSetInodes overrides the search:
