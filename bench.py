@@ -1170,6 +1170,7 @@ def main():
             extra_lines[key] = e
         P.setup(args.variant)
     nnz_local = P.nnz_local
+    setup_split = dict(P.setup_times)
     P.destroy()
 
     achieved_alg = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
@@ -1185,6 +1186,7 @@ def main():
                    "residual_norm_after": rnorm, "reduction_mode": os.environ.get("HIPX_REDUCTIONS", "fast")},
         "ungated": gate["pass"] is None,
         "parity_gate": gate,
+        "setup_split": setup_split,
         "roofline": {"bound": "hbm", "kernel": kname + (" + the CG direction update as its prologue (hipxMatMultCGDirectionDotBegin)" if fused_product else ""),
                      "achieved": achieved_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_alg / HBM_PEAK_GBS,
                      "basis": "algorithmic CSR bytes / launch time (no counter bytes available)", "traffic": None, "traffic_source": None,

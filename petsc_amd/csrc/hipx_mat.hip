@@ -1051,19 +1051,66 @@ __device__ __forceinline__ unsigned long long tm_mix(unsigned long long h, unsig
   return h;
 }
 
+// Coalesced row walk for the set-up passes that look at EVERY entry of the matrix once (round 5).  With one thread per row and each thread reading
+// its own row, neighbouring lanes are a whole row apart: 27-pt 512^3 (43 GB of columns and values) took 111 ms per pass = 0.39 TB/s.  Here a wave
+// owns 64 CONSECUTIVE rows = one contiguous span of the column / value arrays: the span passes through LDS in windows of RW_CH entries, loaded by
+// consecutive lanes (4- and 8-byte accesses, 256 / 512 B per wave instruction); lane l then walks the entries of row r0 + l that lie in the window,
+// in order, out of LDS and hands them to f(k, column, value bits).  Per-row results are exactly the ones of the thread-per-row loops.
+constexpr int RW_CH = 1024;
+__device__ __forceinline__ void rw_wave_sync()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (a wave's LDS operations complete in order; the barrier keeps the compiler from moving them)
+  __builtin_amdgcn_wave_barrier();
+}
+template <typename IT, int CH = RW_CH, class F>
+__device__ __forceinline__ void rowwalk64(hipx_int m, const IT *__restrict__ ai, const hipx_int *__restrict__ aj, const unsigned long long *__restrict__ aa, hipx_int r0, int *lcol,
+                                          unsigned long long *lval, F &&f)
+{
+  const int       lane = threadIdx.x & 63;
+  const long long r    = (long long)r0 + lane;
+  const bool      has  = r < (long long)m;
+  const IT        s = has ? ai[r] : (IT)0, e = has ? ai[r + 1] : (IT)0;
+  const hipx_int  rl   = (m - r0 > 64) ? r0 + 64 : m;
+  const IT        wbeg = ai[r0], wend = ai[rl];
+  IT              k    = s;
+  for (IT w0 = wbeg; w0 < wend; w0 += CH) {
+    const IT wl = (wend - w0 > (IT)CH) ? w0 + (IT)CH : wend;
+#pragma unroll 4
+    for (int i = lane; i < CH; i += 64) {
+      const IT g = w0 + i;
+      if (g < wl) {
+        lcol[i] = aj[g];
+        if (lval) lval[i] = aa[g];
+      }
+    }
+    rw_wave_sync();
+    while (k < e && k < wl) {
+      const int q = (int)(k - w0);
+      f(k, lcol[q], lval ? lval[q] : 0ull);
+      k++;
+    }
+    rw_wave_sync();
+  }
+}
+
 template <typename IT>
 __global__ __launch_bounds__(256) void tmpl_hash_kernel(hipx_int m, const IT *__restrict__ ai, const hipx_int *__restrict__ aj, const unsigned long long *__restrict__ aa,
                                                         unsigned long long *__restrict__ hash, int with_values)
 {
-  for (hipx_int r = (hipx_int)blockIdx.x * 256 + threadIdx.x; r < m; r += (hipx_int)gridDim.x * 256) {
-    const IT           s = ai[r], e = ai[r + 1];
-    unsigned long long h = tm_mix(0x243F6A8885A308D3ull, (unsigned long long)(e - s));
-    for (IT k = s; k < e; k++) {
-      h = tm_mix(h, (unsigned long long)(unsigned)(aj[k] - r));
-      if (with_values) h = tm_mix(h, aa[k]);
-    }
+  __shared__ int                lcol[4][RW_CH];
+  __shared__ unsigned long long lval[4][RW_CH];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long long rb = (long long)blockIdx.x * 256 + 64 * wv; rb < (long long)m; rb += (long long)gridDim.x * 256) {
+    const hipx_int     r0  = (hipx_int)rb;
+    const long long    r   = rb + lane;
+    const bool         has = r < (long long)m;
+    unsigned long long h   = tm_mix(0x243F6A8885A308D3ull, has ? (unsigned long long)(ai[r + 1] - ai[r]) : 0ull);
+    rowwalk64<IT>(m, ai, aj, aa, r0, lcol[wv], with_values ? lval[wv] : nullptr, [&](IT, int c, unsigned long long v) {
+      h = tm_mix(h, (unsigned long long)(unsigned)(c - (int)r));
+      if (with_values) h = tm_mix(h, v);
+    });
     if (h == VD_EMPTY) h ^= 1;
-    hash[r] = h;
+    if (has) hash[r] = h;
   }
 }
 
@@ -1098,20 +1145,38 @@ __global__ __launch_bounds__(256) void tmpl_assign_kernel(hipx_int m, const unsi
   }
 }
 
-template <typename IT>
+template <typename IT, int CH>
 __global__ __launch_bounds__(256) void tmpl_verify_kernel(hipx_int m, hipx_int ncols, const IT *__restrict__ ai, const hipx_int *__restrict__ aj, const unsigned long long *__restrict__ aa,
                                                           const unsigned char *__restrict__ tid, const int *__restrict__ tstart, const int *__restrict__ toff,
-                                                          const unsigned long long *__restrict__ tval, unsigned int *bad, int with_values)
+                                                          const unsigned long long *__restrict__ tval, unsigned int *bad, int with_values, int nent)
 {
-  for (hipx_int r = (hipx_int)blockIdx.x * 256 + threadIdx.x; r < m; r += (hipx_int)gridDim.x * 256) {
-    const IT  s = ai[r], e = ai[r + 1];
-    const int t = tid[r], ts = tstart[t], te = tstart[t + 1];
-    bool      ok = (long long)(e - s) == (long long)(te - ts);
-    if (ok)
-      for (int k = 0; k < te - ts; k++) {
-        const long long c = (long long)r + toff[ts + k];
-        ok = ok && (aj[s + k] - r) == toff[ts + k] && (!with_values || aa[s + k] == tval[ts + k]) && c >= 0 && c < ncols;
+  // dynamic LDS: the four waves' windows (4 CH values, 4 CH columns) and the template table (nent values, nent offsets) -- one LDS read per comparison
+  // instead of a dependent global one.  CH = 1024 when the table leaves room for it inside 64 KiB (few templates: every stencil), else 512
+  extern __shared__ __attribute__((aligned(16))) char vsm[];
+  unsigned long long *lval   = reinterpret_cast<unsigned long long *>(vsm);
+  unsigned long long *s_tval = lval + 4 * CH;
+  int                *lcol   = reinterpret_cast<int *>(s_tval + nent);
+  int                *s_toff = lcol + 4 * CH;
+  for (int k = threadIdx.x; k < nent; k += 256) {
+    s_toff[k] = toff[k];
+    s_tval[k] = with_values ? tval[k] : 0ull;
+  }
+  __syncthreads();
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long long rb = (long long)blockIdx.x * 256 + 64 * wv; rb < (long long)m; rb += (long long)gridDim.x * 256) {
+    const hipx_int  r0  = (hipx_int)rb;
+    const long long r   = rb + lane;
+    const bool      has = r < (long long)m;
+    const IT        s   = has ? ai[r] : (IT)0, e = has ? ai[r + 1] : (IT)0;
+    const int       t = has ? tid[r] : 0, ts = tstart[t], te = tstart[t + 1];
+    bool            ok = !has || (long long)(e - s) == (long long)(te - ts);
+    rowwalk64<IT, CH>(m, ai, aj, aa, r0, lcol + wv * CH, with_values ? lval + wv * CH : nullptr, [&](IT k, int cj, unsigned long long v) {
+      if (ok) {  // (a row of another length than its template's is bad already: its entries are not compared)
+        const int       kk = (int)(k - s), off = s_toff[ts + kk];
+        const long long c  = r + off;
+        ok                 = (cj - (int)r) == off && (!with_values || v == s_tval[ts + kk]) && c >= 0 && c < ncols;
       }
+    });
     if (!ok) atomicAdd(bad, 1u);
   }
 }
@@ -1896,7 +1961,7 @@ struct hipxMarchCG {
 template <int NE, int NQ, int NHALO, bool DOT, bool CG = false, int NT = 256>
 __global__ __launch_bounds__(NT, (NT == 256 || NQ <= 4) ? 2 : 1) void spmv_march2_kernel(const hipxMarchPlan plan, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask, const int ntmpl,
                                                               const double *__restrict__ x, double *__restrict__ yout, double *__restrict__ dotpart, const int tiles, const int pps,
-                                                              const int nplanes, const int xcdmap, const hipxMarchCG cg = hipxMarchCG{})
+                                                              const int nplanes, const int xcdmap, const hipxMarchCG cg = hipxMarchCG{}, const RedOut red = RedOut{}, const int npart_extra = 0)
 {
   using RS = MarchRuns<NE>;
   typedef double dbl2 __attribute__((ext_vector_type(2)));
@@ -2188,7 +2253,115 @@ __global__ __launch_bounds__(NT, (NT == 256 || NQ <= 4) ? 2 : 1) void spmv_march
   }
   if (DOT) {
     const double w = hipx::wave_sum(acc);
-    if (lane == 0) dotpart[(size_t)blockIdx.x * (NT / 64) + wv] = w;
+    if (!red.ticket) {
+      if (lane == 0) dotpart[(size_t)blockIdx.x * (NT / 64) + wv] = w;
+    } else {
+      // The fold of the partials by the LAST workgroup to finish (round 5: sum_kernel's launch, 5-8 us per CG iteration, saved).  The sum is formed in sum_kernel<false>'s own order for a one-workgroup launch (the caller passes `red` only
+      // when red_grid(npart) == 1): virtual thread v of 1024 adds partials v, v + 1024, ...; wave_sum per virtual wave; the 16 wave sums left to
+      // right -- so the value is bit for bit the one the separate kernel produced (real thread t plays the virtual threads t, t + NT, ...).
+      // NO agent-scope release fence here: it writes back the XCD's whole L2, which this kernel has just filled with y, p and x (measured: +24 us
+      // per launch).  The partial goes out as an agent-scope atomic store (sc1: written through to memory), the wave waits for it (vmcnt), the
+      // barrier collects the four waves, then the ticket; the last workgroup reads the partials with agent-scope atomic loads (sc1: never a stale line).
+      __shared__ unsigned s_lastwg;
+      __shared__ double   s_fw[kRedThreads / 64];
+      if (lane == 0) __hip_atomic_store(&dotpart[(size_t)blockIdx.x * (NT / 64) + wv], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) {
+        const unsigned tk = __hip_atomic_fetch_add(red.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_lastwg          = (tk == gridDim.x - 1);
+      }
+      __syncthreads();
+      if (!s_lastwg) return;
+      const int npart = (int)gridDim.x * (NT / 64) + npart_extra;  // (+ the partials of spmv_march2_rem_kernel, written by the launch before this one)
+      constexpr int VQ = kRedThreads / NT, VJ = 8;  // (npart <= 8 kRedThreads: at most eight partials per virtual thread -- all loads in flight at once)
+      double        pv[VQ][VJ];
+#pragma unroll
+      for (int q = 0; q < VQ; q++)
+#pragma unroll
+        for (int j = 0; j < VJ; j++) {
+          const int i = t + NT * q + kRedThreads * j;
+          pv[q][j]    = (i < npart) ? __hip_atomic_load(&dotpart[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+      for (int q = 0; q < VQ; q++) {
+        double a = 0.0;
+#pragma unroll
+        for (int j = 0; j < VJ; j++)
+          if (t + NT * q + kRedThreads * j < npart) a += pv[q][j];
+        a = hipx::wave_sum(a);
+        if (lane == 0) s_fw[wv + (NT / 64) * q] = a;
+      }
+      __syncthreads();
+      if (t == 0) {
+        double r = s_fw[0];
+#pragma unroll
+        for (int k = 1; k < kRedThreads / 64; k++) r += s_fw[k];
+        r = 0.0 + r;  // (sum_kernel's last-workgroup fold of its single partial: 0 + r, then additions of +0.0 only)
+        red.results[0] = r;
+        if (red.dres) red.dres[0] = r;
+        *red.ticket = 0u;
+        __threadfence_system();
+        if (red.seq) __hip_atomic_store(red.flag, red.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
+// The rows a plane has beyond its whole tiles (round 5): spmv_march2_kernel wants S to be a multiple of L; on other grids (200^3: S = 40000 = 19 x 2048
+// + 1088) it now takes the whole tiles and this kernel the rest -- rows k S + row0 + i, i < rem, of every plane k, one thread per row, the base
+// template's entries under the row's mask in ascending column order with the operands gathered from memory (coalesced along the rows): the sums of
+// MatMult_SeqAIJ, and with CG the same p_new = z d + b p per operand (and per own row, stored) and x += a p as the march kernel's prologue forms.
+// One dot partial per workgroup behind the march kernel's (dotpart + pbase); launched BEFORE the march kernel, which may fold all of them.
+template <bool DOT, bool CG>
+__global__ __launch_bounds__(256) void spmv_march2_rem_kernel(const hipxMarchPlan plan, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask, const double *__restrict__ x,
+                                                              double *__restrict__ yout, double *__restrict__ dotpart, const int row0, const int rem, const hipxMarchCG cg)
+{
+  __shared__ double s_w[4];
+  const int         i = (int)blockIdx.x * 256 + (int)threadIdx.x, k = (int)blockIdx.y;
+  double            acc = 0.0;
+  if (i < rem) {
+    const long long row = (long long)k * plan.S + row0 + i;
+    const unsigned  mk  = tmask[tid[row]];
+    double          cgb = 0.0, cga = 0.0, cgd = 1.0;
+    if (CG) {
+      cgb = cg.dev_beta_new ? (*cg.dev_beta_new / *cg.dev_beta_old) : cg.b;
+      cga = cg.dev_beta_new ? (*cg.dev_beta_old / *cg.dev_dpi) : cg.a;
+      cgd = cg.dconst;
+    }
+    double sum = 0.0, xd = 0.0;
+    for (int e = 0; e < plan.ne; e++) {
+      if ((mk >> e) & 1u) {
+        const long long c = row + (e < plan.nlo ? -(long long)plan.S : (e < plan.nlo + plan.nmid ? 0ll : (long long)plan.S)) + plan.b[e];
+        double          xv = x[c];
+        if (CG) {
+          const double zv = cg.z[c] * cgd;
+          xv              = zv + cgb * xv;
+        }
+        sum += plan.a[e] * xv;
+        if (e == plan.ne / 2) xd = xv;
+      }
+    }
+    yout[row] = sum;
+    if (CG) {
+      const double po = x[row], zv = cg.z[row] * cgd;
+      cg.pnew[row]    = zv + cgb * po;
+      cg.xsol[row]    = cg.xsol[row] + cga * po;
+    }
+    if (DOT) acc = xd * sum;
+  }
+  if (DOT) {
+    const double w = hipx::wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double r = s_w[0];
+      r += s_w[1];
+      r += s_w[2];
+      r += s_w[3];
+      // (agent-scope store: the march kernel's last workgroup reads the partials with agent-scope loads; the kernel boundary orders the two launches)
+      __hip_atomic_store(&dotpart[(size_t)blockIdx.y * gridDim.x + blockIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -2235,16 +2408,18 @@ __global__ __launch_bounds__(256) void spmv_tmpl_tail_kernel(hipx_int m, hipx_in
 template <typename IT>
 __global__ void diagpos_kernel(hipx_int m, const IT *ai, const hipx_int *aj, int64_t *diagpos, unsigned int *missing)
 {
-  for (hipx_int r = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (hipx_int)gridDim.x * blockDim.x) {
-    int64_t pos = -1;
-    for (IT k = ai[r]; k < ai[r + 1]; k++) {
-      if (aj[k] == r) {
-        pos = (int64_t)k;
-        break;
-      }
+  __shared__ int lcol[4][RW_CH];  // (launched with 256 threads: a wave per 64 consecutive rows, rowwalk64)
+  const int      wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long long rb = (long long)blockIdx.x * 256 + 64 * wv; rb < (long long)m; rb += (long long)gridDim.x * 256) {
+    const long long r   = rb + lane;
+    int64_t         pos = -1;
+    rowwalk64<IT>(m, ai, aj, nullptr, (hipx_int)rb, lcol[wv], nullptr, [&](IT k, int c, unsigned long long) {
+      if (pos < 0 && c == (int)r) pos = (int64_t)k;  // the FIRST entry on the diagonal, as the row loop found it
+    });
+    if (r < (long long)m) {
+      diagpos[r] = pos;
+      if (pos < 0) atomicAdd(missing, 1u);
     }
-    diagpos[r] = pos;
-    if (pos < 0) atomicAdd(missing, 1u);
   }
 }
 
@@ -2747,8 +2922,16 @@ int build_templates(hipxMat A)
   HIPX_HIP(hipMemcpyAsync(A->d_toff, A->h_toff.data(), sizeof(int) * A->h_toff.size(), hipMemcpyHostToDevice, st));
   HIPX_HIP(hipMemcpyAsync(A->d_tval, A->h_tval.data(), sizeof(double) * A->h_tval.size(), hipMemcpyHostToDevice, st));
   HIPX_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * 2, st));
-  tmpl_verify_kernel<IT><<<g, 256, 0, st>>>(m, A->n, (const IT *)A->d_i, A->d_j, (const unsigned long long *)A->d_a, A->d_tid, A->d_tstart, A->d_toff,
-                                             (const unsigned long long *)A->d_tval, d_cnt, A->ptm_build ? 0 : 1);
+  {
+    const int    vn  = (int)A->h_toff.size();
+    const size_t tab = 12 * (size_t)vn;
+    if (4 * 1024 * 12 + tab <= 64 * 1024)
+      tmpl_verify_kernel<IT, 1024><<<g, 256, 4 * 1024 * 12 + tab, st>>>(m, A->n, (const IT *)A->d_i, A->d_j, (const unsigned long long *)A->d_a, A->d_tid, A->d_tstart, A->d_toff,
+                                                                          (const unsigned long long *)A->d_tval, d_cnt, A->ptm_build ? 0 : 1, vn);
+    else
+      tmpl_verify_kernel<IT, 512><<<g, 256, 4 * 512 * 12 + tab, st>>>(m, A->n, (const IT *)A->d_i, A->d_j, (const unsigned long long *)A->d_a, A->d_tid, A->d_tstart, A->d_toff,
+                                                                        (const unsigned long long *)A->d_tval, d_cnt, A->ptm_build ? 0 : 1, vn);
+  }
   HIPX_HIP(hipMemcpyAsync(hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
   HIPX_HIP(hipStreamSynchronize(st));
   HIPX_LAUNCH_CHECK();
@@ -3043,13 +3226,17 @@ static int march2_check(hipxMat A)
   const hipxMarchPlan &mp = A->march_plan;
   const hipx_int       m  = A->nrows_c;
   if (!A->march_ok || !A->d_tid || !A->d_tmask || A->ntmpl > 256 || A->compressed || m != A->m) return HIPX_SUCCESS;
-  if (m % mp.S || mp.S % mp.L || (mp.L != 2048 && mp.L != 1024 && !(mp.L == 4096 && A->march_nt == 512)) || (mp.H & 1) || mp.H < 2 || mp.H > (A->march_nt == 512 ? 1024 : 768) || mp.H > mp.L) return HIPX_SUCCESS;
+  // (S % L != 0, round 5: the whole tiles of every plane go to the march kernel, the rest to spmv_march2_rem_kernel -- 256-thread forms with at least one whole tile)
+  static const bool norem = getenv("HIPX_MARCH2_NOREM") != nullptr;
+  // ... whose rest is at least a halo long: the last whole tile's upper halo then lies inside the plane, as every other tile's does)
+  if (mp.S % mp.L && (norem || A->march_nt != 256 || mp.S < mp.L || mp.S % mp.L < mp.H)) return HIPX_SUCCESS;
+  if (m % mp.S || (mp.L != 2048 && mp.L != 1024 && !(mp.L == 4096 && A->march_nt == 512)) || (mp.H & 1) || mp.H < 2 || mp.H > (A->march_nt == 512 ? 1024 : 768) || mp.H > mp.L) return HIPX_SUCCESS;
   const int nplanes = (int)(m / mp.S);
   if (nplanes < 3) return HIPX_SUCCESS;
   const bool runs = mp.ne == 7 ? march2_runs_ok<7>(mp) : (mp.ne == 27 ? march2_runs_ok<27>(mp) : (mp.ne == 5 ? march2_runs_ok<5>(mp) : (mp.ne == 9 ? march2_runs_ok<9>(mp) : false)));
   if (!runs) return HIPX_SUCCESS;
   const int nq = mp.L / A->march_nt, nh = (mp.H + A->march_nt - 1) / A->march_nt;  // the instantiated shapes (launch_march2)
-  const bool shape = A->march_nt == 512 ? (mp.ne == 7 && ((nq == 8 && nh <= 2) || (nq == 4 && nh == 1))) : ((mp.ne == 7 && nq == 8 && nh <= 2) || (mp.ne == 27 && nq == 8 && (nh == 2 || nh == 3)) || (nq == 4 && nh == 1));
+  const bool shape = A->march_nt == 512 ? (mp.ne == 7 && ((nq == 8 && nh <= 2) || (nq == 4 && nh == 1))) : ((mp.ne == 7 && nq == 8 && nh <= 2) || (mp.ne == 27 && nq == 8 && nh <= 3) || (nq == 4 && nh == 1));
   if (!shape) return HIPX_SUCCESS;
   unsigned int *d_flag = nullptr, h_flag = 0;
   HIPX_HIP(hipMalloc((void **)&d_flag, sizeof(unsigned int)));
@@ -3080,6 +3267,42 @@ static void march_geometry(hipxMat A, int &tiles, int &nseg, int &pps, int &npla
   units   = tiles * nseg;
 }
 
+// hipxMatMultDotBegin / hipxMatMultCGDirectionDotBegin: the reduction slot (and device copy) the product's dot is wanted in; a march2 launch whose
+// partials one sum_kernel workgroup would fold folds them itself and says so (HIPX_MARCH_NOFOLD=1: always the separate kernel)
+static int     g_m2_fold_slot = -1;
+static double *g_m2_fold_dres = nullptr;
+static bool    g_m2_folded    = false;
+static int     g_m2_extra     = 0;  // dot partials spmv_march2_rem_kernel has written behind the march kernel's (this launch)
+// rows of a plane beyond its whole tiles (0: S is a multiple of L) and the workgroups (= dot partials) of the kernel that takes them
+static inline int march2_rem(hipxMat A) { return (A->march_ok && A->march_plan.L > 0) ? A->march_plan.S % A->march_plan.L : 0; }
+static inline hipx_int march2_rem_parts(hipxMat A)
+{
+  const int rem = march2_rem(A);
+  return rem ? (hipx_int)(A->nrows_c / A->march_plan.S) * ((rem + 255) / 256) : 0;
+}
+// the launch of the remainder kernel; tiles / units / xm become those of the whole tiles
+template <bool DOT, bool CG>
+static int march2_rem_launch(hipxMat A, const double *x, double *yout, double *dotpart, int &units, int &tiles, int nplanes, int &xm, const hipxMarchCG &cg)
+{
+  g_m2_extra    = 0;
+  const int rem = march2_rem(A);
+  if (!rem) return HIPX_SUCCESS;
+  const hipxMarchPlan &mp   = A->march_plan;
+  const int            nseg = units / tiles;
+  tiles                     = mp.S / mp.L;
+  units                     = tiles * nseg;
+  xm                        = (xm & ~1) | ((units % 8 == 0) ? 1 : 0);
+  const dim3 grid((unsigned)((rem + 255) / 256), (unsigned)nplanes);
+  double    *dp = (DOT && dotpart) ? dotpart + (size_t)units * (A->march_nt / 64) : nullptr;
+  if (DOT && dp) spmv_march2_rem_kernel<true, CG><<<grid, 256, 0, rt().compute>>>(mp, A->d_tid, A->d_tmask, x, yout, dp, tiles * mp.L, rem, cg);
+  else spmv_march2_rem_kernel<false, CG><<<grid, 256, 0, rt().compute>>>(mp, A->d_tid, A->d_tmask, x, yout, nullptr, tiles * mp.L, rem, cg);
+  HIPX_LAUNCH_CHECK();
+  if (DOT && dp) {
+    g_m2_extra        = (int)(grid.x * grid.y);
+    A->dot_npart_used = (hipx_int)units * (A->march_nt / 64) + g_m2_extra;
+  }
+  return HIPX_SUCCESS;
+}
 template <int NE, int NQ, int NHALO, bool DOT, bool CG = false, int NT = 256>
 static int launch_march2_inst(hipxMat A, const double *x, double *yout, double *dotpart, int units, int tiles, int pps, int nplanes, int xm, size_t lds, const hipxMarchCG &cg = hipxMarchCG{})
 {
@@ -3088,7 +3311,12 @@ static int launch_march2_inst(hipxMat A, const double *x, double *yout, double *
     HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_march2_kernel<NE, NQ, NHALO, DOT, CG, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, NT == 512 ? 152 * 1024 : 96 * 1024));
     attr = true;
   }
-  spmv_march2_kernel<NE, NQ, NHALO, DOT, CG, NT><<<(unsigned)units, NT, lds, rt().compute>>>(A->march_plan, A->d_tid, A->d_tmask, A->ntmpl, x, yout, dotpart, tiles, pps, nplanes, xm | (dev_sw().nt_store ? 2 : 0) | (4 * dev_sw().nt_x), cg);
+  RedOut red{};
+  if (DOT && g_m2_fold_slot >= 0 && (hipx_int)units * (NT / 64) + g_m2_extra <= (hipx_int)kRedThreads * 8) {  // (= red_grid(npart) == 1: the fold rides in the kernel's last workgroup)
+    red          = red_out(g_m2_fold_slot, true, g_m2_fold_dres);
+    g_m2_folded  = true;
+  }
+  spmv_march2_kernel<NE, NQ, NHALO, DOT, CG, NT><<<(unsigned)units, NT, lds, rt().compute>>>(A->march_plan, A->d_tid, A->d_tmask, A->ntmpl, x, yout, dotpart, tiles, pps, nplanes, xm | (dev_sw().nt_store ? 2 : 0) | (4 * dev_sw().nt_x), cg, red, g_m2_extra);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -3101,12 +3329,13 @@ static bool march2_cg_shape(hipxMat A)
   // the 27-entry kernels too (242-252 registers, no spills): their product is VALU-bound, so the prologue's streams ride along for free --
   // 27-pt 512^3 CG+Jacobi 450 -> 556 it/s, 27-pt 256^3 3.55-3.62k -> 4.27k (same box; HIPX_MARCH_NOCG27 keeps the direction kernel)
   static const bool nocg27 = getenv("HIPX_MARCH_NOCG27") != nullptr;
-  if (!nocg27 && mp.ne == 27 && nq == 8 && (nh == 2 || nh == 3)) return true;
+  if (!nocg27 && mp.ne == 27 && nq == 8 && nh <= 3) return true;
   return (mp.ne == 7 && nq == 8 && nh <= 2) || ((mp.ne == 7 || mp.ne == 5 || mp.ne == 9) && nq == 4 && nh == 1);
 }
 template <bool DOT>
 static int launch_march2_cg(hipxMat A, const double *x, double *yout, double *dotpart, int units, int tiles, int pps, int nplanes, int xm, size_t lds, const hipxMarchCG &cg)
 {
+  if (int ierr = march2_rem_launch<DOT, true>(A, x, yout, dotpart, units, tiles, nplanes, xm, cg)) return ierr;
   const hipxMarchPlan &mp = A->march_plan;
   const int            nq = mp.L / A->march_nt, nh = (mp.H + A->march_nt - 1) / A->march_nt;
   if (A->march_nt == 512) {
@@ -3121,6 +3350,7 @@ static int launch_march2_cg(hipxMat A, const double *x, double *yout, double *do
   if (mp.ne == 7 && nq == 4 && nh == 1) HIPX_M2(7, 4, 1);
   if (mp.ne == 5 && nq == 4 && nh == 1) HIPX_M2(5, 4, 1);
   if (mp.ne == 9 && nq == 4 && nh == 1) HIPX_M2(9, 4, 1);
+  if (mp.ne == 27 && nq == 8 && nh == 1) HIPX_M2(27, 8, 1);  // (lines of up to 254 points on planes that are not whole tiles: 200^3)
   if (mp.ne == 27 && nq == 8 && nh == 2) HIPX_M2(27, 8, 2);
   if (mp.ne == 27 && nq == 8 && nh == 3) HIPX_M2(27, 8, 3);
 #undef HIPX_M2
@@ -3129,6 +3359,7 @@ static int launch_march2_cg(hipxMat A, const double *x, double *yout, double *do
 template <bool DOT>
 static int launch_march2(hipxMat A, const double *x, double *yout, double *dotpart, int units, int tiles, int pps, int nplanes, int xm, size_t lds)
 {
+  if (int ierr = march2_rem_launch<DOT, false>(A, x, yout, dotpart, units, tiles, nplanes, xm, hipxMarchCG{})) return ierr;
   const hipxMarchPlan &mp = A->march_plan;
   const int            nq = mp.L / A->march_nt, nh = (mp.H + A->march_nt - 1) / A->march_nt;
   if (A->march_nt == 512) {
@@ -3140,6 +3371,7 @@ static int launch_march2(hipxMat A, const double *x, double *yout, double *dotpa
 #define HIPX_M2(NE, NQ, NH) return launch_march2_inst<NE, NQ, NH, DOT>(A, x, yout, dotpart, units, tiles, pps, nplanes, xm, lds)
   if (mp.ne == 7 && nq == 8 && nh == 1) HIPX_M2(7, 8, 1);
   if (mp.ne == 7 && nq == 8 && nh == 2) HIPX_M2(7, 8, 2);
+  if (mp.ne == 27 && nq == 8 && nh == 1) HIPX_M2(27, 8, 1);
   if (mp.ne == 27 && nq == 8 && nh == 2) HIPX_M2(27, 8, 2);
   if (mp.ne == 27 && nq == 8 && nh == 3) HIPX_M2(27, 8, 3);
   if (mp.ne == 7 && nq == 4 && nh == 1) HIPX_M2(7, 4, 1);
@@ -4152,6 +4384,14 @@ int hipxMatMultAdd(hipxMat A, const double *x, const double *y, double *z)
   return launch_spmv<1, false>(A, x, A->compressed ? z : y, z, nullptr);
 }
 
+static void m2_fold_arm(int slot, double *dev_dot)
+{
+  static const bool nofold = getenv("HIPX_MARCH_NOFOLD") != nullptr;
+  g_m2_fold_slot = nofold ? -1 : slot;
+  g_m2_fold_dres = dev_dot;
+  g_m2_folded    = false;
+}
+
 static int matmultdot_launch(hipxMat A, const double *x, double *y, hipx_int *npart_out)
 {
   hipx_int npart = 0;
@@ -4159,11 +4399,12 @@ static int matmultdot_launch(hipxMat A, const double *x, double *y, hipx_int *np
   if (ierr0) return ierr0;
   *npart_out = npart;
   if (!npart) return HIPX_SUCCESS;
-  if (npart > A->dotpart_cap) {
+  const hipx_int room = npart + march2_rem_parts(A);  // (+ the partials of the rows beyond the whole tiles, should the march form take this product)
+  if (room > A->dotpart_cap) {
     HIPX_HIP(hipStreamSynchronize(rt().compute));
     (void)hipFree(A->d_dotpart);
-    HIPX_HIP(hipMalloc((void **)&A->d_dotpart, sizeof(double) * (size_t)npart));
-    A->dotpart_cap = npart;
+    HIPX_HIP(hipMalloc((void **)&A->d_dotpart, sizeof(double) * (size_t)room));
+    A->dotpart_cap = room;
   }
   A->dot_npart_used = 0;
   int ierr = launch_spmv<0, true>(A, x, nullptr, y, A->d_dotpart);
@@ -4196,8 +4437,10 @@ int hipxMatMultDotBegin(hipxMat A, const double *x, double *y, int slot, double 
     return ierr ? ierr : launch_dot(x, y, A->m, slot, dev_dot);
   }
   hipx_int npart = 0;
-  int      ierr  = matmultdot_launch(A, x, y, &npart);
-  if (ierr) return ierr;
+  m2_fold_arm(slot, dev_dot);
+  int ierr = matmultdot_launch(A, x, y, &npart);
+  g_m2_fold_slot = -1;
+  if (ierr || g_m2_folded) return ierr;
   return launch_sum(A->d_dotpart, npart, slot, dev_dot);
 }
 
@@ -4222,7 +4465,7 @@ int hipxMatMultCGDirectionDotBegin(hipxMat A, const double *p_old, double *p_new
   if (A->march2_state != 1 || !march2_cg_shape(A)) return HIPX_SUCCESS;
   int tiles, nseg, pps, nplanes, units;
   march_geometry(A, tiles, nseg, pps, nplanes, units);
-  const hipx_int npart = (hipx_int)units * (A->march_nt / 64);
+  hipx_int npart = (hipx_int)units * (A->march_nt / 64) + march2_rem_parts(A);  // (an upper bound when a plane has rows beyond its whole tiles; the launch says what it wrote)
   if (npart > A->dotpart_cap) {
     HIPX_HIP(hipStreamSynchronize(rt().compute));
     (void)hipFree(A->d_dotpart);
@@ -4239,9 +4482,14 @@ int hipxMatMultCGDirectionDotBegin(hipxMat A, const double *p_old, double *p_new
     if ((ierr = prof_mark(false))) return ierr;
     if ((ierr = launch_dot(p_new, w, A->m, slot, dev_dot))) return ierr;
   } else {
-    if ((ierr = launch_march2_cg<true>(A, p_old, w, A->d_dotpart, units, tiles, pps, nplanes, xm, lds, cg))) return ierr;
+    m2_fold_arm(slot, dev_dot);
+    A->dot_npart_used = 0;
+    ierr              = launch_march2_cg<true>(A, p_old, w, A->d_dotpart, units, tiles, pps, nplanes, xm, lds, cg);
+    g_m2_fold_slot    = -1;
+    if (ierr) return ierr;
+    if (A->dot_npart_used) npart = A->dot_npart_used;
     if ((ierr = prof_mark(false))) return ierr;
-    if ((ierr = launch_sum(A->d_dotpart, npart, slot, dev_dot))) return ierr;
+    if (!g_m2_folded && (ierr = launch_sum(A->d_dotpart, npart, slot, dev_dot))) return ierr;
   }
   *fused = 1;
   return HIPX_SUCCESS;

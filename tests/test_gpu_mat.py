@@ -709,6 +709,67 @@ def test_march2_kernel_bit_exact_and_same_bits_as_the_first_march_kernel(hx, kin
     _lib.mat_destroy(A)
 
 
+@pytest.mark.parametrize("kind,n,m", [("7pt", 40, None), ("27pt", 36, None), ("7pt_box", (200, 200, 24), None), ("5pt", 1500, 24), ("27pt", (72, 60, 12), None), ("7pt_box", (50, 42, 30), None)])
+def test_march2_planes_that_are_not_whole_tiles(hx, kind, n, m):
+    """Round 5: planes whose row count is not a multiple of the tile (1600 = 1024 + 576, 1296 = 1024 + 272, 40000 = 19 x 2048 + 1088, lines of 1500
+    points, 4320 = 4 x 1024 + 224, 2100 = 2 x 1024 + 52): spmv_march2_kernel takes the whole tiles, spmv_march2_rem_kernel the rest of every plane.
+    MatMult bit-identical to MatMult_SeqAIJ; the fused dot deterministic; the CG prologue form (p_new, x, w and the dot) bit-identical to the separate
+    kernels -- with the fold of the dot partials inside the product kernel (at these sizes one sum_kernel workgroup would do it, so the fold is the kernel's own)."""
+    from petsc_amd import _lib
+    from test_gpu_sor import box_csr
+    rng = np.random.default_rng(37)
+    if isinstance(n, tuple) and kind == "27pt":
+        ai, aj, aa = box_csr(n[0], n[1], n[2], 27)
+    else:
+        ai, aj, aa = orc.stencil(kind, n, m=m)
+    N = len(ai) - 1
+    x = rng.standard_normal(N)
+    yr = orc.matmult(ai, aj, aa, x)
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    _lib.chk(hx.hipxMatSetSpMVVariant(A, 30))
+    name = kernel_name(hx, A)
+    assert name.startswith("spmv_march2_kernel "), name
+    X, Y = _lib.DVec(N, x), _lib.DVec(N)
+    for _ in range(2):
+        Y.set(np.full(N, np.nan))
+        _lib.chk(hx.hipxMatMult(A, X.ptr, Y.ptr))
+        assert np.array_equal(Y.get(), yr)
+    dot, dot2, dot3 = C.c_double(), C.c_double(), C.c_double()
+    Y.set(np.full(N, np.nan))
+    _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(dot)))
+    assert np.array_equal(Y.get(), yr) and abs(dot.value - float(x @ yr)) <= 1e-12 * np.abs(x * yr).sum()
+    _lib.chk(hx.hipxMatMultDot(A, X.ptr, Y.ptr, C.byref(dot2)))
+    assert dot2.value == dot.value
+    Y.set(np.full(N, np.nan))
+    _lib.chk(hx.hipxMatMultDotBegin(A, X.ptr, Y.ptr, 5, None))  # the fold inside the product kernel (when one sum_kernel workgroup would do it)
+    _lib.chk(hx.hipxRedEnd(5, 1, C.byref(dot3)))
+    assert np.array_equal(Y.get(), yr) and dot3.value == dot.value
+    # the CG prologue form against the separate kernels
+    if kind != "27pt":
+        p0, r, x0 = rng.standard_normal(N), rng.standard_normal(N), rng.standard_normal(N)
+        b, a, dconst = 0.731 / 1.913, 1.913 / 2.57, 0.37
+        P, R, XS, W = _lib.DVec(N, p0), _lib.DVec(N, r), _lib.DVec(N, x0), _lib.DVec(N)
+        _lib.chk(hx.hipxCGAypxAxpyR(P.ptr, b, R.ptr, dconst, XS.ptr, a, N))
+        dref = C.c_double()
+        _lib.chk(hx.hipxMatMultDot(A, P.ptr, W.ptr, C.byref(dref)))
+        pr, xr, wr = P.get(), XS.get(), W.get()
+        assert np.array_equal(wr, orc.matmult(ai, aj, aa, pr))
+        P.set(p0)
+        XS.set(x0)
+        P2, W2 = _lib.DVec(N, np.full(N, np.nan)), _lib.DVec(N, np.full(N, np.nan))
+        fused, d = C.c_int(0), C.c_double()
+        _lib.chk(hx.hipxMatMultCGDirectionDotBegin(A, P.ptr, P2.ptr, R.ptr, dconst, XS.ptr, b, a, None, None, None, W2.ptr, 5, None, C.byref(fused)))
+        assert fused.value == 1
+        _lib.chk(hx.hipxRedEnd(5, 1, C.byref(d)))
+        assert np.array_equal(P2.get(), pr) and np.array_equal(XS.get(), xr) and np.array_equal(W2.get(), wr)
+        assert d.value == dref.value
+        for v in (P, R, XS, W, P2, W2):
+            v.free()
+    for v in (X, Y):
+        v.free()
+    _lib.mat_destroy(A)
+
+
 def test_march2_refuses_matrices_whose_template_ids_are_not_plane_periodic(hx):
     """One interior row of an interior plane loses an entry (its template differs from the same row of the other planes): the second-generation
     kernel's set-up check must see it and the first march kernel takes the matrix -- still bit-identical."""
