@@ -1151,7 +1151,7 @@ def main():
     # every kernel of the timed iteration (HIP events around each launch, second pass of the same K steps)
     by_kernel = [{"role": "product (+ CG direction update as its prologue when the kernel is spmv_march2_kernel<..., true> and the solver is the fused CG)", "match": kname.split(" ")[0],
                   "avg_launch_us": 1e3 * spmv_ms, "launches_per_iteration": launches / float(args.steps)}]
-    for key, role, match in (("cg_update_ms", "fused CG update: r -= a w, z = r d, z.z, z.r (cg.c:306-309,344)", "cg_fused_kernel"),
+    for key, role, match in (("cg_update_ms", "fused CG update: r -= a w, z = r d, z.z, z.r (cg.c:306-309,344)", "cg_fused_"),
                              ("cg_direction_ms", "CG direction: p = z + b p, x += a p (cg.c:249,305) as its own kernel", "cg_aypx_axpy_kernel"),
                              ("dot_fold_ms", "fold of the product's dot partials (cg.c:258)", "sum_kernel")):
         if key in sec:
@@ -1457,7 +1457,7 @@ def main():
             put_traffic(c5["roofline_spmv"], pmc.get("box"), [c5["roofline_spmv"]["kernel"].split(" ")[0]], c5["roofline_spmv"]["avg_launch_ms"],
                         note="counter pass on the same solver at the same size (1024 x 1024 x 128); the product kernel carries the CG direction update as its prologue")
             if pmc.get("box") and pmc["box"][0] and "cg_update_ms" in c5:
-                _, vu = pick_kernel(pmc["box"][0], "cg_fused_kernel")
+                _, vu = pick_kernel(pmc["box"][0], "cg_fused_")
                 if vu:
                     c5["roofline_cg_update"] = {"bound": "hbm", "kernel": "cg_fused_kernel", "avg_launch_ms": c5["cg_update_ms"], "traffic": int(vu["bytes"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                 "frac_counter_bytes": vu["bytes"] / (c5["cg_update_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}

@@ -5,11 +5,9 @@ import json,sys
 d=json.load(open('bench_detail.json'))
 r=d.get('roofline',{})
 print('  it/s %.1f ms %.4f %s kernels %s setup %s' % (d['value'] or -1, d['ms_per_step'], r.get('kernel','')[:30], [(k['match'], round(k['avg_launch_us'],1)) for k in r.get('by_kernel',[])], {k: round(v, 3) for k, v in (d.get('setup_split') or {}).items()}))"; }
-for i in $(seq 1 ${1:-2}); do
-echo "fold in the product kernel"; q --steps 400 --warmup 40
-echo "HIPX_MARCH_NOFOLD=1"; HIPX_MARCH_NOFOLD=1 q --steps 400 --warmup 40
+for i in $(seq 1 ${1:-1}); do
+for g in 8192 4096 2048 1024 512; do
+echo "one-shot update kernel, two-level tickets, G = $g"; HIPX_CG_FUSED_OS_G=$g q --steps 400 --warmup 40
 done
-echo "7-pt 200^3: march2 on the whole tiles + remainder kernel"; q --grid 200 --steps 400 --warmup 40
-echo "7-pt 200^3: HIPX_MARCH2_NOREM=1 (first march kernel)"; HIPX_MARCH2_NOREM=1 q --grid 200 --steps 400 --warmup 40
-echo "27-pt 200^3"; q --grid 200 --stencil 27 --steps 200 --warmup 20
-echo "27-pt 200^3: HIPX_MARCH2_NOREM=1"; HIPX_MARCH2_NOREM=1 q --grid 200 --stencil 27 --steps 200 --warmup 20
+echo "HIPX_CG_FUSED_OS=0 (persistent reduction grid)"; HIPX_CG_FUSED_OS=0 q --steps 400 --warmup 40
+done
