@@ -153,6 +153,11 @@ int hipxRedEnd(int slot, int nvals, double *results); /* synchronises the comput
    the vectors and answers those calls from them (plugin/vechipx.c, "reduction cache"): in the exact reduction mode the values are the ones hipxVecNorm /
    hipxVecDot return, bit for bit; in the fast mode they differ by the association of the partial sums (rounding). */
 int hipxVecPointwiseMultDotsBegin(double *w, const double *x, const double *y, hipx_int n, int slot);
+/* round 5.  y += alpha x, then w = y .* d with the sums w.w and w.y -- VecAXPY (bvec1.c:70-83) followed by VecPointwiseMult (bvec2.c:72-97): "r <- r - a w;
+   z <- B r" of cg.c:306-307 with PCJACOBI -- in ONE pass over the vectors (the kernel of hipxCGFusedUpdate; element by element the operations of the two
+   separate calls, the same bits).  Enqueue only; hipxRedEnd(slot, 2, s): s[0] = w.w, s[1] = w.y.  w may be x (KSPSolve_CG keeps A p in
+   the vector it then overwrites with z, cg.c:145); otherwise the arrays must be distinct. */
+int hipxVecAXPYPointwiseMultDotsBegin(double *y, double alpha, const double *x, double *w, const double *d, double dconst, hipx_int n, int slot); /* d == NULL: w = y * dconst (every entry of the diagonal is dconst: one stream less) */
 
 /* fused CG kernels (same arithmetic as the separate calls, fewer HBM passes) */
 /* x += a p ; r -= a w ; z = r .* d ; sums[0] = z.z ; sums[1] = z.r  (cg.c:305-309,344 with PCJACOBI) */

@@ -1484,6 +1484,19 @@ int hipxCGFusedUpdate(double *x, double *r, double *z, const double *p, const do
   return red_wait(0, 2, sums2);
 }
 
+int hipxVecAXPYPointwiseMultDotsBegin(double *y, double alpha, const double *x, double *w, const double *d, double dconst, hipx_int n, int slot)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2, "reduction slot out of range");
+  HIPX_ARG(n <= 0 || (y && x && w && y != x && w != y && w != d && y != d), "null or aliased argument");  // (w == x is fine: an element is read before it is written, by the same thread)
+  if (n <= 0) return HIPX_SUCCESS;
+  if (d) return launch_cg_fused(nullptr, y, w, nullptr, x, d, -alpha, n, slot);  // (the kernel forms r + (-a) w with a = -alpha: the multiplier is alpha itself)
+  const bool vec = aligned16(y) && aligned16(w) && aligned16(x) && n >= 2;
+  cg_fused_go<false, true>(red_grid(n), rt().compute, nullptr, y, w, nullptr, x, nullptr, -alpha, nullptr, nullptr, n, vec, red_out_g(slot), dconst);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
 int hipxCGAypxAxpy(double *p, double b, const double *z, double *x, double a, hipx_int n)
 {
   HIPX_CHECK_INIT();

@@ -40,6 +40,8 @@ typedef struct {
   PetscInt     d_n;          /* allocated length */
   PetscBool    d_owned;      /* PETSC_FALSE for sub-arrays of a VecDuplicateVecs slab */
   PetscInt     magic;
+  PetscScalar *d_alt;        /* second device buffer (lazy fusion: the CG direction vector is rewritten out of place by the product kernel), or NULL */
+  PetscInt     d_alt_n;
 } VecHIPXExt;
 
 #define VECHIPX_MAGIC   0x48495058
@@ -68,6 +70,14 @@ PETSC_INTERN PetscBool      VecHIPXRedCacheWanted(int kind);
 PETSC_INTERN int            VecHIPXRedCacheSlot(int kind);
 PETSC_INTERN PetscErrorCode VecHIPXRedCachePut(int kind, Vec a, Vec b);
 PETSC_INTERN void           VecHIPXRedCacheInvalidate(Vec v);
+
+/* Lazy fusion (vechipx.c).  VecAXPY / VecAYPX on device-resident hipx vectors are RECORDED, not run: KSPSolve_CG's "x += a p; r -= a w; z = B r" and
+   "p = z + b p; w = A p" (cg.c:305-307, 248-256) then run as the two fused kernels of cghipx -- the consumers (VecPointwiseMult = PCApply_Jacobi, MatMult)
+   recognise the recorded operations; ANY other access to a vector a recorded operation reads or writes (every accessor of vechipx.c, host or device)
+   first runs everything recorded, in order.  -hipx_lazy_fusion 0 turns it off. */
+PETSC_INTERN PetscErrorCode VecHIPXLazySync(Vec v);   /* run the recorded operations if v takes part in one */
+PETSC_INTERN PetscErrorCode VecHIPXLazyFlush(void);   /* run them all */
+PETSC_INTERN PetscErrorCode VecHIPXLazyTryCGProduct(hipxMat dA, Vec xx, Vec yy, PetscBool *done); /* MatMult(A, P, W) with "x += a p; p = z + b p" recorded */
 
 PETSC_INTERN PetscErrorCode VecCreate_SeqHIPX(Vec);
 PETSC_INTERN PetscErrorCode VecCreate_MPIHIPX(Vec);

@@ -145,6 +145,14 @@ static PetscErrorCode MatMult_SeqAIJHIPX(Mat A, Vec xx, Vec yy)
 
   PetscFunctionBegin;
   PetscCall(MatSeqAIJHIPXGetDeviceMat(A, &dA));
+  if (A->rmap->n == A->cmap->n && !a->compressedrow.use) { /* "x += a p; p = z + b p" recorded on xx (lazy fusion, hipxplugin.h): the product kernel's prologue */
+    PetscBool done;
+    PetscCall(VecHIPXLazyTryCGProduct(dA, xx, yy, &done));
+    if (done) {
+      PetscCall(PetscLogFlops(2.0 * a->nz - a->nonzerorowcnt));
+      PetscFunctionReturn(PETSC_SUCCESS);
+    }
+  }
   PetscCall(VecHIPXGetDeviceRead(xx, &x, &tx));
   PetscCall(VecHIPXGetDeviceWrite(yy, &y, &ty));
   {

@@ -19,6 +19,9 @@
 
 static PetscBool hipx_runtime_up = PETSC_FALSE;
 static PetscBool hipx_rc_on      = PETSC_TRUE; /* -hipx_reduction_cache (hipxplugin.h) */
+static PetscBool hipx_lazy_on    = PETSC_TRUE; /* -hipx_lazy_fusion (hipxplugin.h) */
+static PetscInt  hipx_lazy_min   = 32768;      /* -hipx_lazy_min_size: shorter vectors run their operations at once */
+static PetscBool hipx_lazy_view  = PETSC_FALSE; /* -hipx_lazy_view: counts at PetscFinalize */
 
 PetscErrorCode VecHIPXInitRuntime(void)
 {
@@ -37,6 +40,9 @@ PetscErrorCode VecHIPXInitRuntime(void)
   PetscCallHIPX(hipxInit((int)dev));
   PetscCall(PetscOptionsGetBool(NULL, NULL, "-vec_hipx_memtype", &hipx_vec_memtype_ops, NULL));
   PetscCall(PetscOptionsGetBool(NULL, NULL, "-hipx_reduction_cache", &hipx_rc_on, NULL));
+  PetscCall(PetscOptionsGetBool(NULL, NULL, "-hipx_lazy_fusion", &hipx_lazy_on, NULL));
+  PetscCall(PetscOptionsGetInt(NULL, NULL, "-hipx_lazy_min_size", &hipx_lazy_min, NULL));
+  PetscCall(PetscOptionsGetBool(NULL, NULL, "-hipx_lazy_view", &hipx_lazy_view, NULL));
   { /* -hipx_reductions exact|fast: compensated (Dot2) sums in every reduction kernel -- the values the reference's VecDot / VecNorm /
        VecMDot return when its BLAS is exactly rounded (bvec1.c:27, bvec2.c:202-223, dvec2.c:557); default: HIPX_REDUCTIONS or fast */
     char      mode[16] = "";
@@ -138,6 +144,8 @@ static PetscErrorCode VecHIPXAllocate(Vec v)
   PetscFunctionBegin;
   if (e->d_array && e->d_n >= n) PetscFunctionReturn(PETSC_SUCCESS);
   if (e->d_array && e->d_owned) PetscCallHIPX(hipxFree(e->d_array));
+  if (e->d_alt) PetscCallHIPX(hipxFree(e->d_alt));
+  e->d_alt = NULL;
   PetscCallHIPX(hipxMalloc((void **)&e->d_array, sizeof(PetscScalar) * (size_t)(n ? n : 1)));
   e->d_n     = n;
   e->d_owned = PETSC_TRUE;
@@ -216,6 +224,7 @@ PetscErrorCode VecHIPXGetDeviceRead(Vec v, const PetscScalar **d, void **tmp)
 {
   PetscFunctionBegin;
   *tmp = NULL;
+  PetscCall(VecHIPXLazySync(v));
   if (VecIsHIPX(v)) {
     PetscCall(VecHIPXCopyToDevice(v));
     *d = VecHIPXGetExt(v)->d_array;
@@ -235,6 +244,7 @@ PetscErrorCode VecHIPXGetDeviceWrite(Vec v, PetscScalar **d, void **tmp)
 {
   PetscFunctionBegin;
   *tmp = NULL;
+  PetscCall(VecHIPXLazySync(v));
   VecHIPXRedCacheInvalidate(v);
   if (VecIsHIPX(v)) {
     PetscCall(VecHIPXAllocate(v));
@@ -247,6 +257,7 @@ PetscErrorCode VecHIPXGetDeviceReadWrite(Vec v, PetscScalar **d, void **tmp)
 {
   PetscFunctionBegin;
   *tmp = NULL;
+  PetscCall(VecHIPXLazySync(v));
   VecHIPXRedCacheInvalidate(v);
   if (VecIsHIPX(v)) {
     PetscCall(VecHIPXCopyToDevice(v));
@@ -264,10 +275,272 @@ PetscErrorCode VecHIPXRestoreDeviceWrite(Vec v, PetscScalar **d, void **tmp)
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+/* ------------------------------------------------------------------ lazy fusion (hipxplugin.h)
+   The queue holds at most HIPX_LAZY_MAX recorded operations, each "y += s x" (kind 1, VecAXPY_Seq bvec1.c:70-83) or "y = x + s y" (kind 2, VecAYPX_Seq
+   dvec2.c:753-780) on hipx vectors whose device copies are current.  Running them later, in the recorded order, is what running them at once would have
+   been as long as nobody looks at (or changes) a vector that takes part -- every accessor calls VecHIPXLazySync first.  Recognised on the way:
+     [x += a p][p = z + b p] next to each other      -> hipxCGAypxAxpy: p read once (cg_aypx_axpy_kernel)
+     ... and MatMult(A, p, w) asks for the product   -> hipxMatMultCGDirectionDotBegin: the two updates are the product kernel's prologue; p is rewritten
+                                                        OUT OF PLACE (other workgroups still read the old direction): the vector's two device buffers swap
+     [r += s w] and VecPointwiseMult(z, r, d) follows -> hipxVecAXPYPointwiseMultDotsBegin: one pass, the sums z.z and z.r into the reduction cache
+   Every fused kernel performs, element by element, the operations of the separate kernels in their order: the vectors come out bit-identical. */
+#define HIPX_LAZY_MAX 4
+typedef struct {
+  int         kind; /* 1: y += s x, 2: y = x + s y */
+  Vec         y, x;
+  PetscScalar s;
+} HipxLazyOp;
+static HipxLazyOp hipx_lazy[HIPX_LAZY_MAX];
+static PetscInt   hipx_lazy_stat[5] = {0, 0, 0, 0, 0}; /* recorded, run alone, run as "x += a p; p = z + b p", fused into VecPointwiseMult, fused into MatMult (pairs) */
+static PetscBool  hipx_lazy_fin     = PETSC_FALSE;
+
+static PetscErrorCode VecHIPXLazyFinalize(void)
+{
+  PetscFunctionBegin;
+  if (hipx_lazy_view)
+    PetscCall(PetscPrintf(PETSC_COMM_SELF, "hipx lazy fusion: %" PetscInt_FMT " operations recorded; %" PetscInt_FMT " run alone, %" PetscInt_FMT " pairs as one direction kernel, %" PetscInt_FMT " inside VecPointwiseMult, %" PetscInt_FMT " pairs as the prologue of MatMult\n",
+                          hipx_lazy_stat[0], hipx_lazy_stat[1], hipx_lazy_stat[2], hipx_lazy_stat[3], hipx_lazy_stat[4]));
+  for (int k = 0; k < 5; k++) hipx_lazy_stat[k] = 0;
+  hipx_lazy_fin = PETSC_FALSE;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+static int        hipx_nlazy    = 0;
+static PetscBool  hipx_lazy_run = PETSC_FALSE; /* the queue is being run: nothing is recorded, nothing syncs */
+
+static PetscErrorCode VecHIPXLazyRunOne(const HipxLazyOp *o)
+{
+  VecHIPXExt *ey = VecHIPXGetExt(o->y), *ex = VecHIPXGetExt(o->x);
+
+  PetscFunctionBegin;
+  if (o->kind == 1) PetscCallHIPX(hipxVecAXPY(ey->d_array, o->s, ex->d_array, o->y->map->n));
+  else PetscCallHIPX(hipxVecAYPX(ey->d_array, o->s, ex->d_array, o->y->map->n));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* two recorded operations may change places in time unless one writes what the other reads or writes */
+static PetscBool VecHIPXLazyConflict(const HipxLazyOp *a, const HipxLazyOp *b) { return (PetscBool)(a->y == b->y || a->y == b->x || b->y == a->x); }
+
+/* run the operations marked in run[], in their order (a marked "x += a p" directly followed -- among the marked ones -- by "p = z + b p" as one kernel),
+   and keep the others recorded, in their order */
+static PetscErrorCode VecHIPXLazyRunMarked(const PetscBool run[])
+{
+  HipxLazyOp keep[HIPX_LAZY_MAX];
+  int        nkeep = 0, prev = -1;
+
+  PetscFunctionBegin;
+  hipx_lazy_run = PETSC_TRUE;
+  for (int k = 0; k <= hipx_nlazy; k++) {
+    if (k < hipx_nlazy && !run[k]) {
+      keep[nkeep++] = hipx_lazy[k];
+      continue;
+    }
+    /* k == hipx_nlazy: only the operation held back in `prev` is left */
+    if (prev >= 0) {
+      const HipxLazyOp *o = &hipx_lazy[prev], *q = k < hipx_nlazy ? &hipx_lazy[k] : NULL;
+      if (q && o->kind == 1 && q->kind == 2 && o->x == q->y && o->y != q->x && o->y != q->y && q->x != q->y) { /* x += a p; p = z + b p */
+        PetscCallHIPX(hipxCGAypxAxpy(VecHIPXGetExt(q->y)->d_array, q->s, VecHIPXGetExt(q->x)->d_array, VecHIPXGetExt(o->y)->d_array, o->s, q->y->map->n));
+        hipx_lazy_stat[2]++;
+        prev = -1;
+        continue;
+      }
+      PetscCall(VecHIPXLazyRunOne(o));
+      hipx_lazy_stat[1]++;
+    }
+    prev = k < hipx_nlazy ? k : -1;
+  }
+  for (int k = 0; k < nkeep; k++) hipx_lazy[k] = keep[k];
+  hipx_nlazy    = nkeep;
+  hipx_lazy_run = PETSC_FALSE;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PetscErrorCode VecHIPXLazyFlush(void)
+{
+  PetscBool run[HIPX_LAZY_MAX] = {PETSC_TRUE, PETSC_TRUE, PETSC_TRUE, PETSC_TRUE};
+
+  PetscFunctionBegin;
+  if (!hipx_nlazy || hipx_lazy_run) PetscFunctionReturn(PETSC_SUCCESS);
+  PetscCall(VecHIPXLazyRunMarked(run));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* v is about to be looked at or changed: the recorded operations that read or write it must run now -- and with them every EARLIER one that one of
+   those may not overtake (VecHIPXLazyConflict).  The rest stays recorded (CG with the unpreconditioned norm: VecNorm(R) runs "r -= a w" and leaves
+   "x += a p" for the direction kernel). */
+PetscErrorCode VecHIPXLazySync(Vec v)
+{
+  PetscBool run[HIPX_LAZY_MAX] = {PETSC_FALSE, PETSC_FALSE, PETSC_FALSE, PETSC_FALSE}, any = PETSC_FALSE, more = PETSC_TRUE;
+
+  PetscFunctionBegin;
+  if (!hipx_nlazy || hipx_lazy_run) PetscFunctionReturn(PETSC_SUCCESS);
+  for (int k = 0; k < hipx_nlazy; k++)
+    if (hipx_lazy[k].y == v || hipx_lazy[k].x == v) run[k] = any = PETSC_TRUE;
+  if (!any) PetscFunctionReturn(PETSC_SUCCESS);
+  while (more) {
+    more = PETSC_FALSE;
+    for (int k = 0; k < hipx_nlazy; k++)
+      if (run[k])
+        for (int j = 0; j < k; j++)
+          if (!run[j] && VecHIPXLazyConflict(&hipx_lazy[j], &hipx_lazy[k])) run[j] = more = PETSC_TRUE;
+  }
+  PetscCall(VecHIPXLazyRunMarked(run));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* record "y += s x" / "y = x + s y" instead of running it?  Only for two different hipx vectors of one size whose current values are (or now get) on
+   the device, long enough for a pass over them to matter. */
+static PetscErrorCode VecHIPXLazyRecord(int kind, Vec y, PetscScalar s, Vec x, PetscBool *recorded)
+{
+  PetscFunctionBegin;
+  *recorded = PETSC_FALSE;
+  if (!hipx_lazy_on || hipx_lazy_run || x == y || !VecIsHIPX(x) || !VecIsHIPX(y) || x->map->n != y->map->n || y->map->n < hipx_lazy_min) PetscFunctionReturn(PETSC_SUCCESS);
+  if (hipx_nlazy == HIPX_LAZY_MAX) PetscCall(VecHIPXLazyFlush());
+  /* (a vector that takes part in a recorded operation has its current values on the device by construction: these two calls move nothing for it) */
+  PetscCall(VecHIPXCopyToDevice(x));
+  PetscCall(VecHIPXCopyToDevice(y));
+  VecHIPXRedCacheInvalidate(y);
+  hipx_lazy[hipx_nlazy].kind = kind;
+  hipx_lazy[hipx_nlazy].y    = y;
+  hipx_lazy[hipx_nlazy].x    = x;
+  hipx_lazy[hipx_nlazy].s    = s;
+  hipx_nlazy++;
+  hipx_lazy_stat[0]++;
+  if (!hipx_lazy_fin) {
+    PetscCall(PetscRegisterFinalize(VecHIPXLazyFinalize));
+    hipx_lazy_fin = PETSC_TRUE;
+  }
+  y->offloadmask = PETSC_OFFLOAD_GPU;
+  *recorded      = PETSC_TRUE;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscBool VecHIPXLazyTouches(const HipxLazyOp *o, Vec v) { return (PetscBool)(o->y == v || o->x == v); }
+
+/* VecPointwiseMult(w, x, y) with "x += s u" recorded and nothing else recorded on w, x, y, u: one kernel, sums into the reduction cache */
+static PetscErrorCode VecHIPXLazyTryAXPYPointwiseMult(Vec w, Vec x, Vec y, PetscBool *done)
+{
+  int hit = -1;
+
+  PetscFunctionBegin;
+  *done = PETSC_FALSE;
+  if (!hipx_nlazy || hipx_lazy_run || w == x || w == y || x == y || !VecIsHIPX(w) || !VecIsHIPX(y) || w->map->n != x->map->n || y->map->n != x->map->n) PetscFunctionReturn(PETSC_SUCCESS);
+  for (int k = 0; k < hipx_nlazy; k++)
+    if (hipx_lazy[k].kind == 1 && hipx_lazy[k].y == x) hit = k;
+  /* (w may BE the recorded operation's x: KSPSolve_CG keeps A p in the vector it then overwrites with z, cg.c:145 "W = Z" -- every element is read before it
+     is written, by the same thread) */
+  if (hit < 0 || hipx_lazy[hit].x == y || !VecIsHIPX(hipx_lazy[hit].x)) PetscFunctionReturn(PETSC_SUCCESS);
+  for (int k = 0; k < hipx_nlazy; k++)
+    if (k != hit && (VecHIPXLazyTouches(&hipx_lazy[k], w) || VecHIPXLazyTouches(&hipx_lazy[k], x) || VecHIPXLazyTouches(&hipx_lazy[k], y) || VecHIPXLazyTouches(&hipx_lazy[k], hipx_lazy[hit].x)))
+      PetscFunctionReturn(PETSC_SUCCESS);
+  {
+    const HipxLazyOp o = hipx_lazy[hit];
+    hipx_lazy_run      = PETSC_TRUE; /* (the accessors below must not run the queue) */
+    PetscCall(VecHIPXCopyToDevice(y));
+    PetscCall(VecHIPXAllocate(w));
+    hipx_lazy_run = PETSC_FALSE;
+    VecHIPXRedCacheInvalidate(w);
+    {
+      /* a diagonal whose entries are all one (nonzero) value -- PCJACOBI on a constant-coefficient operator -- is not streamed: w = x * value, the same
+         products.  Looked at once per state of y (two device reductions). */
+      static PetscObjectId    cid    = 0;
+      static PetscObjectState cstate = 0;
+      static PetscBool        cconst = PETSC_FALSE;
+      static PetscScalar      cval   = 0.0;
+      PetscObjectState        st;
+      PetscCall(PetscObjectStateGet((PetscObject)y, &st));
+      if (cid != ((PetscObject)y)->id || cstate != st) {
+        double   mn = 0.0, mx = 1.0;
+        hipx_int im, ix;
+        PetscCallHIPX(hipxVecMin(VecHIPXGetExt(y)->d_array, y->map->n, &im, &mn));
+        PetscCallHIPX(hipxVecMax(VecHIPXGetExt(y)->d_array, y->map->n, &ix, &mx));
+        cid    = ((PetscObject)y)->id;
+        cstate = st;
+        cconst = (PetscBool)(mn == mx && mn != 0.0);
+        cval   = mn;
+      }
+      PetscCallHIPX(hipxVecAXPYPointwiseMultDotsBegin(VecHIPXGetExt(x)->d_array, o.s, VecHIPXGetExt(o.x)->d_array, VecHIPXGetExt(w)->d_array, cconst ? NULL : VecHIPXGetExt(y)->d_array, cval, x->map->n,
+                                                      VecHIPXRedCacheSlot(HIPX_RC_PWMULT)));
+    }
+    for (int k = hit; k + 1 < hipx_nlazy; k++) hipx_lazy[k] = hipx_lazy[k + 1];
+    hipx_nlazy--;
+    hipx_lazy_stat[3]++;
+    w->offloadmask = PETSC_OFFLOAD_GPU;
+    PetscCall(VecHIPXRedCachePut(HIPX_RC_PWMULT, w, x));
+    *done = PETSC_TRUE;
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* a second device buffer of the vector's size (kept for the next time) */
+static PetscErrorCode VecHIPXAltBuffer(Vec v, PetscScalar **alt)
+{
+  VecHIPXExt *e = VecHIPXGetExt(v);
+
+  PetscFunctionBegin;
+  if (!e->d_alt || e->d_alt_n < v->map->n) {
+    if (e->d_alt) PetscCallHIPX(hipxFree(e->d_alt));
+    e->d_alt = NULL;
+    PetscCallHIPX(hipxMalloc((void **)&e->d_alt, sizeof(PetscScalar) * (size_t)(v->map->n ? v->map->n : 1)));
+    e->d_alt_n = v->map->n;
+  }
+  *alt = e->d_alt;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static void VecHIPXSwapBuffers(Vec v)
+{
+  VecHIPXExt  *e  = VecHIPXGetExt(v);
+  PetscScalar *t  = e->d_array;
+  PetscInt     tn = e->d_n;
+
+  e->d_array = e->d_alt;
+  e->d_n     = e->d_alt_n;
+  e->d_alt   = t;
+  e->d_alt_n = tn;
+}
+
+/* MatMult(A, xx = p, yy = w) with exactly "x += a p; p = z + b p" recorded: the product kernel with the two updates as its prologue.  The kernel
+   rewrites p OUT OF PLACE (other workgroups still read the old direction in their halos), and w too when it is the vector z lives in (cg.c:145:
+   W = Z -- the halos read z while the rows' owners would be writing w over it): the vectors' two device buffers swap afterwards. */
+PetscErrorCode VecHIPXLazyTryCGProduct(hipxMat dA, Vec xx, Vec yy, PetscBool *done)
+{
+  PetscFunctionBegin;
+  *done = PETSC_FALSE;
+  if (hipx_nlazy != 2 || hipx_lazy_run || !VecIsHIPX(yy)) PetscFunctionReturn(PETSC_SUCCESS);
+  {
+    const HipxLazyOp o = hipx_lazy[0], q = hipx_lazy[1]; /* o: x += a p;  q: p = z + b p */
+    const PetscBool  walias = (PetscBool)(yy == q.x);
+    PetscScalar     *pnew, *wout;
+    int              fused = 0;
+
+    if (!(o.kind == 1 && q.kind == 2 && o.x == xx && q.y == xx && o.y != q.x && o.y != xx && q.x != xx && yy != xx && yy != o.y && yy->map->n == xx->map->n)) PetscFunctionReturn(PETSC_SUCCESS);
+    if (!VecHIPXGetExt(xx)->d_owned || (walias && !VecHIPXGetExt(yy)->d_owned)) PetscFunctionReturn(PETSC_SUCCESS); /* (a buffer somebody else owns cannot be swapped) */
+    PetscCall(VecHIPXAltBuffer(xx, &pnew));
+    if (walias) PetscCall(VecHIPXAltBuffer(yy, &wout));
+    else {
+      PetscCall(VecHIPXAllocate(yy));
+      wout = VecHIPXGetExt(yy)->d_array;
+    }
+    PetscCallHIPX(hipxMatMultCGDirectionDotBegin(dA, VecHIPXGetExt(xx)->d_array, pnew, VecHIPXGetExt(q.x)->d_array, 1.0, VecHIPXGetExt(o.y)->d_array, q.s, o.s, NULL, NULL, NULL, wout,
+                                                 VecHIPXRedCacheSlot(HIPX_RC_MATMULT), NULL, &fused));
+    if (!fused) PetscFunctionReturn(PETSC_SUCCESS); /* nothing was enqueued: the caller's accessors run the queue, then the plain product */
+    VecHIPXSwapBuffers(xx); /* the new direction lives in the other buffer now */
+    if (walias) VecHIPXSwapBuffers(yy);
+    VecHIPXRedCacheInvalidate(yy);
+    hipx_nlazy = 0;
+    hipx_lazy_stat[4]++;
+    yy->offloadmask = PETSC_OFFLOAD_GPU;
+    PetscCall(VecHIPXRedCachePut(HIPX_RC_MATMULT, xx, yy));
+    *done = PETSC_TRUE;
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 /* ------------------------------------------------------------------ host array access (ops->getarray & co) */
 static PetscErrorCode VecGetArray_HIPX(Vec v, PetscScalar **a)
 {
   PetscFunctionBegin;
+  PetscCall(VecHIPXLazySync(v));
   VecHIPXRedCacheInvalidate(v);
   PetscCall(VecHIPXCopyToHost(v));
   *a             = *(PetscScalar **)v->data;
@@ -278,6 +551,7 @@ static PetscErrorCode VecGetArray_HIPX(Vec v, PetscScalar **a)
 static PetscErrorCode VecGetArrayRead_HIPX(Vec v, const PetscScalar **a)
 {
   PetscFunctionBegin;
+  PetscCall(VecHIPXLazySync(v));
   PetscCall(VecHIPXCopyToHost(v));
   *a = *(PetscScalar **)v->data;
   PetscFunctionReturn(PETSC_SUCCESS);
@@ -286,6 +560,7 @@ static PetscErrorCode VecGetArrayRead_HIPX(Vec v, const PetscScalar **a)
 static PetscErrorCode VecGetArrayWrite_HIPX(Vec v, PetscScalar **a)
 {
   PetscFunctionBegin;
+  PetscCall(VecHIPXLazySync(v));
   VecHIPXRedCacheInvalidate(v);
   *a             = *(PetscScalar **)v->data;
   v->offloadmask = PETSC_OFFLOAD_CPU;
@@ -314,6 +589,7 @@ PetscBool hipx_vec_memtype_ops = PETSC_FALSE;
 static PetscErrorCode VecGetArrayAndMemType_HIPX(Vec v, PetscScalar **a, PetscMemType *m)
 {
   PetscFunctionBegin;
+  PetscCall(VecHIPXLazySync(v));
   VecHIPXRedCacheInvalidate(v);
   PetscCall(VecHIPXCopyToDevice(v));
   *a             = VecHIPXGetExt(v)->d_array;
@@ -325,6 +601,7 @@ static PetscErrorCode VecGetArrayAndMemType_HIPX(Vec v, PetscScalar **a, PetscMe
 static PetscErrorCode VecGetArrayReadAndMemType_HIPX(Vec v, const PetscScalar **a, PetscMemType *m)
 {
   PetscFunctionBegin;
+  PetscCall(VecHIPXLazySync(v));
   PetscCall(VecHIPXCopyToDevice(v));
   *a = VecHIPXGetExt(v)->d_array;
   if (m) *m = PETSC_MEMTYPE_HIP;
@@ -334,6 +611,7 @@ static PetscErrorCode VecGetArrayReadAndMemType_HIPX(Vec v, const PetscScalar **
 static PetscErrorCode VecGetArrayWriteAndMemType_HIPX(Vec v, PetscScalar **a, PetscMemType *m)
 {
   PetscFunctionBegin;
+  PetscCall(VecHIPXLazySync(v));
   VecHIPXRedCacheInvalidate(v);
   PetscCall(VecHIPXAllocate(v));
   *a             = VecHIPXGetExt(v)->d_array;
@@ -373,6 +651,7 @@ static PetscErrorCode (*parent_destroy_mpi)(Vec);
 static PetscErrorCode VecPlaceArray_HIPX(Vec v, const PetscScalar *a)
 {
   PetscFunctionBegin;
+  PetscCall(VecHIPXLazySync(v));
   VecHIPXRedCacheInvalidate(v);
   PetscCall(VecHIPXCopyToHost(v)); /* the original array must hold current values when it comes back (VecResetArray) */
   PetscCall((*parent_placearray)(v, a));
@@ -383,6 +662,7 @@ static PetscErrorCode VecPlaceArray_HIPX(Vec v, const PetscScalar *a)
 static PetscErrorCode VecReplaceArray_HIPX(Vec v, const PetscScalar *a)
 {
   PetscFunctionBegin;
+  PetscCall(VecHIPXLazySync(v));
   VecHIPXRedCacheInvalidate(v);
   PetscCall((*parent_replacearray)(v, a));
   v->offloadmask = PETSC_OFFLOAD_CPU;
@@ -392,6 +672,7 @@ static PetscErrorCode VecReplaceArray_HIPX(Vec v, const PetscScalar *a)
 static PetscErrorCode VecResetArray_HIPX(Vec v)
 {
   PetscFunctionBegin;
+  PetscCall(VecHIPXLazySync(v));
   VecHIPXRedCacheInvalidate(v);
   /* results computed on the device while the caller's array was placed must reach that array before it is handed back
      (Place / work on the GPU / Reset: PCApply_BJacobi_Multiblock bjacobi.c:886-895; the reference's device vectors do the
@@ -476,6 +757,14 @@ static PetscErrorCode VecAXPY_HIPX(Vec y, PetscScalar alpha, Vec x) /* VecAXPY_S
 
   PetscFunctionBegin;
   if (alpha == (PetscScalar)0.0) PetscFunctionReturn(PETSC_SUCCESS); /* bvec1.c:75 */
+  {
+    PetscBool rec;
+    PetscCall(VecHIPXLazyRecord(1, y, alpha, x, &rec));
+    if (rec) {
+      PetscCall(PetscLogFlops(2.0 * y->map->n));
+      PetscFunctionReturn(PETSC_SUCCESS);
+    }
+  }
   RD(x, dx, tx);
   RW(y, dy, ty);
   PetscCallHIPX(hipxVecAXPY(dy, alpha, dx, y->map->n));
@@ -495,6 +784,14 @@ static PetscErrorCode VecAYPX_HIPX(Vec y, PetscScalar beta, Vec x) /* VecAYPX_Se
   if (beta == (PetscScalar)0.0) {
     PetscCall(VecCopy_HIPX(x, y));
     PetscFunctionReturn(PETSC_SUCCESS);
+  }
+  {
+    PetscBool rec;
+    PetscCall(VecHIPXLazyRecord(2, y, beta, x, &rec));
+    if (rec) {
+      PetscCall(PetscLogFlops((beta == (PetscScalar)-1.0 ? 1.0 : 2.0) * y->map->n));
+      PetscFunctionReturn(PETSC_SUCCESS);
+    }
   }
   RD(x, dx, tx);
   RW(y, dy, ty);
@@ -568,6 +865,14 @@ static PetscErrorCode VecPointwiseMult_HIPX(Vec w, Vec x, Vec y) /* VecPointwise
   void              *tx, *ty, *tw;
 
   PetscFunctionBegin;
+  {
+    PetscBool done;
+    PetscCall(VecHIPXLazyTryAXPYPointwiseMult(w, x, y, &done)); /* "r -= a w" recorded and z = r .* d asked for: one kernel */
+    if (done) {
+      PetscCall(PetscLogFlops(w->map->n));
+      PetscFunctionReturn(PETSC_SUCCESS);
+    }
+  }
   RD(x, dx, tx);
   RD(y, dy, ty);
   if (w == x || w == y) RW(w, dw, tw);
@@ -863,8 +1168,11 @@ static PetscErrorCode VecHIPXFreeDevice(Vec v)
   VecHIPXExt *e = VecHIPXGetExt(v);
 
   PetscFunctionBegin;
+  if (e->magic == VECHIPX_MAGIC) PetscCall(VecHIPXLazySync(v));
   VecHIPXRedCacheInvalidate(v);
   if (e->magic == VECHIPX_MAGIC && e->d_array && e->d_owned) PetscCallHIPX(hipxFree(e->d_array));
+  if (e->magic == VECHIPX_MAGIC && e->d_alt) PetscCallHIPX(hipxFree(e->d_alt));
+  e->d_alt   = NULL;
   e->d_array = NULL;
   e->magic   = 0;
   PetscFunctionReturn(PETSC_SUCCESS);

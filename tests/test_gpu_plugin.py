@@ -335,6 +335,65 @@ def test_reduction_cache_returns_what_the_separate_kernels_return(args):
     assert (np.abs(on_f - on) / on).max() <= (1e-11 if tol == 1e-12 else 1e-8)
 
 
+LAZY_CASES = ["-stencil 7 -n 48 -ksp_type cg -pc_type jacobi -ksp_norm_type preconditioned -ksp_rtol 1e-50 -ksp_max_it 60",
+              "-stencil 7 -n 64 -ksp_type cg -pc_type jacobi -ksp_norm_type preconditioned -ksp_rtol 1e-50 -ksp_max_it 40 -mat_aijhipx_spmv_variant 30",   # march form: product prologue
+              "-stencil 7 -n 48 -ksp_type cg -pc_type jacobi -ksp_norm_type natural -ksp_rtol 1e-50 -ksp_max_it 40 -mat_aijhipx_spmv_variant 30",          # planes of 2304 = 2 x 1024 + 256 rows
+              "-stencil 27 -n 24 -ksp_type cg -pc_type jacobihipx -ksp_norm_type natural -ksp_rtol 1e-50 -ksp_max_it 40",
+              "-stencil 7 -n 32 -ksp_type cg -pc_type jacobi -ksp_norm_type preconditioned -ksp_rtol 1e-50 -ksp_max_it 30 -mat_axpy",  # a diagonal that is NOT one value: streamed
+              "-stencil 7 -n 32 -ksp_type cg -pc_type jacobi -ksp_norm_type natural -ksp_rtol 1e-50 -ksp_max_it 30 -mat_ops",
+              "-stencil 7 -n 32 -ksp_type cg -pc_type jacobi -ksp_norm_type unpreconditioned -ksp_rtol 1e-50 -ksp_max_it 40",
+              "-stencil 7 -n 32 -ksp_type cg -pc_type none -ksp_rtol 1e-50 -ksp_max_it 40 -mat_aijhipx_spmv_variant 30",
+              "-stencil 7 -n 24 -ksp_type cg -pc_type sor -ksp_rtol 1e-50 -ksp_max_it 30",
+              "-stencil 7 -n 24 -ksp_type cg -ksp_cg_single_reduction -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 40",
+              "-stencil 7 -n 24 -ksp_type cr -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 40",
+              "-stencil 7 -n 24 -ksp_type gmres -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 45",
+              "-stencil 7 -n 24 -ksp_type bcgs -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 12",
+              "-stencil 7 -n 24 -ksp_type chebyshev -pc_type jacobi -ksp_max_it 30 -ksp_norm_type preconditioned -ksp_rtol 1e-50",
+              "-stencil 7 -n 24 -ksp_type richardson -pc_type jacobi -ksp_max_it 30 -ksp_rtol 1e-50 -ksp_richardson_scale 0.1"]
+
+
+@pytest.mark.parametrize("args", LAZY_CASES)
+def test_lazy_fusion_leaves_every_history_as_it_was(args):
+    """Round 5: VecAXPY / VecAYPX on hipx vectors are recorded and run later -- fused into VecPointwiseMult (PCApply_Jacobi), into the product
+    kernel's prologue (march-form matrices; the direction vector's two device buffers swap), or as one direction kernel (plugin/vechipx.c: lazy
+    fusion).  Every fused kernel does the separate kernels' operations element by element: with EXACT reductions the residual histories of the
+    reference's UNMODIFIED Krylov loops with and without it are the same doubles (the iterates feed every later residual: one wrong or stale element
+    would show), for every solver here; with the default reductions they differ by the association of the partial sums only."""
+    a = args.split() + ["-history", "-hipx_lazy_min_size", "1"]
+    on_out = run("ref_driver", a + HIPX + ["-hipx_reductions", "exact", "-hipx_lazy_view"])
+    on = hist_of(on_out)
+    off = hist_of(run("ref_driver", a + HIPX + ["-hipx_reductions", "exact", "-hipx_lazy_fusion", "0"]))
+    assert len(on) == len(off) > (10 if "-mat_" not in args else 3) and np.array_equal(on, off), np.abs(on - off).max()
+    line = [ln for ln in on_out.splitlines() if ln.startswith("hipx lazy fusion:")]
+    if "-ksp_type cg" in args and "single_reduction" not in args:
+        assert line, on_out[-400:]
+        nums = [int(t) for t in line[0].replace(";", " ").replace(",", " ").split() if t.isdigit()]
+        rec, alone, pairs, inpw, inmm = nums[:5]
+        its = len(on) - 1
+        assert rec >= 3 * its - 3
+        if "-mat_" in args:
+            assert inpw >= its - 1, line
+        elif "jacobi" in args and "unpreconditioned" not in args:
+            assert inpw >= its - 1, line  # "r -= a w" inside PCApply_Jacobi's kernel, every iteration
+        if "spmv_variant 30" in args:
+            assert inmm >= its - 2, line  # "x += a p; p = z + b p" as the product's prologue
+        else:
+            assert pairs >= its - 2, line  # ... or as one direction kernel
+    on_f = hist_of(run("ref_driver", a + HIPX))
+    off_f = hist_of(run("ref_driver", a + HIPX + ["-hipx_lazy_fusion", "0"]))
+    assert len(on_f) == len(off_f) == len(on)
+    tol = 1e-12 if all(k not in args for k in ("bcgs", "gmres", "cr")) else 1e-9
+    assert (np.abs(on_f - off_f) / off_f).max() <= tol
+
+
+def test_lazy_fusion_is_invisible_to_the_vector_interface():
+    """The reference's own Vec known-answer test (exact-text golden: norms, dots and printed entries taken right after VecAXPY / VecAYPX / VecWAXPY /
+    VecPointwiseMult on the same vectors) with every operation recorded (-hipx_lazy_min_size 1) and with the feature off: the same text."""
+    on = run("kat_vec_tut_ex1", HIPX[:4] + ["-hipx_lazy_min_size", "1"])
+    off = run("kat_vec_tut_ex1", HIPX[:4] + ["-hipx_lazy_fusion", "0"])
+    assert on == off and "error" not in on.lower().replace("norm of error", "")
+
+
 def test_reduction_cache_entries_die_with_the_first_write():
     """The reference's own Vec tests with the cache on (it is on by default in every other test of this file too): ex1 of the tutorials prints
     norms and dots taken right after VecPointwiseMult / VecScale / VecAXPY on the same vectors -- a stale entry would show up in its exact-text golden."""
