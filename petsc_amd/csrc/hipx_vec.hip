@@ -445,33 +445,21 @@ __global__ __launch_bounds__(kRedThreads) void mdot_wide_kernel(const double *x,
         const hipx_int q = p + u * kRedThreads;
         xa[u]            = (q < c1) ? x2[q] : make_double2(0.0, 0.0);
       }
-      // the vectors in batches of B: all B x U loads of a batch are issued before the first product (round 5: one vector at a time left 32 KiB in flight
-      // per CU -- the kernel sat at 0.48 of the HBM peak on GMRES's 16-vector average).  A batch that reaches past nv re-reads vector nv - 1 (cache hits);
-      // its sums are never looked at.  Per sum the additions are the ones of the one-at-a-time loop, in the same order.
-      constexpr int B = COMP ? 1 : 4;
 #pragma unroll
-      for (int v0 = 0; v0 < NVMAX; v0 += B) {
-        if (v0 < nv) {
-          double2 ya[B][U];
+      for (int v = 0; v < NVMAX; v++) {
+        if (v < nv) {
+          const double2 *y2 = reinterpret_cast<const double2 *>(ys.y[v]);
+          double2        ya[U];
 #pragma unroll
-          for (int b = 0; b < B; b++) {
-            const int      vv = (v0 + b < nv) ? v0 + b : nv - 1;
-            const double2 *y2 = reinterpret_cast<const double2 *>(ys.y[vv]);
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-              const hipx_int q = p + u * kRedThreads;
-              ya[b][u]         = (q < c1) ? y2[q] : make_double2(0.0, 0.0);
-            }
+          for (int u = 0; u < U; u++) {
+            const hipx_int q = p + u * kRedThreads;
+            ya[u]            = (q < c1) ? y2[q] : make_double2(0.0, 0.0);
           }
 #pragma unroll
-          for (int b = 0; b < B; b++)
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-              if (v0 + b < NVMAX) {
-                acc[v0 + b].prod(xa[u].x, ya[b][u].x);
-                acc[v0 + b].prod(xa[u].y, ya[b][u].y);
-              }
-            }
+          for (int u = 0; u < U; u++) {
+            acc[v].prod(xa[u].x, ya[u].x);
+            acc[v].prod(xa[u].y, ya[u].y);
+          }
         }
       }
     }
