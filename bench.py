@@ -186,7 +186,11 @@ def ref_driver(np_, args, plugin=False, timeout=900, bind=False, exact=False):
         out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=timeout).stdout
         m = re.search(r"iterations (\d+) reason (-?\d+) error (\S+) KSPSolve_seconds (\S+)", out)
         hist = [float(l.split()[2]) for l in out.splitlines() if l.startswith("hist ")]
-        return {"its": int(m.group(1)), "reason": int(m.group(2)), "error": float(m.group(3)), "seconds": float(m.group(4)), "history": hist}
+        res = {"its": int(m.group(1)), "reason": int(m.group(2)), "error": float(m.group(3)), "seconds": float(m.group(4)), "history": hist}
+        m2 = re.search(r"second_solve iterations (\d+) KSPSolve_seconds (\S+)", out)  # (-resolve: the same solve again, nothing left to set up)
+        if m2:
+            res["second_its"], res["second_seconds"] = int(m2.group(1)), float(m2.group(2))
+        return res
     except Exception:
         return None
 
@@ -904,6 +908,7 @@ def compact_line(out):
         c["cpu_baseline"] = None
     if out.get("plugin"):
         c["plugin_it_s"] = {k: _num(v.get("iterations_per_s"), 5) for k, v in out["plugin"].items() if isinstance(v, dict)}
+        c["plugin_second_solve_it_s"] = {k: _num(v.get("second_solve_iterations_per_s"), 5) for k, v in out["plugin"].items() if isinstance(v, dict) and v.get("second_solve_iterations_per_s")}
     oc = out.get("other_configs")
     if oc:
         legs = {}
@@ -953,7 +958,7 @@ def compact_line(out):
     # never longer than the driver can read: drop the optional groups, least important first
     def fits():
         return len(json.dumps(c)) <= LINE_LIMIT
-    for victim in ("per_rank", "plugin_it_s", "multi_gpu"):
+    for victim in ("per_rank", "plugin_second_solve_it_s", "plugin_it_s", "multi_gpu"):
         if fits():
             break
         c.pop(victim, None)
@@ -1218,10 +1223,12 @@ def main():
                 if not (always and room(60)) and not (args.full or room(95)):
                     plug[ksp] = {"what": label, "skipped": "budget"}
                     continue
-                a = [x if x != "cg" else ksp for x in head.driver_args(400)]
+                a = [x if x != "cg" else ksp for x in head.driver_args(400)] + ["-resolve"]
                 rr = ref_driver(1, a, plugin=True)
                 plug[ksp] = {"what": label, "iterations_per_s": (rr["its"] / rr["seconds"]) if rr else None, "iterations": rr["its"] if rr else None,
                              "KSPSolve_seconds": rr["seconds"] if rr else None}
+                if rr and rr.get("second_seconds"):  # the second KSPSolve of the same process: formats and buffers exist
+                    plug[ksp]["second_solve_iterations_per_s"] = rr["second_its"] / rr["second_seconds"]
             # Chebyshev as a smoother (first kind, no norms, bounds given: 7-pt Poisson + Jacobi has its spectrum in (0, 2)): the
             # reference's KSPSolve_Chebyshev over the hipx types (4 kernels per iteration) and -ksp_type chebyshevhipx (SpMV + one fused kernel)
             for label, ksp in (("reference KSPSolve_Chebyshev over hipx types (smoother configuration: -ksp_norm_type none)", "chebyshev"),

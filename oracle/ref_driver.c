@@ -573,6 +573,19 @@ assembled:
   PetscCall(VecAXPY(x, -1.0, u));
   PetscCall(VecNorm(x, NORM_2, &norm));
   PetscCall(PetscPrintf(PETSC_COMM_WORLD, "iterations %" PetscInt_FMT " reason %d error %.17g KSPSolve_seconds %.6e\n", its, (int)reason, (double)norm, (double)(t1 - t0)));
+  {
+    PetscBool resolve = PETSC_FALSE; /* -resolve: the same solve once more from x = 0 -- every format and buffer a first solve builds exists: the time of the iterations alone */
+    PetscCall(PetscOptionsGetBool(NULL, NULL, "-resolve", &resolve, NULL));
+    if (resolve) {
+      PetscCall(VecSet(x, 0.0));
+      PetscCall(PetscTime(&t0));
+      PetscCall(KSPSolve(ksp, b, x));
+      PetscCall(VecNorm(x, NORM_INFINITY, &norm));
+      PetscCall(PetscTime(&t1));
+      PetscCall(KSPGetIterationNumber(ksp, &its));
+      PetscCall(PetscPrintf(PETSC_COMM_WORLD, "second_solve iterations %" PetscInt_FMT " KSPSolve_seconds %.6e\n", its, (double)(t1 - t0)));
+    }
+  }
   PetscCall(PetscFree(hist));
   PetscCall(KSPDestroy(&ksp));
   PetscCall(VecDestroy(&u));
