@@ -2829,6 +2829,21 @@ void free_templates(hipxMat A)
   A->ntmpl = A->tmpl_nent = 0;
 }
 
+// HIPX_SETUP_TRACE=1 (developer switch): wall-clock stamps of the format decisions a product goes through (device synchronised at every stamp; the
+// first product of a matrix builds its formats -- where that time goes)
+static void setup_trace(const char *what)
+{
+  static const bool on = getenv("HIPX_SETUP_TRACE") != nullptr;
+  if (!on) return;
+  static double t_prev = 0.0;
+  (void)hipDeviceSynchronize();
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  const double t = ts.tv_sec + 1e-9 * ts.tv_nsec;
+  fprintf(stderr, "[hipx setup trace] %-34s %+9.3f ms\n", what, t_prev == 0.0 ? 0.0 : 1e3 * (t - t_prev));
+  t_prev = t;
+}
+
 template <typename IT>
 int build_templates(hipxMat A)
 {
@@ -2859,6 +2874,7 @@ int build_templates(hipxMat A)
   HIPX_HIP(hipMemcpyAsync(hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
   HIPX_HIP(hipStreamSynchronize(st));
   HIPX_LAUNCH_CHECK();
+  setup_trace("  templates: row hashes + distinct");
   if (hc[1] || hc[0] > cap || !hc[0]) return HIPX_SUCCESS;  // more than 256 distinct rows somewhere: no templates
   std::vector<uint64_t> keys(hc[0]);
   HIPX_HIP(hipMemcpy(keys.data(), d_list, sizeof(uint64_t) * hc[0], hipMemcpyDeviceToHost));
@@ -2935,6 +2951,7 @@ int build_templates(hipxMat A)
   HIPX_HIP(hipMemcpyAsync(hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
   HIPX_HIP(hipStreamSynchronize(st));
   HIPX_LAUNCH_CHECK();
+  setup_trace("  templates: ids + table + verify");
   if (hc[0]) return HIPX_SUCCESS;  // a hash collision (or a column outside the matrix): keep the general formats
   A->ntmpl     = nt;
   A->tmpl_nent = nent;
@@ -3637,6 +3654,7 @@ int use_templates(hipxMat A, bool &use)
   int ierr;
   if (A->auto_sel) {  // auto: only matrices whose values already fit the 256-entry dictionary are worth the hashing passes
     if ((ierr = ensure_vdict(A))) return ierr;
+    setup_trace("  value dictionary");
     if (!A->vd_ok) return HIPX_SUCCESS;
   }
   if ((ierr = ensure_templates(A))) return ierr;
@@ -3801,9 +3819,11 @@ __global__ __launch_bounds__(256) void spmv_inode_kernel(hipx_int m, const IT *_
 template <typename IT, int MODE, bool DOT>
 int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, double *dotpart)
 {
+  setup_trace("product: enter");
   {
     bool ip = false, ips = false;
     int  ierr = use_inode_pair(A, ip, ips);
+    setup_trace("inode decision");
     if (ierr) return ierr;
     if (ip && ips) return hipxSellLaunch_(A->sell_state, MODE, DOT ? 1 : 0, x, yin, yout, dotpart, 1);
     if (ip) {
@@ -3816,14 +3836,20 @@ int launch_spmv_t(hipxMat A, const double *x, const double *yin, double *yout, d
   {
     bool sl = false;
     int  ierr = use_sell(A, sl);
+    setup_trace("SELL decision");
     if (ierr) return ierr;
     if (sl) return hipxSellLaunch_(A->sell_state, MODE, DOT ? 1 : 0, x, yin, yout, dotpart, 0);
   }
   {
     bool tm = false;
     int  ierr = use_templates(A, tm);
+    setup_trace("row templates (decision + build)");
     if (ierr) return ierr;
-    if (tm) return launch_tmpl<MODE, DOT>(A, x, yin, yout, dotpart, nullptr);
+    if (tm) {
+      ierr = launch_tmpl<MODE, DOT>(A, x, yin, yout, dotpart, nullptr);
+      setup_trace("template product launched");
+      return ierr;
+    }
   }
   {
     bool tp = false;
