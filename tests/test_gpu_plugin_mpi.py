@@ -157,6 +157,31 @@ def test_ksp_history_np_vs_cpu_mpi(np_, args, tol):
     assert abs(t_gpu[2] - t_cpu[2]) <= 1e-10 * max(1.0, abs(t_cpu[2])) + 1e-6 * abs(t_cpu[2])
 
 
+@pytest.mark.parametrize("np_,args", [(2, "-stencil 7 -n 20 -ksp_type cg -pc_type jacobi -ksp_norm_type preconditioned -ksp_rtol 1e-50 -ksp_max_it 40"),
+                                      (3, "-stencil 27 -n 16 -ksp_type cg -pc_type jacobi -ksp_norm_type natural -ksp_rtol 1e-50 -ksp_max_it 30"),
+                                      (2, "-stencil 7 -n 16 -ksp_type cg -pc_type jacobi -ksp_norm_type unpreconditioned -ksp_rtol 1e-50 -ksp_max_it 30"),
+                                      (2, "-stencil 27 -n 12 -ksp_type gmres -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 35"),
+                                      (3, "-stencil 7 -n 16 -ksp_type bcgs -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 12")])
+def test_lazy_fusion_on_mpi_vectors(np_, args):
+    """Round 5: the vector type's lazy fusion (VecAXPY / VecAYPX recorded, run fused) with VECMPIHIPX on real MPI ranks: the recorded operations are the
+    ranks' local parts, the MPIAIJ product reaches the vectors through the accessors (which run what is recorded: x += a p and p = z + b p as one kernel),
+    PCJACOBI's VecPointwiseMult takes r -= a w into its kernel.  With exact reductions the histories with and without it are the same doubles."""
+    a = args.split() + ["-history", "-mat_type", "aijhipx", "-hipx_reductions", "exact", "-hipx_lazy_min_size", "1"]
+    on_txt = mpirun(np_, "ref_driver", a + ["-hipx_lazy_view"], True)
+    h_on, _, t_on = parse_driver(on_txt)
+    h_off, _, t_off = parse_driver(mpirun(np_, "ref_driver", a + ["-hipx_lazy_fusion", "0"], True))
+    assert len(h_on) == len(h_off) > 10 and h_on == h_off and t_on[:2] == t_off[:2]
+    if "-ksp_type cg" in args:
+        lines = [ln for ln in on_txt.splitlines() if ln.startswith("hipx lazy fusion:")]
+        assert len(lines) == np_, on_txt[-600:]
+        for ln in lines:
+            nums = [int(t) for t in ln.replace(";", " ").replace(",", " ").split() if t.isdigit()]
+            its = len(h_on) - 1
+            assert nums[0] >= 3 * its - 3 and nums[2] >= its - 2, ln  # every rank: the direction pair as one kernel
+            if "unpreconditioned" not in args:
+                assert nums[3] >= its - 1, ln  # ... and r -= a w inside PCApply_Jacobi's kernel
+
+
 @pytest.mark.parametrize("halo", ["ipc", "host"])
 def test_mpiaijhipx_ghost_exchange_transports(halo):
     """MatMult_MPIAIJ over hipx blocks with the ghost exchange ON THE DEVICE (ranks share this box's GPU, so the transport is
