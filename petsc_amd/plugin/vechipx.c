@@ -416,30 +416,33 @@ static PetscErrorCode VecHIPXLazyRecord(int kind, Vec y, PetscScalar s, Vec x, P
 
 static PetscBool VecHIPXLazyTouches(const HipxLazyOp *o, Vec v) { return (PetscBool)(o->y == v || o->x == v); }
 
-/* VecPointwiseMult(w, x, y) with "x += s u" recorded and nothing else recorded on w, x, y, u: one kernel, sums into the reduction cache */
+/* VecPointwiseMult(w, x, y) -- or VecCopy(x, w) when y == NULL: PCApply_None -- with "x += s u" recorded and nothing else recorded on w, x, y, u: one
+   kernel, sums into the reduction cache */
 static PetscErrorCode VecHIPXLazyTryAXPYPointwiseMult(Vec w, Vec x, Vec y, PetscBool *done)
 {
   int hit = -1;
 
   PetscFunctionBegin;
   *done = PETSC_FALSE;
-  if (!hipx_nlazy || hipx_lazy_run || w == x || w == y || x == y || !VecIsHIPX(w) || !VecIsHIPX(y) || w->map->n != x->map->n || y->map->n != x->map->n) PetscFunctionReturn(PETSC_SUCCESS);
+  if (!hipx_nlazy || hipx_lazy_run || w == x || w == y || x == y || !VecIsHIPX(w) || (y && !VecIsHIPX(y)) || w->map->n != x->map->n || (y && y->map->n != x->map->n)) PetscFunctionReturn(PETSC_SUCCESS);
   for (int k = 0; k < hipx_nlazy; k++)
     if (hipx_lazy[k].kind == 1 && hipx_lazy[k].y == x) hit = k;
   /* (w may BE the recorded operation's x: KSPSolve_CG keeps A p in the vector it then overwrites with z, cg.c:145 "W = Z" -- every element is read before it
      is written, by the same thread) */
   if (hit < 0 || hipx_lazy[hit].x == y || !VecIsHIPX(hipx_lazy[hit].x)) PetscFunctionReturn(PETSC_SUCCESS);
   for (int k = 0; k < hipx_nlazy; k++)
-    if (k != hit && (VecHIPXLazyTouches(&hipx_lazy[k], w) || VecHIPXLazyTouches(&hipx_lazy[k], x) || VecHIPXLazyTouches(&hipx_lazy[k], y) || VecHIPXLazyTouches(&hipx_lazy[k], hipx_lazy[hit].x)))
+    if (k != hit && (VecHIPXLazyTouches(&hipx_lazy[k], w) || VecHIPXLazyTouches(&hipx_lazy[k], x) || (y && VecHIPXLazyTouches(&hipx_lazy[k], y)) || VecHIPXLazyTouches(&hipx_lazy[k], hipx_lazy[hit].x)))
       PetscFunctionReturn(PETSC_SUCCESS);
   {
     const HipxLazyOp o = hipx_lazy[hit];
     hipx_lazy_run      = PETSC_TRUE; /* (the accessors below must not run the queue) */
-    PetscCall(VecHIPXCopyToDevice(y));
+    if (y) PetscCall(VecHIPXCopyToDevice(y));
     PetscCall(VecHIPXAllocate(w));
     hipx_lazy_run = PETSC_FALSE;
     VecHIPXRedCacheInvalidate(w);
-    {
+    if (!y) /* w = x: the kernel's multiplication by 1.0 returns its operand, bit for bit */
+      PetscCallHIPX(hipxVecAXPYPointwiseMultDotsBegin(VecHIPXGetExt(x)->d_array, o.s, VecHIPXGetExt(o.x)->d_array, VecHIPXGetExt(w)->d_array, NULL, 1.0, x->map->n, VecHIPXRedCacheSlot(HIPX_RC_PWMULT)));
+    else {
       /* a diagonal whose entries are all one (nonzero) value -- PCJACOBI on a constant-coefficient operator -- is not streamed: w = x * value, the same
          products.  Looked at once per state of y (two device reductions). */
       static PetscObjectId    cid    = 0;
@@ -710,6 +713,11 @@ static PetscErrorCode VecCopy_HIPX(Vec x, Vec y) /* VecCopy_Seq bvec2.c:151 */
 
   PetscFunctionBegin;
   if (x == y) PetscFunctionReturn(PETSC_SUCCESS);
+  {
+    PetscBool done;
+    PetscCall(VecHIPXLazyTryAXPYPointwiseMult(y, x, NULL, &done)); /* "r -= a w" recorded and z = r asked for (PCApply_None, pcnone.c): one kernel, z.z and z.r with it */
+    if (done) PetscFunctionReturn(PETSC_SUCCESS);
+  }
   RD(x, dx, tx);
   WR(y, dy, ty);
   PetscCallHIPX(hipxVecCopy(dx, dy, x->map->n));

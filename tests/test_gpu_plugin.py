@@ -373,7 +373,7 @@ def test_lazy_fusion_leaves_every_history_as_it_was(args):
         assert rec >= 3 * its - 3
         if "-mat_axpy" in args or "-mat_ops" in args:
             assert inpw >= its - 1, line
-        elif "jacobi" in args and "unpreconditioned" not in args:
+        elif ("jacobi" in args or "-pc_type none" in args) and "unpreconditioned" not in args:
             assert inpw >= its - 1, line  # "r -= a w" inside PCApply_Jacobi's kernel, every iteration
         if "spmv_variant 30" in args:
             assert inmm >= its - 2, line  # "x += a p; p = z + b p" as the product's prologue
