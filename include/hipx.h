@@ -270,6 +270,14 @@ int hipxMatMultDotBegin(hipxMat A, const double *x, double *y, int slot, double 
    five reference loops, hence the same bits.  The caller then forms s = A z and the three sums z.z, z.s, z.r in ONE reduction (hipxVecMDot /
    hipxVecMDotAllreduce with y = {z, s, r}). */
 int hipxCGSingleReductionUpdate(double *p, double *w, double *x, double *r, double *z, const double *s, const double *d, double b, double a, hipx_int n);
+/* round 5: the launch-ahead form.  The scalars are formed on the device from dev_sums3 = {z.z, z.s, z.r} of the reduction queued before (hipxVecMDotBegin /
+   hipxVecMDotBeginAllreduce with y = {z, s, r}) and dev_state_old = {beta, dpi, a} of the iteration before -- b = beta / betaold (cg.c:464), dpi = delta - beta *
+   beta * dpiold / (betaold * betaold) (cg.c:478), a = beta / dpi (cg.c:488), the host's expressions in the host's order -- and dev_state_new <- {beta, dpi, a}.
+   The x update applied is the one the iteration BEFORE left behind (x += a_old p_old, before p changes): the caller applies the last one itself. */
+int hipxCGSingleReductionUpdateDev(double *p, double *w, double *x, double *r, double *z, const double *s, const double *d, const double *dev_sums3, const double *dev_state_old,
+                                   double *dev_state_new, hipx_int n);
+/* x . y_j for j < nv <= 16, enqueued only: hipxRedEnd(slot, nv, ...) collects the sums; dev_results receives a device copy for the kernels queued behind */
+int hipxVecMDotBegin(const double *x, hipx_int nv, const double *const *y, hipx_int n, int slot, double *dev_results);
 /* The CG direction update as the PROLOGUE of the product (round 4): p_new = (z * dconst) + b p_old (cg.c:248-249, VecAYPX dvec2.c:774; z = the
    preconditioned residual with dconst = 1, or the residual itself with the constant Jacobi diagonal / PCNONE), x += a p_old (cg.c:305 of the
    iteration before), w = A p_new, dot = p_new . w (cg.c:257-258) in ONE kernel -- element by element the operations of hipxCGAypxAxpyDev / R
@@ -347,6 +355,7 @@ int hipxMatMultAddMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, doubl
    their scalars from device memory) can be queued before the host has seen the sums.  hipxMatMultMPIDotBegin = MatMult_MPIAIJ +
    VecTDot_MPI (cg.c:257-258); hipxCGFusedUpdateBeginAllreduce = hipxCGFusedUpdateBegin + the 16-byte all-reduce of its two sums. */
 int hipxMatMultMPIDotBegin(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *lvec, double *y, hipx_int n, int slot, double *dev_dot);
+int hipxVecMDotBeginAllreduce(const double *x, hipx_int nv, const double *const *y, hipx_int n, int slot, double *dev_results); /* the same, all-reduced on the stream */
 int hipxCGFusedUpdateBeginAllreduce(double *x, double *r, double *z, const double *p, const double *w, const double *d, double dconst, const double *dev_beta, const double *dev_dpi,
                                     hipx_int n, int slot, double *dev_sums2);
 /* which transport the next exchange of this plan takes: 1 = IPC peer stores, 2 = RCCL send/recv, 0 = none set up */

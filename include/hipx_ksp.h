@@ -68,7 +68,8 @@ typedef struct {
   double   a_pending;
   int      defer_flush;      /* 1: HipxKSPCGStep may return with the x update pending; the caller ends with HipxKSPCGFlush */
   int      external_test;    /* 1: the caller runs its own convergence test after every step (the PETSc plugin: ksp->converged) */
-  int      pipeline;         /* fused CG on one rank: enqueue iteration i+1 before the host has seen the sums of iteration i (default 1) */
+  int      pipeline;         /* fused CG: enqueue iteration i+1 before the host has seen the sums of iteration i (default 1); 2: several ranks stay host-synchronised;
+                                with single_reduction: 4 = the launch-ahead form of the single-reduction loop (round 5), anything else = host-synchronised */
   double  *dscal;            /* device scalars of the launch-ahead path: [0] p.w, [2+2q] z.z, [3+2q] z.r of the iterations of parity q */
   int      single_reduction; /* CG: KSPCGUseSingleReduction (cg.c:364-534): one reduction stage per iteration (three sums in one all-reduce), two more work vectors */
   double  *S, *W;            /* its work vectors S = A z and W (= A p by recurrence) */

@@ -445,6 +445,20 @@ int hipxMatMultMPIDotBegin(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, 
   return red_signal(slot, c.d_red, 1, dev_dot);
 }
 
+// hipxVecMDotBegin with the sums all-reduced on the stream (the single-reduction CG's one 24-byte all-reduce per iteration, launch-ahead form)
+int hipxVecMDotBeginAllreduce(const double *x, hipx_int nv, const double *const *y, hipx_int n, int slot, double *dev_results)
+{
+  HIPX_CHECK_INIT();
+  Comm &c = cm();
+  HIPX_ARG(c.active && nv >= 1 && nv <= 16 && slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2 && dev_results, "communicator not initialised / bad slot / nv");
+  int ierr;
+  if (n > 0) {
+    if ((ierr = launch_mdot_nosignal(x, (int)nv, y, n, slot, c.d_red))) return ierr;
+  } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * 2 * (size_t)nv, rt().compute));
+  if ((ierr = allreduce_dev(c.d_red, (int)nv, red_pairs()))) return ierr;
+  return red_signal(slot, c.d_red, (int)nv, dev_results);
+}
+
 int hipxCGFusedUpdateBeginAllreduce(double *x, double *r, double *z, const double *p, const double *w, const double *d, double dconst, const double *dev_beta, const double *dev_dpi,
                                     hipx_int n, int slot, double *dev_sums2)
 {

@@ -260,6 +260,38 @@ __global__ __launch_bounds__(kEwThreads) void cg_sr_update_kernel(double *p, dou
   }
 }
 
+// The same with its scalars formed ON THE DEVICE (round 5: launch-ahead single-reduction CG): sums = {z.z, z.s, z.r} of the reduction queued before this
+// kernel (delta = sums[1], beta = sums[2]), st_old = {beta, dpi, a} of the iteration before, st_new <- {beta, dpi, a} of this one (one thread writes it: the
+// next iteration's kernel reads it).  b = beta / betaold (cg.c:464), dpi = delta - beta * beta * dpiold / (betaold * betaold) (cg.c:478), a = beta / dpi
+// (cg.c:488): the host's expressions in the host's order -- the same doubles.  The x update is the one the iteration BEFORE left behind (x += a_old p_old,
+// cg.c:490 of that iteration, applied before p changes), so that whatever has been queued ahead when the host stops the loop has applied exactly the
+// updates of completed iterations; the host applies the last one (HipxKSPCGFlush).
+__global__ __launch_bounds__(kEwThreads) void cg_sr_update_dev_kernel(double *p, double *w, double *x, double *r, double *z, const double *s, const double *d, const double *sums,
+                                                                      const double *st_old, double *st_new, hipx_int n)
+{
+  const double beta = sums[2], delta = sums[1], betaold = st_old[0], dpiold = st_old[1], aold = st_old[2];
+  const double b    = beta / betaold;
+  const double dpi  = delta - beta * beta * dpiold / (betaold * betaold);
+  const double a    = beta / dpi;
+  const double ma   = -a;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st_new[0] = beta;
+    st_new[1] = dpi;
+    st_new[2] = a;
+  }
+  for (hipx_int i = (hipx_int)blockIdx.x * kEwThreads + threadIdx.x; i < n; i += (hipx_int)gridDim.x * kEwThreads) {
+    const double po = p[i];
+    x[i]            = x[i] + aold * po;
+    const double pn = z[i] + b * po;
+    const double wn = s[i] + b * w[i];
+    p[i] = pn;
+    w[i] = wn;
+    const double rn = r[i] + ma * wn;
+    r[i] = rn;
+    z[i] = d ? rn * d[i] : rn;
+  }
+}
+
 // ---------------------------------------------------------------- swap
 __global__ __launch_bounds__(kEwThreads) void swap_kernel(double *x, double *y, hipx_int n)
 {
@@ -1552,6 +1584,31 @@ int hipxCGSingleReductionUpdate(double *p, double *w, double *x, double *r, doub
   cg_sr_update_kernel<<<(unsigned)(g < 1 ? 1 : g), kEwThreads, 0, rt().compute>>>(p, w, x, r, z, s, d, b, a, n);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
+}
+
+int hipxCGSingleReductionUpdateDev(double *p, double *w, double *x, double *r, double *z, const double *s, const double *d, const double *dev_sums3, const double *dev_state_old,
+                                   double *dev_state_new, hipx_int n)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(dev_sums3 && dev_state_old && dev_state_new && dev_state_old != dev_state_new, "null / aliased scalar blocks");
+  HIPX_ARG(n <= 0 || (p && w && x && r && z && s), "null argument");
+  hipx_int g = (n + kEwThreads * 2 - 1) / (kEwThreads * 2);
+  if (g > 8192) g = 8192;
+  cg_sr_update_dev_kernel<<<(unsigned)(g < 1 ? 1 : g), kEwThreads, 0, rt().compute>>>(p, w, x, r, z, s, d, dev_sums3, dev_state_old, dev_state_new, n);  // (n == 0: the scalar block still advances)
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+// x . y_j, j < nv <= 16, enqueued: hipxRedEnd(slot, nv, ...) collects the sums, dev_results receives a device copy for kernels queued behind
+int hipxVecMDotBegin(const double *x, hipx_int nv, const double *const *y, hipx_int n, int slot, double *dev_results)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(nv >= 1 && nv <= 16 && slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2, "1 <= nv <= 16, slot in range");
+  HIPX_ARG(n > 0, "hipxVecMDotBegin needs a non-empty vector");
+  g_dres   = dev_results;
+  int ierr = mdot_dispatch(x, nv, y, n, slot);
+  g_dres   = nullptr;
+  return ierr;
 }
 
 int hipxCGFusedUpdateBegin(double *x, double *r, double *z, const double *p, const double *w, const double *d, double dconst, const double *dev_beta, const double *dev_dpi,

@@ -200,7 +200,7 @@ static int ensure_cg_work(HipxKSP *ksp, hipx_int n)
   CHK(hipxMalloc((void **)&ksp->Z, bytes));
   CHK(hipxMalloc((void **)&ksp->P, bytes));
   CHK(hipxMalloc((void **)&ksp->P2, bytes));
-  CHK(hipxMalloc((void **)&ksp->dscal, sizeof(double) * 8));
+  CHK(hipxMalloc((void **)&ksp->dscal, sizeof(double) * 16)); /* device-resident scalars of the launch-ahead loops (two-reduction form: 7, single-reduction form: 12) */
   ksp->work_n = n;
   return 0;
 }
@@ -333,6 +333,124 @@ static int cg_sr_step(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, dou
     }
     ksp->i++;
   }
+  if (!ksp->reason && ksp->i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS; /* cg.c:532 */
+  return 0;
+}
+
+/* Launch-ahead form of the single-reduction loop (round 5; ksp->pipeline == 4; fused PCJACOBI / PCNONE).  Per iteration i >= 1 the device runs
+     U(i): b, dpi, a from {z.s, z.r}(i-1) and {beta, dpi, a}(i-1) -- cg.c:464,478,488, on the device, in the host's expression order --, x += a_{i-1} p_{i-1} (the x
+           update iteration i-1 left behind), p = z + b p, w = s + b w, r -= a w, z = r .* d                        (cg.c:470,477,490,491,493: ONE kernel)
+     M(i): s = A z                                                                                                  (cg.c:494)
+     R(i): {z.z, z.s, z.r} in ONE reduction (on several ranks: one 24-byte all-reduce on the stream)                (cg.c:495,523)
+   and the host enqueues U(i+1), M(i+1), R(i+1) BEFORE it waits for the sums of R(i) -- its own copies of the recurrences (the same IEEE expressions) serve the
+   reference's breakdown checks and the convergence test one step behind the device, as in cg_step_pipelined.  What is queued ahead when the loop stops has
+   applied exactly the x update of the last completed iteration; r, z, p, w are then one iteration further (nobody reads them).  Histories and x: the
+   host-synchronised loop's, bit for bit (the sums come from the same reduction kernel, the vector updates are the same operations). */
+static int sr_sums_begin(HipxMat *A, const double *z, const double *s, const double *r, hipx_int n, int slot, double *dev3)
+{
+  const double *ys[3] = {z, s, r};
+  if (A->nranks > 1) return hipxVecMDotBeginAllreduce(z, 3, ys, n, slot, dev3);
+  return hipxVecMDotBegin(z, 3, ys, n, slot, dev3);
+}
+
+static int cg_sr_step_pipelined(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double *X, hipx_int nsteps)
+{
+  const hipx_int n = A->m;
+  double        *R = ksp->R, *Z = ksp->Z, *P = ksp->P, *S = ksp->S, *W = ksp->W, *ds = ksp->dscal;
+  const double  *dinv  = pc->type == HIPX_PC_JACOBI ? pc->dinv : NULL;
+  int            ahead = 0; /* U, M, R of the current iteration are enqueued already */
+  enum { SLOT_SR = 4 };     /* reduction slots 4, 5 by iteration parity */
+#define SR_SUMS(k) (ds + 3 * (k))
+#define SR_STATE(k) (ds + 6 + 3 * (k))
+  for (hipx_int st = 0; st < nsteps && !ksp->reason && ksp->i < ksp->max_it; st++) {
+    const hipx_int i = ksp->i;
+    const int      q = (int)(i & 1);
+    double         sums[3], dp, dpiold;
+    ksp->its = i + 1;
+    if (ksp->beta == 0.0) { /* cg.c:448 */
+      ksp->reason = KSP_CONVERGED_ATOL;
+      break;
+    } else if ((i > 0) && (ksp->beta * ksp->betaold < 0.0)) { /* cg.c:453 */
+      ksp->reason = KSP_DIVERGED_INDEFINITE_PC;
+      break;
+    }
+    dpiold = ksp->dpi;
+    if (!i) { /* the first iteration forms dpi = p . A p explicitly (cg.c:461,474-475): host-synchronised, its x update left to U(1) or to the flush */
+      CHK(hipxVecCopy(Z, P, n));
+      CHK(HipxMatMult(A, P, W));
+      CHK(HipxVecDot(A, P, W, n, &ksp->dpi));
+      ksp->betaold = ksp->beta;
+      if (isnan(ksp->beta) || isinf(ksp->beta)) {
+        ksp->reason = KSP_DIVERGED_NANORINF;
+        break;
+      }
+      if (ksp->dpi == 0.0) { /* cg.c:483 */
+        ksp->reason = KSP_DIVERGED_INDEFINITE_MAT;
+        break;
+      }
+      ksp->a         = ksp->beta / ksp->dpi;
+      ksp->x_pending = 1; /* cg.c:490 */
+      ksp->a_pending = ksp->a;
+      CHK(hipxVecAXPY(R, -ksp->a, W, n)); /* cg.c:491 */
+      CHK(HipxPCApply(pc, A, R, Z));      /* cg.c:493 */
+      CHK(HipxMatMult(A, Z, S));          /* cg.c:494 */
+      CHK(sr_sums(A, Z, S, R, n, sums));
+    } else {
+      if (!ahead) { /* nothing in flight (first pass of this call): the device's scalar blocks from the host's copies */
+        const double hs[3] = {0.0, ksp->delta, ksp->beta}, ht[3] = {ksp->betaold, ksp->dpi, ksp->x_pending ? ksp->a_pending : 0.0};
+        CHK(hipxMemcpyHtoD(SR_SUMS(1 - q), hs, sizeof(hs)));
+        CHK(hipxMemcpyHtoD(SR_STATE(1 - q), ht, sizeof(ht)));
+        CHK(hipxCGSingleReductionUpdateDev(P, W, X, R, Z, S, dinv, SR_SUMS(1 - q), SR_STATE(1 - q), SR_STATE(q), n));
+        CHK(HipxMatMult(A, Z, S));
+        CHK(sr_sums_begin(A, Z, S, R, n, SLOT_SR + q, SR_SUMS(q)));
+      }
+      ahead          = 0;
+      ksp->x_pending = 0; /* U(i) has applied what iteration i-1 left behind */
+      /* the host's copies of the recurrences: the values U(i) formed on the device */
+      ksp->dpi     = ksp->delta - ksp->beta * ksp->beta * dpiold / (ksp->betaold * ksp->betaold); /* cg.c:478 */
+      ksp->betaold = ksp->beta;
+      if (isnan(ksp->beta) || isinf(ksp->beta)) { /* KSPCheckDot cg.c:481 */
+        ksp->reason = KSP_DIVERGED_NANORINF;
+        break;
+      }
+      if ((ksp->dpi == 0.0) || (ksp->dpi * dpiold <= 0.0)) { /* cg.c:483 */
+        ksp->reason = KSP_DIVERGED_INDEFINITE_MAT;
+        break;
+      }
+      ksp->a         = ksp->beta / ksp->dpi; /* cg.c:488 */
+      ksp->x_pending = 1;                    /* U(i) leaves x += a p to U(i+1) or to the flush */
+      ksp->a_pending = ksp->a;
+      if (st + 1 < nsteps && i + 1 < ksp->max_it) { /* iteration i+1 behind R(i) on the stream, before the host has seen R(i)'s sums */
+        CHK(hipxCGSingleReductionUpdateDev(P, W, X, R, Z, S, dinv, SR_SUMS(q), SR_STATE(q), SR_STATE(1 - q), n));
+        CHK(HipxMatMult(A, Z, S));
+        CHK(sr_sums_begin(A, Z, S, R, n, SLOT_SR + (1 - q), SR_SUMS(1 - q)));
+        ahead          = 1;
+        ksp->x_pending = 0; /* U(i+1) applies it */
+      }
+      CHK(hipxRedEnd(SLOT_SR + q, 3, sums));
+      if (A->nranks > 1) CHK(hipxCommCheckError());
+    }
+    dp = sqrt(sums[0]);
+    if (isnan(dp) || isinf(dp)) {
+      ksp->reason = KSP_DIVERGED_NANORINF;
+      break;
+    }
+    ksp->rnorm = dp;
+    log_history(ksp, dp);
+    CHK(converged_default(ksp, A, pc, i + 1, dp, B, &ksp->reason)); /* cg.c:514 */
+    if (ksp->reason) break;
+    ksp->delta = sums[1];
+    ksp->beta  = sums[2];
+    if (isnan(ksp->beta) || isinf(ksp->beta)) { /* cg.c:526 */
+      ksp->reason = KSP_DIVERGED_NANORINF;
+      break;
+    }
+    ksp->i++;
+  }
+#undef SR_SUMS
+#undef SR_STATE
+  if (ahead) CHK(hipxStreamSynchronize()); /* stopped with iteration i+1 in flight: x is complete once U(i+1) has run */
+  if (!ksp->defer_flush) CHK(HipxKSPCGFlush(ksp, A, X));
   if (!ksp->reason && ksp->i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS; /* cg.c:532 */
   return 0;
 }
@@ -538,7 +656,11 @@ int HipxKSPCGStep(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double 
   double         dp = 0.0, b, dpiold;
   /* fused update kernel (AXPY, AXPY, PCJACOBI, norm, dot): any rank count, its two sums all-reduced together;
      SpMV + dot fusion: only without an off-diagonal block (the dot needs the complete w) */
-  if (ksp->single_reduction && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED) return cg_sr_step(ksp, A, pc, B, X, nsteps);
+  if (ksp->single_reduction && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED) {
+    /* pipeline == 4: the launch-ahead form (fused PCJACOBI / PCNONE; several ranks: with the ghost exchange and the all-reduce on the streams) */
+    if (ksp->pipeline == 4 && ksp->fused && (pc->type == HIPX_PC_JACOBI || pc->type == HIPX_PC_NONE) && ((A->nranks <= 1 && A->m > 0) || (A->nranks > 1 && A->B && A->halo))) return cg_sr_step_pipelined(ksp, A, pc, B, X, nsteps);
+    return cg_sr_step(ksp, A, pc, B, X, nsteps);
+  }
   const int      fused_any = ksp->fused && (pc->type == HIPX_PC_JACOBI || (pc->type == HIPX_PC_NONE && pc->dconst_valid)) && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED;
   const int      fused_upd = fused_any && pc->type == HIPX_PC_JACOBI; /* the host-synchronised loop below streams dinv; PCNONE (round 4) takes the launch-ahead loop, whose kernels multiply by a scalar */
   const int      fused     = fused_upd && !A->B && A->nranks <= 1;

@@ -81,7 +81,7 @@ def test_launch_ahead_cg_on_two_ranks_equals_host_synchronised_loop():
     (HIPX_REDUCTIONS=exact: every sum rounded once, whatever the order, the kernel and the cut into ranks) they are the same double."""
     out = {}
     for mode in ("fast", "exact"):
-        for pipe in ("1", "2", "3"):
+        for pipe in ("1", "2", "3", "4"):
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "64", "--steps", "25", "--warmup", "4", "--quick", "--pipeline", pipe],
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=dict(clean_env(), HIPX_REDUCTIONS=mode), cwd=ROOT)
             assert r.returncode == 0, r.stdout[-3000:]
@@ -94,6 +94,26 @@ def test_launch_ahead_cg_on_two_ranks_equals_host_synchronised_loop():
     assert a["parity_gate"]["max_rel_diff_exact_reductions"] == b["parity_gate"]["max_rel_diff_exact_reductions"]
     c = out["exact", "3"]  # another recurrence: close to, not equal to, the standard form
     assert abs(c["config"]["residual_norm_after"] - b["config"]["residual_norm_after"]) <= 1e-9 * b["config"]["residual_norm_after"]
+    # round 5: the launch-ahead single-reduction form (--pipeline 4: scalars formed on the device, the 24-byte all-reduce on the stream) = the host-synchronised
+    # one (--pipeline 3), bit for bit, in both reduction modes
+    for mode in ("fast", "exact"):
+        assert out[mode, "4"]["config"]["residual_norm_after"] == out[mode, "3"]["config"]["residual_norm_after"], mode
+
+
+def test_two_rank_line_times_the_single_reduction_form_beside_the_headline():
+    """Round 5: on several ranks the default line (`value`: the two-all-reduce launch-ahead loop, gated at 1e-12) also times the launch-ahead single-reduction
+    form (one 24-byte all-reduce per iteration; gated at 1e-9 against the standard form's yardstick) as a leg of its own -- within the wall-clock budget, decided
+    by rank 0 for all ranks; legs that do not fit the budget say so."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "64", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-traffic", "--no-plugin",
+                        "--no-general", "--budget-s", "55"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=clean_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["pipeline"] == 1 and d["parity_gate"]["pass"] is True and d["parity_gate"]["max_rel_diff"] <= 1e-12
+    sr = d["other_configs"]["headline_single_reduction_launch_ahead"]
+    assert sr["pipeline"] == 4 and sr["iterations_per_s"] > 0 and sr["parity"]["pass"] is True and sr["parity"]["max_rel_diff"] <= 1e-9, sr
+    legs = d["other_configs"]
+    assert any(v == {"skipped": "budget"} for v in legs.values()), list(legs)  # (the budget cuts the list somewhere; what ran is gated)
+    assert all(v == {"skipped": "budget"} or v.get("parity", {}).get("pass") is not False for v in legs.values()), {k: v.get("parity") for k, v in legs.items() if isinstance(v, dict)}
 
 
 def test_gmres_sor_on_two_and_four_ranks_follows_the_exact_yardstick_at_1e12():

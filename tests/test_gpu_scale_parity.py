@@ -253,18 +253,21 @@ def host_cg_sr(hx, ks, n, rtol, pcname):
     ones, B, X = _lib.DVec(N, np.ones(N)), _lib.DVec(N), _lib.DVec(N, np.zeros(N))
     _lib.chk(ks.HipxMatMult(C.byref(M), ones.ptr, B.ptr))
     out = {}
-    for fused in (0, 1):
+    for fused in (0, 1, 4):  # 4: the fused update kernel in the launch-ahead loop (HipxKSP.pipeline = 4, round 5)
         pc = _lib.HipxPC()
         ks.HipxPCSetDefaults(C.byref(pc))
         pc.type = {"none": 0, "jacobi": 1}[pcname]
         _lib.chk(ks.HipxPCSetUp(C.byref(pc), C.byref(M)))
         k = _lib.HipxKSP()
         ks.HipxKSPSetDefaults(C.byref(k))
-        k.rtol, k.max_it, k.fused, k.single_reduction = rtol, 10000, fused, 1
+        k.rtol, k.max_it, k.fused, k.single_reduction = rtol, 10000, 1 if fused else 0, 1
+        if fused == 4:
+            k.pipeline = 4
         hist = np.zeros(4000)
         k.history, k.hist_len = hist.ctypes.data, len(hist)
+        X.set(np.zeros(N))
         _lib.chk(ks.HipxKSPSolve_CG(C.byref(k), C.byref(M), C.byref(pc), B.ptr, X.ptr))
-        out[fused] = (hist[:k.hist_n].copy(), int(k.its), int(k.reason))
+        out[fused] = (hist[:k.hist_n].copy(), int(k.its), int(k.reason), X.get())
         ks.HipxKSPDestroyWork(C.byref(k))
         ks.HipxPCDestroy(C.byref(pc))
     for v in (ones, B, X):
@@ -296,6 +299,47 @@ def test_single_reduction_cg_follows_the_reference_in_exact_mode(hx, n, pcname):
     for name, g in (("statement by statement", got[0]), ("fused update kernel", got[1]), ("plugin cghipx", plug)):
         check_history("7-pt %d^3 single-reduction CG+%s EXACT mode: %s vs the REFERENCE's single-reduction run with exact BLAS reductions" % (n, pcname, name), g, refx, tol=1e-10)
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][0], plug[0])
+    # round 5: the launch-ahead form (scalars formed on the device, x updated one kernel later): the same history, iteration count, reason and SOLUTION
+    assert np.array_equal(got[4][0], got[1][0]) and got[4][1:3] == got[1][1:3] and np.array_equal(got[4][3], got[1][3]) and np.array_equal(got[0][3], got[1][3])
+
+
+@pytest.mark.parametrize("n,pcname,chunk", [(24, "jacobi", 1), (24, "jacobi", 3), (32, "none", 7)])
+def test_launch_ahead_single_reduction_cg_default_reductions_and_stepping(hx, n, pcname, chunk):
+    """The launch-ahead single-reduction loop with the DEFAULT reductions: its three sums come from the reduction kernel the host-synchronised loop uses, its
+    vector updates are the same operations -- history and solution are the same doubles; and called in chunks of `chunk` iterations (HipxKSPCGStep: every return
+    leaves x complete, every call re-seeds the device's scalar block from the host's copy) it still is."""
+    from petsc_amd import _lib
+    _, ks = _lib.load()
+    ref = host_cg_sr(hx, ks, n, 1e-8, pcname)
+    assert np.array_equal(ref[4][0], ref[1][0]) and ref[4][1:3] == ref[1][1:3] and np.array_equal(ref[4][3], ref[1][3])
+    N = n ** 3
+    nz = ks.HipxAssemble_poisson7(n, 0, N, None, None, None)
+    ai, aj, aa = np.zeros(N + 1, np.int32), np.zeros(nz, np.int32), np.zeros(nz)
+    ks.HipxAssemble_poisson7(n, 0, N, ai.ctypes.data_as(C.c_void_p), aj.ctypes.data_as(C.c_void_p), aa.ctypes.data_as(C.c_void_p))
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    M = _lib.HipxMat(m=N, A=A, B=None, halo=None, lvec=None, nranks=1)
+    ones, B, X = _lib.DVec(N, np.ones(N)), _lib.DVec(N), _lib.DVec(N, np.zeros(N))
+    _lib.chk(ks.HipxMatMult(C.byref(M), ones.ptr, B.ptr))
+    pc = _lib.HipxPC()
+    ks.HipxPCSetDefaults(C.byref(pc))
+    pc.type = {"none": 0, "jacobi": 1}[pcname]
+    _lib.chk(ks.HipxPCSetUp(C.byref(pc), C.byref(M)))
+    k = _lib.HipxKSP()
+    ks.HipxKSPSetDefaults(C.byref(k))
+    k.rtol, k.max_it, k.fused, k.single_reduction, k.pipeline = 1e-8, 10000, 1, 1, 4
+    hist = np.zeros(4000)
+    k.history, k.hist_len = hist.ctypes.data, len(hist)
+    _lib.chk(ks.HipxKSPCGBegin(C.byref(k), C.byref(M), C.byref(pc), B.ptr, X.ptr))
+    guard = 0
+    while not k.reason and guard < 5000:
+        _lib.chk(ks.HipxKSPCGStep(C.byref(k), C.byref(M), C.byref(pc), B.ptr, X.ptr, chunk))
+        guard += 1
+    assert np.array_equal(hist[:k.hist_n], ref[1][0]) and (int(k.its), int(k.reason)) == ref[1][1:3] and np.array_equal(X.get(), ref[1][3])
+    ks.HipxKSPDestroyWork(C.byref(k))
+    ks.HipxPCDestroy(C.byref(pc))
+    for v in (ones, B, X):
+        v.free()
+    _lib.mat_destroy(A)
 
 
 @pytest.mark.parametrize("np_", [1, 2])
