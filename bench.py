@@ -884,6 +884,8 @@ def compact_line(out):
                    if k in ("workload", "global_rows", "parallelism", "transport", "fused", "pipeline", "reduction_mode", "residual_norm_after")}
     if "error" in out:
         c["error"] = _short(out["error"], 300)
+    if "scaling_legs_error" in out:
+        c["scaling_legs_error"] = _short(out["scaling_legs_error"], 200)
     c["ungated"] = out.get("ungated")
     g = out.get("parity_gate") or {}
     c["parity_gate"] = {k: _num(g.get(k)) for k in ("pass", "max_rel_diff", "tolerance", "iterations", "gated_reduction_mode") if k in g}
@@ -1576,6 +1578,24 @@ def main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync, t_st
                         ("config5_cg_none_7pt_1024x1024x%d_weak" % (128 * world), Cfg(7, (1024, 1024, 128 * world), "cg", "none", "weak"), 60, 5, 12, 16),
                         ("config3_solver_gmres30_sor_27pt_256_parity", Cfg(27, (256, 256, 256), "gmres", "sor", "strong", golden="gmres_sor_27pt_256"), 60, 5, 35, 12)]
         scaling_legs = [leg + (1,) for leg in scaling_legs]
+        # A leg is a collective job on transports no box of five rounds could exercise across GPUs: should one stall, the measured headline must not
+        # be lost with it.  Rank 0 arms a timer (budget + grace); if it fires, the line is printed with what has been collected and the process leaves.
+        watchdog = None
+        if rank == 0 and out is not None and deadline != float("inf"):
+            import threading
+
+            def _give_up():
+                out["other_configs"] = dict(other)
+                out["budget_s"] = args.budget_s
+                out["scaling_legs_error"] = "a scaling leg did not return within the budget + 120 s: the line is printed without it"
+                try:
+                    emit(out, t_start)
+                    sys.stdout.flush()
+                finally:
+                    os._exit(0)
+            watchdog = threading.Timer(max(30.0, deadline - time.time()) + 120.0, _give_up)
+            watchdog.daemon = True
+            watchdog.start()
         if head.ksp == "cg" and head.pc in ("jacobi", "none") and args.pipeline == 1 and args.fused:
             # the one-all-reduce form beside the two-all-reduce one the line's `value` is measured with (round 5: launch-ahead single-reduction CG, cg.c:364-534 -- the same
             # KSPCG with KSPCGUseSingleReduction; its history is gated against the standard form's yardstick at 1e-9, not 1e-12: another recurrence for A p)
@@ -1595,6 +1615,8 @@ def main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync, t_st
                 other[name] = res
             except Exception as e:  # noqa: BLE001
                 other[name] = {"error": str(e)[:400]}
+        if watchdog is not None:
+            watchdog.cancel()
         if out is not None:
             out["other_configs"] = other
             out["budget_s"] = None if deadline == float("inf") else args.budget_s
