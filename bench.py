@@ -66,6 +66,8 @@ class Cfg:
         self.cube = dims[0] == dims[1] == dims[2]
 
     def shape(self):
+        if self.stencil == 5:  # 2-D (ex2.c:70-94: row Ii = i n + j, j fastest): dims = (n, m, 1)
+            return "%dx%d" % self.dims[:2]
         return "%d^3" % self.dims[0] if self.cube else "%dx%dx%d" % self.dims
 
     def pcname(self):
@@ -81,7 +83,9 @@ class Cfg:
 
     def driver_args(self, its):
         a = ["-stencil", str(self.stencil), "-n", str(self.dims[0]), "-ksp_type", self.ksp, "-pc_type", self.pc, "-ksp_rtol", "1e-50", "-ksp_max_it", str(its)]
-        if not self.cube:
+        if self.stencil == 5:
+            a += ["-m", str(self.dims[1])]
+        elif not self.cube:
             a += ["-ny", str(self.dims[1]), "-nz", str(self.dims[2])]
         if self.ksp == "cg":
             a += ["-ksp_norm_type", "preconditioned"]
@@ -130,6 +134,12 @@ def assemble(ks, stencil, dims, rs, re):
     if stencil == 7:
         def f(ai, ai64, aj, aa):
             return ks.HipxAssemble_poisson7_box(nx, ny, nz, rs, re, ai, ai64, aj, aa)
+    elif stencil == 5:  # ex2.c:70-94 on an m x n grid (BASELINE config 1's operator at HBM size): dims = (n, m, 1)
+        assert nz == 1, "the 5-point operator of ex2.c is 2-D"
+
+        def f(ai, ai64, aj, aa):
+            assert ai64 is None
+            return ks.HipxAssemble_ex2(ny, nx, rs, re, ai, aj, aa)
     else:
         assert cube, "the 27-point operator of bench_kspsolve.c is defined on a cube"
 
@@ -898,6 +908,8 @@ def compact_line(out):
         if r.get("by_kernel"):  # [name, us per launch, launches per iteration, HBM bytes per launch, frac]
             rr["by_kernel"] = [[_short(k.get("kernel") or k.get("match"), 60), _num(k.get("avg_launch_us"), 4), _num(k.get("launches_per_iteration"), 3), k.get("traffic"), _num(k.get("frac"), 4)]
                                for k in r["by_kernel"] if k.get("launches_per_iteration", 0) >= 0.5]
+        if isinstance(r.get("general"), dict):  # SURVEY 8(d)'s literal figure: algorithmic CSR bytes / launch time of the kernel that STREAMS the values (verdict r5)
+            rr["frac_csr_bytes"] = _num(r["general"].get("frac"), 4)
         for key in ("general", "unstructured"):
             if isinstance(r.get(key), dict):
                 e = r[key]
@@ -1004,7 +1016,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--grid", dest="n", type=int, default=256, help="grid points per side (not --n: torchrun would read it as an abbreviation of its own options)")
-    ap.add_argument("--stencil", type=int, default=7, choices=[7, 27])
+    ap.add_argument("--stencil", type=int, default=7, choices=[5, 7, 27], help="5: the 2-D operator of ex2.c (BASELINE config 1) on a grid x grid mesh (--grid 4096: 16.8 M rows)")
     ap.add_argument("--ksp", default="cg", choices=["cg", "gmres"])
     ap.add_argument("--pc", default="jacobi", choices=["jacobi", "sor", "none"])
     ap.add_argument("--transport", default=os.environ.get("HIPX_TRANSPORT", "auto"), choices=["auto", "rccl", "ipc"],
@@ -1024,8 +1036,8 @@ def main():
                                                         "instead of a Poisson operator: BASELINE config 4 with the real SuiteSparse file")
     ap.add_argument("--no-other", action="store_true", help="skip the other_configs legs (configs 3/4/5 on one GPU; the scaling legs on N GPUs)")
     ap.add_argument("--quick", action="store_true", help="the timed legs only: no plugin / PMC / CPU-baseline / general-kernel / other-config legs")
-    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("HIPX_BENCH_BUDGET_S", "140")),
-                    help="wall-clock budget of the whole run (default 140 s): the headline (parity gate, timed steps, counter pass, CPU baseline) always runs; the optional legs (plugin rows, "
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("HIPX_BENCH_BUDGET_S", "175")),
+                    help="wall-clock budget of the whole run (default 175 s): the headline (parity gate, timed steps, counter pass, CPU baseline) always runs; the optional legs (plugin rows, "
                          "other_configs, their counter passes and CPU baselines) run in order of importance while their estimated cost still fits, the rest are reported as skipped")
     ap.add_argument("--parity-its", type=int, default=GATE_ITS, help="N > 1: entries of the committed exact-reduction history the headline leg is gated on (default 24; 35 covers a GMRES(30) restart)")
     ap.add_argument("--full", action="store_true", help="no budget: every leg, every counter pass, every CPU-baseline rank count (several minutes)")
@@ -1079,6 +1091,8 @@ def main():
     _, ks = _lib.load()
     n = args.n
     dims = (n, n, n) if args.scaling == "strong" else (n, n, (n // 8) * world)  # weak: config 5 = n x n x n/8 rows per GPU
+    if args.stencil == 5:
+        dims = (n, n, 1)
     head = Cfg(args.stencil, dims, args.ksp, args.pc, args.scaling)
     N = head.N
 
@@ -1190,8 +1204,8 @@ def main():
         "metric": head.metric(), "value": value, "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "3-D %d-pt Poisson %dx%dx%d (N=%d rows, nnz=%d local), KSP%s + %s, b = A*1, x0 = 0; rows split over 1 rank(s)"
-                               % (args.stencil, dims[0], dims[1], dims[2], N, nnz_local, args.ksp.upper(), head.pcname()),
+        "config": {"workload": "%s %d-pt Poisson %dx%dx%d (N=%d rows, nnz=%d local), KSP%s + %s, b = A*1, x0 = 0; rows split over 1 rank(s)"
+                               % ("2-D" if args.stencil == 5 else "3-D", args.stencil, dims[0], dims[1], dims[2], N, nnz_local, args.ksp.upper(), head.pcname()),
                    "global_rows": N, "parallelism": "rows1", "transport": None, "fused": args.fused, "pipeline": args.pipeline, "spmv_variant": args.variant,
                    "residual_norm_after": rnorm, "reduction_mode": os.environ.get("HIPX_REDUCTIONS", "fast")},
         "ungated": gate["pass"] is None,
@@ -1262,7 +1276,9 @@ def main():
         legs = [("config3_solver_gmres30_sor_27pt_256", Cfg(27, (256, 256, 256), "gmres", "sor", golden="gmres_sor_27pt_256"), 60, 5, 35, 10, 8),
                 ("config5_share_cg_none_7pt_1024x1024x128", Cfg(7, (1024, 1024, 128), "cg", "none", scaling="weak"), 50, 5, 12, 10, 9),
                 # the 1-GPU point of north_star's >= 6x target (27-pt 512^3: 3.6e9 nonzeros, 64-bit row offsets, 46 GB of CSR in HBM)
-                ("cg_jacobi_27pt_512_strong", Cfg(27, (512, 512, 512), "cg", "jacobi"), 30, 3, 16, 0, 24)]
+                ("cg_jacobi_27pt_512_strong", Cfg(27, (512, 512, 512), "cg", "jacobi"), 30, 3, 16, 0, 24),
+                # north_star: "5-/7-/27-point Poisson stencils reported" -- BASELINE config 1's operator (ex2.c:70-94) at HBM size: 4096 x 4096 = the headline's row count
+                ("cg_jacobi_5pt_4096x4096", Cfg(5, (4096, 4096, 1), "cg", "jacobi"), 100, 10, 16, 10, 7)]
         for name, cfg, st, wu, pits, cpu_its, est in legs:
             if not room(est + reserve):
                 other[name] = {"skipped": "budget"}
@@ -1341,6 +1357,10 @@ def main():
         if not args.no_other:
             if ran("config3_solver_gmres30_sor_27pt_256") or ran("cg_jacobi_27pt_512_strong"):
                 todo.append(("spmv27", ["--suite", "spmv", "--grid", "256", "--stencil", "27", "--suite-variants", "0"], "27pt_256_spmv", src % "spmv (27-pt 256^3)", 14))
+            if ran("cg_jacobi_27pt_512_strong"):  # the timed instantiation itself (spmv_march2_kernel<27, 8, 3, true, true> at 512^3), not an estimate from 256^3
+                todo.append(("cg27_512", ["--suite", "cg", "--grid", "512", "--stencil", "27", "--pc", "jacobi"], "27pt_512_cg", src % "cg --grid 512 --stencil 27", 36))
+            if ran("cg_jacobi_5pt_4096x4096"):
+                todo.append(("cg5", ["--suite", "cg", "--stencil", "5", "--pc", "jacobi", "--suite-dims", "4096x4096x1"], "5pt_4096_cg", src % "cg --stencil 5 --suite-dims 4096x4096x1", 12))
             if ran("config5_share_cg_none_7pt_1024x1024x128"):
                 todo.append(("box", ["--suite", "cg", "--stencil", "7", "--pc", "none", "--suite-dims", "1024x1024x128"], "config5_share_cg", src % "cg --suite-dims 1024x1024x128 --pc none", 22))
             if ran("config3_sor_arbitrary_values_27pt_256"):
@@ -1473,10 +1493,17 @@ def main():
                 if vu:
                     c5["roofline_cg_update"] = {"bound": "hbm", "kernel": "cg_fused_kernel", "avg_launch_ms": c5["cg_update_ms"], "traffic": int(vu["bytes"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                 "frac_counter_bytes": vu["bytes"] / (c5["cg_update_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        c27 = other.get("cg_jacobi_27pt_512_strong", {})
-        if "roofline_spmv" in c27:
-            put_traffic(c27["roofline_spmv"], pmc.get("spmv27"), [c27["roofline_spmv"]["kernel"].split(" ")[0]], c27["roofline_spmv"]["avg_launch_ms"], scale=8.0,
-                        note="counter pass on the 27-pt 256^3 operator (same kernel family), bytes scaled by the row count (x 8): an estimate, the 512^3 planes have relatively thinner halos")
+        for nm, key in (("cg_jacobi_27pt_512_strong", "cg27_512"), ("cg_jacobi_5pt_4096x4096", "cg5")):
+            cl = other.get(nm, {})
+            if "roofline_spmv" in cl:  # the counter pass ran the same solver at the same size: the product kernel's own bytes (its CG prologue included) over its own launch time
+                if put_traffic(cl["roofline_spmv"], pmc.get(key), [cl["roofline_spmv"]["kernel"].split(" ")[0]], cl["roofline_spmv"]["avg_launch_ms"],
+                               note="counter pass on the same solver at the same size; the product kernel carries the CG direction update as its prologue"):
+                    cl["roofline_spmv"]["achieved"], cl["roofline_spmv"]["frac"] = cl["roofline_spmv"]["achieved_on_counter_bytes"], cl["roofline_spmv"]["frac_counter_bytes"]
+                if pmc.get(key) and pmc[key][0] and "cg_update_ms" in cl:
+                    _, vu = pick_kernel(pmc[key][0], "cg_fused_")
+                    if vu:
+                        cl["roofline_cg_update"] = {"bound": "hbm", "kernel": "cg_fused_kernel", "avg_launch_ms": cl["cg_update_ms"], "traffic": int(vu["bytes"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                    "frac_counter_bytes": vu["bytes"] / (cl["cg_update_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         sv = other.get("config3_sor_arbitrary_values_27pt_256", {})
         if "strand_streamed_coefficients_ms" in sv:
             line = {"bound": "hbm", "kernel": "sor_strand_kernel with streamed coefficients, forward + backward", "avg_call_ms": sv["strand_streamed_coefficients_ms"], "peak": HBM_PEAK_GBS,
@@ -1592,7 +1619,9 @@ def main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync, t_st
                     emit(out, t_start)
                     sys.stdout.flush()
                 finally:
-                    os._exit(0)
+                    # a stalled collective is a failure: leave with a non-zero status -- the launcher (torch.distributed.run) then tears the
+                    # other ranks down instead of leaving them in the collective with their GPUs held; the line above carries `scaling_legs_error`
+                    os._exit(4)
             watchdog = threading.Timer(max(30.0, deadline - time.time()) + 120.0, _give_up)
             watchdog.daemon = True
             watchdog.start()

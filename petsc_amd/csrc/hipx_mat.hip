@@ -2262,6 +2262,10 @@ __global__ __launch_bounds__(NT, (NT == 256 || NQ <= 4) ? 2 : 1) void spmv_march
       // NO agent-scope release fence here: it writes back the XCD's whole L2, which this kernel has just filled with y, p and x (measured: +24 us
       // per launch).  The partial goes out as an agent-scope atomic store (sc1: written through to memory), the wave waits for it (vmcnt), the
       // barrier collects the four waves, then the ticket; the last workgroup reads the partials with agent-scope atomic loads (sc1: never a stale line).
+      // ISA ASSUMPTION: this is the gfx950 "sc1 stores AND sc1 loads on both sides" hand-off of MI355X_MICROARCH (valid forms), which rests on
+      // relaxed agent-scope atomics lowering to global_store/load ... sc1 (write-through / L1-bypassing) and on the ticket RMW being issued after the
+      // drained store -- not on the HIP memory model.  Pinned by tests/test_gpu_mat.py::test_march2_in_kernel_fold_equals_the_separate_fold_under_load
+      // (bitwise against the separate fold kernel, back-to-back launches); HIPX_MARCH_NOFOLD=1 restores the separate kernel.
       __shared__ unsigned s_lastwg;
       __shared__ double   s_fw[kRedThreads / 64];
       if (lane == 0) __hip_atomic_store(&dotpart[(size_t)blockIdx.x * (NT / 64) + wv], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

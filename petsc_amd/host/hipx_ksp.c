@@ -236,11 +236,18 @@ static int sr_sums(HipxMat *A, const double *z, const double *s, const double *r
   return hipxVecMDot(z, 3, ys, n, sums3);
 }
 
+static int sr_dots(HipxMat *A, const double *z, const double *s, const double *r, hipx_int n, double *sums2)
+{
+  const double *ys[2] = {s, r}; /* cg.c:519-523: VecMDot(Z, 2, {S, R}) */
+  if (A->nranks > 1) return hipxVecMDotAllreduce(z, 2, ys, n, sums2);
+  return hipxVecMDot(z, 2, ys, n, sums2);
+}
+
 static int cg_sr_begin(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double *X)
 {
   const hipx_int n = A->m;
-  double        *R = ksp->R, *Z = ksp->Z, sums[3], dp;
-  if (ksp->normtype != HIPX_KSP_NORM_PRECONDITIONED) return HIPX_ERR_SUP; /* the other norm types keep the standard loop */
+  double        *R = ksp->R, *Z = ksp->Z, sums[3], dp = 0.0;
+  const int      precond = ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED, natural = ksp->normtype == HIPX_KSP_NORM_NATURAL;
   if (!ksp->S) {
     const size_t bytes = sizeof(double) * (size_t)(n ? n : 1);
     CHK(hipxMalloc((void **)&ksp->S, bytes));
@@ -251,10 +258,17 @@ static int cg_sr_begin(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, do
     CHK(HipxMatMult(A, X, R));       /* cg.c:397 */
     CHK(hipxVecAYPX(R, -1.0, B, n)); /* cg.c:398 */
   } else CHK(hipxVecCopy(B, R, n));  /* cg.c:400 */
-  CHK(HipxPCApply(pc, A, R, Z));      /* cg.c:405 */
-  CHK(HipxMatMult(A, Z, ksp->S));     /* cg.c:439 (moved before the norm: one reduction for the three sums; the values are the same) */
-  CHK(sr_sums(A, Z, ksp->S, R, n, sums));
-  dp = sqrt(sums[0]);                 /* cg.c:406 */
+  sums[0] = sums[1] = sums[2] = 0.0;
+  if (precond || natural) {          /* cg.c:403-421 */
+    CHK(HipxPCApply(pc, A, R, Z));   /* cg.c:405 / 414 */
+    CHK(HipxMatMult(A, Z, ksp->S));  /* cg.c:439 / 415 (preconditioned norm: moved before the norm -- one reduction for the three sums; the values are the same) */
+    CHK(sr_sums(A, Z, ksp->S, R, n, sums));
+    dp = precond ? sqrt(sums[0]) : sqrt(fabs(sums[2])); /* cg.c:406 / 419 */
+    if (natural && (isnan(sums[2]) || isinf(sums[2]))) {  /* KSPCheckDot cg.c:418 */
+      ksp->reason = KSP_DIVERGED_NANORINF;
+      return 0;
+    }
+  } else if (ksp->normtype == HIPX_KSP_NORM_UNPRECONDITIONED) CHK(HipxVecNorm2(A, R, n, &dp)); /* cg.c:410 */
   if (isnan(dp) || isinf(dp)) {
     ksp->reason = KSP_DIVERGED_NANORINF;
     return 0;
@@ -263,6 +277,11 @@ static int cg_sr_begin(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, do
   ksp->rnorm = dp;
   CHK(converged_default(ksp, A, pc, 0, dp, B, &ksp->reason)); /* cg.c:434 */
   if (ksp->reason) return 0;
+  if (!precond && !natural) {        /* cg.c:437-443 */
+    CHK(HipxPCApply(pc, A, R, Z));
+    CHK(HipxMatMult(A, Z, ksp->S));
+    CHK(sr_dots(A, Z, ksp->S, R, n, sums + 1));
+  }
   ksp->delta = sums[1]; /* cg.c:440 */
   ksp->beta  = sums[2]; /* cg.c:441 */
   if (isnan(ksp->beta) || isinf(ksp->beta)) ksp->reason = KSP_DIVERGED_NANORINF;
@@ -274,6 +293,7 @@ static int cg_sr_step(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, dou
   const hipx_int n = A->m;
   double        *R = ksp->R, *Z = ksp->Z, *P = ksp->P, *S = ksp->S, *W = ksp->W;
   const int      onekernel = ksp->fused && (pc->type == HIPX_PC_JACOBI || pc->type == HIPX_PC_NONE);
+  const int      precond   = ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED;
   for (hipx_int st = 0; st < nsteps && !ksp->reason && ksp->i < ksp->max_it; st++) {
     const hipx_int i = ksp->i;
     double         b = 0.0, dpiold, sums[3], dp;
@@ -312,11 +332,25 @@ static int cg_sr_step(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, dou
       }
       CHK(hipxVecAXPY(X, ksp->a, P, n));  /* cg.c:490 */
       CHK(hipxVecAXPY(R, -ksp->a, W, n)); /* cg.c:491 */
-      CHK(HipxPCApply(pc, A, R, Z));      /* cg.c:493 */
+      CHK(HipxPCApply(pc, A, R, Z));      /* cg.c:493 | 503 | 519: z <- B r once per iteration whatever the norm type (for the unpreconditioned norm and
+                                             KSP_NORM_NONE the reference applies it after the convergence test: nothing in between reads z) */
     }
-    CHK(HipxMatMult(A, Z, S));              /* cg.c:494 */
-    CHK(sr_sums(A, Z, S, R, n, sums));      /* cg.c:495 + 523: VecNorm(Z) and VecMDot(Z, {S, R}) as one reduction */
-    dp = sqrt(sums[0]);
+    sums[0] = sums[1] = sums[2] = 0.0;
+    if (precond) {
+      CHK(HipxMatMult(A, Z, S));              /* cg.c:494 */
+      CHK(sr_sums(A, Z, S, R, n, sums));      /* cg.c:495 + 523: VecNorm(Z) and VecMDot(Z, {S, R}) as one reduction */
+      dp = sqrt(sums[0]);
+    } else if (ksp->normtype == HIPX_KSP_NORM_UNPRECONDITIONED) {
+      CHK(HipxVecNorm2(A, R, n, &dp));        /* cg.c:498 */
+    } else if (ksp->normtype == HIPX_KSP_NORM_NATURAL) {
+      CHK(HipxMatMult(A, Z, S));              /* cg.c:504 */
+      CHK(sr_dots(A, Z, S, R, n, sums + 1));  /* cg.c:505 */
+      if (isnan(sums[2]) || isinf(sums[2])) { /* KSPCheckDot cg.c:508 */
+        ksp->reason = KSP_DIVERGED_NANORINF;
+        break;
+      }
+      dp = sqrt(fabs(sums[2]));               /* cg.c:509 */
+    } else dp = 0.0;                          /* cg.c:511 */
     if (isnan(dp) || isinf(dp)) {
       ksp->reason = KSP_DIVERGED_NANORINF;
       break;
@@ -325,6 +359,10 @@ static int cg_sr_step(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, dou
     log_history(ksp, dp);
     CHK(converged_default(ksp, A, pc, i + 1, dp, B, &ksp->reason)); /* cg.c:514 */
     if (ksp->reason) break;
+    if (!precond && ksp->normtype != HIPX_KSP_NORM_NATURAL) { /* cg.c:518-526 */
+      CHK(HipxMatMult(A, Z, S));
+      CHK(sr_dots(A, Z, S, R, n, sums + 1));
+    }
     ksp->delta = sums[1];
     ksp->beta  = sums[2];
     if (isnan(ksp->beta) || isinf(ksp->beta)) { /* cg.c:526 */
@@ -472,8 +510,6 @@ int HipxKSPCGBegin(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double
   ksp->betaold = 1.0;
   ksp->x_pending = 0;
   ksp->a_pending = 0.0;
-  if (ksp->single_reduction && ksp->normtype != HIPX_KSP_NORM_PRECONDITIONED) return HIPX_ERR_SUP; /* the single-reduction loop is built for the preconditioned norm only:
-                                                                                                       refuse, do not run the standard loop under that name */
   if (ksp->single_reduction) return cg_sr_begin(ksp, A, pc, B, X);
   if (!ksp->guess_nonzero) CHK(hipxVecSet(X, n, 0.0)); /* itfunc.c:908 */
   if (ksp->guess_nonzero) {
@@ -656,9 +692,9 @@ int HipxKSPCGStep(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double 
   double         dp = 0.0, b, dpiold;
   /* fused update kernel (AXPY, AXPY, PCJACOBI, norm, dot): any rank count, its two sums all-reduced together;
      SpMV + dot fusion: only without an off-diagonal block (the dot needs the complete w) */
-  if (ksp->single_reduction && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED) {
-    /* pipeline == 4: the launch-ahead form (fused PCJACOBI / PCNONE; several ranks: with the ghost exchange and the all-reduce on the streams) */
-    if (ksp->pipeline == 4 && ksp->fused && (pc->type == HIPX_PC_JACOBI || pc->type == HIPX_PC_NONE) && ((A->nranks <= 1 && A->m > 0) || (A->nranks > 1 && A->B && A->halo))) return cg_sr_step_pipelined(ksp, A, pc, B, X, nsteps);
+  if (ksp->single_reduction) { /* (every norm type: cg.c:403-421,492-512; round 6) */
+    /* pipeline == 4: the launch-ahead form (preconditioned norm, fused PCJACOBI / PCNONE; several ranks: with the ghost exchange and the all-reduce on the streams) */
+    if (ksp->pipeline == 4 && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED && ksp->fused && (pc->type == HIPX_PC_JACOBI || pc->type == HIPX_PC_NONE) && ((A->nranks <= 1 && A->m > 0) || (A->nranks > 1 && A->B && A->halo))) return cg_sr_step_pipelined(ksp, A, pc, B, X, nsteps);
     return cg_sr_step(ksp, A, pc, B, X, nsteps);
   }
   const int      fused_any = ksp->fused && (pc->type == HIPX_PC_JACOBI || (pc->type == HIPX_PC_NONE && pc->dconst_valid)) && ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED;

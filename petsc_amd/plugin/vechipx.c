@@ -93,6 +93,7 @@ PetscErrorCode VecHIPXRedCachePut(int kind, Vec a, Vec b)
   HipxRedCacheEntry *e = &hipx_rc[kind];
 
   PetscFunctionBegin;
+  if (!hipx_rc_on) PetscFunctionReturn(PETSC_SUCCESS); /* -hipx_reduction_cache 0: no entry ever becomes live, also not from the lazy producers' fused kernels */
   if (e->a && !e->used) hipx_rc_miss[kind]++;
   else hipx_rc_miss[kind] = 0;
   e->a       = ((PetscObject)a)->id;
@@ -118,7 +119,7 @@ static PetscErrorCode VecHIPXRedCacheGet(int kind, Vec a, Vec b, PetscBool order
 
   PetscFunctionBegin;
   *v = NULL;
-  if (!e->live || !((e->a == ia && e->b == ib) || (!ordered && e->a == ib && e->b == ia))) PetscFunctionReturn(PETSC_SUCCESS);
+  if (!hipx_rc_on || !e->live || !((e->a == ia && e->b == ib) || (!ordered && e->a == ib && e->b == ia))) PetscFunctionReturn(PETSC_SUCCESS);
   if (!e->fetched) {
     PetscCallHIPX(hipxRedEnd(hipx_rc_slot[kind], kind == HIPX_RC_PWMULT ? 2 : 1, e->v));
     e->fetched = PETSC_TRUE;
@@ -322,13 +323,12 @@ static PetscBool VecHIPXLazyConflict(const HipxLazyOp *a, const HipxLazyOp *b) {
 
 /* run the operations marked in run[], in their order (a marked "x += a p" directly followed -- among the marked ones -- by "p = z + b p" as one kernel),
    and keep the others recorded, in their order */
-static PetscErrorCode VecHIPXLazyRunMarked(const PetscBool run[])
+static PetscErrorCode VecHIPXLazyRunMarked_Inner(const PetscBool run[])
 {
   HipxLazyOp keep[HIPX_LAZY_MAX];
   int        nkeep = 0, prev = -1;
 
   PetscFunctionBegin;
-  hipx_lazy_run = PETSC_TRUE;
   for (int k = 0; k <= hipx_nlazy; k++) {
     if (k < hipx_nlazy && !run[k]) {
       keep[nkeep++] = hipx_lazy[k];
@@ -349,8 +349,22 @@ static PetscErrorCode VecHIPXLazyRunMarked(const PetscBool run[])
     prev = k < hipx_nlazy ? k : -1;
   }
   for (int k = 0; k < nkeep; k++) hipx_lazy[k] = keep[k];
-  hipx_nlazy    = nkeep;
+  hipx_nlazy = nkeep;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* (a kernel launch that fails in there must not leave the queue "being run" for ever -- every later sync would be a no-op on stale data -- nor keep raw
+   Vec pointers recorded: the state is restored and the queue dropped before the error travels on) */
+static PetscErrorCode VecHIPXLazyRunMarked(const PetscBool run[])
+{
+  PetscErrorCode ierr;
+
+  PetscFunctionBegin;
+  hipx_lazy_run = PETSC_TRUE;
+  ierr          = VecHIPXLazyRunMarked_Inner(run);
   hipx_lazy_run = PETSC_FALSE;
+  if (ierr) hipx_nlazy = 0;
+  PetscCall(ierr);
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -435,10 +449,13 @@ static PetscErrorCode VecHIPXLazyTryAXPYPointwiseMult(Vec w, Vec x, Vec y, Petsc
       PetscFunctionReturn(PETSC_SUCCESS);
   {
     const HipxLazyOp o = hipx_lazy[hit];
+    PetscErrorCode   ierr;
     hipx_lazy_run      = PETSC_TRUE; /* (the accessors below must not run the queue) */
-    if (y) PetscCall(VecHIPXCopyToDevice(y));
-    PetscCall(VecHIPXAllocate(w));
+    ierr               = y ? VecHIPXCopyToDevice(y) : PETSC_SUCCESS;
+    if (!ierr) ierr = VecHIPXAllocate(w);
     hipx_lazy_run = PETSC_FALSE;
+    if (ierr) hipx_nlazy = 0; /* (as in VecHIPXLazyRunMarked: never leave with the flag set or operations recorded) */
+    PetscCall(ierr);
     VecHIPXRedCacheInvalidate(w);
     if (!y) /* w = x: the kernel's multiplication by 1.0 returns its operand, bit for bit */
       PetscCallHIPX(hipxVecAXPYPointwiseMultDotsBegin(VecHIPXGetExt(x)->d_array, o.s, VecHIPXGetExt(o.x)->d_array, VecHIPXGetExt(w)->d_array, NULL, 1.0, x->map->n, VecHIPXRedCacheSlot(HIPX_RC_PWMULT)));

@@ -38,9 +38,11 @@ def entry(hist, source, what, extra=None):
     return e
 
 
-def ref_shim(stencil, n, ksp, pc, its):
+def ref_shim(stencil, n, ksp, pc, its, m=None):
     env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1", LD_PRELOAD=SHIM)
     a = [REF, "-stencil", str(stencil), "-n", str(n), "-ksp_type", ksp, "-pc_type", pc, "-ksp_rtol", "1e-50", "-ksp_max_it", str(its), "-history", "-mat_type", "aij", "-vec_type", "standard"]
+    if m is not None:  # the 2-D 5-point operator of ex2.c on an m x n grid
+        a += ["-m", str(m)]
     if ksp == "cg":
         a += ["-ksp_norm_type", "preconditioned"]
     out = subprocess.run(a, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=7200).stdout
@@ -59,6 +61,8 @@ def jobs():
     J["cg_jacobi_7pt_64"] = lambda: entry(ref_shim(7, 64, "cg", "jacobi", 40), "reference+shim", "7-pt Poisson 64^3, KSPCG + PCJACOBI; 40 iterations (small multi-rank smoke runs of bench.py)")
     J["cg_none_7pt_64x64x16"] = lambda: stream("7pt_box", (64, 64, 16), 64 * 64 * 16, "none", 20, "7-pt 64 x 64 x 16 box, KSPCG + PCNONE; 20 iterations (weak-mode smoke runs: --grid 64 --scaling weak on 2 ranks)")
     J["cg_jacobi_7pt_256"] = lambda: entry(ref_shim(7, 256, "cg", "jacobi", 60), "reference+shim", "BASELINE config 2: 7-pt Poisson 256^3, KSPCG + PCJACOBI, b = A*1, x0 = 0; 60 iterations")
+    # round 6: BASELINE config 1's operator (ex2.c:70-94) at HBM size -- north_star's 5-point leg
+    J["cg_jacobi_5pt_4096x4096x1"] = lambda: entry(ref_shim(5, 4096, "cg", "jacobi", 40, m=4096), "reference+shim", "2-D 5-pt Laplacian (ex2.c) 4096 x 4096 = 16.8 M rows, KSPCG + PCJACOBI, b = A*1, x0 = 0; 40 iterations")
     J["cg_jacobi_27pt_160"] = lambda: entry(ref_shim(27, 160, "cg", "jacobi", 40), "reference+shim", "27-pt (bench_kspsolve.c) 160^3, KSPCG + PCJACOBI; 40 iterations")
     J["cg_jacobi_7pt_512"] = lambda: stream("7pt", 512, 512 ** 3, "jacobi", 24, "7-pt Poisson 512^3 (134 M rows), KSPCG + PCJACOBI; 24 iterations")
     J["cg_jacobi_27pt_512"] = lambda: stream("27pt", 512, 512 ** 3, "jacobi", 16, "north_star scaling target: 27-pt 512^3 (3.6e9 nonzeros), KSPCG + PCJACOBI; 16 iterations")

@@ -98,11 +98,13 @@ def test_bench_goldens_cover_the_configurations_it_gates():
     head = b.Cfg(7, (256, 256, 256), "cg", "jacobi")
     assert head.golden_key() == "cg_jacobi_7pt_256" and head.metric() == "CG iterations/sec, 7-pt Poisson 256^3 fp64, KSPCG+PCJACOBI"
     need = [head.golden_key(), b.Cfg(27, (512, 512, 512), "cg", "jacobi").golden_key(), b.Cfg(7, (1024, 1024, 128), "cg", "none").golden_key(),
-            b.Cfg(7, (1024, 1024, 256), "cg", "none").golden_key(), "gmres_sor_27pt_256_np1", "gmres_sor_27pt_256_np8", "cg_jacobi_7pt_64", "cg_none_7pt_64x64x16"]
+            b.Cfg(7, (1024, 1024, 256), "cg", "none").golden_key(), b.Cfg(5, (4096, 4096, 1), "cg", "jacobi").golden_key(), "gmres_sor_27pt_256_np1", "gmres_sor_27pt_256_np8", "cg_jacobi_7pt_64", "cg_none_7pt_64x64x16"]
     for k in need:
         assert k in g, k
         e = g[k]
         assert len(e["history"]) == len(e["history_hex"]) >= 13 and all(float.fromhex(h) == v for h, v in zip(e["history_hex"], e["history"]))
+    c5 = b.Cfg(5, (4096, 4096, 1), "cg", "jacobi")  # round 6: north_star's 5-point leg = ex2.c's operator (config 1) at HBM size
+    assert c5.golden_key() == "cg_jacobi_5pt_4096x4096x1" and c5.shape() == "4096x4096" and c5.driver_args(3)[:4] == ["-stencil", "5", "-n", "4096"] and "-m" in c5.driver_args(3) and "-nz" not in c5.driver_args(3)
     assert b.Cfg(7, (1024, 1024, 128), "cg", "none").driver_args(5)[:4] == ["-stencil", "7", "-n", "1024"] and "-nz" in b.Cfg(7, (1024, 1024, 128), "cg", "none").driver_args(5)
 
 

@@ -241,7 +241,7 @@ def test_pipelined_and_single_reduction_cg_exact_mode_within_1e12(np_):
         check_history("7-pt 32^3 %s np=%d EXACT mode: plugin vs the REFERENCE with exact BLAS reductions" % (" ".join(ksp), np_), got, refx, tol=TOL_HISTORY)
 
 
-def host_cg_sr(hx, ks, n, rtol, pcname):
+def host_cg_sr(hx, ks, n, rtol, pcname, normtype=1, forms=(0, 1, 4)):
     """the host layer's single-reduction CG (HipxKSP.single_reduction) on the 7-pt n^3 operator, b = A 1"""
     from petsc_amd import _lib
     N = n ** 3
@@ -253,14 +253,14 @@ def host_cg_sr(hx, ks, n, rtol, pcname):
     ones, B, X = _lib.DVec(N, np.ones(N)), _lib.DVec(N), _lib.DVec(N, np.zeros(N))
     _lib.chk(ks.HipxMatMult(C.byref(M), ones.ptr, B.ptr))
     out = {}
-    for fused in (0, 1, 4):  # 4: the fused update kernel in the launch-ahead loop (HipxKSP.pipeline = 4, round 5)
+    for fused in forms:  # 4: the fused update kernel in the launch-ahead loop (HipxKSP.pipeline = 4, round 5)
         pc = _lib.HipxPC()
         ks.HipxPCSetDefaults(C.byref(pc))
         pc.type = {"none": 0, "jacobi": 1}[pcname]
         _lib.chk(ks.HipxPCSetUp(C.byref(pc), C.byref(M)))
         k = _lib.HipxKSP()
         ks.HipxKSPSetDefaults(C.byref(k))
-        k.rtol, k.max_it, k.fused, k.single_reduction = rtol, 10000, 1 if fused else 0, 1
+        k.rtol, k.max_it, k.fused, k.single_reduction, k.normtype = rtol, 10000, 1 if fused else 0, 1, normtype
         if fused == 4:
             k.pipeline = 4
         hist = np.zeros(4000)
@@ -301,6 +301,27 @@ def test_single_reduction_cg_follows_the_reference_in_exact_mode(hx, n, pcname):
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][0], plug[0])
     # round 5: the launch-ahead form (scalars formed on the device, x updated one kernel later): the same history, iteration count, reason and SOLUTION
     assert np.array_equal(got[4][0], got[1][0]) and got[4][1:3] == got[1][1:3] and np.array_equal(got[4][3], got[1][3]) and np.array_equal(got[0][3], got[1][3])
+
+
+@pytest.mark.parametrize("norm,normtype", [("unpreconditioned", 2), ("natural", 3)])
+def test_single_reduction_cg_other_norm_types_follow_the_reference(hx, norm, normtype):
+    """Round 6: KSPSolve_CG_SingleReduction's other norm branches (cg.c:408-421, 497-512, 518-526) in the host layer -- statement by statement and
+    with the fused update kernel the SAME history bit for bit; against the reference's own `-ksp_cg_single_reduction -ksp_norm_type <norm>` run with exact
+    BLAS reductions 1e-10 per entry (the reference's VecMDot(Z, {S, R}) leaves one sum to a plain C loop: see the test above)."""
+    from petsc_amd import _lib
+    _, ks = _lib.load()
+    n = 32
+    args = ["-stencil", "7", "-n", str(n), "-ksp_type", "cg", "-ksp_cg_single_reduction", "-ksp_norm_type", norm, "-pc_type", "jacobi", "-ksp_rtol", "1e-8", "-history"]
+    p_refx = launch(1, args, False, exact=True)
+    _lib.chk(hx.hipxSetReductionMode(1))
+    try:
+        got = host_cg_sr(hx, ks, n, 1e-8, "jacobi", normtype=normtype, forms=(0, 1))
+    finally:
+        _lib.chk(hx.hipxSetReductionMode(0))
+    refx = collect(p_refx)
+    for name, g in (("statement by statement", got[0]), ("fused update kernel", got[1])):
+        check_history("7-pt %d^3 single-reduction CG+jacobi %s norm EXACT mode: %s vs the REFERENCE" % (n, norm, name), g, refx, tol=1e-10)
+    assert np.array_equal(got[0][0], got[1][0]) and got[0][1:3] == got[1][1:3]
 
 
 @pytest.mark.parametrize("n,pcname,chunk", [(24, "jacobi", 1), (24, "jacobi", 3), (32, "none", 7)])
