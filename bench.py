@@ -236,7 +236,9 @@ def oracle_port_baseline(ai, aj, aa, b, budget_s, stencil, n):
 class Problem:
     """One rank's share of the system on the device + the solver objects of the C host layer."""
 
-    def __init__(self, cfg, rank, world, dist, transport="rccl", fused=1, pipeline=1, keep_host=False):
+    def __init__(self, cfg, rank, world, dist, transport="rccl", fused=1, pipeline=1, keep_host=False, loopback=False):
+        """loopback: this process plays rank `rank` of `world` ALONE (per_rank_budget leg): the rank's real blocks, ghost lists and an IPC self-exchange
+        (petsc_amd/dist.py build_plan(..., loopback=True)); a one-rank IPC communicator must be up (dist.comm_init_loopback)."""
         from petsc_amd import _lib
         from petsc_amd import dist as pdist
         self.lib, self.cfg, self.world, self.fused, self.pipeline = _lib, cfg, world, fused, pipeline
@@ -259,8 +261,8 @@ class Problem:
         self.setup_times["host_assembly_s"] = time.perf_counter() - t_a
         t_a = time.perf_counter()
         if world > 1:
-            plan = pdist.build_plan(ai, aj, aa, ranges, rank, dist=dist)
-            self.M, keep = pdist.create_device_mat(plan, world, rank=rank, dist=dist, transport=transport)
+            plan = pdist.build_plan(ai, aj, aa, ranges, rank, dist=dist, loopback=loopback)
+            self.M, keep = pdist.create_device_mat(plan, world, rank=rank, dist=dist, transport=transport, loopback=loopback)
             self.Am = keep[0]
             if len(keep) > 1:
                 self.Bm, self.halo, self.lvec = keep[1], keep[2], keep[3]
@@ -763,6 +765,41 @@ def leg_sor_arbitrary_values(hx, lib, ks, n=256):
     return out
 
 
+def leg_per_rank_budget(hx, lib, torch, sync, cases, steps=60, warmup=8):
+    """What ONE rank of an 8-GPU run does per CG iteration, timed alone on this GPU (verdict r5 item 1): rank 3 of 8's slab -- its real diagonal and off-diagonal
+    blocks, ghost lists, the IPC put / wait / acknowledge kernels and the on-stream all-reduce kernel of a one-rank communicator, the neighbours' planes played
+    by the rank's own (loop-back) -- under the launch-ahead fused CG.  Reported: ms per iteration (everything a rank does except the wire: no xGMI latency, no
+    skew between ranks), the HIP-event time of every section, and the round-5 kernel sequence (separate direction and dot kernels, HipxKSP.fused = 3) beside the
+    round-6 one (hipxMatMultMPICGDirectionDotBegin).  predicted_8gpu_it_s = 1 / that time: an UPPER bound for the 8-GPU rate."""
+    from petsc_amd import dist as pdist
+    pdist.comm_init_loopback()
+    out = {}
+    try:
+        for name, cfg, world, rank in cases:
+            e = {"what": "rank %d of %d of %s, KSPCG + %s, alone on this GPU with a loop-back ghost exchange and a one-rank IPC all-reduce" % (rank, world, cfg.metric(), cfg.pcname())}
+            for label, fused in (("round5_separate_direction_and_dot_kernels", 3), ("fused_mpi_product", 1)):
+                P = Problem(cfg, rank, world, None, transport="ipc", fused=fused, pipeline=1, loopback=True)
+                kname = P.setup(0)
+                r = timed_steps(P, steps, warmup, sync, None, torch)
+                sec = r["sections"]
+                kern = {"product_us": 1e3 * r["spmv_ms"], "product_launches_per_iteration": r["launches"] / float(steps)}
+                for k in ("halo_ms", "allreduce_ms", "offdiag_ms", "cg_update_ms", "cg_direction_ms", "dot_fold_ms"):
+                    if k in sec:
+                        kern[k.replace("_ms", "_us")] = 1e3 * sec[k]
+                        kern[k.replace("_ms", "_per_iteration")] = sec[k.replace("_ms", "_calls")] / float(steps)
+                e[label] = {"ms_per_iteration": 1e3 * r["elapsed"] / steps, "predicted_8gpu_it_s": steps / r["elapsed"], "sections": kern, "spmv_kernel": kname.split(" ")[0],
+                            "rows": P.m, "ghosts": P.nghost, "residual_norm_after": r["rnorm"]}
+                P.destroy()
+            e["ms_per_iteration"] = e["fused_mpi_product"]["ms_per_iteration"]
+            e["predicted_8gpu_it_s"] = e["fused_mpi_product"]["predicted_8gpu_it_s"]
+            e["same_residual_both_sequences"] = bool(abs(e["fused_mpi_product"]["residual_norm_after"] - e["round5_separate_direction_and_dot_kernels"]["residual_norm_after"])
+                                                     <= 1e-10 * abs(e["fused_mpi_product"]["residual_norm_after"]))
+            out[name] = e
+    finally:
+        lib.chk(hx.hipxCommFinalize())
+    return out
+
+
 def leg_matrix_solver(cfg, steps, warmup, sync, torch, best_ranks=None, parity_its=10, cpu_its=10, tmpdir=None, allow_ref_run=True):
     """BASELINE config 4's solver leg: KSPCG + PCJACOBI / PCSOR on a given matrix (a file, or the SPD Flan-like stand-in) on one GPU --
     iterations/s, the SpMV kernel auto picks with its roofline on the CSR bytes, and the first iterations against the REFERENCE's own
@@ -934,6 +971,10 @@ def compact_line(out):
                 continue
             if "error" in leg or "skipped" in leg:
                 legs[name] = {"error": _short(leg["error"], 80)} if "error" in leg else {"skipped": _short(leg["skipped"], 40)}
+                continue
+            if name == "per_rank_budget":  # per case: [ms per iteration of one rank alone (round-6 sequence), the round-5 sequence's, predicted 1 -> 8 GPU scaling]
+                legs[name] = {k: [_num(v.get("ms_per_iteration"), 4), _num((v.get("round5_separate_direction_and_dot_kernels") or {}).get("ms_per_iteration"), 4), _num(v.get("predicted_scaling_1_to_8"), 3)]
+                              for k, v in leg.items() if isinstance(v, dict)}
                 continue
             e = {}
             if leg.get("iterations_per_s") is not None:
@@ -1333,6 +1374,22 @@ def main():
                     other[name] = fn()
             except Exception as e:  # noqa: BLE001
                 other[name] = {"error": str(e)[:400]}
+        if room(14 + reserve):
+            try:
+                with phase("per_rank_budget"):
+                    prb = leg_per_rank_budget(hx, _lib, torch, sync, [("27pt_512_rank3of8", Cfg(27, (512, 512, 512), "cg", "jacobi"), 8, 3), ("7pt_256_rank3of8", Cfg(7, (256, 256, 256), "cg", "jacobi"), 8, 3)])
+                one = other.get("cg_jacobi_27pt_512_strong", {}).get("iterations_per_s")
+                if one and "27pt_512_rank3of8" in prb:
+                    prb["27pt_512_rank3of8"]["one_gpu_it_s_this_run"] = one
+                    prb["27pt_512_rank3of8"]["predicted_scaling_1_to_8"] = prb["27pt_512_rank3of8"]["predicted_8gpu_it_s"] / one
+                if value and "7pt_256_rank3of8" in prb:
+                    prb["7pt_256_rank3of8"]["one_gpu_it_s_this_run"] = value
+                    prb["7pt_256_rank3of8"]["predicted_scaling_1_to_8"] = prb["7pt_256_rank3of8"]["predicted_8gpu_it_s"] / value
+                other["per_rank_budget"] = prb
+            except Exception as e:  # noqa: BLE001
+                other["per_rank_budget"] = {"error": str(e)[:400]}
+        else:
+            other["per_rank_budget"] = {"skipped": "budget"}
         for c4 in (cfg4, cfg4s):
             if c4 is not None:
                 c4._cache = None

@@ -358,6 +358,16 @@ int hipxMatMultMPIDotBegin(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, 
 int hipxVecMDotBeginAllreduce(const double *x, hipx_int nv, const double *const *y, hipx_int n, int slot, double *dev_results); /* the same, all-reduced on the stream */
 int hipxCGFusedUpdateBeginAllreduce(double *x, double *r, double *z, const double *p, const double *w, const double *d, double dconst, const double *dev_beta, const double *dev_dpi,
                                     hipx_int n, int slot, double *dev_sums2);
+/* Round 6: hipxMatMultCGDirectionDotBegin for a rank WITH an off-diagonal block -- MatMult_MPIAIJ (mpiaij.c:1047-1061) + the CG direction update (cg.c:248-249,
+   and cg.c:305 of the iteration before) + VecTDot_MPI (cg.c:258) as: [new direction of the boundary rows formed on the way into the ghost exchange] ||
+   [p_new = z d + b p, x += a p, w = Ad p_new, dot partials of the rows without off-diagonal entries: ONE kernel] -> [w += Bo ghost on the boundary rows, their
+   share of the dot, the fold of all partials: one small kernel] -> all-reduce on the stream -> host slot + device copy.  Replaces the sequence hipxCGAypxAxpyDev,
+   hipxMatMultMPIDotBegin (a separate direction kernel and a separate dot kernel: 7 vector passes more).  Same arguments as the one-rank form plus the blocks,
+   the halo plan and lvec; n = local rows.  *fused = 0: nothing enqueued (the blocks are not a z-slab of a stencil grid in natural ordering, or the march
+   kernel does not take the diagonal block): the caller runs the separate kernels.  Vectors bit-identical to those; the dot = the same products in another
+   order (exact reduction mode: Dot2 over the complete vectors, order-free). */
+int hipxMatMultMPICGDirectionDotBegin(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *p_old, double *p_new, const double *z, double dconst, double *x, double b, double a,
+                                      const double *dev_beta_new, const double *dev_beta_old, const double *dev_dpi, double *lvec, double *w, hipx_int n, int slot, double *dev_dot, int *fused);
 /* which transport the next exchange of this plan takes: 1 = IPC peer stores, 2 = RCCL send/recv, 0 = none set up */
 int hipxHaloTransport(hipxHalo h, int *transport);
 

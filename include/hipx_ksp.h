@@ -52,7 +52,8 @@ typedef struct {
   double   gmres_haptol;
   int      gmres_cgs_refine; /* 0 never, 1 if needed, 2 always */
   int      guess_nonzero;
-  int      fused;            /* CG only: use the fused SpMV+dot / update+PC+dots kernels (same arithmetic) */
+  int      fused;            /* CG only: use the fused SpMV+dot / update+PC+dots kernels (same arithmetic); bit 1 (fused = 3): on several ranks keep the separate
+                                direction and dot kernels around MatMult_MPIAIJ (the round-5 sequence, for A/B timing against hipxMatMultMPICGDirectionDotBegin) */
   /* results */
   hipx_int its;
   int      reason;

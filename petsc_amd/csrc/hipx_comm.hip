@@ -11,6 +11,7 @@
 //     MatMultAdd wait for the receive (the mpiaij.c:1056-1059 shape with stream-level overlap).
 #include "hipx_internal.h"
 #include "hipx_reduce.h"
+#include "hipx_ipc.h"
 #include <rccl/rccl.h>
 #include <cstdlib>
 #include <cstring>
@@ -53,9 +54,26 @@ Comm &cm()
     if (r_ != ncclSuccess) return hipx::fail(HIPX_ERR_GPU, ncclGetErrorString(r_), __FILE__, __LINE__); \
   } while (0)
 
-__global__ void pack_kernel(const double *__restrict__ x, const hipx_int *__restrict__ idx, double *__restrict__ buf, hipx_int n)
+// What travels to the neighbours.  Plain: x[idx].  CG (round 6, hipxMatMultMPICGDirectionDotBegin): the NEW direction p = (z * dconst) + b x[idx] formed on the
+// way out (cg.c:248-249) -- the operations, operands and order of cg_aypx_axpy_kernel / spmv_march2_kernel's prologue, hence the bits the owner's product kernel
+// forms for the same elements a moment later; b = *dev_beta_new / *dev_beta_old when the sums are device-resident (launch-ahead loop), else the argument.
+struct PackCG {
+  const double *z = nullptr;
+  double        dconst = 1.0, b = 0.0;
+  const double *dev_beta_new = nullptr, *dev_beta_old = nullptr;
+};
+template <bool CG>
+__device__ __forceinline__ double halo_value(const double *__restrict__ x, hipx_int i, const PackCG &cg, double b)
 {
-  for (hipx_int i = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (hipx_int)gridDim.x * blockDim.x) buf[i] = x[idx[i]];
+  if (!CG) return x[i];
+  const double zv = cg.z[i] * cg.dconst;
+  return zv + b * x[i];
+}
+template <bool CG>
+__global__ void pack_kernel(const double *__restrict__ x, const hipx_int *__restrict__ idx, double *__restrict__ buf, hipx_int n, const PackCG cg)
+{
+  const double b = CG ? (cg.dev_beta_new ? (*cg.dev_beta_new / *cg.dev_beta_old) : cg.b) : 0.0;
+  for (hipx_int i = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (hipx_int)gridDim.x * blockDim.x) buf[i] = halo_value<CG>(x, idx[i], cg, b);
 }
 
 // ---- IPC transport kernels.  Flags live in fine-grained memory and are accessed with system-scope atomics; payload writes
@@ -75,40 +93,54 @@ static long long ipc_wait_ticks()
   return t;
 }
 
-__device__ __forceinline__ bool ipc_wait_ge(const unsigned long long *flag, unsigned long long want, unsigned int *err, long long IPC_WAIT_TICKS)
-{
-  long long t0 = 0;
-  for (unsigned spins = 1;; spins++) {
-    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return true;
-    __builtin_amdgcn_s_sleep(4);
-    if ((spins & 0x3ff) == 0) {
-      const long long now = (long long)wall_clock64();
-      if (!t0) t0 = now;
-      if (now - t0 > IPC_WAIT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
-        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return false;
-      }
-    }
-  }
-}
-
-// gather x[idx[k]] straight into the neighbour's ghost buffer; the last workgroup to finish publishes the sequence number
-__global__ __launch_bounds__(256) void ipc_put_kernel(const double *__restrict__ x, const hipx_int *__restrict__ idx, hipx_int n, double *dst, const unsigned long long *ack_local,
-                                                      unsigned long long need_ack, unsigned long long *data_flag, unsigned long long seq, unsigned int *ticket, unsigned int *err, long long limit)
+// Round 6: ONE launch sends to every neighbour (blockIdx.y = the neighbour's segment), on the COMPUTE stream in front of the product: a workgroup waits until
+// the receiver has consumed the buffer of exchange seq - 2, gathers x[idx[k]] (CG: forms the new direction on the way, PackCG) and stores PAIRS of doubles
+// straight into the neighbour's ghost buffer as 16-byte write-through stores; the wave drains them, a ticket collects the segment's workgroups, the last one
+// raises the neighbour's sequence flag (hipx_ipc.h: no fences).  The stores are posted: over xGMI the wire time passes while the product kernel runs behind
+// this kernel on the same stream -- the overlap of mpiaij.c:1056-1058 without a second kernel that fights the product for registers (round 5's put kernel
+// on the comm stream could not become resident beside a 512-workgroup product that owns every SIMD's register file: it ran when the product had finished).
+struct PutSeg {
+  const hipx_int           *idx;
+  hipx_int                  n;
+  double                   *dst;
+  const unsigned long long *ack;
+  unsigned long long        need_ack;
+  unsigned long long       *flag;
+  unsigned int             *ticket;
+};
+struct PutArgs {
+  PutSeg seg[4];
+};
+template <bool CG>
+__global__ __launch_bounds__(256) void ipc_put_kernel(const double *__restrict__ x, const PutArgs args, unsigned long long seq, unsigned int *err, long long limit, const PackCG cg)
 {
   __shared__ int ok;
-  if (threadIdx.x == 0) ok = ipc_wait_ge(ack_local, need_ack, err, limit) ? 1 : 0;  // the buffer of exchange seq - 2 has been consumed
+  const PutSeg  &sg = args.seg[blockIdx.y];
+  const hipx_int n2 = sg.n >> 1;
+  if ((hipx_int)blockIdx.x * 256 >= (n2 ? n2 : 1)) return;  // (segments shorter than the longest one: no workgroup, no ticket -- the host counts the same way)
+  if (threadIdx.x == 0) ok = ipc_wait_ge(sg.ack, sg.need_ack, err, limit) ? 1 : 0;  // the buffer of exchange seq - 2 has been consumed
   __syncthreads();
-  if (ok)
-    for (hipx_int i = (hipx_int)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (hipx_int)gridDim.x * blockDim.x) dst[i] = x[idx[i]];
-  __threadfence_system();
+  const double b = CG ? (cg.dev_beta_new ? (*cg.dev_beta_new / *cg.dev_beta_old) : cg.b) : 0.0;
+  if (ok) {
+    const bool al = (reinterpret_cast<uintptr_t>(sg.dst) & 15) == 0;
+    for (hipx_int q = (hipx_int)blockIdx.x * 256 + threadIdx.x; q < n2; q += (hipx_int)gridDim.x * 256) {
+      const double v0 = halo_value<CG>(x, sg.idx[2 * q], cg, b), v1 = halo_value<CG>(x, sg.idx[2 * q + 1], cg, b);
+      if (al) ipc_store16(sg.dst + 2 * q, v0, v1);
+      else {
+        ipc_store8(sg.dst + 2 * q, v0);
+        ipc_store8(sg.dst + 2 * q + 1, v1);
+      }
+    }
+    if ((sg.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) ipc_store8(sg.dst + sg.n - 1, halo_value<CG>(x, sg.idx[sg.n - 1], cg, b));
+  }
+  ipc_drain();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned int t = atomicAdd(ticket, 1u);
-    if (t == gridDim.x - 1) {
-      *ticket = 0;
-      __threadfence_system();
-      __hip_atomic_store(data_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned nwg = (unsigned)(((n2 ? n2 : 1) + 255) / 256) < gridDim.x ? (unsigned)(((n2 ? n2 : 1) + 255) / 256) : gridDim.x;  // workgroups of this segment that got past the early return
+    const unsigned t   = __hip_atomic_fetch_add(sg.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == nwg - 1) {
+      __hip_atomic_store(sg.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sg.flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -120,17 +152,31 @@ __global__ void ipc_wait_kernel(const unsigned long long *data_seq, const int *r
 
 __global__ void ipc_ack_kernel(unsigned long long *const *ack_ptrs, int nrecv, unsigned long long seq)
 {
-  if ((int)threadIdx.x < nrecv) __hip_atomic_store(ack_ptrs[threadIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if ((int)threadIdx.x < nrecv) __hip_atomic_store(ack_ptrs[threadIdx.x], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (the kernels that read the ghost values have finished: stream order)
 }
 
 
 // pairs = 1 (compensated mode): vals holds n unrounded (hi, lo) pairs -- 2n words travel -- and every rank folds the nranks pairs of
 // each sum in rank order with TwoSum, rounding hi + lo once: the same bits on every rank and for every way of cutting the rows.
+// Round 6: the kernel also carries what used to be two more launches around it (5 us each on the critical path of every reduction) -- in front, the
+// acknowledgement of the ghost buffers the kernels before it have consumed (ipc_ack_kernel); behind, the publication of the reduced values to the host slot
+// and to device memory for the kernels queued ahead (red_signal_kernel).
+struct PostAck {
+  unsigned long long *const *ptrs = nullptr;  // per receive neighbour: &peer.ack_seq[me]
+  int                        n    = 0;
+  unsigned long long         seq  = 0;
+};
+struct PostSignal {
+  unsigned long long *flag = nullptr;  // nullptr: no publication
+  unsigned long long  seq  = 0;
+  double             *results = nullptr, *dres = nullptr;
+};
 __global__ __launch_bounds__(64) void ipc_allreduce_kernel(double *vals, int nsums, int pairs, int me, int nranks, char *const *peer, size_t hdr, unsigned long long seq, unsigned int *err,
-                                                           long long limit)
+                                                           long long limit, const PostAck ack, const PostSignal sig)
 {
   const int t = threadIdx.x, q = (int)(seq & 1);
   const int n = pairs ? 2 * nsums : nsums;
+  if (t < ack.n) __hip_atomic_store(ack.ptrs[t], ack.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (t < n) {
     const double v = vals[t];
     for (int p = 0; p < nranks; p++) {
@@ -168,6 +214,17 @@ __global__ __launch_bounds__(64) void ipc_allreduce_kernel(double *vals, int nsu
     }
     vals[t] = sum;
   }
+  if (sig.flag) {
+    __syncthreads();
+    if (t < nsums) {
+      const double v = vals[t];
+      sig.results[t] = v;  // pinned, host-mapped
+      if (sig.dres) sig.dres[t] = v;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(sig.flag, sig.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 }  // namespace
@@ -204,8 +261,9 @@ struct hipxHalo_s {
   unsigned int         *d_ticket = nullptr;    // one per send neighbour
   int                  *d_recv_ranks = nullptr;
   unsigned long long  **d_ack_ptrs = nullptr;  // per recv neighbour: &peer.ack_seq[me]
-  unsigned int         *d_err = nullptr;
-  unsigned int         *h_err = nullptr;       // pinned; checked at the next call (no sync on the data path)
+  unsigned int         *d_err = nullptr;       // device alias of h_err
+  unsigned int         *h_err = nullptr;       // pinned, host-mapped; checked at the next call (no sync on the data path)
+  bool                  wait_pending = false;  // hipxHaloEnd has not launched the wait kernel: the consumer kernel waits itself (halo_wait_args)
   double               *ghost_cur = nullptr;   // ghost values of the exchange in progress / last completed
 };
 
@@ -223,13 +281,13 @@ __global__ __launch_bounds__(64) void dd_fold_ranks_kernel(const double *gathere
 // in-place sum of n doubles in device memory over all ranks, enqueued on the compute stream.  Plain mode: n <= 64 sums.  Compensated
 // mode (pairs): d_vals holds n <= 32 unrounded (hi, lo) pairs on entry (what the local kernels leave when RedOut::pairs is set) and the
 // n rounded totals on exit; the pairs of all ranks are folded in rank order (IPC: inside the kernel; RCCL: all-gather + a fold kernel).
-static int allreduce_dev(double *d_vals, int n, bool pairs = false)
+static int allreduce_dev(double *d_vals, int n, bool pairs = false, const PostAck *ack = nullptr, const PostSignal *sig = nullptr)
 {
   Comm &c = cm();
   int   ierr;
   if ((ierr = prof_section(HIPX_PROF_ALLREDUCE, true, rt().compute))) return ierr;
   if (c.ipc) {
-    ipc_allreduce_kernel<<<1, 64, 0, rt().compute>>>(d_vals, n, pairs ? 1 : 0, c.rank, c.nranks, c.d_peer, c.hdr, ++c.seq, c.d_err, ipc_wait_ticks());
+    ipc_allreduce_kernel<<<1, 64, 0, rt().compute>>>(d_vals, n, pairs ? 1 : 0, c.rank, c.nranks, c.d_peer, c.hdr, ++c.seq, c.d_err, ipc_wait_ticks(), ack ? *ack : PostAck{}, sig ? *sig : PostSignal{});
     HIPX_LAUNCH_CHECK();
   } else if (pairs) {
     HIPX_NCCL(ncclAllGather(d_vals, c.d_gather, (size_t)(2 * n), ncclDouble, c.rcomm, rt().compute));
@@ -238,6 +296,11 @@ static int allreduce_dev(double *d_vals, int n, bool pairs = false)
   } else HIPX_NCCL(ncclAllReduce(d_vals, d_vals, (size_t)n, ncclDouble, ncclSum, c.rcomm, rt().compute));
   return prof_section(HIPX_PROF_ALLREDUCE, false, rt().compute);
 }
+// all-reduce of c.d_red[0 .. n) on the stream, then the values to the slot's host line + sequence flag and (dres) to device memory.  IPC transport: ONE kernel,
+// which (h != NULL) first acknowledges the ghost buffers of h's exchange to their senders; RCCL: ncclAllReduce + red_signal_kernel (the release is the caller's)
+static int halo_release(hipxHalo h);
+static int allreduce_signal(double *d_vals, int n, bool pairs, int slot, double *dres, hipxHalo h);
+static int matmult_mpi(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *lvec, double *y, bool release);
 // what the local kernels of the all-reduce chains leave in c.d_red: sums, or (compensated mode) unrounded pairs
 static inline bool red_pairs() { return rt().red_exact != 0; }
 
@@ -435,14 +498,13 @@ int hipxMatMultMPIDotBegin(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, 
   HIPX_CHECK_INIT();
   Comm &c = cm();
   HIPX_ARG(c.active && slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2 && dev_dot, "communicator not initialised / bad slot");
-  int ierr = hipxMatMultMPI(Ad, Bo, h, x, lvec, y);  // mpiaij.c:1047-1061
+  int ierr = matmult_mpi(Ad, Bo, h, x, lvec, y, false);  // mpiaij.c:1047-1061 (the ghost buffer's acknowledgement rides in the all-reduce kernel below)
   if (ierr) return ierr;
   const double *ys[1] = {y};
   if (n > 0) {
     if ((ierr = launch_mdot_nosignal(x, 1, ys, n, slot, c.d_red))) return ierr;  // cg.c:258 VecXDot(P, W), local part
   } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * 2, rt().compute));
-  if ((ierr = allreduce_dev(c.d_red, 1, red_pairs()))) return ierr;
-  return red_signal(slot, c.d_red, 1, dev_dot);
+  return allreduce_signal(c.d_red, 1, red_pairs(), slot, dev_dot, h);
 }
 
 // hipxVecMDotBegin with the sums all-reduced on the stream (the single-reduction CG's one 24-byte all-reduce per iteration, launch-ahead form)
@@ -455,8 +517,7 @@ int hipxVecMDotBeginAllreduce(const double *x, hipx_int nv, const double *const 
   if (n > 0) {
     if ((ierr = launch_mdot_nosignal(x, (int)nv, y, n, slot, c.d_red))) return ierr;
   } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * 2 * (size_t)nv, rt().compute));
-  if ((ierr = allreduce_dev(c.d_red, (int)nv, red_pairs()))) return ierr;
-  return red_signal(slot, c.d_red, (int)nv, dev_results);
+  return allreduce_signal(c.d_red, (int)nv, red_pairs(), slot, dev_results, nullptr);
 }
 
 int hipxCGFusedUpdateBeginAllreduce(double *x, double *r, double *z, const double *p, const double *w, const double *d, double dconst, const double *dev_beta, const double *dev_dpi,
@@ -470,8 +531,7 @@ int hipxCGFusedUpdateBeginAllreduce(double *x, double *r, double *z, const doubl
   if (n > 0) {
     if ((ierr = launch_cg_fused_dev_nosignal(x, r, z, p, w, d, dconst, dev_beta, dev_dpi, n, slot, c.d_red))) return ierr;
   } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * 4, rt().compute));
-  if ((ierr = allreduce_dev(c.d_red, 2, red_pairs()))) return ierr;
-  return red_signal(slot, c.d_red, 2, dev_sums2);
+  return allreduce_signal(c.d_red, 2, red_pairs(), slot, dev_sums2, nullptr);
 }
 
 int hipxHaloCreate(int nsend, const int *send_ranks, const hipx_int *send_off, const hipx_int *send_idx, int nrecv, const int *recv_ranks, const hipx_int *recv_off,
@@ -508,8 +568,7 @@ int hipxHaloDestroy(hipxHalo *ph)
   (void)hipFree(h->d_ticket);
   (void)hipFree(h->d_recv_ranks);
   (void)hipFree(h->d_ack_ptrs);
-  (void)hipFree(h->d_err);
-  if (h->h_err) (void)hipHostFree(h->h_err);
+  if (h->h_err) (void)hipHostFree(h->h_err);  // (d_err is its device alias)
   (void)hipEventDestroy(h->ev_packed);
   (void)hipEventDestroy(h->ev_done);
   delete h;
@@ -517,48 +576,63 @@ int hipxHaloDestroy(hipxHalo *ph)
   return HIPX_SUCCESS;
 }
 
-int hipxHaloBegin(hipxHalo h, const double *x, double *lvec)
+static int halo_begin(hipxHalo h, const double *x, double *lvec, const PackCG *cgp);
+int hipxHaloBegin(hipxHalo h, const double *x, double *lvec) { return halo_begin(h, x, lvec, nullptr); }
+
+// cgp != NULL: what is sent is the new CG direction formed from x (= the old one) on the way out, see PackCG
+static int halo_begin(hipxHalo h, const double *x, double *lvec, const PackCG *cgp)
 {
   HIPX_CHECK_INIT();
   Comm &c = cm();
   HIPX_ARG(h, "null halo");
   if (h->nsend + h->nrecv == 0) return HIPX_SUCCESS;
+  const PackCG cg = cgp ? *cgp : PackCG{};
   if (h->ipc) {
-    if (*h->h_err) return fail(HIPX_ERR_GPU, "ghost exchange (IPC): a neighbour never published / acknowledged its data (wait limit reached)", __FILE__, __LINE__);
+    if (*reinterpret_cast<volatile unsigned int *>(h->h_err))
+      return fail(HIPX_ERR_GPU, "ghost exchange (IPC): a neighbour never published / acknowledged its data (wait limit reached)", __FILE__, __LINE__);
     const unsigned long long s = ++h->seq;
     const int                q = (int)(s & 1);
     h->ghost_cur = reinterpret_cast<double *>(h->arena + h->hdr_bytes) + (size_t)q * h->nghost;
-    HIPX_HIP(hipEventRecord(h->ev_packed, rt().compute));  // x is complete
-    HIPX_HIP(hipStreamWaitEvent(rt().comm, h->ev_packed, 0));
     {
-      int ierr = prof_section(HIPX_PROF_HALO, true, rt().comm);
+      int ierr = prof_section(HIPX_PROF_HALO, true, rt().compute);
       if (ierr) return ierr;
     }
-    for (int r = 0; r < h->nsend; r++) {
-      const hipx_int cnt = h->send_off[r + 1] - h->send_off[r];
-      if (!cnt) continue;
-      char   *pb  = h->send_base[(size_t)r];
-      double *dst = reinterpret_cast<double *>(pb + h->hdr_bytes) + (size_t)q * (size_t)h->send_peer_nghost[(size_t)r] + h->send_peer_off[(size_t)r];
-      unsigned long long       *flag = reinterpret_cast<unsigned long long *>(pb) + h->me;                                      // peer.data_seq[me]
-      const unsigned long long *ack  = reinterpret_cast<const unsigned long long *>(h->arena) + h->nranks + h->send_ranks[r];  // my ack_seq[peer]
-      hipx_int g = (cnt + 255) / 256;
-      if (g > 512) g = 512;
-      ipc_put_kernel<<<(unsigned)g, 256, 0, rt().comm>>>(x, h->d_send_idx + h->send_off[r], cnt, dst, ack, s >= 2 ? s - 2 : 0, flag, s, h->d_ticket + r, h->d_err, ipc_wait_ticks());
+    // round 6: the put kernel runs on the COMPUTE stream, in front of the product (see ipc_put_kernel); up to four neighbours per launch
+    for (int r0 = 0; r0 < h->nsend; r0 += 4) {
+      PutArgs  pa;
+      hipx_int maxn2 = 0;
+      int      ns    = 0;
+      for (int r = r0; r < h->nsend && ns < 4; r++) {
+        const hipx_int cnt = h->send_off[r + 1] - h->send_off[r];
+        if (!cnt) continue;
+        char *pb = h->send_base[(size_t)r];
+        pa.seg[ns].idx      = h->d_send_idx + h->send_off[r];
+        pa.seg[ns].n        = cnt;
+        pa.seg[ns].dst      = reinterpret_cast<double *>(pb + h->hdr_bytes) + (size_t)q * (size_t)h->send_peer_nghost[(size_t)r] + h->send_peer_off[(size_t)r];
+        pa.seg[ns].flag     = reinterpret_cast<unsigned long long *>(pb) + h->me;                                      // peer.data_seq[me]
+        pa.seg[ns].ack      = reinterpret_cast<const unsigned long long *>(h->arena) + h->nranks + h->send_ranks[r];  // my ack_seq[peer]
+        pa.seg[ns].need_ack = s >= 2 ? s - 2 : 0;
+        pa.seg[ns].ticket   = h->d_ticket + r;
+        maxn2               = std::max<hipx_int>(maxn2, std::max<hipx_int>(cnt >> 1, 1));
+        ns++;
+      }
+      if (!ns) continue;
+      hipx_int g = (maxn2 + 255) / 256;
+      if (g > 1024) g = 1024;
+      const dim3 grid((unsigned)g, (unsigned)ns);
+      if (cgp) ipc_put_kernel<true><<<grid, 256, 0, rt().compute>>>(x, pa, s, h->d_err, ipc_wait_ticks(), cg);
+      else ipc_put_kernel<false><<<grid, 256, 0, rt().compute>>>(x, pa, s, h->d_err, ipc_wait_ticks(), cg);
     }
     HIPX_LAUNCH_CHECK();
-    {
-      int ierr = prof_section(HIPX_PROF_HALO, false, rt().comm);
-      if (ierr) return ierr;
-    }
-    HIPX_HIP(hipEventRecord(h->ev_done, rt().comm));
-    return HIPX_SUCCESS;
+    return prof_section(HIPX_PROF_HALO, false, rt().compute);
   }
   if (!c.active || c.ipc) return fail(HIPX_ERR_ORDER, "hipxCommInit() (RCCL) or hipxHaloIpcAttach() must precede a ghost exchange", __FILE__, __LINE__);
   const hipx_int ns = h->send_off[h->nsend];
   if (ns) {
     hipx_int g = (ns + 255) / 256;
     if (g > 2048) g = 2048;
-    pack_kernel<<<(unsigned)g, 256, 0, rt().compute>>>(x, h->d_send_idx, h->d_sendbuf, ns);
+    if (cgp) pack_kernel<true><<<(unsigned)g, 256, 0, rt().compute>>>(x, h->d_send_idx, h->d_sendbuf, ns, cg);
+    else pack_kernel<false><<<(unsigned)g, 256, 0, rt().compute>>>(x, h->d_send_idx, h->d_sendbuf, ns, cg);
     HIPX_LAUNCH_CHECK();
   }
   // the comm stream may start once the pack kernel (and whatever produced x) has finished
@@ -591,11 +665,26 @@ int hipxHaloEnd(hipxHalo h)
   HIPX_CHECK_INIT();
   HIPX_ARG(h, "null halo");
   if (h->nsend + h->nrecv == 0) return HIPX_SUCCESS;
-  HIPX_HIP(hipStreamWaitEvent(rt().compute, h->ev_done, 0));  // RCCL: the receives landed; IPC: my puts have read x
+  if (!h->ipc) HIPX_HIP(hipStreamWaitEvent(rt().compute, h->ev_done, 0));  // RCCL: the receives landed (IPC: the put kernel ran on this stream)
   if (h->ipc && h->nrecv) {
     ipc_wait_kernel<<<1, 64, 0, rt().compute>>>(reinterpret_cast<const unsigned long long *>(h->arena), h->d_recv_ranks, h->nrecv, h->seq, h->d_err, ipc_wait_ticks());
     HIPX_LAUNCH_CHECK();
   }
+  return HIPX_SUCCESS;
+}
+
+// hipxHaloEnd for a consumer kernel that waits for the neighbours' sequence flags ITSELF (offdiag_dot_kernel): no wait kernel (one launch, ~5 us, less on the
+// critical path); *w says what to wait for -- nothing with RCCL (the event has ordered the receives) or with more than four neighbours (the wait kernel ran)
+static int halo_end_inline(hipxHalo h, IpcWait *w)
+{
+  *w = IpcWait{};
+  if (h->nsend + h->nrecv == 0) return HIPX_SUCCESS;
+  if (!h->ipc || h->nrecv > 4) return hipxHaloEnd(h);
+  for (int r = 0; r < h->nrecv; r++) w->flag[r] = reinterpret_cast<const unsigned long long *>(h->arena) + h->recv_ranks[(size_t)r];  // my data_seq[sender]
+  w->n     = h->nrecv;
+  w->want  = h->seq;
+  w->err   = h->d_err;
+  w->limit = ipc_wait_ticks();
   return HIPX_SUCCESS;
 }
 
@@ -608,8 +697,33 @@ static int halo_release(hipxHalo h)
     ipc_ack_kernel<<<1, 64, 0, rt().compute>>>(h->d_ack_ptrs, h->nrecv, h->seq);
     HIPX_LAUNCH_CHECK();
   }
-  HIPX_HIP(hipMemcpyAsync(h->h_err, h->d_err, sizeof(unsigned int), hipMemcpyDeviceToHost, rt().compute));  // seen at the next call
-  return HIPX_SUCCESS;
+  return HIPX_SUCCESS;  // (a wait that gave up has written the host-mapped error word: seen at the next call)
+}
+
+static int allreduce_signal(double *d_vals, int n, bool pairs, int slot, double *dres, hipxHalo h)
+{
+  Comm &c = cm();
+  int   ierr;
+  if (c.ipc) {
+    Runtime   &r = rt();
+    PostAck    ack;
+    PostSignal sig;
+    if (h && h->ipc && h->nrecv) {
+      if (h->nrecv <= 64) {
+        ack.ptrs = h->d_ack_ptrs;
+        ack.n    = h->nrecv;
+        ack.seq  = h->seq;
+      } else if ((ierr = halo_release(h))) return ierr;
+    }
+    sig.flag    = r.d_flags + slot;
+    sig.seq     = ++r.seq[slot];
+    sig.results = slot_results_dev(slot);
+    sig.dres    = dres;
+    return allreduce_dev(d_vals, n, pairs, &ack, &sig);
+  }
+  if (h && (ierr = halo_release(h))) return ierr;
+  if ((ierr = allreduce_dev(d_vals, n, pairs))) return ierr;
+  return red_signal(slot, d_vals, n, dres);
 }
 
 int hipxHaloIpcExport(hipxHalo h, int rank, int nranks, void *blob)
@@ -626,10 +740,9 @@ int hipxHaloIpcExport(hipxHalo h, int rank, int nranks, void *blob)
     // fine-grained: flags are polled while another process / GPU writes them, and the ghost values are written by the peers
     HIPX_HIP(hipExtMallocWithFlags((void **)&h->arena, bytes, hipDeviceMallocFinegrained));
     HIPX_HIP(hipMemset(h->arena, 0, bytes));
-    HIPX_HIP(hipMalloc((void **)&h->d_err, sizeof(unsigned int)));
-    HIPX_HIP(hipMemset(h->d_err, 0, sizeof(unsigned int)));
-    HIPX_HIP(hipHostMalloc((void **)&h->h_err, sizeof(unsigned int), hipHostMallocDefault));
+    HIPX_HIP(hipHostMalloc((void **)&h->h_err, sizeof(unsigned int), hipHostMallocMapped));  // (host-mapped: a kernel that gives up writes it where the host reads it -- no copy on the data path)
     *h->h_err = 0;
+    HIPX_HIP(hipHostGetDevicePointer((void **)&h->d_err, h->h_err, 0));
   }
   IpcBlob b;
   memset(&b, 0, sizeof(b));
@@ -704,7 +817,9 @@ int hipxHaloIpcAttach(hipxHalo h, const void *all_blobs)
   return HIPX_SUCCESS;
 }
 
-int hipxMatMultMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *lvec, double *y)
+static int matmult_mpi(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *lvec, double *y, bool release);
+int hipxMatMultMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *lvec, double *y) { return matmult_mpi(Ad, Bo, h, x, lvec, y, true); }
+static int matmult_mpi(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *lvec, double *y, bool release)
 {
   HIPX_CHECK_INIT();
   int ierr;
@@ -715,7 +830,7 @@ int hipxMatMultMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *
   const double *ghost = (h && h->ipc) ? h->ghost_cur : lvec;  // IPC transport: the neighbours wrote straight into this rank's ghost buffer
   if (Bo && (ierr = hipxMatMultAdd(Bo, ghost, y, y))) return ierr;  // B->ops->multadd   mpiaij.c:1059
   if ((ierr = prof_section(HIPX_PROF_OFFDIAG, false, rt().compute))) return ierr;
-  return h ? halo_release(h) : HIPX_SUCCESS;
+  return (h && release) ? halo_release(h) : HIPX_SUCCESS;
 }
 
 int hipxMatMultAddMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, double *lvec, const double *y, double *z)
@@ -728,6 +843,69 @@ int hipxMatMultAddMPI(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *x, doubl
   const double *ghost = (h && h->ipc) ? h->ghost_cur : lvec;
   if (Bo && (ierr = hipxMatMultAdd(Bo, ghost, z, z))) return ierr;  // B->ops->multadd   mpiaij.c:1081
   return h ? halo_release(h) : HIPX_SUCCESS;
+}
+
+// ---- the two-kernel CG iteration on a rank WITH an off-diagonal block (round 6) -----------------------------------------------------------------
+// One rank runs [direction update + product + dot] as ONE kernel (hipxMatMultCGDirectionDotBegin).  Here the same for MatMult_MPIAIJ (mpiaij.c:1047-1061):
+//   comm stream:     the new direction of the rows the neighbours need, formed on the way out (PackCG) -> put / send          VecScatterBegin  mpiaij.c:1056
+//   compute stream:  p_new = z d + b p, x += a p, w = Ad p_new, dot partials of the rows WITHOUT off-diagonal entries           A->ops->mult     mpiaij.c:1057
+//                    wait for the ghost values                                                                                   VecScatterEnd    mpiaij.c:1058
+//                    w += Bo ghost on the boundary rows + THEIR p_i w_i + the fold of all partials (offdiag_dot_kernel)          B->ops->multadd  mpiaij.c:1059, cg.c:258
+//                    all-reduce of the one sum -> host slot + device copy
+// i.e. the separate direction kernel (5 vector passes) and the separate dot kernel (2 passes) of hipxCGAypxAxpyDev + hipxMatMultMPIDotBegin are gone.  The
+// vectors are those kernels' bit for bit (same operations per element); the dot is the same set of products p_i w_i summed in another order (default
+// reductions: to rounding; exact reductions: Dot2 over the complete vectors as before, order-free).  *fused = 0: nothing was enqueued (the pair of blocks is
+// not a z-slab of a stencil grid the march kernel takes, hipxMatMPICGPlan_) -- the caller runs the separate kernels.
+extern "C" int hipxMatMPICGPlan_(hipxMat A, hipxMat B, int *ok, int *skipmask);
+extern "C" int hipxMatMultCGDirectionPartial_(hipxMat A, int skipmask, const double *p_old, double *p_new, const double *z, double dconst, double *x, double b, double a,
+                                              const double *dev_beta_new, const double *dev_beta_old, const double *dev_dpi, double *w, int want_dot, int *fused, const double **dotpart,
+                                              hipx_int *npart);
+extern "C" int hipxMatMultAddDotFold_(hipxMat B, const double *ghost, double *w, const double *p, const double *partA, hipx_int npartA, int slot, double *dst, const hipx::IpcWait *wt);
+
+int hipxMatMultMPICGDirectionDotBegin(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *p_old, double *p_new, const double *z, double dconst, double *x, double b, double a,
+                                      const double *dev_beta_new, const double *dev_beta_old, const double *dev_dpi, double *lvec, double *w, hipx_int n, int slot, double *dev_dot, int *fused)
+{
+  HIPX_CHECK_INIT();
+  Comm &c = cm();
+  HIPX_ARG(Ad && fused && p_old && p_new && z && x && w, "null argument");
+  HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2 && dev_dot, "reduction slot out of range / no device copy of the dot");
+  HIPX_ARG(p_old != p_new && p_new != w && p_old != w && x != w && x != p_new && z != w && z != p_new, "the vectors must be distinct");
+  *fused = 0;
+  static const bool off = getenv("HIPX_NO_CGFUSE") != nullptr || getenv("HIPX_NO_MPI_CGFUSE") != nullptr;
+  if (off || !c.active || !Bo || !h || h->nsend + h->nrecv == 0 || n <= 0) return HIPX_SUCCESS;
+  if ((reinterpret_cast<uintptr_t>(p_old) | reinterpret_cast<uintptr_t>(p_new) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) return HIPX_SUCCESS;
+  int ok = 0, skip = 0, ierr;
+  if ((ierr = hipxMatMPICGPlan_(Ad, Bo, &ok, &skip))) return ierr;
+  if (!ok) return HIPX_SUCCESS;
+  PackCG cg;
+  cg.z            = z;
+  cg.dconst       = dconst;
+  cg.b            = b;
+  cg.dev_beta_new = dev_beta_new;
+  cg.dev_beta_old = dev_beta_new ? dev_beta_old : nullptr;
+  if ((ierr = halo_begin(h, p_old, lvec, &cg))) return ierr;
+  const bool    exact = red_pairs();
+  const double *dotpart = nullptr;
+  hipx_int      npart   = 0;
+  int           done    = 0;
+  if ((ierr = hipxMatMultCGDirectionPartial_(Ad, skip, p_old, p_new, z, dconst, x, b, a, dev_beta_new, dev_beta_old, dev_dpi, w, exact ? 0 : 1, &done, &dotpart, &npart))) return ierr;
+  if (!done) return fail(HIPX_ERR_ORDER, "MPIAIJ CG product: the plan said the diagonal block takes the fused kernel, the launch declined (ghost exchange already started)", __FILE__, __LINE__);
+  if ((ierr = prof_section(HIPX_PROF_OFFDIAG, true, rt().compute))) return ierr;
+  const double *ghost = h->ipc ? h->ghost_cur : lvec;
+  if (exact) {
+    if ((ierr = hipxHaloEnd(h))) return ierr;
+    if ((ierr = hipxMatMultAdd(Bo, ghost, w, w))) return ierr;
+    const double *ys[1] = {w};
+    if ((ierr = launch_mdot_nosignal(p_new, 1, ys, n, slot, c.d_red))) return ierr;
+  } else {
+    IpcWait wt;
+    if ((ierr = halo_end_inline(h, &wt))) return ierr;  // (IPC: the off-diagonal kernel waits for the neighbours' flags itself)
+    if ((ierr = hipxMatMultAddDotFold_(Bo, ghost, w, p_new, dotpart, npart, slot, c.d_red, &wt))) return ierr;
+  }
+  if ((ierr = prof_section(HIPX_PROF_OFFDIAG, false, rt().compute))) return ierr;
+  if ((ierr = allreduce_signal(c.d_red, 1, exact, slot, dev_dot, h))) return ierr;  // (IPC: the acknowledgement of the ghost buffer rides in the all-reduce kernel)
+  *fused = 1;
+  return HIPX_SUCCESS;
 }
 
 int hipxHaloGhost(hipxHalo h, const double *lvec, const double **ghost)

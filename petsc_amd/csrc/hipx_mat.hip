@@ -19,6 +19,7 @@
 #include "hipx_internal.h"
 #include <type_traits>
 #include "hipx_reduce.h"
+#include "hipx_ipc.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -161,6 +162,7 @@ extern "C" hipx_int hipxSellDotPartials_(void *p);
 extern "C" int      hipxSellLaunch_(void *p, int mode, int dot, const double *x, const double *yin, double *yout, double *dotpart, int pair);
 extern "C" int      hipxMatEnsureInodes_(hipxMat A);  // hipx_sor.hip: looks for inodes if nobody has said (MatSeqAIJCheckInode)
 extern "C" void hipxSorInvalidate_(void *p);
+static void     mpicg_forget(hipxMat M);  // (plans of hipxMatMPICGPlan_ that name this matrix)
 
 namespace {
 
@@ -2151,6 +2153,9 @@ __global__ __launch_bounds__(NT, (NT == 256 || NQ <= 4) ? 2 : 1) void spmv_march
     if ((k == 1 && k0 == 0) || (k == nplanes - 1 && k > k0)) load_masks(k);  // leaving the grid's first plane / entering its last one (uniform, twice per launch)
     const long long rowbase = (long long)k * S + i0;
     double *yb = yout + rowbase;
+    // MPIAIJ diagonal block (round 6, hipxMatMultMPICGDirectionDotBegin): the rows of the slab's first / last plane get their off-diagonal terms
+    // added by offdiag_dot_kernel, which also forms their share p_i w_i of the dot with the COMPLETE w_i -- here they are left out of the sum
+    const bool dskip = DOT && (((xcdmap & 16) && k == 0) || ((xcdmap & 32) && k == nplanes - 1));  // (uniform)
     // one pair of row groups: the operands of a batch of runs are read together, then the sums in ascending column order.  UNI: every row of
     // this wave's 128 has the full template -- plain multiply-add pairs; otherwise a row that lacks the entry keeps its sum (the product is
     // formed and dropped: the bits of skipping it).  The two forms are separate instantiations behind a wave-uniform branch: written as one
@@ -2227,7 +2232,7 @@ __global__ __launch_bounds__(NT, (NT == 256 || NQ <= 4) ? 2 : 1) void spmv_march
         yb[q0 * 256 + (rjb[j] >> 3)] = sum0;
         yb[q1 * 256 + (rjb[j] >> 3)] = sum1;
       }
-      if (DOT) {  // (every row has its diagonal entry: checked with the masks)
+      if (DOT && !dskip) {  // (every row has its diagonal entry: checked with the masks)
         acc += xd0 * sum0;
         acc += xd1 * sum1;
       }
@@ -2319,10 +2324,11 @@ __global__ __launch_bounds__(NT, (NT == 256 || NQ <= 4) ? 2 : 1) void spmv_march
 // One dot partial per workgroup behind the march kernel's (dotpart + pbase); launched BEFORE the march kernel, which may fold all of them.
 template <bool DOT, bool CG>
 __global__ __launch_bounds__(256) void spmv_march2_rem_kernel(const hipxMarchPlan plan, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask, const double *__restrict__ x,
-                                                              double *__restrict__ yout, double *__restrict__ dotpart, const int row0, const int rem, const hipxMarchCG cg)
+                                                              double *__restrict__ yout, double *__restrict__ dotpart, const int row0, const int rem, const hipxMarchCG cg, const int skipmask = 0)
 {
   __shared__ double s_w[4];
   const int         i = (int)blockIdx.x * 256 + (int)threadIdx.x, k = (int)blockIdx.y;
+  const bool        dskip = ((skipmask & 1) && k == 0) || ((skipmask & 2) && k == (int)gridDim.y - 1);  // (the boundary planes of an MPIAIJ diagonal block: see spmv_march2_kernel)
   double            acc = 0.0;
   if (i < rem) {
     const long long row = (long long)k * plan.S + row0 + i;
@@ -2352,7 +2358,7 @@ __global__ __launch_bounds__(256) void spmv_march2_rem_kernel(const hipxMarchPla
       cg.pnew[row]    = zv + cgb * po;
       cg.xsol[row]    = cg.xsol[row] + cga * po;
     }
-    if (DOT) acc = xd * sum;
+    if (DOT && !dskip) acc = xd * sum;
   }
   if (DOT) {
     const double w = hipx::wave_sum(acc);
@@ -3294,6 +3300,7 @@ static int     g_m2_fold_slot = -1;
 static double *g_m2_fold_dres = nullptr;
 static bool    g_m2_folded    = false;
 static int     g_m2_extra     = 0;  // dot partials spmv_march2_rem_kernel has written behind the march kernel's (this launch)
+static int     g_m2_skip      = 0;  // bit 0 / 1: leave the rows of the first / last plane out of the dot (MPIAIJ diagonal block, hipxMatMultCGDirectionPartial_)
 // rows of a plane beyond its whole tiles (0: S is a multiple of L) and the workgroups (= dot partials) of the kernel that takes them
 static inline int march2_rem(hipxMat A) { return (A->march_ok && A->march_plan.L > 0) ? A->march_plan.S % A->march_plan.L : 0; }
 static inline hipx_int march2_rem_parts(hipxMat A)
@@ -3315,7 +3322,7 @@ static int march2_rem_launch(hipxMat A, const double *x, double *yout, double *d
   xm                        = (xm & ~1) | ((units % 8 == 0) ? 1 : 0);
   const dim3 grid((unsigned)((rem + 255) / 256), (unsigned)nplanes);
   double    *dp = (DOT && dotpart) ? dotpart + (size_t)units * (A->march_nt / 64) : nullptr;
-  if (DOT && dp) spmv_march2_rem_kernel<true, CG><<<grid, 256, 0, rt().compute>>>(mp, A->d_tid, A->d_tmask, x, yout, dp, tiles * mp.L, rem, cg);
+  if (DOT && dp) spmv_march2_rem_kernel<true, CG><<<grid, 256, 0, rt().compute>>>(mp, A->d_tid, A->d_tmask, x, yout, dp, tiles * mp.L, rem, cg, g_m2_skip);
   else spmv_march2_rem_kernel<false, CG><<<grid, 256, 0, rt().compute>>>(mp, A->d_tid, A->d_tmask, x, yout, nullptr, tiles * mp.L, rem, cg);
   HIPX_LAUNCH_CHECK();
   if (DOT && dp) {
@@ -3337,7 +3344,7 @@ static int launch_march2_inst(hipxMat A, const double *x, double *yout, double *
     red          = red_out(g_m2_fold_slot, true, g_m2_fold_dres);
     g_m2_folded  = true;
   }
-  spmv_march2_kernel<NE, NQ, NHALO, DOT, CG, NT><<<(unsigned)units, NT, lds, rt().compute>>>(A->march_plan, A->d_tid, A->d_tmask, A->ntmpl, x, yout, dotpart, tiles, pps, nplanes, xm | (dev_sw().nt_store ? 2 : 0) | (4 * dev_sw().nt_x), cg, red, g_m2_extra);
+  spmv_march2_kernel<NE, NQ, NHALO, DOT, CG, NT><<<(unsigned)units, NT, lds, rt().compute>>>(A->march_plan, A->d_tid, A->d_tmask, A->ntmpl, x, yout, dotpart, tiles, pps, nplanes, xm | (dev_sw().nt_store ? 2 : 0) | (4 * dev_sw().nt_x) | (DOT ? 16 * g_m2_skip : 0), cg, red, g_m2_extra);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
@@ -4115,6 +4122,7 @@ int hipxMatDestroy(hipxMat *pA)
   HIPX_CHECK_INIT();
   if (!pA || !*pA) return HIPX_SUCCESS;
   hipxMat A = *pA;
+  mpicg_forget(A);
   HIPX_HIP(hipStreamSynchronize(rt().compute));
   (void)hipFree(A->d_i);
   (void)hipFree(A->d_j);
@@ -4474,13 +4482,11 @@ int hipxMatMultDotBegin(hipxMat A, const double *x, double *y, int slot, double 
   return launch_sum(A->d_dotpart, npart, slot, dev_dot);
 }
 
-int hipxMatMultCGDirectionDotBegin(hipxMat A, const double *p_old, double *p_new, const double *z, double dconst, double *x, double b, double a, const double *dev_beta_new,
-                                   const double *dev_beta_old, const double *dev_dpi, double *w, int slot, double *dev_dot, int *fused)
+// the common part of hipxMatMultCGDirectionDotBegin (one rank: slot >= 0, the dot folded into the slot) and hipxMatMultCGDirectionPartial_ (the diagonal
+// block of an MPIAIJ operator: slot < 0, the partials of the rows WITHOUT off-diagonal entries are left in A->d_dotpart for offdiag_dot_kernel)
+static int cgdir_product(hipxMat A, const double *p_old, double *p_new, const double *z, double dconst, double *x, double b, double a, const double *dev_beta_new, const double *dev_beta_old,
+                         const double *dev_dpi, double *w, int slot, double *dev_dot, int skipmask, bool want_partials, int *fused, hipx_int *npart_out)
 {
-  HIPX_CHECK_INIT();
-  HIPX_ARG(A && fused && p_old && p_new && z && x && w, "null argument");
-  HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2, "reduction slot out of range");
-  HIPX_ARG(p_old != p_new && p_new != w && p_old != w && x != w && x != p_new && z != w && z != p_new, "the vectors must be distinct (z may not alias w: W = Z in cg.c:145 is for the caller to unalias)");
   *fused = 0;
   static const bool off = getenv("HIPX_NO_CGFUSE") != nullptr;
   if (off || A->compressed || A->m != A->n || A->m <= 0) return HIPX_SUCCESS;
@@ -4507,21 +4513,202 @@ int hipxMatMultCGDirectionDotBegin(hipxMat A, const double *p_old, double *p_new
   const int            xm  = (units % 8 == 0) ? 1 : 0;
   const hipxMarchCG    cg{z, p_new, x, dconst, b, a, dev_beta_new, dev_beta_old, dev_dpi};
   if ((ierr = prof_mark(true))) return ierr;
-  if (rt().red_exact) {  // compensated mode: the epilogue's per-wave partials are plain sums -- Dot2 over the complete vectors instead
+  if (!want_partials && (rt().red_exact || slot < 0)) {  // compensated mode: the epilogue's per-wave partials are plain sums -- Dot2 over the complete vectors instead
     if ((ierr = launch_march2_cg<false>(A, p_old, w, nullptr, units, tiles, pps, nplanes, xm, lds, cg))) return ierr;
     if ((ierr = prof_mark(false))) return ierr;
-    if ((ierr = launch_dot(p_new, w, A->m, slot, dev_dot))) return ierr;
+    if (slot >= 0 && (ierr = launch_dot(p_new, w, A->m, slot, dev_dot))) return ierr;
+    npart = 0;
   } else {
-    m2_fold_arm(slot, dev_dot);
+    if (slot >= 0) m2_fold_arm(slot, dev_dot);
+    else {
+      g_m2_fold_slot = -1;
+      g_m2_folded    = false;
+    }
+    g_m2_skip         = skipmask;
     A->dot_npart_used = 0;
     ierr              = launch_march2_cg<true>(A, p_old, w, A->d_dotpart, units, tiles, pps, nplanes, xm, lds, cg);
     g_m2_fold_slot    = -1;
+    g_m2_skip         = 0;
     if (ierr) return ierr;
     if (A->dot_npart_used) npart = A->dot_npart_used;
     if ((ierr = prof_mark(false))) return ierr;
-    if (!g_m2_folded && (ierr = launch_sum(A->d_dotpart, npart, slot, dev_dot))) return ierr;
+    if (slot >= 0 && !g_m2_folded && (ierr = launch_sum(A->d_dotpart, npart, slot, dev_dot))) return ierr;
   }
+  if (npart_out) *npart_out = npart;
   *fused = 1;
+  return HIPX_SUCCESS;
+}
+
+int hipxMatMultCGDirectionDotBegin(hipxMat A, const double *p_old, double *p_new, const double *z, double dconst, double *x, double b, double a, const double *dev_beta_new,
+                                   const double *dev_beta_old, const double *dev_dpi, double *w, int slot, double *dev_dot, int *fused)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(A && fused && p_old && p_new && z && x && w, "null argument");
+  HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2, "reduction slot out of range");
+  HIPX_ARG(p_old != p_new && p_new != w && p_old != w && x != w && x != p_new && z != w && z != p_new, "the vectors must be distinct (z may not alias w: W = Z in cg.c:145 is for the caller to unalias)");
+  return cgdir_product(A, p_old, p_new, z, dconst, x, b, a, dev_beta_new, dev_beta_old, dev_dpi, w, slot, dev_dot, 0, false, fused, nullptr);
+}
+
+// ---- the same on the diagonal block of an MPIAIJ operator (round 6; internal: hipx_comm.hip's hipxMatMultMPICGDirectionDotBegin drives it) --------------
+// hipxMatMPICGPlan_: can the pair (Ad, Bo) run the two-kernel form?  Ad must take the CG-prologue march kernel; Bo (compressed rows, 32-bit offsets) must have
+// its rows in EXACTLY the first and / or the last plane of Ad's grid (every row of such a plane): a z-slab of a natural-ordered stencil grid.  *skipmask: bit 0
+// = the first plane's rows carry off-diagonal entries, bit 1 = the last plane's.  Decided once per pair (a host copy of Bo's row list, nrows_c integers).
+}  // extern "C"
+struct MpiCgPlan {
+  hipxMat B = nullptr;
+  int     ok = 0, skip = 0;
+};
+static std::vector<std::pair<hipxMat, MpiCgPlan>> g_mpicg;  // keyed by Ad (dropped in hipxMatDestroy)
+static void mpicg_forget(hipxMat M)
+{
+  for (size_t k = g_mpicg.size(); k-- > 0;)
+    if (g_mpicg[k].first == M || g_mpicg[k].second.B == M) g_mpicg.erase(g_mpicg.begin() + (long)k);
+}
+extern "C" {
+
+extern "C" int hipxMatMPICGPlan_(hipxMat A, hipxMat B, int *ok, int *skipmask)
+{
+  *ok = 0;
+  *skipmask = 0;
+  for (auto &e : g_mpicg)
+    if (e.first == A && e.second.B == B) {
+      *ok       = e.second.ok;
+      *skipmask = e.second.skip;
+      return HIPX_SUCCESS;
+    }
+  MpiCgPlan pl;
+  pl.B = B;
+  do {
+    if (!A || !B || A->compressed || !B->compressed || B->is64 || A->m != A->n || A->m <= 0 || B->m != A->m) break;
+    bool tm = false, ip = false, ips = false;
+    int  ierr = use_inode_pair(A, ip, ips);
+    if (ierr) return ierr;
+    if (ip) break;
+    if ((ierr = use_templates(A, tm))) return ierr;
+    if (!tm || !march_applies(A) || dev_sw().march1 || dev_sw().trace) break;
+    if ((ierr = march2_check(A))) return ierr;
+    if (A->march2_state != 1 || !march2_cg_shape(A)) break;
+    const hipx_int S = A->march_plan.S, m = A->m, nr = B->nrows_c;
+    if (S <= 0 || m % S || m / S < 3 || nr <= 0) break;
+    std::vector<hipx_int> ridx((size_t)nr);
+    HIPX_HIP(hipMemcpy(ridx.data(), B->d_ridx, sizeof(hipx_int) * (size_t)nr, hipMemcpyDeviceToHost));
+    hipx_int nlo = 0, nhi = 0;
+    bool     sorted = true;
+    for (hipx_int k = 0; k < nr; k++) {
+      if (k && ridx[(size_t)k] <= ridx[(size_t)k - 1]) sorted = false;
+      if (ridx[(size_t)k] < S) nlo++;
+      else if (ridx[(size_t)k] >= m - S) nhi++;
+    }
+    if (!sorted || nlo + nhi != nr || (nlo && nlo != S) || (nhi && nhi != S)) break;
+    pl.ok   = 1;
+    pl.skip = (nlo ? 1 : 0) | (nhi ? 2 : 0);
+  } while (0);
+  g_mpicg.push_back({A, pl});
+  *ok       = pl.ok;
+  *skipmask = pl.skip;
+  return HIPX_SUCCESS;
+}
+
+// w = Ad p_new with the CG direction update as the prologue (cgdir_product); with want_dot the dot partials of the rows outside the planes of `skipmask`
+// are left in *dotpart (npart of them); otherwise (exact reductions: the caller runs Dot2 over the complete vectors) no partials
+extern "C" int hipxMatMultCGDirectionPartial_(hipxMat A, int skipmask, const double *p_old, double *p_new, const double *z, double dconst, double *x, double b, double a,
+                                              const double *dev_beta_new, const double *dev_beta_old, const double *dev_dpi, double *w, int want_dot, int *fused, const double **dotpart,
+                                              hipx_int *npart)
+{
+  *npart   = 0;
+  *dotpart = nullptr;
+  int ierr = cgdir_product(A, p_old, p_new, z, dconst, x, b, a, dev_beta_new, dev_beta_old, dev_dpi, w, -1, nullptr, skipmask, want_dot != 0, fused, npart);
+  if (!ierr && *fused && want_dot) *dotpart = A->d_dotpart;
+  return ierr;
+}
+
+// B->ops->multadd of MatMult_MPIAIJ (mpiaij.c:1059) on the listed rows, w_i = ((w_i + b_i0 g_0) + b_i1 g_1) ... (MatMultAdd_SeqAIJ's compressed-row loop,
+// aij.c:1629-1641: products and sums rounded separately, left to right), fused with the rows' share of the dot p . w (cg.c:258) and with the FOLD of all the dot
+// partials -- the product kernel's (rows without off-diagonal entries) and this kernel's: a partition of the rows, every product p_i w_i formed once with
+// the complete w_i.  A workgroup takes 256 consecutive listed rows; its nonzeros are one contiguous range, read coalesced, the products parked in LDS (the
+// row-block idea of spmv_stream_kernel); a range beyond the tile falls back to the per-row walk.  The last workgroup (ticket; release / acquire at agent scope:
+// the R1 hand-off of hipx_reduce.h) adds partA[0 .. npartA) and the workgroups' partials in index order per thread, wave tree, 4 wave sums left to right.
+}  // extern "C"
+namespace {
+constexpr int OD_CAP = 4096;
+__global__ __launch_bounds__(256) void offdiag_dot_kernel(hipx_int nrows, const hipx_int *__restrict__ bi, const hipx_int *__restrict__ bj, const double *__restrict__ ba,
+                                                          const hipx_int *__restrict__ ridx, const double *ghost, double *__restrict__ w, const double *__restrict__ p,
+                                                          double *part, const double *partA, int npartA, unsigned int *ticket, double *dst, const IpcWait wt)
+{
+  __shared__ double   s_prod[OD_CAP];
+  __shared__ double   s_w[4];
+  __shared__ unsigned s_last;
+  const int      t  = threadIdx.x;
+  const hipx_int r0 = (hipx_int)blockIdx.x * 256, r1 = (r0 + 256 < nrows) ? r0 + 256 : nrows;
+  const hipx_int k0 = bi[r0], k1 = bi[r1];
+  const bool     staged = (k1 - k0) <= OD_CAP;
+  // IPC transport: the neighbours' put kernels raise this rank's sequence flags when their write-through stores have drained; one lane per flag polls, and the
+  // ghost values are then read with system-scope (sc0 sc1) loads -- the "sc1 stores and sc1 loads on both sides" hand-off of hipx_ipc.h, no wait kernel in front
+  const bool     sysload = wt.n > 0;
+  if (sysload) {
+    if (t < wt.n) ipc_wait_ge(wt.flag[t], wt.want, wt.err, wt.limit);
+    __syncthreads();
+  }
+  if (staged) {
+    for (hipx_int k = k0 + t; k < k1; k += 256) s_prod[k - k0] = ba[k] * (sysload ? ipc_load8(ghost + bj[k]) : ghost[bj[k]]);
+    __syncthreads();
+  }
+  double acc = 0.0;
+  if (r0 + t < r1) {
+    const hipx_int r = r0 + t, row = ridx[r];
+    double         sum = w[row];
+    if (staged)
+      for (hipx_int k = bi[r]; k < bi[r + 1]; k++) sum += s_prod[k - k0];
+    else
+      for (hipx_int k = bi[r]; k < bi[r + 1]; k++) sum += ba[k] * (sysload ? ipc_load8(ghost + bj[k]) : ghost[bj[k]]);
+    w[row] = sum;
+    acc    = p[row] * sum;
+  }
+  acc = hipx::wave_sum(acc);
+  if ((t & 63) == 0) s_w[t >> 6] = acc;
+  __syncthreads();
+  if (t == 0) {
+    double r = s_w[0];
+    r += s_w[1];
+    r += s_w[2];
+    r += s_w[3];
+    // (no agent-scope release fence: it writes back the XCD's L2, full of the product kernel's w / p / x -- 2048 of them cost 60 us here.  The partial goes out
+    // as an agent-scope atomic store (sc1: written through), is drained, then the ticket; the last workgroup reads with agent-scope atomic loads: the
+    // hand-off spmv_march2_kernel's in-kernel fold uses, pinned by tests/test_gpu_mat.py::test_march2_in_kernel_fold_equals_the_separate_fold_under_load)
+    __hip_atomic_store(&part[blockIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last            = (tk == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  double f = 0.0;
+  for (int i = t; i < npartA; i += 256) f += __hip_atomic_load(&partA[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (written by the launch before this one)
+  for (int i = t; i < (int)gridDim.x; i += 256) f += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  f = hipx::wave_sum(f);
+  __syncthreads();
+  if ((t & 63) == 0) s_w[t >> 6] = f;
+  __syncthreads();
+  if (t == 0) {
+    double r = s_w[0];
+    r += s_w[1];
+    r += s_w[2];
+    r += s_w[3];
+    dst[0]  = r;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch (stream-ordered)
+  }
+}
+}  // namespace
+extern "C" {
+
+extern "C" int hipxMatMultAddDotFold_(hipxMat B, const double *ghost, double *w, const double *p, const double *partA, hipx_int npartA, int slot, double *dst, const hipx::IpcWait *wt)
+{
+  HIPX_ARG(B && B->compressed && !B->is64 && B->nrows_c > 0, "off-diagonal block: compressed rows with 32-bit offsets expected");
+  const hipx_int g = (B->nrows_c + 255) / 256;
+  HIPX_ARG(g <= (hipx_int)kMaxRedVals * kRedBlocks, "off-diagonal block: too many rows for the slot's partials");
+  offdiag_dot_kernel<<<(unsigned)g, 256, 0, rt().compute>>>(B->nrows_c, (const hipx_int *)B->d_i, B->d_j, B->d_a, B->d_ridx, ghost, w, p, slot_partials(slot), partA, (int)npartA,
+                                                            rt().d_tickets + slot, dst, wt ? *wt : IpcWait{});
+  HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
 

@@ -26,7 +26,11 @@ def split_ownership(N, nranks):
     return ranges
 
 
-def build_plan(ai, aj, aa, ranges, rank, dist=None, group=None):
+def ng_chk(plan):
+    return int(plan["nghost"]) > 0
+
+
+def build_plan(ai, aj, aa, ranges, rank, dist=None, group=None, loopback=False):
     """Local slab (global column ids) -> dict with the split CSR blocks and the ghost-exchange plan."""
     _, ks = _lib.load()
     nranks = len(ranges) - 1
@@ -57,6 +61,19 @@ def build_plan(ai, aj, aa, ranges, rank, dist=None, group=None):
     ks.HipxMPIAIJSplitFree(C.byref(s))
     out["recv_ranks"] = rr[:nrecv.value].copy()
     out["recv_off"] = ro[:nrecv.value + 1].copy()
+    if loopback:
+        # One process plays rank `rank` of `nranks` ALONE (bench.py's per_rank_budget leg, tests): the slab's two blocks, ghost count and receive lists are the
+        # real ones; the ghost values come from the rank's own rows, wrapped (ghost g <- local row (g - rstart) mod m: the neighbour's last / first plane is
+        # played by the rank's own last / first plane) through ONE self-exchange on the IPC transport -- the same kernels, launches and bytes as between two
+        # neighbours, no peer needed.  The operator this defines (periodic in the slab direction) is only ever compared with itself.
+        assert m > 0 and ng_chk(out), "loopback: the rank needs rows and ghosts"
+        loc = (out["garray"].astype(np.int64) - rs) % m
+        out["recv_ranks"] = np.zeros(1, np.int32)
+        out["recv_off"] = np.asarray([0, len(loc)], np.int32)
+        out["send_ranks"] = np.zeros(1, np.int32)
+        out["send_off"] = np.asarray([0, len(loc)], np.int32)
+        out["send_idx"] = loc.astype(np.int32)
+        return out
     # requests: tell each owner which of its entries we need (global ids); it answers by packing them each MatMult
     requests = [None] * nranks
     for k in range(nrecv.value):
@@ -103,13 +120,35 @@ def comm_init(rank, nranks, dist, transport="rccl"):
         _lib.chk(hx.hipxCommInit(box[0], rank, nranks))
 
 
-def create_device_mat(plan, nranks, rank=0, dist=None, transport="rccl"):
-    """Uploads the blocks and creates the halo object: returns (HipxMat struct, keepalive list)."""
+def comm_init_loopback():
+    """A one-rank IPC communicator (the all-reduce kernel and its flags run as between ranks, over one contribution)."""
+    hx, _ = _lib.load()
+    h = (C.c_char * 64)()
+    _lib.chk(hx.hipxCommIpcExport(0, 1, h))
+    _lib.chk(hx.hipxCommIpcAttach(bytes(h)))
+
+
+def create_device_mat(plan, nranks, rank=0, dist=None, transport="rccl", loopback=False):
+    """Uploads the blocks and creates the halo object: returns (HipxMat struct, keepalive list).  loopback: `plan` came from build_plan(..., loopback=True);
+    the HipxMat says nranks = 2 so that the host layer takes its several-ranks path (all-reduces on the stream) over the one-rank communicator."""
     hx, _ = _lib.load()
     m, ng = plan["m"], plan["nghost"]
     A = _lib.mat_create_csr(m, m, plan["Ai"], plan["Aj"], plan["Aa"])
-    M = _lib.HipxMat(m=m, A=A, B=None, halo=None, lvec=None, nranks=nranks)
+    M = _lib.HipxMat(m=m, A=A, B=None, halo=None, lvec=None, nranks=2 if loopback else nranks)
     keep = [A]
+    if loopback:
+        B = _lib.mat_create_cprow(m, max(ng, 1), plan["nrows_c"], plan["Bi"], plan["ridx"], plan["Bj"], plan["Ba"])
+        halo = C.c_void_p()
+        p = plan
+        _lib.chk(hx.hipxHaloCreate(1, p["send_ranks"].ctypes.data_as(C.c_void_p), p["send_off"].ctypes.data_as(C.c_void_p), p["send_idx"].ctypes.data_as(C.c_void_p), 1,
+                                   p["recv_ranks"].ctypes.data_as(C.c_void_p), p["recv_off"].ctypes.data_as(C.c_void_p), C.byref(halo)))
+        blob = (C.c_char * 1024)()
+        _lib.chk(hx.hipxHaloIpcExport(halo, 0, 1, blob))
+        _lib.chk(hx.hipxHaloIpcAttach(halo, bytes(blob)))
+        lvec = _lib.DVec(max(ng, 1))
+        M.B, M.halo, M.lvec = B, halo, lvec.ptr
+        keep += [B, halo, lvec]
+        return M, keep
     if nranks > 1:
         B = _lib.mat_create_cprow(m, max(ng, 1), plan["nrows_c"], plan["Bi"], plan["ridx"], plan["Bj"], plan["Ba"])
         halo = C.c_void_p()

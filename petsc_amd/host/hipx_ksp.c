@@ -572,15 +572,18 @@ static int fused_update_begin(HipxMat *A, double *r, double *z, const double *p,
   return hipxCGFusedUpdateBegin(NULL, r, z, p, w, d, dconst, dev_beta, dev_dpi, n, slot, dev_sums2);
 }
 
-/* A(i) + B(i) as ONE kernel where the operator supports it (round 4: the direction update as the prologue of the march-form SpMV; one rank,
-   constant Jacobi diagonal or PCNONE so that z = r * dconst is never stored and W = Z's buffer stays free).  The kernel writes p_new into the
+/* A(i) + B(i) as ONE kernel where the operator supports it (round 4: the direction update as the prologue of the march-form SpMV; constant Jacobi
+   diagonal or PCNONE so that z = r * dconst is never stored and W = Z's buffer stays free; round 6: also on a rank with an off-diagonal block).  The kernel writes p_new into the
    second direction vector; on success the two swap (ksp->P is always the current direction).  *done = 0: nothing was enqueued. */
 static int fused_direction_product(HipxKSP *ksp, HipxMat *A, HipxPC *pc, int dcon, double *X, double b, double a, const double *dbn, const double *dbo, const double *ddpi, int slot,
                                    double *dev_dot, int *done)
 {
   *done = 0;
-  if (A->nranks > 1 || A->B || !dcon || !ksp->P2) return 0;
-  CHK(hipxMatMultCGDirectionDotBegin(A->A, ksp->P, ksp->P2, ksp->R, pc->dconst, X, b, a, dbn, dbo, ddpi, ksp->Z, slot, dev_dot, done));
+  if (!dcon || !ksp->P2) return 0;
+  if (A->nranks > 1 || A->B) { /* round 6: a rank with an off-diagonal block runs the same two-kernel iteration (mpiaij.c:1047-1061 around the fused kernel) */
+    if (!(A->nranks > 1 && A->B && A->halo) || (ksp->fused & 2)) return 0; /* (fused = 3: the round-5 sequence -- separate direction and dot kernels -- for A/B timing) */
+    CHK(hipxMatMultMPICGDirectionDotBegin(A->A, A->B, A->halo, ksp->P, ksp->P2, ksp->R, pc->dconst, X, b, a, dbn, dbo, ddpi, A->lvec, ksp->Z, A->m, slot, dev_dot, done));
+  } else CHK(hipxMatMultCGDirectionDotBegin(A->A, ksp->P, ksp->P2, ksp->R, pc->dconst, X, b, a, dbn, dbo, ddpi, ksp->Z, slot, dev_dot, done));
   if (*done) {
     double *t = ksp->P;
     ksp->P    = ksp->P2;
