@@ -122,13 +122,33 @@ __global__ __launch_bounds__(256) void ipc_put_kernel(const double *__restrict__
   __syncthreads();
   const double b = CG ? (cg.dev_beta_new ? (*cg.dev_beta_new / *cg.dev_beta_old) : cg.b) : 0.0;
   if (ok) {
-    const bool al = (reinterpret_cast<uintptr_t>(sg.dst) & 15) == 0;
-    for (hipx_int q = (hipx_int)blockIdx.x * 256 + threadIdx.x; q < n2; q += (hipx_int)gridDim.x * 256) {
-      const double v0 = halo_value<CG>(x, sg.idx[2 * q], cg, b), v1 = halo_value<CG>(x, sg.idx[2 * q + 1], cg, b);
-      if (al) ipc_store16(sg.dst + 2 * q, v0, v1);
-      else {
-        ipc_store8(sg.dst + 2 * q, v0);
-        ipc_store8(sg.dst + 2 * q + 1, v1);
+    const bool     al = (reinterpret_cast<uintptr_t>(sg.dst) & 15) == 0;
+    const hipx_int T  = (hipx_int)gridDim.x * 256;
+    constexpr int  U  = 4;  // pairs in flight per thread (few workgroups -- few arrivals on the ticket word -- with deep loads instead of many shallow ones)
+    for (hipx_int q0 = (hipx_int)blockIdx.x * 256 + threadIdx.x; q0 < n2; q0 += U * T) {
+      hipx_int i0[U], i1[U];
+      double   v0[U], v1[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const hipx_int q = q0 + u * T;
+        i0[u] = q < n2 ? sg.idx[2 * q] : 0;
+        i1[u] = q < n2 ? sg.idx[2 * q + 1] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        v0[u] = halo_value<CG>(x, i0[u], cg, b);
+        v1[u] = halo_value<CG>(x, i1[u], cg, b);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const hipx_int q = q0 + u * T;
+        if (q < n2) {
+          if (al) ipc_store16(sg.dst + 2 * q, v0[u], v1[u]);
+          else {
+            ipc_store8(sg.dst + 2 * q, v0[u]);
+            ipc_store8(sg.dst + 2 * q + 1, v1[u]);
+          }
+        }
       }
     }
     if ((sg.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) ipc_store8(sg.dst + sg.n - 1, halo_value<CG>(x, sg.idx[sg.n - 1], cg, b));
@@ -618,7 +638,7 @@ static int halo_begin(hipxHalo h, const double *x, double *lvec, const PackCG *c
       }
       if (!ns) continue;
       hipx_int g = (maxn2 + 255) / 256;
-      if (g > 1024) g = 1024;
+      if (g > 128) g = 128;  // (every workgroup arrives on its segment's ticket word: ~12 ns per arrival -- 1024 workgroups spent 12 us there)
       const dim3 grid((unsigned)g, (unsigned)ns);
       if (cgp) ipc_put_kernel<true><<<grid, 256, 0, rt().compute>>>(x, pa, s, h->d_err, ipc_wait_ticks(), cg);
       else ipc_put_kernel<false><<<grid, 256, 0, rt().compute>>>(x, pa, s, h->d_err, ipc_wait_ticks(), cg);
@@ -735,7 +755,7 @@ int hipxHaloIpcExport(hipxHalo h, int rank, int nranks, void *blob)
   h->nranks    = nranks;
   h->nghost    = (size_t)h->recv_off[h->nrecv];
   h->hdr_bytes = ((size_t)16 * (size_t)nranks + 255) & ~(size_t)255;
-  const size_t bytes = h->hdr_bytes + 2 * sizeof(double) * std::max<size_t>(h->nghost, 1);
+  const size_t bytes = h->hdr_bytes + 2 * sizeof(double) * std::max<size_t>(h->nghost, 1) + 16;  // (+ 16: offdiag_dot_kernel reads the ghost values in aligned pairs)
   if (!h->arena) {
     // fine-grained: flags are polled while another process / GPU writes them, and the ghost values are written by the peers
     HIPX_HIP(hipExtMallocWithFlags((void **)&h->arena, bytes, hipDeviceMallocFinegrained));
@@ -860,7 +880,7 @@ extern "C" int hipxMatMPICGPlan_(hipxMat A, hipxMat B, int *ok, int *skipmask);
 extern "C" int hipxMatMultCGDirectionPartial_(hipxMat A, int skipmask, const double *p_old, double *p_new, const double *z, double dconst, double *x, double b, double a,
                                               const double *dev_beta_new, const double *dev_beta_old, const double *dev_dpi, double *w, int want_dot, int *fused, const double **dotpart,
                                               hipx_int *npart);
-extern "C" int hipxMatMultAddDotFold_(hipxMat B, const double *ghost, double *w, const double *p, const double *partA, hipx_int npartA, int slot, double *dst, const hipx::IpcWait *wt);
+extern "C" int hipxMatMultAddDotFold_(hipxMat A, hipxMat B, const double *ghost, double *w, const double *p, const double *partA, hipx_int npartA, int slot, double *dst, const hipx::IpcWait *wt);
 
 int hipxMatMultMPICGDirectionDotBegin(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *p_old, double *p_new, const double *z, double dconst, double *x, double b, double a,
                                       const double *dev_beta_new, const double *dev_beta_old, const double *dev_dpi, double *lvec, double *w, hipx_int n, int slot, double *dev_dot, int *fused)
@@ -900,7 +920,7 @@ int hipxMatMultMPICGDirectionDotBegin(hipxMat Ad, hipxMat Bo, hipxHalo h, const 
   } else {
     IpcWait wt;
     if ((ierr = halo_end_inline(h, &wt))) return ierr;  // (IPC: the off-diagonal kernel waits for the neighbours' flags itself)
-    if ((ierr = hipxMatMultAddDotFold_(Bo, ghost, w, p_new, dotpart, npart, slot, c.d_red, &wt))) return ierr;
+    if ((ierr = hipxMatMultAddDotFold_(Ad, Bo, ghost, w, p_new, dotpart, npart, slot, c.d_red, &wt))) return ierr;
   }
   if ((ierr = prof_section(HIPX_PROF_OFFDIAG, false, rt().compute))) return ierr;
   if ((ierr = allreduce_signal(c.d_red, 1, exact, slot, dev_dot, h))) return ierr;  // (IPC: the acknowledgement of the ghost buffer rides in the all-reduce kernel)

@@ -28,6 +28,15 @@ __device__ __forceinline__ double ipc_load8(const double *p)
   return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
 }
 __device__ __forceinline__ void ipc_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// four 16-byte system-scope loads (never a stale cache line) in flight together, then the wait -- ONE asm statement: the compiler does not count loads
+// issued by inline asm, so nothing may touch the destination registers between issue and wait.  Every pointer 16-byte aligned and valid.
+__device__ __forceinline__ void ipc_load16x4(const double *p0, const double *p1, const double *p2, const double *p3, ipc_dbl2 &g0, ipc_dbl2 &g1, ipc_dbl2 &g2, ipc_dbl2 &g3)
+{
+  asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\tglobal_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3)
+               : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+               : "memory");
+}
 
 // spin until *flag >= want; gives up after `limit` ticks of the 100 MHz wall clock (or when another waiter has given up): *err <- 1, returns false
 __device__ __forceinline__ bool ipc_wait_ge(const unsigned long long *flag, unsigned long long want, unsigned int *err, long long limit)

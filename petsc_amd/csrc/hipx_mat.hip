@@ -4553,16 +4553,184 @@ int hipxMatMultCGDirectionDotBegin(hipxMat A, const double *p_old, double *p_new
 // hipxMatMPICGPlan_: can the pair (Ad, Bo) run the two-kernel form?  Ad must take the CG-prologue march kernel; Bo (compressed rows, 32-bit offsets) must have
 // its rows in EXACTLY the first and / or the last plane of Ad's grid (every row of such a plane): a z-slab of a natural-ordered stencil grid.  *skipmask: bit 0
 // = the first plane's rows carry off-diagonal entries, bit 1 = the last plane's.  Decided once per pair (a host copy of Bo's row list, nrows_c integers).
+// B->ops->multadd of MatMult_MPIAIJ (mpiaij.c:1059) on the listed rows, w_i = ((w_i + b_i0 g_0) + b_i1 g_1) ... (MatMultAdd_SeqAIJ's compressed-row loop,
+// aij.c:1629-1641: products and sums rounded separately, left to right), fused with the rows' share of the dot p . w (cg.c:258) and with the FOLD of all the dot
+// partials -- the product kernel's (rows without off-diagonal entries) and this kernel's: a partition of the rows, every product p_i w_i formed once with
+// the complete w_i.  A workgroup takes 256 consecutive listed rows; its nonzeros are one contiguous range, read coalesced, the products parked in LDS (the
+// row-block idea of spmv_stream_kernel); a range beyond the tile falls back to the per-row walk.  The last workgroup (ticket; release / acquire at agent scope:
+// the R1 hand-off of hipx_reduce.h) adds partA[0 .. npartA) and the workgroups' partials in index order per thread, wave tree, 4 wave sums left to right.
+}  // extern "C"
+namespace {
+constexpr int OD_CAP = 2560, OD_WIN = 2048, OD_GRP = 32;
+// the ghost columns the entries of every 256-row workgroup touch: (cmin rounded down to a pair, cmax) -- once per off-diagonal block (hipxMatMultAddDotFold_)
+__global__ __launch_bounds__(256) void offdiag_window_kernel(hipx_int nrows, const hipx_int *__restrict__ bi, const hipx_int *__restrict__ bj, int2 *__restrict__ win)
+{
+  __shared__ hipx_int s_c[2][4];
+  const int      t  = threadIdx.x;
+  const hipx_int r0 = (hipx_int)blockIdx.x * 256, r1 = (r0 + 256 < nrows) ? r0 + 256 : nrows;
+  hipx_int       cmin = 0x7fffffff, cmax = -1;
+  for (hipx_int k = bi[r0] + t; k < bi[r1]; k += 256) {
+    const hipx_int c = bj[k];
+    cmin = c < cmin ? c : cmin;
+    cmax = c > cmax ? c : cmax;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const hipx_int a = __shfl_down(cmin, off, 64), b2 = __shfl_down(cmax, off, 64);
+    cmin = a < cmin ? a : cmin;
+    cmax = b2 > cmax ? b2 : cmax;
+  }
+  if ((t & 63) == 0) {
+    s_c[0][t >> 6] = cmin;
+    s_c[1][t >> 6] = cmax;
+  }
+  __syncthreads();
+  if (t == 0) {
+    for (int q = 1; q < 4; q++) {
+      cmin = s_c[0][q] < cmin ? s_c[0][q] : cmin;
+      cmax = s_c[1][q] > cmax ? s_c[1][q] : cmax;
+    }
+    win[blockIdx.x] = make_int2(cmin & ~1, cmax);
+  }
+}
+
+__global__ __launch_bounds__(256) void offdiag_dot_kernel(hipx_int nrows, const hipx_int *__restrict__ bi, const hipx_int *__restrict__ bj, const double *__restrict__ ba,
+                                                          const hipx_int *__restrict__ ridx, const double *ghost, double *__restrict__ w, const double *__restrict__ p,
+                                                          double *part, const double *partA, int npartA, unsigned int *ticket, unsigned int *gticket, double *dst, const IpcWait wt,
+                                                          const hipx_int ncols, const int2 *__restrict__ win)
+{
+  __shared__ double   s_prod[OD_CAP];
+  __shared__ double   s_g[OD_WIN];
+  __shared__ double   s_w[4];
+  __shared__ unsigned s_last;
+  const int      t  = threadIdx.x;
+  const hipx_int r0 = (hipx_int)blockIdx.x * 256, r1 = (r0 + 256 < nrows) ? r0 + 256 : nrows;
+  const hipx_int k0 = bi[r0], k1 = bi[r1];
+  const bool     staged = (k1 - k0) <= OD_CAP;
+  // IPC transport: the neighbours' put kernels raise this rank's sequence flags when their write-through stores have drained; one lane per flag polls, and the
+  // ghost values are then read with system-scope (sc0 sc1) loads -- the "sc1 stores and sc1 loads on both sides" hand-off of hipx_ipc.h, no wait kernel in front
+  const bool     sysload = wt.n > 0;
+  // the ghost columns this workgroup's rows touch (a stencil's boundary rows: a few consecutive runs): when the window fits it is loaded ONCE, coalesced,
+  // 16 bytes per lane, into LDS and every operand is an LDS read (per-entry system-scope loads go to memory one by one)
+  const int2     wn     = win[blockIdx.x];
+  const hipx_int cmin   = wn.x, cmax = wn.y;
+  const bool     window = staged && cmax >= cmin && (cmax - cmin + 2) <= OD_WIN && ((reinterpret_cast<uintptr_t>(ghost) >> 3) & 1) == 0;
+  if (sysload) {
+    if (t < wt.n) ipc_wait_ge(wt.flag[t], wt.want, wt.err, wt.limit);
+    __syncthreads();
+  }
+  if (window) {
+    const hipx_int np = (cmax - cmin + 2) >> 1;  // pairs (<= OD_WIN / 2: four per thread); one that would reach beyond the ghost vector's last element is read as a single
+    static_assert(OD_WIN / 512 == 4, "four pairs per thread");
+    const double *src[4];
+    bool          single[4];
+    ipc_dbl2      gv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      hipx_int q = t + 256 * u;
+      q          = q < np ? q : np - 1;                            // (threads beyond the window re-read its last pair: every load valid, no branch around the loads)
+      single[u]  = cmin + 2 * q + 1 >= ncols;                      // the pair's second element lies beyond the vector: load the pair before it, fix up below
+      src[u]     = ghost + cmin + 2 * ((single[u] && q > 0) ? q - 1 : q);
+    }
+    if (sysload) ipc_load16x4(src[0], src[1], src[2], src[3], gv[0], gv[1], gv[2], gv[3]);  // all in flight, one wait
+    else {
+#pragma unroll
+      for (int u = 0; u < 4; u++) gv[u] = *reinterpret_cast<const ipc_dbl2 *>(src[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const hipx_int q = t + 256 * u;
+      if (q < np) {
+        if (single[u]) {
+          const double *s1 = ghost + cmin + 2 * q;
+          s_g[2 * q]     = sysload ? ipc_load8(s1) : s1[0];
+          s_g[2 * q + 1] = 0.0;
+        } else {
+          s_g[2 * q]     = gv[u].x;
+          s_g[2 * q + 1] = gv[u].y;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (staged) {
+    if (window)
+      for (hipx_int k = k0 + t; k < k1; k += 256) s_prod[k - k0] = ba[k] * s_g[bj[k] - cmin];
+    else
+      for (hipx_int k = k0 + t; k < k1; k += 256) s_prod[k - k0] = ba[k] * (sysload ? ipc_load8(ghost + bj[k]) : ghost[bj[k]]);
+    __syncthreads();
+  }
+  double acc = 0.0;
+  if (r0 + t < r1) {
+    const hipx_int r = r0 + t, row = ridx[r];
+    double         sum = w[row];
+    if (staged)
+      for (hipx_int k = bi[r]; k < bi[r + 1]; k++) sum += s_prod[k - k0];
+    else
+      for (hipx_int k = bi[r]; k < bi[r + 1]; k++) sum += ba[k] * (sysload ? ipc_load8(ghost + bj[k]) : ghost[bj[k]]);
+    w[row] = sum;
+    acc    = p[row] * sum;
+  }
+  acc = hipx::wave_sum(acc);
+  if ((t & 63) == 0) s_w[t >> 6] = acc;
+  __syncthreads();
+  if (t == 0) {
+    double r = s_w[0];
+    r += s_w[1];
+    r += s_w[2];
+    r += s_w[3];
+    // (no agent-scope release fence: it writes back the XCD's L2, full of the product kernel's w / p / x.  The partial goes out as an agent-scope atomic store
+    // (sc1: written through), is drained, then the tickets; the last workgroup reads with agent-scope atomic loads: the hand-off spmv_march2_kernel's
+    // in-kernel fold uses, pinned by tests/test_gpu_mat.py::test_march2_in_kernel_fold_equals_the_separate_fold_under_load.)  Two ticket levels: one
+    // contended word takes ~12 ns per arrival -- 2048 workgroups on one word were 25 us of this kernel; groups of OD_GRP arrive on their own words, the last
+    // of a group on the top one.
+    __hip_atomic_store(&part[blockIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned grp = blockIdx.x / OD_GRP, ngrp = (gridDim.x + OD_GRP - 1) / OD_GRP;
+    const unsigned gsz = (grp == ngrp - 1) ? gridDim.x - grp * OD_GRP : OD_GRP;
+    bool           last = false;
+    if (__hip_atomic_fetch_add(&gticket[grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsz - 1) {
+      __hip_atomic_store(&gticket[grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1;
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  double f = 0.0;
+  for (int i = t; i < npartA; i += 256) f += __hip_atomic_load(&partA[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (written by the launch before this one)
+  for (int i = t; i < (int)gridDim.x; i += 256) f += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  f = hipx::wave_sum(f);
+  __syncthreads();
+  if ((t & 63) == 0) s_w[t >> 6] = f;
+  __syncthreads();
+  if (t == 0) {
+    double r = s_w[0];
+    r += s_w[1];
+    r += s_w[2];
+    r += s_w[3];
+    dst[0]  = r;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch (stream-ordered)
+  }
+}
+}  // namespace
+extern "C" {
 }  // extern "C"
 struct MpiCgPlan {
-  hipxMat B = nullptr;
-  int     ok = 0, skip = 0;
+  hipxMat       B = nullptr;
+  int           ok = 0, skip = 0;
+  int2         *d_win     = nullptr;  // per 256-row workgroup of offdiag_dot_kernel: the ghost columns its entries touch
+  unsigned int *d_gticket = nullptr;  // its group tickets (zero between launches)
 };
 static std::vector<std::pair<hipxMat, MpiCgPlan>> g_mpicg;  // keyed by Ad (dropped in hipxMatDestroy)
 static void mpicg_forget(hipxMat M)
 {
   for (size_t k = g_mpicg.size(); k-- > 0;)
-    if (g_mpicg[k].first == M || g_mpicg[k].second.B == M) g_mpicg.erase(g_mpicg.begin() + (long)k);
+    if (g_mpicg[k].first == M || g_mpicg[k].second.B == M) {
+      (void)hipFree(g_mpicg[k].second.d_win);
+      (void)hipFree(g_mpicg[k].second.d_gticket);
+      g_mpicg.erase(g_mpicg.begin() + (long)k);
+    }
 }
 extern "C" {
 
@@ -4600,6 +4768,12 @@ extern "C" int hipxMatMPICGPlan_(hipxMat A, hipxMat B, int *ok, int *skipmask)
       else if (ridx[(size_t)k] >= m - S) nhi++;
     }
     if (!sorted || nlo + nhi != nr || (nlo && nlo != S) || (nhi && nhi != S)) break;
+    const hipx_int g = (nr + 255) / 256;
+    HIPX_HIP(hipMalloc((void **)&pl.d_win, sizeof(int2) * (size_t)g));
+    HIPX_HIP(hipMalloc((void **)&pl.d_gticket, sizeof(unsigned int) * (size_t)((g + OD_GRP - 1) / OD_GRP)));
+    HIPX_HIP(hipMemsetAsync(pl.d_gticket, 0, sizeof(unsigned int) * (size_t)((g + OD_GRP - 1) / OD_GRP), rt().compute));
+    offdiag_window_kernel<<<(unsigned)g, 256, 0, rt().compute>>>(nr, (const hipx_int *)B->d_i, B->d_j, pl.d_win);
+    HIPX_LAUNCH_CHECK();
     pl.ok   = 1;
     pl.skip = (nlo ? 1 : 0) | (nhi ? 2 : 0);
   } while (0);
@@ -4622,92 +4796,18 @@ extern "C" int hipxMatMultCGDirectionPartial_(hipxMat A, int skipmask, const dou
   return ierr;
 }
 
-// B->ops->multadd of MatMult_MPIAIJ (mpiaij.c:1059) on the listed rows, w_i = ((w_i + b_i0 g_0) + b_i1 g_1) ... (MatMultAdd_SeqAIJ's compressed-row loop,
-// aij.c:1629-1641: products and sums rounded separately, left to right), fused with the rows' share of the dot p . w (cg.c:258) and with the FOLD of all the dot
-// partials -- the product kernel's (rows without off-diagonal entries) and this kernel's: a partition of the rows, every product p_i w_i formed once with
-// the complete w_i.  A workgroup takes 256 consecutive listed rows; its nonzeros are one contiguous range, read coalesced, the products parked in LDS (the
-// row-block idea of spmv_stream_kernel); a range beyond the tile falls back to the per-row walk.  The last workgroup (ticket; release / acquire at agent scope:
-// the R1 hand-off of hipx_reduce.h) adds partA[0 .. npartA) and the workgroups' partials in index order per thread, wave tree, 4 wave sums left to right.
-}  // extern "C"
-namespace {
-constexpr int OD_CAP = 4096;
-__global__ __launch_bounds__(256) void offdiag_dot_kernel(hipx_int nrows, const hipx_int *__restrict__ bi, const hipx_int *__restrict__ bj, const double *__restrict__ ba,
-                                                          const hipx_int *__restrict__ ridx, const double *ghost, double *__restrict__ w, const double *__restrict__ p,
-                                                          double *part, const double *partA, int npartA, unsigned int *ticket, double *dst, const IpcWait wt)
-{
-  __shared__ double   s_prod[OD_CAP];
-  __shared__ double   s_w[4];
-  __shared__ unsigned s_last;
-  const int      t  = threadIdx.x;
-  const hipx_int r0 = (hipx_int)blockIdx.x * 256, r1 = (r0 + 256 < nrows) ? r0 + 256 : nrows;
-  const hipx_int k0 = bi[r0], k1 = bi[r1];
-  const bool     staged = (k1 - k0) <= OD_CAP;
-  // IPC transport: the neighbours' put kernels raise this rank's sequence flags when their write-through stores have drained; one lane per flag polls, and the
-  // ghost values are then read with system-scope (sc0 sc1) loads -- the "sc1 stores and sc1 loads on both sides" hand-off of hipx_ipc.h, no wait kernel in front
-  const bool     sysload = wt.n > 0;
-  if (sysload) {
-    if (t < wt.n) ipc_wait_ge(wt.flag[t], wt.want, wt.err, wt.limit);
-    __syncthreads();
-  }
-  if (staged) {
-    for (hipx_int k = k0 + t; k < k1; k += 256) s_prod[k - k0] = ba[k] * (sysload ? ipc_load8(ghost + bj[k]) : ghost[bj[k]]);
-    __syncthreads();
-  }
-  double acc = 0.0;
-  if (r0 + t < r1) {
-    const hipx_int r = r0 + t, row = ridx[r];
-    double         sum = w[row];
-    if (staged)
-      for (hipx_int k = bi[r]; k < bi[r + 1]; k++) sum += s_prod[k - k0];
-    else
-      for (hipx_int k = bi[r]; k < bi[r + 1]; k++) sum += ba[k] * (sysload ? ipc_load8(ghost + bj[k]) : ghost[bj[k]]);
-    w[row] = sum;
-    acc    = p[row] * sum;
-  }
-  acc = hipx::wave_sum(acc);
-  if ((t & 63) == 0) s_w[t >> 6] = acc;
-  __syncthreads();
-  if (t == 0) {
-    double r = s_w[0];
-    r += s_w[1];
-    r += s_w[2];
-    r += s_w[3];
-    // (no agent-scope release fence: it writes back the XCD's L2, full of the product kernel's w / p / x -- 2048 of them cost 60 us here.  The partial goes out
-    // as an agent-scope atomic store (sc1: written through), is drained, then the ticket; the last workgroup reads with agent-scope atomic loads: the
-    // hand-off spmv_march2_kernel's in-kernel fold uses, pinned by tests/test_gpu_mat.py::test_march2_in_kernel_fold_equals_the_separate_fold_under_load)
-    __hip_atomic_store(&part[blockIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last            = (tk == gridDim.x - 1);
-  }
-  __syncthreads();
-  if (!s_last) return;
-  double f = 0.0;
-  for (int i = t; i < npartA; i += 256) f += __hip_atomic_load(&partA[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (written by the launch before this one)
-  for (int i = t; i < (int)gridDim.x; i += 256) f += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  f = hipx::wave_sum(f);
-  __syncthreads();
-  if ((t & 63) == 0) s_w[t >> 6] = f;
-  __syncthreads();
-  if (t == 0) {
-    double r = s_w[0];
-    r += s_w[1];
-    r += s_w[2];
-    r += s_w[3];
-    dst[0]  = r;
-    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch (stream-ordered)
-  }
-}
-}  // namespace
-extern "C" {
 
-extern "C" int hipxMatMultAddDotFold_(hipxMat B, const double *ghost, double *w, const double *p, const double *partA, hipx_int npartA, int slot, double *dst, const hipx::IpcWait *wt)
+extern "C" int hipxMatMultAddDotFold_(hipxMat A, hipxMat B, const double *ghost, double *w, const double *p, const double *partA, hipx_int npartA, int slot, double *dst, const hipx::IpcWait *wt)
 {
   HIPX_ARG(B && B->compressed && !B->is64 && B->nrows_c > 0, "off-diagonal block: compressed rows with 32-bit offsets expected");
+  const MpiCgPlan *pl = nullptr;
+  for (auto &e : g_mpicg)
+    if (e.first == A && e.second.B == B && e.second.ok) pl = &e.second;
+  HIPX_ARG(pl && pl->d_win, "off-diagonal block: hipxMatMPICGPlan_ has not accepted this pair of blocks");
   const hipx_int g = (B->nrows_c + 255) / 256;
   HIPX_ARG(g <= (hipx_int)kMaxRedVals * kRedBlocks, "off-diagonal block: too many rows for the slot's partials");
   offdiag_dot_kernel<<<(unsigned)g, 256, 0, rt().compute>>>(B->nrows_c, (const hipx_int *)B->d_i, B->d_j, B->d_a, B->d_ridx, ghost, w, p, slot_partials(slot), partA, (int)npartA,
-                                                            rt().d_tickets + slot, dst, wt ? *wt : IpcWait{});
+                                                            rt().d_tickets + slot, pl->d_gticket, dst, wt ? *wt : IpcWait{}, B->n, pl->d_win);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }
