@@ -188,6 +188,9 @@ int hipxMatCreateCSR64(hipx_int m, hipx_int n, const int64_t *i, const hipx_int 
    only rows ridx[0..nrows) hold entries; ci has nrows+1 offsets. */
 int hipxMatCreateCSRCompressedRow(hipx_int m, hipx_int n, hipx_int nrows, const hipx_int *ci, const hipx_int *ridx, const hipx_int *j, const double *a, hipxMat *A);
 int hipxMatUpdateValues(hipxMat A, const double *a);          /* same nonzero pattern, new values (host) */
+/* builds NOW what the first product would build lazily (inode search, row / pattern templates, march plan, SELL / packed-column copies): the device half of
+   MatAssemblyEnd_SeqAIJ's set-up work (aij.c:1085-1144: inode and compressed-row checks happen there too), so that the first MatMult is a product only */
+int hipxMatSetUp(hipxMat A);
 int hipxMatGetValues(hipxMat A, double *a_host);              /* the value array back to the host (CSR order) */
 /* Value-only updates on the device copy (no host round trip).  Same arithmetic as the reference:
    MatScale_SeqAIJ aij.c:2604-2617 (a *= alpha), MatZeroEntries_SeqAIJ, MatDiagonalScale_SeqAIJ aij.c:2333-2371

@@ -42,7 +42,15 @@ typedef struct {
   PetscInt     magic;
   PetscScalar *d_alt;        /* second device buffer (lazy fusion: the CG direction vector is rewritten out of place by the product kernel), or NULL */
   PetscInt     d_alt_n;
+  PetscBool    d_alt_owned;  /* (after a swap the slab piece of a VecDuplicateVecs vector is the "second" buffer: not ours to free) */
+  struct VecHIPXSlab_s *slab; /* the VecDuplicateVecs slab d_array points into (reference-counted), or NULL */
 } VecHIPXExt;
+/* One device allocation for the m vectors of a VecDuplicateVecs call (the reference: VecDuplicateVecs_Seq_GEMV, bvec2.c:670 -- a Krylov basis is one array of
+   leading dimension lda, which is what lets VecMDot / VecMAXPY be GEMVs there).  Freed when its last vector goes. */
+typedef struct VecHIPXSlab_s {
+  PetscScalar *base;
+  PetscInt     refs;
+} VecHIPXSlab;
 
 #define VECHIPX_MAGIC   0x48495058
 #define VECHIPX_EXT_OFF ((sizeof(Vec_MPI) > sizeof(Vec_Seq) ? sizeof(Vec_MPI) : sizeof(Vec_Seq)) + 16 - ((sizeof(Vec_MPI) > sizeof(Vec_Seq) ? sizeof(Vec_MPI) : sizeof(Vec_Seq)) % 16))
@@ -89,6 +97,7 @@ PETSC_INTERN PetscErrorCode PCCreate_PBJacobiHIPX(PC); /* "pbjacobihipx": PCPBJA
 PETSC_INTERN PetscErrorCode KSPCreate_CGHIPX(KSP); /* "cghipx": KSPCG with the fused device kernels on the hot-path configuration */
 PETSC_INTERN PetscErrorCode KSPCreate_ChebyshevHIPX(KSP); /* "chebyshevhipx": KSPCHEBYSHEV, first kind without norms on one fused kernel per iteration */
 PETSC_INTERN PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA); /* uploads / refreshes the device CSR */
+PETSC_INTERN PetscErrorCode MatSeqAIJHIPXSetUpDevice(Mat A); /* upload + hipxMatSetUp now (set-up phases call it; -mat_hipx_setup_at_assembly 0 turns it off) */
 PETSC_INTERN PetscBool      MatIsSeqAIJHIPX(Mat A);
 PETSC_INTERN PetscErrorCode MatSeqAIJHIPXSetValuesCOO_Private(Mat A, hipxCOO coo, const PetscScalar v[], PetscCount n, InsertMode imode);
 PetscErrorCode MatSeqAIJHIPXAddValuesCOOIndexed_Private(Mat, hipxCOO, const PetscScalar *);

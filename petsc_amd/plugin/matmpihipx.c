@@ -236,6 +236,9 @@ static PetscErrorCode MatAssemblyEnd_MPIAIJHIPX(Mat A, MatAssemblyType mode)
       a->lvec = lv;
     }
     if (!h->halo || h->nzstate != A->nonzerostate) PetscCall(MatMPIAIJHIPXBuildHalo(A)); /* collective: every rank assembles */
+    /* the blocks are final now (MatSetUpMultiply_MPIAIJ has compacted B's columns): their device copies and formats at set-up time (round 6) */
+    if (a->A && MatIsSeqAIJHIPX(a->A)) PetscCall(MatSeqAIJHIPXSetUpDevice(a->A));
+    if (a->B && MatIsSeqAIJHIPX(a->B)) PetscCall(MatSeqAIJHIPXSetUpDevice(a->B));
   }
   PetscFunctionReturn(PETSC_SUCCESS);
 }

@@ -145,7 +145,7 @@ static PetscErrorCode VecHIPXAllocate(Vec v)
   PetscFunctionBegin;
   if (e->d_array && e->d_n >= n) PetscFunctionReturn(PETSC_SUCCESS);
   if (e->d_array && e->d_owned) PetscCallHIPX(hipxFree(e->d_array));
-  if (e->d_alt) PetscCallHIPX(hipxFree(e->d_alt));
+  if (e->d_alt && e->d_alt_owned) PetscCallHIPX(hipxFree(e->d_alt));
   e->d_alt = NULL;
   PetscCallHIPX(hipxMalloc((void **)&e->d_array, sizeof(PetscScalar) * (size_t)(n ? n : 1)));
   e->d_n     = n;
@@ -498,10 +498,11 @@ static PetscErrorCode VecHIPXAltBuffer(Vec v, PetscScalar **alt)
 
   PetscFunctionBegin;
   if (!e->d_alt || e->d_alt_n < v->map->n) {
-    if (e->d_alt) PetscCallHIPX(hipxFree(e->d_alt));
+    if (e->d_alt && e->d_alt_owned) PetscCallHIPX(hipxFree(e->d_alt));
     e->d_alt = NULL;
     PetscCallHIPX(hipxMalloc((void **)&e->d_alt, sizeof(PetscScalar) * (size_t)(v->map->n ? v->map->n : 1)));
-    e->d_alt_n = v->map->n;
+    e->d_alt_n     = v->map->n;
+    e->d_alt_owned = PETSC_TRUE;
   }
   *alt = e->d_alt;
   PetscFunctionReturn(PETSC_SUCCESS);
@@ -513,10 +514,14 @@ static void VecHIPXSwapBuffers(Vec v)
   PetscScalar *t  = e->d_array;
   PetscInt     tn = e->d_n;
 
-  e->d_array = e->d_alt;
-  e->d_n     = e->d_alt_n;
-  e->d_alt   = t;
-  e->d_alt_n = tn;
+  const PetscBool to = e->d_owned;
+
+  e->d_array     = e->d_alt;
+  e->d_n         = e->d_alt_n;
+  e->d_owned     = e->d_alt_owned;
+  e->d_alt       = t;
+  e->d_alt_n     = tn;
+  e->d_alt_owned = to;
 }
 
 /* MatMult(A, xx = p, yy = w) with exactly "x += a p; p = z + b p" recorded: the product kernel with the two updates as its prologue.  The kernel
@@ -534,7 +539,8 @@ PetscErrorCode VecHIPXLazyTryCGProduct(hipxMat dA, Vec xx, Vec yy, PetscBool *do
     int              fused = 0;
 
     if (!(o.kind == 1 && q.kind == 2 && o.x == xx && q.y == xx && o.y != q.x && o.y != xx && q.x != xx && yy != xx && yy != o.y && yy->map->n == xx->map->n)) PetscFunctionReturn(PETSC_SUCCESS);
-    if (!VecHIPXGetExt(xx)->d_owned || (walias && !VecHIPXGetExt(yy)->d_owned)) PetscFunctionReturn(PETSC_SUCCESS); /* (a buffer somebody else owns cannot be swapped) */
+    /* (a VecPlaceArray-style foreign buffer cannot be swapped; a VecDuplicateVecs slab piece can: ownership travels with the buffers) */
+    if ((!VecHIPXGetExt(xx)->d_owned && !VecHIPXGetExt(xx)->slab) || (walias && !VecHIPXGetExt(yy)->d_owned && !VecHIPXGetExt(yy)->slab)) PetscFunctionReturn(PETSC_SUCCESS);
     PetscCall(VecHIPXAltBuffer(xx, &pnew));
     if (walias) PetscCall(VecHIPXAltBuffer(yy, &wout));
     else {
@@ -1196,7 +1202,14 @@ static PetscErrorCode VecHIPXFreeDevice(Vec v)
   if (e->magic == VECHIPX_MAGIC) PetscCall(VecHIPXLazySync(v));
   VecHIPXRedCacheInvalidate(v);
   if (e->magic == VECHIPX_MAGIC && e->d_array && e->d_owned) PetscCallHIPX(hipxFree(e->d_array));
-  if (e->magic == VECHIPX_MAGIC && e->d_alt) PetscCallHIPX(hipxFree(e->d_alt));
+  if (e->magic == VECHIPX_MAGIC && e->slab) {
+    if (--e->slab->refs == 0) {
+      PetscCallHIPX(hipxFree(e->slab->base));
+      PetscCall(PetscFree(e->slab));
+    }
+    e->slab = NULL;
+  }
+  if (e->magic == VECHIPX_MAGIC && e->d_alt && e->d_alt_owned) PetscCallHIPX(hipxFree(e->d_alt));
   e->d_alt   = NULL;
   e->d_array = NULL;
   e->magic   = 0;
@@ -1244,9 +1257,33 @@ static PetscErrorCode VecDuplicate_MPIHIPX(Vec win, Vec *V)
 
 static PetscErrorCode VecDuplicateVecs_HIPX(Vec w, PetscInt m, Vec *V[])
 {
+  static PetscBool slab_on = PETSC_TRUE, looked = PETSC_FALSE;
+  const PetscInt   n  = w->map->n;
+  const size_t     ld = ((size_t)(n > 0 ? n : 1) + 1) & ~(size_t)1; /* every vector 16-byte aligned */
+
   PetscFunctionBegin;
+  if (!looked) {
+    PetscCall(PetscOptionsGetBool(NULL, NULL, "-vec_hipx_duplicatevecs_slab", &slab_on, NULL));
+    looked = PETSC_TRUE;
+  }
   PetscCall(PetscMalloc1(m, V));
   for (PetscInt i = 0; i < m; i++) PetscCall(VecDuplicate(w, &(*V)[i]));
+  /* VecDuplicateVecs_Seq_GEMV (bvec2.c:670-720): the m vectors' storage is ONE array (there: the host array, so that VecMDot / VecMAXPY become dgemv; here: the
+     device mirrors -- one hipMalloc instead of m, the basis contiguous for the wide MDot / MAXPY kernels).  The host arrays stay the parent's. */
+  if (slab_on && m > 1 && n > 0 && VecIsHIPX((*V)[0])) {
+    VecHIPXSlab *sl;
+    PetscCall(PetscNew(&sl));
+    PetscCallHIPX(hipxMalloc((void **)&sl->base, sizeof(PetscScalar) * ld * (size_t)m));
+    sl->refs = m;
+    for (PetscInt i = 0; i < m; i++) {
+      VecHIPXExt *e = VecHIPXGetExt((*V)[i]);
+      if (e->d_array && e->d_owned) PetscCallHIPX(hipxFree(e->d_array));
+      e->d_array = sl->base + ld * (size_t)i;
+      e->d_n     = n;
+      e->d_owned = PETSC_FALSE;
+      e->slab    = sl;
+    }
+  }
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
