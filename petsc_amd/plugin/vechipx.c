@@ -1258,19 +1258,25 @@ static PetscErrorCode VecDuplicate_MPIHIPX(Vec win, Vec *V)
 static PetscErrorCode VecDuplicateVecs_HIPX(Vec w, PetscInt m, Vec *V[])
 {
   static PetscBool slab_on = PETSC_TRUE, looked = PETSC_FALSE;
-  const PetscInt   n  = w->map->n;
-  const size_t     ld = ((size_t)(n > 0 ? n : 1) + 1) & ~(size_t)1; /* every vector 16-byte aligned */
+  static PetscInt  pad = 544; /* doubles between two vectors of a slab: 4 KiB + 256 B, so that a stride of 2^k bytes (n = 256^3) does not put element i of every vector on one HBM channel */
+  const PetscInt   n   = w->map->n;
+  size_t           ld;
 
   PetscFunctionBegin;
   if (!looked) {
     PetscCall(PetscOptionsGetBool(NULL, NULL, "-vec_hipx_duplicatevecs_slab", &slab_on, NULL));
+    PetscCall(PetscOptionsGetInt(NULL, NULL, "-vec_hipx_slab_pad", &pad, NULL));
     looked = PETSC_TRUE;
   }
+  ld = (((size_t)(n > 0 ? n : 1) + (size_t)(pad > 0 ? pad : 0)) + 1) & ~(size_t)1; /* every vector 16-byte aligned */
   PetscCall(PetscMalloc1(m, V));
   for (PetscInt i = 0; i < m; i++) PetscCall(VecDuplicate(w, &(*V)[i]));
   /* VecDuplicateVecs_Seq_GEMV (bvec2.c:670-720): the m vectors' storage is ONE array (there: the host array, so that VecMDot / VecMAXPY become dgemv; here: the
      device mirrors -- one hipMalloc instead of m, the basis contiguous for the wide MDot / MAXPY kernels).  The host arrays stay the parent's. */
-  if (slab_on && m > 1 && n > 0 && VecIsHIPX((*V)[0])) {
+  /* (m >= 8: a Krylov basis.  The three or five work vectors of a CG keep allocations of their own: measured on 7-pt 256^3, stock KSPCG, 400 iterations --
+     separate allocations 109-112 ms, one slab with the 4352-byte skew 113-114, without skew 118, with a 527 KB skew 123: where r, z, p lie relative to each
+     other moves the fused kernels by a few per cent, and the allocator's own placement is the best of those tried) */
+  if (slab_on && m >= 8 && n > 0 && VecIsHIPX((*V)[0])) {
     VecHIPXSlab *sl;
     PetscCall(PetscNew(&sl));
     PetscCallHIPX(hipxMalloc((void **)&sl->base, sizeof(PetscScalar) * ld * (size_t)m));
