@@ -177,6 +177,37 @@ int hipxCGFusedUpdateBegin(double *x, double *r, double *z, const double *p, con
                            hipx_int n, int slot, double *dev_sums2); /* d == NULL: z = r * dconst (constant Jacobi diagonal), one vector pass less;
                                                                       then z == NULL as well: z is not stored (hipxCGAypxAxpyDev/R re-form it) */
 
+/* ---- pipelined CG variants (round 6; csrc/hipx_pipe.hip) ------------------------------------
+   The update blocks of KSPSolve_PIPECG (pipecg.c:132-150), KSPSolve_GROPPCG (groppcg.c:98-100,135-136) and KSPSolve_PIPECR (pipecr.c:101-117) are runs of
+   VecAYPX / VecAXPY calls on up to ten vectors, followed by the sums of the next iteration (VecNormBegin / VecDotBegin, comb.c:338,379).
+   hipxVecBatchAXPYDotsBegin runs such a run as ONE pass: nops operations in their order -- kind[k] 1: y += s x (VecAXPY_Seq bvec1.c:70-83), 2: y = x + s y
+   (VecAYPX_Seq dvec2.c:753-780, general-beta loop; for s = 1, -1 the same bits as the reference's special cases) -- on the nvec DISTINCT device vectors
+   vec[0 .. nvec), addressed by slot: slots are numbered by first appearance (for each operation y, then x).  Every operand is read once, every changed vector
+   written once; element by element the operations and their order are those of the separate calls: the vectors are bit-identical.  The batch must be one of
+   the compiled programs (the three loops above); otherwise nothing is enqueued and *ndots = -1 (the caller runs the calls one by one).  On success *ndots sums
+   of the vectors after the batch, da[k] . db[k] (slots), are on their way to reduction slot `slot`: hipxRedEnd(slot, *ndots, sums). */
+#define HIPX_BATCH_MAX_OPS  8
+#define HIPX_BATCH_MAX_VECS 10
+#define HIPX_BATCH_MAX_DOTS 4
+int hipxVecBatchProgramKnown(int nops, const int *kind, const int *yslot, const int *xslot, int nvec); /* 1: hipxVecBatchAXPYDotsBegin would run this batch; no GPU work */
+int hipxVecBatchAXPYDotsBegin(int nops, const int *kind, const int *yslot, const int *xslot, const double *s, int nvec, double *const *vec, hipx_int n, int slot, int *ndots, int *da,
+                              int *db);
+/* One iteration's vector work of KSPSolve_PIPECG in one pass, the scalars formed on the device (launch-ahead: HipxKSPSolve_PIPECG, hipx_ksp.h):
+     first:     alpha = gamma / delta;  z = n; q = m; p = u; s = w                                                            pipecg.c:132-136
+     otherwise: beta = gamma / gamma_old; alpha = gamma / (delta - beta / alpha_old * gamma);                                 pipecg.c:138-139
+                x += alpha_old p  (the update the iteration before left behind: applied before p changes);  z = n + beta z; q = m + beta q; p = u + beta p; s = w + beta s
+     then       u -= alpha q; w -= alpha z; r -= alpha s                                                                      pipecg.c:148-150
+                m = w .* d  (PCJACOBI; d == NULL: m = w * dconst -- a constant diagonal, or 1.0 = PCNONE's copy)              pipecg.c:115
+     sums of the new vectors -> slot and dev_sums_out[0..3): [0] u.u (normkind 1) | r.r (2) | 0 (0), [1] gamma = r.u, [2] delta = w.u   pipecg.c:106-113
+   gamma, delta = dev_sums[1], [2]; gamma_old = dev_sums_old[1]; alpha is written to *dev_alpha_out (the host forms the same IEEE quotients for the final
+   x += alpha p).  m of THIS iteration (q = m + beta q) is re-formed from w as the kernel before formed it.  v->n = A m of this iteration.  Enqueue only. */
+typedef struct {
+  double       *z, *q, *p, *s, *x, *u, *w, *r, *m;
+  const double *n;
+} hipxPipeCGVecs;
+int hipxPipeCGUpdateBegin(const hipxPipeCGVecs *v, const double *d, double dconst, int normkind, int first, const double *dev_sums, const double *dev_sums_old, const double *dev_alpha_old,
+                          double *dev_alpha_out, hipx_int n, int slot, double *dev_sums_out);
+
 /* ---- Mat (CSR = Mat_SeqAIJ src/mat/impls/aij/seq/aij.h:47-78,150-168) ----------------------- */
 typedef struct hipxMat_s *hipxMat;
 
@@ -371,6 +402,15 @@ int hipxCGFusedUpdateBeginAllreduce(double *x, double *r, double *z, const doubl
    order (exact reduction mode: Dot2 over the complete vectors, order-free). */
 int hipxMatMultMPICGDirectionDotBegin(hipxMat Ad, hipxMat Bo, hipxHalo h, const double *p_old, double *p_new, const double *z, double dconst, double *x, double b, double a,
                                       const double *dev_beta_new, const double *dev_beta_old, const double *dev_dpi, double *lvec, double *w, hipx_int n, int slot, double *dev_dot, int *fused);
+/* Round 6: split-phase all-reduce -- PetscCommSplitReductionBegin / PetscSplitReductionEnd (comb.c:168-290: MPI_Iallreduce now, MPI_Wait at the first End) on the
+   device.  hipxPipeCGUpdateBeginAllreduce = hipxPipeCGUpdateBegin whose three local sums stay in device memory and START their all-reduce (IPC transport: a
+   one-wave kernel stores them into every peer's arena and raises the sequence flags; RCCL: ncclAllReduce on the comm stream behind an event); the caller enqueues
+   the work the reduction hides behind (PIPECG: PCApply + MatMult_MPIAIJ), then hipxAllreduceEnd: the compute stream waits for the peers' contributions, folds them
+   in rank order (plain or compensated), publishes the nvals totals to the host slot and to dev_out.  One all-reduce per PIPECG iteration, overlapped with the product. */
+int hipxPipeCGUpdateBeginAllreduce(const hipxPipeCGVecs *v, const double *d, double dconst, int normkind, int first, const double *dev_sums, const double *dev_sums_old,
+                                   const double *dev_alpha_old, double *dev_alpha_out, hipx_int n, int slot);
+int hipxVecMDotAllreduceBegin(const double *x, hipx_int nv, const double *const *y, hipx_int n, int slot); /* local x . y_j (nv <= 16) + the start of their all-reduce */
+int hipxAllreduceEnd(int slot, int nvals, double *dev_out);
 /* which transport the next exchange of this plan takes: 1 = IPC peer stores, 2 = RCCL send/recv, 0 = none set up */
 int hipxHaloTransport(hipxHalo h, int *transport);
 

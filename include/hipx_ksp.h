@@ -5,6 +5,7 @@
  * It mirrors the reference's caller code, statement by statement, over device vectors:
  *   KSPSolve_CG      src/ksp/ksp/impls/cg/cg.c:119-352
  *   KSPSolve_GMRES   src/ksp/ksp/impls/gmres/gmres.c:88-238,298-395 + borthog2.c:35-113
+ *   KSPSolve_PIPECG  src/ksp/ksp/impls/cg/pipecg/pipecg.c:20-160 (+ the split-phase reduction of src/vec/vec/utils/comb.c:168-379)
  *   KSPConvergedDefault  src/ksp/ksp/interface/iterativ.c:1490-1585
  *   PCApply_Jacobi / PCApply_SOR / PCApply_None   jacobi.c:354, sor.c:27, pcnone
  *   MatMult_SeqAIJ / MatMult_MPIAIJ   aij.c:1444, mpiaij.c:1047
@@ -81,6 +82,8 @@ typedef struct {
   double   gslab_len;        /* its length in doubles (a double: the slab of a 512^3 problem exceeds 2^31 elements) */
   double  *P2;               /* second direction vector: hipxMatMultCGDirectionDotBegin (direction update as the product's prologue) writes p_new here
                                 while other workgroups still read p; P and P2 swap roles after every fused launch (P is always the current direction) */
+  double  *pipe_slab;        /* PIPECG (HipxKSPSolve_PIPECG): its nine work vectors r, u, w, z, q, p, s, m, n in one slab, kept across solves (freed by HipxKSPDestroyWork) */
+  double   pipe_slab_len;    /* its length in doubles */
 } HipxKSP;
 
 /* sizeof of the three descriptor structs, so that a foreign-language mirror (petsc_amd/_lib.py) can verify its layout */
@@ -99,6 +102,9 @@ int HipxVecNorm2(HipxMat *A, const double *x, hipx_int n, double *r);           
 
 int HipxKSPSolve_CG(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, double *x);
 int HipxKSPSolve_GMRES(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, double *x);
+/* replaces KSPSolve_PIPECG pipecg.c:20-160 (PCJACOBI / PCNONE; any norm type): one fused update kernel + one product per iteration, the scalars formed on the
+   device, the iteration's single reduction (all-reduce on several ranks) hidden behind the product; ksp->pipeline = 0: host-synchronised (same bits) */
+int HipxKSPSolve_PIPECG(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, double *x);
 /* replaces KSPSolve_Chebyshev_FirstKind cheby.c:389-555 with given eigenvalue bounds (cheby.c:40-62); ksp->normtype NONE + PCJACOBI / PCNONE
    + ksp->fused: SpMV + one fused elementwise kernel per iteration, no reductions */
 int HipxKSPSolve_Chebyshev(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, double *x, double emin, double emax);

@@ -130,5 +130,5 @@ def _ksp_solve(L, kind, ai, aj, aa, b, pc, rtol, max_it, normtype, restart, refi
     x = np.zeros(m) if x0 is None else np.array(x0, dtype=np.float64)
     k.guess_nonzero = 0 if x0 is None else 1
     bb = np.ascontiguousarray(b, dtype=np.float64)
-    (L.orc_KSPSolve_CG if kind == "cg" else L.orc_KSPSolve_GMRES)(C.byref(k), P(bb), P(x))
+    {"cg": L.orc_KSPSolve_CG, "gmres": L.orc_KSPSolve_GMRES, "pipecg": L.orc_KSPSolve_PIPECG, "groppcg": L.orc_KSPSolve_GROPPCG}[kind](C.byref(k), P(bb), P(x))
     return x, int(k.its), int(k.reason), hist[:min(k.hist_n, len(hist))].copy()

@@ -1151,8 +1151,8 @@ static int converged_default(Ctx *c, OInt n, OScalar rnorm, const OScalar *b)
     } else c->rnorm0 = rnorm;
     c->ttol = fmax(ksp->rtol * c->rnorm0, ksp->abstol);
   }
-  /* chknorm = 0 by default: `if (n <= ksp->chknorm) return` skips the test at n == 0 */
-  if (n <= 0) return 0;
+  /* `if (n <= ksp->chknorm) return` (iterativ.c:1546): chknorm = -1 by default (KSPCreate, itcreate.c:816) -- the test runs at n == 0 too (round 6: until then
+     this restatement skipped it there; it differs only when the initial residual already meets the tolerance: b = 0, or a good nonzero guess) */
   if (isnan(rnorm) || isinf(rnorm)) return ORC_KSP_DIVERGED_NANORINF;
   if (n < ksp->min_it) return 0;
   if (rnorm <= c->ttol) return (rnorm < ksp->abstol) ? ORC_KSP_CONVERGED_ATOL : ORC_KSP_CONVERGED_RTOL;
@@ -1269,6 +1269,175 @@ done:
   free(R);
   free(Z);
   free(P);
+  return ksp->reason;
+}
+
+/* KSPSolve_PIPECG, src/ksp/ksp/impls/cg/pipecg/pipecg.c:20-160, statement by statement.  VecNormBegin/VecDotBegin ... End on one rank are the local
+   reductions (comb.c:338-379: dot_local at Begin, the value handed back at End); on a simulated partition the sums are over the whole vectors as everywhere
+   in this oracle.  Note the loop bound `i <= max_it` (pipecg.c:160) and that nothing but the convergence test ends the loop early. */
+int orc_KSPSolve_PIPECG(OrcKSP *ksp, const OScalar *B, OScalar *X)
+{
+  Ctx      c;
+  OInt     n = ksp->m, i;
+  OScalar  alpha = 0.0, beta = 0.0, gamma = 0.0, gammaold = 0.0, delta = 0.0, dp = 0.0;
+  OScalar *V = (OScalar *)malloc((size_t)n * 9 * sizeof(OScalar));
+  OScalar *R = V, *Z = V + n, *P = V + 2 * n, *N = V + 3 * n, *W = V + 4 * n, *Q = V + 5 * n, *U = V + 6 * n, *M = V + 7 * n, *S = V + 8 * n;
+
+  ctx_setup(&c, ksp);
+  ksp->its    = 0;
+  ksp->reason = 0;
+  ksp->hist_n = 0;
+  if (!ksp->guess_nonzero) memset(X, 0, (size_t)n * sizeof(OScalar)); /* itfunc.c:908 */
+  if (ksp->guess_nonzero) {
+    ksp_mult(&c, X, R);              /* pipecg.c:49 */
+    orc_VecAYPX_Seq(n, R, -1.0, B);  /* pipecg.c:50 */
+  } else orc_VecCopy_Seq(n, B, R);   /* pipecg.c:52 */
+  pc_apply(&c, R, U);                /* pipecg.c:55 */
+  switch (ksp->normtype) {           /* pipecg.c:57-86 */
+  case ORC_KSP_NORM_PRECONDITIONED:
+    dp = orc_VecNorm_Seq(n, U, ORC_NORM_2, NULL);
+    ksp_mult(&c, U, W);
+    break;
+  case ORC_KSP_NORM_UNPRECONDITIONED:
+    dp = orc_VecNorm_Seq(n, R, ORC_NORM_2, NULL);
+    ksp_mult(&c, U, W);
+    break;
+  case ORC_KSP_NORM_NATURAL:
+    gamma = orc_VecDot_Seq(n, R, U);
+    ksp_mult(&c, U, W);
+    if (isnan(gamma) || isinf(gamma)) { /* KSPCheckDot */
+      ksp->reason = ORC_KSP_DIVERGED_NANORINF;
+      goto done;
+    }
+    dp = sqrt(fabs(gamma));
+    break;
+  default:
+    ksp_mult(&c, U, W);
+    dp = 0.0;
+  }
+  log_history(ksp, dp);
+  ksp->rnorm  = dp;
+  ksp->reason = converged_default(&c, 0, dp, B); /* pipecg.c:90 */
+  if (ksp->reason) goto done;
+
+  i = 0;
+  do {
+    if (i > 0 && ksp->normtype == ORC_KSP_NORM_UNPRECONDITIONED) dp = orc_VecNorm_Seq(n, R, ORC_NORM_2, NULL);      /* pipecg.c:95-99 */
+    else if (i > 0 && ksp->normtype == ORC_KSP_NORM_PRECONDITIONED) dp = orc_VecNorm_Seq(n, U, ORC_NORM_2, NULL);
+    if (!(i == 0 && ksp->normtype == ORC_KSP_NORM_NATURAL)) gamma = orc_VecDot_Seq(n, R, U);                        /* pipecg.c:100 */
+    delta = orc_VecDot_Seq(n, W, U);                                                                                 /* pipecg.c:101 */
+    pc_apply(&c, W, M);  /* pipecg.c:104 */
+    ksp_mult(&c, M, N);  /* pipecg.c:105 */
+    if (i > 0) {
+      if (ksp->normtype == ORC_KSP_NORM_NATURAL) dp = sqrt(fabs(gamma));
+      else if (ksp->normtype == ORC_KSP_NORM_NONE) dp = 0.0;
+      ksp->rnorm = dp;
+      log_history(ksp, dp);
+      ksp->reason = converged_default(&c, i, dp, B); /* pipecg.c:124 */
+      if (ksp->reason) goto done;
+    }
+    if (i == 0) {
+      alpha = gamma / delta;      /* pipecg.c:129 */
+      orc_VecCopy_Seq(n, N, Z);
+      orc_VecCopy_Seq(n, M, Q);
+      orc_VecCopy_Seq(n, U, P);
+      orc_VecCopy_Seq(n, W, S);
+    } else {
+      beta  = gamma / gammaold;                             /* pipecg.c:135 */
+      alpha = gamma / (delta - beta / alpha * gamma);       /* pipecg.c:136 */
+      orc_VecAYPX_Seq(n, Z, beta, N);
+      orc_VecAYPX_Seq(n, Q, beta, M);
+      orc_VecAYPX_Seq(n, P, beta, U);
+      orc_VecAYPX_Seq(n, S, beta, W);
+    }
+    orc_VecAXPY_Seq(n, X, alpha, P);   /* pipecg.c:142-145 */
+    orc_VecAXPY_Seq(n, U, -alpha, Q);
+    orc_VecAXPY_Seq(n, W, -alpha, Z);
+    orc_VecAXPY_Seq(n, R, -alpha, S);
+    gammaold = gamma;
+    i++;
+    ksp->its = i;
+  } while (i <= ksp->max_it);
+  if (!ksp->reason) ksp->reason = ORC_KSP_DIVERGED_ITS;
+done:
+  ctx_free(&c);
+  free(V);
+  return ksp->reason;
+}
+
+/* KSPSolve_GROPPCG, src/ksp/ksp/impls/cg/groppcg/groppcg.c:23-140, statement by statement. */
+int orc_KSPSolve_GROPPCG(OrcKSP *ksp, const OScalar *B, OScalar *X)
+{
+  Ctx      c;
+  OInt     n = ksp->m, i;
+  OScalar  alpha, beta = 0.0, gamma, gammaNew = 0.0, t, dp = 0.0;
+  OScalar *V = (OScalar *)malloc((size_t)n * 6 * sizeof(OScalar));
+  OScalar *r = V, *p = V + n, *s = V + 2 * n, *S = V + 3 * n, *z = V + 4 * n, *Z = V + 5 * n;
+
+  ctx_setup(&c, ksp);
+  ksp->its    = 0;
+  ksp->reason = 0;
+  ksp->hist_n = 0;
+  if (!ksp->guess_nonzero) memset(X, 0, (size_t)n * sizeof(OScalar));
+  if (ksp->guess_nonzero) {
+    ksp_mult(&c, X, r);              /* groppcg.c:48 */
+    orc_VecAYPX_Seq(n, r, -1.0, B);
+  } else orc_VecCopy_Seq(n, B, r);   /* groppcg.c:51 */
+  pc_apply(&c, r, z);                /* groppcg.c:54 */
+  orc_VecCopy_Seq(n, z, p);          /* groppcg.c:55 */
+  gamma = orc_VecDot_Seq(n, r, z);   /* groppcg.c:56-59 */
+  ksp_mult(&c, p, s);                /* groppcg.c:58 */
+  switch (ksp->normtype) {           /* groppcg.c:61-80 */
+  case ORC_KSP_NORM_PRECONDITIONED: dp = orc_VecNorm_Seq(n, z, ORC_NORM_2, NULL); break;
+  case ORC_KSP_NORM_UNPRECONDITIONED: dp = orc_VecNorm_Seq(n, r, ORC_NORM_2, NULL); break;
+  case ORC_KSP_NORM_NATURAL:
+    if (isnan(gamma) || isinf(gamma)) {
+      ksp->reason = ORC_KSP_DIVERGED_NANORINF;
+      goto done;
+    }
+    dp = sqrt(fabs(gamma));
+    break;
+  default: dp = 0.0;
+  }
+  log_history(ksp, dp);
+  ksp->rnorm  = dp;
+  ksp->reason = converged_default(&c, 0, dp, B); /* groppcg.c:84 */
+  if (ksp->reason) goto done;
+
+  i = 0;
+  do {
+    ksp->its = i + 1;
+    i++;
+    t = orc_VecDot_Seq(n, p, s);       /* groppcg.c:91 */
+    pc_apply(&c, s, S);                /* groppcg.c:94 */
+    alpha = gamma / t;                 /* groppcg.c:98 */
+    orc_VecAXPY_Seq(n, X, alpha, p);   /* groppcg.c:99-101 */
+    orc_VecAXPY_Seq(n, r, -alpha, s);
+    orc_VecAXPY_Seq(n, z, -alpha, S);
+    if (ksp->normtype == ORC_KSP_NORM_UNPRECONDITIONED) dp = orc_VecNorm_Seq(n, r, ORC_NORM_2, NULL);
+    else if (ksp->normtype == ORC_KSP_NORM_PRECONDITIONED) dp = orc_VecNorm_Seq(n, z, ORC_NORM_2, NULL);
+    gammaNew = orc_VecDot_Seq(n, r, z); /* groppcg.c:108 */
+    ksp_mult(&c, z, Z);                 /* groppcg.c:111 */
+    if (ksp->normtype == ORC_KSP_NORM_NATURAL) {
+      if (isnan(gammaNew) || isinf(gammaNew)) {
+        ksp->reason = ORC_KSP_DIVERGED_NANORINF;
+        goto done;
+      }
+      dp = sqrt(fabs(gammaNew));
+    } else if (ksp->normtype == ORC_KSP_NORM_NONE) dp = 0.0;
+    ksp->rnorm = dp;
+    log_history(ksp, dp);
+    ksp->reason = converged_default(&c, i, dp, B); /* groppcg.c:129 */
+    if (ksp->reason) goto done;
+    beta  = gammaNew / gamma; /* groppcg.c:132 */
+    gamma = gammaNew;
+    orc_VecAYPX_Seq(n, p, beta, z); /* groppcg.c:134 */
+    orc_VecAYPX_Seq(n, s, beta, Z); /* groppcg.c:135 */
+  } while (i < ksp->max_it);
+  if (i >= ksp->max_it) ksp->reason = ORC_KSP_DIVERGED_ITS;
+done:
+  ctx_free(&c);
+  free(V);
   return ksp->reason;
 }
 

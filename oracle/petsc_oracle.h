@@ -162,6 +162,8 @@ typedef struct {
 void orc_KSPSetDefaults(OrcKSP *ksp);
 int  orc_KSPSolve_CG(OrcKSP *ksp, const OScalar *b, OScalar *x);    /* cg.c:119-352 */
 int  orc_KSPSolve_GMRES(OrcKSP *ksp, const OScalar *b, OScalar *x); /* gmres.c:88-238,298-420; borthog2.c:35-113 */
+int  orc_KSPSolve_PIPECG(OrcKSP *ksp, const OScalar *b, OScalar *x);  /* pipecg.c:20-160 */
+int  orc_KSPSolve_GROPPCG(OrcKSP *ksp, const OScalar *b, OScalar *x); /* groppcg.c:23-140 */
 void orc_MatMult_MPIAIJ(OInt m, const OInt *ai, const OInt *aj, const OScalar *aa, int nranks, const OScalar *x, OScalar *y); /* mpiaij.c:1047-1061 on a simulated row partition */
 
 /* PetscSplitOwnership (src/sys/utils/psplit.c): n_local = N/size + ((N % size) > rank) */

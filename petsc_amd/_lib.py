@@ -31,7 +31,8 @@ class HipxKSP(C.Structure):
                 ("guess_nonzero", C.c_int), ("fused", C.c_int), ("its", C.c_int32), ("reason", C.c_int), ("rnorm", C.c_double),
                 ("rnorm0", C.c_double), ("ttol", C.c_double), ("history", C.c_void_p), ("hist_len", C.c_int32), ("hist_n", C.c_int32),
                 ("R", C.c_void_p), ("Z", C.c_void_p), ("P", C.c_void_p), ("beta", C.c_double), ("betaold", C.c_double), ("dpi", C.c_double),
-                ("a", C.c_double), ("i", C.c_int32), ("work_n", C.c_int32), ("x_pending", C.c_int), ("a_pending", C.c_double), ("defer_flush", C.c_int), ("external_test", C.c_int), ("pipeline", C.c_int), ("dscal", C.c_void_p), ("single_reduction", C.c_int), ("S", C.c_void_p), ("W", C.c_void_p), ("delta", C.c_double), ("gslab", C.c_void_p), ("gslab_len", C.c_double), ("P2", C.c_void_p)]
+                ("a", C.c_double), ("i", C.c_int32), ("work_n", C.c_int32), ("x_pending", C.c_int), ("a_pending", C.c_double), ("defer_flush", C.c_int), ("external_test", C.c_int), ("pipeline", C.c_int), ("dscal", C.c_void_p), ("single_reduction", C.c_int), ("S", C.c_void_p), ("W", C.c_void_p), ("delta", C.c_double), ("gslab", C.c_void_p), ("gslab_len", C.c_double), ("P2", C.c_void_p),
+                ("pipe_slab", C.c_void_p), ("pipe_slab_len", C.c_double)]
 
 
 class MPIAIJSplit(C.Structure):

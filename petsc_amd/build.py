@@ -20,7 +20,7 @@ LIB = os.path.join(ROOT, "petsc_amd", "lib")
 INC = os.path.join(ROOT, "include")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
-HIP_SOURCES = ["hipx_runtime.hip", "hipx_vec.hip", "hipx_mat.hip", "hipx_sell.hip", "hipx_sor.hip", "hipx_sorbox.hip", "hipx_comm.hip"]
+HIP_SOURCES = ["hipx_runtime.hip", "hipx_vec.hip", "hipx_pipe.hip", "hipx_mat.hip", "hipx_sell.hip", "hipx_sor.hip", "hipx_sorbox.hip", "hipx_comm.hip"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
              "-DHIPX_BUILD", "-I" + INC, "-I" + CSRC, "-Wall", "-Wno-unused-function"]
 

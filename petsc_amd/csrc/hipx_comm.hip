@@ -41,6 +41,12 @@ struct Comm {
   unsigned long long  seq = 0;
   unsigned int       *d_err = nullptr;  // device alias of h_err
   unsigned int       *h_err = nullptr;  // pinned, host-mapped: a wait that gave up (read by the host after every reduction it waits for)
+  // split-phase all-reduce (round 6): one may be in flight between its Begin and its End
+  double             *d_red2 = nullptr;     // its staging line (d_red stays free for the blocking chains)
+  int                 sp_n = 0;             // sums of the reduction in flight (0: none)
+  bool                sp_pairs = false;
+  hipStream_t         sp_stream = nullptr;  // RCCL: the collective runs here, between two events, while the compute stream goes on
+  hipEvent_t          sp_ev_begin = nullptr, sp_ev_done = nullptr;
 };
 Comm &cm()
 {
@@ -191,25 +197,29 @@ struct PostSignal {
   unsigned long long  seq  = 0;
   double             *results = nullptr, *dres = nullptr;
 };
+// phase (round 6, the split-phase form: hipxPipeCGUpdateBeginAllreduce ... hipxAllreduceEnd = PetscCommSplitReductionBegin ... PetscSplitReductionEnd, comb.c:168-290):
+// 1 = POST only (acknowledgement, this rank's words into every peer's arena, the sequence flags), 2 = FINISH only (wait for the peers' flags, fold, publish),
+// 3 = both in one launch.  Between the two launches of one reduction the stream may run anything that is not another reduction.
 __global__ __launch_bounds__(64) void ipc_allreduce_kernel(double *vals, int nsums, int pairs, int me, int nranks, char *const *peer, size_t hdr, unsigned long long seq, unsigned int *err,
-                                                           long long limit, const PostAck ack, const PostSignal sig)
+                                                           long long limit, const PostAck ack, const PostSignal sig, const int phase)
 {
   const int t = threadIdx.x, q = (int)(seq & 1);
   const int n = pairs ? 2 * nsums : nsums;
-  if (t < ack.n) __hip_atomic_store(ack.ptrs[t], ack.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (t < n) {
-    const double v = vals[t];
-    for (int p = 0; p < nranks; p++) {
-      double *in = reinterpret_cast<double *>(peer[p] + hdr) + ((size_t)me * 2 + q) * 64;
-      __hip_atomic_store(reinterpret_cast<unsigned long long *>(in + t), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (phase & 1) {
+    if (t < ack.n) __hip_atomic_store(ack.ptrs[t], ack.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t < n) {
+      const double v = vals[t];
+      for (int p = 0; p < nranks; p++) {
+        double *in = reinterpret_cast<double *>(peer[p] + hdr) + ((size_t)me * 2 + q) * 64;
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(in + t), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
+    __threadfence_system();
+    __syncthreads();
+    if (t < nranks) __hip_atomic_store(reinterpret_cast<unsigned long long *>(peer[t]) + me, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!(phase & 2)) return;
   }
-  __threadfence_system();
-  __syncthreads();
-  if (t < nranks) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(peer[t]) + me, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    ipc_wait_ge(reinterpret_cast<const unsigned long long *>(peer[me]) + t, seq, err, limit);
-  }
+  if (t < nranks) ipc_wait_ge(reinterpret_cast<const unsigned long long *>(peer[me]) + t, seq, err, limit);
   __threadfence_system();
   __syncthreads();
   if (pairs) {
@@ -307,7 +317,7 @@ static int allreduce_dev(double *d_vals, int n, bool pairs = false, const PostAc
   int   ierr;
   if ((ierr = prof_section(HIPX_PROF_ALLREDUCE, true, rt().compute))) return ierr;
   if (c.ipc) {
-    ipc_allreduce_kernel<<<1, 64, 0, rt().compute>>>(d_vals, n, pairs ? 1 : 0, c.rank, c.nranks, c.d_peer, c.hdr, ++c.seq, c.d_err, ipc_wait_ticks(), ack ? *ack : PostAck{}, sig ? *sig : PostSignal{});
+    ipc_allreduce_kernel<<<1, 64, 0, rt().compute>>>(d_vals, n, pairs ? 1 : 0, c.rank, c.nranks, c.d_peer, c.hdr, ++c.seq, c.d_err, ipc_wait_ticks(), ack ? *ack : PostAck{}, sig ? *sig : PostSignal{}, 3);
     HIPX_LAUNCH_CHECK();
   } else if (pairs) {
     HIPX_NCCL(ncclAllGather(d_vals, c.d_gather, (size_t)(2 * n), ncclDouble, c.rcomm, rt().compute));
@@ -434,6 +444,12 @@ int hipxCommFinalize(void)
   (void)hipFree(c.d_red);
   (void)hipFree(c.d_gather);
   (void)hipHostFree(c.h_red);
+  if (c.d_red2) (void)hipFree(c.d_red2);
+  if (c.sp_stream) {
+    (void)hipStreamDestroy(c.sp_stream);
+    (void)hipEventDestroy(c.sp_ev_begin);
+    (void)hipEventDestroy(c.sp_ev_done);
+  }
   c = Comm();
   return HIPX_SUCCESS;
 }
@@ -552,6 +568,98 @@ int hipxCGFusedUpdateBeginAllreduce(double *x, double *r, double *z, const doubl
     if ((ierr = launch_cg_fused_dev_nosignal(x, r, z, p, w, d, dconst, dev_beta, dev_dpi, n, slot, c.d_red))) return ierr;
   } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * 4, rt().compute));
   return allreduce_signal(c.d_red, 2, red_pairs(), slot, dev_sums2, nullptr);
+}
+
+// ---- split-phase all-reduce (round 6).  Begin: the local sums (or pairs) in c.d_red2 start travelling; End: the compute stream waits for the
+// peers, folds in rank order, publishes to the host slot and to device memory.  Same arithmetic as allreduce_dev: same bits.
+static int split_ensure()
+{
+  Comm &c = cm();
+  if (!c.d_red2) HIPX_HIP(hipMalloc((void **)&c.d_red2, sizeof(double) * 64));
+  if (!c.ipc && !c.sp_stream) {
+    HIPX_HIP(hipStreamCreateWithFlags(&c.sp_stream, hipStreamNonBlocking));
+    HIPX_HIP(hipEventCreateWithFlags(&c.sp_ev_begin, hipEventDisableTiming));
+    HIPX_HIP(hipEventCreateWithFlags(&c.sp_ev_done, hipEventDisableTiming));
+  }
+  return HIPX_SUCCESS;
+}
+static int allreduce_begin(int n, bool pairs)
+{
+  Comm &c = cm();
+  HIPX_ARG(c.sp_n == 0, "a split-phase all-reduce is already in flight (hipxAllreduceEnd first)");
+  HIPX_ARG(n >= 1 && (pairs ? 2 * n : n) <= 64, "at most 64 words per all-reduce");
+  int ierr;
+  if ((ierr = prof_section(HIPX_PROF_ALLREDUCE, true, rt().compute))) return ierr;
+  if (c.ipc) {
+    ipc_allreduce_kernel<<<1, 64, 0, rt().compute>>>(c.d_red2, n, pairs ? 1 : 0, c.rank, c.nranks, c.d_peer, c.hdr, ++c.seq, c.d_err, ipc_wait_ticks(), PostAck{}, PostSignal{}, 1);
+    HIPX_LAUNCH_CHECK();
+  } else {
+    HIPX_HIP(hipEventRecord(c.sp_ev_begin, rt().compute));
+    HIPX_HIP(hipStreamWaitEvent(c.sp_stream, c.sp_ev_begin, 0));
+    if (pairs) {
+      HIPX_NCCL(ncclAllGather(c.d_red2, c.d_gather, (size_t)(2 * n), ncclDouble, c.rcomm, c.sp_stream));
+      dd_fold_ranks_kernel<<<1, 64, 0, c.sp_stream>>>(c.d_gather, n, c.nranks, c.d_red2);
+      HIPX_LAUNCH_CHECK();
+    } else HIPX_NCCL(ncclAllReduce(c.d_red2, c.d_red2, (size_t)n, ncclDouble, ncclSum, c.rcomm, c.sp_stream));
+    HIPX_HIP(hipEventRecord(c.sp_ev_done, c.sp_stream));
+  }
+  c.sp_n     = n;
+  c.sp_pairs = pairs;
+  return prof_section(HIPX_PROF_ALLREDUCE, false, rt().compute);
+}
+
+int hipxAllreduceEnd(int slot, int nvals, double *dev_out)
+{
+  HIPX_CHECK_INIT();
+  Comm &c = cm();
+  HIPX_ARG(c.active && c.sp_n > 0 && nvals == c.sp_n && slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2, "no split-phase all-reduce of that size in flight / bad slot");
+  Runtime &r = rt();
+  int      ierr;
+  c.sp_n = 0;
+  if ((ierr = prof_section(HIPX_PROF_ALLREDUCE, true, r.compute))) return ierr;
+  if (c.ipc) {
+    PostSignal sig;
+    sig.flag    = r.d_flags + slot;
+    sig.seq     = ++r.seq[slot];
+    sig.results = slot_results_dev(slot);
+    sig.dres    = dev_out;
+    ipc_allreduce_kernel<<<1, 64, 0, r.compute>>>(c.d_red2, nvals, c.sp_pairs ? 1 : 0, c.rank, c.nranks, c.d_peer, c.hdr, c.seq, c.d_err, ipc_wait_ticks(), PostAck{}, sig, 2);
+    HIPX_LAUNCH_CHECK();
+  } else {
+    HIPX_HIP(hipStreamWaitEvent(r.compute, c.sp_ev_done, 0));
+    if ((ierr = red_signal(slot, c.d_red2, nvals, dev_out))) return ierr;
+  }
+  return prof_section(HIPX_PROF_ALLREDUCE, false, r.compute);
+}
+
+int hipxPipeCGUpdateBeginAllreduce(const hipxPipeCGVecs *v, const double *d, double dconst, int normkind, int first, const double *dev_sums, const double *dev_sums_old,
+                                   const double *dev_alpha_old, double *dev_alpha_out, hipx_int n, int slot)
+{
+  HIPX_CHECK_INIT();
+  Comm &c = cm();
+  HIPX_ARG(c.active && v && dev_sums && dev_alpha_out && (first || (dev_sums_old && dev_alpha_old)) && slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2, "communicator not initialised / null argument / bad slot");
+  int ierr;
+  if ((ierr = split_ensure())) return ierr;
+  if (n > 0) {
+    RedOut o  = red_out(slot, false, nullptr);
+    o.results = c.d_red2;
+    o.pairs   = rt().red_exact;
+    if ((ierr = launch_pipecg_update(v, d, dconst, normkind, first, dev_sums, dev_sums_old, dev_alpha_old, dev_alpha_out, n, o))) return ierr;
+  } else HIPX_HIP(hipMemsetAsync(c.d_red2, 0, sizeof(double) * 6, rt().compute));  // (a rank without rows: zero sums or pairs; alpha is not needed by anybody there)
+  return allreduce_begin(3, red_pairs());
+}
+
+int hipxVecMDotAllreduceBegin(const double *x, hipx_int nv, const double *const *y, hipx_int n, int slot)
+{
+  HIPX_CHECK_INIT();
+  Comm &c = cm();
+  HIPX_ARG(c.active && nv >= 1 && nv <= 16 && slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2, "communicator not initialised / bad slot / nv");
+  int ierr;
+  if ((ierr = split_ensure())) return ierr;
+  if (n > 0) {
+    if ((ierr = launch_mdot_nosignal(x, (int)nv, y, n, slot, c.d_red2))) return ierr;
+  } else HIPX_HIP(hipMemsetAsync(c.d_red2, 0, sizeof(double) * 2 * (size_t)nv, rt().compute));
+  return allreduce_begin((int)nv, red_pairs());
 }
 
 int hipxHaloCreate(int nsend, const int *send_ranks, const hipx_int *send_off, const hipx_int *send_idx, int nrecv, const int *recv_ranks, const hipx_int *recv_off,

@@ -67,6 +67,9 @@ int launch_mdot_nosignal(const double *x, int nv, const double *const *y, hipx_i
 int launch_cg_fused_nosignal(double *x, double *r, double *z, const double *p, const double *w, const double *d, double a, hipx_int n, int slot, double *dev_results);
 int launch_cg_fused_dev_nosignal(double *x, double *r, double *z, const double *p, const double *w, const double *d, double dconst, const double *dev_beta, const double *dev_dpi, hipx_int n,
                                  int slot, double *dev_results);
+// hipx_pipe.hip: the PIPECG update kernel with an explicit reduction destination (hipx_comm.hip redirects the sums to the all-reduce staging line)
+int launch_pipecg_update(const hipxPipeCGVecs *v, const double *d, double dconst, int normkind, int first, const double *dev_sums, const double *dev_sums_old, const double *dev_alpha_old,
+                         double *dev_alpha_out, hipx_int n, const RedOut &o);
 int red_signal(int slot, const double *dev_results, int nvals, double *dres = nullptr);  // enqueue: publish to the host (values, then sequence flag) and optionally to device memory, stream-ordered
 int red_wait(int slot, int nvals, double *out);
 

@@ -180,7 +180,7 @@ static int converged_default(HipxKSP *ksp, HipxMat *A, HipxPC *pc, hipx_int n, d
     } else ksp->rnorm0 = rnorm;
     ksp->ttol = fmax(ksp->rtol * ksp->rnorm0, ksp->abstol);
   }
-  if (n <= 0) return 0; /* chknorm == 0 */
+  /* (iterativ.c:1546 `if (n <= ksp->chknorm) return`: chknorm = -1 by default, itcreate.c:816 -- the test runs at n == 0 too) */
   if (isnan(rnorm) || isinf(rnorm)) {
     *reason = KSP_DIVERGED_NANORINF;
     return 0;
@@ -218,6 +218,9 @@ int HipxKSPDestroyWork(HipxKSP *ksp)
   if (ksp->gslab) CHK(hipxFree(ksp->gslab));
   ksp->gslab     = NULL;
   ksp->gslab_len = 0.0;
+  if (ksp->pipe_slab) CHK(hipxFree(ksp->pipe_slab));
+  ksp->pipe_slab     = NULL;
+  ksp->pipe_slab_len = 0.0;
   ksp->dscal = NULL;
   ksp->R = ksp->Z = ksp->P = ksp->P2 = NULL;
   ksp->work_n = 0;
@@ -817,6 +820,155 @@ int HipxKSPSolve_CG(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, doubl
   if (ksp->reason) return 0;
   CHK(HipxKSPCGStep(ksp, A, pc, b, x, ksp->max_it));
   return 0;
+}
+
+
+/* ---- KSPSolve_PIPECG (pipecg.c:20-160: Ghysels & Vanroose's pipelined CG) over device vectors, launch-ahead.
+   The reference's iteration i:   [dp_i, gamma_i = r.u, delta_i = w.u: ONE split-phase reduction]  ||  m = B w;  n = A m      (pipecg.c:95-113)
+                                  test dp_i (i > 0);  alpha_i, beta_i;  z, q, p, s (4 VecAYPX);  x, u, w, r (4 VecAXPY)         (pipecg.c:115-150)
+   Here, per iteration, on the compute stream:
+     K(i)   one pass (hipxPipeCGUpdateBegin, csrc/hipx_pipe.hip): alpha_i, beta_i formed on the device from the sums of K(i-1); x += alpha_{i-1} p_{i-1} (the update
+            iteration i-1 left behind -- so what is enqueued ahead when the loop stops is exactly the update that was due); the eight vector updates of
+            iteration i; m = B w (PCJACOBI / PCNONE) for the product; the three sums of iteration i + 1.  9 vector reads + 9 writes.
+     [several ranks: the sums' all-reduce STARTS here (hipxPipeCGUpdateBeginAllreduce) ...]
+     S(i+1) n = A m (MatMult_SeqAIJ | MatMult_MPIAIJ with its ghost exchange)
+     [... and ENDS here (hipxAllreduceEnd): one 24-byte all-reduce per iteration, hidden behind the product -- PetscCommSplitReductionBegin ... End of pipecg.c:103-113]
+   The host enqueues K(i), S(i+1) BEFORE it waits for the sums K(i-1) produced (ksp->pipeline, default on), then logs dp_i and runs the convergence test of
+   iteration i: no host round trip sits between the kernels.  Elementwise the operations and their order are the reference's (the x update is deferred, not
+   reordered); the history differs from the reference's by the rounding of the reductions only (bit-identical to reference + exact BLAS in the exact reduction
+   mode, tests/test_gpu_ksp.py).  Loop bound, iteration count and reason as pipecg.c:158-160 (`i <= max_it`, then KSP_DIVERGED_ITS). */
+static int ensure_pipe_work(HipxKSP *ksp, hipx_int n)
+{
+  const double need = 9.0 * (double)(((size_t)n + 1) & ~(size_t)1) + 2.0;
+  if (!ksp->pipe_slab || ksp->pipe_slab_len < need) {
+    if (ksp->pipe_slab) CHK(hipxFree(ksp->pipe_slab));
+    ksp->pipe_slab     = NULL;
+    ksp->pipe_slab_len = 0.0;
+    CHK(hipxMalloc((void **)&ksp->pipe_slab, sizeof(double) * (size_t)need));
+    ksp->pipe_slab_len = need;
+  }
+  if (!ksp->dscal) CHK(hipxMalloc((void **)&ksp->dscal, sizeof(double) * 16));
+  return 0;
+}
+
+int HipxKSPSolve_PIPECG(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double *X)
+{
+  const hipx_int n    = A->m;
+  const size_t   npad = ((size_t)n + 1) & ~(size_t)1; /* (16-byte aligned pieces) */
+  const int      nrm  = ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED ? 1 : (ksp->normtype == HIPX_KSP_NORM_UNPRECONDITIONED ? 2 : 0);
+  enum { SLOT_P = 6 }; /* reduction slots 6, 7 by iteration parity */
+  hipxPipeCGVecs v;
+  double        *R, *U, *W, *Z, *Q, *P, *S, *M, *N, *ds;
+  const double  *dinv;
+  double         dp = 0.0, gamma = 0.0, delta = 0.0, gammaold = 0.0, alpha = 0.0, sums[3];
+  int            ahead = 0, xpend = 0; /* K(i) of the current iteration enqueued already; x += alpha p of the last K not applied yet */
+  hipx_int       i;
+
+  if (pc->type != HIPX_PC_NONE && pc->type != HIPX_PC_JACOBI) return HIPX_ERR_SUP; /* (m = B w is formed inside the update kernel: pointwise preconditioners) */
+  if (n <= 0 && A->nranks <= 1) return HIPX_ERR_ARG;                               /* (an empty system; a rank without rows among several takes part in the collectives) */
+  CHK(ensure_pipe_work(ksp, n));
+  R = ksp->pipe_slab; U = R + npad; W = U + npad; Z = W + npad; Q = Z + npad; P = Q + npad; S = P + npad; M = S + npad; N = M + npad;
+  ds = ksp->dscal; /* [0..9): the sums of three consecutive iterations, [9], [10]: alpha by iteration parity */
+#define PSUMS(k) (ds + 3 * (int)((k) % 3))
+#define PALPHA(k) (ds + 9 + (int)((k) & 1))
+  v.z = Z; v.q = Q; v.p = P; v.s = S; v.x = X; v.u = U; v.w = W; v.r = R; v.m = M; v.n = N;
+  dinv = (pc->type == HIPX_PC_JACOBI && !(pc->dconst_valid && !getenv("HIPX_NO_DCONST"))) ? pc->dinv : NULL;
+  ksp->its    = 0;
+  ksp->reason = 0;
+  ksp->hist_n = 0;
+  if (!ksp->guess_nonzero) CHK(hipxVecSet(X, n, 0.0)); /* itfunc.c:908 */
+  if (ksp->guess_nonzero) {
+    CHK(HipxMatMult(A, X, R));       /* pipecg.c:49 */
+    CHK(hipxVecAYPX(R, -1.0, B, n)); /* pipecg.c:50 */
+  } else CHK(hipxVecCopy(B, R, n));  /* pipecg.c:52 */
+  CHK(HipxPCApply(pc, A, R, U));     /* pipecg.c:55 */
+  switch (ksp->normtype) {           /* pipecg.c:57-86 */
+  case HIPX_KSP_NORM_PRECONDITIONED:
+    CHK(HipxVecNorm2(A, U, n, &dp));
+    break;
+  case HIPX_KSP_NORM_UNPRECONDITIONED:
+    CHK(HipxVecNorm2(A, R, n, &dp));
+    break;
+  case HIPX_KSP_NORM_NATURAL:
+    CHK(HipxVecDot(A, R, U, n, &gamma));
+    if (isnan(gamma) || isinf(gamma)) { /* KSPCheckDot */
+      ksp->reason = KSP_DIVERGED_NANORINF;
+      return 0;
+    }
+    dp = sqrt(fabs(gamma));
+    break;
+  default:
+    dp = 0.0;
+  }
+  CHK(HipxMatMult(A, U, W)); /* w <- A u */
+  log_history(ksp, dp);
+  ksp->rnorm = dp;
+  CHK(converged_default(ksp, A, pc, 0, dp, B, &ksp->reason)); /* pipecg.c:90 */
+  if (ksp->reason) return 0;
+  { /* the sums of iteration 0 (pipecg.c:100-101; u.u rides along unused): device copy for K(0), host copy for the final x update's alpha */
+    const double *ys[3] = {U, R, W};
+    if (A->nranks > 1) CHK(hipxVecMDotBeginAllreduce(U, 3, ys, n, SLOT_P, PSUMS(0)));
+    else CHK(hipxVecMDotBegin(U, 3, ys, n, SLOT_P, PSUMS(0)));
+    CHK(hipxRedEnd(SLOT_P, 3, sums));
+    if (A->nranks > 1) CHK(hipxCommCheckError());
+    if (ksp->normtype != HIPX_KSP_NORM_NATURAL) gamma = sums[1];
+    else CHK(hipxMemcpyHtoD(PSUMS(0) + 1, &gamma, sizeof(double))); /* (natural norm: iteration 0 keeps the gamma its norm was formed from, pipecg.c:100) */
+    delta = sums[2];
+  }
+  CHK(HipxPCApply(pc, A, W, M)); /* pipecg.c:104 */
+  CHK(HipxMatMult(A, M, N));     /* pipecg.c:105 */
+  i = 0;
+  do {
+    /* top of iteration i: gamma, delta (and dp for i > 0) are the host's copies of sums_i */
+    if (i > 0) {
+      /* launch-ahead: K(i), S(i+1) behind K(i-1), S(i) on the stream before the host looks at sums_i */
+      if (ksp->pipeline && !ahead) {
+        if (A->nranks > 1) CHK(hipxPipeCGUpdateBeginAllreduce(&v, dinv, pc->dconst, nrm, 0, PSUMS(i), PSUMS(i - 1), PALPHA(i - 1), PALPHA(i), n, SLOT_P + (int)((i + 1) & 1)));
+        else CHK(hipxPipeCGUpdateBegin(&v, dinv, pc->dconst, nrm, 0, PSUMS(i), PSUMS(i - 1), PALPHA(i - 1), PALPHA(i), n, SLOT_P + (int)((i + 1) & 1), PSUMS(i + 1)));
+        CHK(HipxMatMult(A, M, N));
+        if (A->nranks > 1) CHK(hipxAllreduceEnd(SLOT_P + (int)((i + 1) & 1), 3, PSUMS(i + 1)));
+        ahead = 1;
+      }
+      CHK(hipxRedEnd(SLOT_P + (int)(i & 1), 3, sums)); /* sums_i, produced by K(i-1) */
+      if (A->nranks > 1) CHK(hipxCommCheckError());
+      gammaold = gamma;
+      gamma    = sums[1];
+      delta    = sums[2];
+      if (ksp->normtype == HIPX_KSP_NORM_NATURAL) dp = sqrt(fabs(gamma));
+      else if (ksp->normtype == HIPX_KSP_NORM_NONE) dp = 0.0;
+      else dp = sqrt(sums[0]);
+      ksp->rnorm = dp;
+      log_history(ksp, dp);
+      CHK(converged_default(ksp, A, pc, i, dp, B, &ksp->reason)); /* pipecg.c:124 */
+      if (ksp->reason) break;
+    }
+    /* the host's copies of the scalars K(i) forms on the device (the same IEEE operations) */
+    if (i == 0) alpha = gamma / delta; /* pipecg.c:129 */
+    else {
+      const double beta = gamma / gammaold;           /* pipecg.c:135 */
+      alpha = gamma / (delta - beta / alpha * gamma); /* pipecg.c:136 */
+    }
+    if (!ahead) {
+      const int first = (i == 0);
+      if (A->nranks > 1) CHK(hipxPipeCGUpdateBeginAllreduce(&v, dinv, pc->dconst, nrm, first, PSUMS(i), first ? NULL : PSUMS(i - 1), first ? NULL : PALPHA(i - 1), PALPHA(i), n, SLOT_P + (int)((i + 1) & 1)));
+      else CHK(hipxPipeCGUpdateBegin(&v, dinv, pc->dconst, nrm, first, PSUMS(i), first ? NULL : PSUMS(i - 1), first ? NULL : PALPHA(i - 1), PALPHA(i), n, SLOT_P + (int)((i + 1) & 1), PSUMS(i + 1)));
+      CHK(HipxMatMult(A, M, N));
+      if (A->nranks > 1) CHK(hipxAllreduceEnd(SLOT_P + (int)((i + 1) & 1), 3, PSUMS(i + 1)));
+    }
+    ahead = 0;
+    xpend = 1; /* K(i) has applied the update of iteration i-1; x += alpha_i p_i waits for K(i+1) or for the flush below */
+    i++;
+    ksp->its = i;
+  } while (i <= ksp->max_it);
+  /* stopped by the test with K(i) enqueued ahead: it applied the update that was due (alpha_{i-1} p_{i-1}) and xpend refers to that one -- nothing is pending;
+     stopped by the test without it, or by the loop bound: the last K left its own update behind */
+  if (ksp->reason && ahead) xpend = 0;
+  CHK(hipxStreamSynchronize());
+  if (xpend && n > 0) CHK(hipxVecAXPY(X, alpha, P, n)); /* pipecg.c:142 of the last iteration that ran (its p is in P: no K has overwritten it) */
+  if (!ksp->reason) ksp->reason = KSP_DIVERGED_ITS;
+  return 0;
+#undef PSUMS
+#undef PALPHA
 }
 
 /* KSPSolve_Chebyshev_FirstKind (cheby.c:389-555), statement by statement, with the eigenvalue bounds given (-ksp_chebyshev_eigenvalues /

@@ -121,7 +121,7 @@ static PetscErrorCode KSPSolve_CGHIPX(KSP ksp)
      stepwise loop below leaves them.  Anything else (-ksp_monitor, KSPSetConvergenceTest, ...) takes the stepwise loop. */
   {
     PetscBool selfdriven = PETSC_FALSE;
-    if (!ksp->numbermonitors && ksp->converged == KSPConvergedDefault && ksp->cnvP && !ksp->chknorm && !ksp->lagnorm && !getenv("HIPX_CGHIPX_STEPWISE")) {
+    if (!ksp->numbermonitors && ksp->converged == KSPConvergedDefault && ksp->cnvP && ksp->chknorm < 0 && !ksp->lagnorm && !getenv("HIPX_CGHIPX_STEPWISE")) { /* (chknorm = -1: KSPCreate's default, itcreate.c:816 -- the test at every iteration, the 0th included) */
       KSPConvergedDefaultCtx *cctx = (KSPConvergedDefaultCtx *)ksp->cnvP;
       if (!cctx->initialrtol && !cctx->mininitialrtol && !cctx->convmaxits) selfdriven = PETSC_TRUE;
     }
@@ -301,6 +301,148 @@ PetscErrorCode KSPCreate_ChebyshevHIPX(KSP ksp)
   PetscCall(KSPCreate_Chebyshev(ksp));
   if (!parent_setup_cheby) parent_setup_cheby = ksp->ops->setup;
   ksp->ops->setup = KSPSetUp_ChebyshevHIPX;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* ---- KSPPIPECGHIPX ("pipecghipx", round 6): KSPPIPECG (pipecg.c:20-160) whose solve is the host layer's launch-ahead loop -- ONE fused update kernel (the eight
+   vector updates, m = B w, the three sums of the next iteration; alpha and beta formed on the device) + one product per iteration, the iteration's single
+   reduction (one 24-byte all-reduce on several ranks) started before the product and collected after it: PetscCommSplitReductionBegin ... End (comb.c:168-290) on
+   the device.  Taken when nothing outside looks between iterations (no monitors, KSPConvergedDefault with its default context) on the hot path's operator
+   (MATSEQAIJHIPX / MATMPIAIJHIPX with the device ghost exchange, PCJACOBI / PCNONE, hipx vectors); everything else runs the reference's KSPSolve_PIPECG --
+   over the hipx types, where the lazy queue of vechipx.c turns its update block into one batch kernel. */
+static PetscErrorCode (*parent_solve_pipecg)(KSP) = NULL;
+
+static PetscBool KSPPIPECGHIPXApplicable(KSP ksp, Mat *Aout, PetscBool *none)
+{
+  Mat          Amat, Pmat;
+  PetscBool    isjac = PETSC_FALSE, isnone = PETSC_FALSE, useabs = PETSC_FALSE, fixdiag = PETSC_TRUE;
+  PCJacobiType jt;
+  PetscMPIInt  size;
+
+  if (ksp->calc_sings || ksp->pc_side != PC_LEFT || ksp->transpose_solve || ksp->dscale || ksp->numbermonitors || ksp->chknorm >= 0 || ksp->lagnorm) return PETSC_FALSE;
+  if (ksp->converged != KSPConvergedDefault || !ksp->cnvP || getenv("HIPX_PIPECGHIPX_PARENT")) return PETSC_FALSE;
+  {
+    KSPConvergedDefaultCtx *cctx = (KSPConvergedDefaultCtx *)ksp->cnvP;
+    if (cctx->initialrtol || cctx->mininitialrtol || cctx->convmaxits) return PETSC_FALSE;
+  }
+  if (MPI_Comm_size(PetscObjectComm((PetscObject)ksp), &size)) return PETSC_FALSE;
+  if (PCGetOperators(ksp->pc, &Amat, &Pmat) || Amat != Pmat || Amat->rmap->n != Amat->cmap->n) return PETSC_FALSE;
+  if (size == 1) {
+    if (!MatIsSeqAIJHIPX(Amat) || Amat->rmap->n == 0) return PETSC_FALSE;
+  } else {
+    PetscBool ismpi = PETSC_FALSE;
+    hipxMat   dA, dB;
+    hipxHalo  halo = NULL;
+    Vec       lvec;
+    if (PetscObjectTypeCompare((PetscObject)Amat, MATMPIAIJHIPX, &ismpi) || !ismpi) return PETSC_FALSE;
+    if (MatMPIAIJHIPXGetDevice(Amat, &dA, &dB, &halo, &lvec) || !halo) return PETSC_FALSE;
+  }
+  if (PetscObjectTypeCompare((PetscObject)ksp->pc, PCJACOBI, &isjac) || PetscObjectTypeCompare((PetscObject)ksp->pc, PCNONE, &isnone) || (!isjac && !isnone)) return PETSC_FALSE;
+  if (isjac) {
+    if (PCJacobiGetType(ksp->pc, &jt) || jt != PC_JACOBI_DIAGONAL) return PETSC_FALSE;
+    if (PCJacobiGetUseAbs(ksp->pc, &useabs) || useabs) return PETSC_FALSE;
+    if (PCJacobiGetFixDiagonal(ksp->pc, &fixdiag) || !fixdiag) return PETSC_FALSE;
+  }
+  if (!VecIsHIPX(ksp->vec_rhs) || !VecIsHIPX(ksp->vec_sol)) return PETSC_FALSE;
+  {
+    MatNullSpace nsp = NULL;
+    if (MatGetNullSpace(Amat, &nsp) || nsp) return PETSC_FALSE;
+  }
+  *Aout = Amat;
+  *none = isnone;
+  return PETSC_TRUE;
+}
+
+static PetscErrorCode KSPSolve_PIPECGHIPX(KSP ksp)
+{
+  Mat                Amat = NULL;
+  PetscBool          isnone = PETSC_FALSE;
+  hipxMat            dA;
+  HipxMat            M;
+  HipxPC             hpc;
+  HipxKSP            k;
+  const PetscScalar *db;
+  PetscScalar       *dx, *dlv = NULL;
+  void              *tb, *tx, *tlv = NULL;
+  PetscMPIInt        size;
+  Vec                lvecv = NULL;
+  double            *hist = NULL;
+  hipx_int           hl;
+  int                herr = 0;
+  char               herrmsg[512] = "";
+
+  PetscFunctionBegin;
+  if (!KSPPIPECGHIPXApplicable(ksp, &Amat, &isnone)) {
+    PetscCall(PetscInfo(ksp, "KSPPIPECGHIPX: configuration outside the fused path, running the reference KSPSolve_PIPECG\n"));
+    PetscCall((*parent_solve_pipecg)(ksp));
+    PetscFunctionReturn(PETSC_SUCCESS);
+  }
+  PetscCallMPI(MPI_Comm_size(PetscObjectComm((PetscObject)ksp), &size));
+  if (size == 1) {
+    PetscCall(MatSeqAIJHIPXGetDeviceMat(Amat, &dA));
+    M.m = (hipx_int)Amat->rmap->n; M.A = dA; M.B = NULL; M.halo = NULL; M.lvec = NULL; M.nranks = 1;
+  } else {
+    hipxMat  dB;
+    hipxHalo halo;
+    PetscCall(MatMPIAIJHIPXGetDevice(Amat, &dA, &dB, &halo, &lvecv));
+    PetscCall(VecHIPXGetDeviceWrite(lvecv, &dlv, &tlv));
+    M.m = (hipx_int)Amat->rmap->n; M.A = dA; M.B = dB; M.halo = halo; M.lvec = dlv; M.nranks = (int)size;
+  }
+  HipxPCSetDefaults(&hpc);
+  hpc.type = isnone ? HIPX_PC_NONE : HIPX_PC_JACOBI;
+  PetscCallHIPX(HipxPCSetUp(&hpc, &M));
+  HipxKSPSetDefaults(&k);
+  k.normtype = ksp->normtype == KSP_NORM_PRECONDITIONED ? HIPX_KSP_NORM_PRECONDITIONED : ksp->normtype == KSP_NORM_UNPRECONDITIONED ? HIPX_KSP_NORM_UNPRECONDITIONED : ksp->normtype == KSP_NORM_NATURAL ? HIPX_KSP_NORM_NATURAL : HIPX_KSP_NORM_NONE;
+  k.max_it        = (hipx_int)ksp->max_it;
+  k.min_it        = (hipx_int)ksp->min_it;
+  k.guess_nonzero = ksp->guess_zero ? 0 : 1;
+  k.rtol          = ksp->rtol;
+  k.abstol        = ksp->abstol;
+  k.divtol        = ksp->divtol;
+  hl              = (hipx_int)((ksp->max_it < 1000000 ? ksp->max_it : 1000000) + 3);
+  PetscCall(PetscMalloc1((size_t)hl, &hist));
+  k.history  = hist;
+  k.hist_len = hl;
+  PetscCall(VecHIPXGetDeviceRead(ksp->vec_rhs, &db, &tb));
+  PetscCall(VecHIPXGetDeviceReadWrite(ksp->vec_sol, &dx, &tx));
+  ksp->its = 0;
+  herr     = HipxKSPSolve_PIPECG(&k, &M, &hpc, db, dx);
+  if (herr) PetscCall(PetscStrncpy(herrmsg, hipxGetErrorString(), sizeof(herrmsg)));
+  else {
+    for (hipx_int e = 0; e < k.hist_n && e < hl; e++) PetscCall(KSPLogResidualHistory(ksp, hist[e]));
+    ksp->its    = (PetscInt)k.its;
+    ksp->rnorm  = k.rnorm;
+    ksp->rnorm0 = k.rnorm0;
+    ksp->ttol   = k.ttol;
+    ksp->reason = (KSPConvergedReason)k.reason;
+    if (ksp->reason == KSP_DIVERGED_NANORINF) { /* (as in KSPSolve_CGHIPX: iterativ.c:1548-1559) */
+      PCFailedReason pcreason;
+      PetscCall(PCReduceFailedReason(ksp->pc));
+      PetscCall(PCGetFailedReason(ksp->pc, &pcreason));
+      if (pcreason) ksp->reason = KSP_DIVERGED_PC_FAILED;
+    }
+  }
+  PetscCall(PetscFree(hist));
+  (void)HipxKSPDestroyWork(&k);
+  (void)HipxPCDestroy(&hpc);
+  if (lvecv) PetscCall(VecHIPXRestoreDeviceWrite(lvecv, &dlv, &tlv));
+  PetscCall(VecHIPXRestoreDeviceWrite(ksp->vec_sol, &dx, &tx));
+  PetscCall(VecHIPXRestoreDeviceRead(ksp->vec_rhs, &db, &tb));
+  PetscCall(PetscObjectStateIncrease((PetscObject)ksp->vec_sol));
+  PetscCheck(herr != HIPX_ERR_SUP, PetscObjectComm((PetscObject)ksp), PETSC_ERR_SUP, "libhipx: %s", herrmsg);
+  PetscCheck(!herr, PetscObjectComm((PetscObject)ksp), PETSC_ERR_GPU, "libhipx: %s", herrmsg);
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PETSC_EXTERN PetscErrorCode KSPCreate_PIPECG(KSP); /* pipecg.c:179: exported by libpetsc */
+
+PetscErrorCode KSPCreate_PIPECGHIPX(KSP ksp)
+{
+  PetscFunctionBegin;
+  PetscCall(VecHIPXInitRuntime());
+  PetscCall(KSPCreate_PIPECG(ksp));
+  if (!parent_solve_pipecg) parent_solve_pipecg = ksp->ops->solve;
+  ksp->ops->solve = KSPSolve_PIPECGHIPX;
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 

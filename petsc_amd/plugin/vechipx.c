@@ -104,11 +104,13 @@ PetscErrorCode VecHIPXRedCachePut(int kind, Vec a, Vec b)
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+static void VecHIPXBatchCacheInvalidate(PetscObjectId id);
 void VecHIPXRedCacheInvalidate(Vec v)
 {
   const PetscObjectId id = ((PetscObject)v)->id;
   for (int k = 0; k < 2; k++)
     if (hipx_rc[k].live && (hipx_rc[k].a == id || hipx_rc[k].b == id)) hipx_rc[k].live = PETSC_FALSE;
+  VecHIPXBatchCacheInvalidate(id);
 }
 
 /* the sums of a live entry on (a, b) in either order, or NULL */
@@ -126,6 +128,44 @@ static PetscErrorCode VecHIPXRedCacheGet(int kind, Vec a, Vec b, PetscBool order
   }
   e->used = PETSC_TRUE;
   *v      = e->v;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* Round 6: the sums a recorded BATCH left behind (VecHIPXLazyTryBatch below: the update blocks of KSPSolve_PIPECG / GROPPCG / PIPECR as one kernel, with the sums
+   their next VecNormBegin / VecDotBegin calls ask for, comb.c:338,379).  Up to HIPX_BATCH_MAX_DOTS pairs of vectors; a pair dies when either vector is handed
+   out for writing (VecHIPXRedCacheInvalidate), exactly like the two entries above. */
+static struct {
+  int           n;
+  PetscObjectId a[HIPX_BATCH_MAX_DOTS], b[HIPX_BATCH_MAX_DOTS];
+  PetscBool     live[HIPX_BATCH_MAX_DOTS], fetched;
+  double        v[HIPX_BATCH_MAX_DOTS];
+} hipx_bc;
+static const int hipx_bc_slot = 59;
+
+static void VecHIPXBatchCacheInvalidate(PetscObjectId id)
+{
+  for (int k = 0; k < hipx_bc.n; k++)
+    if (hipx_bc.live[k] && (hipx_bc.a[k] == id || hipx_bc.b[k] == id)) hipx_bc.live[k] = PETSC_FALSE;
+}
+
+/* x . y from the batch cache (either order; x == y: the square of the 2-norm), or *hit = FALSE */
+static PetscErrorCode VecHIPXBatchCacheGet(Vec x, Vec y, double *val, PetscBool *hit)
+{
+  const PetscObjectId ia = ((PetscObject)x)->id, ib = ((PetscObject)y)->id;
+
+  PetscFunctionBegin;
+  *hit = PETSC_FALSE;
+  if (!hipx_rc_on) PetscFunctionReturn(PETSC_SUCCESS);
+  for (int k = 0; k < hipx_bc.n; k++) {
+    if (!hipx_bc.live[k] || !((hipx_bc.a[k] == ia && hipx_bc.b[k] == ib) || (hipx_bc.a[k] == ib && hipx_bc.b[k] == ia))) continue;
+    if (!hipx_bc.fetched) {
+      PetscCallHIPX(hipxRedEnd(hipx_bc_slot, hipx_bc.n, hipx_bc.v));
+      hipx_bc.fetched = PETSC_TRUE;
+    }
+    *val = hipx_bc.v[k];
+    *hit = PETSC_TRUE;
+    break;
+  }
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -284,15 +324,18 @@ PetscErrorCode VecHIPXRestoreDeviceWrite(Vec v, PetscScalar **d, void **tmp)
      ... and MatMult(A, p, w) asks for the product   -> hipxMatMultCGDirectionDotBegin: the two updates are the product kernel's prologue; p is rewritten
                                                         OUT OF PLACE (other workgroups still read the old direction): the vector's two device buffers swap
      [r += s w] and VecPointwiseMult(z, r, d) follows -> hipxVecAXPYPointwiseMultDotsBegin: one pass, the sums z.z and z.r into the reduction cache
+     the WHOLE queue is one of libhipx's batch programs (round 6: the update blocks of KSPSolve_PIPECG pipecg.c:140-150, KSPSolve_GROPPCG groppcg.c:98-100,
+     135-136, KSPSolve_PIPECR pipecr.c:108-117) when somebody looks at one of its vectors -> hipxVecBatchAXPYDotsBegin: every operand read once, every changed
+     vector written once, and the sums the loop asks for next (VecNormBegin / VecDotBegin, comb.c:338,379) into the batch cache
    Every fused kernel performs, element by element, the operations of the separate kernels in their order: the vectors come out bit-identical. */
-#define HIPX_LAZY_MAX 4
+#define HIPX_LAZY_MAX HIPX_BATCH_MAX_OPS /* (8: the update block of KSPSolve_PIPECG, pipecg.c:140-150) */
 typedef struct {
   int         kind; /* 1: y += s x, 2: y = x + s y */
   Vec         y, x;
   PetscScalar s;
 } HipxLazyOp;
 static HipxLazyOp hipx_lazy[HIPX_LAZY_MAX];
-static PetscInt   hipx_lazy_stat[5] = {0, 0, 0, 0, 0}; /* recorded, run alone, run as "x += a p; p = z + b p", fused into VecPointwiseMult, fused into MatMult (pairs) */
+static PetscInt   hipx_lazy_stat[7] = {0, 0, 0, 0, 0, 0, 0}; /* recorded, run alone, run as "x += a p; p = z + b p", fused into VecPointwiseMult, fused into MatMult (pairs), batches, operations in batches */
 static PetscBool  hipx_lazy_fin     = PETSC_FALSE;
 
 static PetscErrorCode VecHIPXLazyFinalize(void)
@@ -301,7 +344,8 @@ static PetscErrorCode VecHIPXLazyFinalize(void)
   if (hipx_lazy_view)
     PetscCall(PetscPrintf(PETSC_COMM_SELF, "hipx lazy fusion: %" PetscInt_FMT " operations recorded; %" PetscInt_FMT " run alone, %" PetscInt_FMT " pairs as one direction kernel, %" PetscInt_FMT " inside VecPointwiseMult, %" PetscInt_FMT " pairs as the prologue of MatMult\n",
                           hipx_lazy_stat[0], hipx_lazy_stat[1], hipx_lazy_stat[2], hipx_lazy_stat[3], hipx_lazy_stat[4]));
-  for (int k = 0; k < 5; k++) hipx_lazy_stat[k] = 0;
+  if (hipx_lazy_view && hipx_lazy_stat[5]) PetscCall(PetscPrintf(PETSC_COMM_SELF, "hipx lazy fusion: %" PetscInt_FMT " operations in %" PetscInt_FMT " batch kernels\n", hipx_lazy_stat[6], hipx_lazy_stat[5]));
+  for (int k = 0; k < 7; k++) hipx_lazy_stat[k] = 0;
   hipx_lazy_fin = PETSC_FALSE;
   PetscFunctionReturn(PETSC_SUCCESS);
 }
@@ -368,12 +412,87 @@ static PetscErrorCode VecHIPXLazyRunMarked(const PetscBool run[])
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+/* The queue -- or its tail behind a few leading operations, which then run first, one by one, as they would have anyway (an "x += a p" nobody has looked at
+   since the iteration before: KSPSolve_PIPECR) -- as ONE kernel if it is one of libhipx's batch programs (see the head of this section).  Slots: for each
+   operation y, then x, numbered by first appearance: the numbering the programs are written in.  *done = FALSE: nothing ran, the queue is as it was. */
+static PetscErrorCode VecHIPXLazyTryBatch(PetscBool *done)
+{
+  Vec      vecs[HIPX_BATCH_MAX_VECS];
+  double  *ptrs[HIPX_BATCH_MAX_VECS];
+  int      kind[HIPX_LAZY_MAX], ys[HIPX_LAZY_MAX], xs[HIPX_LAZY_MAX], nvec = 0, ndots = -1, da[HIPX_BATCH_MAX_DOTS], db[HIPX_BATCH_MAX_DOTS], start, nops = 0;
+  double   sc[HIPX_LAZY_MAX];
+  PetscInt n = 0;
+
+  PetscFunctionBegin;
+  *done = PETSC_FALSE;
+  if (hipx_nlazy < 2 || hipx_lazy_run) PetscFunctionReturn(PETSC_SUCCESS);
+  for (start = 0; start + 2 <= hipx_nlazy; start++) {
+    PetscBool ok = PETSC_TRUE;
+    nvec = 0;
+    nops = hipx_nlazy - start;
+    n    = hipx_lazy[start].y->map->n;
+    for (int k = 0; k < nops && ok; k++) {
+      Vec pair[2] = {hipx_lazy[start + k].y, hipx_lazy[start + k].x};
+      int slot[2] = {0, 0};
+      for (int h = 0; h < 2 && ok; h++) {
+        int f = -1;
+        for (int u = 0; u < nvec; u++)
+          if (vecs[u] == pair[h]) f = u;
+        if (f < 0) {
+          if (nvec == HIPX_BATCH_MAX_VECS || pair[h]->map->n != n) ok = PETSC_FALSE;
+          else {
+            vecs[nvec] = pair[h];
+            ptrs[nvec] = (double *)VecHIPXGetExt(pair[h])->d_array;
+            for (int u = 0; u < nvec; u++)
+              if (ptrs[u] == ptrs[nvec]) ok = PETSC_FALSE; /* (two vectors on one buffer: the separate kernels' business) */
+            f = nvec++;
+          }
+        }
+        slot[h] = f;
+      }
+      kind[k] = hipx_lazy[start + k].kind;
+      ys[k]   = slot[0];
+      xs[k]   = slot[1];
+      sc[k]   = (double)hipx_lazy[start + k].s;
+    }
+    if (ok && hipxVecBatchProgramKnown(nops, kind, ys, xs, nvec)) break;
+  }
+  if (start + 2 > hipx_nlazy) PetscFunctionReturn(PETSC_SUCCESS); /* no tail of the queue is a compiled program */
+  if (start) { /* the operations in front of the batch, in their order */
+    PetscBool      run[HIPX_LAZY_MAX];
+    const int      keep = nops;
+    HipxLazyOp     tail[HIPX_LAZY_MAX];
+    for (int k = 0; k < HIPX_LAZY_MAX; k++) run[k] = (PetscBool)(k < start);
+    for (int k = 0; k < keep; k++) tail[k] = hipx_lazy[start + k];
+    PetscCall(VecHIPXLazyRunMarked(run)); /* (leaves the unmarked ones -- the batch -- recorded, in order) */
+    PetscCheck(hipx_nlazy == keep, PETSC_COMM_SELF, PETSC_ERR_PLIB, "lazy queue: %d operations left, expected %d", hipx_nlazy, keep);
+    for (int k = 0; k < keep; k++) PetscCheck(hipx_lazy[k].y == tail[k].y && hipx_lazy[k].x == tail[k].x, PETSC_COMM_SELF, PETSC_ERR_PLIB, "lazy queue: order changed");
+  }
+  PetscCallHIPX(hipxVecBatchAXPYDotsBegin(nops, kind, ys, xs, sc, nvec, ptrs, (hipx_int)n, hipx_bc_slot, &ndots, da, db));
+  PetscCheck(ndots >= 0, PETSC_COMM_SELF, PETSC_ERR_PLIB, "libhipx declined a batch it had accepted");
+  hipx_bc.n       = ndots;
+  hipx_bc.fetched = PETSC_FALSE;
+  for (int k = 0; k < ndots; k++) {
+    hipx_bc.a[k]    = ((PetscObject)vecs[da[k]])->id;
+    hipx_bc.b[k]    = ((PetscObject)vecs[db[k]])->id;
+    hipx_bc.live[k] = hipx_rc_on;
+  }
+  hipx_lazy_stat[5]++;
+  hipx_lazy_stat[6] += nops;
+  hipx_nlazy = 0;
+  *done      = PETSC_TRUE;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 PetscErrorCode VecHIPXLazyFlush(void)
 {
-  PetscBool run[HIPX_LAZY_MAX] = {PETSC_TRUE, PETSC_TRUE, PETSC_TRUE, PETSC_TRUE};
+  PetscBool run[HIPX_LAZY_MAX], done;
 
   PetscFunctionBegin;
   if (!hipx_nlazy || hipx_lazy_run) PetscFunctionReturn(PETSC_SUCCESS);
+  PetscCall(VecHIPXLazyTryBatch(&done));
+  if (done) PetscFunctionReturn(PETSC_SUCCESS);
+  for (int k = 0; k < HIPX_LAZY_MAX; k++) run[k] = PETSC_TRUE;
   PetscCall(VecHIPXLazyRunMarked(run));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
@@ -383,13 +502,19 @@ PetscErrorCode VecHIPXLazyFlush(void)
    "x += a p" for the direction kernel). */
 PetscErrorCode VecHIPXLazySync(Vec v)
 {
-  PetscBool run[HIPX_LAZY_MAX] = {PETSC_FALSE, PETSC_FALSE, PETSC_FALSE, PETSC_FALSE}, any = PETSC_FALSE, more = PETSC_TRUE;
+  PetscBool run[HIPX_LAZY_MAX], any = PETSC_FALSE, more = PETSC_TRUE;
 
   PetscFunctionBegin;
   if (!hipx_nlazy || hipx_lazy_run) PetscFunctionReturn(PETSC_SUCCESS);
+  for (int k = 0; k < HIPX_LAZY_MAX; k++) run[k] = PETSC_FALSE;
   for (int k = 0; k < hipx_nlazy; k++)
     if (hipx_lazy[k].y == v || hipx_lazy[k].x == v) run[k] = any = PETSC_TRUE;
   if (!any) PetscFunctionReturn(PETSC_SUCCESS);
+  if (hipx_nlazy >= 2) { /* the whole queue as one batch kernel? (round 6) */
+    PetscBool done;
+    PetscCall(VecHIPXLazyTryBatch(&done));
+    if (done) PetscFunctionReturn(PETSC_SUCCESS);
+  }
   while (more) {
     more = PETSC_FALSE;
     for (int k = 0; k < hipx_nlazy; k++)
@@ -1027,6 +1152,18 @@ static PetscErrorCode VecDotLocal_HIPX(Vec x, Vec y, PetscScalar *z) /* VecDot_S
   void              *tx, *ty;
 
   PetscFunctionBegin;
+  PetscCall(VecHIPXLazySync(x)); /* (a recorded batch that touches x or y runs now -- and may leave exactly this sum behind) */
+  PetscCall(VecHIPXLazySync(y));
+  {
+    PetscBool hit;
+    double    val = 0.0;
+    PetscCall(VecHIPXBatchCacheGet(x, y, &val, &hit));
+    if (hit) {
+      *z = val;
+      PetscCall(PetscLogFlops(PetscMax(2.0 * x->map->n - 1, 0.0)));
+      PetscFunctionReturn(PETSC_SUCCESS);
+    }
+  }
   if (x != y) { /* a sum the kernel that wrote one of the two vectors left behind? (reduction cache, hipxplugin.h) */
     const double *c;
     PetscCall(VecHIPXRedCacheGet(HIPX_RC_MATMULT, x, y, PETSC_FALSE, &c));
@@ -1076,6 +1213,17 @@ static PetscErrorCode VecNormLocal_HIPX(Vec x, NormType type, PetscReal *z) /* V
   int                t = (type == NORM_1) ? 0 : (type == NORM_2) ? 1 : (type == NORM_FROBENIUS) ? 2 : (type == NORM_INFINITY) ? 3 : 4;
 
   PetscFunctionBegin;
+  PetscCall(VecHIPXLazySync(x));
+  if (type == NORM_2 || type == NORM_FROBENIUS) { /* x . x left behind by a batch kernel: sqrt of it, bvec2.c:204 */
+    PetscBool hit;
+    double    val = 0.0;
+    PetscCall(VecHIPXBatchCacheGet(x, x, &val, &hit));
+    if (hit) {
+      *z = PetscSqrtReal(val);
+      PetscCall(PetscLogFlops(PetscMax(2.0 * x->map->n - 1, 0.0)));
+      PetscFunctionReturn(PETSC_SUCCESS);
+    }
+  }
   if ((type == NORM_2 || type == NORM_FROBENIUS) && hipx_rc[HIPX_RC_PWMULT].live && hipx_rc[HIPX_RC_PWMULT].a == ((PetscObject)x)->id) {
     HipxRedCacheEntry *e = &hipx_rc[HIPX_RC_PWMULT]; /* x was written by the fused VecPointwiseMult: sqrt(x . x), bvec2.c:204 */
     if (!e->fetched) {

@@ -63,6 +63,12 @@ def jobs():
     J["cg_jacobi_7pt_256"] = lambda: entry(ref_shim(7, 256, "cg", "jacobi", 60), "reference+shim", "BASELINE config 2: 7-pt Poisson 256^3, KSPCG + PCJACOBI, b = A*1, x0 = 0; 60 iterations")
     # round 6: BASELINE config 1's operator (ex2.c:70-94) at HBM size -- north_star's 5-point leg
     J["cg_jacobi_5pt_4096x4096x1"] = lambda: entry(ref_shim(5, 4096, "cg", "jacobi", 40, m=4096), "reference+shim", "2-D 5-pt Laplacian (ex2.c) 4096 x 4096 = 16.8 M rows, KSPCG + PCJACOBI, b = A*1, x0 = 0; 40 iterations")
+    # round 6: the pipelined variants (pipecg.c, groppcg.c) from the REFERENCE with exact BLAS reductions: the yardsticks of pipecghipx / the batched lazy queue
+    for kk in ("pipecg", "groppcg"):
+        J["%s_jacobi_7pt_64" % kk] = (lambda kk=kk: entry(ref_shim(7, 64, kk, "jacobi", 40), "reference+shim", "7-pt Poisson 64^3, KSP%s + PCJACOBI; 40 iterations" % kk.upper()))
+        J["%s_jacobi_7pt_128" % kk] = (lambda kk=kk: entry(ref_shim(7, 128, kk, "jacobi", 40), "reference+shim", "7-pt Poisson 128^3, KSP%s + PCJACOBI; 40 iterations" % kk.upper()))
+        J["%s_jacobi_27pt_96" % kk] = (lambda kk=kk: entry(ref_shim(27, 96, kk, "jacobi", 30), "reference+shim", "27-pt (bench_kspsolve.c) 96^3, KSP%s + PCJACOBI; 30 iterations" % kk.upper()))
+    J["pipecg_jacobi_7pt_256"] = lambda: entry(ref_shim(7, 256, "pipecg", "jacobi", 40), "reference+shim", "BASELINE config 2's system under KSPPIPECG: 7-pt Poisson 256^3 + PCJACOBI; 40 iterations")
     J["cg_jacobi_27pt_160"] = lambda: entry(ref_shim(27, 160, "cg", "jacobi", 40), "reference+shim", "27-pt (bench_kspsolve.c) 160^3, KSPCG + PCJACOBI; 40 iterations")
     J["cg_jacobi_7pt_512"] = lambda: stream("7pt", 512, 512 ** 3, "jacobi", 24, "7-pt Poisson 512^3 (134 M rows), KSPCG + PCJACOBI; 24 iterations")
     J["cg_jacobi_27pt_512"] = lambda: stream("27pt", 512, 512 ** 3, "jacobi", 16, "north_star scaling target: 27-pt 512^3 (3.6e9 nonzeros), KSPCG + PCJACOBI; 16 iterations")

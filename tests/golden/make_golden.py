@@ -121,6 +121,18 @@ RUNS = {
     "p7_n16_gmres_sor": "-stencil 7 -n 16 -ksp_type gmres -pc_type sor -ksp_rtol 1e-8",
     "p27_n12_gmres_sor": "-stencil 27 -n 12 -ksp_type gmres -pc_type sor -ksp_rtol 1e-8",
     "p7_n16_cg_ssor": "-stencil 7 -n 16 -ksp_type cg -pc_type sor -ksp_rtol 1e-8",
+    # round 6: the pipelined CG variants (pipecg.c, groppcg.c) -- every norm type, and the loop bound (pipecg.c:160 `i <= max_it`)
+    "p7_n20_pipecg_jacobi": "-stencil 7 -n 20 -ksp_type pipecg -pc_type jacobi -ksp_rtol 1e-8",
+    "p7_n20_pipecg_none_unpre": "-stencil 7 -n 20 -ksp_type pipecg -pc_type none -ksp_norm_type unpreconditioned -ksp_rtol 1e-8",
+    "p7_n20_pipecg_jacobi_natural": "-stencil 7 -n 20 -ksp_type pipecg -pc_type jacobi -ksp_norm_type natural -ksp_rtol 1e-8",
+    "p27_n16_pipecg_jacobi": "-stencil 27 -n 16 -ksp_type pipecg -pc_type jacobi -ksp_rtol 1e-8",
+    "p7_n20_pipecg_jacobi_maxit7": "-stencil 7 -n 20 -ksp_type pipecg -pc_type jacobi -ksp_rtol 1e-30 -ksp_max_it 7",
+    "ex2_100x100_pipecg_jacobi": "-stencil 5 -m 100 -n 100 -ksp_type pipecg -pc_type jacobi -ksp_rtol 1e-6",
+    "p7_n20_groppcg_jacobi": "-stencil 7 -n 20 -ksp_type groppcg -pc_type jacobi -ksp_rtol 1e-8",
+    "p7_n20_groppcg_none_unpre": "-stencil 7 -n 20 -ksp_type groppcg -pc_type none -ksp_norm_type unpreconditioned -ksp_rtol 1e-8",
+    "p7_n20_groppcg_jacobi_natural": "-stencil 7 -n 20 -ksp_type groppcg -pc_type jacobi -ksp_norm_type natural -ksp_rtol 1e-8",
+    "p27_n16_groppcg_jacobi": "-stencil 27 -n 16 -ksp_type groppcg -pc_type jacobi -ksp_rtol 1e-8",
+    "p7_n20_groppcg_jacobi_maxit7": "-stencil 7 -n 20 -ksp_type groppcg -pc_type jacobi -ksp_rtol 1e-30 -ksp_max_it 7",
     "ex2_3_gmres_ssor": "-stencil 5 -m 8 -n 7 -pc_type sor -pc_sor_symmetric -ksp_gmres_cgs_refinement_type refine_always -ksp_rtol 1.3888888888888889e-04",
 }
 SPMV = {"p7_n8": "-stencil 7 -n 8", "p27_n6": "-stencil 27 -n 6", "p5_9x7": "-stencil 5 -m 9 -n 7"}

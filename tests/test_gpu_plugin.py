@@ -349,7 +349,16 @@ LAZY_CASES = ["-stencil 7 -n 48 -ksp_type cg -pc_type jacobi -ksp_norm_type prec
               "-stencil 7 -n 24 -ksp_type gmres -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 45",
               "-stencil 7 -n 24 -ksp_type bcgs -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 12",
               "-stencil 7 -n 24 -ksp_type chebyshev -pc_type jacobi -ksp_max_it 30 -ksp_norm_type preconditioned -ksp_rtol 1e-50",
-              "-stencil 7 -n 24 -ksp_type richardson -pc_type jacobi -ksp_max_it 30 -ksp_rtol 1e-50 -ksp_richardson_scale 0.1"]
+              "-stencil 7 -n 24 -ksp_type richardson -pc_type jacobi -ksp_max_it 30 -ksp_rtol 1e-50 -ksp_richardson_scale 0.1",
+              # round 6: the pipelined variants -- their update blocks run as ONE batch kernel (hipxVecBatchAXPYDotsBegin), the sums of the next iteration with it
+              "-stencil 7 -n 32 -ksp_type pipecg -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 40",
+              "-stencil 27 -n 20 -ksp_type pipecg -pc_type none -ksp_norm_type unpreconditioned -ksp_rtol 1e-50 -ksp_max_it 30",
+              "-stencil 7 -n 24 -ksp_type pipecg -pc_type jacobi -ksp_norm_type natural -ksp_rtol 1e-50 -ksp_max_it 30 -mat_axpy",
+              "-stencil 7 -n 24 -ksp_type pipecg -pc_type sor -ksp_rtol 1e-50 -ksp_max_it 20",
+              "-stencil 7 -n 32 -ksp_type groppcg -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 40",
+              "-stencil 27 -n 20 -ksp_type groppcg -pc_type none -ksp_norm_type unpreconditioned -ksp_rtol 1e-50 -ksp_max_it 30",
+              "-stencil 7 -n 24 -ksp_type groppcg -pc_type jacobi -ksp_norm_type natural -ksp_rtol 1e-50 -ksp_max_it 30",
+              "-stencil 7 -n 24 -ksp_type pipecr -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 30"]
 
 
 @pytest.mark.parametrize("args", LAZY_CASES)
@@ -379,11 +388,53 @@ def test_lazy_fusion_leaves_every_history_as_it_was(args):
             assert inmm >= its - 2, line  # "x += a p; p = z + b p" as the product's prologue
         else:
             assert pairs >= its - 2, line  # ... or as one direction kernel
+    if any(k in args for k in ("pipecg", "groppcg", "pipecr")):  # every iteration's update block as batch kernels (one for PIPECG / PIPECR, two for GROPPCG)
+        bl = [ln for ln in on_out.splitlines() if "batch kernels" in ln]
+        assert bl, on_out[-400:]
+        nops, nb = [int(t) for t in bl[0].split() if t.isdigit()][:2]
+        its = len(on) - 1
+        per = {"pipecg": (8, 1), "groppcg": (5, 2), "pipecr": (6, 1)}[[k for k in ("pipecg", "groppcg", "pipecr") if k in args][0]]
+        assert nb >= per[1] * (its - 2) and nops >= per[0] * (its - 2), bl
     on_f = hist_of(run("ref_driver", a + HIPX))
     off_f = hist_of(run("ref_driver", a + HIPX + ["-hipx_lazy_fusion", "0"]))
     assert len(on_f) == len(off_f) == len(on)
-    tol = 1e-12 if all(k not in args for k in ("bcgs", "gmres", "cr")) else 1e-9
-    assert (np.abs(on_f - off_f) / off_f).max() <= tol
+    tol = 1e-12 if all(k not in args for k in ("bcgs", "gmres", "cr", "pipecg", "groppcg")) else (1e-9 if all(k not in args for k in ("pipecg", "groppcg", "pipecr")) else 1e-6)
+    assert (np.abs(on_f - off_f) / off_f).max() <= tol  # (the pipelined recurrences carry the reductions' rounding forward: the reference's own MKL run is 4e-8 from exact)
+
+
+@pytest.mark.parametrize("args", ["-stencil 7 -n 40 -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 40",
+                                  "-stencil 27 -n 20 -pc_type none -ksp_norm_type unpreconditioned -ksp_rtol 1e-50 -ksp_max_it 30",
+                                  "-stencil 7 -n 24 -pc_type jacobi -ksp_norm_type natural -ksp_rtol 1e-50 -ksp_max_it 30",
+                                  "-stencil 7 -n 24 -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 25 -mat_axpy",
+                                  "-stencil 5 -m 100 -n 100 -pc_type jacobi -ksp_rtol 1e-6"])
+def test_ksp_pipecghipx_and_batched_pipecg_equal_the_reference_with_exact_blas(args):
+    """Round 6.  Three runs of the same executable: (a) the REFERENCE's KSPSolve_PIPECG on the CPU types with exact BLAS reductions
+    (oracle/libexactblas.so), (b) the reference's unmodified KSPSolve_PIPECG over the hipx types (update block = one batch kernel) and (c) -ksp_type pipecghipx
+    (the host layer's launch-ahead loop: one fused update kernel + one product per iteration), both with -hipx_reductions exact: the same residual history,
+    iteration count and error norm, bit for bit (north_star's 1e-12 met with 0.0).  Default reductions: within rounding."""
+    a = args.split() + ["-history"]
+    ref = run("ref_driver", a + ["-ksp_type", "pipecg"], exact_blas=True)
+    stock = run("ref_driver", a + ["-ksp_type", "pipecg"] + HIPX + ["-hipx_reductions", "exact"])
+    fused = run("ref_driver", a + ["-ksp_type", "pipecghipx"] + HIPX + ["-hipx_reductions", "exact", "-info", ":ksp"])
+    assert "outside the fused path" not in fused
+    h = hist_of(ref)
+    assert len(h) > 10 and np.array_equal(hist_of(stock), h) and np.array_equal(hist_of(fused), h)
+    tail = lambda t: re.search(r"iterations (\d+) reason (-?\d+) error (\S+)", t).groups()  # noqa: E731
+    assert tail(stock) == tail(ref) == tail(fused)
+    fast = hist_of(run("ref_driver", a + ["-ksp_type", "pipecghipx"] + HIPX))
+    m = min(len(fast), len(h), 12)
+    assert (np.abs(fast[:m] - h[:m]) / h[:m]).max() <= 1e-12
+    assert abs(len(fast) - len(h)) <= 1 and (np.abs(fast[:min(len(fast), len(h))] - h[:min(len(fast), len(h))]) / h[:min(len(fast), len(h))]).max() <= 1e-6
+
+
+def test_ksp_pipecghipx_falls_back_to_the_reference_loop_when_somebody_watches():
+    """-ksp_monitor (or any non-default convergence test) takes the reference's KSPSolve_PIPECG over the hipx types: same text as the CPU run's monitor lines."""
+    a = "-stencil 7 -n 16 -pc_type jacobi -ksp_rtol 1e-6 -ksp_monitor -history".split()
+    out = run("ref_driver", a + ["-ksp_type", "pipecghipx"] + HIPX + ["-info", ":ksp"])
+    assert "outside the fused path" in out
+    cpu = run("ref_driver", a + ["-ksp_type", "pipecg"])
+    mon = lambda t: np.array([float(v) for v in re.findall(r"KSP Residual norm (\S+)", t)])  # noqa: E731
+    assert len(mon(out)) == len(mon(cpu)) > 10 and (np.abs(mon(out) - mon(cpu)) / mon(cpu)).max() <= 1e-8
 
 
 def test_lazy_fusion_is_invisible_to_the_vector_interface():

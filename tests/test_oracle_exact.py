@@ -123,6 +123,25 @@ def test_reference_with_exact_blas_equals_restated_exact_oracle_cg(stencil, n, p
 
 
 @needs_ref
+@pytest.mark.parametrize("ksp", ["pipecg", "groppcg"])
+@pytest.mark.parametrize("stencil,n,pc,norm,its", [("7pt", 32, "jacobi", "preconditioned", 40), ("27pt", 16, "none", "unpreconditioned", 30), ("7pt", 20, "jacobi", "natural", 30),
+                                                    ("27pt", 14, "sor", "preconditioned", 15)])
+def test_reference_with_exact_blas_equals_restated_exact_oracle_pipelined_cg(ksp, stencil, n, pc, norm, its):
+    """Round 6: KSPSolve_PIPECG / KSPSolve_GROPPCG of the REFERENCE (pipecg.c:20-160, groppcg.c:23-140; VecDotBegin/NormBegin ... End, comb.c) with exact BLAS
+    reductions == the oracle's restatements in exact mode, bit for bit (history and iteration count, including pipecg.c:160's `i <= max_it`)."""
+    ai, aj, aa = orc.stencil(stencil, n)
+    b = orc.matmult(ai, aj, aa, np.ones(n ** 3))
+    nt = {"preconditioned": 1, "unpreconditioned": 2, "natural": 3}[norm]
+    _, its_o, reason_o, h_orc = orc.ksp_solve(ksp, ai, aj, aa, b, pc=pc, rtol=1e-50, max_it=its, normtype=nt, exact=True)
+    h_ref, out = run_ref(["-stencil", stencil[:-2], "-n", str(n), "-ksp_type", ksp, "-pc_type", pc, "-ksp_rtol", "1e-50", "-ksp_max_it", str(its), "-ksp_norm_type", norm], True)
+    assert len(h_ref) == len(h_orc) == its + 1, out[-800:]
+    assert np.array_equal(h_ref, h_orc), np.abs(h_ref - h_orc).max()
+    import re
+    m = re.search(r"iterations (\d+) reason (-?\d+)", out)
+    assert (its_o, reason_o) == (int(m.group(1)), int(m.group(2))) == (its + 1 if ksp == "pipecg" else its, -3)
+
+
+@needs_ref
 def test_reference_with_exact_blas_vs_restated_exact_oracle_gmres_sor():
     """GMRES(30) + SOR: dgemv 'T' (VecMDot) is Dot2 per column in both; dgemv 'N' (VecMAXPY) is rounded once per element in the
     shim and in VecMAXPY_Seq's grouping in the oracle -- a last-bit elementwise difference, so the histories agree to rounding
