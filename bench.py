@@ -1277,7 +1277,9 @@ def main():
         plug = {}
         rows = [("reference KSPSolve_CG over hipx types", "cg", 1), ("-ksp_type cghipx (fused kernels under PETSc's monitors / convergence test)", "cghipx", 1),
                 # the reference's reduction-fused / pipelined callers, unmodified, over the hipx types
-                ("reference KSPSolve_PIPECG over hipx types (pipecg.c)", "pipecg", 0), ("reference KSPSolve_GROPPCG over hipx types (groppcg.c)", "groppcg", 0)]
+                ("reference KSPSolve_PIPECG over hipx types (pipecg.c; update block = one batch kernel)", "pipecg", 0),
+                ("-ksp_type pipecghipx (one fused update kernel + one product per iteration, launch-ahead)", "pipecghipx", 0),
+                ("reference KSPSolve_GROPPCG over hipx types (groppcg.c; update blocks = two batch kernels)", "groppcg", 0)]
         with phase("plugin rows"):
             for label, ksp, always in rows:
                 if not (always and room(60)) and not (args.full or room(95)):

@@ -161,7 +161,11 @@ def test_ksp_history_np_vs_cpu_mpi(np_, args, tol):
                                       (3, "-stencil 27 -n 16 -ksp_type cg -pc_type jacobi -ksp_norm_type natural -ksp_rtol 1e-50 -ksp_max_it 30"),
                                       (2, "-stencil 7 -n 16 -ksp_type cg -pc_type jacobi -ksp_norm_type unpreconditioned -ksp_rtol 1e-50 -ksp_max_it 30"),
                                       (2, "-stencil 27 -n 12 -ksp_type gmres -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 35"),
-                                      (3, "-stencil 7 -n 16 -ksp_type bcgs -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 12")])
+                                      (3, "-stencil 7 -n 16 -ksp_type bcgs -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 12"),
+                                      # round 6: the pipelined variants' update blocks as batch kernels on the ranks' local parts
+                                      (2, "-stencil 7 -n 20 -ksp_type pipecg -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 30"),
+                                      (3, "-stencil 27 -n 12 -ksp_type groppcg -pc_type jacobi -ksp_norm_type unpreconditioned -ksp_rtol 1e-50 -ksp_max_it 25"),
+                                      (2, "-stencil 7 -n 16 -ksp_type pipecr -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 25")])
 def test_lazy_fusion_on_mpi_vectors(np_, args):
     """Round 5: the vector type's lazy fusion (VecAXPY / VecAYPX recorded, run fused) with VECMPIHIPX on real MPI ranks: the recorded operations are the
     ranks' local parts, the MPIAIJ product reaches the vectors through the accessors (which run what is recorded: x += a p and p = z + b p as one kernel),
@@ -212,6 +216,38 @@ def test_cghipx_on_mpiaijhipx_fused_solve(np_, args):
     assert t_gpu[:2] == t_cpu[:2] and len(h_gpu) == len(h_cpu)
     assert max(abs(g - c) / c for g, c in zip(h_gpu, h_cpu)) <= 1e-9
     assert abs(t_gpu[2] - t_cpu[2]) <= 1e-6 * abs(t_cpu[2]) + 1e-12
+
+
+@pytest.mark.parametrize("np_,args,kw", [(2, "-stencil 7 -n 24 -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 30", dict(pc="jacobi")),
+                                         (3, "-stencil 27 -n 16 -pc_type none -ksp_norm_type unpreconditioned -ksp_rtol 1e-50 -ksp_max_it 25", dict(pc="none", normtype=2)),
+                                         (4, "-stencil 7 -n 20 -pc_type jacobi -ksp_norm_type natural -ksp_rtol 1e-8", dict(pc="jacobi", normtype=3)),
+                                         (2, "-stencil 7 -n 16 -pc_type jacobi -ksp_rtol 1e-30 -ksp_max_it 7", dict(pc="jacobi"))])
+def test_pipecghipx_on_mpiaijhipx(np_, args, kw):
+    """Round 6: -ksp_type pipecghipx on real MPI ranks (sharing this box's GPU: IPC transport).  Per iteration and rank: the fused update kernel, whose three
+    local sums START their all-reduce (peer stores), the product with its ghost exchange, then the END of the all-reduce (hipxAllreduceEnd) -- PIPECG's single
+    reduction hidden behind the product.  Exact reduction mode: the history is the oracle's exact PIPECG on the same row partition (MatMult_MPIAIJ's
+    association, sums over the whole vectors rounded once), bit for bit -- the restatement tests/test_oracle_exact.py pins to the reference.  Default mode:
+    the CPU MPI run of the reference's KSPSolve_PIPECG to rounding."""
+    import numpy as np
+    import oracle as orc
+    d = dict(zip(args.split()[::2], args.split()[1::2]))
+    n = int(d["-n"])
+    ai, aj, aa = orc.stencil("7pt" if d["-stencil"] == "7" else "27pt", n)
+    b = orc.matmult_mpi(ai, aj, aa, np.ones(n ** 3), np_)  # b = A * 1 as the driver forms it under mpiexec
+    rtol = float(d["-ksp_rtol"])
+    xo, its_o, reason_o, ho = orc.ksp_solve("pipecg", ai, aj, aa, b, rtol=rtol, max_it=int(d.get("-ksp_max_it", 10000)), nranks=np_, exact=True, **kw)
+    a = args.split() + ["-history", "-ksp_type", "pipecghipx", "-mat_type", "aijhipx", "-info", ":ksp"]
+    out = mpirun(np_, "ref_driver", a + ["-hipx_reductions", "exact"], True)
+    assert "outside the fused path" not in out
+    h, _, t = parse_driver(out)
+    assert t[:2] == (its_o, reason_o) and len(h) == len(ho)
+    assert h == [float(v) for v in ho], max(abs(g - c) / c for g, c in zip(h, ho))
+    h_cpu, _, t_cpu = parse_driver(mpirun(np_, "ref_driver", args.split() + ["-history", "-ksp_type", "pipecg"], False))
+    h_f, _, t_f = parse_driver(mpirun(np_, "ref_driver", a, True))
+    assert abs(t_f[0] - t_cpu[0]) <= 1 and t_f[1] == t_cpu[1]
+    m = min(len(h_f), len(h_cpu))
+    assert max(abs(g - c) / c for g, c in zip(h_f[:12], h_cpu[:12])) <= 1e-12
+    assert max(abs(g - c) / c for g, c in zip(h_f[:m], h_cpu[:m])) <= 1e-6
 
 
 @pytest.mark.parametrize("np_", [2, 3])
