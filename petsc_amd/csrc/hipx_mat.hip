@@ -502,8 +502,11 @@ __global__ __launch_bounds__(256) void spmv_pk16_kernel(const hipx_int *__restri
 template <typename IT, int MODE, bool DOT>
 __global__ __launch_bounds__(256) void spmv_pk16r_kernel(const hipx_int *__restrict__ rb, hipx_int nblocks, hipx_int blocks_per_xcd, const IT *__restrict__ ai,
                                                          const hipx_int *__restrict__ aj, const unsigned short *__restrict__ pk, const hipx_int *__restrict__ pkbase,
-                                                         const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout, double *dotpart, hipx_int ncols)
+                                                         const double *__restrict__ aa, const double *__restrict__ x, const double *yin, double *yout, double *dotpart, hipx_int ncols,
+                                                         const int nt = 0)
 {
+  // nt (round 6, HIPX_SPMV_NT_STREAM): the value / code streams are read once per product -- loaded non-temporally they do not push the planes of x
+  // the gathers re-use (a plane serves three generations of workgroups) out of the XCD's L2
   constexpr int THREADS = 256, CAP = 2048;
   __shared__ double         vals[CAP];
   __shared__ unsigned short codes[CAP];
@@ -539,9 +542,15 @@ __global__ __launch_bounds__(256) void spmv_pk16r_kernel(const hipx_int *__restr
           for (int it = 0; it < NIT; it++) {
             const IT q  = (IT)t + (IT)it * THREADS;
             const IT qc = q < nq ? q : nq - 1;
-            va[it]      = a2[2 * qc];
-            vb[it]      = a2[2 * qc + 1];
-            vq[it]      = c4[qc];
+            if (nt) {
+              va[it] = __builtin_nontemporal_load(a2 + 2 * qc);
+              vb[it] = __builtin_nontemporal_load(a2 + 2 * qc + 1);
+              vq[it] = __builtin_nontemporal_load(c4 + qc);
+            } else {
+              va[it] = a2[2 * qc];
+              vb[it] = a2[2 * qc + 1];
+              vq[it] = c4[qc];
+            }
           }
 #pragma unroll
           for (int it = 0; it < NIT; it++) {
@@ -805,7 +814,7 @@ __global__ __launch_bounds__(256) void spmv_vd_kernel(const PkDesc *__restrict__
 template <typename IT, int MODE, bool DOT>
 __global__ __launch_bounds__(256) void spmv_tp_kernel(const hipx_int *__restrict__ rb, hipx_int nblocks, hipx_int blocks_per_xcd, const IT *__restrict__ ai, const unsigned char *__restrict__ ptid,
                                                       const int *__restrict__ tstart, const int *__restrict__ toff, const double *__restrict__ aa, const double *__restrict__ x, const double *yin,
-                                                      double *yout, double *dotpart)
+                                                      double *yout, double *dotpart, const int nt = 0)
 {
   constexpr int THREADS = 256, CAP = 2048;
   __shared__ double vals[CAP];
@@ -835,8 +844,13 @@ __global__ __launch_bounds__(256) void spmv_tp_kernel(const hipx_int *__restrict
       for (int it = 0; it < NIT; it++) {
         const IT q  = (IT)t + (IT)it * THREADS;
         const IT qc = q < nq ? q : nq - 1;
-        va[it]      = a2[2 * qc];
-        vb[it]      = a2[2 * qc + 1];
+        if (nt) {  // (see spmv_pk16r_kernel)
+          va[it] = __builtin_nontemporal_load(a2 + 2 * qc);
+          vb[it] = __builtin_nontemporal_load(a2 + 2 * qc + 1);
+        } else {
+          va[it] = a2[2 * qc];
+          vb[it] = a2[2 * qc + 1];
+        }
       }
 #pragma unroll
       for (int it = 0; it < NIT; it++) {
@@ -3203,7 +3217,7 @@ int ensure_pattern_templates(hipxMat A)
 // start another process.  Only HIPX_MAT_NO_INODE is still read per call (tests flip it inside one process; one lookup per product).
 struct DevSwitches {
   bool nomarch, nosub, nopair, march1, trace, nt_store;
-  int  probe, march_units, nt_x, pairmax;
+  int  probe, march_units, nt_x, pairmax, nt_stream;
 };
 static const DevSwitches &dev_sw()
 {
@@ -3219,6 +3233,7 @@ static const DevSwitches &dev_sw()
     d.march_units = getenv("HIPX_TMPL_MARCH_UNITS") ? atoi(getenv("HIPX_TMPL_MARCH_UNITS")) : 0;
     d.nt_x        = getenv("HIPX_MARCH_NT_X") ? atoi(getenv("HIPX_MARCH_NT_X")) : 0;
     d.pairmax     = getenv("HIPX_TMPL_PAIRMAX") ? atoi(getenv("HIPX_TMPL_PAIRMAX")) : 16;
+    d.nt_stream   = getenv("HIPX_SPMV_NT_STREAM") ? atoi(getenv("HIPX_SPMV_NT_STREAM")) : 0;
     return d;
   }();
   return v;
@@ -3719,7 +3734,7 @@ int launch_pk16(hipxMat A, const double *x, const double *yin, double *yout, dou
     else if (rpt == 4) HIPX_VD_LAUNCH(4, 2, 0);
     else HIPX_VD_LAUNCH(2, 4, 0);
   } else if (rowpar) {
-    spmv_pk16r_kernel<IT, MODE, DOT><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS, x, yin, yout, dotpart, A->n);
+    spmv_pk16r_kernel<IT, MODE, DOT><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS, x, yin, yout, dotpart, A->n, dev_sw().nt_stream);
   } else {
     if (vd) spmv_pk16_kernel<IT, MODE, DOT, true><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS, A->d_vc, A->d_vdict, x, yin, yout, dotpart, A->n);
     else spmv_pk16_kernel<IT, MODE, DOT, false><<<grid, 256, 0, rt().compute>>>(HIPX_PK_ARGS, A->d_vc, A->d_vdict, x, yin, yout, dotpart, A->n);
@@ -3756,7 +3771,7 @@ int launch_tp(hipxMat A, const double *x, const double *yin, double *yout, doubl
   if (nb == 0) return HIPX_SUCCESS;
   const hipx_int per_xcd = (nb + 7) / 8;
   const unsigned grid = (unsigned)(per_xcd * 8);
-  spmv_tp_kernel<IT, MODE, DOT><<<grid, 256, 0, rt().compute>>>(A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_ptid, A->d_ptstart, A->d_ptoff, A->d_a, x, yin, yout, dotpart);
+  spmv_tp_kernel<IT, MODE, DOT><<<grid, 256, 0, rt().compute>>>(A->d_rb[0], nb, per_xcd, (const IT *)A->d_i, A->d_ptid, A->d_ptstart, A->d_ptoff, A->d_a, x, yin, yout, dotpart, dev_sw().nt_stream);
   HIPX_LAUNCH_CHECK();
   return HIPX_SUCCESS;
 }

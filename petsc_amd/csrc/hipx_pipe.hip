@@ -167,8 +167,8 @@ struct PipeCGArgs {
   double       *alpha_out;      // device: alpha of this iteration (one thread writes it)
 };
 
-template <bool FIRST, int PC, int NRM, bool COMP>
-__global__ __launch_bounds__(kRedThreads) void pipecg_update_kernel(const PipeCGArgs a, hipx_int n, bool vec, RedOut out)
+template <bool FIRST, int PC, int NRM, bool COMP, int U>
+__global__ __launch_bounds__(kRedThreads) void pipecg_update_kernel(const PipeCGArgs a, hipx_int n, bool vec, RedOut out, const int nt)
 {
   const double gamma = a.sums[1], delta = a.sums[2];
   double       alpha, beta = 0.0, aold = 0.0;
@@ -205,27 +205,59 @@ __global__ __launch_bounds__(kRedThreads) void pipecg_update_kernel(const PipeCG
     acc[2].prod(w, u);
   };
   if (vec) {
+    // U pairs per stream in flight per thread (all loads of a round issued before the first use); nt bit 0: non-temporal loads, bit 1: non-temporal stores
+    // (every vector is touched once per iteration and the working set is ten vectors: nothing read here is in a cache by the time it is wanted again)
     const hipx_int n2 = n >> 1, stride = (hipx_int)gridDim.x * kRedThreads;
-    for (hipx_int i = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x; i < n2; i += stride) {
-      const double2 z0 = {0.0, 0.0};
-      double2       z = FIRST ? z0 : reinterpret_cast<const double2 *>(a.z)[i], q = FIRST ? z0 : reinterpret_cast<const double2 *>(a.q)[i];
-      double2       p = FIRST ? z0 : reinterpret_cast<const double2 *>(a.p)[i], s = FIRST ? z0 : reinterpret_cast<const double2 *>(a.s)[i];
-      double2       x = FIRST ? z0 : reinterpret_cast<const double2 *>(a.x)[i];
-      double2       u = reinterpret_cast<const double2 *>(a.u)[i], w = reinterpret_cast<const double2 *>(a.w)[i], r = reinterpret_cast<const double2 *>(a.r)[i];
-      const double2 nn = reinterpret_cast<const double2 *>(a.nv)[i];
-      const double2 dd = (PC == 2) ? reinterpret_cast<const double2 *>(a.d)[i] : make_double2(a.dconst, a.dconst);
-      double2       m;
-      one(z.x, q.x, p.x, s.x, x.x, u.x, w.x, r.x, m.x, nn.x, dd.x);
-      one(z.y, q.y, p.y, s.y, x.y, u.y, w.y, r.y, m.y, nn.y, dd.y);
-      reinterpret_cast<double2 *>(a.z)[i] = z;
-      reinterpret_cast<double2 *>(a.q)[i] = q;
-      reinterpret_cast<double2 *>(a.p)[i] = p;
-      reinterpret_cast<double2 *>(a.s)[i] = s;
-      if (!FIRST) reinterpret_cast<double2 *>(a.x)[i] = x;
-      reinterpret_cast<double2 *>(a.u)[i] = u;
-      reinterpret_cast<double2 *>(a.w)[i] = w;
-      reinterpret_cast<double2 *>(a.r)[i] = r;
-      reinterpret_cast<double2 *>(a.m)[i] = m;
+    const double2  z0 = {0.0, 0.0};
+    const auto     ld = [&](const double *b, hipx_int i) -> double2 {
+      if (nt & 1) {
+        double2 v;
+        v.x = __builtin_nontemporal_load(b + 2 * i);
+        v.y = __builtin_nontemporal_load(b + 2 * i + 1);
+        return v;
+      }
+      return reinterpret_cast<const double2 *>(b)[i];
+    };
+    const auto st = [&](double *b, hipx_int i, const double2 v) {
+      if (nt & 2) {
+        __builtin_nontemporal_store(v.x, b + 2 * i);
+        __builtin_nontemporal_store(v.y, b + 2 * i + 1);
+      } else reinterpret_cast<double2 *>(b)[i] = v;
+    };
+    for (hipx_int i0 = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x; i0 < n2; i0 += U * stride) {
+      double2 z[U], q[U], p[U], s[U], x[U], u[U], w[U], r[U], nn[U], dd[U], m[U];
+#pragma unroll
+      for (int k = 0; k < U; k++) {
+        const hipx_int i  = i0 + k * stride;
+        const hipx_int ic = i < n2 ? i : i0;  // (beyond the end: re-read the first pair of the round, results dropped)
+        z[k]  = FIRST ? z0 : ld(a.z, ic);
+        q[k]  = FIRST ? z0 : ld(a.q, ic);
+        p[k]  = FIRST ? z0 : ld(a.p, ic);
+        s[k]  = FIRST ? z0 : ld(a.s, ic);
+        x[k]  = FIRST ? z0 : ld(a.x, ic);
+        u[k]  = ld(a.u, ic);
+        w[k]  = ld(a.w, ic);
+        r[k]  = ld(a.r, ic);
+        nn[k] = ld(a.nv, ic);
+        dd[k] = (PC == 2) ? ld(a.d, ic) : make_double2(a.dconst, a.dconst);
+      }
+#pragma unroll
+      for (int k = 0; k < U; k++) {
+        const hipx_int i = i0 + k * stride;
+        if (i < n2) {
+          one(z[k].x, q[k].x, p[k].x, s[k].x, x[k].x, u[k].x, w[k].x, r[k].x, m[k].x, nn[k].x, dd[k].x);
+          one(z[k].y, q[k].y, p[k].y, s[k].y, x[k].y, u[k].y, w[k].y, r[k].y, m[k].y, nn[k].y, dd[k].y);
+          st(a.z, i, z[k]);
+          st(a.q, i, q[k]);
+          st(a.p, i, p[k]);
+          st(a.s, i, s[k]);
+          if (!FIRST) st(a.x, i, x[k]);
+          st(a.u, i, u[k]);
+          st(a.w, i, w[k]);
+          st(a.r, i, r[k]);
+          st(a.m, i, m[k]);
+        }
+      }
     }
   }
   {  // rows beyond the 16-byte pairs (odd n), or every row of vectors that are not 16-byte aligned
@@ -251,9 +283,12 @@ __global__ __launch_bounds__(kRedThreads) void pipecg_update_kernel(const PipeCG
 template <bool FIRST, int PC, int NRM>
 void pipecg_go2(const PipeCGArgs &a, hipx_int n, bool vec, const RedOut &o)
 {
-  const unsigned g = pipe_grid(n);
-  if (rt().red_exact) pipecg_update_kernel<FIRST, PC, NRM, true><<<g, kRedThreads, 0, rt().compute>>>(a, n, vec, o);
-  else pipecg_update_kernel<FIRST, PC, NRM, false><<<g, kRedThreads, 0, rt().compute>>>(a, n, vec, o);
+  const unsigned   g  = pipe_grid(n);
+  static const int nt = getenv("HIPX_PIPECG_NT") ? atoi(getenv("HIPX_PIPECG_NT")) : 0;   // developer switches (timing experiments): non-temporal loads (1) / stores (2) / both (3)
+  static const int u2 = getenv("HIPX_PIPECG_U") ? atoi(getenv("HIPX_PIPECG_U")) : 1;     // pairs per stream in flight per thread
+  if (rt().red_exact) pipecg_update_kernel<FIRST, PC, NRM, true, 1><<<g, kRedThreads, 0, rt().compute>>>(a, n, vec, o, nt);
+  else if (u2 == 2) pipecg_update_kernel<FIRST, PC, NRM, false, 2><<<g, kRedThreads, 0, rt().compute>>>(a, n, vec, o, nt);
+  else pipecg_update_kernel<FIRST, PC, NRM, false, 1><<<g, kRedThreads, 0, rt().compute>>>(a, n, vec, o, nt);
 }
 template <bool FIRST, int PC>
 void pipecg_go1(const PipeCGArgs &a, int nrm, hipx_int n, bool vec, const RedOut &o)

@@ -1424,6 +1424,11 @@ static PetscErrorCode VecDuplicateVecs_HIPX(Vec w, PetscInt m, Vec *V[])
   /* (m >= 8: a Krylov basis.  The three or five work vectors of a CG keep allocations of their own: measured on 7-pt 256^3, stock KSPCG, 400 iterations --
      separate allocations 109-112 ms, one slab with the 4352-byte skew 113-114, without skew 118, with a 527 KB skew 123: where r, z, p lie relative to each
      other moves the fused kernels by a few per cent, and the allocator's own placement is the best of those tried) */
+  /* Round 6: the work vectors of a Krylov method (KSPSetWorkVecs -> VecDuplicateVecs at KSPSetUp) get their device mirrors NOW when the vector they are modelled
+     on lives on the device: the hipMalloc of a 134 MB buffer costs milliseconds and would otherwise happen inside the first KSPSolve, at each vector's first use
+     (measured: the first of two identical solves 30 ms longer than the second) -- the reference allocates its work vectors at set-up too (VecDuplicateVecs_Default). */
+  if (!(slab_on && m >= 8) && n > 0 && VecIsHIPX(w) && VecHIPXGetExt(w)->d_array && VecIsHIPX((*V)[0]))
+    for (PetscInt i = 0; i < m; i++) PetscCall(VecHIPXAllocate((*V)[i]));
   if (slab_on && m >= 8 && n > 0 && VecIsHIPX((*V)[0])) {
     VecHIPXSlab *sl;
     PetscCall(PetscNew(&sl));
