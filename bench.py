@@ -1711,7 +1711,7 @@ def main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync, t_st
             scaling_legs.insert(2, ("cg_jacobi_27pt_512_strong_single_reduction_launch_ahead", Cfg(27, (512, 512, 512), "cg", "jacobi", "strong"), 60, 5, 16, 20 + 60 // world, 4))
             # round 6: KSPPIPECG (pipecg.c) on the headline's system -- one fused update kernel + one product per iteration and rank, its ONE all-reduce started before the product
             # and collected after it (hipxPipeCGUpdateBeginAllreduce ... hipxAllreduceEnd); a timed "step" is one pass of a complete K-iteration solve
-            if head.cube and head.golden_key().replace("cg_", "pipecg_", 1) in ("pipecg_jacobi_7pt_256",):
+            if head.cube:
                 scaling_legs.append(("headline_pipecg_launch_ahead", Cfg(head.stencil, head.dims, "pipecg", head.pc, head.scaling), args.steps, args.warmup, args.parity_its, 10 + 20 // world, 1))
         for name, cfg, st, wu, pits, est, pipe in scaling_legs:
             go = [time.time() + est <= deadline]

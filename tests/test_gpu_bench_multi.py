@@ -116,6 +116,25 @@ def test_two_rank_line_times_the_single_reduction_form_beside_the_headline():
     assert all(v == {"skipped": "budget"} or v.get("parity", {}).get("pass") is not False for v in legs.values()), {k: v.get("parity") for k, v in legs.items() if isinstance(v, dict)}
 
 
+def test_pipecg_on_two_ranks_through_bench_py():
+    """Round 6: `bench.py --gpus 2 --ksp pipecg` -- the host layer's launch-ahead PIPECG on two ranks sharing the GPU: per iteration and rank one fused update
+    kernel whose three sums START their all-reduce (IPC post phase), the product with its ghost exchange, the all-reduce's END.  Gated in the exact reduction mode
+    against the committed history of the REFERENCE's KSPSolve_PIPECG + exact BLAS (one rank: the two-rank product's association differs from it by rounding,
+    hence 1e-9 instead of equality -- equality against the partitioned oracle: tests/test_gpu_plugin_mpi.py); the CG headline's line carries it as a leg too."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--ksp", "pipecg", "--grid", "64", "--steps", "30", "--warmup", "3", "--quick"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=clean_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and "PIPECG" in d["metric"] and d["value"] > 0
+    g = d["parity_gate"]
+    assert g["pass"] is True and g["gated_reduction_mode"] == "exact" and g["max_rel_diff"] <= 1e-9 and g["max_rel_diff_fast_reductions"] <= 1e-8, g
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "64", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-traffic", "--no-plugin",
+                        "--no-general", "--budget-s", "300"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200, env=clean_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:]
+    leg = last_json(r.stdout)["other_configs"]["headline_pipecg_launch_ahead"]
+    assert leg.get("iterations_per_s", 0) > 0 and leg["parity"]["pass"] is True, leg
+
+
 def test_gmres_sor_on_two_and_four_ranks_follows_the_exact_yardstick_at_1e12():
     """Config 3's solver on 2 and 4 ranks sharing the GPU (IPC transport): in the exact reduction mode -- the ranks' sums folded as unrounded
     pairs, GMRES's MDot included (round 4) -- the first 35 residual norms sit within 1e-12 of the committed exact-reduction history of the same

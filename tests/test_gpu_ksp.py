@@ -32,7 +32,7 @@ def solve_gpu(kind, ai, aj, aa, b, pc="jacobi", rtol=1e-5, max_it=10000, normtyp
     X = _lib.DVec(N, x0 if x0 is not None else np.zeros(N))
     k.guess_nonzero = 0 if x0 is None else 1
     _lib.chk(ks.HipxPCSetUp(C.byref(p), C.byref(M)))
-    f = ks.HipxKSPSolve_CG if kind == "cg" else ks.HipxKSPSolve_GMRES
+    f = {"cg": ks.HipxKSPSolve_CG, "gmres": ks.HipxKSPSolve_GMRES, "pipecg": ks.HipxKSPSolve_PIPECG}[kind]
     _lib.chk(f(C.byref(k), C.byref(M), C.byref(p), B.ptr, X.ptr))
     x = X.get()
     out = (x, int(k.its), int(k.reason), hist[:k.hist_n].copy())
