@@ -197,7 +197,8 @@ int hipxVecBatchAXPYDotsBegin(int nops, const int *kind, const int *yslot, const
      otherwise: beta = gamma / gamma_old; alpha = gamma / (delta - beta / alpha_old * gamma);                                 pipecg.c:138-139
                 x += alpha_old p  (the update the iteration before left behind: applied before p changes);  z = n + beta z; q = m + beta q; p = u + beta p; s = w + beta s
      then       u -= alpha q; w -= alpha z; r -= alpha s                                                                      pipecg.c:148-150
-                m = w .* d  (PCJACOBI; d == NULL: m = w * dconst -- a constant diagonal, or 1.0 = PCNONE's copy)              pipecg.c:115
+                m = w .* d  (PCJACOBI; d == NULL: m = w * dconst -- a constant diagonal; dconst == 1.0 = PCNONE: m is NOT written,
+                the caller multiplies w itself)                                                                               pipecg.c:115
      sums of the new vectors -> slot and dev_sums_out[0..3): [0] u.u (normkind 1) | r.r (2) | 0 (0), [1] gamma = r.u, [2] delta = w.u   pipecg.c:106-113
    gamma, delta = dev_sums[1], [2]; gamma_old = dev_sums_old[1]; alpha is written to *dev_alpha_out (the host forms the same IEEE quotients for the final
    x += alpha p).  m of THIS iteration (q = m + beta q) is re-formed from w as the kernel before formed it.  v->n = A m of this iteration.  Enqueue only. */

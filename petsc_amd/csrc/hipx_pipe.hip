@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kRedThreads) void pipecg_update_kernel(const PipeCG
           st(a.u, i, u[k]);
           st(a.w, i, w[k]);
           st(a.r, i, r[k]);
-          st(a.m, i, m[k]);
+          if (PC != 0) st(a.m, i, m[k]);  // (PCNONE: m IS w -- the product reads w)
         }
       }
     }
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(kRedThreads) void pipecg_update_kernel(const PipeCG
       a.u[i] = u;
       a.w[i] = w;
       a.r[i] = r;
-      a.m[i] = m;
+      if (PC != 0) a.m[i] = m;
     }
   }
   finish_sums<3, COMP>(acc, out);

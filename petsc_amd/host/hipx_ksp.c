@@ -873,6 +873,7 @@ int HipxKSPSolve_PIPECG(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, d
 #define PALPHA(k) (ds + 9 + (int)((k) & 1))
   v.z = Z; v.q = Q; v.p = P; v.s = S; v.x = X; v.u = U; v.w = W; v.r = R; v.m = M; v.n = N;
   dinv = (pc->type == HIPX_PC_JACOBI && !(pc->dconst_valid && !getenv("HIPX_NO_DCONST"))) ? pc->dinv : NULL;
+  if (!dinv && pc->dconst == 1.0) M = W; /* PCNONE (or a diagonal of ones): m = B w is w itself, bit for bit -- the update kernel does not store it, the product reads w */
   ksp->its    = 0;
   ksp->reason = 0;
   ksp->hist_n = 0;
@@ -915,8 +916,8 @@ int HipxKSPSolve_PIPECG(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, d
     else CHK(hipxMemcpyHtoD(PSUMS(0) + 1, &gamma, sizeof(double))); /* (natural norm: iteration 0 keeps the gamma its norm was formed from, pipecg.c:100) */
     delta = sums[2];
   }
-  CHK(HipxPCApply(pc, A, W, M)); /* pipecg.c:104 */
-  CHK(HipxMatMult(A, M, N));     /* pipecg.c:105 */
+  if (M != W) CHK(HipxPCApply(pc, A, W, M)); /* pipecg.c:104 */
+  CHK(HipxMatMult(A, M, N));                 /* pipecg.c:105 */
   i = 0;
   do {
     /* top of iteration i: gamma, delta (and dp for i > 0) are the host's copies of sums_i */
