@@ -762,6 +762,19 @@ extern "C" int hipxSorBoxRun_(void *p, int kind, const double *rhs, double *tout
               us(Jl > 1 ? 2 : 0, 0, 0), us(Jl > 1 ? 2 : 0, 0, 1), us(Jl > 0 ? 1 : 0, cl > 0 ? 1 : 0, 0), us(Jl > 0 ? 1 : 0, cl > 0 ? 1 : 0, 1), cm, us(0, cm, 0), us(0, cm, 1), Jl, 0, us(Jl, 0, 0), us(Jl, 0, 1), Jl, cl,
               us(Jl, cl, 0), us(Jl, cl, 1));
     }
+    if (getenv("HIPX_SORBOX_STATS") && atoi(getenv("HIPX_SORBOX_STATS")) >= 2) {  // every workgroup's start / end (us): row J, column c
+      unsigned long long t0 = ~0ull;
+      for (size_t q = 0; q < (size_t)B->nb * B->nch; q++)
+        if (h[8 + 2 * q] && h[8 + 2 * q] < t0) t0 = h[8 + 2 * q];
+      for (int e = 0; e < 2; e++) {
+        fprintf(stderr, "[sorbox %s us, kind %d, %d blocks x %d chunks]\n", e ? "end" : "start", kind, B->nb, B->nch);
+        for (int J = 0; J < B->nb; J++) {
+          fprintf(stderr, "  J=%d:", J);
+          for (int c = 0; c < B->nch; c++) fprintf(stderr, " %.0f", (double)(long long)(h[8 + 2 * ((size_t)c * B->nb + J) + e] - t0) * 0.01);
+          fprintf(stderr, "\n");
+        }
+      }
+    }
     const double nw = (double)B->nb * B->nch * BX_P;
     fprintf(stderr, "[sorbox kind %d %dx%dx%d] per compute wave: steps %.0f, spins waiting for lower plane %.1f, stager %.1f, upper plane %.1f, flusher %.1f; per stager: ring waits %.1f, halo polls %.1f\n", kind,
             B->nx, B->ny, B->nz, (double)h[6] / nw, (double)h[0] / nw, (double)h[1] / nw, (double)h[2] / nw, (double)h[3] / nw, (double)h[4] / nw, (double)h[5] / nw);
