@@ -325,7 +325,7 @@ class Problem:
         else:
             self.ksp.history, self.ksp.hist_len = None, 0
         lib.chk(self.hx.hipxVecSet(self.X.ptr, self.m, 0.0))
-        f = {"cg": ks.HipxKSPSolve_CG, "gmres": ks.HipxKSPSolve_GMRES, "pipecg": ks.HipxKSPSolve_PIPECG}[self.cfg.ksp]
+        f = {"cg": ks.HipxKSPSolve_CG, "gmres": ks.HipxKSPSolve_GMRES, "pipecg": ks.HipxKSPSolve_PIPECG, "groppcg": ks.HipxKSPSolve_GROPPCG}[self.cfg.ksp]
         lib.chk(f(C.byref(self.ksp), C.byref(self.M), C.byref(self.pc), self.B.ptr, self.X.ptr))
         # (KSPSolve_PIPECG's loop bound is `i <= max_it`, pipecg.c:160: max_it + 1 passes, max_it + 1 history entries)
         assert self.ksp.its == its + (1 if self.cfg.ksp == "pipecg" else 0) and self.ksp.reason == -3, (self.ksp.its, self.ksp.reason)
@@ -638,10 +638,10 @@ def parity_vs_golden(P, its, tol):
         return float((np.abs(hist[:k] - href[:k]) / np.abs(href[:k])).max()), k
     rel_fast, k = dist(0)
     rel_exact, k2 = dist(1)
-    gated = "exact" if P.cfg.ksp in ("gmres", "pipecg") else "fast"  # (PIPECG: r, u = B r and w = A u are all recurred -- every rounding of a reduction is carried forward)
+    gated = "exact" if P.cfg.ksp in ("gmres", "pipecg", "groppcg") else "fast"  # (PIPECG: r, u = B r and w = A u are all recurred -- every rounding of a reduction is carried forward)
     if getattr(P, "pipeline", 1) in (3, 4):  # single-reduction CG: another recurrence for w = A p -- its history leaves the standard form's by rounding, a little more every iteration;
         tol = max(tol, 1e-9)            # bit parity with the REFERENCE's own single-reduction run is what tests/test_gpu_scale_parity.py holds it to
-    if P.cfg.ksp == "pipecg" and P.world > 1:  # the committed history is the one-rank reference's: MatMult_MPIAIJ's association (diagonal block, then the ghost terms) differs from it
+    if P.cfg.ksp in ("pipecg", "groppcg") and P.world > 1:  # the committed history is the one-rank reference's: MatMult_MPIAIJ's association (diagonal block, then the ghost terms) differs from it
         tol = max(tol, 1e-9)                    # by rounding, which the pipelined recurrences carry forward (np > 1 bit parity: tests/test_gpu_plugin_mpi.py against the partitioned oracle)
     rel = rel_exact if gated == "exact" else rel_fast
     out = {"pass": bool(rel <= tol and k == its + 1 and k2 == its + 1), "max_rel_diff": rel, "tolerance": tol, "gated_reduction_mode": gated, "iterations": its, "entries": k,
@@ -1071,7 +1071,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--grid", dest="n", type=int, default=256, help="grid points per side (not --n: torchrun would read it as an abbreviation of its own options)")
     ap.add_argument("--stencil", type=int, default=7, choices=[5, 7, 27], help="5: the 2-D operator of ex2.c (BASELINE config 1) on a grid x grid mesh (--grid 4096: 16.8 M rows)")
-    ap.add_argument("--ksp", default="cg", choices=["cg", "gmres", "pipecg"])
+    ap.add_argument("--ksp", default="cg", choices=["cg", "gmres", "pipecg", "groppcg"])
     ap.add_argument("--pc", default="jacobi", choices=["jacobi", "sor", "none"])
     ap.add_argument("--transport", default=os.environ.get("HIPX_TRANSPORT", "auto"), choices=["auto", "rccl", "ipc"],
                     help="multi-GPU data path: RCCL send/recv + all-reduce over xGMI, or IPC peer stores (also when ranks share a GPU); auto: probe both, time both, report the faster as `value`")
@@ -1294,7 +1294,8 @@ def main():
                 ("reference KSPSolve_CG over hipx types, -pc_type jacobihipx", "cg+jacobihipx", 0),
                 ("reference KSPSolve_PIPECG over hipx types (pipecg.c; update block = one batch kernel)", "pipecg", 0),
                 ("-ksp_type pipecghipx (one fused update kernel + one product per iteration, launch-ahead)", "pipecghipx", 0),
-                ("reference KSPSolve_GROPPCG over hipx types (groppcg.c; update blocks = two batch kernels)", "groppcg", 0)]
+                ("reference KSPSolve_GROPPCG over hipx types (groppcg.c; update blocks = two batch kernels)", "groppcg", 0),
+                ("-ksp_type groppcghipx (two fused passes + one product per iteration, launch-ahead)", "groppcghipx", 0)]
         with phase("plugin rows"):
             for label, ksp, always in rows:
                 if not (always and room(60)) and not (args.full or room(95)):
@@ -1341,7 +1342,9 @@ def main():
                 ("cg_jacobi_5pt_4096x4096", Cfg(5, (4096, 4096, 1), "cg", "jacobi"), 100, 10, 16, 10, 7),
                 # KSPPIPECG (pipecg.c) on the headline's system through the host layer's launch-ahead loop (one fused update kernel + one product per iteration;
                 # a timed "step" here is one pass of a complete K-iteration solve, set-up included)
-                ("pipecg_jacobi_7pt_256", Cfg(7, (256, 256, 256), "pipecg", "jacobi"), 100, 10, 24, 0, 7)]
+                ("pipecg_jacobi_7pt_256", Cfg(7, (256, 256, 256), "pipecg", "jacobi"), 100, 10, 24, 0, 7),
+                # ... and KSPGROPPCG (groppcg.c) the same way: two fused passes + one product per iteration
+                ("groppcg_jacobi_7pt_256", Cfg(7, (256, 256, 256), "groppcg", "jacobi"), 100, 10, 24, 0, 6)]
         for name, cfg, st, wu, pits, cpu_its, est in legs:
             if not room(est + reserve):
                 other[name] = {"skipped": "budget"}
@@ -1713,6 +1716,7 @@ def main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync, t_st
             # and collected after it (hipxPipeCGUpdateBeginAllreduce ... hipxAllreduceEnd); a timed "step" is one pass of a complete K-iteration solve
             if head.cube:
                 scaling_legs.append(("headline_pipecg_launch_ahead", Cfg(head.stencil, head.dims, "pipecg", head.pc, head.scaling), args.steps, args.warmup, args.parity_its, 10 + 20 // world, 1))
+                scaling_legs.append(("headline_groppcg_launch_ahead", Cfg(head.stencil, head.dims, "groppcg", head.pc, head.scaling), args.steps, args.warmup, args.parity_its, 10 + 20 // world, 1))
         for name, cfg, st, wu, pits, est, pipe in scaling_legs:
             go = [time.time() + est <= deadline]
             dist.broadcast_object_list(go, src=0)

@@ -209,6 +209,17 @@ typedef struct {
 int hipxPipeCGUpdateBegin(const hipxPipeCGVecs *v, const double *d, double dconst, int normkind, int first, const double *dev_sums, const double *dev_sums_old, const double *dev_alpha_old,
                           double *dev_alpha_out, hipx_int n, int slot, double *dev_sums_out);
 
+/* Gropp's CG (KSPSolve_GROPPCG groppcg.c:23-140) as two passes per iteration + the product, scalars formed on the device (HipxKSPSolve_GROPPCG, hipx_ksp.h).
+   hipxGroppCGDirectionBegin, iteration i > 1:  x += alpha_{i-1} p  (the update the iteration before left behind: groppcg.c:98, applied before p changes);
+     p = z + beta p; s = Z + beta s  with beta = *dev_gamma_new / *dev_gamma_old  (groppcg.c:132-136);  t = p . s -> slot and *dev_t_out  (groppcg.c:87).
+   hipxGroppCGUpdateBegin:  alpha = *dev_gamma / *dev_t (groppcg.c:96), stored to *dev_alpha_out;  r -= alpha s;  z -= alpha (s .* d)  (S = B s of groppcg.c:92 re-formed per
+     element: d == NULL -> s * dconst, dconst == 1.0 = PCNONE);  sums -> slot and dev_sums2_out: [0] z.z (normkind 1) | r.r (2) | 0, [1] gammaNew = r.z  (groppcg.c:103-108).
+   Same operations per element, in the reference's order: vectors bit-identical.  Enqueue only; the ...Allreduce forms (below) reduce over the ranks on the stream. */
+int hipxGroppCGDirectionBegin(double *p, double *s, double *x, const double *z, const double *Z, const double *dev_gamma_new, const double *dev_gamma_old, const double *dev_alpha_old, hipx_int n,
+                              int slot, double *dev_t_out);
+int hipxGroppCGUpdateBegin(double *r, double *z, const double *s, const double *d, double dconst, int normkind, const double *dev_gamma, const double *dev_t, double *dev_alpha_out, hipx_int n,
+                           int slot, double *dev_sums2_out);
+
 /* ---- Mat (CSR = Mat_SeqAIJ src/mat/impls/aij/seq/aij.h:47-78,150-168) ----------------------- */
 typedef struct hipxMat_s *hipxMat;
 
@@ -410,6 +421,12 @@ int hipxMatMultMPICGDirectionDotBegin(hipxMat Ad, hipxMat Bo, hipxHalo h, const 
    in rank order (plain or compensated), publishes the nvals totals to the host slot and to dev_out.  One all-reduce per PIPECG iteration, overlapped with the product. */
 int hipxPipeCGUpdateBeginAllreduce(const hipxPipeCGVecs *v, const double *d, double dconst, int normkind, int first, const double *dev_sums, const double *dev_sums_old,
                                    const double *dev_alpha_old, double *dev_alpha_out, hipx_int n, int slot);
+/* Gropp's CG on several ranks: the direction pass with its one sum all-reduced on the stream (reduction 1: nothing is left to hide it behind once S = B s is formed inside the
+   update pass), and the update pass whose two sums START their all-reduce -- the product Z = A z runs -- hipxAllreduceEnd (reduction 2 hidden behind the product, groppcg.c:107-117) */
+int hipxGroppCGDirectionBeginAllreduce(double *p, double *s, double *x, const double *z, const double *Z, const double *dev_gamma_new, const double *dev_gamma_old, const double *dev_alpha_old,
+                                       hipx_int n, int slot, double *dev_t_out);
+int hipxGroppCGUpdateBeginAllreduce(double *r, double *z, const double *s, const double *d, double dconst, int normkind, const double *dev_gamma, const double *dev_t, double *dev_alpha_out,
+                                    hipx_int n, int slot);
 int hipxVecMDotAllreduceBegin(const double *x, hipx_int nv, const double *const *y, hipx_int n, int slot); /* local x . y_j (nv <= 16) + the start of their all-reduce */
 int hipxAllreduceEnd(int slot, int nvals, double *dev_out);
 /* which transport the next exchange of this plan takes: 1 = IPC peer stores, 2 = RCCL send/recv, 0 = none set up */

@@ -5,6 +5,7 @@
  * It mirrors the reference's caller code, statement by statement, over device vectors:
  *   KSPSolve_CG      src/ksp/ksp/impls/cg/cg.c:119-352
  *   KSPSolve_GMRES   src/ksp/ksp/impls/gmres/gmres.c:88-238,298-395 + borthog2.c:35-113
+ *   KSPSolve_GROPPCG src/ksp/ksp/impls/cg/groppcg/groppcg.c:23-140
  *   KSPSolve_PIPECG  src/ksp/ksp/impls/cg/pipecg/pipecg.c:20-160 (+ the split-phase reduction of src/vec/vec/utils/comb.c:168-379)
  *   KSPConvergedDefault  src/ksp/ksp/interface/iterativ.c:1490-1585
  *   PCApply_Jacobi / PCApply_SOR / PCApply_None   jacobi.c:354, sor.c:27, pcnone
@@ -105,6 +106,9 @@ int HipxKSPSolve_GMRES(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, do
 /* replaces KSPSolve_PIPECG pipecg.c:20-160 (PCJACOBI / PCNONE; any norm type): one fused update kernel + one product per iteration, the scalars formed on the
    device, the iteration's single reduction (all-reduce on several ranks) hidden behind the product; ksp->pipeline = 0: host-synchronised (same bits) */
 int HipxKSPSolve_PIPECG(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, double *x);
+/* replaces KSPSolve_GROPPCG groppcg.c:23-140 (PCJACOBI / PCNONE; any norm type): two fused passes + one product per iteration, scalars on the device, reduction 2
+   (all-reduce on several ranks) hidden behind the product */
+int HipxKSPSolve_GROPPCG(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, double *x);
 /* replaces KSPSolve_Chebyshev_FirstKind cheby.c:389-555 with given eigenvalue bounds (cheby.c:40-62); ksp->normtype NONE + PCJACOBI / PCNONE
    + ksp->fused: SpMV + one fused elementwise kernel per iteration, no reductions */
 int HipxKSPSolve_Chebyshev(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *b, double *x, double emin, double emax);

@@ -649,6 +649,39 @@ int hipxPipeCGUpdateBeginAllreduce(const hipxPipeCGVecs *v, const double *d, dou
   return allreduce_begin(3, red_pairs());
 }
 
+int hipxGroppCGDirectionBeginAllreduce(double *p, double *s, double *x, const double *z, const double *Z, const double *dev_gamma_new, const double *dev_gamma_old, const double *dev_alpha_old,
+                                       hipx_int n, int slot, double *dev_t_out)
+{
+  HIPX_CHECK_INIT();
+  Comm &c = cm();
+  HIPX_ARG(c.active && dev_gamma_new && dev_gamma_old && dev_alpha_old && dev_t_out && slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2, "communicator not initialised / null scalars / bad slot");
+  int ierr;
+  if (n > 0) {
+    RedOut o  = red_out(slot, false, nullptr);
+    o.results = c.d_red;
+    o.pairs   = rt().red_exact;
+    if ((ierr = launch_gropp_dir(p, s, x, z, Z, dev_gamma_new, dev_gamma_old, dev_alpha_old, n, o))) return ierr;
+  } else HIPX_HIP(hipMemsetAsync(c.d_red, 0, sizeof(double) * 2, rt().compute));
+  return allreduce_signal(c.d_red, 1, red_pairs(), slot, dev_t_out, nullptr);
+}
+
+int hipxGroppCGUpdateBeginAllreduce(double *r, double *z, const double *s, const double *d, double dconst, int normkind, const double *dev_gamma, const double *dev_t, double *dev_alpha_out,
+                                    hipx_int n, int slot)
+{
+  HIPX_CHECK_INIT();
+  Comm &c = cm();
+  HIPX_ARG(c.active && dev_gamma && dev_t && dev_alpha_out && slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2, "communicator not initialised / null scalars / bad slot");
+  int ierr;
+  if ((ierr = split_ensure())) return ierr;
+  if (n > 0) {
+    RedOut o  = red_out(slot, false, nullptr);
+    o.results = c.d_red2;
+    o.pairs   = rt().red_exact;
+    if ((ierr = launch_gropp_update(r, z, s, d, dconst, normkind, dev_gamma, dev_t, dev_alpha_out, n, o))) return ierr;
+  } else HIPX_HIP(hipMemsetAsync(c.d_red2, 0, sizeof(double) * 4, rt().compute));
+  return allreduce_begin(2, red_pairs());
+}
+
 int hipxVecMDotAllreduceBegin(const double *x, hipx_int nv, const double *const *y, hipx_int n, int slot)
 {
   HIPX_CHECK_INIT();

@@ -70,6 +70,10 @@ int launch_cg_fused_dev_nosignal(double *x, double *r, double *z, const double *
 // hipx_pipe.hip: the PIPECG update kernel with an explicit reduction destination (hipx_comm.hip redirects the sums to the all-reduce staging line)
 int launch_pipecg_update(const hipxPipeCGVecs *v, const double *d, double dconst, int normkind, int first, const double *dev_sums, const double *dev_sums_old, const double *dev_alpha_old,
                          double *dev_alpha_out, hipx_int n, const RedOut &o);
+int launch_gropp_dir(double *p, double *s, double *x, const double *z, const double *Z, const double *dev_gamma_new, const double *dev_gamma_old, const double *dev_alpha_old, hipx_int n,
+                     const RedOut &o);
+int launch_gropp_update(double *r, double *z, const double *s, const double *d, double dconst, int normkind, const double *dev_gamma, const double *dev_t, double *dev_alpha_out, hipx_int n,
+                        const RedOut &o);
 int red_signal(int slot, const double *dev_results, int nvals, double *dres = nullptr);  // enqueue: publish to the host (values, then sequence flag) and optionally to device memory, stream-ordered
 int red_wait(int slot, int nvals, double *out);
 

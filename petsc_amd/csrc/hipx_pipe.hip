@@ -305,6 +305,142 @@ void pipecg_go0(const PipeCGArgs &a, int pc, int nrm, hipx_int n, bool vec, cons
   else pipecg_go1<FIRST, 2>(a, nrm, n, vec, o);
 }
 
+// ---------------------------------------------------------------- Gropp's CG (groppcg.c:23-140), scalars on the device
+// The reference's iteration i:  t = p.s [reduction 1] || S = B s;  alpha = gamma / t;  x += alpha p; r -= alpha s; z -= alpha S;
+//                               dp, gammaNew = r.z [reduction 2] || Z = A z;  test;  beta = gammaNew / gamma;  p = z + beta p; s = Z + beta s.
+// Two passes per iteration here (+ the product Z = A z between them):
+//   gropp_dir_kernel     D(i), i > 1: x += alpha_{i-1} p (the update iteration i-1 left behind, applied before p changes); p = z + beta p; s = Z + beta s with
+//                        beta = gammaNew_{i-1} / gamma_{i-2} (groppcg.c:132: formed on the device); partial sums of t_i = p.s.  5 reads + 3 writes.
+//   gropp_update_kernel  U(i): alpha_i = gamma_{i-1} / t_i (groppcg.c:96, on the device; one thread stores it); r -= alpha s; z -= alpha (s .* d) -- S = B s of groppcg.c:92
+//                        re-formed per element, never stored (PC 0: PCNONE S = s, 1: constant Jacobi diagonal, 2: streamed) --; sums dp (z.z | r.r | none), gammaNew = r.z.
+//                        3 reads + 2 writes (+ d).
+// Element by element the operations and their order are the reference's (VecAXPY y + a x, VecAYPX x + b y, VecPointwiseMult x * y): the vectors are bit-identical.
+struct GroppDirArgs {
+  double       *p, *s, *x;
+  const double *z, *Z;
+  const double *gnew, *gold, *alpha_old;  // device scalars: gammaNew_{i-1}, gamma_{i-2}, alpha_{i-1}
+};
+template <bool COMP>
+__global__ __launch_bounds__(kRedThreads) void gropp_dir_kernel(const GroppDirArgs a, hipx_int n, bool vec, RedOut out)
+{
+  const double beta = *a.gnew / *a.gold, aold = *a.alpha_old;
+  Acc<COMP>    acc[1];
+  const auto   one = [&](double &p, double &s, double &x, const double z, const double Zv) {
+    x = x + aold * p;
+    p = z + beta * p;
+    s = Zv + beta * s;
+    acc[0].prod(p, s);
+  };
+  const hipx_int stride = (hipx_int)gridDim.x * kRedThreads;
+  if (vec) {
+    constexpr int  U  = 2;  // pairs per stream in flight per thread (all loads of a round issued before the first use: 10 x 16 B per thread)
+    const hipx_int n2 = n >> 1;
+    for (hipx_int i0 = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x; i0 < n2; i0 += U * stride) {
+      double2 p[U], s[U], x[U], z[U], Zv[U];
+#pragma unroll
+      for (int k = 0; k < U; k++) {
+        const hipx_int i = i0 + k * stride < n2 ? i0 + k * stride : i0;
+        p[k]  = reinterpret_cast<const double2 *>(a.p)[i];
+        s[k]  = reinterpret_cast<const double2 *>(a.s)[i];
+        x[k]  = reinterpret_cast<const double2 *>(a.x)[i];
+        z[k]  = reinterpret_cast<const double2 *>(a.z)[i];
+        Zv[k] = reinterpret_cast<const double2 *>(a.Z)[i];
+      }
+#pragma unroll
+      for (int k = 0; k < U; k++) {
+        const hipx_int i = i0 + k * stride;
+        if (i < n2) {
+          one(p[k].x, s[k].x, x[k].x, z[k].x, Zv[k].x);
+          one(p[k].y, s[k].y, x[k].y, z[k].y, Zv[k].y);
+          reinterpret_cast<double2 *>(a.x)[i] = x[k];
+          reinterpret_cast<double2 *>(a.p)[i] = p[k];
+          reinterpret_cast<double2 *>(a.s)[i] = s[k];
+        }
+      }
+    }
+  }
+  for (hipx_int i = (vec ? (n & ~(hipx_int)1) : 0) + (hipx_int)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += stride) {
+    double p = a.p[i], s = a.s[i], x = a.x[i];
+    one(p, s, x, a.z[i], a.Z[i]);
+    a.x[i] = x;
+    a.p[i] = p;
+    a.s[i] = s;
+  }
+  finish_sums<1, COMP>(acc, out);
+}
+
+struct GroppUpdArgs {
+  double       *r, *z;
+  const double *s, *d;
+  double        dconst;
+  const double *gamma, *t;  // device scalars: gamma_{i-1}, t_i
+  double       *alpha_out;
+};
+template <int PC, int NRM, bool COMP>
+__global__ __launch_bounds__(kRedThreads) void gropp_update_kernel(const GroppUpdArgs a, hipx_int n, bool vec, RedOut out)
+{
+  const double alpha = *a.gamma / *a.t, ma = -alpha;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.alpha_out = alpha;
+  Acc<COMP>  acc[2];
+  const auto one = [&](double &r, double &z, const double s, const double dd) {
+    const double S = (PC == 0) ? s : s * dd;
+    r = r + ma * s;
+    z = z + ma * S;
+    if (NRM == 1) acc[0].prod(z, z);
+    else if (NRM == 2) acc[0].prod(r, r);
+    acc[1].prod(r, z);
+  };
+  const hipx_int stride = (hipx_int)gridDim.x * kRedThreads;
+  if (vec) {
+    constexpr int  U  = (PC == 2) ? 2 : 4;  // pairs per stream in flight per thread (12 / 8 x 16 B)
+    const hipx_int n2 = n >> 1;
+    for (hipx_int i0 = (hipx_int)blockIdx.x * kRedThreads + threadIdx.x; i0 < n2; i0 += U * stride) {
+      double2 r[U], z[U], s[U], dd[U];
+#pragma unroll
+      for (int k = 0; k < U; k++) {
+        const hipx_int i = i0 + k * stride < n2 ? i0 + k * stride : i0;
+        r[k]  = reinterpret_cast<const double2 *>(a.r)[i];
+        z[k]  = reinterpret_cast<const double2 *>(a.z)[i];
+        s[k]  = reinterpret_cast<const double2 *>(a.s)[i];
+        dd[k] = (PC == 2) ? reinterpret_cast<const double2 *>(a.d)[i] : make_double2(a.dconst, a.dconst);
+      }
+#pragma unroll
+      for (int k = 0; k < U; k++) {
+        const hipx_int i = i0 + k * stride;
+        if (i < n2) {
+          one(r[k].x, z[k].x, s[k].x, dd[k].x);
+          one(r[k].y, z[k].y, s[k].y, dd[k].y);
+          reinterpret_cast<double2 *>(a.r)[i] = r[k];
+          reinterpret_cast<double2 *>(a.z)[i] = z[k];
+        }
+      }
+    }
+  }
+  for (hipx_int i = (vec ? (n & ~(hipx_int)1) : 0) + (hipx_int)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += stride) {
+    double r = a.r[i], z = a.z[i];
+    one(r, z, a.s[i], (PC == 2) ? a.d[i] : a.dconst);
+    a.r[i] = r;
+    a.z[i] = z;
+  }
+  finish_sums<2, COMP>(acc, out);
+}
+
+template <int PC>
+void gropp_update_go(const GroppUpdArgs &a, int nrm, hipx_int n, bool vec, const RedOut &o)
+{
+  const unsigned g = pipe_grid(n);
+  hipStream_t    st = rt().compute;
+  if (rt().red_exact) {
+    if (nrm == 1) gropp_update_kernel<PC, 1, true><<<g, kRedThreads, 0, st>>>(a, n, vec, o);
+    else if (nrm == 2) gropp_update_kernel<PC, 2, true><<<g, kRedThreads, 0, st>>>(a, n, vec, o);
+    else gropp_update_kernel<PC, 0, true><<<g, kRedThreads, 0, st>>>(a, n, vec, o);
+  } else {
+    if (nrm == 1) gropp_update_kernel<PC, 1, false><<<g, kRedThreads, 0, st>>>(a, n, vec, o);
+    else if (nrm == 2) gropp_update_kernel<PC, 2, false><<<g, kRedThreads, 0, st>>>(a, n, vec, o);
+    else gropp_update_kernel<PC, 0, false><<<g, kRedThreads, 0, st>>>(a, n, vec, o);
+  }
+}
+
 }  // namespace
 
 int hipx::launch_pipecg_update(const hipxPipeCGVecs *v, const double *d, double dconst, int normkind, int first, const double *dev_sums, const double *dev_sums_old, const double *dev_alpha_old,
@@ -338,6 +474,32 @@ static int batch_find(int nops, const int *kind, const int *yslot, const int *xs
     if (same) return p;
   }
   return -1;
+}
+
+int hipx::launch_gropp_dir(double *p, double *s, double *x, const double *z, const double *Z, const double *dev_gamma_new, const double *dev_gamma_old, const double *dev_alpha_old, hipx_int n,
+                           const RedOut &o)
+{
+  GroppDirArgs a;
+  a.p = p; a.s = s; a.x = x; a.z = z; a.Z = Z;
+  a.gnew = dev_gamma_new; a.gold = dev_gamma_old; a.alpha_old = dev_alpha_old;
+  const bool vec = n >= 2 && aligned16(p) && aligned16(s) && aligned16(x) && aligned16(z) && aligned16(Z);
+  if (rt().red_exact) gropp_dir_kernel<true><<<pipe_grid(n), kRedThreads, 0, rt().compute>>>(a, n, vec, o);
+  else gropp_dir_kernel<false><<<pipe_grid(n), kRedThreads, 0, rt().compute>>>(a, n, vec, o);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+int hipx::launch_gropp_update(double *r, double *z, const double *s, const double *d, double dconst, int normkind, const double *dev_gamma, const double *dev_t, double *dev_alpha_out, hipx_int n,
+                              const RedOut &o)
+{
+  GroppUpdArgs a;
+  a.r = r; a.z = z; a.s = s; a.d = d; a.dconst = dconst; a.gamma = dev_gamma; a.t = dev_t; a.alpha_out = dev_alpha_out;
+  const bool vec = n >= 2 && aligned16(r) && aligned16(z) && aligned16(s) && aligned16(d);
+  if (d) gropp_update_go<2>(a, normkind, n, vec, o);
+  else if (dconst == 1.0) gropp_update_go<0>(a, normkind, n, vec, o);
+  else gropp_update_go<1>(a, normkind, n, vec, o);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
 }
 
 extern "C" {
@@ -385,6 +547,24 @@ int hipxVecBatchAXPYDotsBegin(int nops, const int *kind, const int *yslot, const
     db[d] = P.db[d];
   }
   return HIPX_SUCCESS;
+}
+
+int hipxGroppCGDirectionBegin(double *p, double *s, double *x, const double *z, const double *Z, const double *dev_gamma_new, const double *dev_gamma_old, const double *dev_alpha_old, hipx_int n,
+                              int slot, double *dev_t_out)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(p && s && x && z && Z && dev_gamma_new && dev_gamma_old && dev_alpha_old && dev_t_out, "null argument");
+  HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2 && n > 0, "bad slot / empty vector");
+  return launch_gropp_dir(p, s, x, z, Z, dev_gamma_new, dev_gamma_old, dev_alpha_old, n, red_out(slot, true, dev_t_out));
+}
+
+int hipxGroppCGUpdateBegin(double *r, double *z, const double *s, const double *d, double dconst, int normkind, const double *dev_gamma, const double *dev_t, double *dev_alpha_out, hipx_int n,
+                           int slot, double *dev_sums2_out)
+{
+  HIPX_CHECK_INIT();
+  HIPX_ARG(r && z && s && dev_gamma && dev_t && dev_alpha_out && dev_sums2_out, "null argument");
+  HIPX_ARG(slot >= 0 && slot < HIPX_MAX_RED_SLOTS - 2 && n > 0, "bad slot / empty vector");
+  return launch_gropp_update(r, z, s, d, dconst, normkind, dev_gamma, dev_t, dev_alpha_out, n, red_out(slot, true, dev_sums2_out));
 }
 
 int hipxPipeCGUpdateBegin(const hipxPipeCGVecs *v, const double *d, double dconst, int normkind, int first, const double *dev_sums, const double *dev_sums_old, const double *dev_alpha_old,

@@ -972,6 +972,127 @@ int HipxKSPSolve_PIPECG(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, d
 #undef PALPHA
 }
 
+/* ---- KSPSolve_GROPPCG (groppcg.c:23-140: Gropp's asynchronous CG) over device vectors, launch-ahead (round 6).
+   Per iteration i on the compute stream (csrc/hipx_pipe.hip):
+     D(i)  i > 1: x += alpha_{i-1} p ; p = z + beta p ; s = Z + beta s ; t_i = p.s   (groppcg.c:132-136 of iteration i-1 + the x update it left behind + groppcg.c:87;
+           i = 1: t_1 = p.s alone);  several ranks: t all-reduced on the stream
+     U(i)  alpha_i = gamma_{i-1} / t_i ; r -= alpha s ; z -= alpha (B s) ; dp, gammaNew_i = r.z   (groppcg.c:96-108; S = B s re-formed per element: PCJACOBI / PCNONE);
+           several ranks: the two sums START their all-reduce here ...
+     S(i)  Z = A z                                                                     (groppcg.c:111)
+           ... and it ENDS here (hipxAllreduceEnd): reduction 2 hidden behind the product, as PetscCommSplitReductionBegin ... VecDotEnd hide it in the reference.
+   alpha and beta are formed on the device; the host enqueues iteration i + 1 before it waits for iteration i's sums (ksp->pipeline), logs dp_i and runs the
+   convergence test one step behind.  The x update of iteration i is applied by D(i + 1) or by the flush at the end (alpha_i = gamma_{i-1} / t_i re-formed on the
+   host: the same IEEE quotient), so what is queued ahead when the loop stops has applied exactly the updates of completed iterations.  13 vector passes + the
+   product per iteration against the reference loop's 20 (one kernel per call, S stored).  Elementwise bit-identical to the reference; history equal to
+   reference + exact BLAS in the exact reduction mode (tests/test_gpu_pipecg.py). */
+int HipxKSPSolve_GROPPCG(HipxKSP *ksp, HipxMat *A, HipxPC *pc, const double *B, double *X)
+{
+  const hipx_int n    = A->m;
+  const size_t   npad = ((size_t)n + 1) & ~(size_t)1;
+  const int      nrm  = ksp->normtype == HIPX_KSP_NORM_PRECONDITIONED ? 1 : (ksp->normtype == HIPX_KSP_NORM_UNPRECONDITIONED ? 2 : 0);
+  enum { SLOT_T = 8, SLOT_U = 10 }; /* reduction slots by iteration parity: t_i in 8 / 9, {dp, gammaNew_i} in 10 / 11 */
+  double        *r, *p, *s, *z, *Z, *ds;
+  const double  *dinv;
+  double         dp = 0.0, gamma = 0.0, gammaNew = 0.0, gamma_im1 = 0.0, sums[2], t = 0.0;
+  int            ahead = 0, xpend = 0;
+  hipx_int       i;
+
+  if (pc->type != HIPX_PC_NONE && pc->type != HIPX_PC_JACOBI) return HIPX_ERR_SUP;
+  if (n <= 0 && A->nranks <= 1) return HIPX_ERR_ARG;
+  CHK(ensure_pipe_work(ksp, n));
+  r = ksp->pipe_slab; p = r + npad; s = p + npad; z = s + npad; Z = z + npad;
+  ds = ksp->dscal; /* [0..6): {dp, gamma} of three consecutive iterations; [6], [7]: t by parity; [8], [9]: alpha by parity */
+#define GSUMS(k) (ds + 2 * (int)((k) % 3))
+#define GT(k) (ds + 6 + (int)((k) & 1))
+#define GALPHA(k) (ds + 8 + (int)((k) & 1))
+  dinv = (pc->type == HIPX_PC_JACOBI && !(pc->dconst_valid && !getenv("HIPX_NO_DCONST"))) ? pc->dinv : NULL;
+  ksp->its    = 0;
+  ksp->reason = 0;
+  ksp->hist_n = 0;
+  if (!ksp->guess_nonzero) CHK(hipxVecSet(X, n, 0.0));
+  if (ksp->guess_nonzero) {
+    CHK(HipxMatMult(A, X, r));       /* groppcg.c:48 */
+    CHK(hipxVecAYPX(r, -1.0, B, n)); /* groppcg.c:49 */
+  } else CHK(hipxVecCopy(B, r, n));  /* groppcg.c:51 */
+  CHK(HipxPCApply(pc, A, r, z));     /* groppcg.c:54 */
+  CHK(hipxVecCopy(z, p, n));         /* groppcg.c:55 */
+  CHK(HipxVecDot(A, r, z, n, &gamma)); /* groppcg.c:56-59 */
+  CHK(HipxMatMult(A, p, s));           /* groppcg.c:58 */
+  switch (ksp->normtype) {             /* groppcg.c:61-80 */
+  case HIPX_KSP_NORM_PRECONDITIONED:
+    CHK(HipxVecNorm2(A, z, n, &dp));
+    break;
+  case HIPX_KSP_NORM_UNPRECONDITIONED:
+    CHK(HipxVecNorm2(A, r, n, &dp));
+    break;
+  case HIPX_KSP_NORM_NATURAL:
+    if (isnan(gamma) || isinf(gamma)) { /* KSPCheckDot */
+      ksp->reason = KSP_DIVERGED_NANORINF;
+      return 0;
+    }
+    dp = sqrt(fabs(gamma));
+    break;
+  default:
+    dp = 0.0;
+  }
+  log_history(ksp, dp);
+  ksp->rnorm = dp;
+  CHK(converged_default(ksp, A, pc, 0, dp, B, &ksp->reason)); /* groppcg.c:84 */
+  if (ksp->reason) return 0;
+  CHK(hipxMemcpyHtoD(GSUMS(0) + 1, &gamma, sizeof(double))); /* gamma_0 for U(1) and D(2) */
+  i = 0;
+  do {
+    ksp->its = i + 1;
+    i++;
+    gamma_im1 = gamma;
+    const int had = ahead;
+    ahead         = 0;
+    for (int ka = had ? 1 : 0; ka < 2; ka++) { /* ka = 0: this iteration's kernels (unless queued ahead); ka = 1: the next iteration's, before the host looks at this one's sums */
+      const hipx_int k = i + ka;
+      if (ka == 1 && !(ksp->pipeline && k <= ksp->max_it)) break;
+      if (k == 1) { /* t_1 = p.s (groppcg.c:87) */
+        const double *ys[1] = {s};
+        if (A->nranks > 1) CHK(hipxVecMDotBeginAllreduce(p, 1, ys, n, SLOT_T + (int)(k & 1), GT(k)));
+        else CHK(hipxVecMDotBegin(p, 1, ys, n, SLOT_T + (int)(k & 1), GT(k)));
+      } else if (A->nranks > 1) CHK(hipxGroppCGDirectionBeginAllreduce(p, s, X, z, Z, GSUMS(k - 1) + 1, GSUMS(k - 2) + 1, GALPHA(k - 1), n, SLOT_T + (int)(k & 1), GT(k)));
+      else CHK(hipxGroppCGDirectionBegin(p, s, X, z, Z, GSUMS(k - 1) + 1, GSUMS(k - 2) + 1, GALPHA(k - 1), n, SLOT_T + (int)(k & 1), GT(k)));
+      if (A->nranks > 1) CHK(hipxGroppCGUpdateBeginAllreduce(r, z, s, dinv, pc->dconst, nrm, GSUMS(k - 1) + 1, GT(k), GALPHA(k), n, SLOT_U + (int)(k & 1)));
+      else CHK(hipxGroppCGUpdateBegin(r, z, s, dinv, pc->dconst, nrm, GSUMS(k - 1) + 1, GT(k), GALPHA(k), n, SLOT_U + (int)(k & 1), GSUMS(k)));
+      CHK(HipxMatMult(A, z, Z)); /* groppcg.c:111 */
+      if (A->nranks > 1) CHK(hipxAllreduceEnd(SLOT_U + (int)(k & 1), 2, GSUMS(k)));
+      ahead = ka; /* (1 after the second pass: iteration i + 1 is queued) */
+    }
+    xpend = 1; /* U(i) is queued: x += alpha_i p_i waits for D(i + 1) or for the flush */
+    CHK(hipxRedEnd(SLOT_U + (int)(i & 1), 2, sums)); /* {dp^2, gammaNew_i} */
+    if (A->nranks > 1) CHK(hipxCommCheckError());
+    gammaNew = sums[1];
+    if (ksp->normtype == HIPX_KSP_NORM_NATURAL) {
+      if (isnan(gammaNew) || isinf(gammaNew)) { /* KSPCheckDot, groppcg.c:120 */
+        ksp->reason = KSP_DIVERGED_NANORINF;
+        break;
+      }
+      dp = sqrt(fabs(gammaNew));
+    } else if (ksp->normtype == HIPX_KSP_NORM_NONE) dp = 0.0;
+    else dp = sqrt(sums[0]);
+    ksp->rnorm = dp;
+    log_history(ksp, dp);
+    CHK(converged_default(ksp, A, pc, i, dp, B, &ksp->reason)); /* groppcg.c:129 */
+    if (ksp->reason) break;
+    gamma = gammaNew; /* groppcg.c:133 (beta and the p, s updates are D(i + 1)'s) */
+  } while (i < ksp->max_it);
+  if (ahead) xpend = 0; /* D(i + 1), queued ahead, applies x += alpha_i p_i: exactly the update that was due */
+  CHK(hipxStreamSynchronize());
+  if (xpend && n > 0) { /* groppcg.c:98 of the last iteration: alpha_i = gamma_{i-1} / t_i, the quotient U(i) formed */
+    CHK(hipxMemcpyDtoH(&t, GT(i), sizeof(double)));
+    CHK(hipxVecAXPY(X, gamma_im1 / t, p, n));
+  }
+  if (!ksp->reason && i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS; /* groppcg.c:139 */
+  return 0;
+#undef GSUMS
+#undef GT
+#undef GALPHA
+}
+
 /* KSPSolve_Chebyshev_FirstKind (cheby.c:389-555), statement by statement, with the eigenvalue bounds given (-ksp_chebyshev_eigenvalues /
    KSPChebyshevSetEigenvalues: cheby.c:40-62 returns them as they are).  With no norm requested (the smoother configuration:
    KSP_NORM_NONE) and PCJACOBI or PCNONE an iteration is the SpMV plus ONE elementwise kernel (hipxVecChebyshevStep: residual, PC

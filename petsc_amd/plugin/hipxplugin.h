@@ -95,6 +95,7 @@ PETSC_INTERN PetscErrorCode MatCreate_MPIAIJHIPX(Mat);
 PETSC_INTERN PetscErrorCode PCCreate_JacobiHIPX(PC);
 PETSC_INTERN PetscErrorCode PCCreate_PBJacobiHIPX(PC); /* "pbjacobihipx": PCPBJACOBI with the apply on the device */
 PETSC_INTERN PetscErrorCode KSPCreate_CGHIPX(KSP); /* "cghipx": KSPCG with the fused device kernels on the hot-path configuration */
+PETSC_INTERN PetscErrorCode KSPCreate_GROPPCGHIPX(KSP); /* "groppcghipx": KSPGROPPCG on two fused passes + one product per iteration, launch-ahead (round 6) */
 PETSC_INTERN PetscErrorCode KSPCreate_PIPECGHIPX(KSP); /* "pipecghipx": KSPPIPECG on one fused update kernel + one product per iteration, launch-ahead (round 6) */
 PETSC_INTERN PetscErrorCode KSPCreate_ChebyshevHIPX(KSP); /* "chebyshevhipx": KSPCHEBYSHEV, first kind without norms on one fused kernel per iteration */
 PETSC_INTERN PetscErrorCode MatSeqAIJHIPXGetDeviceMat(Mat A, hipxMat *dA); /* uploads / refreshes the device CSR */

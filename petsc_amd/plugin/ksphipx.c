@@ -320,7 +320,7 @@ static PetscBool KSPPIPECGHIPXApplicable(KSP ksp, Mat *Aout, PetscBool *none)
   PetscMPIInt  size;
 
   if (ksp->calc_sings || ksp->pc_side != PC_LEFT || ksp->transpose_solve || ksp->dscale || ksp->numbermonitors || ksp->chknorm >= 0 || ksp->lagnorm) return PETSC_FALSE;
-  if (ksp->converged != KSPConvergedDefault || !ksp->cnvP || getenv("HIPX_PIPECGHIPX_PARENT")) return PETSC_FALSE;
+  if (ksp->converged != KSPConvergedDefault || !ksp->cnvP || getenv("HIPX_HOSTLOOP_PARENT")) return PETSC_FALSE;
   {
     KSPConvergedDefaultCtx *cctx = (KSPConvergedDefaultCtx *)ksp->cnvP;
     if (cctx->initialrtol || cctx->mininitialrtol || cctx->convmaxits) return PETSC_FALSE;
@@ -353,7 +353,8 @@ static PetscBool KSPPIPECGHIPXApplicable(KSP ksp, Mat *Aout, PetscBool *none)
   return PETSC_TRUE;
 }
 
-static PetscErrorCode KSPSolve_PIPECGHIPX(KSP ksp)
+typedef int (*HipxHostSolve)(HipxKSP *, HipxMat *, HipxPC *, const double *, double *);
+static PetscErrorCode KSPSolve_HostLoopHIPX(KSP ksp, PetscErrorCode (*parent)(KSP), HipxHostSolve solver, const char *what)
 {
   Mat                Amat = NULL;
   PetscBool          isnone = PETSC_FALSE;
@@ -373,8 +374,8 @@ static PetscErrorCode KSPSolve_PIPECGHIPX(KSP ksp)
 
   PetscFunctionBegin;
   if (!KSPPIPECGHIPXApplicable(ksp, &Amat, &isnone)) {
-    PetscCall(PetscInfo(ksp, "KSPPIPECGHIPX: configuration outside the fused path, running the reference KSPSolve_PIPECG\n"));
-    PetscCall((*parent_solve_pipecg)(ksp));
+    PetscCall(PetscInfo(ksp, "%s: configuration outside the fused path, running the reference's loop\n", what));
+    PetscCall((*parent)(ksp));
     PetscFunctionReturn(PETSC_SUCCESS);
   }
   PetscCallMPI(MPI_Comm_size(PetscObjectComm((PetscObject)ksp), &size));
@@ -406,7 +407,7 @@ static PetscErrorCode KSPSolve_PIPECGHIPX(KSP ksp)
   PetscCall(VecHIPXGetDeviceRead(ksp->vec_rhs, &db, &tb));
   PetscCall(VecHIPXGetDeviceReadWrite(ksp->vec_sol, &dx, &tx));
   ksp->its = 0;
-  herr     = HipxKSPSolve_PIPECG(&k, &M, &hpc, db, dx);
+  herr     = (*solver)(&k, &M, &hpc, db, dx);
   if (herr) PetscCall(PetscStrncpy(herrmsg, hipxGetErrorString(), sizeof(herrmsg)));
   else {
     for (hipx_int e = 0; e < k.hist_n && e < hl; e++) PetscCall(KSPLogResidualHistory(ksp, hist[e]));
@@ -431,6 +432,36 @@ static PetscErrorCode KSPSolve_PIPECGHIPX(KSP ksp)
   PetscCall(PetscObjectStateIncrease((PetscObject)ksp->vec_sol));
   PetscCheck(herr != HIPX_ERR_SUP, PetscObjectComm((PetscObject)ksp), PETSC_ERR_SUP, "libhipx: %s", herrmsg);
   PetscCheck(!herr, PetscObjectComm((PetscObject)ksp), PETSC_ERR_GPU, "libhipx: %s", herrmsg);
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode KSPSolve_PIPECGHIPX(KSP ksp)
+{
+  PetscFunctionBegin;
+  PetscCall(KSPSolve_HostLoopHIPX(ksp, parent_solve_pipecg, HipxKSPSolve_PIPECG, "KSPPIPECGHIPX"));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* ---- KSPGROPPCGHIPX ("groppcghipx", round 6): KSPGROPPCG (groppcg.c:23-140) on the host layer's launch-ahead loop -- two fused passes (direction + t; update + dp,
+   gammaNew with S = B s re-formed per element) and one product per iteration, alpha / beta on the device, reduction 2 hidden behind the product -- under the same
+   conditions as pipecghipx; the reference's KSPSolve_GROPPCG (its update blocks as batch kernels of the lazy queue) otherwise. */
+static PetscErrorCode (*parent_solve_groppcg)(KSP) = NULL;
+static PetscErrorCode KSPSolve_GROPPCGHIPX(KSP ksp)
+{
+  PetscFunctionBegin;
+  PetscCall(KSPSolve_HostLoopHIPX(ksp, parent_solve_groppcg, HipxKSPSolve_GROPPCG, "KSPGROPPCGHIPX"));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PETSC_EXTERN PetscErrorCode KSPCreate_GROPPCG(KSP); /* groppcg.c:166: exported by libpetsc */
+
+PetscErrorCode KSPCreate_GROPPCGHIPX(KSP ksp)
+{
+  PetscFunctionBegin;
+  PetscCall(VecHIPXInitRuntime());
+  PetscCall(KSPCreate_GROPPCG(ksp));
+  if (!parent_solve_groppcg) parent_solve_groppcg = ksp->ops->solve;
+  ksp->ops->solve = KSPSolve_GROPPCGHIPX;
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 

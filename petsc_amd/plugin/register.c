@@ -26,6 +26,7 @@ PETSC_EXTERN PetscErrorCode HIPX_PLUGIN_REGISTER(void)
   PetscCall(KSPRegister("cghipx", KSPCreate_CGHIPX));
   PetscCall(KSPRegister("chebyshevhipx", KSPCreate_ChebyshevHIPX));
   PetscCall(KSPRegister("pipecghipx", KSPCreate_PIPECGHIPX));
+  PetscCall(KSPRegister("groppcghipx", KSPCreate_GROPPCGHIPX));
   PetscCall(PetscSFInitializePackage()); /* registers "basic", whose creator the hipx type builds on */
   PetscCall(PetscSFRegister(PETSCSFHIPX, PetscSFCreate_HIPX));
   PetscFunctionReturn(PETSC_SUCCESS);

@@ -68,6 +68,7 @@ def jobs():
         J["%s_jacobi_7pt_64" % kk] = (lambda kk=kk: entry(ref_shim(7, 64, kk, "jacobi", 40), "reference+shim", "7-pt Poisson 64^3, KSP%s + PCJACOBI; 40 iterations" % kk.upper()))
         J["%s_jacobi_7pt_128" % kk] = (lambda kk=kk: entry(ref_shim(7, 128, kk, "jacobi", 40), "reference+shim", "7-pt Poisson 128^3, KSP%s + PCJACOBI; 40 iterations" % kk.upper()))
         J["%s_jacobi_27pt_96" % kk] = (lambda kk=kk: entry(ref_shim(27, 96, kk, "jacobi", 30), "reference+shim", "27-pt (bench_kspsolve.c) 96^3, KSP%s + PCJACOBI; 30 iterations" % kk.upper()))
+    J["groppcg_jacobi_7pt_256"] = lambda: entry(ref_shim(7, 256, "groppcg", "jacobi", 40), "reference+shim", "BASELINE config 2's system under KSPGROPPCG: 7-pt Poisson 256^3 + PCJACOBI; 40 iterations")
     J["pipecg_jacobi_7pt_256"] = lambda: entry(ref_shim(7, 256, "pipecg", "jacobi", 40), "reference+shim", "BASELINE config 2's system under KSPPIPECG: 7-pt Poisson 256^3 + PCJACOBI; 40 iterations")
     J["cg_jacobi_27pt_160"] = lambda: entry(ref_shim(27, 160, "cg", "jacobi", 40), "reference+shim", "27-pt (bench_kspsolve.c) 160^3, KSPCG + PCJACOBI; 40 iterations")
     J["cg_jacobi_7pt_512"] = lambda: stream("7pt", 512, 512 ** 3, "jacobi", 24, "7-pt Poisson 512^3 (134 M rows), KSPCG + PCJACOBI; 24 iterations")

@@ -131,8 +131,9 @@ def test_pipecg_on_two_ranks_through_bench_py():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "64", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-traffic", "--no-plugin",
                         "--no-general", "--budget-s", "300"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200, env=clean_env(), cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:]
-    leg = last_json(r.stdout)["other_configs"]["headline_pipecg_launch_ahead"]
-    assert leg.get("iterations_per_s", 0) > 0 and leg["parity"]["pass"] is True, leg
+    for name in ("headline_pipecg_launch_ahead", "headline_groppcg_launch_ahead"):
+        leg = last_json(r.stdout)["other_configs"][name]
+        assert leg.get("iterations_per_s", 0) > 0 and leg["parity"]["pass"] is True, (name, leg)
 
 
 def test_gmres_sor_on_two_and_four_ranks_follows_the_exact_yardstick_at_1e12():

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "exact_histories.json")))
 
 
-def solve_pipecg(ai, aj, aa, b, pc="jacobi", rtol=1e-5, max_it=10000, normtype=1, pipeline=1, x0=None, exact=False):
+def solve_pipecg(ai, aj, aa, b, pc="jacobi", rtol=1e-5, max_it=10000, normtype=1, pipeline=1, x0=None, exact=False, kind="pipecg"):
     from petsc_amd import _lib
     hx, ks = _lib.load()
     N = len(ai) - 1
@@ -41,7 +41,7 @@ def solve_pipecg(ai, aj, aa, b, pc="jacobi", rtol=1e-5, max_it=10000, normtype=1
         X = _lib.DVec(N, x0 if x0 is not None else np.zeros(N))
         k.guess_nonzero = 0 if x0 is None else 1
         _lib.chk(ks.HipxPCSetUp(C.byref(p), C.byref(M)))
-        _lib.chk(ks.HipxKSPSolve_PIPECG(C.byref(k), C.byref(M), C.byref(p), B.ptr, X.ptr))
+        _lib.chk({"pipecg": ks.HipxKSPSolve_PIPECG, "groppcg": ks.HipxKSPSolve_GROPPCG}[kind](C.byref(k), C.byref(M), C.byref(p), B.ptr, X.ptr))
         x = X.get()
         out = (x, int(k.its), int(k.reason), hist[:k.hist_n].copy())
         ks.HipxKSPDestroyWork(C.byref(k))
@@ -63,6 +63,29 @@ def system(kind, n, scale=None):
         rows = np.repeat(np.arange(N), np.diff(ai))
         aa = aa * d[rows] * d[aj]
     b = orc.matmult(ai, aj, aa, np.ones(len(ai) - 1))
+    return ai, aj, aa, b
+
+
+def golden_system(kind, n):
+    """the operator and b = A * 1 of a committed golden history; 256^3 is assembled by the host layer's own driver loops (no 1.9 GB of Python lists)"""
+    from petsc_amd import _lib
+    hx, ks = _lib.load()
+    N = n ** 3
+    if n < 200:
+        ai, aj, aa = orc.stencil(kind, n)
+        return ai, aj, aa, orc.matmult(ai, aj, aa, np.ones(N))
+    assert kind == "7pt"
+    ai = np.zeros(N + 1, np.int32)
+    nnz = ks.HipxAssemble_poisson7(n, 0, N, None, None, None)
+    aj, aa = np.zeros(nnz, np.int32), np.zeros(nnz)
+    ks.HipxAssemble_poisson7(n, 0, N, ai.ctypes.data_as(C.c_void_p), aj.ctypes.data_as(C.c_void_p), aa.ctypes.data_as(C.c_void_p))
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    one, bb = _lib.DVec(N, np.ones(N)), _lib.DVec(N)
+    _lib.chk(hx.hipxMatMult(A, one.ptr, bb.ptr))
+    b = bb.get()
+    one.free()
+    bb.free()
+    _lib.mat_destroy(A)
     return ai, aj, aa, b
 
 
@@ -116,27 +139,7 @@ def test_pipecg_against_the_reference_with_exact_blas(hx, key, kind, n, its):
     """The committed histories of the REFERENCE's KSPSolve_PIPECG + exact BLAS (tests/golden/make_exact_golden.py), at up to BASELINE config 2's size."""
     if key not in GOLD:
         pytest.skip("golden %s not generated" % key)
-    from petsc_amd import _lib
-    _, ks = _lib.load()
-    N = n ** 3
-    if n >= 200:  # assembled by the host layer's own driver loops (no 1.9 GB of Python lists)
-        ai = np.zeros(N + 1, np.int32)
-        nnz = ks.HipxAssemble_poisson7(n, 0, N, None, None, None)
-        aj = np.zeros(nnz, np.int32)
-        aa = np.zeros(nnz)
-        ks.HipxAssemble_poisson7(n, 0, N, ai.ctypes.data_as(C.c_void_p), aj.ctypes.data_as(C.c_void_p), aa.ctypes.data_as(C.c_void_p))
-        b = np.zeros(N)
-        hx = _lib.load()[0]
-        A = _lib.mat_create_csr(N, N, ai, aj, aa)
-        one, bb = _lib.DVec(N, np.ones(N)), _lib.DVec(N)
-        _lib.chk(hx.hipxMatMult(A, one.ptr, bb.ptr))
-        b = bb.get()
-        one.free()
-        bb.free()
-        _lib.mat_destroy(A)
-    else:
-        ai, aj, aa = orc.stencil(kind, n)
-        b = orc.matmult(ai, aj, aa, np.ones(N))
+    ai, aj, aa, b = golden_system(kind, n)
     href = np.array([float.fromhex(v) for v in GOLD[key]["history_hex"]])
     xg, it, reason, hg = solve_pipecg(ai, aj, aa, b, pc="jacobi", rtol=1e-50, max_it=its, exact=True)
     assert len(hg) == len(href) == its + 1 and (it, reason) == (its + 1, -3)
@@ -145,6 +148,55 @@ def test_pipecg_against_the_reference_with_exact_blas(hx, key, kind, n, its):
     m = 12
     assert (np.abs(hf[:m] - href[:m]) / href[:m]).max() <= 1e-12
     assert (np.abs(hf - href) / href).max() <= 1e-7
+
+
+# ---------------------------------------------------------------- Gropp's CG through the host layer (HipxKSPSolve_GROPPCG)
+@pytest.mark.parametrize("kind,n,pc,normtype,scale", CASES)
+def test_groppcg_exact_mode_equals_the_oracle_bit_for_bit(hx, kind, n, pc, normtype, scale):
+    """HipxKSPSolve_GROPPCG (two fused passes + one product per iteration, alpha / beta on the device, launch-ahead) against the oracle's restatement of
+    groppcg.c:23-140 (pinned bit for bit to the reference + exact BLAS, tests/test_oracle_exact.py): history, iteration count, reason and SOLUTION equal."""
+    ai, aj, aa, b = system(kind, n, scale)
+    mi = 25 if normtype == 0 else 10000
+    xo, its_o, reason_o, ho = orc.ksp_solve("groppcg", ai, aj, aa, b, pc=pc, rtol=1e-8, max_it=mi, normtype=normtype, exact=True)
+    for pipeline in (1, 0):
+        xg, its, reason, hg = solve_pipecg(ai, aj, aa, b, pc=pc, rtol=1e-8, max_it=mi, normtype=normtype, pipeline=pipeline, exact=True, kind="groppcg")
+        assert (its, reason) == (its_o, reason_o), (pipeline, its, its_o, reason, reason_o)
+        assert np.array_equal(hg, ho), (pipeline, np.abs(hg - ho).max())
+        assert np.array_equal(xg, xo), (pipeline, np.abs(xg - xo).max())
+
+
+def test_groppcg_fast_mode_loop_bound_and_nonzero_guess(hx):
+    ai, aj, aa, b = system("7pt", 20)
+    N = len(ai) - 1
+    xo, its_o, reason_o, ho = orc.ksp_solve("groppcg", ai, aj, aa, b, pc="jacobi", rtol=1e-8, exact=True)
+    x1, its1, r1, h1 = solve_pipecg(ai, aj, aa, b, rtol=1e-8, pipeline=1, kind="groppcg")
+    x0, its0, r0, h0 = solve_pipecg(ai, aj, aa, b, rtol=1e-8, pipeline=0, kind="groppcg")
+    assert (its1, r1) == (its0, r0) and np.array_equal(h1, h0) and np.array_equal(x1, x0)  # launch-ahead == host-synchronised
+    assert abs(its1 - its_o) <= 1 and r1 == reason_o
+    m = min(len(h1), len(ho), 12)
+    assert (np.abs(h1[:m] - ho[:m]) / ho[:m]).max() <= 1e-12
+    assert (np.abs(h1[:min(len(h1), len(ho))] - ho[:min(len(h1), len(ho))]) / ho[:min(len(h1), len(ho))]).max() <= 1e-6
+    xo, its_o, reason_o, ho = orc.ksp_solve("groppcg", ai, aj, aa, b, pc="jacobi", rtol=1e-30, max_it=7, exact=True)
+    for pipeline in (1, 0):
+        xg, its, reason, hg = solve_pipecg(ai, aj, aa, b, rtol=1e-30, max_it=7, pipeline=pipeline, exact=True, kind="groppcg")
+        assert (its, reason) == (its_o, reason_o) == (7, -3) and np.array_equal(hg, ho) and np.array_equal(xg, xo)  # groppcg.c:137-139: `i < max_it`
+    g = 0.5 + (np.arange(N) % 5) / 10.0
+    xo, its_o, reason_o, ho = orc.ksp_solve("groppcg", ai, aj, aa, b, pc="jacobi", rtol=1e-8, x0=g, exact=True)
+    xg, its, reason, hg = solve_pipecg(ai, aj, aa, b, rtol=1e-8, x0=g, exact=True, kind="groppcg")
+    assert (its, reason) == (its_o, reason_o) and np.array_equal(hg, ho) and np.array_equal(xg, xo)
+
+
+@pytest.mark.parametrize("key,kind,n,its", [("groppcg_jacobi_7pt_64", "7pt", 64, 40), ("groppcg_jacobi_7pt_128", "7pt", 128, 40), ("groppcg_jacobi_27pt_96", "27pt", 96, 30),
+                                            ("groppcg_jacobi_7pt_256", "7pt", 256, 40)])
+def test_groppcg_against_the_reference_with_exact_blas(hx, key, kind, n, its):
+    """The committed histories of the REFERENCE's KSPSolve_GROPPCG + exact BLAS (tests/golden/make_exact_golden.py)."""
+    if key not in GOLD:
+        pytest.skip("golden %s not generated" % key)
+    ai, aj, aa, b = golden_system(kind, n)
+    href = np.array([float.fromhex(v) for v in GOLD[key]["history_hex"]])
+    xg, it, reason, hg = solve_pipecg(ai, aj, aa, b, pc="jacobi", rtol=1e-50, max_it=its, exact=True, kind="groppcg")
+    assert len(hg) == len(href) == its + 1 and (it, reason) == (its, -3)
+    assert np.array_equal(hg, href), (np.abs(hg - href) / href).max()
 
 
 # ---------------------------------------------------------------- the recorded batches

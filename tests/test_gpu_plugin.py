@@ -427,6 +427,29 @@ def test_ksp_pipecghipx_and_batched_pipecg_equal_the_reference_with_exact_blas(a
     assert abs(len(fast) - len(h)) <= 1 and (np.abs(fast[:min(len(fast), len(h))] - h[:min(len(fast), len(h))]) / h[:min(len(fast), len(h))]).max() <= 1e-6
 
 
+@pytest.mark.parametrize("args", ["-stencil 7 -n 40 -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 40",
+                                  "-stencil 27 -n 20 -pc_type none -ksp_norm_type unpreconditioned -ksp_rtol 1e-50 -ksp_max_it 30",
+                                  "-stencil 7 -n 24 -pc_type jacobi -ksp_norm_type natural -ksp_rtol 1e-50 -ksp_max_it 30",
+                                  "-stencil 7 -n 24 -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 25 -mat_axpy",
+                                  "-stencil 5 -m 100 -n 100 -pc_type jacobi -ksp_rtol 1e-6"])
+def test_ksp_groppcghipx_and_batched_groppcg_equal_the_reference_with_exact_blas(args):
+    """Round 6: the reference's KSPSolve_GROPPCG with exact BLAS on the CPU types, its unmodified loop over the hipx types (two batch kernels per iteration) and
+    -ksp_type groppcghipx (the host layer's two fused passes + one product per iteration), both with -hipx_reductions exact: the same history, iteration count
+    and error norm, bit for bit."""
+    a = args.split() + ["-history"]
+    ref = run("ref_driver", a + ["-ksp_type", "groppcg"], exact_blas=True)
+    stock = run("ref_driver", a + ["-ksp_type", "groppcg"] + HIPX + ["-hipx_reductions", "exact"])
+    fused = run("ref_driver", a + ["-ksp_type", "groppcghipx"] + HIPX + ["-hipx_reductions", "exact", "-info", ":ksp"])
+    assert "outside the fused path" not in fused
+    h = hist_of(ref)
+    assert len(h) > 10 and np.array_equal(hist_of(stock), h) and np.array_equal(hist_of(fused), h)
+    tail = lambda t: re.search(r"iterations (\d+) reason (-?\d+) error (\S+)", t).groups()  # noqa: E731
+    assert tail(stock) == tail(ref) == tail(fused)
+    fast = hist_of(run("ref_driver", a + ["-ksp_type", "groppcghipx"] + HIPX))
+    m = min(len(fast), len(h), 12)
+    assert (np.abs(fast[:m] - h[:m]) / h[:m]).max() <= 1e-12
+
+
 def test_ksp_pipecghipx_falls_back_to_the_reference_loop_when_somebody_watches():
     """-ksp_monitor (or any non-default convergence test) takes the reference's KSPSolve_PIPECG over the hipx types: same text as the CPU run's monitor lines."""
     a = "-stencil 7 -n 16 -pc_type jacobi -ksp_rtol 1e-6 -ksp_monitor -history".split()

@@ -250,6 +250,26 @@ def test_pipecghipx_on_mpiaijhipx(np_, args, kw):
     assert max(abs(g - c) / c for g, c in zip(h_f[:m], h_cpu[:m])) <= 1e-6
 
 
+@pytest.mark.parametrize("np_,args,kw", [(2, "-stencil 7 -n 24 -pc_type jacobi -ksp_rtol 1e-50 -ksp_max_it 30", dict(pc="jacobi")),
+                                         (3, "-stencil 27 -n 16 -pc_type none -ksp_norm_type unpreconditioned -ksp_rtol 1e-50 -ksp_max_it 25", dict(pc="none", normtype=2)),
+                                         (4, "-stencil 7 -n 20 -pc_type jacobi -ksp_norm_type natural -ksp_rtol 1e-8", dict(pc="jacobi", normtype=3))])
+def test_groppcghipx_on_mpiaijhipx(np_, args, kw):
+    """Round 6: -ksp_type groppcghipx on real MPI ranks sharing the GPU: t all-reduced on the stream, {dp, gammaNew} as a split-phase all-reduce around the
+    product.  Exact reduction mode: the oracle's exact GROPPCG on the same row partition, bit for bit."""
+    import numpy as np
+    import oracle as orc
+    d = dict(zip(args.split()[::2], args.split()[1::2]))
+    n = int(d["-n"])
+    ai, aj, aa = orc.stencil("7pt" if d["-stencil"] == "7" else "27pt", n)
+    b = orc.matmult_mpi(ai, aj, aa, np.ones(n ** 3), np_)
+    xo, its_o, reason_o, ho = orc.ksp_solve("groppcg", ai, aj, aa, b, rtol=float(d["-ksp_rtol"]), max_it=int(d.get("-ksp_max_it", 10000)), nranks=np_, exact=True, **kw)
+    out = mpirun(np_, "ref_driver", args.split() + ["-history", "-ksp_type", "groppcghipx", "-mat_type", "aijhipx", "-info", ":ksp", "-hipx_reductions", "exact"], True)
+    assert "outside the fused path" not in out
+    h, _, t = parse_driver(out)
+    assert t[:2] == (its_o, reason_o) and len(h) == len(ho)
+    assert h == [float(v) for v in ho], max(abs(g - c) / c for g, c in zip(h, ho))
+
+
 @pytest.mark.parametrize("np_", [2, 3])
 def test_mpiaijhipx_on_a_matrix_with_inodes(np_, tmp_path):
     """A blocked operator loaded on 2-3 ranks (MatLoad splits the rows wherever PetscSplitOwnership says, nodes cut or not): every rank's
