@@ -126,10 +126,10 @@ def test_single_rank_comm_allreduce_and_self_halo(hx, monkeypatch):
         return res
     ua, ub = fused_update(hx.hipxCGFusedUpdate), fused_update(hx.hipxCGFusedUpdateAllreduce)
     assert all(np.array_equal(p, q) for p, q in zip(ua[:3], ub[:3])) and ua[3] == ub[3]
-    # round 6: PIPECG on the multi-rank code path over RCCL -- the SPLIT-PHASE all-reduce (hipxPipeCGUpdateBeginAllreduce: ncclAllReduce / ncclAllGather + fold on
+    # round 6: PIPECG and Gropp's CG on the multi-rank code path over RCCL -- the SPLIT-PHASE all-reduce (hipxPipeCGUpdateBeginAllreduce: ncclAllReduce / ncclAllGather + fold on
     # its own stream between two events, the product on the compute stream meanwhile, hipxAllreduceEnd) on this 1-rank communicator must reproduce the one-rank
     # descriptor's local reductions bit for bit, plain and compensated, launch-ahead and host-synchronised
-    for exact in (0, 1):
+    for exact, solver, its_expected in ((0, ks.HipxKSPSolve_PIPECG, 9), (1, ks.HipxKSPSolve_PIPECG, 9), (0, ks.HipxKSPSolve_GROPPCG, 8), (1, ks.HipxKSPSolve_GROPPCG, 8)):
         _lib.chk(hx.hipxSetReductionMode(exact))
         try:
             runs = []
@@ -140,11 +140,11 @@ def test_single_rank_comm_allreduce_and_self_halo(hx, monkeypatch):
                 hist = np.zeros(64)
                 k.history, k.hist_len = hist.ctypes.data, 64
                 XS = _lib.DVec(m, np.zeros(m))
-                _lib.chk(ks.HipxKSPSolve_PIPECG(C.byref(k), C.byref(desc), C.byref(pcj), BV.ptr, XS.ptr))
+                _lib.chk(solver(C.byref(k), C.byref(desc), C.byref(pcj), BV.ptr, XS.ptr))
                 runs.append((XS.get(), int(k.its), int(k.reason), hist[:k.hist_n].copy()))
                 ks.HipxKSPDestroyWork(C.byref(k))
                 XS.free()
-            assert runs[0][1:3] == runs[1][1:3] == runs[2][1:3] == (9, -3)
+            assert runs[0][1:3] == runs[1][1:3] == runs[2][1:3] == (its_expected, -3)
             assert np.array_equal(runs[0][3], runs[1][3]) and np.array_equal(runs[1][3], runs[2][3]), (runs[0][3], runs[1][3])
             assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[1][0], runs[2][0])
         finally:
