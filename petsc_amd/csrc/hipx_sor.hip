@@ -378,7 +378,19 @@ __device__ __forceinline__ double dep_coop_minus(double sum, double *Q, const in
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int q = 0; q < cnt; q++) sum -= Q[q];
+    {  // the row's chain in CSR order; round 6: eight products are read from LDS before the first of their subtractions (see inode_coop_minus)
+      int q = 0;
+      for (; q + 8 <= cnt; q += 8) {
+        double tq[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) tq[u] = Q[q + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) asm volatile("" : "+v"(tq[u]));
+#pragma unroll
+        for (int u = 0; u < 8; u++) sum -= tq[u];
+      }
+      for (; q < cnt; q++) sum -= Q[q];
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -410,24 +422,27 @@ __global__ __launch_bounds__(SOR_THREADS) void sor_dep_coop_kernel(hipx_int nslo
       const hipx_int i  = mt.x;
       const int64_t  kd = ks + mt.y, ke = ks + mt.z;
       double         sum, out;
+      // (round 6) what the row's last step needs is requested NOW, with the row's other loads -- read after the chain, each of these was a memory round trip
+      // between the arrival of the row's last operand and its publication, on every dependency level
+      const double idg = idiag[i], xo = (KIND == 1 || KIND == 3 || KIND == 4) ? xold[i] : 0.0, md = (KIND == 4) ? mdiag[i] : 0.0;
       if (KIND == 0) {
         sum = dep_coop_minus<true>(b[i], Q, l, i, ks, kd, pj, pa, xold, xnew, err);
         if (l == 0) t[i] = sum;
-        out = sum * idiag[i];
+        out = sum * idg;
       } else if (KIND == 3) {
         sum = dep_coop_minus<true>(b[i], Q, l, i, ks, kd, pj, pa, xold, xnew, err);
         if (l == 0) t[i] = sum;
         sum = dep_coop_minus<true>(sum, Q, l, i, kd + 1, ke, pj, pa, xold, xnew, err);
-        out = (1. - omega) * xold[i] + sum * idiag[i];
+        out = (1. - omega) * xo + sum * idg;
       } else if (KIND == 1) {
         sum = dep_coop_minus<false>(t[i], Q, l, i, kd + 1, ke, pj, pa, xold, xnew, err);
-        out = (1 - omega) * xold[i] + sum * idiag[i];
+        out = (1 - omega) * xo + sum * idg;
       } else if (KIND == 2) {
         sum = dep_coop_minus<false>(b[i], Q, l, i, kd + 1, ke, pj, pa, xold, xnew, err);
-        out = sum * idiag[i];
+        out = sum * idg;
       } else {
         sum = dep_coop_minus<false>(b[i], Q, l, i, ks, ke, pj, pa, xold, xnew, err);
-        out = (1. - omega) * xold[i] + (sum + mdiag[i] * xold[i]) * idiag[i];
+        out = (1. - omega) * xo + (sum + md * xo) * idg;
       }
       if (l == 0) sor_publish(xnew + i, out);
     }
@@ -2751,9 +2766,29 @@ __device__ __forceinline__ void inode_coop_minus(double (&sum)[NSM], double (*Q)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int q = 0; q < np; q++) {
+    {  // the sequential chain sum_r -= q_r over the pairs in their order.  Round 6: the terms of FOUR pairs are read from LDS before the first of their
+       // subtractions (the loop as written above read, waited ~64 clocks and subtracted once per pair: ~0.6 us of every dependency level's ~2.6 us
+       // were LDS latencies of this chain); the subtractions themselves keep their order.
+      int q = 0;
+      for (; q + 4 <= np; q += 4) {
+        double tq[4][NSM];
 #pragma unroll
-      for (int r = 0; r < NSM; r++) sum[r] -= Q[q][r];
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int r = 0; r < NSM; r++) tq[u][r] = Q[q + u][r];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int r = 0; r < NSM; r++) asm volatile("" : "+v"(tq[u][r]));  // (all twelve reads issued; none re-materialised behind a subtraction)
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int r = 0; r < NSM; r++) sum[r] -= tq[u][r];
+      }
+      for (; q < np; q++) {
+#pragma unroll
+        for (int r = 0; r < NSM; r++) sum[r] -= Q[q][r];
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
