@@ -313,24 +313,26 @@ __global__ __launch_bounds__(SOR_THREADS) void sor_dep_kernel(hipx_int nslots, c
     const hipx_int i  = mt.x;
     const int64_t  kd = ks + mt.y, ke = ks + mt.z;
     double         sum, out;
+    // (round 6) the last step's operands are requested with the row's first loads, not after its chain (see sor_dep_coop_kernel)
+    const double idg = idiag[i], xo = (KIND == 1 || KIND == 3 || KIND == 4) ? xold[i] : 0.0, md = (KIND == 4) ? mdiag[i] : 0.0;
     if (KIND == 0) {
       sum  = sor_minusdot<true>(b[i], i, ks, kd, pj, pa, xold, xnew, err);
       t[i] = sum;
-      out  = sum * idiag[i];
+      out  = sum * idg;
     } else if (KIND == 3) {
       sum  = sor_minusdot<true>(b[i], i, ks, kd, pj, pa, xold, xnew, err);
       t[i] = sum;
       sum  = sor_minusdot<true>(sum, i, kd + 1, ke, pj, pa, xold, xnew, err);  // upper part: old values
-      out  = (1. - omega) * xold[i] + sum * idiag[i];
+      out  = (1. - omega) * xo + sum * idg;
     } else if (KIND == 1) {
       sum = sor_minusdot<false>(t[i], i, kd + 1, ke, pj, pa, xold, xnew, err);
-      out = (1 - omega) * xold[i] + sum * idiag[i];
+      out = (1 - omega) * xo + sum * idg;
     } else if (KIND == 2) {
       sum = sor_minusdot<false>(b[i], i, kd + 1, ke, pj, pa, xold, xnew, err);
-      out = sum * idiag[i];
+      out = sum * idg;
     } else {
       sum = sor_minusdot<false>(b[i], i, ks, ke, pj, pa, xold, xnew, err);  // whole row: lower + diagonal old, upper new
-      out = (1. - omega) * xold[i] + (sum + mdiag[i] * xold[i]) * idiag[i];
+      out = (1. - omega) * xo + (sum + md * xo) * idg;
     }
     sor_publish(xnew + i, out);
     }
