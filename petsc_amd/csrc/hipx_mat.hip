@@ -4641,6 +4641,26 @@ __global__ __launch_bounds__(256) void offdiag_dot_kernel(hipx_int nrows, const 
   // 16 bytes per lane, into LDS and every operand is an LDS read (per-entry system-scope loads go to memory one by one)
   const int2     wn     = win[blockIdx.x];
   const hipx_int cmin   = wn.x, cmax = wn.y;
+  // (round 6) what the row's last step needs -- its place in w, the diagonal block's sum, p, its entry range -- is requested NOW: read where it is used, each of
+  // these (two of them dependent on ridx) was a memory round trip behind the ghost wait, the window and the products, in every workgroup's life
+  const bool     rowok = r0 + t < r1;
+  const hipx_int myrow = rowok ? ridx[r0 + t] : 0;
+  const hipx_int mk0 = rowok ? bi[r0 + t] : k0, mk1 = rowok ? bi[r0 + t + 1] : k0;
+  const double   w_in = rowok ? w[myrow] : 0.0, p_in = rowok ? p[myrow] : 0.0;
+  // ... and so are the workgroup's entries (values and ghost columns: <= OD_CAP / 256 per thread, all in flight at once, before the ghost wait): as a loop with a
+  // run-time trip count each of its ~9 rounds was a memory round trip of its own
+  constexpr int NI = OD_CAP / 256;
+  double        av[NI];
+  hipx_int      cv[NI];
+  if (staged) {
+#pragma unroll
+    for (int u = 0; u < NI; u++) {
+      const hipx_int k  = k0 + t + 256 * u;
+      const hipx_int kk = (k < k1) ? k : k0;  // (beyond the range: a valid entry re-read, never used)
+      av[u]             = (k1 > k0) ? ba[kk] : 0.0;
+      cv[u]             = (k1 > k0) ? bj[kk] : 0;
+    }
+  }
   const bool     window = staged && cmax >= cmin && (cmax - cmin + 2) <= OD_WIN && ((reinterpret_cast<uintptr_t>(ghost) >> 3) & 1) == 0;
   if (sysload) {
     if (t < wt.n) ipc_wait_ge(wt.flag[t], wt.want, wt.err, wt.limit);
@@ -4681,22 +4701,22 @@ __global__ __launch_bounds__(256) void offdiag_dot_kernel(hipx_int nrows, const 
     __syncthreads();
   }
   if (staged) {
-    if (window)
-      for (hipx_int k = k0 + t; k < k1; k += 256) s_prod[k - k0] = ba[k] * s_g[bj[k] - cmin];
-    else
-      for (hipx_int k = k0 + t; k < k1; k += 256) s_prod[k - k0] = ba[k] * (sysload ? ipc_load8(ghost + bj[k]) : ghost[bj[k]]);
+#pragma unroll
+    for (int u = 0; u < NI; u++) {
+      const hipx_int k = k0 + t + 256 * u;
+      if (k < k1) s_prod[k - k0] = av[u] * (window ? s_g[cv[u] - cmin] : (sysload ? ipc_load8(ghost + cv[u]) : ghost[cv[u]]));
+    }
     __syncthreads();
   }
   double acc = 0.0;
-  if (r0 + t < r1) {
-    const hipx_int r = r0 + t, row = ridx[r];
-    double         sum = w[row];
+  if (rowok) {
+    double sum = w_in;
     if (staged)
-      for (hipx_int k = bi[r]; k < bi[r + 1]; k++) sum += s_prod[k - k0];
+      for (hipx_int k = mk0; k < mk1; k++) sum += s_prod[k - k0];
     else
-      for (hipx_int k = bi[r]; k < bi[r + 1]; k++) sum += ba[k] * (sysload ? ipc_load8(ghost + bj[k]) : ghost[bj[k]]);
-    w[row] = sum;
-    acc    = p[row] * sum;
+      for (hipx_int k = mk0; k < mk1; k++) sum += ba[k] * (sysload ? ipc_load8(ghost + bj[k]) : ghost[bj[k]]);
+    w[myrow] = sum;
+    acc      = p_in * sum;
   }
   acc = hipx::wave_sum(acc);
   if ((t & 63) == 0) s_w[t >> 6] = acc;
@@ -4725,8 +4745,22 @@ __global__ __launch_bounds__(256) void offdiag_dot_kernel(hipx_int nrows, const 
   __syncthreads();
   if (!s_last) return;
   double f = 0.0;
-  for (int i = t; i < npartA; i += 256) f += __hip_atomic_load(&partA[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (written by the launch before this one)
-  for (int i = t; i < (int)gridDim.x; i += 256) f += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (the same sums in the same order; eight loads in flight per round instead of one: the last workgroup's fold is the tail of every launch)
+  const auto fold = [&](const double *src, const int n) {
+    for (int i0 = t; i0 < n; i0 += 8 * 256) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + 256 * u;
+        v[u]        = __hip_atomic_load(&src[i < n ? i : i0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (i0 + 256 * u < n) f += v[u];
+    }
+  };
+  fold(partA, npartA);  // (written by the launch before this one)
+  fold(part, (int)gridDim.x);
   f = hipx::wave_sum(f);
   __syncthreads();
   if ((t & 63) == 0) s_w[t >> 6] = f;
