@@ -1090,6 +1090,7 @@ def main():
                                                         "instead of a Poisson operator: BASELINE config 4 with the real SuiteSparse file")
     ap.add_argument("--no-other", action="store_true", help="skip the other_configs legs (configs 3/4/5 on one GPU; the scaling legs on N GPUs)")
     ap.add_argument("--quick", action="store_true", help="the timed legs only: no plugin / PMC / CPU-baseline / general-kernel / other-config legs")
+    ap.add_argument("--only-legs", default="", help="N > 1: run only the scaling legs whose name contains one of these comma-separated strings (tests)")
     ap.add_argument("--budget-s", type=float, default=float(os.environ.get("HIPX_BENCH_BUDGET_S", "175")),
                     help="wall-clock budget of the whole run (default 175 s): the headline (parity gate, timed steps, counter pass, CPU baseline) always runs; the optional legs (plugin rows, "
                          "other_configs, their counter passes and CPU baselines) run in order of importance while their estimated cost still fits, the rest are reported as skipped")
@@ -1717,6 +1718,8 @@ def main_multi(args, head, rank, world, dev, shared, dist, torch, hx, sync, t_st
             if head.cube:
                 scaling_legs.append(("headline_pipecg_launch_ahead", Cfg(head.stencil, head.dims, "pipecg", head.pc, head.scaling), args.steps, args.warmup, args.parity_its, 10 + 20 // world, 1))
                 scaling_legs.append(("headline_groppcg_launch_ahead", Cfg(head.stencil, head.dims, "groppcg", head.pc, head.scaling), args.steps, args.warmup, args.parity_its, 10 + 20 // world, 1))
+        if args.only_legs:
+            scaling_legs = [leg for leg in scaling_legs if any(w and w in leg[0] for w in args.only_legs.split(","))]
         for name, cfg, st, wu, pits, est, pipe in scaling_legs:
             go = [time.time() + est <= deadline]
             dist.broadcast_object_list(go, src=0)

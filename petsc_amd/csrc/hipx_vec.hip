@@ -590,12 +590,19 @@ __global__ __launch_bounds__(kRedThreads) void norm12_kernel(const double *x, hi
   if (vec) {
     const hipx_int n2 = n >> 1;
     const double2 *x2 = reinterpret_cast<const double2 *>(x);
-    for (hipx_int p = tid; p < n2; p += T) {
-      double2 a = x2[p];
-      acc[0].add(fabs(a.x));
-      acc[0].add(fabs(a.y));
-      acc[1].prod(a.x, a.x);
-      acc[1].prod(a.y, a.y);
+    constexpr int U = 4;  // pairs in flight per thread (round 6: one load per round left the kernel at 3.9 TB/s, latency-bound); the accumulation order -- p, p + T, ... -- is unchanged
+    for (hipx_int p0 = tid; p0 < n2; p0 += U * T) {
+      double2 a[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) a[u] = x2[p0 + u * T < n2 ? p0 + u * T : p0];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (p0 + u * T < n2) {
+          acc[0].add(fabs(a[u].x));
+          acc[0].add(fabs(a[u].y));
+          acc[1].prod(a[u].x, a[u].x);
+          acc[1].prod(a[u].y, a[u].y);
+        }
     }
     if ((n & 1) && tid == 0) {
       acc[0].add(fabs(x[n - 1]));

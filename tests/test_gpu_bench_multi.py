@@ -129,7 +129,7 @@ def test_pipecg_on_two_ranks_through_bench_py():
     g = d["parity_gate"]
     assert g["pass"] is True and g["gated_reduction_mode"] == "exact" and g["max_rel_diff"] <= 1e-9 and g["max_rel_diff_fast_reductions"] <= 1e-8, g
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "64", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-traffic", "--no-plugin",
-                        "--no-general", "--budget-s", "300"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200, env=clean_env(), cwd=ROOT)
+                        "--no-general", "--budget-s", "300", "--only-legs", "pipecg,groppcg"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200, env=clean_env(), cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:]
     for name in ("headline_pipecg_launch_ahead", "headline_groppcg_launch_ahead"):
         leg = last_json(r.stdout)["other_configs"][name]
