@@ -33,7 +33,7 @@ using namespace hipx;
 
 namespace {
 
-constexpr int BX_P = 4, BX_G = 8;                             // planes per workgroup, rows per staging group
+constexpr int BX_P = 4;                                       // planes per workgroup (rows per staging / flushing group: the kernel's template parameter G)
 constexpr int BX_RX = 16, BX_RB = 32, BX_RS = 32, BX_RW = 32;  // ring rows: own x lines / rhs / south plane / west lines
 constexpr int BX_THREADS = 4 * BX_P * 64;                      // P compute waves + 2 P stagers (even / odd groups) + P flushers
 // LDS layout (doubles)
@@ -57,6 +57,7 @@ struct BoxParams {
   double       *xout, *tout;
   const int2   *order;          // (J, c) of ticket n
   unsigned int *ctl;            // [0] ticket, [1] error
+  double       *mbox;           // the chunks' top planes on their way up: [chunk c < nch - 1][block J][flush f < T / 2 + 8][lane] pairs of rows, sentinel = not there yet
   int          dbg;             // HIPX_SORBOX_DEBUG (timing probes, WRONG RESULTS): 1 = no staging / flushing (the compute waves alone), 2 = also no waiting for the lower plane
   unsigned long long *stats;    // HIPX_SORBOX_STATS: spin counts of the compute waves by unmet condition [4], stager ring waits [1], stager halo polls [1], steps [1]
 };
@@ -97,30 +98,6 @@ __device__ __forceinline__ bool bx_wait_ge(bx_lds_int *p, int want, bx_lds_int *
     }
   }
   return true;
-}
-
-// a pair of rows of another workgroup's line out of global x: 16-byte agent-scope load, repeated until neither half is the sentinel
-__device__ __forceinline__ bx_double2 bx_poll2(const double *p, bx_lds_int *abortw, unsigned int *gerr)
-{
-  bx_double2 v;
-  int        spins = 0;
-  long long  t0    = 0;
-  for (;;) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
-    if ((unsigned long long)__double_as_longlong(v.x) != BX_SENTINEL && (unsigned long long)__double_as_longlong(v.y) != BX_SENTINEL) break;
-    __builtin_amdgcn_s_sleep(2);
-    if (bx_cnt_load(abortw)) break;
-    if ((++spins & 0xff) == 0) {
-      const long long now = (long long)wall_clock64();
-      if (!t0) t0 = now;
-      if (__hip_atomic_load(gerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || now - t0 > BX_SPIN_TICKS) {
-        __hip_atomic_store(gerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bx_cnt_store(abortw, 1);
-        break;
-      }
-    }
-  }
-  return v;
 }
 
 __device__ __forceinline__ void bx_store2_sc1(double *p, bx_double2 v)
@@ -172,14 +149,19 @@ __device__ __forceinline__ bool bx_wait16(bx_lds_u16 *p, int want, bx_lds_int *a
   return true;
 }
 
-template <bool REV, int EM, int KIND>
+// G: steps per staging / flushing group (8, 4 or 2).  A row leaves for memory when its group of G steps is complete and the workgroup above stages
+// it with ITS group: every hop between workgroups waits out up to G + (14 mod G) steps beyond the recurrence's own skew.
+template <bool REV, int EM, int KIND, int G>
 __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams Q)
 {
+  constexpr int BX_G = G;
+  constexpr int PPL = G / 2, LPP = 64 / PPL, NPASS = 64 / LPP;  // lanes (pairs of rows) per line and group; lines per pass; passes over the 64 lines
+  static_assert(G == 8 || G == 4 || G == 2, "group of 2, 4 or 8 steps");
   extern __shared__ double bx_smem[];
   bx_lds_double *L = (bx_lds_double *)bx_smem;
   // Counters: 16-bit "steps done", one 8-byte record per READER so that a wave fetches everything it waits for with one LDS access:
-  //   C[w] (compute wave w)         = {relaxed by plane w - 1, staged for plane w, relaxed by plane w + 1, flushed of plane w}
-  //   H[w] (stagers / flusher of w) = {relaxed by plane w, relaxed by plane w + 1, staged for plane w, plane w's share of the south plane staged}
+  //   C[w] (compute wave w)         = {relaxed by plane w - 1 (w = 0: virtual steps of the south plane staged), staged for plane w, relaxed by plane w + 1, flushed of plane w}
+  //   H[w] (stagers / flusher of w) = {relaxed by plane w, relaxed by plane w + 1, staged for plane w, unused}
   // A writer stores its counter into every record that holds it (one ds_write_b16, one lane per copy).  Planes that do not exist read 0xffff.
   bx_lds_u16 *c16 = (bx_lds_u16 *)(L + BX_OC);
   bx_lds_int *abortw = (bx_lds_int *)(c16 + 8 * BX_P + 8), *tick = abortw + 1;
@@ -191,7 +173,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
   for (int q = threadIdx.x; q < BX_OB; q += BX_THREADS) L[q] = z0;  // the x, south and west rings start out as the zero element (rows -1 of every line)
   if (threadIdx.x == 0) {
     for (int q = 0; q < 8 * BX_P + 8; q++) bx_put16(c16 + q, 0);
-    bx_put16(Crec(0) + 0, 0xffff);
+    if (Q.dbg & 7) bx_put16(Crec(0) + 0, 0xffff);  // (otherwise: the south plane's virtual steps, published by its poller)
     bx_put16(Crec(BX_P - 1) + 2, 0xffff);
     bx_put16(Hrec(BX_P - 1) + 1, 0xffff);
     bx_cnt_store(abortw, 0);
@@ -236,7 +218,8 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     if (lane == 2) pub = Hrec(w) + 0;
     if (lane == 3 && w > 0) pub = Hrec(w - 1) + 1;
     // what step t needs, checked before its operands are requested:
-    //   lower plane: its row i + 1 of line j + 1 was relaxed in wave w - 1's step t - 3            -> relaxed(w - 1) >= t - 2
+    //   lower plane: its row i + 1 of line j + 1 was relaxed in wave w - 1's step t - 3            -> relaxed(w - 1) >= t - 2   (w = 0: the south plane's
+    //                virtual step t - 3 is staged -> its poller's count >= t)
     //   right-hand side / west / south rows of the step are staged                                  -> staged(w)      >= t + 1
     //   x ring (16 rows): plane k + 1 reads a row up to 7 steps after it was written                -> relaxed(w + 1) >= t - 8
     //   x / t rings: the rows this step overwrites have left for memory                             -> flushed(w)     >= t - 15
@@ -248,9 +231,12 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
       c_low = (int)(lo & 0xffffu), c_stg = (int)(lo >> 16), c_up = (int)(hi & 0xffffu), c_fl = (int)(hi >> 16);
     };
     const int staged_all = Q.ngroups * BX_G;
+    // (readfirstlane: w comes from threadIdx -- as a VGPR value it makes every branch on ready() divergent for the compiler: 850 -> 995 instructions
+    // in the loop of four steps, 304 -> 330 ns per step)
+    const int low_off = __builtin_amdgcn_readfirstlane(w == 0 ? 2 : 0);  // the south plane's poller counts from virtual step -2 (rows 0, 1 of its first line)
     auto ready = [&](int t) -> bool {
       if (Q.dbg == 2) return true;
-      const bool core = (c_low >= (t - 2 < T ? t - 2 : T)) & (c_up >= t - 8);
+      const bool core = (c_low >= (t - 2 < T ? t - 2 : T) + low_off) & (c_up >= t - 8);
       if (Q.dbg == 1) return core;
       return core & (c_stg >= (t + 1 < staged_all ? t + 1 : staged_all)) & (c_fl >= t - (BX_RX - 1));
     };
@@ -260,7 +246,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
       long long t0    = 0;
       while (!ready(t)) {
         if (Q.stats) {
-          if (c_low < (t - 2 < T ? t - 2 : T)) sp_low++;
+          if (c_low < (t - 2 < T ? t - 2 : T) + low_off) sp_low++;
           else if (c_stg < (t + 1 < staged_all ? t + 1 : staged_all)) sp_stg++;
           else if (c_up < t - 8) sp_up++;
           else sp_fl++;
@@ -369,127 +355,314 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     return;
   }
 
-  const int  role = wave / BX_P - 1;  // 0, 1 stagers (groups of this parity), 2 flusher
-  if (Q.dbg) return;
-  const int  w = wave % BX_P, k = k0 + w;
-  const bool plane_ok = k < nz;
+  // ---------------------------------------------------------------------------------------------------------------- helper waves
+  // P .. 3 P - 1: two stagers per plane (even / odd groups of G steps: right-hand side + west lines into the LDS rings); 3 P: the flusher of planes
+  // 0 .. P - 2 (groups of G steps); 3 P + 1: the flusher of the chunk's TOP plane, pair by pair; 3 P + 2: the poller of the SOUTH plane, pair by pair.
+  // The last two are the hop between chunks: a row pair of plane k0 + P - 1 leaves for memory two steps after its first row was relaxed and is in
+  // the ring of the chunk above one memory round trip later (round 5 / 6a: groups of eight steps on both sides, misaligned by two, the south plane
+  // spread over the stagers of all planes and polled task after task: 6.6 us per hop beyond the recurrence's own sixteen steps).
+  if (Q.dbg & 3) return;
+  const int       hw  = wave - BX_P;
   const long long nxl = nx, nyl = ny;
   auto phys = [&](int r, int jj, int kk) -> long long {  // element index of logical row (r, jj, kk); pairs (r, r + 1), r even, are 16-byte aligned
     const long long lr = (long long)r + nxl * ((long long)jj + nyl * (long long)kk);
     return REV ? Q.m - 2 - lr : lr;  // REV: the pair (r, r + 1) lies at m - 2 - lr, halves swapped
   };
-  bx_lds_u16 *hrec = Hrec(w);  // {relaxed(w), relaxed(w + 1), staged(w)}
+  // agent-scope (sc1) loads the compiler can see: the values are waited for where they are used
+  auto ld = [&](const double *q) -> bx_double2 {
+    const unsigned long long *u = reinterpret_cast<const unsigned long long *>(q);
+    bx_double2                v;
+    v.x = __longlong_as_double((long long)__hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    v.y = __longlong_as_double((long long)__hip_atomic_load(u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return v;
+  };
+  auto unset = [](const bx_double2 &v) -> bool {
+    return (unsigned long long)__double_as_longlong(v.x) == BX_SENTINEL || (unsigned long long)__double_as_longlong(v.y) == BX_SENTINEL;
+  };
+  // a helper's poll went on for too long (or another workgroup failed): the launch is given up
+  auto give_up = [&](int &spins, long long &t0) -> bool {
+    if ((++spins & 0xf) == 0 && bx_cnt_load(abortw)) return true;
+    if ((spins & 0xff) == 0) {
+      const long long now = (long long)wall_clock64();
+      if (!t0) t0 = now;
+      if (__hip_atomic_load(gerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || now - t0 > BX_SPIN_TICKS) {
+        __hip_atomic_store(gerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bx_cnt_store(abortw, 1);
+        return true;
+      }
+    }
+    return false;
+  };
 
-  if (role == 2) {
-    // ---------------------------------------------------------------------------------------------------- flusher of plane k0 + w
-    for (int fg = 0; fg * BX_G < T; fg++) {
-      const int need = (fg + 1) * BX_G < T ? (fg + 1) * BX_G : T;
-      if (!bx_wait16(hrec, need, abortw, gerr)) return;
-      bx_lds_acquire();
-      if (plane_ok) {
+  if (hw >= 2 * BX_P) {
+    if (hw == 2 * BX_P || hw == 2 * BX_P + 3) {
+      // ------------------------------------------------------------------------------------------ flushers of planes k0 .. k0 + P - 2
+      // Two waves for P - 1 planes (P = 4: planes 0, 1 and plane 2).  What does not change from group to group is formed once and a group's ring reads
+      // are requested together: with flush_rows' index arithmetic and one LDS round trip per pass the wave with two planes took longer than the eight
+      // steps it has, and its planes -- then everybody -- ran at 400 ns per step instead of 300.
+      constexpr int NPL = (BX_P - 1) / 2 + 1;  // planes of the first wave (the second has the rest)
+      const int     w_lo = hw == 2 * BX_P ? 0 : NPL, w_hi = hw == 2 * BX_P ? NPL : BX_P - 1;
+      bool          lok[NPL][NPASS], xst[NPL][NPASS];
+      int           rb[NPL][NPASS], ro[NPL][NPASS];
+      long long     e0[NPL][NPASS];
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-          const int s = 16 * p + (lane >> 2), qd = lane & 3, jj = 64 * J - k + s;
-          const int r = BX_G * fg - 2 - 2 * s - 4 * w + 2 * qd;
-          if (r >= 0 && r < nx && jj >= 0 && jj < ny) {
-            const int       xo = BX_OX + (w * 64 + s) * (BX_RX + 1);
-            const long long e  = phys(r, jj, k);
-            // forward sweep inside a symmetric application: only the lines other workgroups read go to memory (the last two lanes, the
-            // chunk's top plane); the result of the application is the backward sweep's
-            if (Q.xfull || s >= 62 || w == BX_P - 1) {
-              bx_double2 v;
-              v.x = L[xo + (r & (BX_RX - 1))];
-              v.y = L[xo + ((r + 1) & (BX_RX - 1))];
-              if (REV) {
-                const double tmp = v.x;
-                v.x              = v.y;
-                v.y              = tmp;
-              }
-              bx_store2_sc1(Q.xout + e, v);
-            }
+      for (int pl = 0; pl < NPL; pl++)
+#pragma unroll
+        for (int p = 0; p < NPASS; p++) {
+          const int w = w_lo + pl, s = LPP * p + lane / PPL, qd = lane % PPL, k = k0 + w, jj = 64 * J - k + s;
+          lok[pl][p] = w < w_hi && k < nz && jj >= 0 && jj < ny;
+          xst[pl][p] = Q.xfull || s >= 62;  // forward sweep inside a symmetric application: only the lines other workgroups read go to memory
+          rb[pl][p]  = -2 - 2 * s - 4 * w + 2 * qd;
+          ro[pl][p]  = (w * 64 + s) * (BX_RX + 1);
+          e0[pl][p]  = lok[pl][p] ? phys(0, jj, k) : 0;
+        }
+      for (int fg = 0; fg * BX_G < T; fg++) {
+        const int need = (fg + 1) * BX_G < T ? (fg + 1) * BX_G : T;
+#pragma unroll
+        for (int pl = 0; pl < NPL; pl++) {
+          const int w = w_lo + pl;
+          if (w >= w_hi) break;
+          if (!bx_wait16(Hrec(w), need, abortw, gerr)) return;
+          bx_lds_acquire();
+          bx_double2 xv[NPASS], tv[NPASS];
+#pragma unroll
+          for (int p = 0; p < NPASS; p++) {
+            const int r = BX_G * fg + rb[pl][p];
+            xv[p].x = L[BX_OX + ro[pl][p] + (r & (BX_RX - 1))];
+            xv[p].y = L[BX_OX + ro[pl][p] + ((r + 1) & (BX_RX - 1))];
             if (KIND == 0) {
-              const int  to = BX_OT + (w * 64 + s) * (BX_RX + 1);
-              bx_double2 tv;
-              tv.x = L[to + (r & (BX_RX - 1))];
-              tv.y = L[to + ((r + 1) & (BX_RX - 1))];
-              *reinterpret_cast<bx_double2 *>(Q.tout + e) = tv;  // (forward: never REV)
+              tv[p].x = L[BX_OT + ro[pl][p] + (r & (BX_RX - 1))];
+              tv[p].y = L[BX_OT + ro[pl][p] + ((r + 1) & (BX_RX - 1))];
             }
           }
+#pragma unroll
+          for (int p = 0; p < NPASS; p++) {
+            const int r = BX_G * fg + rb[pl][p];
+            if (lok[pl][p] && r >= 0 && r < nx && !(Q.dbg & 32)) {
+              if (xst[pl][p]) {
+                bx_double2 v = xv[p];
+                if (REV) {
+                  const double tmp = v.x;
+                  v.x              = v.y;
+                  v.y              = tmp;
+                }
+                bx_store2_sc1(Q.xout + (REV ? e0[pl][p] - r : e0[pl][p] + r), v);
+              }
+              if (KIND == 0) *reinterpret_cast<bx_double2 *>(Q.tout + e0[pl][p] + r) = tv[p];  // (forward: never REV)
+            }
+          }
+          bx_lds_release();  // (the ring reads are done; the stores may still be on their way)
+          if (lane == 0) bx_put16(Crec(w) + 3, need);
         }
       }
-      bx_lds_release();  // (the ring reads are done; the stores may still be on their way)
-      if (lane == 0) bx_put16(Crec(w) + 3, need);
+    } else if (hw == 2 * BX_P + 1) {
+      // ------------------------------------------------------------------------------------------ flusher of the top plane k0 + P - 1
+      // (everything that does not change from pair to pair is formed once: the loop must keep up with a pair every two steps, ~1400 clocks,
+      // LDS latencies included -- with the general flush_rows and a sleep after every pair it did not, and the top wave, then everybody, ran at
+      // 400 ns per step instead of 300)
+      constexpr int w = BX_P - 1;
+      const int     k = k0 + w, jj = 64 * J - k + lane;
+      const bool    lok = k < nz && jj >= 0 && jj < ny;
+      const long long e0 = lok ? phys(0, jj, k) : 0;
+      double       *xl = Q.xout + e0, *tl = KIND == 0 ? Q.tout + e0 : nullptr;
+      // the chunk above takes the plane from the MAILBOX: flush f = the 64 lanes' pairs side by side, 1 KB per flush (through x itself the 64 pairs of a
+      // flush lie nx rows apart: 64 partial lines on one or two memory channels per request of its poller)
+      double       *mb = c + 1 < Q.nch ? Q.mbox + ((size_t)c * Q.nb + J) * (size_t)(T / 2 + 8) * 128 + 2 * lane : nullptr;
+      const int     xo = BX_OX + (w * 64 + lane) * (BX_RX + 1), to = BX_OT + (w * 64 + lane) * (BX_RX + 1);
+      bx_lds_u16   *rel = Hrec(w);
+      const int     fstep = (Q.dbg & 8) ? 8 : 2;  // (timing probe: groups of eight steps, nothing flushed)
+      for (int need = fstep; need <= T; need += fstep) {  // (T: a multiple of four)
+        int       spins = 0;
+        long long t0    = 0;
+        while (bx_get16(rel) < need) {
+          __builtin_amdgcn_s_sleep(1);
+          if (give_up(spins, t0)) return;
+        }
+        bx_lds_acquire();
+        const int r = need - 4 - 2 * lane - 4 * w;  // the rows lane s relaxed in steps need - 2, need - 1
+        if (lok && r >= 0 && r < nx && !(Q.dbg & 24)) {
+          bx_double2 v;
+          v.x = L[xo + (r & (BX_RX - 1))];
+          v.y = L[xo + ((r + 1) & (BX_RX - 1))];
+          if (KIND == 0) {
+            bx_double2 tv;
+            tv.x = L[to + (r & (BX_RX - 1))];
+            tv.y = L[to + ((r + 1) & (BX_RX - 1))];
+            *reinterpret_cast<bx_double2 *>(tl + r) = tv;  // (forward: never REV)
+          }
+          if (mb) bx_store2_sc1(mb + (size_t)(need / 2 - 1) * 128, v);  // (logical order: row r first)
+          if (REV) {
+            const double tmp = v.x;
+            v.x              = v.y;
+            v.y              = tmp;
+          }
+          bx_store2_sc1(REV ? xl - r : xl + r, v);
+        }
+        bx_lds_release();
+        if (lane == 0) bx_put16(Crec(w) + 3, need);
+      }
+    } else if (hw == 2 * BX_P + 2) {
+      // ------------------------------------------------------------------------------------------ poller of the south plane k0 - 1
+      // The south plane is "wave -1" of the chunk: its VIRTUAL step v holds row v + 2 - 2 s of line s = 0 .. 63 of block J there (lane <-> line; the
+      // two lines of block J - 1 in front of them are early and come with plane 0's stagers), and plane 0 waits for it exactly as plane w waits for
+      // plane w - 1: staged virtual steps >= t - 2.  Pair n = virtual steps 2 n - 2, 2 n - 1 = rows 2 n - 2 s, + 1.
+      bx_lds_u16 *sc = Crec(0) + 0;
+      if (Q.dbg & 4) return;
+      if (k0 == 0) {  // no plane below: the ring keeps the zero element
+        if (lane == 0) bx_put16(sc, 0xffff);
+        return;
+      }
+      // Pair n of line s = rows 2 n - 2 s, + 1 = what lane s of the chunk below relaxed in its steps 2 n + 14, 2 n + 15 = entry s of its flush n + 7 in
+      // the mailbox.  A pass asks for the next FOUR flushes (4 x 1 KB, one 16-byte load per lane and flush), stages the leading ones that are
+      // complete and puts the sentinel back into what it has read; it keeps no state from pass to pass.  (A window of eight pairs with per-slot
+      // state compiled to ~950 instructions per pass: with a compute wave on the same SIMD a pass took longer than the sixteen steps of lead the
+      // ring allows, and the chunk ran at the poller's pace, 1.5 x slower than the chunk below.)
+      constexpr int WIN = 4;
+      const int     npairs = T / 2 + 1;
+      const int     jj = 64 * J - (k0 - 1) + lane;
+      const bool    line_ok = jj >= 0 && jj < ny;
+      const bool    any_line = __any(line_ok);
+      const int     so = BX_OS + (lane + 2) * (BX_RS + 1);
+      double       *mb  = Q.mbox + ((size_t)(c - 1) * Q.nb + J) * (size_t)(T / 2 + 8) * 128 + 2 * lane;
+      bx_double2    sentinel2;
+      sentinel2.x = sentinel2.y = __longlong_as_double((long long)BX_SENTINEL);
+      int       base = 0, spins = 0;
+      long long t0   = 0;
+      unsigned  n_it = 0, n_empty = 0, n_lim = 0;  // HIPX_SORBOX_STATS: passes, passes that staged nothing, waits for ring space
+      bool      probe = true;
+      while (base < npairs) {
+        // ring space (32 rows): pair n overwrites the rows plane 0 asked for up to step 2 n - 28
+        int lim = (bx_get16(Hrec(0)) + 19) >> 1;
+        lim     = lim < npairs ? lim : npairs;
+        if (lim <= base) {  // nothing may be staged yet: no memory traffic while plane 0 catches up
+          n_lim++;
+          __builtin_amdgcn_s_sleep(2);
+          if (give_up(spins, t0)) return;
+          continue;
+        }
+        const double *ent = mb + (size_t)(base + 7) * 128;
+        if (probe) {
+          // Nothing had arrived on the last pass: ONE lane asks for its rows of the next pair until they are there (all lines' rows of a pair leave the
+          // chunk below in one pass of its flusher): a waiting workgroup costs the memory system one request per round trip.
+          const int                rb   = 2 * base - 2 * lane;
+          const unsigned long long need = __ballot(line_ok && rb >= 0 && rb < nx);
+          if (need) {
+            const int  pl = __ffsll((long long)need) - 1;
+            bx_double2 pv;
+            pv.x = pv.y = z0;
+            if (lane == pl) pv = ld(ent);
+            if (__any(lane == pl && unset(pv))) {
+              __builtin_amdgcn_s_sleep(1);
+              if (give_up(spins, t0)) return;
+              continue;
+            }
+          }
+          probe = false;
+        }
+        n_it++;
+        bx_double2 v0, v1, v2, v3;
+        v0.x = v0.y = v1.x = v1.y = v2.x = v2.y = v3.x = v3.y = z0;
+        if (any_line)  // (a workgroup without any line in the grid asks for nothing)
+          asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+                       "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                       : "v"(ent)
+                       : "memory");
+        const bx_double2 vv[WIN] = {v0, v1, v2, v3};
+        bool             nd[WIN];
+        int              nlead = 0;
+        bool             lead  = true;
+#pragma unroll
+        for (int i = 0; i < WIN; i++) {
+          const int r = 2 * (base + i) - 2 * lane;
+          nd[i]       = line_ok && r >= 0 && r < nx;
+          lead        = lead && base + i < lim && !__any(nd[i] && unset(vv[i]));
+          nlead += lead ? 1 : 0;
+        }
+        if (!nlead) {
+          n_empty++;
+          probe = true;
+          if (give_up(spins, t0)) return;
+          continue;
+        }
+        spins = 0, t0 = 0;
+#pragma unroll
+        for (int i = 0; i < WIN; i++) {
+          if (i < nlead) {
+            const int r = 2 * (base + i) - 2 * lane;
+            if (r >= 0 && r <= nx) {  // (row nx: the line's zero element)
+              bx_double2 v = vv[i];
+              if (!nd[i]) v.x = v.y = z0;
+              L[so + (r & (BX_RS - 1))]       = v.x;
+              L[so + ((r + 1) & (BX_RS - 1))] = v.y;
+            }
+            if (nd[i]) *reinterpret_cast<bx_double2 *>(mb + (size_t)(base + i + 7) * 128) = sentinel2;  // (read once: ready for the next sweep)
+          }
+        }
+        bx_lds_release();
+        base += nlead;
+        if (lane == 0) bx_put16(sc, 2 * base);  // (virtual steps -2 .. 2 base - 3 are staged)
+      }
+      if (Q.stats && lane == 0) {
+        atomicAdd(Q.stats + 7, (unsigned long long)n_it);
+        atomicAdd(Q.stats + 8 + 2 * Q.nb * Q.nch, (unsigned long long)n_empty);
+        atomicAdd(Q.stats + 9 + 2 * Q.nb * Q.nch, (unsigned long long)n_lim);
+      }
     }
     return;
   }
 
   // ---------------------------------------------------------------------------------------------------------- stager of plane k0 + w
-  // Everything of a group -- right-hand side (a), west lines (b), south plane (c, stagers 0) -- is requested from memory two groups before it is
-  // staged: 16-byte loads, four lanes per 64-byte line segment, the halo loads at agent scope (a row of x another workgroup has not written yet
-  // reads as the sentinel and is polled on its own when its turn comes).
+  // Everything of a group -- right-hand side (a), west lines (b) -- is requested from memory two groups before it is staged: 16-byte loads, PPL lanes
+  // per line segment, the halo loads at agent scope (a row of x another workgroup has not written yet reads as the sentinel and is asked for again
+  // when its turn comes).
   // A plane has TWO stagers, one for the even and one for the odd groups: a stager's loads for its next group (two groups on) are requested right
-  // after it has published the current one and are the only ones it has in flight when it needs them -- about sixteen steps later.  (One stager with
-  // two groups in flight waits, at every group, for the loads it has JUST issued -- the compiler's vmcnt(0) -- and the whole workgroup settles at
-  // memory latency / 8 per step.)
-  // The south plane's 66 x 4 pairs are shared by the stagers of ALL planes (task 1: pair 64 w + lane; task 2, plane 0 only: the last eight): three tasks
-  // per lane at most -- a stager polls its pending tasks one after the other, a memory round trip each, and that time is on every hop between chunks
-  constexpr int NT = 3;  // halo tasks per lane: 0 = west lines of the own plane (lanes 0-7), 1, 2 = south plane
-  bx_double2    pre[4], hv[NT];
-  // what halo task tk of group g is for this lane (recomputed where needed: only the loaded values live across the groups in flight)
+  // after it has published the current one and are the only ones it has in flight when it needs them.  (One stager with two groups in flight
+  // waits, at every group, for the loads it has JUST issued -- the compiler's vmcnt(0) -- and the whole workgroup settles at memory latency / 8 per
+  // step.)
+  const int  role = hw / BX_P;  // groups of this parity
+  const int  w = hw % BX_P, k = k0 + w;
+  const bool plane_ok = k < nz;
+  bx_lds_u16 *hrec = Hrec(w);  // {relaxed(w), relaxed(w + 1), staged(w), -}
+  bx_double2  pre[NPASS], hv[2];
+  // halo task tk of group g for this lane (lanes 0 .. 2 PPL - 1), both out of block J - 1's last two lanes: 0 = the two west lines of plane k (lines
+  // 64 J - k - 2, - 1), rows [G g - 4 w, + G); 1 (plane 0's stagers) = the two lines of the south plane k0 - 1 in front of block J's, rows [G g, + G)
   auto halo_desc = [&](int g, const int tk, bool &in, bool &mem, int &off, int &r, const double *&ptr) {
-    int q, qd, jj, kk;
-    if (tk == 0) {  // (b) the two west lines of plane k (lines 64 J - k - 2, - 1: block J - 1's last lanes), rows [8 g - 4 w, + 8): lanes 0-7
-      q = lane >> 2, qd = lane & 3, jj = 64 * J - k - 2 + q, kk = k;
-      r   = BX_G * g - 4 * w + 2 * qd;
-      in  = lane < 8 && r >= 0 && r <= nx;  // (row nx: the line's zero element)
-      mem = in && r < nx && plane_ok && jj >= 0 && jj < ny;
-      off = BX_OW + (w * 2 + (q & 1)) * BX_RW + (r & (BX_RW - 1));
-    } else {  // (c) the south plane k0 - 1 (66 lines: the chunk below and, there, block J - 1's last lanes), line index q rows [8 g - 2 max(q - 2, 0), + 8)
-      const int task = tk == 1 ? 64 * w + lane : 64 * BX_P + lane;
-      q = task >> 2, qd = task & 3, jj = 64 * J - (k0 - 1) + q - 2, kk = k0 - 1;
-      r   = BX_G * g - 2 * (q > 2 ? q - 2 : 0) + 2 * qd;
-      in  = (tk == 1 || (w == 0 && lane < 66 * 4 - 64 * BX_P)) && task < 66 * 4 && r >= 0 && r <= nx;
-      mem = in && r < nx && k0 > 0 && jj >= 0 && jj < ny;
-      off = BX_OS + (q < 66 ? q : 0) * (BX_RS + 1) + (r & (BX_RS - 1));
-    }
+    const int q = lane / PPL, qd = lane % PPL, kk = tk == 0 ? k : k0 - 1, jj = 64 * J - kk - 2 + q;
+    r   = BX_G * g - (tk == 0 ? 4 * w : 0) + 2 * qd;
+    in  = lane < 2 * PPL && r >= 0 && r <= nx;  // (row nx: the line's zero element)
+    mem = in && r < nx && kk >= 0 && kk < nz && jj >= 0 && jj < ny;
+    off = (tk == 0 ? BX_OW + (w * 2 + (q & 1)) * BX_RW : BX_OS + (q & 1) * (BX_RS + 1)) + (r & (BX_RW - 1));
     ptr = mem ? Q.xout + phys(r, jj, kk) : Q.xout;
   };
   auto issue = [&](int g) {
 #pragma unroll
-    for (int p = 0; p < 4; p++) {  // (a) rows [8 g - 2 - 2 s - 4 w, + 8) of the 64 lines
-      const int  s = 16 * p + (lane >> 2), qd = lane & 3, jj = 64 * J - k + s;
+    for (int p = 0; p < NPASS; p++) {  // (a) rows [G g - 2 - 2 s - 4 w, + G) of the 64 lines
+      const int  s = LPP * p + lane / PPL, qd = lane % PPL, jj = 64 * J - k + s;
       const int  r = BX_G * g - 2 - 2 * s - 4 * w + 2 * qd;
       const bool ok = plane_ok && r >= 0 && r < nx && jj >= 0 && jj < ny;
       pre[p]        = *reinterpret_cast<const bx_double2 *>(ok ? Q.rhs + phys(r, jj, k) : Q.rhs);  // (a lane without a row reads element 0: never stored)
     }
-    // agent-scope (sc1) loads the compiler can see: the values are waited for where they are used, two groups later
-    auto ld = [&](const double *q) -> bx_double2 {
-      const unsigned long long *u = reinterpret_cast<const unsigned long long *>(q);
-      bx_double2                v;
-      v.x = __longlong_as_double((long long)__hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      v.y = __longlong_as_double((long long)__hip_atomic_load(u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      return v;
-    };
 #pragma unroll
-    for (int tk = 0; tk < NT; tk++) {
-      if (tk == 2 && w != 0) break;
+    for (int tk = 0; tk < 2; tk++) {
+      if (tk == 1 && w != 0) break;
       bool          in, mem;
       int           off, r;
       const double *ptr;
       halo_desc(g, tk, in, mem, off, r, ptr);
-      hv[tk] = ld(ptr);
+      hv[tk].x = hv[tk].y = z0;
+      if (mem) hv[tk] = ld(ptr);  // (no dummy address for the other lanes: every waiting workgroup asking for xout[0] is a hot spot on one channel)
     }
   };
   unsigned npoll = 0, nring = 0;
   auto stage = [&](int g) -> bool {
     if (Q.stats && (bx_get16(hrec) < BX_G * g - (BX_RW - 16) || bx_get16(hrec + 1) < BX_G * g - (BX_RW - 16))) nring++;
-    // ring space: rhs ring (32 rows) -> the wave is past step 8 g - 24; west / south rings (32 rows, read up to 13 steps after staging) -> waves w and w + 1 past 8 g - 16
+    // ring space: rhs ring (32 rows) -> the wave is past step G g - 24; west / south rings (32 rows, read up to 13 steps after staging) -> waves w and w + 1 past G g - 16
     if (!bx_wait16(hrec, BX_G * g - (BX_RW - 16), abortw, gerr) || !bx_wait16(hrec + 1, BX_G * g - (BX_RW - 16), abortw, gerr)) return false;
-    if (w > 0 && !bx_wait16(Hrec(0), BX_G * g - (BX_RS - 16), abortw, gerr)) return false;  // (its share of the south ring: read by wave 0)
     bx_lds_acquire();
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
-      const int s = 16 * p + (lane >> 2), qd = lane & 3, jj = 64 * J - k + s;
+    for (int p = 0; p < NPASS; p++) {
+      const int s = LPP * p + lane / PPL, qd = lane % PPL, jj = 64 * J - k + s;
       const int r = BX_G * g - 2 - 2 * s - 4 * w + 2 * qd;
       if (plane_ok && r >= 0 && r < nx && jj >= 0 && jj < ny) {
         const int bo = BX_OB + (w * 64 + s) * (BX_RB + 1);
@@ -498,19 +671,26 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
       }
     }
 #pragma unroll
-    for (int tk = 0; tk < NT; tk++) {
-      if (tk == 2 && w != 0) break;
+    for (int tk = 0; tk < 2; tk++) {
+      if (tk == 1 && w != 0) break;
       bool          in, mem;
       int           off, r;
       const double *ptr;
       halo_desc(g, tk, in, mem, off, r, ptr);
+      if (mem && unset(hv[tk])) {  // (block J - 1 is a block hop ahead: seen on the first groups of a workgroup at most)
+        npoll++;
+        int       spins = 0;
+        long long t0    = 0;
+        for (;;) {
+          hv[tk] = ld(ptr);
+          if (!unset(hv[tk])) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (give_up(spins, t0)) break;
+        }
+      }
       if (in) {
         bx_double2 v = hv[tk];
         if (mem) {
-          if ((unsigned long long)__double_as_longlong(v.x) == BX_SENTINEL || (unsigned long long)__double_as_longlong(v.y) == BX_SENTINEL) {
-            npoll++;
-            v = bx_poll2(ptr, abortw, gerr);
-          }
           if (REV) {
             const double tmp = v.x;
             v.x              = v.y;
@@ -523,12 +703,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     }
     bx_lds_release();
     if (!bx_wait16(hrec + 2, BX_G * g, abortw, gerr)) return false;  // (groups are published in order: the other stager's group g - 1 first)
-    if (w == 0) {  // plane 0's rows are complete when the other planes' stagers have staged their shares of the south plane
-#pragma unroll
-      for (int o = 1; o < BX_P; o++)
-        if (!bx_wait16(Hrec(o) + 3, BX_G * (g + 1), abortw, gerr)) return false;
-      if (lane < 2) bx_put16(lane == 0 ? Crec(w) + 1 : hrec + 2, BX_G * (g + 1));
-    } else if (lane < 3) bx_put16(lane == 0 ? Crec(w) + 1 : (lane == 1 ? hrec + 2 : hrec + 3), BX_G * (g + 1));
+    if (lane < 2) bx_put16(lane == 0 ? Crec(w) + 1 : hrec + 2, BX_G * (g + 1));
     return true;
   };
   if (role < Q.ngroups) issue(role);
@@ -540,6 +715,11 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     atomicAdd(Q.stats + 4, (unsigned long long)(lane == 0 ? nring : 0));
     atomicAdd(Q.stats + 5, (unsigned long long)npoll);
   }
+}
+
+__global__ void box_fill_kernel(double *x, size_t n)
+{
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) x[q] = __longlong_as_double((long long)BX_SENTINEL);
 }
 
 // expected presence of the 27 canonical positions at every row against the row's template: count of rows that differ
@@ -560,12 +740,14 @@ __global__ void box_verify_kernel(long long m, int nx, int ny, int nz, const uns
 }  // namespace
 
 struct hipxSorBox_s {
-  int           nx = 0, ny = 0, nz = 0, nb = 0, nch = 0, T = 0, ngroups = 0, em = 0;
+  int           nx = 0, ny = 0, nz = 0, nb = 0, nch = 0, T = 0, em = 0;
   long long     m = 0;
   double        coefF[13], coefB[13], diag = 0.0, z0 = 0.0;
   int2         *d_order = nullptr;
   unsigned int *d_ctl = nullptr;
   unsigned long long *d_stats = nullptr;
+  double       *d_mbox = nullptr;
+  size_t        mbox_len = 0;
 };
 typedef hipxSorBox_s *hipxSorBox;
 
@@ -576,6 +758,7 @@ extern "C" void hipxSorBoxFree_(void *p)
   (void)hipFree(B->d_order);
   (void)hipFree(B->d_ctl);
   (void)hipFree(B->d_stats);
+  (void)hipFree(B->d_mbox);
   delete B;
 }
 
@@ -681,7 +864,6 @@ extern "C" int hipxSorBoxBuild_(long long m, int ntmpl, const int *tstart, const
   B->nb      = (ny + nz - 2) / 64 + 1;
   B->nch     = (nz + BX_P - 1) / BX_P;
   B->T       = (nx + 3 + 2 * 63 + 4 * (BX_P - 1) + 3) & ~3;  // rows -2 .. nx of the last lane of the last wave, rounded up to the unrolled loop's four
-  B->ngroups = (B->T + BX_G - 1) / BX_G;
   // ticket order: by estimated start (a chunk hop ~ 4 P steps + a hand-off, a block hop ~ 128 steps + a hand-off); every dependency of (J, c)
   // -- (J - 1, c), (J - 1, c - 1), (J, c - 1) -- starts earlier
   std::vector<int2> order;
@@ -690,6 +872,12 @@ extern "C" int hipxSorBoxBuild_(long long m, int ntmpl, const int *tstart, const
   std::stable_sort(order.begin(), order.end(), [](const int2 &a, const int2 &b) { return a.y * 5 + a.x * 16 < b.y * 5 + b.x * 16; });
   if (hipMalloc((void **)&B->d_order, sizeof(int2) * order.size()) != hipSuccess || hipMemcpy(B->d_order, order.data(), sizeof(int2) * order.size(), hipMemcpyHostToDevice) != hipSuccess)
     return bail(fail(HIPX_ERR_HIP_BASE, "hipMalloc", __FILE__, __LINE__));
+  // the mailbox of the chunks' top planes: filled with the sentinel once -- whoever reads an entry puts the sentinel back
+  B->mbox_len = (size_t)B->nb * (size_t)(B->nch > 1 ? B->nch - 1 : 0) * (size_t)(B->T / 2 + 8) * 128;  // (eight flushes of padding per workgroup: the poller reads four at a time)
+  if (B->mbox_len) {
+    if (hipMalloc((void **)&B->d_mbox, sizeof(double) * B->mbox_len) != hipSuccess) return bail(fail(HIPX_ERR_HIP_BASE, "hipMalloc", __FILE__, __LINE__));
+    box_fill_kernel<<<4096, 256, 0, st>>>(B->d_mbox, B->mbox_len);
+  }
   *out = B;
   return HIPX_SUCCESS;
 }
@@ -700,11 +888,12 @@ extern "C" void hipxSorBoxShape_(void *p, int *nx, int *ny, int *nz)
   *nx = B->nx, *ny = B->ny, *nz = B->nz;
 }
 
-template <bool REV, int EM, int KIND>
-static int box_launch(hipxSorBox B, const BoxParams &Q)
+template <bool REV, int EM, int KIND, int G>
+static int box_launch_g(hipxSorBox B, BoxParams &Q)
 {
   static bool attr = false;
-  auto        kern = &sor_box_kernel<REV, EM, KIND>;
+  auto        kern = &sor_box_kernel<REV, EM, KIND, G>;
+  Q.ngroups        = (B->T + G - 1) / G;
   if (!attr) {
     HIPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, BX_LDS_BYTES));
     attr = true;
@@ -714,6 +903,15 @@ static int box_launch(hipxSorBox B, const BoxParams &Q)
   return HIPX_SUCCESS;
 }
 
+template <bool REV, int EM, int KIND>
+static int box_launch(hipxSorBox B, BoxParams &Q)
+{
+  static const int g = getenv("HIPX_SORBOX_G") ? atoi(getenv("HIPX_SORBOX_G")) : 4;  // developer switch: steps per staging / flushing group
+  if (g == 8) return box_launch_g<REV, EM, KIND, 8>(B, Q);
+  if (g == 2) return box_launch_g<REV, EM, KIND, 2>(B, Q);
+  return box_launch_g<REV, EM, KIND, 4>(B, Q);
+}
+
 // One zero-guess sweep.  kind 0: forward (rhs = b; t and x written; xfull = 0 inside a symmetric application: only the lines the schedule itself
 // hands between workgroups reach xout); kind 1: backward after forward (rhs = t); kind 2: backward alone (rhs = b).  xout must be filled with the
 // sentinel (sor_fill_kernel) before the launch: a row of x is its own ready flag between workgroups.  Vectors 16-byte aligned.
@@ -721,13 +919,13 @@ extern "C" int hipxSorBoxRun_(void *p, int kind, const double *rhs, double *tout
 {
   hipxSorBox B = (hipxSorBox)p;
   BoxParams  Q;
-  Q.nx = B->nx, Q.ny = B->ny, Q.nz = B->nz, Q.nb = B->nb, Q.nch = B->nch, Q.T = B->T, Q.ngroups = B->ngroups, Q.xfull = xfull;
+  Q.nx = B->nx, Q.ny = B->ny, Q.nz = B->nz, Q.nb = B->nb, Q.nch = B->nch, Q.T = B->T, Q.ngroups = 0, Q.xfull = xfull;
   Q.m = B->m;
   const bool plain = (omega == 1.0 && shift <= 0.0);
   Q.idiag = plain ? 1.0 / B->diag : omega / (shift + B->diag);  // MatInvertDiagonalForSOR_SeqAIJ aij.c:1797-1840
   Q.z0    = B->z0;
   Q.omw   = 1.0 - omega;
-  Q.rhs = rhs, Q.xout = xout, Q.tout = tout, Q.order = B->d_order, Q.ctl = B->d_ctl;
+  Q.rhs = rhs, Q.xout = xout, Q.tout = tout, Q.order = B->d_order, Q.ctl = B->d_ctl, Q.mbox = B->d_mbox;
   static const bool want_stats = getenv("HIPX_SORBOX_STATS") != nullptr;  // developer switch: where the waves wait
   static const int  dbg        = getenv("HIPX_SORBOX_DEBUG") ? atoi(getenv("HIPX_SORBOX_DEBUG")) : 0;
   Q.dbg = dbg;
@@ -778,6 +976,11 @@ extern "C" int hipxSorBoxRun_(void *p, int kind, const double *rhs, double *tout
     const double nw = (double)B->nb * B->nch * BX_P;
     fprintf(stderr, "[sorbox kind %d %dx%dx%d] per compute wave: steps %.0f, spins waiting for lower plane %.1f, stager %.1f, upper plane %.1f, flusher %.1f; per stager: ring waits %.1f, halo polls %.1f\n", kind,
             B->nx, B->ny, B->nz, (double)h[6] / nw, (double)h[0] / nw, (double)h[1] / nw, (double)h[2] / nw, (double)h[3] / nw, (double)h[4] / nw, (double)h[5] / nw);
+    {
+      const double np = (double)B->nb * (B->nch - 1 > 0 ? B->nch - 1 : 1);
+      const size_t o  = 8 + 2 * (size_t)B->nb * B->nch;
+      fprintf(stderr, "[sorbox south pollers] per poller: window passes %.1f, of them empty %.1f, waits for ring space %.1f, for %d pairs\n", (double)h[7] / np, (double)h[o] / np, (double)h[o + 1] / np, B->T / 2 + 1);
+    }
   }
   return ierr;
 }
@@ -787,6 +990,9 @@ extern "C" int hipxSorBoxError_(void *p, unsigned int *err)
   hipxSorBox B = (hipxSorBox)p;
   HIPX_HIP(hipMemcpyAsync(err, B->d_ctl + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, rt().compute));
   HIPX_HIP(hipStreamSynchronize(rt().compute));
-  if (*err) HIPX_HIP(hipMemsetAsync(B->d_ctl, 0, 2 * sizeof(unsigned int), rt().compute));
+  if (*err) {
+    HIPX_HIP(hipMemsetAsync(B->d_ctl, 0, 2 * sizeof(unsigned int), rt().compute));
+    if (B->mbox_len) box_fill_kernel<<<4096, 256, 0, rt().compute>>>(B->d_mbox, B->mbox_len);  // (a launch that gave up leaves entries behind)
+  }
   return HIPX_SUCCESS;
 }

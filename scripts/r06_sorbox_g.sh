@@ -1,0 +1,23 @@
+#!/bin/bash
+# Plane-march PCSOR A/B: bit parity on the small boxes, timings on the large ones, per-workgroup stamps of one application.
+#   bash scripts/r06_sorbox_g.sh [variant ...]     variant = old (the library in ab/old, when present) | g8 | g4 | g2 (HIPX_SORBOX_G of the stagers) | pN (HIPX_SORBOX_PRIO=N)
+#   QUICK=1: timings only; QUICK=2: timings and stamps
+cd "$(dirname "$0")/.." || exit 1
+for V in ${@:-g8}; do
+  unset HIPX_LIBDIR HIPX_SORBOX_G HIPX_SORBOX_PRIO HIPX_SORBOX_DEBUG
+  case $V in
+    old) export HIPX_LIBDIR=$PWD/ab/old ;;
+    g*) export HIPX_SORBOX_G=${V#g} ;;
+    p*) export HIPX_SORBOX_PRIO=${V#p} ;;
+    d*) export HIPX_SORBOX_DEBUG=${V#d} ;;  # timing probes, wrong results: 4 = no south poller, 8 = top plane flushed in groups of eight (nothing stored), 12 = both
+  esac
+  echo "=== variant $V"
+  if [ -z "$QUICK" ]; then
+    timeout 600 python scripts/sor_box_check.py quick 2>&1 | grep -v amdgpu.ids > /tmp/sbq.txt
+    echo "small boxes: $(grep -c 'bit-identical to the oracle' /tmp/sbq.txt) bit-identical, $(grep -c 'DIFFERENT\|ERROR' /tmp/sbq.txt) different"
+    grep 'DIFFERENT\|ERROR' /tmp/sbq.txt | head -5
+    grep ' rows ' /tmp/sbq.txt
+  fi
+  timeout 600 python scripts/sor_box_check.py timeonly 2>&1 | grep ' rows ' | grep "256^3\|slab"
+  [ "$QUICK" = 1 ] || HIPX_SORBOX_STATS=2 timeout 600 python scripts/sor_box_check.py stats 2>&1 | grep -A4 "sorbox" | grep -v "J=[2-9]\|J=1[0-9]" | cut -c1-420 | head -12
+done
