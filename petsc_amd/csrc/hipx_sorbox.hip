@@ -11,7 +11,11 @@
 //     j + 1 of plane k - 1 a row needs is always in its own block and every cross-workgroup dependency points to block J - 1 or to the
 //     chunk of planes below: hand-offs through memory add pipeline-fill latency once per block / chunk, not per plane hop;
 //   * right-hand side, results and the two west lines / the south plane a workgroup needs from its neighbours are moved by HELPER waves in
-//     16-byte accesses, four lanes per 64-byte line segment, transposed through LDS rings -- the compute waves never touch memory;
+//     16-byte accesses, transposed through LDS rings -- the compute waves never touch memory;
+//   * (round 6) the hop between CHUNKS goes through a mailbox: the top plane of a chunk leaves pair of rows by pair of rows, the 64 lanes' pairs of
+//     one flush side by side (1 KB), and a poller wave of the chunk above stages whole flushes as the chunk's "wave -1"; whoever reads an entry
+//     puts the sentinel back, so the mailbox is filled once per matrix.  Hop = 16 steps of skew + 3.7 us (round 5: groups of eight rows through x
+//     itself, 16 + 10 steps + 3.4 us);
 //   * lanes run in lockstep with a fixed skew: in step t wave w lane s is at row i = t - 2 - 2 s - 4 w.  The previous line (lane s - 1)
 //     is then two rows ahead, the lower plane's next line (wave w - 1, lane s) four: exactly what the 27-point stencil needs.
 // Arithmetic: sum = rhs; sum -= a_e * x_e for the dependency-side entries e in CSR order (forward: (dk, dj, di) ascending; backward:
@@ -35,7 +39,7 @@ namespace {
 
 constexpr int BX_P = 4;                                       // planes per workgroup (rows per staging / flushing group: the kernel's template parameter G)
 constexpr int BX_RX = 16, BX_RB = 32, BX_RS = 32, BX_RW = 32;  // ring rows: own x lines / rhs / south plane / west lines
-constexpr int BX_THREADS = 4 * BX_P * 64;                      // P compute waves + 2 P stagers (even / odd groups) + P flushers
+constexpr int BX_THREADS = 4 * BX_P * 64;                      // P compute waves + 2 P stagers (even / odd groups) + 2 flushers of planes 0 .. P - 2 + the top plane's flusher + the south plane's poller
 // LDS layout (doubles)
 constexpr int BX_OX = 0;                                        // X [P][64][RX + 1]
 constexpr int BX_OS = BX_OX + BX_P * 64 * (BX_RX + 1);          // S [66][RS + 1]
@@ -109,9 +113,10 @@ __device__ __forceinline__ void bx_store2_sc1(double *p, bx_double2 v)
 // EM: bit e set = the interior row has the dependency-side entry at canonical position e.  KIND as in hipx_sor.hip: 0 forward zero-guess
 // (t = sum, x = sum idiag), 1 backward after forward (x = (1 - w) (t idiag) + sum idiag: aij.c:1955 with the forward result x = t idiag
 // re-formed from t), 2 backward zero-guess alone.
-// Waves of a workgroup: w = 0..P-1 compute (plane k0 + w), then two stagers per plane (even / odd groups: right-hand side + west lines + south
-// plane into the LDS rings), then one flusher per plane (results out of the rings to memory).  Counters in LDS are the only synchronisation
-// inside the workgroup; between workgroups a row of x in memory is its own ready flag.
+// Waves of a workgroup: w = 0..P-1 compute (plane k0 + w), then two stagers per plane (even / odd groups: right-hand side + west lines into the
+// LDS rings), then two flushers for planes 0 .. P - 2 (results out of the rings to memory), the flusher of the top plane (pair by pair: x, t and
+// the mailbox) and the poller of the south plane.  Counters in LDS are the only synchronisation inside the workgroup; between workgroups a row of
+// x (a mailbox entry) in memory is its own ready flag.
 //
 // What a step costs is INSTRUCTIONS: a lone wave issues one instruction every 4-5 clocks whatever its kind, and the dependent arithmetic of a
 // 27-point row (13 products and differences + the scaling) is 88 clocks by itself (scripts/diag/lat_probe.hip).  The first versions of this loop
@@ -156,12 +161,12 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
 {
   constexpr int BX_G = G;
   constexpr int PPL = G / 2, LPP = 64 / PPL, NPASS = 64 / LPP;  // lanes (pairs of rows) per line and group; lines per pass; passes over the 64 lines
-  static_assert(G == 8 || G == 4 || G == 2, "group of 2, 4 or 8 steps");
+  static_assert(G == 8, "groups of eight steps (the flushers count on two groups per ring)");
   extern __shared__ double bx_smem[];
   bx_lds_double *L = (bx_lds_double *)bx_smem;
   // Counters: 16-bit "steps done", one 8-byte record per READER so that a wave fetches everything it waits for with one LDS access:
   //   C[w] (compute wave w)         = {relaxed by plane w - 1 (w = 0: virtual steps of the south plane staged), staged for plane w, relaxed by plane w + 1, flushed of plane w}
-  //   H[w] (stagers / flusher of w) = {relaxed by plane w, relaxed by plane w + 1, staged for plane w, unused}
+  //   H[w] (stagers / flusher of w) = {relaxed by plane w, relaxed by plane w + 1, staged for plane w, w = P - 1: steps whose rows the mailbox wave has read}
   // A writer stores its counter into every record that holds it (one ds_write_b16, one lane per copy).  Planes that do not exist read 0xffff.
   bx_lds_u16 *c16 = (bx_lds_u16 *)(L + BX_OC);
   bx_lds_int *abortw = (bx_lds_int *)(c16 + 8 * BX_P + 8), *tick = abortw + 1;
@@ -396,25 +401,34 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
 
   if (hw >= 2 * BX_P) {
     if (hw == 2 * BX_P || hw == 2 * BX_P + 3) {
-      // ------------------------------------------------------------------------------------------ flushers of planes k0 .. k0 + P - 2
-      // Two waves for P - 1 planes (P = 4: planes 0, 1 and plane 2).  What does not change from group to group is formed once and a group's ring reads
-      // are requested together: with flush_rows' index arithmetic and one LDS round trip per pass the wave with two planes took longer than the eight
-      // steps it has, and its planes -- then everybody -- ran at 400 ns per step instead of 300.
-      constexpr int NPL = (BX_P - 1) / 2 + 1;  // planes of the first wave (the second has the rest)
-      const int     w_lo = hw == 2 * BX_P ? 0 : NPL, w_hi = hw == 2 * BX_P ? NPL : BX_P - 1;
-      bool          lok[NPL][NPASS], xst[NPL][NPASS];
-      int           rb[NPL][NPASS], ro[NPL][NPASS];
-      long long     e0[NPL][NPASS];
+      // ------------------------------------------------------------------------------------------ flushers of planes k0 .. k0 + P - 1
+      // Two waves for the P planes' results: x and t to memory in groups of G steps, 64-byte pieces.  The wave shares its SIMD with a compute wave
+      // and gets an issue slot every 5-8 clocks: a group of one plane may cost ~70 instructions, not 400 -- ring offsets (two phases: a group is
+      // half the 16-row ring), row numbers and addresses are formed once and advanced by a group per pass.  (With the index arithmetic of the first
+      // version a wave with two planes took longer than the eight steps it has, and its planes -- then everybody -- ran at 360-460 ns per step
+      // instead of 305.)
+      static_assert(BX_G == 8 && BX_RX == 16, "two phases of the ring per group");
+      constexpr int NPL = (BX_P + 1) / 2;  // planes of the first wave (the second has the rest)
+      const int     w_lo = hw == 2 * BX_P ? 0 : NPL, w_hi = hw == 2 * BX_P ? NPL : BX_P;
+      bool          lok[NPL][NPASS], xst[NPL][NPASS], wt[NPL][NPASS];
+      int           rr[NPL][NPASS], la[NPL][NPASS], lb[NPL][NPASS];
+      double       *xp[NPL][NPASS], *tp[NPL][NPASS];
 #pragma unroll
       for (int pl = 0; pl < NPL; pl++)
 #pragma unroll
         for (int p = 0; p < NPASS; p++) {
           const int w = w_lo + pl, s = LPP * p + lane / PPL, qd = lane % PPL, k = k0 + w, jj = 64 * J - k + s;
           lok[pl][p] = w < w_hi && k < nz && jj >= 0 && jj < ny;
-          xst[pl][p] = Q.xfull || s >= 62;  // forward sweep inside a symmetric application: only the lines other workgroups read go to memory
-          rb[pl][p]  = -2 - 2 * s - 4 * w + 2 * qd;
-          ro[pl][p]  = (w * 64 + s) * (BX_RX + 1);
-          e0[pl][p]  = lok[pl][p] ? phys(0, jj, k) : 0;
+          xst[pl][p] = Q.xfull || s >= 62;  // forward sweep inside a symmetric application: only the lines other workgroups read in x itself go to memory
+                                            // (the chunk's top plane travels through the mailbox)
+          wt[pl][p]  = s >= 62;  // (the lines other workgroups poll in x itself -- block J + 1's west lines: write-through, a row is its own ready flag;
+                                 //  everything else only has to be in memory when the kernel ends)
+          rr[pl][p]  = -2 - 2 * s - 4 * w + 2 * qd;  // first row of the pair in group 0 (even: the pair does not wrap in the ring)
+          la[pl][p]  = (w * 64 + s) * (BX_RX + 1) + (rr[pl][p] & (BX_RX - 1));
+          lb[pl][p]  = (w * 64 + s) * (BX_RX + 1) + ((rr[pl][p] + BX_G) & (BX_RX - 1));
+          const long long e0 = lok[pl][p] ? phys(0, jj, k) : 0;
+          xp[pl][p]  = Q.xout + (REV ? e0 - rr[pl][p] : e0 + rr[pl][p]);
+          tp[pl][p]  = KIND == 0 ? Q.tout + e0 + rr[pl][p] : nullptr;
         }
       for (int fg = 0; fg * BX_G < T; fg++) {
         const int need = (fg + 1) * BX_G < T ? (fg + 1) * BX_G : T;
@@ -427,79 +441,73 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
           bx_double2 xv[NPASS], tv[NPASS];
 #pragma unroll
           for (int p = 0; p < NPASS; p++) {
-            const int r = BX_G * fg + rb[pl][p];
-            xv[p].x = L[BX_OX + ro[pl][p] + (r & (BX_RX - 1))];
-            xv[p].y = L[BX_OX + ro[pl][p] + ((r + 1) & (BX_RX - 1))];
+            const int off = (fg & 1) ? lb[pl][p] : la[pl][p];
+            xv[p].x = L[BX_OX + off];
+            xv[p].y = L[BX_OX + off + 1];
             if (KIND == 0) {
-              tv[p].x = L[BX_OT + ro[pl][p] + (r & (BX_RX - 1))];
-              tv[p].y = L[BX_OT + ro[pl][p] + ((r + 1) & (BX_RX - 1))];
+              tv[p].x = L[BX_OT + off];
+              tv[p].y = L[BX_OT + off + 1];
             }
           }
 #pragma unroll
           for (int p = 0; p < NPASS; p++) {
-            const int r = BX_G * fg + rb[pl][p];
-            if (lok[pl][p] && r >= 0 && r < nx && !(Q.dbg & 32)) {
+            if (lok[pl][p] && (unsigned)rr[pl][p] < (unsigned)nx && !(Q.dbg & 32)) {
               if (xst[pl][p]) {
                 bx_double2 v = xv[p];
-                if (REV) {
-                  const double tmp = v.x;
-                  v.x              = v.y;
-                  v.y              = tmp;
-                }
-                bx_store2_sc1(Q.xout + (REV ? e0[pl][p] - r : e0[pl][p] + r), v);
+                if (REV) v.x = xv[p].y, v.y = xv[p].x;
+                if (wt[pl][p]) bx_store2_sc1(xp[pl][p], v);
+                else *reinterpret_cast<bx_double2 *>(xp[pl][p]) = v;
               }
-              if (KIND == 0) *reinterpret_cast<bx_double2 *>(Q.tout + e0[pl][p] + r) = tv[p];  // (forward: never REV)
+              if (KIND == 0) *reinterpret_cast<bx_double2 *>(tp[pl][p]) = tv[p];  // (forward: never REV)
             }
+            rr[pl][p] += BX_G;
+            xp[pl][p] += REV ? -BX_G : BX_G;
+            if (KIND == 0) tp[pl][p] += BX_G;
           }
           bx_lds_release();  // (the ring reads are done; the stores may still be on their way)
+          if (w == BX_P - 1 && !bx_wait16(Hrec(w) + 3, need, abortw, gerr)) return;  // (the top plane's rows are also read by the mailbox wave)
           if (lane == 0) bx_put16(Crec(w) + 3, need);
         }
       }
     } else if (hw == 2 * BX_P + 1) {
       // ------------------------------------------------------------------------------------------ flusher of the top plane k0 + P - 1
-      // (everything that does not change from pair to pair is formed once: the loop must keep up with a pair every two steps, ~1400 clocks,
-      // LDS latencies included -- with the general flush_rows and a sleep after every pair it did not, and the top wave, then everybody, ran at
-      // 400 ns per step instead of 300)
+      // The chunk's top plane on its way up, pair by pair: the 64 lanes' rows of the last two steps into the MAILBOX of the chunk above (flush f = 1 KB
+      // in one store instruction; through x itself the pairs of a flush lie nx rows apart: 64 partial lines for the poller above to collect).  Every
+      // lane writes its entry of every flush from 7 on, the zero element where it has no row (and eight flushes of zero elements past the end of the
+      // lines): the poller checks and stages whole flushes without a per-lane notion of what it needs.  Nothing else goes through this wave's memory
+      // queue: with the plane's x and t in it (pair by pair: 64 partial lines per store instruction in front of the mailbox store, 0.3 ms per
+      // application wherever the vectors lay unfavourably; group by group: every fourth flush late by the group's round trips) the hop grew by 3-8 us.
       constexpr int w = BX_P - 1;
-      const int     k = k0 + w, jj = 64 * J - k + lane;
-      const bool    lok = k < nz && jj >= 0 && jj < ny;
-      const long long e0 = lok ? phys(0, jj, k) : 0;
-      double       *xl = Q.xout + e0, *tl = KIND == 0 ? Q.tout + e0 : nullptr;
-      // the chunk above takes the plane from the MAILBOX: flush f = the 64 lanes' pairs side by side, 1 KB per flush (through x itself the 64 pairs of a
-      // flush lie nx rows apart: 64 partial lines on one or two memory channels per request of its poller)
-      double       *mb = c + 1 < Q.nch ? Q.mbox + ((size_t)c * Q.nb + J) * (size_t)(T / 2 + 8) * 128 + 2 * lane : nullptr;
-      const int     xo = BX_OX + (w * 64 + lane) * (BX_RX + 1), to = BX_OT + (w * 64 + lane) * (BX_RX + 1);
+      const int     k = k0 + w;
+      const bool    lok = k < nz && 64 * J - k + lane >= 0 && 64 * J - k + lane < ny;
+      // H[P - 1][3] = the steps whose rows this wave has read out of the x ring: the plane's flusher lets go of a group only when it is past it
+      if (!(c + 1 < Q.nch && __any(lok))) {  // (no chunk above, or a plane without a line in the grid: nothing is sent, nothing is waited for)
+        if (lane == 0) bx_put16(Hrec(w) + 3, 0xffff);
+        return;
+      }
+      if (lane == 0) bx_put16(Hrec(w) + 3, 14);  // (the flushes before the seventh hold no row of the grid)
+      double       *mb = Q.mbox + ((size_t)c * Q.nb + J) * (size_t)(T / 2 + 8) * 128 + 2 * lane;
+      const int     xo = BX_OX + (w * 64 + lane) * (BX_RX + 1);
       bx_lds_u16   *rel = Hrec(w);
-      const int     fstep = (Q.dbg & 8) ? 8 : 2;  // (timing probe: groups of eight steps, nothing flushed)
-      for (int need = fstep; need <= T; need += fstep) {  // (T: a multiple of four)
+      for (int need = 16; need <= T + 16; need += 2) {  // (T: a multiple of four)
         int       spins = 0;
         long long t0    = 0;
-        while (bx_get16(rel) < need) {
+        const int upto  = need < T ? need : T;
+        while (bx_get16(rel) < upto) {
           __builtin_amdgcn_s_sleep(1);
           if (give_up(spins, t0)) return;
         }
         bx_lds_acquire();
-        const int r = need - 4 - 2 * lane - 4 * w;  // the rows lane s relaxed in steps need - 2, need - 1
-        if (lok && r >= 0 && r < nx && !(Q.dbg & 24)) {
-          bx_double2 v;
+        const int  r = need - 4 - 2 * lane - 4 * w;  // the rows lane s relaxed in steps need - 2, need - 1: still in the ring (16 rows) -- the plane's
+        bx_double2 v;                               // flusher lets go of a group of eight only eight steps after its last row
+        v.x = v.y = z0;
+        if (lok && r >= 0 && r < nx) {
           v.x = L[xo + (r & (BX_RX - 1))];
           v.y = L[xo + ((r + 1) & (BX_RX - 1))];
-          if (KIND == 0) {
-            bx_double2 tv;
-            tv.x = L[to + (r & (BX_RX - 1))];
-            tv.y = L[to + ((r + 1) & (BX_RX - 1))];
-            *reinterpret_cast<bx_double2 *>(tl + r) = tv;  // (forward: never REV)
-          }
-          if (mb) bx_store2_sc1(mb + (size_t)(need / 2 - 1) * 128, v);  // (logical order: row r first)
-          if (REV) {
-            const double tmp = v.x;
-            v.x              = v.y;
-            v.y              = tmp;
-          }
-          bx_store2_sc1(REV ? xl - r : xl + r, v);
         }
+        bx_store2_sc1(mb + (size_t)(need / 2 - 1) * 128, v);  // (logical order: row r first)
         bx_lds_release();
-        if (lane == 0) bx_put16(Crec(w) + 3, need);
+        if (lane == 0) bx_put16(Hrec(w) + 3, upto);
       }
     } else if (hw == 2 * BX_P + 2) {
       // ------------------------------------------------------------------------------------------ poller of the south plane k0 - 1
@@ -520,8 +528,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
       constexpr int WIN = 4;
       const int     npairs = T / 2 + 1;
       const int     jj = 64 * J - (k0 - 1) + lane;
-      const bool    line_ok = jj >= 0 && jj < ny;
-      const bool    any_line = __any(line_ok);
+      const bool    any_line = __any(jj >= 0 && jj < ny);
       const int     so = BX_OS + (lane + 2) * (BX_RS + 1);
       double       *mb  = Q.mbox + ((size_t)(c - 1) * Q.nb + J) * (size_t)(T / 2 + 8) * 128 + 2 * lane;
       bx_double2    sentinel2;
@@ -529,7 +536,17 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
       int       base = 0, spins = 0;
       long long t0   = 0;
       unsigned  n_it = 0, n_empty = 0, n_lim = 0;  // HIPX_SORBOX_STATS: passes, passes that staged nothing, waits for ring space
-      bool      probe = true;
+      bool      probe = any_line;
+      unsigned long long tk_rt = 0, tk_pass = 0, n_staged = 0;
+      // rows 2 n - 2 s, + 1 of line s into the ring (row nx is the line's zero element: the chunk below sent it as such)
+      auto put = [&](int n, const bx_double2 &v, double *e) {
+        const int r = 2 * n - 2 * lane;
+        if ((unsigned)r <= (unsigned)nx) {
+          L[so + (r & (BX_RS - 1))]       = v.x;
+          L[so + ((r + 1) & (BX_RS - 1))] = v.y;
+        }
+        if (any_line) *reinterpret_cast<bx_double2 *>(e) = sentinel2;  // (read once: the entry is ready for the next sweep)
+      };
       while (base < npairs) {
         // ring space (32 rows): pair n overwrites the rows plane 0 asked for up to step 2 n - 28
         int lim = (bx_get16(Hrec(0)) + 19) >> 1;
@@ -540,44 +557,41 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
           if (give_up(spins, t0)) return;
           continue;
         }
-        const double *ent = mb + (size_t)(base + 7) * 128;
-        if (probe) {
-          // Nothing had arrived on the last pass: ONE lane asks for its rows of the next pair until they are there (all lines' rows of a pair leave the
-          // chunk below in one pass of its flusher): a waiting workgroup costs the memory system one request per round trip.
-          const int                rb   = 2 * base - 2 * lane;
-          const unsigned long long need = __ballot(line_ok && rb >= 0 && rb < nx);
-          if (need) {
-            const int  pl = __ffsll((long long)need) - 1;
-            bx_double2 pv;
-            pv.x = pv.y = z0;
-            if (lane == pl) pv = ld(ent);
-            if (__any(lane == pl && unset(pv))) {
-              __builtin_amdgcn_s_sleep(1);
-              if (give_up(spins, t0)) return;
-              continue;
-            }
+        double *ent = mb + (size_t)(base + 7) * 128;
+        if (probe && !(Q.dbg & 512)) {
+          // Nothing had arrived on the last pass: ONE lane asks for its entry of the next flush until it is there (a flush leaves the chunk below in one
+          // store instruction): a waiting workgroup costs the memory system one request per round trip.
+          bx_double2 pv;
+          pv.x = pv.y = z0;
+          if (lane == 0) pv = ld(ent);
+          if (__any(lane == 0 && unset(pv))) {
+            if (!(Q.dbg & 1024)) __builtin_amdgcn_s_sleep(1);
+            if (give_up(spins, t0)) return;
+            continue;
           }
           probe = false;
         }
         n_it++;
+        const unsigned long long tk0 = Q.stats ? wall_clock64() : 0;
         bx_double2 v0, v1, v2, v3;
         v0.x = v0.y = v1.x = v1.y = v2.x = v2.y = v3.x = v3.y = z0;
-        if (any_line)  // (a workgroup without any line in the grid asks for nothing)
+        if (any_line)  // (a plane without any line in the grid: nothing was sent)
           asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
                        "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
                        : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
                        : "v"(ent)
                        : "memory");
-        const bx_double2 vv[WIN] = {v0, v1, v2, v3};
-        bool             nd[WIN];
-        int              nlead = 0;
-        bool             lead  = true;
-#pragma unroll
-        for (int i = 0; i < WIN; i++) {
-          const int r = 2 * (base + i) - 2 * lane;
-          nd[i]       = line_ok && r >= 0 && r < nx;
-          lead        = lead && base + i < lim && !__any(nd[i] && unset(vv[i]));
-          nlead += lead ? 1 : 0;
+        if (Q.stats) tk_rt += wall_clock64() - tk0;
+        int nlead = 0;
+        if (!__any(unset(v0))) {
+          nlead = 1;
+          if (base + 1 < lim && !__any(unset(v1))) {
+            nlead = 2;
+            if (base + 2 < lim && !__any(unset(v2))) {
+              nlead = 3;
+              if (base + 3 < lim && !__any(unset(v3))) nlead = 4;
+            }
+          }
         }
         if (!nlead) {
           n_empty++;
@@ -586,27 +600,22 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
           continue;
         }
         spins = 0, t0 = 0;
-#pragma unroll
-        for (int i = 0; i < WIN; i++) {
-          if (i < nlead) {
-            const int r = 2 * (base + i) - 2 * lane;
-            if (r >= 0 && r <= nx) {  // (row nx: the line's zero element)
-              bx_double2 v = vv[i];
-              if (!nd[i]) v.x = v.y = z0;
-              L[so + (r & (BX_RS - 1))]       = v.x;
-              L[so + ((r + 1) & (BX_RS - 1))] = v.y;
-            }
-            if (nd[i]) *reinterpret_cast<bx_double2 *>(mb + (size_t)(base + i + 7) * 128) = sentinel2;  // (read once: ready for the next sweep)
-          }
-        }
+        put(base, v0, ent);
+        if (nlead > 1) put(base + 1, v1, ent + 128);
+        if (nlead > 2) put(base + 2, v2, ent + 256);
+        if (nlead > 3) put(base + 3, v3, ent + 384);
         bx_lds_release();
         base += nlead;
         if (lane == 0) bx_put16(sc, 2 * base);  // (virtual steps -2 .. 2 base - 3 are staged)
+        if (Q.stats) tk_pass += wall_clock64() - tk0, n_staged += nlead;
       }
       if (Q.stats && lane == 0) {
         atomicAdd(Q.stats + 7, (unsigned long long)n_it);
         atomicAdd(Q.stats + 8 + 2 * Q.nb * Q.nch, (unsigned long long)n_empty);
         atomicAdd(Q.stats + 9 + 2 * Q.nb * Q.nch, (unsigned long long)n_lim);
+        atomicAdd(Q.stats + 10 + 2 * Q.nb * Q.nch, tk_rt);
+        atomicAdd(Q.stats + 11 + 2 * Q.nb * Q.nch, tk_pass);
+        atomicAdd(Q.stats + 12 + 2 * Q.nb * Q.nch, n_staged);
       }
     }
     return;
@@ -906,10 +915,7 @@ static int box_launch_g(hipxSorBox B, BoxParams &Q)
 template <bool REV, int EM, int KIND>
 static int box_launch(hipxSorBox B, BoxParams &Q)
 {
-  static const int g = getenv("HIPX_SORBOX_G") ? atoi(getenv("HIPX_SORBOX_G")) : 4;  // developer switch: steps per staging / flushing group
-  if (g == 8) return box_launch_g<REV, EM, KIND, 8>(B, Q);
-  if (g == 2) return box_launch_g<REV, EM, KIND, 2>(B, Q);
-  return box_launch_g<REV, EM, KIND, 4>(B, Q);
+  return box_launch_g<REV, EM, KIND, 8>(B, Q);  // (groups of 4 and 2 steps were measured in round 6: the stagers cannot keep up -- 2.88 / 3.42 ms against 2.80)
 }
 
 // One zero-guess sweep.  kind 0: forward (rhs = b; t and x written; xfull = 0 inside a symmetric application: only the lines the schedule itself
@@ -980,6 +986,8 @@ extern "C" int hipxSorBoxRun_(void *p, int kind, const double *rhs, double *tout
       const double np = (double)B->nb * (B->nch - 1 > 0 ? B->nch - 1 : 1);
       const size_t o  = 8 + 2 * (size_t)B->nb * B->nch;
       fprintf(stderr, "[sorbox south pollers] per poller: window passes %.1f, of them empty %.1f, waits for ring space %.1f, for %d pairs\n", (double)h[7] / np, (double)h[o] / np, (double)h[o + 1] / np, B->T / 2 + 1);
+      fprintf(stderr, "[sorbox south pollers] per pass: loads %.2f us; a pass that staged something %.2f us, %.2f pairs\n", (double)h[o + 2] * 0.01 / (double)(h[7] ? h[7] : 1),
+              (double)h[o + 3] * 0.01 / (double)((h[7] - h[o]) ? (h[7] - h[o]) : 1), (double)h[o + 4] / (double)((h[7] - h[o]) ? (h[7] - h[o]) : 1));
     }
   }
   return ierr;

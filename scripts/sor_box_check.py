@@ -123,6 +123,8 @@ e0, e1 = C.c_void_p(), C.c_void_p()
 _lib.chk(hx.hipxEventCreate(C.byref(e0)))
 _lib.chk(hx.hipxEventCreate(C.byref(e1)))
 big = [("27-pt 128^3", 27, (128, 128, 128), None), ("7-pt 128^3", 7, (128, 128, 128), None), ("7-pt 512x256x96", 7, (512, 256, 96), None)]
+if "first256" in sys.argv:  # (the 27-pt 256^3 case first and last: its time depends on what the process has allocated and freed before)
+    big = [("27-pt 256^3", 27, (256, 256, 256), None)] + big + [("27-pt 256^3", 27, (256, 256, 256), None)]
 if "quick" not in sys.argv:
     big += [("27-pt 256^3", 27, (256, 256, 256), None), ("7-pt 256^3", 7, (256, 256, 256), None), ("27-pt 512x512x64 (config 3's slab)", 27, (512, 512, 512), 64)]
 for name, st, dims, planes in big:

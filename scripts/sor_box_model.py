@@ -9,8 +9,12 @@ Schedule (logical coordinates; the backward sweep is the forward one on the mirr
                       points to block J - 1, never to J + 1)
   workgroup (J, c)  : planes k = P c + w, wave w = 0..P-1; compute step t: wave w lane s is at row i = t - 2 - 2 s - 4 w
                       (i = -2: idle, i = -1: loads row 0 of its neighbours, 0 <= i < nx: relaxes row i)
-  neighbours        : lower plane k - 1 = ring slot w (slot 0 = south plane, staged from global x by helper 0), line indices s, s+1, s+2;
+  neighbours        : lower plane k - 1 = ring slot w (slot 0 = south plane), line indices s, s+1, s+2;
                       previous line of the same plane = slot w + 1, line index s + 1; index 0, 1 = west lines (from block J - 1 through global x)
+  south plane       : (round 6) "wave -1" of the chunk: its virtual step v holds row v + 2 - 2 s of line index s + 2; a POLLER stages pair n = virtual
+                      steps 2 n - 2, 2 n - 1 = rows 2 n - 2 s, + 1 (what the chunk below flushed pair by pair: its flush n + 7) when wave 0 is past
+                      step 2 n - 17, and wave 0 waits for it as wave w waits for wave w - 1; line indices 0, 1 still come with helper 0's groups
+  flushers          : planes 0 .. P - 2 in groups of G steps, the top plane pair by pair
 """
 import random
 import sys
@@ -79,6 +83,8 @@ class Model:
         hprog = [0] * P        # steps whose inputs are staged (helper w)
         flush = [0] * P        # steps whose outputs are flushed (helper w)
         hgroup = [0] * P
+        pbase = [0]            # south poller: pairs staged (virtual steps -2 .. 2 pbase - 3)
+        npairs = self.T // 2 + 1 + (self.T % 2)
         ngroups = (self.T + G - 1) // G
         nx2 = nx
         regs = {}
@@ -122,8 +128,8 @@ class Model:
                 for r in range(r0, r0 + G):
                     if 0 <= r < nx:
                         W[w + 1][q][r % RW] = (r, gvalue(r, j, k))
-            if w == 0:  # (c) south plane k0 - 1: line index q rows [8 g - 2 max(q - 2, 0), + 8)
-                for q in range(66):
+            if w == 0:  # (c) south plane k0 - 1, the two lines in front of block J's: line index q rows [8 g, + 8)
+                for q in range(2):
                     j = 64 * J - (k0 - 1) + q - 2
                     r0 = G * g - 2 * max(q - 2, 0)
                     for r in range(r0, r0 + G):
@@ -132,16 +138,35 @@ class Model:
             hgroup[w] += 1
             hprog[w] = G * (g + 1)
 
-        def flush_ready(w):  # outputs of step group g leave once the wave has finished it
-            return flush[w] < self.T and cprog[w] >= min(flush[w] + G, self.T)
+        def fgran(w):  # the top plane leaves pair by pair
+            return 2 if w == P - 1 else G
+
+        def flush_ready(w):  # outputs of a group of steps leave once the wave has finished it
+            return flush[w] < self.T and cprog[w] >= min(flush[w] + fgran(w), self.T)
+
+        def poller_ready():
+            n = pbase[0]
+            return n < npairs and cprog[0] >= 2 * n - 17
+
+        def poller_step():
+            n = pbase[0]
+            for s in range(64):
+                j = 64 * J - (k0 - 1) + s
+                for r in (2 * n - 2 * s, 2 * n - 2 * s + 1):
+                    if 0 <= r < nx:
+                        if k0 > 0:
+                            rr, _ = S[s + 2][r % RS] if S[s + 2][r % RS] is not None else (None, None)
+                            assert rr is None or rr <= r - RS or rr == r, ("south ring overwritten before plane 0 read it", s, r, rr)
+                        S[s + 2][r % RS] = (r, gvalue(r, j, k0 - 1))
+            pbase[0] = n + 1
 
         def flush_step(w):
-            g = flush[w] // G
+            g = flush[w] // fgran(w)
             k = k0 + w
             for s in range(64):
                 j = 64 * J - k + s
-                r0 = G * g - 2 - 2 * s - 4 * w
-                for r in range(r0, r0 + G):
+                r0 = fgran(w) * g - 2 - 2 * s - 4 * w
+                for r in range(r0, r0 + fgran(w)):
                     if 0 <= r < nx and 0 <= j < ny and k < nz:
                         rr, v = X[w + 1][s + 2][r % RX]
                         assert rr == r, ("x ring overwritten before the flush", w, s, r, rr)
@@ -149,7 +174,7 @@ class Model:
                         rr, v = TR[w][s][r % RX]
                         assert rr == r
                         self.gt[self.lrow(r, j, k)] = v
-            flush[w] = min(flush[w] + G, self.T)
+            flush[w] = min(flush[w] + fgran(w), self.T)
 
         def read(slot, idx, r):
             if not 0 <= r < nx:
@@ -168,6 +193,8 @@ class Model:
             if t >= self.T:
                 return False
             if w > 0 and cprog[w - 1] < min(t - 2, self.T):  # lower plane: row i + 1 of line j + 1 was relaxed by wave w - 1 in ITS step t - 3
+                return False
+            if w == 0 and 2 * pbase[0] < min(t - 2, self.T) + 2:  # the south plane's virtual step t - 3 is staged
                 return False
             if hprog[w] <= t:  # inputs of this step staged
                 return False
@@ -221,13 +248,13 @@ class Model:
                     regs.pop((w, s))
             cprog[w] = t + 1
 
-        agents = [("h", w) for w in range(P)] + [("c", w) for w in range(P)] + [("f", w) for w in range(P)]
+        agents = [("h", w) for w in range(P)] + [("c", w) for w in range(P)] + [("f", w) for w in range(P)] + [("p", 0)]
         while True:
-            runnable = [a for a in agents if {"h": helper_ready, "c": compute_ready, "f": flush_ready}[a[0]](a[1])]
+            runnable = [a for a in agents if {"h": helper_ready, "c": compute_ready, "f": flush_ready, "p": lambda _w: poller_ready()}[a[0]](a[1])]
             if not runnable:
                 break
             kind, w = self.rng.choice(runnable)
-            {"h": helper_step, "c": compute_step, "f": flush_step}[kind](w)
+            {"h": helper_step, "c": compute_step, "f": flush_step, "p": lambda _w: poller_step()}[kind](w)
         assert all(cprog[w] == self.T for w in range(P)) and all(flush[w] == self.T for w in range(P)), ("deadlock", J, c, cprog[:P], hprog, flush)
 
 

@@ -412,6 +412,36 @@ def test_plane_march_bit_exact(hx, nx, ny, nz, full27, flag, omega, shift):
     assert np.array_equal(g, o), np.abs(g - o).max()
 
 
+@pytest.mark.parametrize("nx,ny,nz,full27", [(64, 30, 32, True), (256, 40, 20, True), (40, 70, 21, False), (10, 5, 70, True)])
+def test_plane_march_mailbox_is_reusable(hx, nx, ny, nz, full27):
+    """Round 6: the hop between chunks goes through a mailbox that is filled with the sentinel ONCE per matrix -- the poller that reads an entry puts the
+    sentinel back.  One matrix, eight applications of different kinds and right-hand sides in a row (forward, backward, symmetric; the forward sweep
+    inside a symmetric application sends its planes through the same mailbox as the backward one): an entry left behind by one sweep would be taken for
+    the next sweep's row.  5 to 18 chunks; one block of lines and several; a grid whose upper chunks have no line of block 0."""
+    from petsc_amd import _lib
+    ai, aj, aa = box_csr(nx, ny, nz, full27)
+    N = nx * ny * nz
+    A = _lib.mat_create_csr(N, N, ai, aj, aa)
+    rng = np.random.default_rng(11)
+    try:
+        with sor_mode("box"):
+            for rep, (flag, omega, shift) in enumerate([(LSYM | ZERO, 1.0, 0.0), (FWD | ZERO, 1.0, 0.0), (BWD | ZERO, 1.3, 0.0), (LSYM | ZERO, 1.3, 0.25), (LSYM | ZERO, 1.0, 0.0), (LBWD | ZERO, 0.8, 0.0),
+                                                        (LFWD | ZERO, 1.0, 0.0), (SYM | ZERO, 1.0, 0.0)]):
+                b = rng.standard_normal(N)
+                B, X = _lib.DVec(N, b), _lib.DVec(N, np.zeros(N))
+                _lib.chk(hx.hipxMatSOR(A, B.ptr, omega, flag, shift, 1, 1, X.ptr))
+                used = C.c_int(-2)
+                _lib.chk(hx.hipxMatGetSORMode(A, C.byref(used)))
+                assert used.value == MODES["box"]
+                g = X.get()
+                B.free()
+                X.free()
+                o = sor_cpu(ai, aj, aa, b, omega, flag, shift, 1, 1, np.zeros(N))
+                assert np.array_equal(g, o), (rep, flag, np.abs(g - o).max())
+    finally:
+        _lib.mat_destroy(A)
+
+
 def test_plane_march_declines_what_it_does_not_cover(hx):
     """Couplings of both signs, a second diagonal value, an odd line length, arbitrary values, nonzero-guess sweeps: the plane march says no and the
     strands / levels run (still bit-identical)."""
