@@ -64,7 +64,8 @@ struct hipxSorState {
 // hipx_sorbox.hip
 extern "C" int  hipxSorBoxBuild_(long long m, int ntmpl, const int *tstart, const int *toff, const double *tval, const int *tdiag, const int64_t *tcount, const unsigned char *d_tid, void **out);
 extern "C" int  hipxSorBoxRun_(void *box, int kind, const double *rhs, double *tout, double *xout, double omega, double shift, int xfull);
-extern "C" int  hipxSorBoxError_(void *box, unsigned int *err);
+extern "C" int  hipxSorBoxError_(void *box, unsigned int *err, int sync);
+extern "C" int  hipxSorBoxFill_(void *box, double *xout, int rev);
 extern "C" void hipxSorBoxFree_(void *box);
 
 extern "C" {
@@ -3211,19 +3212,16 @@ static int mat_sor_impl(hipxMat A, const double *b, double omega, int flag, doub
         const hipx_int gf  = std::min<hipx_int>((m + 255) / 256, 4096);
         const bool     fwd = (flag & 1) || (flag & 4), bwd = (flag & 2) || (flag & 8);
         if (fwd && bwd) {  // the forward result itself is not needed: the backward sweep re-forms x = t idiag from t (aij.c:1955)
-          sor_fill_kernel<<<(unsigned)gf, 256, 0, st>>>(S->d_w1, m);
-          sor_fill_kernel<<<(unsigned)gf, 256, 0, st>>>(x, m);
-          HIPX_LAUNCH_CHECK();
+          if ((ierr = hipxSorBoxFill_(S->box, S->d_w1, 0)) || (ierr = hipxSorBoxFill_(S->box, x, 1))) return ierr;
           if ((ierr = hipxSorBoxRun_(S->box, 0, b, S->d_t, S->d_w1, omega, shift, 0))) return ierr;
           if ((ierr = hipxSorBoxRun_(S->box, 1, S->d_t, nullptr, x, omega, shift, 1))) return ierr;
         } else {
-          sor_fill_kernel<<<(unsigned)gf, 256, 0, st>>>(x, m);
-          HIPX_LAUNCH_CHECK();
+          if ((ierr = hipxSorBoxFill_(S->box, x, fwd ? 0 : 1))) return ierr;
           if ((ierr = hipxSorBoxRun_(S->box, fwd ? 0 : 2, b, S->d_t, x, omega, shift, 1))) return ierr;
         }
         S->mode = S->last_mode = 4;
         unsigned int herr = 0;
-        if ((ierr = hipxSorBoxError_(S->box, &herr))) return ierr;
+        if ((ierr = hipxSorBoxError_(S->box, &herr, 0))) return ierr;  // (the word of the application before this one; this one's: next time)
         if (herr) return fail(HIPX_ERR_GPU, "MatSOR (plane march): a dependency was never published (wait limit reached)", __FILE__, __LINE__);
         return HIPX_SUCCESS;
       }

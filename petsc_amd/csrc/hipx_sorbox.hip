@@ -294,11 +294,11 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     // one step (PH = t & 3): the record is requested; row i is relaxed out of registers; the results go to the rings and the step is published with
     // NO wait in between (a wave's LDS operations are executed in order: whoever sees the counter sees the rows); the record decides whether step
     // t + 2 may be prepared; its operands are requested
-#define BX_STEP(PH) \
+#define BX_STEP(PH, GUARD) \
   { \
     const int t_ = t + (PH), i = t_ + i0; \
     constexpr int M1 = ((PH) + 3) & 3, C0 = (PH), P1 = ((PH) + 1) & 3, S2 = (PH) & 1; \
-    if (t_ + 2 < T) look_issue(); \
+    if (!(GUARD) || t_ + 2 < T) look_issue(); \
     { /* the previous line's row i + 1: lane s - 1 relaxed it in the step before (wavefront shift); lane 0 takes the west line's */ \
       const int nlo = __builtin_amdgcn_update_dpp(__double2loint(Ww[S2]), __double2loint(xcur), 0x138 /* wave_shr:1 */, 0xf, 0xf, false); \
       const int nhi = __builtin_amdgcn_update_dpp(__double2hiint(Ww[S2]), __double2hiint(xcur), 0x138, 0xf, 0xf, false); \
@@ -319,17 +319,23 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     if (KIND == 1) xv = Q.omw * (rhs * Q.idiag) + sum * Q.idiag; \
     else xv = sum * Q.idiag; \
     xcur = (valid && (unsigned)i < (unsigned)nx) ? xv : z0; /* beyond the line, and a lane without a line: the zero element */ \
+    bool rdy_ = true; \
+    if (!(GUARD) || t_ + 2 < T) { /* the record is looked at BEFORE the ring writes are issued: behind them the wait for it is a wait for them too */ \
+      look_take(); \
+      rdy_ = ready(t_ + 2); \
+    } \
     if ((unsigned)i <= (unsigned)nx) L[xo + (i & (BX_RX - 1))] = xcur; \
     if (KIND == 0 && (unsigned)i < (unsigned)nx) L[to + (i & (BX_RX - 1))] = sum; \
     asm volatile("" ::: "memory"); /* ring writes, then the counter: program order = LDS order */ \
     if (lane < 4) bx_put16(pub, t_ + 1); \
-    if (t_ + 2 < T) { \
-      look_take(); \
-      if (!ready(t_ + 2)) { \
+    if (!(GUARD) || t_ + 2 < T) { \
+      if (!rdy_) { \
+        look_issue(); \
+        look_take(); \
         alive = wait_ready(t_ + 2); \
         if (!alive) break; \
       } \
-      bx_lds_acquire(); \
+      bx_lds_acquire(); /* (asking for the operands before the ring writes -- they come out of other waves' rings -- was measured: 279 -> 297 ns per step) */ \
       BX_REQUEST(t_ + 2, M1, S2) \
     } \
   }
@@ -341,11 +347,18 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
       BX_REQUEST(0, 1, 0)
       BX_REQUEST(1, 2, 1)
     }
-    for (int t = 0; t < T && alive; t += 4) {
-      BX_STEP(0)
-      BX_STEP(1)
-      BX_STEP(2)
-      BX_STEP(3)
+    int t = 0;
+    for (; t + 8 <= T && alive; t += 4) {  // (every step of these groups prepares a step t + 2 < T: no end-of-line checks)
+      BX_STEP(0, false)
+      BX_STEP(1, false)
+      BX_STEP(2, false)
+      BX_STEP(3, false)
+    }
+    for (; t < T && alive; t += 4) {
+      BX_STEP(0, true)
+      BX_STEP(1, true)
+      BX_STEP(2, true)
+      BX_STEP(3, true)
     }
 #undef BX_STEP
 #undef BX_REQUEST
@@ -731,6 +744,21 @@ __global__ void box_fill_kernel(double *x, size_t n)
   for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) x[q] = __longlong_as_double((long long)BX_SENTINEL);
 }
 
+// The rows other workgroups poll in x itself are the last two lines of every block (lanes 62, 63: the west lines of block J + 1, and the two lines of
+// the south plane in front of its lines): LOGICAL line j of plane k with (j + k) mod 64 in {62, 63}; rev: the mirrored grid.  One wave per line.
+__global__ void box_fill_lines_kernel(double *x, int nx, int ny, int nz, int rev)
+{
+  const int       lane = threadIdx.x & 63;
+  const long long nl = (long long)ny * nz, wpg = blockDim.x >> 6;
+  for (long long l = (long long)blockIdx.x * wpg + (threadIdx.x >> 6); l < nl; l += (long long)gridDim.x * wpg) {
+    const int j = (int)(l % ny), k = (int)(l / ny);
+    const int jl = rev ? ny - 1 - j : j, kl = rev ? nz - 1 - k : k;
+    if (((jl + kl) & 63) < 62) continue;
+    double *row = x + l * nx;
+    for (int i = lane; i < nx; i += 64) row[i] = __longlong_as_double((long long)BX_SENTINEL);
+  }
+}
+
 // expected presence of the 27 canonical positions at every row against the row's template: count of rows that differ
 __global__ void box_verify_kernel(long long m, int nx, int ny, int nz, const unsigned char *__restrict__ tid, const unsigned int *__restrict__ tmask, unsigned int base_mask, unsigned int *bad)
 {
@@ -757,6 +785,9 @@ struct hipxSorBox_s {
   unsigned long long *d_stats = nullptr;
   double       *d_mbox = nullptr;
   size_t        mbox_len = 0;
+  unsigned int *h_err = nullptr;  // pinned: the error word of the application before
+  hipEvent_t    ev_err = nullptr;
+  bool          err_pending = false;
 };
 typedef hipxSorBox_s *hipxSorBox;
 
@@ -768,6 +799,8 @@ extern "C" void hipxSorBoxFree_(void *p)
   (void)hipFree(B->d_ctl);
   (void)hipFree(B->d_stats);
   (void)hipFree(B->d_mbox);
+  if (B->h_err) (void)hipHostFree(B->h_err);
+  if (B->ev_err) (void)hipEventDestroy(B->ev_err);
   delete B;
 }
 
@@ -919,8 +952,8 @@ static int box_launch(hipxSorBox B, BoxParams &Q)
 }
 
 // One zero-guess sweep.  kind 0: forward (rhs = b; t and x written; xfull = 0 inside a symmetric application: only the lines the schedule itself
-// hands between workgroups reach xout); kind 1: backward after forward (rhs = t); kind 2: backward alone (rhs = b).  xout must be filled with the
-// sentinel (sor_fill_kernel) before the launch: a row of x is its own ready flag between workgroups.  Vectors 16-byte aligned.
+// hands between workgroups reach xout); kind 1: backward after forward (rhs = t); kind 2: backward alone (rhs = b).  The polled rows of xout must hold
+// the sentinel (hipxSorBoxFill_) before the launch: a row of x is its own ready flag between workgroups.  Vectors 16-byte aligned.
 extern "C" int hipxSorBoxRun_(void *p, int kind, const double *rhs, double *tout, double *xout, double omega, double shift, int xfull)
 {
   hipxSorBox B = (hipxSorBox)p;
@@ -993,11 +1026,43 @@ extern "C" int hipxSorBoxRun_(void *p, int kind, const double *rhs, double *tout
   return ierr;
 }
 
-extern "C" int hipxSorBoxError_(void *p, unsigned int *err)
+// Before a sweep: the sentinel into the rows of xout that are their own ready flags (rev: the backward sweeps, kinds 1 and 2).  1 / 32 of the
+// vector -- until round 6 the whole vector was filled, 2 x 134 MB per application at 256^3.
+extern "C" int hipxSorBoxFill_(void *p, double *xout, int rev)
 {
   hipxSorBox B = (hipxSorBox)p;
-  HIPX_HIP(hipMemcpyAsync(err, B->d_ctl + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, rt().compute));
-  HIPX_HIP(hipStreamSynchronize(rt().compute));
+  box_fill_lines_kernel<<<2048, 256, 0, rt().compute>>>(xout, B->nx, B->ny, B->nz, rev);
+  HIPX_LAUNCH_CHECK();
+  return HIPX_SUCCESS;
+}
+
+// The error word of the applications so far (a dependency that was never published: the waits give up after 4 s).  The word of the application
+// just enqueued is copied to pinned host memory behind it and looked at when the NEXT application is set up (or the matrix is destroyed): a host
+// round trip per application cost 25-40 us of idle GPU (1.2 % of PCApply_SOR at 256^3).  A launch that gave up leaves sentinels (NaN) in its
+// result, so a solve does not run on unnoticed; sync != 0 waits for the word of the application just enqueued (tests, HIPX_SORBOX_SYNC_CHECK=1).
+extern "C" int hipxSorBoxError_(void *p, unsigned int *err, int sync)
+{
+  hipxSorBox B = (hipxSorBox)p;
+  static const bool always = getenv("HIPX_SORBOX_SYNC_CHECK") != nullptr;
+  *err = 0;
+  if (!B->h_err) {
+    HIPX_HIP(hipHostMalloc((void **)&B->h_err, 2 * sizeof(unsigned int), hipHostMallocDefault));
+    B->h_err[0] = B->h_err[1] = 0;
+    HIPX_HIP(hipEventCreateWithFlags(&B->ev_err, hipEventDisableTiming));
+  }
+  if (B->err_pending) {  // the previous application's word: long there
+    HIPX_HIP(hipEventSynchronize(B->ev_err));
+    *err |= B->h_err[0];
+    B->err_pending = false;
+  }
+  HIPX_HIP(hipMemcpyAsync(B->h_err, B->d_ctl + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, rt().compute));
+  HIPX_HIP(hipEventRecord(B->ev_err, rt().compute));
+  B->err_pending = true;
+  if (sync || always) {
+    HIPX_HIP(hipEventSynchronize(B->ev_err));
+    *err |= B->h_err[0];
+    B->err_pending = false;
+  }
   if (*err) {
     HIPX_HIP(hipMemsetAsync(B->d_ctl, 0, 2 * sizeof(unsigned int), rt().compute));
     if (B->mbox_len) box_fill_kernel<<<4096, 256, 0, rt().compute>>>(B->d_mbox, B->mbox_len);  // (a launch that gave up leaves entries behind)
