@@ -298,7 +298,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
   { \
     const int t_ = t + (PH), i = t_ + i0; \
     constexpr int M1 = ((PH) + 3) & 3, C0 = (PH), P1 = ((PH) + 1) & 3, S2 = (PH) & 1; \
-    if (!(GUARD) || t_ + 2 < T) look_issue(); \
+    if ((GUARD) != 1 || t_ + 2 < T) look_issue(); \
     { /* the previous line's row i + 1: lane s - 1 relaxed it in the step before (wavefront shift); lane 0 takes the west line's */ \
       const int nlo = __builtin_amdgcn_update_dpp(__double2loint(Ww[S2]), __double2loint(xcur), 0x138 /* wave_shr:1 */, 0xf, 0xf, false); \
       const int nhi = __builtin_amdgcn_update_dpp(__double2hiint(Ww[S2]), __double2hiint(xcur), 0x138, 0xf, 0xf, false); \
@@ -320,7 +320,12 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     else xv = sum * Q.idiag; \
     xcur = (valid && (unsigned)i < (unsigned)nx) ? xv : z0; /* beyond the line, and a lane without a line: the zero element */ \
     bool rdy_ = true; \
-    if (!(GUARD) || t_ + 2 < T) { /* the record is looked at BEFORE the ring writes are issued: behind them the wait for it is a wait for them too */ \
+    if ((GUARD) == 2) { /* main loop: the four comparisons as ONE 64-bit subtraction (fields below 0x8000, no borrow across fields) */ \
+      const unsigned long long R_ = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(raw >> 32)) << 32) | \
+                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)raw); \
+      rdy_ = ((((R_ | 0x8000800080008000ull) - needN) & 0x8000800080008000ull) == 0x8000800080008000ull); \
+      needN += 0x0001000100010001ull; \
+    } else if ((GUARD) != 1 || t_ + 2 < T) { /* the record is looked at BEFORE the ring writes are issued: behind them the wait for it is a wait for them too */ \
       look_take(); \
       rdy_ = ready(t_ + 2); \
     } \
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     if (KIND == 0 && (unsigned)i < (unsigned)nx) L[to + (i & (BX_RX - 1))] = sum; \
     asm volatile("" ::: "memory"); /* ring writes, then the counter: program order = LDS order */ \
     if (lane < 4) bx_put16(pub, t_ + 1); \
-    if (!(GUARD) || t_ + 2 < T) { \
+    if ((GUARD) != 1 || t_ + 2 < T) { \
       if (!rdy_) { \
         look_issue(); \
         look_take(); \
@@ -347,18 +352,32 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
       BX_REQUEST(0, 1, 0)
       BX_REQUEST(1, 2, 1)
     }
-    int t = 0;
-    for (; t + 8 <= T && alive; t += 4) {  // (every step of these groups prepares a step t + 2 < T: no end-of-line checks)
-      BX_STEP(0, false)
-      BX_STEP(1, false)
-      BX_STEP(2, false)
-      BX_STEP(3, false)
-    }
-    for (; t < T && alive; t += 4) {
-      BX_STEP(0, true)
-      BX_STEP(1, true)
-      BX_STEP(2, true)
-      BX_STEP(3, true)
+    // Three phases: the first sixteen steps and the last ones with every check spelled out (needs below zero, the ends of the lines), the steps in
+    // between -- every one prepares a step t + 2 < T and needs nothing negative -- with the four readiness comparisons as one 64-bit subtraction:
+    // need = {t - 2 (+ 2: plane 0), t + 1, t - 8, t - 15} for the step t = t_ + 2 being prepared, in the record's field order, + 1 per step.
+    const bool swar = Q.dbg == 0 && staged_all < 0x8000;
+    unsigned long long needN = 0;
+    int                t = 0;
+    for (int phase = 0; phase < 3 && alive; phase++) {
+      if (phase == 1) {
+        if (!swar) continue;
+        needN = (unsigned long long)(unsigned)(t + low_off) | ((unsigned long long)(unsigned)(t + 3) << 16) | ((unsigned long long)(unsigned)(t - 6) << 32) |
+                ((unsigned long long)(unsigned)(t - 13) << 48);
+        for (; t + 8 <= T && alive; t += 4) {
+          BX_STEP(0, 2)
+          BX_STEP(1, 2)
+          BX_STEP(2, 2)
+          BX_STEP(3, 2)
+        }
+      } else {
+        const int tend = phase == 0 && swar ? 16 : T;
+        for (; t < tend && alive; t += 4) {
+          BX_STEP(0, 1)
+          BX_STEP(1, 1)
+          BX_STEP(2, 1)
+          BX_STEP(3, 1)
+        }
+      }
     }
 #undef BX_STEP
 #undef BX_REQUEST
