@@ -560,24 +560,30 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
       constexpr int WIN = 4;
       const int     npairs = T / 2 + 1;
       const int     jj = 64 * J - (k0 - 1) + lane;
-      const bool    any_line = __any(jj >= 0 && jj < ny);
+      if (!__any(jj >= 0 && jj < ny)) {  // a plane without any line in the grid: nothing was sent, and the ring keeps the zero element
+        if (lane == 0) bx_put16(sc, 0xffff);
+        return;
+      }
       const int     so = BX_OS + (lane + 2) * (BX_RS + 1);
       double       *mb  = Q.mbox + ((size_t)(c - 1) * Q.nb + J) * (size_t)(T / 2 + 8) * 128 + 2 * lane;
       bx_double2    sentinel2;
       sentinel2.x = sentinel2.y = __longlong_as_double((long long)BX_SENTINEL);
-      int       base = 0, spins = 0;
+      int       base = 0, spins = 0, rcur = -2 * lane;  // rcur: this lane's first row of pair base, 2 base - 2 lane
       long long t0   = 0;
       unsigned  n_it = 0, n_empty = 0, n_lim = 0;  // HIPX_SORBOX_STATS: passes, passes that staged nothing, waits for ring space
-      bool      probe = any_line;
+      bool      probe = true;
       unsigned long long tk_rt = 0, tk_pass = 0, n_staged = 0;
-      // rows 2 n - 2 s, + 1 of line s into the ring (row nx is the line's zero element: the chunk below sent it as such)
-      auto put = [&](int n, const bx_double2 &v, double *e) {
-        const int r = 2 * n - 2 * lane;
+      // The wave shares its SIMD with a compute wave that keeps the vector unit ~70 % busy: what a pass costs is its VECTOR instructions (~100 in
+      // the first version, 0.7 us; the memory round trip is 0.4).  Hence: ballots straight from the comparisons, the row number kept running, no
+      // per-lane notion of need (the chunk below sends every lane's entry, zero elements included).
+      // rows r, r + 1 of this lane's line into the ring (row nx is the line's zero element: the chunk below sent it as such); the entry goes back
+      auto put = [&](int r, const bx_double2 &v, double *e) {
         if ((unsigned)r <= (unsigned)nx) {
-          L[so + (r & (BX_RS - 1))]       = v.x;
-          L[so + ((r + 1) & (BX_RS - 1))] = v.y;
+          const int o = so + (r & (BX_RS - 2));  // (r is even: the pair does not wrap in the ring)
+          L[o]     = v.x;
+          L[o + 1] = v.y;
         }
-        if (any_line) *reinterpret_cast<bx_double2 *>(e) = sentinel2;  // (read once: the entry is ready for the next sweep)
+        *reinterpret_cast<bx_double2 *>(e) = sentinel2;  // (read once: the entry is ready for the next sweep)
       };
       while (base < npairs) {
         // ring space (32 rows): pair n overwrites the rows plane 0 asked for up to step 2 n - 28
@@ -590,14 +596,14 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
           continue;
         }
         double *ent = mb + (size_t)(base + 7) * 128;
-        if (probe && !(Q.dbg & 512)) {
+        if (probe) {
           // Nothing had arrived on the last pass: ONE lane asks for its entry of the next flush until it is there (a flush leaves the chunk below in one
           // store instruction): a waiting workgroup costs the memory system one request per round trip.
           bx_double2 pv;
           pv.x = pv.y = z0;
           if (lane == 0) pv = ld(ent);
-          if (__any(lane == 0 && unset(pv))) {
-            if (!(Q.dbg & 1024)) __builtin_amdgcn_s_sleep(1);
+          if (__builtin_amdgcn_ballot_w64(lane == 0 && unset(pv))) {
+            __builtin_amdgcn_s_sleep(1);
             if (give_up(spins, t0)) return;
             continue;
           }
@@ -606,22 +612,20 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
         n_it++;
         const unsigned long long tk0 = Q.stats ? wall_clock64() : 0;
         bx_double2 v0, v1, v2, v3;
-        v0.x = v0.y = v1.x = v1.y = v2.x = v2.y = v3.x = v3.y = z0;
-        if (any_line)  // (a plane without any line in the grid: nothing was sent)
-          asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
-                       "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
-                       : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
-                       : "v"(ent)
-                       : "memory");
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                     : "v"(ent)
+                     : "memory");
         if (Q.stats) tk_rt += wall_clock64() - tk0;
         int nlead = 0;
-        if (!__any(unset(v0))) {
+        if (!__builtin_amdgcn_ballot_w64(unset(v0))) {
           nlead = 1;
-          if (base + 1 < lim && !__any(unset(v1))) {
+          if (base + 1 < lim && !__builtin_amdgcn_ballot_w64(unset(v1))) {
             nlead = 2;
-            if (base + 2 < lim && !__any(unset(v2))) {
+            if (base + 2 < lim && !__builtin_amdgcn_ballot_w64(unset(v2))) {
               nlead = 3;
-              if (base + 3 < lim && !__any(unset(v3))) nlead = 4;
+              if (base + 3 < lim && !__builtin_amdgcn_ballot_w64(unset(v3))) nlead = 4;
             }
           }
         }
@@ -632,12 +636,13 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
           continue;
         }
         spins = 0, t0 = 0;
-        put(base, v0, ent);
-        if (nlead > 1) put(base + 1, v1, ent + 128);
-        if (nlead > 2) put(base + 2, v2, ent + 256);
-        if (nlead > 3) put(base + 3, v3, ent + 384);
+        put(rcur, v0, ent);
+        if (nlead > 1) put(rcur + 2, v1, ent + 128);
+        if (nlead > 2) put(rcur + 4, v2, ent + 256);
+        if (nlead > 3) put(rcur + 6, v3, ent + 384);
         bx_lds_release();
         base += nlead;
+        rcur += 2 * nlead;
         if (lane == 0) bx_put16(sc, 2 * base);  // (virtual steps -2 .. 2 base - 3 are staged)
         if (Q.stats) tk_pass += wall_clock64() - tk0, n_staged += nlead;
       }
