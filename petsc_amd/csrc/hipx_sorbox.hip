@@ -941,7 +941,8 @@ extern "C" int hipxSorBoxBuild_(long long m, int ntmpl, const int *tstart, const
   // the mailbox of the chunks' top planes: filled with the sentinel once -- whoever reads an entry puts the sentinel back
   B->mbox_len = (size_t)B->nb * (size_t)(B->nch > 1 ? B->nch - 1 : 0) * (size_t)(B->T / 2 + 8) * 128;  // (eight flushes of padding per workgroup: the poller reads four at a time)
   if (B->mbox_len) {
-    if (hipMalloc((void **)&B->d_mbox, sizeof(double) * B->mbox_len) != hipSuccess) return bail(fail(HIPX_ERR_HIP_BASE, "hipMalloc", __FILE__, __LINE__));
+    // (+ 4 KB: a poller reads four flushes at a time, the last pass of the last workgroup up to three flushes past its region)
+    if (hipMalloc((void **)&B->d_mbox, sizeof(double) * (B->mbox_len + 4 * 128)) != hipSuccess) return bail(fail(HIPX_ERR_HIP_BASE, "hipMalloc", __FILE__, __LINE__));
     box_fill_kernel<<<4096, 256, 0, st>>>(B->d_mbox, B->mbox_len);
   }
   *out = B;

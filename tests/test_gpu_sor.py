@@ -397,13 +397,15 @@ def box_csr(nx, ny, nz, full27, seed=3):
 
 
 @pytest.mark.parametrize("nx,ny,nz,full27", [(8, 70, 6, True), (8, 70, 6, False), (16, 66, 9, False), (6, 130, 3, True), (12, 12, 12, True), (10, 5, 70, True), (4, 64, 4, True),
-                                             (32, 40, 5, True), (64, 64, 64, True), (64, 64, 64, False), (130, 9, 11, True)])
+                                             (32, 40, 5, True), (64, 64, 64, True), (64, 64, 64, False), (130, 9, 11, True), (33000, 3, 5, True)])
 @pytest.mark.parametrize("flag,omega,shift", [(LSYM | ZERO, 1.0, 0.0), (SYM | ZERO, 1.0, 0.0), (FWD | ZERO, 1.0, 0.0), (BWD | ZERO, 1.0, 0.0), (LSYM | ZERO, 1.3, 0.25), (LFWD | ZERO, 0.8, 0.0),
                                               (LBWD | ZERO, 1.3, 0.0)])
 def test_plane_march_bit_exact(hx, nx, ny, nz, full27, flag, omega, shift):
     """Round 5: the plane-march schedule (csrc/hipx_sorbox.hip) -- zero-guess forward / backward / symmetric sweeps of constant-coefficient box
     stencils: blocks that cross the grid's edges (the skewed block boundaries leave lanes without a line), grids of one block and of several, chunks
-    of planes that do not fill a workgroup, lines shorter than a staging group, omega / shift -- bit-identical to MatSOR_SeqAIJ (aij.c:1930-1958)."""
+    of planes that do not fill a workgroup, lines shorter than a staging group, lines of more than 32768 rows (round 6: the packed readiness check of
+    the main loop needs counters below 0x8000 -- longer lines take the spelled-out checks all the way), omega / shift -- bit-identical to MatSOR_SeqAIJ
+    (aij.c:1930-1958)."""
     ai, aj, aa = box_csr(nx, ny, nz, full27)
     N = nx * ny * nz
     b = np.random.default_rng(5).standard_normal(N)
