@@ -63,6 +63,7 @@ struct BoxParams {
   unsigned int *ctl;            // [0] ticket, [1] error
   double       *mbox;           // the chunks' top planes on their way up: [chunk c < nch - 1][block J][flush f < T / 2 + 8][lane] pairs of rows, sentinel = not there yet
   int          dbg;             // HIPX_SORBOX_DEBUG (timing probes, WRONG RESULTS): 1 = no staging / flushing (the compute waves alone), 2 = also no waiting for the lower plane
+  unsigned long long *trace;    // HIPX_SORBOX_STATS=3: [2 c][f] when workgroup (0, c) mailed flush f, [2 c + 1][f] when workgroup (0, c + 1) had it in its ring (100 MHz clock), c < 8
   unsigned long long *stats;    // HIPX_SORBOX_STATS: spin counts of the compute waves by unmet condition [4], stager ring waits [1], stager halo polls [1], steps [1]
 };
 
@@ -538,6 +539,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
           v.y = L[xo + ((r + 1) & (BX_RX - 1))];
         }
         bx_store2_sc1(mb + (size_t)(need / 2 - 1) * 128, v);  // (logical order: row r first)
+        if (Q.trace && J == 0 && c < 8 && lane == 0 && need / 2 - 1 < 4096) Q.trace[(2 * c) * 4096 + need / 2 - 1] = wall_clock64();
         bx_lds_release();
         if (lane == 0) bx_put16(Hrec(w) + 3, upto);
       }
@@ -645,6 +647,11 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
         rcur += 2 * nlead;
         if (lane == 0) bx_put16(sc, 2 * base);  // (virtual steps -2 .. 2 base - 3 are staged)
         if (Q.stats) tk_pass += wall_clock64() - tk0, n_staged += nlead;
+        if (Q.trace && J == 0 && c <= 8 && lane == 0) {
+          const unsigned long long now = wall_clock64();
+          for (int q = base - nlead; q < base; q++)
+            if (q + 7 < 4096) Q.trace[(2 * (c - 1) + 1) * 4096 + q + 7] = now;
+        }
       }
       if (Q.stats && lane == 0) {
         atomicAdd(Q.stats + 7, (unsigned long long)n_it);
@@ -806,7 +813,7 @@ struct hipxSorBox_s {
   double        coefF[13], coefB[13], diag = 0.0, z0 = 0.0;
   int2         *d_order = nullptr;
   unsigned int *d_ctl = nullptr;
-  unsigned long long *d_stats = nullptr;
+  unsigned long long *d_stats = nullptr, *d_trace = nullptr;
   double       *d_mbox = nullptr;
   size_t        mbox_len = 0;
   unsigned int *h_err = nullptr;  // pinned: the error word of the application before
@@ -822,6 +829,7 @@ extern "C" void hipxSorBoxFree_(void *p)
   (void)hipFree(B->d_order);
   (void)hipFree(B->d_ctl);
   (void)hipFree(B->d_stats);
+  (void)hipFree(B->d_trace);
   (void)hipFree(B->d_mbox);
   if (B->h_err) (void)hipHostFree(B->h_err);
   if (B->ev_err) (void)hipEventDestroy(B->ev_err);
@@ -1000,6 +1008,13 @@ extern "C" int hipxSorBoxRun_(void *p, int kind, const double *rhs, double *tout
     HIPX_HIP(hipMemsetAsync(B->d_stats, 0, nst * sizeof(unsigned long long), rt().compute));
     Q.stats = B->d_stats;
   }
+  Q.trace = nullptr;
+  static const int stats_level = getenv("HIPX_SORBOX_STATS") ? atoi(getenv("HIPX_SORBOX_STATS")) : 0;
+  if (stats_level >= 3) {
+    if (!B->d_trace) HIPX_HIP(hipMalloc((void **)&B->d_trace, 16 * 4096 * sizeof(unsigned long long)));
+    HIPX_HIP(hipMemsetAsync(B->d_trace, 0, 16 * 4096 * sizeof(unsigned long long), rt().compute));
+    Q.trace = B->d_trace;
+  }
   memcpy(Q.coef, kind == 0 ? B->coefF : B->coefB, sizeof(Q.coef));
   HIPX_HIP(hipMemsetAsync(B->d_ctl, 0, sizeof(unsigned int), rt().compute));  // the ticket; the error word is sticky until read
   const bool box27 = B->em == 0x1FFF;
@@ -1035,6 +1050,30 @@ extern "C" int hipxSorBoxRun_(void *p, int kind, const double *rhs, double *tout
           for (int c = 0; c < B->nch; c++) fprintf(stderr, " %.0f", (double)(long long)(h[8 + 2 * ((size_t)c * B->nb + J) + e] - t0) * 0.01);
           fprintf(stderr, "\n");
         }
+      }
+    }
+    if (Q.trace) {  // how long a flush of workgroup (0, c) takes to the ring of workgroup (0, c + 1)
+      std::vector<unsigned long long> tr(16 * 4096);
+      HIPX_HIP(hipMemcpy(tr.data(), B->d_trace, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      for (int cc = 0; cc < 8 && cc + 1 < B->nch; cc++) {
+        const unsigned long long *a = tr.data() + (size_t)(2 * cc) * 4096, *b = a + 4096;
+        std::vector<double>       d;
+        for (int f = 0; f < 4096; f++)
+          if (a[f] && b[f]) d.push_back((double)(long long)(b[f] - a[f]) * 0.01);
+        if (d.empty()) continue;
+        std::vector<double> e = d;
+        std::sort(e.begin(), e.end());
+        unsigned long long f0 = 0, f1 = 0;
+        int                nf = 0;
+        for (int f = 0; f < 4096; f++)
+          if (a[f]) {
+            if (!f0) f0 = a[f];
+            f1 = a[f];
+            nf++;
+          }
+        fprintf(stderr, "[sorbox trace kind %d] (0, %d) mailed -> in the ring of (0, %d), us: min %.2f median %.2f max %.2f; flush 2: %.2f, 20: %.2f, 100: %.2f, 300: %.2f, 600: %.2f, last: %.2f; a flush every %.3f us\n", kind, cc, cc + 1,
+                e.front(), e[e.size() / 2], e.back(), d.size() > 2 ? d[2] : 0.0, d.size() > 20 ? d[20] : 0.0, d.size() > 100 ? d[100] : 0.0, d.size() > 300 ? d[300] : 0.0, d.size() > 600 ? d[600] : 0.0, d.back(),
+                nf > 1 ? (double)(long long)(f1 - f0) * 0.01 / (nf - 1) : 0.0);
       }
     }
     const double nw = (double)B->nb * B->nch * BX_P;
