@@ -62,7 +62,8 @@ struct BoxParams {
   const int2   *order;          // (J, c) of ticket n
   unsigned int *ctl;            // [0] ticket, [1] error
   double       *mbox;           // the chunks' top planes on their way up: [chunk c < nch - 1][block J][flush f < T / 2 + 8][lane] pairs of rows, sentinel = not there yet
-  int          dbg;             // HIPX_SORBOX_DEBUG (timing probes, WRONG RESULTS): 1 = no staging / flushing (the compute waves alone), 2 = also no waiting for the lower plane
+  int          dbg;             // HIPX_SORBOX_DEBUG (timing probes, WRONG RESULTS): 1 = no staging / flushing (the compute waves alone), 2 = also no waiting for the lower plane;
+                                // bits (helpers on): 4 = no south poller (chunks run without their hop; one-block boxes only: nobody mails), 32 = the flushers store nothing
   unsigned long long *trace;    // HIPX_SORBOX_STATS=3: [2 c][f] when workgroup (0, c) mailed flush f, [2 c + 1][f] when workgroup (0, c + 1) had it in its ring (100 MHz clock), c < 8
   unsigned long long *stats;    // HIPX_SORBOX_STATS: spin counts of the compute waves by unmet condition [4], stager ring waits [1], stager halo polls [1], steps [1]
 };

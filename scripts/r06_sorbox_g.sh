@@ -1,14 +1,12 @@
 #!/bin/bash
 # Plane-march PCSOR A/B: bit parity on the small boxes, timings on the large ones, per-workgroup stamps of one application.
-#   bash scripts/r06_sorbox_g.sh [variant ...]     variant = old (the library in ab/old, when present) | g8 | g4 | g2 (HIPX_SORBOX_G of the stagers) | pN (HIPX_SORBOX_PRIO=N)
+#   bash scripts/r06_sorbox_g.sh [variant ...]     variant = new | old (the library scripts/ab_build_old.sh puts into ab/old) | dN (HIPX_SORBOX_DEBUG=N: timing probes, wrong results)
 #   QUICK=1: timings only; QUICK=2: timings and stamps
 cd "$(dirname "$0")/.." || exit 1
-for V in ${@:-g8}; do
-  unset HIPX_LIBDIR HIPX_SORBOX_G HIPX_SORBOX_PRIO HIPX_SORBOX_DEBUG
+for V in ${@:-new}; do
+  unset HIPX_LIBDIR HIPX_SORBOX_DEBUG
   case $V in
     old) export HIPX_LIBDIR=$PWD/ab/old ;;
-    g*) export HIPX_SORBOX_G=${V#g} ;;
-    p*) export HIPX_SORBOX_PRIO=${V#p} ;;
     d*) export HIPX_SORBOX_DEBUG=${V#d} ;;  # timing probes, wrong results: 4 = no south poller, 8 = top plane flushed in groups of eight (nothing stored), 12 = both
   esac
   echo "=== variant $V"

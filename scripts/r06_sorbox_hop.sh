@@ -1,12 +1,10 @@
 #!/bin/bash
-# step time / chunk hop of the plane march (scripts/sor_box_hop.py) for a list of variants: old | new | dN (HIPX_SORBOX_DEBUG=N) | pN | gN
+# step time / chunk hop of the plane march (scripts/sor_box_hop.py) for a list of variants: new | old (scripts/ab_build_old.sh -> ab/old) | dN (HIPX_SORBOX_DEBUG=N)
 cd "$(dirname "$0")/.." || exit 1
 for V in "$@"; do
-  unset HIPX_LIBDIR HIPX_SORBOX_G HIPX_SORBOX_PRIO HIPX_SORBOX_DEBUG
+  unset HIPX_LIBDIR HIPX_SORBOX_DEBUG
   case $V in
     old) export HIPX_LIBDIR=$PWD/ab/old ;;
-    g*) export HIPX_SORBOX_G=${V#g} ;;
-    p*) export HIPX_SORBOX_PRIO=${V#p} ;;
     d*) export HIPX_SORBOX_DEBUG=${V#d} ;;
   esac
   echo "== $V"
