@@ -600,17 +600,24 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
         }
         double *ent = mb + (size_t)(base + 7) * 128;
         if (probe) {
-          // Nothing had arrived on the last pass: ONE lane asks for its entry of the next flush until it is there (a flush leaves the chunk below in one
-          // store instruction): a waiting workgroup costs the memory system one request per round trip.
+          // Nothing had arrived on the last pass: the wave asks for the NEXT flush alone (1 KB in one piece: sixteen requests per round trip of a
+          // waiting workgroup) and stages it the moment it is there -- the first pair of a chunk is in the ring one round trip after it became visible
+          // (a one-lane probe followed by a pass over four flushes: two round trips and the pass's work, on every hop between chunks).
           bx_double2 pv;
-          pv.x = pv.y = z0;
-          if (lane == 0) pv = ld(ent);
-          if (__builtin_amdgcn_ballot_w64(lane == 0 && unset(pv))) {
+          asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(pv) : "v"(ent) : "memory");
+          if (__builtin_amdgcn_ballot_w64(unset(pv))) {
             __builtin_amdgcn_s_sleep(1);
             if (give_up(spins, t0)) return;
             continue;
           }
           probe = false;
+          spins = 0, t0 = 0;
+          put(rcur, pv, ent);
+          bx_lds_release();
+          base += 1;
+          rcur += 2;
+          if (lane == 0) bx_put16(sc, 2 * base);
+          continue;
         }
         n_it++;
         const unsigned long long tk0 = Q.stats ? wall_clock64() : 0;
