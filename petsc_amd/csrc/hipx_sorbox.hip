@@ -322,11 +322,12 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
     else xv = sum * Q.idiag; \
     xcur = (valid && (unsigned)i < (unsigned)nx) ? xv : z0; /* beyond the line, and a lane without a line: the zero element */ \
     bool rdy_ = true; \
-    if ((GUARD) == 2) { /* main loop: the four comparisons as ONE 64-bit subtraction (fields below 0x8000, no borrow across fields) */ \
+    if ((GUARD) >= 2) { /* the four comparisons as ONE 64-bit subtraction (fields below 0x8000, no borrow across fields) */ \
       const unsigned long long R_ = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(raw >> 32)) << 32) | \
                                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)raw); \
       rdy_ = ((((R_ | 0x8000800080008000ull) - needN) & 0x8000800080008000ull) == 0x8000800080008000ull); \
-      needN += 0x0001000100010001ull; \
+      if ((GUARD) == 2) needN += 0x0001000100010001ull; \
+      else needN += 0x0000000000010001ull + ((unsigned long long)(t_ >= 6) << 32) + ((unsigned long long)(t_ >= 13) << 48); /* (needs below zero stay 0) */ \
     } else if ((GUARD) != 1 || t_ + 2 < T) { /* the record is looked at BEFORE the ring writes are issued: behind them the wait for it is a wait for them too */ \
       look_take(); \
       rdy_ = ready(t_ + 2); \
@@ -354,32 +355,33 @@ __global__ __launch_bounds__(BX_THREADS, 1) void sor_box_kernel(const BoxParams 
       BX_REQUEST(0, 1, 0)
       BX_REQUEST(1, 2, 1)
     }
-    // Three phases: the first sixteen steps and the last ones with every check spelled out (needs below zero, the ends of the lines), the steps in
-    // between -- every one prepares a step t + 2 < T and needs nothing negative -- with the four readiness comparisons as one 64-bit subtraction:
-    // need = {t - 2 (+ 2: plane 0), t + 1, t - 8, t - 15} for the step t = t_ + 2 being prepared, in the record's field order, + 1 per step.
+    // The four readiness comparisons of a step as one 64-bit subtraction: need = {t - 2 (+ 2: plane 0), t + 1, t - 8, t - 15} for the step t = t_ + 2
+    // being prepared, in the record's field order, needs below zero held at 0.  Three loops: the first sixteen steps (the needs below zero: the
+    // increment is put together per step), the steps in between (+ 1 per field and step), the last ones with every check spelled out (the ends of the
+    // lines).  (The first sixteen steps spelled out cost ~80 ns each: 1.3 us at the start of every workgroup, that is on every hop between chunks --
+    // a chunk never catches up with the chunk below, it runs at the same pace.)
     const bool swar = Q.dbg == 0 && staged_all < 0x8000;
-    unsigned long long needN = 0;
+    unsigned long long needN = (unsigned long long)(unsigned)low_off | (3ull << 16);
     int                t = 0;
-    for (int phase = 0; phase < 3 && alive; phase++) {
-      if (phase == 1) {
-        if (!swar) continue;
-        needN = (unsigned long long)(unsigned)(t + low_off) | ((unsigned long long)(unsigned)(t + 3) << 16) | ((unsigned long long)(unsigned)(t - 6) << 32) |
-                ((unsigned long long)(unsigned)(t - 13) << 48);
-        for (; t + 8 <= T && alive; t += 4) {
-          BX_STEP(0, 2)
-          BX_STEP(1, 2)
-          BX_STEP(2, 2)
-          BX_STEP(3, 2)
-        }
-      } else {
-        const int tend = phase == 0 && swar ? 16 : T;
-        for (; t < tend && alive; t += 4) {
-          BX_STEP(0, 1)
-          BX_STEP(1, 1)
-          BX_STEP(2, 1)
-          BX_STEP(3, 1)
-        }
+    if (swar) {
+      for (; t < 16 && alive; t += 4) {  // (T >= 148: every one of these steps prepares a step t + 2 < T)
+        BX_STEP(0, 3)
+        BX_STEP(1, 3)
+        BX_STEP(2, 3)
+        BX_STEP(3, 3)
       }
+      for (; t + 8 <= T && alive; t += 4) {
+        BX_STEP(0, 2)
+        BX_STEP(1, 2)
+        BX_STEP(2, 2)
+        BX_STEP(3, 2)
+      }
+    }
+    for (; t < T && alive; t += 4) {
+      BX_STEP(0, 1)
+      BX_STEP(1, 1)
+      BX_STEP(2, 1)
+      BX_STEP(3, 1)
     }
 #undef BX_STEP
 #undef BX_REQUEST
