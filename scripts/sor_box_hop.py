@@ -1,6 +1,7 @@
 """Plane-march PCSOR: the step time and the hop between chunks, measured directly.  Boxes of ONE block of lines (ny + nz - 2 < 64) and 1, 2, 4 ... 16
 chunks of four planes: a sweep takes T steps + (chunks - 1) hops, so the difference between two chunk counts is the hop and the one-chunk time / T is
-the step.  python scripts/sor_box_hop.py [nx]        (HIPX_LIBDIR / HIPX_SORBOX_* select the variant)"""
+the step.  "blocks": ONE chunk (four planes) and 1, 2, 4, 8 blocks of lines instead: the hop between blocks (124 steps of skew + its hand-off).
+python scripts/sor_box_hop.py [nx] [blocks]        (HIPX_LIBDIR / HIPX_SORBOX_* select the variant)"""
 import ctypes as C
 import os
 import sys
@@ -14,6 +15,7 @@ from petsc_amd import _lib  # noqa: E402
 hx = _lib.init(0)
 LSYM, ZERO = 12, 16
 nx = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+blocks = "blocks" in sys.argv
 
 
 def box27(nx, ny, nz):
@@ -40,7 +42,7 @@ _lib.chk(hx.hipxEventCreate(C.byref(e0)))
 _lib.chk(hx.hipxEventCreate(C.byref(e1)))
 T = (nx + 3 + 126 + 12 + 3) & ~3
 res = []
-for ny, nz in ((40, 4), (40, 8), (40, 16), (30, 32)):
+for ny, nz in (((30, 4), (94, 4), (222, 4), (478, 4)) if blocks else ((40, 4), (40, 8), (40, 16), (30, 32))):
     N, ai, aj, aa = box27(nx, ny, nz)
     A = _lib.mat_create_csr(N, N, ai, aj, aa)
     b = 1.0 + (np.arange(N) % 17) / 17.0
@@ -58,10 +60,12 @@ for ny, nz in ((40, 4), (40, 8), (40, 16), (30, 32)):
     ms = C.c_float()
     _lib.chk(hx.hipxEventElapsedMs(e0, e1, C.byref(ms)))
     us = ms.value / reps / 2 * 1e3  # one sweep
-    res.append((nz // 4, us))
-    print("27-pt %d x %d x %d  (mode %d, %d chunks, T = %d steps): %.1f us per sweep" % (nx, ny, nz, used.value, nz // 4, T, us), flush=True)
+    units = (ny + nz - 2) // 64 + 1 if blocks else nz // 4
+    res.append((units, us))
+    print("27-pt %d x %d x %d  (mode %d, %d %s, T = %d steps): %.1f us per sweep" % (nx, ny, nz, used.value, units, "blocks" if blocks else "chunks", T, us), flush=True)
     B.free()
     X.free()
     _lib.mat_destroy(A)
 c1 = res[0][1]
-print("step (one chunk, incl. launch + fill): %.0f ns;  hop between chunks: %s us" % (c1 / T * 1e3, ", ".join("%.2f" % ((us - c1) / (n - 1)) for n, us in res[1:])))
+print("step (one chunk, incl. launch + fill): %.0f ns;  hop between %s: %s us%s" % (c1 / T * 1e3, "blocks" if blocks else "chunks", ", ".join("%.2f" % ((us - c1) / (n - 1)) for n, us in res[1:]),
+      "  (of it 124 steps of skew: %.1f us)" % (124 * c1 / T) if blocks else ""))
